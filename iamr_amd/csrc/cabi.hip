@@ -1,0 +1,223 @@
+// iamr_amd/csrc/cabi.hip -- extern "C" boundary of libiamrx.so (declarations: include/iamrx.h).
+// Exceptions never cross the boundary: they become a non-zero return code + iamrx_last_error().
+#include "../../include/iamrx.h"
+#include "operators.h"
+#include <string>
+#include <cstring>
+
+using namespace iamrx;
+
+struct iamrx_layout_s { LayoutP p; };
+struct iamrx_mf_s { MultiFab mf; };
+
+static thread_local std::string g_err;
+
+#define IAMRX_TRY try {
+#define IAMRX_CATCH                                                   \
+    return 0; }                                                       \
+    catch (const std::exception& e) { g_err = e.what(); return 1; }   \
+    catch (...) { g_err = "unknown error"; return 2; }
+
+static Geometry to_geom(const iamrx_geom* g)
+{
+    Geometry r;
+    for (int d = 0; d < 3; ++d) {
+        r.domain.lo[d] = g->dom_lo[d]; r.domain.hi[d] = g->dom_hi[d];
+        r.problo[d] = g->prob_lo[d]; r.probhi[d] = g->prob_hi[d];
+        r.periodic[d] = g->periodic[d];
+        r.dx[d] = (g->prob_hi[d] - g->prob_lo[d]) / (double)(g->dom_hi[d] - g->dom_lo[d] + 1);
+    }
+    return r;
+}
+
+static MGOpts to_opts(const iamrx_mg_opts* o)
+{
+    MGOpts r;
+    if (!o) return r;
+    r.nu1 = o->nu1; r.nu2 = o->nu2; r.nuf = o->nuf; r.nub = o->nub;
+    r.max_iters = o->max_iters; r.bottom_maxiter = o->bottom_maxiter; r.bottom_reltol = o->bottom_reltol;
+    r.omega = o->omega; r.maxorder = o->maxorder; r.max_coarsening_level = o->max_coarsening_level;
+    r.min_width = o->min_width; r.nodal_sweeps = o->nodal_sweeps; r.nodal_smoother = o->nodal_smoother;
+    r.verbose = o->verbose; r.bottom_smoother_only = o->bottom_smoother_only; r.fixed_iters = o->fixed_iters;
+    return r;
+}
+
+static void from_stats(const MGStats& s, iamrx_mg_stats* o)
+{
+    if (!o) return;
+    o->iters = s.iters; o->resnorm0 = s.resnorm0; o->rhsnorm0 = s.rhsnorm0; o->resnorm = s.resnorm;
+    o->bottom_iters_total = s.bottom_iters_total; o->converged = s.converged; o->vcycle_ms = s.vcycle_ms; o->nlevels = s.nlevels;
+}
+
+static DomainBC to_bc(const int lobc[3], const int hibc[3], int maxorder)
+{
+    DomainBC b;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lobc ? lobc[d] : 0; b.hi[d] = hibc ? hibc[d] : 0; }
+    b.maxorder = maxorder;
+    return b;
+}
+
+extern "C" {
+
+const char* iamrx_last_error(void) { return g_err.c_str(); }
+
+int iamrx_init(int device) { IAMRX_TRY Context::get().init(device); IAMRX_CATCH }
+int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH }
+int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
+void* iamrx_stream(void) { return (void*)Context::get().stream; }
+int iamrx_mem_info(size_t* live, size_t* cached)
+{
+    IAMRX_TRY
+    if (live) *live = Context::get().bytes_live;
+    if (cached) *cached = Context::get().bytes_cached;
+    IAMRX_CATCH
+}
+
+void iamrx_mg_default_opts(iamrx_mg_opts* o)
+{
+    MGOpts d;
+    o->nu1 = d.nu1; o->nu2 = d.nu2; o->nuf = d.nuf; o->nub = d.nub; o->max_iters = d.max_iters;
+    o->bottom_maxiter = d.bottom_maxiter; o->bottom_reltol = d.bottom_reltol; o->omega = d.omega; o->maxorder = d.maxorder;
+    o->max_coarsening_level = d.max_coarsening_level; o->min_width = d.min_width; o->nodal_sweeps = d.nodal_sweeps;
+    o->nodal_smoother = d.nodal_smoother; o->verbose = d.verbose; o->bottom_smoother_only = d.bottom_smoother_only;
+    o->fixed_iters = d.fixed_iters;
+}
+
+int iamrx_layout_create(int nboxes, const int* lo_hi, const int* owner, iamrx_layout* out)
+{
+    IAMRX_TRY
+    IAMRX_ASSERT(Context::get().stream != nullptr);
+    std::vector<BoxD> b(nboxes);
+    std::vector<int> own(nboxes);
+    for (int i = 0; i < nboxes; ++i) {
+        for (int d = 0; d < 3; ++d) { b[i].lo[d] = lo_hi[6 * i + d]; b[i].hi[d] = lo_hi[6 * i + 3 + d]; }
+        own[i] = owner ? owner[i] : 0;
+    }
+    auto* h = new iamrx_layout_s;
+    h->p = std::make_shared<Layout>(b, own, Context::get().comm->rank);
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_layout_destroy(iamrx_layout l) { IAMRX_TRY delete l; IAMRX_CATCH }
+int iamrx_layout_nlocal(iamrx_layout l, int* n) { IAMRX_TRY *n = l->p->nlocal(); IAMRX_CATCH }
+int iamrx_layout_local_box(iamrx_layout l, int li, int lo_hi[6], int* gi)
+{
+    IAMRX_TRY
+    const BoxD& b = l->p->lbox(li);
+    for (int d = 0; d < 3; ++d) { lo_hi[d] = b.lo[d]; lo_hi[3 + d] = b.hi[d]; }
+    if (gi) *gi = l->p->local[li];
+    IAMRX_CATCH
+}
+
+int iamrx_mf_create(iamrx_layout l, const int type[3], int ncomp, int ngrow, iamrx_mf* out)
+{
+    IAMRX_TRY
+    IndexType t{{type[0], type[1], type[2]}};
+    auto* h = new iamrx_mf_s;
+    h->mf.define(l->p, t, ncomp, ngrow);
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_mf_destroy(iamrx_mf m) { IAMRX_TRY delete m; IAMRX_CATCH }
+int iamrx_mf_info(iamrx_mf m, int* ncomp, int* ngrow, int type[3], int* nlocal)
+{
+    IAMRX_TRY
+    if (ncomp) *ncomp = m->mf.ncomp;
+    if (ngrow) *ngrow = m->mf.ngrow;
+    if (type) for (int d = 0; d < 3; ++d) type[d] = m->mf.type.t[d];
+    if (nlocal) *nlocal = m->mf.nlocal();
+    IAMRX_CATCH
+}
+int iamrx_mf_fab_box(iamrx_mf m, int li, int lo_hi[6])
+{
+    IAMRX_TRY
+    BoxD b = m->mf.fabbox(li);
+    for (int d = 0; d < 3; ++d) { lo_hi[d] = b.lo[d]; lo_hi[3 + d] = b.hi[d]; }
+    IAMRX_CATCH
+}
+int iamrx_mf_dev_ptr(iamrx_mf m, int li, double** p) { IAMRX_TRY *p = m->mf.h_tab.at(li).p; IAMRX_CATCH }
+int iamrx_mf_to_host(iamrx_mf m, int li, double* dst) { IAMRX_TRY m->mf.copy_to_host(li, dst); IAMRX_CATCH }
+int iamrx_mf_from_host(iamrx_mf m, int li, const double* src) { IAMRX_TRY m->mf.copy_from_host(li, src); IAMRX_CATCH }
+int iamrx_mf_setval(iamrx_mf m, double v) { IAMRX_TRY m->mf.setVal(v); IAMRX_CATCH }
+int iamrx_mf_copy(iamrx_mf d, iamrx_mf s, int sc, int dc, int nc, int ng) { IAMRX_TRY MultiFab::Copy(d->mf, s->mf, sc, dc, nc, ng); IAMRX_CATCH }
+int iamrx_mf_fill_boundary(iamrx_mf m, const iamrx_geom* g) { IAMRX_TRY m->mf.FillBoundary(to_geom(g)); IAMRX_CATCH }
+int iamrx_mf_norm0(iamrx_mf m, int comp, int nc, int ng, double* out) { IAMRX_TRY *out = m->mf.norm0(comp, nc, ng); IAMRX_CATCH }
+
+static AbecCoef make_coef(double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz, int tensor)
+{
+    AbecCoef c;
+    c.alpha = alpha; c.beta = beta; c.a = a ? &a->mf : nullptr;
+    c.b[0] = &bx->mf; c.b[1] = &by->mf; c.b[2] = &bz->mf; c.tensor = tensor;
+    return c;
+}
+
+int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                    iamrx_mf phi, iamrx_mf rhs, int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder)
+{
+    IAMRX_TRY
+    abec_gsrb(to_geom(g), make_coef(alpha, beta, a, bx, by, bz, 0), phi->mf, rhs->mf, redblack, omega, to_bc(lobc, hibc, maxorder));
+    IAMRX_CATCH
+}
+
+int iamrx_abec_residual(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                        iamrx_mf out, iamrx_mf phi, iamrx_mf rhs, int tensor)
+{
+    IAMRX_TRY
+    abec_residual(to_geom(g), make_coef(alpha, beta, a, bx, by, bz, tensor), out->mf, phi->mf, rhs ? &rhs->mf : nullptr);
+    IAMRX_CATCH
+}
+
+int iamrx_cc_restrict(iamrx_mf c, iamrx_mf f) { IAMRX_TRY cc_restrict(c->mf, f->mf); IAMRX_CATCH }
+int iamrx_cc_prolong_add(iamrx_mf f, iamrx_mf c) { IAMRX_TRY cc_prolong_add(f->mf, c->mf); IAMRX_CATCH }
+int iamrx_face_avgdown(iamrx_mf c, iamrx_mf f, int dir) { IAMRX_TRY face_avgdown(c->mf, f->mf, dir); IAMRX_CATCH }
+
+int iamrx_abec_solve(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                     iamrx_mf phi, iamrx_mf rhs, const int lobc[3], const int hibc[3], double rtol, double atol,
+                     const iamrx_mg_opts* o, int tensor, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    Geometry gg = to_geom(g);
+    MGOpts op = to_opts(o);
+    CellMG mg(gg, phi->mf.layout, phi->mf.ncomp, to_bc(lobc, hibc, op.maxorder), op);
+    mg.setScalars(alpha, beta);
+    if (a) mg.setACoeffs(&a->mf);
+    const MultiFab* b[3] = {&bx->mf, &by->mf, &bz->mf};
+    MultiFab tb[3];
+    if (tensor) {
+        // MLTensorOp::setShearViscosity: b_d(comp) = eta_d * (comp == d ? 4/3 : 1)
+        for (int d = 0; d < 3; ++d) {
+            tb[d].define(phi->mf.layout, face_type(d), 3, 0);
+            tensor_bcoef(tb[d], *b[d], d);
+            b[d] = &tb[d];
+        }
+        mg.setTensor(true);
+    }
+    mg.setBCoeffs(b);
+    mg.prepare();
+    MGStats s = mg.solve(phi->mf, rhs->mf, rtol, atol);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_mlmg_mac_solve(const iamrx_geom* g, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz, iamrx_mf rho, int rho_comp, iamrx_mf S,
+                         iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3], double mac_tol,
+                         double mac_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
+    MGStats s = mlmg_mac_solve(to_geom(g), um, rho->mf, rho_comp, S ? &S->mf : nullptr, mac_phi->mf, rhs_scale,
+                               to_bc(lobc, hibc, op.maxorder), mac_tol, mac_abs_tol, op, nullptr);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz)
+{
+    IAMRX_TRY
+    const MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
+    mac_divergence(to_geom(g), div->mf, um);
+    IAMRX_CATCH
+}
+
+}  // extern "C"

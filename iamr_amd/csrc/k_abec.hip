@@ -1,0 +1,374 @@
+// iamr_amd/csrc/k_abec.hip -- hand-written gfx950 kernels for the cell-centred (alpha*a - beta div b grad)
+// operator: red-black Gauss-Seidel, residual/apply, restriction, prolongation, face coefficient
+// coarsening, fluxes, and the MAC-projection helpers.
+//
+// Role: AMReX MLABecLaplacian / MLCellLinOp primitives used through Hydro::MacProjector at reference
+// Source/MacProj.cpp:1150-1183 and through MLMG at Source/Diffusion.cpp:327-345.
+// All kernels are HBM-bandwidth bound (7-point stencil, fp64): rows are read as contiguous 64-lane
+// wavefront segments, each workgroup marches TZ planes so the k-1/k/k+1 planes are re-used from L1/L2.
+#include "kernels.h"
+#include "launch.h"
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace iamrx {
+
+struct GsrbBC {
+    int dlo[3], dhi[3];
+    double cflo[3], cfhi[3];   // coefficient of the first interior cell in the ghost formula; 0 for periodic
+};
+
+// Lagrange weights for ghost-cell extrapolation through a Dirichlet face (AMReX poly_interp_coeff):
+// points x = {0 (face), 0.5, 1.5, 2.5}, evaluated at -0.5
+static void poly_interp_coeff(double xi, const double* x, int N, double* c)
+{
+    for (int j = 0; j < N; ++j) {
+        double num = 1.0, den = 1.0;
+        for (int i = 0; i < N; ++i) { if (i == j) continue; num *= xi - x[i]; den *= x[j] - x[i]; }
+        c[j] = num / den;
+    }
+}
+static void dirichlet_coefs(int blen, int maxorder, double c[4], int& NX)
+{
+    NX = blen + 1 < maxorder ? blen + 1 : maxorder;
+    const double x[4] = {0.0, 0.5, 1.5, 2.5};
+    c[0] = c[1] = c[2] = c[3] = 0.0;
+    if (NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
+}
+
+static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC& bc)
+{
+    GsrbBC r;
+    for (int d = 0; d < 3; ++d) {
+        r.dlo[d] = g.domain.lo[d]; r.dhi[d] = g.domain.hi[d];
+        r.cflo[d] = r.cfhi[d] = 0.0;
+        if (g.periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            const int b = side == 0 ? bc.lo[d] : bc.hi[d];
+            double cf = 0.0;
+            if (b == lo_neumann) cf = 1.0;
+            else if (b == lo_dirichlet) { double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX); cf = NX >= 2 ? c[1] : 0.0; }
+            (side == 0 ? r.cflo[d] : r.cfhi[d]) = cf;
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------- GSRB
+// One thread per cell of the active colour: lane m of a row handles i = lo + 2m + parity, so a
+// wavefront sweeps 128 consecutive cells of a row; phi(i+-1) and the b pairs are contiguous across
+// lanes.  b arrays have either ncomp comps or 1 (broadcast).
+__global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
+    const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    BoxD hb = b;
+    hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
+    int ih, j, k0, k1;
+    if (!tile_ijk(t, hb, ih, j, k0, k1)) return;
+    const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
+    const bool has_a = (at != nullptr) && alpha != 0.0;
+    FabD A; if (has_a) A = at[fab];
+    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[1] : 0.0;
+    for (int n = 0; n < ncomp; ++n) {
+        const int nb = bnc == 1 ? 0 : n;
+        for (int k = k0; k <= k1; ++k) {
+            const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
+            if (i > b.hi[0]) continue;
+            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[0] : 0.0;
+            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[2] : 0.0;
+            const double bxm = bX(i, j, k, nb), bxp = bX(i + 1, j, k, nb);
+            const double bym = bY(i, j, k, nb), byp = bY(i, j + 1, k, nb);
+            const double bzm = bZ(i, j, k, nb), bzp = bZ(i, j, k + 1, nb);
+            const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
+            const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+            const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
+            const double rho = dhx * (bxm * phi(i - 1, j, k, n) + bxp * phi(i + 1, j, k, n))
+                             + dhy * (bym * phi(i, j - 1, k, n) + byp * phi(i, j + 1, k, n))
+                             + dhz * (bzm * phi(i, j, k - 1, n) + bzp * phi(i, j, k + 1, n));
+            const double p0 = phi(i, j, k, n);
+            const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
+            phi(i, j, k, n) = p0 + omega / g_m_d * res;
+        }
+    }
+}
+
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC& bc)
+{
+    if (phi.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    const Layout& l = *phi.layout;
+    int ml[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
+    Tiling t = make_tiling(ml, l.nlocal(), 8);
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    GsrbBC gb = make_gsrb_bc(g, bc);
+    hipLaunchKernelGGL(k_abec_gsrb, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                       c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb);
+}
+
+// ---------------------------------------------------------------------------- residual / apply
+__global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ outt, const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
+    const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
+    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    int i, j, k0, k1;
+    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    const FabD out = outt[fab], phi = phit[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
+    const bool has_rhs = rhst != nullptr;
+    FabD rhs; if (has_rhs) rhs = rhst[fab];
+    const bool has_a = (at != nullptr) && alpha != 0.0;
+    FabD A; if (has_a) A = at[fab];
+    for (int n = 0; n < ncomp; ++n) {
+        const int nb = bnc == 1 ? 0 : n;
+        double pm = phi(i, j, k0 - 1, n), p0 = phi(i, j, k0, n);
+        for (int k = k0; k <= k1; ++k) {
+            const double pp = phi(i, j, k + 1, n);
+            const double ax = has_a ? alpha * A(i, j, k, 0) * p0 : 0.0;
+            const double y = ax
+                - dhx * (bX(i + 1, j, k, nb) * (phi(i + 1, j, k, n) - p0) - bX(i, j, k, nb) * (p0 - phi(i - 1, j, k, n)))
+                - dhy * (bY(i, j + 1, k, nb) * (phi(i, j + 1, k, n) - p0) - bY(i, j, k, nb) * (p0 - phi(i, j - 1, k, n)))
+                - dhz * (bZ(i, j, k + 1, nb) * (pp - p0) - bZ(i, j, k, nb) * (p0 - pm));
+            out(i, j, k, n) = has_rhs ? rhs(i, j, k, n) - y : y;
+            pm = p0; p0 = pp;
+        }
+    }
+}
+
+void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);   // k_tensor.hip
+
+void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs)
+{
+    if (phi.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    const Layout& l = *phi.layout;
+    Tiling t = level_tiling(l, cell_type(), 0, 8);
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    hipLaunchKernelGGL(k_abec_residual, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
+                       rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                       c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp);
+    if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0);
+}
+
+// ---------------------------------------------------------------------------- domain BC ghost fill
+struct BndryDesc { int fab; BoxD region; int dir, side; };
+
+__global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ descs, const FabD* __restrict__ phit,
+                                                 const FabD* __restrict__ bcvt, int ncomp, int bct_unused,
+                                                 const int* __restrict__ bctype, const double* __restrict__ coefs, int inhomog)
+{
+    const BndryDesc bd = descs[blockIdx.y];
+    const FabD phi = phit[bd.fab];
+    const int nx = bd.region.len(0), ny = bd.region.len(1);
+    const long npts = bd.region.npts();
+    const int d = bd.dir, s = 1 - 2 * bd.side;
+    const int bct = bctype[2 * d + bd.side];
+    const double* c = coefs + 5 * (2 * d + bd.side);   // c[0..3] weights, c[4] = NX
+    const int NX = (int)c[4];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        int idx[3];
+        idx[0] = bd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        idx[1] = bd.region.lo[1] + (int)(r % ny);
+        idx[2] = bd.region.lo[2] + (int)(r / ny);
+        for (int n = 0; n < ncomp; ++n) {
+            double v;
+            int m[3] = {idx[0], idx[1], idx[2]};
+            if (bct == lo_neumann) { m[d] += s; v = phi(m[0], m[1], m[2], n); }
+            else {
+                const double bv = (inhomog && bcvt) ? bcvt[bd.fab](idx[0], idx[1], idx[2], n) : 0.0;
+                if (NX < 2) v = bv;
+                else {
+                    double tmp = 0.0;
+                    for (int q2 = 1; q2 < NX; ++q2) { m[d] = idx[d] + q2 * s; tmp += phi(m[0], m[1], m[2], n) * c[q2]; }
+                    v = tmp + bv * c[0];
+                }
+            }
+            phi(idx[0], idx[1], idx[2], n) = v;
+        }
+    }
+}
+
+void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval)
+{
+    bool any = false;
+    for (int d = 0; d < 3; ++d) if (!g.periodic[d]) any = true;
+    if (!any || phi.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    std::vector<BndryDesc> descs;
+    long maxpts = 0;
+    for (int li = 0; li < phi.nlocal(); ++li) {
+        const BoxD vb = phi.layout->lbox(li);
+        for (int d = 0; d < 3; ++d) {
+            if (g.periodic[d]) continue;
+            for (int side = 0; side < 2; ++side) {
+                const int bt = side == 0 ? bc.lo[d] : bc.hi[d];
+                if (bt != lo_neumann && bt != lo_dirichlet) continue;
+                if (side == 0 && vb.lo[d] != g.domain.lo[d]) continue;
+                if (side == 1 && vb.hi[d] != g.domain.hi[d]) continue;
+                BndryDesc bd; bd.fab = li; bd.dir = d; bd.side = side; bd.region = vb;
+                bd.region.lo[d] = bd.region.hi[d] = side == 0 ? vb.lo[d] - 1 : vb.hi[d] + 1;
+                descs.push_back(bd);
+                maxpts = std::max(maxpts, bd.region.npts());
+            }
+        }
+    }
+    if (descs.empty()) return;
+    // small parameter block: bc types (6 ints) and extrapolation weights (6 x 5 doubles)
+    int h_bct[6]; double h_c[30];
+    for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+        h_bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
+        double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX);
+        for (int q = 0; q < 4; ++q) h_c[5 * (2 * d + side) + q] = c[q];
+        h_c[5 * (2 * d + side) + 4] = NX;
+    }
+    const size_t bytes = descs.size() * sizeof(BndryDesc) + sizeof(h_bct) + sizeof(h_c) + 64;
+    char* dbuf = (char*)ctx.alloc(bytes);
+    std::vector<char> hbuf(bytes);
+    size_t o1 = (descs.size() * sizeof(BndryDesc) + 15) & ~size_t(15), o2 = o1 + 32;
+    memcpy(hbuf.data(), descs.data(), descs.size() * sizeof(BndryDesc));
+    memcpy(hbuf.data() + o1, h_bct, sizeof(h_bct));
+    memcpy(hbuf.data() + o2, h_c, sizeof(h_c));
+    IAMRX_HIP_CHECK(hipMemcpyAsync(dbuf, hbuf.data(), bytes, hipMemcpyHostToDevice, ctx.stream));
+    long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_abec_bc, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream,
+                       (const BndryDesc*)dbuf, phi.d_tab, bcval ? bcval->d_tab : nullptr, phi.ncomp, 0,
+                       (const int*)(dbuf + o1), (const double*)(dbuf + o2), inhomog ? 1 : 0);
+    ctx.sync();          // hbuf is pageable host memory: keep it alive until the copy has completed
+    ctx.free(dbuf);
+}
+
+// ---------------------------------------------------------------------------- transfers
+__global__ void __launch_bounds__(256) k_cc_restrict(Tiling t, const BoxD* __restrict__ cboxes, const FabD* __restrict__ ct,
+                                                     const FabD* __restrict__ ft, int ncomp)
+{
+    const int fab = blockIdx.y;
+    int i, j, k0, k1;
+    if (!tile_ijk(t, cboxes[fab], i, j, k0, k1)) return;
+    const FabD c = ct[fab], f = ft[fab];
+    for (int n = 0; n < ncomp; ++n)
+        for (int k = k0; k <= k1; ++k) {
+            double s = 0.0;
+            for (int kr = 0; kr < 2; ++kr)
+                for (int jr = 0; jr < 2; ++jr) {
+                    s += f(2 * i, 2 * j + jr, 2 * k + kr, n);
+                    s += f(2 * i + 1, 2 * j + jr, 2 * k + kr, n);
+                }
+            c(i, j, k, n) = 0.125 * s;
+        }
+}
+
+void cc_restrict(MultiFab& crse, const MultiFab& fine)
+{
+    if (crse.nlocal() == 0) return;
+    Tiling t = level_tiling(*crse.layout, cell_type(), 0, 4);
+    hipLaunchKernelGGL(k_cc_restrict, t.grid(), Tiling::block(), 0, Context::get().stream, t, crse.layout->d_boxes, crse.d_tab, fine.d_tab, crse.ncomp);
+}
+
+void cc_prolong_add(MultiFab& fine, const MultiFab& crse)
+{
+    if (fine.nlocal() == 0) return;
+    const FabD *ft = fine.d_tab, *ct = crse.d_tab;
+    const int nc = fine.ncomp;
+    for_each(*fine.layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD fa = ft[f], ca = ct[f];
+        for (int n = 0; n < nc; ++n) fa(i, j, k, n) += ca(i >> 1, j >> 1, k >> 1, n);
+    });
+}
+
+void face_avgdown(MultiFab& crse, const MultiFab& fine, int dir)
+{
+    if (crse.nlocal() == 0) return;
+    const FabD *ft = fine.d_tab, *ct = crse.d_tab;
+    const int nc = crse.ncomp;
+    const int d1 = (dir + 1) % 3, d2 = (dir + 2) % 3;
+    const int da = d1 < d2 ? d1 : d2, db = d1 < d2 ? d2 : d1;
+    for_each(*crse.layout, face_type(dir), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD fa = ft[f], ca = ct[f];
+        const int c[3] = {i, j, k};
+        for (int n = 0; n < nc; ++n) {
+            double s = 0.0;
+            for (int rb = 0; rb < 2; ++rb)
+                for (int ra = 0; ra < 2; ++ra) {
+                    int q[3];
+                    q[dir] = 2 * c[dir]; q[da] = 2 * c[da] + ra; q[db] = 2 * c[db] + rb;
+                    s += fa(q[0], q[1], q[2], n);
+                }
+            ca(i, j, k, n) = s * 0.25;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------- fluxes / MAC helpers
+void abec_flux(const Geometry& g, const AbecCoef& c, const MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_to[3])
+{
+    if (phi.nlocal() == 0) return;
+    const FabD* pt = phi.d_tab;
+    const int nc = phi.ncomp;
+    for (int d = 0; d < 3; ++d) {
+        const double fac = c.beta / g.dx[d];
+        const FabD* bt = c.b[d]->d_tab;
+        const int bnc = c.b[d]->ncomp;
+        const FabD* ft = flux && flux[d] ? flux[d]->d_tab : nullptr;
+        const FabD* ut = add_to && add_to[d] ? add_to[d]->d_tab : nullptr;
+        for_each(*phi.layout, face_type(d), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const FabD p = pt[f], b = bt[f];
+            int m[3] = {i, j, k}; m[d] -= 1;
+            for (int n = 0; n < nc; ++n) {
+                const double fl = -fac * b(i, j, k, bnc == 1 ? 0 : n) * (p(i, j, k, n) - p(m[0], m[1], m[2], n));
+                if (ft) ft[f](i, j, k, n) = fl;
+                if (ut) ut[f](i, j, k, n) += fl;
+            }
+        });
+    }
+}
+
+void mac_divergence(const Geometry& g, MultiFab& div, const MultiFab* const umac[3])
+{
+    if (div.nlocal() == 0) return;
+    const FabD *dt = div.d_tab, *ut = umac[0]->d_tab, *vt = umac[1]->d_tab, *wt = umac[2]->d_tab;
+    const double dx = g.dx[0], dy = g.dx[1], dz = g.dx[2];
+    for_each(*div.layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD u = ut[f], v = vt[f], w = wt[f];
+        dt[f](i, j, k, 0) = (u(i + 1, j, k) - u(i, j, k)) / dx + (v(i, j + 1, k) - v(i, j, k)) / dy + (w(i, j, k + 1) - w(i, j, k)) / dz;
+    });
+}
+
+void mac_rhs(const Geometry& g, MultiFab& rhs, const MultiFab* const umac[3], const MultiFab* S)
+{
+    if (rhs.nlocal() == 0) return;
+    const FabD *rt = rhs.d_tab, *ut = umac[0]->d_tab, *vt = umac[1]->d_tab, *wt = umac[2]->d_tab;
+    const FabD* st = S ? S->d_tab : nullptr;
+    const double dx = g.dx[0], dy = g.dx[1], dz = g.dx[2];
+    for_each(*rhs.layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD u = ut[f], v = vt[f], w = wt[f];
+        const double div = (u(i + 1, j, k) - u(i, j, k)) / dx + (v(i, j + 1, k) - v(i, j, k)) / dy + (w(i, j, k + 1) - w(i, j, k)) / dz;
+        double r = -div;
+        if (st) r += st[f](i, j, k, 0);
+        rt[f](i, j, k, 0) = r;
+    });
+}
+
+void mac_bcoef(MultiFab* const b[3], const MultiFab& rho, int rho_comp, double scale)
+{
+    if (rho.nlocal() == 0) return;
+    const FabD* rt = rho.d_tab;
+    for (int d = 0; d < 3; ++d) {
+        const FabD* bt = b[d]->d_tab;
+        for_each(*rho.layout, face_type(d), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const FabD r = rt[f];
+            int m[3] = {i, j, k}; m[d] -= 1;
+            const double rf = 0.5 * (r(m[0], m[1], m[2], rho_comp) + r(i, j, k, rho_comp));
+            bt[f](i, j, k, 0) = scale / rf;
+        });
+    }
+}
+
+}  // namespace iamrx

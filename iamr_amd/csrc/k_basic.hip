@@ -1,0 +1,305 @@
+// iamr_amd/csrc/k_basic.hip -- streaming kernels: fill, plan copies (ghost exchange), BLAS-1 style
+// fused ops and deterministic two-stage reductions (block partials -> single-block finish).
+// Role: amrex MultiFab::{setVal,Copy,Saxpy,Xpay,mult,norm0}, FillBoundary pack/unpack.
+#include "kernels.h"
+#include "launch.h"
+
+namespace iamrx {
+
+__global__ void __launch_bounds__(256) k_fill(double* __restrict__ p, size_t n, double v)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+void launch_fill(double* p, size_t n, double v, hipStream_t s)
+{
+    if (n == 0) return;
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)nb), dim3(256), 0, s, p, n, v);
+}
+
+// one blockIdx.y per copy descriptor; threads stride over region points (x fastest => coalesced rows)
+__global__ void __launch_bounds__(256) k_copy_plan(const CopyDesc* __restrict__ descs, const FabD* __restrict__ src,
+                                                   const FabD* __restrict__ dst, int scomp, int dcomp, int nc)
+{
+    const CopyDesc cd = descs[blockIdx.y];
+    const int nx = cd.region.len(0), ny = cd.region.len(1);
+    const long npts = cd.region.npts();
+    const FabD s = src[cd.src_fab], d = dst[cd.dst_fab];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        const int i = cd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        const int j = cd.region.lo[1] + (int)(r % ny);
+        const int k = cd.region.lo[2] + (int)(r / ny);
+        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+    }
+}
+
+void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s)
+{
+    if (nd == 0) return;
+    long nb = (maxpts + 255) / 256;
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_copy_plan, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, dst, scomp, dcomp, nc);
+}
+
+__global__ void __launch_bounds__(256) k_pack(const CopyDesc* __restrict__ descs, const FabD* __restrict__ src,
+                                              double* __restrict__ buf, long pts_total, int scomp, int nc)
+{
+    const CopyDesc cd = descs[blockIdx.y];
+    const int nx = cd.region.len(0), ny = cd.region.len(1);
+    const long npts = cd.region.npts();
+    const FabD s = src[cd.src_fab];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        const int i = cd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        const int j = cd.region.lo[1] + (int)(r % ny);
+        const int k = cd.region.lo[2] + (int)(r / ny);
+        for (int n = 0; n < nc; ++n) buf[cd.buf_off + q + pts_total * n] = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unpack(const CopyDesc* __restrict__ descs, const FabD* __restrict__ dst,
+                                                const double* __restrict__ buf, long pts_total, int dcomp, int nc)
+{
+    const CopyDesc cd = descs[blockIdx.y];
+    const int nx = cd.region.len(0), ny = cd.region.len(1);
+    const long npts = cd.region.npts();
+    const FabD d = dst[cd.dst_fab];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        const int i = cd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        const int j = cd.region.lo[1] + (int)(r % ny);
+        const int k = cd.region.lo[2] + (int)(r / ny);
+        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = buf[cd.buf_off + q + pts_total * n];
+    }
+}
+
+void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s)
+{
+    if (nd == 0) return;
+    long nb = (maxpts + 255) / 256; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, buf, pts_total, scomp, nc);
+}
+void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s)
+{
+    if (nd == 0) return;
+    long nb = (maxpts + 255) / 256; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, dst, buf, pts_total, dcomp, nc);
+}
+
+// ------------------------------------------------------------------ reductions
+// wavefront (64 lanes) shuffle reduction, then LDS across the 4 waves of the workgroup
+template <int OP> __device__ __forceinline__ double red_op(double a, double b)
+{
+    if (OP == 0) return a + b;
+    return a > b ? a : b;
+}
+template <int OP> __device__ __forceinline__ double block_reduce(double v)
+{
+    __shared__ double sm[4];
+    for (int off = 32; off > 0; off >>= 1) v = red_op<OP>(v, __shfl_down(v, off, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) v = red_op<OP>(red_op<OP>(sm[0], sm[1]), red_op<OP>(sm[2], sm[3]));
+    return v;   // valid in thread 0
+}
+
+// stage 2: out[q] = reduce over partials[q*np .. q*np+np)
+template <int OP> __global__ void __launch_bounds__(256) k_reduce_finish(const double* __restrict__ partials, int np, double* __restrict__ out)
+{
+    const int q = blockIdx.x;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) v = red_op<OP>(v, partials[(size_t)q * np + i]);
+    v = block_reduce<OP>(v);
+    if (threadIdx.x == 0) out[q] = v;
+}
+
+__global__ void __launch_bounds__(256) k_norm0(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
+                                               const FabD* __restrict__ tab, int comp, int nc, double* __restrict__ partials)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    double m = 0.0;
+    if (tile_ijk(t, b, i, j, k0, k1)) {
+        const FabD a = tab[fab];
+        for (int n = 0; n < nc; ++n)
+            for (int k = k0; k <= k1; ++k) { double v = fabs(a(i, j, k, comp + n)); m = v > m ? v : m; }
+    }
+    m = block_reduce<1>(m);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+static double finish_to_host(int op, int nout, int np)
+{
+    auto& ctx = Context::get();
+    double* partials = ctx.d_scratch;
+    double* out = ctx.d_scratch + (size_t)nout * np;
+    if (op == 0) hipLaunchKernelGGL((k_reduce_finish<0>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
+    else hipLaunchKernelGGL((k_reduce_finish<1>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
+    IAMRX_HIP_CHECK(hipMemcpyAsync(ctx.h_scratch, out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx.stream));
+    ctx.sync();
+    return ctx.h_scratch[0];
+}
+
+double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng)
+{
+    if (mf.nlocal() == 0) return 0.0;
+    auto& ctx = Context::get();
+    Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+    dim3 g = t.grid();
+    const int np = (int)(g.x * g.y);
+    ctx.ensure_scratch((size_t)np + 16);
+    hipLaunchKernelGGL(k_norm0, g, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, mf.type.t[0], mf.type.t[1], mf.type.t[2], ng,
+                       mf.d_tab, comp, nc, ctx.d_scratch);
+    return finish_to_host(1, 1, np);
+}
+
+// owner mask for nodal / face data: a box owns index hi+1 in a nodal direction only on a
+// non-periodic domain boundary (elsewhere that point is the low point of a neighbouring box or a
+// periodic image)
+struct OwnerInfo { int type[3]; int dhi[3]; int per[3]; };
+__device__ __forceinline__ bool is_owner(const OwnerInfo& o, const BoxD& cellbox, int i, int j, int k)
+{
+    const int idx[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d)
+        if (o.type[d] && idx[d] == cellbox.hi[d] + 1 && (o.per[d] || idx[d] != o.dhi[d] + 1)) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_dots(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own, int nout,
+                                              const FabD* x0, const FabD* y0, const FabD* x1, const FabD* y1,
+                                              int comp, int nc, double* __restrict__ partials, int np)
+{
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    const BoxD b = dev_grow_convert(cb, own.type[0], own.type[1], own.type[2], 0);
+    int i, j, k0, k1;
+    double s0 = 0.0, s1 = 0.0;
+    if (tile_ijk(t, b, i, j, k0, k1)) {
+        const FabD a0 = x0[fab], b0 = y0[fab];
+        for (int n = 0; n < nc; ++n)
+            for (int k = k0; k <= k1; ++k)
+                if (is_owner(own, cb, i, j, k)) s0 += a0(i, j, k, comp + n) * b0(i, j, k, comp + n);
+        if (nout > 1) {
+            const FabD a1 = x1[fab], b1 = y1[fab];
+            for (int n = 0; n < nc; ++n)
+                for (int k = k0; k <= k1; ++k)
+                    if (is_owner(own, cb, i, j, k)) s1 += a1(i, j, k, comp + n) * b1(i, j, k, comp + n);
+        }
+    }
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    s0 = block_reduce<0>(s0);
+    if (threadIdx.x == 0) partials[slot] = s0;
+    if (nout > 1) {
+        s1 = block_reduce<0>(s1);
+        if (threadIdx.x == 0) partials[(size_t)np + slot] = s1;
+    }
+}
+
+void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local)
+{
+    IAMRX_ASSERT(nout == 1 || nout == 2);
+    auto& ctx = Context::get();
+    const MultiFab& m = *x[0];
+    for (int q = 0; q < nout; ++q) out[q] = 0.0;
+    if (m.nlocal() > 0) {
+        Tiling t = level_tiling(*m.layout, m.type, 0, 8);
+        dim3 gr = t.grid();
+        const int np = (int)(gr.x * gr.y);
+        ctx.ensure_scratch((size_t)np * nout + 16);
+        OwnerInfo own;
+        for (int d = 0; d < 3; ++d) { own.type[d] = m.type.t[d]; own.dhi[d] = g.domain.hi[d]; own.per[d] = g.periodic[d]; }
+        hipLaunchKernelGGL(k_dots, gr, Tiling::block(), 0, ctx.stream, t, m.layout->d_boxes, own, nout,
+                           x[0]->d_tab, y[0]->d_tab, nout > 1 ? x[1]->d_tab : nullptr, nout > 1 ? y[1]->d_tab : nullptr,
+                           comp, nc, ctx.d_scratch, np);
+        finish_to_host(0, nout, np);
+        for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q];
+    }
+    if (!local) ctx.comm->allreduce(out, nout, ReduceOp::Sum);
+}
+
+__global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own,
+                                                    const FabD* __restrict__ tab, int comp, double* __restrict__ partials)
+{
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    const BoxD b = dev_grow_convert(cb, own.type[0], own.type[1], own.type[2], 0);
+    int i, j, k0, k1;
+    double s = 0.0;
+    if (tile_ijk(t, b, i, j, k0, k1)) {
+        const FabD a = tab[fab];
+        for (int k = k0; k <= k1; ++k)
+            if (is_owner(own, cb, i, j, k)) s += a(i, j, k, comp);
+    }
+    s = block_reduce<0>(s);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g)
+{
+    if (mf.nlocal() == 0) return 0.0;
+    auto& ctx = Context::get();
+    Tiling t = level_tiling(*mf.layout, mf.type, 0, 8);
+    dim3 gr = t.grid();
+    const int np = (int)(gr.x * gr.y);
+    ctx.ensure_scratch((size_t)np + 16);
+    OwnerInfo own;
+    for (int d = 0; d < 3; ++d) {
+        own.type[d] = mf.type.t[d];
+        own.dhi[d] = g.domain.hi[d];
+        own.per[d] = g.periodic[d];
+    }
+    hipLaunchKernelGGL(k_sum_unique, gr, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, own, mf.d_tab, comp, ctx.d_scratch);
+    return finish_to_host(0, 1, np);
+}
+
+// ------------------------------------------------------------------ BLAS-1 style
+void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const MultiFab& y, int comp, int nc, int ng)
+{
+    if (!dst.base) return;
+    const FabD *dt = dst.d_tab, *xt = x.d_tab, *yt = y.d_tab;
+    for_each(*dst.layout, dst.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD d = dt[f], xx = xt[f], yy = yt[f];
+        for (int n = 0; n < nc; ++n) d(i, j, k, comp + n) = a * xx(i, j, k, comp + n) + b * yy(i, j, k, comp + n);
+    });
+}
+
+void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, int nc, int ng)
+{
+    if (!y.base) return;
+    const FabD *yt = y.d_tab, *xt = x.d_tab;
+    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD yy = yt[f], xx = xt[f];
+        for (int n = 0; n < nc; ++n) yy(i, j, k, ycomp + n) += a * xx(i, j, k, xcomp + n);
+    });
+}
+
+void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng)
+{
+    if (!y.base) return;
+    const FabD* yt = y.d_tab;
+    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD yy = yt[f];
+        for (int n = 0; n < nc; ++n) yy(i, j, k, comp + n) += a;
+    });
+}
+
+void mf_mult(MultiFab& y, double a, int comp, int nc, int ng)
+{
+    if (!y.base) return;
+    const FabD* yt = y.d_tab;
+    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD yy = yt[f];
+        for (int n = 0; n < nc; ++n) yy(i, j, k, comp + n) *= a;
+    });
+}
+
+}  // namespace iamrx

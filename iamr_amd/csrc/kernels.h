@@ -1,0 +1,52 @@
+// iamr_amd/csrc/kernels.h -- host-callable launchers of the hand-written HIP kernels (gfx950).
+#pragma once
+#include "core.h"
+#include "mf.h"
+
+namespace iamrx {
+
+// ---- k_basic.hip --------------------------------------------------------------------------
+void launch_fill(double* p, size_t n, double v, hipStream_t s);
+void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s);
+void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s);
+void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s);
+double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng);
+double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g);   // local sum over owner copies
+// nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>
+void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);
+// y = a*x + b*y etc. (valid region + ng)
+void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const MultiFab& y, int comp, int nc, int ng);   // dst = a*x + b*y
+void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, int nc, int ng);                          // y += a*x
+void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng);
+void mf_mult(MultiFab& y, double a, int comp, int nc, int ng);
+
+// ---- k_abec.hip ---------------------------------------------------------------------------
+struct AbecCoef {
+    double alpha, beta;
+    const MultiFab* a;        // cell, 1 comp (may be null)
+    const MultiFab* b[3];     // face, ncomp comps (or 1 comp broadcast if b_ncomp == 1)
+    int tensor;               // add MLTensorOp cross terms in apply/residual
+};
+struct DomainBC {             // linear-operator BC of the level's domain
+    int lo[3], hi[3];         // LinOpBC per face
+    int maxorder;
+};
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC& bc);
+// out = rhs - L(phi)  (rhs == nullptr: out = L(phi))
+void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs);
+void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval);
+void cc_restrict(MultiFab& crse, const MultiFab& fine);          // average of 8
+void cc_prolong_add(MultiFab& fine, const MultiFab& crse);       // piecewise constant
+void face_avgdown(MultiFab& crse, const MultiFab& fine, int dir);
+// flux_d = -beta*b_d*dphi/dx_d ; if add_to != nullptr: add_to[d] += flux_d instead of storing
+void abec_flux(const Geometry& g, const AbecCoef& c, const MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_to[3]);
+void mac_rhs(const Geometry& g, MultiFab& rhs, const MultiFab* const umac[3], const MultiFab* S);   // rhs = S - div(umac)
+void mac_bcoef(MultiFab* const b[3], const MultiFab& rho, int rho_comp, double scale);                 // b = scale / avg_face(rho)
+void mac_divergence(const Geometry& g, MultiFab& div, const MultiFab* const umac[3]);
+
+// ---- k_tensor.hip -------------------------------------------------------------------------
+void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
+void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc);
+
+}  // namespace iamrx

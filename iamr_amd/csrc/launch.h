@@ -1,0 +1,91 @@
+// iamr_amd/csrc/launch.h -- level-wide launch geometry for gfx950.
+//
+// One launch covers every local FAB of a level: blockIdx.y = local fab, blockIdx.x = tile.
+// A workgroup is 256 threads = 4 wavefronts of 64; a tile is BX x BY x TZ index points with
+// BX*BY = 256, BX a power of two <= 64 so that each wavefront reads one contiguous x-row segment
+// (coalesced 512 B per row for BX = 64).  Each thread marches TZ points in z.
+#pragma once
+#include "core.h"
+#include "mf.h"
+
+namespace iamrx {
+
+struct Tiling {
+    int bxs;            // log2(BX)
+    int ntx, nty, ntz;  // tiles per direction (for the largest local box)
+    int tz;             // z points per thread
+    int nfab;
+    dim3 grid() const { return dim3((unsigned)(ntx * nty * ntz), (unsigned)(nfab > 0 ? nfab : 1), 1); }
+    static dim3 block() { return dim3(256, 1, 1); }
+};
+
+inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
+{
+    Tiling t;
+    int bx = 64, bxs = 6;
+    while (bx > 4 && bx / 2 >= maxlen[0]) { bx /= 2; --bxs; }
+    int by = 256 / bx;
+    t.bxs = bxs;
+    t.ntx = (maxlen[0] + bx - 1) / bx;
+    t.nty = (maxlen[1] + by - 1) / by;
+    t.tz = tz;
+    t.ntz = (maxlen[2] + tz - 1) / tz;
+    t.nfab = nfab;
+    return t;
+}
+
+// tiling for the local boxes of `l` converted to `type` and grown by ng
+inline Tiling level_tiling(const Layout& l, const IndexType& type, int ng, int tz = 4)
+{
+    int ml[3];
+    for (int d = 0; d < 3; ++d) ml[d] = l.max_len[d] + type.t[d] + 2 * ng;
+    return make_tiling(ml, l.nlocal(), tz);
+}
+
+#ifdef __HIPCC__
+// decode (i, j, k-range) of this thread inside box b; returns false if (i,j) is outside
+__device__ __forceinline__ bool tile_ijk(const Tiling& t, const BoxD& b, int& i, int& j, int& k0, int& k1)
+{
+    const int bx = 1 << t.bxs;
+    const int tid = threadIdx.x;
+    const int tx = tid & (bx - 1), ty = tid >> t.bxs;
+    const int bid = blockIdx.x;
+    const int bxi = bid % t.ntx;
+    const int r = bid / t.ntx;
+    const int byi = r % t.nty, bzi = r / t.nty;
+    i = b.lo[0] + bxi * bx + tx;
+    j = b.lo[1] + byi * (256 >> t.bxs) + ty;
+    k0 = b.lo[2] + bzi * t.tz;
+    k1 = k0 + t.tz - 1;
+    if (k1 > b.hi[2]) k1 = b.hi[2];
+    return i <= b.hi[0] && j <= b.hi[1] && k0 <= b.hi[2];
+}
+
+__device__ __forceinline__ BoxD dev_grow_convert(BoxD b, int t0, int t1, int t2, int ng)
+{
+    b.lo[0] -= ng; b.lo[1] -= ng; b.lo[2] -= ng;
+    b.hi[0] += t0 + ng; b.hi[1] += t1 + ng; b.hi[2] += t2 + ng;
+    return b;
+}
+
+// generic level-wide loop: f(i,j,k,fab) for every point of (valid box converted to type, grown ng)
+template <class F>
+__global__ void __launch_bounds__(256) k_for_each(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, F f)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    for (int k = k0; k <= k1; ++k) f(i, j, k, fab);
+}
+
+template <class F>
+inline void for_each(const Layout& l, const IndexType& type, int ng, hipStream_t s, F f)
+{
+    if (l.nlocal() == 0) return;
+    Tiling t = level_tiling(l, type, ng);
+    hipLaunchKernelGGL((k_for_each<F>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f);
+}
+#endif
+
+}  // namespace iamrx

@@ -1,0 +1,36 @@
+// iamr_amd/csrc/macproj.hip -- MAC (face velocity) projection.
+// Mirrors MacProj::mlmg_mac_solve (reference Source/MacProj.cpp:1084-1184) and the Hydro::MacProjector
+// it drives: beta_face = average_cellcenter_to_face(rho) -> invert(1/rhs_scale) -> FillBoundary
+// (:1115-1127); rhs = S - div(u_mac); solve -div(beta grad phi) = rhs to (mac_tol, mac_abs_tol) with
+// max_order 4 (:1172); u_mac += -beta grad phi (getFluxes, :1181-1183).
+#include "operators.h"
+#include "launch.h"
+
+namespace iamrx {
+
+MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFab& rho, int rho_comp, const MultiFab* S,
+                       MultiFab& mac_phi, double rhs_scale, const DomainBC& bc, double mac_tol, double mac_abs_tol,
+                       const MGOpts& opts, MultiFab* const fluxes[3])
+{
+    LayoutP layout = mac_phi.layout;
+    MultiFab bcoef[3];
+    MultiFab* bp[3];
+    const MultiFab* bcp[3];
+    for (int d = 0; d < 3; ++d) { bcoef[d].define(layout, face_type(d), 1, 0); bp[d] = &bcoef[d]; bcp[d] = &bcoef[d]; }
+    mac_bcoef(bp, rho, rho_comp, 1.0 / rhs_scale);
+
+    MultiFab rhs(layout, cell_type(), 1, 0);
+    const MultiFab* um[3] = {umac[0], umac[1], umac[2]};
+    mac_rhs(g, rhs, um, S);
+
+    CellMG mg(g, layout, 1, bc, opts);
+    mg.setScalars(0.0, 1.0);
+    mg.setBCoeffs(bcp);
+    mg.prepare();
+    MGStats st = mg.solve(mac_phi, rhs, mac_tol, mac_abs_tol);
+    // u_mac += (-beta grad phi); optionally hand the fluxes back (MacProj.cpp:1181-1183)
+    mg.fluxes(mac_phi, fluxes, umac);
+    return st;
+}
+
+}  // namespace iamrx

@@ -1,0 +1,161 @@
+// iamr_amd/csrc/mf.h -- device-resident patch containers (the MultiFab/BoxArray/DistributionMapping
+// role of SURVEY 2.2 a19), ghost-exchange plans and the communicator abstraction.
+//
+// MI355X-first choices: every local FAB of a level lives in ONE HBM allocation; kernels are launched
+// once per level over a device-resident descriptor table (not once per FAB); ghost exchange is a
+// precomputed copy plan executed by a single batched kernel (local) plus packed peer messages (remote).
+#pragma once
+#include "core.h"
+#include <vector>
+#include <memory>
+#include <map>
+#include <array>
+
+namespace iamrx {
+
+// ------------------------------------------------------------------ communicator
+enum class ReduceOp { Sum, Max, Min };
+
+struct Message {
+    int peer;
+    double* dev_ptr;   // device buffer (packed)
+    size_t count;      // doubles
+};
+
+// One process per GPU.  Serial by default; RCCL backend in comm_rccl.cpp; callback backend for tests.
+struct Comm {
+    int rank = 0, nranks = 1;
+    virtual ~Comm() = default;
+    virtual void allreduce(double* host_vals, int n, ReduceOp op) { (void)host_vals; (void)n; (void)op; }
+    // exchange packed device buffers with peers (all sends/recvs posted together)
+    virtual void exchange(const std::vector<Message>& sends, const std::vector<Message>& recvs, hipStream_t s)
+    {
+        (void)s;
+        if (!sends.empty() || !recvs.empty()) throw Error("serial Comm cannot exchange with peers");
+    }
+};
+
+// ------------------------------------------------------------------ context
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<Comm> comm;
+    // caching device allocator (hipMalloc/hipFree synchronise; never call them inside a time step)
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t bytes_live = 0, bytes_cached = 0;
+    double* d_scratch = nullptr;   // reduction scratch
+    double* h_scratch = nullptr;   // pinned
+    size_t scratch_n = 0;
+
+    static Context& get();
+    void init(int dev);
+    void* alloc(size_t bytes);
+    void free(void* p);
+    void release_cache();
+    void sync();
+    void ensure_scratch(size_t n);
+};
+
+// ------------------------------------------------------------------ layout
+// All boxes of one level (cell-centred, non-overlapping) + owner rank of each.
+struct Layout {
+    std::vector<BoxD> boxes;
+    std::vector<int> owner;
+    std::vector<int> local;      // global indices of the boxes owned by this rank
+    std::vector<int> local_of;   // global -> local index or -1
+    BoxD* d_boxes = nullptr;     // device copy of the LOCAL valid boxes
+    int max_len[3] = {0, 0, 0};  // max local box extent (cells)
+    uint64_t id = 0;
+
+    Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myrank);
+    ~Layout();
+    int nlocal() const { return (int)local.size(); }
+    const BoxD& lbox(int li) const { return boxes[local[li]]; }
+    long local_cells() const;
+    long total_cells() const;
+    std::shared_ptr<Layout> coarsened(int ratio) const;
+    bool coarsenable(int ratio, int min_width) const;
+};
+using LayoutP = std::shared_ptr<Layout>;
+
+struct IndexType {
+    int t[3];
+    bool operator<(const IndexType& o) const { return std::lexicographical_compare(t, t + 3, o.t, o.t + 3); }
+    bool cell() const { return !t[0] && !t[1] && !t[2]; }
+};
+inline IndexType cell_type() { return {{0, 0, 0}}; }
+inline IndexType node_type() { return {{1, 1, 1}}; }
+inline IndexType face_type(int d) { IndexType t{{0, 0, 0}}; t.t[d] = 1; return t; }
+
+// ------------------------------------------------------------------ copy plans
+struct CopyDesc {
+    int src_fab, dst_fab;   // local fab indices (or buffer offsets for remote segments)
+    BoxD region;            // destination index region
+    int shift[3];           // src index = dst index + shift
+    long buf_off;           // offset (in doubles, per component block) in a packed message buffer
+};
+
+struct CopyPlan {
+    std::vector<CopyDesc> local;           // host copy
+    CopyDesc* d_local = nullptr;
+    long max_local_pts = 0;
+    // remote: per peer, pack list (src_fab regions -> send buffer) and unpack list (recv buffer -> dst_fab)
+    struct Peer {
+        int rank;
+        std::vector<CopyDesc> pack, unpack;
+        CopyDesc *d_pack = nullptr, *d_unpack = nullptr;
+        long send_pts = 0, recv_pts = 0, max_pack_pts = 0, max_unpack_pts = 0;
+    };
+    std::vector<Peer> peers;
+    ~CopyPlan();
+};
+
+// ------------------------------------------------------------------ MultiFab
+class MultiFab {
+public:
+    LayoutP layout;
+    IndexType type;
+    int ncomp = 0, ngrow = 0;
+    double* base = nullptr;          // single allocation for all local fabs
+    size_t total_doubles = 0;
+    std::vector<FabD> h_tab;         // one entry per local fab
+    FabD* d_tab = nullptr;
+
+    MultiFab() = default;
+    MultiFab(LayoutP l, IndexType t, int nc, int ng);
+    ~MultiFab();
+    MultiFab(const MultiFab&) = delete;
+    MultiFab& operator=(const MultiFab&) = delete;
+    MultiFab(MultiFab&& o) noexcept;
+    MultiFab& operator=(MultiFab&& o) noexcept;
+
+    void define(LayoutP l, IndexType t, int nc, int ng);
+    void clear();
+    bool defined() const { return base != nullptr || (layout && layout->nlocal() == 0); }
+    int nlocal() const { return layout->nlocal(); }
+    BoxD validbox(int li) const { return convert(layout->lbox(li), type.t); }
+    BoxD fabbox(int li) const { return grow(validbox(li), ngrow); }
+
+    void setVal(double v);                              // all comps, incl. ghosts
+    void setVal(double v, int comp, int nc, int ng);
+    void FillBoundary(const Geometry& g);               // same-level + periodic ghost exchange (all comps)
+    void FillBoundary(const Geometry& g, int comp, int nc);
+    // valid + ng ghost cells
+    static void Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng);
+    // dst = a*x + b*y style helpers live in blas (kernels.h)
+    double norm0(int comp, int nc, int ng, bool local = false) const;     // max |.| over valid (+ng) region
+    double sum_unique(const Geometry& g, int comp, bool local = false) const;   // sum over owner copies (nodal aware)
+
+    void copy_to_host(int li, double* dst) const;      // whole fab (all comps, with ghosts)
+    void copy_from_host(int li, const double* src);
+
+private:
+    void release();
+};
+
+// plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g);
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc);
+
+}  // namespace iamrx

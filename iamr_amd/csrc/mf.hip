@@ -1,0 +1,399 @@
+// iamr_amd/csrc/mf.hip -- Context (stream, caching allocator), Layout, MultiFab, ghost-exchange plans.
+// Plays the role of AMReX MultiFab / FillBoundary at IAMR's call sites (SURVEY 2.3 "Same-level ghost
+// exchange": reference Source/MacProj.cpp:1127, Source/Projection.cpp:338-339, ...).
+#include "mf.h"
+#include "launch.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstring>
+#include <atomic>
+
+namespace iamrx {
+
+// ------------------------------------------------------------------ Context
+Context& Context::get()
+{
+    static Context c;
+    return c;
+}
+
+void Context::init(int dev)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        throw Error("iamrx: no HIP device available -- the product path has no CPU fallback");
+    device = dev;
+    IAMRX_HIP_CHECK(hipSetDevice(dev));
+    if (!stream) IAMRX_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!comm) comm = std::make_unique<Comm>();
+    ensure_scratch(1 << 16);
+}
+
+void Context::ensure_scratch(size_t n)
+{
+    if (n <= scratch_n) return;
+    if (d_scratch) { sync(); IAMRX_HIP_CHECK(hipFree(d_scratch)); IAMRX_HIP_CHECK(hipHostFree(h_scratch)); }
+    IAMRX_HIP_CHECK(hipMalloc(&d_scratch, n * sizeof(double)));
+    IAMRX_HIP_CHECK(hipHostMalloc(&h_scratch, n * sizeof(double)));
+    scratch_n = n;
+}
+
+void* Context::alloc(size_t bytes)
+{
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~size_t(255);
+    auto it = free_blocks.lower_bound(bytes);
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + 4096) {
+        void* p = it->second;
+        size_t sz = it->first;
+        free_blocks.erase(it);
+        bytes_cached -= sz;
+        live_blocks[p] = sz;
+        bytes_live += sz;
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        release_cache();
+        IAMRX_HIP_CHECK(hipMalloc(&p, bytes));
+    }
+    live_blocks[p] = bytes;
+    bytes_live += bytes;
+    return p;
+}
+
+void Context::free(void* p)
+{
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    size_t sz = it->second;
+    live_blocks.erase(it);
+    bytes_live -= sz;
+    free_blocks.emplace(sz, p);
+    bytes_cached += sz;
+}
+
+void Context::release_cache()
+{
+    sync();
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    bytes_cached = 0;
+}
+
+void Context::sync() { if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+// ------------------------------------------------------------------ Layout
+static std::atomic<uint64_t> g_layout_id{1};
+
+Layout::Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myrank) : boxes(b), owner(own)
+{
+    IAMRX_ASSERT(b.size() == own.size());
+    id = g_layout_id++;
+    local_of.assign(b.size(), -1);
+    for (size_t g = 0; g < b.size(); ++g)
+        if (own[g] == myrank) { local_of[g] = (int)local.size(); local.push_back((int)g); }
+    std::vector<BoxD> lb;
+    for (int g : local) {
+        lb.push_back(boxes[g]);
+        for (int d = 0; d < 3; ++d) max_len[d] = std::max(max_len[d], boxes[g].len(d));
+    }
+    if (!lb.empty()) {
+        auto& ctx = Context::get();
+        d_boxes = (BoxD*)ctx.alloc(lb.size() * sizeof(BoxD));
+        IAMRX_HIP_CHECK(hipMemcpyAsync(d_boxes, lb.data(), lb.size() * sizeof(BoxD), hipMemcpyHostToDevice, ctx.stream));
+        ctx.sync();
+    }
+}
+
+Layout::~Layout() { if (d_boxes) Context::get().free(d_boxes); }
+
+long Layout::local_cells() const { long n = 0; for (int g : local) n += boxes[g].npts(); return n; }
+long Layout::total_cells() const { long n = 0; for (auto& b : boxes) n += b.npts(); return n; }
+
+bool Layout::coarsenable(int ratio, int min_width) const
+{
+    for (auto& b : boxes)
+        for (int d = 0; d < 3; ++d) {
+            if (b.len(d) % ratio != 0 || b.len(d) / ratio < min_width) return false;
+            int lo = b.lo[d];
+            if (((lo % ratio) + ratio) % ratio != 0) return false;
+        }
+    return true;
+}
+
+std::shared_ptr<Layout> Layout::coarsened(int ratio) const
+{
+    std::vector<BoxD> cb;
+    for (auto& b : boxes) cb.push_back(coarsen(b, ratio));
+    return std::make_shared<Layout>(cb, owner, Context::get().comm->rank);
+}
+
+// ------------------------------------------------------------------ MultiFab
+MultiFab::MultiFab(LayoutP l, IndexType t, int nc, int ng) { define(std::move(l), t, nc, ng); }
+MultiFab::~MultiFab() { release(); }
+
+MultiFab::MultiFab(MultiFab&& o) noexcept { *this = std::move(o); }
+MultiFab& MultiFab::operator=(MultiFab&& o) noexcept
+{
+    if (this != &o) {
+        release();
+        layout = std::move(o.layout); type = o.type; ncomp = o.ncomp; ngrow = o.ngrow;
+        base = o.base; total_doubles = o.total_doubles; h_tab = std::move(o.h_tab); d_tab = o.d_tab;
+        o.base = nullptr; o.d_tab = nullptr; o.total_doubles = 0;
+    }
+    return *this;
+}
+
+void MultiFab::release()
+{
+    auto& ctx = Context::get();
+    if (base) ctx.free(base);
+    if (d_tab) ctx.free(d_tab);
+    base = nullptr; d_tab = nullptr; total_doubles = 0; h_tab.clear();
+}
+
+void MultiFab::clear() { release(); layout.reset(); }
+
+void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)
+{
+    release();
+    layout = std::move(l); type = t; ncomp = nc; ngrow = ng;
+    auto& ctx = Context::get();
+    const int nl = layout->nlocal();
+    h_tab.resize(nl);
+    size_t off = 0;
+    std::vector<size_t> offs(nl);
+    for (int li = 0; li < nl; ++li) {
+        BoxD fb = fabbox(li);
+        FabD& f = h_tab[li];
+        for (int d = 0; d < 3; ++d) { f.lo[d] = fb.lo[d]; f.n[d] = fb.len(d); }
+        f.cs = (long)f.n[0] * f.n[1] * f.n[2];
+        offs[li] = off;
+        off += (size_t)f.cs * nc;
+        off = (off + 31) & ~size_t(31);   // 256-byte alignment of every fab
+    }
+    total_doubles = off;
+    if (nl == 0) return;
+    base = (double*)ctx.alloc(total_doubles * sizeof(double));
+    for (int li = 0; li < nl; ++li) h_tab[li].p = base + offs[li];
+    d_tab = (FabD*)ctx.alloc(nl * sizeof(FabD));
+    IAMRX_HIP_CHECK(hipMemcpyAsync(d_tab, h_tab.data(), nl * sizeof(FabD), hipMemcpyHostToDevice, ctx.stream));
+    ctx.sync();   // h_tab may be reallocated by a later move
+}
+
+void MultiFab::setVal(double v)
+{
+    if (!base) return;
+    launch_fill(base, total_doubles, v, Context::get().stream);
+}
+
+void MultiFab::setVal(double v, int comp, int nc, int ng)
+{
+    if (!base) return;
+    const FabD* tab = d_tab;
+    for_each(*layout, type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD a = tab[f];
+        for (int n = 0; n < nc; ++n) a(i, j, k, comp + n) = v;
+    });
+}
+
+void MultiFab::Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng)
+{
+    IAMRX_ASSERT(dst.layout->id == src.layout->id || dst.layout->boxes.size() == src.layout->boxes.size());
+    IAMRX_ASSERT(ng <= dst.ngrow && ng <= src.ngrow);
+    if (!dst.base) return;
+    const FabD* dt = dst.d_tab;
+    const FabD* st = src.d_tab;
+    for_each(*dst.layout, dst.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD d = dt[f], s = st[f];
+        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i, j, k, scomp + n);
+    });
+}
+
+void MultiFab::copy_to_host(int li, double* dst) const
+{
+    auto& ctx = Context::get();
+    ctx.sync();
+    IAMRX_HIP_CHECK(hipMemcpy(dst, h_tab[li].p, (size_t)h_tab[li].cs * ncomp * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+void MultiFab::copy_from_host(int li, const double* src)
+{
+    auto& ctx = Context::get();
+    ctx.sync();
+    IAMRX_HIP_CHECK(hipMemcpy(h_tab[li].p, src, (size_t)h_tab[li].cs * ncomp * sizeof(double), hipMemcpyHostToDevice));
+}
+
+double MultiFab::norm0(int comp, int nc, int ng, bool local) const
+{
+    double v = reduce_norm0(*this, comp, nc, ng);
+    if (!local) Context::get().comm->allreduce(&v, 1, ReduceOp::Max);
+    return v;
+}
+
+double MultiFab::sum_unique(const Geometry& g, int comp, bool local) const
+{
+    double v = reduce_sum_unique(*this, comp, g);
+    if (!local) Context::get().comm->allreduce(&v, 1, ReduceOp::Sum);
+    return v;
+}
+
+// ------------------------------------------------------------------ FillBoundary plan
+CopyPlan::~CopyPlan()
+{
+    auto& ctx = Context::get();
+    if (d_local) ctx.free(d_local);
+    for (auto& p : peers) { if (p.d_pack) ctx.free(p.d_pack); if (p.d_unpack) ctx.free(p.d_unpack); }
+}
+
+struct PlanKey {
+    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3];
+    bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
+};
+
+static CopyDesc* upload(const std::vector<CopyDesc>& v)
+{
+    if (v.empty()) return nullptr;
+    auto& ctx = Context::get();
+    CopyDesc* d = (CopyDesc*)ctx.alloc(v.size() * sizeof(CopyDesc));
+    IAMRX_HIP_CHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, ctx.stream));
+    ctx.sync();
+    return d;
+}
+
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g)
+{
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.layout_id = l.id; key.t = t; key.ng = ng;
+    for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+
+    auto plan = std::make_unique<CopyPlan>();
+    const int me = Context::get().comm->rank;
+    std::map<int, CopyPlan::Peer> peers;
+    // periodic shift candidates
+    int smin[3], smax[3];
+    for (int d = 0; d < 3; ++d) { smin[d] = g.periodic[d] ? -1 : 0; smax[d] = g.periodic[d] ? 1 : 0; }
+    const int nb = (int)l.boxes.size();
+    for (int gd = 0; gd < nb; ++gd) {
+        const bool dst_mine = l.owner[gd] == me;
+        const BoxD dvalid = convert(l.boxes[gd], t.t);
+        const BoxD dgrown = grow(dvalid, ng);
+        for (int gs = 0; gs < nb; ++gs) {
+            const bool src_mine = l.owner[gs] == me;
+            if (!dst_mine && !src_mine) continue;
+            for (int sz = smin[2]; sz <= smax[2]; ++sz)
+            for (int sy = smin[1]; sy <= smax[1]; ++sy)
+            for (int sx = smin[0]; sx <= smax[0]; ++sx) {
+                if (gs == gd && sx == 0 && sy == 0 && sz == 0) continue;
+                // source valid box translated INTO the destination's index frame
+                int sh[3] = {sx * g.domain.len(0), sy * g.domain.len(1), sz * g.domain.len(2)};
+                BoxD svalid = convert(l.boxes[gs], t.t);
+                for (int d = 0; d < 3; ++d) svalid = shift(svalid, d, sh[d]);
+                BoxD is = intersect(dgrown, svalid);
+                if (!is.ok()) continue;
+                // drop the part inside the destination's own valid region: split `is` minus dvalid
+                // into up to 6 boxes (box difference)
+                std::vector<BoxD> parts;
+                BoxD rem = is;
+                BoxD in = intersect(is, dvalid);
+                if (!in.ok()) parts.push_back(is);
+                else {
+                    for (int d = 2; d >= 0; --d) {
+                        if (rem.lo[d] < in.lo[d]) { BoxD p = rem; p.hi[d] = in.lo[d] - 1; parts.push_back(p); rem.lo[d] = in.lo[d]; }
+                        if (rem.hi[d] > in.hi[d]) { BoxD p = rem; p.lo[d] = in.hi[d] + 1; parts.push_back(p); rem.hi[d] = in.hi[d]; }
+                    }
+                }
+                for (auto& p : parts) {
+                    CopyDesc cd;
+                    cd.region = p;
+                    for (int d = 0; d < 3; ++d) cd.shift[d] = -sh[d];
+                    cd.buf_off = 0;
+                    if (dst_mine && src_mine) {
+                        cd.src_fab = l.local_of[gs]; cd.dst_fab = l.local_of[gd];
+                        plan->local.push_back(cd);
+                        plan->max_local_pts = std::max(plan->max_local_pts, p.npts());
+                    } else if (src_mine) {          // I send to owner of gd
+                        auto& pr = peers[l.owner[gd]];
+                        pr.rank = l.owner[gd];
+                        cd.src_fab = l.local_of[gs]; cd.dst_fab = -1; cd.buf_off = pr.send_pts;
+                        pr.send_pts += p.npts();
+                        pr.max_pack_pts = std::max(pr.max_pack_pts, p.npts());
+                        pr.pack.push_back(cd);
+                    } else {                        // I receive from owner of gs
+                        auto& pr = peers[l.owner[gs]];
+                        pr.rank = l.owner[gs];
+                        cd.src_fab = -1; cd.dst_fab = l.local_of[gd]; cd.buf_off = pr.recv_pts;
+                        pr.recv_pts += p.npts();
+                        pr.max_unpack_pts = std::max(pr.max_unpack_pts, p.npts());
+                        pr.unpack.push_back(cd);
+                    }
+                }
+            }
+        }
+    }
+    plan->d_local = upload(plan->local);
+    for (auto& kv : peers) {
+        kv.second.d_pack = upload(kv.second.pack);
+        kv.second.d_unpack = upload(kv.second.unpack);
+        plan->peers.push_back(std::move(kv.second));
+        kv.second.d_pack = nullptr; kv.second.d_unpack = nullptr;
+    }
+    auto& ref = *plan;
+    cache.emplace(key, std::move(plan));
+    return ref;
+}
+
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc)
+{
+    auto& ctx = Context::get();
+    hipStream_t s = ctx.stream;
+    // remote: pack -> exchange -> unpack
+    std::vector<Message> sends, recvs;
+    std::vector<double*> bufs;
+    for (auto& p : plan.peers) {
+        if (p.send_pts > 0) {
+            double* sb = (double*)ctx.alloc((size_t)p.send_pts * nc * sizeof(double));
+            bufs.push_back(sb);
+            launch_pack(p.d_pack, (int)p.pack.size(), p.max_pack_pts, src.d_tab, sb, p.send_pts, scomp, nc, s);
+            sends.push_back({p.rank, sb, (size_t)p.send_pts * nc});
+        }
+        if (p.recv_pts > 0) {
+            double* rb = (double*)ctx.alloc((size_t)p.recv_pts * nc * sizeof(double));
+            bufs.push_back(rb);
+            recvs.push_back({p.rank, rb, (size_t)p.recv_pts * nc});
+        }
+    }
+    if (!plan.local.empty())
+        launch_copy_plan(plan.d_local, (int)plan.local.size(), plan.max_local_pts, src.d_tab, dst.d_tab, scomp, dcomp, nc, s);
+    if (!sends.empty() || !recvs.empty()) {
+        ctx.comm->exchange(sends, recvs, s);
+        size_t ri = 0;
+        for (auto& p : plan.peers) {
+            if (p.recv_pts > 0) {
+                launch_unpack(p.d_unpack, (int)p.unpack.size(), p.max_unpack_pts, dst.d_tab, recvs[ri].dev_ptr, p.recv_pts, dcomp, nc, s);
+                ++ri;
+            }
+        }
+    }
+    // buffers are stream-ordered: safe to return them to the cache (next user is on the same stream)
+    for (double* b : bufs) ctx.free(b);
+}
+
+void MultiFab::FillBoundary(const Geometry& g) { FillBoundary(g, 0, ncomp); }
+
+void MultiFab::FillBoundary(const Geometry& g, int comp, int nc)
+{
+    if (ngrow == 0) return;
+    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g);
+    execute_plan(plan, *this, *this, comp, comp, nc);
+}
+
+}  // namespace iamrx

@@ -1,0 +1,80 @@
+// iamr_amd/csrc/mlmg.h -- geometric multigrid drivers (host side) for the cell-centred ABec/tensor
+// operator and the nodal Laplacian.  Plays the role of amrex::MLMG + MLABecLaplacian/MLTensorOp/
+// MLNodeLaplacian as used at reference Source/MacProj.cpp:1150-1183, Source/Diffusion.cpp:715-923,
+// Source/Projection.cpp:2512-2542.
+#pragma once
+#include "mf.h"
+#include "kernels.h"
+#include <vector>
+
+namespace iamrx {
+
+struct MGOpts {
+    int nu1 = 2, nu2 = 2, nuf = 8, nub = 0;
+    int max_iters = 200;
+    int bottom_maxiter = 200;
+    double bottom_reltol = 1.e-4;
+    double omega = 1.15;          // GSRB over-relaxation
+    int maxorder = 3;
+    int max_coarsening_level = 30;
+    int min_width = 2;
+    int nodal_sweeps = 4;         // Gauss-Seidel sweeps per nodal smooth call
+    int nodal_smoother = 0;       // 0: 8-colour Gauss-Seidel, 2: weighted Jacobi (2/3)
+    int verbose = 0;
+    int bottom_smoother_only = 0;
+    int fixed_iters = 0;
+};
+
+struct MGStats {
+    int iters = 0;
+    double resnorm0 = 0, rhsnorm0 = 0, resnorm = 0;
+    int bottom_iters_total = 0;
+    int converged = 0;
+    double vcycle_ms = 0;         // mean wall time of one V-cycle (host clock around stream sync)
+    int nlevels = 0;
+};
+
+class CellMG {
+public:
+    CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o);
+    void setScalars(double alpha, double beta) { m_alpha = alpha; m_beta = beta; }
+    void setACoeffs(const MultiFab* a) { m_a0 = a; }
+    void setBCoeffs(const MultiFab* const b[3]) { for (int d = 0; d < 3; ++d) m_b0[d] = b[d]; }
+    void setTensor(bool t) { m_tensor = t; }
+    void prepare();   // build the coarse hierarchy (coefficient averaging)
+    MGStats solve(MultiFab& phi, const MultiFab& rhs, double rtol, double atol);
+    // out = L(phi) with inhomogeneous BC taken from phi's ghost cells
+    void apply(MultiFab& out, MultiFab& phi);
+    void fluxes(MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_to[3]);
+    int nlevels() const { return (int)m_lev.size(); }
+    AbecCoef coef(int l) const;
+    const Geometry& geom(int l) const { return m_lev[l].g; }
+    void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval);
+    void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill);
+    void vcycle(MGStats& st);
+    MultiFab& res(int l) { return m_lev[l].res; }
+    MultiFab& cor(int l) { return m_lev[l].cor; }
+
+private:
+    struct Level {
+        Geometry g;
+        LayoutP layout;
+        MultiFab a, b[3];          // owned (coarse levels)
+        MultiFab cor, res, rescor;
+    };
+    int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
+    void bottom_solve(MGStats& st);
+    void subtract_mean(int l, MultiFab& mf);
+    Geometry m_g;
+    int m_ncomp;
+    DomainBC m_bc;
+    MGOpts m_o;
+    double m_alpha = 0.0, m_beta = 1.0;
+    const MultiFab* m_a0 = nullptr;
+    const MultiFab* m_b0[3] = {nullptr, nullptr, nullptr};
+    bool m_tensor = false;
+    bool m_singular = false;
+    std::vector<Level> m_lev;
+};
+
+}  // namespace iamrx

@@ -1,0 +1,267 @@
+// iamr_amd/csrc/mlmg.hip -- cell-centred multigrid driver: MLMG::solve / oneIter / mgVcycle /
+// actualBottomSolve and MLCGSolver::solve_bicgstab semantics (upstream AMReX), driving the HIP kernels
+// of k_abec.hip / k_tensor.hip.  Reference call sites: Source/MacProj.cpp:1150-1183 (MAC solve,
+// mac_tol 1e-12, max_order 4), Source/Diffusion.cpp:837-929 (tensor solve, visc_tol 1e-10, max_order 2).
+#include "mlmg.h"
+#include "launch.h"
+#include <chrono>
+#include <cmath>
+
+namespace iamrx {
+
+CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
+    : m_g(g), m_ncomp(ncomp), m_bc(bc), m_o(o)
+{
+    m_lev.resize(1);
+    m_lev[0].g = g;
+    m_lev[0].layout = std::move(layout);
+}
+
+AbecCoef CellMG::coef(int l) const
+{
+    AbecCoef c;
+    c.alpha = m_alpha; c.beta = m_beta; c.tensor = m_tensor ? 1 : 0;
+    if (l == 0) {
+        c.a = m_a0;
+        for (int d = 0; d < 3; ++d) c.b[d] = m_b0[d];
+    } else {
+        c.a = m_a0 ? &m_lev[l].a : nullptr;
+        for (int d = 0; d < 3; ++d) c.b[d] = &m_lev[l].b[d];
+    }
+    return c;
+}
+
+void CellMG::prepare()
+{
+    IAMRX_ASSERT(m_b0[0] && m_b0[1] && m_b0[2]);
+    // singular <=> no 'a' term and no Dirichlet boundary (MLABecLaplacian::m_is_singular)
+    m_singular = !(m_alpha != 0.0 && m_a0);
+    for (int d = 0; d < 3; ++d)
+        if (!m_g.periodic[d] && (m_bc.lo[d] == lo_dirichlet || m_bc.hi[d] == lo_dirichlet)) m_singular = false;
+    // coarsen while every box is coarsenable (MLLinOp::defineGrids, mg_box_min_width = 2)
+    m_lev.resize(1);
+    while ((int)m_lev.size() <= m_o.max_coarsening_level) {
+        Level& f = m_lev.back();
+        bool dom_ok = true;
+        for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
+        if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
+        Level c;
+        c.g = f.g;
+        c.g.domain = coarsen(f.g.domain, 2);
+        for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
+        c.layout = f.layout->coarsened(2);
+        m_lev.push_back(std::move(c));
+    }
+    const int nl = (int)m_lev.size();
+    for (int l = 0; l < nl; ++l) {
+        Level& L = m_lev[l];
+        L.cor.define(L.layout, cell_type(), m_ncomp, 1);
+        L.res.define(L.layout, cell_type(), m_ncomp, 0);
+        L.rescor.define(L.layout, cell_type(), m_ncomp, 0);
+        if (l > 0) {
+            AbecCoef fc = coef(l - 1);
+            if (m_a0) { L.a.define(L.layout, cell_type(), 1, 0); cc_restrict(L.a, *fc.a); }
+            for (int d = 0; d < 3; ++d) {
+                L.b[d].define(L.layout, face_type(d), fc.b[d]->ncomp, 0);
+                face_avgdown(L.b[d], *fc.b[d], d);
+            }
+        }
+    }
+}
+
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc);   // k_tensor.hip
+
+void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
+{
+    phi.FillBoundary(m_lev[l].g);
+    abec_apply_domain_bc(m_lev[l].g, phi, m_bc, inhomog, bcval);
+    if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bc);
+}
+
+void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
+{
+    AbecCoef c = coef(l);
+    c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
+    for (int rb = 0; rb < 2; ++rb) {
+        if (!skip_fill) applyBC(l, sol, false, nullptr);
+        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bc);
+        skip_fill = false;
+    }
+}
+
+void CellMG::subtract_mean(int l, MultiFab& mf)
+{
+    const double ncell = (double)m_lev[l].g.domain.npts();
+    for (int n = 0; n < m_ncomp; ++n) {
+        double s = mf.sum_unique(m_lev[l].g, n);
+        mf_add_scalar(mf, -s / ncell, n, 1, 0);
+    }
+}
+
+int CellMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters)
+{
+    Level& L = m_lev[l];
+    const Geometry& g = L.g;
+    const int nc = m_ncomp;
+    AbecCoef c = coef(l);
+    MultiFab ph(L.layout, cell_type(), nc, 1), sh(L.layout, cell_type(), nc, 1);
+    MultiFab sorig(L.layout, cell_type(), nc, 0), p(L.layout, cell_type(), nc, 0), r(L.layout, cell_type(), nc, 0);
+    MultiFab s(L.layout, cell_type(), nc, 0), rh(L.layout, cell_type(), nc, 0), v(L.layout, cell_type(), nc, 0), t(L.layout, cell_type(), nc, 0);
+    ph.setVal(0.0); sh.setVal(0.0);
+    applyBC(l, sol, false, nullptr);
+    abec_residual(g, c, r, sol, &rhs);
+    MultiFab::Copy(sorig, sol, 0, 0, nc, 0);
+    MultiFab::Copy(rh, r, 0, 0, nc, 0);
+    sol.setVal(0.0);
+    double rnorm = r.norm0(0, nc, 0);
+    const double rnorm0 = rnorm;
+    int ret = 0, nit = 1;
+    double rho_1 = 0, alpha = 0, omega = 0;
+    if (rnorm0 == 0 || rnorm0 < eps_abs) { niters = 0; MultiFab::Copy(sol, sorig, 0, 0, nc, 0); return 0; }
+    for (; nit <= m_o.bottom_maxiter; ++nit) {
+        double rho;
+        { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&r}; reduce_dots(1, xs, ys, 0, nc, g, &rho); }
+        if (rho == 0) { ret = 1; break; }
+        if (nit == 1) MultiFab::Copy(p, r, 0, 0, nc, 0);
+        else {
+            const double beta = (rho / rho_1) * (alpha / omega);
+            mf_lincomb(p, 1.0, p, -omega, v, 0, nc, 0);
+            mf_lincomb(p, 1.0, r, beta, p, 0, nc, 0);
+        }
+        MultiFab::Copy(ph, p, 0, 0, nc, 0);
+        applyBC(l, ph, false, nullptr);
+        abec_residual(g, c, v, ph, nullptr);
+        double rhTv;
+        { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&v}; reduce_dots(1, xs, ys, 0, nc, g, &rhTv); }
+        if (rhTv != 0) alpha = rho / rhTv; else { ret = 2; break; }
+        mf_lincomb(sol, 1.0, sol, alpha, ph, 0, nc, 0);
+        mf_lincomb(s, 1.0, r, -alpha, v, 0, nc, 0);
+        rnorm = s.norm0(0, nc, 0);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        MultiFab::Copy(sh, s, 0, 0, nc, 0);
+        applyBC(l, sh, false, nullptr);
+        abec_residual(g, c, t, sh, nullptr);
+        double tv[2];
+        { const MultiFab* xs[2] = {&t, &t}; const MultiFab* ys[2] = {&t, &s}; reduce_dots(2, xs, ys, 0, nc, g, tv); }
+        if (tv[0] != 0) omega = tv[1] / tv[0]; else { ret = 3; break; }
+        mf_lincomb(sol, 1.0, sol, omega, sh, 0, nc, 0);
+        mf_lincomb(r, 1.0, s, -omega, t, 0, nc, 0);
+        rnorm = r.norm0(0, nc, 0);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        if (omega == 0) { ret = 4; break; }
+        rho_1 = rho;
+    }
+    if (ret == 0 && rnorm > eps_rel * rnorm0 && rnorm > eps_abs) ret = 8;
+    if ((ret == 0 || ret == 8) && rnorm < rnorm0) mf_lincomb(sol, 1.0, sol, 1.0, sorig, 0, nc, 0);
+    else { sol.setVal(0.0); mf_lincomb(sol, 1.0, sol, 1.0, sorig, 0, nc, 0); }
+    niters = nit;
+    return ret;
+}
+
+void CellMG::bottom_solve(MGStats& st)
+{
+    const int l = (int)m_lev.size() - 1;
+    Level& L = m_lev[l];
+    L.cor.setVal(0.0);
+    if (m_o.bottom_smoother_only) {
+        bool skip = true;
+        for (int i = 0; i < m_o.nuf; ++i) { smooth(l, L.cor, L.res, skip); skip = false; }
+        return;
+    }
+    MultiFab b(L.layout, cell_type(), m_ncomp, 0);
+    MultiFab::Copy(b, L.res, 0, 0, m_ncomp, 0);
+    if (m_singular) subtract_mean(l, b);
+    int nit = 0;
+    int ret = bicgstab(l, L.cor, b, m_o.bottom_reltol, -1.0, nit);
+    st.bottom_iters_total += nit;
+    if (ret != 0) {
+        L.cor.setVal(0.0);
+        bool skip = true;
+        for (int i = 0; i < m_o.nuf; ++i) { smooth(l, L.cor, L.res, skip); skip = false; }
+    }
+    const int nn = (ret == 0) ? m_o.nub : m_o.nuf;
+    for (int i = 0; i < nn; ++i) smooth(l, L.cor, L.res, false);
+}
+
+void CellMG::vcycle(MGStats& st)
+{
+    const int nl = (int)m_lev.size();
+    for (int l = 0; l < nl - 1; ++l) {
+        Level& L = m_lev[l];
+        L.cor.setVal(0.0);
+        bool skip = true;
+        for (int i = 0; i < m_o.nu1; ++i) { smooth(l, L.cor, L.res, skip); skip = false; }
+        applyBC(l, L.cor, false, nullptr);
+        abec_residual(L.g, coef(l), L.rescor, L.cor, &L.res);
+        cc_restrict(m_lev[l + 1].res, L.rescor);
+    }
+    bottom_solve(st);
+    for (int l = nl - 2; l >= 0; --l) {
+        Level& L = m_lev[l];
+        cc_prolong_add(L.cor, m_lev[l + 1].cor);
+        for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res, false);
+    }
+}
+
+void CellMG::apply(MultiFab& out, MultiFab& phi)
+{
+    MultiFab bcval(m_lev[0].layout, cell_type(), m_ncomp, 1);
+    MultiFab::Copy(bcval, phi, 0, 0, m_ncomp, 1);
+    applyBC(0, phi, true, &bcval);
+    abec_residual(m_lev[0].g, coef(0), out, phi, nullptr);
+}
+
+void CellMG::fluxes(MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_to[3])
+{
+    abec_flux(m_lev[0].g, coef(0), phi, flux, add_to);
+}
+
+MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)
+{
+    auto& ctx = Context::get();
+    MGStats st;
+    st.nlevels = (int)m_lev.size();
+    Level& L0 = m_lev[0];
+    const int nc = m_ncomp;
+    MultiFab rhs(L0.layout, cell_type(), nc, 0);
+    MultiFab::Copy(rhs, rhs_in, 0, 0, nc, 0);
+    if (m_singular) subtract_mean(0, rhs);
+    MultiFab bcval(L0.layout, cell_type(), nc, 1);
+    MultiFab::Copy(bcval, phi, 0, 0, nc, 1);
+
+    applyBC(0, phi, true, &bcval);
+    abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
+    st.resnorm0 = L0.res.norm0(0, nc, 0);
+    st.rhsnorm0 = rhs.norm0(0, nc, 0);
+    const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
+    const double res_target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
+    st.resnorm = st.resnorm0;
+    if (m_o.verbose) printf("iamrx MLMG: rhs %.6e resid0 %.6e target %.3e levels %d\n", st.rhsnorm0, st.resnorm0, res_target, st.nlevels);
+    double vc_ms = 0.0;
+    if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
+    else {
+        const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
+        for (int iter = 0; iter < maxit; ++iter) {
+            if (m_singular) subtract_mean(0, L0.res);
+            ctx.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            vcycle(st);
+            ctx.sync();
+            vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
+            applyBC(0, phi, true, &bcval);
+            abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
+            st.resnorm = L0.res.norm0(0, nc, 0);
+            st.iters = iter + 1;
+            if (m_o.verbose) printf("iamrx MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, st.resnorm, st.resnorm / max_norm);
+            if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
+            if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx MLMG: failing to converge (residual blow-up)");
+        }
+        if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx MLMG: failed to converge after max_iters");
+    }
+    if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
+    applyBC(0, phi, true, &bcval);
+    return st;
+}
+
+}  // namespace iamrx

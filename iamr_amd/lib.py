@@ -1,0 +1,278 @@
+"""ctypes binding of libiamrx.so (C-ABI declared in include/iamrx.h).
+
+The HIP library is the product; there is no CPU fallback: importing works without a GPU (so that the
+build / symbol checks can run), but `init()` raises if no gfx950 device is present.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiamrx.so")
+_lib = None
+
+
+class IamrxError(RuntimeError):
+    pass
+
+
+class Geom(C.Structure):
+    _fields_ = [("dom_lo", C.c_int * 3), ("dom_hi", C.c_int * 3), ("prob_lo", C.c_double * 3),
+                ("prob_hi", C.c_double * 3), ("periodic", C.c_int * 3)]
+
+    @staticmethod
+    def make(n, prob_lo=(0.0, 0.0, 0.0), prob_hi=(1.0, 1.0, 1.0), periodic=(1, 1, 1)):
+        g = Geom()
+        g.dom_lo = (C.c_int * 3)(0, 0, 0)
+        g.dom_hi = (C.c_int * 3)(*[int(n[d]) - 1 for d in range(3)])
+        g.prob_lo = (C.c_double * 3)(*prob_lo)
+        g.prob_hi = (C.c_double * 3)(*prob_hi)
+        g.periodic = (C.c_int * 3)(*periodic)
+        return g
+
+    @property
+    def n(self):
+        return tuple(self.dom_hi[d] - self.dom_lo[d] + 1 for d in range(3))
+
+    @property
+    def dx(self):
+        return tuple((self.prob_hi[d] - self.prob_lo[d]) / self.n[d] for d in range(3))
+
+
+class MgOpts(C.Structure):
+    _fields_ = [("nu1", C.c_int), ("nu2", C.c_int), ("nuf", C.c_int), ("nub", C.c_int), ("max_iters", C.c_int),
+                ("bottom_maxiter", C.c_int), ("bottom_reltol", C.c_double), ("omega", C.c_double),
+                ("maxorder", C.c_int), ("max_coarsening_level", C.c_int), ("min_width", C.c_int),
+                ("nodal_sweeps", C.c_int), ("nodal_smoother", C.c_int), ("verbose", C.c_int),
+                ("bottom_smoother_only", C.c_int), ("fixed_iters", C.c_int)]
+
+
+class MgStats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("resnorm0", C.c_double), ("rhsnorm0", C.c_double), ("resnorm", C.c_double),
+                ("bottom_iters_total", C.c_int), ("converged", C.c_int), ("vcycle_ms", C.c_double), ("nlevels", C.c_int)]
+
+
+def lib():
+    """load libiamrx.so (fails loudly if it has not been built)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IamrxError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for the product path)")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.iamrx_last_error.restype = C.c_char_p
+        _lib.iamrx_stream.restype = C.c_void_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IamrxError(lib().iamrx_last_error().decode())
+
+
+_initialized = False
+
+
+def init(device=0):
+    global _initialized
+    check(lib().iamrx_init(int(device)))
+    _initialized = True
+
+
+def sync():
+    check(lib().iamrx_sync())
+
+
+def mg_opts(**kw):
+    o = MgOpts()
+    lib().iamrx_mg_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+CELL = (0, 0, 0)
+NODE = (1, 1, 1)
+
+
+def face(d):
+    t = [0, 0, 0]
+    t[d] = 1
+    return tuple(t)
+
+
+class Layout:
+    """BoxArray + DistributionMapping of one level."""
+
+    def __init__(self, boxes, owners=None):
+        nb = len(boxes)
+        arr = (C.c_int * (6 * nb))()
+        for i, (lo, hi) in enumerate(boxes):
+            for d in range(3):
+                arr[6 * i + d] = int(lo[d])
+                arr[6 * i + 3 + d] = int(hi[d])
+        own = (C.c_int * nb)(*([0] * nb if owners is None else [int(o) for o in owners]))
+        self.h = C.c_void_p()
+        check(lib().iamrx_layout_create(nb, arr, own, C.byref(self.h)))
+        self.boxes = [(tuple(lo), tuple(hi)) for lo, hi in boxes]
+        self.owners = [0] * nb if owners is None else list(owners)
+
+    @staticmethod
+    def single(n):
+        return Layout([((0, 0, 0), (n[0] - 1, n[1] - 1, n[2] - 1))])
+
+    @staticmethod
+    def decompose(n, max_grid_size, nranks=1):
+        """chop the domain [0,n-1]^3 into boxes of at most max_grid_size, round-robin over ranks"""
+        boxes = []
+        mg = max_grid_size if hasattr(max_grid_size, "__len__") else (max_grid_size,) * 3
+        for k0 in range(0, n[2], mg[2]):
+            for j0 in range(0, n[1], mg[1]):
+                for i0 in range(0, n[0], mg[0]):
+                    boxes.append(((i0, j0, k0), (min(i0 + mg[0], n[0]) - 1, min(j0 + mg[1], n[1]) - 1, min(k0 + mg[2], n[2]) - 1)))
+        per = (len(boxes) + nranks - 1) // nranks
+        owners = [min(i // per, nranks - 1) for i in range(len(boxes))]
+        return Layout(boxes, owners)
+
+    def nlocal(self):
+        n = C.c_int()
+        check(lib().iamrx_layout_nlocal(self.h, C.byref(n)))
+        return n.value
+
+    def local_box(self, li):
+        a = (C.c_int * 6)()
+        gi = C.c_int()
+        check(lib().iamrx_layout_local_box(self.h, li, a, C.byref(gi)))
+        return tuple(a[0:3]), tuple(a[3:6]), gi.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().iamrx_layout_destroy(self.h)
+        except Exception:
+            pass
+
+
+class MultiFab:
+    """device-resident multi-component array over the boxes of a Layout"""
+
+    def __init__(self, layout, typ=CELL, ncomp=1, ngrow=0, _handle=None, _owned=True):
+        self.layout = layout
+        self.typ = tuple(typ)
+        self.ncomp = ncomp
+        self.ngrow = ngrow
+        self._owned = _owned
+        if _handle is not None:
+            self.h = _handle
+        else:
+            self.h = C.c_void_p()
+            check(lib().iamrx_mf_create(layout.h, i3(typ), ncomp, ngrow, C.byref(self.h)))
+
+    def nlocal(self):
+        n = C.c_int()
+        check(lib().iamrx_mf_info(self.h, None, None, None, C.byref(n)))
+        return n.value
+
+    def fab_box(self, li=0):
+        a = (C.c_int * 6)()
+        check(lib().iamrx_mf_fab_box(self.h, li, a))
+        return tuple(a[0:3]), tuple(a[3:6])
+
+    def to_numpy(self, li=0):
+        """(nx,ny,nz,nc) Fortran-ordered copy of local fab li, ghost cells included; returns (array, lo)"""
+        lo, hi = self.fab_box(li)
+        shape = tuple(hi[d] - lo[d] + 1 for d in range(3)) + (self.ncomp,)
+        a = np.empty(shape, dtype=np.float64, order="F")
+        check(lib().iamrx_mf_to_host(self.h, li, a.ctypes.data_as(C.POINTER(C.c_double))))
+        return a, lo
+
+    def from_numpy(self, a, li=0):
+        lo, hi = self.fab_box(li)
+        shape = tuple(hi[d] - lo[d] + 1 for d in range(3)) + (self.ncomp,)
+        a = np.asfortranarray(a, dtype=np.float64).reshape(shape, order="F")
+        check(lib().iamrx_mf_from_host(self.h, li, a.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def set_from_global(self, G, glo):
+        """fill every local fab (valid + ghosts) from a global numpy array G whose index origin is glo"""
+        for li in range(self.nlocal()):
+            lo, hi = self.fab_box(li)
+            sl = tuple(slice(lo[d] - glo[d], hi[d] - glo[d] + 1) for d in range(3))
+            self.from_numpy(G[sl], li)
+
+    def gather_valid(self, n):
+        """assemble the valid regions of all LOCAL fabs into a global array over cells [0,n-1] (+type)"""
+        shape = tuple(n[d] + self.typ[d] for d in range(3)) + (self.ncomp,)
+        G = np.zeros(shape, order="F")
+        for li in range(self.nlocal()):
+            a, lo = self.to_numpy(li)
+            blo, bhi, _ = self.layout.local_box(li)
+            vlo = blo
+            vhi = tuple(bhi[d] + self.typ[d] for d in range(3))
+            src = tuple(slice(vlo[d] - lo[d], vhi[d] - lo[d] + 1) for d in range(3))
+            dst = tuple(slice(vlo[d], vhi[d] + 1) for d in range(3))
+            G[dst] = a[src]
+        return G
+
+    def setval(self, v):
+        check(lib().iamrx_mf_setval(self.h, C.c_double(v)))
+
+    def fill_boundary(self, geom):
+        check(lib().iamrx_mf_fill_boundary(self.h, C.byref(geom)))
+
+    def norm0(self, comp=0, ncomp=None, ngrow=0):
+        out = C.c_double()
+        check(lib().iamrx_mf_norm0(self.h, comp, self.ncomp if ncomp is None else ncomp, ngrow, C.byref(out)))
+        return out.value
+
+    def dev_ptr(self, li=0):
+        p = C.POINTER(C.c_double)()
+        check(lib().iamrx_mf_dev_ptr(self.h, li, C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+    def __del__(self):
+        try:
+            if self._owned and self.h:
+                lib().iamrx_mf_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _h(m):
+    return m.h if m is not None else None
+
+
+def abec_gsrb(geom, alpha, beta, a, b, phi, rhs, redblack, omega=1.15, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=3):
+    check(lib().iamrx_abec_gsrb(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
+                                phi.h, rhs.h, redblack, C.c_double(omega), i3(lobc), i3(hibc), maxorder))
+
+
+def abec_residual(geom, alpha, beta, a, b, out, phi, rhs=None, tensor=0):
+    check(lib().iamrx_abec_residual(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
+                                    out.h, phi.h, _h(rhs), tensor))
+
+
+def abec_solve(geom, alpha, beta, a, b, phi, rhs, lobc=(0, 0, 0), hibc=(0, 0, 0), rtol=1e-12, atol=1e-16, opts=None, tensor=0):
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    check(lib().iamrx_abec_solve(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
+                                 phi.h, rhs.h, i3(lobc), i3(hibc), C.c_double(rtol), C.c_double(atol), C.byref(o), tensor, C.byref(st)))
+    return st
+
+
+def mlmg_mac_solve(geom, umac, rho, rho_comp, S, mac_phi, rhs_scale, lobc=(0, 0, 0), hibc=(0, 0, 0),
+                   mac_tol=1e-12, mac_abs_tol=1e-16, opts=None):
+    """MacProj::mlmg_mac_solve (reference Source/MacProj.cpp:1084-1184)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts(maxorder=4)
+    check(lib().iamrx_mlmg_mac_solve(C.byref(geom), umac[0].h, umac[1].h, umac[2].h, rho.h, rho_comp, _h(S), mac_phi.h,
+                                     C.c_double(rhs_scale), i3(lobc), i3(hibc), C.c_double(mac_tol), C.c_double(mac_abs_tol),
+                                     C.byref(o), C.byref(st)))
+    return st
+
+
+def mac_divergence(geom, div, umac):
+    check(lib().iamrx_mac_divergence(C.byref(geom), div.h, umac[0].h, umac[1].h, umac[2].h))

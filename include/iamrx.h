@@ -1,0 +1,114 @@
+/*
+ * include/iamrx.h -- C-ABI of libiamrx.so: the MI355X-native (gfx950) replacement for the
+ * data-parallel hot path of AMReX-Fluids/IAMR.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, non-zero on failure; iamrx_last_error() gives the
+ *     message.  IAMR itself has no return codes (errors are amrex::Abort, e.g. reference
+ *     Source/NavierStokesBase.cpp:501-507): the reference-side wrapper turns non-zero into Abort.
+ *   - arrays are double precision, AMReX Array4 layout seen at IAMR's seam (reference
+ *     Source/NavierStokesBase.cpp:4665-4677): offset(i,j,k,n) = (i-lo0) + n0*((j-lo1) + n1*((k-lo2) + n2*n)),
+ *     ghost cells included; index boxes are inclusive [lo,hi].
+ *   - all compute runs on the library's HIP stream of the selected device; there is NO CPU fallback:
+ *     iamrx_init fails if no gfx950 device is present.
+ *   - handles are opaque; objects are owned by the library until the matching *_destroy.
+ *
+ * Each function cites the reference interface it replaces (file:line relative to /root/reference).
+ */
+#ifndef IAMRX_H
+#define IAMRX_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iamrx_layout_s* iamrx_layout;   /* BoxArray + DistributionMapping of one level */
+typedef struct iamrx_mf_s* iamrx_mf;           /* MultiFab (device resident) */
+typedef struct iamrx_ns_s* iamrx_ns;           /* NavierStokes level object */
+
+typedef struct iamrx_geom {
+    int dom_lo[3], dom_hi[3];       /* cell-centred domain box */
+    double prob_lo[3], prob_hi[3];
+    int periodic[3];
+} iamrx_geom;
+
+/* MLMG controls (defaults = reference defaults: Source/MacProj.cpp:41-101, Source/Projection.cpp:19-37,
+ * Source/Diffusion.cpp:85-96 and upstream amrex::MLMG nu1=nu2=2, nuf=8, bottom BiCGStab rtol 1e-4) */
+typedef struct iamrx_mg_opts {
+    int nu1, nu2, nuf, nub;
+    int max_iters, bottom_maxiter;
+    double bottom_reltol;
+    double omega;
+    int maxorder;
+    int max_coarsening_level, min_width;
+    int nodal_sweeps, nodal_smoother;
+    int verbose;
+    int bottom_smoother_only;
+    int fixed_iters;
+} iamrx_mg_opts;
+
+typedef struct iamrx_mg_stats {
+    int iters;
+    double resnorm0, rhsnorm0, resnorm;
+    int bottom_iters_total;
+    int converged;
+    double vcycle_ms;
+    int nlevels;
+} iamrx_mg_stats;
+
+/* ---- runtime ---------------------------------------------------------------------------- */
+int iamrx_init(int device);                      /* amrex::Initialize role (Source/main.cpp:26-40) */
+int iamrx_finalize(void);
+const char* iamrx_last_error(void);
+int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
+void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
+int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
+void iamrx_mg_default_opts(iamrx_mg_opts* o);
+
+/* ---- containers (amrex::BoxArray/DistributionMapping/MultiFab role) ----------- */
+int iamrx_layout_create(int nboxes, const int* lo_hi /* 6 ints per box: lo[3],hi[3] */, const int* owner_rank,
+                        iamrx_layout* out);
+int iamrx_layout_destroy(iamrx_layout l);
+int iamrx_layout_nlocal(iamrx_layout l, int* nlocal);
+int iamrx_layout_local_box(iamrx_layout l, int local_idx, int lo_hi[6], int* global_idx);
+int iamrx_mf_create(iamrx_layout l, const int type[3] /* 1 = nodal in that direction */, int ncomp, int ngrow, iamrx_mf* out);
+int iamrx_mf_destroy(iamrx_mf m);
+int iamrx_mf_info(iamrx_mf m, int* ncomp, int* ngrow, int type[3], int* nlocal);
+int iamrx_mf_fab_box(iamrx_mf m, int local_idx, int lo_hi[6]);         /* allocated region incl. ghosts */
+int iamrx_mf_dev_ptr(iamrx_mf m, int local_idx, double** p);
+int iamrx_mf_to_host(iamrx_mf m, int local_idx, double* dst);            /* whole fab, all comps */
+int iamrx_mf_from_host(iamrx_mf m, int local_idx, const double* src);
+int iamrx_mf_setval(iamrx_mf m, double v);                                /* MultiFab::setVal */
+int iamrx_mf_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int ncomp, int ngrow);  /* MultiFab::Copy */
+int iamrx_mf_fill_boundary(iamrx_mf m, const iamrx_geom* g);              /* FillBoundary(geom.periodicity()): Source/MacProj.cpp:1127 */
+int iamrx_mf_norm0(iamrx_mf m, int comp, int ncomp, int ngrow, double* out);   /* MultiFab::norm0: Source/NavierStokesBase.cpp:4408 */
+
+/* ---- cell-centred linear operator primitives (amrex::MLABecLaplacian role) ---- */
+/* one red or black Gauss-Seidel pass of (alpha*a - beta div b grad) phi = rhs; ghost cells of phi must be filled */
+int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                    iamrx_mf phi, iamrx_mf rhs, int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder);
+/* out = rhs - L(phi)  (rhs == NULL: out = L(phi)) */
+int iamrx_abec_residual(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                        iamrx_mf out, iamrx_mf phi, iamrx_mf rhs, int tensor);
+int iamrx_cc_restrict(iamrx_mf crse, iamrx_mf fine);
+int iamrx_cc_prolong_add(iamrx_mf fine, iamrx_mf crse);
+int iamrx_face_avgdown(iamrx_mf crse, iamrx_mf fine, int dir);
+/* full MLMG solve: amrex::MLMG::solve on MLABecLaplacian (tensor = 1: MLTensorOp, b = eta faces with 1 comp) */
+int iamrx_abec_solve(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                     iamrx_mf phi, iamrx_mf rhs, const int lobc[3], const int hibc[3], double rtol, double atol,
+                     const iamrx_mg_opts* o, int tensor, iamrx_mg_stats* st);
+
+/* ---- MAC projection -------------------------------------------------------------------- */
+/* MacProj::mlmg_mac_solve (Source/MacProj.cpp:1084-1184; declaration Source/MacProj.H:82-94):
+ * b = (1/rhs_scale)/rho_face, rhs = S - div(u_mac), solve, u_mac -= b grad phi.  rho needs 1 filled ghost. */
+int iamrx_mlmg_mac_solve(const iamrx_geom* g, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf rho, int rho_comp,
+                         iamrx_mf S /* may be NULL */, iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3],
+                         double mac_tol, double mac_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* MacProj::check_div_cond (Source/MacProj.cpp:792-846): div = div(u_mac) */
+int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,207 @@
+/*
+ * oracle/orc.h -- CPU restatement (plain C, fp64) of IAMR's per-timestep hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liborc.so.  The product (iamr_amd/libiamrx.so)
+ * never links, loads or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in AMReX (`AMReX-Codes/amrex`,
+ * branch development, unpinned) and AMReX-Hydro (`AMReX-Fluids/AMReX-Hydro`, branch main,
+ * unpinned) -- see /root/reference/Exec/Make.IAMR:17-38, Exec/run3d/GNUmakefile:2-3.
+ * Neither is present in the reference tree nor in this container, and the reference
+ * commits no golden data (Test/README.md:23-29).  This restatement follows the in-tree
+ * call sites (cited per function) and the published algorithms (Almgren et al. JCP 142
+ * (1998); AMReX MLMG / AMReX-Hydro documentation).  It is pinned against: the exact
+ * Taylor vortex (Tutorials/TaylorGreen/benchmarks/EXACT_3D.F:75-119), discrete
+ * eigen-answers of the 7-pt and Q1 27-pt operators, and conservation / divergence
+ * invariants (tests/test_oracle_*.py).
+ *
+ * Storage convention = AMReX Array4: for an array allocated on the index
+ * region [lo,hi] (inclusive, ghost cells included) with nc components,
+ *   offset(i,j,k,n) = (i-lo0) + nx*((j-lo1) + ny*((k-lo2) + nz*n)).
+ * Index regions are in the array's own index space: cell (i = cell), x-face (i = face
+ * between cells i-1 and i), node (i = lower corner of cell i).
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_fab {
+    double* p;
+    int lo[3];
+    int hi[3];
+    int nc;
+} orc_fab;
+
+/* geometry of a single-box level: domain cells [0,n-1]^3 */
+typedef struct orc_geom {
+    int n[3];          /* number of cells */
+    double dx[3];
+    double problo[3];
+    int periodic[3];
+} orc_geom;
+
+/* mathematical BC codes = amrex::BCType (AMReX_BC_TYPES.H) */
+enum { ORC_BC_REFLECT_ODD = -1, ORC_BC_INT_DIR = 0, ORC_BC_REFLECT_EVEN = 1,
+       ORC_BC_FOEXTRAP = 2, ORC_BC_EXT_DIR = 3, ORC_BC_HOEXTRAP = 4 };
+
+/* linear-operator domain BC = amrex::LinOpBCType */
+enum { ORC_LO_PERIODIC = 0, ORC_LO_DIRICHLET = 101, ORC_LO_NEUMANN = 102 };
+
+/* bcrec: lo[3], hi[3] per component */
+typedef struct orc_bcrec { int lo[3]; int hi[3]; } orc_bcrec;
+
+/* ---- ghost filling (orc_fill.c) ------------------------------------------------ */
+/* periodic wrap of every ghost entry of `f` whose image lies inside the valid index
+ * region; type[d]=1 for nodal direction d.  Mirrors FillBoundary(geom.periodicity()). */
+void orc_fill_periodic(orc_fab* f, const orc_geom* g, const int type[3]);
+/* physical BC fill of cell-centred ghost cells outside the domain (foextrap, hoextrap,
+ * reflect_even/odd, ext_dir with constant value) -- NS_bcfill.H + amrex FilccCell */
+void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
+                        const double* extdir_lo /*[nc][3]*/, const double* extdir_hi);
+
+/* ---- cell-centred ABec operator + multigrid (orc_abec.c) ------------------------ */
+typedef struct orc_abec_level {
+    orc_geom g;
+    double alpha, beta;       /* scalars: (alpha*a - beta div b grad) */
+    orc_fab a;                /* cell, 1 comp, 0 ghost (may be p==NULL when alpha==0) */
+    orc_fab b[3];             /* face-centred, ncomp comps, 0 ghost */
+    int ncomp;
+    int tensor;               /* 1: MLTensorOp -- b holds eta*(4/3 on the normal comp), cross terms added in apply */
+} orc_abec_level;
+
+typedef struct orc_mg_stats {
+    int iters;
+    double resnorm0, rhsnorm0, resnorm;
+    int bottom_iters_total;
+    int converged;
+} orc_mg_stats;
+
+typedef struct orc_mg_opts {
+    int nu1, nu2, nuf, nub;       /* 2,2,8,0 */
+    int max_iters;                /* 200 */
+    int bottom_maxiter;           /* 200 */
+    double bottom_reltol;         /* 1e-4 */
+    double omega;                 /* GSRB over-relaxation (1.15) */
+    int maxorder;                 /* Dirichlet ghost extrapolation order */
+    int max_coarsening_level;     /* 30 */
+    int min_width;                /* coarsest box width (2) */
+    int nodal_sweeps;             /* nodal: GS sweeps per smooth call (4) */
+    int nodal_smoother;           /* 0 = 8-colour GS, 1 = lexicographic GS, 2 = Jacobi(2/3) */
+    int verbose;
+    int bottom_smoother_only;     /* 1: bottom = nuf smooths instead of BiCGStab */
+    int fixed_iters;              /* >0: do exactly this many V-cycles, ignore tolerances */
+} orc_mg_opts;
+
+void orc_mg_default_opts(orc_mg_opts* o);
+
+void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x /*1 ghost, filled*/);
+void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi /*1 ghost, filled*/, const orc_fab* rhs,
+                   int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder);
+void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
+                      int maxorder, int inhomog, const orc_fab* bcval /*same shape as phi, ghost cells hold BC values*/);
+void orc_cc_restrict(orc_fab* crse, const orc_fab* fine, const int cn[3]);
+void orc_cc_prolong_add(orc_fab* fine, const orc_fab* crse, const int fn[3]);
+void orc_face_avgdown(orc_fab* crse, const orc_fab* fine, int dir, const int cn[3]);
+
+/* solve (alpha*a - beta div b grad) phi = rhs on the single-box level.  phi has 1 ghost
+ * (ghost values at Dirichlet faces = inhomogeneous BC data on entry).  Follows AMReX
+ * MLMG::solve/oneIter/mgVcycle/actualBottomSolve + MLCGSolver::solve_bicgstab. */
+void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs,
+                    const int lobc[3], const int hibc[3],
+                    double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+
+/* flux_d = -beta * b_d * dphi/dx_d on faces (MLMG::getFluxes) */
+void orc_abec_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi);
+
+/* Hydro::MacProjector::project as called from MacProj::mlmg_mac_solve
+ * (reference Source/MacProj.cpp:1084-1184): b = 1/(rhs_scale*rho_face),
+ * rhs = S - div(umac), solve -div(b grad phi) = rhs, umac -= b grad phi. */
+void orc_mac_project(const orc_geom* g, orc_fab* umac[3] /*faces, >=0 ghost*/, const orc_fab* rho /*cell, 1 ghost filled*/,
+                     const orc_fab* S /*cell, may be NULL*/, orc_fab* phi /*cell, 1 ghost*/,
+                     double rhs_scale, const int lobc[3], const int hibc[3],
+                     double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+
+void orc_mac_divergence(const orc_geom* g, orc_fab* div, orc_fab* const umac[3]);
+
+/* ---- Godunov (orc_godunov.c) ------------------------------------------------------ */
+double orc_slope4(const orc_fab* q, int i, int j, int k, int n, int dir);
+/* Godunov::ExtrapVelToFaces (PLM), reference call site Source/NavierStokesBase.cpp:4487-4491 */
+void orc_extrap_vel_to_faces(const orc_geom* g, const orc_fab* vel /*3 comps, 3 ghost filled*/,
+                             const orc_fab* force /*3 comps, 1 ghost*/, orc_fab* umac[3],
+                             double dt, const orc_bcrec* bc /*[3]*/, int use_forces_in_trans);
+/* HydroUtils::ComputeFluxesOnBoxFromState("Godunov", PLM) + ComputeDivergence(mult=-1) +
+ * ComputeConvectiveTerm, then aofs = -update; reference Source/NavierStokesBase.cpp:4701-4842 */
+void orc_compute_aofs(const orc_geom* g, orc_fab* aofs /*ncomp comps starting at acomp*/, int acomp,
+                      const orc_fab* S /*ncomp comps, 3 ghost*/, int ncomp,
+                      const orc_fab* force /*ncomp,1 ghost*/, const orc_fab* divu /*1 ghost or NULL*/,
+                      orc_fab* const umac[3], const int* iconserv, double dt,
+                      const orc_bcrec* bc, int is_velocity, int use_forces_in_trans,
+                      orc_fab* edge_out[3] /*optional, ncomp face comps*/, orc_fab* flux_out[3]);
+
+/* ---- nodal projection (orc_nodal.c) ---------------------------------------------- */
+void orc_nodal_adotx(const orc_geom* g, orc_fab* y, const orc_fab* x /*node,1 ghost*/, const orc_fab* sig /*cell,1 ghost*/);
+void orc_nodal_divu(const orc_geom* g, orc_fab* rhs /*node*/, const orc_fab* vel /*cell,3 comps,1 ghost*/);
+void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const orc_fab* sig, int smoother, int nsweeps,
+                      const int lobc[3], const int hibc[3]);
+void orc_nodal_restrict(orc_fab* crse, const orc_fab* fine, const orc_geom* cg);
+void orc_nodal_interp_add(orc_fab* fine, const orc_fab* crse, const orc_fab* sig_fine, const orc_geom* fg);
+void orc_nodal_mknewu(const orc_geom* g, orc_fab* vel, const orc_fab* phi, const orc_fab* sig);
+void orc_nodal_compgrad(const orc_geom* g, orc_fab* gp, const orc_fab* phi);
+void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, const orc_fab* sig,
+                     const int lobc[3], const int hibc[3], double rtol, double atol,
+                     const orc_mg_opts* o, orc_mg_stats* st);
+/* Hydro::NodalProjector::project as called from Projection::doMLMGNodalProjection
+ * (reference Source/Projection.cpp:2512-2542): rhs = div(vel), solve div(sig grad phi)=rhs,
+ * vel -= sig grad phi. */
+void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc_fab* phi /*node, 1 ghost*/,
+                       const orc_fab* sig, const int lobc[3], const int hibc[3],
+                       double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+
+/* ---- tensor diffusion (orc_tensor.c) ---------------------------------------------- */
+/* y = (alpha*a - beta div tau(u)) with MLTensorOp semantics (3 comps) */
+void orc_tensor_apply(const orc_geom* g, orc_fab* y, const orc_fab* u /*3 comps,1 ghost filled incl. corners*/,
+                      double alpha, double beta, const orc_fab* a, orc_fab* const eta[3] /*faces,1 comp*/);
+void orc_tensor_solve(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                      const orc_fab* a, orc_fab* const eta[3], const int lobc[3], const int hibc[3],
+                      double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+
+/* ---- level time step (orc_ns.c) ---------------------------------------------------- */
+typedef struct orc_ns_params {
+    double cfl, visc_coef, be_cn_theta;
+    double gravity;
+    double mac_tol, mac_abs_tol, proj_tol, proj_abs_tol, visc_tol;
+    int use_forces_in_trans;
+    int do_mom_diff;
+    int init_iter, init_vel_iter;
+    double init_shrink, change_max, fixed_dt;
+    int nscal;                 /* number of scalars incl. density (2) */
+    int verbose;
+} orc_ns_params;
+
+typedef struct orc_ns_state orc_ns_state;
+
+void orc_ns_default_params(orc_ns_params* p);
+orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc_mg_opts* o);
+void orc_ns_destroy(orc_ns_state* s);
+/* pointers to the persistent arrays (for initial conditions and comparison).
+ * which: 0 S_new (NUM_STATE comps, 1 ghost), 1 S_old, 2 P_new (node,1 ghost), 3 P_old,
+ * 4 Gp_new (3 comps,1 ghost), 5 Gp_old, 6..8 umac, 9 aofs */
+orc_fab* orc_ns_fab(orc_ns_state* s, int which);
+void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0);
+/* NavierStokes::post_init sequence: initialVelocityProject, estimate dt, init_iter pressure iterations */
+void orc_ns_post_init(orc_ns_state* s, double stop_time);
+/* one coarse time step: computeNewDt + NavierStokes::advance; returns dt used */
+double orc_ns_step(orc_ns_state* s);
+double orc_ns_time(const orc_ns_state* s);
+double orc_ns_dt(const orc_ns_state* s);
+void orc_ns_last_stats(const orc_ns_state* s, orc_mg_stats* mac, orc_mg_stats* nodal, orc_mg_stats* visc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

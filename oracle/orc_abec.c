@@ -1,0 +1,544 @@
+/* oracle/orc_abec.c -- cell-centred (alpha*a - beta div b grad) operator, geometric multigrid
+ * and the MAC projection, restated on the CPU (test infrastructure only; PARITY UNPINNED, see orc.h).
+ *
+ * Follows (upstream, not in /root/reference): AMReX MLABecLaplacian (mlabeclap_adotx, abec_gsrb,
+ * mlabeclap_flux), MLCellLinOp::applyBC (mllinop_apply_bc_x, poly_interp_coeff), MLMG::solve /
+ * oneIter / mgVcycle / actualBottomSolve, MLCGSolver::solve_bicgstab, amrex_avgdown(_faces),
+ * Hydro::MacProjector::project.  Reference call sites: Source/MacProj.cpp:1084-1184 (coefficients,
+ * BCs, max_order=4, tolerances), Source/Diffusion.cpp:327-345.
+ */
+#include "orc_int.h"
+
+void orc_mg_default_opts(orc_mg_opts* o)
+{
+    o->nu1 = 2; o->nu2 = 2; o->nuf = 8; o->nub = 0;
+    o->max_iters = 200; o->bottom_maxiter = 200; o->bottom_reltol = 1.e-4;
+    o->omega = 1.15; o->maxorder = 3; o->max_coarsening_level = 30; o->min_width = 2;
+    o->nodal_sweeps = 4; o->nodal_smoother = 0; o->verbose = 0; o->bottom_smoother_only = 0;
+    o->fixed_iters = 0;
+}
+
+/* ---------------------------------------------------------------- operator ----- */
+void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_fab* x); /* orc_tensor.c */
+int orc_abec_is_tensor(const orc_abec_level* L);                                          /* orc_tensor.c */
+
+void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x)
+{
+    const orc_geom* g = &L->g;
+    const double dhx = L->beta / (g->dx[0] * g->dx[0]);
+    const double dhy = L->beta / (g->dx[1] * g->dx[1]);
+    const double dhz = L->beta / (g->dx[2] * g->dx[2]);
+    const orc_fab *bX = &L->b[0], *bY = &L->b[1], *bZ = &L->b[2];
+    for (int n = 0; n < L->ncomp; ++n)
+    for (int k = 0; k < g->n[2]; ++k)
+    for (int j = 0; j < g->n[1]; ++j)
+    for (int i = 0; i < g->n[0]; ++i) {
+        double ax = (L->alpha != 0.0 && L->a.p) ? L->alpha * A4(&L->a, i, j, k, 0) * A4(x, i, j, k, n) : 0.0;
+        A4(y, i, j, k, n) = ax
+            - dhx * (A4(bX, i + 1, j, k, n) * (A4(x, i + 1, j, k, n) - A4(x, i, j, k, n))
+                   - A4(bX, i, j, k, n) * (A4(x, i, j, k, n) - A4(x, i - 1, j, k, n)))
+            - dhy * (A4(bY, i, j + 1, k, n) * (A4(x, i, j + 1, k, n) - A4(x, i, j, k, n))
+                   - A4(bY, i, j, k, n) * (A4(x, i, j, k, n) - A4(x, i, j - 1, k, n)))
+            - dhz * (A4(bZ, i, j, k + 1, n) * (A4(x, i, j, k + 1, n) - A4(x, i, j, k, n))
+                   - A4(bZ, i, j, k, n) * (A4(x, i, j, k, n) - A4(x, i, j, k - 1, n)));
+    }
+    if (orc_abec_is_tensor(L)) orc_tensor_cross_terms_add(L, y, x);
+}
+
+/* Lagrange weights c[j] = prod_{i!=j} (xi - x[i])/(x[j]-x[i])  (amrex poly_interp_coeff) */
+static void poly_interp_coeff(double xi, const double* x, int N, double* c)
+{
+    for (int j = 0; j < N; ++j) {
+        double num = 1.0, den = 1.0;
+        for (int i = 0; i < N; ++i) {
+            if (i == j) continue;
+            num *= xi - x[i];
+            den *= x[j] - x[i];
+        }
+        c[j] = num / den;
+    }
+}
+
+/* coefficient of the first interior cell in the ghost-cell formula (mllinop_comp_interp_coef0) */
+static double bc_coef0(int bct, int blen, int maxorder)
+{
+    if (bct == ORC_LO_NEUMANN) return 1.0;
+    if (bct == ORC_LO_DIRICHLET) {
+        int NX = blen + 1 < maxorder ? blen + 1 : maxorder;
+        if (NX < 2) return 0.0;
+        double x[4] = {0.0, 0.5, 1.5, 2.5}, c[4];
+        poly_interp_coeff(-0.5, x, NX, c);
+        return c[1];
+    }
+    return 0.0;
+}
+
+void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
+                      int maxorder, int inhomog, const orc_fab* bcval)
+{
+    const orc_geom* g = &L->g;
+    orc_fill_periodic(phi, g, ORC_CELL);
+    for (int d = 0; d < 3; ++d) {
+        if (g->periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            const int bct = side == 0 ? lobc[d] : hibc[d];
+            const int s = 1 - 2 * side;
+            const int ig = side == 0 ? -1 : g->n[d];
+            const int blen = g->n[d];
+            int NX = blen + 1 < maxorder ? blen + 1 : maxorder;
+            double x[4] = {0.0, 0.5, 1.5, 2.5}, c[4] = {0, 0, 0, 0};
+            if (bct == ORC_LO_DIRICHLET && NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
+            int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+            for (int n = 0; n < L->ncomp; ++n)
+            for (int q2 = 0; q2 < g->n[d2]; ++q2)
+            for (int q1 = 0; q1 < g->n[d1]; ++q1) {
+                int idx[3]; idx[d] = ig; idx[d1] = q1; idx[d2] = q2;
+                double v;
+                if (bct == ORC_LO_NEUMANN) {
+                    int s1[3] = {idx[0], idx[1], idx[2]}; s1[d] = ig + s;
+                    v = A4(phi, s1[0], s1[1], s1[2], n);
+                } else if (bct == ORC_LO_DIRICHLET) {
+                    double bv = (inhomog && bcval) ? A4(bcval, idx[0], idx[1], idx[2], n) : 0.0;
+                    if (NX < 2) v = bv;
+                    else {
+                        double tmp = 0.0;
+                        for (int m = 1; m < NX; ++m) {
+                            int sm[3] = {idx[0], idx[1], idx[2]}; sm[d] = ig + m * s;
+                            tmp += A4(phi, sm[0], sm[1], sm[2], n) * c[m];
+                        }
+                        v = tmp + bv * c[0];
+                    }
+                } else continue;
+                A4(phi, idx[0], idx[1], idx[2], n) = v;
+            }
+        }
+    }
+}
+
+void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, int redblack, double omega,
+                   const int lobc[3], const int hibc[3], int maxorder)
+{
+    const orc_geom* g = &L->g;
+    const double dhx = L->beta / (g->dx[0] * g->dx[0]);
+    const double dhy = L->beta / (g->dx[1] * g->dx[1]);
+    const double dhz = L->beta / (g->dx[2] * g->dx[2]);
+    const orc_fab *bX = &L->b[0], *bY = &L->b[1], *bZ = &L->b[2];
+    double cflo[3], cfhi[3];
+    for (int d = 0; d < 3; ++d) {
+        cflo[d] = g->periodic[d] ? 0.0 : bc_coef0(lobc[d], g->n[d], maxorder);
+        cfhi[d] = g->periodic[d] ? 0.0 : bc_coef0(hibc[d], g->n[d], maxorder);
+    }
+    for (int n = 0; n < L->ncomp; ++n)
+    for (int k = 0; k < g->n[2]; ++k)
+    for (int j = 0; j < g->n[1]; ++j)
+    for (int i = 0; i < g->n[0]; ++i) {
+        if ((i + j + k + redblack) % 2 != 0) continue;
+        double cf0 = (i == 0) ? cflo[0] : 0.0, cf3 = (i == g->n[0] - 1) ? cfhi[0] : 0.0;
+        double cf1 = (j == 0) ? cflo[1] : 0.0, cf4 = (j == g->n[1] - 1) ? cfhi[1] : 0.0;
+        double cf2 = (k == 0) ? cflo[2] : 0.0, cf5 = (k == g->n[2] - 1) ? cfhi[2] : 0.0;
+        double aa = (L->alpha != 0.0 && L->a.p) ? L->alpha * A4(&L->a, i, j, k, 0) : 0.0;
+        double gamma = aa + dhx * (A4(bX, i, j, k, n) + A4(bX, i + 1, j, k, n))
+                          + dhy * (A4(bY, i, j, k, n) + A4(bY, i, j + 1, k, n))
+                          + dhz * (A4(bZ, i, j, k, n) + A4(bZ, i, j, k + 1, n));
+        double g_m_d = gamma - (dhx * (A4(bX, i, j, k, n) * cf0 + A4(bX, i + 1, j, k, n) * cf3)
+                              + dhy * (A4(bY, i, j, k, n) * cf1 + A4(bY, i, j + 1, k, n) * cf4)
+                              + dhz * (A4(bZ, i, j, k, n) * cf2 + A4(bZ, i, j, k + 1, n) * cf5));
+        double rho = dhx * (A4(bX, i, j, k, n) * A4(phi, i - 1, j, k, n) + A4(bX, i + 1, j, k, n) * A4(phi, i + 1, j, k, n))
+                   + dhy * (A4(bY, i, j, k, n) * A4(phi, i, j - 1, k, n) + A4(bY, i, j + 1, k, n) * A4(phi, i, j + 1, k, n))
+                   + dhz * (A4(bZ, i, j, k, n) * A4(phi, i, j, k - 1, n) + A4(bZ, i, j, k + 1, n) * A4(phi, i, j, k + 1, n));
+        double res = A4(rhs, i, j, k, n) - (gamma * A4(phi, i, j, k, n) - rho);
+        A4(phi, i, j, k, n) = A4(phi, i, j, k, n) + omega / g_m_d * res;
+    }
+}
+
+/* ---------------------------------------------------------------- transfers ---- */
+void orc_cc_restrict(orc_fab* crse, const orc_fab* fine, const int cn[3])
+{
+    for (int n = 0; n < crse->nc; ++n)
+    for (int k = 0; k < cn[2]; ++k)
+    for (int j = 0; j < cn[1]; ++j)
+    for (int i = 0; i < cn[0]; ++i) {
+        double c = 0.0;
+        for (int kr = 0; kr < 2; ++kr)
+        for (int jr = 0; jr < 2; ++jr)
+        for (int ir = 0; ir < 2; ++ir)
+            c += A4(fine, 2 * i + ir, 2 * j + jr, 2 * k + kr, n);
+        A4(crse, i, j, k, n) = 0.125 * c;
+    }
+}
+
+void orc_cc_prolong_add(orc_fab* fine, const orc_fab* crse, const int fn[3])
+{
+    for (int n = 0; n < fine->nc; ++n)
+    for (int k = 0; k < fn[2]; ++k)
+    for (int j = 0; j < fn[1]; ++j)
+    for (int i = 0; i < fn[0]; ++i)
+        A4(fine, i, j, k, n) += A4(crse, i >> 1, j >> 1, k >> 1, n);
+}
+
+void orc_face_avgdown(orc_fab* crse, const orc_fab* fine, int dir, const int cn[3])
+{
+    int hi[3] = {cn[0] - 1, cn[1] - 1, cn[2] - 1};
+    hi[dir] += 1;
+    int d1 = (dir + 1) % 3, d2 = (dir + 2) % 3;
+    for (int n = 0; n < crse->nc; ++n)
+    for (int k = 0; k <= hi[2]; ++k)
+    for (int j = 0; j <= hi[1]; ++j)
+    for (int i = 0; i <= hi[0]; ++i) {
+        int c[3] = {i, j, k};
+        double s = 0.0;
+        /* loop order: slower transverse index outer (kref, then jref in amrex_avgdown_faces) */
+        int da = d1 < d2 ? d1 : d2, db = d1 < d2 ? d2 : d1;
+        for (int rb = 0; rb < 2; ++rb)
+        for (int ra = 0; ra < 2; ++ra) {
+            int f[3];
+            f[dir] = 2 * c[dir]; f[da] = 2 * c[da] + ra; f[db] = 2 * c[db] + rb;
+            s += A4(fine, f[0], f[1], f[2], n);
+        }
+        A4(crse, i, j, k, n) = s * 0.25;
+    }
+}
+
+/* ---------------------------------------------------------------- multigrid ---- */
+typedef struct mglev {
+    orc_abec_level L;
+    orc_fab cor, res, rescor;
+    int owns_coef;
+} mglev;
+
+static double norminf_valid(const orc_fab* f, const int n[3], int nc)
+{
+    double m = 0.0;
+    for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i) {
+        double v = fabs(A4(f, i, j, k, c));
+        if (v > m) m = v;
+    }
+    return m;
+}
+static double dot_valid(const orc_fab* x, const orc_fab* y, const int n[3], int nc)
+{
+    double s = 0.0;
+    for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        s += A4(x, i, j, k, c) * A4(y, i, j, k, c);
+    return s;
+}
+static void subtract_mean(orc_fab* f, const int n[3], int nc)
+{
+    for (int c = 0; c < nc; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i) s += A4(f, i, j, k, c);
+        double off = s / ((double)n[0] * n[1] * n[2]);
+        for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i) A4(f, i, j, k, c) -= off;
+    }
+}
+/* dst(valid) = a(valid) + s*b(valid) */
+static void sxay(orc_fab* dst, const orc_fab* a, double s, const orc_fab* b, const int n[3], int nc)
+{
+    for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        A4(dst, i, j, k, c) = A4(a, i, j, k, c) + s * A4(b, i, j, k, c);
+}
+static void copy_valid(orc_fab* dst, const orc_fab* src, const int n[3], int nc)
+{
+    for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        A4(dst, i, j, k, c) = A4(src, i, j, k, c);
+}
+
+static int is_singular(const orc_abec_level* L, const int lobc[3], const int hibc[3])
+{
+    if (L->alpha != 0.0 && L->a.p) return 0;
+    for (int d = 0; d < 3; ++d) {
+        if (L->g.periodic[d]) continue;
+        if (lobc[d] == ORC_LO_DIRICHLET || hibc[d] == ORC_LO_DIRICHLET) return 0;
+    }
+    return 1;
+}
+
+static void smooth(const mglev* m, orc_fab* sol, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                   const orc_mg_opts* o, int skip_fill)
+{
+    for (int rb = 0; rb < 2; ++rb) {
+        if (!skip_fill) orc_abec_applybc(&m->L, sol, lobc, hibc, o->maxorder, 0, NULL);
+        orc_abec_gsrb(&m->L, sol, rhs, rb, o->omega, lobc, hibc, o->maxorder);
+        skip_fill = 0;
+    }
+}
+
+/* r = b - L(x), homogeneous BC */
+static void corr_residual(const mglev* m, orc_fab* r, orc_fab* x, const orc_fab* b,
+                          const int lobc[3], const int hibc[3], const orc_mg_opts* o)
+{
+    orc_abec_applybc(&m->L, x, lobc, hibc, o->maxorder, 0, NULL);
+    orc_abec_apply(&m->L, r, x);
+    const int* n = m->L.g.n;
+    for (int c = 0; c < m->L.ncomp; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        A4(r, i, j, k, c) = A4(b, i, j, k, c) - A4(r, i, j, k, c);
+}
+
+/* MLCGSolver::solve_bicgstab */
+static int bicgstab(const mglev* m, orc_fab* sol, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                    const orc_mg_opts* o, double eps_rel, double eps_abs, int* niters)
+{
+    const int* n = m->L.g.n;
+    const int nc = m->L.ncomp;
+    orc_fab ph = orc_alloc(n, ORC_CELL, 1, nc), sh = orc_alloc(n, ORC_CELL, 1, nc);
+    orc_fab sorig = orc_alloc(n, ORC_CELL, 0, nc), p = orc_alloc(n, ORC_CELL, 0, nc), r = orc_alloc(n, ORC_CELL, 0, nc);
+    orc_fab s = orc_alloc(n, ORC_CELL, 0, nc), rh = orc_alloc(n, ORC_CELL, 0, nc), v = orc_alloc(n, ORC_CELL, 0, nc), t = orc_alloc(n, ORC_CELL, 0, nc);
+    corr_residual(m, &r, sol, rhs, lobc, hibc, o);
+    copy_valid(&sorig, sol, n, nc);
+    copy_valid(&rh, &r, n, nc);
+    orc_setval(sol, 0.0);
+    double rnorm = norminf_valid(&r, n, nc);
+    const double rnorm0 = rnorm;
+    int ret = 0, nit = 1;
+    double rho_1 = 0, alpha = 0, omega = 0;
+    if (rnorm0 == 0 || rnorm0 < eps_abs) { nit = 0; goto done; }
+    for (; nit <= o->bottom_maxiter; ++nit) {
+        const double rho = dot_valid(&rh, &r, n, nc);
+        if (rho == 0) { ret = 1; break; }
+        if (nit == 1) copy_valid(&p, &r, n, nc);
+        else {
+            const double beta = (rho / rho_1) * (alpha / omega);
+            sxay(&p, &p, -omega, &v, n, nc);
+            sxay(&p, &r, beta, &p, n, nc);
+        }
+        copy_valid(&ph, &p, n, nc);
+        orc_abec_applybc(&m->L, &ph, lobc, hibc, o->maxorder, 0, NULL);
+        orc_abec_apply(&m->L, &v, &ph);
+        const double rhTv = dot_valid(&rh, &v, n, nc);
+        if (rhTv != 0) alpha = rho / rhTv; else { ret = 2; break; }
+        sxay(sol, sol, alpha, &ph, n, nc);
+        sxay(&s, &r, -alpha, &v, n, nc);
+        rnorm = norminf_valid(&s, n, nc);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        copy_valid(&sh, &s, n, nc);
+        orc_abec_applybc(&m->L, &sh, lobc, hibc, o->maxorder, 0, NULL);
+        orc_abec_apply(&m->L, &t, &sh);
+        const double tt = dot_valid(&t, &t, n, nc), ts = dot_valid(&t, &s, n, nc);
+        if (tt != 0) omega = ts / tt; else { ret = 3; break; }
+        sxay(sol, sol, omega, &sh, n, nc);
+        sxay(&r, &s, -omega, &t, n, nc);
+        rnorm = norminf_valid(&r, n, nc);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        if (omega == 0) { ret = 4; break; }
+        rho_1 = rho;
+    }
+    if (ret == 0 && rnorm > eps_rel * rnorm0 && rnorm > eps_abs) ret = 8;
+    if ((ret == 0 || ret == 8) && rnorm < rnorm0) sxay(sol, sol, 1.0, &sorig, n, nc);
+    else { orc_setval(sol, 0.0); sxay(sol, sol, 1.0, &sorig, n, nc); }
+done:
+    if (niters) *niters = nit;
+    orc_free(&ph); orc_free(&sh); orc_free(&sorig); orc_free(&p); orc_free(&r); orc_free(&s); orc_free(&rh); orc_free(&v); orc_free(&t);
+    return ret;
+}
+
+static void bottom_solve(mglev* m, const int lobc[3], const int hibc[3], const orc_mg_opts* o, int singular, orc_mg_stats* st)
+{
+    const int* n = m->L.g.n;
+    orc_setval(&m->cor, 0.0);
+    if (o->bottom_smoother_only) {
+        int skip = 1;
+        for (int i = 0; i < o->nuf; ++i) { smooth(m, &m->cor, &m->res, lobc, hibc, o, skip); skip = 0; }
+        return;
+    }
+    orc_fab b = orc_alloc(n, ORC_CELL, 0, m->L.ncomp);
+    copy_valid(&b, &m->res, n, m->L.ncomp);
+    if (singular) subtract_mean(&b, n, m->L.ncomp);
+    int nit = 0;
+    int ret = bicgstab(m, &m->cor, &b, lobc, hibc, o, o->bottom_reltol, -1.0, &nit);
+    if (st) st->bottom_iters_total += nit;
+    if (ret != 0) {
+        orc_setval(&m->cor, 0.0);
+        int skip = 1;
+        for (int i = 0; i < o->nuf; ++i) { smooth(m, &m->cor, &m->res, lobc, hibc, o, skip); skip = 0; }
+    }
+    const int nn = (ret == 0) ? o->nub : o->nuf;
+    for (int i = 0; i < nn; ++i) smooth(m, &m->cor, &m->res, lobc, hibc, o, 0);
+    orc_free(&b);
+}
+
+static void vcycle(mglev* mg, int nlev, const int lobc[3], const int hibc[3], const orc_mg_opts* o, int singular, orc_mg_stats* st)
+{
+    for (int l = 0; l < nlev - 1; ++l) {
+        orc_setval(&mg[l].cor, 0.0);
+        int skip = 1;
+        for (int i = 0; i < o->nu1; ++i) { smooth(&mg[l], &mg[l].cor, &mg[l].res, lobc, hibc, o, skip); skip = 0; }
+        corr_residual(&mg[l], &mg[l].rescor, &mg[l].cor, &mg[l].res, lobc, hibc, o);
+        orc_cc_restrict(&mg[l + 1].res, &mg[l].rescor, mg[l + 1].L.g.n);
+    }
+    if (nlev == 1 && 0) {}
+    bottom_solve(&mg[nlev - 1], lobc, hibc, o, singular, st);
+    for (int l = nlev - 2; l >= 0; --l) {
+        orc_cc_prolong_add(&mg[l].cor, &mg[l + 1].cor, mg[l].L.g.n);
+        for (int i = 0; i < o->nu2; ++i) smooth(&mg[l], &mg[l].cor, &mg[l].res, lobc, hibc, o, 0);
+    }
+}
+
+static int build_hierarchy(const orc_abec_level* L, mglev* mg, const orc_mg_opts* o)
+{
+    int nlev = 1;
+    mg[0].L = *L; mg[0].owns_coef = 0;
+    while (nlev <= o->max_coarsening_level && nlev < 32) {
+        const orc_geom* fg = &mg[nlev - 1].L.g;
+        int ok = 1;
+        for (int d = 0; d < 3; ++d) if (fg->n[d] % 2 != 0 || fg->n[d] / 2 < o->min_width) ok = 0;
+        if (!ok) break;
+        mglev* c = &mg[nlev];
+        c->L = mg[nlev - 1].L;
+        for (int d = 0; d < 3; ++d) { c->L.g.n[d] = fg->n[d] / 2; c->L.g.dx[d] = fg->dx[d] * 2.0; }
+        c->owns_coef = 1;
+        if (L->a.p) {
+            c->L.a = orc_alloc(c->L.g.n, ORC_CELL, 0, 1);
+            orc_cc_restrict(&c->L.a, &mg[nlev - 1].L.a, c->L.g.n);
+        }
+        for (int d = 0; d < 3; ++d) {
+            c->L.b[d] = orc_alloc(c->L.g.n, ORC_FACE[d], 0, L->b[d].nc);
+            orc_face_avgdown(&c->L.b[d], &mg[nlev - 1].L.b[d], d, c->L.g.n);
+        }
+        ++nlev;
+    }
+    for (int l = 0; l < nlev; ++l) {
+        mg[l].cor = orc_alloc(mg[l].L.g.n, ORC_CELL, 1, L->ncomp);
+        mg[l].res = orc_alloc(mg[l].L.g.n, ORC_CELL, 0, L->ncomp);
+        mg[l].rescor = orc_alloc(mg[l].L.g.n, ORC_CELL, 0, L->ncomp);
+    }
+    return nlev;
+}
+
+static void free_hierarchy(mglev* mg, int nlev)
+{
+    for (int l = 0; l < nlev; ++l) {
+        orc_free(&mg[l].cor); orc_free(&mg[l].res); orc_free(&mg[l].rescor);
+        if (mg[l].owns_coef) {
+            if (mg[l].L.a.p) orc_free(&mg[l].L.a);
+            for (int d = 0; d < 3; ++d) orc_free(&mg[l].L.b[d]);
+        }
+    }
+}
+
+void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs_in,
+                    const int lobc[3], const int hibc[3], double rtol, double atol,
+                    const orc_mg_opts* o, orc_mg_stats* st)
+{
+    mglev mg[32];
+    memset(mg, 0, sizeof(mg));
+    const int nlev = build_hierarchy(L, mg, o);
+    const int* n = L->g.n;
+    const int nc = L->ncomp;
+    const int singular = is_singular(L, lobc, hibc);
+    orc_mg_stats loc; memset(&loc, 0, sizeof(loc));
+
+    orc_fab rhs = orc_alloc(n, ORC_CELL, 0, nc);
+    copy_valid(&rhs, rhs_in, n, nc);
+    if (singular) subtract_mean(&rhs, n, nc);
+
+    /* inhomogeneous BC data = ghost values of phi on entry (MLMG setLevelBC) */
+    orc_fab bcval = orc_alloc(n, ORC_CELL, 1, nc);
+    orc_copy_all(&bcval, phi);
+
+    orc_fab* res = &mg[0].res;
+    orc_abec_applybc(L, phi, lobc, hibc, o->maxorder, 1, &bcval);
+    orc_abec_apply(L, res, phi);
+    for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        A4(res, i, j, k, c) = A4(&rhs, i, j, k, c) - A4(res, i, j, k, c);
+
+    loc.resnorm0 = norminf_valid(res, n, nc);
+    loc.rhsnorm0 = norminf_valid(&rhs, n, nc);
+    const double max_norm = loc.rhsnorm0 >= loc.resnorm0 ? loc.rhsnorm0 : loc.resnorm0;
+    const double res_target = fmax(atol, fmax(rtol, 1.e-16) * max_norm);
+    loc.resnorm = loc.resnorm0;
+    if (o->verbose) printf("orc MLMG: initial rhs %.6e resid0 %.6e target %.3e levels %d\n", loc.rhsnorm0, loc.resnorm0, res_target, nlev);
+    if (o->fixed_iters <= 0 && loc.resnorm0 <= res_target) loc.converged = 1;
+    else {
+        const int maxit = o->fixed_iters > 0 ? o->fixed_iters : o->max_iters;
+        for (int iter = 0; iter < maxit; ++iter) {
+            if (singular) subtract_mean(res, n, nc);
+            vcycle(mg, nlev, lobc, hibc, o, singular, &loc);
+            for (int c = 0; c < nc; ++c)
+            for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+                A4(phi, i, j, k, c) += A4(&mg[0].cor, i, j, k, c);
+            orc_abec_applybc(L, phi, lobc, hibc, o->maxorder, 1, &bcval);
+            orc_abec_apply(L, res, phi);
+            for (int c = 0; c < nc; ++c)
+            for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+                A4(res, i, j, k, c) = A4(&rhs, i, j, k, c) - A4(res, i, j, k, c);
+            loc.resnorm = norminf_valid(res, n, nc);
+            loc.iters = iter + 1;
+            if (o->verbose) printf("orc MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, loc.resnorm, loc.resnorm / max_norm);
+            if (o->fixed_iters <= 0 && loc.resnorm <= res_target) { loc.converged = 1; break; }
+        }
+    }
+    /* final ghost fill of the solution (setFinalFillBC-like; harmless for callers that refill) */
+    orc_abec_applybc(L, phi, lobc, hibc, o->maxorder, 1, &bcval);
+    if (st) *st = loc;
+    orc_free(&rhs); orc_free(&bcval);
+    free_hierarchy(mg, nlev);
+}
+
+void orc_abec_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi)
+{
+    const orc_geom* g = &L->g;
+    for (int d = 0; d < 3; ++d) {
+        const double fac = L->beta / g->dx[d];
+        int hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1};
+        hi[d] += 1;
+        for (int n = 0; n < L->ncomp; ++n)
+        for (int k = 0; k <= hi[2]; ++k) for (int j = 0; j <= hi[1]; ++j) for (int i = 0; i <= hi[0]; ++i) {
+            int m[3] = {i, j, k}; m[d] -= 1;
+            A4(flux[d], i, j, k, n) = -fac * A4(&L->b[d], i, j, k, n) * (A4(phi, i, j, k, n) - A4(phi, m[0], m[1], m[2], n));
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- MAC projection */
+void orc_mac_divergence(const orc_geom* g, orc_fab* div, orc_fab* const umac[3])
+{
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(div, i, j, k, 0) = (A4(umac[0], i + 1, j, k, 0) - A4(umac[0], i, j, k, 0)) / g->dx[0]
+                            + (A4(umac[1], i, j + 1, k, 0) - A4(umac[1], i, j, k, 0)) / g->dx[1]
+                            + (A4(umac[2], i, j, k + 1, 0) - A4(umac[2], i, j, k, 0)) / g->dx[2];
+}
+
+void orc_mac_project(const orc_geom* g, orc_fab* umac[3], const orc_fab* rho, const orc_fab* S, orc_fab* phi,
+                     double rhs_scale, const int lobc[3], const int hibc[3], double rtol, double atol,
+                     const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_abec_level L;
+    memset(&L, 0, sizeof(L));
+    L.g = *g; L.alpha = 0.0; L.beta = 1.0; L.ncomp = 1; L.a.p = NULL;
+    /* average_cellcenter_to_face(rho) then invert(1/rhs_scale): b = (1/rhs_scale)/rho_face
+     * (reference Source/MacProj.cpp:1115-1127) */
+    const double scale = 1.0 / rhs_scale;
+    for (int d = 0; d < 3; ++d) {
+        L.b[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1);
+        int hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1}; hi[d] += 1;
+        for (int k = 0; k <= hi[2]; ++k) for (int j = 0; j <= hi[1]; ++j) for (int i = 0; i <= hi[0]; ++i) {
+            int m[3] = {i, j, k}; m[d] -= 1;
+            double rf = 0.5 * (A4(rho, m[0], m[1], m[2], 0) + A4(rho, i, j, k, 0));
+            A4(&L.b[d], i, j, k, 0) = scale / rf;
+        }
+    }
+    orc_fab rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
+    orc_mac_divergence(g, &rhs, umac);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double v = -A4(&rhs, i, j, k, 0);
+        if (S) v += A4(S, i, j, k, 0);
+        A4(&rhs, i, j, k, 0) = v;
+    }
+    orc_abec_solve(&L, phi, &rhs, lobc, hibc, rtol, atol, o, st);
+    orc_fab fl[3]; orc_fab* flp[3];
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); flp[d] = &fl[d]; }
+    orc_abec_flux(&L, flp, phi);
+    for (int d = 0; d < 3; ++d) {
+        int hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1}; hi[d] += 1;
+        for (int k = 0; k <= hi[2]; ++k) for (int j = 0; j <= hi[1]; ++j) for (int i = 0; i <= hi[0]; ++i)
+            A4(umac[d], i, j, k, 0) += A4(&fl[d], i, j, k, 0);
+        orc_free(&fl[d]); orc_free(&L.b[d]);
+    }
+    orc_free(&rhs);
+}

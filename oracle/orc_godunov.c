@@ -1,0 +1,445 @@
+/* oracle/orc_godunov.c -- Godunov (PLM, corner-transport-upwind) extrapolation and advective
+ * update, restated on the CPU as a multi-pass, array-at-a-time algorithm (test infrastructure
+ * only; PARITY UNPINNED, see orc.h).
+ *
+ * Follows (upstream AMReX-Hydro, not in /root/reference): Godunov::ExtrapVelToFaces,
+ * ComputeAdvectiveVel, ExtrapVelToFacesOnBox, Godunov::ComputeEdgeState, PLM::PredictVelOnXFace /
+ * PredictStateOnXFace, amrex_calc_xslope_extdir (order 4), Godunov_corner_couple_*,
+ * SetTransTermXBCs / SetXEdgeBCs, HydroUtils::ComputeFluxes / ComputeDivergence /
+ * ComputeConvectiveTerm.  Reference call sites: Source/NavierStokesBase.cpp:4487-4491
+ * (ExtrapVelToFaces) and :4701-4842 (ComputeAofs: area-weighted fluxes, mult=-1,
+ * convective correction, aofs = -update).
+ *
+ * Index conventions: cell c in direction d has low face c and high face c+1.
+ */
+#include "orc_int.h"
+
+#define SMALL_VEL 1.e-8
+
+static inline double Q(const orc_fab* f, const int c[3], int n) { return A4(f, c[0], c[1], c[2], n); }
+static inline double* QP(orc_fab* f, const int c[3], int n) { return &A4(f, c[0], c[1], c[2], n); }
+static inline void shift(int o[3], const int c[3], int d, int s) { o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[d] += s; }
+
+/* limited 2nd-order slope ingredient (one cell) */
+static inline double lim2(double dlft, double drgt)
+{
+    double dcen = 0.5 * (dlft + drgt);
+    double dsgn = copysign(1.0, dcen);
+    double dlim = (dlft * drgt >= 0.0) ? 2.0 * fmin(fabs(dlft), fabs(drgt)) : 0.0;
+    return dsgn * fmin(dlim, fabs(dcen));
+}
+
+/* amrex_calc_xslope_extdir, order 4, direction dir.  edlo/edhi: ext_dir (or hoextrap) at the
+ * low/high domain face; domlo/domhi: first/last interior cell index in direction dir. */
+static double slope4_extdir(const orc_fab* q, const int c[3], int n, int dir, int edlo, int edhi, int domlo, int domhi)
+{
+    int m1[3], m2[3], p1[3], p2[3];
+    shift(m1, c, dir, -1); shift(m2, c, dir, -2); shift(p1, c, dir, 1); shift(p2, c, dir, 2);
+    const double qi = Q(q, c, n), qm = Q(q, m1, n), qp = Q(q, p1, n), qmm = Q(q, m2, n), qpp = Q(q, p2, n);
+    double dfm = lim2(qm - qmm, qi - qm);
+    double dfp = lim2(qp - qi, qpp - qp);
+    double dlft = qi - qm, drgt = qp - qi;
+    double dcen = 0.5 * (dlft + drgt);
+    double dsgn = copysign(1.0, dcen);
+    double dlim = (dlft * drgt >= 0.0) ? 2.0 * fmin(fabs(dlft), fabs(drgt)) : 0.0;
+    double dtemp = 4.0 / 3.0 * dcen - 1.0 / 6.0 * (dfp + dfm);
+    const int i = c[dir];
+    if (edlo && i == domlo) {
+        dtemp = -16. / 15. * qm + .5 * qi + 2. / 3. * qp - 0.1 * qpp;
+        dlft = 2. * (qi - qm); drgt = 2. * (qp - qi);
+        dlim = (dlft * drgt >= 0.0) ? fmin(fabs(dlft), fabs(drgt)) : 0.0;
+        dsgn = copysign(1.0, dtemp);
+    } else if (edlo && i == domlo + 1) {
+        /* slope of cell domlo recomputed with the one-sided formula */
+        dfm = -16. / 15. * qmm + .5 * qm + 2. / 3. * qi - 0.1 * qp;
+        double l = 2. * (qm - qmm), r = 2. * (qi - qm);
+        double dlimsh = (l * r >= 0.0) ? fmin(fabs(l), fabs(r)) : 0.0;
+        double dsgnsh = copysign(1.0, dfm);
+        dfm = dsgnsh * fmin(dlimsh, fabs(dfm));
+        dtemp = 4.0 / 3.0 * dcen - 1.0 / 6.0 * (dfp + dfm);
+    }
+    if (edhi && i == domhi) {
+        dtemp = 16. / 15. * qp - .5 * qi - 2. / 3. * qm + 0.1 * qmm;
+        dlft = 2. * (qi - qm); drgt = 2. * (qp - qi);
+        dlim = (dlft * drgt >= 0.0) ? fmin(fabs(dlft), fabs(drgt)) : 0.0;
+        dsgn = copysign(1.0, dtemp);
+    } else if (edhi && i == domhi - 1) {
+        dfp = 16. / 15. * qpp - .5 * qp - 2. / 3. * qi + 0.1 * qm;
+        double l = 2. * (qp - qi), r = 2. * (qpp - qp);
+        double dlimsh = (l * r >= 0.0) ? fmin(fabs(l), fabs(r)) : 0.0;
+        double dsgnsh = copysign(1.0, dfp);
+        dfp = dsgnsh * fmin(dlimsh, fabs(dfp));
+        dtemp = 4.0 / 3.0 * dcen - 1.0 / 6.0 * (dfp + dfm);
+    }
+    return dsgn * fmin(dlim, fabs(dtemp));
+}
+
+double orc_slope4(const orc_fab* q, int i, int j, int k, int n, int dir)
+{
+    int c[3] = {i, j, k};
+    return slope4_extdir(q, c, n, dir, 0, 0, 0, 0);
+}
+
+static inline int bc_is_ed_or_ho(int b) { return b == ORC_BC_EXT_DIR || b == ORC_BC_HOEXTRAP; }
+
+/* SetTransTerm{X,Y,Z}BCs: face f (index in direction d), states lo (from cell f-1) and hi (cell f) */
+static void trans_bc(const orc_fab* q, const int fidx[3], int n, int d, double* lo, double* hi,
+                     int bclo, int bchi, int domlo, int domhi, int is_velocity)
+{
+    const int f = fidx[d];
+    if (f <= domlo) {
+        if (bclo == ORC_BC_EXT_DIR) {
+            int c[3] = {fidx[0], fidx[1], fidx[2]}; c[d] = domlo - 1;
+            *lo = Q(q, c, n);
+            if (n == d && is_velocity) *hi = *lo;
+        } else if (bclo == ORC_BC_FOEXTRAP || bclo == ORC_BC_HOEXTRAP || bclo == ORC_BC_REFLECT_EVEN) {
+            *lo = *hi;
+        } else if (bclo == ORC_BC_REFLECT_ODD) {
+            *hi = 0.; *lo = 0.;
+        }
+    } else if (f > domhi) {
+        if (bchi == ORC_BC_EXT_DIR) {
+            int c[3] = {fidx[0], fidx[1], fidx[2]}; c[d] = domhi + 1;
+            *hi = Q(q, c, n);
+            if (n == d && is_velocity) *lo = *hi;
+        } else if (bchi == ORC_BC_FOEXTRAP || bchi == ORC_BC_HOEXTRAP || bchi == ORC_BC_REFLECT_EVEN) {
+            *hi = *lo;
+        } else if (bchi == ORC_BC_REFLECT_ODD) {
+            *lo = 0.; *hi = 0.;
+        }
+    }
+}
+
+/* Set{X,Y,Z}EdgeBCs: final edge states on the domain faces */
+static void edge_bc(const orc_fab* q, const int fidx[3], int n, int d, double* lo, double* hi,
+                    int bclo, int bchi, int domlo, int domhi, int is_velocity)
+{
+    const int f = fidx[d];
+    if (f <= domlo) {
+        if (bclo == ORC_BC_EXT_DIR) {
+            int c[3] = {fidx[0], fidx[1], fidx[2]}; c[d] = domlo - 1;
+            *lo = Q(q, c, n);
+            if (n == d && is_velocity) *hi = *lo;
+        } else if (bclo == ORC_BC_FOEXTRAP || bclo == ORC_BC_HOEXTRAP || bclo == ORC_BC_REFLECT_EVEN) {
+            if (n == d && is_velocity && bclo != ORC_BC_REFLECT_EVEN) *hi = fmin(*hi, 0.);
+            *lo = *hi;
+        } else if (bclo == ORC_BC_REFLECT_ODD) {
+            *hi = 0.; *lo = 0.;
+        }
+    } else if (f > domhi) {
+        if (bchi == ORC_BC_EXT_DIR) {
+            int c[3] = {fidx[0], fidx[1], fidx[2]}; c[d] = domhi + 1;
+            *hi = Q(q, c, n);
+            if (n == d && is_velocity) *lo = *hi;
+        } else if (bchi == ORC_BC_FOEXTRAP || bchi == ORC_BC_HOEXTRAP || bchi == ORC_BC_REFLECT_EVEN) {
+            if (n == d && is_velocity && bchi != ORC_BC_REFLECT_EVEN) *lo = fmax(*lo, 0.);
+            *hi = *lo;
+        } else if (bchi == ORC_BC_REFLECT_ODD) {
+            *lo = 0.; *hi = 0.;
+        }
+    }
+}
+
+/* face-array allocation: faces of direction d over cells grown by gt in the transverse directions */
+static orc_fab alloc_faces(const orc_geom* g, int d, int gt, int nc)
+{
+    orc_fab f;
+    for (int e = 0; e < 3; ++e) { f.lo[e] = (e == d) ? 0 : -gt; f.hi[e] = (e == d) ? g->n[e] : g->n[e] - 1 + gt; }
+    f.nc = nc;
+    f.p = (double*)calloc(orc_npts(&f) * (size_t)nc, sizeof(double));
+    return f;
+}
+
+#define LOOP3(f, c) for (c[2] = (f)->lo[2]; c[2] <= (f)->hi[2]; ++c[2]) for (c[1] = (f)->lo[1]; c[1] <= (f)->hi[1]; ++c[1]) for (c[0] = (f)->lo[0]; c[0] <= (f)->hi[0]; ++c[0])
+
+/* PLM trace: Im[d](c) = state at the low face of cell c, Ip[d](c) = state at the high face of cell c.
+ * trace velocity: cell-centred vcc(c, d) (predict) or face-centred umac (advect, both sides use the
+ * face's own umac -- handled by the caller passing a per-face functor is avoided by splitting). */
+static void plm_predict_vel(const orc_geom* g, const orc_fab* q, int ncomp, const orc_fab* vcc,
+                            orc_fab Im[3], orc_fab Ip[3], double dt, const orc_bcrec* bc)
+{
+    for (int d = 0; d < 3; ++d) {
+        const double dtdx = dt / g->dx[d];
+        int c[3];
+        for (int n = 0; n < ncomp; ++n) {
+            const int edlo = !g->periodic[d] && bc_is_ed_or_ho(bc[n].lo[d]);
+            const int edhi = !g->periodic[d] && bc_is_ed_or_ho(bc[n].hi[d]);
+            LOOP3(&Im[d], c) {
+                double sl = slope4_extdir(q, c, n, d, edlo, edhi, 0, g->n[d] - 1);
+                double u = Q(vcc, c, d);
+                *QP(&Im[d], c, n) = Q(q, c, n) + 0.5 * (-1.0 - u * dtdx) * sl;
+                *QP(&Ip[d], c, n) = Q(q, c, n) + 0.5 * (1.0 - u * dtdx) * sl;
+            }
+        }
+    }
+}
+
+void orc_extrap_vel_to_faces(const orc_geom* g, const orc_fab* vel, const orc_fab* force, orc_fab* umac[3],
+                             double dt, const orc_bcrec* bc, int use_forces_in_trans)
+{
+    const int ncomp = 3;
+    orc_fab Im[3], Ip[3], ad[3], lo_[3], hi_[3], edge[3];
+    for (int d = 0; d < 3; ++d) {
+        Im[d] = orc_alloc(g->n, ORC_CELL, 1, ncomp);
+        Ip[d] = orc_alloc(g->n, ORC_CELL, 1, ncomp);
+        ad[d] = alloc_faces(g, d, 1, 1);
+        lo_[d] = alloc_faces(g, d, 1, ncomp);
+        hi_[d] = alloc_faces(g, d, 1, ncomp);
+        edge[d] = alloc_faces(g, d, 1, ncomp);
+    }
+    plm_predict_vel(g, vel, ncomp, vel, Im, Ip, dt, bc);
+
+    /* ComputeAdvectiveVel: normal component only */
+    for (int d = 0; d < 3; ++d) {
+        int f[3];
+        LOOP3(&ad[d], f) {
+            int cm[3]; shift(cm, f, d, -1);
+            double lo = Q(&Ip[d], cm, d), hi = Q(&Im[d], f, d);
+            if (use_forces_in_trans && force) { lo += 0.5 * dt * Q(force, cm, d); hi += 0.5 * dt * Q(force, f, d); }
+            if (!g->periodic[d]) trans_bc(vel, f, d, d, &lo, &hi, bc[d].lo[d], bc[d].hi[d], 0, g->n[d] - 1, 1);
+            double st = ((lo + hi) >= 0.) ? lo : hi;
+            int ltm = ((lo <= 0. && hi >= 0.) || (fabs(lo + hi) < SMALL_VEL));
+            *QP(&ad[d], f, 0) = ltm ? 0. : st;
+        }
+    }
+    /* upwind every component with the advective velocity */
+    for (int d = 0; d < 3; ++d) {
+        int f[3];
+        for (int n = 0; n < ncomp; ++n)
+        LOOP3(&edge[d], f) {
+            int cm[3]; shift(cm, f, d, -1);
+            double lo = Q(&Ip[d], cm, n), hi = Q(&Im[d], f, n);
+            if (use_forces_in_trans && force) { lo += 0.5 * dt * Q(force, cm, n); hi += 0.5 * dt * Q(force, f, n); }
+            double uad = Q(&ad[d], f, 0);
+            if (!g->periodic[d]) trans_bc(vel, f, n, d, &lo, &hi, bc[n].lo[d], bc[n].hi[d], 0, g->n[d] - 1, 1);
+            *QP(&lo_[d], f, n) = lo; *QP(&hi_[d], f, n) = hi;
+            double st = (uad >= 0.) ? lo : hi;
+            double fu = (fabs(uad) < SMALL_VEL) ? 0.0 : 1.0;
+            *QP(&edge[d], f, n) = fu * st + (1.0 - fu) * 0.5 * (hi + lo);
+        }
+    }
+    /* final states: for normal direction d, component n = d */
+    for (int d = 0; d < 3; ++d) {
+        const int n = d;
+        /* T[t]: state on t-faces corrected with the derivative in the other transverse direction o */
+        orc_fab T[3];
+        for (int t = 0; t < 3; ++t) {
+            if (t == d) { T[t].p = NULL; continue; }
+            const int o = 3 - d - t;
+            /* t-faces over cells: grown 1 in d, 0 in o */
+            orc_fab* Tt = &T[t];
+            for (int e = 0; e < 3; ++e) {
+                if (e == t) { Tt->lo[e] = 0; Tt->hi[e] = g->n[e]; }
+                else if (e == d) { Tt->lo[e] = -1; Tt->hi[e] = g->n[e]; }
+                else { Tt->lo[e] = 0; Tt->hi[e] = g->n[e] - 1; }
+            }
+            Tt->nc = 1;
+            Tt->p = (double*)calloc(orc_npts(Tt), sizeof(double));
+            int f[3];
+            LOOP3(Tt, f) {
+                int cm[3]; shift(cm, f, t, -1);       /* cell on the low side of the t-face */
+                int cmo[3], fo[3];
+                shift(cmo, cm, o, 1); shift(fo, f, o, 1);
+                /* Godunov_corner_couple (non-conservative form) */
+                double l = Q(&lo_[t], f, n) - dt / (6.0 * g->dx[o]) * (Q(&ad[o], cmo, 0) + Q(&ad[o], cm, 0)) * (Q(&edge[o], cmo, n) - Q(&edge[o], cm, n));
+                double h = Q(&hi_[t], f, n) - dt / (6.0 * g->dx[o]) * (Q(&ad[o], fo, 0) + Q(&ad[o], f, 0)) * (Q(&edge[o], fo, n) - Q(&edge[o], f, n));
+                double tad = Q(&ad[t], f, 0);
+                if (!g->periodic[t]) trans_bc(vel, f, n, t, &l, &h, bc[n].lo[t], bc[n].hi[t], 0, g->n[t] - 1, 1);
+                double st = (tad >= 0.) ? l : h;
+                double fu = (fabs(tad) < SMALL_VEL) ? 0.0 : 1.0;
+                *QP(Tt, f, 0) = fu * st + (1.0 - fu) * 0.5 * (h + l);
+            }
+        }
+        int f[3];
+        for (f[2] = 0; f[2] <= g->n[2] - 1 + (d == 2); ++f[2])
+        for (f[1] = 0; f[1] <= g->n[1] - 1 + (d == 1); ++f[1])
+        for (f[0] = 0; f[0] <= g->n[0] - 1 + (d == 0); ++f[0]) {
+            int cm[3]; shift(cm, f, d, -1);
+            double stl = Q(&lo_[d], f, n), sth = Q(&hi_[d], f, n);
+            for (int t = 0; t < 3; ++t) {
+                if (t == d) continue;
+                int cmt[3], ft[3];
+                shift(cmt, cm, t, 1); shift(ft, f, t, 1);
+                stl -= (0.25 * dt / g->dx[t]) * (Q(&ad[t], cmt, 0) + Q(&ad[t], cm, 0)) * (Q(&T[t], cmt, 0) - Q(&T[t], cm, 0));
+                sth -= (0.25 * dt / g->dx[t]) * (Q(&ad[t], ft, 0) + Q(&ad[t], f, 0)) * (Q(&T[t], ft, 0) - Q(&T[t], f, 0));
+            }
+            if (!use_forces_in_trans && force) { stl += 0.5 * dt * Q(force, cm, n); sth += 0.5 * dt * Q(force, f, n); }
+            if (!g->periodic[d]) edge_bc(vel, f, n, d, &stl, &sth, bc[n].lo[d], bc[n].hi[d], 0, g->n[d] - 1, 1);
+            double st = ((stl + sth) >= 0.) ? stl : sth;
+            int ltm = ((stl <= 0. && sth >= 0.) || (fabs(stl + sth) < SMALL_VEL));
+            *QP(umac[d], f, 0) = ltm ? 0. : st;
+        }
+        for (int t = 0; t < 3; ++t) if (T[t].p) orc_free(&T[t]);
+    }
+    for (int d = 0; d < 3; ++d) { orc_free(&Im[d]); orc_free(&Ip[d]); orc_free(&ad[d]); orc_free(&lo_[d]); orc_free(&hi_[d]); orc_free(&edge[d]); }
+}
+
+/* Godunov::ComputeEdgeState (PLM) */
+static void compute_edge_state(const orc_geom* g, const orc_fab* q, int ncomp, const orc_fab* fq, const orc_fab* divu,
+                               orc_fab* const umac[3], const int* iconserv, double dt, const orc_bcrec* bc,
+                               int is_velocity, int use_forces_in_trans, orc_fab edge_out[3])
+{
+    orc_fab Im[3], Ip[3], lo_[3], hi_[3], edge[3];
+    for (int d = 0; d < 3; ++d) {
+        Im[d] = orc_alloc(g->n, ORC_CELL, 1, ncomp);
+        Ip[d] = orc_alloc(g->n, ORC_CELL, 1, ncomp);
+        lo_[d] = alloc_faces(g, d, 1, ncomp);
+        hi_[d] = alloc_faces(g, d, 1, ncomp);
+        edge[d] = alloc_faces(g, d, 1, ncomp);
+    }
+    /* PLM::PredictStateOnXFace: both sides of a face are traced with that face's umac */
+    for (int d = 0; d < 3; ++d) {
+        const double dtdx = dt / g->dx[d];
+        int f[3];
+        for (int n = 0; n < ncomp; ++n) {
+            const int edlo = !g->periodic[d] && bc_is_ed_or_ho(bc[n].lo[d]);
+            const int edhi = !g->periodic[d] && bc_is_ed_or_ho(bc[n].hi[d]);
+            LOOP3(&edge[d], f) {
+                int cm[3]; shift(cm, f, d, -1);
+                double um = Q(umac[d], f, 0);
+                double upls = Q(q, f, n) + 0.5 * (-1.0 - um * dtdx) * slope4_extdir(q, f, n, d, edlo, edhi, 0, g->n[d] - 1);
+                double umns = Q(q, cm, n) + 0.5 * (1.0 - um * dtdx) * slope4_extdir(q, cm, n, d, edlo, edhi, 0, g->n[d] - 1);
+                *QP(&Ip[d], cm, n) = umns;
+                *QP(&Im[d], f, n) = upls;
+            }
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        int f[3];
+        for (int n = 0; n < ncomp; ++n)
+        LOOP3(&edge[d], f) {
+            int cm[3]; shift(cm, f, d, -1);
+            double uad = Q(umac[d], f, 0);
+            double fux = (fabs(uad) < SMALL_VEL) ? 0. : 1.;
+            int uval = uad >= 0.;
+            double lo = Q(&Ip[d], cm, n), hi = Q(&Im[d], f, n);
+            if (use_forces_in_trans && fq) { lo += 0.5 * dt * Q(fq, cm, n); hi += 0.5 * dt * Q(fq, f, n); }
+            if (!g->periodic[d]) trans_bc(q, f, n, d, &lo, &hi, bc[n].lo[d], bc[n].hi[d], 0, g->n[d] - 1, is_velocity);
+            *QP(&lo_[d], f, n) = lo; *QP(&hi_[d], f, n) = hi;
+            double st = uval ? lo : hi;
+            *QP(&edge[d], f, n) = fux * st + (1. - fux) * 0.5 * (hi + lo);
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        orc_fab T[3];
+        for (int t = 0; t < 3; ++t) {
+            if (t == d) { T[t].p = NULL; continue; }
+            const int o = 3 - d - t;
+            orc_fab* Tt = &T[t];
+            for (int e = 0; e < 3; ++e) {
+                if (e == t) { Tt->lo[e] = 0; Tt->hi[e] = g->n[e]; }
+                else if (e == d) { Tt->lo[e] = -1; Tt->hi[e] = g->n[e]; }
+                else { Tt->lo[e] = 0; Tt->hi[e] = g->n[e] - 1; }
+            }
+            Tt->nc = ncomp;
+            Tt->p = (double*)calloc(orc_npts(Tt) * (size_t)ncomp, sizeof(double));
+            int f[3];
+            for (int n = 0; n < ncomp; ++n)
+            LOOP3(Tt, f) {
+                int cm[3]; shift(cm, f, t, -1);
+                int cmo[3], fo[3];
+                shift(cmo, cm, o, 1); shift(fo, f, o, 1);
+                double l, h;
+                if (iconserv[n]) {
+                    double dvl = divu ? Q(divu, cm, 0) : 0.0, dvh = divu ? Q(divu, f, 0) : 0.0;
+                    l = Q(&lo_[t], f, n) - dt / (3.0 * g->dx[o]) * (Q(&edge[o], cmo, n) * Q(umac[o], cmo, 0) - Q(&edge[o], cm, n) * Q(umac[o], cm, 0))
+                        + dt / 3.0 * Q(q, cm, n) * ((Q(umac[o], cmo, 0) - Q(umac[o], cm, 0)) / g->dx[o] - 0.5 * dvl);
+                    h = Q(&hi_[t], f, n) - dt / (3.0 * g->dx[o]) * (Q(&edge[o], fo, n) * Q(umac[o], fo, 0) - Q(&edge[o], f, n) * Q(umac[o], f, 0))
+                        + dt / 3.0 * Q(q, f, n) * ((Q(umac[o], fo, 0) - Q(umac[o], f, 0)) / g->dx[o] - 0.5 * dvh);
+                } else {
+                    l = Q(&lo_[t], f, n) - dt / (6.0 * g->dx[o]) * (Q(umac[o], cmo, 0) + Q(umac[o], cm, 0)) * (Q(&edge[o], cmo, n) - Q(&edge[o], cm, n));
+                    h = Q(&hi_[t], f, n) - dt / (6.0 * g->dx[o]) * (Q(umac[o], fo, 0) + Q(umac[o], f, 0)) * (Q(&edge[o], fo, n) - Q(&edge[o], f, n));
+                }
+                double tad = Q(umac[t], f, 0);
+                if (!g->periodic[t]) trans_bc(q, f, n, t, &l, &h, bc[n].lo[t], bc[n].hi[t], 0, g->n[t] - 1, is_velocity);
+                double st = (tad >= 0.) ? l : h;
+                double fu = (fabs(tad) < SMALL_VEL) ? 0.0 : 1.0;
+                *QP(Tt, f, n) = fu * st + (1.0 - fu) * 0.5 * (h + l);
+            }
+        }
+        int f[3];
+        for (int n = 0; n < ncomp; ++n)
+        for (f[2] = 0; f[2] <= g->n[2] - 1 + (d == 2); ++f[2])
+        for (f[1] = 0; f[1] <= g->n[1] - 1 + (d == 1); ++f[1])
+        for (f[0] = 0; f[0] <= g->n[0] - 1 + (d == 0); ++f[0]) {
+            int cm[3]; shift(cm, f, d, -1);
+            double stl = Q(&lo_[d], f, n), sth = Q(&hi_[d], f, n);
+            if (iconserv[n]) {
+                for (int t = 0; t < 3; ++t) {
+                    if (t == d) continue;
+                    int cmt[3], ft[3];
+                    shift(cmt, cm, t, 1); shift(ft, f, t, 1);
+                    stl += -(0.5 * dt / g->dx[t]) * (Q(&T[t], cmt, n) * Q(umac[t], cmt, 0) - Q(&T[t], cm, n) * Q(umac[t], cm, 0));
+                    sth += -(0.5 * dt / g->dx[t]) * (Q(&T[t], ft, n) * Q(umac[t], ft, 0) - Q(&T[t], f, n) * Q(umac[t], f, 0));
+                }
+                for (int t = 0; t < 3; ++t) {
+                    if (t == d) continue;
+                    int cmt[3], ft[3];
+                    shift(cmt, cm, t, 1); shift(ft, f, t, 1);
+                    stl += (0.5 * dt / g->dx[t]) * Q(q, cm, n) * (Q(umac[t], cmt, 0) - Q(umac[t], cm, 0));
+                    sth += (0.5 * dt / g->dx[t]) * Q(q, f, n) * (Q(umac[t], ft, 0) - Q(umac[t], f, 0));
+                }
+                if (divu) { stl -= 0.5 * dt * Q(q, cm, n) * Q(divu, cm, 0); sth -= 0.5 * dt * Q(q, f, n) * Q(divu, f, 0); }
+            } else {
+                for (int t = 0; t < 3; ++t) {
+                    if (t == d) continue;
+                    int cmt[3], ft[3];
+                    shift(cmt, cm, t, 1); shift(ft, f, t, 1);
+                    stl -= (0.25 * dt / g->dx[t]) * (Q(umac[t], cmt, 0) + Q(umac[t], cm, 0)) * (Q(&T[t], cmt, n) - Q(&T[t], cm, n));
+                    sth -= (0.25 * dt / g->dx[t]) * (Q(umac[t], ft, 0) + Q(umac[t], f, 0)) * (Q(&T[t], ft, n) - Q(&T[t], f, n));
+                }
+            }
+            if (!use_forces_in_trans && fq) { stl += 0.5 * dt * Q(fq, cm, n); sth += 0.5 * dt * Q(fq, f, n); }
+            if (!g->periodic[d]) edge_bc(q, f, n, d, &stl, &sth, bc[n].lo[d], bc[n].hi[d], 0, g->n[d] - 1, is_velocity);
+            double um = Q(umac[d], f, 0);
+            double temp = (um >= 0.) ? stl : sth;
+            temp = (fabs(um) < SMALL_VEL) ? 0.5 * (stl + sth) : temp;
+            *QP(&edge_out[d], f, n) = temp;
+        }
+        for (int t = 0; t < 3; ++t) if (T[t].p) orc_free(&T[t]);
+    }
+    for (int d = 0; d < 3; ++d) { orc_free(&Im[d]); orc_free(&Ip[d]); orc_free(&lo_[d]); orc_free(&hi_[d]); orc_free(&edge[d]); }
+}
+
+void orc_compute_aofs(const orc_geom* g, orc_fab* aofs, int acomp, const orc_fab* S, int ncomp,
+                      const orc_fab* force, const orc_fab* divu, orc_fab* const umac[3], const int* iconserv,
+                      double dt, const orc_bcrec* bc, int is_velocity, int use_forces_in_trans,
+                      orc_fab* edge_out[3], orc_fab* flux_out[3])
+{
+    orc_fab edge[3], flux[3];
+    for (int d = 0; d < 3; ++d) { edge[d] = alloc_faces(g, d, 0, ncomp); flux[d] = alloc_faces(g, d, 0, ncomp); }
+    compute_edge_state(g, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edge);
+    /* ComputeFluxes, area-weighted (NavierStokesBase.cpp:4651) */
+    for (int d = 0; d < 3; ++d) {
+        const double area = g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
+        int f[3];
+        for (int n = 0; n < ncomp; ++n)
+        LOOP3(&flux[d], f) *QP(&flux[d], f, n) = Q(&edge[d], f, n) * Q(umac[d], f, 0) * area;
+    }
+    const double qvol = 1.0 / (g->dx[0] * g->dx[1] * g->dx[2]);
+    int any_convective = 0;
+    for (int n = 0; n < ncomp; ++n) if (!iconserv[n]) any_convective = 1;
+    for (int n = 0; n < ncomp; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        /* ComputeDivergence with mult = -1 */
+        double upd = -1.0 * qvol * ((A4(&flux[0], i + 1, j, k, n) - A4(&flux[0], i, j, k, n))
+                                  + (A4(&flux[1], i, j + 1, k, n) - A4(&flux[1], i, j, k, n))
+                                  + (A4(&flux[2], i, j, k + 1, n) - A4(&flux[2], i, j, k, n)));
+        if (any_convective && !iconserv[n]) {
+            double divum = 1.0 * ((A4(umac[0], i + 1, j, k, 0) - A4(umac[0], i, j, k, 0)) / g->dx[0]
+                                + (A4(umac[1], i, j + 1, k, 0) - A4(umac[1], i, j, k, 0)) / g->dx[1]
+                                + (A4(umac[2], i, j, k + 1, 0) - A4(umac[2], i, j, k, 0)) / g->dx[2]);
+            double qavg = A4(&edge[0], i, j, k, n) + A4(&edge[0], i + 1, j, k, n)
+                        + A4(&edge[1], i, j, k, n) + A4(&edge[1], i, j + 1, k, n)
+                        + A4(&edge[2], i, j, k, n) + A4(&edge[2], i, j, k + 1, n);
+            qavg *= 1.0 / 6.0;
+            upd += qavg * divum;
+        }
+        A4(aofs, i, j, k, acomp + n) = -upd;
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (edge_out && edge_out[d]) memcpy(edge_out[d]->p, edge[d].p, orc_npts(&edge[d]) * ncomp * sizeof(double));
+        if (flux_out && flux_out[d]) memcpy(flux_out[d]->p, flux[d].p, orc_npts(&flux[d]) * ncomp * sizeof(double));
+        orc_free(&edge[d]); orc_free(&flux[d]);
+    }
+}

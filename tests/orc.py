@@ -1,0 +1,195 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so) for the test-suite.
+
+Test infrastructure only: nothing under iamr_amd/ imports this module.
+Arrays use the AMReX Array4 layout (i fastest, component slowest): a numpy array of shape
+(nx, ny, nz, nc) in Fortran order.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORC_DIR], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORC_DIR, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _declare(_LIB)
+    return _LIB
+
+
+class CFab(C.Structure):
+    _fields_ = [("p", C.POINTER(C.c_double)), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("nc", C.c_int)]
+
+
+class CGeom(C.Structure):
+    _fields_ = [("n", C.c_int * 3), ("dx", C.c_double * 3), ("problo", C.c_double * 3), ("periodic", C.c_int * 3)]
+
+
+class CBCRec(C.Structure):
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
+
+
+class CAbecLevel(C.Structure):
+    _fields_ = [("g", CGeom), ("alpha", C.c_double), ("beta", C.c_double), ("a", CFab), ("b", CFab * 3),
+                ("ncomp", C.c_int), ("tensor", C.c_int)]
+
+
+class CMgStats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("resnorm0", C.c_double), ("rhsnorm0", C.c_double), ("resnorm", C.c_double),
+                ("bottom_iters_total", C.c_int), ("converged", C.c_int)]
+
+
+class CMgOpts(C.Structure):
+    _fields_ = [("nu1", C.c_int), ("nu2", C.c_int), ("nuf", C.c_int), ("nub", C.c_int), ("max_iters", C.c_int),
+                ("bottom_maxiter", C.c_int), ("bottom_reltol", C.c_double), ("omega", C.c_double),
+                ("maxorder", C.c_int), ("max_coarsening_level", C.c_int), ("min_width", C.c_int),
+                ("nodal_sweeps", C.c_int), ("nodal_smoother", C.c_int), ("verbose", C.c_int),
+                ("bottom_smoother_only", C.c_int), ("fixed_iters", C.c_int)]
+
+
+class CNsParams(C.Structure):
+    _fields_ = [("cfl", C.c_double), ("visc_coef", C.c_double), ("be_cn_theta", C.c_double), ("gravity", C.c_double),
+                ("mac_tol", C.c_double), ("mac_abs_tol", C.c_double), ("proj_tol", C.c_double),
+                ("proj_abs_tol", C.c_double), ("visc_tol", C.c_double),
+                ("use_forces_in_trans", C.c_int), ("do_mom_diff", C.c_int), ("init_iter", C.c_int),
+                ("init_vel_iter", C.c_int), ("init_shrink", C.c_double), ("change_max", C.c_double),
+                ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int)]
+
+
+PF = C.POINTER(CFab)
+
+
+def _declare(L):
+    L.orc_slope4.restype = C.c_double
+    if hasattr(L, "orc_ns_create"):
+        L.orc_ns_create.restype = C.c_void_p
+        L.orc_ns_fab.restype = PF
+        L.orc_ns_step.restype = C.c_double
+        L.orc_ns_time.restype = C.c_double
+        L.orc_ns_dt.restype = C.c_double
+
+
+CELL = (0, 0, 0)
+NODE = (1, 1, 1)
+
+
+def face(d):
+    t = [0, 0, 0]
+    t[d] = 1
+    return tuple(t)
+
+
+class Fab:
+    """numpy-backed array on cells [0,n-1] converted to `typ` and grown by ng."""
+
+    def __init__(self, n, typ=CELL, ng=0, nc=1, fill=0.0, lo=None, hi=None):
+        if lo is None:
+            lo = [-ng] * 3
+            hi = [n[d] - 1 + typ[d] + ng for d in range(3)]
+        self.lo = list(lo)
+        self.hi = list(hi)
+        self.nc = nc
+        shape = tuple(self.hi[d] - self.lo[d] + 1 for d in range(3)) + (nc,)
+        self.a = np.full(shape, fill, dtype=np.float64, order="F")
+
+    @property
+    def c(self):
+        f = CFab()
+        f.p = self.a.ctypes.data_as(C.POINTER(C.c_double))
+        f.lo = (C.c_int * 3)(*self.lo)
+        f.hi = (C.c_int * 3)(*self.hi)
+        f.nc = self.nc
+        self._c = f
+        return f
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def valid(self, n, typ=CELL):
+        """view of the valid region (cells [0,n-1] converted to typ)"""
+        sl = tuple(slice(-self.lo[d], -self.lo[d] + n[d] + typ[d]) for d in range(3))
+        return self.a[sl]
+
+    def copy(self):
+        g = Fab.__new__(Fab)
+        g.lo, g.hi, g.nc = list(self.lo), list(self.hi), self.nc
+        g.a = self.a.copy(order="F")
+        return g
+
+
+def from_cfab(pf):
+    """numpy view (no copy) of a CFab owned by the oracle"""
+    f = pf.contents
+    shape = tuple(f.hi[d] - f.lo[d] + 1 for d in range(3)) + (f.nc,)
+    size = int(np.prod(shape))
+    arr = np.ctypeslib.as_array(f.p, shape=(size,)).reshape(shape, order="F")
+    out = Fab.__new__(Fab)
+    out.lo, out.hi, out.nc = list(f.lo), list(f.hi), f.nc
+    out.a = arr
+    return out
+
+
+def geom(n, problo=(0.0, 0.0, 0.0), probhi=(1.0, 1.0, 1.0), periodic=(1, 1, 1)):
+    g = CGeom()
+    g.n = (C.c_int * 3)(*n)
+    g.dx = (C.c_double * 3)(*[(probhi[d] - problo[d]) / n[d] for d in range(3)])
+    g.problo = (C.c_double * 3)(*problo)
+    g.periodic = (C.c_int * 3)(*periodic)
+    return g
+
+
+def mg_opts(**kw):
+    o = CMgOpts()
+    lib().orc_mg_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def bcrecs(ncomp, lo=(0, 0, 0), hi=(0, 0, 0)):
+    arr = (CBCRec * ncomp)()
+    for n in range(ncomp):
+        arr[n].lo = (C.c_int * 3)(*lo)
+        arr[n].hi = (C.c_int * 3)(*hi)
+    return arr
+
+
+def i3(v):
+    return (C.c_int * 3)(*v)
+
+
+def fabptrs(fabs):
+    arr = (PF * 3)()
+    keep = []
+    for d in range(3):
+        cf = fabs[d].c
+        keep.append(cf)
+        arr[d] = C.pointer(cf)
+    arr._keep = keep
+    return arr
+
+
+def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0):
+    L = CAbecLevel()
+    L.g = g
+    L.alpha = alpha
+    L.beta = beta
+    if a is not None:
+        L.a = a.c
+    for d in range(3):
+        L.b[d] = b[d].c
+    L.ncomp = ncomp
+    L.tensor = tensor
+    return L
