@@ -4,6 +4,7 @@
 #include "operators.h"
 #include <string>
 #include <cstring>
+#include <vector>
 
 using namespace iamrx;
 
@@ -217,6 +218,38 @@ int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf ux, iamrx_m
     IAMRX_TRY
     const MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
     mac_divergence(to_geom(g), div->mf, um);
+    IAMRX_CATCH
+}
+
+static std::vector<BCRec> to_bcrec(const int* b, int n)
+{
+    std::vector<BCRec> r(n);
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) { r[i].lo[d] = b ? b[6 * i + d] : 0; r[i].hi[d] = b ? b[6 * i + 3 + d] : 0; }
+    return r;
+}
+
+int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz,
+                                      double dt, const int* bcrec, int fit)
+{
+    IAMRX_TRY
+    auto bc = to_bcrec(bcrec, 3);
+    MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
+    godunov_extrap_vel_to_faces(to_geom(g), vel->mf, force ? &force->mf : nullptr, um, dt, bc.data(), fit != 0);
+    IAMRX_CATCH
+}
+
+int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
+                               iamrx_mf ux, iamrx_mf uy, iamrx_mf uz, const int* iconserv, double dt, const int* bcrec,
+                               int is_velocity, int fit, iamrx_mf ex, iamrx_mf ey, iamrx_mf ez, iamrx_mf fx, iamrx_mf fy, iamrx_mf fz)
+{
+    IAMRX_TRY
+    auto bc = to_bcrec(bcrec, ncomp);
+    MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
+    MultiFab* ed[3] = {ex ? &ex->mf : nullptr, ey ? &ey->mf : nullptr, ez ? &ez->mf : nullptr};
+    MultiFab* fl[3] = {fx ? &fx->mf : nullptr, fy ? &fy->mf : nullptr, fz ? &fz->mf : nullptr};
+    godunov_compute_aofs(to_geom(g), aofs->mf, acomp, S->mf, ncomp, force ? &force->mf : nullptr, divu ? &divu->mf : nullptr, um,
+                         iconserv, dt, bc.data(), is_velocity != 0, fit != 0, ex ? ed : nullptr, fx ? fl : nullptr);
     IAMRX_CATCH
 }
 

@@ -44,6 +44,16 @@ void mac_rhs(const Geometry& g, MultiFab& rhs, const MultiFab* const umac[3], co
 void mac_bcoef(MultiFab* const b[3], const MultiFab& rho, int rho_comp, double scale);                 // b = scale / avg_face(rho)
 void mac_divergence(const Geometry& g, MultiFab& div, const MultiFab* const umac[3]);
 
+// ---- k_godunov.hip ------------------------------------------------------------------------
+// Godunov::ExtrapVelToFaces (PLM): vel has >=3 comps and >=3 filled ghost cells, force 3 comps >=1 ghost
+void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
+                                 double dt, const BCRec* bc, bool use_forces_in_trans);
+// ComputeFluxesOnBoxFromState + ComputeDivergence(-1) + ComputeConvectiveTerm, aofs(acomp..) = -update.
+// S: ncomp comps, >=3 ghosts; umac: >=1 ghost (filled); force/divu: >=1 ghost or null
+void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
+                          const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
+                          bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3]);
+
 // ---- k_tensor.hip -------------------------------------------------------------------------
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);

@@ -108,6 +108,21 @@ int iamrx_mlmg_mac_solve(const iamrx_geom* g, iamrx_mf umac_x, iamrx_mf umac_y, 
 /* MacProj::check_div_cond (Source/MacProj.cpp:792-846): div = div(u_mac) */
 int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z);
 
+/* ---- Godunov advection ---------------------------------------------------------------- */
+/* bcrec: 6 ints per component (lo[3], hi[3]) = amrex::BCRec mathematical BC codes
+ * (reference Source/NS_BC.H:7-55). */
+/* Godunov::ExtrapVelToFaces as called from NavierStokesBase::predict_velocity
+ * (Source/NavierStokesBase.cpp:4487-4491): vel (3 comps, 3 filled ghosts), force (3 comps, 1 ghost) -> u_mac */
+int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf umac_x, iamrx_mf umac_y,
+                                      iamrx_mf umac_z, double dt, const int* bcrec /* [3][6] */, int use_forces_in_trans);
+/* the kernel chain of NavierStokesBase::ComputeAofs (Source/NavierStokesBase.cpp:4594-4845):
+ * ComputeFluxesOnBoxFromState("Godunov") + ComputeDivergence(mult=-1, area weighted) + ComputeConvectiveTerm,
+ * aofs(acomp+n) = -update.  edge_* / flux_* (ncomp face comps) are optional outputs (NULL to skip). */
+int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
+                               iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, const int* iconserv, double dt,
+                               const int* bcrec /* [ncomp][6] */, int is_velocity, int use_forces_in_trans,
+                               iamrx_mf edge_x, iamrx_mf edge_y, iamrx_mf edge_z, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
+
 #ifdef __cplusplus
 }
 #endif

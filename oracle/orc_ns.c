@@ -1,0 +1,578 @@
+/* oracle/orc_ns.c -- single-level NavierStokes::advance + initialisation sequence restated on the CPU
+ * (test infrastructure only; PARITY UNPINNED for the upstream kernels, see orc.h).
+ *
+ * Follows the IN-TREE orchestration line by line:
+ *   NavierStokes::advance                  Source/NavierStokes.cpp:543-691
+ *   NSB::advance_setup                     Source/NavierStokesBase.cpp:613-741
+ *   NSB::predict_velocity                  Source/NavierStokesBase.cpp:4376-4512
+ *   NSB::mac_project / MacProj::mac_project Source/NavierStokesBase.cpp:2070-2109, Source/MacProj.cpp:225-353
+ *   NSB::velocity_advection                Source/NavierStokesBase.cpp:3358-3470
+ *   NavierStokes::scalar_advection         Source/NavierStokes.cpp:698-812
+ *   NSB::scalar_advection_update           Source/NavierStokesBase.cpp:2730-2972
+ *   NSB::velocity_advection_update         Source/NavierStokesBase.cpp:3523-3655
+ *   NSB::initial_velocity_diffusion_update Source/NavierStokesBase.cpp:3658-3749
+ *   Diffusion::diffuse_tensor_velocity     Source/Diffusion.cpp:650-957
+ *   Diffusion::getTensorViscTerms          Source/Diffusion.cpp:1655-1777
+ *   Projection::level_project              Source/Projection.cpp:166-450
+ *   Projection::initialVelocityProject     Source/Projection.cpp:615-838
+ *   Projection::initialSyncProject         Source/Projection.cpp:970-1185
+ *   NavierStokes::post_init / post_init_press Source/NavierStokes.cpp:1254-1432
+ *   NSB::estTimeStep / computeNewDt        Source/NavierStokesBase.cpp:1353-1510, 945-1035
+ * Scope: one level, periodic or wall BCs handled by the kernels, constant viscosity, no divu,
+ * NUM_STATE = 5 (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
+ */
+#include "orc_int.h"
+
+enum { Xvel = 0, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
+
+struct orc_ns_state {
+    orc_geom g;
+    orc_ns_params p;
+    orc_mg_opts o;
+    orc_fab S[2];      /* [new, old] swapped by index */
+    orc_fab P[2];
+    orc_fab Gp[2];
+    int inew;          /* index of "new" for S */
+    int pnew;          /* index of "new" for P/Gp */
+    orc_fab umac[3];
+    orc_fab aofs;
+    orc_fab rho_ptime, rho_ctime, rho_half;
+    double time, dt, dt_min_adv;
+    int nstep;
+    int initial_step, initial_iter;
+    orc_mg_stats st_mac, st_nodal, st_visc;
+    int lobc[3], hibc[3];
+    orc_bcrec bc_vel[3], bc_scal[2];
+};
+
+#define S_NEW(s) (&(s)->S[(s)->inew])
+#define S_OLD(s) (&(s)->S[1 - (s)->inew])
+#define P_NEW(s) (&(s)->P[(s)->pnew])
+#define P_OLD(s) (&(s)->P[1 - (s)->pnew])
+#define GP_NEW(s) (&(s)->Gp[(s)->pnew])
+#define GP_OLD(s) (&(s)->Gp[1 - (s)->pnew])
+
+void orc_ns_default_params(orc_ns_params* p)
+{
+    p->cfl = 0.8; p->visc_coef = 0.0; p->be_cn_theta = 0.5; p->gravity = 0.0;
+    p->mac_tol = 1.e-12; p->mac_abs_tol = 1.e-16; p->proj_tol = 1.e-12; p->proj_abs_tol = 1.e-16; p->visc_tol = 1.e-10;
+    p->use_forces_in_trans = 0; p->do_mom_diff = 0; p->init_iter = 2; p->init_vel_iter = 1;
+    p->init_shrink = 1.0; p->change_max = 1.1; p->fixed_dt = -1.0; p->nscal = 2; p->verbose = 0;
+}
+
+orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc_mg_opts* o)
+{
+    orc_ns_state* s = (orc_ns_state*)calloc(1, sizeof(orc_ns_state));
+    s->g = *g; s->p = *p; s->o = *o;
+    for (int q = 0; q < 2; ++q) {
+        s->S[q] = orc_alloc(g->n, ORC_CELL, 1, NUM_STATE);
+        s->P[q] = orc_alloc(g->n, ORC_NODE, 1, 1);
+        s->Gp[q] = orc_alloc(g->n, ORC_CELL, 1, 3);
+    }
+    for (int d = 0; d < 3; ++d) { s->umac[d] = orc_alloc(g->n, ORC_FACE[d], 1, 1); orc_setval(&s->umac[d], 1.e40); }
+    s->aofs = orc_alloc(g->n, ORC_CELL, 0, NUM_STATE);
+    s->rho_ptime = orc_alloc(g->n, ORC_CELL, 1, 1);
+    s->rho_ctime = orc_alloc(g->n, ORC_CELL, 1, 1);
+    s->rho_half = orc_alloc(g->n, ORC_CELL, 1, 1);
+    for (int d = 0; d < 3; ++d) {
+        s->lobc[d] = s->hibc[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_NEUMANN;
+        for (int n = 0; n < 3; ++n) { s->bc_vel[n].lo[d] = s->bc_vel[n].hi[d] = ORC_BC_INT_DIR; }
+        for (int n = 0; n < 2; ++n) { s->bc_scal[n].lo[d] = s->bc_scal[n].hi[d] = ORC_BC_INT_DIR; }
+    }
+    return s;
+}
+
+void orc_ns_destroy(orc_ns_state* s)
+{
+    for (int q = 0; q < 2; ++q) { orc_free(&s->S[q]); orc_free(&s->P[q]); orc_free(&s->Gp[q]); }
+    for (int d = 0; d < 3; ++d) orc_free(&s->umac[d]);
+    orc_free(&s->aofs); orc_free(&s->rho_ptime); orc_free(&s->rho_ctime); orc_free(&s->rho_half);
+    free(s);
+}
+
+orc_fab* orc_ns_fab(orc_ns_state* s, int which)
+{
+    switch (which) {
+    case 0: return S_NEW(s);
+    case 1: return S_OLD(s);
+    case 2: return P_NEW(s);
+    case 3: return P_OLD(s);
+    case 4: return GP_NEW(s);
+    case 5: return GP_OLD(s);
+    case 6: case 7: case 8: return &s->umac[which - 6];
+    case 9: return &s->aofs;
+    default: return NULL;
+    }
+}
+double orc_ns_time(const orc_ns_state* s) { return s->time; }
+double orc_ns_dt(const orc_ns_state* s) { return s->dt; }
+void orc_ns_last_stats(const orc_ns_state* s, orc_mg_stats* mac, orc_mg_stats* nodal, orc_mg_stats* visc)
+{
+    if (mac) *mac = s->st_mac;
+    if (nodal) *nodal = s->st_nodal;
+    if (visc) *visc = s->st_visc;
+}
+
+/* NavierStokes::init_TaylorGreen, reference Source/prob/prob_init.cpp:509-560 */
+void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0)
+{
+    const orc_geom* g = &s->g;
+    const double TwoPi = 2.0 * 3.14159265358979323846264338327950288;
+    orc_fab* S = S_NEW(s);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double x = g->problo[0] + (i + 0.5) * g->dx[0];
+        double y = g->problo[1] + (j + 0.5) * g->dx[1];
+        double z = g->problo[2] + (k + 0.5) * g->dx[2];
+        A4(S, i, j, k, 0) = vfac * sin(a * TwoPi * x) * cos(b * TwoPi * y) * cos(c * TwoPi * z);
+        A4(S, i, j, k, 1) = -vfac * cos(a * TwoPi * x) * sin(b * TwoPi * y) * cos(c * TwoPi * z);
+        A4(S, i, j, k, 2) = 0.0;
+        A4(S, i, j, k, Density) = rho0;
+        A4(S, i, j, k, Tracer) = (rho0 * vfac * vfac / 16.0) * (2.0 + cos(2.0 * c * TwoPi * z)) * (cos(2.0 * a * TwoPi * x) + cos(2.0 * b * TwoPi * y));
+    }
+    orc_setval(P_NEW(s), 0.0); orc_setval(P_OLD(s), 0.0);
+    orc_setval(GP_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0);
+    s->time = 0.0; s->nstep = 0;
+}
+
+/* FillPatch of comps [sc, sc+nc) of src (valid region) into a fresh fab with ng ghosts */
+static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int nc, int ng, const orc_bcrec* bc)
+{
+    const orc_geom* g = &s->g;
+    orc_fab f = orc_alloc(g->n, ORC_CELL, ng, nc);
+    for (int n = 0; n < nc; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&f, i, j, k, n) = A4(src, i, j, k, sc + n);
+    orc_fill_periodic(&f, g, ORC_CELL);
+    if (bc) orc_fill_physbc_cc(&f, g, bc, NULL, NULL);
+    return f;
+}
+static void fill_ghosts(const orc_ns_state* s, orc_fab* f, const int type[3])
+{
+    orc_fill_periodic(f, &s->g, type);
+}
+
+static void floor_small(orc_fab* f)
+{
+    size_t N = orc_npts(f) * (size_t)f->nc;
+    for (size_t q = 0; q < N; ++q) if (fabs(f->p[q]) <= 1.e-20) f->p[q] = 0.0;
+}
+
+static int is_diffusive_vel(const orc_ns_state* s) { return s->p.visc_coef > 0.0; }
+
+static void make_eta(const orc_ns_state* s, orc_fab eta[3])
+{
+    for (int d = 0; d < 3; ++d) { eta[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&eta[d], s->p.visc_coef); }
+}
+
+/* NavierStokes::getViscTerms for velocity: visc = div tau(U(time)), then FillBoundary (+ FirstOrderExtrap at walls) */
+static void get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata)
+{
+    const orc_geom* g = &s->g;
+    orc_setval(visc, 1.e40);
+    if (!is_diffusive_vel(s)) { orc_setval(visc, 0.0); return; }
+    orc_fab stmp = fillpatch(s, Sdata, Xvel, 3, 1, s->bc_vel);
+    orc_fab eta[3]; orc_fab* ep[3];
+    make_eta(s, eta);
+    for (int d = 0; d < 3; ++d) ep[d] = &eta[d];
+    orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 3);
+    orc_tensor_apply(g, &tmp, &stmp, 0.0, -1.0, NULL, ep);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(visc, i, j, k, n) = A4(&tmp, i, j, k, n);
+    orc_fill_periodic(visc, g, ORC_CELL);
+    orc_free(&tmp); orc_free(&stmp);
+    for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
+}
+
+/* getForce: rho-weighted buoyancy in the last direction (Source/NS_getForce.cpp:117-137) */
+static double force_vel(const orc_ns_state* s, int n, double rho)
+{
+    if (fabs(s->p.gravity) > 0.0001 && n == 2) return s->p.gravity * rho;
+    return 0.0;
+}
+
+static double est_time_step(orc_ns_state* s)
+{
+    const orc_geom* g = &s->g;
+    if (s->p.fixed_dt > 0.0) return s->p.fixed_dt;
+    const double small = 1.0e-8;
+    double estdt = 1.0e+20;
+    const orc_fab* S = S_NEW(s);
+    const orc_fab* Gp = GP_NEW(s);
+    double umax[3] = {0, 0, 0}, fmax_[3] = {0, 0, 0};
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double u = fabs(A4(S, i, j, k, n)); if (u > umax[n]) umax[n] = u;
+        double rho = A4(S, i, j, k, Density);
+        double rho_inv = 1.0 / rho;
+        double f = force_vel(s, n, rho);
+        f -= A4(Gp, i, j, k, n);
+        f *= rho_inv;
+        f = fabs(f); if (f > fmax_[n]) fmax_[n] = f;
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (umax[d] > small) estdt = fmin(estdt, g->dx[d] / umax[d]);
+        if (fmax_[d] > small) estdt = fmin(estdt, sqrt(2.0 * g->dx[d] / fmax_[d]));
+    }
+    if (estdt < 1.0e+20) estdt *= s->p.cfl;
+    else { fprintf(stderr, "orc estTimeStep failed\n"); estdt = 1.e-3; }
+    return estdt;
+}
+
+static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost, comps 0..2*/, orc_fab* phi, const orc_fab* sig,
+                                int increment_gp)
+{
+    const orc_geom* g = &s->g;
+    /* set_boundary_velocity + FillBoundary of vel ghost cells (periodic) */
+    orc_fill_periodic(vel, g, ORC_CELL);
+    orc_nodal_project(g, vel, phi, sig, s->lobc, s->hibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+    /* Gp_new := grad(phi) or += (Projection.cpp:2549-2563), then FillPatch(Gp) */
+    orc_fab gp = orc_alloc(g->n, ORC_CELL, 0, 3);
+    orc_nodal_compgrad(g, &gp, phi);
+    orc_fab* G = GP_NEW(s);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (increment_gp) A4(G, i, j, k, n) += A4(&gp, i, j, k, n);
+        else A4(G, i, j, k, n) = A4(&gp, i, j, k, n);
+    }
+    orc_fill_periodic(G, g, ORC_CELL);
+    orc_free(&gp);
+}
+
+/* wrap the velocity comps of a state fab as a 3-comp view (same memory) */
+static orc_fab vel_view(orc_fab* S) { orc_fab v = *S; v.nc = 3; return v; }
+
+static void initial_velocity_project(orc_ns_state* s)
+{
+    const orc_geom* g = &s->g;
+    if (s->p.init_vel_iter <= 0) { orc_setval(P_OLD(s), 0.0); orc_setval(GP_OLD(s), 0.0); return; }
+    for (int iter = 0; iter < s->p.init_vel_iter; ++iter) {
+        orc_fab* phi = P_OLD(s);
+        orc_setval(phi, 0.0);
+        orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
+        orc_setval(&sig, 1.0);       /* constant-density initial projection; scaleVar inverts: 1/1 */
+        orc_fab v = vel_view(S_NEW(s));
+        nodal_project_level(s, &v, phi, &sig, 0);
+        orc_free(&sig);
+        orc_setval(P_OLD(s), 0.0); orc_setval(P_NEW(s), 0.0);
+        orc_setval(GP_OLD(s), 0.0); orc_setval(GP_NEW(s), 0.0);
+    }
+}
+
+static void advance_setup(orc_ns_state* s)
+{
+    for (int d = 0; d < 3; ++d) if (s->nstep == 0 && s->initial_step) { /* keep the 1e40 sentinel of the first allocation */ }
+    s->inew = 1 - s->inew;     /* swapTimeLevels: old <- new, new <- old storage */
+    s->pnew = 1 - s->pnew;
+    /* make_rho_prev_time */
+    orc_fab r = fillpatch(s, S_OLD(s), Density, 1, 1, &s->bc_scal[0]);
+    orc_copy_all(&s->rho_ptime, &r);
+    orc_free(&r);
+}
+
+static double predict_velocity(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab Umf = fillpatch(s, S_OLD(s), Xvel, 3, 3, s->bc_vel);
+    floor_small(&Umf);
+    double cflmax = 0.0;
+    for (int n = 0; n < 3; ++n) {
+        double um = 0.0;
+        size_t N = orc_npts(&Umf);
+        for (size_t q = 0; q < N; ++q) { double v = fabs(Umf.p[q + N * n]); if (v > um) um = v; }
+        double c = dt * um / g->dx[n];
+        if (n == 0 || c > cflmax) cflmax = c;
+    }
+    double tempdt = cflmax == 0 ? s->p.change_max : fmin(s->p.change_max, s->p.cfl / cflmax);
+    orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
+    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
+    orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
+    const orc_fab* Gp = GP_OLD(s);
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        double rho = A4(&Smf, i, j, k, 0);
+        A4(&tf, i, j, k, n) = (force_vel(s, n, rho) + A4(&visc, i, j, k, n) - A4(Gp, i, j, k, n)) / rho;
+    }
+    orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
+    orc_extrap_vel_to_faces(g, &Umf, &tf, um, dt, s->bc_vel, s->p.use_forces_in_trans);
+    orc_free(&Umf); orc_free(&visc); orc_free(&Smf); orc_free(&tf);
+    return dt * tempdt;
+}
+
+static void mac_project(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab phi = orc_alloc(g->n, ORC_CELL, 1, 1);
+    /* MacProj.cpp:262-263: S_old density ghost cells overwritten with rho(time) incl. 1 ghost */
+    orc_fab* So = S_OLD(s);
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+        A4(So, i, j, k, Density) = A4(&s->rho_ptime, i, j, k, 0);
+    orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
+    orc_mg_opts o = s->o; o.maxorder = 4;
+    orc_mac_project(g, um, &s->rho_ptime, NULL, &phi, 2.0 / dt, s->lobc, s->hibc, s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
+    /* create_umac_grown at level 0: FillPatchSingleLevel (periodic ghost faces) */
+    for (int d = 0; d < 3; ++d) fill_ghosts(s, &s->umac[d], ORC_FACE[d]);
+    orc_free(&phi);
+}
+
+static void velocity_advection(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab Umf = fillpatch(s, S_OLD(s), Xvel, 3, 3, s->bc_vel);
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);
+    orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
+    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
+    orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
+    orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    const orc_fab* Gp = GP_OLD(s);
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        double rho = A4(&Smf, i, j, k, 0);
+        double t = force_vel(s, n, rho) + A4(&visc, i, j, k, n) - A4(Gp, i, j, k, n);
+        t /= rho;
+        A4(&tf, i, j, k, n) = t;
+    }
+    int iconserv[3] = {0, 0, 0};
+    orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
+    orc_compute_aofs(g, &s->aofs, Xvel, &Umf, 3, &tf, &divu, um, iconserv, dt, s->bc_vel, 1, s->p.use_forces_in_trans, NULL, NULL);
+    orc_free(&Umf); orc_free(&Smf); orc_free(&visc); orc_free(&tf); orc_free(&divu);
+}
+
+static void scalar_advection(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
+    floor_small(&Smf);
+    orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
+    orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    int iconserv[2] = {1, 0};   /* density conservative; tracer non-conservative (do_cons_trac = 0) */
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        double rho = A4(&Smf, i, j, k, 0);
+        A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc */
+        A4(&tf, i, j, k, 1) = A4(&tf, i, j, k, 1) / rho + 0.0;    /* convective: tf/rho + visc */
+    }
+    orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
+    orc_compute_aofs(g, &s->aofs, Density, &Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, NULL);
+    orc_free(&Smf); orc_free(&tf); orc_free(&divu);
+}
+
+static void scalar_update_rho(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(Sn, i, j, k, Density) = A4(So, i, j, k, Density) - dt * A4(&s->aofs, i, j, k, Density);
+    /* make_rho_curr_time + get_rho_half_time */
+    orc_fab r = fillpatch(s, Sn, Density, 1, 1, &s->bc_scal[0]);
+    orc_copy_all(&s->rho_ctime, &r);
+    orc_free(&r);
+    size_t N = orc_npts(&s->rho_half);
+    for (size_t q = 0; q < N; ++q) s->rho_half.p[q] = 0.5 * (s->rho_ptime.p[q] + s->rho_ctime.p[q]);
+}
+
+static void scalar_update_tracers(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double rho = A4(So, i, j, k, Density) - 0.5 * dt * A4(&s->aofs, i, j, k, Density);
+        double tf = 0.0;
+        A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf / rho);
+    }
+}
+
+static void velocity_advection_update(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
+    const orc_fab* Gp = GP_OLD(s);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double scal_rho = 0.5 * (A4(Uo, i, j, k, Density) + A4(Un, i, j, k, Density));
+        double force = force_vel(s, n, scal_rho);
+        if (s->initial_iter && is_diffusive_vel(s)) force = 0.0;
+        double rh = A4(&s->rho_half, i, j, k, 0);
+        double velold = A4(Uo, i, j, k, n);
+        A4(Un, i, j, k, n) = velold - dt * A4(&s->aofs, i, j, k, n) + dt * force / rh - dt * A4(Gp, i, j, k, n) / rh;
+    }
+}
+
+static void initial_velocity_diffusion_update(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    if (!is_diffusive_vel(s)) return;
+    orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
+    const orc_fab* Gp = GP_OLD(s);
+    orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
+    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, Uo); else orc_setval(&visc, 0.0);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double force = force_vel(s, n, A4(Uo, i, j, k, Density));
+        force += A4(&visc, i, j, k, n) - A4(Gp, i, j, k, n);
+        force /= A4(&s->rho_half, i, j, k, 0);
+        force -= A4(&s->aofs, i, j, k, n);
+        A4(Un, i, j, k, n) = A4(Uo, i, j, k, n) + force * dt;
+    }
+    orc_free(&visc);
+}
+
+/* Diffusion::diffuse_tensor_velocity (rho_flag = 1) */
+static void velocity_diffusion_update(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    if (!is_diffusive_vel(s)) return;
+    const double theta = s->p.be_cn_theta;
+    orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
+    orc_fab eta[3]; orc_fab* ep[3];
+    make_eta(s, eta);
+    for (int d = 0; d < 3; ++d) ep[d] = &eta[d];
+    orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 3);
+    if (theta != 1.0) {
+        orc_fab Soln = fillpatch(s, Uo, Xvel, 3, 1, s->bc_vel);
+        orc_tensor_apply(g, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep);
+        orc_free(&Soln);
+    }
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        A4(Un, i, j, k, n) *= A4(&s->rho_half, i, j, k, 0);     /* Diffusion.cpp:825: state overwritten with rho u* */
+        A4(&Rhs, i, j, k, n) += A4(Un, i, j, k, n);
+    }
+    /* tol_abs = visc_tol * mean_n ||Rhs_n||inf (get_scaled_abs_tol) */
+    double avg = 0.0;
+    for (int n = 0; n < 3; ++n) {
+        double m = 0.0;
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+            double v = fabs(A4(&Rhs, i, j, k, n)); if (v > m) m = v;
+        }
+        avg += (1.0 / 3.0) * m;
+    }
+    const double tol_abs = s->p.visc_tol * avg;
+    orc_fab Soln = fillpatch(s, Un, Xvel, 3, 1, s->bc_vel);   /* initial guess = FillPatch(U_new) = rho u* */
+    orc_fab acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&acoef, i, j, k, 0) = 1.0 * A4(&s->rho_half, i, j, k, 0);
+    orc_mg_opts o = s->o; o.maxorder = 2;
+    int lob[3], hib[3];
+    for (int d = 0; d < 3; ++d) { lob[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_DIRICHLET; hib[d] = lob[d]; }
+    orc_tensor_solve(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, lob, hib, s->p.visc_tol, tol_abs, &o, &s->st_visc);
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+        A4(Un, i, j, k, n) = A4(&Soln, i, j, k, n);
+    orc_free(&Soln); orc_free(&acoef); orc_free(&Rhs);
+    for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
+}
+
+/* Projection::level_project, single level */
+static void level_project(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab* Un = S_NEW(s);
+    orc_fab* Pn = P_NEW(s);
+    const orc_fab* Gp = GP_OLD(s);
+    /* zero P_new on the valid nodal box (level 0: nGrow 0) */
+    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) A4(Pn, i, j, k, 0) = 0.0;
+    const double dt_inv = 1. / dt;
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+        A4(Un, i, j, k, n) *= dt_inv;
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(Un, i, j, k, n) += A4(Gp, i, j, k, n) / A4(&s->rho_half, i, j, k, 0);
+    /* scaleVar: sigma = 1/rho_half */
+    orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
+    orc_fill_periodic(&sig, g, ORC_CELL);
+    orc_fab v = vel_view(Un);
+    nodal_project_level(s, &v, Pn, &sig, 0);
+    orc_free(&sig);
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+        A4(Un, i, j, k, n) *= dt;
+}
+
+static double advance(orc_ns_state* s, double dt)
+{
+    advance_setup(s);
+    double dt_test = predict_velocity(s, dt);
+    mac_project(s, dt);
+    velocity_advection(s, dt);
+    scalar_advection(s, dt);
+    scalar_update_rho(s, dt);
+    scalar_update_tracers(s, dt);
+    velocity_advection_update(s, dt);
+    if (!s->initial_iter) velocity_diffusion_update(s, dt);
+    else initial_velocity_diffusion_update(s, dt);
+    if (!s->initial_step) level_project(s, dt);
+    return dt_test;
+}
+
+/* Projection::initialSyncProject, single level */
+static void initial_sync_project(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    orc_fab* phi = P_OLD(s);
+    orc_setval(phi, 0.0);
+    orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
+    const double dt_inv = 1. / dt;
+    /* ConvertUnew: u_new = (u_new - u_old)/dt */
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(Un, i, j, k, n) = (A4(Un, i, j, k, n) - A4(Uo, i, j, k, n)) * dt_inv;
+    orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
+    orc_fill_periodic(&sig, g, ORC_CELL);
+    orc_fab v = vel_view(Un);
+    nodal_project_level(s, &v, phi, &sig, 1);
+    orc_free(&sig);
+    orc_fab* Pn = P_NEW(s);
+    size_t N = orc_npts(Pn);
+    for (size_t q = 0; q < N; ++q) Pn->p[q] += phi->p[q];
+}
+
+void orc_ns_post_init(orc_ns_state* s, double stop_time)
+{
+    /* post_init_state */
+    initial_velocity_project(s);
+    s->initial_step = 1;
+    /* post_init_estDT: dt = init_shrink * estTimeStep, limited by stop_time */
+    double dt_init = s->p.init_shrink * est_time_step(s);
+    if (stop_time >= 0.0) {
+        const double eps = 0.0001 * dt_init;
+        if (s->time + dt_init > stop_time - eps) dt_init = stop_time - s->time;
+    }
+    s->dt = dt_init;
+    /* post_init_press */
+    if (s->p.init_iter > 0) {
+        s->initial_iter = 1;
+        for (int iter = 0; iter < s->p.init_iter; ++iter) {
+            advance(s, dt_init);
+            initial_sync_project(s, dt_init);
+            /* resetState: state swapped back (new <- initial data), P/Gp: old := new */
+            s->inew = 1 - s->inew;
+            orc_copy_all(P_OLD(s), P_NEW(s));
+            orc_copy_all(GP_OLD(s), GP_NEW(s));
+            s->initial_iter = 0;
+        }
+    }
+    s->initial_step = 0;
+    s->dt_min_adv = 1.e200;
+}
+
+double orc_ns_step(orc_ns_state* s)
+{
+    double dt = s->dt;
+    if (s->nstep > 0) {
+        /* computeNewDt */
+        double dt_min = fmin(s->dt_min_adv, est_time_step(s));
+        if (s->p.fixed_dt <= 0.0) dt_min = fmin(dt_min, s->p.change_max * s->dt);
+        dt = dt_min;
+    }
+    s->dt = dt;
+    s->dt_min_adv = advance(s, dt);
+    s->time += dt;
+    s->nstep += 1;
+    return dt;
+}
