@@ -253,4 +253,145 @@ int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, ia
     IAMRX_CATCH
 }
 
+int iamrx_nodal_residual(const iamrx_geom* g, iamrx_mf out, iamrx_mf phi, iamrx_mf sig, iamrx_mf rhs)
+{
+    IAMRX_TRY nodal_residual(to_geom(g), out->mf, phi->mf, sig->mf, rhs ? &rhs->mf : nullptr); IAMRX_CATCH
+}
+int iamrx_nodal_gs_color(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int color)
+{
+    IAMRX_TRY nodal_gs_color(to_geom(g), phi->mf, rhs->mf, sig->mf, color); IAMRX_CATCH
+}
+int iamrx_nodal_restrict(iamrx_mf c, iamrx_mf f) { IAMRX_TRY nodal_restrict(c->mf, f->mf); IAMRX_CATCH }
+int iamrx_nodal_interp_add(iamrx_mf f, iamrx_mf c, iamrx_mf s) { IAMRX_TRY nodal_interp_add(f->mf, c->mf, s->mf); IAMRX_CATCH }
+int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp) { IAMRX_TRY nodal_divu(to_geom(g), rhs->mf, vel->mf, vcomp); IAMRX_CATCH }
+int iamrx_nodal_compgrad(const iamrx_geom* g, iamrx_mf gp, iamrx_mf phi)
+{
+    IAMRX_TRY nodal_mknewu(to_geom(g), nullptr, 0, phi->mf, nullptr, &gp->mf, false); IAMRX_CATCH
+}
+
+int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_mf phi, iamrx_mf sig, int sig_comp, const int lobc[3],
+                           const int hibc[3], double rel_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mf gp, int increment_gp,
+                           iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    MGStats s = nodal_projection(to_geom(g), vel->mf, vcomp, phi->mf, sig->mf, sig_comp, to_bc(lobc, hibc, op.maxorder), rel_tol, abs_tol,
+                                 op, gp ? &gp->mf : nullptr, increment_gp != 0);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_tensor_apply(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
+                       iamrx_mf ez, const int lobc[3], const int hibc[3], int maxorder)
+{
+    IAMRX_TRY
+    const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
+    tensor_apply(to_geom(g), out->mf, vel->mf, a, b, acoef ? &acoef->mf : nullptr, eta, to_bc(lobc, hibc, maxorder));
+    IAMRX_CATCH
+}
+
+int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
+                       iamrx_mf ez, const int lobc[3], const int hibc[3], double tol_rel, double tol_abs, const iamrx_mg_opts* o,
+                       iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
+    MGStats s = tensor_solve(to_geom(g), soln->mf, rhs->mf, a, b, acoef ? &acoef->mf : nullptr, eta, to_bc(lobc, hibc, op.maxorder),
+                             tol_rel, tol_abs, op);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
+struct iamrx_ns_s {
+    std::unique_ptr<NavierStokes> ns;
+    iamrx_mf_s* views[10];
+};
+
+void iamrx_ns_default_params(iamrx_ns_params* p)
+{
+    NSParams d;
+    p->cfl = d.cfl; p->visc_coef = d.visc_coef; p->be_cn_theta = d.be_cn_theta; p->gravity = d.gravity;
+    p->mac_tol = d.mac_tol; p->mac_abs_tol = d.mac_abs_tol; p->proj_tol = d.proj_tol; p->proj_abs_tol = d.proj_abs_tol;
+    p->visc_tol = d.visc_tol; p->use_forces_in_trans = d.use_forces_in_trans; p->do_mom_diff = d.do_mom_diff;
+    p->init_iter = d.init_iter; p->init_vel_iter = d.init_vel_iter; p->init_shrink = d.init_shrink; p->change_max = d.change_max;
+    p->fixed_dt = d.fixed_dt; p->nscal = d.nscal; p->verbose = d.verbose;
+}
+
+int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
+{
+    IAMRX_TRY
+    NSParams q;
+    q.cfl = p->cfl; q.visc_coef = p->visc_coef; q.be_cn_theta = p->be_cn_theta; q.gravity = p->gravity;
+    q.mac_tol = p->mac_tol; q.mac_abs_tol = p->mac_abs_tol; q.proj_tol = p->proj_tol; q.proj_abs_tol = p->proj_abs_tol;
+    q.visc_tol = p->visc_tol; q.use_forces_in_trans = p->use_forces_in_trans; q.do_mom_diff = p->do_mom_diff;
+    q.init_iter = p->init_iter; q.init_vel_iter = p->init_vel_iter; q.init_shrink = p->init_shrink; q.change_max = p->change_max;
+    q.fixed_dt = p->fixed_dt; q.nscal = p->nscal; q.verbose = p->verbose;
+    if (q.do_mom_diff) throw Error("iamrx: do_mom_diff = 1 not implemented in this round");
+    auto* h = new iamrx_ns_s;
+    h->ns = std::make_unique<NavierStokes>(to_geom(g), l->p, q, to_opts(o));
+    for (auto& v : h->views) v = nullptr;
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_ns_destroy(iamrx_ns ns) { IAMRX_TRY delete ns; IAMRX_CATCH }
+int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, double c, double rho0)
+{
+    IAMRX_TRY ns->ns->init_taylorgreen(vfac, a, b, c, rho0); IAMRX_CATCH
+}
+int iamrx_ns_post_init(iamrx_ns ns, double stop_time) { IAMRX_TRY ns->ns->post_init(stop_time); IAMRX_CATCH }
+int iamrx_ns_step(iamrx_ns ns, double* dt_used) { IAMRX_TRY double d = ns->ns->step(); if (dt_used) *dt_used = d; IAMRX_CATCH }
+int iamrx_ns_advance(iamrx_ns ns, double dt, double* dt_est) { IAMRX_TRY double d = ns->ns->advance(dt); if (dt_est) *dt_est = d; IAMRX_CATCH }
+int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep)
+{
+    IAMRX_TRY
+    if (time) *time = ns->ns->time;
+    if (dt) *dt = ns->ns->dt;
+    if (nstep) *nstep = ns->ns->nstep;
+    IAMRX_CATCH
+}
+
+// non-owning view: the C handle type wraps a MultiFab by value, so expose the persistent arrays through
+// a pointer-carrying subclass-free trick: a dedicated handle whose MultiFab is a shallow alias.
+int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
+{
+    IAMRX_TRY
+    NavierStokes& n = *ns->ns;
+    MultiFab* m = nullptr;
+    switch (which) {
+    case 0: m = &n.get_new_data(0); break;
+    case 1: m = &n.get_old_data(0); break;
+    case 2: m = &n.get_new_data(1); break;
+    case 3: m = &n.get_old_data(1); break;
+    case 4: m = &n.get_new_data(2); break;
+    case 5: m = &n.get_old_data(2); break;
+    case 6: case 7: case 8: m = &n.umac(which - 6); break;
+    case 9: m = &n.Aofs(); break;
+    default: throw Error("iamrx_ns_data: bad selector");
+    }
+    // copy the current contents into a library-owned MultiFab of the same shape (old/new swap every step,
+    // so a stable alias would be misleading); the caller destroys it with iamrx_mf_destroy
+    auto* h = new iamrx_mf_s;
+    h->mf.define(m->layout, m->type, m->ncomp, m->ngrow);
+    MultiFab::Copy(h->mf, *m, 0, 0, m->ncomp, m->ngrow);
+    *out = h;
+    IAMRX_CATCH
+}
+
+int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc)
+{
+    IAMRX_TRY
+    from_stats(ns->ns->st_mac, mac); from_stats(ns->ns->st_nodal, nodal); from_stats(ns->ns->st_visc, visc);
+    IAMRX_CATCH
+}
+
+int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8])
+{
+    IAMRX_TRY
+    if (sections_ms) for (int i = 0; i < 8; ++i) sections_ms[i] = ns->ns->t_sections[i];
+    if (enable >= 0) ns->ns->profile_sections = enable != 0;
+    if (enable == 2) for (int i = 0; i < 8; ++i) ns->ns->t_sections[i] = 0.0;
+    IAMRX_CATCH
+}
+
 }  // extern "C"

@@ -1,0 +1,239 @@
+// iamr_amd/csrc/k_nodal.hip -- nodal (Q1 finite element, cell-centred sigma) Laplacian kernels for gfx950:
+// 27-point operator / residual, 8-colour Gauss-Seidel, weighted Jacobi, full-weighting restriction,
+// sigma-weighted interpolation, nodal divergence, velocity update and cell-centred gradient.
+//
+// Role: AMReX MLNodeLaplacian (mlndlap_adotx_aa, gscolor_aa / jacobi_aa, restriction, interpadd_aa, divu,
+// mknewu_aa) driven by Hydro::NodalProjector at reference Source/Projection.cpp:2512-2542, and
+// MLNodeLaplacian::compGrad at Source/NavierStokesBase.cpp:4106-4118.
+//
+// The 27 stencil coefficients are written per neighbour class (corner / edge / face / centre): the
+// coefficient of a neighbour is w(class) * (sum of sigma over the cells shared with that neighbour).
+#include "kernels.h"
+#include "launch.h"
+
+namespace iamrx {
+
+struct NodeW { double corner, ex, ey, ez, fx, fy, fz, c; };   // class weights
+
+static NodeW make_w(const Geometry& g)
+{
+    const double fx = 1.0 / (g.dx[0] * g.dx[0]) / 36.0, fy = 1.0 / (g.dx[1] * g.dx[1]) / 36.0, fz = 1.0 / (g.dx[2] * g.dx[2]) / 36.0;
+    NodeW w;
+    w.corner = fx + fy + fz;
+    w.ex = -fx + 2.0 * fy + 2.0 * fz;     // edge neighbours with di = 0
+    w.ey = 2.0 * fx - fy + 2.0 * fz;      // dj = 0
+    w.ez = 2.0 * fx + 2.0 * fy - fz;      // dk = 0
+    w.fx = 4.0 * fx - 2.0 * fy - 2.0 * fz;   // face neighbours (di = +-1, dj = dk = 0)
+    w.fy = -2.0 * fx + 4.0 * fy - 2.0 * fz;
+    w.fz = -2.0 * fx - 2.0 * fy + 4.0 * fz;
+    w.c = -4.0 * (fx + fy + fz);
+    return w;
+}
+
+// A x at node (i,j,k) and the diagonal coefficient s0.  s = sigma fab (cell centred, 1 ghost).
+__device__ __forceinline__ double node_Ax(const FabD& x, const FabD& s, const NodeW& w, int i, int j, int k, double& s0)
+{
+    // sigma of the 8 cells around the node: s_{abc}, a,b,c in {m,p} for cell index node-1 / node
+    const double smmm = s(i - 1, j - 1, k - 1), spmm = s(i, j - 1, k - 1), smpm = s(i - 1, j, k - 1), sppm = s(i, j, k - 1);
+    const double smmp = s(i - 1, j - 1, k), spmp = s(i, j - 1, k), smpp = s(i - 1, j, k), sppp = s(i, j, k);
+    s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+    double y = x(i, j, k) * s0;
+    y += w.corner * (x(i - 1, j - 1, k - 1) * smmm + x(i + 1, j - 1, k - 1) * spmm + x(i - 1, j + 1, k - 1) * smpm + x(i + 1, j + 1, k - 1) * sppm
+                   + x(i - 1, j - 1, k + 1) * smmp + x(i + 1, j - 1, k + 1) * spmp + x(i - 1, j + 1, k + 1) * smpp + x(i + 1, j + 1, k + 1) * sppp);
+    y += w.ex * (x(i, j - 1, k - 1) * (smmm + spmm) + x(i, j + 1, k - 1) * (smpm + sppm) + x(i, j - 1, k + 1) * (smmp + spmp) + x(i, j + 1, k + 1) * (smpp + sppp));
+    y += w.ey * (x(i - 1, j, k - 1) * (smmm + smpm) + x(i + 1, j, k - 1) * (spmm + sppm) + x(i - 1, j, k + 1) * (smmp + smpp) + x(i + 1, j, k + 1) * (spmp + sppp));
+    y += w.ez * (x(i - 1, j - 1, k) * (smmm + smmp) + x(i + 1, j - 1, k) * (spmm + spmp) + x(i - 1, j + 1, k) * (smpm + smpp) + x(i + 1, j + 1, k) * (sppm + sppp));
+    y += w.fx * (x(i - 1, j, k) * (smmm + smpm + smmp + smpp) + x(i + 1, j, k) * (spmm + sppm + spmp + sppp));
+    y += w.fy * (x(i, j - 1, k) * (smmm + spmm + smmp + spmp) + x(i, j + 1, k) * (smpm + sppm + smpp + sppp));
+    y += w.fz * (x(i, j, k - 1) * (smmm + spmm + smpm + sppm) + x(i, j, k + 1) * (smmp + spmp + smpp + sppp));
+    return y;
+}
+
+// out = rhs - A x   (rhs null: out = A x)
+void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs)
+{
+    if (x.nlocal() == 0) return;
+    const NodeW w = make_w(g);
+    const FabD *ot = out.d_tab, *xt = x.d_tab, *st = sig.d_tab;
+    const FabD* rt = rhs ? rhs->d_tab : nullptr;
+    for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        double s0;
+        const double y = node_Ax(xt[f], st[f], w, i, j, k, s0);
+        ot[f](i, j, k) = rt ? rt[f](i, j, k) - y : y;
+    });
+}
+
+// one colour of the 8-colour Gauss-Seidel sweep: nodes with (i&1, j&1, k&1) == colour bits
+__global__ void __launch_bounds__(256) k_nodal_gscolor(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ xt,
+    const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int color)
+{
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    // nodal valid box [lo, hi+1]; first index of the right parity in each direction
+    const int cx = color & 1, cy = (color >> 1) & 1, cz = (color >> 2) & 1;
+    const int i0 = cb.lo[0] + (((cb.lo[0] & 1) != cx) ? 1 : 0);
+    const int j0 = cb.lo[1] + (((cb.lo[1] & 1) != cy) ? 1 : 0);
+    const int k0n = cb.lo[2] + (((cb.lo[2] & 1) != cz) ? 1 : 0);
+    BoxD hb;   // index box of the colour lattice (m-space)
+    hb.lo[0] = hb.lo[1] = hb.lo[2] = 0;
+    hb.hi[0] = (cb.hi[0] + 1 - i0) >> 1; hb.hi[1] = (cb.hi[1] + 1 - j0) >> 1; hb.hi[2] = (cb.hi[2] + 1 - k0n) >> 1;
+    if (cb.hi[0] + 1 < i0 || cb.hi[1] + 1 < j0 || cb.hi[2] + 1 < k0n) return;
+    int mi, mj, mk0, mk1;
+    if (!tile_ijk(t, hb, mi, mj, mk0, mk1)) return;
+    const FabD x = xt[fab], r = rt[fab], s = st[fab];
+    const int i = i0 + 2 * mi, j = j0 + 2 * mj;
+    for (int mk = mk0; mk <= mk1; ++mk) {
+        const int k = k0n + 2 * mk;
+        double s0;
+        const double Ax = node_Ax(x, s, w, i, j, k, s0);
+        x(i, j, k) += (r(i, j, k) - Ax) / s0;
+    }
+}
+
+void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color)
+{
+    if (x.nlocal() == 0) return;
+    const Layout& l = *x.layout;
+    int ml[3];
+    for (int d = 0; d < 3; ++d) ml[d] = (l.max_len[d] + 1 + 1) / 2;
+    Tiling t = make_tiling(ml, l.nlocal(), 4);
+    hipLaunchKernelGGL(k_nodal_gscolor, t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g), color);
+}
+
+// weighted Jacobi: x_new = x + (2/3) (rhs - A x)/s0 ; tmp holds x_new, then copied back by the caller
+void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig)
+{
+    if (x.nlocal() == 0) return;
+    const NodeW w = make_w(g);
+    const FabD *nt = xnew.d_tab, *xt = x.d_tab, *rt = rhs.d_tab, *st = sig.d_tab;
+    for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        double s0;
+        const double Ax = node_Ax(xt[f], st[f], w, i, j, k, s0);
+        nt[f](i, j, k) = xt[f](i, j, k) + (2. / 3.) * (rt[f](i, j, k) - Ax) / s0;
+    });
+}
+
+// full weighting (1,2,1)^3/64; the fine array needs one filled ghost-node layer
+void nodal_restrict(MultiFab& crse, const MultiFab& fine)
+{
+    if (crse.nlocal() == 0) return;
+    const FabD *ct = crse.d_tab, *ft = fine.d_tab;
+    for_each(*crse.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD fa = ft[f];
+        const int ii = 2 * i, jj = 2 * j, kk = 2 * k;
+        double s = 0.0;
+        for (int dk = -1; dk <= 1; ++dk)
+            for (int dj = -1; dj <= 1; ++dj)
+                for (int di = -1; di <= 1; ++di) {
+                    const double w = (di == 0 ? 2. : 1.) * (dj == 0 ? 2. : 1.) * (dk == 0 ? 2. : 1.);
+                    s += w * fa(ii + di, jj + dj, kk + dk);
+                }
+        ct[f](i, j, k) = s * (1. / 64.);
+    });
+}
+
+// sigma-weighted interpolation (mlndlap_interpadd_aa)
+__device__ __forceinline__ double w_side(const FabD& s, int i, int j, int k, int d, int side)
+{
+    int lo[3] = {i - 1, j - 1, k - 1}, hi[3] = {i, j, k};
+    lo[d] = hi[d] = (d == 0 ? i : (d == 1 ? j : k)) - 1 + side;
+    double r = 0.0;
+    for (int c = lo[2]; c <= hi[2]; ++c) for (int b = lo[1]; b <= hi[1]; ++b) for (int a = lo[0]; a <= hi[0]; ++a) r += s(a, b, c);
+    return r;
+}
+__device__ __forceinline__ double interp_line(const FabD& c, const FabD& s, int i, int j, int k, int ic, int jc, int kc, int d)
+{
+    const double w1 = w_side(s, i, j, k, d, 0), w2 = w_side(s, i, j, k, d, 1);
+    const double c2 = c(ic + (d == 0), jc + (d == 1), kc + (d == 2));
+    return (c(ic, jc, kc) * w1 + c2 * w2) / (w1 + w2);
+}
+__device__ __forceinline__ double interp_face(const FabD& c, const FabD& s, int i, int j, int k, int ic, int jc, int kc, int d1, int d2)
+{
+    const double w1 = w_side(s, i, j, k, d1, 0), w2 = w_side(s, i, j, k, d1, 1), w3 = w_side(s, i, j, k, d2, 0), w4 = w_side(s, i, j, k, d2, 1);
+    const int e1[3] = {d1 == 0, d1 == 1, d1 == 2}, e2[3] = {d2 == 0, d2 == 1, d2 == 2};
+    double r = 0.0;
+    r += w1 * interp_line(c, s, i - e1[0], j - e1[1], k - e1[2], ic, jc, kc, d2);
+    r += w2 * interp_line(c, s, i + e1[0], j + e1[1], k + e1[2], ic + e1[0], jc + e1[1], kc + e1[2], d2);
+    r += w3 * interp_line(c, s, i - e2[0], j - e2[1], k - e2[2], ic, jc, kc, d1);
+    r += w4 * interp_line(c, s, i + e2[0], j + e2[1], k + e2[2], ic + e2[0], jc + e2[1], kc + e2[2], d1);
+    return r / (w1 + w2 + w3 + w4);
+}
+
+void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine)
+{
+    if (fine.nlocal() == 0) return;
+    const FabD *ft = fine.d_tab, *ct = crse.d_tab, *st = sig_fine.d_tab;
+    for_each(*fine.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD c = ct[f], s = st[f];
+        const int ic = i >> 1, jc = j >> 1, kc = k >> 1;
+        const int io = i & 1, jo = j & 1, ko = k & 1;
+        double v;
+        if (io && jo && ko) {
+            double w[6];
+            for (int d = 0; d < 3; ++d) { w[2 * d] = w_side(s, i, j, k, d, 0); w[2 * d + 1] = w_side(s, i, j, k, d, 1); }
+            v = (w[0] * interp_face(c, s, i - 1, j, k, ic, jc, kc, 1, 2) + w[1] * interp_face(c, s, i + 1, j, k, ic + 1, jc, kc, 1, 2)
+               + w[2] * interp_face(c, s, i, j - 1, k, ic, jc, kc, 0, 2) + w[3] * interp_face(c, s, i, j + 1, k, ic, jc + 1, kc, 0, 2)
+               + w[4] * interp_face(c, s, i, j, k - 1, ic, jc, kc, 0, 1) + w[5] * interp_face(c, s, i, j, k + 1, ic, jc, kc + 1, 0, 1))
+              / (w[0] + w[1] + w[2] + w[3] + w[4] + w[5]);
+        } else if (jo && ko) v = interp_face(c, s, i, j, k, ic, jc, kc, 1, 2);
+        else if (io && ko) v = interp_face(c, s, i, j, k, ic, jc, kc, 0, 2);
+        else if (io && jo) v = interp_face(c, s, i, j, k, ic, jc, kc, 0, 1);
+        else if (io) v = interp_line(c, s, i, j, k, ic, jc, kc, 0);
+        else if (jo) v = interp_line(c, s, i, j, k, ic, jc, kc, 1);
+        else if (ko) v = interp_line(c, s, i, j, k, ic, jc, kc, 2);
+        else v = c(ic, jc, kc);
+        ft[f](i, j, k) += v;
+    });
+}
+
+// rhs(node) = FE divergence of the cell-centred velocity (mlndlap_divu); vel needs 1 filled ghost cell
+void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp)
+{
+    if (rhs.nlocal() == 0) return;
+    const FabD *rt = rhs.d_tab, *vt = vel.d_tab;
+    const double fx = 0.25 / g.dx[0], fy = 0.25 / g.dx[1], fz = 0.25 / g.dx[2];
+    for_each(*rhs.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD v = vt[f];
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+            const int ci = i - 1 + cx, cj = j - 1 + cy, ck = k - 1 + cz;
+            sx += (cx ? 1.0 : -1.0) * v(ci, cj, ck, vcomp);
+            sy += (cy ? 1.0 : -1.0) * v(ci, cj, ck, vcomp + 1);
+            sz += (cz ? 1.0 : -1.0) * v(ci, cj, ck, vcomp + 2);
+        }
+        double r = 0.0;
+        r += fx * sx; r += fy * sy; r += fz * sz;
+        rt[f](i, j, k) = r;
+    });
+}
+
+// vel -= sig * grad(phi) (mlndlap_mknewu_aa); gp (optional) = grad(phi) stored or accumulated (compGrad)
+void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& phi, const MultiFab* sig, MultiFab* gp, bool gp_increment)
+{
+    if (phi.nlocal() == 0) return;
+    const FabD* pt = phi.d_tab;
+    const FabD* vt = vel ? vel->d_tab : nullptr;
+    const FabD* st = sig ? sig->d_tab : nullptr;
+    const FabD* gt = gp ? gp->d_tab : nullptr;
+    const double fac[3] = {0.25 / g.dx[0], 0.25 / g.dx[1], 0.25 / g.dx[2]};
+    const double f0 = fac[0], f1 = fac[1], f2 = fac[2];
+    for_each(*phi.layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD p = pt[f];
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int nz = 0; nz < 2; ++nz) for (int ny = 0; ny < 2; ++ny) for (int nx = 0; nx < 2; ++nx) {
+            const double v = p(i + nx, j + ny, k + nz);
+            s[0] += (nx ? 1.0 : -1.0) * v;
+            s[1] += (ny ? 1.0 : -1.0) * v;
+            s[2] += (nz ? 1.0 : -1.0) * v;
+        }
+        const double gr[3] = {f0 * s[0], f1 * s[1], f2 * s[2]};
+        if (vt) {
+            const double sg = st[f](i, j, k);
+            const double fc[3] = {f0, f1, f2};
+            for (int d = 0; d < 3; ++d) vt[f](i, j, k, vcomp + d) -= sg * fc[d] * s[d];
+        }
+        if (gt) for (int d = 0; d < 3; ++d) { if (gp_increment) gt[f](i, j, k, d) += gr[d]; else gt[f](i, j, k, d) = gr[d]; }
+    });
+}
+
+}  // namespace iamrx

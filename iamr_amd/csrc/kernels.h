@@ -54,6 +54,16 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
                           const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
                           bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3]);
 
+// ---- k_nodal.hip --------------------------------------------------------------------------
+void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
+void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
+void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
+void nodal_restrict(MultiFab& crse, const MultiFab& fine);
+void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
+void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp);
+// vel(vcomp..) -= sig*grad(phi) (vel may be null); gp (may be null) = or += grad(phi)
+void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& phi, const MultiFab* sig, MultiFab* gp, bool gp_increment);
+
 // ---- k_tensor.hip -------------------------------------------------------------------------
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);

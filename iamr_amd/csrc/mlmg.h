@@ -77,4 +77,37 @@ private:
     std::vector<Level> m_lev;
 };
 
+// nodal Laplacian div(sigma grad phi) = rhs  (MLNodeLaplacian + MLMG role)
+class NodalMG {
+public:
+    NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MGOpts& o);
+    // sigma: cell centred, valid region used (ghost cells are filled internally, as MLNodeLaplacian does)
+    void setSigma(const MultiFab& sig, int comp);
+    MGStats solve(MultiFab& phi, const MultiFab& rhs, double rtol, double atol);
+    int nlevels() const { return (int)m_lev.size(); }
+    const MultiFab& sigma(int l) const { return m_lev[l].sig; }
+    const Geometry& geom(int l) const { return m_lev[l].g; }
+    void smooth(int l, MultiFab& x, const MultiFab& rhs);
+    void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b);
+    void vcycle(MGStats& st);
+    MultiFab& res(int l) { return m_lev[l].res; }
+    MultiFab& cor(int l) { return m_lev[l].cor; }
+
+private:
+    struct Level {
+        Geometry g;
+        LayoutP layout;
+        MultiFab sig;              // cell, 1 ghost
+        MultiFab cor, res, rescor; // node, 1 ghost
+        MultiFab tmp;              // Jacobi scratch
+    };
+    int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
+    void subtract_mean(int l, MultiFab& mf);
+    Geometry m_g;
+    DomainBC m_bc;
+    MGOpts m_o;
+    bool m_singular = true;
+    std::vector<Level> m_lev;
+};
+
 }  // namespace iamrx

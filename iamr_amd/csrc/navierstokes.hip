@@ -1,0 +1,485 @@
+// iamr_amd/csrc/navierstokes.hip -- the level time step: host-side C++ keeping the sequencing and the
+// in-place conventions of NavierStokes::advance and its callees, driving the HIP kernels.
+//
+// Reference (all in /root/reference/Source):
+//   NavierStokes::advance                   NavierStokes.cpp:543-691
+//   NSB::advance_setup                      NavierStokesBase.cpp:613-741
+//   NSB::predict_velocity                   NavierStokesBase.cpp:4376-4512
+//   NSB::mac_project -> MacProj::mac_project NavierStokesBase.cpp:2070-2109, MacProj.cpp:225-353
+//   NSB::velocity_advection                 NavierStokesBase.cpp:3358-3470
+//   NavierStokes::scalar_advection          NavierStokes.cpp:698-812
+//   NSB::scalar_advection_update            NavierStokesBase.cpp:2730-2972
+//   NSB::velocity_advection_update          NavierStokesBase.cpp:3523-3655
+//   NSB::initial_velocity_diffusion_update  NavierStokesBase.cpp:3658-3749
+//   Diffusion::diffuse_tensor_velocity      Diffusion.cpp:650-957
+//   NavierStokes::getViscTerms              NavierStokes.cpp:1960-2049
+//   Projection::level_project               Projection.cpp:166-450
+//   Projection::initialVelocityProject      Projection.cpp:615-838
+//   Projection::initialSyncProject          Projection.cpp:970-1185
+//   NavierStokes::post_init(_press)         NavierStokes.cpp:1254-1432
+//   NSB::estTimeStep / computeNewDt         NavierStokesBase.cpp:1353-1510, 945-1035
+// Scope of this round: one level, periodic domain, constant viscosity, divu = 0, NUM_STATE = 5
+// (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
+#include "operators.h"
+#include "launch.h"
+#include <cmath>
+#include <chrono>
+
+namespace iamrx {
+
+namespace {
+struct SectionTimer {
+    NavierStokes& ns; int idx; bool on;
+    std::chrono::steady_clock::time_point t0;
+    SectionTimer(NavierStokes& n, int i) : ns(n), idx(i), on(n.profile_sections)
+    {
+        if (on) { Context::get().sync(); t0 = std::chrono::steady_clock::now(); }
+    }
+    ~SectionTimer()
+    {
+        if (on) { Context::get().sync(); ns.t_sections[idx] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    }
+};
+}  // namespace
+
+NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& par, const MGOpts& opts)
+    : g(geom), layout(std::move(lay)), p(par), o(opts)
+{
+    for (int d = 0; d < 3; ++d)
+        if (!g.periodic[d]) throw Error("iamrx NavierStokes: non-periodic domains are not implemented in this round");
+    for (int q = 0; q < 2; ++q) {
+        S[q].define(layout, cell_type(), NUM_STATE, 1);
+        P[q].define(layout, node_type(), 1, 1);
+        Gp[q].define(layout, cell_type(), 3, 1);
+        S[q].setVal(0.0); P[q].setVal(0.0); Gp[q].setVal(0.0);
+    }
+    for (int d = 0; d < 3; ++d) {
+        u_mac[d].define(layout, face_type(d), 1, 1);
+        u_mac[d].setVal(1.e40);                       // NavierStokesBase.cpp:673
+        eta[d].define(layout, face_type(d), 1, 0);
+        eta[d].setVal(p.visc_coef);
+    }
+    aofs.define(layout, cell_type(), NUM_STATE, 0);
+    rho_ptime.define(layout, cell_type(), 1, 1);
+    rho_ctime.define(layout, cell_type(), 1, 1);
+    rho_half.define(layout, cell_type(), 1, 1);
+    for (int d = 0; d < 3; ++d) {
+        bc_mac.lo[d] = bc_mac.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;      // MacProj.cpp:1187-1208
+        bc_nodal.lo[d] = bc_nodal.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;  // Projection.cpp:2432-2464
+        bc_visc.lo[d] = bc_visc.hi[d] = g.periodic[d] ? lo_periodic : lo_dirichlet;
+        for (int n = 0; n < 3; ++n) bc_vel[n].lo[d] = bc_vel[n].hi[d] = bc_int_dir;
+        for (int n = 0; n < 2; ++n) bc_scal[n].lo[d] = bc_scal[n].hi[d] = bc_int_dir;
+    }
+    bc_mac.maxorder = 4;     // MacProj.cpp:1172
+    bc_nodal.maxorder = 2;
+    bc_visc.maxorder = 2;    // Diffusion.cpp:95-96
+}
+
+void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, double rho0)
+{
+    const double TwoPi = 2.0 * 3.14159265358979323846264338327950288;
+    const FabD* st = S[inew].d_tab;
+    const double plo0 = g.problo[0], plo1 = g.problo[1], plo2 = g.problo[2], dx0 = g.dx[0], dx1 = g.dx[1], dx2 = g.dx[2];
+    const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2];
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD s = st[f];
+        const double x = plo0 + (i - dl0 + 0.5) * dx0, y = plo1 + (j - dl1 + 0.5) * dx1, z = plo2 + (k - dl2 + 0.5) * dx2;
+        s(i, j, k, 0) = vfac * sin(a * TwoPi * x) * cos(b * TwoPi * y) * cos(c * TwoPi * z);
+        s(i, j, k, 1) = -vfac * cos(a * TwoPi * x) * sin(b * TwoPi * y) * cos(c * TwoPi * z);
+        s(i, j, k, 2) = 0.0;
+        s(i, j, k, Density) = rho0;
+        s(i, j, k, Tracer) = (rho0 * vfac * vfac / 16.0) * (2.0 + cos(2.0 * c * TwoPi * z)) * (cos(2.0 * a * TwoPi * x) + cos(2.0 * b * TwoPi * y));
+    });
+    for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }
+    time = 0.0; nstep = 0;
+}
+
+// FillPatch on one level: copy the valid data, then same-level + periodic ghost fill (physical BC fill: later round)
+void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp)
+{
+    MultiFab::Copy(dst, src, scomp, 0, ncomp, 0);
+    dst.FillBoundary(g);
+}
+
+static void floor_small(MultiFab& mf)
+{
+    const FabD* t = mf.d_tab;
+    const int nc = mf.ncomp;
+    for_each(*mf.layout, mf.type, mf.ngrow, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD a = t[f];
+        for (int n = 0; n < nc; ++n) { const double v = a(i, j, k, n); if (fabs(v) <= 1.e-20) a(i, j, k, n) = 0.0; }
+    });
+}
+
+void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
+{
+    visc.setVal(1.e40);                                       // NavierStokes.cpp:1982
+    if (!is_diffusive_vel()) { visc.setVal(0.0); return; }
+    MultiFab stmp(layout, cell_type(), 3, 1);
+    fillpatch(stmp, Sdata, Xvel, 3);
+    MultiFab tmp(layout, cell_type(), 3, 0);
+    const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
+    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
+    MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
+    visc.FillBoundary(g);                                     // + FirstOrderExtrap at walls (later round)
+}
+
+double NavierStokes::estTimeStep()
+{
+    if (p.fixed_dt > 0.0) return p.fixed_dt;
+    const double small = 1.0e-8;
+    double estdt = 1.0e+20;
+    MultiFab& Sn = S[inew];
+    MultiFab& G = Gp[pnew];
+    MultiFab tforces(layout, cell_type(), 3, 0);
+    {
+        const FabD *st = Sn.d_tab, *gt = G.d_tab, *ft = tforces.d_tab;
+        const double grav = p.gravity;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rho = st[f](i, j, k, Density);
+            const double rho_inv = 1.0 / rho;
+            for (int n = 0; n < 3; ++n) {
+                double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
+                fr -= gt[f](i, j, k, n);
+                fr *= rho_inv;
+                ft[f](i, j, k, n) = fr;
+            }
+        });
+    }
+    for (int d = 0; d < 3; ++d) {
+        const double umax = Sn.norm0(d, 1, 0), fmax = tforces.norm0(d, 1, 0);
+        if (umax > small) estdt = std::min(estdt, g.dx[d] / umax);
+        if (fmax > small) estdt = std::min(estdt, std::sqrt(2.0 * g.dx[d] / fmax));
+    }
+    if (estdt < 1.0e+20) estdt *= p.cfl;
+    else throw Error("NavierStokesBase::estTimeStep() failed to provide a good timestep");
+    return estdt;
+}
+
+void NavierStokes::advance_setup()
+{
+    inew = 1 - inew;     // swapTimeLevels
+    pnew = 1 - pnew;
+    fillpatch(rho_ptime, S[1 - inew], Density, 1);   // make_rho_prev_time
+}
+
+double NavierStokes::predict_velocity(double dt_)
+{
+    SectionTimer tm(*this, 0);
+    MultiFab& So = S[1 - inew];
+    MultiFab Umf(layout, cell_type(), 3, 3);
+    fillpatch(Umf, So, Xvel, 3);
+    floor_small(Umf);
+    double cflmax = 0.0;
+    for (int n = 0; n < 3; ++n) {
+        const double c = dt_ * Umf.norm0(n, 1, Umf.ngrow) / g.dx[n];
+        if (n == 0 || c > cflmax) cflmax = c;
+    }
+    const double tempdt = cflmax == 0 ? p.change_max : std::min(p.change_max, p.cfl / cflmax);
+    MultiFab visc(layout, cell_type(), 3, 1);
+    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
+    fillpatch(Smf, So, Density, NUM_SCALARS);
+    MultiFab tf(layout, cell_type(), 3, 1);
+    {
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
+        const double grav = p.gravity;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rho = st[f](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) {
+                const double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
+                tt[f](i, j, k, n) = (fr + vt[f](i, j, k, n) - gt[f](i, j, k, n)) / rho;
+            }
+        });
+    }
+    MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_extrap_vel_to_faces(g, Umf, &tf, um, dt_, bc_vel, p.use_forces_in_trans != 0);
+    return dt_ * tempdt;
+}
+
+void NavierStokes::mac_project(double dt_)
+{
+    SectionTimer tm(*this, 1);
+    MultiFab mac_phi(layout, cell_type(), 1, 1);
+    mac_phi.setVal(0.0);
+    MultiFab& So = S[1 - inew];
+    MultiFab::Copy(So, rho_ptime, 0, Density, 1, 1);            // MacProj.cpp:262-263
+    MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    MGOpts mo = o;
+    mo.maxorder = 4;
+    st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
+    for (int d = 0; d < 3; ++d) u_mac[d].FillBoundary(g);        // create_umac_grown at level 0
+}
+
+void NavierStokes::velocity_advection(double dt_)
+{
+    SectionTimer tm(*this, 2);
+    MultiFab& So = S[1 - inew];
+    MultiFab Umf(layout, cell_type(), 3, 3);
+    fillpatch(Umf, So, Xvel, 3);
+    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
+    fillpatch(Smf, So, Density, NUM_SCALARS);
+    MultiFab visc(layout, cell_type(), 3, 1);
+    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    MultiFab tf(layout, cell_type(), 3, 1), divu(layout, cell_type(), 1, 1);
+    divu.setVal(0.0);
+    {
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
+        const double grav = p.gravity;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rho = st[f](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) {
+                const double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
+                double t = fr + vt[f](i, j, k, n) - gt[f](i, j, k, n);
+                t /= rho;
+                tt[f](i, j, k, n) = t;
+            }
+        });
+    }
+    const int iconserv[3] = {0, 0, 0};
+    MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, nullptr);
+}
+
+void NavierStokes::scalar_advection(double dt_)
+{
+    SectionTimer tm(*this, 2);
+    MultiFab& So = S[1 - inew];
+    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
+    fillpatch(Smf, So, Density, NUM_SCALARS);
+    floor_small(Smf);
+    MultiFab tf(layout, cell_type(), NUM_SCALARS, 1), divu(layout, cell_type(), 1, 1);
+    tf.setVal(0.0); divu.setVal(0.0);
+    {
+        // getForce = 0 and visc = 0 for the (non-diffusive) scalars; keep the reference's arithmetic
+        const FabD *tt = tf.d_tab, *st = Smf.d_tab;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rho = st[f](i, j, k, 0);
+            tt[f](i, j, k, 0) += 0.0;
+            tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + 0.0;
+        });
+    }
+    const int iconserv[2] = {1, 0};
+    MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr);
+}
+
+void NavierStokes::scalar_update_rho(double dt_)
+{
+    SectionTimer tm(*this, 3);
+    const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        nt[f](i, j, k, Density) = ot[f](i, j, k, Density) - dt_ * at[f](i, j, k, Density);
+    });
+    fillpatch(rho_ctime, S[inew], Density, 1);                        // make_rho_curr_time
+    {   // get_rho_half_time (NavierStokesBase.cpp:1561-1565)
+        const FabD *ht = rho_half.d_tab, *pt = rho_ptime.d_tab, *ct = rho_ctime.d_tab;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            ht[f](i, j, k, 0) = 0.5 * (pt[f](i, j, k, 0) + ct[f](i, j, k, 0));
+        });
+    }
+}
+
+void NavierStokes::scalar_update_tracers(double dt_)
+{
+    SectionTimer tm(*this, 3);
+    const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const double rho = ot[f](i, j, k, Density) - 0.5 * dt_ * at[f](i, j, k, Density);
+        const double tfv = 0.0;
+        nt[f](i, j, k, Tracer) = ot[f](i, j, k, Tracer) + dt_ * (-at[f](i, j, k, Tracer) + tfv / rho);
+    });
+}
+
+void NavierStokes::velocity_advection_update(double dt_)
+{
+    SectionTimer tm(*this, 3);
+    const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_half.d_tab;
+    const double grav = p.gravity;
+    const bool zero_force = initial_iter && is_diffusive_vel();
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const double scal_rho = 0.5 * (ot[f](i, j, k, Density) + nt[f](i, j, k, Density));
+        const double rh = rt[f](i, j, k, 0);
+        for (int n = 0; n < 3; ++n) {
+            double force = (fabs(grav) > 0.0001 && n == 2) ? grav * scal_rho : 0.0;
+            if (zero_force) force = 0.0;
+            const double velold = ot[f](i, j, k, n);
+            nt[f](i, j, k, n) = velold - dt_ * at[f](i, j, k, n) + dt_ * force / rh - dt_ * gt[f](i, j, k, n) / rh;
+        }
+    });
+}
+
+void NavierStokes::initial_velocity_diffusion_update(double dt_)
+{
+    if (!is_diffusive_vel()) return;
+    SectionTimer tm(*this, 4);
+    MultiFab& So = S[1 - inew];
+    MultiFab visc(layout, cell_type(), 3, 1);
+    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    const FabD *nt = S[inew].d_tab, *ot = So.d_tab, *at = aofs.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_half.d_tab, *vt = visc.d_tab;
+    const double grav = p.gravity;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        for (int n = 0; n < 3; ++n) {
+            double force = (fabs(grav) > 0.0001 && n == 2) ? grav * ot[f](i, j, k, Density) : 0.0;
+            force += vt[f](i, j, k, n) - gt[f](i, j, k, n);
+            force /= rt[f](i, j, k, 0);
+            force -= at[f](i, j, k, n);
+            nt[f](i, j, k, n) = ot[f](i, j, k, n) + force * dt_;
+        }
+    });
+}
+
+void NavierStokes::velocity_diffusion_update(double dt_)
+{
+    if (!is_diffusive_vel()) return;
+    SectionTimer tm(*this, 4);
+    const double theta = p.be_cn_theta;
+    MultiFab& Sn = S[inew];
+    MultiFab& So = S[1 - inew];
+    const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
+    MultiFab Rhs(layout, cell_type(), 3, 0);
+    if (theta != 1.0) {
+        MultiFab Soln0(layout, cell_type(), 3, 1);
+        fillpatch(Soln0, So, Xvel, 3);
+        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc);
+    } else Rhs.setVal(0.0);
+    {
+        const FabD *nt = Sn.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            for (int n = 0; n < 3; ++n) {
+                nt[f](i, j, k, n) *= ht[f](i, j, k, 0);          // Diffusion.cpp:825: the state holds rho u* from here on
+                rt[f](i, j, k, n) += nt[f](i, j, k, n);
+            }
+        });
+    }
+    double avg = 0.0;                                            // get_scaled_abs_tol (Diffusion.cpp:193-204)
+    for (int n = 0; n < 3; ++n) avg += (1.0 / 3.0) * Rhs.norm0(n, 1, 0);
+    const double tol_abs = p.visc_tol * avg;
+    MultiFab Soln(layout, cell_type(), 3, 1);
+    fillpatch(Soln, Sn, Xvel, 3);                                // initial guess = FillPatch(U_new) = rho u*
+    MultiFab acoef(layout, cell_type(), 1, 0);
+    MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);                 // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
+    MGOpts vo = o;
+    vo.maxorder = 2;
+    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, p.visc_tol, tol_abs, vo);
+    MultiFab::Copy(Sn, Soln, 0, Xvel, 3, 1);                     // Diffusion.cpp:928
+}
+
+void NavierStokes::level_project(double dt_)
+{
+    SectionTimer tm(*this, 5);
+    MultiFab& Sn = S[inew];
+    MultiFab& Pn = P[pnew];
+    Pn.setVal(0.0, 0, 1, 0);                                     // Projection.cpp:236-256 (level 0: valid nodes)
+    mf_mult(Sn, 1.0 / dt_, Xvel, 3, 1);                          // U_new *= 1/dt (:273)
+    {
+        const FabD *nt = Sn.d_tab, *gt = Gp[1 - pnew].d_tab, *ht = rho_half.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) += gt[f](i, j, k, n) / ht[f](i, j, k, 0);   // :296-300
+        });
+    }
+    MultiFab sig(layout, cell_type(), 1, 1);                     // scaleVar: sigma = 1/rho_half (restored implicitly: rho_half untouched)
+    {
+        const FabD *st = sig.d_tab, *ht = rho_half.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            st[f](i, j, k, 0) = 1.0 / ht[f](i, j, k, 0);
+        });
+    }
+    st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+    mf_mult(Sn, dt_, Xvel, 3, 1);                                // U_new *= dt (:438)
+}
+
+void NavierStokes::initial_velocity_project()
+{
+    if (p.init_vel_iter <= 0) { P[1 - pnew].setVal(0.0); Gp[1 - pnew].setVal(0.0); return; }
+    for (int iter = 0; iter < p.init_vel_iter; ++iter) {
+        MultiFab& phi = P[1 - pnew];
+        phi.setVal(0.0);
+        MultiFab sig(layout, cell_type(), 1, 1);
+        sig.setVal(1.0);                                         // constant-density initial projection (rho_wgt_vel_proj = 0)
+        st_nodal = nodal_projection(g, S[inew], Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+        for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }   // Projection.cpp:799-806
+    }
+}
+
+void NavierStokes::initial_sync_project(double dt_)
+{
+    MultiFab& phi = P[1 - pnew];
+    phi.setVal(0.0);
+    MultiFab& Sn = S[inew];
+    MultiFab& So = S[1 - inew];
+    {
+        const double dt_inv = 1. / dt_;
+        const FabD *nt = Sn.d_tab, *ot = So.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) = (nt[f](i, j, k, n) - ot[f](i, j, k, n)) * dt_inv;   // ConvertUnew
+        });
+    }
+    MultiFab sig(layout, cell_type(), 1, 1);
+    {
+        const FabD *st = sig.d_tab, *ht = rho_half.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            st[f](i, j, k, 0) = 1.0 / ht[f](i, j, k, 0);
+        });
+    }
+    st_nodal = nodal_projection(g, Sn, Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], true);
+    mf_saxpy(P[pnew], 1.0, phi, 0, 0, 1, 1);                     // P_new += phi (Projection.cpp:1176-1180)
+}
+
+double NavierStokes::advance(double dt_)
+{
+    advance_setup();
+    const double dt_test = predict_velocity(dt_);
+    mac_project(dt_);
+    velocity_advection(dt_);
+    scalar_advection(dt_);
+    scalar_update_rho(dt_);
+    scalar_update_tracers(dt_);
+    velocity_advection_update(dt_);
+    if (!initial_iter) velocity_diffusion_update(dt_);
+    else initial_velocity_diffusion_update(dt_);
+    if (!initial_step) level_project(dt_);
+    return dt_test;
+}
+
+void NavierStokes::post_init(double stop_time)
+{
+    initial_velocity_project();
+    initial_step = true;
+    double dt_init = p.init_shrink * estTimeStep();
+    if (stop_time >= 0.0) {
+        const double eps = 0.0001 * dt_init;
+        if (time + dt_init > stop_time - eps) dt_init = stop_time - time;
+    }
+    dt = dt_init;
+    if (p.init_iter > 0) {
+        initial_iter = true;
+        for (int iter = 0; iter < p.init_iter; ++iter) {
+            advance(dt_init);
+            initial_sync_project(dt_init);
+            inew = 1 - inew;                                     // resetState: new <- initial data
+            MultiFab::Copy(P[1 - pnew], P[pnew], 0, 0, 1, 1);    // initOldFromNew(Press_Type)
+            MultiFab::Copy(Gp[1 - pnew], Gp[pnew], 0, 0, 3, 1);  // initOldFromNew(Gradp_Type)
+            initial_iter = false;
+        }
+    }
+    initial_step = false;
+    dt_min_adv = 1.e200;
+}
+
+double NavierStokes::step()
+{
+    double dt_ = dt;
+    if (nstep > 0) {
+        double dt_min = std::min(dt_min_adv, estTimeStep());
+        if (p.fixed_dt <= 0.0) dt_min = std::min(dt_min, p.change_max * dt);
+        dt_ = dt_min;
+    }
+    dt = dt_;
+    dt_min_adv = advance(dt_);
+    time += dt_;
+    nstep += 1;
+    return dt_;
+}
+
+}  // namespace iamrx

@@ -1,0 +1,230 @@
+// iamr_amd/csrc/nodalmg.hip -- nodal multigrid driver (MLMG on MLNodeLaplacian semantics) over the HIP
+// kernels of k_nodal.hip.  Reference call site: Source/Projection.cpp:2512-2542 (NodalProjector::project
+// with Gauss-Seidel on, harmonic average off, max_fmg_iter 0, proj_tol 1e-12 / sync_tol 1e-10).
+#include "mlmg.h"
+#include "launch.h"
+#include <chrono>
+#include <cmath>
+
+namespace iamrx {
+
+// kernels (k_nodal.hip)
+void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
+void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
+void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
+void nodal_restrict(MultiFab& crse, const MultiFab& fine);
+void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
+
+NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MGOpts& o) : m_g(g), m_bc(bc), m_o(o)
+{
+    for (int d = 0; d < 3; ++d) {
+        if (!g.periodic[d] && (bc.lo[d] == lo_dirichlet || bc.hi[d] == lo_dirichlet)) m_singular = false;
+        if (!g.periodic[d]) throw Error("iamrx NodalMG: non-periodic boundaries not implemented yet");
+    }
+    m_lev.resize(1);
+    m_lev[0].g = g;
+    m_lev[0].layout = std::move(layout);
+    while ((int)m_lev.size() <= m_o.max_coarsening_level) {
+        Level& f = m_lev.back();
+        bool dom_ok = true;
+        for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
+        if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
+        Level c;
+        c.g = f.g;
+        c.g.domain = coarsen(f.g.domain, 2);
+        for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
+        c.layout = f.layout->coarsened(2);
+        m_lev.push_back(std::move(c));
+    }
+    for (auto& L : m_lev) {
+        L.sig.define(L.layout, cell_type(), 1, 1);
+        L.cor.define(L.layout, node_type(), 1, 1);
+        L.res.define(L.layout, node_type(), 1, 1);
+        L.rescor.define(L.layout, node_type(), 1, 1);
+        L.cor.setVal(0.0); L.res.setVal(0.0); L.rescor.setVal(0.0);
+    }
+}
+
+void NodalMG::setSigma(const MultiFab& sig, int comp)
+{
+    MultiFab::Copy(m_lev[0].sig, sig, comp, 0, 1, 0);
+    m_lev[0].sig.FillBoundary(m_lev[0].g);
+    for (size_t l = 1; l < m_lev.size(); ++l) {
+        cc_restrict(m_lev[l].sig, m_lev[l - 1].sig);      // arithmetic average (harmonic averaging off)
+        m_lev[l].sig.FillBoundary(m_lev[l].g);
+    }
+}
+
+void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
+{
+    Level& L = m_lev[l];
+    for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
+        if (m_o.nodal_smoother == 0) {
+            for (int color = 0; color < 8; ++color) {
+                x.FillBoundary(L.g);
+                nodal_gs_color(L.g, x, rhs, L.sig, color);
+            }
+        } else {
+            if (!L.tmp.defined()) L.tmp.define(L.layout, node_type(), 1, 1);
+            x.FillBoundary(L.g);
+            nodal_jacobi(L.g, L.tmp, x, rhs, L.sig);
+            MultiFab::Copy(x, L.tmp, 0, 0, 1, 0);
+        }
+    }
+    x.FillBoundary(L.g);
+}
+
+void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b)
+{
+    x.FillBoundary(m_lev[l].g);
+    nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b);
+}
+
+void NodalMG::subtract_mean(int l, MultiFab& mf)
+{
+    const Geometry& g = m_lev[l].g;
+    double cnt = 1.0;
+    for (int d = 0; d < 3; ++d) cnt *= (double)(g.domain.len(d) + (g.periodic[d] ? 0 : 1));
+    const double s = mf.sum_unique(g, 0);
+    mf_add_scalar(mf, -s / cnt, 0, 1, 0);
+}
+
+int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters)
+{
+    Level& L = m_lev[l];
+    const Geometry& g = L.g;
+    auto mk = [&](int ng) { return MultiFab(L.layout, node_type(), 1, ng); };
+    MultiFab ph = mk(1), sh = mk(1), sorig = mk(0), p = mk(0), r = mk(0), s = mk(0), rh = mk(0), v = mk(0), t = mk(0);
+    ph.setVal(0.0); sh.setVal(0.0);
+    residual(l, r, sol, rhs);
+    MultiFab::Copy(sorig, sol, 0, 0, 1, 0);
+    MultiFab::Copy(rh, r, 0, 0, 1, 0);
+    sol.setVal(0.0);
+    double rnorm = r.norm0(0, 1, 0);
+    const double rnorm0 = rnorm;
+    int ret = 0, nit = 1;
+    double rho_1 = 0, alpha = 0, omega = 0;
+    if (rnorm0 == 0 || rnorm0 < eps_abs) { niters = 0; MultiFab::Copy(sol, sorig, 0, 0, 1, 0); return 0; }
+    for (; nit <= m_o.bottom_maxiter; ++nit) {
+        double rho;
+        { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&r}; reduce_dots(1, xs, ys, 0, 1, g, &rho); }
+        if (rho == 0) { ret = 1; break; }
+        if (nit == 1) MultiFab::Copy(p, r, 0, 0, 1, 0);
+        else {
+            const double beta = (rho / rho_1) * (alpha / omega);
+            mf_lincomb(p, 1.0, p, -omega, v, 0, 1, 0);
+            mf_lincomb(p, 1.0, r, beta, p, 0, 1, 0);
+        }
+        MultiFab::Copy(ph, p, 0, 0, 1, 0);
+        ph.FillBoundary(g);
+        nodal_residual(g, v, ph, L.sig, nullptr);
+        double rhTv;
+        { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&v}; reduce_dots(1, xs, ys, 0, 1, g, &rhTv); }
+        if (rhTv != 0) alpha = rho / rhTv; else { ret = 2; break; }
+        mf_lincomb(sol, 1.0, sol, alpha, ph, 0, 1, 0);
+        mf_lincomb(s, 1.0, r, -alpha, v, 0, 1, 0);
+        rnorm = s.norm0(0, 1, 0);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        MultiFab::Copy(sh, s, 0, 0, 1, 0);
+        sh.FillBoundary(g);
+        nodal_residual(g, t, sh, L.sig, nullptr);
+        double tv[2];
+        { const MultiFab* xs[2] = {&t, &t}; const MultiFab* ys[2] = {&t, &s}; reduce_dots(2, xs, ys, 0, 1, g, tv); }
+        if (tv[0] != 0) omega = tv[1] / tv[0]; else { ret = 3; break; }
+        mf_lincomb(sol, 1.0, sol, omega, sh, 0, 1, 0);
+        mf_lincomb(r, 1.0, s, -omega, t, 0, 1, 0);
+        rnorm = r.norm0(0, 1, 0);
+        if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
+        if (omega == 0) { ret = 4; break; }
+        rho_1 = rho;
+    }
+    if (ret == 0 && rnorm > eps_rel * rnorm0 && rnorm > eps_abs) ret = 8;
+    if ((ret == 0 || ret == 8) && rnorm < rnorm0) mf_lincomb(sol, 1.0, sol, 1.0, sorig, 0, 1, 0);
+    else { sol.setVal(0.0); mf_lincomb(sol, 1.0, sol, 1.0, sorig, 0, 1, 0); }
+    niters = nit;
+    return ret;
+}
+
+void NodalMG::vcycle(MGStats& st)
+{
+    const int nl = (int)m_lev.size();
+    for (int l = 0; l < nl - 1; ++l) {
+        Level& L = m_lev[l];
+        L.cor.setVal(0.0);
+        for (int i = 0; i < m_o.nu1; ++i) smooth(l, L.cor, L.res);
+        residual(l, L.rescor, L.cor, L.res);
+        L.rescor.FillBoundary(L.g);
+        nodal_restrict(m_lev[l + 1].res, L.rescor);
+    }
+    {
+        const int l = nl - 1;
+        Level& B = m_lev[l];
+        B.cor.setVal(0.0);
+        if (m_o.bottom_smoother_only) {
+            for (int i = 0; i < m_o.nuf; ++i) smooth(l, B.cor, B.res);
+        } else {
+            MultiFab rb(B.layout, node_type(), 1, 0);
+            MultiFab::Copy(rb, B.res, 0, 0, 1, 0);
+            if (m_singular) subtract_mean(l, rb);
+            int nit = 0;
+            const int ret = bicgstab(l, B.cor, rb, m_o.bottom_reltol, -1.0, nit);
+            st.bottom_iters_total += nit;
+            if (ret != 0) {
+                B.cor.setVal(0.0);
+                for (int i = 0; i < m_o.nuf; ++i) smooth(l, B.cor, B.res);
+            }
+            const int nn = ret == 0 ? m_o.nub : m_o.nuf;
+            for (int i = 0; i < nn; ++i) smooth(l, B.cor, B.res);
+        }
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        Level& L = m_lev[l];
+        m_lev[l + 1].cor.FillBoundary(m_lev[l + 1].g);
+        nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
+        for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res);
+    }
+}
+
+MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)
+{
+    auto& ctx = Context::get();
+    MGStats st;
+    st.nlevels = (int)m_lev.size();
+    Level& L0 = m_lev[0];
+    MultiFab rhs(L0.layout, node_type(), 1, 0);
+    MultiFab::Copy(rhs, rhs_in, 0, 0, 1, 0);
+    if (m_singular) subtract_mean(0, rhs);
+    residual(0, L0.res, phi, rhs);
+    st.resnorm0 = L0.res.norm0(0, 1, 0);
+    st.rhsnorm0 = rhs.norm0(0, 1, 0);
+    const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
+    const double res_target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
+    st.resnorm = st.resnorm0;
+    if (m_o.verbose) printf("iamrx nodal MLMG: rhs %.6e resid0 %.6e levels %d\n", st.rhsnorm0, st.resnorm0, st.nlevels);
+    double vc_ms = 0.0;
+    if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
+    else {
+        const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
+        for (int iter = 0; iter < maxit; ++iter) {
+            if (m_singular) subtract_mean(0, L0.res);
+            ctx.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            vcycle(st);
+            ctx.sync();
+            vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            mf_saxpy(phi, 1.0, L0.cor, 0, 0, 1, 0);
+            residual(0, L0.res, phi, rhs);
+            st.resnorm = L0.res.norm0(0, 1, 0);
+            st.iters = iter + 1;
+            if (m_o.verbose) printf("iamrx nodal MLMG: iter %d resid %.6e\n", iter + 1, st.resnorm);
+            if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
+            if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx nodal MLMG: failing to converge (residual blow-up)");
+        }
+        if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx nodal MLMG: failed to converge after max_iters");
+    }
+    if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
+    phi.FillBoundary(L0.g);
+    return st;
+}
+
+}  // namespace iamrx

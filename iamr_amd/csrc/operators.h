@@ -1,5 +1,5 @@
 // iamr_amd/csrc/operators.h -- host-side operator layer keeping IAMR's operator API surface
-// (MacProj / Projection / Diffusion / NavierStokesBase), SURVEY 8(b).
+// (MacProj / Projection / Diffusion / NavierStokesBase::advance), SURVEY 8(b).
 #pragma once
 #include "mf.h"
 #include "mlmg.h"
@@ -7,9 +7,85 @@
 
 namespace iamrx {
 
-// MacProj::mlmg_mac_solve (reference Source/MacProj.H:82-94, Source/MacProj.cpp:1084-1184)
+// ---- MacProj (reference Source/MacProj.H:36-94) ------------------------------------------------------
+// MacProj::mlmg_mac_solve (Source/MacProj.cpp:1084-1184)
 MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFab& rho, int rho_comp, const MultiFab* S,
                        MultiFab& mac_phi, double rhs_scale, const DomainBC& bc, double mac_tol, double mac_abs_tol,
                        const MGOpts& opts, MultiFab* const fluxes[3]);
+
+// ---- Projection (reference Source/Projection.H:53-134, 244-254) --------------------------------------
+// Projection::doMLMGNodalProjection (Source/Projection.cpp:2385-2567), single level:
+// rhs = div(vel) at nodes, solve div(sig grad phi) = rhs, vel -= sig grad phi, Gp = / += grad phi.
+MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& phi, const MultiFab& sig, int sig_comp,
+                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp);
+
+// ---- Diffusion (reference Source/Diffusion.H:53-225) -------------------------------------------------
+// explicit viscous terms div tau(U): Diffusion::getTensorViscTerms (Source/Diffusion.cpp:1655-1777): out = -b * L_tensor(U), a = 0
+void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel /*3 comps, 1 ghost; BC data in ghosts*/, double a_scalar, double b_scalar,
+                  const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC& bc);
+// Crank-Nicolson implicit solve (a*acoef - b div tau) u = rhs: Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929)
+MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
+                     const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts);
+
+// ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
+struct NSParams {
+    double cfl = 0.8, visc_coef = 0.0, be_cn_theta = 0.5, gravity = 0.0;
+    double mac_tol = 1.e-12, mac_abs_tol = 1.e-16, proj_tol = 1.e-12, proj_abs_tol = 1.e-16, visc_tol = 1.e-10;
+    int use_forces_in_trans = 0, do_mom_diff = 0, init_iter = 2, init_vel_iter = 1;
+    double init_shrink = 1.0, change_max = 1.1, fixed_dt = -1.0;
+    int nscal = 2, verbose = 0;
+};
+
+enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
+
+class NavierStokes {
+public:
+    NavierStokes(const Geometry& g, LayoutP layout, const NSParams& p, const MGOpts& o);
+    void init_taylorgreen(double vfac, double a, double b, double c, double rho0);   // Source/prob/prob_init.cpp:509-560
+    void post_init(double stop_time);          // NavierStokes::post_init
+    double step();                             // Amr::coarseTimeStep on one level: computeNewDt + advance
+    double advance(double dt);                 // NavierStokes::advance; returns the dt estimate
+    double estTimeStep();                      // NavierStokesBase::estTimeStep
+    MultiFab& get_new_data(int type) { return type == 0 ? S[inew] : (type == 1 ? P[pnew] : Gp[pnew]); }
+    MultiFab& get_old_data(int type) { return type == 0 ? S[1 - inew] : (type == 1 ? P[1 - pnew] : Gp[1 - pnew]); }
+    MultiFab& umac(int d) { return u_mac[d]; }
+    MultiFab& Aofs() { return aofs; }
+    double time = 0.0, dt = 0.0;
+    int nstep = 0;
+    MGStats st_mac, st_nodal, st_visc;
+    double t_sections[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // accumulated ms: predict, mac, advect, update, visc, nodal
+    bool profile_sections = false;
+
+private:
+    void advance_setup();
+    double predict_velocity(double dt);
+    void mac_project(double dt);
+    void velocity_advection(double dt);
+    void scalar_advection(double dt);
+    void scalar_update_rho(double dt);
+    void scalar_update_tracers(double dt);
+    void velocity_advection_update(double dt);
+    void velocity_diffusion_update(double dt);
+    void initial_velocity_diffusion_update(double dt);
+    void level_project(double dt);
+    void initial_velocity_project();
+    void initial_sync_project(double dt);
+    void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
+    void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp);
+    bool is_diffusive_vel() const { return p.visc_coef > 0.0; }
+
+    Geometry g;
+    LayoutP layout;
+    NSParams p;
+    MGOpts o;
+    MultiFab S[2], P[2], Gp[2];
+    int inew = 0, pnew = 0;
+    MultiFab u_mac[3], aofs, rho_ptime, rho_ctime, rho_half;
+    MultiFab eta[3];
+    double dt_min_adv = 1.e200;
+    bool initial_step = false, initial_iter = false;
+    DomainBC bc_mac, bc_nodal, bc_visc;
+    BCRec bc_vel[3], bc_scal[2];
+};
 
 }  // namespace iamrx

@@ -1,0 +1,73 @@
+// iamr_amd/csrc/projection.hip -- nodal (approximate) projection and tensor-diffusion operator wrappers.
+//
+// nodal_projection mirrors Projection::doMLMGNodalProjection (reference Source/Projection.cpp:2385-2567)
+// for one level: Hydro::NodalProjector computes rhs = div(vel) at nodes (velocity ghost cells filled
+// first), solves div(sigma grad phi) = rhs with MLNodeLaplacian/MLMG, updates vel -= sigma grad phi, and
+// Gradp is REPLACED (increment_gp = false: level / initial velocity projections) or INCREMENTED
+// (true: sync projections) with grad phi (:2549-2563), followed by a ghost fill of Gradp (:2564-2565).
+//
+// tensor_apply / tensor_solve mirror the MLTensorOp set-up of Diffusion::getTensorViscTerms
+// (Source/Diffusion.cpp:1655-1777) and Diffusion::diffuse_tensor_velocity (:650-957).
+#include "operators.h"
+#include "launch.h"
+
+namespace iamrx {
+
+MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& phi, const MultiFab& sig, int sig_comp,
+                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp)
+{
+    LayoutP layout = phi.layout;
+    // set_boundary_velocity + periodic fill of the velocity ghost cells
+    vel.FillBoundary(g, vcomp, 3);
+    NodalMG mg(g, layout, bc, opts);
+    mg.setSigma(sig, sig_comp);
+    MultiFab rhs(layout, node_type(), 1, 0);
+    nodal_divu(g, rhs, vel, vcomp);
+    MGStats st = mg.solve(phi, rhs, rel_tol, abs_tol);
+    nodal_mknewu(g, &vel, vcomp, phi, &mg.sigma(0), gp, increment_gp);
+    if (gp) gp->FillBoundary(g);
+    return st;
+}
+
+static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], LayoutP layout, double a_scalar, double b_scalar,
+                         const MultiFab* acoef, const MultiFab* const eta[3])
+{
+    for (int d = 0; d < 3; ++d) {
+        tb[d].define(layout, face_type(d), 3, 0);
+        tensor_bcoef(tb[d], *eta[d], d);
+        bp[d] = &tb[d];
+    }
+    mg.setScalars(a_scalar, b_scalar);
+    if (acoef) mg.setACoeffs(acoef);
+    mg.setBCoeffs(bp);
+    mg.setTensor(true);
+}
+
+void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
+                  const MultiFab* const eta[3], const DomainBC& bc)
+{
+    MGOpts o;
+    o.max_coarsening_level = 0;      // info.setMaxCoarseningLevel(0) (Diffusion.cpp:708)
+    o.maxorder = bc.maxorder;
+    CellMG mg(g, vel.layout, 3, bc, o);
+    MultiFab tb[3];
+    const MultiFab* bp[3];
+    setup_tensor(mg, tb, bp, vel.layout, a_scalar, b_scalar, acoef, eta);
+    mg.prepare();
+    mg.apply(out, vel);
+}
+
+MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
+                     const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
+{
+    MGOpts o = opts;
+    o.maxorder = bc.maxorder;
+    CellMG mg(g, soln.layout, 3, bc, o);
+    MultiFab tb[3];
+    const MultiFab* bp[3];
+    setup_tensor(mg, tb, bp, soln.layout, a_scalar, b_scalar, acoef, eta);
+    mg.prepare();
+    return mg.solve(soln, rhs, tol_rel, tol_abs);
+}
+
+}  // namespace iamrx

@@ -123,6 +123,55 @@ int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, ia
                                const int* bcrec /* [ncomp][6] */, int is_velocity, int use_forces_in_trans,
                                iamrx_mf edge_x, iamrx_mf edge_y, iamrx_mf edge_z, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
 
+/* ---- nodal projection (amrex::MLNodeLaplacian / Hydro::NodalProjector role) ------- */
+/* out = rhs - div(sig grad phi) at nodes (rhs == NULL: out = div(sig grad phi)); phi and sig need 1 filled ghost */
+int iamrx_nodal_residual(const iamrx_geom* g, iamrx_mf out, iamrx_mf phi, iamrx_mf sig, iamrx_mf rhs);
+/* one colour (0..7) of the 8-colour Gauss-Seidel sweep */
+int iamrx_nodal_gs_color(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int color);
+int iamrx_nodal_restrict(iamrx_mf crse, iamrx_mf fine);
+int iamrx_nodal_interp_add(iamrx_mf fine, iamrx_mf crse, iamrx_mf sig_fine);
+int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp);
+/* MLNodeLaplacian::compGrad as used by NavierStokesBase::computeGradP (Source/NavierStokesBase.cpp:4102-4122) */
+int iamrx_nodal_compgrad(const iamrx_geom* g, iamrx_mf gp, iamrx_mf phi);
+/* Projection::doMLMGNodalProjection, one level (Source/Projection.cpp:2385-2567; declaration Source/Projection.H:244-254):
+ * rhs = div(vel), solve div(sig grad phi) = rhs, vel -= sig grad phi, gp = (increment_gp ? += : =) grad phi */
+int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_mf phi, iamrx_mf sig, int sig_comp,
+                           const int lobc[3], const int hibc[3], double rel_tol, double abs_tol, const iamrx_mg_opts* o,
+                           iamrx_mf gp /* may be NULL */, int increment_gp, iamrx_mg_stats* st);
+
+/* ---- tensor diffusion (amrex::MLTensorOp role) -------------------------------------- */
+/* out = (a*acoef - b div tau(vel)); Diffusion::getTensorViscTerms uses a = 0, b = -1 (Source/Diffusion.cpp:1697-1698).
+ * eta_*: face viscosity (1 comp); vel: 3 comps, 1 ghost */
+int iamrx_tensor_apply(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
+                       iamrx_mf eta_y, iamrx_mf eta_z, const int lobc[3], const int hibc[3], int maxorder);
+/* implicit Crank-Nicolson solve of Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929) */
+int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
+                       iamrx_mf eta_y, iamrx_mf eta_z, const int lobc[3], const int hibc[3], double tol_rel, double tol_abs,
+                       const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
+/* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */
+typedef struct iamrx_ns_params {
+    double cfl, visc_coef, be_cn_theta, gravity;
+    double mac_tol, mac_abs_tol, proj_tol, proj_abs_tol, visc_tol;
+    int use_forces_in_trans, do_mom_diff, init_iter, init_vel_iter;
+    double init_shrink, change_max, fixed_dt;
+    int nscal, verbose;
+} iamrx_ns_params;
+void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */
+int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);
+int iamrx_ns_destroy(iamrx_ns ns);
+int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, double c, double rho0);  /* Source/prob/prob_init.cpp:509-560 */
+int iamrx_ns_post_init(iamrx_ns ns, double stop_time);     /* NavierStokes::post_init (Source/NavierStokes.cpp:1254-1299) */
+int iamrx_ns_step(iamrx_ns ns, double* dt_used);           /* computeNewDt + NavierStokes::advance (Source/NavierStokes.cpp:543-691) */
+int iamrx_ns_advance(iamrx_ns ns, double dt, double* dt_est);
+int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep);
+/* snapshot COPY (caller destroys it with iamrx_mf_destroy) of a persistent array: 0 S_new, 1 S_old, 2 P_new,
+ * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role) */
+int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
+int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc);
+/* per-section wall time accumulation (ms): predict, mac, advect, update, viscous, nodal; enable=1 inserts stream syncs */
+int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8]);
+
 #ifdef __cplusplus
 }
 #endif
