@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native IAMR hot path.
+
+Metric (BASELINE.json): cells-advanced/sec (whole node) + MLMG V-cycle ms, 256^3 TaylorGreen.
+A "step" = one full NavierStokes::advance (predict_velocity, MAC projection, velocity + scalar
+advection, updates, Crank-Nicolson tensor diffusion solve, nodal level projection) of the
+TaylorGreen 3-D problem (reference Tutorials/TaylorGreen/inputs.3d.taylorgreen: nu = 1e-4, cfl 0.7,
+init_iter 2, Godunov_PLM), one 256^3 box per GPU (weak scaling: rank r owns box r of an N-box level).
+Inputs are generated on the device (closed-form initial condition), so the timed region starts with
+everything resident in HBM.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--no-cpu-baseline]
+For N > 1 launch with  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256, help="cells per direction of the per-GPU box")
+    ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def hip_event_time(lib, fn, reps):
+    """average device time (ms) of fn() over reps launches, HIP events recorded on the library's stream"""
+    L = lib.lib()
+    for _ in range(2):
+        fn()
+    lib.sync()
+    lib.check(L.iamrx_timer_start())
+    for _ in range(reps):
+        fn()
+    ms = C.c_double()
+    lib.check(L.iamrx_timer_stop(C.byref(ms)))
+    return ms.value / reps
+
+
+def kernel_rooflines(lib, n):
+    """live per-kernel timings (HIP events on the launch stream) of the roofline-graded kernels at the bench size"""
+    from iamr_amd import ns as N
+    import numpy as np
+    g = lib.Geom.make((n, n, n))
+    lay = lib.Layout.single((n, n, n))
+    cells = float(n) ** 3
+    out = {}
+    # ABec GSRB red+black sweep, variable b: 80 B/cell algorithmic
+    b = [lib.MultiFab(lay, lib.face(d), 1, 0) for d in range(3)]
+    for m in b:
+        m.setval(1.0)
+    phi = lib.MultiFab(lay, lib.CELL, 1, 1)
+    rhs = lib.MultiFab(lay, lib.CELL, 1, 0)
+    phi.setval(0.5)
+    rhs.setval(1.0)
+    t = hip_event_time(lib, lambda: (lib.abec_gsrb(g, 0.0, 1.0, None, b, phi, rhs, 0), lib.abec_gsrb(g, 0.0, 1.0, None, b, phi, rhs, 1)), 20)
+    out["abec_gsrb_sweep"] = {"ms": t, "alg_bytes_per_cell": 80, "GBps": 80 * cells / t / 1e6}
+    res = lib.MultiFab(lay, lib.CELL, 1, 0)
+    t = hip_event_time(lib, lambda: lib.abec_residual(g, 0.0, 1.0, None, b, res, phi, rhs), 20)
+    out["abec_residual"] = {"ms": t, "alg_bytes_per_cell": 48, "GBps": 48 * cells / t / 1e6}
+    del b, phi, rhs, res
+    # nodal 27-pt Gauss-Seidel sweep (8 colours): 32 B/node algorithmic
+    sig = lib.MultiFab(lay, lib.CELL, 1, 1)
+    sig.setval(1.0)
+    x = lib.MultiFab(lay, lib.NODE, 1, 1)
+    r = lib.MultiFab(lay, lib.NODE, 1, 1)
+    x.setval(0.25)
+    r.setval(1.0)
+    nodes = float(n + 1) ** 3
+
+    def gs_sweep():
+        for c in range(8):
+            N.nodal_gs_color(g, x, r, sig, c)
+    t = hip_event_time(lib, gs_sweep, 10)
+    out["nodal_gs_sweep"] = {"ms": t, "alg_bytes_per_node": 32, "GBps": 32 * nodes / t / 1e6}
+    del sig, x, r
+    # Godunov: ExtrapVelToFaces 72 B/cell, ComputeAofs velocity 104 B/cell
+    vel = lib.MultiFab(lay, lib.CELL, 3, 3)
+    frc = lib.MultiFab(lay, lib.CELL, 3, 1)
+    um = [lib.MultiFab(lay, lib.face(d), 1, 1) for d in range(3)]
+    vel.setval(0.3)
+    frc.setval(0.1)
+    dt = 0.3 / n
+    t = hip_event_time(lib, lambda: lib.godunov_extrap_vel_to_faces(g, vel, frc, um, dt), 10)
+    out["extrap_vel_to_faces"] = {"ms": t, "alg_bytes_per_cell": 72, "GBps": 72 * cells / t / 1e6}
+    aofs = lib.MultiFab(lay, lib.CELL, 5, 0)
+    divu = lib.MultiFab(lay, lib.CELL, 1, 1)
+    divu.setval(0.0)
+    t = hip_event_time(lib, lambda: lib.godunov_compute_aofs(g, aofs, 0, vel, 3, frc, divu, um, (0, 0, 0), dt, None, 1, 0), 10)
+    out["compute_aofs_vel"] = {"ms": t, "alg_bytes_per_cell": 104, "GBps": 104 * cells / t / 1e6}
+    return out
+
+
+def cpu_baseline(n, steps):
+    """the CPU oracle (scalar port of the reference algorithm, 1 core) timed on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    L = orc.lib()
+    g = orc.geom((n, n, n))
+    p = orc.CNsParams()
+    L.orc_ns_default_params(C.byref(p))
+    p.cfl = 0.7
+    p.visc_coef = 1e-4
+    p.init_iter = 2
+    o = orc.mg_opts()
+    s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
+    L.orc_ns_init_taylorgreen(s, C.c_double(1.0), C.c_double(1.0), C.c_double(1.0), C.c_double(1.0), C.c_double(1.0))
+    L.orc_ns_post_init(s, C.c_double(-1.0))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        L.orc_ns_step(s)
+    dt = time.perf_counter() - t0
+    L.orc_ns_destroy(s)
+    return {"value": n ** 3 * steps / dt, "unit": "cells-advanced/s", "cores": 1, "kind": "port",
+            "sample": f"TaylorGreen {n}^3 (same physics/settings), {steps} timed steps after post_init, oracle/liborc.so scalar C port, 1 core"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from iamr_amd import lib
+    from iamr_amd import ns as N
+    lib.init(local_rank)
+    if world > 1:
+        from iamr_amd import comm
+        comm.init_rccl_from_torch(dist)
+
+    n = a.n
+    # one n^3 box per GPU, stacked in z: level = world boxes (weak scaling)
+    ntot = (n, n, n * world)
+    boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(world)]
+    lay = lib.Layout(boxes, list(range(world)))
+    g = lib.Geom.make(ntot, prob_hi=(1.0, 1.0, float(world)))
+    params = N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0)
+    ns = N.NavierStokes(g, lay, params, lib.mg_opts())
+    ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
+    ns.post_init(-1.0)
+    for _ in range(a.warmup):
+        ns.step()
+
+    def barrier():
+        lib.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    mac_ms, nod_ms, visc_ms, mac_it, nod_it, visc_it = [], [], [], [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ns.step()
+        sm, sn, sv = ns.stats()
+        mac_ms.append(sm.vcycle_ms); nod_ms.append(sn.vcycle_ms); visc_ms.append(sv.vcycle_ms)
+        mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    cells_total = float(n) ** 3 * world
+    value = cells_total * a.steps / el
+
+    out = None
+    if rank == 0:
+        import statistics as st
+        # per-section breakdown (separate, synchronised pass so it does not perturb the timed region)
+        ns.profile(2)
+        for _ in range(2):
+            ns.step()
+        sec = ns.profile(0)
+        kr = kernel_rooflines(lib, n) if world == 1 else {}
+        # dominant kernel of the step (profiles/round1_*): the nodal Gauss-Seidel colour kernel
+        dom = kr.get("nodal_gs_sweep")
+        roofline = None
+        if dom:
+            roofline = {"kernel": "k_nodal_gscolor (8 colour passes = 1 Gauss-Seidel sweep)", "bound": "hbm",
+                        "achieved": dom["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": None,
+                        "algorithmic_bytes_per_launch": 32 * (n + 1) ** 3, "avg_ms": dom["ms"]}
+        out = {
+            "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"TaylorGreen 3D single level, one {n}^3 box per GPU ({ntot[0]}x{ntot[1]}x{ntot[2]} cells), periodic, "
+                                   f"nu=1e-4 cfl=0.7 Godunov_PLM be_cn_theta=0.5, full NavierStokes::advance per step",
+                       "cells": cells_total, "prob_c": a.c},
+            "mlmg_vcycle_ms": {"mac_cc": st.median(mac_ms), "nodal": st.median(nod_ms), "tensor_visc": st.median(visc_ms)},
+            "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
+            "sections_ms_per_step": {k: v / 2 for k, v in zip(["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"], sec[:6])},
+            "kernels": kr,
+            "roofline": roofline,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

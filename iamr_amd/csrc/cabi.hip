@@ -74,6 +74,25 @@ int iamrx_mem_info(size_t* live, size_t* cached)
     IAMRX_CATCH
 }
 
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+int iamrx_timer_start(void)
+{
+    IAMRX_TRY
+    if (!g_ev0) { IAMRX_HIP_CHECK(hipEventCreate(&g_ev0)); IAMRX_HIP_CHECK(hipEventCreate(&g_ev1)); }
+    IAMRX_HIP_CHECK(hipEventRecord(g_ev0, Context::get().stream));
+    IAMRX_CATCH
+}
+int iamrx_timer_stop(double* ms)
+{
+    IAMRX_TRY
+    IAMRX_HIP_CHECK(hipEventRecord(g_ev1, Context::get().stream));
+    IAMRX_HIP_CHECK(hipEventSynchronize(g_ev1));
+    float f = 0.f;
+    IAMRX_HIP_CHECK(hipEventElapsedTime(&f, g_ev0, g_ev1));
+    *ms = (double)f;
+    IAMRX_CATCH
+}
+
 void iamrx_mg_default_opts(iamrx_mg_opts* o)
 {
     MGOpts d;

@@ -13,7 +13,8 @@
 //                       lo/hi arrays), transverse terms + forcing + BCs + final upwinding.
 //   pass 3  k_aofs    : per cell: area-weighted fluxes, -div, convective correction, aofs = -update.
 // Only 3+3*ncomp face arrays are materialised in HBM between the passes.
-// All index shifts are done with linear strides so one code path serves the three directions.
+// The direction is a template parameter and all index shifts are linear strides, so every array index is
+// static after unrolling (no scratch memory); run-time parameters live in a small device-resident block.
 #include "kernels.h"
 #include "launch.h"
 
@@ -25,6 +26,18 @@ struct GodBC {
     int dlo[3], dhi[3];
     int per[3];
     BCRec bc[5];
+};
+
+struct GodParams {
+    double dt;
+    double dx[3];
+    int ncomp;
+    int is_velocity;
+    int fit;            // use_forces_in_trans
+    int has_force;
+    int has_divu;
+    int iconserv[5];
+    GodBC bc;
 };
 
 __device__ __forceinline__ double lim2(double dlft, double drgt)
@@ -131,94 +144,90 @@ __device__ __forceinline__ void trace_lohi(const double* __restrict__ qn /*state
     }
 }
 
-struct GodParams {
-    double dt;
-    double dx[3];
-    int ncomp;
-    int is_velocity;
-    int fit;            // use_forces_in_trans
-    int has_force;
-    int has_divu;
-    int iconserv[5];
-    GodBC bc;
-};
+template <int D> __device__ __forceinline__ long stride_of(const FabD& a)
+{
+    return D == 0 ? 1L : (D == 1 ? (long)a.n[0] : (long)a.n[0] * a.n[1]);
+}
 
 // -------------------------------------------------------------------------------- pass 1
 // grid over faces of direction D, transverse directions grown by 1.
 // PRED: writes ad[D] (1 comp) and e0[D] (ncomp comps, upwinded with ad).  ADV: mac given, writes e0[D].
-template <bool PRED>
-__global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict__ boxes, int D,
+template <bool PRED, int D>
+__global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ qt, const FabD* __restrict__ ft, const FabD* __restrict__ mact /*ADV: umac[D]; PRED: out ad[D]*/,
-    const FabD* __restrict__ e0t, GodParams P)
+    const FabD* __restrict__ e0t, const GodParams* __restrict__ Pp)
 {
+    const GodParams& P = *Pp;
     const int fab = blockIdx.y;
     BoxD b = boxes[fab];
+#pragma unroll
     for (int e = 0; e < 3; ++e) { if (e == D) b.hi[e] += 1; else { b.lo[e] -= 1; b.hi[e] += 1; } }
     int i, j, k0, k1;
     if (!tile_ijk(t, b, i, j, k0, k1)) return;
     const FabD q = qt[fab], e0 = e0t[fab], mac = mact[fab];
-    FabD frc; if (P.has_force) frc = ft[fab];
-    const long qs[3] = {1, q.n[0], (long)q.n[0] * q.n[1]};
-    const long s = qs[D];
+    const bool has_force = P.has_force != 0, fit = P.fit != 0;
+    FabD frc; if (has_force) frc = ft[fab];
+    const long s = stride_of<D>(q);
+    const long fs = has_force ? stride_of<D>(frc) : 0;
+    const double hdt = 0.5 * P.dt;
     const double dtdx = P.dt / P.dx[D];
     const int domlo = P.bc.dlo[D], domhi = P.bc.dhi[D];
     const bool nonper = !P.bc.per[D];
+    const int ncomp = P.ncomp;
+    const bool is_vel = P.is_velocity != 0;
     for (int k = k0; k <= k1; ++k) {
-        const int idx[3] = {i, j, k};
-        const int f = idx[D];
+        const int f = D == 0 ? i : (D == 1 ? j : k);
         const long qo = q.off(i, j, k);
-        double um = 0.0;
-        if (!PRED) um = mac(i, j, k, 0);
-        double lo[5], hi[5];
-        for (int n = 0; n < P.ncomp; ++n) {
-            const int bl = P.bc.bc[n].lo[D], bh = P.bc.bc[n].hi[D];
-            const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
-            trace_lohi<PRED>(q.p + qo + q.cs * n, q.p + qo + q.cs * D, s, um, dtdx, edlo, edhi, f, domlo, domhi, lo[n], hi[n]);
-            if (P.fit && P.has_force) {
-                const long fo = frc.off(i, j, k);
-                const long fs = D == 0 ? 1 : (D == 1 ? frc.n[0] : (long)frc.n[0] * frc.n[1]);
-                lo[n] += 0.5 * P.dt * frc.p[fo - fs + frc.cs * n];
-                hi[n] += 0.5 * P.dt * frc.p[fo + frc.cs * n];
-            }
-            if (nonper) trans_bc(q.p + qo + q.cs * n, s, f, P.is_velocity && n == D, lo[n], hi[n], bl, bh, domlo, domhi);
-        }
+        const long fo = has_force ? frc.off(i, j, k) : 0;
         double uad;
         if (PRED) {
-            const double l = lo[D], h = hi[D];
+            // advective velocity from the traced normal component
+            const int bl = P.bc.bc[D].lo[D], bh = P.bc.bc[D].hi[D];
+            const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
+            double l, h;
+            trace_lohi<true>(q.p + qo + q.cs * D, q.p + qo + q.cs * D, s, 0.0, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+            if (fit && has_force) { l += hdt * frc.p[fo - fs + frc.cs * D]; h += hdt * frc.p[fo + frc.cs * D]; }
+            if (nonper) trans_bc(q.p + qo + q.cs * D, s, f, is_vel, l, h, bl, bh, domlo, domhi);
             const double st = ((l + h) >= 0.) ? l : h;
             const bool ltm = ((l <= 0. && h >= 0.) || (fabs(l + h) < SMALL_VEL));
             uad = ltm ? 0. : st;
             mac(i, j, k, 0) = uad;
-        } else uad = um;
+        } else uad = mac(i, j, k, 0);
         const double fu = (fabs(uad) < SMALL_VEL) ? 0.0 : 1.0;
-        for (int n = 0; n < P.ncomp; ++n) {
-            const double st = (uad >= 0.) ? lo[n] : hi[n];
-            e0(i, j, k, n) = fu * st + (1.0 - fu) * 0.5 * (hi[n] + lo[n]);
+        for (int n = 0; n < ncomp; ++n) {
+            const int bl = P.bc.bc[n].lo[D], bh = P.bc.bc[n].hi[D];
+            const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
+            double l, h;
+            trace_lohi<PRED>(q.p + qo + q.cs * n, q.p + qo + q.cs * D, s, uad, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+            if (fit && has_force) { l += hdt * frc.p[fo - fs + frc.cs * n]; h += hdt * frc.p[fo + frc.cs * n]; }
+            if (nonper) trans_bc(q.p + qo + q.cs * n, s, f, is_vel && n == D, l, h, bl, bh, domlo, domhi);
+            const double st = (uad >= 0.) ? l : h;
+            e0(i, j, k, n) = fu * st + (1.0 - fu) * 0.5 * (h + l);
         }
     }
 }
 
-// corner-coupled, upwinded state on the T-face at index position (pointer offsets already applied):
-//   qn  : state comp n at the cell on the high side of the T-face
-//   lo/hi traced along T, corrected with the O-derivative built from mac[O] and e0[O], upwinded with mac[T]
+// corner-coupled, upwinded state on one T-face.  All pointers are already positioned:
+//   qn   : state comp n at the cell on the high side of the T-face (cell index == face index fT)
+//   vT   : vcc comp T at the same cell (PRED only)
+//   macO : mac[O] at that cell's low O-face;  eO : pass-1 state on that O-face (comp n)
 template <bool PRED>
 __device__ __forceinline__ double corner_state(const double* __restrict__ qn, const double* __restrict__ vT, long sT, int fT,
     double macT_f, const double* __restrict__ macO, long mOsT, long mOsO,
     const double* __restrict__ eO, long eOsT, long eOsO,
     const double* __restrict__ frcn, long fsT, double dtdxT, double c_o /* dt/(6 dxO) or dt/(3 dxO) */, double dt3, double dxO,
-    bool conserv, const double* __restrict__ divu, long dsT, bool has_divu,
+    bool conserv, const double* __restrict__ divu, long dsT,
     bool fit, double hdt, bool nonperT, bool normal_vel, int bl, int bh, int domlo, int domhi)
 {
     const bool edlo = nonperT && ed_or_ho(bl), edhi = nonperT && ed_or_ho(bh);
     double l, h;
     trace_lohi<PRED>(qn, vT, sT, macT_f, dtdxT, edlo, edhi, fT, domlo, domhi, l, h);
     if (fit && frcn) { l += hdt * frcn[-fsT]; h += hdt * frcn[0]; }
-    if (nonperT) trans_bc(qn, sT, fT, normal_vel, l, h, bl, bh, domlo, domhi);   // BCs of the traced states (pass 1 order)
-    // mac[O] / e0[O] at the low-side cell (cm = f - eT) and at the high-side cell (f), O-faces c and c+eO
+    if (nonperT) trans_bc(qn, sT, fT, normal_vel, l, h, bl, bh, domlo, domhi);   // BCs of the traced states (pass-1 order)
     const double mo_cm = macO[-mOsT], mo_cmo = macO[-mOsT + mOsO], mo_f = macO[0], mo_fo = macO[mOsO];
     const double eo_cm = eO[-eOsT], eo_cmo = eO[-eOsT + eOsO], eo_f = eO[0], eo_fo = eO[eOsO];
     if (conserv) {
-        const double dvl = has_divu ? divu[-dsT] : 0.0, dvh = has_divu ? divu[0] : 0.0;
+        const double dvl = divu ? divu[-dsT] : 0.0, dvh = divu ? divu[0] : 0.0;
         l = l - c_o * (eo_cmo * mo_cmo - eo_cm * mo_cm) + dt3 * qn[-sT] * ((mo_cmo - mo_cm) / dxO - 0.5 * dvl);
         h = h - c_o * (eo_fo * mo_fo - eo_f * mo_f) + dt3 * qn[0] * ((mo_fo - mo_f) / dxO - 0.5 * dvh);
     } else {
@@ -231,121 +240,131 @@ __device__ __forceinline__ double corner_state(const double* __restrict__ qn, co
     return fu * st + (1.0 - fu) * 0.5 * (h + l);
 }
 
+// the four corner states (low-side cell / high-side cell of the D-face) x (T-face c / c+1) for transverse direction T
+template <bool PRED, int D, int T>
+__device__ __forceinline__ void corner_quad(const GodParams& P, int n, bool conserv, int fT,
+    const double* __restrict__ qn, const double* __restrict__ qT, const FabD& q,
+    const FabD& mT, long mTo, const FabD& mO, long mOo, const FabD& eO, long eOo,
+    const double* __restrict__ frcn, const FabD& frc, const double* __restrict__ dvp, const FabD& dv,
+    double& Tl0, double& Tl1, double& Th0, double& Th1)
+{
+    constexpr int O = 3 - D - T;
+    const long qsD = stride_of<D>(q), qsT = stride_of<T>(q);
+    const long mTsD = stride_of<D>(mT), mTsT = stride_of<T>(mT);
+    const long mOsD = stride_of<D>(mO), mOsT = stride_of<T>(mO), mOsO = stride_of<O>(mO);
+    const long eOsD = stride_of<D>(eO), eOsT = stride_of<T>(eO), eOsO = stride_of<O>(eO);
+    const long fsD = frcn ? stride_of<D>(frc) : 0, fsT = frcn ? stride_of<T>(frc) : 0;
+    const long dsD = dvp ? stride_of<D>(dv) : 0, dsT = dvp ? stride_of<T>(dv) : 0;
+    const double c_o = conserv ? P.dt / (3.0 * P.dx[O]) : P.dt / (6.0 * P.dx[O]);
+    const double dt3 = P.dt / 3.0;
+    const double dtdxT = P.dt / P.dx[T];
+    const double hdt = 0.5 * P.dt;
+    const int bl = P.bc.bc[n].lo[T], bh = P.bc.bc[n].hi[T];
+    const bool nonperT = !P.bc.per[T];
+    const bool nvel = P.is_velocity && n == T;
+    const bool fit = P.fit != 0;
+    const int dlo = P.bc.dlo[T], dhi = P.bc.dhi[T];
+#define IAMRX_CORNER(SIDE, UP)                                                                                                   \
+    corner_state<PRED>(qn + ((SIDE) ? 0 : -qsD) + (UP) * qsT, qT + ((SIDE) ? 0 : -qsD) + (UP) * qsT, qsT, fT + (UP),                \
+                       mT.p[mTo + ((SIDE) ? 0 : -mTsD) + (UP) * mTsT], mO.p + mOo + ((SIDE) ? 0 : -mOsD) + (UP) * mOsT, mOsT, mOsO, \
+                       eO.p + eOo + ((SIDE) ? 0 : -eOsD) + (UP) * eOsT, eOsT, eOsO,                                                \
+                       frcn ? frcn + ((SIDE) ? 0 : -fsD) + (UP) * fsT : nullptr, fsT, dtdxT, c_o, dt3, P.dx[O], conserv,             \
+                       dvp ? dvp + ((SIDE) ? 0 : -dsD) + (UP) * dsT : nullptr, dsT, fit, hdt, nonperT, nvel, bl, bh, dlo, dhi)
+    Tl0 = IAMRX_CORNER(0, 0);
+    Tl1 = IAMRX_CORNER(0, 1);
+    Th0 = IAMRX_CORNER(1, 0);
+    Th1 = IAMRX_CORNER(1, 1);
+#undef IAMRX_CORNER
+}
+
 // -------------------------------------------------------------------------------- pass 2
 // grid over the valid faces of direction D.  PRED: only component n = D, output umac[D];
 // ADV: all components, output final edge states edge[D](ncomp).
-template <bool PRED>
-__global__ void __launch_bounds__(256) k_final(Tiling t, const BoxD* __restrict__ boxes, int D,
+template <bool PRED, int D>
+__global__ void __launch_bounds__(256) k_final(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ qt, const FabD* __restrict__ ft, const FabD* __restrict__ divut,
     const FabD* __restrict__ m0t, const FabD* __restrict__ m1t, const FabD* __restrict__ m2t,
     const FabD* __restrict__ e0t, const FabD* __restrict__ e1t, const FabD* __restrict__ e2t,
-    const FabD* __restrict__ outt, GodParams P)
+    const FabD* __restrict__ outt, const GodParams* __restrict__ Pp)
 {
+    constexpr int TA = D == 0 ? 1 : 0;            // transverse directions in ascending order
+    constexpr int TB = D == 2 ? 1 : 2;
+    const GodParams& P = *Pp;
     const int fab = blockIdx.y;
     BoxD b = boxes[fab];
     b.hi[D] += 1;
     int i, j, k0, k1;
     if (!tile_ijk(t, b, i, j, k0, k1)) return;
     const FabD q = qt[fab], out = outt[fab];
-    const FabD mac[3] = {m0t[fab], m1t[fab], m2t[fab]};
-    const FabD e0[3] = {e0t[fab], e1t[fab], e2t[fab]};
-    FabD frc; if (P.has_force) frc = ft[fab];
-    FabD dv; if (P.has_divu) dv = divut[fab];
-    const long qs[3] = {1, q.n[0], (long)q.n[0] * q.n[1]};
-    long fs[3] = {0, 0, 0}, ds[3] = {0, 0, 0};
-    if (P.has_force) { fs[0] = 1; fs[1] = frc.n[0]; fs[2] = (long)frc.n[0] * frc.n[1]; }
-    if (P.has_divu) { ds[0] = 1; ds[1] = dv.n[0]; ds[2] = (long)dv.n[0] * dv.n[1]; }
-    const double hdt = 0.5 * P.dt;
-    const double dtdxD = P.dt / P.dx[D];
+    const FabD m0 = m0t[fab], m1 = m1t[fab], m2 = m2t[fab];
+    const FabD e0 = e0t[fab], e1 = e1t[fab], e2 = e2t[fab];
+    const FabD& mD = D == 0 ? m0 : (D == 1 ? m1 : m2);
+    const FabD& mA = TA == 0 ? m0 : (TA == 1 ? m1 : m2);
+    const FabD& mB = TB == 0 ? m0 : (TB == 1 ? m1 : m2);
+    const FabD& eA = TA == 0 ? e0 : (TA == 1 ? e1 : e2);
+    const FabD& eB = TB == 0 ? e0 : (TB == 1 ? e1 : e2);
+    const bool has_force = P.has_force != 0, has_divu = P.has_divu != 0, fit = P.fit != 0;
+    FabD frc; if (has_force) frc = ft[fab];
+    FabD dv; if (has_divu) dv = divut[fab];
+    const long qsD = stride_of<D>(q);
+    const long fsD = has_force ? stride_of<D>(frc) : 0, dsD = has_divu ? stride_of<D>(dv) : 0;
+    const long mAsD = stride_of<D>(mA), mAsT = stride_of<TA>(mA), mBsD = stride_of<D>(mB), mBsT = stride_of<TB>(mB);
+    const double dt = P.dt, hdt = 0.5 * P.dt;
+    const double dtdxD = dt / P.dx[D];
     const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    const bool nonperD = !P.bc.per[D];
+    const int dloD = P.bc.dlo[D], dhiD = P.bc.dhi[D];
+    const bool is_vel = P.is_velocity != 0;
     for (int k = k0; k <= k1; ++k) {
-        const int idx[3] = {i, j, k};
-        const int f = idx[D];
+        const int f = D == 0 ? i : (D == 1 ? j : k);
+        const int fA = TA == 0 ? i : (TA == 1 ? j : k), fB = TB == 0 ? i : (TB == 1 ? j : k);
         const long qo = q.off(i, j, k);
-        const long fo = P.has_force ? frc.off(i, j, k) : 0;
-        const long dvo = P.has_divu ? dv.off(i, j, k) : 0;
-        const double umD = mac[D](i, j, k, 0);
+        const long fo = has_force ? frc.off(i, j, k) : 0;
+        const long dvo = has_divu ? dv.off(i, j, k) : 0;
+        const long mAo = mA.off(i, j, k), mBo = mB.off(i, j, k);
+        const double umD = mD(i, j, k, 0);
         for (int n = nbeg; n < nend; ++n) {
             const double* qn = q.p + qo + q.cs * n;
-            const double* frcn = P.has_force ? frc.p + fo + frc.cs * n : nullptr;
-            const bool conserv = !PRED && P.iconserv[n];
+            const double* frcn = has_force ? frc.p + fo + frc.cs * n : nullptr;
+            const double* dvp = has_divu ? dv.p + dvo : nullptr;
+            const bool conserv = !PRED && P.iconserv[n] != 0;
+            const int blD = P.bc.bc[n].lo[D], bhD = P.bc.bc[n].hi[D];
             // own traced states along D
             double stl, sth;
             {
-                const int bl = P.bc.bc[n].lo[D], bh = P.bc.bc[n].hi[D];
-                const bool nonper = !P.bc.per[D];
-                const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
-                trace_lohi<PRED>(qn, q.p + qo + q.cs * D, qs[D], umD, dtdxD, edlo, edhi, f, P.bc.dlo[D], P.bc.dhi[D], stl, sth);
-                if (P.fit && P.has_force) { stl += hdt * frcn[-fs[D]]; sth += hdt * frcn[0]; }
-                if (nonper) trans_bc(qn, qs[D], f, P.is_velocity && n == D, stl, sth, bl, bh, P.bc.dlo[D], P.bc.dhi[D]);
+                const bool edlo = nonperD && ed_or_ho(blD), edhi = nonperD && ed_or_ho(bhD);
+                trace_lohi<PRED>(qn, q.p + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
+                if (fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
+                if (nonperD) trans_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
             }
-            double Tl[3][2], Th[3][2];   // corner states on the T-faces of the low-side cell (cm) and the high-side cell (f): [T][0]=face c, [1]=face c+eT
-            for (int T = 0; T < 3; ++T) {
-                if (T == D) continue;
-                const int O = 3 - D - T;
-                const FabD& mT = mac[T]; const FabD& mO = mac[O]; const FabD& eO = e0[O];
-                const long mTs[3] = {1, mT.n[0], (long)mT.n[0] * mT.n[1]};
-                const long mOs[3] = {1, mO.n[0], (long)mO.n[0] * mO.n[1]};
-                const long eOs[3] = {1, eO.n[0], (long)eO.n[0] * eO.n[1]};
-                const long mTo = mT.off(i, j, k), mOo = mO.off(i, j, k), eOo = eO.off(i, j, k) + eO.cs * n;
-                const double c_o = conserv ? P.dt / (3.0 * P.dx[O]) : P.dt / (6.0 * P.dx[O]);
-                const double dt3 = P.dt / 3.0;
-                const double dtdxT = P.dt / P.dx[T];
-                const int bl = P.bc.bc[n].lo[T], bh = P.bc.bc[n].hi[T];
-                const bool nonperT = !P.bc.per[T];
-                const bool nvel = P.is_velocity && n == T;
-                for (int side = 0; side < 2; ++side) {          // 0: low-side cell cm = f - eD ; 1: high-side cell f
-                    const long shD_q = side ? 0 : -qs[D];
-                    for (int up = 0; up < 2; ++up) {            // T-face index c (0) or c+1 (1) of that cell
-                        const long oq = shD_q + up * qs[T];
-                        const long om = (side ? 0 : -mTs[D]) + up * mTs[T];
-                        const long oO = (side ? 0 : -mOs[D]) + up * mOs[T];
-                        const long oe = (side ? 0 : -eOs[D]) + up * eOs[T];
-                        const long of = (side ? 0 : -fs[D]) + up * fs[T];
-                        const long od = (side ? 0 : -ds[D]) + up * ds[T];
-                        const double v = corner_state<PRED>(qn + oq, q.p + qo + q.cs * T + oq, qs[T], idx[T] + up,
-                            mT.p[mTo + om], mO.p + mOo + oO, mOs[T], mOs[O], eO.p + eOo + oe, eOs[T], eOs[O],
-                            P.has_force ? frcn + of : nullptr, fs[T], dtdxT, c_o, dt3, P.dx[O], conserv,
-                            P.has_divu ? dv.p + dvo + od : nullptr, ds[T], P.has_divu != 0,
-                            P.fit != 0, hdt, nonperT, nvel, bl, bh, P.bc.dlo[T], P.bc.dhi[T]);
-                        if (side == 0) Tl[T][up] = v; else Th[T][up] = v;
-                    }
-                }
-            }
-            // transverse terms, ascending transverse direction
+            // corner-coupled transverse states: direction TA is corrected with the TB-derivative and vice versa
+            double Al0, Al1, Ah0, Ah1, Bl0, Bl1, Bh0, Bh1;
+            corner_quad<PRED, D, TA>(P, n, conserv, fA, qn, q.p + qo + q.cs * TA, q, mA, mAo, mB, mBo, eB, eB.off(i, j, k) + eB.cs * n,
+                                     frcn, frc, dvp, dv, Al0, Al1, Ah0, Ah1);
+            corner_quad<PRED, D, TB>(P, n, conserv, fB, qn, q.p + qo + q.cs * TB, q, mB, mBo, mA, mAo, eA, eA.off(i, j, k) + eA.cs * n,
+                                     frcn, frc, dvp, dv, Bl0, Bl1, Bh0, Bh1);
+            const double mA_l0 = mA.p[mAo - mAsD], mA_l1 = mA.p[mAo - mAsD + mAsT], mA_h0 = mA.p[mAo], mA_h1 = mA.p[mAo + mAsT];
+            const double mB_l0 = mB.p[mBo - mBsD], mB_l1 = mB.p[mBo - mBsD + mBsT], mB_h0 = mB.p[mBo], mB_h1 = mB.p[mBo + mBsT];
             if (conserv) {
-                for (int T = 0; T < 3; ++T) {
-                    if (T == D) continue;
-                    const FabD& mT = mac[T];
-                    const long mTs[3] = {1, mT.n[0], (long)mT.n[0] * mT.n[1]};
-                    const long mTo = mT.off(i, j, k);
-                    const double c = 0.5 * P.dt / P.dx[T];
-                    stl += -c * (Tl[T][1] * mT.p[mTo - mTs[D] + mTs[T]] - Tl[T][0] * mT.p[mTo - mTs[D]]);
-                    sth += -c * (Th[T][1] * mT.p[mTo + mTs[T]] - Th[T][0] * mT.p[mTo]);
-                }
-                for (int T = 0; T < 3; ++T) {
-                    if (T == D) continue;
-                    const FabD& mT = mac[T];
-                    const long mTs[3] = {1, mT.n[0], (long)mT.n[0] * mT.n[1]};
-                    const long mTo = mT.off(i, j, k);
-                    const double c = 0.5 * P.dt / P.dx[T];
-                    stl += c * qn[-qs[D]] * (mT.p[mTo - mTs[D] + mTs[T]] - mT.p[mTo - mTs[D]]);
-                    sth += c * qn[0] * (mT.p[mTo + mTs[T]] - mT.p[mTo]);
-                }
-                if (P.has_divu) { stl -= 0.5 * P.dt * qn[-qs[D]] * dv.p[dvo - ds[D]]; sth -= 0.5 * P.dt * qn[0] * dv.p[dvo]; }
+                const double cA = 0.5 * dt / P.dx[TA], cB = 0.5 * dt / P.dx[TB];
+                stl += -cA * (Al1 * mA_l1 - Al0 * mA_l0);
+                sth += -cA * (Ah1 * mA_h1 - Ah0 * mA_h0);
+                stl += -cB * (Bl1 * mB_l1 - Bl0 * mB_l0);
+                sth += -cB * (Bh1 * mB_h1 - Bh0 * mB_h0);
+                stl += cA * qn[-qsD] * (mA_l1 - mA_l0);
+                sth += cA * qn[0] * (mA_h1 - mA_h0);
+                stl += cB * qn[-qsD] * (mB_l1 - mB_l0);
+                sth += cB * qn[0] * (mB_h1 - mB_h0);
+                if (has_divu) { stl -= 0.5 * dt * qn[-qsD] * dvp[-dsD]; sth -= 0.5 * dt * qn[0] * dvp[0]; }
             } else {
-                for (int T = 0; T < 3; ++T) {
-                    if (T == D) continue;
-                    const FabD& mT = mac[T];
-                    const long mTs[3] = {1, mT.n[0], (long)mT.n[0] * mT.n[1]};
-                    const long mTo = mT.off(i, j, k);
-                    const double c = 0.25 * P.dt / P.dx[T];
-                    stl -= c * (mT.p[mTo - mTs[D] + mTs[T]] + mT.p[mTo - mTs[D]]) * (Tl[T][1] - Tl[T][0]);
-                    sth -= c * (mT.p[mTo + mTs[T]] + mT.p[mTo]) * (Th[T][1] - Th[T][0]);
-                }
+                const double cA = 0.25 * dt / P.dx[TA], cB = 0.25 * dt / P.dx[TB];
+                stl -= cA * (mA_l1 + mA_l0) * (Al1 - Al0);
+                sth -= cA * (mA_h1 + mA_h0) * (Ah1 - Ah0);
+                stl -= cB * (mB_l1 + mB_l0) * (Bl1 - Bl0);
+                sth -= cB * (mB_h1 + mB_h0) * (Bh1 - Bh0);
             }
-            if (!P.fit && P.has_force) { stl += hdt * frcn[-fs[D]]; sth += hdt * frcn[0]; }
-            if (!P.bc.per[D]) edge_bc(qn, qs[D], f, P.is_velocity && n == D, stl, sth, P.bc.bc[n].lo[D], P.bc.bc[n].hi[D], P.bc.dlo[D], P.bc.dhi[D]);
+            if (!fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
+            if (nonperD) edge_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
             if (PRED) {
                 const double st = ((stl + sth) >= 0.) ? stl : sth;
                 const bool ltm = ((stl <= 0. && sth >= 0.) || (fabs(stl + sth) < SMALL_VEL));
@@ -372,11 +391,43 @@ static GodParams make_params(const Geometry& g, double dt, int ncomp, const BCRe
     return P;
 }
 
+// run-time parameter block in device memory (stream-ordered ring: the H2D copy of a slot is ordered after the
+// kernels that used it before; the host source is pageable, so hipMemcpyAsync stages it before returning)
+static const GodParams* upload_params(const GodParams& P)
+{
+    static GodParams* ring = nullptr;
+    static int slot = 0;
+    constexpr int NSLOT = 64;
+    auto& ctx = Context::get();
+    if (!ring) ring = (GodParams*)ctx.alloc(NSLOT * sizeof(GodParams));
+    GodParams* d = ring + (slot++ % NSLOT);
+    IAMRX_HIP_CHECK(hipMemcpyAsync(d, &P, sizeof(GodParams), hipMemcpyHostToDevice, ctx.stream));
+    return d;
+}
+
 static Tiling face_tiling(const Layout& l, int D, int gt, int tz)
 {
     int ml[3];
     for (int e = 0; e < 3; ++e) ml[e] = l.max_len[e] + (e == D ? 1 : 2 * gt);
     return make_tiling(ml, l.nlocal(), tz);
+}
+
+template <bool PRED, int D>
+static void launch_trace(const Layout& l, const MultiFab& q, const MultiFab* force, const MultiFab& mac, const MultiFab& e0, const GodParams* dP)
+{
+    Tiling t = face_tiling(l, D, 1, 4);
+    hipLaunchKernelGGL((k_trace<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+                       force ? force->d_tab : nullptr, mac.d_tab, e0.d_tab, dP);
+}
+
+template <bool PRED, int D>
+static void launch_final(const Layout& l, const MultiFab& q, const MultiFab* force, const MultiFab* divu, MultiFab* const mac[3],
+                         const MultiFab e0[3], MultiFab& out, const GodParams* dP)
+{
+    Tiling t = face_tiling(l, D, 0, 4);
+    hipLaunchKernelGGL((k_final<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+                       force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[0]->d_tab, mac[1]->d_tab, mac[2]->d_tab,
+                       e0[0].d_tab, e0[1].d_tab, e0[2].d_tab, out.d_tab, dP);
 }
 
 void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
@@ -385,46 +436,43 @@ void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const M
     if (vel.nlocal() == 0) return;
     IAMRX_ASSERT(vel.ngrow >= 3 && vel.ncomp >= 3);
     IAMRX_ASSERT(!force || force->ngrow >= 1);
-    auto& ctx = Context::get();
     const Layout& l = *vel.layout;
     MultiFab ad[3], e0[3];
-    for (int d = 0; d < 3; ++d) { ad[d].define(vel.layout, face_type(d), 1, 1); e0[d].define(vel.layout, face_type(d), 3, 1); }
-    GodParams P = make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false);
-    for (int d = 0; d < 3; ++d) {
-        Tiling t = face_tiling(l, d, 1, 4);
-        hipLaunchKernelGGL((k_trace<true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, d, vel.d_tab,
-                           force ? force->d_tab : nullptr, ad[d].d_tab, e0[d].d_tab, P);
-    }
-    for (int d = 0; d < 3; ++d) {
-        Tiling t = face_tiling(l, d, 0, 4);
-        hipLaunchKernelGGL((k_final<true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, d, vel.d_tab,
-                           force ? force->d_tab : nullptr, nullptr, ad[0].d_tab, ad[1].d_tab, ad[2].d_tab,
-                           e0[0].d_tab, e0[1].d_tab, e0[2].d_tab, umac[d]->d_tab, P);
-    }
+    MultiFab* adp[3];
+    for (int d = 0; d < 3; ++d) { ad[d].define(vel.layout, face_type(d), 1, 1); e0[d].define(vel.layout, face_type(d), 3, 1); adp[d] = &ad[d]; }
+    const GodParams* dP = upload_params(make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false));
+    launch_trace<true, 0>(l, vel, force, ad[0], e0[0], dP);
+    launch_trace<true, 1>(l, vel, force, ad[1], e0[1], dP);
+    launch_trace<true, 2>(l, vel, force, ad[2], e0[2], dP);
+    launch_final<true, 0>(l, vel, force, nullptr, adp, e0, *umac[0], dP);
+    launch_final<true, 1>(l, vel, force, nullptr, adp, e0, *umac[1], dP);
+    launch_final<true, 2>(l, vel, force, nullptr, adp, e0, *umac[2], dP);
 }
 
 // -------------------------------------------------------------------------------- pass 3
 __global__ void __launch_bounds__(256) k_aofs(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ aofst, int acomp,
     const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
     const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
-    const FabD* __restrict__ fxt, const FabD* __restrict__ fyt, const FabD* __restrict__ fzt, GodParams P)
+    const FabD* __restrict__ fxt, const FabD* __restrict__ fyt, const FabD* __restrict__ fzt, const GodParams* __restrict__ Pp)
 {
+    const GodParams& P = *Pp;
     const int fab = blockIdx.y;
     int i, j, k0, k1;
     if (!tile_ijk(t, boxes[fab], i, j, k0, k1)) return;
     const FabD aofs = aofst[fab], ex = ext[fab], ey = eyt[fab], ez = ezt[fab], ux = uxt[fab], uy = uyt[fab], uz = uzt[fab];
     const bool store_flux = fxt != nullptr;
-    const double ax = P.dx[1] * P.dx[2], ay = P.dx[2] * P.dx[0], az = P.dx[0] * P.dx[1];
-    const double qvol = 1.0 / (P.dx[0] * P.dx[1] * P.dx[2]);
+    const double dx0 = P.dx[0], dx1 = P.dx[1], dx2 = P.dx[2];
+    const double ax = dx1 * dx2, ay = dx2 * dx0, az = dx0 * dx1;
+    const double qvol = 1.0 / (dx0 * dx1 * dx2);
+    const int ncomp = P.ncomp;
     for (int k = k0; k <= k1; ++k) {
         const double uxl = ux(i, j, k), uxh = ux(i + 1, j, k), uyl = uy(i, j, k), uyh = uy(i, j + 1, k), uzl = uz(i, j, k), uzh = uz(i, j, k + 1);
-        const double divum = 1.0 * ((uxh - uxl) / P.dx[0] + (uyh - uyl) / P.dx[1] + (uzh - uzl) / P.dx[2]);
-        for (int n = 0; n < P.ncomp; ++n) {
+        const double divum = 1.0 * ((uxh - uxl) / dx0 + (uyh - uyl) / dx1 + (uzh - uzl) / dx2);
+        for (int n = 0; n < ncomp; ++n) {
             const double exl = ex(i, j, k, n), exh = ex(i + 1, j, k, n), eyl = ey(i, j, k, n), eyh = ey(i, j + 1, k, n), ezl = ez(i, j, k, n), ezh = ez(i, j, k + 1, n);
             const double fxl = exl * uxl * ax, fxh = exh * uxh * ax, fyl = eyl * uyl * ay, fyh = eyh * uyh * ay, fzl = ezl * uzl * az, fzh = ezh * uzh * az;
             if (store_flux) {
                 fxt[fab](i, j, k, n) = fxl; fyt[fab](i, j, k, n) = fyl; fzt[fab](i, j, k, n) = fzl;
-                // high faces on the box boundary are not owned by any other cell of this fab
                 const BoxD bb = boxes[fab];
                 if (i == bb.hi[0]) fxt[fab](i + 1, j, k, n) = fxh;
                 if (j == bb.hi[1]) fyt[fab](i, j + 1, k, n) = fyh;
@@ -457,23 +505,18 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
         if (edge_out && edge_out[d]) ed[d] = edge_out[d];
         else { edge[d].define(S.layout, face_type(d), ncomp, 0); ed[d] = &edge[d]; }
     }
-    GodParams P = make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr);
-    for (int d = 0; d < 3; ++d) {
-        Tiling t = face_tiling(l, d, 1, 4);
-        hipLaunchKernelGGL((k_trace<false>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, d, S.d_tab,
-                           force ? force->d_tab : nullptr, umac[d]->d_tab, e0[d].d_tab, P);
-    }
-    for (int d = 0; d < 3; ++d) {
-        Tiling t = face_tiling(l, d, 0, 4);
-        hipLaunchKernelGGL((k_final<false>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, d, S.d_tab,
-                           force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr,
-                           umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, e0[0].d_tab, e0[1].d_tab, e0[2].d_tab, ed[d]->d_tab, P);
-    }
+    const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
+    launch_trace<false, 0>(l, S, force, *umac[0], e0[0], dP);
+    launch_trace<false, 1>(l, S, force, *umac[1], e0[1], dP);
+    launch_trace<false, 2>(l, S, force, *umac[2], e0[2], dP);
+    launch_final<false, 0>(l, S, force, divu, umac, e0, *ed[0], dP);
+    launch_final<false, 1>(l, S, force, divu, umac, e0, *ed[1], dP);
+    launch_final<false, 2>(l, S, force, divu, umac, e0, *ed[2], dP);
     Tiling t = level_tiling(l, cell_type(), 0, 4);
     const bool sf = flux_out && flux_out[0];
     hipLaunchKernelGGL(k_aofs, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, aofs.d_tab, acomp,
                        ed[0]->d_tab, ed[1]->d_tab, ed[2]->d_tab, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab,
-                       sf ? flux_out[0]->d_tab : nullptr, sf ? flux_out[1]->d_tab : nullptr, sf ? flux_out[2]->d_tab : nullptr, P);
+                       sf ? flux_out[0]->d_tab : nullptr, sf ? flux_out[1]->d_tab : nullptr, sf ? flux_out[2]->d_tab : nullptr, dP);
 }
 
 }  // namespace iamrx

@@ -64,6 +64,10 @@ const char* iamrx_last_error(void);
 int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
 void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
 int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
+/* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
+ * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */
+int iamrx_timer_start(void);
+int iamrx_timer_stop(double* ms);
 void iamrx_mg_default_opts(iamrx_mg_opts* o);
 
 /* ---- containers (amrex::BoxArray/DistributionMapping/MultiFab role) ----------- */
