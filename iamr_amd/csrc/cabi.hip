@@ -5,6 +5,7 @@
 #include <string>
 #include <cstring>
 #include <vector>
+#include <map>
 
 using namespace iamrx;
 
@@ -71,6 +72,45 @@ int iamrx_mem_info(size_t* live, size_t* cached)
     IAMRX_TRY
     if (live) *live = Context::get().bytes_live;
     if (cached) *cached = Context::get().bytes_cached;
+    IAMRX_CATCH
+}
+
+// host-only (no device needed): the ghost-exchange plan rank `rank` would execute for a level.
+// desc layout (16 ints): kind (0 local copy, 1 pack+send, 2 recv+unpack), peer rank (-1 local), src global box (-1 recv),
+// dst global box (-1 send), region lo[3], hi[3] (destination index frame), shift[3] (src = dst + shift), buf_off (points), pad
+int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
+                         int max_desc, int* desc, int* ndesc)
+{
+    IAMRX_TRY
+    std::vector<BoxD> b(nboxes);
+    std::vector<int> own(nboxes), local_of(nboxes, -1), local;
+    for (int i = 0; i < nboxes; ++i) {
+        for (int d = 0; d < 3; ++d) { b[i].lo[d] = lo_hi[6 * i + d]; b[i].hi[d] = lo_hi[6 * i + 3 + d]; }
+        own[i] = owner ? owner[i] : 0;
+        if (own[i] == rank) { local_of[i] = (int)local.size(); local.push_back(i); }
+    }
+    CopyPlan plan;
+    std::map<int, CopyPlan::Peer> peers;
+    IndexType t{{type[0], type[1], type[2]}};
+    build_fill_plan_host(b, own, local_of, rank, t, ngrow, to_geom(g), plan, peers);
+    int n = 0;
+    auto emit = [&](int kind, int peer, const CopyDesc& cd) {
+        if (n < max_desc && desc) {
+            int* o = desc + 16 * n;
+            o[0] = kind; o[1] = peer;
+            o[2] = cd.src_fab >= 0 ? local[cd.src_fab] : -1;
+            o[3] = cd.dst_fab >= 0 ? local[cd.dst_fab] : -1;
+            for (int d = 0; d < 3; ++d) { o[4 + d] = cd.region.lo[d]; o[7 + d] = cd.region.hi[d]; o[10 + d] = cd.shift[d]; }
+            o[13] = (int)cd.buf_off; o[14] = 0; o[15] = 0;
+        }
+        ++n;
+    };
+    for (auto& cd : plan.local) emit(0, -1, cd);
+    for (auto& kv : peers) {
+        for (auto& cd : kv.second.pack) emit(1, kv.first, cd);
+        for (auto& cd : kv.second.unpack) emit(2, kv.first, cd);
+    }
+    *ndesc = n;
     IAMRX_CATCH
 }
 

@@ -17,6 +17,7 @@
 // static after unrolling (no scratch memory); run-time parameters live in a small device-resident block.
 #include "kernels.h"
 #include "launch.h"
+#include <cstdlib>
 
 namespace iamrx {
 
@@ -378,6 +379,136 @@ __global__ void __launch_bounds__(256) k_final(Tiling t, const BoxD* __restrict_
     }
 }
 
+// -------------------------------------------------------------------------------- pass 2a / 2b (split variant)
+// 2a: k_corner<D,T> materialises the corner-coupled transverse states on the T-faces (cells grown by 1 in D)
+// 2b: k_final_s<D> combines them.  Less register pressure and no slope recomputation per corner than the
+// fully fused k_final above (which stays selectable with IAMRX_GODUNOV_FUSED=1 for A/B measurements).
+template <bool PRED, int D, int T>
+__global__ void __launch_bounds__(256) k_corner(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ qt, const FabD* __restrict__ ft, const FabD* __restrict__ divut,
+    const FabD* __restrict__ mTt, const FabD* __restrict__ mOt, const FabD* __restrict__ eOt,
+    const FabD* __restrict__ outt, const GodParams* __restrict__ Pp)
+{
+    constexpr int O = 3 - D - T;
+    const GodParams& P = *Pp;
+    const int fab = blockIdx.y;
+    BoxD b = boxes[fab];
+    b.hi[T] += 1; b.lo[D] -= 1; b.hi[D] += 1;
+    int i, j, k0, k1;
+    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    const FabD q = qt[fab], mT = mTt[fab], mO = mOt[fab], eO = eOt[fab], out = outt[fab];
+    const bool has_force = P.has_force != 0, has_divu = P.has_divu != 0, fit = P.fit != 0;
+    FabD frc; if (has_force) frc = ft[fab];
+    FabD dv; if (has_divu) dv = divut[fab];
+    const long qsT = stride_of<T>(q);
+    const long mOsT = stride_of<T>(mO), mOsO = stride_of<O>(mO), eOsT = stride_of<T>(eO), eOsO = stride_of<O>(eO);
+    const long fsT = has_force ? stride_of<T>(frc) : 0, dsT = has_divu ? stride_of<T>(dv) : 0;
+    const double dt3 = P.dt / 3.0, dtdxT = P.dt / P.dx[T], hdt = 0.5 * P.dt;
+    const bool nonperT = !P.bc.per[T];
+    const int dlo = P.bc.dlo[T], dhi = P.bc.dhi[T];
+    const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    for (int k = k0; k <= k1; ++k) {
+        const int fT = T == 0 ? i : (T == 1 ? j : k);
+        const long qo = q.off(i, j, k);
+        const double macT = mT(i, j, k, 0);
+        const long mOo = mO.off(i, j, k), eOo = eO.off(i, j, k);
+        for (int n = nbeg; n < nend; ++n) {
+            const bool conserv = !PRED && P.iconserv[n] != 0;
+            const double c_o = conserv ? P.dt / (3.0 * P.dx[O]) : P.dt / (6.0 * P.dx[O]);
+            const double v = corner_state<PRED>(q.p + qo + q.cs * n, q.p + qo + q.cs * T, qsT, fT, macT, mO.p + mOo, mOsT, mOsO,
+                eO.p + eOo + eO.cs * n, eOsT, eOsO, has_force ? frc.p + frc.off(i, j, k) + frc.cs * n : nullptr, fsT, dtdxT, c_o, dt3,
+                P.dx[O], conserv, has_divu ? dv.p + dv.off(i, j, k) : nullptr, dsT, fit, hdt, nonperT, P.is_velocity && n == T,
+                P.bc.bc[n].lo[T], P.bc.bc[n].hi[T], dlo, dhi);
+            out(i, j, k, PRED ? 0 : n) = v;
+        }
+    }
+}
+
+template <bool PRED, int D>
+__global__ void __launch_bounds__(256) k_final_s(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ qt, const FabD* __restrict__ ft, const FabD* __restrict__ divut,
+    const FabD* __restrict__ mDt, const FabD* __restrict__ mAt, const FabD* __restrict__ mBt,
+    const FabD* __restrict__ cAt, const FabD* __restrict__ cBt, const FabD* __restrict__ outt, const GodParams* __restrict__ Pp)
+{
+    constexpr int TA = D == 0 ? 1 : 0;
+    constexpr int TB = D == 2 ? 1 : 2;
+    const GodParams& P = *Pp;
+    const int fab = blockIdx.y;
+    BoxD b = boxes[fab];
+    b.hi[D] += 1;
+    int i, j, k0, k1;
+    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    const FabD q = qt[fab], out = outt[fab], mD = mDt[fab], mA = mAt[fab], mB = mBt[fab], cA = cAt[fab], cB = cBt[fab];
+    const bool has_force = P.has_force != 0, has_divu = P.has_divu != 0, fit = P.fit != 0;
+    FabD frc; if (has_force) frc = ft[fab];
+    FabD dv; if (has_divu) dv = divut[fab];
+    const long qsD = stride_of<D>(q);
+    const long fsD = has_force ? stride_of<D>(frc) : 0, dsD = has_divu ? stride_of<D>(dv) : 0;
+    const long mAsD = stride_of<D>(mA), mAsT = stride_of<TA>(mA), mBsD = stride_of<D>(mB), mBsT = stride_of<TB>(mB);
+    const long cAsD = stride_of<D>(cA), cAsT = stride_of<TA>(cA), cBsD = stride_of<D>(cB), cBsT = stride_of<TB>(cB);
+    const double dt = P.dt, hdt = 0.5 * P.dt;
+    const double dtdxD = dt / P.dx[D];
+    const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    const bool nonperD = !P.bc.per[D];
+    const int dloD = P.bc.dlo[D], dhiD = P.bc.dhi[D];
+    const bool is_vel = P.is_velocity != 0;
+    for (int k = k0; k <= k1; ++k) {
+        const int f = D == 0 ? i : (D == 1 ? j : k);
+        const long qo = q.off(i, j, k);
+        const long fo = has_force ? frc.off(i, j, k) : 0;
+        const long dvo = has_divu ? dv.off(i, j, k) : 0;
+        const long mAo = mA.off(i, j, k), mBo = mB.off(i, j, k);
+        const double umD = mD(i, j, k, 0);
+        const double mA_l0 = mA.p[mAo - mAsD], mA_l1 = mA.p[mAo - mAsD + mAsT], mA_h0 = mA.p[mAo], mA_h1 = mA.p[mAo + mAsT];
+        const double mB_l0 = mB.p[mBo - mBsD], mB_l1 = mB.p[mBo - mBsD + mBsT], mB_h0 = mB.p[mBo], mB_h1 = mB.p[mBo + mBsT];
+        for (int n = nbeg; n < nend; ++n) {
+            const double* qn = q.p + qo + q.cs * n;
+            const double* frcn = has_force ? frc.p + fo + frc.cs * n : nullptr;
+            const bool conserv = !PRED && P.iconserv[n] != 0;
+            const int blD = P.bc.bc[n].lo[D], bhD = P.bc.bc[n].hi[D];
+            double stl, sth;
+            {
+                const bool edlo = nonperD && ed_or_ho(blD), edhi = nonperD && ed_or_ho(bhD);
+                trace_lohi<PRED>(qn, q.p + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
+                if (fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
+                if (nonperD) trans_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
+            }
+            const long cAo = cA.off(i, j, k) + cA.cs * (PRED ? 0 : n), cBo = cB.off(i, j, k) + cB.cs * (PRED ? 0 : n);
+            const double Al0 = cA.p[cAo - cAsD], Al1 = cA.p[cAo - cAsD + cAsT], Ah0 = cA.p[cAo], Ah1 = cA.p[cAo + cAsT];
+            const double Bl0 = cB.p[cBo - cBsD], Bl1 = cB.p[cBo - cBsD + cBsT], Bh0 = cB.p[cBo], Bh1 = cB.p[cBo + cBsT];
+            if (conserv) {
+                const double cfA = 0.5 * dt / P.dx[TA], cfB = 0.5 * dt / P.dx[TB];
+                stl += -cfA * (Al1 * mA_l1 - Al0 * mA_l0);
+                sth += -cfA * (Ah1 * mA_h1 - Ah0 * mA_h0);
+                stl += -cfB * (Bl1 * mB_l1 - Bl0 * mB_l0);
+                sth += -cfB * (Bh1 * mB_h1 - Bh0 * mB_h0);
+                stl += cfA * qn[-qsD] * (mA_l1 - mA_l0);
+                sth += cfA * qn[0] * (mA_h1 - mA_h0);
+                stl += cfB * qn[-qsD] * (mB_l1 - mB_l0);
+                sth += cfB * qn[0] * (mB_h1 - mB_h0);
+                if (has_divu) { stl -= 0.5 * dt * qn[-qsD] * dv.p[dvo - dsD]; sth -= 0.5 * dt * qn[0] * dv.p[dvo]; }
+            } else {
+                const double cfA = 0.25 * dt / P.dx[TA], cfB = 0.25 * dt / P.dx[TB];
+                stl -= cfA * (mA_l1 + mA_l0) * (Al1 - Al0);
+                sth -= cfA * (mA_h1 + mA_h0) * (Ah1 - Ah0);
+                stl -= cfB * (mB_l1 + mB_l0) * (Bl1 - Bl0);
+                sth -= cfB * (mB_h1 + mB_h0) * (Bh1 - Bh0);
+            }
+            if (!fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
+            if (nonperD) edge_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
+            if (PRED) {
+                const double st = ((stl + sth) >= 0.) ? stl : sth;
+                const bool ltm = ((stl <= 0. && sth >= 0.) || (fabs(stl + sth) < SMALL_VEL));
+                out(i, j, k, 0) = ltm ? 0. : st;
+            } else {
+                double temp = (umD >= 0.) ? stl : sth;
+                temp = (fabs(umD) < SMALL_VEL) ? 0.5 * (stl + sth) : temp;
+                out(i, j, k, n) = temp;
+            }
+        }
+    }
+}
+
 static GodParams make_params(const Geometry& g, double dt, int ncomp, const BCRec* bc, const int* iconserv, bool is_vel, bool fit,
                              bool has_force, bool has_divu)
 {
@@ -420,10 +551,45 @@ static void launch_trace(const Layout& l, const MultiFab& q, const MultiFab* for
                        force ? force->d_tab : nullptr, mac.d_tab, e0.d_tab, dP);
 }
 
+static bool use_fused_final()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_FUSED"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+template <bool PRED, int D, int T>
+static void launch_corner(const Layout& l, const MultiFab& q, const MultiFab* force, const MultiFab* divu, const MultiFab& mT,
+                          const MultiFab& mO, const MultiFab& eO, MultiFab& out, const GodParams* dP)
+{
+    int ml[3];
+    for (int e = 0; e < 3; ++e) ml[e] = l.max_len[e] + (e == T ? 1 : 0) + (e == D ? 2 : 0);
+    Tiling t = make_tiling(ml, l.nlocal(), 4);
+    hipLaunchKernelGGL((k_corner<PRED, D, T>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+                       force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mT.d_tab, mO.d_tab, eO.d_tab, out.d_tab, dP);
+}
+
+template <bool PRED, int D>
+static void launch_final_split(const Layout& l, const MultiFab& q, int ncomp, const MultiFab* force, const MultiFab* divu,
+                               MultiFab* const mac[3], const MultiFab e0[3], MultiFab& out, const GodParams* dP)
+{
+    constexpr int TA = D == 0 ? 1 : 0;
+    constexpr int TB = D == 2 ? 1 : 2;
+    const int nc = PRED ? 1 : ncomp;
+    MultiFab cA(q.layout, face_type(TA), nc, 1), cB(q.layout, face_type(TB), nc, 1);
+    launch_corner<PRED, D, TA>(l, q, force, divu, *mac[TA], *mac[TB], e0[TB], cA, dP);
+    launch_corner<PRED, D, TB>(l, q, force, divu, *mac[TB], *mac[TA], e0[TA], cB, dP);
+    Tiling t = face_tiling(l, D, 0, 4);
+    hipLaunchKernelGGL((k_final_s<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+                       force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab,
+                       cA.d_tab, cB.d_tab, out.d_tab, dP);
+}
+
 template <bool PRED, int D>
 static void launch_final(const Layout& l, const MultiFab& q, const MultiFab* force, const MultiFab* divu, MultiFab* const mac[3],
                          const MultiFab e0[3], MultiFab& out, const GodParams* dP)
 {
+    if (!use_fused_final()) { launch_final_split<PRED, D>(l, q, e0[0].ncomp, force, divu, mac, e0, out, dP); return; }
     Tiling t = face_tiling(l, D, 0, 4);
     hipLaunchKernelGGL((k_final<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[0]->d_tab, mac[1]->d_tab, mac[2]->d_tab,

@@ -154,6 +154,10 @@ private:
     void release();
 };
 
+// host-only plan construction (no device access; unit-testable on CPU)
+void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers);
+
 // plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
 const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g);
 void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc);

@@ -265,29 +265,20 @@ static CopyDesc* upload(const std::vector<CopyDesc>& v)
     return d;
 }
 
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g)
+// host-only construction of a ghost-exchange plan (no device access: unit-testable on CPU)
+void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers)
 {
-    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
-    PlanKey key;
-    std::memset(&key, 0, sizeof(key));
-    key.layout_id = l.id; key.t = t; key.ng = ng;
-    for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
-    auto it = cache.find(key);
-    if (it != cache.end()) return *it->second;
-
-    auto plan = std::make_unique<CopyPlan>();
-    const int me = Context::get().comm->rank;
-    std::map<int, CopyPlan::Peer> peers;
     // periodic shift candidates
     int smin[3], smax[3];
     for (int d = 0; d < 3; ++d) { smin[d] = g.periodic[d] ? -1 : 0; smax[d] = g.periodic[d] ? 1 : 0; }
-    const int nb = (int)l.boxes.size();
+    const int nb = (int)boxes.size();
     for (int gd = 0; gd < nb; ++gd) {
-        const bool dst_mine = l.owner[gd] == me;
-        const BoxD dvalid = convert(l.boxes[gd], t.t);
+        const bool dst_mine = owner[gd] == me;
+        const BoxD dvalid = convert(boxes[gd], t.t);
         const BoxD dgrown = grow(dvalid, ng);
         for (int gs = 0; gs < nb; ++gs) {
-            const bool src_mine = l.owner[gs] == me;
+            const bool src_mine = owner[gs] == me;
             if (!dst_mine && !src_mine) continue;
             for (int sz = smin[2]; sz <= smax[2]; ++sz)
             for (int sy = smin[1]; sy <= smax[1]; ++sy)
@@ -295,7 +286,7 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
                 if (gs == gd && sx == 0 && sy == 0 && sz == 0) continue;
                 // source valid box translated INTO the destination's index frame
                 int sh[3] = {sx * g.domain.len(0), sy * g.domain.len(1), sz * g.domain.len(2)};
-                BoxD svalid = convert(l.boxes[gs], t.t);
+                BoxD svalid = convert(boxes[gs], t.t);
                 for (int d = 0; d < 3; ++d) svalid = shift(svalid, d, sh[d]);
                 BoxD is = intersect(dgrown, svalid);
                 if (!is.ok()) continue;
@@ -317,20 +308,20 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
                     for (int d = 0; d < 3; ++d) cd.shift[d] = -sh[d];
                     cd.buf_off = 0;
                     if (dst_mine && src_mine) {
-                        cd.src_fab = l.local_of[gs]; cd.dst_fab = l.local_of[gd];
-                        plan->local.push_back(cd);
-                        plan->max_local_pts = std::max(plan->max_local_pts, p.npts());
+                        cd.src_fab = local_of[gs]; cd.dst_fab = local_of[gd];
+                        plan.local.push_back(cd);
+                        plan.max_local_pts = std::max(plan.max_local_pts, p.npts());
                     } else if (src_mine) {          // I send to owner of gd
-                        auto& pr = peers[l.owner[gd]];
-                        pr.rank = l.owner[gd];
-                        cd.src_fab = l.local_of[gs]; cd.dst_fab = -1; cd.buf_off = pr.send_pts;
+                        auto& pr = peers[owner[gd]];
+                        pr.rank = owner[gd];
+                        cd.src_fab = local_of[gs]; cd.dst_fab = -1; cd.buf_off = pr.send_pts;
                         pr.send_pts += p.npts();
                         pr.max_pack_pts = std::max(pr.max_pack_pts, p.npts());
                         pr.pack.push_back(cd);
                     } else {                        // I receive from owner of gs
-                        auto& pr = peers[l.owner[gs]];
-                        pr.rank = l.owner[gs];
-                        cd.src_fab = -1; cd.dst_fab = l.local_of[gd]; cd.buf_off = pr.recv_pts;
+                        auto& pr = peers[owner[gs]];
+                        pr.rank = owner[gs];
+                        cd.src_fab = -1; cd.dst_fab = local_of[gd]; cd.buf_off = pr.recv_pts;
                         pr.recv_pts += p.npts();
                         pr.max_unpack_pts = std::max(pr.max_unpack_pts, p.npts());
                         pr.unpack.push_back(cd);
@@ -339,6 +330,21 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
             }
         }
     }
+}
+
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g)
+{
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.layout_id = l.id; key.t = t; key.ng = ng;
+    for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+
+    auto plan = std::make_unique<CopyPlan>();
+    std::map<int, CopyPlan::Peer> peers;
+    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers);
     plan->d_local = upload(plan->local);
     for (auto& kv : peers) {
         kv.second.d_pack = upload(kv.second.pack);

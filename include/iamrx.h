@@ -88,6 +88,13 @@ int iamrx_mf_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int ncomp, i
 int iamrx_mf_fill_boundary(iamrx_mf m, const iamrx_geom* g);              /* FillBoundary(geom.periodicity()): Source/MacProj.cpp:1127 */
 int iamrx_mf_norm0(iamrx_mf m, int comp, int ncomp, int ngrow, double* out);   /* MultiFab::norm0: Source/NavierStokesBase.cpp:4408 */
 
+/* host-only (works without a GPU): the ghost-exchange plan that `rank` executes for FillBoundary of a level
+ * (FabArray::FillBoundary role).  desc: 16 ints per descriptor = kind (0 local copy, 1 pack+send, 2 recv+unpack),
+ * peer rank, src global box, dst global box, region lo[3] hi[3] (destination index frame), shift[3]
+ * (src index = dst index + shift), buffer offset in points, 2 pad.  Call with desc == NULL to size. */
+int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
+                         int max_desc, int* desc, int* ndesc);
+
 /* ---- cell-centred linear operator primitives (amrex::MLABecLaplacian role) ---- */
 /* one red or black Gauss-Seidel pass of (alpha*a - beta div b grad) phi = rhs; ghost cells of phi must be filled */
 int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
