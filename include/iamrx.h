@@ -70,6 +70,20 @@ int iamrx_timer_start(void);
 int iamrx_timer_stop(double* ms);
 void iamrx_mg_default_opts(iamrx_mg_opts* o);
 
+/* ---- communicator (amrex::ParallelDescriptor / FabArray point-to-point role) ------ */
+/* One process per GPU.  Call AFTER iamrx_init and BEFORE creating layouts.  RCCL: rank 0 obtains a unique id,
+ * the host program broadcasts the 128 bytes (MPI_Bcast / torch.distributed), every rank calls init. */
+int iamrx_comm_get_unique_id(char id[128]);
+int iamrx_comm_init_rccl(const char id[128], int rank, int nranks);
+/* transport supplied by the host program (tests: torch.distributed gloo); buffers are host memory.
+ * op: 0 sum, 1 max, 2 min */
+typedef void (*iamrx_allreduce_cb)(double* vals, int n, int op);
+typedef void (*iamrx_exchange_cb)(int nsend, const int* send_peers, double** send_bufs, const long* send_counts,
+                                  int nrecv, const int* recv_peers, double** recv_bufs, const long* recv_counts);
+int iamrx_comm_init_callback(int rank, int nranks, iamrx_allreduce_cb ar, iamrx_exchange_cb ex);
+int iamrx_comm_rank(int* rank, int* nranks);
+const char* iamrx_comm_last_error(void);
+
 /* ---- containers (amrex::BoxArray/DistributionMapping/MultiFab role) ----------- */
 int iamrx_layout_create(int nboxes, const int* lo_hi /* 6 ints per box: lo[3],hi[3] */, const int* owner_rank,
                         iamrx_layout* out);
