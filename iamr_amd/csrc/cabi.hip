@@ -320,6 +320,20 @@ int iamrx_nodal_gs_color(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
 {
     IAMRX_TRY nodal_gs_color(to_geom(g), phi->mf, rhs->mf, sig->mf, color); IAMRX_CATCH
 }
+int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int fused)
+{
+    IAMRX_TRY
+    Geometry gg = to_geom(g);
+    if (fused == 2) {
+        if (!nodal_smooth_small(gg, phi->mf, rhs->mf, sig->mf, 1)) throw Error("level does not qualify for the single-workgroup smoother");
+        phi->mf.FillBoundary(gg);
+    } else if (fused) {
+        for (int kpar = 0; kpar < 2; ++kpar) { phi->mf.FillBoundary(gg); nodal_gs_fused_pass(gg, phi->mf, rhs->mf, sig->mf, kpar); }
+    } else {
+        for (int c = 0; c < 8; ++c) { phi->mf.FillBoundary(gg); nodal_gs_color(gg, phi->mf, rhs->mf, sig->mf, c); }
+    }
+    IAMRX_CATCH
+}
 int iamrx_nodal_restrict(iamrx_mf c, iamrx_mf f) { IAMRX_TRY nodal_restrict(c->mf, f->mf); IAMRX_CATCH }
 int iamrx_nodal_interp_add(iamrx_mf f, iamrx_mf c, iamrx_mf s) { IAMRX_TRY nodal_interp_add(f->mf, c->mf, s->mf); IAMRX_CATCH }
 int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp) { IAMRX_TRY nodal_divu(to_geom(g), rhs->mf, vel->mf, vcomp); IAMRX_CATCH }

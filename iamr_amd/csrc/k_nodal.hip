@@ -100,6 +100,170 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
     hipLaunchKernelGGL(k_nodal_gscolor, t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g), color);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Plane-fused 8-colour Gauss-Seidel: the four colours of one k-parity (colours 0-3: k even, 4-7: k odd)
+// are applied in ONE pass.  A workgroup stages the x-planes k-1,k,k+1 and the two sigma cell planes of a
+// (TX+8)x(TY+8) footprint in LDS, runs the four in-plane colour updates back to back on shrinking regions
+// (grown by 3,2,1,0 nodes: the halo is recomputed instead of exchanged) and writes the interior TXxTY nodes
+// of plane k.  The k+-1 planes belong to the other parity and are read-only during the pass, so the result
+// is identical to four sequential colour passes with a ghost fill in front of each of them -- provided the
+// arrays carry 4 ghost nodes (x, sigma) / 3 (rhs) that hold true periodic / neighbour images.
+// HBM traffic per sweep drops from 8 full-array passes to 2; kernel launches from 8+8 fills to 2+2.
+template <int TX, int TY>
+__global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xt,
+    const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty)
+{
+    constexpr int RX = TX + 8, RY = TY + 8;
+    __shared__ double X[3][RY][RX];
+    __shared__ double S[2][RY][RX];
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    const int bid = blockIdx.x;
+    const int tix = bid % ntx;
+    const int r1 = bid / ntx;
+    const int tiy = r1 % nty, pk = r1 / nty;
+    const int kfirst = cb.lo[2] + (((cb.lo[2] & 1) != kpar) ? 1 : 0);
+    const int k = kfirst + 2 * pk;
+    const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;   // last valid node
+    const int tx0 = cb.lo[0] + tix * TX, ty0 = cb.lo[1] + tiy * TY;
+    if (k > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
+    const int txe = min(tx0 + TX - 1, nhi0), tye = min(ty0 + TY - 1, nhi1);
+    const FabD x = xt[fab], r = rt[fab], s = st[fab];
+    const int ox = tx0 - 4, oy = ty0 - 4;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < RX * RY; idx += 256) {
+        const int lx = idx % RX, ly = idx / RX;
+        const int gi = ox + lx, gj = oy + ly;
+        const bool inx = gi >= x.lo[0] && gi < x.lo[0] + x.n[0] && gj >= x.lo[1] && gj < x.lo[1] + x.n[1];
+        const bool ins = gi >= s.lo[0] && gi < s.lo[0] + s.n[0] && gj >= s.lo[1] && gj < s.lo[1] + s.n[1];
+        X[0][ly][lx] = inx ? x(gi, gj, k - 1) : 0.0;
+        X[1][ly][lx] = inx ? x(gi, gj, k) : 0.0;
+        X[2][ly][lx] = inx ? x(gi, gj, k + 1) : 0.0;
+        S[0][ly][lx] = ins ? s(gi, gj, k - 1) : 0.0;
+        S[1][ly][lx] = ins ? s(gi, gj, k) : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        const int cx = c & 1, cy = c >> 1, g = 3 - c;
+        const int rlo0 = tx0 - g, rhi0 = txe + g, rlo1 = ty0 - g, rhi1 = tye + g;
+        const int i0 = rlo0 + (((rlo0 & 1) != cx) ? 1 : 0), j0 = rlo1 + (((rlo1 & 1) != cy) ? 1 : 0);
+        const int ni = i0 > rhi0 ? 0 : ((rhi0 - i0) >> 1) + 1, nj = j0 > rhi1 ? 0 : ((rhi1 - j0) >> 1) + 1;
+        for (int idx = tid; idx < ni * nj; idx += 256) {
+            const int i = i0 + 2 * (idx % ni), j = j0 + 2 * (idx / ni);
+            const int lx = i - ox, ly = j - oy;
+            const double smmm = S[0][ly - 1][lx - 1], spmm = S[0][ly - 1][lx], smpm = S[0][ly][lx - 1], sppm = S[0][ly][lx];
+            const double smmp = S[1][ly - 1][lx - 1], spmp = S[1][ly - 1][lx], smpp = S[1][ly][lx - 1], sppp = S[1][ly][lx];
+            const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+            const double xc = X[1][ly][lx];
+            double y = xc * s0;
+            y += w.corner * (X[0][ly - 1][lx - 1] * smmm + X[0][ly - 1][lx + 1] * spmm + X[0][ly + 1][lx - 1] * smpm + X[0][ly + 1][lx + 1] * sppm
+                           + X[2][ly - 1][lx - 1] * smmp + X[2][ly - 1][lx + 1] * spmp + X[2][ly + 1][lx - 1] * smpp + X[2][ly + 1][lx + 1] * sppp);
+            y += w.ex * (X[0][ly - 1][lx] * (smmm + spmm) + X[0][ly + 1][lx] * (smpm + sppm) + X[2][ly - 1][lx] * (smmp + spmp) + X[2][ly + 1][lx] * (smpp + sppp));
+            y += w.ey * (X[0][ly][lx - 1] * (smmm + smpm) + X[0][ly][lx + 1] * (spmm + sppm) + X[2][ly][lx - 1] * (smmp + smpp) + X[2][ly][lx + 1] * (spmp + sppp));
+            y += w.ez * (X[1][ly - 1][lx - 1] * (smmm + smmp) + X[1][ly - 1][lx + 1] * (spmm + spmp) + X[1][ly + 1][lx - 1] * (smpm + smpp) + X[1][ly + 1][lx + 1] * (sppm + sppp));
+            y += w.fx * (X[1][ly][lx - 1] * (smmm + smpm + smmp + smpp) + X[1][ly][lx + 1] * (spmm + sppm + spmp + sppp));
+            y += w.fy * (X[1][ly - 1][lx] * (smmm + spmm + smmp + spmp) + X[1][ly + 1][lx] * (smpm + sppm + smpp + sppp));
+            y += w.fz * (X[0][ly][lx] * (smmm + spmm + smpm + sppm) + X[2][ly][lx] * (smmp + spmp + smpp + sppp));
+            X[1][ly][lx] = xc + (r(i, j, k) - y) / s0;
+        }
+        __syncthreads();
+    }
+    const int wx = txe - tx0 + 1, wy = tye - ty0 + 1;
+    for (int idx = tid; idx < wx * wy; idx += 256) {
+        const int i = tx0 + idx % wx, j = ty0 + idx / wx;
+        x(i, j, k) = X[1][j - oy][i - ox];
+    }
+}
+
+// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
+void nodal_gs_fused_pass(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int kpar)
+{
+    if (x.nlocal() == 0) return;
+    IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3);
+    constexpr int TX = 32, TY = 16;
+    const Layout& l = *x.layout;
+    const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
+    dim3 grid((unsigned)(ntx * nty * npl), (unsigned)l.nlocal());
+    hipLaunchKernelGGL((k_nodal_gs4<TX, TY>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab,
+                       make_w(g), kpar, ntx, nty);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Coarse-level smoother: ALL sweeps x 8 colours of a small single-box, fully periodic level in ONE launch of
+// one workgroup (periodic images are taken by index wrap, colours are separated by __syncthreads).  Replaces
+// nsweeps*8*(ghost fill + colour kernel) launches whose cost on <= 32^3 levels is pure launch latency.
+// Same arithmetic and ordering as the general path (the wrapped neighbour IS the ghost value).
+__device__ __forceinline__ double node_Ax_wrap(const FabD& x, const FabD& s, const NodeW& w, int im, int i, int ip, int jm, int j, int jp,
+                                               int km, int k, int kp, double& s0)
+{
+    const double smmm = s(im, jm, km), spmm = s(i, jm, km), smpm = s(im, j, km), sppm = s(i, j, km);
+    const double smmp = s(im, jm, k), spmp = s(i, jm, k), smpp = s(im, j, k), sppp = s(i, j, k);
+    s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+    double y = x(i, j, k) * s0;
+    y += w.corner * (x(im, jm, km) * smmm + x(ip, jm, km) * spmm + x(im, jp, km) * smpm + x(ip, jp, km) * sppm
+                   + x(im, jm, kp) * smmp + x(ip, jm, kp) * spmp + x(im, jp, kp) * smpp + x(ip, jp, kp) * sppp);
+    y += w.ex * (x(i, jm, km) * (smmm + spmm) + x(i, jp, km) * (smpm + sppm) + x(i, jm, kp) * (smmp + spmp) + x(i, jp, kp) * (smpp + sppp));
+    y += w.ey * (x(im, j, km) * (smmm + smpm) + x(ip, j, km) * (spmm + sppm) + x(im, j, kp) * (smmp + smpp) + x(ip, j, kp) * (spmp + sppp));
+    y += w.ez * (x(im, jm, k) * (smmm + smmp) + x(ip, jm, k) * (spmm + spmp) + x(im, jp, k) * (smpm + smpp) + x(ip, jp, k) * (sppm + sppp));
+    y += w.fx * (x(im, j, k) * (smmm + smpm + smmp + smpp) + x(ip, j, k) * (spmm + sppm + spmp + sppp));
+    y += w.fy * (x(i, jm, k) * (smmm + spmm + smmp + spmp) + x(i, jp, k) * (smpm + sppm + smpp + sppp));
+    y += w.fz * (x(i, j, km) * (smmm + spmm + smpm + sppm) + x(i, j, kp) * (smmp + spmp + smpp + sppp));
+    return y;
+}
+
+__global__ void __launch_bounds__(1024) k_nodal_smooth_small(const FabD* __restrict__ xt, const FabD* __restrict__ rt,
+    const FabD* __restrict__ st, NodeW w, int n0, int n1, int n2, int lo0, int lo1, int lo2, int nsweeps)
+{
+    const FabD x = xt[0], r = rt[0], s = st[0];
+    const int h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
+    const int nlat = h0 * h1 * h2;
+    for (int ns = 0; ns < nsweeps; ++ns) {
+        for (int c = 0; c < 8; ++c) {
+            const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+            for (int idx = threadIdx.x; idx < nlat; idx += 1024) {
+                const int a = idx % h0, q = idx / h0;
+                const int b = q % h1, d = q / h1;
+                // unique nodes 0..n-1 relative to the box origin; absolute parity = (lo + rel) & 1, lo is even for a coarsenable box
+                const int ri = 2 * a + ((cx - lo0) & 1), rj = 2 * b + ((cy - lo1) & 1), rk = 2 * d + ((cz - lo2) & 1);
+                const int i = lo0 + ri, j = lo1 + rj, k = lo2 + rk;
+                const int im = lo0 + (ri == 0 ? n0 - 1 : ri - 1), ip = lo0 + (ri == n0 - 1 ? 0 : ri + 1);
+                const int jm = lo1 + (rj == 0 ? n1 - 1 : rj - 1), jp = lo1 + (rj == n1 - 1 ? 0 : rj + 1);
+                const int km = lo2 + (rk == 0 ? n2 - 1 : rk - 1), kp = lo2 + (rk == n2 - 1 ? 0 : rk + 1);
+                double s0;
+                const double Ax = node_Ax_wrap(x, s, w, im, i, ip, jm, j, jp, km, k, kp, s0);
+                x(i, j, k) += (r(i, j, k) - Ax) / s0;
+            }
+            __syncthreads();
+        }
+    }
+    // periodic duplicates (index n) take the owner's value; ghosts are filled by the caller's FillBoundary
+    const int m0 = n0 + 1, m1 = n1 + 1, m2 = n2 + 1;
+    for (int idx = threadIdx.x; idx < m0 * m1 * m2; idx += 1024) {
+        const int ri = idx % m0, q = idx / m0;
+        const int rj = q % m1, rk = q / m1;
+        if (ri == n0 || rj == n1 || rk == n2)
+            x(lo0 + ri, lo1 + rj, lo2 + rk) = x(lo0 + (ri == n0 ? 0 : ri), lo1 + (rj == n1 ? 0 : rj), lo2 + (rk == n2 ? 0 : rk));
+    }
+}
+
+// returns false if the level does not qualify (then the caller uses the general path)
+bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps)
+{
+    const Layout& l = *x.layout;
+    if (l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    const BoxD& b = l.boxes[0];
+    long cells = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (!g.periodic[d] || b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || (b.len(d) & 1)) return false;
+        cells *= b.len(d);
+    }
+    if (cells > 8L * 8 * 8) return false;     // measured: one workgroup wins up to 8^3 (13 us/sweep), loses from 32^3 on
+    hipLaunchKernelGGL(k_nodal_smooth_small, dim3(1), dim3(1024), 0, Context::get().stream, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g),
+                       b.len(0), b.len(1), b.len(2), b.lo[0], b.lo[1], b.lo[2], nsweeps);
+    return true;
+}
+
 // weighted Jacobi: x_new = x + (2/3) (rhs - A x)/s0 ; tmp holds x_new, then copied back by the caller
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig)
 {

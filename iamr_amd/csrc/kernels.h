@@ -57,6 +57,10 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
 // ---- k_nodal.hip --------------------------------------------------------------------------
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
 void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
+// one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3)
+void nodal_gs_fused_pass(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int kpar);
+// all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
+bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);

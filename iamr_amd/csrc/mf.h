@@ -74,7 +74,11 @@ struct Layout {
     const BoxD& lbox(int li) const { return boxes[local[li]]; }
     long local_cells() const;
     long total_cells() const;
+    // memoised: the multigrid hierarchies of successive solves share the same coarse Layout objects, so their
+    // ghost-exchange plans (keyed by layout id) are built once
     std::shared_ptr<Layout> coarsened(int ratio) const;
+    mutable std::shared_ptr<Layout> m_coarse;
+    mutable int m_coarse_ratio = 0;
     bool coarsenable(int ratio, int min_width) const;
 };
 using LayoutP = std::shared_ptr<Layout>;

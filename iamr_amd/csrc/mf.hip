@@ -127,9 +127,12 @@ bool Layout::coarsenable(int ratio, int min_width) const
 
 std::shared_ptr<Layout> Layout::coarsened(int ratio) const
 {
+    if (m_coarse && m_coarse_ratio == ratio) return m_coarse;
     std::vector<BoxD> cb;
     for (auto& b : boxes) cb.push_back(coarsen(b, ratio));
-    return std::make_shared<Layout>(cb, owner, Context::get().comm->rank);
+    m_coarse = std::make_shared<Layout>(cb, owner, Context::get().comm->rank);
+    m_coarse_ratio = ratio;
+    return m_coarse;
 }
 
 // ------------------------------------------------------------------ MultiFab
@@ -271,7 +274,11 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
 {
     // periodic shift candidates
     int smin[3], smax[3];
-    for (int d = 0; d < 3; ++d) { smin[d] = g.periodic[d] ? -1 : 0; smax[d] = g.periodic[d] ? 1 : 0; }
+    for (int d = 0; d < 3; ++d) {
+        // ghost regions wider than the domain (coarse MG levels with 4 ghost layers) need several periods
+        const int nper = g.periodic[d] ? std::max(1, (ng + g.domain.len(d) - 1) / g.domain.len(d)) : 0;
+        smin[d] = -nper; smax[d] = nper;
+    }
     const int nb = (int)boxes.size();
     for (int gd = 0; gd < nb; ++gd) {
         const bool dst_mine = owner[gd] == me;

@@ -118,7 +118,11 @@ int CellMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, 
     int ret = 0, nit = 1;
     double rho_1 = 0, alpha = 0, omega = 0;
     if (rnorm0 == 0 || rnorm0 < eps_abs) { niters = 0; MultiFab::Copy(sol, sorig, 0, 0, nc, 0); return 0; }
-    for (; nit <= m_o.bottom_maxiter; ++nit) {
+    // Krylov bound: an N-unknown system needs at most N iterations in exact arithmetic; more only chases round-off
+    // (observed: ~175 iterations per V-cycle on a 2^3 level whose rhs is at round-off level).  Cap at 2N.
+    const long nunk = (long)g.domain.npts() * nc;
+    const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+    for (; nit <= maxiter; ++nit) {
         double rho;
         { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&r}; reduce_dots(1, xs, ys, 0, nc, g, &rho); }
         if (rho == 0) { ret = 1; break; }

@@ -29,6 +29,11 @@ def nodal_gs_color(geom, phi, rhs, sig, color):
     check(lib().iamrx_nodal_gs_color(C.byref(geom), phi.h, rhs.h, sig.h, color))
 
 
+def nodal_gs_sweep(geom, phi, rhs, sig, fused=1):
+    """one 8-colour Gauss-Seidel sweep incl. ghost fills (fused: plane-fused two-pass variant, same arithmetic)"""
+    check(lib().iamrx_nodal_gs_sweep(C.byref(geom), phi.h, rhs.h, sig.h, int(fused)))
+
+
 def nodal_restrict(crse, fine):
     check(lib().iamrx_nodal_restrict(crse.h, fine.h))
 

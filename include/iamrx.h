@@ -153,6 +153,10 @@ int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, ia
 int iamrx_nodal_residual(const iamrx_geom* g, iamrx_mf out, iamrx_mf phi, iamrx_mf sig, iamrx_mf rhs);
 /* one colour (0..7) of the 8-colour Gauss-Seidel sweep */
 int iamrx_nodal_gs_color(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int color);
+/* one full 8-colour Gauss-Seidel sweep incl. its ghost fills.  fused = 0: eight colour passes (8 fills);
+ * fused = 1: plane-fused variant, two passes (2 fills), identical arithmetic; needs phi/sig ngrow >= 4, rhs >= 3
+ * (rhs ghosts must be filled by the caller) */
+int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int fused);
 int iamrx_nodal_restrict(iamrx_mf crse, iamrx_mf fine);
 int iamrx_nodal_interp_add(iamrx_mf fine, iamrx_mf crse, iamrx_mf sig_fine);
 int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp);

@@ -297,7 +297,11 @@ static int bicgstab(const mglev* m, orc_fab* sol, const orc_fab* rhs, const int 
     int ret = 0, nit = 1;
     double rho_1 = 0, alpha = 0, omega = 0;
     if (rnorm0 == 0 || rnorm0 < eps_abs) { nit = 0; goto done; }
-    for (; nit <= o->bottom_maxiter; ++nit) {
+    /* Krylov bound: at most 2N iterations for N unknowns (mirrors the product; beyond N only round-off is chased) */
+    long nunk = (long)n[0] * n[1] * n[2] * nc;
+    long cap = 2 * nunk < 8 ? 8 : 2 * nunk;
+    const int maxiter = (int)(o->bottom_maxiter < cap ? o->bottom_maxiter : cap);
+    for (; nit <= maxiter; ++nit) {
         const double rho = dot_valid(&rh, &r, n, nc);
         if (rho == 0) { ret = 1; break; }
         if (nit == 1) copy_valid(&p, &r, n, nc);

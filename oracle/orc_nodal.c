@@ -295,7 +295,12 @@ static int nd_bicgstab(const nlev* L, orc_fab* sol, const orc_fab* rhs, const or
     int ret = 0, nit = 1;
     double rho_1 = 0, alpha = 0, omega = 0;
     if (rnorm0 == 0 || rnorm0 < eps_abs) { nit = 0; goto done; }
-    for (; nit <= o->bottom_maxiter; ++nit) {
+    /* Krylov bound: at most 2N iterations for N unique nodes (mirrors the product) */
+    long nunk = 1;
+    for (int d = 0; d < 3; ++d) nunk *= g->n[d] + (g->periodic[d] ? 0 : 1);
+    long cap = 2 * nunk < 8 ? 8 : 2 * nunk;
+    const int maxiter = (int)(o->bottom_maxiter < cap ? o->bottom_maxiter : cap);
+    for (; nit <= maxiter; ++nit) {
         const double rho = nd_dot(g, &rh, &r);
         if (rho == 0) { ret = 1; break; }
         if (nit == 1) nd_copy(g, &p, &r);
