@@ -165,7 +165,13 @@ def main():
         torch.cuda.synchronize()
 
     mac_ms, nod_ms, visc_ms, mac_it, nod_it, visc_it = [], [], [], [], [], []
+    def nmalloc():
+        v = C.c_size_t()
+        lib.check(lib.lib().iamrx_alloc_count(C.byref(v)))
+        return v.value
+
     barrier()
+    m0 = nmalloc()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ns.step()
@@ -174,6 +180,7 @@ def main():
         mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
     barrier()
     el = time.perf_counter() - t0
+    mallocs_in_loop = nmalloc() - m0
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,6 +214,7 @@ def main():
             "mlmg_vcycle_ms": {"mac_cc": st.median(mac_ms), "nodal": st.median(nod_ms), "tensor_visc": st.median(visc_ms)},
             "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
             "sections_ms_per_step": {k: v / 2 for k, v in zip(["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"], sec[:6])},
+            "device_mallocs_in_timed_region": mallocs_in_loop,
             "kernels": kr,
             "roofline": roofline,
         }

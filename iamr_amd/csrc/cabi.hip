@@ -67,6 +67,12 @@ int iamrx_init(int device) { IAMRX_TRY Context::get().init(device); IAMRX_CATCH 
 int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH }
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
+int iamrx_alloc_count(size_t* n_device_malloc)
+{
+    IAMRX_TRY
+    *n_device_malloc = Context::get().n_device_malloc;
+    IAMRX_CATCH
+}
 int iamrx_mem_info(size_t* live, size_t* cached)
 {
     IAMRX_TRY
@@ -286,6 +292,14 @@ static std::vector<BCRec> to_bcrec(const int* b, int n)
     for (int i = 0; i < n; ++i)
         for (int d = 0; d < 3; ++d) { r[i].lo[d] = b ? b[6 * i + d] : 0; r[i].hi[d] = b ? b[6 * i + 3 + d] : 0; }
     return r;
+}
+
+int iamrx_mf_fill_physbc(iamrx_mf m, const iamrx_geom* g, int scomp, int ncomp, const int* bcrec, const double* edlo, const double* edhi)
+{
+    IAMRX_TRY
+    auto bc = to_bcrec(bcrec, ncomp);
+    fill_physbc_cc(to_geom(g), m->mf, scomp, ncomp, bc.data(), edlo, edhi);
+    IAMRX_CATCH
 }
 
 int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz,

@@ -1,0 +1,111 @@
+// iamr_amd/csrc/k_bc.hip -- physical boundary fill of cell-centred ghost cells outside the domain.
+//
+// Role: the BCRec-driven part of FillPatch (amrex FilccCell semantics: int_dir / ext_dir / foextrap / hoextrap /
+// reflect_even / reflect_odd) plus IAMR's ext-Dirichlet functors with constant boundary values
+// (reference Source/NS_bcfill.H:17-95, BC tables Source/NS_BC.H:7-55, values Source/NavierStokes.cpp:72-83,125-168).
+// Directions are applied one after the other (x, then y, then z) over the WHOLE grown extent of the other
+// directions, so edge/corner ghosts get the composition of the two/three one-dimensional rules.
+#include "kernels.h"
+#include "launch.h"
+#include <vector>
+#include <cstring>
+
+namespace iamrx {
+
+struct PhysBcDesc { int fab; BoxD region; int side; };
+struct PhysBcParams {
+    int dir, dlo, dhi;
+    int ncomp, scomp;
+    int bclo[8], bchi[8];
+    double edlo[8], edhi[8];
+};
+
+__global__ void __launch_bounds__(256) k_physbc(const PhysBcDesc* __restrict__ descs, const FabD* __restrict__ tab, PhysBcParams P)
+{
+    const PhysBcDesc bd = descs[blockIdx.y];
+    const FabD a = tab[bd.fab];
+    const int nx = bd.region.len(0), ny = bd.region.len(1);
+    const long npts = bd.region.npts();
+    const int d = P.dir;
+    const int fhi_d = a.lo[d] + a.n[d] - 1;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        int idx[3];
+        idx[0] = bd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        idx[1] = bd.region.lo[1] + (int)(r % ny);
+        idx[2] = bd.region.lo[2] + (int)(r / ny);
+        const int c = idx[d];
+        for (int n = 0; n < P.ncomp; ++n) {
+            const int bc = bd.side == 0 ? P.bclo[n] : P.bchi[n];
+            int s1[3] = {idx[0], idx[1], idx[2]}, s2[3] = {idx[0], idx[1], idx[2]}, s3[3] = {idx[0], idx[1], idx[2]};
+            double v;
+            if (bd.side == 0) {
+                if (bc == bc_foextrap) { s1[d] = P.dlo; v = a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_hoextrap) {
+                    s1[d] = P.dlo; s2[d] = P.dlo + 1; s3[d] = P.dlo + 2;
+                    if (c < P.dlo - 1) v = a(s1[0], s1[1], s1[2], P.scomp + n);
+                    else if (P.dlo + 2 <= (fhi_d < P.dhi ? fhi_d : P.dhi))
+                        v = 0.125 * (15. * a(s1[0], s1[1], s1[2], P.scomp + n) - 10. * a(s2[0], s2[1], s2[2], P.scomp + n) + 3. * a(s3[0], s3[1], s3[2], P.scomp + n));
+                    else v = 0.5 * (3. * a(s1[0], s1[1], s1[2], P.scomp + n) - a(s2[0], s2[1], s2[2], P.scomp + n));
+                }
+                else if (bc == bc_reflect_even) { s1[d] = 2 * P.dlo - c - 1; v = a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_reflect_odd) { s1[d] = 2 * P.dlo - c - 1; v = -a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_ext_dir) v = P.edlo[n];
+                else continue;
+            } else {
+                const int flo_d = a.lo[d];
+                if (bc == bc_foextrap) { s1[d] = P.dhi; v = a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_hoextrap) {
+                    s1[d] = P.dhi; s2[d] = P.dhi - 1; s3[d] = P.dhi - 2;
+                    if (c > P.dhi + 1) v = a(s1[0], s1[1], s1[2], P.scomp + n);
+                    else if (P.dhi - 2 >= (flo_d > P.dlo ? flo_d : P.dlo))
+                        v = 0.125 * (15. * a(s1[0], s1[1], s1[2], P.scomp + n) - 10. * a(s2[0], s2[1], s2[2], P.scomp + n) + 3. * a(s3[0], s3[1], s3[2], P.scomp + n));
+                    else v = 0.5 * (3. * a(s1[0], s1[1], s1[2], P.scomp + n) - a(s2[0], s2[1], s2[2], P.scomp + n));
+                }
+                else if (bc == bc_reflect_even) { s1[d] = 2 * P.dhi - c + 1; v = a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_reflect_odd) { s1[d] = 2 * P.dhi - c + 1; v = -a(s1[0], s1[1], s1[2], P.scomp + n); }
+                else if (bc == bc_ext_dir) v = P.edhi[n];
+                else continue;
+            }
+            a(idx[0], idx[1], idx[2], P.scomp + n) = v;
+        }
+    }
+}
+
+// bc[n], extdir_lo/hi[n*3+d] for the ncomp components starting at scomp (ncomp <= 8)
+void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const BCRec* bc, const double* extdir_lo, const double* extdir_hi)
+{
+    if (mf.nlocal() == 0 || mf.ngrow == 0) return;
+    IAMRX_ASSERT(ncomp <= 8 && mf.type.cell());
+    auto& ctx = Context::get();
+    for (int d = 0; d < 3; ++d) {
+        if (g.periodic[d]) continue;
+        std::vector<PhysBcDesc> descs;
+        long maxpts = 0;
+        for (int li = 0; li < mf.nlocal(); ++li) {
+            const BoxD fb = mf.fabbox(li);
+            for (int side = 0; side < 2; ++side) {
+                BoxD r = fb;
+                if (side == 0) { if (fb.lo[d] >= g.domain.lo[d]) continue; r.hi[d] = g.domain.lo[d] - 1; }
+                else { if (fb.hi[d] <= g.domain.hi[d]) continue; r.lo[d] = g.domain.hi[d] + 1; }
+                descs.push_back({li, r, side});
+                maxpts = std::max(maxpts, r.npts());
+            }
+        }
+        if (descs.empty()) continue;
+        PhysBcParams P;
+        P.dir = d; P.dlo = g.domain.lo[d]; P.dhi = g.domain.hi[d]; P.ncomp = ncomp; P.scomp = scomp;
+        for (int n = 0; n < 8; ++n) {
+            P.bclo[n] = n < ncomp ? bc[n].lo[d] : 0; P.bchi[n] = n < ncomp ? bc[n].hi[d] : 0;
+            P.edlo[n] = (n < ncomp && extdir_lo) ? extdir_lo[n * 3 + d] : 0.0;
+            P.edhi[n] = (n < ncomp && extdir_hi) ? extdir_hi[n * 3 + d] : 0.0;
+        }
+        PhysBcDesc* dd = (PhysBcDesc*)ctx.alloc(descs.size() * sizeof(PhysBcDesc));
+        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(PhysBcDesc));
+        long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(k_physbc, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, mf.d_tab, P);
+        ctx.free(dd);    // stream-ordered reuse
+    }
+}
+
+}  // namespace iamrx

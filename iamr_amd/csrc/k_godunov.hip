@@ -532,7 +532,7 @@ static const GodParams* upload_params(const GodParams& P)
     auto& ctx = Context::get();
     if (!ring) ring = (GodParams*)ctx.alloc(NSLOT * sizeof(GodParams));
     GodParams* d = ring + (slot++ % NSLOT);
-    IAMRX_HIP_CHECK(hipMemcpyAsync(d, &P, sizeof(GodParams), hipMemcpyHostToDevice, ctx.stream));
+    ctx.upload_async(d, &P, sizeof(GodParams));
     return d;
 }
 

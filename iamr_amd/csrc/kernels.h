@@ -20,6 +20,10 @@ void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, in
 void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng);
 void mf_mult(MultiFab& y, double a, int comp, int nc, int ng);
 
+// ---- k_bc.hip -----------------------------------------------------------------------------
+// physical-BC fill of cell-centred ghost cells outside the domain; extdir_lo/hi[n*3+d] constant ext_dir values
+void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
+
 // ---- k_abec.hip ---------------------------------------------------------------------------
 struct AbecCoef {
     double alpha, beta;

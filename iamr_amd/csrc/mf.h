@@ -44,6 +44,7 @@ struct Context {
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     size_t bytes_live = 0, bytes_cached = 0;
+    size_t n_device_malloc = 0;    // hipMalloc calls (cache misses): must stay flat inside the time loop
     double* d_scratch = nullptr;   // reduction scratch
     double* h_scratch = nullptr;   // pinned
     size_t scratch_n = 0;
@@ -55,6 +56,9 @@ struct Context {
     void release_cache();
     void sync();
     void ensure_scratch(size_t n);
+    void upload_async(void* dst, const void* src, size_t bytes);
+    char* h_ring = nullptr;
+    size_t ring_off = 0;
 };
 
 // ------------------------------------------------------------------ layout

@@ -54,6 +54,7 @@ void* Context::alloc(size_t bytes)
         return p;
     }
     void* p = nullptr;
+    ++n_device_malloc;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         release_cache();
@@ -85,6 +86,25 @@ void Context::release_cache()
 }
 
 void Context::sync() { if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+// small host->device uploads (descriptor tables, parameter blocks) without synchronising the stream: the source
+// is copied into a pinned ring buffer first, so the caller's memory may die immediately.  A slot is only reused
+// after RING bytes of later uploads; a stream sync is inserted on wrap-around to make that safe.
+void Context::upload_async(void* dst, const void* src, size_t bytes)
+{
+    constexpr size_t RING = 8u << 20;
+    if (bytes > RING / 4) {
+        IAMRX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        sync();
+        return;
+    }
+    if (!h_ring) IAMRX_HIP_CHECK(hipHostMalloc((void**)&h_ring, RING));
+    const size_t need = (bytes + 63) & ~size_t(63);
+    if (ring_off + need > RING) { sync(); ring_off = 0; }
+    std::memcpy(h_ring + ring_off, src, bytes);
+    IAMRX_HIP_CHECK(hipMemcpyAsync(dst, h_ring + ring_off, bytes, hipMemcpyHostToDevice, stream));
+    ring_off += need;
+}
 
 // ------------------------------------------------------------------ Layout
 static std::atomic<uint64_t> g_layout_id{1};
@@ -184,8 +204,7 @@ void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)
     base = (double*)ctx.alloc(total_doubles * sizeof(double));
     for (int li = 0; li < nl; ++li) h_tab[li].p = base + offs[li];
     d_tab = (FabD*)ctx.alloc(nl * sizeof(FabD));
-    IAMRX_HIP_CHECK(hipMemcpyAsync(d_tab, h_tab.data(), nl * sizeof(FabD), hipMemcpyHostToDevice, ctx.stream));
-    ctx.sync();   // h_tab may be reallocated by a later move
+    ctx.upload_async(d_tab, h_tab.data(), nl * sizeof(FabD));   // staged through the pinned ring: no stream sync
 }
 
 void MultiFab::setVal(double v)

@@ -223,6 +223,13 @@ class MultiFab:
     def fill_boundary(self, geom):
         check(lib().iamrx_mf_fill_boundary(self.h, C.byref(geom)))
 
+    def fill_physbc(self, geom, bc, extdir_lo=None, extdir_hi=None, scomp=0, ncomp=None):
+        """physical BC fill outside the domain; bc: list of (lo[3], hi[3]) BCType codes per component"""
+        nc = self.ncomp if ncomp is None else ncomp
+        el = None if extdir_lo is None else (C.c_double * (3 * nc))(*[float(x) for row in extdir_lo for x in row])
+        eh = None if extdir_hi is None else (C.c_double * (3 * nc))(*[float(x) for row in extdir_hi for x in row])
+        check(lib().iamrx_mf_fill_physbc(self.h, C.byref(geom), scomp, nc, _bcrec(nc, bc), el, eh))
+
     def norm0(self, comp=0, ncomp=None, ngrow=0):
         out = C.c_double()
         check(lib().iamrx_mf_norm0(self.h, comp, self.ncomp if ncomp is None else ncomp, ngrow, C.byref(out)))

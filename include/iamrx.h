@@ -64,6 +64,7 @@ const char* iamrx_last_error(void);
 int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
 void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
 int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
+int iamrx_alloc_count(size_t* n_device_malloc);  /* hipMalloc calls so far (caching-allocator misses; The_Arena role) */
 /* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
  * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */
 int iamrx_timer_start(void);
@@ -100,6 +101,11 @@ int iamrx_mf_from_host(iamrx_mf m, int local_idx, const double* src);
 int iamrx_mf_setval(iamrx_mf m, double v);                                /* MultiFab::setVal */
 int iamrx_mf_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int ncomp, int ngrow);  /* MultiFab::Copy */
 int iamrx_mf_fill_boundary(iamrx_mf m, const iamrx_geom* g);              /* FillBoundary(geom.periodicity()): Source/MacProj.cpp:1127 */
+/* physical-BC fill of cell-centred ghost cells outside the domain (the BCRec part of FillPatch; ext_dir with constant
+ * boundary values as in Source/NS_bcfill.H:17-95 / Source/NavierStokes.cpp:72-83).  bcrec: [ncomp][6];
+ * extdir_lo/hi: [ncomp][3] boundary values (may be NULL) */
+int iamrx_mf_fill_physbc(iamrx_mf m, const iamrx_geom* g, int scomp, int ncomp, const int* bcrec, const double* extdir_lo,
+                         const double* extdir_hi);
 int iamrx_mf_norm0(iamrx_mf m, int comp, int ncomp, int ngrow, double* out);   /* MultiFab::norm0: Source/NavierStokesBase.cpp:4408 */
 
 /* host-only (works without a GPU): the ghost-exchange plan that `rank` executes for FillBoundary of a level
