@@ -350,7 +350,16 @@ int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
 }
 int iamrx_nodal_restrict(iamrx_mf c, iamrx_mf f) { IAMRX_TRY nodal_restrict(c->mf, f->mf); IAMRX_CATCH }
 int iamrx_nodal_interp_add(iamrx_mf f, iamrx_mf c, iamrx_mf s) { IAMRX_TRY nodal_interp_add(f->mf, c->mf, s->mf); IAMRX_CATCH }
-int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp) { IAMRX_TRY nodal_divu(to_geom(g), rhs->mf, vel->mf, vcomp); IAMRX_CATCH }
+int iamrx_nodal_divu(const iamrx_geom* g, iamrx_mf rhs, iamrx_mf vel, int vcomp)
+{
+    IAMRX_TRY
+    Geometry gg = to_geom(g);
+    DomainBC bc;      // non-periodic faces are treated as Neumann walls (the only non-periodic nodal BC implemented)
+    for (int d = 0; d < 3; ++d) bc.lo[d] = bc.hi[d] = gg.periodic[d] ? lo_periodic : lo_neumann;
+    bc.maxorder = 2;
+    nodal_divu(gg, rhs->mf, vel->mf, vcomp, &bc);
+    IAMRX_CATCH
+}
 int iamrx_nodal_compgrad(const iamrx_geom* g, iamrx_mf gp, iamrx_mf phi)
 {
     IAMRX_TRY nodal_mknewu(to_geom(g), nullptr, 0, phi->mf, nullptr, &gp->mf, false); IAMRX_CATCH

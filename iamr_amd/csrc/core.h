@@ -95,6 +95,8 @@ struct Geometry {
     BoxD domain;          // cell-centred index box
     double problo[3], probhi[3], dx[3];
     int periodic[3];
+    // nodal solves with Neumann walls: wall nodes carry weight 1/2 in sums and dot products (set by NodalMG)
+    int half_lo[3] = {0, 0, 0}, half_hi[3] = {0, 0, 0};
 };
 
 }  // namespace iamrx

@@ -165,13 +165,29 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng)
 // owner mask for nodal / face data: a box owns index hi+1 in a nodal direction only on a
 // non-periodic domain boundary (elsewhere that point is the low point of a neighbouring box or a
 // periodic image)
-struct OwnerInfo { int type[3]; int dhi[3]; int per[3]; };
-__device__ __forceinline__ bool is_owner(const OwnerInfo& o, const BoxD& cellbox, int i, int j, int k)
+struct OwnerInfo { int type[3]; int dlo[3]; int dhi[3]; int per[3]; int half_lo[3]; int half_hi[3]; };
+// weight of a point in sums / dot products: 0 for non-owner copies, 1/2 per Neumann wall a NODE lies on (the nodal
+// system is stored in doubled form at wall nodes: MLNodeLinOp dot mask), 1 otherwise
+__device__ __forceinline__ double owner_weight(const OwnerInfo& o, const BoxD& cellbox, int i, int j, int k)
 {
     const int idx[3] = {i, j, k};
-    for (int d = 0; d < 3; ++d)
-        if (o.type[d] && idx[d] == cellbox.hi[d] + 1 && (o.per[d] || idx[d] != o.dhi[d] + 1)) return false;
-    return true;
+    double w = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        if (!o.type[d]) continue;
+        if (idx[d] == cellbox.hi[d] + 1 && (o.per[d] || idx[d] != o.dhi[d] + 1)) return 0.0;
+        if (o.half_lo[d] && idx[d] == o.dlo[d]) w *= 0.5;
+        if (o.half_hi[d] && idx[d] == o.dhi[d] + 1) w *= 0.5;
+    }
+    return w;
+}
+static OwnerInfo make_owner(const MultiFab& m, const Geometry& g)
+{
+    OwnerInfo own;
+    for (int d = 0; d < 3; ++d) {
+        own.type[d] = m.type.t[d]; own.dlo[d] = g.domain.lo[d]; own.dhi[d] = g.domain.hi[d]; own.per[d] = g.periodic[d];
+        own.half_lo[d] = g.half_lo[d]; own.half_hi[d] = g.half_hi[d];
+    }
+    return own;
 }
 
 __global__ void __launch_bounds__(256) k_dots(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own, int nout,
@@ -187,12 +203,12 @@ __global__ void __launch_bounds__(256) k_dots(Tiling t, const BoxD* __restrict__
         const FabD a0 = x0[fab], b0 = y0[fab];
         for (int n = 0; n < nc; ++n)
             for (int k = k0; k <= k1; ++k)
-                if (is_owner(own, cb, i, j, k)) s0 += a0(i, j, k, comp + n) * b0(i, j, k, comp + n);
+                { const double w = owner_weight(own, cb, i, j, k); if (w != 0.0) s0 += w * (a0(i, j, k, comp + n) * b0(i, j, k, comp + n)); }
         if (nout > 1) {
             const FabD a1 = x1[fab], b1 = y1[fab];
             for (int n = 0; n < nc; ++n)
                 for (int k = k0; k <= k1; ++k)
-                    if (is_owner(own, cb, i, j, k)) s1 += a1(i, j, k, comp + n) * b1(i, j, k, comp + n);
+                    { const double w = owner_weight(own, cb, i, j, k); if (w != 0.0) s1 += w * (a1(i, j, k, comp + n) * b1(i, j, k, comp + n)); }
         }
     }
     const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -215,8 +231,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
         dim3 gr = t.grid();
         const int np = (int)(gr.x * gr.y);
         ctx.ensure_scratch((size_t)np * nout + 16);
-        OwnerInfo own;
-        for (int d = 0; d < 3; ++d) { own.type[d] = m.type.t[d]; own.dhi[d] = g.domain.hi[d]; own.per[d] = g.periodic[d]; }
+        const OwnerInfo own = make_owner(m, g);
         hipLaunchKernelGGL(k_dots, gr, Tiling::block(), 0, ctx.stream, t, m.layout->d_boxes, own, nout,
                            x[0]->d_tab, y[0]->d_tab, nout > 1 ? x[1]->d_tab : nullptr, nout > 1 ? y[1]->d_tab : nullptr,
                            comp, nc, ctx.d_scratch, np);
@@ -237,7 +252,7 @@ __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __rest
     if (tile_ijk(t, b, i, j, k0, k1)) {
         const FabD a = tab[fab];
         for (int k = k0; k <= k1; ++k)
-            if (is_owner(own, cb, i, j, k)) s += a(i, j, k, comp);
+            { const double w = owner_weight(own, cb, i, j, k); if (w != 0.0) s += w * a(i, j, k, comp); }
     }
     s = block_reduce<0>(s);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
@@ -251,12 +266,7 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g)
     dim3 gr = t.grid();
     const int np = (int)(gr.x * gr.y);
     ctx.ensure_scratch((size_t)np + 16);
-    OwnerInfo own;
-    for (int d = 0; d < 3; ++d) {
-        own.type[d] = mf.type.t[d];
-        own.dhi[d] = g.domain.hi[d];
-        own.per[d] = g.periodic[d];
-    }
+    const OwnerInfo own = make_owner(mf, g);
     hipLaunchKernelGGL(k_sum_unique, gr, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, own, mf.d_tab, comp, ctx.d_scratch);
     return finish_to_host(0, 1, np);
 }

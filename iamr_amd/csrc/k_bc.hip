@@ -108,4 +108,58 @@ void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Nodal data at Neumann walls: even reflection of the ghost nodes about the wall node, x(w - m) = x(w + m)
+// (mlndlap_applybc).  Directions one after the other over the full grown extent of the others.
+struct ReflDesc { int fab; BoxD region; int wall; };
+
+__global__ void __launch_bounds__(256) k_nodal_reflect(const ReflDesc* __restrict__ descs, const FabD* __restrict__ tab, int dir, int ncomp)
+{
+    const ReflDesc bd = descs[blockIdx.y];
+    const FabD a = tab[bd.fab];
+    const int nx = bd.region.len(0), ny = bd.region.len(1);
+    const long npts = bd.region.npts();
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        int idx[3];
+        idx[0] = bd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        idx[1] = bd.region.lo[1] + (int)(r % ny);
+        idx[2] = bd.region.lo[2] + (int)(r / ny);
+        int s[3] = {idx[0], idx[1], idx[2]};
+        s[dir] = 2 * bd.wall - idx[dir];
+        for (int n = 0; n < ncomp; ++n) a(idx[0], idx[1], idx[2], n) = a(s[0], s[1], s[2], n);
+    }
+}
+
+void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc)
+{
+    if (mf.nlocal() == 0 || mf.ngrow == 0) return;
+    auto& ctx = Context::get();
+    for (int d = 0; d < 3; ++d) {
+        if (g.periodic[d]) continue;
+        std::vector<ReflDesc> descs;
+        long maxpts = 0;
+        for (int li = 0; li < mf.nlocal(); ++li) {
+            const BoxD fb = mf.fabbox(li);
+            const int wlo = g.domain.lo[d], whi = g.domain.hi[d] + 1;      // wall node indices
+            if (bc.lo[d] == lo_neumann && fb.lo[d] < wlo) { BoxD r = fb; r.hi[d] = wlo - 1; descs.push_back({li, r, wlo}); maxpts = std::max(maxpts, r.npts()); }
+            if (bc.hi[d] == lo_neumann && fb.hi[d] > whi) { BoxD r = fb; r.lo[d] = whi + 1; descs.push_back({li, r, whi}); maxpts = std::max(maxpts, r.npts()); }
+        }
+        if (descs.empty()) continue;
+        ReflDesc* dd = (ReflDesc*)ctx.alloc(descs.size() * sizeof(ReflDesc));
+        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(ReflDesc));
+        long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(k_nodal_reflect, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, mf.d_tab, d, mf.ncomp);
+        ctx.free(dd);
+    }
+}
+
+// cell-centred mirror across every non-periodic wall (mlndlap_fillbc_cc for sigma): reflect_even on all faces
+void cc_mirror_bc(const Geometry& g, MultiFab& mf)
+{
+    BCRec bc[8];
+    for (int n = 0; n < 8; ++n) for (int d = 0; d < 3; ++d) bc[n].lo[d] = bc[n].hi[d] = bc_reflect_even;
+    fill_physbc_cc(g, mf, 0, mf.ncomp, bc, nullptr, nullptr);
+}
+
 }  // namespace iamrx

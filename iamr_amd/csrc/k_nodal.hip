@@ -351,22 +351,38 @@ void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_
 }
 
 // rhs(node) = FE divergence of the cell-centred velocity (mlndlap_divu); vel needs 1 filled ghost cell
-void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp)
+// bc (may be null = periodic / interior only): cells outside a Neumann wall contribute zero velocity and the rhs of
+// wall nodes is doubled per wall direction (mlndlap_divu + mlndlap_impose_neumann_bc)
+void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp, const DomainBC* bc)
 {
     if (rhs.nlocal() == 0) return;
     const FabD *rt = rhs.d_tab, *vt = vel.d_tab;
     const double fx = 0.25 / g.dx[0], fy = 0.25 / g.dx[1], fz = 0.25 / g.dx[2];
+    int wl[3], wh[3];     // Neumann wall flags
+    for (int d = 0; d < 3; ++d) {
+        wl[d] = (bc && !g.periodic[d] && bc->lo[d] == lo_neumann) ? 1 : 0;
+        wh[d] = (bc && !g.periodic[d] && bc->hi[d] == lo_neumann) ? 1 : 0;
+    }
+    const int wl0 = wl[0], wl1 = wl[1], wl2 = wl[2], wh0 = wh[0], wh1 = wh[1], wh2 = wh[2];
+    const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2], dh0 = g.domain.hi[0], dh1 = g.domain.hi[1], dh2 = g.domain.hi[2];
     for_each(*rhs.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         const FabD v = vt[f];
         double sx = 0.0, sy = 0.0, sz = 0.0;
         for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
             const int ci = i - 1 + cx, cj = j - 1 + cy, ck = k - 1 + cz;
-            sx += (cx ? 1.0 : -1.0) * v(ci, cj, ck, vcomp);
-            sy += (cy ? 1.0 : -1.0) * v(ci, cj, ck, vcomp + 1);
-            sz += (cz ? 1.0 : -1.0) * v(ci, cj, ck, vcomp + 2);
+            const bool outside = (wl0 && ci < dl0) || (wh0 && ci > dh0) || (wl1 && cj < dl1) || (wh1 && cj > dh1) || (wl2 && ck < dl2) || (wh2 && ck > dh2);
+            sx += (cx ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp));
+            sy += (cy ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp + 1));
+            sz += (cz ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp + 2));
         }
         double r = 0.0;
         r += fx * sx; r += fy * sy; r += fz * sz;
+        if (wl0 && i == dl0) r *= 2.0;
+        if (wh0 && i == dh0 + 1) r *= 2.0;
+        if (wl1 && j == dl1) r *= 2.0;
+        if (wh1 && j == dh1 + 1) r *= 2.0;
+        if (wl2 && k == dl2) r *= 2.0;
+        if (wh2 && k == dh2 + 1) r *= 2.0;
         rt[f](i, j, k) = r;
     });
 }

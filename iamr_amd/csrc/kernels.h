@@ -20,9 +20,13 @@ void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, in
 void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng);
 void mf_mult(MultiFab& y, double a, int comp, int nc, int ng);
 
+struct DomainBC;
 // ---- k_bc.hip -----------------------------------------------------------------------------
 // physical-BC fill of cell-centred ghost cells outside the domain; extdir_lo/hi[n*3+d] constant ext_dir values
 void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
+
+void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc);   // ghost nodes: even reflection about Neumann walls
+void cc_mirror_bc(const Geometry& g, MultiFab& mf);                           // cell-centred mirror across all non-periodic walls
 
 // ---- k_abec.hip ---------------------------------------------------------------------------
 struct AbecCoef {
@@ -68,7 +72,7 @@ bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, con
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
-void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp);
+void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp, const DomainBC* bc);
 // vel(vcomp..) -= sig*grad(phi) (vel may be null); gp (may be null) = or += grad(phi)
 void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& phi, const MultiFab* sig, MultiFab* gp, bool gp_increment);
 

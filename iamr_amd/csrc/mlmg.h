@@ -103,6 +103,7 @@ private:
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void subtract_mean(int l, MultiFab& mf);
+    void fillbc(int l, MultiFab& x);
     Geometry m_g;
     DomainBC m_bc;
     MGOpts m_o;

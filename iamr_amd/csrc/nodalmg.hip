@@ -37,10 +37,13 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MG
 {
     for (int d = 0; d < 3; ++d) {
         if (!g.periodic[d] && (bc.lo[d] == lo_dirichlet || bc.hi[d] == lo_dirichlet)) m_singular = false;
-        if (!g.periodic[d]) throw Error("iamrx NodalMG: non-periodic boundaries not implemented yet");
+        if (!g.periodic[d] && (bc.lo[d] != lo_neumann || bc.hi[d] != lo_neumann))
+            throw Error("iamrx NodalMG: only periodic and Neumann (wall) domain boundaries are implemented (no outflow/Dirichlet yet)");
+        // wall nodes carry weight 1/2 in sums and dot products (doubled rows, MLNodeLinOp dot mask)
+        m_g.half_lo[d] = m_g.half_hi[d] = g.periodic[d] ? 0 : 1;
     }
     m_lev.resize(1);
-    m_lev[0].g = g;
+    m_lev[0].g = m_g;
     m_lev[0].layout = std::move(layout);
     while ((int)m_lev.size() <= m_o.max_coarsening_level) {
         Level& f = m_lev.back();
@@ -69,10 +72,19 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
 {
     MultiFab::Copy(m_lev[0].sig, sig, comp, 0, 1, 0);
     m_lev[0].sig.FillBoundary(m_lev[0].g);
+    cc_mirror_bc(m_lev[0].g, m_lev[0].sig);                // mlndlap_fillbc_cc: mirror sigma across walls
     for (size_t l = 1; l < m_lev.size(); ++l) {
         cc_restrict(m_lev[l].sig, m_lev[l - 1].sig);      // arithmetic average (harmonic averaging off)
         m_lev[l].sig.FillBoundary(m_lev[l].g);
+        cc_mirror_bc(m_lev[l].g, m_lev[l].sig);
     }
+}
+
+// ghost nodes: same-level + periodic images, then even reflection about Neumann walls
+void NodalMG::fillbc(int l, MultiFab& x)
+{
+    x.FillBoundary(m_lev[l].g);
+    nodal_reflect_bc(m_lev[l].g, x, m_bc);
 }
 
 void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
@@ -80,36 +92,36 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
     Level& L = m_lev[l];
     // small single-box periodic levels: all sweeps x colours in one single-workgroup launch
     if (m_o.nodal_smoother == 0 && nodal_small() && nodal_smooth_small(L.g, x, rhs, L.sig, m_o.nodal_sweeps)) {
-        x.FillBoundary(L.g);
+        fillbc(l, x);
         return;
     }
     for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
         if (m_o.nodal_smoother == 0 && nodal_fused()) {
             // colours 0-3 (k even) in one pass, colours 4-7 (k odd) in a second one: identical arithmetic to the
             // eight sequential colour passes below
-            if (ns == 0) const_cast<MultiFab&>(rhs).FillBoundary(L.g);
-            x.FillBoundary(L.g);
+            if (ns == 0) fillbc(l, const_cast<MultiFab&>(rhs));
+            fillbc(l, x);
             nodal_gs_fused_pass(L.g, x, rhs, L.sig, 0);
-            x.FillBoundary(L.g);
+            fillbc(l, x);
             nodal_gs_fused_pass(L.g, x, rhs, L.sig, 1);
         } else if (m_o.nodal_smoother == 0) {
             for (int color = 0; color < 8; ++color) {
-                x.FillBoundary(L.g);
+                fillbc(l, x);
                 nodal_gs_color(L.g, x, rhs, L.sig, color);
             }
         } else {
             if (!L.tmp.defined()) L.tmp.define(L.layout, node_type(), 1, 1);
-            x.FillBoundary(L.g);
+            fillbc(l, x);
             nodal_jacobi(L.g, L.tmp, x, rhs, L.sig);
             MultiFab::Copy(x, L.tmp, 0, 0, 1, 0);
         }
     }
-    x.FillBoundary(L.g);
+    fillbc(l, x);
 }
 
 void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b)
 {
-    x.FillBoundary(m_lev[l].g);
+    fillbc(l, x);
     nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b);
 }
 
@@ -117,7 +129,7 @@ void NodalMG::subtract_mean(int l, MultiFab& mf)
 {
     const Geometry& g = m_lev[l].g;
     double cnt = 1.0;
-    for (int d = 0; d < 3; ++d) cnt *= (double)(g.domain.len(d) + (g.periodic[d] ? 0 : 1));
+    for (int d = 0; d < 3; ++d) cnt *= (double)g.domain.len(d);   // sum of weights: n unique nodes (periodic) or (n-1) + 2*(1/2) (walls)
     const double s = mf.sum_unique(g, 0);
     mf_add_scalar(mf, -s / cnt, 0, 1, 0);
 }
@@ -153,7 +165,7 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
             mf_lincomb(p, 1.0, r, beta, p, 0, 1, 0);
         }
         MultiFab::Copy(ph, p, 0, 0, 1, 0);
-        ph.FillBoundary(g);
+        fillbc(l, ph);
         nodal_residual(g, v, ph, L.sig, nullptr);
         double rhTv;
         { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&v}; reduce_dots(1, xs, ys, 0, 1, g, &rhTv); }
@@ -163,7 +175,7 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
         rnorm = s.norm0(0, 1, 0);
         if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
         MultiFab::Copy(sh, s, 0, 0, 1, 0);
-        sh.FillBoundary(g);
+        fillbc(l, sh);
         nodal_residual(g, t, sh, L.sig, nullptr);
         double tv[2];
         { const MultiFab* xs[2] = {&t, &t}; const MultiFab* ys[2] = {&t, &s}; reduce_dots(2, xs, ys, 0, 1, g, tv); }
@@ -190,7 +202,7 @@ void NodalMG::vcycle(MGStats& st)
         L.cor.setVal(0.0);
         for (int i = 0; i < m_o.nu1; ++i) smooth(l, L.cor, L.res);
         residual(l, L.rescor, L.cor, L.res);
-        L.rescor.FillBoundary(L.g);
+        fillbc(l, L.rescor);
         nodal_restrict(m_lev[l + 1].res, L.rescor);
     }
     {
@@ -216,7 +228,7 @@ void NodalMG::vcycle(MGStats& st)
     }
     for (int l = nl - 2; l >= 0; --l) {
         Level& L = m_lev[l];
-        m_lev[l + 1].cor.FillBoundary(m_lev[l + 1].g);
+        fillbc(l + 1, m_lev[l + 1].cor);
         nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
         for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res);
     }
@@ -261,7 +273,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx nodal MLMG: failed to converge after max_iters");
     }
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
-    phi.FillBoundary(L0.g);
+    fillbc(0, phi);
     return st;
 }
 

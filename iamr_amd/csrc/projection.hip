@@ -22,7 +22,7 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
     NodalMG mg(g, layout, bc, opts);
     mg.setSigma(sig, sig_comp);
     MultiFab rhs(layout, node_type(), 1, 0);
-    nodal_divu(g, rhs, vel, vcomp);
+    nodal_divu(g, rhs, vel, vcomp, &bc);
     MGStats st = mg.solve(phi, rhs, rel_tol, abs_tol);
     nodal_mknewu(g, &vel, vcomp, phi, &mg.sigma(0), gp, increment_gp);
     if (gp) gp->FillBoundary(g);

@@ -51,7 +51,9 @@ void orc_nodal_adotx(const orc_geom* g, orc_fab* y, const orc_fab* x, const orc_
         A4(y, i, j, k, 0) = node_Ax(g, x, sig, i, j, k, NULL);
 }
 
-void orc_nodal_divu(const orc_geom* g, orc_fab* rhs, const orc_fab* vel)
+/* mlndlap_divu + mlndlap_impose_neumann_bc: cells outside a Neumann wall contribute zero velocity, then the rhs of
+ * wall nodes is doubled per wall direction (the operator rows there are doubled by the mirrored ghost data). */
+void orc_nodal_divu_bc(const orc_geom* g, orc_fab* rhs, const orc_fab* vel, const int lobc[3], const int hibc[3])
 {
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
         double r = 0.0;
@@ -59,13 +61,30 @@ void orc_nodal_divu(const orc_geom* g, orc_fab* rhs, const orc_fab* vel)
             double fac = 0.25 / g->dx[d], s = 0.0;
             for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
                 int c[3] = {cx, cy, cz};
+                int cell[3] = {i - 1 + cx, j - 1 + cy, k - 1 + cz};
+                int outside = 0;
+                for (int e = 0; e < 3; ++e)
+                    if (!g->periodic[e] && ((cell[e] < 0 && lobc[e] == ORC_LO_NEUMANN) || (cell[e] > g->n[e] - 1 && hibc[e] == ORC_LO_NEUMANN))) outside = 1;
                 double sgn = c[d] ? 1.0 : -1.0;
-                s += sgn * A4(vel, i - 1 + cx, j - 1 + cy, k - 1 + cz, d);
+                s += sgn * (outside ? 0.0 : A4(vel, cell[0], cell[1], cell[2], d));
             }
             r += fac * s;
         }
+        const int idx[3] = {i, j, k};
+        for (int e = 0; e < 3; ++e) {
+            if (g->periodic[e]) continue;
+            if (idx[e] == 0 && lobc[e] == ORC_LO_NEUMANN) r *= 2.0;
+            if (idx[e] == g->n[e] && hibc[e] == ORC_LO_NEUMANN) r *= 2.0;
+        }
         A4(rhs, i, j, k, 0) = r;
     }
+}
+
+void orc_nodal_divu(const orc_geom* g, orc_fab* rhs, const orc_fab* vel)
+{
+    int bc[3];
+    for (int d = 0; d < 3; ++d) bc[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_NEUMANN;
+    orc_nodal_divu_bc(g, rhs, vel, bc, bc);
 }
 
 void orc_nodal_mknewu(const orc_geom* g, orc_fab* vel, const orc_fab* phi, const orc_fab* sig)
@@ -94,15 +113,63 @@ void orc_nodal_compgrad(const orc_geom* g, orc_fab* gp, const orc_fab* phi)
         }
 }
 
-static void nodal_fill(const orc_geom* g, orc_fab* x)
+/* Ghost nodes: periodic images, then even reflection about Neumann walls (mlndlap_applybc): x(lo-m) = x(lo+m).
+ * Directions are processed one after the other over the full extent of the others, so edge/corner ghosts compose. */
+static void nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], const int hibc[3])
 {
     orc_fill_periodic(x, g, ORC_NODE);
+    for (int d = 0; d < 3; ++d) {
+        if (g->periodic[d]) continue;
+        for (int k = x->lo[2]; k <= x->hi[2]; ++k) for (int j = x->lo[1]; j <= x->hi[1]; ++j) for (int i = x->lo[0]; i <= x->hi[0]; ++i) {
+            int idx[3] = {i, j, k}, s[3] = {i, j, k};
+            if (idx[d] < 0 && lobc && lobc[d] == ORC_LO_NEUMANN) s[d] = -idx[d];
+            else if (idx[d] > g->n[d] && hibc && hibc[d] == ORC_LO_NEUMANN) s[d] = 2 * g->n[d] - idx[d];
+            else continue;
+            A4(x, i, j, k, 0) = A4(x, s[0], s[1], s[2], 0);
+        }
+    }
+}
+static const int PERIODIC_BC[3] = {ORC_LO_PERIODIC, ORC_LO_PERIODIC, ORC_LO_PERIODIC};
+/* BCs of the solve in progress (the oracle is single-threaded) */
+static const int *g_lobc = PERIODIC_BC, *g_hibc = PERIODIC_BC;
+static void nodal_fill(const orc_geom* g, orc_fab* x) { nodal_fill_bc(g, x, g_lobc, g_hibc); }
+
+/* sigma ghost cells: periodic images, mirror across non-periodic walls (mlndlap_fillbc_cc): sig(lo-m) = sig(lo+m-1) */
+static void sigma_fill_bc(const orc_geom* g, orc_fab* s)
+{
+    orc_fill_periodic(s, g, ORC_CELL);
+    for (int d = 0; d < 3; ++d) {
+        if (g->periodic[d]) continue;
+        for (int k = s->lo[2]; k <= s->hi[2]; ++k) for (int j = s->lo[1]; j <= s->hi[1]; ++j) for (int i = s->lo[0]; i <= s->hi[0]; ++i) {
+            int idx[3] = {i, j, k}, q[3] = {i, j, k};
+            if (idx[d] < 0) q[d] = -idx[d] - 1;
+            else if (idx[d] > g->n[d] - 1) q[d] = 2 * g->n[d] - 1 - idx[d];
+            else continue;
+            A4(s, i, j, k, 0) = A4(s, q[0], q[1], q[2], 0);
+        }
+    }
+}
+
+/* weight of a node in sums / dot products: 0 for periodic duplicates, 1/2 per Neumann wall the node lies on
+ * (the nodal system is stored in the "doubled" form A_full = 2^k A_half at wall nodes; MLNodeLinOp dot mask) */
+static inline double node_weight(const orc_geom* g, const int lobc[3], const int hibc[3], int i, int j, int k)
+{
+    const int idx[3] = {i, j, k};
+    double w = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        if (g->periodic[d]) { if (idx[d] == g->n[d]) return 0.0; }
+        else {
+            if (idx[d] == 0 && lobc[d] == ORC_LO_NEUMANN) w *= 0.5;
+            if (idx[d] == g->n[d] && hibc[d] == ORC_LO_NEUMANN) w *= 0.5;
+        }
+    }
+    return w;
 }
 
 void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const orc_fab* sig, int smoother, int nsweeps,
                       const int lobc[3], const int hibc[3])
 {
-    (void)lobc; (void)hibc;
+    g_lobc = lobc ? lobc : PERIODIC_BC; g_hibc = hibc ? hibc : PERIODIC_BC;
     for (int ns = 0; ns < nsweeps; ++ns) {
         if (smoother == 0) {
             for (int color = 0; color < 8; ++color) {
@@ -250,14 +317,14 @@ static double nd_dot(const orc_geom* g, const orc_fab* x, const orc_fab* y)
 {
     double s = 0.0;
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
-        if (owner(g, i, j, k)) s += A4(x, i, j, k, 0) * A4(y, i, j, k, 0);
+    { const double w = node_weight(g, g_lobc, g_hibc, i, j, k); if (w != 0.0) s += w * (A4(x, i, j, k, 0) * A4(y, i, j, k, 0)); }
     return s;
 }
 static void nd_subtract_mean(const orc_geom* g, orc_fab* f)
 {
     double s = 0.0, cnt = 0.0;
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
-        if (owner(g, i, j, k)) { s += A4(f, i, j, k, 0); cnt += 1.0; }
+    { const double w = node_weight(g, g_lobc, g_hibc, i, j, k); if (w != 0.0) { s += w * A4(f, i, j, k, 0); cnt += w; } }
     double off = s / cnt;
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
         A4(f, i, j, k, 0) -= off;
@@ -385,12 +452,13 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, con
 {
     nlev mg[32];
     memset(mg, 0, sizeof(mg));
+    g_lobc = lobc ? lobc : PERIODIC_BC; g_hibc = hibc ? hibc : PERIODIC_BC;
     int nl = 1;
     mg[0].g = *g;
     mg[0].sig = orc_alloc(g->n, ORC_CELL, 1, 1);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&mg[0].sig, i, j, k, 0) = A4(sig, i, j, k, 0);
-    orc_fill_periodic(&mg[0].sig, g, ORC_CELL);
+    sigma_fill_bc(g, &mg[0].sig);
     while (nl <= o->max_coarsening_level && nl < 32) {
         const orc_geom* fg = &mg[nl - 1].g;
         int ok = 1;
@@ -400,7 +468,7 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, con
         for (int d = 0; d < 3; ++d) { mg[nl].g.n[d] = fg->n[d] / 2; mg[nl].g.dx[d] = fg->dx[d] * 2.0; }
         mg[nl].sig = orc_alloc(mg[nl].g.n, ORC_CELL, 1, 1);
         orc_cc_restrict(&mg[nl].sig, &mg[nl - 1].sig, mg[nl].g.n);
-        orc_fill_periodic(&mg[nl].sig, &mg[nl].g, ORC_CELL);
+        sigma_fill_bc(&mg[nl].g, &mg[nl].sig);
         ++nl;
     }
     for (int l = 0; l < nl; ++l) {
@@ -448,7 +516,7 @@ void orc_nodal_project(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_
                        const orc_mg_opts* o, orc_mg_stats* st)
 {
     orc_fab rhs = orc_alloc(g->n, ORC_NODE, 0, 1);
-    orc_nodal_divu(g, &rhs, vel);
+    orc_nodal_divu_bc(g, &rhs, vel, lobc, hibc);
     orc_nodal_solve(g, phi, &rhs, sig, lobc, hibc, rtol, atol, o, st);
     orc_nodal_mknewu(g, vel, phi, sig);
     orc_free(&rhs);

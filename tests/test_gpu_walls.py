@@ -128,6 +128,42 @@ def test_godunov_with_walls(orc, gpu, boxes):
         assert np.array_equal(aofs_d.gather_valid(n), aofs_o.valid(n))
 
 
+@pytest.mark.parametrize("per,boxes", [((0, 0, 0), None), ((0, 1, 0), None), ((0, 0, 0), 8)])
+def test_nodal_projection_with_neumann_walls(orc, gpu, per, boxes):
+    """nodal projection in a box with solid walls (Neumann for phi; LidDrivenCavity / RayleighTaylor set-up):
+    mirrored sigma and phi ghosts, zero velocity outside, doubled wall rows, half-weighted wall nodes in sums."""
+    lib = gpu
+    from iamr_amd import ns as N
+    L = orc.lib()
+    n = (16, 16, 16)
+    g_o = orc.geom(n, periodic=per)
+    g_d = lib.Geom.make(n, periodic=per)
+    lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
+    xc = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*xc, indexing="ij")
+    sig = orc.Fab(n, orc.CELL, 1, 1)
+    sig.a[..., 0] = 1.0 / (1.0 + 0.5 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y))
+    vel = orc.Fab(n, orc.CELL, 1, 3)
+    vel.a[..., 0] = np.sin(np.pi * X) * np.cos(np.pi * Y) * np.cos(np.pi * Z) + 0.2 * np.sin(np.pi * X)
+    vel.a[..., 1] = np.cos(np.pi * X) * np.sin(2 * np.pi * Y) * np.cos(np.pi * Z)
+    vel.a[..., 2] = 0.7 * np.cos(np.pi * X) * np.cos(np.pi * Y) * np.sin(np.pi * Z)
+    L.orc_fill_periodic(vel.ref(), C.byref(g_o), orc.i3(orc.CELL))
+    bc = [0 if per[d] else 102 for d in range(3)]
+    vel_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel_d.set_from_global(vel.a, vel.lo)
+    sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global(sig.a, sig.lo)
+    p_o = orc.Fab(n, orc.NODE, 1, 1)
+    st_o = orc.CMgStats()
+    oo = orc.mg_opts()
+    L.orc_nodal_project(C.byref(g_o), vel.ref(), p_o.ref(), sig.ref(), orc.i3(bc), orc.i3(bc), C.c_double(1e-11), C.c_double(1e-16),
+                        C.byref(oo), C.byref(st_o))
+    p_d = lib.MultiFab(lay, lib.NODE, 1, 1); p_d.setval(0.0)
+    st = N.nodal_projection(g_d, vel_d, 0, p_d, sig_d, 0, lobc=bc, hibc=bc, rel_tol=1e-11)
+    assert st.converged == 1 and st_o.converged == 1 and st.iters == st_o.iters, (st.iters, st_o.iters)
+    pg = p_d.gather_valid(n)[..., 0]; pr = p_o.valid(n, orc.NODE)[..., 0]
+    assert np.abs((pg - pg.mean()) - (pr - pr.mean())).max() <= 1e-8 * np.abs(pr - pr.mean()).max()
+    assert np.abs(vel_d.gather_valid(n) - vel.valid(n)).max() <= 1e-8
+
+
 @pytest.mark.parametrize("bctype,alpha", [(102, 0.0), (101, 0.0), (101, 1.0), (102, 1.0)])
 def test_cell_mg_with_domain_bcs(orc, gpu, bctype, alpha):
     """MLABecLaplacian solve with Neumann (102, MAC projection at walls) / Dirichlet (101, diffusion) faces in x and z,
