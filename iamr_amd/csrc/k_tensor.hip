@@ -5,6 +5,8 @@
 // :858-923 (implicit solve); SURVEY a10, a11.
 #include "kernels.h"
 #include "launch.h"
+#include <vector>
+#include <algorithm>
 
 namespace iamrx {
 
@@ -94,13 +96,106 @@ void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir)
     });
 }
 
-// edge/corner ghost cells of the velocity needed by the cross terms.  Fully periodic levels get them
-// from FillBoundary; wall-bounded levels: TODO(next): mltensor_fill_edges/corners.
-void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc)
+// Edge/corner ghost cells of the velocity needed by the cross terms (MLTensorOp::applyBCTensor ->
+// mltensor_fill_edges / mltensor_fill_corners).  Fully periodic or interior edges are filled by FillBoundary.  A cell
+// outside the box in >= 2 directions of which at least one is a non-periodic domain face gets the average over those
+// exterior directions of the one-dimensional face rule applied along that direction (Neumann: neighbour copy;
+// Dirichlet: the face extrapolation polynomial on the already filled ghost cells + boundary value of bcval).
+struct EdgeDesc { int fab; BoxD region; int sgn[3]; int ext[3]; };
+struct EdgeParams { int bclo[3], bchi[3]; int NX[3]; double c[3][4]; int inhomog; int ncomp; };
+
+__global__ void __launch_bounds__(256) k_tensor_edges(const EdgeDesc* __restrict__ descs, const FabD* __restrict__ pt,
+                                                      const FabD* __restrict__ bvt, EdgeParams P)
 {
-    (void)phi; (void)bc;
-    for (int d = 0; d < 3; ++d)
-        if (!g.periodic[d]) throw Error("iamrx: tensor operator with non-periodic boundaries not implemented yet");
+    const EdgeDesc ed = descs[blockIdx.y];
+    const FabD phi = pt[ed.fab];
+    const int nx = ed.region.len(0), ny = ed.region.len(1);
+    const long npts = ed.region.npts();
+    const int next = ed.ext[0] + ed.ext[1] + ed.ext[2];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        int idx[3];
+        idx[0] = ed.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        idx[1] = ed.region.lo[1] + (int)(r % ny);
+        idx[2] = ed.region.lo[2] + (int)(r / ny);
+        for (int n = 0; n < P.ncomp; ++n) {
+            double sum = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                if (!ed.ext[d]) continue;
+                const int bct = ed.sgn[d] < 0 ? P.bclo[d] : P.bchi[d];
+                const int s = ed.sgn[d] < 0 ? 1 : -1;
+                double v;
+                int m3[3] = {idx[0], idx[1], idx[2]};
+                if (bct == lo_neumann) { m3[d] += s; v = phi(m3[0], m3[1], m3[2], n); }
+                else {
+                    const double bv = (P.inhomog && bvt) ? bvt[ed.fab](idx[0], idx[1], idx[2], n) : 0.0;
+                    if (P.NX[d] < 2) v = bv;
+                    else {
+                        double tmp = 0.0;
+                        for (int m = 1; m < P.NX[d]; ++m) { m3[d] = idx[d] + m * s; tmp += phi(m3[0], m3[1], m3[2], n) * P.c[d][m]; }
+                        v = tmp + bv * P.c[d][0];
+                    }
+                }
+                sum += v;
+            }
+            phi(idx[0], idx[1], idx[2], n) = sum / (double)next;
+        }
+    }
+}
+
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval)
+{
+    bool anywall = false;
+    for (int d = 0; d < 3; ++d) if (!g.periodic[d]) anywall = true;
+    if (!anywall || phi.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    EdgeParams P;
+    for (int d = 0; d < 3; ++d) {
+        P.bclo[d] = bc.lo[d]; P.bchi[d] = bc.hi[d];
+        const int blen = g.domain.len(d);
+        P.NX[d] = blen + 1 < bc.maxorder ? blen + 1 : bc.maxorder;
+        const double x[4] = {0.0, 0.5, 1.5, 2.5};
+        for (int j = 0; j < 4; ++j) P.c[d][j] = 0.0;
+        for (int j = 0; j < P.NX[d]; ++j) {
+            double num = 1.0, den = 1.0;
+            for (int i = 0; i < P.NX[d]; ++i) { if (i == j) continue; num *= -0.5 - x[i]; den *= x[j] - x[i]; }
+            P.c[d][j] = num / den;
+        }
+    }
+    P.inhomog = inhomog ? 1 : 0;
+    P.ncomp = phi.ncomp;
+    for (int nout = 2; nout <= 3; ++nout) {
+        std::vector<EdgeDesc> descs;
+        long maxpts = 0;
+        for (int li = 0; li < phi.nlocal(); ++li) {
+            const BoxD vb = phi.layout->lbox(li);
+            for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+                const int sg[3] = {sx, sy, sz};
+                if ((sx != 0) + (sy != 0) + (sz != 0) != nout) continue;
+                EdgeDesc e;
+                e.fab = li;
+                int next = 0;
+                for (int d = 0; d < 3; ++d) {
+                    e.sgn[d] = sg[d];
+                    e.region.lo[d] = sg[d] < 0 ? vb.lo[d] - 1 : (sg[d] > 0 ? vb.hi[d] + 1 : vb.lo[d]);
+                    e.region.hi[d] = sg[d] < 0 ? vb.lo[d] - 1 : (sg[d] > 0 ? vb.hi[d] + 1 : vb.hi[d]);
+                    const bool at_face = sg[d] < 0 ? vb.lo[d] == g.domain.lo[d] : (sg[d] > 0 ? vb.hi[d] == g.domain.hi[d] : false);
+                    e.ext[d] = (sg[d] != 0 && !g.periodic[d] && at_face) ? 1 : 0;
+                    next += e.ext[d];
+                }
+                if (next == 0) continue;
+                descs.push_back(e);
+                maxpts = std::max(maxpts, e.region.npts());
+            }
+        }
+        if (descs.empty()) continue;
+        EdgeDesc* dd = (EdgeDesc*)ctx.alloc(descs.size() * sizeof(EdgeDesc));
+        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(EdgeDesc));
+        long nb = (maxpts + 255) / 256; if (nb > 16) nb = 16; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(k_tensor_edges, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, phi.d_tab,
+                           bcval ? bcval->d_tab : nullptr, P);
+        ctx.free(dd);
+    }
 }
 
 }  // namespace iamrx

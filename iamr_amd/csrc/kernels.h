@@ -79,6 +79,6 @@ void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& p
 // ---- k_tensor.hip -------------------------------------------------------------------------
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);
-void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc);
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval);
 
 }  // namespace iamrx

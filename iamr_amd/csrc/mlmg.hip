@@ -69,13 +69,12 @@ void CellMG::prepare()
     }
 }
 
-void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc);   // k_tensor.hip
 
 void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
 {
     phi.FillBoundary(m_lev[l].g);
     abec_apply_domain_bc(m_lev[l].g, phi, m_bc, inhomog, bcval);
-    if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bc);
+    if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bc, inhomog, bcval);
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)

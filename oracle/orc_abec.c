@@ -21,6 +21,8 @@ void orc_mg_default_opts(orc_mg_opts* o)
 /* ---------------------------------------------------------------- operator ----- */
 void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_fab* x); /* orc_tensor.c */
 int orc_abec_is_tensor(const orc_abec_level* L);                                          /* orc_tensor.c */
+void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
+                                   int maxorder, int inhomog, const orc_fab* bcval);    /* orc_tensor.c */
 
 void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x)
 {
@@ -113,6 +115,7 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
             }
         }
     }
+    if (orc_abec_is_tensor(L)) orc_tensor_fill_edges_corners(L, phi, lobc, hibc, maxorder, inhomog, bcval);
 }
 
 void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, int redblack, double omega,

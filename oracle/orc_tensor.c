@@ -12,6 +12,65 @@
 
 int orc_abec_is_tensor(const orc_abec_level* L) { return L->tensor; }
 
+/* Edge and corner ghost cells needed by the cross terms (MLTensorOp::applyBCTensor -> mltensor_fill_edges/corners).
+ * A ghost cell that is outside the box in two or three directions and, in at least one of them, outside a
+ * NON-periodic domain face gets the AVERAGE over those exterior directions d of the one-dimensional BC rule applied
+ * along d (Neumann: copy of the neighbour; Dirichlet: the same extrapolation polynomial as on faces, using the ghost
+ * cells already filled with one exterior direction less, plus the boundary value stored in that cell of bcval).
+ * Cells whose outside directions are all periodic are plain periodic images. */
+static void lagr(double xi, const double* x, int N, double* c)
+{
+    for (int j = 0; j < N; ++j) {
+        double num = 1.0, den = 1.0;
+        for (int i = 0; i < N; ++i) { if (i == j) continue; num *= xi - x[i]; den *= x[j] - x[i]; }
+        c[j] = num / den;
+    }
+}
+
+void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
+                                   int maxorder, int inhomog, const orc_fab* bcval)
+{
+    const orc_geom* g = &L->g;
+    int anywall = 0;
+    for (int d = 0; d < 3; ++d) if (!g->periodic[d]) anywall = 1;
+    if (!anywall) return;
+    for (int nout = 2; nout <= 3; ++nout)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        const int idx[3] = {i, j, k};
+        int out[3], cnt = 0, next = 0;
+        for (int d = 0; d < 3; ++d) { out[d] = idx[d] < 0 ? -1 : (idx[d] > g->n[d] - 1 ? 1 : 0); if (out[d]) ++cnt; }
+        if (cnt != nout) continue;
+        for (int d = 0; d < 3; ++d) if (out[d] && !g->periodic[d]) ++next;
+        if (next == 0) continue;
+        for (int n = 0; n < L->ncomp; ++n) {
+            double sum = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                if (!out[d] || g->periodic[d]) continue;
+                const int bct = out[d] < 0 ? lobc[d] : hibc[d];
+                const int s = out[d] < 0 ? 1 : -1;
+                double v;
+                if (bct == ORC_LO_NEUMANN) {
+                    int q[3] = {i, j, k}; q[d] += s;
+                    v = A4(phi, q[0], q[1], q[2], n);
+                } else {
+                    const int NX = g->n[d] + 1 < maxorder ? g->n[d] + 1 : maxorder;
+                    const double bv = (inhomog && bcval) ? A4(bcval, i, j, k, n) : 0.0;
+                    if (NX < 2) v = bv;
+                    else {
+                        double x[4] = {0.0, 0.5, 1.5, 2.5}, c[4];
+                        lagr(-0.5, x, NX, c);
+                        double tmp = 0.0;
+                        for (int m = 1; m < NX; ++m) { int q[3] = {i, j, k}; q[d] += m * s; tmp += A4(phi, q[0], q[1], q[2], n) * c[m]; }
+                        v = tmp + bv * c[0];
+                    }
+                }
+                sum += v;
+            }
+            A4(phi, i, j, k, n) = sum / (double)next;
+        }
+    }
+}
+
 void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_fab* v)
 {
     const orc_geom* g = &L->g;
