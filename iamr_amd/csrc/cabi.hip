@@ -221,7 +221,8 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, 
                     iamrx_mf phi, iamrx_mf rhs, int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder)
 {
     IAMRX_TRY
-    abec_gsrb(to_geom(g), make_coef(alpha, beta, a, bx, by, bz, 0), phi->mf, rhs->mf, redblack, omega, to_bc(lobc, hibc, maxorder));
+    DomainBC b = to_bc(lobc, hibc, maxorder);
+    abec_gsrb(to_geom(g), make_coef(alpha, beta, a, bx, by, bz, 0), phi->mf, rhs->mf, redblack, omega, &b, 1);
     IAMRX_CATCH
 }
 
@@ -378,23 +379,28 @@ int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_m
 }
 
 int iamrx_tensor_apply(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
-                       iamrx_mf ez, const int lobc[3], const int hibc[3], int maxorder)
+                       iamrx_mf ez, const int* lobc, const int* hibc, int nbc, int maxorder)
 {
     IAMRX_TRY
+    IAMRX_ASSERT(nbc == 1 || nbc == 3);
     const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
-    tensor_apply(to_geom(g), out->mf, vel->mf, a, b, acoef ? &acoef->mf : nullptr, eta, to_bc(lobc, hibc, maxorder));
+    DomainBC bcs[3];
+    for (int n = 0; n < nbc; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, maxorder);
+    tensor_apply(to_geom(g), out->mf, vel->mf, a, b, acoef ? &acoef->mf : nullptr, eta, bcs, nbc);
     IAMRX_CATCH
 }
 
 int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
-                       iamrx_mf ez, const int lobc[3], const int hibc[3], double tol_rel, double tol_abs, const iamrx_mg_opts* o,
+                       iamrx_mf ez, const int* lobc, const int* hibc, int nbc, double tol_rel, double tol_abs, const iamrx_mg_opts* o,
                        iamrx_mg_stats* st)
 {
     IAMRX_TRY
+    IAMRX_ASSERT(nbc == 1 || nbc == 3);
     MGOpts op = to_opts(o);
     const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
-    MGStats s = tensor_solve(to_geom(g), soln->mf, rhs->mf, a, b, acoef ? &acoef->mf : nullptr, eta, to_bc(lobc, hibc, op.maxorder),
-                             tol_rel, tol_abs, op);
+    DomainBC bcs[3];
+    for (int n = 0; n < nbc; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, op.maxorder);
+    MGStats s = tensor_solve(to_geom(g), soln->mf, rhs->mf, a, b, acoef ? &acoef->mf : nullptr, eta, bcs, nbc, tol_rel, tol_abs, op);
     from_stats(s, st);
     IAMRX_CATCH
 }

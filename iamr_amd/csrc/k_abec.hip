@@ -16,7 +16,8 @@ namespace iamrx {
 
 struct GsrbBC {
     int dlo[3], dhi[3];
-    double cflo[3], cfhi[3];   // coefficient of the first interior cell in the ghost formula; 0 for periodic
+    double cflo[3][3], cfhi[3][3];   // [comp][dir]: coefficient of the first interior cell in the ghost formula; 0 for periodic
+    int nbc;                         // 1: the same BC for every component
 };
 
 // Lagrange weights for ghost-cell extrapolation through a Dirichlet face (AMReX poly_interp_coeff):
@@ -37,19 +38,23 @@ static void dirichlet_coefs(int blen, int maxorder, double c[4], int& NX)
     if (NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
 }
 
-static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC& bc)
+static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
 {
     GsrbBC r;
-    for (int d = 0; d < 3; ++d) {
-        r.dlo[d] = g.domain.lo[d]; r.dhi[d] = g.domain.hi[d];
-        r.cflo[d] = r.cfhi[d] = 0.0;
-        if (g.periodic[d]) continue;
-        for (int side = 0; side < 2; ++side) {
-            const int b = side == 0 ? bc.lo[d] : bc.hi[d];
-            double cf = 0.0;
-            if (b == lo_neumann) cf = 1.0;
-            else if (b == lo_dirichlet) { double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX); cf = NX >= 2 ? c[1] : 0.0; }
-            (side == 0 ? r.cflo[d] : r.cfhi[d]) = cf;
+    r.nbc = nbc;
+    for (int d = 0; d < 3; ++d) { r.dlo[d] = g.domain.lo[d]; r.dhi[d] = g.domain.hi[d]; }
+    for (int n = 0; n < 3; ++n) {
+        const DomainBC& bc = bcs[n < nbc ? n : 0];
+        for (int d = 0; d < 3; ++d) {
+            r.cflo[n][d] = r.cfhi[n][d] = 0.0;
+            if (g.periodic[d]) continue;
+            for (int side = 0; side < 2; ++side) {
+                const int b = side == 0 ? bc.lo[d] : bc.hi[d];
+                double cf = 0.0;
+                if (b == lo_neumann) cf = 1.0;
+                else if (b == lo_dirichlet) { double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX); cf = NX >= 2 ? c[1] : 0.0; }
+                (side == 0 ? r.cflo[n][d] : r.cfhi[n][d]) = cf;
+            }
         }
     }
     return r;
@@ -73,14 +78,15 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
-    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[1] : 0.0;
     for (int n = 0; n < ncomp; ++n) {
         const int nb = bnc == 1 ? 0 : n;
+        const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
+        const double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
         for (int k = k0; k <= k1; ++k) {
             const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
             if (i > b.hi[0]) continue;
-            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[0] : 0.0;
-            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[2] : 0.0;
+            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
+            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
             const double bxm = bX(i, j, k, nb), bxp = bX(i + 1, j, k, nb);
             const double bym = bY(i, j, k, nb), byp = bY(i, j + 1, k, nb);
             const double bzm = bZ(i, j, k, nb), bzp = bZ(i, j, k + 1, nb);
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     }
 }
 
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC& bc)
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc)
 {
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
@@ -105,7 +111,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     int ml[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
     Tiling t = make_tiling(ml, l.nlocal(), 8);
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
-    GsrbBC gb = make_gsrb_bc(g, bc);
+    GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
     hipLaunchKernelGGL(k_abec_gsrb, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
                        c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb);
@@ -161,7 +167,7 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
 struct BndryDesc { int fab; BoxD region; int dir, side; };
 
 __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ descs, const FabD* __restrict__ phit,
-                                                 const FabD* __restrict__ bcvt, int ncomp, int bct_unused,
+                                                 const FabD* __restrict__ bcvt, int ncomp, int comp0,
                                                  const int* __restrict__ bctype, const double* __restrict__ coefs, int inhomog)
 {
     const BndryDesc bd = descs[blockIdx.y];
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
         const long r = q / nx;
         idx[1] = bd.region.lo[1] + (int)(r % ny);
         idx[2] = bd.region.lo[2] + (int)(r / ny);
-        for (int n = 0; n < ncomp; ++n) {
+        for (int n = comp0; n < comp0 + ncomp; ++n) {
             double v;
             int m[3] = {idx[0], idx[1], idx[2]};
             if (bct == lo_neumann) { m[d] += s; v = phi(m[0], m[1], m[2], n); }
@@ -196,8 +202,9 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
     }
 }
 
-void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval)
+void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0, int ncomp)
 {
+    if (ncomp < 0) ncomp = phi.ncomp - comp0;
     bool any = false;
     for (int d = 0; d < 3; ++d) if (!g.periodic[d]) any = true;
     if (!any || phi.nlocal() == 0) return;
@@ -239,7 +246,7 @@ void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, 
     IAMRX_HIP_CHECK(hipMemcpyAsync(dbuf, hbuf.data(), bytes, hipMemcpyHostToDevice, ctx.stream));
     long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_abec_bc, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream,
-                       (const BndryDesc*)dbuf, phi.d_tab, bcval ? bcval->d_tab : nullptr, phi.ncomp, 0,
+                       (const BndryDesc*)dbuf, phi.d_tab, bcval ? bcval->d_tab : nullptr, ncomp, comp0,
                        (const int*)(dbuf + o1), (const double*)(dbuf + o2), inhomog ? 1 : 0);
     ctx.sync();          // hbuf is pageable host memory: keep it alive until the copy has completed
     ctx.free(dbuf);

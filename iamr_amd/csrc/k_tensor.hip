@@ -102,7 +102,7 @@ void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir)
 // exterior directions of the one-dimensional face rule applied along that direction (Neumann: neighbour copy;
 // Dirichlet: the face extrapolation polynomial on the already filled ghost cells + boundary value of bcval).
 struct EdgeDesc { int fab; BoxD region; int sgn[3]; int ext[3]; };
-struct EdgeParams { int bclo[3], bchi[3]; int NX[3]; double c[3][4]; int inhomog; int ncomp; };
+struct EdgeParams { int bclo[3], bchi[3]; int NX[3]; double c[3][4]; int inhomog; int ncomp; int comp0; };
 
 __global__ void __launch_bounds__(256) k_tensor_edges(const EdgeDesc* __restrict__ descs, const FabD* __restrict__ pt,
                                                       const FabD* __restrict__ bvt, EdgeParams P)
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_tensor_edges(const EdgeDesc* __restrict
         const long r = q / nx;
         idx[1] = ed.region.lo[1] + (int)(r % ny);
         idx[2] = ed.region.lo[2] + (int)(r / ny);
-        for (int n = 0; n < P.ncomp; ++n) {
+        for (int n = P.comp0; n < P.comp0 + P.ncomp; ++n) {
             double sum = 0.0;
             for (int d = 0; d < 3; ++d) {
                 if (!ed.ext[d]) continue;
@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(256) k_tensor_edges(const EdgeDesc* __restrict
     }
 }
 
-void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval)
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0, int ncomp)
 {
+    if (ncomp < 0) ncomp = phi.ncomp - comp0;
     bool anywall = false;
     for (int d = 0; d < 3; ++d) if (!g.periodic[d]) anywall = true;
     if (!anywall || phi.nlocal() == 0) return;
@@ -163,7 +164,7 @@ void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, b
         }
     }
     P.inhomog = inhomog ? 1 : 0;
-    P.ncomp = phi.ncomp;
+    P.ncomp = ncomp; P.comp0 = comp0;
     for (int nout = 2; nout <= 3; ++nout) {
         std::vector<EdgeDesc> descs;
         long maxpts = 0;

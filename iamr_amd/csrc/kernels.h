@@ -39,10 +39,11 @@ struct DomainBC {             // linear-operator BC of the level's domain
     int lo[3], hi[3];         // LinOpBC per face
     int maxorder;
 };
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC& bc);
+// bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc);
 // out = rhs - L(phi)  (rhs == nullptr: out = L(phi))
 void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs);
-void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval);
+void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 void cc_restrict(MultiFab& crse, const MultiFab& fine);          // average of 8
 void cc_prolong_add(MultiFab& fine, const MultiFab& crse);       // piecewise constant
 void face_avgdown(MultiFab& crse, const MultiFab& fine, int dir);
@@ -79,6 +80,6 @@ void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& p
 // ---- k_tensor.hip -------------------------------------------------------------------------
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);
-void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval);
+void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 
 }  // namespace iamrx

@@ -41,6 +41,8 @@ public:
     void setACoeffs(const MultiFab* a) { m_a0 = a; }
     void setBCoeffs(const MultiFab* const b[3]) { for (int d = 0; d < 3; ++d) m_b0[d] = b[d]; }
     void setTensor(bool t) { m_tensor = t; }
+    // one DomainBC per component (MLTensorOp::setDomainBC with per-component arrays)
+    void setDomainBCs(const DomainBC* bcs, int n) { m_bcn.assign(bcs, bcs + n); }
     void prepare();   // build the coarse hierarchy (coefficient averaging)
     MGStats solve(MultiFab& phi, const MultiFab& rhs, double rtol, double atol);
     // out = L(phi) with inhomogeneous BC taken from phi's ghost cells
@@ -68,6 +70,7 @@ private:
     Geometry m_g;
     int m_ncomp;
     DomainBC m_bc;
+    std::vector<DomainBC> m_bcn;
     MGOpts m_o;
     double m_alpha = 0.0, m_beta = 1.0;
     const MultiFab* m_a0 = nullptr;

@@ -12,6 +12,7 @@ namespace iamrx {
 CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
     : m_g(g), m_ncomp(ncomp), m_bc(bc), m_o(o)
 {
+    m_bcn.assign(1, bc);
     m_lev.resize(1);
     m_lev[0].g = g;
     m_lev[0].layout = std::move(layout);
@@ -37,7 +38,7 @@ void CellMG::prepare()
     // singular <=> no 'a' term and no Dirichlet boundary (MLABecLaplacian::m_is_singular)
     m_singular = !(m_alpha != 0.0 && m_a0);
     for (int d = 0; d < 3; ++d)
-        if (!m_g.periodic[d] && (m_bc.lo[d] == lo_dirichlet || m_bc.hi[d] == lo_dirichlet)) m_singular = false;
+        for (auto& b : m_bcn) if (!m_g.periodic[d] && (b.lo[d] == lo_dirichlet || b.hi[d] == lo_dirichlet)) m_singular = false;
     // coarsen while every box is coarsenable (MLLinOp::defineGrids, mg_box_min_width = 2)
     m_lev.resize(1);
     while ((int)m_lev.size() <= m_o.max_coarsening_level) {
@@ -73,8 +74,14 @@ void CellMG::prepare()
 void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
 {
     phi.FillBoundary(m_lev[l].g);
-    abec_apply_domain_bc(m_lev[l].g, phi, m_bc, inhomog, bcval);
-    if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bc, inhomog, bcval);
+    if (m_bcn.size() == 1) {
+        abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
+        if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
+    } else {
+        // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference Source/Diffusion.cpp:724-731)
+        for (int n = 0; n < m_ncomp; ++n) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
+        if (m_tensor) for (int n = 0; n < m_ncomp; ++n) fill_tensor_corners(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
+    }
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
@@ -83,7 +90,7 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
     for (int rb = 0; rb < 2; ++rb) {
         if (!skip_fill) applyBC(l, sol, false, nullptr);
-        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bc);
+        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bcn.data(), (int)m_bcn.size());
         skip_fill = false;
     }
 }

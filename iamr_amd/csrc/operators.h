@@ -22,10 +22,15 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
 // ---- Diffusion (reference Source/Diffusion.H:53-225) -------------------------------------------------
 // explicit viscous terms div tau(U): Diffusion::getTensorViscTerms (Source/Diffusion.cpp:1655-1777): out = -b * L_tensor(U), a = 0
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel /*3 comps, 1 ghost; BC data in ghosts*/, double a_scalar, double b_scalar,
-                  const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC& bc);
+                  const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC* bcs, int nbc /*1 or 3 (per component)*/);
+inline void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
+                         const MultiFab* const eta[3], const DomainBC& bc) { tensor_apply(g, out, vel, a_scalar, b_scalar, acoef, eta, &bc, 1); }
 // Crank-Nicolson implicit solve (a*acoef - b div tau) u = rhs: Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929)
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
-                     const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts);
+                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts);
+inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
+                            const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
+{ return tensor_solve(g, soln, rhs, a_scalar, b_scalar, acoef, eta, &bc, 1, tol_rel, tol_abs, opts); }
 
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {

@@ -44,12 +44,13 @@ static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], Layo
 }
 
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
-                  const MultiFab* const eta[3], const DomainBC& bc)
+                  const MultiFab* const eta[3], const DomainBC* bcs, int nbc)
 {
     MGOpts o;
     o.max_coarsening_level = 0;      // info.setMaxCoarseningLevel(0) (Diffusion.cpp:708)
-    o.maxorder = bc.maxorder;
-    CellMG mg(g, vel.layout, 3, bc, o);
+    o.maxorder = bcs[0].maxorder;
+    CellMG mg(g, vel.layout, 3, bcs[0], o);
+    if (nbc > 1) mg.setDomainBCs(bcs, nbc);
     MultiFab tb[3];
     const MultiFab* bp[3];
     setup_tensor(mg, tb, bp, vel.layout, a_scalar, b_scalar, acoef, eta);
@@ -58,11 +59,12 @@ void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scal
 }
 
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
-                     const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
+                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts)
 {
     MGOpts o = opts;
-    o.maxorder = bc.maxorder;
-    CellMG mg(g, soln.layout, 3, bc, o);
+    o.maxorder = bcs[0].maxorder;
+    CellMG mg(g, soln.layout, 3, bcs[0], o);
+    if (nbc > 1) mg.setDomainBCs(bcs, nbc);
     MultiFab tb[3];
     const MultiFab* bp[3];
     setup_tensor(mg, tb, bp, soln.layout, a_scalar, b_scalar, acoef, eta);

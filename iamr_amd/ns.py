@@ -61,16 +61,27 @@ def nodal_projection(geom, vel, vcomp, phi, sig, sig_comp=0, lobc=(0, 0, 0), hib
     return st
 
 
+def _bcn(lobc, hibc):
+    """(lo, hi, nbc): lobc/hibc are 3 codes, or 3 x 3 codes (one triple per velocity component)"""
+    if hasattr(lobc[0], "__len__"):
+        flat_lo = [int(v) for c in lobc for v in c]
+        flat_hi = [int(v) for c in hibc for v in c]
+        return (C.c_int * 9)(*flat_lo), (C.c_int * 9)(*flat_hi), 3
+    return i3(lobc), i3(hibc), 1
+
+
 def tensor_apply(geom, out, vel, a, b, acoef, eta, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=2):
+    lo, hi, nbc = _bcn(lobc, hibc)
     check(lib().iamrx_tensor_apply(C.byref(geom), out.h, vel.h, C.c_double(a), C.c_double(b), _h(acoef), eta[0].h, eta[1].h,
-                                   eta[2].h, i3(lobc), i3(hibc), maxorder))
+                                   eta[2].h, lo, hi, nbc, maxorder))
 
 
 def tensor_solve(geom, soln, rhs, a, b, acoef, eta, lobc=(0, 0, 0), hibc=(0, 0, 0), tol_rel=1e-10, tol_abs=0.0, opts=None):
     st = MgStats()
     o = opts if opts is not None else mg_opts(maxorder=2)
+    lo, hi, nbc = _bcn(lobc, hibc)
     check(lib().iamrx_tensor_solve(C.byref(geom), soln.h, rhs.h, C.c_double(a), C.c_double(b), _h(acoef), eta[0].h, eta[1].h,
-                                   eta[2].h, i3(lobc), i3(hibc), C.c_double(tol_rel), C.c_double(tol_abs), C.byref(o), C.byref(st)))
+                                   eta[2].h, lo, hi, nbc, C.c_double(tol_rel), C.c_double(tol_abs), C.byref(o), C.byref(st)))
     return st
 
 

@@ -176,12 +176,14 @@ int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_m
 
 /* ---- tensor diffusion (amrex::MLTensorOp role) -------------------------------------- */
 /* out = (a*acoef - b div tau(vel)); Diffusion::getTensorViscTerms uses a = 0, b = -1 (Source/Diffusion.cpp:1697-1698).
- * eta_*: face viscosity (1 comp); vel: 3 comps, 1 ghost */
+ * eta_*: face viscosity (1 comp); vel: 3 comps, 1 ghost.
+ * lobc/hibc: nbc*3 LinOpBC codes, [n*3+d]; nbc = 1 (all components alike) or 3 (one set per velocity component, the
+ * per-component arrays Diffusion::setDomainBC hands to MLTensorOp, Source/Diffusion.cpp:724-731, 1939-2020) */
 int iamrx_tensor_apply(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
-                       iamrx_mf eta_y, iamrx_mf eta_z, const int lobc[3], const int hibc[3], int maxorder);
+                       iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, int maxorder);
 /* implicit Crank-Nicolson solve of Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929) */
 int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
-                       iamrx_mf eta_y, iamrx_mf eta_z, const int lobc[3], const int hibc[3], double tol_rel, double tol_abs,
+                       iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, double tol_rel, double tol_abs,
                        const iamrx_mg_opts* o, iamrx_mg_stats* st);
 
 /* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */

@@ -72,6 +72,8 @@ typedef struct orc_abec_level {
     orc_fab b[3];             /* face-centred, ncomp comps, 0 ghost */
     int ncomp;
     int tensor;               /* 1: MLTensorOp -- b holds eta*(4/3 on the normal comp), cross terms added in apply */
+    int bc_percomp;           /* 1: the lobc/hibc arguments hold ncomp*3 codes, [n*3+d] (MLTensorOp::setDomainBC per component,
+                                 reference Source/Diffusion.cpp:724-731) */
 } orc_abec_level;
 
 typedef struct orc_mg_stats {
@@ -166,6 +168,9 @@ void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc
 /* y = (alpha*a - beta div tau(u)) with MLTensorOp semantics (3 comps) */
 void orc_tensor_apply(const orc_geom* g, orc_fab* y, const orc_fab* u /*3 comps,1 ghost filled incl. corners*/,
                       double alpha, double beta, const orc_fab* a, orc_fab* const eta[3] /*faces,1 comp*/);
+void orc_tensor_solve_bcn(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                          const orc_fab* a, orc_fab* const eta[3], const int* lobc /*9: [n*3+d]*/, const int* hibc,
+                          double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 void orc_tensor_solve(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
                       const orc_fab* a, orc_fab* const eta[3], const int lobc[3], const int hibc[3],
                       double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);

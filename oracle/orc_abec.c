@@ -75,6 +75,8 @@ static double bc_coef0(int bct, int blen, int maxorder)
     return 0.0;
 }
 
+#define BCOFF(L, n) ((L)->bc_percomp ? 3 * (n) : 0)
+
 void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
                       int maxorder, int inhomog, const orc_fab* bcval)
 {
@@ -83,15 +85,15 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
     for (int d = 0; d < 3; ++d) {
         if (g->periodic[d]) continue;
         for (int side = 0; side < 2; ++side) {
-            const int bct = side == 0 ? lobc[d] : hibc[d];
             const int s = 1 - 2 * side;
             const int ig = side == 0 ? -1 : g->n[d];
             const int blen = g->n[d];
             int NX = blen + 1 < maxorder ? blen + 1 : maxorder;
             double x[4] = {0.0, 0.5, 1.5, 2.5}, c[4] = {0, 0, 0, 0};
-            if (bct == ORC_LO_DIRICHLET && NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
+            if (NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
             int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-            for (int n = 0; n < L->ncomp; ++n)
+            for (int n = 0; n < L->ncomp; ++n) {
+            const int bct = side == 0 ? lobc[BCOFF(L, n) + d] : hibc[BCOFF(L, n) + d];
             for (int q2 = 0; q2 < g->n[d2]; ++q2)
             for (int q1 = 0; q1 < g->n[d1]; ++q1) {
                 int idx[3]; idx[d] = ig; idx[d1] = q1; idx[d2] = q2;
@@ -113,6 +115,7 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
                 } else continue;
                 A4(phi, idx[0], idx[1], idx[2], n) = v;
             }
+            }
         }
     }
     if (orc_abec_is_tensor(L)) orc_tensor_fill_edges_corners(L, phi, lobc, hibc, maxorder, inhomog, bcval);
@@ -126,12 +129,12 @@ void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, in
     const double dhy = L->beta / (g->dx[1] * g->dx[1]);
     const double dhz = L->beta / (g->dx[2] * g->dx[2]);
     const orc_fab *bX = &L->b[0], *bY = &L->b[1], *bZ = &L->b[2];
+    for (int n = 0; n < L->ncomp; ++n) {
     double cflo[3], cfhi[3];
     for (int d = 0; d < 3; ++d) {
-        cflo[d] = g->periodic[d] ? 0.0 : bc_coef0(lobc[d], g->n[d], maxorder);
-        cfhi[d] = g->periodic[d] ? 0.0 : bc_coef0(hibc[d], g->n[d], maxorder);
+        cflo[d] = g->periodic[d] ? 0.0 : bc_coef0(lobc[BCOFF(L, n) + d], g->n[d], maxorder);
+        cfhi[d] = g->periodic[d] ? 0.0 : bc_coef0(hibc[BCOFF(L, n) + d], g->n[d], maxorder);
     }
-    for (int n = 0; n < L->ncomp; ++n)
     for (int k = 0; k < g->n[2]; ++k)
     for (int j = 0; j < g->n[1]; ++j)
     for (int i = 0; i < g->n[0]; ++i) {
@@ -151,6 +154,7 @@ void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, in
                    + dhz * (A4(bZ, i, j, k, n) * A4(phi, i, j, k - 1, n) + A4(bZ, i, j, k + 1, n) * A4(phi, i, j, k + 1, n));
         double res = A4(rhs, i, j, k, n) - (gamma * A4(phi, i, j, k, n) - rho);
         A4(phi, i, j, k, n) = A4(phi, i, j, k, n) + omega / g_m_d * res;
+    }
     }
 }
 
@@ -255,7 +259,8 @@ static int is_singular(const orc_abec_level* L, const int lobc[3], const int hib
     if (L->alpha != 0.0 && L->a.p) return 0;
     for (int d = 0; d < 3; ++d) {
         if (L->g.periodic[d]) continue;
-        if (lobc[d] == ORC_LO_DIRICHLET || hibc[d] == ORC_LO_DIRICHLET) return 0;
+        for (int n = 0; n < (L->bc_percomp ? L->ncomp : 1); ++n)
+            if (lobc[3 * n + d] == ORC_LO_DIRICHLET || hibc[3 * n + d] == ORC_LO_DIRICHLET) return 0;
     }
     return 1;
 }

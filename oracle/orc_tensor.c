@@ -46,7 +46,7 @@ void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const 
             double sum = 0.0;
             for (int d = 0; d < 3; ++d) {
                 if (!out[d] || g->periodic[d]) continue;
-                const int bct = out[d] < 0 ? lobc[d] : hibc[d];
+                const int bct = out[d] < 0 ? lobc[(L->bc_percomp ? 3 * n : 0) + d] : hibc[(L->bc_percomp ? 3 * n : 0) + d];
                 const int s = out[d] < 0 ? 1 : -1;
                 double v;
                 if (bct == ORC_LO_NEUMANN) {
@@ -143,6 +143,20 @@ void orc_tensor_apply(const orc_geom* g, orc_fab* y, const orc_fab* u, double al
     orc_abec_level L;
     build_level(g, &L, alpha, beta, a, eta);
     orc_abec_apply(&L, y, u);
+    for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+}
+
+/* lobc/hibc hold 9 codes [n*3+d]: one BC triple per velocity component (Diffusion::setDomainBC per component,
+ * reference Source/Diffusion.cpp:724-731 and 1939-2020: slip walls are Dirichlet for the normal and Neumann for the
+ * tangential components) */
+void orc_tensor_solve_bcn(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                          const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc,
+                          double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_abec_level L;
+    build_level(g, &L, alpha, beta, a, eta);
+    L.bc_percomp = 1;
+    orc_abec_solve(&L, u, rhs, lobc, hibc, rtol, atol, o, st);
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
 }
 

@@ -43,7 +43,7 @@ class CBCRec(C.Structure):
 
 class CAbecLevel(C.Structure):
     _fields_ = [("g", CGeom), ("alpha", C.c_double), ("beta", C.c_double), ("a", CFab), ("b", CFab * 3),
-                ("ncomp", C.c_int), ("tensor", C.c_int)]
+                ("ncomp", C.c_int), ("tensor", C.c_int), ("bc_percomp", C.c_int)]
 
 
 class CMgStats(C.Structure):
@@ -181,7 +181,7 @@ def fabptrs(fabs):
     return arr
 
 
-def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0):
+def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0, bc_percomp=0):
     L = CAbecLevel()
     L.g = g
     L.alpha = alpha
@@ -192,4 +192,5 @@ def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0):
         L.b[d] = b[d].c
     L.ncomp = ncomp
     L.tensor = tensor
+    L.bc_percomp = bc_percomp
     return L
