@@ -418,6 +418,9 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     p->visc_tol = d.visc_tol; p->use_forces_in_trans = d.use_forces_in_trans; p->do_mom_diff = d.do_mom_diff;
     p->init_iter = d.init_iter; p->init_vel_iter = d.init_vel_iter; p->init_shrink = d.init_shrink; p->change_max = d.change_max;
     p->fixed_dt = d.fixed_dt; p->nscal = d.nscal; p->verbose = d.verbose;
+    p->init_dt = d.init_dt; p->tracer_diff_coef = d.tracer_diff_coef;
+    for (int i = 0; i < 3; ++i) { p->phys_lo[i] = d.phys_lo[i]; p->phys_hi[i] = d.phys_hi[i]; }
+    for (int i = 0; i < 9; ++i) { p->wall_vel_lo[i] = d.wall_vel_lo[i]; p->wall_vel_hi[i] = d.wall_vel_hi[i]; }
 }
 
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
@@ -429,6 +432,9 @@ int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* 
     q.visc_tol = p->visc_tol; q.use_forces_in_trans = p->use_forces_in_trans; q.do_mom_diff = p->do_mom_diff;
     q.init_iter = p->init_iter; q.init_vel_iter = p->init_vel_iter; q.init_shrink = p->init_shrink; q.change_max = p->change_max;
     q.fixed_dt = p->fixed_dt; q.nscal = p->nscal; q.verbose = p->verbose;
+    q.init_dt = p->init_dt; q.tracer_diff_coef = p->tracer_diff_coef;
+    for (int i = 0; i < 3; ++i) { q.phys_lo[i] = p->phys_lo[i]; q.phys_hi[i] = p->phys_hi[i]; }
+    for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
     if (q.do_mom_diff) throw Error("iamrx: do_mom_diff = 1 not implemented in this round");
     auto* h = new iamrx_ns_s;
     h->ns = std::make_unique<NavierStokes>(to_geom(g), l->p, q, to_opts(o));
@@ -441,6 +447,7 @@ int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, doub
 {
     IAMRX_TRY ns->ns->init_taylorgreen(vfac, a, b, c, rho0); IAMRX_CATCH
 }
+int iamrx_ns_init_rest(iamrx_ns ns, double rho0) { IAMRX_TRY ns->ns->init_rest(rho0); IAMRX_CATCH }
 int iamrx_ns_post_init(iamrx_ns ns, double stop_time) { IAMRX_TRY ns->ns->post_init(stop_time); IAMRX_CATCH }
 int iamrx_ns_step(iamrx_ns ns, double* dt_used) { IAMRX_TRY double d = ns->ns->step(); if (dt_used) *dt_used = d; IAMRX_CATCH }
 int iamrx_ns_advance(iamrx_ns ns, double dt, double* dt_est) { IAMRX_TRY double d = ns->ns->advance(dt); if (dt_est) *dt_est = d; IAMRX_CATCH }
@@ -477,6 +484,26 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
     h->mf.define(m->layout, m->type, m->ncomp, m->ngrow);
     MultiFab::Copy(h->mf, *m, 0, 0, m->ncomp, m->ngrow);
     *out = h;
+    IAMRX_CATCH
+}
+
+// overwrite one of the level's arrays (same selectors as iamrx_ns_data) with src: problem set-up from caller data
+int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
+{
+    IAMRX_TRY
+    NavierStokes& n = *ns->ns;
+    MultiFab* m = nullptr;
+    switch (which) {
+    case 0: m = &n.get_new_data(0); break;
+    case 1: m = &n.get_old_data(0); break;
+    case 2: m = &n.get_new_data(1); break;
+    case 3: m = &n.get_old_data(1); break;
+    case 4: m = &n.get_new_data(2); break;
+    case 5: m = &n.get_old_data(2); break;
+    default: throw Error("iamrx_ns_set_data: bad selector");
+    }
+    IAMRX_ASSERT(src->mf.ncomp == m->ncomp && src->mf.ngrow == m->ngrow && src->mf.layout->id == m->layout->id);
+    MultiFab::Copy(*m, src->mf, 0, 0, m->ncomp, m->ngrow);
     IAMRX_CATCH
 }
 

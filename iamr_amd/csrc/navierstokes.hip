@@ -18,7 +18,11 @@
 //   Projection::initialSyncProject          Projection.cpp:970-1185
 //   NavierStokes::post_init(_press)         NavierStokes.cpp:1254-1432
 //   NSB::estTimeStep / computeNewDt         NavierStokesBase.cpp:1353-1510, 945-1035
-// Scope of this round: one level, periodic domain, constant viscosity, divu = 0, NUM_STATE = 5
+//   NavierStokes::scalar_diffusion_update   NavierStokes.cpp:867-1000 -> Diffusion::diffuse_scalar Diffusion.cpp:207-599
+//   Diffusion::getViscTerms (scalars)       Diffusion.cpp:1539-1652
+//   physical BC tables                      NS_BC.H:7-55, NS_setup.cpp:21-128, NS_bcfill.H:17-180
+// Scope of this round: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls
+// through xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, divu = 0, NUM_STATE = 5
 // (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
 #include "operators.h"
 #include "launch.h"
@@ -45,8 +49,6 @@ struct SectionTimer {
 NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& par, const MGOpts& opts)
     : g(geom), layout(std::move(lay)), p(par), o(opts)
 {
-    for (int d = 0; d < 3; ++d)
-        if (!g.periodic[d]) throw Error("iamrx NavierStokes: non-periodic domains are not implemented in this round");
     for (int q = 0; q < 2; ++q) {
         S[q].define(layout, cell_type(), NUM_STATE, 1);
         P[q].define(layout, node_type(), 1, 1);
@@ -58,21 +60,56 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         u_mac[d].setVal(1.e40);                       // NavierStokesBase.cpp:673
         eta[d].define(layout, face_type(d), 1, 0);
         eta[d].setVal(p.visc_coef);
+        if (is_diffusive_tracer()) { diff_b[d].define(layout, face_type(d), 1, 0); diff_b[d].setVal(p.tracer_diff_coef); }
     }
     aofs.define(layout, cell_type(), NUM_STATE, 0);
     rho_ptime.define(layout, cell_type(), 1, 1);
     rho_ctime.define(layout, cell_type(), 1, 1);
     rho_half.define(layout, cell_type(), 1, 1);
+    // BCType of a velocity component / scalar for a physical BC: NS_BC.H:7-25 (norm_vel_bc, tang_vel_bc, scalar_bc)
+    auto vel_bctype = [](int phys, bool normal) {
+        if (phys == phys_interior) return (int)bc_int_dir;
+        if (phys == phys_noslipwall) return (int)bc_ext_dir;
+        return normal ? (int)bc_ext_dir : (int)bc_hoextrap;      // SlipWall
+    };
+    auto scal_bctype = [](int phys) { return phys == phys_interior ? (int)bc_int_dir : (int)bc_foextrap; };
+    // Diffusion::setDomainBC, Diffusion.cpp:1886-1941
+    auto linop_of = [](int bct) {
+        if (bct == bc_ext_dir) return (int)lo_dirichlet;
+        if (bct == bc_foextrap || bct == bc_hoextrap || bct == bc_reflect_even) return (int)lo_neumann;
+        return (int)lo_periodic;
+    };
     for (int d = 0; d < 3; ++d) {
+        const int plo = g.periodic[d] ? (int)phys_interior : p.phys_lo[d], phi_ = g.periodic[d] ? (int)phys_interior : p.phys_hi[d];
+        if (!g.periodic[d]) {
+            any_wall = true;
+            const bool ok = (plo == phys_slipwall || plo == phys_noslipwall) && (phi_ == phys_slipwall || phi_ == phys_noslipwall);
+            if (!ok) throw Error("iamrx NavierStokes: a non-periodic direction needs SlipWall (4) or NoSlipWall (5) on both sides; "
+                                 "inflow/outflow/symmetry are not implemented");
+        }
         bc_mac.lo[d] = bc_mac.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;      // MacProj.cpp:1187-1208
         bc_nodal.lo[d] = bc_nodal.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;  // Projection.cpp:2432-2464
-        bc_visc.lo[d] = bc_visc.hi[d] = g.periodic[d] ? lo_periodic : lo_dirichlet;
-        for (int n = 0; n < 3; ++n) bc_vel[n].lo[d] = bc_vel[n].hi[d] = bc_int_dir;
-        for (int n = 0; n < 2; ++n) bc_scal[n].lo[d] = bc_scal[n].hi[d] = bc_int_dir;
+        for (int n = 0; n < 3; ++n) {
+            bc_vel[n].lo[d] = vel_bctype(plo, n == d); bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
+            bc_gp[n].lo[d] = scal_bctype(plo); bc_gp[n].hi[d] = scal_bctype(phi_);   // norm/tang_gradp_bc: foextrap at walls
+            ed_vel_lo[n * 3 + d] = p.wall_vel_lo[d * 3 + n]; ed_vel_hi[n * 3 + d] = p.wall_vel_hi[d * 3 + n];
+            bc_visc[n].lo[d] = linop_of(bc_vel[n].lo[d]); bc_visc[n].hi[d] = linop_of(bc_vel[n].hi[d]);
+        }
+        for (int n = 0; n < 2; ++n) { bc_scal[n].lo[d] = scal_bctype(plo); bc_scal[n].hi[d] = scal_bctype(phi_); }
+        bc_scal_lin.lo[d] = linop_of(bc_scal[1].lo[d]); bc_scal_lin.hi[d] = linop_of(bc_scal[1].hi[d]);
     }
     bc_mac.maxorder = 4;     // MacProj.cpp:1172
     bc_nodal.maxorder = 2;
-    bc_visc.maxorder = 2;    // Diffusion.cpp:95-96
+    for (int n = 0; n < 3; ++n) bc_visc[n].maxorder = 2;    // Diffusion.cpp:95-96
+    bc_scal_lin.maxorder = 2;
+}
+
+void NavierStokes::init_rest(double rho0)
+{
+    S[inew].setVal(0.0);
+    S[inew].setVal(rho0, Density, 1, 0);
+    for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }
+    time = 0.0; nstep = 0;
 }
 
 void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, double rho0)
@@ -94,11 +131,43 @@ void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, d
     time = 0.0; nstep = 0;
 }
 
-// FillPatch on one level: copy the valid data, then same-level + periodic ghost fill (physical BC fill: later round)
-void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp)
+// FillPatch on one level: copy the valid data, same-level + periodic ghost fill, then the physical-BC fill
+// (StateDataPhysBCFunct: FilccCell rules + the ext_dir functors of NS_bcfill.H)
+void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)
 {
     MultiFab::Copy(dst, src, scomp, 0, ncomp, 0);
     dst.FillBoundary(g);
+    if (any_wall) {
+        const bool is_vel = (bc == bc_vel);
+        fill_physbc_cc(g, dst, 0, ncomp, bc, is_vel ? ed_vel_lo : nullptr, is_vel ? ed_vel_hi : nullptr);
+    }
+}
+
+// Extrapolater::FirstOrderExtrap role (NavierStokes.cpp:2047): ghost cells outside the physical domain take the value
+// of the nearest cell inside it (index clamp in the non-periodic directions).  These cells only feed Godunov states on
+// wall faces, which the wall BC overrides.
+void NavierStokes::first_order_extrap(MultiFab& mf)
+{
+    if (!any_wall) return;
+    const FabD* t = mf.d_tab;
+    const int nc = mf.ncomp;
+    const BoxD dom = g.domain;
+    const int per0 = g.periodic[0], per1 = g.periodic[1], per2 = g.periodic[2];
+    for_each(*layout, cell_type(), mf.ngrow, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        int q0 = i, q1 = j, q2 = k;
+        if (!per0) q0 = min(max(i, dom.lo[0]), dom.hi[0]);
+        if (!per1) q1 = min(max(j, dom.lo[1]), dom.hi[1]);
+        if (!per2) q2 = min(max(k, dom.lo[2]), dom.hi[2]);
+        if (q0 == i && q1 == j && q2 == k) return;
+        const FabD a = t[f];
+        for (int n = 0; n < nc; ++n) a(i, j, k, n) = a(q0, q1, q2, n);
+    });
+}
+
+// FillPatch(Gradp_Type) after a projection (Projection.cpp:2565): foextrap at walls
+void NavierStokes::fill_gradp_bc()
+{
+    if (any_wall) fill_physbc_cc(g, Gp[pnew], 0, 3, bc_gp, nullptr, nullptr);
 }
 
 static void floor_small(MultiFab& mf)
@@ -116,12 +185,35 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
     visc.setVal(1.e40);                                       // NavierStokes.cpp:1982
     if (!is_diffusive_vel()) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 3, 1);
-    fillpatch(stmp, Sdata, Xvel, 3);
+    fillpatch(stmp, Sdata, Xvel, 3, bc_vel);
     MultiFab tmp(layout, cell_type(), 3, 0);
     const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
-    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
+    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc, 3);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
     MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
-    visc.FillBoundary(g);                                     // + FirstOrderExtrap at walls (later round)
+    visc.FillBoundary(g);
+    first_order_extrap(visc);
+}
+
+// NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0): visc = div(beta grad S(time))
+void NavierStokes::get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata)
+{
+    visc.setVal(1.e40);
+    if (!is_diffusive_tracer()) { visc.setVal(0.0); return; }
+    MultiFab stmp(layout, cell_type(), 1, 1);
+    fillpatch(stmp, Sdata, Tracer, 1, &bc_scal[1]);
+    MGOpts mo;
+    mo.max_coarsening_level = 0;       // info.setMaxCoarseningLevel(0) (Diffusion.cpp:1574)
+    mo.maxorder = 2;
+    CellMG mg(g, layout, 1, bc_scal_lin, mo);
+    mg.setScalars(0.0, -1.0);
+    const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
+    mg.setBCoeffs(bp);
+    mg.prepare();
+    MultiFab tmp(layout, cell_type(), 1, 0);
+    mg.apply(tmp, stmp);
+    MultiFab::Copy(visc, tmp, 0, 0, 1, 0);
+    visc.FillBoundary(g);
+    first_order_extrap(visc);
 }
 
 double NavierStokes::estTimeStep()
@@ -152,7 +244,9 @@ double NavierStokes::estTimeStep()
         if (fmax > small) estdt = std::min(estdt, std::sqrt(2.0 * g.dx[d] / fmax));
     }
     if (estdt < 1.0e+20) estdt *= p.cfl;
-    else throw Error("NavierStokesBase::estTimeStep() failed to provide a good timestep");
+    else if (p.init_dt > 0.0) estdt = p.init_dt;                 // NavierStokesBase.cpp:1463-1481
+    else throw Error("NavierStokesBase::estTimeStep() failed to provide a good timestep (probably because the initial velocity "
+                     "field is zero with no external forcing); use init_dt");
     return estdt;
 }
 
@@ -160,7 +254,7 @@ void NavierStokes::advance_setup()
 {
     inew = 1 - inew;     // swapTimeLevels
     pnew = 1 - pnew;
-    fillpatch(rho_ptime, S[1 - inew], Density, 1);   // make_rho_prev_time
+    fillpatch(rho_ptime, S[1 - inew], Density, 1, &bc_scal[0]);   // make_rho_prev_time
 }
 
 double NavierStokes::predict_velocity(double dt_)
@@ -168,7 +262,7 @@ double NavierStokes::predict_velocity(double dt_)
     SectionTimer tm(*this, 0);
     MultiFab& So = S[1 - inew];
     MultiFab Umf(layout, cell_type(), 3, 3);
-    fillpatch(Umf, So, Xvel, 3);
+    fillpatch(Umf, So, Xvel, 3, bc_vel);
     floor_small(Umf);
     double cflmax = 0.0;
     for (int n = 0; n < 3; ++n) {
@@ -179,7 +273,7 @@ double NavierStokes::predict_velocity(double dt_)
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
     MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
-    fillpatch(Smf, So, Density, NUM_SCALARS);
+    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
     MultiFab tf(layout, cell_type(), 3, 1);
     {
         const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
@@ -216,9 +310,9 @@ void NavierStokes::velocity_advection(double dt_)
     SectionTimer tm(*this, 2);
     MultiFab& So = S[1 - inew];
     MultiFab Umf(layout, cell_type(), 3, 3);
-    fillpatch(Umf, So, Xvel, 3);
+    fillpatch(Umf, So, Xvel, 3, bc_vel);
     MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
-    fillpatch(Smf, So, Density, NUM_SCALARS);
+    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
     MultiFab tf(layout, cell_type(), 3, 1), divu(layout, cell_type(), 1, 1);
@@ -246,17 +340,19 @@ void NavierStokes::scalar_advection(double dt_)
     SectionTimer tm(*this, 2);
     MultiFab& So = S[1 - inew];
     MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
-    fillpatch(Smf, So, Density, NUM_SCALARS);
+    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
     floor_small(Smf);
     MultiFab tf(layout, cell_type(), NUM_SCALARS, 1), divu(layout, cell_type(), 1, 1);
     tf.setVal(0.0); divu.setVal(0.0);
+    MultiFab visc(layout, cell_type(), 1, 1);
+    if (p.be_cn_theta != 1.0) get_visc_terms_tracer(visc, So); else visc.setVal(0.0);
     {
-        // getForce = 0 and visc = 0 for the (non-diffusive) scalars; keep the reference's arithmetic
-        const FabD *tt = tf.d_tab, *st = Smf.d_tab;
+        // getForce = 0; density is not diffusive; keep the reference's arithmetic
+        const FabD *tt = tf.d_tab, *st = Smf.d_tab, *vt = visc.d_tab;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = st[f](i, j, k, 0);
-            tt[f](i, j, k, 0) += 0.0;
-            tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + 0.0;
+            tt[f](i, j, k, 0) += 0.0;                                               // conservative: tf += visc
+            tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + vt[f](i, j, k, 0);         // convective: tf/rho + visc
         });
     }
     const int iconserv[2] = {1, 0};
@@ -271,7 +367,7 @@ void NavierStokes::scalar_update_rho(double dt_)
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         nt[f](i, j, k, Density) = ot[f](i, j, k, Density) - dt_ * at[f](i, j, k, Density);
     });
-    fillpatch(rho_ctime, S[inew], Density, 1);                        // make_rho_curr_time
+    fillpatch(rho_ctime, S[inew], Density, 1, &bc_scal[0]);           // make_rho_curr_time
     {   // get_rho_half_time (NavierStokesBase.cpp:1561-1565)
         const FabD *ht = rho_half.d_tab, *pt = rho_ptime.d_tab, *ct = rho_ctime.d_tab;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -289,6 +385,45 @@ void NavierStokes::scalar_update_tracers(double dt_)
         const double tfv = 0.0;
         nt[f](i, j, k, Tracer) = ot[f](i, j, k, Tracer) + dt_ * (-at[f](i, j, k, Tracer) + tfv / rho);
     });
+}
+
+// Diffusion::diffuse_scalar for the tracer (rho_flag 0): (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old
+void NavierStokes::scalar_diffusion_update(double dt_)
+{
+    if (!is_diffusive_tracer()) return;
+    SectionTimer tm(*this, 4);
+    const double theta = p.be_cn_theta;
+    MultiFab& Sn = S[inew];
+    MultiFab& So = S[1 - inew];
+    const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
+    MultiFab Rhs(layout, cell_type(), 1, 0);
+    if (theta != 1.0) {
+        MultiFab Soln0(layout, cell_type(), 1, 1);
+        fillpatch(Soln0, So, Tracer, 1, &bc_scal[1]);
+        MGOpts mo;
+        mo.max_coarsening_level = 0;                             // infon.setMaxCoarseningLevel(0) (Diffusion.cpp:318)
+        mo.maxorder = 2;
+        CellMG opn(g, layout, 1, bc_scal_lin, mo);
+        opn.setScalars(0.0, -(1.0 - theta) * dt_);
+        opn.setBCoeffs(bp);
+        opn.prepare();
+        opn.apply(Rhs, Soln0);
+    } else Rhs.setVal(0.0);
+    mf_saxpy(Rhs, 1.0, Sn, Tracer, 0, 1, 0);                     // rhs += S_new (Diffusion.cpp:479-493)
+    const double tol_abs = p.visc_tol * Rhs.norm0(0, 1, 0);      // get_scaled_abs_tol
+    MultiFab Soln(layout, cell_type(), 1, 1);
+    fillpatch(Soln, Sn, Tracer, 1, &bc_scal[1]);                 // FillPatch(S_new, ng 1): initial guess + level BC
+    MultiFab acoef(layout, cell_type(), 1, 0);
+    acoef.setVal(1.0);                                           // computeAlpha, rho_flag 0
+    MGOpts so = o;
+    so.maxorder = 2;                                             // Diffusion::max_order
+    CellMG opnp1(g, layout, 1, bc_scal_lin, so);
+    opnp1.setScalars(1.0, theta * dt_);
+    opnp1.setACoeffs(&acoef);
+    opnp1.setBCoeffs(bp);
+    opnp1.prepare();
+    st_scal = opnp1.solve(Soln, Rhs, p.visc_tol, tol_abs);
+    MultiFab::Copy(Sn, Soln, 0, Tracer, 1, 0);
 }
 
 void NavierStokes::velocity_advection_update(double dt_)
@@ -340,8 +475,8 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     MultiFab Rhs(layout, cell_type(), 3, 0);
     if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 3, 1);
-        fillpatch(Soln0, So, Xvel, 3);
-        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc);
+        fillpatch(Soln0, So, Xvel, 3, bc_vel);
+        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc, 3);
     } else Rhs.setVal(0.0);
     {
         const FabD *nt = Sn.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
@@ -356,12 +491,12 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     for (int n = 0; n < 3; ++n) avg += (1.0 / 3.0) * Rhs.norm0(n, 1, 0);
     const double tol_abs = p.visc_tol * avg;
     MultiFab Soln(layout, cell_type(), 3, 1);
-    fillpatch(Soln, Sn, Xvel, 3);                                // initial guess = FillPatch(U_new) = rho u*
+    fillpatch(Soln, Sn, Xvel, 3, bc_vel);                        // initial guess = FillPatch(U_new) = rho u* (+ wall values)
     MultiFab acoef(layout, cell_type(), 1, 0);
     MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);                 // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
     MGOpts vo = o;
     vo.maxorder = 2;
-    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, p.visc_tol, tol_abs, vo);
+    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, 3, p.visc_tol, tol_abs, vo);
     MultiFab::Copy(Sn, Soln, 0, Xvel, 3, 1);                     // Diffusion.cpp:928
 }
 
@@ -386,6 +521,7 @@ void NavierStokes::level_project(double dt_)
         });
     }
     st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+    fill_gradp_bc();
     mf_mult(Sn, dt_, Xvel, 3, 1);                                // U_new *= dt (:438)
 }
 
@@ -423,6 +559,7 @@ void NavierStokes::initial_sync_project(double dt_)
         });
     }
     st_nodal = nodal_projection(g, Sn, Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], true);
+    fill_gradp_bc();
     mf_saxpy(P[pnew], 1.0, phi, 0, 0, 1, 1);                     // P_new += phi (Projection.cpp:1176-1180)
 }
 
@@ -435,6 +572,7 @@ double NavierStokes::advance(double dt_)
     scalar_advection(dt_);
     scalar_update_rho(dt_);
     scalar_update_tracers(dt_);
+    scalar_diffusion_update(dt_);
     velocity_advection_update(dt_);
     if (!initial_iter) velocity_diffusion_update(dt_);
     else initial_velocity_diffusion_update(dt_);

@@ -39,6 +39,10 @@ struct NSParams {
     int use_forces_in_trans = 0, do_mom_diff = 0, init_iter = 2, init_vel_iter = 1;
     double init_shrink = 1.0, change_max = 1.1, fixed_dt = -1.0;
     int nscal = 2, verbose = 0;
+    double init_dt = -1.0;               // ns.init_dt
+    double tracer_diff_coef = 0.0;       // ns.scal_diff_coefs[0]
+    int phys_lo[3] = {0, 0, 0}, phys_hi[3] = {0, 0, 0};   // ns.lo_bc / ns.hi_bc (PhysBCType: 0 Interior, 4 SlipWall, 5 NoSlipWall)
+    double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
 };
 
 enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
@@ -47,6 +51,7 @@ class NavierStokes {
 public:
     NavierStokes(const Geometry& g, LayoutP layout, const NSParams& p, const MGOpts& o);
     void init_taylorgreen(double vfac, double a, double b, double c, double rho0);   // Source/prob/prob_init.cpp:509-560
+    void init_rest(double rho0);               // probtype 1 (LidDrivenCavity), Source/prob/prob_init.cpp:102-109
     void post_init(double stop_time);          // NavierStokes::post_init
     double step();                             // Amr::coarseTimeStep on one level: computeNewDt + advance
     double advance(double dt);                 // NavierStokes::advance; returns the dt estimate
@@ -57,7 +62,7 @@ public:
     MultiFab& Aofs() { return aofs; }
     double time = 0.0, dt = 0.0;
     int nstep = 0;
-    MGStats st_mac, st_nodal, st_visc;
+    MGStats st_mac, st_nodal, st_visc, st_scal;
     double t_sections[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // accumulated ms: predict, mac, advect, update, visc, nodal
     bool profile_sections = false;
 
@@ -70,13 +75,18 @@ private:
     void scalar_update_rho(double dt);
     void scalar_update_tracers(double dt);
     void velocity_advection_update(double dt);
+    void scalar_diffusion_update(double dt);
+    void get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata);
+    void first_order_extrap(MultiFab& mf);
+    void fill_gradp_bc();
+    bool is_diffusive_tracer() const { return p.tracer_diff_coef > 0.0; }
     void velocity_diffusion_update(double dt);
     void initial_velocity_diffusion_update(double dt);
     void level_project(double dt);
     void initial_velocity_project();
     void initial_sync_project(double dt);
     void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
-    void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp);
+    void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc);
     bool is_diffusive_vel() const { return p.visc_coef > 0.0; }
 
     Geometry g;
@@ -89,8 +99,11 @@ private:
     MultiFab eta[3];
     double dt_min_adv = 1.e200;
     bool initial_step = false, initial_iter = false;
-    DomainBC bc_mac, bc_nodal, bc_visc;
-    BCRec bc_vel[3], bc_scal[2];
+    DomainBC bc_mac, bc_nodal, bc_visc[3], bc_scal_lin;
+    BCRec bc_vel[3], bc_scal[2], bc_gp[3];
+    double ed_vel_lo[9], ed_vel_hi[9];     // ext_dir values [n*3+d]
+    MultiFab diff_b[3];                    // tracer diffusivity on faces
+    bool any_wall = false;
 };
 
 }  // namespace iamrx

@@ -10,14 +10,21 @@ class NsParams(C.Structure):
                 ("proj_abs_tol", C.c_double), ("visc_tol", C.c_double),
                 ("use_forces_in_trans", C.c_int), ("do_mom_diff", C.c_int), ("init_iter", C.c_int),
                 ("init_vel_iter", C.c_int), ("init_shrink", C.c_double), ("change_max", C.c_double),
-                ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int)]
+                ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int),
+                ("init_dt", C.c_double), ("tracer_diff_coef", C.c_double), ("phys_lo", C.c_int * 3), ("phys_hi", C.c_int * 3),
+                ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9)]
 
 
 def ns_params(**kw):
     p = NsParams()
     lib().iamrx_ns_default_params(C.byref(p))
     for k, v in kw.items():
-        setattr(p, k, v)
+        if k in ("phys_lo", "phys_hi"):
+            setattr(p, k, (C.c_int * 3)(*[int(x) for x in v]))
+        elif k in ("wall_vel_lo", "wall_vel_hi"):
+            setattr(p, k, (C.c_double * 9)(*[float(x) for x in v]))
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -101,6 +108,12 @@ class NavierStokes:
 
     def init_taylorgreen(self, vfac=1.0, a=1.0, b=1.0, c=0.0, rho0=1.0):
         check(lib().iamrx_ns_init_taylorgreen(self.h, C.c_double(vfac), C.c_double(a), C.c_double(b), C.c_double(c), C.c_double(rho0)))
+
+    def init_rest(self, rho0=1.0):
+        check(lib().iamrx_ns_init_rest(self.h, C.c_double(rho0)))
+
+    def set_data(self, which, mf):
+        check(lib().iamrx_ns_set_data(self.h, int(which), mf.h))
 
     def post_init(self, stop_time=-1.0):
         check(lib().iamrx_ns_post_init(self.h, C.c_double(stop_time)))

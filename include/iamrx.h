@@ -193,11 +193,16 @@ typedef struct iamrx_ns_params {
     int use_forces_in_trans, do_mom_diff, init_iter, init_vel_iter;
     double init_shrink, change_max, fixed_dt;
     int nscal, verbose;
+    double init_dt;              /* ns.init_dt: dt when the state has no velocity/force scale (LidDrivenCavity start) */
+    double tracer_diff_coef;     /* ns.scal_diff_coefs[0] (<= 0: tracer not diffusive) */
+    int phys_lo[3], phys_hi[3];  /* ns.lo_bc / ns.hi_bc, Source/NS_BC.H: 0 Interior (periodic), 4 SlipWall, 5 NoSlipWall */
+    double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
 } iamrx_ns_params;
 void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);
 int iamrx_ns_destroy(iamrx_ns ns);
 int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, double c, double rho0);  /* Source/prob/prob_init.cpp:509-560 */
+int iamrx_ns_init_rest(iamrx_ns ns, double rho0);          /* probtype 1, LidDrivenCavity (Source/prob/prob_init.cpp:102-109) */
 int iamrx_ns_post_init(iamrx_ns ns, double stop_time);     /* NavierStokes::post_init (Source/NavierStokes.cpp:1254-1299) */
 int iamrx_ns_step(iamrx_ns ns, double* dt_used);           /* computeNewDt + NavierStokes::advance (Source/NavierStokes.cpp:543-691) */
 int iamrx_ns_advance(iamrx_ns ns, double dt, double* dt_est);
@@ -205,6 +210,9 @@ int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep);
 /* snapshot COPY (caller destroys it with iamrx_mf_destroy) of a persistent array: 0 S_new, 1 S_old, 2 P_new,
  * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role) */
 int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
+/* overwrite state (0,1), pressure (2,3) or grad p (4,5) with src (same layout, ncomp, ngrow): the role of
+ * NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420) */
+int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src);
 int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc);
 /* per-section wall time accumulation (ms): predict, mac, advect, update, viscous, nodal; enable=1 inserts stream syncs */
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8]);

@@ -168,6 +168,9 @@ void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc
 /* y = (alpha*a - beta div tau(u)) with MLTensorOp semantics (3 comps) */
 void orc_tensor_apply(const orc_geom* g, orc_fab* y, const orc_fab* u /*3 comps,1 ghost filled incl. corners*/,
                       double alpha, double beta, const orc_fab* a, orc_fab* const eta[3] /*faces,1 comp*/);
+void orc_tensor_apply_bcn(const orc_geom* g, orc_fab* y, orc_fab* u /*3 comps, 1 ghost: BC data in, operator ghosts out*/,
+                          double alpha, double beta, const orc_fab* a, orc_fab* const eta[3],
+                          const int* lobc /*9: [n*3+d]*/, const int* hibc, int maxorder);
 void orc_tensor_solve_bcn(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
                           const orc_fab* a, orc_fab* const eta[3], const int* lobc /*9: [n*3+d]*/, const int* hibc,
                           double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
@@ -186,6 +189,10 @@ typedef struct orc_ns_params {
     double init_shrink, change_max, fixed_dt;
     int nscal;                 /* number of scalars incl. density (2) */
     int verbose;
+    double init_dt;            /* ns.init_dt: used when estTimeStep finds no velocity/force scale (-1: abort) */
+    double tracer_diff_coef;   /* ns.scal_diff_coefs[0]: tracer diffusivity (<= 0: not diffusive) */
+    int phys_lo[3], phys_hi[3];/* ns.lo_bc / ns.hi_bc: 0 Interior (periodic), 4 SlipWall, 5 NoSlipWall (Source/NS_BC.H) */
+    double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
 } orc_ns_params;
 
 typedef struct orc_ns_state orc_ns_state;
@@ -199,6 +206,8 @@ void orc_ns_destroy(orc_ns_state* s);
 orc_fab* orc_ns_fab(orc_ns_state* s, int which);
 void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0);
 /* NavierStokes::post_init sequence: initialVelocityProject, estimate dt, init_iter pressure iterations */
+void orc_ns_init_rest(orc_ns_state* s, double rho0);     /* probtype 1: LidDrivenCavity start */
+void orc_ns_test_set_extrap_scale(double v);            /* test hook, see orc_ns.c first_order_extrap */
 void orc_ns_post_init(orc_ns_state* s, double stop_time);
 /* one coarse time step: computeNewDt + NavierStokes::advance; returns dt used */
 double orc_ns_step(orc_ns_state* s);

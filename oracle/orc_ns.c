@@ -18,8 +18,12 @@
  *   Projection::initialSyncProject         Source/Projection.cpp:970-1185
  *   NavierStokes::post_init / post_init_press Source/NavierStokes.cpp:1254-1432
  *   NSB::estTimeStep / computeNewDt        Source/NavierStokesBase.cpp:1353-1510, 945-1035
- * Scope: one level, periodic or wall BCs handled by the kernels, constant viscosity, no divu,
- * NUM_STATE = 5 (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
+ *   NavierStokes::scalar_diffusion_update  Source/NavierStokes.cpp:867-1000 -> Diffusion::diffuse_scalar Source/Diffusion.cpp:207-599
+ *   Diffusion::getViscTerms (scalars)      Source/Diffusion.cpp:1539-1652
+ *   physical BC tables                     Source/NS_BC.H:7-55, Source/NS_setup.cpp:21-128, Source/NS_bcfill.H:17-180
+ * Scope: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls through
+ * xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, no divu, NUM_STATE = 5
+ * (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
  */
 #include "orc_int.h"
 
@@ -40,9 +44,12 @@ struct orc_ns_state {
     double time, dt, dt_min_adv;
     int nstep;
     int initial_step, initial_iter;
-    orc_mg_stats st_mac, st_nodal, st_visc;
-    int lobc[3], hibc[3];
-    orc_bcrec bc_vel[3], bc_scal[2];
+    orc_mg_stats st_mac, st_nodal, st_visc, st_scal;
+    int lobc[3], hibc[3];          /* LinOp BC of the projections: Neumann at walls */
+    orc_bcrec bc_vel[3], bc_scal[2], bc_gp[3];
+    double ed_vel_lo[9], ed_vel_hi[9];   /* ext_dir values [n*3+d] for the velocity fill */
+    int vlobc[9], vhibc[9];        /* tensor-solve LinOp BC per velocity component [n*3+d] */
+    int slobc[3], shibc[3];        /* scalar-diffusion LinOp BC (tracer) */
 };
 
 #define S_NEW(s) (&(s)->S[(s)->inew])
@@ -58,6 +65,26 @@ void orc_ns_default_params(orc_ns_params* p)
     p->mac_tol = 1.e-12; p->mac_abs_tol = 1.e-16; p->proj_tol = 1.e-12; p->proj_abs_tol = 1.e-16; p->visc_tol = 1.e-10;
     p->use_forces_in_trans = 0; p->do_mom_diff = 0; p->init_iter = 2; p->init_vel_iter = 1;
     p->init_shrink = 1.0; p->change_max = 1.1; p->fixed_dt = -1.0; p->nscal = 2; p->verbose = 0;
+    p->init_dt = -1.0; p->tracer_diff_coef = 0.0;
+    for (int d = 0; d < 3; ++d) p->phys_lo[d] = p->phys_hi[d] = 0;
+    for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
+}
+
+/* BCType of a velocity component / scalar / grad p component for a physical BC (Source/NS_BC.H:7-35) */
+enum { PHYS_INTERIOR = 0, PHYS_SLIPWALL = 4, PHYS_NOSLIPWALL = 5 };
+static int vel_bctype(int phys, int normal)
+{
+    if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    if (phys == PHYS_NOSLIPWALL) return ORC_BC_EXT_DIR;
+    return normal ? ORC_BC_EXT_DIR : ORC_BC_HOEXTRAP;          /* SlipWall */
+}
+static int scal_bctype(int phys) { return phys == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_FOEXTRAP; }
+/* Diffusion::setDomainBC, Source/Diffusion.cpp:1886-1941 */
+static int linop_of_bctype(int bct)
+{
+    if (bct == ORC_BC_EXT_DIR) return ORC_LO_DIRICHLET;
+    if (bct == ORC_BC_FOEXTRAP || bct == ORC_BC_HOEXTRAP || bct == ORC_BC_REFLECT_EVEN) return ORC_LO_NEUMANN;
+    return ORC_LO_PERIODIC;
 }
 
 orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc_mg_opts* o)
@@ -75,9 +102,21 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     s->rho_ctime = orc_alloc(g->n, ORC_CELL, 1, 1);
     s->rho_half = orc_alloc(g->n, ORC_CELL, 1, 1);
     for (int d = 0; d < 3; ++d) {
+        const int plo = g->periodic[d] ? PHYS_INTERIOR : p->phys_lo[d], phi_ = g->periodic[d] ? PHYS_INTERIOR : p->phys_hi[d];
+        if (!g->periodic[d] && !((plo == PHYS_SLIPWALL || plo == PHYS_NOSLIPWALL) && (phi_ == PHYS_SLIPWALL || phi_ == PHYS_NOSLIPWALL))) {
+            fprintf(stderr, "orc_ns_create: non-periodic direction %d needs SlipWall(4)/NoSlipWall(5) on both sides\n", d);
+            free(s); return NULL;
+        }
+        /* MacProj::set_mac_solve_bc (Source/MacProj.cpp:1187-1208), Projection.cpp:2434-2464: walls are Neumann */
         s->lobc[d] = s->hibc[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_NEUMANN;
-        for (int n = 0; n < 3; ++n) { s->bc_vel[n].lo[d] = s->bc_vel[n].hi[d] = ORC_BC_INT_DIR; }
-        for (int n = 0; n < 2; ++n) { s->bc_scal[n].lo[d] = s->bc_scal[n].hi[d] = ORC_BC_INT_DIR; }
+        for (int n = 0; n < 3; ++n) {
+            s->bc_vel[n].lo[d] = vel_bctype(plo, n == d); s->bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
+            s->bc_gp[n].lo[d] = scal_bctype(plo); s->bc_gp[n].hi[d] = scal_bctype(phi_);   /* norm/tang_gradp_bc: foextrap at walls */
+            s->ed_vel_lo[n * 3 + d] = p->wall_vel_lo[d * 3 + n]; s->ed_vel_hi[n * 3 + d] = p->wall_vel_hi[d * 3 + n];
+            s->vlobc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].lo[d]); s->vhibc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].hi[d]);
+        }
+        for (int n = 0; n < 2; ++n) { s->bc_scal[n].lo[d] = scal_bctype(plo); s->bc_scal[n].hi[d] = scal_bctype(phi_); }
+        s->slobc[d] = linop_of_bctype(s->bc_scal[1].lo[d]); s->shibc[d] = linop_of_bctype(s->bc_scal[1].hi[d]);
     }
     return s;
 }
@@ -134,22 +173,39 @@ void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, d
     s->time = 0.0; s->nstep = 0;
 }
 
+/* probtype 1 (LidDrivenCavity): fluid at rest, rho = rho0, tracer = 0 (reference Source/prob/prob_init.cpp:102-109) */
+void orc_ns_init_rest(orc_ns_state* s, double rho0)
+{
+    orc_fab* S = S_NEW(s);
+    orc_setval(S, 0.0);
+    const orc_geom* g = &s->g;
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S, i, j, k, Density) = rho0;
+    orc_setval(P_NEW(s), 0.0); orc_setval(P_OLD(s), 0.0);
+    orc_setval(GP_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0);
+    s->time = 0.0; s->nstep = 0;
+}
+
 /* FillPatch of comps [sc, sc+nc) of src (valid region) into a fresh fab with ng ghosts */
 static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int nc, int ng, const orc_bcrec* bc)
 {
+    const int is_vel = (bc == s->bc_vel);
     const orc_geom* g = &s->g;
     orc_fab f = orc_alloc(g->n, ORC_CELL, ng, nc);
     for (int n = 0; n < nc; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&f, i, j, k, n) = A4(src, i, j, k, sc + n);
     orc_fill_periodic(&f, g, ORC_CELL);
-    if (bc) orc_fill_physbc_cc(&f, g, bc, NULL, NULL);
+    if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : NULL, is_vel ? s->ed_vel_hi : NULL);
     return f;
 }
 static void fill_ghosts(const orc_ns_state* s, orc_fab* f, const int type[3])
 {
     orc_fill_periodic(f, &s->g, type);
 }
+
+/* test hook: scale factor applied to the extrapolated wall ghost cells of the viscous terms (1 = the algorithm) */
+static double s_extrap_scale = 1.0;
+void orc_ns_test_set_extrap_scale(double v) { s_extrap_scale = v; }
 
 static void floor_small(orc_fab* f)
 {
@@ -164,6 +220,56 @@ static void make_eta(const orc_ns_state* s, orc_fab eta[3])
     for (int d = 0; d < 3; ++d) { eta[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&eta[d], s->p.visc_coef); }
 }
 
+/* Extrapolater::FirstOrderExtrap role (reference Source/NavierStokes.cpp:2047): give the ghost cells outside the physical
+ * domain a first-order value.  Restated as: copy of the nearest cell inside the domain (index clamp in the non-periodic
+ * directions).  These cells only feed Godunov states on wall faces that the wall BC overrides, see
+ * tests/test_cpu_oracle.py::test_wall_ghost_forcing_is_immaterial. */
+static void first_order_extrap(orc_fab* f, const orc_geom* g)
+{
+    for (int n = 0; n < f->nc; ++n)
+    for (int k = f->lo[2]; k <= f->hi[2]; ++k) for (int j = f->lo[1]; j <= f->hi[1]; ++j) for (int i = f->lo[0]; i <= f->hi[0]; ++i) {
+        int q[3] = {i, j, k}, out = 0;
+        for (int d = 0; d < 3; ++d) {
+            if (g->periodic[d]) continue;
+            if (q[d] < 0) { q[d] = 0; out = 1; } else if (q[d] > g->n[d] - 1) { q[d] = g->n[d] - 1; out = 1; }
+        }
+        if (out) A4(f, i, j, k, n) = A4(f, q[0], q[1], q[2], n) * s_extrap_scale;
+    }
+}
+
+static int is_diffusive_tracer(const orc_ns_state* s) { return s->p.tracer_diff_coef > 0.0; }
+
+/* the (constant-coefficient) scalar diffusion operator of the tracer: MLABecLaplacian with b = diffusivity on faces */
+static void tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a)
+{
+    memset(L, 0, sizeof(*L));
+    L->g = s->g; L->alpha = alpha; L->beta = beta; L->ncomp = 1; L->tensor = 0;
+    if (a) L->a = *a; else L->a.p = NULL;
+    for (int d = 0; d < 3; ++d) { L->b[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&L->b[d], s->p.tracer_diff_coef); }
+}
+
+/* NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0: Laplacian_S): visc = div(beta grad S(time)) */
+static void get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata)
+{
+    const orc_geom* g = &s->g;
+    orc_setval(visc, 1.e40);
+    if (!is_diffusive_tracer(s)) { orc_setval(visc, 0.0); return; }
+    orc_fab stmp = fillpatch(s, Sdata, Tracer, 1, 1, &s->bc_scal[1]);
+    orc_abec_level L;
+    tracer_level(s, &L, 0.0, -1.0, NULL);
+    orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_copy_all(&bcval, &stmp);
+    orc_abec_applybc(&L, &stmp, s->slobc, s->shibc, 2, 1, &bcval);
+    orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 1);
+    orc_abec_apply(&L, &tmp, &stmp);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(visc, i, j, k, 0) = A4(&tmp, i, j, k, 0);
+    orc_fill_periodic(visc, g, ORC_CELL);
+    first_order_extrap(visc, g);
+    orc_free(&tmp); orc_free(&bcval); orc_free(&stmp);
+    for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+}
+
 /* NavierStokes::getViscTerms for velocity: visc = div tau(U(time)), then FillBoundary (+ FirstOrderExtrap at walls) */
 static void get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata)
 {
@@ -175,11 +281,12 @@ static void get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1
     make_eta(s, eta);
     for (int d = 0; d < 3; ++d) ep[d] = &eta[d];
     orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 3);
-    orc_tensor_apply(g, &tmp, &stmp, 0.0, -1.0, NULL, ep);
+    orc_tensor_apply_bcn(g, &tmp, &stmp, 0.0, -1.0, NULL, ep, s->vlobc, s->vhibc, 2);
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(visc, i, j, k, n) = A4(&tmp, i, j, k, n);
     orc_fill_periodic(visc, g, ORC_CELL);
+    first_order_extrap(visc, g);
     orc_free(&tmp); orc_free(&stmp);
     for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
 }
@@ -215,7 +322,8 @@ static double est_time_step(orc_ns_state* s)
         if (fmax_[d] > small) estdt = fmin(estdt, sqrt(2.0 * g->dx[d] / fmax_[d]));
     }
     if (estdt < 1.0e+20) estdt *= s->p.cfl;
-    else { fprintf(stderr, "orc estTimeStep failed\n"); estdt = 1.e-3; }
+    else if (s->p.init_dt > 0.0) estdt = s->p.init_dt;          /* NavierStokesBase.cpp:1463-1481 */
+    else { fprintf(stderr, "orc estTimeStep failed (zero velocity and force: set init_dt)\n"); abort(); }
     return estdt;
 }
 
@@ -236,6 +344,7 @@ static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost,
         else A4(G, i, j, k, n) = A4(&gp, i, j, k, n);
     }
     orc_fill_periodic(G, g, ORC_CELL);
+    orc_fill_physbc_cc(G, g, s->bc_gp, NULL, NULL);   /* FillPatch(Gradp_Type), Projection.cpp:2565 */
     orc_free(&gp);
 }
 
@@ -347,11 +456,14 @@ static void scalar_advection(orc_ns_state* s, double dt)
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
     orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
     int iconserv[2] = {1, 0};   /* density conservative; tracer non-conservative (do_cons_trac = 0) */
+    orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
+    if (s->p.be_cn_theta != 1.0) get_visc_terms_tracer(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         double rho = A4(&Smf, i, j, k, 0);
-        A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc */
-        A4(&tf, i, j, k, 1) = A4(&tf, i, j, k, 1) / rho + 0.0;    /* convective: tf/rho + visc */
+        A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc (density: not diffusive) */
+        A4(&tf, i, j, k, 1) = A4(&tf, i, j, k, 1) / rho + A4(&visc, i, j, k, 0);    /* convective: tf/rho + visc */
     }
+    orc_free(&visc);
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
     orc_compute_aofs(g, &s->aofs, Density, &Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, NULL);
     orc_free(&Smf); orc_free(&tf); orc_free(&divu);
@@ -380,6 +492,50 @@ static void scalar_update_tracers(orc_ns_state* s, double dt)
         double tf = 0.0;
         A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf / rho);
     }
+}
+
+/* NavierStokes::scalar_diffusion_update -> Diffusion::diffuse_scalar for the tracer (rho_flag 0, Laplacian_S;
+ * reference Source/NavierStokes.cpp:867-1000, Source/Diffusion.cpp:207-599): Crank-Nicolson
+ *   (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old */
+static void scalar_diffusion_update(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    if (!is_diffusive_tracer(s)) return;
+    const double theta = s->p.be_cn_theta;
+    orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
+    orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
+    if (theta != 1.0) {
+        /* FillPatch(S_old, ng 1) then opn.setLevelBC(Soln = S_old tracer with ghosts); a = 0, b = -(1-theta) dt */
+        orc_fab Soln = fillpatch(s, So, Tracer, 1, 1, &s->bc_scal[1]);
+        orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
+        orc_copy_all(&bcval, &Soln);
+        orc_abec_level Ln;
+        tracer_level(s, &Ln, 0.0, -(1.0 - theta) * dt, NULL);
+        orc_abec_applybc(&Ln, &Soln, s->slobc, s->shibc, 2, 1, &bcval);
+        orc_abec_apply(&Ln, &Rhs, &Soln);
+        for (int d = 0; d < 3; ++d) orc_free(&Ln.b[d]);
+        orc_free(&Soln); orc_free(&bcval);
+    }
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&Rhs, i, j, k, 0) += A4(Sn, i, j, k, Tracer);
+    double m = 0.0;     /* get_scaled_abs_tol: visc_tol * ||Rhs||inf (one component) */
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        double v = fabs(A4(&Rhs, i, j, k, 0)); if (v > m) m = v;
+    }
+    const double tol_abs = s->p.visc_tol * m;
+    orc_fab Soln = fillpatch(s, Sn, Tracer, 1, 1, &s->bc_scal[1]);     /* FillPatch(S_new, ng 1): initial guess + level BC */
+    orc_fab acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
+    orc_setval(&acoef, 1.0);                                            /* computeAlpha, rho_flag 0: alpha = 1 */
+    orc_abec_level L;
+    tracer_level(s, &L, 1.0, theta * dt, &acoef);
+    orc_mg_opts o = s->o; o.maxorder = 2;                                /* Diffusion::max_order = 2 */
+    orc_mg_stats st;
+    orc_abec_solve(&L, &Soln, &Rhs, s->slobc, s->shibc, s->p.visc_tol, tol_abs, &o, &st);
+    s->st_scal = st;
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(Sn, i, j, k, Tracer) = A4(&Soln, i, j, k, 0);
+    for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+    orc_free(&Soln); orc_free(&acoef); orc_free(&Rhs);
 }
 
 static void velocity_advection_update(orc_ns_state* s, double dt)
@@ -430,7 +586,7 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 3);
     if (theta != 1.0) {
         orc_fab Soln = fillpatch(s, Uo, Xvel, 3, 1, s->bc_vel);
-        orc_tensor_apply(g, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep);
+        orc_tensor_apply_bcn(g, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep, s->vlobc, s->vhibc, 2);
         orc_free(&Soln);
     }
     for (int n = 0; n < 3; ++n)
@@ -453,9 +609,7 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&acoef, i, j, k, 0) = 1.0 * A4(&s->rho_half, i, j, k, 0);
     orc_mg_opts o = s->o; o.maxorder = 2;
-    int lob[3], hib[3];
-    for (int d = 0; d < 3; ++d) { lob[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_DIRICHLET; hib[d] = lob[d]; }
-    orc_tensor_solve(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, lob, hib, s->p.visc_tol, tol_abs, &o, &s->st_visc);
+    orc_tensor_solve_bcn(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, s->vlobc, s->vhibc, s->p.visc_tol, tol_abs, &o, &s->st_visc);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
         A4(Un, i, j, k, n) = A4(&Soln, i, j, k, n);
@@ -501,6 +655,7 @@ static double advance(orc_ns_state* s, double dt)
     scalar_advection(s, dt);
     scalar_update_rho(s, dt);
     scalar_update_tracers(s, dt);
+    scalar_diffusion_update(s, dt);
     velocity_advection_update(s, dt);
     if (!s->initial_iter) velocity_diffusion_update(s, dt);
     else initial_velocity_diffusion_update(s, dt);

@@ -146,6 +146,22 @@ void orc_tensor_apply(const orc_geom* g, orc_fab* y, const orc_fab* u, double al
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
 }
 
+/* MLMG::apply with setLevelBC(u): the ghost cells of u hold the boundary data on entry (Diffusion::getTensorViscTerms,
+ * reference Source/Diffusion.cpp:1655-1777); on exit they hold the operator's ghost values (face, edge, corner fill) */
+void orc_tensor_apply_bcn(const orc_geom* g, orc_fab* y, orc_fab* u, double alpha, double beta, const orc_fab* a,
+                          orc_fab* const eta[3], const int* lobc, const int* hibc, int maxorder)
+{
+    orc_abec_level L;
+    build_level(g, &L, alpha, beta, a, eta);
+    L.bc_percomp = 1;
+    orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 3);
+    orc_copy_all(&bcval, u);
+    orc_abec_applybc(&L, u, lobc, hibc, maxorder, 1, &bcval);
+    orc_abec_apply(&L, y, u);
+    orc_free(&bcval);
+    for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+}
+
 /* lobc/hibc hold 9 codes [n*3+d]: one BC triple per velocity component (Diffusion::setDomainBC per component,
  * reference Source/Diffusion.cpp:724-731 and 1939-2020: slip walls are Dirichlet for the normal and Neumann for the
  * tangential components) */

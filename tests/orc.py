@@ -65,7 +65,9 @@ class CNsParams(C.Structure):
                 ("proj_abs_tol", C.c_double), ("visc_tol", C.c_double),
                 ("use_forces_in_trans", C.c_int), ("do_mom_diff", C.c_int), ("init_iter", C.c_int),
                 ("init_vel_iter", C.c_int), ("init_shrink", C.c_double), ("change_max", C.c_double),
-                ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int)]
+                ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int),
+                ("init_dt", C.c_double), ("tracer_diff_coef", C.c_double), ("phys_lo", C.c_int * 3), ("phys_hi", C.c_int * 3),
+                ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9)]
 
 
 PF = C.POINTER(CFab)

@@ -222,3 +222,75 @@ def test_golden_fixture_regression(orc):
     S, P, t = run_tg(orc, 16, None, visc=float(gold["visc"]), c=float(gold["c"]), nsteps=int(gold["nsteps"]))
     assert abs(t - float(gold["time"])) <= 1e-14
     assert np.abs(S - gold["S"]).max() <= 1e-12
+
+
+def run_ldc(orc, n, phys_lo, phys_hi, nsteps, extrap_scale=1.0, init=None, per=(0, 0, 0), **kw):
+    """LidDrivenCavity set-up of Exec/run3d/regtest.3d.lid_driven_cavity:5-46 (lid zhi.velocity = 1 0 0)"""
+    L = orc.lib()
+    g = orc.geom(n, periodic=per)
+    p = orc.CNsParams()
+    L.orc_ns_default_params(C.byref(p))
+    par = dict(cfl=0.3, visc_coef=0.01, init_dt=0.0140625, init_shrink=0.3, init_iter=3, tracer_diff_coef=0.001)
+    par.update(kw)
+    for k, v in par.items():
+        setattr(p, k, v)
+    for d in range(3):
+        p.phys_lo[d] = 0 if per[d] else phys_lo[d]
+        p.phys_hi[d] = 0 if per[d] else phys_hi[d]
+    p.wall_vel_hi[2 * 3 + 0] = 1.0
+    o = orc.mg_opts()
+    L.orc_ns_test_set_extrap_scale(C.c_double(extrap_scale))
+    s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
+    L.orc_ns_init_rest(s, C.c_double(1.0))
+    if init is not None:
+        orc.from_cfab(L.orc_ns_fab(s, 0)).a[1:-1, 1:-1, 1:-1, :] = init
+    L.orc_ns_post_init(s, C.c_double(-1.0))
+    dts = [L.orc_ns_step(s) for _ in range(nsteps)]
+    S = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+    t = L.orc_ns_time(s)
+    L.orc_ns_destroy(s)
+    L.orc_ns_test_set_extrap_scale(C.c_double(1.0))
+    return S, t, dts
+
+
+def test_lid_driven_cavity_slip_side_walls_stay_two_dimensional(orc):
+    """cavity with slip walls in y on both sides: the flow driven by the x-moving lid has v = 0 and no y dependence;
+    first dt = init_shrink * init_dt, later dts grow by change_max until the CFL limit binds"""
+    n = (12, 8, 12)
+    S, t, dts = run_ldc(orc, n, (5, 4, 5), (5, 4, 5), 4)
+    assert abs(dts[0] - 0.3 * 0.0140625) < 1e-15
+    assert all(abs(dts[i + 1] / dts[i] - 1.1) < 1e-12 for i in range(3))
+    assert np.abs(S[..., 0]).max() > 0.03
+    assert np.abs(S[..., 1]).max() < 1e-11
+    assert np.abs(S - S[:, :1]).max() < 1e-11
+    assert np.abs(S[..., 3] - 1.0).max() < 1e-10 and np.abs(S[..., 4]).max() == 0.0
+
+
+def test_wall_ghost_forcing_is_immaterial(orc):
+    """the viscous-term ghost cells outside the walls (Extrapolater::FirstOrderExtrap in the reference; restated as a
+    nearest-cell copy) only feed Godunov states that the wall BC overrides: scaling them by 1e3 changes nothing"""
+    n = (8, 8, 8)
+    rng = np.random.default_rng(11)
+    x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    init = np.zeros(n + (5,))
+    init[..., 0] = np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 1] = 0.4 * np.sin(2 * np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 2] = 0.2 * rng.random(n) * np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 3] = 1.0
+    init[..., 4] = np.exp(-30.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2))
+    kw = dict(cfl=0.5, visc_coef=0.05, tracer_diff_coef=0.02, init_iter=1)
+    a, _, _ = run_ldc(orc, n, (4, 4, 5), (5, 5, 5), 2, 1.0, init, **kw)
+    b, _, _ = run_ldc(orc, n, (4, 4, 5), (5, 5, 5), 2, 1.0e3, init, **kw)
+    assert np.abs(a[..., 0]).max() > 0.1
+    assert np.array_equal(a, b)
+
+
+def test_golden_fixture_regression_lid_driven_cavity(orc):
+    path = os.path.join(HERE, "golden", "liddrivencavity16_oracle.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    gold = np.load(path)
+    S, t, dts = run_ldc(orc, (16, 16, 16), (4, 4, 5), (5, 5, 5), int(gold["nsteps"]))
+    assert abs(t - float(gold["time"])) <= 1e-14
+    assert np.abs(S - gold["S"]).max() <= 1e-12
