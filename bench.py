@@ -143,7 +143,17 @@ def main():
     lib.init(local_rank)
     if world > 1:
         from iamr_amd import comm
-        comm.init_rccl_from_torch(dist)
+        transport = "rccl"
+        ok = torch.ones(1, device="cuda")
+        try:
+            comm.init_rccl_from_torch(dist)
+        except Exception as e:      # keep the run alive on a host-staged transport rather than produce no number
+            print(f"[bench] rank {rank}: RCCL transport failed to initialise ({e}); falling back to gloo host staging", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            transport = "gloo-host-staged (fallback)"
+            comm.init_gloo_callback(dist, dist.new_group(backend="gloo"))
 
     n = a.n
     # one n^3 box per GPU, stacked in z: level = world boxes (weak scaling)
@@ -215,6 +225,7 @@ def main():
             "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
             "sections_ms_per_step": {k: v / 2 for k, v in zip(["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"], sec[:6])},
             "device_mallocs_in_timed_region": mallocs_in_loop,
+            "transport": transport if world > 1 else "none (single GPU)",
             "kernels": kr,
             "roofline": roofline,
         }

@@ -37,7 +37,7 @@ EX_CB = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_d
                     C.c_int, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_long))
 
 
-def init_gloo_callback(dist):
+def init_gloo_callback(dist, group=None):
     import torch
     L = lib()
     L.iamrx_comm_last_error.restype = C.c_char_p
@@ -46,7 +46,7 @@ def init_gloo_callback(dist):
     def allreduce(vals, n, op):
         a = np.ctypeslib.as_array(vals, shape=(n,))
         t = torch.from_numpy(a.copy())
-        dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[op])
+        dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[op], group=group)
         a[:] = t.numpy()
 
     def exchange(ns, speers, sbufs, scounts, nr, rpeers, rbufs, rcounts):
@@ -54,10 +54,10 @@ def init_gloo_callback(dist):
         for i in range(nr):
             t = torch.empty(rcounts[i], dtype=torch.float64)
             recvs.append((t, rbufs[i], rcounts[i]))
-            reqs.append(dist.irecv(t, rpeers[i], tag=0))
+            reqs.append(dist.irecv(t, rpeers[i], group=group, tag=0))
         for i in range(ns):
             a = np.ctypeslib.as_array(sbufs[i], shape=(scounts[i],))
-            reqs.append(dist.isend(torch.from_numpy(a.copy()), speers[i], tag=0))
+            reqs.append(dist.isend(torch.from_numpy(a.copy()), speers[i], group=group, tag=0))
         for r in reqs:
             r.wait()
         for t, ptr, cnt in recvs:

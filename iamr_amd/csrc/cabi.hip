@@ -343,7 +343,12 @@ int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
         if (!nodal_smooth_small(gg, phi->mf, rhs->mf, sig->mf, 1)) throw Error("level does not qualify for the single-workgroup smoother");
         phi->mf.FillBoundary(gg);
     } else if (fused) {
-        for (int kpar = 0; kpar < 2; ++kpar) { phi->mf.FillBoundary(gg); nodal_gs_fused_pass(gg, phi->mf, rhs->mf, sig->mf, kpar); }
+        MultiFab xb(phi->mf.layout, node_type(), 1, phi->mf.ngrow);
+        phi->mf.FillBoundary(gg);
+        nodal_gs_fused_pass(gg, phi->mf, phi->mf, xb, rhs->mf, sig->mf, 0);
+        xb.FillBoundary(gg);
+        nodal_gs_fused_pass(gg, phi->mf, xb, xb, rhs->mf, sig->mf, 1);
+        MultiFab::Copy(phi->mf, xb, 0, 0, 1, 0);
     } else {
         for (int c = 0; c < 8; ++c) { phi->mf.FillBoundary(gg); nodal_gs_color(gg, phi->mf, rhs->mf, sig->mf, c); }
     }

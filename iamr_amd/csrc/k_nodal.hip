@@ -108,14 +108,20 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // of plane k.  The k+-1 planes belong to the other parity and are read-only during the pass, so the result
 // is identical to four sequential colour passes with a ghost fill in front of each of them -- provided the
 // arrays carry 4 ghost nodes (x, sigma) / 3 (rhs) that hold true periodic / neighbour images.
+// The pass is OUT OF PLACE: plane k is read from xc (state before the pass), the k+-1 planes from xn and the result goes
+// to xo.  In place, a workgroup could read halo nodes of plane k that a neighbouring workgroup has already updated (not
+// all workgroups of a large level are resident together), which would silently change the Gauss-Seidel ordering.
 // HBM traffic per sweep drops from 8 full-array passes to 2; kernel launches from 8+8 fills to 2+2.
 template <int TX, int TY>
-__global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xt,
-    const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty)
+__global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
+    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty)
 {
-    constexpr int RX = TX + 8, RY = TY + 8;
-    __shared__ double X[3][RY][RX];
-    __shared__ double S[2][RY][RX];
+    // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
+    // column, so its 64 lanes then read consecutive doubles (no bank conflicts) instead of a stride-2 pattern.
+    constexpr int RX = TX + 8, RY = TY + 8, HX = RX / 2, PX = RX + 2;   // PX: padded row pitch
+    __shared__ double X[3][RY][PX];
+    __shared__ double S[2][RY][PX];
+    __shared__ double R[RY][PX];
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
     const int bid = blockIdx.x;
@@ -128,19 +134,23 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
     const int tx0 = cb.lo[0] + tix * TX, ty0 = cb.lo[1] + tiy * TY;
     if (k > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
     const int txe = min(tx0 + TX - 1, nhi0), tye = min(ty0 + TY - 1, nhi1);
-    const FabD x = xt[fab], r = rt[fab], s = st[fab];
+    const FabD x = xct[fab], xn = xnt[fab], xo = xot[fab], r = rt[fab], s = st[fab];
     const int ox = tx0 - 4, oy = ty0 - 4;
     const int tid = threadIdx.x;
+#define COL(lx) ((((lx) & 1) * HX) + ((lx) >> 1))
     for (int idx = tid; idx < RX * RY; idx += 256) {
         const int lx = idx % RX, ly = idx / RX;
         const int gi = ox + lx, gj = oy + ly;
         const bool inx = gi >= x.lo[0] && gi < x.lo[0] + x.n[0] && gj >= x.lo[1] && gj < x.lo[1] + x.n[1];
         const bool ins = gi >= s.lo[0] && gi < s.lo[0] + s.n[0] && gj >= s.lo[1] && gj < s.lo[1] + s.n[1];
-        X[0][ly][lx] = inx ? x(gi, gj, k - 1) : 0.0;
-        X[1][ly][lx] = inx ? x(gi, gj, k) : 0.0;
-        X[2][ly][lx] = inx ? x(gi, gj, k + 1) : 0.0;
-        S[0][ly][lx] = ins ? s(gi, gj, k - 1) : 0.0;
-        S[1][ly][lx] = ins ? s(gi, gj, k) : 0.0;
+        const bool inr = gi >= r.lo[0] && gi < r.lo[0] + r.n[0] && gj >= r.lo[1] && gj < r.lo[1] + r.n[1];
+        const int cl = COL(lx);
+        X[0][ly][cl] = inx ? xn(gi, gj, k - 1) : 0.0;
+        X[1][ly][cl] = inx ? x(gi, gj, k) : 0.0;
+        X[2][ly][cl] = inx ? xn(gi, gj, k + 1) : 0.0;
+        S[0][ly][cl] = ins ? s(gi, gj, k - 1) : 0.0;
+        S[1][ly][cl] = ins ? s(gi, gj, k) : 0.0;
+        R[ly][cl] = inr ? r(gi, gj, k) : 0.0;
     }
     __syncthreads();
 #pragma unroll 1
@@ -152,40 +162,43 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
         for (int idx = tid; idx < ni * nj; idx += 256) {
             const int i = i0 + 2 * (idx % ni), j = j0 + 2 * (idx / ni);
             const int lx = i - ox, ly = j - oy;
-            const double smmm = S[0][ly - 1][lx - 1], spmm = S[0][ly - 1][lx], smpm = S[0][ly][lx - 1], sppm = S[0][ly][lx];
-            const double smmp = S[1][ly - 1][lx - 1], spmp = S[1][ly - 1][lx], smpp = S[1][ly][lx - 1], sppp = S[1][ly][lx];
+            const int c0 = COL(lx), cm = COL(lx - 1), cp = COL(lx + 1);
+            const double smmm = S[0][ly - 1][cm], spmm = S[0][ly - 1][c0], smpm = S[0][ly][cm], sppm = S[0][ly][c0];
+            const double smmp = S[1][ly - 1][cm], spmp = S[1][ly - 1][c0], smpp = S[1][ly][cm], sppp = S[1][ly][c0];
             const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
-            const double xc = X[1][ly][lx];
+            const double xc = X[1][ly][c0];
             double y = xc * s0;
-            y += w.corner * (X[0][ly - 1][lx - 1] * smmm + X[0][ly - 1][lx + 1] * spmm + X[0][ly + 1][lx - 1] * smpm + X[0][ly + 1][lx + 1] * sppm
-                           + X[2][ly - 1][lx - 1] * smmp + X[2][ly - 1][lx + 1] * spmp + X[2][ly + 1][lx - 1] * smpp + X[2][ly + 1][lx + 1] * sppp);
-            y += w.ex * (X[0][ly - 1][lx] * (smmm + spmm) + X[0][ly + 1][lx] * (smpm + sppm) + X[2][ly - 1][lx] * (smmp + spmp) + X[2][ly + 1][lx] * (smpp + sppp));
-            y += w.ey * (X[0][ly][lx - 1] * (smmm + smpm) + X[0][ly][lx + 1] * (spmm + sppm) + X[2][ly][lx - 1] * (smmp + smpp) + X[2][ly][lx + 1] * (spmp + sppp));
-            y += w.ez * (X[1][ly - 1][lx - 1] * (smmm + smmp) + X[1][ly - 1][lx + 1] * (spmm + spmp) + X[1][ly + 1][lx - 1] * (smpm + smpp) + X[1][ly + 1][lx + 1] * (sppm + sppp));
-            y += w.fx * (X[1][ly][lx - 1] * (smmm + smpm + smmp + smpp) + X[1][ly][lx + 1] * (spmm + sppm + spmp + sppp));
-            y += w.fy * (X[1][ly - 1][lx] * (smmm + spmm + smmp + spmp) + X[1][ly + 1][lx] * (smpm + sppm + smpp + sppp));
-            y += w.fz * (X[0][ly][lx] * (smmm + spmm + smpm + sppm) + X[2][ly][lx] * (smmp + spmp + smpp + sppp));
-            X[1][ly][lx] = xc + (r(i, j, k) - y) / s0;
+            y += w.corner * (X[0][ly - 1][cm] * smmm + X[0][ly - 1][cp] * spmm + X[0][ly + 1][cm] * smpm + X[0][ly + 1][cp] * sppm
+                           + X[2][ly - 1][cm] * smmp + X[2][ly - 1][cp] * spmp + X[2][ly + 1][cm] * smpp + X[2][ly + 1][cp] * sppp);
+            y += w.ex * (X[0][ly - 1][c0] * (smmm + spmm) + X[0][ly + 1][c0] * (smpm + sppm) + X[2][ly - 1][c0] * (smmp + spmp) + X[2][ly + 1][c0] * (smpp + sppp));
+            y += w.ey * (X[0][ly][cm] * (smmm + smpm) + X[0][ly][cp] * (spmm + sppm) + X[2][ly][cm] * (smmp + smpp) + X[2][ly][cp] * (spmp + sppp));
+            y += w.ez * (X[1][ly - 1][cm] * (smmm + smmp) + X[1][ly - 1][cp] * (spmm + spmp) + X[1][ly + 1][cm] * (smpm + smpp) + X[1][ly + 1][cp] * (sppm + sppp));
+            y += w.fx * (X[1][ly][cm] * (smmm + smpm + smmp + smpp) + X[1][ly][cp] * (spmm + sppm + spmp + sppp));
+            y += w.fy * (X[1][ly - 1][c0] * (smmm + spmm + smmp + spmp) + X[1][ly + 1][c0] * (smpm + sppm + smpp + sppp));
+            y += w.fz * (X[0][ly][c0] * (smmm + spmm + smpm + sppm) + X[2][ly][c0] * (smmp + spmp + smpp + sppp));
+            X[1][ly][c0] = xc + (R[ly][c0] - y) / s0;
         }
         __syncthreads();
     }
     const int wx = txe - tx0 + 1, wy = tye - ty0 + 1;
     for (int idx = tid; idx < wx * wy; idx += 256) {
         const int i = tx0 + idx % wx, j = ty0 + idx / wx;
-        x(i, j, k) = X[1][j - oy][i - ox];
+        xo(i, j, k) = X[1][j - oy][COL(i - ox)];
     }
+#undef COL
 }
 
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
-void nodal_gs_fused_pass(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int kpar)
+void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar)
 {
+    const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
-    IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3);
+    IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3 && xn.ngrow == x.ngrow && xo.ngrow == x.ngrow && xo.d_tab != xc.d_tab);
     constexpr int TX = 32, TY = 16;
     const Layout& l = *x.layout;
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
     dim3 grid((unsigned)(ntx * nty * npl), (unsigned)l.nlocal());
-    hipLaunchKernelGGL((k_nodal_gs4<TX, TY>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab,
+    hipLaunchKernelGGL((k_nodal_gs4<TX, TY>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab, sig.d_tab,
                        make_w(g), kpar, ntx, nty);
 }
 

@@ -103,6 +103,7 @@ private:
         MultiFab sig;              // cell, 1 ghost
         MultiFab cor, res, rescor; // node, 1 ghost
         MultiFab tmp;              // Jacobi scratch
+        MultiFab xb;               // second buffer of the out-of-place fused Gauss-Seidel sweeps
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void subtract_mean(int l, MultiFab& mf);

@@ -95,15 +95,26 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         fillbc(l, x);
         return;
     }
+    if (m_o.nodal_smoother == 0 && nodal_fused()) {
+        // colours 0-3 (k even) in one pass, colours 4-7 (k odd) in a second one: identical arithmetic to the eight
+        // sequential colour passes below.  Each sweep goes from one buffer to the other (see k_nodal_gs4).
+        if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
+        fillbc(l, const_cast<MultiFab&>(rhs));
+        MultiFab* a = &x;
+        MultiFab* b = &L.xb;
+        for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
+            fillbc(l, *a);
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0);      // even planes: a -> b
+            fillbc(l, *b);                                             // ghost images of the new even planes
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1);      // odd planes: centre from a, neighbours from b
+            std::swap(a, b);
+        }
+        if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
+        fillbc(l, x);
+        return;
+    }
     for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
-        if (m_o.nodal_smoother == 0 && nodal_fused()) {
-            // colours 0-3 (k even) in one pass, colours 4-7 (k odd) in a second one: identical arithmetic to the
-            // eight sequential colour passes below
-            if (ns == 0) fillbc(l, const_cast<MultiFab&>(rhs));
-            fillbc(l, x);
-            nodal_gs_fused_pass(L.g, x, rhs, L.sig, 0);
-            fillbc(l, x);
-            nodal_gs_fused_pass(L.g, x, rhs, L.sig, 1);
+        if (false) {
         } else if (m_o.nodal_smoother == 0) {
             for (int color = 0; color < 8; ++color) {
                 fillbc(l, x);

@@ -6,7 +6,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,boxes", [((16, 16, 16), None), ((48, 24, 20), None), ((32, 32, 16), (16, 16, 8)), ((4, 4, 4), None), ((2, 2, 2), None)])
+# the 160x128x96 case has far more workgroups than fit on the device at once: an in-place pass would let late workgroups
+# read already-updated halo nodes (caught here as a mismatch with the sequential colour passes)
+@pytest.mark.parametrize("n,boxes", [((16, 16, 16), None), ((48, 24, 20), None), ((32, 32, 16), (16, 16, 8)), ((4, 4, 4), None), ((2, 2, 2), None),
+                                     ((160, 128, 96), None), ((128, 128, 64), (64, 64, 32))])
 def test_fused_sweep_equals_eight_colour_passes(gpu, n, boxes):
     lib = gpu
     from iamr_amd import ns as N
