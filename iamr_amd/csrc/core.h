@@ -34,7 +34,14 @@ struct FabD {
     {
         return (long)(i - lo[0]) + (long)n[0] * ((long)(j - lo[1]) + (long)n[1] * (long)(k - lo[2]));
     }
+    typedef __attribute__((address_space(1))) double gdouble;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // device side: the table entry is loaded from memory, so the compiler cannot see that p points to global memory and
+    // would emit flat_load/flat_store (which also tie up the LDS counter); say so explicitly -> global_load/global_store
+    __device__ gdouble& operator()(int i, int j, int k, int c = 0) const { return ((gdouble*)p)[off(i, j, k) + cs * c]; }
+#else
     __host__ __device__ double& operator()(int i, int j, int k, int c = 0) const { return p[off(i, j, k) + cs * c]; }
+#endif
 };
 
 inline BoxD make_box(const int lo[3], const int hi[3])

@@ -138,19 +138,38 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
     const int ox = tx0 - 4, oy = ty0 - 4;
     const int tid = threadIdx.x;
 #define COL(lx) ((((lx) & 1) * HX) + ((lx) >> 1))
-    for (int idx = tid; idx < RX * RY; idx += 256) {
-        const int lx = idx % RX, ly = idx / RX;
-        const int gi = ox + lx, gj = oy + ly;
-        const bool inx = gi >= x.lo[0] && gi < x.lo[0] + x.n[0] && gj >= x.lo[1] && gj < x.lo[1] + x.n[1];
-        const bool ins = gi >= s.lo[0] && gi < s.lo[0] + s.n[0] && gj >= s.lo[1] && gj < s.lo[1] + s.n[1];
-        const bool inr = gi >= r.lo[0] && gi < r.lo[0] + r.n[0] && gj >= r.lo[1] && gj < r.lo[1] + r.n[1];
-        const int cl = COL(lx);
-        X[0][ly][cl] = inx ? xn(gi, gj, k - 1) : 0.0;
-        X[1][ly][cl] = inx ? x(gi, gj, k) : 0.0;
-        X[2][ly][cl] = inx ? xn(gi, gj, k + 1) : 0.0;
-        S[0][ly][cl] = ins ? s(gi, gj, k - 1) : 0.0;
-        S[1][ly][cl] = ins ? s(gi, gj, k) : 0.0;
-        R[ly][cl] = inr ? r(gi, gj, k) : 0.0;
+    {
+        // stage the footprint: all global loads are issued before the first LDS store (addresses are clamped into the
+        // arrays instead of predicated -- footprint points beyond the ghost width are never used by the colour passes)
+        constexpr int NLD = (RX * RY + 255) / 256;
+        double v[NLD][6];
+        const long xo_k = (long)x.n[0] * x.n[1], so_k = (long)s.n[0] * s.n[1];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = min(tid + it * 256, RX * RY - 1);
+            const int lx = idx % RX, ly = idx / RX;
+            const int gi = ox + lx, gj = oy + ly;
+            const int xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1), xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
+            const int si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1), sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
+            const int ri = min(max(gi, r.lo[0]), r.lo[0] + r.n[0] - 1), rj = min(max(gj, r.lo[1]), r.lo[1] + r.n[1] - 1);
+            const long xoff = x.off(xi, xj, k), soff = s.off(si, sj, k);
+            v[it][0] = ((FabD::gdouble*)xn.p)[xoff - xo_k];
+            v[it][1] = ((FabD::gdouble*)x.p)[xoff];
+            v[it][2] = ((FabD::gdouble*)xn.p)[xoff + xo_k];
+            v[it][3] = ((FabD::gdouble*)s.p)[soff - so_k];
+            v[it][4] = ((FabD::gdouble*)s.p)[soff];
+            v[it][5] = r(ri, rj, k);
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < RX * RY) {
+                const int lx = idx % RX, ly = idx / RX;
+                const int cl = COL(lx);
+                X[0][ly][cl] = v[it][0]; X[1][ly][cl] = v[it][1]; X[2][ly][cl] = v[it][2];
+                S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4]; R[ly][cl] = v[it][5];
+            }
+        }
     }
     __syncthreads();
 #pragma unroll 1
