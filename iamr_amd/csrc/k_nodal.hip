@@ -49,13 +49,109 @@ __device__ __forceinline__ double node_Ax(const FabD& x, const FabD& s, const No
     return y;
 }
 
-// out = rhs - A x   (rhs null: out = A x)
+// out = rhs - A x   (rhs null: out = A x).  z-marching: a workgroup owns a TXxTY column of nodes and walks KC planes; the
+// three x-planes and two sigma-planes it needs live in LDS (rolling), every plane is fetched from HBM once per column
+// (+ the 1-node halo ring), and the loads of plane k+2 are in flight while plane k is being evaluated.
+template <int TX, int TY>
+__global__ void __launch_bounds__(TX * TY) k_nodal_residual_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ ot, const FabD* __restrict__ xt,
+    const FabD* __restrict__ st, const FabD* __restrict__ rt, NodeW w, int ntx, int nty, int kc)
+{
+    constexpr int RX = TX + 2, RY = TY + 2, NT = TX * TY, NLD = (RX * RY + NT - 1) / NT;
+    __shared__ double X[3][RY][RX];
+    __shared__ double S[2][RY][RX];
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    const int bid = blockIdx.x;
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, ck = r1 / nty;
+    const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;
+    const int tx0 = cb.lo[0] + tix * TX, ty0 = cb.lo[1] + tiy * TY, k0 = cb.lo[2] + ck * kc;
+    if (tx0 > nhi0 || ty0 > nhi1 || k0 > nhi2) return;
+    const int k1 = min(k0 + kc - 1, nhi2);
+    const FabD x = xt[fab], s = st[fab], o = ot[fab];
+    const int ox = tx0 - 1, oy = ty0 - 1;
+    const int tid = threadIdx.x;
+    // footprint addressing (clamped into the arrays; clamped entries are never used by a valid node)
+    long xoff[NLD], soff[NLD];
+    int lidx[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = min(tid + it * NT, RX * RY - 1);
+        lidx[it] = idx;
+        const int gi = ox + idx % RX, gj = oy + idx / RX;
+        const int xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1), xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
+        const int si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1), sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
+        xoff[it] = x.off(xi, xj, x.lo[2]);
+        soff[it] = s.off(si, sj, s.lo[2]);
+    }
+    const long xpl = (long)x.n[0] * x.n[1], spl = (long)s.n[0] * s.n[1];
+    const FabD::gdouble* xp = (const FabD::gdouble*)x.p;
+    const FabD::gdouble* sp = (const FabD::gdouble*)s.p;
+    auto ldx = [&](int it, int k) { return xp[xoff[it] + xpl * (k - x.lo[2])]; };
+    auto lds_ = [&](int it, int k) { return sp[soff[it] + spl * (k - s.lo[2])]; };
+    // prologue: planes k0-1, k0 of x and cell plane k0-1 of sigma
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int ly = lidx[it] / RX, lx = lidx[it] % RX;
+        X[(k0 + 2) % 3][ly][lx] = ldx(it, k0 - 1);
+        X[k0 % 3][ly][lx] = ldx(it, k0);
+        S[(k0 + 1) & 1][ly][lx] = lds_(it, k0 - 1);
+    }
+    double vx[NLD], vs[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) { vx[it] = ldx(it, k0 + 1); vs[it] = lds_(it, k0); }
+    const int lx = tid % TX + 1, ly = tid / TX + 1;
+    const int i = ox + lx, j = oy + ly;
+    const bool valid = i <= nhi0 && j <= nhi1;
+    for (int k = k0; k <= k1; ++k) {
+        const int a0 = (k + 2) % 3, a1 = k % 3, a2 = (k + 1) % 3, b0 = (k + 1) & 1, b1 = k & 1;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int qy = lidx[it] / RX, qx = lidx[it] % RX;
+            X[a2][qy][qx] = vx[it];
+            S[b1][qy][qx] = vs[it];
+        }
+        __syncthreads();
+        if (k < k1) {
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) { vx[it] = ldx(it, k + 2); vs[it] = lds_(it, k + 1); }
+        }
+        if (valid) {
+            const double smmm = S[b0][ly - 1][lx - 1], spmm = S[b0][ly - 1][lx], smpm = S[b0][ly][lx - 1], sppm = S[b0][ly][lx];
+            const double smmp = S[b1][ly - 1][lx - 1], spmp = S[b1][ly - 1][lx], smpp = S[b1][ly][lx - 1], sppp = S[b1][ly][lx];
+            const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+            double y = X[a1][ly][lx] * s0;
+            y += w.corner * (X[a0][ly - 1][lx - 1] * smmm + X[a0][ly - 1][lx + 1] * spmm + X[a0][ly + 1][lx - 1] * smpm + X[a0][ly + 1][lx + 1] * sppm
+                           + X[a2][ly - 1][lx - 1] * smmp + X[a2][ly - 1][lx + 1] * spmp + X[a2][ly + 1][lx - 1] * smpp + X[a2][ly + 1][lx + 1] * sppp);
+            y += w.ex * (X[a0][ly - 1][lx] * (smmm + spmm) + X[a0][ly + 1][lx] * (smpm + sppm) + X[a2][ly - 1][lx] * (smmp + spmp) + X[a2][ly + 1][lx] * (smpp + sppp));
+            y += w.ey * (X[a0][ly][lx - 1] * (smmm + smpm) + X[a0][ly][lx + 1] * (spmm + sppm) + X[a2][ly][lx - 1] * (smmp + smpp) + X[a2][ly][lx + 1] * (spmp + sppp));
+            y += w.ez * (X[a1][ly - 1][lx - 1] * (smmm + smmp) + X[a1][ly - 1][lx + 1] * (spmm + spmp) + X[a1][ly + 1][lx - 1] * (smpm + smpp) + X[a1][ly + 1][lx + 1] * (sppm + sppp));
+            y += w.fx * (X[a1][ly][lx - 1] * (smmm + smpm + smmp + smpp) + X[a1][ly][lx + 1] * (spmm + sppm + spmp + sppp));
+            y += w.fy * (X[a1][ly - 1][lx] * (smmm + spmm + smmp + spmp) + X[a1][ly + 1][lx] * (smpm + sppm + smpp + sppp));
+            y += w.fz * (X[a0][ly][lx] * (smmm + spmm + smpm + sppm) + X[a2][ly][lx] * (smmp + spmp + smpp + sppp));
+            o(i, j, k) = rt ? rt[fab](i, j, k) - y : y;
+        }
+        __syncthreads();
+    }
+}
+
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs)
 {
     if (x.nlocal() == 0) return;
     const NodeW w = make_w(g);
     const FabD *ot = out.d_tab, *xt = x.d_tab, *st = sig.d_tab;
     const FabD* rt = rhs ? rhs->d_tab : nullptr;
+    const Layout& l = *x.layout;
+    static const bool zmarch = !(getenv("IAMRX_NODAL_RES_ZM") && atoi(getenv("IAMRX_NODAL_RES_ZM")) == 0);
+    if (zmarch && l.max_len[0] >= 16 && l.max_len[1] >= 8 && x.ngrow >= 1 && sig.ngrow >= 1) {
+        constexpr int TX = 32, TY = 8;
+        const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY;
+        const int nk = l.max_len[2] + 1;
+        const int kc = nk >= 128 ? 32 : (nk >= 32 ? 16 : nk);
+        const int nck = (nk + kc - 1) / kc;
+        dim3 grid((unsigned)(ntx * nty * nck), (unsigned)l.nlocal());
+        hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc);
+        return;
+    }
     for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         double s0;
         const double y = node_Ax(xt[f], st[f], w, i, j, k, s0);
@@ -114,7 +210,7 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // HBM traffic per sweep drops from 8 full-array passes to 2; kernel launches from 8+8 fills to 2+2.
 template <int TX, int TY>
 __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
-    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty)
+    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk)
 {
     // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
     // column, so its 64 lanes then read consecutive doubles (no bank conflicts) instead of a stride-2 pattern.
@@ -124,10 +220,23 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
     __shared__ double R[RY][PX];
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
-    const int bid = blockIdx.x;
-    const int tix = bid % ntx;
-    const int r1 = bid / ntx;
-    const int tiy = r1 % nty, pk = r1 / nty;
+    int tix, tiy, pk;
+    if (xcd_chunk > 0) {
+        // XCD-aware order (workgroup b runs on XCD b % 8, speed only): every XCD sweeps its own contiguous slab of tiles plane
+        // by plane, so the halo overlap of neighbouring tiles and the k+-1 planes shared by consecutive planes stay in its L2
+        const int q = blockIdx.x & 7, m = blockIdx.x >> 3;
+        const int nt = ntx * nty;
+        const int tlo = (q * nt) >> 3, cnt = (((q + 1) * nt) >> 3) - tlo;
+        if (cnt == 0 || m >= cnt * xcd_chunk) return;
+        const int t = tlo + m % cnt;
+        pk = m / cnt;
+        tix = t % ntx; tiy = t / ntx;
+    } else {
+        const int bid = blockIdx.x;
+        tix = bid % ntx;
+        const int r1 = bid / ntx;
+        tiy = r1 % nty; pk = r1 / nty;
+    }
     const int kfirst = cb.lo[2] + (((cb.lo[2] & 1) != kpar) ? 1 : 0);
     const int k = kfirst + 2 * pk;
     const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;   // last valid node
@@ -216,9 +325,18 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     constexpr int TX = 32, TY = 16;
     const Layout& l = *x.layout;
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
-    dim3 grid((unsigned)(ntx * nty * npl), (unsigned)l.nlocal());
+    const int nt = ntx * nty;
+    static const bool xcd_aware = !(getenv("IAMRX_XCD_AWARE") && atoi(getenv("IAMRX_XCD_AWARE")) == 0);
+    int xcd_chunk = 0;
+    unsigned gx = (unsigned)(nt * npl);
+    if (xcd_aware && nt >= 16) {
+        xcd_chunk = npl;                                   // planes per tile
+        const int maxcnt = (nt + 7) / 8;                   // tiles of the largest slab
+        gx = 8u * (unsigned)(maxcnt * npl);
+    }
+    dim3 grid(gx, (unsigned)l.nlocal());
     hipLaunchKernelGGL((k_nodal_gs4<TX, TY>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab, sig.d_tab,
-                       make_w(g), kpar, ntx, nty);
+                       make_w(g), kpar, ntx, nty, xcd_chunk);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -355,30 +473,36 @@ __device__ __forceinline__ double interp_face(const FabD& c, const FabD& s, int 
     return r / (w1 + w2 + w3 + w4);
 }
 
+// one thread per COARSE node: it produces the (up to) 8 fine nodes 2*(ic,jc,kc) + {0,1}^3, so that every lane of a wavefront
+// walks the same sequence of node classes (coincident, 3 edge, 3 face, 1 centre class) instead of diverging 8 ways
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine)
 {
     if (fine.nlocal() == 0) return;
     const FabD *ft = fine.d_tab, *ct = crse.d_tab, *st = sig_fine.d_tab;
-    for_each(*fine.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD c = ct[f], s = st[f];
-        const int ic = i >> 1, jc = j >> 1, kc = k >> 1;
-        const int io = i & 1, jo = j & 1, ko = k & 1;
-        double v;
-        if (io && jo && ko) {
+    const BoxD* fb = fine.layout->d_boxes;
+    for_each(*crse.layout, node_type(), 0, Context::get().stream, [=] __device__(int ic, int jc, int kc, int f) {
+        const FabD c = ct[f], s = st[f], fa = ft[f];
+        const BoxD vb = fb[f];
+        const int nhi0 = vb.hi[0] + 1, nhi1 = vb.hi[1] + 1, nhi2 = vb.hi[2] + 1;
+        const int i0 = 2 * ic, j0 = 2 * jc, k0 = 2 * kc;
+        const bool xi = i0 + 1 <= nhi0, xj = j0 + 1 <= nhi1, xk = k0 + 1 <= nhi2;
+        fa(i0, j0, k0) += c(ic, jc, kc);
+        if (xi) fa(i0 + 1, j0, k0) += interp_line(c, s, i0 + 1, j0, k0, ic, jc, kc, 0);
+        if (xj) fa(i0, j0 + 1, k0) += interp_line(c, s, i0, j0 + 1, k0, ic, jc, kc, 1);
+        if (xk) fa(i0, j0, k0 + 1) += interp_line(c, s, i0, j0, k0 + 1, ic, jc, kc, 2);
+        if (xi && xj) fa(i0 + 1, j0 + 1, k0) += interp_face(c, s, i0 + 1, j0 + 1, k0, ic, jc, kc, 0, 1);
+        if (xi && xk) fa(i0 + 1, j0, k0 + 1) += interp_face(c, s, i0 + 1, j0, k0 + 1, ic, jc, kc, 0, 2);
+        if (xj && xk) fa(i0, j0 + 1, k0 + 1) += interp_face(c, s, i0, j0 + 1, k0 + 1, ic, jc, kc, 1, 2);
+        if (xi && xj && xk) {
+            const int i = i0 + 1, j = j0 + 1, k = k0 + 1;
             double w[6];
             for (int d = 0; d < 3; ++d) { w[2 * d] = w_side(s, i, j, k, d, 0); w[2 * d + 1] = w_side(s, i, j, k, d, 1); }
-            v = (w[0] * interp_face(c, s, i - 1, j, k, ic, jc, kc, 1, 2) + w[1] * interp_face(c, s, i + 1, j, k, ic + 1, jc, kc, 1, 2)
+            const double v = (w[0] * interp_face(c, s, i - 1, j, k, ic, jc, kc, 1, 2) + w[1] * interp_face(c, s, i + 1, j, k, ic + 1, jc, kc, 1, 2)
                + w[2] * interp_face(c, s, i, j - 1, k, ic, jc, kc, 0, 2) + w[3] * interp_face(c, s, i, j + 1, k, ic, jc + 1, kc, 0, 2)
                + w[4] * interp_face(c, s, i, j, k - 1, ic, jc, kc, 0, 1) + w[5] * interp_face(c, s, i, j, k + 1, ic, jc, kc + 1, 0, 1))
               / (w[0] + w[1] + w[2] + w[3] + w[4] + w[5]);
-        } else if (jo && ko) v = interp_face(c, s, i, j, k, ic, jc, kc, 1, 2);
-        else if (io && ko) v = interp_face(c, s, i, j, k, ic, jc, kc, 0, 2);
-        else if (io && jo) v = interp_face(c, s, i, j, k, ic, jc, kc, 0, 1);
-        else if (io) v = interp_line(c, s, i, j, k, ic, jc, kc, 0);
-        else if (jo) v = interp_line(c, s, i, j, k, ic, jc, kc, 1);
-        else if (ko) v = interp_line(c, s, i, j, k, ic, jc, kc, 2);
-        else v = c(ic, jc, kc);
-        ft[f](i, j, k) += v;
+            fa(i, j, k) += v;
+        }
     });
 }
 
