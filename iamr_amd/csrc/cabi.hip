@@ -226,6 +226,30 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, 
     IAMRX_CATCH
 }
 
+// one red+black sweep incl. the BC / ghost fills in front of each colour (fused = 1: the single-pass out-of-place kernel + the
+// black pass over the box surfaces); homogeneous BC as inside a V-cycle
+int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                          iamrx_mf phi, iamrx_mf rhs, double omega, const int lobc[3], const int hibc[3], int maxorder, int fused)
+{
+    IAMRX_TRY
+    Geometry gg = to_geom(g);
+    DomainBC b = to_bc(lobc, hibc, maxorder);
+    AbecCoef c = make_coef(alpha, beta, a, bx, by, bz, 0);
+    MultiFab& p = phi->mf;
+    auto fill = [&](MultiFab& m) { m.FillBoundary(gg); abec_apply_domain_bc(gg, m, b, false, nullptr); };
+    if (fused) {
+        MultiFab buf(p.layout, cell_type(), p.ncomp, 1);
+        fill(p);
+        abec_gsrb_fused(gg, c, p, buf, rhs->mf, omega, &b, 1);
+        fill(buf);
+        abec_gsrb(gg, c, buf, rhs->mf, 1, omega, &b, 1, true);
+        MultiFab::Copy(p, buf, 0, 0, p.ncomp, 0);
+    } else {
+        for (int rb = 0; rb < 2; ++rb) { fill(p); abec_gsrb(gg, c, p, rhs->mf, rb, omega, &b, 1); }
+    }
+    IAMRX_CATCH
+}
+
 int iamrx_abec_residual(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
                         iamrx_mf out, iamrx_mf phi, iamrx_mf rhs, int tensor)
 {

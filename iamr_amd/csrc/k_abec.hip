@@ -67,7 +67,7 @@ static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc)
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
         for (int k = k0; k <= k1; ++k) {
             const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
             if (i > b.hi[0]) continue;
+            if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
             const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
             const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
             const double bxm = bX(i, j, k, nb), bxp = bX(i + 1, j, k, nb);
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     }
 }
 
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc)
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only)
 {
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
@@ -114,7 +115,171 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
     hipLaunchKernelGGL(k_abec_gsrb, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb);
+                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------- fused red+black sweep
+// One pass over the level does the red update of every cell and the black update of every cell that is not on the
+// surface of its box; the black cells of that one-cell shell need ghost values that depend on the red update of other
+// boxes / the domain BC and are done afterwards by k_abec_gsrb(shell_only) once the ghosts are refreshed.  A workgroup
+// owns a TXxTY column and marches in z: phi planes live in a rolling LDS window (k-1..k+2), the red update of plane k+1
+// runs one plane ahead of the black update of plane k, and the red values of the one-cell ring around the column are
+// recomputed instead of exchanged.  Out of place (pin -> pout): other workgroups read pin in their rings.
+// Arithmetic per cell is that of k_abec_gsrb, so the result equals applyBC+red, applyBC+black bit for bit.
+template <int TX, int TY>
+__global__ void __launch_bounds__(256) k_abec_gsrb_fused(const BoxD* __restrict__ boxes, const FabD* __restrict__ pint, const FabD* __restrict__ poutt,
+    const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
+    double alpha, double dhx, double dhy, double dhz, double omega, int ncomp, int bnc, GsrbBC bc, int ntx, int nty, int kc)
+{
+    static_assert(TX * TY == 512, "one red and one black cell per thread and plane");
+    constexpr int FX = TX + 4, FY = TY + 4, NLD = (FX * FY + 255) / 256;
+    constexpr int NRING = (TX + 2) + (TX + 2) + TY + TY;          // cells of the one-cell ring around the column
+    __shared__ double P[4][FY][FX];
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    const int bid = blockIdx.x;
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, ck = r1 / nty;
+    const int tx0 = b.lo[0] + tix * TX, ty0 = b.lo[1] + tiy * TY, k0 = b.lo[2] + ck * kc;
+    if (tx0 > b.hi[0] || ty0 > b.hi[1] || k0 > b.hi[2]) return;
+    const int txe = min(tx0 + TX - 1, b.hi[0]), tye = min(ty0 + TY - 1, b.hi[1]), k1 = min(k0 + kc - 1, b.hi[2]);
+    const FabD pin = pint[fab], pout = poutt[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
+    const bool has_a = (at != nullptr) && alpha != 0.0;
+    FabD A; if (has_a) A = at[fab];
+    const int ox = tx0 - 2, oy = ty0 - 2;
+    const int tid = threadIdx.x;
+    long poff[NLD];
+    int lrow[NLD], lcol[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = min(tid + it * 256, FX * FY - 1);
+        lcol[it] = idx % FX; lrow[it] = idx / FX;
+        const int gi = min(max(ox + lcol[it], pin.lo[0]), pin.lo[0] + pin.n[0] - 1), gj = min(max(oy + lrow[it], pin.lo[1]), pin.lo[1] + pin.n[1] - 1);
+        poff[it] = pin.off(gi, gj, pin.lo[2]);
+    }
+    const long ppl = (long)pin.n[0] * pin.n[1];
+    const int pklo = pin.lo[2], pkhi = pin.lo[2] + pin.n[2] - 1;
+    // this thread's pair of cells (x = px, px+1 in row py) and its ring cell (threads < NRING)
+    const int px = tx0 + 2 * (tid % (TX / 2)), py = ty0 + tid / (TX / 2);
+    int rgx, rgy;
+    {
+        const int q = tid;
+        if (q < TX + 2) { rgx = tx0 - 1 + q; rgy = ty0 - 1; }
+        else if (q < 2 * (TX + 2)) { rgx = tx0 - 1 + (q - (TX + 2)); rgy = ty0 + TY; }
+        else if (q < 2 * (TX + 2) + TY) { rgx = tx0 - 1; rgy = ty0 + (q - 2 * (TX + 2)); }
+        else { rgx = tx0 + TX; rgy = ty0 + (q - 2 * (TX + 2) - TY); }
+    }
+    // the ring of a clipped column (box narrower than the tile) hugs the clipped column
+    const bool ring_thread = tid < NRING;
+    struct Cf { double bxm, bxp, bym, byp, bzm, bzp, aa, r; };
+    for (int n = 0; n < ncomp; ++n) {
+        const int nb = bnc == 1 ? 0 : n;
+        const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
+        const FabD::gdouble* pp = (const FabD::gdouble*)pin.p + pin.cs * n;
+        auto fetch_plane = [&](int m, double (&v)[NLD]) {
+            const int mc = min(max(m, pklo), pkhi);
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) v[it] = pp[poff[it] + ppl * (mc - pklo)];
+        };
+        auto store_plane = [&](int m, const double (&v)[NLD]) {
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) if (tid + it * 256 < FX * FY) P[m & 3][lrow[it]][lcol[it]] = v[it];
+        };
+        // coefficients of cell (i,j,m); indices clamped into the box so that the loads are unconditional
+        auto fetch_cf = [&](int i, int j, int m) {
+            const int ic = min(max(i, b.lo[0]), b.hi[0]), jc = min(max(j, b.lo[1]), b.hi[1]), mc = min(max(m, b.lo[2]), b.hi[2]);
+            Cf c;
+            c.bxm = bX(ic, jc, mc, nb); c.bxp = bX(ic + 1, jc, mc, nb);
+            c.bym = bY(ic, jc, mc, nb); c.byp = bY(ic, jc + 1, mc, nb);
+            c.bzm = bZ(ic, jc, mc, nb); c.bzp = bZ(ic, jc, mc + 1, nb);
+            c.aa = has_a ? A(ic, jc, mc, 0) : 0.0;
+            c.r = rhs(ic, jc, mc, n);
+            return c;
+        };
+        auto update = [&](int i, int j, int m, const Cf& c) {
+            const int lx = i - ox, ly = j - oy;
+            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
+            const double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
+            const double cf2 = (m == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (m == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            const double aa = has_a ? alpha * c.aa : 0.0;
+            const double gamma = aa + dhx * (c.bxm + c.bxp) + dhy * (c.bym + c.byp) + dhz * (c.bzm + c.bzp);
+            const double g_m_d = gamma - (dhx * (c.bxm * cf0 + c.bxp * cf3) + dhy * (c.bym * cf1 + c.byp * cf4) + dhz * (c.bzm * cf2 + c.bzp * cf5));
+            const double (*Pc)[FX] = P[m & 3];
+            const double rho = dhx * (c.bxm * Pc[ly][lx - 1] + c.bxp * Pc[ly][lx + 1])
+                             + dhy * (c.bym * Pc[ly - 1][lx] + c.byp * Pc[ly + 1][lx])
+                             + dhz * (c.bzm * P[(m - 1) & 3][ly][lx] + c.bzp * P[(m + 1) & 3][ly][lx]);
+            const double p0 = Pc[ly][lx];
+            const double res = c.r - (gamma * p0 - rho);
+            return p0 + omega / g_m_d * res;
+        };
+        auto in_box = [&](int i, int j, int m) { return i >= b.lo[0] && i <= b.hi[0] && j >= b.lo[1] && j <= b.hi[1] && m >= b.lo[2] && m <= b.hi[2]; };
+        // red update of plane m: the thread's own red cell and, for ring threads, a red ring cell
+        auto red_x = [&](int m) { return px + ((px + py + m) & 1); };
+        auto red_plane = [&](int m, const Cf& own, const Cf& rg) {
+            if (m < b.lo[2] || m > b.hi[2]) return;
+            const int i = red_x(m);
+            if (i <= txe && py <= tye) P[m & 3][py - oy][i - ox] = update(i, py, m, own);
+            if (ring_thread && ((rgx + rgy + m) & 1) == 0 && in_box(rgx, rgy, m) && rgx <= txe + 1 && rgy <= tye + 1)
+                P[m & 3][rgy - oy][rgx - ox] = update(rgx, rgy, m, rg);
+        };
+        double pv[NLD];
+        fetch_plane(k0 - 2, pv); store_plane(k0 - 2, pv);
+        fetch_plane(k0 - 1, pv); store_plane(k0 - 1, pv);
+        fetch_plane(k0, pv); store_plane(k0, pv);
+        fetch_plane(k0 + 1, pv); store_plane(k0 + 1, pv);
+        {
+            const Cf o1 = fetch_cf(red_x(k0 - 1), py, k0 - 1), g1 = fetch_cf(rgx, rgy, k0 - 1);
+            const Cf o2 = fetch_cf(red_x(k0), py, k0), g2 = fetch_cf(rgx, rgy, k0);
+            __syncthreads();
+            red_plane(k0 - 1, o1, g1);
+            __syncthreads();
+            red_plane(k0, o2, g2);
+        }
+        __syncthreads();
+        for (int k = k0; k <= k1; ++k) {
+            // everything this step needs from memory is requested up front
+            fetch_plane(k + 2, pv);
+            const int ir = red_x(k + 1);                  // red cell of plane k+1
+            const int ib = px + 1 - ((px + py + k) & 1);  // black cell of plane k
+            const Cf cr = fetch_cf(ir, py, k + 1), cg = fetch_cf(rgx, rgy, k + 1), cb = fetch_cf(ib, py, k);
+            store_plane(k + 2, pv);                       // slot of plane k-2, no longer needed
+            __syncthreads();
+            red_plane(k + 1, cr, cg);
+            __syncthreads();
+            // output plane k: the red cell is final; the black cell gets its update unless it lies on the box surface
+            if (py <= tye) {
+                const int irk = red_x(k);
+                if (irk <= txe) pout(irk, py, k, n) = P[k & 3][py - oy][irk - ox];
+                if (ib <= txe) {
+                    const bool inner = ib > b.lo[0] && ib < b.hi[0] && py > b.lo[1] && py < b.hi[1] && k > b.lo[2] && k < b.hi[2];
+                    pout(ib, py, k, n) = inner ? update(ib, py, k, cb) : P[k & 3][py - oy][ib - ox];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one full red+black sweep, phi_in (ghost cells filled by the caller) -> phi_out (valid cells; the black cells on box surfaces still
+// hold their old value: refresh the ghost cells of phi_out, then call abec_gsrb(..., redblack = 1, shell_only = true))
+void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,
+                     const DomainBC* bcs, int nbc)
+{
+    if (phi_in.nlocal() == 0) return;
+    IAMRX_ASSERT(phi_in.d_tab != phi_out.d_tab && phi_in.ngrow >= 1);
+    auto& ctx = Context::get();
+    const Layout& l = *phi_in.layout;
+    constexpr int TX = 64, TY = 8;
+    const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+    const int nk = l.max_len[2];
+    int kc = nk;
+    while (kc > 16 && (long)ntx * nty * ((nk + kc - 1) / kc) * l.nlocal() < 1536) kc = (kc + 1) / 2;
+    const int nck = (nk + kc - 1) / kc;
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
+    dim3 grid((unsigned)(ntx * nty * nck), (unsigned)l.nlocal());
+    hipLaunchKernelGGL((k_abec_gsrb_fused<TX, TY>), grid, dim3(256), 0, ctx.stream, l.d_boxes, phi_in.d_tab, phi_out.d_tab, rhs.d_tab,
+                       c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                       c.alpha, dhx, dhy, dhz, omega, phi_in.ncomp, c.b[0]->ncomp, gb, ntx, nty, kc);
 }
 
 // ---------------------------------------------------------------------------- residual / apply

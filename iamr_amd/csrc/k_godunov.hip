@@ -536,6 +536,15 @@ static const GodParams* upload_params(const GodParams& P)
     return d;
 }
 
+// planes marched per thread.  Kernels whose stencil extends in z re-read the planes shared with the z-neighbouring tiles;
+// those tiles are far apart in launch order, so the re-reads miss L2: march more planes per thread there.
+static int tz_for(bool z_stencil)
+{
+    static int tzz = -1;
+    if (tzz < 0) { const char* e = getenv("IAMRX_GODUNOV_TZ"); tzz = e ? atoi(e) : 4; }
+    return z_stencil ? tzz : 4;
+}
+
 static Tiling face_tiling(const Layout& l, int D, int gt, int tz)
 {
     int ml[3];
@@ -546,7 +555,7 @@ static Tiling face_tiling(const Layout& l, int D, int gt, int tz)
 template <bool PRED, int D>
 static void launch_trace(const Layout& l, const MultiFab& q, const MultiFab* force, const MultiFab& mac, const MultiFab& e0, const GodParams* dP)
 {
-    Tiling t = face_tiling(l, D, 1, 4);
+    Tiling t = face_tiling(l, D, 1, tz_for(D == 2));
     hipLaunchKernelGGL((k_trace<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, mac.d_tab, e0.d_tab, dP);
 }
@@ -564,7 +573,7 @@ static void launch_corner(const Layout& l, const MultiFab& q, const MultiFab* fo
 {
     int ml[3];
     for (int e = 0; e < 3; ++e) ml[e] = l.max_len[e] + (e == T ? 1 : 0) + (e == D ? 2 : 0);
-    Tiling t = make_tiling(ml, l.nlocal(), 4);
+    Tiling t = make_tiling(ml, l.nlocal(), tz_for(T == 2 || D == 2));
     hipLaunchKernelGGL((k_corner<PRED, D, T>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mT.d_tab, mO.d_tab, eO.d_tab, out.d_tab, dP);
 }
@@ -579,7 +588,7 @@ static void launch_final_split(const Layout& l, const MultiFab& q, int ncomp, co
     MultiFab cA(q.layout, face_type(TA), nc, 1), cB(q.layout, face_type(TB), nc, 1);
     launch_corner<PRED, D, TA>(l, q, force, divu, *mac[TA], *mac[TB], e0[TB], cA, dP);
     launch_corner<PRED, D, TB>(l, q, force, divu, *mac[TB], *mac[TA], e0[TA], cB, dP);
-    Tiling t = face_tiling(l, D, 0, 4);
+    Tiling t = face_tiling(l, D, 0, tz_for(true));
     hipLaunchKernelGGL((k_final_s<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab,
                        cA.d_tab, cB.d_tab, out.d_tab, dP);
@@ -655,6 +664,315 @@ __global__ void __launch_bounds__(256) k_aofs(Tiling t, const BoxD* __restrict__
     }
 }
 
+// -------------------------------------------------------------------------------- single-pass tile kernel (advection)
+// One workgroup = one TXxTYxTZ tile of cells and one component at a time.  The state tile (3 ghost cells) is staged in
+// LDS, the pass-1 transverse states E[d], the corner-coupled states C (two arrays per final direction) and the final edge
+// states G[d] of the tile never leave LDS, and aofs is written straight from them: per cell and component HBM sees the
+// state, the forcing, the mac velocities and aofs -- the algorithmic traffic of SURVEY 8d -- instead of 6+3 intermediate
+// face arrays.  Faces on tile boundaries (and the one-cell rings the corner coupling needs) are recomputed by both tiles
+// with identical arithmetic, so the result is bit-identical to the multi-pass kernels above.
+struct LBox {
+    int lo0, lo1, lo2, n0, n1, n2;
+    __device__ __forceinline__ int off(int i, int j, int k) const { return (i - lo0) + n0 * ((j - lo1) + n1 * (k - lo2)); }
+    __device__ __forceinline__ int size() const { return n0 * n1 * n2; }
+    template <int D> __device__ __forceinline__ int stride() const { return D == 0 ? 1 : (D == 1 ? n0 : n0 * n1); }
+    __device__ __forceinline__ void ijk(int idx, int& i, int& j, int& k) const
+    {
+        i = lo0 + idx % n0; const int r = idx / n0; j = lo1 + r % n1; k = lo2 + r / n1;
+    }
+};
+__device__ __forceinline__ LBox make_lbox(const int lo[3], const int hi[3])
+{
+    LBox b; b.lo0 = lo[0]; b.lo1 = lo[1]; b.lo2 = lo[2]; b.n0 = hi[0] - lo[0] + 1; b.n1 = hi[1] - lo[1] + 1; b.n2 = hi[2] - lo[2] + 1; return b;
+}
+
+struct TileCtx {
+    const GodParams* P;
+    FabD q, frc, dv, mac[3];
+    bool has_force, has_divu, fit, is_vel;
+    int tlo[3], thi[3];
+    LBox qb, eb[3], gb[3], mb[3], fb;
+    double *Qs, *Es[3], *Gs[3], *Ca, *Cb, *Ms[3], *Fs;
+};
+
+// pass 1 on the tile: E[D] on the D-faces [tlo_D, thi_D+1] x (transverse cells grown by 1)
+template <int D>
+__device__ __forceinline__ void tile_stage1(const TileCtx& c, int n)
+{
+    const GodParams& P = *c.P;
+    const LBox eb = c.eb[D];
+    const int s = c.qb.template stride<D>();
+    const double hdt = 0.5 * P.dt, dtdx = P.dt / P.dx[D];
+    const int domlo = P.bc.dlo[D], domhi = P.bc.dhi[D];
+    const bool nonper = !P.bc.per[D];
+    const int bl = P.bc.bc[n].lo[D], bh = P.bc.bc[n].hi[D];
+    const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
+    const int fs = c.fb.template stride<D>();
+    for (int idx = threadIdx.x; idx < eb.size(); idx += blockDim.x) {
+        int i, j, k; eb.ijk(idx, i, j, k);
+        const int f = D == 0 ? i : (D == 1 ? j : k);
+        const double uad = c.Ms[D][c.mb[D].off(i, j, k)];
+        const double fu = (fabs(uad) < SMALL_VEL) ? 0.0 : 1.0;
+        const double* qn = c.Qs + c.qb.off(i, j, k);
+        double l, h;
+        trace_lohi<false>(qn, nullptr, s, uad, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+        if (c.fit && c.has_force) { const int fo = c.fb.off(i, j, k); l += hdt * c.Fs[fo - fs]; h += hdt * c.Fs[fo]; }
+        if (nonper) trans_bc(qn, s, f, c.is_vel && n == D, l, h, bl, bh, domlo, domhi);
+        const double st = (uad >= 0.) ? l : h;
+        c.Es[D][idx] = fu * st + (1.0 - fu) * 0.5 * (h + l);
+    }
+}
+
+// pass 2a on the tile: corner-coupled states on the T-faces [tlo_T, thi_T+1], D cells grown by 1, O cells of the tile
+template <int D, int T>
+__device__ __forceinline__ void tile_corner(const TileCtx& c, int n, double* out, const LBox& cb)
+{
+    constexpr int O = 3 - D - T;
+    const GodParams& P = *c.P;
+    const bool conserv = P.iconserv[n] != 0;
+    const double c_o = conserv ? P.dt / (3.0 * P.dx[O]) : P.dt / (6.0 * P.dx[O]);
+    const double dt3 = P.dt / 3.0, dtdxT = P.dt / P.dx[T], hdt = 0.5 * P.dt;
+    const bool nonperT = !P.bc.per[T];
+    const int dlo = P.bc.dlo[T], dhi = P.bc.dhi[T];
+    const int qsT = c.qb.template stride<T>();
+    const LBox eo = c.eb[O];
+    const int eOsT = eo.template stride<T>(), eOsO = eo.template stride<O>();
+    const LBox mo = c.mb[O];
+    const int mOsT = mo.template stride<T>(), mOsO = mo.template stride<O>();
+    const int fsT = c.fb.template stride<T>();
+    const long dsT = c.has_divu ? stride_of<T>(c.dv) : 0;
+    for (int idx = threadIdx.x; idx < cb.size(); idx += blockDim.x) {
+        int i, j, k; cb.ijk(idx, i, j, k);
+        const int fT = T == 0 ? i : (T == 1 ? j : k);
+        const double macT = c.Ms[T][c.mb[T].off(i, j, k)];
+        out[idx] = corner_state<false>(c.Qs + c.qb.off(i, j, k), nullptr, qsT, fT, macT, c.Ms[O] + mo.off(i, j, k), mOsT, mOsO,
+            c.Es[O] + eo.off(i, j, k), eOsT, eOsO, c.has_force ? c.Fs + c.fb.off(i, j, k) : nullptr, fsT, dtdxT, c_o, dt3,
+            P.dx[O], conserv, c.has_divu ? c.dv.p + c.dv.off(i, j, k) : nullptr, dsT, c.fit, hdt, nonperT, c.is_vel && n == T,
+            P.bc.bc[n].lo[T], P.bc.bc[n].hi[T], dlo, dhi);
+    }
+}
+
+// pass 2b on the tile: final edge states on the D-faces [tlo_D, thi_D+1] of the tile's cells -> G[D]
+template <int D>
+__device__ __forceinline__ void tile_final(const TileCtx& c, int n, const LBox& ab, const LBox& bb)
+{
+    constexpr int TA = D == 0 ? 1 : 0;
+    constexpr int TB = D == 2 ? 1 : 2;
+    const GodParams& P = *c.P;
+    const LBox gb = c.gb[D];
+    const int qsD = c.qb.template stride<D>();
+    const int fsD = c.fb.template stride<D>();
+    const long dsD = c.has_divu ? stride_of<D>(c.dv) : 0;
+    const LBox ma = c.mb[TA], mbx = c.mb[TB];
+    const double* mAp = c.Ms[TA]; const double* mBp = c.Ms[TB];
+    const int mAsD = ma.template stride<D>(), mAsT = ma.template stride<TA>(), mBsD = mbx.template stride<D>(), mBsT = mbx.template stride<TB>();
+    const int cAsD = ab.template stride<D>(), cAsT = ab.template stride<TA>(), cBsD = bb.template stride<D>(), cBsT = bb.template stride<TB>();
+    const double dt = P.dt, hdt = 0.5 * P.dt, dtdxD = dt / P.dx[D];
+    const bool nonperD = !P.bc.per[D];
+    const int dloD = P.bc.dlo[D], dhiD = P.bc.dhi[D];
+    const bool conserv = P.iconserv[n] != 0;
+    const int blD = P.bc.bc[n].lo[D], bhD = P.bc.bc[n].hi[D];
+    const bool edlo = nonperD && ed_or_ho(blD), edhi = nonperD && ed_or_ho(bhD);
+    for (int idx = threadIdx.x; idx < gb.size(); idx += blockDim.x) {
+        int i, j, k; gb.ijk(idx, i, j, k);
+        const int f = D == 0 ? i : (D == 1 ? j : k);
+        const double* qn = c.Qs + c.qb.off(i, j, k);
+        const int fo = c.fb.off(i, j, k);
+        const long dvo = c.has_divu ? c.dv.off(i, j, k) : 0;
+        const int mAo = ma.off(i, j, k), mBo = mbx.off(i, j, k);
+        const double umD = c.Ms[D][c.mb[D].off(i, j, k)];
+        const double mA_l0 = mAp[mAo - mAsD], mA_l1 = mAp[mAo - mAsD + mAsT], mA_h0 = mAp[mAo], mA_h1 = mAp[mAo + mAsT];
+        const double mB_l0 = mBp[mBo - mBsD], mB_l1 = mBp[mBo - mBsD + mBsT], mB_h0 = mBp[mBo], mB_h1 = mBp[mBo + mBsT];
+        double stl, sth;
+        trace_lohi<false>(qn, nullptr, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
+        if (c.fit && c.has_force) { stl += hdt * c.Fs[fo - fsD]; sth += hdt * c.Fs[fo]; }
+        if (nonperD) trans_bc(qn, qsD, f, c.is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
+        const int cAo = ab.off(i, j, k), cBo = bb.off(i, j, k);
+        const double Al0 = c.Ca[cAo - cAsD], Al1 = c.Ca[cAo - cAsD + cAsT], Ah0 = c.Ca[cAo], Ah1 = c.Ca[cAo + cAsT];
+        const double Bl0 = c.Cb[cBo - cBsD], Bl1 = c.Cb[cBo - cBsD + cBsT], Bh0 = c.Cb[cBo], Bh1 = c.Cb[cBo + cBsT];
+        if (conserv) {
+            const double cfA = 0.5 * dt / P.dx[TA], cfB = 0.5 * dt / P.dx[TB];
+            stl += -cfA * (Al1 * mA_l1 - Al0 * mA_l0);
+            sth += -cfA * (Ah1 * mA_h1 - Ah0 * mA_h0);
+            stl += -cfB * (Bl1 * mB_l1 - Bl0 * mB_l0);
+            sth += -cfB * (Bh1 * mB_h1 - Bh0 * mB_h0);
+            stl += cfA * qn[-qsD] * (mA_l1 - mA_l0);
+            sth += cfA * qn[0] * (mA_h1 - mA_h0);
+            stl += cfB * qn[-qsD] * (mB_l1 - mB_l0);
+            sth += cfB * qn[0] * (mB_h1 - mB_h0);
+            if (c.has_divu) { stl -= 0.5 * dt * qn[-qsD] * c.dv.p[dvo - dsD]; sth -= 0.5 * dt * qn[0] * c.dv.p[dvo]; }
+        } else {
+            const double cfA = 0.25 * dt / P.dx[TA], cfB = 0.25 * dt / P.dx[TB];
+            stl -= cfA * (mA_l1 + mA_l0) * (Al1 - Al0);
+            sth -= cfA * (mA_h1 + mA_h0) * (Ah1 - Ah0);
+            stl -= cfB * (mB_l1 + mB_l0) * (Bl1 - Bl0);
+            sth -= cfB * (mB_h1 + mB_h0) * (Bh1 - Bh0);
+        }
+        if (!c.fit && c.has_force) { stl += hdt * c.Fs[fo - fsD]; sth += hdt * c.Fs[fo]; }
+        if (nonperD) edge_bc(qn, qsD, f, c.is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
+        double temp = (umD >= 0.) ? stl : sth;
+        temp = (fabs(umD) < SMALL_VEL) ? 0.5 * (stl + sth) : temp;
+        c.Gs[D][idx] = temp;
+    }
+}
+
+// both corner arrays + the final states of direction D
+template <int D>
+__device__ __forceinline__ void tile_direction(const TileCtx& c, int n)
+{
+    constexpr int TA = D == 0 ? 1 : 0;
+    constexpr int TB = D == 2 ? 1 : 2;
+    int lo[3], hi[3];
+    for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e]; hi[e] = c.thi[e]; }
+    lo[D] -= 1; hi[D] += 1;
+    int la[3] = {lo[0], lo[1], lo[2]}, ha[3] = {hi[0], hi[1], hi[2]};
+    ha[TA] += 1;
+    const LBox ab = make_lbox(la, ha);
+    int lb[3] = {lo[0], lo[1], lo[2]}, hb[3] = {hi[0], hi[1], hi[2]};
+    hb[TB] += 1;
+    const LBox bb = make_lbox(lb, hb);
+    tile_corner<D, TA>(c, n, c.Ca, ab);
+    tile_corner<D, TB>(c, n, c.Cb, bb);
+    __syncthreads();
+    tile_final<D>(c, n, ab, bb);
+    __syncthreads();
+}
+
+template <int TX, int TY, int TZ, int NTH>
+__global__ void __launch_bounds__(NTH) k_godunov_tile(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
+    const FabD* __restrict__ divut, const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
+    const FabD* __restrict__ aofst, int acomp, const FabD* __restrict__ e0t, const FabD* __restrict__ e1t, const FabD* __restrict__ e2t,
+    const FabD* __restrict__ f0t, const FabD* __restrict__ f1t, const FabD* __restrict__ f2t,
+    const GodParams* __restrict__ Pp, int ntx, int nty, int ntz)
+{
+    constexpr int NQ = (TX + 6) * (TY + 6) * (TZ + 6);
+    constexpr int NE0 = (TX + 1) * (TY + 2) * (TZ + 2), NE1 = (TX + 2) * (TY + 1) * (TZ + 2), NE2 = (TX + 2) * (TY + 2) * (TZ + 1);
+    constexpr int NG0 = (TX + 1) * TY * TZ, NG1 = TX * (TY + 1) * TZ, NG2 = TX * TY * (TZ + 1);
+    constexpr int c01 = (TX + 2) * (TY + 1) * TZ, c02 = (TX + 2) * TY * (TZ + 1);     // D = 0: T = 1, 2
+    constexpr int c10 = (TX + 1) * (TY + 2) * TZ, c12 = TX * (TY + 2) * (TZ + 1);     // D = 1: T = 0, 2
+    constexpr int c20 = (TX + 1) * TY * (TZ + 2), c21 = TX * (TY + 1) * (TZ + 2);     // D = 2: T = 0, 1
+    constexpr int NCA = c01 > c10 ? (c01 > c20 ? c01 : c20) : (c10 > c20 ? c10 : c20);
+    constexpr int NCB = c02 > c12 ? (c02 > c21 ? c02 : c21) : (c12 > c21 ? c12 : c21);
+    __shared__ double Qs[NQ];
+    __shared__ double E0[NE0], E1[NE1], E2[NE2];
+    __shared__ double G0[NG0], G1[NG1], G2[NG2];
+    __shared__ double Ca[NCA], Cb[NCB];
+    constexpr int NM0 = (TX + 3) * (TY + 2) * (TZ + 2), NM1 = (TX + 2) * (TY + 3) * (TZ + 2), NM2 = (TX + 2) * (TY + 2) * (TZ + 3);
+    constexpr int NF = (TX + 2) * (TY + 2) * (TZ + 2);
+    __shared__ double M0[NM0], M1[NM1], M2[NM2];
+    __shared__ double Fs[NF];
+    const GodParams& P = *Pp;
+    const int fab = blockIdx.y;
+    const BoxD bx = boxes[fab];
+    const int bid = blockIdx.x;
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, tiz = r1 / nty;
+    TileCtx c;
+    c.P = Pp;
+    c.tlo[0] = bx.lo[0] + tix * TX; c.tlo[1] = bx.lo[1] + tiy * TY; c.tlo[2] = bx.lo[2] + tiz * TZ;
+    if (c.tlo[0] > bx.hi[0] || c.tlo[1] > bx.hi[1] || c.tlo[2] > bx.hi[2]) return;
+    c.thi[0] = min(c.tlo[0] + TX - 1, bx.hi[0]); c.thi[1] = min(c.tlo[1] + TY - 1, bx.hi[1]); c.thi[2] = min(c.tlo[2] + TZ - 1, bx.hi[2]);
+    c.q = qt[fab];
+    c.has_force = P.has_force != 0; c.has_divu = P.has_divu != 0; c.fit = P.fit != 0; c.is_vel = P.is_velocity != 0;
+    if (c.has_force) c.frc = ft[fab];
+    if (c.has_divu) c.dv = divut[fab];
+    c.mac[0] = uxt[fab]; c.mac[1] = uyt[fab]; c.mac[2] = uzt[fab];
+    c.Ms[0] = M0; c.Ms[1] = M1; c.Ms[2] = M2; c.Fs = Fs;
+    c.Qs = Qs; c.Es[0] = E0; c.Es[1] = E1; c.Es[2] = E2; c.Gs[0] = G0; c.Gs[1] = G1; c.Gs[2] = G2; c.Ca = Ca; c.Cb = Cb;
+    {
+        int lo[3], hi[3];
+        for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e] - 3; hi[e] = c.thi[e] + 3; }
+        c.qb = make_lbox(lo, hi);
+        for (int d = 0; d < 3; ++d) {
+            for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e] - (e == d ? 0 : 1); hi[e] = c.thi[e] + 1; }
+            c.eb[d] = make_lbox(lo, hi);
+            for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e]; hi[e] = c.thi[e] + (e == d ? 1 : 0); }
+            c.gb[d] = make_lbox(lo, hi);
+            for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e] - 1; hi[e] = c.thi[e] + 1 + (e == d ? 1 : 0); }
+            c.mb[d] = make_lbox(lo, hi);
+        }
+        for (int e = 0; e < 3; ++e) { lo[e] = c.tlo[e] - 1; hi[e] = c.thi[e] + 1; }
+        c.fb = make_lbox(lo, hi);
+    }
+    // the mac velocities of the tile (cells grown by 1) are shared by all components
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const FabD::gdouble* mp = (const FabD::gdouble*)c.mac[d].p;
+        for (int idx = threadIdx.x; idx < c.mb[d].size(); idx += NTH) {
+            int i, j, k; c.mb[d].ijk(idx, i, j, k);
+            c.Ms[d][idx] = mp[c.mac[d].off(i, j, k)];
+        }
+    }
+    const FabD aofs = aofst[fab];
+    const double dx0 = P.dx[0], dx1 = P.dx[1], dx2 = P.dx[2];
+    const double ax = dx1 * dx2, ay = dx2 * dx0, az = dx0 * dx1;
+    const double qvol = 1.0 / (dx0 * dx1 * dx2);
+    const int ncomp = P.ncomp;
+    const int tnx = c.thi[0] - c.tlo[0] + 1, tny = c.thi[1] - c.tlo[1] + 1, tnz = c.thi[2] - c.tlo[2] + 1;
+    for (int n = 0; n < ncomp; ++n) {
+        // stage the state tile (3 ghost cells) of component n
+        {
+            const FabD::gdouble* qp = (const FabD::gdouble*)c.q.p + c.q.cs * n;
+            for (int idx = threadIdx.x; idx < c.qb.size(); idx += NTH) {
+                int i, j, k; c.qb.ijk(idx, i, j, k);
+                Qs[idx] = qp[c.q.off(i, j, k)];
+            }
+            if (c.has_force) {
+                const FabD::gdouble* fp = (const FabD::gdouble*)c.frc.p + c.frc.cs * n;
+                for (int idx = threadIdx.x; idx < c.fb.size(); idx += NTH) {
+                    int i, j, k; c.fb.ijk(idx, i, j, k);
+                    Fs[idx] = fp[c.frc.off(i, j, k)];
+                }
+            }
+        }
+        __syncthreads();
+        tile_stage1<0>(c, n);
+        tile_stage1<1>(c, n);
+        tile_stage1<2>(c, n);
+        __syncthreads();
+        tile_direction<0>(c, n);
+        tile_direction<1>(c, n);
+        tile_direction<2>(c, n);
+        // aofs (ComputeFluxes, ComputeDivergence(-1), ComputeConvectiveTerm) and the optional edge-state / flux outputs
+        for (int idx = threadIdx.x; idx < tnx * tny * tnz; idx += NTH) {
+            const int i = c.tlo[0] + idx % tnx, r = idx / tnx, j = c.tlo[1] + r % tny, k = c.tlo[2] + r / tny;
+            const double uxl = M0[c.mb[0].off(i, j, k)], uxh = M0[c.mb[0].off(i + 1, j, k)], uyl = M1[c.mb[1].off(i, j, k)], uyh = M1[c.mb[1].off(i, j + 1, k)];
+            const double uzl = M2[c.mb[2].off(i, j, k)], uzh = M2[c.mb[2].off(i, j, k + 1)];
+            const double exl = G0[c.gb[0].off(i, j, k)], exh = G0[c.gb[0].off(i + 1, j, k)];
+            const double eyl = G1[c.gb[1].off(i, j, k)], eyh = G1[c.gb[1].off(i, j + 1, k)];
+            const double ezl = G2[c.gb[2].off(i, j, k)], ezh = G2[c.gb[2].off(i, j, k + 1)];
+            const double fxl = exl * uxl * ax, fxh = exh * uxh * ax, fyl = eyl * uyl * ay, fyh = eyh * uyh * ay, fzl = ezl * uzl * az, fzh = ezh * uzh * az;
+            if (e0t) {
+                e0t[fab](i, j, k, n) = exl; e1t[fab](i, j, k, n) = eyl; e2t[fab](i, j, k, n) = ezl;
+                if (i == bx.hi[0]) e0t[fab](i + 1, j, k, n) = exh;
+                if (j == bx.hi[1]) e1t[fab](i, j + 1, k, n) = eyh;
+                if (k == bx.hi[2]) e2t[fab](i, j, k + 1, n) = ezh;
+            }
+            if (f0t) {
+                f0t[fab](i, j, k, n) = fxl; f1t[fab](i, j, k, n) = fyl; f2t[fab](i, j, k, n) = fzl;
+                if (i == bx.hi[0]) f0t[fab](i + 1, j, k, n) = fxh;
+                if (j == bx.hi[1]) f1t[fab](i, j + 1, k, n) = fyh;
+                if (k == bx.hi[2]) f2t[fab](i, j, k + 1, n) = fzh;
+            }
+            double upd = -1.0 * qvol * ((fxh - fxl) + (fyh - fyl) + (fzh - fzl));
+            if (!P.iconserv[n]) {
+                const double divum = 1.0 * ((uxh - uxl) / dx0 + (uyh - uyl) / dx1 + (uzh - uzl) / dx2);
+                double qavg = exl + exh + eyl + eyh + ezl + ezh;
+                qavg *= 1.0 / 6.0;
+                upd += qavg * divum;
+            }
+            aofs(i, j, k, acomp + n) = -upd;
+        }
+        __syncthreads();
+    }
+}
+
+static bool use_tile_kernel()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_TILE"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
                           const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
                           bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3])
@@ -666,12 +984,24 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     const Layout& l = *S.layout;
     MultiFab e0[3], edge[3];
     MultiFab* ed[3];
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 3 && !use_tile_kernel(); ++d) {
         e0[d].define(S.layout, face_type(d), ncomp, 1);
         if (edge_out && edge_out[d]) ed[d] = edge_out[d];
         else { edge[d].define(S.layout, face_type(d), ncomp, 0); ed[d] = &edge[d]; }
     }
     const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
+    if (use_tile_kernel()) {
+        constexpr int TX = 16, TY = 8, TZ = 4, NTH = 1024;
+        const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY, ntz = (l.max_len[2] + TZ - 1) / TZ;
+        const bool se = edge_out && edge_out[0], sf = flux_out && flux_out[0];
+        dim3 grid((unsigned)(ntx * nty * ntz), (unsigned)l.nlocal());
+        hipLaunchKernelGGL((k_godunov_tile<TX, TY, TZ, NTH>), grid, dim3(NTH), 0, ctx.stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
+                           divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp,
+                           se ? edge_out[0]->d_tab : nullptr, se ? edge_out[1]->d_tab : nullptr, se ? edge_out[2]->d_tab : nullptr,
+                           sf ? flux_out[0]->d_tab : nullptr, sf ? flux_out[1]->d_tab : nullptr, sf ? flux_out[2]->d_tab : nullptr,
+                           dP, ntx, nty, ntz);
+        return;
+    }
     launch_trace<false, 0>(l, S, force, *umac[0], e0[0], dP);
     launch_trace<false, 1>(l, S, force, *umac[1], e0[1], dP);
     launch_trace<false, 2>(l, S, force, *umac[2], e0[2], dP);

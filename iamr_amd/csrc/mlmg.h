@@ -53,6 +53,9 @@ public:
     const Geometry& geom(int l) const { return m_lev[l].g; }
     void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval);
     void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill);
+    // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
+    void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill);
+    bool fused_smoother_ok(int l) const;
     void vcycle(MGStats& st);
     MultiFab& res(int l) { return m_lev[l].res; }
     MultiFab& cor(int l) { return m_lev[l].cor; }
@@ -63,6 +66,7 @@ private:
         LayoutP layout;
         MultiFab a, b[3];          // owned (coarse levels)
         MultiFab cor, res, rescor;
+        MultiFab buf;              // second buffer of the fused (out-of-place) GSRB sweeps
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void bottom_solve(MGStats& st);

@@ -257,6 +257,11 @@ def abec_gsrb(geom, alpha, beta, a, b, phi, rhs, redblack, omega=1.15, lobc=(0, 
                                 phi.h, rhs.h, redblack, C.c_double(omega), i3(lobc), i3(hibc), maxorder))
 
 
+def abec_gsrb_sweep(geom, alpha, beta, a, b, phi, rhs, omega=1.15, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=2, fused=1):
+    check(lib().iamrx_abec_gsrb_sweep(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
+                                      phi.h, rhs.h, C.c_double(omega), i3(lobc), i3(hibc), maxorder, int(fused)))
+
+
 def abec_residual(geom, alpha, beta, a, b, out, phi, rhs=None, tensor=0):
     check(lib().iamrx_abec_residual(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
                                     out.h, phi.h, _h(rhs), tensor))

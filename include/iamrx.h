@@ -119,6 +119,10 @@ int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int ran
 /* one red or black Gauss-Seidel pass of (alpha*a - beta div b grad) phi = rhs; ghost cells of phi must be filled */
 int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
                     iamrx_mf phi, iamrx_mf rhs, int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder);
+/* one full red+black sweep with the ghost/BC fill in front of each colour (homogeneous BC, as inside MLMG::mgVcycle);
+ * fused = 1: single-pass kernel (red everywhere + black off the box surfaces) followed by the black pass on the box surfaces */
+int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                          iamrx_mf phi, iamrx_mf rhs, double omega, const int lobc[3], const int hibc[3], int maxorder, int fused);
 /* out = rhs - L(phi)  (rhs == NULL: out = L(phi)) */
 int iamrx_abec_residual(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
                         iamrx_mf out, iamrx_mf phi, iamrx_mf rhs, int tensor);
