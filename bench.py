@@ -84,6 +84,8 @@ def kernel_rooflines(lib, n):
     # one full Gauss-Seidel sweep incl. its ghost fills: plane-fused (2 passes) and reference form (8 colour passes)
     t = hip_event_time(lib, lambda: N.nodal_gs_sweep(g, x, r, sig, 1), 10)
     out["nodal_gs_sweep"] = {"ms": t, "alg_bytes_per_node": 32, "GBps": 32 * nodes / t / 1e6}
+    t = hip_event_time(lib, lambda: N.nodal_gs_sweep(g, x, r, sig, 3), 10)     # the two kernel launches alone
+    out["nodal_gs4_launch"] = {"ms": t / 2, "alg_bytes_per_launch": 16 * nodes, "GBps": 16 * nodes / (t / 2) / 1e6}
     t = hip_event_time(lib, lambda: N.nodal_gs_sweep(g, x, r, sig, 0), 5)
     out["nodal_gs_sweep_8pass"] = {"ms": t, "alg_bytes_per_node": 32, "GBps": 32 * nodes / t / 1e6}
     del sig, x, r
@@ -208,12 +210,22 @@ def main():
         sec = ns.profile(0)
         kr = kernel_rooflines(lib, n) if world == 1 else {}
         # dominant kernel of the step (profiles/round1_*): the nodal Gauss-Seidel colour kernel
-        dom = kr.get("nodal_gs_sweep")
+        dom = kr.get("nodal_gs4_launch")
         roofline = None
         if dom:
-            roofline = {"kernel": "k_nodal_gs4 (plane-fused 8-colour Gauss-Seidel sweep = 2 launches + 2 ghost fills)", "bound": "hbm",
-                        "achieved": dom["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": None,
-                        "algorithmic_bytes_per_launch": 32 * (n + 1) ** 3, "avg_ms": dom["ms"]}
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, corrected as calibrated in
+            # profiles/round1_pmc.json); only valid for the size it was collected at
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))
+                if n == 256:
+                    traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "k_nodal_gs4" in k][0]
+            except Exception:
+                traffic = None
+            roofline = {"kernel": "k_nodal_gs4<32,16> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch; the dominant kernel of the step, "
+                                  "profiles/round1_*_kernel_stats.csv)", "bound": "hbm",
+                        "achieved": dom["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": dom["ms"]}
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -363,7 +363,12 @@ int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
 {
     IAMRX_TRY
     Geometry gg = to_geom(g);
-    if (fused == 2) {
+    if (fused == 3) {
+        // timing aid: the two k_nodal_gs4 launches of a sweep alone (no ghost fills, result left in a scratch buffer)
+        MultiFab xb(phi->mf.layout, node_type(), 1, phi->mf.ngrow);
+        nodal_gs_fused_pass(gg, phi->mf, phi->mf, xb, rhs->mf, sig->mf, 0);
+        nodal_gs_fused_pass(gg, phi->mf, xb, xb, rhs->mf, sig->mf, 1);
+    } else if (fused == 2) {
         if (!nodal_smooth_small(gg, phi->mf, rhs->mf, sig->mf, 1)) throw Error("level does not qualify for the single-workgroup smoother");
         phi->mf.FillBoundary(gg);
     } else if (fused) {
