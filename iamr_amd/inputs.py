@@ -1,0 +1,159 @@
+"""ParmParse-compatible inputs for the level driver.
+
+Reads IAMR `inputs.*` / `regtest.*` files (`key = value ...`, `#` comments, later definitions override earlier ones, trailing
+`key=value` command-line arguments override the file -- the amrex::ParmParse rules used by Source/main.cpp:60-75) and maps the
+keys this library implements onto `ns_params`, the geometry and the box layout:
+
+  amr.n_cell, amr.max_level (must be 0), amr.max_grid_size (32), geometry.prob_lo / prob_hi / is_periodic / coord_sys (0),
+  ns.cfl, ns.init_iter, ns.init_vel_iter, ns.init_shrink, ns.change_max, ns.fixed_dt, ns.init_dt, ns.gravity,
+  ns.be_cn_theta, ns.do_mom_diff, ns.vel_visc_coef, ns.scal_diff_coefs, ns.lo_bc, ns.hi_bc, ns.advection_scheme,
+  ns.visc_tol, godunov.use_forces_in_trans, mac_proj.mac_tol / mac_abs_tol, proj.proj_tol / proj_abs_tol,
+  {x,y,z}{lo,hi}.velocity, prob.probtype (1: fluid at rest, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
+  prob.density_ic, max_step, stop_time
+(reference: Source/NavierStokesBase.cpp:431-557, Source/NavierStokes.cpp:250-310, Source/MacProj.cpp:62-75,
+Source/Projection.cpp:49-65, Source/Diffusion.cpp:98-118, Source/prob/prob_init.cpp:8-60, Source/main.cpp:60-145).
+Keys that select features this library does not have (AMR levels, EB, particles, inflow/outflow ...) raise; keys that only
+concern I/O or verbosity are ignored and listed in `Inputs.ignored`.  Host-only code: no GPU needed to parse."""
+import re
+
+_IGNORED_PREFIXES = ("amr.check", "amr.plot", "amr.v", "amr.derive", "amr.probin", "amr.grid_log", "amr.checkpoint",
+                     "amr.blocking_factor", "amr.regrid", "amr.ref_ratio", "amr.refinement_indicators", "amr.n_error_buf",
+                     "amr.grid_eff", "amr.restart", "amr.subcycling", "ns.v", "ns.sum_interval", "ns.getForceVerbose",
+                     "mg.", "proj.v", "mac_proj.v", "mac.v", "diffuse.v", "fab.", "amrex.", "particles.", "nodal_proj.verbose",
+                     "mac_proj.verbose", "ns.do_init_vort_proj", "ns.do_init_proj", "ns.do_mac_proj", "ns.do_reflux",
+                     "ns.do_sync_proj")
+
+
+def parse_text(text, table=None):
+    """ParmParse tokenisation: `name = v1 v2 ...` (values up to the next `name =` or end of line; quotes group)"""
+    table = {} if table is None else table
+    for raw in text.splitlines():
+        line = raw.split("#", 1)[0].strip()
+        if not line:
+            continue
+        # several definitions may share a line
+        parts = re.split(r"(?:(?<=\s)|^)([A-Za-z_][\w\.\-]*)\s*=", line)
+        # parts: ['', name1, vals1, name2, vals2, ...]
+        if len(parts) < 3:
+            raise ValueError(f"cannot parse inputs line: {raw!r}")
+        for i in range(1, len(parts) - 1, 2):
+            vals = re.findall(r'"[^"]*"|\S+', parts[i + 1])
+            table[parts[i]] = [v.strip('"') for v in vals]
+    return table
+
+
+class Inputs:
+    def __init__(self, files=(), overrides=()):
+        self.table = {}
+        for f in files:
+            with open(f) as fh:
+                parse_text(fh.read(), self.table)
+        for o in overrides:
+            parse_text(o, self.table)
+        self.used = set()
+        self.ignored = []
+
+    # ParmParse-style accessors ------------------------------------------------------------------------------------
+    def has(self, k):
+        return k in self.table
+
+    def _get(self, k, n=None):
+        self.used.add(k)
+        v = self.table[k]
+        if n is not None and len(v) < n:
+            raise ValueError(f"inputs: {k} needs {n} values, has {len(v)}")
+        return v
+
+    def real(self, k, default=None):
+        if k not in self.table:
+            if default is None:
+                raise KeyError(f"inputs: required key {k} is missing")
+            return default
+        return float(self._get(k, 1)[0])
+
+    def integer(self, k, default=None):
+        if k not in self.table:
+            if default is None:
+                raise KeyError(f"inputs: required key {k} is missing")
+            return default
+        return int(self._get(k, 1)[0])
+
+    def string(self, k, default=None):
+        if k not in self.table:
+            return default
+        return self._get(k, 1)[0]
+
+    def reals(self, k, n, default=None):
+        if k not in self.table:
+            if default is None:
+                raise KeyError(f"inputs: required key {k} is missing")
+            return list(default)
+        return [float(x) for x in self._get(k, n)[:n]]
+
+    def ints(self, k, n, default=None):
+        if k not in self.table:
+            if default is None:
+                raise KeyError(f"inputs: required key {k} is missing")
+            return list(default)
+        return [int(x) for x in self._get(k, n)[:n]]
+
+    # mapping ----------------------------------------------------------------------------------------------------------
+    def problem(self):
+        """-> dict(n, prob_lo, prob_hi, periodic, max_grid_size, params (kwargs of ns_params), prob (dict), max_step, stop_time)"""
+        if self.integer("amr.max_level", 0) != 0:
+            raise NotImplementedError("inputs: amr.max_level > 0 (AMR levels, SURVEY row a18) is not implemented; pass amr.max_level=0")
+        if self.integer("geometry.coord_sys", 0) != 0:
+            raise NotImplementedError("inputs: only Cartesian coordinates (geometry.coord_sys = 0)")
+        n = self.ints("amr.n_cell", 3)
+        mgs = self.ints("amr.max_grid_size", 1, [32])[0]
+        prob_lo = self.reals("geometry.prob_lo", 3)
+        prob_hi = self.reals("geometry.prob_hi", 3)
+        per = self.ints("geometry.is_periodic", 3, [0, 0, 0])
+        lo_bc = self.ints("ns.lo_bc", 3)
+        hi_bc = self.ints("ns.hi_bc", 3)
+        for d in range(3):
+            if per[d] and (lo_bc[d] != 0 or hi_bc[d] != 0):
+                raise ValueError("inputs: periodic direction with a non-Interior ns.lo_bc/hi_bc (NavierStokesBase.cpp:563-590)")
+            if not per[d] and (lo_bc[d] not in (4, 5) or hi_bc[d] not in (4, 5)):
+                raise NotImplementedError(f"inputs: ns.lo_bc/hi_bc = {lo_bc[d]}/{hi_bc[d]} in direction {d}: only Interior (0), "
+                                          "SlipWall (4) and NoSlipWall (5) are implemented (SURVEY row f3)")
+        scheme = self.string("ns.advection_scheme", "Godunov_PLM")
+        if scheme != "Godunov_PLM":
+            raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; only Godunov_PLM is implemented")
+        for k in ("ns.do_temp", "ns.do_trac2", "ns.do_cons_trac", "ns.do_LES", "ns.do_mom_diff", "particles.do_nspc_particles", "eb2.geom_type"):
+            if self.has(k) and self.string(k) not in ("0", "all_regular"):
+                raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented")
+        sdc = self.reals("ns.scal_diff_coefs", 1, [0.0])
+        p = dict(cfl=self.real("ns.cfl"), visc_coef=self.real("ns.vel_visc_coef", 0.0), tracer_diff_coef=sdc[0],
+                 init_iter=self.integer("ns.init_iter", 2), init_vel_iter=self.integer("ns.init_vel_iter", 1),
+                 init_shrink=self.real("ns.init_shrink", 1.0), change_max=self.real("ns.change_max", 1.1),
+                 fixed_dt=self.real("ns.fixed_dt", -1.0), init_dt=self.real("ns.init_dt", -1.0), gravity=self.real("ns.gravity", 0.0),
+                 be_cn_theta=self.real("ns.be_cn_theta", 0.5), visc_tol=self.real("ns.visc_tol", 1.0e-10),
+                 use_forces_in_trans=self.integer("godunov.use_forces_in_trans", 0),
+                 mac_tol=self.real("mac_proj.mac_tol", 1.0e-12), mac_abs_tol=self.real("mac_proj.mac_abs_tol", 1.0e-16),
+                 proj_tol=self.real("proj.proj_tol", 1.0e-12), proj_abs_tol=self.real("proj.proj_abs_tol", 1.0e-16),
+                 phys_lo=lo_bc, phys_hi=hi_bc)
+        wlo, whi = [0.0] * 9, [0.0] * 9
+        for d, name in enumerate("xyz"):
+            if self.has(f"{name}lo.velocity"):
+                wlo[3 * d:3 * d + 3] = self.reals(f"{name}lo.velocity", 3)
+            if self.has(f"{name}hi.velocity"):
+                whi[3 * d:3 * d + 3] = self.reals(f"{name}hi.velocity", 3)
+        p["wall_vel_lo"], p["wall_vel_hi"] = wlo, whi
+        probtype = self.integer("prob.probtype")
+        if probtype == 1:
+            prob = dict(probtype=1, rho0=1.0)
+        elif probtype == 11:
+            prob = dict(probtype=11, vfac=self.real("prob.velocity_factor", 0.0), a=self.real("prob.a", 1.0), b=self.real("prob.b", 1.0),
+                        c=self.real("prob.c", 1.0), rho0=self.real("prob.density_ic", 1.0))
+        else:
+            raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 11 (TaylorGreen)")
+        out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
+                   max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0))
+        for k in self.table:
+            if k not in self.used:
+                if k.startswith(_IGNORED_PREFIXES):
+                    self.ignored.append(k)
+                else:
+                    raise KeyError(f"inputs: key {k} is not understood by this library (not silently ignored)")
+        return out

@@ -1,0 +1,68 @@
+"""`python -m iamr_amd.run <inputs file> [key=value ...]` -- the single-level equivalent of IAMR's main loop
+(Source/main.cpp:60-145: ParmParse, Amr::init, `while (step < max_step && time < stop_time) coarseTimeStep`), driving
+libiamrx.so from an unmodified IAMR inputs file.  Under torch.distributed.run it shards the boxes over the
+ranks (one process per GPU)."""
+import os
+import sys
+import time
+
+
+def build(inp, lib, N, nranks=1):
+    pr = inp.problem()
+    g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
+    lay = lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], nranks)
+    ns = N.NavierStokes(g, lay, N.ns_params(**pr["params"]))
+    pb = pr["prob"]
+    if pb["probtype"] == 1:
+        ns.init_rest(pb["rho0"])
+    else:
+        ns.init_taylorgreen(pb["vfac"], pb["a"], pb["b"], pb["c"], pb["rho0"])
+    return ns, lay, g, pr
+
+
+def main(argv):
+    from .inputs import Inputs
+    files = [a for a in argv if "=" not in a]
+    over = [a for a in argv if "=" in a]
+    if not files:
+        print(__doc__)
+        return 2
+    inp = Inputs(files, over)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from . import lib
+    from . import ns as N
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib.init(local_rank)
+    if world > 1:
+        from . import comm
+        comm.init_rccl_from_torch(dist)
+    ns, lay, g, pr = build(inp, lib, N, world)
+    if rank == 0 and inp.ignored:
+        print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
+    ns.post_init(pr["stop_time"])
+    t0 = time.perf_counter()
+    step = 0
+    while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or ns.time < pr["stop_time"] - 1e-14):
+        if pr["max_step"] < 0 and pr["stop_time"] < 0:
+            break
+        dt = ns.step()
+        step += 1
+        if rank == 0:
+            print(f"STEP = {step} TIME = {ns.time:.12g} DT = {dt:.12g}")
+    lib.sync()
+    if rank == 0:
+        print(f"Run time = {time.perf_counter() - t0:.6f}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

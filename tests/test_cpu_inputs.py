@@ -1,0 +1,40 @@
+"""ParmParse-compatible inputs (row f4): parsing rules and the key mapping, no GPU needed."""
+import os
+
+import pytest
+
+from iamr_amd.inputs import Inputs, parse_text
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LDC = os.path.join(HERE, "golden", "inputs.3d.lid_driven_cavity16")
+
+
+def test_parse_rules():
+    t = parse_text('a.b = 1 2 3  # comment\n\n# only comment\nname = "two words" x\nc=4 d = 5\n')
+    assert t == {"a.b": ["1", "2", "3"], "name": ["two words", "x"], "c": ["4"], "d": ["5"]}
+    t = parse_text("a.b = 9\n", t)            # later definitions override
+    assert t["a.b"] == ["9"]
+
+
+def test_lid_driven_cavity_mapping_and_overrides():
+    inp = Inputs([LDC], ["ns.cfl=0.25", "max_step = 2"])
+    pr = inp.problem()
+    assert pr["n"] == [16, 16, 16] and pr["periodic"] == [0, 0, 0] and pr["max_grid_size"] == 8
+    p = pr["params"]
+    assert p["cfl"] == 0.25 and p["init_dt"] == 0.0140625 and p["init_shrink"] == 0.3 and p["init_iter"] == 3
+    assert p["visc_coef"] == 0.01 and p["tracer_diff_coef"] == 0.001
+    assert p["phys_lo"] == [4, 4, 5] and p["phys_hi"] == [5, 5, 5]
+    assert p["wall_vel_hi"][6:9] == [1.0, 0.0, 0.0] and sum(p["wall_vel_lo"]) == 0.0
+    assert pr["prob"]["probtype"] == 1 and pr["max_step"] == 2
+    assert set(inp.ignored) == {"amr.v", "amr.check_int", "amr.plot_int"}
+
+
+def test_unsupported_features_are_rejected_loudly():
+    with pytest.raises(NotImplementedError):
+        Inputs([LDC], ["amr.max_level=1"]).problem()
+    with pytest.raises(NotImplementedError):
+        Inputs([LDC], ["ns.lo_bc = 1 4 5"]).problem()
+    with pytest.raises(NotImplementedError):
+        Inputs([LDC], ["prob.probtype=10"]).problem()
+    with pytest.raises(KeyError):
+        Inputs([LDC], ["ns.some_unknown_knob=1"]).problem()

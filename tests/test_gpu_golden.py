@@ -39,3 +39,20 @@ def test_liddrivencavity16_fixture(gpu):
     assert np.allclose(dts, gold["dts"], rtol=1e-9, atol=0)
     S = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
     assert np.abs(S - gold["S"]).max() <= 1e-8
+
+
+def test_liddrivencavity16_from_inputs_file(gpu):
+    """the same run driven by an IAMR-format inputs file through iamr_amd.inputs / iamr_amd.run (row f4)"""
+    from iamr_amd import ns as N
+    from iamr_amd.inputs import Inputs
+    from iamr_amd.run import build
+    lib = gpu
+    gold = np.load(os.path.join(HERE, "golden", "liddrivencavity16_oracle.npz"))
+    inp = Inputs([os.path.join(HERE, "golden", "inputs.3d.lid_driven_cavity16")])
+    ns, lay, g, pr = build(inp, lib, N)
+    assert lay.nlocal() == 8 and pr["max_step"] == 5
+    ns.post_init(pr["stop_time"])
+    dts = [ns.step() for _ in range(pr["max_step"])]
+    assert np.allclose(dts, gold["dts"], rtol=1e-9, atol=0)
+    S = ns.data(N.NavierStokes.S_NEW).gather_valid((16, 16, 16))
+    assert np.abs(S - gold["S"]).max() <= 1e-8

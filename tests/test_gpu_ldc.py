@@ -27,9 +27,9 @@ def oracle_params(orc, per, phys_lo, phys_hi, lid, **kw):
     return p
 
 
-def run_oracle(orc, n, per, phys_lo, phys_hi, lid, nsteps, init, **kw):
+def run_oracle(orc, n, per, phys_lo, phys_hi, lid, nsteps, init, prob_hi=(1.0, 1.0, 1.0), **kw):
     L = orc.lib()
-    g = orc.geom(n, periodic=per)
+    g = orc.geom(n, probhi=prob_hi, periodic=per)
     p = oracle_params(orc, per, phys_lo, phys_hi, lid, **kw)
     o = orc.mg_opts()
     s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
@@ -50,9 +50,9 @@ def run_oracle(orc, n, per, phys_lo, phys_hi, lid, nsteps, init, **kw):
     return S, Pn, Gp, T, dts, st
 
 
-def run_gpu(lib, n, per, phys_lo, phys_hi, lid, nsteps, init, boxes, **kw):
+def run_gpu(lib, n, per, phys_lo, phys_hi, lid, nsteps, init, boxes, prob_hi=(1.0, 1.0, 1.0), **kw):
     from iamr_amd import ns as N
-    g = lib.Geom.make(n, periodic=per)
+    g = lib.Geom.make(n, prob_hi=prob_hi, periodic=per)
     lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
     plo = [0 if per[d] else phys_lo[d] for d in range(3)]
     phi = [0 if per[d] else phys_hi[d] for d in range(3)]
@@ -131,6 +131,27 @@ def test_walls_general_state_and_tracer_diffusion(orc, gpu):
     assert S[..., 4].max() < 0.97 * init[..., 4].max()
     # total tracer is conserved by diffusion with zero-flux walls up to the (non-conservative) advection: sanity only
     assert abs(S[..., 4].sum() - init[..., 4].sum()) < 0.05 * init[..., 4].sum()
+
+
+def test_ragged_boxes_anisotropic_mesh_with_walls(orc, gpu):
+    """non-cubic domain 48x32x16 with dx != dy != dz, chopped into boxes of unequal size (32+16 cells in x), x periodic,
+    y slip / no-slip, z no-slip + lid, variable density, diffusive tracer: 2 pressure iterations + 3 steps vs the oracle"""
+    n = (48, 32, 16)
+    per = (1, 0, 0)
+    prob_hi = (1.5, 1.0, 0.4)
+    x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    init = np.zeros(n + (5,))
+    init[..., 0] = 0.8 * np.sin(2 * np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 1] = 0.3 * np.cos(4 * np.pi * X) * np.sin(np.pi * Y) ** 2 * np.sin(2 * np.pi * Z)
+    init[..., 2] = 0.1 * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(np.pi * Z) ** 2
+    init[..., 3] = 1.0 + 0.3 * np.cos(2 * np.pi * X) * np.sin(np.pi * Y)
+    init[..., 4] = np.exp(-30.0 * ((X - 0.3) ** 2 + (Y - 0.6) ** 2 + (Z - 0.5) ** 2))
+    kw = dict(cfl=0.4, visc_coef=0.005, init_iter=2, tracer_diff_coef=0.004)
+    ref = run_oracle(orc, n, per, (0, 4, 5), (0, 5, 5), LID, 3, init, prob_hi=prob_hi, **kw)
+    ns, lay, g, dts = run_gpu(gpu, n, per, (0, 4, 5), (0, 5, 5), LID, 3, init, (32, 16, 16), prob_hi=prob_hi, **kw)
+    assert lay.nlocal() == 4
+    compare(gpu, ns, lay, g, n, dts, ref)
 
 
 def test_rejects_unsupported_physical_bc(gpu):
