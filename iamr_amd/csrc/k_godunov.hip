@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) k_final(Tiling t, const BoxD* __restrict_
     const long mAsD = stride_of<D>(mA), mAsT = stride_of<TA>(mA), mBsD = stride_of<D>(mB), mBsT = stride_of<TB>(mB);
     const double dt = P.dt, hdt = 0.5 * P.dt;
     const double dtdxD = dt / P.dx[D];
-    const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    const int nbeg = PRED ? D : (gridDim.z > 1 ? (int)blockIdx.z : 0), nend = PRED ? D + 1 : (gridDim.z > 1 ? nbeg + 1 : P.ncomp);
     const bool nonperD = !P.bc.per[D];
     const int dloD = P.bc.dlo[D], dhiD = P.bc.dhi[D];
     const bool is_vel = P.is_velocity != 0;
@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(256) k_corner(Tiling t, const BoxD* __restrict
     const double dt3 = P.dt / 3.0, dtdxT = P.dt / P.dx[T], hdt = 0.5 * P.dt;
     const bool nonperT = !P.bc.per[T];
     const int dlo = P.bc.dlo[T], dhi = P.bc.dhi[T];
-    const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    // advection: one component per blockIdx.z (fewer live registers, more workgroups); prediction: the normal component only
+    const int nbeg = PRED ? D : (gridDim.z > 1 ? (int)blockIdx.z : 0), nend = PRED ? D + 1 : (gridDim.z > 1 ? nbeg + 1 : P.ncomp);
     for (int k = k0; k <= k1; ++k) {
         const int fT = T == 0 ? i : (T == 1 ? j : k);
         const long qo = q.off(i, j, k);
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(256) k_final_s(Tiling t, const BoxD* __restric
     const long cAsD = stride_of<D>(cA), cAsT = stride_of<TA>(cA), cBsD = stride_of<D>(cB), cBsT = stride_of<TB>(cB);
     const double dt = P.dt, hdt = 0.5 * P.dt;
     const double dtdxD = dt / P.dx[D];
-    const int nbeg = PRED ? D : 0, nend = PRED ? D + 1 : P.ncomp;
+    const int nbeg = PRED ? D : (gridDim.z > 1 ? (int)blockIdx.z : 0), nend = PRED ? D + 1 : (gridDim.z > 1 ? nbeg + 1 : P.ncomp);
     const bool nonperD = !P.bc.per[D];
     const int dloD = P.bc.dlo[D], dhiD = P.bc.dhi[D];
     const bool is_vel = P.is_velocity != 0;
@@ -545,6 +546,13 @@ static int tz_for(bool z_stencil)
     return z_stencil ? tzz : 4;
 }
 
+static bool comp_split()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_COMP_SPLIT"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 static Tiling face_tiling(const Layout& l, int D, int gt, int tz)
 {
     int ml[3];
@@ -574,7 +582,9 @@ static void launch_corner(const Layout& l, const MultiFab& q, const MultiFab* fo
     int ml[3];
     for (int e = 0; e < 3; ++e) ml[e] = l.max_len[e] + (e == T ? 1 : 0) + (e == D ? 2 : 0);
     Tiling t = make_tiling(ml, l.nlocal(), tz_for(T == 2 || D == 2));
-    hipLaunchKernelGGL((k_corner<PRED, D, T>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+    dim3 gr = t.grid();
+    if (!PRED && comp_split()) gr.z = (unsigned)out.ncomp;
+    hipLaunchKernelGGL((k_corner<PRED, D, T>), gr, Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mT.d_tab, mO.d_tab, eO.d_tab, out.d_tab, dP);
 }
 
@@ -589,7 +599,9 @@ static void launch_final_split(const Layout& l, const MultiFab& q, int ncomp, co
     launch_corner<PRED, D, TA>(l, q, force, divu, *mac[TA], *mac[TB], e0[TB], cA, dP);
     launch_corner<PRED, D, TB>(l, q, force, divu, *mac[TB], *mac[TA], e0[TA], cB, dP);
     Tiling t = face_tiling(l, D, 0, tz_for(true));
-    hipLaunchKernelGGL((k_final_s<PRED, D>), t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
+    dim3 gr = t.grid();
+    if (!PRED && comp_split()) gr.z = (unsigned)nc;
+    hipLaunchKernelGGL((k_final_s<PRED, D>), gr, Tiling::block(), 0, Context::get().stream, t, l.d_boxes, q.d_tab,
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab,
                        cA.d_tab, cB.d_tab, out.d_tab, dP);
 }
