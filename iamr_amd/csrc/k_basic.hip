@@ -238,7 +238,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
         finish_to_host(0, nout, np);
         for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q];
     }
-    if (!local) ctx.comm->allreduce(out, nout, ReduceOp::Sum);
+    if (!local && !m.layout->replicated) ctx.comm->allreduce(out, nout, ReduceOp::Sum);
 }
 
 __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own,

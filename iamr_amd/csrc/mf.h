@@ -71,6 +71,9 @@ struct Layout {
     BoxD* d_boxes = nullptr;     // device copy of the LOCAL valid boxes
     int max_len[3] = {0, 0, 0};  // max local box extent (cells)
     uint64_t id = 0;
+    // replicated: every rank holds ALL boxes (MG levels below the agglomeration level); nothing on such a layout communicates
+    bool replicated = false;
+    uint64_t replicated_of = 0;   // id of the distributed layout it was made from
 
     Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myrank);
     ~Layout();
@@ -84,6 +87,9 @@ struct Layout {
     mutable std::shared_ptr<Layout> m_coarse;
     mutable int m_coarse_ratio = 0;
     bool coarsenable(int ratio, int min_width) const;
+    // same boxes, all of them owned by this rank (on every rank)
+    std::shared_ptr<Layout> make_replicated() const;
+    mutable std::shared_ptr<Layout> m_repl;
 };
 using LayoutP = std::shared_ptr<Layout>;
 
@@ -169,5 +175,8 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
 // plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
 const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g);
 void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc);
+// multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes
+void gather_to_replicated(MultiFab& repl, const MultiFab& dist);
+void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng);
 
 }  // namespace iamrx

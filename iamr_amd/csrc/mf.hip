@@ -151,8 +151,20 @@ std::shared_ptr<Layout> Layout::coarsened(int ratio) const
     std::vector<BoxD> cb;
     for (auto& b : boxes) cb.push_back(coarsen(b, ratio));
     m_coarse = std::make_shared<Layout>(cb, owner, Context::get().comm->rank);
+    m_coarse->replicated = replicated;
     m_coarse_ratio = ratio;
     return m_coarse;
+}
+
+std::shared_ptr<Layout> Layout::make_replicated() const
+{
+    if (m_repl) return m_repl;
+    const int me = Context::get().comm->rank;
+    std::vector<int> own(boxes.size(), me);
+    m_repl = std::make_shared<Layout>(boxes, own, me);
+    m_repl->replicated = true;
+    m_repl->replicated_of = id;
+    return m_repl;
 }
 
 // ------------------------------------------------------------------ MultiFab
@@ -253,14 +265,14 @@ void MultiFab::copy_from_host(int li, const double* src)
 double MultiFab::norm0(int comp, int nc, int ng, bool local) const
 {
     double v = reduce_norm0(*this, comp, nc, ng);
-    if (!local) Context::get().comm->allreduce(&v, 1, ReduceOp::Max);
+    if (!local && !layout->replicated) Context::get().comm->allreduce(&v, 1, ReduceOp::Max);
     return v;
 }
 
 double MultiFab::sum_unique(const Geometry& g, int comp, bool local) const
 {
     double v = reduce_sum_unique(*this, comp, g);
-    if (!local) Context::get().comm->allreduce(&v, 1, ReduceOp::Sum);
+    if (!local && !layout->replicated) Context::get().comm->allreduce(&v, 1, ReduceOp::Sum);
     return v;
 }
 
@@ -417,6 +429,93 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
     }
     // buffers are stream-ordered: safe to return them to the cache (next user is on the same stream)
     for (double* b : bufs) ctx.free(b);
+}
+
+// ------------------------------------------------------------------ agglomeration transfers
+// dist (boxes spread over the ranks) -> repl (same boxes, all of them on every rank): an all-gather of the valid regions,
+// expressed as a CopyPlan so that it runs through execute_plan (pack kernel, one message per peer, unpack kernel).
+static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
+{
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.layout_id = dist.id; key.t = t; key.ng = -1;
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+    auto plan = std::make_unique<CopyPlan>();
+    const int me = Context::get().comm->rank, nr = Context::get().comm->nranks;
+    std::map<int, CopyPlan::Peer> peers;
+    for (int g = 0; g < (int)dist.boxes.size(); ++g) {
+        CopyDesc cd;
+        cd.region = convert(dist.boxes[g], t.t);
+        cd.shift[0] = cd.shift[1] = cd.shift[2] = 0;
+        cd.buf_off = 0;
+        const long np = cd.region.npts();
+        if (dist.owner[g] == me) {
+            cd.src_fab = dist.local_of[g]; cd.dst_fab = g;
+            plan->local.push_back(cd);
+            plan->max_local_pts = std::max(plan->max_local_pts, np);
+            for (int r = 0; r < nr; ++r) {
+                if (r == me) continue;
+                auto& pr = peers[r];
+                pr.rank = r;
+                CopyDesc pd = cd;
+                pd.dst_fab = -1; pd.buf_off = pr.send_pts;
+                pr.send_pts += np; pr.max_pack_pts = std::max(pr.max_pack_pts, np);
+                pr.pack.push_back(pd);
+            }
+        } else {
+            auto& pr = peers[dist.owner[g]];
+            pr.rank = dist.owner[g];
+            cd.src_fab = -1; cd.dst_fab = g; cd.buf_off = pr.recv_pts;
+            pr.recv_pts += np; pr.max_unpack_pts = std::max(pr.max_unpack_pts, np);
+            pr.unpack.push_back(cd);
+        }
+    }
+    plan->d_local = upload(plan->local);
+    for (auto& kv : peers) {
+        kv.second.d_pack = upload(kv.second.pack);
+        kv.second.d_unpack = upload(kv.second.unpack);
+        plan->peers.push_back(std::move(kv.second));
+        kv.second.d_pack = nullptr; kv.second.d_unpack = nullptr;
+    }
+    auto& ref = *plan;
+    cache.emplace(key, std::move(plan));
+    return ref;
+}
+
+void gather_to_replicated(MultiFab& repl, const MultiFab& dist)
+{
+    IAMRX_ASSERT(repl.layout->replicated && repl.layout->replicated_of == dist.layout->id && repl.ncomp == dist.ncomp);
+    execute_plan(gather_plan(*dist.layout, dist.type), repl, dist, 0, 0, dist.ncomp);
+}
+
+// repl -> dist: every rank picks its own boxes (valid region grown by ng, ng <= both ghost widths); purely local
+void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
+{
+    IAMRX_ASSERT(repl.layout->replicated && repl.layout->replicated_of == dist.layout->id && repl.ncomp == dist.ncomp);
+    IAMRX_ASSERT(ng <= dist.ngrow && ng <= repl.ngrow);
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.layout_id = dist.layout->id; key.t = dist.type; key.ng = ng;
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        auto plan = std::make_unique<CopyPlan>();
+        const Layout& l = *dist.layout;
+        for (int li = 0; li < l.nlocal(); ++li) {
+            CopyDesc cd;
+            cd.region = grow(convert(l.lbox(li), dist.type.t), ng);
+            cd.shift[0] = cd.shift[1] = cd.shift[2] = 0;
+            cd.buf_off = 0;
+            cd.src_fab = l.local[li]; cd.dst_fab = li;
+            plan->local.push_back(cd);
+            plan->max_local_pts = std::max(plan->max_local_pts, cd.region.npts());
+        }
+        plan->d_local = upload(plan->local);
+        it = cache.emplace(key, std::move(plan)).first;
+    }
+    execute_plan(*it->second, dist, repl, 0, 0, dist.ncomp);
 }
 
 void MultiFab::FillBoundary(const Geometry& g) { FillBoundary(g, 0, ncomp); }

@@ -25,6 +25,10 @@ struct MGOpts {
     int fixed_iters = 0;
 };
 
+// multi-rank runs: MG levels whose total size is at most this many cells are replicated on every rank (one all-gather per
+// V-cycle instead of a halo exchange per smoothing pass and an all-reduce per Krylov dot product); 0 disables
+long mg_agglomeration_cells();
+
 struct MGStats {
     int iters = 0;
     double resnorm0 = 0, rhsnorm0 = 0, resnorm = 0;
@@ -67,6 +71,11 @@ private:
         MultiFab a, b[3];          // owned (coarse levels)
         MultiFab cor, res, rescor;
         MultiFab buf;              // second buffer of the fused (out-of-place) GSRB sweeps
+        // agglomeration (multi-rank): from this level down every rank holds the whole level; dist = the distributed coarsening
+        // of the level above, through which restriction results are gathered and corrections are picked out
+        bool agg = false;
+        LayoutP dist;
+        MultiFab tmp_d;
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void bottom_solve(MGStats& st);
@@ -107,6 +116,9 @@ private:
         MultiFab sig;              // cell, 1 ghost
         MultiFab cor, res, rescor; // node, 1 ghost
         MultiFab tmp;              // Jacobi scratch
+        bool agg = false;          // see CellMG::Level
+        LayoutP dist;
+        MultiFab tmp_d;
         MultiFab xb;               // second buffer of the out-of-place fused Gauss-Seidel sweeps
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);

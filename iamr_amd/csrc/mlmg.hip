@@ -9,6 +9,13 @@
 
 namespace iamrx {
 
+long mg_agglomeration_cells()
+{
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("IAMRX_MG_AGGLOMERATE_CELLS"); v = e ? atol(e) : 524288L; }
+    return v;
+}
+
 CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
     : m_g(g), m_ncomp(ncomp), m_bc(bc), m_o(o)
 {
@@ -51,6 +58,11 @@ void CellMG::prepare()
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
+        if (Context::get().comm->nranks > 1 && !c.layout->replicated && c.layout->total_cells() <= mg_agglomeration_cells()) {
+            c.agg = true;
+            c.dist = c.layout;
+            c.layout = c.dist->make_replicated();
+        }
         m_lev.push_back(std::move(c));
     }
     const int nl = (int)m_lev.size();
@@ -61,10 +73,16 @@ void CellMG::prepare()
         L.rescor.define(L.layout, cell_type(), m_ncomp, 0);
         if (l > 0) {
             AbecCoef fc = coef(l - 1);
-            if (m_a0) { L.a.define(L.layout, cell_type(), 1, 0); cc_restrict(L.a, *fc.a); }
+            if (L.agg) L.tmp_d.define(L.dist, cell_type(), m_ncomp, 0);
+            if (m_a0) {
+                L.a.define(L.layout, cell_type(), 1, 0);
+                if (L.agg) { MultiFab t(L.dist, cell_type(), 1, 0); cc_restrict(t, *fc.a); gather_to_replicated(L.a, t); }
+                else cc_restrict(L.a, *fc.a);
+            }
             for (int d = 0; d < 3; ++d) {
                 L.b[d].define(L.layout, face_type(d), fc.b[d]->ncomp, 0);
-                face_avgdown(L.b[d], *fc.b[d], d);
+                if (L.agg) { MultiFab t(L.dist, face_type(d), fc.b[d]->ncomp, 0); face_avgdown(t, *fc.b[d], d); gather_to_replicated(L.b[d], t); }
+                else face_avgdown(L.b[d], *fc.b[d], d);
             }
         }
     }
@@ -248,11 +266,19 @@ void CellMG::vcycle(MGStats& st)
         smooth_n(l, L.cor, L.res, m_o.nu1, true);
         applyBC(l, L.cor, false, nullptr);
         abec_residual(L.g, coef(l), L.rescor, L.cor, &L.res);
+        if (m_lev[l + 1].agg) {
+            cc_restrict(m_lev[l + 1].tmp_d, L.rescor);
+            gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
+        } else
         cc_restrict(m_lev[l + 1].res, L.rescor);
     }
     bottom_solve(st);
     for (int l = nl - 2; l >= 0; --l) {
         Level& L = m_lev[l];
+        if (m_lev[l + 1].agg) {
+            scatter_from_replicated(m_lev[l + 1].tmp_d, m_lev[l + 1].cor, 0);
+            cc_prolong_add(L.cor, m_lev[l + 1].tmp_d);
+        } else
         cc_prolong_add(L.cor, m_lev[l + 1].cor);
         smooth_n(l, L.cor, L.res, m_o.nu2, false);
     }

@@ -55,9 +55,15 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MG
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
+        if (Context::get().comm->nranks > 1 && !c.layout->replicated && c.layout->total_cells() <= mg_agglomeration_cells()) {
+            c.agg = true;
+            c.dist = c.layout;
+            c.layout = c.dist->make_replicated();
+        }
         m_lev.push_back(std::move(c));
     }
     for (auto& L : m_lev) {
+        if (L.agg) L.tmp_d.define(L.dist, node_type(), 1, 1);
         // 4 ghost layers: the plane-fused Gauss-Seidel recomputes its halo instead of exchanging it per colour
         const int ng = nodal_fused() ? 4 : 1;
         L.sig.define(L.layout, cell_type(), 1, ng);
@@ -74,6 +80,11 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
     m_lev[0].sig.FillBoundary(m_lev[0].g);
     cc_mirror_bc(m_lev[0].g, m_lev[0].sig);                // mlndlap_fillbc_cc: mirror sigma across walls
     for (size_t l = 1; l < m_lev.size(); ++l) {
+        if (m_lev[l].agg) {
+            MultiFab sd(m_lev[l].dist, cell_type(), 1, 0);
+            cc_restrict(sd, m_lev[l - 1].sig);
+            gather_to_replicated(m_lev[l].sig, sd);
+        } else
         cc_restrict(m_lev[l].sig, m_lev[l - 1].sig);      // arithmetic average (harmonic averaging off)
         m_lev[l].sig.FillBoundary(m_lev[l].g);
         cc_mirror_bc(m_lev[l].g, m_lev[l].sig);
@@ -214,6 +225,10 @@ void NodalMG::vcycle(MGStats& st)
         for (int i = 0; i < m_o.nu1; ++i) smooth(l, L.cor, L.res);
         residual(l, L.rescor, L.cor, L.res);
         fillbc(l, L.rescor);
+        if (m_lev[l + 1].agg) {
+            nodal_restrict(m_lev[l + 1].tmp_d, L.rescor);
+            gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
+        } else
         nodal_restrict(m_lev[l + 1].res, L.rescor);
     }
     {
@@ -240,6 +255,10 @@ void NodalMG::vcycle(MGStats& st)
     for (int l = nl - 2; l >= 0; --l) {
         Level& L = m_lev[l];
         fillbc(l + 1, m_lev[l + 1].cor);
+        if (m_lev[l + 1].agg) {
+            scatter_from_replicated(m_lev[l + 1].tmp_d, m_lev[l + 1].cor, 1);
+            nodal_interp_add(L.cor, m_lev[l + 1].tmp_d, L.sig);
+        } else
         nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
         for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res);
     }

@@ -14,8 +14,10 @@ BOXES = [((0, 0, 0), (15, 15, 7)), ((0, 0, 8), (15, 15, 15))]
 NSTEPS = 2
 
 
-def run(rank, world, port, out_dir):
+def run(rank, world, port, out_dir, agg, case="tg"):
     sys.path.insert(0, ROOT)
+    if agg is not None:
+        os.environ["IAMRX_MG_AGGLOMERATE_CELLS"] = agg
     from iamr_amd import lib
     from iamr_amd import ns as NS
     lib.init(0)
@@ -28,9 +30,17 @@ def run(rank, world, port, out_dir):
         comm.init_gloo_callback(dist)
     owners = [0, 1] if world > 1 else [0, 0]
     lay = lib.Layout(BOXES, owners)
-    g = lib.Geom.make(N)
-    ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
-    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    if case == "tg":
+        g = lib.Geom.make(N)
+        ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    else:   # lid-driven cavity: walls in every direction, the lid sits on rank 1's box
+        g = lib.Geom.make(N, periodic=(0, 0, 0))
+        lid = [0.0] * 9
+        lid[6] = 1.0
+        ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.3, visc_coef=0.01, init_dt=0.0140625, init_shrink=0.3, init_iter=3, tracer_diff_coef=0.001,
+                                                  phys_lo=[4, 4, 5], phys_hi=[5, 5, 5], wall_vel_hi=lid))
+        ns.init_rest(1.0)
     ns.post_init(-1.0)
     dts = [ns.step() for _ in range(NSTEPS)]
     S = ns.data(NS.NavierStokes.S_NEW)
@@ -47,11 +57,29 @@ def run(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_rank(tmp_path):
+@pytest.mark.parametrize("agg", [None, "0", "64"])
+def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, agg):
+    """agg: multigrid agglomeration threshold in cells (None: default, every coarse level of this small problem is replicated on
+    both ranks; "0": all levels stay distributed; "64": only the 4^3 and 2^3 levels are replicated)"""
     import torch.multiprocessing as mp
     port = 29600 + (os.getpid() % 2000)
-    mp.spawn(run, args=(1, port, str(tmp_path)), nprocs=1, join=True)
-    mp.spawn(run, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(run, args=(1, port, str(tmp_path), agg), nprocs=1, join=True)
+    mp.spawn(run, args=(2, port, str(tmp_path), agg), nprocs=2, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        assert np.array_equal(z["iters"], ref["iters"])
+        key = f"box{r}"
+        assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+def test_two_ranks_lid_driven_cavity(tmp_path):
+    """wall BCs (physical BC fills, Neumann projections, per-component tensor BCs, tracer diffusion) across a rank boundary"""
+    import torch.multiprocessing as mp
+    port = 31600 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "ldc"), nprocs=1, join=True)
+    mp.spawn(run, args=(2, port, str(tmp_path), None, "ldc"), nprocs=2, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
