@@ -12,7 +12,7 @@ namespace iamrx {
 long mg_agglomeration_cells()
 {
     static long v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_MG_AGGLOMERATE_CELLS"); v = e ? atol(e) : 524288L; }
+    if (v < 0) { const char* e = getenv("IAMRX_MG_AGGLOMERATE_CELLS"); v = e ? atol(e) : 2097152L; }
     return v;
 }
 
