@@ -541,6 +541,19 @@ int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
     IAMRX_CATCH
 }
 
+int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int ncomp, int src_ng, int dst_ng, const iamrx_geom* periodic_geom)
+{
+    IAMRX_TRY
+    Geometry g;
+    if (periodic_geom) g = to_geom(periodic_geom);
+    parallel_copy(dst->mf, src->mf, scomp, dcomp, ncomp, src_ng, dst_ng, periodic_geom ? &g : nullptr);
+    IAMRX_CATCH
+}
+int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio)
+{
+    IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH
+}
+
 int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc)
 {
     IAMRX_TRY

@@ -32,6 +32,12 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
                             const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
 { return tensor_solve(g, soln, rhs, a_scalar, b_scalar, acoef, eta, &bc, 1, tol_rel, tol_abs, opts); }
 
+// ---- inter-level data motion (amr.hip) ------------------------------------------------------------------------
+// amrex::MultiFab::ParallelCopy between different layouts of one index space; periodic_geom != nullptr adds the periodic images
+void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom);
+// amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
+void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, int ratio);
+
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {
     double cfl = 0.8, visc_coef = 0.0, be_cn_theta = 0.5, gravity = 0.0;

@@ -257,6 +257,15 @@ def abec_gsrb(geom, alpha, beta, a, b, phi, rhs, redblack, omega=1.15, lobc=(0, 
                                 phi.h, rhs.h, redblack, C.c_double(omega), i3(lobc), i3(hibc), maxorder))
 
 
+def parallel_copy(dst, src, scomp=0, dcomp=0, ncomp=None, src_ng=0, dst_ng=0, periodic_geom=None):
+    nc = src.ncomp if ncomp is None else ncomp
+    check(lib().iamrx_parallel_copy(dst.h, src.h, scomp, dcomp, nc, src_ng, dst_ng, C.byref(periodic_geom) if periodic_geom is not None else None))
+
+
+def average_down(fine, crse, scomp=0, ncomp=None, ratio=2):
+    check(lib().iamrx_average_down(fine.h, crse.h, scomp, crse.ncomp if ncomp is None else ncomp, ratio))
+
+
 def abec_gsrb_sweep(geom, alpha, beta, a, b, phi, rhs, omega=1.15, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=2, fused=1):
     check(lib().iamrx_abec_gsrb_sweep(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
                                       phi.h, rhs.h, C.c_double(omega), i3(lobc), i3(hibc), maxorder, int(fused)))

@@ -190,6 +190,14 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
                        iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, double tol_rel, double tol_abs,
                        const iamrx_mg_opts* o, iamrx_mg_stats* st);
 
+/* ---- inter-level data motion (first building blocks) ------------------------------------------------------ */
+/* amrex::MultiFab::ParallelCopy: dst(valid + dst_ng) <- src(valid + src_ng) wherever they intersect; dst and src may live on
+ * different layouts of the same index space (same index type); periodic_geom != NULL adds the periodic images of src */
+int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int ncomp, int src_ng, int dst_ng, const iamrx_geom* periodic_geom);
+/* amrex::average_down / average_down_faces / average_down_nodal (by index type) as called from NavierStokesBase::avgDown_StatePress
+ * (Source/NavierStokesBase.cpp:4125-4193): crse(scomp..) <- mean / injection of fine(scomp..); ratio 2 or 4 */
+int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio);
+
 /* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */
 typedef struct iamrx_ns_params {
     double cfl, visc_coef, be_cn_theta, gravity;
