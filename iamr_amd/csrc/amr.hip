@@ -10,6 +10,8 @@
 #include "launch.h"
 #include <map>
 #include <cstring>
+#include <cmath>
+#include <algorithm>
 
 namespace iamrx {
 
@@ -136,6 +138,224 @@ void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, in
     MultiFab cf(cfl, crse.type, ncomp, 0);
     coarsen_onto(cf, fine, scomp, ncomp, ratio);
     parallel_copy(crse, cf, 0, scomp, ncomp, 0, 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// FillPatch on a refined level (AmrLevel::FillPatch -> amrex::FillPatchTwoLevels with the StateDescriptor's interpolater,
+// `cell_cons_interp` for State_Type and Gradp_Type, reference Source/NS_setup.cpp:206-394):
+//   1. same-level data (time-interpolated between the old and new StateData) -> dst valid + ghost cells, periodic images incl.
+//   2. the part of dst inside the (periodically extended) domain that no fine box covers is interpolated from the coarse
+//      level: the coarse data (time-interpolated, physical BC applied at the coarse domain boundary) are gathered on
+//      coarsen(region) grown by one cell and prolonged with amrex::CellConservativeLinear (linear limiting on):
+//        central slopes (one-sided 4-point formula next to an ext_dir / hoextrap domain face), limited slope
+//        s = sign(dc) min(|dc|, 2|forward|, 2|backward|) (0 at an extremum), one factor alpha_d = min_n s_n/dc_n per direction
+//        shared by ALL components (the limiter stays linear in the state), fine = crse + sum_d off_d alpha_d dc_d
+//   3. physical BC fill of dst at the fine domain boundary.
+// The regions of step 2 and the coarse gather layout depend only on the two fine layouts and are cached.
+namespace {
+
+void box_diff(const BoxD& b, const BoxD& cut, std::vector<BoxD>& out)   // b minus cut
+{
+    const BoxD in = intersect(b, cut);
+    if (!in.ok()) { out.push_back(b); return; }
+    BoxD rem = b;
+    for (int d = 2; d >= 0; --d) {
+        if (rem.lo[d] < in.lo[d]) { BoxD p = rem; p.hi[d] = in.lo[d] - 1; out.push_back(p); rem.lo[d] = in.lo[d]; }
+        if (rem.hi[d] > in.hi[d]) { BoxD p = rem; p.lo[d] = in.hi[d] + 1; out.push_back(p); rem.hi[d] = in.hi[d]; }
+    }
+}
+
+struct FPInfo {
+    LayoutP fine_patch;       // uncovered regions (fine index space), owner = owner of the dst box
+    LayoutP crse_patch;       // coarsen(region) grown by 2
+    std::vector<int> dst_local;   // per LOCAL patch box: local fab index of dst
+    int* d_dst_local = nullptr;
+    ~FPInfo() { if (d_dst_local) Context::get().free(d_dst_local); }
+};
+
+struct FPKey {
+    uint64_t dl, fl; int ng, ratio; int per[3]; int dlo[3], dhi[3];
+    bool operator<(const FPKey& o) const { return std::memcmp(this, &o, sizeof(FPKey)) < 0; }
+};
+
+const FPInfo& fp_info(const Layout& dl, const Layout& fl, int ng, int ratio, const Geometry& fgeom)
+{
+    static std::map<FPKey, std::unique_ptr<FPInfo>> cache;
+    FPKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.dl = dl.id; key.fl = fl.id; key.ng = ng; key.ratio = ratio;
+    for (int d = 0; d < 3; ++d) { key.per[d] = fgeom.periodic[d]; key.dlo[d] = fgeom.domain.lo[d]; key.dhi[d] = fgeom.domain.hi[d]; }
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+    auto info = std::make_unique<FPInfo>();
+    const int me = Context::get().comm->rank;
+    // fine valid boxes and their periodic images
+    std::vector<BoxD> covered;
+    int smin[3] = {0, 0, 0}, smax[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) if (fgeom.periodic[d]) { smin[d] = -1; smax[d] = 1; }
+    for (auto& b : fl.boxes)
+        for (int sz = smin[2]; sz <= smax[2]; ++sz) for (int sy = smin[1]; sy <= smax[1]; ++sy) for (int sx = smin[0]; sx <= smax[0]; ++sx) {
+            BoxD q = b;
+            q = shift(q, 0, sx * fgeom.domain.len(0)); q = shift(q, 1, sy * fgeom.domain.len(1)); q = shift(q, 2, sz * fgeom.domain.len(2));
+            covered.push_back(q);
+        }
+    BoxD dext = fgeom.domain;                    // cells outside it are the physical BC's business
+    for (int d = 0; d < 3; ++d) if (fgeom.periodic[d]) { dext.lo[d] -= ng; dext.hi[d] += ng; }
+    std::vector<BoxD> fboxes, cboxes;
+    std::vector<int> owners, dst_of;
+    for (int g = 0; g < (int)dl.boxes.size(); ++g) {
+        std::vector<BoxD> todo{intersect(grow(dl.boxes[g], ng), dext)};
+        if (!todo[0].ok()) continue;
+        for (auto& c : covered) {
+            std::vector<BoxD> next;
+            for (auto& t : todo) box_diff(t, c, next);
+            todo.swap(next);
+            if (todo.empty()) break;
+        }
+        for (auto& u : todo) {
+            fboxes.push_back(u);
+            // one cell for the central slopes + one more so that the 4-point one-sided slope next to an ext_dir / hoextrap
+            // domain face never has to fall back to its short form (the result then does not depend on how the uncovered region
+            // happens to be chopped into boxes)
+            cboxes.push_back(grow(coarsen(u, ratio), 2));
+            owners.push_back(dl.owner[g]);
+            dst_of.push_back(g);
+        }
+    }
+    info->fine_patch = std::make_shared<Layout>(fboxes, owners, me);
+    info->crse_patch = std::make_shared<Layout>(cboxes, owners, me);
+    for (int p : info->fine_patch->local) info->dst_local.push_back(dl.local_of[dst_of[p]]);
+    if (!info->dst_local.empty()) {
+        auto& ctx = Context::get();
+        info->d_dst_local = (int*)ctx.alloc(info->dst_local.size() * sizeof(int));
+        IAMRX_HIP_CHECK(hipMemcpyAsync(info->d_dst_local, info->dst_local.data(), info->dst_local.size() * sizeof(int), hipMemcpyHostToDevice, ctx.stream));
+        ctx.sync();
+    }
+    return *cache.emplace(key, std::move(info)).first->second;
+}
+
+// StateData time interpolation (amrex::FillPatchSingleLevel): old or new if `time` is within 1e-3 (t_new - t_old) of it
+const MultiFab* time_interp(const TimeData& td, double time, int scomp, int ncomp, MultiFab& tmp, int& comp0)
+{
+    comp0 = scomp;
+    if (!td.old_ || td.old_ == td.new_) return td.new_;
+    const double eps = 1.e-3 * std::abs(td.t_new - td.t_old);
+    if (std::abs(time - td.t_new) <= eps) return td.new_;
+    if (std::abs(time - td.t_old) <= eps) return td.old_;
+    tmp.define(td.new_->layout, td.new_->type, ncomp, 0);
+    const double a = (td.t_new - time) / (td.t_new - td.t_old), b = (time - td.t_old) / (td.t_new - td.t_old);
+    const FabD *tt = tmp.d_tab, *ot = td.old_->d_tab, *nt = td.new_->d_tab;
+    for_each(*tmp.layout, tmp.type, 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        for (int n = 0; n < ncomp; ++n) tt[f](i, j, k, n) = a * ot[f](i, j, k, scomp + n) + b * nt[f](i, j, k, scomp + n);
+    });
+    comp0 = 0;
+    return &tmp;
+}
+
+struct InterpBC { int dlo[3], dhi[3]; int lo[8][3], hi[8][3]; };   // coarse domain + BCType per component
+
+// unlimited central slope of component n in direction D at coarse cell c (pointer + stride), amrex::mf_compute_slopes_{x,y,z}
+__device__ __forceinline__ double cslope(const double* u, long s, int idx, int plo, int phi, int domlo, int domhi, int bclo, int bchi)
+{
+    double dc = 0.5 * (u[s] - u[-s]);
+    if (idx == domlo && (bclo == bc_ext_dir || bclo == bc_hoextrap)) {
+        if (idx + 2 <= phi) dc = -16. / 15. * u[-s] + 0.5 * u[0] + 2. / 3. * u[s] - 0.1 * u[2 * s];
+        else dc = 0.25 * (u[s] + 5. * u[0] - 6. * u[-s]);
+    }
+    if (idx == domhi && (bchi == bc_ext_dir || bchi == bc_hoextrap)) {
+        if (idx - 2 >= plo) dc = 16. / 15. * u[s] - 0.5 * u[0] - 2. / 3. * u[-s] + 0.1 * u[-2 * s];
+        else dc = -0.25 * (u[-s] + 5. * u[0] - 6. * u[s]);
+    }
+    return dc;
+}
+
+__global__ void __launch_bounds__(256) k_cellconslin(const BoxD* __restrict__ pboxes, const int* __restrict__ dst_local, const FabD* __restrict__ dstt,
+    const FabD* __restrict__ crt, int dcomp, int ncomp, int ratio, InterpBC bc)
+{
+    const int p = blockIdx.y;
+    const BoxD b = pboxes[p];
+    const FabD dst = dstt[dst_local[p]], cr = crt[p];
+    const long npts = b.npts();
+    const int nx = b.len(0), ny = b.len(1);
+    const long s[3] = {1, (long)cr.n[0], (long)cr.n[0] * cr.n[1]};
+    const double rinv = 1.0 / (double)ratio;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        const int i = b.lo[0] + (int)(q % nx), j = b.lo[1] + (int)((q / nx) % ny), k = b.lo[2] + (int)(q / ((long)nx * ny));
+        const int f[3] = {i, j, k};
+        int c[3];
+        double off[3];
+        for (int d = 0; d < 3; ++d) {
+            c[d] = f[d] >= 0 ? f[d] / ratio : -((-f[d] + ratio - 1) / ratio);
+            off[d] = ((double)(f[d] - c[d] * ratio) + 0.5) * rinv - 0.5;
+        }
+        const long co = cr.off(c[0], c[1], c[2]);
+        // per-direction limiter factor common to all components
+        double alpha[3] = {1.0, 1.0, 1.0};
+        for (int n = 0; n < ncomp; ++n) {
+            const double* u = cr.p + co + cr.cs * n;
+            for (int d = 0; d < 3; ++d) {
+                const double dc = cslope(u, s[d], c[d], cr.lo[d], cr.lo[d] + cr.n[d] - 1, bc.dlo[d], bc.dhi[d], bc.lo[n][d], bc.hi[n][d]);
+                const double df = 2.0 * (u[s[d]] - u[0]), db = 2.0 * (u[0] - u[-s[d]]);
+                double sl = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+                sl = copysign(1.0, dc) * fmin(sl, fabs(dc));
+                if (dc != 0.0) alpha[d] = fmin(alpha[d], sl / dc);
+            }
+        }
+        for (int n = 0; n < ncomp; ++n) {
+            const double* u = cr.p + co + cr.cs * n;
+            double v = u[0];
+            for (int d = 0; d < 3; ++d) {
+                const double dc = cslope(u, s[d], c[d], cr.lo[d], cr.lo[d] + cr.n[d] - 1, bc.dlo[d], bc.dhi[d], bc.lo[n][d], bc.hi[n][d]);
+                v += off[d] * (alpha[d] * dc);
+            }
+            dst(i, j, k, dcomp + n) = v;
+        }
+    }
+}
+
+}  // namespace
+
+void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
+                          const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi)
+{
+    IAMRX_ASSERT(dst.type.cell() && ncomp <= 8 && (ratio == 2 || ratio == 4));
+    auto& ctx = Context::get();
+    const int ng = dst.ngrow;
+    // 1. same level
+    MultiFab ftmp, ctmp;
+    int fc0, cc0;
+    const MultiFab* fs = time_interp(fine, time, scomp, ncomp, ftmp, fc0);
+    parallel_copy(dst, *fs, fc0, dcomp, ncomp, 0, ng, &fgeom);
+    // 2. coarse-fine
+    const FPInfo& info = fp_info(*dst.layout, *fine.new_->layout, ng, ratio, fgeom);
+    if (!info.fine_patch->boxes.empty()) {
+        const MultiFab* cs = time_interp(crse, time, scomp, ncomp, ctmp, cc0);
+        MultiFab cmf(info.crse_patch, cell_type(), ncomp, 0);
+        parallel_copy(cmf, *cs, cc0, 0, ncomp, 0, 0, &cgeom);
+        bool any_wall = false;
+        for (int d = 0; d < 3; ++d) any_wall = any_wall || !cgeom.periodic[d];
+        if (any_wall) fill_physbc_cc(cgeom, cmf, 0, ncomp, bc, extdir_lo, extdir_hi);
+        const Layout& pl = *info.fine_patch;
+        if (pl.nlocal() > 0) {
+            InterpBC ib;
+            for (int d = 0; d < 3; ++d) {
+                ib.dlo[d] = cgeom.domain.lo[d]; ib.dhi[d] = cgeom.domain.hi[d];
+                for (int n = 0; n < 8; ++n) {
+                    ib.lo[n][d] = (n < ncomp && !cgeom.periodic[d] && bc) ? bc[n].lo[d] : (int)bc_int_dir;
+                    ib.hi[n][d] = (n < ncomp && !cgeom.periodic[d] && bc) ? bc[n].hi[d] : (int)bc_int_dir;
+                }
+            }
+            long maxpts = 0;
+            for (int li = 0; li < pl.nlocal(); ++li) maxpts = std::max(maxpts, pl.lbox(li).npts());
+            const unsigned gx = (unsigned)std::min<long>((maxpts + 255) / 256, 1024);
+            hipLaunchKernelGGL(k_cellconslin, dim3(gx, (unsigned)pl.nlocal()), dim3(256), 0, ctx.stream, pl.d_boxes, info.d_dst_local, dst.d_tab,
+                               cmf.d_tab, dcomp, ncomp, ratio, ib);
+        }
+    }
+    // 3. physical BC at the fine domain boundary
+    bool any_wall = false;
+    for (int d = 0; d < 3; ++d) any_wall = any_wall || !fgeom.periodic[d];
+    if (any_wall) fill_physbc_cc(fgeom, dst, dcomp, ncomp, bc, extdir_lo, extdir_hi);
 }
 
 }  // namespace iamrx

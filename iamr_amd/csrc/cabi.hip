@@ -549,6 +549,17 @@ int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int nc
     parallel_copy(dst->mf, src->mf, scomp, dcomp, ncomp, src_ng, dst_ng, periodic_geom ? &g : nullptr);
     IAMRX_CATCH
 }
+int iamrx_fillpatch_two_levels(iamrx_mf dst, int dcomp, double time, iamrx_mf fine_old, iamrx_mf fine_new, double t_fine_old, double t_fine_new,
+                               iamrx_mf crse_old, iamrx_mf crse_new, double t_crse_old, double t_crse_new, int scomp, int ncomp,
+                               const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio, const int* bcrec, const double* edlo, const double* edhi)
+{
+    IAMRX_TRY
+    auto bc = to_bcrec(bcrec, ncomp);
+    TimeData f{fine_old ? &fine_old->mf : nullptr, &fine_new->mf, t_fine_old, t_fine_new};
+    TimeData c{crse_old ? &crse_old->mf : nullptr, &crse_new->mf, t_crse_old, t_crse_new};
+    fillpatch_two_levels(dst->mf, dcomp, time, f, c, scomp, ncomp, to_geom(cgeom), to_geom(fgeom), ratio, bc.data(), edlo, edhi);
+    IAMRX_CATCH
+}
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio)
 {
     IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_physbc(const PhysBcDesc* __restrict__ d
 // bc[n], extdir_lo/hi[n*3+d] for the ncomp components starting at scomp (ncomp <= 8)
 void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const BCRec* bc, const double* extdir_lo, const double* extdir_hi)
 {
-    if (mf.nlocal() == 0 || mf.ngrow == 0) return;
+    if (mf.nlocal() == 0) return;      // ngrow may be 0: patch arrays (coarse-fine interpolation) extend beyond the domain as such
     IAMRX_ASSERT(ncomp <= 8 && mf.type.cell());
     auto& ctx = Context::get();
     for (int d = 0; d < 3; ++d) {

@@ -37,6 +37,11 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
 void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, int ratio);
+// StateData of one level: old/new MultiFabs and their times (old_ may be null: only one time level)
+struct TimeData { const MultiFab* old_; const MultiFab* new_; double t_old, t_new; };
+// AmrLevel::FillPatch on a refined level (FillPatchTwoLevels + CellConservativeLinear + physical BC), see amr.hip
+void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
+                          const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
 
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {

@@ -262,6 +262,17 @@ def parallel_copy(dst, src, scomp=0, dcomp=0, ncomp=None, src_ng=0, dst_ng=0, pe
     check(lib().iamrx_parallel_copy(dst.h, src.h, scomp, dcomp, nc, src_ng, dst_ng, C.byref(periodic_geom) if periodic_geom is not None else None))
 
 
+def fillpatch_two_levels(dst, time, fine, crse, cgeom, fgeom, scomp=0, ncomp=None, dcomp=0, ratio=2, bc=None, extdir_lo=None, extdir_hi=None):
+    """fine / crse: (old MultiFab or None, new MultiFab, t_old, t_new)"""
+    nc = dst.ncomp if ncomp is None else ncomp
+    el = None if extdir_lo is None else (C.c_double * (3 * nc))(*[float(x) for row in extdir_lo for x in row])
+    eh = None if extdir_hi is None else (C.c_double * (3 * nc))(*[float(x) for row in extdir_hi for x in row])
+    bcs = bc if bc is not None else [((0, 0, 0), (0, 0, 0))] * nc
+    check(lib().iamrx_fillpatch_two_levels(dst.h, dcomp, C.c_double(time), _h(fine[0]), fine[1].h, C.c_double(fine[2]), C.c_double(fine[3]),
+                                           _h(crse[0]), crse[1].h, C.c_double(crse[2]), C.c_double(crse[3]), scomp, nc,
+                                           C.byref(cgeom), C.byref(fgeom), ratio, _bcrec(nc, bcs), el, eh))
+
+
 def average_down(fine, crse, scomp=0, ncomp=None, ratio=2):
     check(lib().iamrx_average_down(fine.h, crse.h, scomp, crse.ncomp if ncomp is None else ncomp, ratio))
 

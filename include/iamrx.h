@@ -197,6 +197,15 @@ int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int nc
 /* amrex::average_down / average_down_faces / average_down_nodal (by index type) as called from NavierStokesBase::avgDown_StatePress
  * (Source/NavierStokesBase.cpp:4125-4193): crse(scomp..) <- mean / injection of fine(scomp..); ratio 2 or 4 */
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio);
+/* AmrLevel::FillPatch of cell-centred StateData on a refined level = amrex::FillPatchTwoLevels with cell_cons_interp
+ * (CellConservativeLinear, linear limiting), the interpolater IAMR registers for State_Type / Gradp_Type (Source/NS_setup.cpp:206-394;
+ * call sites e.g. Source/NavierStokesBase.cpp:3382-3418, 4399-4435): dst (fine layout, dst ghost width) <- fine data where a fine box
+ * (or its periodic image) exists, conservative-linear interpolation of the coarse data elsewhere inside the domain, physical BC
+ * outside; both levels are linearly interpolated in time between their old and new data (old may be NULL).
+ * bcrec: ncomp x {lo[3], hi[3]} amrex::BCType codes; extdir_*: [n*3+d] ext_dir values (NS_bcfill.H) or NULL */
+int iamrx_fillpatch_two_levels(iamrx_mf dst, int dcomp, double time, iamrx_mf fine_old, iamrx_mf fine_new, double t_fine_old, double t_fine_new,
+                               iamrx_mf crse_old, iamrx_mf crse_new, double t_crse_old, double t_crse_new, int scomp, int ncomp,
+                               const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio, const int* bcrec, const double* extdir_lo, const double* extdir_hi);
 
 /* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */
 typedef struct iamrx_ns_params {

@@ -61,6 +61,10 @@ typedef struct orc_bcrec { int lo[3]; int hi[3]; } orc_bcrec;
 void orc_fill_periodic(orc_fab* f, const orc_geom* g, const int type[3]);
 /* physical BC fill of cell-centred ghost cells outside the domain (foextrap, hoextrap,
  * reflect_even/odd, ext_dir with constant value) -- NS_bcfill.H + amrex FilccCell */
+/* coarse-fine part of FillPatchTwoLevels with CellConservativeLinear (see orc_fill.c) */
+void orc_fill_coarse_fine(orc_fab* fine, const int flo[3], const int fhi[3], const int vlo[3], const int vhi[3],
+                          const orc_fab* crse, const int cdomlo[3], const int cdomhi[3], const int periodic[3], int ratio,
+                          const orc_bcrec* bc);
 void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
                         const double* extdir_lo /*[nc][3]*/, const double* extdir_hi);
 

@@ -100,3 +100,67 @@ void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
             physbc_dir(f, g, d, n, bc[n].lo[d], bc[n].hi[d], el, eh);
         }
 }
+
+/* ---- coarse-fine fill (amrex::FillPatchTwoLevels with CellConservativeLinear, linear limiting; the interpolater IAMR
+ * registers for State_Type / Gradp_Type, reference Source/NS_setup.cpp:206-394).  Published algorithm restated:
+ * unlimited central slope dc (one-sided 4-point formula in the coarse cell next to an ext_dir / hoextrap domain face), limited
+ * slope s = sign(dc) min(|dc|, 2|u(i+1)-u(i)|, 2|u(i)-u(i-1)|) or 0 at an extremum, ONE factor per direction
+ * alpha_d = min over the components of s/dc, fine = crse + sum_d offset_d * alpha_d * dc_d.
+ * crse: coarse level data with >= 1 filled ghost cell (periodic / physical BC already applied), covering what is needed.
+ * Fills every cell of `fine` (incl. ghosts) that lies inside [flo,fhi] (the region to fill) but OUTSIDE [vlo,vhi] (the fine
+ * level's own valid box). */
+static double cf_cslope(const orc_fab* u, const int c[3], int n, int d, int domlo, int domhi, int bclo, int bchi)
+{
+    int m[3] = {c[0], c[1], c[2]}, p[3] = {c[0], c[1], c[2]};
+    m[d] -= 1; p[d] += 1;
+    double dc = 0.5 * (A4(u, p[0], p[1], p[2], n) - A4(u, m[0], m[1], m[2], n));
+    const double um = A4(u, m[0], m[1], m[2], n), u0 = A4(u, c[0], c[1], c[2], n), up = A4(u, p[0], p[1], p[2], n);
+    if (c[d] == domlo && (bclo == ORC_BC_EXT_DIR || bclo == ORC_BC_HOEXTRAP)) {
+        int pp[3] = {c[0], c[1], c[2]}; pp[d] += 2;
+        if (pp[d] <= u->hi[d]) dc = -16. / 15. * um + 0.5 * u0 + 2. / 3. * up - 0.1 * A4(u, pp[0], pp[1], pp[2], n);
+        else dc = 0.25 * (up + 5. * u0 - 6. * um);
+    }
+    if (c[d] == domhi && (bchi == ORC_BC_EXT_DIR || bchi == ORC_BC_HOEXTRAP)) {
+        int mm[3] = {c[0], c[1], c[2]}; mm[d] -= 2;
+        if (mm[d] >= u->lo[d]) dc = 16. / 15. * up - 0.5 * u0 - 2. / 3. * um + 0.1 * A4(u, mm[0], mm[1], mm[2], n);
+        else dc = -0.25 * (um + 5. * u0 - 6. * up);
+    }
+    return dc;
+}
+
+void orc_fill_coarse_fine(orc_fab* fine, const int flo[3], const int fhi[3], const int vlo[3], const int vhi[3],
+                          const orc_fab* crse, const int cdomlo[3], const int cdomhi[3], const int periodic[3], int ratio,
+                          const orc_bcrec* bc)
+{
+    const int nc = fine->nc;
+    for (int k = flo[2]; k <= fhi[2]; ++k) for (int j = flo[1]; j <= fhi[1]; ++j) for (int i = flo[0]; i <= fhi[0]; ++i) {
+        if (i >= vlo[0] && i <= vhi[0] && j >= vlo[1] && j <= vhi[1] && k >= vlo[2] && k <= vhi[2]) continue;
+        const int f[3] = {i, j, k};
+        int c[3];
+        double off[3], alpha[3] = {1.0, 1.0, 1.0};
+        for (int d = 0; d < 3; ++d) {
+            c[d] = f[d] >= 0 ? f[d] / ratio : -((-f[d] + ratio - 1) / ratio);
+            off[d] = ((double)(f[d] - c[d] * ratio) + 0.5) / (double)ratio - 0.5;
+        }
+        for (int n = 0; n < nc; ++n)
+            for (int d = 0; d < 3; ++d) {
+                const int bl = periodic[d] ? ORC_BC_INT_DIR : bc[n].lo[d], bh = periodic[d] ? ORC_BC_INT_DIR : bc[n].hi[d];
+                const double dc = cf_cslope(crse, c, n, d, cdomlo[d], cdomhi[d], bl, bh);
+                int m[3] = {c[0], c[1], c[2]}, p[3] = {c[0], c[1], c[2]};
+                m[d] -= 1; p[d] += 1;
+                const double u0 = A4(crse, c[0], c[1], c[2], n);
+                const double df = 2.0 * (A4(crse, p[0], p[1], p[2], n) - u0), db = 2.0 * (u0 - A4(crse, m[0], m[1], m[2], n));
+                double sl = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+                sl = copysign(1.0, dc) * fmin(sl, fabs(dc));
+                if (dc != 0.0) alpha[d] = fmin(alpha[d], sl / dc);
+            }
+        for (int n = 0; n < nc; ++n) {
+            double v = A4(crse, c[0], c[1], c[2], n);
+            for (int d = 0; d < 3; ++d) {
+                const int bl = periodic[d] ? ORC_BC_INT_DIR : bc[n].lo[d], bh = periodic[d] ? ORC_BC_INT_DIR : bc[n].hi[d];
+                v += off[d] * (alpha[d] * cf_cslope(crse, c, n, d, cdomlo[d], cdomhi[d], bl, bh));
+            }
+            A4(fine, i, j, k, n) = v;
+        }
+    }
+}

@@ -63,3 +63,71 @@ def test_average_down_fine_patch_onto_coarse_level(gpu, typ):
     assert np.array_equal(got[..., 0], Cg[..., 0])                       # untouched component
     assert np.abs(got[..., 1:3] - exp[..., 1:3]).max() <= 1e-15
     assert np.abs(got - Cg).max() > 0.1
+
+
+def test_fillpatch_two_levels_matches_oracle(orc, gpu):
+    """AmrLevel::FillPatch on a refined level: same-level copy, periodic image, conservative-linear (linear-limited) interpolation
+    from the time-interpolated coarse level, physical BC -- all ghost cells of a 2-box fine patch that touches a periodic
+    boundary (x-lo) and a wall (y-lo) against the CPU oracle.  Tolerance: 1e-13 (same formulas, different summation order of
+    the time interpolation)."""
+    import ctypes as C
+    lib = gpu
+    L = orc.lib()
+    nc, nf, ncomp, ng, ratio = (16, 16, 16), (32, 32, 32), 3, 3, 2
+    per = (1, 0, 1)
+    cg = lib.Geom.make(nc, periodic=per)
+    fg = lib.Geom.make(nf, periodic=per)
+    crse_lay = lib.Layout.decompose(nc, (8, 16, 8))
+    # fine patch: coarse cells [0..7] x [0..7] x [4..11]  ->  fine [0..15] x [0..15] x [8..23], two boxes split in z
+    fboxes = [((0, 0, 8), (15, 15, 15)), ((0, 0, 16), (15, 15, 23))]
+    fine_lay = lib.Layout(fboxes, [0, 0])
+    # comp 0: foextrap at the walls, comp 1: ext_dir (values 0.3 / -0.2), comp 2: hoextrap
+    bcs = [((0, 2, 0), (0, 2, 0)), ((0, 3, 0), (0, 3, 0)), ((0, 4, 0), (0, 4, 0))]
+    edlo = [[0.0, 0.0, 0.0], [0.0, 0.3, 0.0], [0.0, 0.0, 0.0]]
+    edhi = [[0.0, 0.0, 0.0], [0.0, -0.2, 0.0], [0.0, 0.0, 0.0]]
+    rng = np.random.default_rng(8)
+    xc = [(np.arange(nc[d]) + 0.5) / nc[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*xc, indexing="ij")
+    def smooth(seed):
+        r = np.random.default_rng(seed)
+        out = np.zeros(nc + (ncomp,))
+        for n in range(ncomp):
+            a, b, c = r.random(3)
+            out[..., n] = np.sin(2 * np.pi * (X + a)) * np.cos(np.pi * (Y + b)) * np.sin(2 * np.pi * (Z + c)) + 0.3 * r.standard_normal(nc)
+        return out
+    Cold, Cnew = smooth(1), smooth(2)
+    Fnew = rng.standard_normal(nf + (ncomp,))
+    t_co, t_cn, time = 0.0, 1.0, 0.3
+    cold = lib.MultiFab(crse_lay, lib.CELL, ncomp, 0); cold.set_from_global(Cold, (0, 0, 0))
+    cnew = lib.MultiFab(crse_lay, lib.CELL, ncomp, 0); cnew.set_from_global(Cnew, (0, 0, 0))
+    fnew = lib.MultiFab(fine_lay, lib.CELL, ncomp, 0); fnew.set_from_global(Fnew, (0, 0, 0))
+    dst = lib.MultiFab(fine_lay, lib.CELL, ncomp, ng); dst.setval(-99.0)
+    lib.fillpatch_two_levels(dst, time, (None, fnew, time, time), (cold, cnew, t_co, t_cn), cg, fg, bc=bcs, extdir_lo=edlo, extdir_hi=edhi, ratio=ratio)
+    # ---- oracle
+    g_c = orc.geom(nc, periodic=per)
+    g_f = orc.geom(nf, periodic=per)
+    cf = orc.Fab(nc, orc.CELL, 4, ncomp)
+    cf.a[4:-4, 4:-4, 4:-4, :] = (t_cn - time) / (t_cn - t_co) * Cold + (time - t_co) / (t_cn - t_co) * Cnew
+    L.orc_fill_periodic(cf.ref(), C.byref(g_c), orc.i3(orc.CELL))
+    bcr = (orc.CBCRec * ncomp)()
+    for n in range(ncomp):
+        bcr[n].lo = (C.c_int * 3)(*bcs[n][0]); bcr[n].hi = (C.c_int * 3)(*bcs[n][1])
+    el = (C.c_double * 9)(*[v for row in edlo for v in row]); eh = (C.c_double * 9)(*[v for row in edhi for v in row])
+    L.orc_fill_physbc_cc(cf.ref(), C.byref(g_c), bcr, el, eh)
+    vlo, vhi = (0, 0, 8), (15, 15, 23)
+    ff = orc.Fab(nf, orc.CELL, 0, ncomp, lo=tuple(v - ng for v in vlo), hi=tuple(v + ng for v in vhi))
+    ff.a[...] = -99.0
+    ff.a[ng:-ng, ng:-ng, ng:-ng, :] = Fnew[vlo[0]:vhi[0] + 1, vlo[1]:vhi[1] + 1, vlo[2]:vhi[2] + 1]
+    flo = [vlo[d] - ng if per[d] else max(vlo[d] - ng, 0) for d in range(3)]
+    fhi = [vhi[d] + ng if per[d] else min(vhi[d] + ng, nf[d] - 1) for d in range(3)]
+    # periodic image of the fine patch itself: x spans [0,15] only, so ghost cells at x < 0 come from the coarse level
+    L.orc_fill_coarse_fine(ff.ref(), orc.i3(flo), orc.i3(fhi), orc.i3(vlo), orc.i3(vhi), cf.ref(), orc.i3((0, 0, 0)), orc.i3(tuple(v - 1 for v in nc)),
+                           orc.i3(per), ratio, bcr)
+    L.orc_fill_physbc_cc(ff.ref(), C.byref(g_f), bcr, el, eh)
+    # ---- compare every cell (valid + ghost) of both fine boxes
+    for li in range(dst.nlocal()):
+        a, lo = dst.to_numpy(li)
+        sl = tuple(slice(lo[d] - ff.lo[d], lo[d] - ff.lo[d] + a.shape[d]) for d in range(3))
+        ref = ff.a[sl]
+        assert np.abs(ref).max() < 50.0                        # every cell was filled by the oracle
+        assert np.abs(a - ref).max() <= 1e-13, (li, np.abs(a - ref).max())
