@@ -80,7 +80,7 @@ void build_parallel_copy_plan_host(const std::vector<BoxD>& dboxes, const std::v
     }
 }
 
-void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom)
+void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add)
 {
     IAMRX_ASSERT(dst.type.t[0] == src.type.t[0] && dst.type.t[1] == src.type.t[1] && dst.type.t[2] == src.type.t[2]);
     IAMRX_ASSERT(src_ng <= src.ngrow && dst_ng <= dst.ngrow && scomp + nc <= src.ncomp && dcomp + nc <= dst.ncomp);
@@ -105,7 +105,7 @@ void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int
         }
         it = cache.emplace(key, std::move(plan)).first;
     }
-    execute_plan(*it->second, dst, src, scomp, dcomp, nc);
+    execute_plan(*it->second, dst, src, scomp, dcomp, nc, add);
 }
 
 // fine -> coarsened-fine layout: mean of the ratio^3 children (cells), of the ratio^2 coplanar children (faces), injection (nodes)
@@ -356,6 +356,108 @@ void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData&
     bool any_wall = false;
     for (int d = 0; d < 3; ++d) any_wall = any_wall || !fgeom.periodic[d];
     if (any_wall) fill_physbc_cc(fgeom, dst, dcomp, ncomp, bc, extdir_lo, extdir_hi);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Flux register of a coarse-fine interface (amrex::FluxRegister / YAFluxRegister as IAMR uses them: advective registers in
+// NavierStokesBase::ComputeAofs, reference Source/NavierStokesBase.cpp:5036-5096; viscous registers in
+// NavierStokes::scalar_diffusion_update / Diffusion::diffuse_tensor_velocity, Source/NavierStokes.cpp:975-992,
+// Source/Diffusion.cpp:940-953; consumed by NavierStokes::reflux, Source/NavierStokes.cpp:1736-1838).
+// One register value per coarse face on the boundary of every (coarsened) fine box, per component:
+//   CrseInit / CrseAdd : reg  = / += mult * coarse flux          (IAMR: mult = -dt_crse, fluxes already area-weighted)
+//   FineAdd            : reg += mult * sum of the ratio^2 fine fluxes on that coarse face   (mult = +dt_fine)
+//   Reflux             : S(coarse cell outside the fine box) -= / += scale * reg / volume   (low / high side of the fine box)
+// Storage: per direction and side one face-type MultiFab on the layout of one-cell-thick slabs of OUTSIDE coarse cells
+// (owner = owner of the fine box); the register lives on the slab's face that touches the fine box.  Reflux adds the six
+// slab sets one after the other (slabs of one set are disjoint), with the periodic images of the coarse domain.
+FluxRegister::FluxRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, int ratio, int ncomp)
+    : m_fine(std::move(fine)), m_crse(std::move(crse)), m_cgeom(cgeom), m_ratio(ratio), m_ncomp(ncomp)
+{
+    for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+            std::vector<BoxD> slabs;
+            for (auto& b : m_fine->boxes) {
+                BoxD cb = coarsen(b, ratio);
+                BoxD s = cb;
+                if (side == 0) { s.lo[d] = s.hi[d] = cb.lo[d] - 1; } else { s.lo[d] = s.hi[d] = cb.hi[d] + 1; }
+                slabs.push_back(s);
+            }
+            m_slab[d][side] = std::make_shared<Layout>(slabs, m_fine->owner, Context::get().comm->rank);
+            m_reg[d][side].define(m_slab[d][side], face_type(d), ncomp, 0);
+            m_reg[d][side].setVal(0.0);
+        }
+}
+
+void FluxRegister::setVal(double v)
+{
+    for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) m_reg[d][s].setVal(v);
+}
+
+void FluxRegister::CrseInit(const MultiFab& flux, int dir, int scomp, int dcomp, int nc, double mult, bool add)
+{
+    IAMRX_ASSERT(flux.type.t[dir] == 1 && dcomp + nc <= m_ncomp);
+    for (int side = 0; side < 2; ++side) {
+        MultiFab& reg = m_reg[dir][side];
+        MultiFab tmp(m_slab[dir][side], face_type(dir), nc, 0);
+        tmp.setVal(0.0);
+        parallel_copy(tmp, flux, scomp, 0, nc, 0, 0, nullptr);
+        const FabD *rt = reg.d_tab, *tt = tmp.d_tab;
+        const BoxD* sb = m_slab[dir][side]->d_boxes;
+        const int plane_off = side == 0 ? 1 : 0;       // the slab's face that touches the fine box
+        for_each(*m_slab[dir][side], cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            int q[3] = {i, j, k};
+            q[dir] = (dir == 0 ? sb[f].lo[0] : (dir == 1 ? sb[f].lo[1] : sb[f].lo[2])) + plane_off;
+            for (int n = 0; n < nc; ++n) {
+                const double v = mult * tt[f](q[0], q[1], q[2], n);
+                if (add) rt[f](q[0], q[1], q[2], dcomp + n) += v; else rt[f](q[0], q[1], q[2], dcomp + n) = v;
+            }
+        });
+    }
+}
+
+void FluxRegister::FineAdd(const MultiFab& flux, int dir, int scomp, int dcomp, int nc, double mult)
+{
+    IAMRX_ASSERT(flux.type.t[dir] == 1 && flux.layout->id == m_fine->id && dcomp + nc <= m_ncomp);
+    const int r = m_ratio;
+    const int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    for (int side = 0; side < 2; ++side) {
+        MultiFab& reg = m_reg[dir][side];
+        const FabD *rt = reg.d_tab, *ft = flux.d_tab;
+        const BoxD* sb = m_slab[dir][side]->d_boxes;
+        const int plane_off = side == 0 ? 1 : 0;
+        for_each(*m_slab[dir][side], cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            int q[3] = {i, j, k};
+            q[dir] = (dir == 0 ? sb[f].lo[0] : (dir == 1 ? sb[f].lo[1] : sb[f].lo[2])) + plane_off;     // coarse face index
+            for (int n = 0; n < nc; ++n) {
+                double s = 0.0;
+                for (int b = 0; b < r; ++b)
+                    for (int a = 0; a < r; ++a) {
+                        int p[3];
+                        p[dir] = r * q[dir]; p[d1] = r * q[d1] + a; p[d2] = r * q[d2] + b;
+                        s += ft[f](p[0], p[1], p[2], scomp + n);
+                    }
+                rt[f](q[0], q[1], q[2], dcomp + n) += mult * s;
+            }
+        });
+    }
+}
+
+void FluxRegister::Reflux(MultiFab& S, double volume, double scale, int scomp, int dcomp, int nc)
+{
+    IAMRX_ASSERT(S.type.cell() && S.layout->id == m_crse->id);
+    for (int dir = 0; dir < 3; ++dir)
+        for (int side = 0; side < 2; ++side) {
+            MultiFab tmp(m_slab[dir][side], cell_type(), nc, 0);
+            const FabD *rt = m_reg[dir][side].d_tab, *tt = tmp.d_tab;
+            const int plane_off = side == 0 ? 1 : 0;
+            const double m = (side == 0 ? -scale : scale) / volume;     // FluxRegister::Reflux: low side of the fine box: -scale
+            for_each(*m_slab[dir][side], cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                int q[3] = {i, j, k};
+                q[dir] += plane_off;
+                for (int n = 0; n < nc; ++n) tt[f](i, j, k, n) = m * rt[f](q[0], q[1], q[2], scomp + n);
+            });
+            parallel_copy(S, tmp, 0, dcomp, nc, 0, 0, &m_cgeom, true);
+        }
 }
 
 }  // namespace iamrx

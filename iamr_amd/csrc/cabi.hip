@@ -560,6 +560,29 @@ int iamrx_fillpatch_two_levels(iamrx_mf dst, int dcomp, double time, iamrx_mf fi
     fillpatch_two_levels(dst->mf, dcomp, time, f, c, scomp, ncomp, to_geom(cgeom), to_geom(fgeom), ratio, bc.data(), edlo, edhi);
     IAMRX_CATCH
 }
+struct iamrx_fluxreg_s { std::unique_ptr<FluxRegister> fr; };
+int iamrx_fluxreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom* cgeom, int ratio, int ncomp, iamrx_fluxreg* out)
+{
+    IAMRX_TRY
+    auto* h = new iamrx_fluxreg_s;
+    h->fr = std::make_unique<FluxRegister>(fine->p, crse->p, to_geom(cgeom), ratio, ncomp);
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_fluxreg_destroy(iamrx_fluxreg fr) { IAMRX_TRY delete fr; IAMRX_CATCH }
+int iamrx_fluxreg_setval(iamrx_fluxreg fr, double v) { IAMRX_TRY fr->fr->setVal(v); IAMRX_CATCH }
+int iamrx_fluxreg_crse_init(iamrx_fluxreg fr, iamrx_mf flux, int dir, int scomp, int dcomp, int ncomp, double mult, int add)
+{
+    IAMRX_TRY fr->fr->CrseInit(flux->mf, dir, scomp, dcomp, ncomp, mult, add != 0); IAMRX_CATCH
+}
+int iamrx_fluxreg_fine_add(iamrx_fluxreg fr, iamrx_mf flux, int dir, int scomp, int dcomp, int ncomp, double mult)
+{
+    IAMRX_TRY fr->fr->FineAdd(flux->mf, dir, scomp, dcomp, ncomp, mult); IAMRX_CATCH
+}
+int iamrx_fluxreg_reflux(iamrx_fluxreg fr, iamrx_mf S, double volume, double scale, int scomp, int dcomp, int ncomp)
+{
+    IAMRX_TRY fr->fr->Reflux(S->mf, volume, scale, scomp, dcomp, ncomp); IAMRX_CATCH
+}
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio)
 {
     IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH

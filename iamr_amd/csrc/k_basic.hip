@@ -23,7 +23,7 @@ void launch_fill(double* p, size_t n, double v, hipStream_t s)
 
 // one blockIdx.y per copy descriptor; threads stride over region points (x fastest => coalesced rows)
 __global__ void __launch_bounds__(256) k_copy_plan(const CopyDesc* __restrict__ descs, const FabD* __restrict__ src,
-                                                   const FabD* __restrict__ dst, int scomp, int dcomp, int nc)
+                                                   const FabD* __restrict__ dst, int scomp, int dcomp, int nc, int add)
 {
     const CopyDesc cd = descs[blockIdx.y];
     const int nx = cd.region.len(0), ny = cd.region.len(1);
@@ -34,17 +34,18 @@ __global__ void __launch_bounds__(256) k_copy_plan(const CopyDesc* __restrict__ 
         const long r = q / nx;
         const int j = cd.region.lo[1] + (int)(r % ny);
         const int k = cd.region.lo[2] + (int)(r / ny);
-        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+        if (add) for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) += s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+        else for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
     }
 }
 
-void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s)
+void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add)
 {
     if (nd == 0) return;
     long nb = (maxpts + 255) / 256;
     if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_copy_plan, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, dst, scomp, dcomp, nc);
+    hipLaunchKernelGGL(k_copy_plan, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, dst, scomp, dcomp, nc, add ? 1 : 0);
 }
 
 __global__ void __launch_bounds__(256) k_pack(const CopyDesc* __restrict__ descs, const FabD* __restrict__ src,
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(256) k_pack(const CopyDesc* __restrict__ descs
 }
 
 __global__ void __launch_bounds__(256) k_unpack(const CopyDesc* __restrict__ descs, const FabD* __restrict__ dst,
-                                                const double* __restrict__ buf, long pts_total, int dcomp, int nc)
+                                                const double* __restrict__ buf, long pts_total, int dcomp, int nc, int add)
 {
     const CopyDesc cd = descs[blockIdx.y];
     const int nx = cd.region.len(0), ny = cd.region.len(1);
@@ -75,7 +76,8 @@ __global__ void __launch_bounds__(256) k_unpack(const CopyDesc* __restrict__ des
         const long r = q / nx;
         const int j = cd.region.lo[1] + (int)(r % ny);
         const int k = cd.region.lo[2] + (int)(r / ny);
-        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = buf[cd.buf_off + q + pts_total * n];
+        if (add) for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) += buf[cd.buf_off + q + pts_total * n];
+        else for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = buf[cd.buf_off + q + pts_total * n];
     }
 }
 
@@ -85,11 +87,11 @@ void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double
     long nb = (maxpts + 255) / 256; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, buf, pts_total, scomp, nc);
 }
-void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s)
+void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add)
 {
     if (nd == 0) return;
     long nb = (maxpts + 255) / 256; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_unpack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, dst, buf, pts_total, dcomp, nc);
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, dst, buf, pts_total, dcomp, nc, add ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ reductions

@@ -7,9 +7,9 @@ namespace iamrx {
 
 // ---- k_basic.hip --------------------------------------------------------------------------
 void launch_fill(double* p, size_t n, double v, hipStream_t s);
-void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s);
+void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add = false);
 void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s);
-void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s);
+void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add = false);
 double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng);
 double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g);   // local sum over owner copies
 // nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>

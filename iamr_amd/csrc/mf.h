@@ -174,7 +174,8 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
 
 // plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
 const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g);
-void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc);
+// add: dst += src instead of dst = src (the regions of one plan must then not overlap in dst)
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false);
 // multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes
 void gather_to_replicated(MultiFab& repl, const MultiFab& dist);
 void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng);

@@ -395,7 +395,7 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
     return ref;
 }
 
-void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc)
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add)
 {
     auto& ctx = Context::get();
     hipStream_t s = ctx.stream;
@@ -416,13 +416,13 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
         }
     }
     if (!plan.local.empty())
-        launch_copy_plan(plan.d_local, (int)plan.local.size(), plan.max_local_pts, src.d_tab, dst.d_tab, scomp, dcomp, nc, s);
+        launch_copy_plan(plan.d_local, (int)plan.local.size(), plan.max_local_pts, src.d_tab, dst.d_tab, scomp, dcomp, nc, s, add);
     if (!sends.empty() || !recvs.empty()) {
         ctx.comm->exchange(sends, recvs, s);
         size_t ri = 0;
         for (auto& p : plan.peers) {
             if (p.recv_pts > 0) {
-                launch_unpack(p.d_unpack, (int)p.unpack.size(), p.max_unpack_pts, dst.d_tab, recvs[ri].dev_ptr, p.recv_pts, dcomp, nc, s);
+                launch_unpack(p.d_unpack, (int)p.unpack.size(), p.max_unpack_pts, dst.d_tab, recvs[ri].dev_ptr, p.recv_pts, dcomp, nc, s, add);
                 ++ri;
             }
         }

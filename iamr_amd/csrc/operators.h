@@ -34,7 +34,8 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
 
 // ---- inter-level data motion (amr.hip) ------------------------------------------------------------------------
 // amrex::MultiFab::ParallelCopy between different layouts of one index space; periodic_geom != nullptr adds the periodic images
-void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom);
+// add = true: dst += src (MultiFab::ParallelAdd); the source regions must then map to disjoint destination cells
+void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add = false);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
 void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, int ratio);
 // StateData of one level: old/new MultiFabs and their times (old_ may be null: only one time level)
@@ -42,6 +43,23 @@ struct TimeData { const MultiFab* old_; const MultiFab* new_; double t_old, t_ne
 // AmrLevel::FillPatch on a refined level (FillPatchTwoLevels + CellConservativeLinear + physical BC), see amr.hip
 void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
                           const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
+
+// amrex::FluxRegister / YAFluxRegister role (see amr.hip)
+class FluxRegister {
+public:
+    FluxRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, int ratio, int ncomp);
+    void setVal(double v);
+    void CrseInit(const MultiFab& flux /*coarse level, face type dir*/, int dir, int scomp, int dcomp, int nc, double mult, bool add);
+    void FineAdd(const MultiFab& flux /*fine level, face type dir*/, int dir, int scomp, int dcomp, int nc, double mult);
+    void Reflux(MultiFab& S /*coarse level, cells*/, double volume, double scale, int scomp, int dcomp, int nc);
+    const MultiFab& reg(int dir, int side) const { return m_reg[dir][side]; }
+private:
+    LayoutP m_fine, m_crse;
+    Geometry m_cgeom;
+    int m_ratio, m_ncomp;
+    LayoutP m_slab[3][2];
+    MultiFab m_reg[3][2];
+};
 
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {

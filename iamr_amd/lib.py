@@ -273,6 +273,35 @@ def fillpatch_two_levels(dst, time, fine, crse, cgeom, fgeom, scomp=0, ncomp=Non
                                            C.byref(cgeom), C.byref(fgeom), ratio, _bcrec(nc, bcs), el, eh))
 
 
+class FluxRegister:
+    """amrex::FluxRegister role (names as in the reference: CrseInit, FineAdd, Reflux)"""
+
+    def __init__(self, fine_layout, crse_layout, cgeom, ratio, ncomp):
+        self.h = C.c_void_p()
+        self._keep = (fine_layout, crse_layout)
+        check(lib().iamrx_fluxreg_create(fine_layout.h, crse_layout.h, C.byref(cgeom), ratio, ncomp, C.byref(self.h)))
+
+    def setVal(self, v):
+        check(lib().iamrx_fluxreg_setval(self.h, C.c_double(v)))
+
+    def CrseInit(self, flux, dir, scomp, dcomp, ncomp, mult, add=False):
+        check(lib().iamrx_fluxreg_crse_init(self.h, flux.h, dir, scomp, dcomp, ncomp, C.c_double(mult), int(add)))
+
+    def FineAdd(self, flux, dir, scomp, dcomp, ncomp, mult):
+        check(lib().iamrx_fluxreg_fine_add(self.h, flux.h, dir, scomp, dcomp, ncomp, C.c_double(mult)))
+
+    def Reflux(self, S, volume, scale, scomp, dcomp, ncomp):
+        check(lib().iamrx_fluxreg_reflux(self.h, S.h, C.c_double(volume), C.c_double(scale), scomp, dcomp, ncomp))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().iamrx_fluxreg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def average_down(fine, crse, scomp=0, ncomp=None, ratio=2):
     check(lib().iamrx_average_down(fine.h, crse.h, scomp, crse.ncomp if ncomp is None else ncomp, ratio))
 

@@ -197,6 +197,17 @@ int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int nc
 /* amrex::average_down / average_down_faces / average_down_nodal (by index type) as called from NavierStokesBase::avgDown_StatePress
  * (Source/NavierStokesBase.cpp:4125-4193): crse(scomp..) <- mean / injection of fine(scomp..); ratio 2 or 4 */
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio);
+/* amrex::FluxRegister / YAFluxRegister role for one coarse-fine interface (advective registers: Source/NavierStokesBase.cpp:5036-5096,
+ * viscous: Source/NavierStokes.cpp:975-992, Source/Diffusion.cpp:940-953; consumer NavierStokes::reflux, Source/NavierStokes.cpp:1736-1838).
+ * Fluxes are extensive (area-weighted) as in IAMR.  crse_init: reg = (add: +=) mult*coarse flux; fine_add: reg += mult * sum of the fine
+ * fluxes of a coarse face; reflux: S(outside coarse cell) -=/+= scale*reg/volume on the low/high side of a fine box (periodic images incl.) */
+typedef struct iamrx_fluxreg_s* iamrx_fluxreg;
+int iamrx_fluxreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom* cgeom, int ratio, int ncomp, iamrx_fluxreg* out);
+int iamrx_fluxreg_destroy(iamrx_fluxreg fr);
+int iamrx_fluxreg_setval(iamrx_fluxreg fr, double v);
+int iamrx_fluxreg_crse_init(iamrx_fluxreg fr, iamrx_mf crse_flux, int dir, int scomp, int dcomp, int ncomp, double mult, int add);
+int iamrx_fluxreg_fine_add(iamrx_fluxreg fr, iamrx_mf fine_flux, int dir, int scomp, int dcomp, int ncomp, double mult);
+int iamrx_fluxreg_reflux(iamrx_fluxreg fr, iamrx_mf S_crse, double volume, double scale, int scomp, int dcomp, int ncomp);
 /* AmrLevel::FillPatch of cell-centred StateData on a refined level = amrex::FillPatchTwoLevels with cell_cons_interp
  * (CellConservativeLinear, linear limiting), the interpolater IAMR registers for State_Type / Gradp_Type (Source/NS_setup.cpp:206-394;
  * call sites e.g. Source/NavierStokesBase.cpp:3382-3418, 4399-4435): dst (fine layout, dst ghost width) <- fine data where a fine box

@@ -131,3 +131,78 @@ def test_fillpatch_two_levels_matches_oracle(orc, gpu):
         ref = ff.a[sl]
         assert np.abs(ref).max() < 50.0                        # every cell was filled by the oracle
         assert np.abs(a - ref).max() <= 1e-13, (li, np.abs(a - ref).max())
+
+
+def test_flux_register_reflux_matches_direct_evaluation(gpu):
+    """FluxRegister CrseInit(-dt_c) + two FineAdd(+dt_f) + Reflux, for a two-box fine patch that touches a periodic boundary;
+    expected coarse-cell corrections evaluated directly with numpy.  Also the telescoping property: with fine fluxes that are
+    the exact refinement of the coarse ones the registers cancel and Reflux changes nothing."""
+    lib = gpu
+    nc, ratio, ncomp = (16, 12, 8), 2, 2
+    cg = lib.Geom.make(nc)
+    crse_lay = lib.Layout.decompose(nc, (8, 12, 8))
+    # coarse cells covered by the patch: [0..7] x [2..9] x [2..5]  (x-lo face on the periodic boundary)
+    cboxes = [((0, 2, 2), (3, 9, 5)), ((4, 2, 2), (7, 9, 5))]
+    fboxes = [(tuple(2 * v for v in lo), tuple(2 * v + 1 for v in hi)) for lo, hi in cboxes]
+    fine_lay = lib.Layout(fboxes, [0, 0])
+    rng = np.random.default_rng(6)
+    nf = tuple(2 * v for v in nc)
+    dt_c, dt_f, vol = 0.1, 0.05, 0.25
+    CF, FF1, FF2, cf_mf, ff1_mf, ff2_mf = [], [], [], [], [], []
+    for d in range(3):
+        sc = list(nc); sc[d] += 1
+        sf = list(nf); sf[d] += 1
+        c = rng.standard_normal(tuple(sc) + (ncomp,))
+        # periodic consistency of the coarse flux on the domain faces
+        lo = [slice(None)] * 3; hi = [slice(None)] * 3
+        lo[d] = 0; hi[d] = nc[d]
+        c[tuple(hi)] = c[tuple(lo)]
+        CF.append(c); FF1.append(rng.standard_normal(tuple(sf) + (ncomp,))); FF2.append(rng.standard_normal(tuple(sf) + (ncomp,)))
+        m = lib.MultiFab(crse_lay, lib.face(d), ncomp, 0); m.set_from_global(c, (0, 0, 0)); cf_mf.append(m)
+        m = lib.MultiFab(fine_lay, lib.face(d), ncomp, 0); m.set_from_global(FF1[d], (0, 0, 0)); ff1_mf.append(m)
+        m = lib.MultiFab(fine_lay, lib.face(d), ncomp, 0); m.set_from_global(FF2[d], (0, 0, 0)); ff2_mf.append(m)
+    fr = lib.FluxRegister(fine_lay, crse_lay, cg, ratio, ncomp)
+    for d in range(3):
+        fr.CrseInit(cf_mf[d], d, 0, 0, ncomp, -dt_c)
+        fr.FineAdd(ff1_mf[d], d, 0, 0, ncomp, dt_f)
+        fr.FineAdd(ff2_mf[d], d, 0, 0, ncomp, dt_f)
+    S = lib.MultiFab(crse_lay, lib.CELL, ncomp, 0); S.setval(0.0)
+    fr.Reflux(S, vol, 1.0, 0, 0, ncomp)
+    exp = np.zeros(nc + (ncomp,))
+    for (lo, hi) in cboxes:
+        for d in range(3):
+            d1, d2 = [e for e in range(3) if e != d]
+            for side in (0, 1):
+                face = lo[d] if side == 0 else hi[d] + 1
+                out = (lo[d] - 1) % nc[d] if side == 0 else (hi[d] + 1) % nc[d]
+                for a in range(lo[d1], hi[d1] + 1):
+                    for b in range(lo[d2], hi[d2] + 1):
+                        ci = [0, 0, 0]; ci[d] = face; ci[d1] = a; ci[d2] = b
+                        fsum = np.zeros(ncomp)
+                        for ra in range(2):
+                            for rb in range(2):
+                                fi = [0, 0, 0]; fi[d] = 2 * face; fi[d1] = 2 * a + ra; fi[d2] = 2 * b + rb
+                                fsum += FF1[d][tuple(fi)] + FF2[d][tuple(fi)]
+                        reg = -dt_c * CF[d][tuple(ci)] + dt_f * fsum
+                        oc = [0, 0, 0]; oc[d] = out; oc[d1] = a; oc[d2] = b
+                        exp[tuple(oc)] += (-1.0 if side == 0 else 1.0) * reg / vol
+    got = S.gather_valid(nc)
+    assert np.abs(exp).max() > 0.5
+    assert np.abs(got - exp).max() <= 1e-13
+    # telescoping: fine flux = coarse flux / 4 on every child face, dt_f = dt_c / 2, two fine steps
+    fr.setVal(0.0)
+    for d in range(3):
+        F = np.repeat(np.repeat(np.repeat(CF[d], 2, axis=0), 2, axis=1), 2, axis=2)
+        sl = [slice(None)] * 3
+        sl[d] = slice(0, 2 * nc[d] + 1, 1)
+        # refine the face-normal direction by injection: fine face 2i <-> coarse face i
+        idx = [np.arange(nf[e] + (1 if e == d else 0)) // 2 for e in range(3)]
+        idx[d] = np.minimum(np.arange(nf[d] + 1) // 2 + (np.arange(nf[d] + 1) % 2), nc[d])   # odd fine faces are never used by the register
+        Fd = CF[d][np.ix_(*idx)] * 0.25
+        m = lib.MultiFab(fine_lay, lib.face(d), ncomp, 0); m.set_from_global(Fd, (0, 0, 0))
+        fr.CrseInit(cf_mf[d], d, 0, 0, ncomp, -dt_c)
+        fr.FineAdd(m, d, 0, 0, ncomp, dt_f)
+        fr.FineAdd(m, d, 0, 0, ncomp, dt_f)
+    S.setval(0.0)
+    fr.Reflux(S, vol, 1.0, 0, 0, ncomp)
+    assert np.abs(S.gather_valid(nc)).max() <= 1e-14
