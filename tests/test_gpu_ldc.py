@@ -162,3 +162,31 @@ def test_rejects_unsupported_physical_bc(gpu):
     lay = lib.Layout.single(n)
     with pytest.raises(RuntimeError):
         N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2]))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(gravity=-9.8, use_forces_in_trans=0),
+    dict(gravity=-9.8, use_forces_in_trans=1),
+    dict(be_cn_theta=1.0),
+    dict(init_iter=0, init_vel_iter=0, fixed_dt=2.0e-3),
+    dict(visc_coef=0.0, tracer_diff_coef=0.0),
+], ids=["gravity", "gravity+forces_in_trans", "backward_euler", "no_init_iters_fixed_dt", "inviscid"])
+def test_parameter_variants_match_oracle(orc, gpu, kw):
+    """ns.* knobs that change the code path of the step (buoyancy forcing with variable density, godunov.use_forces_in_trans,
+    be_cn_theta = 1, no initial iterations + fixed_dt, inviscid): periodic x, walls in y and z, 2 + 2 boxes, 3 steps"""
+    n = (16, 16, 16)
+    per = (1, 0, 0)
+    x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    init = np.zeros(n + (5,))
+    init[..., 0] = 0.6 * np.sin(2 * np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 1] = 0.3 * np.cos(2 * np.pi * X) * np.sin(np.pi * Y) ** 2 * np.sin(2 * np.pi * Z)
+    init[..., 2] = 0.2 * np.sin(4 * np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z) ** 2
+    init[..., 3] = 1.0 + 0.4 * np.exp(-25.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.6) ** 2))
+    init[..., 4] = np.cos(2 * np.pi * X) * Y * (1 - Z)
+    base = dict(cfl=0.5, visc_coef=0.01, init_iter=2, tracer_diff_coef=0.005)
+    base.update(kw)
+    nolid = [0.0] * 9
+    ref = run_oracle(orc, n, per, (0, 4, 5), (0, 5, 4), nolid, 3, init, **base)
+    ns, lay, g, dts = run_gpu(gpu, n, per, (0, 4, 5), (0, 5, 4), nolid, 3, init, (8, 16, 8), **base)
+    compare(gpu, ns, lay, g, n, dts, ref)
