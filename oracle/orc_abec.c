@@ -135,6 +135,8 @@ void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, in
         cflo[d] = g->periodic[d] ? 0.0 : bc_coef0(lobc[BCOFF(L, n) + d], g->n[d], maxorder);
         cfhi[d] = g->periodic[d] ? 0.0 : bc_coef0(hibc[BCOFF(L, n) + d], g->n[d], maxorder);
     }
+    /* cells of one colour are independent: same result for any thread count */
+    _Pragma("omp parallel for schedule(static)")
     for (int k = 0; k < g->n[2]; ++k)
     for (int j = 0; j < g->n[1]; ++j)
     for (int i = 0; i < g->n[0]; ++i) {
