@@ -39,8 +39,10 @@ struct FabD {
     // device side: the table entry is loaded from memory, so the compiler cannot see that p points to global memory and
     // would emit flat_load/flat_store (which also tie up the LDS counter); say so explicitly -> global_load/global_store
     __device__ gdouble& operator()(int i, int j, int k, int c = 0) const { return ((gdouble*)p)[off(i, j, k) + cs * c]; }
+    __device__ gdouble* gp() const { return (gdouble*)p; }      // base pointer in the global address space
 #else
     __host__ __device__ double& operator()(int i, int j, int k, int c = 0) const { return p[off(i, j, k) + cs * c]; }
+    __host__ __device__ double* gp() const { return p; }
 #endif
 };
 

@@ -51,7 +51,8 @@ __device__ __forceinline__ double lim2(double dlft, double drgt)
 
 // amrex_calc_{x,y,z}slope_extdir, order 4.  q points at the cell, s = stride in the slope direction,
 // i = cell index in that direction.
-__device__ __forceinline__ double slope4(const double* __restrict__ q, long s, bool edlo, bool edhi, int i, int domlo, int domhi)
+template <class P>
+__device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi)
 {
     const double qi = q[0], qm = q[-s], qp = q[s], qmm = q[-2 * s], qpp = q[2 * s];
     double dfm = lim2(qm - qmm, qi - qm);
@@ -94,7 +95,8 @@ __device__ __forceinline__ bool ed_or_ho(int b) { return b == bc_ext_dir || b ==
 
 // SetTransTerm{X,Y,Z}BCs.  qc points at the state value of the cell on the HIGH side of the face
 // (cell index f in direction d), s = stride in d, f = face index.
-__device__ __forceinline__ void trans_bc(const double* __restrict__ qc, long s, int f, bool normal_vel, double& lo, double& hi,
+template <class P>
+__device__ __forceinline__ void trans_bc(P qc, long s, int f, bool normal_vel, double& lo, double& hi,
                                          int bclo, int bchi, int domlo, int domhi)
 {
     if (f <= domlo) {
@@ -109,7 +111,8 @@ __device__ __forceinline__ void trans_bc(const double* __restrict__ qc, long s, 
 }
 
 // Set{X,Y,Z}EdgeBCs
-__device__ __forceinline__ void edge_bc(const double* __restrict__ qc, long s, int f, bool normal_vel, double& lo, double& hi,
+template <class P>
+__device__ __forceinline__ void edge_bc(P qc, long s, int f, bool normal_vel, double& lo, double& hi,
                                         int bclo, int bchi, int domlo, int domhi)
 {
     if (f <= domlo) {
@@ -129,14 +132,14 @@ __device__ __forceinline__ void edge_bc(const double* __restrict__ qc, long s, i
 
 // traced states on face f of direction d for component n: lo from cell f-1, hi from cell f.
 // PRED: trace velocity = cell-centred vcc(cell, d); else the face's own mac velocity `um`.
-template <bool PRED>
-__device__ __forceinline__ void trace_lohi(const double* __restrict__ qn /*state comp n at cell f*/, const double* __restrict__ vd /*vcc comp d at cell f (PRED)*/,
+template <bool PRED, class P, class PV>
+__device__ __forceinline__ void trace_lohi(P qn /*state comp n at cell f*/, PV vd /*vcc comp d at cell f (PRED)*/,
                                            long s, double um, double dtdx, bool edlo, bool edhi, int f, int domlo, int domhi,
                                            double& lo, double& hi)
 {
     const double slh = slope4(qn, s, edlo, edhi, f, domlo, domhi);
     const double sll = slope4(qn - s, s, edlo, edhi, f - 1, domlo, domhi);
-    if (PRED) {
+    if constexpr (PRED) {
         hi = qn[0] + 0.5 * (-1.0 - vd[0] * dtdx) * slh;
         lo = qn[-s] + 0.5 * (1.0 - vd[-s] * dtdx) * sll;
     } else {
@@ -186,9 +189,9 @@ __global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict_
             const int bl = P.bc.bc[D].lo[D], bh = P.bc.bc[D].hi[D];
             const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
             double l, h;
-            trace_lohi<true>(q.p + qo + q.cs * D, q.p + qo + q.cs * D, s, 0.0, dtdx, edlo, edhi, f, domlo, domhi, l, h);
-            if (fit && has_force) { l += hdt * frc.p[fo - fs + frc.cs * D]; h += hdt * frc.p[fo + frc.cs * D]; }
-            if (nonper) trans_bc(q.p + qo + q.cs * D, s, f, is_vel, l, h, bl, bh, domlo, domhi);
+            trace_lohi<true>(q.gp() + qo + q.cs * D, q.gp() + qo + q.cs * D, s, 0.0, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+            if (fit && has_force) { l += hdt * frc.gp()[fo - fs + frc.cs * D]; h += hdt * frc.gp()[fo + frc.cs * D]; }
+            if (nonper) trans_bc(q.gp() + qo + q.cs * D, s, f, is_vel, l, h, bl, bh, domlo, domhi);
             const double st = ((l + h) >= 0.) ? l : h;
             const bool ltm = ((l <= 0. && h >= 0.) || (fabs(l + h) < SMALL_VEL));
             uad = ltm ? 0. : st;
@@ -199,9 +202,9 @@ __global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict_
             const int bl = P.bc.bc[n].lo[D], bh = P.bc.bc[n].hi[D];
             const bool edlo = nonper && ed_or_ho(bl), edhi = nonper && ed_or_ho(bh);
             double l, h;
-            trace_lohi<PRED>(q.p + qo + q.cs * n, q.p + qo + q.cs * D, s, uad, dtdx, edlo, edhi, f, domlo, domhi, l, h);
-            if (fit && has_force) { l += hdt * frc.p[fo - fs + frc.cs * n]; h += hdt * frc.p[fo + frc.cs * n]; }
-            if (nonper) trans_bc(q.p + qo + q.cs * n, s, f, is_vel && n == D, l, h, bl, bh, domlo, domhi);
+            trace_lohi<PRED>(q.gp() + qo + q.cs * n, q.gp() + qo + q.cs * D, s, uad, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+            if (fit && has_force) { l += hdt * frc.gp()[fo - fs + frc.cs * n]; h += hdt * frc.gp()[fo + frc.cs * n]; }
+            if (nonper) trans_bc(q.gp() + qo + q.cs * n, s, f, is_vel && n == D, l, h, bl, bh, domlo, domhi);
             const double st = (uad >= 0.) ? l : h;
             e0(i, j, k, n) = fu * st + (1.0 - fu) * 0.5 * (h + l);
         }
@@ -212,12 +215,12 @@ __global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict_
 //   qn   : state comp n at the cell on the high side of the T-face (cell index == face index fT)
 //   vT   : vcc comp T at the same cell (PRED only)
 //   macO : mac[O] at that cell's low O-face;  eO : pass-1 state on that O-face (comp n)
-template <bool PRED>
-__device__ __forceinline__ double corner_state(const double* __restrict__ qn, const double* __restrict__ vT, long sT, int fT,
-    double macT_f, const double* __restrict__ macO, long mOsT, long mOsO,
-    const double* __restrict__ eO, long eOsT, long eOsO,
-    const double* __restrict__ frcn, long fsT, double dtdxT, double c_o /* dt/(6 dxO) or dt/(3 dxO) */, double dt3, double dxO,
-    bool conserv, const double* __restrict__ divu, long dsT,
+template <bool PRED, class PQ, class PV, class PM, class PE, class PF, class PD>
+__device__ __forceinline__ double corner_state(PQ qn, PV vT, long sT, int fT,
+    double macT_f, PM macO, long mOsT, long mOsO,
+    PE eO, long eOsT, long eOsO,
+    PF frcn, long fsT, double dtdxT, double c_o /* dt/(6 dxO) or dt/(3 dxO) */, double dt3, double dxO,
+    bool conserv, PD divu, long dsT,
     bool fit, double hdt, bool nonperT, bool normal_vel, int bl, int bh, int domlo, int domhi)
 {
     const bool edlo = nonperT && ed_or_ho(bl), edhi = nonperT && ed_or_ho(bh);
@@ -242,11 +245,11 @@ __device__ __forceinline__ double corner_state(const double* __restrict__ qn, co
 }
 
 // the four corner states (low-side cell / high-side cell of the D-face) x (T-face c / c+1) for transverse direction T
-template <bool PRED, int D, int T>
+template <bool PRED, int D, int T, class PQ, class PF, class PD>
 __device__ __forceinline__ void corner_quad(const GodParams& P, int n, bool conserv, int fT,
-    const double* __restrict__ qn, const double* __restrict__ qT, const FabD& q,
+    PQ qn, PQ qT, const FabD& q,
     const FabD& mT, long mTo, const FabD& mO, long mOo, const FabD& eO, long eOo,
-    const double* __restrict__ frcn, const FabD& frc, const double* __restrict__ dvp, const FabD& dv,
+    PF frcn, const FabD& frc, PD dvp, const FabD& dv,
     double& Tl0, double& Tl1, double& Th0, double& Th1)
 {
     constexpr int O = 3 - D - T;
@@ -267,8 +270,8 @@ __device__ __forceinline__ void corner_quad(const GodParams& P, int n, bool cons
     const int dlo = P.bc.dlo[T], dhi = P.bc.dhi[T];
 #define IAMRX_CORNER(SIDE, UP)                                                                                                   \
     corner_state<PRED>(qn + ((SIDE) ? 0 : -qsD) + (UP) * qsT, qT + ((SIDE) ? 0 : -qsD) + (UP) * qsT, qsT, fT + (UP),                \
-                       mT.p[mTo + ((SIDE) ? 0 : -mTsD) + (UP) * mTsT], mO.p + mOo + ((SIDE) ? 0 : -mOsD) + (UP) * mOsT, mOsT, mOsO, \
-                       eO.p + eOo + ((SIDE) ? 0 : -eOsD) + (UP) * eOsT, eOsT, eOsO,                                                \
+                       mT.gp()[mTo + ((SIDE) ? 0 : -mTsD) + (UP) * mTsT], mO.gp() + mOo + ((SIDE) ? 0 : -mOsD) + (UP) * mOsT, mOsT, mOsO, \
+                       eO.gp() + eOo + ((SIDE) ? 0 : -eOsD) + (UP) * eOsT, eOsT, eOsO,                                                \
                        frcn ? frcn + ((SIDE) ? 0 : -fsD) + (UP) * fsT : nullptr, fsT, dtdxT, c_o, dt3, P.dx[O], conserv,             \
                        dvp ? dvp + ((SIDE) ? 0 : -dsD) + (UP) * dsT : nullptr, dsT, fit, hdt, nonperT, nvel, bl, bh, dlo, dhi)
     Tl0 = IAMRX_CORNER(0, 0);
@@ -325,27 +328,27 @@ __global__ void __launch_bounds__(256) k_final(Tiling t, const BoxD* __restrict_
         const long mAo = mA.off(i, j, k), mBo = mB.off(i, j, k);
         const double umD = mD(i, j, k, 0);
         for (int n = nbeg; n < nend; ++n) {
-            const double* qn = q.p + qo + q.cs * n;
-            const double* frcn = has_force ? frc.p + fo + frc.cs * n : nullptr;
-            const double* dvp = has_divu ? dv.p + dvo : nullptr;
+            const auto qn = q.gp() + qo + q.cs * n;
+            const auto frcn = has_force ? frc.gp() + fo + frc.cs * n : (decltype(frc.gp()))nullptr;
+            const auto dvp = has_divu ? dv.gp() + dvo : (decltype(dv.gp()))nullptr;
             const bool conserv = !PRED && P.iconserv[n] != 0;
             const int blD = P.bc.bc[n].lo[D], bhD = P.bc.bc[n].hi[D];
             // own traced states along D
             double stl, sth;
             {
                 const bool edlo = nonperD && ed_or_ho(blD), edhi = nonperD && ed_or_ho(bhD);
-                trace_lohi<PRED>(qn, q.p + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
+                trace_lohi<PRED>(qn, q.gp() + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
                 if (fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
                 if (nonperD) trans_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
             }
             // corner-coupled transverse states: direction TA is corrected with the TB-derivative and vice versa
             double Al0, Al1, Ah0, Ah1, Bl0, Bl1, Bh0, Bh1;
-            corner_quad<PRED, D, TA>(P, n, conserv, fA, qn, q.p + qo + q.cs * TA, q, mA, mAo, mB, mBo, eB, eB.off(i, j, k) + eB.cs * n,
+            corner_quad<PRED, D, TA>(P, n, conserv, fA, qn, q.gp() + qo + q.cs * TA, q, mA, mAo, mB, mBo, eB, eB.off(i, j, k) + eB.cs * n,
                                      frcn, frc, dvp, dv, Al0, Al1, Ah0, Ah1);
-            corner_quad<PRED, D, TB>(P, n, conserv, fB, qn, q.p + qo + q.cs * TB, q, mB, mBo, mA, mAo, eA, eA.off(i, j, k) + eA.cs * n,
+            corner_quad<PRED, D, TB>(P, n, conserv, fB, qn, q.gp() + qo + q.cs * TB, q, mB, mBo, mA, mAo, eA, eA.off(i, j, k) + eA.cs * n,
                                      frcn, frc, dvp, dv, Bl0, Bl1, Bh0, Bh1);
-            const double mA_l0 = mA.p[mAo - mAsD], mA_l1 = mA.p[mAo - mAsD + mAsT], mA_h0 = mA.p[mAo], mA_h1 = mA.p[mAo + mAsT];
-            const double mB_l0 = mB.p[mBo - mBsD], mB_l1 = mB.p[mBo - mBsD + mBsT], mB_h0 = mB.p[mBo], mB_h1 = mB.p[mBo + mBsT];
+            const double mA_l0 = mA.gp()[mAo - mAsD], mA_l1 = mA.gp()[mAo - mAsD + mAsT], mA_h0 = mA.gp()[mAo], mA_h1 = mA.gp()[mAo + mAsT];
+            const double mB_l0 = mB.gp()[mBo - mBsD], mB_l1 = mB.gp()[mBo - mBsD + mBsT], mB_h0 = mB.gp()[mBo], mB_h1 = mB.gp()[mBo + mBsT];
             if (conserv) {
                 const double cA = 0.5 * dt / P.dx[TA], cB = 0.5 * dt / P.dx[TB];
                 stl += -cA * (Al1 * mA_l1 - Al0 * mA_l0);
@@ -416,9 +419,9 @@ __global__ void __launch_bounds__(256) k_corner(Tiling t, const BoxD* __restrict
         for (int n = nbeg; n < nend; ++n) {
             const bool conserv = !PRED && P.iconserv[n] != 0;
             const double c_o = conserv ? P.dt / (3.0 * P.dx[O]) : P.dt / (6.0 * P.dx[O]);
-            const double v = corner_state<PRED>(q.p + qo + q.cs * n, q.p + qo + q.cs * T, qsT, fT, macT, mO.p + mOo, mOsT, mOsO,
-                eO.p + eOo + eO.cs * n, eOsT, eOsO, has_force ? frc.p + frc.off(i, j, k) + frc.cs * n : nullptr, fsT, dtdxT, c_o, dt3,
-                P.dx[O], conserv, has_divu ? dv.p + dv.off(i, j, k) : nullptr, dsT, fit, hdt, nonperT, P.is_velocity && n == T,
+            const double v = corner_state<PRED>(q.gp() + qo + q.cs * n, q.gp() + qo + q.cs * T, qsT, fT, macT, mO.gp() + mOo, mOsT, mOsO,
+                eO.gp() + eOo + eO.cs * n, eOsT, eOsO, has_force ? frc.gp() + frc.off(i, j, k) + frc.cs * n : nullptr, fsT, dtdxT, c_o, dt3,
+                P.dx[O], conserv, has_divu ? dv.gp() + dv.off(i, j, k) : nullptr, dsT, fit, hdt, nonperT, P.is_velocity && n == T,
                 P.bc.bc[n].lo[T], P.bc.bc[n].hi[T], dlo, dhi);
             out(i, j, k, PRED ? 0 : n) = v;
         }
@@ -460,23 +463,23 @@ __global__ void __launch_bounds__(256) k_final_s(Tiling t, const BoxD* __restric
         const long dvo = has_divu ? dv.off(i, j, k) : 0;
         const long mAo = mA.off(i, j, k), mBo = mB.off(i, j, k);
         const double umD = mD(i, j, k, 0);
-        const double mA_l0 = mA.p[mAo - mAsD], mA_l1 = mA.p[mAo - mAsD + mAsT], mA_h0 = mA.p[mAo], mA_h1 = mA.p[mAo + mAsT];
-        const double mB_l0 = mB.p[mBo - mBsD], mB_l1 = mB.p[mBo - mBsD + mBsT], mB_h0 = mB.p[mBo], mB_h1 = mB.p[mBo + mBsT];
+        const double mA_l0 = mA.gp()[mAo - mAsD], mA_l1 = mA.gp()[mAo - mAsD + mAsT], mA_h0 = mA.gp()[mAo], mA_h1 = mA.gp()[mAo + mAsT];
+        const double mB_l0 = mB.gp()[mBo - mBsD], mB_l1 = mB.gp()[mBo - mBsD + mBsT], mB_h0 = mB.gp()[mBo], mB_h1 = mB.gp()[mBo + mBsT];
         for (int n = nbeg; n < nend; ++n) {
-            const double* qn = q.p + qo + q.cs * n;
-            const double* frcn = has_force ? frc.p + fo + frc.cs * n : nullptr;
+            const auto qn = q.gp() + qo + q.cs * n;
+            const auto frcn = has_force ? frc.gp() + fo + frc.cs * n : (decltype(frc.gp()))nullptr;
             const bool conserv = !PRED && P.iconserv[n] != 0;
             const int blD = P.bc.bc[n].lo[D], bhD = P.bc.bc[n].hi[D];
             double stl, sth;
             {
                 const bool edlo = nonperD && ed_or_ho(blD), edhi = nonperD && ed_or_ho(bhD);
-                trace_lohi<PRED>(qn, q.p + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
+                trace_lohi<PRED>(qn, q.gp() + qo + q.cs * D, qsD, umD, dtdxD, edlo, edhi, f, dloD, dhiD, stl, sth);
                 if (fit && has_force) { stl += hdt * frcn[-fsD]; sth += hdt * frcn[0]; }
                 if (nonperD) trans_bc(qn, qsD, f, is_vel && n == D, stl, sth, blD, bhD, dloD, dhiD);
             }
             const long cAo = cA.off(i, j, k) + cA.cs * (PRED ? 0 : n), cBo = cB.off(i, j, k) + cB.cs * (PRED ? 0 : n);
-            const double Al0 = cA.p[cAo - cAsD], Al1 = cA.p[cAo - cAsD + cAsT], Ah0 = cA.p[cAo], Ah1 = cA.p[cAo + cAsT];
-            const double Bl0 = cB.p[cBo - cBsD], Bl1 = cB.p[cBo - cBsD + cBsT], Bh0 = cB.p[cBo], Bh1 = cB.p[cBo + cBsT];
+            const double Al0 = cA.gp()[cAo - cAsD], Al1 = cA.gp()[cAo - cAsD + cAsT], Ah0 = cA.gp()[cAo], Ah1 = cA.gp()[cAo + cAsT];
+            const double Bl0 = cB.gp()[cBo - cBsD], Bl1 = cB.gp()[cBo - cBsD + cBsT], Bh0 = cB.gp()[cBo], Bh1 = cB.gp()[cBo + cBsT];
             if (conserv) {
                 const double cfA = 0.5 * dt / P.dx[TA], cfB = 0.5 * dt / P.dx[TB];
                 stl += -cfA * (Al1 * mA_l1 - Al0 * mA_l0);
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(256) k_final_s(Tiling t, const BoxD* __restric
                 sth += cfA * qn[0] * (mA_h1 - mA_h0);
                 stl += cfB * qn[-qsD] * (mB_l1 - mB_l0);
                 sth += cfB * qn[0] * (mB_h1 - mB_h0);
-                if (has_divu) { stl -= 0.5 * dt * qn[-qsD] * dv.p[dvo - dsD]; sth -= 0.5 * dt * qn[0] * dv.p[dvo]; }
+                if (has_divu) { stl -= 0.5 * dt * qn[-qsD] * dv.gp()[dvo - dsD]; sth -= 0.5 * dt * qn[0] * dv.gp()[dvo]; }
             } else {
                 const double cfA = 0.25 * dt / P.dx[TA], cfB = 0.25 * dt / P.dx[TB];
                 stl -= cfA * (mA_l1 + mA_l0) * (Al1 - Al0);

@@ -104,6 +104,8 @@ typedef struct orc_mg_opts {
 } orc_mg_opts;
 
 void orc_mg_default_opts(orc_mg_opts* o);
+extern int orc_threads;
+void orc_set_threads(int n);      /* OpenMP threads of the smoother colour loops (default 1) */
 
 void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x /*1 ghost, filled*/);
 void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi /*1 ghost, filled*/, const orc_fab* rhs,

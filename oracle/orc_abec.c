@@ -9,6 +9,11 @@
  */
 #include "orc_int.h"
 
+/* threads used by the OpenMP-parallel colour loops of the smoothers (default 1: the oracle is a deterministic checker first;
+ * a box whose CPU quota is smaller than its core count would crawl with one spinning thread per core) */
+int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
+
 void orc_mg_default_opts(orc_mg_opts* o)
 {
     o->nu1 = 2; o->nu2 = 2; o->nuf = 8; o->nub = 0;
@@ -136,7 +141,7 @@ void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, in
         cfhi[d] = g->periodic[d] ? 0.0 : bc_coef0(hibc[BCOFF(L, n) + d], g->n[d], maxorder);
     }
     /* cells of one colour are independent: same result for any thread count */
-    _Pragma("omp parallel for schedule(static)")
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k < g->n[2]; ++k)
     for (int j = 0; j < g->n[1]; ++j)
     for (int i = 0; i < g->n[0]; ++i) {

@@ -47,7 +47,7 @@ static inline double node_Ax(const orc_geom* g, const orc_fab* x, const orc_fab*
 
 void orc_nodal_adotx(const orc_geom* g, orc_fab* y, const orc_fab* x, const orc_fab* sig)
 {
-    _Pragma("omp parallel for schedule(static)")
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
         A4(y, i, j, k, 0) = node_Ax(g, x, sig, i, j, k, NULL);
 }
@@ -176,7 +176,7 @@ void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const o
             for (int color = 0; color < 8; ++color) {
                 nodal_fill(g, x);
                 /* nodes of one colour do not depend on each other: the loop order (and the thread count) cannot change the result */
-                _Pragma("omp parallel for schedule(static)")
+                _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
                 for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
                     if (((i & 1) | ((j & 1) << 1) | ((k & 1) << 2)) != color) continue;
                     double dg, Ax = node_Ax(g, x, sig, i, j, k, &dg);
