@@ -460,4 +460,117 @@ void FluxRegister::Reflux(MultiFab& S, double volume, double scale, int scomp, i
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// NavierStokesBase::create_umac_grown on a refined level (reference Source/NavierStokesBase.cpp:1108-1311):
+//   1. ghost faces of the fine mac velocities: amrex::FillPatchTwoLevels with the FaceLinear interpolater (linear between the
+//      two coarse faces in the face-normal direction, piecewise constant in the transverse ones), fine data where a fine box
+//      (or its periodic image) covers them;
+//   2. IAMR's own divergence fix: a ghost CELL that is not covered by fine data and has exactly one face neighbour inside the
+//      fine level gets the outer face (w.r.t. that neighbour) reset so that div(u_mac) = divu in it; grid edges / corners
+//      are left alone.  Level mask values as in the reference: interior 0, covered 1, notcovered 2, physbnd 3.
+namespace {
+
+struct MaskKey { uint64_t fl; int per[3]; int dlo[3], dhi[3]; bool operator<(const MaskKey& o) const { return std::memcmp(this, &o, sizeof(MaskKey)) < 0; } };
+
+// the level mask (2 ghost cells), kept as doubles in a cell-centred MultiFab
+const MultiFab& level_mask(const LayoutP& fl, const Geometry& fgeom)
+{
+    static std::map<MaskKey, std::unique_ptr<MultiFab>> cache;
+    MaskKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.fl = fl->id;
+    for (int d = 0; d < 3; ++d) { key.per[d] = fgeom.periodic[d]; key.dlo[d] = fgeom.domain.lo[d]; key.dhi[d] = fgeom.domain.hi[d]; }
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+    auto m = std::make_unique<MultiFab>(fl, cell_type(), 1, 2);
+    const BoxD dom = fgeom.domain;
+    const int p0 = fgeom.periodic[0], p1 = fgeom.periodic[1], p2 = fgeom.periodic[2];
+    const FabD* mt = m->d_tab;
+    for_each(*fl, cell_type(), 2, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const bool in = (p0 || (i >= dom.lo[0] && i <= dom.hi[0])) && (p1 || (j >= dom.lo[1] && j <= dom.hi[1])) && (p2 || (k >= dom.lo[2] && k <= dom.hi[2]));
+        mt[f](i, j, k) = in ? 2.0 : 3.0;                                   // notcovered : physbnd
+    });
+    MultiFab ones(fl, cell_type(), 1, 0);
+    ones.setVal(1.0);
+    parallel_copy(*m, ones, 0, 0, 1, 0, 2, &fgeom);                        // covered (own valid region included for now)
+    for_each(*fl, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) { mt[f](i, j, k) = 0.0; });   // interior
+    return *cache.emplace(key, std::move(m)).first->second;
+}
+
+}  // namespace
+
+void create_umac_grown(MultiFab* const umac_fine[3], const MultiFab* const umac_crse[3], const MultiFab* divu,
+                       const Geometry& cgeom, const Geometry& fgeom, int ratio)
+{
+    const LayoutP fl = umac_fine[0]->layout;
+    IAMRX_ASSERT(umac_fine[0]->ngrow >= 1 && (ratio == 2 || ratio == 4));
+    auto& ctx = Context::get();
+    // coarse faces under every fine box grown by one cell
+    std::vector<BoxD> cb;
+    for (auto& b : fl->boxes) cb.push_back(coarsen(grow(b, 1), ratio));
+    static std::map<std::pair<uint64_t, int>, LayoutP> cl_cache;
+    LayoutP& cl = cl_cache[{fl->id, ratio}];
+    if (!cl) cl = std::make_shared<Layout>(cb, fl->owner, ctx.comm->rank);
+    for (int d = 0; d < 3; ++d) {
+        MultiFab& uf = *umac_fine[d];
+        MultiFab cpatch(cl, face_type(d), 1, 0);
+        cpatch.setVal(0.0);
+        parallel_copy(cpatch, *umac_crse[d], 0, 0, 1, 0, 0, &cgeom);
+        const FabD *ft = uf.d_tab, *ct = cpatch.d_tab;
+        const BoxD* vb = fl->d_boxes;
+        const int r = ratio;
+        const double rinv = 1.0 / (double)ratio;
+        // every ghost face (faces of the grown box that are not faces of the valid box) from the coarse level: FaceLinear
+        for_each(*fl, face_type(d), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const BoxD b = vb[f];
+            const int fi[3] = {i, j, k};
+            bool valid = true;
+            for (int e = 0; e < 3; ++e) valid = valid && fi[e] >= b.lo[e] && fi[e] <= b.hi[e] + (e == d ? 1 : 0);
+            if (valid) return;
+            int c[3];
+            for (int e = 0; e < 3; ++e) c[e] = fi[e] >= 0 ? fi[e] / r : -((-fi[e] + r - 1) / r);
+            const FabD cf = ct[f];
+            const int rem = fi[d] - c[d] * r;
+            double v;
+            if (rem == 0) v = cf(c[0], c[1], c[2]);
+            else {
+                const double w = (double)rem * rinv;
+                int cp[3] = {c[0], c[1], c[2]};
+                cp[d] += 1;
+                v = (1.0 - w) * cf(c[0], c[1], c[2]) + w * cf(cp[0], cp[1], cp[2]);
+            }
+            ft[f](i, j, k) = v;
+        });
+        uf.FillBoundary(fgeom);          // ghost faces covered by other fine boxes (or periodic images) take the fine data
+    }
+    // divergence fix in the not-covered ghost cells with exactly one face neighbour inside the level
+    const MultiFab& mask = level_mask(fl, fgeom);
+    const FabD *mt = mask.d_tab, *ut = umac_fine[0]->d_tab, *vt = umac_fine[1]->d_tab, *wt = umac_fine[2]->d_tab;
+    const FabD* dt_ = divu ? divu->d_tab : nullptr;
+    const BoxD* vb = fl->d_boxes;
+    const double dx0 = fgeom.dx[0], dx1 = fgeom.dx[1], dx2 = fgeom.dx[2];
+    const double dxi0 = 1.0 / dx0, dxi1 = 1.0 / dx1, dxi2 = 1.0 / dx2;
+    for_each(*fl, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD m = mt[f];
+        if (m(i, j, k) != 2.0) return;
+        int count = 0;
+        count += (m(i - 1, j, k) == 0.0 || m(i - 1, j, k) == 1.0); count += (m(i + 1, j, k) == 0.0 || m(i + 1, j, k) == 1.0);
+        count += (m(i, j - 1, k) == 0.0 || m(i, j - 1, k) == 1.0); count += (m(i, j + 1, k) == 0.0 || m(i, j + 1, k) == 1.0);
+        count += (m(i, j, k - 1) == 0.0 || m(i, j, k - 1) == 1.0); count += (m(i, j, k + 1) == 0.0 || m(i, j, k + 1) == 1.0);
+        if (count != 1) return;
+        const BoxD b = vb[f];
+        const FabD u = ut[f], v = vt[f], w = wt[f];
+        const double div = dt_ ? dt_[f](i, j, k) : 0.0;
+        const double dux = dxi0 * (u(i + 1, j, k) - u(i, j, k));
+        const double duy = dxi1 * (v(i, j + 1, k) - v(i, j, k));
+        const double duz = dxi2 * (w(i, j, k + 1) - w(i, j, k));
+        if (i < b.lo[0] && m(i + 1, j, k) != 2.0) u(i, j, k) = u(i + 1, j, k) + dx0 * (duy + duz - div);
+        else if (i > b.hi[0] && m(i - 1, j, k) != 2.0) u(i + 1, j, k) = u(i, j, k) - dx0 * (duy + duz - div);
+        if (j < b.lo[1] && m(i, j + 1, k) != 2.0) v(i, j, k) = v(i, j + 1, k) + dx1 * (dux + duz - div);
+        else if (j > b.hi[1] && m(i, j - 1, k) != 2.0) v(i, j + 1, k) = v(i, j, k) - dx1 * (dux + duz - div);
+        if (k < b.lo[2] && m(i, j, k + 1) != 2.0) w(i, j, k) = w(i, j, k + 1) + dx2 * (dux + duy - div);
+        else if (k > b.hi[2] && m(i, j, k - 1) != 2.0) w(i, j, k + 1) = w(i, j, k) - dx2 * (dux + duy - div);
+    });
+}
+
 }  // namespace iamrx

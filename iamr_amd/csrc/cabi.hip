@@ -583,6 +583,15 @@ int iamrx_fluxreg_reflux(iamrx_fluxreg fr, iamrx_mf S, double volume, double sca
 {
     IAMRX_TRY fr->fr->Reflux(S->mf, volume, scale, scomp, dcomp, ncomp); IAMRX_CATCH
 }
+int iamrx_create_umac_grown(iamrx_mf fx, iamrx_mf fy, iamrx_mf fz, iamrx_mf cx, iamrx_mf cy, iamrx_mf cz, iamrx_mf divu,
+                            const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio)
+{
+    IAMRX_TRY
+    MultiFab* uf[3] = {&fx->mf, &fy->mf, &fz->mf};
+    const MultiFab* uc[3] = {&cx->mf, &cy->mf, &cz->mf};
+    create_umac_grown(uf, uc, divu ? &divu->mf : nullptr, to_geom(cgeom), to_geom(fgeom), ratio);
+    IAMRX_CATCH
+}
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio)
 {
     IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH

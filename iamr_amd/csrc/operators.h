@@ -44,6 +44,10 @@ struct TimeData { const MultiFab* old_; const MultiFab* new_; double t_old, t_ne
 void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
                           const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
 
+// NavierStokesBase::create_umac_grown on a refined level: FaceLinear coarse-fine fill of the ghost faces + IAMR's divergence fix
+// (Source/NavierStokesBase.cpp:1108-1311); umac_fine need 1 ghost layer, divu (fine cells, >= 1 ghost) may be null
+void create_umac_grown(MultiFab* const umac_fine[3], const MultiFab* const umac_crse[3], const MultiFab* divu,
+                       const Geometry& cgeom, const Geometry& fgeom, int ratio);
 // amrex::FluxRegister / YAFluxRegister role (see amr.hip)
 class FluxRegister {
 public:

@@ -273,6 +273,11 @@ def fillpatch_two_levels(dst, time, fine, crse, cgeom, fgeom, scomp=0, ncomp=Non
                                            C.byref(cgeom), C.byref(fgeom), ratio, _bcrec(nc, bcs), el, eh))
 
 
+def create_umac_grown(umac_fine, umac_crse, cgeom, fgeom, ratio=2, divu=None):
+    check(lib().iamrx_create_umac_grown(umac_fine[0].h, umac_fine[1].h, umac_fine[2].h, umac_crse[0].h, umac_crse[1].h, umac_crse[2].h,
+                                        _h(divu), C.byref(cgeom), C.byref(fgeom), ratio))
+
+
 class FluxRegister:
     """amrex::FluxRegister role (names as in the reference: CrseInit, FineAdd, Reflux)"""
 

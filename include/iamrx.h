@@ -197,6 +197,11 @@ int iamrx_parallel_copy(iamrx_mf dst, iamrx_mf src, int scomp, int dcomp, int nc
 /* amrex::average_down / average_down_faces / average_down_nodal (by index type) as called from NavierStokesBase::avgDown_StatePress
  * (Source/NavierStokesBase.cpp:4125-4193): crse(scomp..) <- mean / injection of fine(scomp..); ratio 2 or 4 */
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio);
+/* NavierStokesBase::create_umac_grown on a refined level (Source/NavierStokesBase.cpp:1108-1311): ghost faces of the fine mac velocities
+ * (1 ghost layer) from the coarse ones (FaceLinear) or from neighbouring fine boxes, then IAMR's divergence fix of the outer face of every
+ * not-covered ghost cell that has exactly one face neighbour inside the fine level; divu: fine cells with >= 1 ghost, or NULL */
+int iamrx_create_umac_grown(iamrx_mf umac_fine_x, iamrx_mf umac_fine_y, iamrx_mf umac_fine_z, iamrx_mf umac_crse_x, iamrx_mf umac_crse_y,
+                            iamrx_mf umac_crse_z, iamrx_mf divu, const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio);
 /* amrex::FluxRegister / YAFluxRegister role for one coarse-fine interface (advective registers: Source/NavierStokesBase.cpp:5036-5096,
  * viscous: Source/NavierStokes.cpp:975-992, Source/Diffusion.cpp:940-953; consumer NavierStokes::reflux, Source/NavierStokes.cpp:1736-1838).
  * Fluxes are extensive (area-weighted) as in IAMR.  crse_init: reg = (add: +=) mult*coarse flux; fine_add: reg += mult * sum of the fine

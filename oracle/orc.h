@@ -65,6 +65,9 @@ void orc_fill_periodic(orc_fab* f, const orc_geom* g, const int type[3]);
 void orc_fill_coarse_fine(orc_fab* fine, const int flo[3], const int fhi[3], const int vlo[3], const int vhi[3],
                           const orc_fab* crse, const int cdomlo[3], const int cdomhi[3], const int periodic[3], int ratio,
                           const orc_bcrec* bc);
+/* NavierStokesBase::create_umac_grown on a refined level, single fine box (see orc_fill.c) */
+void orc_create_umac_grown(orc_fab* uf[3], const int vlo[3], const int vhi[3], const orc_fab* uc[3], int ratio,
+                           const double fdx[3], const int fdom_n[3], const int periodic[3]);
 void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
                         const double* extdir_lo /*[nc][3]*/, const double* extdir_hi);
 

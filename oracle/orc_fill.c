@@ -164,3 +164,63 @@ void orc_fill_coarse_fine(orc_fab* fine, const int flo[3], const int fhi[3], con
         }
     }
 }
+
+/* ---- NavierStokesBase::create_umac_grown on a refined level, one fine box (reference Source/NavierStokesBase.cpp:1108-1311):
+ * ghost faces by FaceLinear interpolation of the coarse mac velocities (linear in the face-normal direction between the two
+ * coarse faces, piecewise constant transversally), then the in-tree divergence fix: a ghost cell inside the domain with
+ * exactly one face neighbour in the valid box gets its outer face reset so that div(u_mac) = 0 in it. */
+void orc_create_umac_grown(orc_fab* uf[3], const int vlo[3], const int vhi[3], const orc_fab* uc[3], int ratio,
+                           const double fdx[3], const int fdom_n[3], const int periodic[3])
+{
+    for (int d = 0; d < 3; ++d) {
+        orc_fab* f = uf[d];
+        for (int k = f->lo[2]; k <= f->hi[2]; ++k) for (int j = f->lo[1]; j <= f->hi[1]; ++j) for (int i = f->lo[0]; i <= f->hi[0]; ++i) {
+            const int fi[3] = {i, j, k};
+            int valid = 1;
+            for (int e = 0; e < 3; ++e) if (fi[e] < vlo[e] || fi[e] > vhi[e] + (e == d ? 1 : 0)) valid = 0;
+            if (valid) continue;
+            int c[3];
+            for (int e = 0; e < 3; ++e) c[e] = fi[e] >= 0 ? fi[e] / ratio : -((-fi[e] + ratio - 1) / ratio);
+            const int rem = fi[d] - c[d] * ratio;
+            double v;
+            if (rem == 0) v = A4(uc[d], c[0], c[1], c[2], 0);
+            else {
+                const double w = (double)rem / (double)ratio;
+                int cp[3] = {c[0], c[1], c[2]}; cp[d] += 1;
+                v = (1.0 - w) * A4(uc[d], c[0], c[1], c[2], 0) + w * A4(uc[d], cp[0], cp[1], cp[2], 0);
+            }
+            A4(f, i, j, k, 0) = v;
+        }
+    }
+    /* level mask on the box grown by 2: 0 interior, 2 not covered, 3 outside the physical domain */
+    #define MASK(i, j, k) mask_of(i, j, k, vlo, vhi, fdom_n, periodic)
+    for (int k = vlo[2] - 1; k <= vhi[2] + 1; ++k) for (int j = vlo[1] - 1; j <= vhi[1] + 1; ++j) for (int i = vlo[0] - 1; i <= vhi[0] + 1; ++i) {
+        int idx[3] = {i, j, k};
+        int m = 0, outside = 0;
+        for (int e = 0; e < 3; ++e) { if (idx[e] < vlo[e] || idx[e] > vhi[e]) m = 2; if (!periodic[e] && (idx[e] < 0 || idx[e] > fdom_n[e] - 1)) outside = 1; }
+        if (m != 2 || outside) continue;
+        int count = 0;
+        for (int e = 0; e < 3; ++e)
+            for (int s = -1; s <= 1; s += 2) {
+                int q[3] = {i, j, k}; q[e] += s;
+                int in = 1;
+                for (int r = 0; r < 3; ++r) if (q[r] < vlo[r] || q[r] > vhi[r]) in = 0;
+                count += in;
+            }
+        if (count != 1) continue;
+        orc_fab *u = uf[0], *v = uf[1], *w = uf[2];
+        const double dux = (A4(u, i + 1, j, k, 0) - A4(u, i, j, k, 0)) / fdx[0];
+        const double duy = (A4(v, i, j + 1, k, 0) - A4(v, i, j, k, 0)) / fdx[1];
+        const double duz = (A4(w, i, j, k + 1, 0) - A4(w, i, j, k, 0)) / fdx[2];
+        /* "m(i+1,j,k) != notcovered" for a single box == that neighbour is interior */
+        #define INBOX(a, b, c) ((a) >= vlo[0] && (a) <= vhi[0] && (b) >= vlo[1] && (b) <= vhi[1] && (c) >= vlo[2] && (c) <= vhi[2])
+        if (i < vlo[0] && INBOX(i + 1, j, k)) A4(u, i, j, k, 0) = A4(u, i + 1, j, k, 0) + fdx[0] * (duy + duz - 0.0);
+        else if (i > vhi[0] && INBOX(i - 1, j, k)) A4(u, i + 1, j, k, 0) = A4(u, i, j, k, 0) - fdx[0] * (duy + duz - 0.0);
+        if (j < vlo[1] && INBOX(i, j + 1, k)) A4(v, i, j, k, 0) = A4(v, i, j + 1, k, 0) + fdx[1] * (dux + duz - 0.0);
+        else if (j > vhi[1] && INBOX(i, j - 1, k)) A4(v, i, j + 1, k, 0) = A4(v, i, j, k, 0) - fdx[1] * (dux + duz - 0.0);
+        if (k < vlo[2] && INBOX(i, j, k + 1)) A4(w, i, j, k, 0) = A4(w, i, j, k + 1, 0) + fdx[2] * (dux + duy - 0.0);
+        else if (k > vhi[2] && INBOX(i, j, k - 1)) A4(w, i, j, k + 1, 0) = A4(w, i, j, k, 0) - fdx[2] * (dux + duy - 0.0);
+        #undef INBOX
+    }
+    #undef MASK
+}
