@@ -67,7 +67,7 @@ static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only)
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -88,9 +88,11 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
             const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
             const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
-            const double bxm = bX(i, j, k, nb), bxp = bX(i + 1, j, k, nb);
-            const double bym = bY(i, j, k, nb), byp = bY(i, j + 1, k, nb);
-            const double bzm = bZ(i, j, k, nb), bzp = bZ(i, j, k + 1, nb);
+            // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
+            const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
+            const double bxm = bX(i, j, k, nb) * sx, bxp = bX(i + 1, j, k, nb) * sx;
+            const double bym = bY(i, j, k, nb) * sy, byp = bY(i, j + 1, k, nb) * sy;
+            const double bzm = bZ(i, j, k, nb) * sz, bzp = bZ(i, j, k + 1, nb) * sz;
             const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
@@ -115,7 +117,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
     hipLaunchKernelGGL(k_abec_gsrb, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0);
+                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
 }
 
 // ---------------------------------------------------------------------------- fused red+black sweep
@@ -129,7 +131,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
 template <int TX, int TY>
 __global__ void __launch_bounds__(256) k_abec_gsrb_fused(const BoxD* __restrict__ boxes, const FabD* __restrict__ pint, const FabD* __restrict__ poutt,
     const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, double omega, int ncomp, int bnc, GsrbBC bc, int ntx, int nty, int kc)
+    double alpha, double dhx, double dhy, double dhz, double omega, int ncomp, int bnc, GsrbBC bc, int ntx, int nty, int kc, int tens)
 {
     static_assert(TX * TY == 512, "one red and one black cell per thread and plane");
     constexpr int FX = TX + 4, FY = TY + 4, NLD = (FX * FY + 255) / 256;
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb_fused(const BoxD* __restrict_
     for (int n = 0; n < ncomp; ++n) {
         const int nb = bnc == 1 ? 0 : n;
         const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
+        const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
         const FabD::gdouble* pp = (const FabD::gdouble*)pin.p + pin.cs * n;
         auto fetch_plane = [&](int m, double (&v)[NLD]) {
             const int mc = min(max(m, pklo), pkhi);
@@ -188,9 +191,9 @@ __global__ void __launch_bounds__(256) k_abec_gsrb_fused(const BoxD* __restrict_
         auto fetch_cf = [&](int i, int j, int m) {
             const int ic = min(max(i, b.lo[0]), b.hi[0]), jc = min(max(j, b.lo[1]), b.hi[1]), mc = min(max(m, b.lo[2]), b.hi[2]);
             Cf c;
-            c.bxm = bX(ic, jc, mc, nb); c.bxp = bX(ic + 1, jc, mc, nb);
-            c.bym = bY(ic, jc, mc, nb); c.byp = bY(ic, jc + 1, mc, nb);
-            c.bzm = bZ(ic, jc, mc, nb); c.bzp = bZ(ic, jc, mc + 1, nb);
+            c.bxm = bX(ic, jc, mc, nb) * sx; c.bxp = bX(ic + 1, jc, mc, nb) * sx;
+            c.bym = bY(ic, jc, mc, nb) * sy; c.byp = bY(ic, jc + 1, mc, nb) * sy;
+            c.bzm = bZ(ic, jc, mc, nb) * sz; c.bzp = bZ(ic, jc, mc + 1, nb) * sz;
             c.aa = has_a ? A(ic, jc, mc, 0) : 0.0;
             c.r = rhs(ic, jc, mc, n);
             return c;
@@ -279,14 +282,14 @@ void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_i
     dim3 grid((unsigned)(ntx * nty * nck), (unsigned)l.nlocal());
     hipLaunchKernelGGL((k_abec_gsrb_fused<TX, TY>), grid, dim3(256), 0, ctx.stream, l.d_boxes, phi_in.d_tab, phi_out.d_tab, rhs.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, omega, phi_in.ncomp, c.b[0]->ncomp, gb, ntx, nty, kc);
+                       c.alpha, dhx, dhy, dhz, omega, phi_in.ncomp, c.b[0]->ncomp, gb, ntx, nty, kc, c.tensor_eta);
 }
 
 // ---------------------------------------------------------------------------- residual / apply
 __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ outt, const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc)
+    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc, int tens)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -299,14 +302,15 @@ __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __r
     FabD A; if (has_a) A = at[fab];
     for (int n = 0; n < ncomp; ++n) {
         const int nb = bnc == 1 ? 0 : n;
+        const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
         double pm = phi(i, j, k0 - 1, n), p0 = phi(i, j, k0, n);
         for (int k = k0; k <= k1; ++k) {
             const double pp = phi(i, j, k + 1, n);
             const double ax = has_a ? alpha * A(i, j, k, 0) * p0 : 0.0;
             const double y = ax
-                - dhx * (bX(i + 1, j, k, nb) * (phi(i + 1, j, k, n) - p0) - bX(i, j, k, nb) * (p0 - phi(i - 1, j, k, n)))
-                - dhy * (bY(i, j + 1, k, nb) * (phi(i, j + 1, k, n) - p0) - bY(i, j, k, nb) * (p0 - phi(i, j - 1, k, n)))
-                - dhz * (bZ(i, j, k + 1, nb) * (pp - p0) - bZ(i, j, k, nb) * (p0 - pm));
+                - dhx * ((bX(i + 1, j, k, nb) * sx) * (phi(i + 1, j, k, n) - p0) - (bX(i, j, k, nb) * sx) * (p0 - phi(i - 1, j, k, n)))
+                - dhy * ((bY(i, j + 1, k, nb) * sy) * (phi(i, j + 1, k, n) - p0) - (bY(i, j, k, nb) * sy) * (p0 - phi(i, j - 1, k, n)))
+                - dhz * ((bZ(i, j, k + 1, nb) * sz) * (pp - p0) - (bZ(i, j, k, nb) * sz) * (p0 - pm));
             out(i, j, k, n) = has_rhs ? rhs(i, j, k, n) - y : y;
             pm = p0; p0 = pp;
         }
@@ -324,7 +328,7 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     hipLaunchKernelGGL(k_abec_residual, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
                        rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp);
+                       c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta);
     if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0);
 }
 

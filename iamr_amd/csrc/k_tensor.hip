@@ -11,10 +11,14 @@
 namespace iamrx {
 
 // cross flux on the d-face (i,j,k) for component n.  eta_n = b_d(comp d) * 3/4 (normal), eta_t = b_d(comp != d)
-template <int D>
+// ETA1: eta holds the 1-component face viscosity (b_d(comp) is formed here exactly as tensor_bcoef stores it)
+template <int D, bool ETA1>
 __device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i, int j, int k, double dxi, double dyi, double dzi, double f[3])
 {
     constexpr double twoThirds = 2.0 / 3.0;
+    const double e1 = ETA1 ? eta(i, j, k, 0) : 0.0;
+    const double bn = ETA1 ? e1 * (4.0 / 3.0) : eta(i, j, k, D);        // normal component coefficient
+    const double bt = ETA1 ? e1 * 1.0 : eta(i, j, k, D == 0 ? 1 : 0);   // tangential
     if (D == 0) {
         const double dudy = (v(i, j + 1, k, 0) + v(i - 1, j + 1, k, 0) - v(i, j - 1, k, 0) - v(i - 1, j - 1, k, 0)) * (0.25 * dyi);
         const double dvdy = (v(i, j + 1, k, 1) + v(i - 1, j + 1, k, 1) - v(i, j - 1, k, 1) - v(i - 1, j - 1, k, 1)) * (0.25 * dyi);
@@ -22,7 +26,7 @@ __device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i
         const double dwdz = (v(i, j, k + 1, 2) + v(i - 1, j, k + 1, 2) - v(i, j, k - 1, 2) - v(i - 1, j, k - 1, 2)) * (0.25 * dzi);
         const double divu = dvdy + dwdz;
         const double xif = 0.0;
-        const double mun = 0.75 * (eta(i, j, k, 0) - xif), mut = eta(i, j, k, 1);
+        const double mun = 0.75 * (bn - xif), mut = bt;
         f[0] = -mun * (-twoThirds * divu) - xif * divu;
         f[1] = -mut * dudy;
         f[2] = -mut * dudz;
@@ -33,7 +37,7 @@ __device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i
         const double dwdz = (v(i, j, k + 1, 2) + v(i, j - 1, k + 1, 2) - v(i, j, k - 1, 2) - v(i, j - 1, k - 1, 2)) * (0.25 * dzi);
         const double divu = dudx + dwdz;
         const double xif = 0.0;
-        const double mun = 0.75 * (eta(i, j, k, 1) - xif), mut = eta(i, j, k, 0);
+        const double mun = 0.75 * (bn - xif), mut = bt;
         f[0] = -mut * dvdx;
         f[1] = -mun * (-twoThirds * divu) - xif * divu;
         f[2] = -mut * dvdz;
@@ -44,13 +48,14 @@ __device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i
         const double dwdy = (v(i, j + 1, k, 2) + v(i, j + 1, k - 1, 2) - v(i, j - 1, k, 2) - v(i, j - 1, k - 1, 2)) * (0.25 * dyi);
         const double divu = dudx + dvdy;
         const double xif = 0.0;
-        const double mun = 0.75 * (eta(i, j, k, 2) - xif), mut = eta(i, j, k, 0);
+        const double mun = 0.75 * (bn - xif), mut = bt;
         f[0] = -mut * dwdx;
         f[1] = -mut * dwdy;
         f[2] = -mun * (-twoThirds * divu) - xif * divu;
     }
 }
 
+template <bool ETA1>
 __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ outt,
     const FabD* __restrict__ vt, const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
     double dxi, double dyi, double dzi, double sbeta)
@@ -60,14 +65,14 @@ __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __re
     if (!tile_ijk(t, boxes[fab], i, j, k0, k1)) return;
     const FabD out = outt[fab], v = vt[fab], ex = ext[fab], ey = eyt[fab], ez = ezt[fab];
     double fzl[3];
-    cross_flux<2>(v, ez, i, j, k0, dxi, dyi, dzi, fzl);
+    cross_flux<2, ETA1>(v, ez, i, j, k0, dxi, dyi, dzi, fzl);
     for (int k = k0; k <= k1; ++k) {
         double fxl[3], fxh[3], fyl[3], fyh[3], fzh[3];
-        cross_flux<0>(v, ex, i, j, k, dxi, dyi, dzi, fxl);
-        cross_flux<0>(v, ex, i + 1, j, k, dxi, dyi, dzi, fxh);
-        cross_flux<1>(v, ey, i, j, k, dxi, dyi, dzi, fyl);
-        cross_flux<1>(v, ey, i, j + 1, k, dxi, dyi, dzi, fyh);
-        cross_flux<2>(v, ez, i, j, k + 1, dxi, dyi, dzi, fzh);
+        cross_flux<0, ETA1>(v, ex, i, j, k, dxi, dyi, dzi, fxl);
+        cross_flux<0, ETA1>(v, ex, i + 1, j, k, dxi, dyi, dzi, fxh);
+        cross_flux<1, ETA1>(v, ey, i, j, k, dxi, dyi, dzi, fyl);
+        cross_flux<1, ETA1>(v, ey, i, j + 1, k, dxi, dyi, dzi, fyh);
+        cross_flux<2, ETA1>(v, ez, i, j, k + 1, dxi, dyi, dzi, fzh);
         for (int n = 0; n < 3; ++n) {
             out(i, j, k, n) += sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
             fzl[n] = fzh[n];
@@ -79,9 +84,14 @@ __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __re
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign)
 {
     if (out.nlocal() == 0) return;
-    IAMRX_ASSERT(vel.ncomp == 3 && c.b[0]->ncomp == 3);
+    IAMRX_ASSERT(vel.ncomp == 3 && c.b[0]->ncomp == (c.tensor_eta ? 1 : 3));
     Tiling t = level_tiling(*out.layout, cell_type(), 0, 8);
-    hipLaunchKernelGGL(k_tensor_cross, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
+    if (c.tensor_eta) {
+        hipLaunchKernelGGL(k_tensor_cross<true>, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
+                           c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta);
+        return;
+    }
+    hipLaunchKernelGGL(k_tensor_cross<false>, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
                        c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta);
 }
 

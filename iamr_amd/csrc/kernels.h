@@ -34,6 +34,7 @@ struct AbecCoef {
     const MultiFab* a;        // cell, 1 comp (may be null)
     const MultiFab* b[3];     // face, ncomp comps (or 1 comp broadcast if b_ncomp == 1)
     int tensor;               // add MLTensorOp cross terms in apply/residual
+    int tensor_eta = 0;       // b[d] hold the 1-component face viscosity eta_d; the kernels apply b_d(comp) = eta_d * (comp == d ? 4/3 : 1)
 };
 struct DomainBC {             // linear-operator BC of the level's domain
     int lo[3], hi[3];         // LinOpBC per face

@@ -45,6 +45,9 @@ public:
     void setACoeffs(const MultiFab* a) { m_a0 = a; }
     void setBCoeffs(const MultiFab* const b[3]) { for (int d = 0; d < 3; ++d) m_b0[d] = b[d]; }
     void setTensor(bool t) { m_tensor = t; }
+    // tensor operator with the B coefficients given as the 1-component face viscosity: the finest level streams eta instead of the
+    // three-component b = eta * (4/3 on the normal component) arrays (a third of the coefficient traffic of the smoother)
+    void setTensorEta(bool t) { m_tensor_eta = t; }
     // one DomainBC per component (MLTensorOp::setDomainBC with per-component arrays)
     void setDomainBCs(const DomainBC* bcs, int n) { m_bcn.assign(bcs, bcs + n); }
     void prepare();   // build the coarse hierarchy (coefficient averaging)
@@ -89,6 +92,7 @@ private:
     const MultiFab* m_a0 = nullptr;
     const MultiFab* m_b0[3] = {nullptr, nullptr, nullptr};
     bool m_tensor = false;
+    bool m_tensor_eta = false;
     bool m_singular = false;
     std::vector<Level> m_lev;
 };

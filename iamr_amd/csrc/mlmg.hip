@@ -32,6 +32,7 @@ AbecCoef CellMG::coef(int l) const
     if (l == 0) {
         c.a = m_a0;
         for (int d = 0; d < 3; ++d) c.b[d] = m_b0[d];
+        c.tensor_eta = m_tensor_eta ? 1 : 0;
     } else {
         c.a = m_a0 ? &m_lev[l].a : nullptr;
         for (int d = 0; d < 3; ++d) c.b[d] = &m_lev[l].b[d];
@@ -80,9 +81,13 @@ void CellMG::prepare()
                 else cc_restrict(L.a, *fc.a);
             }
             for (int d = 0; d < 3; ++d) {
-                L.b[d].define(L.layout, face_type(d), fc.b[d]->ncomp, 0);
-                if (L.agg) { MultiFab t(L.dist, face_type(d), fc.b[d]->ncomp, 0); face_avgdown(t, *fc.b[d], d); gather_to_replicated(L.b[d], t); }
-                else face_avgdown(L.b[d], *fc.b[d], d);
+                // coarsening the finest level of an eta-form tensor operator: average the three-component coefficients it stands for
+                MultiFab b3;
+                const MultiFab* fb = fc.b[d];
+                if (l == 1 && m_tensor_eta) { b3.define(m_lev[0].layout, face_type(d), 3, 0); tensor_bcoef(b3, *fc.b[d], d); fb = &b3; }
+                L.b[d].define(L.layout, face_type(d), fb->ncomp, 0);
+                if (L.agg) { MultiFab t(L.dist, face_type(d), fb->ncomp, 0); face_avgdown(t, *fb, d); gather_to_replicated(L.b[d], t); }
+                else face_avgdown(L.b[d], *fb, d);
             }
         }
     }

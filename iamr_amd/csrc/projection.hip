@@ -10,6 +10,7 @@
 // (Source/Diffusion.cpp:1655-1777) and Diffusion::diffuse_tensor_velocity (:650-957).
 #include "operators.h"
 #include "launch.h"
+#include <cstdlib>
 
 namespace iamrx {
 
@@ -32,11 +33,14 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
 static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], LayoutP layout, double a_scalar, double b_scalar,
                          const MultiFab* acoef, const MultiFab* const eta[3])
 {
+    static const bool eta_form = !(getenv("IAMRX_TENSOR_ETA") && atoi(getenv("IAMRX_TENSOR_ETA")) == 0);
     for (int d = 0; d < 3; ++d) {
+        if (eta_form) { bp[d] = eta[d]; continue; }
         tb[d].define(layout, face_type(d), 3, 0);
         tensor_bcoef(tb[d], *eta[d], d);
         bp[d] = &tb[d];
     }
+    mg.setTensorEta(eta_form);
     mg.setScalars(a_scalar, b_scalar);
     if (acoef) mg.setACoeffs(acoef);
     mg.setBCoeffs(bp);
