@@ -64,6 +64,8 @@ static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
 // One thread per cell of the active colour: lane m of a row handles i = lo + 2m + parity, so a
 // wavefront sweeps 128 consecutive cells of a row; phi(i+-1) and the b pairs are contiguous across
 // lanes.  b arrays have either ncomp comps or 1 (broadcast).
+// SHARE: several components on one shared 1-component coefficient set (eta form of the tensor operator)
+template <bool SHARE>
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
@@ -78,6 +80,40 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
+    if (SHARE) {
+    // plane loop outside, component loop inside: a one-component coefficient set (bnc == 1: scalar problems and the eta form of
+    // the tensor operator) is then read once per cell and shared by all components
+    for (int k = k0; k <= k1; ++k) {
+        const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
+        if (i > b.hi[0]) continue;
+        if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
+        double b1xm = 0, b1xp = 0, b1ym = 0, b1yp = 0, b1zm = 0, b1zp = 0;
+        if (bnc == 1) {
+            b1xm = bX(i, j, k, 0); b1xp = bX(i + 1, j, k, 0); b1ym = bY(i, j, k, 0); b1yp = bY(i, j + 1, k, 0); b1zm = bZ(i, j, k, 0); b1zp = bZ(i, j, k + 1, 0);
+        }
+        const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
+        for (int n = 0; n < ncomp; ++n) {
+            const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
+            const double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
+            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
+            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
+            const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
+            const double bxm = (bnc == 1 ? b1xm : bX(i, j, k, n)) * sx, bxp = (bnc == 1 ? b1xp : bX(i + 1, j, k, n)) * sx;
+            const double bym = (bnc == 1 ? b1ym : bY(i, j, k, n)) * sy, byp = (bnc == 1 ? b1yp : bY(i, j + 1, k, n)) * sy;
+            const double bzm = (bnc == 1 ? b1zm : bZ(i, j, k, n)) * sz, bzp = (bnc == 1 ? b1zp : bZ(i, j, k + 1, n)) * sz;
+            const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+            const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
+            const double rho = dhx * (bxm * phi(i - 1, j, k, n) + bxp * phi(i + 1, j, k, n))
+                             + dhy * (bym * phi(i, j - 1, k, n) + byp * phi(i, j + 1, k, n))
+                             + dhz * (bzm * phi(i, j, k - 1, n) + bzp * phi(i, j, k + 1, n));
+            const double p0 = phi(i, j, k, n);
+            const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
+            phi(i, j, k, n) = p0 + omega / g_m_d * res;
+        }
+    }
+        return;
+    }
     for (int n = 0; n < ncomp; ++n) {
         const int nb = bnc == 1 ? 0 : n;
         const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
@@ -115,9 +151,14 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     Tiling t = make_tiling(ml, l.nlocal(), 8);
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
-    hipLaunchKernelGGL(k_abec_gsrb, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
-                       c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
+    if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
+        hipLaunchKernelGGL(k_abec_gsrb<true>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                           c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
+    else
+        hipLaunchKernelGGL(k_abec_gsrb<false>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                           c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
 }
 
 // ---------------------------------------------------------------------------- fused red+black sweep
