@@ -208,7 +208,20 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // to xo.  In place, a workgroup could read halo nodes of plane k that a neighbouring workgroup has already updated (not
 // all workgroups of a large level are resident together), which would silently change the Gauss-Seidel ordering.
 // HBM traffic per sweep drops from 8 full-array passes to 2; kernel launches from 8+8 fills to 2+2.
-template <int TX, int TY>
+// periodic image of a node / cell index inside the one box [lo, hi] (cells) that spans the periodic domain
+__device__ __forceinline__ int wrap_node(int g, int lo, int hi)
+{
+    // the staging halo is one node wide and the box has >= 2 cells: one conditional shift is enough
+    const int n = hi - lo + 1;
+    return g < lo ? g + n : (g > hi + 1 ? g - n : g);
+}
+__device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
+{
+    const int n = hi - lo + 1;
+    return g < lo ? g + n : (g > hi ? g - n : g);
+}
+
+template <int TX, int TY, bool WRAP>
 __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk)
 {
@@ -252,21 +265,30 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
         // arrays instead of predicated -- footprint points beyond the ghost width are never used by the colour passes)
         constexpr int NLD = (RX * RY + 255) / 256;
         double v[NLD][6];
-        const long xo_k = (long)x.n[0] * x.n[1], so_k = (long)s.n[0] * s.n[1];
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int idx = min(tid + it * 256, RX * RY - 1);
             const int lx = idx % RX, ly = idx / RX;
             const int gi = ox + lx, gj = oy + ly;
-            const int xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1), xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
-            const int si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1), sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
-            const int ri = min(max(gi, r.lo[0]), r.lo[0] + r.n[0] - 1), rj = min(max(gj, r.lo[1]), r.lo[1] + r.n[1] - 1);
-            const long xoff = x.off(xi, xj, k), soff = s.off(si, sj, k);
-            v[it][0] = ((FabD::gdouble*)xn.p)[xoff - xo_k];
-            v[it][1] = ((FabD::gdouble*)x.p)[xoff];
-            v[it][2] = ((FabD::gdouble*)xn.p)[xoff + xo_k];
-            v[it][3] = ((FabD::gdouble*)s.p)[soff - so_k];
-            v[it][4] = ((FabD::gdouble*)s.p)[soff];
+            int xi, xj, si, sj, ri, rj, xkm = k - 1, xkp = k + 1, skm = k - 1, sk0 = k;
+            if constexpr (WRAP) {
+                // the box spans the periodic domain: a ghost index is the periodic image of a valid index of the SAME box, so the
+                // staging reads the valid data directly and no ghost fill is needed (node hi+1 duplicates node lo)
+                xi = wrap_node(gi, cb.lo[0], cb.hi[0]); xj = wrap_node(gj, cb.lo[1], cb.hi[1]);
+                si = wrap_cell(gi, cb.lo[0], cb.hi[0]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]);
+                ri = xi; rj = xj;
+                xkm = wrap_node(k - 1, cb.lo[2], cb.hi[2]); xkp = wrap_node(k + 1, cb.lo[2], cb.hi[2]);
+                skm = wrap_cell(k - 1, cb.lo[2], cb.hi[2]); sk0 = wrap_cell(k, cb.lo[2], cb.hi[2]);
+            } else {
+                xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
+                si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
+                ri = min(max(gi, r.lo[0]), r.lo[0] + r.n[0] - 1); rj = min(max(gj, r.lo[1]), r.lo[1] + r.n[1] - 1);
+            }
+            v[it][0] = xn(xi, xj, xkm);
+            v[it][1] = x(xi, xj, k);
+            v[it][2] = xn(xi, xj, xkp);
+            v[it][3] = s(si, sj, skm);
+            v[it][4] = s(si, sj, sk0);
             v[it][5] = r(ri, rj, k);
         }
 #pragma unroll
@@ -316,8 +338,20 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
 #undef COL
 }
 
+// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see nodal_gs_wrap_ok
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
-void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar)
+// true if the level is one box that spans a fully periodic domain: the fused pass can then read periodic images straight from
+// the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
+bool nodal_gs_wrap_ok(const Geometry& g, const Layout& l)
+{
+    static const bool on = !(getenv("IAMRX_NODAL_WRAP") && atoi(getenv("IAMRX_NODAL_WRAP")) == 0);
+    if (!on || l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    for (int d = 0; d < 3; ++d)
+        if (!g.periodic[d] || l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < 2) return false;
+    return true;
+}
+
+void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap)
 {
     const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
@@ -335,8 +369,12 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
         gx = 8u * (unsigned)(maxcnt * npl);
     }
     dim3 grid(gx, (unsigned)l.nlocal());
-    hipLaunchKernelGGL((k_nodal_gs4<TX, TY>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab, sig.d_tab,
-                       make_w(g), kpar, ntx, nty, xcd_chunk);
+    if (wrap)
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, true>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
+                           sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
+    else
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, false>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
+                           sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -74,7 +74,9 @@ void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const M
 void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
 // one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3), out of place: plane k from xc, planes
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
-void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar);
+void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
+                         bool wrap = false);
+bool nodal_gs_wrap_ok(const Geometry& g, const Layout& l);
 // all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);

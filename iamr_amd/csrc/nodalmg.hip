@@ -15,7 +15,6 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
-void nodal_gs_fused_pass(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int kpar);
 
 static bool nodal_fused()
 {
@@ -110,14 +109,16 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         // colours 0-3 (k even) in one pass, colours 4-7 (k odd) in a second one: identical arithmetic to the eight
         // sequential colour passes below.  Each sweep goes from one buffer to the other (see k_nodal_gs4).
         if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
-        fillbc(l, const_cast<MultiFab&>(rhs));
+        // one box spanning a fully periodic domain: the kernel takes periodic images from the valid data, no ghost fills
+        const bool wrap = nodal_gs_wrap_ok(L.g, *L.layout);
+        if (!wrap) fillbc(l, const_cast<MultiFab&>(rhs));
         MultiFab* a = &x;
         MultiFab* b = &L.xb;
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
-            fillbc(l, *a);
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0);      // even planes: a -> b
-            fillbc(l, *b);                                             // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1);      // odd planes: centre from a, neighbours from b
+            if (!wrap) fillbc(l, *a);
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap);      // even planes: a -> b
+            if (!wrap) fillbc(l, *b);                                        // ghost images of the new even planes
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
