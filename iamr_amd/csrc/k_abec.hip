@@ -69,7 +69,7 @@ template <bool SHARE>
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens)
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
+    // wrap: the box spans a fully periodic domain, neighbours across the box faces are the periodic images inside the same box
+    // (no ghost fill needed in front of the sweep)
+    const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
     if (SHARE) {
     // plane loop outside, component loop inside: a one-component coefficient set (bnc == 1: scalar problems and the eta form of
     // the tensor operator) is then read once per cell and shared by all components
@@ -87,6 +90,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
         const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
         if (i > b.hi[0]) continue;
         if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
+        const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
+        const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
         double b1xm = 0, b1xp = 0, b1ym = 0, b1yp = 0, b1zm = 0, b1zp = 0;
         if (bnc == 1) {
             b1xm = bX(i, j, k, 0); b1xp = bX(i + 1, j, k, 0); b1ym = bY(i, j, k, 0); b1yp = bY(i, j + 1, k, 0); b1zm = bZ(i, j, k, 0); b1zp = bZ(i, j, k + 1, 0);
@@ -104,9 +109,9 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double bzm = (bnc == 1 ? b1zm : bZ(i, j, k, n)) * sz, bzp = (bnc == 1 ? b1zp : bZ(i, j, k + 1, n)) * sz;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
-            const double rho = dhx * (bxm * phi(i - 1, j, k, n) + bxp * phi(i + 1, j, k, n))
-                             + dhy * (bym * phi(i, j - 1, k, n) + byp * phi(i, j + 1, k, n))
-                             + dhz * (bzm * phi(i, j, k - 1, n) + bzp * phi(i, j, k + 1, n));
+            const double rho = dhx * (bxm * phi(im, j, k, n) + bxp * phi(ip, j, k, n))
+                             + dhy * (bym * phi(i, jm, k, n) + byp * phi(i, jp, k, n))
+                             + dhz * (bzm * phi(i, j, km, n) + bzp * phi(i, j, kp, n));
             const double p0 = phi(i, j, k, n);
             const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
             phi(i, j, k, n) = p0 + omega / g_m_d * res;
@@ -124,6 +129,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
             const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
             const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
+            const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
             // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
             const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
             const double bxm = bX(i, j, k, nb) * sx, bxp = bX(i + 1, j, k, nb) * sx;
@@ -132,9 +139,9 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
-            const double rho = dhx * (bxm * phi(i - 1, j, k, n) + bxp * phi(i + 1, j, k, n))
-                             + dhy * (bym * phi(i, j - 1, k, n) + byp * phi(i, j + 1, k, n))
-                             + dhz * (bzm * phi(i, j, k - 1, n) + bzp * phi(i, j, k + 1, n));
+            const double rho = dhx * (bxm * phi(im, j, k, n) + bxp * phi(ip, j, k, n))
+                             + dhy * (bym * phi(i, jm, k, n) + byp * phi(i, jp, k, n))
+                             + dhz * (bzm * phi(i, j, km, n) + bzp * phi(i, j, kp, n));
             const double p0 = phi(i, j, k, n);
             const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
             phi(i, j, k, n) = p0 + omega / g_m_d * res;
@@ -142,7 +149,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     }
 }
 
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only)
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
+               bool wrap)
 {
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
@@ -154,11 +162,11 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
         hipLaunchKernelGGL(k_abec_gsrb<true>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0);
     else
         hipLaunchKernelGGL(k_abec_gsrb<false>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------- fused red+black sweep

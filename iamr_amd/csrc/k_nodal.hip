@@ -338,13 +338,12 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
 #undef COL
 }
 
-// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see nodal_gs_wrap_ok
-// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
-// true if the level is one box that spans a fully periodic domain: the fused pass can then read periodic images straight from
+// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
+// true if the level is one box that spans a fully periodic domain: the smoother kernels can then read periodic images straight from
 // the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
-bool nodal_gs_wrap_ok(const Geometry& g, const Layout& l)
+bool periodic_wrap_ok(const Geometry& g, const Layout& l)
 {
-    static const bool on = !(getenv("IAMRX_NODAL_WRAP") && atoi(getenv("IAMRX_NODAL_WRAP")) == 0);
+    static const bool on = !(getenv("IAMRX_PERIODIC_WRAP") && atoi(getenv("IAMRX_PERIODIC_WRAP")) == 0);
     if (!on || l.boxes.size() != 1 || l.nlocal() != 1) return false;
     for (int d = 0; d < 3; ++d)
         if (!g.periodic[d] || l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < 2) return false;

@@ -42,7 +42,7 @@ struct DomainBC {             // linear-operator BC of the level's domain
 };
 // bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc,
-               bool shell_only = false);
+               bool shell_only = false, bool wrap = false);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,
@@ -76,7 +76,7 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
                          bool wrap = false);
-bool nodal_gs_wrap_ok(const Geometry& g, const Layout& l);
+bool periodic_wrap_ok(const Geometry& g, const Layout& l);
 // all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
