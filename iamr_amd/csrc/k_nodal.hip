@@ -211,7 +211,7 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // periodic image of a node / cell index inside the one box [lo, hi] (cells) that spans the periodic domain
 __device__ __forceinline__ int wrap_node(int g, int lo, int hi)
 {
-    // the staging halo is one node wide and the box has >= 2 cells: one conditional shift is enough
+    // the staging halo is 4 nodes wide and the box has >= 4 cells (periodic_wrap_ok(g, l, 4)): one conditional shift is enough
     const int n = hi - lo + 1;
     return g < lo ? g + n : (g > hi + 1 ? g - n : g);
 }
@@ -221,8 +221,8 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
     return g < lo ? g + n : (g > hi ? g - n : g);
 }
 
-template <int TX, int TY, bool WRAP>
-__global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
+template <int TX, int TY, int NT, bool WRAP>
+__global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk)
 {
     // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
@@ -230,7 +230,6 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
     constexpr int RX = TX + 8, RY = TY + 8, HX = RX / 2, PX = RX + 2;   // PX: padded row pitch
     __shared__ double X[3][RY][PX];
     __shared__ double S[2][RY][PX];
-    __shared__ double R[RY][PX];
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
     int tix, tiy, pk;
@@ -260,57 +259,68 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
     const int ox = tx0 - 4, oy = ty0 - 4;
     const int tid = threadIdx.x;
 #define COL(lx) ((((lx) & 1) * HX) + ((lx) >> 1))
+    // colour pass c updates the tile grown by 3 - c nodes; every thread owns at most one node of a pass
+    static_assert(((TX + 7) / 2) * ((TY + 7) / 2) <= NT, "one node per thread and colour pass");
+    int pi[4], pj[4];
+    double rr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cx = c & 1, cy = c >> 1, g = 3 - c;
+        const int rlo0 = tx0 - g, rhi0 = txe + g, rlo1 = ty0 - g, rhi1 = tye + g;
+        const int i0 = rlo0 + (((rlo0 & 1) != cx) ? 1 : 0), j0 = rlo1 + (((rlo1 & 1) != cy) ? 1 : 0);
+        const int ni = i0 > rhi0 ? 0 : ((rhi0 - i0) >> 1) + 1, nj = j0 > rhi1 ? 0 : ((rhi1 - j0) >> 1) + 1;
+        const bool on = tid < ni * nj;
+        pi[c] = on ? i0 + 2 * (tid % max(ni, 1)) : INT_MIN;
+        pj[c] = j0 + 2 * (tid / max(ni, 1));
+        // right-hand side of the node: straight to a register (issued together with the staging loads below)
+        int ri = on ? pi[c] : tx0, rj = on ? pj[c] : ty0;
+        if constexpr (WRAP) { ri = wrap_node(ri, cb.lo[0], cb.hi[0]); rj = wrap_node(rj, cb.lo[1], cb.hi[1]); }
+        rr[c] = r(ri, rj, k);
+    }
     {
         // stage the footprint: all global loads are issued before the first LDS store (addresses are clamped into the
         // arrays instead of predicated -- footprint points beyond the ghost width are never used by the colour passes)
-        constexpr int NLD = (RX * RY + 255) / 256;
-        double v[NLD][6];
+        constexpr int NLD = (RX * RY + NT - 1) / NT;
+        double v[NLD][5];
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int idx = min(tid + it * 256, RX * RY - 1);
+            const int idx = min(tid + it * NT, RX * RY - 1);
             const int lx = idx % RX, ly = idx / RX;
             const int gi = ox + lx, gj = oy + ly;
-            int xi, xj, si, sj, ri, rj, xkm = k - 1, xkp = k + 1, skm = k - 1, sk0 = k;
+            int xi, xj, si, sj, xkm = k - 1, xkp = k + 1, skm = k - 1, sk0 = k;
             if constexpr (WRAP) {
                 // the box spans the periodic domain: a ghost index is the periodic image of a valid index of the SAME box, so the
                 // staging reads the valid data directly and no ghost fill is needed (node hi+1 duplicates node lo)
                 xi = wrap_node(gi, cb.lo[0], cb.hi[0]); xj = wrap_node(gj, cb.lo[1], cb.hi[1]);
                 si = wrap_cell(gi, cb.lo[0], cb.hi[0]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]);
-                ri = xi; rj = xj;
                 xkm = wrap_node(k - 1, cb.lo[2], cb.hi[2]); xkp = wrap_node(k + 1, cb.lo[2], cb.hi[2]);
                 skm = wrap_cell(k - 1, cb.lo[2], cb.hi[2]); sk0 = wrap_cell(k, cb.lo[2], cb.hi[2]);
             } else {
                 xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
                 si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
-                ri = min(max(gi, r.lo[0]), r.lo[0] + r.n[0] - 1); rj = min(max(gj, r.lo[1]), r.lo[1] + r.n[1] - 1);
             }
             v[it][0] = xn(xi, xj, xkm);
             v[it][1] = x(xi, xj, k);
             v[it][2] = xn(xi, xj, xkp);
             v[it][3] = s(si, sj, skm);
             v[it][4] = s(si, sj, sk0);
-            v[it][5] = r(ri, rj, k);
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             if (idx < RX * RY) {
                 const int lx = idx % RX, ly = idx / RX;
                 const int cl = COL(lx);
                 X[0][ly][cl] = v[it][0]; X[1][ly][cl] = v[it][1]; X[2][ly][cl] = v[it][2];
-                S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4]; R[ly][cl] = v[it][5];
+                S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4];
             }
         }
     }
     __syncthreads();
-#pragma unroll 1
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int cx = c & 1, cy = c >> 1, g = 3 - c;
-        const int rlo0 = tx0 - g, rhi0 = txe + g, rlo1 = ty0 - g, rhi1 = tye + g;
-        const int i0 = rlo0 + (((rlo0 & 1) != cx) ? 1 : 0), j0 = rlo1 + (((rlo1 & 1) != cy) ? 1 : 0);
-        const int ni = i0 > rhi0 ? 0 : ((rhi0 - i0) >> 1) + 1, nj = j0 > rhi1 ? 0 : ((rhi1 - j0) >> 1) + 1;
-        for (int idx = tid; idx < ni * nj; idx += 256) {
-            const int i = i0 + 2 * (idx % ni), j = j0 + 2 * (idx / ni);
+        if (pi[c] != INT_MIN) {
+            const int i = pi[c], j = pj[c];
             const int lx = i - ox, ly = j - oy;
             const int c0 = COL(lx), cm = COL(lx - 1), cp = COL(lx + 1);
             const double smmm = S[0][ly - 1][cm], spmm = S[0][ly - 1][c0], smpm = S[0][ly][cm], sppm = S[0][ly][c0];
@@ -326,37 +336,22 @@ __global__ void __launch_bounds__(256) k_nodal_gs4(const BoxD* __restrict__ boxe
             y += w.fx * (X[1][ly][cm] * (smmm + smpm + smmp + smpp) + X[1][ly][cp] * (spmm + sppm + spmp + sppp));
             y += w.fy * (X[1][ly - 1][c0] * (smmm + spmm + smmp + spmp) + X[1][ly + 1][c0] * (smpm + sppm + smpp + sppp));
             y += w.fz * (X[0][ly][c0] * (smmm + spmm + smpm + sppm) + X[2][ly][c0] * (smmp + spmp + smpp + sppp));
-            X[1][ly][c0] = xc + (R[ly][c0] - y) / s0;
+            X[1][ly][c0] = xc + (rr[c] - y) / s0;
         }
         __syncthreads();
     }
     const int wx = txe - tx0 + 1, wy = tye - ty0 + 1;
-    for (int idx = tid; idx < wx * wy; idx += 256) {
+    for (int idx = tid; idx < wx * wy; idx += NT) {
         const int i = tx0 + idx % wx, j = ty0 + idx / wx;
         xo(i, j, k) = X[1][j - oy][COL(i - ox)];
     }
 #undef COL
 }
 
-// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
-// true if the level is one box that spans a fully periodic domain: the smoother kernels can then read periodic images straight from
-// the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
-bool periodic_wrap_ok(const Geometry& g, const Layout& l)
+template <int TX, int TY, int NT>
+static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
+                       int kpar, bool wrap)
 {
-    static const bool on = !(getenv("IAMRX_PERIODIC_WRAP") && atoi(getenv("IAMRX_PERIODIC_WRAP")) == 0);
-    if (!on || l.boxes.size() != 1 || l.nlocal() != 1) return false;
-    for (int d = 0; d < 3; ++d)
-        if (!g.periodic[d] || l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < 2) return false;
-    return true;
-}
-
-void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap)
-{
-    const MultiFab& x = xc;
-    if (x.nlocal() == 0) return;
-    IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3 && xn.ngrow == x.ngrow && xo.ngrow == x.ngrow && xo.d_tab != xc.d_tab);
-    constexpr int TX = 32, TY = 16;
-    const Layout& l = *x.layout;
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
     static const bool xcd_aware = !(getenv("IAMRX_XCD_AWARE") && atoi(getenv("IAMRX_XCD_AWARE")) == 0);
@@ -369,11 +364,36 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     }
     dim3 grid(gx, (unsigned)l.nlocal());
     if (wrap)
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, true>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, true>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
                            sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
     else
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, false>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
                            sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
+}
+
+// one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
+// true if the level is one box that spans a fully periodic domain: the smoother kernels can then read periodic images straight from
+// the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
+bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
+{
+    static const bool on = !(getenv("IAMRX_PERIODIC_WRAP") && atoi(getenv("IAMRX_PERIODIC_WRAP")) == 0);
+    if (!on || l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    for (int d = 0; d < 3; ++d)
+        if (!g.periodic[d] || l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < min_len) return false;
+    return true;
+}
+
+void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap)
+{
+    const MultiFab& x = xc;
+    if (x.nlocal() == 0) return;
+    IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3 && xn.ngrow == x.ngrow && xo.ngrow == x.ngrow && xo.d_tab != xc.d_tab);
+    const Layout& l = *x.layout;
+    // tile shape: 32x32 nodes / 512 threads (40x40 footprint: 1.56 loads and 1.20 updates per written node, 2 workgroups = 16
+    // waves per CU) against 32x16 / 256 (1.88 loads, 1.31 updates, 3 workgroups = 12 waves); IAMRX_GS4_TILE=0 selects the latter
+    static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 1);
+    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
+    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -76,7 +76,7 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
                          bool wrap = false);
-bool periodic_wrap_ok(const Geometry& g, const Layout& l);
+bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len);
 // all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);

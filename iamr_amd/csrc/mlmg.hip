@@ -112,7 +112,7 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
     AbecCoef c = coef(l);
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
     // one box spanning a fully periodic domain: the kernel reads the periodic images from the valid cells, no ghost fills
-    const bool wrap = periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout);
+    const bool wrap = periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
     for (int rb = 0; rb < 2; ++rb) {
         if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr);
         abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap);

@@ -110,7 +110,7 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         // sequential colour passes below.  Each sweep goes from one buffer to the other (see k_nodal_gs4).
         if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
         // one box spanning a fully periodic domain: the kernel takes periodic images from the valid data, no ghost fills
-        const bool wrap = periodic_wrap_ok(L.g, *L.layout);
+        const bool wrap = periodic_wrap_ok(L.g, *L.layout, 4);
         if (!wrap) fillbc(l, const_cast<MultiFab&>(rhs));
         MultiFab* a = &x;
         MultiFab* b = &L.xb;
