@@ -389,9 +389,10 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     if (x.nlocal() == 0) return;
     IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3 && xn.ngrow == x.ngrow && xo.ngrow == x.ngrow && xo.d_tab != xc.d_tab);
     const Layout& l = *x.layout;
-    // tile shape: 32x32 nodes / 512 threads (40x40 footprint: 1.56 loads and 1.20 updates per written node, 2 workgroups = 16
-    // waves per CU) against 32x16 / 256 (1.88 loads, 1.31 updates, 3 workgroups = 12 waves); IAMRX_GS4_TILE=0 selects the latter
-    static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 1);
+    // tile shape: 32x16 nodes / 256 threads (40x24 footprint, 40 KB of LDS: 4 workgroups = 16 waves per CU).  Measured at 256^3
+    // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
+    // updates but 8-wave barriers)
+    static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 0);
     if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
     else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
 }
