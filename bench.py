@@ -148,6 +148,25 @@ def cpu_baseline(n, steps, threads=1):
                       f"(scalar; multigrid smoother loops OpenMP-threaded over {threads} thread(s))"}
 
 
+def transport_selftest(lib, rank, world):
+    """one halo exchange + one reduction over the freshly initialised transport (8^3 box per rank, stacked in z like the
+    workload): the ghost planes must hold the neighbour ranks' values.  Raises if the transport does not deliver."""
+    import numpy as np
+    n = 8
+    boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(world)]
+    lay = lib.Layout(boxes, list(range(world)))
+    g = lib.Geom.make((n, n, n * world), prob_hi=(1.0, 1.0, float(world)))
+    mf = lib.MultiFab(lay, lib.CELL, 1, 1)
+    mf.setval(float(rank + 1))
+    mf.fill_boundary(g)
+    a, _ = mf.to_numpy(0)
+    lo_nb, hi_nb = (rank - 1) % world + 1, (rank + 1) % world + 1
+    if not (np.all(a[1:-1, 1:-1, 0, 0] == lo_nb) and np.all(a[1:-1, 1:-1, -1, 0] == hi_nb) and np.all(a[1:-1, 1:-1, 1:-1, 0] == rank + 1)):
+        raise RuntimeError("halo exchange self-test delivered wrong ghost values")
+    if mf.norm0() != float(world):
+        raise RuntimeError("all-reduce self-test delivered a wrong maximum")
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -167,6 +186,7 @@ def main():
         ok = torch.ones(1, device="cuda")
         try:
             comm.init_rccl_from_torch(dist)
+            transport_selftest(lib, rank, world)
         except Exception as e:      # keep the run alive on a host-staged transport rather than produce no number
             print(f"[bench] rank {rank}: RCCL transport failed to initialise ({e}); falling back to gloo host staging", file=sys.stderr)
             ok.zero_()

@@ -28,6 +28,8 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         comm.init_gloo_callback(dist)
+        import bench
+        bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
     owners = [0, 1] if world > 1 else [0, 0]
     lay = lib.Layout(BOXES, owners)
     if case == "tg":
