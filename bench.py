@@ -252,15 +252,15 @@ def main():
         roofline = None
         if dom:
             # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, corrected as calibrated in
-            # profiles/round1_pmc.json); only valid for the size it was collected at
+            # profiles/round1_e_pmc.json); only valid for the size it was collected at
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_e_pmc.json")))
                 if n == 256:
                     traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "k_nodal_gs4" in k][0]
             except Exception:
                 traffic = None
-            roofline = {"kernel": "k_nodal_gs4<32,16> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch; the dominant kernel of the step, "
+            roofline = {"kernel": "k_nodal_gs4<32,16,256> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch; the dominant kernel of the step, "
                                   "profiles/round1_*_kernel_stats.csv)", "bound": "hbm",
                         "achieved": dom["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": traffic,
                         "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": dom["ms"]}
