@@ -412,6 +412,18 @@ int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_m
     IAMRX_CATCH
 }
 
+int iamrx_nodal_solve(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int sig_comp, const int lobc[3], const int hibc[3],
+                      double rel_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    NodalMG mg(to_geom(g), phi->mf.layout, to_bc(lobc, hibc, op.maxorder), op);
+    mg.setSigma(sig->mf, sig_comp);
+    MGStats s = mg.solve(phi->mf, rhs->mf, rel_tol, abs_tol);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
 int iamrx_tensor_apply(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
                        iamrx_mf ez, const int* lobc, const int* hibc, int nbc, int maxorder)
 {

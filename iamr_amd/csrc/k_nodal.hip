@@ -161,7 +161,7 @@ void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const M
 
 // one colour of the 8-colour Gauss-Seidel sweep: nodes with (i&1, j&1, k&1) == colour bits
 __global__ void __launch_bounds__(256) k_nodal_gscolor(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ xt,
-    const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int color)
+    const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int color, const FabD* __restrict__ dmt)
 {
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
@@ -180,20 +180,22 @@ __global__ void __launch_bounds__(256) k_nodal_gscolor(Tiling t, const BoxD* __r
     const int i = i0 + 2 * mi, j = j0 + 2 * mj;
     for (int mk = mk0; mk <= mk1; ++mk) {
         const int k = k0n + 2 * mk;
+        if (dmt && dmt[fab](i, j, k) != 0.0) continue;      // Dirichlet node: keeps its value
         double s0;
         const double Ax = node_Ax(x, s, w, i, j, k, s0);
         x(i, j, k) += (r(i, j, k) - Ax) / s0;
     }
 }
 
-void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color)
+void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color, const MultiFab* dmask)
 {
     if (x.nlocal() == 0) return;
     const Layout& l = *x.layout;
     int ml[3];
     for (int d = 0; d < 3; ++d) ml[d] = (l.max_len[d] + 1 + 1) / 2;
     Tiling t = make_tiling(ml, l.nlocal(), 4);
-    hipLaunchKernelGGL(k_nodal_gscolor, t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g), color);
+    hipLaunchKernelGGL(k_nodal_gscolor, t.grid(), Tiling::block(), 0, Context::get().stream, t, l.d_boxes, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g), color,
+                       dmask ? dmask->d_tab : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -221,9 +223,10 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
     return g < lo ? g + n : (g > hi ? g - n : g);
 }
 
-template <int TX, int TY, int NT, bool WRAP>
+template <int TX, int TY, int NT, bool WRAP, bool MASK>
 __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
-    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk)
+    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk,
+    const FabD* __restrict__ dmt)
 {
     // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
     // column, so its 64 lanes then read consecutive doubles (no bank conflicts) instead of a stride-2 pattern.
@@ -263,6 +266,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
     static_assert(((TX + 7) / 2) * ((TY + 7) / 2) <= NT, "one node per thread and colour pass");
     int pi[4], pj[4];
     double rr[4];
+    bool fixed[4];        // MASK: the node of this thread in pass c is a Dirichlet node (keeps its value)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int cx = c & 1, cy = c >> 1, g = 3 - c;
@@ -276,6 +280,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
         int ri = on ? pi[c] : tx0, rj = on ? pj[c] : ty0;
         if constexpr (WRAP) { ri = wrap_node(ri, cb.lo[0], cb.hi[0]); rj = wrap_node(rj, cb.lo[1], cb.hi[1]); }
         rr[c] = r(ri, rj, k);
+        if constexpr (MASK) fixed[c] = dmt[fab](ri, rj, k) != 0.0; else fixed[c] = false;
     }
     {
         // stage the footprint: all global loads are issued before the first LDS store (addresses are clamped into the
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (pi[c] != INT_MIN) {
+        if (pi[c] != INT_MIN && !(MASK && fixed[c])) {
             const int i = pi[c], j = pj[c];
             const int lx = i - ox, ly = j - oy;
             const int c0 = COL(lx), cm = COL(lx - 1), cp = COL(lx + 1);
@@ -350,7 +355,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 
 template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap)
+                       int kpar, bool wrap, const MultiFab* dmask)
 {
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
@@ -363,12 +368,16 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
         gx = 8u * (unsigned)(maxcnt * npl);
     }
     dim3 grid(gx, (unsigned)l.nlocal());
-    if (wrap)
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, true>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
-                           sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
+    if (dmask) {
+        IAMRX_ASSERT(!wrap && dmask->ngrow >= 3);
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false, true>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
+                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask->d_tab);
+    } else if (wrap)
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, true, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
+                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, nullptr);
     else
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab, rhs.d_tab,
-                           sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk);
+        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
+                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, nullptr);
 }
 
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
@@ -383,7 +392,8 @@ bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
     return true;
 }
 
-void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap)
+void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap,
+                         const MultiFab* dmask)
 {
     const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
@@ -393,8 +403,8 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
     static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 0);
-    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
-    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap);
+    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask);
+    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -473,15 +483,59 @@ bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, con
 }
 
 // weighted Jacobi: x_new = x + (2/3) (rhs - A x)/s0 ; tmp holds x_new, then copied back by the caller
-void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig)
+void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig, const MultiFab* dmask)
 {
     if (x.nlocal() == 0) return;
     const NodeW w = make_w(g);
-    const FabD *nt = xnew.d_tab, *xt = x.d_tab, *rt = rhs.d_tab, *st = sig.d_tab;
+    const FabD *nt = xnew.d_tab, *xt = x.d_tab, *rt = rhs.d_tab, *st = sig.d_tab, *dt = dmask ? dmask->d_tab : nullptr;
     for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        if (dt && dt[f](i, j, k) != 0.0) { nt[f](i, j, k) = xt[f](i, j, k); return; }
         double s0;
         const double Ax = node_Ax(xt[f], st[f], w, i, j, k, s0);
         nt[f](i, j, k) = xt[f](i, j, k) + (2. / 3.) * (rt[f](i, j, k) - Ax) / s0;
+    });
+}
+
+// mf = 0 on Dirichlet nodes (dmask != 0): residuals, operator rows, restricted residuals and prolonged corrections there
+void nodal_zero_masked(MultiFab& mf, const MultiFab& dmask)
+{
+    if (mf.nlocal() == 0) return;
+    const FabD *mt = mf.d_tab, *dt = dmask.d_tab;
+    for_each(*mf.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        if (dt[f](i, j, k) != 0.0) mt[f](i, j, k) = 0.0;
+    });
+}
+
+// Dirichlet node mask of a level (MLNodeLaplacian dirichlet mask): 1 on nodes with at least one of the 8 surrounding cells
+// outside the problem -- beyond a Dirichlet (outflow) domain face or not covered by the level's boxes; cells beyond a Neumann
+// wall mirror the cells inside, periodic images count.  cov: cell array, 1 ghost cell, 1 on the level's cells (ghosts filled
+// from neighbours / periodic images, 0 elsewhere).  Ghost nodes of dm keep the value they had (the caller presets 1).
+void nodal_build_dmask(const Geometry& g, MultiFab& dm, const MultiFab& cov, const DomainBC& bc)
+{
+    if (dm.nlocal() == 0) return;
+    const FabD *dt = dm.d_tab, *ct = cov.d_tab;
+    int lo[3], hi[3], tlo[3], thi[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = g.domain.lo[d]; hi[d] = g.domain.hi[d];
+        tlo[d] = g.periodic[d] ? 0 : bc.lo[d]; thi[d] = g.periodic[d] ? 0 : bc.hi[d];
+    }
+    const int l0 = lo[0], l1 = lo[1], l2 = lo[2], h0 = hi[0], h1 = hi[1], h2 = hi[2];
+    const int a0 = tlo[0], a1 = tlo[1], a2 = tlo[2], b0 = thi[0], b1 = thi[1], b2 = thi[2];
+    for_each(*dm.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD c = ct[f];
+        bool in = true;
+        for (int q = 0; q < 8; ++q) {
+            int ci = i - 1 + (q & 1), cj = j - 1 + ((q >> 1) & 1), ck = k - 1 + ((q >> 2) & 1);
+            bool out = false;
+            if (ci < l0) { if (a0 == lo_neumann) ci = 2 * l0 - 1 - ci; else if (a0 != 0) out = true; }
+            else if (ci > h0) { if (b0 == lo_neumann) ci = 2 * h0 + 1 - ci; else if (b0 != 0) out = true; }
+            if (cj < l1) { if (a1 == lo_neumann) cj = 2 * l1 - 1 - cj; else if (a1 != 0) out = true; }
+            else if (cj > h1) { if (b1 == lo_neumann) cj = 2 * h1 + 1 - cj; else if (b1 != 0) out = true; }
+            if (ck < l2) { if (a2 == lo_neumann) ck = 2 * l2 - 1 - ck; else if (a2 != 0) out = true; }
+            else if (ck > h2) { if (b2 == lo_neumann) ck = 2 * h2 + 1 - ck; else if (b2 != 0) out = true; }
+            if (out || c(ci, cj, ck) == 0.0) in = false;
+        }
+        dt[f](i, j, k) = in ? 0.0 : 1.0;
     });
 }
 

@@ -71,15 +71,17 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
 
 // ---- k_nodal.hip --------------------------------------------------------------------------
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
-void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
+void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color, const MultiFab* dmask = nullptr);
 // one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3), out of place: plane k from xc, planes
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
-                         bool wrap = false);
+                         bool wrap = false, const MultiFab* dmask = nullptr);
+void nodal_zero_masked(MultiFab& mf, const MultiFab& dmask);
+void nodal_build_dmask(const Geometry& g, MultiFab& dm, const MultiFab& cov, const DomainBC& bc);
 bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len);
 // all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
-void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
+void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig, const MultiFab* dmask = nullptr);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
 void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp, const DomainBC* bc);

@@ -105,6 +105,8 @@ public:
     void setSigma(const MultiFab& sig, int comp);
     MGStats solve(MultiFab& phi, const MultiFab& rhs, double rtol, double atol);
     int nlevels() const { return (int)m_lev.size(); }
+    bool masked() const { return m_masked; }
+    const MultiFab* dmask(int l) const { return m_lev[l].dmask(); }
     const MultiFab& sigma(int l) const { return m_lev[l].sig; }
     const Geometry& geom(int l) const { return m_lev[l].g; }
     void smooth(int l, MultiFab& x, const MultiFab& rhs);
@@ -124,6 +126,8 @@ private:
         LayoutP dist;
         MultiFab tmp_d;
         MultiFab xb;               // second buffer of the out-of-place fused Gauss-Seidel sweeps
+        MultiFab dm;               // Dirichlet node mask (defined only if the level has Dirichlet nodes, see NodalMG ctor)
+        const MultiFab* dmask() const { return dm.defined() ? &dm : nullptr; }
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void subtract_mean(int l, MultiFab& mf);
@@ -132,6 +136,7 @@ private:
     DomainBC m_bc;
     MGOpts m_o;
     bool m_singular = true;
+    bool m_masked = false;         // some nodes are Dirichlet nodes (outflow faces / level boundary inside the domain)
     std::vector<Level> m_lev;
 };
 

@@ -11,8 +11,6 @@ namespace iamrx {
 
 // kernels (k_nodal.hip)
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
-void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color);
-void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
 
@@ -35,11 +33,12 @@ bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, con
 NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MGOpts& o) : m_g(g), m_bc(bc), m_o(o)
 {
     for (int d = 0; d < 3; ++d) {
-        if (!g.periodic[d] && (bc.lo[d] == lo_dirichlet || bc.hi[d] == lo_dirichlet)) m_singular = false;
-        if (!g.periodic[d] && (bc.lo[d] != lo_neumann || bc.hi[d] != lo_neumann))
-            throw Error("iamrx NodalMG: only periodic and Neumann (wall) domain boundaries are implemented (no outflow/Dirichlet yet)");
-        // wall nodes carry weight 1/2 in sums and dot products (doubled rows, MLNodeLinOp dot mask)
-        m_g.half_lo[d] = m_g.half_hi[d] = g.periodic[d] ? 0 : 1;
+        if (!g.periodic[d])
+            for (int t : {bc.lo[d], bc.hi[d]})
+                if (t != lo_neumann && t != lo_dirichlet) throw Error("iamrx NodalMG: domain boundaries must be periodic, Neumann (wall / inflow) or Dirichlet (outflow)");
+        // Neumann-wall nodes carry weight 1/2 in sums and dot products (doubled rows, MLNodeLinOp dot mask)
+        m_g.half_lo[d] = (!g.periodic[d] && bc.lo[d] == lo_neumann) ? 1 : 0;
+        m_g.half_hi[d] = (!g.periodic[d] && bc.hi[d] == lo_neumann) ? 1 : 0;
     }
     m_lev.resize(1);
     m_lev[0].g = m_g;
@@ -71,6 +70,32 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MG
         L.rescor.define(L.layout, node_type(), 1, 1);
         L.cor.setVal(0.0); L.res.setVal(0.0); L.rescor.setVal(0.0);
     }
+    // Dirichlet nodes: on Dirichlet (outflow) domain faces and on the boundary of a level that does not cover the domain
+    // (coarse/fine boundary of an AMR level).  They keep their value, carry no residual and take no correction.
+    bool need_mask = false;
+    for (int d = 0; d < 3; ++d) if (!g.periodic[d] && (bc.lo[d] == lo_dirichlet || bc.hi[d] == lo_dirichlet)) need_mask = true;
+    if (m_lev[0].layout->total_cells() != g.domain.npts()) need_mask = true;
+    for (auto& L : m_lev) {
+        if (!need_mask) break;
+        MultiFab cov(L.layout, cell_type(), 1, 1);
+        cov.setVal(0.0);
+        mf_add_scalar(cov, 1.0, 0, 1, 0);
+        cov.FillBoundary(L.g);
+        const int ng = L.cor.ngrow;
+        L.dm.define(L.layout, node_type(), 1, ng);
+        L.dm.setVal(1.0);                                  // ghost nodes outside the level: never updated
+        nodal_build_dmask(L.g, L.dm, cov, m_bc);
+        if (L.dm.norm0(0, 1, 0) == 0.0) L.dm = MultiFab();
+        else {
+            m_masked = true;
+            L.dm.FillBoundary(L.g);
+            nodal_reflect_bc(L.g, L.dm, m_bc);
+        }
+    }
+    if (m_masked) {
+        m_singular = false;
+        for (auto& L : m_lev) IAMRX_ASSERT(L.dm.defined());
+    }
 }
 
 void NodalMG::setSigma(const MultiFab& sig, int comp)
@@ -101,7 +126,8 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
 {
     Level& L = m_lev[l];
     // small single-box periodic levels: all sweeps x colours in one single-workgroup launch
-    if (m_o.nodal_smoother == 0 && nodal_small() && nodal_smooth_small(L.g, x, rhs, L.sig, m_o.nodal_sweeps)) {
+    const MultiFab* dmk = L.dmask();
+    if (!dmk && m_o.nodal_smoother == 0 && nodal_small() && nodal_smooth_small(L.g, x, rhs, L.sig, m_o.nodal_sweeps)) {
         fillbc(l, x);
         return;
     }
@@ -110,15 +136,15 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         // sequential colour passes below.  Each sweep goes from one buffer to the other (see k_nodal_gs4).
         if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
         // one box spanning a fully periodic domain: the kernel takes periodic images from the valid data, no ghost fills
-        const bool wrap = periodic_wrap_ok(L.g, *L.layout, 4);
+        const bool wrap = !dmk && periodic_wrap_ok(L.g, *L.layout, 4);
         if (!wrap) fillbc(l, const_cast<MultiFab&>(rhs));
         MultiFab* a = &x;
         MultiFab* b = &L.xb;
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
             if (!wrap) fillbc(l, *a);
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap);      // even planes: a -> b
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk);      // even planes: a -> b
             if (!wrap) fillbc(l, *b);                                        // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap);      // odd planes: centre from a, neighbours from b
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
@@ -130,12 +156,12 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         } else if (m_o.nodal_smoother == 0) {
             for (int color = 0; color < 8; ++color) {
                 fillbc(l, x);
-                nodal_gs_color(L.g, x, rhs, L.sig, color);
+                nodal_gs_color(L.g, x, rhs, L.sig, color, dmk);
             }
         } else {
             if (!L.tmp.defined()) L.tmp.define(L.layout, node_type(), 1, 1);
             fillbc(l, x);
-            nodal_jacobi(L.g, L.tmp, x, rhs, L.sig);
+            nodal_jacobi(L.g, L.tmp, x, rhs, L.sig, dmk);
             MultiFab::Copy(x, L.tmp, 0, 0, 1, 0);
         }
     }
@@ -146,6 +172,7 @@ void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b)
 {
     fillbc(l, x);
     nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b);
+    if (m_lev[l].dmask()) nodal_zero_masked(r, m_lev[l].dm);
 }
 
 void NodalMG::subtract_mean(int l, MultiFab& mf)
@@ -190,6 +217,7 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
         MultiFab::Copy(ph, p, 0, 0, 1, 0);
         fillbc(l, ph);
         nodal_residual(g, v, ph, L.sig, nullptr);
+        if (L.dmask()) nodal_zero_masked(v, L.dm);
         double rhTv;
         { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&v}; reduce_dots(1, xs, ys, 0, 1, g, &rhTv); }
         if (rhTv != 0) alpha = rho / rhTv; else { ret = 2; break; }
@@ -200,6 +228,7 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
         MultiFab::Copy(sh, s, 0, 0, 1, 0);
         fillbc(l, sh);
         nodal_residual(g, t, sh, L.sig, nullptr);
+        if (L.dmask()) nodal_zero_masked(t, L.dm);
         double tv[2];
         { const MultiFab* xs[2] = {&t, &t}; const MultiFab* ys[2] = {&t, &s}; reduce_dots(2, xs, ys, 0, 1, g, tv); }
         if (tv[0] != 0) omega = tv[1] / tv[0]; else { ret = 3; break; }
@@ -231,6 +260,7 @@ void NodalMG::vcycle(MGStats& st)
             gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
         } else
         nodal_restrict(m_lev[l + 1].res, L.rescor);
+        if (m_lev[l + 1].dmask()) nodal_zero_masked(m_lev[l + 1].res, m_lev[l + 1].dm);   // mlndlap_restriction: 0 on Dirichlet nodes
     }
     {
         const int l = nl - 1;
@@ -261,6 +291,7 @@ void NodalMG::vcycle(MGStats& st)
             nodal_interp_add(L.cor, m_lev[l + 1].tmp_d, L.sig);
         } else
         nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
+        if (L.dmask()) nodal_zero_masked(L.cor, L.dm);                  // mlndlap_interpadd: Dirichlet nodes take no correction
         for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res);
     }
 }
@@ -273,6 +304,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     Level& L0 = m_lev[0];
     MultiFab rhs(L0.layout, node_type(), 1, 0);
     MultiFab::Copy(rhs, rhs_in, 0, 0, 1, 0);
+    if (L0.dmask()) nodal_zero_masked(rhs, L0.dm);
     if (m_singular) subtract_mean(0, rhs);
     residual(0, L0.res, phi, rhs);
     st.resnorm0 = L0.res.norm0(0, 1, 0);

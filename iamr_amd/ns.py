@@ -58,6 +58,15 @@ def nodal_compgrad(geom, gp, phi):
     check(lib().iamrx_nodal_compgrad(C.byref(geom), gp.h, phi.h))
 
 
+def nodal_solve(geom, phi, rhs, sig, sig_comp=0, lobc=(0, 0, 0), hibc=(0, 0, 0), rel_tol=1e-12, abs_tol=1e-16, opts=None):
+    """div(sig grad phi) = rhs; Dirichlet nodes (outflow faces, boundary of a level that does not cover the domain) keep phi"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    check(lib().iamrx_nodal_solve(C.byref(geom), _h(phi), _h(rhs), _h(sig), sig_comp, i3(lobc), i3(hibc),
+                                      C.c_double(rel_tol), C.c_double(abs_tol), C.byref(o), C.byref(st)))
+    return st
+
+
 def nodal_projection(geom, vel, vcomp, phi, sig, sig_comp=0, lobc=(0, 0, 0), hibc=(0, 0, 0), rel_tol=1e-12, abs_tol=1e-16,
                      opts=None, gp=None, increment_gp=False):
     """Projection::doMLMGNodalProjection on one level (reference Source/Projection.cpp:2385-2567)"""

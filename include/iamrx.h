@@ -178,6 +178,14 @@ int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_m
                            const int lobc[3], const int hibc[3], double rel_tol, double abs_tol, const iamrx_mg_opts* o,
                            iamrx_mf gp /* may be NULL */, int increment_gp, iamrx_mg_stats* st);
 
+/* the nodal solve alone: div(sig grad phi) = rhs on the level `phi` lives on (MLMG::solve on MLNodeLaplacian, as driven by
+ * Hydro::NodalProjector inside Projection::doMLMGNodalProjection, Source/Projection.cpp:2512-2542, and by the sync solves of
+ * Projection::MLsyncProject, :457-607).  LinOpBC codes: Neumann (walls, inflow), Dirichlet (outflow).  Nodes on Dirichlet domain
+ * faces and -- if the level does not cover the domain (an AMR level > 0) -- on the level's boundary inside the domain are
+ * Dirichlet nodes: they keep the incoming phi (MLNodeLaplacian's Dirichlet mask). */
+int iamrx_nodal_solve(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_mf sig, int sig_comp, const int lobc[3], const int hibc[3],
+                      double rel_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
 /* ---- tensor diffusion (amrex::MLTensorOp role) -------------------------------------- */
 /* out = (a*acoef - b div tau(vel)); Diffusion::getTensorViscTerms uses a = 0, b = -1 (Source/Diffusion.cpp:1697-1698).
  * eta_*: face viscosity (1 comp); vel: 3 comps, 1 ghost.

@@ -169,6 +169,11 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, const 
 /* Hydro::NodalProjector::project as called from Projection::doMLMGNodalProjection
  * (reference Source/Projection.cpp:2512-2542): rhs = div(vel), solve div(sig grad phi)=rhs,
  * vel -= sig grad phi. */
+/* the same solve on a level that covers only the cells with cov != 0 (NULL: all) and/or has Dirichlet (outflow) domain faces:
+ * nodes on the boundary of the covered region keep the incoming phi (MLNodeLaplacian Dirichlet mask) */
+void orc_nodal_solve_cov(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, const orc_fab* sig,
+                         const int lobc[3], const int hibc[3], const orc_fab* cov /*cell, 0 ghost*/, double rtol, double atol,
+                         const orc_mg_opts* o, orc_mg_stats* st);
 void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc_fab* phi /*node, 1 ghost*/,
                        const orc_fab* sig, const int lobc[3], const int hibc[3],
                        double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);

@@ -134,6 +134,11 @@ static const int PERIODIC_BC[3] = {ORC_LO_PERIODIC, ORC_LO_PERIODIC, ORC_LO_PERI
 /* BCs of the solve in progress (the oracle is single-threaded) */
 static const int *g_lobc = PERIODIC_BC, *g_hibc = PERIODIC_BC;
 static void nodal_fill(const orc_geom* g, orc_fab* x) { nodal_fill_bc(g, x, g_lobc, g_hibc); }
+/* Dirichlet node mask of the level being worked on (NULL: none): nodes with mask != 0 keep their value, carry no residual
+ * and take no correction (MLNodeLaplacian dirichlet mask: outflow faces and the boundary of a level that does not cover the
+ * domain) */
+static const orc_fab* g_dm = NULL;
+static inline int dm_on(int i, int j, int k) { return g_dm && A4(g_dm, i, j, k, 0) != 0.0; }
 
 /* sigma ghost cells: periodic images, mirror across non-periodic walls (mlndlap_fillbc_cc): sig(lo-m) = sig(lo+m-1) */
 static void sigma_fill_bc(const orc_geom* g, orc_fab* s)
@@ -179,6 +184,7 @@ void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const o
                 _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
                 for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
                     if (((i & 1) | ((j & 1) << 1) | ((k & 1) << 2)) != color) continue;
+                    if (dm_on(i, j, k)) continue;
                     double dg, Ax = node_Ax(g, x, sig, i, j, k, &dg);
                     A4(x, i, j, k, 0) += (A4(rhs, i, j, k, 0) - Ax) / dg;
                 }
@@ -187,6 +193,7 @@ void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const o
             /* lexicographic Gauss-Seidel (the reference's CPU ordering); periodic images refreshed first */
             nodal_fill(g, x);
             for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+                if (dm_on(i, j, k)) continue;
                 double dg, Ax = node_Ax(g, x, sig, i, j, k, &dg);
                 A4(x, i, j, k, 0) += (A4(rhs, i, j, k, 0) - Ax) / dg;
             }
@@ -201,6 +208,7 @@ void orc_nodal_smooth(const orc_geom* g, orc_fab* x, const orc_fab* rhs, const o
             nodal_fill(g, x);
             orc_fab t = orc_alloc(g->n, ORC_NODE, 0, 1);
             for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+                if (dm_on(i, j, k)) { A4(&t, i, j, k, 0) = A4(x, i, j, k, 0); continue; }
                 double dg, Ax = node_Ax(g, x, sig, i, j, k, &dg);
                 A4(&t, i, j, k, 0) = A4(x, i, j, k, 0) + (2. / 3.) * (A4(rhs, i, j, k, 0) - Ax) / dg;
             }
@@ -271,6 +279,7 @@ static double interp_face(const orc_fab* crse, const orc_fab* sig, int i, int j,
 void orc_nodal_interp_add(orc_fab* fine, const orc_fab* crse, const orc_fab* sig, const orc_geom* fg)
 {
     for (int k = 0; k <= fg->n[2]; ++k) for (int j = 0; j <= fg->n[1]; ++j) for (int i = 0; i <= fg->n[0]; ++i) {
+        if (dm_on(i, j, k)) continue;
         int ic = i >> 1, jc = j >> 1, kc = k >> 1;
         int io = i & 1, jo = j & 1, ko = k & 1;
         double v;
@@ -301,7 +310,21 @@ typedef struct nlev {
     orc_fab sig;          /* cell, 1 ghost */
     orc_fab cor, res, rescor;
     int owns_sig;
+    orc_fab dm;           /* node Dirichlet mask (p == NULL: none) */
 } nlev;
+static inline const orc_fab* lev_dm(const nlev* L) { return L->dm.p ? &L->dm : NULL; }
+static void nd_zero_masked(const orc_geom* g, orc_fab* f, const orc_fab* dm)
+{
+    if (!dm) return;
+    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+        if (A4(dm, i, j, k, 0) != 0.0) A4(f, i, j, k, 0) = 0.0;
+}
+/* y = A x with zero rows at Dirichlet nodes */
+static void nd_adotx(const nlev* L, orc_fab* y, const orc_fab* x)
+{
+    orc_nodal_adotx(&L->g, y, x, &L->sig);
+    nd_zero_masked(&L->g, y, lev_dm(L));
+}
 
 /* 1 on the owner copy of every node (periodic duplicates at index n excluded) */
 static inline int owner(const orc_geom* g, int i, int j, int k)
@@ -349,6 +372,7 @@ static void nd_residual(const nlev* L, orc_fab* r, orc_fab* x, const orc_fab* b)
     const orc_geom* g = &L->g;
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
         A4(r, i, j, k, 0) = A4(b, i, j, k, 0) - A4(r, i, j, k, 0);
+    nd_zero_masked(g, r, lev_dm(L));
 }
 
 static int nd_bicgstab(const nlev* L, orc_fab* sol, const orc_fab* rhs, const orc_mg_opts* o, double eps_rel, double eps_abs, int* niters)
@@ -380,7 +404,7 @@ static int nd_bicgstab(const nlev* L, orc_fab* sol, const orc_fab* rhs, const or
             nd_sxay(g, &p, &r, beta, &p);
         }
         nd_copy(g, &ph, &p); nodal_fill(g, &ph);
-        orc_nodal_adotx(g, &v, &ph, &L->sig);
+        nd_adotx(L, &v, &ph);
         const double rhTv = nd_dot(g, &rh, &v);
         if (rhTv != 0) alpha = rho / rhTv; else { ret = 2; break; }
         nd_sxay(g, sol, sol, alpha, &ph);
@@ -388,7 +412,7 @@ static int nd_bicgstab(const nlev* L, orc_fab* sol, const orc_fab* rhs, const or
         rnorm = nd_norminf(g, &s);
         if (rnorm < eps_rel * rnorm0 || rnorm < eps_abs) break;
         nd_copy(g, &sh, &s); nodal_fill(g, &sh);
-        orc_nodal_adotx(g, &t, &sh, &L->sig);
+        nd_adotx(L, &t, &sh);
         const double tt = nd_dot(g, &t, &t), ts = nd_dot(g, &t, &s);
         if (tt != 0) omega = ts / tt; else { ret = 3; break; }
         nd_sxay(g, sol, sol, omega, &sh);
@@ -409,7 +433,9 @@ done:
 
 static void nd_smooth(const nlev* L, orc_fab* x, const orc_fab* rhs, const orc_mg_opts* o, const int lobc[3], const int hibc[3])
 {
+    g_dm = lev_dm(L);
     orc_nodal_smooth(&L->g, x, rhs, &L->sig, o->nodal_smoother, o->nodal_sweeps, lobc, hibc);
+    g_dm = NULL;
 }
 
 static void nd_vcycle(nlev* mg, int nl, const orc_mg_opts* o, const int lobc[3], const int hibc[3], int singular, orc_mg_stats* st)
@@ -420,6 +446,7 @@ static void nd_vcycle(nlev* mg, int nl, const orc_mg_opts* o, const int lobc[3],
         nd_residual(&mg[l], &mg[l].rescor, &mg[l].cor, &mg[l].res);
         nodal_fill(&mg[l].g, &mg[l].rescor);
         orc_nodal_restrict(&mg[l + 1].res, &mg[l].rescor, &mg[l + 1].g);
+        nd_zero_masked(&mg[l + 1].g, &mg[l + 1].res, lev_dm(&mg[l + 1]));      /* mlndlap_restriction: Dirichlet coarse nodes get 0 */
     }
     {
         nlev* b = &mg[nl - 1];
@@ -444,14 +471,57 @@ static void nd_vcycle(nlev* mg, int nl, const orc_mg_opts* o, const int lobc[3],
     }
     for (int l = nl - 2; l >= 0; --l) {
         nodal_fill(&mg[l + 1].g, &mg[l + 1].cor);
+        g_dm = lev_dm(&mg[l]);
         orc_nodal_interp_add(&mg[l].cor, &mg[l + 1].cor, &mg[l].sig, &mg[l].g);
+        g_dm = NULL;
         for (int i = 0; i < o->nu2; ++i) nd_smooth(&mg[l], &mg[l].cor, &mg[l].res, o, lobc, hibc);
     }
+}
+
+/* Dirichlet node mask of one MG level: a node is Dirichlet if one of the 8 cells around it is not part of the problem --
+ * outside a Dirichlet (outflow) domain face, or not covered by the level (cov: cell fab, != 0 on covered cells; NULL: the
+ * level covers the domain).  Cells beyond a periodic face are the periodic images, cells beyond a Neumann wall mirror the
+ * cells inside. */
+static int cell_in(const orc_geom* g, const int lobc[3], const int hibc[3], const orc_fab* cov, int ci, int cj, int ck)
+{
+    int c[3] = {ci, cj, ck};
+    for (int d = 0; d < 3; ++d) {
+        if (c[d] < 0) {
+            if (g->periodic[d]) c[d] += g->n[d];
+            else if (lobc[d] == ORC_LO_NEUMANN) c[d] = -c[d] - 1;
+            else return 0;
+        } else if (c[d] >= g->n[d]) {
+            if (g->periodic[d]) c[d] -= g->n[d];
+            else if (hibc[d] == ORC_LO_NEUMANN) c[d] = 2 * g->n[d] - 1 - c[d];
+            else return 0;
+        }
+    }
+    return cov ? A4(cov, c[0], c[1], c[2], 0) != 0.0 : 1;
+}
+static int build_dmask(const orc_geom* g, const int lobc[3], const int hibc[3], const orc_fab* cov, orc_fab* dm)
+{
+    int any = 0;
+    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+        int in = 1;
+        for (int c = 0; c < 8 && in; ++c) in = cell_in(g, lobc, hibc, cov, i - 1 + (c & 1), j - 1 + ((c >> 1) & 1), k - 1 + ((c >> 2) & 1));
+        A4(dm, i, j, k, 0) = in ? 0.0 : 1.0;
+        any |= !in;
+    }
+    return any;
 }
 
 void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, const orc_fab* sig,
                      const int lobc[3], const int hibc[3], double rtol, double atol,
                      const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_nodal_solve_cov(g, phi, rhs_in, sig, lobc, hibc, NULL, rtol, atol, o, st);
+}
+
+/* cov (optional): cell fab, != 0 on the cells of the level.  With cov or Dirichlet faces the nodes on the boundary of the
+ * covered region hold Dirichlet data (phi keeps its incoming value there); sigma is taken as 0 on uncovered cells. */
+void orc_nodal_solve_cov(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, const orc_fab* sig,
+                         const int lobc[3], const int hibc[3], const orc_fab* cov, double rtol, double atol,
+                         const orc_mg_opts* o, orc_mg_stats* st)
 {
     nlev mg[32];
     memset(mg, 0, sizeof(mg));
@@ -460,8 +530,15 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, con
     mg[0].g = *g;
     mg[0].sig = orc_alloc(g->n, ORC_CELL, 1, 1);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-        A4(&mg[0].sig, i, j, k, 0) = A4(sig, i, j, k, 0);
+        A4(&mg[0].sig, i, j, k, 0) = (cov && A4(cov, i, j, k, 0) == 0.0) ? 0.0 : A4(sig, i, j, k, 0);
     sigma_fill_bc(g, &mg[0].sig);
+    orc_fab covl[32];
+    memset(covl, 0, sizeof(covl));
+    if (cov) {
+        covl[0] = orc_alloc(g->n, ORC_CELL, 0, 1);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&covl[0], i, j, k, 0) = A4(cov, i, j, k, 0) != 0.0 ? 1.0 : 0.0;
+    }
     while (nl <= o->max_coarsening_level && nl < 32) {
         const orc_geom* fg = &mg[nl - 1].g;
         int ok = 1;
@@ -472,15 +549,26 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, con
         mg[nl].sig = orc_alloc(mg[nl].g.n, ORC_CELL, 1, 1);
         orc_cc_restrict(&mg[nl].sig, &mg[nl - 1].sig, mg[nl].g.n);
         sigma_fill_bc(&mg[nl].g, &mg[nl].sig);
+        if (cov) {
+            /* the level's boxes coarsen with the multigrid (aligned to 2^l by construction): a coarse cell is covered if its
+             * first fine cell is */
+            covl[nl] = orc_alloc(mg[nl].g.n, ORC_CELL, 0, 1);
+            for (int k = 0; k < mg[nl].g.n[2]; ++k) for (int j = 0; j < mg[nl].g.n[1]; ++j) for (int i = 0; i < mg[nl].g.n[0]; ++i)
+                A4(&covl[nl], i, j, k, 0) = A4(&covl[nl - 1], 2 * i, 2 * j, 2 * k, 0);
+        }
         ++nl;
+    }
+    int singular = 1;
+    for (int l = 0; l < nl; ++l) {
+        mg[l].dm = orc_alloc(mg[l].g.n, ORC_NODE, 0, 1);
+        if (!build_dmask(&mg[l].g, g_lobc, g_hibc, cov ? &covl[l] : NULL, &mg[l].dm)) orc_free(&mg[l].dm);
+        else singular = 0;
     }
     for (int l = 0; l < nl; ++l) {
         mg[l].cor = orc_alloc(mg[l].g.n, ORC_NODE, 1, 1);
         mg[l].res = orc_alloc(mg[l].g.n, ORC_NODE, 1, 1);
         mg[l].rescor = orc_alloc(mg[l].g.n, ORC_NODE, 1, 1);
     }
-    int singular = 1;
-    for (int d = 0; d < 3; ++d) if (!g->periodic[d] && (lobc[d] == ORC_LO_DIRICHLET || hibc[d] == ORC_LO_DIRICHLET)) singular = 0;
     orc_mg_stats loc; memset(&loc, 0, sizeof(loc));
 
     orc_fab rhs = orc_alloc(g->n, ORC_NODE, 0, 1);
@@ -511,7 +599,11 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs_in, con
     nodal_fill(g, phi);
     if (st) *st = loc;
     orc_free(&rhs);
-    for (int l = 0; l < nl; ++l) { orc_free(&mg[l].cor); orc_free(&mg[l].res); orc_free(&mg[l].rescor); orc_free(&mg[l].sig); }
+    for (int l = 0; l < nl; ++l) {
+        orc_free(&mg[l].cor); orc_free(&mg[l].res); orc_free(&mg[l].rescor); orc_free(&mg[l].sig);
+        if (mg[l].dm.p) orc_free(&mg[l].dm);
+        if (covl[l].p) orc_free(&covl[l]);
+    }
 }
 
 void orc_nodal_project(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig,

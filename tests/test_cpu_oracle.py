@@ -294,3 +294,54 @@ def test_golden_fixture_regression_lid_driven_cavity(orc):
     S, t, dts = run_ldc(orc, (16, 16, 16), (4, 4, 5), (5, 5, 5), int(gold["nsteps"]))
     assert abs(t - float(gold["time"])) <= 1e-14
     assert np.abs(S - gold["S"]).max() <= 1e-12
+
+
+def test_nodal_solve_with_dirichlet_nodes():
+    """orc_nodal_solve_cov: (a) all-Dirichlet box recovers a manufactured solution; (b) a level covering a sub-box of a periodic
+    domain changes only its interior nodes and drives the residual there to the tolerance"""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_nodal_solve_cov.restype = None
+    n = (16, 16, 16)
+    rng = np.random.default_rng(0)
+    sig = orc.Fab(n, orc.CELL, 1, 1)
+    sig.a[...] = 1.0 + 0.5 * rng.random(sig.a.shape)
+    # (a)
+    g = orc.geom(n, periodic=(0, 0, 0))
+    D = (C.c_int * 3)(101, 101, 101)
+    x = np.arange(0, n[0] + 1) / n[0]
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    ex = np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    phi_e = orc.Fab(n, orc.NODE, 1, 1)
+    phi_e.a[1:-1, 1:-1, 1:-1, 0] = ex
+    rhs = orc.Fab(n, orc.NODE, 0, 1)
+    L.orc_nodal_adotx(C.byref(g), rhs.ref(), phi_e.ref(), sig.ref())
+    phi = orc.Fab(n, orc.NODE, 1, 1)
+    o = orc.mg_opts()
+    st = orc.CMgStats()
+    L.orc_nodal_solve_cov(C.byref(g), phi.ref(), rhs.ref(), sig.ref(), D, D, None, C.c_double(1e-11), C.c_double(0.0), C.byref(o), C.byref(st))
+    assert st.converged and st.iters <= 6
+    assert np.abs(phi.a[1:-1, 1:-1, 1:-1, 0] - ex).max() < 1e-10
+    # (b)
+    g2 = orc.geom(n)
+    P = (C.c_int * 3)(0, 0, 0)
+    cov = orc.Fab(n, orc.CELL, 0, 1)
+    cov.a[4:12, 4:12, 2:14, 0] = 1.0
+    phi = orc.Fab(n, orc.NODE, 1, 1)
+    phi.a[...] = rng.random(phi.a.shape)
+    phi0 = phi.a.copy()
+    rhs = orc.Fab(n, orc.NODE, 0, 1)
+    rhs.a[...] = rng.standard_normal(rhs.a.shape)
+    o = orc.mg_opts(max_coarsening_level=1)
+    L.orc_nodal_solve_cov(C.byref(g2), phi.ref(), rhs.ref(), sig.ref(), P, P, cov.ref(), C.c_double(1e-11), C.c_double(0.0), C.byref(o), C.byref(st))
+    assert st.converged
+    chg = np.abs(phi.a - phi0)[1:-1, 1:-1, 1:-1, 0] > 0
+    interior = np.zeros_like(chg)
+    interior[5:12, 5:12, 3:14] = True
+    assert (chg & ~interior).sum() == 0 and chg.sum() == interior.sum()
+    sg = sig.copy()
+    sg.a[1:-1, 1:-1, 1:-1, 0] *= cov.a[..., 0]
+    y = orc.Fab(n, orc.NODE, 0, 1)
+    L.orc_nodal_adotx(C.byref(g2), y.ref(), phi.ref(), sg.ref())
+    r = (rhs.a - y.a)[..., 0]
+    assert np.abs(r[interior]).max() <= 1e-11 * st.resnorm0 * 10

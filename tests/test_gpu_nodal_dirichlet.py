@@ -1,0 +1,115 @@
+"""GPU parity: nodal solves with Dirichlet nodes -- (a) Dirichlet (outflow) domain faces, SURVEY row f3, and (b) a level that
+does not cover the domain (AMR level > 0: the nodes on its boundary inside the domain hold Dirichlet data) --
+through the C-ABI (iamrx_nodal_solve) against the oracle (orc_nodal_solve_cov).  Same multigrid on both sides (8-colour GS,
+full-weighting restriction, sigma-weighted interpolation, BiCGStab bottom); results agree to round-off of the different
+summation orders (tolerance stated per assert)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PERIODIC, DIRICHLET, NEUMANN = 0, 101, 102
+
+
+def setup_fields(orc, n, seed):
+    rng = np.random.default_rng(seed)
+    sig = orc.Fab(n, orc.CELL, 1, 1)
+    sig.a[...] = 0.5 + rng.random(sig.a.shape)
+    rhs = orc.Fab(n, orc.NODE, 0, 1)
+    rhs.a[...] = rng.standard_normal(rhs.a.shape)
+    phi = orc.Fab(n, orc.NODE, 1, 1)
+    phi.a[...] = rng.standard_normal(phi.a.shape)          # also the Dirichlet data
+    return sig, rhs, phi
+
+
+def make_periodic_consistent(a, n, per, node=True):
+    """the periodic duplicate node n equals node 0 (array index: ghost offset 1)"""
+    for d in range(3):
+        if per[d] and node:
+            sl_hi = [slice(None)] * 4; sl_lo = [slice(None)] * 4
+            off = 1 if a.shape[d] == n[d] + 3 else 0
+            sl_hi[d] = off + n[d]; sl_lo[d] = off
+            a[tuple(sl_hi)] = a[tuple(sl_lo)]
+
+
+def run_both(orc, lib, n, per, lobc, hibc, boxes, owners_cov, seed, fixed_iters=0, rtol=1e-10):
+    from iamr_amd import ns as N
+    L = orc.lib()
+    L.orc_nodal_solve_cov.restype = None
+    g_o = orc.geom(n, periodic=per)
+    g_d = lib.Geom.make(n, periodic=per)
+    sig, rhs, phi = setup_fields(orc, n, seed)
+    make_periodic_consistent(rhs.a, n, per)
+    make_periodic_consistent(phi.a, n, per)
+    lay = lib.Layout(boxes)
+    cov = None
+    if owners_cov:
+        cov = orc.Fab(n, orc.CELL, 0, 1)
+        for lo, hi in boxes:
+            cov.a[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1, 0] = 1.0
+    # product
+    sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global(sig.a, sig.lo)
+    rhs_d = lib.MultiFab(lay, lib.NODE, 1, 0); rhs_d.set_from_global(rhs.a, rhs.lo)
+    phi_d = lib.MultiFab(lay, lib.NODE, 1, 1); phi_d.set_from_global(phi.a, phi.lo)
+    st_d = N.nodal_solve(g_d, phi_d, rhs_d, sig_d, 0, lobc, hibc, rtol, 0.0, lib.mg_opts(fixed_iters=fixed_iters))
+    # oracle with the same multigrid depth
+    o = orc.mg_opts(fixed_iters=fixed_iters, max_coarsening_level=st_d.nlevels - 1)
+    st_o = orc.CMgStats()
+    L.orc_nodal_solve_cov(C.byref(g_o), phi.ref(), rhs.ref(), sig.ref(), orc.i3(lobc), orc.i3(hibc), cov.ref() if cov else None,
+                          C.c_double(rtol), C.c_double(0.0), C.byref(o), C.byref(st_o))
+    got = []
+    ref = []
+    for li in range(phi_d.nlocal()):
+        a, lo = phi_d.to_numpy(li)
+        blo, bhi, gi = lay.local_box(li)
+        v = a[1:-1, 1:-1, 1:-1, 0]                          # valid nodes blo .. bhi+1
+        got.append(v)
+        ref.append(phi.a[1 + blo[0]:1 + bhi[0] + 2, 1 + blo[1]:1 + bhi[1] + 2, 1 + blo[2]:1 + bhi[2] + 2, 0])
+    return st_d, st_o, got, ref
+
+
+@pytest.mark.parametrize("case", ["outflow_x", "outflow_all", "outflow_two_boxes"])
+def test_dirichlet_faces(orc, gpu, case):
+    lib = gpu
+    if case == "outflow_x":         # channel: inflow/walls Neumann, outflow Dirichlet at x-hi, periodic in y
+        n, per = (32, 16, 16), (0, 1, 0)
+        lobc, hibc = (NEUMANN, PERIODIC, NEUMANN), (DIRICHLET, PERIODIC, NEUMANN)
+        boxes = [((0, 0, 0), (31, 15, 15))]
+    elif case == "outflow_all":
+        n, per = (16, 16, 16), (0, 0, 0)
+        lobc, hibc = (DIRICHLET,) * 3, (DIRICHLET,) * 3
+        boxes = [((0, 0, 0), (15, 15, 15))]
+    else:
+        n, per = (32, 16, 16), (0, 0, 0)
+        lobc, hibc = (NEUMANN, NEUMANN, DIRICHLET), (DIRICHLET, NEUMANN, NEUMANN)
+        boxes = [((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 15, 15))]
+    # same number of V-cycles on both sides: the iterates agree to round-off
+    st_d, st_o, got, ref = run_both(orc, lib, n, per, lobc, hibc, boxes, False, 7, fixed_iters=3)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+    # to convergence: same iteration count, same answer
+    st_d, st_o, got, ref = run_both(orc, lib, n, per, lobc, hibc, boxes, False, 7)
+    assert st_d.converged and st_d.iters == st_o.iters, (st_d.iters, st_o.iters)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-9 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+
+
+@pytest.mark.parametrize("case", ["one_box", "two_boxes_periodic_z", "l_shape"])
+def test_level_not_covering_the_domain(orc, gpu, case):
+    lib = gpu
+    n, per = (32, 32, 32), (1, 1, 1)
+    P = (PERIODIC,) * 3
+    if case == "one_box":
+        boxes = [((8, 8, 8), (23, 23, 23))]
+    elif case == "two_boxes_periodic_z":     # the level wraps around the periodic z direction: coarse/fine boundary in x and y only
+        boxes = [((8, 8, 0), (23, 23, 15)), ((8, 8, 16), (23, 23, 31))]
+    else:
+        boxes = [((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 15, 15)), ((0, 16, 0), (15, 31, 15))]
+    st_d, st_o, got, ref = run_both(orc, lib, n, per, P, P, boxes, True, 11, fixed_iters=3)
+    assert st_d.nlevels >= 3
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+    st_d, st_o, got, ref = run_both(orc, lib, n, per, P, P, boxes, True, 11)
+    assert st_d.converged and st_d.iters == st_o.iters, (st_d.iters, st_o.iters)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-9 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
