@@ -296,7 +296,7 @@ def test_golden_fixture_regression_lid_driven_cavity(orc):
     assert np.abs(S - gold["S"]).max() <= 1e-12
 
 
-def test_nodal_solve_with_dirichlet_nodes():
+def test_nodal_solve_with_dirichlet_nodes(orc):
     """orc_nodal_solve_cov: (a) all-Dirichlet box recovers a manufactured solution; (b) a level covering a sub-box of a periodic
     domain changes only its interior nodes and drives the residual there to the tolerance"""
     import ctypes as C
