@@ -626,12 +626,17 @@ void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp
     if (rhs.nlocal() == 0) return;
     const FabD *rt = rhs.d_tab, *vt = vel.d_tab;
     const double fx = 0.25 / g.dx[0], fy = 0.25 / g.dx[1], fz = 0.25 / g.dx[2];
-    int wl[3], wh[3];     // Neumann wall flags
+    // set_boundary_velocity (Source/Projection.cpp:2570-2663) + mlndlap_divu: cells outside a Neumann wall carry no velocity,
+    // outside an inflow face only the normal component (the inflow value) survives; the rhs of wall / inflow nodes is doubled
+    int wl[3], wh[3], il[3], ih[3];     // Neumann wall flags, inflow flags
     for (int d = 0; d < 3; ++d) {
         wl[d] = (bc && !g.periodic[d] && bc->lo[d] == lo_neumann) ? 1 : 0;
         wh[d] = (bc && !g.periodic[d] && bc->hi[d] == lo_neumann) ? 1 : 0;
+        il[d] = (bc && !g.periodic[d] && bc->lo[d] == lo_inflow) ? 1 : 0;
+        ih[d] = (bc && !g.periodic[d] && bc->hi[d] == lo_inflow) ? 1 : 0;
     }
     const int wl0 = wl[0], wl1 = wl[1], wl2 = wl[2], wh0 = wh[0], wh1 = wh[1], wh2 = wh[2];
+    const int il0 = il[0], il1 = il[1], il2 = il[2], ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
     const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2], dh0 = g.domain.hi[0], dh1 = g.domain.hi[1], dh2 = g.domain.hi[2];
     for_each(*rhs.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         const FabD v = vt[f];
@@ -639,18 +644,19 @@ void nodal_divu(const Geometry& g, MultiFab& rhs, const MultiFab& vel, int vcomp
         for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
             const int ci = i - 1 + cx, cj = j - 1 + cy, ck = k - 1 + cz;
             const bool outside = (wl0 && ci < dl0) || (wh0 && ci > dh0) || (wl1 && cj < dl1) || (wh1 && cj > dh1) || (wl2 && ck < dl2) || (wh2 && ck > dh2);
-            sx += (cx ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp));
-            sy += (cy ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp + 1));
-            sz += (cz ? 1.0 : -1.0) * (outside ? 0.0 : v(ci, cj, ck, vcomp + 2));
+            const bool in0 = (il0 && ci < dl0) || (ih0 && ci > dh0), in1 = (il1 && cj < dl1) || (ih1 && cj > dh1), in2 = (il2 && ck < dl2) || (ih2 && ck > dh2);
+            sx += (cx ? 1.0 : -1.0) * ((outside || in1 || in2) ? 0.0 : v(ci, cj, ck, vcomp));
+            sy += (cy ? 1.0 : -1.0) * ((outside || in0 || in2) ? 0.0 : v(ci, cj, ck, vcomp + 1));
+            sz += (cz ? 1.0 : -1.0) * ((outside || in0 || in1) ? 0.0 : v(ci, cj, ck, vcomp + 2));
         }
         double r = 0.0;
         r += fx * sx; r += fy * sy; r += fz * sz;
-        if (wl0 && i == dl0) r *= 2.0;
-        if (wh0 && i == dh0 + 1) r *= 2.0;
-        if (wl1 && j == dl1) r *= 2.0;
-        if (wh1 && j == dh1 + 1) r *= 2.0;
-        if (wl2 && k == dl2) r *= 2.0;
-        if (wh2 && k == dh2 + 1) r *= 2.0;
+        if ((wl0 || il0) && i == dl0) r *= 2.0;
+        if ((wh0 || ih0) && i == dh0 + 1) r *= 2.0;
+        if ((wl1 || il1) && j == dl1) r *= 2.0;
+        if ((wh1 || ih1) && j == dh1 + 1) r *= 2.0;
+        if ((wl2 || il2) && k == dl2) r *= 2.0;
+        if ((wh2 || ih2) && k == dh2 + 1) r *= 2.0;
         rt[f](i, j, k) = r;
     });
 }

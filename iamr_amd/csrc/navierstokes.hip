@@ -69,10 +69,17 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
     // BCType of a velocity component / scalar for a physical BC: NS_BC.H:7-25 (norm_vel_bc, tang_vel_bc, scalar_bc)
     auto vel_bctype = [](int phys, bool normal) {
         if (phys == phys_interior) return (int)bc_int_dir;
+        if (phys == phys_inflow) return (int)bc_ext_dir;
+        if (phys == phys_outflow) return (int)bc_foextrap;
         if (phys == phys_noslipwall) return (int)bc_ext_dir;
         return normal ? (int)bc_ext_dir : (int)bc_hoextrap;      // SlipWall
     };
-    auto scal_bctype = [](int phys) { return phys == phys_interior ? (int)bc_int_dir : (int)bc_foextrap; };
+    auto scal_bctype = [](int phys) {
+        if (phys == phys_interior) return (int)bc_int_dir;
+        return phys == phys_inflow ? (int)bc_ext_dir : (int)bc_foextrap;
+    };
+    auto gp_bctype = [](int phys) { return phys == phys_interior ? (int)bc_int_dir : (int)bc_foextrap; };   // norm/tang_gradp_bc
+    auto phys_ok = [](int phys) { return phys == phys_inflow || phys == phys_outflow || phys == phys_slipwall || phys == phys_noslipwall; };
     // Diffusion::setDomainBC, Diffusion.cpp:1886-1941
     auto linop_of = [](int bct) {
         if (bct == bc_ext_dir) return (int)lo_dirichlet;
@@ -83,19 +90,28 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         const int plo = g.periodic[d] ? (int)phys_interior : p.phys_lo[d], phi_ = g.periodic[d] ? (int)phys_interior : p.phys_hi[d];
         if (!g.periodic[d]) {
             any_wall = true;
-            const bool ok = (plo == phys_slipwall || plo == phys_noslipwall) && (phi_ == phys_slipwall || phi_ == phys_noslipwall);
-            if (!ok) throw Error("iamrx NavierStokes: a non-periodic direction needs SlipWall (4) or NoSlipWall (5) on both sides; "
-                                 "inflow/outflow/symmetry are not implemented");
+            if (!(phys_ok(plo) && phys_ok(phi_)))
+                throw Error("iamrx NavierStokes: a non-periodic direction needs Inflow (1), Outflow (2), SlipWall (4) or NoSlipWall (5) on "
+                            "both sides; Symmetry (3) is not implemented");
+            if ((plo == phys_outflow || phi_ == phys_outflow) && p.gravity != 0.0)
+                throw Error("iamrx NavierStokes: outflow with gravity (hydrostatic outflow pressure, Projection::set_outflow_bcs) is not implemented");
         }
-        bc_mac.lo[d] = bc_mac.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;      // MacProj.cpp:1187-1208
-        bc_nodal.lo[d] = bc_nodal.hi[d] = g.periodic[d] ? lo_periodic : lo_neumann;  // Projection.cpp:2432-2464
+        // MacProj::set_mac_solve_bc (MacProj.cpp:1187-1208): outflow Dirichlet, everything else Neumann
+        bc_mac.lo[d] = g.periodic[d] ? lo_periodic : (plo == phys_outflow ? lo_dirichlet : lo_neumann);
+        bc_mac.hi[d] = g.periodic[d] ? lo_periodic : (phi_ == phys_outflow ? lo_dirichlet : lo_neumann);
+        // Projection.cpp:2432-2464: outflow Dirichlet, inflow "inflow", everything else Neumann
+        bc_nodal.lo[d] = (!g.periodic[d] && plo == phys_inflow) ? (int)lo_inflow : bc_mac.lo[d];
+        bc_nodal.hi[d] = (!g.periodic[d] && phi_ == phys_inflow) ? (int)lo_inflow : bc_mac.hi[d];
         for (int n = 0; n < 3; ++n) {
             bc_vel[n].lo[d] = vel_bctype(plo, n == d); bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
-            bc_gp[n].lo[d] = scal_bctype(plo); bc_gp[n].hi[d] = scal_bctype(phi_);   // norm/tang_gradp_bc: foextrap at walls
+            bc_gp[n].lo[d] = gp_bctype(plo); bc_gp[n].hi[d] = gp_bctype(phi_);
             ed_vel_lo[n * 3 + d] = p.wall_vel_lo[d * 3 + n]; ed_vel_hi[n * 3 + d] = p.wall_vel_hi[d * 3 + n];
             bc_visc[n].lo[d] = linop_of(bc_vel[n].lo[d]); bc_visc[n].hi[d] = linop_of(bc_vel[n].hi[d]);
         }
-        for (int n = 0; n < 2; ++n) { bc_scal[n].lo[d] = scal_bctype(plo); bc_scal[n].hi[d] = scal_bctype(phi_); }
+        for (int n = 0; n < 2; ++n) {
+            bc_scal[n].lo[d] = scal_bctype(plo); bc_scal[n].hi[d] = scal_bctype(phi_);
+            ed_scal_lo[n * 3 + d] = p.scal_bc_lo[d * 2 + n]; ed_scal_hi[n * 3 + d] = p.scal_bc_hi[d * 2 + n];
+        }
         bc_scal_lin.lo[d] = linop_of(bc_scal[1].lo[d]); bc_scal_lin.hi[d] = linop_of(bc_scal[1].hi[d]);
     }
     bc_mac.maxorder = 4;     // MacProj.cpp:1172
@@ -139,7 +155,10 @@ void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int 
     dst.FillBoundary(g);
     if (any_wall) {
         const bool is_vel = (bc == bc_vel);
-        fill_physbc_cc(g, dst, 0, ncomp, bc, is_vel ? ed_vel_lo : nullptr, is_vel ? ed_vel_hi : nullptr);
+        const bool is_scal = (bc >= bc_scal && bc < bc_scal + 2);
+        const long so = is_scal ? 3 * (bc - bc_scal) : 0;
+        fill_physbc_cc(g, dst, 0, ncomp, bc, is_vel ? ed_vel_lo : (is_scal ? ed_scal_lo + so : nullptr),
+                       is_vel ? ed_vel_hi : (is_scal ? ed_scal_hi + so : nullptr));
     }
 }
 
@@ -520,9 +539,31 @@ void NavierStokes::level_project(double dt_)
             st[f](i, j, k, 0) = 1.0 / ht[f](i, j, k, 0);
         });
     }
+    set_inflow_ghosts(Sn, 1.0 / dt_);
     st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
     fill_gradp_bc();
     mf_mult(Sn, dt_, Xvel, 3, 1);                                // U_new *= dt (:438)
+}
+
+// Ghost cells outside an inflow face hold the boundary value of the field being projected (setPhysBoundaryValues before the
+// scaling of U_new, Projection.cpp:199-207): inflow velocity x scale (1/dt in level_project, 1 in the initial velocity
+// projection, 0 for the time difference of a steady inflow in initialSyncProject).  nodal_divu keeps only this normal component.
+void NavierStokes::set_inflow_ghosts(MultiFab& vel, double scale)
+{
+    for (int d = 0; d < 3; ++d) {
+        if (g.periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            if ((side == 0 ? bc_nodal.lo[d] : bc_nodal.hi[d]) != lo_inflow) continue;
+            const double uin = (side == 0 ? ed_vel_lo[d * 3 + d] : ed_vel_hi[d * 3 + d]) * scale;
+            const int face = side == 0 ? g.domain.lo[d] - 1 : g.domain.hi[d] + 1;
+            const FabD* vt = vel.d_tab;
+            const int dd = d;
+            for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                const int idx = dd == 0 ? i : (dd == 1 ? j : k);
+                if (idx == face) vt[f](i, j, k, Xvel + dd) = uin;
+            });
+        }
+    }
 }
 
 void NavierStokes::initial_velocity_project()
@@ -533,6 +574,7 @@ void NavierStokes::initial_velocity_project()
         phi.setVal(0.0);
         MultiFab sig(layout, cell_type(), 1, 1);
         sig.setVal(1.0);                                         // constant-density initial projection (rho_wgt_vel_proj = 0)
+        set_inflow_ghosts(S[inew], 1.0);
         st_nodal = nodal_projection(g, S[inew], Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
         for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }   // Projection.cpp:799-806
     }
@@ -558,6 +600,7 @@ void NavierStokes::initial_sync_project(double dt_)
             st[f](i, j, k, 0) = 1.0 / ht[f](i, j, k, 0);
         });
     }
+    set_inflow_ghosts(Sn, 0.0);
     st_nodal = nodal_projection(g, Sn, Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], true);
     fill_gradp_bc();
     mf_saxpy(P[pnew], 1.0, phi, 0, 0, 1, 1);                     // P_new += phi (Projection.cpp:1176-1180)

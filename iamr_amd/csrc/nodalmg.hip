@@ -30,8 +30,11 @@ static bool nodal_small()
 }
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 
-NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc, const MGOpts& o) : m_g(g), m_bc(bc), m_o(o)
+NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const MGOpts& o) : m_g(g), m_bc(bc_in), m_o(o)
 {
+    // the operator does not distinguish inflow faces from walls (the difference is in div(u), nodal_divu)
+    for (int d = 0; d < 3; ++d) { if (m_bc.lo[d] == lo_inflow) m_bc.lo[d] = lo_neumann; if (m_bc.hi[d] == lo_inflow) m_bc.hi[d] = lo_neumann; }
+    const DomainBC& bc = m_bc;
     for (int d = 0; d < 3; ++d) {
         if (!g.periodic[d])
             for (int t : {bc.lo[d], bc.hi[d]})

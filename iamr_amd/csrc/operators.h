@@ -76,6 +76,7 @@ struct NSParams {
     double tracer_diff_coef = 0.0;       // ns.scal_diff_coefs[0]
     int phys_lo[3] = {0, 0, 0}, phys_hi[3] = {0, 0, 0};   // ns.lo_bc / ns.hi_bc (PhysBCType: 0 Interior, 4 SlipWall, 5 NoSlipWall)
     double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
+    double scal_bc_lo[6] = {0, 0, 0, 0, 0, 0}, scal_bc_hi[6] = {0, 0, 0, 0, 0, 0};   // xlo.density, xlo.tracer ... (inflow values): [d*2+n]
 };
 
 enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
@@ -112,6 +113,7 @@ private:
     void get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata);
     void first_order_extrap(MultiFab& mf);
     void fill_gradp_bc();
+    void set_inflow_ghosts(MultiFab& vel, double scale);
     bool is_diffusive_tracer() const { return p.tracer_diff_coef > 0.0; }
     void velocity_diffusion_update(double dt);
     void initial_velocity_diffusion_update(double dt);
@@ -135,6 +137,7 @@ private:
     DomainBC bc_mac, bc_nodal, bc_visc[3], bc_scal_lin;
     BCRec bc_vel[3], bc_scal[2], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];     // ext_dir values [n*3+d]
+    double ed_scal_lo[6], ed_scal_hi[6];   // ext_dir (inflow) values of density, tracer [n*3+d]
     MultiFab diff_b[3];                    // tracer diffusivity on faces
     bool any_wall = false;
 };

@@ -8,7 +8,7 @@ keys this library implements onto `ns_params`, the geometry and the box layout:
   ns.cfl, ns.init_iter, ns.init_vel_iter, ns.init_shrink, ns.change_max, ns.fixed_dt, ns.init_dt, ns.gravity,
   ns.be_cn_theta, ns.do_mom_diff, ns.vel_visc_coef, ns.scal_diff_coefs, ns.lo_bc, ns.hi_bc, ns.advection_scheme,
   ns.visc_tol, godunov.use_forces_in_trans, mac_proj.mac_tol / mac_abs_tol, proj.proj_tol / proj_abs_tol,
-  {x,y,z}{lo,hi}.velocity, prob.probtype (1: fluid at rest, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
+  {x,y,z}{lo,hi}.velocity / .density / .tracer, prob.probtype (1: fluid at rest, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
   prob.density_ic, max_step, stop_time
 (reference: Source/NavierStokesBase.cpp:431-557, Source/NavierStokes.cpp:250-310, Source/MacProj.cpp:62-75,
 Source/Projection.cpp:49-65, Source/Diffusion.cpp:98-118, Source/prob/prob_init.cpp:8-60, Source/main.cpp:60-145).
@@ -114,9 +114,9 @@ class Inputs:
         for d in range(3):
             if per[d] and (lo_bc[d] != 0 or hi_bc[d] != 0):
                 raise ValueError("inputs: periodic direction with a non-Interior ns.lo_bc/hi_bc (NavierStokesBase.cpp:563-590)")
-            if not per[d] and (lo_bc[d] not in (4, 5) or hi_bc[d] not in (4, 5)):
-                raise NotImplementedError(f"inputs: ns.lo_bc/hi_bc = {lo_bc[d]}/{hi_bc[d]} in direction {d}: only Interior (0), "
-                                          "SlipWall (4) and NoSlipWall (5) are implemented (SURVEY row f3)")
+            if not per[d] and (lo_bc[d] not in (1, 2, 4, 5) or hi_bc[d] not in (1, 2, 4, 5)):
+                raise NotImplementedError(f"inputs: ns.lo_bc/hi_bc = {lo_bc[d]}/{hi_bc[d]} in direction {d}: implemented are Interior (0), "
+                                          "Inflow (1), Outflow (2), SlipWall (4) and NoSlipWall (5); Symmetry (3) is not")
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
         if scheme != "Godunov_PLM":
             raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; only Godunov_PLM is implemented")
@@ -140,6 +140,13 @@ class Inputs:
             if self.has(f"{name}hi.velocity"):
                 whi[3 * d:3 * d + 3] = self.reals(f"{name}hi.velocity", 3)
         p["wall_vel_lo"], p["wall_vel_hi"] = wlo, whi
+        # inflow values of the scalars: {x,y,z}{lo,hi}.density / .tracer (NS_bcfill.H functors)
+        slo, shi = [0.0] * 6, [0.0] * 6
+        for d, name in enumerate("xyz"):
+            for q, sname in enumerate(("density", "tracer")):
+                slo[2 * d + q] = self.real(f"{name}lo.{sname}", 0.0) if self.has(f"{name}lo.{sname}") else 0.0
+                shi[2 * d + q] = self.real(f"{name}hi.{sname}", 0.0) if self.has(f"{name}hi.{sname}") else 0.0
+        p["scal_bc_lo"], p["scal_bc_hi"] = slo, shi
         probtype = self.integer("prob.probtype")
         if probtype == 1:
             prob = dict(probtype=1, rho0=1.0)

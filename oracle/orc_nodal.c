@@ -14,6 +14,9 @@
  */
 #include "orc_int.h"
 
+/* Neumann-like faces of the nodal operator: walls and inflow faces */
+#define NEU(b) ((b) == ORC_LO_NEUMANN || (b) == ORC_LO_INFLOW)
+
 /* local node a = (ax,ay,az) in {0,1}^3 ; weight of x_b in row a for one element with sigma=1:
  * w_ab = -[ sx/hx^2 my mz + sy/hy^2 mx mz + sz/hz^2 mx my ],  s=+1 same / -1 differ,  m=1/3 same / 1/6 differ */
 static inline double elem_w(int a, int b, const double* dx)
@@ -63,9 +66,15 @@ void orc_nodal_divu_bc(const orc_geom* g, orc_fab* rhs, const orc_fab* vel, cons
             for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
                 int c[3] = {cx, cy, cz};
                 int cell[3] = {i - 1 + cx, j - 1 + cy, k - 1 + cz};
+                /* set_boundary_velocity (Source/Projection.cpp:2570-2663) + mlndlap_divu: cells outside a Neumann wall carry no
+                 * velocity; outside an inflow face only the normal component (the inflow value) survives */
                 int outside = 0;
-                for (int e = 0; e < 3; ++e)
-                    if (!g->periodic[e] && ((cell[e] < 0 && lobc[e] == ORC_LO_NEUMANN) || (cell[e] > g->n[e] - 1 && hibc[e] == ORC_LO_NEUMANN))) outside = 1;
+                for (int e = 0; e < 3; ++e) {
+                    if (g->periodic[e]) continue;
+                    const int bt = cell[e] < 0 ? lobc[e] : (cell[e] > g->n[e] - 1 ? hibc[e] : 0);
+                    if (bt == ORC_LO_NEUMANN) outside = 1;
+                    else if (bt == ORC_LO_INFLOW && e != d) outside = 1;
+                }
                 double sgn = c[d] ? 1.0 : -1.0;
                 s += sgn * (outside ? 0.0 : A4(vel, cell[0], cell[1], cell[2], d));
             }
@@ -74,8 +83,8 @@ void orc_nodal_divu_bc(const orc_geom* g, orc_fab* rhs, const orc_fab* vel, cons
         const int idx[3] = {i, j, k};
         for (int e = 0; e < 3; ++e) {
             if (g->periodic[e]) continue;
-            if (idx[e] == 0 && lobc[e] == ORC_LO_NEUMANN) r *= 2.0;
-            if (idx[e] == g->n[e] && hibc[e] == ORC_LO_NEUMANN) r *= 2.0;
+            if (idx[e] == 0 && NEU(lobc[e])) r *= 2.0;
+            if (idx[e] == g->n[e] && NEU(hibc[e])) r *= 2.0;
         }
         A4(rhs, i, j, k, 0) = r;
     }
@@ -123,8 +132,8 @@ static void nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], cons
         if (g->periodic[d]) continue;
         for (int k = x->lo[2]; k <= x->hi[2]; ++k) for (int j = x->lo[1]; j <= x->hi[1]; ++j) for (int i = x->lo[0]; i <= x->hi[0]; ++i) {
             int idx[3] = {i, j, k}, s[3] = {i, j, k};
-            if (idx[d] < 0 && lobc && lobc[d] == ORC_LO_NEUMANN) s[d] = -idx[d];
-            else if (idx[d] > g->n[d] && hibc && hibc[d] == ORC_LO_NEUMANN) s[d] = 2 * g->n[d] - idx[d];
+            if (idx[d] < 0 && lobc && NEU(lobc[d])) s[d] = -idx[d];
+            else if (idx[d] > g->n[d] && hibc && NEU(hibc[d])) s[d] = 2 * g->n[d] - idx[d];
             else continue;
             A4(x, i, j, k, 0) = A4(x, s[0], s[1], s[2], 0);
         }
@@ -165,8 +174,8 @@ static inline double node_weight(const orc_geom* g, const int lobc[3], const int
     for (int d = 0; d < 3; ++d) {
         if (g->periodic[d]) { if (idx[d] == g->n[d]) return 0.0; }
         else {
-            if (idx[d] == 0 && lobc[d] == ORC_LO_NEUMANN) w *= 0.5;
-            if (idx[d] == g->n[d] && hibc[d] == ORC_LO_NEUMANN) w *= 0.5;
+            if (idx[d] == 0 && NEU(lobc[d])) w *= 0.5;
+            if (idx[d] == g->n[d] && NEU(hibc[d])) w *= 0.5;
         }
     }
     return w;
@@ -488,11 +497,11 @@ static int cell_in(const orc_geom* g, const int lobc[3], const int hibc[3], cons
     for (int d = 0; d < 3; ++d) {
         if (c[d] < 0) {
             if (g->periodic[d]) c[d] += g->n[d];
-            else if (lobc[d] == ORC_LO_NEUMANN) c[d] = -c[d] - 1;
+            else if (NEU(lobc[d])) c[d] = -c[d] - 1;
             else return 0;
         } else if (c[d] >= g->n[d]) {
             if (g->periodic[d]) c[d] -= g->n[d];
-            else if (hibc[d] == ORC_LO_NEUMANN) c[d] = 2 * g->n[d] - 1 - c[d];
+            else if (NEU(hibc[d])) c[d] = 2 * g->n[d] - 1 - c[d];
             else return 0;
         }
     }

@@ -45,7 +45,9 @@ struct orc_ns_state {
     int nstep;
     int initial_step, initial_iter;
     orc_mg_stats st_mac, st_nodal, st_visc, st_scal;
-    int lobc[3], hibc[3];          /* LinOp BC of the projections: Neumann at walls */
+    int lobc[3], hibc[3];          /* LinOp BC of the MAC projection: Neumann at walls / inflow, Dirichlet at outflow */
+    int nlobc[3], nhibc[3];        /* nodal projection: the same with ORC_LO_INFLOW on inflow faces */
+    double ed_scal_lo[6], ed_scal_hi[6];   /* ext_dir (inflow) values [n*3+d] of density, tracer */
     orc_bcrec bc_vel[3], bc_scal[2], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];   /* ext_dir values [n*3+d] for the velocity fill */
     int vlobc[9], vhibc[9];        /* tensor-solve LinOp BC per velocity component [n*3+d] */
@@ -68,17 +70,26 @@ void orc_ns_default_params(orc_ns_params* p)
     p->init_dt = -1.0; p->tracer_diff_coef = 0.0;
     for (int d = 0; d < 3; ++d) p->phys_lo[d] = p->phys_hi[d] = 0;
     for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
+    for (int q = 0; q < 6; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
 }
 
 /* BCType of a velocity component / scalar / grad p component for a physical BC (Source/NS_BC.H:7-35) */
-enum { PHYS_INTERIOR = 0, PHYS_SLIPWALL = 4, PHYS_NOSLIPWALL = 5 };
+enum { PHYS_INTERIOR = 0, PHYS_INFLOW = 1, PHYS_OUTFLOW = 2, PHYS_SLIPWALL = 4, PHYS_NOSLIPWALL = 5 };
 static int vel_bctype(int phys, int normal)
 {
     if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    if (phys == PHYS_INFLOW) return ORC_BC_EXT_DIR;
+    if (phys == PHYS_OUTFLOW) return ORC_BC_FOEXTRAP;
     if (phys == PHYS_NOSLIPWALL) return ORC_BC_EXT_DIR;
     return normal ? ORC_BC_EXT_DIR : ORC_BC_HOEXTRAP;          /* SlipWall */
 }
-static int scal_bctype(int phys) { return phys == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_FOEXTRAP; }
+static int scal_bctype(int phys)
+{
+    if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    return phys == PHYS_INFLOW ? ORC_BC_EXT_DIR : ORC_BC_FOEXTRAP;
+}
+static int gp_bctype(int phys) { return phys == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_FOEXTRAP; }   /* norm/tang_gradp_bc */
+static int phys_ok(int phys) { return phys == PHYS_INFLOW || phys == PHYS_OUTFLOW || phys == PHYS_SLIPWALL || phys == PHYS_NOSLIPWALL; }
 /* Diffusion::setDomainBC, Source/Diffusion.cpp:1886-1941 */
 static int linop_of_bctype(int bct)
 {
@@ -103,19 +114,30 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     s->rho_half = orc_alloc(g->n, ORC_CELL, 1, 1);
     for (int d = 0; d < 3; ++d) {
         const int plo = g->periodic[d] ? PHYS_INTERIOR : p->phys_lo[d], phi_ = g->periodic[d] ? PHYS_INTERIOR : p->phys_hi[d];
-        if (!g->periodic[d] && !((plo == PHYS_SLIPWALL || plo == PHYS_NOSLIPWALL) && (phi_ == PHYS_SLIPWALL || phi_ == PHYS_NOSLIPWALL))) {
-            fprintf(stderr, "orc_ns_create: non-periodic direction %d needs SlipWall(4)/NoSlipWall(5) on both sides\n", d);
+        if (!g->periodic[d] && !(phys_ok(plo) && phys_ok(phi_))) {
+            fprintf(stderr, "orc_ns_create: non-periodic direction %d needs Inflow(1)/Outflow(2)/SlipWall(4)/NoSlipWall(5) on both sides\n", d);
             free(s); return NULL;
         }
-        /* MacProj::set_mac_solve_bc (Source/MacProj.cpp:1187-1208), Projection.cpp:2434-2464: walls are Neumann */
-        s->lobc[d] = s->hibc[d] = g->periodic[d] ? ORC_LO_PERIODIC : ORC_LO_NEUMANN;
+        if ((plo == PHYS_OUTFLOW || phi_ == PHYS_OUTFLOW) && p->gravity != 0.0) {
+            fprintf(stderr, "orc_ns_create: outflow with gravity (hydrostatic outflow pressure, do_outflow_bcs) is not restated\n");
+            free(s); return NULL;
+        }
+        /* MacProj::set_mac_solve_bc (Source/MacProj.cpp:1187-1208): outflow Dirichlet, everything else Neumann;
+         * Projection.cpp:2434-2464: outflow Dirichlet, inflow "inflow", everything else Neumann */
+        s->lobc[d] = g->periodic[d] ? ORC_LO_PERIODIC : (plo == PHYS_OUTFLOW ? ORC_LO_DIRICHLET : ORC_LO_NEUMANN);
+        s->hibc[d] = g->periodic[d] ? ORC_LO_PERIODIC : (phi_ == PHYS_OUTFLOW ? ORC_LO_DIRICHLET : ORC_LO_NEUMANN);
+        s->nlobc[d] = (!g->periodic[d] && plo == PHYS_INFLOW) ? ORC_LO_INFLOW : s->lobc[d];
+        s->nhibc[d] = (!g->periodic[d] && phi_ == PHYS_INFLOW) ? ORC_LO_INFLOW : s->hibc[d];
         for (int n = 0; n < 3; ++n) {
             s->bc_vel[n].lo[d] = vel_bctype(plo, n == d); s->bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
-            s->bc_gp[n].lo[d] = scal_bctype(plo); s->bc_gp[n].hi[d] = scal_bctype(phi_);   /* norm/tang_gradp_bc: foextrap at walls */
+            s->bc_gp[n].lo[d] = gp_bctype(plo); s->bc_gp[n].hi[d] = gp_bctype(phi_);
             s->ed_vel_lo[n * 3 + d] = p->wall_vel_lo[d * 3 + n]; s->ed_vel_hi[n * 3 + d] = p->wall_vel_hi[d * 3 + n];
             s->vlobc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].lo[d]); s->vhibc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].hi[d]);
         }
-        for (int n = 0; n < 2; ++n) { s->bc_scal[n].lo[d] = scal_bctype(plo); s->bc_scal[n].hi[d] = scal_bctype(phi_); }
+        for (int n = 0; n < 2; ++n) {
+            s->bc_scal[n].lo[d] = scal_bctype(plo); s->bc_scal[n].hi[d] = scal_bctype(phi_);
+            s->ed_scal_lo[n * 3 + d] = p->scal_bc_lo[d * 2 + n]; s->ed_scal_hi[n * 3 + d] = p->scal_bc_hi[d * 2 + n];
+        }
         s->slobc[d] = linop_of_bctype(s->bc_scal[1].lo[d]); s->shibc[d] = linop_of_bctype(s->bc_scal[1].hi[d]);
     }
     return s;
@@ -195,7 +217,10 @@ static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int 
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&f, i, j, k, n) = A4(src, i, j, k, sc + n);
     orc_fill_periodic(&f, g, ORC_CELL);
-    if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : NULL, is_vel ? s->ed_vel_hi : NULL);
+    const int is_scal = (bc >= s->bc_scal && bc < s->bc_scal + 2);
+    const long so = is_scal ? 3 * (bc - s->bc_scal) : 0;
+    if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : (is_scal ? s->ed_scal_lo + so : NULL),
+                               is_vel ? s->ed_vel_hi : (is_scal ? s->ed_scal_hi + so : NULL));
     return f;
 }
 static void fill_ghosts(const orc_ns_state* s, orc_fab* f, const int type[3])
@@ -328,12 +353,22 @@ static double est_time_step(orc_ns_state* s)
 }
 
 static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost, comps 0..2*/, orc_fab* phi, const orc_fab* sig,
-                                int increment_gp)
+                                int increment_gp, double inflow_scale)
 {
     const orc_geom* g = &s->g;
     /* set_boundary_velocity + FillBoundary of vel ghost cells (periodic) */
     orc_fill_periodic(vel, g, ORC_CELL);
-    orc_nodal_project(g, vel, phi, sig, s->lobc, s->hibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+    /* inflow faces: the ghost cells hold the boundary value of the projected field (setPhysBoundaryValues before the scaling of
+     * U_new, Projection.cpp:199-207): inflow velocity x inflow_scale (1/dt in level_project, 1 in the initial velocity projection,
+     * 0 for the time-difference of a steady inflow in initialSyncProject) */
+    for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+        if ((side == 0 ? s->nlobc[d] : s->nhibc[d]) != ORC_LO_INFLOW) continue;
+        const double uin = (side == 0 ? s->ed_vel_lo[d * 3 + d] : s->ed_vel_hi[d * 3 + d]) * inflow_scale;
+        int lo[3] = {-1, -1, -1}, hi[3] = {g->n[0], g->n[1], g->n[2]};
+        lo[d] = hi[d] = side == 0 ? -1 : g->n[d];
+        for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i) A4(vel, i, j, k, d) = uin;
+    }
+    orc_nodal_project(g, vel, phi, sig, s->nlobc, s->nhibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
     /* Gp_new := grad(phi) or += (Projection.cpp:2549-2563), then FillPatch(Gp) */
     orc_fab gp = orc_alloc(g->n, ORC_CELL, 0, 3);
     orc_nodal_compgrad(g, &gp, phi);
@@ -361,7 +396,7 @@ static void initial_velocity_project(orc_ns_state* s)
         orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_setval(&sig, 1.0);       /* constant-density initial projection; scaleVar inverts: 1/1 */
         orc_fab v = vel_view(S_NEW(s));
-        nodal_project_level(s, &v, phi, &sig, 0);
+        nodal_project_level(s, &v, phi, &sig, 0, 1.0);
         orc_free(&sig);
         orc_setval(P_OLD(s), 0.0); orc_setval(P_NEW(s), 0.0);
         orc_setval(GP_OLD(s), 0.0); orc_setval(GP_NEW(s), 0.0);
@@ -639,7 +674,7 @@ static void level_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, Pn, &sig, 0);
+    nodal_project_level(s, &v, Pn, &sig, 0, 1.0 / dt);
     orc_free(&sig);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
@@ -680,7 +715,7 @@ static void initial_sync_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, phi, &sig, 1);
+    nodal_project_level(s, &v, phi, &sig, 1, 0.0);
     orc_free(&sig);
     orc_fab* Pn = P_NEW(s);
     size_t N = orc_npts(Pn);

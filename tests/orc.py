@@ -67,7 +67,8 @@ class CNsParams(C.Structure):
                 ("init_vel_iter", C.c_int), ("init_shrink", C.c_double), ("change_max", C.c_double),
                 ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int),
                 ("init_dt", C.c_double), ("tracer_diff_coef", C.c_double), ("phys_lo", C.c_int * 3), ("phys_hi", C.c_int * 3),
-                ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9)]
+                ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9),
+                ("scal_bc_lo", C.c_double * 6), ("scal_bc_hi", C.c_double * 6)]
 
 
 PF = C.POINTER(CFab)

@@ -33,8 +33,15 @@ def test_unsupported_features_are_rejected_loudly():
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["amr.max_level=1"]).problem()
     with pytest.raises(NotImplementedError):
-        Inputs([LDC], ["ns.lo_bc = 1 4 5"]).problem()
+        Inputs([LDC], ["ns.lo_bc = 3 4 5"]).problem()          # Symmetry
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["prob.probtype=10"]).problem()
     with pytest.raises(KeyError):
         Inputs([LDC], ["ns.some_unknown_knob=1"]).problem()
+
+
+def test_inflow_outflow_keys():
+    pr = Inputs([LDC], ["ns.lo_bc = 1 4 5", "ns.hi_bc = 2 4 5", "xlo.velocity = 1. 0. 0.", "xlo.density = 1.", "xlo.tracer = 0.25"]).problem()
+    p = pr["params"]
+    assert p["phys_lo"] == [1, 4, 5] and p["phys_hi"] == [2, 4, 5]
+    assert p["wall_vel_lo"][:3] == [1.0, 0.0, 0.0] and p["scal_bc_lo"][:2] == [1.0, 0.25] and p["scal_bc_hi"] == [0.0] * 6
