@@ -262,6 +262,26 @@ int iamrx_cc_restrict(iamrx_mf c, iamrx_mf f) { IAMRX_TRY cc_restrict(c->mf, f->
 int iamrx_cc_prolong_add(iamrx_mf f, iamrx_mf c) { IAMRX_TRY cc_prolong_add(f->mf, c->mf); IAMRX_CATCH }
 int iamrx_face_avgdown(iamrx_mf c, iamrx_mf f, int dir) { IAMRX_TRY face_avgdown(c->mf, f->mf, dir); IAMRX_CATCH }
 
+int iamrx_abec_solve_cf(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                        iamrx_mf phi, iamrx_mf rhs, const int lobc[3], const int hibc[3], iamrx_mf crse_phi, const iamrx_geom* cgeom,
+                        int ratio, double rel_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    IAMRX_ASSERT(ratio == 2);
+    Geometry gg = to_geom(g);
+    MGOpts op = to_opts(o);
+    CellMG mg(gg, phi->mf.layout, phi->mf.ncomp, to_bc(lobc, hibc, op.maxorder), op);
+    mg.setScalars(alpha, beta);
+    if (a) mg.setACoeffs(&a->mf);
+    const MultiFab* b[3] = {&bx->mf, &by->mf, &bz->mf};
+    mg.setBCoeffs(b);
+    mg.setCoarseFineBC(crse_phi ? &crse_phi->mf : nullptr, to_geom(cgeom), ratio);
+    mg.prepare();
+    MGStats s = mg.solve(phi->mf, rhs->mf, rel_tol, abs_tol);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
 int iamrx_abec_solve(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
                      iamrx_mf phi, iamrx_mf rhs, const int lobc[3], const int hibc[3], double rtol, double atol,
                      const iamrx_mg_opts* o, int tensor, iamrx_mg_stats* st)

@@ -14,6 +14,8 @@
 
 namespace iamrx {
 
+struct CfC1 { double c1[3][3]; int maxorder; };   // CfTab::c[d][NX-2][1]
+
 struct GsrbBC {
     int dlo[3], dhi[3];
     double cflo[3][3], cfhi[3][3];   // [comp][dir]: coefficient of the first interior cell in the ghost formula; 0 for periodic
@@ -69,7 +71,8 @@ template <bool SHARE>
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap)
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap,
+    const FabD* __restrict__ cfmt, CfC1 cfc)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -80,6 +83,11 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
+    // coarse/fine faces: the first-interior-cell weight of the ghost formula depends on the box length (NX = min(len + 1, maxorder))
+    const bool cf = cfmt != nullptr;
+    FabD cfm; if (cf) cfm = cfmt[fab];
+    const double c1x = cf ? cfc.c1[0][min(b.len(0) + 1, cfc.maxorder) - 2] : 0.0, c1y = cf ? cfc.c1[1][min(b.len(1) + 1, cfc.maxorder) - 2] : 0.0;
+    const double c1z = cf ? cfc.c1[2][min(b.len(2) + 1, cfc.maxorder) - 2] : 0.0;
     // wrap: the box spans a fully periodic domain, neighbours across the box faces are the periodic images inside the same box
     // (no ghost fill needed in front of the sweep)
     const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
@@ -99,9 +107,17 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
         const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
         for (int n = 0; n < ncomp; ++n) {
             const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
-            const double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
-            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
-            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
+            double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
+            double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            if (cf) {
+                if (i == b.lo[0] && cfm(i - 1, j, k) == 1.0) cf0 = c1x;
+                if (i == b.hi[0] && cfm(i + 1, j, k) == 1.0) cf3 = c1x;
+                if (j == b.lo[1] && cfm(i, j - 1, k) == 1.0) cf1 = c1y;
+                if (j == b.hi[1] && cfm(i, j + 1, k) == 1.0) cf4 = c1y;
+                if (k == b.lo[2] && cfm(i, j, k - 1) == 1.0) cf2 = c1z;
+                if (k == b.hi[2] && cfm(i, j, k + 1) == 1.0) cf5 = c1z;
+            }
             // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
             const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
             const double bxm = (bnc == 1 ? b1xm : bX(i, j, k, n)) * sx, bxp = (bnc == 1 ? b1xp : bX(i + 1, j, k, n)) * sx;
@@ -122,13 +138,22 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     for (int n = 0; n < ncomp; ++n) {
         const int nb = bnc == 1 ? 0 : n;
         const int nq = bc.nbc == 1 ? 0 : (n < 3 ? n : 0);
-        const double cf1 = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
+        const double cf1d = (j == bc.dlo[1]) ? bc.cflo[nq][1] : 0.0, cf4d = (j == bc.dhi[1]) ? bc.cfhi[nq][1] : 0.0;
         for (int k = k0; k <= k1; ++k) {
             const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
             if (i > b.hi[0]) continue;
             if (shell_only && i > b.lo[0] && i < b.hi[0] && j > b.lo[1] && j < b.hi[1] && k > b.lo[2] && k < b.hi[2]) continue;
-            const double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
-            const double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            double cf0 = (i == bc.dlo[0]) ? bc.cflo[nq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[nq][0] : 0.0;
+            double cf2 = (k == bc.dlo[2]) ? bc.cflo[nq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[nq][2] : 0.0;
+            double cf1 = cf1d, cf4 = cf4d;
+            if (cf) {
+                if (i == b.lo[0] && cfm(i - 1, j, k) == 1.0) cf0 = c1x;
+                if (i == b.hi[0] && cfm(i + 1, j, k) == 1.0) cf3 = c1x;
+                if (j == b.lo[1] && cfm(i, j - 1, k) == 1.0) cf1 = c1y;
+                if (j == b.hi[1] && cfm(i, j + 1, k) == 1.0) cf4 = c1y;
+                if (k == b.lo[2] && cfm(i, j, k - 1) == 1.0) cf2 = c1z;
+                if (k == b.hi[2] && cfm(i, j, k + 1) == 1.0) cf5 = c1z;
+            }
             const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
             const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
             // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
@@ -150,8 +175,12 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
 }
 
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
-               bool wrap)
+               bool wrap, const MultiFab* cfm, const CfTab* cftab)
 {
+    CfC1 cfc;
+    cfc.maxorder = cftab ? cftab->maxorder : 2;
+    for (int d = 0; d < 3; ++d) for (int q = 0; q < 3; ++q) cfc.c1[d][q] = cftab ? cftab->c[d][q][1] : 0.0;
+    const FabD* cft = (cfm && cftab) ? cfm->d_tab : nullptr;
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
     const Layout& l = *phi.layout;
@@ -162,11 +191,11 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
         hipLaunchKernelGGL(k_abec_gsrb<true>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
     else
         hipLaunchKernelGGL(k_abec_gsrb<false>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
 }
 
 // ---------------------------------------------------------------------------- fused red+black sweep
@@ -468,6 +497,121 @@ void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, 
                        (const int*)(dbuf + o1), (const double*)(dbuf + o2), inhomog ? 1 : 0);
     ctx.sync();          // hbuf is pageable host memory: keep it alive until the copy has completed
     ctx.free(dbuf);
+}
+
+
+// ---------------------------------------------------------------------------- coarse/fine faces
+CfTab cf_make_tab(const double loc[3], const double dx[3], int maxorder)
+{
+    CfTab t;
+    t.maxorder = maxorder < 2 ? 2 : (maxorder > 4 ? 4 : maxorder);
+    for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < 3; ++q) {
+            const int NX = q + 2;
+            const double x[4] = {-loc[d] / dx[d], 0.5, 1.5, 2.5};
+            for (int m = 0; m < 4; ++m) t.c[d][q][m] = 0.0;
+            poly_interp_coeff(-0.5, x, NX, t.c[d][q]);
+        }
+    return t;
+}
+
+void cf_build_mask(const Geometry& g, MultiFab& cfm)
+{
+    cfm.setVal(1.0);
+    cfm.setVal(0.0, 0, 1, 0);
+    cfm.FillBoundary(g);                 // ghost cells covered by another box of the level or by a periodic image become 0
+    if (cfm.nlocal() == 0) return;
+    const FabD* ct = cfm.d_tab;
+    const BoxD dom = g.domain;
+    const int p0 = g.periodic[0], p1 = g.periodic[1], p2 = g.periodic[2];
+    for_each(*cfm.layout, cell_type(), cfm.ngrow, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const bool out = (!p0 && (i < dom.lo[0] || i > dom.hi[0])) || (!p1 && (j < dom.lo[1] || j > dom.hi[1])) || (!p2 && (k < dom.lo[2] || k > dom.hi[2]));
+        if (out) ct[f](i, j, k) = 2.0;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ phit,
+    const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog)
+{
+    const int fab = blockIdx.y;
+    const BoxD vb = boxes[fab];
+    BoxD gb = vb;
+    for (int d = 0; d < 3; ++d) { gb.lo[d] -= 1; gb.hi[d] += 1; }
+    int i, j, k0, k1;
+    if (!tile_ijk(t, gb, i, j, k0, k1)) return;
+    const FabD phi = phit[fab], cfm = cfmt[fab];
+    for (int k = k0; k <= k1; ++k) {
+        const int idx[3] = {i, j, k};
+        int d = -1, nout = 0, s = 0;
+        for (int e = 0; e < 3; ++e) {
+            if (idx[e] < vb.lo[e]) { ++nout; d = e; s = 1; }
+            else if (idx[e] > vb.hi[e]) { ++nout; d = e; s = -1; }
+        }
+        if (nout != 1 || cfm(i, j, k) != 1.0) continue;       // only face-adjacent coarse/fine ghost cells
+        const int NX = min(vb.len(d) + 1, tab.maxorder);
+        const double* c = tab.c[d][NX - 2];
+        for (int n = 0; n < ncomp; ++n) {
+            double v = (inhomog && bcvt) ? bcvt[fab](i, j, k, n) * c[0] : 0.0;
+            int m[3] = {i, j, k};
+            for (int q = 1; q < NX; ++q) { m[d] = idx[d] + q * s; v += phi(m[0], m[1], m[2], n) * c[q]; }
+            phi(i, j, k, n) = v;
+        }
+    }
+}
+
+void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval)
+{
+    if (phi.nlocal() == 0) return;
+    Tiling t = level_tiling(*phi.layout, cell_type(), 1, 4);
+    hipLaunchKernelGGL(k_cf_fill, t.grid(), Tiling::block(), 0, Context::get().stream, t, phi.layout->d_boxes, phi.d_tab,
+                       bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0);
+}
+
+// interpbndrydata_{x,y,z}_o3: value at the fine ghost cell from the coarse cell under it and its tangential neighbours; a
+// neighbour takes part only if the ghost cell `ratio` cells further along is a coarse/fine ghost cell too (mask 1)
+__global__ void __launch_bounds__(256) k_cf_interp(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ bcvt,
+    const FabD* __restrict__ cpt, const FabD* __restrict__ cfmt, int ncomp, int r)
+{
+    const int fab = blockIdx.y;
+    const BoxD vb = boxes[fab];
+    BoxD gb = vb;
+    for (int d = 0; d < 3; ++d) { gb.lo[d] -= 1; gb.hi[d] += 1; }
+    int i, j, k0, k1;
+    if (!tile_ijk(t, gb, i, j, k0, k1)) return;
+    const FabD bcv = bcvt[fab], cp = cpt[fab], cfm = cfmt[fab];
+    for (int k = k0; k <= k1; ++k) {
+        const int q[3] = {i, j, k};
+        int d = -1, nout = 0;
+        for (int e = 0; e < 3; ++e) if (q[e] < vb.lo[e] || q[e] > vb.hi[e]) { ++nout; d = e; }
+        if (nout != 1 || cfm(i, j, k) != 1.0) continue;
+        const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+        int c[3];
+        for (int e = 0; e < 3; ++e) c[e] = q[e] >= 0 ? q[e] / r : -((-q[e] + r - 1) / r);
+        auto msk = [&](int o1, int o2) { int a[3] = {i, j, k}; a[t1] += o1 * r; a[t2] += o2 * r; return cfm(a[0], a[1], a[2]) == 1.0; };
+        const bool m1m = msk(-1, 0), m1p = msk(1, 0), m2m = msk(0, -1), m2p = msk(0, 1);
+        const bool diag = msk(-1, -1) && msk(1, -1) && msk(-1, 1) && msk(1, 1);
+        const int l1 = m1m ? -1 : 0, h1 = m1p ? 1 : 0, l2 = m2m ? -1 : 0, h2 = m2p ? 1 : 0;
+        const double f1 = (h1 == l1 + 1) ? 1.0 : 0.5, f2 = (h2 == l2 + 1) ? 1.0 : 0.5;
+        const double y1 = -0.5 + (q[t1] - c[t1] * r + 0.5) / r, y2 = -0.5 + (q[t2] - c[t2] * r + 0.5) / r;
+        for (int n = 0; n < ncomp; ++n) {
+            auto CC = [&](int o1, int o2) { int z[3] = {c[0], c[1], c[2]}; z[t1] += o1; z[t2] += o2; return (double)cp(z[0], z[1], z[2], n); };
+            const double d1 = f1 * (CC(h1, 0) - CC(l1, 0));
+            const double d11 = (h1 == l1 + 2) ? 0.5 * (CC(1, 0) - 2.0 * CC(0, 0) + CC(-1, 0)) : 0.0;
+            const double d2 = f2 * (CC(0, h2) - CC(0, l2));
+            const double d22 = (h2 == l2 + 2) ? 0.5 * (CC(0, 1) - 2.0 * CC(0, 0) + CC(0, -1)) : 0.0;
+            const double d12 = diag ? 0.25 * (CC(1, 1) - CC(-1, 1) + CC(-1, -1) - CC(1, -1)) : 0.0;
+            bcv(i, j, k, n) = CC(0, 0) + y1 * d1 + (y1 * y1) * d11 + y2 * d2 + (y2 * y2) * d22 + y1 * y2 * d12;
+        }
+    }
+}
+
+void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio)
+{
+    if (bcval.nlocal() == 0) return;
+    IAMRX_ASSERT(cfm.ngrow >= 1 + ratio - 1 + 1 - 1 && cfm.ngrow >= 2 && cpatch.ngrow >= 1 && bcval.ngrow >= 1 && ratio == 2);
+    Tiling t = level_tiling(*bcval.layout, cell_type(), 1, 4);
+    hipLaunchKernelGGL(k_cf_interp, t.grid(), Tiling::block(), 0, Context::get().stream, t, bcval.layout->d_boxes, bcval.d_tab,
+                       cpatch.d_tab, cfm.d_tab, bcval.ncomp, ratio);
 }
 
 // ---------------------------------------------------------------------------- transfers

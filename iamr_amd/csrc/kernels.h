@@ -40,9 +40,22 @@ struct DomainBC {             // linear-operator BC of the level's domain
     int lo[3], hi[3];         // LinOpBC per face
     int maxorder;
 };
+// Coarse/fine faces of a level that does not cover the domain (MLLinOp::setCoarseFineBC): Dirichlet data half a coarse cell behind
+// the face.  c[d][NX-2][m]: Lagrange weights of the ghost formula through x = {-loc/dx, 0.5, 1.5, 2.5} (m = 0: the coarse datum),
+// NX = min(box length + 1, maxorder).
+struct CfTab { double c[3][3][4]; int maxorder; };
+CfTab cf_make_tab(const double loc[3], const double dx[3], int maxorder);
+// cell mask, ghost cells included: 0 = cell of the level (valid, neighbour box or periodic image), 1 = coarse/fine ghost cell,
+// 2 = outside the physical domain
+void cf_build_mask(const Geometry& g, MultiFab& cfm);
+// ghost cells with mask 1 next to a box face: phi = c[0] * bcval (inhomog) + sum_m c[m] * phi(m-th cell inside)   (mllinop_apply_bc)
+void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval);
+// bcval(ghost cells with mask 1) = coarse data of cpatch (coarsened layout, 1 ghost cell) interpolated in the tangential directions
+// (InterpBndryData::setBndryValues, third order, ratio 2); cfm needs 2 ghost cells
+void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
 // bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc,
-               bool shell_only = false, bool wrap = false);
+               bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,

@@ -50,6 +50,9 @@ public:
     void setTensorEta(bool t) { m_tensor_eta = t; }
     // one DomainBC per component (MLTensorOp::setDomainBC with per-component arrays)
     void setDomainBCs(const DomainBC* bcs, int n) { m_bcn.assign(bcs, bcs + n); }
+    // MLLinOp::setCoarseFineBC: the level does not cover the domain; crse = the coarse level's solution (cell centred, valid data on
+    // the coarse level's own layout), cgeom its geometry.  crse == nullptr: homogeneous coarse/fine data.  Call before prepare().
+    void setCoarseFineBC(const MultiFab* crse, const Geometry& cgeom, int ratio) { m_cf = true; m_crse = crse; m_cgeom = cgeom; m_ratio = ratio; }
     void prepare();   // build the coarse hierarchy (coefficient averaging)
     MGStats solve(MultiFab& phi, const MultiFab& rhs, double rtol, double atol);
     // out = L(phi) with inhomogeneous BC taken from phi's ghost cells
@@ -79,9 +82,12 @@ private:
         bool agg = false;
         LayoutP dist;
         MultiFab tmp_d;
+        MultiFab cfm;              // coarse/fine mask (levels that do not cover the domain), see cf_build_mask
+        CfTab cftab;
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void bottom_solve(MGStats& st);
+    void cf_bcval(MultiFab& bcval);
     void subtract_mean(int l, MultiFab& mf);
     Geometry m_g;
     int m_ncomp;
@@ -94,6 +100,10 @@ private:
     bool m_tensor = false;
     bool m_tensor_eta = false;
     bool m_singular = false;
+    bool m_cf = false;
+    const MultiFab* m_crse = nullptr;
+    Geometry m_cgeom;
+    int m_ratio = 2;
     std::vector<Level> m_lev;
 };
 

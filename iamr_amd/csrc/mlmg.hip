@@ -9,6 +9,9 @@
 
 namespace iamrx {
 
+// amr.hip
+void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add);
+
 long mg_agglomeration_cells()
 {
     static long v = -1;
@@ -47,6 +50,7 @@ void CellMG::prepare()
     m_singular = !(m_alpha != 0.0 && m_a0);
     for (int d = 0; d < 3; ++d)
         for (auto& b : m_bcn) if (!m_g.periodic[d] && (b.lo[d] == lo_dirichlet || b.hi[d] == lo_dirichlet)) m_singular = false;
+    if (m_cf) m_singular = false;           // coarse/fine faces carry Dirichlet data
     // coarsen while every box is coarsenable (MLLinOp::defineGrids, mg_box_min_width = 2)
     m_lev.resize(1);
     while ((int)m_lev.size() <= m_o.max_coarsening_level) {
@@ -72,6 +76,14 @@ void CellMG::prepare()
         L.cor.define(L.layout, cell_type(), m_ncomp, 1);
         L.res.define(L.layout, cell_type(), m_ncomp, 0);
         L.rescor.define(L.layout, cell_type(), m_ncomp, 0);
+        if (m_cf) {
+            // the Dirichlet data sit half a coarse cell (of the AMR level below) behind the face on every MG level
+            double loc[3];
+            for (int d = 0; d < 3; ++d) loc[d] = 0.5 * m_ratio * m_g.dx[d];
+            L.cftab = cf_make_tab(loc, L.g.dx, m_o.maxorder);
+            L.cfm.define(L.layout, cell_type(), 1, l == 0 ? 2 : 1);
+            cf_build_mask(L.g, L.cfm);
+        }
         if (l > 0) {
             AbecCoef fc = coef(l - 1);
             if (L.agg) L.tmp_d.define(L.dist, cell_type(), m_ncomp, 0);
@@ -105,6 +117,19 @@ void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
         for (int n = 0; n < m_ncomp; ++n) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
         if (m_tensor) for (int n = 0; n < m_ncomp; ++n) fill_tensor_corners(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
     }
+    if (m_cf) cf_fill_ghosts(phi, m_lev[l].cfm, m_lev[l].cftab, inhomog, bcval);
+}
+
+// level BC data at the coarse/fine ghost cells: the coarse solution interpolated along the faces
+void CellMG::cf_bcval(MultiFab& bcval)
+{
+    if (!m_cf) return;
+    IAMRX_ASSERT(!m_tensor);    // the tensor cross terms at coarse/fine faces are not implemented
+    LayoutP cl = m_lev[0].layout->coarsened(m_ratio);
+    MultiFab cpatch(cl, cell_type(), m_ncomp, 1);
+    cpatch.setVal(0.0);
+    if (m_crse) parallel_copy(cpatch, *m_crse, 0, 0, m_ncomp, 0, 1, &m_cgeom, false);
+    cf_interp_bndry(bcval, cpatch, m_lev[0].cfm, m_ratio);
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
@@ -112,10 +137,11 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
     AbecCoef c = coef(l);
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
     // one box spanning a fully periodic domain: the kernel reads the periodic images from the valid cells, no ghost fills
-    const bool wrap = periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
+    const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
     for (int rb = 0; rb < 2; ++rb) {
         if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr);
-        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap);
+        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
+                  m_cf ? &m_lev[l].cftab : nullptr);
         skip_fill = false;
     }
 }
@@ -128,7 +154,7 @@ bool CellMG::fused_smoother_ok(int l) const
     // opt-in: on MI355X the single-pass kernel (62 B/cell of HBM traffic instead of 130) is still slower than the two colour
     // passes (233 VGPRs -> 2 waves/SIMD with three barriers per plane: 0.41 ms vs 2 x 0.18 ms at 256^3)
     static const bool on = getenv("IAMRX_GSRB_FUSED") && atoi(getenv("IAMRX_GSRB_FUSED")) != 0;
-    if (!on) return false;
+    if (!on || m_cf) return false;
     const Level& L = m_lev[l];
     for (int d = 0; d < 3; ++d) {
         if (L.layout->max_len[d] < 16) return false;
@@ -295,6 +321,7 @@ void CellMG::apply(MultiFab& out, MultiFab& phi)
 {
     MultiFab bcval(m_lev[0].layout, cell_type(), m_ncomp, 1);
     MultiFab::Copy(bcval, phi, 0, 0, m_ncomp, 1);
+    cf_bcval(bcval);
     applyBC(0, phi, true, &bcval);
     abec_residual(m_lev[0].g, coef(0), out, phi, nullptr);
 }
@@ -316,6 +343,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     if (m_singular) subtract_mean(0, rhs);
     MultiFab bcval(L0.layout, cell_type(), nc, 1);
     MultiFab::Copy(bcval, phi, 0, 0, nc, 1);
+    cf_bcval(bcval);
 
     applyBC(0, phi, true, &bcval);
     abec_residual(L0.g, coef(0), L0.res, phi, &rhs);

@@ -329,6 +329,16 @@ def abec_solve(geom, alpha, beta, a, b, phi, rhs, lobc=(0, 0, 0), hibc=(0, 0, 0)
     return st
 
 
+def abec_solve_cf(geom, alpha, beta, a, b, phi, rhs, crse_phi, cgeom, ratio=2, lobc=(0, 0, 0), hibc=(0, 0, 0), rtol=1e-12, atol=1e-16, opts=None):
+    """abec_solve on an AMR level that does not cover the domain: coarse/fine faces take Dirichlet data from crse_phi"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    check(lib().iamrx_abec_solve_cf(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a) if a is not None else None, _h(b[0]), _h(b[1]), _h(b[2]),
+                                    _h(phi), _h(rhs), i3(lobc), i3(hibc), _h(crse_phi) if crse_phi is not None else None, C.byref(cgeom), ratio,
+                                    C.c_double(rtol), C.c_double(atol), C.byref(o), C.byref(st)))
+    return st
+
+
 def mlmg_mac_solve(geom, umac, rho, rho_comp, S, mac_phi, rhs_scale, lobc=(0, 0, 0), hibc=(0, 0, 0),
                    mac_tol=1e-12, mac_abs_tol=1e-16, opts=None):
     """MacProj::mlmg_mac_solve (reference Source/MacProj.cpp:1084-1184)"""

@@ -178,6 +178,15 @@ int iamrx_nodal_projection(const iamrx_geom* g, iamrx_mf vel, int vcomp, iamrx_m
                            const int lobc[3], const int hibc[3], double rel_tol, double abs_tol, const iamrx_mg_opts* o,
                            iamrx_mf gp /* may be NULL */, int increment_gp, iamrx_mg_stats* st);
 
+/* iamrx_abec_solve on an AMR level > 0 (MLLinOp::setCoarseFineBC + setLevelBC as MacProj::mlmg_mac_solve and the Diffusion solves use
+ * them on refined levels, Source/MacProj.cpp:1166-1170): the level of phi does not cover the domain; its box faces inside the domain
+ * that touch no other box of the level are coarse/fine faces with Dirichlet data taken from crse_phi (the coarse level's solution on its
+ * own layout, geometry cgeom; NULL: zero), interpolated along the face (InterpBndryData, third order) and applied with the level's
+ * maxorder half a coarse cell behind the face. */
+int iamrx_abec_solve_cf(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,
+                        iamrx_mf phi, iamrx_mf rhs, const int lobc[3], const int hibc[3], iamrx_mf crse_phi, const iamrx_geom* cgeom,
+                        int ratio, double rel_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
 /* the nodal solve alone: div(sig grad phi) = rhs on the level `phi` lives on (MLMG::solve on MLNodeLaplacian, as driven by
  * Hydro::NodalProjector inside Projection::doMLMGNodalProjection, Source/Projection.cpp:2512-2542, and by the sync solves of
  * Projection::MLsyncProject, :457-607).  LinOpBC codes: Neumann (walls, inflow), Dirichlet (outflow).  Nodes on Dirichlet domain

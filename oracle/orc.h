@@ -82,6 +82,12 @@ typedef struct orc_abec_level {
     int tensor;               /* 1: MLTensorOp -- b holds eta*(4/3 on the normal comp), cross terms added in apply */
     int bc_percomp;           /* 1: the lobc/hibc arguments hold ncomp*3 codes, [n*3+d] (MLTensorOp::setDomainBC per component,
                                  reference Source/Diffusion.cpp:724-731) */
+    /* AMR level that does not cover the domain (nbox > 0): the level's cells are the union of the boxes (6 ints each: lo, hi);
+     * faces of a box that touch neither another box (incl. periodic images) nor the physical boundary are coarse/fine faces with
+     * Dirichlet data cf_loc[d] behind them (MLLinOp::setCoarseFineBC: half a coarse cell = 0.5*ratio*dx of the level) */
+    int nbox;
+    const int* boxes;
+    double cf_loc[3];
 } orc_abec_level;
 
 typedef struct orc_mg_stats {
@@ -116,6 +122,14 @@ void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi /*1 ghost, filled*/, co
                    int redblack, double omega, const int lobc[3], const int hibc[3], int maxorder);
 void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
                       int maxorder, int inhomog, const orc_fab* bcval /*same shape as phi, ghost cells hold BC values*/);
+/* Dirichlet data of the coarse/fine faces of level L (nbox > 0): the coarse solution cphi (cell, 1 ghost, ncomp comps; periodic ghosts
+ * filled by the caller) interpolated to the fine ghost cells -- InterpBndryData::setBndryValues, third order in the tangential
+ * directions (quadratic with one-sided / dropped terms where the neighbouring ghost cell is not a coarse/fine ghost cell).
+ * bcval: cell, 1 ghost, 3*ncomp comps, [n*3+d] = value for a face of direction d */
+void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi, orc_fab* bcval);
+/* orc_abec_solve on a level with coarse/fine faces: cf_bcval from orc_cf_interp_bndry (NULL: homogeneous) */
+void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                       const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 void orc_cc_restrict(orc_fab* crse, const orc_fab* fine, const int cn[3]);
 void orc_cc_prolong_add(orc_fab* fine, const orc_fab* crse, const int fn[3]);
 void orc_face_avgdown(orc_fab* crse, const orc_fab* fine, int dir, const int cn[3]);

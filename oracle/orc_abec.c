@@ -29,8 +29,10 @@ int orc_abec_is_tensor(const orc_abec_level* L);                                
 void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
                                    int maxorder, int inhomog, const orc_fab* bcval);    /* orc_tensor.c */
 
+static void cf_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x);
 void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x)
 {
+    if (L->nbox > 0) { cf_apply(L, y, x); return; }
     const orc_geom* g = &L->g;
     const double dhx = L->beta / (g->dx[0] * g->dx[0]);
     const double dhy = L->beta / (g->dx[1] * g->dx[1]);
@@ -82,10 +84,166 @@ static double bc_coef0(int bct, int blen, int maxorder)
 
 #define BCOFF(L, n) ((L)->bc_percomp ? 3 * (n) : 0)
 
+/* ------------------------------------------------------------- coarse/fine faces (level with nbox > 0) ----
+ * The level's cells are the union of its boxes.  The operator is evaluated box by box on a private copy of the box grown by
+ * one cell -- exactly how MLCellLinOp sees its data: ghost cells covered by another box (or a periodic image) carry that
+ * box's value, ghost cells outside the physical domain carry the domain-BC ghost value of the global array, and the remaining
+ * ghost cells are coarse/fine ghost cells filled by the Dirichlet formula of mllinop_apply_bc with the boundary value
+ * cf_loc[d] behind the face: ghost = c[0]*bcval + sum_m c[m]*phi(m-th cell inside), Lagrange weights through
+ * x = {-cf_loc/dx, 0.5, 1.5, 2.5}, order NX = min(box length + 1, maxorder). */
+static const orc_fab* g_cf_bcval = NULL;     /* coarse/fine Dirichlet data of the solve in progress */
+static int g_cf_inhomog = 0;                 /* set by orc_abec_applybc: the next apply uses the data (1) or zero (0) */
+static int g_cf_maxorder = 2;
+
+static int box_of(const orc_abec_level* L, int i, int j, int k)
+{
+    /* index (1-based) of the box holding cell (i,j,k) after periodic wrap; 0: inside the domain, not covered; -1: outside */
+    int c[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d) {
+        if (c[d] < 0 || c[d] >= L->g.n[d]) {
+            if (!L->g.periodic[d]) return -1;
+            c[d] = (c[d] % L->g.n[d] + L->g.n[d]) % L->g.n[d];
+        }
+    }
+    for (int b = 0; b < L->nbox; ++b) {
+        const int* bx = L->boxes + 6 * b;
+        if (c[0] >= bx[0] && c[0] <= bx[3] && c[1] >= bx[1] && c[1] <= bx[4] && c[2] >= bx[2] && c[2] <= bx[5]) return b + 1;
+    }
+    return 0;
+}
+static inline double wrapped(const orc_abec_level* L, const orc_fab* x, int i, int j, int k, int n)
+{
+    int c[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d) if (L->g.periodic[d]) c[d] = (c[d] % L->g.n[d] + L->g.n[d]) % L->g.n[d];
+    return A4(x, c[0], c[1], c[2], n);
+}
+static void cf_coefs(const orc_abec_level* L, int d, int blen, int maxorder, double c[4], int* NXo)
+{
+    int NX = blen + 1 < maxorder ? blen + 1 : maxorder;
+    double x[4] = {-L->cf_loc[d] / L->g.dx[d], 0.5, 1.5, 2.5};
+    c[0] = c[1] = c[2] = c[3] = 0.0;
+    if (NX >= 2) poly_interp_coeff(-0.5, x, NX, c);
+    *NXo = NX;
+}
+/* value of x in the cell next to cell (i,j,k) of box bx in direction d, side s = -1 / +1, as the box sees it */
+static double box_nbr(const orc_abec_level* L, const orc_fab* x, const int* bx, int i, int j, int k, int n, int d, int s, int* is_cf)
+{
+    int q[3] = {i, j, k};
+    q[d] += s;
+    *is_cf = 0;
+    if (q[d] >= bx[d] && q[d] <= bx[3 + d]) return A4(x, q[0], q[1], q[2], n);          /* inside the box */
+    const int w = box_of(L, q[0], q[1], q[2]);
+    if (w < 0) return A4(x, q[0], q[1], q[2], n);                                        /* physical boundary: stored ghost value */
+    if (w > 0) return wrapped(L, x, q[0], q[1], q[2], n);                                /* another box / periodic image */
+    *is_cf = 1;
+    double c[4]; int NX;
+    cf_coefs(L, d, bx[3 + d] - bx[d] + 1, g_cf_maxorder, c, &NX);
+    const double bv = (g_cf_inhomog && g_cf_bcval) ? A4(g_cf_bcval, q[0], q[1], q[2], n * 3 + d) : 0.0;
+    if (NX < 2) return bv;
+    double v = bv * c[0];
+    for (int m = 1; m < NX; ++m) {
+        int r[3] = {i, j, k};
+        r[d] -= s * (m - 1);
+        v += c[m] * A4(x, r[0], r[1], r[2], n);
+    }
+    return v;
+}
+static void cf_zero_uncovered(const orc_abec_level* L, orc_fab* y)
+{
+    const orc_geom* g = &L->g;
+    for (int n = 0; n < y->nc; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        if (box_of(L, i, j, k) == 0) A4(y, i, j, k, n) = 0.0;
+}
+static void cf_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x)
+{
+    const orc_geom* g = &L->g;
+    const double dh[3] = {L->beta / (g->dx[0] * g->dx[0]), L->beta / (g->dx[1] * g->dx[1]), L->beta / (g->dx[2] * g->dx[2])};
+    cf_zero_uncovered(L, y);
+    for (int b = 0; b < L->nbox; ++b) {
+        const int* bx = L->boxes + 6 * b;
+        for (int n = 0; n < L->ncomp; ++n)
+        for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) {
+            const double xc = A4(x, i, j, k, n);
+            double v = (L->alpha != 0.0 && L->a.p) ? L->alpha * A4(&L->a, i, j, k, 0) * xc : 0.0;
+            for (int d = 0; d < 3; ++d) {
+                int f[3] = {i, j, k}, cf;
+                const double blo = A4(&L->b[d], f[0], f[1], f[2], n);
+                f[d] += 1;
+                const double bhi = A4(&L->b[d], f[0], f[1], f[2], n);
+                const double xm = box_nbr(L, x, bx, i, j, k, n, d, -1, &cf), xp = box_nbr(L, x, bx, i, j, k, n, d, +1, &cf);
+                v -= dh[d] * (bhi * (xp - xc) - blo * (xc - xm));
+            }
+            A4(y, i, j, k, n) = v;
+        }
+    }
+}
+static void cf_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, int redblack, double omega,
+                    const int lobc[3], const int hibc[3], int maxorder)
+{
+    const orc_geom* g = &L->g;
+    const double dh[3] = {L->beta / (g->dx[0] * g->dx[0]), L->beta / (g->dx[1] * g->dx[1]), L->beta / (g->dx[2] * g->dx[2])};
+    for (int b = 0; b < L->nbox; ++b) {
+        const int* bx = L->boxes + 6 * b;
+        /* ghost cells of the box as MLCellLinOp::applyBC leaves them in front of the colour pass: formed from the state BEFORE
+         * the pass (the coarse/fine formula reaches up to three cells into the box, i.e. cells of both colours) */
+        const int gn[3] = {bx[3] - bx[0] + 3, bx[4] - bx[1] + 3, bx[5] - bx[2] + 3};
+        double* gh = (double*)malloc(sizeof(double) * (size_t)gn[0] * gn[1] * gn[2] * L->ncomp);
+        unsigned char* gcf = (unsigned char*)calloc((size_t)gn[0] * gn[1] * gn[2], 1);
+#define GH(i, j, k, n) gh[((size_t)(n) * gn[2] + ((k) - bx[2] + 1)) * gn[1] * gn[0] + (size_t)((j) - bx[1] + 1) * gn[0] + ((i) - bx[0] + 1)]
+#define GCF(i, j, k) gcf[((size_t)((k) - bx[2] + 1) * gn[1] + ((j) - bx[1] + 1)) * gn[0] + ((i) - bx[0] + 1)]
+        for (int n = 0; n < L->ncomp; ++n)
+        for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            int lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+            lo[d] = hi[d] = side == 0 ? bx[d] : bx[3 + d];
+            for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i) {
+                int q[3] = {i, j, k}, cf;
+                q[d] += side == 0 ? -1 : 1;
+                GH(q[0], q[1], q[2], n) = box_nbr(L, phi, bx, i, j, k, n, d, side == 0 ? -1 : 1, &cf);
+                GCF(q[0], q[1], q[2]) = (unsigned char)cf;
+            }
+        }
+        for (int n = 0; n < L->ncomp; ++n)
+        for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) {
+            if ((i + j + k + redblack) % 2 != 0) continue;
+            const int idx[3] = {i, j, k};
+            const double aa = (L->alpha != 0.0 && L->a.p) ? L->alpha * A4(&L->a, i, j, k, 0) : 0.0;
+            double gamma = aa, corr = 0.0, rho = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                int f[3] = {i, j, k}, m[3] = {i, j, k}, p[3] = {i, j, k};
+                const double blo = A4(&L->b[d], f[0], f[1], f[2], n);
+                f[d] += 1;
+                const double bhi = A4(&L->b[d], f[0], f[1], f[2], n);
+                m[d] -= 1; p[d] += 1;
+                const int olo = idx[d] == bx[d], ohi = idx[d] == bx[3 + d];
+                const double xm = olo ? GH(m[0], m[1], m[2], n) : A4(phi, m[0], m[1], m[2], n);
+                const double xp = ohi ? GH(p[0], p[1], p[2], n) : A4(phi, p[0], p[1], p[2], n);
+                const int cfl = olo && GCF(m[0], m[1], m[2]), cfh = ohi && GCF(p[0], p[1], p[2]);
+                /* coefficient of the first interior cell in the ghost formula (mllinop_comp_interp_coef0) */
+                double cl = 0.0, ch = 0.0, c[4]; int NX;
+                if (cfl || cfh) cf_coefs(L, d, bx[3 + d] - bx[d] + 1, maxorder, c, &NX);
+                if (cfl) cl = c[1];
+                else if (!g->periodic[d] && idx[d] == 0) cl = bc_coef0(lobc[BCOFF(L, n) + d], g->n[d], maxorder);
+                if (cfh) ch = c[1];
+                else if (!g->periodic[d] && idx[d] == g->n[d] - 1) ch = bc_coef0(hibc[BCOFF(L, n) + d], g->n[d], maxorder);
+                gamma += dh[d] * (blo + bhi);
+                corr += dh[d] * (blo * cl + bhi * ch);
+                rho += dh[d] * (blo * xm + bhi * xp);
+            }
+            const double res = A4(rhs, i, j, k, n) - (gamma * A4(phi, i, j, k, n) - rho);
+            A4(phi, i, j, k, n) = A4(phi, i, j, k, n) + omega / (gamma - corr) * res;
+        }
+#undef GH
+#undef GCF
+        free(gh); free(gcf);
+    }
+}
+
 void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], const int hibc[3],
                       int maxorder, int inhomog, const orc_fab* bcval)
 {
     const orc_geom* g = &L->g;
+    g_cf_inhomog = inhomog; g_cf_maxorder = maxorder;      /* coarse/fine ghost values are formed on the fly (box_nbr) */
     orc_fill_periodic(phi, g, ORC_CELL);
     for (int d = 0; d < 3; ++d) {
         if (g->periodic[d]) continue;
@@ -129,6 +287,7 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
 void orc_abec_gsrb(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, int redblack, double omega,
                    const int lobc[3], const int hibc[3], int maxorder)
 {
+    if (L->nbox > 0) { cf_gsrb(L, phi, rhs, redblack, omega, lobc, hibc, maxorder); return; }
     const orc_geom* g = &L->g;
     const double dhx = L->beta / (g->dx[0] * g->dx[0]);
     const double dhy = L->beta / (g->dx[1] * g->dx[1]);
@@ -213,6 +372,47 @@ void orc_face_avgdown(orc_fab* crse, const orc_fab* fine, int dir, const int cn[
     }
 }
 
+
+/* InterpBndryData::setBndryValues, max_order 3 (interpbndrydata_{x,y,z}_o3) */
+void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi, orc_fab* bcval)
+{
+    orc_setval(bcval, 0.0);
+    const int r = ratio;
+    for (int b = 0; b < L->nbox; ++b) {
+        const int* bx = L->boxes + 6 * b;
+        for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;       /* tangential directions, ascending */
+            int lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+            lo[d] = hi[d] = side == 0 ? bx[d] - 1 : bx[3 + d] + 1;
+            for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i) {
+                if (box_of(L, i, j, k) != 0) continue;                 /* covered or outside the domain: not a coarse/fine ghost cell */
+                const int q[3] = {i, j, k};
+                int c[3];
+                for (int e = 0; e < 3; ++e) c[e] = q[e] >= 0 ? q[e] / r : -((-q[e] + r - 1) / r);
+                /* not_covered mask of the neighbouring ghost cells (same ghost layer) */
+                int m1m, m1p, m2m, m2p, mmm, mpm, mmp, mpp;
+                { int a[3] = {i, j, k}; a[t1] -= r; m1m = box_of(L, a[0], a[1], a[2]) == 0; a[t1] += 2 * r; m1p = box_of(L, a[0], a[1], a[2]) == 0; }
+                { int a[3] = {i, j, k}; a[t2] -= r; m2m = box_of(L, a[0], a[1], a[2]) == 0; a[t2] += 2 * r; m2p = box_of(L, a[0], a[1], a[2]) == 0; }
+                { int a[3] = {i, j, k}; a[t1] -= r; a[t2] -= r; mmm = box_of(L, a[0], a[1], a[2]) == 0; a[t1] += 2 * r; mpm = box_of(L, a[0], a[1], a[2]) == 0;
+                  a[t2] += 2 * r; mpp = box_of(L, a[0], a[1], a[2]) == 0; a[t1] -= 2 * r; mmp = box_of(L, a[0], a[1], a[2]) == 0; }
+                for (int n = 0; n < L->ncomp; ++n) {
+#define CC(o1, o2) ({ int z[3] = {c[0], c[1], c[2]}; z[t1] += (o1); z[t2] += (o2); A4(cphi, z[0], z[1], z[2], n); })
+                    const int l1 = m1m ? -1 : 0, h1 = m1p ? 1 : 0, l2 = m2m ? -1 : 0, h2 = m2p ? 1 : 0;
+                    const double f1 = (h1 == l1 + 1) ? 1.0 : 0.5, f2 = (h2 == l2 + 1) ? 1.0 : 0.5;
+                    const double d1 = f1 * (CC(h1, 0) - CC(l1, 0));
+                    const double d11 = (h1 == l1 + 2) ? 0.5 * (CC(1, 0) - 2.0 * CC(0, 0) + CC(-1, 0)) : 0.0;
+                    const double d2 = f2 * (CC(0, h2) - CC(0, l2));
+                    const double d22 = (h2 == l2 + 2) ? 0.5 * (CC(0, 1) - 2.0 * CC(0, 0) + CC(0, -1)) : 0.0;
+                    const double d12 = (mmm && mpm && mmp && mpp) ? 0.25 * (CC(1, 1) - CC(-1, 1) + CC(-1, -1) - CC(1, -1)) : 0.0;
+                    const double y1 = -0.5 + (q[t1] - c[t1] * r + 0.5) / r, y2 = -0.5 + (q[t2] - c[t2] * r + 0.5) / r;
+                    A4(bcval, i, j, k, n * 3 + d) = CC(0, 0) + y1 * d1 + (y1 * y1) * d11 + y2 * d2 + (y2 * y2) * d22 + y1 * y2 * d12;
+#undef CC
+                }
+            }
+        }
+    }
+}
+
 /* ---------------------------------------------------------------- multigrid ---- */
 typedef struct mglev {
     orc_abec_level L;
@@ -263,6 +463,7 @@ static void copy_valid(orc_fab* dst, const orc_fab* src, const int n[3], int nc)
 
 static int is_singular(const orc_abec_level* L, const int lobc[3], const int hibc[3])
 {
+    if (L->nbox > 0) return 0;                 /* coarse/fine faces carry Dirichlet data */
     if (L->alpha != 0.0 && L->a.p) return 0;
     for (int d = 0; d < 3; ++d) {
         if (L->g.periodic[d]) continue;
@@ -275,6 +476,7 @@ static int is_singular(const orc_abec_level* L, const int lobc[3], const int hib
 static void smooth(const mglev* m, orc_fab* sol, const orc_fab* rhs, const int lobc[3], const int hibc[3],
                    const orc_mg_opts* o, int skip_fill)
 {
+    g_cf_inhomog = 0; g_cf_maxorder = o->maxorder;          /* corrections: homogeneous coarse/fine data (also when the fill is skipped) */
     for (int rb = 0; rb < 2; ++rb) {
         if (!skip_fill) orc_abec_applybc(&m->L, sol, lobc, hibc, o->maxorder, 0, NULL);
         orc_abec_gsrb(&m->L, sol, rhs, rb, o->omega, lobc, hibc, o->maxorder);
@@ -292,6 +494,7 @@ static void corr_residual(const mglev* m, orc_fab* r, orc_fab* x, const orc_fab*
     for (int c = 0; c < m->L.ncomp; ++c)
     for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
         A4(r, i, j, k, c) = A4(b, i, j, k, c) - A4(r, i, j, k, c);
+    if (m->L.nbox > 0) cf_zero_uncovered(&m->L, r);
 }
 
 /* MLCGSolver::solve_bicgstab */
@@ -408,6 +611,20 @@ static int build_hierarchy(const orc_abec_level* L, mglev* mg, const orc_mg_opts
         if (!ok) break;
         mglev* c = &mg[nlev];
         c->L = mg[nlev - 1].L;
+        if (L->nbox > 0) {
+            /* the level's boxes coarsen with the multigrid; stop when one of them cannot (MLLinOp: box array not coarsenable) */
+            const int* fb = mg[nlev - 1].L.boxes;
+            for (int q = 0; q < L->nbox && ok; ++q)
+                for (int d = 0; d < 3; ++d) {
+                    const int lo = fb[6 * q + d], len = fb[6 * q + 3 + d] - lo + 1;
+                    if (lo % 2 != 0 || len % 2 != 0 || len / 2 < o->min_width) ok = 0;
+                }
+            if (!ok) break;
+            int* cb = (int*)malloc(sizeof(int) * 6 * L->nbox);
+            for (int q = 0; q < L->nbox; ++q)
+                for (int d = 0; d < 3; ++d) { cb[6 * q + d] = fb[6 * q + d] / 2; cb[6 * q + 3 + d] = (fb[6 * q + 3 + d] + 1) / 2 - 1; }
+            c->L.boxes = cb;
+        }
         for (int d = 0; d < 3; ++d) { c->L.g.n[d] = fg->n[d] / 2; c->L.g.dx[d] = fg->dx[d] * 2.0; }
         c->owns_coef = 1;
         if (L->a.p) {
@@ -433,10 +650,19 @@ static void free_hierarchy(mglev* mg, int nlev)
     for (int l = 0; l < nlev; ++l) {
         orc_free(&mg[l].cor); orc_free(&mg[l].res); orc_free(&mg[l].rescor);
         if (mg[l].owns_coef) {
+            if (mg[l].L.nbox > 0) free((void*)mg[l].L.boxes);
             if (mg[l].L.a.p) orc_free(&mg[l].L.a);
             for (int d = 0; d < 3; ++d) orc_free(&mg[l].L.b[d]);
         }
     }
+}
+
+void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                       const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    g_cf_bcval = cf_bcval;
+    orc_abec_solve(L, phi, rhs, lobc, hibc, rtol, atol, o, st);
+    g_cf_bcval = NULL;
 }
 
 void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs_in,
@@ -453,6 +679,7 @@ void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs_in
 
     orc_fab rhs = orc_alloc(n, ORC_CELL, 0, nc);
     copy_valid(&rhs, rhs_in, n, nc);
+    if (L->nbox > 0) cf_zero_uncovered(L, &rhs);
     if (singular) subtract_mean(&rhs, n, nc);
 
     /* inhomogeneous BC data = ghost values of phi on entry (MLMG setLevelBC) */
@@ -465,6 +692,7 @@ void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs_in
     for (int c = 0; c < nc; ++c)
     for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
         A4(res, i, j, k, c) = A4(&rhs, i, j, k, c) - A4(res, i, j, k, c);
+    if (L->nbox > 0) cf_zero_uncovered(L, res);
 
     loc.resnorm0 = norminf_valid(res, n, nc);
     loc.rhsnorm0 = norminf_valid(&rhs, n, nc);
@@ -486,6 +714,7 @@ void orc_abec_solve(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs_in
             for (int c = 0; c < nc; ++c)
             for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
                 A4(res, i, j, k, c) = A4(&rhs, i, j, k, c) - A4(res, i, j, k, c);
+            if (L->nbox > 0) cf_zero_uncovered(L, res);
             loc.resnorm = norminf_valid(res, n, nc);
             loc.iters = iter + 1;
             if (o->verbose) printf("orc MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, loc.resnorm, loc.resnorm / max_norm);

@@ -43,7 +43,8 @@ class CBCRec(C.Structure):
 
 class CAbecLevel(C.Structure):
     _fields_ = [("g", CGeom), ("alpha", C.c_double), ("beta", C.c_double), ("a", CFab), ("b", CFab * 3),
-                ("ncomp", C.c_int), ("tensor", C.c_int), ("bc_percomp", C.c_int)]
+                ("ncomp", C.c_int), ("tensor", C.c_int), ("bc_percomp", C.c_int),
+                ("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)), ("cf_loc", C.c_double * 3)]
 
 
 class CMgStats(C.Structure):
@@ -184,8 +185,16 @@ def fabptrs(fabs):
     return arr
 
 
-def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0, bc_percomp=0):
+def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0, bc_percomp=0, boxes=None, ratio=2):
+    """boxes: [(lo, hi), ...] of an AMR level that does not cover the domain (coarse/fine faces, see orc.h)"""
     L = CAbecLevel()
+    if boxes:
+        flat = [v for lo, hi in boxes for v in (*lo, *hi)]
+        L._boxes_keep = (C.c_int * len(flat))(*flat)
+        L.nbox = len(boxes)
+        L.boxes = C.cast(L._boxes_keep, C.POINTER(C.c_int))
+        for d in range(3):
+            L.cf_loc[d] = 0.5 * ratio * g.dx[d]
     L.g = g
     L.alpha = alpha
     L.beta = beta

@@ -378,3 +378,45 @@ def test_inflow_outflow_channel_conserves_the_inflow_flux(orc):
     # outflow with gravity is refused (hydrostatic outflow pressure not restated)
     p.gravity = -1.0
     assert not L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o))
+
+
+def test_cf_abec_solve_is_second_order_on_a_refined_patch(orc):
+    """orc_cf_interp_bndry + orc_abec_solve_cf: -lap(phi) = f on two refined boxes inside a periodic domain, coarse data = the
+    exact solution at the coarse cell centres.  The multigrid converges in a few cycles and the error drops ~4x per refinement."""
+    L = orc.lib()
+    L.orc_abec_solve_cf.restype = None
+    L.orc_cf_interp_bndry.restype = None
+
+    def exact(nn):
+        x = (np.arange(-1, nn + 1) + 0.5) / nn
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        return np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(2 * np.pi * Z) + 0.3 * np.cos(2 * np.pi * X)
+
+    errs = []
+    for nf in (16, 32):
+        n, nc = (nf,) * 3, (nf // 2,) * 3
+        g = orc.geom(n)
+        q = nf // 4
+        boxes = [((q, q, q), (3 * q - 1, 3 * q - 1, 2 * q - 1)), ((q, q, 2 * q), (3 * q - 1, 3 * q - 1, 3 * q - 1))]
+        b = [orc.Fab(n, orc.face(d), 0, 1, fill=1.0) for d in range(3)]
+        Lv = orc.abec_level(g, b, boxes=boxes)
+        cphi = orc.Fab(nc, orc.CELL, 1, 1)
+        cphi.a[..., 0] = exact(nc[0])
+        x = (np.arange(nf) + 0.5) / nf
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        rhs = orc.Fab(n, orc.CELL, 0, 1)
+        rhs.a[..., 0] = 12 * np.pi ** 2 * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(2 * np.pi * Z) + 0.3 * 4 * np.pi ** 2 * np.cos(2 * np.pi * X)
+        bcv = orc.Fab(n, orc.CELL, 1, 3)
+        L.orc_cf_interp_bndry(C.byref(Lv), 2, cphi.ref(), bcv.ref())
+        phi = orc.Fab(n, orc.CELL, 1, 1)
+        o = orc.mg_opts(maxorder=3)
+        st = orc.CMgStats()
+        P = (C.c_int * 3)(0, 0, 0)
+        L.orc_abec_solve_cf(C.byref(Lv), phi.ref(), rhs.ref(), P, P, bcv.ref(), C.c_double(1e-10), C.c_double(0.0), C.byref(o), C.byref(st))
+        assert st.converged and st.iters <= 12
+        cov = np.zeros(n, bool)
+        for lo, hi in boxes:
+            cov[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] = True
+        errs.append(np.abs(phi.a[1:-1, 1:-1, 1:-1, 0] - exact(nf)[1:-1, 1:-1, 1:-1])[cov].max())
+        assert np.abs(phi.a[1:-1, 1:-1, 1:-1, 0][~cov]).max() == 0.0        # cells outside the level are never touched
+    assert errs[1] < 0.3 * errs[0] and errs[1] < 3e-3, errs

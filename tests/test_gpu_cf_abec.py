@@ -1,0 +1,114 @@
+"""GPU parity: cell-centred multigrid on an AMR level that does not cover the domain (what MacProj::mlmg_mac_solve
+and the Diffusion solves need on refined levels -- MLLinOp::setCoarseFineBC, Source/MacProj.cpp:1166-1170): Dirichlet data from
+the coarse level interpolated along the coarse/fine faces (InterpBndryData, third order), applied half a coarse cell behind the
+face with the level's maxorder, multigrid on the coarsened boxes.  Product (iamrx_abec_solve_cf) against the oracle
+(orc_cf_interp_bndry + orc_abec_solve_cf), and against a manufactured solution."""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def exact(nn, ng=1):
+    x = (np.arange(-ng, nn + ng) + 0.5) / nn
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    return np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(2 * np.pi * Z) + 0.3 * np.cos(2 * np.pi * X) + 0.2 * np.sin(2 * np.pi * (Y + Z))
+
+
+def setup(orc, lib, nf, boxes, variable_b, seed, maxorder):
+    n, nc = (nf,) * 3, (nf // 2,) * 3
+    rng = np.random.default_rng(seed)
+    g_o, g_d = orc.geom(n), lib.Geom.make(n)
+    gc_d = lib.Geom.make(nc)
+    b_o = [orc.Fab(n, orc.face(d), 0, 1, fill=1.0) for d in range(3)]
+    if variable_b:
+        for d in range(3):
+            b_o[d].a[...] = 0.5 + rng.random(b_o[d].a.shape)
+            sl_hi = [slice(None)] * 4; sl_lo = [slice(None)] * 4
+            sl_hi[d] = nf; sl_lo[d] = 0
+            b_o[d].a[tuple(sl_hi)] = b_o[d].a[tuple(sl_lo)]          # periodic duplicate face
+    cphi = orc.Fab(nc, orc.CELL, 1, 1)
+    cphi.a[..., 0] = exact(nc[0])
+    rhs = orc.Fab(n, orc.CELL, 0, 1)
+    rhs.a[..., 0] = rng.standard_normal(n)
+    phi0 = orc.Fab(n, orc.CELL, 1, 1)
+    phi0.a[..., 0] = 0.1 * rng.standard_normal(tuple(v + 2 for v in n))
+    return n, nc, g_o, g_d, gc_d, b_o, cphi, rhs, phi0
+
+
+def solve_both(orc, lib, nf, boxes, variable_b=True, seed=3, maxorder=4, fixed_iters=0, rhs_override=None, rtol=1e-10):
+    L = orc.lib()
+    L.orc_abec_solve_cf.restype = None
+    L.orc_cf_interp_bndry.restype = None
+    n, nc, g_o, g_d, gc_d, b_o, cphi, rhs, phi0 = setup(orc, lib, nf, boxes, variable_b, seed, maxorder)
+    if rhs_override is not None:
+        rhs.a[..., 0] = rhs_override
+        phi0.a[...] = 0.0
+    lay = lib.Layout(boxes)
+    clay = lib.Layout.single(nc)
+    # product
+    b_d = []
+    for d in range(3):
+        m = lib.MultiFab(lay, lib.face(d), 1, 0); m.set_from_global(b_o[d].a, b_o[d].lo); b_d.append(m)
+    phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.set_from_global(phi0.a, phi0.lo)
+    rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs.a, rhs.lo)
+    cphi_d = lib.MultiFab(clay, lib.CELL, 1, 1); cphi_d.set_from_global(cphi.a, cphi.lo)
+    st_d = lib.abec_solve_cf(g_d, 0.0, 1.0, None, b_d, phi_d, rhs_d, cphi_d, gc_d, 2, rtol=rtol, atol=0.0,
+                             opts=lib.mg_opts(maxorder=maxorder, fixed_iters=fixed_iters))
+    # oracle, same multigrid depth
+    Lv = orc.abec_level(g_o, b_o, boxes=boxes)
+    bcv = orc.Fab(n, orc.CELL, 1, 3)
+    L.orc_cf_interp_bndry(C.byref(Lv), 2, cphi.ref(), bcv.ref())
+    phi = phi0.copy()
+    o = orc.mg_opts(maxorder=maxorder, fixed_iters=fixed_iters, max_coarsening_level=st_d.nlevels - 1)
+    st_o = orc.CMgStats()
+    P = (C.c_int * 3)(0, 0, 0)
+    L.orc_abec_solve_cf(C.byref(Lv), phi.ref(), rhs.ref(), P, P, bcv.ref(), C.c_double(rtol), C.c_double(0.0), C.byref(o), C.byref(st_o))
+    got, ref = [], []
+    for li in range(phi_d.nlocal()):
+        a, lo = phi_d.to_numpy(li)
+        blo, bhi, gi = lay.local_box(li)
+        got.append(a[1:-1, 1:-1, 1:-1, 0])
+        ref.append(phi.a[1 + blo[0]:2 + bhi[0], 1 + blo[1]:2 + bhi[1], 1 + blo[2]:2 + bhi[2], 0])
+    return st_d, st_o, got, ref
+
+
+CASES = {
+    "one_box": [((8, 8, 8), (23, 23, 23))],
+    "two_boxes_wrap_z": [((8, 8, 0), (23, 23, 15)), ((8, 8, 16), (23, 23, 31))],      # coarse/fine faces in x and y only
+    "l_shape": [((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 15, 15)), ((0, 16, 0), (15, 31, 15))],
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("maxorder", [2, 4])
+def test_cf_solve_matches_oracle(orc, gpu, case, maxorder):
+    boxes = CASES[case]
+    st_d, st_o, got, ref = solve_both(orc, gpu, 32, boxes, maxorder=maxorder, fixed_iters=3)
+    assert st_d.nlevels >= 3
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+    st_d, st_o, got, ref = solve_both(orc, gpu, 32, boxes, maxorder=maxorder)
+    assert st_d.converged and st_d.iters == st_o.iters, (st_d.iters, st_o.iters)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-8 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+
+
+def test_cf_solve_reproduces_a_smooth_solution(orc, gpu):
+    """-lap(phi) = f on the refined patch with coarse data = the exact solution at the coarse cell centres: second-order accurate"""
+    errs = []
+    for nf in (16, 32):
+        q = nf // 4
+        boxes = [((q, q, q), (3 * q - 1, 3 * q - 1, 2 * q - 1)), ((q, q, 2 * q), (3 * q - 1, 3 * q - 1, 3 * q - 1))]
+        x = (np.arange(nf) + 0.5) / nf
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        f = 12 * np.pi ** 2 * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(2 * np.pi * Z) + 0.3 * 4 * np.pi ** 2 * np.cos(2 * np.pi * X) \
+            + 0.2 * 8 * np.pi ** 2 * np.sin(2 * np.pi * (Y + Z))
+        st_d, st_o, got, ref = solve_both(orc, gpu, nf, boxes, variable_b=False, maxorder=3, rhs_override=f)
+        ex = exact(nf, 0)
+        err = 0.0
+        for g, (lo, hi) in zip(got, boxes):
+            err = max(err, np.abs(g - ex[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]).max())
+        errs.append(err)
+    assert errs[1] < 0.3 * errs[0] and errs[1] < 5e-3, errs
