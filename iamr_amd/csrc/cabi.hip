@@ -323,6 +323,21 @@ int iamrx_mlmg_mac_solve(const iamrx_geom* g, iamrx_mf ux, iamrx_mf uy, iamrx_mf
     IAMRX_CATCH
 }
 
+int iamrx_mlmg_mac_solve_cf(const iamrx_geom* g, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz, iamrx_mf rho, int rho_comp, iamrx_mf S,
+                            iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3], iamrx_mf crse_phi,
+                            const iamrx_geom* cgeom, int ratio, double mac_tol, double mac_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    IAMRX_ASSERT(ratio == 2 && cgeom);
+    MGOpts op = to_opts(o);
+    MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
+    const Geometry cg = to_geom(cgeom);
+    MGStats s = mlmg_mac_solve(to_geom(g), um, rho->mf, rho_comp, S ? &S->mf : nullptr, mac_phi->mf, rhs_scale,
+                               to_bc(lobc, hibc, op.maxorder), mac_tol, mac_abs_tol, op, nullptr, crse_phi ? &crse_phi->mf : nullptr, &cg, ratio);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
 int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz)
 {
     IAMRX_TRY

@@ -10,7 +10,7 @@ namespace iamrx {
 
 MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFab& rho, int rho_comp, const MultiFab* S,
                        MultiFab& mac_phi, double rhs_scale, const DomainBC& bc, double mac_tol, double mac_abs_tol,
-                       const MGOpts& opts, MultiFab* const fluxes[3])
+                       const MGOpts& opts, MultiFab* const fluxes[3], const MultiFab* cphi, const Geometry* cgeom, int ratio)
 {
     LayoutP layout = mac_phi.layout;
     MultiFab bcoef[3];
@@ -26,6 +26,8 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
     CellMG mg(g, layout, 1, bc, opts);
     mg.setScalars(0.0, 1.0);
     mg.setBCoeffs(bcp);
+    // level > 0: Dirichlet data on the coarse/fine faces from the coarse level's MAC phi (MacProj.cpp:1166-1170)
+    if (cgeom) mg.setCoarseFineBC(cphi, *cgeom, ratio);
     mg.prepare();
     MGStats st = mg.solve(mac_phi, rhs, mac_tol, mac_abs_tol);
     // u_mac += (-beta grad phi); optionally hand the fluxes back (MacProj.cpp:1181-1183)

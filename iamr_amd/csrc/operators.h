@@ -11,7 +11,7 @@ namespace iamrx {
 // MacProj::mlmg_mac_solve (Source/MacProj.cpp:1084-1184)
 MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFab& rho, int rho_comp, const MultiFab* S,
                        MultiFab& mac_phi, double rhs_scale, const DomainBC& bc, double mac_tol, double mac_abs_tol,
-                       const MGOpts& opts, MultiFab* const fluxes[3]);
+                       const MGOpts& opts, MultiFab* const fluxes[3], const MultiFab* cphi = nullptr, const Geometry* cgeom = nullptr, int ratio = 2);
 
 // ---- Projection (reference Source/Projection.H:53-134, 244-254) --------------------------------------
 // Projection::doMLMGNodalProjection (Source/Projection.cpp:2385-2567), single level:

@@ -350,6 +350,17 @@ def mlmg_mac_solve(geom, umac, rho, rho_comp, S, mac_phi, rhs_scale, lobc=(0, 0,
     return st
 
 
+def mlmg_mac_solve_cf(geom, umac, rho, rho_comp, S, mac_phi, rhs_scale, crse_phi, cgeom, ratio=2, lobc=(0, 0, 0), hibc=(0, 0, 0),
+                      mac_tol=1e-12, mac_abs_tol=1e-16, opts=None):
+    """MAC solve on an AMR level > 0: coarse/fine Dirichlet data from the coarse level's MAC phi (MacProj.cpp:1166-1170)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts(maxorder=4)
+    check(lib().iamrx_mlmg_mac_solve_cf(C.byref(geom), umac[0].h, umac[1].h, umac[2].h, rho.h, rho_comp, _h(S), mac_phi.h,
+                                        C.c_double(rhs_scale), i3(lobc), i3(hibc), _h(crse_phi), C.byref(cgeom), ratio,
+                                        C.c_double(mac_tol), C.c_double(mac_abs_tol), C.byref(o), C.byref(st)))
+    return st
+
+
 def mac_divergence(geom, div, umac):
     check(lib().iamrx_mac_divergence(C.byref(geom), div.h, umac[0].h, umac[1].h, umac[2].h))
 

@@ -140,6 +140,13 @@ int iamrx_abec_solve(const iamrx_geom* g, double alpha, double beta, iamrx_mf a,
 int iamrx_mlmg_mac_solve(const iamrx_geom* g, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf rho, int rho_comp,
                          iamrx_mf S /* may be NULL */, iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3],
                          double mac_tol, double mac_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* the same on an AMR level > 0: cphi = mac_phi_crse[level-1] (the coarse level's MAC phi on its own layout, geometry cgeom) supplies the
+ * Dirichlet data of the coarse/fine faces (macproj.setCoarseFineBC(cphi, ratio), Source/MacProj.cpp:1166-1170).  rho needs its ghost cells
+ * filled (FillPatch from the coarse level at coarse/fine faces). */
+int iamrx_mlmg_mac_solve_cf(const iamrx_geom* g, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf rho, int rho_comp,
+                            iamrx_mf S /* may be NULL */, iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3],
+                            iamrx_mf crse_phi, const iamrx_geom* cgeom, int ratio, double mac_tol, double mac_abs_tol,
+                            const iamrx_mg_opts* o, iamrx_mg_stats* st);
 /* MacProj::check_div_cond (Source/MacProj.cpp:792-846): div = div(u_mac) */
 int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z);
 

@@ -130,6 +130,13 @@ void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi
 /* orc_abec_solve on a level with coarse/fine faces: cf_bcval from orc_cf_interp_bndry (NULL: homogeneous) */
 void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
                        const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+/* MacProj::mac_project on an AMR level > 0 (Source/MacProj.cpp:225-353 with cphi = mac_phi_crse[level-1], :1166-1170): the level is the
+ * union of nbox boxes (6 ints each) of the fine index space g; cphi = coarse-level MAC phi (cell, 1 ghost, periodic ghosts filled).
+ * umac / rho / S / phi are whole-domain fabs of the fine index space, only the entries of the level are used / changed; rho needs its
+ * ghost cells next to the level filled (FillPatch from the coarse level). */
+void orc_mac_project_cf(const orc_geom* g, orc_fab* umac[3], const orc_fab* rho, const orc_fab* S, orc_fab* phi, double rhs_scale,
+                        const int lobc[3], const int hibc[3], int nbox, const int* boxes, int ratio, const orc_fab* cphi,
+                        double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 void orc_cc_restrict(orc_fab* crse, const orc_fab* fine, const int cn[3]);
 void orc_cc_prolong_add(orc_fab* fine, const orc_fab* crse, const int fn[3]);
 void orc_face_avgdown(orc_fab* crse, const orc_fab* fine, int dir, const int cn[3]);

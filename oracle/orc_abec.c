@@ -790,3 +790,70 @@ void orc_mac_project(const orc_geom* g, orc_fab* umac[3], const orc_fab* rho, co
     }
     orc_free(&rhs);
 }
+
+void orc_mac_project_cf(const orc_geom* g, orc_fab* umac[3], const orc_fab* rho, const orc_fab* S, orc_fab* phi, double rhs_scale,
+                        const int lobc[3], const int hibc[3], int nbox, const int* boxes, int ratio, const orc_fab* cphi,
+                        double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_abec_level L;
+    memset(&L, 0, sizeof(L));
+    L.g = *g; L.alpha = 0.0; L.beta = 1.0; L.ncomp = 1; L.a.p = NULL;
+    L.nbox = nbox; L.boxes = boxes;
+    for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * ratio * g->dx[d];
+    const double scale = 1.0 / rhs_scale;
+    orc_fab rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
+    orc_setval(&rhs, 0.0);
+    for (int d = 0; d < 3; ++d) { L.b[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); orc_setval(&L.b[d], 0.0); }
+    for (int b = 0; b < nbox; ++b) {
+        const int* bx = boxes + 6 * b;
+        for (int d = 0; d < 3; ++d) {
+            int hi[3] = {bx[3], bx[4], bx[5]}; hi[d] += 1;
+            for (int k = bx[2]; k <= hi[2]; ++k) for (int j = bx[1]; j <= hi[1]; ++j) for (int i = bx[0]; i <= hi[0]; ++i) {
+                int m[3] = {i, j, k}; m[d] -= 1;
+                const double rf = 0.5 * (A4(rho, m[0], m[1], m[2], 0) + A4(rho, i, j, k, 0));
+                A4(&L.b[d], i, j, k, 0) = scale / rf;
+            }
+        }
+        for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) {
+            double dv = (A4(umac[0], i + 1, j, k, 0) - A4(umac[0], i, j, k, 0)) / g->dx[0]
+                      + (A4(umac[1], i, j + 1, k, 0) - A4(umac[1], i, j, k, 0)) / g->dx[1]
+                      + (A4(umac[2], i, j, k + 1, 0) - A4(umac[2], i, j, k, 0)) / g->dx[2];
+            A4(&rhs, i, j, k, 0) = (S ? A4(S, i, j, k, 0) : 0.0) - dv;
+        }
+    }
+    orc_fab bcv = orc_alloc(g->n, ORC_CELL, 1, 3);
+    orc_cf_interp_bndry(&L, ratio, cphi, &bcv);
+    orc_abec_solve_cf(&L, phi, &rhs, lobc, hibc, &bcv, rtol, atol, o, st);
+    /* u_mac -= b grad phi on every face of the level, each face once (a face shared by two boxes sees the same two cells) */
+    g_cf_bcval = &bcv; g_cf_inhomog = 1; g_cf_maxorder = o->maxorder;
+    for (int d = 0; d < 3; ++d) {
+        orc_fab done = orc_alloc(g->n, ORC_FACE[d], 0, 1);
+        orc_setval(&done, 0.0);
+        const double fac = L.beta / g->dx[d];
+        for (int b = 0; b < nbox; ++b) {
+            const int* bx = boxes + 6 * b;
+            for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) {
+                const int idx[3] = {i, j, k};
+                for (int side = 0; side < 2; ++side) {
+                    if (side == 1 && idx[d] != bx[3 + d]) continue;            /* the high face of the last cell only */
+                    int f[3] = {i, j, k}, cf;
+                    if (side == 1) f[d] += 1;
+                    if (A4(&done, f[0], f[1], f[2], 0) != 0.0) continue;
+                    const double xn = box_nbr(&L, phi, bx, i, j, k, 0, d, side == 0 ? -1 : 1, &cf);
+                    const double dphi = side == 0 ? A4(phi, i, j, k, 0) - xn : xn - A4(phi, i, j, k, 0);
+                    A4(umac[d], f[0], f[1], f[2], 0) += -fac * A4(&L.b[d], f[0], f[1], f[2], 0) * dphi;
+                    A4(&done, f[0], f[1], f[2], 0) = 1.0;
+                    /* the periodic image of a face on the domain boundary */
+                    if (g->periodic[d] && (f[d] == 0 || f[d] == g->n[d])) {
+                        int f2[3] = {f[0], f[1], f[2]}; f2[d] = f[d] == 0 ? g->n[d] : 0;
+                        if (A4(&done, f2[0], f2[1], f2[2], 0) == 0.0) { A4(umac[d], f2[0], f2[1], f2[2], 0) = A4(umac[d], f[0], f[1], f[2], 0); A4(&done, f2[0], f2[1], f2[2], 0) = 1.0; }
+                    }
+                }
+            }
+        }
+        orc_free(&done);
+    }
+    g_cf_bcval = NULL;
+    orc_free(&bcv); orc_free(&rhs);
+    for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+}

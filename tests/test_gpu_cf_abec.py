@@ -112,3 +112,79 @@ def test_cf_solve_reproduces_a_smooth_solution(orc, gpu):
             err = max(err, np.abs(g - ex[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]).max())
         errs.append(err)
     assert errs[1] < 0.3 * errs[0] and errs[1] < 5e-3, errs
+
+
+@pytest.mark.parametrize("case", ["one_box", "l_shape"])
+def test_mac_projection_on_a_refined_level(orc, gpu, case):
+    """MacProj::mac_project at level 1: coarse MAC solve on the periodic 16^3 level, then the fine solve on the refined boxes with
+    the coarse phi on the coarse/fine faces; variable density.  The projected fine field is discretely divergence free on the
+    patch and equals the oracle's."""
+    lib = gpu
+    L = orc.lib()
+    L.orc_mac_project_cf.restype = None
+    boxes = CASES[case]
+    nf, ncr = 32, 16
+    n, nc = (nf,) * 3, (ncr,) * 3
+    rng = np.random.default_rng(5)
+    g_o, g_d, gc_o, gc_d = orc.geom(n), lib.Geom.make(n), orc.geom(nc), lib.Geom.make(nc)
+    dt = 0.01
+
+    def vel_face(nn, d, seed):
+        t = orc.face(d)
+        ax = [(np.arange(-1, nn + t[e] + 1) + (0.0 if t[e] else 0.5)) / nn for e in range(3)]
+        X, Y, Z = np.meshgrid(*ax, indexing="ij")
+        ph = np.random.default_rng(seed).uniform(0, 2 * np.pi, 3)
+        return np.sin(2 * np.pi * X + ph[0]) * np.cos(2 * np.pi * Y + ph[1]) + 0.5 * np.cos(2 * np.pi * Z + ph[2])
+
+    def rho_cc(nn):
+        x = (np.arange(-1, nn + 1) + 0.5) / nn
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        return 1.0 + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.1 * np.cos(4 * np.pi * Z)
+
+    # ---- coarse level (oracle and product give the same phi to 1e-10; take the oracle's for both fine solves)
+    umc = [orc.Fab(nc, orc.face(d), 1, 1) for d in range(3)]
+    for d in range(3):
+        umc[d].a[..., 0] = vel_face(ncr, d, 10 + d)
+    rhoc = orc.Fab(nc, orc.CELL, 1, 1); rhoc.a[..., 0] = rho_cc(ncr)
+    cphi = orc.Fab(nc, orc.CELL, 1, 1)
+    o4 = orc.mg_opts(maxorder=4)
+    st = orc.CMgStats()
+    P = (C.c_int * 3)(0, 0, 0)
+    L.orc_mac_project(C.byref(gc_o), orc.fabptrs(umc), rhoc.ref(), None, cphi.ref(), C.c_double(2.0 / dt), P, P,
+                      C.c_double(1e-12), C.c_double(1e-16), C.byref(o4), C.byref(st))
+    L.orc_fill_periodic(cphi.ref(), C.byref(gc_o), orc.i3(orc.CELL))
+    # ---- fine level
+    umf = [orc.Fab(n, orc.face(d), 1, 1) for d in range(3)]
+    for d in range(3):
+        umf[d].a[..., 0] = vel_face(nf, d, 10 + d) + 0.05 * vel_face(nf, d, 40 + d)
+    rhof = orc.Fab(n, orc.CELL, 1, 1); rhof.a[..., 0] = rho_cc(nf)
+    lay = lib.Layout(boxes)
+    clay = lib.Layout.single(nc)
+    um_d = []
+    for d in range(3):
+        m = lib.MultiFab(lay, lib.face(d), 1, 1); m.set_from_global(umf[d].a, umf[d].lo); um_d.append(m)
+    rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rhof.a, rhof.lo)
+    phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.setval(0.0)
+    cphi_d = lib.MultiFab(clay, lib.CELL, 1, 1); cphi_d.set_from_global(cphi.a, cphi.lo)
+    st_d = lib.mlmg_mac_solve_cf(g_d, um_d, rho_d, 0, None, phi_d, 2.0 / dt, cphi_d, gc_d, 2, mac_tol=1e-11)
+    assert st_d.converged
+    div = lib.MultiFab(lay, lib.CELL, 1, 0)
+    lib.mac_divergence(g_d, div, um_d)
+    assert div.norm0() <= 1e-8
+    flat = [v for lo, hi in boxes for v in (*lo, *hi)]
+    bx = (C.c_int * len(flat))(*flat)
+    phif = orc.Fab(n, orc.CELL, 1, 1)
+    o = orc.mg_opts(maxorder=4, max_coarsening_level=st_d.nlevels - 1)
+    L.orc_mac_project_cf(C.byref(g_o), orc.fabptrs(umf), rhof.ref(), None, phif.ref(), C.c_double(2.0 / dt), P, P, len(boxes), bx, 2,
+                         cphi.ref(), C.c_double(1e-11), C.c_double(1e-16), C.byref(o), C.byref(st))
+    assert st.iters == st_d.iters
+    for li in range(phi_d.nlocal()):
+        blo, bhi, gi = lay.local_box(li)
+        a, lo = phi_d.to_numpy(li)
+        ref = phif.a[1 + blo[0]:2 + bhi[0], 1 + blo[1]:2 + bhi[1], 1 + blo[2]:2 + bhi[2], 0]
+        assert np.abs(a[1:-1, 1:-1, 1:-1, 0] - ref).max() <= 1e-8 * max(np.abs(ref).max(), 1e-3)
+        for d in range(3):
+            u, ulo = um_d[d].to_numpy(li)
+            hi = [bhi[e] + (1 if e == d else 0) for e in range(3)]
+            uref = umf[d].a[1 + blo[0]:2 + hi[0], 1 + blo[1]:2 + hi[1], 1 + blo[2]:2 + hi[2], 0]
+            assert np.abs(u[1:-1, 1:-1, 1:-1, 0] - uref).max() <= 1e-8, (d, np.abs(u[1:-1, 1:-1, 1:-1, 0] - uref).max())
