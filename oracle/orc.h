@@ -196,6 +196,8 @@ void orc_nodal_solve(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, const 
 void orc_nodal_solve_cov(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, const orc_fab* sig,
                          const int lobc[3], const int hibc[3], const orc_fab* cov /*cell, 0 ghost*/, double rtol, double atol,
                          const orc_mg_opts* o, orc_mg_stats* st);
+void orc_nodal_project_cov(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig, const int lobc[3], const int hibc[3],
+                           const orc_fab* cov, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc_fab* phi /*node, 1 ghost*/,
                        const orc_fab* sig, const int lobc[3], const int hibc[3],
                        double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);

@@ -625,3 +625,22 @@ void orc_nodal_project(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_
     orc_nodal_mknewu(g, vel, phi, sig);
     orc_free(&rhs);
 }
+
+/* Projection::doMLMGNodalProjection on one AMR level > 0 (Source/Projection.cpp:2385-2567 with c_lev > 0, nlevel = 1): the level
+ * covers the cells with cov != 0; the nodes on its boundary inside the domain keep the incoming phi (Dirichlet mask).  rhs = div(vel)
+ * needs vel on the level only (boundary nodes carry no equation); vel -= sig grad phi on the level's cells. */
+void orc_nodal_project_cov(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig, const int lobc[3], const int hibc[3],
+                           const orc_fab* cov, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_fab rhs = orc_alloc(g->n, ORC_NODE, 0, 1);
+    orc_nodal_divu_bc(g, &rhs, vel, lobc, hibc);
+    orc_nodal_solve_cov(g, phi, &rhs, sig, lobc, hibc, cov, rtol, atol, o, st);
+    orc_fab v2 = orc_alloc(g->n, ORC_CELL, 0, 3);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&v2, i, j, k, n) = A4(vel, i, j, k, n);
+    orc_nodal_mknewu(g, &v2, phi, sig);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        if (!cov || A4(cov, i, j, k, 0) != 0.0) A4(vel, i, j, k, n) = A4(&v2, i, j, k, n);
+    orc_free(&v2); orc_free(&rhs);
+}

@@ -113,3 +113,47 @@ def test_level_not_covering_the_domain(orc, gpu, case):
     assert st_d.converged and st_d.iters == st_o.iters, (st_d.iters, st_o.iters)
     for g, r in zip(got, ref):
         assert np.abs(g - r).max() <= 1e-9 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+
+
+@pytest.mark.parametrize("case", ["one_box", "l_shape"])
+def test_nodal_projection_on_a_refined_level(orc, gpu, case):
+    """Projection::doMLMGNodalProjection for one AMR level > 0 (single-level solve, nodes on the coarse/fine boundary Dirichlet):
+    product iamrx_nodal_projection on a layout that does not cover the domain against orc_nodal_project_cov; velocity
+    and iteration count agree (the projection is approximate: D(u - sig G phi) is not zero, so there is no divergence pin)"""
+    from iamr_amd import ns as N
+    lib = gpu
+    L = orc.lib()
+    L.orc_nodal_project_cov.restype = None
+    n, per = (32, 32, 32), (1, 1, 1)
+    P = (PERIODIC,) * 3
+    boxes = [((8, 8, 8), (23, 23, 23))] if case == "one_box" else \
+        [((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 15, 15)), ((0, 16, 0), (15, 31, 15))]
+    g_o, g_d = orc.geom(n, periodic=per), lib.Geom.make(n, periodic=per)
+    rng = np.random.default_rng(21)
+    x = (np.arange(-1, n[0] + 1) + 0.5) / n[0]
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    vel = orc.Fab(n, orc.CELL, 1, 3)
+    vel.a[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.3 * np.cos(2 * np.pi * Z)
+    vel.a[..., 1] = np.cos(2 * np.pi * X) * np.sin(4 * np.pi * Y) + 0.2 * np.sin(2 * np.pi * Z)
+    vel.a[..., 2] = 0.5 * np.sin(2 * np.pi * (X + Z)) * np.cos(2 * np.pi * Y)
+    sig = orc.Fab(n, orc.CELL, 1, 1)
+    sig.a[..., 0] = 1.0 / (1.0 + 0.3 * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y))
+    phi = orc.Fab(n, orc.NODE, 1, 1)            # zero Dirichlet data on the coarse/fine boundary (incremental projection)
+    cov = orc.Fab(n, orc.CELL, 0, 1)
+    for lo, hi in boxes:
+        cov.a[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1, 0] = 1.0
+    lay = lib.Layout(boxes)
+    vel_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel_d.set_from_global(vel.a, vel.lo)
+    sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global(sig.a, sig.lo)
+    phi_d = lib.MultiFab(lay, lib.NODE, 1, 1); phi_d.setval(0.0)
+    st_d = N.nodal_projection(g_d, vel_d, 0, phi_d, sig_d, 0, P, P, 1e-11, 0.0)
+    o = orc.mg_opts(max_coarsening_level=st_d.nlevels - 1)
+    st_o = orc.CMgStats()
+    L.orc_nodal_project_cov(C.byref(g_o), vel.ref(), phi.ref(), sig.ref(), orc.i3(P), orc.i3(P), cov.ref(), C.c_double(1e-11), C.c_double(0.0),
+                            C.byref(o), C.byref(st_o))
+    assert st_d.converged and st_d.iters == st_o.iters
+    for li in range(vel_d.nlocal()):
+        blo, bhi, gi = lay.local_box(li)
+        a, lo = vel_d.to_numpy(li)
+        ref = vel.a[1 + blo[0]:2 + bhi[0], 1 + blo[1]:2 + bhi[1], 1 + blo[2]:2 + bhi[2], :]
+        assert np.abs(a[1:-1, 1:-1, 1:-1, :] - ref).max() <= 1e-9
