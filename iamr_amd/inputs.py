@@ -156,7 +156,8 @@ class Inputs:
         else:
             raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
-                   max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0))
+                   max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
+                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"))
         for k in self.table:
             if k not in self.used:
                 if k.startswith(_IGNORED_PREFIXES):

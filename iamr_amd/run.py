@@ -20,6 +20,23 @@ def build(inp, lib, N, nranks=1):
     return ns, lay, g, pr
 
 
+def write_plot(ns, lay, pr, N, step, root):
+    """NavierStokesBase::writePlotFile role (single level, the five state components): AMReX-format plotfile <root><step:05d>.
+    Single-rank runs only (every box is local)."""
+    from .plotfile import from_level_data
+    S = ns.data(N.NavierStokes.S_NEW)
+    boxes, arrs = [], []
+    for li in range(S.nlocal()):
+        a, lo = S.to_numpy(li)
+        blo, bhi, gi = lay.local_box(li)
+        ng = (a.shape[0] - (bhi[0] - blo[0] + 1)) // 2
+        arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
+        boxes.append((tuple(blo), tuple(bhi)))
+    path = f"{root}{step:05d}"
+    from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step).write(path)
+    return path
+
+
 def main(argv):
     from .inputs import Inputs
     files = [a for a in argv if "=" not in a]
@@ -46,6 +63,9 @@ def main(argv):
     if rank == 0 and inp.ignored:
         print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
     ns.post_init(pr["stop_time"])
+    plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
+    if plot_int > 0 and world == 1:
+        print("PLOTFILE:", write_plot(ns, lay, pr, N, 0, plot_root))
     t0 = time.perf_counter()
     step = 0
     while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or ns.time < pr["stop_time"] - 1e-14):
@@ -55,6 +75,8 @@ def main(argv):
         step += 1
         if rank == 0:
             print(f"STEP = {step} TIME = {ns.time:.12g} DT = {dt:.12g}")
+        if plot_int > 0 and world == 1 and step % plot_int == 0:
+            print("PLOTFILE:", write_plot(ns, lay, pr, N, step, plot_root))
     lib.sync()
     if rank == 0:
         print(f"Run time = {time.perf_counter() - t0:.6f}")

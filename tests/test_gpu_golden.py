@@ -56,3 +56,27 @@ def test_liddrivencavity16_from_inputs_file(gpu):
     assert np.allclose(dts, gold["dts"], rtol=1e-9, atol=0)
     S = ns.data(N.NavierStokes.S_NEW).gather_valid((16, 16, 16))
     assert np.abs(S - gold["S"]).max() <= 1e-8
+
+
+def test_plotfile_of_the_golden_run(gpu, tmp_path):
+    """row f2: the state of the inputs-driven run written as an AMReX plotfile (iamr_amd.plotfile) and read back: the file holds
+    the golden state of the oracle run box by box"""
+    from iamr_amd import ns as N
+    from iamr_amd.inputs import Inputs
+    from iamr_amd.run import build, write_plot
+    from iamr_amd.plotfile import PlotFile
+    lib = gpu
+    gold = np.load(os.path.join(HERE, "golden", "liddrivencavity16_oracle.npz"))
+    inp = Inputs([os.path.join(HERE, "golden", "inputs.3d.lid_driven_cavity16")])
+    ns, lay, g, pr = build(inp, lib, N)
+    ns.post_init(pr["stop_time"])
+    for _ in range(pr["max_step"]):
+        ns.step()
+    path = write_plot(ns, lay, pr, N, pr["max_step"], str(tmp_path / "plt"))
+    assert path.endswith("plt00005")
+    pf = PlotFile.read(path)
+    assert pf.names == ["x_velocity", "y_velocity", "z_velocity", "density", "tracer"] and len(pf.levels) == 1
+    assert pf.levels[0].domain == ((0, 0, 0), (15, 15, 15)) and len(pf.levels[0].boxes) == 8 and abs(pf.time - ns.time) < 1e-15
+    for (lo, hi), a in zip(pf.levels[0].boxes, pf.levels[0].data):
+        ref = gold["S"][lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1, :]
+        assert np.abs(a - ref).max() <= 1e-8
