@@ -161,7 +161,10 @@ def test_rejects_unsupported_physical_bc(gpu):
     g = lib.Geom.make(n, periodic=(1, 1, 0))
     lay = lib.Layout.single(n)
     with pytest.raises(RuntimeError):
-        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2]))
+        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 3], phys_hi=[0, 0, 5]))                   # Symmetry
+    with pytest.raises(RuntimeError):
+        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2], gravity=-1.0))     # outflow + gravity (hydrostatic outflow pressure)
+    N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2]))                       # inflow / outflow are accepted
 
 
 @pytest.mark.parametrize("kw", [
