@@ -338,6 +338,43 @@ int iamrx_mlmg_mac_solve_cf(const iamrx_geom* g, iamrx_mf ux, iamrx_mf uy, iamrx
     IAMRX_CATCH
 }
 
+int iamrx_derive_mag_vort(const iamrx_geom* g, iamrx_mf out, int ocomp, iamrx_mf vel, int vcomp)
+{
+    IAMRX_TRY derive_mag_vort(to_geom(g), out->mf, ocomp, vel->mf, vcomp); IAMRX_CATCH
+}
+
+int iamrx_error_tag(const iamrx_geom* g, iamrx_mf tags, iamrx_mf field, int comp, int mode, double value, int level,
+                    const double* realbox_lo, const double* realbox_hi)
+{
+    IAMRX_TRY error_tag(to_geom(g), tags->mf, field->mf, comp, mode, value, level, realbox_lo, realbox_hi); IAMRX_CATCH
+}
+
+int iamrx_cluster_tags(const iamrx_geom* g, iamrx_mf tags, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
+                       int* boxes, int* nboxes)
+{
+    IAMRX_TRY
+    const Geometry gg = to_geom(g);
+    const MultiFab& T = tags->mf;
+    IAMRX_ASSERT(Context::get().comm->nranks == 1);      // tags of all boxes are gathered on the (single) rank
+    const int n0 = gg.domain.len(0), n1 = gg.domain.len(1), n2 = gg.domain.len(2);
+    std::vector<unsigned char> h((size_t)n0 * n1 * n2, 0);
+    for (int li = 0; li < T.nlocal(); ++li) {
+        const BoxD fb = T.fabbox(li);
+        std::vector<double> buf((size_t)fb.npts() * T.ncomp);
+        T.copy_to_host(li, buf.data());
+        const BoxD vb = T.layout->lbox(li);
+        for (int k = vb.lo[2]; k <= vb.hi[2]; ++k) for (int j = vb.lo[1]; j <= vb.hi[1]; ++j) for (int i = vb.lo[0]; i <= vb.hi[0]; ++i) {
+            const size_t o = ((size_t)(k - fb.lo[2]) * fb.len(1) + (j - fb.lo[1])) * fb.len(0) + (i - fb.lo[0]);
+            if (buf[o] != 0.0) h[((size_t)(k - gg.domain.lo[2]) * n1 + (j - gg.domain.lo[1])) * n0 + (i - gg.domain.lo[0])] = 1;
+        }
+    }
+    std::vector<BoxD> bx = cluster_tags(h.data(), gg.domain, blocking_factor, max_grid_size, grid_eff, n_error_buf);
+    if ((int)bx.size() > *nboxes) throw Error("iamrx_cluster_tags: box capacity too small");
+    *nboxes = (int)bx.size();
+    for (size_t q = 0; q < bx.size(); ++q) for (int d = 0; d < 3; ++d) { boxes[6 * q + d] = bx[q].lo[d]; boxes[6 * q + 3 + d] = bx[q].hi[d]; }
+    IAMRX_CATCH
+}
+
 int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz)
 {
     IAMRX_TRY

@@ -35,6 +35,13 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
 // ---- inter-level data motion (amr.hip) ------------------------------------------------------------------------
 // amrex::MultiFab::ParallelCopy between different layouts of one index space; periodic_geom != nullptr adds the periodic images
 // add = true: dst += src (MultiFab::ParallelAdd); the source regions must then map to disjoint destination cells
+// ---- regrid.hip: error estimation + grid generation
+void derive_mag_vort(const Geometry& g, MultiFab& out, int ocomp, const MultiFab& vel, int vcomp);
+void error_tag(const Geometry& g, MultiFab& tags, const MultiFab& field, int comp, int mode, double value, int level,
+               const double* rb_lo, const double* rb_hi);
+std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
+                               int n_error_buf);
+
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add = false);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
 void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, int ratio);

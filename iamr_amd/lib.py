@@ -361,6 +361,30 @@ def mlmg_mac_solve_cf(geom, umac, rho, rho_comp, S, mac_phi, rhs_scale, crse_phi
     return st
 
 
+def derive_mag_vort(geom, out, vel, ocomp=0, vcomp=0):
+    """|curl u| (dermgvort, NS_derive.cpp:86-264); vel with 1 filled ghost cell"""
+    check(lib().iamrx_derive_mag_vort(C.byref(geom), _h(out), ocomp, _h(vel), vcomp))
+
+
+TAG_GREATER, TAG_LESS, TAG_VORT, TAG_GRAD = 0, 1, 2, 3
+
+
+def error_tag(geom, tags, field, mode, value, comp=0, level=0, realbox=None):
+    """one amr.refinement_indicators entry (NS_error.cpp:10-145); tagged cells of `tags` are set to 1"""
+    lo = hi = None
+    if realbox is not None:
+        lo = (C.c_double * 3)(*realbox[0]); hi = (C.c_double * 3)(*realbox[1])
+    check(lib().iamrx_error_tag(C.byref(geom), _h(tags), _h(field), comp, mode, C.c_double(value), level, lo, hi))
+
+
+def cluster_tags(geom, tags, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1, capacity=4096):
+    """Berger-Rigoutsos grid generation from the tags of a level -> [(lo, hi), ...] in the index space of the tags"""
+    buf = (C.c_int * (6 * capacity))()
+    nb = C.c_int(capacity)
+    check(lib().iamrx_cluster_tags(C.byref(geom), _h(tags), blocking_factor, max_grid_size, C.c_double(grid_eff), n_error_buf, buf, C.byref(nb)))
+    return [(tuple(buf[6 * q:6 * q + 3]), tuple(buf[6 * q + 3:6 * q + 6])) for q in range(nb.value)]
+
+
 def mac_divergence(geom, div, umac):
     check(lib().iamrx_mac_divergence(C.byref(geom), div.h, umac[0].h, umac[1].h, umac[2].h))
 

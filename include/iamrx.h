@@ -247,6 +247,20 @@ int iamrx_fillpatch_two_levels(iamrx_mf dst, int dcomp, double time, iamrx_mf fi
                                iamrx_mf crse_old, iamrx_mf crse_new, double t_crse_old, double t_crse_new, int scomp, int ncomp,
                                const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio, const int* bcrec, const double* extdir_lo, const double* extdir_hi);
 
+/* ---- error estimation and grid generation ---------------------------------------------- */
+/* "mag_vort" derived quantity (dermgvort, Source/NS_derive.cpp:86-264, non-EB): out(ocomp) = |curl u|, vel needs 1 filled ghost cell */
+int iamrx_derive_mag_vort(const iamrx_geom* g, iamrx_mf out, int ocomp, iamrx_mf vel, int vcomp);
+/* one amr.refinement_indicators entry (NavierStokes::error_setup / errorEst, Source/NS_error.cpp:10-145; AMRErrorTag):
+ * mode 0 value_greater, 1 value_less, 2 vorticity_greater (value x 2^level), 3 adjacent_difference_greater (field with 1 ghost cell);
+ * realbox_lo/hi: in_box_lo / in_box_hi or NULL.  tags: cell-centred, 1 comp; tagged cells are set to 1 */
+int iamrx_error_tag(const iamrx_geom* g, iamrx_mf tags, iamrx_mf field, int comp, int mode, double value, int level,
+                    const double* realbox_lo, const double* realbox_hi);
+/* grid generation from the tags of a level (AmrMesh::MakeNewGrids role: buffer by n_error_buf, Berger-Rigoutsos clustering on the
+ * blocking-factor lattice until grid_eff is met, chop to max_grid_size).  Boxes are returned in the index space of the tags
+ * (6 ints each: lo, hi); *nboxes in: capacity of boxes, out: number of boxes (error if the capacity is too small). */
+int iamrx_cluster_tags(const iamrx_geom* g, iamrx_mf tags, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
+                       int* boxes, int* nboxes);
+
 /* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */
 typedef struct iamrx_ns_params {
     double cfl, visc_coef, be_cn_theta, gravity;

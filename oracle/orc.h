@@ -72,6 +72,11 @@ void orc_create_umac_grown(orc_fab* uf[3], const int vlo[3], const int vhi[3], c
 void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
                         const double* extdir_lo /*[nc][3]*/, const double* extdir_hi);
 
+/* ---- error estimation (orc_regrid.c) ------------------------------------------------ */
+void orc_mag_vort(const orc_geom* g, orc_fab* out, const orc_fab* vel /*3 comps, 1 ghost filled*/);
+void orc_error_tag(const orc_geom* g, orc_fab* tags, const orc_fab* f, int comp, int mode, double value, int level,
+                   const double* rb_lo, const double* rb_hi);
+
 /* ---- cell-centred ABec operator + multigrid (orc_abec.c) ------------------------ */
 typedef struct orc_abec_level {
     orc_geom g;
