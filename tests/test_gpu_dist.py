@@ -16,6 +16,10 @@ NSTEPS = 2
 
 def run(rank, world, port, out_dir, agg, case="tg"):
     sys.path.insert(0, ROOT)
+    global N, BOXES
+    if case == "stack4":     # the weak-scaling layout of bench.py: one box per rank, stacked in z
+        N = (16, 16, 64)
+        BOXES = [((0, 0, 16 * r), (15, 15, 16 * r + 15)) for r in range(4)]
     if agg is not None:
         os.environ["IAMRX_MG_AGGLOMERATE_CELLS"] = agg
     from iamr_amd import lib
@@ -30,9 +34,13 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         comm.init_gloo_callback(dist)
         import bench
         bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
-    owners = [0, 1] if world > 1 else [0, 0]
+    owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)
     lay = lib.Layout(BOXES, owners)
-    if case == "tg":
+    if case == "stack4":
+        g = lib.Geom.make(N, prob_hi=(1.0, 1.0, 4.0))
+        ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    elif case == "tg":
         g = lib.Geom.make(N)
         ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
         ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
@@ -89,3 +97,20 @@ def test_two_ranks_lid_driven_cavity(tmp_path):
         assert np.array_equal(z["iters"], ref["iters"])
         key = f"box{r}"
         assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+def test_four_ranks_stacked_boxes_like_the_bench(tmp_path):
+    """bench.py's weak-scaling layout (one box per rank stacked in z, domain 16 x 16 x 64) on 4 ranks sharing the GPU, with the
+    default agglomeration threshold and with a threshold that keeps the first coarse level distributed: same result as one rank"""
+    import torch.multiprocessing as mp
+    port = 33600 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "stack4"), nprocs=1, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    for agg in (None, "1024"):
+        mp.spawn(run, args=(4, port + 7, str(tmp_path), agg, "stack4"), nprocs=4, join=True)
+        for r in range(4):
+            z = np.load(os.path.join(str(tmp_path), f"w4_r{r}.npz"))
+            assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+            assert np.array_equal(z["iters"], ref["iters"])
+            key = f"box{r}"
+            assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
