@@ -792,13 +792,13 @@ static bool use_dir_fused()
     return v != 0;
 }
 
-template <bool PRED, int D, int DTX>
+template <bool PRED, int D, int DTX, int DTY>
 static void launch_dir_t(const Layout& l, const MultiFab& q, int ncomp, const MultiFab* force, const MultiFab* divu,
                        MultiFab* const mac[3], const MultiFab e0[3], const MultiFab sl[3], MultiFab& out, const GodParams* dP)
 {
     constexpr int TA = D == 0 ? 1 : 0;
     constexpr int TB = D == 2 ? 1 : 2;
-    constexpr int TX = DTX, TY = 8;
+    constexpr int TX = DTX, TY = DTY;
     constexpr int NT = (2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX * TY + 63) / 64) * 64;
     int nf[3];
     for (int e = 0; e < 3; ++e) nf[e] = l.max_len[e] + (e == D ? 1 : 0);
@@ -820,8 +820,11 @@ static void launch_dir(const Layout& l, const MultiFab& q, int ncomp, const Mult
 {
     // 16 x 8 tiles (8 wavefronts, 2 workgroups per CU) measured 6% faster than 32 x 8 (14 wavefronts, 1 per CU) at 256^3
     static const int tx = [] { const char* e = getenv("IAMRX_GODUNOV_DIR_TX"); return e ? atoi(e) : 16; }();
-    if (tx == 16) launch_dir_t<PRED, D, 16>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
-    else launch_dir_t<PRED, D, 32>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
+    static const int ty = [] { const char* e = getenv("IAMRX_GODUNOV_DIR_TY"); return e ? atoi(e) : 8; }();
+    if (tx == 16 && ty == 4) launch_dir_t<PRED, D, 16, 4>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
+    else if (tx == 32 && ty == 4) launch_dir_t<PRED, D, 32, 4>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
+    else if (tx == 16) launch_dir_t<PRED, D, 16, 8>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
+    else launch_dir_t<PRED, D, 32, 8>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
 }
 
 template <bool PRED, int D>
