@@ -8,6 +8,8 @@
 // wavefront segments, each workgroup marches TZ planes so the k-1/k/k+1 planes are re-used from L1/L2.
 #include "kernels.h"
 #include "launch.h"
+#include <map>
+#include <array>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -413,17 +415,19 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
 // ---------------------------------------------------------------------------- domain BC ghost fill
 struct BndryDesc { int fab; BoxD region; int dir, side; };
 
+struct BcParams { int bct[6]; double c[6][5]; };   // per face (2*d + side): LinOpBC type; Dirichlet weights c[0..3] and NX
+
 __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ descs, const FabD* __restrict__ phit,
-                                                 const FabD* __restrict__ bcvt, int ncomp, int comp0,
-                                                 const int* __restrict__ bctype, const double* __restrict__ coefs, int inhomog)
+                                                 const FabD* __restrict__ bcvt, int ncomp, int comp0, BcParams P, int inhomog)
 {
     const BndryDesc bd = descs[blockIdx.y];
     const FabD phi = phit[bd.fab];
     const int nx = bd.region.len(0), ny = bd.region.len(1);
     const long npts = bd.region.npts();
     const int d = bd.dir, s = 1 - 2 * bd.side;
-    const int bct = bctype[2 * d + bd.side];
-    const double* c = coefs + 5 * (2 * d + bd.side);   // c[0..3] weights, c[4] = NX
+    const int bct = P.bct[2 * d + bd.side];
+    if (bct != lo_neumann && bct != lo_dirichlet) return;
+    const double* c = P.c[2 * d + bd.side];   // c[0..3] weights, c[4] = NX
     const int NX = (int)c[4];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
         int idx[3];
@@ -449,6 +453,17 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
     }
 }
 
+// The ghost slabs of the box faces on the non-periodic domain boundary depend on the layout and the domain only: built and
+// uploaded once per (layout, domain) and kept (a level's multigrid calls this for every colour pass of every smooth).
+namespace {
+struct BcDescCache { BndryDesc* d = nullptr; int n = 0; long maxpts = 0; };
+std::map<std::array<long, 8>, BcDescCache>& bc_desc_cache()
+{
+    static std::map<std::array<long, 8>, BcDescCache> m;
+    return m;
+}
+}  // namespace
+
 void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0, int ncomp)
 {
     if (ncomp < 0) ncomp = phi.ncomp - comp0;
@@ -456,49 +471,47 @@ void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, 
     for (int d = 0; d < 3; ++d) if (!g.periodic[d]) any = true;
     if (!any || phi.nlocal() == 0) return;
     auto& ctx = Context::get();
-    std::vector<BndryDesc> descs;
-    long maxpts = 0;
-    for (int li = 0; li < phi.nlocal(); ++li) {
-        const BoxD vb = phi.layout->lbox(li);
-        for (int d = 0; d < 3; ++d) {
-            if (g.periodic[d]) continue;
-            for (int side = 0; side < 2; ++side) {
-                const int bt = side == 0 ? bc.lo[d] : bc.hi[d];
-                if (bt != lo_neumann && bt != lo_dirichlet) continue;
-                if (side == 0 && vb.lo[d] != g.domain.lo[d]) continue;
-                if (side == 1 && vb.hi[d] != g.domain.hi[d]) continue;
-                BndryDesc bd; bd.fab = li; bd.dir = d; bd.side = side; bd.region = vb;
-                bd.region.lo[d] = bd.region.hi[d] = side == 0 ? vb.lo[d] - 1 : vb.hi[d] + 1;
-                descs.push_back(bd);
-                maxpts = std::max(maxpts, bd.region.npts());
+    const std::array<long, 8> key = {(long)phi.layout->id, g.domain.lo[0], g.domain.lo[1], g.domain.lo[2], g.domain.hi[0], g.domain.hi[1], g.domain.hi[2],
+                                     (long)(g.periodic[0] | (g.periodic[1] << 1) | (g.periodic[2] << 2))};
+    auto& cache = bc_desc_cache();
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<BndryDesc> descs;
+        BcDescCache e;
+        for (int li = 0; li < phi.nlocal(); ++li) {
+            const BoxD vb = phi.layout->lbox(li);
+            for (int d = 0; d < 3; ++d) {
+                if (g.periodic[d]) continue;
+                for (int side = 0; side < 2; ++side) {
+                    if (side == 0 && vb.lo[d] != g.domain.lo[d]) continue;
+                    if (side == 1 && vb.hi[d] != g.domain.hi[d]) continue;
+                    BndryDesc bd; bd.fab = li; bd.dir = d; bd.side = side; bd.region = vb;
+                    bd.region.lo[d] = bd.region.hi[d] = side == 0 ? vb.lo[d] - 1 : vb.hi[d] + 1;
+                    descs.push_back(bd);
+                    e.maxpts = std::max(e.maxpts, bd.region.npts());
+                }
             }
         }
+        e.n = (int)descs.size();
+        if (e.n > 0) {
+            IAMRX_HIP_CHECK(hipMalloc(&e.d, descs.size() * sizeof(BndryDesc)));
+            IAMRX_HIP_CHECK(hipMemcpy(e.d, descs.data(), descs.size() * sizeof(BndryDesc), hipMemcpyHostToDevice));
+        }
+        it = cache.emplace(key, e).first;
     }
-    if (descs.empty()) return;
-    // small parameter block: bc types (6 ints) and extrapolation weights (6 x 5 doubles)
-    int h_bct[6]; double h_c[30];
+    const BcDescCache& e = it->second;
+    if (e.n == 0) return;
+    BcParams P;
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
-        h_bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
+        P.bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
         double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX);
-        for (int q = 0; q < 4; ++q) h_c[5 * (2 * d + side) + q] = c[q];
-        h_c[5 * (2 * d + side) + 4] = NX;
+        for (int q = 0; q < 4; ++q) P.c[2 * d + side][q] = c[q];
+        P.c[2 * d + side][4] = NX;
     }
-    const size_t bytes = descs.size() * sizeof(BndryDesc) + sizeof(h_bct) + sizeof(h_c) + 64;
-    char* dbuf = (char*)ctx.alloc(bytes);
-    std::vector<char> hbuf(bytes);
-    size_t o1 = (descs.size() * sizeof(BndryDesc) + 15) & ~size_t(15), o2 = o1 + 32;
-    memcpy(hbuf.data(), descs.data(), descs.size() * sizeof(BndryDesc));
-    memcpy(hbuf.data() + o1, h_bct, sizeof(h_bct));
-    memcpy(hbuf.data() + o2, h_c, sizeof(h_c));
-    IAMRX_HIP_CHECK(hipMemcpyAsync(dbuf, hbuf.data(), bytes, hipMemcpyHostToDevice, ctx.stream));
-    long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_abec_bc, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream,
-                       (const BndryDesc*)dbuf, phi.d_tab, bcval ? bcval->d_tab : nullptr, ncomp, comp0,
-                       (const int*)(dbuf + o1), (const double*)(dbuf + o2), inhomog ? 1 : 0);
-    ctx.sync();          // hbuf is pageable host memory: keep it alive until the copy has completed
-    ctx.free(dbuf);
+    long nb = (e.maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_abec_bc, dim3((unsigned)nb, (unsigned)e.n), dim3(256), 0, ctx.stream,
+                       (const BndryDesc*)e.d, phi.d_tab, bcval ? bcval->d_tab : nullptr, ncomp, comp0, P, inhomog ? 1 : 0);
 }
-
 
 // ---------------------------------------------------------------------------- coarse/fine faces
 CfTab cf_make_tab(const double loc[3], const double dx[3], int maxorder)
