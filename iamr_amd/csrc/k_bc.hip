@@ -80,19 +80,22 @@ void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const
     auto& ctx = Context::get();
     for (int d = 0; d < 3; ++d) {
         if (g.periodic[d]) continue;
-        std::vector<PhysBcDesc> descs;
-        long maxpts = 0;
-        for (int li = 0; li < mf.nlocal(); ++li) {
-            const BoxD fb = mf.fabbox(li);
-            for (int side = 0; side < 2; ++side) {
-                BoxD r = fb;
-                if (side == 0) { if (fb.lo[d] >= g.domain.lo[d]) continue; r.hi[d] = g.domain.lo[d] - 1; }
-                else { if (fb.hi[d] <= g.domain.hi[d]) continue; r.lo[d] = g.domain.hi[d] + 1; }
-                descs.push_back({li, r, side});
-                maxpts = std::max(maxpts, r.npts());
-            }
-        }
-        if (descs.empty()) continue;
+        static std::map<std::array<long, 10>, std::tuple<PhysBcDesc*, int, long>> cache;
+        int nd; long maxpts;
+        const PhysBcDesc* dd = cached_descs(cache, {(long)mf.layout->id, mf.ngrow, d, g.domain.lo[d], g.domain.hi[d], 0, 0, 0, 0, 0},
+            [&](std::vector<PhysBcDesc>& descs, long& mp) {
+                for (int li = 0; li < mf.nlocal(); ++li) {
+                    const BoxD fb = mf.fabbox(li);
+                    for (int side = 0; side < 2; ++side) {
+                        BoxD r = fb;
+                        if (side == 0) { if (fb.lo[d] >= g.domain.lo[d]) continue; r.hi[d] = g.domain.lo[d] - 1; }
+                        else { if (fb.hi[d] <= g.domain.hi[d]) continue; r.lo[d] = g.domain.hi[d] + 1; }
+                        descs.push_back({li, r, side});
+                        mp = std::max(mp, r.npts());
+                    }
+                }
+            }, nd, maxpts);
+        if (nd == 0) continue;
         PhysBcParams P;
         P.dir = d; P.dlo = g.domain.lo[d]; P.dhi = g.domain.hi[d]; P.ncomp = ncomp; P.scomp = scomp;
         for (int n = 0; n < 8; ++n) {
@@ -100,20 +103,21 @@ void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const
             P.edlo[n] = (n < ncomp && extdir_lo) ? extdir_lo[n * 3 + d] : 0.0;
             P.edhi[n] = (n < ncomp && extdir_hi) ? extdir_hi[n * 3 + d] : 0.0;
         }
-        PhysBcDesc* dd = (PhysBcDesc*)ctx.alloc(descs.size() * sizeof(PhysBcDesc));
-        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(PhysBcDesc));
         long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(k_physbc, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, mf.d_tab, P);
-        ctx.free(dd);    // stream-ordered reuse
+        hipLaunchKernelGGL(k_physbc, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, ctx.stream, dd, mf.d_tab, P);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Nodal data at Neumann walls: even reflection of the ghost nodes about the wall node, x(w - m) = x(w + m)
 // (mlndlap_applybc).  Directions one after the other over the full grown extent of the others.
-struct ReflDesc { int fab; BoxD region; int wall; };
+struct ReflDesc { int fab; BoxD region; };
+struct ReflWalls { int lo[3], hi[3]; int has_lo[3], has_hi[3]; };   // wall node index per direction and side (has_*: Neumann wall there)
 
-__global__ void __launch_bounds__(256) k_nodal_reflect(const ReflDesc* __restrict__ descs, const FabD* __restrict__ tab, int dir, int ncomp)
+// One launch for all directions: a ghost node outside one or more walls takes the value of the node obtained by reflecting
+// EVERY out-of-wall coordinate (the same result as reflecting direction by direction over the full extent of the others, since a
+// reflected coordinate always lands inside the walls).  Slabs of different directions overlap along edges: they write the same value.
+__global__ void __launch_bounds__(256) k_nodal_reflect(const ReflDesc* __restrict__ descs, const FabD* __restrict__ tab, ReflWalls W, int ncomp)
 {
     const ReflDesc bd = descs[blockIdx.y];
     const FabD a = tab[bd.fab];
@@ -126,7 +130,10 @@ __global__ void __launch_bounds__(256) k_nodal_reflect(const ReflDesc* __restric
         idx[1] = bd.region.lo[1] + (int)(r % ny);
         idx[2] = bd.region.lo[2] + (int)(r / ny);
         int s[3] = {idx[0], idx[1], idx[2]};
-        s[dir] = 2 * bd.wall - idx[dir];
+        for (int d = 0; d < 3; ++d) {
+            if (W.has_lo[d] && idx[d] < W.lo[d]) s[d] = 2 * W.lo[d] - idx[d];
+            else if (W.has_hi[d] && idx[d] > W.hi[d]) s[d] = 2 * W.hi[d] - idx[d];
+        }
         for (int n = 0; n < ncomp; ++n) a(idx[0], idx[1], idx[2], n) = a(s[0], s[1], s[2], n);
     }
 }
@@ -135,23 +142,31 @@ void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc)
 {
     if (mf.nlocal() == 0 || mf.ngrow == 0) return;
     auto& ctx = Context::get();
+    ReflWalls W;
+    long code = 0;
     for (int d = 0; d < 3; ++d) {
-        if (g.periodic[d]) continue;
-        std::vector<ReflDesc> descs;
-        long maxpts = 0;
-        for (int li = 0; li < mf.nlocal(); ++li) {
-            const BoxD fb = mf.fabbox(li);
-            const int wlo = g.domain.lo[d], whi = g.domain.hi[d] + 1;      // wall node indices
-            if (bc.lo[d] == lo_neumann && fb.lo[d] < wlo) { BoxD r = fb; r.hi[d] = wlo - 1; descs.push_back({li, r, wlo}); maxpts = std::max(maxpts, r.npts()); }
-            if (bc.hi[d] == lo_neumann && fb.hi[d] > whi) { BoxD r = fb; r.lo[d] = whi + 1; descs.push_back({li, r, whi}); maxpts = std::max(maxpts, r.npts()); }
-        }
-        if (descs.empty()) continue;
-        ReflDesc* dd = (ReflDesc*)ctx.alloc(descs.size() * sizeof(ReflDesc));
-        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(ReflDesc));
-        long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(k_nodal_reflect, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, mf.d_tab, d, mf.ncomp);
-        ctx.free(dd);
+        W.lo[d] = g.domain.lo[d]; W.hi[d] = g.domain.hi[d] + 1;      // wall node indices
+        W.has_lo[d] = (!g.periodic[d] && bc.lo[d] == lo_neumann) ? 1 : 0;
+        W.has_hi[d] = (!g.periodic[d] && bc.hi[d] == lo_neumann) ? 1 : 0;
+        code = code * 4 + W.has_lo[d] * 2 + W.has_hi[d];
     }
+    if (code == 0) return;
+    static std::map<std::array<long, 10>, std::tuple<ReflDesc*, int, long>> cache;
+    int nd; long maxpts;
+    const ReflDesc* dd = cached_descs(cache, {(long)mf.layout->id, mf.ngrow, code, g.domain.lo[0], g.domain.lo[1], g.domain.lo[2], g.domain.hi[0],
+                                              g.domain.hi[1], g.domain.hi[2], mf.type.t[0] + 2 * mf.type.t[1] + 4 * mf.type.t[2]},
+        [&](std::vector<ReflDesc>& descs, long& mp) {
+            for (int li = 0; li < mf.nlocal(); ++li) {
+                const BoxD fb = mf.fabbox(li);
+                for (int d = 0; d < 3; ++d) {
+                    if (W.has_lo[d] && fb.lo[d] < W.lo[d]) { BoxD r = fb; r.hi[d] = W.lo[d] - 1; descs.push_back({li, r}); mp = std::max(mp, r.npts()); }
+                    if (W.has_hi[d] && fb.hi[d] > W.hi[d]) { BoxD r = fb; r.lo[d] = W.hi[d] + 1; descs.push_back({li, r}); mp = std::max(mp, r.npts()); }
+                }
+            }
+        }, nd, maxpts);
+    if (nd == 0) return;
+    long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_nodal_reflect, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, ctx.stream, dd, mf.d_tab, W, mf.ncomp);
 }
 
 // cell-centred mirror across every non-periodic wall (mlndlap_fillbc_cc for sigma): reflect_even on all faces

@@ -176,8 +176,11 @@ void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, b
     P.inhomog = inhomog ? 1 : 0;
     P.ncomp = ncomp; P.comp0 = comp0;
     for (int nout = 2; nout <= 3; ++nout) {
-        std::vector<EdgeDesc> descs;
-        long maxpts = 0;
+        static std::map<std::array<long, 10>, std::tuple<EdgeDesc*, int, long>> cache;
+        int nd; long maxpts;
+        const EdgeDesc* dd = cached_descs(cache, {(long)phi.layout->id, nout, g.domain.lo[0], g.domain.lo[1], g.domain.lo[2], g.domain.hi[0],
+                                                  g.domain.hi[1], g.domain.hi[2], g.periodic[0] + 2 * g.periodic[1] + 4 * g.periodic[2], 0},
+            [&](std::vector<EdgeDesc>& descs, long& mp) {
         for (int li = 0; li < phi.nlocal(); ++li) {
             const BoxD vb = phi.layout->lbox(li);
             for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
@@ -196,16 +199,14 @@ void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, b
                 }
                 if (next == 0) continue;
                 descs.push_back(e);
-                maxpts = std::max(maxpts, e.region.npts());
+                mp = std::max(mp, e.region.npts());
             }
         }
-        if (descs.empty()) continue;
-        EdgeDesc* dd = (EdgeDesc*)ctx.alloc(descs.size() * sizeof(EdgeDesc));
-        ctx.upload_async(dd, descs.data(), descs.size() * sizeof(EdgeDesc));
+            }, nd, maxpts);
+        if (nd == 0) continue;
         long nb = (maxpts + 255) / 256; if (nb > 16) nb = 16; if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(k_tensor_edges, dim3((unsigned)nb, (unsigned)descs.size()), dim3(256), 0, ctx.stream, dd, phi.d_tab,
+        hipLaunchKernelGGL(k_tensor_edges, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, ctx.stream, dd, phi.d_tab,
                            bcval ? bcval->d_tab : nullptr, P);
-        ctx.free(dd);
     }
 }
 

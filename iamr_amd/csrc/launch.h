@@ -7,6 +7,10 @@
 #pragma once
 #include "core.h"
 #include "mf.h"
+#include <map>
+#include <array>
+#include <tuple>
+#include <vector>
 
 namespace iamrx {
 
@@ -48,6 +52,30 @@ inline Tiling level_tiling(const Layout& l, const IndexType& type, int ng, int t
     int ml[3];
     for (int d = 0; d < 3; ++d) ml[d] = l.max_len[d] + type.t[d] + 2 * ng;
     return make_tiling(ml, l.nlocal(), tz);
+}
+
+// Boundary-region descriptor lists (which ghost slabs of which box lie outside the domain / on a wall) depend only on the layout, the
+// ghost width and the domain: built on the host and uploaded ONCE per key, then reused by every later call (a multigrid level calls
+// its BC fills for every colour pass).  The device copies live for the life of the process (a few KB per layout).
+template <class D, class F>
+inline const D* cached_descs(std::map<std::array<long, 10>, std::tuple<D*, int, long>>& cache, const std::array<long, 10>& key, F build,
+                             int& n, long& maxpts)
+{
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<D> v;
+        long mp = 0;
+        build(v, mp);
+        D* d = nullptr;
+        if (!v.empty()) {
+            IAMRX_HIP_CHECK(hipMalloc(&d, v.size() * sizeof(D)));
+            IAMRX_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(D), hipMemcpyHostToDevice));
+        }
+        it = cache.emplace(key, std::make_tuple(d, (int)v.size(), mp)).first;
+    }
+    n = std::get<1>(it->second);
+    maxpts = std::get<2>(it->second);
+    return std::get<0>(it->second);
 }
 
 #ifdef __HIPCC__
