@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256, help="cells per direction of the per-GPU box")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("IAMRX_BENCH_N", "256")), help="cells per direction of the per-GPU box")
     ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=64)
@@ -174,13 +174,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    if world > 1:
+    # IAMRX_BENCH_TRANSPORT=gloo: all ranks share GPU 0 and talk through the host-staged gloo transport -- lets the N > 1 code path
+    # of this script run on a 1-GPU box (tests/test_gpu_dist.py); the numbers of such a run mean nothing
+    shared_gpu = world > 1 and os.environ.get("IAMRX_BENCH_TRANSPORT") == "gloo"
+    tdev = "cpu" if shared_gpu else "cuda"
+    if shared_gpu:
+        local_rank = 0
+        dist.init_process_group("gloo")
+    elif world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from iamr_amd import lib
     from iamr_amd import ns as N
     lib.init(local_rank)
-    if world > 1:
+    if shared_gpu:
+        from iamr_amd import comm
+        transport = "gloo-host-staged (forced, shared GPU)"
+        comm.init_gloo_callback(dist)
+        transport_selftest(lib, rank, world)
+    elif world > 1:
         from iamr_amd import comm
         transport = "rccl"
         ok = torch.ones(1, device="cuda")
@@ -232,20 +244,21 @@ def main():
     el = time.perf_counter() - t0
     mallocs_in_loop = nmalloc() - m0
     if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     cells_total = float(n) ** 3 * world
     value = cells_total * a.steps / el
 
     out = None
+    # per-section breakdown (separate, synchronised pass so it does not perturb the timed region); a time step is collective:
+    # EVERY rank takes these two steps
+    ns.profile(2)
+    for _ in range(2):
+        ns.step()
+    sec = ns.profile(0)
     if rank == 0:
         import statistics as st
-        # per-section breakdown (separate, synchronised pass so it does not perturb the timed region)
-        ns.profile(2)
-        for _ in range(2):
-            ns.step()
-        sec = ns.profile(0)
         kr = kernel_rooflines(lib, n) if world == 1 else {}
         # dominant kernel of the step (profiles/round1_*): the nodal Gauss-Seidel colour kernel
         dom = kr.get("nodal_gs4_launch")
@@ -279,7 +292,7 @@ def main():
             "kernels": kr,
             "roofline": roofline,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))
     if world > 1:

@@ -114,3 +114,23 @@ def test_four_ranks_stacked_boxes_like_the_bench(tmp_path):
             assert np.array_equal(z["iters"], ref["iters"])
             key = f"box{r}"
             assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+def test_bench_script_multi_rank_path(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with 2 ranks
+    sharing the GPU over the host-staged transport (IAMRX_BENCH_TRANSPORT=gloo): the script must run to the end on every rank and
+    rank 0 must print one JSON line with the whole-job aggregate"""
+    import json
+    import subprocess
+    env = dict(os.environ, IAMRX_BENCH_TRANSPORT="gloo", MASTER_ADDR="127.0.0.1", IAMRX_BENCH_N="32")     # "--n" would be eaten by torchrun
+    port = 35600 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["cells"] == 2 * 32 ** 3 and "cpu_baseline" not in d and d["transport"].startswith("gloo")
+    assert abs(d["value"] - d["config"]["cells"] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
