@@ -285,7 +285,7 @@ CopyPlan::~CopyPlan()
 }
 
 struct PlanKey {
-    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3];
+    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3]; int ngv[3];
     bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -301,8 +301,11 @@ static CopyDesc* upload(const std::vector<CopyDesc>& v)
 
 // host-only construction of a ghost-exchange plan (no device access: unit-testable on CPU)
 void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
-                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers)
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv)
 {
+    // ngv: ghost depth to fill per direction (<= ng; nullptr: ng everywhere).  A consumer whose stencil reaches less far in one
+    // direction (the plane-fused nodal smoother: 4 nodes in-plane, 1 plane in z) exchanges correspondingly thinner slabs.
+    const int gv[3] = {ngv ? ngv[0] : ng, ngv ? ngv[1] : ng, ngv ? ngv[2] : ng};
     // periodic shift candidates
     int smin[3], smax[3];
     for (int d = 0; d < 3; ++d) {
@@ -314,7 +317,8 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
     for (int gd = 0; gd < nb; ++gd) {
         const bool dst_mine = owner[gd] == me;
         const BoxD dvalid = convert(boxes[gd], t.t);
-        const BoxD dgrown = grow(dvalid, ng);
+        BoxD dgrown = dvalid;
+        for (int d = 0; d < 3; ++d) { dgrown.lo[d] -= gv[d]; dgrown.hi[d] += gv[d]; }
         for (int gs = 0; gs < nb; ++gs) {
             const bool src_mine = owner[gs] == me;
             if (!dst_mine && !src_mine) continue;
@@ -370,19 +374,20 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
     }
 }
 
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g)
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv)
 {
     static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = l.id; key.t = t; key.ng = ng;
+    for (int d = 0; d < 3; ++d) key.ngv[d] = ngv ? ngv[d] : ng;
     for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
 
     auto plan = std::make_unique<CopyPlan>();
     std::map<int, CopyPlan::Peer> peers;
-    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers);
+    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv);
     plan->d_local = upload(plan->local);
     for (auto& kv : peers) {
         kv.second.d_pack = upload(kv.second.pack);
@@ -520,10 +525,10 @@ void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
 
 void MultiFab::FillBoundary(const Geometry& g) { FillBoundary(g, 0, ncomp); }
 
-void MultiFab::FillBoundary(const Geometry& g, int comp, int nc)
+void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv)
 {
     if (ngrow == 0) return;
-    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g);
+    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g, ngv);
     execute_plan(plan, *this, *this, comp, comp, nc);
 }
 

@@ -121,7 +121,9 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
 // ghost nodes: same-level + periodic images, then even reflection about Neumann walls
 void NodalMG::fillbc(int l, MultiFab& x)
 {
-    x.FillBoundary(m_lev[l].g);
+    // the plane-fused smoother recomputes a 4-node halo in-plane but reaches only one plane up and down: exchange 1 plane in z
+    const int ngv[3] = {x.ngrow, x.ngrow, 1};
+    x.FillBoundary(m_lev[l].g, 0, x.ncomp, ngv);
     nodal_reflect_bc(m_lev[l].g, x, m_bc);
 }
 

@@ -1,0 +1,36 @@
+"""counts halo exchanges / all-reduces per time step of the bench workload on 2 ranks sharing one GPU (scratch tool):
+   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29777 tools/count_comm.py [n]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch.distributed as dist
+from iamr_amd import lib, comm
+from iamr_amd import ns as N
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib.init(0)
+cnt = {"ex": 0, "ar": 0, "bytes": 0}
+orig_irecv, orig_ar = dist.irecv, dist.all_reduce
+def irecv(t, *a, **k):
+    cnt["ex"] += 1; cnt["bytes"] += t.numel() * 8
+    return orig_irecv(t, *a, **k)
+def ar(t, *a, **k):
+    cnt["ar"] += 1
+    return orig_ar(t, *a, **k)
+dist.irecv, dist.all_reduce = irecv, ar
+comm.init_gloo_callback(dist)
+boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(world)]
+lay = lib.Layout(boxes, list(range(world)))
+g = lib.Geom.make((n, n, n * world), prob_hi=(1.0, 1.0, float(world)))
+ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+ns.post_init(-1.0)
+ns.step()
+for k in cnt: cnt[k] = 0
+ns.step()
+sm, sn, sv = ns.stats()
+if rank == 0:
+    print(f"n={n} world={world}: per step and rank: {cnt['ex']} peer messages received ({cnt['bytes']/1e6:.1f} MB), {cnt['ar']} all-reduces; "
+          f"MG iterations mac {sm.iters} nodal {sn.iters} visc {sv.iters}")
+dist.barrier(); dist.destroy_process_group()
