@@ -27,13 +27,13 @@ __global__ void __launch_bounds__(256) k_copy_plan(const CopyDesc* __restrict__ 
 {
     const CopyDesc cd = descs[blockIdx.y];
     const int nx = cd.region.len(0), ny = cd.region.len(1);
-    const long npts = cd.region.npts();
+    const long npts = cd.npts();
     const FabD s = src[cd.src_fab], d = dst[cd.dst_fab];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
         const int i = cd.region.lo[0] + (int)(q % nx);
         const long r = q / nx;
         const int j = cd.region.lo[1] + (int)(r % ny);
-        const int k = cd.region.lo[2] + (int)(r / ny);
+        const int k = cd.region.lo[2] + cd.kstep * (int)(r / ny);
         if (add) for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) += s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
         else for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
     }
@@ -53,13 +53,13 @@ __global__ void __launch_bounds__(256) k_pack(const CopyDesc* __restrict__ descs
 {
     const CopyDesc cd = descs[blockIdx.y];
     const int nx = cd.region.len(0), ny = cd.region.len(1);
-    const long npts = cd.region.npts();
+    const long npts = cd.npts();
     const FabD s = src[cd.src_fab];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
         const int i = cd.region.lo[0] + (int)(q % nx);
         const long r = q / nx;
         const int j = cd.region.lo[1] + (int)(r % ny);
-        const int k = cd.region.lo[2] + (int)(r / ny);
+        const int k = cd.region.lo[2] + cd.kstep * (int)(r / ny);
         for (int n = 0; n < nc; ++n) buf[cd.buf_off + q + pts_total * n] = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
     }
 }
@@ -69,13 +69,13 @@ __global__ void __launch_bounds__(256) k_unpack(const CopyDesc* __restrict__ des
 {
     const CopyDesc cd = descs[blockIdx.y];
     const int nx = cd.region.len(0), ny = cd.region.len(1);
-    const long npts = cd.region.npts();
+    const long npts = cd.npts();
     const FabD d = dst[cd.dst_fab];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
         const int i = cd.region.lo[0] + (int)(q % nx);
         const long r = q / nx;
         const int j = cd.region.lo[1] + (int)(r % ny);
-        const int k = cd.region.lo[2] + (int)(r / ny);
+        const int k = cd.region.lo[2] + cd.kstep * (int)(r / ny);
         if (add) for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) += buf[cd.buf_off + q + pts_total * n];
         else for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = buf[cd.buf_off + q + pts_total * n];
     }

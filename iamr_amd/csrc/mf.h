@@ -108,6 +108,9 @@ struct CopyDesc {
     BoxD region;            // destination index region
     int shift[3];           // src index = dst index + shift
     long buf_off;           // offset (in doubles, per component block) in a packed message buffer
+    int kstep = 1;          // 2: only every second z-plane of the region, starting at region.lo[2] (parity-filtered fills)
+    __host__ __device__ int nk() const { return (region.hi[2] - region.lo[2]) / kstep + 1; }
+    __host__ __device__ long npts() const { return (long)region.len(0) * region.len(1) * nk(); }
 };
 
 struct CopyPlan {
@@ -154,7 +157,7 @@ public:
     void setVal(double v);                              // all comps, incl. ghosts
     void setVal(double v, int comp, int nc, int ng);
     void FillBoundary(const Geometry& g);               // same-level + periodic ghost exchange (all comps)
-    void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr);   // ngv: ghost depth per direction (<= ngrow)
+    void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr, int kpar = -1);   // ngv: ghost depth per direction (<= ngrow)
     // valid + ng ghost cells
     static void Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng);
     // dst = a*x + b*y style helpers live in blas (kernels.h)
@@ -170,10 +173,12 @@ private:
 
 // host-only plan construction (no device access; unit-testable on CPU)
 void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
-                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv = nullptr);
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv = nullptr,
+                          int kpar = -1);
 
 // plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv = nullptr);
+// kpar = 0 / 1: only the z-planes of that parity (global index) are exchanged
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv = nullptr, int kpar = -1);
 // add: dst += src instead of dst = src (the regions of one plan must then not overlap in dst)
 void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false);
 // multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes

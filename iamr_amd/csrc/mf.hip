@@ -285,7 +285,7 @@ CopyPlan::~CopyPlan()
 }
 
 struct PlanKey {
-    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3]; int ngv[3];
+    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3]; int ngv[3]; int kpar;
     bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -301,7 +301,7 @@ static CopyDesc* upload(const std::vector<CopyDesc>& v)
 
 // host-only construction of a ghost-exchange plan (no device access: unit-testable on CPU)
 void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
-                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv)
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv, int kpar)
 {
     // ngv: ghost depth to fill per direction (<= ng; nullptr: ng everywhere).  A consumer whose stencil reaches less far in one
     // direction (the plane-fused nodal smoother: 4 nodes in-plane, 1 plane in z) exchanges correspondingly thinner slabs.
@@ -314,14 +314,45 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
         smin[d] = -nper; smax[d] = nper;
     }
     const int nb = (int)boxes.size();
+    // box difference a \ b appended to out
+    auto subtract = [](const BoxD& a, const BoxD& b, std::vector<BoxD>& out) {
+        BoxD in = intersect(a, b);
+        if (!in.ok()) { out.push_back(a); return; }
+        BoxD rem = a;
+        for (int d = 2; d >= 0; --d) {
+            if (rem.lo[d] < in.lo[d]) { BoxD p = rem; p.hi[d] = in.lo[d] - 1; out.push_back(p); rem.lo[d] = in.lo[d]; }
+            if (rem.hi[d] > in.hi[d]) { BoxD p = rem; p.lo[d] = in.hi[d] + 1; out.push_back(p); rem.hi[d] = in.hi[d]; }
+        }
+    };
+    const bool nodal = t.t[0] || t.t[1] || t.t[2];
     for (int gd = 0; gd < nb; ++gd) {
         const bool dst_mine = owner[gd] == me;
         const BoxD dvalid = convert(boxes[gd], t.t);
         BoxD dgrown = dvalid;
         for (int d = 0; d < 3; ++d) { dgrown.lo[d] -= gv[d]; dgrown.hi[d] += gv[d]; }
+        // Nodal / face data: boxes share the points on their common faces, so a ghost point can have several sources.  Whatever a
+        // box of the destination's own rank supplies is not requested from another rank as well (both sides of a message evaluate
+        // this rule on the same global box list, so the plans stay symmetric).
+        std::vector<BoxD> own_cov;
+        if (nodal) {
+            for (int gs = 0; gs < nb; ++gs) {
+                if (owner[gs] != owner[gd]) continue;
+                for (int sz = smin[2]; sz <= smax[2]; ++sz)
+                for (int sy = smin[1]; sy <= smax[1]; ++sy)
+                for (int sx = smin[0]; sx <= smax[0]; ++sx) {
+                    if (gs == gd && sx == 0 && sy == 0 && sz == 0) continue;
+                    BoxD svalid = convert(boxes[gs], t.t);
+                    const int sh[3] = {sx * g.domain.len(0), sy * g.domain.len(1), sz * g.domain.len(2)};
+                    for (int d = 0; d < 3; ++d) svalid = shift(svalid, d, sh[d]);
+                    BoxD is = intersect(dgrown, svalid);
+                    if (is.ok()) own_cov.push_back(is);
+                }
+            }
+        }
         for (int gs = 0; gs < nb; ++gs) {
             const bool src_mine = owner[gs] == me;
             if (!dst_mine && !src_mine) continue;
+            const bool remote_src = owner[gs] != owner[gd];
             for (int sz = smin[2]; sz <= smax[2]; ++sz)
             for (int sy = smin[1]; sy <= smax[1]; ++sy)
             for (int sx = smin[0]; sx <= smax[0]; ++sx) {
@@ -344,28 +375,47 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                         if (rem.hi[d] > in.hi[d]) { BoxD p = rem; p.lo[d] = in.hi[d] + 1; parts.push_back(p); rem.hi[d] = in.hi[d]; }
                     }
                 }
-                for (auto& p : parts) {
+                if (remote_src && !own_cov.empty()) {
+                    for (const BoxD& c : own_cov) {
+                        std::vector<BoxD> next;
+                        for (const BoxD& q : parts) subtract(q, c, next);
+                        parts.swap(next);
+                        if (parts.empty()) break;
+                    }
+                }
+                for (auto& p0 : parts) {
+                    BoxD p = p0;
                     CopyDesc cd;
+                    if (kpar >= 0) {
+                        // keep the z-planes of parity kpar only
+                        int k0 = p.lo[2];
+                        if ((((k0 % 2) + 2) % 2) != kpar) ++k0;
+                        if (k0 > p.hi[2]) continue;
+                        p.lo[2] = k0;
+                        p.hi[2] = k0 + 2 * ((p.hi[2] - k0) / 2);
+                        cd.kstep = 2;
+                    }
                     cd.region = p;
+                    const long np = cd.npts();
                     for (int d = 0; d < 3; ++d) cd.shift[d] = -sh[d];
                     cd.buf_off = 0;
                     if (dst_mine && src_mine) {
                         cd.src_fab = local_of[gs]; cd.dst_fab = local_of[gd];
                         plan.local.push_back(cd);
-                        plan.max_local_pts = std::max(plan.max_local_pts, p.npts());
+                        plan.max_local_pts = std::max(plan.max_local_pts, np);
                     } else if (src_mine) {          // I send to owner of gd
                         auto& pr = peers[owner[gd]];
                         pr.rank = owner[gd];
                         cd.src_fab = local_of[gs]; cd.dst_fab = -1; cd.buf_off = pr.send_pts;
-                        pr.send_pts += p.npts();
-                        pr.max_pack_pts = std::max(pr.max_pack_pts, p.npts());
+                        pr.send_pts += np;
+                        pr.max_pack_pts = std::max(pr.max_pack_pts, np);
                         pr.pack.push_back(cd);
                     } else {                        // I receive from owner of gs
                         auto& pr = peers[owner[gs]];
                         pr.rank = owner[gs];
                         cd.src_fab = -1; cd.dst_fab = local_of[gd]; cd.buf_off = pr.recv_pts;
-                        pr.recv_pts += p.npts();
-                        pr.max_unpack_pts = std::max(pr.max_unpack_pts, p.npts());
+                        pr.recv_pts += np;
+                        pr.max_unpack_pts = std::max(pr.max_unpack_pts, np);
                         pr.unpack.push_back(cd);
                     }
                 }
@@ -374,20 +424,21 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
     }
 }
 
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv)
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv, int kpar)
 {
     static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = l.id; key.t = t; key.ng = ng;
     for (int d = 0; d < 3; ++d) key.ngv[d] = ngv ? ngv[d] : ng;
+    key.kpar = kpar;
     for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
 
     auto plan = std::make_unique<CopyPlan>();
     std::map<int, CopyPlan::Peer> peers;
-    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv);
+    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv, kpar);
     plan->d_local = upload(plan->local);
     for (auto& kv : peers) {
         kv.second.d_pack = upload(kv.second.pack);
@@ -525,10 +576,10 @@ void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
 
 void MultiFab::FillBoundary(const Geometry& g) { FillBoundary(g, 0, ncomp); }
 
-void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv)
+void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv, int kpar)
 {
     if (ngrow == 0) return;
-    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g, ngv);
+    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g, ngv, kpar);
     execute_plan(plan, *this, *this, comp, comp, nc);
 }
 

@@ -119,11 +119,11 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
 }
 
 // ghost nodes: same-level + periodic images, then even reflection about Neumann walls
-void NodalMG::fillbc(int l, MultiFab& x)
+void NodalMG::fillbc(int l, MultiFab& x, int kpar)
 {
     // the plane-fused smoother recomputes a 4-node halo in-plane but reaches only one plane up and down: exchange 1 plane in z
     const int ngv[3] = {x.ngrow, x.ngrow, 1};
-    x.FillBoundary(m_lev[l].g, 0, x.ncomp, ngv);
+    x.FillBoundary(m_lev[l].g, 0, x.ncomp, ngv, kpar);
     nodal_reflect_bc(m_lev[l].g, x, m_bc);
 }
 
@@ -145,10 +145,15 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         if (!wrap) fillbc(l, const_cast<MultiFab&>(rhs));
         MultiFab* a = &x;
         MultiFab* b = &L.xb;
+        // Ghost traffic: the even pass changes even planes only and reads the odd planes next to them, the odd pass the reverse.
+        // After the first (full) fill it is therefore enough to refresh the ghost nodes of the planes of ONE parity in front of each
+        // pass: the odd planes before the even pass, the even planes before the odd pass (half the halo volume; on boxes stacked in
+        // z, where one ghost plane is exchanged, every second message disappears).
+        static const bool par_fill = !(getenv("IAMRX_NODAL_PARITY_FILL") && atoi(getenv("IAMRX_NODAL_PARITY_FILL")) == 0);
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
-            if (!wrap) fillbc(l, *a);
+            if (!wrap) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
             nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk);      // even planes: a -> b
-            if (!wrap) fillbc(l, *b);                                        // ghost images of the new even planes
+            if (!wrap) fillbc(l, *b, par_fill ? 0 : -1);                     // ghost images of the new even planes
             nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }

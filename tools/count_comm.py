@@ -11,9 +11,11 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 lib.init(0)
 cnt = {"ex": 0, "ar": 0, "bytes": 0}
+import collections
+hist = collections.Counter()
 orig_irecv, orig_ar = dist.irecv, dist.all_reduce
 def irecv(t, *a, **k):
-    cnt["ex"] += 1; cnt["bytes"] += t.numel() * 8
+    cnt["ex"] += 1; cnt["bytes"] += t.numel() * 8; hist[t.numel()] += 1
     return orig_irecv(t, *a, **k)
 def ar(t, *a, **k):
     cnt["ar"] += 1
@@ -28,9 +30,11 @@ ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
 ns.post_init(-1.0)
 ns.step()
 for k in cnt: cnt[k] = 0
+hist.clear()
 ns.step()
 sm, sn, sv = ns.stats()
 if rank == 0:
     print(f"n={n} world={world}: per step and rank: {cnt['ex']} peer messages received ({cnt['bytes']/1e6:.1f} MB), {cnt['ar']} all-reduces; "
           f"MG iterations mac {sm.iters} nodal {sn.iters} visc {sv.iters}")
+if rank == 0: print("sizes (doubles: count):", sorted(hist.items()))
 dist.barrier(); dist.destroy_process_group()
