@@ -136,6 +136,7 @@ private:
         LayoutP dist;
         MultiFab tmp_d;
         MultiFab xb;               // second buffer of the out-of-place fused Gauss-Seidel sweeps
+        bool res_filled = false;   // the ghost nodes of `res` are current (filled once per V-cycle, not once per smooth call)
         MultiFab dm;               // Dirichlet node mask (defined only if the level has Dirichlet nodes, see NodalMG ctor)
         const MultiFab* dmask() const { return dm.defined() ? &dm : nullptr; }
     };

@@ -142,7 +142,11 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
         // one box spanning a fully periodic domain: the kernel takes periodic images from the valid data, no ghost fills
         const bool wrap = !dmk && periodic_wrap_ok(L.g, *L.layout, 4);
-        if (!wrap) fillbc(l, const_cast<MultiFab&>(rhs));
+        if (!wrap) {
+            // the right-hand side of the level's smooth calls is its residual array, unchanged within a V-cycle: fill its ghosts once
+            if (&rhs == &L.res) { if (!L.res_filled) { fillbc(l, L.res); L.res_filled = true; } }
+            else fillbc(l, const_cast<MultiFab&>(rhs));
+        }
         MultiFab* a = &x;
         MultiFab* b = &L.xb;
         // Ghost traffic: the even pass changes even planes only and reads the odd planes next to them, the odd pass the reverse.
@@ -270,6 +274,7 @@ void NodalMG::vcycle(MGStats& st)
             gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
         } else
         nodal_restrict(m_lev[l + 1].res, L.rescor);
+        m_lev[l + 1].res_filled = false;
         if (m_lev[l + 1].dmask()) nodal_zero_masked(m_lev[l + 1].res, m_lev[l + 1].dm);   // mlndlap_restriction: 0 on Dirichlet nodes
     }
     {
@@ -317,6 +322,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     if (L0.dmask()) nodal_zero_masked(rhs, L0.dm);
     if (m_singular) subtract_mean(0, rhs);
     residual(0, L0.res, phi, rhs);
+    L0.res_filled = false;
     st.resnorm0 = L0.res.norm0(0, 1, 0);
     st.rhsnorm0 = rhs.norm0(0, 1, 0);
     const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
@@ -329,7 +335,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     else {
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         for (int iter = 0; iter < maxit; ++iter) {
-            if (m_singular) subtract_mean(0, L0.res);
+            if (m_singular) { subtract_mean(0, L0.res); L0.res_filled = false; }
             ctx.sync();
             auto t0 = std::chrono::steady_clock::now();
             vcycle(st);
@@ -337,6 +343,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
             vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, 1, 0);
             residual(0, L0.res, phi, rhs);
+            L0.res_filled = false;
             st.resnorm = L0.res.norm0(0, 1, 0);
             st.iters = iter + 1;
             if (m_o.verbose) printf("iamrx nodal MLMG: iter %d resid %.6e\n", iter + 1, st.resnorm);
