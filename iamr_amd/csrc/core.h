@@ -95,6 +95,7 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 enum BCType : int { bc_reflect_odd = -1, bc_int_dir = 0, bc_reflect_even = 1, bc_foextrap = 2, bc_ext_dir = 3, bc_hoextrap = 4 };
 // amrex::LinOpBCType
 enum LinOpBC : int { lo_periodic = 0, lo_dirichlet = 101, lo_neumann = 102,
+                     lo_reflect_odd = 104 /* cell-centred solvers: ghost = -first interior cell (LinOpBCType::reflect_odd, normal velocity at a Symmetry face) */,
                      lo_inflow = 103 /* nodal projection only (LinOpBCType::inflow): Neumann operator, the normal velocity outside the face enters div(u) */ };
 // IAMR PhysBCType (reference Source/NS_BC.H)
 enum PhysBC : int { phys_interior = 0, phys_inflow = 1, phys_outflow = 2, phys_symmetry = 3, phys_slipwall = 4, phys_noslipwall = 5 };

@@ -56,6 +56,7 @@ static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
                 const int b = side == 0 ? bc.lo[d] : bc.hi[d];
                 double cf = 0.0;
                 if (b == lo_neumann) cf = 1.0;
+                else if (b == lo_reflect_odd) cf = -1.0;
                 else if (b == lo_dirichlet) { double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX); cf = NX >= 2 ? c[1] : 0.0; }
                 (side == 0 ? r.cflo[n][d] : r.cfhi[n][d]) = cf;
             }
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
     const long npts = bd.region.npts();
     const int d = bd.dir, s = 1 - 2 * bd.side;
     const int bct = P.bct[2 * d + bd.side];
-    if (bct != lo_neumann && bct != lo_dirichlet) return;
+    if (bct != lo_neumann && bct != lo_dirichlet && bct != lo_reflect_odd) return;
     const double* c = P.c[2 * d + bd.side];   // c[0..3] weights, c[4] = NX
     const int NX = (int)c[4];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
@@ -439,6 +440,7 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
             double v;
             int m[3] = {idx[0], idx[1], idx[2]};
             if (bct == lo_neumann) { m[d] += s; v = phi(m[0], m[1], m[2], n); }
+            else if (bct == lo_reflect_odd) { m[d] += s; v = -phi(m[0], m[1], m[2], n); }
             else {
                 const double bv = (inhomog && bcvt) ? bcvt[bd.fab](idx[0], idx[1], idx[2], n) : 0.0;
                 if (NX < 2) v = bv;

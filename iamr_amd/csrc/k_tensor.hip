@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(256) k_tensor_edges(const EdgeDesc* __restrict
                 double v;
                 int m3[3] = {idx[0], idx[1], idx[2]};
                 if (bct == lo_neumann) { m3[d] += s; v = phi(m3[0], m3[1], m3[2], n); }
+                else if (bct == lo_reflect_odd) { m3[d] += s; v = -phi(m3[0], m3[1], m3[2], n); }
                 else {
                     const double bv = (P.inhomog && bvt) ? bvt[ed.fab](idx[0], idx[1], idx[2], n) : 0.0;
                     if (P.NX[d] < 2) v = bv;

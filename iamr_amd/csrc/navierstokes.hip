@@ -71,19 +71,26 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         if (phys == phys_interior) return (int)bc_int_dir;
         if (phys == phys_inflow) return (int)bc_ext_dir;
         if (phys == phys_outflow) return (int)bc_foextrap;
+        if (phys == phys_symmetry) return normal ? (int)bc_reflect_odd : (int)bc_reflect_even;
         if (phys == phys_noslipwall) return (int)bc_ext_dir;
         return normal ? (int)bc_ext_dir : (int)bc_hoextrap;      // SlipWall
     };
     auto scal_bctype = [](int phys) {
         if (phys == phys_interior) return (int)bc_int_dir;
+        if (phys == phys_symmetry) return (int)bc_reflect_even;
         return phys == phys_inflow ? (int)bc_ext_dir : (int)bc_foextrap;
     };
-    auto gp_bctype = [](int phys) { return phys == phys_interior ? (int)bc_int_dir : (int)bc_foextrap; };   // norm/tang_gradp_bc
-    auto phys_ok = [](int phys) { return phys == phys_inflow || phys == phys_outflow || phys == phys_slipwall || phys == phys_noslipwall; };
+    auto gp_bctype = [](int phys, bool normal) {     // norm/tang_gradp_bc
+        if (phys == phys_interior) return (int)bc_int_dir;
+        if (phys == phys_symmetry) return normal ? (int)bc_reflect_odd : (int)bc_reflect_even;
+        return (int)bc_foextrap;
+    };
+    auto phys_ok = [](int phys) { return phys == phys_inflow || phys == phys_outflow || phys == phys_symmetry || phys == phys_slipwall || phys == phys_noslipwall; };
     // Diffusion::setDomainBC, Diffusion.cpp:1886-1941
     auto linop_of = [](int bct) {
         if (bct == bc_ext_dir) return (int)lo_dirichlet;
         if (bct == bc_foextrap || bct == bc_hoextrap || bct == bc_reflect_even) return (int)lo_neumann;
+        if (bct == bc_reflect_odd) return (int)lo_reflect_odd;
         return (int)lo_periodic;
     };
     for (int d = 0; d < 3; ++d) {
@@ -91,8 +98,8 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         if (!g.periodic[d]) {
             any_wall = true;
             if (!(phys_ok(plo) && phys_ok(phi_)))
-                throw Error("iamrx NavierStokes: a non-periodic direction needs Inflow (1), Outflow (2), SlipWall (4) or NoSlipWall (5) on "
-                            "both sides; Symmetry (3) is not implemented");
+                throw Error("iamrx NavierStokes: a non-periodic direction needs Inflow (1), Outflow (2), Symmetry (3), SlipWall (4) or "
+                            "NoSlipWall (5) on both sides");
             if ((plo == phys_outflow || phi_ == phys_outflow) && p.gravity != 0.0)
                 throw Error("iamrx NavierStokes: outflow with gravity (hydrostatic outflow pressure, Projection::set_outflow_bcs) is not implemented");
         }
@@ -104,7 +111,7 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         bc_nodal.hi[d] = (!g.periodic[d] && phi_ == phys_inflow) ? (int)lo_inflow : bc_mac.hi[d];
         for (int n = 0; n < 3; ++n) {
             bc_vel[n].lo[d] = vel_bctype(plo, n == d); bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
-            bc_gp[n].lo[d] = gp_bctype(plo); bc_gp[n].hi[d] = gp_bctype(phi_);
+            bc_gp[n].lo[d] = gp_bctype(plo, n == d); bc_gp[n].hi[d] = gp_bctype(phi_, n == d);
             ed_vel_lo[n * 3 + d] = p.wall_vel_lo[d * 3 + n]; ed_vel_hi[n * 3 + d] = p.wall_vel_hi[d * 3 + n];
             bc_visc[n].lo[d] = linop_of(bc_vel[n].lo[d]); bc_visc[n].hi[d] = linop_of(bc_vel[n].hi[d]);
         }

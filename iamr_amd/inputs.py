@@ -114,9 +114,9 @@ class Inputs:
         for d in range(3):
             if per[d] and (lo_bc[d] != 0 or hi_bc[d] != 0):
                 raise ValueError("inputs: periodic direction with a non-Interior ns.lo_bc/hi_bc (NavierStokesBase.cpp:563-590)")
-            if not per[d] and (lo_bc[d] not in (1, 2, 4, 5) or hi_bc[d] not in (1, 2, 4, 5)):
+            if not per[d] and (lo_bc[d] not in (1, 2, 3, 4, 5) or hi_bc[d] not in (1, 2, 3, 4, 5)):
                 raise NotImplementedError(f"inputs: ns.lo_bc/hi_bc = {lo_bc[d]}/{hi_bc[d]} in direction {d}: implemented are Interior (0), "
-                                          "Inflow (1), Outflow (2), SlipWall (4) and NoSlipWall (5); Symmetry (3) is not")
+                                          "Inflow (1), Outflow (2), Symmetry (3), SlipWall (4) and NoSlipWall (5)")
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
         if scheme != "Godunov_PLM":
             raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; only Godunov_PLM is implemented")

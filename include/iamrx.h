@@ -270,7 +270,7 @@ typedef struct iamrx_ns_params {
     int nscal, verbose;
     double init_dt;              /* ns.init_dt: dt when the state has no velocity/force scale (LidDrivenCavity start) */
     double tracer_diff_coef;     /* ns.scal_diff_coefs[0] (<= 0: tracer not diffusive) */
-    int phys_lo[3], phys_hi[3];  /* ns.lo_bc / ns.hi_bc, Source/NS_BC.H: 0 Interior (periodic), 1 Inflow, 2 Outflow, 4 SlipWall, 5 NoSlipWall */
+    int phys_lo[3], phys_hi[3];  /* ns.lo_bc / ns.hi_bc, Source/NS_BC.H: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall */
     double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];     /* xlo.density, xlo.tracer ... zhi.* (inflow values): [d*2+n], n = 0 density, 1 tracer */
 } iamrx_ns_params;

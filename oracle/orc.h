@@ -51,6 +51,7 @@ enum { ORC_BC_REFLECT_ODD = -1, ORC_BC_INT_DIR = 0, ORC_BC_REFLECT_EVEN = 1,
 
 /* linear-operator domain BC = amrex::LinOpBCType */
 enum { ORC_LO_PERIODIC = 0, ORC_LO_DIRICHLET = 101, ORC_LO_NEUMANN = 102,
+       ORC_LO_REFLECT_ODD = 104 /* cell-centred solvers: ghost = -first interior cell (LinOpBCType::reflect_odd, the normal velocity at a Symmetry face) */,
        ORC_LO_INFLOW = 103 /* nodal solver only (LinOpBCType::inflow): Neumann operator, the normal velocity outside the face enters div(u) */ };
 
 /* bcrec: lo[3], hi[3] per component */
@@ -234,7 +235,7 @@ typedef struct orc_ns_params {
     int verbose;
     double init_dt;            /* ns.init_dt: used when estTimeStep finds no velocity/force scale (-1: abort) */
     double tracer_diff_coef;   /* ns.scal_diff_coefs[0]: tracer diffusivity (<= 0: not diffusive) */
-    int phys_lo[3], phys_hi[3];/* ns.lo_bc / ns.hi_bc: 0 Interior (periodic), 1 Inflow, 2 Outflow, 4 SlipWall, 5 NoSlipWall (Source/NS_BC.H) */
+    int phys_lo[3], phys_hi[3];/* ns.lo_bc / ns.hi_bc: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall (Source/NS_BC.H) */
     double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];   /* xlo.density, xlo.tracer ... (inflow values): [d*2+n], n = 0 density, 1 tracer */
 } orc_ns_params;

@@ -72,6 +72,7 @@ static void poly_interp_coeff(double xi, const double* x, int N, double* c)
 static double bc_coef0(int bct, int blen, int maxorder)
 {
     if (bct == ORC_LO_NEUMANN) return 1.0;
+    if (bct == ORC_LO_REFLECT_ODD) return -1.0;
     if (bct == ORC_LO_DIRICHLET) {
         int NX = blen + 1 < maxorder ? blen + 1 : maxorder;
         if (NX < 2) return 0.0;
@@ -261,9 +262,10 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
             for (int q1 = 0; q1 < g->n[d1]; ++q1) {
                 int idx[3]; idx[d] = ig; idx[d1] = q1; idx[d2] = q2;
                 double v;
-                if (bct == ORC_LO_NEUMANN) {
+                if (bct == ORC_LO_NEUMANN || bct == ORC_LO_REFLECT_ODD) {
                     int s1[3] = {idx[0], idx[1], idx[2]}; s1[d] = ig + s;
                     v = A4(phi, s1[0], s1[1], s1[2], n);
+                    if (bct == ORC_LO_REFLECT_ODD) v = -v;
                 } else if (bct == ORC_LO_DIRICHLET) {
                     double bv = (inhomog && bcval) ? A4(bcval, idx[0], idx[1], idx[2], n) : 0.0;
                     if (NX < 2) v = bv;

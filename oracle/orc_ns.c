@@ -74,27 +74,35 @@ void orc_ns_default_params(orc_ns_params* p)
 }
 
 /* BCType of a velocity component / scalar / grad p component for a physical BC (Source/NS_BC.H:7-35) */
-enum { PHYS_INTERIOR = 0, PHYS_INFLOW = 1, PHYS_OUTFLOW = 2, PHYS_SLIPWALL = 4, PHYS_NOSLIPWALL = 5 };
+enum { PHYS_INTERIOR = 0, PHYS_INFLOW = 1, PHYS_OUTFLOW = 2, PHYS_SYMMETRY = 3, PHYS_SLIPWALL = 4, PHYS_NOSLIPWALL = 5 };
 static int vel_bctype(int phys, int normal)
 {
     if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
     if (phys == PHYS_INFLOW) return ORC_BC_EXT_DIR;
     if (phys == PHYS_OUTFLOW) return ORC_BC_FOEXTRAP;
+    if (phys == PHYS_SYMMETRY) return normal ? ORC_BC_REFLECT_ODD : ORC_BC_REFLECT_EVEN;
     if (phys == PHYS_NOSLIPWALL) return ORC_BC_EXT_DIR;
     return normal ? ORC_BC_EXT_DIR : ORC_BC_HOEXTRAP;          /* SlipWall */
 }
 static int scal_bctype(int phys)
 {
     if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    if (phys == PHYS_SYMMETRY) return ORC_BC_REFLECT_EVEN;
     return phys == PHYS_INFLOW ? ORC_BC_EXT_DIR : ORC_BC_FOEXTRAP;
 }
-static int gp_bctype(int phys) { return phys == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_FOEXTRAP; }   /* norm/tang_gradp_bc */
-static int phys_ok(int phys) { return phys == PHYS_INFLOW || phys == PHYS_OUTFLOW || phys == PHYS_SLIPWALL || phys == PHYS_NOSLIPWALL; }
+static int gp_bctype(int phys, int normal)   /* norm/tang_gradp_bc */
+{
+    if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    if (phys == PHYS_SYMMETRY) return normal ? ORC_BC_REFLECT_ODD : ORC_BC_REFLECT_EVEN;
+    return ORC_BC_FOEXTRAP;
+}
+static int phys_ok(int phys) { return phys == PHYS_INFLOW || phys == PHYS_OUTFLOW || phys == PHYS_SYMMETRY || phys == PHYS_SLIPWALL || phys == PHYS_NOSLIPWALL; }
 /* Diffusion::setDomainBC, Source/Diffusion.cpp:1886-1941 */
 static int linop_of_bctype(int bct)
 {
     if (bct == ORC_BC_EXT_DIR) return ORC_LO_DIRICHLET;
     if (bct == ORC_BC_FOEXTRAP || bct == ORC_BC_HOEXTRAP || bct == ORC_BC_REFLECT_EVEN) return ORC_LO_NEUMANN;
+    if (bct == ORC_BC_REFLECT_ODD) return ORC_LO_REFLECT_ODD;
     return ORC_LO_PERIODIC;
 }
 
@@ -115,7 +123,7 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     for (int d = 0; d < 3; ++d) {
         const int plo = g->periodic[d] ? PHYS_INTERIOR : p->phys_lo[d], phi_ = g->periodic[d] ? PHYS_INTERIOR : p->phys_hi[d];
         if (!g->periodic[d] && !(phys_ok(plo) && phys_ok(phi_))) {
-            fprintf(stderr, "orc_ns_create: non-periodic direction %d needs Inflow(1)/Outflow(2)/SlipWall(4)/NoSlipWall(5) on both sides\n", d);
+            fprintf(stderr, "orc_ns_create: non-periodic direction %d needs Inflow(1)/Outflow(2)/Symmetry(3)/SlipWall(4)/NoSlipWall(5) on both sides\n", d);
             free(s); return NULL;
         }
         if ((plo == PHYS_OUTFLOW || phi_ == PHYS_OUTFLOW) && p->gravity != 0.0) {
@@ -130,7 +138,7 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
         s->nhibc[d] = (!g->periodic[d] && phi_ == PHYS_INFLOW) ? ORC_LO_INFLOW : s->hibc[d];
         for (int n = 0; n < 3; ++n) {
             s->bc_vel[n].lo[d] = vel_bctype(plo, n == d); s->bc_vel[n].hi[d] = vel_bctype(phi_, n == d);
-            s->bc_gp[n].lo[d] = gp_bctype(plo); s->bc_gp[n].hi[d] = gp_bctype(phi_);
+            s->bc_gp[n].lo[d] = gp_bctype(plo, n == d); s->bc_gp[n].hi[d] = gp_bctype(phi_, n == d);
             s->ed_vel_lo[n * 3 + d] = p->wall_vel_lo[d * 3 + n]; s->ed_vel_hi[n * 3 + d] = p->wall_vel_hi[d * 3 + n];
             s->vlobc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].lo[d]); s->vhibc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].hi[d]);
         }

@@ -49,9 +49,10 @@ void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const 
                 const int bct = out[d] < 0 ? lobc[(L->bc_percomp ? 3 * n : 0) + d] : hibc[(L->bc_percomp ? 3 * n : 0) + d];
                 const int s = out[d] < 0 ? 1 : -1;
                 double v;
-                if (bct == ORC_LO_NEUMANN) {
+                if (bct == ORC_LO_NEUMANN || bct == ORC_LO_REFLECT_ODD) {
                     int q[3] = {i, j, k}; q[d] += s;
                     v = A4(phi, q[0], q[1], q[2], n);
+                    if (bct == ORC_LO_REFLECT_ODD) v = -v;
                 } else {
                     const int NX = g->n[d] + 1 < maxorder ? g->n[d] + 1 : maxorder;
                     const double bv = (inhomog && bcval) ? A4(bcval, i, j, k, n) : 0.0;

@@ -33,7 +33,7 @@ def test_unsupported_features_are_rejected_loudly():
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["amr.max_level=1"]).problem()
     with pytest.raises(NotImplementedError):
-        Inputs([LDC], ["ns.lo_bc = 3 4 5"]).problem()          # Symmetry
+        Inputs([LDC], ["ns.lo_bc = 6 4 5"]).problem()          # not a physical BC type
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["prob.probtype=10"]).problem()
     with pytest.raises(KeyError):

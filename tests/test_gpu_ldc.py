@@ -161,10 +161,11 @@ def test_rejects_unsupported_physical_bc(gpu):
     g = lib.Geom.make(n, periodic=(1, 1, 0))
     lay = lib.Layout.single(n)
     with pytest.raises(RuntimeError):
-        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 3], phys_hi=[0, 0, 5]))                   # Symmetry
+        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 6], phys_hi=[0, 0, 5]))                   # not a physical BC type
     with pytest.raises(RuntimeError):
         N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2], gravity=-1.0))     # outflow + gravity (hydrostatic outflow pressure)
     N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2]))                       # inflow / outflow are accepted
+    N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 3], phys_hi=[0, 0, 3]))                       # so is Symmetry
 
 
 @pytest.mark.parametrize("kw", [
@@ -193,3 +194,44 @@ def test_parameter_variants_match_oracle(orc, gpu, kw):
     ref = run_oracle(orc, n, per, (0, 4, 5), (0, 5, 4), nolid, 3, init, **base)
     ns, lay, g, dts = run_gpu(gpu, n, per, (0, 4, 5), (0, 5, 4), nolid, 3, init, (8, 16, 8), **base)
     compare(gpu, ns, lay, g, n, dts, ref)
+
+
+def test_symmetry_planes_match_oracle(orc, gpu):
+    """Symmetry (3) in y (normal velocity reflect_odd, everything else reflect_even; the tensor solve sees LinOpBCType::reflect_odd
+    for v), no-slip z with the lid, x periodic: product against the oracle"""
+    n = (16, 16, 16)
+    per = (1, 0, 0)
+    x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    init = np.zeros(n + (5,))
+    init[..., 0] = np.sin(2 * np.pi * X) * np.cos(np.pi * Y) * np.sin(np.pi * Z)
+    init[..., 1] = 0.5 * np.cos(2 * np.pi * X) * np.sin(np.pi * Y) * np.sin(2 * np.pi * Z)        # odd about the symmetry planes
+    init[..., 2] = 0.3 * np.sin(4 * np.pi * X) * np.cos(np.pi * Y) * np.sin(np.pi * Z) ** 2
+    init[..., 3] = 1.0 + 0.2 * np.sin(2 * np.pi * X) * np.cos(np.pi * Y)
+    init[..., 4] = np.exp(-40.0 * ((X - 0.5) ** 2 + (Y - 0.4) ** 2 + (Z - 0.6) ** 2))
+    kw = dict(cfl=0.5, visc_coef=0.02, init_iter=2, tracer_diff_coef=0.01)
+    ref = run_oracle(orc, n, per, (0, 3, 5), (0, 3, 5), LID, 3, init, **kw)
+    ns, lay, g, dts = run_gpu(gpu, n, per, (0, 3, 5), (0, 3, 5), LID, 3, init, 8, **kw)
+    compare(gpu, ns, lay, g, n, dts, ref)
+
+
+def test_symmetry_plane_reproduces_half_of_a_symmetric_periodic_flow(gpu):
+    """pin of the Symmetry BC that needs no oracle: TaylorGreen is odd in u / even in v, w, rho about the planes x = 0 and x = 1/2,
+    so the half domain [0, 1/2] with Symmetry faces in x carries the same solution as the periodic unit cube"""
+    from iamr_amd import ns as N
+    lib = gpu
+    kw = dict(cfl=0.5, visc_coef=0.01, init_iter=2)
+    gF = lib.Geom.make((32, 16, 16))
+    nsF = N.NavierStokes(gF, lib.Layout.single((32, 16, 16)), N.ns_params(**kw))
+    gH = lib.Geom.make((16, 16, 16), prob_hi=(0.5, 1.0, 1.0), periodic=(0, 1, 1))
+    nsH = N.NavierStokes(gH, lib.Layout.single((16, 16, 16)), N.ns_params(phys_lo=[3, 0, 0], phys_hi=[3, 0, 0], **kw))
+    for ns in (nsF, nsH):
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+        ns.post_init(-1.0)
+    for _ in range(4):
+        dF, dH = nsF.step(), nsH.step()
+        assert abs(dF - dH) <= 1e-10 * dF
+    SF = nsF.data(N.NavierStokes.S_NEW).gather_valid((32, 16, 16))
+    SH = nsH.data(N.NavierStokes.S_NEW).gather_valid((16, 16, 16))
+    assert np.abs(SH - SF[:16]).max() <= 1e-8
+    assert np.abs(SF[..., 0]).max() > 0.5
