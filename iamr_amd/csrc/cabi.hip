@@ -563,6 +563,10 @@ int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* 
     IAMRX_CATCH
 }
 int iamrx_ns_destroy(iamrx_ns ns) { IAMRX_TRY delete ns; IAMRX_CATCH }
+int iamrx_ns_init_rayleightaylor(iamrx_ns ns, double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width)
+{
+    IAMRX_TRY ns->ns->init_rayleightaylor(rho_1, rho_2, tra_1, tra_2, pertamp, interface_width); IAMRX_CATCH
+}
 int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, double c, double rho0)
 {
     IAMRX_TRY ns->ns->init_taylorgreen(vfac, a, b, c, rho0); IAMRX_CATCH

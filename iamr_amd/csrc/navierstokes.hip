@@ -154,6 +154,29 @@ void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, d
     time = 0.0; nstep = 0;
 }
 
+void NavierStokes::init_rayleightaylor(double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width)
+{
+    const double Pi = 3.14159265358979323846264338327950288;
+    const FabD* st = S[inew].d_tab;
+    const double plo0 = g.problo[0], plo1 = g.problo[1], plo2 = g.problo[2], dx0 = g.dx[0], dx1 = g.dx[1], dx2 = g.dx[2];
+    const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2];
+    const double Lx = g.dx[0] * g.domain.len(0), Ly = g.dx[1] * g.domain.len(1);
+    const double splitz = 0.5 * (plo2 + (plo2 + g.dx[2] * g.domain.len(2)));
+    const double ranampl = 2. * (0.6544437533747718 - 0.5);
+    const double ranphse1 = 2. * Pi * 0.1556190326530211, ranphse2 = 2. * Pi * 0.4196144025537369;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD s = st[f];
+        const double x = plo0 + (i - dl0 + 0.5) * dx0, y = plo1 + (j - dl1 + 0.5) * dx1, z = plo2 + (k - dl2 + 0.5) * dx2;
+        const double pert = ranampl * sin(2.0 * Pi * x / Lx + ranphse1) * sin(2.0 * Pi * y / Ly + ranphse2);
+        const double pertheight = splitz - pertamp * pert;
+        s(i, j, k, 0) = 0.0; s(i, j, k, 1) = 0.0; s(i, j, k, 2) = 0.0;
+        s(i, j, k, Density) = rho_1 + ((rho_2 - rho_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+        s(i, j, k, Tracer) = tra_1 + ((tra_2 - tra_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+    });
+    for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }
+    time = 0.0; nstep = 0;
+}
+
 // FillPatch on one level: copy the valid data, same-level + periodic ghost fill, then the physical-BC fill
 // (StateDataPhysBCFunct: FilccCell rules + the ext_dir functors of NS_bcfill.H)
 void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)

@@ -92,6 +92,9 @@ class NavierStokes {
 public:
     NavierStokes(const Geometry& g, LayoutP layout, const NSParams& p, const MGOpts& o);
     void init_taylorgreen(double vfac, double a, double b, double c, double rho0);   // Source/prob/prob_init.cpp:509-560
+    // probtype 10 (Source/prob/prob_init.cpp:407-488, 3-D branch): fluid at rest, tanh density / tracer interface at mid height,
+    // perturbed by the hard-coded random amplitude and phases of the reference
+    void init_rayleightaylor(double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width);
     void init_rest(double rho0);               // probtype 1 (LidDrivenCavity), Source/prob/prob_init.cpp:102-109
     void post_init(double stop_time);          // NavierStokes::post_init
     double step();                             // Amr::coarseTimeStep on one level: computeNewDt + advance

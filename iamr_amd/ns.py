@@ -118,6 +118,10 @@ class NavierStokes:
         self.h = C.c_void_p()
         check(lib().iamrx_ns_create(C.byref(geom), layout.h, C.byref(self.params), C.byref(self.opts), C.byref(self.h)))
 
+    def init_rayleightaylor(self, rho_1, rho_2, tra_1=0.0, tra_2=0.0, pertamp=0.0, interface_width=1.0):
+        check(lib().iamrx_ns_init_rayleightaylor(self.h, C.c_double(rho_1), C.c_double(rho_2), C.c_double(tra_1), C.c_double(tra_2),
+                                                 C.c_double(pertamp), C.c_double(interface_width)))
+
     def init_taylorgreen(self, vfac=1.0, a=1.0, b=1.0, c=0.0, rho0=1.0):
         check(lib().iamrx_ns_init_taylorgreen(self.h, C.c_double(vfac), C.c_double(a), C.c_double(b), C.c_double(c), C.c_double(rho0)))
 

@@ -15,6 +15,8 @@ def build(inp, lib, N, nranks=1):
     pb = pr["prob"]
     if pb["probtype"] == 1:
         ns.init_rest(pb["rho0"])
+    elif pb["probtype"] == 10:
+        ns.init_rayleightaylor(pb["rho_1"], pb["rho_2"], pb["tra_1"], pb["tra_2"], pb["pertamp"], pb["interface_width"])
     else:
         ns.init_taylorgreen(pb["vfac"], pb["a"], pb["b"], pb["c"], pb["rho0"])
     return ns, lay, g, pr

@@ -278,6 +278,8 @@ void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/Navi
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);
 int iamrx_ns_destroy(iamrx_ns ns);
 int iamrx_ns_init_taylorgreen(iamrx_ns ns, double vfac, double a, double b, double c, double rho0);  /* Source/prob/prob_init.cpp:509-560 */
+/* prob.probtype = 10, RayleighTaylor (Source/prob/prob_init.cpp:407-488) */
+int iamrx_ns_init_rayleightaylor(iamrx_ns ns, double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width);
 int iamrx_ns_init_rest(iamrx_ns ns, double rho0);          /* probtype 1, LidDrivenCavity (Source/prob/prob_init.cpp:102-109) */
 int iamrx_ns_post_init(iamrx_ns ns, double stop_time);     /* NavierStokes::post_init (Source/NavierStokes.cpp:1254-1299) */
 int iamrx_ns_step(iamrx_ns ns, double* dt_used);           /* computeNewDt + NavierStokes::advance (Source/NavierStokes.cpp:543-691) */

@@ -250,6 +250,8 @@ void orc_ns_destroy(orc_ns_state* s);
  * 4 Gp_new (3 comps,1 ghost), 5 Gp_old, 6..8 umac, 9 aofs */
 orc_fab* orc_ns_fab(orc_ns_state* s, int which);
 void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0);
+/* prob.probtype = 10 (Source/prob/prob_init.cpp:407-488, 3-D branch) */
+void orc_ns_init_rayleightaylor(orc_ns_state* s, double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width);
 /* NavierStokes::post_init sequence: initialVelocityProject, estimate dt, init_iter pressure iterations */
 void orc_ns_init_rest(orc_ns_state* s, double rho0);     /* probtype 1: LidDrivenCavity start */
 void orc_ns_test_set_extrap_scale(double v);            /* test hook, see orc_ns.c first_order_extrap */

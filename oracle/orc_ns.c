@@ -183,6 +183,28 @@ void orc_ns_last_stats(const orc_ns_state* s, orc_mg_stats* mac, orc_mg_stats* n
 }
 
 /* NavierStokes::init_TaylorGreen, reference Source/prob/prob_init.cpp:509-560 */
+void orc_ns_init_rayleightaylor(orc_ns_state* s, double rho_1, double rho_2, double tra_1, double tra_2, double pertamp, double interface_width)
+{
+    const double Pi = 3.14159265358979323846264338327950288;
+    orc_fab* S = S_NEW(s);
+    orc_setval(S, 0.0);
+    const orc_geom* g = &s->g;
+    const double Lx = g->dx[0] * g->n[0], Ly = g->dx[1] * g->n[1];
+    const double splitz = 0.5 * (g->problo[2] + (g->problo[2] + g->dx[2] * g->n[2]));
+    const double ranampl = 2. * (0.6544437533747718 - 0.5);
+    const double ranphse1 = 2. * Pi * 0.1556190326530211, ranphse2 = 2. * Pi * 0.4196144025537369;
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        const double x = g->problo[0] + (i + 0.5) * g->dx[0], y = g->problo[1] + (j + 0.5) * g->dx[1], z = g->problo[2] + (k + 0.5) * g->dx[2];
+        const double pert = ranampl * sin(2.0 * Pi * x / Lx + ranphse1) * sin(2.0 * Pi * y / Ly + ranphse2);
+        const double pertheight = splitz - pertamp * pert;
+        A4(S, i, j, k, Density) = rho_1 + ((rho_2 - rho_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+        A4(S, i, j, k, Tracer) = tra_1 + ((tra_2 - tra_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+    }
+    orc_setval(P_NEW(s), 0.0); orc_setval(P_OLD(s), 0.0);
+    orc_setval(GP_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0);
+    s->time = 0.0; s->nstep = 0;
+}
+
 void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0)
 {
     const orc_geom* g = &s->g;

@@ -35,7 +35,7 @@ def test_unsupported_features_are_rejected_loudly():
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["ns.lo_bc = 6 4 5"]).problem()          # not a physical BC type
     with pytest.raises(NotImplementedError):
-        Inputs([LDC], ["prob.probtype=10"]).problem()
+        Inputs([LDC], ["prob.probtype=7"]).problem()
     with pytest.raises(KeyError):
         Inputs([LDC], ["ns.some_unknown_knob=1"]).problem()
 
@@ -45,3 +45,10 @@ def test_inflow_outflow_keys():
     p = pr["params"]
     assert p["phys_lo"] == [1, 4, 5] and p["phys_hi"] == [2, 4, 5]
     assert p["wall_vel_lo"][:3] == [1.0, 0.0, 0.0] and p["scal_bc_lo"][:2] == [1.0, 0.25] and p["scal_bc_hi"] == [0.0] * 6
+
+
+def test_rayleightaylor_keys():
+    pr = Inputs([LDC], ["prob.probtype=10", "prob.rho_1=2.0", "prob.rho_2=1.0", "prob.tra_1=1.0", "prob.interface_width=0.05",
+                        "prob.perturbation_amplitude=0.1", "ns.gravity=-9.8"]).problem()
+    assert pr["prob"] == dict(probtype=10, rho_1=2.0, rho_2=1.0, tra_1=1.0, tra_2=0.0, pertamp=0.1, interface_width=0.05)
+    assert pr["params"]["gravity"] == -9.8

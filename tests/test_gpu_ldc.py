@@ -235,3 +235,38 @@ def test_symmetry_plane_reproduces_half_of_a_symmetric_periodic_flow(gpu):
     SH = nsH.data(N.NavierStokes.S_NEW).gather_valid((16, 16, 16))
     assert np.abs(SH - SF[:16]).max() <= 1e-8
     assert np.abs(SF[..., 0]).max() > 0.5
+
+
+def test_rayleigh_taylor_matches_oracle(orc, gpu):
+    """BASELINE config C5 reduced to its single-level physics at a size the oracle finishes quickly: probtype 10 (tanh density /
+    tracer interface with the reference's hard-coded perturbation), gravity, slip walls in z, periodic x / y, variable density in
+    both projections, forces in the transverse terms (godunov.use_forces_in_trans = 1 as in regtest.3d.rayleightaylor)"""
+    from iamr_amd import ns as N
+    lib = gpu
+    L = orc.lib()
+    n, per, prob_lo, prob_hi = (16, 16, 32), (1, 1, 0), (0.0, 0.0, 0.0), (1.0, 1.0, 2.0)
+    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=3, gravity=-9.8, use_forces_in_trans=1)
+    rt = dict(rho_1=1.0, rho_2=2.0, tra_1=1.0, tra_2=0.0, pertamp=0.1, interface_width=0.08)
+    # oracle
+    g_o = orc.geom(n, problo=prob_lo, probhi=prob_hi, periodic=per)
+    p = oracle_params(orc, per, (0, 0, 4), (0, 0, 4), [0.0] * 9, **kw)
+    o = orc.mg_opts()
+    s = C.c_void_p(L.orc_ns_create(C.byref(g_o), C.byref(p), C.byref(o)))
+    L.orc_ns_init_rayleightaylor(s, *[C.c_double(rt[k]) for k in ("rho_1", "rho_2", "tra_1", "tra_2", "pertamp", "interface_width")])
+    L.orc_ns_post_init(s, C.c_double(-1.0))
+    dts_o = [L.orc_ns_step(s) for _ in range(3)]
+    S_o = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+    L.orc_ns_destroy(s)
+    # product, two boxes in z
+    g_d = lib.Geom.make(n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per)
+    lay = lib.Layout.decompose(n, 16)
+    ns = N.NavierStokes(g_d, lay, N.ns_params(phys_lo=[0, 0, 4], phys_hi=[0, 0, 4], **kw))
+    ns.init_rayleightaylor(**rt)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(3)]
+    assert np.allclose(dts, dts_o, rtol=1e-9, atol=0)
+    S = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
+    for comp in range(5):
+        scale = max(np.abs(S_o[..., comp]).max(), 1e-3)
+        assert np.abs(S[..., comp] - S_o[..., comp]).max() <= 1e-8 * scale, comp
+    assert np.abs(S[..., 2]).max() > 1e-3 and S[..., 3].min() > 0.99 and S[..., 3].max() < 2.01     # the heavy fluid starts to fall
