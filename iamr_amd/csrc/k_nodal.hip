@@ -223,16 +223,17 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
     return g < lo ? g + n : (g > hi ? g - n : g);
 }
 
-template <int TX, int TY, int NT, bool WRAP, bool MASK>
+template <int TX, int TY, int NT, bool WRAP, bool MASK, bool CSIG>
 __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk,
-    const FabD* __restrict__ dmt)
+    const FabD* __restrict__ dmt, double csig)
 {
     // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
     // column, so its 64 lanes then read consecutive doubles (no bank conflicts) instead of a stride-2 pattern.
     constexpr int RX = TX + 8, RY = TY + 8, HX = RX / 2, PX = RX + 2;   // PX: padded row pitch
     __shared__ double X[3][RY][PX];
-    __shared__ double S[2][RY][PX];
+    // CSIG: sigma is one constant on the whole level (constant-density flow): no sigma planes in LDS (24 KB per workgroup: 6 per CU)
+    __shared__ double S[CSIG ? 1 : 2][CSIG ? 1 : RY][CSIG ? 1 : PX];
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
     int tix, tiy, pk;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
         // stage the footprint: all global loads are issued before the first LDS store (addresses are clamped into the
         // arrays instead of predicated -- footprint points beyond the ghost width are never used by the colour passes)
         constexpr int NLD = (RX * RY + NT - 1) / NT;
-        double v[NLD][5];
+        double v[NLD][CSIG ? 3 : 5];
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int idx = min(tid + it * NT, RX * RY - 1);
@@ -307,8 +308,10 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
             v[it][0] = xn(xi, xj, xkm);
             v[it][1] = x(xi, xj, k);
             v[it][2] = xn(xi, xj, xkp);
-            v[it][3] = s(si, sj, skm);
-            v[it][4] = s(si, sj, sk0);
+            if constexpr (!CSIG) {
+                v[it][3] = s(si, sj, skm);
+                v[it][4] = s(si, sj, sk0);
+            }
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
                 const int lx = idx % RX, ly = idx / RX;
                 const int cl = COL(lx);
                 X[0][ly][cl] = v[it][0]; X[1][ly][cl] = v[it][1]; X[2][ly][cl] = v[it][2];
-                S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4];
+                if constexpr (!CSIG) { S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4]; }
             }
         }
     }
@@ -328,8 +331,13 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
             const int i = pi[c], j = pj[c];
             const int lx = i - ox, ly = j - oy;
             const int c0 = COL(lx), cm = COL(lx - 1), cp = COL(lx + 1);
-            const double smmm = S[0][ly - 1][cm], spmm = S[0][ly - 1][c0], smpm = S[0][ly][cm], sppm = S[0][ly][c0];
-            const double smmp = S[1][ly - 1][cm], spmp = S[1][ly - 1][c0], smpp = S[1][ly][cm], sppp = S[1][ly][c0];
+            // CSIG: the same expression tree on eight copies of the constant -- bit-identical to the variable-sigma path
+            double smmm, spmm, smpm, sppm, smmp, spmp, smpp, sppp;
+            if constexpr (CSIG) { smmm = spmm = smpm = sppm = smmp = spmp = smpp = sppp = csig; }
+            else {
+                smmm = S[0][ly - 1][cm]; spmm = S[0][ly - 1][c0]; smpm = S[0][ly][cm]; sppm = S[0][ly][c0];
+                smmp = S[1][ly - 1][cm]; spmp = S[1][ly - 1][c0]; smpp = S[1][ly][cm]; sppp = S[1][ly][c0];
+            }
             const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
             const double xc = X[1][ly][c0];
             double y = xc * s0;
@@ -355,7 +363,7 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 
 template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap, const MultiFab* dmask)
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig)
 {
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
@@ -368,16 +376,14 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
         gx = 8u * (unsigned)(maxcnt * npl);
     }
     dim3 grid(gx, (unsigned)l.nlocal());
+#define IAMRX_GS4(W, M, C) hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
+                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
     if (dmask) {
-        IAMRX_ASSERT(!wrap && dmask->ngrow >= 3);
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false, true>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
-                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask->d_tab);
-    } else if (wrap)
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, true, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
-                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, nullptr);
-    else
-        hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, false, false>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, xo.d_tab,
-                           rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, nullptr);
+        IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
+        IAMRX_GS4(false, true, false);
+    } else if (wrap) { if (csig) IAMRX_GS4(true, false, true); else IAMRX_GS4(true, false, false); }
+    else { if (csig) IAMRX_GS4(false, false, true); else IAMRX_GS4(false, false, false); }
+#undef IAMRX_GS4
 }
 
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
@@ -393,7 +399,7 @@ bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
 }
 
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap,
-                         const MultiFab* dmask)
+                         const MultiFab* dmask, const double* csig)
 {
     const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
@@ -403,8 +409,8 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
     static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 0);
-    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask);
-    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask);
+    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
+    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
 }
 
 // ------------------------------------------------------------------------------------------------------

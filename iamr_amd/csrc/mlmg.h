@@ -147,6 +147,8 @@ private:
     DomainBC m_bc;
     MGOpts m_o;
     bool m_singular = true;
+    bool m_csig = false;           // sigma is one constant on every level (constant density): the smoother skips the sigma planes
+    double m_csig_val = 0.0;
     bool m_masked = false;         // some nodes are Dirichlet nodes (outflow faces / level boundary inside the domain)
     std::vector<Level> m_lev;
 };

@@ -116,6 +116,18 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
         m_lev[l].sig.FillBoundary(m_lev[l].g);
         cc_mirror_bc(m_lev[l].g, m_lev[l].sig);
     }
+    // Constant sigma (constant-density flow, the common IAMR case): every coarsened level then holds the same constant (the average
+    // of 8 equal numbers is exact) and periodic / mirrored ghost cells too, so the smoother can take sigma from a register instead
+    // of staging two sigma planes per node plane.  Same expression tree => bit-identical results.  IAMRX_NODAL_CSIG=0 disables.
+    static const bool csig_on = !(getenv("IAMRX_NODAL_CSIG") && atoi(getenv("IAMRX_NODAL_CSIG")) == 0);
+    m_csig = false;
+    if (csig_on && !m_masked) {
+        const double smax = m_lev[0].sig.norm0(0, 1, 0);
+        MultiFab t(m_lev[0].layout, cell_type(), 1, 0);
+        MultiFab::Copy(t, m_lev[0].sig, 0, 0, 1, 0);
+        mf_add_scalar(t, -smax, 0, 1, 0);
+        if (smax > 0.0 && t.norm0(0, 1, 0) == 0.0) { m_csig = true; m_csig_val = smax; }
+    }
 }
 
 // ghost nodes: same-level + periodic images, then even reflection about Neumann walls
@@ -156,9 +168,10 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         static const bool par_fill = !(getenv("IAMRX_NODAL_PARITY_FILL") && atoi(getenv("IAMRX_NODAL_PARITY_FILL")) == 0);
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
             if (!wrap) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk);      // even planes: a -> b
+            const double* cs = m_csig ? &m_csig_val : nullptr;
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs);      // even planes: a -> b
             if (!wrap) fillbc(l, *b, par_fill ? 0 : -1);                     // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk);      // odd planes: centre from a, neighbours from b
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
