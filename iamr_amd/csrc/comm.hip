@@ -9,9 +9,10 @@
 //                   buffers.  Used by the tests to run the *same* rank-aware code with torch.distributed
 //                   (gloo) as transport, including two ranks sharing one GPU.
 //
-// STATUS (round 1): exercised by tests/test_gpu_dist.py through CallbackComm (2 ranks on one GPU, results
-// identical to 1 rank); the RCCL transport is written to the same interface but could not be executed in
-// this round (the development box has a single GPU).
+// STATUS (round 1): the rank-aware code is exercised by tests/test_gpu_dist.py through CallbackComm (2 and 4 ranks on one GPU,
+// results identical to 1 rank).  The RCCL back end runs on the 1-GPU box with a 1-rank communicator: ncclGetUniqueId /
+// ncclCommInitRank / ncclAllReduce under two full time steps, and grouped ncclSend / ncclRecv as a loop-back to the own rank
+// (iamrx_comm_probe_exchange).  Peer-to-peer between two GPUs could not be executed in this round.
 #include "mf.h"
 #include "../../include/iamrx.h"
 #include <dlfcn.h>
@@ -153,6 +154,31 @@ int iamrx_comm_rank(int* rank, int* nranks)
     if (rank) *rank = c ? c->rank : 0;
     if (nranks) *nranks = c ? c->nranks : 1;
     return 0;
+}
+// transport probe: every rank sends `count` doubles to `peer` and receives as many from it through the installed communicator's
+// exchange() (the halo-exchange primitive); peer == own rank is a loop-back through the same Send / Recv calls.  Returns 0 if the
+// received data are the pattern the peer sent.
+int iamrx_comm_probe_exchange(int peer, long count)
+{
+    try {
+        auto& ctx = Context::get();
+        IAMRX_ASSERT(ctx.comm && count > 0);
+        const int me = ctx.comm->rank;
+        std::vector<double> h((size_t)count), back((size_t)count, -1.0);
+        for (long i = 0; i < count; ++i) h[(size_t)i] = 1000.0 * me + 0.5 * (double)i;
+        double* ds = (double*)ctx.alloc((size_t)count * sizeof(double));
+        double* dr = (double*)ctx.alloc((size_t)count * sizeof(double));
+        IAMRX_HIP_CHECK(hipMemcpy(ds, h.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+        IAMRX_HIP_CHECK(hipMemset(dr, 0, (size_t)count * sizeof(double)));
+        std::vector<Message> sends{{peer, ds, (size_t)count}}, recvs{{peer, dr, (size_t)count}};
+        ctx.comm->exchange(sends, recvs, ctx.stream);
+        ctx.sync();
+        IAMRX_HIP_CHECK(hipMemcpy(back.data(), dr, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+        ctx.free(ds); ctx.free(dr);
+        for (long i = 0; i < count; ++i)
+            if (back[(size_t)i] != 1000.0 * peer + 0.5 * (double)i) throw Error("iamrx_comm_probe_exchange: wrong data received");
+        return 0;
+    } catch (const std::exception& e) { g_cerr = e.what(); return 1; }
 }
 const char* iamrx_comm_last_error(void) { return g_cerr.c_str(); }
 

@@ -83,6 +83,8 @@ typedef void (*iamrx_exchange_cb)(int nsend, const int* send_peers, double** sen
                                   int nrecv, const int* recv_peers, double** recv_bufs, const long* recv_counts);
 int iamrx_comm_init_callback(int rank, int nranks, iamrx_allreduce_cb ar, iamrx_exchange_cb ex);
 int iamrx_comm_rank(int* rank, int* nranks);
+/* transport probe: exchange `count` doubles with `peer` through the installed communicator (peer == own rank: loop-back); 0 = data intact */
+int iamrx_comm_probe_exchange(int peer, long count);
 const char* iamrx_comm_last_error(void);
 
 /* ---- containers (amrex::BoxArray/DistributionMapping/MultiFab role) ----------- */

@@ -134,3 +134,47 @@ def test_bench_script_multi_rank_path(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["cells"] == 2 * 32 ** 3 and "cpu_baseline" not in d and d["transport"].startswith("gloo")
     assert abs(d["value"] - d["config"]["cells"] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def _rccl_single(rank, out_dir):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    from iamr_amd import lib
+    from iamr_amd import ns as NS
+    lib.init(0)
+    Lb = lib.lib()
+    Lb.iamrx_comm_last_error.restype = C.c_char_p
+    buf = (C.c_char * 128)()
+    assert Lb.iamrx_comm_get_unique_id(buf) == 0, Lb.iamrx_comm_last_error()
+    assert Lb.iamrx_comm_init_rccl(buf, 0, 1) == 0, Lb.iamrx_comm_last_error()
+    # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, looped back to the own rank
+    assert Lb.iamrx_comm_probe_exchange(0, C.c_long(100000)) == 0, Lb.iamrx_comm_last_error()
+    n = (16, 16, 16)
+    g = lib.Geom.make(n)
+    lay = lib.Layout.decompose(n, 8)
+    ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(2)]
+    S = ns.data(NS.NavierStokes.S_NEW).gather_valid(n)
+    np.savez(os.path.join(out_dir, "rccl1.npz"), dts=np.array(dts), S=S)
+
+
+def test_rccl_transport_single_rank(tmp_path):
+    """the RCCL back end itself (dlopen of librccl, ncclGetUniqueId / ncclCommInitRank / ncclAllReduce through the resolved
+    symbols) with a 1-rank communicator: every reduction of two time steps goes through ncclAllReduce; same result as the serial
+    communicator; the halo-exchange primitive (grouped ncclSend / ncclRecv) is exercised as a loop-back to the own rank."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_single, args=(str(tmp_path),), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), "rccl1.npz"))
+    sys.path.insert(0, ROOT)
+    from iamr_amd import lib
+    from iamr_amd import ns as NS
+    lib.init(0)
+    n = (16, 16, 16)
+    ns = NS.NavierStokes(lib.Geom.make(n), lib.Layout.decompose(n, 8), NS.ns_params(cfl=0.5, visc_coef=1e-2))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(2)]
+    assert np.array_equal(np.array(dts), z["dts"])
+    assert np.array_equal(ns.data(NS.NavierStokes.S_NEW).gather_valid(n), z["S"])
