@@ -660,6 +660,18 @@ int iamrx_fluxreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom*
     IAMRX_CATCH
 }
 int iamrx_fluxreg_destroy(iamrx_fluxreg fr) { IAMRX_TRY delete fr; IAMRX_CATCH }
+int iamrx_mac_sync_solve(const iamrx_geom* g, iamrx_fluxreg mac_reg, iamrx_mf rho_half, double dt, iamrx_layout fine, int ratio,
+                         iamrx_mf ux, iamrx_mf uy, iamrx_mf uz, iamrx_mf mac_sync_phi, const int lobc[3], const int hibc[3],
+                         double tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    MultiFab* uc[3] = {&ux->mf, &uy->mf, &uz->mf};
+    MGStats s = mac_sync_solve(to_geom(g), *mac_reg->fr, rho_half->mf, dt, fine->p, ratio, uc, mac_sync_phi->mf, to_bc(lobc, hibc, op.maxorder),
+                               tol, abs_tol, op);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
 int iamrx_fluxreg_setval(iamrx_fluxreg fr, double v) { IAMRX_TRY fr->fr->setVal(v); IAMRX_CATCH }
 int iamrx_fluxreg_crse_init(iamrx_fluxreg fr, iamrx_mf flux, int dir, int scomp, int dcomp, int ncomp, double mult, int add)
 {

@@ -35,4 +35,31 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
     return st;
 }
 
+// MacProj::mac_sync_solve (Source/MacProj.cpp:359-470): the coarse-level correction of the MAC velocity for the mismatch between the
+// coarse and the (time-averaged) fine face velocities on the coarse/fine interface.  mr: the level's mac register after
+// CrseInit(u_mac * area, -1) and the FineAdd(u_mac * area, 1/ncycle) of the fine sub-steps.
+//   Rhs = Reflux(mr, scale -1) on the coarse cells next to the fine grids, 0 under them;  Rhs.negate();
+//   solve -div(b grad phi) = Rhs with b = (dt/2)/rho_half on faces, no velocity;  Ucorr = -(-b grad phi)
+MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_half, double dt, LayoutP fine_layout, int ratio,
+                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts)
+{
+    LayoutP layout = mac_sync_phi.layout;
+    MultiFab Rhs(layout, cell_type(), 1, 0);
+    Rhs.setVal(0.0);
+    mr.Reflux(Rhs, g.dx[0] * g.dx[1] * g.dx[2], -1.0, 0, 0, 1);
+    {
+        MultiFab fz(fine_layout, cell_type(), 1, 0);      // zero under the fine grids (MacProj.cpp:395-415)
+        fz.setVal(0.0);
+        average_down(fz, Rhs, 0, 1, ratio);
+    }
+    mac_sync_phi.setVal(0.0);
+    mf_mult(Rhs, -1.0, 0, 1, 0);
+    MultiFab um[3];
+    MultiFab* ump[3];
+    for (int d = 0; d < 3; ++d) { um[d].define(layout, face_type(d), 1, 0); um[d].setVal(0.0); ump[d] = &um[d]; }
+    MGStats st = mlmg_mac_solve(g, ump, rho_half, 0, &Rhs, mac_sync_phi, 2.0 / dt, bc, tol, abs_tol, opts, Ucorr);
+    for (int d = 0; d < 3; ++d) mf_mult(*Ucorr[d], -1.0, 0, 1, 0);
+    return st;
+}
+
 }  // namespace iamrx

@@ -35,6 +35,11 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
 // ---- inter-level data motion (amr.hip) ------------------------------------------------------------------------
 // amrex::MultiFab::ParallelCopy between different layouts of one index space; periodic_geom != nullptr adds the periodic images
 // add = true: dst += src (MultiFab::ParallelAdd); the source regions must then map to disjoint destination cells
+class FluxRegister;
+// MacProj::mac_sync_solve (Source/MacProj.cpp:359-470)
+MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_half, double dt, LayoutP fine_layout, int ratio,
+                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts);
+
 // ---- regrid.hip: error estimation + grid generation
 void derive_mag_vort(const Geometry& g, MultiFab& out, int ocomp, const MultiFab& vel, int vcomp);
 void error_tag(const Geometry& g, MultiFab& tags, const MultiFab& field, int comp, int mode, double value, int level,

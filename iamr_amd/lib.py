@@ -385,6 +385,17 @@ def cluster_tags(geom, tags, blocking_factor=8, max_grid_size=32, grid_eff=0.7, 
     return [(tuple(buf[6 * q:6 * q + 3]), tuple(buf[6 * q + 3:6 * q + 6])) for q in range(nb.value)]
 
 
+def mac_sync_solve(geom, mac_reg, rho_half, dt, fine_layout, ucorr, mac_sync_phi, ratio=2, lobc=(0, 0, 0), hibc=(0, 0, 0),
+                   tol=1e-10, abs_tol=1e-16, opts=None):
+    """MacProj::mac_sync_solve (Source/MacProj.cpp:359-470)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts(maxorder=4)
+    check(lib().iamrx_mac_sync_solve(C.byref(geom), mac_reg.h, _h(rho_half), C.c_double(dt), fine_layout.h, ratio, _h(ucorr[0]), _h(ucorr[1]),
+                                     _h(ucorr[2]), _h(mac_sync_phi), i3(lobc), i3(hibc), C.c_double(tol), C.c_double(abs_tol), C.byref(o),
+                                     C.byref(st)))
+    return st
+
+
 def mac_divergence(geom, div, umac):
     check(lib().iamrx_mac_divergence(C.byref(geom), div.h, umac[0].h, umac[1].h, umac[2].h))
 

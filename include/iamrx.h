@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 typedef struct iamrx_layout_s* iamrx_layout;   /* BoxArray + DistributionMapping of one level */
+typedef struct iamrx_fluxreg_s* iamrx_fluxreg; /* amrex::FluxRegister of one coarse/fine interface (see below) */
 typedef struct iamrx_mf_s* iamrx_mf;           /* MultiFab (device resident) */
 typedef struct iamrx_ns_s* iamrx_ns;           /* NavierStokes level object */
 
@@ -149,6 +150,13 @@ int iamrx_mlmg_mac_solve_cf(const iamrx_geom* g, iamrx_mf umac_x, iamrx_mf umac_
                             iamrx_mf S /* may be NULL */, iamrx_mf mac_phi, double rhs_scale, const int lobc[3], const int hibc[3],
                             iamrx_mf crse_phi, const iamrx_geom* cgeom, int ratio, double mac_tol, double mac_abs_tol,
                             const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* MacProj::mac_sync_solve (Source/MacProj.cpp:359-470): coarse-level solve for the correction velocity that removes the mismatch between
+ * the coarse MAC velocity and the fine one on the coarse/fine interface.  mac_reg: the interface's register after
+ * CrseInit(u_mac_crse, mult = -area_crse) and FineAdd(u_mac_fine, mult = +area_fine / ncycle) (Source/MacProj.cpp:306-346);
+ * ucorr_*: coarse face arrays (out), mac_sync_phi: coarse cells, 1 ghost (out); fine: the fine level's layout. */
+int iamrx_mac_sync_solve(const iamrx_geom* g, iamrx_fluxreg mac_reg, iamrx_mf rho_half, double dt, iamrx_layout fine, int ratio,
+                         iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z, iamrx_mf mac_sync_phi, const int lobc[3], const int hibc[3],
+                         double mac_sync_tol, double mac_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
 /* MacProj::check_div_cond (Source/MacProj.cpp:792-846): div = div(u_mac) */
 int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z);
 
@@ -232,7 +240,6 @@ int iamrx_create_umac_grown(iamrx_mf umac_fine_x, iamrx_mf umac_fine_y, iamrx_mf
  * viscous: Source/NavierStokes.cpp:975-992, Source/Diffusion.cpp:940-953; consumer NavierStokes::reflux, Source/NavierStokes.cpp:1736-1838).
  * Fluxes are extensive (area-weighted) as in IAMR.  crse_init: reg = (add: +=) mult*coarse flux; fine_add: reg += mult * sum of the fine
  * fluxes of a coarse face; reflux: S(outside coarse cell) -=/+= scale*reg/volume on the low/high side of a fine box (periodic images incl.) */
-typedef struct iamrx_fluxreg_s* iamrx_fluxreg;
 int iamrx_fluxreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom* cgeom, int ratio, int ncomp, iamrx_fluxreg* out);
 int iamrx_fluxreg_destroy(iamrx_fluxreg fr);
 int iamrx_fluxreg_setval(iamrx_fluxreg fr, double v);

@@ -378,3 +378,71 @@ def test_create_umac_grown_on_refined_level_matches_oracle(orc, gpu):
     assert np.abs(div[0, 1:-1, 1:-1]).max() < 1e-10 and np.abs(div[-1, 1:-1, 1:-1]).max() < 1e-10
     assert np.abs(div[1:-1, 0, 1:-1]).max() < 1e-10 and np.abs(div[1:-1, 1:-1, -1]).max() < 1e-10
     assert np.abs(div[1:-1, 1:-1, 1:-1]).max() > 1.0            # the (random) interior is not divergence free: the fix is what zeroed the ring
+
+
+def test_mac_sync_solve_makes_the_composite_mac_field_divergence_free(gpu):
+    """MacProj::mac_sync_solve (Source/MacProj.cpp:359-470) on a 2-level hierarchy: coarse MAC projection (periodic 16^3), fine MAC
+    projection on a refined box with the coarse phi on its coarse/fine faces, mac register = fine - coarse face velocity on the
+    interface (CrseInit -area, FineAdd +area).  The pin: the divergence of the coarse cells next to the fine grid, evaluated with the
+    fine fluxes on the shared faces, is the register's reflux; adding the sync correction Ucorr as IAMR applies it (the coarse field
+    advects with u_mac - ... see below) removes it to solver tolerance."""
+    lib = gpu
+    ncr, nf = 16, 32
+    nc, n = (ncr,) * 3, (nf,) * 3
+    gc, gf = lib.Geom.make(nc), lib.Geom.make(n)
+    clay = lib.Layout.decompose(nc, 8)
+    fboxes = [((8, 8, 8), (23, 23, 23))]
+    flay = lib.Layout(fboxes)
+    dt = 0.01
+
+    def face_field(nn, d, seed):
+        t = [1 if e == d else 0 for e in range(3)]
+        ax = [(np.arange(-1, nn + t[e] + 1) + (0.0 if t[e] else 0.5)) / nn for e in range(3)]
+        X, Y, Z = np.meshgrid(*ax, indexing="ij")
+        ph = np.random.default_rng(seed).uniform(0, 2 * np.pi, 3)
+        return (np.sin(2 * np.pi * X + ph[0]) * np.cos(2 * np.pi * Y + ph[1]) + 0.5 * np.cos(2 * np.pi * Z + ph[2]))[..., None]
+
+    def rho_cc(nn):
+        x = (np.arange(-1, nn + 1) + 0.5) / nn
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        return (1.0 + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y))[..., None]
+
+    umc = [lib.MultiFab(clay, lib.face(d), 1, 1) for d in range(3)]
+    umf = [lib.MultiFab(flay, lib.face(d), 1, 1) for d in range(3)]
+    for d in range(3):
+        umc[d].set_from_global(face_field(ncr, d, 10 + d), (-1, -1, -1))
+        umf[d].set_from_global(face_field(nf, d, 10 + d) + 0.05 * face_field(nf, d, 40 + d), (-1, -1, -1))
+    rhoc = lib.MultiFab(clay, lib.CELL, 1, 1); rhoc.set_from_global(rho_cc(ncr), (-1, -1, -1))
+    rhof = lib.MultiFab(flay, lib.CELL, 1, 1); rhof.set_from_global(rho_cc(nf), (-1, -1, -1))
+    phic = lib.MultiFab(clay, lib.CELL, 1, 1); phic.setval(0.0)
+    phif = lib.MultiFab(flay, lib.CELL, 1, 1); phif.setval(0.0)
+    lib.mlmg_mac_solve(gc, umc, rhoc, 0, None, phic, 2.0 / dt, mac_tol=1e-12)
+    lib.mlmg_mac_solve_cf(gf, umf, rhof, 0, None, phif, 2.0 / dt, phic, gc, 2, mac_tol=1e-12)
+    dc = 1.0 / ncr
+    area_c, area_f, vol_c = dc * dc, (dc / 2) ** 2, dc ** 3
+    mr = lib.FluxRegister(flay, clay, gc, 2, 1)
+    mr.setVal(0.0)
+    for d in range(3):
+        mr.CrseInit(umc[d], d, 0, 0, 1, -area_c)
+        mr.FineAdd(umf[d], d, 0, 0, 1, area_f)
+    # composite divergence of the unsynced coarse field = reflux of the register (coarse field itself is divergence free)
+    comp0 = lib.MultiFab(clay, lib.CELL, 1, 0)
+    lib.mac_divergence(gc, comp0, umc)
+    assert comp0.norm0() <= 1e-9
+    mr.Reflux(comp0, vol_c, -1.0, 0, 0, 1)
+    mismatch = comp0.norm0()
+    assert mismatch > 1e-2                                   # the two levels do disagree on the interface
+    ucorr = [lib.MultiFab(clay, lib.face(d), 1, 0) for d in range(3)]
+    sync_phi = lib.MultiFab(clay, lib.CELL, 1, 1)
+    st = lib.mac_sync_solve(gc, mr, rhoc, dt, flay, ucorr, sync_phi, tol=1e-11)
+    assert st.converged
+    # D(Ucorr) equals the interface mismatch on the cells outside the fine grid (and vanishes elsewhere): u_mac - Ucorr is the
+    # coarse velocity consistent with the fine one, the field mac_sync_compute re-advects with
+    dU = lib.MultiFab(clay, lib.CELL, 1, 0)
+    lib.mac_divergence(gc, dU, ucorr)
+    D = dU.gather_valid(nc)[..., 0]
+    R = comp0.gather_valid(nc)[..., 0]
+    under = np.zeros(nc, bool)
+    under[4:12, 4:12, 4:12] = True
+    assert np.abs(D - R)[~under].max() <= 1e-8 * mismatch
+    assert np.abs(D[under]).max() <= 1e-8 * mismatch
