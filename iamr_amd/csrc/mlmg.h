@@ -91,7 +91,6 @@ private:
     void subtract_mean(int l, MultiFab& mf);
     Geometry m_g;
     int m_ncomp;
-    DomainBC m_bc;
     std::vector<DomainBC> m_bcn;
     MGOpts m_o;
     double m_alpha = 0.0, m_beta = 1.0;

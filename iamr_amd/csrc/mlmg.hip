@@ -20,7 +20,7 @@ long mg_agglomeration_cells()
 }
 
 CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
-    : m_g(g), m_ncomp(ncomp), m_bc(bc), m_o(o)
+    : m_g(g), m_ncomp(ncomp), m_o(o)
 {
     m_bcn.assign(1, bc);
     m_lev.resize(1);
@@ -272,7 +272,6 @@ void CellMG::bottom_solve(MGStats& st)
     Level& L = m_lev[l];
     L.cor.setVal(0.0);
     if (m_o.bottom_smoother_only) {
-        bool skip = true;
         smooth_n(l, L.cor, L.res, m_o.nuf, true);
         return;
     }
