@@ -540,6 +540,7 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     for (int i = 0; i < 3; ++i) { p->phys_lo[i] = d.phys_lo[i]; p->phys_hi[i] = d.phys_hi[i]; }
     for (int i = 0; i < 9; ++i) { p->wall_vel_lo[i] = d.wall_vel_lo[i]; p->wall_vel_hi[i] = d.wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { p->scal_bc_lo[i] = d.scal_bc_lo[i]; p->scal_bc_hi[i] = d.scal_bc_hi[i]; }
+    p->do_cons_trac = d.do_cons_trac;
 }
 
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
@@ -555,7 +556,7 @@ int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* 
     for (int i = 0; i < 3; ++i) { q.phys_lo[i] = p->phys_lo[i]; q.phys_hi[i] = p->phys_hi[i]; }
     for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
-    if (q.do_mom_diff) throw Error("iamrx: do_mom_diff = 1 not implemented in this round");
+    q.do_cons_trac = p->do_cons_trac;
     auto* h = new iamrx_ns_s;
     h->ns = std::make_unique<NavierStokes>(to_geom(g), l->p, q, to_opts(o));
     for (auto& v : h->views) v = nullptr;

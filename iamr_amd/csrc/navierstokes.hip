@@ -23,7 +23,7 @@
 //   physical BC tables                      NS_BC.H:7-55, NS_setup.cpp:21-128, NS_bcfill.H:17-180
 // Scope of this round: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls
 // through xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, divu = 0, NUM_STATE = 5
-// (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
+// (u,v,w,rho,tracer), do_mom_diff = 0 or 1, Godunov_PLM.
 #include "operators.h"
 #include "launch.h"
 #include <cmath>
@@ -244,12 +244,23 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
 }
 
 // NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0): visc = div(beta grad S(time))
+// y(comp 0) *= x(xcomp) or /= x(xcomp), ng ghost cells included
+static void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool divide)
+{
+    const FabD *yt = y.d_tab, *xt = x.d_tab;
+    for_each(*y.layout, cell_type(), ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const double r = xt[f](i, j, k, xcomp);
+        if (divide) yt[f](i, j, k, 0) /= r; else yt[f](i, j, k, 0) *= r;
+    });
+}
+
 void NavierStokes::get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata)
 {
     visc.setVal(1.e40);
     if (!is_diffusive_tracer()) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 1, 1);
     fillpatch(stmp, Sdata, Tracer, 1, &bc_scal[1]);
+    if (p.do_cons_trac) scale_by(stmp, rho_ptime, 0, 1, true);    // rho_flag 2 (Diffusion.cpp:1612-1615): div beta grad(S/rho), old time
     MGOpts mo;
     mo.max_coarsening_level = 0;       // info.setMaxCoarseningLevel(0) (Diffusion.cpp:1574)
     mo.maxorder = 2;
@@ -358,8 +369,19 @@ void NavierStokes::velocity_advection(double dt_)
 {
     SectionTimer tm(*this, 2);
     MultiFab& So = S[1 - inew];
+    const bool mom = p.do_mom_diff != 0;
     MultiFab Umf(layout, cell_type(), 3, 3);
     fillpatch(Umf, So, Xvel, 3, bc_vel);
+    if (mom) {
+        // NavierStokesBase.cpp:3397-3413: the advected state is the momentum rho^n u^n, ghost cells included
+        MultiFab Rmf(layout, cell_type(), 1, 3);
+        fillpatch(Rmf, So, Density, 1, bc_scal);
+        const FabD *ut = Umf.d_tab, *rt = Rmf.d_tab;
+        for_each(*layout, cell_type(), 3, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double r = rt[f](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) *= r;
+        });
+    }
     MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
     fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
     MultiFab visc(layout, cell_type(), 3, 1);
@@ -374,12 +396,13 @@ void NavierStokes::velocity_advection(double dt_)
             for (int n = 0; n < 3; ++n) {
                 const double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
                 double t = fr + vt[f](i, j, k, n) - gt[f](i, j, k, n);
-                t /= rho;
+                if (!mom) t /= rho;                     // NavierStokesBase.cpp:3459-3466: convective form only
                 tt[f](i, j, k, n) = t;
             }
         });
     }
-    const int iconserv[3] = {0, 0, 0};
+    const int ic = mom ? 1 : 0;                         // NS_setup.cpp:297-301: velocity advectionType = Conservative
+    const int iconserv[3] = {ic, ic, ic};
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, nullptr);
 }
@@ -398,13 +421,15 @@ void NavierStokes::scalar_advection(double dt_)
     {
         // getForce = 0; density is not diffusive; keep the reference's arithmetic
         const FabD *tt = tf.d_tab, *st = Smf.d_tab, *vt = visc.d_tab;
+        const bool cons = p.do_cons_trac != 0;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = st[f](i, j, k, 0);
             tt[f](i, j, k, 0) += 0.0;                                               // conservative: tf += visc
-            tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + vt[f](i, j, k, 0);         // convective: tf/rho + visc
+            if (cons) tt[f](i, j, k, 1) += vt[f](i, j, k, 0);                        // NavierStokes.cpp:780-792
+            else tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + vt[f](i, j, k, 0);    // convective: tf/rho + visc
         });
     }
-    const int iconserv[2] = {1, 0};
+    const int iconserv[2] = {1, p.do_cons_trac ? 1 : 0};                            // NS_setup.cpp:304-310
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr);
 }
@@ -431,7 +456,7 @@ void NavierStokes::scalar_update_tracers(double dt_)
     const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab;
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         const double rho = ot[f](i, j, k, Density) - 0.5 * dt_ * at[f](i, j, k, Density);
-        const double tfv = 0.0;
+        const double tfv = 0.0;               // getForce = 0 for the tracer: the conservative form (+ tf, no 1/rho; NavierStokesBase.cpp:2889) gives the same value
         nt[f](i, j, k, Tracer) = ot[f](i, j, k, Tracer) + dt_ * (-at[f](i, j, k, Tracer) + tfv / rho);
     });
 }
@@ -442,6 +467,7 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     if (!is_diffusive_tracer()) return;
     SectionTimer tm(*this, 4);
     const double theta = p.be_cn_theta;
+    const bool cons = p.do_cons_trac != 0;                       // diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308)
     MultiFab& Sn = S[inew];
     MultiFab& So = S[1 - inew];
     const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
@@ -449,6 +475,11 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 1, 1);
         fillpatch(Soln0, So, Tracer, 1, &bc_scal[1]);
+        if (cons) {                                              // Diffusion.cpp:396-413: Soln = S_old / rho_old on the grown box
+            MultiFab R(layout, cell_type(), 1, 1);
+            fillpatch(R, So, Density, 1, &bc_scal[0]);
+            scale_by(Soln0, R, 0, 1, true);
+        }
         MGOpts mo;
         mo.max_coarsening_level = 0;                             // infon.setMaxCoarseningLevel(0) (Diffusion.cpp:318)
         mo.maxorder = 2;
@@ -464,6 +495,12 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     fillpatch(Soln, Sn, Tracer, 1, &bc_scal[1]);                 // FillPatch(S_new, ng 1): initial guess + level BC
     MultiFab acoef(layout, cell_type(), 1, 0);
     acoef.setVal(1.0);                                           // computeAlpha, rho_flag 0
+    if (cons) {                                                  // rho_flag 2: Soln = S_new / rho_new (Diffusion.cpp:520-540), alpha = rho_new
+        MultiFab R(layout, cell_type(), 1, 1);
+        fillpatch(R, Sn, Density, 1, &bc_scal[0]);
+        scale_by(Soln, R, 0, 1, true);
+        MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
+    }
     MGOpts so = o;
     so.maxorder = 2;                                             // Diffusion::max_order
     CellMG opnp1(g, layout, 1, bc_scal_lin, so);
@@ -472,6 +509,7 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     opnp1.setBCoeffs(bp);
     opnp1.prepare();
     st_scal = opnp1.solve(Soln, Rhs, p.visc_tol, tol_abs);
+    if (cons) scale_by(Soln, Sn, Density, 0, false);            // Diffusion.cpp:583-590
     MultiFab::Copy(Sn, Soln, 0, Tracer, 1, 0);
 }
 
@@ -481,14 +519,21 @@ void NavierStokes::velocity_advection_update(double dt_)
     const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_half.d_tab;
     const double grav = p.gravity;
     const bool zero_force = initial_iter && is_diffusive_vel();
+    const bool mom = p.do_mom_diff != 0;
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const double scal_rho = 0.5 * (ot[f](i, j, k, Density) + nt[f](i, j, k, Density));
+        const double ro = ot[f](i, j, k, Density), rn = nt[f](i, j, k, Density);
+        const double scal_rho = 0.5 * (ro + rn);
         const double rh = rt[f](i, j, k, 0);
         for (int n = 0; n < 3; ++n) {
             double force = (fabs(grav) > 0.0001 && n == 2) ? grav * scal_rho : 0.0;
             if (zero_force) force = 0.0;
-            const double velold = ot[f](i, j, k, n);
-            nt[f](i, j, k, n) = velold - dt_ * at[f](i, j, k, n) + dt_ * force / rh - dt_ * gt[f](i, j, k, n) / rh;
+            double velold = ot[f](i, j, k, n);
+            if (mom) {                                  // NavierStokesBase.cpp:3609-3616
+                velold *= ro;
+                const double v = velold - dt_ * at[f](i, j, k, n) + dt_ * force - dt_ * gt[f](i, j, k, n);
+                nt[f](i, j, k, n) = v / rn;
+            } else
+                nt[f](i, j, k, n) = velold - dt_ * at[f](i, j, k, n) + dt_ * force / rh - dt_ * gt[f](i, j, k, n) / rh;
         }
     });
 }
@@ -502,13 +547,17 @@ void NavierStokes::initial_velocity_diffusion_update(double dt_)
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
     const FabD *nt = S[inew].d_tab, *ot = So.d_tab, *at = aofs.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_half.d_tab, *vt = visc.d_tab;
     const double grav = p.gravity;
+    const bool mom = p.do_mom_diff != 0;
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         for (int n = 0; n < 3; ++n) {
             double force = (fabs(grav) > 0.0001 && n == 2) ? grav * ot[f](i, j, k, Density) : 0.0;
             force += vt[f](i, j, k, n) - gt[f](i, j, k, n);
-            force /= rt[f](i, j, k, 0);
+            if (!mom) force /= rt[f](i, j, k, 0);
             force -= at[f](i, j, k, n);
-            nt[f](i, j, k, n) = ot[f](i, j, k, n) + force * dt_;
+            if (mom)                                    // NavierStokesBase.cpp:3737-3739
+                nt[f](i, j, k, n) = (force * dt_ + ot[f](i, j, k, n) * ot[f](i, j, k, Density)) / nt[f](i, j, k, Density);
+            else
+                nt[f](i, j, k, n) = ot[f](i, j, k, n) + force * dt_;
         }
     });
 }
@@ -528,10 +577,12 @@ void NavierStokes::velocity_diffusion_update(double dt_)
         tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc, 3);
     } else Rhs.setVal(0.0);
     {
-        const FabD *nt = Sn.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
+        const FabD *nt = Sn.d_tab, *ot = So.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
+        const bool mom = p.do_mom_diff != 0;                     // rho_flag 3 (NavierStokes.cpp:1016): the OLD density (Diffusion.cpp:819)
         for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double r = mom ? ot[f](i, j, k, Density) : ht[f](i, j, k, 0);
             for (int n = 0; n < 3; ++n) {
-                nt[f](i, j, k, n) *= ht[f](i, j, k, 0);          // Diffusion.cpp:825: the state holds rho u* from here on
+                nt[f](i, j, k, n) *= r;                          // Diffusion.cpp:825: the state holds rho u* from here on
                 rt[f](i, j, k, n) += nt[f](i, j, k, n);
             }
         });
@@ -542,7 +593,8 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     MultiFab Soln(layout, cell_type(), 3, 1);
     fillpatch(Soln, Sn, Xvel, 3, bc_vel);                        // initial guess = FillPatch(U_new) = rho u* (+ wall values)
     MultiFab acoef(layout, cell_type(), 1, 0);
-    MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);                 // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
+    if (p.do_mom_diff) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);   // rho_flag 3: alpha = rho_new (Diffusion.cpp:893)
+    else MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);            // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
     MGOpts vo = o;
     vo.maxorder = 2;
     st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, 3, p.visc_tol, tol_abs, vo);

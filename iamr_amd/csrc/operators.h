@@ -89,6 +89,7 @@ struct NSParams {
     int phys_lo[3] = {0, 0, 0}, phys_hi[3] = {0, 0, 0};   // ns.lo_bc / ns.hi_bc (PhysBCType: 0 Interior, 4 SlipWall, 5 NoSlipWall)
     double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
     double scal_bc_lo[6] = {0, 0, 0, 0, 0, 0}, scal_bc_hi[6] = {0, 0, 0, 0, 0, 0};   // xlo.density, xlo.tracer ... (inflow values): [d*2+n]
+    int do_cons_trac = 0;                // ns.do_cons_trac
 };
 
 enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };

@@ -6,7 +6,7 @@ keys this library implements onto `ns_params`, the geometry and the box layout:
 
   amr.n_cell, amr.max_level (must be 0), amr.max_grid_size (32), geometry.prob_lo / prob_hi / is_periodic / coord_sys (0),
   ns.cfl, ns.init_iter, ns.init_vel_iter, ns.init_shrink, ns.change_max, ns.fixed_dt, ns.init_dt, ns.gravity,
-  ns.be_cn_theta, ns.do_mom_diff, ns.vel_visc_coef, ns.scal_diff_coefs, ns.lo_bc, ns.hi_bc, ns.advection_scheme,
+  ns.be_cn_theta, ns.do_mom_diff, ns.do_cons_trac, ns.vel_visc_coef, ns.scal_diff_coefs, ns.lo_bc, ns.hi_bc, ns.advection_scheme,
   ns.visc_tol, godunov.use_forces_in_trans, mac_proj.mac_tol / mac_abs_tol, proj.proj_tol / proj_abs_tol,
   {x,y,z}{lo,hi}.velocity / .density / .tracer, prob.probtype (1: fluid at rest, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
   prob.density_ic, prob.rho_1 / rho_2 / tra_1 / tra_2 / interface_width / perturbation_amplitude (probtype 10), max_step, stop_time
@@ -120,7 +120,7 @@ class Inputs:
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
         if scheme != "Godunov_PLM":
             raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; only Godunov_PLM is implemented")
-        for k in ("ns.do_temp", "ns.do_trac2", "ns.do_cons_trac", "ns.do_LES", "ns.do_mom_diff", "particles.do_nspc_particles", "eb2.geom_type"):
+        for k in ("ns.do_temp", "ns.do_trac2", "ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
             if self.has(k) and self.string(k) not in ("0", "all_regular"):
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented")
         sdc = self.reals("ns.scal_diff_coefs", 1, [0.0])
@@ -129,7 +129,7 @@ class Inputs:
                  init_shrink=self.real("ns.init_shrink", 1.0), change_max=self.real("ns.change_max", 1.1),
                  fixed_dt=self.real("ns.fixed_dt", -1.0), init_dt=self.real("ns.init_dt", -1.0), gravity=self.real("ns.gravity", 0.0),
                  be_cn_theta=self.real("ns.be_cn_theta", 0.5), visc_tol=self.real("ns.visc_tol", 1.0e-10),
-                 use_forces_in_trans=self.integer("godunov.use_forces_in_trans", 0),
+                 use_forces_in_trans=self.integer("godunov.use_forces_in_trans", 0), do_mom_diff=self.integer("ns.do_mom_diff", 0), do_cons_trac=self.integer("ns.do_cons_trac", 0),
                  mac_tol=self.real("mac_proj.mac_tol", 1.0e-12), mac_abs_tol=self.real("mac_proj.mac_abs_tol", 1.0e-16),
                  proj_tol=self.real("proj.proj_tol", 1.0e-12), proj_abs_tol=self.real("proj.proj_abs_tol", 1.0e-16),
                  phys_lo=lo_bc, phys_hi=hi_bc)

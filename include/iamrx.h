@@ -282,6 +282,7 @@ typedef struct iamrx_ns_params {
     int phys_lo[3], phys_hi[3];  /* ns.lo_bc / ns.hi_bc, Source/NS_BC.H: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall */
     double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];     /* xlo.density, xlo.tracer ... zhi.* (inflow values): [d*2+n], n = 0 density, 1 tracer */
+    int do_cons_trac;            /* ns.do_cons_trac: the tracer is rho*q, advected conservatively and diffused as div beta grad(S/rho) (Source/NS_setup.cpp:306-310) */
 } iamrx_ns_params;
 void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);

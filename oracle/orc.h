@@ -238,6 +238,7 @@ typedef struct orc_ns_params {
     int phys_lo[3], phys_hi[3];/* ns.lo_bc / ns.hi_bc: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall (Source/NS_BC.H) */
     double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];   /* xlo.density, xlo.tracer ... (inflow values): [d*2+n], n = 0 density, 1 tracer */
+    int do_cons_trac;          /* ns.do_cons_trac (Source/NS_setup.cpp:306-310): Conservative advection, Laplacian_SoverRho diffusion */
 } orc_ns_params;
 
 typedef struct orc_ns_state orc_ns_state;

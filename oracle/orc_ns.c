@@ -23,7 +23,7 @@
  *   physical BC tables                     Source/NS_BC.H:7-55, Source/NS_setup.cpp:21-128, Source/NS_bcfill.H:17-180
  * Scope: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls through
  * xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, no divu, NUM_STATE = 5
- * (u,v,w,rho,tracer), do_mom_diff = 0, Godunov_PLM.
+ * (u,v,w,rho,tracer), do_mom_diff = 0 or 1, Godunov_PLM.
  */
 #include "orc_int.h"
 
@@ -71,6 +71,7 @@ void orc_ns_default_params(orc_ns_params* p)
     for (int d = 0; d < 3; ++d) p->phys_lo[d] = p->phys_hi[d] = 0;
     for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
     for (int q = 0; q < 6; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
+    p->do_cons_trac = 0;
 }
 
 /* BCType of a velocity component / scalar / grad p component for a physical BC (Source/NS_BC.H:7-35) */
@@ -303,13 +304,18 @@ static void tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha,
     for (int d = 0; d < 3; ++d) { L->b[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&L->b[d], s->p.tracer_diff_coef); }
 }
 
-/* NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0: Laplacian_S): visc = div(beta grad S(time)) */
+/* NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0: Laplacian_S): visc = div(beta grad S(time));
+ * called at the old time only (Sdata = S_old, get_rho(time) = rho_ptime) */
 static void get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata)
 {
     const orc_geom* g = &s->g;
     orc_setval(visc, 1.e40);
     if (!is_diffusive_tracer(s)) { orc_setval(visc, 0.0); return; }
     orc_fab stmp = fillpatch(s, Sdata, Tracer, 1, 1, &s->bc_scal[1]);
+    if (s->p.do_cons_trac) {    /* rho_flag 2 (Diffusion.cpp:1612-1615): evaluate div beta grad(S/rho), rho = get_rho(time) incl. the ghost cells */
+        const size_t N = orc_npts(&stmp);
+        for (size_t q = 0; q < N; ++q) stmp.p[q] /= s->rho_ptime.p[q];
+    }
     orc_abec_level L;
     tracer_level(s, &L, 0.0, -1.0, NULL);
     orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
@@ -493,7 +499,16 @@ static void mac_project(orc_ns_state* s, double dt)
 static void velocity_advection(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
+    const int mom = s->p.do_mom_diff;
     orc_fab Umf = fillpatch(s, S_OLD(s), Xvel, 3, 3, s->bc_vel);
+    if (mom) {
+        /* NavierStokesBase.cpp:3397-3413: the advected state is the momentum rho^n u^n, ghost cells included (both factors
+         * FillPatched with their own physical BC) */
+        orc_fab Rmf = fillpatch(s, S_OLD(s), Density, 1, 3, &s->bc_scal[0]);
+        const size_t N = orc_npts(&Umf);
+        for (int n = 0; n < 3; ++n) for (size_t q = 0; q < N; ++q) Umf.p[q + N * n] *= Rmf.p[q];
+        orc_free(&Rmf);
+    }
     orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
@@ -504,10 +519,10 @@ static void velocity_advection(orc_ns_state* s, double dt)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         double rho = A4(&Smf, i, j, k, 0);
         double t = force_vel(s, n, rho) + A4(&visc, i, j, k, n) - A4(Gp, i, j, k, n);
-        t /= rho;
+        if (!mom) t /= rho;                     /* NavierStokesBase.cpp:3459-3466: convective form only */
         A4(&tf, i, j, k, n) = t;
     }
-    int iconserv[3] = {0, 0, 0};
+    int iconserv[3] = {mom, mom, mom};          /* NS_setup.cpp:297-301: velocity advectionType = Conservative */
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
     orc_compute_aofs(g, &s->aofs, Xvel, &Umf, 3, &tf, &divu, um, iconserv, dt, s->bc_vel, 1, s->p.use_forces_in_trans, NULL, NULL);
     orc_free(&Umf); orc_free(&Smf); orc_free(&visc); orc_free(&tf); orc_free(&divu);
@@ -520,12 +535,14 @@ static void scalar_advection(orc_ns_state* s, double dt)
     floor_small(&Smf);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
     orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
-    int iconserv[2] = {1, 0};   /* density conservative; tracer non-conservative (do_cons_trac = 0) */
+    int iconserv[2] = {1, s->p.do_cons_trac ? 1 : 0};   /* density conservative; tracer: NS_setup.cpp:304-310 */
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
     if (s->p.be_cn_theta != 1.0) get_visc_terms_tracer(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         double rho = A4(&Smf, i, j, k, 0);
         A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc (density: not diffusive) */
+        if (s->p.do_cons_trac) A4(&tf, i, j, k, 1) += A4(&visc, i, j, k, 0);         /* NavierStokes.cpp:780-792 */
+        else
         A4(&tf, i, j, k, 1) = A4(&tf, i, j, k, 1) / rho + A4(&visc, i, j, k, 0);    /* convective: tf/rho + visc */
     }
     orc_free(&visc);
@@ -555,6 +572,8 @@ static void scalar_update_tracers(orc_ns_state* s, double dt)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         double rho = A4(So, i, j, k, Density) - 0.5 * dt * A4(&s->aofs, i, j, k, Density);
         double tf = 0.0;
+        if (s->p.do_cons_trac) A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf);   /* NavierStokesBase.cpp:2889-2891 */
+        else
         A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf / rho);
     }
 }
@@ -567,11 +586,18 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
     const orc_geom* g = &s->g;
     if (!is_diffusive_tracer(s)) return;
     const double theta = s->p.be_cn_theta;
+    const int cons = s->p.do_cons_trac;     /* diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308, Diffusion.cpp:1870-1873) */
     orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
     orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
     if (theta != 1.0) {
         /* FillPatch(S_old, ng 1) then opn.setLevelBC(Soln = S_old tracer with ghosts); a = 0, b = -(1-theta) dt */
         orc_fab Soln = fillpatch(s, So, Tracer, 1, 1, &s->bc_scal[1]);
+        if (cons) {             /* Diffusion.cpp:396-413: Soln = S_old / rho_old on the grown box */
+            orc_fab R = fillpatch(s, So, Density, 1, 1, &s->bc_scal[0]);
+            const size_t N = orc_npts(&Soln);
+            for (size_t q = 0; q < N; ++q) Soln.p[q] /= R.p[q];
+            orc_free(&R);
+        }
         orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_copy_all(&bcval, &Soln);
         orc_abec_level Ln;
@@ -591,6 +617,14 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
     orc_fab Soln = fillpatch(s, Sn, Tracer, 1, 1, &s->bc_scal[1]);     /* FillPatch(S_new, ng 1): initial guess + level BC */
     orc_fab acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
     orc_setval(&acoef, 1.0);                                            /* computeAlpha, rho_flag 0: alpha = 1 */
+    if (cons) {                 /* rho_flag 2: Soln = S_new / rho_new on the grown box (Diffusion.cpp:520-540), alpha = rho_new (:1380-1383) */
+        orc_fab R = fillpatch(s, Sn, Density, 1, 1, &s->bc_scal[0]);
+        const size_t N = orc_npts(&Soln);
+        for (size_t q = 0; q < N; ++q) Soln.p[q] /= R.p[q];
+        orc_free(&R);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&acoef, i, j, k, 0) = A4(Sn, i, j, k, Density);
+    }
     orc_abec_level L;
     tracer_level(s, &L, 1.0, theta * dt, &acoef);
     orc_mg_opts o = s->o; o.maxorder = 2;                                /* Diffusion::max_order = 2 */
@@ -598,7 +632,7 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
     orc_abec_solve(&L, &Soln, &Rhs, s->slobc, s->shibc, s->p.visc_tol, tol_abs, &o, &st);
     s->st_scal = st;
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-        A4(Sn, i, j, k, Tracer) = A4(&Soln, i, j, k, 0);
+        A4(Sn, i, j, k, Tracer) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);    /* Diffusion.cpp:583-590 */
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
     orc_free(&Soln); orc_free(&acoef); orc_free(&Rhs);
 }
@@ -615,6 +649,11 @@ static void velocity_advection_update(orc_ns_state* s, double dt)
         if (s->initial_iter && is_diffusive_vel(s)) force = 0.0;
         double rh = A4(&s->rho_half, i, j, k, 0);
         double velold = A4(Uo, i, j, k, n);
+        if (s->p.do_mom_diff) {                 /* NavierStokesBase.cpp:3609-3616 */
+            velold *= A4(Uo, i, j, k, Density);
+            double v = velold - dt * A4(&s->aofs, i, j, k, n) + dt * force - dt * A4(Gp, i, j, k, n);
+            A4(Un, i, j, k, n) = v / A4(Un, i, j, k, Density);
+        } else
         A4(Un, i, j, k, n) = velold - dt * A4(&s->aofs, i, j, k, n) + dt * force / rh - dt * A4(Gp, i, j, k, n) / rh;
     }
 }
@@ -631,18 +670,22 @@ static void initial_velocity_diffusion_update(orc_ns_state* s, double dt)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         double force = force_vel(s, n, A4(Uo, i, j, k, Density));
         force += A4(&visc, i, j, k, n) - A4(Gp, i, j, k, n);
-        force /= A4(&s->rho_half, i, j, k, 0);
+        if (!s->p.do_mom_diff) force /= A4(&s->rho_half, i, j, k, 0);
         force -= A4(&s->aofs, i, j, k, n);
+        if (s->p.do_mom_diff)                   /* NavierStokesBase.cpp:3737-3739 */
+            A4(Un, i, j, k, n) = (force * dt + A4(Uo, i, j, k, n) * A4(Uo, i, j, k, Density)) / A4(Un, i, j, k, Density);
+        else
         A4(Un, i, j, k, n) = A4(Uo, i, j, k, n) + force * dt;
     }
     orc_free(&visc);
 }
 
-/* Diffusion::diffuse_tensor_velocity (rho_flag = 1) */
+/* Diffusion::diffuse_tensor_velocity (rho_flag = 1, or 3 with do_mom_diff: NavierStokes.cpp:1016) */
 static void velocity_diffusion_update(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
     if (!is_diffusive_vel(s)) return;
+    const int mom = s->p.do_mom_diff;
     const double theta = s->p.be_cn_theta;
     orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
     orc_fab eta[3]; orc_fab* ep[3];
@@ -656,7 +699,8 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     }
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
-        A4(Un, i, j, k, n) *= A4(&s->rho_half, i, j, k, 0);     /* Diffusion.cpp:825: state overwritten with rho u* */
+        /* Diffusion.cpp:819-825: state overwritten with rho u*; rho_flag 3 (do_mom_diff) multiplies by the OLD density */
+        A4(Un, i, j, k, n) *= mom ? A4(Uo, i, j, k, Density) : A4(&s->rho_half, i, j, k, 0);
         A4(&Rhs, i, j, k, n) += A4(Un, i, j, k, n);
     }
     /* tol_abs = visc_tol * mean_n ||Rhs_n||inf (get_scaled_abs_tol) */
@@ -672,7 +716,7 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     orc_fab Soln = fillpatch(s, Un, Xvel, 3, 1, s->bc_vel);   /* initial guess = FillPatch(U_new) = rho u* */
     orc_fab acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-        A4(&acoef, i, j, k, 0) = 1.0 * A4(&s->rho_half, i, j, k, 0);
+        A4(&acoef, i, j, k, 0) = mom ? A4(Un, i, j, k, Density) : A4(&s->rho_half, i, j, k, 0);   /* Diffusion.cpp:893: rho_flag 3 -> rho_new */
     orc_mg_opts o = s->o; o.maxorder = 2;
     orc_tensor_solve_bcn(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, s->vlobc, s->vhibc, s->p.visc_tol, tol_abs, &o, &s->st_visc);
     for (int n = 0; n < 3; ++n)
@@ -716,6 +760,8 @@ static double advance(orc_ns_state* s, double dt)
     advance_setup(s);
     double dt_test = predict_velocity(s, dt);
     mac_project(s, dt);
+    /* NavierStokes.cpp:606-623: with do_mom_diff the reference calls velocity_advection after the density update; it reads only
+     * time-n data and the MAC velocities, so the result does not depend on that order */
     velocity_advection(s, dt);
     scalar_advection(s, dt);
     scalar_update_rho(s, dt);

@@ -51,4 +51,8 @@ def test_rayleightaylor_keys():
     pr = Inputs([LDC], ["prob.probtype=10", "prob.rho_1=2.0", "prob.rho_2=1.0", "prob.tra_1=1.0", "prob.interface_width=0.05",
                         "prob.perturbation_amplitude=0.1", "ns.gravity=-9.8"]).problem()
     assert pr["prob"] == dict(probtype=10, rho_1=2.0, rho_2=1.0, tra_1=1.0, tra_2=0.0, pertamp=0.1, interface_width=0.05)
-    assert pr["params"]["gravity"] == -9.8
+    assert pr["params"]["gravity"] == -9.8 and pr["params"]["do_mom_diff"] == 0 and pr["params"]["do_cons_trac"] == 0
+    pr = Inputs([LDC], ["ns.do_mom_diff=1", "ns.do_cons_trac=1"]).problem()          # Exec/run3d/regtest.3d.rayleightaylor:6-7
+    assert pr["params"]["do_mom_diff"] == 1 and pr["params"]["do_cons_trac"] == 1
+    with pytest.raises(NotImplementedError):
+        Inputs([LDC], ["ns.do_temp=1"]).problem()

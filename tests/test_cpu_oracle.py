@@ -286,6 +286,52 @@ def test_wall_ghost_forcing_is_immaterial(orc):
     assert np.array_equal(a, b)
 
 
+def test_momentum_form_and_conservative_tracer(orc):
+    """ns.do_mom_diff / ns.do_cons_trac (NS_setup.cpp:297-310) on a periodic box: (a) with uniform density the momentum form differs from
+    the convective form only in the truncation error of the transverse terms ((T_avg - q) du/dx instead of 0), which shrinks under
+    refinement; (b) with variable density it is a different scheme; (c) a conservative tracer S = c rho stays c rho (same conservative
+    update, limiters are homogeneous) and sum(S) is conserved, with and without diffusion of S/rho"""
+    per = (1, 1, 1)
+    kw = dict(cfl=0.5, visc_coef=0.02, tracer_diff_coef=0.0, init_iter=1, init_dt=-1.0, init_shrink=1.0, fixed_dt=0.01)
+    diffs = []
+    for N in (8, 16):
+        n = (N, N, N)
+        x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+        X, Y, Z = np.meshgrid(*x, indexing="ij")
+        init = np.zeros(n + (5,))
+        init[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.2 * np.sin(2 * np.pi * Z)
+        init[..., 1] = -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+        init[..., 2] = 0.3 * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+        init[..., 3] = 1.0
+        init[..., 4] = np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Z)
+        a, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 2, 1.0, init, per, **kw)
+        b, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 2, 1.0, init, per, do_mom_diff=1, **kw)
+        assert np.abs(a[..., 0]).max() > 0.5
+        diffs.append(np.abs(a - b).max())
+    assert 0 < diffs[1] < 0.4 * diffs[0] < 2e-3
+    del kw["fixed_dt"]
+    n = (8, 8, 8)
+    x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    init = init[::2, ::2, ::2].copy()
+    init[..., 3] = 1.0 + 0.5 * np.exp(-20.0 * ((X - 0.5) ** 2 + (Y - 0.4) ** 2 + (Z - 0.6) ** 2))
+    a, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 2, 1.0, init, per, **kw)
+    b, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 2, 1.0, init, per, do_mom_diff=1, **kw)
+    assert np.abs(a[..., :3] - b[..., :3]).max() > 1e-3
+    init[..., 4] = 0.75 * init[..., 3]
+    for diff in (0.0, 0.05):
+        kw["tracer_diff_coef"] = diff
+        c, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 3, 1.0, init, per, do_mom_diff=1, do_cons_trac=1, **kw)
+        assert np.abs(c[..., 4] - 0.75 * c[..., 3]).max() < 1e-12
+        assert np.abs(c[..., 3] - init[..., 3]).max() > 1e-3
+        assert abs(c[..., 4].sum() - init[..., 4].sum()) < 1e-10 * init[..., 4].sum()
+    init[..., 4] = init[..., 3] * (0.5 + 0.3 * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Z))
+    c, _, _ = run_ldc(orc, n, (0, 0, 0), (0, 0, 0), 3, 1.0, init, per, do_cons_trac=1, **kw)       # diffusive, non-trivial concentration
+    assert abs(c[..., 4].sum() - init[..., 4].sum()) < 1e-9 * init[..., 4].sum()
+    q0, q1 = init[..., 4] / init[..., 3], c[..., 4] / c[..., 3]
+    assert q1.max() < q0.max() and q1.min() > q0.min()                                          # diffusion of q = S/rho
+
+
 def test_golden_fixture_regression_lid_driven_cavity(orc):
     path = os.path.join(HERE, "golden", "liddrivencavity16_oracle.npz")
     if not os.path.exists(path):

@@ -174,10 +174,16 @@ def test_rejects_unsupported_physical_bc(gpu):
     dict(be_cn_theta=1.0),
     dict(init_iter=0, init_vel_iter=0, fixed_dt=2.0e-3),
     dict(visc_coef=0.0, tracer_diff_coef=0.0),
-], ids=["gravity", "gravity+forces_in_trans", "backward_euler", "no_init_iters_fixed_dt", "inviscid"])
+    dict(do_mom_diff=1, gravity=-9.8, use_forces_in_trans=1),
+    dict(do_mom_diff=1, be_cn_theta=1.0),
+    dict(do_cons_trac=1),
+    dict(do_mom_diff=1, do_cons_trac=1, visc_coef=0.0, tracer_diff_coef=0.0, gravity=-9.8),
+], ids=["gravity", "gravity+forces_in_trans", "backward_euler", "no_init_iters_fixed_dt", "inviscid",
+        "mom_diff+gravity", "mom_diff+backward_euler", "cons_trac", "mom_diff+cons_trac_inviscid"])
 def test_parameter_variants_match_oracle(orc, gpu, kw):
     """ns.* knobs that change the code path of the step (buoyancy forcing with variable density, godunov.use_forces_in_trans,
-    be_cn_theta = 1, no initial iterations + fixed_dt, inviscid): periodic x, walls in y and z, 2 + 2 boxes, 3 steps"""
+    be_cn_theta = 1, no initial iterations + fixed_dt, inviscid, ns.do_mom_diff = 1 (momentum-form velocity update, tensor solve with
+    rho_flag 3), ns.do_cons_trac = 1 (conservative tracer, diffusion of S/rho with rho_flag 2)): periodic x, walls in y and z, 2 + 2 boxes, 3 steps"""
     n = (16, 16, 16)
     per = (1, 0, 0)
     x = [(np.arange(n[d]) + 0.5) / n[d] for d in range(3)]
@@ -237,15 +243,17 @@ def test_symmetry_plane_reproduces_half_of_a_symmetric_periodic_flow(gpu):
     assert np.abs(SF[..., 0]).max() > 0.5
 
 
-def test_rayleigh_taylor_matches_oracle(orc, gpu):
+@pytest.mark.parametrize("forms", [dict(), dict(do_mom_diff=1, do_cons_trac=1)], ids=["convective", "mom_diff+cons_trac"])
+def test_rayleigh_taylor_matches_oracle(orc, gpu, forms):
     """BASELINE config C5 reduced to its single-level physics at a size the oracle finishes quickly: probtype 10 (tanh density /
     tracer interface with the reference's hard-coded perturbation), gravity, slip walls in z, periodic x / y, variable density in
-    both projections, forces in the transverse terms (godunov.use_forces_in_trans = 1 as in regtest.3d.rayleightaylor)"""
+    both projections, forces in the transverse terms (godunov.use_forces_in_trans = 1 as in regtest.3d.rayleightaylor); the second
+    case uses that regtest's ns.do_mom_diff = 1 / ns.do_cons_trac = 1 (Exec/run3d/regtest.3d.rayleightaylor:6-7)"""
     from iamr_amd import ns as N
     lib = gpu
     L = orc.lib()
     n, per, prob_lo, prob_hi = (16, 16, 32), (1, 1, 0), (0.0, 0.0, 0.0), (1.0, 1.0, 2.0)
-    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=3, gravity=-9.8, use_forces_in_trans=1)
+    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=3, gravity=-9.8, use_forces_in_trans=1, **forms)
     rt = dict(rho_1=1.0, rho_2=2.0, tra_1=1.0, tra_2=0.0, pertamp=0.1, interface_width=0.08)
     # oracle
     g_o = orc.geom(n, problo=prob_lo, probhi=prob_hi, periodic=per)
