@@ -34,7 +34,7 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         comm.init_gloo_callback(dist)
         import bench
         bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
-    owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)
+    owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
     lay = lib.Layout(BOXES, owners)
     if case == "stack4":
         g = lib.Geom.make(N, prob_hi=(1.0, 1.0, 4.0))
@@ -78,6 +78,24 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, agg):
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        assert np.array_equal(z["iters"], ref["iters"])
+        key = f"box{r}"
+        assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+def test_a_rank_without_boxes_takes_part_in_the_step(tmp_path):
+    """more ranks than boxes (AMReX allows it; coarse AMR levels routinely have fewer grids than ranks): rank 2 owns nothing, launches
+    no kernels, but joins every reduction and exchange; ranks 0 and 1 reproduce the 1-rank result"""
+    import torch.multiprocessing as mp
+    port = 35600 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None), nprocs=1, join=True)
+    mp.spawn(run, args=(3, port, str(tmp_path), None), nprocs=3, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    idle = np.load(os.path.join(str(tmp_path), "w3_r2.npz"))
+    assert not [k for k in idle.files if k.startswith("box")] and np.allclose(idle["dts"], ref["dts"], rtol=1e-10, atol=0)
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"w3_r{r}.npz"))
         assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
         assert np.array_equal(z["iters"], ref["iters"])
         key = f"box{r}"
