@@ -591,11 +591,120 @@ __device__ __forceinline__ double interp_face(const FabD& c, const FabD& s, int 
     return r / (w1 + w2 + w3 + w4);
 }
 
+// the six side weights of a fine node from the 8 cells around it, summed in w_side's order
+__device__ __forceinline__ void side_weights(const FabD& s, int i, int j, int k, double w[6])
+{
+    double g[2][2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) g[c][b][a] = s(i - 1 + a, j - 1 + b, k - 1 + c);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        w[t] = ((g[0][0][t] + g[0][1][t]) + g[1][0][t]) + g[1][1][t];
+        w[2 + t] = ((g[0][t][0] + g[0][t][1]) + g[1][t][0]) + g[1][t][1];
+        w[4 + t] = ((g[t][0][0] + g[t][0][1]) + g[t][1][0]) + g[t][1][1];
+    }
+}
+
+// Staged version of the interpolation below: one workgroup owns the fine nodes of CX x CY x CZ coarse cells.  The recursion of
+// mlndlap_interpadd_aa (edge nodes from coarse nodes, face nodes from edge nodes, centre nodes from face nodes) runs class by class
+// on the (2C+1)^3 fine-node tile in LDS, so that every intermediate value is computed once (the per-coarse-node version recomputes
+// the edge values inside the face values inside the centre value: ~200 dependent sigma loads for one centre node), then the tile is
+// added to the fine array with unit-stride stores.  Same expressions, same association order: bit-identical results.
+// the fine nodes of one parity class (PX, PY, PZ) of the tile, enumerated densely (all lanes busy)
+template <int PX, int PY, int PZ, int CX, int CY, int CZ>
+__device__ __forceinline__ void interp_class(double (*T)[2 * CY + 1][2 * CX + 1], const FabD& c, const FabD& s, int fi0, int fj0, int fk0,
+                                             int nhi0, int nhi1, int nhi2, int tid)
+{
+    constexpr int NX = PX ? CX : CX + 1, NY = PY ? CY : CY + 1, NZ = PZ ? CZ : CZ + 1, CLS = PX + PY + PZ;
+    for (int idx = tid; idx < NX * NY * NZ; idx += 256) {
+        const int lx = 2 * (idx % NX) + PX, q = idx / NX, ly = 2 * (q % NY) + PY, lz = 2 * (q / NY) + PZ;
+        const int i = fi0 + lx, j = fj0 + ly, k = fk0 + lz;
+        if (i > nhi0 || j > nhi1 || k > nhi2) continue;
+        if (CLS == 0) { T[lz][ly][lx] = c(i >> 1, j >> 1, k >> 1); continue; }
+        double w[6];
+        side_weights(s, i, j, k, w);
+        if (CLS == 1) {
+            constexpr int d = PX ? 0 : (PY ? 1 : 2);
+            const double w1 = w[2 * d], w2 = w[2 * d + 1];
+            T[lz][ly][lx] = (T[lz - PZ][ly - PY][lx - PX] * w1 + T[lz + PZ][ly + PY][lx + PX] * w2) / (w1 + w2);
+        } else if (CLS == 2) {
+            constexpr int d1 = PX ? 0 : 1, d2 = PZ ? 2 : 1;
+            constexpr int ax = d1 == 0, ay = d1 == 1, by = d2 == 1, bz = d2 == 2;
+            const double w1 = w[2 * d1], w2 = w[2 * d1 + 1], w3 = w[2 * d2], w4 = w[2 * d2 + 1];
+            double r = 0.0;
+            r += w1 * T[lz][ly - ay][lx - ax];
+            r += w2 * T[lz][ly + ay][lx + ax];
+            r += w3 * T[lz - bz][ly - by][lx];
+            r += w4 * T[lz + bz][ly + by][lx];
+            T[lz][ly][lx] = r / (w1 + w2 + w3 + w4);
+        } else {
+            T[lz][ly][lx] = (w[0] * T[lz][ly][lx - 1] + w[1] * T[lz][ly][lx + 1] + w[2] * T[lz][ly - 1][lx] + w[3] * T[lz][ly + 1][lx]
+                             + w[4] * T[lz - 1][ly][lx] + w[5] * T[lz + 1][ly][lx]) / (w[0] + w[1] + w[2] + w[3] + w[4] + w[5]);
+        }
+    }
+}
+
+template <int CX, int CY, int CZ>
+__global__ void __launch_bounds__(256) k_nodal_interp_lds(const BoxD* __restrict__ fboxes, const FabD* __restrict__ ft, const FabD* __restrict__ ct,
+    const FabD* __restrict__ st, int ntx, int nty)
+{
+    constexpr int FX = 2 * CX + 1, FY = 2 * CY + 1, FZ = 2 * CZ + 1, NF = FX * FY * FZ;
+    __shared__ double T[FZ][FY][FX];
+    const int fab = blockIdx.y;
+    const BoxD vb = fboxes[fab];
+    const int bid = blockIdx.x;
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, tiz = r1 / nty;
+    const int nhi0 = vb.hi[0] + 1, nhi1 = vb.hi[1] + 1, nhi2 = vb.hi[2] + 1;
+    const int fi0 = vb.lo[0] + tix * 2 * CX, fj0 = vb.lo[1] + tiy * 2 * CY, fk0 = vb.lo[2] + tiz * 2 * CZ;
+    if (fi0 >= nhi0 || fj0 >= nhi1 || fk0 >= nhi2) return;
+    const FabD c = ct[fab], s = st[fab], fa = ft[fab];
+    const int tid = threadIdx.x;
+#define IAMRX_ICLS(PX, PY, PZ) interp_class<PX, PY, PZ, CX, CY, CZ>(T, c, s, fi0, fj0, fk0, nhi0, nhi1, nhi2, tid)
+    IAMRX_ICLS(0, 0, 0);
+    __syncthreads();
+    IAMRX_ICLS(1, 0, 0); IAMRX_ICLS(0, 1, 0); IAMRX_ICLS(0, 0, 1);
+    __syncthreads();
+    IAMRX_ICLS(1, 1, 0); IAMRX_ICLS(1, 0, 1); IAMRX_ICLS(0, 1, 1);
+    __syncthreads();
+    IAMRX_ICLS(1, 1, 1);
+    __syncthreads();
+#undef IAMRX_ICLS
+    for (int idx = tid; idx < NF; idx += 256) {
+        const int lx = idx % FX, q = idx / FX, ly = q % FY, lz = q / FY;
+        const int i = fi0 + lx, j = fj0 + ly, k = fk0 + lz;
+        if (i > nhi0 || j > nhi1 || k > nhi2) continue;
+        if ((lx == 2 * CX && i != nhi0) || (ly == 2 * CY && j != nhi1) || (lz == 2 * CZ && k != nhi2)) continue;   // the next tile owns it
+        fa(i, j, k) += T[lz][ly][lx];
+    }
+}
+
+static bool nodal_interp_lds_enabled()
+{
+    static const bool on = [] { const char* e = getenv("IAMRX_NODAL_INTERP_LDS"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 // one thread per COARSE node: it produces the (up to) 8 fine nodes 2*(ic,jc,kc) + {0,1}^3, so that every lane of a wavefront
 // walks the same sequence of node classes (coincident, 3 edge, 3 face, 1 centre class) instead of diverging 8 ways
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine)
 {
     if (fine.nlocal() == 0) return;
+    if (nodal_interp_lds_enabled()) {
+        const Layout& l = *fine.layout;
+        bool even = true;                                   // fine boxes start on even indices (they are refinements of the coarse boxes)
+        for (int d = 0; d < 3; ++d) even = even && l.all_lo_even[d];
+        if (even) {
+            constexpr int CX = 16, CY = 4, CZ = 4;
+            const int ntx = (l.max_len[0] + 2 * CX - 1) / (2 * CX), nty = (l.max_len[1] + 2 * CY - 1) / (2 * CY), ntz = (l.max_len[2] + 2 * CZ - 1) / (2 * CZ);
+            dim3 grid((unsigned)(ntx * nty * ntz), (unsigned)l.nlocal());
+            hipLaunchKernelGGL((k_nodal_interp_lds<CX, CY, CZ>), grid, dim3(256), 0, Context::get().stream, l.d_boxes, fine.d_tab, crse.d_tab, sig_fine.d_tab, ntx, nty);
+            return;
+        }
+    }
     const FabD *ft = fine.d_tab, *ct = crse.d_tab, *st = sig_fine.d_tab;
     const BoxD* fb = fine.layout->d_boxes;
     for_each(*crse.layout, node_type(), 0, Context::get().stream, [=] __device__(int ic, int jc, int kc, int f) {

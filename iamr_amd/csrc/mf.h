@@ -70,6 +70,7 @@ struct Layout {
     std::vector<int> local_of;   // global -> local index or -1
     BoxD* d_boxes = nullptr;     // device copy of the LOCAL valid boxes
     int max_len[3] = {0, 0, 0};  // max local box extent (cells)
+    bool all_lo_even[3] = {true, true, true};   // every local box starts on an even, non-negative index
     uint64_t id = 0;
     // replicated: every rank holds ALL boxes (MG levels below the agglomeration level); nothing on such a layout communicates
     bool replicated = false;

@@ -119,7 +119,10 @@ Layout::Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myra
     std::vector<BoxD> lb;
     for (int g : local) {
         lb.push_back(boxes[g]);
-        for (int d = 0; d < 3; ++d) max_len[d] = std::max(max_len[d], boxes[g].len(d));
+        for (int d = 0; d < 3; ++d) {
+            max_len[d] = std::max(max_len[d], boxes[g].len(d));
+            if (boxes[g].lo[d] < 0 || (boxes[g].lo[d] & 1)) all_lo_even[d] = false;
+        }
     }
     if (!lb.empty()) {
         auto& ctx = Context::get();
