@@ -8,7 +8,7 @@ keys this library implements onto `ns_params`, the geometry and the box layout:
   ns.cfl, ns.init_iter, ns.init_vel_iter, ns.init_shrink, ns.change_max, ns.fixed_dt, ns.init_dt, ns.gravity,
   ns.be_cn_theta, ns.do_mom_diff, ns.do_cons_trac, ns.vel_visc_coef, ns.scal_diff_coefs, ns.lo_bc, ns.hi_bc, ns.advection_scheme,
   ns.visc_tol, godunov.use_forces_in_trans, mac_proj.mac_tol / mac_abs_tol, proj.proj_tol / proj_abs_tol,
-  {x,y,z}{lo,hi}.velocity / .density / .tracer, prob.probtype (1: fluid at rest, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
+  {x,y,z}{lo,hi}.velocity / .density / .tracer, prob.probtype (1: fluid at rest, 4: constant velocity + blob, 5: DoubleShearLayer, 7: Euler, 10: RayleighTaylor, 11: TaylorGreen), prob.velocity_factor, prob.a/b/c,
   prob.density_ic, prob.rho_1 / rho_2 / tra_1 / tra_2 / interface_width / perturbation_amplitude (probtype 10), max_step, stop_time
 (reference: Source/NavierStokesBase.cpp:431-557, Source/NavierStokes.cpp:250-310, Source/MacProj.cpp:62-75,
 Source/Projection.cpp:49-65, Source/Diffusion.cpp:98-118, Source/prob/prob_init.cpp:8-60, Source/main.cpp:60-145).
@@ -157,9 +157,13 @@ class Inputs:
             prob = dict(probtype=10, rho_1=self.real("prob.rho_1"), rho_2=self.real("prob.rho_2"), tra_1=self.real("prob.tra_1", 0.0),
                         tra_2=self.real("prob.tra_2", 0.0), pertamp=self.real("prob.perturbation_amplitude", 0.0),
                         interface_width=self.real("prob.interface_width", 1.0))
+        elif probtype in (4, 5, 7):     # host-side initial data (iamr_amd/probinit.py)
+            prob = dict(probtype=probtype, density_ic=self.real("prob.density_ic", 1.0), direction=self.integer("prob.direction", 0),
+                        interface_width=self.real("prob.interface_width", 1.0), blob_radius=self.real("prob.blob_radius", 0.1),
+                        blob_center=self.reals("prob.blob_center", 3, [0.0, 0.0, 0.0]), velocity_ic=self.reals("prob.velocity_ic", 3, [0.0, 0.0, 0.0]))
         else:
-            raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), "
-                                      "10 (RayleighTaylor), 11 (TaylorGreen)")
+            raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 4 (constant "
+                                      "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
                    plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"))

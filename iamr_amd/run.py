@@ -15,6 +15,10 @@ def build(inp, lib, N, nranks=1):
     pb = pr["prob"]
     if pb["probtype"] == 1:
         ns.init_rest(pb["rho0"])
+    elif pb["probtype"] in (4, 5, 7):
+        from .probinit import set_initial_state
+        ns.init_rest(pb["density_ic"])
+        set_initial_state(ns, lay, lib, N, pb, pr["n"], pr["prob_lo"], pr["prob_hi"])
     elif pb["probtype"] == 10:
         ns.init_rayleightaylor(pb["rho_1"], pb["rho_2"], pb["tra_1"], pb["tra_2"], pb["pertamp"], pb["interface_width"])
     else:

@@ -35,7 +35,7 @@ def test_unsupported_features_are_rejected_loudly():
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["ns.lo_bc = 6 4 5"]).problem()          # not a physical BC type
     with pytest.raises(NotImplementedError):
-        Inputs([LDC], ["prob.probtype=7"]).problem()
+        Inputs([LDC], ["prob.probtype=3"]).problem()
     with pytest.raises(KeyError):
         Inputs([LDC], ["ns.some_unknown_knob=1"]).problem()
 
@@ -56,3 +56,28 @@ def test_rayleightaylor_keys():
     assert pr["params"]["do_mom_diff"] == 1 and pr["params"]["do_cons_trac"] == 1
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["ns.do_temp=1"]).problem()
+
+
+def test_host_side_problem_setups():
+    """probtypes 4 / 5 / 7 (Source/prob/prob_init.cpp:232-281, :346-405, :562-610): keys, defaults (prob_init.H:9-35) and a few point values"""
+    import numpy as np
+    from iamr_amd.probinit import cell_centres, initial_state
+    pr = Inputs([LDC], ["prob.probtype=7", "geometry.is_periodic=1 1 1", "ns.lo_bc=0 0 0", "ns.hi_bc=0 0 0"]).problem()
+    assert pr["prob"]["probtype"] == 7 and pr["prob"]["density_ic"] == 1.0 and pr["prob"]["blob_radius"] == 0.1
+    n = (32, 32, 32)
+    X, Y, Z = cell_centres(n, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    assert X[0, 0, 0] == 0.5 / 32 and Z[0, 0, 31] == 31.5 / 32
+    S = initial_state(pr["prob"], X, Y, Z)
+    r = np.sqrt((Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+    assert np.allclose(S[..., 0], np.tanh((0.15 - r) / 0.0333)) and np.all(S[..., 1] == 0.0) and np.all(S[..., 3] == 1.0)
+    assert abs(S[..., 2].max() - 0.05 * np.exp(-15.0 * 2 * (0.5 / 32) ** 2)) < 1e-15 and S[..., 4].max() <= 1.0
+    assert np.array_equal(S[..., 0], S[::-1, ..., 0]) and np.array_equal(S[..., 0], S[:, ::-1, :, 0])       # tube along x, axisymmetric
+    pr = Inputs([LDC], ["prob.probtype=5", "prob.direction=1", "prob.interface_width=1.0", "prob.blob_center=0.5 0.5 0.5", "prob.blob_radius=0.2"]).problem()
+    S = initial_state(pr["prob"], X, Y, Z)
+    assert np.allclose(S[..., 1], np.tanh(30.0 * (0.5 - X))) and np.allclose(S[..., 0], -0.05 * np.sin(np.pi * Y))
+    assert set(np.unique(S[..., 4])) == {0.0, 1.0} and S[16, 16, 16, 4] == 1.0 and S[0, 0, 0, 4] == 0.0
+    pr = Inputs([LDC], ["prob.probtype=4", "prob.velocity_ic=1. 0. 0.", "prob.blob_center=0.15 0.5 0.5", "prob.interface_width=0.001"]).problem()
+    S = initial_state(pr["prob"], X, Y, Z)
+    assert np.all(S[..., 0] == 1.0) and np.all(S[..., 1:3] == 0.0) and S[..., 4].min() == 0.0 and S[4, 16, 16, 4] == 1.0
+    with pytest.raises(ValueError):
+        initial_state(dict(pr["prob"], probtype=5, direction=2), X, Y, Z)

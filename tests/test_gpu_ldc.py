@@ -4,6 +4,7 @@ nodal projections, tracer diffusion (Diffusion::diffuse_scalar), init_dt start f
 Reference inputs: Exec/run3d/regtest.3d.lid_driven_cavity:5-46."""
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
@@ -278,3 +279,31 @@ def test_rayleigh_taylor_matches_oracle(orc, gpu, forms):
         scale = max(np.abs(S_o[..., comp]).max(), 1e-3)
         assert np.abs(S[..., comp] - S_o[..., comp]).max() <= 1e-8 * scale, comp
     assert np.abs(S[..., 2]).max() > 1e-3 and S[..., 3].min() > 0.99 and S[..., 3].max() < 2.01     # the heavy fluid starts to fall
+
+
+def test_euler_regtest_single_level_matches_oracle(orc, gpu):
+    """Exec/run3d/regtest.3d.euler reduced to its base level (32^3, periodic, inviscid, cfl 0.9, prob.probtype = 7: vortex tube with a
+    wobble, Source/prob/prob_init.cpp:562-610): initial data from iamr_amd/probinit.py on both sides, three steps; and the same run
+    through the inputs-file driver (iamr_amd.run.build)"""
+    from iamr_amd.probinit import cell_centres, initial_state
+    from iamr_amd.inputs import Inputs
+    from iamr_amd import run as R, ns as N
+    n, per = (32, 32, 32), (1, 1, 1)
+    prob = dict(probtype=7, density_ic=1.0)
+    init = initial_state(prob, *cell_centres(n, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    kw = dict(cfl=0.9, visc_coef=0.0, tracer_diff_coef=0.0, init_shrink=1.0)
+    nolid = [0.0] * 9
+    ref = run_oracle(orc, n, per, (0, 0, 0), (0, 0, 0), nolid, 3, init, **kw)
+    ns, lay, g, dts = run_gpu(gpu, n, per, (0, 0, 0), (0, 0, 0), nolid, 3, init, (16, 32, 16), **kw)
+    compare(gpu, ns, lay, g, n, dts, ref)
+    S1 = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
+    ldc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs.3d.lid_driven_cavity16")
+    inp = Inputs([ldc], ["amr.n_cell=32 32 32", "amr.max_grid_size=16", "geometry.is_periodic=1 1 1", "ns.lo_bc=0 0 0", "ns.hi_bc=0 0 0",
+                         "prob.probtype=7", "ns.cfl=0.9", "ns.init_shrink=1.0", "ns.vel_visc_coef=0.0", "ns.scal_diff_coefs=0.0",
+                         "ns.init_iter=2", "ns.init_dt=-1.0"])
+    ns2, lay2, g2, pr = R.build(inp, gpu, N)
+    ns2.post_init(-1.0)
+    dts2 = [ns2.step() for _ in range(3)]
+    S2 = ns2.data(N.NavierStokes.S_NEW).gather_valid(n)
+    assert np.allclose(dts2, dts, rtol=1e-10, atol=0) and np.abs(S2 - S1).max() < 1e-9
+    assert np.abs(S1[..., 2]).max() > 0.04 and np.abs(S1[..., 0]).max() > 0.99
