@@ -217,8 +217,16 @@ def main():
     ns = N.NavierStokes(g, lay, params, lib.mg_opts())
     ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
     ns.post_init(-1.0)
+    # HIP events around every 8th finest-level launch of the dominant kernel (k_nodal_gs4), on its launch stream: opened during the warm-up
+    # (creates the event pool), re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
+    probe_on = world == 1 and os.environ.get("IAMRX_BENCH_PROBE", "1") != "0"
+    if probe_on:
+        ns.profile(3)
     for _ in range(a.warmup):
         ns.step()
+    if probe_on:
+        ns.profile(0)
+        ns.profile(3)
 
     def barrier():
         lib.sync()
@@ -242,6 +250,11 @@ def main():
         mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
     barrier()
     el = time.perf_counter() - t0
+    gs4_insitu = None
+    if probe_on:
+        pr = ns.profile(0)
+        if pr[7] > 0:
+            gs4_insitu = (pr[6] / pr[7], int(pr[7]))      # mean duration (ms), number of launches in the timed region
     mallocs_in_loop = nmalloc() - m0
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=tdev)
@@ -273,10 +286,17 @@ def main():
                     traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "k_nodal_gs4" in k][0]
             except Exception:
                 traffic = None
+            # duration: mean over the finest-level launches inside the timed steps (HIP events on the launch stream); the isolated
+            # back-to-back loop of kernel_rooflines() is kept beside it (warm L2, no interleaved fills: shorter)
+            ms = gs4_insitu[0] if gs4_insitu else dom["ms"]
+            gbps = dom["alg_bytes_per_launch"] / ms / 1e6
             roofline = {"kernel": "k_nodal_gs4<32,16,256> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch; the dominant kernel of the step, "
                                   "profiles/round1_*_kernel_stats.csv)", "bound": "hbm",
-                        "achieved": dom["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": dom["ms"]}
+                        "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
+                        "launches_timed": gs4_insitu[1] if gs4_insitu else None,
+                        "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
+                        "isolated_loop_ms": dom["ms"]}
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -526,6 +526,8 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
 struct iamrx_ns_s {
     std::unique_ptr<NavierStokes> ns;
     iamrx_mf_s* views[10];
+    bool probing = false;
+    LayoutP layout;
 };
 
 void iamrx_ns_default_params(iamrx_ns_params* p)
@@ -559,6 +561,7 @@ int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* 
     q.do_cons_trac = p->do_cons_trac;
     auto* h = new iamrx_ns_s;
     h->ns = std::make_unique<NavierStokes>(to_geom(g), l->p, q, to_opts(o));
+    h->layout = l->p;
     for (auto& v : h->views) v = nullptr;
     *out = h;
     IAMRX_CATCH
@@ -710,9 +713,20 @@ int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamr
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8])
 {
     IAMRX_TRY
+    if (ns->probing) {          // close the kernel probe opened by enable = 3
+        double ms = 0.0; long n = 0;
+        gs4_probe_stop(&ms, &n);
+        ns->ns->t_sections[6] = ms; ns->ns->t_sections[7] = (double)n;
+        ns->probing = false;
+    }
     if (sections_ms) for (int i = 0; i < 8; ++i) sections_ms[i] = ns->ns->t_sections[i];
-    if (enable >= 0) ns->ns->profile_sections = enable != 0;
+    if (enable >= 0) ns->ns->profile_sections = enable == 1 || enable == 2;
     if (enable == 2) for (int i = 0; i < 8; ++i) ns->ns->t_sections[i] = 0.0;
+    if (enable == 3) {
+        const Layout& l = *ns->layout;
+        gs4_probe_start((long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1), 8);
+        ns->probing = true;
+    }
     IAMRX_CATCH
 }
 

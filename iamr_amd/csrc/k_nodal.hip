@@ -361,6 +361,37 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 #undef COL
 }
 
+// HIP-event probe around the k_nodal_gs4 launches of levels with at least min_nodes nodes per box (bench.py: the finest level), on the
+// launch stream, so that the roofline figure of the dominant kernel is measured inside the running time step
+namespace {
+struct Gs4Probe {
+    bool on = false;
+    long min_nodes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    long seen = 0;
+    int stride = 1;          // every stride-th qualifying launch is timed (keeps the event overhead out of the step time)
+};
+Gs4Probe g_gs4_probe;
+}
+void gs4_probe_start(long min_nodes, int stride)
+{
+    g_gs4_probe.on = true; g_gs4_probe.min_nodes = min_nodes; g_gs4_probe.used = 0; g_gs4_probe.seen = 0; g_gs4_probe.stride = stride < 1 ? 1 : stride;
+}
+void gs4_probe_stop(double* total_ms, long* launches)
+{
+    Gs4Probe& pb = g_gs4_probe;
+    Context::get().sync();
+    double ms = 0.0;
+    for (size_t i = 0; i < pb.used; ++i) {
+        float t = 0.f;
+        IAMRX_HIP_CHECK(hipEventElapsedTime(&t, pb.ev[i].first, pb.ev[i].second));
+        ms += t;
+    }
+    *total_ms = ms; *launches = (long)pb.used;
+    pb.on = false; pb.used = 0;
+}
+
 template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
                        int kpar, bool wrap, const MultiFab* dmask, const double* csig)
@@ -376,6 +407,16 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
         gx = 8u * (unsigned)(maxcnt * npl);
     }
     dim3 grid(gx, (unsigned)l.nlocal());
+    Gs4Probe& pb = g_gs4_probe;
+    const bool rec = pb.on && (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1) >= pb.min_nodes && (pb.seen++ % pb.stride) == 0;
+    if (rec) {
+        if (pb.used == pb.ev.size()) {
+            hipEvent_t e0, e1;
+            IAMRX_HIP_CHECK(hipEventCreate(&e0)); IAMRX_HIP_CHECK(hipEventCreate(&e1));
+            pb.ev.emplace_back(e0, e1);
+        }
+        IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].first, Context::get().stream));
+    }
 #define IAMRX_GS4(W, M, C) hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
                                              xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
     if (dmask) {
@@ -384,6 +425,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     } else if (wrap) { if (csig) IAMRX_GS4(true, false, true); else IAMRX_GS4(true, false, false); }
     else { if (csig) IAMRX_GS4(false, false, true); else IAMRX_GS4(false, false, false); }
 #undef IAMRX_GS4
+    if (rec) { IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].second, Context::get().stream)); ++pb.used; }
 }
 
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3

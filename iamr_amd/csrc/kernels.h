@@ -15,6 +15,9 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g);   // 
 // nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>
 void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);
 // y = a*x + b*y etc. (valid region + ng)
+// HIP-event probe around the k_nodal_gs4 launches of levels with >= min_nodes nodes per box (see k_nodal.hip)
+void gs4_probe_start(long min_nodes, int stride);
+void gs4_probe_stop(double* total_ms, long* launches);
 void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const MultiFab& y, int comp, int nc, int ng);   // dst = a*x + b*y
 void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, int nc, int ng);                          // y += a*x
 void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng);

@@ -302,7 +302,9 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
  * NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420) */
 int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src);
 int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc);
-/* per-section wall time accumulation (ms): predict, mac, advect, update, viscous, nodal; enable=1 inserts stream syncs */
+/* per-section wall time accumulation (ms): predict, mac, advect, update, viscous, nodal; enable=1 inserts stream syncs (2: and resets).
+ * enable=3: no syncs; HIP events on the launch stream around every 8th k_nodal_gs4 launch of the level's own (finest) MG level until the
+ * next call, which returns their total duration (ms) in sections_ms[6] and their number in sections_ms[7] */
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8]);
 
 #ifdef __cplusplus
