@@ -277,13 +277,14 @@ def main():
         dom = kr.get("nodal_gs4_launch")
         roofline = None
         if dom:
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, corrected as calibrated in
-            # profiles/round1_e_pmc.json); only valid for the size it was collected at
+            # HBM bytes per launch of the 256^3-level launches inside the step, from the PMC passes over this script (FETCH_SIZE / WRITE_SIZE,
+            # separate rocprofv3 runs, corrected as calibrated in profiles/round1_pmc.json); only valid for the size it was collected at
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_e_pmc.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_k_pmc.json")))     # PMC passes over bench.py itself
                 if n == 256:
-                    traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "k_nodal_gs4" in k][0]
+                    traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()
+                               if "k_nodal_gs4<32, 16, 256, true, false, false> grid=5324800" in k][0]
             except Exception:
                 traffic = None
             # duration: mean over the finest-level launches inside the timed steps (HIP events on the launch stream); the isolated
