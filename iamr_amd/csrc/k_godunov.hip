@@ -591,7 +591,9 @@ __global__ void __launch_bounds__(256) k_final_s(Tiling t, const BoxD* __restric
 //   D = 2   : iteration t: A, B -> cell plane k0+t                      [prologue: plane k0-1], consumer -> z-face k0+t-1
 // Arithmetic: corner_at / final_edge, the device functions k_corner / k_final_s run, with the limited slopes read from the
 // arrays k_trace wrote instead of being recomputed (same values), so the result is bit-identical to the split passes.
-template <bool PRED, int D, int TX, int TY>
+// SLA: the limited slopes come from the arrays k_trace wrote (true) or are recomputed from q (false: 24 B per cell and component less
+// HBM traffic, the slope arithmetic again; same values)
+template <bool PRED, int D, int TX, int TY, bool SLA>
 __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX * TY + 63) / 64) * 64) k_dir(const BoxD* __restrict__ boxes,
     const FabD* __restrict__ qt, const FabD* __restrict__ ft, const FabD* __restrict__ divut,
     const FabD* __restrict__ mDt, const FabD* __restrict__ mAt, const FabD* __restrict__ mBt,
@@ -643,16 +645,16 @@ __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX *
         const bool pro = D == 2 || !isA;
         if (isA) {
             const FabD eB = eBt[fab], slA = slAt[fab];
-            if (pro && on) CA[ring(k0 - 1 + off)][lo] = corner_at<PRED, D, TA, true>(P, n, ci, cj, k0 - 1 + off, q, frc, dv, mA, mB, eB, has_force, has_divu, &slA);
+            if (pro && on) CA[ring(k0 - 1 + off)][lo] = corner_at<PRED, D, TA, SLA>(P, n, ci, cj, k0 - 1 + off, q, frc, dv, mA, mB, eB, has_force, has_divu, SLA ? &slA : nullptr);
             for (int t = 0; t <= nk; ++t) {
-                if (t < nk && on) CA[ring(k0 + t + off)][lo] = corner_at<PRED, D, TA, true>(P, n, ci, cj, k0 + t + off, q, frc, dv, mA, mB, eB, has_force, has_divu, &slA);
+                if (t < nk && on) CA[ring(k0 + t + off)][lo] = corner_at<PRED, D, TA, SLA>(P, n, ci, cj, k0 + t + off, q, frc, dv, mA, mB, eB, has_force, has_divu, SLA ? &slA : nullptr);
                 __syncthreads();
             }
         } else {
             const FabD eA = eAt[fab], slB = slBt[fab];
-            if (pro && on) CB[ring(k0 - 1 + off)][lo] = corner_at<PRED, D, TB, true>(P, n, ci, cj, k0 - 1 + off, q, frc, dv, mB, mA, eA, has_force, has_divu, &slB);
+            if (pro && on) CB[ring(k0 - 1 + off)][lo] = corner_at<PRED, D, TB, SLA>(P, n, ci, cj, k0 - 1 + off, q, frc, dv, mB, mA, eA, has_force, has_divu, SLA ? &slB : nullptr);
             for (int t = 0; t <= nk; ++t) {
-                if (t < nk && on) CB[ring(k0 + t + off)][lo] = corner_at<PRED, D, TB, true>(P, n, ci, cj, k0 + t + off, q, frc, dv, mB, mA, eA, has_force, has_divu, &slB);
+                if (t < nk && on) CB[ring(k0 + t + off)][lo] = corner_at<PRED, D, TB, SLA>(P, n, ci, cj, k0 + t + off, q, frc, dv, mB, mA, eA, has_force, has_divu, SLA ? &slB : nullptr);
                 __syncthreads();
             }
         }
@@ -680,8 +682,8 @@ __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX *
                 if (D == 0) { cAsD = 1; cAsT = PW; cBsD = 1; cBsT = (long)(&CB[ring(k + 1)][0] - &CB[ring(k)][0]); }
                 else if (D == 1) { cAsD = PW; cAsT = 1; cBsD = PW; cBsT = (long)(&CB[ring(k + 1)][0] - &CB[ring(k)][0]); }
                 else { cAsD = (long)(&CA[ring(k)][0] - &CA[ring(k - 1)][0]); cAsT = 1; cBsD = (long)(&CB[ring(k)][0] - &CB[ring(k - 1)][0]); cBsT = PW; }
-                out(fi, fj, k, cn) = final_edge<PRED, D, true>(P, n, fi, fj, k, q, frc, dv, has_force, has_divu, umD, mA_l0, mA_l1, mA_h0, mA_h1,
-                                                              mB_l0, mB_l1, mB_h0, mB_h1, cAp, cAsD, cAsT, cBp, cBsD, cBsT, &slD);
+                out(fi, fj, k, cn) = final_edge<PRED, D, SLA>(P, n, fi, fj, k, q, frc, dv, has_force, has_divu, umD, mA_l0, mA_l1, mA_h0, mA_h1,
+                                                              mB_l0, mB_l1, mB_h0, mB_h1, cAp, cAsD, cAsT, cBp, cBsD, cBsT, SLA ? &slD : nullptr);
             }
             __syncthreads();
         }
@@ -809,9 +811,12 @@ static void launch_dir_t(const Layout& l, const MultiFab& q, int ncomp, const Mu
     const int total = ntx * nty * nkc;
     const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
     dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), (unsigned)(PRED ? 1 : ncomp));
-    hipLaunchKernelGGL((k_dir<PRED, D, TX, TY>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, q.d_tab,
-                       force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab,
-                       e0[TA].d_tab, e0[TB].d_tab, sl[D].d_tab, sl[TA].d_tab, sl[TB].d_tab, out.d_tab, dP, ntx, nty, nkc, kc, xcd_cnt);
+    static const bool sla = !(getenv("IAMRX_GODUNOV_DIR_SLOPES") && atoi(getenv("IAMRX_GODUNOV_DIR_SLOPES")) == 0);
+#define IAMRX_KDIR(SLA) hipLaunchKernelGGL((k_dir<PRED, D, TX, TY, SLA>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, q.d_tab, \
+                       force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab, \
+                       e0[TA].d_tab, e0[TB].d_tab, sl[D].d_tab, sl[TA].d_tab, sl[TB].d_tab, out.d_tab, dP, ntx, nty, nkc, kc, xcd_cnt)
+    if (sla) IAMRX_KDIR(true); else IAMRX_KDIR(false);
+#undef IAMRX_KDIR
 }
 
 template <bool PRED, int D>
