@@ -263,6 +263,29 @@ double orc_ns_time(const orc_ns_state* s);
 double orc_ns_dt(const orc_ns_state* s);
 void orc_ns_last_stats(const orc_ns_state* s, orc_mg_stats* mac, orc_mg_stats* nodal, orc_mg_stats* visc);
 
+/* ---- multi-level hierarchy (orc_amr.c): Amr::coarseTimeStep with subcycling, reflux, average down, MAC sync, sync projection ------- */
+/* every level > 0 is the union of nbox[l] boxes (6 ints each: lo, hi, in the level's own index space, aligned to the refinement
+ * ratio), held as whole-domain arrays of that index space: orc_ns_fab(orc_amr_level(a, l), which) are fabs on [0, n0*ratio^l - 1]^3;
+ * only the entries inside the boxes are data of the level.  boxes: concatenation for levels 1 .. nlev-1; nbox[0] is ignored. */
+typedef struct orc_amr orc_amr;
+orc_amr* orc_amr_create(const orc_geom* g0, const orc_ns_params* p, const orc_mg_opts* o, int nlev, int ratio, const int* nbox, const int* boxes);
+void orc_amr_destroy(orc_amr* a);
+orc_ns_state* orc_amr_level(orc_amr* a, int lev);
+const orc_fab* orc_amr_cov(orc_amr* a, int lev);            /* cell fab, 1 on the level's cells (NULL on level 0) */
+/* NavierStokes::post_init for the hierarchy; S_new of every level must hold the initial data on the level's cells */
+void orc_amr_post_init(orc_amr* a, double stop_time);
+double orc_amr_coarse_step(orc_amr* a);                      /* returns the level-0 dt */
+double orc_amr_time(const orc_amr* a);
+double orc_amr_dt(const orc_amr* a, int lev);
+void orc_amr_sync_stats(const orc_amr* a, orc_mg_stats* st);
+/* Hydro::NodalProjector::project on levels c0 .. c0+nl-1 (composite nodal projection), see orc_amr.c */
+void amr_composite_project(orc_amr* a, int c0, int nl, orc_fab* vel[], orc_fab* phi[], const orc_fab* sig[], const orc_fab* rhnd, double rtol,
+                           double atol, int increment_gp, double inflow_scale, orc_mg_stats* st);
+/* ComputeAofs with is_sync (orc_godunov.c) */
+void orc_compute_aofs_sync(const orc_geom* g, orc_fab* sync, int acomp, const orc_fab* S, int ncomp,
+                           const orc_fab* force, const orc_fab* divu, orc_fab* const umac[3], orc_fab* const ucorr[3], const int* iconserv,
+                           double dt, const orc_bcrec* bc, int is_velocity, int use_forces_in_trans, orc_fab* flux_out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,11 +101,15 @@ void orc_fill_physbc_cc(orc_fab* f, const orc_geom* g, const orc_bcrec* bc,
         }
 }
 
-/* ---- coarse-fine fill (amrex::FillPatchTwoLevels with CellConservativeLinear, linear limiting; the interpolater IAMR
- * registers for State_Type / Gradp_Type, reference Source/NS_setup.cpp:206-394).  Published algorithm restated:
+/* ---- coarse-fine fill (amrex::FillPatchTwoLevels with the interpolater IAMR registers for State_Type / Gradp_Type, `cell_cons_interp`,
+ * reference Source/NS_setup.cpp:206-394, = amrex::CellConservativeLinear constructed with do_linear_limiting = FALSE, i.e. the
+ * per-component monotonised-central variant (upstream mf_cell_cons_lin_interp_mcslope).  Published algorithm restated, per component:
  * unlimited central slope dc (one-sided 4-point formula in the coarse cell next to an ext_dir / hoextrap domain face), limited
- * slope s = sign(dc) min(|dc|, 2|u(i+1)-u(i)|, 2|u(i)-u(i-1)|) or 0 at an extremum, ONE factor per direction
- * alpha_d = min over the components of s/dc, fine = crse + sum_d offset_d * alpha_d * dc_d.
+ * slope s_d = sign(dc) min(|dc|, 2|u(i+1)-u(i)|, 2|u(i)-u(i-1)|) or 0 at an extremum; then ONE factor alpha <= 1 for the three
+ * slopes of the component so that the largest excursion inside the coarse cell, sum_d |s_d| (r-1)/(2r), stays within the minimum /
+ * maximum of the 27 coarse neighbours; fine = crse + sum_d offset_d * alpha * s_d.
+ * (Round 1 restated the linear-limiting variant `lincc_interp`, whose limiter factor is shared by all components; a component
+ * that is zero up to round-off noise -- w in a two-dimensional flow -- then switches the slopes of every component off.)
  * crse: coarse level data with >= 1 filled ghost cell (periodic / physical BC already applied), covering what is needed.
  * Fills every cell of `fine` (incl. ghosts) that lies inside [flo,fhi] (the region to fill) but OUTSIDE [vlo,vhi] (the fine
  * level's own valid box). */
@@ -133,34 +137,40 @@ void orc_fill_coarse_fine(orc_fab* fine, const int flo[3], const int fhi[3], con
                           const orc_bcrec* bc)
 {
     const int nc = fine->nc;
+    const double exc = (double)(ratio - 1) / (double)(2 * ratio);
     for (int k = flo[2]; k <= fhi[2]; ++k) for (int j = flo[1]; j <= fhi[1]; ++j) for (int i = flo[0]; i <= fhi[0]; ++i) {
         if (i >= vlo[0] && i <= vhi[0] && j >= vlo[1] && j <= vhi[1] && k >= vlo[2] && k <= vhi[2]) continue;
         const int f[3] = {i, j, k};
         int c[3];
-        double off[3], alpha[3] = {1.0, 1.0, 1.0};
+        double off[3];
         for (int d = 0; d < 3; ++d) {
             c[d] = f[d] >= 0 ? f[d] / ratio : -((-f[d] + ratio - 1) / ratio);
             off[d] = ((double)(f[d] - c[d] * ratio) + 0.5) / (double)ratio - 0.5;
         }
-        for (int n = 0; n < nc; ++n)
+        for (int n = 0; n < nc; ++n) {
+            const double u0 = A4(crse, c[0], c[1], c[2], n);
+            double sl[3];
             for (int d = 0; d < 3; ++d) {
                 const int bl = periodic[d] ? ORC_BC_INT_DIR : bc[n].lo[d], bh = periodic[d] ? ORC_BC_INT_DIR : bc[n].hi[d];
                 const double dc = cf_cslope(crse, c, n, d, cdomlo[d], cdomhi[d], bl, bh);
                 int m[3] = {c[0], c[1], c[2]}, p[3] = {c[0], c[1], c[2]};
                 m[d] -= 1; p[d] += 1;
-                const double u0 = A4(crse, c[0], c[1], c[2], n);
                 const double df = 2.0 * (A4(crse, p[0], p[1], p[2], n) - u0), db = 2.0 * (u0 - A4(crse, m[0], m[1], m[2], n));
-                double sl = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
-                sl = copysign(1.0, dc) * fmin(sl, fabs(dc));
-                if (dc != 0.0) alpha[d] = fmin(alpha[d], sl / dc);
+                double s = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+                sl[d] = copysign(1.0, dc) * fmin(s, fabs(dc));
             }
-        for (int n = 0; n < nc; ++n) {
-            double v = A4(crse, c[0], c[1], c[2], n);
-            for (int d = 0; d < 3; ++d) {
-                const int bl = periodic[d] ? ORC_BC_INT_DIR : bc[n].lo[d], bh = periodic[d] ? ORC_BC_INT_DIR : bc[n].hi[d];
-                v += off[d] * (alpha[d] * cf_cslope(crse, c, n, d, cdomlo[d], cdomhi[d], bl, bh));
+            double alpha = 1.0;
+            if (sl[0] != 0.0 || sl[1] != 0.0 || sl[2] != 0.0) {
+                const double dumax = fabs(sl[0]) * exc + fabs(sl[1]) * exc + fabs(sl[2]) * exc;
+                double umax = u0, umin = u0;
+                for (int ko = -1; ko <= 1; ++ko) for (int jo = -1; jo <= 1; ++jo) for (int io = -1; io <= 1; ++io) {
+                    const double v = A4(crse, c[0] + io, c[1] + jo, c[2] + ko, n);
+                    umin = fmin(umin, v); umax = fmax(umax, v);
+                }
+                if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
+                if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
             }
-            A4(fine, i, j, k, n) = v;
+            A4(fine, i, j, k, n) = u0 + off[0] * (sl[0] * alpha) + off[1] * (sl[1] * alpha) + off[2] * (sl[2] * alpha);
         }
     }
 }

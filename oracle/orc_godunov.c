@@ -443,3 +443,34 @@ void orc_compute_aofs(const orc_geom* g, orc_fab* aofs, int acomp, const orc_fab
         orc_free(&edge[d]); orc_free(&flux[d]);
     }
 }
+
+/* NavierStokesBase::ComputeAofs with is_sync = true (Source/NavierStokesBase.cpp:4594-4845 as called from MacProj::mac_sync_compute,
+ * Source/MacProj.cpp:700-731): the edge states are traced with the level's u_mac, the fluxes are formed with the correction velocity
+ * Ucorr (:4681-4683), the update is the conservative one for every component (:4777: no convective term in a sync) and the result
+ * is accumulated: sync -= update with update = -div(F)/vol (:4826-4832). */
+void orc_compute_aofs_sync(const orc_geom* g, orc_fab* sync, int acomp, const orc_fab* S, int ncomp,
+                           const orc_fab* force, const orc_fab* divu, orc_fab* const umac[3], orc_fab* const ucorr[3], const int* iconserv,
+                           double dt, const orc_bcrec* bc, int is_velocity, int use_forces_in_trans, orc_fab* flux_out[3])
+{
+    orc_fab edge[3], flux[3];
+    for (int d = 0; d < 3; ++d) { edge[d] = alloc_faces(g, d, 0, ncomp); flux[d] = alloc_faces(g, d, 0, ncomp); }
+    compute_edge_state(g, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edge);
+    for (int d = 0; d < 3; ++d) {
+        const double area = g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
+        int f[3];
+        for (int n = 0; n < ncomp; ++n)
+        LOOP3(&flux[d], f) *QP(&flux[d], f, n) = Q(&edge[d], f, n) * Q(ucorr[d], f, 0) * area;
+    }
+    const double qvol = 1.0 / (g->dx[0] * g->dx[1] * g->dx[2]);
+    for (int n = 0; n < ncomp; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        const double upd = -1.0 * qvol * ((A4(&flux[0], i + 1, j, k, n) - A4(&flux[0], i, j, k, n))
+                                        + (A4(&flux[1], i, j + 1, k, n) - A4(&flux[1], i, j, k, n))
+                                        + (A4(&flux[2], i, j, k + 1, n) - A4(&flux[2], i, j, k, n)));
+        A4(sync, i, j, k, acomp + n) -= upd;
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (flux_out && flux_out[d]) memcpy(flux_out[d]->p, flux[d].p, orc_npts(&flux[d]) * ncomp * sizeof(double));
+        orc_free(&edge[d]); orc_free(&flux[d]);
+    }
+}

@@ -13,6 +13,8 @@
  * Source/NavierStokesBase.cpp:4102-4122 (computeGradP -> compGrad).
  */
 #include "orc_int.h"
+void orc_nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], const int hibc[3]);
+void orc_sigma_fill_bc(const orc_geom* g, orc_fab* s);
 
 /* Neumann-like faces of the nodal operator: walls and inflow faces */
 #define NEU(b) ((b) == ORC_LO_NEUMANN || (b) == ORC_LO_INFLOW)
@@ -139,6 +141,7 @@ static void nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], cons
         }
     }
 }
+void orc_nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], const int hibc[3]) { nodal_fill_bc(g, x, lobc, hibc); }
 static const int PERIODIC_BC[3] = {ORC_LO_PERIODIC, ORC_LO_PERIODIC, ORC_LO_PERIODIC};
 /* BCs of the solve in progress (the oracle is single-threaded) */
 static const int *g_lobc = PERIODIC_BC, *g_hibc = PERIODIC_BC;
@@ -164,6 +167,8 @@ static void sigma_fill_bc(const orc_geom* g, orc_fab* s)
         }
     }
 }
+
+void orc_sigma_fill_bc(const orc_geom* g, orc_fab* s) { sigma_fill_bc(g, s); }
 
 /* weight of a node in sums / dot products: 0 for periodic duplicates, 1/2 per Neumann wall the node lies on
  * (the nodal system is stored in the "doubled" form A_full = 2^k A_half at wall nodes; MLNodeLinOp dot mask) */

@@ -25,41 +25,7 @@
  * xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, no divu, NUM_STATE = 5
  * (u,v,w,rho,tracer), do_mom_diff = 0 or 1, Godunov_PLM.
  */
-#include "orc_int.h"
-
-enum { Xvel = 0, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
-
-struct orc_ns_state {
-    orc_geom g;
-    orc_ns_params p;
-    orc_mg_opts o;
-    orc_fab S[2];      /* [new, old] swapped by index */
-    orc_fab P[2];
-    orc_fab Gp[2];
-    int inew;          /* index of "new" for S */
-    int pnew;          /* index of "new" for P/Gp */
-    orc_fab umac[3];
-    orc_fab aofs;
-    orc_fab rho_ptime, rho_ctime, rho_half;
-    double time, dt, dt_min_adv;
-    int nstep;
-    int initial_step, initial_iter;
-    orc_mg_stats st_mac, st_nodal, st_visc, st_scal;
-    int lobc[3], hibc[3];          /* LinOp BC of the MAC projection: Neumann at walls / inflow, Dirichlet at outflow */
-    int nlobc[3], nhibc[3];        /* nodal projection: the same with ORC_LO_INFLOW on inflow faces */
-    double ed_scal_lo[6], ed_scal_hi[6];   /* ext_dir (inflow) values [n*3+d] of density, tracer */
-    orc_bcrec bc_vel[3], bc_scal[2], bc_gp[3];
-    double ed_vel_lo[9], ed_vel_hi[9];   /* ext_dir values [n*3+d] for the velocity fill */
-    int vlobc[9], vhibc[9];        /* tensor-solve LinOp BC per velocity component [n*3+d] */
-    int slobc[3], shibc[3];        /* scalar-diffusion LinOp BC (tracer) */
-};
-
-#define S_NEW(s) (&(s)->S[(s)->inew])
-#define S_OLD(s) (&(s)->S[1 - (s)->inew])
-#define P_NEW(s) (&(s)->P[(s)->pnew])
-#define P_OLD(s) (&(s)->P[1 - (s)->pnew])
-#define GP_NEW(s) (&(s)->Gp[(s)->pnew])
-#define GP_OLD(s) (&(s)->Gp[1 - (s)->pnew])
+#include "orc_ns_int.h"
 
 void orc_ns_default_params(orc_ns_params* p)
 {
@@ -121,6 +87,10 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     s->rho_ptime = orc_alloc(g->n, ORC_CELL, 1, 1);
     s->rho_ctime = orc_alloc(g->n, ORC_CELL, 1, 1);
     s->rho_half = orc_alloc(g->n, ORC_CELL, 1, 1);
+    s->mac_phi = orc_alloc(g->n, ORC_CELL, 1, 1);
+    s->level = 0; s->ratio = 1; s->crse = s->fine = NULL; s->nbox = 0; s->boxes = NULL; s->cov.p = NULL;
+    s->iteration = 1; s->ncycle = 1;
+    ns_set_time_level(s, 0.0, 0.0, 0.0);
     for (int d = 0; d < 3; ++d) {
         const int plo = g->periodic[d] ? PHYS_INTERIOR : p->phys_lo[d], phi_ = g->periodic[d] ? PHYS_INTERIOR : p->phys_hi[d];
         if (!g->periodic[d] && !(phys_ok(plo) && phys_ok(phi_))) {
@@ -157,6 +127,16 @@ void orc_ns_destroy(orc_ns_state* s)
     for (int q = 0; q < 2; ++q) { orc_free(&s->S[q]); orc_free(&s->P[q]); orc_free(&s->Gp[q]); }
     for (int d = 0; d < 3; ++d) orc_free(&s->umac[d]);
     orc_free(&s->aofs); orc_free(&s->rho_ptime); orc_free(&s->rho_ctime); orc_free(&s->rho_half);
+    orc_free(&s->mac_phi);
+    if (s->cov.p) orc_free(&s->cov);
+    if (s->rho_avg.p) orc_free(&s->rho_avg);
+    if (s->p_avg.p) orc_free(&s->p_avg);
+    if (s->Vsync.p) orc_free(&s->Vsync);
+    if (s->Ssync.p) orc_free(&s->Ssync);
+    for (int d = 0; d < 3; ++d) { if (s->reg_adv[d].p) orc_free(&s->reg_adv[d]); if (s->reg_visc[d].p) orc_free(&s->reg_visc[d]); if (s->reg_mac[d].p) orc_free(&s->reg_mac[d]); }
+    if (s->sync_reg.p) orc_free(&s->sync_reg);
+    if (s->sync_resid_crse.p) orc_free(&s->sync_resid_crse);
+    free(s->boxes);
     free(s);
 }
 
@@ -171,6 +151,13 @@ orc_fab* orc_ns_fab(orc_ns_state* s, int which)
     case 5: return GP_OLD(s);
     case 6: case 7: case 8: return &s->umac[which - 6];
     case 9: return &s->aofs;
+    case 10: return &s->mac_phi;
+    case 11: return &s->rho_half;
+    case 12: return s->Vsync.p ? &s->Vsync : NULL;
+    case 13: return s->Ssync.p ? &s->Ssync : NULL;
+    case 14: return s->rho_avg.p ? &s->rho_avg : NULL;
+    case 15: return s->p_avg.p ? &s->p_avg : NULL;
+    case 16: return s->sync_reg.p ? &s->sync_reg : NULL;
     default: return NULL;
     }
 }
@@ -238,9 +225,133 @@ void orc_ns_init_rest(orc_ns_state* s, double rho0)
     s->time = 0.0; s->nstep = 0;
 }
 
-/* FillPatch of comps [sc, sc+nc) of src (valid region) into a fresh fab with ng ghosts */
+/* ---- AMR-aware pieces (a level > 0 is a whole-domain array + coverage mask, see orc_ns_int.h) ---------------------------- */
+static inline int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
+
+int ns_covered(const orc_ns_state* s, int i, int j, int k)
+{
+    int c[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d) {
+        if (c[d] < 0 || c[d] >= s->g.n[d]) { if (!s->g.periodic[d]) return 0; c[d] = wrapi(c[d], s->g.n[d]); }
+    }
+    return s->cov.p ? A4(&s->cov, c[0], c[1], c[2], 0) != 0.0 : 1;
+}
+
+int ns_in_grown(const orc_ns_state* s, int i, int j, int k, int ng)
+{
+    const int c[3] = {i, j, k};
+    if (s->level == 0) {
+        for (int d = 0; d < 3; ++d) if (c[d] < -ng || c[d] > s->g.n[d] - 1 + ng) return 0;
+        return 1;
+    }
+    for (int b = 0; b < s->nbox; ++b) {
+        const int* bx = s->boxes + 6 * b;
+        int in = 1;
+        for (int d = 0; d < 3 && in; ++d) {
+            int ok = 0;
+            for (int sh = -1; sh <= 1 && !ok; ++sh) {
+                if (sh != 0 && !s->g.periodic[d]) continue;
+                const int q = c[d] - sh * s->g.n[d];
+                if (q >= bx[d] - ng && q <= bx[3 + d] + ng) ok = 1;
+            }
+            in = ok;
+        }
+        if (in) return 1;
+    }
+    return 0;
+}
+
+/* NavierStokesBase::setTimeLevel (NavierStokesBase.cpp:2978-2996) with amrex::StateData::setTimeLevel semantics: State_Type is a
+ * Point type, Press_Type / Gradp_Type are Interval types (NS_setup.cpp:228-341) shifted back by dt_old */
+void ns_set_time_level(orc_ns_state* s, double time, double dt_old, double dt_new)
+{
+    (void)dt_new;
+    s->st_new = time; s->st_old = time - dt_old;
+    const double tp = time - dt_old;               /* state[Press_Type].setTimeLevel(time-dt_old,dt_old,dt_old) */
+    s->pt_new[0] = tp; s->pt_new[1] = tp + dt_old;
+    s->pt_old[0] = tp - dt_old; s->pt_old[1] = tp;
+}
+
+/* StateData::swapTimeLevels(dt) */
+static void swap_time_levels(orc_ns_state* s, double dt)
+{
+    s->st_old = s->st_new; s->st_new += dt;
+    s->pt_old[0] = s->pt_new[0]; s->pt_old[1] = s->pt_new[1];
+    s->pt_new[0] = s->pt_new[1]; s->pt_new[1] += dt;
+}
+
+/* the level's own State_Type data at `time` (valid cells only matter): amrex::StateData::getData for a Point type -- old or new
+ * within 1e-3 (t_new - t_old) of their times, linear interpolation otherwise.  Returns a 0-ghost fab with nc comps. */
+static orc_fab state_at(const orc_ns_state* s, double time, int sc, int nc)
+{
+    const orc_geom* g = &s->g;
+    orc_fab f = orc_alloc(g->n, ORC_CELL, 0, nc);
+    const orc_fab *So = S_OLD(s), *Sn = S_NEW(s);
+    const double teps = 1.e-3 * fabs(s->st_new - s->st_old);
+    double a = 0.0, b = 1.0;
+    if (fabs(time - s->st_new) <= teps) { a = 0.0; b = 1.0; }
+    else if (fabs(time - s->st_old) <= teps) { a = 1.0; b = 0.0; }
+    else { a = (s->st_new - time) / (s->st_new - s->st_old); b = (time - s->st_old) / (s->st_new - s->st_old); }
+    for (int n = 0; n < nc; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (a == 0.0) A4(&f, i, j, k, n) = A4(Sn, i, j, k, sc + n);
+        else if (b == 0.0) A4(&f, i, j, k, n) = A4(So, i, j, k, sc + n);
+        else A4(&f, i, j, k, n) = a * A4(So, i, j, k, sc + n) + b * A4(Sn, i, j, k, sc + n);
+    }
+    return f;
+}
+
+/* Gradp_Type (Interval): the data whose time interval contains `time` (amrex::StateData::getData) */
+static orc_fab gradp_at(const orc_ns_state* s, double time)
+{
+    const orc_geom* g = &s->g;
+    const double teps = 1.e-3 * fabs(s->pt_new[0] - s->pt_old[0]);
+    const orc_fab* G;
+    if (time >= s->pt_new[0] - teps && time <= s->pt_new[1] + teps) G = GP_NEW(s);
+    else if (time >= s->pt_old[0] - teps && time <= s->pt_old[1] + teps) G = GP_OLD(s);
+    else { fprintf(stderr, "orc gradp_at: level %d has no Gradp data at time %.17g (old [%g,%g] new [%g,%g])\n", s->level, time, s->pt_old[0], s->pt_old[1], s->pt_new[0], s->pt_new[1]); abort(); }
+    orc_fab f = orc_alloc(g->n, ORC_CELL, 0, 3);
+    for (int n = 0; n < 3; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&f, i, j, k, n) = A4(G, i, j, k, n);
+    return f;
+}
+
+/* AmrLevel::FillPatch (FillPatchSingleLevel / FillPatchTwoLevels with cell_cons_interp, NS_setup.cpp:206-394): the level's own data
+ * where the level has cells, conservative-linear interpolation of the (recursively FillPatch'ed) coarse data elsewhere, periodic
+ * images, then the physical BC.  type 0: State_Type comps [sc, sc+nc); type 1: Gradp_Type (3 comps). */
+orc_fab ns_fillpatch_time(const orc_ns_state* s, double time, int type, int sc, int nc, int ng)
+{
+    const orc_geom* g = &s->g;
+    const orc_bcrec* bc = type == 1 ? s->bc_gp : (sc < 3 ? s->bc_vel + sc : s->bc_scal + (sc - 3));
+    const double* edlo = type == 1 ? NULL : (sc < 3 ? s->ed_vel_lo + 3 * sc : s->ed_scal_lo + 3 * (sc - 3));
+    const double* edhi = type == 1 ? NULL : (sc < 3 ? s->ed_vel_hi + 3 * sc : s->ed_scal_hi + 3 * (sc - 3));
+    orc_fab own = type == 1 ? gradp_at(s, time) : state_at(s, time, sc, nc);
+    orc_fab f = orc_alloc(g->n, ORC_CELL, ng, nc);
+    if (s->level > 0) {
+        const int r = s->ratio;
+        const int ngc = (ng + r - 1) / r + 2;          /* coarsen(ghost region) + 1 for the slopes + 1 for the one-sided slope form */
+        orc_fab c = ns_fillpatch_time(s->crse, time, type, sc, nc, ngc);
+        const int cdomlo[3] = {0, 0, 0}, cdomhi[3] = {s->crse->g.n[0] - 1, s->crse->g.n[1] - 1, s->crse->g.n[2] - 1};
+        const int vlo[3] = {1, 1, 1}, vhi[3] = {0, 0, 0};      /* empty "valid box": interpolate everywhere, the level's cells are overwritten below */
+        orc_fill_coarse_fine(&f, f.lo, f.hi, vlo, vhi, &c, cdomlo, cdomhi, g->periodic, r, bc);
+        orc_free(&c);
+    }
+    for (int n = 0; n < nc; ++n)
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        if (s->level == 0 || A4(&s->cov, i, j, k, 0) != 0.0) A4(&f, i, j, k, n) = A4(&own, i, j, k, n);
+    orc_free(&own);
+    orc_fill_periodic(&f, g, ORC_CELL);
+    orc_fill_physbc_cc(&f, g, bc, edlo, edhi);
+    return f;
+}
+
+/* FillPatch of comps [sc, sc+nc) of src (S_OLD or S_NEW of the level) into a fresh fab with ng ghosts */
 static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int nc, int ng, const orc_bcrec* bc)
 {
+    if (s->level > 0) {
+        if (src != S_OLD(s) && src != S_NEW(s)) { fprintf(stderr, "orc fillpatch: level > 0 needs a StateData source\n"); abort(); }
+        return ns_fillpatch_time(s, src == S_OLD(s) ? s->st_old : s->st_new, 0, sc, nc, ng);
+    }
     const int is_vel = (bc == s->bc_vel);
     const orc_geom* g = &s->g;
     orc_fab f = orc_alloc(g->n, ORC_CELL, ng, nc);
@@ -253,6 +364,26 @@ static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int 
     if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : (is_scal ? s->ed_scal_lo + so : NULL),
                                is_vel ? s->ed_vel_hi : (is_scal ? s->ed_scal_hi + so : NULL));
     return f;
+}
+
+/* FillPatch(Gradp_Type) of array G (GP_OLD or GP_NEW) at `time`: ghost cells only (Projection.cpp:2564-2565,
+ * NavierStokesBase.cpp:4421-4422); the valid data are left alone */
+void ns_fill_gp(orc_ns_state* s, orc_fab* G, double time)
+{
+    const orc_geom* g = &s->g;
+    if (s->level == 0) {
+        orc_fill_periodic(G, g, ORC_CELL);
+        orc_fill_physbc_cc(G, g, s->bc_gp, NULL, NULL);
+        return;
+    }
+    orc_fab f = ns_fillpatch_time(s, time, 1, 0, 3, 1);
+    for (int n = 0; n < 3; ++n)
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        const int inside = i >= 0 && i < g->n[0] && j >= 0 && j < g->n[1] && k >= 0 && k < g->n[2];
+        if (inside && A4(&s->cov, i, j, k, 0) != 0.0) continue;
+        A4(G, i, j, k, n) = A4(&f, i, j, k, n);
+    }
+    orc_free(&f);
 }
 static void fill_ghosts(const orc_ns_state* s, orc_fab* f, const int type[3])
 {
@@ -359,7 +490,7 @@ static double force_vel(const orc_ns_state* s, int n, double rho)
     return 0.0;
 }
 
-static double est_time_step(orc_ns_state* s)
+double ns_est_time_step(orc_ns_state* s)
 {
     const orc_geom* g = &s->g;
     if (s->p.fixed_dt > 0.0) return s->p.fixed_dt;
@@ -370,6 +501,7 @@ static double est_time_step(orc_ns_state* s)
     double umax[3] = {0, 0, 0}, fmax_[3] = {0, 0, 0};
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (s->cov.p && A4(&s->cov, i, j, k, 0) == 0.0) continue;
         double u = fabs(A4(S, i, j, k, n)); if (u > umax[n]) umax[n] = u;
         double rho = A4(S, i, j, k, Density);
         double rho_inv = 1.0 / rho;
@@ -388,12 +520,9 @@ static double est_time_step(orc_ns_state* s)
     return estdt;
 }
 
-static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost, comps 0..2*/, orc_fab* phi, const orc_fab* sig,
-                                int increment_gp, double inflow_scale)
+void ns_set_inflow_ghosts(const orc_ns_state* s, orc_fab* vel, double inflow_scale)
 {
     const orc_geom* g = &s->g;
-    /* set_boundary_velocity + FillBoundary of vel ghost cells (periodic) */
-    orc_fill_periodic(vel, g, ORC_CELL);
     /* inflow faces: the ghost cells hold the boundary value of the projected field (setPhysBoundaryValues before the scaling of
      * U_new, Projection.cpp:199-207): inflow velocity x inflow_scale (1/dt in level_project, 1 in the initial velocity projection,
      * 0 for the time-difference of a steady inflow in initialSyncProject) */
@@ -404,19 +533,50 @@ static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost,
         lo[d] = hi[d] = side == 0 ? -1 : g->n[d];
         for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i) A4(vel, i, j, k, d) = uin;
     }
-    orc_nodal_project(g, vel, phi, sig, s->nlobc, s->nhibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+}
+
+/* Projection::doMLMGNodalProjection on ONE level (Projection.cpp:2385-2567).  sync != 0 (level_project only): the sync residuals of
+ * Projection.cpp:367-377 are computed from the unprojected velocity and the solution and go into the sync registers (:401-431). */
+static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost, comps 0..2*/, orc_fab* phi, const orc_fab* sig,
+                                int increment_gp, double inflow_scale, int sync)
+{
+    const orc_geom* g = &s->g;
+    /* set_boundary_velocity + FillBoundary of vel ghost cells (periodic) */
+    orc_fill_periodic(vel, g, ORC_CELL);
+    ns_set_inflow_ghosts(s, vel, inflow_scale);
+    const int want_crse = sync && s->fine != NULL;
+    const int want_fine = sync && s->level > 0 && s->iteration == s->ncycle;
+    orc_fab vold; vold.p = NULL;
+    if (want_crse || want_fine) {
+        vold = orc_alloc(g->n, ORC_CELL, 1, 3);
+        for (int n = 0; n < 3; ++n)
+        for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) A4(&vold, i, j, k, n) = A4(vel, i, j, k, n);
+    }
+    if (s->level == 0) orc_nodal_project(g, vel, phi, sig, s->nlobc, s->nhibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+    else orc_nodal_project_cov(g, vel, phi, sig, s->nlobc, s->nhibc, &s->cov, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
     /* Gp_new := grad(phi) or += (Projection.cpp:2549-2563), then FillPatch(Gp) */
     orc_fab gp = orc_alloc(g->n, ORC_CELL, 0, 3);
     orc_nodal_compgrad(g, &gp, phi);
     orc_fab* G = GP_NEW(s);
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (s->cov.p && A4(&s->cov, i, j, k, 0) == 0.0) continue;
         if (increment_gp) A4(G, i, j, k, n) += A4(&gp, i, j, k, n);
         else A4(G, i, j, k, n) = A4(&gp, i, j, k, n);
     }
-    orc_fill_periodic(G, g, ORC_CELL);
-    orc_fill_physbc_cc(G, g, s->bc_gp, NULL, NULL);   /* FillPatch(Gradp_Type), Projection.cpp:2565 */
+    ns_fill_gp(s, G, 0.5 * (s->pt_new[0] + s->pt_new[1]));   /* FillPatch(Gradp_Type) at its current time, Projection.cpp:2564-2565 */
     orc_free(&gp);
+    if (want_crse) {            /* crse_sync_reg->CrseInit(sync_resid_crse, geom, 1.0) */
+        orc_fab r = amr_sync_resid_crse(s, &vold, phi, sig);
+        syncreg_crse_init(s->fine, &r, 1.0);
+        orc_free(&r);
+    }
+    if (want_fine) {            /* fine_sync_reg->FineAdd(sync_resid_fine, crse_geom, 1/crse_dt_ratio) */
+        orc_fab r = amr_sync_resid_fine(s, &vold, phi, sig);
+        syncreg_fine_add(s, &r, 1.0 / (double)s->ncycle);
+        orc_free(&r);
+    }
+    if (vold.p) orc_free(&vold);
 }
 
 /* wrap the velocity comps of a state fab as a 3-comp view (same memory) */
@@ -432,18 +592,31 @@ static void initial_velocity_project(orc_ns_state* s)
         orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_setval(&sig, 1.0);       /* constant-density initial projection; scaleVar inverts: 1/1 */
         orc_fab v = vel_view(S_NEW(s));
-        nodal_project_level(s, &v, phi, &sig, 0, 1.0);
+        nodal_project_level(s, &v, phi, &sig, 0, 1.0, 0);
         orc_free(&sig);
         orc_setval(P_OLD(s), 0.0); orc_setval(P_NEW(s), 0.0);
         orc_setval(GP_OLD(s), 0.0); orc_setval(GP_NEW(s), 0.0);
     }
 }
 
-static void advance_setup(orc_ns_state* s)
+/* NavierStokesBase::advance_setup (NavierStokesBase.cpp:613-741) */
+static void advance_setup(orc_ns_state* s, double dt, int iteration, int ncycle)
 {
-    for (int d = 0; d < 3; ++d) if (s->nstep == 0 && s->initial_step) { /* keep the 1e40 sentinel of the first allocation */ }
+    const orc_geom* g = &s->g;
+    s->iteration = iteration; s->ncycle = ncycle;
+    if (s->fine) {
+        orc_setval(&s->Vsync, 0.0); orc_setval(&s->Ssync, 0.0);          /* :643-650 */
+        reg_setval(s->fine->reg_adv, 0.0); reg_setval(s->fine->reg_visc, 0.0);   /* :655-659 */
+    }
+    if (!s->initial_step && s->level > 0 && iteration == 1) {           /* initRhoAvg(0.5/ncycle), :685-687 (before the swap) */
+        const double alpha = 0.5 / (double)ncycle;
+        orc_setval(&s->rho_avg, 1.e200);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&s->rho_avg, i, j, k, 0) = A4(S_NEW(s), i, j, k, Density) * alpha;
+    }
     s->inew = 1 - s->inew;     /* swapTimeLevels: old <- new, new <- old storage */
     s->pnew = 1 - s->pnew;
+    swap_time_levels(s, dt);
     /* make_rho_prev_time */
     orc_fab r = fillpatch(s, S_OLD(s), Density, 1, 1, &s->bc_scal[0]);
     orc_copy_all(&s->rho_ptime, &r);
@@ -458,11 +631,15 @@ static double predict_velocity(orc_ns_state* s, double dt)
     double cflmax = 0.0;
     for (int n = 0; n < 3; ++n) {
         double um = 0.0;
-        size_t N = orc_npts(&Umf);
-        for (size_t q = 0; q < N; ++q) { double v = fabs(Umf.p[q + N * n]); if (v > um) um = v; }
+        for (int k = Umf.lo[2]; k <= Umf.hi[2]; ++k) for (int j = Umf.lo[1]; j <= Umf.hi[1]; ++j) for (int i = Umf.lo[0]; i <= Umf.hi[0]; ++i) {
+            if (s->level > 0 && !ns_in_grown(s, i, j, k, 3)) continue;     /* norm0 over the FillPatch'ed boxes of the level, 3 ghost cells */
+            double v = fabs(A4(&Umf, i, j, k, n)); if (v > um) um = v;
+        }
         double c = dt * um / g->dx[n];
         if (n == 0 || c > cflmax) cflmax = c;
     }
+    /* NavierStokesBase.cpp:4417-4422: on a refined level the ghost cells of the old Gradp are re-filled, the coarse data have changed */
+    if (s->level > 0) ns_fill_gp(s, GP_OLD(s), 0.5 * (s->pt_old[0] + s->pt_old[1]));
     double tempdt = cflmax == 0 ? s->p.change_max : fmin(s->p.change_max, s->p.cfl / cflmax);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
@@ -480,20 +657,103 @@ static double predict_velocity(orc_ns_state* s, double dt)
     return dt * tempdt;
 }
 
+/* NavierStokesBase::create_umac_grown on a refined level (NavierStokesBase.cpp:1108-1311): ghost faces by FaceLinear interpolation of
+ * the coarse mac velocities where no fine face exists, then the divergence fix of the outer face of every ghost cell that is not
+ * covered and has exactly one face neighbour inside the level.  Whole-domain form: assumes that two boxes of a level are never
+ * separated by a gap of exactly two cells (blocking factor >= 4), so that no face is the outer face of two ghost cells. */
+static void create_umac_grown_fine(orc_ns_state* s)
+{
+    const orc_geom* g = &s->g;
+    const int r = s->ratio;
+    for (int d = 0; d < 3; ++d) {
+        orc_fab* f = &s->umac[d];
+        const orc_fab* uc = &s->crse->umac[d];
+        for (int k = f->lo[2]; k <= f->hi[2]; ++k) for (int j = f->lo[1]; j <= f->hi[1]; ++j) for (int i = f->lo[0]; i <= f->hi[0]; ++i) {
+            int m[3] = {i, j, k}; m[d] -= 1;
+            if (ns_covered(s, i, j, k) || ns_covered(s, m[0], m[1], m[2])) continue;     /* a face of the level */
+            const int fi[3] = {i, j, k};
+            int c[3];
+            for (int e = 0; e < 3; ++e) c[e] = fi[e] >= 0 ? fi[e] / r : -((-fi[e] + r - 1) / r);
+            int ok = 1;
+            for (int e = 0; e < 3; ++e) if (c[e] < uc->lo[e] || c[e] + (e == d ? 1 : 0) > uc->hi[e]) ok = 0;
+            if (!ok) continue;                                                           /* beyond the coarse ghost faces: never used */
+            const int rem = fi[d] - c[d] * r;
+            double v;
+            if (rem == 0) v = A4(uc, c[0], c[1], c[2], 0);
+            else {
+                const double w = (double)rem / (double)r;
+                int cp[3] = {c[0], c[1], c[2]}; cp[d] += 1;
+                v = (1.0 - w) * A4(uc, c[0], c[1], c[2], 0) + w * A4(uc, cp[0], cp[1], cp[2], 0);
+            }
+            A4(f, i, j, k, 0) = v;
+        }
+        orc_fill_periodic(f, g, ORC_FACE[d]);
+    }
+    orc_fab *u = &s->umac[0], *v = &s->umac[1], *w = &s->umac[2];
+    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+        const int idx[3] = {i, j, k};
+        int outside = 0;
+        for (int e = 0; e < 3; ++e) if (!g->periodic[e] && (idx[e] < 0 || idx[e] > g->n[e] - 1)) outside = 1;
+        if (outside || ns_covered(s, i, j, k)) continue;
+        int count = 0;
+        for (int e = 0; e < 3; ++e) for (int sg = -1; sg <= 1; sg += 2) { int q[3] = {i, j, k}; q[e] += sg; count += ns_covered(s, q[0], q[1], q[2]); }
+        if (count != 1) continue;
+        const double dux = (A4(u, i + 1, j, k, 0) - A4(u, i, j, k, 0)) / g->dx[0];
+        const double duy = (A4(v, i, j + 1, k, 0) - A4(v, i, j, k, 0)) / g->dx[1];
+        const double duz = (A4(w, i, j, k + 1, 0) - A4(w, i, j, k, 0)) / g->dx[2];
+        if (ns_covered(s, i + 1, j, k)) A4(u, i, j, k, 0) = A4(u, i + 1, j, k, 0) + g->dx[0] * (duy + duz - 0.0);
+        else if (ns_covered(s, i - 1, j, k)) A4(u, i + 1, j, k, 0) = A4(u, i, j, k, 0) - g->dx[0] * (duy + duz - 0.0);
+        if (ns_covered(s, i, j + 1, k)) A4(v, i, j, k, 0) = A4(v, i, j + 1, k, 0) + g->dx[1] * (dux + duz - 0.0);
+        else if (ns_covered(s, i, j - 1, k)) A4(v, i, j + 1, k, 0) = A4(v, i, j, k, 0) - g->dx[1] * (dux + duz - 0.0);
+        if (ns_covered(s, i, j, k + 1)) A4(w, i, j, k, 0) = A4(w, i, j, k + 1, 0) + g->dx[2] * (dux + duy - 0.0);
+        else if (ns_covered(s, i, j, k - 1)) A4(w, i, j, k + 1, 0) = A4(w, i, j, k, 0) - g->dx[2] * (dux + duy - 0.0);
+    }
+    for (int d = 0; d < 3; ++d) orc_fill_periodic(&s->umac[d], g, ORC_FACE[d]);
+}
+
+static orc_fab dbg_umac[3];
+orc_fab* orc_dbg_umac(int d) { return &dbg_umac[d]; }
 static void mac_project(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
-    orc_fab phi = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_fab* phi = &s->mac_phi;                                 /* mac_phi_crse[level]: kept as the coarse/fine data of the next finer level */
+    orc_setval(phi, 0.0);
     /* MacProj.cpp:262-263: S_old density ghost cells overwritten with rho(time) incl. 1 ghost */
     orc_fab* So = S_OLD(s);
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
         A4(So, i, j, k, Density) = A4(&s->rho_ptime, i, j, k, 0);
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
     orc_mg_opts o = s->o; o.maxorder = 4;
-    orc_mac_project(g, um, &s->rho_ptime, NULL, &phi, 2.0 / dt, s->lobc, s->hibc, s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
-    /* create_umac_grown at level 0: FillPatchSingleLevel (periodic ghost faces) */
-    for (int d = 0; d < 3; ++d) fill_ghosts(s, &s->umac[d], ORC_FACE[d]);
-    orc_free(&phi);
+    if (getenv("ORC_DBG_UMAC") && s->level == atoi(getenv("ORC_DBG_UMAC"))) {
+        for (int d = 0; d < 3; ++d) { if (dbg_umac[d].p) orc_free(&dbg_umac[d]); dbg_umac[d] = orc_alloc(g->n, ORC_FACE[d], 1, 1); orc_copy_all(&dbg_umac[d], &s->umac[d]); }
+    }
+    if (s->level == 0) {
+        orc_mac_project(g, um, &s->rho_ptime, NULL, phi, 2.0 / dt, s->lobc, s->hibc, s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
+        /* create_umac_grown at level 0: FillPatchSingleLevel (periodic ghost faces) */
+        for (int d = 0; d < 3; ++d) fill_ghosts(s, &s->umac[d], ORC_FACE[d]);
+    } else {
+        orc_fill_periodic(&s->crse->mac_phi, &s->crse->g, ORC_CELL);
+        orc_mac_project_cf(g, um, &s->rho_ptime, NULL, phi, 2.0 / dt, s->lobc, s->hibc, s->nbox, s->boxes, s->ratio, &s->crse->mac_phi,
+                           s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
+    }
+    orc_fill_periodic(phi, g, ORC_CELL);
+    /* MAC registers (MacProj.cpp:304-348): fluxes = u_mac * area */
+    for (int d = 0; d < 3; ++d) {
+        const double area = g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
+        if (s->fine) reg_crse_init(s->fine, s->fine->reg_mac, &s->umac[d], d, 0, 0, 1, -1.0 * area, 0);
+        if (s->level > 0) reg_fine_add(s, s->reg_mac, &s->umac[d], d, 0, 0, 1, area / (double)s->ncycle);
+    }
+    if (s->level > 0) create_umac_grown_fine(s);
+}
+
+/* NavierStokesBase::ComputeAofs, flux-register part (NavierStokesBase.cpp:5075-5096): CrseAdd into the register of the next finer
+ * level, FineAdd into the level's own; YAFluxRegister semantics written as CrseInit(-dt) / FineAdd(+dt), see orc_amr.c */
+static void adv_registers(orc_ns_state* s, orc_fab* flux[3], int state_indx, int ncomp, double dt)
+{
+    for (int d = 0; d < 3; ++d) {
+        if (s->fine) reg_crse_init(s->fine, s->fine->reg_adv, flux[d], d, 0, state_indx, ncomp, -dt, 1);
+        if (s->level > 0) reg_fine_add(s, s->reg_adv, flux[d], d, 0, state_indx, ncomp, dt);
+    }
 }
 
 static void velocity_advection(orc_ns_state* s, double dt)
@@ -524,7 +784,11 @@ static void velocity_advection(orc_ns_state* s, double dt)
     }
     int iconserv[3] = {mom, mom, mom};          /* NS_setup.cpp:297-301: velocity advectionType = Conservative */
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
-    orc_compute_aofs(g, &s->aofs, Xvel, &Umf, 3, &tf, &divu, um, iconserv, dt, s->bc_vel, 1, s->p.use_forces_in_trans, NULL, NULL);
+    orc_fab fl[3]; orc_fab* flp[3];
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); flp[d] = &fl[d]; }
+    orc_compute_aofs(g, &s->aofs, Xvel, &Umf, 3, &tf, &divu, um, iconserv, dt, s->bc_vel, 1, s->p.use_forces_in_trans, NULL, flp);
+    adv_registers(s, flp, Xvel, 3, dt);
+    for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
     orc_free(&Umf); orc_free(&Smf); orc_free(&visc); orc_free(&tf); orc_free(&divu);
 }
 
@@ -547,7 +811,11 @@ static void scalar_advection(orc_ns_state* s, double dt)
     }
     orc_free(&visc);
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
-    orc_compute_aofs(g, &s->aofs, Density, &Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, NULL);
+    orc_fab fl[3]; orc_fab* flp[3];
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, NUM_SCALARS); flp[d] = &fl[d]; }
+    orc_compute_aofs(g, &s->aofs, Density, &Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, flp);
+    adv_registers(s, flp, Density, NUM_SCALARS, dt);
+    for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
     orc_free(&Smf); orc_free(&tf); orc_free(&divu);
 }
 
@@ -726,15 +994,52 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
 }
 
-/* Projection::level_project, single level */
+/* trilinear interpolation of a coarse nodal array at fine node (i,j,k) (amrex::NodeBilinear) */
+static double node_interp(const orc_fab* c, int r, int i, int j, int k)
+{
+    const int f[3] = {i, j, k};
+    int c0[3]; double w[3];
+    for (int d = 0; d < 3; ++d) {
+        c0[d] = f[d] >= 0 ? f[d] / r : -((-f[d] + r - 1) / r);
+        w[d] = (double)(f[d] - c0[d] * r) / (double)r;
+    }
+    double v = 0.0;
+    for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+        const double ww = (cx ? w[0] : 1.0 - w[0]) * (cy ? w[1] : 1.0 - w[1]) * (cz ? w[2] : 1.0 - w[2]);
+        if (ww != 0.0) v += ww * A4(c, c0[0] + cx, c0[1] + cy, c0[2] + cz, 0);
+    }
+    return v;
+}
+
+/* Projection::level_project (Projection.cpp:166-450) */
 static void level_project(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
     orc_fab* Un = S_NEW(s);
     orc_fab* Pn = P_NEW(s);
     const orc_fab* Gp = GP_OLD(s);
-    /* zero P_new on the valid nodal box (level 0: nGrow 0) */
-    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) A4(Pn, i, j, k, 0) = 0.0;
+    if (s->level == 0) {
+        /* zero P_new on the valid nodal box (level 0: nGrow 0) */
+        for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) A4(Pn, i, j, k, 0) = 0.0;
+    } else {
+        /* :232-256: FillCoarsePatch(P_new, cur_pres_time) -- Press_Type is an Interval type, cur_pres_time lies in the coarse level's
+         * NEW interval (the coarse level has already advanced), node_bilinear_interp -- then zero on every box shrunk by one node:
+         * the nodes on the box faces keep the interpolated coarse pressure (Dirichlet data on the coarse/fine boundary, the initial
+         * guess on faces shared by two boxes) */
+        const orc_ns_state* c = s->crse;
+        const double tp = 0.5 * (s->pt_new[0] + s->pt_new[1]);
+        const double teps = 1.e-3 * fabs(c->pt_new[0] - c->pt_old[0]);
+        const orc_fab* Pc;
+        if (tp >= c->pt_new[0] - teps && tp <= c->pt_new[1] + teps) Pc = P_NEW(c);
+        else if (tp >= c->pt_old[0] - teps && tp <= c->pt_old[1] + teps) Pc = P_OLD(c);
+        else { fprintf(stderr, "orc level_project: no coarse pressure at time %g\n", tp); abort(); }
+        for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+            A4(Pn, i, j, k, 0) = node_interp(Pc, s->ratio, i, j, k);
+        for (int b = 0; b < s->nbox; ++b) {
+            const int* bx = s->boxes + 6 * b;
+            for (int k = bx[2] + 1; k <= bx[5]; ++k) for (int j = bx[1] + 1; j <= bx[4]; ++j) for (int i = bx[0] + 1; i <= bx[3]; ++i) A4(Pn, i, j, k, 0) = 0.0;
+        }
+    }
     const double dt_inv = 1. / dt;
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
@@ -748,16 +1053,25 @@ static void level_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, Pn, &sig, 0, 1.0 / dt);
+    nodal_project_level(s, &v, Pn, &sig, 0, 1.0 / dt, 1);
     orc_free(&sig);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
         A4(Un, i, j, k, n) *= dt;
 }
 
-static double advance(orc_ns_state* s, double dt)
+void ns_make_rho_curr_time(orc_ns_state* s)
 {
-    advance_setup(s);
+    orc_fab r = fillpatch(s, S_NEW(s), Density, 1, 1, &s->bc_scal[0]);
+    orc_copy_all(&s->rho_ctime, &r);
+    orc_free(&r);
+}
+
+/* NavierStokes::advance (NavierStokes.cpp:543-691) */
+double ns_advance(orc_ns_state* s, double dt, int iteration, int ncycle)
+{
+    const orc_geom* g = &s->g;
+    advance_setup(s, dt, iteration, ncycle);
     double dt_test = predict_velocity(s, dt);
     mac_project(s, dt);
     /* NavierStokes.cpp:606-623: with do_mom_diff the reference calls velocity_advection after the density update; it reads only
@@ -770,8 +1084,21 @@ static double advance(orc_ns_state* s, double dt)
     velocity_advection_update(s, dt);
     if (!s->initial_iter) velocity_diffusion_update(s, dt);
     else initial_velocity_diffusion_update(s, dt);
-    if (!s->initial_step) level_project(s, dt);
+    if (!s->initial_step) {
+        if (s->level > 0) {              /* incrRhoAvg((iteration==ncycle ? 0.5 : 1.0) / ncycle), :644-645 */
+            const double alpha = (iteration == ncycle ? 0.5 : 1.0) / (double)ncycle;
+            for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+                A4(&s->rho_avg, i, j, k, 0) += alpha * A4(S_NEW(s), i, j, k, Density);
+        }
+        level_project(s, dt);
+        if (s->level > 0 && iteration == 1) orc_setval(&s->p_avg, 0.0);      /* :670-671 */
+    }
     return dt_test;
+}
+
+static double advance(orc_ns_state* s, double dt)
+{
+    return ns_advance(s, dt, 1, 1);
 }
 
 /* Projection::initialSyncProject, single level */
@@ -791,7 +1118,7 @@ static void initial_sync_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, phi, &sig, 1, 0.0);
+    nodal_project_level(s, &v, phi, &sig, 1, 0.0, 0);
     orc_free(&sig);
     orc_fab* Pn = P_NEW(s);
     size_t N = orc_npts(Pn);
@@ -804,7 +1131,7 @@ void orc_ns_post_init(orc_ns_state* s, double stop_time)
     initial_velocity_project(s);
     s->initial_step = 1;
     /* post_init_estDT: dt = init_shrink * estTimeStep, limited by stop_time */
-    double dt_init = s->p.init_shrink * est_time_step(s);
+    double dt_init = s->p.init_shrink * ns_est_time_step(s);
     if (stop_time >= 0.0) {
         const double eps = 0.0001 * dt_init;
         if (s->time + dt_init > stop_time - eps) dt_init = stop_time - s->time;
@@ -832,7 +1159,7 @@ double orc_ns_step(orc_ns_state* s)
     double dt = s->dt;
     if (s->nstep > 0) {
         /* computeNewDt */
-        double dt_min = fmin(s->dt_min_adv, est_time_step(s));
+        double dt_min = fmin(s->dt_min_adv, ns_est_time_step(s));
         if (s->p.fixed_dt <= 0.0) dt_min = fmin(dt_min, s->p.change_max * s->dt);
         dt = dt_min;
     }

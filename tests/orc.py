@@ -206,3 +206,103 @@ def abec_level(g, b, alpha=0.0, beta=1.0, a=None, ncomp=1, tensor=0, bc_percomp=
     L.tensor = tensor
     L.bc_percomp = bc_percomp
     return L
+
+
+# ---- multi-level hierarchy (oracle/orc_amr.c) ---------------------------------------------------------------------------
+def ns_params(**kw):
+    p = CNsParams()
+    lib().orc_ns_default_params(C.byref(p))
+    for k, v in kw.items():
+        if isinstance(v, (list, tuple)):
+            arr = getattr(p, k)
+            for q, x in enumerate(v):
+                arr[q] = x
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class OrcAmr:
+    """levels: list of box lists; levels[0] is ignored (the base level covers the domain), levels[l] = [(lo, hi), ...] in the
+    index space of level l."""
+
+    def __init__(self, g0, params, opts, levels, ratio=2):
+        L = lib()
+        L.orc_amr_create.restype = C.c_void_p
+        L.orc_amr_level.restype = C.c_void_p
+        L.orc_amr_cov.restype = PF
+        L.orc_amr_coarse_step.restype = C.c_double
+        L.orc_amr_time.restype = C.c_double
+        L.orc_amr_dt.restype = C.c_double
+        self.nlev = len(levels)
+        self.g0 = g0
+        self.ratio = ratio
+        nbox = (C.c_int * self.nlev)(*[len(b) for b in levels])
+        flat = [v for lev in levels[1:] for lo, hi in lev for v in (*lo, *hi)]
+        boxes = (C.c_int * max(1, len(flat)))(*flat)
+        self.h = C.c_void_p(L.orc_amr_create(C.byref(g0), C.byref(params), C.byref(opts), self.nlev, ratio, nbox, boxes))
+        assert self.h
+        self.levels = levels
+
+    def n(self, lev):
+        return [self.g0.n[d] * self.ratio ** lev for d in range(3)]
+
+    def dx(self, lev):
+        return [self.g0.dx[d] / self.ratio ** lev for d in range(3)]
+
+    def fab(self, lev, which):
+        L = lib()
+        ns = C.c_void_p(L.orc_amr_level(self.h, lev))
+        return from_cfab(L.orc_ns_fab(ns, which))
+
+    def cov(self, lev):
+        if lev == 0:
+            return np.ones(tuple(self.n(0)), dtype=bool)
+        return from_cfab(lib().orc_amr_cov(self.h, lev)).a[..., 0] != 0.0
+
+    def post_init(self, stop_time=-1.0):
+        lib().orc_amr_post_init(self.h, C.c_double(stop_time))
+
+    def step(self):
+        return lib().orc_amr_coarse_step(self.h)
+
+    def time(self):
+        return lib().orc_amr_time(self.h)
+
+    def dt(self, lev):
+        return lib().orc_amr_dt(self.h, C.c_int(lev))
+
+    def sync_stats(self):
+        st = CMgStats()
+        lib().orc_amr_sync_stats(self.h, C.byref(st))
+        return st
+
+    def cell_centres(self, lev):
+        n, dx = self.n(lev), self.dx(lev)
+        ax = [self.g0.problo[d] + (np.arange(n[d]) + 0.5) * dx[d] for d in range(3)]
+        return np.meshgrid(*ax, indexing="ij")
+
+    def set_state(self, lev, arr):
+        """arr: (nx, ny, nz, 5) valid data of the level's whole index space"""
+        f = self.fab(lev, 0)
+        n = self.n(lev)
+        f.valid(n)[...] = arr
+
+    def state(self, lev, which=0):
+        return self.fab(lev, which).valid(self.n(lev)).copy()
+
+    def __del__(self):
+        try:
+            lib().orc_amr_destroy(self.h)
+        except Exception:
+            pass
+
+
+def taylorgreen_state(X, Y, Z, vfac=1.0, a=1.0, b=1.0, c=1.0, rho0=1.0):
+    tp = 2.0 * np.pi
+    S = np.zeros(X.shape + (5,), order="F")
+    S[..., 0] = vfac * np.sin(a * tp * X) * np.cos(b * tp * Y) * np.cos(c * tp * Z)
+    S[..., 1] = -vfac * np.cos(a * tp * X) * np.sin(b * tp * Y) * np.cos(c * tp * Z)
+    S[..., 3] = rho0
+    S[..., 4] = (rho0 * vfac * vfac / 16.0) * (2.0 + np.cos(2.0 * c * tp * Z)) * (np.cos(2.0 * a * tp * X) + np.cos(2.0 * b * tp * Y))
+    return S
