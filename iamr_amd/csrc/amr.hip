@@ -289,26 +289,30 @@ __global__ void __launch_bounds__(256) k_cellconslin(const BoxD* __restrict__ pb
             off[d] = ((double)(f[d] - c[d] * ratio) + 0.5) * rinv - 0.5;
         }
         const long co = cr.off(c[0], c[1], c[2]);
-        // per-direction limiter factor common to all components
-        double alpha[3] = {1.0, 1.0, 1.0};
+        const double exc = (double)(ratio - 1) / (double)(2 * ratio);
         for (int n = 0; n < ncomp; ++n) {
             const double* u = cr.p + co + cr.cs * n;
+            const double u0 = u[0];
+            double sl[3];
             for (int d = 0; d < 3; ++d) {
                 const double dc = cslope(u, s[d], c[d], cr.lo[d], cr.lo[d] + cr.n[d] - 1, bc.dlo[d], bc.dhi[d], bc.lo[n][d], bc.hi[n][d]);
-                const double df = 2.0 * (u[s[d]] - u[0]), db = 2.0 * (u[0] - u[-s[d]]);
-                double sl = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
-                sl = copysign(1.0, dc) * fmin(sl, fabs(dc));
-                if (dc != 0.0) alpha[d] = fmin(alpha[d], sl / dc);
+                const double df = 2.0 * (u[s[d]] - u0), db = 2.0 * (u0 - u[-s[d]]);
+                const double sm = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+                sl[d] = copysign(1.0, dc) * fmin(sm, fabs(dc));
             }
-        }
-        for (int n = 0; n < ncomp; ++n) {
-            const double* u = cr.p + co + cr.cs * n;
-            double v = u[0];
-            for (int d = 0; d < 3; ++d) {
-                const double dc = cslope(u, s[d], c[d], cr.lo[d], cr.lo[d] + cr.n[d] - 1, bc.dlo[d], bc.dhi[d], bc.lo[n][d], bc.hi[n][d]);
-                v += off[d] * (alpha[d] * dc);
+            // one factor per component: the largest excursion inside the coarse cell stays within the 27 coarse neighbours' range
+            double alpha = 1.0;
+            if (sl[0] != 0.0 || sl[1] != 0.0 || sl[2] != 0.0) {
+                const double dumax = fabs(sl[0]) * exc + fabs(sl[1]) * exc + fabs(sl[2]) * exc;
+                double umax = u0, umin = u0;
+                for (int ko = -1; ko <= 1; ++ko) for (int jo = -1; jo <= 1; ++jo) for (int io = -1; io <= 1; ++io) {
+                    const double v = u[io * s[0] + jo * s[1] + ko * s[2]];
+                    umin = fmin(umin, v); umax = fmax(umax, v);
+                }
+                if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
+                if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
             }
-            dst(i, j, k, dcomp + n) = v;
+            dst(i, j, k, dcomp + n) = u0 + off[0] * (sl[0] * alpha) + off[1] * (sl[1] * alpha) + off[2] * (sl[2] * alpha);
         }
     }
 }

@@ -1,0 +1,932 @@
+// iamr_amd/csrc/amrns.hip -- the multi-level time step: subcycled advance of a hierarchy of NavierStokes levels, reflux,
+// average down, MAC sync, sync registers, the multi-level (composite) nodal projections and the multi-level initialisation.
+//
+// Reference (all in /root/reference/Source):
+//   Amr::timeStep / coarseTimeStep (upstream AMReX): advance(level); ncycle x timeStep(level+1); post_timestep(level)
+//   NavierStokesBase::post_timestep        NavierStokesBase.cpp:2546-2636
+//   NavierStokes::reflux                   NavierStokes.cpp:1736-1838
+//   NavierStokes::avgDown / avgDown_StatePress NavierStokes.cpp:1845-1873, NavierStokesBase.cpp:4125-4163
+//   NavierStokes::mac_sync                 NavierStokes.cpp:1438-1730
+//   MacProj::mac_sync_solve / mac_sync_compute MacProj.cpp:359-479, 490-731
+//   NavierStokesBase::level_sync           NavierStokesBase.cpp:1927-2044
+//   Projection::MLsyncProject              Projection.cpp:457-607
+//   SyncRegister                           SyncRegister.cpp:19-607
+//   NavierStokesBase::SyncInterp           NavierStokesBase.cpp:3071-3276
+//   Projection::initialVelocityProject / initialPressureProject / initialSyncProject Projection.cpp:615-1185
+//   NavierStokes::post_init / post_init_press, NSB::post_init_state / post_init_estDT NavierStokes.cpp:1254-1432, NavierStokesBase.cpp:2307-2439
+//   NavierStokesBase::computeNewDt         NavierStokesBase.cpp:945-1035
+//
+// MI355X-first choices: every register is a device-resident MultiFab driven by the cached copy plans of amr.hip (no per-face host
+// loops); the composite nodal system is solved by a fast-adaptive-composite multigrid cycle whose level solves are the V-cycles of
+// the hand-written nodal smoother / residual kernels (k_nodal.hip), with the coarse/fine coupling expressed through the same
+// full-weighting restriction and trilinear interpolation kernels as the multigrid itself.
+#include "operators.h"
+#include "launch.h"
+#include "amrns.h"
+#include <cmath>
+#include <algorithm>
+#include <cstring>
+
+namespace iamrx {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// small level-wide helpers
+namespace {
+
+// cell MultiFab (1 ghost): 1 on the cells of `l` (neighbour boxes and periodic images included), 0 elsewhere
+MultiFab coverage(const LayoutP& l, const Geometry& g)
+{
+    MultiFab cov(l, cell_type(), 1, 1);
+    cov.setVal(0.0);
+    mf_add_scalar(cov, 1.0, 0, 1, 0);
+    cov.FillBoundary(g);
+    return cov;
+}
+// cell MultiFab on the coarse layout (1 ghost): 1 on the coarse cells the fine layout covers
+MultiFab fine_coverage(const LayoutP& crse, const LayoutP& fine, const Geometry& cgeom, int ratio)
+{
+    MultiFab fc(crse, cell_type(), 1, 1);
+    fc.setVal(0.0);
+    MultiFab ones(fine, cell_type(), 1, 0);
+    ones.setVal(1.0);
+    average_down(ones, fc, 0, 1, ratio);
+    fc.FillBoundary(cgeom);
+    return fc;
+}
+// node class with respect to a cell coverage (1 ghost): 0 none of the surrounding in-domain cells covered, 1 all of them, 2 some
+void node_class(MultiFab& out, const MultiFab& cov, const Geometry& g)
+{
+    const FabD *ot = out.d_tab, *ct = cov.d_tab;
+    const BoxD dom = g.domain;
+    const int p0 = g.periodic[0], p1 = g.periodic[1], p2 = g.periodic[2];
+    for_each(*out.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        int nin = 0, ntot = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int ci = i - 1 + (q & 1), cj = j - 1 + ((q >> 1) & 1), ck = k - 1 + ((q >> 2) & 1);
+            if ((!p0 && (ci < dom.lo[0] || ci > dom.hi[0])) || (!p1 && (cj < dom.lo[1] || cj > dom.hi[1])) || (!p2 && (ck < dom.lo[2] || ck > dom.hi[2]))) continue;
+            ++ntot;
+            nin += ct[f](ci, cj, ck) != 0.0;
+        }
+        ot[f](i, j, k) = nin == 0 ? 0.0 : (nin == ntot ? 1.0 : 2.0);
+    });
+}
+// y(ycomp..) *= (keep_where_zero ? (m == 0) : (m != 0)) on valid + ng
+void mask_mult(MultiFab& y, int ycomp, int nc, const MultiFab& m, bool keep_where_zero, int ng)
+{
+    const FabD *yt = y.d_tab, *mt = m.d_tab;
+    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const bool on = keep_where_zero ? (mt[f](i, j, k) == 0.0) : (mt[f](i, j, k) != 0.0);
+        if (!on) for (int n = 0; n < nc; ++n) yt[f](i, j, k, ycomp + n) = 0.0;
+    });
+}
+// node masks of the composite system: keep y where cls == v
+void keep_class(MultiFab& y, const MultiFab& cls, double v)
+{
+    const FabD *yt = y.d_tab, *mt = cls.d_tab;
+    for_each(*y.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        if (mt[f](i, j, k) != v) yt[f](i, j, k) = 0.0;
+    });
+}
+DomainBC all_neumann(const Geometry& g)
+{
+    DomainBC b;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = g.periodic[d] ? lo_periodic : lo_neumann; b.hi[d] = b.lo[d]; }
+    b.maxorder = 2;
+    return b;
+}
+DomainBC op_bc(const DomainBC& bc)        // the operator does not distinguish inflow faces from walls
+{
+    DomainBC b = bc;
+    for (int d = 0; d < 3; ++d) { if (b.lo[d] == lo_inflow) b.lo[d] = lo_neumann; if (b.hi[d] == lo_inflow) b.hi[d] = lo_neumann; }
+    return b;
+}
+// fine nodal field -> nodes of the coarse level (full weighting = transpose of the trilinear interpolation / ratio^3, the weights
+// of SyncRegister::FineAdd, SyncRegister.cpp:478-536).  fine: 1 ghost node layer, valid data set, ghosts arbitrary; out: coarse layout.
+void restrict_to_crse(MultiFab& out, MultiFab& fine, const Geometry& fgeom, const Geometry& cgeom, int ratio)
+{
+    IAMRX_ASSERT(ratio == 2);
+    fine.FillBoundary(fgeom);
+    nodal_reflect_bc(fgeom, fine, all_neumann(fgeom));
+    MultiFab cf(fine.layout->coarsened(ratio), node_type(), 1, 0);
+    nodal_restrict(cf, fine);
+    out.setVal(0.0);
+    parallel_copy(out, cf, 0, 0, 1, 0, 0, &cgeom);
+}
+
+}  // namespace
+
+void node_interp_from_crse(MultiFab& fine, const MultiFab& crse, const Geometry& cgeom, int ratio, const MultiFab* mask, bool add)
+{
+    if (fine.layout->boxes.empty()) return;
+    MultiFab cp(fine.layout->coarsened(ratio), node_type(), 1, 0);
+    cp.setVal(0.0);
+    parallel_copy(cp, crse, 0, 0, 1, 0, 0, &cgeom);
+    const FabD *ft = fine.d_tab, *ct = cp.d_tab;
+    const FabD* mt = mask ? mask->d_tab : nullptr;
+    const int r = ratio;
+    const double rinv = 1.0 / (double)ratio;
+    for_each(*fine.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        if (mt && mt[f](i, j, k) == 0.0) return;
+        const int fi[3] = {i, j, k};
+        int c0[3];
+        double w[3];
+        for (int d = 0; d < 3; ++d) {
+            c0[d] = fi[d] >= 0 ? fi[d] / r : -((-fi[d] + r - 1) / r);
+            w[d] = (double)(fi[d] - c0[d] * r) * rinv;
+        }
+        const FabD c = ct[f];
+        double v = 0.0;
+        for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+            const double ww = (cx ? w[0] : 1.0 - w[0]) * (cy ? w[1] : 1.0 - w[1]) * (cz ? w[2] : 1.0 - w[2]);
+            if (ww != 0.0) v += ww * c(c0[0] + cx, c0[1] + cy, c0[2] + cz);
+        }
+        if (add) ft[f](i, j, k) += v; else ft[f](i, j, k) = v;
+    });
+}
+
+void sync_interp_cellcons(MultiFab& dst, int dcomp, const MultiFab& crse, int scomp, int ncomp, const Geometry& cgeom, const Geometry& fgeom,
+                          int ratio, const BCRec* bc)
+{
+    // FillPatchTwoLevels against an EMPTY fine level: every cell of dst is interpolated from the coarse data
+    static LayoutP empty_layout;
+    if (!empty_layout) empty_layout = std::make_shared<Layout>(std::vector<BoxD>{}, std::vector<int>{}, Context::get().comm->rank);
+    MultiFab none(empty_layout, cell_type(), crse.ncomp, 0);
+    MultiFab tmp(dst.layout, cell_type(), ncomp, 0);
+    TimeData fd{nullptr, &none, 0.0, 0.0};
+    TimeData cd{nullptr, &crse, 0.0, 0.0};
+    double zero[24];
+    std::memset(zero, 0, sizeof(zero));
+    fillpatch_two_levels(tmp, 0, 0.0, fd, cd, scomp, ncomp, cgeom, fgeom, ratio, bc, zero, zero);      // HomExtDirFill
+    MultiFab::Copy(dst, tmp, 0, dcomp, ncomp, 0);
+}
+
+void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
+                               const MultiFab* divu, MultiFab* const umac[3], MultiFab* const ucorr[3], const int* iconserv, double dt,
+                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3])
+{
+    MultiFab scratch(S.layout, cell_type(), ncomp, 0);
+    MultiFab ed[3];
+    MultiFab* edp[3];
+    for (int d = 0; d < 3; ++d) { ed[d].define(S.layout, face_type(d), ncomp, 0); edp[d] = &ed[d]; }
+    godunov_compute_aofs(g, scratch, 0, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edp, nullptr);
+    auto& ctx = Context::get();
+    for (int d = 0; d < 3; ++d) {                      // fluxes = edge state * Ucorr * area (NavierStokesBase.cpp:4681-4683)
+        const double area = g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3];
+        const FabD *et = ed[d].d_tab, *ut = ucorr[d]->d_tab;
+        const FabD* ft = flux_out ? flux_out[d]->d_tab : et;
+        for_each(*S.layout, face_type(d), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const double u = ut[f](i, j, k);
+            for (int n = 0; n < ncomp; ++n) ft[f](i, j, k, n) = et[f](i, j, k, n) * u * area;
+        });
+    }
+    const FabD *fx = (flux_out ? flux_out[0] : &ed[0])->d_tab, *fy = (flux_out ? flux_out[1] : &ed[1])->d_tab, *fz = (flux_out ? flux_out[2] : &ed[2])->d_tab;
+    const FabD* st = sync.d_tab;
+    const double qvol = 1.0 / (g.dx[0] * g.dx[1] * g.dx[2]);
+    for_each(*S.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+        for (int n = 0; n < ncomp; ++n) {
+            const double upd = -1.0 * qvol * ((fx[f](i + 1, j, k, n) - fx[f](i, j, k, n)) + (fy[f](i, j + 1, k, n) - fy[f](i, j, k, n))
+                                            + (fz[f](i, j, k + 1, n) - fz[f](i, j, k, n)));
+            st[f](i, j, k, acomp + n) -= upd;          // aofs -= update, update = -div F (:4826-4832)
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// sync residuals
+MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side)
+{
+    const Geometry& g = ns.geom();
+    const LayoutP& layout = ns.lay();
+    auto& ctx = Context::get();
+    const DomainBC bcn = ns.nodal_bc();
+    MultiFab cls(layout, node_type(), 1, 0);
+    MultiFab fc;
+    if (crse_side) { fc = fine_coverage(layout, ns.fine->lay(), g, ns.fine->ratio); node_class(cls, fc, g); }
+    else { MultiFab cov = coverage(layout, g); node_class(cls, cov, g); }
+    // sigma and velocity restricted to the cells that count (zero elsewhere, also in the ghost cells outside the level)
+    MultiFab sm(layout, cell_type(), 1, 1), um(layout, cell_type(), 3, 1);
+    sm.setVal(0.0); um.setVal(0.0);
+    MultiFab::Copy(sm, sig, 0, 0, 1, 0);
+    MultiFab::Copy(um, vold, 0, 0, 3, 0);
+    if (crse_side) { mask_mult(sm, 0, 1, fc, true, 0); mask_mult(um, 0, 3, fc, true, 0); }
+    sm.FillBoundary(g);
+    cc_mirror_bc(g, sm);
+    um.FillBoundary(g);
+    {   // cells outside the physical domain keep the incoming values (inflow data; nodal_divu ignores the rest)
+        const FabD *ut = um.d_tab, *vt = vold.d_tab;
+        const BoxD dom = g.domain;
+        const int p0 = g.periodic[0], p1 = g.periodic[1], p2 = g.periodic[2];
+        for_each(*layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const bool out = (!p0 && (i < dom.lo[0] || i > dom.hi[0])) || (!p1 && (j < dom.lo[1] || j > dom.hi[1])) || (!p2 && (k < dom.lo[2] || k > dom.hi[2]));
+            if (out) for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) = vt[f](i, j, k, n);
+        });
+    }
+    MultiFab rhs(layout, node_type(), 1, 0), ph(layout, node_type(), 1, 1), r(layout, node_type(), 1, 1);
+    nodal_divu(g, rhs, um, 0, &bcn);
+    ph.setVal(0.0);
+    MultiFab::Copy(ph, phi, 0, 0, 1, 0);
+    ph.FillBoundary(g);
+    nodal_reflect_bc(g, ph, op_bc(bcn));
+    r.setVal(0.0);
+    nodal_residual(g, r, ph, sm, &rhs);
+    keep_class(r, cls, 2.0);
+    // nodes on Dirichlet (outflow) faces carry no residual
+    for (int d = 0; d < 3; ++d) {
+        if (g.periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            if ((side == 0 ? bcn.lo[d] : bcn.hi[d]) != lo_dirichlet) continue;
+            const int face = side == 0 ? g.domain.lo[d] : g.domain.hi[d] + 1;
+            const FabD* rt = r.d_tab;
+            const int dd = d;
+            for_each(*layout, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) rt[f](i, j, k) = 0.0;
+            });
+        }
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// SyncRegister
+SyncRegister::SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, const Geometry& fgeom, int ratio, const int phys_lo[3], const int phys_hi[3])
+    : m_fine(std::move(fine)), m_crse(std::move(crse)), m_cgeom(cgeom), m_fgeom(fgeom), m_ratio(ratio)
+{
+    for (int d = 0; d < 3; ++d) { m_plo[d] = phys_lo[d]; m_phi[d] = phys_hi[d]; }
+    m_reg.define(m_crse, node_type(), 1, 0);
+    m_reg.setVal(0.0);
+    m_onreg.define(m_crse, node_type(), 1, 0);
+    m_vsfine.define(m_crse, node_type(), 1, 0);
+    MultiFab fc = fine_coverage(m_crse, m_fine, m_cgeom, m_ratio);
+    node_class(m_vsfine, fc, m_cgeom);
+    // nodes on the faces of the coarsened fine boxes (and their periodic images)
+    std::vector<BoxD> nb;
+    for (auto& b : m_fine->boxes) {
+        const BoxD cb = coarsen(b, m_ratio);
+        for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+            const int sh[3] = {sx, sy, sz};
+            bool ok = true;
+            for (int d = 0; d < 3; ++d) if (sh[d] != 0 && !m_cgeom.periodic[d]) ok = false;
+            if (!ok) continue;
+            BoxD q = cb;
+            for (int d = 0; d < 3; ++d) { q.lo[d] += sh[d] * m_cgeom.domain.len(d); q.hi[d] += sh[d] * m_cgeom.domain.len(d) + 1; }   // nodal box
+            nb.push_back(q);
+        }
+    }
+    auto& ctx = Context::get();
+    BoxD* d_nb = (BoxD*)ctx.alloc(std::max<size_t>(1, nb.size()) * sizeof(BoxD));
+    if (!nb.empty()) IAMRX_HIP_CHECK(hipMemcpyAsync(d_nb, nb.data(), nb.size() * sizeof(BoxD), hipMemcpyHostToDevice, ctx.stream));
+    ctx.sync();
+    const int nnb = (int)nb.size();
+    const FabD* ot = m_onreg.d_tab;
+    for_each(*m_crse, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+        double on = 0.0;
+        for (int b = 0; b < nnb; ++b) {
+            const BoxD q = d_nb[b];
+            if (!q.contains(i, j, k)) continue;
+            if (i == q.lo[0] || i == q.hi[0] || j == q.lo[1] || j == q.hi[1] || k == q.lo[2] || k == q.hi[2]) { on = 1.0; break; }
+        }
+        ot[f](i, j, k) = on;
+    });
+    ctx.sync();
+    ctx.free(d_nb);
+}
+
+void SyncRegister::CrseInit(const MultiFab& resid, double mult)
+{
+    const FabD *rt = m_reg.d_tab, *ot = m_onreg.d_tab, *st = resid.d_tab;
+    for_each(*m_crse, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        rt[f](i, j, k) = ot[f](i, j, k) != 0.0 ? mult * st[f](i, j, k) : 0.0;
+    });
+}
+
+void SyncRegister::FineAdd(const MultiFab& resid_fine, double mult)
+{
+    MultiFab rf(m_fine, node_type(), 1, 1);
+    rf.setVal(0.0);
+    MultiFab::Copy(rf, resid_fine, 0, 0, 1, 0);
+    mf_mult(rf, mult, 0, 1, 0);
+    MultiFab rc(m_crse, node_type(), 1, 0);
+    restrict_to_crse(rc, rf, m_fgeom, m_cgeom, m_ratio);
+    const FabD *rt = m_reg.d_tab, *ot = m_onreg.d_tab, *ct = rc.d_tab;
+    for_each(*m_crse, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        if (ot[f](i, j, k) != 0.0) rt[f](i, j, k) += ct[f](i, j, k);
+    });
+}
+
+void SyncRegister::InitRHS(MultiFab& rhs)
+{
+    const FabD *rt = m_reg.d_tab, *ot = m_onreg.d_tab, *vt = m_vsfine.d_tab, *ht = rhs.d_tab;
+    const BoxD dom = m_cgeom.domain;
+    int olo[3], ohi[3];
+    for (int d = 0; d < 3; ++d) { olo[d] = (!m_cgeom.periodic[d] && m_plo[d] == phys_outflow) ? 1 : 0; ohi[d] = (!m_cgeom.periodic[d] && m_phi[d] == phys_outflow) ? 1 : 0; }
+    const int a0 = olo[0], a1 = olo[1], a2 = olo[2], b0 = ohi[0], b1 = ohi[1], b2 = ohi[2];
+    for_each(*m_crse, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        double v = ot[f](i, j, k) != 0.0 ? rt[f](i, j, k) : 0.0;
+        if ((a0 && i == dom.lo[0]) || (b0 && i == dom.hi[0] + 1) || (a1 && j == dom.lo[1]) || (b1 && j == dom.hi[1] + 1) || (a2 && k == dom.lo[2]) || (b2 && k == dom.hi[2] + 1)) v = 0.0;
+        if (vt[f](i, j, k) == 1.0) v = 0.0;             // bndry_mask: nodes surrounded by fine cells only
+        ht[f](i, j, k) = v;
+    });
+}
+
+NavierStokes::~NavierStokes() = default;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Composite nodal projection over levels c0 .. c0+nl-1 (Hydro::NodalProjector::project on several AMR levels as driven by
+// Projection::doMLMGNodalProjection, Projection.cpp:2385-2567).
+//
+// Discretisation = the conforming Q1 finite-element composite operator (see oracle/orc_amr.c for the statement): the cells of a level
+// that the next finer level does not cover contribute their element matrices; a node of level l+1 on that level's boundary is a
+// slave (trilinear interpolant of level l), what the fine cells contribute to it goes to level l with the transposed weights /
+// ratio^3 (full-weighting restriction); boundary nodes of the coarsest level of the solve and nodes on Dirichlet faces keep their
+// incoming value.  Solver: fast adaptive composite cycle -- V-cycle of every refined level (zero Dirichlet data on its boundary),
+// V-cycle of the coarsest level on the composite residual, trilinear interpolation of the coarse correction, V-cycles of the
+// refined levels again -- repeated until the composite residual meets MLMG's criterion.
+namespace {
+
+struct CLev {
+    NavierStokes* ns;
+    Geometry g;
+    LayoutP layout;
+    std::unique_ptr<NodalMG> mg;
+    MultiFab sigm;          // sigma on the uncovered cells, ghost cells filled
+    MultiFab own, slave;    // node masks (1 / 0)
+    MultiFab fcov;          // coverage by the next level of the solve (cells, 1 ghost)
+    MultiFab b, x, r, y, e; // node arrays, 1 ghost
+    DomainBC bc;            // operator BC
+    double wscale;
+};
+
+void fill_nodes(CLev& L, MultiFab& x) { x.FillBoundary(L.g); nodal_reflect_bc(L.g, x, L.bc); }
+
+void comp_fill_slaves(std::vector<CLev>& L)
+{
+    for (size_t l = 0; l < L.size(); ++l) {
+        if (l > 0) node_interp_from_crse(L[l].x, L[l - 1].x, L[l - 1].g, L[l].ns->ratio, &L[l].slave, false);
+        fill_nodes(L[l], L[l].x);
+    }
+}
+
+// y = A x on the unknowns (0 elsewhere)
+void comp_apply(std::vector<CLev>& L)
+{
+    comp_fill_slaves(L);
+    const int nl = (int)L.size();
+    for (int l = nl - 1; l >= 0; --l) {
+        MultiFab ax(L[l].layout, node_type(), 1, 0);
+        nodal_residual(L[l].g, ax, L[l].x, L[l].sigm, nullptr);
+        if (l == nl - 1) MultiFab::Copy(L[l].y, ax, 0, 0, 1, 0);
+        else mf_saxpy(L[l].y, 1.0, ax, 0, 0, 1, 0);           // y already holds the contributions of the finer level
+        if (l > 0) {
+            MultiFab bb(L[l].layout, node_type(), 1, 1);
+            bb.setVal(0.0);
+            MultiFab::Copy(bb, L[l].y, 0, 0, 1, 0);
+            mask_mult(bb, 0, 1, L[l].slave, false, 0);
+            restrict_to_crse(L[l - 1].y, bb, L[l].g, L[l - 1].g, L[l].ns->ratio);
+        }
+        mask_mult(L[l].y, 0, 1, L[l].own, false, 0);
+    }
+}
+
+double comp_dot_own(std::vector<CLev>& L, int which /*0: <own,b>, 1: <own,own>*/)
+{
+    double s = 0.0;
+    for (auto& l : L) {
+        const MultiFab* xs[1] = {&l.own};
+        const MultiFab* ys[1] = {which == 0 ? &l.b : &l.own};
+        double v;
+        Geometry gg = l.g;
+        for (int d = 0; d < 3; ++d) { gg.half_lo[d] = (!gg.periodic[d] && l.bc.lo[d] == lo_neumann) ? 1 : 0; gg.half_hi[d] = (!gg.periodic[d] && l.bc.hi[d] == lo_neumann) ? 1 : 0; }
+        reduce_dots(1, xs, ys, 0, 1, gg, &v);
+        s += l.wscale * v;
+    }
+    return s;
+}
+
+double comp_norm(std::vector<CLev>& L, MultiFab CLev::*fld)
+{
+    double m = 0.0;
+    for (auto& l : L) m = std::max(m, (l.*fld).norm0(0, 1, 0));
+    return m;
+}
+
+void comp_residual(std::vector<CLev>& L)        // r = b - A x on the unknowns
+{
+    comp_apply(L);
+    for (auto& l : L) mf_lincomb(l.r, 1.0, l.b, -1.0, l.y, 0, 1, 0);
+}
+
+}  // namespace
+
+MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
+                                 const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale)
+{
+    auto& ctx = Context::get();
+    std::vector<CLev> L(nl);
+    bool singular = true;
+    double scale = 1.0;
+    for (int l = 0; l < nl; ++l) {
+        CLev& C = L[l];
+        C.ns = lev[c0 + l].get();
+        C.g = C.ns->geom(); C.layout = C.ns->lay();
+        C.bc = op_bc(C.ns->nodal_bc());
+        const bool has_fine = l < nl - 1;
+        for (MultiFab* m : {&C.b, &C.x, &C.r, &C.y, &C.e}) { m->define(C.layout, node_type(), 1, 1); m->setVal(0.0); }
+        C.own.define(C.layout, node_type(), 1, 0); C.slave.define(C.layout, node_type(), 1, 0);
+        MultiFab cls(C.layout, node_type(), 1, 0);
+        MultiFab cov = coverage(C.layout, C.g);
+        node_class(cls, cov, C.g);
+        MultiFab vsf(C.layout, node_type(), 1, 0);
+        vsf.setVal(0.0);
+        if (has_fine) { C.fcov = fine_coverage(C.layout, C.ns->fine->lay(), C.g, C.ns->fine->ratio); node_class(vsf, C.fcov, C.g); }
+        const bool partial = C.layout->total_cells() != C.g.domain.npts();
+        bool dir_face = false;
+        int dlo[3], dhi[3];
+        for (int d = 0; d < 3; ++d) {
+            dlo[d] = (!C.g.periodic[d] && C.bc.lo[d] == lo_dirichlet) ? 1 : 0; dhi[d] = (!C.g.periodic[d] && C.bc.hi[d] == lo_dirichlet) ? 1 : 0;
+            dir_face = dir_face || dlo[d] || dhi[d];
+        }
+        if (dir_face || (l == 0 && partial)) singular = false;
+        {
+            const FabD *ot = C.own.d_tab, *st = C.slave.d_tab, *ct = cls.d_tab, *vt = vsf.d_tab;
+            const BoxD dom = C.g.domain;
+            const int a0 = dlo[0], a1 = dlo[1], a2 = dlo[2], b0 = dhi[0], b1 = dhi[1], b2 = dhi[2];
+            const bool first = l == 0;
+            for_each(*C.layout, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                const double c = ct[f](i, j, k);
+                double own = c == 1.0 ? 1.0 : 0.0, slave = (c == 2.0 && !first) ? 1.0 : 0.0;
+                const bool onD = (a0 && i == dom.lo[0]) || (b0 && i == dom.hi[0] + 1) || (a1 && j == dom.lo[1]) || (b1 && j == dom.hi[1] + 1) || (a2 && k == dom.lo[2]) || (b2 && k == dom.hi[2] + 1);
+                if (onD) { own = 0.0; slave = 0.0; }
+                if (vt[f](i, j, k) == 1.0) own = 0.0;
+                ot[f](i, j, k) = own; st[f](i, j, k) = slave;
+            });
+        }
+        C.wscale = scale;
+        scale /= 8.0;
+        // sigma on the cells of the level that the next level of the solve does not cover
+        C.sigm.define(C.layout, cell_type(), 1, 1);
+        C.sigm.setVal(0.0);
+        MultiFab::Copy(C.sigm, *sig[l], 0, 0, 1, 0);
+        if (has_fine) mask_mult(C.sigm, 0, 1, C.fcov, true, 0);
+        C.sigm.FillBoundary(C.g);
+        cc_mirror_bc(C.g, C.sigm);
+        MGOpts mo = o;
+        C.mg = std::make_unique<NodalMG>(C.g, C.layout, C.ns->nodal_bc(), mo);
+        C.mg->setSigma(*sig[l], 0);
+    }
+    // right-hand side: div(vel) of the uncovered cells (+ rhnd), fine boundary contributions handed down
+    for (int l = nl - 1; l >= 0; --l) {
+        CLev& C = L[l];
+        vel[l]->FillBoundary(C.g, vcomp[l], 3);
+        C.ns->set_inflow_ghosts(*vel[l], inflow_scale);
+        MultiFab um(C.layout, cell_type(), 3, 1);
+        um.setVal(0.0);
+        MultiFab::Copy(um, *vel[l], vcomp[l], 0, 3, 0);
+        if (l < nl - 1) mask_mult(um, 0, 3, C.fcov, true, 0);
+        um.FillBoundary(C.g);
+        {
+            const FabD *ut = um.d_tab, *vt = vel[l]->d_tab;
+            const BoxD dom = C.g.domain;
+            const int p0 = C.g.periodic[0], p1 = C.g.periodic[1], p2 = C.g.periodic[2], vc = vcomp[l];
+            for_each(*C.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                const bool out = (!p0 && (i < dom.lo[0] || i > dom.hi[0])) || (!p1 && (j < dom.lo[1] || j > dom.hi[1])) || (!p2 && (k < dom.lo[2] || k > dom.hi[2]));
+                if (out) for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) = vt[f](i, j, k, vc + n);
+            });
+        }
+        MultiFab dv(C.layout, node_type(), 1, 0);
+        const DomainBC bcn = C.ns->nodal_bc();
+        nodal_divu(C.g, dv, um, 0, &bcn);
+        mf_saxpy(C.b, 1.0, dv, 0, 0, 1, 0);                    // b may already hold what the finer level handed down
+        if (l == 0 && rhnd) mf_saxpy(C.b, 1.0, *rhnd, 0, 0, 1, 0);
+        if (l > 0) {
+            MultiFab bb(C.layout, node_type(), 1, 1);
+            bb.setVal(0.0);
+            MultiFab::Copy(bb, C.b, 0, 0, 1, 0);
+            mask_mult(bb, 0, 1, C.slave, false, 0);
+            restrict_to_crse(L[l - 1].b, bb, C.g, L[l - 1].g, C.ns->ratio);
+        }
+        mask_mult(C.b, 0, 1, C.own, false, 0);
+    }
+    for (int l = 0; l < nl; ++l) MultiFab::Copy(L[l].x, *phi[l], 0, 0, 1, 0);
+    if (singular) {                      // MLMG::makeSolvable: remove the mean of the right-hand side over the composite unknowns
+        const double off = comp_dot_own(L, 0) / comp_dot_own(L, 1);
+        for (auto& C : L) { mf_add_scalar(C.b, -off, 0, 1, 0); mask_mult(C.b, 0, 1, C.own, false, 0); }
+    }
+    MGStats st;
+    st.nlevels = nl;
+    comp_residual(L);
+    st.rhsnorm0 = comp_norm(L, &CLev::b);
+    st.resnorm0 = comp_norm(L, &CLev::r);
+    st.resnorm = st.resnorm0;
+    const double max_norm = std::max(st.rhsnorm0, st.resnorm0);
+    const double target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
+    if (st.resnorm0 <= target) st.converged = 1;
+    MGStats vst;
+    for (int it = 0; it < o.max_iters && !st.converged; ++it) {
+        // refined levels, finest first
+        for (int l = nl - 1; l >= 1; --l) {
+            L[l].mg->vcycle_correction(L[l].e, L[l].r, vst);
+            mf_saxpy(L[l].x, 1.0, L[l].e, 0, 0, 1, 0);
+            comp_residual(L);
+        }
+        // coarsest level on the composite residual, correction interpolated to every finer level
+        L[0].mg->vcycle_correction(L[0].e, L[0].r, vst);
+        mf_saxpy(L[0].x, 1.0, L[0].e, 0, 0, 1, 0);
+        for (int l = 1; l < nl; ++l) {                          // e of level l = the interpolant of the coarse correction (all nodes)
+            fill_nodes(L[l - 1], L[l - 1].e);
+            L[l].e.setVal(0.0);
+            node_interp_from_crse(L[l].e, L[l - 1].e, L[l - 1].g, L[l].ns->ratio, nullptr, false);
+            MultiFab t(L[l].layout, node_type(), 1, 0);
+            MultiFab::Copy(t, L[l].e, 0, 0, 1, 0);
+            mask_mult(t, 0, 1, L[l].own, false, 0);
+            mf_saxpy(L[l].x, 1.0, t, 0, 0, 1, 0);
+        }
+        comp_residual(L);
+        for (int l = 1; l < nl; ++l) {
+            L[l].mg->vcycle_correction(L[l].e, L[l].r, vst);
+            mf_saxpy(L[l].x, 1.0, L[l].e, 0, 0, 1, 0);
+            comp_residual(L);
+        }
+        st.resnorm = comp_norm(L, &CLev::r);
+        st.iters = it + 1;
+        if (o.verbose) printf("iamrx composite nodal solve: iter %d resid %.6e (target %.3e)\n", it + 1, st.resnorm, target);
+        if (st.resnorm <= target) { st.converged = 1; break; }
+        if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx composite nodal solve: residual blow-up");
+    }
+    if (!st.converged) throw Error("iamrx composite nodal solve: failed to converge");
+    // slaves, covered coarse nodes (injection of the fine solution), ghost nodes
+    comp_fill_slaves(L);
+    for (int l = nl - 2; l >= 0; --l) { average_down(L[l + 1].x, L[l].x, 0, 1, L[l + 1].ns->ratio); fill_nodes(L[l], L[l].x); }
+    for (int l = 0; l < nl; ++l) {
+        CLev& C = L[l];
+        MultiFab::Copy(*phi[l], C.x, 0, 0, 1, 1);
+        MultiFab sg(C.layout, cell_type(), 1, 0);
+        MultiFab::Copy(sg, *sig[l], 0, 0, 1, 0);
+        nodal_mknewu(C.g, vel[l], vcomp[l], *phi[l], &sg, &C.ns->Gp[C.ns->pnew], increment_gp);
+    }
+    for (int l = nl - 1; l >= 1; --l) {                  // NodalProjector::averageDown(vel)
+        MultiFab vf(L[l].layout, cell_type(), 3, 0), vc(L[l - 1].layout, cell_type(), 3, 0);
+        MultiFab::Copy(vf, *vel[l], vcomp[l], 0, 3, 0);
+        MultiFab::Copy(vc, *vel[l - 1], vcomp[l - 1], 0, 3, 0);
+        average_down(vf, vc, 0, 3, L[l].ns->ratio);
+        MultiFab::Copy(*vel[l - 1], vc, 0, vcomp[l - 1], 3, 0);
+    }
+    for (int l = 0; l < nl; ++l) L[l].ns->fill_gradp_bc();
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+AmrNS::AmrNS(const Geometry& g0, const std::vector<LayoutP>& layouts, int ratio, const NSParams& p_, const MGOpts& o_) : p(p_), o(o_)
+{
+    IAMRX_ASSERT(ratio == 2 && !layouts.empty());
+    Geometry g = g0;
+    for (size_t l = 0; l < layouts.size(); ++l) {
+        if (l > 0) {
+            for (int d = 0; d < 3; ++d) { g.domain.lo[d] *= ratio; g.domain.hi[d] = (g.domain.hi[d] + 1) * ratio - 1; g.dx[d] /= (double)ratio; }
+        }
+        lev.push_back(std::make_unique<NavierStokes>(g, layouts[l], p, o));
+        NavierStokes& s = *lev.back();
+        s.level = (int)l; s.ratio = l > 0 ? ratio : 1;
+        n_cycle.push_back(l > 0 ? ratio : 1);
+        dt_level.push_back(0.0); dt_min.push_back(1.e200);
+        if (l > 0) {
+            NavierStokes& c = *lev[l - 1];
+            s.crse = &c; c.fine = &s;
+            s.rho_avg.define(s.layout, cell_type(), 1, 1); s.rho_avg.setVal(0.0);
+            s.p_avg.define(s.layout, node_type(), 1, 0); s.p_avg.setVal(0.0);
+            s.reg_adv = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
+            s.reg_visc = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
+            s.reg_mac = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, 1);
+            s.sync_reg = std::make_unique<SyncRegister>(s.layout, c.layout, c.g, s.g, ratio, p.phys_lo, p.phys_hi);
+            c.Vsync.define(c.layout, cell_type(), 3, 1); c.Vsync.setVal(0.0);
+            c.Ssync.define(c.layout, cell_type(), NUM_STATE - 3, 1); c.Ssync.setVal(0.0);
+        }
+    }
+}
+
+// NavierStokes::avgDown (NavierStokes.cpp:1845-1873) + avgDown_StatePress (NavierStokesBase.cpp:4125-4163)
+void AmrNS::avg_down(int l)
+{
+    NavierStokes &c = *lev[l], &f = *lev[l + 1];
+    average_down(f.S[f.inew], c.S[c.inew], 0, NUM_STATE, f.ratio);
+    for (size_t q = l; q < lev.size(); ++q) lev[q]->make_rho_curr_time();
+    average_down(c.initial_step ? f.P[f.pnew] : f.p_avg, c.P[c.pnew], 0, 1, f.ratio);
+    average_down(f.Gp[f.pnew], c.Gp[c.pnew], 0, 3, f.ratio);
+}
+
+// NavierStokes::reflux (NavierStokes.cpp:1736-1838)
+void AmrNS::reflux(int l)
+{
+    NavierStokes &c = *lev[l], &f = *lev[l + 1];
+    auto& ctx = Context::get();
+    const double vol = c.g.dx[0] * c.g.dx[1] * c.g.dx[2], dt_crse = dt_level[l];
+    f.reg_visc->Reflux(c.Vsync, vol, 1.0, 0, 0, 3);
+    f.reg_visc->Reflux(c.Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    {
+        const FabD *vt = c.Vsync.d_tab, *st = c.Ssync.d_tab, *ht = c.rho_half.d_tab;
+        const bool mom = c.p.do_mom_diff != 0, cons_trac = c.p.do_cons_trac != 0;
+        for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+            const double rh = ht[fb](i, j, k);
+            if (!mom) for (int n = 0; n < 3; ++n) vt[fb](i, j, k, n) /= rh;
+            if (!cons_trac) st[fb](i, j, k, Tracer - 3) /= rh;            // the non-conservative scalars (density is conservative)
+        });
+    }
+    f.reg_adv->Reflux(c.Vsync, vol, 1.0, 0, 0, 3);
+    f.reg_adv->Reflux(c.Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    mf_mult(c.Vsync, 1.0 / dt_crse, 0, 3, 1);
+    mf_mult(c.Ssync, 1.0 / dt_crse, 0, NUM_STATE - 3, 1);
+    // zero the coarse cells under the fine grids (grown tile box: ghost cells included)
+    MultiFab fc = fine_coverage(c.layout, f.layout, c.g, f.ratio);
+    mask_mult(c.Vsync, 0, 3, fc, true, 1);
+    mask_mult(c.Ssync, 0, NUM_STATE - 3, fc, true, 1);
+}
+
+// NavierStokes::mac_sync (NavierStokes.cpp:1438-1730) with MacProj::mac_sync_solve / mac_sync_compute; non-diffusive scalars,
+// inviscid velocity
+void AmrNS::mac_sync(int l)
+{
+    NavierStokes &c = *lev[l], &f = *lev[l + 1];
+    if (l != 0) throw Error("iamrx AmrNS::mac_sync: level > 0 (three or more levels) is not implemented");
+    if (c.is_diffusive_vel() || c.is_diffusive_tracer()) throw Error("iamrx AmrNS::mac_sync: the viscous / diffusive sync is not implemented");
+    auto& ctx = Context::get();
+    const double dt = dt_level[l];
+    MultiFab Ucorr[3];
+    MultiFab* uc[3];
+    for (int d = 0; d < 3; ++d) { Ucorr[d].define(c.layout, face_type(d), 1, 1); Ucorr[d].setVal(0.0); uc[d] = &Ucorr[d]; }
+    MGOpts mo = o;
+    mo.maxorder = 4;
+    st_mac_sync = mac_sync_solve(c.g, *f.reg_mac, c.rho_half, dt, f.layout, f.ratio, uc, c.mac_phi, c.bc_mac, 1.e-10 /*mac_sync_tol*/, c.p.mac_abs_tol, mo);
+    for (int d = 0; d < 3; ++d) Ucorr[d].FillBoundary(c.g);
+    // ---- mac_sync_compute (MacProj.cpp:490-731)
+    {
+        const bool mom = c.p.do_mom_diff != 0;
+        MultiFab Smf(c.layout, cell_type(), 3, 3), Sc(c.layout, cell_type(), NUM_SCALARS, 3);
+        c.fillpatch(Smf, c.S[1 - c.inew], Xvel, 3, c.bc_vel);
+        c.fillpatch(Sc, c.S[1 - c.inew], Density, NUM_SCALARS, c.bc_scal);
+        if (mom) {
+            const FabD *ut = Smf.d_tab, *rt = Sc.d_tab;
+            for_each(*c.layout, cell_type(), 3, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+                const double r = rt[fb](i, j, k, 0);
+                for (int n = 0; n < 3; ++n) ut[fb](i, j, k, n) *= r;
+            });
+        }
+        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), NUM_SCALARS, 1), divu(c.layout, cell_type(), 1, 1);
+        tfs.setVal(0.0); divu.setVal(0.0);
+        {
+            const FabD *tt = tfv.d_tab, *gt = c.Gp[1 - c.pnew].d_tab, *st = Sc.d_tab;
+            const double grav = c.p.gravity;
+            for_each(*c.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+                const double rho = st[fb](i, j, k, 0);
+                for (int n = 0; n < 3; ++n) {
+                    double t = ((fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0) + 0.0 - gt[fb](i, j, k, n);
+                    if (!mom) t /= rho;
+                    tt[fb](i, j, k, n) = t;
+                }
+            });
+        }
+        MultiFab* um[3] = {&c.u_mac[0], &c.u_mac[1], &c.u_mac[2]};
+        const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0}, ics[2] = {1, c.p.do_cons_trac ? 1 : 0};
+        MultiFab flv[3], fls[3];
+        MultiFab *flvp[3], *flsp[3];
+        for (int d = 0; d < 3; ++d) { flv[d].define(c.layout, face_type(d), 3, 0); fls[d].define(c.layout, face_type(d), NUM_SCALARS, 0); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
+        godunov_compute_aofs_sync(c.g, c.Vsync, 0, Smf, 3, &tfv, &divu, um, uc, icv, dt, c.bc_vel, true, c.p.use_forces_in_trans != 0, flvp);
+        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, NUM_SCALARS, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp);
+        for (int d = 0; d < 3; ++d) {            // NavierStokesBase.cpp:5083-5096 with sync_factor = -1
+            f.reg_adv->CrseInit(flv[d], d, 0, 0, 3, dt, true);
+            f.reg_adv->CrseInit(fls[d], d, 0, Density, NUM_SCALARS, dt, true);
+        }
+    }
+    // ---- NavierStokes.cpp:1490-1690
+    MultiFab& Sn = c.S[c.inew];
+    MultiFab Delta(c.layout, cell_type(), 1, 0);
+    const bool cons_trac = c.p.do_cons_trac != 0, mom = c.p.do_mom_diff != 0;
+    {
+        const FabD *st = c.Ssync.d_tab, *vt = c.Vsync.d_tab, *nt = Sn.d_tab, *dt_ = Delta.d_tab;
+        for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+            const double rho = nt[fb](i, j, k, Density);
+            if (cons_trac) {                 // conservative Q = rho q: sync -= (sync of rho) * q, added back below
+                const double dl = nt[fb](i, j, k, Tracer) * st[fb](i, j, k, 0) / rho;
+                dt_[fb](i, j, k) = dl;
+                st[fb](i, j, k, Tracer - 3) -= dl;
+            }
+            if (mom) for (int n = 0; n < 3; ++n) vt[fb](i, j, k, n) /= rho;
+        });
+    }
+    mf_mult(c.Ssync, dt, 0, NUM_STATE - 3, 1);              // not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
+    if (cons_trac) mf_saxpy(c.Ssync, dt, Delta, 0, Tracer - 3, 1, 0);
+    mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, NUM_STATE - 3, 0);
+    c.make_rho_curr_time();
+    // interpolate the sync correction to the finer level (:1697-1725)
+    if (lev.size() > (size_t)l + 2) throw Error("iamrx AmrNS::mac_sync: SyncInterp over more than one level is not implemented");
+    {
+        MultiFab incr(f.layout, cell_type(), NUM_STATE - 3, 0);
+        sync_interp_cellcons(incr, 0, c.Ssync, 0, NUM_STATE - 3, c.g, f.g, f.ratio, c.bc_scal);
+        mf_saxpy(f.S[f.inew], 1.0, incr, 0, Density, NUM_STATE - 3, 0);
+        f.make_rho_curr_time();
+        mf_saxpy(f.rho_avg, 1.0, incr, 0, 0, 1, 0);
+    }
+}
+
+// NavierStokesBase::level_sync (NavierStokesBase.cpp:1927-2044) + Projection::MLsyncProject (Projection.cpp:457-607)
+void AmrNS::level_sync(int l)
+{
+    NavierStokes &c = *lev[l], &f = *lev[l + 1];
+    if (l != 0) throw Error("iamrx AmrNS::level_sync: level > 0 (SyncRegister::CompAdd) is not implemented");
+    auto& ctx = Context::get();
+    const double dt = dt_level[l];
+    c.Vsync.FillBoundary(c.g);
+    MultiFab V_corr(f.layout, cell_type(), 3, 1);
+    V_corr.setVal(0.0);
+    sync_interp_cellcons(V_corr, 0, c.Vsync, 0, 3, c.g, f.g, f.ratio, c.bc_vel);          // SyncInterp, increment = 0
+    MultiFab phi_c(c.layout, node_type(), 1, 1), phi_f(f.layout, node_type(), 1, 1), rhnd(c.layout, node_type(), 1, 0);
+    phi_c.setVal(0.0); phi_f.setVal(0.0);
+    f.sync_reg->InitRHS(rhnd);
+    if (f.layout->boxes.size() == 1 && f.layout->boxes[0].npts() == f.g.domain.npts()) rhnd.setVal(0.0);   // Projection.cpp:506-510
+    // scaleVar: sigma = 1/rho (rho_half on the coarse level, rho_avg on the fine one); then velocity and sigma averaged down
+    MultiFab sig_c(c.layout, cell_type(), 1, 0), sig_f(f.layout, cell_type(), 1, 0);
+    {
+        const FabD *st = sig_c.d_tab, *ht = c.rho_half.d_tab;
+        for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) = 1.0 / ht[fb](i, j, k); });
+        const FabD *sf = sig_f.d_tab, *hf = f.rho_avg.d_tab;
+        for_each(*f.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { sf[fb](i, j, k) = 1.0 / hf[fb](i, j, k); });
+    }
+    {
+        MultiFab vf(f.layout, cell_type(), 3, 0), vc(c.layout, cell_type(), 3, 0);
+        MultiFab::Copy(vf, V_corr, 0, 0, 3, 0);
+        MultiFab::Copy(vc, c.Vsync, 0, 0, 3, 0);
+        average_down(vf, vc, 0, 3, f.ratio);
+        MultiFab::Copy(c.Vsync, vc, 0, 0, 3, 0);
+        average_down(sig_f, sig_c, 0, 1, f.ratio);
+    }
+    MultiFab* vel[2] = {&c.Vsync, &V_corr};
+    const int vcomp[2] = {0, 0};
+    MultiFab* phi[2] = {&phi_c, &phi_f};
+    const MultiFab* sig[2] = {&sig_c, &sig_f};
+    st_sync = composite_project(l, 2, vel, vcomp, phi, sig, &rhnd, 1.e-10 /*sync_tol*/, c.p.proj_abs_tol, true, 0.0);
+    mf_saxpy(c.P[c.pnew], 1.0, phi_c, 0, 0, 1, 1);
+    mf_saxpy(f.P[f.pnew], 1.0, phi_f, 0, 0, 1, 1);
+    mf_saxpy(c.S[c.inew], dt, c.Vsync, 0, Xvel, 3, 1);
+    mf_saxpy(f.S[f.inew], dt, V_corr, 0, Xvel, 3, 1);
+    if (lev.size() > (size_t)l + 2) throw Error("iamrx AmrNS::level_sync: SyncInterp / SyncProjInterp to levels > level+1 is not implemented");
+}
+
+// NavierStokesBase::post_timestep (NavierStokesBase.cpp:2546-2636)
+void AmrNS::post_timestep(int l)
+{
+    if (l < (int)lev.size() - 1) {
+        reflux(l);
+        avg_down(l);
+        mac_sync(l);
+        level_sync(l);
+    }
+    if (l > 0) mf_saxpy(lev[l]->p_avg, 1.0 / (double)n_cycle[l], lev[l]->P[lev[l]->pnew], 0, 0, 1, 0);      // incrPAvg
+}
+
+// Amr::timeStep
+void AmrNS::time_step(int l, double time, int iteration, int niter)
+{
+    NavierStokes& s = *lev[l];
+    s.time = time;
+    const double dt_new = s.advance(dt_level[l], iteration, niter);
+    dt_min[l] = iteration == 1 ? dt_new : std::min(dt_min[l], dt_new);
+    s.time = time + dt_level[l];
+    s.nstep += 1;
+    if (l < (int)lev.size() - 1) {
+        const int nc = n_cycle[l + 1];
+        for (int i = 1; i <= nc; ++i) time_step(l + 1, time + (i - 1) * dt_level[l + 1], i, nc);
+    }
+    post_timestep(l);
+}
+
+// NavierStokes::post_init (NavierStokes.cpp:1254-1299) for the hierarchy; S_new of every level holds the initial data
+void AmrNS::post_init(double stop_time_)
+{
+    auto& ctx = Context::get();
+    const int nl = (int)lev.size(), fin = nl - 1;
+    stop_time = stop_time_;
+    for (auto& s : lev) {
+        for (int q = 0; q < 2; ++q) { s->P[q].setVal(0.0); s->Gp[q].setVal(0.0); }
+        s->time = 0.0; s->nstep = 0;
+        s->set_time_level(0.0, 0.0, 0.0);
+    }
+    std::vector<MultiFab*> vel(nl), phi(nl);
+    std::vector<const MultiFab*> sigp(nl);
+    std::vector<MultiFab> sig(nl), vv(nl);
+    std::vector<int> vcomp(nl, 0);
+    // ---- post_init_state (NavierStokesBase.cpp:2369-2439)
+    if (p.init_vel_iter <= 0) { for (auto& s : lev) { s->P[1 - s->pnew].setVal(0.0); s->Gp[1 - s->pnew].setVal(0.0); } }
+    else
+    for (int iter = 0; iter < p.init_vel_iter; ++iter) {             // Projection::initialVelocityProject
+        for (int l = 0; l < nl; ++l) {
+            NavierStokes& s = *lev[l];
+            s.P[1 - s.pnew].setVal(0.0);
+            sig[l].define(s.layout, cell_type(), 1, 0); sig[l].setVal(1.0);      // rho_wgt_vel_proj = 0
+            vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
+        }
+        lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 1.0);
+        for (auto& s : lev) for (int q = 0; q < 2; ++q) { s->P[q].setVal(0.0); s->Gp[q].setVal(0.0); }
+    }
+    for (auto& s : lev) s->initial_step = true;
+    for (int l = fin - 1; l >= 0; --l) avg_down(l);
+    if (std::abs(p.gravity) > 0.0) {                                  // Projection::initialPressureProject (Projection.cpp:841-960)
+        for (int l = 0; l < nl; ++l) {
+            NavierStokes& s = *lev[l];
+            sig[l].define(s.layout, cell_type(), 1, 0);
+            const FabD *st = sig[l].d_tab, *nt = s.S[s.inew].d_tab;
+            for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / nt[f](i, j, k, Density); });
+            vv[l].define(s.layout, cell_type(), 3, 1);
+            vv[l].setVal(0.0);
+            vv[l].setVal(p.gravity, 2, 1, 1);
+            vel[l] = &vv[l]; vcomp[l] = 0; phi[l] = &s.P[s.pnew]; sigp[l] = &sig[l];
+        }
+        lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 0.0);
+        for (auto& s : lev) { MultiFab::Copy(s->P[1 - s->pnew], s->P[s->pnew], 0, 0, 1, 1); MultiFab::Copy(s->Gp[1 - s->pnew], s->Gp[s->pnew], 0, 0, 3, 1); }
+    }
+    // ---- post_init_estDT (NavierStokesBase.cpp:2307-2362)
+    std::vector<double> dt_save(nl);
+    std::vector<int> nc_save(nl);
+    double dt_init = 1.0e+100;
+    for (int k = 0; k < nl; ++k) {
+        nc_save[k] = n_cycle[k];
+        dt_save[k] = p.init_shrink * lev[k]->estTimeStep();           // initialTimeStep
+        int n_factor = 1;
+        for (int m = fin; m > k; --m) n_factor *= n_cycle[m];
+        dt_init = std::min(dt_init, dt_save[k] / (double)n_factor);
+    }
+    double dt0 = dt_save[0];
+    { int n_factor = 1; for (int k = 0; k < nl; ++k) { n_factor *= nc_save[k]; dt0 = std::min(dt0, n_factor * dt_save[k]); } }
+    if (stop_time >= 0.0) { const double eps = 0.0001 * dt0; if (0.0 + dt0 > stop_time - eps) dt0 = stop_time - 0.0; }
+    { int n_factor = 1; for (int k = 0; k < nl; ++k) { n_factor *= nc_save[k]; dt_save[k] = dt0 / (double)n_factor; } }
+    for (int k = 0; k < nl; ++k) { dt_level[k] = dt_init; n_cycle[k] = 1; lev[k]->set_time_level(0.0, dt_init, dt_init); }
+    // ---- post_init_press (NavierStokes.cpp:1306-1432)
+    if (p.init_iter > 0) {
+        for (auto& s : lev) s->initial_iter = true;
+        for (int iter = 0; iter < p.init_iter; ++iter) {
+            for (int k = 0; k < nl; ++k) lev[k]->advance(dt_init, 1, 1);
+            // Projection::initialSyncProject (Projection.cpp:970-1185)
+            for (int l = 0; l < nl; ++l) {
+                NavierStokes& s = *lev[l];
+                s.P[1 - s.pnew].setVal(0.0);
+                {
+                    const double dt_inv = 1. / dt_init;
+                    const FabD *nt = s.S[s.inew].d_tab, *ot = s.S[1 - s.inew].d_tab;
+                    for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                        for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) = (nt[f](i, j, k, n) - ot[f](i, j, k, n)) * dt_inv;   // ConvertUnew
+                    });
+                }
+                sig[l].define(s.layout, cell_type(), 1, 0);
+                const FabD *st = sig[l].d_tab, *ht = s.rho_half.d_tab;
+                for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / ht[f](i, j, k); });
+                vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
+            }
+            for (int l = fin; l >= 1; --l) {
+                MultiFab vf(lev[l]->layout, cell_type(), 3, 0), vc(lev[l - 1]->layout, cell_type(), 3, 0);
+                MultiFab::Copy(vf, *vel[l], Xvel, 0, 3, 0);
+                MultiFab::Copy(vc, *vel[l - 1], Xvel, 0, 3, 0);
+                average_down(vf, vc, 0, 3, lev[l]->ratio);
+                MultiFab::Copy(*vel[l - 1], vc, 0, Xvel, 3, 0);
+            }
+            lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, true, 0.0);
+            for (auto& s : lev) mf_saxpy(s->P[s->pnew], 1.0, s->P[1 - s->pnew], 0, 0, 1, 1);
+            for (int k = fin - 1; k >= 0; --k) avg_down(k);
+            for (auto& s : lev) {                                     // resetState(strt_time, dt_init, dt_init)
+                s->inew = 1 - s->inew;
+                MultiFab::Copy(s->P[1 - s->pnew], s->P[s->pnew], 0, 0, 1, 1);
+                MultiFab::Copy(s->Gp[1 - s->pnew], s->Gp[s->pnew], 0, 0, 3, 1);
+                s->set_time_level(0.0, dt_init, dt_init);
+                s->initial_iter = false;
+            }
+        }
+    }
+    for (int k = 0; k < nl; ++k) {
+        NavierStokes& s = *lev[k];
+        s.initial_step = false; s.initial_iter = false;
+        s.set_time_level(0.0, dt_save[k], dt_save[k]);
+        dt_level[k] = dt_save[k]; n_cycle[k] = nc_save[k]; dt_min[k] = 1.e200;
+        s.dt = dt_save[k];
+    }
+    level_steps = 0;
+}
+
+// Amr::coarseTimeStep: computeNewDt (NavierStokesBase.cpp:945-1035) + timeStep(0)
+double AmrNS::coarse_step()
+{
+    const int nl = (int)lev.size();
+    const double cur_time = lev[0]->time;
+    if (level_steps > 0) {
+        for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], lev[i]->estTimeStep());
+        if (p.fixed_dt <= 0.0) for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], p.change_max * dt_level[i]);
+        double dt_0 = 1.0e+100;
+        int n_factor = 1;
+        for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_0 = std::min(dt_0, n_factor * dt_min[i]); }
+        const double eps = 0.0001 * dt_0;
+        if (stop_time >= 0.0 && cur_time + dt_0 > stop_time - eps) dt_0 = stop_time - cur_time;
+        n_factor = 1;
+        for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_level[i] = dt_0 / (double)n_factor; }
+    }
+    time_step(0, cur_time, 1, 1);
+    level_steps += 1;
+    for (int i = 0; i < nl; ++i) lev[i]->dt = dt_level[i];
+    return dt_level[0];
+}
+
+}  // namespace iamrx

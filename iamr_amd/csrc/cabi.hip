@@ -2,6 +2,7 @@
 // Exceptions never cross the boundary: they become a non-zero return code + iamrx_last_error().
 #include "../../include/iamrx.h"
 #include "operators.h"
+#include "amrns.h"
 #include <string>
 #include <cstring>
 #include <vector>
@@ -524,7 +525,8 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
 }
 
 struct iamrx_ns_s {
-    std::unique_ptr<NavierStokes> ns;
+    std::unique_ptr<NavierStokes> owned;     // null for a level borrowed from an iamrx_amr hierarchy
+    NavierStokes* ns = nullptr;
     iamrx_mf_s* views[10];
     bool probing = false;
     LayoutP layout;
@@ -545,9 +547,8 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     p->do_cons_trac = d.do_cons_trac;
 }
 
-int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
+static NSParams to_params(const iamrx_ns_params* p)
 {
-    IAMRX_TRY
     NSParams q;
     q.cfl = p->cfl; q.visc_coef = p->visc_coef; q.be_cn_theta = p->be_cn_theta; q.gravity = p->gravity;
     q.mac_tol = p->mac_tol; q.mac_abs_tol = p->mac_abs_tol; q.proj_tol = p->proj_tol; q.proj_abs_tol = p->proj_abs_tol;
@@ -559,8 +560,15 @@ int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* 
     for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
     q.do_cons_trac = p->do_cons_trac;
+    return q;
+}
+
+int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
+{
+    IAMRX_TRY
     auto* h = new iamrx_ns_s;
-    h->ns = std::make_unique<NavierStokes>(to_geom(g), l->p, q, to_opts(o));
+    h->owned = std::make_unique<NavierStokes>(to_geom(g), l->p, to_params(p), to_opts(o));
+    h->ns = h->owned.get();
     h->layout = l->p;
     for (auto& v : h->views) v = nullptr;
     *out = h;
@@ -701,6 +709,46 @@ int iamrx_create_umac_grown(iamrx_mf fx, iamrx_mf fy, iamrx_mf fz, iamrx_mf cx, 
 int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int ratio)
 {
     IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH
+}
+
+// ---- AMR hierarchy (amrns.hip)
+struct iamrx_amr_s {
+    std::unique_ptr<AmrNS> amr;
+    std::vector<std::unique_ptr<iamrx_ns_s>> levels;     // borrowed level handles
+};
+int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts, int ratio, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_amr* out)
+{
+    IAMRX_TRY
+    std::vector<LayoutP> ls;
+    for (int l = 0; l < nlev; ++l) ls.push_back(layouts[l]->p);
+    auto* h = new iamrx_amr_s;
+    h->amr = std::make_unique<AmrNS>(to_geom(g0), ls, ratio, to_params(p), to_opts(o));
+    for (int l = 0; l < nlev; ++l) {
+        auto v = std::make_unique<iamrx_ns_s>();
+        v->ns = &h->amr->level(l);
+        v->layout = ls[l];
+        for (auto& q : v->views) q = nullptr;
+        h->levels.push_back(std::move(v));
+    }
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_amr_destroy(iamrx_amr a) { IAMRX_TRY delete a; IAMRX_CATCH }
+int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out) { IAMRX_TRY *out = a->levels.at(lev).get(); IAMRX_CATCH }
+int iamrx_amr_post_init(iamrx_amr a, double stop_time) { IAMRX_TRY a->amr->post_init(stop_time); IAMRX_CATCH }
+int iamrx_amr_coarse_step(iamrx_amr a, double* dt0) { IAMRX_TRY const double d = a->amr->coarse_step(); if (dt0) *dt0 = d; IAMRX_CATCH }
+int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels)
+{
+    IAMRX_TRY
+    if (time) *time = a->amr->time();
+    if (dt_levels) for (int l = 0; l < a->amr->nlevels(); ++l) dt_levels[l] = a->amr->dt(l);
+    IAMRX_CATCH
+}
+int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync, iamrx_mg_stats* mac_sync)
+{
+    IAMRX_TRY
+    from_stats(a->amr->st_sync, sync); from_stats(a->amr->st_mac_sync, mac_sync);
+    IAMRX_CATCH
 }
 
 int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc)

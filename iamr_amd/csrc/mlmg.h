@@ -121,6 +121,9 @@ public:
     void smooth(int l, MultiFab& x, const MultiFab& rhs);
     void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b);
     void vcycle(MGStats& st);
+    // one V-cycle for the residual equation A e = r, zero initial guess; e is zero on Dirichlet nodes, its ghost nodes are filled.
+    // Building block of the composite (multi-level) solver, amrns.hip.
+    void vcycle_correction(MultiFab& e, const MultiFab& r, MGStats& st);
     MultiFab& res(int l) { return m_lev[l].res; }
     MultiFab& cor(int l) { return m_lev[l].cor; }
 

@@ -63,6 +63,8 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         if (is_diffusive_tracer()) { diff_b[d].define(layout, face_type(d), 1, 0); diff_b[d].setVal(p.tracer_diff_coef); }
     }
     aofs.define(layout, cell_type(), NUM_STATE, 0);
+    mac_phi.define(layout, cell_type(), 1, 1);
+    mac_phi.setVal(0.0);
     rho_ptime.define(layout, cell_type(), 1, 1);
     rho_ctime.define(layout, cell_type(), 1, 1);
     rho_half.define(layout, cell_type(), 1, 1);
@@ -177,19 +179,65 @@ void NavierStokes::init_rayleightaylor(double rho_1, double rho_2, double tra_1,
     time = 0.0; nstep = 0;
 }
 
-// FillPatch on one level: copy the valid data, same-level + periodic ghost fill, then the physical-BC fill
-// (StateDataPhysBCFunct: FilccCell rules + the ext_dir functors of NS_bcfill.H)
+// NavierStokesBase::setTimeLevel (NavierStokesBase.cpp:2978-2996) with amrex::StateData::setTimeLevel semantics
+void NavierStokes::set_time_level(double time_, double dt_old, double dt_new)
+{
+    (void)dt_new;
+    st_new = time_; st_old = time_ - dt_old;
+    const double tp = time_ - dt_old;                 // state[Press_Type].setTimeLevel(time-dt_old,dt_old,dt_old)
+    pt_new[0] = tp; pt_new[1] = tp + dt_old;
+    pt_old[0] = tp - dt_old; pt_old[1] = tp;
+}
+
+void NavierStokes::swap_time_levels(double dt_)      // StateData::swapTimeLevels
+{
+    st_old = st_new; st_new += dt_;
+    pt_old[0] = pt_new[0]; pt_old[1] = pt_new[1];
+    pt_new[0] = pt_new[1]; pt_new[1] += dt_;
+}
+
+// FillPatch: copy the valid data, same-level + periodic ghost fill, then the physical-BC fill
+// (StateDataPhysBCFunct: FilccCell rules + the ext_dir functors of NS_bcfill.H).  On a refined level: FillPatchTwoLevels with the
+// coarse level's data interpolated in time (amr.hip); src must be the level's old or new State_Type data.
 void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)
 {
+    const bool is_vel = (bc == bc_vel);
+    const bool is_scal = (bc >= bc_scal && bc < bc_scal + 2);
+    const long so = is_scal ? 3 * (bc - bc_scal) : 0;
+    const double* edlo = is_vel ? ed_vel_lo : (is_scal ? ed_scal_lo + so : nullptr);
+    const double* edhi = is_vel ? ed_vel_hi : (is_scal ? ed_scal_hi + so : nullptr);
+    if (level > 0) {
+        IAMRX_ASSERT(&src == &S[0] || &src == &S[1]);
+        const double time_ = (&src == &S[1 - inew]) ? st_old : st_new;
+        TimeData fd{&S[1 - inew], &S[inew], st_old, st_new};
+        TimeData cd{&crse->S[1 - crse->inew], &crse->S[crse->inew], crse->st_old, crse->st_new};
+        fillpatch_two_levels(dst, 0, time_, fd, cd, scomp, ncomp, crse->g, g, ratio, bc, edlo, edhi);
+        return;
+    }
     MultiFab::Copy(dst, src, scomp, 0, ncomp, 0);
     dst.FillBoundary(g);
-    if (any_wall) {
-        const bool is_vel = (bc == bc_vel);
-        const bool is_scal = (bc >= bc_scal && bc < bc_scal + 2);
-        const long so = is_scal ? 3 * (bc - bc_scal) : 0;
-        fill_physbc_cc(g, dst, 0, ncomp, bc, is_vel ? ed_vel_lo : (is_scal ? ed_scal_lo + so : nullptr),
-                       is_vel ? ed_vel_hi : (is_scal ? ed_scal_hi + so : nullptr));
+    if (any_wall) fill_physbc_cc(g, dst, 0, ncomp, bc, edlo, edhi);
+}
+
+// FillPatch(Gradp_Type) at `time` into the ghost cells of G (the level's old or new Gradp): Projection.cpp:2564-2565,
+// NavierStokesBase.cpp:4417-4422.  Gradp_Type is an Interval type: the coarse data are those whose interval contains `time`.
+void NavierStokes::fill_gp(MultiFab& G, double time_)
+{
+    if (level == 0) {
+        G.FillBoundary(g);
+        if (any_wall) fill_physbc_cc(g, G, 0, 3, bc_gp, nullptr, nullptr);
+        return;
     }
+    const double teps = 1.e-3 * std::abs(crse->pt_new[0] - crse->pt_old[0]);
+    const MultiFab* Gc;
+    if (time_ >= crse->pt_new[0] - teps && time_ <= crse->pt_new[1] + teps) Gc = &crse->Gp[crse->pnew];
+    else if (time_ >= crse->pt_old[0] - teps && time_ <= crse->pt_old[1] + teps) Gc = &crse->Gp[1 - crse->pnew];
+    else throw Error("iamrx NavierStokes::fill_gp: the coarse level has no Gradp data at the requested time");
+    MultiFab tmp(layout, cell_type(), 3, 1);
+    TimeData fd{nullptr, &G, time_, time_};
+    TimeData cd{nullptr, Gc, time_, time_};
+    fillpatch_two_levels(tmp, 0, time_, fd, cd, 0, 3, crse->g, g, ratio, bc_gp, nullptr, nullptr);
+    MultiFab::Copy(G, tmp, 0, 0, 3, 1);
 }
 
 // Extrapolater::FirstOrderExtrap role (NavierStokes.cpp:2047): ghost cells outside the physical domain take the value
@@ -216,7 +264,7 @@ void NavierStokes::first_order_extrap(MultiFab& mf)
 // FillPatch(Gradp_Type) after a projection (Projection.cpp:2565): foextrap at walls
 void NavierStokes::fill_gradp_bc()
 {
-    if (any_wall) fill_physbc_cc(g, Gp[pnew], 0, 3, bc_gp, nullptr, nullptr);
+    fill_gp(Gp[pnew], 0.5 * (pt_new[0] + pt_new[1]));
 }
 
 static void floor_small(MultiFab& mf)
@@ -310,11 +358,38 @@ double NavierStokes::estTimeStep()
     return estdt;
 }
 
-void NavierStokes::advance_setup()
+// NavierStokesBase::advance_setup (NavierStokesBase.cpp:613-741)
+void NavierStokes::advance_setup(double dt_, int iteration_, int ncycle_)
 {
+    iteration = iteration_; ncycle = ncycle_;
+    if (fine) {
+        Vsync.setVal(0.0); Ssync.setVal(0.0);                            // :643-650
+        fine->reg_adv->setVal(0.0); fine->reg_visc->setVal(0.0);          // :655-659
+    }
+    if (!initial_step && level > 0 && iteration == 1) {                  // initRhoAvg(0.5/ncycle), :685-687 (before the swap)
+        rho_avg.setVal(1.e200);
+        MultiFab::Copy(rho_avg, S[inew], Density, 0, 1, 0);
+        mf_mult(rho_avg, 0.5 / (double)ncycle, 0, 1, 0);
+    }
     inew = 1 - inew;     // swapTimeLevels
     pnew = 1 - pnew;
+    swap_time_levels(dt_);
     fillpatch(rho_ptime, S[1 - inew], Density, 1, &bc_scal[0]);   // make_rho_prev_time
+}
+
+void NavierStokes::make_rho_curr_time()
+{
+    fillpatch(rho_ctime, S[inew], Density, 1, &bc_scal[0]);
+}
+
+// NavierStokesBase::ComputeAofs, flux-register part (NavierStokesBase.cpp:5075-5096): CrseAdd into the register of the next finer
+// level, FineAdd into the level's own (YAFluxRegister semantics written as CrseInit(-dt F, add) / FineAdd(+dt F), see amr.hip)
+void NavierStokes::adv_registers(MultiFab* const flux[3], int state_indx, int ncomp, double dt_)
+{
+    for (int d = 0; d < 3; ++d) {
+        if (fine) fine->reg_adv->CrseInit(*flux[d], d, 0, state_indx, ncomp, -dt_, true);
+        if (level > 0) reg_adv->FineAdd(*flux[d], d, 0, state_indx, ncomp, dt_);
+    }
 }
 
 double NavierStokes::predict_velocity(double dt_)
@@ -330,6 +405,8 @@ double NavierStokes::predict_velocity(double dt_)
         if (n == 0 || c > cflmax) cflmax = c;
     }
     const double tempdt = cflmax == 0 ? p.change_max : std::min(p.change_max, p.cfl / cflmax);
+    // NavierStokesBase.cpp:4417-4422: on a refined level the ghost cells of the old Gradp are re-filled, the coarse data have changed
+    if (level > 0) fill_gp(Gp[1 - pnew], 0.5 * (pt_old[0] + pt_old[1]));
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
     MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
@@ -354,15 +431,25 @@ double NavierStokes::predict_velocity(double dt_)
 void NavierStokes::mac_project(double dt_)
 {
     SectionTimer tm(*this, 1);
-    MultiFab mac_phi(layout, cell_type(), 1, 1);
-    mac_phi.setVal(0.0);
+    mac_phi.setVal(0.0);                                          // mac_phi_crse[level]: kept as the coarse/fine data of the next finer level
     MultiFab& So = S[1 - inew];
     MultiFab::Copy(So, rho_ptime, 0, Density, 1, 1);            // MacProj.cpp:262-263
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     MGOpts mo = o;
     mo.maxorder = 4;
-    st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
-    for (int d = 0; d < 3; ++d) u_mac[d].FillBoundary(g);        // create_umac_grown at level 0
+    if (level == 0) st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
+    else st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr, &crse->mac_phi, &crse->g, ratio);
+    // MAC registers (MacProj.cpp:304-348): fluxes = u_mac * area
+    for (int d = 0; d < 3; ++d) {
+        const double area = g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3];
+        if (fine) fine->reg_mac->CrseInit(u_mac[d], d, 0, 0, 1, -1.0 * area, false);
+        if (level > 0) reg_mac->FineAdd(u_mac[d], d, 0, 0, 1, area / (double)ncycle);
+    }
+    if (level == 0) for (int d = 0; d < 3; ++d) u_mac[d].FillBoundary(g);        // create_umac_grown at level 0
+    else {
+        const MultiFab* uc[3] = {&crse->u_mac[0], &crse->u_mac[1], &crse->u_mac[2]};
+        create_umac_grown(um, uc, nullptr, crse->g, g, ratio);
+    }
 }
 
 void NavierStokes::velocity_advection(double dt_)
@@ -404,6 +491,13 @@ void NavierStokes::velocity_advection(double dt_)
     const int ic = mom ? 1 : 0;                         // NS_setup.cpp:297-301: velocity advectionType = Conservative
     const int iconserv[3] = {ic, ic, ic};
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    if (fine || level > 0) {
+        MultiFab fl[3];
+        MultiFab* flp[3];
+        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), 3, 0); flp[d] = &fl[d]; }
+        godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, flp);
+        adv_registers(flp, Xvel, 3, dt_);
+    } else
     godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, nullptr);
 }
 
@@ -431,6 +525,13 @@ void NavierStokes::scalar_advection(double dt_)
     }
     const int iconserv[2] = {1, p.do_cons_trac ? 1 : 0};                            // NS_setup.cpp:304-310
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    if (fine || level > 0) {
+        MultiFab fl[3];
+        MultiFab* flp[3];
+        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_SCALARS, 0); flp[d] = &fl[d]; }
+        godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, flp);
+        adv_registers(flp, Density, NUM_SCALARS, dt_);
+    } else
     godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr);
 }
 
@@ -441,7 +542,7 @@ void NavierStokes::scalar_update_rho(double dt_)
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         nt[f](i, j, k, Density) = ot[f](i, j, k, Density) - dt_ * at[f](i, j, k, Density);
     });
-    fillpatch(rho_ctime, S[inew], Density, 1, &bc_scal[0]);           // make_rho_curr_time
+    make_rho_curr_time();
     {   // get_rho_half_time (NavierStokesBase.cpp:1561-1565)
         const FabD *ht = rho_half.d_tab, *pt = rho_ptime.d_tab, *ct = rho_ctime.d_tab;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -606,7 +707,26 @@ void NavierStokes::level_project(double dt_)
     SectionTimer tm(*this, 5);
     MultiFab& Sn = S[inew];
     MultiFab& Pn = P[pnew];
-    Pn.setVal(0.0, 0, 1, 0);                                     // Projection.cpp:236-256 (level 0: valid nodes)
+    if (level == 0) Pn.setVal(0.0, 0, 1, 0);                     // Projection.cpp:236-256 (level 0: valid nodes)
+    else {
+        // :232-256: FillCoarsePatch(P_new, cur_pres_time) -- Press_Type is an Interval type and cur_pres_time lies in the coarse level's
+        // NEW interval (the coarse level has advanced already), node_bilinear_interp -- then zero on every box shrunk by one node:
+        // the nodes on the box faces keep the interpolated coarse pressure (Dirichlet data on the coarse/fine boundary, initial guess
+        // on faces shared by two boxes)
+        const double tp = 0.5 * (pt_new[0] + pt_new[1]);
+        const double teps = 1.e-3 * std::abs(crse->pt_new[0] - crse->pt_old[0]);
+        const MultiFab* Pc;
+        if (tp >= crse->pt_new[0] - teps && tp <= crse->pt_new[1] + teps) Pc = &crse->P[crse->pnew];
+        else if (tp >= crse->pt_old[0] - teps && tp <= crse->pt_old[1] + teps) Pc = &crse->P[1 - crse->pnew];
+        else throw Error("iamrx NavierStokes::level_project: the coarse level has no pressure at the requested time");
+        node_interp_from_crse(Pn, *Pc, crse->g, ratio, nullptr, false);
+        const FabD* pt = Pn.d_tab;
+        const BoxD* vb = layout->d_boxes;
+        for_each(*layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const BoxD b = vb[f];
+            if (i > b.lo[0] && i <= b.hi[0] && j > b.lo[1] && j <= b.hi[1] && k > b.lo[2] && k <= b.hi[2]) pt[f](i, j, k) = 0.0;
+        });
+    }
     mf_mult(Sn, 1.0 / dt_, Xvel, 3, 1);                          // U_new *= 1/dt (:273)
     {
         const FabD *nt = Sn.d_tab, *gt = Gp[1 - pnew].d_tab, *ht = rho_half.d_tab;
@@ -622,8 +742,23 @@ void NavierStokes::level_project(double dt_)
         });
     }
     set_inflow_ghosts(Sn, 1.0 / dt_);
+    const bool want_crse = fine != nullptr, want_fine = level > 0 && iteration == ncycle;
+    MultiFab vold;
+    if (want_crse || want_fine) {                                // the sync residuals are formed with the unprojected velocity
+        Sn.FillBoundary(g, Xvel, 3);
+        vold.define(layout, cell_type(), 3, 1);
+        MultiFab::Copy(vold, Sn, Xvel, 0, 3, 1);
+    }
     st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
     fill_gradp_bc();
+    if (want_crse) {                                             // crse_sync_reg->CrseInit(sync_resid_crse, geom, 1.0), Projection.cpp:401-410
+        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, true);
+        fine->sync_reg->CrseInit(r, 1.0);
+    }
+    if (want_fine) {                                             // fine_sync_reg->FineAdd(sync_resid_fine, crse_geom, 1/crse_dt_ratio), :411-431
+        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, false);
+        sync_reg->FineAdd(r, 1.0 / (double)ncycle);
+    }
     mf_mult(Sn, dt_, Xvel, 3, 1);                                // U_new *= dt (:438)
 }
 
@@ -688,9 +823,9 @@ void NavierStokes::initial_sync_project(double dt_)
     mf_saxpy(P[pnew], 1.0, phi, 0, 0, 1, 1);                     // P_new += phi (Projection.cpp:1176-1180)
 }
 
-double NavierStokes::advance(double dt_)
+double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
 {
-    advance_setup();
+    advance_setup(dt_, iteration_, ncycle_);
     const double dt_test = predict_velocity(dt_);
     mac_project(dt_);
     velocity_advection(dt_);
@@ -701,7 +836,12 @@ double NavierStokes::advance(double dt_)
     velocity_advection_update(dt_);
     if (!initial_iter) velocity_diffusion_update(dt_);
     else initial_velocity_diffusion_update(dt_);
-    if (!initial_step) level_project(dt_);
+    if (!initial_step) {
+        if (level > 0)                                           // incrRhoAvg((iteration==ncycle ? 0.5 : 1.0) / ncycle), NavierStokes.cpp:644-645
+            mf_saxpy(rho_avg, (iteration == ncycle ? 0.5 : 1.0) / (double)ncycle, S[inew], Density, 0, 1, 0);
+        level_project(dt_);
+        if (level > 0 && iteration == 1) p_avg.setVal(0.0);      // :670-671
+    }
     return dt_test;
 }
 

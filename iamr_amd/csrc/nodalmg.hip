@@ -324,6 +324,19 @@ void NodalMG::vcycle(MGStats& st)
     }
 }
 
+void NodalMG::vcycle_correction(MultiFab& e, const MultiFab& r, MGStats& st)
+{
+    Level& L0 = m_lev[0];
+    MultiFab::Copy(L0.res, r, 0, 0, 1, 0);
+    if (L0.dmask()) nodal_zero_masked(L0.res, L0.dm);
+    if (m_singular) subtract_mean(0, L0.res);
+    L0.res_filled = false;
+    vcycle(st);
+    MultiFab::Copy(e, L0.cor, 0, 0, 1, 0);
+    e.FillBoundary(L0.g);
+    nodal_reflect_bc(L0.g, e, m_bc);
+}
+
 MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)
 {
     auto& ctx = Context::get();

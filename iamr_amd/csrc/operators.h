@@ -4,6 +4,7 @@
 #include "mf.h"
 #include "mlmg.h"
 #include "kernels.h"
+#include <memory>
 
 namespace iamrx {
 
@@ -77,6 +78,45 @@ private:
     MultiFab m_reg[3][2];
 };
 
+// ---- multi-level pieces (amrns.hip) -----------------------------------------------------------------------------
+// trilinear interpolation (amrex::NodeBilinear) of a coarse nodal MultiFab at the valid nodes of `fine`: fine = (add: +=) interp(crse);
+// mask (nodal, fine layout; may be null): only where mask != 0
+void node_interp_from_crse(MultiFab& fine, const MultiFab& crse, const Geometry& cgeom, int ratio, const MultiFab* mask, bool add);
+// NavierStokesBase::SyncInterp with cell_cons_interp (Source/NavierStokesBase.cpp:3071-3276): conservative-linear interpolation of
+// the coarse cell data crse(scomp..) (valid region; periodic images and homogeneous-ext_dir / extrapolated values outside walls are
+// built here) to every valid cell of dst(dcomp..)
+void sync_interp_cellcons(MultiFab& dst, int dcomp, const MultiFab& crse, int scomp, int ncomp, const Geometry& cgeom, const Geometry& fgeom,
+                          int ratio, const BCRec* bc);
+// NavierStokesBase::ComputeAofs with is_sync = true (Source/NavierStokesBase.cpp:4594-4845 as called from MacProj::mac_sync_compute):
+// edge states traced with umac, fluxes formed with ucorr, conservative update for every component, sync(acomp..) -= update
+void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
+                               const MultiFab* divu, MultiFab* const umac[3], MultiFab* const ucorr[3], const int* iconserv, double dt,
+                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3]);
+
+// SyncRegister (Source/SyncRegister.cpp): nodal values on the faces of the coarsened fine boxes, kept as ONE single-valued nodal
+// MultiFab on the coarse level's layout + the node masks that InitRHS needs
+class SyncRegister {
+public:
+    SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, const Geometry& fgeom, int ratio, const int phys_lo[3], const int phys_hi[3]);
+    void CrseInit(const MultiFab& sync_resid_crse, double mult);          // SyncRegister.cpp:306-318
+    void FineAdd(const MultiFab& sync_resid_fine, double mult);           // :350-607
+    void InitRHS(MultiFab& rhs);                                          // :47-304
+    const MultiFab& reg() const { return m_reg; }
+    const MultiFab& vs_fine() const { return m_vsfine; }                  // node class of the coarse nodes w.r.t. the fine level: 0 untouched, 1 inside, 2 on its boundary
+private:
+    LayoutP m_fine, m_crse;
+    Geometry m_cgeom, m_fgeom;
+    int m_ratio;
+    int m_plo[3], m_phi[3];
+    MultiFab m_reg, m_onreg, m_vsfine;
+};
+
+class NavierStokes;
+// sync residual of a level projection (Hydro::NodalProjector::computeSyncResidualCoarse / Fine): crse_side: on the nodes of the level
+// that touch both cells covered by the next finer level and cells that are not, rhs - L(phi) formed with the uncovered cells only;
+// fine side: on the nodes of the level's own boundary inside the domain, formed with the level's cells only.  Zero elsewhere.
+MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side);
+
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {
     double cfl = 0.8, visc_coef = 0.0, be_cn_theta = 0.5, gravity = 0.0;
@@ -94,9 +134,12 @@ struct NSParams {
 
 enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
 
+class SyncRegister;
+class AmrNS;
 class NavierStokes {
 public:
     NavierStokes(const Geometry& g, LayoutP layout, const NSParams& p, const MGOpts& o);
+    ~NavierStokes();
     void init_taylorgreen(double vfac, double a, double b, double c, double rho0);   // Source/prob/prob_init.cpp:509-560
     // probtype 10 (Source/prob/prob_init.cpp:407-488, 3-D branch): fluid at rest, tanh density / tracer interface at mid height,
     // perturbed by the hard-coded random amplitude and phases of the reference
@@ -104,7 +147,8 @@ public:
     void init_rest(double rho0);               // probtype 1 (LidDrivenCavity), Source/prob/prob_init.cpp:102-109
     void post_init(double stop_time);          // NavierStokes::post_init
     double step();                             // Amr::coarseTimeStep on one level: computeNewDt + advance
-    double advance(double dt);                 // NavierStokes::advance; returns the dt estimate
+    double advance(double dt) { return advance(dt, 1, 1); }
+    double advance(double dt, int iteration, int ncycle);   // NavierStokes::advance(time, dt, iteration, ncycle); returns the dt estimate
     double estTimeStep();                      // NavierStokesBase::estTimeStep
     MultiFab& get_new_data(int type) { return type == 0 ? S[inew] : (type == 1 ? P[pnew] : Gp[pnew]); }
     MultiFab& get_old_data(int type) { return type == 0 ? S[1 - inew] : (type == 1 ? P[1 - pnew] : Gp[1 - pnew]); }
@@ -116,8 +160,30 @@ public:
     double t_sections[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // accumulated ms: predict, mac, advect, update, visc, nodal
     bool profile_sections = false;
 
+    // ---- AMR hierarchy (amrns.hip): level index, neighbours, StateData times (State_Type: Point; Press_Type / Gradp_Type: Interval,
+    // NavierStokesBase::setTimeLevel, Source/NavierStokesBase.cpp:2978-2996), registers owned by the fine level of an interface
+    int level = 0, ratio = 1;
+    NavierStokes *crse = nullptr, *fine = nullptr;
+    double st_new = 0.0, st_old = 0.0, pt_new[2] = {0.0, 0.0}, pt_old[2] = {0.0, 0.0};
+    int iteration = 1, ncycle = 1;
+    MultiFab mac_phi;                          // MacProj::mac_phi_crse[level]
+    MultiFab rho_avg, p_avg;                   // level > 0
+    MultiFab Vsync, Ssync;                     // level < finest
+    std::unique_ptr<FluxRegister> reg_adv, reg_visc, reg_mac;
+    std::unique_ptr<SyncRegister> sync_reg;
+    void set_time_level(double time, double dt_old, double dt_new);
+    const Geometry& geom() const { return g; }
+    const LayoutP& lay() const { return layout; }
+    const NSParams& params() const { return p; }
+    const DomainBC& nodal_bc() const { return bc_nodal; }
+    friend class AmrNS;
+
 private:
-    void advance_setup();
+    void advance_setup(double dt, int iteration, int ncycle);
+    void swap_time_levels(double dt);
+    void fill_gp(MultiFab& G, double time);
+    void make_rho_curr_time();
+    void adv_registers(MultiFab* const flux[3], int state_indx, int ncomp, double dt);
     double predict_velocity(double dt);
     void mac_project(double dt);
     void velocity_advection(double dt);

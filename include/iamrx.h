@@ -27,6 +27,7 @@ typedef struct iamrx_layout_s* iamrx_layout;   /* BoxArray + DistributionMapping
 typedef struct iamrx_fluxreg_s* iamrx_fluxreg; /* amrex::FluxRegister of one coarse/fine interface (see below) */
 typedef struct iamrx_mf_s* iamrx_mf;           /* MultiFab (device resident) */
 typedef struct iamrx_ns_s* iamrx_ns;           /* NavierStokes level object */
+typedef struct iamrx_amr_s* iamrx_amr;         /* hierarchy of NavierStokes levels (the Amr / AmrLevel role for the hot path) */
 
 typedef struct iamrx_geom {
     int dom_lo[3], dom_hi[3];       /* cell-centred domain box */
@@ -306,6 +307,25 @@ int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamr
  * enable=3: no syncs; HIP events on the launch stream around every 8th k_nodal_gs4 launch of the level's own (finest) MG level until the
  * next call, which returns their total duration (ms) in sections_ms[6] and their number in sections_ms[7] */
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8]);
+
+/* ---- multi-level time step ------------------------------------------------------------------------------------
+ * One coarse time step of a hierarchy of levels with subcycling = amrex::Amr::coarseTimeStep -> timeStep(level): advance(level),
+ * ncycle x timeStep(level+1), NavierStokesBase::post_timestep(level) (Source/NavierStokesBase.cpp:2546-2636):
+ *   NavierStokes::reflux (Source/NavierStokes.cpp:1736-1838), avgDown (:1845-1873), mac_sync (:1438-1730) with
+ *   MacProj::mac_sync_solve / mac_sync_compute (Source/MacProj.cpp:359-731), NavierStokesBase::level_sync (Source/NavierStokesBase.cpp:1927-2044)
+ *   with Projection::MLsyncProject (Source/Projection.cpp:457-607), SyncRegister (Source/SyncRegister.cpp), SyncInterp (:3071-3276);
+ * and NavierStokes::post_init for all levels (initialVelocityProject, initialPressureProject, init_iter x {advance, initialSyncProject},
+ * Source/NavierStokes.cpp:1254-1432, Source/Projection.cpp:615-1185).
+ * layouts[l]: the boxes of level l in the index space of that level (level 0 must cover g0's domain; finer levels must be aligned to
+ * the refinement ratio and properly nested).  ratio: 2.  The level handles returned by iamrx_amr_level are borrowed: use them with
+ * iamrx_ns_data / iamrx_ns_set_data / iamrx_ns_time / iamrx_ns_stats, do not destroy them. */
+int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts, int ratio, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_amr* out);
+int iamrx_amr_destroy(iamrx_amr a);
+int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out);
+int iamrx_amr_post_init(iamrx_amr a, double stop_time);      /* S_new of every level must hold the initial data (iamrx_ns_set_data) */
+int iamrx_amr_coarse_step(iamrx_amr a, double* dt0);         /* dt0: the level-0 time step used */
+int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels /* [nlev] or NULL */);
+int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync_project, iamrx_mg_stats* mac_sync);
 
 #ifdef __cplusplus
 }
