@@ -387,12 +387,12 @@ void comp_apply(std::vector<CLev>& L)
     }
 }
 
-double comp_dot_own(std::vector<CLev>& L, int which /*0: <own,b>, 1: <own,own>*/)
+double comp_dot_own(std::vector<CLev>& L, int which /*0: <own,b>, 1: <own,own>, 2: <own,x>*/)
 {
     double s = 0.0;
     for (auto& l : L) {
         const MultiFab* xs[1] = {&l.own};
-        const MultiFab* ys[1] = {which == 0 ? &l.b : &l.own};
+        const MultiFab* ys[1] = {which == 0 ? &l.b : (which == 2 ? &l.x : &l.own)};
         double v;
         Geometry gg = l.g;
         for (int d = 0; d < 3; ++d) { gg.half_lo[d] = (!gg.periodic[d] && l.bc.lo[d] == lo_neumann) ? 1 : 0; gg.half_hi[d] = (!gg.periodic[d] && l.bc.hi[d] == lo_neumann) ? 1 : 0; }
@@ -553,6 +553,14 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx composite nodal solve: residual blow-up");
     }
     if (!st.converged) throw Error("iamrx composite nodal solve: failed to converge");
+    if (singular) {                      // the solution of the singular system is fixed by a zero weighted mean over the composite unknowns
+        const double off = comp_dot_own(L, 2) / comp_dot_own(L, 1);
+        for (auto& C : L) {
+            MultiFab t(C.layout, node_type(), 1, 0);
+            MultiFab::Copy(t, C.own, 0, 0, 1, 0);
+            mf_saxpy(C.x, -off, t, 0, 0, 1, 0);
+        }
+    }
     // slaves, covered coarse nodes (injection of the fine solution), ghost nodes
     comp_fill_slaves(L);
     for (int l = nl - 2; l >= 0; --l) { average_down(L[l + 1].x, L[l].x, 0, 1, L[l + 1].ns->ratio); fill_nodes(L[l], L[l].x); }
@@ -611,6 +619,9 @@ void AmrNS::avg_down(int l)
     for (size_t q = l; q < lev.size(); ++q) lev[q]->make_rho_curr_time();
     average_down(c.initial_step ? f.P[f.pnew] : f.p_avg, c.P[c.pnew], 0, 1, f.ratio);
     average_down(f.Gp[f.pnew], c.Gp[c.pnew], 0, 3, f.ratio);
+    // The reference leaves the ghost cells of the coarse Gradp as they were (filled before the average), which makes the next
+    // predictor depend on how the coarse level happens to be chopped into boxes.  Here (and in the oracle) they are re-filled.
+    c.fill_gradp_bc();
 }
 
 // NavierStokes::reflux (NavierStokes.cpp:1736-1838)

@@ -546,6 +546,22 @@ void amr_composite_project(orc_amr* a, int c0, int nl, orc_fab* vel[] /*cell, 3 
         }
     }
     if (!loc.converged) fprintf(stderr, "orc composite nodal solve: not converged (res %.3e target %.3e)\n", loc.resnorm, target);
+    if (singular) {                      /* the solution of the singular system is fixed by a zero weighted mean over the composite unknowns */
+        double sw = 0.0, sx = 0.0;
+        for (int l = 0; l < nl; ++l) {
+            const orc_geom* g = &L[l].s->g;
+            for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+                const double w = A4(&L[l].wt, i, j, k, 0);
+                sw += w; sx += w * A4(&x[l], i, j, k, 0);
+            }
+        }
+        const double off = sx / sw;
+        for (int l = 0; l < nl; ++l) {
+            const orc_geom* g = &L[l].s->g;
+            for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+                if (A4(&L[l].own, i, j, k, 0) != 0.0) A4(&x[l], i, j, k, 0) -= off;
+        }
+    }
     if (st) *st = loc;
     /* slaves, covered coarse nodes (injection of the fine solution), ghost nodes */
     comp_fill_slaves(L, nl, x);
@@ -623,6 +639,9 @@ static void avg_down(orc_amr* a, int lev)
     for (int l = lev; l < a->nlev; ++l) ns_make_rho_curr_time(a->lev[l]);
     avg_down_nodes(f, c->initial_step ? P_NEW(f) : &f->p_avg, P_NEW(c));
     avg_down_cells(f, GP_NEW(f), GP_NEW(c), 0, 3);
+    /* The reference leaves the ghost cells of the coarse Gradp as they were (filled before the average), which makes the next
+     * predictor depend on how the coarse level happens to be chopped into boxes.  Here (and in the product) they are re-filled. */
+    ns_fill_gp(c, GP_NEW(c), 0.5 * (c->pt_new[0] + c->pt_new[1]));
 }
 
 /* NavierStokes::reflux (NavierStokes.cpp:1736-1838) */
@@ -850,8 +869,9 @@ static void post_timestep(orc_amr* a, int lev, int crse_iteration)
     }
     if (lev > 0) {                       /* incrPAvg */
         const double alpha = 1.0 / (double)a->n_cycle[lev];
-        const size_t N = orc_npts(&s->p_avg);
-        for (size_t q = 0; q < N; ++q) s->p_avg.p[q] += alpha * P_NEW(s)->p[q];
+        const orc_geom* g = &s->g;
+        for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+            A4(&s->p_avg, i, j, k, 0) += alpha * A4(P_NEW(s), i, j, k, 0);
     }
 }
 
