@@ -334,7 +334,7 @@ NavierStokes::~NavierStokes() = default;
 // Composite nodal projection over levels c0 .. c0+nl-1 (Hydro::NodalProjector::project on several AMR levels as driven by
 // Projection::doMLMGNodalProjection, Projection.cpp:2385-2567).
 //
-// Discretisation = the conforming Q1 finite-element composite operator (see oracle/orc_amr.c for the statement): the cells of a level
+// Discretisation = the conforming Q1 finite-element composite operator: the cells of a level
 // that the next finer level does not cover contribute their element matrices; a node of level l+1 on that level's boundary is a
 // slave (trilinear interpolant of level l), what the fine cells contribute to it goes to level l with the transposed weights /
 // ratio^3 (full-weighting restriction); boundary nodes of the coarsest level of the solve and nodes on Dirichlet faces keep their
@@ -620,7 +620,7 @@ void AmrNS::avg_down(int l)
     average_down(c.initial_step ? f.P[f.pnew] : f.p_avg, c.P[c.pnew], 0, 1, f.ratio);
     average_down(f.Gp[f.pnew], c.Gp[c.pnew], 0, 3, f.ratio);
     // The reference leaves the ghost cells of the coarse Gradp as they were (filled before the average), which makes the next
-    // predictor depend on how the coarse level happens to be chopped into boxes.  Here (and in the oracle) they are re-filled.
+    // predictor depend on how the coarse level happens to be chopped into boxes.  Here they are re-filled.
     c.fill_gradp_bc();
 }
 

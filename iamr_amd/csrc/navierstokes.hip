@@ -845,9 +845,30 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
     return dt_test;
 }
 
+// Projection::initialPressureProject (Projection.cpp:841-960), called from NavierStokesBase::post_init_state (NavierStokesBase.cpp:2416-2426)
+// whenever gravity is set: project (0,0,g) with sigma = 1/rho to establish the hydrostatic pressure; P and Gradp, old = new.
+void NavierStokes::initial_pressure_project()
+{
+    if (!(std::abs(p.gravity) > 0.0)) return;
+    MultiFab sig(layout, cell_type(), 1, 1);
+    {
+        const FabD *st = sig.d_tab, *nt = S[inew].d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k, 0) = 1.0 / nt[f](i, j, k, Density); });
+    }
+    MultiFab vel(layout, cell_type(), 3, 1);
+    vel.setVal(0.0);
+    vel.setVal(p.gravity, 2, 1, 1);
+    st_nodal = nodal_projection(g, vel, 0, P[pnew], sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+    fill_gradp_bc();
+    MultiFab::Copy(P[1 - pnew], P[pnew], 0, 0, 1, 1);
+    MultiFab::Copy(Gp[1 - pnew], Gp[pnew], 0, 0, 3, 1);
+}
+
 void NavierStokes::post_init(double stop_time)
 {
+    m_stop_time = stop_time;
     initial_velocity_project();
+    initial_pressure_project();
     initial_step = true;
     double dt_init = p.init_shrink * estTimeStep();
     if (stop_time >= 0.0) {
@@ -877,6 +898,10 @@ double NavierStokes::step()
         double dt_min = std::min(dt_min_adv, estTimeStep());
         if (p.fixed_dt <= 0.0) dt_min = std::min(dt_min, p.change_max * dt);
         dt_ = dt_min;
+        if (m_stop_time >= 0.0) {                               // computeNewDt, NavierStokesBase.cpp:1008-1015
+            const double eps = 0.0001 * dt_;
+            if (time + dt_ > m_stop_time - eps) dt_ = m_stop_time - time;
+        }
     }
     dt = dt_;
     dt_min_adv = advance(dt_);

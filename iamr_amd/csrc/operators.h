@@ -201,6 +201,8 @@ private:
     void initial_velocity_diffusion_update(double dt);
     void level_project(double dt);
     void initial_velocity_project();
+    void initial_pressure_project();
+    double m_stop_time = -1.0;
     void initial_sync_project(double dt);
     void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
     void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc);

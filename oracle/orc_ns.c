@@ -91,6 +91,7 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     s->level = 0; s->ratio = 1; s->crse = s->fine = NULL; s->nbox = 0; s->boxes = NULL; s->cov.p = NULL;
     s->iteration = 1; s->ncycle = 1;
     ns_set_time_level(s, 0.0, 0.0, 0.0);
+    s->stop_time = -1.0;
     for (int d = 0; d < 3; ++d) {
         const int plo = g->periodic[d] ? PHYS_INTERIOR : p->phys_lo[d], phi_ = g->periodic[d] ? PHYS_INTERIOR : p->phys_hi[d];
         if (!g->periodic[d] && !(phys_ok(plo) && phys_ok(phi_))) {
@@ -1125,10 +1126,30 @@ static void initial_sync_project(orc_ns_state* s, double dt)
     for (size_t q = 0; q < N; ++q) Pn->p[q] += phi->p[q];
 }
 
+/* Projection::initialPressureProject (Projection.cpp:841-960; called from NavierStokesBase::post_init_state, NavierStokesBase.cpp:2416-2426,
+ * whenever gravity is set): project (0,0,g) with sigma = 1/rho to establish the hydrostatic pressure; P and Gradp, old = new */
+static void initial_pressure_project(orc_ns_state* s)
+{
+    const orc_geom* g = &s->g;
+    if (!(fabs(s->p.gravity) > 0.0)) return;
+    orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(&sig, i, j, k, 0) = 1.0 / A4(S_NEW(s), i, j, k, Density);
+    orc_fill_periodic(&sig, g, ORC_CELL);
+    orc_fab vel = orc_alloc(g->n, ORC_CELL, 1, 3);
+    { const size_t N = orc_npts(&vel); for (size_t q = 0; q < N; ++q) vel.p[q + 2 * N] = s->p.gravity; }
+    nodal_project_level(s, &vel, P_NEW(s), &sig, 0, 0.0, 0);
+    orc_copy_all(P_OLD(s), P_NEW(s));
+    orc_copy_all(GP_OLD(s), GP_NEW(s));
+    orc_free(&sig); orc_free(&vel);
+}
+
 void orc_ns_post_init(orc_ns_state* s, double stop_time)
 {
+    s->stop_time = stop_time;
     /* post_init_state */
     initial_velocity_project(s);
+    initial_pressure_project(s);
     s->initial_step = 1;
     /* post_init_estDT: dt = init_shrink * estTimeStep, limited by stop_time */
     double dt_init = s->p.init_shrink * ns_est_time_step(s);
@@ -1162,6 +1183,10 @@ double orc_ns_step(orc_ns_state* s)
         double dt_min = fmin(s->dt_min_adv, ns_est_time_step(s));
         if (s->p.fixed_dt <= 0.0) dt_min = fmin(dt_min, s->p.change_max * s->dt);
         dt = dt_min;
+        if (s->stop_time >= 0.0) {                               /* computeNewDt, NavierStokesBase.cpp:1008-1015 */
+            const double eps = 0.0001 * dt;
+            if (s->time + dt > s->stop_time - eps) dt = s->stop_time - s->time;
+        }
     }
     s->dt = dt;
     s->dt_min_adv = advance(s, dt);

@@ -43,6 +43,7 @@ struct orc_ns_state {
     double st_new, st_old;         /* StateData times of State_Type (Point) */
     double pt_new[2], pt_old[2];   /* time intervals of Press_Type / Gradp_Type (Interval): NavierStokesBase::setTimeLevel, NavierStokesBase.cpp:2978-2996 */
     int iteration, ncycle;         /* of the advance in progress */
+    double stop_time;              /* single-level driver (orc_ns_step): computeNewDt's stop_time clamp */
     orc_fab mac_phi;               /* MacProj::mac_phi_crse[level] */
     orc_fab rho_avg, p_avg;        /* level > 0 */
     orc_fab Vsync, Ssync;          /* level < finest: 3 / NUM_STATE-3 comps, 1 ghost */

@@ -1,0 +1,118 @@
+"""Pins of the multi-level oracle (oracle/orc_amr.c) and of the round-2 additions to the single-level one that do not need a GPU:
+known answers and invariants that do not depend on the product (usable pins while AMReX / AMReX-Hydro are absent)."""
+import ctypes as C
+import numpy as np
+
+import orc
+
+
+def _amr(n0, fine, state_fn, **kw):
+    a = orc.OrcAmr(orc.geom([n0] * 3), orc.ns_params(**kw), orc.mg_opts(), [[], fine])
+    for l in range(2):
+        a.set_state(l, state_fn(*a.cell_centres(l)))
+    return a
+
+
+def _uniform(X, Y, Z):
+    S = np.zeros(X.shape + (5,), order="F")
+    S[..., 0], S[..., 1], S[..., 2], S[..., 3] = 1.0, 0.5, 0.25, 1.0
+    S[..., 4] = np.exp(-((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2) / 0.02)
+    return S
+
+
+def _composite(a, comp):
+    S0, S1, c1 = a.state(0), a.state(1), a.cov(1)
+    return (S0[..., comp] * ~c1[::2, ::2, ::2]).sum() * np.prod(a.dx(0)) + (S1[..., comp] * c1).sum() * np.prod(a.dx(1))
+
+
+def test_uniform_flow_is_preserved_and_tracer_is_conserved_across_the_interface():
+    """A uniform velocity field with constant density is an exact solution of every piece of the algorithm: predictor, both MAC
+    solves (coarse/fine Dirichlet data), create_umac_grown, level projections, reflux, MAC sync and sync projection must leave it
+    alone to round-off, while the tracer blob is advected through the coarse/fine interface without losing mass."""
+    a = _amr(8, [([4, 4, 4], [11, 11, 11])], _uniform, cfl=0.7, init_iter=2)
+    a.post_init()
+    m0 = _composite(a, 4)
+    for _ in range(3):
+        a.step()
+    for l in range(2):
+        S, c = a.state(l), a.cov(l)
+        assert abs(S[..., 0] - 1.0)[c].max() < 1e-13 and abs(S[..., 1] - 0.5)[c].max() < 1e-13 and abs(S[..., 2] - 0.25)[c].max() < 1e-13
+        assert abs(S[..., 3] - 1.0)[c].max() < 1e-13
+        assert abs(a.fab(l, 2).a).max() < 1e-12          # no pressure develops
+    assert abs(_composite(a, 4) - m0) < 1e-14
+    assert abs(_composite(a, 3) - 1.0) < 1e-14
+
+
+def test_composite_projection_is_second_order_consistent():
+    """The cell-centred Taylor-Green field is discretely divergence free on each level separately; the composite divergence at the
+    coarse/fine nodes is not (different quadrature of the two sides), so the initial composite projection changes the field -- by
+    O(h^2) if the composite operator and right-hand side are consistent."""
+    ch = []
+    for n0 in (8, 16):
+        lo, hi = n0 // 4, n0 // 4 + n0 - 1
+        a = _amr(n0, [([lo] * 3, [hi] * 3)], lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=0.0), init_iter=0)
+        a.post_init()
+        e = 0.0
+        for l in range(2):
+            ex = orc.taylorgreen_state(*a.cell_centres(l), c=0.0)
+            e = max(e, abs(a.state(l)[..., :3] - ex[..., :3])[a.cov(l)].max())
+        ch.append(e)
+    assert ch[0] < 0.05 and ch[1] < ch[0] / 3.0
+
+
+def test_two_level_taylor_vortex_conserves_and_converges_to_tolerance():
+    """two coarse steps of the exact Taylor vortex (prob.c = 0) on 16^3 + a refined patch: mass and tracer conserved to round-off,
+    momentum to the tolerance of the sync solves, the sync solves converge, the error stays at the level of the single-level scheme"""
+    a = _amr(16, [([4, 4, 4], [19, 19, 19])], lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=0.0), cfl=0.7, init_iter=2)
+    a.post_init()
+    m0 = [_composite(a, c) for c in range(5)]
+    for _ in range(2):
+        a.step()
+        st = a.sync_stats()
+        assert st.converged == 1 and st.resnorm <= 1e-10 * max(st.rhsnorm0, st.resnorm0) * 1.0001
+    m1 = [_composite(a, c) for c in range(5)]
+    assert abs(m1[3] - m0[3]) < 1e-13 and abs(m1[4] - m0[4]) < 1e-13
+    for c in range(3):
+        assert abs(m1[c] - m0[c]) < 1e-9
+    for l in range(2):
+        ex = orc.taylorgreen_state(*a.cell_centres(l), c=0.0)
+        assert abs(a.state(l)[..., :3] - ex[..., :3])[a.cov(l)].max() < 0.03
+
+
+def test_hydrostatic_initial_pressure():
+    """NavierStokesBase::post_init_state (NavierStokesBase.cpp:2416-2426): with gravity the initial pressure projection makes
+    grad p = rho g; a stably stratified fluid at rest then stays at rest (known answer, independent of the product)."""
+    n = 16
+    g = orc.geom([n] * 3, periodic=(1, 1, 0))
+    p = orc.ns_params(cfl=0.5, gravity=-9.8, init_iter=2, phys_lo=[0, 0, 4], phys_hi=[0, 0, 4], init_dt=0.01)
+    L = orc.lib()
+    ns = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(orc.mg_opts())))
+    S = orc.from_cfab(L.orc_ns_fab(ns, 0))
+    z = (np.arange(n) + 0.5) / n
+    S.valid([n] * 3)[...] = 0.0
+    S.valid([n] * 3)[..., 3] = (2.0 - z)[None, None, :]
+    L.orc_ns_post_init(ns, C.c_double(-1.0))
+    Gp = orc.from_cfab(L.orc_ns_fab(ns, 4)).valid([n] * 3)
+    rho = orc.from_cfab(L.orc_ns_fab(ns, 0)).valid([n] * 3)[..., 3]
+    assert abs(Gp[..., 2] - rho * (-9.8)).max() < 1e-11 and abs(Gp[..., :2]).max() < 1e-11
+    for _ in range(2):
+        L.orc_ns_step(ns)
+    assert abs(orc.from_cfab(L.orc_ns_fab(ns, 0)).valid([n] * 3)[..., :3]).max() < 1e-10
+    L.orc_ns_destroy(ns)
+
+
+def test_stop_time_is_hit_exactly():
+    """computeNewDt (NavierStokesBase.cpp:1008-1015): the last step is shortened to land on stop_time"""
+    n = 8
+    g = orc.geom([n] * 3)
+    L = orc.lib()
+    ns = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(orc.ns_params(cfl=0.7, init_iter=1)), C.byref(orc.mg_opts())))
+    L.orc_ns_init_taylorgreen(ns, C.c_double(1.0), C.c_double(1.0), C.c_double(1.0), C.c_double(0.0), C.c_double(1.0))
+    stop = 0.21
+    L.orc_ns_post_init(ns, C.c_double(stop))
+    for _ in range(50):
+        if L.orc_ns_time(ns) >= stop - 1e-14:
+            break
+        L.orc_ns_step(ns)
+    assert L.orc_ns_time(ns) == stop
+    L.orc_ns_destroy(ns)
