@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+PMC_FILE = "round2_pmc.json"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,8 +35,10 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("IAMRX_BENCH_N", "256")), help="cells per direction of the per-GPU box")
     ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-n", type=int, default=96)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--amr-n", type=int, default=128, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
+    ap.add_argument("--amr-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the oracle's smoother loops (the rest of the port is scalar); 0 = the CPUs this process may really use")
     return ap.parse_args()
@@ -145,7 +150,58 @@ def cpu_baseline(n, steps, threads=1):
     L.orc_ns_destroy(s)
     return {"value": n ** 3 * steps / dt, "unit": "cells-advanced/s", "cores": threads, "kind": "port",
             "sample": f"TaylorGreen {n}^3 (same physics/settings), {steps} timed step(s) after post_init, oracle/liborc.so C port "
-                      f"(scalar; multigrid smoother loops OpenMP-threaded over {threads} thread(s))"}
+                      f"(OpenMP over planes in the Godunov, tensor and multigrid smoother / operator loops, {threads} thread(s)); "
+                      f"NOT the IAMR CPU build (its sources need AMReX / AMReX-Hydro, absent here)"}
+
+
+def proc_grid(world):
+    """px >= py >= pz with px*py*pz = world, as cubic as possible (2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2)"""
+    best = (world, 1, 1)
+    for pz in range(1, world + 1):
+        if world % pz:
+            continue
+        for py in range(pz, world // pz + 1):
+            if (world // pz) % py:
+                continue
+            px = world // (pz * py)
+            if px >= py and px - pz < best[0] - best[2]:
+                best = (px, py, pz)
+    return best
+
+
+def file_blob_sha(path):
+    """git blob hash of a file (what `git hash-object` prints)"""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def amr_workload(lib, n0, steps):
+    """secondary workload (north_star: 2-level AMR TaylorGreen): base level n0^3 in one box, one ratio-2 refined box over the central
+    (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; Euler (nu = 0: the viscous coarse/fine sync is not implemented yet).
+    cells advanced per coarse step = n0^3 + 2 * n0^3."""
+    from iamr_amd import ns as N
+    from iamr_amd.amr import Amr
+    g0 = lib.Geom.make((n0,) * 3)
+    lo, hi = n0 // 2, n0 // 2 + n0 - 1
+    lays = [lib.Layout.single((n0,) * 3), lib.Layout([((lo,) * 3, (hi,) * 3)])]
+    amr = Amr(g0, lays, N.ns_params(cfl=0.7, visc_coef=0.0, init_iter=2), lib.mg_opts())
+    for l in range(2):
+        amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    amr.post_init()
+    amr.coarse_step()
+    lib.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        amr.coarse_step()
+    lib.sync()
+    el = time.perf_counter() - t0
+    st, stm = amr.sync_stats()
+    cells = float(n0) ** 3 * 3.0
+    return {"workload": f"TaylorGreen 3D, 2 levels: {n0}^3 base + one {n0}^3 refined box (ratio 2, subcycled), Euler, periodic; "
+                        f"advance + reflux + avgDown + mac_sync + MLsyncProject per coarse step",
+            "cells_advanced_per_sec": cells * steps / el, "ms_per_coarse_step": el / steps * 1e3, "coarse_steps": steps,
+            "sync_project_iters": st.iters, "mac_sync_iters": stm.iters}
 
 
 def transport_selftest(lib, rank, world):
@@ -195,24 +251,22 @@ def main():
     elif world > 1:
         from iamr_amd import comm
         transport = "rccl"
-        ok = torch.ones(1, device="cuda")
-        try:
-            comm.init_rccl_from_torch(dist)
-            transport_selftest(lib, rank, world)
-        except Exception as e:      # keep the run alive on a host-staged transport rather than produce no number
-            print(f"[bench] rank {rank}: RCCL transport failed to initialise ({e}); falling back to gloo host staging", file=sys.stderr)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            transport = "gloo-host-staged (fallback)"
-            comm.init_gloo_callback(dist, dist.new_group(backend="gloo"))
+        # N real GPUs: the RCCL transport (grouped ncclSend/ncclRecv + ncclAllReduce over xGMI) must come up, a scaling number measured
+        # over host-staged gloo would mean nothing -- fail loudly instead (IAMRX_BENCH_TRANSPORT=gloo is the explicit test-only override)
+        comm.init_rccl_from_torch(dist)
+        transport_selftest(lib, rank, world)
 
     n = a.n
-    # one n^3 box per GPU, stacked in z: level = world boxes (weak scaling)
-    ntot = (n, n, n * world)
-    boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(world)]
+    # one n^3 box per GPU (weak scaling) arranged as compactly as possible: 2x1x1, 2x2x1, 2x2x2 (= config C4's 512^3 at n = 256, every
+    # box then has a face neighbour on every xGMI link it can use) -- SURVEY 8(e)
+    pgrid = proc_grid(world)
+    ntot = tuple(n * pgrid[d] for d in range(3))
+    boxes = []
+    for r in range(world):
+        ix, iy, iz = r % pgrid[0], (r // pgrid[0]) % pgrid[1], r // (pgrid[0] * pgrid[1])
+        boxes.append(((ix * n, iy * n, iz * n), ((ix + 1) * n - 1, (iy + 1) * n - 1, (iz + 1) * n - 1)))
     lay = lib.Layout(boxes, list(range(world)))
-    g = lib.Geom.make(ntot, prob_hi=(1.0, 1.0, float(world)))
+    g = lib.Geom.make(ntot, prob_hi=tuple(float(pgrid[d]) for d in range(3)))
     params = N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0)
     ns = N.NavierStokes(g, lay, params, lib.mg_opts())
     ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
@@ -240,8 +294,14 @@ def main():
         lib.check(lib.lib().iamrx_alloc_count(C.byref(v)))
         return v.value
 
+    def nsync():
+        v = C.c_size_t()
+        lib.check(lib.lib().iamrx_sync_count(C.byref(v)))
+        return v.value
+
     barrier()
     m0 = nmalloc()
+    s0 = nsync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ns.step()
@@ -256,6 +316,7 @@ def main():
         if pr[7] > 0:
             gs4_insitu = (pr[6] / pr[7], int(pr[7]))      # mean duration (ms), number of launches in the timed region
     mallocs_in_loop = nmalloc() - m0
+    syncs_in_loop = nsync() - s0
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -281,8 +342,10 @@ def main():
             # separate rocprofv3 runs, corrected as calibrated in profiles/round1_pmc.json); only valid for the size it was collected at
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_k_pmc.json")))     # PMC passes over bench.py itself
-                if n == 256:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))     # PMC passes over bench.py itself
+                # the counters describe ONE build of the kernel: the file records the git blob hash of k_nodal.hip it was collected
+                # with; any other source => traffic is unknown (null), never a stale figure
+                if n == 256 and pmc.get("k_nodal_hip_blob") == file_blob_sha(os.path.join(ROOT, "iamr_amd", "csrc", "k_nodal.hip")):
                     traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()
                                if "k_nodal_gs4<32, 16, 256, true, false, false> grid=5324800" in k][0]
             except Exception:
@@ -302,17 +365,20 @@ def main():
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"TaylorGreen 3D single level, one {n}^3 box per GPU ({ntot[0]}x{ntot[1]}x{ntot[2]} cells), periodic, "
+            "config": {"workload": f"TaylorGreen 3D single level, one {n}^3 box per GPU in a {pgrid[0]}x{pgrid[1]}x{pgrid[2]} arrangement ({ntot[0]}x{ntot[1]}x{ntot[2]} cells), periodic, "
                                    f"nu=1e-4 cfl=0.7 Godunov_PLM be_cn_theta=0.5, full NavierStokes::advance per step",
                        "cells": cells_total, "prob_c": a.c},
             "mlmg_vcycle_ms": {"mac_cc": st.median(mac_ms), "nodal": st.median(nod_ms), "tensor_visc": st.median(visc_ms)},
             "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
             "sections_ms_per_step": {k: v / 2 for k, v in zip(["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"], sec[:6])},
             "device_mallocs_in_timed_region": mallocs_in_loop,
+            "host_syncs_per_step": syncs_in_loop / a.steps,
             "transport": transport if world > 1 else "none (single GPU)",
             "kernels": kr,
             "roofline": roofline,
         }
+        if world == 1 and a.amr_n > 0:
+            out["amr"] = amr_workload(lib, a.amr_n, a.amr_steps)
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))

@@ -68,6 +68,7 @@ int iamrx_init(int device) { IAMRX_TRY Context::get().init(device); IAMRX_CATCH 
 int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH }
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
+int iamrx_sync_count(size_t* n_stream_sync) { IAMRX_TRY *n_stream_sync = Context::get().n_stream_sync; IAMRX_CATCH }
 int iamrx_alloc_count(size_t* n_device_malloc)
 {
     IAMRX_TRY
@@ -711,6 +712,71 @@ int iamrx_average_down(iamrx_mf fine, iamrx_mf crse, int scomp, int ncomp, int r
     IAMRX_TRY average_down(fine->mf, crse->mf, scomp, ncomp, ratio); IAMRX_CATCH
 }
 
+// ---- zero-copy alias, level projection entry, sync-operator entries
+int iamrx_mf_alias(iamrx_layout l, const int type[3], int ncomp, int ngrow, double* const* dev_ptrs, iamrx_mf* out)
+{
+    IAMRX_TRY
+    auto* h = new iamrx_mf_s;
+    IndexType t{{type[0], type[1], type[2]}};
+    h->mf.alias(l->p, t, ncomp, ngrow, dev_ptrs);
+    *out = h;
+    IAMRX_CATCH
+}
+
+int iamrx_level_project(const iamrx_geom* g, double dt, iamrx_mf U_new, int vcomp, iamrx_mf P_new, iamrx_mf Gp_old, iamrx_mf Gp_new,
+                        iamrx_mf rho_half, const int lobc[3], const int hibc[3], double proj_tol, double proj_abs_tol,
+                        const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    DomainBC bc;
+    for (int d = 0; d < 3; ++d) { bc.lo[d] = lobc[d]; bc.hi[d] = hibc[d]; }
+    bc.maxorder = 2;
+    MGStats s = level_project_single(to_geom(g), dt, U_new->mf, vcomp, P_new->mf, Gp_old->mf, Gp_new->mf, rho_half->mf, bc, proj_tol, proj_abs_tol, to_opts(o));
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
+struct iamrx_syncreg_s { std::unique_ptr<SyncRegister> sr; };
+int iamrx_syncreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio,
+                         const int phys_lo[3], const int phys_hi[3], iamrx_syncreg* out)
+{
+    IAMRX_TRY
+    auto* h = new iamrx_syncreg_s;
+    h->sr = std::make_unique<SyncRegister>(fine->p, crse->p, to_geom(cgeom), to_geom(fgeom), ratio, phys_lo, phys_hi);
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_syncreg_destroy(iamrx_syncreg r) { IAMRX_TRY delete r; IAMRX_CATCH }
+int iamrx_syncreg_crse_init(iamrx_syncreg r, iamrx_mf sync_resid_crse, double mult) { IAMRX_TRY r->sr->CrseInit(sync_resid_crse->mf, mult); IAMRX_CATCH }
+int iamrx_syncreg_fine_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, double mult) { IAMRX_TRY r->sr->FineAdd(sync_resid_fine->mf, mult); IAMRX_CATCH }
+int iamrx_syncreg_init_rhs(iamrx_syncreg r, iamrx_mf rhs) { IAMRX_TRY r->sr->InitRHS(rhs->mf); IAMRX_CATCH }
+
+int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scomp, int ncomp, const iamrx_geom* cgeom, const iamrx_geom* fgeom,
+                      int ratio, const int* bcrec)
+{
+    IAMRX_TRY
+    std::vector<BCRec> bc(ncomp);
+    for (int n = 0; n < ncomp; ++n) for (int d = 0; d < 3; ++d) { bc[n].lo[d] = bcrec ? bcrec[6 * n + d] : 0; bc[n].hi[d] = bcrec ? bcrec[6 * n + 3 + d] : 0; }
+    sync_interp_cellcons(fine_dst->mf, dcomp, crse_sync->mf, scomp, ncomp, to_geom(cgeom), to_geom(fgeom), ratio, bc.data());
+    IAMRX_CATCH
+}
+
+int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
+                                    iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z,
+                                    const int* iconserv, double dt, const int* bcrec, int is_velocity, int use_forces_in_trans,
+                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z)
+{
+    IAMRX_TRY
+    std::vector<BCRec> bc(ncomp);
+    for (int n = 0; n < ncomp; ++n) for (int d = 0; d < 3; ++d) { bc[n].lo[d] = bcrec ? bcrec[6 * n + d] : 0; bc[n].hi[d] = bcrec ? bcrec[6 * n + 3 + d] : 0; }
+    MultiFab* um[3] = {&umac_x->mf, &umac_y->mf, &umac_z->mf};
+    MultiFab* uc[3] = {&ucorr_x->mf, &ucorr_y->mf, &ucorr_z->mf};
+    MultiFab* fl[3] = {flux_x ? &flux_x->mf : nullptr, flux_y ? &flux_y->mf : nullptr, flux_z ? &flux_z->mf : nullptr};
+    godunov_compute_aofs_sync(to_geom(g), sync->mf, acomp, S->mf, ncomp, force ? &force->mf : nullptr, divu ? &divu->mf : nullptr, um, uc,
+                              iconserv, dt, bc.data(), is_velocity != 0, use_forces_in_trans != 0, flux_x ? fl : nullptr);
+    IAMRX_CATCH
+}
+
 // ---- AMR hierarchy (amrns.hip)
 struct iamrx_amr_s {
     std::unique_ptr<AmrNS> amr;
@@ -744,6 +810,10 @@ int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels)
     if (dt_levels) for (int l = 0; l < a->amr->nlevels(); ++l) dt_levels[l] = a->amr->dt(l);
     IAMRX_CATCH
 }
+int iamrx_amr_reflux(iamrx_amr a, int lev) { IAMRX_TRY a->amr->reflux(lev); IAMRX_CATCH }
+int iamrx_amr_avg_down(iamrx_amr a, int lev) { IAMRX_TRY a->amr->avg_down(lev); IAMRX_CATCH }
+int iamrx_amr_mac_sync(iamrx_amr a, int lev) { IAMRX_TRY a->amr->mac_sync(lev); IAMRX_CATCH }
+int iamrx_amr_level_sync(iamrx_amr a, int lev) { IAMRX_TRY a->amr->level_sync(lev); IAMRX_CATCH }
 int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync, iamrx_mg_stats* mac_sync)
 {
     IAMRX_TRY

@@ -45,6 +45,7 @@ struct Context {
     std::map<void*, size_t> live_blocks;
     size_t bytes_live = 0, bytes_cached = 0;
     size_t n_device_malloc = 0;    // hipMalloc calls (cache misses): must stay flat inside the time loop
+    size_t n_stream_sync = 0;      // host waits on the stream (Context::sync): reductions read back, plan uploads
     double* d_scratch = nullptr;   // reduction scratch
     double* h_scratch = nullptr;   // pinned
     size_t scratch_n = 0;
@@ -149,6 +150,10 @@ public:
     MultiFab& operator=(MultiFab&& o) noexcept;
 
     void define(LayoutP l, IndexType t, int nc, int ng);
+    // zero-copy view of caller-owned device FABs (one pointer per LOCAL box, each fab contiguous in the Array4 layout incl. ghost
+    // cells): the library never frees or moves them (amrex::MultiFab alias over The_Arena memory)
+    void alias(LayoutP l, IndexType t, int nc, int ng, double* const* fab_ptrs);
+    bool is_alias = false;
     void clear();
     bool defined() const { return base != nullptr || (layout && layout->nlocal() == 0); }
     int nlocal() const { return layout->nlocal(); }

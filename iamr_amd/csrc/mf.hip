@@ -2,6 +2,7 @@
 // Plays the role of AMReX MultiFab / FillBoundary at IAMR's call sites (SURVEY 2.3 "Same-level ghost
 // exchange": reference Source/MacProj.cpp:1127, Source/Projection.cpp:338-339, ...).
 #include "mf.h"
+#include <tuple>
 #include "launch.h"
 #include "kernels.h"
 #include <algorithm>
@@ -85,7 +86,7 @@ void Context::release_cache()
     bytes_cached = 0;
 }
 
-void Context::sync() { if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
+void Context::sync() { ++n_stream_sync; if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
 
 // small host->device uploads (descriptor tables, parameter blocks) without synchronising the stream: the source
 // is copied into a pinned ring buffer first, so the caller's memory may die immediately.  A slot is only reused
@@ -132,7 +133,8 @@ Layout::Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myra
     }
 }
 
-Layout::~Layout() { if (d_boxes) Context::get().free(d_boxes); }
+void evict_layout_tables(uint64_t lid);
+Layout::~Layout() { evict_layout_tables(id); if (d_boxes) Context::get().free(d_boxes); }
 
 long Layout::local_cells() const { long n = 0; for (int g : local) n += boxes[g].npts(); return n; }
 long Layout::total_cells() const { long n = 0; for (auto& b : boxes) n += b.npts(); return n; }
@@ -180,18 +182,63 @@ MultiFab& MultiFab::operator=(MultiFab&& o) noexcept
     if (this != &o) {
         release();
         layout = std::move(o.layout); type = o.type; ncomp = o.ncomp; ngrow = o.ngrow;
-        base = o.base; total_doubles = o.total_doubles; h_tab = std::move(o.h_tab); d_tab = o.d_tab;
-        o.base = nullptr; o.d_tab = nullptr; o.total_doubles = 0;
+        base = o.base; total_doubles = o.total_doubles; h_tab = std::move(o.h_tab); d_tab = o.d_tab; is_alias = o.is_alias;
+        o.base = nullptr; o.d_tab = nullptr; o.total_doubles = 0; o.is_alias = false;
     }
     return *this;
+}
+
+// Device descriptor tables are a pure function of (layout, index type, ncomp, ngrow, base address).  The caching allocator hands the
+// same blocks back step after step, so the tables are kept in a cache owned by the context instead of being re-uploaded for every
+// temporary MultiFab (round 1: ~10 k small host-to-device copies per profiled run).  Entries die with their layout.
+namespace {
+struct TabKey {
+    uint64_t lid; int t0, t1, t2, nc, ng; const double* base;
+    bool operator<(const TabKey& o) const
+    { return std::tie(lid, t0, t1, t2, nc, ng, base) < std::tie(o.lid, o.t0, o.t1, o.t2, o.nc, o.ng, o.base); }
+};
+std::map<TabKey, FabD*>& tab_cache() { static std::map<TabKey, FabD*> c; return c; }
+}  // namespace
+
+void evict_layout_tables(uint64_t lid)
+{
+    auto& c = tab_cache();
+    for (auto it = c.lower_bound(TabKey{lid, 0, 0, 0, 0, 0, nullptr}); it != c.end() && it->first.lid == lid;) {
+        Context::get().free(it->second);
+        it = c.erase(it);
+    }
 }
 
 void MultiFab::release()
 {
     auto& ctx = Context::get();
-    if (base) ctx.free(base);
-    if (d_tab) ctx.free(d_tab);
-    base = nullptr; d_tab = nullptr; total_doubles = 0; h_tab.clear();
+    if (is_alias) { if (d_tab) ctx.free(d_tab); }         // the data belong to the caller, the table to this object
+    else if (base) ctx.free(base);
+    base = nullptr; d_tab = nullptr; total_doubles = 0; h_tab.clear(); is_alias = false;      // d_tab of an owning MultiFab belongs to the table cache
+}
+
+void MultiFab::alias(LayoutP l, IndexType t, int nc, int ng, double* const* fab_ptrs)
+{
+    release();
+    layout = std::move(l); type = t; ncomp = nc; ngrow = ng;
+    auto& ctx = Context::get();
+    const int nl = layout->nlocal();
+    h_tab.resize(nl);
+    for (int li = 0; li < nl; ++li) {
+        BoxD fb = fabbox(li);
+        FabD& f = h_tab[li];
+        for (int d = 0; d < 3; ++d) { f.lo[d] = fb.lo[d]; f.n[d] = fb.len(d); }
+        f.cs = (long)f.n[0] * f.n[1] * f.n[2];
+        f.p = fab_ptrs[li];
+        if (!f.p) throw Error("iamrx MultiFab::alias: null fab pointer");
+        total_doubles += (size_t)f.cs * nc;
+    }
+    if (nl == 0) return;
+    is_alias = true;
+    base = h_tab[0].p;
+    FabD* d = (FabD*)ctx.alloc(nl * sizeof(FabD));
+    ctx.upload_async(d, h_tab.data(), nl * sizeof(FabD));
+    d_tab = d;
 }
 
 void MultiFab::clear() { release(); layout.reset(); }
@@ -218,13 +265,21 @@ void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)
     if (nl == 0) return;
     base = (double*)ctx.alloc(total_doubles * sizeof(double));
     for (int li = 0; li < nl; ++li) h_tab[li].p = base + offs[li];
-    d_tab = (FabD*)ctx.alloc(nl * sizeof(FabD));
-    ctx.upload_async(d_tab, h_tab.data(), nl * sizeof(FabD));   // staged through the pinned ring: no stream sync
+    const TabKey key{layout->id, type.t[0], type.t[1], type.t[2], nc, ng, base};
+    auto& cache = tab_cache();
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        FabD* d = (FabD*)ctx.alloc(nl * sizeof(FabD));
+        ctx.upload_async(d, h_tab.data(), nl * sizeof(FabD));   // staged through the pinned ring: no stream sync
+        it = cache.emplace(key, d).first;
+    }
+    d_tab = it->second;
 }
 
 void MultiFab::setVal(double v)
 {
     if (!base) return;
+    if (is_alias) { setVal(v, 0, ncomp, ngrow); return; }      // the fabs of an alias are not one allocation
     launch_fill(base, total_doubles, v, Context::get().stream);
 }
 

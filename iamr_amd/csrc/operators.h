@@ -20,6 +20,12 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
 MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& phi, const MultiFab& sig, int sig_comp,
                          const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp);
 
+// Projection::level_project on one level that covers the domain (Source/Projection.cpp:166-450; declaration Projection.H:53-75):
+// P_new = 0; U_new /= dt; U_new += Gp_old/rho_half; sigma = 1/rho_half; nodal projection (Gp_new = grad phi, P_new = phi); U_new *= dt.
+// U_new: state with the velocity at comps vcomp..vcomp+2, 1 ghost; rho_half: 1 ghost.
+MGStats level_project_single(const Geometry& g, double dt, MultiFab& U_new, int vcomp, MultiFab& P_new, const MultiFab& Gp_old, MultiFab& Gp_new,
+                             const MultiFab& rho_half, const DomainBC& bc, double proj_tol, double proj_abs_tol, const MGOpts& opts);
+
 // ---- Diffusion (reference Source/Diffusion.H:53-225) -------------------------------------------------
 // explicit viscous terms div tau(U): Diffusion::getTensorViscTerms (Source/Diffusion.cpp:1655-1777): out = -b * L_tensor(U), a = 0
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel /*3 comps, 1 ghost; BC data in ghosts*/, double a_scalar, double b_scalar,

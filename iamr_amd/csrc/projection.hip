@@ -30,6 +30,27 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
     return st;
 }
 
+MGStats level_project_single(const Geometry& g, double dt, MultiFab& U_new, int vcomp, MultiFab& P_new, const MultiFab& Gp_old, MultiFab& Gp_new,
+                             const MultiFab& rho_half, const DomainBC& bc, double proj_tol, double proj_abs_tol, const MGOpts& opts)
+{
+    LayoutP layout = P_new.layout;
+    IAMRX_ASSERT(layout->total_cells() == g.domain.npts());
+    P_new.setVal(0.0, 0, 1, 0);                                  // Projection.cpp:236-256
+    mf_mult(U_new, 1.0 / dt, vcomp, 3, 1);                       // :273
+    MultiFab sig(layout, cell_type(), 1, 1);
+    {
+        const FabD *nt = U_new.d_tab, *gt = Gp_old.d_tab, *ht = rho_half.d_tab, *st = sig.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rh = ht[f](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) nt[f](i, j, k, vcomp + n) += gt[f](i, j, k, n) / rh;       // :296-300
+            st[f](i, j, k, 0) = 1.0 / rh;                                                            // scaleVar
+        });
+    }
+    MGStats st = nodal_projection(g, U_new, vcomp, P_new, sig, 0, bc, proj_tol, proj_abs_tol, opts, &Gp_new, false);
+    mf_mult(U_new, dt, vcomp, 3, 1);                             // :438
+    return st;
+}
+
 static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], LayoutP layout, double a_scalar, double b_scalar,
                          const MultiFab* acoef, const MultiFab* const eta[3])
 {

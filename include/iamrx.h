@@ -27,6 +27,7 @@ typedef struct iamrx_layout_s* iamrx_layout;   /* BoxArray + DistributionMapping
 typedef struct iamrx_fluxreg_s* iamrx_fluxreg; /* amrex::FluxRegister of one coarse/fine interface (see below) */
 typedef struct iamrx_mf_s* iamrx_mf;           /* MultiFab (device resident) */
 typedef struct iamrx_ns_s* iamrx_ns;           /* NavierStokes level object */
+typedef struct iamrx_syncreg_s* iamrx_syncreg; /* SyncRegister of one coarse/fine interface */
 typedef struct iamrx_amr_s* iamrx_amr;         /* hierarchy of NavierStokes levels (the Amr / AmrLevel role for the hot path) */
 
 typedef struct iamrx_geom {
@@ -67,6 +68,7 @@ int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
 void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
 int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
 int iamrx_alloc_count(size_t* n_device_malloc);  /* hipMalloc calls so far (caching-allocator misses; The_Arena role) */
+int iamrx_sync_count(size_t* n_stream_sync);     /* host waits on the library stream so far (scalar read-backs of norms / dot products, plan uploads) */
 /* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
  * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */
 int iamrx_timer_start(void);
@@ -308,6 +310,43 @@ int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamr
  * next call, which returns their total duration (ms) in sections_ms[6] and their number in sections_ms[7] */
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8]);
 
+/* ---- zero-copy view of caller-owned device memory ----------------------------------------------------------------------
+ * AMReX keeps its FABs in device memory on GPU builds (The_Arena); with the same Array4 layout on both sides a MultiFab needs no
+ * copy at the seam: dev_ptrs[li] = FArrayBox::dataPtr() of the li-th LOCAL box (allocated region = valid box converted to `type`
+ * and grown by ngrow).  The library never frees, moves or reallocates the memory; destroy the handle with iamrx_mf_destroy. */
+int iamrx_mf_alias(iamrx_layout l, const int type[3], int ncomp, int ngrow, double* const* dev_ptrs, iamrx_mf* out);
+
+/* Projection::level_project on a level that covers the domain (Source/Projection.cpp:166-450; declaration Source/Projection.H:53-75), the
+ * call NavierStokesBase::level_projector makes (Source/NavierStokesBase.cpp:1894-1924): P_new = 0; U_new /= dt; U_new += Gp_old/rho_half;
+ * sigma = 1/rho_half; doMLMGNodalProjection (Gp_new = grad phi, P_new = phi); U_new *= dt.  In place, like the reference.
+ * U_new: velocity at comps vcomp..vcomp+2, 1 ghost cell (inflow data in the ghost cells of inflow faces, in U/dt units);
+ * lobc/hibc: LinOpBC codes of Projection.cpp:2432-2464 (102 Neumann, 101 outflow, 103 inflow). */
+int iamrx_level_project(const iamrx_geom* g, double dt, iamrx_mf U_new, int vcomp, iamrx_mf P_new, iamrx_mf Gp_old, iamrx_mf Gp_new,
+                        iamrx_mf rho_half, const int lobc[3], const int hibc[3], double proj_tol, double proj_abs_tol,
+                        const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
+/* SyncRegister (Source/SyncRegister.H:40-49, Source/SyncRegister.cpp): nodal register on the faces of the coarsened fine boxes.
+ * crse_init: SyncRegister::CrseInit(Sync_resid_crse, crse_geom, mult) (:306-318); fine_add: FineAdd(Sync_resid_fine, crse_geom, mult)
+ * (:350-607; the fine residual needs no ghost nodes here); init_rhs: InitRHS(rhs, geom, phys_bc) (:47-304; rhs: nodal, coarse layout).
+ * phys_lo/hi: PhysBCType codes of ns.lo_bc / ns.hi_bc (outflow faces are zeroed in InitRHS). */
+int iamrx_syncreg_create(iamrx_layout fine, iamrx_layout crse, const iamrx_geom* cgeom, const iamrx_geom* fgeom, int ratio,
+                         const int phys_lo[3], const int phys_hi[3], iamrx_syncreg* out);
+int iamrx_syncreg_destroy(iamrx_syncreg r);
+int iamrx_syncreg_crse_init(iamrx_syncreg r, iamrx_mf sync_resid_crse, double mult);
+int iamrx_syncreg_fine_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, double mult);
+int iamrx_syncreg_init_rhs(iamrx_syncreg r, iamrx_mf rhs);
+/* NavierStokesBase::SyncInterp with cell_cons_interp (Source/NavierStokesBase.cpp:3071-3276): fine_dst(dcomp..) = conservative-linear
+ * interpolant of crse_sync(scomp..) on every cell of the fine level; the caller applies `increment` / dt_clev (:3215-3262) */
+int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scomp, int ncomp, const iamrx_geom* cgeom, const iamrx_geom* fgeom,
+                      int ratio, const int* bcrec /* [ncomp][6] */);
+/* NavierStokesBase::ComputeAofs with is_sync = true as MacProj::mac_sync_compute calls it (Source/MacProj.cpp:700-731,
+ * Source/NavierStokesBase.cpp:4681-4683, 4777, 4826-4832): edge states traced with u_mac, fluxes = edge * Ucorr * area,
+ * sync(acomp..) -= -div(F)/vol; flux_* (optional) receive the fluxes for the flux registers */
+int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
+                                    iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z,
+                                    const int* iconserv, double dt, const int* bcrec, int is_velocity, int use_forces_in_trans,
+                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
+
 /* ---- multi-level time step ------------------------------------------------------------------------------------
  * One coarse time step of a hierarchy of levels with subcycling = amrex::Amr::coarseTimeStep -> timeStep(level): advance(level),
  * ncycle x timeStep(level+1), NavierStokesBase::post_timestep(level) (Source/NavierStokesBase.cpp:2546-2636):
@@ -325,6 +364,13 @@ int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out);
 int iamrx_amr_post_init(iamrx_amr a, double stop_time);      /* S_new of every level must hold the initial data (iamrx_ns_set_data) */
 int iamrx_amr_coarse_step(iamrx_amr a, double* dt0);         /* dt0: the level-0 time step used */
 int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels /* [nlev] or NULL */);
+/* the pieces of NavierStokesBase::post_timestep(lev) one by one (lev < finest), for a caller that drives the loop itself:
+ * NavierStokes::reflux, avgDown, mac_sync (= MacProj::mac_sync_solve + mac_sync_compute + the state update and SyncInterp),
+ * NavierStokesBase::level_sync (= SyncInterp + Projection::MLsyncProject) */
+int iamrx_amr_reflux(iamrx_amr a, int lev);
+int iamrx_amr_avg_down(iamrx_amr a, int lev);
+int iamrx_amr_mac_sync(iamrx_amr a, int lev);
+int iamrx_amr_level_sync(iamrx_amr a, int lev);
 int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync_project, iamrx_mg_stats* mac_sync);
 
 #ifdef __cplusplus

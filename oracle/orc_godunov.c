@@ -150,7 +150,11 @@ static orc_fab alloc_faces(const orc_geom* g, int d, int gt, int nc)
     return f;
 }
 
-#define LOOP3(f, c) for (c[2] = (f)->lo[2]; c[2] <= (f)->hi[2]; ++c[2]) for (c[1] = (f)->lo[1]; c[1] <= (f)->hi[1]; ++c[1]) for (c[0] = (f)->lo[0]; c[0] <= (f)->hi[0]; ++c[0])
+/* every iteration declares its own index triple (the enclosing declaration of the same name is shadowed), so the planes can be
+ * shared out to OpenMP threads (orc_threads, default 1; used by bench.py's cpu_baseline) without changing any result */
+#define LOOP3(f, c) _Pragma("omp parallel for schedule(static) num_threads(orc_threads)") \
+    for (int c##_k = (f)->lo[2]; c##_k <= (f)->hi[2]; ++c##_k) for (int c##_j = (f)->lo[1]; c##_j <= (f)->hi[1]; ++c##_j) \
+    for (int c##_i = (f)->lo[0]; c##_i <= (f)->hi[0]; ++c##_i) for (int c[3] = {c##_i, c##_j, c##_k}, c##_once = 1; c##_once; c##_once = 0)
 
 /* PLM trace: Im[d](c) = state at the low face of cell c, Ip[d](c) = state at the high face of cell c.
  * trace velocity: cell-centred vcc(c, d) (predict) or face-centred umac (advect, both sides use the
@@ -420,6 +424,7 @@ void orc_compute_aofs(const orc_geom* g, orc_fab* aofs, int acomp, const orc_fab
     int any_convective = 0;
     for (int n = 0; n < ncomp; ++n) if (!iconserv[n]) any_convective = 1;
     for (int n = 0; n < ncomp; ++n)
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         /* ComputeDivergence with mult = -1 */
         double upd = -1.0 * qvol * ((A4(&flux[0], i + 1, j, k, n) - A4(&flux[0], i, j, k, n))

@@ -80,6 +80,7 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
     orc_fab fx = orc_alloc(g->n, ORC_FACE[0], 0, 3), fy = orc_alloc(g->n, ORC_FACE[1], 0, 3), fz = orc_alloc(g->n, ORC_FACE[2], 0, 3);
     const orc_fab *etax = &L->b[0], *etay = &L->b[1], *etaz = &L->b[2];
     const double xif = 0.0; /* bulk viscosity kappa = 0 */
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
         double dudy = (A4(v, i, j + 1, k, 0) + A4(v, i - 1, j + 1, k, 0) - A4(v, i, j - 1, k, 0) - A4(v, i - 1, j - 1, k, 0)) * (0.25 * dyi);
         double dvdy = (A4(v, i, j + 1, k, 1) + A4(v, i - 1, j + 1, k, 1) - A4(v, i, j - 1, k, 1) - A4(v, i - 1, j - 1, k, 1)) * (0.25 * dyi);
@@ -92,6 +93,7 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
         A4(&fx, i, j, k, 1) = -mut * dudy;
         A4(&fx, i, j, k, 2) = -mut * dudz;
     }
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         double dudx = (A4(v, i + 1, j, k, 0) + A4(v, i + 1, j - 1, k, 0) - A4(v, i - 1, j, k, 0) - A4(v, i - 1, j - 1, k, 0)) * (0.25 * dxi);
         double dvdx = (A4(v, i + 1, j, k, 1) + A4(v, i + 1, j - 1, k, 1) - A4(v, i - 1, j, k, 1) - A4(v, i - 1, j - 1, k, 1)) * (0.25 * dxi);
@@ -104,6 +106,7 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
         A4(&fy, i, j, k, 1) = -mun * (-twoThirds * divu) - xif * divu;
         A4(&fy, i, j, k, 2) = -mut * dvdz;
     }
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         double dudx = (A4(v, i + 1, j, k, 0) + A4(v, i + 1, j, k - 1, 0) - A4(v, i - 1, j, k, 0) - A4(v, i - 1, j, k - 1, 0)) * (0.25 * dxi);
         double dwdx = (A4(v, i + 1, j, k, 2) + A4(v, i + 1, j, k - 1, 2) - A4(v, i - 1, j, k, 2) - A4(v, i - 1, j, k - 1, 2)) * (0.25 * dxi);

@@ -39,7 +39,8 @@ def test_stratified_fluid_at_rest_stays_at_rest_and_matches_oracle():
     O.orc_ns_post_init(ons, C.c_double(-1.0))
     Po = orc.from_cfab(O.orc_ns_fab(ons, 2)).valid([n] * 3, orc.NODE)[..., 0]
     P = ns.data(ns.P_NEW).gather_valid([n] * 3)[..., 0]
-    assert abs(P - Po).max() <= 1e-8 * abs(Po).max()
+    # all-Neumann / periodic solve: the additive constant is not determined
+    assert abs((P - P.mean()) - (Po - Po.mean())).max() <= 1e-8 * abs(Po - Po.mean()).max()
     for _ in range(2):
         ns.step()
     assert abs(ns.data(ns.S_NEW).gather_valid([n] * 3)[..., :3]).max() < 1e-9
