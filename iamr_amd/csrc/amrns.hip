@@ -695,6 +695,7 @@ void AmrNS::mac_sync(int l)
             });
         }
         MultiFab* um[3] = {&c.u_mac[0], &c.u_mac[1], &c.u_mac[2]};
+        godunov_set_ppm(c.p.use_ppm != 0);
         const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0}, ics[2] = {1, c.p.do_cons_trac ? 1 : 0};
         MultiFab flv[3], fls[3];
         MultiFab *flvp[3], *flsp[3];

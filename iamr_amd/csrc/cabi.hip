@@ -68,6 +68,7 @@ int iamrx_init(int device) { IAMRX_TRY Context::get().init(device); IAMRX_CATCH 
 int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH }
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
+int iamrx_godunov_set_ppm(int use_ppm) { IAMRX_TRY godunov_set_ppm(use_ppm != 0); IAMRX_CATCH }
 int iamrx_sync_count(size_t* n_stream_sync) { IAMRX_TRY *n_stream_sync = Context::get().n_stream_sync; IAMRX_CATCH }
 int iamrx_alloc_count(size_t* n_device_malloc)
 {
@@ -561,6 +562,7 @@ static NSParams to_params(const iamrx_ns_params* p)
     for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
     q.do_cons_trac = p->do_cons_trac;
+    q.use_ppm = p->use_ppm;
     return q;
 }
 

@@ -95,6 +95,55 @@ __device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int 
 
 __device__ __forceinline__ bool ed_or_ho(int b) { return b == bc_ext_dir || b == bc_hoextrap; }
 
+// ---- PPM (ns.advection_scheme = Godunov_PPM: reference Source/NavierStokesBase.cpp:548-553, 4654-4656 pass use_ppm to AMReX-Hydro's
+// "Godunov").  Colella & Woodward's piecewise-parabolic reconstruction as hydro_godunov_ppm states it (upstream; restated from the
+// published algorithm): van Leer slopes -> 4th-order edge values clipped to the two neighbouring cells -> one-sided edge values at
+// ext_dir / hoextrap faces -> monotonisation -> parabola integrated over the domain of dependence |u| dt of the face.
+// Selected per call through a device-resident switch (every traced state of every pass goes through trace_lohi).
+__device__ int g_ppm_dev = 0;
+
+__device__ __forceinline__ double vanleer(double s0, double sm1, double sp1)
+{
+    const double dsc = 0.5 * (sp1 - sm1), dsl = 2.0 * (s0 - sm1), dsr = 2.0 * (sp1 - s0);
+    return (dsl * dsr > 0.0) ? copysign(1.0, dsc) * fmin(fabs(dsc), fmin(fabs(dsl), fabs(dsr))) : 0.0;
+}
+__device__ __forceinline__ double clip2(double v, double a, double b) { return fmax(fmin(v, fmax(a, b)), fmin(a, b)); }
+
+// monotonised edge values (sm: low face, sp: high face) of the cell q points at; i = its index in the direction of stride s
+template <class P>
+__device__ __forceinline__ void ppm_edges(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi, double& sm, double& sp)
+{
+    const double s0 = q[0], sm1 = q[-s], sm2 = q[-2 * s], sp1 = q[s], sp2 = q[2 * s];
+    const double dm = vanleer(sm1, sm2, s0), d0 = vanleer(s0, sm1, sp1), dp = vanleer(sp1, s0, sp2);
+    sm = clip2(0.5 * (s0 + sm1) - (1.0 / 6.0) * (d0 - dm), s0, sm1);
+    sp = clip2(0.5 * (sp1 + s0) - (1.0 / 6.0) * (dp - d0), sp1, s0);
+    if (edlo && (i == domlo || i == domlo + 1)) {
+        const long o = (long)(domlo - i) * s;       // offset of cell domlo
+        const double sb = q[o - s], a0 = q[o], a1 = q[o + s], a2 = q[o + 2 * s];
+        const double se = clip2(-0.2 * sb + 0.75 * a0 + 0.5 * a1 - 0.05 * a2, a1, a0);
+        if (i == domlo) { sm = sb; sp = se; } else sm = se;
+    }
+    if (edhi && (i == domhi || i == domhi - 1)) {
+        const long o = (long)(domhi - i) * s;
+        const double sb = q[o + s], a0 = q[o], a1 = q[o - s], a2 = q[o - 2 * s];
+        const double se = clip2(-0.2 * sb + 0.75 * a0 + 0.5 * a1 - 0.05 * a2, a1, a0);
+        if (i == domhi) { sp = sb; sm = se; } else sp = se;
+    }
+    if ((sp - s0) * (s0 - sm) <= 0.0) { sp = s0; sm = s0; }
+    else if (fabs(sp - s0) >= 2.0 * fabs(sm - s0)) sp = 3.0 * s0 - 2.0 * sm;
+    else if (fabs(sm - s0) >= 2.0 * fabs(sp - s0)) sm = 3.0 * s0 - 2.0 * sp;
+}
+// state on the high (side) / low face of the cell traced with velocity u
+template <class P>
+__device__ __forceinline__ double ppm_trace(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi, double u, double dtdx, bool side)
+{
+    double sm, sp;
+    ppm_edges(q, s, edlo, edhi, i, domlo, domhi, sm, sp);
+    const double s0 = q[0], s6 = 6.0 * s0 - 3.0 * (sm + sp), sigma = fabs(u) * dtdx;
+    if (side) return (u > SMALL_VEL) ? sp - (0.5 * sigma) * ((sp - sm) - (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+    return (u < -SMALL_VEL) ? sm + (0.5 * sigma) * ((sp - sm) + (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+}
+
 // SetTransTerm{X,Y,Z}BCs.  qc points at the state value of the cell on the HIGH side of the face
 // (cell index f in direction d), s = stride in d, f = face index.
 template <class P>
@@ -152,6 +201,14 @@ __device__ __forceinline__ void trace_lohi(P qn /*state comp n at cell f*/, PV v
                                            long s, double um, double dtdx, bool edlo, bool edhi, int f, int domlo, int domhi,
                                            double& lo, double& hi)
 {
+    if (g_ppm_dev) {
+        // lo: high face of cell f-1, hi: low face of cell f; PRED traces with the cell-centred velocity of each cell
+        double ul = um, uh = um;
+        if constexpr (PRED) { ul = vd[-s]; uh = vd[0]; }
+        lo = ppm_trace(qn - s, s, edlo, edhi, f - 1, domlo, domhi, ul, dtdx, true);
+        hi = ppm_trace(qn, s, edlo, edhi, f, domlo, domhi, uh, dtdx, false);
+        return;
+    }
     const double slh = slope4(qn, s, edlo, edhi, f, domlo, domhi);
     const double sll = slope4(qn - s, s, edlo, edhi, f - 1, domlo, domhi);
     trace_from_slopes<PRED>(qn, vd, s, um, dtdx, slh, sll, lo, hi);
@@ -163,7 +220,10 @@ __device__ __forceinline__ void trace_lohi_sl(P qn, PV vd, long s, double um, do
                                               PS slp, long ss, double& lo, double& hi)
 {
     if constexpr (std::is_same<PS, std::nullptr_t>::value) trace_lohi<PRED>(qn, vd, s, um, dtdx, edlo, edhi, f, domlo, domhi, lo, hi);
-    else trace_from_slopes<PRED>(qn, vd, s, um, dtdx, slp[0], slp[-ss], lo, hi);
+    else {
+        if (g_ppm_dev) trace_lohi<PRED>(qn, vd, s, um, dtdx, edlo, edhi, f, domlo, domhi, lo, hi);      // no slope arrays with PPM
+        else trace_from_slopes<PRED>(qn, vd, s, um, dtdx, slp[0], slp[-ss], lo, hi);
+    }
 }
 
 template <int D> __device__ __forceinline__ long stride_of(const FabD& a)
@@ -225,6 +285,8 @@ __global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict_
             double l, h;
             {
                 const auto qn = q.gp() + qo + q.cs * n;
+                if (g_ppm_dev) trace_lohi<PRED>(qn, q.gp() + qo + q.cs * D, s, uad, dtdx, edlo, edhi, f, domlo, domhi, l, h);
+                else {
                 const double slh = slope4(qn, s, edlo, edhi, f, domlo, domhi);
                 const double sll = slope4(qn - s, s, edlo, edhi, f - 1, domlo, domhi);
                 trace_from_slopes<PRED>(qn, q.gp() + qo + q.cs * D, s, uad, dtdx, slh, sll, l, h);
@@ -233,6 +295,7 @@ __global__ void __launch_bounds__(256) k_trace(Tiling t, const BoxD* __restrict_
                     const long so = sl.off(i, j, k) + sl.cs * n;
                     sl.gp()[so] = slh;
                     if (f == flo) sl.gp()[so - stride_of<D>(sl)] = sll;
+                }
                 }
             }
             if (fit && has_force) { l += hdt * frc.gp()[fo - fs + frc.cs * n]; h += hdt * frc.gp()[fo + frc.cs * n]; }
@@ -689,6 +752,18 @@ __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX *
         }
     }
 }
+
+static int g_ppm_host = 0;
+void godunov_set_ppm(bool on)
+{
+    const int v = on ? 1 : 0;
+    if (v == g_ppm_host) return;
+    g_ppm_host = v;
+    auto& ctx = Context::get();
+    IAMRX_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ppm_dev), &g_ppm_host, sizeof(int), 0, hipMemcpyHostToDevice, ctx.stream));
+    ctx.sync();
+}
+bool godunov_get_ppm() { return g_ppm_host != 0; }
 
 static GodParams make_params(const Geometry& g, double dt, int ncomp, const BCRec* bc, const int* iconserv, bool is_vel, bool fit,
                              bool has_force, bool has_divu)

@@ -85,6 +85,10 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
                           const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
                           bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3]);
 
+// edge-state reconstruction of every later Godunov call: false = PLM (4th-order limited slopes), true = PPM (ns.advection_scheme = Godunov_PPM)
+void godunov_set_ppm(bool on);
+bool godunov_get_ppm();
+
 // ---- k_nodal.hip --------------------------------------------------------------------------
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
 void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color, const MultiFab* dmask = nullptr);

@@ -424,6 +424,7 @@ double NavierStokes::predict_velocity(double dt_)
         });
     }
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_set_ppm(p.use_ppm != 0);
     godunov_extrap_vel_to_faces(g, Umf, &tf, um, dt_, bc_vel, p.use_forces_in_trans != 0);
     return dt_ * tempdt;
 }
@@ -491,6 +492,7 @@ void NavierStokes::velocity_advection(double dt_)
     const int ic = mom ? 1 : 0;                         // NS_setup.cpp:297-301: velocity advectionType = Conservative
     const int iconserv[3] = {ic, ic, ic};
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_set_ppm(p.use_ppm != 0);
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
@@ -525,6 +527,7 @@ void NavierStokes::scalar_advection(double dt_)
     }
     const int iconserv[2] = {1, p.do_cons_trac ? 1 : 0};                            // NS_setup.cpp:304-310
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_set_ppm(p.use_ppm != 0);
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];

@@ -136,6 +136,7 @@ struct NSParams {
     double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
     double scal_bc_lo[6] = {0, 0, 0, 0, 0, 0}, scal_bc_hi[6] = {0, 0, 0, 0, 0, 0};   // xlo.density, xlo.tracer ... (inflow values): [d*2+n]
     int do_cons_trac = 0;                // ns.do_cons_trac
+    int use_ppm = 0;                     // ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM (NavierStokesBase.cpp:548-553)
 };
 
 enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };

@@ -178,6 +178,9 @@ int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, ia
                                const int* bcrec /* [ncomp][6] */, int is_velocity, int use_forces_in_trans,
                                iamrx_mf edge_x, iamrx_mf edge_y, iamrx_mf edge_z, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
 
+/* edge-state reconstruction of the two entries above (godunov_use_ppm, Source/NavierStokesBase.cpp:4654-4656): 0 PLM (default), 1 PPM */
+int iamrx_godunov_set_ppm(int use_ppm);
+
 /* ---- nodal projection (amrex::MLNodeLaplacian / Hydro::NodalProjector role) ------- */
 /* out = rhs - div(sig grad phi) at nodes (rhs == NULL: out = div(sig grad phi)); phi and sig need 1 filled ghost */
 int iamrx_nodal_residual(const iamrx_geom* g, iamrx_mf out, iamrx_mf phi, iamrx_mf sig, iamrx_mf rhs);
@@ -286,6 +289,7 @@ typedef struct iamrx_ns_params {
     double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];     /* xlo.density, xlo.tracer ... zhi.* (inflow values): [d*2+n], n = 0 density, 1 tracer */
     int do_cons_trac;            /* ns.do_cons_trac: the tracer is rho*q, advected conservatively and diffused as div beta grad(S/rho) (Source/NS_setup.cpp:306-310) */
+    int use_ppm;                 /* ns.advection_scheme: 0 = Godunov_PLM, 1 = Godunov_PPM (Source/NavierStokesBase.cpp:548-553, 4654-4656) */
 } iamrx_ns_params;
 void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);

@@ -182,6 +182,10 @@ void orc_compute_aofs(const orc_geom* g, orc_fab* aofs /*ncomp comps starting at
                       const orc_bcrec* bc, int is_velocity, int use_forces_in_trans,
                       orc_fab* edge_out[3] /*optional, ncomp face comps*/, orc_fab* flux_out[3]);
 
+/* edge-state reconstruction used by the two routines above: 0 PLM (default), 1 PPM */
+void orc_godunov_set_ppm(int on);
+int orc_godunov_get_ppm(void);
+
 /* ---- nodal projection (orc_nodal.c) ---------------------------------------------- */
 void orc_nodal_adotx(const orc_geom* g, orc_fab* y, const orc_fab* x /*node,1 ghost*/, const orc_fab* sig /*cell,1 ghost*/);
 void orc_nodal_divu(const orc_geom* g, orc_fab* rhs /*node*/, const orc_fab* vel /*cell,3 comps,1 ghost*/);
@@ -239,6 +243,7 @@ typedef struct orc_ns_params {
     double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];   /* xlo.density, xlo.tracer ... (inflow values): [d*2+n], n = 0 density, 1 tracer */
     int do_cons_trac;          /* ns.do_cons_trac (Source/NS_setup.cpp:306-310): Conservative advection, Laplacian_SoverRho diffusion */
+    int use_ppm;               /* ns.advection_scheme = Godunov_PPM (Source/NavierStokesBase.cpp:548-553); 0: Godunov_PLM */
 } orc_ns_params;
 
 typedef struct orc_ns_state orc_ns_state;

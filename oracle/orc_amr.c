@@ -729,6 +729,7 @@ static void mac_sync_compute(orc_amr* a, int lev, orc_fab Ucorr[3])
     orc_ns_state* c = a->lev[lev];
     const orc_geom* g = &c->g;
     const double dt = a->dt_level[lev], prev_time = c->st_old;
+    orc_godunov_set_ppm(c->p.use_ppm);
     if (c->p.visc_coef > 0.0 || c->p.tracer_diff_coef > 0.0) { fprintf(stderr, "orc mac_sync_compute: viscous terms of the sync forcing not restated\n"); abort(); }
     orc_fab Smf = ns_fillpatch_time(c, prev_time, 0, 0, 3, 3);
     orc_fab Sc = ns_fillpatch_time(c, prev_time, 0, Density, NUM_SCALARS, 3);

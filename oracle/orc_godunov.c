@@ -82,6 +82,65 @@ double orc_slope4(const orc_fab* q, int i, int j, int k, int n, int dir)
 
 static inline int bc_is_ed_or_ho(int b) { return b == ORC_BC_EXT_DIR || b == ORC_BC_HOEXTRAP; }
 
+/* ---- PPM (ns.advection_scheme = Godunov_PPM, reference Source/NavierStokesBase.cpp:548-553, 4654-4656: AMReX-Hydro "Godunov" with
+ * use_ppm).  The piecewise-parabolic reconstruction of Colella & Woodward (JCP 54, 1984) as AMReX-Hydro's hydro_godunov_ppm states it
+ * (upstream, not in the reference tree; restated from the published algorithm):
+ *   van Leer slopes  dvl(c) = sign(dc) min(|dc|, 2|s_c - s_{c-1}|, 2|s_{c+1} - s_c|) (0 at an extremum), dc = (s_{c+1} - s_{c-1})/2
+ *   edge values      s_{c+1/2} = (s_c + s_{c+1})/2 - (dvl(c+1) - dvl(c))/6, clipped to [min, max] of the two cells
+ *   ext_dir / hoextrap face at the low end: the first cell takes the boundary value on its low edge and the one-sided 4-point value
+ *     -1/5 s_b + 3/4 s_0 + 1/2 s_1 - 1/20 s_2 (clipped to cells 0, 1) on its high edge, which is also the low edge of the second cell
+ *   monotonisation   (sp - s)(s - sm) <= 0 -> sp = sm = s;  |sp - s| >= 2|sm - s| -> sp = 3s - 2sm;  |sm - s| >= 2|sp - s| -> sm = 3s - 2sp
+ *   tracing          s6 = 6s - 3(sm + sp), sigma = |u| dt/dx;
+ *                    high face: u > small ? sp - sigma/2 ((sp - sm) - (1 - 2/3 sigma) s6) : s
+ *                    low  face: u < -small ? sm + sigma/2 ((sp - sm) + (1 - 2/3 sigma) s6) : s */
+static int g_use_ppm = 0;
+void orc_godunov_set_ppm(int on) { g_use_ppm = on; }
+int orc_godunov_get_ppm(void) { return g_use_ppm; }
+
+static inline double vanleer(double s0, double sm1, double sp1)
+{
+    const double dsc = 0.5 * (sp1 - sm1), dsl = 2.0 * (s0 - sm1), dsr = 2.0 * (sp1 - s0);
+    return (dsl * dsr > 0.0) ? copysign(1.0, dsc) * fmin(fabs(dsc), fmin(fabs(dsl), fabs(dsr))) : 0.0;
+}
+static inline double clip2(double v, double a, double b) { return fmax(fmin(v, fmax(a, b)), fmin(a, b)); }
+static inline double qd(const orc_fab* q, const int c[3], int n, int d, int o) { int e[3] = {c[0], c[1], c[2]}; e[d] += o; return A4(q, e[0], e[1], e[2], n); }
+
+/* monotonised edge values of cell c in direction d */
+static void ppm_edges(const orc_fab* q, const int c[3], int n, int d, int edlo, int edhi, int domlo, int domhi, double* smo, double* spo)
+{
+    const double s0 = qd(q, c, n, d, 0), sm1 = qd(q, c, n, d, -1), sm2 = qd(q, c, n, d, -2), sp1 = qd(q, c, n, d, 1), sp2 = qd(q, c, n, d, 2);
+    const double dm = vanleer(sm1, sm2, s0), d0 = vanleer(s0, sm1, sp1), dp = vanleer(sp1, s0, sp2);
+    double sm = clip2(0.5 * (s0 + sm1) - (1.0 / 6.0) * (d0 - dm), s0, sm1);
+    double sp = clip2(0.5 * (sp1 + s0) - (1.0 / 6.0) * (dp - d0), sp1, s0);
+    const int i = c[d];
+    if (edlo && (i == domlo || i == domlo + 1)) {
+        const int o = domlo - i;        /* offset of cell domlo from c */
+        const double sb = qd(q, c, n, d, o - 1), a0 = qd(q, c, n, d, o), a1 = qd(q, c, n, d, o + 1), a2 = qd(q, c, n, d, o + 2);
+        const double se = clip2(-0.2 * sb + 0.75 * a0 + 0.5 * a1 - 0.05 * a2, a1, a0);
+        if (i == domlo) { sm = sb; sp = se; } else sm = se;
+    }
+    if (edhi && (i == domhi || i == domhi - 1)) {
+        const int o = domhi - i;
+        const double sb = qd(q, c, n, d, o + 1), a0 = qd(q, c, n, d, o), a1 = qd(q, c, n, d, o - 1), a2 = qd(q, c, n, d, o - 2);
+        const double se = clip2(-0.2 * sb + 0.75 * a0 + 0.5 * a1 - 0.05 * a2, a1, a0);
+        if (i == domhi) { sp = sb; sm = se; } else sp = se;
+    }
+    if ((sp - s0) * (s0 - sm) <= 0.0) { sp = s0; sm = s0; }
+    else if (fabs(sp - s0) >= 2.0 * fabs(sm - s0)) sp = 3.0 * s0 - 2.0 * sm;
+    else if (fabs(sm - s0) >= 2.0 * fabs(sp - s0)) sm = 3.0 * s0 - 2.0 * sp;
+    *smo = sm; *spo = sp;
+}
+#define PPM_SMALL_VEL 1.e-8
+/* state on the high (side = 1) / low (side = 0) face of cell c traced with velocity u */
+static double ppm_trace(const orc_fab* q, const int c[3], int n, int d, int edlo, int edhi, int domlo, int domhi, double u, double dtdx, int side)
+{
+    double sm, sp;
+    ppm_edges(q, c, n, d, edlo, edhi, domlo, domhi, &sm, &sp);
+    const double s0 = Q(q, c, n), s6 = 6.0 * s0 - 3.0 * (sm + sp), sigma = fabs(u) * dtdx;
+    if (side) return (u > PPM_SMALL_VEL) ? sp - (0.5 * sigma) * ((sp - sm) - (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+    return (u < -PPM_SMALL_VEL) ? sm + (0.5 * sigma) * ((sp - sm) + (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+}
+
 /* SetTransTerm{X,Y,Z}BCs: face f (index in direction d), states lo (from cell f-1) and hi (cell f) */
 static void trans_bc(const orc_fab* q, const int fidx[3], int n, int d, double* lo, double* hi,
                      int bclo, int bchi, int domlo, int domhi, int is_velocity)
@@ -164,13 +223,17 @@ static void plm_predict_vel(const orc_geom* g, const orc_fab* q, int ncomp, cons
 {
     for (int d = 0; d < 3; ++d) {
         const double dtdx = dt / g->dx[d];
-        int c[3];
         for (int n = 0; n < ncomp; ++n) {
             const int edlo = !g->periodic[d] && bc_is_ed_or_ho(bc[n].lo[d]);
             const int edhi = !g->periodic[d] && bc_is_ed_or_ho(bc[n].hi[d]);
             LOOP3(&Im[d], c) {
-                double sl = slope4_extdir(q, c, n, d, edlo, edhi, 0, g->n[d] - 1);
                 double u = Q(vcc, c, d);
+                if (g_use_ppm) {
+                    *QP(&Im[d], c, n) = ppm_trace(q, c, n, d, edlo, edhi, 0, g->n[d] - 1, u, dtdx, 0);
+                    *QP(&Ip[d], c, n) = ppm_trace(q, c, n, d, edlo, edhi, 0, g->n[d] - 1, u, dtdx, 1);
+                    continue;
+                }
+                double sl = slope4_extdir(q, c, n, d, edlo, edhi, 0, g->n[d] - 1);
                 *QP(&Im[d], c, n) = Q(q, c, n) + 0.5 * (-1.0 - u * dtdx) * sl;
                 *QP(&Ip[d], c, n) = Q(q, c, n) + 0.5 * (1.0 - u * dtdx) * sl;
             }
@@ -195,7 +258,6 @@ void orc_extrap_vel_to_faces(const orc_geom* g, const orc_fab* vel, const orc_fa
 
     /* ComputeAdvectiveVel: normal component only */
     for (int d = 0; d < 3; ++d) {
-        int f[3];
         LOOP3(&ad[d], f) {
             int cm[3]; shift(cm, f, d, -1);
             double lo = Q(&Ip[d], cm, d), hi = Q(&Im[d], f, d);
@@ -208,7 +270,6 @@ void orc_extrap_vel_to_faces(const orc_geom* g, const orc_fab* vel, const orc_fa
     }
     /* upwind every component with the advective velocity */
     for (int d = 0; d < 3; ++d) {
-        int f[3];
         for (int n = 0; n < ncomp; ++n)
         LOOP3(&edge[d], f) {
             int cm[3]; shift(cm, f, d, -1);
@@ -239,7 +300,6 @@ void orc_extrap_vel_to_faces(const orc_geom* g, const orc_fab* vel, const orc_fa
             }
             Tt->nc = 1;
             Tt->p = (double*)calloc(orc_npts(Tt), sizeof(double));
-            int f[3];
             LOOP3(Tt, f) {
                 int cm[3]; shift(cm, f, t, -1);       /* cell on the low side of the t-face */
                 int cmo[3], fo[3];
@@ -294,22 +354,26 @@ static void compute_edge_state(const orc_geom* g, const orc_fab* q, int ncomp, c
     /* PLM::PredictStateOnXFace: both sides of a face are traced with that face's umac */
     for (int d = 0; d < 3; ++d) {
         const double dtdx = dt / g->dx[d];
-        int f[3];
         for (int n = 0; n < ncomp; ++n) {
             const int edlo = !g->periodic[d] && bc_is_ed_or_ho(bc[n].lo[d]);
             const int edhi = !g->periodic[d] && bc_is_ed_or_ho(bc[n].hi[d]);
             LOOP3(&edge[d], f) {
                 int cm[3]; shift(cm, f, d, -1);
                 double um = Q(umac[d], f, 0);
-                double upls = Q(q, f, n) + 0.5 * (-1.0 - um * dtdx) * slope4_extdir(q, f, n, d, edlo, edhi, 0, g->n[d] - 1);
-                double umns = Q(q, cm, n) + 0.5 * (1.0 - um * dtdx) * slope4_extdir(q, cm, n, d, edlo, edhi, 0, g->n[d] - 1);
+                double upls, umns;
+                if (g_use_ppm) {       /* PPM::PredictStateOnXFace: both sides of the face traced with the face's umac */
+                    upls = ppm_trace(q, f, n, d, edlo, edhi, 0, g->n[d] - 1, um, dtdx, 0);
+                    umns = ppm_trace(q, cm, n, d, edlo, edhi, 0, g->n[d] - 1, um, dtdx, 1);
+                } else {
+                upls = Q(q, f, n) + 0.5 * (-1.0 - um * dtdx) * slope4_extdir(q, f, n, d, edlo, edhi, 0, g->n[d] - 1);
+                umns = Q(q, cm, n) + 0.5 * (1.0 - um * dtdx) * slope4_extdir(q, cm, n, d, edlo, edhi, 0, g->n[d] - 1);
+                }
                 *QP(&Ip[d], cm, n) = umns;
                 *QP(&Im[d], f, n) = upls;
             }
         }
     }
     for (int d = 0; d < 3; ++d) {
-        int f[3];
         for (int n = 0; n < ncomp; ++n)
         LOOP3(&edge[d], f) {
             int cm[3]; shift(cm, f, d, -1);
@@ -337,7 +401,6 @@ static void compute_edge_state(const orc_geom* g, const orc_fab* q, int ncomp, c
             }
             Tt->nc = ncomp;
             Tt->p = (double*)calloc(orc_npts(Tt) * (size_t)ncomp, sizeof(double));
-            int f[3];
             for (int n = 0; n < ncomp; ++n)
             LOOP3(Tt, f) {
                 int cm[3]; shift(cm, f, t, -1);
@@ -416,7 +479,6 @@ void orc_compute_aofs(const orc_geom* g, orc_fab* aofs, int acomp, const orc_fab
     /* ComputeFluxes, area-weighted (NavierStokesBase.cpp:4651) */
     for (int d = 0; d < 3; ++d) {
         const double area = g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
-        int f[3];
         for (int n = 0; n < ncomp; ++n)
         LOOP3(&flux[d], f) *QP(&flux[d], f, n) = Q(&edge[d], f, n) * Q(umac[d], f, 0) * area;
     }
@@ -462,7 +524,6 @@ void orc_compute_aofs_sync(const orc_geom* g, orc_fab* sync, int acomp, const or
     compute_edge_state(g, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edge);
     for (int d = 0; d < 3; ++d) {
         const double area = g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
-        int f[3];
         for (int n = 0; n < ncomp; ++n)
         LOOP3(&flux[d], f) *QP(&flux[d], f, n) = Q(&edge[d], f, n) * Q(ucorr[d], f, 0) * area;
     }

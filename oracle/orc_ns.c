@@ -38,6 +38,7 @@ void orc_ns_default_params(orc_ns_params* p)
     for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
     for (int q = 0; q < 6; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
     p->do_cons_trac = 0;
+    p->use_ppm = 0;
 }
 
 /* BCType of a velocity component / scalar / grad p component for a physical BC (Source/NS_BC.H:7-35) */
@@ -627,6 +628,7 @@ static void advance_setup(orc_ns_state* s, double dt, int iteration, int ncycle)
 static double predict_velocity(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
+    orc_godunov_set_ppm(s->p.use_ppm);
     orc_fab Umf = fillpatch(s, S_OLD(s), Xvel, 3, 3, s->bc_vel);
     floor_small(&Umf);
     double cflmax = 0.0;
@@ -760,6 +762,7 @@ static void adv_registers(orc_ns_state* s, orc_fab* flux[3], int state_indx, int
 static void velocity_advection(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
+    orc_godunov_set_ppm(s->p.use_ppm);
     const int mom = s->p.do_mom_diff;
     orc_fab Umf = fillpatch(s, S_OLD(s), Xvel, 3, 3, s->bc_vel);
     if (mom) {
@@ -796,6 +799,7 @@ static void velocity_advection(orc_ns_state* s, double dt)
 static void scalar_advection(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
+    orc_godunov_set_ppm(s->p.use_ppm);
     orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
     floor_small(&Smf);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
