@@ -25,8 +25,8 @@ public:
     void reflux(int l);
     void avg_down(int l);
     void mac_sync(int l);
-    void level_sync(int l);
-    void post_timestep(int l);
+    void level_sync(int l, int crse_iteration = -1);      // crse_iteration: of level l within the step of level l-1 (-1: the last one)
+    void post_timestep(int l, int crse_iteration = -1);
     void time_step(int l, double time, int iteration, int niter);
 
 private:

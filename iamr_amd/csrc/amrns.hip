@@ -338,9 +338,10 @@ NavierStokes::~NavierStokes() = default;
 // that the next finer level does not cover contribute their element matrices; a node of level l+1 on that level's boundary is a
 // slave (trilinear interpolant of level l), what the fine cells contribute to it goes to level l with the transposed weights /
 // ratio^3 (full-weighting restriction); boundary nodes of the coarsest level of the solve and nodes on Dirichlet faces keep their
-// incoming value.  Solver: fast adaptive composite cycle -- V-cycle of every refined level (zero Dirichlet data on its boundary),
-// V-cycle of the coarsest level on the composite residual, trilinear interpolation of the coarse correction, V-cycles of the
-// refined levels again -- repeated until the composite residual meets MLMG's criterion.
+// incoming value.  Solver: fast adaptive composite cycle -- a symmetric sweep finest -> coarsest -> finest of level corrections; each
+// is one V-cycle of that level's own multigrid (zero data on the level's boundary) on the composite residual restricted to the
+// level (full weighting of the finer levels' residuals), its result interpolated trilinearly to the unknowns of every finer level
+// -- repeated until the composite residual meets MLMG's criterion.
 namespace {
 
 struct CLev {
@@ -521,31 +522,43 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
     const double target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
     if (st.resnorm0 <= target) st.converged = 1;
     MGStats vst;
-    for (int it = 0; it < o.max_iters && !st.converged; ++it) {
-        // refined levels, finest first
-        for (int l = nl - 1; l >= 1; --l) {
-            L[l].mg->vcycle_correction(L[l].e, L[l].r, vst);
-            mf_saxpy(L[l].x, 1.0, L[l].e, 0, 0, 1, 0);
-            comp_residual(L);
-        }
-        // coarsest level on the composite residual, correction interpolated to every finer level
-        L[0].mg->vcycle_correction(L[0].e, L[0].r, vst);
-        mf_saxpy(L[0].x, 1.0, L[0].e, 0, 0, 1, 0);
-        for (int l = 1; l < nl; ++l) {                          // e of level l = the interpolant of the coarse correction (all nodes)
-            fill_nodes(L[l - 1], L[l - 1].e);
-            L[l].e.setVal(0.0);
-            node_interp_from_crse(L[l].e, L[l - 1].e, L[l - 1].g, L[l].ns->ratio, nullptr, false);
-            MultiFab t(L[l].layout, node_type(), 1, 0);
-            MultiFab::Copy(t, L[l].e, 0, 0, 1, 0);
-            mask_mult(t, 0, 1, L[l].own, false, 0);
-            mf_saxpy(L[l].x, 1.0, t, 0, 0, 1, 0);
-        }
+    // one subspace correction: the space of level l = its trilinear functions vanishing on the level's boundary, prolonged to the
+    // unknowns of every finer level.  Right-hand side = the composite residual tested with those functions: the level's own entries
+    // plus the full-weighting restriction of the finer levels' entries.
+    auto correct_level = [&](int l) {
         comp_residual(L);
-        for (int l = 1; l < nl; ++l) {
-            L[l].mg->vcycle_correction(L[l].e, L[l].r, vst);
-            mf_saxpy(L[l].x, 1.0, L[l].e, 0, 0, 1, 0);
-            comp_residual(L);
+        MultiFab acc;                                          // on level m-1: what levels >= m hand down
+        for (int m = nl - 1; m > l; --m) {
+            MultiFab bb(L[m].layout, node_type(), 1, 1);
+            bb.setVal(0.0);
+            MultiFab::Copy(bb, L[m].r, 0, 0, 1, 0);
+            if (m < nl - 1) mf_saxpy(bb, 1.0, acc, 0, 0, 1, 0);
+            MultiFab down(L[m - 1].layout, node_type(), 1, 0);
+            restrict_to_crse(down, bb, L[m].g, L[m - 1].g, L[m].ns->ratio);
+            acc = std::move(down);
         }
+        MultiFab rhs(L[l].layout, node_type(), 1, 1);
+        rhs.setVal(0.0);
+        MultiFab::Copy(rhs, L[l].r, 0, 0, 1, 0);
+        if (l < nl - 1) mf_saxpy(rhs, 1.0, acc, 0, 0, 1, 0);
+        L[l].mg->vcycle_correction(L[l].e, rhs, vst);
+        for (int m = l; m < nl; ++m) {
+            if (m > l) {                                        // e of level m = the interpolant of the coarser correction (all nodes)
+                fill_nodes(L[m - 1], L[m - 1].e);
+                L[m].e.setVal(0.0);
+                node_interp_from_crse(L[m].e, L[m - 1].e, L[m - 1].g, L[m].ns->ratio, nullptr, false);
+            }
+            MultiFab t(L[m].layout, node_type(), 1, 0);
+            MultiFab::Copy(t, L[m].e, 0, 0, 1, 0);
+            mask_mult(t, 0, 1, L[m].own, false, 0);
+            mf_saxpy(L[m].x, 1.0, t, 0, 0, 1, 0);
+        }
+    };
+    for (int it = 0; it < o.max_iters && !st.converged; ++it) {
+        for (int l = nl - 1; l >= 1; --l) correct_level(l);     // finest first, down to the coarsest level of the solve, and up again
+        correct_level(0);
+        for (int l = 1; l < nl; ++l) correct_level(l);
+        comp_residual(L);
         st.resnorm = comp_norm(L, &CLev::r);
         st.iters = it + 1;
         if (o.verbose) printf("iamrx composite nodal solve: iter %d resid %.6e (target %.3e)\n", it + 1, st.resnorm, target);
@@ -598,6 +611,32 @@ AmrNS::AmrNS(const Geometry& g0, const std::vector<LayoutP>& layouts, int ratio,
         dt_level.push_back(0.0); dt_min.push_back(1.e200);
         if (l > 0) {
             NavierStokes& c = *lev[l - 1];
+            // proper nesting: the Godunov ghost cells (3) of every box plus the interpolation stencil (1 coarse cell) must lie inside the
+            // next coarser level or outside a non-periodic domain face -- what amrex::Amr's grid generation guarantees for IAMR
+            // (blocking_factor >= 8).  Layouts that violate it would read cells no level defines.
+            if (l > 1) {
+                const BoxD cdom = c.g.domain;
+                for (auto& fb : layouts[l]->boxes) {
+                    BoxD R = grow(coarsen(grow(fb, 3), ratio), 1);
+                    for (int d = 0; d < 3; ++d) if (!c.g.periodic[d]) { R.lo[d] = std::max(R.lo[d], cdom.lo[d]); R.hi[d] = std::min(R.hi[d], cdom.hi[d]); }
+                    long covered = 0;
+                    for (auto& cb : layouts[l - 1]->boxes)
+                        for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+                            const int sh[3] = {sx, sy, sz};
+                            bool ok = true;
+                            BoxD q = cb;
+                            for (int d = 0; d < 3; ++d) {
+                                if (sh[d] != 0 && !c.g.periodic[d]) ok = false;
+                                q.lo[d] += sh[d] * cdom.len(d); q.hi[d] += sh[d] * cdom.len(d);
+                            }
+                            if (!ok) continue;
+                            const BoxD is = intersect(R, q);
+                            if (is.ok()) covered += is.npts();
+                        }
+                    if (covered != R.npts()) throw Error("iamrx AmrNS: level " + std::to_string(l) + " is not properly nested in level " + std::to_string(l - 1) +
+                                                         " (3 ghost cells + 1 coarse stencil cell must lie inside the coarser level)");
+                }
+            }
             s.crse = &c; c.fine = &s;
             s.rho_avg.define(s.layout, cell_type(), 1, 1); s.rho_avg.setVal(0.0);
             s.p_avg.define(s.layout, node_type(), 1, 0); s.p_avg.setVal(0.0);
@@ -656,7 +695,6 @@ void AmrNS::reflux(int l)
 void AmrNS::mac_sync(int l)
 {
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
-    if (l != 0) throw Error("iamrx AmrNS::mac_sync: level > 0 (three or more levels) is not implemented");
     if (c.is_diffusive_vel() || c.is_diffusive_tracer()) throw Error("iamrx AmrNS::mac_sync: the viscous / diffusive sync is not implemented");
     auto& ctx = Context::get();
     const double dt = dt_level[l];
@@ -665,7 +703,8 @@ void AmrNS::mac_sync(int l)
     for (int d = 0; d < 3; ++d) { Ucorr[d].define(c.layout, face_type(d), 1, 1); Ucorr[d].setVal(0.0); uc[d] = &Ucorr[d]; }
     MGOpts mo = o;
     mo.maxorder = 4;
-    st_mac_sync = mac_sync_solve(c.g, *f.reg_mac, c.rho_half, dt, f.layout, f.ratio, uc, c.mac_phi, c.bc_mac, 1.e-10 /*mac_sync_tol*/, c.p.mac_abs_tol, mo);
+    st_mac_sync = mac_sync_solve(c.g, *f.reg_mac, c.rho_half, dt, f.layout, f.ratio, uc, c.mac_phi, c.bc_mac, 1.e-10 /*mac_sync_tol*/, c.p.mac_abs_tol, mo,
+                                 l > 0 ? &c.crse->g : nullptr, c.ratio);
     for (int d = 0; d < 3; ++d) Ucorr[d].FillBoundary(c.g);
     // ---- mac_sync_compute (MacProj.cpp:490-731)
     {
@@ -705,6 +744,11 @@ void AmrNS::mac_sync(int l)
         for (int d = 0; d < 3; ++d) {            // NavierStokesBase.cpp:5083-5096 with sync_factor = -1
             f.reg_adv->CrseInit(flv[d], d, 0, 0, 3, dt, true);
             f.reg_adv->CrseInit(fls[d], d, 0, Density, NUM_SCALARS, dt, true);
+            if (l > 0) {                         // this level is itself the fine side of the interface below
+                c.reg_adv->FineAdd(flv[d], d, 0, 0, 3, -dt);
+                c.reg_adv->FineAdd(fls[d], d, 0, Density, NUM_SCALARS, -dt);
+                c.reg_mac->FineAdd(Ucorr[d], d, 0, 0, 1, -c.g.dx[(d + 1) % 3] * c.g.dx[(d + 2) % 3] / (double)n_cycle[l]);   // MacProj.cpp:720-727
+            }
         }
     }
     // ---- NavierStokes.cpp:1490-1690
@@ -727,22 +771,26 @@ void AmrNS::mac_sync(int l)
     if (cons_trac) mf_saxpy(c.Ssync, dt, Delta, 0, Tracer - 3, 1, 0);
     mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, NUM_STATE - 3, 0);
     c.make_rho_curr_time();
-    // interpolate the sync correction to the finer level (:1697-1725)
-    if (lev.size() > (size_t)l + 2) throw Error("iamrx AmrNS::mac_sync: SyncInterp over more than one level is not implemented");
-    {
-        MultiFab incr(f.layout, cell_type(), NUM_STATE - 3, 0);
-        sync_interp_cellcons(incr, 0, c.Ssync, 0, NUM_STATE - 3, c.g, f.g, f.ratio, c.bc_scal);
-        mf_saxpy(f.S[f.inew], 1.0, incr, 0, Density, NUM_STATE - 3, 0);
-        f.make_rho_curr_time();
-        mf_saxpy(f.rho_avg, 1.0, incr, 0, 0, 1, 0);
+    if (l > 0) mf_saxpy(c.rho_avg, 1.0, c.Ssync, 0, 0, 1, 0);      // :1684-1688
+    // interpolate the sync correction to every finer level, straight from this one with the accumulated ratio (:1697-1725)
+    int ratio = 1;
+    for (size_t q = (size_t)l + 1; q < lev.size(); ++q) {
+        NavierStokes& ff = *lev[q];
+        ratio *= ff.ratio;
+        MultiFab incr(ff.layout, cell_type(), NUM_STATE - 3, 0);
+        sync_interp_cellcons(incr, 0, c.Ssync, 0, NUM_STATE - 3, c.g, ff.g, ratio, c.bc_scal);
+        mf_saxpy(ff.S[ff.inew], 1.0, incr, 0, Density, NUM_STATE - 3, 0);
+        ff.make_rho_curr_time();
+        mf_saxpy(ff.rho_avg, 1.0, incr, 0, 0, 1, 0);
     }
 }
 
 // NavierStokesBase::level_sync (NavierStokesBase.cpp:1927-2044) + Projection::MLsyncProject (Projection.cpp:457-607)
-void AmrNS::level_sync(int l)
+void AmrNS::level_sync(int l, int crse_iteration)
 {
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
-    if (l != 0) throw Error("iamrx AmrNS::level_sync: level > 0 (SyncRegister::CompAdd) is not implemented");
+    const int crse_dt_ratio = n_cycle[l];
+    if (crse_iteration < 0) crse_iteration = crse_dt_ratio;
     auto& ctx = Context::get();
     const double dt = dt_level[l];
     c.Vsync.FillBoundary(c.g);
@@ -773,22 +821,56 @@ void AmrNS::level_sync(int l)
     const int vcomp[2] = {0, 0};
     MultiFab* phi[2] = {&phi_c, &phi_f};
     const MultiFab* sig[2] = {&sig_c, &sig_f};
+    // Projection.cpp:544-569: a sync projection above levels 0-1 changes the level-l velocity; the residual of the composite solution
+    // on the boundary nodes of level l goes to the sync register of the interface below (SyncRegister::CompAdd, SyncRegister.cpp:321-348)
+    const bool want_resid = l > 0 && crse_iteration == crse_dt_ratio;
+    MultiFab vold_c;
+    if (want_resid) {
+        c.Vsync.FillBoundary(c.g);
+        vold_c.define(c.layout, cell_type(), 3, 1);
+        MultiFab::Copy(vold_c, c.Vsync, 0, 0, 3, 1);
+    }
     st_sync = composite_project(l, 2, vel, vcomp, phi, sig, &rhnd, 1.e-10 /*sync_tol*/, c.p.proj_abs_tol, true, 0.0);
+    if (want_resid) {
+        MultiFab r = amr_sync_resid(c, vold_c, phi_c, sig_c, false);
+        MultiFab vsf(c.layout, node_type(), 1, 0);                    // CompAdd: zero on the nodes of the coarsened level-(l+1) boxes
+        MultiFab fc = fine_coverage(c.layout, f.layout, c.g, f.ratio);
+        node_class(vsf, fc, c.g);
+        mask_mult(r, 0, 1, vsf, true, 0);
+        c.sync_reg->FineAdd(r, 1.0 / (double)crse_dt_ratio);
+    }
     mf_saxpy(c.P[c.pnew], 1.0, phi_c, 0, 0, 1, 1);
     mf_saxpy(f.P[f.pnew], 1.0, phi_f, 0, 0, 1, 1);
     mf_saxpy(c.S[c.inew], dt, c.Vsync, 0, Xvel, 3, 1);
     mf_saxpy(f.S[f.inew], dt, V_corr, 0, Xvel, 3, 1);
-    if (lev.size() > (size_t)l + 2) throw Error("iamrx AmrNS::level_sync: SyncInterp / SyncProjInterp to levels > level+1 is not implemented");
+    // NavierStokesBase.cpp:2018-2040: the levels above l+1 get the interpolated velocity correction (SyncInterp, increment, x dt) and
+    // pressure correction (SyncProjInterp: node_bilinear_interp of phi, added to P_new AND P_old), then computeGradP at both times
+    int ratio = 1;
+    for (size_t q = (size_t)l + 2; q < lev.size(); ++q) {
+        NavierStokes& ff = *lev[q];
+        ratio *= ff.ratio;
+        MultiFab Vi(ff.layout, cell_type(), 3, 0);
+        sync_interp_cellcons(Vi, 0, V_corr, 0, 3, f.g, ff.g, ratio, f.bc_vel);
+        mf_saxpy(ff.S[ff.inew], dt, Vi, 0, Xvel, 3, 0);
+        MultiFab pi(ff.layout, node_type(), 1, 0);
+        pi.setVal(0.0);
+        node_interp_from_crse(pi, phi_f, f.g, ratio, nullptr, false);
+        for (int w = 0; w < 2; ++w) {
+            mf_saxpy(ff.P[w], 1.0, pi, 0, 0, 1, 0);
+            nodal_mknewu(ff.g, nullptr, 0, ff.P[w], nullptr, &ff.Gp[w], false);          // computeGradP
+            ff.fill_gp(ff.Gp[w], w == ff.pnew ? 0.5 * (ff.pt_new[0] + ff.pt_new[1]) : 0.5 * (ff.pt_old[0] + ff.pt_old[1]));
+        }
+    }
 }
 
 // NavierStokesBase::post_timestep (NavierStokesBase.cpp:2546-2636)
-void AmrNS::post_timestep(int l)
+void AmrNS::post_timestep(int l, int crse_iteration)
 {
     if (l < (int)lev.size() - 1) {
         reflux(l);
         avg_down(l);
         mac_sync(l);
-        level_sync(l);
+        level_sync(l, crse_iteration);
     }
     if (l > 0) mf_saxpy(lev[l]->p_avg, 1.0 / (double)n_cycle[l], lev[l]->P[lev[l]->pnew], 0, 0, 1, 0);      // incrPAvg
 }
@@ -806,7 +888,7 @@ void AmrNS::time_step(int l, double time, int iteration, int niter)
         const int nc = n_cycle[l + 1];
         for (int i = 1; i <= nc; ++i) time_step(l + 1, time + (i - 1) * dt_level[l + 1], i, nc);
     }
-    post_timestep(l);
+    post_timestep(l, iteration);
 }
 
 // NavierStokes::post_init (NavierStokes.cpp:1254-1299) for the hierarchy; S_new of every level holds the initial data

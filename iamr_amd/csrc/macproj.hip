@@ -41,7 +41,8 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
 //   Rhs = Reflux(mr, scale -1) on the coarse cells next to the fine grids, 0 under them;  Rhs.negate();
 //   solve -div(b grad phi) = Rhs with b = (dt/2)/rho_half on faces, no velocity;  Ucorr = -(-b grad phi)
 MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_half, double dt, LayoutP fine_layout, int ratio,
-                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts)
+                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts,
+                       const Geometry* cgeom, int cratio)
 {
     LayoutP layout = mac_sync_phi.layout;
     MultiFab Rhs(layout, cell_type(), 1, 0);
@@ -57,7 +58,8 @@ MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_
     MultiFab um[3];
     MultiFab* ump[3];
     for (int d = 0; d < 3; ++d) { um[d].define(layout, face_type(d), 1, 0); um[d].setVal(0.0); ump[d] = &um[d]; }
-    MGStats st = mlmg_mac_solve(g, ump, rho_half, 0, &Rhs, mac_sync_phi, 2.0 / dt, bc, tol, abs_tol, opts, Ucorr);
+    // on a refined level the coarse/fine faces carry homogeneous Dirichlet data (cphi = null, MacProj.cpp:454-456)
+    MGStats st = mlmg_mac_solve(g, ump, rho_half, 0, &Rhs, mac_sync_phi, 2.0 / dt, bc, tol, abs_tol, opts, Ucorr, nullptr, cgeom, cratio);
     for (int d = 0; d < 3; ++d) mf_mult(*Ucorr[d], -1.0, 0, 1, 0);
     return st;
 }

@@ -45,7 +45,8 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
 class FluxRegister;
 // MacProj::mac_sync_solve (Source/MacProj.cpp:359-470)
 MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_half, double dt, LayoutP fine_layout, int ratio,
-                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts);
+                       MultiFab* const Ucorr[3], MultiFab& mac_sync_phi, const DomainBC& bc, double tol, double abs_tol, const MGOpts& opts,
+                       const Geometry* cgeom = nullptr, int cratio = 2);
 
 // ---- regrid.hip: error estimation + grid generation
 void derive_mag_vort(const Geometry& g, MultiFab& out, int ocomp, const MultiFab& vel, int vcomp);

@@ -677,6 +677,8 @@ static void reflux(orc_amr* a, int lev)
  * ext_dir / extrapolation outside walls) to the cells of the fine level: NavierStokesBase::SyncInterp with cell_cons_interp */
 static orc_fab sync_interp(const orc_ns_state* c, const orc_ns_state* f, const orc_fab* crse, int sc, int nc, const orc_bcrec* bc)
 {
+    int ratio = 1;
+    for (const orc_ns_state* q = f; q != c; q = q->crse) ratio *= q->ratio;
     const orc_geom* cg = &c->g;
     orc_fab cd = orc_alloc(cg->n, ORC_CELL, 2, nc);
     for (int n = 0; n < nc; ++n)
@@ -687,7 +689,7 @@ static orc_fab sync_interp(const orc_ns_state* c, const orc_ns_state* f, const o
     orc_fab fd = orc_alloc(f->g.n, ORC_CELL, 0, nc);
     const int cdomlo[3] = {0, 0, 0}, cdomhi[3] = {cg->n[0] - 1, cg->n[1] - 1, cg->n[2] - 1};
     const int vlo[3] = {1, 1, 1}, vhi[3] = {0, 0, 0};
-    orc_fill_coarse_fine(&fd, fd.lo, fd.hi, vlo, vhi, &cd, cdomlo, cdomhi, cg->periodic, f->ratio, bc);
+    orc_fill_coarse_fine(&fd, fd.lo, fd.hi, vlo, vhi, &cd, cdomlo, cdomhi, cg->periodic, ratio, bc);
     orc_free(&cd);
     return fd;
 }
@@ -709,9 +711,14 @@ static void mac_sync_solve(orc_amr* a, int lev, orc_fab Ucorr[3])
     for (int d = 0; d < 3; ++d) { Ucorr[d] = orc_alloc(g->n, ORC_FACE[d], 1, 1); um[d] = &Ucorr[d]; }
     orc_mg_opts o = c->o; o.maxorder = 4;
     orc_mg_stats st;
-    if (lev != 0) { fprintf(stderr, "orc mac_sync_solve: level > 0 not restated\n"); abort(); }
-    /* mlmg_mac_solve with a null velocity: rhs = S, solve, the returned fluxes -b grad(phi) are the correction; IAMR negates them */
-    orc_mac_project(g, um, &c->rho_half, &Rhs, &c->mac_phi, 2.0 / dt, c->lobc, c->hibc, 1.e-10 /*mac_sync_tol, MacProj.cpp:44*/, c->p.mac_abs_tol, &o, &st);
+    /* mlmg_mac_solve with a null velocity: rhs = S, solve, the returned fluxes -b grad(phi) are the correction; IAMR negates them.
+     * On a refined level cphi is null (MacProj.cpp:454-456): homogeneous Dirichlet data on the coarse/fine faces */
+    if (lev == 0) orc_mac_project(g, um, &c->rho_half, &Rhs, &c->mac_phi, 2.0 / dt, c->lobc, c->hibc, 1.e-10 /*mac_sync_tol, MacProj.cpp:44*/, c->p.mac_abs_tol, &o, &st);
+    else {
+        orc_fab zero = orc_alloc(c->crse->g.n, ORC_CELL, 1, 1);
+        orc_mac_project_cf(g, um, &c->rho_half, &Rhs, &c->mac_phi, 2.0 / dt, c->lobc, c->hibc, c->nbox, c->boxes, c->ratio, &zero, 1.e-10, c->p.mac_abs_tol, &o, &st);
+        orc_free(&zero);
+    }
     for (int d = 0; d < 3; ++d) {
         const size_t N = orc_npts(&Ucorr[d]);
         for (size_t q = 0; q < N; ++q) Ucorr[d].p[q] = -Ucorr[d].p[q];
@@ -796,7 +803,6 @@ static void mac_sync(orc_amr* a, int lev)
     /* interpolate the sync correction to the finer levels (:1697-1725) */
     for (int fl = lev + 1; fl < a->nlev; ++fl) {
         orc_ns_state* f = a->lev[fl];
-        if (fl != lev + 1) { fprintf(stderr, "orc mac_sync: SyncInterp over more than one level not restated\n"); abort(); }
         orc_fab incr = sync_interp(c, f, &c->Ssync, 0, numscal, c->bc_scal);
         const orc_geom* fg = &f->g;
         orc_fab* Sf = S_NEW(f);
@@ -812,11 +818,10 @@ static void mac_sync(orc_amr* a, int lev)
 /* NavierStokesBase::level_sync (NavierStokesBase.cpp:1927-2044) + Projection::MLsyncProject (Projection.cpp:457-607) */
 static void level_sync(orc_amr* a, int lev, int crse_iteration)
 {
-    (void)crse_iteration;
     orc_ns_state *c = a->lev[lev], *f = a->lev[lev + 1];
     const orc_geom *g = &c->g, *fg = &f->g;
     const double dt = a->dt_level[lev];
-    if (lev > 0) { fprintf(stderr, "orc level_sync: level > 0 (CompAdd) not restated\n"); abort(); }
+    const int crse_dt_ratio = a->n_cycle[lev];
     orc_fill_periodic(&c->Vsync, g, ORC_CELL);
     /* SyncInterp(Vsync -> V_corr), increment = 0 */
     orc_fab Vc = sync_interp(c, f, &c->Vsync, 0, 3, c->bc_vel);
@@ -844,7 +849,27 @@ static void level_sync(orc_amr* a, int lev, int crse_iteration)
     orc_fab* vel[2] = {&c->Vsync, &V_corr};
     orc_fab* phi[2] = {&phi_c, &phi_f};
     const orc_fab* sig[2] = {&sig_c, &sig_f};
+    /* Projection.cpp:544-569: a sync projection that is not at levels 0-1 changes the level-c velocity; that change enters the sync
+     * register of the interface below through the residual of the composite solution on the boundary nodes of level c */
+    const int want_resid = lev > 0 && crse_iteration == crse_dt_ratio;
+    orc_fab vold_c; vold_c.p = NULL;
+    if (want_resid) {
+        orc_fill_periodic(&c->Vsync, g, ORC_CELL);
+        vold_c = orc_alloc(g->n, ORC_CELL, 1, 3);
+        orc_copy_all(&vold_c, &c->Vsync);
+    }
     amr_composite_project(a, lev, 2, vel, phi, sig, &rhnd, 1.e-10 /*sync_tol, Projection.cpp:27*/, c->p.proj_abs_tol, 1, 0.0, &a->st_sync);
+    if (want_resid) {
+        /* SyncRegister::CompAdd (SyncRegister.cpp:321-348): zero under the boxes of level lev+1, then FineAdd with 1/crse_dt_ratio.
+         * The residual lives on the boundary of level c, which the next finer level never touches (proper nesting). */
+        orc_fab sg1 = orc_alloc(g->n, ORC_CELL, 1, 1);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&sg1, i, j, k, 0) = A4(&sig_c, i, j, k, 0);
+        orc_fab r = amr_sync_resid_fine(c, &vold_c, &phi_c, &sg1);
+        for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+            if (node_vs_fine(f, i, j, k) != 0) A4(&r, i, j, k, 0) = 0.0;
+        syncreg_fine_add(c, &r, 1.0 / (double)crse_dt_ratio);
+        orc_free(&r); orc_free(&sg1); orc_free(&vold_c);
+    }
     /* add phi to the pressures (with ghost nodes), the projected corrections to the velocities (1 ghost) */
     { const size_t N = orc_npts(P_NEW(c)); for (size_t q = 0; q < N; ++q) P_NEW(c)->p[q] += phi_c.p[q]; }
     { const size_t N = orc_npts(P_NEW(f)); for (size_t q = 0; q < N; ++q) P_NEW(f)->p[q] += phi_f.p[q]; }
@@ -852,7 +877,42 @@ static void level_sync(orc_amr* a, int lev, int crse_iteration)
         for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) A4(S_NEW(c), i, j, k, n) += dt * A4(&c->Vsync, i, j, k, n);
         for (int k = -1; k <= fg->n[2]; ++k) for (int j = -1; j <= fg->n[1]; ++j) for (int i = -1; i <= fg->n[0]; ++i) A4(S_NEW(f), i, j, k, n) += dt * A4(&V_corr, i, j, k, n);
     }
-    if (a->nlev > lev + 2) { fprintf(stderr, "orc level_sync: SyncInterp / SyncProjInterp to levels > level+1 not restated\n"); abort(); }
+    /* NavierStokesBase.cpp:2018-2040: levels above lev+1 get the interpolated velocity correction (SyncInterp, increment = 1, x dt) and
+     * pressure correction (SyncProjInterp: node_bilinear_interp of phi, added to P_new AND P_old), then computeGradP at both times */
+    for (int l2 = lev + 2; l2 < a->nlev; ++l2) {
+        orc_ns_state* ff = a->lev[l2];
+        const orc_geom* gg = &ff->g;
+        orc_fab Vi = sync_interp(f, ff, &V_corr, 0, 3, f->bc_vel);
+        int ratio = 1;
+        for (const orc_ns_state* q = ff; q != f; q = q->crse) ratio *= q->ratio;
+        for (int n = 0; n < 3; ++n)
+        for (int k = 0; k < gg->n[2]; ++k) for (int j = 0; j < gg->n[1]; ++j) for (int i = 0; i < gg->n[0]; ++i)
+            if (A4(&ff->cov, i, j, k, 0) != 0.0) A4(S_NEW(ff), i, j, k, n) += dt * A4(&Vi, i, j, k, n);
+        orc_free(&Vi);
+        orc_nodal_fill_bc(fg, &phi_f, f->nlobc, f->nhibc);
+        for (int k = 0; k <= gg->n[2]; ++k) for (int j = 0; j <= gg->n[1]; ++j) for (int i = 0; i <= gg->n[0]; ++i) {
+            if (node_class(ff, i, j, k) == ND_NONE) continue;
+            const int fi[3] = {i, j, k};
+            int c0[3]; double w[3];
+            for (int d = 0; d < 3; ++d) { c0[d] = fi[d] / ratio; w[d] = (double)(fi[d] - c0[d] * ratio) / (double)ratio; }
+            double v = 0.0;
+            for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+                const double ww = (cx ? w[0] : 1.0 - w[0]) * (cy ? w[1] : 1.0 - w[1]) * (cz ? w[2] : 1.0 - w[2]);
+                if (ww != 0.0) v += ww * A4(&phi_f, c0[0] + cx, c0[1] + cy, c0[2] + cz, 0);
+            }
+            A4(P_NEW(ff), i, j, k, 0) += v; A4(P_OLD(ff), i, j, k, 0) += v;
+        }
+        for (int which = 0; which < 2; ++which) {            /* computeGradP(prevTime), computeGradP(curTime) */
+            orc_fab* G = which ? GP_NEW(ff) : GP_OLD(ff);
+            orc_fab gp = orc_alloc(gg->n, ORC_CELL, 0, 3);
+            orc_nodal_compgrad(gg, &gp, which ? P_NEW(ff) : P_OLD(ff));
+            for (int n = 0; n < 3; ++n)
+            for (int k = 0; k < gg->n[2]; ++k) for (int j = 0; j < gg->n[1]; ++j) for (int i = 0; i < gg->n[0]; ++i)
+                if (A4(&ff->cov, i, j, k, 0) != 0.0) A4(G, i, j, k, n) = A4(&gp, i, j, k, n);
+            orc_free(&gp);
+            ns_fill_gp(ff, G, which ? 0.5 * (ff->pt_new[0] + ff->pt_new[1]) : 0.5 * (ff->pt_old[0] + ff->pt_old[1]));
+        }
+    }
     orc_free(&V_corr); orc_free(&phi_c); orc_free(&phi_f); orc_free(&rhnd); orc_free(&sig_c); orc_free(&sig_f);
 }
 

@@ -116,3 +116,32 @@ def test_stop_time_is_hit_exactly():
         L.orc_ns_step(ns)
     assert L.orc_ns_time(ns) == stop
     L.orc_ns_destroy(ns)
+
+
+def test_three_level_uniform_flow_and_conservation():
+    """three levels (sync operations on a refined level: mac_sync_solve with homogeneous coarse/fine data, CompAdd, SyncInterp with
+    the accumulated ratio 4, SyncProjInterp): the uniform flow stays uniform to round-off and the tracer blob crossing both
+    interfaces keeps its composite mass"""
+    a = orc.OrcAmr(orc.geom([8] * 3), orc.ns_params(cfl=0.7, init_iter=2), orc.mg_opts(),
+                   [[], [([2, 2, 2], [13, 13, 13])], [([10, 10, 10], [21, 21, 21])]])
+    for l in range(3):
+        a.set_state(l, _uniform(*a.cell_centres(l)))
+
+    def comp(c):
+        tot = 0.0
+        for l in range(3):
+            m = a.cov(l).copy()
+            if l < 2:
+                m &= ~a.cov(l + 1)[::2, ::2, ::2]
+            tot += (a.state(l)[..., c] * m).sum() * np.prod(a.dx(l))
+        return tot
+    a.post_init()
+    m0 = comp(4)
+    for _ in range(2):
+        a.step()
+    for l in range(3):
+        S, c = a.state(l), a.cov(l)
+        for q, v in enumerate((1.0, 0.5, 0.25, 1.0)):
+            assert abs(S[..., q] - v)[c].max() < 1e-13
+        assert abs(a.fab(l, 2).a).max() < 1e-12
+    assert abs(comp(4) - m0) < 1e-14 and abs(comp(3) - 1.0) < 1e-14
