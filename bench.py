@@ -377,7 +377,7 @@ def main():
             "kernels": kr,
             "roofline": roofline,
         }
-        if world == 1 and a.amr_n > 0:
+        if world == 1 and a.amr_n > 0 and a.amr_steps > 0:
             out["amr"] = amr_workload(lib, a.amr_n, a.amr_steps)
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())

@@ -224,22 +224,29 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
 }
 
 template <int TX, int TY, int NT, bool WRAP, bool MASK, bool CSIG>
+// no minimum-occupancy bound: measured at 256^3 on MI355X (profiles/round2_b_*), forcing 4 waves/SIMD on the variable-sigma variant (168 VGPRs
+// -> 128 + 41 spilled) costs 2x (325 us against 165 us per launch), 5-6 on the constant-sigma one (104 VGPRs) gains nothing / loses 35 %
 __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk,
-    const FabD* __restrict__ dmt, double csig)
+    const FabD* __restrict__ dmt, double csig, int ppc)
 {
+    // A workgroup owns one TXxTY tile and marches through ppc consecutive planes of its parity (k, k+2, ...).  Plane k+1 staged
+    // for plane k is the k-1 plane of the next one and stays in LDS (two x planes loaded per plane instead of three); the loads of
+    // the next plane are issued BEFORE the four colour passes of the current one and land in registers while those run, so the
+    // global-load latency that bounded the one-plane-per-workgroup version is hidden behind the LDS phase.
     // LDS rows are stored parity-split: column lx lives at (lx&1)*HX + (lx>>1).  A colour pass touches every second
     // column, so its 64 lanes then read consecutive doubles (no bank conflicts) instead of a stride-2 pattern.
     constexpr int RX = TX + 8, RY = TY + 8, HX = RX / 2, PX = RX + 2;   // PX: padded row pitch
-    __shared__ double X[3][RY][PX];
+    constexpr int PL = RY * PX;                                         // one staged plane
+    __shared__ double Xf[3 * PL];
     // CSIG: sigma is one constant on the whole level (constant-density flow): no sigma planes in LDS (24 KB per workgroup: 6 per CU)
-    __shared__ double S[CSIG ? 1 : 2][CSIG ? 1 : RY][CSIG ? 1 : PX];
+    __shared__ double Sf[CSIG ? 1 : 2 * PL];
     const int fab = blockIdx.y;
     const BoxD cb = boxes[fab];
     int tix, tiy, pk;
     if (xcd_chunk > 0) {
-        // XCD-aware order (workgroup b runs on XCD b % 8, speed only): every XCD sweeps its own contiguous slab of tiles plane
-        // by plane, so the halo overlap of neighbouring tiles and the k+-1 planes shared by consecutive planes stay in its L2
+        // XCD-aware order (workgroup b runs on XCD b % 8, speed only): every XCD sweeps its own contiguous slab of tiles chunk
+        // by chunk, so the halo overlap of neighbouring tiles stays in its L2
         const int q = blockIdx.x & 7, m = blockIdx.x >> 3;
         const int nt = ntx * nty;
         const int tlo = (q * nt) >> 3, cnt = (((q + 1) * nt) >> 3) - tlo;
@@ -254,10 +261,11 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
         tiy = r1 % nty; pk = r1 / nty;
     }
     const int kfirst = cb.lo[2] + (((cb.lo[2] & 1) != kpar) ? 1 : 0);
-    const int k = kfirst + 2 * pk;
+    const int k0 = kfirst + 2 * pk * ppc;
     const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;   // last valid node
     const int tx0 = cb.lo[0] + tix * TX, ty0 = cb.lo[1] + tiy * TY;
-    if (k > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
+    if (k0 > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
+    const int kend = min(k0 + 2 * (ppc - 1), nhi2);                            // last plane of the chunk is the last k <= kend of the parity
     const int txe = min(tx0 + TX - 1, nhi0), tye = min(ty0 + TY - 1, nhi1);
     const FabD x = xct[fab], xn = xnt[fab], xo = xot[fab], r = rt[fab], s = st[fab];
     const int ox = tx0 - 4, oy = ty0 - 4;
@@ -265,9 +273,13 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 #define COL(lx) ((((lx) & 1) * HX) + ((lx) >> 1))
     // colour pass c updates the tile grown by 3 - c nodes; every thread owns at most one node of a pass
     static_assert(((TX + 7) / 2) * ((TY + 7) / 2) <= NT, "one node per thread and colour pass");
-    int pi[4], pj[4];
+    int q0[4], qm[4];     // LDS offsets of the node of this thread in pass c (row * PX + column) and of its lx-1 neighbour (lx+1 sits at qm + 1); q0 < 0: none
+    int roff[4], doff[4]; // offsets of that node in plane 0 of the right-hand side / the Dirichlet mask
     double rr[4];
     bool fixed[4];        // MASK: the node of this thread in pass c is a Dirichlet node (keeps its value)
+    const int rks = r.n[0] * r.n[1];
+    int dks = 0;
+    if constexpr (MASK) dks = dmt[fab].n[0] * dmt[fab].n[1];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int cx = c & 1, cy = c >> 1, g = 3 - c;
@@ -275,88 +287,137 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
         const int i0 = rlo0 + (((rlo0 & 1) != cx) ? 1 : 0), j0 = rlo1 + (((rlo1 & 1) != cy) ? 1 : 0);
         const int ni = i0 > rhi0 ? 0 : ((rhi0 - i0) >> 1) + 1, nj = j0 > rhi1 ? 0 : ((rhi1 - j0) >> 1) + 1;
         const bool on = tid < ni * nj;
-        pi[c] = on ? i0 + 2 * (tid % max(ni, 1)) : INT_MIN;
-        pj[c] = j0 + 2 * (tid / max(ni, 1));
+        const int pi = i0 + 2 * (tid % max(ni, 1)), pj = j0 + 2 * (tid / max(ni, 1));
+        const int lx = pi - ox, ly = pj - oy;
+        q0[c] = on ? ly * PX + COL(lx) : -1;
+        qm[c] = ly * PX + COL(lx - 1);
         // right-hand side of the node: straight to a register (issued together with the staging loads below)
-        int ri = on ? pi[c] : tx0, rj = on ? pj[c] : ty0;
+        int ri = on ? pi : tx0, rj = on ? pj : ty0;
         if constexpr (WRAP) { ri = wrap_node(ri, cb.lo[0], cb.hi[0]); rj = wrap_node(rj, cb.lo[1], cb.hi[1]); }
-        rr[c] = r(ri, rj, k);
-        if constexpr (MASK) fixed[c] = dmt[fab](ri, rj, k) != 0.0; else fixed[c] = false;
+        roff[c] = (int)r.off(ri, rj, r.lo[2]);
+        rr[c] = r.gp()[roff[c] + (long)(k0 - r.lo[2]) * rks];
+        if constexpr (MASK) {
+            doff[c] = (int)dmt[fab].off(ri, rj, dmt[fab].lo[2]);
+            fixed[c] = dmt[fab].gp()[doff[c] + (long)(k0 - dmt[fab].lo[2]) * dks] != 0.0;
+        } else { doff[c] = 0; fixed[c] = false; }
     }
+    // footprint point of this thread in staging round `it`: array offsets (indices clamped into the arrays instead of predicated --
+    // footprint points beyond the ghost width are never used by the colour passes) and LDS slot.  32-bit offsets: the launcher
+    // checks that the arrays hold fewer than 2^31 values
+    constexpr int NLD = (RX * RY + NT - 1) / NT;
+    int xoff[NLD], soff[NLD];            // offsets of (xi, xj, plane 0) in the x arrays (xc, xn and xo share one shape) and in sigma
+    int lslot[NLD];
+    const int xks = x.n[0] * x.n[1], sks = s.n[0] * s.n[1];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = min(tid + it * NT, RX * RY - 1);
+        const int lx = idx % RX, ly = idx / RX;
+        const int gi = ox + lx, gj = oy + ly;
+        int xi, xj, si, sj;
+        if constexpr (WRAP) {
+            // the box spans the periodic domain: a ghost index is the periodic image of a valid index of the SAME box, so the
+            // staging reads the valid data directly and no ghost fill is needed (node hi+1 duplicates node lo)
+            xi = wrap_node(gi, cb.lo[0], cb.hi[0]); xj = wrap_node(gj, cb.lo[1], cb.hi[1]);
+            si = wrap_cell(gi, cb.lo[0], cb.hi[0]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]);
+        } else {
+            xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
+            si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
+        }
+        xoff[it] = (int)x.off(xi, xj, x.lo[2]);
+        soff[it] = CSIG ? 0 : (int)s.off(si, sj, s.lo[2]);
+        lslot[it] = (tid + it * NT < RX * RY) ? ly * PX + COL(lx) : -1;
+    }
+    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_node(kk, cb.lo[2], cb.hi[2]); return (long)(kk - x.lo[2]) * xks; };
+    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_cell(kk, cb.lo[2], cb.hi[2]); return (long)(kk - s.lo[2]) * sks; };
+    double* Xm = Xf;                   // plane k-1
+    double* Xc = Xf + PL;              // plane k (updated in place)
+    double* Xp = Xf + 2 * PL;          // plane k+1
     {
-        // stage the footprint: all global loads are issued before the first LDS store (addresses are clamped into the
-        // arrays instead of predicated -- footprint points beyond the ghost width are never used by the colour passes)
-        constexpr int NLD = (RX * RY + NT - 1) / NT;
+        // stage the first plane: all global loads are issued before the first LDS store
         double v[NLD][CSIG ? 3 : 5];
+        const auto *pm = xn.gp() + xk(k0 - 1), *pc = x.gp() + xk(k0), *pp = xn.gp() + xk(k0 + 1);
+        const auto *ps0 = s.gp() + sk(k0 - 1), *ps1 = s.gp() + sk(k0);
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int idx = min(tid + it * NT, RX * RY - 1);
-            const int lx = idx % RX, ly = idx / RX;
-            const int gi = ox + lx, gj = oy + ly;
-            int xi, xj, si, sj, xkm = k - 1, xkp = k + 1, skm = k - 1, sk0 = k;
-            if constexpr (WRAP) {
-                // the box spans the periodic domain: a ghost index is the periodic image of a valid index of the SAME box, so the
-                // staging reads the valid data directly and no ghost fill is needed (node hi+1 duplicates node lo)
-                xi = wrap_node(gi, cb.lo[0], cb.hi[0]); xj = wrap_node(gj, cb.lo[1], cb.hi[1]);
-                si = wrap_cell(gi, cb.lo[0], cb.hi[0]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]);
-                xkm = wrap_node(k - 1, cb.lo[2], cb.hi[2]); xkp = wrap_node(k + 1, cb.lo[2], cb.hi[2]);
-                skm = wrap_cell(k - 1, cb.lo[2], cb.hi[2]); sk0 = wrap_cell(k, cb.lo[2], cb.hi[2]);
-            } else {
-                xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
-                si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
-            }
-            v[it][0] = xn(xi, xj, xkm);
-            v[it][1] = x(xi, xj, k);
-            v[it][2] = xn(xi, xj, xkp);
-            if constexpr (!CSIG) {
-                v[it][3] = s(si, sj, skm);
-                v[it][4] = s(si, sj, sk0);
-            }
+            v[it][0] = pm[xoff[it]];
+            v[it][1] = pc[xoff[it]];
+            v[it][2] = pp[xoff[it]];
+            if constexpr (!CSIG) { v[it][3] = ps0[soff[it]]; v[it][4] = ps1[soff[it]]; }
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int idx = tid + it * NT;
-            if (idx < RX * RY) {
-                const int lx = idx % RX, ly = idx / RX;
-                const int cl = COL(lx);
-                X[0][ly][cl] = v[it][0]; X[1][ly][cl] = v[it][1]; X[2][ly][cl] = v[it][2];
-                if constexpr (!CSIG) { S[0][ly][cl] = v[it][3]; S[1][ly][cl] = v[it][4]; }
+            if (lslot[it] >= 0) {
+                Xm[lslot[it]] = v[it][0]; Xc[lslot[it]] = v[it][1]; Xp[lslot[it]] = v[it][2];
+                if constexpr (!CSIG) { Sf[lslot[it]] = v[it][3]; Sf[PL + lslot[it]] = v[it][4]; }
             }
         }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (pi[c] != INT_MIN && !(MASK && fixed[c])) {
-            const int i = pi[c], j = pj[c];
-            const int lx = i - ox, ly = j - oy;
-            const int c0 = COL(lx), cm = COL(lx - 1), cp = COL(lx + 1);
-            // CSIG: the same expression tree on eight copies of the constant -- bit-identical to the variable-sigma path
-            double smmm, spmm, smpm, sppm, smmp, spmp, smpp, sppp;
-            if constexpr (CSIG) { smmm = spmm = smpm = sppm = smmp = spmp = smpp = sppp = csig; }
-            else {
-                smmm = S[0][ly - 1][cm]; spmm = S[0][ly - 1][c0]; smpm = S[0][ly][cm]; sppm = S[0][ly][c0];
-                smmp = S[1][ly - 1][cm]; spmp = S[1][ly - 1][c0]; smpp = S[1][ly][cm]; sppp = S[1][ly][c0];
-            }
-            const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
-            const double xc = X[1][ly][c0];
-            double y = xc * s0;
-            y += w.corner * (X[0][ly - 1][cm] * smmm + X[0][ly - 1][cp] * spmm + X[0][ly + 1][cm] * smpm + X[0][ly + 1][cp] * sppm
-                           + X[2][ly - 1][cm] * smmp + X[2][ly - 1][cp] * spmp + X[2][ly + 1][cm] * smpp + X[2][ly + 1][cp] * sppp);
-            y += w.ex * (X[0][ly - 1][c0] * (smmm + spmm) + X[0][ly + 1][c0] * (smpm + sppm) + X[2][ly - 1][c0] * (smmp + spmp) + X[2][ly + 1][c0] * (smpp + sppp));
-            y += w.ey * (X[0][ly][cm] * (smmm + smpm) + X[0][ly][cp] * (spmm + sppm) + X[2][ly][cm] * (smmp + smpp) + X[2][ly][cp] * (spmp + sppp));
-            y += w.ez * (X[1][ly - 1][cm] * (smmm + smmp) + X[1][ly - 1][cp] * (spmm + spmp) + X[1][ly + 1][cm] * (smpm + smpp) + X[1][ly + 1][cp] * (sppm + sppp));
-            y += w.fx * (X[1][ly][cm] * (smmm + smpm + smmp + smpp) + X[1][ly][cp] * (spmm + sppm + spmp + sppp));
-            y += w.fy * (X[1][ly - 1][c0] * (smmm + spmm + smmp + spmp) + X[1][ly + 1][c0] * (smpm + sppm + smpp + sppp));
-            y += w.fz * (X[0][ly][c0] * (smmm + spmm + smpm + sppm) + X[2][ly][c0] * (smmp + spmp + smpp + sppp));
-            X[1][ly][c0] = xc + (rr[c] - y) / s0;
-        }
-        __syncthreads();
     }
     const int wx = txe - tx0 + 1, wy = tye - ty0 + 1;
-    for (int idx = tid; idx < wx * wy; idx += NT) {
-        const int i = tx0 + idx % wx, j = ty0 + idx / wx;
-        xo(i, j, k) = X[1][j - oy][COL(i - ox)];
+    for (int k = k0;; k += 2) {
+        const bool has_next = k + 2 <= kend;
+        // prefetch of plane k+2 (own plane from xc, its k+3 neighbour from xn, sigma cell planes k+1 and k+2, right-hand side)
+        double nv[NLD][CSIG ? 2 : 4], rrn[4];
+        bool fixedn[4];
+        if (has_next) {
+            const auto *pc = x.gp() + xk(k + 2), *pp = xn.gp() + xk(k + 3);
+            const auto *ps0 = s.gp() + sk(k + 1), *ps1 = s.gp() + sk(k + 2);
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                nv[it][0] = pc[xoff[it]];
+                nv[it][1] = pp[xoff[it]];
+                if constexpr (!CSIG) { nv[it][2] = ps0[soff[it]]; nv[it][3] = ps1[soff[it]]; }
+            }
+            const auto* pr = r.gp() + (long)(k + 2 - r.lo[2]) * rks;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                rrn[c] = pr[roff[c]];
+                if constexpr (MASK) fixedn[c] = dmt[fab].gp()[doff[c] + (long)(k + 2 - dmt[fab].lo[2]) * dks] != 0.0; else fixedn[c] = false;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (q0[c] >= 0 && !(MASK && fixed[c])) {
+                const int a0 = q0[c], am = qm[c], ap = am + 1;          // row r0: columns c0, cm, cp
+                // CSIG: the same expression tree on eight copies of the constant -- bit-identical to the variable-sigma path
+                double smmm, spmm, smpm, sppm, smmp, spmp, smpp, sppp;
+                if constexpr (CSIG) { smmm = spmm = smpm = sppm = smmp = spmp = smpp = sppp = csig; }
+                else {
+                    smmm = Sf[am - PX]; spmm = Sf[a0 - PX]; smpm = Sf[am]; sppm = Sf[a0];
+                    smmp = Sf[PL + am - PX]; spmp = Sf[PL + a0 - PX]; smpp = Sf[PL + am]; sppp = Sf[PL + a0];
+                }
+                const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+                const double xc = Xc[a0];
+                double y = xc * s0;
+                y += w.corner * (Xm[am - PX] * smmm + Xm[ap - PX] * spmm + Xm[am + PX] * smpm + Xm[ap + PX] * sppm
+                               + Xp[am - PX] * smmp + Xp[ap - PX] * spmp + Xp[am + PX] * smpp + Xp[ap + PX] * sppp);
+                y += w.ex * (Xm[a0 - PX] * (smmm + spmm) + Xm[a0 + PX] * (smpm + sppm) + Xp[a0 - PX] * (smmp + spmp) + Xp[a0 + PX] * (smpp + sppp));
+                y += w.ey * (Xm[am] * (smmm + smpm) + Xm[ap] * (spmm + sppm) + Xp[am] * (smmp + smpp) + Xp[ap] * (spmp + sppp));
+                y += w.ez * (Xc[am - PX] * (smmm + smmp) + Xc[ap - PX] * (spmm + spmp) + Xc[am + PX] * (smpm + smpp) + Xc[ap + PX] * (sppm + sppp));
+                y += w.fx * (Xc[am] * (smmm + smpm + smmp + smpp) + Xc[ap] * (spmm + sppm + spmp + sppp));
+                y += w.fy * (Xc[a0 - PX] * (smmm + spmm + smmp + spmp) + Xc[a0 + PX] * (smpm + sppm + smpp + sppp));
+                y += w.fz * (Xm[a0] * (smmm + spmm + smpm + sppm) + Xp[a0] * (smmp + spmp + smpp + sppp));
+                Xc[a0] = xc + (rr[c] - y) / s0;
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < wx * wy; idx += NT) {
+            const int i = tx0 + idx % wx, j = ty0 + idx / wx;
+            xo(i, j, k) = Xc[(j - oy) * PX + COL(i - ox)];
+        }
+        if (!has_next) break;
+        __syncthreads();                 // the write-out above still reads Xc
+        // rotate: k+1 becomes the k-1 plane, the prefetched planes take the two freed buffers
+        double* t = Xm; Xm = Xp; Xp = Xc; Xc = t;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            if (lslot[it] >= 0) {
+                Xc[lslot[it]] = nv[it][0]; Xp[lslot[it]] = nv[it][1];
+                if constexpr (!CSIG) { Sf[lslot[it]] = nv[it][2]; Sf[PL + lslot[it]] = nv[it][3]; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { rr[c] = rrn[c]; fixed[c] = fixedn[c]; }
     }
 #undef COL
 }
@@ -396,8 +457,17 @@ template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
                        int kpar, bool wrap, const MultiFab* dmask, const double* csig)
 {
-    const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl = (l.max_len[2] + 1 + 1) / 2 + 1;
+    const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
+    // planes per workgroup (z-march): as long as the launch still fills the chip about twice over (256 CUs x 4-6 resident workgroups)
+    static const int ppc_env = getenv("IAMRX_GS4_PPC") ? atoi(getenv("IAMRX_GS4_PPC")) : 0;
+    static const long wg_target = getenv("IAMRX_GS4_WGS") ? atol(getenv("IAMRX_GS4_WGS")) : 2048;
+    int ppc = ppc_env > 0 ? ppc_env : (int)std::max<long>(1, std::min<long>(16, (long)nt * l.nlocal() * npl_all / wg_target));
+    const int npl = (npl_all + ppc - 1) / ppc;             // chunks per tile
+    for (int f = 0; f < l.nlocal(); ++f) {                  // the kernel indexes with 32-bit offsets
+        const BoxD& b = l.boxes[l.local[f]];
+        IAMRX_ASSERT((long)(b.len(0) + 1 + 2 * xc.ngrow) * (b.len(1) + 1 + 2 * xc.ngrow) * (b.len(2) + 1 + 2 * xc.ngrow) < 2147483647L);
+    }
     static const bool xcd_aware = !(getenv("IAMRX_XCD_AWARE") && atoi(getenv("IAMRX_XCD_AWARE")) == 0);
     int xcd_chunk = 0;
     unsigned gx = (unsigned)(nt * npl);
@@ -418,7 +488,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
         IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].first, Context::get().stream));
     }
 #define IAMRX_GS4(W, M, C) hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
-                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
+                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0, ppc)
     if (dmask) {
         IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
         IAMRX_GS4(false, true, false);

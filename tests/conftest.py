@@ -36,3 +36,17 @@ def godunov_same(got, ref, tag=None, rel=1e-13):
     else:
         err = float(np.abs(got - ref).max())
         assert err <= rel * max(1.0, float(np.abs(ref).max())), (tag, err)
+
+
+@pytest.fixture(autouse=True)
+def _plm_by_default(request):
+    """the reconstruction switch of the Godunov kernels (iamrx_godunov_set_ppm / orc_godunov_set_ppm) is process-wide state that the
+    level drivers set from ns.use_ppm at every advance; tests of the raw Godunov entry points expect PLM unless they ask for PPM"""
+    if "gpu" in request.keywords:
+        from iamr_amd import lib
+        if lib._initialized:
+            lib.check(lib.lib().iamrx_godunov_set_ppm(0))
+        import orc as _orc
+        if getattr(_orc, "_LIB", None) is not None:
+            _orc.lib().orc_godunov_set_ppm(0)
+    yield
