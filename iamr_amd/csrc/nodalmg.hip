@@ -279,7 +279,7 @@ void NodalMG::vcycle(MGStats& st)
     for (int l = 0; l < nl - 1; ++l) {
         Level& L = m_lev[l];
         L.cor.setVal(0.0);
-        for (int i = 0; i < m_o.nu1; ++i) smooth(l, L.cor, L.res);
+        for (int i = 0; i < m_o.nodal_nu1; ++i) smooth(l, L.cor, L.res);
         residual(l, L.rescor, L.cor, L.res);
         fillbc(l, L.rescor);
         if (m_lev[l + 1].agg) {
@@ -320,7 +320,7 @@ void NodalMG::vcycle(MGStats& st)
         } else
         nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
         if (L.dmask()) nodal_zero_masked(L.cor, L.dm);                  // mlndlap_interpadd: Dirichlet nodes take no correction
-        for (int i = 0; i < m_o.nu2; ++i) smooth(l, L.cor, L.res);
+        for (int i = 0; i < m_o.nodal_nu2; ++i) smooth(l, L.cor, L.res);
     }
 }
 

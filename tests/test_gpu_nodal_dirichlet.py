@@ -51,7 +51,7 @@ def run_both(orc, lib, n, per, lobc, hibc, boxes, owners_cov, seed, fixed_iters=
     sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global(sig.a, sig.lo)
     rhs_d = lib.MultiFab(lay, lib.NODE, 1, 0); rhs_d.set_from_global(rhs.a, rhs.lo)
     phi_d = lib.MultiFab(lay, lib.NODE, 1, 1); phi_d.set_from_global(phi.a, phi.lo)
-    st_d = N.nodal_solve(g_d, phi_d, rhs_d, sig_d, 0, lobc, hibc, rtol, 0.0, lib.mg_opts(fixed_iters=fixed_iters))
+    st_d = N.nodal_solve(g_d, phi_d, rhs_d, sig_d, 0, lobc, hibc, rtol, 0.0, lib.mg_opts(fixed_iters=fixed_iters, **orc.UPSTREAM_NODAL_CYCLE))
     # oracle with the same multigrid depth
     o = orc.mg_opts(fixed_iters=fixed_iters, max_coarsening_level=st_d.nlevels - 1)
     st_o = orc.CMgStats()
@@ -146,7 +146,7 @@ def test_nodal_projection_on_a_refined_level(orc, gpu, case):
     vel_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel_d.set_from_global(vel.a, vel.lo)
     sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global(sig.a, sig.lo)
     phi_d = lib.MultiFab(lay, lib.NODE, 1, 1); phi_d.setval(0.0)
-    st_d = N.nodal_projection(g_d, vel_d, 0, phi_d, sig_d, 0, P, P, 1e-11, 0.0)
+    st_d = N.nodal_projection(g_d, vel_d, 0, phi_d, sig_d, 0, P, P, 1e-11, 0.0, opts=lib.mg_opts(**orc.UPSTREAM_NODAL_CYCLE))
     o = orc.mg_opts(max_coarsening_level=st_d.nlevels - 1)
     st_o = orc.CMgStats()
     L.orc_nodal_project_cov(C.byref(g_o), vel.ref(), phi.ref(), sig.ref(), orc.i3(P), orc.i3(P), cov.ref(), C.c_double(1e-11), C.c_double(0.0),

@@ -55,7 +55,7 @@ def test_nodal_operator_and_projection(orc, gpu):
     L.orc_nodal_project(C.byref(g_o), v_o.ref(), p_o.ref(), sig.ref(), z3, z3, C.c_double(1e-12), C.c_double(1e-16), C.byref(oo), C.byref(st_o))
     p_d = lib.MultiFab(lay, lib.NODE, 1, 1); p_d.setval(0.0)
     gp_d = lib.MultiFab(lay, lib.CELL, 3, 1)
-    st = N.nodal_projection(g_d, vel_d, 0, p_d, sig_d, 0, gp=gp_d)
+    st = N.nodal_projection(g_d, vel_d, 0, p_d, sig_d, 0, gp=gp_d, opts=lib.mg_opts(**orc.UPSTREAM_NODAL_CYCLE))
     assert st.converged == 1 and st.iters == st_o.iters
     pg = p_d.gather_valid(n)[..., 0]; pr = p_o.valid(n, orc.NODE)[..., 0]
     assert np.abs((pg - pg.mean()) - (pr - pr.mean())).max() <= 1e-9 * np.abs(pr).max()

@@ -24,6 +24,6 @@ for label, kw in cfgs:
     vel.from_numpy(a)
     phi = lib.MultiFab(lay, lib.NODE, 1, 1); phi.setval(0.0)
     lib.sync(); t0 = time.perf_counter()
-    st = N.nodal_projection(g, vel, 0, phi, sig, opts=lib.mg_opts(**kw))
+    st = N.nodal_projection(g, vel, 0, phi, sig, rel_tol=1e-11, opts=lib.mg_opts(**kw))
     lib.sync(); wall = (time.perf_counter()-t0)*1e3
     print(f"{label:16s} iters {st.iters} vcycle_ms {st.vcycle_ms:.2f} wall {wall:.1f} bottom_its {st.bottom_iters_total} res {st.resnorm:.2e}", flush=True)
