@@ -271,16 +271,31 @@ def main():
     ns = N.NavierStokes(g, lay, params, lib.mg_opts())
     ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
     ns.post_init(-1.0)
-    # HIP events around every 8th finest-level launch of the dominant kernel (k_nodal_gs4), on its launch stream: opened during the warm-up
-    # (creates the event pool), re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
+    # HIP events around every 8th finest-level launch of the two smoother kernels that lead the step's kernel time (k_abec_gsrb,
+    # k_nodal_gs4; profiles/round2_c_kernel_stats.csv), on their launch stream: opened during the warm-up (creates the event pools),
+    # re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
     probe_on = world == 1 and os.environ.get("IAMRX_BENCH_PROBE", "1") != "0"
+    PROBES = {"gs4": (0, (n + 1) ** 3), "gsrb": (1, n ** 3)}
+
+    def probes_start():
+        for which, pts in PROBES.values():
+            lib.check(lib.lib().iamrx_kernel_probe_start(which, C.c_long(pts), 8))
+
+    def probes_stop():
+        res = {}
+        for name, (which, pts) in PROBES.items():
+            ms, nl = C.c_double(), C.c_long()
+            lib.check(lib.lib().iamrx_kernel_probe_stop(which, C.byref(ms), C.byref(nl)))
+            res[name] = (ms.value / nl.value, nl.value) if nl.value > 0 else None
+        return res
+
     if probe_on:
-        ns.profile(3)
+        probes_start()
     for _ in range(a.warmup):
         ns.step()
     if probe_on:
-        ns.profile(0)
-        ns.profile(3)
+        probes_stop()
+        probes_start()
 
     def barrier():
         lib.sync()
@@ -310,11 +325,9 @@ def main():
         mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
     barrier()
     el = time.perf_counter() - t0
-    gs4_insitu = None
-    if probe_on:
-        pr = ns.profile(0)
-        if pr[7] > 0:
-            gs4_insitu = (pr[6] / pr[7], int(pr[7]))      # mean duration (ms), number of launches in the timed region
+    insitu = probes_stop() if probe_on else {}      # name -> (mean duration in ms, number of launches timed inside the timed region)
+    gs4_insitu = insitu.get("gs4")
+    gsrb_insitu = insitu.get("gsrb")
     mallocs_in_loop = nmalloc() - m0
     syncs_in_loop = nsync() - s0
     if world > 1:
@@ -334,33 +347,56 @@ def main():
     if rank == 0:
         import statistics as st
         kr = kernel_rooflines(lib, n) if world == 1 else {}
-        # dominant kernel of the step (profiles/round1_*): the nodal Gauss-Seidel colour kernel
-        dom = kr.get("nodal_gs4_launch")
+        # dominant kernel of the step by summed duration (profiles/round2_c_kernel_stats.csv): k_abec_gsrb, one colour pass of the
+        # cell-centred GSRB smoother (MAC projection, scalar diffusion); second: k_nodal_gs4 (reported beside it)
         roofline = None
-        if dom:
-            # HBM bytes per launch of the 256^3-level launches inside the step, from the PMC passes over this script (FETCH_SIZE / WRITE_SIZE,
-            # separate rocprofv3 runs, corrected as calibrated in profiles/round1_pmc.json); only valid for the size it was collected at
-            traffic = None
+        cells = float(n) ** 3
+
+        def pmc_traffic(key_substr):
+            """HBM bytes per launch of the 256^3-level launches inside the step, from the PMC passes over this script (FETCH_SIZE / WRITE_SIZE,
+            separate rocprofv3 runs, tools/collect_pmc.sh, corrected as calibrated in profiles/round1_pmc.json).  The counters describe ONE
+            build of the kernels: the file records the git blob hashes of the kernel sources it was collected with; any other source =>
+            traffic is unknown (null), never a stale figure"""
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))     # PMC passes over bench.py itself
-                # the counters describe ONE build of the kernel: the file records the git blob hash of k_nodal.hip it was collected
-                # with; any other source => traffic is unknown (null), never a stale figure
-                if n == 256 and pmc.get("k_nodal_hip_blob") == file_blob_sha(os.path.join(ROOT, "iamr_amd", "csrc", "k_nodal.hip")):
-                    traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()
-                               if "k_nodal_gs4<32, 16, 256, true, false, false> grid=5324800" in k][0]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                if n != 256:
+                    return None
+                for src, blob in pmc.get("source_blobs", {}).items():
+                    if blob != file_blob_sha(os.path.join(ROOT, "iamr_amd", "csrc", src)):
+                        return None
+                hits = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if key_substr in k]
+                return hits[0] if hits else None
             except Exception:
-                traffic = None
+                return None
+
+        gsrb_iso = kr.get("abec_gsrb_sweep")
+        if gsrb_iso:
+            alg = 40.0 * cells                       # SURVEY 8d: one colour pass, variable b: phi 1, rhs 1/2, b 3 reads, phi 1/2 write = 40 B/cell
+            ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
+            gbps = alg / ms / 1e6
+            roofline = {"kernel": "k_abec_gsrb<false> (one red or black pass of the cell-centred GSRB smoother, variable b; the dominant kernel of the "
+                                  "step, profiles/round2_c_kernel_stats.csv)", "bound": "hbm",
+                        "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                        "traffic": pmc_traffic("k_abec_gsrb<false> grid=%d" % (n ** 3 // 16)),
+                        "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
+                        "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
+                        "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
+                        "isolated_loop_ms": gsrb_iso["ms"] / 2}
+        dom = kr.get("nodal_gs4_launch")
+        roofline_gs4 = None
+        if dom:
             # duration: mean over the finest-level launches inside the timed steps (HIP events on the launch stream); the isolated
             # back-to-back loop of kernel_rooflines() is kept beside it (warm L2, no interleaved fills: shorter)
             ms = gs4_insitu[0] if gs4_insitu else dom["ms"]
             gbps = dom["alg_bytes_per_launch"] / ms / 1e6
-            roofline = {"kernel": "k_nodal_gs4<32,16,256> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch; the dominant kernel of the step, "
-                                  "profiles/round1_*_kernel_stats.csv)", "bound": "hbm",
-                        "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
-                        "launches_timed": gs4_insitu[1] if gs4_insitu else None,
-                        "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
-                        "isolated_loop_ms": dom["ms"]}
+            roofline_gs4 = {"kernel": "k_nodal_gs4<32,16,256> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch, variable sigma; second in the "
+                                      "step's kernel time)", "bound": "hbm",
+                            "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                            "traffic": pmc_traffic("k_nodal_gs4<32, 16, 256, true, false, false> grid="),
+                            "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
+                            "launches_timed": gs4_insitu[1] if gs4_insitu else None,
+                            "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
+                            "isolated_loop_ms": dom["ms"]}
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -376,6 +412,7 @@ def main():
             "transport": transport if world > 1 else "none (single GPU)",
             "kernels": kr,
             "roofline": roofline,
+            "roofline_nodal_gs4": roofline_gs4,
         }
         if world == 1 and a.amr_n > 0 and a.amr_steps > 0:
             out["amr"] = amr_workload(lib, a.amr_n, a.amr_steps)

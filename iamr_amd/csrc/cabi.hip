@@ -831,6 +831,21 @@ int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamr
     IAMRX_CATCH
 }
 
+int iamrx_kernel_probe_start(int which, long min_points, int stride)
+{
+    IAMRX_TRY
+    if (which < 0 || which >= PROBE_COUNT) throw Error("iamrx_kernel_probe_start: unknown probe");
+    kernel_probe_start(which, min_points, stride);
+    IAMRX_CATCH
+}
+int iamrx_kernel_probe_stop(int which, double* total_ms, long* launches)
+{
+    IAMRX_TRY
+    if (which < 0 || which >= PROBE_COUNT) throw Error("iamrx_kernel_probe_stop: unknown probe");
+    kernel_probe_stop(which, total_ms, launches);
+    IAMRX_CATCH
+}
+
 int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8])
 {
     IAMRX_TRY

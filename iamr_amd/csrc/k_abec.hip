@@ -191,6 +191,8 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     Tiling t = make_tiling(ml, l.nlocal(), 8);
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
+    // the scalar (MAC projection / scalar diffusion) colour pass over whole boxes can be timed in place (bench.py)
+    const bool rec = phi.ncomp == 1 && !shell_only && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
     if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
         hipLaunchKernelGGL(k_abec_gsrb<true>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
@@ -199,6 +201,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
         hipLaunchKernelGGL(k_abec_gsrb<false>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
                            c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
+    if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 
 // ---------------------------------------------------------------------------- fused red+black sweep

@@ -422,26 +422,27 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 #undef COL
 }
 
-// HIP-event probe around the k_nodal_gs4 launches of levels with at least min_nodes nodes per box (bench.py: the finest level), on the
-// launch stream, so that the roofline figure of the dominant kernel is measured inside the running time step
+// HIP-event probes around selected kernel launches (kernels.h: kernel_probe_*), on the launch stream, so that the roofline figures of the
+// dominant kernels are measured inside the running time step (bench.py)
 namespace {
-struct Gs4Probe {
+struct KProbe {
     bool on = false;
-    long min_nodes = 0;
+    long min_points = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     long seen = 0;
     int stride = 1;          // every stride-th qualifying launch is timed (keeps the event overhead out of the step time)
 };
-Gs4Probe g_gs4_probe;
+KProbe g_probe[PROBE_COUNT];
 }
-void gs4_probe_start(long min_nodes, int stride)
+void kernel_probe_start(int which, long min_points, int stride)
 {
-    g_gs4_probe.on = true; g_gs4_probe.min_nodes = min_nodes; g_gs4_probe.used = 0; g_gs4_probe.seen = 0; g_gs4_probe.stride = stride < 1 ? 1 : stride;
+    KProbe& pb = g_probe[which];
+    pb.on = true; pb.min_points = min_points; pb.used = 0; pb.seen = 0; pb.stride = stride < 1 ? 1 : stride;
 }
-void gs4_probe_stop(double* total_ms, long* launches)
+void kernel_probe_stop(int which, double* total_ms, long* launches)
 {
-    Gs4Probe& pb = g_gs4_probe;
+    KProbe& pb = g_probe[which];
     Context::get().sync();
     double ms = 0.0;
     for (size_t i = 0; i < pb.used; ++i) {
@@ -452,6 +453,26 @@ void gs4_probe_stop(double* total_ms, long* launches)
     *total_ms = ms; *launches = (long)pb.used;
     pb.on = false; pb.used = 0;
 }
+bool kernel_probe_begin(int which, long points)
+{
+    KProbe& pb = g_probe[which];
+    if (!(pb.on && points >= pb.min_points && (pb.seen++ % pb.stride) == 0)) return false;
+    if (pb.used == pb.ev.size()) {
+        hipEvent_t e0, e1;
+        IAMRX_HIP_CHECK(hipEventCreate(&e0)); IAMRX_HIP_CHECK(hipEventCreate(&e1));
+        pb.ev.emplace_back(e0, e1);
+    }
+    IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].first, Context::get().stream));
+    return true;
+}
+void kernel_probe_end(int which)
+{
+    KProbe& pb = g_probe[which];
+    IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].second, Context::get().stream));
+    ++pb.used;
+}
+void gs4_probe_start(long min_nodes, int stride) { kernel_probe_start(PROBE_NODAL_GS4, min_nodes, stride); }
+void gs4_probe_stop(double* total_ms, long* launches) { kernel_probe_stop(PROBE_NODAL_GS4, total_ms, launches); }
 
 template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
@@ -477,16 +498,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
         gx = 8u * (unsigned)(maxcnt * npl);
     }
     dim3 grid(gx, (unsigned)l.nlocal());
-    Gs4Probe& pb = g_gs4_probe;
-    const bool rec = pb.on && (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1) >= pb.min_nodes && (pb.seen++ % pb.stride) == 0;
-    if (rec) {
-        if (pb.used == pb.ev.size()) {
-            hipEvent_t e0, e1;
-            IAMRX_HIP_CHECK(hipEventCreate(&e0)); IAMRX_HIP_CHECK(hipEventCreate(&e1));
-            pb.ev.emplace_back(e0, e1);
-        }
-        IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].first, Context::get().stream));
-    }
+    const bool rec = kernel_probe_begin(PROBE_NODAL_GS4, (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1));
 #define IAMRX_GS4(W, M, C) hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
                                              xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0, ppc)
     if (dmask) {
@@ -495,7 +507,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     } else if (wrap) { if (csig) IAMRX_GS4(true, false, true); else IAMRX_GS4(true, false, false); }
     else { if (csig) IAMRX_GS4(false, false, true); else IAMRX_GS4(false, false, false); }
 #undef IAMRX_GS4
-    if (rec) { IAMRX_HIP_CHECK(hipEventRecord(pb.ev[pb.used].second, Context::get().stream)); ++pb.used; }
+    if (rec) kernel_probe_end(PROBE_NODAL_GS4);
 }
 
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3

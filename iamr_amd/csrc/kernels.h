@@ -16,6 +16,12 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g);   // 
 void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);
 // y = a*x + b*y etc. (valid region + ng)
 // HIP-event probe around the k_nodal_gs4 launches of levels with >= min_nodes nodes per box (see k_nodal.hip)
+// HIP-event probes around the launches of one kernel family on levels with at least min_points cells / nodes per box (every stride-th one)
+enum { PROBE_NODAL_GS4 = 0, PROBE_ABEC_GSRB = 1, PROBE_COUNT = 2 };
+void kernel_probe_start(int which, long min_points, int stride);
+void kernel_probe_stop(int which, double* total_ms, long* launches);
+bool kernel_probe_begin(int which, long points);     // true: the start event was recorded, call kernel_probe_end after the launch
+void kernel_probe_end(int which);
 void gs4_probe_start(long min_nodes, int stride);
 void gs4_probe_stop(double* total_ms, long* launches);
 void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const MultiFab& y, int comp, int nc, int ng);   // dst = a*x + b*y

@@ -78,6 +78,11 @@ int iamrx_sync_count(size_t* n_stream_sync);     /* host waits on the library st
 int iamrx_timer_start(void);
 int iamrx_timer_stop(double* ms);
 void iamrx_mg_default_opts(iamrx_mg_opts* o);
+/* HIP-event probes around the launches of one kernel family inside running solves (the role of TINY_PROFILE rows such as MLMG smoother
+ * times): which = 0 nodal Gauss-Seidel pass (k_nodal_gs4), 1 scalar GSRB colour pass (k_abec_gsrb); only launches on levels
+ * with at least min_points nodes / cells per box, every stride-th one.  stop waits for the stream and returns the summed durations. */
+int iamrx_kernel_probe_start(int which, long min_points, int stride);
+int iamrx_kernel_probe_stop(int which, double* total_ms, long* launches);
 
 /* ---- communicator (amrex::ParallelDescriptor / FabArray point-to-point role) ------ */
 /* One process per GPU.  Call AFTER iamrx_init and BEFORE creating layouts.  RCCL: rank 0 obtains a unique id,

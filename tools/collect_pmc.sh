@@ -22,7 +22,7 @@ sys.path.insert(0, "$root")
 import bench
 p = "$out/${tag}_pmc.json"
 d = json.load(open(p))
-d["k_nodal_hip_blob"] = bench.file_blob_sha("$root/iamr_amd/csrc/k_nodal.hip")
+d["source_blobs"] = {f: bench.file_blob_sha("$root/iamr_amd/csrc/" + f) for f in ("k_nodal.hip", "k_abec.hip", "k_godunov.hip")}
 d["note"] = d["note"].replace("tools/pmc_kernels.py 256", "python bench.py --steps 2 --warmup 1 --cpu-steps 0 --amr-steps 0 (kernels INSIDE the running step, keyed by kernel and launch grid)")
 json.dump(d, open(p, "w"), indent=1)
 PY
