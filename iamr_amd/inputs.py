@@ -16,12 +16,18 @@ Keys that select features this library does not have (AMR levels, EB, particles,
 concern I/O or verbosity are ignored and listed in `Inputs.ignored`.  Host-only code: no GPU needed to parse."""
 import re
 
-_IGNORED_PREFIXES = ("amr.check", "amr.plot", "amr.v", "amr.derive", "amr.probin", "amr.grid_log", "amr.checkpoint",
-                     "amr.blocking_factor", "amr.regrid", "amr.ref_ratio", "amr.refinement_indicators", "amr.n_error_buf",
-                     "amr.grid_eff", "amr.restart", "amr.subcycling", "ns.v", "ns.sum_interval", "ns.getForceVerbose",
-                     "mg.", "proj.v", "mac_proj.v", "mac.v", "diffuse.v", "fab.", "amrex.", "particles.", "nodal_proj.verbose",
-                     "mac_proj.verbose", "ns.do_init_vort_proj", "ns.do_init_proj", "ns.do_mac_proj", "ns.do_reflux",
-                     "ns.do_sync_proj")
+# I/O, verbosity and grid-generation keys that do not change the numbers of a fixed-grid run: matched EXACTLY or, for the entries
+# ending in ".", as a prefix of a whole ParmParse namespace
+_IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.verbose", "mac_proj.v", "mac_proj.verbose", "mac.v", "diffuse.v",
+                 "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
+                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
+                 "amr.check_file", "amr.check_int", "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
+                 "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
+                 "ns.do_sync_proj")
+_IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
+# keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
+_UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
+                         "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
 
 
 def parse_text(text, table=None):
@@ -167,9 +173,14 @@ class Inputs:
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
                    plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"))
+        for k, dflt in _UNIMPLEMENTED_UNLESS.items():
+            if self.has(k) and self.string(k) != dflt:
+                raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented (only {dflt})")
+        if self.has("amr.restart"):
+            raise NotImplementedError("inputs: amr.restart (checkpoint restart, SURVEY f2) is not implemented")
         for k in self.table:
             if k not in self.used:
-                if k.startswith(_IGNORED_PREFIXES):
+                if k in _IGNORED_KEYS or k.startswith(_IGNORED_NAMESPACES):
                     self.ignored.append(k)
                 else:
                     raise KeyError(f"inputs: key {k} is not understood by this library (not silently ignored)")

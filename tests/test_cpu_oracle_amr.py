@@ -145,3 +145,78 @@ def test_three_level_uniform_flow_and_conservation():
             assert abs(S[..., q] - v)[c].max() < 1e-13
         assert abs(a.fab(l, 2).a).max() < 1e-12
     assert abs(comp(4) - m0) < 1e-14 and abs(comp(3) - 1.0) < 1e-14
+
+
+def test_ppm_is_exact_for_parabolic_data():
+    """Known answer for the restated Colella-Woodward reconstruction (oracle/orc_godunov.c, Godunov_PPM): away from extrema and from the
+    periodic wrap the limiters are inactive, the reconstructed parabola IS the data and the state traced to a face is the exact average
+    of that parabola over the domain of dependence [x_f - u dt, x_f].  PLM (second order) does not reproduce it."""
+    n = (32, 4, 4)
+    g = orc.geom(n)
+    L = orc.lib()
+    h, dt = 1.0 / n[0], 0.4 / n[0]
+    x = (np.arange(-3, n[0] + 3) + 0.5) * h
+    a, b, c = 0.6, 0.3, 0.5                              # u(x) = a + b x + c x^2 > 0 and increasing on [0, 1]
+    vel = orc.Fab(n, orc.CELL, 3, 3)
+    vel.a[...] = 0.0
+    vel.a[..., 0] = (a + b * x + c * x * x)[:, None, None]
+    force = orc.Fab(n, orc.CELL, 1, 3)
+    force.a[...] = 0.0
+    res = {}
+    for ppm in (1, 0):
+        L.orc_godunov_set_ppm(ppm)
+        um = [orc.Fab(n, orc.face(d), 1, 1) for d in range(3)]
+        L.orc_extrap_vel_to_faces(C.byref(g), vel.ref(), force.ref(), orc.fabptrs(um), C.c_double(dt), orc.bcrecs(3), 0)
+        res[ppm] = um[0].valid(n, orc.face(0))[:, 0, 0, 0].copy()
+    L.orc_godunov_set_ppm(0)
+    # the input values are point values q(x_i) = cell average of q - c h^2/12: PPM reconstructs q - c h^2/12.  Face i+1/2 takes the state
+    # traced from cell i (u > 0): average over [x_f - s, x_f] with s = u_i dt
+    i = np.arange(6, n[0] - 6)
+    xf = (i + 1) * h
+    ui = a + b * (i + 0.5) * h + c * ((i + 0.5) * h) ** 2
+    s = ui * dt
+    exact = a + b * (xf - s / 2) + c * (xf * xf - xf * s + s * s / 3) - c * h * h / 12
+    assert np.abs(res[1][i + 1] - exact).max() < 1e-13
+    assert np.abs(res[0][i + 1] - exact).max() > 1e-6
+
+
+def test_cell_cons_interp_known_answers():
+    """CellConservativeLinear(false) = IAMR's cell_cons_interp (coarse -> fine data of FillPatch, FillCoarsePatch and SyncInterp): exact for
+    linear data, conservative (the fine cells of a coarse cell average to it) and bounded by the 27 neighbouring coarse values
+    for any data -- per component, so that a rough component does not switch the slopes of a smooth one off."""
+    nc, r = (8, 8, 8), 2
+    nf = tuple(v * r for v in nc)
+    L = orc.lib()
+    gc = orc.geom(nc)
+    rng = np.random.default_rng(5)
+    xc = [(np.arange(-4, nc[d] + 4) + 0.5) / nc[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*xc, indexing="ij")
+    cf = orc.Fab(nc, orc.CELL, 4, 2)
+    cf.a[..., 0] = 1.0 + 2.0 * X - 3.0 * Y + 0.5 * Z                        # linear (not periodic: only interior cells are checked)
+    cf.a[..., 1] = rng.standard_normal(X.shape)                             # rough
+    L.orc_fill_periodic(cf.ref(), C.byref(gc), orc.i3(orc.CELL))
+    cf.a[..., 0] = 1.0 + 2.0 * X - 3.0 * Y + 0.5 * Z
+    ff = orc.Fab(nf, orc.CELL, 0, 2)
+    ff.a[...] = -99.0
+    empty_lo, empty_hi = (1, 1, 1), (0, 0, 0)
+    L.orc_fill_coarse_fine(ff.ref(), orc.i3((0, 0, 0)), orc.i3(tuple(v - 1 for v in nf)), orc.i3(empty_lo), orc.i3(empty_hi), cf.ref(),
+                           orc.i3((0, 0, 0)), orc.i3(tuple(v - 1 for v in nc)), orc.i3((1, 1, 1)), r, orc.bcrecs(2))
+    F = ff.a
+    xf = [(np.arange(nf[d]) + 0.5) / nf[d] for d in range(3)]
+    Xf, Yf, Zf = np.meshgrid(*xf, indexing="ij")
+    inner = (slice(2, -2),) * 3
+    assert np.abs(F[..., 0] - (1.0 + 2.0 * Xf - 3.0 * Yf + 0.5 * Zf))[inner].max() < 1e-13
+    Cv = cf.a[4:-4, 4:-4, 4:-4, :]
+    avg = F.reshape(nc[0], r, nc[1], r, nc[2], r, 2).mean(axis=(1, 3, 5))
+    assert np.abs(avg - Cv).max() < 1e-13                                    # conservative, both components
+    # no new extrema: every fine value lies between the min and max of the 27 coarse neighbours of its coarse cell
+    P = cf.a[3:-3, 3:-3, 3:-3, 1]
+    lo = np.full(nc, np.inf); hi = np.full(nc, -np.inf)
+    for dx in range(3):
+        for dy in range(3):
+            for dz in range(3):
+                blk = P[dx:dx + nc[0], dy:dy + nc[1], dz:dz + nc[2]]
+                lo, hi = np.minimum(lo, blk), np.maximum(hi, blk)
+    Fr = F[..., 1].reshape(nc[0], r, nc[1], r, nc[2], r)
+    assert (Fr >= lo[:, None, :, None, :, None] - 1e-13).all() and (Fr <= hi[:, None, :, None, :, None] + 1e-13).all()
+    assert np.abs(Fr - Cv[:, None, :, None, :, None, 1]).max() > 1e-3          # the slopes of the rough component are not all limited to zero
