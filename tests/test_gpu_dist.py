@@ -20,6 +20,15 @@ def run(rank, world, port, out_dir, agg, case="tg"):
     if case == "stack4":     # the weak-scaling layout of bench.py: one box per rank, stacked in z
         N = (16, 16, 64)
         BOXES = [((0, 0, 16 * r), (15, 15, 16 * r + 15)) for r in range(4)]
+    if case.startswith("grid"):   # bench.py's layout for N ranks: one 16^3 box per rank on the most cubic process grid (4 -> 2x2x1, 8 -> 2x2x2)
+        import bench
+        nr = int(case[4:])
+        pg = bench.proc_grid(nr)
+        N = tuple(16 * pg[d] for d in range(3))
+        BOXES = []
+        for r in range(nr):
+            ix, iy, iz = r % pg[0], (r // pg[0]) % pg[1], r // (pg[0] * pg[1])
+            BOXES.append(((16 * ix, 16 * iy, 16 * iz), (16 * ix + 15, 16 * iy + 15, 16 * iz + 15)))
     if agg is not None:
         os.environ["IAMRX_MG_AGGLOMERATE_CELLS"] = agg
     from iamr_amd import lib
@@ -36,7 +45,11 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
     owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
     lay = lib.Layout(BOXES, owners)
-    if case == "stack4":
+    if case.startswith("grid"):
+        g = lib.Geom.make(N, prob_hi=tuple(N[d] / 16.0 for d in range(3)))
+        ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    elif case == "stack4":
         g = lib.Geom.make(N, prob_hi=(1.0, 1.0, 4.0))
         ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
         ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
@@ -132,6 +145,22 @@ def test_four_ranks_stacked_boxes_like_the_bench(tmp_path):
             assert np.array_equal(z["iters"], ref["iters"])
             key = f"box{r}"
             assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+@pytest.mark.parametrize("nr", [4, 8])
+def test_bench_process_grid_layouts(tmp_path, nr):
+    """the box layout bench.py builds for 4 / 8 GPUs (proc_grid: 2x2x1 / 2x2x2, every rank has a neighbour in each refined direction,
+    SURVEY 8e) on nr ranks sharing the GPU over the callback transport: same result as one rank holding all boxes"""
+    import torch.multiprocessing as mp
+    port = 36100 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, f"grid{nr}"), nprocs=1, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    mp.spawn(run, args=(nr, port + 11, str(tmp_path), None, f"grid{nr}"), nprocs=nr, join=True)
+    for r in range(nr):
+        z = np.load(os.path.join(str(tmp_path), f"w{nr}_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        key = f"box{r}"
+        assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
 
 
 def test_bench_script_multi_rank_path(tmp_path):
