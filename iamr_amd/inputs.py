@@ -14,13 +14,14 @@ keys this library implements onto `ns_params`, the geometry and the box layout:
 Source/Projection.cpp:49-65, Source/Diffusion.cpp:98-118, Source/prob/prob_init.cpp:8-60, Source/main.cpp:60-145).
 Keys that select features this library does not have (AMR levels, EB, particles, inflow/outflow ...) raise; keys that only
 concern I/O or verbosity are ignored and listed in `Inputs.ignored`.  Host-only code: no GPU needed to parse."""
+import os
 import re
 
 # I/O, verbosity and grid-generation keys that do not change the numbers of a fixed-grid run: matched EXACTLY or, for the entries
 # ending in ".", as a prefix of a whole ParmParse namespace
 _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.verbose", "mac_proj.v", "mac_proj.verbose", "mac.v", "diffuse.v",
                  "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
-                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
+                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
                  "amr.check_file", "amr.check_int", "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
                  "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
@@ -28,6 +29,31 @@ _IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
 # keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
 _UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
                          "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
+
+
+def read_grid_file(path, ref_ratio):
+    """amr.regrid_file / amr.initial_grid_file (upstream Amr::readProbinFile-era format, e.g. Exec/run2d/test_grids/fixed_grids_2): number
+    of refined levels, then per level the number of boxes and the boxes `((lo) (hi) (type))` given in the index space of the NEXT
+    COARSER level.  Returns, per refined level, the boxes refined by ref_ratio[level-1] -- the level's own index space (pinned on the
+    reference's committed plotfile of the same run, tests/test_cpu_plotfile.py)."""
+    toks = open(path).read().split("\n")
+    lines = [t.split("#", 1)[0].strip() for t in toks]
+    lines = [t for t in lines if t]
+    nlev = int(lines[0])
+    out, q = [], 1
+    for l in range(nlev):
+        nb = int(lines[q]); q += 1
+        boxes = []
+        for _ in range(nb):
+            m = re.match(r"\(\(([-\d, ]+)\)\s*\(([-\d, ]+)\)\s*\(([-\d, ]+)\)\)", lines[q]); q += 1
+            if not m:
+                raise ValueError(f"grid file {path}: cannot parse box {lines[q - 1]!r}")
+            lo = [int(v) for v in m.group(1).split(",")]
+            hi = [int(v) for v in m.group(2).split(",")]
+            r = ref_ratio[l]
+            boxes.append((tuple(v * r for v in lo), tuple((v + 1) * r - 1 for v in hi)))
+        out.append(boxes)
+    return out
 
 
 def parse_text(text, table=None):
@@ -51,6 +77,7 @@ def parse_text(text, table=None):
 class Inputs:
     def __init__(self, files=(), overrides=()):
         self.table = {}
+        self.files = list(files)
         for f in files:
             with open(f) as fh:
                 parse_text(fh.read(), self.table)
@@ -106,8 +133,26 @@ class Inputs:
     # mapping ----------------------------------------------------------------------------------------------------------
     def problem(self):
         """-> dict(n, prob_lo, prob_hi, periodic, max_grid_size, params (kwargs of ns_params), prob (dict), max_step, stop_time)"""
-        if self.integer("amr.max_level", 0) != 0:
-            raise NotImplementedError("inputs: amr.max_level > 0 (AMR levels, SURVEY row a18) is not implemented; pass amr.max_level=0")
+        max_level = self.integer("amr.max_level", 0)
+        fine_boxes = []
+        if max_level > 0:
+            # fixed refined grids only (amr.regrid_file, as Exec/run2d/test_grids/inputs_*): the tagging / clustering blocks exist
+            # (iamrx_error_tag, iamrx_cluster_tags) but no regrid driver runs them during a run yet
+            gf = None
+            for k in ("amr.regrid_file", "amr.initial_grid_file"):
+                if self.has(k):
+                    gf = self.string(k)
+            if gf is None:
+                raise NotImplementedError("inputs: amr.max_level > 0 needs fixed grids (amr.regrid_file / amr.initial_grid_file); "
+                                          "regridding during a run is not implemented")
+            rr = self.ints("amr.ref_ratio", max_level, [2] * max_level)
+            if any(r != 2 for r in rr):
+                raise NotImplementedError(f"inputs: amr.ref_ratio = {rr}: only ratio 2 is implemented")
+            if not os.path.isabs(gf) and self.files:
+                gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
+            fine_boxes = read_grid_file(gf, rr)[:max_level]
+            if self.has("ns.vel_visc_coef") and self.real("ns.vel_visc_coef", 0.0) != 0.0 or any(v != 0.0 for v in self.reals("ns.scal_diff_coefs", 1, [0.0])):
+                raise NotImplementedError("inputs: viscous / diffusive runs on a refined hierarchy are not implemented (coarse/fine viscous sync)")
         if self.integer("geometry.coord_sys", 0) != 0:
             raise NotImplementedError("inputs: only Cartesian coordinates (geometry.coord_sys = 0)")
         n = self.ints("amr.n_cell", 3)
@@ -172,7 +217,7 @@ class Inputs:
                                       "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
-                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"))
+                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes)
         for k, dflt in _UNIMPLEMENTED_UNLESS.items():
             if self.has(k) and self.string(k) != dflt:
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented (only {dflt})")

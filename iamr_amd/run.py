@@ -1,14 +1,90 @@
-"""`python -m iamr_amd.run <inputs file> [key=value ...]` -- the single-level equivalent of IAMR's main loop
-(Source/main.cpp:60-145: ParmParse, Amr::init, `while (step < max_step && time < stop_time) coarseTimeStep`), driving
-libiamrx.so from an unmodified IAMR inputs file.  Under torch.distributed.run it shards the boxes over the
-ranks (one process per GPU)."""
+"""`python -m iamr_amd.run <inputs file> [key=value ...]` -- IAMR's main loop (Source/main.cpp:60-145: ParmParse, Amr::init,
+`while (step < max_step && time < stop_time) coarseTimeStep`) driving libiamrx.so from an unmodified IAMR inputs file (SURVEY row
+f4): one level, or a hierarchy of fixed refined grids (amr.max_level > 0 with amr.regrid_file, subcycled, inviscid).  Under
+torch.distributed.run a single-level run shards its boxes over the ranks (one process per GPU)."""
 import os
 import sys
 import time
 
 
-def build(inp, lib, N, nranks=1):
-    pr = inp.problem()
+def init_level(ns, lay, lib, N, pr, n):
+    """initial data of one level (prob_initData role, Source/prob/prob_init.cpp), n = the level's cell counts"""
+    pb = pr["prob"]
+    if pb["probtype"] == 1:
+        ns.init_rest(pb["rho0"])
+    elif pb["probtype"] in (4, 5, 7):
+        from .probinit import set_initial_state
+        ns.init_rest(pb["density_ic"])
+        set_initial_state(ns, lay, lib, N, pb, n, pr["prob_lo"], pr["prob_hi"])
+    elif pb["probtype"] == 10:
+        ns.init_rayleightaylor(pb["rho_1"], pb["rho_2"], pb["tra_1"], pb["tra_2"], pb["pertamp"], pb["interface_width"])
+    else:
+        ns.init_taylorgreen(pb["vfac"], pb["a"], pb["b"], pb["c"], pb["rho0"])
+
+
+def build_amr(pr, lib, N):
+    """hierarchy of fixed grids: level 0 chopped by amr.max_grid_size, the refined levels as the grid file gives them"""
+    from .amr import Amr
+    g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
+    lays = [lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], 1)] + [lib.Layout(b) for b in pr["fine_boxes"]]
+    amr = Amr(g0, lays, N.ns_params(**pr["params"]))
+    for l, lev in enumerate(amr.levels):
+        init_level(lev, lays[l], lib, N, pr, [v * 2 ** l for v in pr["n"]])
+    return amr, lays, g0
+
+
+def level_arrays(ns, lay, N):
+    S = ns.data(N.NavierStokes.S_NEW)
+    boxes, arrs = [], []
+    for li in range(S.nlocal()):
+        a, lo = S.to_numpy(li)
+        blo, bhi, gi = lay.local_box(li)
+        ng = (a.shape[0] - (bhi[0] - blo[0] + 1)) // 2
+        arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
+        boxes.append((tuple(blo), tuple(bhi)))
+    return boxes, arrs
+
+
+def write_plot_amr(amr, lays, pr, N, step, root):
+    """NavierStokesBase::writePlotFile role for the hierarchy: one AMReX plotfile with every level (the five state components)"""
+    from .plotfile import PlotFile, Level, STATE_NAMES_3D
+    levels = []
+    dts = amr.dts()
+    for l, lev in enumerate(amr.levels):
+        n = [v * 2 ** l for v in pr["n"]]
+        dx = [(pr["prob_hi"][d] - pr["prob_lo"][d]) / n[d] for d in range(3)]
+        boxes, arrs = level_arrays(lev, lays[l], N)
+        levels.append(Level(((0, 0, 0), tuple(v - 1 for v in n)), dx, boxes, arrs, step * 2 ** l, amr.time))
+    path = f"{root}{step:05d}"
+    PlotFile(STATE_NAMES_3D, amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
+    return path
+
+
+def main_amr(pr, inp, lib, N):
+    amr, lays, g0 = build_amr(pr, lib, N)
+    if inp.ignored:
+        print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
+    amr.post_init(pr["stop_time"])
+    plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
+    if plot_int > 0:
+        print("PLOTFILE:", write_plot_amr(amr, lays, pr, N, 0, plot_root))
+    t0 = time.perf_counter()
+    step = 0
+    while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or amr.time < pr["stop_time"] - 1e-14):
+        if pr["max_step"] < 0 and pr["stop_time"] < 0:
+            break
+        dt = amr.coarse_step()
+        step += 1
+        print(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g}")
+        if plot_int > 0 and step % plot_int == 0:
+            print("PLOTFILE:", write_plot_amr(amr, lays, pr, N, step, plot_root))
+    lib.sync()
+    print(f"Run time = {time.perf_counter() - t0:.6f}")
+    return 0
+
+
+def build(inp, lib, N, nranks=1, pr=None):
+    pr = pr if pr is not None else inp.problem()
     g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
     lay = lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], nranks)
     ns = N.NavierStokes(g, lay, N.ns_params(**pr["params"]))
@@ -65,7 +141,12 @@ def main(argv):
     if world > 1:
         from . import comm
         comm.init_rccl_from_torch(dist)
-    ns, lay, g, pr = build(inp, lib, N, world)
+    pr = inp.problem()
+    if pr["fine_boxes"]:
+        if world > 1:
+            raise NotImplementedError("iamr_amd.run: refined hierarchies run on one rank (the multi-level driver does not shard levels yet)")
+        return main_amr(pr, inp, lib, N)
+    ns, lay, g, pr = build(inp, lib, N, world, pr)
     if rank == 0 and inp.ignored:
         print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
     ns.post_init(pr["stop_time"])

@@ -81,3 +81,28 @@ def test_host_side_problem_setups():
     assert np.all(S[..., 0] == 1.0) and np.all(S[..., 1:3] == 0.0) and S[..., 4].min() == 0.0 and S[4, 16, 16, 4] == 1.0
     with pytest.raises(ValueError):
         initial_state(dict(pr["prob"], probtype=5, direction=2), X, Y, Z)
+
+
+def test_fixed_grid_hierarchy_keys():
+    """amr.max_level > 0 with amr.regrid_file (the fixed-grid runs of Exec/run2d/test_grids): boxes come out in each level's own index space;
+    without a grid file, with a ratio other than 2 or with viscosity the run is refused"""
+    amr_inp = os.path.join(HERE, "golden", "inputs.3d.taylorgreen_amr16")
+    pr = Inputs([amr_inp]).problem()
+    assert pr["fine_boxes"] == [[((4, 4, 4), (27, 27, 27))], [((20, 20, 20), (31, 43, 43)), ((32, 20, 20), (43, 43, 43))]]
+    assert pr["params"]["visc_coef"] == 0.0 and pr["prob"]["probtype"] == 11
+    with pytest.raises(NotImplementedError):
+        Inputs([amr_inp], ["amr.ref_ratio = 4 2"]).problem()
+    with pytest.raises(NotImplementedError):
+        Inputs([amr_inp], ["ns.vel_visc_coef = 0.01"]).problem()
+    with pytest.raises(NotImplementedError):
+        Inputs([LDC], ["amr.max_level=1"]).problem()                       # no grid file: would need regridding
+
+
+def test_physics_keys_are_not_swallowed_by_verbosity_prefixes():
+    """`ns.v` must not match ns.variable_vel_visc / ns.visc_abs_tol / ns.vorterr ..."""
+    for k in ("ns.variable_vel_visc=1", "ns.variable_scal_diff=1", "ns.do_init_proj=0", "ns.do_mac_proj=0", "amr.restart=chk00010"):
+        with pytest.raises(NotImplementedError):
+            Inputs([LDC], [k]).problem()
+    with pytest.raises(KeyError):
+        Inputs([LDC], ["ns.vorterr=1.0"]).problem()
+    assert Inputs([LDC], ["ns.variable_vel_visc=0", "ns.do_init_proj=1", "ns.v=1"]).problem()["n"] == [16, 16, 16]

@@ -64,3 +64,25 @@ def test_round_trip_and_compare(tmp_path):
     d = compare(a, b)
     assert d["tracer"][0] == 1e-3 or abs(d["tracer"][0] - 1e-3) < 1e-15
     assert all(d[k][0] == 0.0 for k in pf.names if k != "tracer")
+
+
+def test_three_level_reference_plotfile_round_trip_and_grid_file(tmp_path):
+    """tests/golden/plt0000_2 = Exec/run2d/test_grids/plt0000_2 (data files of the reference: three levels, ref_ratio 4 2): the reader decodes
+    every level, the writer reproduces the Header text and the FAB bytes of every level, and the boxes of the refined levels are the
+    ones of the run's fixed-grid file (tests/golden/fixed_grids_2 = Exec/run2d/test_grids/fixed_grids_2, amr.regrid_file of
+    inputs_2_xy_ysolid) refined from the next coarser level's index space -- the convention iamr_amd.inputs.read_grid_file follows."""
+    from iamr_amd.inputs import read_grid_file
+    gold = os.path.join(os.path.dirname(GOLD), "plt0000_2")
+    pf = PlotFile.read(gold)
+    assert len(pf.levels) == 3 and pf.ref_ratio == [4, 2] and pf.names[:4] == ["x_velocity", "y_velocity", "density", "tracer"]
+    assert pf.header_text() == open(os.path.join(gold, "Header")).read()
+    grids = read_grid_file(os.path.join(os.path.dirname(GOLD), "fixed_grids_2"), [4, 2])
+    assert len(grids) == 2
+    for l in (1, 2):
+        assert sorted(pf.levels[l].boxes) == sorted(grids[l - 1]), (l, pf.levels[l].boxes, grids[l - 1])
+    out = str(tmp_path / "plt")
+    pf.write(out)
+    for l in range(3):
+        assert open(os.path.join(out, f"Level_{l}", "Cell_D_00000"), "rb").read() == open(os.path.join(gold, f"Level_{l}", "Cell_D_0000"), "rb").read()
+    back = PlotFile.read(out)
+    assert all(np.array_equal(a, b) for l in range(3) for a, b in zip(back.levels[l].data, pf.levels[l].data))

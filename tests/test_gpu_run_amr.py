@@ -1,0 +1,42 @@
+"""SURVEY rows f4 + f2 on a hierarchy: `python -m iamr_amd.run` on an IAMR-format inputs file with amr.max_level = 2 and fixed grids
+(tests/golden/inputs.3d.taylorgreen_amr16 + fixed_grids_3d_tg), three levels subcycled through the C-ABI, and the multi-level AMReX
+plotfile it writes: the plotfile holds every level's state, and the run equals the oracle's (same grids, same steps)."""
+import os
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_inputs_file_run_on_three_levels_and_its_plotfile(gpu, tmp_path, capsys):
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    from iamr_amd.inputs import Inputs
+    inp_file = os.path.join(HERE, "golden", "inputs.3d.taylorgreen_amr16")
+    root = str(tmp_path / "plt")
+    assert R.main([inp_file, f"amr.plot_file={root}"]) == 0
+    out = capsys.readouterr().out
+    steps = [l for l in out.splitlines() if l.startswith("STEP =")]
+    assert len(steps) == 2 and "PLOTFILE:" in out
+    pf = PlotFile.read(root + "00002")
+    assert len(pf.levels) == 3 and pf.ref_ratio == [2, 2] and pf.names == ["x_velocity", "y_velocity", "z_velocity", "density", "tracer"]
+    assert [lv.domain[1] for lv in pf.levels] == [(15, 15, 15), (31, 31, 31), (63, 63, 63)]
+    assert pf.levels[1].boxes == [((4, 4, 4), (27, 27, 27))] and len(pf.levels[2].boxes) == 2 and len(pf.levels[0].boxes) == 8
+    # the oracle on the same hierarchy
+    pr = Inputs([inp_file]).problem()
+    kw = {k: pr["params"][k] for k in ("cfl", "visc_coef", "init_iter", "init_shrink")}
+    oa = orc.OrcAmr(orc.geom([16] * 3), orc.ns_params(**kw), orc.mg_opts(), [[]] + pr["fine_boxes"])
+    for l in range(3):
+        oa.set_state(l, orc.taylorgreen_state(*oa.cell_centres(l), c=1.0))
+    oa.post_init()
+    for _ in range(2):
+        oa.step()
+    assert abs(pf.time - oa.time()) <= 1e-9 * oa.time()
+    for l in range(3):
+        So = oa.state(l)
+        for (lo, hi), a in zip(pf.levels[l].boxes, pf.levels[l].data):
+            ref = So[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1, :]
+            assert np.abs(a - ref).max() <= 2e-8, (l, lo, np.abs(a - ref).max())
