@@ -103,6 +103,7 @@ private:
     bool m_tensor = false;
     bool m_tensor_eta = false;
     bool m_singular = false;
+    int m_dd_sweeps = 0;          // > 0: diagonally dominant operator solved by sweeps of the finest level only (prepare())
     bool m_cf = false;
     const MultiFab* m_crse = nullptr;
     Geometry m_cgeom;

@@ -51,9 +51,35 @@ void CellMG::prepare()
     for (int d = 0; d < 3; ++d)
         for (auto& b : m_bcn) if (!m_g.periodic[d] && (b.lo[d] == lo_dirichlet || b.hi[d] == lo_dirichlet)) m_singular = false;
     if (m_cf) m_singular = false;           // coarse/fine faces carry Dirichlet data
+    // Strongly diagonally dominant operators (alpha a - beta div b grad with beta b / h^2 << alpha a: the Crank-Nicolson viscous and
+    // diffusive solves at small nu dt / h^2): the Gauss-Seidel sweeps of the finest level alone contract the error by more than a
+    // V-cycle needs to, so no coarse hierarchy is built and a "cycle" is m_dd_sweeps sweeps.  Bound of the Jacobi contraction:
+    // q / (alpha min(a) + q), q = beta max(b) sum_d 2 / h_d^2; red-black Gauss-Seidel contracts by about its square per sweep.
+    // Same converged answer (tests/test_gpu_sensitivity.py covers the solver choices); IAMRX_MG_DIAG_SHORTCUT=0 disables.
+    m_dd_sweeps = 0;
+    static const bool dd_on = !(getenv("IAMRX_MG_DIAG_SHORTCUT") && atoi(getenv("IAMRX_MG_DIAG_SHORTCUT")) == 0);
+    if (dd_on && m_alpha > 0.0 && m_beta > 0.0 && m_a0 && m_o.fixed_iters <= 0 && m_o.max_coarsening_level > 0) {
+        double bmax = 0.0;
+        for (int d = 0; d < 3; ++d) bmax = std::max(bmax, m_b0[d]->norm0(0, m_b0[d]->ncomp, 0));
+        if (m_tensor_eta) bmax *= 4.0 / 3.0;
+        MultiFab inv(m_lev[0].layout, cell_type(), 1, 0);
+        {
+            const FabD *it = inv.d_tab, *at = m_a0->d_tab;
+            for_each(*m_lev[0].layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                const double a = at[f](i, j, k);
+                it[f](i, j, k) = a > 0.0 ? 1.0 / a : 1.e300;
+            });
+        }
+        const double ainv = inv.norm0(0, 1, 0);
+        double q = 0.0;
+        for (int d = 0; d < 3; ++d) q += 2.0 / (m_g.dx[d] * m_g.dx[d]);
+        q *= m_beta * bmax;
+        const double jac = ainv < 1.e299 ? q / (m_alpha / ainv + q) : 1.0;
+        if (jac < 0.2) m_dd_sweeps = jac < 0.05 ? 2 : (jac < 0.12 ? 3 : 4);
+    }
     // coarsen while every box is coarsenable (MLLinOp::defineGrids, mg_box_min_width = 2)
     m_lev.resize(1);
-    while ((int)m_lev.size() <= m_o.max_coarsening_level) {
+    while (m_dd_sweeps == 0 && (int)m_lev.size() <= m_o.max_coarsening_level) {
         Level& f = m_lev.back();
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
@@ -271,6 +297,10 @@ void CellMG::bottom_solve(MGStats& st)
     const int l = (int)m_lev.size() - 1;
     Level& L = m_lev[l];
     L.cor.setVal(0.0);
+    if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
+        smooth_n(l, L.cor, L.res, m_dd_sweeps, true);
+        return;
+    }
     if (m_o.bottom_smoother_only) {
         smooth_n(l, L.cor, L.res, m_o.nuf, true);
         return;
