@@ -527,6 +527,37 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
     IAMRX_CATCH
 }
 
+int iamrx_tensor_apply_cf(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
+                          iamrx_mf ez, const int* lobc, const int* hibc, int nbc, int maxorder, iamrx_mf crse_vel, const iamrx_geom* cgeom, int ratio)
+{
+    IAMRX_TRY
+    IAMRX_ASSERT(nbc == 1 || nbc == 3);
+    const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
+    DomainBC bcs[3];
+    for (int n = 0; n < nbc; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, maxorder);
+    Geometry cg = to_geom(cgeom);
+    TensorCF cf{crse_vel ? &crse_vel->mf : nullptr, &cg, ratio};
+    tensor_apply(to_geom(g), out->mf, vel->mf, a, b, acoef ? &acoef->mf : nullptr, eta, bcs, nbc, &cf);
+    IAMRX_CATCH
+}
+
+int iamrx_tensor_solve_cf(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
+                          iamrx_mf ez, const int* lobc, const int* hibc, int nbc, iamrx_mf crse_vel, const iamrx_geom* cgeom, int ratio,
+                          double tol_rel, double tol_abs, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    IAMRX_ASSERT(nbc == 1 || nbc == 3);
+    MGOpts op = to_opts(o);
+    const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
+    DomainBC bcs[3];
+    for (int n = 0; n < nbc; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, op.maxorder);
+    Geometry cg = to_geom(cgeom);
+    TensorCF cf{crse_vel ? &crse_vel->mf : nullptr, &cg, ratio};
+    MGStats s = tensor_solve(to_geom(g), soln->mf, rhs->mf, a, b, acoef ? &acoef->mf : nullptr, eta, bcs, nbc, tol_rel, tol_abs, op, &cf);
+    from_stats(s, st);
+    IAMRX_CATCH
+}
+
 struct iamrx_ns_s {
     std::unique_ptr<NavierStokes> owned;     // null for a level borrowed from an iamrx_amr hierarchy
     NavierStokes* ns = nullptr;

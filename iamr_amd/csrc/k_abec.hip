@@ -549,7 +549,7 @@ void cf_build_mask(const Geometry& g, MultiFab& cfm)
 }
 
 __global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ phit,
-    const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog)
+    const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog, int edges)
 {
     const int fab = blockIdx.y;
     const BoxD vb = boxes[fab];
@@ -565,7 +565,14 @@ __global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restric
             if (idx[e] < vb.lo[e]) { ++nout; d = e; s = 1; }
             else if (idx[e] > vb.hi[e]) { ++nout; d = e; s = -1; }
         }
-        if (nout != 1 || cfm(i, j, k) != 1.0) continue;       // only face-adjacent coarse/fine ghost cells
+        if (cfm(i, j, k) != 1.0) continue;
+        if (nout >= 2) {
+            // tensor operator: edge / corner coarse-fine ghost cells (read by the cross terms only) hold the coarse data interpolated to
+            // the cell centre (cf_interp_edges), frozen during the solve; zero in the correction form
+            if (edges) for (int n = 0; n < ncomp; ++n) phi(i, j, k, n) = (inhomog && bcvt) ? (double)bcvt[fab](i, j, k, n) : 0.0;
+            continue;
+        }
+        if (nout != 1) continue;                               // face-adjacent coarse/fine ghost cells
         const int NX = min(vb.len(d) + 1, tab.maxorder);
         const double* c = tab.c[d][NX - 2];
         for (int n = 0; n < ncomp; ++n) {
@@ -577,12 +584,53 @@ __global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restric
     }
 }
 
-void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval)
+void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval, bool edges)
 {
     if (phi.nlocal() == 0) return;
     Tiling t = level_tiling(*phi.layout, cell_type(), 1, 4);
     hipLaunchKernelGGL(k_cf_fill, t.grid(), Tiling::block(), 0, Context::get().stream, t, phi.layout->d_boxes, phi.d_tab,
-                       bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0);
+                       bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0);
+}
+
+// bcval(edge / corner coarse-fine ghost cells) = the coarse data of cpatch interpolated to the cell centre, quadratically in every
+// direction: centred stencil (c-1, c, c+1) in the directions in which the cell lies inside the box's index range, one-sided towards
+// the box (c, c+s, c+2s) in the directions in which it lies outside (third order: the cross terms difference these values over h)
+void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio)
+{
+    if (bcval.nlocal() == 0) return;
+    IAMRX_ASSERT(cpatch.ngrow >= 1 && bcval.ngrow >= 1 && cfm.ngrow >= 1);
+    const FabD *bt = bcval.d_tab, *ct = cpatch.d_tab, *mt = cfm.d_tab;
+    const BoxD* boxes = bcval.layout->d_boxes;
+    const int nc = bcval.ncomp, r = ratio;
+    for_each(*bcval.layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const BoxD vb = boxes[f];
+        const int q[3] = {i, j, k};
+        int nout = 0;
+        for (int e = 0; e < 3; ++e) if (q[e] < vb.lo[e] || q[e] > vb.hi[e]) ++nout;
+        if (nout < 2 || mt[f](i, j, k) != 1.0) return;
+        int c[3], o[3][3];
+        double w[3][3];
+        for (int e = 0; e < 3; ++e) {
+            c[e] = q[e] >= 0 ? q[e] / r : -((-q[e] + r - 1) / r);
+            const double off = (q[e] - c[e] * r + 0.5) / r - 0.5;
+            if (q[e] < vb.lo[e] || q[e] > vb.hi[e]) {
+                const int s = q[e] < vb.lo[e] ? 1 : -1;
+                const double u = off * s;
+                o[e][0] = 0; o[e][1] = s; o[e][2] = 2 * s;
+                w[e][0] = 0.5 * (u - 1.0) * (u - 2.0); w[e][1] = -u * (u - 2.0); w[e][2] = 0.5 * u * (u - 1.0);
+            } else {
+                o[e][0] = -1; o[e][1] = 0; o[e][2] = 1;
+                w[e][0] = 0.5 * off * (off - 1.0); w[e][1] = 1.0 - off * off; w[e][2] = 0.5 * off * (off + 1.0);
+            }
+        }
+        const FabD cp = ct[f];
+        for (int n = 0; n < nc; ++n) {
+            double v = 0.0;
+            for (int cz = 0; cz < 3; ++cz) for (int cy = 0; cy < 3; ++cy) for (int cx = 0; cx < 3; ++cx)
+                v += w[0][cx] * w[1][cy] * w[2][cz] * cp(c[0] + o[0][cx], c[1] + o[1][cy], c[2] + o[2][cz], n);
+            bt[f](i, j, k, n) = v;
+        }
+    });
 }
 
 // interpbndrydata_{x,y,z}_o3: value at the fine ghost cell from the coarse cell under it and its tangential neighbours; a

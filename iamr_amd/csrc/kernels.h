@@ -58,7 +58,9 @@ CfTab cf_make_tab(const double loc[3], const double dx[3], int maxorder);
 // 2 = outside the physical domain
 void cf_build_mask(const Geometry& g, MultiFab& cfm);
 // ghost cells with mask 1 next to a box face: phi = c[0] * bcval (inhomog) + sum_m c[m] * phi(m-th cell inside)   (mllinop_apply_bc)
-void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval);
+// edges: also the edge / corner coarse-fine ghost cells (tensor operator): bcval there (cf_interp_edges) or zero
+void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval, bool edges = false);
+void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
 // bcval(ghost cells with mask 1) = coarse data of cpatch (coarsened layout, 1 ghost cell) interpolated in the tangential directions
 // (InterpBndryData::setBndryValues, third order, ratio 2); cfm needs 2 ghost cells
 void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);

@@ -135,27 +135,30 @@ void CellMG::prepare()
 void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
 {
     phi.FillBoundary(m_lev[l].g);
-    if (m_bcn.size() == 1) {
-        abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
-        if (m_tensor) fill_tensor_corners(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
-    } else {
-        // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference Source/Diffusion.cpp:724-731)
+    // order: domain faces, coarse/fine faces (+ the frozen edge / corner values of the tensor operator), then the edge / corner cells
+    // outside the physical domain, which are extrapolated from cells filled by the first two
+    if (m_bcn.size() == 1) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
+    else   // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference Source/Diffusion.cpp:724-731)
         for (int n = 0; n < m_ncomp; ++n) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
-        if (m_tensor) for (int n = 0; n < m_ncomp; ++n) fill_tensor_corners(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
+    if (m_cf) cf_fill_ghosts(phi, m_lev[l].cfm, m_lev[l].cftab, inhomog, bcval, m_tensor);
+    if (m_tensor) {
+        if (m_bcn.size() == 1) fill_tensor_corners(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
+        else for (int n = 0; n < m_ncomp; ++n) fill_tensor_corners(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
     }
-    if (m_cf) cf_fill_ghosts(phi, m_lev[l].cfm, m_lev[l].cftab, inhomog, bcval);
 }
 
 // level BC data at the coarse/fine ghost cells: the coarse solution interpolated along the faces
 void CellMG::cf_bcval(MultiFab& bcval)
 {
     if (!m_cf) return;
-    IAMRX_ASSERT(!m_tensor);    // the tensor cross terms at coarse/fine faces are not implemented
     LayoutP cl = m_lev[0].layout->coarsened(m_ratio);
     MultiFab cpatch(cl, cell_type(), m_ncomp, 1);
     cpatch.setVal(0.0);
     if (m_crse) parallel_copy(cpatch, *m_crse, 0, 0, m_ncomp, 0, 1, &m_cgeom, false);
     cf_interp_bndry(bcval, cpatch, m_lev[0].cfm, m_ratio);
+    // tensor cross terms: the edge / corner coarse-fine ghost cells take the coarse data interpolated to their centres (no upstream
+    // MLTensorOp::applyBCTensor to follow: DESIGN.md section 2)
+    if (m_tensor) cf_interp_edges(bcval, cpatch, m_lev[0].cfm, m_ratio);
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)

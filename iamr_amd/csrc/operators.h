@@ -28,13 +28,18 @@ MGStats level_project_single(const Geometry& g, double dt, MultiFab& U_new, int 
 
 // ---- Diffusion (reference Source/Diffusion.H:53-225) -------------------------------------------------
 // explicit viscous terms div tau(U): Diffusion::getTensorViscTerms (Source/Diffusion.cpp:1655-1777): out = -b * L_tensor(U), a = 0
+// coarse/fine faces of a refined level (tensorop.setCoarseFineBC): crse = the coarse level's velocity (3 comps, valid data on its own
+// layout) or null for homogeneous data
+struct TensorCF { const MultiFab* crse; const Geometry* cgeom; int ratio; };
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel /*3 comps, 1 ghost; BC data in ghosts*/, double a_scalar, double b_scalar,
-                  const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC* bcs, int nbc /*1 or 3 (per component)*/);
+                  const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC* bcs, int nbc /*1 or 3 (per component)*/,
+                  const TensorCF* cf = nullptr);
 inline void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
                          const MultiFab* const eta[3], const DomainBC& bc) { tensor_apply(g, out, vel, a_scalar, b_scalar, acoef, eta, &bc, 1); }
 // Crank-Nicolson implicit solve (a*acoef - b div tau) u = rhs: Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929)
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
-                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts);
+                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts,
+                     const TensorCF* cf = nullptr);
 inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
                             const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
 { return tensor_solve(g, soln, rhs, a_scalar, b_scalar, acoef, eta, &bc, 1, tol_rel, tol_abs, opts); }

@@ -69,7 +69,7 @@ static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], Layo
 }
 
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
-                  const MultiFab* const eta[3], const DomainBC* bcs, int nbc)
+                  const MultiFab* const eta[3], const DomainBC* bcs, int nbc, const TensorCF* cf)
 {
     MGOpts o;
     o.max_coarsening_level = 0;      // info.setMaxCoarseningLevel(0) (Diffusion.cpp:708)
@@ -79,12 +79,13 @@ void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scal
     MultiFab tb[3];
     const MultiFab* bp[3];
     setup_tensor(mg, tb, bp, vel.layout, a_scalar, b_scalar, acoef, eta);
+    if (cf) mg.setCoarseFineBC(cf->crse, *cf->cgeom, cf->ratio);      // tensorop.setCoarseFineBC (Diffusion.cpp:1725-1736)
     mg.prepare();
     mg.apply(out, vel);
 }
 
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
-                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts)
+                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts, const TensorCF* cf)
 {
     MGOpts o = opts;
     o.maxorder = bcs[0].maxorder;
@@ -93,6 +94,7 @@ MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, dou
     MultiFab tb[3];
     const MultiFab* bp[3];
     setup_tensor(mg, tb, bp, soln.layout, a_scalar, b_scalar, acoef, eta);
+    if (cf) mg.setCoarseFineBC(cf->crse, *cf->cgeom, cf->ratio);      // Diffusion.cpp:876-887 (crse == null: :1096-1099)
     mg.prepare();
     return mg.solve(soln, rhs, tol_rel, tol_abs);
 }

@@ -104,6 +104,24 @@ def tensor_solve(geom, soln, rhs, a, b, acoef, eta, lobc=(0, 0, 0), hibc=(0, 0, 
     return st
 
 
+def tensor_apply_cf(geom, out, vel, a, b, acoef, eta, crse_vel, cgeom, ratio=2, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=2):
+    """tensor operator on a refined level (tensorop.setCoarseFineBC(&crsedata, ratio), Source/Diffusion.cpp:1725-1736); crse_vel None: homogeneous"""
+    lo, hi, nbc = _bcn(lobc, hibc)
+    check(lib().iamrx_tensor_apply_cf(C.byref(geom), out.h, vel.h, C.c_double(a), C.c_double(b), _h(acoef), eta[0].h, eta[1].h,
+                                      eta[2].h, lo, hi, nbc, maxorder, _h(crse_vel), C.byref(cgeom), int(ratio)))
+
+
+def tensor_solve_cf(geom, soln, rhs, a, b, acoef, eta, crse_vel, cgeom, ratio=2, lobc=(0, 0, 0), hibc=(0, 0, 0), tol_rel=1e-10, tol_abs=0.0,
+                    opts=None):
+    st = MgStats()
+    o = opts if opts is not None else mg_opts(maxorder=2)
+    lo, hi, nbc = _bcn(lobc, hibc)
+    check(lib().iamrx_tensor_solve_cf(C.byref(geom), soln.h, rhs.h, C.c_double(a), C.c_double(b), _h(acoef), eta[0].h, eta[1].h,
+                                      eta[2].h, lo, hi, nbc, _h(crse_vel), C.byref(cgeom), int(ratio), C.c_double(tol_rel), C.c_double(tol_abs),
+                                      C.byref(o), C.byref(st)))
+    return st
+
+
 class NavierStokes:
     """level object with the reference's method names (NavierStokes::advance, post_init, ...)"""
     S_NEW, S_OLD, P_NEW, P_OLD, GP_NEW, GP_OLD, UMAC_X, UMAC_Y, UMAC_Z, AOFS = range(10)

@@ -239,6 +239,16 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
                        iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, double tol_rel, double tol_abs,
                        const iamrx_mg_opts* o, iamrx_mg_stats* st);
 
+/* the same on a refined level that does not cover the domain (tensorop.setCoarseFineBC(&crsedata, ratio), Source/Diffusion.cpp:733-744,
+ * 876-887, 1725-1736; crse_vel == NULL: homogeneous coarse/fine data as in diffuse_tensor_Vsync, :1096-1099).  crse_vel: the coarse
+ * level's velocity (3 comps, valid data on its own layout) at the time of the operator. */
+int iamrx_tensor_apply_cf(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
+                          iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, int maxorder,
+                          iamrx_mf crse_vel, const iamrx_geom* cgeom, int ratio);
+int iamrx_tensor_solve_cf(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double a, double b, iamrx_mf acoef, iamrx_mf eta_x,
+                          iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, iamrx_mf crse_vel,
+                          const iamrx_geom* cgeom, int ratio, double tol_rel, double tol_abs, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
 /* ---- inter-level data motion (first building blocks) ------------------------------------------------------ */
 /* amrex::MultiFab::ParallelCopy: dst(valid + dst_ng) <- src(valid + src_ng) wherever they intersect; dst and src may live on
  * different layouts of the same index space (same index type); periodic_geom != NULL adds the periodic images of src */

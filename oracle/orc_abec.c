@@ -30,9 +30,10 @@ void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const 
                                    int maxorder, int inhomog, const orc_fab* bcval);    /* orc_tensor.c */
 
 static void cf_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x);
+void orc_tensor_cross_terms_add_cf(const orc_abec_level* L, orc_fab* y, const orc_fab* x);   /* orc_tensor.c */
 void orc_abec_apply(const orc_abec_level* L, orc_fab* y, const orc_fab* x)
 {
-    if (L->nbox > 0) { cf_apply(L, y, x); return; }
+    if (L->nbox > 0) { cf_apply(L, y, x); if (orc_abec_is_tensor(L)) orc_tensor_cross_terms_add_cf(L, y, x); return; }
     const orc_geom* g = &L->g;
     const double dhx = L->beta / (g->dx[0] * g->dx[0]);
     const double dhy = L->beta / (g->dx[1] * g->dx[1]);
@@ -93,6 +94,8 @@ static double bc_coef0(int bct, int blen, int maxorder)
  * cf_loc[d] behind the face: ghost = c[0]*bcval + sum_m c[m]*phi(m-th cell inside), Lagrange weights through
  * x = {-cf_loc/dx, 0.5, 1.5, 2.5}, order NX = min(box length + 1, maxorder). */
 static const orc_fab* g_cf_bcval = NULL;     /* coarse/fine Dirichlet data of the solve in progress */
+static const orc_fab* g_cf_edgeval = NULL;   /* tensor operator: the coarse data (cell centred, >= 1 filled ghost cell) behind the edge / corner coarse-fine ghost cells */
+static int g_cf_edge_ratio = 2;
 static int g_cf_inhomog = 0;                 /* set by orc_abec_applybc: the next apply uses the data (1) or zero (0) */
 static int g_cf_maxorder = 2;
 
@@ -149,6 +152,57 @@ static double box_nbr(const orc_abec_level* L, const orc_fab* x, const int* bx, 
     }
     return v;
 }
+/* value of x in cell (i,j,k) of the grown box bx (one ghost layer) as the box sees it: valid data of the level (own box, other boxes,
+ * periodic images), the stored ghost value outside the physical domain, the coarse/fine face formula next to a face of the box, and
+ * in the edge / corner coarse-fine ghost cells (tensor cross terms only) the coarse data interpolated to the cell centre -- frozen
+ * during the solve, zero in the homogeneous (correction) form of the operator */
+double orc_cf_box_value(const orc_abec_level* L, const orc_fab* x, const int* bx, int i, int j, int k, int n)
+{
+    const int q[3] = {i, j, k};
+    int nout = 0, d = -1, s = 0;
+    for (int e = 0; e < 3; ++e) {
+        if (q[e] < bx[e]) { ++nout; d = e; s = -1; }
+        else if (q[e] > bx[3 + e]) { ++nout; d = e; s = 1; }
+    }
+    if (nout == 0) return A4(x, i, j, k, n);
+    const int w = box_of(L, i, j, k);
+    if (w < 0) return A4(x, i, j, k, n);
+    if (w > 0) return wrapped(L, x, i, j, k, n);
+    if (nout == 1) {
+        int r[3] = {i, j, k}, cf;
+        r[d] -= s;                                  /* the cell of the box next to the face */
+        return box_nbr(L, x, bx, r[0], r[1], r[2], n, d, s, &cf);
+    }
+    if (!(g_cf_inhomog && g_cf_edgeval)) return 0.0;
+    /* coarse data interpolated to the cell centre, quadratically in every direction: centred stencil where the cell lies inside the
+     * box's index range, one-sided towards the box where it lies outside */
+    const int r = g_cf_edge_ratio;
+    int c[3], o[3][3];
+    double wq[3][3];
+    for (int e = 0; e < 3; ++e) {
+        c[e] = q[e] >= 0 ? q[e] / r : -((-q[e] + r - 1) / r);
+        const double off = (q[e] - c[e] * r + 0.5) / r - 0.5;
+        if (q[e] < bx[e] || q[e] > bx[3 + e]) {
+            const int sg = q[e] < bx[e] ? 1 : -1;
+            const double u = off * sg;
+            o[e][0] = 0; o[e][1] = sg; o[e][2] = 2 * sg;
+            wq[e][0] = 0.5 * (u - 1.0) * (u - 2.0); wq[e][1] = -u * (u - 2.0); wq[e][2] = 0.5 * u * (u - 1.0);
+        } else {
+            o[e][0] = -1; o[e][1] = 0; o[e][2] = 1;
+            wq[e][0] = 0.5 * off * (off - 1.0); wq[e][1] = 1.0 - off * off; wq[e][2] = 0.5 * off * (off + 1.0);
+        }
+    }
+    const int cn[3] = {L->g.n[0] / r, L->g.n[1] / r, L->g.n[2] / r};
+    double v = 0.0;
+    for (int cz = 0; cz < 3; ++cz) for (int cy = 0; cy < 3; ++cy) for (int cx = 0; cx < 3; ++cx) {
+        int z[3] = {c[0] + o[0][cx], c[1] + o[1][cy], c[2] + o[2][cz]};
+        for (int e = 0; e < 3; ++e) if (L->g.periodic[e]) z[e] = (z[e] % cn[e] + cn[e]) % cn[e];
+        v += wq[0][cx] * wq[1][cy] * wq[2][cz] * A4(g_cf_edgeval, z[0], z[1], z[2], n);
+    }
+    return v;
+}
+void orc_cf_set_edgeval(const orc_fab* e, int ratio) { g_cf_edgeval = e; g_cf_edge_ratio = ratio; }
+void orc_cf_set_bcval(const orc_fab* b, int inhomog, int maxorder) { g_cf_bcval = b; g_cf_inhomog = inhomog; g_cf_maxorder = maxorder; }
 static void cf_zero_uncovered(const orc_abec_level* L, orc_fab* y)
 {
     const orc_geom* g = &L->g;

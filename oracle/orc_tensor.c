@@ -72,16 +72,18 @@ void orc_tensor_fill_edges_corners(const orc_abec_level* L, orc_fab* phi, const 
     }
 }
 
-void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_fab* v)
+/* cross-term face fluxes and their divergence for the cells lo..hi; v must hold every cell of the range grown by one */
+static void cross_terms_range(const orc_abec_level* L, orc_fab* y, const orc_fab* v, const int lo[3], const int hi[3],
+                              orc_fab* fxp, orc_fab* fyp, orc_fab* fzp, orc_fab* const flux_out[3], double flux_scale)
 {
     const orc_geom* g = &L->g;
     const double dxi = 1.0 / g->dx[0], dyi = 1.0 / g->dx[1], dzi = 1.0 / g->dx[2];
     const double twoThirds = 2.0 / 3.0;
-    orc_fab fx = orc_alloc(g->n, ORC_FACE[0], 0, 3), fy = orc_alloc(g->n, ORC_FACE[1], 0, 3), fz = orc_alloc(g->n, ORC_FACE[2], 0, 3);
+    orc_fab fx = *fxp, fy = *fyp, fz = *fzp;
     const orc_fab *etax = &L->b[0], *etay = &L->b[1], *etaz = &L->b[2];
     const double xif = 0.0; /* bulk viscosity kappa = 0 */
     _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
-    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+    for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0] + 1; ++i) {
         double dudy = (A4(v, i, j + 1, k, 0) + A4(v, i - 1, j + 1, k, 0) - A4(v, i, j - 1, k, 0) - A4(v, i - 1, j - 1, k, 0)) * (0.25 * dyi);
         double dvdy = (A4(v, i, j + 1, k, 1) + A4(v, i - 1, j + 1, k, 1) - A4(v, i, j - 1, k, 1) - A4(v, i - 1, j - 1, k, 1)) * (0.25 * dyi);
         double dudz = (A4(v, i, j, k + 1, 0) + A4(v, i - 1, j, k + 1, 0) - A4(v, i, j, k - 1, 0) - A4(v, i - 1, j, k - 1, 0)) * (0.25 * dzi);
@@ -94,7 +96,7 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
         A4(&fx, i, j, k, 2) = -mut * dudz;
     }
     _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
-    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+    for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1] + 1; ++j) for (int i = lo[0]; i <= hi[0]; ++i) {
         double dudx = (A4(v, i + 1, j, k, 0) + A4(v, i + 1, j - 1, k, 0) - A4(v, i - 1, j, k, 0) - A4(v, i - 1, j - 1, k, 0)) * (0.25 * dxi);
         double dvdx = (A4(v, i + 1, j, k, 1) + A4(v, i + 1, j - 1, k, 1) - A4(v, i - 1, j, k, 1) - A4(v, i - 1, j - 1, k, 1)) * (0.25 * dxi);
         double dvdz = (A4(v, i, j, k + 1, 1) + A4(v, i, j - 1, k + 1, 1) - A4(v, i, j, k - 1, 1) - A4(v, i, j - 1, k - 1, 1)) * (0.25 * dzi);
@@ -107,7 +109,7 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
         A4(&fy, i, j, k, 2) = -mut * dvdz;
     }
     _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
-    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+    for (int k = lo[2]; k <= hi[2] + 1; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i) {
         double dudx = (A4(v, i + 1, j, k, 0) + A4(v, i + 1, j, k - 1, 0) - A4(v, i - 1, j, k, 0) - A4(v, i - 1, j, k - 1, 0)) * (0.25 * dxi);
         double dwdx = (A4(v, i + 1, j, k, 2) + A4(v, i + 1, j, k - 1, 2) - A4(v, i - 1, j, k, 2) - A4(v, i - 1, j, k - 1, 2)) * (0.25 * dxi);
         double dvdy = (A4(v, i, j + 1, k, 1) + A4(v, i, j + 1, k - 1, 1) - A4(v, i, j - 1, k, 1) - A4(v, i, j - 1, k - 1, 1)) * (0.25 * dyi);
@@ -119,13 +121,79 @@ void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_f
         A4(&fz, i, j, k, 1) = -mut * dwdy;
         A4(&fz, i, j, k, 2) = -mun * (-twoThirds * divu) - xif * divu;
     }
+    if (y)
     for (int n = 0; n < 3; ++n)
-    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+    for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) for (int i = lo[0]; i <= hi[0]; ++i)
         A4(y, i, j, k, n) += L->beta * (dxi * (A4(&fx, i + 1, j, k, n) - A4(&fx, i, j, k, n))
                                       + dyi * (A4(&fy, i, j + 1, k, n) - A4(&fy, i, j, k, n))
                                       + dzi * (A4(&fz, i, j, k + 1, n) - A4(&fz, i, j, k, n)));
+    if (flux_out) {                       /* MLTensorOp::compFlux: the cross-term part of the face fluxes, flux += beta * f */
+        orc_fab* fl[3] = {&fx, &fy, &fz};
+        for (int d = 0; d < 3; ++d) {
+            int h[3] = {hi[0], hi[1], hi[2]}; h[d] += 1;
+            for (int n = 0; n < 3; ++n)
+            for (int k = lo[2]; k <= h[2]; ++k) for (int j = lo[1]; j <= h[1]; ++j) for (int i = lo[0]; i <= h[0]; ++i)
+                A4(flux_out[d], i, j, k, n) += flux_scale * L->beta * A4(fl[d], i, j, k, n);
+        }
+    }
+}
+
+void orc_tensor_cross_terms_add(const orc_abec_level* L, orc_fab* y, const orc_fab* v)
+{
+    const orc_geom* g = &L->g;
+    orc_fab fx = orc_alloc(g->n, ORC_FACE[0], 0, 3), fy = orc_alloc(g->n, ORC_FACE[1], 0, 3), fz = orc_alloc(g->n, ORC_FACE[2], 0, 3);
+    const int lo[3] = {0, 0, 0}, hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1};
+    cross_terms_range(L, y, v, lo, hi, &fx, &fy, &fz, NULL, 0.0);
     orc_free(&fx); orc_free(&fy); orc_free(&fz);
 }
+
+/* the same on a level that does not cover the domain: box by box, on a copy of the box grown by one cell whose ghost cells hold what
+ * the box sees there (orc_cf_box_value).  flux_out (may be NULL): the cross-term fluxes are ADDED to it, scaled, on the faces of every box */
+double orc_cf_box_value(const orc_abec_level* L, const orc_fab* x, const int* bx, int i, int j, int k, int n);   /* orc_abec.c */
+static void cross_terms_cf(const orc_abec_level* L, orc_fab* y, const orc_fab* x, orc_fab* const flux_out[3], double flux_scale)
+{
+    const orc_geom* g = &L->g;
+    orc_fab fx = orc_alloc(g->n, ORC_FACE[0], 0, 3), fy = orc_alloc(g->n, ORC_FACE[1], 0, 3), fz = orc_alloc(g->n, ORC_FACE[2], 0, 3);
+    for (int b = 0; b < L->nbox; ++b) {
+        const int* bx = L->boxes + 6 * b;
+        const int bn[3] = {bx[3] - bx[0] + 1, bx[4] - bx[1] + 1, bx[5] - bx[2] + 1};
+        orc_fab vl = orc_alloc(bn, ORC_CELL, 1, 3);
+        for (int d = 0; d < 3; ++d) { vl.lo[d] += bx[d]; vl.hi[d] += bx[d]; }
+        for (int n = 0; n < 3; ++n)
+        for (int k = bx[2] - 1; k <= bx[5] + 1; ++k) for (int j = bx[1] - 1; j <= bx[4] + 1; ++j) for (int i = bx[0] - 1; i <= bx[3] + 1; ++i)
+            A4(&vl, i, j, k, n) = orc_cf_box_value(L, x, bx, i, j, k, n);
+        const int lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        /* a face shared by two boxes gets the same flux from both (both see the same values there): adding it twice must be avoided */
+        if (flux_out) {
+            orc_fab t[3]; orc_fab* tp[3];
+            for (int d = 0; d < 3; ++d) { t[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); tp[d] = &t[d]; }
+            cross_terms_range(L, y, &vl, lo, hi, &fx, &fy, &fz, tp, flux_scale);
+            for (int d = 0; d < 3; ++d) {
+                int h[3] = {hi[0], hi[1], hi[2]}; h[d] += 1;
+                for (int n = 0; n < 3; ++n)
+                for (int k = lo[2]; k <= h[2]; ++k) for (int j = lo[1]; j <= h[1]; ++j) for (int i = lo[0]; i <= h[0]; ++i) {
+                    const int f[3] = {i, j, k};
+                    /* the low box of a shared face writes it; faces on the box's low side that belong to another box of the level are skipped */
+                    if (f[d] == lo[d]) {
+                        int c[3] = {i, j, k}; c[d] -= 1;
+                        int owned = 0;
+                        for (int b2 = 0; b2 < L->nbox && !owned; ++b2) {
+                            if (b2 == b) continue;
+                            const int* o = L->boxes + 6 * b2;
+                            if (c[0] >= o[0] && c[0] <= o[3] && c[1] >= o[1] && c[1] <= o[4] && c[2] >= o[2] && c[2] <= o[5]) owned = 1;
+                        }
+                        if (owned) continue;
+                    }
+                    A4(flux_out[d], i, j, k, n) += A4(&t[d], i, j, k, n);
+                }
+                orc_free(&t[d]);
+            }
+        } else cross_terms_range(L, y, &vl, lo, hi, &fx, &fy, &fz, NULL, 0.0);
+        orc_free(&vl);
+    }
+    orc_free(&fx); orc_free(&fy); orc_free(&fz);
+}
+void orc_tensor_cross_terms_add_cf(const orc_abec_level* L, orc_fab* y, const orc_fab* x) { cross_terms_cf(L, y, x, NULL, 0.0); }
 
 static void build_level(const orc_geom* g, orc_abec_level* L, double alpha, double beta, const orc_fab* a, orc_fab* const eta[3])
 {
@@ -188,4 +256,57 @@ void orc_tensor_solve(const orc_geom* g, orc_fab* u, const orc_fab* rhs, double 
     build_level(g, &L, alpha, beta, a, eta);
     orc_abec_solve(&L, u, rhs, lobc, hibc, rtol, atol, o, st);
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+}
+
+/* ---- tensor operator on an AMR level that does not cover the domain (Diffusion::getTensorViscTerms / diffuse_tensor_velocity /
+ * diffuse_tensor_Vsync at level > 0: tensorop.setCoarseFineBC(&crsedata or nullptr, ratio), Source/Diffusion.cpp:733-744, 876-887,
+ * 1096-1099, 1725-1736).  Face ghost cells at coarse/fine faces: the MLCellLinOp formula per component (orc_abec.c).  Edge / corner
+ * coarse-fine ghost cells (needed by the cross terms only): the coarse velocity interpolated quadratically to the cell centre
+ * (orc_cf_box_value), frozen during the solve, zero in the correction form -- upstream's MLTensorOp::applyBCTensor is not available to follow (PARITY UNPINNED). */
+void orc_cf_set_edgeval(const orc_fab* e, int ratio);
+void orc_cf_set_bcval(const orc_fab* b, int inhomog, int maxorder);
+void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi, orc_fab* bcval);
+void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                       const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+typedef struct tensor_cf { orc_abec_level L; orc_fab bcv; } tensor_cf;
+static void tcf_begin(tensor_cf* T, const orc_geom* g, int nbox, const int* boxes, int ratio, double alpha, double beta, const orc_fab* a,
+                      orc_fab* const eta[3], const orc_fab* cvel)
+{
+    build_level(g, &T->L, alpha, beta, a, eta);
+    T->L.bc_percomp = 1;
+    T->L.nbox = nbox; T->L.boxes = boxes;
+    for (int d = 0; d < 3; ++d) T->L.cf_loc[d] = 0.5 * ratio * g->dx[d];
+    T->bcv = orc_alloc(g->n, ORC_CELL, 1, 9);
+    orc_setval(&T->bcv, 0.0);
+    if (cvel) orc_cf_interp_bndry(&T->L, ratio, cvel, &T->bcv);
+    orc_cf_set_edgeval(cvel, ratio);
+}
+static void tcf_end(tensor_cf* T)
+{
+    orc_cf_set_edgeval(NULL, 2); orc_cf_set_bcval(NULL, 0, 2);
+    orc_free(&T->bcv);
+    for (int d = 0; d < 3; ++d) orc_free(&T->L.b[d]);
+}
+/* y = (alpha a - beta div tau) u on the cells of the level; the ghost cells of u outside the physical domain hold the boundary data on entry */
+void orc_tensor_apply_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* y, orc_fab* u, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, int maxorder, const orc_fab* cvel)
+{
+    tensor_cf T;
+    tcf_begin(&T, g, nbox, boxes, ratio, alpha, beta, a, eta, cvel);
+    orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 3);
+    orc_copy_all(&bcval, u);
+    orc_cf_set_bcval(&T.bcv, 1, maxorder);
+    orc_abec_applybc(&T.L, u, lobc, hibc, maxorder, 1, &bcval);
+    orc_abec_apply(&T.L, y, u);
+    orc_free(&bcval);
+    tcf_end(&T);
+}
+void orc_tensor_solve_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, const orc_fab* cvel,
+                         double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    tensor_cf T;
+    tcf_begin(&T, g, nbox, boxes, ratio, alpha, beta, a, eta, cvel);
+    orc_abec_solve_cf(&T.L, u, rhs, lobc, hibc, &T.bcv, rtol, atol, o, st);
+    tcf_end(&T);
 }
