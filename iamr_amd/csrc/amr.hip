@@ -319,6 +319,11 @@ __global__ void __launch_bounds__(256) k_cellconslin(const BoxD* __restrict__ pb
 
 }  // namespace
 
+const MultiFab* state_time_interp(const TimeData& td, double time, int scomp, int ncomp, MultiFab& tmp, int& comp0)
+{
+    return time_interp(td, time, scomp, ncomp, tmp, comp0);
+}
+
 void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
                           const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi)
 {

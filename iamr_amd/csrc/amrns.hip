@@ -695,7 +695,6 @@ void AmrNS::reflux(int l)
 void AmrNS::mac_sync(int l)
 {
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
-    if (c.is_diffusive_vel() || c.is_diffusive_tracer()) throw Error("iamrx AmrNS::mac_sync: the viscous / diffusive sync is not implemented");
     auto& ctx = Context::get();
     const double dt = dt_level[l];
     MultiFab Ucorr[3];
@@ -721,13 +720,25 @@ void AmrNS::mac_sync(int l)
         }
         MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), NUM_SCALARS, 1), divu(c.layout, cell_type(), 1, 1);
         tfs.setVal(0.0); divu.setVal(0.0);
+        // viscous forcing at the old time (MacProj.cpp:566-572): getViscTerms(visc_terms, 0, num_state_comps, prev_time)
+        MultiFab vvisc(c.layout, cell_type(), 3, 1);
+        vvisc.setVal(0.0);
+        if (c.p.be_cn_theta != 1.0) {
+            if (c.is_diffusive_vel()) c.get_visc_terms_vel(vvisc, c.S[1 - c.inew]);
+            if (c.is_diffusive_tracer()) {
+                // conservative tracer: tf += visc, convective: tf = tf / rho + visc with tf = 0 (MacProj.cpp:641-683)
+                MultiFab sv(c.layout, cell_type(), 1, 1);
+                c.get_visc_terms_tracer(sv, c.S[1 - c.inew]);
+                MultiFab::Copy(tfs, sv, 0, Tracer - 3, 1, 1);
+            }
+        }
         {
-            const FabD *tt = tfv.d_tab, *gt = c.Gp[1 - c.pnew].d_tab, *st = Sc.d_tab;
+            const FabD *tt = tfv.d_tab, *gt = c.Gp[1 - c.pnew].d_tab, *st = Sc.d_tab, *vt = vvisc.d_tab;
             const double grav = c.p.gravity;
             for_each(*c.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
                 const double rho = st[fb](i, j, k, 0);
                 for (int n = 0; n < 3; ++n) {
-                    double t = ((fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0) + 0.0 - gt[fb](i, j, k, n);
+                    double t = ((fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0) + vt[fb](i, j, k, n) - gt[fb](i, j, k, n);
                     if (!mom) t /= rho;
                     tt[fb](i, j, k, n) = t;
                 }
@@ -767,7 +778,85 @@ void AmrNS::mac_sync(int l)
             if (mom) for (int n = 0; n < 3; ++n) vt[fb](i, j, k, n) /= rho;
         });
     }
-    mf_mult(c.Ssync, dt, 0, NUM_STATE - 3, 1);              // not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
+    const double theta = c.p.be_cn_theta;
+    if (c.is_diffusive_vel()) {
+        // Diffusion::diffuse_Vsync -> diffuse_tensor_Vsync (Diffusion.cpp:960-1178): (rho - theta dt div tau) Vsync' = rho Vsync, homogeneous
+        // boundary and coarse/fine data.  NOTE the face coefficients of this solve are set to 1.0 upstream (:1122-1135), not to the
+        // viscosity -- followed as written.
+        const bool rf3 = mom;                                   // rho_flag 3 for momentum differencing (NavierStokes.cpp:1552)
+        MultiFab Rhs(c.layout, cell_type(), 3, 0), acoef(c.layout, cell_type(), 1, 0), Soln(c.layout, cell_type(), 3, 1);
+        MultiFab::Copy(Rhs, c.Vsync, 0, 0, 3, 0);
+        {
+            const FabD *rt = Rhs.d_tab, *ht = c.rho_half.d_tab, *ot = c.S[1 - c.inew].d_tab;
+            for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+                const double r = rf3 ? ot[fb](i, j, k, Density) : ht[fb](i, j, k, 0);
+                for (int n = 0; n < 3; ++n) rt[fb](i, j, k, n) *= r;
+            });
+        }
+        if (rf3) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0); else MultiFab::Copy(acoef, c.rho_half, 0, 0, 1, 0);
+        Soln.setVal(0.0);
+        MultiFab one[3];
+        const MultiFab* ep[3];
+        for (int d = 0; d < 3; ++d) { one[d].define(c.layout, face_type(d), 1, 0); one[d].setVal(1.0); ep[d] = &one[d]; }
+        MGOpts vo = o;
+        vo.maxorder = 2;
+        TensorCF cf{nullptr, l > 0 ? &c.crse->g : nullptr, c.ratio};
+        MultiFab tflux[3];
+        TensorFlux fx{{&tflux[0], &tflux[1], &tflux[2]}, theta, false};
+        if (l > 0) for (int d = 0; d < 3; ++d) tflux[d].define(c.layout, face_type(d), 3, 0);
+        tensor_solve(c.g, Soln, Rhs, 1.0, theta * dt, &acoef, ep, c.bc_visc, 3, c.p.visc_tol, -1.0, vo, l > 0 ? &cf : nullptr, l > 0 ? &fx : nullptr);
+        MultiFab::Copy(c.Vsync, Soln, 0, 0, 3, 1);
+        if (l > 0) for (int d = 0; d < 3; ++d) c.reg_visc->FineAdd(tflux[d], d, 0, Xvel, 3, dt * dt);     // :1166-1176
+        // ghost cells outside ext_dir faces back to zero (:987-1008)
+        for (int n = 0; n < 3; ++n) for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            if (c.g.periodic[d] || (side == 0 ? c.bc_vel[n].lo[d] : c.bc_vel[n].hi[d]) != bc_ext_dir) continue;
+            const int face = side == 0 ? c.g.domain.lo[d] - 1 : c.g.domain.hi[d] + 1;
+            const FabD* vt = c.Vsync.d_tab;
+            const int dd = d, nn = n;
+            for_each(*c.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+                if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) vt[fb](i, j, k, nn) = 0.0;
+            });
+        }
+    }
+    mf_mult(c.Ssync, dt, 0, 1, 1);                           // density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
+    if (c.is_diffusive_tracer()) {
+        // Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
+        // flux): (alpha - theta dt div D grad) s = dt Ssync, alpha = rho_new for S = rho q (rho_flag 2) else 1; Ssync = s (x rho_new).
+        // On a refined level upstream passes no coarse data (has_coarse_data = false): homogeneous coarse/fine data here.
+        const bool cons = cons_trac;
+        MultiFab Rhs(c.layout, cell_type(), 1, 0), Soln(c.layout, cell_type(), 1, 1), acoef(c.layout, cell_type(), 1, 0);
+        MultiFab::Copy(Rhs, c.Ssync, Tracer - 3, 0, 1, 0);
+        mf_mult(Rhs, dt, 0, 1, 0);
+        Soln.setVal(0.0);
+        acoef.setVal(1.0);
+        if (cons) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
+        const double tol_abs = c.p.visc_tol * Rhs.norm0(0, 1, 0);
+        MGOpts so = o;
+        so.maxorder = 2;
+        CellMG op(c.g, c.layout, 1, c.bc_scal_lin, so);
+        op.setScalars(1.0, theta * dt);
+        op.setACoeffs(&acoef);
+        const MultiFab* bp[3] = {&c.diff_b[0], &c.diff_b[1], &c.diff_b[2]};
+        op.setBCoeffs(bp);
+        if (l > 0) op.setCoarseFineBC(nullptr, c.crse->g, c.ratio);
+        op.prepare();
+        op.solve(Soln, Rhs, c.p.visc_tol, tol_abs);
+        if (l > 0) {                                              // fluxSC -> viscous register, x dt (NavierStokes.cpp:1630-1638)
+            MultiFab sf[3];
+            MultiFab* sfp[3] = {&sf[0], &sf[1], &sf[2]};
+            for (int d = 0; d < 3; ++d) sf[d].define(c.layout, face_type(d), 1, 0);
+            op.fluxes(Soln, sfp, nullptr);
+            for (int d = 0; d < 3; ++d) {
+                mf_mult(sf[d], c.g.dx[(d + 1) % 3] * c.g.dx[(d + 2) % 3] / dt, 0, 1, 0);          // theta * area * (-D grad s)
+                c.reg_visc->FineAdd(sf[d], d, 0, Tracer, 1, dt);
+            }
+        }
+        if (cons) {
+            const FabD *st = Soln.d_tab, *nt = Sn.d_tab;
+            for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) *= nt[fb](i, j, k, Density); });
+        }
+        MultiFab::Copy(c.Ssync, Soln, 0, Tracer - 3, 1, 0);
+    } else mf_mult(c.Ssync, dt, Tracer - 3, 1, 1);
     if (cons_trac) mf_saxpy(c.Ssync, dt, Delta, 0, Tracer - 3, 1, 0);
     mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, NUM_STATE - 3, 0);
     c.make_rho_curr_time();

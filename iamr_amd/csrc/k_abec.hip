@@ -595,16 +595,20 @@ void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool i
 // bcval(edge / corner coarse-fine ghost cells) = the coarse data of cpatch interpolated to the cell centre, quadratically in every
 // direction: centred stencil (c-1, c, c+1) in the directions in which the cell lies inside the box's index range, one-sided towards
 // the box (c, c+s, c+2s) in the directions in which it lies outside (third order: the cross terms difference these values over h)
-void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio)
+void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio, const Geometry& cgeom)
 {
     if (bcval.nlocal() == 0) return;
     IAMRX_ASSERT(cpatch.ngrow >= 1 && bcval.ngrow >= 1 && cfm.ngrow >= 1);
     const FabD *bt = bcval.d_tab, *ct = cpatch.d_tab, *mt = cfm.d_tab;
     const BoxD* boxes = bcval.layout->d_boxes;
     const int nc = bcval.ncomp, r = ratio;
+    const BoxD cdom = cgeom.domain;
+    const int cper[3] = {cgeom.periodic[0], cgeom.periodic[1], cgeom.periodic[2]};
+    const int cp0 = cper[0], cp1 = cper[1], cp2 = cper[2];
     for_each(*bcval.layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         const BoxD vb = boxes[f];
         const int q[3] = {i, j, k};
+        const int per[3] = {cp0, cp1, cp2};
         int nout = 0;
         for (int e = 0; e < 3; ++e) if (q[e] < vb.lo[e] || q[e] > vb.hi[e]) ++nout;
         if (nout < 2 || mt[f](i, j, k) != 1.0) return;
@@ -618,6 +622,12 @@ void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cf
                 const double u = off * s;
                 o[e][0] = 0; o[e][1] = s; o[e][2] = 2 * s;
                 w[e][0] = 0.5 * (u - 1.0) * (u - 2.0); w[e][1] = -u * (u - 2.0); w[e][2] = 0.5 * u * (u - 1.0);
+            } else if (!per[e] && c[e] - 1 < cdom.lo[e]) {        // next to a wall: one-sided, no coarse cell outside the physical domain
+                o[e][0] = 0; o[e][1] = 1; o[e][2] = 2;
+                w[e][0] = 0.5 * (off - 1.0) * (off - 2.0); w[e][1] = -off * (off - 2.0); w[e][2] = 0.5 * off * (off - 1.0);
+            } else if (!per[e] && c[e] + 1 > cdom.hi[e]) {
+                o[e][0] = -2; o[e][1] = -1; o[e][2] = 0;
+                w[e][0] = 0.5 * off * (off + 1.0); w[e][1] = -off * (off + 2.0); w[e][2] = 0.5 * (off + 1.0) * (off + 2.0);
             } else {
                 o[e][0] = -1; o[e][1] = 0; o[e][2] = 1;
                 w[e][0] = 0.5 * off * (off - 1.0); w[e][1] = 1.0 - off * off; w[e][2] = 0.5 * off * (off + 1.0);

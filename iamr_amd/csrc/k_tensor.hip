@@ -96,6 +96,38 @@ void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out,
 }
 
 // MLTensorOp::setShearViscosity: b_d(comp) = eta_d * (comp == d ? 4/3 : 1), bulk viscosity 0
+// Diffusion::computeExtensiveFluxes on the tensor operator (Source/Diffusion.cpp:1463-1537: MLMG::getFluxes, i.e. the face fluxes of
+// the operator without its b scalar, times fac x face area): flux_d(n) = fac * area_d * ( -eta_d (4/3 if n == d) du_n/dx_d + cross_d(n) ).
+// vel: 3 comps, the ghost cells hold what the operator put there (CellMG::applyBC); eta: 1-component face viscosity; flux_d: 3 comps
+template <int D>
+static void tensor_flux_dir(const Geometry& g, const MultiFab& vel, const MultiFab& eta, MultiFab& flux, double fac, bool add)
+{
+    const FabD *vt = vel.d_tab, *et = eta.d_tab, *ft = flux.d_tab;
+    const double dxi = 1.0 / g.dx[0], dyi = 1.0 / g.dx[1], dzi = 1.0 / g.dx[2];
+    const double hinv = 1.0 / g.dx[D];
+    const double scale = fac * g.dx[(D + 1) % 3] * g.dx[(D + 2) % 3];
+    for_each(*vel.layout, face_type(D), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD v = vt[f], e = et[f];
+        double cf[3];
+        cross_flux<D, true>(v, e, i, j, k, dxi, dyi, dzi, cf);
+        const int im = i - (D == 0), jm = j - (D == 1), km = k - (D == 2);
+        const double e1 = e(i, j, k, 0);
+        for (int n = 0; n < 3; ++n) {
+            const double b = e1 * (n == D ? 4.0 / 3.0 : 1.0);
+            const double fl = scale * (-b * (v(i, j, k, n) - v(im, jm, km, n)) * hinv + cf[n]);
+            if (add) ft[f](i, j, k, n) += fl; else ft[f](i, j, k, n) = fl;
+        }
+    });
+}
+void tensor_extensive_flux(const Geometry& g, const MultiFab& vel, const MultiFab* const eta[3], MultiFab* const flux[3], double fac, bool add)
+{
+    if (vel.nlocal() == 0) return;
+    IAMRX_ASSERT(vel.ncomp >= 3 && vel.ngrow >= 1 && eta[0]->ncomp == 1);
+    tensor_flux_dir<0>(g, vel, *eta[0], *flux[0], fac, add);
+    tensor_flux_dir<1>(g, vel, *eta[1], *flux[1], fac, add);
+    tensor_flux_dir<2>(g, vel, *eta[2], *flux[2], fac, add);
+}
+
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir)
 {
     if (b3.nlocal() == 0) return;

@@ -60,7 +60,7 @@ void cf_build_mask(const Geometry& g, MultiFab& cfm);
 // ghost cells with mask 1 next to a box face: phi = c[0] * bcval (inhomog) + sum_m c[m] * phi(m-th cell inside)   (mllinop_apply_bc)
 // edges: also the edge / corner coarse-fine ghost cells (tensor operator): bcval there (cf_interp_edges) or zero
 void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval, bool edges = false);
-void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
+void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio, const Geometry& cgeom);
 // bcval(ghost cells with mask 1) = coarse data of cpatch (coarsened layout, 1 ghost cell) interpolated in the tangential directions
 // (InterpBndryData::setBndryValues, third order, ratio 2); cfm needs 2 ghost cells
 void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
@@ -118,6 +118,8 @@ void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& p
 
 // ---- k_tensor.hip -------------------------------------------------------------------------
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
+// extensive face fluxes of the tensor operator (Diffusion::computeExtensiveFluxes): fac * area * (-eta (4/3) du_n/dx_d + cross terms)
+void tensor_extensive_flux(const Geometry& g, const MultiFab& vel, const MultiFab* const eta[3], MultiFab* const flux[3], double fac, bool add);
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);
 void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 

@@ -158,7 +158,7 @@ void CellMG::cf_bcval(MultiFab& bcval)
     cf_interp_bndry(bcval, cpatch, m_lev[0].cfm, m_ratio);
     // tensor cross terms: the edge / corner coarse-fine ghost cells take the coarse data interpolated to their centres (no upstream
     // MLTensorOp::applyBCTensor to follow: DESIGN.md section 2)
-    if (m_tensor) cf_interp_edges(bcval, cpatch, m_lev[0].cfm, m_ratio);
+    if (m_tensor) cf_interp_edges(bcval, cpatch, m_lev[0].cfm, m_ratio, m_cgeom);
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)

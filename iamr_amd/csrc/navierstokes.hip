@@ -240,11 +240,48 @@ void NavierStokes::fill_gp(MultiFab& G, double time_)
     MultiFab::Copy(G, tmp, 0, 0, 3, 1);
 }
 
-// Extrapolater::FirstOrderExtrap role (NavierStokes.cpp:2047): ghost cells outside the physical domain take the value
-// of the nearest cell inside it (index clamp in the non-periodic directions).  These cells only feed Godunov states on
-// wall faces, which the wall BC overrides.
+// Extrapolater::FirstOrderExtrap role (NavierStokes.cpp:2047), after FillBoundary.  Ghost cells outside the physical domain take the
+// value of the nearest cell inside it (index clamp in the non-periodic directions); these cells only feed Godunov states on wall
+// faces, which the wall BC overrides.  Ghost cells at coarse/fine boundaries (level > 0: inside the domain, not covered by the level)
+// take the mean of the level's cells among their face neighbours, else among their edge neighbours, else among their corner
+// neighbours -- a single-valued rule (upstream extrapolates box by box; its source is not in the reference tree: unpinned).
+const MultiFab& NavierStokes::cf_mask()
+{
+    if (!m_cf_mask_built) { m_cf_mask.define(layout, cell_type(), 1, 2); cf_build_mask(g, m_cf_mask); m_cf_mask_built = true; }
+    return m_cf_mask;
+}
+
 void NavierStokes::first_order_extrap(MultiFab& mf)
 {
+    IAMRX_ASSERT(mf.ngrow == 1 && mf.ncomp <= 8);
+    if (level > 0) {
+        const MultiFab& cm = cf_mask();
+        MultiFab src(layout, cell_type(), mf.ncomp, 1);
+        MultiFab::Copy(src, mf, 0, 0, mf.ncomp, 1);
+        const FabD *t = mf.d_tab, *st = src.d_tab, *mt = cm.d_tab;
+        const int nc = mf.ncomp;
+        const BoxD* vb = layout->d_boxes;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const FabD m = mt[f];
+            if (m(i, j, k) != 1.0) return;
+            BoxD gb = vb[f];
+            for (int d = 0; d < 3; ++d) { gb.lo[d] -= 1; gb.hi[d] += 1; }
+            const FabD a = t[f], sa = st[f];
+            for (int cls = 1; cls <= 3; ++cls) {
+                int cnt = 0;
+                double sum[8];
+                for (int n = 0; n < nc; ++n) sum[n] = 0.0;
+                for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                    if ((dx != 0) + (dy != 0) + (dz != 0) != cls) continue;
+                    const int ii = i + dx, jj = j + dy, kk = k + dz;
+                    if (!gb.contains(ii, jj, kk) || m(ii, jj, kk) != 0.0) continue;
+                    ++cnt;
+                    for (int n = 0; n < nc; ++n) sum[n] += sa(ii, jj, kk, n);
+                }
+                if (cnt > 0) { for (int n = 0; n < nc; ++n) a(i, j, k, n) = sum[n] / (double)cnt; return; }
+            }
+        });
+    }
     if (!any_wall) return;
     const FabD* t = mf.d_tab;
     const int nc = mf.ncomp;
@@ -259,6 +296,26 @@ void NavierStokes::first_order_extrap(MultiFab& mf)
         const FabD a = t[f];
         for (int n = 0; n < nc; ++n) a(i, j, k, n) = a(q0, q1, q2, n);
     });
+}
+
+void NavierStokes::crse_state_at(MultiFab& out, double t, int scomp, int ncomp)
+{
+    TimeData cd{&crse->S[1 - crse->inew], &crse->S[crse->inew], crse->st_old, crse->st_new};
+    MultiFab tmp;
+    int c0 = 0;
+    const MultiFab* src = state_time_interp(cd, t, scomp, ncomp, tmp, c0);
+    out.define(crse->layout, cell_type(), ncomp, 0);
+    MultiFab::Copy(out, *src, c0, 0, ncomp, 0);
+}
+
+void NavierStokes::crse_scalar_at(MultiFab& out, double t, bool over_rho)
+{
+    crse_state_at(out, t, Tracer, 1);
+    if (!over_rho) return;
+    MultiFab r;
+    crse_state_at(r, t, Density, 1);
+    const FabD *ot = out.d_tab, *rt = r.d_tab;
+    for_each(*crse->layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) { ot[f](i, j, k) /= rt[f](i, j, k); });
 }
 
 // FillPatch(Gradp_Type) after a projection (Projection.cpp:2565): foextrap at walls
@@ -285,7 +342,10 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
     fillpatch(stmp, Sdata, Xvel, 3, bc_vel);
     MultiFab tmp(layout, cell_type(), 3, 0);
     const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
-    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc, 3);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
+    MultiFab cdata;
+    TensorCF cf{&cdata, level > 0 ? &crse->g : nullptr, ratio};
+    if (level > 0) crse_state_at(cdata, state_time(Sdata), Xvel, 3);        // Diffusion.cpp:1725-1736
+    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc, 3, level > 0 ? &cf : nullptr);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
     MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
     visc.FillBoundary(g);
     first_order_extrap(visc);
@@ -316,6 +376,11 @@ void NavierStokes::get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata)
     mg.setScalars(0.0, -1.0);
     const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
     mg.setBCoeffs(bp);
+    MultiFab cdata;
+    if (level > 0) {                                              // mlabec.setCoarseFineBC(&crsedata, ratio), Diffusion.cpp:1600-1609
+        crse_scalar_at(cdata, state_time(Sdata), p.do_cons_trac != 0);
+        mg.setCoarseFineBC(&cdata, crse->g, ratio);
+    }
     mg.prepare();
     MultiFab tmp(layout, cell_type(), 1, 0);
     mg.apply(tmp, stmp);
@@ -576,6 +641,11 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     MultiFab& So = S[1 - inew];
     const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
     MultiFab Rhs(layout, cell_type(), 1, 0);
+    const bool want_flux = fine != nullptr || level > 0;         // NavierStokes.cpp:949-990
+    MultiFab sflux[3], sflux1[3];
+    MultiFab *sfp[3] = {&sflux[0], &sflux[1], &sflux[2]}, *sfp1[3] = {&sflux1[0], &sflux1[1], &sflux1[2]};
+    if (want_flux) for (int d = 0; d < 3; ++d) { sflux[d].define(layout, face_type(d), 1, 0); sflux[d].setVal(0.0); sflux1[d].define(layout, face_type(d), 1, 0); }
+    MultiFab cdata;
     if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 1, 1);
         fillpatch(Soln0, So, Tracer, 1, &bc_scal[1]);
@@ -590,8 +660,13 @@ void NavierStokes::scalar_diffusion_update(double dt_)
         CellMG opn(g, layout, 1, bc_scal_lin, mo);
         opn.setScalars(0.0, -(1.0 - theta) * dt_);
         opn.setBCoeffs(bp);
+        if (level > 0) { crse_scalar_at(cdata, st_old, cons); opn.setCoarseFineBC(&cdata, crse->g, ratio); }     // Diffusion.cpp:376-396
         opn.prepare();
         opn.apply(Rhs, Soln0);
+        if (want_flux) {                                         // fluxn = (1 - theta) * area * (-D grad s_old) (Diffusion.cpp:437-438)
+            opn.fluxes(Soln0, sfp, nullptr);                     // -beta_scalar * b * grad
+            for (int d = 0; d < 3; ++d) mf_mult(sflux[d], (1.0 - theta) * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (-(1.0 - theta) * dt_), 0, 1, 0);
+        }
     } else Rhs.setVal(0.0);
     mf_saxpy(Rhs, 1.0, Sn, Tracer, 0, 1, 0);                     // rhs += S_new (Diffusion.cpp:479-493)
     const double tol_abs = p.visc_tol * Rhs.norm0(0, 1, 0);      // get_scaled_abs_tol
@@ -611,8 +686,17 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     opnp1.setScalars(1.0, theta * dt_);
     opnp1.setACoeffs(&acoef);
     opnp1.setBCoeffs(bp);
+    if (level > 0) { crse_scalar_at(cdata, st_new, cons); opnp1.setCoarseFineBC(&cdata, crse->g, ratio); }   // Diffusion.cpp:506-518
     opnp1.prepare();
     st_scal = opnp1.solve(Soln, Rhs, p.visc_tol, tol_abs);
+    if (want_flux) {                                             // fluxnp1 = theta * area * (-D grad s_new) (Diffusion.cpp:569-570); registers NavierStokes.cpp:949-990
+        opnp1.fluxes(Soln, sfp1, nullptr);
+        for (int d = 0; d < 3; ++d) {
+            mf_saxpy(sflux[d], theta * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (theta * dt_), sflux1[d], 0, 0, 1, 0);
+            if (level > 0) reg_visc->FineAdd(sflux[d], d, 0, Tracer, 1, dt_);
+            if (fine) fine->reg_visc->CrseInit(sflux[d], d, 0, Tracer, 1, -dt_, false);
+        }
+    }
     if (cons) scale_by(Soln, Sn, Density, 0, false);            // Diffusion.cpp:583-590
     MultiFab::Copy(Sn, Soln, 0, Tracer, 1, 0);
 }
@@ -675,10 +759,19 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     MultiFab& So = S[1 - inew];
     const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
     MultiFab Rhs(layout, cell_type(), 3, 0);
+    // viscous fluxes for the registers of the interfaces above and below (do_reflux && (level < finest_level || level > 0), Diffusion.cpp:790-796, 932-956)
+    const bool want_flux = fine != nullptr || level > 0;
+    MultiFab tflux[3];
+    TensorFlux fx{{&tflux[0], &tflux[1], &tflux[2]}, 0.0, false};
+    if (want_flux) for (int d = 0; d < 3; ++d) { tflux[d].define(layout, face_type(d), 3, 0); tflux[d].setVal(0.0); }
+    MultiFab cdata;
+    TensorCF cf{&cdata, level > 0 ? &crse->g : nullptr, ratio};
     if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 3, 1);
         fillpatch(Soln0, So, Xvel, 3, bc_vel);
-        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc, 3);
+        if (level > 0) crse_state_at(cdata, st_old, Xvel, 3);                 // crsedata at prev_time (Diffusion.cpp:733-744)
+        fx.fac = 1.0 - theta; fx.add = false;                                // computeExtensiveFluxes(..., -b/dt), b = -(1-theta) dt
+        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc, 3, level > 0 ? &cf : nullptr, want_flux ? &fx : nullptr);
     } else Rhs.setVal(0.0);
     {
         const FabD *nt = Sn.d_tab, *ot = So.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
@@ -701,8 +794,16 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     else MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);            // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
     MGOpts vo = o;
     vo.maxorder = 2;
-    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, 3, p.visc_tol, tol_abs, vo);
+    if (level > 0) crse_state_at(cdata, st_new, Xvel, 3);        // crsedata at cur_time (Diffusion.cpp:876-887)
+    fx.fac = theta; fx.add = true;                               // computeExtensiveFluxes(..., b/dt) added to the old-time fluxes (:941-945)
+    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, 3, p.visc_tol, tol_abs, vo, level > 0 ? &cf : nullptr,
+                           want_flux ? &fx : nullptr);
     MultiFab::Copy(Sn, Soln, 0, Xvel, 3, 1);                     // Diffusion.cpp:928
+    if (want_flux)
+        for (int d = 0; d < 3; ++d) {
+            if (level > 0) reg_visc->FineAdd(tflux[d], d, 0, Xvel, 3, dt_);                        // :946-949
+            if (fine) fine->reg_visc->CrseInit(tflux[d], d, 0, Xvel, 3, -dt_, false);             // :950-954
+        }
 }
 
 void NavierStokes::level_project(double dt_)

@@ -31,15 +31,17 @@ MGStats level_project_single(const Geometry& g, double dt, MultiFab& U_new, int 
 // coarse/fine faces of a refined level (tensorop.setCoarseFineBC): crse = the coarse level's velocity (3 comps, valid data on its own
 // layout) or null for homogeneous data
 struct TensorCF { const MultiFab* crse; const Geometry* cgeom; int ratio; };
+// Diffusion::computeExtensiveFluxes after the apply / solve: flux[d] (3 comps, face d) = or += fac * area * operator flux
+struct TensorFlux { MultiFab* flux[3]; double fac; bool add; };
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel /*3 comps, 1 ghost; BC data in ghosts*/, double a_scalar, double b_scalar,
                   const MultiFab* acoef, const MultiFab* const eta[3], const DomainBC* bcs, int nbc /*1 or 3 (per component)*/,
-                  const TensorCF* cf = nullptr);
+                  const TensorCF* cf = nullptr, const TensorFlux* fx = nullptr);
 inline void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
                          const MultiFab* const eta[3], const DomainBC& bc) { tensor_apply(g, out, vel, a_scalar, b_scalar, acoef, eta, &bc, 1); }
 // Crank-Nicolson implicit solve (a*acoef - b div tau) u = rhs: Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:837-929)
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
                      const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts,
-                     const TensorCF* cf = nullptr);
+                     const TensorCF* cf = nullptr, const TensorFlux* fx = nullptr);
 inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
                             const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
 { return tensor_solve(g, soln, rhs, a_scalar, b_scalar, acoef, eta, &bc, 1, tol_rel, tol_abs, opts); }
@@ -66,6 +68,8 @@ void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, in
 // StateData of one level: old/new MultiFabs and their times (old_ may be null: only one time level)
 struct TimeData { const MultiFab* old_; const MultiFab* new_; double t_old, t_new; };
 // AmrLevel::FillPatch on a refined level (FillPatchTwoLevels + CellConservativeLinear + physical BC), see amr.hip
+// StateData time interpolation (old or new if `time` is within 1e-3 (t_new - t_old) of it); returns the MultiFab to read and its first component
+const MultiFab* state_time_interp(const TimeData& td, double time, int scomp, int ncomp, MultiFab& tmp, int& comp0);
 void fillpatch_two_levels(MultiFab& dst, int dcomp, double time, const TimeData& fine, const TimeData& crse, int scomp, int ncomp,
                           const Geometry& cgeom, const Geometry& fgeom, int ratio, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
 
@@ -207,6 +211,13 @@ private:
     void scalar_diffusion_update(double dt);
     void get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata);
     void first_order_extrap(MultiFab& mf);
+    // data of the coarse level at this level's time t, on the coarse level's own layout (the crsedata of Diffusion.cpp:733-744, 1725-1736)
+    void crse_state_at(MultiFab& out, double t, int scomp, int ncomp);
+    void crse_scalar_at(MultiFab& out, double t, bool over_rho);   // the coarse tracer (divided by the coarse density: rho_flag 2)
+    double state_time(const MultiFab& Sdata) const { return &Sdata == &S[1 - inew] ? st_old : st_new; }
+    const MultiFab& cf_mask();                 // cf_build_mask of the level (2 ghost cells), level > 0
+    MultiFab m_cf_mask;
+    bool m_cf_mask_built = false;
     void fill_gradp_bc();
     void set_inflow_ghosts(MultiFab& vel, double scale);
     bool is_diffusive_tracer() const { return p.tracer_diff_coef > 0.0; }

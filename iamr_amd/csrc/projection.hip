@@ -69,7 +69,7 @@ static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], Layo
 }
 
 void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scalar, double b_scalar, const MultiFab* acoef,
-                  const MultiFab* const eta[3], const DomainBC* bcs, int nbc, const TensorCF* cf)
+                  const MultiFab* const eta[3], const DomainBC* bcs, int nbc, const TensorCF* cf, const TensorFlux* fx)
 {
     MGOpts o;
     o.max_coarsening_level = 0;      // info.setMaxCoarseningLevel(0) (Diffusion.cpp:708)
@@ -82,10 +82,12 @@ void tensor_apply(const Geometry& g, MultiFab& out, MultiFab& vel, double a_scal
     if (cf) mg.setCoarseFineBC(cf->crse, *cf->cgeom, cf->ratio);      // tensorop.setCoarseFineBC (Diffusion.cpp:1725-1736)
     mg.prepare();
     mg.apply(out, vel);
+    if (fx) tensor_extensive_flux(g, vel, eta, fx->flux, fx->fac, fx->add);      // computeExtensiveFluxes after mlmg.apply (Diffusion.cpp:790-796)
 }
 
 MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, double a_scalar, double b_scalar, const MultiFab* acoef,
-                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts, const TensorCF* cf)
+                     const MultiFab* const eta[3], const DomainBC* bcs, int nbc, double tol_rel, double tol_abs, const MGOpts& opts, const TensorCF* cf,
+                     const TensorFlux* fx)
 {
     MGOpts o = opts;
     o.maxorder = bcs[0].maxorder;
@@ -96,7 +98,9 @@ MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& rhs, dou
     setup_tensor(mg, tb, bp, soln.layout, a_scalar, b_scalar, acoef, eta);
     if (cf) mg.setCoarseFineBC(cf->crse, *cf->cgeom, cf->ratio);      // Diffusion.cpp:876-887 (crse == null: :1096-1099)
     mg.prepare();
-    return mg.solve(soln, rhs, tol_rel, tol_abs);
+    MGStats st = mg.solve(soln, rhs, tol_rel, tol_abs);        // ends with the ghost cells of soln filled by the operator (setFinalFillBC)
+    if (fx) tensor_extensive_flux(g, soln, eta, fx->flux, fx->fac, fx->add);
+    return st;
 }
 
 }  // namespace iamrx

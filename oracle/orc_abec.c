@@ -96,6 +96,9 @@ static double bc_coef0(int bct, int blen, int maxorder)
 static const orc_fab* g_cf_bcval = NULL;     /* coarse/fine Dirichlet data of the solve in progress */
 static const orc_fab* g_cf_edgeval = NULL;   /* tensor operator: the coarse data (cell centred, >= 1 filled ghost cell) behind the edge / corner coarse-fine ghost cells */
 static int g_cf_edge_ratio = 2;
+/* domain boundary conditions of the operator in use (set by orc_abec_applybc): needed where a coarse/fine ghost column meets a wall */
+static const int *g_bc_lobc = NULL, *g_bc_hibc = NULL;
+static const orc_fab* g_bc_bcval = NULL;
 static int g_cf_inhomog = 0;                 /* set by orc_abec_applybc: the next apply uses the data (1) or zero (0) */
 static int g_cf_maxorder = 2;
 
@@ -166,7 +169,40 @@ double orc_cf_box_value(const orc_abec_level* L, const orc_fab* x, const int* bx
     }
     if (nout == 0) return A4(x, i, j, k, n);
     const int w = box_of(L, i, j, k);
-    if (w < 0) return A4(x, i, j, k, n);
+    if (w < 0) {
+        /* outside the physical domain.  If the cell's projection into the domain is a cell of the level, the stored ghost value (formed by
+         * orc_abec_applybc from that column of level cells) is what the box sees.  Otherwise the column next to the wall consists of
+         * coarse/fine ghost cells of this box: the one-dimensional boundary rule is applied to what the box sees there, averaged over the
+         * exterior directions (MLTensorOp::applyBCTensor's edge / corner fill, as orc_tensor_fill_edges_corners) */
+        int qc[3] = {i, j, k};
+        for (int e = 0; e < 3; ++e) if (!L->g.periodic[e]) { if (qc[e] < 0) qc[e] = 0; if (qc[e] > L->g.n[e] - 1) qc[e] = L->g.n[e] - 1; }
+        const int inbox = qc[0] >= bx[0] && qc[0] <= bx[3] && qc[1] >= bx[1] && qc[1] <= bx[4] && qc[2] >= bx[2] && qc[2] <= bx[5];
+        if (inbox || box_of(L, qc[0], qc[1], qc[2]) != 0 || !g_bc_lobc) return A4(x, i, j, k, n);
+        double sum = 0.0; int cnt = 0;
+        for (int e = 0; e < 3; ++e) {
+            if (L->g.periodic[e] || (q[e] >= 0 && q[e] <= L->g.n[e] - 1)) continue;
+            const int sg = q[e] < 0 ? 1 : -1;
+            const int bct = q[e] < 0 ? g_bc_lobc[BCOFF(L, n) + e] : g_bc_hibc[BCOFF(L, n) + e];
+            double v;
+            if (bct == ORC_LO_NEUMANN || bct == ORC_LO_REFLECT_ODD) {
+                int r[3] = {i, j, k}; r[e] += sg;
+                v = orc_cf_box_value(L, x, bx, r[0], r[1], r[2], n);
+                if (bct == ORC_LO_REFLECT_ODD) v = -v;
+            } else {
+                const int NX = L->g.n[e] + 1 < g_cf_maxorder ? L->g.n[e] + 1 : g_cf_maxorder;
+                const double bv = (g_cf_inhomog && g_bc_bcval) ? A4(g_bc_bcval, i, j, k, n) : 0.0;
+                if (NX < 2) v = bv;
+                else {
+                    double xs[4] = {0.0, 0.5, 1.5, 2.5}, c[4] = {0, 0, 0, 0};
+                    poly_interp_coeff(-0.5, xs, NX, c);
+                    v = bv * c[0];
+                    for (int m = 1; m < NX; ++m) { int r[3] = {i, j, k}; r[e] += m * sg; v += c[m] * orc_cf_box_value(L, x, bx, r[0], r[1], r[2], n); }
+                }
+            }
+            sum += v; ++cnt;
+        }
+        return sum / (double)cnt;
+    }
     if (w > 0) return wrapped(L, x, i, j, k, n);
     if (nout == 1) {
         int r[3] = {i, j, k}, cf;
@@ -187,6 +223,12 @@ double orc_cf_box_value(const orc_abec_level* L, const orc_fab* x, const int* bx
             const double u = off * sg;
             o[e][0] = 0; o[e][1] = sg; o[e][2] = 2 * sg;
             wq[e][0] = 0.5 * (u - 1.0) * (u - 2.0); wq[e][1] = -u * (u - 2.0); wq[e][2] = 0.5 * u * (u - 1.0);
+        } else if (!L->g.periodic[e] && c[e] - 1 < 0) {             /* next to a wall: one-sided, no coarse cell outside the physical domain */
+            o[e][0] = 0; o[e][1] = 1; o[e][2] = 2;
+            wq[e][0] = 0.5 * (off - 1.0) * (off - 2.0); wq[e][1] = -off * (off - 2.0); wq[e][2] = 0.5 * off * (off - 1.0);
+        } else if (!L->g.periodic[e] && c[e] + 1 > L->g.n[e] / r - 1) {
+            o[e][0] = -2; o[e][1] = -1; o[e][2] = 0;
+            wq[e][0] = 0.5 * off * (off + 1.0); wq[e][1] = -off * (off + 2.0); wq[e][2] = 0.5 * (off + 1.0) * (off + 2.0);
         } else {
             o[e][0] = -1; o[e][1] = 0; o[e][2] = 1;
             wq[e][0] = 0.5 * off * (off - 1.0); wq[e][1] = 1.0 - off * off; wq[e][2] = 0.5 * off * (off + 1.0);
@@ -299,6 +341,21 @@ void orc_abec_applybc(const orc_abec_level* L, orc_fab* phi, const int lobc[3], 
 {
     const orc_geom* g = &L->g;
     g_cf_inhomog = inhomog; g_cf_maxorder = maxorder;      /* coarse/fine ghost values are formed on the fly (box_nbr) */
+    {   /* kept as copies: the flux evaluation that follows an apply / solve (orc_*_extensive_flux) still needs them */
+        static int lo_copy[9], hi_copy[9];
+        static orc_fab bcv_copy = {NULL, {0, 0, 0}, {0, 0, 0}, 0};
+        const int nb = L->bc_percomp ? 3 * L->ncomp : 3;
+        for (int q = 0; q < nb && q < 9; ++q) { lo_copy[q] = lobc[q]; hi_copy[q] = hibc[q]; }
+        g_bc_lobc = lo_copy; g_bc_hibc = hi_copy;
+        if (bcval) {
+            const size_t N = orc_npts(bcval) * (size_t)bcval->nc;
+            if (!bcv_copy.p || orc_npts(&bcv_copy) * (size_t)bcv_copy.nc != N) { if (bcv_copy.p) free(bcv_copy.p); bcv_copy = *bcval; bcv_copy.p = (double*)malloc(N * sizeof(double)); }
+            for (int d = 0; d < 3; ++d) { bcv_copy.lo[d] = bcval->lo[d]; bcv_copy.hi[d] = bcval->hi[d]; }
+            bcv_copy.nc = bcval->nc;
+            memcpy(bcv_copy.p, bcval->p, N * sizeof(double));
+            g_bc_bcval = &bcv_copy;
+        } else g_bc_bcval = NULL;
+    }
     orc_fill_periodic(phi, g, ORC_CELL);
     for (int d = 0; d < 3; ++d) {
         if (g->periodic[d]) continue;
@@ -796,6 +853,50 @@ void orc_abec_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi
             int m[3] = {i, j, k}; m[d] -= 1;
             A4(flux[d], i, j, k, n) = -fac * A4(&L->b[d], i, j, k, n) * (A4(phi, i, j, k, n) - A4(phi, m[0], m[1], m[2], n));
         }
+    }
+}
+
+/* Diffusion::computeExtensiveFluxes on the ABec part of an operator (Source/Diffusion.cpp:1463-1537: MLMG::getFluxes = the face fluxes
+ * WITHOUT the b scalar, times fac x face area): flux_d(n) = or += fac * area_d * ( -b_d(n) dphi_n/dx_d ) on every face of the level.
+ * phi: ghost cells outside the physical domain as the operator's applyBC left them; on a partial level (nbox > 0) the coarse/fine
+ * state of the solve (orc_cf_set_bcval) must be set: coarse/fine faces use the ghost formula. */
+void orc_abec_extensive_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi, double fac, int add)
+{
+    const orc_geom* g = &L->g;
+    for (int d = 0; d < 3; ++d) {
+        const double sc = fac * g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3] / g->dx[d];
+        orc_fab t = orc_alloc(g->n, ORC_FACE[d], 0, L->ncomp);
+        orc_setval(&t, 0.0);
+        if (L->nbox == 0) {
+            int hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1};
+            hi[d] += 1;
+            for (int n = 0; n < L->ncomp; ++n)
+            for (int k = 0; k <= hi[2]; ++k) for (int j = 0; j <= hi[1]; ++j) for (int i = 0; i <= hi[0]; ++i) {
+                int m[3] = {i, j, k}; m[d] -= 1;
+                A4(&t, i, j, k, n) = -A4(&L->b[d], i, j, k, n) * (A4(phi, i, j, k, n) - A4(phi, m[0], m[1], m[2], n));
+            }
+        } else {
+            for (int b = 0; b < L->nbox; ++b) {
+                const int* bx = L->boxes + 6 * b;
+                for (int n = 0; n < L->ncomp; ++n)
+                for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) {
+                    const int idx[3] = {i, j, k};
+                    int cf;
+                    {   /* low face of the cell */
+                        const double xm = box_nbr(L, phi, bx, i, j, k, n, d, -1, &cf);
+                        A4(&t, i, j, k, n) = -A4(&L->b[d], i, j, k, n) * (A4(phi, i, j, k, n) - xm);
+                    }
+                    if (idx[d] == bx[3 + d]) {          /* high face of the last cell */
+                        int f[3] = {i, j, k}; f[d] += 1;
+                        const double xp = box_nbr(L, phi, bx, i, j, k, n, d, +1, &cf);
+                        A4(&t, f[0], f[1], f[2], n) = -A4(&L->b[d], f[0], f[1], f[2], n) * (xp - A4(phi, i, j, k, n));
+                    }
+                }
+            }
+        }
+        const size_t N = orc_npts(&t) * (size_t)L->ncomp;
+        for (size_t q = 0; q < N; ++q) flux[d]->p[q] = (add ? flux[d]->p[q] : 0.0) + sc * t.p[q];
+        orc_free(&t);
     }
 }
 

@@ -737,21 +737,30 @@ static void mac_sync_compute(orc_amr* a, int lev, orc_fab Ucorr[3])
     const orc_geom* g = &c->g;
     const double dt = a->dt_level[lev], prev_time = c->st_old;
     orc_godunov_set_ppm(c->p.use_ppm);
-    if (c->p.visc_coef > 0.0 || c->p.tracer_diff_coef > 0.0) { fprintf(stderr, "orc mac_sync_compute: viscous terms of the sync forcing not restated\n"); abort(); }
     orc_fab Smf = ns_fillpatch_time(c, prev_time, 0, 0, 3, 3);
     orc_fab Sc = ns_fillpatch_time(c, prev_time, 0, Density, NUM_SCALARS, 3);
     const int mom = c->p.do_mom_diff;
     if (mom) { const size_t N = orc_npts(&Smf); for (int n = 0; n < 3; ++n) for (size_t q = 0; q < N; ++q) Smf.p[q + N * n] *= Sc.p[q]; }
     orc_fab tfv = orc_alloc(g->n, ORC_CELL, 1, 3), tfs = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS), divu = orc_alloc(g->n, ORC_CELL, 1, 1);
     const orc_fab* Gp = GP_OLD(c);
+    /* viscous forcing at the old time (MacProj.cpp:566-572) */
+    orc_fab vvisc = orc_alloc(g->n, ORC_CELL, 1, 3);
+    if (c->p.be_cn_theta != 1.0 && c->p.visc_coef > 0.0) ns_get_visc_terms_vel(c, &vvisc, S_OLD(c));
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         const double rho = A4(&Sc, i, j, k, 0);
-        double t = ((fabs(c->p.gravity) > 0.0001 && n == 2) ? c->p.gravity * rho : 0.0) + 0.0 - A4(Gp, i, j, k, n);
+        double t = ((fabs(c->p.gravity) > 0.0001 && n == 2) ? c->p.gravity * rho : 0.0) + A4(&vvisc, i, j, k, n) - A4(Gp, i, j, k, n);
         if (!mom) t /= rho;
         A4(&tfv, i, j, k, n) = t;
     }
-    /* scalars: getForce = 0, visc = 0; conservative: tf += visc; convective: tf = tf/rho + visc (MacProj.cpp:641-683) */
+    orc_free(&vvisc);
+    /* scalars: getForce = 0; conservative: tf += visc; convective: tf = tf/rho + visc (MacProj.cpp:641-683); density does not diffuse */
+    if (c->p.be_cn_theta != 1.0 && c->p.tracer_diff_coef > 0.0) {
+        orc_fab sv = orc_alloc(g->n, ORC_CELL, 1, 1);
+        ns_get_visc_terms_tracer(c, &sv, S_OLD(c));
+        for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) A4(&tfs, i, j, k, Tracer - 3) = A4(&sv, i, j, k, 0);
+        orc_free(&sv);
+    }
     orc_fab *um[3] = {&c->umac[0], &c->umac[1], &c->umac[2]}, *uc[3] = {&Ucorr[0], &Ucorr[1], &Ucorr[2]};
     const int icv[3] = {mom, mom, mom}, ics[2] = {1, c->p.do_cons_trac ? 1 : 0};
     orc_fab flv[3], fls[3]; orc_fab *flvp[3], *flsp[3];
@@ -790,8 +799,80 @@ static void mac_sync(orc_amr* a, int lev)
     if (c->p.do_mom_diff == 1)
         for (int n = 0; n < 3; ++n)
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Vsync, i, j, k, n) /= A4(Sn, i, j, k, Density);
-    /* not diffusive: Ssync.mult(dt, sigma, 1, ngrow) (:1667-1675) */
-    { const size_t N = orc_npts(&c->Ssync) * (size_t)numscal; for (size_t q = 0; q < N; ++q) c->Ssync.p[q] *= dt; }
+    const double theta = c->p.be_cn_theta;
+    if (c->p.visc_coef > 0.0) {
+        /* Diffusion::diffuse_Vsync -> diffuse_tensor_Vsync (Diffusion.cpp:960-1178): (rho - theta dt div tau) Vsync' = rho Vsync with
+         * homogeneous boundary and coarse/fine data; upstream sets the face coefficients of this solve to 1.0 (:1122-1135), not to the
+         * viscosity -- followed as written */
+        const int rf3 = c->p.do_mom_diff;
+        orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 3), acoef = orc_alloc(g->n, ORC_CELL, 0, 1), Soln = orc_alloc(g->n, ORC_CELL, 1, 3);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+            const double r = rf3 ? A4(S_OLD(c), i, j, k, Density) : A4(&c->rho_half, i, j, k, 0);
+            for (int n = 0; n < 3; ++n) A4(&Rhs, i, j, k, n) = A4(&c->Vsync, i, j, k, n) * r;
+            A4(&acoef, i, j, k, 0) = rf3 ? A4(Sn, i, j, k, Density) : A4(&c->rho_half, i, j, k, 0);
+        }
+        orc_fab one[3]; orc_fab* ep[3];
+        for (int d = 0; d < 3; ++d) { one[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); orc_setval(&one[d], 1.0); ep[d] = &one[d]; }
+        orc_mg_opts vo = c->o; vo.maxorder = 2;
+        orc_mg_stats st;
+        if (c->level > 0) orc_tensor_solve_cf(g, c->nbox, c->boxes, c->ratio, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, c->vlobc, c->vhibc, NULL, c->p.visc_tol, -1.0, &vo, &st);
+        else orc_tensor_solve_bcn(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, c->vlobc, c->vhibc, c->p.visc_tol, -1.0, &vo, &st);
+        orc_copy_all(&c->Vsync, &Soln);
+        if (c->level > 0) {                       /* :1166-1176: viscflux_reg->FineAdd(tensorflux, ..., dt * dt) */
+            orc_fab fl[3]; orc_fab* flp[3];
+            for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); flp[d] = &fl[d]; }
+            orc_tensor_extensive_flux(g, c->nbox, c->boxes, c->ratio, flp, &Soln, ep, theta, 0, NULL, 2);
+            for (int d = 0; d < 3; ++d) { reg_fine_add(c, c->reg_visc, &fl[d], d, 0, Xvel, 3, dt * dt); orc_free(&fl[d]); }
+        }
+        /* ghost cells outside ext_dir faces back to zero (:987-1008) */
+        for (int n = 0; n < 3; ++n) for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            if (g->periodic[d] || (side == 0 ? c->bc_vel[n].lo[d] : c->bc_vel[n].hi[d]) != ORC_BC_EXT_DIR) continue;
+            const int face = side == 0 ? -1 : g->n[d];
+            for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+                if ((d == 0 ? i : (d == 1 ? j : k)) == face) A4(&c->Vsync, i, j, k, n) = 0.0;
+        }
+        orc_free(&Rhs); orc_free(&acoef); orc_free(&Soln);
+        for (int d = 0; d < 3; ++d) orc_free(&one[d]);
+    }
+    /* density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow) (:1667-1675) */
+    { const size_t N = orc_npts(&c->Ssync); for (size_t q = 0; q < N; ++q) c->Ssync.p[q] *= dt; }
+    if (c->p.tracer_diff_coef > 0.0) {
+        /* Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
+         * flux): (alpha - theta dt div D grad) s = dt Ssync, alpha = rho_new for S = rho q (rho_flag 2) else 1; Ssync = s (x rho_new);
+         * on a refined level no coarse data are passed upstream: homogeneous coarse/fine data */
+        const int cons = cons_trac;
+        orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1), Soln = orc_alloc(g->n, ORC_CELL, 1, 1), acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
+        double m = 0.0;
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+            A4(&Rhs, i, j, k, 0) = dt * A4(&c->Ssync, i, j, k, Tracer - 3);
+            A4(&acoef, i, j, k, 0) = cons ? A4(Sn, i, j, k, Density) : 1.0;
+            if (c->level > 0 && A4(&c->cov, i, j, k, 0) == 0.0) continue;
+            if (fabs(A4(&Rhs, i, j, k, 0)) > m) m = fabs(A4(&Rhs, i, j, k, 0));
+        }
+        orc_abec_level L;
+        ns_tracer_level(c, &L, 1.0, theta * dt, &acoef);
+        orc_mg_opts so = c->o; so.maxorder = 2;
+        orc_mg_stats st;
+        orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
+        if (c->level > 0) {
+            L.nbox = c->nbox; L.boxes = c->boxes;
+            for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * c->ratio * g->dx[d];
+            orc_abec_solve_cf(&L, &Soln, &Rhs, c->slobc, c->shibc, &cfb, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
+            orc_fab fl[3]; orc_fab* flp[3];
+            for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); flp[d] = &fl[d]; }
+            orc_cf_set_bcval(&cfb, 1, 2);
+            orc_abec_extensive_flux(&L, flp, &Soln, theta, 0);
+            orc_cf_set_bcval(NULL, 0, 2);
+            for (int d = 0; d < 3; ++d) { reg_fine_add(c, c->reg_visc, &fl[d], d, 0, Tracer, 1, dt); orc_free(&fl[d]); }   /* NavierStokes.cpp:1630-1638 */
+        } else orc_abec_solve(&L, &Soln, &Rhs, c->slobc, c->shibc, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&c->Ssync, i, j, k, Tracer - 3) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);
+        for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
+        orc_free(&Rhs); orc_free(&Soln); orc_free(&acoef); orc_free(&cfb);
+    } else {
+        const size_t N = orc_npts(&c->Ssync);
+        for (size_t q = 0; q < N; ++q) c->Ssync.p[q + N * (Tracer - 3)] *= dt;
+    }
     if (cons_trac)
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Ssync, i, j, k, Tracer - 3) += dt * A4(&Delta, i, j, k, 0);
     orc_free(&Delta);

@@ -428,8 +428,63 @@ static void first_order_extrap(orc_fab* f, const orc_geom* g)
 
 static int is_diffusive_tracer(const orc_ns_state* s) { return s->p.tracer_diff_coef > 0.0; }
 
+/* ---- refined levels: coarse data of the coarse/fine boundary conditions and the C/F part of FirstOrderExtrap ---- */
+void orc_tensor_apply_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* y, orc_fab* u, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, int maxorder, const orc_fab* cvel);
+void orc_tensor_solve_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, const orc_fab* cvel,
+                         double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+void orc_tensor_extensive_flux(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* flux[3], const orc_fab* u, orc_fab* const eta[3],
+                               double fac, int add, const orc_fab* cvel, int maxorder);
+void orc_abec_extensive_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi, double fac, int add);
+void orc_cf_set_bcval(const orc_fab* b, int inhomog, int maxorder);
+void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi, orc_fab* bcval);
+void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                       const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+/* the coarse level's data at time t (FillPatch of the coarse level, 1 ghost cell): the crsedata of Diffusion.cpp:733-744, 1725-1736 */
+static orc_fab crse_vel_at(const orc_ns_state* s, double t) { return ns_fillpatch_time(s->crse, t, 0, Xvel, 3, 1); }
+static orc_fab crse_tracer_at(const orc_ns_state* s, double t, int over_rho)
+{
+    orc_fab c = ns_fillpatch_time(s->crse, t, 0, Tracer, 1, 1);
+    if (over_rho) {
+        orc_fab r = ns_fillpatch_time(s->crse, t, 0, Density, 1, 1);
+        const size_t N = orc_npts(&c);
+        for (size_t q = 0; q < N; ++q) c.p[q] /= r.p[q];
+        orc_free(&r);
+    }
+    return c;
+}
+static double time_of(const orc_ns_state* s, const orc_fab* Sdata) { return Sdata == S_OLD(s) ? s->st_old : s->st_new; }
+/* ghost cells at coarse/fine boundaries (cells of the domain outside the level): the mean of the level's cells among the face
+ * neighbours, else among the edge neighbours, else among the corner neighbours (the product's single-valued rule, navierstokes.hip) */
+static void first_order_extrap_cf(const orc_ns_state* s, orc_fab* f)
+{
+    if (s->level == 0) return;
+    const orc_geom* g = &s->g;
+    orc_fab src = orc_alloc(g->n, ORC_CELL, 1, f->nc);
+    orc_copy_all(&src, f);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (A4(&s->cov, i, j, k, 0) != 0.0) continue;
+        for (int cls = 1; cls <= 3; ++cls) {
+            int cnt = 0;
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                if ((dx != 0) + (dy != 0) + (dz != 0) != cls) continue;
+                if (!ns_covered(s, i + dx, j + dy, k + dz)) continue;
+                int q[3] = {i + dx, j + dy, k + dz};
+                for (int d = 0; d < 3; ++d) if (g->periodic[d]) q[d] = (q[d] % g->n[d] + g->n[d]) % g->n[d];
+                ++cnt;
+                for (int n = 0; n < f->nc; ++n) sum[n] += A4(&src, q[0], q[1], q[2], n);
+            }
+            if (cnt > 0) { for (int n = 0; n < f->nc; ++n) A4(f, i, j, k, n) = sum[n] / (double)cnt; break; }
+        }
+    }
+    orc_free(&src);
+    orc_fill_periodic(f, g, ORC_CELL);
+}
+
 /* the (constant-coefficient) scalar diffusion operator of the tracer: MLABecLaplacian with b = diffusivity on faces */
-static void tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a)
+void ns_tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a)
 {
     memset(L, 0, sizeof(*L));
     L->g = s->g; L->alpha = alpha; L->beta = beta; L->ncomp = 1; L->tensor = 0;
@@ -439,7 +494,7 @@ static void tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha,
 
 /* NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0: Laplacian_S): visc = div(beta grad S(time));
  * called at the old time only (Sdata = S_old, get_rho(time) = rho_ptime) */
-static void get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata)
+void ns_get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata)
 {
     const orc_geom* g = &s->g;
     orc_setval(visc, 1.e40);
@@ -450,22 +505,34 @@ static void get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp,
         for (size_t q = 0; q < N; ++q) stmp.p[q] /= s->rho_ptime.p[q];
     }
     orc_abec_level L;
-    tracer_level(s, &L, 0.0, -1.0, NULL);
+    ns_tracer_level(s, &L, 0.0, -1.0, NULL);
     orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
     orc_copy_all(&bcval, &stmp);
+    orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
+    if (s->level > 0) {                         /* mlabec.setCoarseFineBC(&crsedata, ratio), Diffusion.cpp:1600-1609 */
+        L.nbox = s->nbox; L.boxes = s->boxes;
+        for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
+        orc_fab cd = crse_tracer_at(s, time_of(s, Sdata), s->p.do_cons_trac);
+        orc_cf_interp_bndry(&L, s->ratio, &cd, &cfb);
+        orc_free(&cd);
+        orc_cf_set_bcval(&cfb, 1, 2);
+    }
     orc_abec_applybc(&L, &stmp, s->slobc, s->shibc, 2, 1, &bcval);
     orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 1);
     orc_abec_apply(&L, &tmp, &stmp);
+    orc_cf_set_bcval(NULL, 0, 2);
+    orc_free(&cfb);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(visc, i, j, k, 0) = A4(&tmp, i, j, k, 0);
     orc_fill_periodic(visc, g, ORC_CELL);
+    first_order_extrap_cf(s, visc);
     first_order_extrap(visc, g);
     orc_free(&tmp); orc_free(&bcval); orc_free(&stmp);
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
 }
 
 /* NavierStokes::getViscTerms for velocity: visc = div tau(U(time)), then FillBoundary (+ FirstOrderExtrap at walls) */
-static void get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata)
+void ns_get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata)
 {
     const orc_geom* g = &s->g;
     orc_setval(visc, 1.e40);
@@ -475,11 +542,17 @@ static void get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1
     make_eta(s, eta);
     for (int d = 0; d < 3; ++d) ep[d] = &eta[d];
     orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 3);
+    if (s->level > 0) {                         /* tensorop.setCoarseFineBC(&crsedata, ratio), Diffusion.cpp:1725-1736 */
+        orc_fab cd = crse_vel_at(s, time_of(s, Sdata));
+        orc_tensor_apply_cf(g, s->nbox, s->boxes, s->ratio, &tmp, &stmp, 0.0, -1.0, NULL, ep, s->vlobc, s->vhibc, 2, &cd);
+        orc_free(&cd);
+    } else
     orc_tensor_apply_bcn(g, &tmp, &stmp, 0.0, -1.0, NULL, ep, s->vlobc, s->vhibc, 2);
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(visc, i, j, k, n) = A4(&tmp, i, j, k, n);
     orc_fill_periodic(visc, g, ORC_CELL);
+    first_order_extrap_cf(s, visc);
     first_order_extrap(visc, g);
     orc_free(&tmp); orc_free(&stmp);
     for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
@@ -645,7 +718,7 @@ static double predict_velocity(orc_ns_state* s, double dt)
     if (s->level > 0) ns_fill_gp(s, GP_OLD(s), 0.5 * (s->pt_old[0] + s->pt_old[1]));
     double tempdt = cflmax == 0 ? s->p.change_max : fmin(s->p.change_max, s->p.cfl / cflmax);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
-    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
+    if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
     const orc_fab* Gp = GP_OLD(s);
@@ -775,7 +848,7 @@ static void velocity_advection(orc_ns_state* s, double dt)
     }
     orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
-    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
+    if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
     orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
     const orc_fab* Gp = GP_OLD(s);
@@ -806,7 +879,7 @@ static void scalar_advection(orc_ns_state* s, double dt)
     orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
     int iconserv[2] = {1, s->p.do_cons_trac ? 1 : 0};   /* density conservative; tracer: NS_setup.cpp:304-310 */
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
-    if (s->p.be_cn_theta != 1.0) get_visc_terms_tracer(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
+    if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_tracer(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         double rho = A4(&Smf, i, j, k, 0);
         A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc (density: not diffusive) */
@@ -862,6 +935,10 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
     const int cons = s->p.do_cons_trac;     /* diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308, Diffusion.cpp:1870-1873) */
     orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
     orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
+    const int want_flux = s->fine != NULL || s->level > 0;        /* viscous flux registers, NavierStokes.cpp:949-990 */
+    orc_fab fl[3]; orc_fab* flp[3];
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); orc_setval(&fl[d], 0.0); flp[d] = &fl[d]; }
+    orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (theta != 1.0) {
         /* FillPatch(S_old, ng 1) then opn.setLevelBC(Soln = S_old tracer with ghosts); a = 0, b = -(1-theta) dt */
         orc_fab Soln = fillpatch(s, So, Tracer, 1, 1, &s->bc_scal[1]);
@@ -874,9 +951,19 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
         orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_copy_all(&bcval, &Soln);
         orc_abec_level Ln;
-        tracer_level(s, &Ln, 0.0, -(1.0 - theta) * dt, NULL);
+        ns_tracer_level(s, &Ln, 0.0, -(1.0 - theta) * dt, NULL);
+        if (s->level > 0) {                     /* opn.setCoarseFineBC(Solnc = coarse S_old (/ rho_old), ratio), Diffusion.cpp:376-396 */
+            Ln.nbox = s->nbox; Ln.boxes = s->boxes;
+            for (int d = 0; d < 3; ++d) Ln.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
+            orc_fab cd = crse_tracer_at(s, s->st_old, cons);
+            orc_cf_interp_bndry(&Ln, s->ratio, &cd, &cfb);
+            orc_free(&cd);
+            orc_cf_set_bcval(&cfb, 1, 2);
+        }
         orc_abec_applybc(&Ln, &Soln, s->slobc, s->shibc, 2, 1, &bcval);
         orc_abec_apply(&Ln, &Rhs, &Soln);
+        if (want_flux) orc_abec_extensive_flux(&Ln, flp, &Soln, 1.0 - theta, 0);     /* fluxn: computeExtensiveFluxes(..., -b/dt), Diffusion.cpp:437-438 */
+        orc_cf_set_bcval(NULL, 0, 2);
         for (int d = 0; d < 3; ++d) orc_free(&Ln.b[d]);
         orc_free(&Soln); orc_free(&bcval);
     }
@@ -884,6 +971,7 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
         A4(&Rhs, i, j, k, 0) += A4(Sn, i, j, k, Tracer);
     double m = 0.0;     /* get_scaled_abs_tol: visc_tol * ||Rhs||inf (one component) */
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (s->level > 0 && A4(&s->cov, i, j, k, 0) == 0.0) continue;
         double v = fabs(A4(&Rhs, i, j, k, 0)); if (v > m) m = v;
     }
     const double tol_abs = s->p.visc_tol * m;
@@ -899,11 +987,30 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
             A4(&acoef, i, j, k, 0) = A4(Sn, i, j, k, Density);
     }
     orc_abec_level L;
-    tracer_level(s, &L, 1.0, theta * dt, &acoef);
+    ns_tracer_level(s, &L, 1.0, theta * dt, &acoef);
     orc_mg_opts o = s->o; o.maxorder = 2;                                /* Diffusion::max_order = 2 */
     orc_mg_stats st;
+    if (s->level > 0) {                         /* opnp1.setCoarseFineBC(coarse S_new (/ rho_new), ratio), Diffusion.cpp:506-518 */
+        L.nbox = s->nbox; L.boxes = s->boxes;
+        for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
+        orc_fab cd = crse_tracer_at(s, s->st_new, cons);
+        orc_cf_interp_bndry(&L, s->ratio, &cd, &cfb);
+        orc_free(&cd);
+        orc_abec_solve_cf(&L, &Soln, &Rhs, s->slobc, s->shibc, &cfb, s->p.visc_tol, tol_abs, &o, &st);
+    } else
     orc_abec_solve(&L, &Soln, &Rhs, s->slobc, s->shibc, s->p.visc_tol, tol_abs, &o, &st);
     s->st_scal = st;
+    if (want_flux) {                            /* fluxnp1 = theta * area * (-D grad s_new), Diffusion.cpp:569-570; registers NavierStokes.cpp:949-990 */
+        orc_cf_set_bcval(s->level > 0 ? &cfb : NULL, 1, 2);
+        orc_abec_extensive_flux(&L, flp, &Soln, theta, 1);
+        orc_cf_set_bcval(NULL, 0, 2);
+        for (int d = 0; d < 3; ++d) {
+            if (s->level > 0) reg_fine_add(s, s->reg_visc, &fl[d], d, 0, Tracer, 1, dt);
+            if (s->fine) reg_crse_init(s->fine, s->fine->reg_visc, &fl[d], d, 0, Tracer, 1, -dt, 0);
+        }
+    }
+    for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
+    orc_free(&cfb);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(Sn, i, j, k, Tracer) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);    /* Diffusion.cpp:583-590 */
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
@@ -938,7 +1045,7 @@ static void initial_velocity_diffusion_update(orc_ns_state* s, double dt)
     orc_fab *Un = S_NEW(s), *Uo = S_OLD(s);
     const orc_fab* Gp = GP_OLD(s);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
-    if (s->p.be_cn_theta != 1.0) get_visc_terms_vel(s, &visc, Uo); else orc_setval(&visc, 0.0);
+    if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, Uo); else orc_setval(&visc, 0.0);
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         double force = force_vel(s, n, A4(Uo, i, j, k, Density));
@@ -965,9 +1072,20 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     make_eta(s, eta);
     for (int d = 0; d < 3; ++d) ep[d] = &eta[d];
     orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 3);
+    const int want_flux = s->fine != NULL || s->level > 0;        /* do_reflux && (level < finest_level || level > 0), Diffusion.cpp:790-796, 932-956 */
+    orc_fab fl[3]; orc_fab* flp[3];
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); orc_setval(&fl[d], 0.0); flp[d] = &fl[d]; }
     if (theta != 1.0) {
         orc_fab Soln = fillpatch(s, Uo, Xvel, 3, 1, s->bc_vel);
-        orc_tensor_apply_bcn(g, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep, s->vlobc, s->vhibc, 2);
+        if (s->level > 0) {                     /* crsedata at prev_time, Diffusion.cpp:733-744 */
+            orc_fab cd = crse_vel_at(s, s->st_old);
+            orc_tensor_apply_cf(g, s->nbox, s->boxes, s->ratio, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep, s->vlobc, s->vhibc, 2, &cd);
+            if (want_flux) orc_tensor_extensive_flux(g, s->nbox, s->boxes, s->ratio, flp, &Soln, ep, 1.0 - theta, 0, &cd, 2);
+            orc_free(&cd);
+        } else {
+            orc_tensor_apply_bcn(g, &Rhs, &Soln, 0.0, -(1.0 - theta) * dt, NULL, ep, s->vlobc, s->vhibc, 2);
+            if (want_flux) orc_tensor_extensive_flux(g, 0, NULL, 2, flp, &Soln, ep, 1.0 - theta, 0, NULL, 2);
+        }
         orc_free(&Soln);
     }
     for (int n = 0; n < 3; ++n)
@@ -981,6 +1099,7 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     for (int n = 0; n < 3; ++n) {
         double m = 0.0;
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+            if (s->level > 0 && A4(&s->cov, i, j, k, 0) == 0.0) continue;
             double v = fabs(A4(&Rhs, i, j, k, n)); if (v > m) m = v;
         }
         avg += (1.0 / 3.0) * m;
@@ -991,10 +1110,24 @@ static void velocity_diffusion_update(orc_ns_state* s, double dt)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&acoef, i, j, k, 0) = mom ? A4(Un, i, j, k, Density) : A4(&s->rho_half, i, j, k, 0);   /* Diffusion.cpp:893: rho_flag 3 -> rho_new */
     orc_mg_opts o = s->o; o.maxorder = 2;
-    orc_tensor_solve_bcn(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, s->vlobc, s->vhibc, s->p.visc_tol, tol_abs, &o, &s->st_visc);
+    if (s->level > 0) {                         /* crsedata at cur_time, Diffusion.cpp:876-887 */
+        orc_fab cd = crse_vel_at(s, s->st_new);
+        orc_tensor_solve_cf(g, s->nbox, s->boxes, s->ratio, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, s->vlobc, s->vhibc, &cd, s->p.visc_tol, tol_abs, &o, &s->st_visc);
+        if (want_flux) orc_tensor_extensive_flux(g, s->nbox, s->boxes, s->ratio, flp, &Soln, ep, theta, 1, &cd, 2);
+        orc_free(&cd);
+    } else {
+        orc_tensor_solve_bcn(g, &Soln, &Rhs, 1.0, theta * dt, &acoef, ep, s->vlobc, s->vhibc, s->p.visc_tol, tol_abs, &o, &s->st_visc);
+        if (want_flux) orc_tensor_extensive_flux(g, 0, NULL, 2, flp, &Soln, ep, theta, 1, NULL, 2);
+    }
+    if (want_flux)
+        for (int d = 0; d < 3; ++d) {
+            if (s->level > 0) reg_fine_add(s, s->reg_visc, &fl[d], d, 0, Xvel, 3, dt);                          /* :946-949 */
+            if (s->fine) reg_crse_init(s->fine, s->fine->reg_visc, &fl[d], d, 0, Xvel, 3, -dt, 0);              /* :950-954 */
+        }
+    for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
-        A4(Un, i, j, k, n) = A4(&Soln, i, j, k, n);
+        if (s->level == 0 || ns_in_grown(s, i, j, k, 1)) A4(Un, i, j, k, n) = A4(&Soln, i, j, k, n);
     orc_free(&Soln); orc_free(&acoef); orc_free(&Rhs);
     for (int d = 0; d < 3; ++d) orc_free(&eta[d]);
 }

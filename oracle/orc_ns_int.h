@@ -73,6 +73,10 @@ double ns_est_time_step(orc_ns_state* s);
 void ns_make_rho_curr_time(orc_ns_state* s);
 void ns_fill_gp(orc_ns_state* s, orc_fab* G, double time);
 void ns_set_inflow_ghosts(const orc_ns_state* s, orc_fab* vel, double inflow_scale);
+/* NavierStokes::getViscTerms at the time of Sdata (S_OLD or S_NEW of the level), 1 filled ghost cell */
+void ns_get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata);
+void ns_get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata);
+void ns_tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a);
 
 /* ---- flux registers of the interface between level s (fine) and s->crse (orc_amr.c) ---- */
 /* side of coarse face f (direction d): 0 not a coarse/fine face, +1 the fine level is on the low side (the coarse cell outside is
@@ -95,5 +99,19 @@ void syncreg_fine_add(orc_ns_state* fine, const orc_fab* resid_fine /*nodes of f
 void orc_nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], const int hibc[3]);
 void orc_sigma_fill_bc(const orc_geom* g, orc_fab* s);
 void orc_nodal_divu_bc(const orc_geom* g, orc_fab* rhs, const orc_fab* vel, const int lobc[3], const int hibc[3]);
+
+/* ---- operators on refined levels (orc_tensor.c, orc_abec.c) ---- */
+void orc_tensor_apply_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* y, orc_fab* u, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, int maxorder, const orc_fab* cvel);
+void orc_tensor_solve_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* u, const orc_fab* rhs, double alpha, double beta,
+                         const orc_fab* a, orc_fab* const eta[3], const int* lobc, const int* hibc, const orc_fab* cvel,
+                         double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+void orc_tensor_extensive_flux(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* flux[3], const orc_fab* u, orc_fab* const eta[3],
+                               double fac, int add, const orc_fab* cvel, int maxorder);
+void orc_abec_extensive_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi, double fac, int add);
+void orc_cf_set_bcval(const orc_fab* b, int inhomog, int maxorder);
+void orc_cf_interp_bndry(const orc_abec_level* L, int ratio, const orc_fab* cphi, orc_fab* bcval);
+void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs, const int lobc[3], const int hibc[3],
+                       const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 
 #endif

@@ -310,3 +310,34 @@ void orc_tensor_solve_cf(const orc_geom* g, int nbox, const int* boxes, int rati
     orc_abec_solve_cf(&T.L, u, rhs, lobc, hibc, &T.bcv, rtol, atol, o, st);
     tcf_end(&T);
 }
+
+/* Diffusion::computeExtensiveFluxes on the tensor operator (Source/Diffusion.cpp:1463-1537; MLTensorOp::compFlux = ABec flux + cross
+ * terms, without the b scalar): flux_d(n) = or += fac * area_d * ( -eta_d (4/3 if n == d) du_n/dx_d + cross_d(n) ) on every face of
+ * the level.  u: as the operator left it (ghost cells outside the physical domain filled by applyBC).  nbox > 0: level that does not
+ * cover the domain, cvel = the coarse velocity of the coarse/fine data (NULL: homogeneous). */
+void orc_abec_extensive_flux(const orc_abec_level* L, orc_fab* flux[3], const orc_fab* phi, double fac, int add);
+void orc_tensor_extensive_flux(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* flux[3], const orc_fab* u, orc_fab* const eta[3],
+                               double fac, int add, const orc_fab* cvel, int maxorder)
+{
+    tensor_cf T;
+    tcf_begin(&T, g, nbox, boxes, ratio, 0.0, 1.0, NULL, eta, cvel);
+    if (nbox == 0) orc_cf_set_edgeval(NULL, 2);
+    orc_cf_set_bcval(nbox > 0 ? &T.bcv : NULL, 1, maxorder);
+    orc_abec_extensive_flux(&T.L, flux, u, fac, add);              /* b = eta (4/3 on the normal component): the ABec part */
+    orc_fab t[3]; orc_fab* tp[3];
+    for (int d = 0; d < 3; ++d) { t[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); orc_setval(&t[d], 0.0); tp[d] = &t[d]; }
+    if (nbox > 0) cross_terms_cf(&T.L, NULL, u, tp, 1.0);          /* beta = 1: t += the cross-term face fluxes */
+    else {
+        orc_fab fx = orc_alloc(g->n, ORC_FACE[0], 0, 3), fy = orc_alloc(g->n, ORC_FACE[1], 0, 3), fz = orc_alloc(g->n, ORC_FACE[2], 0, 3);
+        const int lo[3] = {0, 0, 0}, hi[3] = {g->n[0] - 1, g->n[1] - 1, g->n[2] - 1};
+        cross_terms_range(&T.L, NULL, u, lo, hi, &fx, &fy, &fz, tp, 1.0);
+        orc_free(&fx); orc_free(&fy); orc_free(&fz);
+    }
+    for (int d = 0; d < 3; ++d) {
+        const double sc = fac * g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3];
+        const size_t N = orc_npts(&t[d]) * 3;
+        for (size_t q = 0; q < N; ++q) flux[d]->p[q] += sc * t[d].p[q];
+        orc_free(&t[d]);
+    }
+    tcf_end(&T);
+}

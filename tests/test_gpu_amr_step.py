@@ -81,17 +81,25 @@ def _composite_sum(amr_levels_state, cov1, dx0, dx1, comp):
     return (S0[..., comp] * ~covc).sum() * np.prod(dx0) + (S1[..., comp] * cov1).sum() * np.prod(dx1)
 
 
-@pytest.mark.parametrize("case", ["one_box", "l_shape"])
+@pytest.mark.parametrize("case", ["one_box", "l_shape", "viscous", "viscous_l_shape_cons"])
 def test_two_level_taylorgreen_matches_oracle(case):
     n0 = 16
-    if case == "one_box":
+    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
+    if case in ("one_box", "viscous"):
         fine = [([4, 4, 4], [19, 19, 19])]
         split = 16
+        if case == "viscous":
+            # viscous / diffusive hierarchy: tensor solve with coarse/fine faces on the refined level, viscous flux registers, viscous terms in
+            # the sync forcing, diffuse_Vsync / the scalar sync solve in mac_sync
+            kw.update(visc_coef=0.01, tracer_diff_coef=0.005)
+    elif case == "viscous_l_shape_cons":
+        fine = [([8, 8, 8], [15, 15, 23]), ([16, 8, 8], [23, 15, 23]), ([8, 16, 8], [15, 23, 23])]
+        split = 8
+        kw.update(visc_coef=0.02, tracer_diff_coef=0.01, do_mom_diff=1, do_cons_trac=1, be_cn_theta=1.0)
     else:
         # L-shaped refined region made of three boxes (the shape of Exec/run2d/test_grids/fixed_grids_2), coarse level in 8 boxes
         fine = [([8, 8, 8], [15, 15, 23]), ([16, 8, 8], [23, 15, 23]), ([8, 16, 8], [15, 23, 23])]
         split = 8
-    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
     amr, oa = _make(n0, fine, split, kw, lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=1.0))
     amr.post_init()
     oa.post_init()
@@ -124,16 +132,20 @@ def _composite_sum_n(states, covs, dxs, comp):
     return tot
 
 
-@pytest.mark.parametrize("case", ["nested_boxes", "ppm_gravity_walls"])
+@pytest.mark.parametrize("case", ["nested_boxes", "ppm_gravity_walls", "viscous"])
 def test_three_level_step_matches_oracle(case):
     """three levels: MAC sync and sync projection on a refined level (homogeneous coarse/fine data in mac_sync_solve, the level's own
     corrections entering the registers of the interface below, SyncRegister::CompAdd), SyncInterp over two levels (ratio 4),
     SyncProjInterp + computeGradP on the finest level, composite projections over three levels in post_init."""
     n0 = 8
     l1 = [([2, 2, 2], [13, 13, 13])]
-    if case == "nested_boxes":
+    if case in ("nested_boxes", "viscous"):
         l2 = [([10, 10, 10], [21, 21, 21])]
         kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
+        if case == "viscous":
+            # the viscous sync on a refined level: diffuse_Vsync / the scalar sync solve with homogeneous coarse/fine data, their fluxes into
+            # the viscous register of the interface below (x dt^2 / x dt), viscous fluxes of level 1 as fine AND coarse side
+            kw.update(visc_coef=0.01, tracer_diff_coef=0.005)
         fn = lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=1.0)
         per = (1, 1, 1)
     else:
@@ -177,3 +189,30 @@ def test_improperly_nested_level_is_refused():
     lays = [L.Layout.single([8] * 3), L.Layout([((2, 2, 2), (13, 13, 13))]), L.Layout([((8, 8, 8), (15, 15, 15))])]
     with pytest.raises(L.IamrxError, match="properly nested"):
         Amr(L.Geom.make([8] * 3), lays, ns_params(), L.mg_opts())
+
+
+def test_two_level_lid_driven_cavity_refined_at_the_lid():
+    """viscous hierarchy with walls: the lid-driven cavity of config C4 (no-slip / slip walls, moving lid, tracer diffusion) with a refined
+    box that touches the lid and two side walls -- coarse/fine faces of the tensor and scalar solves meeting physical boundaries,
+    viscous flux registers, viscous sync.  Product vs oracle after the initial iterations and two coarse steps."""
+    n0 = 16
+    fine = [([0, 8, 16], [31, 23, 31])]            # x: wall to wall, z: up to the lid
+    lid = [0.0] * 9
+    lid[6] = 1.0
+    kw = dict(cfl=0.3, visc_coef=0.01, tracer_diff_coef=0.001, init_iter=2, init_dt=0.0140625 * 4, init_shrink=0.3,
+              phys_lo=[4, 4, 5], phys_hi=[5, 5, 5], wall_vel_hi=lid)
+
+    def rest(X, Y, Z):
+        S = np.zeros(X.shape + (5,), order="F")
+        S[..., 3] = 1.0
+        S[..., 4] = np.exp(-((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.75) ** 2) / 0.02)
+        return S
+    amr, oa = _make(n0, fine, 8, kw, rest, periodic=(0, 0, 0))
+    amr.post_init()
+    oa.post_init()
+    _compare(amr, oa, 2e-8, "after post_init")
+    for step in range(2):
+        dt = amr.coarse_step()
+        dto = oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto
+        _compare(amr, oa, 2e-8, f"after coarse step {step + 1}")
