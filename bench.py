@@ -178,14 +178,14 @@ def file_blob_sha(path):
 
 def amr_workload(lib, n0, steps):
     """secondary workload (north_star: 2-level AMR TaylorGreen): base level n0^3 in one box, one ratio-2 refined box over the central
-    (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; Euler (nu = 0: the viscous coarse/fine sync is not implemented yet).
+    (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; nu = 1e-4 as in Tutorials/TaylorGreen/inputs.3d.taylorgreen.
     cells advanced per coarse step = n0^3 + 2 * n0^3."""
     from iamr_amd import ns as N
     from iamr_amd.amr import Amr
     g0 = lib.Geom.make((n0,) * 3)
     lo, hi = n0 // 2, n0 // 2 + n0 - 1
     lays = [lib.Layout.single((n0,) * 3), lib.Layout([((lo,) * 3, (hi,) * 3)])]
-    amr = Amr(g0, lays, N.ns_params(cfl=0.7, visc_coef=0.0, init_iter=2), lib.mg_opts())
+    amr = Amr(g0, lays, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
     for l in range(2):
         amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
     amr.post_init()
@@ -198,8 +198,8 @@ def amr_workload(lib, n0, steps):
     el = time.perf_counter() - t0
     st, stm = amr.sync_stats()
     cells = float(n0) ** 3 * 3.0
-    return {"workload": f"TaylorGreen 3D, 2 levels: {n0}^3 base + one {n0}^3 refined box (ratio 2, subcycled), Euler, periodic; "
-                        f"advance + reflux + avgDown + mac_sync + MLsyncProject per coarse step",
+    return {"workload": f"TaylorGreen 3D, 2 levels: {n0}^3 base + one {n0}^3 refined box (ratio 2, subcycled), nu = 1e-4, periodic; "
+                        f"advance + reflux + avgDown + mac_sync (incl. viscous sync) + MLsyncProject per coarse step",
             "cells_advanced_per_sec": cells * steps / el, "ms_per_coarse_step": el / steps * 1e3, "coarse_steps": steps,
             "sync_project_iters": st.iters, "mac_sync_iters": stm.iters}
 

@@ -527,6 +527,16 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
     IAMRX_CATCH
 }
 
+int iamrx_tensor_extensive_flux(const iamrx_geom* g, iamrx_mf vel, iamrx_mf ex, iamrx_mf ey, iamrx_mf ez, iamrx_mf fx, iamrx_mf fy, iamrx_mf fz,
+                                double fac, int add)
+{
+    IAMRX_TRY
+    const MultiFab* eta[3] = {&ex->mf, &ey->mf, &ez->mf};
+    MultiFab* fl[3] = {&fx->mf, &fy->mf, &fz->mf};
+    tensor_extensive_flux(to_geom(g), vel->mf, eta, fl, fac, add != 0);
+    IAMRX_CATCH
+}
+
 int iamrx_tensor_apply_cf(const iamrx_geom* g, iamrx_mf out, iamrx_mf vel, double a, double b, iamrx_mf acoef, iamrx_mf ex, iamrx_mf ey,
                           iamrx_mf ez, const int* lobc, const int* hibc, int nbc, int maxorder, iamrx_mf crse_vel, const iamrx_geom* cgeom, int ratio)
 {

@@ -151,8 +151,6 @@ class Inputs:
             if not os.path.isabs(gf) and self.files:
                 gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
             fine_boxes = read_grid_file(gf, rr)[:max_level]
-            if self.has("ns.vel_visc_coef") and self.real("ns.vel_visc_coef", 0.0) != 0.0 or any(v != 0.0 for v in self.reals("ns.scal_diff_coefs", 1, [0.0])):
-                raise NotImplementedError("inputs: viscous / diffusive runs on a refined hierarchy are not implemented (coarse/fine viscous sync)")
         if self.integer("geometry.coord_sys", 0) != 0:
             raise NotImplementedError("inputs: only Cartesian coordinates (geometry.coord_sys = 0)")
         n = self.ints("amr.n_cell", 3)

@@ -239,6 +239,12 @@ int iamrx_tensor_solve(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, double 
                        iamrx_mf eta_y, iamrx_mf eta_z, const int* lobc, const int* hibc, int nbc, double tol_rel, double tol_abs,
                        const iamrx_mg_opts* o, iamrx_mg_stats* st);
 
+/* Diffusion::computeExtensiveFluxes on the tensor operator (Source/Diffusion.cpp:1463-1537: MLMG::getFluxes -- the face fluxes of the operator
+ * without its b scalar -- times fac x face area), the input of viscflux_reg->FineAdd / CrseInit (:946-954):
+ * flux_d(n) = or += fac * area_d * ( -eta_d (4/3 if n == d) du_n/dx_d + cross terms ).  vel: 3 comps, >= 1 ghost cell, as the operator
+ * left it after iamrx_tensor_apply(_cf) / iamrx_tensor_solve(_cf) (ghost cells filled with the operator's boundary values). */
+int iamrx_tensor_extensive_flux(const iamrx_geom* g, iamrx_mf vel, iamrx_mf eta_x, iamrx_mf eta_y, iamrx_mf eta_z,
+                                iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z, double fac, int add);
 /* the same on a refined level that does not cover the domain (tensorop.setCoarseFineBC(&crsedata, ratio), Source/Diffusion.cpp:733-744,
  * 876-887, 1725-1736; crse_vel == NULL: homogeneous coarse/fine data as in diffuse_tensor_Vsync, :1096-1099).  crse_vel: the coarse
  * level's velocity (3 comps, valid data on its own layout) at the time of the operator. */

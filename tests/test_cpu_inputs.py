@@ -85,15 +85,14 @@ def test_host_side_problem_setups():
 
 def test_fixed_grid_hierarchy_keys():
     """amr.max_level > 0 with amr.regrid_file (the fixed-grid runs of Exec/run2d/test_grids): boxes come out in each level's own index space;
-    without a grid file, with a ratio other than 2 or with viscosity the run is refused"""
+    without a grid file or with a ratio other than 2 the run is refused"""
     amr_inp = os.path.join(HERE, "golden", "inputs.3d.taylorgreen_amr16")
     pr = Inputs([amr_inp]).problem()
     assert pr["fine_boxes"] == [[((4, 4, 4), (27, 27, 27))], [((20, 20, 20), (31, 43, 43)), ((32, 20, 20), (43, 43, 43))]]
     assert pr["params"]["visc_coef"] == 0.0 and pr["prob"]["probtype"] == 11
     with pytest.raises(NotImplementedError):
         Inputs([amr_inp], ["amr.ref_ratio = 4 2"]).problem()
-    with pytest.raises(NotImplementedError):
-        Inputs([amr_inp], ["ns.vel_visc_coef = 0.01"]).problem()
+    assert Inputs([amr_inp], ["ns.vel_visc_coef = 0.01"]).problem()["params"]["visc_coef"] == 0.01      # viscous hierarchies run
     with pytest.raises(NotImplementedError):
         Inputs([LDC], ["amr.max_level=1"]).problem()                       # no grid file: would need regridding
 
