@@ -497,7 +497,18 @@ double NavierStokes::predict_velocity(double dt_)
 void NavierStokes::mac_project(double dt_)
 {
     SectionTimer tm(*this, 1);
-    mac_phi.setVal(0.0);                                          // mac_phi_crse[level]: kept as the coarse/fine data of the next finer level
+    // mac_phi_crse[level]: kept as the coarse/fine data of the next finer level.  Upstream zeroes it before the solve (MacProj.cpp:255);
+    // the converged answer does not depend on the initial guess, the number of V-cycles does: the MAC potential is pressure-like and
+    // changes little from step to step, so the previous one is the initial guess here (IAMRX_WARM_START=0: upstream's zero)
+    static const bool warm = !(getenv("IAMRX_WARM_START") && atoi(getenv("IAMRX_WARM_START")) == 0);
+    static const bool extrap = !(getenv("IAMRX_WARM_EXTRAP") && atoi(getenv("IAMRX_WARM_EXTRAP")) == 0);
+    mac_phi.setVal(0.0);                        // the ghost cells carry the (homogeneous) boundary data of the solve: always zero
+    if (warm && m_have_mac_prev) {
+        // linear extrapolation in time from the last two potentials once both exist (regular steps only)
+        if (extrap && m_have_mac_prev2 && !initial_iter && !initial_step && dt_prev_mac > 0.0)
+            mf_lincomb(mac_phi, 1.0 + dt_ / dt_prev_mac, m_mac_phi_prev, -dt_ / dt_prev_mac, m_mac_phi_prev2, 0, 1, 0);
+        else MultiFab::Copy(mac_phi, m_mac_phi_prev, 0, 0, 1, 0);
+    }
     MultiFab& So = S[1 - inew];
     MultiFab::Copy(So, rho_ptime, 0, Density, 1, 1);            // MacProj.cpp:262-263
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
@@ -505,6 +516,13 @@ void NavierStokes::mac_project(double dt_)
     mo.maxorder = 4;
     if (level == 0) st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
     else st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr, &crse->mac_phi, &crse->g, ratio);
+    if (warm) {
+        if (!m_have_mac_prev) { m_mac_phi_prev.define(layout, cell_type(), 1, 0); m_mac_phi_prev2.define(layout, cell_type(), 1, 0); }
+        else if (!initial_iter && !initial_step) { std::swap(m_mac_phi_prev, m_mac_phi_prev2); m_have_mac_prev2 = true; }
+        MultiFab::Copy(m_mac_phi_prev, mac_phi, 0, 0, 1, 0);
+        m_have_mac_prev = true;
+        dt_prev_mac = dt_;
+    }
     // MAC registers (MacProj.cpp:304-348): fluxes = u_mac * area
     for (int d = 0; d < 3; ++d) {
         const double area = g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3];
@@ -811,7 +829,18 @@ void NavierStokes::level_project(double dt_)
     SectionTimer tm(*this, 5);
     MultiFab& Sn = S[inew];
     MultiFab& Pn = P[pnew];
-    if (level == 0) Pn.setVal(0.0, 0, 1, 0);                     // Projection.cpp:236-256 (level 0: valid nodes)
+    // Projection.cpp:236-256 zeroes P_new (level 0: valid nodes; level > 0: the interior of every box) before the solve, which uses it as
+    // initial guess and for the Dirichlet data.  Initial guess here: the previous pressure (same converged answer, fewer V-cycles;
+    // IAMRX_WARM_START=0: upstream's zero)
+    static const bool warm = !(getenv("IAMRX_WARM_START") && atoi(getenv("IAMRX_WARM_START")) == 0);
+    static const bool extrap = !(getenv("IAMRX_WARM_EXTRAP") && atoi(getenv("IAMRX_WARM_EXTRAP")) == 0);
+    if (level == 0) {
+        // P_new still holds the pressure of two steps ago (the arrays alternate): extrapolate linearly in time on regular steps
+        const double dto = pt_old[1] - pt_old[0];
+        if (warm && extrap && nstep >= 2 && !initial_iter && !initial_step && dto > 0.0) mf_lincomb(Pn, 1.0 + dt_ / dto, P[1 - pnew], -dt_ / dto, Pn, 0, 1, 0);
+        else if (warm) MultiFab::Copy(Pn, P[1 - pnew], 0, 0, 1, 0);
+        else Pn.setVal(0.0, 0, 1, 0);
+    }
     else {
         // :232-256: FillCoarsePatch(P_new, cur_pres_time) -- Press_Type is an Interval type and cur_pres_time lies in the coarse level's
         // NEW interval (the coarse level has advanced already), node_bilinear_interp -- then zero on every box shrunk by one node:
@@ -824,11 +853,12 @@ void NavierStokes::level_project(double dt_)
         else if (tp >= crse->pt_old[0] - teps && tp <= crse->pt_old[1] + teps) Pc = &crse->P[1 - crse->pnew];
         else throw Error("iamrx NavierStokes::level_project: the coarse level has no pressure at the requested time");
         node_interp_from_crse(Pn, *Pc, crse->g, ratio, nullptr, false);
-        const FabD* pt = Pn.d_tab;
+        const FabD *pt = Pn.d_tab, *po = P[1 - pnew].d_tab;
         const BoxD* vb = layout->d_boxes;
+        const bool use_old = warm;
         for_each(*layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const BoxD b = vb[f];
-            if (i > b.lo[0] && i <= b.hi[0] && j > b.lo[1] && j <= b.hi[1] && k > b.lo[2] && k <= b.hi[2]) pt[f](i, j, k) = 0.0;
+            if (i > b.lo[0] && i <= b.hi[0] && j > b.lo[1] && j <= b.hi[1] && k > b.lo[2] && k <= b.hi[2]) pt[f](i, j, k) = use_old ? (double)po[f](i, j, k) : 0.0;
         });
     }
     mf_mult(Sn, 1.0 / dt_, Xvel, 3, 1);                          // U_new *= 1/dt (:273)

@@ -217,6 +217,9 @@ private:
     double state_time(const MultiFab& Sdata) const { return &Sdata == &S[1 - inew] ? st_old : st_new; }
     const MultiFab& cf_mask();                 // cf_build_mask of the level (2 ghost cells), level > 0
     MultiFab m_cf_mask;
+    MultiFab m_mac_phi_prev, m_mac_phi_prev2;  // initial guess of the next MAC solve (last two potentials)
+    bool m_have_mac_prev = false, m_have_mac_prev2 = false;
+    double dt_prev_mac = 0.0;
     bool m_cf_mask_built = false;
     void fill_gradp_bc();
     void set_inflow_ghosts(MultiFab& vel, double scale);
