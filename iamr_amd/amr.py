@@ -5,6 +5,11 @@ from .lib import lib, check, mg_opts, MgStats
 from .ns import NavierStokes, ns_params
 
 
+class TagRule(C.Structure):
+    _fields_ = [("comp", C.c_int), ("mode", C.c_int), ("nvalue", C.c_int), ("max_level", C.c_int), ("has_box", C.c_int),
+                ("value", C.c_double * 8), ("box_lo", C.c_double * 3), ("box_hi", C.c_double * 3)]
+
+
 class _Level(NavierStokes):
     """a level borrowed from an Amr hierarchy (never destroyed on its own)"""
 
@@ -30,10 +35,65 @@ class Amr:
         arr = (C.c_void_p * len(self.layouts))(*[l.h for l in self.layouts])
         check(lib().iamrx_amr_create(C.byref(geom0), len(self.layouts), arr, int(ratio), C.byref(self.params), C.byref(self.opts), C.byref(self.h)))
         self.levels = []
-        for l in range(len(self.layouts)):
+        self._refresh(keep_layouts=True)
+
+    def _refresh(self, keep_layouts=False):
+        """(re)build the Python views of the levels; after a regrid the layouts are re-created from the hierarchy's box lists"""
+        from .lib import Layout
+        n = C.c_int()
+        check(lib().iamrx_amr_nlevels(self.h, C.byref(n)))
+        if not keep_layouts:
+            lays = [self.layouts[0]]
+            for l in range(1, n.value):
+                nb = C.c_int(0)
+                check(lib().iamrx_amr_level_boxes(self.h, l, C.byref(nb), None))
+                arr = (C.c_int * (6 * nb.value))()
+                check(lib().iamrx_amr_level_boxes(self.h, l, C.byref(nb), arr))
+                hl = C.c_void_p()
+                check(lib().iamrx_amr_level_layout(self.h, l, C.byref(hl)))
+                lays.append(Layout.from_handle(hl, [(tuple(arr[6 * q:6 * q + 3]), tuple(arr[6 * q + 3:6 * q + 6])) for q in range(nb.value)]))
+            self.layouts = lays
+        self.levels = []
+        for l in range(n.value):
             hl = C.c_void_p()
             check(lib().iamrx_amr_level(self.h, l, C.byref(hl)))
             self.levels.append(_Level(hl, self.level_geom(l), self.layouts[l], self.params, self.opts))
+
+    def set_regrid(self, max_level, regrid_int, rules, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1):
+        """rules: list of dicts(comp (0..4, -1 = mag_vort), mode (0 greater, 1 less, 2 vorticity, 3 adjacent difference), value (list per level),
+        max_level (optional), box_lo / box_hi (optional)) -- amr.refinement_indicators of NS_error.cpp"""
+        arr = (TagRule * max(1, len(rules)))()
+        for q, r in enumerate(rules):
+            arr[q].comp, arr[q].mode = int(r.get("comp", 4)), int(r.get("mode", 0))
+            vals = list(r["value"]) if hasattr(r["value"], "__len__") else [r["value"]]
+            arr[q].nvalue = len(vals)
+            for i, v in enumerate(vals[:8]):
+                arr[q].value[i] = float(v)
+            arr[q].max_level = int(r.get("max_level", 1000))
+            arr[q].has_box = 1 if "box_lo" in r else 0
+            for d in range(3):
+                arr[q].box_lo[d] = float(r.get("box_lo", (0, 0, 0))[d])
+                arr[q].box_hi[d] = float(r.get("box_hi", (0, 0, 0))[d])
+        check(lib().iamrx_amr_set_regrid(self.h, int(max_level), int(regrid_int), int(blocking_factor), int(max_grid_size), C.c_double(grid_eff),
+                                         int(n_error_buf), len(rules), arr))
+
+    def regrid(self):
+        ch = C.c_int()
+        check(lib().iamrx_amr_regrid(self.h, C.byref(ch)))
+        if ch.value:
+            self._refresh()
+        return bool(ch.value)
+
+    def install_grids(self, grids):
+        """grids: per refined level the list of (lo, hi) boxes in that level's index space"""
+        nb = (C.c_int * max(1, len(grids)))(*[len(g) for g in grids])
+        flat = [v for g in grids for lo, hi in g for v in (*lo, *hi)]
+        arr = (C.c_int * max(1, len(flat)))(*flat)
+        ch = C.c_int()
+        check(lib().iamrx_amr_install_grids(self.h, len(grids), nb, arr, C.byref(ch)))
+        if ch.value:
+            self._refresh()
+        return bool(ch.value)
 
     def level_geom(self, l):
         from .lib import Geom
@@ -50,7 +110,27 @@ class Amr:
     def coarse_step(self):
         dt = C.c_double()
         check(lib().iamrx_amr_coarse_step(self.h, C.byref(dt)))
+        n = C.c_int()
+        check(lib().iamrx_amr_nlevels(self.h, C.byref(n)))
+        boxes_now = []
+        for l in range(1, n.value):
+            nb = C.c_int(0)
+            check(lib().iamrx_amr_level_boxes(self.h, l, C.byref(nb), None))
+            boxes_now.append(nb.value)
+        if n.value != len(self.levels) or self._grids_changed():
+            self._refresh()
         return dt.value
+
+    def _grids_changed(self):
+        for l in range(1, len(self.levels)):
+            nb = C.c_int(0)
+            check(lib().iamrx_amr_level_boxes(self.h, l, C.byref(nb), None))
+            arr = (C.c_int * (6 * max(1, nb.value)))()
+            check(lib().iamrx_amr_level_boxes(self.h, l, C.byref(nb), arr))
+            now = [(tuple(arr[6 * q:6 * q + 3]), tuple(arr[6 * q + 3:6 * q + 6])) for q in range(nb.value)]
+            if now != self.layouts[l].boxes:
+                return True
+        return False
 
     @property
     def time(self):

@@ -28,6 +28,32 @@ public:
     void level_sync(int l, int crse_iteration = -1);      // crse_iteration: of level l within the step of level l-1 (-1: the last one)
     void post_timestep(int l, int crse_iteration = -1);
     void time_step(int l, double time, int iteration, int niter);
+    // ---- regridding (Amr::regrid from level 0 at the start of a coarse step; NavierStokes::errorEst, NS_error.cpp:10-145;
+    // NavierStokesBase::init(AmrLevel&) / init(), NavierStokesBase.cpp:1713-1806) ----
+    struct TagRule {
+        int comp = Tracer;              // state component, or -1: magnitude of vorticity (mag_vort)
+        int mode = 0;                   // 0 value_greater, 1 value_less, 2 vorticity_greater (x 2^level), 3 adjacent_difference_greater
+        std::vector<double> value;      // per level (the last one repeats)
+        int max_level = 1000;           // tags only on levels < max_level
+        bool has_box = false;
+        double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
+    };
+    struct RegridOpts {
+        int max_level = 0, regrid_int = 0;
+        int blocking_factor = 8, max_grid_size = 32, n_error_buf = 1;
+        double grid_eff = 0.7;
+        std::vector<TagRule> rules;
+    };
+    void set_regrid(const RegridOpts& r) { rg = r; }
+    // new grids of levels 1 .. max_level from the tags of the current data (coarse to fine nesting enforced); the level-l boxes
+    std::vector<std::vector<BoxD>> make_new_grids();
+    // install grids (levels 1 ..): new levels are filled from the old level where it existed and from the next coarser level elsewhere;
+    // returns false if nothing changed
+    bool install_grids(const std::vector<std::vector<BoxD>>& grids);
+    bool regrid() { return install_grids(make_new_grids()); }
+    int level_count = 0;                // coarse steps since the last regrid (Amr::level_count[0])
+    uint64_t grid_generation() const { return m_grid_gen; }   // incremented whenever the grids change
+    uint64_t m_grid_gen = 0;
 
 private:
     NSParams p;
@@ -37,6 +63,11 @@ private:
     std::vector<double> dt_level, dt_min;
     int level_steps = 0;
     double stop_time = -1.0;
+    RegridOpts rg;
+    int m_ratio = 2;
+    void link_level(int l);
+    void check_nesting(const Layout& fine, const Layout& crse, const Geometry& cgeom, int l) const;
+    void compute_new_dt(bool post_regrid);
 };
 
 }  // namespace iamrx

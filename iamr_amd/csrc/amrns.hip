@@ -611,43 +611,55 @@ AmrNS::AmrNS(const Geometry& g0, const std::vector<LayoutP>& layouts, int ratio,
         dt_level.push_back(0.0); dt_min.push_back(1.e200);
         if (l > 0) {
             NavierStokes& c = *lev[l - 1];
-            // proper nesting: the Godunov ghost cells (3) of every box plus the interpolation stencil (1 coarse cell) must lie inside the
-            // next coarser level or outside a non-periodic domain face -- what amrex::Amr's grid generation guarantees for IAMR
-            // (blocking_factor >= 8).  Layouts that violate it would read cells no level defines.
-            if (l > 1) {
-                const BoxD cdom = c.g.domain;
-                for (auto& fb : layouts[l]->boxes) {
-                    BoxD R = grow(coarsen(grow(fb, 3), ratio), 1);
-                    for (int d = 0; d < 3; ++d) if (!c.g.periodic[d]) { R.lo[d] = std::max(R.lo[d], cdom.lo[d]); R.hi[d] = std::min(R.hi[d], cdom.hi[d]); }
-                    long covered = 0;
-                    for (auto& cb : layouts[l - 1]->boxes)
-                        for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
-                            const int sh[3] = {sx, sy, sz};
-                            bool ok = true;
-                            BoxD q = cb;
-                            for (int d = 0; d < 3; ++d) {
-                                if (sh[d] != 0 && !c.g.periodic[d]) ok = false;
-                                q.lo[d] += sh[d] * cdom.len(d); q.hi[d] += sh[d] * cdom.len(d);
-                            }
-                            if (!ok) continue;
-                            const BoxD is = intersect(R, q);
-                            if (is.ok()) covered += is.npts();
-                        }
-                    if (covered != R.npts()) throw Error("iamrx AmrNS: level " + std::to_string(l) + " is not properly nested in level " + std::to_string(l - 1) +
-                                                         " (3 ghost cells + 1 coarse stencil cell must lie inside the coarser level)");
-                }
-            }
-            s.crse = &c; c.fine = &s;
-            s.rho_avg.define(s.layout, cell_type(), 1, 1); s.rho_avg.setVal(0.0);
-            s.p_avg.define(s.layout, node_type(), 1, 0); s.p_avg.setVal(0.0);
-            s.reg_adv = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
-            s.reg_visc = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
-            s.reg_mac = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, 1);
-            s.sync_reg = std::make_unique<SyncRegister>(s.layout, c.layout, c.g, s.g, ratio, p.phys_lo, p.phys_hi);
-            c.Vsync.define(c.layout, cell_type(), 3, 1); c.Vsync.setVal(0.0);
-            c.Ssync.define(c.layout, cell_type(), NUM_STATE - 3, 1); c.Ssync.setVal(0.0);
+            if (l > 1) check_nesting(*layouts[l], *layouts[l - 1], c.g, (int)l);
+            link_level((int)l);
         }
     }
+}
+
+// proper nesting: the Godunov ghost cells (3) of every box plus the interpolation stencil (1 coarse cell) must lie inside the next
+// coarser level or outside a non-periodic domain face -- what amrex::Amr's grid generation guarantees for IAMR (blocking_factor >= 8).
+// Layouts that violate it would read cells no level defines.
+void AmrNS::check_nesting(const Layout& fine, const Layout& crse, const Geometry& cgeom, int l) const
+{
+    const int ratio = m_ratio;
+    const BoxD cdom = cgeom.domain;
+    for (auto& fb : fine.boxes) {
+        BoxD R = grow(coarsen(grow(fb, 3), ratio), 1);
+        for (int d = 0; d < 3; ++d) if (!cgeom.periodic[d]) { R.lo[d] = std::max(R.lo[d], cdom.lo[d]); R.hi[d] = std::min(R.hi[d], cdom.hi[d]); }
+        long covered = 0;
+        for (auto& cb : crse.boxes)
+            for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+                const int sh[3] = {sx, sy, sz};
+                bool ok = true;
+                BoxD q = cb;
+                for (int d = 0; d < 3; ++d) {
+                    if (sh[d] != 0 && !cgeom.periodic[d]) ok = false;
+                    q.lo[d] += sh[d] * cdom.len(d); q.hi[d] += sh[d] * cdom.len(d);
+                }
+                if (!ok) continue;
+                const BoxD is = intersect(R, q);
+                if (is.ok()) covered += is.npts();
+            }
+        if (covered != R.npts()) throw Error("iamrx AmrNS: level " + std::to_string(l) + " is not properly nested in level " + std::to_string(l - 1) +
+                                             " (3 ghost cells + 1 coarse stencil cell must lie inside the coarser level)");
+    }
+}
+
+// the interface data of level l > 0 and its coarser level: registers (owned by the fine level), rho_avg / p_avg, Vsync / Ssync of the coarse one
+void AmrNS::link_level(int l)
+{
+    NavierStokes &s = *lev[l], &c = *lev[l - 1];
+    const int ratio = s.ratio;
+    s.crse = &c; c.fine = &s;
+    s.rho_avg.define(s.layout, cell_type(), 1, 1); s.rho_avg.setVal(0.0);
+    s.p_avg.define(s.layout, node_type(), 1, 0); s.p_avg.setVal(0.0);
+    s.reg_adv = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
+    s.reg_visc = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
+    s.reg_mac = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, 1);
+    s.sync_reg = std::make_unique<SyncRegister>(s.layout, c.layout, c.g, s.g, ratio, p.phys_lo, p.phys_hi);
+    c.Vsync.define(c.layout, cell_type(), 3, 1); c.Vsync.setVal(0.0);
+    c.Ssync.define(c.layout, cell_type(), NUM_STATE - 3, 1); c.Ssync.setVal(0.0);
 }
 
 // NavierStokes::avgDown (NavierStokes.cpp:1845-1873) + avgDown_StatePress (NavierStokesBase.cpp:4125-4163)
@@ -1090,25 +1102,35 @@ void AmrNS::post_init(double stop_time_)
     level_steps = 0;
 }
 
-// Amr::coarseTimeStep: computeNewDt (NavierStokesBase.cpp:945-1035) + timeStep(0)
-double AmrNS::coarse_step()
+// NavierStokesBase::computeNewDt (NavierStokesBase.cpp:945-1035); post_regrid: limited by the pre-regrid dt instead of change_max x dt
+void AmrNS::compute_new_dt(bool post_regrid)
 {
     const int nl = (int)lev.size();
     const double cur_time = lev[0]->time;
-    if (level_steps > 0) {
-        for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], lev[i]->estTimeStep());
-        if (p.fixed_dt <= 0.0) for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], p.change_max * dt_level[i]);
-        double dt_0 = 1.0e+100;
-        int n_factor = 1;
-        for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_0 = std::min(dt_0, n_factor * dt_min[i]); }
-        const double eps = 0.0001 * dt_0;
-        if (stop_time >= 0.0 && cur_time + dt_0 > stop_time - eps) dt_0 = stop_time - cur_time;
-        n_factor = 1;
-        for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_level[i] = dt_0 / (double)n_factor; }
+    for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], lev[i]->estTimeStep());
+    if (p.fixed_dt <= 0.0) for (int i = 0; i < nl; ++i) dt_min[i] = std::min(dt_min[i], post_regrid ? dt_level[i] : p.change_max * dt_level[i]);
+    double dt_0 = 1.0e+100;
+    int n_factor = 1;
+    for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_0 = std::min(dt_0, n_factor * dt_min[i]); }
+    const double eps = 0.0001 * dt_0;
+    if (stop_time >= 0.0 && cur_time + dt_0 > stop_time - eps) dt_0 = stop_time - cur_time;
+    n_factor = 1;
+    for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_level[i] = dt_0 / (double)n_factor; }
+}
+
+// Amr::coarseTimeStep: computeNewDt + timeStep(0); Amr::timeStep regrids from level 0 at the start of the step once regrid_int coarse
+// steps have been taken since the last regrid, then recomputes the time steps with post_regrid_flag = 1
+double AmrNS::coarse_step()
+{
+    if (level_steps > 0) compute_new_dt(false);
+    if (rg.regrid_int > 0 && rg.max_level > 0 && level_count >= rg.regrid_int) {
+        level_count = 0;
+        if (regrid()) compute_new_dt(true);
     }
-    time_step(0, cur_time, 1, 1);
+    time_step(0, lev[0]->time, 1, 1);
     level_steps += 1;
-    for (int i = 0; i < nl; ++i) lev[i]->dt = dt_level[i];
+    level_count += 1;
+    for (size_t i = 0; i < lev.size(); ++i) lev[i]->dt = dt_level[i];
     return dt_level[0];
 }
 

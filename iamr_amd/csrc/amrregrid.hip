@@ -1,0 +1,175 @@
+// iamr_amd/csrc/amrregrid.hip -- regridding of the hierarchy (SURVEY f1 on top of a18): Amr::regrid from level 0 as IAMR drives it.
+//
+// Reference:
+//   NavierStokes::errorEst / error_setup     Source/NS_error.cpp:10-145 (amr.refinement_indicators: value_greater, value_less,
+//                                            vorticity_greater, adjacent_difference_greater, in_box_lo/hi, max_level)
+//   NavierStokesBase::init(AmrLevel& old)    Source/NavierStokesBase.cpp:1713-1754 (a level that existed: FillPatch of State, Press, Gradp)
+//   NavierStokesBase::init()                 Source/NavierStokesBase.cpp:1759-1806 (a new level: FillCoarsePatch, dt = dt_crse / ratio)
+//   NavierStokesBase::computeNewDt           Source/NavierStokesBase.cpp:971-982 (post_regrid_flag = 1)
+//   Amr::regrid / AmrMesh::MakeNewGrids      upstream AMReX (tag, buffer, cluster on the blocking-factor lattice, proper nesting)
+//
+// Grid generation, top-down: for lev = finest-possible .. 0 the tags of level lev are the error tags of its data plus the cells under
+// the already generated level lev+2 grids grown by the nesting buffer, so that every new level nests properly in the one below
+// (3 ghost cells of the Godunov stencil + 1 coarse interpolation cell, the condition AmrNS's constructor checks).
+#include "operators.h"
+#include "launch.h"
+#include "amrns.h"
+#include <algorithm>
+#include <cmath>
+
+namespace iamrx {
+
+// regrid.hip
+std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
+                               int n_error_buf);
+
+namespace {
+
+bool same_boxes(std::vector<BoxD> a, std::vector<BoxD> b)
+{
+    if (a.size() != b.size()) return false;
+    auto key = [](const BoxD& x, const BoxD& y) {
+        for (int d = 2; d >= 0; --d) { if (x.lo[d] != y.lo[d]) return x.lo[d] < y.lo[d]; }
+        for (int d = 2; d >= 0; --d) { if (x.hi[d] != y.hi[d]) return x.hi[d] < y.hi[d]; }
+        return false;
+    };
+    std::sort(a.begin(), a.end(), key); std::sort(b.begin(), b.end(), key);
+    for (size_t q = 0; q < a.size(); ++q) for (int d = 0; d < 3; ++d) if (a[q].lo[d] != b[q].lo[d] || a[q].hi[d] != b[q].hi[d]) return false;
+    return true;
+}
+
+}  // namespace
+
+std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
+{
+    IAMRX_ASSERT(Context::get().comm->nranks == 1);      // the tags of a level are gathered on the (single) rank
+    const int finest = (int)lev.size() - 1;
+    const int max_level = rg.max_level;
+    std::vector<std::vector<BoxD>> grids(max_level + 1);                 // grids[l]: boxes of level l (index space of level l), l >= 1
+    const int nest_buf = 3;                                              // in cells of the level being nested (see the header comment)
+    for (int l = std::min(finest, max_level - 1); l >= 0; --l) {
+        NavierStokes& s = *lev[l];
+        const BoxD dom = s.g.domain;
+        const int n0 = dom.len(0), n1 = dom.len(1), n2 = dom.len(2);
+        std::vector<unsigned char> h((size_t)n0 * n1 * n2, 0);
+        // ---- NavierStokes::errorEst on the level's current data
+        MultiFab tags(s.layout, cell_type(), 1, 0);
+        tags.setVal(0.0);
+        for (const TagRule& r : rg.rules) {
+            if (l >= r.max_level || r.value.empty()) continue;
+            const double v = r.value[std::min<size_t>((size_t)l, r.value.size() - 1)];
+            MultiFab fld(s.layout, cell_type(), 1, 1);
+            if (r.comp < 0 || r.mode == 2) {
+                MultiFab vel(s.layout, cell_type(), 3, 1);
+                s.fillpatch(vel, s.S[s.inew], Xvel, 3, s.bc_vel);
+                derive_mag_vort(s.g, fld, 0, vel, 0);
+            } else if (r.comp < 3) {
+                MultiFab vel(s.layout, cell_type(), 3, 1);
+                s.fillpatch(vel, s.S[s.inew], Xvel, 3, s.bc_vel);
+                MultiFab::Copy(fld, vel, r.comp, 0, 1, 1);
+            } else s.fillpatch(fld, s.S[s.inew], r.comp, 1, &s.bc_scal[r.comp - 3]);
+            error_tag(s.g, tags, fld, 0, r.mode, v, l, r.has_box ? r.box_lo : nullptr, r.has_box ? r.box_hi : nullptr);
+        }
+        for (int li = 0; li < tags.nlocal(); ++li) {
+            const BoxD fb = tags.fabbox(li), vb = s.layout->lbox(li);
+            std::vector<double> buf((size_t)fb.npts());
+            tags.copy_to_host(li, buf.data());
+            for (int k = vb.lo[2]; k <= vb.hi[2]; ++k) for (int j = vb.lo[1]; j <= vb.hi[1]; ++j) for (int i = vb.lo[0]; i <= vb.hi[0]; ++i) {
+                const size_t o = ((size_t)(k - fb.lo[2]) * fb.len(1) + (j - fb.lo[1])) * fb.len(0) + (i - fb.lo[0]);
+                if (buf[o] != 0.0) h[((size_t)(k - dom.lo[2]) * n1 + (j - dom.lo[1])) * n0 + (i - dom.lo[0])] = 1;
+            }
+        }
+        // ---- cells under the new level l+2 grids (grown by the nesting buffer at level l+1), so that level l+1 will contain them
+        if (l + 2 <= max_level)
+            for (const BoxD& b2 : grids[l + 2]) {
+                const BoxD c = coarsen(grow(coarsen(b2, m_ratio), nest_buf), m_ratio);
+                for (int k = c.lo[2]; k <= c.hi[2]; ++k) for (int j = c.lo[1]; j <= c.hi[1]; ++j) for (int i = c.lo[0]; i <= c.hi[0]; ++i) {
+                    int q[3] = {i, j, k};
+                    bool ok = true;
+                    for (int d = 0; d < 3; ++d) {
+                        if (q[d] < dom.lo[d] || q[d] > dom.hi[d]) {
+                            if (!s.g.periodic[d]) { ok = false; break; }
+                            q[d] = dom.lo[d] + ((q[d] - dom.lo[d]) % dom.len(d) + dom.len(d)) % dom.len(d);
+                        }
+                    }
+                    if (ok) h[((size_t)(q[2] - dom.lo[2]) * n1 + (q[1] - dom.lo[1])) * n0 + (q[0] - dom.lo[0])] = 1;
+                }
+            }
+        // tags outside the level's own cells cannot exist (no data there): boxes of level l+1 stay inside refine(level l) as long as
+        // the clustering does not reach over the level's edge; the nesting of the OLD level l+1 in the OLD level l keeps a margin
+        const int bf = std::max(1, rg.blocking_factor / m_ratio), mg = std::max(bf, rg.max_grid_size / m_ratio);
+        std::vector<BoxD> cb = cluster_tags(h.data(), dom, bf, mg, rg.grid_eff, rg.n_error_buf);
+        for (const BoxD& b : cb) grids[l + 1].push_back(refine(b, m_ratio));
+    }
+    // a level can only exist if the one below it does
+    for (int l = 1; l <= max_level; ++l) if (grids[l].empty()) { for (int q = l; q <= max_level; ++q) grids[q].clear(); break; }
+    grids.erase(grids.begin());                                          // -> index 0 = level 1
+    while (!grids.empty() && grids.back().empty()) grids.pop_back();
+    return grids;
+}
+
+bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
+{
+    auto& ctx = Context::get();
+    const int old_finest = (int)lev.size() - 1, new_finest = (int)grids.size();
+    bool same = old_finest == new_finest;
+    for (int l = 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->layout->boxes, grids[l - 1]);
+    if (same) return false;
+    ++m_grid_gen;
+    const double cur_time = lev[0]->time;
+    std::vector<std::unique_ptr<NavierStokes>> old;
+    for (int l = 1; l <= old_finest; ++l) old.push_back(std::move(lev[l]));
+    lev.resize(1);
+    lev[0]->fine = nullptr;
+    n_cycle.resize(new_finest + 1, m_ratio); dt_level.resize(new_finest + 1, 0.0); dt_min.resize(new_finest + 1, 1.e200);
+    static LayoutP empty_layout;
+    if (!empty_layout) empty_layout = std::make_shared<Layout>(std::vector<BoxD>{}, std::vector<int>{}, ctx.comm->rank);
+    for (int l = 1; l <= new_finest; ++l) {
+        NavierStokes& c = *lev[l - 1];
+        Geometry g = c.g;
+        for (int d = 0; d < 3; ++d) { g.domain.lo[d] *= m_ratio; g.domain.hi[d] = (g.domain.hi[d] + 1) * m_ratio - 1; g.dx[d] /= (double)m_ratio; }
+        LayoutP nl = std::make_shared<Layout>(grids[l - 1], std::vector<int>(grids[l - 1].size(), 0), ctx.comm->rank);
+        if (l > 1) check_nesting(*nl, *c.layout, c.g, l);
+        lev.push_back(std::make_unique<NavierStokes>(g, nl, p, o));
+        NavierStokes& s = *lev.back();
+        s.level = l; s.ratio = m_ratio;
+        NavierStokes* ol = (l <= old_finest) ? old[l - 1].get() : nullptr;
+        link_level(l);
+        // ---- times (init(old): setTimeLevel(cur_time, dt_old, dt_new); init(): dt = dt_crse / ratio, dt_old = (coarse dt_old) / ratio)
+        const double dt_new = ol ? dt_level[l] : dt_level[l - 1] / (double)m_ratio;
+        const double dt_old = ol ? ol->st_new - ol->st_old : (c.st_new - c.st_old) / (double)m_ratio;
+        dt_level[l] = dt_new; n_cycle[l] = m_ratio; dt_min[l] = ol ? dt_min[l] : 1.e200;
+        s.time = cur_time; s.nstep = ol ? ol->nstep : 0; s.dt = dt_new;
+        s.inew = 0; s.pnew = 0;
+        s.set_time_level(cur_time, dt_old, dt_new);
+        s.initial_step = false; s.initial_iter = false;
+        // ---- data: FillPatch(old, S_new / P_new / Gp_new) resp. FillCoarsePatch: the old level's cells where it existed, the
+        // (already rebuilt) coarser level interpolated elsewhere
+        MultiFab none_c(empty_layout, cell_type(), NUM_STATE, 0);
+        const MultiFab* fS = ol ? &ol->S[ol->inew] : &none_c;
+        TimeData fd{nullptr, fS, cur_time, cur_time};
+        TimeData cd{nullptr, &c.S[c.inew], cur_time, cur_time};
+        MultiFab tmp3(s.layout, cell_type(), 3, 1), tmp1(s.layout, cell_type(), 1, 1);
+        fillpatch_two_levels(tmp3, 0, cur_time, fd, cd, Xvel, 3, c.g, s.g, m_ratio, s.bc_vel, s.ed_vel_lo, s.ed_vel_hi);
+        MultiFab::Copy(s.S[0], tmp3, 0, Xvel, 3, 1);
+        for (int q = 0; q < NUM_SCALARS; ++q) {
+            fillpatch_two_levels(tmp1, 0, cur_time, fd, cd, Density + q, 1, c.g, s.g, m_ratio, &s.bc_scal[q], s.ed_scal_lo + 3 * q, s.ed_scal_hi + 3 * q);
+            MultiFab::Copy(s.S[0], tmp1, 0, Density + q, 1, 1);
+        }
+        MultiFab::Copy(s.S[1], s.S[0], 0, 0, NUM_STATE, 1);
+        MultiFab none_g(empty_layout, cell_type(), 3, 0);
+        TimeData fg{nullptr, ol ? &ol->Gp[ol->pnew] : &none_g, cur_time, cur_time};
+        TimeData cg{nullptr, &c.Gp[c.pnew], cur_time, cur_time};
+        fillpatch_two_levels(tmp3, 0, cur_time, fg, cg, 0, 3, c.g, s.g, m_ratio, s.bc_gp, nullptr, nullptr);
+        MultiFab::Copy(s.Gp[0], tmp3, 0, 0, 3, 1);
+        MultiFab::Copy(s.Gp[1], s.Gp[0], 0, 0, 3, 1);
+        s.P[0].setVal(0.0);
+        node_interp_from_crse(s.P[0], c.P[c.pnew], c.g, m_ratio, nullptr, false);
+        if (ol) parallel_copy(s.P[0], ol->P[ol->pnew], 0, 0, 1, 0, 0, &s.g);
+        MultiFab::Copy(s.P[1], s.P[0], 0, 0, 1, 1);
+        s.make_rho_curr_time();
+    }
+    return true;
+}
+
+}  // namespace iamrx

@@ -844,9 +844,91 @@ int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts
     IAMRX_CATCH
 }
 int iamrx_amr_destroy(iamrx_amr a) { IAMRX_TRY delete a; IAMRX_CATCH }
+static void amr_refresh_levels(iamrx_amr a)
+{
+    // the level handles given out so far stay valid objects but refer to levels that no longer exist: rebuild the table
+    a->levels.clear();
+    for (int l = 0; l < a->amr->nlevels(); ++l) {
+        auto v = std::make_unique<iamrx_ns_s>();
+        v->ns = &a->amr->level(l);
+        v->layout = a->amr->level(l).lay();
+        for (auto& q : v->views) q = nullptr;
+        a->levels.push_back(std::move(v));
+    }
+}
+int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
+                         int nrules, const iamrx_tag_rule* rules)
+{
+    IAMRX_TRY
+    AmrNS::RegridOpts r;
+    r.max_level = max_level; r.regrid_int = regrid_int; r.blocking_factor = blocking_factor; r.max_grid_size = max_grid_size;
+    r.grid_eff = grid_eff; r.n_error_buf = n_error_buf;
+    for (int q = 0; q < nrules; ++q) {
+        AmrNS::TagRule t;
+        t.comp = rules[q].comp; t.mode = rules[q].mode; t.max_level = rules[q].max_level;
+        for (int v = 0; v < rules[q].nvalue && v < 8; ++v) t.value.push_back(rules[q].value[v]);
+        t.has_box = rules[q].has_box != 0;
+        for (int d = 0; d < 3; ++d) { t.box_lo[d] = rules[q].box_lo[d]; t.box_hi[d] = rules[q].box_hi[d]; }
+        r.rules.push_back(t);
+    }
+    a->amr->set_regrid(r);
+    IAMRX_CATCH
+}
+int iamrx_amr_regrid(iamrx_amr a, int* changed)
+{
+    IAMRX_TRY
+    const bool c = a->amr->regrid();
+    if (c) amr_refresh_levels(a);
+    if (changed) *changed = c ? 1 : 0;
+    IAMRX_CATCH
+}
+int iamrx_amr_install_grids(iamrx_amr a, int nfine_levels, const int* nboxes, const int* boxes, int* changed)
+{
+    IAMRX_TRY
+    std::vector<std::vector<BoxD>> g(nfine_levels);
+    int q = 0;
+    for (int l = 0; l < nfine_levels; ++l)
+        for (int b = 0; b < nboxes[l]; ++b, ++q) {
+            BoxD x;
+            for (int d = 0; d < 3; ++d) { x.lo[d] = boxes[6 * q + d]; x.hi[d] = boxes[6 * q + 3 + d]; }
+            g[l].push_back(x);
+        }
+    const bool c = a->amr->install_grids(g);
+    if (c) amr_refresh_levels(a);
+    if (changed) *changed = c ? 1 : 0;
+    IAMRX_CATCH
+}
+int iamrx_amr_nlevels(iamrx_amr a, int* nlev) { IAMRX_TRY *nlev = a->amr->nlevels(); IAMRX_CATCH }
+int iamrx_amr_level_layout(iamrx_amr a, int lev, iamrx_layout* out)
+{
+    IAMRX_TRY
+    auto* h = new iamrx_layout_s;
+    h->p = a->amr->level(lev).lay();
+    *out = h;
+    IAMRX_CATCH
+}
+int iamrx_amr_level_boxes(iamrx_amr a, int lev, int* nboxes, int* boxes /* 6 ints per box, or NULL to query the count */)
+{
+    IAMRX_TRY
+    const auto& bx = a->amr->level(lev).lay()->boxes;
+    if (boxes) {
+        if (*nboxes < (int)bx.size()) throw Error("iamrx_amr_level_boxes: box capacity too small");
+        for (size_t q = 0; q < bx.size(); ++q) for (int d = 0; d < 3; ++d) { boxes[6 * q + d] = bx[q].lo[d]; boxes[6 * q + 3 + d] = bx[q].hi[d]; }
+    }
+    *nboxes = (int)bx.size();
+    IAMRX_CATCH
+}
 int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out) { IAMRX_TRY *out = a->levels.at(lev).get(); IAMRX_CATCH }
 int iamrx_amr_post_init(iamrx_amr a, double stop_time) { IAMRX_TRY a->amr->post_init(stop_time); IAMRX_CATCH }
-int iamrx_amr_coarse_step(iamrx_amr a, double* dt0) { IAMRX_TRY const double d = a->amr->coarse_step(); if (dt0) *dt0 = d; IAMRX_CATCH }
+int iamrx_amr_coarse_step(iamrx_amr a, double* dt0)
+{
+    IAMRX_TRY
+    const uint64_t before = a->amr->grid_generation();
+    const double d = a->amr->coarse_step();
+    if (a->amr->grid_generation() != before) amr_refresh_levels(a);      // the step regridded
+    if (dt0) *dt0 = d;
+    IAMRX_CATCH
+}
 int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels)
 {
     IAMRX_TRY

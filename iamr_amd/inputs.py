@@ -21,7 +21,7 @@ import re
 # ending in ".", as a prefix of a whole ParmParse namespace
 _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.verbose", "mac_proj.v", "mac_proj.verbose", "mac.v", "diffuse.v",
                  "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
-                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
+                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.refinement_indicators", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
                  "amr.check_file", "amr.check_int", "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
                  "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
@@ -130,11 +130,49 @@ class Inputs:
             return list(default)
         return [int(x) for x in self._get(k, n)[:n]]
 
+    def refinement_indicators(self, max_level):
+        """amr.refinement_indicators and their sub-keys (NavierStokes::error_setup, Source/NS_error.cpp:10-108) -> the arguments of
+        Amr.set_regrid"""
+        names = self.table.get("amr.refinement_indicators", [])
+        self.used.add("amr.refinement_indicators")
+        comps = {"x_velocity": 0, "y_velocity": 1, "z_velocity": 2, "density": 3, "tracer": 4, "mag_vort": -1}
+        rules = []
+        for nm in names:
+            pre = f"amr.{nm}."
+            r = {}
+            for key, mode in (("value_greater", 0), ("value_less", 1), ("vorticity_greater", 2), ("adjacent_difference_greater", 3)):
+                if self.has(pre + key):
+                    r["mode"] = mode
+                    r["value"] = [float(v) for v in self._get(pre + key)]
+            if "mode" not in r:
+                raise NotImplementedError(f"inputs: refinement indicator {nm}: none of value_greater / value_less / vorticity_greater / "
+                                          "adjacent_difference_greater given")
+            if r["mode"] == 2:
+                r["comp"] = -1
+            else:
+                fld = self.string(pre + "field_name")
+                if fld not in comps:
+                    raise NotImplementedError(f"inputs: refinement indicator {nm}: field {fld} is not available (state components and mag_vort are)")
+                r["comp"] = comps[fld]
+            if self.has(pre + "max_level"):
+                r["max_level"] = self.integer(pre + "max_level")
+            if self.has(pre + "in_box_lo"):
+                r["box_lo"] = self.reals(pre + "in_box_lo", 3)
+                r["box_hi"] = self.reals(pre + "in_box_hi", 3)
+            for key in ("start_time", "end_time"):
+                if self.has(pre + key):
+                    raise NotImplementedError(f"inputs: refinement indicator {nm}: {key} is not implemented")
+            rules.append(r)
+        return dict(max_level=max_level, regrid_int=self.ints("amr.regrid_int", 1, [1])[0], rules=rules,
+                    blocking_factor=self.ints("amr.blocking_factor", 1, [8])[0], max_grid_size=self.ints("amr.max_grid_size", 1, [32])[0],
+                    grid_eff=self.real("amr.grid_eff", 0.7), n_error_buf=self.ints("amr.n_error_buf", 1, [1])[0])
+
     # mapping ----------------------------------------------------------------------------------------------------------
     def problem(self):
         """-> dict(n, prob_lo, prob_hi, periodic, max_grid_size, params (kwargs of ns_params), prob (dict), max_step, stop_time)"""
         max_level = self.integer("amr.max_level", 0)
         fine_boxes = []
+        regrid = None
         if max_level > 0:
             # fixed refined grids only (amr.regrid_file, as Exec/run2d/test_grids/inputs_*): the tagging / clustering blocks exist
             # (iamrx_error_tag, iamrx_cluster_tags) but no regrid driver runs them during a run yet
@@ -142,15 +180,17 @@ class Inputs:
             for k in ("amr.regrid_file", "amr.initial_grid_file"):
                 if self.has(k):
                     gf = self.string(k)
-            if gf is None:
-                raise NotImplementedError("inputs: amr.max_level > 0 needs fixed grids (amr.regrid_file / amr.initial_grid_file); "
-                                          "regridding during a run is not implemented")
             rr = self.ints("amr.ref_ratio", max_level, [2] * max_level)
             if any(r != 2 for r in rr):
                 raise NotImplementedError(f"inputs: amr.ref_ratio = {rr}: only ratio 2 is implemented")
-            if not os.path.isabs(gf) and self.files:
-                gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
-            fine_boxes = read_grid_file(gf, rr)[:max_level]
+            if gf is not None:
+                if not os.path.isabs(gf) and self.files:
+                    gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
+                fine_boxes = read_grid_file(gf, rr)[:max_level]
+            else:
+                regrid = self.refinement_indicators(max_level)
+                if not regrid["rules"]:
+                    raise NotImplementedError("inputs: amr.max_level > 0 needs amr.refinement_indicators or fixed grids (amr.regrid_file)")
         if self.integer("geometry.coord_sys", 0) != 0:
             raise NotImplementedError("inputs: only Cartesian coordinates (geometry.coord_sys = 0)")
         n = self.ints("amr.n_cell", 3)
@@ -215,7 +255,7 @@ class Inputs:
                                       "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
-                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes)
+                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level)
         for k, dflt in _UNIMPLEMENTED_UNLESS.items():
             if self.has(k) and self.string(k) != dflt:
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented (only {dflt})")

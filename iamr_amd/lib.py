@@ -122,6 +122,15 @@ class Layout:
         self.owners = [0] * nb if owners is None else list(owners)
 
     @staticmethod
+    def from_handle(h, boxes, owners=None):
+        """wrap a layout handle obtained from the library (e.g. iamrx_amr_level_layout)"""
+        self = Layout.__new__(Layout)
+        self.h = h
+        self.boxes = [(tuple(lo), tuple(hi)) for lo, hi in boxes]
+        self.owners = [0] * len(boxes) if owners is None else list(owners)
+        return self
+
+    @staticmethod
     def single(n):
         return Layout([((0, 0, 0), (n[0] - 1, n[1] - 1, n[2] - 1))])
 

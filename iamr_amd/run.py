@@ -30,7 +30,19 @@ def build_amr(pr, lib, N):
     amr = Amr(g0, lays, N.ns_params(**pr["params"]))
     for l, lev in enumerate(amr.levels):
         init_level(lev, lays[l], lib, N, pr, [v * 2 ** l for v in pr["n"]])
-    return amr, lays, g0
+    if pr.get("regrid"):
+        # Amr::bldFineLevels: the initial hierarchy from the tags of the initial data, one level at a time; the new level's data are
+        # the problem's initial data (initData), not the interpolant
+        amr.set_regrid(**pr["regrid"])
+        for _ in range(pr["regrid"]["max_level"]):
+            nl = amr.nlev
+            if not amr.regrid():
+                break
+            for l in range(1, amr.nlev):
+                init_level(amr.levels[l], amr.layouts[l], lib, N, pr, [v * 2 ** l for v in pr["n"]])
+            if amr.nlev == nl and amr.nlev > pr["regrid"]["max_level"]:
+                break
+    return amr, amr.layouts, g0
 
 
 def level_arrays(ns, lay, N):
@@ -74,8 +86,9 @@ def main_amr(pr, inp, lib, N):
         if pr["max_step"] < 0 and pr["stop_time"] < 0:
             break
         dt = amr.coarse_step()
+        lays = amr.layouts                      # a regrid during the step replaces them
         step += 1
-        print(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g}")
+        print(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g} LEVELS = {amr.nlev} GRIDS = {[len(l.boxes) for l in lays]}")
         if plot_int > 0 and step % plot_int == 0:
             print("PLOTFILE:", write_plot_amr(amr, lays, pr, N, step, plot_root))
     lib.sync()
@@ -142,7 +155,7 @@ def main(argv):
         from . import comm
         comm.init_rccl_from_torch(dist)
     pr = inp.problem()
-    if pr["fine_boxes"]:
+    if pr["fine_boxes"] or pr.get("regrid"):
         if world > 1:
             raise NotImplementedError("iamr_amd.run: refined hierarchies run on one rank (the multi-level driver does not shard levels yet)")
         return main_amr(pr, inp, lib, N)

@@ -389,6 +389,22 @@ int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acom
  * iamrx_ns_data / iamrx_ns_set_data / iamrx_ns_time / iamrx_ns_stats, do not destroy them. */
 int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts, int ratio, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_amr* out);
 int iamrx_amr_destroy(iamrx_amr a);
+/* ---- regridding: Amr::regrid from level 0 with IAMR's error estimation (amr.refinement_indicators, Source/NS_error.cpp:10-145) and
+ * NavierStokesBase::init(AmrLevel&) / init() for the data of the new levels (Source/NavierStokesBase.cpp:1713-1806).
+ * comp: state component 0..4 (velocity, density, tracer) or -1 = mag_vort; mode: 0 value_greater, 1 value_less, 2 vorticity_greater
+ * (x 2^level), 3 adjacent_difference_greater; value[nvalue]: per level (the last one repeats); tags only on levels < max_level;
+ * has_box: in_box_lo / in_box_hi.  regrid_int > 0: iamrx_amr_coarse_step regrids at the start of every regrid_int-th coarse step.
+ * After a regrid the level handles of iamrx_amr_level must be fetched again. */
+typedef struct iamrx_tag_rule { int comp, mode, nvalue, max_level, has_box; double value[8]; double box_lo[3], box_hi[3]; } iamrx_tag_rule;
+int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
+                         int nrules, const iamrx_tag_rule* rules);
+int iamrx_amr_regrid(iamrx_amr a, int* changed);
+/* install given grids of levels 1 .. nfine_levels (boxes in each level's own index space, 6 ints per box, level by level) and fill them */
+int iamrx_amr_install_grids(iamrx_amr a, int nfine_levels, const int* nboxes, const int* boxes, int* changed);
+int iamrx_amr_nlevels(iamrx_amr a, int* nlev);
+/* a handle of the layout level `lev` currently lives on (release it with iamrx_layout_destroy): for containers that exchange data with the level */
+int iamrx_amr_level_layout(iamrx_amr a, int lev, iamrx_layout* out);
+int iamrx_amr_level_boxes(iamrx_amr a, int lev, int* nboxes, int* boxes /* NULL: query the count */);
 int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out);
 int iamrx_amr_post_init(iamrx_amr a, double stop_time);      /* S_new of every level must hold the initial data (iamrx_ns_set_data) */
 int iamrx_amr_coarse_step(iamrx_amr a, double* dt0);         /* dt0: the level-0 time step used */

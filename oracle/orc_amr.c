@@ -1202,6 +1202,133 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
 }
 
 /* Amr::coarseTimeStep: computeNewDt (NavierStokesBase.cpp:945-1035) + timeStep(0) */
+/* NavierStokesBase::computeNewDt (NavierStokesBase.cpp:945-1035); post_regrid: limited by the pre-regrid dt (:973-982) */
+static void compute_new_dt(orc_amr* a, int post_regrid)
+{
+    const int nl = a->nlev;
+    const orc_ns_params* p = &a->lev[0]->p;
+    const double cur_time = a->lev[0]->time;
+    for (int i = 0; i < nl; ++i) a->dt_min[i] = fmin(a->dt_min[i], ns_est_time_step(a->lev[i]));
+    if (p->fixed_dt <= 0.0) for (int i = 0; i < nl; ++i) a->dt_min[i] = fmin(a->dt_min[i], post_regrid ? a->dt_level[i] : p->change_max * a->dt_level[i]);
+    double dt_0 = 1.0e+100;
+    int n_factor = 1;
+    for (int i = 0; i < nl; ++i) { n_factor *= a->n_cycle[i]; dt_0 = fmin(dt_0, n_factor * a->dt_min[i]); }
+    const double eps = 0.0001 * dt_0;
+    if (a->stop_time >= 0.0 && cur_time + dt_0 > a->stop_time - eps) dt_0 = a->stop_time - cur_time;
+    n_factor = 1;
+    for (int i = 0; i < nl; ++i) { n_factor *= a->n_cycle[i]; a->dt_level[i] = dt_0 / (double)n_factor; }
+}
+
+/* Amr::regrid from level 0 with GIVEN new grids (the grid generation itself -- tags, clustering -- is tested on its own,
+ * orc_regrid.c): the data of the new levels as NavierStokesBase::init(AmrLevel& old) / init() fill them
+ * (NavierStokesBase.cpp:1713-1806): FillPatch of State / Gradp (the old level's cells where it existed, cell_cons_interp of the
+ * rebuilt coarser level elsewhere) and of Press (node_bilinear_interp + the old level's nodes); time levels
+ * setTimeLevel(cur_time, dt_old, dt_new); a new level starts with dt = dt_crse / ratio.  Call between coarse steps; the caller then
+ * uses orc_amr_coarse_step_post_regrid for the next step (computeNewDt with post_regrid_flag = 1). */
+void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
+{
+    const int old_nlev = a->nlev, ratio = 2;
+    const double cur_time = a->lev[0]->time;
+    orc_ns_state* old[8];
+    for (int l = 0; l < 8; ++l) old[l] = l < old_nlev ? a->lev[l] : NULL;
+    const int* bp = boxes;
+    a->lev[0]->fine = NULL;
+    for (int l = 1; l <= nfine; ++l) {
+        orc_ns_state* c = a->lev[l - 1];
+        orc_geom g = c->g;
+        for (int d = 0; d < 3; ++d) { g.n[d] *= ratio; g.dx[d] /= (double)ratio; }
+        orc_ns_state* s = orc_ns_create(&g, &c->p, &c->o);
+        orc_ns_state* ol = old[l];
+        s->level = l; s->ratio = ratio;
+        s->crse = c; c->fine = s;
+        s->nbox = nbox[l - 1];
+        s->boxes = (int*)malloc(sizeof(int) * 6 * (size_t)s->nbox);
+        memcpy(s->boxes, bp, sizeof(int) * 6 * (size_t)s->nbox);
+        bp += 6 * s->nbox;
+        s->cov = orc_alloc(g.n, ORC_CELL, 0, 1);
+        for (int b = 0; b < s->nbox; ++b) {
+            const int* bx = s->boxes + 6 * b;
+            for (int k = bx[2]; k <= bx[5]; ++k) for (int j = bx[1]; j <= bx[4]; ++j) for (int i = bx[0]; i <= bx[3]; ++i) A4(&s->cov, i, j, k, 0) = 1.0;
+        }
+        s->rho_avg = orc_alloc(g.n, ORC_CELL, 1, 1); s->p_avg = orc_alloc(g.n, ORC_NODE, 0, 1);
+        const orc_geom* cg = &c->g;
+        for (int d = 0; d < 3; ++d) {
+            s->reg_adv[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
+            s->reg_visc[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
+            s->reg_mac[d] = orc_alloc(cg->n, ORC_FACE[d], 0, 1);
+        }
+        s->sync_reg = orc_alloc(cg->n, ORC_NODE, 0, 1);
+        if (!c->Vsync.p) { c->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3); c->Ssync = orc_alloc(cg->n, ORC_CELL, 1, NUM_STATE - 3); }
+        /* times */
+        const double dt_new = ol ? a->dt_level[l] : a->dt_level[l - 1] / (double)ratio;
+        const double dt_old = ol ? ol->st_new - ol->st_old : (c->st_new - c->st_old) / (double)ratio;
+        a->dt_level[l] = dt_new; a->n_cycle[l] = ratio;
+        if (!ol) a->dt_min[l] = 1.e200;
+        s->time = cur_time; s->nstep = ol ? ol->nstep : 0; s->dt = dt_new;
+        ns_set_time_level(s, cur_time, dt_old, dt_new);
+        s->initial_step = 0; s->initial_iter = 0;
+        /* data.  A temporary view of the new level that still holds the OLD level's coverage and data serves as FillPatch source:
+         * whole-domain arrays interpolated from the (new) coarser level, overwritten by the old level's cells where it existed */
+        {
+            orc_ns_state src = *s;                   /* shallow: geometry, BCs, crse pointer of the NEW level */
+            if (ol) { src.cov = ol->cov; src.nbox = ol->nbox; src.boxes = ol->boxes; src.S[0] = ol->S[0]; src.S[1] = ol->S[1]; src.inew = ol->inew;
+                      src.Gp[0] = ol->Gp[0]; src.Gp[1] = ol->Gp[1]; src.P[0] = ol->P[0]; src.P[1] = ol->P[1]; src.pnew = ol->pnew;
+                      src.st_new = cur_time; src.st_old = ol->st_old; src.pt_new[0] = ol->pt_new[0]; src.pt_new[1] = ol->pt_new[1];
+                      src.pt_old[0] = ol->pt_old[0]; src.pt_old[1] = ol->pt_old[1]; }
+            else { orc_fab none = orc_alloc(g.n, ORC_CELL, 0, 1); src.cov = none; src.nbox = 0; src.st_new = cur_time; src.st_old = cur_time - dt_old; }
+            src.crse = c;
+            orc_fab Sv = ns_fillpatch_time(&src, cur_time, 0, Xvel, 3, 1);
+            orc_fab Sd = ns_fillpatch_time(&src, cur_time, 0, Density, 1, 1), St = ns_fillpatch_time(&src, cur_time, 0, Tracer, 1, 1);
+            const double tp = 0.5 * (s->pt_new[0] + s->pt_new[1]);
+            orc_fab Gv = ns_fillpatch_time(&src, ol ? 0.5 * (ol->pt_new[0] + ol->pt_new[1]) : tp, 1, 0, 3, 1);
+            for (int q = 0; q < 2; ++q) {
+                for (int n = 0; n < 3; ++n)
+                for (int k = -1; k <= g.n[2]; ++k) for (int j = -1; j <= g.n[1]; ++j) for (int i = -1; i <= g.n[0]; ++i) {
+                    A4(&s->S[q], i, j, k, n) = A4(&Sv, i, j, k, n);
+                    A4(&s->Gp[q], i, j, k, n) = A4(&Gv, i, j, k, n);
+                }
+                for (int k = -1; k <= g.n[2]; ++k) for (int j = -1; j <= g.n[1]; ++j) for (int i = -1; i <= g.n[0]; ++i) {
+                    A4(&s->S[q], i, j, k, Density) = A4(&Sd, i, j, k, 0);
+                    A4(&s->S[q], i, j, k, Tracer) = A4(&St, i, j, k, 0);
+                }
+            }
+            orc_free(&Sv); orc_free(&Sd); orc_free(&St); orc_free(&Gv);
+            if (!ol) orc_free(&src.cov);
+            /* pressure: node_bilinear_interp of the coarse pressure on every node of the new level, then the old level's nodes */
+            const orc_fab* Pc = P_NEW(c);
+            for (int k = 0; k <= g.n[2]; ++k) for (int j = 0; j <= g.n[1]; ++j) for (int i = 0; i <= g.n[0]; ++i) {
+                if (node_class(s, i, j, k) == ND_NONE) continue;
+                const int fi[3] = {i, j, k};
+                int c0[3]; double w[3];
+                for (int d = 0; d < 3; ++d) { c0[d] = fi[d] / ratio; w[d] = (double)(fi[d] - c0[d] * ratio) / (double)ratio; }
+                double v = 0.0;
+                for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+                    const double ww = (cx ? w[0] : 1.0 - w[0]) * (cy ? w[1] : 1.0 - w[1]) * (cz ? w[2] : 1.0 - w[2]);
+                    if (ww != 0.0) v += ww * A4(Pc, c0[0] + cx, c0[1] + cy, c0[2] + cz, 0);
+                }
+                if (ol && node_class(ol, i, j, k) != ND_NONE) v = A4(P_NEW(ol), i, j, k, 0);
+                A4(&s->P[0], i, j, k, 0) = v; A4(&s->P[1], i, j, k, 0) = v;
+            }
+        }
+        ns_make_rho_curr_time(s);
+        a->lev[l] = s;
+    }
+    for (int l = 1; l < old_nlev; ++l) if (old[l]) orc_ns_destroy(old[l]);
+    for (int l = nfine + 1; l < 8; ++l) a->lev[l] = NULL;
+    a->nlev = nfine + 1;
+}
+
+/* the coarse step that follows a regrid: computeNewDt as usual, then again with post_regrid_flag = 1 (Amr::timeStep) */
+double orc_amr_coarse_step_post_regrid(orc_amr* a)
+{
+    compute_new_dt(a, 1);
+    time_step(a, 0, a->lev[0]->time, 1, 1);
+    a->level_steps += 1;
+    for (int i = 0; i < a->nlev; ++i) a->lev[i]->dt = a->dt_level[i];
+    return a->dt_level[0];
+}
+void orc_amr_compute_new_dt(orc_amr* a) { if (a->level_steps > 0) compute_new_dt(a, 0); }
+
 double orc_amr_coarse_step(orc_amr* a)
 {
     const int nl = a->nlev;

@@ -275,6 +275,20 @@ class OrcAmr:
     def time(self):
         return lib().orc_amr_time(self.h)
 
+    def regrid_then_step(self, grids):
+        """the coarse step during which the hierarchy is regridded to `grids` (per refined level a list of (lo, hi) in that level's
+        index space): computeNewDt, Amr::regrid with these grids, computeNewDt(post_regrid_flag = 1), timeStep"""
+        L = lib()
+        L.orc_amr_coarse_step_post_regrid.restype = C.c_double
+        L.orc_amr_compute_new_dt(self.h)
+        nb = (C.c_int * max(1, len(grids)))(*[len(g) for g in grids])
+        flat = [v for g in grids for lo, hi in g for v in (*lo, *hi)]
+        arr = (C.c_int * max(1, len(flat)))(*flat)
+        L.orc_amr_regrid(self.h, len(grids), nb, arr)
+        self.nlev = len(grids) + 1
+        self.levels = [[]] + [list(g) for g in grids]
+        return L.orc_amr_coarse_step_post_regrid(self.h)
+
     def dt(self, lev):
         return lib().orc_amr_dt(self.h, C.c_int(lev))
 

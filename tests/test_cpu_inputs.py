@@ -105,3 +105,16 @@ def test_physics_keys_are_not_swallowed_by_verbosity_prefixes():
     with pytest.raises(KeyError):
         Inputs([LDC], ["ns.vorterr=1.0"]).problem()
     assert Inputs([LDC], ["ns.variable_vel_visc=0", "ns.do_init_proj=1", "ns.v=1"]).problem()["n"] == [16, 16, 16]
+
+
+def test_refinement_indicator_keys():
+    """amr.refinement_indicators (NS_error.cpp:10-108) -> the tagging rules of the regrid driver"""
+    pr = Inputs([os.path.join(HERE, "golden", "inputs.3d.tracer_regrid16")]).problem()
+    rg = pr["regrid"]
+    assert pr["fine_boxes"] == [] and rg["max_level"] == 2 and rg["regrid_int"] == 2 and rg["blocking_factor"] == 4 and rg["n_error_buf"] == 1
+    assert rg["rules"] == [dict(mode=0, value=[0.25], comp=4), dict(mode=0, value=[0.6, 0.6], comp=4)]
+    with pytest.raises(KeyError):          # indicator sub-keys that no listed indicator uses are not silently dropped
+        Inputs([os.path.join(HERE, "golden", "inputs.3d.tracer_regrid16")], ["amr.refinement_indicators = blob"]).problem()
+    pr = Inputs([LDC], ["amr.max_level = 1", "amr.refinement_indicators = vort", "amr.vort.vorticity_greater = 5.0", "ns.vel_visc_coef = 0.01",
+                 "amr.vort.max_level = 1", "amr.vort.in_box_lo = 0. 0. 0.", "amr.vort.in_box_hi = 1. 1. 0.5"]).problem()
+    assert pr["regrid"]["rules"] == [dict(mode=2, value=[5.0], comp=-1, max_level=1, box_lo=[0.0, 0.0, 0.0], box_hi=[1.0, 1.0, 0.5])]

@@ -1,0 +1,90 @@
+"""SURVEY row f1 on top of a18: regridding of the running hierarchy -- NavierStokes::errorEst (tracer / vorticity indicators,
+Source/NS_error.cpp:10-145), grid generation (tags + buffer, Berger-Rigoutsos clusters on the blocking-factor lattice, proper
+nesting of every new level), NavierStokesBase::init(AmrLevel&) / init() for the data of the new levels
+(Source/NavierStokesBase.cpp:1713-1806) and computeNewDt with post_regrid_flag = 1 (:971-982), driven by Amr::regrid semantics from level
+0 every regrid_int coarse steps.  The oracle is given the grids the product generated (its own tagging is pinned separately,
+tests/test_gpu_regrid.py) and must agree on the data after the regrid steps."""
+import numpy as np
+import pytest
+
+import orc
+from test_gpu_amr_step import _make, _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(X, Y, Z, c):
+    S = orc.taylorgreen_state(X, Y, Z, c=1.0)
+    S[..., 4] = np.exp(-((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) / 0.01)
+    return S
+
+
+def _covers(boxes, mask):
+    """every cell of `mask` (bool array over the level's domain) lies in one of the boxes"""
+    cov = np.zeros(mask.shape, bool)
+    for lo, hi in boxes:
+        cov[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] = True
+    return not (mask & ~cov).any()
+
+
+def test_tracer_blob_is_followed_by_the_refined_level():
+    """a tracer blob advected by the Taylor-Green flow plus a uniform drift: level 1 = where tracer > 0.3 (+ buffer), regridded every second
+    coarse step; the new grids cover the tagged cells, move with the blob, and the data agree with the oracle given the same grids"""
+    n0 = 16
+    fine0 = [([8, 8, 8], [23, 23, 23])]
+    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
+
+    def fn(X, Y, Z):
+        S = _blob(X, Y, Z, (0.5, 0.5, 0.5))
+        S[..., 0] += 1.0                                # drift in x: the blob leaves the initial box
+        return S
+    amr, oa = _make(n0, fine0, 16, kw, fn)
+    amr.set_regrid(max_level=1, regrid_int=2, rules=[dict(comp=4, mode=0, value=[0.3])], blocking_factor=4, max_grid_size=16, n_error_buf=1)
+    amr.post_init()
+    oa.post_init()
+    grids_seen = [list(amr.layouts[1].boxes)]
+    for step in range(6):
+        before = list(amr.layouts[1].boxes) if amr.nlev > 1 else []
+        dt = amr.coarse_step()
+        after = list(amr.layouts[1].boxes) if amr.nlev > 1 else []
+        if after != before:
+            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in after]])
+            grids_seen.append(after)
+        else:
+            dto = oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
+        _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
+    assert len(grids_seen) >= 2                         # the grids did change
+    lo1 = np.array([b[0] for b in amr.layouts[1].boxes]).min(axis=0)
+    assert lo1[0] > 8                                  # the refined region moved downstream with the blob
+    assert all(((np.array(hi) - np.array(lo) + 1) % 4 == 0).all() and (np.array(lo) % 4 == 0).all() for lo, hi in amr.layouts[1].boxes)   # blocking factor
+
+
+def test_three_levels_stay_properly_nested_and_match_the_oracle():
+    """vorticity + tracer indicators on two refined levels: after each regrid level 2 lies inside level 1 with the nesting buffer (the
+    constructor's check would throw otherwise), a level can appear where none was, and the data agree with the oracle"""
+    n0 = 16
+    l1 = [([8, 8, 8], [23, 23, 23])]
+    kw = dict(cfl=0.7, visc_coef=0.002, tracer_diff_coef=0.0, init_iter=2)
+
+    def fn(X, Y, Z):
+        S = _blob(X, Y, Z, (0.5, 0.5, 0.5))
+        S[..., 1] += 0.5
+        return S
+    amr, oa = _make(n0, l1, 16, kw, fn)
+    amr.set_regrid(max_level=2, regrid_int=1, rules=[dict(comp=4, mode=0, value=[0.2, 0.6])], blocking_factor=4, max_grid_size=16, n_error_buf=1)
+    amr.post_init()
+    oa.post_init()
+    had_three = False
+    for step in range(4):
+        before = [list(l.boxes) for l in amr.layouts[1:]]
+        dt = amr.coarse_step()
+        after = [list(l.boxes) for l in amr.layouts[1:]]
+        if after != before:
+            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after])
+        else:
+            dto = oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
+        _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
+        had_three = had_three or amr.nlev == 3
+    assert had_three

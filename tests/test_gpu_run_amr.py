@@ -40,3 +40,46 @@ def test_inputs_file_run_on_three_levels_and_its_plotfile(gpu, tmp_path, capsys)
         for (lo, hi), a in zip(pf.levels[l].boxes, pf.levels[l].data):
             ref = So[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1, :]
             assert np.abs(a - ref).max() <= 2e-8, (l, lo, np.abs(a - ref).max())
+
+
+def test_inputs_file_run_with_refinement_indicators(gpu, tmp_path, capsys):
+    """amr.max_level = 2 with amr.refinement_indicators and no grid file: the driver builds the initial hierarchy from the tags of the initial
+    data (Amr::bldFineLevels), regrids every amr.regrid_int coarse steps, and writes the hierarchy it ends with; the tracer blob stays
+    inside the refined region, its composite mass is conserved, and level 2 sits where the tracer exceeds the second threshold"""
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    inp_file = os.path.join(HERE, "golden", "inputs.3d.tracer_regrid16")
+    root = str(tmp_path / "plt")
+    assert R.main([inp_file, f"amr.plot_file={root}"]) == 0
+    out = capsys.readouterr().out
+    steps = [l for l in out.splitlines() if l.startswith("STEP =")]
+    assert len(steps) == 4 and all("LEVELS = 3" in l for l in steps)
+    p0, p4 = PlotFile.read(root + "00000"), PlotFile.read(root + "00004")
+    assert len(p0.levels) == 3 and len(p4.levels) == 3 and p0.levels[1].boxes != p4.levels[1].boxes      # the grids followed the blob
+
+    def composite(pf, comp):
+        tot = 0.0
+        for l, lv in enumerate(pf.levels):
+            n = [d + 1 for d in lv.domain[1]]
+            covered = np.zeros(n, bool)
+            if l + 1 < len(pf.levels):
+                for lo, hi in pf.levels[l + 1].boxes:
+                    covered[lo[0] // 2:hi[0] // 2 + 1, lo[1] // 2:hi[1] // 2 + 1, lo[2] // 2:hi[2] // 2 + 1] = True
+            for (lo, hi), a in zip(lv.boxes, lv.data):
+                m = ~covered[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]
+                tot += (a[..., comp] * m).sum() * np.prod(lv.dx)
+        return tot
+    # prob.probtype 4: the tracer is advected non-conservatively in this set-up (do_cons_trac = 0) by a divergence-free field: its integral
+    # changes only through the truncation error of the scheme and of the interpolation at regrids
+    assert abs(composite(p4, 4) - composite(p0, 4)) <= 2e-3 * composite(p0, 4)
+    assert abs(composite(p4, 3) - composite(p0, 3)) <= 1e-12
+    # every cell of level 0 / level 1 above its threshold lies under the next finer level (tags at the last regrid + buffer; two steps old at most)
+    for l, thr in ((0, 0.35), (1, 0.7)):
+        lv, fv = p4.levels[l], p4.levels[l + 1]
+        n = [d + 1 for d in lv.domain[1]]
+        under = np.zeros(n, bool)
+        for lo, hi in fv.boxes:
+            under[lo[0] // 2:hi[0] // 2 + 1, lo[1] // 2:hi[1] // 2 + 1, lo[2] // 2:hi[2] // 2 + 1] = True
+        for (lo, hi), a in zip(lv.boxes, lv.data):
+            hot = a[..., 4] >= thr
+            assert not (hot & ~under[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]).any(), (l, lo)
