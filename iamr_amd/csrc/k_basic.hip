@@ -169,7 +169,12 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng)
 // periodic image)
 struct OwnerInfo { int type[3]; int dlo[3]; int dhi[3]; int per[3]; int half_lo[3]; int half_hi[3]; };
 // weight of a point in sums / dot products: 0 for non-owner copies, 1/2 per Neumann wall a NODE lies on (the nodal
-// system is stored in doubled form at wall nodes: MLNodeLinOp dot mask), 1 otherwise
+// system is stored in doubled form at wall nodes: MLNodeLinOp dot mask), 1 otherwise.
+// Ownership rule: the hi+1 point of a box in a nodal direction belongs to the neighbouring box (or periodic image) as its low point,
+// unless it lies on a non-periodic domain face.  On a level that does not cover the domain the hi+1 points on coarse/fine faces have
+// no such neighbour and get weight 0: every caller on such levels (NodalMG with its Dirichlet mask, the composite solver's `own`
+// masks, amrns.hip) holds zero / excluded values exactly there, so the sums are unaffected; face-centred sums are only taken on
+// levels that cover the domain.
 __device__ __forceinline__ double owner_weight(const OwnerInfo& o, const BoxD& cellbox, int i, int j, int k)
 {
     const int idx[3] = {i, j, k};

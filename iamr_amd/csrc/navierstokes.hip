@@ -621,6 +621,69 @@ void NavierStokes::scalar_advection(double dt_)
     godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr);
 }
 
+// velocity_advection + scalar_advection in ONE pass of the Godunov chain over all five state components (NavierStokes.cpp:698-812 calls
+// ComputeAofs twice; both calls read the same old state and MAC velocity and write disjoint components of aofs, so one five-component
+// call gives the same numbers -- each component's arithmetic is untouched -- while the MAC velocity, the upwind logic and the tile
+// set-up are shared).  is_velocity only matters for component n == direction D < 3, which the scalars (n = 3, 4) never are.
+void NavierStokes::advection_all(double dt_)
+{
+    SectionTimer tm(*this, 2);
+    MultiFab& So = S[1 - inew];
+    const bool mom = p.do_mom_diff != 0, cons = p.do_cons_trac != 0;
+    MultiFab Q(layout, cell_type(), NUM_STATE, 3);
+    {
+        MultiFab Umf(layout, cell_type(), 3, 3), Smf(layout, cell_type(), NUM_SCALARS, 3);
+        fillpatch(Umf, So, Xvel, 3, bc_vel);
+        fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
+        const FabD *qt = Q.d_tab, *ut = Umf.d_tab, *st = Smf.d_tab;
+        for_each(*layout, cell_type(), 3, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double r = st[f](i, j, k, 0);              // momentum rho^n u^n with the unfloored density (NavierStokesBase.cpp:3397-3413)
+            for (int n = 0; n < 3; ++n) qt[f](i, j, k, n) = mom ? ut[f](i, j, k, n) * r : (double)ut[f](i, j, k, n);
+            for (int n = 0; n < NUM_SCALARS; ++n) { const double v = st[f](i, j, k, n); qt[f](i, j, k, Density + n) = fabs(v) <= 1.e-20 ? 0.0 : v; }   // floor_small
+        });
+    }
+    MultiFab visc(layout, cell_type(), 3, 1), svisc(layout, cell_type(), 1, 1);
+    if (p.be_cn_theta != 1.0) { get_visc_terms_vel(visc, So); get_visc_terms_tracer(svisc, So); } else { visc.setVal(0.0); svisc.setVal(0.0); }
+    MultiFab tf(layout, cell_type(), NUM_STATE, 1), divu(layout, cell_type(), 1, 1);
+    divu.setVal(0.0);
+    {
+        MultiFab R1(layout, cell_type(), 1, 1);
+        fillpatch(R1, So, Density, 1, bc_scal);              // the 1-ghost density of the forcing (velocity_advection's Smf)
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *wt = svisc.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = R1.d_tab, *qt = Q.d_tab;
+        const double grav = p.gravity;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double rho = rt[f](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) {
+                const double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
+                double t = fr + vt[f](i, j, k, n) - gt[f](i, j, k, n);
+                if (!mom) t /= rho;
+                tt[f](i, j, k, n) = t;
+            }
+            const double rhof = qt[f](i, j, k, Density);     // scalar_advection divides by the floored density of ITS state
+            double t0 = 0.0, t1 = 0.0;
+            t0 += 0.0;
+            if (cons) t1 += wt[f](i, j, k, 0); else t1 = t1 / rhof + wt[f](i, j, k, 0);
+            tt[f](i, j, k, Density) = t0;
+            tt[f](i, j, k, Tracer) = t1;
+        });
+    }
+    const int ic = mom ? 1 : 0;
+    const int iconserv[NUM_STATE] = {ic, ic, ic, 1, cons ? 1 : 0};
+    BCRec bc5[NUM_STATE];
+    for (int n = 0; n < 3; ++n) bc5[n] = bc_vel[n];
+    for (int n = 0; n < NUM_SCALARS; ++n) bc5[3 + n] = bc_scal[n];
+    MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
+    godunov_set_ppm(p.use_ppm != 0);
+    if (fine || level > 0) {
+        MultiFab fl[3];
+        MultiFab* flp[3];
+        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_STATE, 0); flp[d] = &fl[d]; }
+        godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, flp);
+        adv_registers(flp, Xvel, NUM_STATE, dt_);
+    } else
+    godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr);
+}
+
 void NavierStokes::scalar_update_rho(double dt_)
 {
     SectionTimer tm(*this, 3);
@@ -962,8 +1025,9 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
     advance_setup(dt_, iteration_, ncycle_);
     const double dt_test = predict_velocity(dt_);
     mac_project(dt_);
-    velocity_advection(dt_);
-    scalar_advection(dt_);
+    static const bool fused_adv = !(getenv("IAMRX_FUSED_ADVECTION") && atoi(getenv("IAMRX_FUSED_ADVECTION")) == 0);
+    if (fused_adv) advection_all(dt_);
+    else { velocity_advection(dt_); scalar_advection(dt_); }
     scalar_update_rho(dt_);
     scalar_update_tracers(dt_);
     scalar_diffusion_update(dt_);

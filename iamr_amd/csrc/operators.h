@@ -232,6 +232,7 @@ private:
     double m_stop_time = -1.0;
     void initial_sync_project(double dt);
     void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
+    void advection_all(double dt);
     void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc);
     bool is_diffusive_vel() const { return p.visc_coef > 0.0; }
 
