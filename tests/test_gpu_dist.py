@@ -43,6 +43,8 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         comm.init_gloo_callback(dist)
         import bench
         bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
+    if case == "amr":
+        return run_amr(rank, world, out_dir)
     owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
     lay = lib.Layout(BOXES, owners)
     if case.startswith("grid"):
@@ -78,6 +80,56 @@ def run(rank, world, port, out_dir, agg, case="tg"):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_amr(rank, world, out_dir):
+    """two-level hierarchy (viscous TaylorGreen): coarse level in 8 boxes, refined level in 4 boxes, both spread over the ranks"""
+    from iamr_amd import lib
+    from iamr_amd import ns as NS
+    from iamr_amd.amr import Amr
+    import torch.distributed as dist
+    n0 = 16
+    cb = [((i, j, k), (i + 7, j + 7, k + 7)) for k in (0, 8) for j in (0, 8) for i in (0, 8)]
+    fb = [((8 + 8 * i, 8 + 8 * j, 8), (15 + 8 * i, 15 + 8 * j, 23)) for j in (0, 1) for i in (0, 1)]
+    own = (lambda n: [q % world for q in range(n)]) if world > 1 else (lambda n: [0] * n)
+    lays = [lib.Layout(cb, own(len(cb))), lib.Layout(fb, own(len(fb)))]
+    amr = Amr(lib.Geom.make((n0,) * 3), lays, NS.ns_params(cfl=0.7, visc_coef=0.01, tracer_diff_coef=0.005, init_iter=2), lib.mg_opts())
+    for l in range(2):
+        amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    amr.post_init()
+    dts = [amr.coarse_step() for _ in range(2)]
+    out = {"dts": np.array(dts)}
+    for l in range(2):
+        S = amr.levels[l].data(0)
+        for li in range(S.nlocal()):
+            a, lo = S.to_numpy(li)
+            blo, bhi, gi = lays[l].local_box(li)
+            out[f"l{l}box{gi}"] = a[1:-1, 1:-1, 1:-1, :]
+    st, stm = amr.sync_stats()
+    out["iters"] = np.array([st.iters, stm.iters])
+    np.savez(os.path.join(out_dir, f"amr_w{world}_r{rank}.npz"), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_level_hierarchy_on_two_ranks(tmp_path):
+    """the multi-level time step (subcycling, registers, MAC sync incl. the viscous solves, composite sync projection, multi-level
+    initialisation) with the boxes of BOTH levels distributed over two ranks sharing the GPU: every box equals the one-rank result"""
+    import torch.multiprocessing as mp
+    port = 37100 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "amr"), nprocs=1, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "amr_w1_r0.npz"))
+    mp.spawn(run, args=(2, port + 5, str(tmp_path), None, "amr"), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"amr_w2_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        for key in z.files:
+            if "box" in key:
+                seen.add(key)
+                assert np.abs(z[key] - ref[key]).max() <= 1e-8, (key, np.abs(z[key] - ref[key]).max())
+    assert seen == {k for k in ref.files if "box" in k}
 
 
 @pytest.mark.parametrize("agg", [None, "0", "64"])
