@@ -88,3 +88,37 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
         _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
         had_three = had_three or amr.nlev == 3
     assert had_three
+
+
+def test_rayleigh_taylor_physics_with_regridding():
+    """the ingredients of config C5 (Exec/run3d/regtest.3d.rayleightaylor: Godunov_PPM, do_mom_diff, do_cons_trac, gravity, periodic x / y,
+    slip walls in z) on a hierarchy that refines the density interface (adjacent_difference_greater on density) on two levels and is
+    regridded every coarse step: product vs oracle on the product's grids"""
+    n0 = 16
+    l1 = [([0, 0, 8], [31, 31, 23])]
+    kw = dict(cfl=0.5, visc_coef=0.0, init_iter=1, use_ppm=1, do_mom_diff=1, do_cons_trac=1, gravity=-2.0, use_forces_in_trans=1,
+              phys_lo=[0, 0, 4], phys_hi=[0, 0, 4])
+
+    def fn(X, Y, Z):
+        S = np.zeros(X.shape + (5,), order="F")
+        eta = 0.5 + 0.04 * np.cos(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+        S[..., 3] = 1.0 + 0.5 * (1.0 + np.tanh((Z - eta) / 0.04))          # heavy fluid on top
+        S[..., 4] = S[..., 3] * 0.5 * (1.0 + np.tanh((Z - eta) / 0.04))    # conservative tracer S = rho q
+        return S
+    amr, oa = _make(n0, l1, 16, kw, fn, periodic=(1, 1, 0))
+    amr.set_regrid(max_level=2, regrid_int=1, rules=[dict(comp=3, mode=3, value=[0.08, 0.12])], blocking_factor=4, max_grid_size=16, n_error_buf=1)
+    amr.post_init()
+    oa.post_init()
+    changes = 0
+    for step in range(3):
+        before = [list(l.boxes) for l in amr.layouts[1:]]
+        dt = amr.coarse_step()
+        after = [list(l.boxes) for l in amr.layouts[1:]]
+        if after != before:
+            changes += 1
+            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after])
+        else:
+            dto = oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
+        _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
+    assert changes >= 1 and amr.nlev >= 2
