@@ -51,12 +51,9 @@ __device__ __forceinline__ double lim2(double dlft, double drgt)
     return dsgn * fmin(dlim, fabs(dcen));
 }
 
-// amrex_calc_{x,y,z}slope_extdir, order 4.  q points at the cell, s = stride in the slope direction,
-// i = cell index in that direction.
-template <class P>
-__device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi)
+// amrex_calc_{x,y,z}slope_extdir, order 4, on the five values q(i-2..i+2); i = cell index in the slope direction.
+__device__ __forceinline__ double slope4v(double qmm, double qm, double qi, double qp, double qpp, bool edlo, bool edhi, int i, int domlo, int domhi)
 {
-    const double qi = q[0], qm = q[-s], qp = q[s], qmm = q[-2 * s], qpp = q[2 * s];
     double dfm = lim2(qm - qmm, qi - qm);
     double dfp = lim2(qp - qi, qpp - qp);
     double dlft = qi - qm, drgt = qp - qi;
@@ -91,6 +88,12 @@ __device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int 
         dtemp = 4.0 / 3.0 * dcen - 1.0 / 6.0 * (dfp + dfm);
     }
     return dsgn * fmin(dlim, fabs(dtemp));
+}
+// q points at the cell, s = stride in the slope direction
+template <class P>
+__device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi)
+{
+    return slope4v(q[-2 * s], q[-s], q[0], q[s], q[2 * s], edlo, edhi, i, domlo, domhi);
 }
 
 __device__ __forceinline__ bool ed_or_ho(int b) { return b == bc_ext_dir || b == bc_hoextrap; }
@@ -179,6 +182,100 @@ __device__ __forceinline__ void edge_bc(P qc, long s, int f, bool normal_vel, do
             hi = lo;
         } else if (bchi == bc_reflect_odd) { lo = 0.; hi = 0.; }
     }
+}
+
+// value forms of trans_bc / edge_bc for a face f with domlo <= f <= domhi + 1: the ext_dir data of the low boundary sits in the
+// low-side cell of the face (qlc), that of the high boundary in the high-side cell (qhc)
+__device__ __forceinline__ void trans_bc_v(double qlc, double qhc, int f, bool normal_vel, double& lo, double& hi,
+                                           int bclo, int bchi, int domlo, int domhi)
+{
+    if (f <= domlo) {
+        if (bclo == bc_ext_dir) { lo = qlc; if (normal_vel) hi = lo; }
+        else if (bclo == bc_foextrap || bclo == bc_hoextrap || bclo == bc_reflect_even) lo = hi;
+        else if (bclo == bc_reflect_odd) { hi = 0.; lo = 0.; }
+    } else if (f > domhi) {
+        if (bchi == bc_ext_dir) { hi = qhc; if (normal_vel) lo = hi; }
+        else if (bchi == bc_foextrap || bchi == bc_hoextrap || bchi == bc_reflect_even) hi = lo;
+        else if (bchi == bc_reflect_odd) { lo = 0.; hi = 0.; }
+    }
+}
+__device__ __forceinline__ void edge_bc_v(double qlc, double qhc, int f, bool normal_vel, double& lo, double& hi,
+                                          int bclo, int bchi, int domlo, int domhi)
+{
+    if (f <= domlo) {
+        if (bclo == bc_ext_dir) { lo = qlc; if (normal_vel) hi = lo; }
+        else if (bclo == bc_foextrap || bclo == bc_hoextrap || bclo == bc_reflect_even) {
+            if (normal_vel && bclo != bc_reflect_even) hi = fmin(hi, 0.);
+            lo = hi;
+        } else if (bclo == bc_reflect_odd) { hi = 0.; lo = 0.; }
+    } else if (f > domhi) {
+        if (bchi == bc_ext_dir) { hi = qhc; if (normal_vel) lo = hi; }
+        else if (bchi == bc_foextrap || bchi == bc_hoextrap || bchi == bc_reflect_even) {
+            if (normal_vel && bchi != bc_reflect_even) lo = fmax(lo, 0.);
+            hi = lo;
+        } else if (bchi == bc_reflect_odd) { lo = 0.; hi = 0.; }
+    }
+}
+
+// single-valued state of a face from its two traced states and the advecting velocity
+__device__ __forceinline__ double upwind_fu(double um, double l, double h)
+{
+    const double st = (um >= 0.) ? l : h;
+    const double fu = (fabs(um) < SMALL_VEL) ? 0.0 : 1.0;
+    return fu * st + (1.0 - fu) * 0.5 * (h + l);
+}
+
+// second half of corner_state on values: transverse correction of the traced states l, h of a T-face by the O-direction, BCs, upwinding.
+// mo_* / eo_*: mac velocity / pass-1 state on the low (cm, f) and high (cmo, fo) O-face of the low-side / high-side cell of the T-face.
+__device__ __forceinline__ double corner_core(double l, double h, double qlc, double qhc, double macT_f,
+    double mo_cm, double mo_cmo, double mo_f, double mo_fo, double eo_cm, double eo_cmo, double eo_f, double eo_fo,
+    double dvl, double dvh, bool conserv, double c_o, double dt3, double dxO,
+    bool nonperT, bool normal_vel, int fT, int bl, int bh, int domlo, int domhi)
+{
+    if (conserv) {
+        l = l - c_o * (eo_cmo * mo_cmo - eo_cm * mo_cm) + dt3 * qlc * ((mo_cmo - mo_cm) / dxO - 0.5 * dvl);
+        h = h - c_o * (eo_fo * mo_fo - eo_f * mo_f) + dt3 * qhc * ((mo_fo - mo_f) / dxO - 0.5 * dvh);
+    } else {
+        l = l - c_o * (mo_cmo + mo_cm) * (eo_cmo - eo_cm);
+        h = h - c_o * (mo_fo + mo_f) * (eo_fo - eo_f);
+    }
+    if (nonperT) trans_bc_v(qlc, qhc, fT, normal_vel, l, h, bl, bh, domlo, domhi);
+    return upwind_fu(macT_f, l, h);
+}
+
+// second half of final_edge on values (advection form): transverse terms from the corner-coupled states A?? / B?? (l / h: low-side / high-side
+// cell of the D-face, 0 / 1: its low / high TA- or TB-face), forcing, BCs, upwinding with the mac velocity umD
+__device__ __forceinline__ double final_core(double stl, double sth, double umD,
+    double mA_l0, double mA_l1, double mA_h0, double mA_h1, double mB_l0, double mB_l1, double mB_h0, double mB_h1,
+    double Al0, double Al1, double Ah0, double Ah1, double Bl0, double Bl1, double Bh0, double Bh1,
+    double qlc, double qhc, double frl, double frh, double dvl, double dvh,
+    bool conserv, bool has_divu, bool late_force, double dt, double dxA, double dxB,
+    bool nonperD, bool normal_vel, int f, int blD, int bhD, int dloD, int dhiD)
+{
+    const double hdt = 0.5 * dt;
+    if (conserv) {
+        const double cfA = 0.5 * dt / dxA, cfB = 0.5 * dt / dxB;
+        stl += -cfA * (Al1 * mA_l1 - Al0 * mA_l0);
+        sth += -cfA * (Ah1 * mA_h1 - Ah0 * mA_h0);
+        stl += -cfB * (Bl1 * mB_l1 - Bl0 * mB_l0);
+        sth += -cfB * (Bh1 * mB_h1 - Bh0 * mB_h0);
+        stl += cfA * qlc * (mA_l1 - mA_l0);
+        sth += cfA * qhc * (mA_h1 - mA_h0);
+        stl += cfB * qlc * (mB_l1 - mB_l0);
+        sth += cfB * qhc * (mB_h1 - mB_h0);
+        if (has_divu) { stl -= 0.5 * dt * qlc * dvl; sth -= 0.5 * dt * qhc * dvh; }
+    } else {
+        const double cfA = 0.25 * dt / dxA, cfB = 0.25 * dt / dxB;
+        stl -= cfA * (mA_l1 + mA_l0) * (Al1 - Al0);
+        sth -= cfA * (mA_h1 + mA_h0) * (Ah1 - Ah0);
+        stl -= cfB * (mB_l1 + mB_l0) * (Bl1 - Bl0);
+        sth -= cfB * (mB_h1 + mB_h0) * (Bh1 - Bh0);
+    }
+    if (late_force) { stl += hdt * frl; sth += hdt * frh; }
+    if (nonperD) edge_bc_v(qlc, qhc, f, normal_vel, stl, sth, blD, bhD, dloD, dhiD);
+    double temp = (umD >= 0.) ? stl : sth;
+    temp = (fabs(umD) < SMALL_VEL) ? 0.5 * (stl + sth) : temp;
+    return temp;
 }
 
 // traced states from the limited slopes slh (cell f) and sll (cell f-1)
@@ -1284,6 +1381,290 @@ __global__ void __launch_bounds__(NTH) k_godunov_tile(const BoxD* __restrict__ b
     }
 }
 
+// -------------------------------------------------------------------------------- fused z-marching advection (default, PLM)
+// k_god_z: one launch = ComputeFluxesOnBoxFromState + ComputeDivergence / ComputeConvectiveTerm for one component per blockIdx.z.
+// A workgroup owns a TX x TY column of cells and marches through the planes of its z-chunk; thread (ci,cj) of the tile grown by one
+// cell keeps its column for the whole march: the z-stencil (q(P-2..P+2), the z-slopes, the traced z-states) lives in registers, the
+// in-plane stencils read one state plane (3 ghost cells) from LDS, and every intermediate of the corner-transport scheme -- the
+// pass-1 states E_d, the six corner-coupled states C_{T|O} and the final edge states -- passes through two-slot LDS ring planes and
+// never reaches HBM.  Iteration P (k0-1 .. k1+1):
+//   stage 0  prefetched registers -> LDS: state plane P, mac_x / mac_y / force / divu of plane P, mac_z of face P
+//   stage A  E_x(P), E_y(P), E_z(face P)            (limited slopes of the own and of the low-side neighbour cell, trace, BCs, upwind)
+//   stage B  C_{x|y}(P), C_{y|x}(P), C_{z|x}(P), C_{z|y}(P)  and  C_{x|z}(P-1), C_{y|z}(P-1)   (these need E_z of the faces P-1, P)
+//   stage C  final states of the x- and y-faces of plane P-1 and of the z-face P
+//   stage D  fluxes and aofs of plane P-1 (the x / y states of the high faces come from the neighbour threads through LDS)
+// Four barriers per plane; all array offsets of a thread are loop invariants.  HBM sees the state (1.6x for the in-plane halo + the
+// own column), mac, forcing, divu and aofs.  Arithmetic: slope4v / trans_bc_v / corner_core / final_core = the expressions of the
+// multi-pass kernels above, which remain as the PPM path and as the reference of tests/test_gpu_godunov_fused.py.
+struct GodTabs3 { const FabD* t[3]; };
+
+template <int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) k_god_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
+    const FabD* __restrict__ divut, const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
+    const FabD* __restrict__ aofst, int acomp, GodTabs3 edge_t, GodTabs3 flux_t, const GodParams* __restrict__ Pp,
+    int ntx, int nty, int nkc, int kc, int xcd_cnt)
+{
+    constexpr int PW = TX + 2, PH = TY + 2, PS = PW * PH, QW = TX + 6, QH = TY + 6, QS = QW * QH;
+    constexpr int NQ = (QS + NT - 1) / NT;
+    static_assert(NT >= PS, "one thread per column of the grown tile");
+    __shared__ double Qb[QS + QW];      // one spare row in front: the (unused) slope of the cell below the grown tile reads it
+    __shared__ double MX[2][PS], MY[2][PS], MZ[2][PS], FR[2][PS], DV[2][PS];
+    __shared__ double EX[2][PS], EY[2][PS], EZ[2][PS];
+    __shared__ double CZX[2][PS], CZY[2][PS], CXY[2][PS], CYX[2][PS], CXZ[PS], CYZ[PS];
+    double* const Q = Qb + QW;
+    const GodParams& P = *Pp;
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    int bid = blockIdx.x;
+    if (xcd_cnt > 0) {
+        bid = (bid & 7) * xcd_cnt + (bid >> 3);          // XCD-aware order, see make_tiling
+        if (bid >= ntx * nty * nkc) return;
+    }
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, kci = r1 / nty;
+    const int tx0 = b.lo[0] + tix * TX, ty0 = b.lo[1] + tiy * TY, k0 = b.lo[2] + kci * kc;
+    if (tx0 > b.hi[0] || ty0 > b.hi[1] || k0 > b.hi[2]) return;
+    const int txe = min(tx0 + TX - 1, b.hi[0]), tye = min(ty0 + TY - 1, b.hi[1]), k1 = min(k0 + kc - 1, b.hi[2]);
+    const int n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int li = tid % PW, lj = tid / PW;
+    const bool act = tid < PS && tx0 - 1 + li <= txe + 1 && ty0 - 1 + lj <= tye + 1;
+    const int ci = act ? tx0 - 1 + li : tx0, cj = act ? ty0 - 1 + lj : ty0;
+    // LDS offsets of the own column and of its neighbours (clamped inside the grown tile: values read through a clamped offset
+    // only reach results that are not used)
+    const int o = (ci - (tx0 - 1)) + PW * (cj - (ty0 - 1));
+    const int oxm = ci > tx0 - 1 ? o - 1 : o, oxp = ci < txe + 1 ? o + 1 : o;
+    const int oym = cj > ty0 - 1 ? o - PW : o, oyp = cj < tye + 1 ? o + PW : o;
+    const int oxm_yp = oxm + (oyp - o), oxp_ym = oxp + (oym - o);
+    const int qo = (ci - (tx0 - 3)) + QW * (cj - (ty0 - 3));
+    const bool in_tile = act && ci >= tx0 && ci <= txe && cj >= ty0 && cj <= tye;
+
+    const bool has_force = P.has_force != 0, has_divu = P.has_divu != 0, fit = P.fit != 0, is_vel = P.is_velocity != 0;
+    const bool early_force = fit && has_force, late_force = !fit && has_force;
+    const bool conserv = P.iconserv[n] != 0;
+    const double dt = P.dt, hdt = 0.5 * dt, dt3 = dt / 3.0;
+    const double dx0 = P.dx[0], dx1 = P.dx[1], dx2 = P.dx[2];
+    const double dtdx0 = dt / dx0, dtdx1 = dt / dx1, dtdx2 = dt / dx2;
+    const double co0 = conserv ? dt / (3.0 * dx0) : dt / (6.0 * dx0), co1 = conserv ? dt / (3.0 * dx1) : dt / (6.0 * dx1),
+                 co2 = conserv ? dt / (3.0 * dx2) : dt / (6.0 * dx2);
+    const bool np0 = !P.bc.per[0], np1 = !P.bc.per[1], np2 = !P.bc.per[2];
+    const int bl0 = P.bc.bc[n].lo[0], bh0 = P.bc.bc[n].hi[0], bl1 = P.bc.bc[n].lo[1], bh1 = P.bc.bc[n].hi[1],
+              bl2 = P.bc.bc[n].lo[2], bh2 = P.bc.bc[n].hi[2];
+    const int dl0 = P.bc.dlo[0], dh0 = P.bc.dhi[0], dl1 = P.bc.dlo[1], dh1 = P.bc.dhi[1], dl2 = P.bc.dlo[2], dh2 = P.bc.dhi[2];
+    const bool edl0 = np0 && ed_or_ho(bl0), edh0 = np0 && ed_or_ho(bh0), edl1 = np1 && ed_or_ho(bl1), edh1 = np1 && ed_or_ho(bh1),
+               edl2 = np2 && ed_or_ho(bl2), edh2 = np2 && ed_or_ho(bh2);
+    const bool nv0 = is_vel && n == 0, nv1 = is_vel && n == 1, nv2 = is_vel && n == 2;
+
+    // global pointers of the own column at plane / face k0-1 (state: plane k0+1 = the next one the z-ring takes in)
+    const FabD q = qt[fab], ux = uxt[fab], uy = uyt[fab], uz = uzt[fab], aofs = aofst[fab];
+    FabD frc = q, dv = q;
+    if (has_force) frc = ft[fab];
+    if (has_divu) dv = divut[fab];
+    const long qsz = (long)q.n[0] * q.n[1], uxsz = (long)ux.n[0] * ux.n[1], uysz = (long)uy.n[0] * uy.n[1], uzsz = (long)uz.n[0] * uz.n[1];
+    const long fsz = (long)frc.n[0] * frc.n[1], dsz = (long)dv.n[0] * dv.n[1];
+    auto qcol = q.gp() + q.off(ci, cj, k0 - 3) + q.cs * n;
+    auto uxp = ux.gp() + ux.off(ci, cj, k0 - 1), uyp = uy.gp() + uy.off(ci, cj, k0 - 1), uzp = uz.gp() + uz.off(ci, cj, k0 - 1);
+    auto frp = frc.gp() + frc.off(ci, cj, k0 - 1) + (has_force ? frc.cs * n : 0);
+    auto dvp = dv.gp() + dv.off(ci, cj, k0 - 1);
+    // state plane with 3 ghost cells: entries tid + r NT
+    long qpo[NQ]; bool qpv[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+        const int e = tid + r * NT, qi = tx0 - 3 + e % QW, qj = ty0 - 3 + e / QW;
+        qpv[r] = e < QS && qi <= txe + 3 && qj <= tye + 3;
+        qpo[r] = qpv[r] ? q.off(qi, qj, k0 - 1) + q.cs * n : 0;
+    }
+    // z-ring of the own column: r0..r4 = q(P-2..P+2) in iteration P
+    double r0 = 0., r1v = 0., r2 = 0., r3 = 0., r4 = 0.;
+    if (act) { r1v = qcol[0]; r2 = qcol[qsz]; r3 = qcol[2 * qsz]; r4 = qcol[3 * qsz]; }
+    qcol += 4 * qsz;
+    // prefetch registers for the first iteration
+    double pq = 0., pmx = 0., pmy = 0., pmz = 0., pfr = 0., pdv = 0., pQ[NQ];
+    if (act) {
+        pq = qcol[0]; pmx = uxp[0]; pmy = uyp[0]; pmz = uzp[0];
+        if (has_force) pfr = frp[0];
+        if (has_divu) pdv = dvp[0];
+    }
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) pQ[r] = qpv[r] ? q.gp()[qpo[r]] : 0.;
+    // values of plane P-1 kept from the previous iteration
+    double xl1 = 0., xh1 = 0., yl1 = 0., yh1 = 0., qxm1 = 0., qym1 = 0., mx1 = 0., my1 = 0., mz1 = 0., fr1 = 0., dv1 = 0., slz1 = 0., Zprev = 0.;
+    const double ax = dx1 * dx2, ay = dx2 * dx0, az = dx0 * dx1, qvol = 1.0 / (dx0 * dx1 * dx2);
+    const bool store_edge = edge_t.t[0] != nullptr, store_flux = flux_t.t[0] != nullptr;
+
+    int it = 0;
+    for (int Pk = k0 - 1; Pk <= k1 + 1; ++Pk, ++it) {
+        const int s = it & 1, sp = s ^ 1;
+        // ---------------- stage 0
+        r0 = r1v; r1v = r2; r2 = r3; r3 = r4; r4 = pq;
+        const double mx0 = pmx, my0 = pmy, mz0 = pmz, fr0 = pfr, dv0 = pdv;
+        if (act) { MX[s][o] = mx0; MY[s][o] = my0; MZ[s][o] = mz0; FR[s][o] = fr0; DV[s][o] = dv0; }
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) { const int e = tid + r * NT; if (e < QS) Q[e] = pQ[r]; }
+        if (Pk <= k1) {
+            qcol += qsz; uxp += uxsz; uyp += uysz; uzp += uzsz; frp += fsz; dvp += dsz;
+            if (act) {
+                pq = qcol[0]; pmx = uxp[0]; pmy = uyp[0]; pmz = uzp[0];
+                if (has_force) pfr = frp[0];
+                if (has_divu) pdv = dvp[0];
+            }
+#pragma unroll
+            for (int r = 0; r < NQ; ++r) { qpo[r] += qsz; pQ[r] = qpv[r] ? q.gp()[qpo[r]] : 0.; }
+        }
+        __syncthreads();
+        // ---------------- stage A: pass 1
+        double xl0, xh0, yl0, yh0, zl, zh, qxm0, qym0;
+        {
+            const double* qc = Q + qo;
+            const double a3 = qc[-3], a2 = qc[-2], a1 = qc[-1], c0 = qc[0], b1 = qc[1], b2 = qc[2];
+            qxm0 = a1;
+            const double sll = slope4v(a3, a2, a1, c0, b1, edl0, edh0, ci - 1, dl0, dh0);
+            const double slh = slope4v(a2, a1, c0, b1, b2, edl0, edh0, ci, dl0, dh0);
+            xh0 = c0 + 0.5 * (-1.0 - mx0 * dtdx0) * slh;
+            xl0 = a1 + 0.5 * (1.0 - mx0 * dtdx0) * sll;
+            if (early_force) { xl0 += hdt * FR[s][oxm]; xh0 += hdt * fr0; }
+            if (np0) trans_bc_v(a1, c0, ci, nv0, xl0, xh0, bl0, bh0, dl0, dh0);
+            if (act) EX[s][o] = upwind_fu(mx0, xl0, xh0);
+        }
+        {
+            const double* qc = Q + qo;
+            const double a3 = qc[-3 * QW], a2 = qc[-2 * QW], a1 = qc[-QW], c0 = qc[0], b1 = qc[QW], b2 = qc[2 * QW];
+            qym0 = a1;
+            const double sll = slope4v(a3, a2, a1, c0, b1, edl1, edh1, cj - 1, dl1, dh1);
+            const double slh = slope4v(a2, a1, c0, b1, b2, edl1, edh1, cj, dl1, dh1);
+            yh0 = c0 + 0.5 * (-1.0 - my0 * dtdx1) * slh;
+            yl0 = a1 + 0.5 * (1.0 - my0 * dtdx1) * sll;
+            if (early_force) { yl0 += hdt * FR[s][oym]; yh0 += hdt * fr0; }
+            if (np1) trans_bc_v(a1, c0, cj, nv1, yl0, yh0, bl1, bh1, dl1, dh1);
+            if (act) EY[s][o] = upwind_fu(my0, yl0, yh0);
+        }
+        double slz0;
+        {
+            slz0 = slope4v(r0, r1v, r2, r3, r4, edl2, edh2, Pk, dl2, dh2);
+            zh = r2 + 0.5 * (-1.0 - mz0 * dtdx2) * slz0;
+            zl = r1v + 0.5 * (1.0 - mz0 * dtdx2) * slz1;
+            if (early_force) { zl += hdt * fr1; zh += hdt * fr0; }
+            if (np2) trans_bc_v(r1v, r2, Pk, nv2, zl, zh, bl2, bh2, dl2, dh2);
+            if (act) EZ[s][o] = upwind_fu(mz0, zl, zh);
+        }
+        __syncthreads();
+        // ---------------- stage B: corner coupling
+        {
+            const double myA = MY[s][oxm], myB = MY[s][oxm_yp], myD = MY[s][oyp];
+            const double mxA = MX[s][oym], mxB = MX[s][oxp_ym], mxD = MX[s][oxp];
+            const double mxp1 = MX[sp][oxp], myp1 = MY[sp][oyp];
+            const double mzxm1 = MZ[sp][oxm], mzxm0 = MZ[s][oxm], mzym1 = MZ[sp][oym], mzym0 = MZ[s][oym];
+            const double dvxm0 = has_divu ? DV[s][oxm] : 0., dvym0 = has_divu ? DV[s][oym] : 0.;
+            const double dvxm1 = has_divu ? DV[sp][oxm] : 0., dvym1 = has_divu ? DV[sp][oym] : 0.;
+            // x-face corrected by y, plane P
+            const double cxy = corner_core(xl0, xh0, qxm0, r2, mx0, myA, myB, my0, myD, EY[s][oxm], EY[s][oxm_yp], EY[s][o], EY[s][oyp],
+                                           dvxm0, dv0, conserv, co1, dt3, dx1, np0, nv0, ci, bl0, bh0, dl0, dh0);
+            // y-face corrected by x, plane P
+            const double cyx = corner_core(yl0, yh0, qym0, r2, my0, mxA, mxB, mx0, mxD, EX[s][oym], EX[s][oxp_ym], EX[s][o], EX[s][oxp],
+                                           dvym0, dv0, conserv, co0, dt3, dx0, np1, nv1, cj, bl1, bh1, dl1, dh1);
+            // z-face P corrected by x / by y: low-side cell = plane P-1
+            const double czx = corner_core(zl, zh, r1v, r2, mz0, mx1, mxp1, mx0, mxD, EX[sp][o], EX[sp][oxp], EX[s][o], EX[s][oxp],
+                                           dv1, dv0, conserv, co0, dt3, dx0, np2, nv2, Pk, bl2, bh2, dl2, dh2);
+            const double czy = corner_core(zl, zh, r1v, r2, mz0, my1, myp1, my0, myD, EY[sp][o], EY[sp][oyp], EY[s][o], EY[s][oyp],
+                                           dv1, dv0, conserv, co1, dt3, dx1, np2, nv2, Pk, bl2, bh2, dl2, dh2);
+            // x- / y-face of plane P-1 corrected by z
+            const double cxz = corner_core(xl1, xh1, qxm1, r1v, mx1, mzxm1, mzxm0, mz1, mz0, EZ[sp][oxm], EZ[s][oxm], EZ[sp][o], EZ[s][o],
+                                           dvxm1, dv1, conserv, co2, dt3, dx2, np0, nv0, ci, bl0, bh0, dl0, dh0);
+            const double cyz = corner_core(yl1, yh1, qym1, r1v, my1, mzym1, mzym0, mz1, mz0, EZ[sp][oym], EZ[s][oym], EZ[sp][o], EZ[s][o],
+                                           dvym1, dv1, conserv, co2, dt3, dx2, np1, nv1, cj, bl1, bh1, dl1, dh1);
+            if (act) { CXY[s][o] = cxy; CYX[s][o] = cyx; CZX[s][o] = czx; CZY[s][o] = czy; CXZ[o] = cxz; CYZ[o] = cyz; }
+        }
+        __syncthreads();
+        // ---------------- stage C: final edge states: x, y of plane P-1; z of face P
+        double Xe, Ye, Ze, uxh, uyh;
+        {
+            const double mxp1 = MX[sp][oxp], myp1 = MY[sp][oyp], mxp0 = MX[s][oxp], myp0 = MY[s][oyp];
+            uxh = mxp1; uyh = myp1;
+            const double mzxm1 = MZ[sp][oxm], mzxm0 = MZ[s][oxm], mzym1 = MZ[sp][oym], mzym0 = MZ[s][oym];
+            Xe = final_core(xl1, xh1, mx1, MY[sp][oxm], MY[sp][oxm_yp], my1, myp1, mzxm1, mzxm0, mz1, mz0,
+                            CYZ[oxm], CYZ[oxm_yp], CYZ[o], CYZ[oyp], CZY[sp][oxm], CZY[s][oxm], CZY[sp][o], CZY[s][o],
+                            qxm1, r1v, late_force ? FR[sp][oxm] : 0., fr1, has_divu ? DV[sp][oxm] : 0., dv1,
+                            conserv, has_divu, late_force, dt, dx1, dx2, np0, nv0, ci, bl0, bh0, dl0, dh0);
+            Ye = final_core(yl1, yh1, my1, MX[sp][oym], MX[sp][oxp_ym], mx1, mxp1, mzym1, mzym0, mz1, mz0,
+                            CXZ[oym], CXZ[oxp_ym], CXZ[o], CXZ[oxp], CZX[sp][oym], CZX[s][oym], CZX[sp][o], CZX[s][o],
+                            qym1, r1v, late_force ? FR[sp][oym] : 0., fr1, has_divu ? DV[sp][oym] : 0., dv1,
+                            conserv, has_divu, late_force, dt, dx0, dx2, np1, nv1, cj, bl1, bh1, dl1, dh1);
+            Ze = final_core(zl, zh, mz0, mx1, mxp1, mx0, mxp0, my1, myp1, my0, myp0,
+                            CXY[sp][o], CXY[sp][oxp], CXY[s][o], CXY[s][oxp], CYX[sp][o], CYX[sp][oyp], CYX[s][o], CYX[s][oyp],
+                            r1v, r2, fr1, fr0, dv1, dv0,
+                            conserv, has_divu, late_force, dt, dx0, dx1, np2, nv2, Pk, bl2, bh2, dl2, dh2);
+            // x / y states for the neighbour threads: the E_z / E_x slots of face / plane P-1 are free from here on
+            if (act) { EZ[sp][o] = Xe; EX[sp][o] = Ye; }
+        }
+        __syncthreads();
+        // ---------------- stage D: plane P-1
+        {
+            const int k = Pk - 1;
+            const double exh = EZ[sp][oxp], eyh = EX[sp][oyp];
+            if (act && k >= k0 && k <= k1) {
+                const double fxl = Xe * mx1 * ax, fyl = Ye * my1 * ay, fzl = Zprev * mz1 * az;
+                if (in_tile) {
+                    const double fxh = exh * uxh * ax, fyh = eyh * uyh * ay, fzh = Ze * mz0 * az;
+                    const double divum = 1.0 * ((uxh - mx1) / dx0 + (uyh - my1) / dx1 + (mz0 - mz1) / dx2);
+                    double upd = -1.0 * qvol * ((fxh - fxl) + (fyh - fyl) + (fzh - fzl));
+                    if (!conserv) {
+                        double qavg = Xe + exh + Ye + eyh + Zprev + Ze;
+                        qavg *= 1.0 / 6.0;
+                        upd += qavg * divum;
+                    }
+                    aofs(ci, cj, k, acomp + n) = -upd;
+                }
+                // faces: every face is written by the tile on its high side, the faces on the high end of the box by the last tile
+                const bool wx = cj >= ty0 && cj <= tye && ci >= tx0 && (ci <= txe || ci == b.hi[0] + 1);
+                const bool wy = ci >= tx0 && ci <= txe && cj >= ty0 && (cj <= tye || cj == b.hi[1] + 1);
+                if (store_edge) {
+                    if (wx) edge_t.t[0][fab](ci, cj, k, n) = Xe;
+                    if (wy) edge_t.t[1][fab](ci, cj, k, n) = Ye;
+                    if (in_tile) edge_t.t[2][fab](ci, cj, k, n) = Zprev;
+                }
+                if (store_flux) {
+                    if (wx) flux_t.t[0][fab](ci, cj, k, n) = fxl;
+                    if (wy) flux_t.t[1][fab](ci, cj, k, n) = fyl;
+                    if (in_tile) flux_t.t[2][fab](ci, cj, k, n) = fzl;
+                }
+            }
+            if (in_tile && k == b.hi[2]) {
+                // the z-face on the high end of the box
+                if (store_edge) edge_t.t[2][fab](ci, cj, k + 1, n) = Ze;
+                if (store_flux) flux_t.t[2][fab](ci, cj, k + 1, n) = Ze * mz0 * az;
+            }
+        }
+        xl1 = xl0; xh1 = xh0; yl1 = yl0; yh1 = yh0; qxm1 = qxm0; qym1 = qym0;
+        mx1 = mx0; my1 = my0; mz1 = mz0; fr1 = fr0; dv1 = dv0; slz1 = slz0; Zprev = Ze;
+    }
+}
+
+static bool use_z_kernel()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_Z"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+template <int TX, int TY>
+static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force, const MultiFab* divu,
+                         MultiFab* const umac[3], MultiFab* const edge_out[3], MultiFab* const flux_out[3], const GodParams* dP)
+{
+    constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
+    const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+    static const int kc_env = [] { const char* e = getenv("IAMRX_GODUNOV_ZKC"); return e ? atoi(e) : 0; }();
+    const int kc = kc_env > 0 ? kc_env : std::min(64, std::max(8, l.max_len[2] / 4));       // planes marched per workgroup
+    const int nkc = (l.max_len[2] + kc - 1) / kc;
+    const int total = ntx * nty * nkc;
+    const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
+    dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), (unsigned)ncomp);
+    GodTabs3 et{{nullptr, nullptr, nullptr}}, ftb{{nullptr, nullptr, nullptr}};
+    if (edge_out && edge_out[0]) for (int d = 0; d < 3; ++d) et.t[d] = edge_out[d]->d_tab;
+    if (flux_out && flux_out[0]) for (int d = 0; d < 3; ++d) ftb.t[d] = flux_out[d]->d_tab;
+    hipLaunchKernelGGL((k_god_z<TX, TY, NT>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
+                       divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp, et, ftb, dP,
+                       ntx, nty, nkc, kc, xcd_cnt);
+}
+
 static bool use_tile_kernel()
 {
     static int v = -1;
@@ -1303,13 +1684,20 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     MultiFab e0[3], edge[3], sl[3];
     MultiFab* ed[3];
     const bool ws = use_dir_fused();
-    for (int d = 0; d < 3 && !use_tile_kernel(); ++d) {
+    const bool zk = use_z_kernel() && !godunov_get_ppm();
+    for (int d = 0; d < 3 && !use_tile_kernel() && !zk; ++d) {
         e0[d].define(S.layout, face_type(d), ncomp, 1);
         if (ws) sl[d].define(S.layout, cell_type(), ncomp, 1);
         if (edge_out && edge_out[d]) ed[d] = edge_out[d];
         else { edge[d].define(S.layout, face_type(d), ncomp, 0); ed[d] = &edge[d]; }
     }
     const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
+    if (zk) {
+        static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 32; }();
+        if (ztx == 16) launch_god_z<16, 8>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP);
+        else launch_god_z<32, 8>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP);
+        return;
+    }
     if (use_tile_kernel()) {
         constexpr int TX = 16, TY = 8, TZ = 4, NTH = 1024;
         const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY, ntz = (l.max_len[2] + TZ - 1) / TZ;
