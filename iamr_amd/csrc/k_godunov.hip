@@ -244,7 +244,8 @@ __device__ __forceinline__ double corner_core(double l, double h, double qlc, do
 }
 
 // second half of final_edge on values (advection form): transverse terms from the corner-coupled states A?? / B?? (l / h: low-side / high-side
-// cell of the D-face, 0 / 1: its low / high TA- or TB-face), forcing, BCs, upwinding with the mac velocity umD
+// cell of the D-face, 0 / 1: its low / high TA- or TB-face), forcing, BCs, upwinding with the mac velocity umD (PRED: with itself)
+template <bool PRED>
 __device__ __forceinline__ double final_core(double stl, double sth, double umD,
     double mA_l0, double mA_l1, double mA_h0, double mA_h1, double mB_l0, double mB_l1, double mB_h0, double mB_h1,
     double Al0, double Al1, double Ah0, double Ah1, double Bl0, double Bl1, double Bh0, double Bh1,
@@ -273,6 +274,11 @@ __device__ __forceinline__ double final_core(double stl, double sth, double umD,
     }
     if (late_force) { stl += hdt * frl; sth += hdt * frh; }
     if (nonperD) edge_bc_v(qlc, qhc, f, normal_vel, stl, sth, blD, bhD, dloD, dhiD);
+    if (PRED) {
+        const double st = ((stl + sth) >= 0.) ? stl : sth;
+        const bool ltm = ((stl <= 0. && sth >= 0.) || (fabs(stl + sth) < SMALL_VEL));
+        return ltm ? 0. : st;
+    }
     double temp = (umD >= 0.) ? stl : sth;
     temp = (fabs(umD) < SMALL_VEL) ? 0.5 * (stl + sth) : temp;
     return temp;
@@ -1016,6 +1022,9 @@ static void launch_final(const Layout& l, const MultiFab& q, const MultiFab* for
                        e0[0].d_tab, e0[1].d_tab, e0[2].d_tab, out.d_tab, dP);
 }
 
+static bool use_z_kernel();
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP);
+
 void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
                                  double dt, const BCRec* bc, bool use_forces_in_trans)
 {
@@ -1023,6 +1032,10 @@ void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const M
     IAMRX_ASSERT(vel.ngrow >= 3 && vel.ncomp >= 3);
     IAMRX_ASSERT(!force || force->ngrow >= 1);
     const Layout& l = *vel.layout;
+    if (use_z_kernel() && !godunov_get_ppm()) {
+        godunov_pred_z(l, vel, force, umac, upload_params(make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false)));
+        return;
+    }
     MultiFab ad[3], e0[3], sl[3];
     MultiFab* adp[3];
     for (int d = 0; d < 3; ++d) {
@@ -1398,8 +1411,8 @@ __global__ void __launch_bounds__(NTH) k_godunov_tile(const BoxD* __restrict__ b
 // multi-pass kernels above, which remain as the PPM path and as the reference of tests/test_gpu_godunov_fused.py.
 struct GodTabs3 { const FabD* t[3]; };
 
-template <int TX, int TY, int NT>
-__global__ void __launch_bounds__(NT) k_god_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
+template <int TX, int TY, int NT, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
     const FabD* __restrict__ divut, const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
     const FabD* __restrict__ aofst, int acomp, GodTabs3 edge_t, GodTabs3 flux_t, const GodParams* __restrict__ Pp,
     int ntx, int nty, int nkc, int kc, int xcd_cnt)
@@ -1580,15 +1593,15 @@ __global__ void __launch_bounds__(NT) k_god_z(const BoxD* __restrict__ boxes, co
             const double mxp1 = MX[sp][oxp], myp1 = MY[sp][oyp], mxp0 = MX[s][oxp], myp0 = MY[s][oyp];
             uxh = mxp1; uyh = myp1;
             const double mzxm1 = MZ[sp][oxm], mzxm0 = MZ[s][oxm], mzym1 = MZ[sp][oym], mzym0 = MZ[s][oym];
-            Xe = final_core(xl1, xh1, mx1, MY[sp][oxm], MY[sp][oxm_yp], my1, myp1, mzxm1, mzxm0, mz1, mz0,
+            Xe = final_core<false>(xl1, xh1, mx1, MY[sp][oxm], MY[sp][oxm_yp], my1, myp1, mzxm1, mzxm0, mz1, mz0,
                             CYZ[oxm], CYZ[oxm_yp], CYZ[o], CYZ[oyp], CZY[sp][oxm], CZY[s][oxm], CZY[sp][o], CZY[s][o],
                             qxm1, r1v, late_force ? FR[sp][oxm] : 0., fr1, has_divu ? DV[sp][oxm] : 0., dv1,
                             conserv, has_divu, late_force, dt, dx1, dx2, np0, nv0, ci, bl0, bh0, dl0, dh0);
-            Ye = final_core(yl1, yh1, my1, MX[sp][oym], MX[sp][oxp_ym], mx1, mxp1, mzym1, mzym0, mz1, mz0,
+            Ye = final_core<false>(yl1, yh1, my1, MX[sp][oym], MX[sp][oxp_ym], mx1, mxp1, mzym1, mzym0, mz1, mz0,
                             CXZ[oym], CXZ[oxp_ym], CXZ[o], CXZ[oxp], CZX[sp][oym], CZX[s][oym], CZX[sp][o], CZX[s][o],
                             qym1, r1v, late_force ? FR[sp][oym] : 0., fr1, has_divu ? DV[sp][oym] : 0., dv1,
                             conserv, has_divu, late_force, dt, dx0, dx2, np1, nv1, cj, bl1, bh1, dl1, dh1);
-            Ze = final_core(zl, zh, mz0, mx1, mxp1, mx0, mxp0, my1, myp1, my0, myp0,
+            Ze = final_core<false>(zl, zh, mz0, mx1, mxp1, mx0, mxp0, my1, myp1, my0, myp0,
                             CXY[sp][o], CXY[sp][oxp], CXY[s][o], CXY[s][oxp], CYX[sp][o], CYX[sp][oyp], CYX[s][o], CYX[s][oyp],
                             r1v, r2, fr1, fr0, dv1, dv0,
                             conserv, has_divu, late_force, dt, dx0, dx1, np2, nv2, Pk, bl2, bh2, dl2, dh2);
@@ -1645,7 +1658,7 @@ static bool use_z_kernel()
     return v != 0;
 }
 
-template <int TX, int TY>
+template <int TX, int TY, int WPE>
 static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force, const MultiFab* divu,
                          MultiFab* const umac[3], MultiFab* const edge_out[3], MultiFab* const flux_out[3], const GodParams* dP)
 {
@@ -1660,9 +1673,267 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
     GodTabs3 et{{nullptr, nullptr, nullptr}}, ftb{{nullptr, nullptr, nullptr}};
     if (edge_out && edge_out[0]) for (int d = 0; d < 3; ++d) et.t[d] = edge_out[d]->d_tab;
     if (flux_out && flux_out[0]) for (int d = 0; d < 3; ++d) ftb.t[d] = flux_out[d]->d_tab;
-    hipLaunchKernelGGL((k_god_z<TX, TY, NT>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
+    hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
                        divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp, et, ftb, dP,
                        ntx, nty, nkc, kc, xcd_cnt);
+}
+
+// -------------------------------------------------------------------------------- fused z-marching velocity prediction (PLM)
+// k_pred_z: ExtrapVelToFaces in one launch, organised as k_god_z.  The traced states use the cell-centred velocity of the trace
+// direction, the advective velocities ad_x / ad_y / ad_z (upwinded normal components) take the place of the mac velocities and live
+// in LDS like the pass-1 states; the final x- / y- / z-face state is that of u / v / w, so the corner-coupled state C_{T|O} is formed
+// for the component 3-T-O only: E_x(v,w), E_y(u,w), E_z(u,v), six corner arrays, three final states per column and plane.
+// Three barriers per plane (the final states go straight to umac).
+template <int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
+    const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt, const GodParams* __restrict__ Pp,
+    int ntx, int nty, int nkc, int kc, int xcd_cnt)
+{
+    constexpr int PW = TX + 2, PH = TY + 2, PS = PW * PH, QW = TX + 6, QH = TY + 6, QS = QW * QH;
+    constexpr int NQ = (QS + NT - 1) / NT;
+    static_assert(NT >= PS, "one thread per column of the grown tile");
+    __shared__ double Qb[3][QS + QW];
+    __shared__ double AX[2][PS], AY[2][PS], AZ[2][PS], FR[2][3][PS];
+    __shared__ double EXv[2][PS], EXw[2][PS], EYu[2][PS], EYw[2][PS], EZu[2][PS], EZv[2][PS];
+    __shared__ double CZX[2][PS], CZY[2][PS], CXY[2][PS], CYX[2][PS], CXZ[PS], CYZ[PS];
+    const GodParams& P = *Pp;
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    int bid = blockIdx.x;
+    if (xcd_cnt > 0) {
+        bid = (bid & 7) * xcd_cnt + (bid >> 3);
+        if (bid >= ntx * nty * nkc) return;
+    }
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, kci = r1 / nty;
+    const int tx0 = b.lo[0] + tix * TX, ty0 = b.lo[1] + tiy * TY, k0 = b.lo[2] + kci * kc;
+    if (tx0 > b.hi[0] || ty0 > b.hi[1] || k0 > b.hi[2]) return;
+    const int txe = min(tx0 + TX - 1, b.hi[0]), tye = min(ty0 + TY - 1, b.hi[1]), k1 = min(k0 + kc - 1, b.hi[2]);
+    const int tid = threadIdx.x;
+    const int li = tid % PW, lj = tid / PW;
+    const bool act = tid < PS && tx0 - 1 + li <= txe + 1 && ty0 - 1 + lj <= tye + 1;
+    const int ci = act ? tx0 - 1 + li : tx0, cj = act ? ty0 - 1 + lj : ty0;
+    const int o = (ci - (tx0 - 1)) + PW * (cj - (ty0 - 1));
+    const int oxm = ci > tx0 - 1 ? o - 1 : o, oxp = ci < txe + 1 ? o + 1 : o;
+    const int oym = cj > ty0 - 1 ? o - PW : o, oyp = cj < tye + 1 ? o + PW : o;
+    const int oxm_yp = oxm + (oyp - o), oxp_ym = oxp + (oym - o);
+    const int qo = QW + (ci - (tx0 - 3)) + QW * (cj - (ty0 - 3));
+    const bool in_tile = act && ci >= tx0 && ci <= txe && cj >= ty0 && cj <= tye;
+    const bool wx = act && cj >= ty0 && cj <= tye && ci >= tx0 && (ci <= txe || ci == b.hi[0] + 1);
+    const bool wy = act && ci >= tx0 && ci <= txe && cj >= ty0 && (cj <= tye || cj == b.hi[1] + 1);
+
+    const bool has_force = P.has_force != 0, fit = P.fit != 0;
+    const bool early_force = fit && has_force, late_force = !fit && has_force;
+    const double dt = P.dt, hdt = 0.5 * dt, dt3 = dt / 3.0;
+    const double dx0 = P.dx[0], dx1 = P.dx[1], dx2 = P.dx[2];
+    const double dtdx0 = dt / dx0, dtdx1 = dt / dx1, dtdx2 = dt / dx2;
+    const double co0 = dt / (6.0 * dx0), co1 = dt / (6.0 * dx1), co2 = dt / (6.0 * dx2);
+    const bool np0 = !P.bc.per[0], np1 = !P.bc.per[1], np2 = !P.bc.per[2];
+    const int dl0 = P.bc.dlo[0], dh0 = P.bc.dhi[0], dl1 = P.bc.dlo[1], dh1 = P.bc.dhi[1], dl2 = P.bc.dlo[2], dh2 = P.bc.dhi[2];
+
+    const FabD q = qt[fab], ux = uxt[fab], uy = uyt[fab], uz = uzt[fab];
+    FabD frc = q;
+    if (has_force) frc = ft[fab];
+    const long qsz = (long)q.n[0] * q.n[1], fsz = (long)frc.n[0] * frc.n[1];
+    auto qcol = q.gp() + q.off(ci, cj, k0 - 3);
+    auto frp = frc.gp() + frc.off(ci, cj, k0 - 1);
+    long qpo[NQ]; bool qpv[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+        const int e = tid + r * NT, qi = tx0 - 3 + e % QW, qj = ty0 - 3 + e / QW;
+        qpv[r] = e < QS && qi <= txe + 3 && qj <= tye + 3;
+        qpo[r] = qpv[r] ? q.off(qi, qj, k0 - 1) : 0;
+    }
+    // z-rings of the own column: rz[c][0..4] = q_c(P-2..P+2) in iteration P
+    double rz[3][5];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rz[c][0] = 0.;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rz[c][m + 1] = act ? qcol[m * qsz + q.cs * c] : 0.;
+    }
+    qcol += 4 * qsz;
+    double pq[3], pfr[3], pQ[3][NQ];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pq[c] = act ? qcol[q.cs * c] : 0.;
+        pfr[c] = (act && has_force) ? frp[frc.cs * c] : 0.;
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) pQ[c][r] = qpv[r] ? q.gp()[qpo[r] + q.cs * c] : 0.;
+    }
+    double xl1u = 0., xh1u = 0., xl1v = 0., xh1v = 0., yl1u = 0., yh1u = 0., yl1v = 0., yh1v = 0.;
+    double qxm1u = 0., qxm1v = 0., qym1u = 0., qym1v = 0., fr1[3] = {0., 0., 0.}, slz1[3] = {0., 0., 0.};
+
+    int it = 0;
+    for (int Pk = k0 - 1; Pk <= k1 + 1; ++Pk, ++it) {
+        const int s = it & 1, sp = s ^ 1;
+        // ---------------- stage 0
+        double fr0[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rz[c][0] = rz[c][1]; rz[c][1] = rz[c][2]; rz[c][2] = rz[c][3]; rz[c][3] = rz[c][4]; rz[c][4] = pq[c];
+            fr0[c] = pfr[c];
+            if (act && has_force) FR[s][c][o] = fr0[c];
+#pragma unroll
+            for (int r = 0; r < NQ; ++r) { const int e = tid + r * NT; if (e < QS) Qb[c][QW + e] = pQ[c][r]; }
+        }
+        if (Pk <= k1) {
+            qcol += qsz; frp += fsz;
+#pragma unroll
+            for (int r = 0; r < NQ; ++r) qpo[r] += qsz;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (act) { pq[c] = qcol[q.cs * c]; if (has_force) pfr[c] = frp[frc.cs * c]; }
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) pQ[c][r] = qpv[r] ? q.gp()[qpo[r] + q.cs * c] : 0.;
+            }
+        }
+        __syncthreads();
+        // ---------------- stage A: pass 1 (traces with the cell-centred velocity of the trace direction)
+        double xl0u, xh0u, xl0v, xh0v, xl0w, xh0w, yl0u, yh0u, yl0v, yh0v, yl0w, yh0w, zlu, zhu, zlv, zhv, zlw, zhw;
+        double qxm0u, qxm0v, qxm0w, qym0u, qym0v, qym0w, adx, ady, adz, slz0[3];
+        {
+            const double vlo = Qb[0][qo - 1], vhi = Qb[0][qo];
+            double l[3], h[3], am[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double* qc = &Qb[c][qo];
+                const double a3 = qc[-3], a2 = qc[-2], a1 = qc[-1], c0 = qc[0], b1 = qc[1], b2 = qc[2];
+                const int bl = P.bc.bc[c].lo[0], bh = P.bc.bc[c].hi[0];
+                const bool edlo = np0 && ed_or_ho(bl), edhi = np0 && ed_or_ho(bh);
+                const double sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, ci - 1, dl0, dh0);
+                const double slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, ci, dl0, dh0);
+                h[c] = c0 + 0.5 * (-1.0 - vhi * dtdx0) * slh;
+                l[c] = a1 + 0.5 * (1.0 - vlo * dtdx0) * sll;
+                if (early_force) { l[c] += hdt * FR[s][c][oxm]; h[c] += hdt * fr0[c]; }
+                if (np0) trans_bc_v(a1, c0, ci, c == 0, l[c], h[c], bl, bh, dl0, dh0);
+                am[c] = a1;
+            }
+            const double st = ((l[0] + h[0]) >= 0.) ? l[0] : h[0];
+            const bool ltm = ((l[0] <= 0. && h[0] >= 0.) || (fabs(l[0] + h[0]) < SMALL_VEL));
+            adx = ltm ? 0. : st;
+            xl0u = l[0]; xh0u = h[0]; xl0v = l[1]; xh0v = h[1]; xl0w = l[2]; xh0w = h[2];
+            qxm0u = am[0]; qxm0v = am[1]; qxm0w = am[2];
+            if (act) { AX[s][o] = adx; EXv[s][o] = upwind_fu(adx, l[1], h[1]); EXw[s][o] = upwind_fu(adx, l[2], h[2]); }
+        }
+        {
+            const double vlo = Qb[1][qo - QW], vhi = Qb[1][qo];
+            double l[3], h[3], am[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double* qc = &Qb[c][qo];
+                const double a3 = qc[-3 * QW], a2 = qc[-2 * QW], a1 = qc[-QW], c0 = qc[0], b1 = qc[QW], b2 = qc[2 * QW];
+                const int bl = P.bc.bc[c].lo[1], bh = P.bc.bc[c].hi[1];
+                const bool edlo = np1 && ed_or_ho(bl), edhi = np1 && ed_or_ho(bh);
+                const double sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, cj - 1, dl1, dh1);
+                const double slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, cj, dl1, dh1);
+                h[c] = c0 + 0.5 * (-1.0 - vhi * dtdx1) * slh;
+                l[c] = a1 + 0.5 * (1.0 - vlo * dtdx1) * sll;
+                if (early_force) { l[c] += hdt * FR[s][c][oym]; h[c] += hdt * fr0[c]; }
+                if (np1) trans_bc_v(a1, c0, cj, c == 1, l[c], h[c], bl, bh, dl1, dh1);
+                am[c] = a1;
+            }
+            const double st = ((l[1] + h[1]) >= 0.) ? l[1] : h[1];
+            const bool ltm = ((l[1] <= 0. && h[1] >= 0.) || (fabs(l[1] + h[1]) < SMALL_VEL));
+            ady = ltm ? 0. : st;
+            yl0u = l[0]; yh0u = h[0]; yl0v = l[1]; yh0v = h[1]; yl0w = l[2]; yh0w = h[2];
+            qym0u = am[0]; qym0v = am[1]; qym0w = am[2];
+            if (act) { AY[s][o] = ady; EYu[s][o] = upwind_fu(ady, l[0], h[0]); EYw[s][o] = upwind_fu(ady, l[2], h[2]); }
+        }
+        {
+            const double vlo = rz[2][1], vhi = rz[2][2];
+            double l[3], h[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int bl = P.bc.bc[c].lo[2], bh = P.bc.bc[c].hi[2];
+                const bool edlo = np2 && ed_or_ho(bl), edhi = np2 && ed_or_ho(bh);
+                slz0[c] = slope4v(rz[c][0], rz[c][1], rz[c][2], rz[c][3], rz[c][4], edlo, edhi, Pk, dl2, dh2);
+                h[c] = rz[c][2] + 0.5 * (-1.0 - vhi * dtdx2) * slz0[c];
+                l[c] = rz[c][1] + 0.5 * (1.0 - vlo * dtdx2) * slz1[c];
+                if (early_force) { l[c] += hdt * fr1[c]; h[c] += hdt * fr0[c]; }
+                if (np2) trans_bc_v(rz[c][1], rz[c][2], Pk, c == 2, l[c], h[c], bl, bh, dl2, dh2);
+            }
+            const double st = ((l[2] + h[2]) >= 0.) ? l[2] : h[2];
+            const bool ltm = ((l[2] <= 0. && h[2] >= 0.) || (fabs(l[2] + h[2]) < SMALL_VEL));
+            adz = ltm ? 0. : st;
+            zlu = l[0]; zhu = h[0]; zlv = l[1]; zhv = h[1]; zlw = l[2]; zhw = h[2];
+            if (act) { AZ[s][o] = adz; EZu[s][o] = upwind_fu(adz, l[0], h[0]); EZv[s][o] = upwind_fu(adz, l[1], h[1]); }
+        }
+        __syncthreads();
+        // ---------------- stage B: corner coupling (convective form)
+        double frxm1 = 0., frym1 = 0.;
+        {
+            const double ayA = AY[s][oxm], ayB = AY[s][oxm_yp], ayD = AY[s][oyp];
+            const double axA = AX[s][oym], axB = AX[s][oxp_ym], axD = AX[s][oxp];
+            const double ax1 = AX[sp][o], ay1 = AY[sp][o], az1 = AZ[sp][o], axp1 = AX[sp][oxp], ayp1 = AY[sp][oyp];
+            const double azxm1 = AZ[sp][oxm], azxm0 = AZ[s][oxm], azym1 = AZ[sp][oym], azym0 = AZ[s][oym];
+            const int bxl_w = P.bc.bc[2].lo[0], bxh_w = P.bc.bc[2].hi[0], byl_w = P.bc.bc[2].lo[1], byh_w = P.bc.bc[2].hi[1];
+            const int bzl_v = P.bc.bc[1].lo[2], bzh_v = P.bc.bc[1].hi[2], bzl_u = P.bc.bc[0].lo[2], bzh_u = P.bc.bc[0].hi[2];
+            const int bxl_v = P.bc.bc[1].lo[0], bxh_v = P.bc.bc[1].hi[0], byl_u = P.bc.bc[0].lo[1], byh_u = P.bc.bc[0].hi[1];
+            const double cxy = corner_core(xl0w, xh0w, qxm0w, rz[2][2], adx, ayA, ayB, ady, ayD, EYw[s][oxm], EYw[s][oxm_yp], EYw[s][o], EYw[s][oyp],
+                                           0., 0., false, co1, dt3, dx1, np0, false, ci, bxl_w, bxh_w, dl0, dh0);
+            const double cyx = corner_core(yl0w, yh0w, qym0w, rz[2][2], ady, axA, axB, adx, axD, EXw[s][oym], EXw[s][oxp_ym], EXw[s][o], EXw[s][oxp],
+                                           0., 0., false, co0, dt3, dx0, np1, false, cj, byl_w, byh_w, dl1, dh1);
+            const double czx = corner_core(zlv, zhv, rz[1][1], rz[1][2], adz, ax1, axp1, adx, axD, EXv[sp][o], EXv[sp][oxp], EXv[s][o], EXv[s][oxp],
+                                           0., 0., false, co0, dt3, dx0, np2, false, Pk, bzl_v, bzh_v, dl2, dh2);
+            const double czy = corner_core(zlu, zhu, rz[0][1], rz[0][2], adz, ay1, ayp1, ady, ayD, EYu[sp][o], EYu[sp][oyp], EYu[s][o], EYu[s][oyp],
+                                           0., 0., false, co1, dt3, dx1, np2, false, Pk, bzl_u, bzh_u, dl2, dh2);
+            const double cxz = corner_core(xl1v, xh1v, qxm1v, rz[1][1], ax1, azxm1, azxm0, az1, adz, EZv[sp][oxm], EZv[s][oxm], EZv[sp][o], EZv[s][o],
+                                           0., 0., false, co2, dt3, dx2, np0, false, ci, bxl_v, bxh_v, dl0, dh0);
+            const double cyz = corner_core(yl1u, yh1u, qym1u, rz[0][1], ay1, azym1, azym0, az1, adz, EZu[sp][oym], EZu[s][oym], EZu[sp][o], EZu[s][o],
+                                           0., 0., false, co2, dt3, dx2, np1, false, cj, byl_u, byh_u, dl1, dh1);
+            if (act) { CXY[s][o] = cxy; CYX[s][o] = cyx; CZX[s][o] = czx; CZY[s][o] = czy; CXZ[o] = cxz; CYZ[o] = cyz; }
+            if (late_force) { frxm1 = FR[sp][0][oxm]; frym1 = FR[sp][1][oym]; }
+        }
+        __syncthreads();
+        // ---------------- stage C: u on the x-faces and v on the y-faces of plane P-1, w on the z-face P
+        {
+            const double ax1 = AX[sp][o], ay1 = AY[sp][o], az1 = AZ[sp][o];
+            const double axp1 = AX[sp][oxp], ayp1 = AY[sp][oyp], axp0 = AX[s][oxp], ayp0 = AY[s][oyp];
+            const double azxm1 = AZ[sp][oxm], azxm0 = AZ[s][oxm], azym1 = AZ[sp][oym], azym0 = AZ[s][oym];
+            const double Xe = final_core<true>(xl1u, xh1u, ax1, AY[sp][oxm], AY[sp][oxm_yp], ay1, ayp1, azxm1, azxm0, az1, adz,
+                            CYZ[oxm], CYZ[oxm_yp], CYZ[o], CYZ[oyp], CZY[sp][oxm], CZY[s][oxm], CZY[sp][o], CZY[s][o],
+                            qxm1u, rz[0][1], frxm1, fr1[0], 0., 0., false, false, late_force, dt, dx1, dx2,
+                            np0, true, ci, P.bc.bc[0].lo[0], P.bc.bc[0].hi[0], dl0, dh0);
+            const double Ye = final_core<true>(yl1v, yh1v, ay1, AX[sp][oym], AX[sp][oxp_ym], ax1, axp1, azym1, azym0, az1, adz,
+                            CXZ[oym], CXZ[oxp_ym], CXZ[o], CXZ[oxp], CZX[sp][oym], CZX[s][oym], CZX[sp][o], CZX[s][o],
+                            qym1v, rz[1][1], frym1, fr1[1], 0., 0., false, false, late_force, dt, dx0, dx2,
+                            np1, true, cj, P.bc.bc[1].lo[1], P.bc.bc[1].hi[1], dl1, dh1);
+            const double Ze = final_core<true>(zlw, zhw, adz, ax1, axp1, adx, axp0, ay1, ayp1, ady, ayp0,
+                            CXY[sp][o], CXY[sp][oxp], CXY[s][o], CXY[s][oxp], CYX[sp][o], CYX[sp][oyp], CYX[s][o], CYX[s][oyp],
+                            rz[2][1], rz[2][2], fr1[2], fr0[2], 0., 0., false, false, late_force, dt, dx0, dx1,
+                            np2, true, Pk, P.bc.bc[2].lo[2], P.bc.bc[2].hi[2], dl2, dh2);
+            const int k = Pk - 1;
+            if (k >= k0 && k <= k1) {
+                if (wx) ux(ci, cj, k, 0) = Xe;
+                if (wy) uy(ci, cj, k, 0) = Ye;
+            }
+            if (in_tile && Pk >= k0 && (Pk <= k1 || Pk == b.hi[2] + 1)) uz(ci, cj, Pk, 0) = Ze;
+        }
+        xl1u = xl0u; xh1u = xh0u; xl1v = xl0v; xh1v = xh0v; yl1u = yl0u; yh1u = yh0u; yl1v = yl0v; yh1v = yh0v;
+        qxm1u = qxm0u; qxm1v = qxm0v; qym1u = qym0u; qym1v = qym0v;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { fr1[c] = fr0[c]; slz1[c] = slz0[c]; }
+    }
+}
+
+template <int TX, int TY>
+static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP)
+{
+    constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
+    const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+    static const int kc_env = [] { const char* e = getenv("IAMRX_GODUNOV_ZKC"); return e ? atoi(e) : 0; }();
+    const int kc = kc_env > 0 ? kc_env : std::min(64, std::max(8, l.max_len[2] / 4));
+    const int nkc = (l.max_len[2] + kc - 1) / kc;
+    const int total = ntx * nty * nkc;
+    const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
+    dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), 1u);
+    hipLaunchKernelGGL((k_pred_z<TX, TY, NT>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
+                       umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, dP, ntx, nty, nkc, kc, xcd_cnt);
+}
+
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP)
+{
+    launch_pred_z<16, 8>(l, vel, force, umac, dP);
 }
 
 static bool use_tile_kernel()
@@ -1693,9 +1964,15 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     }
     const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
     if (zk) {
-        static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 32; }();
-        if (ztx == 16) launch_god_z<16, 8>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP);
-        else launch_god_z<32, 8>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP);
+        static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 16; }();
+        static const int zty = [] { const char* e = getenv("IAMRX_GODUNOV_ZTY"); return e ? atoi(e) : 8; }();
+#define IAMRX_GZ(TX, TY, W) launch_god_z<TX, TY, W>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP)
+        // 16 x 8 tiles (3 wavefronts, 40 KB of LDS) measured 5.8 ms for 5 components at 256^3, 16 x 16: 6.4 ms, 32 x 8: 6.4 ms;
+        // bounding the registers for a third wavefront per SIMD spills (17 ms)
+        if (ztx == 16 && zty == 8) IAMRX_GZ(16, 8, 2);
+        else if (ztx == 16) IAMRX_GZ(16, 16, 2);
+        else IAMRX_GZ(32, 8, 2);
+#undef IAMRX_GZ
         return;
     }
     if (use_tile_kernel()) {
