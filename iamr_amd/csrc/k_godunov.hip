@@ -1023,7 +1023,7 @@ static void launch_final(const Layout& l, const MultiFab& q, const MultiFab* for
 }
 
 static bool use_z_kernel();
-static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP);
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs);
 
 void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
                                  double dt, const BCRec* bc, bool use_forces_in_trans)
@@ -1033,7 +1033,8 @@ void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const M
     IAMRX_ASSERT(!force || force->ngrow >= 1);
     const Layout& l = *vel.layout;
     if (use_z_kernel() && !godunov_get_ppm()) {
-        godunov_pred_z(l, vel, force, umac, upload_params(make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false)));
+        godunov_pred_z(l, vel, force, umac, upload_params(make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false)),
+                       !(g.periodic[0] && g.periodic[1] && g.periodic[2]));
         return;
     }
     MultiFab ad[3], e0[3], sl[3];
@@ -1411,7 +1412,7 @@ __global__ void __launch_bounds__(NTH) k_godunov_tile(const BoxD* __restrict__ b
 // multi-pass kernels above, which remain as the PPM path and as the reference of tests/test_gpu_godunov_fused.py.
 struct GodTabs3 { const FabD* t[3]; };
 
-template <int TX, int TY, int NT, int WPE>
+template <int TX, int TY, int NT, int WPE, bool BCS>
 __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
     const FabD* __restrict__ divut, const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
     const FabD* __restrict__ aofst, int acomp, GodTabs3 edge_t, GodTabs3 flux_t, const GodParams* __restrict__ Pp,
@@ -1459,7 +1460,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
     const double dtdx0 = dt / dx0, dtdx1 = dt / dx1, dtdx2 = dt / dx2;
     const double co0 = conserv ? dt / (3.0 * dx0) : dt / (6.0 * dx0), co1 = conserv ? dt / (3.0 * dx1) : dt / (6.0 * dx1),
                  co2 = conserv ? dt / (3.0 * dx2) : dt / (6.0 * dx2);
-    const bool np0 = !P.bc.per[0], np1 = !P.bc.per[1], np2 = !P.bc.per[2];
+    const bool np0 = BCS && !P.bc.per[0], np1 = BCS && !P.bc.per[1], np2 = BCS && !P.bc.per[2];   // BCS = false: periodic in every direction
     const int bl0 = P.bc.bc[n].lo[0], bh0 = P.bc.bc[n].hi[0], bl1 = P.bc.bc[n].lo[1], bh1 = P.bc.bc[n].hi[1],
               bl2 = P.bc.bc[n].lo[2], bh2 = P.bc.bc[n].hi[2];
     const int dl0 = P.bc.dlo[0], dh0 = P.bc.dhi[0], dl1 = P.bc.dlo[1], dh1 = P.bc.dhi[1], dl2 = P.bc.dlo[2], dh2 = P.bc.dhi[2];
@@ -1658,7 +1659,7 @@ static bool use_z_kernel()
     return v != 0;
 }
 
-template <int TX, int TY, int WPE>
+template <int TX, int TY, int WPE, bool BCS>
 static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force, const MultiFab* divu,
                          MultiFab* const umac[3], MultiFab* const edge_out[3], MultiFab* const flux_out[3], const GodParams* dP)
 {
@@ -1673,7 +1674,7 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
     GodTabs3 et{{nullptr, nullptr, nullptr}}, ftb{{nullptr, nullptr, nullptr}};
     if (edge_out && edge_out[0]) for (int d = 0; d < 3; ++d) et.t[d] = edge_out[d]->d_tab;
     if (flux_out && flux_out[0]) for (int d = 0; d < 3; ++d) ftb.t[d] = flux_out[d]->d_tab;
-    hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
+    hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
                        divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp, et, ftb, dP,
                        ntx, nty, nkc, kc, xcd_cnt);
 }
@@ -1684,7 +1685,7 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
 // in LDS like the pass-1 states; the final x- / y- / z-face state is that of u / v / w, so the corner-coupled state C_{T|O} is formed
 // for the component 3-T-O only: E_x(v,w), E_y(u,w), E_z(u,v), six corner arrays, three final states per column and plane.
 // Three barriers per plane (the final states go straight to umac).
-template <int TX, int TY, int NT>
+template <int TX, int TY, int NT, bool BCS>
 __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
     const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt, const GodParams* __restrict__ Pp,
     int ntx, int nty, int nkc, int kc, int xcd_cnt)
@@ -1727,7 +1728,7 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
     const double dx0 = P.dx[0], dx1 = P.dx[1], dx2 = P.dx[2];
     const double dtdx0 = dt / dx0, dtdx1 = dt / dx1, dtdx2 = dt / dx2;
     const double co0 = dt / (6.0 * dx0), co1 = dt / (6.0 * dx1), co2 = dt / (6.0 * dx2);
-    const bool np0 = !P.bc.per[0], np1 = !P.bc.per[1], np2 = !P.bc.per[2];
+    const bool np0 = BCS && !P.bc.per[0], np1 = BCS && !P.bc.per[1], np2 = BCS && !P.bc.per[2];   // BCS = false: periodic in every direction
     const int dl0 = P.bc.dlo[0], dh0 = P.bc.dhi[0], dl1 = P.bc.dlo[1], dh1 = P.bc.dhi[1], dl2 = P.bc.dlo[2], dh2 = P.bc.dhi[2];
 
     const FabD q = qt[fab], ux = uxt[fab], uy = uyt[fab], uz = uzt[fab];
@@ -1916,7 +1917,7 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
     }
 }
 
-template <int TX, int TY>
+template <int TX, int TY, bool BCS>
 static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP)
 {
     constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
@@ -1927,13 +1928,14 @@ static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* 
     const int total = ntx * nty * nkc;
     const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
     dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), 1u);
-    hipLaunchKernelGGL((k_pred_z<TX, TY, NT>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
+    hipLaunchKernelGGL((k_pred_z<TX, TY, NT, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
                        umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, dP, ntx, nty, nkc, kc, xcd_cnt);
 }
 
-static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP)
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs)
 {
-    launch_pred_z<16, 8>(l, vel, force, umac, dP);
+    if (bcs) launch_pred_z<16, 8, true>(l, vel, force, umac, dP);
+    else launch_pred_z<16, 8, false>(l, vel, force, umac, dP);
 }
 
 static bool use_tile_kernel()
@@ -1966,7 +1968,9 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     if (zk) {
         static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 16; }();
         static const int zty = [] { const char* e = getenv("IAMRX_GODUNOV_ZTY"); return e ? atoi(e) : 8; }();
-#define IAMRX_GZ(TX, TY, W) launch_god_z<TX, TY, W>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP)
+        const bool bcs = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+#define IAMRX_GZ(TX, TY, W) (bcs ? launch_god_z<TX, TY, W, true>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP) \
+                                  : launch_god_z<TX, TY, W, false>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP))
         // 16 x 8 tiles (3 wavefronts, 40 KB of LDS) measured 5.8 ms for 5 components at 256^3, 16 x 16: 6.4 ms, 32 x 8: 6.4 ms;
         // bounding the registers for a third wavefront per SIMD spills (17 ms)
         if (ztx == 16 && zty == 8) IAMRX_GZ(16, 8, 2);
