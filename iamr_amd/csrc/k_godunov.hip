@@ -24,6 +24,13 @@
 namespace iamrx {
 
 #define SMALL_VEL 1.e-8
+// x / dx in the fused kernels: a true division in the bit-reproducible build (STRICT_FP=1, the oracle's arithmetic), a multiplication
+// with the reciprocal otherwise (an fp64 division is ~12 vector instructions; the difference is one rounding, inside the 1e-13 bar)
+#ifdef IAMRX_STRICT_FP
+#define IAMRX_DIVDX(x, dx, rdx) ((x) / (dx))
+#else
+#define IAMRX_DIVDX(x, dx, rdx) ((x) * (rdx))
+#endif
 
 struct GodBC {
     int dlo[3], dhi[3];
@@ -233,8 +240,9 @@ __device__ __forceinline__ double corner_core(double l, double h, double qlc, do
     bool nonperT, bool normal_vel, int fT, int bl, int bh, int domlo, int domhi)
 {
     if (conserv) {
-        l = l - c_o * (eo_cmo * mo_cmo - eo_cm * mo_cm) + dt3 * qlc * ((mo_cmo - mo_cm) / dxO - 0.5 * dvl);
-        h = h - c_o * (eo_fo * mo_fo - eo_f * mo_f) + dt3 * qhc * ((mo_fo - mo_f) / dxO - 0.5 * dvh);
+        const double rdxO = 1.0 / dxO;      // uniform: hoisted out of the plane loop
+        l = l - c_o * (eo_cmo * mo_cmo - eo_cm * mo_cm) + dt3 * qlc * (IAMRX_DIVDX(mo_cmo - mo_cm, dxO, rdxO) - 0.5 * dvl);
+        h = h - c_o * (eo_fo * mo_fo - eo_f * mo_f) + dt3 * qhc * (IAMRX_DIVDX(mo_fo - mo_f, dxO, rdxO) - 0.5 * dvh);
     } else {
         l = l - c_o * (mo_cmo + mo_cm) * (eo_cmo - eo_cm);
         h = h - c_o * (mo_fo + mo_f) * (eo_fo - eo_f);
@@ -1503,6 +1511,8 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
     // values of plane P-1 kept from the previous iteration
     double xl1 = 0., xh1 = 0., yl1 = 0., yh1 = 0., qxm1 = 0., qym1 = 0., mx1 = 0., my1 = 0., mz1 = 0., fr1 = 0., dv1 = 0., slz1 = 0., Zprev = 0.;
     const double ax = dx1 * dx2, ay = dx2 * dx0, az = dx0 * dx1, qvol = 1.0 / (dx0 * dx1 * dx2);
+    const double rdx0 = 1.0 / dx0, rdx1 = 1.0 / dx1, rdx2 = 1.0 / dx2;
+    (void)rdx0; (void)rdx1; (void)rdx2;
     const bool store_edge = edge_t.t[0] != nullptr, store_flux = flux_t.t[0] != nullptr;
 
     int it = 0;
@@ -1618,7 +1628,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
                 const double fxl = Xe * mx1 * ax, fyl = Ye * my1 * ay, fzl = Zprev * mz1 * az;
                 if (in_tile) {
                     const double fxh = exh * uxh * ax, fyh = eyh * uyh * ay, fzh = Ze * mz0 * az;
-                    const double divum = 1.0 * ((uxh - mx1) / dx0 + (uyh - my1) / dx1 + (mz0 - mz1) / dx2);
+                    const double divum = 1.0 * (IAMRX_DIVDX(uxh - mx1, dx0, rdx0) + IAMRX_DIVDX(uyh - my1, dx1, rdx1) + IAMRX_DIVDX(mz0 - mz1, dx2, rdx2));
                     double upd = -1.0 * qvol * ((fxh - fxl) + (fyh - fyl) + (fzh - fzl));
                     if (!conserv) {
                         double qavg = Xe + exh + Ye + eyh + Zprev + Ze;
@@ -1652,11 +1662,11 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
     }
 }
 
+// IAMRX_GODUNOV_Z=0 selects the multi-pass kernels (read at every call: tests/test_gpu_godunov_fused.py compares the two paths)
 static bool use_z_kernel()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_Z"); v = e ? atoi(e) : 1; }
-    return v != 0;
+    const char* e = getenv("IAMRX_GODUNOV_Z");
+    return e ? atoi(e) != 0 : true;
 }
 
 template <int TX, int TY, int WPE, bool BCS>
