@@ -110,6 +110,12 @@ def kernel_rooflines(lib, n):
     divu.setval(0.0)
     t = hip_event_time(lib, lambda: lib.godunov_compute_aofs(g, aofs, 0, vel, 3, frc, divu, um, (0, 0, 0), dt, None, 1, 0), 10)
     out["compute_aofs_vel"] = {"ms": t, "alg_bytes_per_cell": 104, "GBps": 104 * cells / t / 1e6}
+    S5 = lib.MultiFab(lay, lib.CELL, 5, 3)
+    f5 = lib.MultiFab(lay, lib.CELL, 5, 1)
+    S5.setval(0.3)
+    f5.setval(0.1)
+    t = hip_event_time(lib, lambda: lib.godunov_compute_aofs(g, aofs, 0, S5, 5, f5, divu, um, (0, 0, 0, 1, 0), dt, None, 1, 0), 10)
+    out["compute_aofs_state5"] = {"ms": t, "alg_bytes_per_cell": 152, "GBps": 152 * cells / t / 1e6}
     return out
 
 
@@ -275,15 +281,15 @@ def main():
     # k_nodal_gs4; profiles/round2_c_kernel_stats.csv), on their launch stream: opened during the warm-up (creates the event pools),
     # re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
     probe_on = world == 1 and os.environ.get("IAMRX_BENCH_PROBE", "1") != "0"
-    PROBES = {"gs4": (0, (n + 1) ** 3), "gsrb": (1, n ** 3)}
+    PROBES = {"gs4": (0, (n + 1) ** 3, 8), "gsrb": (1, n ** 3, 8), "god_z": (2, n ** 3, 1), "pred_z": (3, n ** 3, 1)}
 
     def probes_start():
-        for which, pts in PROBES.values():
-            lib.check(lib.lib().iamrx_kernel_probe_start(which, C.c_long(pts), 8))
+        for which, pts, stride in PROBES.values():
+            lib.check(lib.lib().iamrx_kernel_probe_start(which, C.c_long(pts), stride))
 
     def probes_stop():
         res = {}
-        for name, (which, pts) in PROBES.items():
+        for name, (which, pts, _stride) in PROBES.items():
             ms, nl = C.c_double(), C.c_long()
             lib.check(lib.lib().iamrx_kernel_probe_stop(which, C.byref(ms), C.byref(nl)))
             res[name] = (ms.value / nl.value, nl.value) if nl.value > 0 else None
@@ -352,7 +358,7 @@ def main():
         roofline = None
         cells = float(n) ** 3
 
-        def pmc_traffic(key_substr):
+        def pmc_traffic(key_substr, field="hbm_bytes_per_launch"):
             """HBM bytes per launch of the 256^3-level launches inside the step, from the PMC passes over this script (FETCH_SIZE / WRITE_SIZE,
             separate rocprofv3 runs, tools/collect_pmc.sh, corrected as calibrated in profiles/round1_pmc.json).  The counters describe ONE
             build of the kernels: the file records the git blob hashes of the kernel sources it was collected with; any other source =>
@@ -364,8 +370,8 @@ def main():
                 for src, blob in pmc.get("source_blobs", {}).items():
                     if blob != file_blob_sha(os.path.join(ROOT, "iamr_amd", "csrc", src)):
                         return None
-                hits = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if key_substr in k]
-                return hits[0] if hits else None
+                hits = [v for k, v in pmc["kernels"].items() if key_substr in k]
+                return (hits[0].get(field) if hits else None)
             except Exception:
                 return None
 
@@ -397,6 +403,30 @@ def main():
                             "launches_timed": gs4_insitu[1] if gs4_insitu else None,
                             "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
                             "isolated_loop_ms": dom["ms"]}
+        # the Godunov kernels are bound by the vector pipe, not by HBM: both fractions are reported.  valu_frac =
+        # wave-level vector instructions per launch (SQ_INSTS_VALU, third PMC pass of tools/collect_pmc.sh) / duration / the issue peak
+        # of 256 CUs x 4 SIMDs x 1 wave64 instruction per 4 cycles at 2.4 GHz
+        VALU_PEAK = 256 * 4 * 2.4e9 / 4
+
+        def godunov_roofline(name, probe, grid_key, alg_bytes, what):
+            if not probe:
+                return None
+            ms = probe[0]
+            gbps = alg_bytes / ms / 1e6
+            valu = pmc_traffic(grid_key, "SQ_INSTS_VALU")
+            return {"kernel": what, "bound": "valu", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                    "traffic": pmc_traffic(grid_key), "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": ms, "launches_timed": probe[1],
+                    "timing": "HIP events around every launch inside the timed steps",
+                    "valu_insts_per_launch": valu, "valu_frac": (valu / (ms * 1e-3) / VALU_PEAK) if valu else None,
+                    "valu_peak_wave_insts_per_s": VALU_PEAK}
+
+        # algorithmic bytes per cell: advection of the 5 state components in one launch = 5 x (state 8 + forcing 8 + aofs 8) + mac 24 + divu 8;
+        # prediction = velocity 24 + forcing 24 + the three face velocities 24
+        roofline_god = godunov_roofline("god_z", insitu.get("god_z"), "k_god_z<16, 8, 192, 2, false> grid=", 152.0 * cells,
+                                        "k_god_z<16,8> (fused z-marching Godunov advection of the 5 state components: ComputeFluxesOnBoxFromState + "
+                                        "ComputeDivergence / ComputeConvectiveTerm in one launch)")
+        roofline_pred = godunov_roofline("pred_z", insitu.get("pred_z"), "k_pred_z<16, 8, 192, false> grid=", 72.0 * cells,
+                                         "k_pred_z<16,8> (fused z-marching ExtrapVelToFaces)")
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -413,6 +443,8 @@ def main():
             "kernels": kr,
             "roofline": roofline,
             "roofline_nodal_gs4": roofline_gs4,
+            "roofline_godunov_advection": roofline_god,
+            "roofline_godunov_prediction": roofline_pred,
         }
         if world == 1 and a.amr_n > 0 and a.amr_steps > 0:
             out["amr"] = amr_workload(lib, a.amr_n, a.amr_steps)

@@ -1684,9 +1684,11 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
     GodTabs3 et{{nullptr, nullptr, nullptr}}, ftb{{nullptr, nullptr, nullptr}};
     if (edge_out && edge_out[0]) for (int d = 0; d < 3; ++d) et.t[d] = edge_out[d]->d_tab;
     if (flux_out && flux_out[0]) for (int d = 0; d < 3; ++d) ftb.t[d] = flux_out[d]->d_tab;
+    const bool rec = kernel_probe_begin(PROBE_GOD_Z, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
     hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
                        divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp, et, ftb, dP,
                        ntx, nty, nkc, kc, xcd_cnt);
+    if (rec) kernel_probe_end(PROBE_GOD_Z);
 }
 
 // -------------------------------------------------------------------------------- fused z-marching velocity prediction (PLM)
@@ -1938,8 +1940,10 @@ static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* 
     const int total = ntx * nty * nkc;
     const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
     dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), 1u);
+    const bool rec = kernel_probe_begin(PROBE_PRED_Z, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
     hipLaunchKernelGGL((k_pred_z<TX, TY, NT, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
                        umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, dP, ntx, nty, nkc, kc, xcd_cnt);
+    if (rec) kernel_probe_end(PROBE_PRED_Z);
 }
 
 static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs)

@@ -17,7 +17,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
 // y = a*x + b*y etc. (valid region + ng)
 // HIP-event probe around the k_nodal_gs4 launches of levels with >= min_nodes nodes per box (see k_nodal.hip)
 // HIP-event probes around the launches of one kernel family on levels with at least min_points cells / nodes per box (every stride-th one)
-enum { PROBE_NODAL_GS4 = 0, PROBE_ABEC_GSRB = 1, PROBE_COUNT = 2 };
+enum { PROBE_NODAL_GS4 = 0, PROBE_ABEC_GSRB = 1, PROBE_GOD_Z = 2, PROBE_PRED_Z = 3, PROBE_COUNT = 4 };
 void kernel_probe_start(int which, long min_points, int stride);
 void kernel_probe_stop(int which, double* total_ms, long* launches);
 bool kernel_probe_begin(int which, long points);     // true: the start event was recorded, call kernel_probe_end after the launch

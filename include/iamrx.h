@@ -79,7 +79,8 @@ int iamrx_timer_start(void);
 int iamrx_timer_stop(double* ms);
 void iamrx_mg_default_opts(iamrx_mg_opts* o);
 /* HIP-event probes around the launches of one kernel family inside running solves (the role of TINY_PROFILE rows such as MLMG smoother
- * times): which = 0 nodal Gauss-Seidel pass (k_nodal_gs4), 1 scalar GSRB colour pass (k_abec_gsrb); only launches on levels
+ * times): which = 0 nodal Gauss-Seidel pass (k_nodal_gs4), 1 scalar GSRB colour pass (k_abec_gsrb), 2 fused Godunov advection (k_god_z), 3 fused
+ * velocity prediction (k_pred_z); only launches on levels
  * with at least min_points nodes / cells per box, every stride-th one.  stop waits for the stream and returns the summed durations. */
 int iamrx_kernel_probe_start(int which, long min_points, int stride);
 int iamrx_kernel_probe_stop(int which, double* total_ms, long* launches);

@@ -1,5 +1,6 @@
 #!/bin/bash
-# HBM traffic of the kernels inside the running bench step: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE cannot share a pass,
+# HBM traffic and vector-instruction counts of the kernels inside the running bench step: three rocprofv3 counter passes (FETCH_SIZE,
+# WRITE_SIZE cannot share a pass; SQ_INSTS_VALU for the valu_frac of the Godunov kernels,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") over bench.py, --kernel-trace only.  Run on the GPU box from the repo root:
 #   bash tools/collect_pmc.sh roundN      -> gpurun_out/roundN_pmc.json (+ the two reduced CSVs); copy them to profiles/
 set -e
@@ -8,14 +9,14 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rm -rf /tmp/pmc_$c
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --amr-steps 0 > $out/${tag}_pmc_$c.log 2>&1
     f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
     test -n "$f" && cp "$f" $out/${tag}_pmc_$(echo $c | tr A-Z a-z).csv
 done
 cd $root
-python tools/pmc_report.py $out/${tag}_pmc_fetch_size.csv $out/${tag}_pmc_write_size.csv $out/${tag}_pmc.json > $out/${tag}_pmc_report.txt
+python tools/pmc_report.py $out/${tag}_pmc_fetch_size.csv $out/${tag}_pmc_write_size.csv $out/${tag}_pmc.json $out/${tag}_pmc_sq_insts_valu.csv > $out/${tag}_pmc_report.txt
 python - <<PY
 import json, subprocess, sys
 sys.path.insert(0, "$root")
