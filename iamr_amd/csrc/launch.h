@@ -33,6 +33,11 @@ inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
     t.bxs = bxs;
     t.ntx = (maxlen[0] + bx - 1) / bx;
     t.nty = (maxlen[1] + by - 1) / by;
+    // small levels: a workgroup that marches tz planes pays their memory latencies one after the other while most of the chip idles
+    // (an 8^3 multigrid level was ONE workgroup with 32 active threads, 10 us per colour pass); give the planes to more workgroups
+    // until the launch holds ~512 of them
+    static const int tz_adapt = [] { const char* e = getenv("IAMRX_TZ_ADAPT"); return e ? atoi(e) : 1; }();
+    while (tz_adapt && tz > 1 && (long)t.ntx * t.nty * (nfab > 0 ? nfab : 1) * ((maxlen[2] + tz - 1) / tz) < 512) tz /= 2;
     t.tz = tz;
     t.ntz = (maxlen[2] + tz - 1) / tz;
     t.nfab = nfab;
