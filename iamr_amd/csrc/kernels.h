@@ -73,6 +73,10 @@ void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_i
                      const DomainBC* bcs, int nbc);
 // out = rhs - L(phi)  (rhs == nullptr: out = L(phi))
 void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs);
+// bottom solve (BiCGStab + post-smoothing, CellMG::bottom_solve) of a single-box level of at most 8^3 cells in one single-workgroup launch
+bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp);
+void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
+                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters);
 void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 void cc_restrict(MultiFab& crse, const MultiFab& fine);          // average of 8
 void cc_prolong_add(MultiFab& fine, const MultiFab& crse);       // piecewise constant

@@ -27,6 +27,10 @@ struct MGOpts {
     int bottom_smoother_only = 0;
     int fixed_iters = 0;
     int nodal_nu1 = 1, nodal_nu2 = 1;   // pre / post smooth calls of the nodal V-cycle (nu1 / nu2 above: the cell-centred one)
+    // cell-centred hierarchy: 1 = stop coarsening at the first single-box level of at most 8^3 cells and solve it with the
+    // single-workgroup device BiCGStab (k_abec_bottom, no host synchronisation); 0 = coarsen to min_width and drive BiCGStab from the
+    // host (upstream's shape; same converged solution, iteration counts may differ by one)
+    int device_bottom = 1;
 };
 
 // multi-rank runs: MG levels whose total size is at most this many cells are replicated on every rank (one all-gather per
@@ -103,6 +107,7 @@ private:
     bool m_tensor = false;
     bool m_tensor_eta = false;
     bool m_singular = false;
+    bool m_bottom_dev = false;    // the coarsest level is solved by k_abec_bottom (one single-workgroup launch, no host synchronisation)
     int m_dd_sweeps = 0;          // > 0: diagonally dominant operator solved by sweeps of the finest level only (prepare())
     bool m_cf = false;
     const MultiFab* m_crse = nullptr;

@@ -81,6 +81,9 @@ void CellMG::prepare()
     m_lev.resize(1);
     while (m_dd_sweeps == 0 && (int)m_lev.size() <= m_o.max_coarsening_level) {
         Level& f = m_lev.back();
+        // a single box of at most 8^3 cells is solved by the single-workgroup device bottom solver (k_abec_bottom): no need to coarsen
+        // further (IAMRX_MG_DEVICE_BOTTOM=0: host-driven BiCGStab on the coarsest possible level, upstream's shape)
+        if (m_o.device_bottom && !m_cf && !m_tensor && !m_o.bottom_smoother_only && abec_bottom_device_ok(f.g, *f.layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp)) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
@@ -97,6 +100,8 @@ void CellMG::prepare()
         m_lev.push_back(std::move(c));
     }
     const int nl = (int)m_lev.size();
+    m_bottom_dev = m_o.device_bottom && m_dd_sweeps == 0 && !m_cf && !m_tensor && !m_o.bottom_smoother_only &&
+                   abec_bottom_device_ok(m_lev.back().g, *m_lev.back().layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp);
     for (int l = 0; l < nl; ++l) {
         Level& L = m_lev[l];
         L.cor.define(L.layout, cell_type(), m_ncomp, 1);
@@ -295,6 +300,14 @@ int CellMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, 
     return ret;
 }
 
+// Krylov iterations of the device bottom solver, summed over the V-cycles of the running solve (one counter: solves do not overlap)
+static int* bottom_iters_dev()
+{
+    static int* d = nullptr;
+    if (!d) { IAMRX_HIP_CHECK(hipMalloc(&d, sizeof(int))); IAMRX_HIP_CHECK(hipMemset(d, 0, sizeof(int))); }
+    return d;
+}
+
 void CellMG::bottom_solve(MGStats& st)
 {
     const int l = (int)m_lev.size() - 1;
@@ -306,6 +319,12 @@ void CellMG::bottom_solve(MGStats& st)
     }
     if (m_o.bottom_smoother_only) {
         smooth_n(l, L.cor, L.res, m_o.nuf, true);
+        return;
+    }
+    if (m_bottom_dev) {
+        const long nunk = (long)L.g.domain.npts() * m_ncomp;
+        const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+        abec_bottom_solve(L.g, coef(l), L.cor, L.res, m_bcn[0], m_singular, m_o.bottom_reltol, maxiter, m_o.nub, m_o.nuf, m_o.omega, bottom_iters_dev());
         return;
     }
     MultiFab b(L.layout, cell_type(), m_ncomp, 0);
@@ -386,6 +405,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     st.resnorm = st.resnorm0;
     if (m_o.verbose) printf("iamrx MLMG: rhs %.6e resid0 %.6e target %.3e levels %d\n", st.rhsnorm0, st.resnorm0, res_target, st.nlevels);
     double vc_ms = 0.0;
+    if (m_bottom_dev) IAMRX_HIP_CHECK(hipMemsetAsync(bottom_iters_dev(), 0, sizeof(int), ctx.stream));
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
     else {
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
@@ -409,6 +429,12 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     }
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
     applyBC(0, phi, true, &bcval);
+    if (m_bottom_dev && st.iters > 0) {
+        int h = 0;
+        IAMRX_HIP_CHECK(hipMemcpyAsync(&h, bottom_iters_dev(), sizeof(int), hipMemcpyDeviceToHost, ctx.stream));
+        ctx.sync();
+        st.bottom_iters_total = h;
+    }
     return st;
 }
 

@@ -44,7 +44,8 @@ class MgOpts(C.Structure):
                 ("bottom_maxiter", C.c_int), ("bottom_reltol", C.c_double), ("omega", C.c_double),
                 ("maxorder", C.c_int), ("max_coarsening_level", C.c_int), ("min_width", C.c_int),
                 ("nodal_sweeps", C.c_int), ("nodal_smoother", C.c_int), ("verbose", C.c_int),
-                ("bottom_smoother_only", C.c_int), ("fixed_iters", C.c_int), ("nodal_nu1", C.c_int), ("nodal_nu2", C.c_int)]
+                ("bottom_smoother_only", C.c_int), ("fixed_iters", C.c_int), ("nodal_nu1", C.c_int), ("nodal_nu2", C.c_int),
+                ("device_bottom", C.c_int)]
 
 
 class MgStats(C.Structure):

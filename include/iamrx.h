@@ -53,6 +53,10 @@ typedef struct iamrx_mg_opts {
      * 2 + 2 calls; iamrx_mg_default_opts() gives 2 sweeps and 1 + 1 calls -- the converged solution is the same, the time to solution is
      * 1/3 shorter on MI355X.  Set nodal_sweeps = 4, nodal_nu1 = nodal_nu2 = 2 for the upstream cycle. */
     int nodal_nu1, nodal_nu2;
+    /* cell-centred bottom: 1 (default) = the hierarchy ends at the first single-box level of <= 8^3 cells, solved by one single-workgroup
+     * device launch (BiCGStab to bottom_reltol + nub sweeps, no host synchronisation); 0 = coarsen to min_width, host-driven BiCGStab
+     * (amrex::MLMG's shape).  Same converged solution. */
+    int device_bottom;
 } iamrx_mg_opts;
 
 typedef struct iamrx_mg_stats {

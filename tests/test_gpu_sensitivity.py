@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = {
     "upstream nodal cycle (4 sweeps, 2+2)": dict(nodal_sweeps=4, nodal_nu1=2, nodal_nu2=2),
+    "host-driven BiCGStab on the 2^3 level (upstream hierarchy)": dict(device_bottom=0),
     "nodal 1 sweep, 2+2": dict(nodal_sweeps=1, nodal_nu1=2, nodal_nu2=2),
     "nodal Jacobi smoother": dict(nodal_smoother=2, nodal_sweeps=4, nodal_nu1=2, nodal_nu2=2),
     "GSRB omega 1.0": dict(omega=1.0),
