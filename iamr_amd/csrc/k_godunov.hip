@@ -4,7 +4,10 @@
 // and HydroUtils::ComputeFluxesOnBoxFromState / ComputeDivergence / ComputeConvectiveTerm
 // (Source/NavierStokesBase.cpp:4701-4842), SURVEY a3 / a8.
 //
-// MI355X-first structure (NOT the reference's ~20 scratch arrays per box):
+// MI355X-first structure (NOT the reference's ~20 scratch arrays per box).  PLM, the default: ONE fused z-marching launch per
+// operation -- k_god_z (advection: edge states, fluxes, aofs) and k_pred_z (ExtrapVelToFaces) further down: the z-stencil of a
+// column in registers, every intermediate of the corner-transport scheme in LDS ring planes, nothing but inputs and results in HBM.
+// PPM (and IAMRX_GODUNOV_Z=0, the reference of tests/test_gpu_godunov_fused.py): the multi-pass kernels
 //   pass 1  k_trace   : per face of each direction (transverse grown by 1): 4th-order limited slopes are
 //                       evaluated in registers, the two traced states are upwinded at once ->
 //                       advective velocity (predict mode) + single-valued transverse states.
