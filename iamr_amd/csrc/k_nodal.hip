@@ -542,7 +542,8 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
 // one workgroup (periodic images are taken by index wrap, colours are separated by __syncthreads).  Replaces
 // nsweeps*8*(ghost fill + colour kernel) launches whose cost on <= 32^3 levels is pure launch latency.
 // Same arithmetic and ordering as the general path (the wrapped neighbour IS the ghost value).
-__device__ __forceinline__ double node_Ax_wrap(const FabD& x, const FabD& s, const NodeW& w, int im, int i, int ip, int jm, int j, int jp,
+template <class XA>
+__device__ __forceinline__ double node_Ax_wrap(const XA& x, const FabD& s, const NodeW& w, int im, int i, int ip, int jm, int j, int jp,
                                                int km, int k, int kp, double& s0)
 {
     const double smmm = s(im, jm, km), spmm = s(i, jm, km), smpm = s(im, j, km), sppm = s(i, j, km);
@@ -610,6 +611,152 @@ bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, con
     hipLaunchKernelGGL(k_nodal_smooth_small, dim3(1), dim3(1024), 0, Context::get().stream, x.d_tab, rhs.d_tab, sig.d_tab, make_w(g),
                        b.len(0), b.len(1), b.len(2), b.lo[0], b.lo[1], b.lo[2], nsweeps);
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Bottom solve of a small single-box, fully periodic level on the device (the nodal counterpart of k_abec_bottom, k_abec.hip):
+// NodalMG::vcycle's bottom block -- BiCGStab to bottom_reltol as NodalMG::bicgstab drives it from the host, then nub (or, after a
+// breakdown, nuf + nuf) smooth calls of nsweeps 8-colour Gauss-Seidel sweeps -- in ONE launch of ONE workgroup: one unique node per
+// thread, vectors in registers, the vector the operator is applied to in LDS with index wrap (node_Ax_wrap: the wrapped neighbour
+// IS the periodic ghost value), reductions inside the workgroup.  No host synchronisation, no further launches.
+constexpr int NBOT_NT = 512;
+struct LdsNodes {
+    const double* p; int n0, n1, lo0, lo1, lo2;
+    __device__ __forceinline__ double operator()(int i, int j, int k) const { return p[(i - lo0) + n0 * ((j - lo1) + n1 * (k - lo2))]; }
+};
+__device__ __forceinline__ double nb_sum(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NBOT_NT / 64; ++w) s += red[w];
+    return s;
+}
+__device__ __forceinline__ double nb_max(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NBOT_NT / 64; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+__global__ void __launch_bounds__(NBOT_NT) k_nodal_bottom(const FabD* __restrict__ cort, const FabD* __restrict__ rest, const FabD* __restrict__ sigt,
+    NodeW w, int n0, int n1, int n2, int lo0, int lo1, int lo2, int singular, double eps_rel, int maxiter, int nsweeps, int nub, int nuf,
+    int* __restrict__ iters_out)
+{
+    __shared__ double V[NBOT_NT];
+    __shared__ double red[NBOT_NT / 64];
+    const FabD cor = cort[0], res = rest[0], s = sigt[0];
+    const int N = n0 * n1 * n2, tid = threadIdx.x;
+    const bool on = tid < N;
+    const int ri = on ? tid % n0 : 0, rj = on ? (tid / n0) % n1 : 0, rk = on ? tid / (n0 * n1) : 0;
+    const int i = lo0 + ri, j = lo1 + rj, k = lo2 + rk;
+    const int im = lo0 + (ri == 0 ? n0 - 1 : ri - 1), ip = lo0 + (ri == n0 - 1 ? 0 : ri + 1);
+    const int jm = lo1 + (rj == 0 ? n1 - 1 : rj - 1), jp = lo1 + (rj == n1 - 1 ? 0 : rj + 1);
+    const int km = lo2 + (rk == 0 ? n2 - 1 : rk - 1), kp = lo2 + (rk == n2 - 1 ? 0 : rk + 1);
+    const LdsNodes A{V, n0, n1, lo0, lo1, lo2};
+    const double rhs0 = on ? (double)res(i, j, k) : 0.0;
+    double s0 = 1.0;
+    auto apply = [&](double xv) -> double {
+        __syncthreads();
+        if (on) V[tid] = xv;
+        __syncthreads();
+        if (!on) return 0.0;
+        return node_Ax_wrap(A, s, w, im, i, ip, jm, j, jp, km, k, kp, s0);
+    };
+    double bb = rhs0;
+    if (singular) bb -= nb_sum(rhs0, red) / (double)N;
+    if (!on) bb = 0.0;
+    double x = 0.0, r = bb, p = 0.0, v = 0.0;
+    const double rh = r;
+    const double rnorm0 = nb_max(fabs(r), red);
+    double rnorm = rnorm0;
+    int ret = 0, nit = 0;
+    if (rnorm0 != 0.0) {
+        double rho_1 = 0.0, alph = 0.0, omg = 0.0;
+        for (nit = 1; nit <= maxiter; ++nit) {
+            const double rho = nb_sum(rh * r, red);
+            if (rho == 0.0) { ret = 1; break; }
+            if (nit == 1) p = r;
+            else {
+                const double beta = (rho / rho_1) * (alph / omg);
+                p = p - omg * v;
+                p = r + beta * p;
+            }
+            v = apply(p);
+            const double rhTv = nb_sum(rh * v, red);
+            if (rhTv != 0.0) alph = rho / rhTv; else { ret = 2; break; }
+            x = x + alph * p;
+            const double sv = r - alph * v;
+            rnorm = nb_max(fabs(sv), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            const double t = apply(sv);
+            const double tt = nb_sum(t * t, red), ts = nb_sum(t * sv, red);
+            if (tt != 0.0) omg = ts / tt; else { ret = 3; break; }
+            x = x + omg * sv;
+            r = sv - omg * t;
+            rnorm = nb_max(fabs(r), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            if (omg == 0.0) { ret = 4; break; }
+            rho_1 = rho;
+        }
+        if (ret == 0 && rnorm > eps_rel * rnorm0) ret = 8;
+        if (!((ret == 0 || ret == 8) && rnorm < rnorm0)) x = 0.0;
+    }
+    if (tid == 0 && iters_out) atomicAdd(iters_out, nit);
+    int ncalls = ret == 0 ? nub : nuf;
+    if (ret != 0) { x = 0.0; ncalls += nuf; }
+    __syncthreads();
+    if (on) V[tid] = x;
+    __syncthreads();
+    for (int sw = 0; sw < ncalls * nsweeps; ++sw)
+        for (int c = 0; c < 8; ++c) {
+            const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+            if (on && (i & 1) == cx && (j & 1) == cy && (k & 1) == cz) {
+                const double Ax = node_Ax_wrap(A, s, w, im, i, ip, jm, j, jp, km, k, kp, s0);
+                x += (rhs0 - Ax) / s0;
+                V[tid] = x;         // nodes of one colour are not neighbours of each other
+            }
+            __syncthreads();
+        }
+    if (on) cor(i, j, k) = x;
+    __syncthreads();
+    // periodic duplicates (index n) take the owner's value; ghosts are filled by the caller's FillBoundary
+    const int m0 = n0 + 1, m1 = n1 + 1, m2 = n2 + 1;
+    for (int idx = tid; idx < m0 * m1 * m2; idx += NBOT_NT) {
+        const int qi = idx % m0, q = idx / m0;
+        const int qj = q % m1, qk = q / m1;
+        if (qi == n0 || qj == n1 || qk == n2)
+            cor(lo0 + qi, lo1 + qj, lo2 + qk) = V[(qi == n0 ? 0 : qi) + n0 * ((qj == n1 ? 0 : qj) + n1 * (qk == n2 ? 0 : qk))];
+    }
+}
+
+bool nodal_bottom_device_ok(const Geometry& g, const Layout& l)
+{
+    static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
+    if (!enabled || l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    const BoxD& b = l.boxes[0];
+    long cells = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (!g.periodic[d] || b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || b.len(d) < 2) return false;
+        cells *= b.len(d);
+    }
+    return cells <= NBOT_NT;
+}
+
+void nodal_bottom_solve(const Geometry& g, MultiFab& cor, const MultiFab& res, const MultiFab& sig, bool singular, double eps_rel, int maxiter,
+                        int nsweeps, int nub, int nuf, int* d_iters)
+{
+    const Layout& l = *cor.layout;
+    IAMRX_ASSERT(nodal_bottom_device_ok(g, l));
+    const BoxD& b = l.boxes[0];
+    hipLaunchKernelGGL(k_nodal_bottom, dim3(1), dim3(NBOT_NT), 0, Context::get().stream, cor.d_tab, res.d_tab, sig.d_tab, make_w(g),
+                       b.len(0), b.len(1), b.len(2), b.lo[0], b.lo[1], b.lo[2], singular ? 1 : 0, eps_rel, maxiter, nsweeps, nub, nuf, d_iters);
 }
 
 // weighted Jacobi: x_new = x + (2/3) (rhs - A x)/s0 ; tmp holds x_new, then copied back by the caller

@@ -29,6 +29,15 @@ static bool nodal_small()
     return v == 1;
 }
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
+bool nodal_bottom_device_ok(const Geometry& g, const Layout& l);
+void nodal_bottom_solve(const Geometry& g, MultiFab& cor, const MultiFab& res, const MultiFab& sig, bool singular, double eps_rel, int maxiter,
+                        int nsweeps, int nub, int nuf, int* d_iters);
+static int* nodal_bottom_iters_dev()
+{
+    static int* d = nullptr;
+    if (!d) { IAMRX_HIP_CHECK(hipMalloc(&d, sizeof(int))); IAMRX_HIP_CHECK(hipMemset(d, 0, sizeof(int))); }
+    return d;
+}
 
 NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const MGOpts& o) : m_g(g), m_bc(bc_in), m_o(o)
 {
@@ -48,6 +57,8 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
     m_lev[0].layout = std::move(layout);
     while ((int)m_lev.size() <= m_o.max_coarsening_level) {
         Level& f = m_lev.back();
+        // a fully periodic single box of at most 8^3 cells is solved by the single-workgroup device bottom solver (k_nodal_bottom)
+        if (m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only && nodal_bottom_device_ok(f.g, *f.layout)) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
@@ -273,6 +284,12 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
     return ret;
 }
 
+bool NodalMG::bottom_on_device()
+{
+    Level& B = m_lev.back();
+    return m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only && !B.dmask() && nodal_bottom_device_ok(B.g, *B.layout);
+}
+
 void NodalMG::vcycle(MGStats& st)
 {
     const int nl = (int)m_lev.size();
@@ -296,6 +313,12 @@ void NodalMG::vcycle(MGStats& st)
         B.cor.setVal(0.0);
         if (m_o.bottom_smoother_only) {
             for (int i = 0; i < m_o.nuf; ++i) smooth(l, B.cor, B.res);
+        } else if (bottom_on_device()) {
+            long nunk = 1;
+            for (int d = 0; d < 3; ++d) nunk *= B.g.domain.len(d);
+            const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+            nodal_bottom_solve(B.g, B.cor, B.res, B.sig, m_singular, m_o.bottom_reltol, maxiter, m_o.nodal_sweeps, m_o.nub, m_o.nuf,
+                               nodal_bottom_iters_dev());
         } else {
             MultiFab rb(B.layout, node_type(), 1, 0);
             MultiFab::Copy(rb, B.res, 0, 0, 1, 0);
@@ -357,6 +380,8 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     if (m_o.verbose) printf("iamrx nodal MLMG: rhs %.6e resid0 %.6e levels %d (fused sweep %d, single-workgroup coarse smoother %d, ghost width %d)\n",
                             st.rhsnorm0, st.resnorm0, st.nlevels, (int)nodal_fused(), (int)nodal_small(), L0.cor.ngrow);
     double vc_ms = 0.0;
+    const bool bdev = bottom_on_device();
+    if (bdev) IAMRX_HIP_CHECK(hipMemsetAsync(nodal_bottom_iters_dev(), 0, sizeof(int), ctx.stream));
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
     else {
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
@@ -379,6 +404,12 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx nodal MLMG: failed to converge after max_iters");
     }
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
+    if (bdev && st.iters > 0) {
+        int h = 0;
+        IAMRX_HIP_CHECK(hipMemcpyAsync(&h, nodal_bottom_iters_dev(), sizeof(int), hipMemcpyDeviceToHost, ctx.stream));
+        ctx.sync();
+        st.bottom_iters_total = h;
+    }
     fillbc(0, phi);
     return st;
 }

@@ -157,7 +157,8 @@ def geom(n, problo=(0.0, 0.0, 0.0), probhi=(1.0, 1.0, 1.0), periodic=(1, 1, 1)):
 # amrex::MLNodeLaplacian / MLMG's V-cycle shape (4 Gauss-Seidel sweeps per smooth call, nu1 = nu2 = 2), which the oracle restates.  The
 # product's default is a shorter cycle (iamrx_mg_opts: 2 sweeps, 1 + 1 calls; same converged solution); tests that compare iterates or
 # iteration counts with the oracle ask the product for the upstream shape.
-UPSTREAM_NODAL_CYCLE = dict(nodal_sweeps=4, nodal_nu1=2, nodal_nu2=2)
+# upstream's V-cycle shape and hierarchy (coarsened to 2^3, host-driven BiCGStab there): what the oracle runs -> equal iteration counts
+UPSTREAM_NODAL_CYCLE = dict(nodal_sweeps=4, nodal_nu1=2, nodal_nu2=2, device_bottom=0)
 
 
 def mg_opts(**kw):

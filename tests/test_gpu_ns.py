@@ -59,6 +59,15 @@ def test_nodal_operator_and_projection(orc, gpu):
     assert st.converged == 1 and st.iters == st_o.iters
     pg = p_d.gather_valid(n)[..., 0]; pr = p_o.valid(n, orc.NODE)[..., 0]
     assert np.abs((pg - pg.mean()) - (pr - pr.mean())).max() <= 1e-9 * np.abs(pr).max()
+    # the default hierarchy ends at 8^3 with the single-workgroup device bottom solver (k_nodal_bottom): same projection
+    vel2_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel2_d.set_from_global(vel.a, vel.lo)
+    p2_d = lib.MultiFab(lay, lib.NODE, 1, 1); p2_d.setval(0.0)
+    kw = dict(orc.UPSTREAM_NODAL_CYCLE); kw["device_bottom"] = 1
+    st2 = N.nodal_projection(g_d, vel2_d, 0, p2_d, sig_d, 0, opts=lib.mg_opts(**kw))
+    assert st2.converged == 1 and st2.iters <= st_o.iters + 1 and (st2.nlevels < st.nlevels or n[0] <= 8)
+    p2 = p2_d.gather_valid(n)[..., 0]
+    assert np.abs((p2 - p2.mean()) - (pr - pr.mean())).max() <= 1e-9 * np.abs(pr).max()
+    assert np.abs(vel2_d.gather_valid(n) - v_o.valid(n)).max() <= 1e-9
     vg = vel_d.gather_valid(n); vr = v_o.valid(n)
     assert np.abs(vg - vr).max() <= 1e-9 * np.abs(vr).max()
     # Gp = grad(phi) (compGrad) consistent with the velocity update: vel_new = vel - sig * Gp
