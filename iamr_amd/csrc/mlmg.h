@@ -108,6 +108,7 @@ private:
     bool m_tensor_eta = false;
     bool m_singular = false;
     bool m_bottom_dev = false;    // the coarsest level is solved by k_abec_bottom (one single-workgroup launch, no host synchronisation)
+    double m_dd_rho = 0.0;        // estimated contraction of one red-black sweep of a diagonally dominant operator (prepare())
     int m_dd_sweeps = 0;          // > 0: diagonally dominant operator solved by sweeps of the finest level only (prepare())
     bool m_cf = false;
     const MultiFab* m_crse = nullptr;

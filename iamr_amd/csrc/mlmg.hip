@@ -76,6 +76,11 @@ void CellMG::prepare()
         q *= m_beta * bmax;
         const double jac = ainv < 1.e299 ? q / (m_alpha / ainv + q) : 1.0;
         if (jac < 0.2) m_dd_sweeps = jac < 0.05 ? 2 : (jac < 0.12 ? 3 : 4);
+        // red-black Gauss-Seidel contracts by about the square of the Jacobi factor per sweep: solve() sizes every cycle with it
+        m_dd_rho = m_dd_sweeps > 0 ? std::max(jac * jac, 1.e-6) : 0.0;
+        static const int dd_force = [] { const char* e = getenv("IAMRX_MG_DD_SWEEPS"); return e ? atoi(e) : 0; }();
+        if (m_dd_sweeps > 0 && dd_force > 0) { m_dd_sweeps = dd_force; m_dd_rho = 0.0; }
+        if (m_o.verbose) printf("iamrx MLMG: Jacobi bound %.3e -> %d sweeps per cycle\n", jac, m_dd_sweeps);
     }
     // coarsen while every box is coarsenable (MLLinOp::defineGrids, mg_box_min_width = 2)
     m_lev.resize(1);
@@ -166,6 +171,12 @@ void CellMG::cf_bcval(MultiFab& bcval)
     if (m_tensor) cf_interp_edges(bcval, cpatch, m_lev[0].cfm, m_ratio, m_cgeom);
 }
 
+static double dd_omega()
+{
+    static const double v = [] { const char* e = getenv("IAMRX_MG_DD_OMEGA"); return e ? atof(e) : 1.0; }();
+    return v;
+}
+
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
 {
     AbecCoef c = coef(l);
@@ -174,7 +185,9 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
     const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
     for (int rb = 0; rb < 2; ++rb) {
         if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr);
-        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
+        // diagonally dominant shortcut: plain Gauss-Seidel -- over-relaxation leaves a (1 - omega) = 0.15 floor per sweep on an operator
+        // that is almost its diagonal, where omega = 1 contracts by the square of the Jacobi factor
+        abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_dd_sweeps > 0 ? dd_omega() : m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
                   m_cf ? &m_lev[l].cftab : nullptr);
         skip_fill = false;
     }
@@ -411,6 +424,12 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         for (int iter = 0; iter < maxit; ++iter) {
             if (m_singular) subtract_mean(0, L0.res);
+            if (m_dd_sweeps > 0 && m_dd_rho > 0.0 && st.resnorm > 0.0) {
+                // diagonally dominant operator: as many sweeps as the remaining reduction needs (measured at 256^3, nu dt/h^2 = 0.02:
+                // 4 + 2 sweeps in two cycles instead of 3 x 3 sweeps; the second cycle only removes the lagged cross-term defect)
+                const double need = std::min(0.5, res_target / st.resnorm);
+                m_dd_sweeps = std::min(6, std::max(1, (int)std::ceil(std::log(need) / std::log(m_dd_rho))));
+            }
             ctx.sync();
             auto t0 = std::chrono::steady_clock::now();
             vcycle(st);
