@@ -383,10 +383,13 @@ void CellMG::vcycle(MGStats& st)
 
 void CellMG::apply(MultiFab& out, MultiFab& phi)
 {
-    MultiFab bcval(m_lev[0].layout, cell_type(), m_ncomp, 1);
-    MultiFab::Copy(bcval, phi, 0, 0, m_ncomp, 1);
-    cf_bcval(bcval);
-    applyBC(0, phi, true, &bcval);
+    const Geometry& g0 = m_lev[0].g;
+    if (m_cf || !(g0.periodic[0] && g0.periodic[1] && g0.periodic[2])) {
+        MultiFab bcval(m_lev[0].layout, cell_type(), m_ncomp, 1);
+        MultiFab::Copy(bcval, phi, 0, 0, m_ncomp, 1);
+        cf_bcval(bcval);
+        applyBC(0, phi, true, &bcval);
+    } else applyBC(0, phi, true, nullptr);         // fully periodic, no coarse/fine faces: no boundary data to keep
     abec_residual(m_lev[0].g, coef(0), out, phi, nullptr);
 }
 
@@ -402,14 +405,26 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     st.nlevels = (int)m_lev.size();
     Level& L0 = m_lev[0];
     const int nc = m_ncomp;
-    MultiFab rhs(L0.layout, cell_type(), nc, 0);
-    MultiFab::Copy(rhs, rhs_in, 0, 0, nc, 0);
-    if (m_singular) subtract_mean(0, rhs);
-    MultiFab bcval(L0.layout, cell_type(), nc, 1);
-    MultiFab::Copy(bcval, phi, 0, 0, nc, 1);
-    cf_bcval(bcval);
+    // the right-hand side is only changed (mean removed) for a singular system: everything else solves on the caller's array
+    MultiFab rhs_own;
+    if (m_singular) {
+        rhs_own.define(L0.layout, cell_type(), nc, 0);
+        MultiFab::Copy(rhs_own, rhs_in, 0, 0, nc, 0);
+        subtract_mean(0, rhs_own);
+    }
+    const MultiFab& rhs = m_singular ? rhs_own : rhs_in;
+    // boundary data = the ghost cells of the initial phi (domain faces) and the coarse solution (coarse/fine faces); a fully periodic
+    // level without coarse/fine faces has none
+    const bool has_bcdata = m_cf || !(L0.g.periodic[0] && L0.g.periodic[1] && L0.g.periodic[2]);
+    MultiFab bcval_own;
+    if (has_bcdata) {
+        bcval_own.define(L0.layout, cell_type(), nc, 1);
+        MultiFab::Copy(bcval_own, phi, 0, 0, nc, 1);
+        cf_bcval(bcval_own);
+    }
+    const MultiFab* bcvp = has_bcdata ? &bcval_own : nullptr;
 
-    applyBC(0, phi, true, &bcval);
+    applyBC(0, phi, true, bcvp);
     abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
     st.resnorm0 = L0.res.norm0(0, nc, 0);
     st.rhsnorm0 = rhs.norm0(0, nc, 0);
@@ -436,7 +451,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
             ctx.sync();
             vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
-            applyBC(0, phi, true, &bcval);
+            applyBC(0, phi, true, bcvp);
             abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
             st.resnorm = L0.res.norm0(0, nc, 0);
             st.iters = iter + 1;
@@ -447,7 +462,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx MLMG: failed to converge after max_iters");
     }
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
-    applyBC(0, phi, true, &bcval);
+    applyBC(0, phi, true, bcvp);
     if (m_bottom_dev && st.iters > 0) {
         int h = 0;
         IAMRX_HIP_CHECK(hipMemcpyAsync(&h, bottom_iters_dev(), sizeof(int), hipMemcpyDeviceToHost, ctx.stream));
