@@ -336,6 +336,9 @@ static void floor_small(MultiFab& mf)
 
 void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
 {
+    static const bool cache_on = !(getenv("IAMRX_VISC_CACHE") && atoi(getenv("IAMRX_VISC_CACHE")) == 0);
+    const bool old_state = cache_on && m_in_advance && &Sdata == &S[1 - inew] && visc.ngrow <= 1;
+    if (old_state && m_visc_old_valid) { MultiFab::Copy(visc, m_visc_old, 0, 0, 3, visc.ngrow); return; }
     visc.setVal(1.e40);                                       // NavierStokes.cpp:1982
     if (!is_diffusive_vel()) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 3, 1);
@@ -349,6 +352,11 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
     MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
     visc.FillBoundary(g);
     first_order_extrap(visc);
+    if (old_state && visc.ngrow == 1) {
+        if (!m_visc_old.defined() || m_visc_old.layout.get() != layout.get()) m_visc_old.define(layout, cell_type(), 3, 1);
+        MultiFab::Copy(m_visc_old, visc, 0, 0, 3, 1);
+        m_visc_old_valid = true;
+    }
 }
 
 // NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0): visc = div(beta grad S(time))
@@ -847,7 +855,10 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     if (want_flux) for (int d = 0; d < 3; ++d) { tflux[d].define(layout, face_type(d), 3, 0); tflux[d].setVal(0.0); }
     MultiFab cdata;
     TensorCF cf{&cdata, level > 0 ? &crse->g : nullptr, ratio};
-    if (theta != 1.0) {
+    if (theta != 1.0 && !want_flux && m_visc_old_valid) {
+        // (1 - theta) dt div tau(U^n) from the viscous terms the prediction / advection forcing already evaluated (no fluxes wanted)
+        mf_lincomb(Rhs, (1.0 - theta) * dt_, m_visc_old, 0.0, m_visc_old, 0, 3, 0);
+    } else if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 3, 1);
         fillpatch(Soln0, So, Xvel, 3, bc_vel);
         if (level > 0) crse_state_at(cdata, st_old, Xvel, 3);                 // crsedata at prev_time (Diffusion.cpp:733-744)
@@ -1023,6 +1034,7 @@ void NavierStokes::initial_sync_project(double dt_)
 double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
 {
     advance_setup(dt_, iteration_, ncycle_);
+    m_in_advance = true; m_visc_old_valid = false;
     const double dt_test = predict_velocity(dt_);
     mac_project(dt_);
     static const bool fused_adv = !(getenv("IAMRX_FUSED_ADVECTION") && atoi(getenv("IAMRX_FUSED_ADVECTION")) == 0);
@@ -1040,6 +1052,7 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
         level_project(dt_);
         if (level > 0 && iteration == 1) p_avg.setVal(0.0);      // :670-671
     }
+    m_in_advance = false; m_visc_old_valid = false;
     return dt_test;
 }
 

@@ -216,6 +216,10 @@ private:
     void crse_scalar_at(MultiFab& out, double t, bool over_rho);   // the coarse tracer (divided by the coarse density: rho_flag 2)
     double state_time(const MultiFab& Sdata) const { return &Sdata == &S[1 - inew] ? st_old : st_new; }
     const MultiFab& cf_mask();                 // cf_build_mask of the level (2 ghost cells), level > 0
+    // div tau(U^n) of the running advance: getViscTerms(prev_time) is asked for by the velocity prediction, by the advection forcing and
+    // (times (1 - theta) dt) by the Crank-Nicolson right-hand side -- one tensor apply instead of three (valid only inside advance())
+    MultiFab m_visc_old;
+    bool m_visc_old_valid = false, m_in_advance = false;
     MultiFab m_cf_mask;
     MultiFab m_mac_phi_prev, m_mac_phi_prev2;  // initial guess of the next MAC solve (last two potentials)
     bool m_have_mac_prev = false, m_have_mac_prev2 = false;
