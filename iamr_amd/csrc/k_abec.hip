@@ -585,8 +585,10 @@ __global__ void __launch_bounds__(BOT_NT) k_abec_bottom(BoxD b, const FabD* __re
 bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp)
 {
     static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
-    if (!enabled || ncomp != 1 || nbc != 1 || l.boxes.size() != 1 || l.nlocal() != 1) return false;
-    const BoxD b = l.lbox(0);
+    // the answer must be the same on every rank (it decides the depth of the hierarchy): global information only.  A rank that does not
+    // own the box has nothing to do in the bottom solve (no collectives in it)
+    if (!enabled || ncomp != 1 || nbc != 1 || l.boxes.size() != 1) return false;
+    const BoxD b = l.boxes[0];
     for (int d = 0; d < 3; ++d) {
         if (b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || b.len(d) > 8) return false;
         if (g.periodic[d]) continue;
@@ -603,6 +605,7 @@ void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, cons
 {
     const Layout& l = *cor.layout;
     IAMRX_ASSERT(abec_bottom_device_ok(g, l, &bc, 1, cor.ncomp) && cor.ngrow >= 1);
+    if (l.nlocal() == 0) return;
     BotBC bb;
     for (int d = 0; d < 3; ++d) {
         bb.per[d] = g.periodic[d];
@@ -614,7 +617,7 @@ void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, cons
         }
     }
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
-    hipLaunchKernelGGL(k_abec_bottom, dim3(1), dim3(BOT_NT), 0, Context::get().stream, l.lbox(0), cor.d_tab, res.d_tab,
+    hipLaunchKernelGGL(k_abec_bottom, dim3(1), dim3(BOT_NT), 0, Context::get().stream, l.boxes[0], cor.d_tab, res.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, c.alpha, dhx, dhy, dhz, bb,
                        make_gsrb_bc(g, &bc, 1), singular ? 1 : 0, eps_rel, maxiter, nub, nuf, omega, d_iters);
 }

@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(NBOT_NT) k_nodal_bottom(const FabD* __restrict
 bool nodal_bottom_device_ok(const Geometry& g, const Layout& l)
 {
     static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
-    if (!enabled || l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    if (!enabled || l.boxes.size() != 1) return false;      // global information only: every rank must build the same hierarchy
     const BoxD& b = l.boxes[0];
     long cells = 1;
     for (int d = 0; d < 3; ++d) {
@@ -754,6 +754,7 @@ void nodal_bottom_solve(const Geometry& g, MultiFab& cor, const MultiFab& res, c
 {
     const Layout& l = *cor.layout;
     IAMRX_ASSERT(nodal_bottom_device_ok(g, l));
+    if (l.nlocal() == 0) return;
     const BoxD& b = l.boxes[0];
     hipLaunchKernelGGL(k_nodal_bottom, dim3(1), dim3(NBOT_NT), 0, Context::get().stream, cor.d_tab, res.d_tab, sig.d_tab, make_w(g),
                        b.len(0), b.len(1), b.len(2), b.lo[0], b.lo[1], b.lo[2], singular ? 1 : 0, eps_rel, maxiter, nsweeps, nub, nuf, d_iters);
