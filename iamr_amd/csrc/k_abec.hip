@@ -370,15 +370,30 @@ void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_i
 }
 
 // ---------------------------------------------------------------------------- residual / apply
+// max norm of what a residual launch wrote, as a by-product: wave maximum -> one atomicMax per wavefront on the bit pattern of the
+// (non-negative, NaN -> +inf) value.  Order independent, hence deterministic.
+__device__ __forceinline__ void norm_commit(double mx, unsigned long long* out)
+{
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) {
+        // the running maximum only grows: a plain read filters out almost every wavefront before the atomic (262 k atomics on one address
+        // cost 130 us per 256^3 launch without it)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
+__device__ __forceinline__ double norm_term(double v) { const double a = fabs(v); return a == a ? a : INFINITY; }
+
 __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ outt, const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc, int tens)
+    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc, int tens, unsigned long long* __restrict__ normout)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
     int i, j, k0, k1;
-    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    double mx = 0.0;
+    if (!tile_ijk(t, b, i, j, k0, k1)) { if (normout) norm_commit(mx, normout); return; }
     const FabD out = outt[fab], phi = phit[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
     const bool has_rhs = rhst != nullptr;
     FabD rhs; if (has_rhs) rhs = rhst[fab];
@@ -395,25 +410,44 @@ __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __r
                 - dhx * ((bX(i + 1, j, k, nb) * sx) * (phi(i + 1, j, k, n) - p0) - (bX(i, j, k, nb) * sx) * (p0 - phi(i - 1, j, k, n)))
                 - dhy * ((bY(i, j + 1, k, nb) * sy) * (phi(i, j + 1, k, n) - p0) - (bY(i, j, k, nb) * sy) * (p0 - phi(i, j - 1, k, n)))
                 - dhz * ((bZ(i, j, k + 1, nb) * sz) * (pp - p0) - (bZ(i, j, k, nb) * sz) * (p0 - pm));
-            out(i, j, k, n) = has_rhs ? rhs(i, j, k, n) - y : y;
+            const double o = has_rhs ? rhs(i, j, k, n) - y : y;
+            out(i, j, k, n) = o;
+            mx = fmax(mx, norm_term(o));
             pm = p0; p0 = pp;
         }
     }
+    if (normout) norm_commit(mx, normout);
 }
 
-void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);   // k_tensor.hip
 
-void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs)
+// norm_out != null: *norm_out = max norm of `out` over all components and ranks, computed by the launch that writes it last (saves
+// the separate norm pass of every multigrid iteration)
+void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs, double* norm_out)
 {
-    if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
-    const Layout& l = *phi.layout;
-    Tiling t = level_tiling(l, cell_type(), 0, 8);
-    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
-    hipLaunchKernelGGL(k_abec_residual, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
-                       rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                       c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta);
-    if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0);
+    static unsigned long long* d_norm = nullptr;
+    if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, sizeof(unsigned long long)));
+    if (phi.nlocal() > 0) {
+        const Layout& l = *phi.layout;
+        Tiling t = level_tiling(l, cell_type(), 0, 8);
+        const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+        if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        hipLaunchKernelGGL(k_abec_residual, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
+                           rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                           c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta, (norm_out && !c.tensor) ? d_norm : nullptr);
+        if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0, norm_out ? d_norm : nullptr);
+    }
+    if (norm_out) {
+        double v = 0.0;
+        if (phi.nlocal() > 0) {
+            unsigned long long bits = 0;
+            IAMRX_HIP_CHECK(hipMemcpyAsync(&bits, d_norm, sizeof(bits), hipMemcpyDeviceToHost, ctx.stream));
+            ctx.sync();
+            std::memcpy(&v, &bits, sizeof(v));
+        }
+        if (!phi.layout->replicated) ctx.comm->allreduce(&v, 1, ReduceOp::Max);
+        *norm_out = v;
+    }
 }
 
 // ---------------------------------------------------------------------------- bottom solve of a small level on the device

@@ -55,14 +55,27 @@ __device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i
     }
 }
 
+// max norm of the launch's output as a by-product (see norm_commit, k_abec.hip)
+__device__ __forceinline__ void tnorm_commit(double mx, unsigned long long* out)
+{
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) {
+        // the running maximum only grows: a plain read filters out almost every wavefront before the atomic (262 k atomics on one address
+        // cost 130 us per 256^3 launch without it)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
+
 template <bool ETA1>
 __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ outt,
     const FabD* __restrict__ vt, const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
-    double dxi, double dyi, double dzi, double sbeta)
+    double dxi, double dyi, double dzi, double sbeta, unsigned long long* __restrict__ normout)
 {
     const int fab = blockIdx.y;
     int i, j, k0, k1;
-    if (!tile_ijk(t, boxes[fab], i, j, k0, k1)) return;
+    double mx = 0.0;
+    if (!tile_ijk(t, boxes[fab], i, j, k0, k1)) { if (normout) tnorm_commit(mx, normout); return; }
     const FabD out = outt[fab], v = vt[fab], ex = ext[fab], ey = eyt[fab], ez = ezt[fab];
     double fzl[3];
     cross_flux<2, ETA1>(v, ez, i, j, k0, dxi, dyi, dzi, fzl);
@@ -74,25 +87,29 @@ __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __re
         cross_flux<1, ETA1>(v, ey, i, j + 1, k, dxi, dyi, dzi, fyh);
         cross_flux<2, ETA1>(v, ez, i, j, k + 1, dxi, dyi, dzi, fzh);
         for (int n = 0; n < 3; ++n) {
-            out(i, j, k, n) += sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
+            const double o = out(i, j, k, n) + sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
+            out(i, j, k, n) = o;
+            const double a = fabs(o);
+            mx = fmax(mx, a == a ? a : INFINITY);
             fzl[n] = fzh[n];
         }
     }
+    if (normout) tnorm_commit(mx, normout);
 }
 
 // out += sign * beta * div(cross fluxes)
-void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign)
+void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign, unsigned long long* normout)
 {
     if (out.nlocal() == 0) return;
     IAMRX_ASSERT(vel.ncomp == 3 && c.b[0]->ncomp == (c.tensor_eta ? 1 : 3));
     Tiling t = level_tiling(*out.layout, cell_type(), 0, 8);
     if (c.tensor_eta) {
         hipLaunchKernelGGL(k_tensor_cross<true>, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
-                           c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta);
+                           c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta, normout);
         return;
     }
     hipLaunchKernelGGL(k_tensor_cross<false>, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
-                       c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta);
+                       c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta, normout);
 }
 
 // MLTensorOp::setShearViscosity: b_d(comp) = eta_d * (comp == d ? 4/3 : 1), bulk viscosity 0

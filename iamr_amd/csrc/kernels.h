@@ -72,7 +72,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,
                      const DomainBC* bcs, int nbc);
 // out = rhs - L(phi)  (rhs == nullptr: out = L(phi))
-void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs);
+void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs, double* norm_out = nullptr);
 // bottom solve (BiCGStab + post-smoothing, CellMG::bottom_solve) of a single-box level of at most 8^3 cells in one single-workgroup launch
 bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp);
 void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
@@ -124,7 +124,7 @@ void nodal_mknewu(const Geometry& g, MultiFab* vel, int vcomp, const MultiFab& p
 void tensor_bcoef(MultiFab& b3, const MultiFab& eta, int dir);
 // extensive face fluxes of the tensor operator (Diffusion::computeExtensiveFluxes): fac * area * (-eta (4/3) du_n/dx_d + cross terms)
 void tensor_extensive_flux(const Geometry& g, const MultiFab& vel, const MultiFab* const eta[3], MultiFab* const flux[3], double fac, bool add);
-void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign);
+void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign, unsigned long long* normout = nullptr);
 void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 
 }  // namespace iamrx

@@ -425,8 +425,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     const MultiFab* bcvp = has_bcdata ? &bcval_own : nullptr;
 
     applyBC(0, phi, true, bcvp);
-    abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
-    st.resnorm0 = L0.res.norm0(0, nc, 0);
+    abec_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm0);      // the residual launch reduces its own max norm
     st.rhsnorm0 = rhs.norm0(0, nc, 0);
     const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
     const double res_target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
@@ -452,8 +451,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
             vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
             applyBC(0, phi, true, bcvp);
-            abec_residual(L0.g, coef(0), L0.res, phi, &rhs);
-            st.resnorm = L0.res.norm0(0, nc, 0);
+            abec_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);
             st.iters = iter + 1;
             if (m_o.verbose) printf("iamrx MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, st.resnorm, st.resnorm / max_norm);
             if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
