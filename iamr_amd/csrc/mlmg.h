@@ -69,7 +69,7 @@ public:
     int nlevels() const { return (int)m_lev.size(); }
     AbecCoef coef(int l) const;
     const Geometry& geom(int l) const { return m_lev[l].g; }
-    void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval);
+    void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, bool corners = true);
     void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill);
     // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
     void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill);

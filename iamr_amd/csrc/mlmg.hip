@@ -142,7 +142,9 @@ void CellMG::prepare()
 }
 
 
-void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
+// corners: also the edge / corner ghost cells that only the tensor cross terms read (not needed in front of a smoothing pass: the
+// smoother acts on the 7-point part)
+void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, bool corners)
 {
     phi.FillBoundary(m_lev[l].g);
     // order: domain faces, coarse/fine faces (+ the frozen edge / corner values of the tensor operator), then the edge / corner cells
@@ -151,7 +153,7 @@ void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval)
     else   // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference Source/Diffusion.cpp:724-731)
         for (int n = 0; n < m_ncomp; ++n) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
     if (m_cf) cf_fill_ghosts(phi, m_lev[l].cfm, m_lev[l].cftab, inhomog, bcval, m_tensor);
-    if (m_tensor) {
+    if (m_tensor && corners) {
         if (m_bcn.size() == 1) fill_tensor_corners(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
         else for (int n = 0; n < m_ncomp; ++n) fill_tensor_corners(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
     }
@@ -184,7 +186,7 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
     // one box spanning a fully periodic domain: the kernel reads the periodic images from the valid cells, no ghost fills
     const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
     for (int rb = 0; rb < 2; ++rb) {
-        if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr);
+        if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr, false);
         // diagonally dominant shortcut: plain Gauss-Seidel -- over-relaxation leaves a (1 - omega) = 0.15 floor per sweep on an operator
         // that is almost its diagonal, where omega = 1 contracts by the square of the Jacobi factor
         abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_dd_sweeps > 0 ? dd_omega() : m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
