@@ -6,14 +6,15 @@
 #include "kernels.h"
 #include "launch.h"
 #include <vector>
+#include <cstdlib>
 #include <algorithm>
 
 namespace iamrx {
 
 // cross flux on the d-face (i,j,k) for component n.  eta_n = b_d(comp d) * 3/4 (normal), eta_t = b_d(comp != d)
 // ETA1: eta holds the 1-component face viscosity (b_d(comp) is formed here exactly as tensor_bcoef stores it)
-template <int D, bool ETA1>
-__device__ __forceinline__ void cross_flux(const FabD& v, const FabD& eta, int i, int j, int k, double dxi, double dyi, double dzi, double f[3])
+template <int D, bool ETA1, class VA>
+__device__ __forceinline__ void cross_flux(const VA& v, const FabD& eta, int i, int j, int k, double dxi, double dyi, double dzi, double f[3])
 {
     constexpr double twoThirds = 2.0 / 3.0;
     const double e1 = ETA1 ? eta(i, j, k, 0) : 0.0;
@@ -97,11 +98,115 @@ __global__ void __launch_bounds__(256) k_tensor_cross(Tiling t, const BoxD* __re
     if (normout) tnorm_commit(mx, normout);
 }
 
+// LDS-staged form of k_tensor_cross for levels with at least one full tile: a workgroup owns a TX x TY column of cells and marches
+// through a chunk of planes with a three-plane ring of the 3-component velocity tile (one ghost cell in x and y) in LDS; the five face
+// fluxes of a cell read their 80 velocity values from LDS instead of L1 / L2 (k_tensor_cross: 0.62 ms per 256^3 launch, load-issue
+// bound).  Same expressions (cross_flux), same results.
+template <int TX, int TY>
+struct LdsVel {
+    static constexpr int W = TX + 2, H = TY + 2, PS = W * H;
+    const double *pm, *p0, *pp;      // planes kc-1, kc, kc+1 (3 components each, component stride PS)
+    int kc, i0, j0;
+    __device__ __forceinline__ double operator()(int i, int j, int k, int n) const
+    {
+        const int d = k - kc;
+        const double* p = d < 0 ? pm : (d > 0 ? pp : p0);
+        return p[(i - i0) + W * (j - j0) + PS * n];
+    }
+};
+
+template <bool ETA1, int TX, int TY>
+__global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ outt,
+    const FabD* __restrict__ vt, const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
+    double dxi, double dyi, double dzi, double sbeta, unsigned long long* __restrict__ normout, int ntx, int nty, int nkc, int kcs, int xcd_cnt)
+{
+    constexpr int NT = TX * TY, W = TX + 2, H = TY + 2, PS = W * H;
+    __shared__ double V[3][3 * PS];
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    double mx = 0.0;
+    int bid = blockIdx.x;
+    bool live = true;
+    if (xcd_cnt > 0) {
+        bid = (bid & 7) * xcd_cnt + (bid >> 3);          // XCD-aware order, see make_tiling
+        if (bid >= ntx * nty * nkc) live = false;
+    }
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, kci = r1 / nty;
+    const int tx0 = b.lo[0] + tix * TX, ty0 = b.lo[1] + tiy * TY, k0 = b.lo[2] + kci * kcs;
+    if (tx0 > b.hi[0] || ty0 > b.hi[1] || k0 > b.hi[2]) live = false;
+    if (!live) { if (normout) tnorm_commit(mx, normout); return; }
+    const int k1 = min(k0 + kcs - 1, b.hi[2]);
+    const int tid = threadIdx.x;
+    const int i = tx0 + tid % TX, j = ty0 + tid / TX;
+    const bool on = i <= b.hi[0] && j <= b.hi[1];
+    const FabD out = outt[fab], v = vt[fab], ex = ext[fab], ey = eyt[fab], ez = ezt[fab];
+    const int vhx = min(tx0 + TX, b.hi[0] + 1), vhy = min(ty0 + TY, b.hi[1] + 1);      // last staged column / row (ghost included)
+    auto stage = [&](int k) {
+        double* dst = V[((k % 3) + 3) % 3];
+        for (int e = tid; e < PS; e += NT) {
+            const int ii = tx0 - 1 + e % W, jj = ty0 - 1 + e / W;
+            if (ii <= vhx && jj <= vhy) {
+                const long o = v.off(ii, jj, k);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dst[e + PS * n] = v.gp()[o + v.cs * n];
+            }
+        }
+    };
+    stage(k0 - 1);
+    stage(k0);
+    __syncthreads();
+    LdsVel<TX, TY> a;
+    a.i0 = tx0 - 1; a.j0 = ty0 - 1;
+    double fzl[3] = {0., 0., 0.};
+    {
+        a.kc = k0; a.pm = V[((k0 - 1) % 3 + 3) % 3]; a.p0 = V[(k0 % 3 + 3) % 3]; a.pp = a.p0;
+        if (on) cross_flux<2, ETA1>(a, ez, i, j, k0, dxi, dyi, dzi, fzl);
+    }
+    for (int k = k0; k <= k1; ++k) {
+        stage(k + 1);
+        __syncthreads();
+        a.kc = k; a.pm = V[((k - 1) % 3 + 3) % 3]; a.p0 = V[(k % 3 + 3) % 3]; a.pp = V[((k + 1) % 3 + 3) % 3];
+        if (on) {
+            double fxl[3], fxh[3], fyl[3], fyh[3], fzh[3];
+            cross_flux<0, ETA1>(a, ex, i, j, k, dxi, dyi, dzi, fxl);
+            cross_flux<0, ETA1>(a, ex, i + 1, j, k, dxi, dyi, dzi, fxh);
+            cross_flux<1, ETA1>(a, ey, i, j, k, dxi, dyi, dzi, fyl);
+            cross_flux<1, ETA1>(a, ey, i, j + 1, k, dxi, dyi, dzi, fyh);
+            cross_flux<2, ETA1>(a, ez, i, j, k + 1, dxi, dyi, dzi, fzh);
+            for (int n = 0; n < 3; ++n) {
+                const double o = out(i, j, k, n) + sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
+                out(i, j, k, n) = o;
+                const double ab = fabs(o);
+                mx = fmax(mx, ab == ab ? ab : INFINITY);
+                fzl[n] = fzh[n];
+            }
+        }
+        __syncthreads();
+    }
+    if (normout) tnorm_commit(mx, normout);
+}
+
 // out += sign * beta * div(cross fluxes)
 void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, double sign, unsigned long long* normout)
 {
     if (out.nlocal() == 0) return;
     IAMRX_ASSERT(vel.ncomp == 3 && c.b[0]->ncomp == (c.tensor_eta ? 1 : 3));
+    const Layout& l = *out.layout;
+    static const bool zm = !(getenv("IAMRX_TENSOR_CROSS_ZM") && atoi(getenv("IAMRX_TENSOR_CROSS_ZM")) == 0);
+    if (zm && l.max_len[0] >= 32 && l.max_len[1] >= 8 && vel.ngrow >= 1) {
+        constexpr int TX = 32, TY = 8;
+        const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+        const int kcs = std::min(32, std::max(4, l.max_len[2] / 8));
+        const int nkc = (l.max_len[2] + kcs - 1) / kcs;
+        const int total = ntx * nty * nkc;
+        const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
+        dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal());
+#define IAMRX_TCZ(E) hipLaunchKernelGGL((k_tensor_cross_zm<E, TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, out.d_tab, vel.d_tab, \
+                       c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta, normout, ntx, nty, nkc, kcs, xcd_cnt)
+        if (c.tensor_eta) IAMRX_TCZ(true); else IAMRX_TCZ(false);
+#undef IAMRX_TCZ
+        return;
+    }
     Tiling t = level_tiling(*out.layout, cell_type(), 0, 8);
     if (c.tensor_eta) {
         hipLaunchKernelGGL(k_tensor_cross<true>, t.grid(), Tiling::block(), 0, Context::get().stream, t, out.layout->d_boxes, out.d_tab, vel.d_tab,
