@@ -788,31 +788,40 @@ void cf_build_mask(const Geometry& g, MultiFab& cfm)
     });
 }
 
-__global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restrict__ boxes, const FabD* __restrict__ phit,
+// grid: x = points of one ghost slab, y = box, z = the six slabs of the one-cell shell around the box (slab 2 d + side: the ghost layer
+// of direction d, transverse ranges grown by one so that edges and corners are covered; a cell on an edge belongs to two or three
+// slabs and receives the same value from each).  The shell is 6 n^2 points, the grown box the kernel used to scan (n + 2)^3.
+__global__ void __launch_bounds__(256) k_cf_fill(const BoxD* __restrict__ boxes, const FabD* __restrict__ phit,
     const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog, int edges)
 {
     const int fab = blockIdx.y;
     const BoxD vb = boxes[fab];
-    BoxD gb = vb;
-    for (int d = 0; d < 3; ++d) { gb.lo[d] -= 1; gb.hi[d] += 1; }
-    int i, j, k0, k1;
-    if (!tile_ijk(t, gb, i, j, k0, k1)) return;
+    const int sd = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int da = sd == 0 ? 1 : 0, db = sd == 2 ? 1 : 2;                // transverse directions, da < db
+    const int na = vb.len(da) + 2, nb = vb.len(db) + 2;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)na * nb) return;
+    int idx3[3];
+    idx3[sd] = side == 0 ? vb.lo[sd] - 1 : vb.hi[sd] + 1;
+    idx3[da] = vb.lo[da] - 1 + (int)(q % na);
+    idx3[db] = vb.lo[db] - 1 + (int)(q / na);
+    const int i = idx3[0], j = idx3[1], k = idx3[2];
     const FabD phi = phit[fab], cfm = cfmt[fab];
-    for (int k = k0; k <= k1; ++k) {
+    {
         const int idx[3] = {i, j, k};
         int d = -1, nout = 0, s = 0;
         for (int e = 0; e < 3; ++e) {
             if (idx[e] < vb.lo[e]) { ++nout; d = e; s = 1; }
             else if (idx[e] > vb.hi[e]) { ++nout; d = e; s = -1; }
         }
-        if (cfm(i, j, k) != 1.0) continue;
+        if (cfm(i, j, k) != 1.0) return;
         if (nout >= 2) {
             // tensor operator: edge / corner coarse-fine ghost cells (read by the cross terms only) hold the coarse data interpolated to
             // the cell centre (cf_interp_edges), frozen during the solve; zero in the correction form
             if (edges) for (int n = 0; n < ncomp; ++n) phi(i, j, k, n) = (inhomog && bcvt) ? (double)bcvt[fab](i, j, k, n) : 0.0;
-            continue;
+            return;
         }
-        if (nout != 1) continue;                               // face-adjacent coarse/fine ghost cells
+        if (nout != 1) return;                               // face-adjacent coarse/fine ghost cells
         const int NX = min(vb.len(d) + 1, tab.maxorder);
         const double* c = tab.c[d][NX - 2];
         for (int n = 0; n < ncomp; ++n) {
@@ -827,9 +836,12 @@ __global__ void __launch_bounds__(256) k_cf_fill(Tiling t, const BoxD* __restric
 void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool inhomog, const MultiFab* bcval, bool edges)
 {
     if (phi.nlocal() == 0) return;
-    Tiling t = level_tiling(*phi.layout, cell_type(), 1, 4);
-    hipLaunchKernelGGL(k_cf_fill, t.grid(), Tiling::block(), 0, Context::get().stream, t, phi.layout->d_boxes, phi.d_tab,
-                       bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0);
+    const Layout& l = *phi.layout;
+    int m[3] = {l.max_len[0] + 2, l.max_len[1] + 2, l.max_len[2] + 2};
+    std::sort(m, m + 3);
+    const long maxpts = (long)m[1] * m[2];                    // the largest slab
+    hipLaunchKernelGGL(k_cf_fill, dim3((unsigned)((maxpts + 255) / 256), (unsigned)l.nlocal(), 6u), dim3(256), 0, Context::get().stream,
+                       l.d_boxes, phi.d_tab, bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0);
 }
 
 // bcval(edge / corner coarse-fine ghost cells) = the coarse data of cpatch interpolated to the cell centre, quadratically in every
