@@ -760,6 +760,198 @@ void nodal_bottom_solve(const Geometry& g, MultiFab& cor, const MultiFab& res, c
                        b.len(0), b.len(1), b.len(2), b.lo[0], b.lo[1], b.lo[2], singular ? 1 : 0, eps_rel, maxiter, nsweeps, nub, nuf, d_iters);
 }
 
+// General form of the device bottom solve: a single box of at most 8^3 cells whose directions are either periodic over the whole
+// domain (unique nodes 0..n-1, index wrap) or bounded (nodes 0..n: Neumann walls by index reflection -- the ghost node -1 IS node 1,
+// nodal_reflect_bc -- and Dirichlet / coarse-fine faces through the level's Dirichlet mask, whose nodes stay zero and never reach
+// outside the box).  sigma is read with its ghost cells (periodic images / mirrored across walls, NodalMG::setSigma).  Weights of the
+// dot products and of the mean: owner_weight's rule (1/2 per Neumann wall a node lies on; k_basic.hip).  Covers the levels of a
+// refined patch and wall-bounded domains (LidDrivenCavity, RayleighTaylor); k_nodal_bottom stays the kernel of the periodic case.
+constexpr int NBG_NT = 1024;
+struct NBotGeom {
+    int m[3];            // unknown nodes per direction
+    int wrap[3];         // periodic over the box
+    int lo[3], n[3];     // low cell index and number of cells of the box
+    int half_lo[3], half_hi[3], dlo[3], dhi[3];     // Neumann walls of the domain and their node indices
+};
+__device__ __forceinline__ double nbg_sum(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NBG_NT / 64; ++w) s += red[w];
+    return s;
+}
+__device__ __forceinline__ double nbg_max(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NBG_NT / 64; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+__global__ void __launch_bounds__(NBG_NT) k_nodal_bottom_g(const FabD* __restrict__ cort, const FabD* __restrict__ rest, const FabD* __restrict__ sigt,
+    const FabD* __restrict__ dmt, NodeW w, NBotGeom G, int singular, double mean_cnt, double eps_rel, int maxiter, int nsweeps, int nub, int nuf,
+    int* __restrict__ iters_out)
+{
+    __shared__ double V[NBG_NT];
+    __shared__ double red[NBG_NT / 64];
+    const FabD cor = cort[0], res = rest[0], sg = sigt[0];
+    const int m0 = G.m[0], m1 = G.m[1], m2 = G.m[2], M = m0 * m1 * m2, tid = threadIdx.x;
+    const bool in = tid < M;
+    const int ri = in ? tid % m0 : 0, rj = in ? (tid / m0) % m1 : 0, rk = in ? tid / (m0 * m1) : 0;
+    const int i = G.lo[0] + ri, j = G.lo[1] + rj, k = G.lo[2] + rk;
+    auto nb = [](int r, int m, int wrap, int dir) {     // relative index of the low / high neighbour: wrap or reflect
+        if (dir < 0) return r == 0 ? (wrap ? m - 1 : 1) : r - 1;
+        return r == m - 1 ? (wrap ? 0 : m - 2) : r + 1;
+    };
+    const int im = nb(ri, m0, G.wrap[0], -1), ip = nb(ri, m0, G.wrap[0], 1);
+    const int jm = nb(rj, m1, G.wrap[1], -1), jp = nb(rj, m1, G.wrap[1], 1);
+    const int km = nb(rk, m2, G.wrap[2], -1), kp = nb(rk, m2, G.wrap[2], 1);
+    const bool masked = in && dmt != nullptr && dmt[0](i, j, k) != 0.0;
+    const bool on = in && !masked;
+    // weight of the node in sums and dot products
+    double wt = on ? 1.0 : 0.0;
+    {
+        const int idx[3] = {i, j, k};
+        for (int d = 0; d < 3; ++d) {
+            if (G.wrap[d]) continue;
+            if (idx[d] == G.lo[d] + G.n[d] && idx[d] != G.dhi[d] + 1) wt = 0.0;       // high face of the box inside the domain (coarse/fine): masked anyway
+            if (G.half_lo[d] && idx[d] == G.dlo[d]) wt *= 0.5;
+            if (G.half_hi[d] && idx[d] == G.dhi[d] + 1) wt *= 0.5;
+        }
+    }
+    // sigma of the eight cells around the node (ghost cells included) and the diagonal
+    double smmm = 0, spmm = 0, smpm = 0, sppm = 0, smmp = 0, spmp = 0, smpp = 0, sppp = 0;
+    if (in) {
+        smmm = sg(i - 1, j - 1, k - 1); spmm = sg(i, j - 1, k - 1); smpm = sg(i - 1, j, k - 1); sppm = sg(i, j, k - 1);
+        smmp = sg(i - 1, j - 1, k); spmp = sg(i, j - 1, k); smpp = sg(i - 1, j, k); sppp = sg(i, j, k);
+    }
+    const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+    auto X = [&](int a, int b, int c) { return V[a + m0 * (b + m1 * c)]; };
+    auto Ax = [&]() -> double {          // node_Ax on the LDS vector (same expression as node_Ax_wrap)
+        double y = X(ri, rj, rk) * s0;
+        y += w.corner * (X(im, jm, km) * smmm + X(ip, jm, km) * spmm + X(im, jp, km) * smpm + X(ip, jp, km) * sppm
+                       + X(im, jm, kp) * smmp + X(ip, jm, kp) * spmp + X(im, jp, kp) * smpp + X(ip, jp, kp) * sppp);
+        y += w.ex * (X(ri, jm, km) * (smmm + spmm) + X(ri, jp, km) * (smpm + sppm) + X(ri, jm, kp) * (smmp + spmp) + X(ri, jp, kp) * (smpp + sppp));
+        y += w.ey * (X(im, rj, km) * (smmm + smpm) + X(ip, rj, km) * (spmm + sppm) + X(im, rj, kp) * (smmp + smpp) + X(ip, rj, kp) * (spmp + sppp));
+        y += w.ez * (X(im, jm, rk) * (smmm + smmp) + X(ip, jm, rk) * (spmm + spmp) + X(im, jp, rk) * (smpm + smpp) + X(ip, jp, rk) * (sppm + sppp));
+        y += w.fx * (X(im, rj, rk) * (smmm + smpm + smmp + smpp) + X(ip, rj, rk) * (spmm + sppm + spmp + sppp));
+        y += w.fy * (X(ri, jm, rk) * (smmm + spmm + smmp + spmp) + X(ri, jp, rk) * (smpm + sppm + smpp + sppp));
+        y += w.fz * (X(ri, rj, km) * (smmm + spmm + smpm + sppm) + X(ri, rj, kp) * (smmp + spmp + smpp + sppp));
+        return y;
+    };
+    auto apply = [&](double xv) -> double {
+        __syncthreads();
+        if (in) V[tid] = xv;
+        __syncthreads();
+        return on ? Ax() : 0.0;
+    };
+    const double rhs0 = on ? (double)res(i, j, k) : 0.0;
+    double bb = rhs0;
+    if (singular) bb -= nbg_sum(wt * rhs0, red) / mean_cnt;
+    if (!on) bb = 0.0;
+    double x = 0.0, r = bb, p = 0.0, v = 0.0;
+    const double rh = r;
+    const double rnorm0 = nbg_max(fabs(r), red);
+    double rnorm = rnorm0;
+    int ret = 0, nit = 0;
+    if (rnorm0 != 0.0) {
+        double rho_1 = 0.0, alph = 0.0, omg = 0.0;
+        for (nit = 1; nit <= maxiter; ++nit) {
+            const double rho = nbg_sum(wt * rh * r, red);
+            if (rho == 0.0) { ret = 1; break; }
+            if (nit == 1) p = r;
+            else {
+                const double beta = (rho / rho_1) * (alph / omg);
+                p = p - omg * v;
+                p = r + beta * p;
+            }
+            v = apply(p);
+            const double rhTv = nbg_sum(wt * rh * v, red);
+            if (rhTv != 0.0) alph = rho / rhTv; else { ret = 2; break; }
+            x = x + alph * p;
+            const double sv = r - alph * v;
+            rnorm = nbg_max(fabs(sv), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            const double t = apply(sv);
+            const double tt = nbg_sum(wt * t * t, red), ts = nbg_sum(wt * t * sv, red);
+            if (tt != 0.0) omg = ts / tt; else { ret = 3; break; }
+            x = x + omg * sv;
+            r = sv - omg * t;
+            rnorm = nbg_max(fabs(r), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            if (omg == 0.0) { ret = 4; break; }
+            rho_1 = rho;
+        }
+        if (ret == 0 && rnorm > eps_rel * rnorm0) ret = 8;
+        if (!((ret == 0 || ret == 8) && rnorm < rnorm0)) x = 0.0;
+    }
+    if (tid == 0 && iters_out) atomicAdd(iters_out, nit);
+    int ncalls = ret == 0 ? nub : nuf;
+    if (ret != 0) { x = 0.0; ncalls += nuf; }
+    __syncthreads();
+    if (in) V[tid] = x;
+    __syncthreads();
+    for (int sw = 0; sw < ncalls * nsweeps; ++sw)
+        for (int c = 0; c < 8; ++c) {
+            const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+            if (on && (i & 1) == cx && (j & 1) == cy && (k & 1) == cz) {
+                x += (rhs0 - Ax()) / s0;
+                V[tid] = x;
+            }
+            __syncthreads();
+        }
+    // all nodes of the box, the periodic duplicates (index n of a wrapped direction) included
+    const int f0 = G.n[0] + 1, f1 = G.n[1] + 1, f2 = G.n[2] + 1;
+    for (int q = tid; q < f0 * f1 * f2; q += NBG_NT) {
+        const int qi = q % f0, qq = q / f0, qj = qq % f1, qk = qq / f1;
+        const int a = (G.wrap[0] && qi == G.n[0]) ? 0 : qi, b = (G.wrap[1] && qj == G.n[1]) ? 0 : qj, c = (G.wrap[2] && qk == G.n[2]) ? 0 : qk;
+        cor(G.lo[0] + qi, G.lo[1] + qj, G.lo[2] + qk) = V[a + m0 * (b + m1 * c)];
+    }
+}
+
+static bool nbg_geom(const Geometry& g, const Layout& l, NBotGeom& G)
+{
+    if (l.boxes.size() != 1) return false;                      // global information only: every rank must build the same hierarchy
+    const BoxD& b = l.boxes[0];
+    long M = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (b.len(d) < 2 || b.len(d) > 8) return false;
+        G.wrap[d] = (g.periodic[d] && b.lo[d] == g.domain.lo[d] && b.hi[d] == g.domain.hi[d]) ? 1 : 0;
+        G.m[d] = b.len(d) + (G.wrap[d] ? 0 : 1);
+        G.lo[d] = b.lo[d]; G.n[d] = b.len(d);
+        G.half_lo[d] = g.half_lo[d]; G.half_hi[d] = g.half_hi[d]; G.dlo[d] = g.domain.lo[d]; G.dhi[d] = g.domain.hi[d];
+        M *= G.m[d];
+    }
+    return M <= NBG_NT;
+}
+
+bool nodal_bottom_device_ok_general(const Geometry& g, const Layout& l)
+{
+    static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0) &&
+                                !(getenv("IAMRX_MG_DEVICE_BOTTOM_GENERAL") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM_GENERAL")) == 0);
+    NBotGeom G;
+    return enabled && nbg_geom(g, l, G);
+}
+
+void nodal_bottom_solve_general(const Geometry& g, MultiFab& cor, const MultiFab& res, const MultiFab& sig, const MultiFab* dmask, bool singular,
+                                double eps_rel, int maxiter, int nsweeps, int nub, int nuf, int* d_iters)
+{
+    const Layout& l = *cor.layout;
+    NBotGeom G;
+    IAMRX_ASSERT(nbg_geom(g, l, G) && sig.ngrow >= 1);
+    if (l.nlocal() == 0) return;
+    double cnt = 1.0;
+    for (int d = 0; d < 3; ++d) cnt *= (double)g.domain.len(d);
+    hipLaunchKernelGGL(k_nodal_bottom_g, dim3(1), dim3(NBG_NT), 0, Context::get().stream, cor.d_tab, res.d_tab, sig.d_tab,
+                       dmask ? dmask->d_tab : nullptr, make_w(g), G, singular ? 1 : 0, cnt, eps_rel, maxiter, nsweeps, nub, nuf, d_iters);
+}
+
 // weighted Jacobi: x_new = x + (2/3) (rhs - A x)/s0 ; tmp holds x_new, then copied back by the caller
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig, const MultiFab* dmask)
 {

@@ -32,6 +32,9 @@ bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, con
 bool nodal_bottom_device_ok(const Geometry& g, const Layout& l);
 void nodal_bottom_solve(const Geometry& g, MultiFab& cor, const MultiFab& res, const MultiFab& sig, bool singular, double eps_rel, int maxiter,
                         int nsweeps, int nub, int nuf, int* d_iters);
+bool nodal_bottom_device_ok_general(const Geometry& g, const Layout& l);
+void nodal_bottom_solve_general(const Geometry& g, MultiFab& cor, const MultiFab& res, const MultiFab& sig, const MultiFab* dmask, bool singular,
+                                double eps_rel, int maxiter, int nsweeps, int nub, int nuf, int* d_iters);
 static int* nodal_bottom_iters_dev()
 {
     static int* d = nullptr;
@@ -58,7 +61,8 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
     while ((int)m_lev.size() <= m_o.max_coarsening_level) {
         Level& f = m_lev.back();
         // a fully periodic single box of at most 8^3 cells is solved by the single-workgroup device bottom solver (k_nodal_bottom)
-        if (m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only && nodal_bottom_device_ok(f.g, *f.layout)) break;
+        if (m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only &&
+            (nodal_bottom_device_ok(f.g, *f.layout) || nodal_bottom_device_ok_general(f.g, *f.layout))) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
@@ -287,7 +291,8 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
 bool NodalMG::bottom_on_device()
 {
     Level& B = m_lev.back();
-    return m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only && !B.dmask() && nodal_bottom_device_ok(B.g, *B.layout);
+    if (!(m_o.device_bottom && m_o.nodal_smoother == 0 && !m_o.bottom_smoother_only)) return false;
+    return (!B.dmask() && nodal_bottom_device_ok(B.g, *B.layout)) || nodal_bottom_device_ok_general(B.g, *B.layout);
 }
 
 void NodalMG::vcycle(MGStats& st)
@@ -315,10 +320,14 @@ void NodalMG::vcycle(MGStats& st)
             for (int i = 0; i < m_o.nuf; ++i) smooth(l, B.cor, B.res);
         } else if (bottom_on_device()) {
             long nunk = 1;
-            for (int d = 0; d < 3; ++d) nunk *= B.g.domain.len(d);
+            for (int d = 0; d < 3; ++d) nunk *= B.g.domain.len(d) + (B.g.periodic[d] ? 0 : 1);
             const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
-            nodal_bottom_solve(B.g, B.cor, B.res, B.sig, m_singular, m_o.bottom_reltol, maxiter, m_o.nodal_sweeps, m_o.nub, m_o.nuf,
-                               nodal_bottom_iters_dev());
+            if (!B.dmask() && nodal_bottom_device_ok(B.g, *B.layout))           // fully periodic: the wrap-only kernel
+                nodal_bottom_solve(B.g, B.cor, B.res, B.sig, m_singular, m_o.bottom_reltol, maxiter, m_o.nodal_sweeps, m_o.nub, m_o.nuf,
+                                   nodal_bottom_iters_dev());
+            else                                                                // walls / Dirichlet mask / refined patch
+                nodal_bottom_solve_general(B.g, B.cor, B.res, B.sig, B.dmask(), m_singular, m_o.bottom_reltol, maxiter, m_o.nodal_sweeps, m_o.nub,
+                                           m_o.nuf, nodal_bottom_iters_dev());
         } else {
             MultiFab rb(B.layout, node_type(), 1, 0);
             MultiFab::Copy(rb, B.res, 0, 0, 1, 0);
