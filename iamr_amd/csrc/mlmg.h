@@ -33,6 +33,26 @@ struct MGOpts {
     int device_bottom = 1;
 };
 
+// V-cycle wall time without draining the stream: HIP events recorded in front of and behind every cycle on the launch stream; the
+// durations are read after the solve (its last residual norm has synchronised the stream by then)
+struct CycleTimer {
+    std::vector<hipEvent_t> ev;
+    int used = 0;
+    void mark(hipStream_t s)
+    {
+        if (used == (int)ev.size()) { hipEvent_t e; IAMRX_HIP_CHECK(hipEventCreate(&e)); ev.push_back(e); }
+        IAMRX_HIP_CHECK(hipEventRecord(ev[used++], s));
+    }
+    double total_ms()        // pairs (0,1), (2,3), ...; the events must have completed
+    {
+        double t = 0.0;
+        for (int i = 0; i + 1 < used; i += 2) { float ms = 0.f; IAMRX_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); t += ms; }
+        used = 0;
+        return t;
+    }
+};
+CycleTimer& cycle_timer();
+
 // multi-rank runs: MG levels whose total size is at most this many cells are replicated on every rank (one all-gather per
 // V-cycle instead of a halo exchange per smoothing pass and an all-reduce per Krylov dot product); 0 disables
 long mg_agglomeration_cells();

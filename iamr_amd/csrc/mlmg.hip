@@ -12,6 +12,8 @@ namespace iamrx {
 // amr.hip
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add);
 
+CycleTimer& cycle_timer() { static CycleTimer t; return t; }
+
 long mg_agglomeration_cells()
 {
     static long v = -1;
@@ -434,6 +436,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     st.resnorm = st.resnorm0;
     if (m_o.verbose) printf("iamrx MLMG: rhs %.6e resid0 %.6e target %.3e levels %d\n", st.rhsnorm0, st.resnorm0, res_target, st.nlevels);
     double vc_ms = 0.0;
+    cycle_timer().used = 0;
     if (m_bottom_dev) IAMRX_HIP_CHECK(hipMemsetAsync(bottom_iters_dev(), 0, sizeof(int), ctx.stream));
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
     else {
@@ -446,11 +449,9 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
                 const double need = std::min(0.5, res_target / st.resnorm);
                 m_dd_sweeps = std::min(6, std::max(1, (int)std::ceil(std::log(need) / std::log(m_dd_rho))));
             }
-            ctx.sync();
-            auto t0 = std::chrono::steady_clock::now();
+            cycle_timer().mark(ctx.stream);
             vcycle(st);
-            ctx.sync();
-            vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
             applyBC(0, phi, true, bcvp);
             abec_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);
@@ -461,6 +462,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
         }
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx MLMG: failed to converge after max_iters");
     }
+    vc_ms = cycle_timer().total_ms();          // the last residual norm has synchronised the stream
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
     applyBC(0, phi, true, bcvp);
     if (m_bottom_dev && st.iters > 0) {

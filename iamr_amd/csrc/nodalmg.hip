@@ -389,6 +389,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     if (m_o.verbose) printf("iamrx nodal MLMG: rhs %.6e resid0 %.6e levels %d (fused sweep %d, single-workgroup coarse smoother %d, ghost width %d)\n",
                             st.rhsnorm0, st.resnorm0, st.nlevels, (int)nodal_fused(), (int)nodal_small(), L0.cor.ngrow);
     double vc_ms = 0.0;
+    cycle_timer().used = 0;
     const bool bdev = bottom_on_device();
     if (bdev) IAMRX_HIP_CHECK(hipMemsetAsync(nodal_bottom_iters_dev(), 0, sizeof(int), ctx.stream));
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
@@ -396,11 +397,9 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         for (int iter = 0; iter < maxit; ++iter) {
             if (m_singular) { subtract_mean(0, L0.res); L0.res_filled = false; }
-            ctx.sync();
-            auto t0 = std::chrono::steady_clock::now();
+            cycle_timer().mark(ctx.stream);
             vcycle(st);
-            ctx.sync();
-            vc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, 1, 0);
             residual(0, L0.res, phi, rhs);
             L0.res_filled = false;
@@ -412,6 +411,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         }
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx nodal MLMG: failed to converge after max_iters");
     }
+    vc_ms = cycle_timer().total_ms();          // the last residual norm has synchronised the stream
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
     if (bdev && st.iters > 0) {
         int h = 0;
