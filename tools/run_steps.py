@@ -1,0 +1,22 @@
+"""Runs TaylorGreen 256^3 (bench settings): post_init + 2 warm-up steps, then 4 steps between two marker launches (k_fill on a 7^3\nMultiFab) -- the workload of tools/profile_step.sh, which turns the rocprofv3 kernel trace between the markers into per-step totals."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iamr_amd import lib, ns as N
+lib.init(0)
+n = 256
+g = lib.Geom.make((n, n, n)); lay = lib.Layout.single((n, n, n))
+s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+s.post_init(-1.0)
+for _ in range(2): s.step()
+lib.sync()
+print("MARK_BEGIN", flush=True)
+# marker kernel: a distinctive fill size
+m = lib.MultiFab(lib.Layout.single((7, 7, 7)), lib.CELL, 1, 0)
+m.setval(1.0); lib.sync()
+t0 = time.perf_counter()
+for _ in range(4): s.step()
+lib.sync()
+print("ms/step", (time.perf_counter() - t0) * 250)
+m.setval(2.0); lib.sync()
