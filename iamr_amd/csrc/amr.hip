@@ -84,7 +84,14 @@ void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int
 {
     IAMRX_ASSERT(dst.type.t[0] == src.type.t[0] && dst.type.t[1] == src.type.t[1] && dst.type.t[2] == src.type.t[2]);
     IAMRX_ASSERT(src_ng <= src.ngrow && dst_ng <= dst.ngrow && scomp + nc <= src.ncomp && dcomp + nc <= dst.ncomp);
-    static std::map<PCKey, std::unique_ptr<CopyPlan>> cache;
+    static std::map<PCKey, std::unique_ptr<CopyPlan>>& cache = [] () -> std::map<PCKey, std::unique_ptr<CopyPlan>>& {
+        auto* c = new std::map<PCKey, std::unique_ptr<CopyPlan>>();
+        register_layout_evictor([c](uint64_t lid) {
+            std::vector<std::unique_ptr<CopyPlan>> dead;
+            for (auto it = c->begin(); it != c->end();) { if (it->first.dl == lid || it->first.sl == lid) { dead.push_back(std::move(it->second)); it = c->erase(it); } else ++it; }
+        });
+        return *c;
+    }();
     PCKey key;
     std::memset(&key, 0, sizeof(key));
     key.dl = dst.layout->id; key.sl = src.layout->id; key.t = dst.type; key.dng = dst_ng; key.sng = src_ng;
@@ -180,7 +187,14 @@ struct FPKey {
 
 const FPInfo& fp_info(const Layout& dl, const Layout& fl, int ng, int ratio, const Geometry& fgeom)
 {
-    static std::map<FPKey, std::unique_ptr<FPInfo>> cache;
+    static std::map<FPKey, std::unique_ptr<FPInfo>>& cache = [] () -> std::map<FPKey, std::unique_ptr<FPInfo>>& {
+        auto* c = new std::map<FPKey, std::unique_ptr<FPInfo>>();
+        register_layout_evictor([c](uint64_t lid) {
+            std::vector<std::unique_ptr<FPInfo>> dead;
+            for (auto it = c->begin(); it != c->end();) { if (it->first.dl == lid || it->first.fl == lid) { dead.push_back(std::move(it->second)); it = c->erase(it); } else ++it; }
+        });
+        return *c;
+    }();
     FPKey key;
     std::memset(&key, 0, sizeof(key));
     key.dl = dl.id; key.fl = fl.id; key.ng = ng; key.ratio = ratio;
@@ -484,7 +498,15 @@ struct MaskKey { uint64_t fl; int per[3]; int dlo[3], dhi[3]; bool operator<(con
 // the level mask (2 ghost cells), kept as doubles in a cell-centred MultiFab
 const MultiFab& level_mask(const LayoutP& fl, const Geometry& fgeom)
 {
-    static std::map<MaskKey, std::unique_ptr<MultiFab>> cache;
+    static std::map<MaskKey, std::unique_ptr<MultiFab>>& cache = [] () -> std::map<MaskKey, std::unique_ptr<MultiFab>>& {
+        auto* c = new std::map<MaskKey, std::unique_ptr<MultiFab>>();
+        // the mask holds its layout: only an explicit evict_layout_caches (regrid) reaches this entry
+        register_layout_evictor([c](uint64_t lid) {
+            std::vector<std::unique_ptr<MultiFab>> dead;
+            for (auto it = c->begin(); it != c->end();) { if (it->first.fl == lid) { dead.push_back(std::move(it->second)); it = c->erase(it); } else ++it; }
+        });
+        return *c;
+    }();
     MaskKey key;
     std::memset(&key, 0, sizeof(key));
     key.fl = fl->id;
@@ -517,7 +539,14 @@ void create_umac_grown(MultiFab* const umac_fine[3], const MultiFab* const umac_
     // coarse faces under every fine box grown by one cell
     std::vector<BoxD> cb;
     for (auto& b : fl->boxes) cb.push_back(coarsen(grow(b, 1), ratio));
-    static std::map<std::pair<uint64_t, int>, LayoutP> cl_cache;
+    static std::map<std::pair<uint64_t, int>, LayoutP>& cl_cache = [] () -> std::map<std::pair<uint64_t, int>, LayoutP>& {
+        auto* c = new std::map<std::pair<uint64_t, int>, LayoutP>();
+        register_layout_evictor([c](uint64_t lid) {
+            std::vector<LayoutP> dead;
+            for (auto it = c->begin(); it != c->end();) { if (it->first.first == lid) { dead.push_back(std::move(it->second)); it = c->erase(it); } else ++it; }
+        });
+        return *c;
+    }();
     LayoutP& cl = cl_cache[{fl->id, ratio}];
     if (!cl) cl = std::make_shared<Layout>(cb, fl->owner, ctx.comm->rank);
     for (int d = 0; d < 3; ++d) {

@@ -169,6 +169,11 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
         MultiFab::Copy(s.P[1], s.P[0], 0, 0, 1, 1);
         s.make_rho_curr_time();
     }
+    // the replaced levels: drop what the layout-keyed caches hold for them (a cached level mask keeps its layout alive otherwise)
+    std::vector<uint64_t> dead_ids;
+    for (auto& o_ : old) if (o_ && o_->layout) dead_ids.push_back(o_->layout->id);
+    old.clear();                                   // the old levels' arrays go first, then what the caches hold for their layouts
+    for (uint64_t id_ : dead_ids) evict_layout_caches(id_);
     return true;
 }
 

@@ -704,8 +704,17 @@ namespace {
 struct BcDescCache { BndryDesc* d = nullptr; int n = 0; long maxpts = 0; };
 std::map<std::array<long, 8>, BcDescCache>& bc_desc_cache()
 {
-    static std::map<std::array<long, 8>, BcDescCache> m;
-    return m;
+    // never destroyed; key[0] = layout id, entries leave with their layout
+    static auto* m = [] {
+        auto* c = new std::map<std::array<long, 8>, BcDescCache>();
+        register_layout_evictor([c](uint64_t lid) {
+            for (auto it = c->begin(); it != c->end();) {
+                if ((uint64_t)it->first[0] == lid) { if (it->second.d) (void)hipFree(it->second.d); it = c->erase(it); } else ++it;
+            }
+        });
+        return c;
+    }();
+    return *m;
 }
 }  // namespace
 

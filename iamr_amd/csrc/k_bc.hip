@@ -80,7 +80,7 @@ void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const
     auto& ctx = Context::get();
     for (int d = 0; d < 3; ++d) {
         if (g.periodic[d]) continue;
-        static std::map<std::array<long, 10>, std::tuple<PhysBcDesc*, int, long>> cache;
+        static auto& cache = make_desc_cache<PhysBcDesc>();
         int nd; long maxpts;
         const PhysBcDesc* dd = cached_descs(cache, {(long)mf.layout->id, mf.ngrow, d, g.domain.lo[d], g.domain.hi[d], 0, 0, 0, 0, 0},
             [&](std::vector<PhysBcDesc>& descs, long& mp) {
@@ -151,7 +151,7 @@ void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc)
         code = code * 4 + W.has_lo[d] * 2 + W.has_hi[d];
     }
     if (code == 0) return;
-    static std::map<std::array<long, 10>, std::tuple<ReflDesc*, int, long>> cache;
+    static auto& cache = make_desc_cache<ReflDesc>();
     int nd; long maxpts;
     const ReflDesc* dd = cached_descs(cache, {(long)mf.layout->id, mf.ngrow, code, g.domain.lo[0], g.domain.lo[1], g.domain.lo[2], g.domain.hi[0],
                                               g.domain.hi[1], g.domain.hi[2], mf.type.t[0] + 2 * mf.type.t[1] + 4 * mf.type.t[2]},

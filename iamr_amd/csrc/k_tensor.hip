@@ -331,7 +331,7 @@ void fill_tensor_corners(const Geometry& g, MultiFab& phi, const DomainBC& bc, b
     P.inhomog = inhomog ? 1 : 0;
     P.ncomp = ncomp; P.comp0 = comp0;
     for (int nout = 2; nout <= 3; ++nout) {
-        static std::map<std::array<long, 10>, std::tuple<EdgeDesc*, int, long>> cache;
+        static auto& cache = make_desc_cache<EdgeDesc>();
         int nd; long maxpts;
         const EdgeDesc* dd = cached_descs(cache, {(long)phi.layout->id, nout, g.domain.lo[0], g.domain.lo[1], g.domain.lo[2], g.domain.hi[0],
                                                   g.domain.hi[1], g.domain.hi[2], g.periodic[0] + 2 * g.periodic[1] + 4 * g.periodic[2], 0},

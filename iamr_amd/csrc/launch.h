@@ -62,6 +62,19 @@ inline Tiling level_tiling(const Layout& l, const IndexType& type, int ng, int t
 // Boundary-region descriptor lists (which ghost slabs of which box lie outside the domain / on a wall) depend only on the layout, the
 // ghost width and the domain: built on the host and uploaded ONCE per key, then reused by every later call (a multigrid level calls
 // its BC fills for every colour pass).  The device copies live for the life of the process (a few KB per layout).
+// descriptor cache of one call site: key[0] is the layout id; never destroyed, entries leave with their layout
+template <class D>
+inline std::map<std::array<long, 10>, std::tuple<D*, int, long>>& make_desc_cache()
+{
+    auto* c = new std::map<std::array<long, 10>, std::tuple<D*, int, long>>();
+    register_layout_evictor([c](uint64_t lid) {
+        for (auto it = c->begin(); it != c->end();) {
+            if ((uint64_t)it->first[0] == lid) { if (std::get<0>(it->second)) (void)hipFree(std::get<0>(it->second)); it = c->erase(it); } else ++it;
+        }
+    });
+    return *c;
+}
+
 template <class D, class F>
 inline const D* cached_descs(std::map<std::array<long, 10>, std::tuple<D*, int, long>>& cache, const std::array<long, 10>& key, F build,
                              int& n, long& maxpts)

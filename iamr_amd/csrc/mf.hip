@@ -2,6 +2,7 @@
 // Plays the role of AMReX MultiFab / FillBoundary at IAMR's call sites (SURVEY 2.3 "Same-level ghost
 // exchange": reference Source/MacProj.cpp:1127, Source/Projection.cpp:338-339, ...).
 #include "mf.h"
+#include <functional>
 #include <tuple>
 #include "launch.h"
 #include "kernels.h"
@@ -134,7 +135,16 @@ Layout::Layout(const std::vector<BoxD>& b, const std::vector<int>& own, int myra
 }
 
 void evict_layout_tables(uint64_t lid);
-Layout::~Layout() { evict_layout_tables(id); if (d_boxes) Context::get().free(d_boxes); }
+// the registry and the caches it serves are never destroyed (leaked on purpose): a layout may die during static destruction
+static std::vector<std::function<void(uint64_t)>>& layout_evictors() { static auto* v = new std::vector<std::function<void(uint64_t)>>(); return *v; }
+void register_layout_evictor(std::function<void(uint64_t)> f) { layout_evictors().push_back(std::move(f)); }
+void evict_layout_caches(uint64_t lid)
+{
+    evict_layout_tables(lid);
+    auto& ev = layout_evictors();
+    for (size_t q = 0; q < ev.size(); ++q) ev[q](lid);       // by index: an evictor may destroy a derived layout, which re-enters here
+}
+Layout::~Layout() { evict_layout_caches(id); if (d_boxes) Context::get().free(d_boxes); }
 
 long Layout::local_cells() const { long n = 0; for (int g : local) n += boxes[g].npts(); return n; }
 long Layout::total_cells() const { long n = 0; for (auto& b : boxes) n += b.npts(); return n; }
@@ -482,9 +492,21 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
     }
 }
 
+
+// plan cache keyed by PlanKey::layout_id: created on first use, never destroyed, entries leave with their layout
+static std::map<PlanKey, std::unique_ptr<CopyPlan>>& make_plan_cache()
+{
+    auto* c = new std::map<PlanKey, std::unique_ptr<CopyPlan>>();
+    register_layout_evictor([c](uint64_t lid) {
+        std::vector<std::unique_ptr<CopyPlan>> dead;
+        for (auto it = c->begin(); it != c->end();) { if (it->first.layout_id == lid) { dead.push_back(std::move(it->second)); it = c->erase(it); } else ++it; }
+    });
+    return *c;
+}
+
 const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv, int kpar)
 {
-    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>>& cache = make_plan_cache();
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = l.id; key.t = t; key.ng = ng;
@@ -550,7 +572,7 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
 // expressed as a CopyPlan so that it runs through execute_plan (pack kernel, one message per peer, unpack kernel).
 static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
 {
-    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>>& cache = make_plan_cache();
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = dist.id; key.t = t; key.ng = -1;
@@ -609,7 +631,7 @@ void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
 {
     IAMRX_ASSERT(repl.layout->replicated && repl.layout->replicated_of == dist.layout->id && repl.ncomp == dist.ncomp);
     IAMRX_ASSERT(ng <= dist.ngrow && ng <= repl.ngrow);
-    static std::map<PlanKey, std::unique_ptr<CopyPlan>> cache;
+    static std::map<PlanKey, std::unique_ptr<CopyPlan>>& cache = make_plan_cache();
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = dist.layout->id; key.t = dist.type; key.ng = ng;
