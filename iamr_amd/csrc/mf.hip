@@ -41,6 +41,14 @@ void Context::ensure_scratch(size_t n)
     scratch_n = n;
 }
 
+// IAMRX_POISON_ALLOC=1 (debugging aid): device blocks are filled with 0xFF bytes (NaN as doubles) when they are handed out, so that a
+// kernel reading memory nobody has written shows up deterministically instead of depending on what the recycled block held before
+static bool poison_allocs()
+{
+    static const bool on = getenv("IAMRX_POISON_ALLOC") && atoi(getenv("IAMRX_POISON_ALLOC")) != 0;
+    return on;
+}
+
 void* Context::alloc(size_t bytes)
 {
     if (bytes == 0) bytes = 256;
@@ -53,6 +61,7 @@ void* Context::alloc(size_t bytes)
         bytes_cached -= sz;
         live_blocks[p] = sz;
         bytes_live += sz;
+        if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, 0xFF, sz, stream));      // debug: every block starts as NaNs
         return p;
     }
     void* p = nullptr;
@@ -64,6 +73,7 @@ void* Context::alloc(size_t bytes)
     }
     live_blocks[p] = bytes;
     bytes_live += bytes;
+    if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, 0xFF, bytes, stream));
     return p;
 }
 

@@ -83,6 +83,9 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
         // 4 ghost layers: the plane-fused Gauss-Seidel recomputes its halo instead of exchanging it per colour
         const int ng = nodal_fused() ? 4 : 1;
         L.sig.define(L.layout, cell_type(), 1, ng);
+        // ghost cells beyond a coarse/fine boundary are never filled (setSigma: valid cells, neighbours / periodic images, wall mirrors);
+        // the prolongation forms sigma-weighted averages at the (masked) boundary nodes before they are zeroed: keep them finite
+        L.sig.setVal(0.0);
         L.cor.define(L.layout, node_type(), 1, ng);
         L.res.define(L.layout, node_type(), 1, ng);
         L.rescor.define(L.layout, node_type(), 1, 1);
