@@ -14,12 +14,12 @@ def main():
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
         if filt and not any(f in name for f in filt):
             continue
-        acc[(name, int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        acc[(name, int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r.get("Grid_Size_Z", 1) or 1))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Grid_Size_X", "Grid_Size_Y", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
-        for (name, gx, gy), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-            w.writerow([name, gx, gy, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
+        w.writerow(["Name", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for (name, gx, gy, gz), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):      # gz: components of the fused Godunov launches
+            w.writerow([name, gx, gy, gz, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
 
 
 if __name__ == "__main__":
