@@ -204,10 +204,20 @@ def amr_workload(lib, n0, steps):
     el = time.perf_counter() - t0
     st, stm = amr.sync_stats()
     cells = float(n0) ** 3 * 3.0
+    # section breakdown: separate, synchronised pass of two coarse steps (does not perturb the timed region)
+    amr.profile(1)
+    for _ in range(2):
+        amr.coarse_step()
+    sec, lsec = amr.profile(0)
+    names = ["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"]
+    sections = {"reflux": sec[0] / 2, "avg_down": sec[1] / 2, "mac_sync_solve": sec[2] / 2, "mac_sync_rest": sec[3] / 2, "level_sync": sec[4] / 2}
+    for l in range(amr.nlev):
+        sections[f"advance_level{l}"] = sec[8 + l] / 2
+        sections[f"advance_level{l}_sections"] = {k: v / 2 for k, v in zip(names, lsec[l][:6])}
     return {"workload": f"TaylorGreen 3D, 2 levels: {n0}^3 base + one {n0}^3 refined box (ratio 2, subcycled), nu = 1e-4, periodic; "
                         f"advance + reflux + avgDown + mac_sync (incl. viscous sync) + MLsyncProject per coarse step",
             "cells_advanced_per_sec": cells * steps / el, "ms_per_coarse_step": el / steps * 1e3, "coarse_steps": steps,
-            "sync_project_iters": st.iters, "mac_sync_iters": stm.iters}
+            "sync_project_iters": st.iters, "mac_sync_iters": stm.iters, "sections_ms_per_coarse_step": sections}
 
 
 def transport_selftest(lib, rank, world):

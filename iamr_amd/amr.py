@@ -59,7 +59,7 @@ class Amr:
             check(lib().iamrx_amr_level(self.h, l, C.byref(hl)))
             self.levels.append(_Level(hl, self.level_geom(l), self.layouts[l], self.params, self.opts))
 
-    def set_regrid(self, max_level, regrid_int, rules, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1):
+    def set_regrid(self, max_level, regrid_int, rules, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1, compute_new_dt_on_regrid=0):
         """rules: list of dicts(comp (0..4, -1 = mag_vort), mode (0 greater, 1 less, 2 vorticity, 3 adjacent difference), value (list per level),
         max_level (optional), box_lo / box_hi (optional)) -- amr.refinement_indicators of NS_error.cpp"""
         arr = (TagRule * max(1, len(rules)))()
@@ -76,6 +76,7 @@ class Amr:
                 arr[q].box_hi[d] = float(r.get("box_hi", (0, 0, 0))[d])
         check(lib().iamrx_amr_set_regrid(self.h, int(max_level), int(regrid_int), int(blocking_factor), int(max_grid_size), C.c_double(grid_eff),
                                          int(n_error_buf), len(rules), arr))
+        check(lib().iamrx_amr_set_compute_new_dt_on_regrid(self.h, int(compute_new_dt_on_regrid)))
 
     def regrid(self):
         ch = C.c_int()
@@ -142,6 +143,13 @@ class Amr:
         arr = (C.c_double * self.nlev)()
         check(lib().iamrx_amr_time(self.h, None, arr))
         return list(arr)
+
+    def profile(self, enable):
+        """-> (hierarchy sections [16], per-level sections [nlev][8]) accumulated so far; then enable: 1 reset + start, 0 stop, -1 keep"""
+        sec = (C.c_double * 16)()
+        lv = (C.c_double * (8 * self.nlev))()
+        check(lib().iamrx_amr_profile(self.h, int(enable), sec, lv))
+        return list(sec), [list(lv[8 * l:8 * l + 8]) for l in range(self.nlev)]
 
     def sync_stats(self):
         a, b = MgStats(), MgStats()

@@ -42,9 +42,11 @@ public:
         int max_level = 0, regrid_int = 0;
         int blocking_factor = 8, max_grid_size = 32, n_error_buf = 1;
         double grid_eff = 0.7;
+        int compute_new_dt_on_regrid = 0;   // amr.compute_new_dt_on_regrid (Amr::timeStep: computeNewDt(post_regrid_flag = 1) after a level-0 regrid; default 0)
         std::vector<TagRule> rules;
     };
-    void set_regrid(const RegridOpts& r) { rg = r; }
+    void set_regrid(const RegridOpts& r) { const int keep = rg.compute_new_dt_on_regrid; rg = r; if (!r.compute_new_dt_on_regrid) rg.compute_new_dt_on_regrid = keep; }
+    void set_compute_new_dt_on_regrid(int on) { rg.compute_new_dt_on_regrid = on; }
     // new grids of levels 1 .. max_level from the tags of the current data (coarse to fine nesting enforced); the level-l boxes
     std::vector<std::vector<BoxD>> make_new_grids();
     // install grids (levels 1 ..): new levels are filled from the old level where it existed and from the next coarser level elsewhere;
@@ -54,6 +56,12 @@ public:
     int level_count = 0;                // coarse steps since the last regrid (Amr::level_count[0])
     uint64_t grid_generation() const { return m_grid_gen; }   // incremented whenever the grids change
     uint64_t m_grid_gen = 0;
+    // section profile of the coarse step (host clock around stream syncs, only while profile_on): [0] reflux, [1] avgDown,
+    // [2] mac_sync_solve, [3] mac_sync rest (re-advection, viscous / scalar sync solves, SyncInterp), [4] level_sync (MLsyncProject +
+    // interpolation to finer levels), [5] regrid, [8 + l] advance of level l (all its sub-steps; the level's own t_sections split it further)
+    bool profile_on = false;
+    double t_prof[16] = {0};
+    void set_profile(bool on);
 
 private:
     NSParams p;
@@ -66,7 +74,8 @@ private:
     RegridOpts rg;
     int m_ratio = 2;
     void link_level(int l);
-    void check_nesting(const Layout& fine, const Layout& crse, const Geometry& cgeom, int l) const;
+    void check_nesting(const std::vector<BoxD>& fine, const std::vector<BoxD>& crse, const Geometry& cgeom, int l) const;
+    void validate_grids(const std::vector<std::vector<BoxD>>& grids) const;   // throws before anything is modified
     void compute_new_dt(bool post_regrid);
 };
 

@@ -23,6 +23,7 @@
 #include "operators.h"
 #include "launch.h"
 #include "amrns.h"
+#include <chrono>
 #include <cmath>
 #include <algorithm>
 #include <cstring>
@@ -611,7 +612,7 @@ AmrNS::AmrNS(const Geometry& g0, const std::vector<LayoutP>& layouts, int ratio,
         dt_level.push_back(0.0); dt_min.push_back(1.e200);
         if (l > 0) {
             NavierStokes& c = *lev[l - 1];
-            if (l > 1) check_nesting(*layouts[l], *layouts[l - 1], c.g, (int)l);
+            if (l > 1) check_nesting(layouts[l]->boxes, layouts[l - 1]->boxes, c.g, (int)l);
             link_level((int)l);
         }
     }
@@ -620,15 +621,15 @@ AmrNS::AmrNS(const Geometry& g0, const std::vector<LayoutP>& layouts, int ratio,
 // proper nesting: the Godunov ghost cells (3) of every box plus the interpolation stencil (1 coarse cell) must lie inside the next
 // coarser level or outside a non-periodic domain face -- what amrex::Amr's grid generation guarantees for IAMR (blocking_factor >= 8).
 // Layouts that violate it would read cells no level defines.
-void AmrNS::check_nesting(const Layout& fine, const Layout& crse, const Geometry& cgeom, int l) const
+void AmrNS::check_nesting(const std::vector<BoxD>& fine, const std::vector<BoxD>& crse, const Geometry& cgeom, int l) const
 {
     const int ratio = m_ratio;
     const BoxD cdom = cgeom.domain;
-    for (auto& fb : fine.boxes) {
+    for (auto& fb : fine) {
         BoxD R = grow(coarsen(grow(fb, 3), ratio), 1);
         for (int d = 0; d < 3; ++d) if (!cgeom.periodic[d]) { R.lo[d] = std::max(R.lo[d], cdom.lo[d]); R.hi[d] = std::min(R.hi[d], cdom.hi[d]); }
         long covered = 0;
-        for (auto& cb : crse.boxes)
+        for (auto& cb : crse)
             for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
                 const int sh[3] = {sx, sy, sz};
                 bool ok = true;
@@ -661,6 +662,15 @@ void AmrNS::link_level(int l)
     c.Vsync.define(c.layout, cell_type(), 3, 1); c.Vsync.setVal(0.0);
     c.Ssync.define(c.layout, cell_type(), NUM_STATE - 3, 1); c.Ssync.setVal(0.0);
 }
+
+namespace {
+struct AmrTimer {
+    AmrNS& a; int idx; bool on;
+    std::chrono::steady_clock::time_point t0;
+    AmrTimer(AmrNS& a_, int i) : a(a_), idx(i), on(a_.profile_on) { if (on) { Context::get().sync(); t0 = std::chrono::steady_clock::now(); } }
+    ~AmrTimer() { if (on) { Context::get().sync(); a.t_prof[idx] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
+};
+}  // namespace
 
 // NavierStokes::avgDown (NavierStokes.cpp:1845-1873) + avgDown_StatePress (NavierStokesBase.cpp:4125-4163)
 void AmrNS::avg_down(int l)
@@ -714,8 +724,12 @@ void AmrNS::mac_sync(int l)
     for (int d = 0; d < 3; ++d) { Ucorr[d].define(c.layout, face_type(d), 1, 1); Ucorr[d].setVal(0.0); uc[d] = &Ucorr[d]; }
     MGOpts mo = o;
     mo.maxorder = 4;
-    st_mac_sync = mac_sync_solve(c.g, *f.reg_mac, c.rho_half, dt, f.layout, f.ratio, uc, c.mac_phi, c.bc_mac, 1.e-10 /*mac_sync_tol*/, c.p.mac_abs_tol, mo,
-                                 l > 0 ? &c.crse->g : nullptr, c.ratio);
+    {
+        AmrTimer t(*this, 2);
+        st_mac_sync = mac_sync_solve(c.g, *f.reg_mac, c.rho_half, dt, f.layout, f.ratio, uc, c.mac_phi, c.bc_mac, 1.e-10 /*mac_sync_tol*/, c.p.mac_abs_tol, mo,
+                                     l > 0 ? &c.crse->g : nullptr, c.ratio);
+    }
+    AmrTimer t_rest(*this, 3);
     for (int d = 0; d < 3; ++d) Ucorr[d].FillBoundary(c.g);
     // ---- mac_sync_compute (MacProj.cpp:490-731)
     {
@@ -964,14 +978,22 @@ void AmrNS::level_sync(int l, int crse_iteration)
     }
 }
 
+
+void AmrNS::set_profile(bool on)
+{
+    profile_on = on;
+    for (auto& s : lev) s->profile_sections = on;
+    if (on) { for (double& t : t_prof) t = 0.0; for (auto& s : lev) for (double& t : s->t_sections) t = 0.0; }
+}
+
 // NavierStokesBase::post_timestep (NavierStokesBase.cpp:2546-2636)
 void AmrNS::post_timestep(int l, int crse_iteration)
 {
     if (l < (int)lev.size() - 1) {
-        reflux(l);
-        avg_down(l);
+        { AmrTimer t(*this, 0); reflux(l); }
+        { AmrTimer t(*this, 1); avg_down(l); }
         mac_sync(l);
-        level_sync(l, crse_iteration);
+        { AmrTimer t(*this, 4); level_sync(l, crse_iteration); }
     }
     if (l > 0) mf_saxpy(lev[l]->p_avg, 1.0 / (double)n_cycle[l], lev[l]->P[lev[l]->pnew], 0, 0, 1, 0);      // incrPAvg
 }
@@ -981,7 +1003,8 @@ void AmrNS::time_step(int l, double time, int iteration, int niter)
 {
     NavierStokes& s = *lev[l];
     s.time = time;
-    const double dt_new = s.advance(dt_level[l], iteration, niter);
+    double dt_new;
+    { AmrTimer t(*this, 8 + std::min(l, 7)); dt_new = s.advance(dt_level[l], iteration, niter); }
     dt_min[l] = iteration == 1 ? dt_new : std::min(dt_min[l], dt_new);
     s.time = time + dt_level[l];
     s.nstep += 1;
@@ -1119,13 +1142,16 @@ void AmrNS::compute_new_dt(bool post_regrid)
 }
 
 // Amr::coarseTimeStep: computeNewDt + timeStep(0); Amr::timeStep regrids from level 0 at the start of the step once regrid_int coarse
-// steps have been taken since the last regrid, then recomputes the time steps with post_regrid_flag = 1
+// steps have been taken since the last regrid; only with amr.compute_new_dt_on_regrid = 1 (default 0) it then recomputes the time steps
+// with post_regrid_flag = 1 -- otherwise levels that existed keep their dt and new levels start with dt_level[l-1] / n_cycle[l]
+// (install_grids)
 double AmrNS::coarse_step()
 {
     if (level_steps > 0) compute_new_dt(false);
     if (rg.regrid_int > 0 && rg.max_level > 0 && level_count >= rg.regrid_int) {
         level_count = 0;
-        if (regrid()) compute_new_dt(true);
+        AmrTimer t(*this, 5);
+        if (regrid() && rg.compute_new_dt_on_regrid) compute_new_dt(true);
     }
     time_step(0, lev[0]->time, 1, 1);
     level_steps += 1;

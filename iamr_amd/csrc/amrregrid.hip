@@ -108,9 +108,37 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
     return grids;
 }
 
+// Everything that can be wrong with caller-supplied grids is found here, before the hierarchy is touched (install_grids moves the old
+// levels out first: a throw half way would leave it half-built): boxes non-empty, inside the level's domain, aligned to the refinement
+// ratio (a fine box covers whole coarse cells), pairwise disjoint, and every level properly nested in the one below.
+void AmrNS::validate_grids(const std::vector<std::vector<BoxD>>& grids) const
+{
+    BoxD dom = lev[0]->g.domain;
+    Geometry cg = lev[0]->g;
+    for (size_t q = 0; q < grids.size(); ++q) {
+        const int l = (int)q + 1;
+        if (q > 0) for (int d = 0; d < 3; ++d) { cg.domain = dom; cg.dx[d] /= (double)m_ratio; }
+        dom = refine(dom, m_ratio);
+        const auto& bl = grids[q];
+        if (bl.empty()) throw Error("iamrx install_grids: level " + std::to_string(l) + " has no boxes");
+        for (size_t a = 0; a < bl.size(); ++a) {
+            const BoxD& b = bl[a];
+            if (!b.ok()) throw Error("iamrx install_grids: empty box on level " + std::to_string(l));
+            for (int d = 0; d < 3; ++d) {
+                if (b.lo[d] < dom.lo[d] || b.hi[d] > dom.hi[d]) throw Error("iamrx install_grids: a box of level " + std::to_string(l) + " lies outside the domain");
+                if (b.lo[d] % m_ratio != 0 || (b.hi[d] + 1) % m_ratio != 0)
+                    throw Error("iamrx install_grids: a box of level " + std::to_string(l) + " is not aligned to the refinement ratio");
+            }
+            for (size_t c = 0; c < a; ++c) if (intersect(b, bl[c]).ok()) throw Error("iamrx install_grids: boxes of level " + std::to_string(l) + " overlap");
+        }
+        if (l > 1) check_nesting(bl, grids[q - 1], cg, l);
+    }
+}
+
 bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
 {
     auto& ctx = Context::get();
+    validate_grids(grids);
     const int old_finest = (int)lev.size() - 1, new_finest = (int)grids.size();
     bool same = old_finest == new_finest;
     for (int l = 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->layout->boxes, grids[l - 1]);
@@ -129,7 +157,6 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
         Geometry g = c.g;
         for (int d = 0; d < 3; ++d) { g.domain.lo[d] *= m_ratio; g.domain.hi[d] = (g.domain.hi[d] + 1) * m_ratio - 1; g.dx[d] /= (double)m_ratio; }
         LayoutP nl = std::make_shared<Layout>(grids[l - 1], std::vector<int>(grids[l - 1].size(), 0), ctx.comm->rank);
-        if (l > 1) check_nesting(*nl, *c.layout, c.g, l);
         lev.push_back(std::make_unique<NavierStokes>(g, nl, p, o));
         NavierStokes& s = *lev.back();
         s.level = l; s.ratio = m_ratio;

@@ -570,7 +570,14 @@ int iamrx_tensor_solve_cf(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, doub
 
 struct iamrx_ns_s {
     std::unique_ptr<NavierStokes> owned;     // null for a level borrowed from an iamrx_amr hierarchy
-    NavierStokes* ns = nullptr;
+    // borrowed handles of a hierarchy that has regridded since are kept alive as retired objects (ns_ == nullptr): every entry point
+    // reports an error on them instead of touching a freed level
+    struct Ref {
+        NavierStokes* p = nullptr;
+        NavierStokes* operator->() const { if (!p) throw Error("stale level handle: the hierarchy was regridded, fetch the level again with iamrx_amr_level"); return p; }
+        NavierStokes& operator*() const { return *operator->(); }
+        Ref& operator=(NavierStokes* q) { p = q; return *this; }
+    } ns;
     iamrx_mf_s* views[10];
     bool probing = false;
     LayoutP layout;
@@ -579,6 +586,7 @@ struct iamrx_ns_s {
 void iamrx_ns_default_params(iamrx_ns_params* p)
 {
     NSParams d;
+    memset(p, 0, sizeof *p);      // fields added later start from zero for callers that fill a stack struct through this function
     p->cfl = d.cfl; p->visc_coef = d.visc_coef; p->be_cn_theta = d.be_cn_theta; p->gravity = d.gravity;
     p->mac_tol = d.mac_tol; p->mac_abs_tol = d.mac_abs_tol; p->proj_tol = d.proj_tol; p->proj_abs_tol = d.proj_abs_tol;
     p->visc_tol = d.visc_tol; p->use_forces_in_trans = d.use_forces_in_trans; p->do_mom_diff = d.do_mom_diff;
@@ -589,6 +597,7 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     for (int i = 0; i < 9; ++i) { p->wall_vel_lo[i] = d.wall_vel_lo[i]; p->wall_vel_hi[i] = d.wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { p->scal_bc_lo[i] = d.scal_bc_lo[i]; p->scal_bc_hi[i] = d.scal_bc_hi[i]; }
     p->do_cons_trac = d.do_cons_trac;
+    p->use_ppm = d.use_ppm;
 }
 
 static NSParams to_params(const iamrx_ns_params* p)
@@ -825,6 +834,7 @@ int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acom
 struct iamrx_amr_s {
     std::unique_ptr<AmrNS> amr;
     std::vector<std::unique_ptr<iamrx_ns_s>> levels;     // borrowed level handles
+    std::vector<std::unique_ptr<iamrx_ns_s>> retired;    // handles given out before a regrid: alive until the hierarchy dies, ns == nullptr
 };
 int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts, int ratio, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_amr* out)
 {
@@ -846,7 +856,14 @@ int iamrx_amr_create(const iamrx_geom* g0, int nlev, const iamrx_layout* layouts
 int iamrx_amr_destroy(iamrx_amr a) { IAMRX_TRY delete a; IAMRX_CATCH }
 static void amr_refresh_levels(iamrx_amr a)
 {
-    // the level handles given out so far stay valid objects but refer to levels that no longer exist: rebuild the table
+    // the level handles given out so far stay valid objects (retired: every iamrx_ns_* entry returns an error on them) but the
+    // levels they referred to no longer exist: rebuild the table
+    for (auto& v : a->levels) {
+        v->ns = nullptr;
+        for (auto& q : v->views) { delete q; q = nullptr; }
+        v->layout.reset();
+        a->retired.push_back(std::move(v));
+    }
     a->levels.clear();
     for (int l = 0; l < a->amr->nlevels(); ++l) {
         auto v = std::make_unique<iamrx_ns_s>();
@@ -874,6 +891,7 @@ int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blockin
     a->amr->set_regrid(r);
     IAMRX_CATCH
 }
+int iamrx_amr_set_compute_new_dt_on_regrid(iamrx_amr a, int on) { IAMRX_TRY a->amr->set_compute_new_dt_on_regrid(on != 0); IAMRX_CATCH }
 int iamrx_amr_regrid(iamrx_amr a, int* changed)
 {
     IAMRX_TRY
@@ -893,7 +911,10 @@ int iamrx_amr_install_grids(iamrx_amr a, int nfine_levels, const int* nboxes, co
             for (int d = 0; d < 3; ++d) { x.lo[d] = boxes[6 * q + d]; x.hi[d] = boxes[6 * q + 3 + d]; }
             g[l].push_back(x);
         }
-    const bool c = a->amr->install_grids(g);
+    const uint64_t before = a->amr->grid_generation();
+    bool c = false;
+    try { c = a->amr->install_grids(g); }
+    catch (...) { if (a->amr->grid_generation() != before) amr_refresh_levels(a); throw; }
     if (c) amr_refresh_levels(a);
     if (changed) *changed = c ? 1 : 0;
     IAMRX_CATCH
@@ -940,6 +961,14 @@ int iamrx_amr_reflux(iamrx_amr a, int lev) { IAMRX_TRY a->amr->reflux(lev); IAMR
 int iamrx_amr_avg_down(iamrx_amr a, int lev) { IAMRX_TRY a->amr->avg_down(lev); IAMRX_CATCH }
 int iamrx_amr_mac_sync(iamrx_amr a, int lev) { IAMRX_TRY a->amr->mac_sync(lev); IAMRX_CATCH }
 int iamrx_amr_level_sync(iamrx_amr a, int lev) { IAMRX_TRY a->amr->level_sync(lev); IAMRX_CATCH }
+int iamrx_amr_profile(iamrx_amr a, int enable, double sections_ms[16], double level_sections_ms /* [nlev][8] or NULL */[])
+{
+    IAMRX_TRY
+    if (sections_ms) for (int i = 0; i < 16; ++i) sections_ms[i] = a->amr->t_prof[i];
+    if (level_sections_ms) for (int l = 0; l < a->amr->nlevels(); ++l) for (int i = 0; i < 8; ++i) level_sections_ms[8 * l + i] = a->amr->level(l).t_sections[i];
+    if (enable >= 0) a->amr->set_profile(enable != 0);
+    IAMRX_CATCH
+}
 int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync, iamrx_mg_stats* mac_sync)
 {
     IAMRX_TRY

@@ -217,7 +217,7 @@ struct TabKey {
     bool operator<(const TabKey& o) const
     { return std::tie(lid, t0, t1, t2, nc, ng, base) < std::tie(o.lid, o.t0, o.t1, o.t2, o.nc, o.ng, o.base); }
 };
-std::map<TabKey, FabD*>& tab_cache() { static std::map<TabKey, FabD*> c; return c; }
+std::map<TabKey, FabD*>& tab_cache() { static auto* c = new std::map<TabKey, FabD*>(); return *c; }   // leaked on purpose: layouts can die during static destruction
 }  // namespace
 
 void evict_layout_tables(uint64_t lid)

@@ -165,7 +165,8 @@ class Inputs:
             rules.append(r)
         return dict(max_level=max_level, regrid_int=self.ints("amr.regrid_int", 1, [1])[0], rules=rules,
                     blocking_factor=self.ints("amr.blocking_factor", 1, [8])[0], max_grid_size=self.ints("amr.max_grid_size", 1, [32])[0],
-                    grid_eff=self.real("amr.grid_eff", 0.7), n_error_buf=self.ints("amr.n_error_buf", 1, [1])[0])
+                    grid_eff=self.real("amr.grid_eff", 0.7), n_error_buf=self.ints("amr.n_error_buf", 1, [1])[0],
+                    compute_new_dt_on_regrid=self.integer("amr.compute_new_dt_on_regrid", 0))
 
     # mapping ----------------------------------------------------------------------------------------------------------
     def problem(self):
@@ -176,10 +177,15 @@ class Inputs:
         if max_level > 0:
             # fixed refined grids only (amr.regrid_file, as Exec/run2d/test_grids/inputs_*): the tagging / clustering blocks exist
             # (iamrx_error_tag, iamrx_cluster_tags) but no regrid driver runs them during a run yet
+            # amr.regrid_file: fixed grids for the whole run; amr.initial_grid_file: only the initial hierarchy comes from the file,
+            # the run then regrids from amr.refinement_indicators every amr.regrid_int steps (upstream Amr::initialInit / Amr::regrid)
             gf = None
-            for k in ("amr.regrid_file", "amr.initial_grid_file"):
-                if self.has(k):
-                    gf = self.string(k)
+            initial_only = False
+            if self.has("amr.regrid_file"):
+                gf = self.string("amr.regrid_file")
+            elif self.has("amr.initial_grid_file"):
+                gf = self.string("amr.initial_grid_file")
+                initial_only = True
             rr = self.ints("amr.ref_ratio", max_level, [2] * max_level)
             if any(r != 2 for r in rr):
                 raise NotImplementedError(f"inputs: amr.ref_ratio = {rr}: only ratio 2 is implemented")
@@ -187,6 +193,11 @@ class Inputs:
                 if not os.path.isabs(gf) and self.files:
                     gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
                 fine_boxes = read_grid_file(gf, rr)[:max_level]
+                if initial_only:
+                    regrid = self.refinement_indicators(max_level)
+                    if not regrid["rules"]:
+                        raise NotImplementedError("inputs: amr.initial_grid_file without amr.refinement_indicators: the grids would have to be "
+                                                  "regenerated from error tags this run does not define (use amr.regrid_file for fixed grids)")
             else:
                 regrid = self.refinement_indicators(max_level)
                 if not regrid["rules"]:

@@ -34,7 +34,8 @@ def build_amr(pr, lib, N):
         # Amr::bldFineLevels: the initial hierarchy from the tags of the initial data, one level at a time; the new level's data are
         # the problem's initial data (initData), not the interpolant
         amr.set_regrid(**pr["regrid"])
-        for _ in range(pr["regrid"]["max_level"]):
+        # amr.initial_grid_file: the initial hierarchy is the file's, the tags only drive the regrids during the run
+        for _ in range(0 if pr["fine_boxes"] else pr["regrid"]["max_level"]):
             nl = amr.nlev
             if not amr.regrid():
                 break

@@ -399,10 +399,16 @@ int iamrx_amr_destroy(iamrx_amr a);
  * comp: state component 0..4 (velocity, density, tracer) or -1 = mag_vort; mode: 0 value_greater, 1 value_less, 2 vorticity_greater
  * (x 2^level), 3 adjacent_difference_greater; value[nvalue]: per level (the last one repeats); tags only on levels < max_level;
  * has_box: in_box_lo / in_box_hi.  regrid_int > 0: iamrx_amr_coarse_step regrids at the start of every regrid_int-th coarse step.
- * After a regrid the level handles of iamrx_amr_level must be fetched again. */
+ * After a regrid (check iamrx_amr_nlevels / iamrx_amr_level_boxes, or simply re-fetch after every coarse step) the level handles of
+ * iamrx_amr_level must be fetched again: handles given out before stay allocated until iamrx_amr_destroy but are retired -- every
+ * iamrx_ns_* call on them returns an error ("stale level handle") instead of touching a freed level. */
 typedef struct iamrx_tag_rule { int comp, mode, nvalue, max_level, has_box; double value[8]; double box_lo[3], box_hi[3]; } iamrx_tag_rule;
 int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
                          int nrules, const iamrx_tag_rule* rules);
+/* amr.compute_new_dt_on_regrid (default 0): 1 = after a regrid from level 0 that changed the grids the time steps are recomputed with
+ * NavierStokesBase::computeNewDt(post_regrid_flag = 1) (Source/NavierStokesBase.cpp:971-982), as Amr::timeStep does; 0 = levels that
+ * existed keep their dt, new levels start with dt_level[l-1] / n_cycle[l]. */
+int iamrx_amr_set_compute_new_dt_on_regrid(iamrx_amr a, int on);
 int iamrx_amr_regrid(iamrx_amr a, int* changed);
 /* install given grids of levels 1 .. nfine_levels (boxes in each level's own index space, 6 ints per box, level by level) and fill them */
 int iamrx_amr_install_grids(iamrx_amr a, int nfine_levels, const int* nboxes, const int* boxes, int* changed);
@@ -422,6 +428,11 @@ int iamrx_amr_avg_down(iamrx_amr a, int lev);
 int iamrx_amr_mac_sync(iamrx_amr a, int lev);
 int iamrx_amr_level_sync(iamrx_amr a, int lev);
 int iamrx_amr_sync_stats(iamrx_amr a, iamrx_mg_stats* sync_project, iamrx_mg_stats* mac_sync);
+/* section profile of the coarse steps (synchronising; measurement aid like iamrx_ns_profile).  Reads the accumulated times first, then
+ * enable: 1 = reset and start, 0 = stop, -1 = leave as is.  sections_ms[16]: [0] reflux, [1] avgDown, [2] mac_sync_solve, [3] rest of mac_sync
+ * (mac_sync_compute, viscous / scalar sync solves, SyncInterp), [4] level_sync (MLsyncProject), [5] regrid, [8 + l] advance of level l;
+ * level_sections_ms[8 * l + i]: the sections of iamrx_ns_profile of level l (may be NULL). */
+int iamrx_amr_profile(iamrx_amr a, int enable, double sections_ms[16], double level_sections_ms[]);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,11 @@ struct orc_amr {
 };
 typedef struct orc_amr orc_amr;
 
+int orc_syncreg_literal = 1;
+double orc_syncreg_diff_max = 0.0;
+void orc_set_syncreg_literal(int on) { orc_syncreg_literal = on; }
+double orc_syncreg_last_diff(int reset) { const double v = orc_syncreg_diff_max; if (reset) orc_syncreg_diff_max = 0.0; return v; }
+
 static inline int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
 
 /* is the cell (ci,cj,ck) of level f->crse covered by level f */
@@ -915,6 +920,23 @@ static void level_sync(orc_amr* a, int lev, int crse_iteration)
     orc_fab phi_c = orc_alloc(g->n, ORC_NODE, 1, 1), phi_f = orc_alloc(fg->n, ORC_NODE, 1, 1);
     orc_fab rhnd = orc_alloc(g->n, ORC_NODE, 0, 1);
     syncreg_init_rhs(f, &rhnd);
+    {   /* SyncRegister::InitRHS of the literal register (orc_syncreg.c) on the coarse level's boxes */
+        orc_ndmf* rb = orc_level_ndmf(c, 0);
+        orc_syncreg_init_rhs(f->sync_lit, rb, g, c->p.phys_lo, c->p.phys_hi);
+        orc_fab lit = orc_alloc(g->n, ORC_NODE, 0, 1);
+        orc_ndmf_to_domain(rb, &lit);
+        orc_ndmf_destroy(rb);
+        double dmax = 0.0, vmax = 0.0;
+        for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+            if (node_vs_fine(f, i, j, k) == 1) continue;
+            if (c->level > 0 && node_class(c, i, j, k) == ND_NONE) continue;
+            dmax = fmax(dmax, fabs(A4(&lit, i, j, k, 0) - A4(&rhnd, i, j, k, 0)));
+            vmax = fmax(vmax, fabs(A4(&rhnd, i, j, k, 0)));
+        }
+        orc_syncreg_diff_max = fmax(orc_syncreg_diff_max, vmax > 0.0 ? dmax / vmax : dmax);
+        if (orc_syncreg_literal) orc_copy_all(&rhnd, &lit);
+        orc_free(&lit);
+    }
     {
         int whole = f->nbox == 1;
         for (int d = 0; d < 3 && whole; ++d) if (f->boxes[d] != 0 || f->boxes[3 + d] != fg->n[d] - 1) whole = 0;
@@ -949,6 +971,13 @@ static void level_sync(orc_amr* a, int lev, int crse_iteration)
         for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
             if (node_vs_fine(f, i, j, k) != 0) A4(&r, i, j, k, 0) = 0.0;
         syncreg_fine_add(c, &r, 1.0 / (double)crse_dt_ratio);
+        {   /* literally: crsr_sync_reg->CompAdd(sync_resid_fine, crse_geom, crsr_geom, coarsened boxes of level lev+1, invrat) */
+            orc_ndmf* rb = orc_sync_resid_fine_boxes(c, &vold_c, &phi_c, &sg1);
+            int* pb = (int*)malloc(sizeof(int) * 6 * (size_t)f->nbox);
+            for (int q = 0; q < f->nbox; ++q) for (int d = 0; d < 3; ++d) { pb[6 * q + d] = f->boxes[6 * q + d] / f->ratio; pb[6 * q + 3 + d] = (f->boxes[6 * q + 3 + d] + 1) / f->ratio - 1; }
+            orc_syncreg_comp_add(c->sync_lit, rb, g, &c->crse->g, f->nbox, pb, 1.0 / (double)crse_dt_ratio);
+            free(pb); orc_ndmf_destroy(rb);
+        }
         orc_free(&r); orc_free(&sg1); orc_free(&vold_c);
     }
     /* add phi to the pressures (with ghost nodes), the projected corrections to the velocities (1 ghost) */
@@ -1068,6 +1097,7 @@ orc_amr* orc_amr_create(const orc_geom* g0, const orc_ns_params* p, const orc_mg
                 s->reg_mac[d] = orc_alloc(cg->n, ORC_FACE[d], 0, 1);
             }
             s->sync_reg = orc_alloc(cg->n, ORC_NODE, 0, 1);
+            s->sync_lit = orc_syncreg_create(s->nbox, s->boxes, s->ratio);
             s->crse->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3);
             s->crse->Ssync = orc_alloc(cg->n, ORC_CELL, 1, NUM_STATE - 3);
         }
@@ -1258,6 +1288,7 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
             s->reg_mac[d] = orc_alloc(cg->n, ORC_FACE[d], 0, 1);
         }
         s->sync_reg = orc_alloc(cg->n, ORC_NODE, 0, 1);
+        s->sync_lit = orc_syncreg_create(s->nbox, s->boxes, s->ratio);
         if (!c->Vsync.p) { c->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3); c->Ssync = orc_alloc(cg->n, ORC_CELL, 1, NUM_STATE - 3); }
         /* times */
         const double dt_new = ol ? a->dt_level[l] : a->dt_level[l - 1] / (double)ratio;
@@ -1318,10 +1349,11 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
     a->nlev = nfine + 1;
 }
 
-/* the coarse step that follows a regrid: computeNewDt as usual, then again with post_regrid_flag = 1 (Amr::timeStep) */
-double orc_amr_coarse_step_post_regrid(orc_amr* a)
+/* the coarse step that follows a regrid: computeNewDt as usual (orc_amr_compute_new_dt, before the regrid), then -- only with
+ * amr.compute_new_dt_on_regrid = 1, Amr::timeStep; the default is 0 -- again with post_regrid_flag = 1 */
+double orc_amr_coarse_step_post_regrid(orc_amr* a, int compute_new_dt_on_regrid)
 {
-    compute_new_dt(a, 1);
+    if (compute_new_dt_on_regrid) compute_new_dt(a, 1);
     time_step(a, 0, a->lev[0]->time, 1, 1);
     a->level_steps += 1;
     for (int i = 0; i < a->nlev; ++i) a->lev[i]->dt = a->dt_level[i];

@@ -137,6 +137,7 @@ void orc_ns_destroy(orc_ns_state* s)
     if (s->Ssync.p) orc_free(&s->Ssync);
     for (int d = 0; d < 3; ++d) { if (s->reg_adv[d].p) orc_free(&s->reg_adv[d]); if (s->reg_visc[d].p) orc_free(&s->reg_visc[d]); if (s->reg_mac[d].p) orc_free(&s->reg_mac[d]); }
     if (s->sync_reg.p) orc_free(&s->sync_reg);
+    if (s->sync_lit) { orc_syncreg_destroy(s->sync_lit); s->sync_lit = NULL; }
     if (s->sync_resid_crse.p) orc_free(&s->sync_resid_crse);
     free(s->boxes);
     free(s);
@@ -645,11 +646,17 @@ static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost,
         orc_fab r = amr_sync_resid_crse(s, &vold, phi, sig);
         syncreg_crse_init(s->fine, &r, 1.0);
         orc_free(&r);
+        orc_ndmf* rb = orc_sync_resid_crse_boxes(s, &vold, phi, sig);          /* the same, box by box, into the literal register */
+        orc_syncreg_crse_init(s->fine->sync_lit, rb, g, 1.0);
+        orc_ndmf_destroy(rb);
     }
     if (want_fine) {            /* fine_sync_reg->FineAdd(sync_resid_fine, crse_geom, 1/crse_dt_ratio) */
         orc_fab r = amr_sync_resid_fine(s, &vold, phi, sig);
         syncreg_fine_add(s, &r, 1.0 / (double)s->ncycle);
         orc_free(&r);
+        orc_ndmf* rb = orc_sync_resid_fine_boxes(s, &vold, phi, sig);
+        orc_syncreg_fine_add(s->sync_lit, rb, &s->crse->g, 1.0 / (double)s->ncycle);
+        orc_ndmf_destroy(rb);
     }
     if (vold.p) orc_free(&vold);
 }

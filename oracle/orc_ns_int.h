@@ -48,7 +48,8 @@ struct orc_ns_state {
     orc_fab rho_avg, p_avg;        /* level > 0 */
     orc_fab Vsync, Ssync;          /* level < finest: 3 / NUM_STATE-3 comps, 1 ghost */
     orc_fab reg_adv[3], reg_visc[3], reg_mac[3];   /* level > 0: coarse-level faces, NUM_STATE / NUM_STATE / 1 comps */
-    orc_fab sync_reg;              /* level > 0: coarse-level nodes */
+    orc_fab sync_reg;              /* level > 0: coarse-level nodes (single-valued restatement, orc_amr.c) */
+    struct orc_syncreg* sync_lit;  /* level > 0: the literal box-by-box SyncRegister (orc_syncreg.c) */
     orc_fab sync_resid_crse;       /* scratch of the last level projection (coarse-level nodes), see ns_level_project */
 };
 
@@ -94,6 +95,28 @@ orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const or
 orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
 void syncreg_crse_init(orc_ns_state* fine, const orc_fab* resid_crse /*nodes of fine->crse*/, double mult);   /* SyncRegister::CrseInit */
 void syncreg_fine_add(orc_ns_state* fine, const orc_fab* resid_fine /*nodes of fine*/, double mult);          /* SyncRegister::FineAdd */
+
+/* ---- literal SyncRegister and box-by-box sync residuals (orc_syncreg.c) ---- */
+typedef struct orc_ndmf orc_ndmf;
+typedef struct orc_syncreg orc_syncreg;
+orc_ndmf* orc_ndmf_create(int nbox, const int* boxes, int ng);
+void orc_ndmf_destroy(orc_ndmf* m);
+orc_syncreg* orc_syncreg_create(int nbox, const int* fine_boxes, int ratio);
+void orc_syncreg_destroy(orc_syncreg* sr);
+void orc_syncreg_setval(orc_syncreg* sr, double v);
+void orc_syncreg_crse_init(orc_syncreg* sr, orc_ndmf* resid_crse, const orc_geom* cgeom, double mult);
+void orc_syncreg_fine_add(orc_syncreg* sr, orc_ndmf* resid_fine, const orc_geom* cgeom, double mult);
+void orc_syncreg_comp_add(orc_syncreg* sr, orc_ndmf* resid_fine, const orc_geom* fgeom, const orc_geom* cgeom, int nP, const int* Pboxes, double mult);
+void orc_syncreg_init_rhs(orc_syncreg* sr, orc_ndmf* rhs, const orc_geom* geom, const int phys_lo[3], const int phys_hi[3]);
+orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
+orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
+orc_ndmf* orc_level_ndmf(const orc_ns_state* s, int ng);
+void orc_ndmf_to_domain(const orc_ndmf* m, orc_fab* out);
+/* 1 (default): the multi-level step feeds MLsyncProject from the literal register; 0: from the single-valued restatement.  Both are
+ * always run; orc_syncreg_last_diff() = max |difference| of the two right-hand sides of the last MLsyncProject (nodes strictly inside
+ * the fine level excluded: the literal 3-D register does not mask them) relative to max |rhs| */
+extern int orc_syncreg_literal;
+extern double orc_syncreg_diff_max;
 
 /* ---- nodal pieces shared with the composite solver (orc_nodal.c) ---- */
 void orc_nodal_fill_bc(const orc_geom* g, orc_fab* x, const int lobc[3], const int hibc[3]);

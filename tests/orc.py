@@ -276,9 +276,9 @@ class OrcAmr:
     def time(self):
         return lib().orc_amr_time(self.h)
 
-    def regrid_then_step(self, grids):
+    def regrid_then_step(self, grids, compute_new_dt_on_regrid=0):
         """the coarse step during which the hierarchy is regridded to `grids` (per refined level a list of (lo, hi) in that level's
-        index space): computeNewDt, Amr::regrid with these grids, computeNewDt(post_regrid_flag = 1), timeStep"""
+        index space): computeNewDt, Amr::regrid with these grids, computeNewDt(post_regrid_flag = 1) if amr.compute_new_dt_on_regrid, timeStep"""
         L = lib()
         L.orc_amr_coarse_step_post_regrid.restype = C.c_double
         L.orc_amr_compute_new_dt(self.h)
@@ -288,7 +288,7 @@ class OrcAmr:
         L.orc_amr_regrid(self.h, len(grids), nb, arr)
         self.nlev = len(grids) + 1
         self.levels = [[]] + [list(g) for g in grids]
-        return L.orc_amr_coarse_step_post_regrid(self.h)
+        return L.orc_amr_coarse_step_post_regrid(self.h, C.c_int(compute_new_dt_on_regrid))
 
     def dt(self, lev):
         return lib().orc_amr_dt(self.h, C.c_int(lev))

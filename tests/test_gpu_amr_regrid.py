@@ -72,7 +72,10 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
         S[..., 1] += 0.5
         return S
     amr, oa = _make(n0, l1, 16, kw, fn)
-    amr.set_regrid(max_level=2, regrid_int=1, rules=[dict(comp=4, mode=0, value=[0.2, 0.6])], blocking_factor=4, max_grid_size=16, n_error_buf=1)
+    # amr.compute_new_dt_on_regrid = 1 on both sides here (computeNewDt with post_regrid_flag = 1 after the regrid); the other tests
+    # run the default 0
+    amr.set_regrid(max_level=2, regrid_int=1, rules=[dict(comp=4, mode=0, value=[0.2, 0.6])], blocking_factor=4, max_grid_size=16, n_error_buf=1,
+                   compute_new_dt_on_regrid=1)
     amr.post_init()
     oa.post_init()
     had_three = False
@@ -81,7 +84,7 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
         if after != before:
-            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after])
+            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after], 1)
         else:
             dto = oa.step()
         assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)

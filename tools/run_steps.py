@@ -14,9 +14,9 @@ lib.sync()
 print("MARK_BEGIN", flush=True)
 # marker kernel: a distinctive fill size
 m = lib.MultiFab(lib.Layout.single((7, 7, 7)), lib.CELL, 1, 0)
-m.setval(1.0); lib.sync()
+m.setval(1.0); m.setval(1.0); m.setval(1.0); lib.sync()   # marker: three consecutive tiny fills
 t0 = time.perf_counter()
 for _ in range(4): s.step()
 lib.sync()
 print("ms/step", (time.perf_counter() - t0) * 250)
-m.setval(2.0); lib.sync()
+m.setval(2.0); m.setval(2.0); m.setval(2.0); lib.sync()
