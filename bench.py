@@ -182,28 +182,47 @@ def file_blob_sha(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def amr_workload(lib, n0, steps):
-    """secondary workload (north_star: 2-level AMR TaylorGreen): base level n0^3 in one box, one ratio-2 refined box over the central
-    (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; nu = 1e-4 as in Tutorials/TaylorGreen/inputs.3d.taylorgreen.
-    cells advanced per coarse step = n0^3 + 2 * n0^3."""
+def amr_workload(lib, n0, steps, rank=0, world=1, dist=None):
+    """secondary workload (north_star: 2-level AMR TaylorGreen).  Per GPU: an n0^3 box of the base level and one ratio-2 refined box over
+    its central (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; nu = 1e-4 as in Tutorials/TaylorGreen/inputs.3d.taylorgreen.  N GPUs:
+    the base boxes in the same process grid as the main workload (weak scaling), rank r owns base box r and refined box r.
+    cells advanced per coarse step and GPU = n0^3 + 2 * n0^3."""
     from iamr_amd import ns as N
     from iamr_amd.amr import Amr
-    g0 = lib.Geom.make((n0,) * 3)
-    lo, hi = n0 // 2, n0 // 2 + n0 - 1
-    lays = [lib.Layout.single((n0,) * 3), lib.Layout([((lo,) * 3, (hi,) * 3)])]
+    pg = proc_grid(world)
+    ntot = tuple(n0 * pg[d] for d in range(3))
+    g0 = lib.Geom.make(ntot, prob_hi=tuple(float(pg[d]) for d in range(3)))
+    cb, fb = [], []
+    for r in range(world):
+        o = (r % pg[0], (r // pg[0]) % pg[1], r // (pg[0] * pg[1]))
+        cb.append((tuple(o[d] * n0 for d in range(3)), tuple((o[d] + 1) * n0 - 1 for d in range(3))))
+        fb.append((tuple(2 * o[d] * n0 + n0 // 2 for d in range(3)), tuple(2 * o[d] * n0 + n0 // 2 + n0 - 1 for d in range(3))))
+    own = list(range(world))
+    lays = [lib.Layout(cb, own), lib.Layout(fb, own)]
     amr = Amr(g0, lays, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
     for l in range(2):
         amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
     amr.post_init()
     amr.coarse_step()
-    lib.sync()
+
+    def barrier():
+        lib.sync()
+        if world > 1:
+            dist.barrier()
+
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         amr.coarse_step()
-    lib.sync()
+    barrier()
     el = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        tt = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
     st, stm = amr.sync_stats()
-    cells = float(n0) ** 3 * 3.0
+    cells = float(n0) ** 3 * 3.0 * world
     # section breakdown: separate, synchronised pass of two coarse steps (does not perturb the timed region)
     amr.profile(1)
     for _ in range(2):
@@ -214,8 +233,9 @@ def amr_workload(lib, n0, steps):
     for l in range(amr.nlev):
         sections[f"advance_level{l}"] = sec[8 + l] / 2
         sections[f"advance_level{l}_sections"] = {k: v / 2 for k, v in zip(names, lsec[l][:6])}
-    return {"workload": f"TaylorGreen 3D, 2 levels: {n0}^3 base + one {n0}^3 refined box (ratio 2, subcycled), nu = 1e-4, periodic; "
-                        f"advance + reflux + avgDown + mac_sync (incl. viscous sync) + MLsyncProject per coarse step",
+    return {"workload": f"TaylorGreen 3D, 2 levels, per GPU: {n0}^3 base box + one {n0}^3 refined box over its centre (ratio 2, subcycled), "
+                        f"{pg[0]}x{pg[1]}x{pg[2]} GPUs, nu = 1e-4, periodic; advance + reflux + avgDown + mac_sync (incl. viscous sync) + MLsyncProject per coarse step",
+            "n_gpus": world,
             "cells_advanced_per_sec": cells * steps / el, "ms_per_coarse_step": el / steps * 1e3, "coarse_steps": steps,
             "sync_project_iters": st.iters, "mac_sync_iters": stm.iters, "sections_ms_per_coarse_step": sections}
 
@@ -354,6 +374,8 @@ def main():
     value = cells_total * a.steps / el
 
     out = None
+    # the 2-level AMR workload is collective too: every rank runs it (base and refined level sharded over the ranks)
+    amr_res = amr_workload(lib, a.amr_n, a.amr_steps, rank, world, dist if world > 1 else None) if (a.amr_n > 0 and a.amr_steps > 0) else None
     # per-section breakdown (separate, synchronised pass so it does not perturb the timed region); a time step is collective:
     # EVERY rank takes these two steps
     ns.profile(2)
@@ -458,8 +480,8 @@ def main():
             "roofline_godunov_advection": roofline_god,
             "roofline_godunov_prediction": roofline_pred,
         }
-        if world == 1 and a.amr_n > 0 and a.amr_steps > 0:
-            out["amr"] = amr_workload(lib, a.amr_n, a.amr_steps)
+        if amr_res is not None:
+            out["amr"] = amr_res
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))

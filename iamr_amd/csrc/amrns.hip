@@ -368,17 +368,17 @@ void comp_fill_slaves(std::vector<CLev>& L)
     }
 }
 
-// y = A x on the unknowns (0 elsewhere)
-void comp_apply(std::vector<CLev>& L)
+// y = A x on the unknowns (0 elsewhere) of the levels >= lmin (the rows of a level need the contributions of the finer levels only)
+void comp_apply(std::vector<CLev>& L, int lmin = 0)
 {
     comp_fill_slaves(L);
     const int nl = (int)L.size();
-    for (int l = nl - 1; l >= 0; --l) {
+    for (int l = nl - 1; l >= lmin; --l) {
         MultiFab ax(L[l].layout, node_type(), 1, 0);
         nodal_residual(L[l].g, ax, L[l].x, L[l].sigm, nullptr);
         if (l == nl - 1) MultiFab::Copy(L[l].y, ax, 0, 0, 1, 0);
         else mf_saxpy(L[l].y, 1.0, ax, 0, 0, 1, 0);           // y already holds the contributions of the finer level
-        if (l > 0) {
+        if (l > lmin) {
             MultiFab bb(L[l].layout, node_type(), 1, 1);
             bb.setVal(0.0);
             MultiFab::Copy(bb, L[l].y, 0, 0, 1, 0);
@@ -411,10 +411,10 @@ double comp_norm(std::vector<CLev>& L, MultiFab CLev::*fld)
     return m;
 }
 
-void comp_residual(std::vector<CLev>& L)        // r = b - A x on the unknowns
+void comp_residual(std::vector<CLev>& L, int lmin = 0)        // r = b - A x on the unknowns of the levels >= lmin
 {
-    comp_apply(L);
-    for (auto& l : L) mf_lincomb(l.r, 1.0, l.b, -1.0, l.y, 0, 1, 0);
+    comp_apply(L, lmin);
+    for (size_t l = (size_t)lmin; l < L.size(); ++l) mf_lincomb(L[l].r, 1.0, L[l].b, -1.0, L[l].y, 0, 1, 0);
 }
 
 }  // namespace
@@ -423,6 +423,9 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
                                  const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale)
 {
     auto& ctx = Context::get();
+    ProfScope ps_all_("composite_project");
+    std::unique_ptr<ProfScope> psec;
+    PROF_NEXT(psec, "cp_setup");
     std::vector<CLev> L(nl);
     bool singular = true;
     double scale = 1.0;
@@ -475,6 +478,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         C.mg = std::make_unique<NodalMG>(C.g, C.layout, C.ns->nodal_bc(), mo);
         C.mg->setSigma(*sig[l], 0);
     }
+    PROF_NEXT(psec, "cp_rhs");
     // right-hand side: div(vel) of the uncovered cells (+ rhnd), fine boundary contributions handed down
     for (int l = nl - 1; l >= 0; --l) {
         CLev& C = L[l];
@@ -513,6 +517,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         const double off = comp_dot_own(L, 0) / comp_dot_own(L, 1);
         for (auto& C : L) { mf_add_scalar(C.b, -off, 0, 1, 0); mask_mult(C.b, 0, 1, C.own, false, 0); }
     }
+    PROF_NEXT(psec, "cp_cycles");
     MGStats st;
     st.nlevels = nl;
     comp_residual(L);
@@ -526,8 +531,11 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
     // one subspace correction: the space of level l = its trilinear functions vanishing on the level's boundary, prolonged to the
     // unknowns of every finer level.  Right-hand side = the composite residual tested with those functions: the level's own entries
     // plus the full-weighting restriction of the finer levels' entries.
+    int fresh_from = 0;                  // L[m].r is current for m >= fresh_from (nl: nothing is)
     auto correct_level = [&](int l) {
-        comp_residual(L);
+        if (fresh_from > l) { ProfScope ps("cp_residual"); comp_residual(L, l); }
+        fresh_from = nl;                 // the correction below changes x
+        ProfScope* ps_dn = new ProfScope("cp_restrict_rhs");
         MultiFab acc;                                          // on level m-1: what levels >= m hand down
         for (int m = nl - 1; m > l; --m) {
             MultiFab bb(L[m].layout, node_type(), 1, 1);
@@ -542,7 +550,9 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         rhs.setVal(0.0);
         MultiFab::Copy(rhs, L[l].r, 0, 0, 1, 0);
         if (l < nl - 1) mf_saxpy(rhs, 1.0, acc, 0, 0, 1, 0);
-        L[l].mg->vcycle_correction(L[l].e, rhs, vst);
+        delete ps_dn;
+        { ProfScope ps("cp_vcycle"); L[l].mg->vcycle_correction(L[l].e, rhs, vst); }
+        ProfScope ps_up("cp_interp_update");
         for (int m = l; m < nl; ++m) {
             if (m > l) {                                        // e of level m = the interpolant of the coarser correction (all nodes)
                 fill_nodes(L[m - 1], L[m - 1].e);
@@ -556,10 +566,14 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         }
     };
     for (int it = 0; it < o.max_iters && !st.converged; ++it) {
-        for (int l = nl - 1; l >= 1; --l) correct_level(l);     // finest first, down to the coarsest level of the solve, and up again
+        // symmetric sweep: finest first, down to the coarsest level of the solve, and up again.  From the second iteration on the downward
+        // half starts one level below the finest: the upward half of the iteration before has just ended with a correction of the finest
+        // level and nothing has changed since (two corrections of the same space in a row: the second finds only what the first left)
+        for (int l = nl - 1 - (it > 0 && nl > 1 ? 1 : 0); l >= 1; --l) correct_level(l);
         correct_level(0);
         for (int l = 1; l < nl; ++l) correct_level(l);
-        comp_residual(L);
+        { ProfScope ps("cp_residual"); comp_residual(L); }
+        fresh_from = 0;
         st.resnorm = comp_norm(L, &CLev::r);
         st.iters = it + 1;
         if (o.verbose) printf("iamrx composite nodal solve: iter %d resid %.6e (target %.3e)\n", it + 1, st.resnorm, target);
@@ -575,6 +589,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
             mf_saxpy(C.x, -off, t, 0, 0, 1, 0);
         }
     }
+    PROF_NEXT(psec, "cp_finish");
     // slaves, covered coarse nodes (injection of the fine solution), ghost nodes
     comp_fill_slaves(L);
     for (int l = nl - 2; l >= 0; --l) { average_down(L[l + 1].x, L[l].x, 0, 1, L[l + 1].ns->ratio); fill_nodes(L[l], L[l].x); }
@@ -730,6 +745,9 @@ void AmrNS::mac_sync(int l)
                                      l > 0 ? &c.crse->g : nullptr, c.ratio);
     }
     AmrTimer t_rest(*this, 3);
+    ProfScope ps_ms_("mac_sync_rest");
+    std::unique_ptr<ProfScope> psec;
+    PROF_NEXT(psec, "ms_compute");
     for (int d = 0; d < 3; ++d) Ucorr[d].FillBoundary(c.g);
     // ---- mac_sync_compute (MacProj.cpp:490-731)
     {
@@ -788,6 +806,7 @@ void AmrNS::mac_sync(int l)
             }
         }
     }
+    PROF_NEXT(psec, "ms_update");
     // ---- NavierStokes.cpp:1490-1690
     MultiFab& Sn = c.S[c.inew];
     MultiFab Delta(c.layout, cell_type(), 1, 0);
@@ -805,6 +824,7 @@ void AmrNS::mac_sync(int l)
         });
     }
     const double theta = c.p.be_cn_theta;
+    PROF_NEXT(psec, "ms_vsync_diffuse");
     if (c.is_diffusive_vel()) {
         // Diffusion::diffuse_Vsync -> diffuse_tensor_Vsync (Diffusion.cpp:960-1178): (rho - theta dt div tau) Vsync' = rho Vsync, homogeneous
         // boundary and coarse/fine data.  NOTE the face coefficients of this solve are set to 1.0 upstream (:1122-1135), not to the
@@ -844,6 +864,7 @@ void AmrNS::mac_sync(int l)
             });
         }
     }
+    PROF_NEXT(psec, "ms_ssync");
     mf_mult(c.Ssync, dt, 0, 1, 1);                           // density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
     if (c.is_diffusive_tracer()) {
         // Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
@@ -887,6 +908,7 @@ void AmrNS::mac_sync(int l)
     mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, NUM_STATE - 3, 0);
     c.make_rho_curr_time();
     if (l > 0) mf_saxpy(c.rho_avg, 1.0, c.Ssync, 0, 0, 1, 0);      // :1684-1688
+    PROF_NEXT(psec, "ms_sync_interp");
     // interpolate the sync correction to every finer level, straight from this one with the accumulated ratio (:1697-1725)
     int ratio = 1;
     for (size_t q = (size_t)l + 1; q < lev.size(); ++q) {
@@ -908,6 +930,9 @@ void AmrNS::level_sync(int l, int crse_iteration)
     if (crse_iteration < 0) crse_iteration = crse_dt_ratio;
     auto& ctx = Context::get();
     const double dt = dt_level[l];
+    ProfScope ps_ls_("level_sync");
+    std::unique_ptr<ProfScope> psec;
+    PROF_NEXT(psec, "ls_pre");
     c.Vsync.FillBoundary(c.g);
     MultiFab V_corr(f.layout, cell_type(), 3, 1);
     V_corr.setVal(0.0);
@@ -945,7 +970,9 @@ void AmrNS::level_sync(int l, int crse_iteration)
         vold_c.define(c.layout, cell_type(), 3, 1);
         MultiFab::Copy(vold_c, c.Vsync, 0, 0, 3, 1);
     }
+    psec.reset();
     st_sync = composite_project(l, 2, vel, vcomp, phi, sig, &rhnd, 1.e-10 /*sync_tol*/, c.p.proj_abs_tol, true, 0.0);
+    PROF_NEXT(psec, "ls_post");
     if (want_resid) {
         MultiFab r = amr_sync_resid(c, vold_c, phi_c, sig_c, false);
         MultiFab vsf(c.layout, node_type(), 1, 0);                    // CompAdd: zero on the nodes of the coarsened level-(l+1) boxes

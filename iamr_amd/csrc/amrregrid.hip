@@ -25,6 +25,25 @@ std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domai
 
 namespace {
 
+// DistributionMapping of a new level: the boxes, largest first, each to the rank with the least cells so far (knapsack; ties -> lowest
+// rank).  A function of the box list alone: every rank computes the same owners.
+std::vector<int> distribute_boxes(const std::vector<BoxD>& boxes, int nranks)
+{
+    std::vector<int> owner(boxes.size(), 0);
+    if (nranks <= 1) return owner;
+    std::vector<size_t> order(boxes.size());
+    for (size_t q = 0; q < order.size(); ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return boxes[a].npts() > boxes[b].npts(); });
+    std::vector<long> load(nranks, 0);
+    for (size_t q : order) {
+        int best = 0;
+        for (int r = 1; r < nranks; ++r) if (load[r] < load[best]) best = r;
+        owner[q] = best;
+        load[best] += boxes[q].npts();
+    }
+    return owner;
+}
+
 bool same_boxes(std::vector<BoxD> a, std::vector<BoxD> b)
 {
     if (a.size() != b.size()) return false;
@@ -42,7 +61,6 @@ bool same_boxes(std::vector<BoxD> a, std::vector<BoxD> b)
 
 std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
 {
-    IAMRX_ASSERT(Context::get().comm->nranks == 1);      // the tags of a level are gathered on the (single) rank
     const int finest = (int)lev.size() - 1;
     const int max_level = rg.max_level;
     std::vector<std::vector<BoxD>> grids(max_level + 1);                 // grids[l]: boxes of level l (index space of level l), l >= 1
@@ -78,6 +96,15 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
                 const size_t o = ((size_t)(k - fb.lo[2]) * fb.len(1) + (j - fb.lo[1])) * fb.len(0) + (i - fb.lo[0]);
                 if (buf[o] != 0.0) h[((size_t)(k - dom.lo[2]) * n1 + (j - dom.lo[1])) * n0 + (i - dom.lo[0])] = 1;
             }
+        }
+        // multi-rank: every rank has tagged the cells of its own boxes; the level's tag map is their union.  A cell belongs to one box,
+        // hence to one rank, so the sum of the rank-local bit maps IS the union: 32 tag bits per double (exact integers), one all-reduce
+        if (Context::get().comm->nranks > 1) {
+            const size_t nw = (h.size() + 31) / 32;
+            std::vector<double> w(nw, 0.0);
+            for (size_t q = 0; q < h.size(); ++q) if (h[q]) w[q >> 5] += (double)(1u << (q & 31));
+            Context::get().comm->allreduce(w.data(), (int)nw, ReduceOp::Sum);
+            for (size_t q = 0; q < h.size(); ++q) h[q] = (((unsigned long long)w[q >> 5]) >> (q & 31)) & 1ull;
         }
         // ---- cells under the new level l+2 grids (grown by the nesting buffer at level l+1), so that level l+1 will contain them
         if (l + 2 <= max_level)
@@ -156,7 +183,7 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
         NavierStokes& c = *lev[l - 1];
         Geometry g = c.g;
         for (int d = 0; d < 3; ++d) { g.domain.lo[d] *= m_ratio; g.domain.hi[d] = (g.domain.hi[d] + 1) * m_ratio - 1; g.dx[d] /= (double)m_ratio; }
-        LayoutP nl = std::make_shared<Layout>(grids[l - 1], std::vector<int>(grids[l - 1].size(), 0), ctx.comm->rank);
+        LayoutP nl = std::make_shared<Layout>(grids[l - 1], distribute_boxes(grids[l - 1], ctx.comm->nranks), ctx.comm->rank);
         lev.push_back(std::make_unique<NavierStokes>(g, nl, p, o));
         NavierStokes& s = *lev.back();
         s.level = l; s.ratio = m_ratio;

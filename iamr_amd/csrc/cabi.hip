@@ -70,6 +70,13 @@ int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
 int iamrx_godunov_set_ppm(int use_ppm) { IAMRX_TRY godunov_set_ppm(use_ppm != 0); IAMRX_CATCH }
+int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity)
+{
+    IAMRX_TRY
+    if (report && capacity > 0) { const std::string r = scope_profile_report(); strncpy(report, r.c_str(), capacity - 1); report[capacity - 1] = 0; }
+    if (enable >= 0) scope_profile_enable(enable != 0, reset != 0);
+    IAMRX_CATCH
+}
 int iamrx_sync_count(size_t* n_stream_sync) { IAMRX_TRY *n_stream_sync = Context::get().n_stream_sync; IAMRX_CATCH }
 int iamrx_alloc_count(size_t* n_device_malloc)
 {

@@ -74,10 +74,22 @@ struct RcclComm : Comm {
         IAMRX_HIP_CHECK(hipMalloc(&d_red, 64 * sizeof(double)));
         IAMRX_HIP_CHECK(hipHostMalloc(&h_red, 64 * sizeof(double)));
     }
+    int red_cap = 64;
+    void allreduce_device(double* dev_vals, int n, ReduceOp op, hipStream_t s) override
+    {
+        const int rop = op == ReduceOp::Sum ? kNcclSum : (op == ReduceOp::Max ? kNcclMax : kNcclMin);
+        IAMRX_NCCL_CHECK(g_rccl.AllReduce(dev_vals, dev_vals, (size_t)n, kNcclDouble, rop, comm, s));
+    }
     void allreduce(double* vals, int n, ReduceOp op) override
     {
-        IAMRX_ASSERT(n <= 64);
         hipStream_t s = Context::get().stream;
+        if (n > red_cap) {               // rare large host-side reductions (the tag maps of a regrid)
+            IAMRX_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(d_red); (void)hipHostFree(h_red);
+            red_cap = n;
+            IAMRX_HIP_CHECK(hipMalloc(&d_red, (size_t)red_cap * sizeof(double)));
+            IAMRX_HIP_CHECK(hipHostMalloc(&h_red, (size_t)red_cap * sizeof(double)));
+        }
         std::memcpy(h_red, vals, n * sizeof(double));
         IAMRX_HIP_CHECK(hipMemcpyAsync(d_red, h_red, n * sizeof(double), hipMemcpyHostToDevice, s));
         const int rop = op == ReduceOp::Sum ? kNcclSum : (op == ReduceOp::Max ? kNcclMax : kNcclMin);
@@ -101,6 +113,16 @@ struct CallbackComm : Comm {
     iamrx_exchange_cb ex;
     CallbackComm(int r, int n, iamrx_allreduce_cb a, iamrx_exchange_cb e) : ar(a), ex(e) { rank = r; nranks = n; }
     void allreduce(double* vals, int n, ReduceOp op) override { ar(vals, n, op == ReduceOp::Sum ? 0 : (op == ReduceOp::Max ? 1 : 2)); }
+    // host-staged transport of the tests: drain, copy down, reduce through the callback, copy up (the RCCL transport reduces in place)
+    void allreduce_device(double* dev_vals, int n, ReduceOp op, hipStream_t s) override
+    {
+        std::vector<double> h((size_t)n);
+        IAMRX_HIP_CHECK(hipMemcpyAsync(h.data(), dev_vals, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        IAMRX_HIP_CHECK(hipStreamSynchronize(s));
+        allreduce(h.data(), n, op);
+        IAMRX_HIP_CHECK(hipMemcpyAsync(dev_vals, h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        IAMRX_HIP_CHECK(hipStreamSynchronize(s));
+    }
     void exchange(const std::vector<Message>& sends, const std::vector<Message>& recvs, hipStream_t s) override
     {
         IAMRX_HIP_CHECK(hipStreamSynchronize(s));

@@ -16,7 +16,39 @@
 
 namespace iamrx {
 
-struct CfC1 { double c1[3][3]; int maxorder; };   // CfTab::c[d][NX-2][1]
+struct CfC1 { double c1[3][3]; double c2[3][3], c3[3][3]; int maxorder; int maintain; };   // CfTab::c[d][NX-2][1..3]; maintain: see cf_maintain
+
+// Coarse/fine ghost cells kept current by the colour passes themselves (homogeneous data, one component).  The ghost G of a line normal
+// to a coarse/fine face is c1 p1 + c2 p2 + c3 p3 of the first NX - 1 cells inside (k_cf_fill).  A pass of colour C reads G only in
+// lines whose first cell p1 has colour C; p1 and p3 then have colour C, p2 the other one, so the G such a pass reads went stale in the
+// pass of the OTHER colour, through p2 alone.  The thread that updates a cell at distance 2 from a coarse/fine face therefore rewrites
+// that line's G with its new value (p1, p3 do not change during its pass; nobody reads this G during its pass): the next pass finds
+// exactly what a k_cf_fill launch in front of it would have written (same expression, same operands) -- one fill in front of the first
+// pass of a smoothing call instead of one per pass.  NX == 2 (boxes one cell wide): G = c1 p1, rewritten by the thread of p1.
+__device__ __forceinline__ void cf_maintain(const FabD& phi, const FabD& cfm, const BoxD& b, const CfC1& t, int i, int j, int k, double pnew)
+{
+    const int idx[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d) {
+        const int NX = min(b.len(d) + 1, t.maxorder);
+        if (NX < 2) continue;
+        const int target = NX == 2 ? 1 : 2;
+        for (int side = 0; side < 2; ++side) {
+            const int s = side == 0 ? 1 : -1, f = side == 0 ? b.lo[d] : b.hi[d];
+            if ((idx[d] - f) * s + 1 != target) continue;
+            int g[3] = {i, j, k};
+            g[d] = f - s;
+            if (cfm(g[0], g[1], g[2]) != 1.0) continue;
+            const double cq[4] = {0.0, t.c1[d][NX - 2], t.c2[d][NX - 2], t.c3[d][NX - 2]};
+            double v = 0.0;
+            int m[3] = {i, j, k};
+            for (int q = 1; q < NX; ++q) {
+                m[d] = g[d] + q * s;
+                v += (q == target ? pnew : (double)phi(m[0], m[1], m[2], 0)) * cq[q];
+            }
+            phi(g[0], g[1], g[2], 0) = v;
+        }
+    }
+}
 
 struct GsrbBC {
     int dlo[3], dhi[3];
@@ -172,17 +204,23 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
                              + dhz * (bzm * phi(i, j, km, n) + bzp * phi(i, j, kp, n));
             const double p0 = phi(i, j, k, n);
             const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
-            phi(i, j, k, n) = p0 + omega / g_m_d * res;
+            const double pn = p0 + omega / g_m_d * res;
+            phi(i, j, k, n) = pn;
+            if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
+                cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
         }
     }
 }
 
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
-               bool wrap, const MultiFab* cfm, const CfTab* cftab)
+               bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts)
 {
     CfC1 cfc;
     cfc.maxorder = cftab ? cftab->maxorder : 2;
-    for (int d = 0; d < 3; ++d) for (int q = 0; q < 3; ++q) cfc.c1[d][q] = cftab ? cftab->c[d][q][1] : 0.0;
+    cfc.maintain = (cf_maintain_ghosts && cfm && cftab && phi.ncomp == 1 && !shell_only) ? 1 : 0;
+    for (int d = 0; d < 3; ++d) for (int q = 0; q < 3; ++q) {
+        cfc.c1[d][q] = cftab ? cftab->c[d][q][1] : 0.0; cfc.c2[d][q] = cftab ? cftab->c[d][q][2] : 0.0; cfc.c3[d][q] = cftab ? cftab->c[d][q][3] : 0.0;
+    }
     const FabD* cft = (cfm && cftab) ? cfm->d_tab : nullptr;
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
@@ -426,7 +464,7 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
 {
     auto& ctx = Context::get();
     static unsigned long long* d_norm = nullptr;
-    if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, sizeof(unsigned long long)));
+    if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, 2 * sizeof(unsigned long long)));
     if (phi.nlocal() > 0) {
         const Layout& l = *phi.layout;
         Tiling t = level_tiling(l, cell_type(), 0, 8);
@@ -438,14 +476,18 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
         if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0, norm_out ? d_norm : nullptr);
     }
     if (norm_out) {
+        // the bit pattern of a non-negative double orders like the double: the ranks' maxima are combined in place on the device
+        // (Comm::allreduce_device), then read back once
         double v = 0.0;
-        if (phi.nlocal() > 0) {
+        const bool global = !phi.layout->replicated && ctx.comm->nranks > 1;
+        if (phi.nlocal() == 0 && global) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        if (global) ctx.comm->allreduce_device(reinterpret_cast<double*>(d_norm), 1, ReduceOp::Max, ctx.stream);
+        if (phi.nlocal() > 0 || global) {
             unsigned long long bits = 0;
             IAMRX_HIP_CHECK(hipMemcpyAsync(&bits, d_norm, sizeof(bits), hipMemcpyDeviceToHost, ctx.stream));
             ctx.sync();
             std::memcpy(&v, &bits, sizeof(v));
         }
-        if (!phi.layout->replicated) ctx.comm->allreduce(&v, 1, ReduceOp::Max);
         *norm_out = v;
     }
 }
@@ -616,7 +658,9 @@ __global__ void __launch_bounds__(BOT_NT) k_abec_bottom(BoxD b, const FabD* __re
     if (on) cor(i, j, k, 0) = x;
 }
 
-bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp)
+// cftab != nullptr: the level belongs to a refined AMR level (MLLinOp::setCoarseFineBC): faces of the box that are not domain faces (or
+// are faces of a periodic direction the box does not span) carry homogeneous coarse/fine Dirichlet data with the level's CfTab weights
+bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp, bool cf)
 {
     static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
     // the answer must be the same on every rank (it decides the depth of the hierarchy): global information only.  A rank that does not
@@ -624,9 +668,13 @@ bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* b
     if (!enabled || ncomp != 1 || nbc != 1 || l.boxes.size() != 1) return false;
     const BoxD b = l.boxes[0];
     for (int d = 0; d < 3; ++d) {
-        if (b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || b.len(d) > 8) return false;
+        if (b.len(d) > 8) return false;
+        const bool spans = b.lo[d] == g.domain.lo[d] && b.hi[d] == g.domain.hi[d];
+        if (!cf && !spans) return false;
         if (g.periodic[d]) continue;
         for (int side = 0; side < 2; ++side) {
+            const bool on_dom = side == 0 ? b.lo[d] == g.domain.lo[d] : b.hi[d] == g.domain.hi[d];
+            if (!on_dom) continue;
             const int t = side == 0 ? bcs[0].lo[d] : bcs[0].hi[d];
             if (t != lo_neumann && t != lo_dirichlet && t != lo_reflect_odd) return false;
         }
@@ -635,25 +683,46 @@ bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* b
 }
 
 void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
-                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters)
+                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters, const CfTab* cftab)
 {
     const Layout& l = *cor.layout;
-    IAMRX_ASSERT(abec_bottom_device_ok(g, l, &bc, 1, cor.ncomp) && cor.ngrow >= 1);
+    IAMRX_ASSERT(abec_bottom_device_ok(g, l, &bc, 1, cor.ncomp, cftab != nullptr) && cor.ngrow >= 1);
     if (l.nlocal() == 0) return;
+    const BoxD b = l.boxes[0];
     BotBC bb;
+    GsrbBC gb;                       // first-interior-cell weights of the ghost formulas, relative to the faces of the box
+    gb.nbc = 1;
     for (int d = 0; d < 3; ++d) {
-        bb.per[d] = g.periodic[d];
+        const bool spans = b.lo[d] == g.domain.lo[d] && b.hi[d] == g.domain.hi[d];
+        bb.per[d] = g.periodic[d] && spans;
+        gb.dlo[d] = b.lo[d]; gb.dhi[d] = b.hi[d];
         for (int side = 0; side < 2; ++side) {
-            bb.bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
-            double cc[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, cc, NX);
+            const bool on_dom = !g.periodic[d] && (side == 0 ? b.lo[d] == g.domain.lo[d] : b.hi[d] == g.domain.hi[d]);
+            double cc[4] = {0.0, 0.0, 0.0, 0.0};
+            int NX = 0, type = lo_periodic;
+            double first = 0.0;
+            if (bb.per[d]) { type = lo_periodic; }
+            else if (on_dom) {
+                type = side == 0 ? bc.lo[d] : bc.hi[d];
+                dirichlet_coefs(g.domain.len(d), bc.maxorder, cc, NX);
+                first = type == lo_neumann ? 1.0 : (type == lo_reflect_odd ? -1.0 : (NX >= 2 ? cc[1] : 0.0));
+            } else {                 // coarse/fine face: Dirichlet point half a coarse cell behind the face (CfTab), homogeneous in the correction
+                IAMRX_ASSERT(cftab != nullptr);
+                type = lo_dirichlet;
+                NX = std::min(b.len(d) + 1, cftab->maxorder);
+                for (int q = 0; q < NX; ++q) cc[q] = cftab->c[d][NX - 2][q];
+                first = cc[1];
+            }
+            bb.bct[2 * d + side] = type;
             for (int q = 0; q < 4; ++q) bb.c[2 * d + side][q] = cc[q];
             bb.c[2 * d + side][4] = NX;
+            for (int n = 0; n < 3; ++n) (side == 0 ? gb.cflo[n][d] : gb.cfhi[n][d]) = first;
         }
     }
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
-    hipLaunchKernelGGL(k_abec_bottom, dim3(1), dim3(BOT_NT), 0, Context::get().stream, l.boxes[0], cor.d_tab, res.d_tab,
+    hipLaunchKernelGGL(k_abec_bottom, dim3(1), dim3(BOT_NT), 0, Context::get().stream, b, cor.d_tab, res.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, c.alpha, dhx, dhy, dhz, bb,
-                       make_gsrb_bc(g, &bc, 1), singular ? 1 : 0, eps_rel, maxiter, nub, nuf, omega, d_iters);
+                       gb, singular ? 1 : 0, eps_rel, maxiter, nub, nuf, omega, d_iters);
 }
 
 // ---------------------------------------------------------------------------- domain BC ghost fill

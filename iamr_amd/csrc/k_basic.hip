@@ -139,21 +139,28 @@ __global__ void __launch_bounds__(256) k_norm0(Tiling t, const BoxD* __restrict_
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
 }
 
-static double finish_to_host(int op, int nout, int np)
+// Stage 2 of every reduction: the block partials -> nout values on the device; global: combined across the ranks IN PLACE on the device
+// (Comm::allreduce_device: ncclAllReduce on the launch stream, no host round trip); then ONE read-back.  np == 0: this rank holds no
+// data of the level and contributes the identity (0: sums, and maxima of absolute values).
+static double finish_to_host(int op, int nout, int np, bool global)
 {
     auto& ctx = Context::get();
+    ctx.ensure_scratch((size_t)nout * np + 16);
     double* partials = ctx.d_scratch;
     double* out = ctx.d_scratch + (size_t)nout * np;
-    if (op == 0) hipLaunchKernelGGL((k_reduce_finish<0>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
+    if (np == 0) IAMRX_HIP_CHECK(hipMemsetAsync(out, 0, nout * sizeof(double), ctx.stream));
+    else if (op == 0) hipLaunchKernelGGL((k_reduce_finish<0>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
     else hipLaunchKernelGGL((k_reduce_finish<1>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
+    if (global && ctx.comm->nranks > 1) ctx.comm->allreduce_device(out, nout, op == 0 ? ReduceOp::Sum : ReduceOp::Max, ctx.stream);
     IAMRX_HIP_CHECK(hipMemcpyAsync(ctx.h_scratch, out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx.stream));
     ctx.sync();
     return ctx.h_scratch[0];
 }
 
-double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng)
+double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
 {
-    if (mf.nlocal() == 0) return 0.0;
+    global = global && !mf.layout->replicated;
+    if (mf.nlocal() == 0) return (global && Context::get().comm->nranks > 1) ? finish_to_host(1, 1, 0, true) : 0.0;
     auto& ctx = Context::get();
     Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
     dim3 g = t.grid();
@@ -161,7 +168,7 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng)
     ctx.ensure_scratch((size_t)np + 16);
     hipLaunchKernelGGL(k_norm0, g, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, mf.type.t[0], mf.type.t[1], mf.type.t[2], ng,
                        mf.d_tab, comp, nc, ctx.d_scratch);
-    return finish_to_host(1, 1, np);
+    return finish_to_host(1, 1, np, global);
 }
 
 // owner mask for nodal / face data: a box owns index hi+1 in a nodal direction only on a
@@ -233,6 +240,8 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
     auto& ctx = Context::get();
     const MultiFab& m = *x[0];
     for (int q = 0; q < nout; ++q) out[q] = 0.0;
+    const bool global = !local && !m.layout->replicated && ctx.comm->nranks > 1;
+    if (m.nlocal() == 0 && global) { finish_to_host(0, nout, 0, true); for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q]; }
     if (m.nlocal() > 0) {
         Tiling t = level_tiling(*m.layout, m.type, 0, 8);
         dim3 gr = t.grid();
@@ -242,10 +251,9 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
         hipLaunchKernelGGL(k_dots, gr, Tiling::block(), 0, ctx.stream, t, m.layout->d_boxes, own, nout,
                            x[0]->d_tab, y[0]->d_tab, nout > 1 ? x[1]->d_tab : nullptr, nout > 1 ? y[1]->d_tab : nullptr,
                            comp, nc, ctx.d_scratch, np);
-        finish_to_host(0, nout, np);
+        finish_to_host(0, nout, np, global);
         for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q];
     }
-    if (!local && !m.layout->replicated) ctx.comm->allreduce(out, nout, ReduceOp::Sum);
 }
 
 __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own,
@@ -265,9 +273,10 @@ __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __rest
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g)
+double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool global)
 {
-    if (mf.nlocal() == 0) return 0.0;
+    global = global && !mf.layout->replicated;
+    if (mf.nlocal() == 0) return (global && Context::get().comm->nranks > 1) ? finish_to_host(0, 1, 0, true) : 0.0;
     auto& ctx = Context::get();
     Tiling t = level_tiling(*mf.layout, mf.type, 0, 8);
     dim3 gr = t.grid();
@@ -275,7 +284,7 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g)
     ctx.ensure_scratch((size_t)np + 16);
     const OwnerInfo own = make_owner(mf, g);
     hipLaunchKernelGGL(k_sum_unique, gr, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, own, mf.d_tab, comp, ctx.d_scratch);
-    return finish_to_host(0, 1, np);
+    return finish_to_host(0, 1, np, global);
 }
 
 // ------------------------------------------------------------------ BLAS-1 style

@@ -10,8 +10,9 @@ void launch_fill(double* p, size_t n, double v, hipStream_t s);
 void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add = false);
 void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s);
 void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add = false);
-double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng);
-double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g);   // local sum over owner copies
+// global: combined over the ranks (on the device, before the single read-back) unless the layout is replicated
+double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global = false);
+double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool global = false);   // sum over owner copies
 // nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>
 void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);
 // y = a*x + b*y etc. (valid region + ng)
@@ -66,7 +67,7 @@ void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cf
 void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
 // bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc,
-               bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr);
+               bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr, bool cf_maintain_ghosts = false);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,
@@ -74,9 +75,9 @@ void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_i
 // out = rhs - L(phi)  (rhs == nullptr: out = L(phi))
 void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs, double* norm_out = nullptr);
 // bottom solve (BiCGStab + post-smoothing, CellMG::bottom_solve) of a single-box level of at most 8^3 cells in one single-workgroup launch
-bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp);
+bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp, bool cf = false);
 void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
-                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters);
+                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters, const CfTab* cftab = nullptr);
 void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
 void cc_restrict(MultiFab& crse, const MultiFab& fine);          // average of 8
 void cc_prolong_add(MultiFab& fine, const MultiFab& crse);       // piecewise constant

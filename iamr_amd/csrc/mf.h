@@ -28,6 +28,9 @@ struct Comm {
     int rank = 0, nranks = 1;
     virtual ~Comm() = default;
     virtual void allreduce(double* host_vals, int n, ReduceOp op) { (void)host_vals; (void)n; (void)op; }
+    // in place on a DEVICE buffer, ordered on stream s, no host synchronisation: the reductions of the solvers (norms, dot products)
+    // finish on the device, are combined across ranks where they are, and are read back once (k_basic.hip finish_to_host)
+    virtual void allreduce_device(double* dev_vals, int n, ReduceOp op, hipStream_t s) { (void)dev_vals; (void)n; (void)op; (void)s; }
     // exchange packed device buffers with peers (all sends/recvs posted together)
     virtual void exchange(const std::vector<Message>& sends, const std::vector<Message>& recvs, hipStream_t s)
     {
@@ -62,6 +65,21 @@ struct Context {
     char* h_ring = nullptr;
     size_t ring_off = 0;
 };
+
+// ------------------------------------------------------------------ scoped profiler (measurement aid)
+// ProfScope p("name") accumulates the wall time of the scope (stream drained at both ends) under its name while profiling is enabled
+// (iamrx_scope_profile); nested scopes are reported with their path "outer/inner".  Off: two predictable branches, no synchronisation.
+struct ProfScope {
+    static bool enabled;
+    bool on;
+    std::string key;
+    double t0 = 0.0;
+    explicit ProfScope(const char* name);
+    ~ProfScope();
+};
+#define PROF_NEXT(var, name) do { (var).reset(); (var) = std::make_unique<::iamrx::ProfScope>(name); } while (0)
+void scope_profile_enable(bool on, bool reset);
+std::string scope_profile_report();
 
 // ------------------------------------------------------------------ layout
 // All boxes of one level (cell-centred, non-overlapping) + owner rank of each.

@@ -2,6 +2,7 @@
 // Plays the role of AMReX MultiFab / FillBoundary at IAMR's call sites (SURVEY 2.3 "Same-level ghost
 // exchange": reference Source/MacProj.cpp:1127, Source/Projection.cpp:338-339, ...).
 #include "mf.h"
+#include <chrono>
 #include <functional>
 #include <tuple>
 #include "launch.h"
@@ -95,6 +96,41 @@ void Context::release_cache()
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     free_blocks.clear();
     bytes_cached = 0;
+}
+
+// ---- scoped profiler
+bool ProfScope::enabled = false;
+namespace {
+struct ScopeStat { double ms = 0.0; long calls = 0; };
+std::map<std::string, ScopeStat>& scope_stats() { static auto* m = new std::map<std::string, ScopeStat>(); return *m; }
+std::vector<std::string>& scope_stack() { static auto* v = new std::vector<std::string>(); return *v; }
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+ProfScope::ProfScope(const char* name) : on(enabled)
+{
+    if (!on) return;
+    auto& st = scope_stack();
+    key = st.empty() ? std::string(name) : st.back() + "/" + name;
+    st.push_back(key);
+    Context::get().sync();
+    t0 = now_ms();
+}
+ProfScope::~ProfScope()
+{
+    if (!on) return;
+    Context::get().sync();
+    auto& e = scope_stats()[key];
+    e.ms += now_ms() - t0; e.calls += 1;
+    auto& st = scope_stack();
+    if (!st.empty()) st.pop_back();
+}
+void scope_profile_enable(bool on, bool reset) { ProfScope::enabled = on; if (reset) { scope_stats().clear(); scope_stack().clear(); } }
+std::string scope_profile_report()
+{
+    std::string out;
+    char buf[256];
+    for (auto& kv : scope_stats()) { snprintf(buf, sizeof buf, "%-70s %10.3f ms %8ld calls\n", kv.first.c_str(), kv.second.ms, kv.second.calls); out += buf; }
+    return out;
 }
 
 void Context::sync() { ++n_stream_sync; if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
@@ -342,16 +378,12 @@ void MultiFab::copy_from_host(int li, const double* src)
 
 double MultiFab::norm0(int comp, int nc, int ng, bool local) const
 {
-    double v = reduce_norm0(*this, comp, nc, ng);
-    if (!local && !layout->replicated) Context::get().comm->allreduce(&v, 1, ReduceOp::Max);
-    return v;
+    return reduce_norm0(*this, comp, nc, ng, !local);
 }
 
 double MultiFab::sum_unique(const Geometry& g, int comp, bool local) const
 {
-    double v = reduce_sum_unique(*this, comp, g);
-    if (!local && !layout->replicated) Context::get().comm->allreduce(&v, 1, ReduceOp::Sum);
-    return v;
+    return reduce_sum_unique(*this, comp, g, !local);
 }
 
 // ------------------------------------------------------------------ FillBoundary plan

@@ -90,7 +90,8 @@ public:
     AbecCoef coef(int l) const;
     const Geometry& geom(int l) const { return m_lev[l].g; }
     void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, bool corners = true);
-    void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill);
+    // cf_ghosts_current: the coarse/fine ghost cells are already what a fill would write (kept so by the passes themselves, k_abec.hip cf_maintain)
+    void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current = false);
     // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
     void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill);
     bool fused_smoother_ok(int l) const;

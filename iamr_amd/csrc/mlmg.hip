@@ -90,7 +90,7 @@ void CellMG::prepare()
         Level& f = m_lev.back();
         // a single box of at most 8^3 cells is solved by the single-workgroup device bottom solver (k_abec_bottom): no need to coarsen
         // further (IAMRX_MG_DEVICE_BOTTOM=0: host-driven BiCGStab on the coarsest possible level, upstream's shape)
-        if (m_o.device_bottom && !m_cf && !m_tensor && !m_o.bottom_smoother_only && abec_bottom_device_ok(f.g, *f.layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp)) break;
+        if (m_o.device_bottom && !m_tensor && !m_o.bottom_smoother_only && abec_bottom_device_ok(f.g, *f.layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp, m_cf)) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
@@ -107,8 +107,8 @@ void CellMG::prepare()
         m_lev.push_back(std::move(c));
     }
     const int nl = (int)m_lev.size();
-    m_bottom_dev = m_o.device_bottom && m_dd_sweeps == 0 && !m_cf && !m_tensor && !m_o.bottom_smoother_only &&
-                   abec_bottom_device_ok(m_lev.back().g, *m_lev.back().layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp);
+    m_bottom_dev = m_o.device_bottom && m_dd_sweeps == 0 && !m_tensor && !m_o.bottom_smoother_only &&
+                   abec_bottom_device_ok(m_lev.back().g, *m_lev.back().layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp, m_cf);
     for (int l = 0; l < nl; ++l) {
         Level& L = m_lev[l];
         L.cor.define(L.layout, cell_type(), m_ncomp, 1);
@@ -181,18 +181,32 @@ static double dd_omega()
     return v;
 }
 
-void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill)
+// one-component coarse/fine levels: the colour passes keep the coarse/fine ghost cells current themselves (cf_maintain, k_abec.hip), so only
+// the first pass of a smoothing call needs the k_cf_fill launch; IAMRX_CF_MAINTAIN=0: a fill in front of every pass
+static bool cf_maintain_on()
+{
+    static const bool v = !(getenv("IAMRX_CF_MAINTAIN") && atoi(getenv("IAMRX_CF_MAINTAIN")) == 0);
+    return v;
+}
+
+void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current)
 {
     AbecCoef c = coef(l);
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
     // one box spanning a fully periodic domain: the kernel reads the periodic images from the valid cells, no ghost fills
     const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
+    const bool maint = m_cf && m_ncomp == 1 && !m_tensor && cf_maintain_on();
     for (int rb = 0; rb < 2; ++rb) {
-        if (!skip_fill && !wrap) applyBC(l, sol, false, nullptr, false);
+        if (!skip_fill && !wrap) {
+            if (maint && (cf_ghosts_current || rb == 1)) {        // everything but the coarse/fine ghost cells
+                sol.FillBoundary(m_lev[l].g);
+                abec_apply_domain_bc(m_lev[l].g, sol, m_bcn[0], false, nullptr);
+            } else applyBC(l, sol, false, nullptr, false);
+        }
         // diagonally dominant shortcut: plain Gauss-Seidel -- over-relaxation leaves a (1 - omega) = 0.15 floor per sweep on an operator
         // that is almost its diagonal, where omega = 1 contracts by the square of the Jacobi factor
         abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_dd_sweeps > 0 ? dd_omega() : m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
-                  m_cf ? &m_lev[l].cftab : nullptr);
+                  m_cf ? &m_lev[l].cftab : nullptr, maint);
         skip_fill = false;
     }
 }
@@ -225,7 +239,7 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
 {
     if (nsweeps <= 0) return;
     if (!fused_smoother_ok(l)) {
-        for (int i = 0; i < nsweeps; ++i) smooth(l, sol, rhs, skip_first_fill && i == 0);
+        for (int i = 0; i < nsweeps; ++i) smooth(l, sol, rhs, skip_first_fill && i == 0, i > 0);
         return;
     }
     Level& L = m_lev[l];
@@ -339,9 +353,10 @@ void CellMG::bottom_solve(MGStats& st)
         return;
     }
     if (m_bottom_dev) {
-        const long nunk = (long)L.g.domain.npts() * m_ncomp;
+        const long nunk = L.layout->total_cells() * m_ncomp;
         const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
-        abec_bottom_solve(L.g, coef(l), L.cor, L.res, m_bcn[0], m_singular, m_o.bottom_reltol, maxiter, m_o.nub, m_o.nuf, m_o.omega, bottom_iters_dev());
+        abec_bottom_solve(L.g, coef(l), L.cor, L.res, m_bcn[0], m_singular, m_o.bottom_reltol, maxiter, m_o.nub, m_o.nuf, m_o.omega, bottom_iters_dev(),
+                          m_cf ? &L.cftab : nullptr);
         return;
     }
     MultiFab b(L.layout, cell_type(), m_ncomp, 0);

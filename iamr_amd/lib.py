@@ -317,6 +317,32 @@ class FluxRegister:
             pass
 
 
+class SyncRegister:
+    """IAMR's SyncRegister (Source/SyncRegister.H:10-66; names as in the reference: CrseInit, FineAdd, InitRHS) of one coarse/fine interface"""
+
+    def __init__(self, fine_layout, crse_layout, cgeom, fgeom, ratio=2, phys_lo=(0, 0, 0), phys_hi=(0, 0, 0)):
+        self.h = C.c_void_p()
+        self._keep = (fine_layout, crse_layout)
+        check(lib().iamrx_syncreg_create(fine_layout.h, crse_layout.h, C.byref(cgeom), C.byref(fgeom), int(ratio), i3(phys_lo), i3(phys_hi), C.byref(self.h)))
+
+    def CrseInit(self, sync_resid_crse, mult):
+        check(lib().iamrx_syncreg_crse_init(self.h, sync_resid_crse.h, C.c_double(mult)))
+
+    def FineAdd(self, sync_resid_fine, mult):
+        check(lib().iamrx_syncreg_fine_add(self.h, sync_resid_fine.h, C.c_double(mult)))
+
+    def InitRHS(self, rhs):
+        check(lib().iamrx_syncreg_init_rhs(self.h, rhs.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().iamrx_syncreg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def average_down(fine, crse, scomp=0, ncomp=None, ratio=2):
     check(lib().iamrx_average_down(fine.h, crse.h, scomp, crse.ncomp if ncomp is None else ncomp, ratio))
 

@@ -22,11 +22,11 @@ def init_level(ns, lay, lib, N, pr, n):
         ns.init_taylorgreen(pb["vfac"], pb["a"], pb["b"], pb["c"], pb["rho0"])
 
 
-def build_amr(pr, lib, N):
+def build_amr(pr, lib, N, world=1):
     """hierarchy of fixed grids: level 0 chopped by amr.max_grid_size, the refined levels as the grid file gives them"""
     from .amr import Amr
     g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
-    lays = [lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], 1)] + [lib.Layout(b) for b in pr["fine_boxes"]]
+    lays = [lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], world)] + [lib.Layout(b, [q % world for q in range(len(b))]) for b in pr["fine_boxes"]]
     amr = Amr(g0, lays, N.ns_params(**pr["params"]))
     for l, lev in enumerate(amr.levels):
         init_level(lev, lays[l], lib, N, pr, [v * 2 ** l for v in pr["n"]])
@@ -73,14 +73,19 @@ def write_plot_amr(amr, lays, pr, N, step, root):
     return path
 
 
-def main_amr(pr, inp, lib, N):
-    amr, lays, g0 = build_amr(pr, lib, N)
+def main_amr(pr, inp, lib, N, rank=0, world=1):
+    """hierarchy run; world > 1: the boxes of every level are spread over the ranks (level 0 by Layout.decompose, fixed refined grids
+    round-robin, regridded levels by the library's knapsack), plotfiles are written by single-rank runs only"""
+    amr, lays, g0 = build_amr(pr, lib, N, world)
+    say = print if rank == 0 else (lambda *a, **k: None)
     if inp.ignored:
-        print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
+        say("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
     amr.post_init(pr["stop_time"])
     plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
+    if world > 1:
+        plot_int = -1
     if plot_int > 0:
-        print("PLOTFILE:", write_plot_amr(amr, lays, pr, N, 0, plot_root))
+        say("PLOTFILE:", write_plot_amr(amr, lays, pr, N, 0, plot_root))
     t0 = time.perf_counter()
     step = 0
     while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or amr.time < pr["stop_time"] - 1e-14):
@@ -89,11 +94,11 @@ def main_amr(pr, inp, lib, N):
         dt = amr.coarse_step()
         lays = amr.layouts                      # a regrid during the step replaces them
         step += 1
-        print(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g} LEVELS = {amr.nlev} GRIDS = {[len(l.boxes) for l in lays]}")
+        say(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g} LEVELS = {amr.nlev} GRIDS = {[len(l.boxes) for l in lays]}")
         if plot_int > 0 and step % plot_int == 0:
-            print("PLOTFILE:", write_plot_amr(amr, lays, pr, N, step, plot_root))
+            say("PLOTFILE:", write_plot_amr(amr, lays, pr, N, step, plot_root))
     lib.sync()
-    print(f"Run time = {time.perf_counter() - t0:.6f}")
+    say(f"Run time = {time.perf_counter() - t0:.6f}")
     return 0
 
 
@@ -157,9 +162,7 @@ def main(argv):
         comm.init_rccl_from_torch(dist)
     pr = inp.problem()
     if pr["fine_boxes"] or pr.get("regrid"):
-        if world > 1:
-            raise NotImplementedError("iamr_amd.run: refined hierarchies run on one rank (the multi-level driver does not shard levels yet)")
-        return main_amr(pr, inp, lib, N)
+        return main_amr(pr, inp, lib, N, rank, world)
     ns, lay, g, pr = build(inp, lib, N, world, pr)
     if rank == 0 and inp.ignored:
         print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))

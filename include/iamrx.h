@@ -76,6 +76,10 @@ int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
 void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
 int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
 int iamrx_alloc_count(size_t* n_device_malloc);  /* hipMalloc calls so far (caching-allocator misses; The_Arena role) */
+/* scoped wall-time profile of the library's host-side sections (measurement aid; synchronises the stream at every scope boundary while
+ * enabled).  Writes the accumulated report (one line per scope path: name, ms, calls) into report[capacity] first (may be NULL), then
+ * enable: 1 on, 0 off, -1 unchanged; reset != 0 clears the accumulated times. */
+int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity);
 int iamrx_sync_count(size_t* n_stream_sync);     /* host waits on the library stream so far (scalar read-backs of norms / dot products, plan uploads) */
 /* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
  * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */

@@ -37,7 +37,7 @@ def setup(orc, lib, nf, boxes, variable_b, seed, maxorder):
     return n, nc, g_o, g_d, gc_d, b_o, cphi, rhs, phi0
 
 
-def solve_both(orc, lib, nf, boxes, variable_b=True, seed=3, maxorder=4, fixed_iters=0, rhs_override=None, rtol=1e-10):
+def solve_both(orc, lib, nf, boxes, variable_b=True, seed=3, maxorder=4, fixed_iters=0, rhs_override=None, rtol=1e-10, device_bottom=0):
     L = orc.lib()
     L.orc_abec_solve_cf.restype = None
     L.orc_cf_interp_bndry.restype = None
@@ -55,7 +55,7 @@ def solve_both(orc, lib, nf, boxes, variable_b=True, seed=3, maxorder=4, fixed_i
     rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs.a, rhs.lo)
     cphi_d = lib.MultiFab(clay, lib.CELL, 1, 1); cphi_d.set_from_global(cphi.a, cphi.lo)
     st_d = lib.abec_solve_cf(g_d, 0.0, 1.0, None, b_d, phi_d, rhs_d, cphi_d, gc_d, 2, rtol=rtol, atol=0.0,
-                             opts=lib.mg_opts(maxorder=maxorder, fixed_iters=fixed_iters))
+                             opts=lib.mg_opts(maxorder=maxorder, fixed_iters=fixed_iters, device_bottom=device_bottom))
     # oracle, same multigrid depth
     Lv = orc.abec_level(g_o, b_o, boxes=boxes)
     bcv = orc.Fab(n, orc.CELL, 1, 3)
@@ -91,6 +91,18 @@ def test_cf_solve_matches_oracle(orc, gpu, case, maxorder):
         assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
     st_d, st_o, got, ref = solve_both(orc, gpu, 32, boxes, maxorder=maxorder)
     assert st_d.converged and st_d.iters == st_o.iters, (st_d.iters, st_o.iters)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 1e-8 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_cf_solve_with_the_device_bottom_solver(orc, gpu, case):
+    """the single-workgroup bottom solver on a coarse/fine level (k_abec_bottom with the CfTab ghost formula on the faces of the box that
+    are not domain faces): the hierarchy ends at the first single-box level of at most 8^3 cells; same converged solution as the
+    oracle's upstream-shaped hierarchy, within one cycle of its iteration count"""
+    boxes = CASES[case]
+    st_d, st_o, got, ref = solve_both(orc, gpu, 32, boxes, device_bottom=1)
+    assert st_d.converged and abs(st_d.iters - st_o.iters) <= 1, (st_d.iters, st_o.iters)
     for g, r in zip(got, ref):
         assert np.abs(g - r).max() <= 1e-8 * max(1.0, np.abs(r).max()), np.abs(g - r).max()
 

@@ -21,3 +21,12 @@ for step in range(3):
               f"nodal {nd.iters} ({nd.vcycle_ms:.3f} ms, levels {nd.nlevels}) visc {v.iters} ({v.vcycle_ms:.3f} ms)")
     s, ms = amr.sync_stats()
     print(f"   sync project {s.iters} cycles ({s.vcycle_ms:.3f} ms) res0 {s.resnorm0:.3e} res {s.resnorm:.3e}; mac_sync {ms.iters} ({ms.vcycle_ms:.3f} ms)")
+import ctypes as C
+L = lib.lib()
+lib.check(L.iamrx_scope_profile(1, 1, None, C.c_size_t(0)))
+for _ in range(2):
+    amr.coarse_step()
+buf = C.create_string_buffer(1 << 16)
+lib.check(L.iamrx_scope_profile(0, 0, buf, C.c_size_t(1 << 16)))
+print("scope profile of 2 coarse steps:")
+print(buf.value.decode())
