@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("IAMRX_BENCH_N", "256")), help="cells per direction of the per-GPU box")
     ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-multibox", action="store_true", help="skip the single-GPU 8-box / 64-box runs of the same problem")
     ap.add_argument("--cpu-n", type=int, default=96)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--amr-n", type=int, default=128, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
@@ -182,22 +183,25 @@ def file_blob_sha(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def amr_workload(lib, n0, steps, rank=0, world=1, dist=None):
+def amr_workload(lib, n0, steps, rank=0, world=1, dist=None, layout_gpus=None, keep=None):
     """secondary workload (north_star: 2-level AMR TaylorGreen).  Per GPU: an n0^3 box of the base level and one ratio-2 refined box over
     its central (n0/2)^3 coarse cells (n0^3 fine cells), subcycled; nu = 1e-4 as in Tutorials/TaylorGreen/inputs.3d.taylorgreen.  N GPUs:
     the base boxes in the same process grid as the main workload (weak scaling), rank r owns base box r and refined box r.
-    cells advanced per coarse step and GPU = n0^3 + 2 * n0^3."""
+    cells advanced per coarse step and GPU = n0^3 + 2 * n0^3.
+    layout_gpus (tests): build the layout of that many GPUs but spread it over the `world` ranks present (box q -> rank q % world);
+    keep: a list that receives the hierarchy object (tests compare its state)."""
     from iamr_amd import ns as N
     from iamr_amd.amr import Amr
-    pg = proc_grid(world)
+    nbox = layout_gpus if layout_gpus else world
+    pg = proc_grid(nbox)
     ntot = tuple(n0 * pg[d] for d in range(3))
     g0 = lib.Geom.make(ntot, prob_hi=tuple(float(pg[d]) for d in range(3)))
     cb, fb = [], []
-    for r in range(world):
+    for r in range(nbox):
         o = (r % pg[0], (r // pg[0]) % pg[1], r // (pg[0] * pg[1]))
         cb.append((tuple(o[d] * n0 for d in range(3)), tuple((o[d] + 1) * n0 - 1 for d in range(3))))
         fb.append((tuple(2 * o[d] * n0 + n0 // 2 for d in range(3)), tuple(2 * o[d] * n0 + n0 // 2 + n0 - 1 for d in range(3))))
-    own = list(range(world))
+    own = [q % world for q in range(nbox)]
     lays = [lib.Layout(cb, own), lib.Layout(fb, own)]
     amr = Amr(g0, lays, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
     for l in range(2):
@@ -222,7 +226,9 @@ def amr_workload(lib, n0, steps, rank=0, world=1, dist=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     st, stm = amr.sync_stats()
-    cells = float(n0) ** 3 * 3.0 * world
+    cells = float(n0) ** 3 * 3.0 * nbox
+    if keep is not None:
+        keep.append(amr)
     # section breakdown: separate, synchronised pass of two coarse steps (does not perturb the timed region)
     amr.profile(1)
     for _ in range(2):
@@ -235,9 +241,35 @@ def amr_workload(lib, n0, steps, rank=0, world=1, dist=None):
         sections[f"advance_level{l}_sections"] = {k: v / 2 for k, v in zip(names, lsec[l][:6])}
     return {"workload": f"TaylorGreen 3D, 2 levels, per GPU: {n0}^3 base box + one {n0}^3 refined box over its centre (ratio 2, subcycled), "
                         f"{pg[0]}x{pg[1]}x{pg[2]} GPUs, nu = 1e-4, periodic; advance + reflux + avgDown + mac_sync (incl. viscous sync) + MLsyncProject per coarse step",
-            "n_gpus": world,
+            "n_gpus": world, "boxes_per_level": nbox,
             "cells_advanced_per_sec": cells * steps / el, "ms_per_coarse_step": el / steps * 1e3, "coarse_steps": steps,
             "sync_project_iters": st.iters, "mac_sync_iters": stm.iters, "sections_ms_per_coarse_step": sections}
+
+
+def multibox_workload(lib, n, steps=3):
+    """the main workload's n^3 problem on ONE GPU chopped into 8 and 64 boxes: what the real ghost-exchange path costs (copy plans between
+    boxes, no periodic-wrap specialisation of the single-box level: DESIGN.md section 4) -- the per-GPU cost a multi-GPU run inherits"""
+    from iamr_amd import ns as N
+    out = {}
+    for parts in (2, 4):
+        mg = n // parts
+        g = lib.Geom.make((n,) * 3)
+        lay = lib.Layout.decompose((n,) * 3, mg)
+        ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+        ns.post_init(-1.0)
+        ns.step()
+        lib.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ns.step()
+        lib.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        sm, sn, sv = ns.stats()
+        out[f"{parts ** 3}x{mg}^3"] = {"ms_per_step": ms, "cells_per_sec": float(n) ** 3 / ms * 1e3, "mlmg_iters": [sm.iters, sn.iters, sv.iters],
+                                       "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
+        del ns
+    return out
 
 
 def transport_selftest(lib, rank, world):
@@ -482,6 +514,9 @@ def main():
         }
         if amr_res is not None:
             out["amr"] = amr_res
+        if world == 1 and not a.no_multibox:
+            out["single_gpu_multibox"] = multibox_workload(lib, n)
+            out["single_gpu_multibox"]["1x%d^3" % n] = {"ms_per_step": el / a.steps * 1e3, "cells_per_sec": value}
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))

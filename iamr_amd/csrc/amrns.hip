@@ -163,13 +163,13 @@ void sync_interp_cellcons(MultiFab& dst, int dcomp, const MultiFab& crse, int sc
 
 void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
                                const MultiFab* divu, MultiFab* const umac[3], MultiFab* const ucorr[3], const int* iconserv, double dt,
-                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3])
+                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3], int scheme)
 {
     MultiFab scratch(S.layout, cell_type(), ncomp, 0);
     MultiFab ed[3];
     MultiFab* edp[3];
     for (int d = 0; d < 3; ++d) { ed[d].define(S.layout, face_type(d), ncomp, 0); edp[d] = &ed[d]; }
-    godunov_compute_aofs(g, scratch, 0, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edp, nullptr);
+    godunov_compute_aofs(g, scratch, 0, S, ncomp, force, divu, umac, iconserv, dt, bc, is_velocity, use_forces_in_trans, edp, nullptr, scheme);
     auto& ctx = Context::get();
     for (int d = 0; d < 3; ++d) {                      // fluxes = edge state * Ucorr * area (NavierStokesBase.cpp:4681-4683)
         const double area = g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3];
@@ -789,13 +789,12 @@ void AmrNS::mac_sync(int l)
             });
         }
         MultiFab* um[3] = {&c.u_mac[0], &c.u_mac[1], &c.u_mac[2]};
-        godunov_set_ppm(c.p.use_ppm != 0);
         const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0}, ics[2] = {1, c.p.do_cons_trac ? 1 : 0};
         MultiFab flv[3], fls[3];
         MultiFab *flvp[3], *flsp[3];
         for (int d = 0; d < 3; ++d) { flv[d].define(c.layout, face_type(d), 3, 0); fls[d].define(c.layout, face_type(d), NUM_SCALARS, 0); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
-        godunov_compute_aofs_sync(c.g, c.Vsync, 0, Smf, 3, &tfv, &divu, um, uc, icv, dt, c.bc_vel, true, c.p.use_forces_in_trans != 0, flvp);
-        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, NUM_SCALARS, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp);
+        godunov_compute_aofs_sync(c.g, c.Vsync, 0, Smf, 3, &tfv, &divu, um, uc, icv, dt, c.bc_vel, true, c.p.use_forces_in_trans != 0, flvp, c.p.use_ppm);
+        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, NUM_SCALARS, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp, c.p.use_ppm);
         for (int d = 0; d < 3; ++d) {            // NavierStokesBase.cpp:5083-5096 with sync_factor = -1
             f.reg_adv->CrseInit(flv[d], d, 0, 0, 3, dt, true);
             f.reg_adv->CrseInit(fls[d], d, 0, Density, NUM_SCALARS, dt, true);
@@ -1166,6 +1165,19 @@ void AmrNS::compute_new_dt(bool post_regrid)
     if (stop_time >= 0.0 && cur_time + dt_0 > stop_time - eps) dt_0 = stop_time - cur_time;
     n_factor = 1;
     for (int i = 0; i < nl; ++i) { n_factor *= n_cycle[i]; dt_level[i] = dt_0 / (double)n_factor; }
+}
+
+void AmrNS::get_restart_state(double* dt_lev, double* dt_mn, int* ncyc, int counters[2], double* stop) const
+{
+    for (size_t l = 0; l < lev.size(); ++l) { dt_lev[l] = dt_level[l]; dt_mn[l] = dt_min[l]; ncyc[l] = n_cycle[l]; }
+    counters[0] = level_steps; counters[1] = level_count;
+    *stop = stop_time;
+}
+void AmrNS::set_restart_state(const double* dt_lev, const double* dt_mn, const int* ncyc, const int counters[2], double stop)
+{
+    for (size_t l = 0; l < lev.size(); ++l) { dt_level[l] = dt_lev[l]; dt_min[l] = dt_mn[l]; n_cycle[l] = ncyc[l]; lev[l]->dt = dt_lev[l]; }
+    level_steps = counters[0]; level_count = counters[1];
+    stop_time = stop;
 }
 
 // Amr::coarseTimeStep: computeNewDt + timeStep(0); Amr::timeStep regrids from level 0 at the start of the step once regrid_int coarse

@@ -69,7 +69,6 @@ int iamrx_init(int device) { IAMRX_TRY Context::get().init(device); IAMRX_CATCH 
 int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH }
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
-int iamrx_godunov_set_ppm(int use_ppm) { IAMRX_TRY godunov_set_ppm(use_ppm != 0); IAMRX_CATCH }
 int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity)
 {
     IAMRX_TRY
@@ -411,18 +410,18 @@ int iamrx_mf_fill_physbc(iamrx_mf m, const iamrx_geom* g, int scomp, int ncomp, 
 }
 
 int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf ux, iamrx_mf uy, iamrx_mf uz,
-                                      double dt, const int* bcrec, int fit)
+                                      double dt, const int* bcrec, int fit, int scheme)
 {
     IAMRX_TRY
     auto bc = to_bcrec(bcrec, 3);
     MultiFab* um[3] = {&ux->mf, &uy->mf, &uz->mf};
-    godunov_extrap_vel_to_faces(to_geom(g), vel->mf, force ? &force->mf : nullptr, um, dt, bc.data(), fit != 0);
+    godunov_extrap_vel_to_faces(to_geom(g), vel->mf, force ? &force->mf : nullptr, um, dt, bc.data(), fit != 0, scheme);
     IAMRX_CATCH
 }
 
 int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
                                iamrx_mf ux, iamrx_mf uy, iamrx_mf uz, const int* iconserv, double dt, const int* bcrec,
-                               int is_velocity, int fit, iamrx_mf ex, iamrx_mf ey, iamrx_mf ez, iamrx_mf fx, iamrx_mf fy, iamrx_mf fz)
+                               int is_velocity, int fit, iamrx_mf ex, iamrx_mf ey, iamrx_mf ez, iamrx_mf fx, iamrx_mf fy, iamrx_mf fz, int scheme)
 {
     IAMRX_TRY
     auto bc = to_bcrec(bcrec, ncomp);
@@ -430,7 +429,7 @@ int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, ia
     MultiFab* ed[3] = {ex ? &ex->mf : nullptr, ey ? &ey->mf : nullptr, ez ? &ez->mf : nullptr};
     MultiFab* fl[3] = {fx ? &fx->mf : nullptr, fy ? &fy->mf : nullptr, fz ? &fz->mf : nullptr};
     godunov_compute_aofs(to_geom(g), aofs->mf, acomp, S->mf, ncomp, force ? &force->mf : nullptr, divu ? &divu->mf : nullptr, um,
-                         iconserv, dt, bc.data(), is_velocity != 0, fit != 0, ex ? ed : nullptr, fx ? fl : nullptr);
+                         iconserv, dt, bc.data(), is_velocity != 0, fit != 0, ex ? ed : nullptr, fx ? fl : nullptr, scheme);
     IAMRX_CATCH
 }
 
@@ -657,6 +656,13 @@ int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep)
     IAMRX_CATCH
 }
 
+int iamrx_ns_restart_state(iamrx_ns ns, int set, double state[16])
+{
+    IAMRX_TRY
+    if (set) ns->ns->set_restart_state(state); else ns->ns->get_restart_state(state);
+    IAMRX_CATCH
+}
+
 // non-owning view: the C handle type wraps a MultiFab by value, so expose the persistent arrays through
 // a pointer-carrying subclass-free trick: a dedicated handle whose MultiFab is a shallow alias.
 int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
@@ -673,6 +679,7 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
     case 5: m = &n.get_old_data(2); break;
     case 6: case 7: case 8: m = &n.umac(which - 6); break;
     case 9: m = &n.Aofs(); break;
+    case 10: case 11: m = &n.mac_phi_history(which - 10); break;
     default: throw Error("iamrx_ns_data: bad selector");
     }
     // copy the current contents into a library-owned MultiFab of the same shape (old/new swap every step,
@@ -697,6 +704,7 @@ int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
     case 3: m = &n.get_old_data(1); break;
     case 4: m = &n.get_new_data(2); break;
     case 5: m = &n.get_old_data(2); break;
+    case 10: case 11: m = &n.mac_phi_history(which - 10); break;
     default: throw Error("iamrx_ns_set_data: bad selector");
     }
     IAMRX_ASSERT(src->mf.ncomp == m->ncomp && src->mf.ngrow == m->ngrow && src->mf.layout->id == m->layout->id);
@@ -824,7 +832,7 @@ int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scom
 int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
                                     iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z,
                                     const int* iconserv, double dt, const int* bcrec, int is_velocity, int use_forces_in_trans,
-                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z)
+                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z, int scheme)
 {
     IAMRX_TRY
     std::vector<BCRec> bc(ncomp);
@@ -833,7 +841,7 @@ int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acom
     MultiFab* uc[3] = {&ucorr_x->mf, &ucorr_y->mf, &ucorr_z->mf};
     MultiFab* fl[3] = {flux_x ? &flux_x->mf : nullptr, flux_y ? &flux_y->mf : nullptr, flux_z ? &flux_z->mf : nullptr};
     godunov_compute_aofs_sync(to_geom(g), sync->mf, acomp, S->mf, ncomp, force ? &force->mf : nullptr, divu ? &divu->mf : nullptr, um, uc,
-                              iconserv, dt, bc.data(), is_velocity != 0, use_forces_in_trans != 0, flux_x ? fl : nullptr);
+                              iconserv, dt, bc.data(), is_velocity != 0, use_forces_in_trans != 0, flux_x ? fl : nullptr, scheme);
     IAMRX_CATCH
 }
 
@@ -962,6 +970,13 @@ int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels)
     IAMRX_TRY
     if (time) *time = a->amr->time();
     if (dt_levels) for (int l = 0; l < a->amr->nlevels(); ++l) dt_levels[l] = a->amr->dt(l);
+    IAMRX_CATCH
+}
+int iamrx_amr_restart_state(iamrx_amr a, int set, double* dt_level, double* dt_min, int* n_cycle, int counters[2], double* stop_time)
+{
+    IAMRX_TRY
+    if (set) a->amr->set_restart_state(dt_level, dt_min, n_cycle, counters, *stop_time);
+    else a->amr->get_restart_state(dt_level, dt_min, n_cycle, counters, stop_time);
     IAMRX_CATCH
 }
 int iamrx_amr_reflux(iamrx_amr a, int lev) { IAMRX_TRY a->amr->reflux(lev); IAMRX_CATCH }

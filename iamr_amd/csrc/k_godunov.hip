@@ -146,15 +146,19 @@ __device__ __forceinline__ void ppm_edges(P q, long s, bool edlo, bool edhi, int
     else if (fabs(sp - s0) >= 2.0 * fabs(sm - s0)) sp = 3.0 * s0 - 2.0 * sm;
     else if (fabs(sm - s0) >= 2.0 * fabs(sp - s0)) sm = 3.0 * s0 - 2.0 * sp;
 }
-// state on the high (side) / low face of the cell traced with velocity u
+// state on the high (side) / low face of a cell with value s0 and monotonised edge values sm, sp, traced with velocity u
+__device__ __forceinline__ double ppm_state(double s0, double sm, double sp, double u, double dtdx, bool side)
+{
+    const double s6 = 6.0 * s0 - 3.0 * (sm + sp), sigma = fabs(u) * dtdx;
+    if (side) return (u > SMALL_VEL) ? sp - (0.5 * sigma) * ((sp - sm) - (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+    return (u < -SMALL_VEL) ? sm + (0.5 * sigma) * ((sp - sm) + (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+}
 template <class P>
 __device__ __forceinline__ double ppm_trace(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi, double u, double dtdx, bool side)
 {
     double sm, sp;
     ppm_edges(q, s, edlo, edhi, i, domlo, domhi, sm, sp);
-    const double s0 = q[0], s6 = 6.0 * s0 - 3.0 * (sm + sp), sigma = fabs(u) * dtdx;
-    if (side) return (u > SMALL_VEL) ? sp - (0.5 * sigma) * ((sp - sm) - (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
-    return (u < -SMALL_VEL) ? sm + (0.5 * sigma) * ((sp - sm) + (1.0 - (2.0 / 3.0) * sigma) * s6) : s0;
+    return ppm_state(q[0], sm, sp, u, dtdx, side);
 }
 
 // SetTransTerm{X,Y,Z}BCs.  qc points at the state value of the cell on the HIGH side of the face
@@ -867,17 +871,19 @@ __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX *
     }
 }
 
-static int g_ppm_host = 0;
-void godunov_set_ppm(bool on)
+// The reconstruction is an ARGUMENT of every Godunov entry point (scheme: 0 Godunov_PLM, 1 Godunov_PPM; ns.advection_scheme,
+// Source/NavierStokesBase.cpp:548-553).  The fused z-marching kernels are compiled per scheme; the multi-pass kernels read a device
+// word that the entry point sets on the launch stream in front of its own launches (stream-ordered, no synchronisation): no
+// process-wide mode outlives a call.
+static void set_scheme(int scheme)
 {
-    const int v = on ? 1 : 0;
-    if (v == g_ppm_host) return;
-    g_ppm_host = v;
-    auto& ctx = Context::get();
-    IAMRX_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ppm_dev), &g_ppm_host, sizeof(int), 0, hipMemcpyHostToDevice, ctx.stream));
-    ctx.sync();
+    if (scheme != 0 && scheme != 1) throw Error("iamrx Godunov: advection scheme " + std::to_string(scheme) + " is not implemented (0 Godunov_PLM, 1 Godunov_PPM)");
+    static const int vals[2] = {0, 1};
+    static int current = -1;
+    if (scheme == current) return;
+    current = scheme;
+    IAMRX_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ppm_dev), &vals[scheme], sizeof(int), 0, hipMemcpyHostToDevice, Context::get().stream));
 }
-bool godunov_get_ppm() { return g_ppm_host != 0; }
 
 static GodParams make_params(const Geometry& g, double dt, int ncomp, const BCRec* bc, const int* iconserv, bool is_vel, bool fit,
                              bool has_force, bool has_divu)
@@ -1034,18 +1040,20 @@ static void launch_final(const Layout& l, const MultiFab& q, const MultiFab* for
 }
 
 static bool use_z_kernel();
-static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs);
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs, bool ppm);
+static void set_scheme(int scheme);
 
 void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
-                                 double dt, const BCRec* bc, bool use_forces_in_trans)
+                                 double dt, const BCRec* bc, bool use_forces_in_trans, int scheme)
 {
     if (vel.nlocal() == 0) return;
+    set_scheme(scheme);
     IAMRX_ASSERT(vel.ngrow >= 3 && vel.ncomp >= 3);
     IAMRX_ASSERT(!force || force->ngrow >= 1);
     const Layout& l = *vel.layout;
-    if (use_z_kernel() && !godunov_get_ppm()) {
+    if (use_z_kernel()) {
         godunov_pred_z(l, vel, force, umac, upload_params(make_params(g, dt, 3, bc, nullptr, true, use_forces_in_trans, force != nullptr, false)),
-                       !(g.periodic[0] && g.periodic[1] && g.periodic[2]));
+                       !(g.periodic[0] && g.periodic[1] && g.periodic[2]), scheme == 1);
         return;
     }
     MultiFab ad[3], e0[3], sl[3];
@@ -1423,7 +1431,7 @@ __global__ void __launch_bounds__(NTH) k_godunov_tile(const BoxD* __restrict__ b
 // multi-pass kernels above, which remain as the PPM path and as the reference of tests/test_gpu_godunov_fused.py.
 struct GodTabs3 { const FabD* t[3]; };
 
-template <int TX, int TY, int NT, int WPE, bool BCS>
+template <int TX, int TY, int NT, int WPE, bool BCS, bool PPM>
 __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
     const FabD* __restrict__ divut, const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt,
     const FabD* __restrict__ aofst, int acomp, GodTabs3 edge_t, GodTabs3 flux_t, const GodParams* __restrict__ Pp,
@@ -1513,6 +1521,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
     for (int r = 0; r < NQ; ++r) pQ[r] = qpv[r] ? q.gp()[qpo[r]] : 0.;
     // values of plane P-1 kept from the previous iteration
     double xl1 = 0., xh1 = 0., yl1 = 0., yh1 = 0., qxm1 = 0., qym1 = 0., mx1 = 0., my1 = 0., mz1 = 0., fr1 = 0., dv1 = 0., slz1 = 0., Zprev = 0.;
+    double smz1 = 0., spz1 = 0.;
     const double ax = dx1 * dx2, ay = dx2 * dx0, az = dx0 * dx1, qvol = 1.0 / (dx0 * dx1 * dx2);
     const double rdx0 = 1.0 / dx0, rdx1 = 1.0 / dx1, rdx2 = 1.0 / dx2;
     (void)rdx0; (void)rdx1; (void)rdx2;
@@ -1544,10 +1553,16 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
             const double* qc = Q + qo;
             const double a3 = qc[-3], a2 = qc[-2], a1 = qc[-1], c0 = qc[0], b1 = qc[1], b2 = qc[2];
             qxm0 = a1;
+            if constexpr (PPM) {
+                xl0 = ppm_trace(qc - 1, 1L, edl0, edh0, ci - 1, dl0, dh0, mx0, dtdx0, true);
+                xh0 = ppm_trace(qc, 1L, edl0, edh0, ci, dl0, dh0, mx0, dtdx0, false);
+                (void)a3; (void)a2; (void)b1; (void)b2;
+            } else {
             const double sll = slope4v(a3, a2, a1, c0, b1, edl0, edh0, ci - 1, dl0, dh0);
             const double slh = slope4v(a2, a1, c0, b1, b2, edl0, edh0, ci, dl0, dh0);
             xh0 = c0 + 0.5 * (-1.0 - mx0 * dtdx0) * slh;
             xl0 = a1 + 0.5 * (1.0 - mx0 * dtdx0) * sll;
+            }
             if (early_force) { xl0 += hdt * FR[s][oxm]; xh0 += hdt * fr0; }
             if (np0) trans_bc_v(a1, c0, ci, nv0, xl0, xh0, bl0, bh0, dl0, dh0);
             if (act) EX[s][o] = upwind_fu(mx0, xl0, xh0);
@@ -1556,19 +1571,34 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
             const double* qc = Q + qo;
             const double a3 = qc[-3 * QW], a2 = qc[-2 * QW], a1 = qc[-QW], c0 = qc[0], b1 = qc[QW], b2 = qc[2 * QW];
             qym0 = a1;
+            if constexpr (PPM) {
+                yl0 = ppm_trace(qc - QW, (long)QW, edl1, edh1, cj - 1, dl1, dh1, my0, dtdx1, true);
+                yh0 = ppm_trace(qc, (long)QW, edl1, edh1, cj, dl1, dh1, my0, dtdx1, false);
+                (void)a3; (void)a2; (void)b1; (void)b2;
+            } else {
             const double sll = slope4v(a3, a2, a1, c0, b1, edl1, edh1, cj - 1, dl1, dh1);
             const double slh = slope4v(a2, a1, c0, b1, b2, edl1, edh1, cj, dl1, dh1);
             yh0 = c0 + 0.5 * (-1.0 - my0 * dtdx1) * slh;
             yl0 = a1 + 0.5 * (1.0 - my0 * dtdx1) * sll;
+            }
             if (early_force) { yl0 += hdt * FR[s][oym]; yh0 += hdt * fr0; }
             if (np1) trans_bc_v(a1, c0, cj, nv1, yl0, yh0, bl1, bh1, dl1, dh1);
             if (act) EY[s][o] = upwind_fu(my0, yl0, yh0);
         }
-        double slz0;
+        double slz0 = 0.0, smz0 = 0.0, spz0 = 0.0;
         {
+            if constexpr (PPM) {
+                // the parabola of cell P from the z-ring; the one of cell P-1 is kept from the iteration before (both faces of a cell
+                // are traced with the velocity of the face in question)
+                const double zr[5] = {r0, r1v, r2, r3, r4};
+                ppm_edges(zr + 2, 1L, edl2, edh2, Pk, dl2, dh2, smz0, spz0);
+                zh = ppm_state(r2, smz0, spz0, mz0, dtdx2, false);
+                zl = ppm_state(r1v, smz1, spz1, mz0, dtdx2, true);
+            } else {
             slz0 = slope4v(r0, r1v, r2, r3, r4, edl2, edh2, Pk, dl2, dh2);
             zh = r2 + 0.5 * (-1.0 - mz0 * dtdx2) * slz0;
             zl = r1v + 0.5 * (1.0 - mz0 * dtdx2) * slz1;
+            }
             if (early_force) { zl += hdt * fr1; zh += hdt * fr0; }
             if (np2) trans_bc_v(r1v, r2, Pk, nv2, zl, zh, bl2, bh2, dl2, dh2);
             if (act) EZ[s][o] = upwind_fu(mz0, zl, zh);
@@ -1662,6 +1692,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
         }
         xl1 = xl0; xh1 = xh0; yl1 = yl0; yh1 = yh0; qxm1 = qxm0; qym1 = qym0;
         mx1 = mx0; my1 = my0; mz1 = mz0; fr1 = fr0; dv1 = dv0; slz1 = slz0; Zprev = Ze;
+        smz1 = smz0; spz1 = spz0;
     }
 }
 
@@ -1672,7 +1703,7 @@ static bool use_z_kernel()
     return e ? atoi(e) != 0 : true;
 }
 
-template <int TX, int TY, int WPE, bool BCS>
+template <int TX, int TY, int WPE, bool BCS, bool PPM>
 static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force, const MultiFab* divu,
                          MultiFab* const umac[3], MultiFab* const edge_out[3], MultiFab* const flux_out[3], const GodParams* dP)
 {
@@ -1688,7 +1719,7 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
     if (edge_out && edge_out[0]) for (int d = 0; d < 3; ++d) et.t[d] = edge_out[d]->d_tab;
     if (flux_out && flux_out[0]) for (int d = 0; d < 3; ++d) ftb.t[d] = flux_out[d]->d_tab;
     const bool rec = kernel_probe_begin(PROBE_GOD_Z, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
-    hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
+    hipLaunchKernelGGL((k_god_z<TX, TY, NT, WPE, BCS, PPM>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, S.d_tab, force ? force->d_tab : nullptr,
                        divu ? divu->d_tab : nullptr, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, aofs.d_tab, acomp, et, ftb, dP,
                        ntx, nty, nkc, kc, xcd_cnt);
     if (rec) kernel_probe_end(PROBE_GOD_Z);
@@ -1700,7 +1731,7 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
 // in LDS like the pass-1 states; the final x- / y- / z-face state is that of u / v / w, so the corner-coupled state C_{T|O} is formed
 // for the component 3-T-O only: E_x(v,w), E_y(u,w), E_z(u,v), six corner arrays, three final states per column and plane.
 // Three barriers per plane (the final states go straight to umac).
-template <int TX, int TY, int NT, bool BCS>
+template <int TX, int TY, int NT, bool BCS, bool PPM>
 __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes, const FabD* __restrict__ qt, const FabD* __restrict__ ft,
     const FabD* __restrict__ uxt, const FabD* __restrict__ uyt, const FabD* __restrict__ uzt, const GodParams* __restrict__ Pp,
     int ntx, int nty, int nkc, int kc, int xcd_cnt)
@@ -1778,6 +1809,7 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
     }
     double xl1u = 0., xh1u = 0., xl1v = 0., xh1v = 0., yl1u = 0., yh1u = 0., yl1v = 0., yh1v = 0.;
     double qxm1u = 0., qxm1v = 0., qym1u = 0., qym1v = 0., fr1[3] = {0., 0., 0.}, slz1[3] = {0., 0., 0.};
+    double smz1[3] = {0., 0., 0.}, spz1[3] = {0., 0., 0.};
 
     int it = 0;
     for (int Pk = k0 - 1; Pk <= k1 + 1; ++Pk, ++it) {
@@ -1807,6 +1839,7 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
         // ---------------- stage A: pass 1 (traces with the cell-centred velocity of the trace direction)
         double xl0u, xh0u, xl0v, xh0v, xl0w, xh0w, yl0u, yh0u, yl0v, yh0v, yl0w, yh0w, zlu, zhu, zlv, zhv, zlw, zhw;
         double qxm0u, qxm0v, qxm0w, qym0u, qym0v, qym0w, adx, ady, adz, slz0[3];
+        double smz0[3] = {0., 0., 0.}, spz0[3] = {0., 0., 0.};
         {
             const double vlo = Qb[0][qo - 1], vhi = Qb[0][qo];
             double l[3], h[3], am[3];
@@ -1816,10 +1849,16 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
                 const double a3 = qc[-3], a2 = qc[-2], a1 = qc[-1], c0 = qc[0], b1 = qc[1], b2 = qc[2];
                 const int bl = P.bc.bc[c].lo[0], bh = P.bc.bc[c].hi[0];
                 const bool edlo = np0 && ed_or_ho(bl), edhi = np0 && ed_or_ho(bh);
+                if constexpr (PPM) {
+                    l[c] = ppm_trace(qc - 1, 1L, edlo, edhi, ci - 1, dl0, dh0, vlo, dtdx0, true);
+                    h[c] = ppm_trace(qc, 1L, edlo, edhi, ci, dl0, dh0, vhi, dtdx0, false);
+                    (void)a3; (void)a2; (void)b1; (void)b2;
+                } else {
                 const double sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, ci - 1, dl0, dh0);
                 const double slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, ci, dl0, dh0);
                 h[c] = c0 + 0.5 * (-1.0 - vhi * dtdx0) * slh;
                 l[c] = a1 + 0.5 * (1.0 - vlo * dtdx0) * sll;
+                }
                 if (early_force) { l[c] += hdt * FR[s][c][oxm]; h[c] += hdt * fr0[c]; }
                 if (np0) trans_bc_v(a1, c0, ci, c == 0, l[c], h[c], bl, bh, dl0, dh0);
                 am[c] = a1;
@@ -1840,10 +1879,16 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
                 const double a3 = qc[-3 * QW], a2 = qc[-2 * QW], a1 = qc[-QW], c0 = qc[0], b1 = qc[QW], b2 = qc[2 * QW];
                 const int bl = P.bc.bc[c].lo[1], bh = P.bc.bc[c].hi[1];
                 const bool edlo = np1 && ed_or_ho(bl), edhi = np1 && ed_or_ho(bh);
+                if constexpr (PPM) {
+                    l[c] = ppm_trace(qc - QW, (long)QW, edlo, edhi, cj - 1, dl1, dh1, vlo, dtdx1, true);
+                    h[c] = ppm_trace(qc, (long)QW, edlo, edhi, cj, dl1, dh1, vhi, dtdx1, false);
+                    (void)a3; (void)a2; (void)b1; (void)b2;
+                } else {
                 const double sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, cj - 1, dl1, dh1);
                 const double slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, cj, dl1, dh1);
                 h[c] = c0 + 0.5 * (-1.0 - vhi * dtdx1) * slh;
                 l[c] = a1 + 0.5 * (1.0 - vlo * dtdx1) * sll;
+                }
                 if (early_force) { l[c] += hdt * FR[s][c][oym]; h[c] += hdt * fr0[c]; }
                 if (np1) trans_bc_v(a1, c0, cj, c == 1, l[c], h[c], bl, bh, dl1, dh1);
                 am[c] = a1;
@@ -1862,9 +1907,16 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
             for (int c = 0; c < 3; ++c) {
                 const int bl = P.bc.bc[c].lo[2], bh = P.bc.bc[c].hi[2];
                 const bool edlo = np2 && ed_or_ho(bl), edhi = np2 && ed_or_ho(bh);
+                if constexpr (PPM) {
+                    slz0[c] = 0.0;
+                    ppm_edges(&rz[c][2], 1L, edlo, edhi, Pk, dl2, dh2, smz0[c], spz0[c]);
+                    h[c] = ppm_state(rz[c][2], smz0[c], spz0[c], vhi, dtdx2, false);
+                    l[c] = ppm_state(rz[c][1], smz1[c], spz1[c], vlo, dtdx2, true);
+                } else {
                 slz0[c] = slope4v(rz[c][0], rz[c][1], rz[c][2], rz[c][3], rz[c][4], edlo, edhi, Pk, dl2, dh2);
                 h[c] = rz[c][2] + 0.5 * (-1.0 - vhi * dtdx2) * slz0[c];
                 l[c] = rz[c][1] + 0.5 * (1.0 - vlo * dtdx2) * slz1[c];
+                }
                 if (early_force) { l[c] += hdt * fr1[c]; h[c] += hdt * fr0[c]; }
                 if (np2) trans_bc_v(rz[c][1], rz[c][2], Pk, c == 2, l[c], h[c], bl, bh, dl2, dh2);
             }
@@ -1928,11 +1980,11 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
         xl1u = xl0u; xh1u = xh0u; xl1v = xl0v; xh1v = xh0v; yl1u = yl0u; yh1u = yh0u; yl1v = yl0v; yh1v = yh0v;
         qxm1u = qxm0u; qxm1v = qxm0v; qym1u = qym0u; qym1v = qym0v;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { fr1[c] = fr0[c]; slz1[c] = slz0[c]; }
+        for (int c = 0; c < 3; ++c) { fr1[c] = fr0[c]; slz1[c] = slz0[c]; smz1[c] = smz0[c]; spz1[c] = spz0[c]; }
     }
 }
 
-template <int TX, int TY, bool BCS>
+template <int TX, int TY, bool BCS, bool PPM>
 static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP)
 {
     constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
@@ -1944,15 +1996,15 @@ static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* 
     const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
     dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), 1u);
     const bool rec = kernel_probe_begin(PROBE_PRED_Z, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
-    hipLaunchKernelGGL((k_pred_z<TX, TY, NT, BCS>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
+    hipLaunchKernelGGL((k_pred_z<TX, TY, NT, BCS, PPM>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, vel.d_tab, force ? force->d_tab : nullptr,
                        umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab, dP, ntx, nty, nkc, kc, xcd_cnt);
     if (rec) kernel_probe_end(PROBE_PRED_Z);
 }
 
-static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs)
+static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs, bool ppm)
 {
-    if (bcs) launch_pred_z<16, 8, true>(l, vel, force, umac, dP);
-    else launch_pred_z<16, 8, false>(l, vel, force, umac, dP);
+    if (ppm) { if (bcs) launch_pred_z<16, 8, true, true>(l, vel, force, umac, dP); else launch_pred_z<16, 8, false, true>(l, vel, force, umac, dP); }
+    else { if (bcs) launch_pred_z<16, 8, true, false>(l, vel, force, umac, dP); else launch_pred_z<16, 8, false, false>(l, vel, force, umac, dP); }
 }
 
 static bool use_tile_kernel()
@@ -1964,7 +2016,7 @@ static bool use_tile_kernel()
 
 void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
                           const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
-                          bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3])
+                          bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3], int scheme)
 {
     if (S.nlocal() == 0) return;
     IAMRX_ASSERT(S.ngrow >= 3 && ncomp <= 5 && S.ncomp >= ncomp);
@@ -1974,7 +2026,9 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     MultiFab e0[3], edge[3], sl[3];
     MultiFab* ed[3];
     const bool ws = use_dir_fused();
-    const bool zk = use_z_kernel() && !godunov_get_ppm();
+    const bool ppm = scheme == 1;
+    set_scheme(scheme);
+    const bool zk = use_z_kernel();
     for (int d = 0; d < 3 && !use_tile_kernel() && !zk; ++d) {
         e0[d].define(S.layout, face_type(d), ncomp, 1);
         if (ws) sl[d].define(S.layout, cell_type(), ncomp, 1);
@@ -1986,14 +2040,16 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
         static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 16; }();
         static const int zty = [] { const char* e = getenv("IAMRX_GODUNOV_ZTY"); return e ? atoi(e) : 8; }();
         const bool bcs = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
-#define IAMRX_GZ(TX, TY, W) (bcs ? launch_god_z<TX, TY, W, true>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP) \
-                                  : launch_god_z<TX, TY, W, false>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP))
+#define IAMRX_GZP(TX, TY, W, PPM) (bcs ? launch_god_z<TX, TY, W, true, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP) \
+                                       : launch_god_z<TX, TY, W, false, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP))
+#define IAMRX_GZ(TX, TY, W) (ppm ? IAMRX_GZP(TX, TY, W, true) : IAMRX_GZP(TX, TY, W, false))
         // 16 x 8 tiles (3 wavefronts, 40 KB of LDS) measured 5.8 ms for 5 components at 256^3, 16 x 16: 6.4 ms, 32 x 8: 6.4 ms;
         // bounding the registers for a third wavefront per SIMD spills (17 ms)
         if (ztx == 16 && zty == 8) IAMRX_GZ(16, 8, 2);
         else if (ztx == 16) IAMRX_GZ(16, 16, 2);
         else IAMRX_GZ(32, 8, 2);
 #undef IAMRX_GZ
+#undef IAMRX_GZP
         return;
     }
     if (use_tile_kernel()) {

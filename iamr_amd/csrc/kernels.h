@@ -90,17 +90,15 @@ void mac_divergence(const Geometry& g, MultiFab& div, const MultiFab* const umac
 
 // ---- k_godunov.hip ------------------------------------------------------------------------
 // Godunov::ExtrapVelToFaces (PLM): vel has >=3 comps and >=3 filled ghost cells, force 3 comps >=1 ghost
+// scheme: ns.advection_scheme, 0 Godunov_PLM (4th-order limited slopes), 1 Godunov_PPM -- an argument of every call, no process-wide mode
 void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3],
-                                 double dt, const BCRec* bc, bool use_forces_in_trans);
+                                 double dt, const BCRec* bc, bool use_forces_in_trans, int scheme = 0);
 // ComputeFluxesOnBoxFromState + ComputeDivergence(-1) + ComputeConvectiveTerm, aofs(acomp..) = -update.
 // S: ncomp comps, >=3 ghosts; umac: >=1 ghost (filled); force/divu: >=1 ghost or null
 void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
                           const MultiFab* divu, MultiFab* const umac[3], const int* iconserv, double dt, const BCRec* bc,
-                          bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3]);
+                          bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3], int scheme = 0);
 
-// edge-state reconstruction of every later Godunov call: false = PLM (4th-order limited slopes), true = PPM (ns.advection_scheme = Godunov_PPM)
-void godunov_set_ppm(bool on);
-bool godunov_get_ppm();
 
 // ---- k_nodal.hip --------------------------------------------------------------------------
 void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);

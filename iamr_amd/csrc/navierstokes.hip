@@ -189,6 +189,27 @@ void NavierStokes::set_time_level(double time_, double dt_old, double dt_new)
     pt_old[0] = tp - dt_old; pt_old[1] = tp;
 }
 
+void NavierStokes::get_restart_state(double v[16]) const
+{
+    v[0] = time; v[1] = dt; v[2] = (double)nstep; v[3] = st_new; v[4] = st_old; v[5] = pt_new[0]; v[6] = pt_new[1]; v[7] = pt_old[0]; v[8] = pt_old[1];
+    v[9] = dt_prev_mac; v[10] = m_have_mac_prev ? 1.0 : 0.0; v[11] = m_have_mac_prev2 ? 1.0 : 0.0; v[12] = dt_min_adv; v[13] = m_stop_time;
+    v[14] = (double)inew; v[15] = (double)pnew;
+}
+void NavierStokes::set_restart_state(const double v[16])
+{
+    time = v[0]; dt = v[1]; nstep = (int)v[2]; st_new = v[3]; st_old = v[4]; pt_new[0] = v[5]; pt_new[1] = v[6]; pt_old[0] = v[7]; pt_old[1] = v[8];
+    dt_prev_mac = v[9]; m_have_mac_prev = v[10] != 0.0; m_have_mac_prev2 = v[11] != 0.0; dt_min_adv = v[12]; m_stop_time = v[13];
+    // inew / pnew are not restored: the arrays were handed over as "new" / "old" data, whichever buffers hold them now
+    initial_step = false; initial_iter = false;
+    m_visc_old_valid = false;
+    make_rho_curr_time();
+}
+MultiFab& NavierStokes::mac_phi_history(int which)
+{
+    if (!m_mac_phi_prev.defined()) { m_mac_phi_prev.define(layout, cell_type(), 1, 0); m_mac_phi_prev2.define(layout, cell_type(), 1, 0); m_mac_phi_prev.setVal(0.0); m_mac_phi_prev2.setVal(0.0); }
+    return which == 0 ? m_mac_phi_prev : m_mac_phi_prev2;
+}
+
 void NavierStokes::swap_time_levels(double dt_)      // StateData::swapTimeLevels
 {
     st_old = st_new; st_new += dt_;
@@ -497,8 +518,7 @@ double NavierStokes::predict_velocity(double dt_)
         });
     }
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
-    godunov_set_ppm(p.use_ppm != 0);
-    godunov_extrap_vel_to_faces(g, Umf, &tf, um, dt_, bc_vel, p.use_forces_in_trans != 0);
+    godunov_extrap_vel_to_faces(g, Umf, &tf, um, dt_, bc_vel, p.use_forces_in_trans != 0, p.use_ppm);
     return dt_ * tempdt;
 }
 
@@ -583,15 +603,14 @@ void NavierStokes::velocity_advection(double dt_)
     const int ic = mom ? 1 : 0;                         // NS_setup.cpp:297-301: velocity advectionType = Conservative
     const int iconserv[3] = {ic, ic, ic};
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
-    godunov_set_ppm(p.use_ppm != 0);
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
         for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), 3, 0); flp[d] = &fl[d]; }
-        godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, flp);
+        godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
         adv_registers(flp, Xvel, 3, dt_);
     } else
-    godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, nullptr);
+    godunov_compute_aofs(g, aofs, Xvel, Umf, 3, &tf, &divu, um, iconserv, dt_, bc_vel, true, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
 void NavierStokes::scalar_advection(double dt_)
@@ -618,15 +637,14 @@ void NavierStokes::scalar_advection(double dt_)
     }
     const int iconserv[2] = {1, p.do_cons_trac ? 1 : 0};                            // NS_setup.cpp:304-310
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
-    godunov_set_ppm(p.use_ppm != 0);
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
         for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_SCALARS, 0); flp[d] = &fl[d]; }
-        godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, flp);
+        godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
         adv_registers(flp, Density, NUM_SCALARS, dt_);
     } else
-    godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr);
+    godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
 // velocity_advection + scalar_advection in ONE pass of the Godunov chain over all five state components (NavierStokes.cpp:698-812 calls
@@ -681,15 +699,14 @@ void NavierStokes::advection_all(double dt_)
     for (int n = 0; n < 3; ++n) bc5[n] = bc_vel[n];
     for (int n = 0; n < NUM_SCALARS; ++n) bc5[3 + n] = bc_scal[n];
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
-    godunov_set_ppm(p.use_ppm != 0);
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
         for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_STATE, 0); flp[d] = &fl[d]; }
-        godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, flp);
+        godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
         adv_registers(flp, Xvel, NUM_STATE, dt_);
     } else
-    godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr);
+    godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
 void NavierStokes::scalar_update_rho(double dt_)

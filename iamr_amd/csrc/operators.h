@@ -107,7 +107,7 @@ void sync_interp_cellcons(MultiFab& dst, int dcomp, const MultiFab& crse, int sc
 // edge states traced with umac, fluxes formed with ucorr, conservative update for every component, sync(acomp..) -= update
 void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, const MultiFab& S, int ncomp, const MultiFab* force,
                                const MultiFab* divu, MultiFab* const umac[3], MultiFab* const ucorr[3], const int* iconserv, double dt,
-                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3]);
+                               const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3], int scheme = 0);
 
 // SyncRegister (Source/SyncRegister.cpp): nodal values on the faces of the coarsened fine boxes, kept as ONE single-valued nodal
 // MultiFab on the coarse level's layout + the node masks that InitRHS needs
@@ -189,6 +189,13 @@ public:
     std::unique_ptr<FluxRegister> reg_adv, reg_visc, reg_mac;
     std::unique_ptr<SyncRegister> sync_reg;
     void set_time_level(double time, double dt_old, double dt_new);
+    // checkpoint / restart (AmrLevel::checkPoint / restart role, Source/NavierStokesBase.cpp:856-897, 2706-2727): everything of the level
+    // that outlives a time step besides the State / Press / Gradp arrays -- the StateData times, step counters, and the initial-guess
+    // history of the MAC solve (this library's addition: it makes a restarted run bit-identical to the uninterrupted one).
+    // v[0..15] = time, dt, nstep, st_new, st_old, pt_new[2], pt_old[2], dt_prev_mac, have_mac_prev, have_mac_prev2, dt_min_adv, stop_time, inew, pnew
+    void get_restart_state(double v[16]) const;
+    void set_restart_state(const double v[16]);            // call after the arrays are set; also leaves the initial-step state
+    MultiFab& mac_phi_history(int which);                  // 0: last MAC potential, 1: the one before (defined on demand)
     const Geometry& geom() const { return g; }
     const LayoutP& lay() const { return layout; }
     const NSParams& params() const { return p; }

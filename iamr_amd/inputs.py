@@ -22,7 +22,7 @@ import re
 _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.verbose", "mac_proj.v", "mac_proj.verbose", "mac.v", "diffuse.v",
                  "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
                  "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.refinement_indicators", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
-                 "amr.check_file", "amr.check_int", "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
+                 "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
                  "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
 _IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
@@ -266,12 +266,12 @@ class Inputs:
                                       "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
-                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level)
+                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level,
+                   check_int=self.integer("amr.check_int", -1), check_file=self.string("amr.check_file", "chk"),
+                   restart=self.string("amr.restart", "") if self.has("amr.restart") else "")
         for k, dflt in _UNIMPLEMENTED_UNLESS.items():
             if self.has(k) and self.string(k) != dflt:
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented (only {dflt})")
-        if self.has("amr.restart"):
-            raise NotImplementedError("inputs: amr.restart (checkpoint restart, SURVEY f2) is not implemented")
         for k in self.table:
             if k not in self.used:
                 if k in _IGNORED_KEYS or k.startswith(_IGNORED_NAMESPACES):

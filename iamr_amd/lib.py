@@ -447,18 +447,18 @@ def _bcrec(ncomp, bc=None):
     return arr
 
 
-def godunov_extrap_vel_to_faces(geom, vel, force, umac, dt, bc=None, use_forces_in_trans=0):
+def godunov_extrap_vel_to_faces(geom, vel, force, umac, dt, bc=None, use_forces_in_trans=0, scheme=0):
     """Godunov::ExtrapVelToFaces (reference call site Source/NavierStokesBase.cpp:4487-4491)"""
     check(lib().iamrx_godunov_extrap_vel_to_faces(C.byref(geom), vel.h, _h(force), umac[0].h, umac[1].h, umac[2].h,
-                                                  C.c_double(dt), _bcrec(3, bc), use_forces_in_trans))
+                                                  C.c_double(dt), _bcrec(3, bc), use_forces_in_trans, int(scheme)))
 
 
 def godunov_compute_aofs(geom, aofs, acomp, S, ncomp, force, divu, umac, iconserv, dt, bc=None, is_velocity=0,
-                         use_forces_in_trans=0, edge=None, flux=None):
+                         use_forces_in_trans=0, edge=None, flux=None, scheme=0):
     """kernel chain of NavierStokesBase::ComputeAofs (reference Source/NavierStokesBase.cpp:4594-4845)"""
     ic = (C.c_int * ncomp)(*[int(x) for x in iconserv])
     e = [None] * 3 if edge is None else edge
     f = [None] * 3 if flux is None else flux
     check(lib().iamrx_godunov_compute_aofs(C.byref(geom), aofs.h, acomp, S.h, ncomp, _h(force), _h(divu), umac[0].h, umac[1].h,
                                            umac[2].h, ic, C.c_double(dt), _bcrec(ncomp, bc), is_velocity, use_forces_in_trans,
-                                           _h(e[0]), _h(e[1]), _h(e[2]), _h(f[0]), _h(f[1]), _h(f[2])))
+                                           _h(e[0]), _h(e[1]), _h(e[2]), _h(f[0]), _h(f[1]), _h(f[2]), int(scheme)))

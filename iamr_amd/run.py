@@ -76,18 +76,32 @@ def write_plot_amr(amr, lays, pr, N, step, root):
 def main_amr(pr, inp, lib, N, rank=0, world=1):
     """hierarchy run; world > 1: the boxes of every level are spread over the ranks (level 0 by Layout.decompose, fixed refined grids
     round-robin, regridded levels by the library's knapsack), plotfiles are written by single-rank runs only"""
-    amr, lays, g0 = build_amr(pr, lib, N, world)
     say = print if rank == 0 else (lambda *a, **k: None)
-    if inp.ignored:
-        say("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
-    amr.post_init(pr["stop_time"])
+    check_int, check_root = (pr.get("check_int", -1), pr.get("check_file", "chk")) if world == 1 else (-1, "chk")
     plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
     if world > 1:
         plot_int = -1
-    if plot_int > 0:
-        say("PLOTFILE:", write_plot_amr(amr, lays, pr, N, 0, plot_root))
+    if pr.get("restart"):
+        # amr.restart (Amr::restart): grids, data, times and step counters come from the checkpoint, parameters from the inputs file
+        from . import checkpoint
+        if world > 1:
+            raise NotImplementedError("iamr_amd.run: amr.restart runs on one rank")
+        g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
+        amr = checkpoint.restart(pr["restart"], g0, N.ns_params(**pr["params"]))
+        if pr.get("regrid"):
+            amr.set_regrid(**pr["regrid"])
+        lays = amr.layouts
+        step = checkpoint.read_header(pr["restart"])["level_steps"][0]
+        say(f"RESTART from {pr['restart']}: step {step}, time {amr.time:.12g}, levels {amr.nlev}")
+    else:
+        amr, lays, g0 = build_amr(pr, lib, N, world)
+        amr.post_init(pr["stop_time"])
+        step = 0
+        if plot_int > 0:
+            say("PLOTFILE:", write_plot_amr(amr, lays, pr, N, 0, plot_root))
+    if inp.ignored:
+        say("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
     t0 = time.perf_counter()
-    step = 0
     while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or amr.time < pr["stop_time"] - 1e-14):
         if pr["max_step"] < 0 and pr["stop_time"] < 0:
             break
@@ -97,6 +111,9 @@ def main_amr(pr, inp, lib, N, rank=0, world=1):
         say(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g} LEVELS = {amr.nlev} GRIDS = {[len(l.boxes) for l in lays]}")
         if plot_int > 0 and step % plot_int == 0:
             say("PLOTFILE:", write_plot_amr(amr, lays, pr, N, step, plot_root))
+        if check_int > 0 and step % check_int == 0:
+            from . import checkpoint
+            say("CHECKPOINT:", checkpoint.write(amr, check_root, step, pr.get("max_level")))
     lib.sync()
     say(f"Run time = {time.perf_counter() - t0:.6f}")
     return 0
@@ -161,17 +178,28 @@ def main(argv):
         from . import comm
         comm.init_rccl_from_torch(dist)
     pr = inp.problem()
-    if pr["fine_boxes"] or pr.get("regrid"):
+    if pr["fine_boxes"] or pr.get("regrid") or (pr.get("restart") and pr.get("max_level", 0) > 0):
         return main_amr(pr, inp, lib, N, rank, world)
-    ns, lay, g, pr = build(inp, lib, N, world, pr)
+    plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
+    check_int, check_root = (pr.get("check_int", -1), pr.get("check_file", "chk")) if world == 1 else (-1, "chk")
+    if pr.get("restart"):
+        from . import checkpoint
+        if world > 1:
+            raise NotImplementedError("iamr_amd.run: amr.restart runs on one rank")
+        g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
+        ns = checkpoint.restart(pr["restart"], g, N.ns_params(**pr["params"]), single_level=True)
+        lay = ns.layout
+        step = checkpoint.read_header(pr["restart"])["level_steps"][0]
+        print(f"RESTART from {pr['restart']}: step {step}, time {ns.time:.12g}")
+    else:
+        ns, lay, g, pr = build(inp, lib, N, world, pr)
+        ns.post_init(pr["stop_time"])
+        step = 0
+        if plot_int > 0 and world == 1:
+            print("PLOTFILE:", write_plot(ns, lay, pr, N, 0, plot_root))
     if rank == 0 and inp.ignored:
         print("inputs: ignored (I/O / verbosity / AMR bookkeeping) keys:", " ".join(sorted(inp.ignored)))
-    ns.post_init(pr["stop_time"])
-    plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
-    if plot_int > 0 and world == 1:
-        print("PLOTFILE:", write_plot(ns, lay, pr, N, 0, plot_root))
     t0 = time.perf_counter()
-    step = 0
     while (pr["max_step"] < 0 or step < pr["max_step"]) and (pr["stop_time"] < 0 or ns.time < pr["stop_time"] - 1e-14):
         if pr["max_step"] < 0 and pr["stop_time"] < 0:
             break
@@ -181,6 +209,9 @@ def main(argv):
             print(f"STEP = {step} TIME = {ns.time:.12g} DT = {dt:.12g}")
         if plot_int > 0 and world == 1 and step % plot_int == 0:
             print("PLOTFILE:", write_plot(ns, lay, pr, N, step, plot_root))
+        if check_int > 0 and step % check_int == 0:
+            from . import checkpoint
+            print("CHECKPOINT:", checkpoint.write(ns, check_root, step))
     lib.sync()
     if rank == 0:
         print(f"Run time = {time.perf_counter() - t0:.6f}")

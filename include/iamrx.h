@@ -184,20 +184,22 @@ int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iam
 /* ---- Godunov advection ---------------------------------------------------------------- */
 /* bcrec: 6 ints per component (lo[3], hi[3]) = amrex::BCRec mathematical BC codes
  * (reference Source/NS_BC.H:7-55). */
+/* scheme (last argument of the three entries): the edge-state reconstruction, ns.advection_scheme / godunov_use_ppm
+ * (Source/NavierStokesBase.cpp:548-553, 4654-4656): IAMRX_GODUNOV_PLM 0, IAMRX_GODUNOV_PPM 1.  Per call: the library keeps no
+ * process-wide advection mode. */
+#define IAMRX_GODUNOV_PLM 0
+#define IAMRX_GODUNOV_PPM 1
 /* Godunov::ExtrapVelToFaces as called from NavierStokesBase::predict_velocity
  * (Source/NavierStokesBase.cpp:4487-4491): vel (3 comps, 3 filled ghosts), force (3 comps, 1 ghost) -> u_mac */
 int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf umac_x, iamrx_mf umac_y,
-                                      iamrx_mf umac_z, double dt, const int* bcrec /* [3][6] */, int use_forces_in_trans);
+                                      iamrx_mf umac_z, double dt, const int* bcrec /* [3][6] */, int use_forces_in_trans, int scheme);
 /* the kernel chain of NavierStokesBase::ComputeAofs (Source/NavierStokesBase.cpp:4594-4845):
  * ComputeFluxesOnBoxFromState("Godunov") + ComputeDivergence(mult=-1, area weighted) + ComputeConvectiveTerm,
  * aofs(acomp+n) = -update.  edge_* / flux_* (ncomp face comps) are optional outputs (NULL to skip). */
 int iamrx_godunov_compute_aofs(const iamrx_geom* g, iamrx_mf aofs, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
                                iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, const int* iconserv, double dt,
                                const int* bcrec /* [ncomp][6] */, int is_velocity, int use_forces_in_trans,
-                               iamrx_mf edge_x, iamrx_mf edge_y, iamrx_mf edge_z, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
-
-/* edge-state reconstruction of the two entries above (godunov_use_ppm, Source/NavierStokesBase.cpp:4654-4656): 0 PLM (default), 1 PPM */
-int iamrx_godunov_set_ppm(int use_ppm);
+                               iamrx_mf edge_x, iamrx_mf edge_y, iamrx_mf edge_z, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z, int scheme);
 
 /* ---- nodal projection (amrex::MLNodeLaplacian / Hydro::NodalProjector role) ------- */
 /* out = rhs - div(sig grad phi) at nodes (rhs == NULL: out = div(sig grad phi)); phi and sig need 1 filled ghost */
@@ -337,11 +339,18 @@ int iamrx_ns_step(iamrx_ns ns, double* dt_used);           /* computeNewDt + Nav
 int iamrx_ns_advance(iamrx_ns ns, double dt, double* dt_est);
 int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep);
 /* snapshot COPY (caller destroys it with iamrx_mf_destroy) of a persistent array: 0 S_new, 1 S_old, 2 P_new,
- * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role) */
+ * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role); 10, 11: the last two MAC potentials (the
+ * initial-guess history of the MAC solve, part of a checkpoint) */
 int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
 /* overwrite state (0,1), pressure (2,3) or grad p (4,5) with src (same layout, ncomp, ngrow): the role of
  * NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420) */
-int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src);
+int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src);      /* which: 0..5, 10, 11 */
+/* checkpoint / restart of one level (AmrLevel::checkPoint / NavierStokesBase::restart role, Source/NavierStokesBase.cpp:856-897,
+ * 2706-2727): what outlives a time step besides the arrays of iamrx_ns_data.  state[16] = time, dt, nstep, State_Type new / old time,
+ * Press_Type new interval [2], old interval [2], dt of the last MAC solve, two history flags, dt estimate of the last advance,
+ * stop_time, 2 unused.  set = 0: read; set = 1: write (after the arrays have been set with iamrx_ns_set_data; the level then continues
+ * as if it had taken the steps itself -- no post_init). */
+int iamrx_ns_restart_state(iamrx_ns ns, int set, double state[16]);
 int iamrx_ns_stats(iamrx_ns ns, iamrx_mg_stats* mac, iamrx_mg_stats* nodal, iamrx_mg_stats* visc);
 /* per-section wall time accumulation (ms): predict, mac, advect, update, viscous, nodal; enable=1 inserts stream syncs (2: and resets).
  * enable=3: no syncs; HIP events on the launch stream around every 8th k_nodal_gs4 launch of the level's own (finest) MG level until the
@@ -383,7 +392,7 @@ int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scom
 int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acomp, iamrx_mf S, int ncomp, iamrx_mf force, iamrx_mf divu,
                                     iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z,
                                     const int* iconserv, double dt, const int* bcrec, int is_velocity, int use_forces_in_trans,
-                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
+                                    iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z, int scheme);
 
 /* ---- multi-level time step ------------------------------------------------------------------------------------
  * One coarse time step of a hierarchy of levels with subcycling = amrex::Amr::coarseTimeStep -> timeStep(level): advance(level),
@@ -422,6 +431,9 @@ int iamrx_amr_level_layout(iamrx_amr a, int lev, iamrx_layout* out);
 int iamrx_amr_level_boxes(iamrx_amr a, int lev, int* nboxes, int* boxes /* NULL: query the count */);
 int iamrx_amr_level(iamrx_amr a, int lev, iamrx_ns* out);
 int iamrx_amr_post_init(iamrx_amr a, double stop_time);      /* S_new of every level must hold the initial data (iamrx_ns_set_data) */
+/* Amr::checkPoint / Amr::restart role for the hierarchy: dt_level, dt_min, n_cycle per level, counters = {level_steps, level_count},
+ * stop_time.  set = 0: read, 1: write (instead of iamrx_amr_post_init, after every level has been restored). */
+int iamrx_amr_restart_state(iamrx_amr a, int set, double* dt_level, double* dt_min, int* n_cycle, int counters[2], double* stop_time);
 int iamrx_amr_coarse_step(iamrx_amr a, double* dt0);         /* dt0: the level-0 time step used */
 int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels /* [nlev] or NULL */);
 /* the pieces of NavierStokesBase::post_timestep(lev) one by one (lev < finest), for a caller that drives the loop itself:

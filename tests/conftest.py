@@ -40,12 +40,10 @@ def godunov_same(got, ref, tag=None, rel=1e-13):
 
 @pytest.fixture(autouse=True)
 def _plm_by_default(request):
-    """the reconstruction switch of the Godunov kernels (iamrx_godunov_set_ppm / orc_godunov_set_ppm) is process-wide state that the
-    level drivers set from ns.use_ppm at every advance; tests of the raw Godunov entry points expect PLM unless they ask for PPM"""
+    """the ORACLE's reconstruction switch (orc_godunov_set_ppm) is process-wide state that its level drivers set from ns.use_ppm at
+    every advance; tests of its raw Godunov entry points expect PLM unless they ask for PPM.  (The product takes the scheme as an
+    argument of every call and keeps no such state.)"""
     if "gpu" in request.keywords:
-        from iamr_amd import lib
-        if lib._initialized:
-            lib.check(lib.lib().iamrx_godunov_set_ppm(0))
         import orc as _orc
         if getattr(_orc, "_LIB", None) is not None:
             _orc.lib().orc_godunov_set_ppm(0)

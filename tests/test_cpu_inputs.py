@@ -26,7 +26,8 @@ def test_lid_driven_cavity_mapping_and_overrides():
     assert p["phys_lo"] == [4, 4, 5] and p["phys_hi"] == [5, 5, 5]
     assert p["wall_vel_hi"][6:9] == [1.0, 0.0, 0.0] and sum(p["wall_vel_lo"]) == 0.0
     assert pr["prob"]["probtype"] == 1 and pr["max_step"] == 2
-    assert set(inp.ignored) == {"amr.v", "amr.check_int"} and pr["plot_int"] > 0          # amr.plot_int drives the plotfile writer
+    assert set(inp.ignored) == {"amr.v"} and pr["plot_int"] > 0          # amr.plot_int drives the plotfile writer
+    assert pr["check_int"] > 0 and pr["check_file"] == "chk" and pr["restart"] == ""      # amr.check_int drives the checkpoint writer
 
 
 def test_unsupported_features_are_rejected_loudly():
@@ -99,9 +100,10 @@ def test_fixed_grid_hierarchy_keys():
 
 def test_physics_keys_are_not_swallowed_by_verbosity_prefixes():
     """`ns.v` must not match ns.variable_vel_visc / ns.visc_abs_tol / ns.vorterr ..."""
-    for k in ("ns.variable_vel_visc=1", "ns.variable_scal_diff=1", "ns.do_init_proj=0", "ns.do_mac_proj=0", "amr.restart=chk00010"):
+    for k in ("ns.variable_vel_visc=1", "ns.variable_scal_diff=1", "ns.do_init_proj=0", "ns.do_mac_proj=0"):
         with pytest.raises(NotImplementedError):
             Inputs([LDC], [k]).problem()
+    assert Inputs([LDC], ["amr.restart=chk00010"]).problem()["restart"] == "chk00010"      # checkpoint restart (SURVEY f2)
     with pytest.raises(KeyError):
         Inputs([LDC], ["ns.vorterr=1.0"]).problem()
     assert Inputs([LDC], ["ns.variable_vel_visc=0", "ns.do_init_proj=1", "ns.v=1"]).problem()["n"] == [16, 16, 16]

@@ -45,6 +45,10 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         bench.transport_selftest(lib, rank, world)   # the check bench.py runs on a freshly initialised transport
     if case == "amr":
         return run_amr(rank, world, out_dir)
+    if case.startswith("amrbench"):
+        return run_amrbench(rank, world, out_dir, int(case[8:]))
+    if case == "regrid":
+        return run_regrid(rank, world, out_dir)
     owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
     lay = lib.Layout(BOXES, owners)
     if case.startswith("grid"):
@@ -111,6 +115,121 @@ def run_amr(rank, world, out_dir):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_amrbench(rank, world, out_dir, nbox):
+    """bench.py's 2-level AMR workload in the layout it builds for `nbox` GPUs (one base box + one refined box per GPU on the process
+    grid), spread over the `world` ranks present"""
+    from iamr_amd import lib
+    import bench
+    import torch.distributed as dist
+    keep = []
+    res = bench.amr_workload(lib, 16, 1, rank, world, dist if world > 1 else None, layout_gpus=nbox, keep=keep)
+    amr = keep[0]
+    out = {"rate": np.array([res["cells_advanced_per_sec"]]), "iters": np.array([res["sync_project_iters"], res["mac_sync_iters"]]), "dts": np.array(amr.dts())}
+    for l in range(2):
+        S = amr.levels[l].data(0)
+        for li in range(S.nlocal()):
+            a, lo = S.to_numpy(li)
+            blo, bhi, gi = amr.layouts[l].local_box(li)
+            out[f"l{l}box{gi}"] = a[1:-1, 1:-1, 1:-1, :]
+    np.savez(os.path.join(out_dir, f"amrbench_w{world}_r{rank}.npz"), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_regrid(rank, world, out_dir):
+    """a tracer blob drifting through the Taylor-Green flow, level 1 = where tracer > 0.3, regridded at the start of every coarse step:
+    tag maps combined over the ranks, new boxes dealt out by the knapsack, data of the new level moved between ranks"""
+    from iamr_amd import lib
+    from iamr_amd import ns as NS
+    from iamr_amd.amr import Amr
+    import torch.distributed as dist
+    n0 = 16
+    cb = [((i, j, k), (i + 7, j + 7, k + 7)) for k in (0, 8) for j in (0, 8) for i in (0, 8)]
+    fb = [((8, 8, 8), (23, 23, 23))]
+    own = (lambda n: [q % world for q in range(n)])
+    lays = [lib.Layout(cb, own(len(cb))), lib.Layout(fb, own(len(fb)))]
+    amr = Amr(lib.Geom.make((n0,) * 3), lays, NS.ns_params(cfl=0.7, visc_coef=0.0, init_iter=2), lib.mg_opts())
+
+    def state(X, Y, Z):
+        S = np.zeros(X.shape + (5,), order="F")
+        S[..., 0] = 1.0 + np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(2 * np.pi * Z)
+        S[..., 1] = -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.cos(2 * np.pi * Z)
+        S[..., 3] = 1.0
+        S[..., 4] = np.exp(-((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2) / 0.01)
+        return S
+    for l in range(2):
+        lev = amr.levels[l]
+        n = n0 * 2 ** l
+        m = lib.MultiFab(lev.layout, lib.CELL, 5, 1)
+        for li in range(m.nlocal()):
+            lo, hi = m.fab_box(li)
+            c = [(np.arange(lo[d], hi[d] + 1) + 0.5) / n for d in range(3)]
+            m.from_numpy(state(*np.meshgrid(*c, indexing="ij")), li)
+        lev.set_data(lev.S_NEW, m)
+    amr.set_regrid(max_level=1, regrid_int=1, rules=[dict(comp=4, mode=0, value=[0.3])], blocking_factor=4, max_grid_size=8, n_error_buf=1)
+    amr.post_init()
+    out = {"dts": []}
+    grids = []
+    for step in range(3):
+        out["dts"].append(amr.coarse_step())
+        grids.append(sorted(amr.layouts[1].boxes))
+    out["dts"] = np.array(out["dts"])
+    out["grids"] = np.array([v for g in grids for lo, hi in g for v in (*lo, *hi)] + [len(g) for g in grids])
+    for l in range(amr.nlev):
+        S = amr.levels[l].data(0)
+        for li in range(S.nlocal()):
+            a, lo = S.to_numpy(li)
+            blo, bhi, gi = amr.layouts[l].local_box(li)
+            out["l%dbox_%d_%d_%d" % ((l,) + tuple(blo))] = a[1:-1, 1:-1, 1:-1, :]
+    out["nlocal"] = np.array([amr.levels[l].data(0).nlocal() for l in range(amr.nlev)])
+    np.savez(os.path.join(out_dir, f"regrid_w{world}_r{rank}.npz"), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nr", [2, 4])
+def test_amr_bench_workload_sharded_over_ranks(tmp_path, nr):
+    """the AMR workload of bench.py --gpus nr (base level and refined level each one box per GPU) on nr ranks sharing the GPU: every box of
+    both levels, the time steps and the iteration counts of the sync solves equal the run of ONE rank holding the same 2 nr boxes"""
+    import torch.multiprocessing as mp
+    port = 33100 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, f"amrbench{nr}"), nprocs=1, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "amrbench_w1_r0.npz"))
+    mp.spawn(run, args=(nr, port + 7, str(tmp_path), None, f"amrbench{nr}"), nprocs=nr, join=True)
+    seen = set()
+    for r in range(nr):
+        z = np.load(os.path.join(str(tmp_path), f"amrbench_w{nr}_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-12, atol=0)
+        assert np.array_equal(z["iters"], ref["iters"])
+        for key in z.files:
+            if "box" in key:
+                seen.add(key)
+                assert np.abs(z[key] - ref[key]).max() <= 1e-9, (key, np.abs(z[key] - ref[key]).max())
+    assert seen == {k for k in ref.files if "box" in k}
+
+
+def test_regrid_on_two_ranks_matches_one_rank(tmp_path):
+    """Amr::regrid with the levels spread over two ranks: same grids after every regrid, same data, both ranks own boxes of the new level"""
+    import torch.multiprocessing as mp
+    port = 34100 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "regrid"), nprocs=1, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "regrid_w1_r0.npz"))
+    mp.spawn(run, args=(2, port + 9, str(tmp_path), None, "regrid"), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"regrid_w2_r{r}.npz"))
+        assert np.array_equal(z["grids"], ref["grids"])
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        assert z["nlocal"][1] >= 1
+        for key in z.files:
+            if "box" in key:
+                seen.add(key)
+                assert np.abs(z[key] - ref[key]).max() <= 1e-8, (key, np.abs(z[key] - ref[key]).max())
+    assert seen == {k for k in ref.files if "box" in k}
 
 
 def test_two_level_hierarchy_on_two_ranks(tmp_path):

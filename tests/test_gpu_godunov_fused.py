@@ -1,4 +1,5 @@
-"""GPU: the fused z-marching Godunov kernels (k_god_z / k_pred_z, iamr_amd/csrc/k_godunov.hip -- the default PLM path) against the
+"""GPU: the fused z-marching Godunov kernels (k_god_z / k_pred_z, iamr_amd/csrc/k_godunov.hip -- the default path of both Godunov_PLM and
+Godunov_PPM) against the
 multi-pass kernels (k_trace / k_dir / k_aofs, IAMRX_GODUNOV_Z=0) through the C-ABI on the same device data: edge states, fluxes, aofs
 and predicted face velocities agree to 1e-13 (FMA contraction may differ between the two instruction streams; both are compared with
 the oracle in tests/test_gpu_godunov.py and tests/test_gpu_walls.py).  Sizes are chosen so that a box holds partial tiles (16 x 8),
@@ -50,13 +51,14 @@ def close(a, b, tag):
     assert err <= 1e-13 * max(1.0, float(np.abs(b).max())), (tag, err)
 
 
+@pytest.mark.parametrize("scheme", [0, 1], ids=["plm", "ppm"])
 @pytest.mark.parametrize("n,boxes,periodic,fit", [
     ((48, 40, 72), None, (1, 1, 1), 0),
     ((48, 40, 72), 24, (1, 1, 1), 1),
     ((40, 24, 48), None, (0, 1, 0), 0),
     ((32, 32, 32), 16, (0, 1, 0), 1),
 ])
-def test_fused_equals_multipass(gpu, n, boxes, periodic, fit):
+def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme):
     lib = gpu
     g = lib.Geom.make(n, periodic=periodic)
     lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
@@ -79,7 +81,7 @@ def test_fused_equals_multipass(gpu, n, boxes, periodic, fit):
         for m in um[z]:
             m.setval(0.0)
         with path(z):
-            lib.godunov_extrap_vel_to_faces(g, S, frc, um[z], dt, bc5[:3], fit)
+            lib.godunov_extrap_vel_to_faces(g, S, frc, um[z], dt, bc5[:3], fit, scheme=scheme)
     for d in range(3):
         close(um[1][d].gather_valid(n), um[0][d].gather_valid(n), ("umac", d))
     # advection of all five components with mac velocities that carry ghost faces
@@ -96,7 +98,7 @@ def test_fused_equals_multipass(gpu, n, boxes, periodic, fit):
         edge = [lib.MultiFab(lay, lib.face(d), 5, 0) for d in range(3)]
         flux = [lib.MultiFab(lay, lib.face(d), 5, 0) for d in range(3)]
         with path(z):
-            lib.godunov_compute_aofs(g, aofs, 1, S, 5, frc, divu, mac, (0, 0, 0, 1, 0), dt, bc5, 1, fit, edge=edge, flux=flux)
+            lib.godunov_compute_aofs(g, aofs, 1, S, 5, frc, divu, mac, (0, 0, 0, 1, 0), dt, bc5, 1, fit, edge=edge, flux=flux, scheme=scheme)
         out[z] = (aofs.gather_valid(n), [e.gather_valid(n) for e in edge], [f.gather_valid(n) for f in flux])
     assert np.all(out[1][0][..., 0] == -7.0)                   # acomp offset respected
     close(out[1][0], out[0][0], "aofs")

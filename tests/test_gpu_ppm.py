@@ -13,11 +13,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def ppm(orc, gpu):
+    # the oracle keeps a global switch (test infrastructure); the product takes the scheme as an argument of every call
     orc.lib().orc_godunov_set_ppm(1)
-    gpu.check(gpu.lib().iamrx_godunov_set_ppm(1))
     yield
     orc.lib().orc_godunov_set_ppm(0)
-    gpu.check(gpu.lib().iamrx_godunov_set_ppm(0))
 
 
 @pytest.mark.parametrize("n,boxes,fit", [((16, 16, 16), None, 0), ((32, 16, 24), 8, 1)])
@@ -38,7 +37,7 @@ def test_ppm_extrap_vel_to_faces(orc, gpu, ppm, n, boxes, fit):
     L.orc_godunov_set_ppm(1)
     vel_d, force_d = to_dev(lib, lay, vel, lib.CELL, 3), to_dev(lib, lay, force, lib.CELL, 1)
     um_d = [lib.MultiFab(lay, lib.face(d), 1, 1) for d in range(3)]
-    lib.godunov_extrap_vel_to_faces(g_d, vel_d, force_d, um_d, dt, None, fit)
+    lib.godunov_extrap_vel_to_faces(g_d, vel_d, force_d, um_d, dt, None, fit, scheme=1)
     for d in range(3):
         got, ref = um_d[d].gather_valid(n)[..., 0], um_o[d].valid(n, orc.face(d))[..., 0]
         godunov_same(got, ref, d)
@@ -75,7 +74,7 @@ def test_ppm_compute_aofs(orc, gpu, ppm, n, boxes, ncomp, iconserv, isvel, fit):
     aofs_d = lib.MultiFab(lay, lib.CELL, 5, 0)
     aofs_d.setval(0.0)
     edge_d = [lib.MultiFab(lay, lib.face(d), ncomp, 0) for d in range(3)]
-    lib.godunov_compute_aofs(g_d, aofs_d, 1, S_d, ncomp, force_d, divu_d, um_d, iconserv, dt, None, isvel, fit, edge=edge_d)
+    lib.godunov_compute_aofs(g_d, aofs_d, 1, S_d, ncomp, force_d, divu_d, um_d, iconserv, dt, None, isvel, fit, edge=edge_d, scheme=1)
     for d in range(3):
         godunov_same(edge_d[d].gather_valid(n), edge_o[d].valid(n, orc.face(d)), ("edge", d))
     godunov_same(aofs_d.gather_valid(n)[..., 1:1 + ncomp], aofs_o.valid(n)[..., 1:1 + ncomp], "aofs")
@@ -103,7 +102,6 @@ def test_rayleigh_taylor_regtest_physics_with_ppm(orc, gpu):
     ns.init_rayleightaylor(**rt)
     ns.post_init(-1.0)
     dts = [ns.step() for _ in range(3)]
-    lib.check(lib.lib().iamrx_godunov_set_ppm(0))
     assert np.allclose(dts, dts_o, rtol=1e-9, atol=0)
     S = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
     for comp in range(5):
@@ -117,4 +115,4 @@ def test_ppm_with_walls(orc, gpu, ppm, boxes):
     """the wall test of the PLM kernels (no-slip / slip walls, moving lid: ext_dir, hoextrap and foextrap faces) with the PPM switch on:
     one-sided edge values next to ext_dir / hoextrap faces"""
     from test_gpu_walls import test_godunov_with_walls
-    test_godunov_with_walls(orc, gpu, boxes)
+    test_godunov_with_walls(orc, gpu, boxes, scheme=1)

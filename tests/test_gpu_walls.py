@@ -68,7 +68,7 @@ def test_physbc_fill(orc, gpu, boxes):
 
 
 @pytest.mark.parametrize("boxes", [None, 8])
-def test_godunov_with_walls(orc, gpu, boxes):
+def test_godunov_with_walls(orc, gpu, boxes, scheme=0):
     lib = gpu
     L = orc.lib()
     n = (16, 16, 16)
@@ -93,7 +93,7 @@ def test_godunov_with_walls(orc, gpu, boxes):
     vel_d = lib.MultiFab(lay, lib.CELL, 3, 3); vel_d.set_from_global(vel.a, vel.lo)
     frc_d = lib.MultiFab(lay, lib.CELL, 3, 1); frc_d.set_from_global(force.a, force.lo)
     um_d = [lib.MultiFab(lay, lib.face(d), 1, 1) for d in range(3)]
-    lib.godunov_extrap_vel_to_faces(g_d, vel_d, frc_d, um_d, dt, VEL_BC, 0)
+    lib.godunov_extrap_vel_to_faces(g_d, vel_d, frc_d, um_d, dt, VEL_BC, 0, scheme=scheme)
     for d in range(3):
         got = um_d[d].gather_valid(n)[..., 0]
         ref = um_o[d].valid(n, orc.face(d))[..., 0]
@@ -123,7 +123,7 @@ def test_godunov_with_walls(orc, gpu, boxes):
         f_d = lib.MultiFab(lay, lib.CELL, ncomp, 1); f_d.setval(0.0)
         aofs_d = lib.MultiFab(lay, lib.CELL, ncomp, 0)
         edge_d = [lib.MultiFab(lay, lib.face(d), ncomp, 0) for d in range(3)]
-        lib.godunov_compute_aofs(g_d, aofs_d, 0, S_d, ncomp, f_d, None, um_d, icons, dt, S_bc, isvel, 0, edge=edge_d)
+        lib.godunov_compute_aofs(g_d, aofs_d, 0, S_d, ncomp, f_d, None, um_d, icons, dt, S_bc, isvel, 0, edge=edge_d, scheme=scheme)
         for d in range(3):
             godunov_same(edge_d[d].gather_valid(n), edge_o[d].valid(n, orc.face(d)), ("edge", d))
         godunov_same(aofs_d.gather_valid(n), aofs_o.valid(n), "aofs")

@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 from iamr_amd import lib, ns as N
 lib.init(0)
 n = 256
-g = lib.Geom.make((n, n, n)); lay = lib.Layout.single((n, n, n))
+mg = int(os.environ.get('IAMRX_MAXGRID', str(n)))
+g = lib.Geom.make((n, n, n)); lay = lib.Layout.decompose((n, n, n), mg)     # IAMRX_MAXGRID=128: the 8-box decomposition
 s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
 s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
 s.post_init(-1.0)
