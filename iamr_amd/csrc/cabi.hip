@@ -603,6 +603,7 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     for (int i = 0; i < 9; ++i) { p->wall_vel_lo[i] = d.wall_vel_lo[i]; p->wall_vel_hi[i] = d.wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { p->scal_bc_lo[i] = d.scal_bc_lo[i]; p->scal_bc_hi[i] = d.scal_bc_hi[i]; }
     p->do_cons_trac = d.do_cons_trac;
+    p->do_denminmax = d.do_denminmax; p->do_scalminmax = d.do_scalminmax;
     p->use_ppm = d.use_ppm;
 }
 
@@ -619,6 +620,7 @@ static NSParams to_params(const iamrx_ns_params* p)
     for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
     for (int i = 0; i < 6; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
     q.do_cons_trac = p->do_cons_trac;
+    q.do_denminmax = p->do_denminmax; q.do_scalminmax = p->do_scalminmax;
     q.use_ppm = p->use_ppm;
     return q;
 }

@@ -877,7 +877,7 @@ __global__ void __launch_bounds__((2 * (((TX + 1) * (TY + 1) + 63) / 64) + (TX *
 // process-wide mode outlives a call.
 static void set_scheme(int scheme)
 {
-    if (scheme != 0 && scheme != 1) throw Error("iamrx Godunov: advection scheme " + std::to_string(scheme) + " is not implemented (0 Godunov_PLM, 1 Godunov_PPM)");
+    if (scheme != 0 && scheme != 1) throw Error("iamrx Godunov: advection scheme " + std::to_string(scheme) + " is not implemented (0 Godunov_PLM, 1 Godunov_PPM, 2 BDS)");
     static const int vals[2] = {0, 1};
     static int current = -1;
     if (scheme == current) return;
@@ -1047,6 +1047,7 @@ void godunov_extrap_vel_to_faces(const Geometry& g, const MultiFab& vel, const M
                                  double dt, const BCRec* bc, bool use_forces_in_trans, int scheme)
 {
     if (vel.nlocal() == 0) return;
+    if (scheme == 2) scheme = 0;          // BDS: the velocity prediction is Godunov_PLM (NavierStokesBase.cpp:4487: godunov_use_ppm = (scheme == Godunov_PPM))
     set_scheme(scheme);
     IAMRX_ASSERT(vel.ngrow >= 3 && vel.ncomp >= 3);
     IAMRX_ASSERT(!force || force->ngrow >= 1);
@@ -2007,6 +2008,236 @@ static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab*
     else { if (bcs) launch_pred_z<16, 8, true, false>(l, vel, force, umac, dP); else launch_pred_z<16, 8, false, false>(l, vel, force, umac, dP); }
 }
 
+
+// -------------------------------------------------------------------------------- BDS (ns.advection_scheme = BDS)
+// Bell-Dawson-Shubin edge states: the ComputeFluxesOnBoxFromState(..., "BDS") branch of NavierStokesBase::ComputeAofs
+// (Source/NavierStokesBase.cpp:4701-4717; AMReX-Hydro's BDS::ComputeEdgeState is not in the reference tree -- restated from the
+// published algorithm, Docs/sphinx_documentation/source/TimeStep.rst:92-133, Nonaka et al. SISC 33 (2011); DESIGN.md section 2 for
+// the statement of the scheme and tests/test_cpu_bds.py for its known answers).  Three level-wide launches per component: the
+// fourth-order nodal interpolant, the limited trilinear slopes (7 per cell, cells grown by one), the edge states of every direction.
+namespace {
+struct BdsGeom { double h[3]; int dlo[3], dhi[3]; int lo_phys[3], hi_phys[3]; };
+
+__device__ __forceinline__ double bds_eval(double s0, const double* sl, const double* del)
+{
+    return s0 + del[0] * sl[0] + del[1] * sl[1] + del[2] * sl[2] + del[0] * del[1] * sl[3] + del[0] * del[2] * sl[4] + del[1] * del[2] * sl[5]
+              + del[0] * del[1] * del[2] * sl[6];
+}
+struct BdsCtx {
+    FabD s, sl, mac[3], fq;
+    int n, conserv, has_f;
+    double dt, h[3];
+    __device__ __forceinline__ double macv(int d, const int f[3]) const { return mac[d](f[0], f[1], f[2]); }
+    __device__ __forceinline__ double dvel(int d, const int q[3]) const
+    {
+        int p[3] = {q[0], q[1], q[2]};
+        p[d] += 1;
+        return (macv(d, p) - macv(d, q)) / h[d];
+    }
+    __device__ __forceinline__ double poly(const int q[3], const double del[3]) const
+    {
+        double sl7[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) sl7[m] = sl(q[0], q[1], q[2], m);
+        return bds_eval(s(q[0], q[1], q[2], n), sl7, del);
+    }
+};
+
+__device__ double bds_edge(const BdsCtx& c, int D, const int f[3])
+{
+    const double dt = c.dt, dt2 = dt / 2.0, dt3 = dt / 3.0, dt4 = dt / 4.0;
+    const double* h = c.h;
+    const double uD = c.macv(D, f);
+    const int sgnD = uD > 0.0 ? 1 : -1, offD = uD > 0.0 ? -1 : 0;
+    int I[3] = {f[0], f[1], f[2]};
+    I[D] += offD;
+    double del[3] = {0.0, 0.0, 0.0};
+    del[D] = sgnD * 0.5 * h[D] - 0.5 * uD * dt;
+    double sedge = c.poly(I, del);
+    const int Ta = (D + 1) % 3, Tb = (D + 2) % 3;
+    if (c.conserv) sedge *= 1.0 - dt2 * c.dvel(D, I);
+    else sedge *= 1.0 + dt2 * (c.dvel(Ta, I) + c.dvel(Tb, I));
+    if (c.has_f) sedge += dt2 * c.fq(I[0], I[1], I[2], c.n);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int T = pass == 0 ? Ta : Tb, O = pass == 0 ? Tb : Ta;
+        for (int sideT = 1; sideT >= -1; sideT -= 2) {
+            int ft[3] = {I[0], I[1], I[2]};
+            if (sideT > 0) ft[T] += 1;
+            const double V = c.macv(T, ft);
+            const int sgnT = V > 0.0 ? 1 : -1;
+            const int offT = sideT > 0 ? (V > 0.0 ? 0 : 1) : (V > 0.0 ? -1 : 0);
+            int J[3] = {I[0], I[1], I[2]};
+            J[T] += offT;
+            int fD[3] = {f[0], f[1], f[2]};
+            fD[T] += offT;
+            const double uS = c.macv(D, fD);
+            const double u = uD * uS > 0.0 ? uS : 0.0;
+            double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0}, p3[3] = {0, 0, 0};
+            p1[D] = sgnD * 0.5 * h[D];           p1[T] = sgnT * 0.5 * h[T];
+            p2[D] = sgnD * 0.5 * h[D] - uD * dt; p2[T] = sgnT * 0.5 * h[T];
+            p3[D] = sgnD * 0.5 * h[D] - u * dt;  p3[T] = sgnT * 0.5 * h[T] - V * dt;
+            double d1[3], d2[3], d3[3];
+            for (int l = 0; l < 3; ++l) { d1[l] = 0.5 * (p2[l] + p3[l]); d2[l] = 0.5 * (p1[l] + p3[l]); d3[l] = 0.5 * (p1[l] + p2[l]); }
+            double gamma = (c.poly(J, d1) + c.poly(J, d2) + c.poly(J, d3)) / 3.0;
+            if (c.conserv) gamma *= 1.0 - dt3 * (c.dvel(D, J) + c.dvel(T, J));
+            else gamma *= 1.0 + dt3 * c.dvel(O, J);
+            for (int sideO = 1; sideO >= -1; sideO -= 2) {
+                int fo[3] = {J[0], J[1], J[2]};
+                if (sideO > 0) fo[O] += 1;
+                const double W = c.macv(O, fo);
+                const int sgnO = W > 0.0 ? 1 : -1;
+                const int offO = sideO > 0 ? (W > 0.0 ? 0 : 1) : (W > 0.0 ? -1 : 0);
+                int K[3] = {J[0], J[1], J[2]};
+                K[O] += offO;
+                int fD2[3] = {fD[0], fD[1], fD[2]};
+                fD2[O] += offO;
+                const double uS2 = c.macv(D, fD2);
+                const double uu = uD * uS2 > 0.0 ? uS2 : 0.0;
+                int ft2[3] = {ft[0], ft[1], ft[2]};
+                ft2[O] += offO;
+                const double vS2 = c.macv(T, ft2);
+                const double vv = V * vS2 > 0.0 ? vS2 : 0.0;
+                double q1[3], q2[3], q3[3], q4[3];
+                for (int l = 0; l < 3; ++l) { q1[l] = p1[l]; q2[l] = p2[l]; q3[l] = p3[l]; q4[l] = 0.0; }
+                q1[O] = q2[O] = q3[O] = sgnO * 0.5 * h[O];
+                q4[D] = sgnD * 0.5 * h[D] - uu * dt; q4[T] = sgnT * 0.5 * h[T] - vv * dt; q4[O] = sgnO * 0.5 * h[O] - W * dt;
+                double e1[3], e2[3], e3[3], e4[3], e5[3];
+                const double a = 0.5, b = 1.0 / 6.0;
+                for (int l = 0; l < 3; ++l) {
+                    e1[l] = a * q1[l] + b * q2[l] + b * q3[l] + b * q4[l];
+                    e2[l] = b * q1[l] + a * q2[l] + b * q3[l] + b * q4[l];
+                    e3[l] = b * q1[l] + b * q2[l] + a * q3[l] + b * q4[l];
+                    e4[l] = b * q1[l] + b * q2[l] + b * q3[l] + a * q4[l];
+                    e5[l] = 0.25 * (q1[l] + q2[l] + q3[l] + q4[l]);
+                }
+                double gamma2 = -0.8 * c.poly(K, e5) + 0.45 * (c.poly(K, e1) + c.poly(K, e2) + c.poly(K, e3) + c.poly(K, e4));
+                if (c.conserv) gamma2 *= 1.0 - dt4 * (c.dvel(D, K) + c.dvel(T, K) + c.dvel(O, K));
+                gamma2 *= W;
+                gamma -= (double)sideO * dt * gamma2 / (3.0 * h[O]);
+            }
+            gamma *= V;
+            sedge -= (double)sideT * dt * gamma / (2.0 * h[T]);
+        }
+    }
+    return sedge;
+}
+
+inline bool bds_is_phys(int b) { return b == bc_foextrap || b == bc_hoextrap || b == bc_ext_dir; }
+}  // namespace
+
+// edge[d](.., n) for n < ncomp on the valid faces of every box; S: >= 3 filled ghost cells, umac: >= 1 filled ghost layer
+static void bds_edge_states(const Geometry& g, const MultiFab& S, int ncomp, const MultiFab* force, MultiFab* const umac[3], const int* iconserv,
+                            double dt, const BCRec* bc, MultiFab* const edge[3])
+{
+    auto& ctx = Context::get();
+    const Layout& l = *S.layout;
+    MultiFab sint(S.layout, node_type(), 1, 2), sl(S.layout, cell_type(), 7, 1);
+    for (int n = 0; n < ncomp; ++n) {
+        BdsGeom G;
+        for (int d = 0; d < 3; ++d) {
+            G.h[d] = g.dx[d]; G.dlo[d] = g.domain.lo[d]; G.dhi[d] = g.domain.hi[d];
+            G.lo_phys[d] = (!g.periodic[d] && bc && bds_is_phys(bc[n].lo[d])) ? 1 : 0;
+            G.hi_phys[d] = (!g.periodic[d] && bc && bds_is_phys(bc[n].hi[d])) ? 1 : 0;
+        }
+        const FabD *st = S.d_tab, *it = sint.d_tab, *lt = sl.d_tab;
+        // 1. nodal values: node (i,j,k) = lower corner of cell (i,j,k); tensor product of (-1, 7, 7, -1) / 12 over the 4^3 cells around
+        // it; on / beyond a physical boundary: the average of the four ghost cells around the node in the boundary plane
+        for_each(l, node_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const int idx[3] = {i, j, k};
+            int bd = -1, bcell = 0;
+            for (int d = 0; d < 3 && bd < 0; ++d) {
+                if (G.lo_phys[d] && idx[d] <= G.dlo[d]) { bd = d; bcell = G.dlo[d] - 1; }
+                else if (G.hi_phys[d] && idx[d] >= G.dhi[d] + 1) { bd = d; bcell = G.dhi[d] + 1; }
+            }
+            double v = 0.0;
+            if (bd >= 0) {
+                const int t1 = (bd + 1) % 3, t2 = (bd + 2) % 3;
+                for (int b = -1; b <= 0; ++b) for (int a = -1; a <= 0; ++a) {
+                    int c[3];
+                    c[bd] = bcell; c[t1] = idx[t1] + a; c[t2] = idx[t2] + b;
+                    v += 0.25 * st[f](c[0], c[1], c[2], n);
+                }
+            } else {
+                const double w4[4] = {-1.0 / 12.0, 7.0 / 12.0, 7.0 / 12.0, -1.0 / 12.0};
+                for (int c = 0; c < 4; ++c) for (int b = 0; b < 4; ++b) for (int a = 0; a < 4; ++a)
+                    v += w4[a] * w4[b] * w4[c] * st[f](i - 2 + a, j - 2 + b, k - 2 + c, n);
+            }
+            it[f](i, j, k) = v;
+        });
+        // 2. limited slopes on the cells grown by one
+        for_each(l, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const double* h = G.h;
+            double sc[8], smin[8], smax[8], sl7[7];
+            const double s0 = st[f](i, j, k, n);
+            for (int m = 0; m < 8; ++m) sc[m] = it[f](i + (m & 1), j + ((m >> 1) & 1), k + ((m >> 2) & 1));
+            auto corners_to_slopes = [&]() {
+                sl7[0] = 0.25 * ((sc[1] + sc[3] + sc[5] + sc[7]) - (sc[0] + sc[2] + sc[4] + sc[6])) / h[0];
+                sl7[1] = 0.25 * ((sc[2] + sc[3] + sc[6] + sc[7]) - (sc[0] + sc[1] + sc[4] + sc[5])) / h[1];
+                sl7[2] = 0.25 * ((sc[4] + sc[5] + sc[6] + sc[7]) - (sc[0] + sc[1] + sc[2] + sc[3])) / h[2];
+                sl7[3] = 0.5 * ((sc[0] + sc[3] + sc[4] + sc[7]) - (sc[1] + sc[2] + sc[5] + sc[6])) / (h[0] * h[1]);
+                sl7[4] = 0.5 * ((sc[0] + sc[5] + sc[2] + sc[7]) - (sc[1] + sc[4] + sc[3] + sc[6])) / (h[0] * h[2]);
+                sl7[5] = 0.5 * ((sc[0] + sc[6] + sc[1] + sc[7]) - (sc[2] + sc[4] + sc[3] + sc[5])) / (h[1] * h[2]);
+                sl7[6] = ((sc[7] + sc[1] + sc[2] + sc[4]) - (sc[0] + sc[3] + sc[5] + sc[6])) / (h[0] * h[1] * h[2]);
+            };
+            corners_to_slopes();
+            for (int m = 0; m < 8; ++m) {
+                const int mx = m & 1, my = (m >> 1) & 1, mz = (m >> 2) & 1;
+                const double del[3] = {(mx ? 0.5 : -0.5) * h[0], (my ? 0.5 : -0.5) * h[1], (mz ? 0.5 : -0.5) * h[2]};
+                sc[m] = bds_eval(s0, sl7, del);
+                double mn = s0, mxv = s0;
+                for (int c = -1; c <= 0; ++c) for (int b = -1; b <= 0; ++b) for (int a = -1; a <= 0; ++a) {
+                    const double q = st[f](i + mx + a, j + my + b, k + mz + c, n);
+                    mn = fmin(mn, q); mxv = fmax(mxv, q);
+                }
+                smin[m] = mn; smax[m] = mxv;
+                sc[m] = fmax(fmin(sc[m], smax[m]), smin[m]);
+            }
+            const double eps = 1.0e-10;
+            for (int ll = 0; ll < 3; ++ll) {
+                double sumloc = 0.0;
+                for (int m = 0; m < 8; ++m) sumloc += sc[m];
+                sumloc *= 0.125;
+                double sumdif = (sumloc - s0) * 8.0;
+                const double sgndif = copysign(1.0, sumdif);
+                double diff[8];
+                int kdp = 0;
+                for (int m = 0; m < 8; ++m) { diff[m] = (sc[m] - s0) * sgndif; if (diff[m] > eps) ++kdp; }
+                for (int m = 0; m < 8; ++m) {
+                    const double div = kdp < 1 ? 1.0 : (double)kdp;
+                    double redfac = 0.0;
+                    if (diff[m] > eps) { redfac = sumdif * sgndif / div; --kdp; }
+                    const double redmax = sgndif > 0.0 ? sc[m] - smin[m] : smax[m] - sc[m];
+                    redfac = fmin(redfac, redmax);
+                    sumdif -= redfac * sgndif;
+                    sc[m] -= redfac * sgndif;
+                }
+            }
+            corners_to_slopes();
+            for (int q = 0; q < 7; ++q) lt[f](i, j, k, q) = sl7[q];
+        });
+        // 3. edge states
+        for (int D = 0; D < 3; ++D) {
+            const FabD *et = edge[D]->d_tab, *ux = umac[0]->d_tab, *uy = umac[1]->d_tab, *uz = umac[2]->d_tab;
+            const FabD* ft = force ? force->d_tab : nullptr;
+            const int conserv = iconserv[n] ? 1 : 0, lo_p = G.lo_phys[D], hi_p = G.hi_phys[D];
+            for_each(l, face_type(D), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                const int fi[3] = {i, j, k};
+                double v;
+                if (lo_p && fi[D] == G.dlo[D]) { int c[3] = {i, j, k}; c[D] -= 1; v = st[f](c[0], c[1], c[2], n); }
+                else if (hi_p && fi[D] == G.dhi[D] + 1) v = st[f](i, j, k, n);
+                else {
+                    BdsCtx c;
+                    c.s = st[f]; c.sl = lt[f]; c.mac[0] = ux[f]; c.mac[1] = uy[f]; c.mac[2] = uz[f];
+                    c.has_f = ft != nullptr; if (ft) c.fq = ft[f]; else c.fq = st[f];
+                    c.n = n; c.conserv = conserv; c.dt = dt; c.h[0] = G.h[0]; c.h[1] = G.h[1]; c.h[2] = G.h[2];
+                    v = bds_edge(c, D, fi);
+                }
+                et[f](i, j, k, n) = v;
+            });
+        }
+    }
+}
+
 static bool use_tile_kernel()
 {
     static int v = -1;
@@ -2026,6 +2257,24 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     MultiFab e0[3], edge[3], sl[3];
     MultiFab* ed[3];
     const bool ws = use_dir_fused();
+    if (scheme == 2) {
+        // BDS edge states, then the flux / divergence / convective-term kernel of the Godunov path
+        IAMRX_ASSERT(force == nullptr || force->ngrow >= 1);
+        MultiFab edge_own[3];
+        MultiFab* edp[3];
+        for (int d = 0; d < 3; ++d) {
+            if (edge_out && edge_out[d]) edp[d] = edge_out[d];
+            else { edge_own[d].define(S.layout, face_type(d), ncomp, 0); edp[d] = &edge_own[d]; }
+        }
+        bds_edge_states(g, S, ncomp, force, umac, iconserv, dt, bc, edp);
+        const GodParams* dPb = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
+        Tiling tb = level_tiling(l, cell_type(), 0, 4);
+        const bool sfb = flux_out && flux_out[0];
+        hipLaunchKernelGGL(k_aofs, tb.grid(), Tiling::block(), 0, ctx.stream, tb, l.d_boxes, aofs.d_tab, acomp,
+                           edp[0]->d_tab, edp[1]->d_tab, edp[2]->d_tab, umac[0]->d_tab, umac[1]->d_tab, umac[2]->d_tab,
+                           sfb ? flux_out[0]->d_tab : nullptr, sfb ? flux_out[1]->d_tab : nullptr, sfb ? flux_out[2]->d_tab : nullptr, dPb);
+        return;
+    }
     const bool ppm = scheme == 1;
     set_scheme(scheme);
     const bool zk = use_z_kernel();

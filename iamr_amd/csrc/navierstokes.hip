@@ -562,6 +562,26 @@ void NavierStokes::mac_project(double dt_)
         const MultiFab* uc[3] = {&crse->u_mac[0], &crse->u_mac[1], &crse->u_mac[2]};
         create_umac_grown(um, uc, nullptr, crse->g, g, ratio);
     }
+    // "BDS needs physical BCs filled" (NavierStokesBase.cpp:1097-1105: FillPatchSingleLevel of u_mac with the velocity's boundary
+    // functor): the ghost faces outside a non-periodic domain face take the nearest face inside or on the boundary (first-order
+    // extrapolation -- the functor itself is upstream; the normal velocity on the boundary face is the boundary value already)
+    if (p.use_ppm == 2 && any_wall)
+        for (int d = 0; d < 3; ++d) {
+            const FabD* ut = u_mac[d].d_tab;
+            const BoxD dom = g.domain;
+            const int p0 = g.periodic[0], p1 = g.periodic[1], p2 = g.periodic[2], dd = d;
+            for_each(*layout, face_type(d), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                const int per[3] = {p0, p1, p2};
+                int q[3] = {i, j, k};
+                bool out = false;
+                for (int e = 0; e < 3; ++e) {
+                    if (per[e]) continue;
+                    const int lo = dom.lo[e], hi = dom.hi[e] + (e == dd ? 1 : 0);
+                    if (q[e] < lo) { q[e] = lo; out = true; } else if (q[e] > hi) { q[e] = hi; out = true; }
+                }
+                if (out) ut[f](i, j, k) = (double)ut[f](q[0], q[1], q[2]);
+            });
+        }
 }
 
 void NavierStokes::velocity_advection(double dt_)
@@ -709,6 +729,26 @@ void NavierStokes::advection_all(double dt_)
     godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
+// NavierStokesBase::ConservativeScalMinMax / ConvectiveScalMinMax (NavierStokesBase.cpp:4256-4368): the new value (per unit mass if
+// conservative) clipped to the min / max of the FillPatch'ed old data over the 27 neighbours; the running maximum starts from
+// std::numeric_limits<Real>::min() (the smallest positive double) as written upstream
+void NavierStokes::scal_min_max(int comp, bool conservative)
+{
+    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
+    fillpatch(Smf, S[1 - inew], Density, NUM_SCALARS, bc_scal);
+    const FabD *nt = S[inew].d_tab, *ot = Smf.d_tab;
+    const int oc = comp - Density;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        double smn = 1.7976931348623157e308, smx = 2.2250738585072014e-308;
+        for (int kk = -1; kk <= 1; ++kk) for (int jj = -1; jj <= 1; ++jj) for (int ii = -1; ii <= 1; ++ii) {
+            const double v = conservative ? ot[f](i + ii, j + jj, k + kk, oc) / ot[f](i + ii, j + jj, k + kk, 0) : (double)ot[f](i + ii, j + jj, k + kk, oc);
+            smn = fmin(smn, v); smx = fmax(smx, v);
+        }
+        if (conservative) { const double rn = nt[f](i, j, k, Density); nt[f](i, j, k, comp) = fmin(fmax(nt[f](i, j, k, comp) / rn, smn), smx) * rn; }
+        else nt[f](i, j, k, comp) = fmin(fmax((double)nt[f](i, j, k, comp), smn), smx);
+    });
+}
+
 void NavierStokes::scalar_update_rho(double dt_)
 {
     SectionTimer tm(*this, 3);
@@ -716,6 +756,7 @@ void NavierStokes::scalar_update_rho(double dt_)
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         nt[f](i, j, k, Density) = ot[f](i, j, k, Density) - dt_ * at[f](i, j, k, Density);
     });
+    if (p.do_denminmax) scal_min_max(Density, true);                                   // NavierStokesBase.cpp:2771-2788
     make_rho_curr_time();
     {   // get_rho_half_time (NavierStokesBase.cpp:1561-1565)
         const FabD *ht = rho_half.d_tab, *pt = rho_ptime.d_tab, *ct = rho_ctime.d_tab;
@@ -734,6 +775,7 @@ void NavierStokes::scalar_update_tracers(double dt_)
         const double tfv = 0.0;               // getForce = 0 for the tracer: the conservative form (+ tf, no 1/rho; NavierStokesBase.cpp:2889) gives the same value
         nt[f](i, j, k, Tracer) = ot[f](i, j, k, Tracer) + dt_ * (-at[f](i, j, k, Tracer) + tfv / rho);
     });
+    if (p.do_scalminmax) scal_min_max(Tracer, p.do_cons_trac != 0);                     // NavierStokesBase.cpp:2907-2935
 }
 
 // Diffusion::diffuse_scalar for the tracer (rho_flag 0): (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old

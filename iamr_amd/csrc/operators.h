@@ -146,6 +146,7 @@ struct NSParams {
     double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
     double scal_bc_lo[6] = {0, 0, 0, 0, 0, 0}, scal_bc_hi[6] = {0, 0, 0, 0, 0, 0};   // xlo.density, xlo.tracer ... (inflow values): [d*2+n]
     int do_cons_trac = 0;                // ns.do_cons_trac
+    int do_denminmax = 0, do_scalminmax = 0;   // ns.do_denminmax / ns.do_scalminmax (NavierStokesBase.cpp:466-467)
     int use_ppm = 0;                     // ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM (NavierStokesBase.cpp:548-553)
 };
 
@@ -214,6 +215,7 @@ private:
     void scalar_advection(double dt);
     void scalar_update_rho(double dt);
     void scalar_update_tracers(double dt);
+    void scal_min_max(int comp, bool conservative);
     void velocity_advection_update(double dt);
     void scalar_diffusion_update(double dt);
     void get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata);

@@ -26,6 +26,8 @@ _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.v
                  "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
 _IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
+# boundary values of the second tracer: read by upstream only with ns.do_trac2 = 1 (which raises here), unused otherwise
+_IGNORED_KEYS = _IGNORED_KEYS + tuple(f"{d}{s}.tracer2" for d in "xyz" for s in ("lo", "hi"))
 # keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
 _UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
                          "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
@@ -218,8 +220,8 @@ class Inputs:
                 raise NotImplementedError(f"inputs: ns.lo_bc/hi_bc = {lo_bc[d]}/{hi_bc[d]} in direction {d}: implemented are Interior (0), "
                                           "Inflow (1), Outflow (2), Symmetry (3), SlipWall (4) and NoSlipWall (5)")
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
-        if scheme not in ("Godunov_PLM", "Godunov_PPM"):      # NavierStokesBase.cpp:548-553; BDS is not implemented
-            raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; Godunov_PLM and Godunov_PPM are implemented")
+        if scheme not in ("Godunov_PLM", "Godunov_PPM", "BDS"):      # NavierStokesBase.cpp:548-553
+            raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; Godunov_PLM, Godunov_PPM and BDS are implemented")
         for k in ("ns.do_temp", "ns.do_trac2", "ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
             if self.has(k) and self.string(k) not in ("0", "all_regular"):
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented")
@@ -229,7 +231,8 @@ class Inputs:
                  init_shrink=self.real("ns.init_shrink", 1.0), change_max=self.real("ns.change_max", 1.1),
                  fixed_dt=self.real("ns.fixed_dt", -1.0), init_dt=self.real("ns.init_dt", -1.0), gravity=self.real("ns.gravity", 0.0),
                  be_cn_theta=self.real("ns.be_cn_theta", 0.5), visc_tol=self.real("ns.visc_tol", 1.0e-10),
-                 use_forces_in_trans=self.integer("godunov.use_forces_in_trans", 0), do_mom_diff=self.integer("ns.do_mom_diff", 0), do_cons_trac=self.integer("ns.do_cons_trac", 0), use_ppm=1 if scheme == "Godunov_PPM" else 0,
+                 use_forces_in_trans=self.integer("godunov.use_forces_in_trans", 0), do_mom_diff=self.integer("ns.do_mom_diff", 0), do_cons_trac=self.integer("ns.do_cons_trac", 0), use_ppm={"Godunov_PLM": 0, "Godunov_PPM": 1, "BDS": 2}[scheme],
+                 do_denminmax=self.integer("ns.do_denminmax", 0), do_scalminmax=self.integer("ns.do_scalminmax", 0),
                  mac_tol=self.real("mac_proj.mac_tol", 1.0e-12), mac_abs_tol=self.real("mac_proj.mac_abs_tol", 1.0e-16),
                  proj_tol=self.real("proj.proj_tol", 1.0e-12), proj_abs_tol=self.real("proj.proj_abs_tol", 1.0e-16),
                  phys_lo=lo_bc, phys_hi=hi_bc)

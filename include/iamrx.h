@@ -189,6 +189,7 @@ int iamrx_mac_divergence(const iamrx_geom* g, iamrx_mf div, iamrx_mf umac_x, iam
  * process-wide advection mode. */
 #define IAMRX_GODUNOV_PLM 0
 #define IAMRX_GODUNOV_PPM 1
+#define IAMRX_BDS 2          /* Bell-Dawson-Shubin edge states in ComputeAofs (the velocity prediction stays Godunov_PLM, as upstream) */
 /* Godunov::ExtrapVelToFaces as called from NavierStokesBase::predict_velocity
  * (Source/NavierStokesBase.cpp:4487-4491): vel (3 comps, 3 filled ghosts), force (3 comps, 1 ghost) -> u_mac */
 int iamrx_godunov_extrap_vel_to_faces(const iamrx_geom* g, iamrx_mf vel, iamrx_mf force, iamrx_mf umac_x, iamrx_mf umac_y,
@@ -325,7 +326,8 @@ typedef struct iamrx_ns_params {
     double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];     /* xlo.density, xlo.tracer ... zhi.* (inflow values): [d*2+n], n = 0 density, 1 tracer */
     int do_cons_trac;            /* ns.do_cons_trac: the tracer is rho*q, advected conservatively and diffused as div beta grad(S/rho) (Source/NS_setup.cpp:306-310) */
-    int use_ppm;                 /* ns.advection_scheme: 0 = Godunov_PLM, 1 = Godunov_PPM (Source/NavierStokesBase.cpp:548-553, 4654-4656) */
+    int do_denminmax, do_scalminmax;   /* ns.do_denminmax / ns.do_scalminmax (Source/NavierStokesBase.cpp:466-467): clip the advected density / scalars to the 27-point min / max of the old data (ConservativeScalMinMax / ConvectiveScalMinMax, :4256-4368) */
+    int use_ppm;                 /* ns.advection_scheme: 0 = Godunov_PLM, 1 = Godunov_PPM, 2 = BDS (Source/NavierStokesBase.cpp:548-553, 4654-4656) */
 } iamrx_ns_params;
 void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out);

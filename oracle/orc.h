@@ -183,7 +183,7 @@ void orc_compute_aofs(const orc_geom* g, orc_fab* aofs /*ncomp comps starting at
                       orc_fab* edge_out[3] /*optional, ncomp face comps*/, orc_fab* flux_out[3]);
 
 /* edge-state reconstruction used by the two routines above: 0 PLM (default), 1 PPM */
-void orc_godunov_set_ppm(int on);
+void orc_godunov_set_ppm(int scheme);   /* ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM, 2 BDS */
 int orc_godunov_get_ppm(void);
 
 /* ---- nodal projection (orc_nodal.c) ---------------------------------------------- */
@@ -243,6 +243,7 @@ typedef struct orc_ns_params {
     double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
     double scal_bc_lo[6], scal_bc_hi[6];   /* xlo.density, xlo.tracer ... (inflow values): [d*2+n], n = 0 density, 1 tracer */
     int do_cons_trac;          /* ns.do_cons_trac (Source/NS_setup.cpp:306-310): Conservative advection, Laplacian_SoverRho diffusion */
+    int do_denminmax, do_scalminmax;   /* ns.do_denminmax / ns.do_scalminmax (Source/NavierStokesBase.cpp:466-467, 2771-2788, 2907-2935) */
     int use_ppm;               /* ns.advection_scheme = Godunov_PPM (Source/NavierStokesBase.cpp:548-553); 0: Godunov_PLM */
 } orc_ns_params;
 

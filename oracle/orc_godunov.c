@@ -93,9 +93,13 @@ static inline int bc_is_ed_or_ho(int b) { return b == ORC_BC_EXT_DIR || b == ORC
  *   tracing          s6 = 6s - 3(sm + sp), sigma = |u| dt/dx;
  *                    high face: u > small ? sp - sigma/2 ((sp - sm) - (1 - 2/3 sigma) s6) : s
  *                    low  face: u < -small ? sm + sigma/2 ((sp - sm) + (1 - 2/3 sigma) s6) : s */
-static int g_use_ppm = 0;
-void orc_godunov_set_ppm(int on) { g_use_ppm = on; }
-int orc_godunov_get_ppm(void) { return g_use_ppm; }
+/* the value is ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM, 2 BDS (edge states of ComputeAofs by orc_bds.c; the velocity
+ * prediction stays Godunov_PLM: NavierStokesBase.cpp:4487 passes godunov_use_ppm = (advection_scheme == "Godunov_PPM")) */
+static int g_use_ppm = 0, g_bds = 0;
+void orc_godunov_set_ppm(int scheme) { g_use_ppm = scheme == 1; g_bds = scheme == 2; }
+int orc_godunov_get_ppm(void) { return g_bds ? 2 : g_use_ppm; }
+void orc_bds_edge_state(const orc_geom* g, const orc_fab* q, int ncomp, const orc_fab* fq, orc_fab* const mac[3], const int* iconserv,
+                        double dt, const orc_bcrec* bc, int is_velocity, orc_fab* edge);
 
 static inline double vanleer(double s0, double sm1, double sp1)
 {
@@ -343,6 +347,7 @@ static void compute_edge_state(const orc_geom* g, const orc_fab* q, int ncomp, c
                                orc_fab* const umac[3], const int* iconserv, double dt, const orc_bcrec* bc,
                                int is_velocity, int use_forces_in_trans, orc_fab edge_out[3])
 {
+    if (g_bds) { orc_bds_edge_state(g, q, ncomp, fq, umac, iconserv, dt, bc, is_velocity, edge_out); return; }
     orc_fab Im[3], Ip[3], lo_[3], hi_[3], edge[3];
     for (int d = 0; d < 3; ++d) {
         Im[d] = orc_alloc(g->n, ORC_CELL, 1, ncomp);

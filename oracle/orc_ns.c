@@ -38,6 +38,7 @@ void orc_ns_default_params(orc_ns_params* p)
     for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
     for (int q = 0; q < 6; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
     p->do_cons_trac = 0;
+    p->do_denminmax = 0; p->do_scalminmax = 0;
     p->use_ppm = 0;
 }
 
@@ -827,6 +828,21 @@ static void mac_project(orc_ns_state* s, double dt)
         if (s->level > 0) reg_fine_add(s, s->reg_mac, &s->umac[d], d, 0, 0, 1, area / (double)s->ncycle);
     }
     if (s->level > 0) create_umac_grown_fine(s);
+    /* "BDS needs physical BCs filled" (NavierStokesBase.cpp:1097-1105): ghost faces outside a non-periodic domain face = the nearest
+     * face inside or on the boundary (first-order extrapolation; the boundary functor itself is upstream) */
+    if (s->p.use_ppm == 2)
+        for (int d = 0; d < 3; ++d) {
+            orc_fab* u = &s->umac[d];
+            for (int k = u->lo[2]; k <= u->hi[2]; ++k) for (int j = u->lo[1]; j <= u->hi[1]; ++j) for (int i = u->lo[0]; i <= u->hi[0]; ++i) {
+                int q[3] = {i, j, k}, out = 0;
+                for (int e = 0; e < 3; ++e) {
+                    if (g->periodic[e]) continue;
+                    const int hi = g->n[e] - 1 + (e == d ? 1 : 0);
+                    if (q[e] < 0) { q[e] = 0; out = 1; } else if (q[e] > hi) { q[e] = hi; out = 1; }
+                }
+                if (out) A4(u, i, j, k, 0) = A4(u, q[0], q[1], q[2], 0);
+            }
+        }
 }
 
 /* NavierStokesBase::ComputeAofs, flux-register part (NavierStokesBase.cpp:5075-5096): CrseAdd into the register of the next finer
@@ -904,12 +920,35 @@ static void scalar_advection(orc_ns_state* s, double dt)
     orc_free(&Smf); orc_free(&tf); orc_free(&divu);
 }
 
+/* NavierStokesBase::ConservativeScalMinMax / ConvectiveScalMinMax (NavierStokesBase.cpp:4256-4368): the new value (per unit mass if
+ * conservative) clipped to the min / max of the FillPatch'ed old data over the 27 neighbours.  As written upstream the running maximum
+ * starts from std::numeric_limits<Real>::min() -- the smallest POSITIVE double, not the lowest. */
+static void scal_min_max(orc_ns_state* s, int comp, int conservative)
+{
+    const orc_geom* g = &s->g;
+    orc_fab* Sn = S_NEW(s);
+    orc_fab So = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);       /* FillPatchIterator(S_old, 1, prev_time, Density, num_scalars) */
+    const int oc = comp - Density;
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        if (s->cov.p && A4(&s->cov, i, j, k, 0) == 0.0) continue;
+        double smn = 1.7976931348623157e308, smx = 2.2250738585072014e-308;
+        for (int kk = -1; kk <= 1; ++kk) for (int jj = -1; jj <= 1; ++jj) for (int ii = -1; ii <= 1; ++ii) {
+            const double v = conservative ? A4(&So, i + ii, j + jj, k + kk, oc) / A4(&So, i + ii, j + jj, k + kk, 0) : A4(&So, i + ii, j + jj, k + kk, oc);
+            smn = fmin(smn, v); smx = fmax(smx, v);
+        }
+        if (conservative) { const double rn = A4(Sn, i, j, k, Density); A4(Sn, i, j, k, comp) = fmin(fmax(A4(Sn, i, j, k, comp) / rn, smn), smx) * rn; }
+        else A4(Sn, i, j, k, comp) = fmin(fmax(A4(Sn, i, j, k, comp), smn), smx);
+    }
+    orc_free(&So);
+}
+
 static void scalar_update_rho(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
     orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(Sn, i, j, k, Density) = A4(So, i, j, k, Density) - dt * A4(&s->aofs, i, j, k, Density);
+    if (s->p.do_denminmax) scal_min_max(s, Density, 1);                                 /* :2771-2788 */
     /* make_rho_curr_time + get_rho_half_time */
     orc_fab r = fillpatch(s, Sn, Density, 1, 1, &s->bc_scal[0]);
     orc_copy_all(&s->rho_ctime, &r);
@@ -929,6 +968,7 @@ static void scalar_update_tracers(orc_ns_state* s, double dt)
         else
         A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf / rho);
     }
+    if (s->p.do_scalminmax) scal_min_max(s, Tracer, s->p.do_cons_trac);                 /* :2907-2935 */
 }
 
 /* NavierStokes::scalar_diffusion_update -> Diffusion::diffuse_scalar for the tracer (rho_flag 0, Laplacian_S;

@@ -307,3 +307,47 @@ def test_euler_regtest_single_level_matches_oracle(orc, gpu):
     S2 = ns2.data(N.NavierStokes.S_NEW).gather_valid(n)
     assert np.allclose(dts2, dts, rtol=1e-10, atol=0) and np.abs(S2 - S1).max() < 1e-9
     assert np.abs(S1[..., 2]).max() > 0.04 and np.abs(S1[..., 0]).max() > 0.99
+
+
+def test_scal_min_max_matches_oracle_and_bounds_the_scalars(orc, gpu):
+    """ns.do_denminmax / ns.do_scalminmax (Source/NavierStokesBase.cpp:466-467): ConservativeScalMinMax / ConvectiveScalMinMax
+    (:4256-4368) after the advective update -- a sharp tracer / density front advected by the Taylor-Green flow: product vs oracle, and
+    the clipped fields stay inside the initial bounds where the unclipped run overshoots"""
+    from iamr_amd import ns as N
+    lib, L = gpu, orc.lib()
+    n = (16, 16, 16)
+    res = {}
+    for clip in (0, 1):
+        kw = dict(cfl=0.9, visc_coef=0.0, init_iter=1, do_denminmax=clip, do_scalminmax=clip)
+        g_o = orc.geom(n)
+        s = C.c_void_p(L.orc_ns_create(C.byref(g_o), C.byref(orc.ns_params(**kw)), C.byref(orc.mg_opts())))
+        So = orc.from_cfab(L.orc_ns_fab(s, 0))
+        X, Y, Z = np.meshgrid(*[(np.arange(n[d]) + 0.5) / n[d] for d in range(3)], indexing="ij")
+        S0 = orc.taylorgreen_state(X, Y, Z, c=1.0)
+        S0[..., 3] = np.where(np.abs(X - 0.5) < 0.2, 2.0, 1.0)            # density step
+        S0[..., 4] = np.where((np.abs(Y - 0.5) < 0.2) & (np.abs(Z - 0.5) < 0.25), 1.0, 0.0)   # tracer box
+        So.valid(n)[...] = S0
+        L.orc_ns_post_init(s, C.c_double(-1.0))
+        dts_o = [L.orc_ns_step(s) for _ in range(3)]
+        ref = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+        L.orc_ns_destroy(s)
+        g_d = lib.Geom.make(n)
+        lay = lib.Layout.decompose(n, 8)
+        ns = N.NavierStokes(g_d, lay, N.ns_params(**kw))
+        m = lib.MultiFab(lay, lib.CELL, 5, 1)
+        G = np.zeros(tuple(v + 2 for v in n) + (5,), order="F")
+        G[1:-1, 1:-1, 1:-1] = S0
+        m.set_from_global(G, (-1, -1, -1))
+        ns.set_data(ns.S_NEW, m)
+        ns.post_init(-1.0)
+        dts = [ns.step() for _ in range(3)]
+        got = ns.data(ns.S_NEW).gather_valid(n)
+        assert np.allclose(dts, dts_o, rtol=1e-9, atol=0)
+        for c in range(5):
+            assert np.abs(got[..., c] - ref[..., c]).max() <= 2e-8 * max(1.0, np.abs(ref[..., c]).max()), (clip, c)
+        res[clip] = got
+    # density: upstream calls ConservativeScalMinMax(S_new, Density, Density, ...) -- new rho / new rho = 1 clipped to the range of
+    # old rho / old rho = 1 and multiplied back: a no-op as written (NavierStokesBase.cpp:2771-2788), followed as written
+    assert np.array_equal(res[1][..., 3] == res[0][..., 3], np.ones(n, bool)) or np.abs(res[1][..., 3] - res[0][..., 3]).max() < 1e-6
+    assert res[1][..., 4].min() >= -1e-12 and res[1][..., 4].max() <= 1.0 + 1e-12
+    assert res[0][..., 4].max() > 1.0 + 1e-4 or res[0][..., 4].min() < -1e-4        # the unclipped run does overshoot

@@ -42,11 +42,11 @@ def test_reference_euler_restart_regtest(gpu, tmp_path, capsys):
 
 def test_single_level_viscous_restart(gpu, tmp_path, capsys):
     """one level, viscous (the Crank-Nicolson solves and the warm-started projections carry state from step to step): TaylorGreen inputs,
-    checkpoint at step 3 of 6"""
+    checkpoint at step 3 of 6 (stop_time raised so that the step count, not the time, ends the run)"""
     from iamr_amd import run as R
     inp = os.path.join(HERE, "golden", "inputs.3d.taylorgreen")
     plt, chk = str(tmp_path / "plt"), str(tmp_path / "chk")
-    args = [inp, "amr.n_cell=32 32 32", "max_step=6", "amr.plot_int=6", "amr.max_grid_size=16"]
+    args = [inp, "amr.n_cell=32 32 32", "max_step=6", "stop_time=100.0", "amr.plot_int=6", "amr.max_grid_size=16"]
     assert R.main(args + [f"amr.plot_file={plt}", f"amr.check_file={chk}", "amr.check_int=3"]) == 0
     capsys.readouterr()
     plt2 = str(tmp_path / "rst")

@@ -132,6 +132,26 @@ def test_double_shear_layer_as_z_uniform_slab(gpu, tmp_path, capsys):
     assert e4 <= e0 * (1 + 1e-12) and e4 >= 0.97 * e0, (e0, e4)
 
 
+def test_reference_bds_regtest_inputs(gpu, tmp_path, capsys):
+    """Exec/run3d/regtest.3d.traceradvect_bds (ns.advection_scheme = BDS; constant velocity + tracer blob, inflow / outflow in y, slip and
+    no-slip walls in z, gravity, one refined level following the tracer, regridded every second step), unmodified except for
+    ns.do_trac2 = 0 (the second tracer needs a sixth state component: DESIGN section 8): the run completes on two levels, the
+    refined level follows the blob, the fields stay finite and the tracer stays within its initial bounds (BDS's limited slopes)"""
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    root = str(tmp_path / "plt")
+    assert R.main([os.path.join(HERE, "golden", "regtest.3d.traceradvect_bds"), "ns.do_trac2=0", "max_step=4", "amr.plot_int=4", f"amr.plot_file={root}"]) == 0
+    out = capsys.readouterr().out
+    steps = [l for l in out.splitlines() if l.startswith("STEP =")]
+    assert len(steps) == 4 and all("LEVELS = 2" in l for l in steps)
+    pf = PlotFile.read(root + "00004")
+    assert len(pf.levels) == 2
+    for lv in pf.levels:
+        for a in lv.data:
+            assert np.isfinite(a).all() and a[..., 3].min() > 0.0
+            assert a[..., 4].min() > -1e-6 and a[..., 4].max() < 1.0 + 1e-6
+
+
 def test_reference_rayleightaylor_regtest_inputs(gpu, tmp_path, capsys):
     """BASELINE config C5: the reference's own regression inputs (Exec/run3d/regtest.3d.rayleightaylor, committed unmodified as a data
     fixture: Godunov_PPM, do_mom_diff, do_cons_trac, use_forces_in_trans, gravity, slip walls in z, max_level 2 driven by the vorticity
@@ -177,7 +197,7 @@ def test_reference_rayleightaylor_regtest_inputs(gpu, tmp_path, capsys):
 def test_reference_inputs_files_run_unmodified(gpu, tmp_path, capsys, name, levels):
     """the reference's own 3-D inputs files (committed unmodified as data fixtures) drive the library through `python -m iamr_amd.run`;
     only the grid size and the step count are overridden on the command line, as IAMR's ParmParse allows.  Not runnable: regtest.3d.poiseuille
-    (ns.do_trac2), regtest.3d.hotspot (do_temp), regtest.3d.euler-restart (checkpoints), regtest.3d.traceradvect_bds (BDS): DESIGN section 8."""
+    (ns.do_trac2), regtest.3d.hotspot (do_temp): DESIGN section 8; regtest.3d.euler-restart: tests/test_gpu_restart.py; regtest.3d.traceradvect_bds: below."""
     from iamr_amd import run as R
     from iamr_amd.plotfile import PlotFile
     root = str(tmp_path / "plt")

@@ -9,6 +9,7 @@ from iamr_amd import ns as N
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+single = os.environ.get('COUNT_SINGLE_OWNER') == '1'      # same boxes, all owned by rank 0 (run with one process)
 lib.init(0)
 cnt = {"ex": 0, "ar": 0, "bytes": 0}
 import collections
@@ -23,18 +24,26 @@ def ar(t, *a, **k):
 dist.irecv, dist.all_reduce = irecv, ar
 comm.init_gloo_callback(dist)
 boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(world)]
-lay = lib.Layout(boxes, list(range(world)))
-g = lib.Geom.make((n, n, n * world), prob_hi=(1.0, 1.0, float(world)))
+nb = int(os.environ.get('COUNT_BOXES', str(world)))
+boxes = [((0, 0, r * n), (n - 1, n - 1, (r + 1) * n - 1)) for r in range(nb)]
+lay = lib.Layout(boxes, [r % world for r in range(nb)])
+g = lib.Geom.make((n, n, n * nb), prob_hi=(1.0, 1.0, float(nb)))
 ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
 ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
 ns.post_init(-1.0)
 ns.step()
 for k in cnt: cnt[k] = 0
 hist.clear()
+import ctypes as C
+def nsync():
+    v = C.c_size_t(); lib.check(lib.lib().iamrx_sync_count(C.byref(v))); return v.value
+s0 = nsync()
 ns.step()
+syncs = nsync() - s0
 sm, sn, sv = ns.stats()
 if rank == 0:
     print(f"n={n} world={world}: per step and rank: {cnt['ex']} peer messages received ({cnt['bytes']/1e6:.1f} MB), {cnt['ar']} all-reduces; "
+          f"{syncs} host synchronisations (the host-staged test transport adds two per all-reduce; RCCL reduces in place on the stream); "
           f"MG iterations mac {sm.iters} nodal {sn.iters} visc {sv.iters}")
 if rank == 0: print("sizes (doubles: count):", sorted(hist.items()))
 dist.barrier(); dist.destroy_process_group()
