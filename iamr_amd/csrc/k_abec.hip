@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(BOT_NT) k_abec_bottom(BoxD b, const FabD* __re
 // are faces of a periodic direction the box does not span) carry homogeneous coarse/fine Dirichlet data with the level's CfTab weights
 bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* bcs, int nbc, int ncomp, bool cf)
 {
-    static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
+    const bool enabled = tune("MG_DEVICE_BOTTOM", 1) != 0;
     // the answer must be the same on every rank (it decides the depth of the hierarchy): global information only.  A rank that does not
     // own the box has nothing to do in the bottom solve (no collectives in it)
     if (!enabled || ncomp != 1 || nbc != 1 || l.boxes.size() != 1) return false;

@@ -916,15 +916,13 @@ static const GodParams* upload_params(const GodParams& P)
 // those tiles are far apart in launch order, so the re-reads miss L2: march more planes per thread there.
 static int tz_for(bool z_stencil)
 {
-    static int tzz = -1;
-    if (tzz < 0) { const char* e = getenv("IAMRX_GODUNOV_TZ"); tzz = e ? atoi(e) : 4; }
+    const int tzz = (int)tune("GODUNOV_TZ", 4);
     return z_stencil ? tzz : 4;
 }
 
 static bool comp_split()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_COMP_SPLIT"); v = e ? atoi(e) : 0; }
+    const int v = (int)tune("GODUNOV_COMP_SPLIT", 0);
     return v != 0;
 }
 
@@ -946,8 +944,7 @@ static void launch_trace(const Layout& l, const MultiFab& q, const MultiFab* for
 
 static bool use_fused_final()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_FUSED"); v = (e && e[0] == '1') ? 1 : 0; }
+    const int v = tune("GODUNOV_FUSED", 0) == 1 ? 1 : 0;
     return v == 1;
 }
 
@@ -984,8 +981,7 @@ static void launch_final_split(const Layout& l, const MultiFab& q, int ncomp, co
 
 static bool use_dir_fused()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_DIR"); v = e ? atoi(e) : 1; }
+    const int v = (int)tune("GODUNOV_DIR", 1);
     return v != 0;
 }
 
@@ -1000,13 +996,13 @@ static void launch_dir_t(const Layout& l, const MultiFab& q, int ncomp, const Mu
     int nf[3];
     for (int e = 0; e < 3; ++e) nf[e] = l.max_len[e] + (e == D ? 1 : 0);
     const int ntx = (nf[0] + TX - 1) / TX, nty = (nf[1] + TY - 1) / TY;
-    static const int kc_env = [] { const char* e = getenv("IAMRX_GODUNOV_KC"); return e ? atoi(e) : 0; }();
+    const int kc_env = (int)tune("GODUNOV_KC", 0);
     const int kc = kc_env > 0 ? kc_env : std::min(32, std::max(8, nf[2] / 8));       // planes marched per workgroup
     const int nkc = (nf[2] + kc - 1) / kc;
     const int total = ntx * nty * nkc;
     const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
     dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal(), (unsigned)(PRED ? 1 : ncomp));
-    static const bool sla = !(getenv("IAMRX_GODUNOV_DIR_SLOPES") && atoi(getenv("IAMRX_GODUNOV_DIR_SLOPES")) == 0);
+    const bool sla = tune("GODUNOV_DIR_SLOPES", 1) != 0;
 #define IAMRX_KDIR(SLA) hipLaunchKernelGGL((k_dir<PRED, D, TX, TY, SLA>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, q.d_tab, \
                        force ? force->d_tab : nullptr, divu ? divu->d_tab : nullptr, mac[D]->d_tab, mac[TA]->d_tab, mac[TB]->d_tab, \
                        e0[TA].d_tab, e0[TB].d_tab, sl[D].d_tab, sl[TA].d_tab, sl[TB].d_tab, out.d_tab, dP, ntx, nty, nkc, kc, xcd_cnt)
@@ -1019,8 +1015,8 @@ static void launch_dir(const Layout& l, const MultiFab& q, int ncomp, const Mult
                        MultiFab* const mac[3], const MultiFab e0[3], const MultiFab sl[3], MultiFab& out, const GodParams* dP)
 {
     // 16 x 8 tiles (8 wavefronts, 2 workgroups per CU) measured 6% faster than 32 x 8 (14 wavefronts, 1 per CU) at 256^3
-    static const int tx = [] { const char* e = getenv("IAMRX_GODUNOV_DIR_TX"); return e ? atoi(e) : 16; }();
-    static const int ty = [] { const char* e = getenv("IAMRX_GODUNOV_DIR_TY"); return e ? atoi(e) : 8; }();
+    const int tx = (int)tune("GODUNOV_DIR_TX", 16);
+    const int ty = (int)tune("GODUNOV_DIR_TY", 8);
     if (tx == 16 && ty == 4) launch_dir_t<PRED, D, 16, 4>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
     else if (tx == 32 && ty == 4) launch_dir_t<PRED, D, 32, 4>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
     else if (tx == 16) launch_dir_t<PRED, D, 16, 8>(l, q, ncomp, force, divu, mac, e0, sl, out, dP);
@@ -1700,8 +1696,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
 // IAMRX_GODUNOV_Z=0 selects the multi-pass kernels (read at every call: tests/test_gpu_godunov_fused.py compares the two paths)
 static bool use_z_kernel()
 {
-    const char* e = getenv("IAMRX_GODUNOV_Z");
-    return e ? atoi(e) != 0 : true;
+    return tune("GODUNOV_Z", 1) != 0;
 }
 
 template <int TX, int TY, int WPE, bool BCS, bool PPM>
@@ -1710,7 +1705,7 @@ static void launch_god_z(const Layout& l, MultiFab& aofs, int acomp, const Multi
 {
     constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
     const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
-    static const int kc_env = [] { const char* e = getenv("IAMRX_GODUNOV_ZKC"); return e ? atoi(e) : 0; }();
+    const int kc_env = (int)tune("GODUNOV_ZKC", 0);
     const int kc = kc_env > 0 ? kc_env : std::min(64, std::max(8, l.max_len[2] / 4));       // planes marched per workgroup
     const int nkc = (l.max_len[2] + kc - 1) / kc;
     const int total = ntx * nty * nkc;
@@ -1990,7 +1985,7 @@ static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* 
 {
     constexpr int NT = (((TX + 2) * (TY + 2)) + 63) / 64 * 64;
     const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
-    static const int kc_env = [] { const char* e = getenv("IAMRX_GODUNOV_ZKC"); return e ? atoi(e) : 0; }();
+    const int kc_env = (int)tune("GODUNOV_ZKC", 0);
     const int kc = kc_env > 0 ? kc_env : std::min(64, std::max(8, l.max_len[2] / 4));
     const int nkc = (l.max_len[2] + kc - 1) / kc;
     const int total = ntx * nty * nkc;
@@ -2240,8 +2235,7 @@ static void bds_edge_states(const Geometry& g, const MultiFab& S, int ncomp, con
 
 static bool use_tile_kernel()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_GODUNOV_TILE"); v = e ? atoi(e) : 0; }
+    const int v = (int)tune("GODUNOV_TILE", 0);
     return v != 0;
 }
 
@@ -2286,8 +2280,8 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     }
     const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
     if (zk) {
-        static const int ztx = [] { const char* e = getenv("IAMRX_GODUNOV_ZTX"); return e ? atoi(e) : 16; }();
-        static const int zty = [] { const char* e = getenv("IAMRX_GODUNOV_ZTY"); return e ? atoi(e) : 8; }();
+        const int ztx = (int)tune("GODUNOV_ZTX", 16);
+        const int zty = (int)tune("GODUNOV_ZTY", 8);
         const bool bcs = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
 #define IAMRX_GZP(TX, TY, W, PPM) (bcs ? launch_god_z<TX, TY, W, true, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP) \
                                        : launch_god_z<TX, TY, W, false, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP))

@@ -141,7 +141,7 @@ void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const M
     const FabD *ot = out.d_tab, *xt = x.d_tab, *st = sig.d_tab;
     const FabD* rt = rhs ? rhs->d_tab : nullptr;
     const Layout& l = *x.layout;
-    static const bool zmarch = !(getenv("IAMRX_NODAL_RES_ZM") && atoi(getenv("IAMRX_NODAL_RES_ZM")) == 0);
+    const bool zmarch = tune("NODAL_RES_ZM", 1) != 0;
     if (zmarch && l.max_len[0] >= 16 && l.max_len[1] >= 8 && x.ngrow >= 1 && sig.ngrow >= 1) {
         constexpr int TX = 32, TY = 8;
         const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY;
@@ -481,15 +481,15 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
     // planes per workgroup (z-march): as long as the launch still fills the chip about twice over (256 CUs x 4-6 resident workgroups)
-    static const int ppc_env = getenv("IAMRX_GS4_PPC") ? atoi(getenv("IAMRX_GS4_PPC")) : 0;
-    static const long wg_target = getenv("IAMRX_GS4_WGS") ? atol(getenv("IAMRX_GS4_WGS")) : 2048;
+    const int ppc_env = (int)tune("GS4_PPC", 0);
+    const long wg_target = (long)tune("GS4_WGS", 2048);
     int ppc = ppc_env > 0 ? ppc_env : (int)std::max<long>(1, std::min<long>(16, (long)nt * l.nlocal() * npl_all / wg_target));
     const int npl = (npl_all + ppc - 1) / ppc;             // chunks per tile
     for (int f = 0; f < l.nlocal(); ++f) {                  // the kernel indexes with 32-bit offsets
         const BoxD& b = l.boxes[l.local[f]];
         IAMRX_ASSERT((long)(b.len(0) + 1 + 2 * xc.ngrow) * (b.len(1) + 1 + 2 * xc.ngrow) * (b.len(2) + 1 + 2 * xc.ngrow) < 2147483647L);
     }
-    static const bool xcd_aware = !(getenv("IAMRX_XCD_AWARE") && atoi(getenv("IAMRX_XCD_AWARE")) == 0);
+    const bool xcd_aware = tune("XCD_AWARE", 1) != 0;
     int xcd_chunk = 0;
     unsigned gx = (unsigned)(nt * npl);
     if (xcd_aware && nt >= 16) {
@@ -515,7 +515,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
 // the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
 bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
 {
-    static const bool on = !(getenv("IAMRX_PERIODIC_WRAP") && atoi(getenv("IAMRX_PERIODIC_WRAP")) == 0);
+    const bool on = tune("PERIODIC_WRAP", 1) != 0;
     if (!on || l.boxes.size() != 1 || l.nlocal() != 1) return false;
     for (int d = 0; d < 3; ++d)
         if (!g.periodic[d] || l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < min_len) return false;
@@ -532,7 +532,7 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // tile shape: 32x16 nodes / 256 threads (40x24 footprint, 40 KB of LDS: 4 workgroups = 16 waves per CU).  Measured at 256^3
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
-    static const int big = (getenv("IAMRX_GS4_TILE") ? atoi(getenv("IAMRX_GS4_TILE")) : 0);
+    const int big = (int)tune("GS4_TILE", 0);
     if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
     else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
 }
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(NBOT_NT) k_nodal_bottom(const FabD* __restrict
 
 bool nodal_bottom_device_ok(const Geometry& g, const Layout& l)
 {
-    static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0);
+    const bool enabled = tune("MG_DEVICE_BOTTOM", 1) != 0;
     if (!enabled || l.boxes.size() != 1) return false;      // global information only: every rank must build the same hierarchy
     const BoxD& b = l.boxes[0];
     long cells = 1;
@@ -933,8 +933,7 @@ static bool nbg_geom(const Geometry& g, const Layout& l, NBotGeom& G)
 
 bool nodal_bottom_device_ok_general(const Geometry& g, const Layout& l)
 {
-    static const bool enabled = !(getenv("IAMRX_MG_DEVICE_BOTTOM") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM")) == 0) &&
-                                !(getenv("IAMRX_MG_DEVICE_BOTTOM_GENERAL") && atoi(getenv("IAMRX_MG_DEVICE_BOTTOM_GENERAL")) == 0);
+    const bool enabled = tune("MG_DEVICE_BOTTOM", 1) != 0 && tune("MG_DEVICE_BOTTOM_GENERAL", 1) != 0;
     NBotGeom G;
     return enabled && nbg_geom(g, l, G);
 }
@@ -1148,7 +1147,7 @@ __global__ void __launch_bounds__(256) k_nodal_interp_lds(const BoxD* __restrict
 
 static bool nodal_interp_lds_enabled()
 {
-    static const bool on = [] { const char* e = getenv("IAMRX_NODAL_INTERP_LDS"); return !(e && atoi(e) == 0); }();
+    const bool on = tune("NODAL_INTERP_LDS", 1) != 0;
     return on;
 }
 

@@ -192,7 +192,7 @@ void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out,
     if (out.nlocal() == 0) return;
     IAMRX_ASSERT(vel.ncomp == 3 && c.b[0]->ncomp == (c.tensor_eta ? 1 : 3));
     const Layout& l = *out.layout;
-    static const bool zm = !(getenv("IAMRX_TENSOR_CROSS_ZM") && atoi(getenv("IAMRX_TENSOR_CROSS_ZM")) == 0);
+    const bool zm = tune("TENSOR_CROSS_ZM", 1) != 0;
     if (zm && l.max_len[0] >= 32 && l.max_len[1] >= 8 && vel.ngrow >= 1) {
         constexpr int TX = 32, TY = 8;
         const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;

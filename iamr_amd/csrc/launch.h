@@ -36,7 +36,7 @@ inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
     // small levels: a workgroup that marches tz planes pays their memory latencies one after the other while most of the chip idles
     // (an 8^3 multigrid level was ONE workgroup with 32 active threads, 10 us per colour pass); give the planes to more workgroups
     // until the launch holds ~512 of them
-    static const int tz_adapt = [] { const char* e = getenv("IAMRX_TZ_ADAPT"); return e ? atoi(e) : 1; }();
+    const int tz_adapt = (int)tune("TZ_ADAPT", 1);
     while (tz_adapt && tz > 1 && (long)t.ntx * t.nty * (nfab > 0 ? nfab : 1) * ((maxlen[2] + tz - 1) / tz) < 512) tz /= 2;
     t.tz = tz;
     t.ntz = (maxlen[2] + tz - 1) / tz;
@@ -45,7 +45,7 @@ inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
     // run on other XCDs, so the stencil halo rows shared by neighbouring tiles are fetched from HBM once per XCD.  XCD-aware
     // order: XCD q works through the contiguous tile range [q*cnt, (q+1)*cnt) (a z-slab of the box), neighbouring tiles then
     // meet in the same L2.  Speed only -- every tile is still processed exactly once.
-    static const int xcd_on = [] { const char* e = getenv("IAMRX_XCD_TILES"); return e ? atoi(e) : 1; }();
+    const int xcd_on = (int)tune("XCD_TILES", 1);
     const int total = t.ntx * t.nty * t.ntz;
     t.xcd_cnt = (xcd_on && total >= 64) ? (total + 7) / 8 : 0;
     return t;

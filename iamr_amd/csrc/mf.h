@@ -66,6 +66,14 @@ struct Context {
     size_t ring_off = 0;
 };
 
+// ------------------------------------------------------------------ tuning registry
+// Every run-time switch of the library is a key of ONE registry: filled once, at iamrx_init, from the environment
+// variables IAMRX_<KEY> that are set, changed afterwards only through iamrx_tuning_set, and read by the code at the point of use
+// (tune(key, default)) -- no function-local static caches a choice for the life of the process.
+double tune(const char* key, double dflt);
+void tuning_set(const char* key, double value);
+void tuning_load_environment();          // called by Context::init
+
 // ------------------------------------------------------------------ scoped profiler (measurement aid)
 // ProfScope p("name") accumulates the wall time of the scope (stream drained at both ends) under its name while profiling is enabled
 // (iamrx_scope_profile); nested scopes are reported with their path "outer/inner".  Off: two predictable branches, no synchronisation.

@@ -22,6 +22,7 @@ Context& Context::get()
 
 void Context::init(int dev)
 {
+    tuning_load_environment();
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -46,7 +47,7 @@ void Context::ensure_scratch(size_t n)
 // kernel reading memory nobody has written shows up deterministically instead of depending on what the recycled block held before
 static bool poison_allocs()
 {
-    static const bool on = getenv("IAMRX_POISON_ALLOC") && atoi(getenv("IAMRX_POISON_ALLOC")) != 0;
+    const bool on = tune("POISON_ALLOC", 0) != 0;
     return on;
 }
 
@@ -97,6 +98,32 @@ void Context::release_cache()
     free_blocks.clear();
     bytes_cached = 0;
 }
+
+// ---- tuning registry
+namespace {
+std::map<std::string, double>& tuning_map() { static auto* m = new std::map<std::string, double>(); return *m; }
+}  // namespace
+extern "C" char** environ;
+void tuning_load_environment()
+{
+    auto& m = tuning_map();
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "IAMRX_", 6) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        if (!eq) continue;
+        const std::string key(*e + 6, eq - (*e + 6));
+        char* end = nullptr;
+        const double v = strtod(eq + 1, &end);
+        if (end != eq + 1 && !m.count(key)) m[key] = v;           // values set through iamrx_tuning_set before init win
+    }
+}
+double tune(const char* key, double dflt)
+{
+    auto& m = tuning_map();
+    auto it = m.find(key);
+    return it == m.end() ? dflt : it->second;
+}
+void tuning_set(const char* key, double value) { tuning_map()[key] = value; }
 
 // ---- scoped profiler
 bool ProfScope::enabled = false;

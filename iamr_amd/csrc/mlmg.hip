@@ -17,7 +17,7 @@ CycleTimer& cycle_timer() { static CycleTimer t; return t; }
 long mg_agglomeration_cells()
 {
     static long v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_MG_AGGLOMERATE_CELLS"); v = e ? atol(e) : 2097152L; }
+    v = (long)tune("MG_AGGLOMERATE_CELLS", 2097152.0);
     return v;
 }
 
@@ -59,7 +59,7 @@ void CellMG::prepare()
     // q / (alpha min(a) + q), q = beta max(b) sum_d 2 / h_d^2; red-black Gauss-Seidel contracts by about its square per sweep.
     // Same converged answer (tests/test_gpu_sensitivity.py covers the solver choices); IAMRX_MG_DIAG_SHORTCUT=0 disables.
     m_dd_sweeps = 0;
-    static const bool dd_on = !(getenv("IAMRX_MG_DIAG_SHORTCUT") && atoi(getenv("IAMRX_MG_DIAG_SHORTCUT")) == 0);
+    const bool dd_on = tune("MG_DIAG_SHORTCUT", 1) != 0;
     if (dd_on && m_alpha > 0.0 && m_beta > 0.0 && m_a0 && m_o.fixed_iters <= 0 && m_o.max_coarsening_level > 0) {
         double bmax = 0.0;
         for (int d = 0; d < 3; ++d) bmax = std::max(bmax, m_b0[d]->norm0(0, m_b0[d]->ncomp, 0));
@@ -80,7 +80,7 @@ void CellMG::prepare()
         if (jac < 0.2) m_dd_sweeps = jac < 0.05 ? 2 : (jac < 0.12 ? 3 : 4);
         // red-black Gauss-Seidel contracts by about the square of the Jacobi factor per sweep: solve() sizes every cycle with it
         m_dd_rho = m_dd_sweeps > 0 ? std::max(jac * jac, 1.e-6) : 0.0;
-        static const int dd_force = [] { const char* e = getenv("IAMRX_MG_DD_SWEEPS"); return e ? atoi(e) : 0; }();
+        const int dd_force = (int)tune("MG_DD_SWEEPS", 0);
         if (m_dd_sweeps > 0 && dd_force > 0) { m_dd_sweeps = dd_force; m_dd_rho = 0.0; }
         if (m_o.verbose) printf("iamrx MLMG: Jacobi bound %.3e -> %d sweeps per cycle\n", jac, m_dd_sweeps);
     }
@@ -177,16 +177,14 @@ void CellMG::cf_bcval(MultiFab& bcval)
 
 static double dd_omega()
 {
-    static const double v = [] { const char* e = getenv("IAMRX_MG_DD_OMEGA"); return e ? atof(e) : 1.0; }();
-    return v;
+    return tune("MG_DD_OMEGA", 1.0);
 }
 
 // one-component coarse/fine levels: the colour passes keep the coarse/fine ghost cells current themselves (cf_maintain, k_abec.hip), so only
 // the first pass of a smoothing call needs the k_cf_fill launch; IAMRX_CF_MAINTAIN=0: a fill in front of every pass
 static bool cf_maintain_on()
 {
-    static const bool v = !(getenv("IAMRX_CF_MAINTAIN") && atoi(getenv("IAMRX_CF_MAINTAIN")) == 0);
-    return v;
+    return tune("CF_MAINTAIN", 1) != 0;
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current)
@@ -218,7 +216,7 @@ bool CellMG::fused_smoother_ok(int l) const
 {
     // opt-in: on MI355X the single-pass kernel (62 B/cell of HBM traffic instead of 130) is still slower than the two colour
     // passes (233 VGPRs -> 2 waves/SIMD with three barriers per plane: 0.41 ms vs 2 x 0.18 ms at 256^3)
-    static const bool on = getenv("IAMRX_GSRB_FUSED") && atoi(getenv("IAMRX_GSRB_FUSED")) != 0;
+    const bool on = tune("GSRB_FUSED", 0) != 0;
     if (!on || m_cf) return false;
     const Level& L = m_lev[l];
     for (int d = 0; d < 3; ++d) {

@@ -357,7 +357,7 @@ static void floor_small(MultiFab& mf)
 
 void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
 {
-    static const bool cache_on = !(getenv("IAMRX_VISC_CACHE") && atoi(getenv("IAMRX_VISC_CACHE")) == 0);
+    const bool cache_on = tune("VISC_CACHE", 1) != 0;
     const bool old_state = cache_on && m_in_advance && &Sdata == &S[1 - inew] && visc.ngrow <= 1;
     if (old_state && m_visc_old_valid) { MultiFab::Copy(visc, m_visc_old, 0, 0, 3, visc.ngrow); return; }
     visc.setVal(1.e40);                                       // NavierStokes.cpp:1982
@@ -528,8 +528,8 @@ void NavierStokes::mac_project(double dt_)
     // mac_phi_crse[level]: kept as the coarse/fine data of the next finer level.  Upstream zeroes it before the solve (MacProj.cpp:255);
     // the converged answer does not depend on the initial guess, the number of V-cycles does: the MAC potential is pressure-like and
     // changes little from step to step, so the previous one is the initial guess here (IAMRX_WARM_START=0: upstream's zero)
-    static const bool warm = !(getenv("IAMRX_WARM_START") && atoi(getenv("IAMRX_WARM_START")) == 0);
-    static const bool extrap = !(getenv("IAMRX_WARM_EXTRAP") && atoi(getenv("IAMRX_WARM_EXTRAP")) == 0);
+    const bool warm = tune("WARM_START", 1) != 0;
+    const bool extrap = tune("WARM_EXTRAP", 1) != 0;
     mac_phi.setVal(0.0);                        // the ghost cells carry the (homogeneous) boundary data of the solve: always zero
     if (warm && m_have_mac_prev) {
         // linear extrapolation in time from the last two potentials once both exist (regular steps only)
@@ -965,8 +965,8 @@ void NavierStokes::level_project(double dt_)
     // Projection.cpp:236-256 zeroes P_new (level 0: valid nodes; level > 0: the interior of every box) before the solve, which uses it as
     // initial guess and for the Dirichlet data.  Initial guess here: the previous pressure (same converged answer, fewer V-cycles;
     // IAMRX_WARM_START=0: upstream's zero)
-    static const bool warm = !(getenv("IAMRX_WARM_START") && atoi(getenv("IAMRX_WARM_START")) == 0);
-    static const bool extrap = !(getenv("IAMRX_WARM_EXTRAP") && atoi(getenv("IAMRX_WARM_EXTRAP")) == 0);
+    const bool warm = tune("WARM_START", 1) != 0;
+    const bool extrap = tune("WARM_EXTRAP", 1) != 0;
     if (level == 0) {
         // P_new still holds the pressure of two steps ago (the arrays alternate): extrapolate linearly in time on regular steps
         const double dto = pt_old[1] - pt_old[0];
@@ -1096,7 +1096,7 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
     m_in_advance = true; m_visc_old_valid = false;
     const double dt_test = predict_velocity(dt_);
     mac_project(dt_);
-    static const bool fused_adv = !(getenv("IAMRX_FUSED_ADVECTION") && atoi(getenv("IAMRX_FUSED_ADVECTION")) == 0);
+    const bool fused_adv = tune("FUSED_ADVECTION", 1) != 0;
     if (fused_adv) advection_all(dt_);
     else { velocity_advection(dt_); scalar_advection(dt_); }
     scalar_update_rho(dt_);

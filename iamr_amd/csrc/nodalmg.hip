@@ -19,13 +19,13 @@ static bool nodal_fused()
     static int v = -1;
     // plane-fused sweep (2 launches + 2 fills instead of 8 + 8): measured per sweep on MI355X 0.69 vs 0.79 ms at 256^3,
     // 0.11 vs 0.20 ms at 128^3, 0.03 vs 0.09 ms at <= 64^3.  IAMRX_NODAL_FUSED=0 selects the 8 colour passes.
-    if (v < 0) { const char* e = getenv("IAMRX_NODAL_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
+    v = tune("NODAL_FUSED", 1) != 0 ? 1 : 0;
     return v == 1;
 }
 static bool nodal_small()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("IAMRX_NODAL_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    v = tune("NODAL_SMALL", 1) != 0 ? 1 : 0;
     return v == 1;
 }
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
@@ -137,7 +137,7 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
     // Constant sigma (constant-density flow, the common IAMR case): every coarsened level then holds the same constant (the average
     // of 8 equal numbers is exact) and periodic / mirrored ghost cells too, so the smoother can take sigma from a register instead
     // of staging two sigma planes per node plane.  Same expression tree => bit-identical results.  IAMRX_NODAL_CSIG=0 disables.
-    static const bool csig_on = !(getenv("IAMRX_NODAL_CSIG") && atoi(getenv("IAMRX_NODAL_CSIG")) == 0);
+    const bool csig_on = tune("NODAL_CSIG", 1) != 0;
     m_csig = false;
     if (csig_on && !m_masked) {
         const double smax = m_lev[0].sig.norm0(0, 1, 0);
@@ -183,7 +183,7 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         // After the first (full) fill it is therefore enough to refresh the ghost nodes of the planes of ONE parity in front of each
         // pass: the odd planes before the even pass, the even planes before the odd pass (half the halo volume; on boxes stacked in
         // z, where one ghost plane is exchanged, every second message disappears).
-        static const bool par_fill = !(getenv("IAMRX_NODAL_PARITY_FILL") && atoi(getenv("IAMRX_NODAL_PARITY_FILL")) == 0);
+        const bool par_fill = tune("NODAL_PARITY_FILL", 1) != 0;
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
             if (!wrap) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
             const double* cs = m_csig ? &m_csig_val : nullptr;

@@ -54,7 +54,7 @@ MGStats level_project_single(const Geometry& g, double dt, MultiFab& U_new, int 
 static void setup_tensor(CellMG& mg, MultiFab tb[3], const MultiFab* bp[3], LayoutP layout, double a_scalar, double b_scalar,
                          const MultiFab* acoef, const MultiFab* const eta[3])
 {
-    static const bool eta_form = !(getenv("IAMRX_TENSOR_ETA") && atoi(getenv("IAMRX_TENSOR_ETA")) == 0);
+    const bool eta_form = tune("TENSOR_ETA", 1) != 0;
     for (int d = 0; d < 3; ++d) {
         if (eta_form) { bp[d] = eta[d]; continue; }
         tb[d].define(layout, face_type(d), 3, 0);

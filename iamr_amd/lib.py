@@ -80,6 +80,17 @@ def init(device=0):
     _initialized = True
 
 
+def tuning_set(key, value):
+    """run-time switch of the library (include/iamrx.h: iamrx_tuning_set); key without the IAMRX_ prefix"""
+    check(lib().iamrx_tuning_set(key.encode(), C.c_double(float(value))))
+
+
+def tuning_get(key, default):
+    v = C.c_double()
+    check(lib().iamrx_tuning_get(key.encode(), C.c_double(float(default)), C.byref(v)))
+    return v.value
+
+
 def sync():
     check(lib().iamrx_sync())
 

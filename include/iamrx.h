@@ -76,6 +76,13 @@ int iamrx_sync(void);                            /* amrex::Gpu::synchronize */
 void* iamrx_stream(void);                        /* the hipStream_t every kernel is launched on */
 int iamrx_mem_info(size_t* bytes_live, size_t* bytes_cached);
 int iamrx_alloc_count(size_t* n_device_malloc);  /* hipMalloc calls so far (caching-allocator misses; The_Arena role) */
+/* Run-time switches (kernel variants kept for A/B measurement and as references of the parity tests, solver
+ * shortcuts, tile shapes) live in ONE registry.  It is filled once, at iamrx_init, from the environment variables IAMRX_<KEY> that are
+ * set (e.g. IAMRX_GODUNOV_Z=0 -> key "GODUNOV_Z"), can be changed afterwards only through iamrx_tuning_set, and is consulted at the
+ * point of use -- a change takes effect at the next call; nothing is cached for the life of the process.  Per-solve choices that belong
+ * to a call are arguments (iamrx_mg_opts, the Godunov `scheme`), not keys. */
+int iamrx_tuning_set(const char* key, double value);
+int iamrx_tuning_get(const char* key, double default_value, double* value);
 /* scoped wall-time profile of the library's host-side sections (measurement aid; synchronises the stream at every scope boundary while
  * enabled).  Writes the accumulated report (one line per scope path: name, ms, calls) into report[capacity] first (may be NULL), then
  * enable: 1 on, 0 off, -1 unchanged; reset != 0 clears the accumulated times. */

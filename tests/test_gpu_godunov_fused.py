@@ -1,6 +1,6 @@
 """GPU: the fused z-marching Godunov kernels (k_god_z / k_pred_z, iamr_amd/csrc/k_godunov.hip -- the default path of both Godunov_PLM and
 Godunov_PPM) against the
-multi-pass kernels (k_trace / k_dir / k_aofs, IAMRX_GODUNOV_Z=0) through the C-ABI on the same device data: edge states, fluxes, aofs
+multi-pass kernels (k_trace / k_dir / k_aofs, tuning key GODUNOV_Z = 0) through the C-ABI on the same device data: edge states, fluxes, aofs
 and predicted face velocities agree to 1e-13 (FMA contraction may differ between the two instruction streams; both are compared with
 the oracle in tests/test_gpu_godunov.py and tests/test_gpu_walls.py).  Sizes are chosen so that a box holds partial tiles (16 x 8),
 several z-chunks and, in the wall cases, every BC branch; the periodic cases run the BC-free specialisation."""
@@ -36,14 +36,13 @@ class path:
         self.z = z
 
     def __enter__(self):
-        self.old = os.environ.get("IAMRX_GODUNOV_Z")
-        os.environ["IAMRX_GODUNOV_Z"] = str(self.z)
+        from iamr_amd import lib
+        self.old = lib.tuning_get("GODUNOV_Z", 1)
+        lib.tuning_set("GODUNOV_Z", self.z)
 
     def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["IAMRX_GODUNOV_Z"]
-        else:
-            os.environ["IAMRX_GODUNOV_Z"] = self.old
+        from iamr_amd import lib
+        lib.tuning_set("GODUNOV_Z", self.old)
 
 
 def close(a, b, tag):
