@@ -29,7 +29,7 @@ import numpy as np
 from .plotfile import REAL_DESC, _fmt17
 
 STATE_TYPES = [  # (name, selector new, selector old, index type, ncomp)
-    ("State_Type", 0, 1, (0, 0, 0), 5),
+    ("State_Type", 0, 1, (0, 0, 0), 5),      # 5 + do_trac2 + do_temp components (the level's nstate)
     ("Press_Type", 2, 3, (1, 1, 1), 1),
     ("Gradp_Type", 4, 5, (0, 0, 0), 3),
 ]
@@ -234,7 +234,7 @@ def restart(path, geom0, params, opts=None, single_level=False):
         for t, (name, snew, sold, typ, nc) in enumerate(STATE_TYPES):
             for tag, sel in (("New", snew), ("Old", sold)):
                 arrays = _read_vismf(ld, f"SD_{t}_{tag}_MF")
-                mf = Lb.MultiFab(lays[l], typ, nc, 1)
+                mf = Lb.MultiFab(lays[l], typ, lev.nstate if t == 0 else nc, 1)
                 for li, a in enumerate(arrays):
                     mf.from_numpy(a, li)
                 lev.set_data(sel, mf)

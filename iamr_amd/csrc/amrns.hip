@@ -670,12 +670,12 @@ void AmrNS::link_level(int l)
     s.crse = &c; c.fine = &s;
     s.rho_avg.define(s.layout, cell_type(), 1, 1); s.rho_avg.setVal(0.0);
     s.p_avg.define(s.layout, node_type(), 1, 0); s.p_avg.setVal(0.0);
-    s.reg_adv = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
-    s.reg_visc = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, NUM_STATE);
+    s.reg_adv = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, s.nstate);
+    s.reg_visc = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, s.nstate);
     s.reg_mac = std::make_unique<FluxRegister>(s.layout, c.layout, c.g, ratio, 1);
     s.sync_reg = std::make_unique<SyncRegister>(s.layout, c.layout, c.g, s.g, ratio, p.phys_lo, p.phys_hi);
     c.Vsync.define(c.layout, cell_type(), 3, 1); c.Vsync.setVal(0.0);
-    c.Ssync.define(c.layout, cell_type(), NUM_STATE - 3, 1); c.Ssync.setVal(0.0);
+    c.Ssync.define(c.layout, cell_type(), c.nstate - 3, 1); c.Ssync.setVal(0.0);
 }
 
 namespace {
@@ -691,7 +691,7 @@ struct AmrTimer {
 void AmrNS::avg_down(int l)
 {
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
-    average_down(f.S[f.inew], c.S[c.inew], 0, NUM_STATE, f.ratio);
+    average_down(f.S[f.inew], c.S[c.inew], 0, c.nstate, f.ratio);
     for (size_t q = l; q < lev.size(); ++q) lev[q]->make_rho_curr_time();
     average_down(c.initial_step ? f.P[f.pnew] : f.p_avg, c.P[c.pnew], 0, 1, f.ratio);
     average_down(f.Gp[f.pnew], c.Gp[c.pnew], 0, 3, f.ratio);
@@ -707,24 +707,27 @@ void AmrNS::reflux(int l)
     auto& ctx = Context::get();
     const double vol = c.g.dx[0] * c.g.dx[1] * c.g.dx[2], dt_crse = dt_level[l];
     f.reg_visc->Reflux(c.Vsync, vol, 1.0, 0, 0, 3);
-    f.reg_visc->Reflux(c.Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    f.reg_visc->Reflux(c.Ssync, vol, 1.0, 3, 0, c.nstate - 3);
     {
         const FabD *vt = c.Vsync.d_tab, *st = c.Ssync.d_tab, *ht = c.rho_half.d_tab;
-        const bool mom = c.p.do_mom_diff != 0, cons_trac = c.p.do_cons_trac != 0;
+        const bool mom = c.p.do_mom_diff != 0;
+        ScalForm sf;
+        for (int n = 0; n < MAXSCAL; ++n) sf.form[n] = c.scal_cons[n];
+        const int ns_ = c.nscal;
         for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
             const double rh = ht[fb](i, j, k);
             if (!mom) for (int n = 0; n < 3; ++n) vt[fb](i, j, k, n) /= rh;
-            if (!cons_trac) st[fb](i, j, k, Tracer - 3) /= rh;            // the non-conservative scalars (density is conservative)
+            for (int n = 1; n < ns_; ++n) if (!sf.form[n]) st[fb](i, j, k, n) /= rh;   // the non-conservative scalars (density is conservative)
         });
     }
     f.reg_adv->Reflux(c.Vsync, vol, 1.0, 0, 0, 3);
-    f.reg_adv->Reflux(c.Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    f.reg_adv->Reflux(c.Ssync, vol, 1.0, 3, 0, c.nstate - 3);
     mf_mult(c.Vsync, 1.0 / dt_crse, 0, 3, 1);
-    mf_mult(c.Ssync, 1.0 / dt_crse, 0, NUM_STATE - 3, 1);
+    mf_mult(c.Ssync, 1.0 / dt_crse, 0, c.nstate - 3, 1);
     // zero the coarse cells under the fine grids (grown tile box: ghost cells included)
     MultiFab fc = fine_coverage(c.layout, f.layout, c.g, f.ratio);
     mask_mult(c.Vsync, 0, 3, fc, true, 1);
-    mask_mult(c.Ssync, 0, NUM_STATE - 3, fc, true, 1);
+    mask_mult(c.Ssync, 0, c.nstate - 3, fc, true, 1);
 }
 
 // NavierStokes::mac_sync (NavierStokes.cpp:1438-1730) with MacProj::mac_sync_solve / mac_sync_compute; non-diffusive scalars,
@@ -752,9 +755,9 @@ void AmrNS::mac_sync(int l)
     // ---- mac_sync_compute (MacProj.cpp:490-731)
     {
         const bool mom = c.p.do_mom_diff != 0;
-        MultiFab Smf(c.layout, cell_type(), 3, 3), Sc(c.layout, cell_type(), NUM_SCALARS, 3);
+        MultiFab Smf(c.layout, cell_type(), 3, 3), Sc(c.layout, cell_type(), c.nscal, 3);
         c.fillpatch(Smf, c.S[1 - c.inew], Xvel, 3, c.bc_vel);
-        c.fillpatch(Sc, c.S[1 - c.inew], Density, NUM_SCALARS, c.bc_scal);
+        c.fillpatch(Sc, c.S[1 - c.inew], Density, c.nscal, c.bc_scal);
         if (mom) {
             const FabD *ut = Smf.d_tab, *rt = Sc.d_tab;
             for_each(*c.layout, cell_type(), 3, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
@@ -762,18 +765,20 @@ void AmrNS::mac_sync(int l)
                 for (int n = 0; n < 3; ++n) ut[fb](i, j, k, n) *= r;
             });
         }
-        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), NUM_SCALARS, 1), divu(c.layout, cell_type(), 1, 1);
+        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), c.nscal, 1), divu(c.layout, cell_type(), 1, 1);
         tfs.setVal(0.0); divu.setVal(0.0);
         // viscous forcing at the old time (MacProj.cpp:566-572): getViscTerms(visc_terms, 0, num_state_comps, prev_time)
         MultiFab vvisc(c.layout, cell_type(), 3, 1);
         vvisc.setVal(0.0);
         if (c.p.be_cn_theta != 1.0) {
             if (c.is_diffusive_vel()) c.get_visc_terms_vel(vvisc, c.S[1 - c.inew]);
-            if (c.is_diffusive_tracer()) {
-                // conservative tracer: tf += visc, convective: tf = tf / rho + visc with tf = 0 (MacProj.cpp:641-683)
+            for (int n = 1; n < c.nscal; ++n) {
+                if (!c.is_diffusive_scal(Density + n)) continue;
+                // conservative scalar: tf += visc, convective: tf = tf / rho + visc with tf = 0, temperature: (tf + visc) / rho (MacProj.cpp:641-683)
                 MultiFab sv(c.layout, cell_type(), 1, 1);
-                c.get_visc_terms_tracer(sv, c.S[1 - c.inew]);
-                MultiFab::Copy(tfs, sv, 0, Tracer - 3, 1, 1);
+                c.get_visc_terms_scalar(sv, c.S[1 - c.inew], Density + n);
+                if (Density + n == c.Temp) scale_by(sv, Sc, 0, 1, true);
+                MultiFab::Copy(tfs, sv, 0, n, 1, 1);
             }
         }
         {
@@ -789,18 +794,19 @@ void AmrNS::mac_sync(int l)
             });
         }
         MultiFab* um[3] = {&c.u_mac[0], &c.u_mac[1], &c.u_mac[2]};
-        const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0}, ics[2] = {1, c.p.do_cons_trac ? 1 : 0};
+        const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0};
+        const int* ics = c.scal_cons;
         MultiFab flv[3], fls[3];
         MultiFab *flvp[3], *flsp[3];
-        for (int d = 0; d < 3; ++d) { flv[d].define(c.layout, face_type(d), 3, 0); fls[d].define(c.layout, face_type(d), NUM_SCALARS, 0); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
+        for (int d = 0; d < 3; ++d) { flv[d].define(c.layout, face_type(d), 3, 0); fls[d].define(c.layout, face_type(d), c.nscal, 0); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
         godunov_compute_aofs_sync(c.g, c.Vsync, 0, Smf, 3, &tfv, &divu, um, uc, icv, dt, c.bc_vel, true, c.p.use_forces_in_trans != 0, flvp, c.p.use_ppm);
-        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, NUM_SCALARS, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp, c.p.use_ppm);
+        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, c.nscal, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp, c.p.use_ppm);
         for (int d = 0; d < 3; ++d) {            // NavierStokesBase.cpp:5083-5096 with sync_factor = -1
             f.reg_adv->CrseInit(flv[d], d, 0, 0, 3, dt, true);
-            f.reg_adv->CrseInit(fls[d], d, 0, Density, NUM_SCALARS, dt, true);
+            f.reg_adv->CrseInit(fls[d], d, 0, Density, c.nscal, dt, true);
             if (l > 0) {                         // this level is itself the fine side of the interface below
                 c.reg_adv->FineAdd(flv[d], d, 0, 0, 3, -dt);
-                c.reg_adv->FineAdd(fls[d], d, 0, Density, NUM_SCALARS, -dt);
+                c.reg_adv->FineAdd(fls[d], d, 0, Density, c.nscal, -dt);
                 c.reg_mac->FineAdd(Ucorr[d], d, 0, 0, 1, -c.g.dx[(d + 1) % 3] * c.g.dx[(d + 2) % 3] / (double)n_cycle[l]);   // MacProj.cpp:720-727
             }
         }
@@ -808,16 +814,19 @@ void AmrNS::mac_sync(int l)
     PROF_NEXT(psec, "ms_update");
     // ---- NavierStokes.cpp:1490-1690
     MultiFab& Sn = c.S[c.inew];
-    MultiFab Delta(c.layout, cell_type(), 1, 0);
-    const bool cons_trac = c.p.do_cons_trac != 0, mom = c.p.do_mom_diff != 0;
+    MultiFab Delta(c.layout, cell_type(), c.nscal, 0);
+    const bool mom = c.p.do_mom_diff != 0;
     {
         const FabD *st = c.Ssync.d_tab, *vt = c.Vsync.d_tab, *nt = Sn.d_tab, *dt_ = Delta.d_tab;
+        ScalForm sf;
+        for (int n = 0; n < MAXSCAL; ++n) sf.form[n] = c.scal_cons[n];
+        const int ns_ = c.nscal;
         for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
             const double rho = nt[fb](i, j, k, Density);
-            if (cons_trac) {                 // conservative Q = rho q: sync -= (sync of rho) * q, added back below
-                const double dl = nt[fb](i, j, k, Tracer) * st[fb](i, j, k, 0) / rho;
-                dt_[fb](i, j, k) = dl;
-                st[fb](i, j, k, Tracer - 3) -= dl;
+            for (int n = 1; n < ns_; ++n) if (sf.form[n]) {   // conservative Q = rho q: sync -= (sync of rho) * q, added back below
+                const double dl = nt[fb](i, j, k, Density + n) * st[fb](i, j, k, 0) / rho;
+                dt_[fb](i, j, k, n) = dl;
+                st[fb](i, j, k, n) -= dl;
             }
             if (mom) for (int n = 0; n < 3; ++n) vt[fb](i, j, k, n) /= rho;
         });
@@ -865,24 +874,28 @@ void AmrNS::mac_sync(int l)
     }
     PROF_NEXT(psec, "ms_ssync");
     mf_mult(c.Ssync, dt, 0, 1, 1);                           // density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
-    if (c.is_diffusive_tracer()) {
+    for (int sn = 1; sn < c.nscal; ++sn) {
+    const int sigma = Density + sn, rho_flag = c.scal_rho_flag[sn];
+    if (c.is_diffusive_scal(sigma)) {
         // Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
         // flux): (alpha - theta dt div D grad) s = dt Ssync, alpha = rho_new for S = rho q (rho_flag 2) else 1; Ssync = s (x rho_new).
         // On a refined level upstream passes no coarse data (has_coarse_data = false): homogeneous coarse/fine data here.
-        const bool cons = cons_trac;
+        const bool cons = rho_flag == 2;
         MultiFab Rhs(c.layout, cell_type(), 1, 0), Soln(c.layout, cell_type(), 1, 1), acoef(c.layout, cell_type(), 1, 0);
-        MultiFab::Copy(Rhs, c.Ssync, Tracer - 3, 0, 1, 0);
+        MultiFab::Copy(Rhs, c.Ssync, sn, 0, 1, 0);
         mf_mult(Rhs, dt, 0, 1, 0);
+        if (rho_flag == 1) scale_by(Rhs, c.rho_half, 0, 0, false);       // Diffusion.cpp:470-475
         Soln.setVal(0.0);
         acoef.setVal(1.0);
         if (cons) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
+        else if (rho_flag == 1) MultiFab::Copy(acoef, c.rho_half, 0, 0, 1, 0);
         const double tol_abs = c.p.visc_tol * Rhs.norm0(0, 1, 0);
         MGOpts so = o;
         so.maxorder = 2;
-        CellMG op(c.g, c.layout, 1, c.bc_scal_lin, so);
+        CellMG op(c.g, c.layout, 1, c.bc_scal_lin[sn], so);
         op.setScalars(1.0, theta * dt);
         op.setACoeffs(&acoef);
-        const MultiFab* bp[3] = {&c.diff_b[0], &c.diff_b[1], &c.diff_b[2]};
+        const MultiFab* bp[3] = {&c.diff_b[sn][0], &c.diff_b[sn][1], &c.diff_b[sn][2]};
         op.setBCoeffs(bp);
         if (l > 0) op.setCoarseFineBC(nullptr, c.crse->g, c.ratio);
         op.prepare();
@@ -894,17 +907,18 @@ void AmrNS::mac_sync(int l)
             op.fluxes(Soln, sfp, nullptr);
             for (int d = 0; d < 3; ++d) {
                 mf_mult(sf[d], c.g.dx[(d + 1) % 3] * c.g.dx[(d + 2) % 3] / dt, 0, 1, 0);          // theta * area * (-D grad s)
-                c.reg_visc->FineAdd(sf[d], d, 0, Tracer, 1, dt);
+                c.reg_visc->FineAdd(sf[d], d, 0, sigma, 1, dt);
             }
         }
         if (cons) {
             const FabD *st = Soln.d_tab, *nt = Sn.d_tab;
             for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) *= nt[fb](i, j, k, Density); });
         }
-        MultiFab::Copy(c.Ssync, Soln, 0, Tracer - 3, 1, 0);
-    } else mf_mult(c.Ssync, dt, Tracer - 3, 1, 1);
-    if (cons_trac) mf_saxpy(c.Ssync, dt, Delta, 0, Tracer - 3, 1, 0);
-    mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, NUM_STATE - 3, 0);
+        MultiFab::Copy(c.Ssync, Soln, 0, sn, 1, 0);
+    } else mf_mult(c.Ssync, dt, sn, 1, 1);
+    if (c.scal_cons[sn]) mf_saxpy(c.Ssync, dt, Delta, sn, sn, 1, 0);
+    }
+    mf_saxpy(Sn, 1.0, c.Ssync, 0, Density, c.nstate - 3, 0);
     c.make_rho_curr_time();
     if (l > 0) mf_saxpy(c.rho_avg, 1.0, c.Ssync, 0, 0, 1, 0);      // :1684-1688
     PROF_NEXT(psec, "ms_sync_interp");
@@ -913,9 +927,9 @@ void AmrNS::mac_sync(int l)
     for (size_t q = (size_t)l + 1; q < lev.size(); ++q) {
         NavierStokes& ff = *lev[q];
         ratio *= ff.ratio;
-        MultiFab incr(ff.layout, cell_type(), NUM_STATE - 3, 0);
-        sync_interp_cellcons(incr, 0, c.Ssync, 0, NUM_STATE - 3, c.g, ff.g, ratio, c.bc_scal);
-        mf_saxpy(ff.S[ff.inew], 1.0, incr, 0, Density, NUM_STATE - 3, 0);
+        MultiFab incr(ff.layout, cell_type(), c.nstate - 3, 0);
+        sync_interp_cellcons(incr, 0, c.Ssync, 0, c.nstate - 3, c.g, ff.g, ratio, c.bc_scal);
+        mf_saxpy(ff.S[ff.inew], 1.0, incr, 0, Density, c.nstate - 3, 0);
         ff.make_rho_curr_time();
         mf_saxpy(ff.rho_avg, 1.0, incr, 0, 0, 1, 0);
     }

@@ -199,18 +199,18 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
         s.initial_step = false; s.initial_iter = false;
         // ---- data: FillPatch(old, S_new / P_new / Gp_new) resp. FillCoarsePatch: the old level's cells where it existed, the
         // (already rebuilt) coarser level interpolated elsewhere
-        MultiFab none_c(empty_layout, cell_type(), NUM_STATE, 0);
+        MultiFab none_c(empty_layout, cell_type(), s.nstate, 0);
         const MultiFab* fS = ol ? &ol->S[ol->inew] : &none_c;
         TimeData fd{nullptr, fS, cur_time, cur_time};
         TimeData cd{nullptr, &c.S[c.inew], cur_time, cur_time};
         MultiFab tmp3(s.layout, cell_type(), 3, 1), tmp1(s.layout, cell_type(), 1, 1);
         fillpatch_two_levels(tmp3, 0, cur_time, fd, cd, Xvel, 3, c.g, s.g, m_ratio, s.bc_vel, s.ed_vel_lo, s.ed_vel_hi);
         MultiFab::Copy(s.S[0], tmp3, 0, Xvel, 3, 1);
-        for (int q = 0; q < NUM_SCALARS; ++q) {
+        for (int q = 0; q < s.nscal; ++q) {
             fillpatch_two_levels(tmp1, 0, cur_time, fd, cd, Density + q, 1, c.g, s.g, m_ratio, &s.bc_scal[q], s.ed_scal_lo + 3 * q, s.ed_scal_hi + 3 * q);
             MultiFab::Copy(s.S[0], tmp1, 0, Density + q, 1, 1);
         }
-        MultiFab::Copy(s.S[1], s.S[0], 0, 0, NUM_STATE, 1);
+        MultiFab::Copy(s.S[1], s.S[0], 0, 0, s.nstate, 1);
         MultiFab none_g(empty_layout, cell_type(), 3, 0);
         TimeData fg{nullptr, ol ? &ol->Gp[ol->pnew] : &none_g, cur_time, cur_time};
         TimeData cg{nullptr, &c.Gp[c.pnew], cur_time, cur_time};

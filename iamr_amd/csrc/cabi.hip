@@ -603,9 +603,10 @@ void iamrx_ns_default_params(iamrx_ns_params* p)
     p->init_dt = d.init_dt; p->tracer_diff_coef = d.tracer_diff_coef;
     for (int i = 0; i < 3; ++i) { p->phys_lo[i] = d.phys_lo[i]; p->phys_hi[i] = d.phys_hi[i]; }
     for (int i = 0; i < 9; ++i) { p->wall_vel_lo[i] = d.wall_vel_lo[i]; p->wall_vel_hi[i] = d.wall_vel_hi[i]; }
-    for (int i = 0; i < 6; ++i) { p->scal_bc_lo[i] = d.scal_bc_lo[i]; p->scal_bc_hi[i] = d.scal_bc_hi[i]; }
+    for (int i = 0; i < 12; ++i) { p->scal_bc_lo[i] = d.scal_bc_lo[i]; p->scal_bc_hi[i] = d.scal_bc_hi[i]; }
     p->do_cons_trac = d.do_cons_trac;
     p->do_denminmax = d.do_denminmax; p->do_scalminmax = d.do_scalminmax;
+    p->do_trac2 = d.do_trac2; p->do_cons_trac2 = d.do_cons_trac2; p->tracer2_diff_coef = d.tracer2_diff_coef; p->do_temp = d.do_temp; p->temp_cond_coef = d.temp_cond_coef;
     p->use_ppm = d.use_ppm;
 }
 
@@ -620,9 +621,10 @@ static NSParams to_params(const iamrx_ns_params* p)
     q.init_dt = p->init_dt; q.tracer_diff_coef = p->tracer_diff_coef;
     for (int i = 0; i < 3; ++i) { q.phys_lo[i] = p->phys_lo[i]; q.phys_hi[i] = p->phys_hi[i]; }
     for (int i = 0; i < 9; ++i) { q.wall_vel_lo[i] = p->wall_vel_lo[i]; q.wall_vel_hi[i] = p->wall_vel_hi[i]; }
-    for (int i = 0; i < 6; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
+    for (int i = 0; i < 12; ++i) { q.scal_bc_lo[i] = p->scal_bc_lo[i]; q.scal_bc_hi[i] = p->scal_bc_hi[i]; }
     q.do_cons_trac = p->do_cons_trac;
     q.do_denminmax = p->do_denminmax; q.do_scalminmax = p->do_scalminmax;
+    q.do_trac2 = p->do_trac2; q.do_cons_trac2 = p->do_cons_trac2; q.tracer2_diff_coef = p->tracer2_diff_coef; q.do_temp = p->do_temp; q.temp_cond_coef = p->temp_cond_coef;
     q.use_ppm = p->use_ppm;
     return q;
 }

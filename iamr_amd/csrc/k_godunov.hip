@@ -35,10 +35,12 @@ namespace iamrx {
 #define IAMRX_DIVDX(x, dx, rdx) ((x) * (rdx))
 #endif
 
+constexpr int GOD_MAXC = 8;    // components of one call: the whole state (3 velocities + density + tracer(s) + temperature) at most
+
 struct GodBC {
     int dlo[3], dhi[3];
     int per[3];
-    BCRec bc[5];
+    BCRec bc[GOD_MAXC];
 };
 
 struct GodParams {
@@ -49,7 +51,7 @@ struct GodParams {
     int fit;            // use_forces_in_trans
     int has_force;
     int has_divu;
-    int iconserv[5];
+    int iconserv[GOD_MAXC];
     GodBC bc;
 };
 
@@ -891,7 +893,7 @@ static GodParams make_params(const Geometry& g, double dt, int ncomp, const BCRe
     GodParams P;
     P.dt = dt; P.ncomp = ncomp; P.is_velocity = is_vel; P.fit = fit; P.has_force = has_force; P.has_divu = has_divu;
     for (int d = 0; d < 3; ++d) { P.dx[d] = g.dx[d]; P.bc.dlo[d] = g.domain.lo[d]; P.bc.dhi[d] = g.domain.hi[d]; P.bc.per[d] = g.periodic[d]; }
-    for (int n = 0; n < 5; ++n) {
+    for (int n = 0; n < GOD_MAXC; ++n) {
         P.iconserv[n] = (iconserv && n < ncomp) ? iconserv[n] : 0;
         for (int d = 0; d < 3; ++d) { P.bc.bc[n].lo[d] = (bc && n < ncomp) ? bc[n].lo[d] : 0; P.bc.bc[n].hi[d] = (bc && n < ncomp) ? bc[n].hi[d] : 0; }
     }
@@ -2244,7 +2246,7 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
                           bool is_velocity, bool use_forces_in_trans, MultiFab* const edge_out[3], MultiFab* const flux_out[3], int scheme)
 {
     if (S.nlocal() == 0) return;
-    IAMRX_ASSERT(S.ngrow >= 3 && ncomp <= 5 && S.ncomp >= ncomp);
+    IAMRX_ASSERT(S.ngrow >= 3 && ncomp <= GOD_MAXC && S.ncomp >= ncomp);
     IAMRX_ASSERT(umac[0]->ngrow >= 1);
     auto& ctx = Context::get();
     const Layout& l = *S.layout;

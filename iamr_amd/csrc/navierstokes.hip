@@ -22,7 +22,7 @@
 //   Diffusion::getViscTerms (scalars)       Diffusion.cpp:1539-1652
 //   physical BC tables                      NS_BC.H:7-55, NS_setup.cpp:21-128, NS_bcfill.H:17-180
 // Scope of this round: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls
-// through xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, divu = 0, NUM_STATE = 5
+// through xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, divu = 0; nstate = 5 + do_trac2 + do_temp
 // (u,v,w,rho,tracer), do_mom_diff = 0 or 1, Godunov_PLM.
 #include "operators.h"
 #include "launch.h"
@@ -49,8 +49,15 @@ struct SectionTimer {
 NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& par, const MGOpts& opts)
     : g(geom), layout(std::move(lay)), p(par), o(opts)
 {
+    nstate = Tracer + 1;
+    if (p.do_trac2) Tracer2 = nstate++;
+    if (p.do_temp) Temp = nstate++;
+    nscal = nstate - Density;
+    scal_cons[1] = p.do_cons_trac != 0; scal_rho_flag[1] = p.do_cons_trac ? 2 : 0; scal_diff[1] = p.tracer_diff_coef;      // NS_setup.cpp:304-310
+    if (p.do_trac2) { const int n = Tracer2 - Density; scal_cons[n] = p.do_cons_trac2 != 0; scal_rho_flag[n] = p.do_cons_trac2 ? 2 : 0; scal_diff[n] = p.tracer2_diff_coef; }
+    if (p.do_temp) { const int n = Temp - Density; scal_cons[n] = 0; scal_rho_flag[n] = 1; scal_diff[n] = p.temp_cond_coef; }   // NS_setup.cpp:302
     for (int q = 0; q < 2; ++q) {
-        S[q].define(layout, cell_type(), NUM_STATE, 1);
+        S[q].define(layout, cell_type(), nstate, 1);
         P[q].define(layout, node_type(), 1, 1);
         Gp[q].define(layout, cell_type(), 3, 1);
         S[q].setVal(0.0); P[q].setVal(0.0); Gp[q].setVal(0.0);
@@ -60,9 +67,9 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         u_mac[d].setVal(1.e40);                       // NavierStokesBase.cpp:673
         eta[d].define(layout, face_type(d), 1, 0);
         eta[d].setVal(p.visc_coef);
-        if (is_diffusive_tracer()) { diff_b[d].define(layout, face_type(d), 1, 0); diff_b[d].setVal(p.tracer_diff_coef); }
+        for (int n = 1; n < nscal; ++n) if (scal_diff[n] > 0.0) { diff_b[n][d].define(layout, face_type(d), 1, 0); diff_b[n][d].setVal(scal_diff[n]); }
     }
-    aofs.define(layout, cell_type(), NUM_STATE, 0);
+    aofs.define(layout, cell_type(), nstate, 0);
     mac_phi.define(layout, cell_type(), 1, 1);
     mac_phi.setVal(0.0);
     rho_ptime.define(layout, cell_type(), 1, 1);
@@ -81,6 +88,11 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         if (phys == phys_interior) return (int)bc_int_dir;
         if (phys == phys_symmetry) return (int)bc_reflect_even;
         return phys == phys_inflow ? (int)bc_ext_dir : (int)bc_foextrap;
+    };
+    auto temp_bctype = [](int phys) {                // temp_bc, NS_BC.H:37-40
+        if (phys == phys_interior) return (int)bc_int_dir;
+        if (phys == phys_inflow) return (int)bc_ext_dir;
+        return phys == phys_outflow ? (int)bc_hoextrap : (int)bc_reflect_even;
     };
     auto gp_bctype = [](int phys, bool normal) {     // norm/tang_gradp_bc
         if (phys == phys_interior) return (int)bc_int_dir;
@@ -117,16 +129,17 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
             ed_vel_lo[n * 3 + d] = p.wall_vel_lo[d * 3 + n]; ed_vel_hi[n * 3 + d] = p.wall_vel_hi[d * 3 + n];
             bc_visc[n].lo[d] = linop_of(bc_vel[n].lo[d]); bc_visc[n].hi[d] = linop_of(bc_vel[n].hi[d]);
         }
-        for (int n = 0; n < 2; ++n) {
-            bc_scal[n].lo[d] = scal_bctype(plo); bc_scal[n].hi[d] = scal_bctype(phi_);
-            ed_scal_lo[n * 3 + d] = p.scal_bc_lo[d * 2 + n]; ed_scal_hi[n * 3 + d] = p.scal_bc_hi[d * 2 + n];
+        for (int n = 0; n < nscal; ++n) {
+            const bool is_temp = Density + n == Temp;                                  // set_scalar_bc / set_temp_bc (NS_setup.cpp:263-283)
+            bc_scal[n].lo[d] = is_temp ? temp_bctype(plo) : scal_bctype(plo); bc_scal[n].hi[d] = is_temp ? temp_bctype(phi_) : scal_bctype(phi_);
+            ed_scal_lo[n * 3 + d] = p.scal_bc_lo[d * 4 + n]; ed_scal_hi[n * 3 + d] = p.scal_bc_hi[d * 4 + n];
+            bc_scal_lin[n].lo[d] = linop_of(bc_scal[n].lo[d]); bc_scal_lin[n].hi[d] = linop_of(bc_scal[n].hi[d]);
         }
-        bc_scal_lin.lo[d] = linop_of(bc_scal[1].lo[d]); bc_scal_lin.hi[d] = linop_of(bc_scal[1].hi[d]);
     }
     bc_mac.maxorder = 4;     // MacProj.cpp:1172
     bc_nodal.maxorder = 2;
     for (int n = 0; n < 3; ++n) bc_visc[n].maxorder = 2;    // Diffusion.cpp:95-96
-    bc_scal_lin.maxorder = 2;
+    for (int n = 0; n < MAXSCAL; ++n) bc_scal_lin[n].maxorder = 2;
 }
 
 void NavierStokes::init_rest(double rho0)
@@ -141,6 +154,7 @@ void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, d
 {
     const double TwoPi = 2.0 * 3.14159265358979323846264338327950288;
     const FabD* st = S[inew].d_tab;
+    const int ns_ = nstate;
     const double plo0 = g.problo[0], plo1 = g.problo[1], plo2 = g.problo[2], dx0 = g.dx[0], dx1 = g.dx[1], dx2 = g.dx[2];
     const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2];
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -151,6 +165,7 @@ void NavierStokes::init_taylorgreen(double vfac, double a, double b, double c, d
         s(i, j, k, 2) = 0.0;
         s(i, j, k, Density) = rho0;
         s(i, j, k, Tracer) = (rho0 * vfac * vfac / 16.0) * (2.0 + cos(2.0 * c * TwoPi * z)) * (cos(2.0 * a * TwoPi * x) + cos(2.0 * b * TwoPi * y));
+        for (int nt = Tracer + 1; nt < ns_; ++nt) s(i, j, k, nt) = 1.0;       // prob_init.cpp:555-558
     });
     for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }
     time = 0.0; nstep = 0;
@@ -160,6 +175,7 @@ void NavierStokes::init_rayleightaylor(double rho_1, double rho_2, double tra_1,
 {
     const double Pi = 3.14159265358979323846264338327950288;
     const FabD* st = S[inew].d_tab;
+    const int ns_ = nstate;
     const double plo0 = g.problo[0], plo1 = g.problo[1], plo2 = g.problo[2], dx0 = g.dx[0], dx1 = g.dx[1], dx2 = g.dx[2];
     const int dl0 = g.domain.lo[0], dl1 = g.domain.lo[1], dl2 = g.domain.lo[2];
     const double Lx = g.dx[0] * g.domain.len(0), Ly = g.dx[1] * g.domain.len(1);
@@ -174,6 +190,7 @@ void NavierStokes::init_rayleightaylor(double rho_1, double rho_2, double tra_1,
         s(i, j, k, 0) = 0.0; s(i, j, k, 1) = 0.0; s(i, j, k, 2) = 0.0;
         s(i, j, k, Density) = rho_1 + ((rho_2 - rho_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
         s(i, j, k, Tracer) = tra_1 + ((tra_2 - tra_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+        for (int nt = Tracer + 1; nt < ns_; ++nt) s(i, j, k, nt) = 1.0;       // prob_init.cpp:482-485
     });
     for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }
     time = 0.0; nstep = 0;
@@ -223,7 +240,7 @@ void NavierStokes::swap_time_levels(double dt_)      // StateData::swapTimeLevel
 void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)
 {
     const bool is_vel = (bc == bc_vel);
-    const bool is_scal = (bc >= bc_scal && bc < bc_scal + 2);
+    const bool is_scal = (bc >= bc_scal && bc < bc_scal + MAXSCAL);
     const long so = is_scal ? 3 * (bc - bc_scal) : 0;
     const double* edlo = is_vel ? ed_vel_lo : (is_scal ? ed_scal_lo + so : nullptr);
     const double* edhi = is_vel ? ed_vel_hi : (is_scal ? ed_scal_hi + so : nullptr);
@@ -329,9 +346,9 @@ void NavierStokes::crse_state_at(MultiFab& out, double t, int scomp, int ncomp)
     MultiFab::Copy(out, *src, c0, 0, ncomp, 0);
 }
 
-void NavierStokes::crse_scalar_at(MultiFab& out, double t, bool over_rho)
+void NavierStokes::crse_scalar_at(MultiFab& out, double t, int comp, bool over_rho)
 {
-    crse_state_at(out, t, Tracer, 1);
+    crse_state_at(out, t, comp, 1);
     if (!over_rho) return;
     MultiFab r;
     crse_state_at(r, t, Density, 1);
@@ -382,7 +399,7 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
 
 // NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0): visc = div(beta grad S(time))
 // y(comp 0) *= x(xcomp) or /= x(xcomp), ng ghost cells included
-static void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool divide)
+void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool divide)
 {
     const FabD *yt = y.d_tab, *xt = x.d_tab;
     for_each(*y.layout, cell_type(), ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -391,23 +408,25 @@ static void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool div
     });
 }
 
-void NavierStokes::get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata)
+void NavierStokes::get_visc_terms_scalar(MultiFab& visc, MultiFab& Sdata, int comp)
 {
+    const int sn = comp - Density;
+    const bool over_rho = scal_rho_flag[sn] == 2;
     visc.setVal(1.e40);
-    if (!is_diffusive_tracer()) { visc.setVal(0.0); return; }
+    if (!is_diffusive_scal(comp)) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 1, 1);
-    fillpatch(stmp, Sdata, Tracer, 1, &bc_scal[1]);
-    if (p.do_cons_trac) scale_by(stmp, rho_ptime, 0, 1, true);    // rho_flag 2 (Diffusion.cpp:1612-1615): div beta grad(S/rho), old time
+    fillpatch(stmp, Sdata, comp, 1, &bc_scal[sn]);
+    if (over_rho) scale_by(stmp, rho_ptime, 0, 1, true);    // rho_flag 2 (Diffusion.cpp:1612-1615): div beta grad(S/rho), old time
     MGOpts mo;
     mo.max_coarsening_level = 0;       // info.setMaxCoarseningLevel(0) (Diffusion.cpp:1574)
     mo.maxorder = 2;
-    CellMG mg(g, layout, 1, bc_scal_lin, mo);
+    CellMG mg(g, layout, 1, bc_scal_lin[sn], mo);
     mg.setScalars(0.0, -1.0);
-    const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
+    const MultiFab* bp[3] = {&diff_b[sn][0], &diff_b[sn][1], &diff_b[sn][2]};
     mg.setBCoeffs(bp);
     MultiFab cdata;
     if (level > 0) {                                              // mlabec.setCoarseFineBC(&crsedata, ratio), Diffusion.cpp:1600-1609
-        crse_scalar_at(cdata, state_time(Sdata), p.do_cons_trac != 0);
+        crse_scalar_at(cdata, state_time(Sdata), comp, over_rho);
         mg.setCoarseFineBC(&cdata, crse->g, ratio);
     }
     mg.prepare();
@@ -503,8 +522,8 @@ double NavierStokes::predict_velocity(double dt_)
     if (level > 0) fill_gp(Gp[1 - pnew], 0.5 * (pt_old[0] + pt_old[1]));
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
-    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
-    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
+    MultiFab Smf(layout, cell_type(), nscal, 3);
+    fillpatch(Smf, So, Density, nscal, bc_scal);
     MultiFab tf(layout, cell_type(), 3, 1);
     {
         const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
@@ -601,8 +620,8 @@ void NavierStokes::velocity_advection(double dt_)
             for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) *= r;
         });
     }
-    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
-    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
+    MultiFab Smf(layout, cell_type(), nscal, 1);
+    fillpatch(Smf, So, Density, nscal, bc_scal);
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
     MultiFab tf(layout, cell_type(), 3, 1), divu(layout, cell_type(), 1, 1);
@@ -637,34 +656,33 @@ void NavierStokes::scalar_advection(double dt_)
 {
     SectionTimer tm(*this, 2);
     MultiFab& So = S[1 - inew];
-    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 3);
-    fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
+    MultiFab Smf(layout, cell_type(), nscal, 3);
+    fillpatch(Smf, So, Density, nscal, bc_scal);
     floor_small(Smf);
-    MultiFab tf(layout, cell_type(), NUM_SCALARS, 1), divu(layout, cell_type(), 1, 1);
+    MultiFab tf(layout, cell_type(), nscal, 1), divu(layout, cell_type(), 1, 1);
     tf.setVal(0.0); divu.setVal(0.0);
     MultiFab visc(layout, cell_type(), 1, 1);
-    if (p.be_cn_theta != 1.0) get_visc_terms_tracer(visc, So); else visc.setVal(0.0);
-    {
-        // getForce = 0; density is not diffusive; keep the reference's arithmetic
+    for (int n = 1; n < nscal; ++n) {            // getForce = 0; density (n = 0) is not diffusive; keep the reference's arithmetic
+        if (p.be_cn_theta != 1.0) get_visc_terms_scalar(visc, So, Density + n); else visc.setVal(0.0);
         const FabD *tt = tf.d_tab, *st = Smf.d_tab, *vt = visc.d_tab;
-        const bool cons = p.do_cons_trac != 0;
+        const int form = Density + n == Temp ? 2 : (scal_cons[n] ? 1 : 0);
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = st[f](i, j, k, 0);
-            tt[f](i, j, k, 0) += 0.0;                                               // conservative: tf += visc
-            if (cons) tt[f](i, j, k, 1) += vt[f](i, j, k, 0);                        // NavierStokes.cpp:780-792
-            else tt[f](i, j, k, 1) = tt[f](i, j, k, 1) / rho + vt[f](i, j, k, 0);    // convective: tf/rho + visc
+            if (form == 2) tt[f](i, j, k, n) = (tt[f](i, j, k, n) + vt[f](i, j, k, 0)) / rho;    // temperature: NavierStokes.cpp:766-778
+            else if (form == 1) tt[f](i, j, k, n) += vt[f](i, j, k, 0);                          // conservative: tf += visc (:780-792)
+            else tt[f](i, j, k, n) = tt[f](i, j, k, n) / rho + vt[f](i, j, k, 0);                // convective: tf/rho + visc (:794-806)
         });
     }
-    const int iconserv[2] = {1, p.do_cons_trac ? 1 : 0};                            // NS_setup.cpp:304-310
+    const int* iconserv = scal_cons;                                               // NS_setup.cpp:297-320
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
-        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_SCALARS, 0); flp[d] = &fl[d]; }
-        godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
-        adv_registers(flp, Density, NUM_SCALARS, dt_);
+        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), nscal, 0); flp[d] = &fl[d]; }
+        godunov_compute_aofs(g, aofs, Density, Smf, nscal, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
+        adv_registers(flp, Density, nscal, dt_);
     } else
-    godunov_compute_aofs(g, aofs, Density, Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
+    godunov_compute_aofs(g, aofs, Density, Smf, nscal, &tf, &divu, um, iconserv, dt_, bc_scal, false, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
 // velocity_advection + scalar_advection in ONE pass of the Godunov chain over all five state components (NavierStokes.cpp:698-812 calls
@@ -675,22 +693,30 @@ void NavierStokes::advection_all(double dt_)
 {
     SectionTimer tm(*this, 2);
     MultiFab& So = S[1 - inew];
-    const bool mom = p.do_mom_diff != 0, cons = p.do_cons_trac != 0;
-    MultiFab Q(layout, cell_type(), NUM_STATE, 3);
+    const bool mom = p.do_mom_diff != 0;
+    const int ns_ = nscal;
+    MultiFab Q(layout, cell_type(), nstate, 3);
     {
-        MultiFab Umf(layout, cell_type(), 3, 3), Smf(layout, cell_type(), NUM_SCALARS, 3);
+        MultiFab Umf(layout, cell_type(), 3, 3), Smf(layout, cell_type(), nscal, 3);
         fillpatch(Umf, So, Xvel, 3, bc_vel);
-        fillpatch(Smf, So, Density, NUM_SCALARS, bc_scal);
+        fillpatch(Smf, So, Density, nscal, bc_scal);
         const FabD *qt = Q.d_tab, *ut = Umf.d_tab, *st = Smf.d_tab;
         for_each(*layout, cell_type(), 3, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double r = st[f](i, j, k, 0);              // momentum rho^n u^n with the unfloored density (NavierStokesBase.cpp:3397-3413)
             for (int n = 0; n < 3; ++n) qt[f](i, j, k, n) = mom ? ut[f](i, j, k, n) * r : (double)ut[f](i, j, k, n);
-            for (int n = 0; n < NUM_SCALARS; ++n) { const double v = st[f](i, j, k, n); qt[f](i, j, k, Density + n) = fabs(v) <= 1.e-20 ? 0.0 : v; }   // floor_small
+            for (int n = 0; n < ns_; ++n) { const double v = st[f](i, j, k, n); qt[f](i, j, k, Density + n) = fabs(v) <= 1.e-20 ? 0.0 : v; }   // floor_small
         });
     }
-    MultiFab visc(layout, cell_type(), 3, 1), svisc(layout, cell_type(), 1, 1);
-    if (p.be_cn_theta != 1.0) { get_visc_terms_vel(visc, So); get_visc_terms_tracer(svisc, So); } else { visc.setVal(0.0); svisc.setVal(0.0); }
-    MultiFab tf(layout, cell_type(), NUM_STATE, 1), divu(layout, cell_type(), 1, 1);
+    MultiFab visc(layout, cell_type(), 3, 1), svisc(layout, cell_type(), nscal, 1);
+    svisc.setVal(0.0);
+    if (p.be_cn_theta != 1.0) {
+        get_visc_terms_vel(visc, So);
+        MultiFab one(layout, cell_type(), 1, 1);
+        for (int n = 1; n < nscal; ++n) { get_visc_terms_scalar(one, So, Density + n); MultiFab::Copy(svisc, one, 0, n, 1, 1); }
+    } else visc.setVal(0.0);
+    ScalForm sf;                                 // per scalar slot: 0 convective, 1 conservative, 2 temperature
+    for (int n = 0; n < MAXSCAL; ++n) sf.form[n] = (n < nscal && Density + n == Temp) ? 2 : (scal_cons[n] ? 1 : 0);
+    MultiFab tf(layout, cell_type(), nstate, 1), divu(layout, cell_type(), 1, 1);
     divu.setVal(0.0);
     {
         MultiFab R1(layout, cell_type(), 1, 1);
@@ -706,27 +732,33 @@ void NavierStokes::advection_all(double dt_)
                 tt[f](i, j, k, n) = t;
             }
             const double rhof = qt[f](i, j, k, Density);     // scalar_advection divides by the floored density of ITS state
-            double t0 = 0.0, t1 = 0.0;
+            double t0 = 0.0;
             t0 += 0.0;
-            if (cons) t1 += wt[f](i, j, k, 0); else t1 = t1 / rhof + wt[f](i, j, k, 0);
             tt[f](i, j, k, Density) = t0;
-            tt[f](i, j, k, Tracer) = t1;
+            for (int n = 1; n < ns_; ++n) {
+                double t1 = 0.0;
+                if (sf.form[n] == 2) t1 = (t1 + wt[f](i, j, k, n)) / rhof;
+                else if (sf.form[n] == 1) t1 += wt[f](i, j, k, n);
+                else t1 = t1 / rhof + wt[f](i, j, k, n);
+                tt[f](i, j, k, Density + n) = t1;
+            }
         });
     }
     const int ic = mom ? 1 : 0;
-    const int iconserv[NUM_STATE] = {ic, ic, ic, 1, cons ? 1 : 0};
-    BCRec bc5[NUM_STATE];
+    int iconserv[MAXSTATE] = {ic, ic, ic};
+    for (int n = 0; n < nscal; ++n) iconserv[3 + n] = scal_cons[n];
+    BCRec bc5[MAXSTATE];
     for (int n = 0; n < 3; ++n) bc5[n] = bc_vel[n];
-    for (int n = 0; n < NUM_SCALARS; ++n) bc5[3 + n] = bc_scal[n];
+    for (int n = 0; n < nscal; ++n) bc5[3 + n] = bc_scal[n];
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     if (fine || level > 0) {
         MultiFab fl[3];
         MultiFab* flp[3];
-        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), NUM_STATE, 0); flp[d] = &fl[d]; }
-        godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
-        adv_registers(flp, Xvel, NUM_STATE, dt_);
+        for (int d = 0; d < 3; ++d) { fl[d].define(layout, face_type(d), nstate, 0); flp[d] = &fl[d]; }
+        godunov_compute_aofs(g, aofs, Xvel, Q, nstate, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, flp, p.use_ppm);
+        adv_registers(flp, Xvel, nstate, dt_);
     } else
-    godunov_compute_aofs(g, aofs, Xvel, Q, NUM_STATE, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
+    godunov_compute_aofs(g, aofs, Xvel, Q, nstate, &tf, &divu, um, iconserv, dt_, bc5, true, p.use_forces_in_trans != 0, nullptr, nullptr, p.use_ppm);
 }
 
 // NavierStokesBase::ConservativeScalMinMax / ConvectiveScalMinMax (NavierStokesBase.cpp:4256-4368): the new value (per unit mass if
@@ -734,8 +766,8 @@ void NavierStokes::advection_all(double dt_)
 // std::numeric_limits<Real>::min() (the smallest positive double) as written upstream
 void NavierStokes::scal_min_max(int comp, bool conservative)
 {
-    MultiFab Smf(layout, cell_type(), NUM_SCALARS, 1);
-    fillpatch(Smf, S[1 - inew], Density, NUM_SCALARS, bc_scal);
+    MultiFab Smf(layout, cell_type(), nscal, 1);
+    fillpatch(Smf, S[1 - inew], Density, nscal, bc_scal);
     const FabD *nt = S[inew].d_tab, *ot = Smf.d_tab;
     const int oc = comp - Density;
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -770,24 +802,31 @@ void NavierStokes::scalar_update_tracers(double dt_)
 {
     SectionTimer tm(*this, 3);
     const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab, *at = aofs.d_tab;
+    const int ns_ = nstate;
     for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
         const double rho = ot[f](i, j, k, Density) - 0.5 * dt_ * at[f](i, j, k, Density);
-        const double tfv = 0.0;               // getForce = 0 for the tracer: the conservative form (+ tf, no 1/rho; NavierStokesBase.cpp:2889) gives the same value
-        nt[f](i, j, k, Tracer) = ot[f](i, j, k, Tracer) + dt_ * (-at[f](i, j, k, Tracer) + tfv / rho);
+        const double tfv = 0.0;               // getForce = 0 for the scalars: the conservative form (+ tf, no 1/rho; NavierStokesBase.cpp:2889) gives the same value
+        for (int sigma = Tracer; sigma < ns_; ++sigma) nt[f](i, j, k, sigma) = ot[f](i, j, k, sigma) + dt_ * (-at[f](i, j, k, sigma) + tfv / rho);
     });
-    if (p.do_scalminmax) scal_min_max(Tracer, p.do_cons_trac != 0);                     // NavierStokesBase.cpp:2907-2935
+    if (p.do_scalminmax) for (int sigma = Tracer; sigma < nstate; ++sigma) scal_min_max(sigma, scal_cons[sigma - Density] != 0);   // NavierStokesBase.cpp:2907-2935
 }
 
-// Diffusion::diffuse_scalar for the tracer (rho_flag 0): (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old
+// Diffusion::diffuse_scalar for one scalar (rho_flag 0): (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old
 void NavierStokes::scalar_diffusion_update(double dt_)
 {
-    if (!is_diffusive_tracer()) return;
+    for (int sigma = Tracer; sigma < nstate; ++sigma) scalar_diffusion_update_one(dt_, sigma);    // NavierStokes.cpp:912-1000
+}
+
+void NavierStokes::scalar_diffusion_update_one(double dt_, int sigma)
+{
+    if (!is_diffusive_scal(sigma)) return;
     SectionTimer tm(*this, 4);
     const double theta = p.be_cn_theta;
-    const bool cons = p.do_cons_trac != 0;                       // diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308)
+    const int sn = sigma - Density, rho_flag = scal_rho_flag[sn];
+    const bool cons = rho_flag == 2;                             // diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308)
     MultiFab& Sn = S[inew];
     MultiFab& So = S[1 - inew];
-    const MultiFab* bp[3] = {&diff_b[0], &diff_b[1], &diff_b[2]};
+    const MultiFab* bp[3] = {&diff_b[sn][0], &diff_b[sn][1], &diff_b[sn][2]};
     MultiFab Rhs(layout, cell_type(), 1, 0);
     const bool want_flux = fine != nullptr || level > 0;         // NavierStokes.cpp:949-990
     MultiFab sflux[3], sflux1[3];
@@ -796,7 +835,7 @@ void NavierStokes::scalar_diffusion_update(double dt_)
     MultiFab cdata;
     if (theta != 1.0) {
         MultiFab Soln0(layout, cell_type(), 1, 1);
-        fillpatch(Soln0, So, Tracer, 1, &bc_scal[1]);
+        fillpatch(Soln0, So, sigma, 1, &bc_scal[sn]);
         if (cons) {                                              // Diffusion.cpp:396-413: Soln = S_old / rho_old on the grown box
             MultiFab R(layout, cell_type(), 1, 1);
             fillpatch(R, So, Density, 1, &bc_scal[0]);
@@ -805,10 +844,10 @@ void NavierStokes::scalar_diffusion_update(double dt_)
         MGOpts mo;
         mo.max_coarsening_level = 0;                             // infon.setMaxCoarseningLevel(0) (Diffusion.cpp:318)
         mo.maxorder = 2;
-        CellMG opn(g, layout, 1, bc_scal_lin, mo);
+        CellMG opn(g, layout, 1, bc_scal_lin[sn], mo);
         opn.setScalars(0.0, -(1.0 - theta) * dt_);
         opn.setBCoeffs(bp);
-        if (level > 0) { crse_scalar_at(cdata, st_old, cons); opn.setCoarseFineBC(&cdata, crse->g, ratio); }     // Diffusion.cpp:376-396
+        if (level > 0) { crse_scalar_at(cdata, st_old, sigma, cons); opn.setCoarseFineBC(&cdata, crse->g, ratio); }     // Diffusion.cpp:376-396
         opn.prepare();
         opn.apply(Rhs, Soln0);
         if (want_flux) {                                         // fluxn = (1 - theta) * area * (-D grad s_old) (Diffusion.cpp:437-438)
@@ -816,10 +855,14 @@ void NavierStokes::scalar_diffusion_update(double dt_)
             for (int d = 0; d < 3; ++d) mf_mult(sflux[d], (1.0 - theta) * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (-(1.0 - theta) * dt_), 0, 1, 0);
         }
     } else Rhs.setVal(0.0);
-    mf_saxpy(Rhs, 1.0, Sn, Tracer, 0, 1, 0);                     // rhs += S_new (Diffusion.cpp:479-493)
+    if (rho_flag == 1) {                                         // rhs += rho_half * S_new (Diffusion.cpp:476-486)
+        const FabD *rt = Rhs.d_tab, *st = Sn.d_tab, *ht = rho_half.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) { rt[f](i, j, k, 0) += st[f](i, j, k, sigma) * ht[f](i, j, k, 0); });
+    } else
+    mf_saxpy(Rhs, 1.0, Sn, sigma, 0, 1, 0);                      // rhs += S_new (Diffusion.cpp:479-493)
     const double tol_abs = p.visc_tol * Rhs.norm0(0, 1, 0);      // get_scaled_abs_tol
     MultiFab Soln(layout, cell_type(), 1, 1);
-    fillpatch(Soln, Sn, Tracer, 1, &bc_scal[1]);                 // FillPatch(S_new, ng 1): initial guess + level BC
+    fillpatch(Soln, Sn, sigma, 1, &bc_scal[sn]);                 // FillPatch(S_new, ng 1): initial guess + level BC
     MultiFab acoef(layout, cell_type(), 1, 0);
     acoef.setVal(1.0);                                           // computeAlpha, rho_flag 0
     if (cons) {                                                  // rho_flag 2: Soln = S_new / rho_new (Diffusion.cpp:520-540), alpha = rho_new
@@ -827,26 +870,26 @@ void NavierStokes::scalar_diffusion_update(double dt_)
         fillpatch(R, Sn, Density, 1, &bc_scal[0]);
         scale_by(Soln, R, 0, 1, true);
         MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
-    }
+    } else if (rho_flag == 1) MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);   // RhoInverse_Laplacian_S: alpha = rho_half (Diffusion.cpp:551-556)
     MGOpts so = o;
     so.maxorder = 2;                                             // Diffusion::max_order
-    CellMG opnp1(g, layout, 1, bc_scal_lin, so);
+    CellMG opnp1(g, layout, 1, bc_scal_lin[sn], so);
     opnp1.setScalars(1.0, theta * dt_);
     opnp1.setACoeffs(&acoef);
     opnp1.setBCoeffs(bp);
-    if (level > 0) { crse_scalar_at(cdata, st_new, cons); opnp1.setCoarseFineBC(&cdata, crse->g, ratio); }   // Diffusion.cpp:506-518
+    if (level > 0) { crse_scalar_at(cdata, st_new, sigma, cons); opnp1.setCoarseFineBC(&cdata, crse->g, ratio); }   // Diffusion.cpp:506-518
     opnp1.prepare();
     st_scal = opnp1.solve(Soln, Rhs, p.visc_tol, tol_abs);
     if (want_flux) {                                             // fluxnp1 = theta * area * (-D grad s_new) (Diffusion.cpp:569-570); registers NavierStokes.cpp:949-990
         opnp1.fluxes(Soln, sfp1, nullptr);
         for (int d = 0; d < 3; ++d) {
             mf_saxpy(sflux[d], theta * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (theta * dt_), sflux1[d], 0, 0, 1, 0);
-            if (level > 0) reg_visc->FineAdd(sflux[d], d, 0, Tracer, 1, dt_);
-            if (fine) fine->reg_visc->CrseInit(sflux[d], d, 0, Tracer, 1, -dt_, false);
+            if (level > 0) reg_visc->FineAdd(sflux[d], d, 0, sigma, 1, dt_);
+            if (fine) fine->reg_visc->CrseInit(sflux[d], d, 0, sigma, 1, -dt_, false);
         }
     }
     if (cons) scale_by(Soln, Sn, Density, 0, false);            // Diffusion.cpp:583-590
-    MultiFab::Copy(Sn, Soln, 0, Tracer, 1, 0);
+    MultiFab::Copy(Sn, Soln, 0, sigma, 1, 0);
 }
 
 void NavierStokes::velocity_advection_update(double dt_)

@@ -144,14 +144,20 @@ struct NSParams {
     double tracer_diff_coef = 0.0;       // ns.scal_diff_coefs[0]
     int phys_lo[3] = {0, 0, 0}, phys_hi[3] = {0, 0, 0};   // ns.lo_bc / ns.hi_bc (PhysBCType: 0 Interior, 4 SlipWall, 5 NoSlipWall)
     double wall_vel_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wall_vel_hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // xlo.velocity ...: [d*3+n]
-    double scal_bc_lo[6] = {0, 0, 0, 0, 0, 0}, scal_bc_hi[6] = {0, 0, 0, 0, 0, 0};   // xlo.density, xlo.tracer ... (inflow values): [d*2+n]
+    double scal_bc_lo[12] = {0}, scal_bc_hi[12] = {0};   // xlo.density, xlo.tracer, xlo.tracer2, xlo.temp (inflow values): [d*4+n], n = the scalar's slot
     int do_cons_trac = 0;                // ns.do_cons_trac
     int do_denminmax = 0, do_scalminmax = 0;   // ns.do_denminmax / ns.do_scalminmax (NavierStokesBase.cpp:466-467)
+    int do_trac2 = 0, do_cons_trac2 = 0; // ns.do_trac2 / ns.do_cons_trac2: a second tracer (NavierStokes.cpp:45-46, NS_setup.cpp:312-320)
+    double tracer2_diff_coef = 0.0;      // ns.scal_diff_coefs[1]
+    int do_temp = 0;                     // ns.do_temp: temperature, the last state component (NavierStokes.cpp:47-48)
+    double temp_cond_coef = 0.0;         // ns.temp_cond_coef
     int use_ppm = 0;                     // ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM (NavierStokesBase.cpp:548-553)
 };
 
-enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
+enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, MAXSCAL = 4, MAXSTATE = 3 + MAXSCAL };   // Tracer2 / Temp: NavierStokes::Tracer2 / Temp (-1: absent)
 
+struct ScalForm { int form[MAXSCAL]; };   // captured by device lambdas
+void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool divide);   // y (comp 0) *= or /= x(xcomp) on ng ghost cells
 class SyncRegister;
 class AmrNS;
 class NavierStokes {
@@ -218,11 +224,12 @@ private:
     void scal_min_max(int comp, bool conservative);
     void velocity_advection_update(double dt);
     void scalar_diffusion_update(double dt);
-    void get_visc_terms_tracer(MultiFab& visc, MultiFab& Sdata);
+    void get_visc_terms_scalar(MultiFab& visc, MultiFab& Sdata, int comp);
+    void scalar_diffusion_update_one(double dt, int sigma);
     void first_order_extrap(MultiFab& mf);
     // data of the coarse level at this level's time t, on the coarse level's own layout (the crsedata of Diffusion.cpp:733-744, 1725-1736)
     void crse_state_at(MultiFab& out, double t, int scomp, int ncomp);
-    void crse_scalar_at(MultiFab& out, double t, bool over_rho);   // the coarse tracer (divided by the coarse density: rho_flag 2)
+    void crse_scalar_at(MultiFab& out, double t, int comp, bool over_rho);   // a coarse scalar (divided by the coarse density: rho_flag 2)
     double state_time(const MultiFab& Sdata) const { return &Sdata == &S[1 - inew] ? st_old : st_new; }
     const MultiFab& cf_mask();                 // cf_build_mask of the level (2 ghost cells), level > 0
     // div tau(U^n) of the running advance: getViscTerms(prev_time) is asked for by the velocity prediction, by the advection forcing and
@@ -236,7 +243,7 @@ private:
     bool m_cf_mask_built = false;
     void fill_gradp_bc();
     void set_inflow_ghosts(MultiFab& vel, double scale);
-    bool is_diffusive_tracer() const { return p.tracer_diff_coef > 0.0; }
+    bool is_diffusive_scal(int comp) const { return scal_diff[comp - Density] > 0.0; }
     void velocity_diffusion_update(double dt);
     void initial_velocity_diffusion_update(double dt);
     void level_project(double dt);
@@ -259,11 +266,16 @@ private:
     MultiFab eta[3];
     double dt_min_adv = 1.e200;
     bool initial_step = false, initial_iter = false;
-    DomainBC bc_mac, bc_nodal, bc_visc[3], bc_scal_lin;
-    BCRec bc_vel[3], bc_scal[2], bc_gp[3];
+    // NavierStokes::Initialize (NavierStokes.cpp:43-55): Density, Tracer, [Tracer2], [Temp]; per scalar slot (0 = density): advectionType ==
+    // Conservative (NS_setup.cpp:297-320), Diffusion::set_rho_flag(diffusionType) (0 Laplacian_S, 1 RhoInverse_Laplacian_S, 2 Laplacian_SoverRho)
+    int nstate = 5, nscal = 2, Tracer2 = -1, Temp = -1;
+    int scal_cons[MAXSCAL] = {1, 0, 0, 0}, scal_rho_flag[MAXSCAL] = {1, 0, 0, 1};
+    double scal_diff[MAXSCAL] = {-1.0, 0.0, 0.0, 0.0};
+    DomainBC bc_mac, bc_nodal, bc_visc[3], bc_scal_lin[MAXSCAL];
+    BCRec bc_vel[3], bc_scal[MAXSCAL], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];     // ext_dir values [n*3+d]
-    double ed_scal_lo[6], ed_scal_hi[6];   // ext_dir (inflow) values of density, tracer [n*3+d]
-    MultiFab diff_b[3];                    // tracer diffusivity on faces
+    double ed_scal_lo[3 * MAXSCAL], ed_scal_hi[3 * MAXSCAL];   // ext_dir (inflow) values of density, tracer, ... [n*3+d]
+    MultiFab diff_b[MAXSCAL][3];           // scalar diffusivities on faces (defined for the diffusive slots)
     bool any_wall = false;
 };
 

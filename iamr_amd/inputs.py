@@ -27,7 +27,6 @@ _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.v
                  "ns.do_sync_proj")
 _IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
 # boundary values of the second tracer: read by upstream only with ns.do_trac2 = 1 (which raises here), unused otherwise
-_IGNORED_KEYS = _IGNORED_KEYS + tuple(f"{d}{s}.tracer2" for d in "xyz" for s in ("lo", "hi"))
 # keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
 _UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
                          "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
@@ -138,6 +137,11 @@ class Inputs:
         names = self.table.get("amr.refinement_indicators", [])
         self.used.add("amr.refinement_indicators")
         comps = {"x_velocity": 0, "y_velocity": 1, "z_velocity": 2, "density": 3, "tracer": 4, "mag_vort": -1}
+        nxt = 5
+        for flag, nm_ in (("ns.do_trac2", "tracer2"), ("ns.do_temp", "temp")):      # NavierStokes.cpp:43-48
+            if self.integer(flag, 0):
+                comps[nm_] = nxt
+                nxt += 1
         rules = []
         for nm in names:
             pre = f"amr.{nm}."
@@ -222,11 +226,17 @@ class Inputs:
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
         if scheme not in ("Godunov_PLM", "Godunov_PPM", "BDS"):      # NavierStokesBase.cpp:548-553
             raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; Godunov_PLM, Godunov_PPM and BDS are implemented")
-        for k in ("ns.do_temp", "ns.do_trac2", "ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
+        for k in ("ns.do_temp", "ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
             if self.has(k) and self.string(k) not in ("0", "all_regular"):
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented")
-        sdc = self.reals("ns.scal_diff_coefs", 1, [0.0])
+        do_trac2, do_temp = self.integer("ns.do_trac2", 0), self.integer("ns.do_temp", 0)
+        ntrac = 2 if do_trac2 else 1
+        # NavierStokes.cpp:268-282: n_scal_diff_coefs + n_temp_cond_coef must equal NUM_SCALARS - 1
+        sdc = self.reals("ns.scal_diff_coefs", ntrac, [0.0] * ntrac)
+        snames = ["density", "tracer"] + (["tracer2"] if do_trac2 else []) + (["temp"] if do_temp else [])
         p = dict(cfl=self.real("ns.cfl"), visc_coef=self.real("ns.vel_visc_coef", 0.0), tracer_diff_coef=sdc[0],
+                 do_trac2=do_trac2, do_cons_trac2=self.integer("ns.do_cons_trac2", 0), tracer2_diff_coef=sdc[1] if do_trac2 else 0.0,
+                 do_temp=do_temp, temp_cond_coef=self.real("ns.temp_cond_coef", 0.0) if do_temp else 0.0,
                  init_iter=self.integer("ns.init_iter", 2), init_vel_iter=self.integer("ns.init_vel_iter", 1),
                  init_shrink=self.real("ns.init_shrink", 1.0), change_max=self.real("ns.change_max", 1.1),
                  fixed_dt=self.real("ns.fixed_dt", -1.0), init_dt=self.real("ns.init_dt", -1.0), gravity=self.real("ns.gravity", 0.0),
@@ -243,12 +253,18 @@ class Inputs:
             if self.has(f"{name}hi.velocity"):
                 whi[3 * d:3 * d + 3] = self.reals(f"{name}hi.velocity", 3)
         p["wall_vel_lo"], p["wall_vel_hi"] = wlo, whi
-        # inflow values of the scalars: {x,y,z}{lo,hi}.density / .tracer (NS_bcfill.H functors)
-        slo, shi = [0.0] * 6, [0.0] * 6
+        # inflow values of the scalars: {x,y,z}{lo,hi}.density / .tracer / .tracer2 / .temp (NavierStokes::Initialize_bcs,
+        # NavierStokes.cpp:66-170: defaults density 1, tracers 0, temp 1), [d*4 + slot]
+        slo, shi = [0.0] * 12, [0.0] * 12
         for d, name in enumerate("xyz"):
-            for q, sname in enumerate(("density", "tracer")):
-                slo[2 * d + q] = self.real(f"{name}lo.{sname}", 0.0) if self.has(f"{name}lo.{sname}") else 0.0
-                shi[2 * d + q] = self.real(f"{name}hi.{sname}", 0.0) if self.has(f"{name}hi.{sname}") else 0.0
+            for q, sname in enumerate(snames):
+                dflt = 1.0 if sname in ("density", "temp") else 0.0
+                slo[4 * d + q] = self.real(f"{name}lo.{sname}", dflt) if self.has(f"{name}lo.{sname}") else dflt
+                shi[4 * d + q] = self.real(f"{name}hi.{sname}", dflt) if self.has(f"{name}hi.{sname}") else dflt
+            for sname in ("tracer2", "temp"):           # values of absent scalars are read and dropped upstream
+                for side in ("lo", "hi"):
+                    if sname not in snames and self.has(f"{name}{side}.{sname}"):
+                        self.real(f"{name}{side}.{sname}", 0.0)
         p["scal_bc_lo"], p["scal_bc_hi"] = slo, shi
         probtype = self.integer("prob.probtype")
         if probtype == 1:
@@ -260,12 +276,12 @@ class Inputs:
             prob = dict(probtype=10, rho_1=self.real("prob.rho_1"), rho_2=self.real("prob.rho_2"), tra_1=self.real("prob.tra_1", 0.0),
                         tra_2=self.real("prob.tra_2", 0.0), pertamp=self.real("prob.perturbation_amplitude", 0.0),
                         interface_width=self.real("prob.interface_width", 1.0))
-        elif probtype in (4, 5, 7):     # host-side initial data (iamr_amd/probinit.py)
+        elif probtype in (2, 4, 5, 6, 7):     # host-side initial data (iamr_amd/probinit.py)
             prob = dict(probtype=probtype, density_ic=self.real("prob.density_ic", 1.0), direction=self.integer("prob.direction", 0),
                         interface_width=self.real("prob.interface_width", 1.0), blob_radius=self.real("prob.blob_radius", 0.1),
                         blob_center=self.reals("prob.blob_center", 3, [0.0, 0.0, 0.0]), velocity_ic=self.reals("prob.velocity_ic", 3, [0.0, 0.0, 0.0]))
         else:
-            raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 4 (constant "
+            raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 2 / 6 (bubble / hot spot), 4 (constant "
                                       "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),

@@ -13,7 +13,8 @@ class NsParams(C.Structure):
                 ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int),
                 ("init_dt", C.c_double), ("tracer_diff_coef", C.c_double), ("phys_lo", C.c_int * 3), ("phys_hi", C.c_int * 3),
                 ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9),
-                ("scal_bc_lo", C.c_double * 6), ("scal_bc_hi", C.c_double * 6), ("do_cons_trac", C.c_int), ("do_denminmax", C.c_int), ("do_scalminmax", C.c_int), ("use_ppm", C.c_int)]
+                ("scal_bc_lo", C.c_double * 12), ("scal_bc_hi", C.c_double * 12), ("do_cons_trac", C.c_int), ("do_denminmax", C.c_int), ("do_scalminmax", C.c_int),
+                ("do_trac2", C.c_int), ("do_cons_trac2", C.c_int), ("tracer2_diff_coef", C.c_double), ("do_temp", C.c_int), ("temp_cond_coef", C.c_double), ("use_ppm", C.c_int)]
 
 
 def ns_params(**kw):
@@ -24,8 +25,11 @@ def ns_params(**kw):
             setattr(p, k, (C.c_int * 3)(*[int(x) for x in v]))
         elif k in ("wall_vel_lo", "wall_vel_hi"):
             setattr(p, k, (C.c_double * 9)(*[float(x) for x in v]))
-        elif k in ("scal_bc_lo", "scal_bc_hi"):
-            setattr(p, k, (C.c_double * 6)(*[float(x) for x in v]))
+        elif k in ("scal_bc_lo", "scal_bc_hi"):        # [d*4+n]; a 6-entry list is the two-scalar layout [d*2+n]
+            v = [float(x) for x in v]
+            if len(v) == 6:
+                v = [v[2 * d + n] if n < 2 else 0.0 for d in range(3) for n in range(4)]
+            setattr(p, k, (C.c_double * 12)(*v))
         else:
             setattr(p, k, v)
     return p
@@ -178,7 +182,14 @@ class NavierStokes:
         h = C.c_void_p()
         check(lib().iamrx_ns_data(self.h, which, C.byref(h)))
         typ, nc, ng = self._types[which]
+        if nc == 5:
+            nc = self.nstate
         return MultiFab(self.layout, typ, nc, ng, _handle=h, _owned=True)
+
+    @property
+    def nstate(self):
+        """NUM_STATE (NavierStokes.cpp:43-48): u v w density tracer [tracer2] [temp]"""
+        return 5 + (1 if self.params.do_trac2 else 0) + (1 if self.params.do_temp else 0)
 
     def stats(self):
         a, b, c = MgStats(), MgStats(), MgStats()

@@ -195,6 +195,11 @@ def compare(path_a, path_b):
 STATE_NAMES_3D = ["x_velocity", "y_velocity", "z_velocity", "density", "tracer"]
 
 
+def state_names(do_trac2=0, do_temp=0):
+    """names of the State_Type components (NS_setup.cpp:250-283)"""
+    return STATE_NAMES_3D + (["tracer2"] if do_trac2 else []) + (["temp"] if do_temp else [])
+
+
 def from_level_data(geom_n, prob_lo, prob_hi, boxes, arrays, time, step, names=None):
     """single-level PlotFile from per-box arrays (valid region, (nx,ny,nz,ncomp))"""
     dim = len(geom_n)

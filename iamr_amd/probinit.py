@@ -16,11 +16,27 @@ def cell_centres(n, prob_lo, prob_hi, lo=(0, 0, 0), hi=None):
     return np.meshgrid(*c, indexing="ij")
 
 
-def initial_state(prob, X, Y, Z):
-    """prob: the dict Inputs.problem()['prob'] builds; X, Y, Z: cell-centre coordinates (3-D arrays) -> array (..., 5)"""
-    S = np.zeros(X.shape + (5,))
+def initial_state(prob, X, Y, Z, nstate=5):
+    """prob: the dict Inputs.problem()['prob'] builds; X, Y, Z: cell-centre coordinates (3-D arrays) -> array (..., nstate);
+    components past the tracer (tracer2, temp) as prob_init.cpp's `for nt = 2 .. nscal-1` loops set them"""
+    S = np.zeros(X.shape + (nstate,))
     pt = prob["probtype"]
+    extra = 1.0                              # prob_init.cpp:400-403 (5), 605-608 (7)
+    if pt in (2, 6):                         # init_bubble, prob_init.cpp:164-229; 6: hot bubble with temperature as the last scalar
+        v = prob["velocity_ic"]
+        S[..., 0], S[..., 1], S[..., 2] = v[0], v[1], v[2]
+        bc = prob["blob_center"]
+        dist = np.sqrt((X - bc[0]) ** 2 + (Y - bc[1]) ** 2 + (Z - bc[2]) ** 2)
+        blob = np.where(dist < prob["blob_radius"], 1.0, 0.0)
+        S[..., 4:] = blob[..., None]
+        if pt == 6:
+            S[..., 3] = 1.0 / prob["density_ic"] + 0.5 * (1.0 - 1.0 / prob["density_ic"]) * (1.0 + np.tanh(40.0 * (dist - prob["blob_radius"]) / prob["interface_width"]))
+            S[..., nstate - 1] = 1.0 / S[..., 3]
+        else:
+            S[..., 3] = 1.0 + 0.5 * (prob["density_ic"] - 1.0) * (1.0 - np.tanh(30.0 * (dist - prob["blob_radius"]) / prob["interface_width"]))
+        return S
     if pt == 4:
+        extra = 0.0                          # prob_init.cpp:275-279
         v = prob["velocity_ic"]
         S[..., 0], S[..., 1], S[..., 2] = v[0], v[1], v[2]
         bc = prob["blob_center"]
@@ -51,14 +67,16 @@ def initial_state(prob, X, Y, Z):
         S[..., 4] = np.exp(-kappa * (rho_in - r) ** 2)
     else:
         raise NotImplementedError(f"probinit: prob.probtype = {pt}")
+    S[..., 5:] = extra
     return S
 
 
 def set_initial_state(ns, lay, lib, N, prob, n, prob_lo, prob_hi):
     """fill S_new of `ns` (valid cells; post_init fills the ghost cells) on every local box"""
-    m = lib.MultiFab(lay, lib.CELL, 5, 1)
+    nstate = ns.nstate
+    m = lib.MultiFab(lay, lib.CELL, nstate, 1)
     for li in range(m.nlocal()):
         lo, hi = m.fab_box(li)
         X, Y, Z = cell_centres(n, prob_lo, prob_hi, lo, hi)
-        m.from_numpy(initial_state(prob, X, Y, Z), li)
+        m.from_numpy(initial_state(prob, X, Y, Z, nstate), li)
     ns.set_data(N.NavierStokes.S_NEW, m)

@@ -12,7 +12,7 @@ def init_level(ns, lay, lib, N, pr, n):
     pb = pr["prob"]
     if pb["probtype"] == 1:
         ns.init_rest(pb["rho0"])
-    elif pb["probtype"] in (4, 5, 7):
+    elif pb["probtype"] in (2, 4, 5, 6, 7):
         from .probinit import set_initial_state
         ns.init_rest(pb["density_ic"])
         set_initial_state(ns, lay, lib, N, pb, n, pr["prob_lo"], pr["prob_hi"])
@@ -60,7 +60,7 @@ def level_arrays(ns, lay, N):
 
 def write_plot_amr(amr, lays, pr, N, step, root):
     """NavierStokesBase::writePlotFile role for the hierarchy: one AMReX plotfile with every level (the five state components)"""
-    from .plotfile import PlotFile, Level, STATE_NAMES_3D
+    from .plotfile import PlotFile, Level, state_names
     levels = []
     dts = amr.dts()
     for l, lev in enumerate(amr.levels):
@@ -69,7 +69,7 @@ def write_plot_amr(amr, lays, pr, N, step, root):
         boxes, arrs = level_arrays(lev, lays[l], N)
         levels.append(Level(((0, 0, 0), tuple(v - 1 for v in n)), dx, boxes, arrs, step * 2 ** l, amr.time))
     path = f"{root}{step:05d}"
-    PlotFile(STATE_NAMES_3D, amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
+    PlotFile(state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)), amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
     return path
 
 
@@ -127,7 +127,7 @@ def build(inp, lib, N, nranks=1, pr=None):
     pb = pr["prob"]
     if pb["probtype"] == 1:
         ns.init_rest(pb["rho0"])
-    elif pb["probtype"] in (4, 5, 7):
+    elif pb["probtype"] in (2, 4, 5, 6, 7):
         from .probinit import set_initial_state
         ns.init_rest(pb["density_ic"])
         set_initial_state(ns, lay, lib, N, pb, pr["n"], pr["prob_lo"], pr["prob_hi"])
@@ -141,7 +141,7 @@ def build(inp, lib, N, nranks=1, pr=None):
 def write_plot(ns, lay, pr, N, step, root):
     """NavierStokesBase::writePlotFile role (single level, the five state components): AMReX-format plotfile <root><step:05d>.
     Single-rank runs only (every box is local)."""
-    from .plotfile import from_level_data
+    from .plotfile import from_level_data, state_names
     S = ns.data(N.NavierStokes.S_NEW)
     boxes, arrs = [], []
     for li in range(S.nlocal()):
@@ -151,7 +151,8 @@ def write_plot(ns, lay, pr, N, step, root):
         arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
         boxes.append((tuple(blo), tuple(bhi)))
     path = f"{root}{step:05d}"
-    from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step).write(path)
+    from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step,
+                    names=state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0))).write(path)
     return path
 
 

@@ -331,9 +331,13 @@ typedef struct iamrx_ns_params {
     double tracer_diff_coef;     /* ns.scal_diff_coefs[0] (<= 0: tracer not diffusive) */
     int phys_lo[3], phys_hi[3];  /* ns.lo_bc / ns.hi_bc, Source/NS_BC.H: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall */
     double wall_vel_lo[9], wall_vel_hi[9];   /* xlo.velocity ... zhi.velocity: [d*3+n] = component n on the lo/hi face of direction d */
-    double scal_bc_lo[6], scal_bc_hi[6];     /* xlo.density, xlo.tracer ... zhi.* (inflow values): [d*2+n], n = 0 density, 1 tracer */
+    double scal_bc_lo[12], scal_bc_hi[12];   /* xlo.density, xlo.tracer, xlo.tracer2, xlo.temp ... zhi.* (inflow values): [d*4+n], n = the scalar's slot: 0 density, 1 tracer, then tracer2 / temp as present */
     int do_cons_trac;            /* ns.do_cons_trac: the tracer is rho*q, advected conservatively and diffused as div beta grad(S/rho) (Source/NS_setup.cpp:306-310) */
     int do_denminmax, do_scalminmax;   /* ns.do_denminmax / ns.do_scalminmax (Source/NavierStokesBase.cpp:466-467): clip the advected density / scalars to the 27-point min / max of the old data (ConservativeScalMinMax / ConvectiveScalMinMax, :4256-4368) */
+    int do_trac2, do_cons_trac2; /* ns.do_trac2 / ns.do_cons_trac2: a second tracer, state component 5 (Source/NavierStokes.cpp:45-46, Source/NS_setup.cpp:312-320) */
+    double tracer2_diff_coef;    /* ns.scal_diff_coefs[1] */
+    int do_temp;                 /* ns.do_temp: temperature as the last state component (Source/NavierStokes.cpp:47-48; temp_bc, RhoInverse_Laplacian_S) */
+    double temp_cond_coef;       /* ns.temp_cond_coef */
     int use_ppm;                 /* ns.advection_scheme: 0 = Godunov_PLM, 1 = Godunov_PPM, 2 = BDS (Source/NavierStokesBase.cpp:548-553, 4654-4656) */
 } iamrx_ns_params;
 void iamrx_ns_default_params(iamrx_ns_params* p);     /* defaults of Source/NavierStokesBase.cpp:96-170 */

@@ -241,9 +241,13 @@ typedef struct orc_ns_params {
     double tracer_diff_coef;   /* ns.scal_diff_coefs[0]: tracer diffusivity (<= 0: not diffusive) */
     int phys_lo[3], phys_hi[3];/* ns.lo_bc / ns.hi_bc: 0 Interior (periodic), 1 Inflow, 2 Outflow, 3 Symmetry, 4 SlipWall, 5 NoSlipWall (Source/NS_BC.H) */
     double wall_vel_lo[9], wall_vel_hi[9]; /* xlo.velocity ... zhi.velocity: [d*3+n] = comp n on the lo/hi face of direction d */
-    double scal_bc_lo[6], scal_bc_hi[6];   /* xlo.density, xlo.tracer ... (inflow values): [d*2+n], n = 0 density, 1 tracer */
+    double scal_bc_lo[12], scal_bc_hi[12]; /* xlo.density, xlo.tracer, xlo.tracer2, xlo.temp (inflow values): [d*4+n], n = the scalar's slot (0 density, 1 tracer, then tracer2 / temp as present) */
     int do_cons_trac;          /* ns.do_cons_trac (Source/NS_setup.cpp:306-310): Conservative advection, Laplacian_SoverRho diffusion */
     int do_denminmax, do_scalminmax;   /* ns.do_denminmax / ns.do_scalminmax (Source/NavierStokesBase.cpp:466-467, 2771-2788, 2907-2935) */
+    int do_trac2, do_cons_trac2;       /* ns.do_trac2 / ns.do_cons_trac2: a second tracer (NavierStokes.cpp:45-46, NS_setup.cpp:312-320) */
+    double tracer2_diff_coef;          /* ns.scal_diff_coefs[1] */
+    int do_temp;                       /* ns.do_temp: temperature as the last state component (NavierStokes.cpp:47-48), Divu_Type / Dsdt_Type exist */
+    double temp_cond_coef;             /* ns.temp_cond_coef */
     int use_ppm;               /* ns.advection_scheme = Godunov_PPM (Source/NavierStokesBase.cpp:548-553); 0: Godunov_PLM */
 } orc_ns_params;
 
@@ -253,7 +257,7 @@ void orc_ns_default_params(orc_ns_params* p);
 orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc_mg_opts* o);
 void orc_ns_destroy(orc_ns_state* s);
 /* pointers to the persistent arrays (for initial conditions and comparison).
- * which: 0 S_new (NUM_STATE comps, 1 ghost), 1 S_old, 2 P_new (node,1 ghost), 3 P_old,
+ * which: 0 S_new (nstate comps, 1 ghost), 1 S_old, 2 P_new (node,1 ghost), 3 P_old,
  * 4 Gp_new (3 comps,1 ghost), 5 Gp_old, 6..8 umac, 9 aofs */
 orc_fab* orc_ns_fab(orc_ns_state* s, int which);
 void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, double c, double rho0);

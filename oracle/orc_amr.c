@@ -640,7 +640,7 @@ static void avg_down_nodes(const orc_ns_state* f, const orc_fab* fine, orc_fab* 
 static void avg_down(orc_amr* a, int lev)
 {
     orc_ns_state *c = a->lev[lev], *f = a->lev[lev + 1];
-    avg_down_cells(f, S_NEW(f), S_NEW(c), 0, NUM_STATE);
+    avg_down_cells(f, S_NEW(f), S_NEW(c), 0, c->nstate);
     for (int l = lev; l < a->nlev; ++l) ns_make_rho_curr_time(a->lev[l]);
     avg_down_nodes(f, c->initial_step ? P_NEW(f) : &f->p_avg, P_NEW(c));
     avg_down_cells(f, GP_NEW(f), GP_NEW(c), 0, 3);
@@ -656,25 +656,25 @@ static void reflux(orc_amr* a, int lev)
     const orc_geom* g = &c->g;
     const double vol = g->dx[0] * g->dx[1] * g->dx[2], dt_crse = a->dt_level[lev];
     reg_reflux(f, f->reg_visc, &c->Vsync, vol, 1.0, 0, 0, 3);
-    reg_reflux(f, f->reg_visc, &c->Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    reg_reflux(f, f->reg_visc, &c->Ssync, vol, 1.0, 3, 0, c->nstate - 3);
     if (c->p.do_mom_diff == 0)
         for (int n = 0; n < 3; ++n)
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Vsync, i, j, k, n) /= A4(&c->rho_half, i, j, k, 0);
-    for (int istate = 3; istate < NUM_STATE; ++istate) {
-        const int conservative = istate == Density || (istate == Tracer && c->p.do_cons_trac);
+    for (int istate = 3; istate < c->nstate; ++istate) {
+        const int conservative = c->scal_cons[istate - Density];
         if (!conservative)
             for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Ssync, i, j, k, istate - 3) /= A4(&c->rho_half, i, j, k, 0);
     }
     reg_reflux(f, f->reg_adv, &c->Vsync, vol, 1.0, 0, 0, 3);
-    reg_reflux(f, f->reg_adv, &c->Ssync, vol, 1.0, 3, 0, NUM_STATE - 3);
+    reg_reflux(f, f->reg_adv, &c->Ssync, vol, 1.0, 3, 0, c->nstate - 3);
     const double scale = 1.0 / dt_crse;
     { size_t N = orc_npts(&c->Vsync) * 3; for (size_t q = 0; q < N; ++q) c->Vsync.p[q] *= scale; }
-    { size_t N = orc_npts(&c->Ssync) * (NUM_STATE - 3); for (size_t q = 0; q < N; ++q) c->Ssync.p[q] *= scale; }
+    { size_t N = orc_npts(&c->Ssync) * (c->nstate - 3); for (size_t q = 0; q < N; ++q) c->Ssync.p[q] *= scale; }
     /* zero the coarse cells under the fine grids (grown tile box: ghost cells included) */
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
         if (!cell_in_domain(g, i, j, k) || !fine_covers(f, i, j, k)) continue;
         for (int n = 0; n < 3; ++n) A4(&c->Vsync, i, j, k, n) = 0.0;
-        for (int n = 0; n < NUM_STATE - 3; ++n) A4(&c->Ssync, i, j, k, n) = 0.0;
+        for (int n = 0; n < c->nstate - 3; ++n) A4(&c->Ssync, i, j, k, n) = 0.0;
     }
 }
 
@@ -743,10 +743,10 @@ static void mac_sync_compute(orc_amr* a, int lev, orc_fab Ucorr[3])
     const double dt = a->dt_level[lev], prev_time = c->st_old;
     orc_godunov_set_ppm(c->p.use_ppm);
     orc_fab Smf = ns_fillpatch_time(c, prev_time, 0, 0, 3, 3);
-    orc_fab Sc = ns_fillpatch_time(c, prev_time, 0, Density, NUM_SCALARS, 3);
+    orc_fab Sc = ns_fillpatch_time(c, prev_time, 0, Density, c->nscal, 3);
     const int mom = c->p.do_mom_diff;
     if (mom) { const size_t N = orc_npts(&Smf); for (int n = 0; n < 3; ++n) for (size_t q = 0; q < N; ++q) Smf.p[q + N * n] *= Sc.p[q]; }
-    orc_fab tfv = orc_alloc(g->n, ORC_CELL, 1, 3), tfs = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS), divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_fab tfv = orc_alloc(g->n, ORC_CELL, 1, 3), tfs = orc_alloc(g->n, ORC_CELL, 1, c->nscal), divu = orc_alloc(g->n, ORC_CELL, 1, 1);
     const orc_fab* Gp = GP_OLD(c);
     /* viscous forcing at the old time (MacProj.cpp:566-572) */
     orc_fab vvisc = orc_alloc(g->n, ORC_CELL, 1, 3);
@@ -760,22 +760,25 @@ static void mac_sync_compute(orc_amr* a, int lev, orc_fab Ucorr[3])
     }
     orc_free(&vvisc);
     /* scalars: getForce = 0; conservative: tf += visc; convective: tf = tf/rho + visc (MacProj.cpp:641-683); density does not diffuse */
-    if (c->p.be_cn_theta != 1.0 && c->p.tracer_diff_coef > 0.0) {
+    for (int n = 1; n < c->nscal; ++n) {
+        if (!(c->p.be_cn_theta != 1.0 && c->scal_diff[n] > 0.0)) continue;
         orc_fab sv = orc_alloc(g->n, ORC_CELL, 1, 1);
-        ns_get_visc_terms_tracer(c, &sv, S_OLD(c));
-        for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) A4(&tfs, i, j, k, Tracer - 3) = A4(&sv, i, j, k, 0);
+        ns_get_visc_terms_scalar(c, &sv, S_OLD(c), Density + n);
+        for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
+            A4(&tfs, i, j, k, n) = Density + n == c->Temp ? A4(&sv, i, j, k, 0) / A4(&Sc, i, j, k, 0) : A4(&sv, i, j, k, 0);   /* MacProj.cpp:641-683 */
         orc_free(&sv);
     }
     orc_fab *um[3] = {&c->umac[0], &c->umac[1], &c->umac[2]}, *uc[3] = {&Ucorr[0], &Ucorr[1], &Ucorr[2]};
-    const int icv[3] = {mom, mom, mom}, ics[2] = {1, c->p.do_cons_trac ? 1 : 0};
+    const int icv[3] = {mom, mom, mom};
+    int ics[ORC_MAXSCAL]; for (int n = 0; n < c->nscal; ++n) ics[n] = c->scal_cons[n];
     orc_fab flv[3], fls[3]; orc_fab *flvp[3], *flsp[3];
-    for (int d = 0; d < 3; ++d) { flv[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); fls[d] = orc_alloc(g->n, ORC_FACE[d], 0, NUM_SCALARS); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
+    for (int d = 0; d < 3; ++d) { flv[d] = orc_alloc(g->n, ORC_FACE[d], 0, 3); fls[d] = orc_alloc(g->n, ORC_FACE[d], 0, c->nscal); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
     orc_compute_aofs_sync(g, &c->Vsync, 0, &Smf, 3, &tfv, &divu, um, uc, icv, dt, c->bc_vel, 1, c->p.use_forces_in_trans, flvp);
-    orc_compute_aofs_sync(g, &c->Ssync, 0, &Sc, NUM_SCALARS, &tfs, &divu, um, uc, ics, dt, c->bc_scal, 0, c->p.use_forces_in_trans, flsp);
+    orc_compute_aofs_sync(g, &c->Ssync, 0, &Sc, c->nscal, &tfs, &divu, um, uc, ics, dt, c->bc_scal, 0, c->p.use_forces_in_trans, flsp);
     /* NavierStokesBase.cpp:5083-5096 with sync_factor = -1 (do_crse_add = false) */
     for (int d = 0; d < 3; ++d) {
-        if (c->fine) { reg_crse_init(c->fine, c->fine->reg_adv, &flv[d], d, 0, 0, 3, dt, 1); reg_crse_init(c->fine, c->fine->reg_adv, &fls[d], d, 0, Density, NUM_SCALARS, dt, 1); }
-        if (c->level > 0) { reg_fine_add(c, c->reg_adv, &flv[d], d, 0, 0, 3, -dt); reg_fine_add(c, c->reg_adv, &fls[d], d, 0, Density, NUM_SCALARS, -dt); }
+        if (c->fine) { reg_crse_init(c->fine, c->fine->reg_adv, &flv[d], d, 0, 0, 3, dt, 1); reg_crse_init(c->fine, c->fine->reg_adv, &fls[d], d, 0, Density, c->nscal, dt, 1); }
+        if (c->level > 0) { reg_fine_add(c, c->reg_adv, &flv[d], d, 0, 0, 3, -dt); reg_fine_add(c, c->reg_adv, &fls[d], d, 0, Density, c->nscal, -dt); }
         if (c->level > 0) reg_fine_add(c, c->reg_mac, &Ucorr[d], d, 0, 0, 1, -g->dx[(d + 1) % 3] * g->dx[(d + 2) % 3] / (double)a->n_cycle[lev]);
         orc_free(&flv[d]); orc_free(&fls[d]);
     }
@@ -788,18 +791,18 @@ static void mac_sync(orc_amr* a, int lev)
     orc_ns_state* c = a->lev[lev];
     const orc_geom* g = &c->g;
     const double dt = a->dt_level[lev];
-    const int numscal = NUM_STATE - 3;
+    const int numscal = c->nstate - 3;
     orc_fab Ucorr[3];
     mac_sync_solve(a, lev, Ucorr);
     mac_sync_compute(a, lev, Ucorr);
     for (int d = 0; d < 3; ++d) orc_free(&Ucorr[d]);
     orc_fab* Sn = S_NEW(c);
-    orc_fab Delta = orc_alloc(g->n, ORC_CELL, 0, 1);
-    const int cons_trac = c->p.do_cons_trac;
-    if (cons_trac)                     /* :1500-1528: conservative Q = rho q: sync -= (sync of rho) * q */
+    orc_fab Delta = orc_alloc(g->n, ORC_CELL, 0, ORC_MAXSCAL);
+    for (int sn = 1; sn < numscal; ++sn)        /* :1500-1528: conservative Q = rho q: sync -= (sync of rho) * q */
+        if (c->scal_cons[sn])
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
-            A4(&Delta, i, j, k, 0) = A4(Sn, i, j, k, Tracer) * A4(&c->Ssync, i, j, k, 0) / A4(Sn, i, j, k, Density);
-            A4(&c->Ssync, i, j, k, Tracer - 3) -= A4(&Delta, i, j, k, 0);
+            A4(&Delta, i, j, k, sn) = A4(Sn, i, j, k, Density + sn) * A4(&c->Ssync, i, j, k, 0) / A4(Sn, i, j, k, Density);
+            A4(&c->Ssync, i, j, k, sn) -= A4(&Delta, i, j, k, sn);
         }
     if (c->p.do_mom_diff == 1)
         for (int n = 0; n < 3; ++n)
@@ -841,45 +844,49 @@ static void mac_sync(orc_amr* a, int lev)
     }
     /* density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow) (:1667-1675) */
     { const size_t N = orc_npts(&c->Ssync); for (size_t q = 0; q < N; ++q) c->Ssync.p[q] *= dt; }
-    if (c->p.tracer_diff_coef > 0.0) {
+    for (int sn = 1; sn < numscal; ++sn) {
+    const int sigma = Density + sn, rho_flag = c->scal_rho_flag[sn];
+    const int* slobc = c->slobc + 3 * sn; const int* shibc = c->shibc + 3 * sn;
+    if (c->scal_diff[sn] > 0.0) {
         /* Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
          * flux): (alpha - theta dt div D grad) s = dt Ssync, alpha = rho_new for S = rho q (rho_flag 2) else 1; Ssync = s (x rho_new);
          * on a refined level no coarse data are passed upstream: homogeneous coarse/fine data */
-        const int cons = cons_trac;
+        const int cons = rho_flag == 2;
         orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1), Soln = orc_alloc(g->n, ORC_CELL, 1, 1), acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
         double m = 0.0;
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
-            A4(&Rhs, i, j, k, 0) = dt * A4(&c->Ssync, i, j, k, Tracer - 3);
-            A4(&acoef, i, j, k, 0) = cons ? A4(Sn, i, j, k, Density) : 1.0;
+            A4(&Rhs, i, j, k, 0) = dt * A4(&c->Ssync, i, j, k, sn) * (rho_flag == 1 ? A4(&c->rho_half, i, j, k, 0) : 1.0);   /* Diffusion.cpp:470-475 */
+            A4(&acoef, i, j, k, 0) = cons ? A4(Sn, i, j, k, Density) : (rho_flag == 1 ? A4(&c->rho_half, i, j, k, 0) : 1.0);
             if (c->level > 0 && A4(&c->cov, i, j, k, 0) == 0.0) continue;
             if (fabs(A4(&Rhs, i, j, k, 0)) > m) m = fabs(A4(&Rhs, i, j, k, 0));
         }
         orc_abec_level L;
-        ns_tracer_level(c, &L, 1.0, theta * dt, &acoef);
+        ns_scalar_level(c, &L, sigma, 1.0, theta * dt, &acoef);
         orc_mg_opts so = c->o; so.maxorder = 2;
         orc_mg_stats st;
         orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
         if (c->level > 0) {
             L.nbox = c->nbox; L.boxes = c->boxes;
             for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * c->ratio * g->dx[d];
-            orc_abec_solve_cf(&L, &Soln, &Rhs, c->slobc, c->shibc, &cfb, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
+            orc_abec_solve_cf(&L, &Soln, &Rhs, slobc, shibc, &cfb, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
             orc_fab fl[3]; orc_fab* flp[3];
             for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, 1); flp[d] = &fl[d]; }
             orc_cf_set_bcval(&cfb, 1, 2);
             orc_abec_extensive_flux(&L, flp, &Soln, theta, 0);
             orc_cf_set_bcval(NULL, 0, 2);
-            for (int d = 0; d < 3; ++d) { reg_fine_add(c, c->reg_visc, &fl[d], d, 0, Tracer, 1, dt); orc_free(&fl[d]); }   /* NavierStokes.cpp:1630-1638 */
-        } else orc_abec_solve(&L, &Soln, &Rhs, c->slobc, c->shibc, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
+            for (int d = 0; d < 3; ++d) { reg_fine_add(c, c->reg_visc, &fl[d], d, 0, sigma, 1, dt); orc_free(&fl[d]); }   /* NavierStokes.cpp:1630-1638 */
+        } else orc_abec_solve(&L, &Soln, &Rhs, slobc, shibc, c->p.visc_tol, c->p.visc_tol * m, &so, &st);
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-            A4(&c->Ssync, i, j, k, Tracer - 3) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);
+            A4(&c->Ssync, i, j, k, sn) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);
         for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
         orc_free(&Rhs); orc_free(&Soln); orc_free(&acoef); orc_free(&cfb);
     } else {
         const size_t N = orc_npts(&c->Ssync);
-        for (size_t q = 0; q < N; ++q) c->Ssync.p[q + N * (Tracer - 3)] *= dt;
+        for (size_t q = 0; q < N; ++q) c->Ssync.p[q + N * sn] *= dt;
     }
-    if (cons_trac)
-        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Ssync, i, j, k, Tracer - 3) += dt * A4(&Delta, i, j, k, 0);
+    if (c->scal_cons[sn])
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&c->Ssync, i, j, k, sn) += dt * A4(&Delta, i, j, k, sn);
+    }
     orc_free(&Delta);
     for (int n = 0; n < numscal; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(Sn, i, j, k, 3 + n) += A4(&c->Ssync, i, j, k, n);
@@ -1092,14 +1099,14 @@ orc_amr* orc_amr_create(const orc_geom* g0, const orc_ns_params* p, const orc_mg
             s->rho_avg = orc_alloc(g.n, ORC_CELL, 1, 1); s->p_avg = orc_alloc(g.n, ORC_NODE, 0, 1);
             const orc_geom* cg = &s->crse->g;
             for (int d = 0; d < 3; ++d) {
-                s->reg_adv[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
-                s->reg_visc[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
+                s->reg_adv[d] = orc_alloc(cg->n, ORC_FACE[d], 0, s->nstate);
+                s->reg_visc[d] = orc_alloc(cg->n, ORC_FACE[d], 0, s->nstate);
                 s->reg_mac[d] = orc_alloc(cg->n, ORC_FACE[d], 0, 1);
             }
             s->sync_reg = orc_alloc(cg->n, ORC_NODE, 0, 1);
             s->sync_lit = orc_syncreg_create(s->nbox, s->boxes, s->ratio);
             s->crse->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3);
-            s->crse->Ssync = orc_alloc(cg->n, ORC_CELL, 1, NUM_STATE - 3);
+            s->crse->Ssync = orc_alloc(cg->n, ORC_CELL, 1, s->nstate - 3);
         }
     }
     return a;
@@ -1160,6 +1167,35 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
             vv[l] = orc_alloc(g->n, ORC_CELL, 1, 3);
             { const size_t N = orc_npts(&vv[l]); for (size_t q = 0; q < N; ++q) vv[l].p[q + 2 * N] = p->gravity; }
             vel[l] = &vv[l]; phi[l] = P_NEW(s); sigp[l] = &sig[l];
+        }
+        /* set_outflow_bcs(INITIAL_PRESS, c_lev = 0 .. f_lev; Projection.cpp:893-905, 1776-1803): the finest level that covers the whole
+         * strip of an outflow face computes the hydrostatic data, putDown (:1656-1712) injects them into the coarser levels.  With one
+         * outflow face or none this is: finest covering level first, injection below it */
+        {
+            int done = 0;
+            for (int l = nl - 1; l >= 0; --l) {
+                orc_ns_state* s = a->lev[l];
+                const orc_geom* g = &s->g;
+                if (!done) {
+                    orc_fab rho = ns_fillpatch_time(s, s->st_new, 0, Density, 1, 1);
+                    orc_fab mark = orc_alloc(g->n, ORC_NODE, 1, 1);
+                    orc_setval(&mark, -7.e33);
+                    ns_set_outflow_bcs(s, &mark, &rho);
+                    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
+                        if (A4(&mark, i, j, k, 0) != -7.e33) { A4(phi[l], i, j, k, 0) = A4(&mark, i, j, k, 0); done = 1; }
+                    orc_free(&rho); orc_free(&mark);
+                } else {
+                    const orc_ns_state* f = a->lev[l + 1];
+                    const int r = f->ratio;
+                    for (int D = 0; D < 2; ++D) for (int side = 0; side < 2; ++side) {
+                        if (g->periodic[D] || (side == 0 ? s->p.phys_lo[D] : s->p.phys_hi[D]) != 2 /*Outflow*/) continue;
+                        for (int k = 0; k <= g->n[2]; ++k) for (int t = 0; t <= g->n[1 - D]; ++t) {
+                            int q[3]; q[D] = side == 0 ? 0 : g->n[D]; q[1 - D] = t; q[2] = k;
+                            A4(phi[l], q[0], q[1], q[2], 0) = A4(phi[l + 1], q[0] * r, q[1] * r, q[2] * r, 0);
+                        }
+                    }
+                }
+            }
         }
         amr_composite_project(a, 0, nl, vel, phi, sigp, NULL, p->proj_tol, p->proj_abs_tol, 0, 0.0, &a->lev[0]->st_nodal);
         for (int l = 0; l < nl; ++l) {
@@ -1283,13 +1319,13 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
         s->rho_avg = orc_alloc(g.n, ORC_CELL, 1, 1); s->p_avg = orc_alloc(g.n, ORC_NODE, 0, 1);
         const orc_geom* cg = &c->g;
         for (int d = 0; d < 3; ++d) {
-            s->reg_adv[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
-            s->reg_visc[d] = orc_alloc(cg->n, ORC_FACE[d], 0, NUM_STATE);
+            s->reg_adv[d] = orc_alloc(cg->n, ORC_FACE[d], 0, s->nstate);
+            s->reg_visc[d] = orc_alloc(cg->n, ORC_FACE[d], 0, s->nstate);
             s->reg_mac[d] = orc_alloc(cg->n, ORC_FACE[d], 0, 1);
         }
         s->sync_reg = orc_alloc(cg->n, ORC_NODE, 0, 1);
         s->sync_lit = orc_syncreg_create(s->nbox, s->boxes, s->ratio);
-        if (!c->Vsync.p) { c->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3); c->Ssync = orc_alloc(cg->n, ORC_CELL, 1, NUM_STATE - 3); }
+        if (!c->Vsync.p) { c->Vsync = orc_alloc(cg->n, ORC_CELL, 1, 3); c->Ssync = orc_alloc(cg->n, ORC_CELL, 1, c->nstate - 3); }
         /* times */
         const double dt_new = ol ? a->dt_level[l] : a->dt_level[l - 1] / (double)ratio;
         const double dt_old = ol ? ol->st_new - ol->st_old : (c->st_new - c->st_old) / (double)ratio;
@@ -1309,7 +1345,8 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
             else { orc_fab none = orc_alloc(g.n, ORC_CELL, 0, 1); src.cov = none; src.nbox = 0; src.st_new = cur_time; src.st_old = cur_time - dt_old; }
             src.crse = c;
             orc_fab Sv = ns_fillpatch_time(&src, cur_time, 0, Xvel, 3, 1);
-            orc_fab Sd = ns_fillpatch_time(&src, cur_time, 0, Density, 1, 1), St = ns_fillpatch_time(&src, cur_time, 0, Tracer, 1, 1);
+            orc_fab Sq[ORC_MAXSCAL];
+            for (int n = 0; n < s->nscal; ++n) Sq[n] = ns_fillpatch_time(&src, cur_time, 0, Density + n, 1, 1);
             const double tp = 0.5 * (s->pt_new[0] + s->pt_new[1]);
             orc_fab Gv = ns_fillpatch_time(&src, ol ? 0.5 * (ol->pt_new[0] + ol->pt_new[1]) : tp, 1, 0, 3, 1);
             for (int q = 0; q < 2; ++q) {
@@ -1318,12 +1355,11 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
                     A4(&s->S[q], i, j, k, n) = A4(&Sv, i, j, k, n);
                     A4(&s->Gp[q], i, j, k, n) = A4(&Gv, i, j, k, n);
                 }
-                for (int k = -1; k <= g.n[2]; ++k) for (int j = -1; j <= g.n[1]; ++j) for (int i = -1; i <= g.n[0]; ++i) {
-                    A4(&s->S[q], i, j, k, Density) = A4(&Sd, i, j, k, 0);
-                    A4(&s->S[q], i, j, k, Tracer) = A4(&St, i, j, k, 0);
-                }
+                for (int n = 0; n < s->nscal; ++n)
+                for (int k = -1; k <= g.n[2]; ++k) for (int j = -1; j <= g.n[1]; ++j) for (int i = -1; i <= g.n[0]; ++i)
+                    A4(&s->S[q], i, j, k, Density + n) = A4(&Sq[n], i, j, k, 0);
             }
-            orc_free(&Sv); orc_free(&Sd); orc_free(&St); orc_free(&Gv);
+            orc_free(&Sv); for (int n = 0; n < s->nscal; ++n) orc_free(&Sq[n]); orc_free(&Gv);
             if (!ol) orc_free(&src.cov);
             /* pressure: node_bilinear_interp of the coarse pressure on every node of the new level, then the old level's nodes */
             const orc_fab* Pc = P_NEW(c);

@@ -22,7 +22,7 @@
  *   Diffusion::getViscTerms (scalars)      Source/Diffusion.cpp:1539-1652
  *   physical BC tables                     Source/NS_BC.H:7-55, Source/NS_setup.cpp:21-128, Source/NS_bcfill.H:17-180
  * Scope: one level; each direction periodic or bounded by SlipWall / NoSlipWall (moving walls through
- * xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, no divu, NUM_STATE = 5
+ * xlo.velocity ... zhi.velocity); constant viscosity / tracer diffusivity, no divu; nstate = 5 + do_trac2 + do_temp
  * (u,v,w,rho,tracer), do_mom_diff = 0 or 1, Godunov_PLM.
  */
 #include "orc_ns_int.h"
@@ -36,9 +36,10 @@ void orc_ns_default_params(orc_ns_params* p)
     p->init_dt = -1.0; p->tracer_diff_coef = 0.0;
     for (int d = 0; d < 3; ++d) p->phys_lo[d] = p->phys_hi[d] = 0;
     for (int q = 0; q < 9; ++q) p->wall_vel_lo[q] = p->wall_vel_hi[q] = 0.0;
-    for (int q = 0; q < 6; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
+    for (int q = 0; q < 12; ++q) p->scal_bc_lo[q] = p->scal_bc_hi[q] = 0.0;
     p->do_cons_trac = 0;
     p->do_denminmax = 0; p->do_scalminmax = 0;
+    p->do_trac2 = 0; p->do_cons_trac2 = 0; p->tracer2_diff_coef = 0.0; p->do_temp = 0; p->temp_cond_coef = 0.0;
     p->use_ppm = 0;
 }
 
@@ -58,6 +59,12 @@ static int scal_bctype(int phys)
     if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
     if (phys == PHYS_SYMMETRY) return ORC_BC_REFLECT_EVEN;
     return phys == PHYS_INFLOW ? ORC_BC_EXT_DIR : ORC_BC_FOEXTRAP;
+}
+static int temp_bctype(int phys)             /* temp_bc, Source/NS_BC.H:37-40 */
+{
+    if (phys == PHYS_INTERIOR) return ORC_BC_INT_DIR;
+    if (phys == PHYS_INFLOW) return ORC_BC_EXT_DIR;
+    return phys == PHYS_OUTFLOW ? ORC_BC_HOEXTRAP : ORC_BC_REFLECT_EVEN;
 }
 static int gp_bctype(int phys, int normal)   /* norm/tang_gradp_bc */
 {
@@ -79,13 +86,23 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
 {
     orc_ns_state* s = (orc_ns_state*)calloc(1, sizeof(orc_ns_state));
     s->g = *g; s->p = *p; s->o = *o;
+    /* NavierStokes::Initialize (NavierStokes.cpp:43-55): Density, Tracer, [Tracer2], [Temp] */
+    s->nstate = Tracer + 1; s->Tracer2 = -1; s->Temp = -1;
+    if (p->do_trac2) s->Tracer2 = s->nstate++;
+    if (p->do_temp) s->Temp = s->nstate++;
+    s->nscal = s->nstate - Density;
+    for (int n = 0; n < ORC_MAXSCAL; ++n) { s->scal_cons[n] = 0; s->scal_rho_flag[n] = 1; s->scal_diff[n] = 0.0; }
+    s->scal_cons[0] = 1; s->scal_diff[0] = -1.0;                                  /* density: conservative, never diffusive (NS_setup.cpp:303, NavierStokes.cpp:291) */
+    s->scal_cons[1] = p->do_cons_trac != 0; s->scal_rho_flag[1] = p->do_cons_trac ? 2 : 0; s->scal_diff[1] = p->tracer_diff_coef;   /* NS_setup.cpp:304-310 */
+    if (p->do_trac2) { const int n = s->Tracer2 - Density; s->scal_cons[n] = p->do_cons_trac2 != 0; s->scal_rho_flag[n] = p->do_cons_trac2 ? 2 : 0; s->scal_diff[n] = p->tracer2_diff_coef; }
+    if (p->do_temp) { const int n = s->Temp - Density; s->scal_cons[n] = 0; s->scal_rho_flag[n] = 1; s->scal_diff[n] = p->temp_cond_coef; }   /* NS_setup.cpp:302, default RhoInverse_Laplacian_S */
     for (int q = 0; q < 2; ++q) {
-        s->S[q] = orc_alloc(g->n, ORC_CELL, 1, NUM_STATE);
+        s->S[q] = orc_alloc(g->n, ORC_CELL, 1, s->nstate);
         s->P[q] = orc_alloc(g->n, ORC_NODE, 1, 1);
         s->Gp[q] = orc_alloc(g->n, ORC_CELL, 1, 3);
     }
     for (int d = 0; d < 3; ++d) { s->umac[d] = orc_alloc(g->n, ORC_FACE[d], 1, 1); orc_setval(&s->umac[d], 1.e40); }
-    s->aofs = orc_alloc(g->n, ORC_CELL, 0, NUM_STATE);
+    s->aofs = orc_alloc(g->n, ORC_CELL, 0, s->nstate);
     s->rho_ptime = orc_alloc(g->n, ORC_CELL, 1, 1);
     s->rho_ctime = orc_alloc(g->n, ORC_CELL, 1, 1);
     s->rho_half = orc_alloc(g->n, ORC_CELL, 1, 1);
@@ -100,10 +117,6 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
             fprintf(stderr, "orc_ns_create: non-periodic direction %d needs Inflow(1)/Outflow(2)/Symmetry(3)/SlipWall(4)/NoSlipWall(5) on both sides\n", d);
             free(s); return NULL;
         }
-        if ((plo == PHYS_OUTFLOW || phi_ == PHYS_OUTFLOW) && p->gravity != 0.0) {
-            fprintf(stderr, "orc_ns_create: outflow with gravity (hydrostatic outflow pressure, do_outflow_bcs) is not restated\n");
-            free(s); return NULL;
-        }
         /* MacProj::set_mac_solve_bc (Source/MacProj.cpp:1187-1208): outflow Dirichlet, everything else Neumann;
          * Projection.cpp:2434-2464: outflow Dirichlet, inflow "inflow", everything else Neumann */
         s->lobc[d] = g->periodic[d] ? ORC_LO_PERIODIC : (plo == PHYS_OUTFLOW ? ORC_LO_DIRICHLET : ORC_LO_NEUMANN);
@@ -116,11 +129,12 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
             s->ed_vel_lo[n * 3 + d] = p->wall_vel_lo[d * 3 + n]; s->ed_vel_hi[n * 3 + d] = p->wall_vel_hi[d * 3 + n];
             s->vlobc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].lo[d]); s->vhibc[n * 3 + d] = linop_of_bctype(s->bc_vel[n].hi[d]);
         }
-        for (int n = 0; n < 2; ++n) {
-            s->bc_scal[n].lo[d] = scal_bctype(plo); s->bc_scal[n].hi[d] = scal_bctype(phi_);
-            s->ed_scal_lo[n * 3 + d] = p->scal_bc_lo[d * 2 + n]; s->ed_scal_hi[n * 3 + d] = p->scal_bc_hi[d * 2 + n];
+        for (int n = 0; n < s->nscal; ++n) {
+            const int is_temp = Density + n == s->Temp;                            /* set_scalar_bc / set_temp_bc (NS_setup.cpp:263-283) */
+            s->bc_scal[n].lo[d] = is_temp ? temp_bctype(plo) : scal_bctype(plo); s->bc_scal[n].hi[d] = is_temp ? temp_bctype(phi_) : scal_bctype(phi_);
+            s->ed_scal_lo[n * 3 + d] = p->scal_bc_lo[d * 4 + n]; s->ed_scal_hi[n * 3 + d] = p->scal_bc_hi[d * 4 + n];
+            s->slobc[n * 3 + d] = linop_of_bctype(s->bc_scal[n].lo[d]); s->shibc[n * 3 + d] = linop_of_bctype(s->bc_scal[n].hi[d]);
         }
-        s->slobc[d] = linop_of_bctype(s->bc_scal[1].lo[d]); s->shibc[d] = linop_of_bctype(s->bc_scal[1].hi[d]);
     }
     return s;
 }
@@ -191,6 +205,7 @@ void orc_ns_init_rayleightaylor(orc_ns_state* s, double rho_1, double rho_2, dou
         const double pertheight = splitz - pertamp * pert;
         A4(S, i, j, k, Density) = rho_1 + ((rho_2 - rho_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
         A4(S, i, j, k, Tracer) = tra_1 + ((tra_2 - tra_1) / 2.0) * (1.0 + tanh((z - pertheight) / interface_width));
+        for (int nt = Tracer + 1; nt < s->nstate; ++nt) A4(S, i, j, k, nt) = 1.0;      /* prob_init.cpp:482-485 */
     }
     orc_setval(P_NEW(s), 0.0); orc_setval(P_OLD(s), 0.0);
     orc_setval(GP_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0);
@@ -211,6 +226,7 @@ void orc_ns_init_taylorgreen(orc_ns_state* s, double vfac, double a, double b, d
         A4(S, i, j, k, 2) = 0.0;
         A4(S, i, j, k, Density) = rho0;
         A4(S, i, j, k, Tracer) = (rho0 * vfac * vfac / 16.0) * (2.0 + cos(2.0 * c * TwoPi * z)) * (cos(2.0 * a * TwoPi * x) + cos(2.0 * b * TwoPi * y));
+        for (int nt = Tracer + 1; nt < s->nstate; ++nt) A4(S, i, j, k, nt) = 1.0;      /* prob_init.cpp:555-558 */
     }
     orc_setval(P_NEW(s), 0.0); orc_setval(P_OLD(s), 0.0);
     orc_setval(GP_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0);
@@ -363,7 +379,7 @@ static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int 
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&f, i, j, k, n) = A4(src, i, j, k, sc + n);
     orc_fill_periodic(&f, g, ORC_CELL);
-    const int is_scal = (bc >= s->bc_scal && bc < s->bc_scal + 2);
+    const int is_scal = (bc >= s->bc_scal && bc < s->bc_scal + ORC_MAXSCAL);
     const long so = is_scal ? 3 * (bc - s->bc_scal) : 0;
     if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : (is_scal ? s->ed_scal_lo + so : NULL),
                                is_vel ? s->ed_vel_hi : (is_scal ? s->ed_scal_hi + so : NULL));
@@ -428,7 +444,7 @@ static void first_order_extrap(orc_fab* f, const orc_geom* g)
     }
 }
 
-static int is_diffusive_tracer(const orc_ns_state* s) { return s->p.tracer_diff_coef > 0.0; }
+static int is_diffusive_scal(const orc_ns_state* s, int comp) { return s->scal_diff[comp - Density] > 0.0; }
 
 /* ---- refined levels: coarse data of the coarse/fine boundary conditions and the C/F part of FirstOrderExtrap ---- */
 void orc_tensor_apply_cf(const orc_geom* g, int nbox, const int* boxes, int ratio, orc_fab* y, orc_fab* u, double alpha, double beta,
@@ -445,9 +461,9 @@ void orc_abec_solve_cf(const orc_abec_level* L, orc_fab* phi, const orc_fab* rhs
                        const orc_fab* cf_bcval, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 /* the coarse level's data at time t (FillPatch of the coarse level, 1 ghost cell): the crsedata of Diffusion.cpp:733-744, 1725-1736 */
 static orc_fab crse_vel_at(const orc_ns_state* s, double t) { return ns_fillpatch_time(s->crse, t, 0, Xvel, 3, 1); }
-static orc_fab crse_tracer_at(const orc_ns_state* s, double t, int over_rho)
+static orc_fab crse_scalar_at(const orc_ns_state* s, double t, int comp, int over_rho)
 {
-    orc_fab c = ns_fillpatch_time(s->crse, t, 0, Tracer, 1, 1);
+    orc_fab c = ns_fillpatch_time(s->crse, t, 0, comp, 1, 1);
     if (over_rho) {
         orc_fab r = ns_fillpatch_time(s->crse, t, 0, Density, 1, 1);
         const size_t N = orc_npts(&c);
@@ -485,41 +501,43 @@ static void first_order_extrap_cf(const orc_ns_state* s, orc_fab* f)
     orc_fill_periodic(f, g, ORC_CELL);
 }
 
-/* the (constant-coefficient) scalar diffusion operator of the tracer: MLABecLaplacian with b = diffusivity on faces */
-void ns_tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a)
+/* the (constant-coefficient) scalar diffusion operator of state component comp: MLABecLaplacian with b = diffusivity on faces */
+void ns_scalar_level(const orc_ns_state* s, orc_abec_level* L, int comp, double alpha, double beta, const orc_fab* a)
 {
     memset(L, 0, sizeof(*L));
     L->g = s->g; L->alpha = alpha; L->beta = beta; L->ncomp = 1; L->tensor = 0;
     if (a) L->a = *a; else L->a.p = NULL;
-    for (int d = 0; d < 3; ++d) { L->b[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&L->b[d], s->p.tracer_diff_coef); }
+    for (int d = 0; d < 3; ++d) { L->b[d] = orc_alloc(s->g.n, ORC_FACE[d], 0, 1); orc_setval(&L->b[d], s->scal_diff[comp - Density]); }
 }
 
-/* NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0: Laplacian_S): visc = div(beta grad S(time));
- * called at the old time only (Sdata = S_old, get_rho(time) = rho_ptime) */
-void ns_get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata)
+/* NavierStokes::getViscTerms for one scalar (Diffusion::getViscTerms, Diffusion.cpp:1540-1650): visc = div(beta grad S(time)),
+ * rho_flag 2 (Laplacian_SoverRho): of S / rho; called at the old time only (Sdata = S_old, get_rho(time) = rho_ptime) */
+void ns_get_visc_terms_scalar(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata, int comp)
 {
     const orc_geom* g = &s->g;
+    const int sn = comp - Density, over_rho = s->scal_rho_flag[sn] == 2;
+    const int* slobc = s->slobc + 3 * sn; const int* shibc = s->shibc + 3 * sn;
     orc_setval(visc, 1.e40);
-    if (!is_diffusive_tracer(s)) { orc_setval(visc, 0.0); return; }
-    orc_fab stmp = fillpatch(s, Sdata, Tracer, 1, 1, &s->bc_scal[1]);
-    if (s->p.do_cons_trac) {    /* rho_flag 2 (Diffusion.cpp:1612-1615): evaluate div beta grad(S/rho), rho = get_rho(time) incl. the ghost cells */
+    if (!is_diffusive_scal(s, comp)) { orc_setval(visc, 0.0); return; }
+    orc_fab stmp = fillpatch(s, Sdata, comp, 1, 1, &s->bc_scal[sn]);
+    if (over_rho) {             /* rho_flag 2 (Diffusion.cpp:1612-1615): evaluate div beta grad(S/rho), rho = get_rho(time) incl. the ghost cells */
         const size_t N = orc_npts(&stmp);
         for (size_t q = 0; q < N; ++q) stmp.p[q] /= s->rho_ptime.p[q];
     }
     orc_abec_level L;
-    ns_tracer_level(s, &L, 0.0, -1.0, NULL);
+    ns_scalar_level(s, &L, comp, 0.0, -1.0, NULL);
     orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
     orc_copy_all(&bcval, &stmp);
     orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->level > 0) {                         /* mlabec.setCoarseFineBC(&crsedata, ratio), Diffusion.cpp:1600-1609 */
         L.nbox = s->nbox; L.boxes = s->boxes;
         for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
-        orc_fab cd = crse_tracer_at(s, time_of(s, Sdata), s->p.do_cons_trac);
+        orc_fab cd = crse_scalar_at(s, time_of(s, Sdata), comp, over_rho);
         orc_cf_interp_bndry(&L, s->ratio, &cd, &cfb);
         orc_free(&cd);
         orc_cf_set_bcval(&cfb, 1, 2);
     }
-    orc_abec_applybc(&L, &stmp, s->slobc, s->shibc, 2, 1, &bcval);
+    orc_abec_applybc(&L, &stmp, slobc, shibc, 2, 1, &bcval);
     orc_fab tmp = orc_alloc(g->n, ORC_CELL, 0, 1);
     orc_abec_apply(&L, &tmp, &stmp);
     orc_cf_set_bcval(NULL, 0, 2);
@@ -727,7 +745,7 @@ static double predict_velocity(orc_ns_state* s, double dt)
     double tempdt = cflmax == 0 ? s->p.change_max : fmin(s->p.change_max, s->p.cfl / cflmax);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
-    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, s->nscal, 3, s->bc_scal);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
     const orc_fab* Gp = GP_OLD(s);
     for (int n = 0; n < 3; ++n)
@@ -869,7 +887,7 @@ static void velocity_advection(orc_ns_state* s, double dt)
         for (int n = 0; n < 3; ++n) for (size_t q = 0; q < N; ++q) Umf.p[q + N * n] *= Rmf.p[q];
         orc_free(&Rmf);
     }
-    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, s->nscal, 1, s->bc_scal);
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
@@ -896,26 +914,28 @@ static void scalar_advection(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
     orc_godunov_set_ppm(s->p.use_ppm);
-    orc_fab Smf = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 3, s->bc_scal);
+    orc_fab Smf = fillpatch(s, S_OLD(s), Density, s->nscal, 3, s->bc_scal);
     floor_small(&Smf);
-    orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, NUM_SCALARS);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
+    orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, s->nscal);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
     orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
-    int iconserv[2] = {1, s->p.do_cons_trac ? 1 : 0};   /* density conservative; tracer: NS_setup.cpp:304-310 */
+    int iconserv[ORC_MAXSCAL];                          /* advectionType, NS_setup.cpp:297-320 */
+    for (int n = 0; n < s->nscal; ++n) iconserv[n] = s->scal_cons[n];
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
-    if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_tracer(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
-    for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
-        double rho = A4(&Smf, i, j, k, 0);
-        A4(&tf, i, j, k, 0) += 0.0;                                /* conservative: tf += visc (density: not diffusive) */
-        if (s->p.do_cons_trac) A4(&tf, i, j, k, 1) += A4(&visc, i, j, k, 0);         /* NavierStokes.cpp:780-792 */
-        else
-        A4(&tf, i, j, k, 1) = A4(&tf, i, j, k, 1) / rho + A4(&visc, i, j, k, 0);    /* convective: tf/rho + visc */
+    for (int n = 1; n < s->nscal; ++n) {                /* n = 0: density, tf += visc = 0 */
+        if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_scalar(s, &visc, S_OLD(s), Density + n); else orc_setval(&visc, 0.0);
+        for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
+            const double rho = A4(&Smf, i, j, k, 0);
+            if (Density + n == s->Temp) A4(&tf, i, j, k, n) = (A4(&tf, i, j, k, n) + A4(&visc, i, j, k, 0)) / rho;   /* NavierStokes.cpp:766-778 */
+            else if (s->scal_cons[n]) A4(&tf, i, j, k, n) += A4(&visc, i, j, k, 0);                                   /* :780-792 */
+            else A4(&tf, i, j, k, n) = A4(&tf, i, j, k, n) / rho + A4(&visc, i, j, k, 0);                              /* :794-806: convective, tf/rho + visc */
+        }
     }
     orc_free(&visc);
     orc_fab* um[3] = {&s->umac[0], &s->umac[1], &s->umac[2]};
     orc_fab fl[3]; orc_fab* flp[3];
-    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, NUM_SCALARS); flp[d] = &fl[d]; }
-    orc_compute_aofs(g, &s->aofs, Density, &Smf, NUM_SCALARS, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, flp);
-    adv_registers(s, flp, Density, NUM_SCALARS, dt);
+    for (int d = 0; d < 3; ++d) { fl[d] = orc_alloc(g->n, ORC_FACE[d], 0, s->nscal); flp[d] = &fl[d]; }
+    orc_compute_aofs(g, &s->aofs, Density, &Smf, s->nscal, &tf, &divu, um, iconserv, dt, s->bc_scal, 0, s->p.use_forces_in_trans, NULL, flp);
+    adv_registers(s, flp, Density, s->nscal, dt);
     for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
     orc_free(&Smf); orc_free(&tf); orc_free(&divu);
 }
@@ -927,7 +947,7 @@ static void scal_min_max(orc_ns_state* s, int comp, int conservative)
 {
     const orc_geom* g = &s->g;
     orc_fab* Sn = S_NEW(s);
-    orc_fab So = fillpatch(s, S_OLD(s), Density, NUM_SCALARS, 1, s->bc_scal);       /* FillPatchIterator(S_old, 1, prev_time, Density, num_scalars) */
+    orc_fab So = fillpatch(s, S_OLD(s), Density, s->nscal, 1, s->bc_scal);       /* FillPatchIterator(S_old, 1, prev_time, Density, num_scalars) */
     const int oc = comp - Density;
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         if (s->cov.p && A4(&s->cov, i, j, k, 0) == 0.0) continue;
@@ -961,25 +981,30 @@ static void scalar_update_tracers(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
     orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
-    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
-        double rho = A4(So, i, j, k, Density) - 0.5 * dt * A4(&s->aofs, i, j, k, Density);
-        double tf = 0.0;
-        if (s->p.do_cons_trac) A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf);   /* NavierStokesBase.cpp:2889-2891 */
-        else
-        A4(Sn, i, j, k, Tracer) = A4(So, i, j, k, Tracer) + dt * (-A4(&s->aofs, i, j, k, Tracer) + tf / rho);
+    for (int sigma = Tracer; sigma < s->nstate; ++sigma) {
+        const int cons = s->scal_cons[sigma - Density];
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+            double rho = A4(So, i, j, k, Density) - 0.5 * dt * A4(&s->aofs, i, j, k, Density);
+            double tf = 0.0;
+            if (cons) A4(Sn, i, j, k, sigma) = A4(So, i, j, k, sigma) + dt * (-A4(&s->aofs, i, j, k, sigma) + tf);   /* NavierStokesBase.cpp:2889-2891 */
+            else
+            A4(Sn, i, j, k, sigma) = A4(So, i, j, k, sigma) + dt * (-A4(&s->aofs, i, j, k, sigma) + tf / rho);
+        }
+        if (s->p.do_scalminmax) scal_min_max(s, sigma, cons);                           /* :2907-2935 */
     }
-    if (s->p.do_scalminmax) scal_min_max(s, Tracer, s->p.do_cons_trac);                 /* :2907-2935 */
 }
 
 /* NavierStokes::scalar_diffusion_update -> Diffusion::diffuse_scalar for the tracer (rho_flag 0, Laplacian_S;
  * reference Source/NavierStokes.cpp:867-1000, Source/Diffusion.cpp:207-599): Crank-Nicolson
  *   (1 - theta dt div beta grad) S_new = S* + (1-theta) dt div beta grad S_old */
-static void scalar_diffusion_update(orc_ns_state* s, double dt)
+static void scalar_diffusion_update_one(orc_ns_state* s, double dt, int sigma)
 {
     const orc_geom* g = &s->g;
-    if (!is_diffusive_tracer(s)) return;
+    if (!is_diffusive_scal(s, sigma)) return;
     const double theta = s->p.be_cn_theta;
-    const int cons = s->p.do_cons_trac;     /* diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308, Diffusion.cpp:1870-1873) */
+    const int sn = sigma - Density, rho_flag = s->scal_rho_flag[sn];
+    const int cons = rho_flag == 2;         /* diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308, Diffusion.cpp:1870-1873) */
+    const int* slobc = s->slobc + 3 * sn; const int* shibc = s->shibc + 3 * sn;
     orc_fab *Sn = S_NEW(s), *So = S_OLD(s);
     orc_fab Rhs = orc_alloc(g->n, ORC_CELL, 0, 1);
     const int want_flux = s->fine != NULL || s->level > 0;        /* viscous flux registers, NavierStokes.cpp:949-990 */
@@ -988,7 +1013,7 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
     orc_fab cfb = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (theta != 1.0) {
         /* FillPatch(S_old, ng 1) then opn.setLevelBC(Soln = S_old tracer with ghosts); a = 0, b = -(1-theta) dt */
-        orc_fab Soln = fillpatch(s, So, Tracer, 1, 1, &s->bc_scal[1]);
+        orc_fab Soln = fillpatch(s, So, sigma, 1, 1, &s->bc_scal[sn]);
         if (cons) {             /* Diffusion.cpp:396-413: Soln = S_old / rho_old on the grown box */
             orc_fab R = fillpatch(s, So, Density, 1, 1, &s->bc_scal[0]);
             const size_t N = orc_npts(&Soln);
@@ -998,16 +1023,16 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
         orc_fab bcval = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_copy_all(&bcval, &Soln);
         orc_abec_level Ln;
-        ns_tracer_level(s, &Ln, 0.0, -(1.0 - theta) * dt, NULL);
+        ns_scalar_level(s, &Ln, sigma, 0.0, -(1.0 - theta) * dt, NULL);
         if (s->level > 0) {                     /* opn.setCoarseFineBC(Solnc = coarse S_old (/ rho_old), ratio), Diffusion.cpp:376-396 */
             Ln.nbox = s->nbox; Ln.boxes = s->boxes;
             for (int d = 0; d < 3; ++d) Ln.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
-            orc_fab cd = crse_tracer_at(s, s->st_old, cons);
+            orc_fab cd = crse_scalar_at(s, s->st_old, sigma, cons);
             orc_cf_interp_bndry(&Ln, s->ratio, &cd, &cfb);
             orc_free(&cd);
             orc_cf_set_bcval(&cfb, 1, 2);
         }
-        orc_abec_applybc(&Ln, &Soln, s->slobc, s->shibc, 2, 1, &bcval);
+        orc_abec_applybc(&Ln, &Soln, slobc, shibc, 2, 1, &bcval);
         orc_abec_apply(&Ln, &Rhs, &Soln);
         if (want_flux) orc_abec_extensive_flux(&Ln, flp, &Soln, 1.0 - theta, 0);     /* fluxn: computeExtensiveFluxes(..., -b/dt), Diffusion.cpp:437-438 */
         orc_cf_set_bcval(NULL, 0, 2);
@@ -1015,14 +1040,14 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
         orc_free(&Soln); orc_free(&bcval);
     }
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-        A4(&Rhs, i, j, k, 0) += A4(Sn, i, j, k, Tracer);
+        A4(&Rhs, i, j, k, 0) += A4(Sn, i, j, k, sigma) * (rho_flag == 1 ? A4(&s->rho_half, i, j, k, 0) : 1.0);   /* Diffusion.cpp:476-486 */
     double m = 0.0;     /* get_scaled_abs_tol: visc_tol * ||Rhs||inf (one component) */
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
         if (s->level > 0 && A4(&s->cov, i, j, k, 0) == 0.0) continue;
         double v = fabs(A4(&Rhs, i, j, k, 0)); if (v > m) m = v;
     }
     const double tol_abs = s->p.visc_tol * m;
-    orc_fab Soln = fillpatch(s, Sn, Tracer, 1, 1, &s->bc_scal[1]);     /* FillPatch(S_new, ng 1): initial guess + level BC */
+    orc_fab Soln = fillpatch(s, Sn, sigma, 1, 1, &s->bc_scal[sn]);     /* FillPatch(S_new, ng 1): initial guess + level BC */
     orc_fab acoef = orc_alloc(g->n, ORC_CELL, 0, 1);
     orc_setval(&acoef, 1.0);                                            /* computeAlpha, rho_flag 0: alpha = 1 */
     if (cons) {                 /* rho_flag 2: Soln = S_new / rho_new on the grown box (Diffusion.cpp:520-540), alpha = rho_new (:1380-1383) */
@@ -1032,36 +1057,44 @@ static void scalar_diffusion_update(orc_ns_state* s, double dt)
         orc_free(&R);
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
             A4(&acoef, i, j, k, 0) = A4(Sn, i, j, k, Density);
+    } else if (rho_flag == 1) { /* RhoInverse_Laplacian_S: alpha = rho_half (Diffusion.cpp:551-556, computeAlpha :1380-1383) */
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&acoef, i, j, k, 0) = A4(&s->rho_half, i, j, k, 0);
     }
     orc_abec_level L;
-    ns_tracer_level(s, &L, 1.0, theta * dt, &acoef);
+    ns_scalar_level(s, &L, sigma, 1.0, theta * dt, &acoef);
     orc_mg_opts o = s->o; o.maxorder = 2;                                /* Diffusion::max_order = 2 */
     orc_mg_stats st;
     if (s->level > 0) {                         /* opnp1.setCoarseFineBC(coarse S_new (/ rho_new), ratio), Diffusion.cpp:506-518 */
         L.nbox = s->nbox; L.boxes = s->boxes;
         for (int d = 0; d < 3; ++d) L.cf_loc[d] = 0.5 * s->ratio * g->dx[d];
-        orc_fab cd = crse_tracer_at(s, s->st_new, cons);
+        orc_fab cd = crse_scalar_at(s, s->st_new, sigma, cons);
         orc_cf_interp_bndry(&L, s->ratio, &cd, &cfb);
         orc_free(&cd);
-        orc_abec_solve_cf(&L, &Soln, &Rhs, s->slobc, s->shibc, &cfb, s->p.visc_tol, tol_abs, &o, &st);
+        orc_abec_solve_cf(&L, &Soln, &Rhs, slobc, shibc, &cfb, s->p.visc_tol, tol_abs, &o, &st);
     } else
-    orc_abec_solve(&L, &Soln, &Rhs, s->slobc, s->shibc, s->p.visc_tol, tol_abs, &o, &st);
+    orc_abec_solve(&L, &Soln, &Rhs, slobc, shibc, s->p.visc_tol, tol_abs, &o, &st);
     s->st_scal = st;
     if (want_flux) {                            /* fluxnp1 = theta * area * (-D grad s_new), Diffusion.cpp:569-570; registers NavierStokes.cpp:949-990 */
         orc_cf_set_bcval(s->level > 0 ? &cfb : NULL, 1, 2);
         orc_abec_extensive_flux(&L, flp, &Soln, theta, 1);
         orc_cf_set_bcval(NULL, 0, 2);
         for (int d = 0; d < 3; ++d) {
-            if (s->level > 0) reg_fine_add(s, s->reg_visc, &fl[d], d, 0, Tracer, 1, dt);
-            if (s->fine) reg_crse_init(s->fine, s->fine->reg_visc, &fl[d], d, 0, Tracer, 1, -dt, 0);
+            if (s->level > 0) reg_fine_add(s, s->reg_visc, &fl[d], d, 0, sigma, 1, dt);
+            if (s->fine) reg_crse_init(s->fine, s->fine->reg_visc, &fl[d], d, 0, sigma, 1, -dt, 0);
         }
     }
     for (int d = 0; d < 3; ++d) orc_free(&fl[d]);
     orc_free(&cfb);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
-        A4(Sn, i, j, k, Tracer) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);    /* Diffusion.cpp:583-590 */
+        A4(Sn, i, j, k, sigma) = A4(&Soln, i, j, k, 0) * (cons ? A4(Sn, i, j, k, Density) : 1.0);    /* Diffusion.cpp:583-590 */
     for (int d = 0; d < 3; ++d) orc_free(&L.b[d]);
     orc_free(&Soln); orc_free(&acoef); orc_free(&Rhs);
+}
+
+static void scalar_diffusion_update(orc_ns_state* s, double dt)
+{
+    for (int sigma = Tracer; sigma < s->nstate; ++sigma) scalar_diffusion_update_one(s, dt, sigma);   /* NavierStokes.cpp:912-1000 */
 }
 
 static void velocity_advection_update(orc_ns_state* s, double dt)
@@ -1196,6 +1229,71 @@ static double node_interp(const orc_fab* c, int r, int i, int j, int k)
     return v;
 }
 
+/* Projection::set_outflow_bcs / set_outflow_bcs_at_level / computeRhoG (Projection.cpp:1721-2370), 3-D: hydrostatic pressure on the
+ * nodes of an outflow face when gravity != 0.  z-hi: zero (nothing to do); z-lo: upstream aborts; x / y faces: on every node column of
+ * the face, integrating down from the top,  rhog -= gravity * rhoExt * dz,  phi(node k) = rhog,  rhoExt = (3 rho1 - rho2) / 2
+ * extrapolated to the face from the first two cells inside it (rho1, rho2: means of the two cell columns next to the node column;
+ * at a domain edge of the face the density's BCRec decides: ext_dir the ghost column, foextrap the first column, hoextrap extrapolated).
+ * Applied only where the level covers the whole two-cell strip along the face (:1776-1803).  rho: 1 filled ghost cell.
+ * Upstream's y-hi branch differs from the other three as written: rho2 of the regular columns is the mean of rho(i, j-1) and
+ * rho(i-1, j-2) (:2303-2304), followed here; its ext_dir low-edge column reads outside the strip (:2317-2318), refused here. */
+void ns_set_outflow_bcs(const orc_ns_state* s, orc_fab* phi, const orc_fab* rho)
+{
+    const orc_geom* g = &s->g;
+    const double grav = s->p.gravity;
+    if (!(fabs(grav) > 0.0)) return;
+    const int nz = g->n[2];
+    const double dh = g->dx[2];
+    for (int D = 0; D < 3; ++D) for (int side = 0; side < 2; ++side) {
+        if (g->periodic[D] || (side == 0 ? s->p.phys_lo[D] : s->p.phys_hi[D]) != PHYS_OUTFLOW) continue;
+        if (D == 2) {
+            if (side == 1) continue;
+            fprintf(stderr, "orc set_outflow_bcs: outflow at the bottom with gravity (Projection::computeRhoG aborts)\n"); abort();
+        }
+        const int T = 1 - D, nD = g->n[D], nT = g->n[T];
+        /* the level must cover the whole strip (two cells deep) */
+        if (s->level > 0) {
+            int all = 1, any = 0;
+            for (int k = 0; k < nz && (all || !any); ++k) for (int t = 0; t < nT; ++t) for (int a = 1; a <= 2; ++a) {
+                int q[3]; q[D] = side == 0 ? a - 1 : nD - a; q[T] = t; q[2] = k;
+                if (A4(&s->cov, q[0], q[1], q[2], 0) != 0.0) any = 1; else all = 0;
+            }
+            if (!all) continue;
+        }
+#define RS(a, t, k) (D == 0 ? A4(rho, side == 0 ? (a) - 1 : nD - (a), (t), (k), 0) : A4(rho, (t), side == 0 ? (a) - 1 : nD - (a), (k), 0))
+        const int blo = s->bc_scal[0].lo[T], bhi = s->bc_scal[0].hi[T];
+        const int edge_lo = !g->periodic[T] && (blo == ORC_BC_EXT_DIR || blo == ORC_BC_HOEXTRAP || blo == ORC_BC_FOEXTRAP);
+        const int edge_hi = !g->periodic[T] && (bhi == ORC_BC_EXT_DIR || bhi == ORC_BC_HOEXTRAP || bhi == ORC_BC_FOEXTRAP);
+        const int yhi = (D == 1 && side == 1);
+        if (yhi && edge_lo && blo == ORC_BC_EXT_DIR) { fprintf(stderr, "orc set_outflow_bcs: y-hi outflow with x-lo inflow reads outside the strip upstream\n"); abort(); }
+        for (int t = 0; t <= nT; ++t) {
+            double rhog = 0.0;
+            for (int k = nz - 1; k >= 0; --k) {
+                double r1, r2;
+                if (t == 0 && edge_lo) {
+                    if (blo == ORC_BC_EXT_DIR) { r1 = RS(1, -1, k); r2 = RS(2, -1, k); }
+                    else if (blo == ORC_BC_HOEXTRAP) { r1 = 0.5 * (3. * RS(1, 0, k) - RS(1, 1, k)); r2 = 0.5 * (3. * RS(2, 0, k) - RS(2, 1, k)); }
+                    else { r1 = RS(1, 0, k); r2 = RS(2, 0, k); }
+                } else if (t == nT && edge_hi) {
+                    if (bhi == ORC_BC_EXT_DIR) { r1 = RS(1, nT, k); r2 = RS(2, nT, k); }
+                    else if (bhi == ORC_BC_HOEXTRAP) { r1 = 0.5 * (3. * RS(1, nT - 1, k) - RS(1, nT - 2, k)); r2 = 0.5 * (3. * RS(2, nT - 1, k) - RS(2, nT - 2, k)); }
+                    else { r1 = RS(1, nT - 1, k); r2 = RS(2, nT - 1, k); }
+                } else {
+                    r1 = 0.5 * (RS(1, t, k) + RS(1, t - 1, k));
+                    r2 = yhi ? 0.5 * (RS(1, t, k) + RS(2, t - 1, k)) : 0.5 * (RS(2, t, k) + RS(2, t - 1, k));
+                }
+                const double rhoExt = 0.5 * (3. * r1 - r2);
+                rhog -= grav * rhoExt * dh;
+                int q[3]; q[D] = side == 0 ? 0 : nD; q[T] = t; q[2] = k;
+                A4(phi, q[0], q[1], q[2], 0) = 0.0 + rhog;
+            }
+            int q[3]; q[D] = side == 0 ? 0 : nD; q[T] = t; q[2] = nz;
+            A4(phi, q[0], q[1], q[2], 0) = 0.0;
+        }
+#undef RS
+    }
+}
+
 /* Projection::level_project (Projection.cpp:166-450) */
 static void level_project(orc_ns_state* s, double dt)
 {
@@ -1232,6 +1330,7 @@ static void level_project(orc_ns_state* s, double dt)
     for (int n = 0; n < 3; ++n)
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(Un, i, j, k, n) += A4(Gp, i, j, k, n) / A4(&s->rho_half, i, j, k, 0);
+    ns_set_outflow_bcs(s, Pn, &s->rho_half);                     /* Projection.cpp:308-325 (LEVEL_PROJ) */
     /* scaleVar: sigma = 1/rho_half */
     orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
@@ -1322,6 +1421,11 @@ static void initial_pressure_project(orc_ns_state* s)
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab vel = orc_alloc(g->n, ORC_CELL, 1, 3);
     { const size_t N = orc_npts(&vel); for (size_t q = 0; q < N; ++q) vel.p[q + 2 * N] = s->p.gravity; }
+    {   /* Projection.cpp:855-905: sig = FillBoundary'ed + physical-BC'ed new density (1 ghost), set_outflow_bcs(INITIAL_PRESS) */
+        orc_fab rho = fillpatch(s, S_NEW(s), Density, 1, 1, &s->bc_scal[0]);
+        ns_set_outflow_bcs(s, P_NEW(s), &rho);
+        orc_free(&rho);
+    }
     nodal_project_level(s, &vel, P_NEW(s), &sig, 0, 0.0, 0);
     orc_copy_all(P_OLD(s), P_NEW(s));
     orc_copy_all(GP_OLD(s), GP_NEW(s));

@@ -10,7 +10,7 @@
 #define ORC_NS_INT_H
 #include "orc_int.h"
 
-enum { Xvel = 0, Density = 3, Tracer = 4, NUM_STATE = 5, NUM_SCALARS = 2 };
+enum { Xvel = 0, Density = 3, Tracer = 4, ORC_MAXSCAL = 4 };   /* Tracer2 / Temp: s->Tracer2 / s->Temp (-1: absent), NavierStokes.cpp:43-48 */
 
 struct orc_ns_state {
     orc_geom g;
@@ -30,11 +30,16 @@ struct orc_ns_state {
     orc_mg_stats st_mac, st_nodal, st_visc, st_scal;
     int lobc[3], hibc[3];          /* LinOp BC of the MAC projection: Neumann at walls / inflow, Dirichlet at outflow */
     int nlobc[3], nhibc[3];        /* nodal projection: the same with ORC_LO_INFLOW on inflow faces */
-    double ed_scal_lo[6], ed_scal_hi[6];   /* ext_dir (inflow) values [n*3+d] of density, tracer */
-    orc_bcrec bc_vel[3], bc_scal[2], bc_gp[3];
+    int nstate, nscal;             /* NUM_STATE, NUM_SCALARS = NUM_STATE - Density (NavierStokes.cpp:43-55) */
+    int Tracer2, Temp;             /* state components, -1 when ns.do_trac2 / ns.do_temp are off */
+    int scal_cons[ORC_MAXSCAL];    /* advectionType == Conservative (NS_setup.cpp:297-320) per scalar slot (0 = density) */
+    int scal_rho_flag[ORC_MAXSCAL];/* Diffusion::set_rho_flag(diffusionType): 0 Laplacian_S, 1 RhoInverse_Laplacian_S (Temp), 2 Laplacian_SoverRho */
+    double scal_diff[ORC_MAXSCAL]; /* visc_coef[Density + n] (<= 0: not diffusive) */
+    double ed_scal_lo[3 * ORC_MAXSCAL], ed_scal_hi[3 * ORC_MAXSCAL];   /* ext_dir (inflow) values [n*3+d] of density, tracer, ... */
+    orc_bcrec bc_vel[3], bc_scal[ORC_MAXSCAL], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];   /* ext_dir values [n*3+d] for the velocity fill */
     int vlobc[9], vhibc[9];        /* tensor-solve LinOp BC per velocity component [n*3+d] */
-    int slobc[3], shibc[3];        /* scalar-diffusion LinOp BC (tracer) */
+    int slobc[3 * ORC_MAXSCAL], shibc[3 * ORC_MAXSCAL];   /* scalar-diffusion LinOp BC [n*3+d] per scalar slot */
     /* ---- AMR (orc_amr.c) ---- */
     int level, ratio;              /* ratio to the next coarser level */
     struct orc_ns_state *crse, *fine;
@@ -46,8 +51,8 @@ struct orc_ns_state {
     double stop_time;              /* single-level driver (orc_ns_step): computeNewDt's stop_time clamp */
     orc_fab mac_phi;               /* MacProj::mac_phi_crse[level] */
     orc_fab rho_avg, p_avg;        /* level > 0 */
-    orc_fab Vsync, Ssync;          /* level < finest: 3 / NUM_STATE-3 comps, 1 ghost */
-    orc_fab reg_adv[3], reg_visc[3], reg_mac[3];   /* level > 0: coarse-level faces, NUM_STATE / NUM_STATE / 1 comps */
+    orc_fab Vsync, Ssync;          /* level < finest: 3 / nstate-3 comps, 1 ghost */
+    orc_fab reg_adv[3], reg_visc[3], reg_mac[3];   /* level > 0: coarse-level faces, nstate / nstate / 1 comps */
     orc_fab sync_reg;              /* level > 0: coarse-level nodes (single-valued restatement, orc_amr.c) */
     struct orc_syncreg* sync_lit;  /* level > 0: the literal box-by-box SyncRegister (orc_syncreg.c) */
     orc_fab sync_resid_crse;       /* scratch of the last level projection (coarse-level nodes), see ns_level_project */
@@ -73,11 +78,12 @@ double ns_advance(orc_ns_state* s, double dt, int iteration, int ncycle);
 double ns_est_time_step(orc_ns_state* s);
 void ns_make_rho_curr_time(orc_ns_state* s);
 void ns_fill_gp(orc_ns_state* s, orc_fab* G, double time);
+void ns_set_outflow_bcs(const orc_ns_state* s, orc_fab* phi, const orc_fab* rho);
 void ns_set_inflow_ghosts(const orc_ns_state* s, orc_fab* vel, double inflow_scale);
 /* NavierStokes::getViscTerms at the time of Sdata (S_OLD or S_NEW of the level), 1 filled ghost cell */
 void ns_get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata);
-void ns_get_visc_terms_tracer(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata);
-void ns_tracer_level(const orc_ns_state* s, orc_abec_level* L, double alpha, double beta, const orc_fab* a);
+void ns_get_visc_terms_scalar(const orc_ns_state* s, orc_fab* visc /*1 comp, 1 ghost*/, const orc_fab* Sdata, int comp);
+void ns_scalar_level(const orc_ns_state* s, orc_abec_level* L, int comp, double alpha, double beta, const orc_fab* a);
 
 /* ---- flux registers of the interface between level s (fine) and s->crse (orc_amr.c) ---- */
 /* side of coarse face f (direction d): 0 not a coarse/fine face, +1 the fine level is on the low side (the coarse cell outside is

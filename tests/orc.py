@@ -69,7 +69,8 @@ class CNsParams(C.Structure):
                 ("fixed_dt", C.c_double), ("nscal", C.c_int), ("verbose", C.c_int),
                 ("init_dt", C.c_double), ("tracer_diff_coef", C.c_double), ("phys_lo", C.c_int * 3), ("phys_hi", C.c_int * 3),
                 ("wall_vel_lo", C.c_double * 9), ("wall_vel_hi", C.c_double * 9),
-                ("scal_bc_lo", C.c_double * 6), ("scal_bc_hi", C.c_double * 6), ("do_cons_trac", C.c_int), ("do_denminmax", C.c_int), ("do_scalminmax", C.c_int), ("use_ppm", C.c_int)]
+                ("scal_bc_lo", C.c_double * 12), ("scal_bc_hi", C.c_double * 12), ("do_cons_trac", C.c_int), ("do_denminmax", C.c_int), ("do_scalminmax", C.c_int),
+                ("do_trac2", C.c_int), ("do_cons_trac2", C.c_int), ("tracer2_diff_coef", C.c_double), ("do_temp", C.c_int), ("temp_cond_coef", C.c_double), ("use_ppm", C.c_int)]
 
 
 PF = C.POINTER(CFab)

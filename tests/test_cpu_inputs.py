@@ -45,7 +45,7 @@ def test_inflow_outflow_keys():
     pr = Inputs([LDC], ["ns.lo_bc = 1 4 5", "ns.hi_bc = 2 4 5", "xlo.velocity = 1. 0. 0.", "xlo.density = 1.", "xlo.tracer = 0.25"]).problem()
     p = pr["params"]
     assert p["phys_lo"] == [1, 4, 5] and p["phys_hi"] == [2, 4, 5]
-    assert p["wall_vel_lo"][:3] == [1.0, 0.0, 0.0] and p["scal_bc_lo"][:2] == [1.0, 0.25] and p["scal_bc_hi"] == [0.0] * 6
+    assert p["wall_vel_lo"][:3] == [1.0, 0.0, 0.0] and p["scal_bc_lo"][:2] == [1.0, 0.25] and p["scal_bc_hi"] == [1.0, 0.0, 0.0, 0.0] * 3   # [d*4 + slot]; defaults: density 1, tracer 0 (NavierStokes.cpp:70-84)
 
 
 def test_rayleightaylor_keys():

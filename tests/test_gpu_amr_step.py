@@ -29,8 +29,8 @@ def _make(n0, fine_boxes, crse_split, params_kw, state_fn, finer=(), periodic=(1
         S = state_fn(*oa.cell_centres(l))
         oa.set_state(l, S)
         lev = amr.levels[l]
-        mf = L.MultiFab(lev.layout, L.CELL, 5, 1)
-        G = np.zeros(tuple(s + 2 for s in S.shape[:3]) + (5,), order="F")
+        mf = L.MultiFab(lev.layout, L.CELL, S.shape[-1], 1)
+        G = np.zeros(tuple(s + 2 for s in S.shape[:3]) + (S.shape[-1],), order="F")
         G[1:-1, 1:-1, 1:-1] = S
         mf.set_from_global(G, (-1, -1, -1))
         lev.set_data(lev.S_NEW, mf)
@@ -81,11 +81,34 @@ def _composite_sum(amr_levels_state, cov1, dx0, dx1, comp):
     return (S0[..., comp] * ~covc).sum() * np.prod(dx0) + (S1[..., comp] * cov1).sum() * np.prod(dx1)
 
 
-@pytest.mark.parametrize("case", ["one_box", "l_shape", "viscous", "viscous_l_shape_cons"])
+def _two_tracer_state(X, Y, Z):
+    """Taylor-Green velocity, a density that varies, the usual tracer and a second one (ns.do_trac2: state component 5)"""
+    S5 = orc.taylorgreen_state(X, Y, Z, c=1.0)
+    S = np.zeros(S5.shape[:3] + (6,), order="F")
+    S[..., :5] = S5
+    tp = 2.0 * np.pi
+    S[..., 3] = 1.0 + 0.2 * np.sin(tp * Y) * np.cos(tp * X)
+    S[..., 5] = 1.0 + 0.5 * np.sin(tp * X) * np.cos(tp * Z) + 0.25 * np.cos(2.0 * tp * Y)
+    return S
+
+
+@pytest.mark.parametrize("case", ["one_box", "l_shape", "viscous", "viscous_l_shape_cons", "two_tracers", "two_tracers_cons"])
 def test_two_level_taylorgreen_matches_oracle(case):
     n0 = 16
     kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
-    if case in ("one_box", "viscous"):
+    state_fn = lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=1.0)
+    ncomp = 5
+    if case.startswith("two_tracers"):
+        # ns.do_trac2 (regtest.3d.poiseuille, regtest.3d.hotspot): NUM_STATE = 6, both tracers diffusive with their own coefficients, one
+        # advected convectively (Laplacian_S) and one conservatively (Laplacian_SoverRho); variable density; viscous
+        fine = [([8, 8, 8], [15, 15, 23]), ([16, 8, 8], [23, 15, 23]), ([8, 16, 8], [15, 23, 23])]
+        split = 8
+        cons = case.endswith("cons")
+        kw.update(visc_coef=0.01, tracer_diff_coef=0.005, do_trac2=1, do_cons_trac2=0 if cons else 1, do_cons_trac=1 if cons else 0,
+                  tracer2_diff_coef=0.01, do_mom_diff=1 if cons else 0)
+        state_fn = _two_tracer_state
+        ncomp = 6
+    elif case in ("one_box", "viscous"):
         fine = [([4, 4, 4], [19, 19, 19])]
         split = 16
         if case == "viscous":
@@ -100,13 +123,13 @@ def test_two_level_taylorgreen_matches_oracle(case):
         # L-shaped refined region made of three boxes (the shape of Exec/run2d/test_grids/fixed_grids_2), coarse level in 8 boxes
         fine = [([8, 8, 8], [15, 15, 23]), ([16, 8, 8], [23, 15, 23]), ([8, 16, 8], [15, 23, 23])]
         split = 8
-    amr, oa = _make(n0, fine, split, kw, lambda X, Y, Z: orc.taylorgreen_state(X, Y, Z, c=1.0))
+    amr, oa = _make(n0, fine, split, kw, state_fn)
     amr.post_init()
     oa.post_init()
     assert abs(amr.dts()[0] - oa.dt(0)) <= 1e-9 * oa.dt(0) and abs(amr.dts()[1] - oa.dt(1)) <= 1e-9 * oa.dt(1)
     _compare(amr, oa, 2e-8, "after post_init")
     cov1 = oa.cov(1)
-    m0 = [_composite_sum((oa.state(0), oa.state(1)), cov1, oa.dx(0), oa.dx(1), c) for c in range(5)]
+    m0 = [_composite_sum((oa.state(0), oa.state(1)), cov1, oa.dx(0), oa.dx(1), c) for c in range(ncomp)]
     for step in range(2):
         dt = amr.coarse_step()
         dto = oa.step()
@@ -117,9 +140,13 @@ def test_two_level_taylorgreen_matches_oracle(case):
     # composite conservation of mass, tracer and momentum (periodic domain, conservative updates + reflux + sync)
     n = [oa.n(0), oa.n(1)]
     Sg = [amr.levels[l].data(0).gather_valid(n[l]) for l in range(2)]
-    m1 = [_composite_sum(Sg, cov1, oa.dx(0), oa.dx(1), c) for c in range(5)]
+    m1 = [_composite_sum(Sg, cov1, oa.dx(0), oa.dx(1), c) for c in range(ncomp)]
     assert abs(m1[3] - m0[3]) <= 1e-12
-    assert abs(m1[4] - m0[4]) <= 1e-11
+    if not case.startswith("two_tracers"):
+        assert abs(m1[4] - m0[4]) <= 1e-11
+    else:                                   # the conservatively advected tracer of the pair is conserved on the composite grid
+        c = 4 if case.endswith("cons") else 5
+        assert Sg[0].shape[-1] == 6 and abs(m1[c] - m0[c]) <= 1e-11
 
 
 def _composite_sum_n(states, covs, dxs, comp):
