@@ -59,7 +59,8 @@ class Amr:
             check(lib().iamrx_amr_level(self.h, l, C.byref(hl)))
             self.levels.append(_Level(hl, self.level_geom(l), self.layouts[l], self.params, self.opts))
 
-    def set_regrid(self, max_level, regrid_int, rules, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1, compute_new_dt_on_regrid=0):
+    def set_regrid(self, max_level, regrid_int, rules, blocking_factor=8, max_grid_size=32, grid_eff=0.7, n_error_buf=1, compute_new_dt_on_regrid=0,
+                   do_refine_outflow=0, do_derefine_outflow=1, nbuf_outflow=1):
         """rules: list of dicts(comp (0..4, -1 = mag_vort), mode (0 greater, 1 less, 2 vorticity, 3 adjacent difference), value (list per level),
         max_level (optional), box_lo / box_hi (optional)) -- amr.refinement_indicators of NS_error.cpp"""
         arr = (TagRule * max(1, len(rules)))()
@@ -77,6 +78,7 @@ class Amr:
         check(lib().iamrx_amr_set_regrid(self.h, int(max_level), int(regrid_int), int(blocking_factor), int(max_grid_size), C.c_double(grid_eff),
                                          int(n_error_buf), len(rules), arr))
         check(lib().iamrx_amr_set_compute_new_dt_on_regrid(self.h, int(compute_new_dt_on_regrid)))
+        check(lib().iamrx_amr_set_outflow_tagging(self.h, int(do_refine_outflow), int(do_derefine_outflow), int(nbuf_outflow)))
 
     def regrid(self):
         ch = C.c_int()

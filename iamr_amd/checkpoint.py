@@ -234,7 +234,7 @@ def restart(path, geom0, params, opts=None, single_level=False):
         for t, (name, snew, sold, typ, nc) in enumerate(STATE_TYPES):
             for tag, sel in (("New", snew), ("Old", sold)):
                 arrays = _read_vismf(ld, f"SD_{t}_{tag}_MF")
-                mf = Lb.MultiFab(lays[l], typ, lev.nstate if t == 0 else nc, 1)
+                mf = Lb.MultiFab(lays[l], typ, arrays[0].shape[-1] if (t == 0 and arrays) else nc, 1)
                 for li, a in enumerate(arrays):
                     mf.from_numpy(a, li)
                 lev.set_data(sel, mf)

@@ -20,7 +20,7 @@ public:
     MGStats st_sync, st_mac_sync;                // last MLsyncProject / mac_sync_solve
     // Hydro::NodalProjector::project on levels c0 .. c0+nl-1 (Projection::doMLMGNodalProjection with nlevel > 1)
     MGStats composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
-                              const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale);
+                              const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MultiFab* const rhcc[] = nullptr);
     // building blocks, public for the unit tests
     void reflux(int l);
     void avg_down(int l);
@@ -42,11 +42,13 @@ public:
         int max_level = 0, regrid_int = 0;
         int blocking_factor = 8, max_grid_size = 32, n_error_buf = 1;
         double grid_eff = 0.7;
+        int do_refine_outflow = 0, do_derefine_outflow = 1, nbuf_outflow = 1;   // ns.do_refine_outflow / do_derefine_outflow / Nbuf_outflow (NavierStokesBase.cpp:136-138)
         int compute_new_dt_on_regrid = 0;   // amr.compute_new_dt_on_regrid (Amr::timeStep: computeNewDt(post_regrid_flag = 1) after a level-0 regrid; default 0)
         std::vector<TagRule> rules;
     };
     void set_regrid(const RegridOpts& r) { const int keep = rg.compute_new_dt_on_regrid; rg = r; if (!r.compute_new_dt_on_regrid) rg.compute_new_dt_on_regrid = keep; }
     void set_compute_new_dt_on_regrid(int on) { rg.compute_new_dt_on_regrid = on; }
+    void set_outflow_tagging(int refine, int derefine, int nbuf) { rg.do_refine_outflow = refine; rg.do_derefine_outflow = derefine; rg.nbuf_outflow = nbuf; }
     // new grids of levels 1 .. max_level from the tags of the current data (coarse to fine nesting enforced); the level-l boxes
     std::vector<std::vector<BoxD>> make_new_grids();
     // install grids (levels 1 ..): new levels are filled from the old level where it existed and from the next coarser level elsewhere;

@@ -71,6 +71,7 @@ void node_class(MultiFab& out, const MultiFab& cov, const Geometry& g)
         ot[f](i, j, k) = nin == 0 ? 0.0 : (nin == ntot ? 1.0 : 2.0);
     });
 }
+}  // namespace
 // y(ycomp..) *= (keep_where_zero ? (m == 0) : (m != 0)) on valid + ng
 void mask_mult(MultiFab& y, int ycomp, int nc, const MultiFab& m, bool keep_where_zero, int ng)
 {
@@ -80,6 +81,7 @@ void mask_mult(MultiFab& y, int ycomp, int nc, const MultiFab& m, bool keep_wher
         if (!on) for (int n = 0; n < nc; ++n) yt[f](i, j, k, ycomp + n) = 0.0;
     });
 }
+namespace {
 // node masks of the composite system: keep y where cls == v
 void keep_class(MultiFab& y, const MultiFab& cls, double v)
 {
@@ -194,7 +196,7 @@ void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, con
 
 // ------------------------------------------------------------------------------------------------------------------------
 // sync residuals
-MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side)
+MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side, const MultiFab* rhcc)
 {
     const Geometry& g = ns.geom();
     const LayoutP& layout = ns.lay();
@@ -224,6 +226,7 @@ MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& 
     }
     MultiFab rhs(layout, node_type(), 1, 0), ph(layout, node_type(), 1, 1), r(layout, node_type(), 1, 1);
     nodal_divu(g, rhs, um, 0, &bcn);
+    if (rhcc) { MultiFab rc = make_rhcc(g, *rhcc, 0, 1.0, crse_side ? &fc : nullptr); nodal_rhcc_add(g, rhs, rc, bcn); }
     ph.setVal(0.0);
     MultiFab::Copy(ph, phi, 0, 0, 1, 0);
     ph.FillBoundary(g);
@@ -420,7 +423,7 @@ void comp_residual(std::vector<CLev>& L, int lmin = 0)        // r = b - A x on 
 }  // namespace
 
 MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
-                                 const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale)
+                                 const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MultiFab* const rhcc[])
 {
     auto& ctx = Context::get();
     ProfScope ps_all_("composite_project");
@@ -501,6 +504,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         MultiFab dv(C.layout, node_type(), 1, 0);
         const DomainBC bcn = C.ns->nodal_bc();
         nodal_divu(C.g, dv, um, 0, &bcn);
+        if (rhcc && rhcc[l]) { MultiFab rc = make_rhcc(C.g, *rhcc[l], 0, 1.0, l < nl - 1 ? &C.fcov : nullptr); nodal_rhcc_add(C.g, dv, rc, bcn); }
         mf_saxpy(C.b, 1.0, dv, 0, 0, 1, 0);                    // b may already hold what the finer level handed down
         if (l == 0 && rhnd) mf_saxpy(C.b, 1.0, *rhnd, 0, 0, 1, 0);
         if (l > 0) {
@@ -691,7 +695,7 @@ struct AmrTimer {
 void AmrNS::avg_down(int l)
 {
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
-    average_down(f.S[f.inew], c.S[c.inew], 0, c.nstate, f.ratio);
+    average_down(f.S[f.inew], c.S[c.inew], 0, c.nalloc, f.ratio);     // state, and divu / dsdt (NavierStokes.cpp:1859-1872)
     for (size_t q = l; q < lev.size(); ++q) lev[q]->make_rho_curr_time();
     average_down(c.initial_step ? f.P[f.pnew] : f.p_avg, c.P[c.pnew], 0, 1, f.ratio);
     average_down(f.Gp[f.pnew], c.Gp[c.pnew], 0, 3, f.ratio);
@@ -765,8 +769,9 @@ void AmrNS::mac_sync(int l)
                 for (int n = 0; n < 3; ++n) ut[fb](i, j, k, n) *= r;
             });
         }
-        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), c.nscal, 1), divu(c.layout, cell_type(), 1, 1);
-        tfs.setVal(0.0); divu.setVal(0.0);
+        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), c.nscal, 1), divu;
+        tfs.setVal(0.0);
+        c.divu_half(divu, dt, 1, false);                             // getDivCond(nghost_force, prev_time), MacProj.cpp:562
         // viscous forcing at the old time (MacProj.cpp:566-572): getViscTerms(visc_terms, 0, num_state_comps, prev_time)
         MultiFab vvisc(c.layout, cell_type(), 3, 1);
         vvisc.setVal(0.0);
@@ -837,84 +842,29 @@ void AmrNS::mac_sync(int l)
         // Diffusion::diffuse_Vsync -> diffuse_tensor_Vsync (Diffusion.cpp:960-1178): (rho - theta dt div tau) Vsync' = rho Vsync, homogeneous
         // boundary and coarse/fine data.  NOTE the face coefficients of this solve are set to 1.0 upstream (:1122-1135), not to the
         // viscosity -- followed as written.
-        const bool rf3 = mom;                                   // rho_flag 3 for momentum differencing (NavierStokes.cpp:1552)
-        MultiFab Rhs(c.layout, cell_type(), 3, 0), acoef(c.layout, cell_type(), 1, 0), Soln(c.layout, cell_type(), 3, 1);
-        MultiFab::Copy(Rhs, c.Vsync, 0, 0, 3, 0);
-        {
-            const FabD *rt = Rhs.d_tab, *ht = c.rho_half.d_tab, *ot = c.S[1 - c.inew].d_tab;
-            for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
-                const double r = rf3 ? ot[fb](i, j, k, Density) : ht[fb](i, j, k, 0);
-                for (int n = 0; n < 3; ++n) rt[fb](i, j, k, n) *= r;
-            });
-        }
-        if (rf3) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0); else MultiFab::Copy(acoef, c.rho_half, 0, 0, 1, 0);
-        Soln.setVal(0.0);
         MultiFab one[3];
         const MultiFab* ep[3];
         for (int d = 0; d < 3; ++d) { one[d].define(c.layout, face_type(d), 1, 0); one[d].setVal(1.0); ep[d] = &one[d]; }
-        MGOpts vo = o;
-        vo.maxorder = 2;
-        TensorCF cf{nullptr, l > 0 ? &c.crse->g : nullptr, c.ratio};
         MultiFab tflux[3];
-        TensorFlux fx{{&tflux[0], &tflux[1], &tflux[2]}, theta, false};
+        MultiFab* tfp[3] = {&tflux[0], &tflux[1], &tflux[2]};
         if (l > 0) for (int d = 0; d < 3; ++d) tflux[d].define(c.layout, face_type(d), 3, 0);
-        tensor_solve(c.g, Soln, Rhs, 1.0, theta * dt, &acoef, ep, c.bc_visc, 3, c.p.visc_tol, -1.0, vo, l > 0 ? &cf : nullptr, l > 0 ? &fx : nullptr);
-        MultiFab::Copy(c.Vsync, Soln, 0, 0, 3, 1);
+        diffuse_tensor_Vsync(c.g, c.Vsync, dt, theta, c.rho_half, mom ? 3 : 1 /* NavierStokes.cpp:1552 */, &c.S[1 - c.inew], &Sn, Density, ep, c.bc_visc, c.bc_vel,
+                             l > 0 ? &c.crse->g : nullptr, c.ratio, l > 0 ? tfp : nullptr, c.p.visc_tol, o);
         if (l > 0) for (int d = 0; d < 3; ++d) c.reg_visc->FineAdd(tflux[d], d, 0, Xvel, 3, dt * dt);     // :1166-1176
-        // ghost cells outside ext_dir faces back to zero (:987-1008)
-        for (int n = 0; n < 3; ++n) for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
-            if (c.g.periodic[d] || (side == 0 ? c.bc_vel[n].lo[d] : c.bc_vel[n].hi[d]) != bc_ext_dir) continue;
-            const int face = side == 0 ? c.g.domain.lo[d] - 1 : c.g.domain.hi[d] + 1;
-            const FabD* vt = c.Vsync.d_tab;
-            const int dd = d, nn = n;
-            for_each(*c.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
-                if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) vt[fb](i, j, k, nn) = 0.0;
-            });
-        }
     }
     PROF_NEXT(psec, "ms_ssync");
     mf_mult(c.Ssync, dt, 0, 1, 1);                           // density: not diffusive: Ssync.mult(dt, sigma, 1, ngrow)
     for (int sn = 1; sn < c.nscal; ++sn) {
     const int sigma = Density + sn, rho_flag = c.scal_rho_flag[sn];
     if (c.is_diffusive_scal(sigma)) {
-        // Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640: S_old = {}, S_new = 0, delta_rhs = Ssync, no old-time
-        // flux): (alpha - theta dt div D grad) s = dt Ssync, alpha = rho_new for S = rho q (rho_flag 2) else 1; Ssync = s (x rho_new).
-        // On a refined level upstream passes no coarse data (has_coarse_data = false): homogeneous coarse/fine data here.
-        const bool cons = rho_flag == 2;
-        MultiFab Rhs(c.layout, cell_type(), 1, 0), Soln(c.layout, cell_type(), 1, 1), acoef(c.layout, cell_type(), 1, 0);
-        MultiFab::Copy(Rhs, c.Ssync, sn, 0, 1, 0);
-        mf_mult(Rhs, dt, 0, 1, 0);
-        if (rho_flag == 1) scale_by(Rhs, c.rho_half, 0, 0, false);       // Diffusion.cpp:470-475
-        Soln.setVal(0.0);
-        acoef.setVal(1.0);
-        if (cons) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
-        else if (rho_flag == 1) MultiFab::Copy(acoef, c.rho_half, 0, 0, 1, 0);
-        const double tol_abs = c.p.visc_tol * Rhs.norm0(0, 1, 0);
-        MGOpts so = o;
-        so.maxorder = 2;
-        CellMG op(c.g, c.layout, 1, c.bc_scal_lin[sn], so);
-        op.setScalars(1.0, theta * dt);
-        op.setACoeffs(&acoef);
+        // Diffusion::diffuse_scalar as the sync solve (NavierStokes.cpp:1590-1640), fluxSC -> viscous register x dt (:1630-1638)
         const MultiFab* bp[3] = {&c.diff_b[sn][0], &c.diff_b[sn][1], &c.diff_b[sn][2]};
-        op.setBCoeffs(bp);
-        if (l > 0) op.setCoarseFineBC(nullptr, c.crse->g, c.ratio);
-        op.prepare();
-        op.solve(Soln, Rhs, c.p.visc_tol, tol_abs);
-        if (l > 0) {                                              // fluxSC -> viscous register, x dt (NavierStokes.cpp:1630-1638)
-            MultiFab sf[3];
-            MultiFab* sfp[3] = {&sf[0], &sf[1], &sf[2]};
-            for (int d = 0; d < 3; ++d) sf[d].define(c.layout, face_type(d), 1, 0);
-            op.fluxes(Soln, sfp, nullptr);
-            for (int d = 0; d < 3; ++d) {
-                mf_mult(sf[d], c.g.dx[(d + 1) % 3] * c.g.dx[(d + 2) % 3] / dt, 0, 1, 0);          // theta * area * (-D grad s)
-                c.reg_visc->FineAdd(sf[d], d, 0, sigma, 1, dt);
-            }
-        }
-        if (cons) {
-            const FabD *st = Soln.d_tab, *nt = Sn.d_tab;
-            for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) *= nt[fb](i, j, k, Density); });
-        }
-        MultiFab::Copy(c.Ssync, Soln, 0, sn, 1, 0);
+        MultiFab sf[3];
+        MultiFab* sfp[3] = {&sf[0], &sf[1], &sf[2]};
+        if (l > 0) for (int d = 0; d < 3; ++d) sf[d].define(c.layout, face_type(d), 1, 0);
+        diffuse_Ssync(c.g, c.Ssync, sn, dt, theta, c.rho_half, rho_flag, Sn, Density, bp, c.bc_scal_lin[sn], l > 0 ? &c.crse->g : nullptr, c.ratio,
+                      l > 0 ? sfp : nullptr, c.p.visc_tol, o);
+        if (l > 0) for (int d = 0; d < 3; ++d) c.reg_visc->FineAdd(sf[d], d, 0, sigma, 1, dt);
     } else mf_mult(c.Ssync, dt, sn, 1, 1);
     if (c.scal_cons[sn]) mf_saxpy(c.Ssync, dt, Delta, sn, sn, 1, 0);
     }
@@ -1070,6 +1020,16 @@ void AmrNS::post_init(double stop_time_)
     std::vector<const MultiFab*> sigp(nl);
     std::vector<MultiFab> sig(nl), vv(nl);
     std::vector<int> vcomp(nl, 0);
+    const bool have_divu = lev[0]->have_divu;
+    std::vector<MultiFab> rc(nl);
+    std::vector<const MultiFab*> rcp(nl, nullptr);
+    if (have_divu)                                                   // NavierStokes::initData (NavierStokes.cpp:457-479): rho at both times, divu, dsdt = 0
+        for (auto& s : lev) {
+            s->make_rho_curr_time();
+            MultiFab::Copy(s->rho_ptime, s->rho_ctime, 0, 0, 1, 1);
+            s->calc_divu(true);
+            s->S[s->inew].setVal(0.0, s->Dsdt, 1, 0);
+        }
     // ---- post_init_state (NavierStokesBase.cpp:2369-2439)
     if (p.init_vel_iter <= 0) { for (auto& s : lev) { s->P[1 - s->pnew].setVal(0.0); s->Gp[1 - s->pnew].setVal(0.0); } }
     else
@@ -1079,8 +1039,14 @@ void AmrNS::post_init(double stop_time_)
             s.P[1 - s.pnew].setVal(0.0);
             sig[l].define(s.layout, cell_type(), 1, 0); sig[l].setVal(1.0);      // rho_wgt_vel_proj = 0
             vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
+            if (have_divu) {                                         // rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788
+                rc[l].define(s.layout, cell_type(), 1, 0);
+                MultiFab::Copy(rc[l], s.S[s.inew], s.Divu, 0, 1, 0);
+                mf_mult(rc[l], -1.0, 0, 1, 0);
+                rcp[l] = &rc[l];
+            }
         }
-        lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 1.0);
+        lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 1.0, have_divu ? rcp.data() : nullptr);
         for (auto& s : lev) for (int q = 0; q < 2; ++q) { s->P[q].setVal(0.0); s->Gp[q].setVal(0.0); }
     }
     for (auto& s : lev) s->initial_step = true;
@@ -1095,6 +1061,24 @@ void AmrNS::post_init(double stop_time_)
             vv[l].setVal(0.0);
             vv[l].setVal(p.gravity, 2, 1, 1);
             vel[l] = &vv[l]; vcomp[l] = 0; phi[l] = &s.P[s.pnew]; sigp[l] = &sig[l];
+        }
+        // set_outflow_bcs(INITIAL_PRESS, c_lev = 0 .. f_lev; Projection.cpp:893-905, 1776-1803): the finest level that covers the whole strip of
+        // an outflow face computes the hydrostatic data, putDown (:1656-1712) injects them into the coarser levels
+        {
+            bool done = false;
+            for (int l = nl - 1; l >= 0; --l) {
+                NavierStokes& s = *lev[l];
+                if (!done) { done = s.set_outflow_bcs(*phi[l], s.S[s.inew], Density); continue; }
+                MultiFab tmp(s.layout, node_type(), 1, 0);
+                MultiFab::Copy(tmp, *phi[l], 0, 0, 1, 0);
+                average_down(*phi[l + 1], tmp, 0, 1, lev[l + 1]->ratio);
+                const FabD *pt = phi[l]->d_tab, *tt = tmp.d_tab;
+                for (int D = 0; D < 2; ++D) for (int side = 0; side < 2; ++side) {
+                    if (s.g.periodic[D] || (side == 0 ? s.p.phys_lo[D] : s.p.phys_hi[D]) != phys_outflow) continue;
+                    const int face = side == 0 ? s.g.domain.lo[D] : s.g.domain.hi[D] + 1;
+                    for_each(*s.layout, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { if ((D == 0 ? i : j) == face) pt[f](i, j, k) = tt[f](i, j, k); });
+                }
+            }
         }
         lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 0.0);
         for (auto& s : lev) { MultiFab::Copy(s->P[1 - s->pnew], s->P[s->pnew], 0, 0, 1, 1); MultiFab::Copy(s->Gp[1 - s->pnew], s->Gp[s->pnew], 0, 0, 3, 1); }
@@ -1135,6 +1119,13 @@ void AmrNS::post_init(double stop_time_)
                 const FabD *st = sig[l].d_tab, *ht = s.rho_half.d_tab;
                 for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / ht[f](i, j, k); });
                 vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
+                if (have_divu) {                                     // rhcc = -(divu(strt_time + dt) - divu(strt_time)) / dt, Projection.cpp:1008-1075, 1142-1148
+                    rc[l].define(s.layout, cell_type(), 1, 0);
+                    MultiFab::Copy(rc[l], s.S[s.inew], s.Divu, 0, 1, 0);
+                    mf_saxpy(rc[l], -1.0, s.S[1 - s.inew], s.Divu, 0, 1, 0);
+                    mf_mult(rc[l], -1.0 / dt_init, 0, 1, 0);
+                    rcp[l] = &rc[l];
+                }
             }
             for (int l = fin; l >= 1; --l) {
                 MultiFab vf(lev[l]->layout, cell_type(), 3, 0), vc(lev[l - 1]->layout, cell_type(), 3, 0);
@@ -1143,11 +1134,12 @@ void AmrNS::post_init(double stop_time_)
                 average_down(vf, vc, 0, 3, lev[l]->ratio);
                 MultiFab::Copy(*vel[l - 1], vc, 0, Xvel, 3, 0);
             }
-            lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, true, 0.0);
+            lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, true, 0.0, have_divu ? rcp.data() : nullptr);
             for (auto& s : lev) mf_saxpy(s->P[s->pnew], 1.0, s->P[1 - s->pnew], 0, 0, 1, 1);
             for (int k = fin - 1; k >= 0; --k) avg_down(k);
             for (auto& s : lev) {                                     // resetState(strt_time, dt_init, dt_init)
                 s->inew = 1 - s->inew;
+                if (s->have_divu) MultiFab::Copy(s->S[s->inew], s->S[1 - s->inew], s->Dsdt, s->Dsdt, 1, 0);   // Dsdt_Type is not reset (NavierStokesBase.cpp:2669-2676)
                 MultiFab::Copy(s->P[1 - s->pnew], s->P[s->pnew], 0, 0, 1, 1);
                 MultiFab::Copy(s->Gp[1 - s->pnew], s->Gp[s->pnew], 0, 0, 3, 1);
                 s->set_time_level(0.0, dt_init, dt_init);

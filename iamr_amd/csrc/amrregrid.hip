@@ -20,8 +20,6 @@
 namespace iamrx {
 
 // regrid.hip
-std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
-                               int n_error_buf);
 
 namespace {
 
@@ -125,7 +123,17 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
         // tags outside the level's own cells cannot exist (no data there): boxes of level l+1 stay inside refine(level l) as long as
         // the clustering does not reach over the level's edge; the nesting of the OLD level l+1 in the OLD level l keeps a margin
         const int bf = std::max(1, rg.blocking_factor / m_ratio), mg = std::max(bf, rg.max_grid_size / m_ratio);
-        std::vector<BoxD> cb = cluster_tags(h.data(), dom, bf, mg, rg.grid_eff, rg.n_error_buf);
+        OutflowTags oft;
+        for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side)
+            if (!s.g.periodic[d] && (side == 0 ? s.p.phys_lo[d] : s.p.phys_hi[d]) == phys_outflow) { oft.dir[oft.nface] = d; oft.side[oft.nface] = side; ++oft.nface; }
+        oft.mode = rg.do_refine_outflow ? 1 : (rg.do_derefine_outflow ? 2 : 0);
+        if (oft.mode == 2) {                      // NavierStokesBase.cpp:2147-2176 (the blocking factor and the ratio are the same on every level)
+            const int np = 1;                     // Amr::nProper
+            int ncc = (rg.nbuf_outflow + bf - 1) / bf, nlc = ncc * bf;
+            for (int j = 1; j <= l; ++j) { nlc = nlc * m_ratio + np; ncc = (nlc + bf - 1) / bf; nlc = ncc * bf; }
+            oft.ncoarse = ncc;
+        }
+        std::vector<BoxD> cb = cluster_tags(h.data(), dom, bf, mg, rg.grid_eff, rg.n_error_buf, oft.nface ? &oft : nullptr);
         for (const BoxD& b : cb) grids[l + 1].push_back(refine(b, m_ratio));
     }
     // a level can only exist if the one below it does
@@ -199,18 +207,18 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
         s.initial_step = false; s.initial_iter = false;
         // ---- data: FillPatch(old, S_new / P_new / Gp_new) resp. FillCoarsePatch: the old level's cells where it existed, the
         // (already rebuilt) coarser level interpolated elsewhere
-        MultiFab none_c(empty_layout, cell_type(), s.nstate, 0);
+        MultiFab none_c(empty_layout, cell_type(), s.nalloc, 0);
         const MultiFab* fS = ol ? &ol->S[ol->inew] : &none_c;
         TimeData fd{nullptr, fS, cur_time, cur_time};
         TimeData cd{nullptr, &c.S[c.inew], cur_time, cur_time};
         MultiFab tmp3(s.layout, cell_type(), 3, 1), tmp1(s.layout, cell_type(), 1, 1);
         fillpatch_two_levels(tmp3, 0, cur_time, fd, cd, Xvel, 3, c.g, s.g, m_ratio, s.bc_vel, s.ed_vel_lo, s.ed_vel_hi);
         MultiFab::Copy(s.S[0], tmp3, 0, Xvel, 3, 1);
-        for (int q = 0; q < s.nscal; ++q) {
+        for (int q = 0; q < s.nalloc - 3; ++q) {      // the scalars, and divu / dsdt (NavierStokesBase.cpp:1742-1754, 1800-1805)
             fillpatch_two_levels(tmp1, 0, cur_time, fd, cd, Density + q, 1, c.g, s.g, m_ratio, &s.bc_scal[q], s.ed_scal_lo + 3 * q, s.ed_scal_hi + 3 * q);
             MultiFab::Copy(s.S[0], tmp1, 0, Density + q, 1, 1);
         }
-        MultiFab::Copy(s.S[1], s.S[0], 0, 0, s.nstate, 1);
+        MultiFab::Copy(s.S[1], s.S[0], 0, 0, s.nalloc, 1);
         MultiFab none_g(empty_layout, cell_type(), 3, 0);
         TimeData fg{nullptr, ol ? &ol->Gp[ol->pnew] : &none_g, cur_time, cur_time};
         TimeData cg{nullptr, &c.Gp[c.pnew], cur_time, cur_time};

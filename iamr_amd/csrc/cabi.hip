@@ -713,8 +713,9 @@ int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
     case 10: case 11: m = &n.mac_phi_history(which - 10); break;
     default: throw Error("iamrx_ns_set_data: bad selector");
     }
-    IAMRX_ASSERT(src->mf.ncomp == m->ncomp && src->mf.ngrow == m->ngrow && src->mf.layout->id == m->layout->id);
-    MultiFab::Copy(*m, src->mf, 0, 0, m->ncomp, m->ngrow);
+    // fewer components than the level holds: the leading ones (the state without the divu / dsdt components a temperature run appends)
+    IAMRX_ASSERT(src->mf.ncomp <= m->ncomp && src->mf.ngrow == m->ngrow && src->mf.layout->id == m->layout->id);
+    MultiFab::Copy(*m, src->mf, 0, 0, src->mf.ncomp, m->ngrow);
     IAMRX_CATCH
 }
 
@@ -913,6 +914,13 @@ int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blockin
     IAMRX_CATCH
 }
 int iamrx_amr_set_compute_new_dt_on_regrid(iamrx_amr a, int on) { IAMRX_TRY a->amr->set_compute_new_dt_on_regrid(on != 0); IAMRX_CATCH }
+int iamrx_amr_set_outflow_tagging(iamrx_amr a, int do_refine_outflow, int do_derefine_outflow, int nbuf_outflow)
+{
+    IAMRX_TRY
+    if (do_refine_outflow && do_derefine_outflow) throw Error("iamrx_amr_set_outflow_tagging: do_refine_outflow and do_derefine_outflow cannot both be set (NavierStokesBase.cpp:514-516)");
+    a->amr->set_outflow_tagging(do_refine_outflow, do_derefine_outflow, nbuf_outflow);
+    IAMRX_CATCH
+}
 int iamrx_amr_regrid(iamrx_amr a, int* changed)
 {
     IAMRX_TRY

@@ -56,8 +56,9 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
     scal_cons[1] = p.do_cons_trac != 0; scal_rho_flag[1] = p.do_cons_trac ? 2 : 0; scal_diff[1] = p.tracer_diff_coef;      // NS_setup.cpp:304-310
     if (p.do_trac2) { const int n = Tracer2 - Density; scal_cons[n] = p.do_cons_trac2 != 0; scal_rho_flag[n] = p.do_cons_trac2 ? 2 : 0; scal_diff[n] = p.tracer2_diff_coef; }
     if (p.do_temp) { const int n = Temp - Density; scal_cons[n] = 0; scal_rho_flag[n] = 1; scal_diff[n] = p.temp_cond_coef; }   // NS_setup.cpp:302
+    have_divu = p.do_temp != 0; Divu = nstate; Dsdt = nstate + 1; nalloc = nstate + (have_divu ? 2 : 0);
     for (int q = 0; q < 2; ++q) {
-        S[q].define(layout, cell_type(), nstate, 1);
+        S[q].define(layout, cell_type(), nalloc, 1);
         P[q].define(layout, node_type(), 1, 1);
         Gp[q].define(layout, cell_type(), 3, 1);
         S[q].setVal(0.0); P[q].setVal(0.0); Gp[q].setVal(0.0);
@@ -114,8 +115,6 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
             if (!(phys_ok(plo) && phys_ok(phi_)))
                 throw Error("iamrx NavierStokes: a non-periodic direction needs Inflow (1), Outflow (2), Symmetry (3), SlipWall (4) or "
                             "NoSlipWall (5) on both sides");
-            if ((plo == phys_outflow || phi_ == phys_outflow) && p.gravity != 0.0)
-                throw Error("iamrx NavierStokes: outflow with gravity (hydrostatic outflow pressure, Projection::set_outflow_bcs) is not implemented");
         }
         // MacProj::set_mac_solve_bc (MacProj.cpp:1187-1208): outflow Dirichlet, everything else Neumann
         bc_mac.lo[d] = g.periodic[d] ? lo_periodic : (plo == phys_outflow ? lo_dirichlet : lo_neumann);
@@ -134,6 +133,13 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
             bc_scal[n].lo[d] = is_temp ? temp_bctype(plo) : scal_bctype(plo); bc_scal[n].hi[d] = is_temp ? temp_bctype(phi_) : scal_bctype(phi_);
             ed_scal_lo[n * 3 + d] = p.scal_bc_lo[d * 4 + n]; ed_scal_hi[n * 3 + d] = p.scal_bc_hi[d * 4 + n];
             bc_scal_lin[n].lo[d] = linop_of(bc_scal[n].lo[d]); bc_scal_lin[n].hi[d] = linop_of(bc_scal[n].hi[d]);
+        }
+        if (have_divu) {     // divu_bc / dsdt_bc, NS_BC.H:42-50; dsdt's ext_dir faces are filled with zero (homogeneous_bf, NS_setup.cpp:383)
+            const int a = nscal, b = nscal + 1;
+            auto dsdt_bct = [](int phys) { return phys == phys_interior ? (int)bc_int_dir : ((phys == phys_inflow || phys == phys_outflow) ? (int)bc_ext_dir : (int)bc_reflect_even); };
+            bc_scal[a].lo[d] = plo == phys_interior ? (int)bc_int_dir : (int)bc_reflect_even; bc_scal[a].hi[d] = phi_ == phys_interior ? (int)bc_int_dir : (int)bc_reflect_even;
+            bc_scal[b].lo[d] = dsdt_bct(plo); bc_scal[b].hi[d] = dsdt_bct(phi_);
+            ed_scal_lo[a * 3 + d] = ed_scal_hi[a * 3 + d] = ed_scal_lo[b * 3 + d] = ed_scal_hi[b * 3 + d] = 0.0;
         }
     }
     bc_mac.maxorder = 4;     // MacProj.cpp:1172
@@ -240,7 +246,7 @@ void NavierStokes::swap_time_levels(double dt_)      // StateData::swapTimeLevel
 void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)
 {
     const bool is_vel = (bc == bc_vel);
-    const bool is_scal = (bc >= bc_scal && bc < bc_scal + MAXSCAL);
+    const bool is_scal = (bc >= bc_scal && bc < bc_scal + MAXSLOT);
     const long so = is_scal ? 3 * (bc - bc_scal) : 0;
     const double* edlo = is_vel ? ed_vel_lo : (is_scal ? ed_scal_lo + so : nullptr);
     const double* edhi = is_vel ? ed_vel_hi : (is_scal ? ed_scal_hi + so : nullptr);
@@ -541,6 +547,43 @@ double NavierStokes::predict_velocity(double dt_)
     return dt_ * tempdt;
 }
 
+void NavierStokes::calc_divu(bool use_new)
+{
+    if (!have_divu) return;
+    MultiFab& Sd = use_new ? S[inew] : S[1 - inew];
+    if (!is_diffusive_scal(Temp)) { Sd.setVal(0.0, Divu, 1, 0); return; }
+    MultiFab visc(layout, cell_type(), 1, 1);
+    get_visc_terms_scalar(visc, Sd, Temp);
+    const FabD *st = Sd.d_tab, *vt = visc.d_tab, *rt = (use_new ? rho_ctime : rho_ptime).d_tab;     // get_rho(time)
+    const int cT = Temp, cD = Divu;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        st[f](i, j, k, cD) = vt[f](i, j, k, 0) / (rt[f](i, j, k, 0) * st[f](i, j, k, cT));
+    });
+}
+
+void NavierStokes::calc_dsdt(double dt_)
+{
+    if (!have_divu) return;
+    const FabD *nt = S[inew].d_tab, *ot = S[1 - inew].d_tab;
+    const int cD = Divu, cS = Dsdt;
+    for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        nt[f](i, j, k, cS) = (nt[f](i, j, k, cD) - ot[f](i, j, k, cD)) / dt_;
+    });
+}
+
+void NavierStokes::divu_half(MultiFab& out, double dt_, int ng, bool with_dsdt)
+{
+    out.define(layout, cell_type(), 1, ng);
+    if (!have_divu) { out.setVal(0.0); return; }
+    MultiFab& So = S[1 - inew];
+    fillpatch(out, So, Divu, 1, &bc_scal[Divu - Density]);
+    if (with_dsdt) {
+        MultiFab e(layout, cell_type(), 1, ng);
+        fillpatch(e, So, Dsdt, 1, &bc_scal[Dsdt - Density]);
+        mf_saxpy(out, 0.5 * dt_, e, 0, 0, 1, ng);
+    }
+}
+
 void NavierStokes::mac_project(double dt_)
 {
     SectionTimer tm(*this, 1);
@@ -561,8 +604,11 @@ void NavierStokes::mac_project(double dt_)
     MultiFab* um[3] = {&u_mac[0], &u_mac[1], &u_mac[2]};
     MGOpts mo = o;
     mo.maxorder = 4;
-    if (level == 0) st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
-    else st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, nullptr, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr, &crse->mac_phi, &crse->g, ratio);
+    MultiFab mac_rhs;                                            // create_mac_rhs(mac_rhs, 1, time, dt), NavierStokes.cpp:592-596
+    if (have_divu) divu_half(mac_rhs, dt_, 1, true);
+    const MultiFab* Sp = have_divu ? &mac_rhs : nullptr;
+    if (level == 0) st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, Sp, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr);
+    else st_mac = mlmg_mac_solve(g, um, rho_ptime, 0, Sp, mac_phi, 2.0 / dt_, bc_mac, p.mac_tol, p.mac_abs_tol, mo, nullptr, &crse->mac_phi, &crse->g, ratio);
     if (warm) {
         if (!m_have_mac_prev) { m_mac_phi_prev.define(layout, cell_type(), 1, 0); m_mac_phi_prev2.define(layout, cell_type(), 1, 0); }
         else if (!initial_iter && !initial_step) { std::swap(m_mac_phi_prev, m_mac_phi_prev2); m_have_mac_prev2 = true; }
@@ -579,7 +625,7 @@ void NavierStokes::mac_project(double dt_)
     if (level == 0) for (int d = 0; d < 3; ++d) u_mac[d].FillBoundary(g);        // create_umac_grown at level 0
     else {
         const MultiFab* uc[3] = {&crse->u_mac[0], &crse->u_mac[1], &crse->u_mac[2]};
-        create_umac_grown(um, uc, nullptr, crse->g, g, ratio);
+        create_umac_grown(um, uc, Sp, crse->g, g, ratio);
     }
     // "BDS needs physical BCs filled" (NavierStokesBase.cpp:1097-1105: FillPatchSingleLevel of u_mac with the velocity's boundary
     // functor): the ghost faces outside a non-periodic domain face take the nearest face inside or on the boundary (first-order
@@ -624,8 +670,8 @@ void NavierStokes::velocity_advection(double dt_)
     fillpatch(Smf, So, Density, nscal, bc_scal);
     MultiFab visc(layout, cell_type(), 3, 1);
     if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
-    MultiFab tf(layout, cell_type(), 3, 1), divu(layout, cell_type(), 1, 1);
-    divu.setVal(0.0);
+    MultiFab tf(layout, cell_type(), 3, 1), divu;
+    divu_half(divu, dt_, 1, true);                               // NavierStokesBase.cpp:3377, 3421-3424
     {
         const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
         const double grav = p.gravity;
@@ -659,8 +705,9 @@ void NavierStokes::scalar_advection(double dt_)
     MultiFab Smf(layout, cell_type(), nscal, 3);
     fillpatch(Smf, So, Density, nscal, bc_scal);
     floor_small(Smf);
-    MultiFab tf(layout, cell_type(), nscal, 1), divu(layout, cell_type(), 1, 1);
-    tf.setVal(0.0); divu.setVal(0.0);
+    MultiFab tf(layout, cell_type(), nscal, 1), divu;
+    tf.setVal(0.0);
+    divu_half(divu, dt_, 1, true);                               // NavierStokes.cpp:712-733
     MultiFab visc(layout, cell_type(), 1, 1);
     for (int n = 1; n < nscal; ++n) {            // getForce = 0; density (n = 0) is not diffusive; keep the reference's arithmetic
         if (p.be_cn_theta != 1.0) get_visc_terms_scalar(visc, So, Density + n); else visc.setVal(0.0);
@@ -716,8 +763,8 @@ void NavierStokes::advection_all(double dt_)
     } else visc.setVal(0.0);
     ScalForm sf;                                 // per scalar slot: 0 convective, 1 conservative, 2 temperature
     for (int n = 0; n < MAXSCAL; ++n) sf.form[n] = (n < nscal && Density + n == Temp) ? 2 : (scal_cons[n] ? 1 : 0);
-    MultiFab tf(layout, cell_type(), nstate, 1), divu(layout, cell_type(), 1, 1);
-    divu.setVal(0.0);
+    MultiFab tf(layout, cell_type(), nstate, 1), divu;
+    divu_half(divu, dt_, 1, true);
     {
         MultiFab R1(layout, cell_type(), 1, 1);
         fillpatch(R1, So, Density, 1, bc_scal);              // the 1-ghost density of the forcing (velocity_advection's Smf)
@@ -823,73 +870,35 @@ void NavierStokes::scalar_diffusion_update_one(double dt_, int sigma)
     SectionTimer tm(*this, 4);
     const double theta = p.be_cn_theta;
     const int sn = sigma - Density, rho_flag = scal_rho_flag[sn];
-    const bool cons = rho_flag == 2;                             // diffusionType Laplacian_SoverRho -> rho_flag 2 (NS_setup.cpp:308)
     MultiFab& Sn = S[inew];
     MultiFab& So = S[1 - inew];
     const MultiFab* bp[3] = {&diff_b[sn][0], &diff_b[sn][1], &diff_b[sn][2]};
-    MultiFab Rhs(layout, cell_type(), 1, 0);
     const bool want_flux = fine != nullptr || level > 0;         // NavierStokes.cpp:949-990
     MultiFab sflux[3], sflux1[3];
     MultiFab *sfp[3] = {&sflux[0], &sflux[1], &sflux[2]}, *sfp1[3] = {&sflux1[0], &sflux1[1], &sflux1[2]};
-    if (want_flux) for (int d = 0; d < 3; ++d) { sflux[d].define(layout, face_type(d), 1, 0); sflux[d].setVal(0.0); sflux1[d].define(layout, face_type(d), 1, 0); }
-    MultiFab cdata;
-    if (theta != 1.0) {
-        MultiFab Soln0(layout, cell_type(), 1, 1);
-        fillpatch(Soln0, So, sigma, 1, &bc_scal[sn]);
-        if (cons) {                                              // Diffusion.cpp:396-413: Soln = S_old / rho_old on the grown box
-            MultiFab R(layout, cell_type(), 1, 1);
-            fillpatch(R, So, Density, 1, &bc_scal[0]);
-            scale_by(Soln0, R, 0, 1, true);
-        }
-        MGOpts mo;
-        mo.max_coarsening_level = 0;                             // infon.setMaxCoarseningLevel(0) (Diffusion.cpp:318)
-        mo.maxorder = 2;
-        CellMG opn(g, layout, 1, bc_scal_lin[sn], mo);
-        opn.setScalars(0.0, -(1.0 - theta) * dt_);
-        opn.setBCoeffs(bp);
-        if (level > 0) { crse_scalar_at(cdata, st_old, sigma, cons); opn.setCoarseFineBC(&cdata, crse->g, ratio); }     // Diffusion.cpp:376-396
-        opn.prepare();
-        opn.apply(Rhs, Soln0);
-        if (want_flux) {                                         // fluxn = (1 - theta) * area * (-D grad s_old) (Diffusion.cpp:437-438)
-            opn.fluxes(Soln0, sfp, nullptr);                     // -beta_scalar * b * grad
-            for (int d = 0; d < 3; ++d) mf_mult(sflux[d], (1.0 - theta) * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (-(1.0 - theta) * dt_), 0, 1, 0);
-        }
-    } else Rhs.setVal(0.0);
-    if (rho_flag == 1) {                                         // rhs += rho_half * S_new (Diffusion.cpp:476-486)
-        const FabD *rt = Rhs.d_tab, *st = Sn.d_tab, *ht = rho_half.d_tab;
-        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) { rt[f](i, j, k, 0) += st[f](i, j, k, sigma) * ht[f](i, j, k, 0); });
-    } else
-    mf_saxpy(Rhs, 1.0, Sn, sigma, 0, 1, 0);                      // rhs += S_new (Diffusion.cpp:479-493)
-    const double tol_abs = p.visc_tol * Rhs.norm0(0, 1, 0);      // get_scaled_abs_tol
-    MultiFab Soln(layout, cell_type(), 1, 1);
-    fillpatch(Soln, Sn, sigma, 1, &bc_scal[sn]);                 // FillPatch(S_new, ng 1): initial guess + level BC
-    MultiFab acoef(layout, cell_type(), 1, 0);
-    acoef.setVal(1.0);                                           // computeAlpha, rho_flag 0
-    if (cons) {                                                  // rho_flag 2: Soln = S_new / rho_new (Diffusion.cpp:520-540), alpha = rho_new
-        MultiFab R(layout, cell_type(), 1, 1);
-        fillpatch(R, Sn, Density, 1, &bc_scal[0]);
-        scale_by(Soln, R, 0, 1, true);
-        MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);
-    } else if (rho_flag == 1) MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);   // RhoInverse_Laplacian_S: alpha = rho_half (Diffusion.cpp:551-556)
-    MGOpts so = o;
-    so.maxorder = 2;                                             // Diffusion::max_order
-    CellMG opnp1(g, layout, 1, bc_scal_lin[sn], so);
-    opnp1.setScalars(1.0, theta * dt_);
-    opnp1.setACoeffs(&acoef);
-    opnp1.setBCoeffs(bp);
-    if (level > 0) { crse_scalar_at(cdata, st_new, sigma, cons); opnp1.setCoarseFineBC(&cdata, crse->g, ratio); }   // Diffusion.cpp:506-518
-    opnp1.prepare();
-    st_scal = opnp1.solve(Soln, Rhs, p.visc_tol, tol_abs);
-    if (want_flux) {                                             // fluxnp1 = theta * area * (-D grad s_new) (Diffusion.cpp:569-570); registers NavierStokes.cpp:949-990
-        opnp1.fluxes(Soln, sfp1, nullptr);
+    if (want_flux) for (int d = 0; d < 3; ++d) { sflux[d].define(layout, face_type(d), 1, 0); sflux1[d].define(layout, face_type(d), 1, 0); }
+    // NavierStokes.cpp:870-871: FillPatch of the scalars of both time levels, one ghost cell (the level BC and the S / rho of rho_flag 2)
+    for (MultiFab* Sd : {&So, &Sn}) {
+        if (Sd == &So && theta == 1.0) continue;
+        MultiFab tmp(layout, cell_type(), 1, 1);
+        fillpatch(tmp, *Sd, sigma, 1, &bc_scal[sn]);
+        MultiFab::Copy(*Sd, tmp, 0, sigma, 1, 1);
+        if (rho_flag == 2) { fillpatch(tmp, *Sd, Density, 1, &bc_scal[0]); MultiFab::Copy(*Sd, tmp, 0, Density, 1, 1); }
+    }
+    MultiFab co, cn;
+    DiffusionCrse dc{nullptr, nullptr, level > 0 ? &crse->g : nullptr, ratio};
+    if (level > 0) {                                             // the coarse state at both times (Diffusion.cpp:376-396, 506-518)
+        if (theta != 1.0) { crse_state_at(co, st_old, 0, nstate); dc.crse_old = &co; }
+        crse_state_at(cn, st_new, 0, nstate); dc.crse_new = &cn;
+    }
+    st_scal = diffuse_scalar(g, &So, nullptr, Sn, nullptr, sigma, Density, dt_, theta, rho_half, rho_flag, want_flux ? sfp : nullptr, want_flux ? sfp1 : nullptr,
+                             nullptr, 0, bp, bp, bc_scal_lin[sn], level > 0 ? &dc : nullptr, true, p.visc_tol, o);
+    if (want_flux)                                               // viscous flux registers, NavierStokes.cpp:949-990
         for (int d = 0; d < 3; ++d) {
-            mf_saxpy(sflux[d], theta * g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3] / (theta * dt_), sflux1[d], 0, 0, 1, 0);
+            mf_saxpy(sflux[d], 1.0, sflux1[d], 0, 0, 1, 0);
             if (level > 0) reg_visc->FineAdd(sflux[d], d, 0, sigma, 1, dt_);
             if (fine) fine->reg_visc->CrseInit(sflux[d], d, 0, sigma, 1, -dt_, false);
         }
-    }
-    if (cons) scale_by(Soln, Sn, Density, 0, false);            // Diffusion.cpp:583-590
-    MultiFab::Copy(Sn, Soln, 0, sigma, 1, 0);
 }
 
 void NavierStokes::velocity_advection_update(double dt_)
@@ -949,50 +958,26 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     MultiFab& Sn = S[inew];
     MultiFab& So = S[1 - inew];
     const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
-    MultiFab Rhs(layout, cell_type(), 3, 0);
     // viscous fluxes for the registers of the interfaces above and below (do_reflux && (level < finest_level || level > 0), Diffusion.cpp:790-796, 932-956)
     const bool want_flux = fine != nullptr || level > 0;
     MultiFab tflux[3];
-    TensorFlux fx{{&tflux[0], &tflux[1], &tflux[2]}, 0.0, false};
-    if (want_flux) for (int d = 0; d < 3; ++d) { tflux[d].define(layout, face_type(d), 3, 0); tflux[d].setVal(0.0); }
-    MultiFab cdata;
-    TensorCF cf{&cdata, level > 0 ? &crse->g : nullptr, ratio};
-    if (theta != 1.0 && !want_flux && m_visc_old_valid) {
-        // (1 - theta) dt div tau(U^n) from the viscous terms the prediction / advection forcing already evaluated (no fluxes wanted)
-        mf_lincomb(Rhs, (1.0 - theta) * dt_, m_visc_old, 0.0, m_visc_old, 0, 3, 0);
-    } else if (theta != 1.0) {
-        MultiFab Soln0(layout, cell_type(), 3, 1);
-        fillpatch(Soln0, So, Xvel, 3, bc_vel);
-        if (level > 0) crse_state_at(cdata, st_old, Xvel, 3);                 // crsedata at prev_time (Diffusion.cpp:733-744)
-        fx.fac = 1.0 - theta; fx.add = false;                                // computeExtensiveFluxes(..., -b/dt), b = -(1-theta) dt
-        tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt_, nullptr, ep, bc_visc, 3, level > 0 ? &cf : nullptr, want_flux ? &fx : nullptr);
-    } else Rhs.setVal(0.0);
-    {
-        const FabD *nt = Sn.d_tab, *ot = So.d_tab, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
-        const bool mom = p.do_mom_diff != 0;                     // rho_flag 3 (NavierStokes.cpp:1016): the OLD density (Diffusion.cpp:819)
-        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-            const double r = mom ? ot[f](i, j, k, Density) : ht[f](i, j, k, 0);
-            for (int n = 0; n < 3; ++n) {
-                nt[f](i, j, k, n) *= r;                          // Diffusion.cpp:825: the state holds rho u* from here on
-                rt[f](i, j, k, n) += nt[f](i, j, k, n);
-            }
-        });
+    MultiFab* tfp[3] = {&tflux[0], &tflux[1], &tflux[2]};
+    if (want_flux) for (int d = 0; d < 3; ++d) tflux[d].define(layout, face_type(d), 3, 0);
+    const bool reuse = theta != 1.0 && !want_flux && m_visc_old_valid;    // div tau(U^n) of the prediction / advection forcing
+    auto refill = [this](MultiFab& U, MultiFab& from) {                   // FillPatch of the velocity: ghost cells only change
+        MultiFab tmp(layout, cell_type(), 3, 1);
+        fillpatch(tmp, from, Xvel, 3, bc_vel);
+        MultiFab::Copy(U, tmp, 0, Xvel, 3, 1);
+    };
+    if (theta != 1.0 && !reuse) refill(So, So);
+    MultiFab co, cn;
+    DiffusionCrse dc{nullptr, nullptr, level > 0 ? &crse->g : nullptr, ratio};
+    if (level > 0) {                                             // crsedata at prev_time / cur_time (Diffusion.cpp:733-744, 876-887)
+        if (theta != 1.0 && !reuse) { crse_state_at(co, st_old, Xvel, 3); dc.crse_old = &co; }
+        crse_state_at(cn, st_new, Xvel, 3); dc.crse_new = &cn;
     }
-    double avg = 0.0;                                            // get_scaled_abs_tol (Diffusion.cpp:193-204)
-    for (int n = 0; n < 3; ++n) avg += (1.0 / 3.0) * Rhs.norm0(n, 1, 0);
-    const double tol_abs = p.visc_tol * avg;
-    MultiFab Soln(layout, cell_type(), 3, 1);
-    fillpatch(Soln, Sn, Xvel, 3, bc_vel);                        // initial guess = FillPatch(U_new) = rho u* (+ wall values)
-    MultiFab acoef(layout, cell_type(), 1, 0);
-    if (p.do_mom_diff) MultiFab::Copy(acoef, Sn, Density, 0, 1, 0);   // rho_flag 3: alpha = rho_new (Diffusion.cpp:893)
-    else MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);            // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
-    MGOpts vo = o;
-    vo.maxorder = 2;
-    if (level > 0) crse_state_at(cdata, st_new, Xvel, 3);        // crsedata at cur_time (Diffusion.cpp:876-887)
-    fx.fac = theta; fx.add = true;                               // computeExtensiveFluxes(..., b/dt) added to the old-time fluxes (:941-945)
-    st_visc = tensor_solve(g, Soln, Rhs, 1.0, theta * dt_, &acoef, ep, bc_visc, 3, p.visc_tol, tol_abs, vo, level > 0 ? &cf : nullptr,
-                           want_flux ? &fx : nullptr);
-    MultiFab::Copy(Sn, Soln, 0, Xvel, 3, 1);                     // Diffusion.cpp:928
+    st_visc = diffuse_tensor_velocity(g, &So, Sn, Density, dt_, theta, rho_half, p.do_mom_diff ? 3 : 1, reuse ? &m_visc_old : nullptr, ep, ep, bc_visc,
+                                      level > 0 ? &dc : nullptr, want_flux ? tfp : nullptr, p.visc_tol, o, [&](MultiFab& U) { refill(U, U); });
     if (want_flux)
         for (int d = 0; d < 3; ++d) {
             if (level > 0) reg_visc->FineAdd(tflux[d], d, 0, Xvel, 3, dt_);                        // :946-949
@@ -1044,6 +1029,7 @@ void NavierStokes::level_project(double dt_)
             for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) += gt[f](i, j, k, n) / ht[f](i, j, k, 0);   // :296-300
         });
     }
+    set_outflow_bcs(Pn, rho_half, 0);                            // Projection.cpp:308-325 (LEVEL_PROJ)
     MultiFab sig(layout, cell_type(), 1, 1);                     // scaleVar: sigma = 1/rho_half (restored implicitly: rho_half untouched)
     {
         const FabD *st = sig.d_tab, *ht = rho_half.d_tab;
@@ -1059,14 +1045,23 @@ void NavierStokes::level_project(double dt_)
         vold.define(layout, cell_type(), 3, 1);
         MultiFab::Copy(vold, Sn, Xvel, 0, 3, 1);
     }
-    st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+    MultiFab rhv, rhcc;                                          // divusource = getDivCond(1, time + dt) / dt, rhcc = -divusource (Projection.cpp:267-276, 379-389)
+    if (have_divu) {
+        rhv.define(layout, cell_type(), 1, 0);
+        MultiFab::Copy(rhv, Sn, Divu, 0, 1, 0);
+        mf_mult(rhv, 1.0 / dt_, 0, 1, 0);
+        mf_mult(rhv, -1.0, 0, 1, 0);
+        rhcc = make_rhcc(g, rhv, 0, 1.0, nullptr);
+    }
+    const MultiFab* rv = have_divu ? &rhv : nullptr;
+    st_nodal = nodal_projection(g, Sn, Xvel, Pn, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false, have_divu ? &rhcc : nullptr);
     fill_gradp_bc();
     if (want_crse) {                                             // crse_sync_reg->CrseInit(sync_resid_crse, geom, 1.0), Projection.cpp:401-410
-        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, true);
+        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, true, rv);
         fine->sync_reg->CrseInit(r, 1.0);
     }
     if (want_fine) {                                             // fine_sync_reg->FineAdd(sync_resid_fine, crse_geom, 1/crse_dt_ratio), :411-431
-        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, false);
+        MultiFab r = amr_sync_resid(*this, vold, Pn, sig, false, rv);
         sync_reg->FineAdd(r, 1.0 / (double)ncycle);
     }
     mf_mult(Sn, dt_, Xvel, 3, 1);                                // U_new *= dt (:438)
@@ -1102,7 +1097,9 @@ void NavierStokes::initial_velocity_project()
         MultiFab sig(layout, cell_type(), 1, 1);
         sig.setVal(1.0);                                         // constant-density initial projection (rho_wgt_vel_proj = 0)
         set_inflow_ghosts(S[inew], 1.0);
-        st_nodal = nodal_projection(g, S[inew], Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
+        MultiFab rhcc;                                           // rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788
+        if (have_divu) rhcc = make_rhcc(g, S[inew], Divu, -1.0, nullptr);
+        st_nodal = nodal_projection(g, S[inew], Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false, have_divu ? &rhcc : nullptr);
         for (int q = 0; q < 2; ++q) { P[q].setVal(0.0); Gp[q].setVal(0.0); }   // Projection.cpp:799-806
     }
 }
@@ -1128,7 +1125,15 @@ void NavierStokes::initial_sync_project(double dt_)
         });
     }
     set_inflow_ghosts(Sn, 0.0);
-    st_nodal = nodal_projection(g, Sn, Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], true);
+    MultiFab rhcc;                                               // rhcc = -(divu(strt_time + dt) - divu(strt_time)) / dt, Projection.cpp:1008-1075, 1142-1148
+    if (have_divu) {
+        MultiFab d(layout, cell_type(), 1, 0);
+        MultiFab::Copy(d, Sn, Divu, 0, 1, 0);
+        mf_saxpy(d, -1.0, So, Divu, 0, 1, 0);
+        mf_mult(d, 1.0 / dt_, 0, 1, 0);
+        rhcc = make_rhcc(g, d, 0, -1.0, nullptr);
+    }
+    st_nodal = nodal_projection(g, Sn, Xvel, phi, sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], true, have_divu ? &rhcc : nullptr);
     fill_gradp_bc();
     mf_saxpy(P[pnew], 1.0, phi, 0, 0, 1, 1);                     // P_new += phi (Projection.cpp:1176-1180)
 }
@@ -1145,6 +1150,11 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
     scalar_update_rho(dt_);
     scalar_update_tracers(dt_);
     scalar_diffusion_update(dt_);
+    if (have_divu) {                                             // NavierStokes.cpp:631-641
+        calc_divu(true);
+        calc_dsdt(dt_);
+        if (initial_step) MultiFab::Copy(S[1 - inew], S[inew], Dsdt, Dsdt, 1, 0);
+    }
     velocity_advection_update(dt_);
     if (!initial_iter) velocity_diffusion_update(dt_);
     else initial_velocity_diffusion_update(dt_);
@@ -1156,6 +1166,105 @@ double NavierStokes::advance(double dt_, int iteration_, int ncycle_)
     }
     m_in_advance = false; m_visc_old_valid = false;
     return dt_test;
+}
+
+// Projection::set_outflow_bcs / set_outflow_bcs_at_level / computeRhoG (Projection.cpp:1721-2370), 3-D: hydrostatic pressure on the nodes of an
+// outflow face when gravity != 0.  z-hi: zero (nothing to do); z-lo: upstream aborts; x / y faces: on every node column of the face,
+// integrating down from the top,  rhog -= gravity * rhoExt * dz,  phi(node k) = rhog,  rhoExt = (3 rho1 - rho2) / 2 extrapolated to the face
+// from the first two cells inside it (rho1, rho2: means of the two cell columns next to the node column; at a domain edge of the face the
+// density's BCRec decides: ext_dir the boundary value, foextrap the first column, hoextrap extrapolated).  Applied only where the level covers
+// the whole two-cell strip along the face (:1776-1803).  As upstream, the column sums run on the host: the strip (2 x nT x nz cells) is
+// gathered to rank 0, summed there, shared with the other ranks and written into phi by a kernel.  Upstream's y-hi branch differs from
+// the other three as written: rho2 of the regular columns is the mean of rho(i, j-1) and rho(i-1, j-2) (:2303-2304), followed here; its
+// ext_dir low-edge column reads outside the strip (:2317-2318), refused here.  Returns true if some face was set.
+bool NavierStokes::set_outflow_bcs(MultiFab& phi, const MultiFab& rho, int rcomp)
+{
+    const double grav = p.gravity;
+    if (!(std::abs(grav) > 0.0)) return false;
+    auto& ctx = Context::get();
+    bool any = false;
+    const int nz = g.domain.len(2);
+    const double dh = g.dx[2];
+    for (int D = 0; D < 3; ++D) for (int side = 0; side < 2; ++side) {
+        if (g.periodic[D] || (side == 0 ? p.phys_lo[D] : p.phys_hi[D]) != phys_outflow) continue;
+        if (D == 2) {
+            if (side == 1) continue;
+            throw Error("iamrx NavierStokes: outflow at the bottom with gravity (Projection::computeRhoG aborts)");
+        }
+        const int T = 1 - D, nD = g.domain.len(D), nT = g.domain.len(T);
+        BoxD sb;
+        sb.lo[D] = side == 0 ? g.domain.lo[D] : g.domain.hi[D] - 1; sb.hi[D] = sb.lo[D] + 1;
+        sb.lo[T] = g.domain.lo[T]; sb.hi[T] = g.domain.hi[T]; sb.lo[2] = g.domain.lo[2]; sb.hi[2] = g.domain.hi[2];
+        {   // the level must cover the whole strip
+            long cov = 0;
+            for (const BoxD& b : layout->boxes) {
+                long v = 1;
+                for (int d = 0; d < 3; ++d) v *= std::max(0, std::min(b.hi[d], sb.hi[d]) - std::max(b.lo[d], sb.lo[d]) + 1);
+                cov += v;
+            }
+            if (cov != 2L * nT * nz) continue;
+        }
+        const int blo = bc_scal[0].lo[T], bhi = bc_scal[0].hi[T];
+        const bool edge_lo = !g.periodic[T] && (blo == bc_ext_dir || blo == bc_hoextrap || blo == bc_foextrap);
+        const bool edge_hi = !g.periodic[T] && (bhi == bc_ext_dir || bhi == bc_hoextrap || bhi == bc_foextrap);
+        const bool yhi = D == 1 && side == 1;
+        if (yhi && edge_lo && blo == bc_ext_dir) throw Error("iamrx NavierStokes: y-hi outflow with x-lo inflow and gravity: Projection::computeRhoG reads outside its strip");
+        const int fi = D * 2 + side;
+        if (!m_outflow_strip[fi]) m_outflow_strip[fi] = std::make_shared<Layout>(std::vector<BoxD>{sb}, std::vector<int>{0}, ctx.comm->rank);
+        MultiFab rs(m_outflow_strip[fi], cell_type(), 1, 0);
+        parallel_copy(rs, rho, rcomp, 0, 1, 0, 0, nullptr);
+        std::vector<double> col((size_t)(nT + 1) * (nz + 1), 0.0);
+        if (rs.nlocal() > 0) {
+            std::vector<double> h((size_t)2 * nT * nz);
+            ctx.sync();
+            rs.copy_to_host(0, h.data());
+            // a = 1: the first cell inside the face, 2: the second; t: cell along T (ghost columns -1 / nT by the density's boundary condition)
+            auto R = [&](int a, int t, int k) -> double {
+                if (t < 0) t = g.periodic[T] ? nT - 1 : (blo == bc_ext_dir ? -1 : 0);
+                else if (t >= nT) t = g.periodic[T] ? 0 : (bhi == bc_ext_dir ? -2 : nT - 1);
+                if (t == -1) return ed_scal_lo[0 * 3 + T];
+                if (t == -2) return ed_scal_hi[0 * 3 + T];
+                const int q = side == 0 ? a - 1 : 2 - a;             // index along D inside the strip
+                int c[3]; c[D] = q; c[T] = t; c[2] = k;
+                const int n0 = D == 0 ? 2 : nT, n1 = D == 1 ? 2 : nT;
+                return h[(size_t)c[0] + (size_t)n0 * ((size_t)c[1] + (size_t)n1 * (size_t)c[2])];
+            };
+            for (int t = 0; t <= nT; ++t) {
+                double rhog = 0.0;
+                for (int k = nz - 1; k >= 0; --k) {
+                    double r1, r2;
+                    if (t == 0 && edge_lo) {
+                        if (blo == bc_ext_dir) { r1 = R(1, -1, k); r2 = R(2, -1, k); }
+                        else if (blo == bc_hoextrap) { r1 = 0.5 * (3. * R(1, 0, k) - R(1, 1, k)); r2 = 0.5 * (3. * R(2, 0, k) - R(2, 1, k)); }
+                        else { r1 = R(1, 0, k); r2 = R(2, 0, k); }
+                    } else if (t == nT && edge_hi) {
+                        if (bhi == bc_ext_dir) { r1 = R(1, nT, k); r2 = R(2, nT, k); }
+                        else if (bhi == bc_hoextrap) { r1 = 0.5 * (3. * R(1, nT - 1, k) - R(1, nT - 2, k)); r2 = 0.5 * (3. * R(2, nT - 1, k) - R(2, nT - 2, k)); }
+                        else { r1 = R(1, nT - 1, k); r2 = R(2, nT - 1, k); }
+                    } else {
+                        r1 = 0.5 * (R(1, t, k) + R(1, t - 1, k));
+                        r2 = yhi ? 0.5 * (R(1, t, k) + R(2, t - 1, k)) : 0.5 * (R(2, t, k) + R(2, t - 1, k));
+                    }
+                    const double rhoExt = 0.5 * (3. * r1 - r2);
+                    rhog -= grav * rhoExt * dh;
+                    col[(size_t)t * (nz + 1) + k] = 0.0 + rhog;
+                }
+            }
+        }
+        ctx.comm->allreduce(col.data(), (int)col.size(), ReduceOp::Sum);      // rank 0 holds the sums, the others zeros
+        double* dcol = (double*)ctx.alloc(col.size() * sizeof(double));
+        ctx.upload_async(dcol, col.data(), col.size() * sizeof(double));
+        const FabD* pt = phi.d_tab;
+        const int face = side == 0 ? g.domain.lo[D] : g.domain.hi[D] + 1, tlo = g.domain.lo[T], klo = g.domain.lo[2], nzp = nz + 1;
+        for_each(*layout, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const int id = D == 0 ? i : j, it = D == 0 ? j : i;
+            if (id == face) pt[f](i, j, k) = dcol[(long)(it - tlo) * nzp + (k - klo)];
+        });
+        ctx.free(dcol);
+        (void)nD;
+        any = true;
+    }
+    return any;
 }
 
 // Projection::initialPressureProject (Projection.cpp:841-960), called from NavierStokesBase::post_init_state (NavierStokesBase.cpp:2416-2426)
@@ -1171,6 +1280,7 @@ void NavierStokes::initial_pressure_project()
     MultiFab vel(layout, cell_type(), 3, 1);
     vel.setVal(0.0);
     vel.setVal(p.gravity, 2, 1, 1);
+    set_outflow_bcs(P[pnew], S[inew], Density);                  // Projection.cpp:893-905 (INITIAL_PRESS)
     st_nodal = nodal_projection(g, vel, 0, P[pnew], sig, 0, bc_nodal, p.proj_tol, p.proj_abs_tol, o, &Gp[pnew], false);
     fill_gradp_bc();
     MultiFab::Copy(P[1 - pnew], P[pnew], 0, 0, 1, 1);
@@ -1180,6 +1290,12 @@ void NavierStokes::initial_pressure_project()
 void NavierStokes::post_init(double stop_time)
 {
     m_stop_time = stop_time;
+    if (have_divu) {                                             // NavierStokes::initData, NavierStokes.cpp:457-479: rho at both times, divu of the initial data, dsdt = 0
+        make_rho_curr_time();
+        MultiFab::Copy(rho_ptime, rho_ctime, 0, 0, 1, 1);
+        calc_divu(true);
+        S[inew].setVal(0.0, Dsdt, 1, 0);
+    }
     initial_velocity_project();
     initial_pressure_project();
     initial_step = true;
@@ -1195,6 +1311,7 @@ void NavierStokes::post_init(double stop_time)
             advance(dt_init);
             initial_sync_project(dt_init);
             inew = 1 - inew;                                     // resetState: new <- initial data
+            if (have_divu) MultiFab::Copy(S[inew], S[1 - inew], Dsdt, Dsdt, 1, 0);   // Dsdt_Type is not reset (NavierStokesBase.cpp:2669-2676)
             MultiFab::Copy(P[1 - pnew], P[pnew], 0, 0, 1, 1);    // initOldFromNew(Press_Type)
             MultiFab::Copy(Gp[1 - pnew], Gp[pnew], 0, 0, 3, 1);  // initOldFromNew(Gradp_Type)
             initial_iter = false;

@@ -5,6 +5,7 @@
 #include "mlmg.h"
 #include "kernels.h"
 #include <memory>
+#include <functional>
 
 namespace iamrx {
 
@@ -18,7 +19,11 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
 // Projection::doMLMGNodalProjection (Source/Projection.cpp:2385-2567), single level:
 // rhs = div(vel) at nodes, solve div(sig grad phi) = rhs, vel -= sig grad phi, Gp = / += grad phi.
 MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& phi, const MultiFab& sig, int sig_comp,
-                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp);
+                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp,
+                         const MultiFab* rhcc = nullptr /* cell-centred source prepared by make_rhcc: div(sig grad phi) = div(vel) + <rhcc> */);
+void nodal_rhcc_add(const Geometry& g, MultiFab& rhs, const MultiFab& rc, const DomainBC& bc);
+MultiFab make_rhcc(const Geometry& g, const MultiFab& src, int comp, double scale, const MultiFab* drop);
+void mask_mult(MultiFab& y, int ycomp, int nc, const MultiFab& m, bool keep_where_zero, int ng);   // y *= (m == 0) or (m != 0), amrns.hip
 
 // Projection::level_project on one level that covers the domain (Source/Projection.cpp:166-450; declaration Projection.H:53-75):
 // P_new = 0; U_new /= dt; U_new += Gp_old/rho_half; sigma = 1/rho_half; nodal projection (Gp_new = grad phi, P_new = phi); U_new *= dt.
@@ -46,6 +51,39 @@ inline MGStats tensor_solve(const Geometry& g, MultiFab& soln, const MultiFab& r
                             const MultiFab* const eta[3], const DomainBC& bc, double tol_rel, double tol_abs, const MGOpts& opts)
 { return tensor_solve(g, soln, rhs, a_scalar, b_scalar, acoef, eta, &bc, 1, tol_rel, tol_abs, opts); }
 
+// ---- Diffusion operator entries on caller-owned data (diffusion.hip; reference Source/Diffusion.H:53-225) -------------------
+// the coarse level's state at the old / new time (valid cells on its own layout; the same component numbering as the fine arrays);
+// crse_new == nullptr: homogeneous coarse/fine data (the sync solves)
+struct DiffusionCrse { const MultiFab* crse_old; const MultiFab* crse_new; const Geometry* cgeom; int ratio; };
+// Diffusion::diffuse_scalar (Source/Diffusion.cpp:207-599): Crank-Nicolson update of component sigma of S_new,
+//   (alpha - theta dt div beta grad) s_new = alpha s* + (1 - theta) dt div beta grad s_old + dt delta_rhs,
+// rho_flag 0: s = S, alpha = 1; 1: alpha = rho_half; 2: s = S / rho, alpha = rho_new, S_new = s rho_new.  S_old / S_new: at least 1 ghost
+// cell, FILLED by the caller (FillPatch: boundary values of the level, Diffusion.cpp:237-239).  fluxn / fluxnp1 (may be null): the
+// extensive fluxes (1 - theta) area (-beta grad s_old) and theta area (-beta grad s_new).  add_old_time_divFlux = false: the sync form
+// (S_old unused).  Rho_old / Rho_new (null: S_old / S_new): the arrays holding the density in rho_comp.  bc: Diffusion::setDomainBC of the component.
+MGStats diffuse_scalar(const Geometry& g, const MultiFab* S_old, const MultiFab* Rho_old, MultiFab& S_new, const MultiFab* Rho_new, int sigma, int rho_comp, double dt, double theta,
+                       const MultiFab& rho_half, int rho_flag, MultiFab* const fluxn[3], MultiFab* const fluxnp1[3],
+                       const MultiFab* delta_rhs, int rhs_comp, const MultiFab* const betan[3], const MultiFab* const betanp1[3],
+                       const DomainBC& bc, const DiffusionCrse* crse, bool add_old_time_divFlux, double visc_tol, const MGOpts& o);
+// Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:617-957): (alpha - theta dt div tau) u_new = alpha u* + (1 - theta) dt div tau(u_old),
+// alpha = rho_half (rho_flag 1) or rho_new with u* weighted by rho_old (rho_flag 3, do_mom_diff).  U_old / U_new: states with the velocity
+// in components 0..2 and the density in rho_comp, 1 filled ghost cell.  visc_old_term (may be null): div tau(u_old) if the caller has it
+// already and wants no fluxes.  tflux (may be null): the summed extensive viscous fluxes.  fill_new: refills the ghost cells of U_new's
+// velocity once it holds rho u* (the FillPatch of Diffusion.cpp:866); null: they are used as they came.
+MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiFab& U_new, int rho_comp, double dt, double theta,
+                                const MultiFab& rho_half, int rho_flag, const MultiFab* visc_old_term, const MultiFab* const eta_n[3],
+                                const MultiFab* const eta_np1[3], const DomainBC bc_visc[3], const DiffusionCrse* crse,
+                                MultiFab* const tflux[3], double visc_tol, const MGOpts& o, const std::function<void(MultiFab&)>& fill_new);
+
+// Diffusion::diffuse_tensor_Vsync (Source/Diffusion.cpp:1010-1178) and Diffusion::diffuse_Ssync as NavierStokes::mac_sync uses them; see diffusion.hip
+MGStats diffuse_tensor_Vsync(const Geometry& g, MultiFab& Vsync, double dt, double theta, const MultiFab& rho_half, int rho_flag,
+                             const MultiFab* Rho_old, const MultiFab* Rho_new, int rho_comp, const MultiFab* const eta[3],
+                             const DomainBC bc_visc[3], const BCRec bc_vel[3], const Geometry* cgeom, int ratio, MultiFab* const tflux[3],
+                             double visc_tol, const MGOpts& o);
+MGStats diffuse_Ssync(const Geometry& g, MultiFab& Ssync, int sn, double dt, double theta, const MultiFab& rho_half, int rho_flag,
+                      const MultiFab& Rho_new, int rho_comp, const MultiFab* const beta[3], const DomainBC& bc, const Geometry* cgeom, int ratio,
+                      MultiFab* const flux[3], double visc_tol, const MGOpts& o);
+
 // ---- inter-level data motion (amr.hip) ------------------------------------------------------------------------
 // amrex::MultiFab::ParallelCopy between different layouts of one index space; periodic_geom != nullptr adds the periodic images
 // add = true: dst += src (MultiFab::ParallelAdd); the source regions must then map to disjoint destination cells
@@ -59,8 +97,11 @@ MGStats mac_sync_solve(const Geometry& g, FluxRegister& mr, const MultiFab& rho_
 void derive_mag_vort(const Geometry& g, MultiFab& out, int ocomp, const MultiFab& vel, int vcomp);
 void error_tag(const Geometry& g, MultiFab& tags, const MultiFab& field, int comp, int mode, double value, int level,
                const double* rb_lo, const double* rb_hi);
+// manual_tags_placement at the outflow faces (NavierStokesBase.cpp:2112-2215): mode 1 do_refine_outflow, 2 do_derefine_outflow with
+// ncoarse layers (of blocking-factor-coarsened cells) left unrefined
+struct OutflowTags { int nface = 0; int dir[6], side[6]; int mode = 0; int ncoarse = 0; };
 std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
-                               int n_error_buf);
+                               int n_error_buf, const OutflowTags* oft = nullptr);
 
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add = false);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
@@ -131,7 +172,7 @@ class NavierStokes;
 // sync residual of a level projection (Hydro::NodalProjector::computeSyncResidualCoarse / Fine): crse_side: on the nodes of the level
 // that touch both cells covered by the next finer level and cells that are not, rhs - L(phi) formed with the uncovered cells only;
 // fine side: on the nodes of the level's own boundary inside the domain, formed with the level's cells only.  Zero elsewhere.
-MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side);
+MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side, const MultiFab* rhcc = nullptr /* valid cells */);
 
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----
 struct NSParams {
@@ -154,7 +195,7 @@ struct NSParams {
     int use_ppm = 0;                     // ns.advection_scheme: 0 Godunov_PLM, 1 Godunov_PPM (NavierStokesBase.cpp:548-553)
 };
 
-enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, MAXSCAL = 4, MAXSTATE = 3 + MAXSCAL };   // Tracer2 / Temp: NavierStokes::Tracer2 / Temp (-1: absent)
+enum StateComp { Xvel = 0, Yvel = 1, Zvel = 2, Density = 3, Tracer = 4, MAXSCAL = 4, MAXSTATE = 3 + MAXSCAL, MAXSLOT = MAXSCAL + 2 };   // Tracer2 / Temp: NavierStokes::Tracer2 / Temp (-1: absent)
 
 struct ScalForm { int form[MAXSCAL]; };   // captured by device lambdas
 void scale_by(MultiFab& y, const MultiFab& x, int xcomp, int ng, bool divide);   // y (comp 0) *= or /= x(xcomp) on ng ghost cells
@@ -249,6 +290,8 @@ private:
     void level_project(double dt);
     void initial_velocity_project();
     void initial_pressure_project();
+    bool set_outflow_bcs(MultiFab& phi, const MultiFab& rho, int rcomp);   // hydrostatic data on outflow faces (Projection::set_outflow_bcs)
+    LayoutP m_outflow_strip[6];
     double m_stop_time = -1.0;
     void initial_sync_project(double dt);
     void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
@@ -269,12 +312,20 @@ private:
     // NavierStokes::Initialize (NavierStokes.cpp:43-55): Density, Tracer, [Tracer2], [Temp]; per scalar slot (0 = density): advectionType ==
     // Conservative (NS_setup.cpp:297-320), Diffusion::set_rho_flag(diffusionType) (0 Laplacian_S, 1 RhoInverse_Laplacian_S, 2 Laplacian_SoverRho)
     int nstate = 5, nscal = 2, Tracer2 = -1, Temp = -1;
+    // ns.do_temp: Divu_Type and Dsdt_Type exist (NS_setup.cpp:365-383).  They are Point-type cell data with the times of State_Type and are kept
+    // here as two more components of the S arrays (Divu = nstate, Dsdt = nstate + 1, nalloc = nstate + 2), with their BCRecs in the slots
+    // after the scalars: FillPatch in time and from the coarse level, averaging down and the regrid fill treat them like the state
+    bool have_divu = false;
+    int nalloc = 5, Divu = -1, Dsdt = -1;
+    void calc_divu(bool use_new);                                 // NavierStokes::calc_divu (NavierStokes.cpp:1876-1958)
+    void calc_dsdt(double dt);                                    // NavierStokesBase::calc_dsdt (NavierStokesBase.cpp:818-858)
+    void divu_half(MultiFab& out, double dt, int ng, bool with_dsdt);   // getDivCond(prev_time) (+ dt/2 getDsdt(prev_time)), zero without divu
     int scal_cons[MAXSCAL] = {1, 0, 0, 0}, scal_rho_flag[MAXSCAL] = {1, 0, 0, 1};
     double scal_diff[MAXSCAL] = {-1.0, 0.0, 0.0, 0.0};
     DomainBC bc_mac, bc_nodal, bc_visc[3], bc_scal_lin[MAXSCAL];
-    BCRec bc_vel[3], bc_scal[MAXSCAL], bc_gp[3];
+    BCRec bc_vel[3], bc_scal[MAXSLOT], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];     // ext_dir values [n*3+d]
-    double ed_scal_lo[3 * MAXSCAL], ed_scal_hi[3 * MAXSCAL];   // ext_dir (inflow) values of density, tracer, ... [n*3+d]
+    double ed_scal_lo[3 * MAXSLOT], ed_scal_hi[3 * MAXSLOT];   // ext_dir (inflow) values of density, tracer, ... [n*3+d]
     MultiFab diff_b[MAXSCAL][3];           // scalar diffusivities on faces (defined for the diffusive slots)
     bool any_wall = false;
 };

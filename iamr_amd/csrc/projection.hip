@@ -14,8 +14,47 @@
 
 namespace iamrx {
 
+// MLNodeLaplacian::compRHS, the cell-centred source (mlndlap_rhcc, then mlndlap_impose_neumann_bc on the sum with div(vel)):
+// rhs(node) += 1/8 of the sum over the 8 cells around the node, doubled per Neumann / inflow wall direction the node lies on.
+// rc: 1 ghost cell, zero outside the domain and on the cells that do not count (make_rhcc)
+void nodal_rhcc_add(const Geometry& g, MultiFab& rhs, const MultiFab& rc, const DomainBC& bc)
+{
+    IAMRX_ASSERT(rc.ngrow >= 1);
+    const FabD *rt = rhs.d_tab, *ct = rc.d_tab;
+    const BoxD dom = g.domain;
+    int nlo[3], nhi[3];
+    for (int d = 0; d < 3; ++d) {
+        nlo[d] = !g.periodic[d] && (bc.lo[d] == lo_neumann || bc.lo[d] == lo_inflow);
+        nhi[d] = !g.periodic[d] && (bc.hi[d] == lo_neumann || bc.hi[d] == lo_inflow);
+    }
+    const int a0 = nlo[0], a1 = nlo[1], a2 = nlo[2], b0 = nhi[0], b1 = nhi[1], b2 = nhi[2];
+    for_each(*rhs.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD c = ct[f];
+        double s = 0.0;
+        for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) s += c(i - 1 + cx, j - 1 + cy, k - 1 + cz);
+        double r = 0.125 * s;
+        if ((a0 && i == dom.lo[0]) || (b0 && i == dom.hi[0] + 1)) r *= 2.0;
+        if ((a1 && j == dom.lo[1]) || (b1 && j == dom.hi[1] + 1)) r *= 2.0;
+        if ((a2 && k == dom.lo[2]) || (b2 && k == dom.hi[2] + 1)) r *= 2.0;
+        rt[f](i, j, k) += r;
+    });
+}
+
+// scale * src(comp) on the valid cells (times the 0/1 complement of `drop` if given: cells where drop != 0 do not count), 1 ghost cell:
+// neighbours and periodic images, zero elsewhere
+MultiFab make_rhcc(const Geometry& g, const MultiFab& src, int comp, double scale, const MultiFab* drop)
+{
+    MultiFab rc(src.layout, cell_type(), 1, 1);
+    rc.setVal(0.0);
+    MultiFab::Copy(rc, src, comp, 0, 1, 0);
+    if (scale != 1.0) mf_mult(rc, scale, 0, 1, 0);
+    if (drop) mask_mult(rc, 0, 1, *drop, true, 0);
+    rc.FillBoundary(g);
+    return rc;
+}
+
 MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& phi, const MultiFab& sig, int sig_comp,
-                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp)
+                         const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp, const MultiFab* rhcc)
 {
     LayoutP layout = phi.layout;
     // set_boundary_velocity + periodic fill of the velocity ghost cells
@@ -24,6 +63,7 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
     mg.setSigma(sig, sig_comp);
     MultiFab rhs(layout, node_type(), 1, 0);
     nodal_divu(g, rhs, vel, vcomp, &bc);
+    if (rhcc) nodal_rhcc_add(g, rhs, *rhcc, bc);
     MGStats st = mg.solve(phi, rhs, rel_tol, abs_tol);
     nodal_mknewu(g, &vel, vcomp, phi, &mg.sigma(0), gp, increment_gp);
     if (gp) gp->FillBoundary(g);

@@ -152,7 +152,7 @@ void br(const TagGrid& T, IBox b, double eff, std::vector<IBox>& out)
 // tags_host: domain-sized 0/1 array (x fastest); returns boxes of the SAME index space as the tags (the caller refines them by the
 // refinement ratio), each aligned to blocking_factor, at most max_grid_size long, disjoint, covering every tagged cell grown by n_error_buf
 std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
-                               int n_error_buf)
+                               int n_error_buf, const OutflowTags* oft)
 {
     const int bf = std::max(1, blocking_factor);
     int n[3], nc[3];
@@ -171,6 +171,23 @@ std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domai
             for (int jj = std::max(0, j - n_error_buf); jj <= std::min(n[1] - 1, j + n_error_buf); ++jj)
                 for (int ii = std::max(0, i - n_error_buf); ii <= std::min(n[0] - 1, i + n_error_buf); ++ii)
                     T.t[((size_t)(kk / bf) * nc[1] + jj / bf) * nc[0] + ii / bf] = 1;
+    }
+    // NavierStokesBase::manual_tags_placement (NavierStokesBase.cpp:2112-2215), on the tags coarsened by the blocking factor
+    if (oft) for (int f = 0; f < oft->nface; ++f) {
+        const int D = oft->dir[f], hi = oft->side[f];
+        IBox ob;
+        for (int d = 0; d < 3; ++d) { ob.lo[d] = 0; ob.hi[d] = nc[d] - 1; }
+        if (oft->mode == 1) {                           // do_refine_outflow: the layer next to the face, all of it if any of it is tagged
+            ob.lo[D] = ob.hi[D] = hi ? nc[D] - 1 : 0;
+            bool has = false;
+            for (int k = ob.lo[2]; k <= ob.hi[2] && !has; ++k) for (int j = ob.lo[1]; j <= ob.hi[1] && !has; ++j) for (int i = ob.lo[0]; i <= ob.hi[0]; ++i)
+                if (T.t[((size_t)k * nc[1] + j) * nc[0] + i]) { has = true; break; }
+            if (!has) continue;
+            for (int k = ob.lo[2]; k <= ob.hi[2]; ++k) for (int j = ob.lo[1]; j <= ob.hi[1]; ++j) for (int i = ob.lo[0]; i <= ob.hi[0]; ++i) T.t[((size_t)k * nc[1] + j) * nc[0] + i] = 1;
+        } else if (oft->mode == 2 && oft->ncoarse > 0) {   // do_derefine_outflow: N_coarse_cells layers next to the face are cleared
+            if (hi) ob.lo[D] = std::max(0, nc[D] - oft->ncoarse); else ob.hi[D] = std::min(nc[D] - 1, oft->ncoarse - 1);
+            for (int k = ob.lo[2]; k <= ob.hi[2]; ++k) for (int j = ob.lo[1]; j <= ob.hi[1]; ++j) for (int i = ob.lo[0]; i <= ob.hi[0]; ++i) T.t[((size_t)k * nc[1] + j) * nc[0] + i] = 0;
+        }
     }
     std::vector<IBox> cl;
     IBox all;

@@ -172,7 +172,9 @@ class Inputs:
         return dict(max_level=max_level, regrid_int=self.ints("amr.regrid_int", 1, [1])[0], rules=rules,
                     blocking_factor=self.ints("amr.blocking_factor", 1, [8])[0], max_grid_size=self.ints("amr.max_grid_size", 1, [32])[0],
                     grid_eff=self.real("amr.grid_eff", 0.7), n_error_buf=self.ints("amr.n_error_buf", 1, [1])[0],
-                    compute_new_dt_on_regrid=self.integer("amr.compute_new_dt_on_regrid", 0))
+                    compute_new_dt_on_regrid=self.integer("amr.compute_new_dt_on_regrid", 0),
+                    do_refine_outflow=self.integer("ns.do_refine_outflow", 0), do_derefine_outflow=self.integer("ns.do_derefine_outflow", 1),
+                    nbuf_outflow=self.integer("ns.Nbuf_outflow", 1))
 
     # mapping ----------------------------------------------------------------------------------------------------------
     def problem(self):
@@ -226,7 +228,7 @@ class Inputs:
         scheme = self.string("ns.advection_scheme", "Godunov_PLM")
         if scheme not in ("Godunov_PLM", "Godunov_PPM", "BDS"):      # NavierStokesBase.cpp:548-553
             raise NotImplementedError(f"inputs: ns.advection_scheme = {scheme}; Godunov_PLM, Godunov_PPM and BDS are implemented")
-        for k in ("ns.do_temp", "ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
+        for k in ("ns.do_LES", "particles.do_nspc_particles", "eb2.geom_type"):
             if self.has(k) and self.string(k) not in ("0", "all_regular"):
                 raise NotImplementedError(f"inputs: {k} = {self.string(k)} is not implemented")
         do_trac2, do_temp = self.integer("ns.do_trac2", 0), self.integer("ns.do_temp", 0)

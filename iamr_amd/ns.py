@@ -183,13 +183,18 @@ class NavierStokes:
         check(lib().iamrx_ns_data(self.h, which, C.byref(h)))
         typ, nc, ng = self._types[which]
         if nc == 5:
-            nc = self.nstate
+            nc = self.nalloc if which in (0, 1) else self.nstate
         return MultiFab(self.layout, typ, nc, ng, _handle=h, _owned=True)
 
     @property
     def nstate(self):
         """NUM_STATE (NavierStokes.cpp:43-48): u v w density tracer [tracer2] [temp]"""
         return 5 + (1 if self.params.do_trac2 else 0) + (1 if self.params.do_temp else 0)
+
+    @property
+    def nalloc(self):
+        """components of the S arrays: the state, plus divu and dsdt (Divu_Type, Dsdt_Type) in a temperature run"""
+        return self.nstate + (2 if self.params.do_temp else 0)
 
     def stats(self):
         a, b, c = MgStats(), MgStats(), MgStats()

@@ -196,8 +196,8 @@ STATE_NAMES_3D = ["x_velocity", "y_velocity", "z_velocity", "density", "tracer"]
 
 
 def state_names(do_trac2=0, do_temp=0):
-    """names of the State_Type components (NS_setup.cpp:250-283)"""
-    return STATE_NAMES_3D + (["tracer2"] if do_trac2 else []) + (["temp"] if do_temp else [])
+    """names of the State_Type components (NS_setup.cpp:250-283), then divu and dsdt (Divu_Type, Dsdt_Type) in a temperature run"""
+    return STATE_NAMES_3D + (["tracer2"] if do_trac2 else []) + (["temp", "divu", "dsdt"] if do_temp else [])
 
 
 def from_level_data(geom_n, prob_lo, prob_hi, boxes, arrays, time, step, names=None):

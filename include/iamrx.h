@@ -355,8 +355,10 @@ int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep);
  * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role); 10, 11: the last two MAC potentials (the
  * initial-guess history of the MAC solve, part of a checkpoint) */
 int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
-/* overwrite state (0,1), pressure (2,3) or grad p (4,5) with src (same layout, ncomp, ngrow): the role of
- * NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420) */
+/* overwrite state (0,1), pressure (2,3) or grad p (4,5) with src (same layout and ngrow; ncomp at most the array's: the leading
+ * components are set): the role of NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420).
+ * The state arrays hold u v w density tracer [tracer2] [temp], and with ns.do_temp two more components, divu and dsdt (the
+ * reference's Divu_Type / Dsdt_Type), which the library computes. */
 int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src);      /* which: 0..5, 10, 11 */
 /* checkpoint / restart of one level (AmrLevel::checkPoint / NavierStokesBase::restart role, Source/NavierStokesBase.cpp:856-897,
  * 2706-2727): what outlives a time step besides the arrays of iamrx_ns_data.  state[16] = time, dt, nstep, State_Type new / old time,
@@ -435,6 +437,11 @@ int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blockin
  * NavierStokesBase::computeNewDt(post_regrid_flag = 1) (Source/NavierStokesBase.cpp:971-982), as Amr::timeStep does; 0 = levels that
  * existed keep their dt, new levels start with dt_level[l-1] / n_cycle[l]. */
 int iamrx_amr_set_compute_new_dt_on_regrid(iamrx_amr a, int on);
+/* NavierStokesBase::manual_tags_placement (Source/NavierStokesBase.cpp:2112-2215; ns.do_refine_outflow = 0, ns.do_derefine_outflow = 1,
+ * ns.Nbuf_outflow = 1 are the defaults here as upstream): with an outflow face, either refine the whole layer next to it once it holds a
+ * tag, or keep Nbuf_outflow level-0 cells (rounded up to the blocking factor, grown level by level) next to it unrefined.  Call after
+ * iamrx_amr_set_regrid. */
+int iamrx_amr_set_outflow_tagging(iamrx_amr a, int do_refine_outflow, int do_derefine_outflow, int nbuf_outflow);
 int iamrx_amr_regrid(iamrx_amr a, int* changed);
 /* install given grids of levels 1 .. nfine_levels (boxes in each level's own index space, 6 ints per box, level by level) and fill them */
 int iamrx_amr_install_grids(iamrx_amr a, int nfine_levels, const int* nboxes, const int* boxes, int* changed);

@@ -208,6 +208,9 @@ void orc_nodal_solve_cov(const orc_geom* g, orc_fab* phi, const orc_fab* rhs, co
                          const orc_mg_opts* o, orc_mg_stats* st);
 void orc_nodal_project_cov(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig, const int lobc[3], const int hibc[3],
                            const orc_fab* cov, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
+void orc_nodal_rhcc_add(const orc_geom* g, orc_fab* rhs, const orc_fab* rhcc, const int lobc[3], const int hibc[3], const orc_fab* cov);
+void orc_nodal_project_rhcc(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig, const int lobc[3], const int hibc[3],
+                            const orc_fab* cov, const orc_fab* rhcc, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);
 void orc_nodal_project(const orc_geom* g, orc_fab* vel /*3 comps, 1 ghost*/, orc_fab* phi /*node, 1 ghost*/,
                        const orc_fab* sig, const int lobc[3], const int hibc[3],
                        double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st);

@@ -37,6 +37,8 @@ struct orc_amr {
 };
 typedef struct orc_amr orc_amr;
 
+void amr_composite_project_rhcc(orc_amr* a, int c0, int nl, orc_fab* vel[], orc_fab* phi[], const orc_fab* sig[], const orc_fab* rhnd,
+                                orc_fab* const rhcc[], double rtol, double atol, int increment_gp, double inflow_scale, orc_mg_stats* st);
 int orc_syncreg_literal = 1;
 double orc_syncreg_diff_max = 0.0;
 void orc_set_syncreg_literal(int on) { orc_syncreg_literal = on; }
@@ -193,6 +195,18 @@ static orc_fab masked_sigma(const orc_ns_state* s, const orc_fab* sig, int excl_
     orc_sigma_fill_bc(g, &m);
     return m;
 }
+/* 1 on the cells of the level (not under the next finer level if excl_fine), 0 elsewhere */
+static orc_fab cell_mask(const orc_ns_state* s, int excl_fine)
+{
+    const orc_geom* g = &s->g;
+    orc_fab m = orc_alloc(g->n, ORC_CELL, 0, 1);
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) {
+        int on = ns_covered(s, i, j, k);
+        if (on && excl_fine && s->fine && fine_covers(s->fine, i, j, k)) on = 0;
+        A4(&m, i, j, k, 0) = on ? 1.0 : 0.0;
+    }
+    return m;
+}
 /* velocity (3 comps, 1 ghost) with the same restriction; ghost cells: periodic images of the masked field, cells outside walls
  * keep the incoming values (inflow data; orc_nodal_divu_bc ignores the rest) */
 static orc_fab masked_vel(const orc_ns_state* s, const orc_fab* vel, int excl_fine)
@@ -223,7 +237,7 @@ static void restrict_nodes(const orc_ns_state* f, orc_fab* crse, orc_fab* fine /
 /* Hydro::NodalProjector::computeSyncResidualCoarse -> MLNodeLaplacian::compSyncResidualCoarse: on the nodes of level s that touch
  * both cells covered by the finer level and cells that are not, the residual rhs - L(phi) formed with the uncovered cells only
  * (velocity and sigma zeroed under the fine level); zero elsewhere. */
-orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig)
+orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc)
 {
     const orc_geom* g = &s->g;
     orc_fab r = orc_alloc(g->n, ORC_NODE, 1, 1);
@@ -233,6 +247,7 @@ orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const or
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) A4(&ph, i, j, k, 0) = A4(phi, i, j, k, 0);
     orc_nodal_fill_bc(g, &ph, s->nlobc, s->nhibc);
     orc_nodal_divu_bc(g, &rhs, &um, s->nlobc, s->nhibc);
+    if (rhcc) { orc_fab cm = cell_mask(s, 1); orc_nodal_rhcc_add(g, &rhs, rhcc, s->nlobc, s->nhibc, &cm); orc_free(&cm); }
     orc_nodal_adotx(g, &ax, &ph, &sm);
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
         A4(&r, i, j, k, 0) = (node_vs_fine(s->fine, i, j, k) == 2 && !on_dirichlet_face(s, i, j, k)) ? A4(&rhs, i, j, k, 0) - A4(&ax, i, j, k, 0) : 0.0;
@@ -242,7 +257,7 @@ orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const or
 
 /* computeSyncResidualFine -> compSyncResidualFine: on the nodes of the boundary of level s (> 0) inside the domain, the residual
  * formed with the cells of the level only; zero elsewhere. */
-orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig)
+orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc)
 {
     const orc_geom* g = &s->g;
     orc_fab r = orc_alloc(g->n, ORC_NODE, 1, 1);
@@ -252,6 +267,7 @@ orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const or
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) A4(&ph, i, j, k, 0) = A4(phi, i, j, k, 0);
     orc_nodal_fill_bc(g, &ph, s->nlobc, s->nhibc);
     orc_nodal_divu_bc(g, &rhs, &um, s->nlobc, s->nhibc);
+    if (rhcc) { orc_fab cm = cell_mask(s, 0); orc_nodal_rhcc_add(g, &rhs, rhcc, s->nlobc, s->nhibc, &cm); orc_free(&cm); }
     orc_nodal_adotx(g, &ax, &ph, &sm);
     for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
         A4(&r, i, j, k, 0) = (node_class(s, i, j, k) == ND_BOUNDARY && !on_dirichlet_face(s, i, j, k)) ? A4(&rhs, i, j, k, 0) - A4(&ax, i, j, k, 0) : 0.0;
@@ -420,6 +436,13 @@ void amr_composite_project(orc_amr* a, int c0, int nl, orc_fab* vel[] /*cell, 3 
                            const orc_fab* sig[] /*cell, valid*/, const orc_fab* rhnd /*nodes of level c0 or NULL*/, double rtol, double atol,
                            int increment_gp, double inflow_scale, orc_mg_stats* st)
 {
+    amr_composite_project_rhcc(a, c0, nl, vel, phi, sig, rhnd, NULL, rtol, atol, increment_gp, inflow_scale, st);
+}
+/* the same with a cell-centred source per level (rhcc[l] or NULL): div(sig grad phi) = div(vel) + rhnd + <rhcc>, <.> = the node average
+ * over the uncovered cells of the level (MLNodeLaplacian::compRHS) */
+void amr_composite_project_rhcc(orc_amr* a, int c0, int nl, orc_fab* vel[], orc_fab* phi[], const orc_fab* sig[], const orc_fab* rhnd,
+                                orc_fab* const rhcc[], double rtol, double atol, int increment_gp, double inflow_scale, orc_mg_stats* st)
+{
     clev L[8];
     orc_fab b[8], x[8], r[8], p[8], q[8];
     int singular = 1;
@@ -470,6 +493,7 @@ void amr_composite_project(orc_amr* a, int c0, int nl, orc_fab* vel[] /*cell, 3 
             }
             orc_fab d = orc_alloc(g->n, ORC_NODE, 0, 1);
             orc_nodal_divu_bc(g, &d, &um, s->nlobc, s->nhibc);
+            if (rhcc && rhcc[l]) { orc_fab cm = cell_mask(s, l < nl - 1); orc_nodal_rhcc_add(g, &d, rhcc[l], s->nlobc, s->nhibc, &cm); orc_free(&cm); }
             for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
                 double v = A4(&d, i, j, k, 0);
                 if (l == 0 && rhnd) v += A4(rhnd, i, j, k, 0);
@@ -640,7 +664,7 @@ static void avg_down_nodes(const orc_ns_state* f, const orc_fab* fine, orc_fab* 
 static void avg_down(orc_amr* a, int lev)
 {
     orc_ns_state *c = a->lev[lev], *f = a->lev[lev + 1];
-    avg_down_cells(f, S_NEW(f), S_NEW(c), 0, c->nstate);
+    avg_down_cells(f, S_NEW(f), S_NEW(c), 0, c->nalloc);        /* state, and divu / dsdt (NavierStokes.cpp:1859-1872) */
     for (int l = lev; l < a->nlev; ++l) ns_make_rho_curr_time(a->lev[l]);
     avg_down_nodes(f, c->initial_step ? P_NEW(f) : &f->p_avg, P_NEW(c));
     avg_down_cells(f, GP_NEW(f), GP_NEW(c), 0, 3);
@@ -746,7 +770,7 @@ static void mac_sync_compute(orc_amr* a, int lev, orc_fab Ucorr[3])
     orc_fab Sc = ns_fillpatch_time(c, prev_time, 0, Density, c->nscal, 3);
     const int mom = c->p.do_mom_diff;
     if (mom) { const size_t N = orc_npts(&Smf); for (int n = 0; n < 3; ++n) for (size_t q = 0; q < N; ++q) Smf.p[q + N * n] *= Sc.p[q]; }
-    orc_fab tfv = orc_alloc(g->n, ORC_CELL, 1, 3), tfs = orc_alloc(g->n, ORC_CELL, 1, c->nscal), divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_fab tfv = orc_alloc(g->n, ORC_CELL, 1, 3), tfs = orc_alloc(g->n, ORC_CELL, 1, c->nscal), divu = ns_divu_half(c, dt, 1, 0);   /* getDivCond(nghost_force, prev_time), MacProj.cpp:562 */
     const orc_fab* Gp = GP_OLD(c);
     /* viscous forcing at the old time (MacProj.cpp:566-572) */
     orc_fab vvisc = orc_alloc(g->n, ORC_CELL, 1, 3);
@@ -974,12 +998,12 @@ static void level_sync(orc_amr* a, int lev, int crse_iteration)
          * The residual lives on the boundary of level c, which the next finer level never touches (proper nesting). */
         orc_fab sg1 = orc_alloc(g->n, ORC_CELL, 1, 1);
         for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&sg1, i, j, k, 0) = A4(&sig_c, i, j, k, 0);
-        orc_fab r = amr_sync_resid_fine(c, &vold_c, &phi_c, &sg1);
+        orc_fab r = amr_sync_resid_fine(c, &vold_c, &phi_c, &sg1, NULL);
         for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i)
             if (node_vs_fine(f, i, j, k) != 0) A4(&r, i, j, k, 0) = 0.0;
         syncreg_fine_add(c, &r, 1.0 / (double)crse_dt_ratio);
         {   /* literally: crsr_sync_reg->CompAdd(sync_resid_fine, crse_geom, crsr_geom, coarsened boxes of level lev+1, invrat) */
-            orc_ndmf* rb = orc_sync_resid_fine_boxes(c, &vold_c, &phi_c, &sg1);
+            orc_ndmf* rb = orc_sync_resid_fine_boxes(c, &vold_c, &phi_c, &sg1, NULL);
             int* pb = (int*)malloc(sizeof(int) * 6 * (size_t)f->nbox);
             for (int q = 0; q < f->nbox; ++q) for (int d = 0; d < 3; ++d) { pb[6 * q + d] = f->boxes[6 * q + d] / f->ratio; pb[6 * q + 3 + d] = (f->boxes[6 * q + 3 + d] + 1) / f->ratio - 1; }
             orc_syncreg_comp_add(c->sync_lit, rb, g, &c->crse->g, f->nbox, pb, 1.0 / (double)crse_dt_ratio);
@@ -1135,6 +1159,18 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
         ns_set_time_level(s, 0.0, 0.0, 0.0);
     }
     orc_fab* vel[8]; orc_fab* phi[8]; const orc_fab* sigp[8]; orc_fab sig[8], vv[8];
+    orc_fab rc[8]; orc_fab* rcp[8];
+    const int have_divu = a->lev[0]->have_divu;
+    for (int l = 0; l < nl; ++l) { rc[l].p = NULL; rcp[l] = NULL; }
+    if (have_divu)                          /* NavierStokes::initData (NavierStokes.cpp:457-479), level by level: rho at both times, divu, dsdt = 0 */
+        for (int l = 0; l < nl; ++l) {
+            orc_ns_state* s = a->lev[l];
+            const orc_geom* g = &s->g;
+            ns_make_rho_curr_time(s);
+            orc_copy_all(&s->rho_ptime, &s->rho_ctime);
+            ns_calc_divu(s, 1);
+            for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S_NEW(s), i, j, k, s->Dsdt) = 0.0;
+        }
     /* ---- post_init_state (NavierStokesBase.cpp:2369-2439) ---- */
     const orc_ns_params* p = &a->lev[0]->p;
     if (p->init_vel_iter <= 0) {
@@ -1147,8 +1183,14 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
             sig[l] = orc_alloc(s->g.n, ORC_CELL, 0, 1); orc_setval(&sig[l], 1.0);       /* rho_wgt_vel_proj = 0 */
             vv[l] = *S_NEW(s); vv[l].nc = 3;
             vel[l] = &vv[l]; phi[l] = P_OLD(s); sigp[l] = &sig[l];
+            if (have_divu) {                /* rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788 */
+                const orc_geom* g = &s->g;
+                rc[l] = orc_alloc(g->n, ORC_CELL, 0, 1); rcp[l] = &rc[l];
+                for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&rc[l], i, j, k, 0) = -A4(S_NEW(s), i, j, k, s->Divu);
+            }
         }
-        amr_composite_project(a, 0, nl, vel, phi, sigp, NULL, p->proj_tol, p->proj_abs_tol, 0, 1.0, &a->lev[0]->st_nodal);
+        amr_composite_project_rhcc(a, 0, nl, vel, phi, sigp, NULL, have_divu ? rcp : NULL, p->proj_tol, p->proj_abs_tol, 0, 1.0, &a->lev[0]->st_nodal);
+        for (int l = 0; l < nl; ++l) if (rc[l].p) { orc_free(&rc[l]); rc[l].p = NULL; }
         for (int l = 0; l < nl; ++l) {
             orc_ns_state* s = a->lev[l];
             orc_setval(P_OLD(s), 0.0); orc_setval(P_NEW(s), 0.0); orc_setval(GP_OLD(s), 0.0); orc_setval(GP_NEW(s), 0.0);
@@ -1238,9 +1280,15 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
                     A4(&sig[l], i, j, k, 0) = ns_covered(s, i, j, k) ? 1.0 / A4(&s->rho_half, i, j, k, 0) : 0.0;
                 vv[l] = *Un; vv[l].nc = 3;
                 vel[l] = &vv[l]; phi[l] = P_OLD(s); sigp[l] = &sig[l];
+                if (have_divu) {            /* rhcc = -(divu(strt_time + dt) - divu(strt_time)) / dt, Projection.cpp:1008-1075, 1142-1148 */
+                    rc[l] = orc_alloc(g->n, ORC_CELL, 0, 1); rcp[l] = &rc[l];
+                    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+                        A4(&rc[l], i, j, k, 0) = -((A4(S_NEW(s), i, j, k, s->Divu) - A4(S_OLD(s), i, j, k, s->Divu)) * (1. / dt_init));
+                }
             }
             for (int l = fin; l >= 1; --l) avg_down_cells(a->lev[l], vel[l], vel[l - 1], 0, 3);
-            amr_composite_project(a, 0, nl, vel, phi, sigp, NULL, p->proj_tol, p->proj_abs_tol, 1, 0.0, &a->lev[0]->st_nodal);
+            amr_composite_project_rhcc(a, 0, nl, vel, phi, sigp, NULL, have_divu ? rcp : NULL, p->proj_tol, p->proj_abs_tol, 1, 0.0, &a->lev[0]->st_nodal);
+            for (int l = 0; l < nl; ++l) if (rc[l].p) { orc_free(&rc[l]); rc[l].p = NULL; }
             for (int l = 0; l < nl; ++l) {
                 orc_ns_state* s = a->lev[l];
                 const size_t N = orc_npts(P_NEW(s));
@@ -1251,6 +1299,10 @@ void orc_amr_post_init(orc_amr* a, double stop_time)
             for (int k = 0; k < nl; ++k) {                           /* resetState(strt_time, dt_init, dt_init) */
                 orc_ns_state* s = a->lev[k];
                 s->inew = 1 - s->inew;
+                if (s->have_divu) {         /* Dsdt_Type is not reset (NavierStokesBase.cpp:2669-2676) */
+                    const orc_geom* g = &s->g;
+                    for (int kk = 0; kk < g->n[2]; ++kk) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S_NEW(s), i, j, kk, s->Dsdt) = A4(S_OLD(s), i, j, kk, s->Dsdt);
+                }
                 orc_copy_all(P_OLD(s), P_NEW(s)); orc_copy_all(GP_OLD(s), GP_NEW(s));
                 ns_set_time_level(s, 0.0, dt_init, dt_init);
                 s->initial_iter = 0;
@@ -1345,8 +1397,8 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
             else { orc_fab none = orc_alloc(g.n, ORC_CELL, 0, 1); src.cov = none; src.nbox = 0; src.st_new = cur_time; src.st_old = cur_time - dt_old; }
             src.crse = c;
             orc_fab Sv = ns_fillpatch_time(&src, cur_time, 0, Xvel, 3, 1);
-            orc_fab Sq[ORC_MAXSCAL];
-            for (int n = 0; n < s->nscal; ++n) Sq[n] = ns_fillpatch_time(&src, cur_time, 0, Density + n, 1, 1);
+            orc_fab Sq[ORC_MAXSLOT];                  /* the scalars, and divu / dsdt (NavierStokesBase.cpp:1742-1754, 1800-1805) */
+            for (int n = 0; n < s->nalloc - 3; ++n) Sq[n] = ns_fillpatch_time(&src, cur_time, 0, Density + n, 1, 1);
             const double tp = 0.5 * (s->pt_new[0] + s->pt_new[1]);
             orc_fab Gv = ns_fillpatch_time(&src, ol ? 0.5 * (ol->pt_new[0] + ol->pt_new[1]) : tp, 1, 0, 3, 1);
             for (int q = 0; q < 2; ++q) {
@@ -1355,11 +1407,11 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
                     A4(&s->S[q], i, j, k, n) = A4(&Sv, i, j, k, n);
                     A4(&s->Gp[q], i, j, k, n) = A4(&Gv, i, j, k, n);
                 }
-                for (int n = 0; n < s->nscal; ++n)
+                for (int n = 0; n < s->nalloc - 3; ++n)
                 for (int k = -1; k <= g.n[2]; ++k) for (int j = -1; j <= g.n[1]; ++j) for (int i = -1; i <= g.n[0]; ++i)
                     A4(&s->S[q], i, j, k, Density + n) = A4(&Sq[n], i, j, k, 0);
             }
-            orc_free(&Sv); for (int n = 0; n < s->nscal; ++n) orc_free(&Sq[n]); orc_free(&Gv);
+            orc_free(&Sv); for (int n = 0; n < s->nalloc - 3; ++n) orc_free(&Sq[n]); orc_free(&Gv);
             if (!ol) orc_free(&src.cov);
             /* pressure: node_bilinear_interp of the coarse pressure on every node of the new level, then the old level's nodes */
             const orc_fab* Pc = P_NEW(c);

@@ -649,3 +649,54 @@ void orc_nodal_project_cov(const orc_geom* g, orc_fab* vel, orc_fab* phi, const 
         if (!cov || A4(cov, i, j, k, 0) != 0.0) A4(vel, i, j, k, n) = A4(&v2, i, j, k, n);
     orc_free(&v2); orc_free(&rhs);
 }
+
+/* MLNodeLaplacian::compRHS, the cell-centred source (mlndlap_rhcc, then mlndlap_impose_neumann_bc on the sum with div(vel)):
+ * rhs(node) += 1/8 of the sum over the 8 cells around the node -- cells outside a non-periodic domain face, or outside `cov`
+ * (NULL: the whole domain), count zero -- doubled per Neumann / inflow wall direction the node lies on */
+void orc_nodal_rhcc_add(const orc_geom* g, orc_fab* rhs, const orc_fab* rhcc, const int lobc[3], const int hibc[3], const orc_fab* cov)
+{
+    for (int k = 0; k <= g->n[2]; ++k) for (int j = 0; j <= g->n[1]; ++j) for (int i = 0; i <= g->n[0]; ++i) {
+        double s = 0.0;
+        for (int cz = 0; cz < 2; ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) {
+            int cell[3] = {i - 1 + cx, j - 1 + cy, k - 1 + cz}, out = 0;
+            for (int e = 0; e < 3; ++e) {
+                if (cell[e] >= 0 && cell[e] < g->n[e]) continue;
+                if (g->periodic[e]) cell[e] = (cell[e] % g->n[e] + g->n[e]) % g->n[e]; else out = 1;
+            }
+            if (out) continue;
+            if (cov && A4(cov, cell[0], cell[1], cell[2], 0) == 0.0) continue;
+            s += A4(rhcc, cell[0], cell[1], cell[2], 0);
+        }
+        double r = 0.125 * s;
+        const int idx[3] = {i, j, k};
+        for (int e = 0; e < 3; ++e) {
+            if (g->periodic[e]) continue;
+            if (idx[e] == 0 && NEU(lobc[e])) r *= 2.0;
+            if (idx[e] == g->n[e] && NEU(hibc[e])) r *= 2.0;
+        }
+        A4(rhs, i, j, k, 0) += r;
+    }
+}
+
+/* orc_nodal_project / orc_nodal_project_cov with a cell-centred source: div(sig grad phi) = div(vel) + <rhcc> (Hydro::NodalProjector
+ * with rhcc; Projection.cpp passes rhcc = -divu/dt) */
+void orc_nodal_project_rhcc(const orc_geom* g, orc_fab* vel, orc_fab* phi, const orc_fab* sig, const int lobc[3], const int hibc[3],
+                            const orc_fab* cov, const orc_fab* rhcc, double rtol, double atol, const orc_mg_opts* o, orc_mg_stats* st)
+{
+    orc_fab rhs = orc_alloc(g->n, ORC_NODE, 0, 1);
+    orc_nodal_divu_bc(g, &rhs, vel, lobc, hibc);
+    if (rhcc) orc_nodal_rhcc_add(g, &rhs, rhcc, lobc, hibc, cov);
+    if (!cov) { orc_nodal_solve(g, phi, &rhs, sig, lobc, hibc, rtol, atol, o, st); orc_nodal_mknewu(g, vel, phi, sig); }
+    else {
+        orc_nodal_solve_cov(g, phi, &rhs, sig, lobc, hibc, cov, rtol, atol, o, st);
+        orc_fab v2 = orc_alloc(g->n, ORC_CELL, 0, 3);
+        for (int n = 0; n < 3; ++n)
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&v2, i, j, k, n) = A4(vel, i, j, k, n);
+        orc_nodal_mknewu(g, &v2, phi, sig);
+        for (int n = 0; n < 3; ++n)
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            if (A4(cov, i, j, k, 0) != 0.0) A4(vel, i, j, k, n) = A4(&v2, i, j, k, n);
+        orc_free(&v2);
+    }
+    orc_free(&rhs);
+}

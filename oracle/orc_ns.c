@@ -96,8 +96,9 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
     s->scal_cons[1] = p->do_cons_trac != 0; s->scal_rho_flag[1] = p->do_cons_trac ? 2 : 0; s->scal_diff[1] = p->tracer_diff_coef;   /* NS_setup.cpp:304-310 */
     if (p->do_trac2) { const int n = s->Tracer2 - Density; s->scal_cons[n] = p->do_cons_trac2 != 0; s->scal_rho_flag[n] = p->do_cons_trac2 ? 2 : 0; s->scal_diff[n] = p->tracer2_diff_coef; }
     if (p->do_temp) { const int n = s->Temp - Density; s->scal_cons[n] = 0; s->scal_rho_flag[n] = 1; s->scal_diff[n] = p->temp_cond_coef; }   /* NS_setup.cpp:302, default RhoInverse_Laplacian_S */
+    s->have_divu = p->do_temp != 0; s->Divu = s->nstate; s->Dsdt = s->nstate + 1; s->nalloc = s->nstate + (s->have_divu ? 2 : 0);
     for (int q = 0; q < 2; ++q) {
-        s->S[q] = orc_alloc(g->n, ORC_CELL, 1, s->nstate);
+        s->S[q] = orc_alloc(g->n, ORC_CELL, 1, s->nalloc);
         s->P[q] = orc_alloc(g->n, ORC_NODE, 1, 1);
         s->Gp[q] = orc_alloc(g->n, ORC_CELL, 1, 3);
     }
@@ -134,6 +135,13 @@ orc_ns_state* orc_ns_create(const orc_geom* g, const orc_ns_params* p, const orc
             s->bc_scal[n].lo[d] = is_temp ? temp_bctype(plo) : scal_bctype(plo); s->bc_scal[n].hi[d] = is_temp ? temp_bctype(phi_) : scal_bctype(phi_);
             s->ed_scal_lo[n * 3 + d] = p->scal_bc_lo[d * 4 + n]; s->ed_scal_hi[n * 3 + d] = p->scal_bc_hi[d * 4 + n];
             s->slobc[n * 3 + d] = linop_of_bctype(s->bc_scal[n].lo[d]); s->shibc[n * 3 + d] = linop_of_bctype(s->bc_scal[n].hi[d]);
+        }
+        if (s->have_divu) {     /* divu_bc / dsdt_bc, NS_BC.H:42-50; dsdt's ext_dir faces are filled with zero (homogeneous_bf, NS_setup.cpp:383) */
+            const int a = s->nscal, b = s->nscal + 1;
+            s->bc_scal[a].lo[d] = plo == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_REFLECT_EVEN; s->bc_scal[a].hi[d] = phi_ == PHYS_INTERIOR ? ORC_BC_INT_DIR : ORC_BC_REFLECT_EVEN;
+            s->bc_scal[b].lo[d] = plo == PHYS_INTERIOR ? ORC_BC_INT_DIR : ((plo == PHYS_INFLOW || plo == PHYS_OUTFLOW) ? ORC_BC_EXT_DIR : ORC_BC_REFLECT_EVEN);
+            s->bc_scal[b].hi[d] = phi_ == PHYS_INTERIOR ? ORC_BC_INT_DIR : ((phi_ == PHYS_INFLOW || phi_ == PHYS_OUTFLOW) ? ORC_BC_EXT_DIR : ORC_BC_REFLECT_EVEN);
+            s->ed_scal_lo[a * 3 + d] = s->ed_scal_hi[a * 3 + d] = s->ed_scal_lo[b * 3 + d] = s->ed_scal_hi[b * 3 + d] = 0.0;
         }
     }
     return s;
@@ -379,7 +387,7 @@ static orc_fab fillpatch(const orc_ns_state* s, const orc_fab* src, int sc, int 
     for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
         A4(&f, i, j, k, n) = A4(src, i, j, k, sc + n);
     orc_fill_periodic(&f, g, ORC_CELL);
-    const int is_scal = (bc >= s->bc_scal && bc < s->bc_scal + ORC_MAXSCAL);
+    const int is_scal = (bc >= s->bc_scal && bc < s->bc_scal + ORC_MAXSLOT);
     const long so = is_scal ? 3 * (bc - s->bc_scal) : 0;
     if (bc) orc_fill_physbc_cc(&f, g, bc, is_vel ? s->ed_vel_lo : (is_scal ? s->ed_scal_lo + so : NULL),
                                is_vel ? s->ed_vel_hi : (is_scal ? s->ed_scal_hi + so : NULL));
@@ -633,7 +641,7 @@ void ns_set_inflow_ghosts(const orc_ns_state* s, orc_fab* vel, double inflow_sca
 /* Projection::doMLMGNodalProjection on ONE level (Projection.cpp:2385-2567).  sync != 0 (level_project only): the sync residuals of
  * Projection.cpp:367-377 are computed from the unprojected velocity and the solution and go into the sync registers (:401-431). */
 static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost, comps 0..2*/, orc_fab* phi, const orc_fab* sig,
-                                int increment_gp, double inflow_scale, int sync)
+                                int increment_gp, double inflow_scale, int sync, const orc_fab* rhcc /* cell source (-divu/dt ...) or NULL */)
 {
     const orc_geom* g = &s->g;
     /* set_boundary_velocity + FillBoundary of vel ghost cells (periodic) */
@@ -647,7 +655,8 @@ static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost,
         for (int n = 0; n < 3; ++n)
         for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) A4(&vold, i, j, k, n) = A4(vel, i, j, k, n);
     }
-    if (s->level == 0) orc_nodal_project(g, vel, phi, sig, s->nlobc, s->nhibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+    if (rhcc) orc_nodal_project_rhcc(g, vel, phi, sig, s->nlobc, s->nhibc, s->level == 0 ? NULL : &s->cov, rhcc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
+    else if (s->level == 0) orc_nodal_project(g, vel, phi, sig, s->nlobc, s->nhibc, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
     else orc_nodal_project_cov(g, vel, phi, sig, s->nlobc, s->nhibc, &s->cov, s->p.proj_tol, s->p.proj_abs_tol, &s->o, &s->st_nodal);
     /* Gp_new := grad(phi) or += (Projection.cpp:2549-2563), then FillPatch(Gp) */
     orc_fab gp = orc_alloc(g->n, ORC_CELL, 0, 3);
@@ -662,18 +671,18 @@ static void nodal_project_level(orc_ns_state* s, orc_fab* vel /*3 comps 1 ghost,
     ns_fill_gp(s, G, 0.5 * (s->pt_new[0] + s->pt_new[1]));   /* FillPatch(Gradp_Type) at its current time, Projection.cpp:2564-2565 */
     orc_free(&gp);
     if (want_crse) {            /* crse_sync_reg->CrseInit(sync_resid_crse, geom, 1.0) */
-        orc_fab r = amr_sync_resid_crse(s, &vold, phi, sig);
+        orc_fab r = amr_sync_resid_crse(s, &vold, phi, sig, rhcc);
         syncreg_crse_init(s->fine, &r, 1.0);
         orc_free(&r);
-        orc_ndmf* rb = orc_sync_resid_crse_boxes(s, &vold, phi, sig);          /* the same, box by box, into the literal register */
+        orc_ndmf* rb = orc_sync_resid_crse_boxes(s, &vold, phi, sig, rhcc);          /* the same, box by box, into the literal register */
         orc_syncreg_crse_init(s->fine->sync_lit, rb, g, 1.0);
         orc_ndmf_destroy(rb);
     }
     if (want_fine) {            /* fine_sync_reg->FineAdd(sync_resid_fine, crse_geom, 1/crse_dt_ratio) */
-        orc_fab r = amr_sync_resid_fine(s, &vold, phi, sig);
+        orc_fab r = amr_sync_resid_fine(s, &vold, phi, sig, rhcc);
         syncreg_fine_add(s, &r, 1.0 / (double)s->ncycle);
         orc_free(&r);
-        orc_ndmf* rb = orc_sync_resid_fine_boxes(s, &vold, phi, sig);
+        orc_ndmf* rb = orc_sync_resid_fine_boxes(s, &vold, phi, sig, rhcc);
         orc_syncreg_fine_add(s->sync_lit, rb, &s->crse->g, 1.0 / (double)s->ncycle);
         orc_ndmf_destroy(rb);
     }
@@ -693,7 +702,13 @@ static void initial_velocity_project(orc_ns_state* s)
         orc_fab sig = orc_alloc(g->n, ORC_CELL, 1, 1);
         orc_setval(&sig, 1.0);       /* constant-density initial projection; scaleVar inverts: 1/1 */
         orc_fab v = vel_view(S_NEW(s));
-        nodal_project_level(s, &v, phi, &sig, 0, 1.0, 0);
+        orc_fab rhcc; rhcc.p = NULL;
+        if (s->have_divu) {                 /* rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788 */
+            rhcc = orc_alloc(g->n, ORC_CELL, 0, 1);
+            for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&rhcc, i, j, k, 0) = -A4(S_NEW(s), i, j, k, s->Divu);
+        }
+        nodal_project_level(s, &v, phi, &sig, 0, 1.0, 0, rhcc.p ? &rhcc : NULL);
+        if (rhcc.p) orc_free(&rhcc);
         orc_free(&sig);
         orc_setval(P_OLD(s), 0.0); orc_setval(P_NEW(s), 0.0);
         orc_setval(GP_OLD(s), 0.0); orc_setval(GP_NEW(s), 0.0);
@@ -763,7 +778,7 @@ static double predict_velocity(orc_ns_state* s, double dt)
  * the coarse mac velocities where no fine face exists, then the divergence fix of the outer face of every ghost cell that is not
  * covered and has exactly one face neighbour inside the level.  Whole-domain form: assumes that two boxes of a level are never
  * separated by a gap of exactly two cells (blocking factor >= 4), so that no face is the outer face of two ghost cells. */
-static void create_umac_grown_fine(orc_ns_state* s)
+static void create_umac_grown_fine(orc_ns_state* s, const orc_fab* divu /* 1 ghost, or NULL: 0 */)
 {
     const orc_geom* g = &s->g;
     const int r = s->ratio;
@@ -803,18 +818,60 @@ static void create_umac_grown_fine(orc_ns_state* s)
         const double dux = (A4(u, i + 1, j, k, 0) - A4(u, i, j, k, 0)) / g->dx[0];
         const double duy = (A4(v, i, j + 1, k, 0) - A4(v, i, j, k, 0)) / g->dx[1];
         const double duz = (A4(w, i, j, k + 1, 0) - A4(w, i, j, k, 0)) / g->dx[2];
-        if (ns_covered(s, i + 1, j, k)) A4(u, i, j, k, 0) = A4(u, i + 1, j, k, 0) + g->dx[0] * (duy + duz - 0.0);
-        else if (ns_covered(s, i - 1, j, k)) A4(u, i + 1, j, k, 0) = A4(u, i, j, k, 0) - g->dx[0] * (duy + duz - 0.0);
-        if (ns_covered(s, i, j + 1, k)) A4(v, i, j, k, 0) = A4(v, i, j + 1, k, 0) + g->dx[1] * (dux + duz - 0.0);
-        else if (ns_covered(s, i, j - 1, k)) A4(v, i, j + 1, k, 0) = A4(v, i, j, k, 0) - g->dx[1] * (dux + duz - 0.0);
-        if (ns_covered(s, i, j, k + 1)) A4(w, i, j, k, 0) = A4(w, i, j, k + 1, 0) + g->dx[2] * (dux + duy - 0.0);
-        else if (ns_covered(s, i, j, k - 1)) A4(w, i, j, k + 1, 0) = A4(w, i, j, k, 0) - g->dx[2] * (dux + duy - 0.0);
+        const double dv = divu ? A4(divu, i, j, k, 0) : 0.0;                /* the divergence constraint of the cell, NavierStokesBase.cpp:1235 */
+        if (ns_covered(s, i + 1, j, k)) A4(u, i, j, k, 0) = A4(u, i + 1, j, k, 0) + g->dx[0] * (duy + duz - dv);
+        else if (ns_covered(s, i - 1, j, k)) A4(u, i + 1, j, k, 0) = A4(u, i, j, k, 0) - g->dx[0] * (duy + duz - dv);
+        if (ns_covered(s, i, j + 1, k)) A4(v, i, j, k, 0) = A4(v, i, j + 1, k, 0) + g->dx[1] * (dux + duz - dv);
+        else if (ns_covered(s, i, j - 1, k)) A4(v, i, j + 1, k, 0) = A4(v, i, j, k, 0) - g->dx[1] * (dux + duz - dv);
+        if (ns_covered(s, i, j, k + 1)) A4(w, i, j, k, 0) = A4(w, i, j, k + 1, 0) + g->dx[2] * (dux + duy - dv);
+        else if (ns_covered(s, i, j, k - 1)) A4(w, i, j, k + 1, 0) = A4(w, i, j, k, 0) - g->dx[2] * (dux + duy - dv);
     }
     for (int d = 0; d < 3; ++d) orc_fill_periodic(&s->umac[d], g, ORC_FACE[d]);
 }
 
 static orc_fab dbg_umac[3];
 orc_fab* orc_dbg_umac(int d) { return &dbg_umac[d]; }
+/* NavierStokes::calc_divu (NavierStokes.cpp:1876-1958): divu = div(lambda grad T) / (rho T) at the new (use_new) or old time, valid cells */
+void ns_calc_divu(orc_ns_state* s, int use_new)
+{
+    const orc_geom* g = &s->g;
+    if (!s->have_divu) return;
+    orc_fab* S = use_new ? S_NEW(s) : S_OLD(s);
+    if (!(s->scal_diff[s->Temp - Density] > 0.0)) {
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S, i, j, k, s->Divu) = 0.0;
+        return;
+    }
+    orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
+    ns_get_visc_terms_scalar(s, &visc, S, s->Temp);
+    const orc_fab* rho = use_new ? &s->rho_ctime : &s->rho_ptime;          /* get_rho(time) */
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(S, i, j, k, s->Divu) = A4(&visc, i, j, k, 0) / (A4(rho, i, j, k, 0) * A4(S, i, j, k, s->Temp));
+    orc_free(&visc);
+}
+/* NavierStokesBase::calc_dsdt (NavierStokesBase.cpp:818-858): dsdt_new = (divu_new - divu_old) / dt */
+void ns_calc_dsdt(orc_ns_state* s, double dt)
+{
+    const orc_geom* g = &s->g;
+    if (!s->have_divu) return;
+    for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+        A4(S_NEW(s), i, j, k, s->Dsdt) = (A4(S_NEW(s), i, j, k, s->Divu) - A4(S_OLD(s), i, j, k, s->Divu)) / dt;
+}
+/* getDivCond(ng, prev_time) (+ dt/2 getDsdt(ng, prev_time)): the constraint of the MAC projection (create_mac_rhs, NavierStokesBase.cpp:
+ * 1038-1065) and of the advective update (NavierStokesBase.cpp:3377-3424, NavierStokes.cpp:712-733); zero without divu */
+orc_fab ns_divu_half(const orc_ns_state* s, double dt, int ng, int with_dsdt)
+{
+    const orc_geom* g = &s->g;
+    if (!s->have_divu) return orc_alloc(g->n, ORC_CELL, ng, 1);
+    orc_fab d = ns_fillpatch_time(s, s->st_old, 0, s->Divu, 1, ng);
+    if (with_dsdt) {
+        orc_fab e = ns_fillpatch_time(s, s->st_old, 0, s->Dsdt, 1, ng);
+        const size_t N = orc_npts(&d);
+        for (size_t q = 0; q < N; ++q) d.p[q] += 0.5 * dt * e.p[q];
+        orc_free(&e);
+    }
+    return d;
+}
+
 static void mac_project(orc_ns_state* s, double dt)
 {
     const orc_geom* g = &s->g;
@@ -829,13 +886,15 @@ static void mac_project(orc_ns_state* s, double dt)
     if (getenv("ORC_DBG_UMAC") && s->level == atoi(getenv("ORC_DBG_UMAC"))) {
         for (int d = 0; d < 3; ++d) { if (dbg_umac[d].p) orc_free(&dbg_umac[d]); dbg_umac[d] = orc_alloc(g->n, ORC_FACE[d], 1, 1); orc_copy_all(&dbg_umac[d], &s->umac[d]); }
     }
+    orc_fab mac_rhs = ns_divu_half(s, dt, 1, 1);                 /* create_mac_rhs(mac_rhs, 1, time, dt), NavierStokes.cpp:592-596 */
+    const orc_fab* Sp = s->have_divu ? &mac_rhs : NULL;
     if (s->level == 0) {
-        orc_mac_project(g, um, &s->rho_ptime, NULL, phi, 2.0 / dt, s->lobc, s->hibc, s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
+        orc_mac_project(g, um, &s->rho_ptime, Sp, phi, 2.0 / dt, s->lobc, s->hibc, s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
         /* create_umac_grown at level 0: FillPatchSingleLevel (periodic ghost faces) */
         for (int d = 0; d < 3; ++d) fill_ghosts(s, &s->umac[d], ORC_FACE[d]);
     } else {
         orc_fill_periodic(&s->crse->mac_phi, &s->crse->g, ORC_CELL);
-        orc_mac_project_cf(g, um, &s->rho_ptime, NULL, phi, 2.0 / dt, s->lobc, s->hibc, s->nbox, s->boxes, s->ratio, &s->crse->mac_phi,
+        orc_mac_project_cf(g, um, &s->rho_ptime, Sp, phi, 2.0 / dt, s->lobc, s->hibc, s->nbox, s->boxes, s->ratio, &s->crse->mac_phi,
                            s->p.mac_tol, s->p.mac_abs_tol, &o, &s->st_mac);
     }
     orc_fill_periodic(phi, g, ORC_CELL);
@@ -845,7 +904,8 @@ static void mac_project(orc_ns_state* s, double dt)
         if (s->fine) reg_crse_init(s->fine, s->fine->reg_mac, &s->umac[d], d, 0, 0, 1, -1.0 * area, 0);
         if (s->level > 0) reg_fine_add(s, s->reg_mac, &s->umac[d], d, 0, 0, 1, area / (double)s->ncycle);
     }
-    if (s->level > 0) create_umac_grown_fine(s);
+    if (s->level > 0) create_umac_grown_fine(s, Sp);
+    orc_free(&mac_rhs);
     /* "BDS needs physical BCs filled" (NavierStokesBase.cpp:1097-1105): ghost faces outside a non-periodic domain face = the nearest
      * face inside or on the boundary (first-order extrapolation; the boundary functor itself is upstream) */
     if (s->p.use_ppm == 2)
@@ -891,7 +951,7 @@ static void velocity_advection(orc_ns_state* s, double dt)
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 3);
     if (s->p.be_cn_theta != 1.0) ns_get_visc_terms_vel(s, &visc, S_OLD(s)); else orc_setval(&visc, 0.0);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, 3);
-    orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_fab divu = ns_divu_half(s, dt, 1, 1);              /* getDivCond(prev_time) + dt/2 getDsdt(prev_time): NavierStokesBase.cpp:3377-3424, NavierStokes.cpp:712-733 */
     const orc_fab* Gp = GP_OLD(s);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i) {
@@ -917,7 +977,7 @@ static void scalar_advection(orc_ns_state* s, double dt)
     orc_fab Smf = fillpatch(s, S_OLD(s), Density, s->nscal, 3, s->bc_scal);
     floor_small(&Smf);
     orc_fab tf = orc_alloc(g->n, ORC_CELL, 1, s->nscal);   /* getForce = 0, visc = 0 (non-diffusive scalars) */
-    orc_fab divu = orc_alloc(g->n, ORC_CELL, 1, 1);
+    orc_fab divu = ns_divu_half(s, dt, 1, 1);              /* getDivCond(prev_time) + dt/2 getDsdt(prev_time): NavierStokesBase.cpp:3377-3424, NavierStokes.cpp:712-733 */
     int iconserv[ORC_MAXSCAL];                          /* advectionType, NS_setup.cpp:297-320 */
     for (int n = 0; n < s->nscal; ++n) iconserv[n] = s->scal_cons[n];
     orc_fab visc = orc_alloc(g->n, ORC_CELL, 1, 1);
@@ -1337,7 +1397,13 @@ static void level_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, Pn, &sig, 0, 1.0 / dt, 1);
+    orc_fab rhcc; rhcc.p = NULL;
+    if (s->have_divu) {                     /* divusource = getDivCond(1, time + dt) / dt, rhcc = -divusource (Projection.cpp:267-276, 379-389) */
+        rhcc = orc_alloc(g->n, ORC_CELL, 0, 1);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(&rhcc, i, j, k, 0) = -(A4(S_NEW(s), i, j, k, s->Divu) * dt_inv);
+    }
+    nodal_project_level(s, &v, Pn, &sig, 0, 1.0 / dt, 1, rhcc.p ? &rhcc : NULL);
+    if (rhcc.p) orc_free(&rhcc);
     orc_free(&sig);
     for (int n = 0; n < 3; ++n)
     for (int k = -1; k <= g->n[2]; ++k) for (int j = -1; j <= g->n[1]; ++j) for (int i = -1; i <= g->n[0]; ++i)
@@ -1365,6 +1431,12 @@ double ns_advance(orc_ns_state* s, double dt, int iteration, int ncycle)
     scalar_update_rho(s, dt);
     scalar_update_tracers(s, dt);
     scalar_diffusion_update(s, dt);
+    if (s->have_divu) {                     /* NavierStokes.cpp:631-641 */
+        ns_calc_divu(s, 1);
+        ns_calc_dsdt(s, dt);
+        if (s->initial_step)
+            for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S_OLD(s), i, j, k, s->Dsdt) = A4(S_NEW(s), i, j, k, s->Dsdt);
+    }
     velocity_advection_update(s, dt);
     if (!s->initial_iter) velocity_diffusion_update(s, dt);
     else initial_velocity_diffusion_update(s, dt);
@@ -1402,7 +1474,14 @@ static void initial_sync_project(orc_ns_state* s, double dt)
         A4(&sig, i, j, k, 0) = 1.0 / A4(&s->rho_half, i, j, k, 0);
     orc_fill_periodic(&sig, g, ORC_CELL);
     orc_fab v = vel_view(Un);
-    nodal_project_level(s, &v, phi, &sig, 1, 0.0, 0);
+    orc_fab rhcc; rhcc.p = NULL;
+    if (s->have_divu) {                     /* rhcc = -(divu(strt_time + dt) - divu(strt_time)) / dt, Projection.cpp:1008-1075, 1142-1148 */
+        rhcc = orc_alloc(g->n, ORC_CELL, 0, 1);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i)
+            A4(&rhcc, i, j, k, 0) = -((A4(S_NEW(s), i, j, k, s->Divu) - A4(S_OLD(s), i, j, k, s->Divu)) * dt_inv);
+    }
+    nodal_project_level(s, &v, phi, &sig, 1, 0.0, 0, rhcc.p ? &rhcc : NULL);
+    if (rhcc.p) orc_free(&rhcc);
     orc_free(&sig);
     orc_fab* Pn = P_NEW(s);
     size_t N = orc_npts(Pn);
@@ -1426,7 +1505,7 @@ static void initial_pressure_project(orc_ns_state* s)
         ns_set_outflow_bcs(s, P_NEW(s), &rho);
         orc_free(&rho);
     }
-    nodal_project_level(s, &vel, P_NEW(s), &sig, 0, 0.0, 0);
+    nodal_project_level(s, &vel, P_NEW(s), &sig, 0, 0.0, 0, NULL);
     orc_copy_all(P_OLD(s), P_NEW(s));
     orc_copy_all(GP_OLD(s), GP_NEW(s));
     orc_free(&sig); orc_free(&vel);
@@ -1435,6 +1514,14 @@ static void initial_pressure_project(orc_ns_state* s)
 void orc_ns_post_init(orc_ns_state* s, double stop_time)
 {
     s->stop_time = stop_time;
+    if (s->have_divu) {                     /* NavierStokes::initData, NavierStokes.cpp:457-479: rho at both times, divu of the initial data, dsdt = 0 */
+        const orc_geom* g = &s->g;
+        orc_fab r = fillpatch(s, S_NEW(s), Density, 1, 1, &s->bc_scal[0]);
+        orc_copy_all(&s->rho_ctime, &r); orc_copy_all(&s->rho_ptime, &r);
+        orc_free(&r);
+        ns_calc_divu(s, 1);
+        for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S_NEW(s), i, j, k, s->Dsdt) = 0.0;
+    }
     /* post_init_state */
     initial_velocity_project(s);
     initial_pressure_project(s);
@@ -1452,8 +1539,13 @@ void orc_ns_post_init(orc_ns_state* s, double stop_time)
         for (int iter = 0; iter < s->p.init_iter; ++iter) {
             advance(s, dt_init);
             initial_sync_project(s, dt_init);
-            /* resetState: state swapped back (new <- initial data), P/Gp: old := new */
+            /* resetState: state swapped back (new <- initial data), P/Gp: old := new; Dsdt_Type is not reset ("we want to improve dsdt with
+             * press iters", NavierStokesBase.cpp:2669-2676): the computed dsdt stays the new data */
             s->inew = 1 - s->inew;
+            if (s->have_divu) {
+                const orc_geom* g = &s->g;
+                for (int k = 0; k < g->n[2]; ++k) for (int j = 0; j < g->n[1]; ++j) for (int i = 0; i < g->n[0]; ++i) A4(S_NEW(s), i, j, k, s->Dsdt) = A4(S_OLD(s), i, j, k, s->Dsdt);
+            }
             orc_copy_all(P_OLD(s), P_NEW(s));
             orc_copy_all(GP_OLD(s), GP_NEW(s));
             s->initial_iter = 0;

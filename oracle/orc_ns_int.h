@@ -10,7 +10,7 @@
 #define ORC_NS_INT_H
 #include "orc_int.h"
 
-enum { Xvel = 0, Density = 3, Tracer = 4, ORC_MAXSCAL = 4 };   /* Tracer2 / Temp: s->Tracer2 / s->Temp (-1: absent), NavierStokes.cpp:43-48 */
+enum { Xvel = 0, Density = 3, Tracer = 4, ORC_MAXSCAL = 4, ORC_MAXSLOT = ORC_MAXSCAL + 2 };   /* Tracer2 / Temp: s->Tracer2 / s->Temp (-1: absent), NavierStokes.cpp:43-48 */
 
 struct orc_ns_state {
     orc_geom g;
@@ -31,12 +31,16 @@ struct orc_ns_state {
     int lobc[3], hibc[3];          /* LinOp BC of the MAC projection: Neumann at walls / inflow, Dirichlet at outflow */
     int nlobc[3], nhibc[3];        /* nodal projection: the same with ORC_LO_INFLOW on inflow faces */
     int nstate, nscal;             /* NUM_STATE, NUM_SCALARS = NUM_STATE - Density (NavierStokes.cpp:43-55) */
+    int have_divu;                 /* ns.do_temp: Divu_Type and Dsdt_Type exist (NS_setup.cpp:365-383).  They are Point-type cell data with the
+                                    * times of State_Type and are kept here as two more components of the S arrays -- Divu = nstate,
+                                    * Dsdt = nstate + 1, nalloc = nstate + 2 -- with their own BCRecs in the slots after the scalars */
+    int nalloc, Divu, Dsdt;
     int Tracer2, Temp;             /* state components, -1 when ns.do_trac2 / ns.do_temp are off */
     int scal_cons[ORC_MAXSCAL];    /* advectionType == Conservative (NS_setup.cpp:297-320) per scalar slot (0 = density) */
     int scal_rho_flag[ORC_MAXSCAL];/* Diffusion::set_rho_flag(diffusionType): 0 Laplacian_S, 1 RhoInverse_Laplacian_S (Temp), 2 Laplacian_SoverRho */
     double scal_diff[ORC_MAXSCAL]; /* visc_coef[Density + n] (<= 0: not diffusive) */
-    double ed_scal_lo[3 * ORC_MAXSCAL], ed_scal_hi[3 * ORC_MAXSCAL];   /* ext_dir (inflow) values [n*3+d] of density, tracer, ... */
-    orc_bcrec bc_vel[3], bc_scal[ORC_MAXSCAL], bc_gp[3];
+    double ed_scal_lo[3 * ORC_MAXSLOT], ed_scal_hi[3 * ORC_MAXSLOT];   /* ext_dir (inflow) values [n*3+d] of density, tracer, ... */
+    orc_bcrec bc_vel[3], bc_scal[ORC_MAXSLOT], bc_gp[3];
     double ed_vel_lo[9], ed_vel_hi[9];   /* ext_dir values [n*3+d] for the velocity fill */
     int vlobc[9], vhibc[9];        /* tensor-solve LinOp BC per velocity component [n*3+d] */
     int slobc[3 * ORC_MAXSCAL], shibc[3 * ORC_MAXSCAL];   /* scalar-diffusion LinOp BC [n*3+d] per scalar slot */
@@ -79,6 +83,10 @@ double ns_est_time_step(orc_ns_state* s);
 void ns_make_rho_curr_time(orc_ns_state* s);
 void ns_fill_gp(orc_ns_state* s, orc_fab* G, double time);
 void ns_set_outflow_bcs(const orc_ns_state* s, orc_fab* phi, const orc_fab* rho);
+/* have_divu: calc_divu into the new (which = 0) or old (1) Divu component, calc_dsdt into the new Dsdt; divu at the old time + dt/2 dsdt */
+void ns_calc_divu(orc_ns_state* s, int use_new);
+void ns_calc_dsdt(orc_ns_state* s, double dt);
+orc_fab ns_divu_half(const orc_ns_state* s, double dt, int ng, int with_dsdt);
 void ns_set_inflow_ghosts(const orc_ns_state* s, orc_fab* vel, double inflow_scale);
 /* NavierStokes::getViscTerms at the time of Sdata (S_OLD or S_NEW of the level), 1 filled ghost cell */
 void ns_get_visc_terms_vel(const orc_ns_state* s, orc_fab* visc /*3 comps, 1 ghost*/, const orc_fab* Sdata);
@@ -96,9 +104,9 @@ void reg_reflux(const orc_ns_state* fine, orc_fab reg[3], orc_fab* S /*coarse ce
 
 /* ---- sync registers and residuals (orc_amr.c) ---- */
 /* sync residual of level s towards its finer level (Hydro::NodalProjector::computeSyncResidualCoarse): nodal fab of level s */
-orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
+orc_fab amr_sync_resid_crse(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc);
 /* sync residual of level s (> 0) towards its coarser level (computeSyncResidualFine): nodal fab of level s */
-orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
+orc_fab amr_sync_resid_fine(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc);
 void syncreg_crse_init(orc_ns_state* fine, const orc_fab* resid_crse /*nodes of fine->crse*/, double mult);   /* SyncRegister::CrseInit */
 void syncreg_fine_add(orc_ns_state* fine, const orc_fab* resid_fine /*nodes of fine*/, double mult);          /* SyncRegister::FineAdd */
 
@@ -114,8 +122,8 @@ void orc_syncreg_crse_init(orc_syncreg* sr, orc_ndmf* resid_crse, const orc_geom
 void orc_syncreg_fine_add(orc_syncreg* sr, orc_ndmf* resid_fine, const orc_geom* cgeom, double mult);
 void orc_syncreg_comp_add(orc_syncreg* sr, orc_ndmf* resid_fine, const orc_geom* fgeom, const orc_geom* cgeom, int nP, const int* Pboxes, double mult);
 void orc_syncreg_init_rhs(orc_syncreg* sr, orc_ndmf* rhs, const orc_geom* geom, const int phys_lo[3], const int phys_hi[3]);
-orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
-orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig);
+orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc);
+orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc);
 orc_ndmf* orc_level_ndmf(const orc_ns_state* s, int ng);
 void orc_ndmf_to_domain(const orc_ndmf* m, orc_fab* out);
 /* 1 (default): the multi-level step feeds MLsyncProject from the literal register; 0: from the single-valued restatement.  Both are

@@ -398,7 +398,7 @@ static int on_dirichlet(const orc_ns_state* s, int i, int j, int k)
  * rhs - L(phi) at node (i,j,k): div(vold) of mlndlap_divu minus the element rows of the operator; cells beyond an inflow face next to
  * an own cell contribute their normal velocity (set_boundary_velocity, Source/Projection.cpp:2570-2663) */
 static double box_resid_at(const orc_ns_state* s, const int* bx, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig,
-                           int (*skip)(const orc_ns_state*, int, int, int), int i, int j, int k)
+                           int (*skip)(const orc_ns_state*, int, int, int), int i, int j, int k, const orc_fab* rhcc)
 {
     const orc_geom* g = &s->g;
     double r = 0.0;
@@ -418,6 +418,7 @@ static double box_resid_at(const orc_ns_state* s, const int* bx, const orc_fab* 
         }
         if (nout > 1 || !in_box(bx, cell[0], cell[1], cell[2]) || (skip && skip(s, cell[0], cell[1], cell[2]))) continue;
         for (int d = 0; d < 3; ++d) r += 0.25 / g->dx[d] * (c[d] ? 1.0 : -1.0) * A4(vold, cell[0], cell[1], cell[2], d);
+        if (rhcc) r += 0.125 * A4(rhcc, cell[0], cell[1], cell[2], 0);            /* mlndlap_rhcc: the cell-centred source of the own cells */
         const double sg = A4(sig, cell[0], cell[1], cell[2], 0);
         const int a = (1 - cx) | ((1 - cy) << 1) | ((1 - cz) << 2);
         for (int b = 0; b < 8; ++b) r -= sg * elem_w(a, b, g->dx) * A4(phi, cell[0] + (b & 1), cell[1] + ((b >> 1) & 1), cell[2] + ((b >> 2) & 1), 0);
@@ -426,7 +427,7 @@ static double box_resid_at(const orc_ns_state* s, const int* bx, const orc_fab* 
 }
 
 /* compSyncResidualFine of level s (> 0): nodal MultiFab on the level's boxes, ngrow = ratio - 1 (ghost nodes zero) */
-orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig)
+orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc)
 {
     const int nb = level_nbox(s);
     int* bxs = (int*)malloc(sizeof(int) * 6 * (size_t)nb);
@@ -435,7 +436,7 @@ orc_ndmf* orc_sync_resid_fine_boxes(const orc_ns_state* s, const orc_fab* vold, 
     for (int b = 0; b < nb; ++b) {
         const int* bx = bxs + 6 * b;
         for (int k = bx[2]; k <= bx[5] + 1; ++k) for (int j = bx[1]; j <= bx[4] + 1; ++j) for (int i = bx[0]; i <= bx[3] + 1; ++i)
-            A4(&m->fab[b], i, j, k, 0) = on_dirichlet(s, i, j, k) ? 0.0 : box_resid_at(s, bx, vold, phi, sig, NULL, i, j, k);
+            A4(&m->fab[b], i, j, k, 0) = on_dirichlet(s, i, j, k) ? 0.0 : box_resid_at(s, bx, vold, phi, sig, NULL, i, j, k, rhcc);
     }
     free(bxs);
     return m;
@@ -458,7 +459,7 @@ static int covered_mirror(const orc_ns_state* s, int i, int j, int k)
     return covered_by_fine(s, q[0], q[1], q[2]);
 }
 /* compSyncResidualCoarse of level s (which has a finer level): nodal MultiFab on the level's boxes, one ghost node (Projection.cpp:368) */
-orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig)
+orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, const orc_fab* phi, const orc_fab* sig, const orc_fab* rhcc)
 {
     const int nb = level_nbox(s);
     int* bxs = (int*)malloc(sizeof(int) * 6 * (size_t)nb);
@@ -471,7 +472,7 @@ orc_ndmf* orc_sync_resid_crse_boxes(const orc_ns_state* s, const orc_fab* vold, 
             for (int c = 0; c < 8; ++c) ncov += covered_mirror(s, i - 1 + (c & 1), j - 1 + ((c >> 1) & 1), k - 1 + ((c >> 2) & 1));
             double r = 0.0;
             if (ncov != 0 && ncov != 8 && !on_dirichlet(s, i, j, k)) {          /* mlndlap_crse_resid */
-                r = box_resid_at(s, bx, vold, phi, sig, covered_by_fine, i, j, k);
+                r = box_resid_at(s, bx, vold, phi, sig, covered_by_fine, i, j, k, rhcc);
                 const int idx[3] = {i, j, k};
                 for (int d = 0; d < 3; ++d) {
                     if (s->g.periodic[d]) continue;

