@@ -21,6 +21,7 @@ public:
     // Hydro::NodalProjector::project on levels c0 .. c0+nl-1 (Projection::doMLMGNodalProjection with nlevel > 1)
     MGStats composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
                               const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MultiFab* const rhcc[] = nullptr);
+    ProjLevel proj_level(int l);                 // the descriptor of level l for composite_project / ml_sync_project
     // building blocks, public for the unit tests
     void reflux(int l);
     void avg_down(int l);

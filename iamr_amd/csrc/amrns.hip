@@ -198,13 +198,17 @@ void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, con
 // sync residuals
 MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side, const MultiFab* rhcc)
 {
-    const Geometry& g = ns.geom();
-    const LayoutP& layout = ns.lay();
+    return sync_resid(ns.geom(), ns.lay(), ns.nodal_bc(), crse_side ? ns.fine->lay() : LayoutP(), crse_side ? ns.fine->ratio : 2, vold, phi, sig, rhcc);
+}
+
+MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bcn, const LayoutP& fine_layout, int fine_ratio, const MultiFab& vold,
+                    const MultiFab& phi, const MultiFab& sig, const MultiFab* rhcc)
+{
     auto& ctx = Context::get();
-    const DomainBC bcn = ns.nodal_bc();
+    const bool crse_side = (bool)fine_layout;
     MultiFab cls(layout, node_type(), 1, 0);
     MultiFab fc;
-    if (crse_side) { fc = fine_coverage(layout, ns.fine->lay(), g, ns.fine->ratio); node_class(cls, fc, g); }
+    if (crse_side) { fc = fine_coverage(layout, fine_layout, g, fine_ratio); node_class(cls, fc, g); }
     else { MultiFab cov = coverage(layout, g); node_class(cls, cov, g); }
     // sigma and velocity restricted to the cells that count (zero elsewhere, also in the ghost cells outside the level)
     MultiFab sm(layout, cell_type(), 1, 1), um(layout, cell_type(), 3, 1);
@@ -349,7 +353,7 @@ NavierStokes::~NavierStokes() = default;
 namespace {
 
 struct CLev {
-    NavierStokes* ns;
+    const ProjLevel* pl;
     Geometry g;
     LayoutP layout;
     std::unique_ptr<NodalMG> mg;
@@ -366,7 +370,7 @@ void fill_nodes(CLev& L, MultiFab& x) { x.FillBoundary(L.g); nodal_reflect_bc(L.
 void comp_fill_slaves(std::vector<CLev>& L)
 {
     for (size_t l = 0; l < L.size(); ++l) {
-        if (l > 0) node_interp_from_crse(L[l].x, L[l - 1].x, L[l - 1].g, L[l].ns->ratio, &L[l].slave, false);
+        if (l > 0) node_interp_from_crse(L[l].x, L[l - 1].x, L[l - 1].g, L[l].pl->ratio, &L[l].slave, false);
         fill_nodes(L[l], L[l].x);
     }
 }
@@ -386,7 +390,7 @@ void comp_apply(std::vector<CLev>& L, int lmin = 0)
             bb.setVal(0.0);
             MultiFab::Copy(bb, L[l].y, 0, 0, 1, 0);
             mask_mult(bb, 0, 1, L[l].slave, false, 0);
-            restrict_to_crse(L[l - 1].y, bb, L[l].g, L[l - 1].g, L[l].ns->ratio);
+            restrict_to_crse(L[l - 1].y, bb, L[l].g, L[l - 1].g, L[l].pl->ratio);
         }
         mask_mult(L[l].y, 0, 1, L[l].own, false, 0);
     }
@@ -425,7 +429,27 @@ void comp_residual(std::vector<CLev>& L, int lmin = 0)        // r = b - A x on 
 MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
                                  const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MultiFab* const rhcc[])
 {
+    std::vector<ProjLevel> PL(nl);
+    for (int l = 0; l < nl; ++l) PL[l] = proj_level(c0 + l);
+    return iamrx::composite_project(PL, vel, vcomp, phi, sig, rhnd, rtol, atol, increment_gp, inflow_scale, o, rhcc);
+}
+
+ProjLevel AmrNS::proj_level(int l)
+{
+    NavierStokes* s = lev[l].get();
+    ProjLevel P;
+    P.g = s->geom(); P.layout = s->lay(); P.nodal_bc = s->nodal_bc(); P.ratio = s->ratio;
+    P.gp = &s->Gp[s->pnew];
+    P.set_inflow = [s](MultiFab& v, double scale) { s->set_inflow_ghosts(v, scale); };
+    P.fill_gp = [s]() { s->fill_gradp_bc(); };
+    return P;
+}
+
+MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
+                          const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MGOpts& o, const MultiFab* const rhcc[])
+{
     auto& ctx = Context::get();
+    const int nl = (int)PL.size();
     ProfScope ps_all_("composite_project");
     std::unique_ptr<ProfScope> psec;
     PROF_NEXT(psec, "cp_setup");
@@ -434,9 +458,9 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
     double scale = 1.0;
     for (int l = 0; l < nl; ++l) {
         CLev& C = L[l];
-        C.ns = lev[c0 + l].get();
-        C.g = C.ns->geom(); C.layout = C.ns->lay();
-        C.bc = op_bc(C.ns->nodal_bc());
+        C.pl = &PL[l];
+        C.g = C.pl->g; C.layout = C.pl->layout;
+        C.bc = op_bc(C.pl->nodal_bc);
         const bool has_fine = l < nl - 1;
         for (MultiFab* m : {&C.b, &C.x, &C.r, &C.y, &C.e}) { m->define(C.layout, node_type(), 1, 1); m->setVal(0.0); }
         C.own.define(C.layout, node_type(), 1, 0); C.slave.define(C.layout, node_type(), 1, 0);
@@ -445,7 +469,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         node_class(cls, cov, C.g);
         MultiFab vsf(C.layout, node_type(), 1, 0);
         vsf.setVal(0.0);
-        if (has_fine) { C.fcov = fine_coverage(C.layout, C.ns->fine->lay(), C.g, C.ns->fine->ratio); node_class(vsf, C.fcov, C.g); }
+        if (has_fine) { C.fcov = fine_coverage(C.layout, PL[l + 1].layout, C.g, PL[l + 1].ratio); node_class(vsf, C.fcov, C.g); }
         const bool partial = C.layout->total_cells() != C.g.domain.npts();
         bool dir_face = false;
         int dlo[3], dhi[3];
@@ -478,7 +502,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
         C.sigm.FillBoundary(C.g);
         cc_mirror_bc(C.g, C.sigm);
         MGOpts mo = o;
-        C.mg = std::make_unique<NodalMG>(C.g, C.layout, C.ns->nodal_bc(), mo);
+        C.mg = std::make_unique<NodalMG>(C.g, C.layout, C.pl->nodal_bc, mo);
         C.mg->setSigma(*sig[l], 0);
     }
     PROF_NEXT(psec, "cp_rhs");
@@ -486,7 +510,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
     for (int l = nl - 1; l >= 0; --l) {
         CLev& C = L[l];
         vel[l]->FillBoundary(C.g, vcomp[l], 3);
-        C.ns->set_inflow_ghosts(*vel[l], inflow_scale);
+        if (C.pl->set_inflow) C.pl->set_inflow(*vel[l], inflow_scale);
         MultiFab um(C.layout, cell_type(), 3, 1);
         um.setVal(0.0);
         MultiFab::Copy(um, *vel[l], vcomp[l], 0, 3, 0);
@@ -502,7 +526,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
             });
         }
         MultiFab dv(C.layout, node_type(), 1, 0);
-        const DomainBC bcn = C.ns->nodal_bc();
+        const DomainBC bcn = C.pl->nodal_bc;
         nodal_divu(C.g, dv, um, 0, &bcn);
         if (rhcc && rhcc[l]) { MultiFab rc = make_rhcc(C.g, *rhcc[l], 0, 1.0, l < nl - 1 ? &C.fcov : nullptr); nodal_rhcc_add(C.g, dv, rc, bcn); }
         mf_saxpy(C.b, 1.0, dv, 0, 0, 1, 0);                    // b may already hold what the finer level handed down
@@ -512,7 +536,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
             bb.setVal(0.0);
             MultiFab::Copy(bb, C.b, 0, 0, 1, 0);
             mask_mult(bb, 0, 1, C.slave, false, 0);
-            restrict_to_crse(L[l - 1].b, bb, C.g, L[l - 1].g, C.ns->ratio);
+            restrict_to_crse(L[l - 1].b, bb, C.g, L[l - 1].g, C.pl->ratio);
         }
         mask_mult(C.b, 0, 1, C.own, false, 0);
     }
@@ -547,7 +571,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
             MultiFab::Copy(bb, L[m].r, 0, 0, 1, 0);
             if (m < nl - 1) mf_saxpy(bb, 1.0, acc, 0, 0, 1, 0);
             MultiFab down(L[m - 1].layout, node_type(), 1, 0);
-            restrict_to_crse(down, bb, L[m].g, L[m - 1].g, L[m].ns->ratio);
+            restrict_to_crse(down, bb, L[m].g, L[m - 1].g, L[m].pl->ratio);
             acc = std::move(down);
         }
         MultiFab rhs(L[l].layout, node_type(), 1, 1);
@@ -561,7 +585,7 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
             if (m > l) {                                        // e of level m = the interpolant of the coarser correction (all nodes)
                 fill_nodes(L[m - 1], L[m - 1].e);
                 L[m].e.setVal(0.0);
-                node_interp_from_crse(L[m].e, L[m - 1].e, L[m - 1].g, L[m].ns->ratio, nullptr, false);
+                node_interp_from_crse(L[m].e, L[m - 1].e, L[m - 1].g, L[m].pl->ratio, nullptr, false);
             }
             MultiFab t(L[m].layout, node_type(), 1, 0);
             MultiFab::Copy(t, L[m].e, 0, 0, 1, 0);
@@ -596,22 +620,22 @@ MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const in
     PROF_NEXT(psec, "cp_finish");
     // slaves, covered coarse nodes (injection of the fine solution), ghost nodes
     comp_fill_slaves(L);
-    for (int l = nl - 2; l >= 0; --l) { average_down(L[l + 1].x, L[l].x, 0, 1, L[l + 1].ns->ratio); fill_nodes(L[l], L[l].x); }
+    for (int l = nl - 2; l >= 0; --l) { average_down(L[l + 1].x, L[l].x, 0, 1, L[l + 1].pl->ratio); fill_nodes(L[l], L[l].x); }
     for (int l = 0; l < nl; ++l) {
         CLev& C = L[l];
         MultiFab::Copy(*phi[l], C.x, 0, 0, 1, 1);
         MultiFab sg(C.layout, cell_type(), 1, 0);
         MultiFab::Copy(sg, *sig[l], 0, 0, 1, 0);
-        nodal_mknewu(C.g, vel[l], vcomp[l], *phi[l], &sg, &C.ns->Gp[C.ns->pnew], increment_gp);
+        nodal_mknewu(C.g, vel[l], vcomp[l], *phi[l], &sg, C.pl->gp, increment_gp);
     }
     for (int l = nl - 1; l >= 1; --l) {                  // NodalProjector::averageDown(vel)
         MultiFab vf(L[l].layout, cell_type(), 3, 0), vc(L[l - 1].layout, cell_type(), 3, 0);
         MultiFab::Copy(vf, *vel[l], vcomp[l], 0, 3, 0);
         MultiFab::Copy(vc, *vel[l - 1], vcomp[l - 1], 0, 3, 0);
-        average_down(vf, vc, 0, 3, L[l].ns->ratio);
+        average_down(vf, vc, 0, 3, L[l].pl->ratio);
         MultiFab::Copy(*vel[l - 1], vc, 0, vcomp[l - 1], 3, 0);
     }
-    for (int l = 0; l < nl; ++l) L[l].ns->fill_gradp_bc();
+    for (int l = 0; l < nl; ++l) if (L[l].pl->fill_gp) L[l].pl->fill_gp();
     return st;
 }
 
@@ -885,6 +909,64 @@ void AmrNS::mac_sync(int l)
     }
 }
 
+// Projection::MLsyncProject (Projection.cpp:457-607) on caller-owned data, see operators.h
+MGStats ml_sync_project(const ProjLevel PL[2], MultiFab& pres_crse, MultiFab& vel_crse, int vcomp_c, MultiFab& pres_fine, MultiFab& vel_fine, int vcomp_f,
+                        const MultiFab& rho_crse, const MultiFab& rho_fine, MultiFab& Vsync, MultiFab& V_corr, MultiFab& phi_c, MultiFab& phi_f,
+                        SyncRegister& rhs_sync_reg, SyncRegister* crse_sync_reg, double dt, int crse_iteration, int crse_dt_ratio,
+                        double sync_tol, double abs_tol, const MGOpts& o)
+{
+    auto& ctx = Context::get();
+    const ProjLevel &C = PL[0], &F = PL[1];
+    MultiFab rhnd(C.layout, node_type(), 1, 0);
+    phi_c.setVal(0.0); phi_f.setVal(0.0);
+    rhs_sync_reg.InitRHS(rhnd);
+    if (F.layout->boxes.size() == 1 && F.layout->boxes[0].npts() == F.g.domain.npts()) rhnd.setVal(0.0);   // Projection.cpp:506-510
+    // scaleVar: sigma = 1/rho (rho_half on the coarse level, rho_avg on the fine one); then velocity and sigma averaged down
+    MultiFab sig_c(C.layout, cell_type(), 1, 0), sig_f(F.layout, cell_type(), 1, 0);
+    {
+        const FabD *st = sig_c.d_tab, *ht = rho_crse.d_tab;
+        for_each(*C.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) = 1.0 / ht[fb](i, j, k); });
+        const FabD *sf = sig_f.d_tab, *hf = rho_fine.d_tab;
+        for_each(*F.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { sf[fb](i, j, k) = 1.0 / hf[fb](i, j, k); });
+    }
+    {
+        MultiFab vf(F.layout, cell_type(), 3, 0), vc(C.layout, cell_type(), 3, 0);
+        MultiFab::Copy(vf, V_corr, 0, 0, 3, 0);
+        MultiFab::Copy(vc, Vsync, 0, 0, 3, 0);
+        average_down(vf, vc, 0, 3, F.ratio);
+        MultiFab::Copy(Vsync, vc, 0, 0, 3, 0);
+        average_down(sig_f, sig_c, 0, 1, F.ratio);
+    }
+    MultiFab* vel[2] = {&Vsync, &V_corr};
+    const int vcomp[2] = {0, 0};
+    MultiFab* phi[2] = {&phi_c, &phi_f};
+    const MultiFab* sig[2] = {&sig_c, &sig_f};
+    // Projection.cpp:544-569: a sync projection above levels 0-1 changes the level-l velocity; the residual of the composite solution
+    // on the boundary nodes of level l goes to the sync register of the interface below (SyncRegister::CompAdd, SyncRegister.cpp:321-348)
+    const bool want_resid = crse_sync_reg != nullptr && crse_iteration == crse_dt_ratio;
+    MultiFab vold_c;
+    if (want_resid) {
+        Vsync.FillBoundary(C.g);
+        vold_c.define(C.layout, cell_type(), 3, 1);
+        MultiFab::Copy(vold_c, Vsync, 0, 0, 3, 1);
+    }
+    std::vector<ProjLevel> pl = {C, F};
+    MGStats st = composite_project(pl, vel, vcomp, phi, sig, &rhnd, sync_tol, abs_tol, true, 0.0, o);
+    if (want_resid) {
+        MultiFab r = sync_resid(C.g, C.layout, C.nodal_bc, LayoutP(), 2, vold_c, phi_c, sig_c);
+        MultiFab vsf(C.layout, node_type(), 1, 0);                    // CompAdd: zero on the nodes of the coarsened level-(l+1) boxes
+        MultiFab fc = fine_coverage(C.layout, F.layout, C.g, F.ratio);
+        node_class(vsf, fc, C.g);
+        mask_mult(r, 0, 1, vsf, true, 0);
+        crse_sync_reg->FineAdd(r, 1.0 / (double)crse_dt_ratio);
+    }
+    mf_saxpy(pres_crse, 1.0, phi_c, 0, 0, 1, 1);
+    mf_saxpy(pres_fine, 1.0, phi_f, 0, 0, 1, 1);
+    mf_saxpy(vel_crse, dt, Vsync, 0, vcomp_c, 3, 1);
+    mf_saxpy(vel_fine, dt, V_corr, 0, vcomp_f, 3, 1);
+    return st;
+}
+
 // NavierStokesBase::level_sync (NavierStokesBase.cpp:1927-2044) + Projection::MLsyncProject (Projection.cpp:457-607)
 void AmrNS::level_sync(int l, int crse_iteration)
 {
@@ -900,54 +982,12 @@ void AmrNS::level_sync(int l, int crse_iteration)
     MultiFab V_corr(f.layout, cell_type(), 3, 1);
     V_corr.setVal(0.0);
     sync_interp_cellcons(V_corr, 0, c.Vsync, 0, 3, c.g, f.g, f.ratio, c.bc_vel);          // SyncInterp, increment = 0
-    MultiFab phi_c(c.layout, node_type(), 1, 1), phi_f(f.layout, node_type(), 1, 1), rhnd(c.layout, node_type(), 1, 0);
-    phi_c.setVal(0.0); phi_f.setVal(0.0);
-    f.sync_reg->InitRHS(rhnd);
-    if (f.layout->boxes.size() == 1 && f.layout->boxes[0].npts() == f.g.domain.npts()) rhnd.setVal(0.0);   // Projection.cpp:506-510
-    // scaleVar: sigma = 1/rho (rho_half on the coarse level, rho_avg on the fine one); then velocity and sigma averaged down
-    MultiFab sig_c(c.layout, cell_type(), 1, 0), sig_f(f.layout, cell_type(), 1, 0);
-    {
-        const FabD *st = sig_c.d_tab, *ht = c.rho_half.d_tab;
-        for_each(*c.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { st[fb](i, j, k) = 1.0 / ht[fb](i, j, k); });
-        const FabD *sf = sig_f.d_tab, *hf = f.rho_avg.d_tab;
-        for_each(*f.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int fb) { sf[fb](i, j, k) = 1.0 / hf[fb](i, j, k); });
-    }
-    {
-        MultiFab vf(f.layout, cell_type(), 3, 0), vc(c.layout, cell_type(), 3, 0);
-        MultiFab::Copy(vf, V_corr, 0, 0, 3, 0);
-        MultiFab::Copy(vc, c.Vsync, 0, 0, 3, 0);
-        average_down(vf, vc, 0, 3, f.ratio);
-        MultiFab::Copy(c.Vsync, vc, 0, 0, 3, 0);
-        average_down(sig_f, sig_c, 0, 1, f.ratio);
-    }
-    MultiFab* vel[2] = {&c.Vsync, &V_corr};
-    const int vcomp[2] = {0, 0};
-    MultiFab* phi[2] = {&phi_c, &phi_f};
-    const MultiFab* sig[2] = {&sig_c, &sig_f};
-    // Projection.cpp:544-569: a sync projection above levels 0-1 changes the level-l velocity; the residual of the composite solution
-    // on the boundary nodes of level l goes to the sync register of the interface below (SyncRegister::CompAdd, SyncRegister.cpp:321-348)
-    const bool want_resid = l > 0 && crse_iteration == crse_dt_ratio;
-    MultiFab vold_c;
-    if (want_resid) {
-        c.Vsync.FillBoundary(c.g);
-        vold_c.define(c.layout, cell_type(), 3, 1);
-        MultiFab::Copy(vold_c, c.Vsync, 0, 0, 3, 1);
-    }
+    MultiFab phi_c(c.layout, node_type(), 1, 1), phi_f(f.layout, node_type(), 1, 1);
     psec.reset();
-    st_sync = composite_project(l, 2, vel, vcomp, phi, sig, &rhnd, 1.e-10 /*sync_tol*/, c.p.proj_abs_tol, true, 0.0);
+    const ProjLevel PL[2] = {proj_level(l), proj_level(l + 1)};
+    st_sync = ml_sync_project(PL, c.P[c.pnew], c.S[c.inew], Xvel, f.P[f.pnew], f.S[f.inew], Xvel, c.rho_half, f.rho_avg, c.Vsync, V_corr, phi_c, phi_f,
+                              *f.sync_reg, l > 0 ? c.sync_reg.get() : nullptr, dt, crse_iteration, crse_dt_ratio, 1.e-10 /*sync_tol*/, c.p.proj_abs_tol, o);
     PROF_NEXT(psec, "ls_post");
-    if (want_resid) {
-        MultiFab r = amr_sync_resid(c, vold_c, phi_c, sig_c, false);
-        MultiFab vsf(c.layout, node_type(), 1, 0);                    // CompAdd: zero on the nodes of the coarsened level-(l+1) boxes
-        MultiFab fc = fine_coverage(c.layout, f.layout, c.g, f.ratio);
-        node_class(vsf, fc, c.g);
-        mask_mult(r, 0, 1, vsf, true, 0);
-        c.sync_reg->FineAdd(r, 1.0 / (double)crse_dt_ratio);
-    }
-    mf_saxpy(c.P[c.pnew], 1.0, phi_c, 0, 0, 1, 1);
-    mf_saxpy(f.P[f.pnew], 1.0, phi_f, 0, 0, 1, 1);
-    mf_saxpy(c.S[c.inew], dt, c.Vsync, 0, Xvel, 3, 1);
-    mf_saxpy(f.S[f.inew], dt, V_corr, 0, Xvel, 3, 1);
     // NavierStokesBase.cpp:2018-2040: the levels above l+1 get the interpolated velocity correction (SyncInterp, increment, x dt) and
     // pressure correction (SyncProjInterp: node_bilinear_interp of phi, added to P_new AND P_old), then computeGradP at both times
     int ratio = 1;

@@ -2,6 +2,7 @@
 // Exceptions never cross the boundary: they become a non-zero return code + iamrx_last_error().
 #include "../../include/iamrx.h"
 #include "operators.h"
+#include "launch.h"
 #include "amrns.h"
 #include <string>
 #include <cstring>
@@ -576,6 +577,102 @@ int iamrx_tensor_solve_cf(const iamrx_geom* g, iamrx_mf soln, iamrx_mf rhs, doub
     IAMRX_CATCH
 }
 
+// ---- Diffusion operator entries on caller-owned data (diffusion.hip) -----------------------------------------------------------------
+namespace {
+struct CrseArgs { DiffusionCrse dc; Geometry cg; bool on = false; };
+void to_crse(const iamrx_diffusion_crse* c, CrseArgs& a)
+{
+    if (!c) return;
+    a.cg = to_geom(c->cgeom);
+    a.dc = DiffusionCrse{c->crse_old ? &c->crse_old->mf : nullptr, c->crse_new ? &c->crse_new->mf : nullptr, &a.cg, c->ratio};
+    a.on = true;
+}
+}  // namespace
+
+int iamrx_diffuse_scalar(const iamrx_geom* g, iamrx_mf S_old, iamrx_mf Rho_old, iamrx_mf S_new, iamrx_mf Rho_new, int sigma, int rho_comp, double dt,
+                         double be_cn_theta, iamrx_mf rho_half, int rho_flag, const iamrx_mf* fluxn, const iamrx_mf* fluxnp1, iamrx_mf delta_rhs,
+                         int rhs_comp, const iamrx_mf* betan, const iamrx_mf* betanp1, const int* lobc, const int* hibc,
+                         const iamrx_diffusion_crse* crse, int add_old_time_divFlux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    MultiFab *fn[3] = {nullptr, nullptr, nullptr}, *fp[3] = {nullptr, nullptr, nullptr};
+    const MultiFab *bn[3] = {nullptr, nullptr, nullptr}, *bp[3];
+    for (int d = 0; d < 3; ++d) {
+        if (fluxn && fluxnp1) { fn[d] = &fluxn[d]->mf; fp[d] = &fluxnp1[d]->mf; }
+        if (betan) bn[d] = &betan[d]->mf;
+        bp[d] = &betanp1[d]->mf;
+    }
+    CrseArgs ca;
+    to_crse(crse, ca);
+    MGStats s = diffuse_scalar(to_geom(g), S_old ? &S_old->mf : nullptr, Rho_old ? &Rho_old->mf : nullptr, S_new->mf, Rho_new ? &Rho_new->mf : nullptr, sigma,
+                               rho_comp, dt, be_cn_theta, rho_half->mf, rho_flag, (fluxn && fluxnp1) ? fn : nullptr, (fluxn && fluxnp1) ? fp : nullptr,
+                               delta_rhs ? &delta_rhs->mf : nullptr, rhs_comp, betan ? bn : nullptr, bp, to_bc(lobc, hibc, 2), ca.on ? &ca.dc : nullptr,
+                               add_old_time_divFlux != 0, visc_tol, op);
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_diffuse_tensor_velocity(const iamrx_geom* g, iamrx_mf U_old, iamrx_mf U_new, int rho_comp, double dt, double be_cn_theta, iamrx_mf rho_half,
+                                  int rho_flag, iamrx_mf visc_old_term, const iamrx_mf* eta_n, const iamrx_mf* eta_np1, const int* lobc, const int* hibc,
+                                  const iamrx_diffusion_crse* crse, const iamrx_mf* tflux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st,
+                                  void (*fill_new)(void* ctx, iamrx_mf U_new), void* ctx)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    const MultiFab *en[3] = {nullptr, nullptr, nullptr}, *ep[3];
+    MultiFab* tf[3] = {nullptr, nullptr, nullptr};
+    for (int d = 0; d < 3; ++d) { if (eta_n) en[d] = &eta_n[d]->mf; ep[d] = &eta_np1[d]->mf; if (tflux) tf[d] = &tflux[d]->mf; }
+    DomainBC bcs[3];
+    for (int n = 0; n < 3; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, 2);
+    CrseArgs ca;
+    to_crse(crse, ca);
+    std::function<void(MultiFab&)> fill;
+    if (fill_new) fill = [&](MultiFab&) { fill_new(ctx, U_new); };
+    MGStats s = diffuse_tensor_velocity(to_geom(g), U_old ? &U_old->mf : nullptr, U_new->mf, rho_comp, dt, be_cn_theta, rho_half->mf, rho_flag,
+                                        visc_old_term ? &visc_old_term->mf : nullptr, eta_n ? en : ep, ep, bcs, ca.on ? &ca.dc : nullptr, tflux ? tf : nullptr,
+                                        visc_tol, op, fill);
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_diffuse_tensor_vsync(const iamrx_geom* g, iamrx_mf Vsync, double dt, double be_cn_theta, iamrx_mf rho_half, int rho_flag, iamrx_mf Rho_old,
+                               iamrx_mf Rho_new, int rho_comp, const iamrx_mf* eta, const int* lobc, const int* hibc, const int* bcrec_vel,
+                               const iamrx_geom* cgeom, int ratio, const iamrx_mf* tflux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    const MultiFab* ep[3];
+    MultiFab* tf[3] = {nullptr, nullptr, nullptr};
+    for (int d = 0; d < 3; ++d) { ep[d] = &eta[d]->mf; if (tflux) tf[d] = &tflux[d]->mf; }
+    DomainBC bcs[3];
+    for (int n = 0; n < 3; ++n) bcs[n] = to_bc(lobc + 3 * n, hibc + 3 * n, 2);
+    std::vector<BCRec> bv = to_bcrec(bcrec_vel, 3);
+    Geometry cg;
+    if (cgeom) cg = to_geom(cgeom);
+    MGStats s = diffuse_tensor_Vsync(to_geom(g), Vsync->mf, dt, be_cn_theta, rho_half->mf, rho_flag, Rho_old ? &Rho_old->mf : nullptr, Rho_new ? &Rho_new->mf : nullptr,
+                                     rho_comp, ep, bcs, bv.data(), cgeom ? &cg : nullptr, ratio, tflux ? tf : nullptr, visc_tol, op);
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_diffuse_ssync(const iamrx_geom* g, iamrx_mf Ssync, int comp, double dt, double be_cn_theta, iamrx_mf rho_half, int rho_flag, iamrx_mf Rho_new,
+                        int rho_comp, const iamrx_mf* beta, const int* lobc, const int* hibc, const iamrx_geom* cgeom, int ratio, const iamrx_mf* flux,
+                        double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    const MultiFab* bp[3];
+    MultiFab* fl[3] = {nullptr, nullptr, nullptr};
+    for (int d = 0; d < 3; ++d) { bp[d] = &beta[d]->mf; if (flux) fl[d] = &flux[d]->mf; }
+    Geometry cg;
+    if (cgeom) cg = to_geom(cgeom);
+    MGStats s = diffuse_Ssync(to_geom(g), Ssync->mf, comp, dt, be_cn_theta, rho_half->mf, rho_flag, Rho_new->mf, rho_comp, bp, to_bc(lobc, hibc, 2),
+                              cgeom ? &cg : nullptr, ratio, flux ? fl : nullptr, visc_tol, op);
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
+
 struct iamrx_ns_s {
     std::unique_ptr<NavierStokes> owned;     // null for a level borrowed from an iamrx_amr hierarchy
     // borrowed handles of a hierarchy that has regridded since are kept alive as retired objects (ns_ == nullptr): every entry point
@@ -825,6 +922,43 @@ int iamrx_syncreg_destroy(iamrx_syncreg r) { IAMRX_TRY delete r; IAMRX_CATCH }
 int iamrx_syncreg_crse_init(iamrx_syncreg r, iamrx_mf sync_resid_crse, double mult) { IAMRX_TRY r->sr->CrseInit(sync_resid_crse->mf, mult); IAMRX_CATCH }
 int iamrx_syncreg_fine_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, double mult) { IAMRX_TRY r->sr->FineAdd(sync_resid_fine->mf, mult); IAMRX_CATCH }
 int iamrx_syncreg_init_rhs(iamrx_syncreg r, iamrx_mf rhs) { IAMRX_TRY r->sr->InitRHS(rhs->mf); IAMRX_CATCH }
+
+// Projection::MLsyncProject on caller-owned data (amrns.hip ml_sync_project)
+int iamrx_mlsync_project(const iamrx_proj_level* crse, const iamrx_proj_level* fine, iamrx_mf pres_crse, iamrx_mf vel_crse, int vcomp_crse, iamrx_mf pres_fine,
+                         iamrx_mf vel_fine, int vcomp_fine, iamrx_mf rho_crse, iamrx_mf rho_fine, iamrx_mf Vsync, iamrx_mf V_corr, iamrx_mf phi_crse,
+                         iamrx_mf phi_fine, iamrx_syncreg rhs_sync_reg, iamrx_syncreg crse_sync_reg, double dt, int crse_iteration, int crse_dt_ratio,
+                         double sync_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    MGOpts op = to_opts(o);
+    ProjLevel PL[2];
+    const iamrx_proj_level* in[2] = {crse, fine};
+    for (int l = 0; l < 2; ++l) {
+        ProjLevel& P = PL[l];
+        P.g = to_geom(in[l]->geom); P.layout = in[l]->layout->p; P.ratio = in[l]->ratio;
+        P.nodal_bc = to_bc(in[l]->lobc, in[l]->hibc, 2);
+        P.gp = in[l]->gp ? &in[l]->gp->mf : nullptr;
+        const Geometry g = P.g;
+        const DomainBC bc = P.nodal_bc;
+        // the sync increments carry no inflow data: ghost velocities outside inflow faces are zero (inflow_scale = 0, Projection.cpp:2570-2663)
+        P.set_inflow = [g, bc](MultiFab& vel, double) {
+            for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+                if (g.periodic[d] || (side == 0 ? bc.lo[d] : bc.hi[d]) != lo_inflow) continue;
+                const int face = side == 0 ? g.domain.lo[d] - 1 : g.domain.hi[d] + 1;
+                const FabD* vt = vel.d_tab;
+                const int dd = d;
+                for_each(*vel.layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                    if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) vt[f](i, j, k, dd) = 0.0;
+                });
+            }
+        };
+    }
+    MGStats s = ml_sync_project(PL, pres_crse->mf, vel_crse->mf, vcomp_crse, pres_fine->mf, vel_fine->mf, vcomp_fine, rho_crse->mf, rho_fine->mf, Vsync->mf,
+                                V_corr->mf, phi_crse->mf, phi_fine->mf, *rhs_sync_reg->sr, crse_sync_reg ? crse_sync_reg->sr.get() : nullptr, dt, crse_iteration,
+                                crse_dt_ratio, sync_tol, abs_tol, op);
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
 
 int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scomp, int ncomp, const iamrx_geom* cgeom, const iamrx_geom* fgeom,
                       int ratio, const int* bcrec)

@@ -172,6 +172,34 @@ class NavierStokes;
 // sync residual of a level projection (Hydro::NodalProjector::computeSyncResidualCoarse / Fine): crse_side: on the nodes of the level
 // that touch both cells covered by the next finer level and cells that are not, rhs - L(phi) formed with the uncovered cells only;
 // fine side: on the nodes of the level's own boundary inside the domain, formed with the level's cells only.  Zero elsewhere.
+// ---- multi-level nodal projection on caller-owned data (amrns.hip) ----------------------------------------------------------------
+// one level of a composite projection: its geometry, boxes, the nodal LinOp BC (Projection.cpp:2432-2464) and the ratio to the next
+// coarser level of the solve; gp: the Gradp array that receives (or accumulates) grad phi (may be null); set_inflow: fills the ghost
+// velocities outside inflow faces (Projection::set_boundary_velocity), fill_gp: FillPatch of Gradp afterwards (both may be empty)
+struct ProjLevel {
+    Geometry g; LayoutP layout; DomainBC nodal_bc; int ratio = 2;
+    MultiFab* gp = nullptr;
+    std::function<void(MultiFab&, double)> set_inflow;
+    std::function<void()> fill_gp;
+};
+// Hydro::NodalProjector::project on the levels PL[0 .. nl-1] (Projection::doMLMGNodalProjection with nlevel > 1, Projection.cpp:2385-2567):
+// div(sig grad phi) = div(vel) + rhnd + <rhcc> on the composite grid; vel -= sig grad phi; gp = / += grad phi
+MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
+                          const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MGOpts& o,
+                          const MultiFab* const rhcc[] = nullptr);
+// compSyncResidualCoarse (fine_layout given: the level's nodes that touch both cells covered by fine_layout and cells that are not, formed
+// with the uncovered cells) / compSyncResidualFine (fine_layout null: the nodes of the level's own boundary inside the domain)
+MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bcn, const LayoutP& fine_layout, int fine_ratio, const MultiFab& vold,
+                    const MultiFab& phi, const MultiFab& sig, const MultiFab* rhcc = nullptr);
+// Projection::MLsyncProject (Source/Projection.cpp:457-607) on caller-owned data: the two-level sync projection of the velocity increments
+// Vsync (coarse level, 3 comps, 1 ghost) and V_corr (fine level: the interpolated Vsync), with sigma = 1 / rho_crse, 1 / rho_fine and the
+// sync register's right-hand side; phi_crse / phi_fine (1 ghost, zeroed here) return the pressure correction, which is also added to
+// pres_crse / pres_fine; vel_* += dt * the projected increments; PL[l].gp += grad phi.  crse_sync_reg (level PL[0] is itself refined and
+// crse_iteration == crse_dt_ratio): receives the residual of the composite solution on PL[0]'s boundary (SyncRegister::CompAdd).
+MGStats ml_sync_project(const ProjLevel PL[2], MultiFab& pres_crse, MultiFab& vel_crse, int vcomp_c, MultiFab& pres_fine, MultiFab& vel_fine, int vcomp_f,
+                        const MultiFab& rho_crse, const MultiFab& rho_fine, MultiFab& Vsync, MultiFab& V_corr, MultiFab& phi_crse, MultiFab& phi_fine,
+                        SyncRegister& rhs_sync_reg, SyncRegister* crse_sync_reg, double dt, int crse_iteration, int crse_dt_ratio,
+                        double sync_tol, double abs_tol, const MGOpts& o);
 MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side, const MultiFab* rhcc = nullptr /* valid cells */);
 
 // ---- NavierStokes level (reference Source/NavierStokes.cpp:543-691 advance, :1254-1432 post_init) -----

@@ -473,3 +473,92 @@ def godunov_compute_aofs(geom, aofs, acomp, S, ncomp, force, divu, umac, iconser
     check(lib().iamrx_godunov_compute_aofs(C.byref(geom), aofs.h, acomp, S.h, ncomp, _h(force), _h(divu), umac[0].h, umac[1].h,
                                            umac[2].h, ic, C.c_double(dt), _bcrec(ncomp, bc), is_velocity, use_forces_in_trans,
                                            _h(e[0]), _h(e[1]), _h(e[2]), _h(f[0]), _h(f[1]), _h(f[2]), int(scheme)))
+
+
+# ---- Diffusion operator entries on caller-owned data (include/iamrx.h; reference Source/Diffusion.H:53-225) ----------------------------
+class DiffusionCrse(C.Structure):
+    _fields_ = [("crse_old", C.c_void_p), ("crse_new", C.c_void_p), ("cgeom", C.c_void_p), ("ratio", C.c_int)]
+
+
+def _mf3(v):
+    return (C.c_void_p * 3)(*[m.h for m in v]) if v is not None else None
+
+
+def _crse(crse):
+    """crse = (crse_old or None, crse_new or None, cgeom, ratio) or None"""
+    if crse is None:
+        return None, None
+    co, cn, cg, r = crse
+    d = DiffusionCrse(_h(co) if co is not None else None, _h(cn) if cn is not None else None, C.cast(C.pointer(cg), C.c_void_p), int(r))
+    return C.byref(d), d
+
+
+def diffuse_scalar(geom, S_old, S_new, sigma, rho_comp, dt, theta, rho_half, rho_flag, betanp1, betan=None, fluxn=None, fluxnp1=None, delta_rhs=None,
+                   rhs_comp=0, lobc=(0, 0, 0), hibc=(0, 0, 0), crse=None, add_old_time_divFlux=True, visc_tol=1e-10, opts=None, Rho_old=None, Rho_new=None):
+    """Diffusion::diffuse_scalar (Source/Diffusion.cpp:207-599) on caller-owned MultiFabs"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    cp, keep = _crse(crse)
+    check(lib().iamrx_diffuse_scalar(C.byref(geom), _h(S_old), _h(Rho_old), S_new.h, _h(Rho_new), int(sigma), int(rho_comp), C.c_double(dt), C.c_double(theta),
+                                     rho_half.h, int(rho_flag), _mf3(fluxn), _mf3(fluxnp1), _h(delta_rhs), int(rhs_comp), _mf3(betan), _mf3(betanp1),
+                                     i3(lobc), i3(hibc), cp, int(bool(add_old_time_divFlux)), C.c_double(visc_tol), C.byref(o), C.byref(st)))
+    return st
+
+
+def diffuse_tensor_velocity(geom, U_old, U_new, rho_comp, dt, theta, rho_half, rho_flag, eta_np1, eta_n=None, visc_old_term=None, lobc=(0,) * 9, hibc=(0,) * 9,
+                            crse=None, tflux=None, visc_tol=1e-10, opts=None, fill_new=None):
+    """Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:617-957); fill_new(): refill the ghost cells of U_new once it holds rho u*"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    cp, keep = _crse(crse)
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    cb = CB(lambda ctx, h: fill_new()) if fill_new is not None else C.cast(None, CB)
+    check(lib().iamrx_diffuse_tensor_velocity(C.byref(geom), _h(U_old), U_new.h, int(rho_comp), C.c_double(dt), C.c_double(theta), rho_half.h, int(rho_flag),
+                                              _h(visc_old_term), _mf3(eta_n), _mf3(eta_np1), (C.c_int * 9)(*lobc), (C.c_int * 9)(*hibc), cp, _mf3(tflux),
+                                              C.c_double(visc_tol), C.byref(o), C.byref(st), cb, None))
+    return st
+
+
+def diffuse_tensor_vsync(geom, Vsync, dt, theta, rho_half, rho_flag, eta, bcrec_vel, Rho_old=None, Rho_new=None, rho_comp=3, lobc=(0,) * 9, hibc=(0,) * 9,
+                         cgeom=None, ratio=2, tflux=None, visc_tol=1e-10, opts=None):
+    """Diffusion::diffuse_tensor_Vsync (Source/Diffusion.cpp:1010-1178)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    check(lib().iamrx_diffuse_tensor_vsync(C.byref(geom), Vsync.h, C.c_double(dt), C.c_double(theta), rho_half.h, int(rho_flag), _h(Rho_old), _h(Rho_new), int(rho_comp),
+                                           _mf3(eta), (C.c_int * 9)(*lobc), (C.c_int * 9)(*hibc), (C.c_int * 18)(*bcrec_vel),
+                                           C.byref(cgeom) if cgeom is not None else None, int(ratio), _mf3(tflux), C.c_double(visc_tol), C.byref(o), C.byref(st)))
+    return st
+
+
+def diffuse_ssync(geom, Ssync, comp, dt, theta, rho_half, rho_flag, Rho_new, rho_comp, beta, lobc=(0, 0, 0), hibc=(0, 0, 0), cgeom=None, ratio=2, flux=None,
+                  visc_tol=1e-10, opts=None):
+    """Diffusion::diffuse_Ssync as NavierStokes::mac_sync calls it (Source/NavierStokes.cpp:1590-1640)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    check(lib().iamrx_diffuse_ssync(C.byref(geom), Ssync.h, int(comp), C.c_double(dt), C.c_double(theta), rho_half.h, int(rho_flag), Rho_new.h, int(rho_comp),
+                                    _mf3(beta), i3(lobc), i3(hibc), C.byref(cgeom) if cgeom is not None else None, int(ratio), _mf3(flux), C.c_double(visc_tol),
+                                    C.byref(o), C.byref(st)))
+    return st
+
+
+class ProjLevel(C.Structure):
+    """iamrx_proj_level: a level of a multi-level nodal projection on caller-owned data"""
+    _fields_ = [("geom", C.c_void_p), ("layout", C.c_void_p), ("lobc", C.c_int * 3), ("hibc", C.c_int * 3), ("ratio", C.c_int), ("gp", C.c_void_p)]
+
+
+def mlsync_project(crse, fine, pres_crse, vel_crse, pres_fine, vel_fine, rho_crse, rho_fine, Vsync, V_corr, phi_crse, phi_fine, rhs_sync_reg, dt,
+                   crse_sync_reg=None, crse_iteration=1, crse_dt_ratio=1, vcomp_crse=0, vcomp_fine=0, sync_tol=1e-10, abs_tol=1e-16, opts=None):
+    """Projection::MLsyncProject (Source/Projection.cpp:457-607) on caller-owned arrays; crse / fine: (geom, layout, lobc, hibc, ratio, gp or None)"""
+    st = MgStats()
+    o = opts if opts is not None else mg_opts()
+    keep = []
+
+    def mk(lv):
+        g, lay, lo, hi, r, gp = lv
+        keep.append(g)
+        return ProjLevel(C.cast(C.pointer(g), C.c_void_p), lay.h, i3(lo), i3(hi), int(r), _h(gp) if gp is not None else None)
+    pc, pf = mk(crse), mk(fine)
+    check(lib().iamrx_mlsync_project(C.byref(pc), C.byref(pf), pres_crse.h, vel_crse.h, int(vcomp_crse), pres_fine.h, vel_fine.h, int(vcomp_fine), rho_crse.h,
+                                     rho_fine.h, Vsync.h, V_corr.h, phi_crse.h, phi_fine.h, rhs_sync_reg.h, crse_sync_reg.h if crse_sync_reg is not None else None,
+                                     C.c_double(dt), int(crse_iteration), int(crse_dt_ratio), C.c_double(sync_tol), C.c_double(abs_tol), C.byref(o), C.byref(st)))
+    return st

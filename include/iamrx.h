@@ -320,6 +320,46 @@ int iamrx_error_tag(const iamrx_geom* g, iamrx_mf tags, iamrx_mf field, int comp
 int iamrx_cluster_tags(const iamrx_geom* g, iamrx_mf tags, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
                        int* boxes, int* nboxes);
 
+/* ---- Diffusion operator entries on caller-owned data (the operator-level boundary) -------------------------------------
+ * What NavierStokes::scalar_diffusion_update / velocity_diffusion_update / mac_sync hand to the reference's Diffusion class, for a host
+ * code that keeps its own state.  All arrays are the caller's; the level's own time step (iamrx_ns_advance) goes through the same code.
+ * LinOp BC types (lobc / hibc): as iamrx_abec_* (Diffusion::setDomainBC, Source/Diffusion.cpp:1886-1941); per velocity component for
+ * the tensor entries ([n*3+d]).  crse: the coarse level of a refined level, NULL on level 0: its state at the old / new time (valid cells
+ * on its own layout, same component numbering as the fine arrays), crse_new NULL = homogeneous coarse/fine data. */
+typedef struct iamrx_diffusion_crse { iamrx_mf crse_old, crse_new; const iamrx_geom* cgeom; int ratio; } iamrx_diffusion_crse;
+/* Diffusion::diffuse_scalar (Source/Diffusion.cpp:207-599; declaration Source/Diffusion.H:79-104): Crank-Nicolson update of component sigma,
+ *   (alpha - theta dt div beta grad) s_new = alpha s* + (1 - theta) dt div beta grad s_old + dt delta_rhs,
+ * rho_flag 0: s = S, alpha = 1; 1: alpha = rho_half; 2: s = S / rho, alpha = rho_new, S_new = s rho_new.  S_old / S_new: >= 1 ghost cell
+ * FILLED by the caller (FillPatch, Source/Diffusion.cpp:237-239); Rho_old / Rho_new (NULL: S_old / S_new) hold the density in rho_comp;
+ * fluxn / fluxnp1 (3 face arrays each, or NULL): the extensive fluxes (1 - theta) area (-beta grad s_old), theta area (-beta grad s_new);
+ * delta_rhs (NULL: none); betan / betanp1: 3 face arrays of the diffusivity (betan NULL with theta = 1 or add_old_time_divFlux = 0). */
+int iamrx_diffuse_scalar(const iamrx_geom* g, iamrx_mf S_old, iamrx_mf Rho_old, iamrx_mf S_new, iamrx_mf Rho_new, int sigma, int rho_comp, double dt,
+                         double be_cn_theta, iamrx_mf rho_half, int rho_flag, const iamrx_mf* fluxn, const iamrx_mf* fluxnp1, iamrx_mf delta_rhs,
+                         int rhs_comp, const iamrx_mf* betan, const iamrx_mf* betanp1, const int* lobc, const int* hibc,
+                         const iamrx_diffusion_crse* crse, int add_old_time_divFlux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* Diffusion::diffuse_tensor_velocity (Source/Diffusion.cpp:617-957; Source/Diffusion.H:117-127): (alpha - theta dt div tau) u_new =
+ * alpha u* + (1 - theta) dt div tau(u_old), alpha = rho_half (rho_flag 1) or rho_new with u* weighted by rho_old (rho_flag 3).  U_old / U_new:
+ * states with the velocity in components 0..2 and the density in rho_comp, 1 filled ghost cell.  visc_old_term (NULL: evaluate): div tau(u_old).
+ * tflux (3 face arrays of 3 components, or NULL).  fill_new (NULL: none): called once U_new's velocity holds rho u*, to refill its ghost
+ * cells (the FillPatch of Source/Diffusion.cpp:866). */
+int iamrx_diffuse_tensor_velocity(const iamrx_geom* g, iamrx_mf U_old, iamrx_mf U_new, int rho_comp, double dt, double be_cn_theta, iamrx_mf rho_half,
+                                  int rho_flag, iamrx_mf visc_old_term, const iamrx_mf* eta_n, const iamrx_mf* eta_np1, const int* lobc, const int* hibc,
+                                  const iamrx_diffusion_crse* crse, const iamrx_mf* tflux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st,
+                                  void (*fill_new)(void* ctx, iamrx_mf U_new), void* ctx);
+/* Diffusion::diffuse_Vsync -> diffuse_tensor_Vsync (Source/Diffusion.cpp:960-1178): Vsync (3 components, 1 ghost cell) is replaced by the
+ * solution of (alpha - theta dt div tau) V = rho Vsync with homogeneous boundary and coarse/fine data (cgeom NULL: level 0); eta: the face
+ * coefficients (upstream passes ones, :1122-1135); bcrec_vel: the BCRecs of the velocity (6 ints per component), ghost cells outside
+ * ext_dir faces end up zero (:987-1008); tflux: theta area (-tau), or NULL. */
+int iamrx_diffuse_tensor_vsync(const iamrx_geom* g, iamrx_mf Vsync, double dt, double be_cn_theta, iamrx_mf rho_half, int rho_flag, iamrx_mf Rho_old,
+                               iamrx_mf Rho_new, int rho_comp, const iamrx_mf* eta, const int* lobc, const int* hibc, const int* bcrec_vel,
+                               const iamrx_geom* cgeom, int ratio, const iamrx_mf* tflux, double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* Diffusion::diffuse_Ssync as NavierStokes::mac_sync calls it (Source/NavierStokes.cpp:1590-1640, Source/Diffusion.cpp:1181-1352): component
+ * comp of Ssync (a rate) becomes the diffused sync increment, (alpha - theta dt div beta grad) s = dt Ssync (x rho_half for rho_flag 1),
+ * Ssync = s (x rho_new for rho_flag 2); flux: theta area (-beta grad s), or NULL. */
+int iamrx_diffuse_ssync(const iamrx_geom* g, iamrx_mf Ssync, int comp, double dt, double be_cn_theta, iamrx_mf rho_half, int rho_flag, iamrx_mf Rho_new,
+                        int rho_comp, const iamrx_mf* beta, const int* lobc, const int* hibc, const iamrx_geom* cgeom, int ratio, const iamrx_mf* flux,
+                        double visc_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
+
 /* ---- level time step (NavierStokes::advance and the init sequence) ----------------------------------- */
 typedef struct iamrx_ns_params {
     double cfl, visc_coef, be_cn_theta, gravity;
@@ -397,6 +437,20 @@ int iamrx_syncreg_destroy(iamrx_syncreg r);
 int iamrx_syncreg_crse_init(iamrx_syncreg r, iamrx_mf sync_resid_crse, double mult);
 int iamrx_syncreg_fine_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, double mult);
 int iamrx_syncreg_init_rhs(iamrx_syncreg r, iamrx_mf rhs);
+/* Projection::MLsyncProject (Source/Projection.cpp:457-607; declaration Source/Projection.H:99-118) on caller-owned data: the two-level sync
+ * projection NavierStokesBase::level_sync drives (Source/NavierStokesBase.cpp:1927-2044).  A level of the solve: its geometry and boxes,
+ * the nodal LinOp BC (lobc / hibc: periodic / Neumann / Dirichlet at outflow / inflow, Source/Projection.cpp:2432-2464), the ratio to the
+ * next coarser level, gp (or NULL): the Gradp array that accumulates grad(phi).
+ * Vsync (coarse, 3 components, 1 ghost cell) and V_corr (fine: Vsync interpolated with iamrx_sync_interp) are projected with
+ * sigma = 1 / rho_crse, 1 / rho_fine and the right-hand side of rhs_sync_reg (SyncRegister::InitRHS); phi_crse / phi_fine (nodal, 1 ghost
+ * cell) return the pressure correction, which is also added to pres_crse / pres_fine; vel_* (velocity at vcomp_*) += dt * the projected
+ * increments.  crse_sync_reg (NULL on level 0): the register of the interface BELOW the coarse level, which receives the residual of the
+ * composite solution on that level's boundary when crse_iteration == crse_dt_ratio (SyncRegister::CompAdd, Source/SyncRegister.cpp:302-348). */
+typedef struct iamrx_proj_level { const iamrx_geom* geom; iamrx_layout layout; int lobc[3], hibc[3]; int ratio; iamrx_mf gp; } iamrx_proj_level;
+int iamrx_mlsync_project(const iamrx_proj_level* crse, const iamrx_proj_level* fine, iamrx_mf pres_crse, iamrx_mf vel_crse, int vcomp_crse, iamrx_mf pres_fine,
+                         iamrx_mf vel_fine, int vcomp_fine, iamrx_mf rho_crse, iamrx_mf rho_fine, iamrx_mf Vsync, iamrx_mf V_corr, iamrx_mf phi_crse,
+                         iamrx_mf phi_fine, iamrx_syncreg rhs_sync_reg, iamrx_syncreg crse_sync_reg, double dt, int crse_iteration, int crse_dt_ratio,
+                         double sync_tol, double abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
 /* NavierStokesBase::SyncInterp with cell_cons_interp (Source/NavierStokesBase.cpp:3071-3276): fine_dst(dcomp..) = conservative-linear
  * interpolant of crse_sync(scomp..) on every cell of the fine level; the caller applies `increment` / dt_clev (:3215-3262) */
 int iamrx_sync_interp(iamrx_mf fine_dst, int dcomp, iamrx_mf crse_sync, int scomp, int ncomp, const iamrx_geom* cgeom, const iamrx_geom* fgeom,

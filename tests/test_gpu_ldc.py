@@ -163,8 +163,11 @@ def test_rejects_unsupported_physical_bc(gpu):
     lay = lib.Layout.single(n)
     with pytest.raises(RuntimeError):
         N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 6], phys_hi=[0, 0, 5]))                   # not a physical BC type
-    with pytest.raises(RuntimeError):
-        N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2], gravity=-1.0))     # outflow + gravity (hydrostatic outflow pressure)
+    N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2], gravity=-1.0))         # outflow on top with gravity: hydrostatic pressure zero there
+    bottom = N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 2], phys_hi=[0, 0, 1], gravity=-1.0))
+    bottom.init_rest(1.0)
+    with pytest.raises(RuntimeError):                                                               # outflow at the bottom with gravity: Projection::computeRhoG aborts
+        bottom.post_init(-1.0)
     N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 1], phys_hi=[0, 0, 2]))                       # inflow / outflow are accepted
     N.NavierStokes(g, lay, N.ns_params(phys_lo=[0, 0, 3], phys_hi=[0, 0, 3]))                       # so is Symmetry
 
