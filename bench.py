@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-PMC_FILE = "round2_pmc.json"
+PMC_FILE = "round3_pmc.json"
 
 
 def parse():
@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("IAMRX_BENCH_N", "256")), help="cells per direction of the per-GPU box")
     ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upstream-shape", action="store_true", help="skip the pass with the reference's multigrid cycle shape")
     ap.add_argument("--no-multibox", action="store_true", help="skip the single-GPU 8-box / 64-box runs of the same problem")
     ap.add_argument("--cpu-n", type=int, default=96)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -291,6 +292,33 @@ def transport_selftest(lib, rank, world):
         raise RuntimeError("all-reduce self-test delivered a wrong maximum")
 
 
+def upstream_shape_pass(lib, N, g, lay, c, steps=3):
+    """the same level advanced with the multigrid cycle amrex::MLMG / MLNodeLaplacian use as the reference drives them (VERDICT r2 item 4):
+    nodal smoother 4 sweeps, 2 + 2 smooth calls; zero initial guess for the MAC and nodal solves (no warm start).  Reported beside the
+    product's default cycle so that the V-cycle metric BASELINE.json names is comparable."""
+    import statistics as st
+    lib.tuning_set("WARM_START", 0)
+    try:
+        ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts(nodal_sweeps=4, nodal_nu1=2, nodal_nu2=2))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, c, 1.0)
+        ns.post_init(-1.0)
+        ns.step()
+        lib.sync()
+        ms, its = {"mac_cc": [], "nodal": [], "tensor_visc": []}, {"mac_cc": [], "nodal": [], "tensor_visc": []}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ns.step()
+            for k, s in zip(("mac_cc", "nodal", "tensor_visc"), ns.stats()):
+                ms[k].append(s.vcycle_ms)
+                its[k].append(s.iters)
+        lib.sync()
+        el = time.perf_counter() - t0
+        del ns
+    finally:
+        lib.tuning_set("WARM_START", 1)
+    return ({k: st.median(v) for k, v in ms.items()}, {k: st.median(v) for k, v in its.items()}, el / steps * 1e3)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -340,7 +368,7 @@ def main():
     ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
     ns.post_init(-1.0)
     # HIP events around every 8th finest-level launch of the two smoother kernels that lead the step's kernel time (k_abec_gsrb,
-    # k_nodal_gs4; profiles/round2_c_kernel_stats.csv), on their launch stream: opened during the warm-up (creates the event pools),
+    # k_nodal_gs4; profiles/round3_kernel_stats.csv), on their launch stream: opened during the warm-up (creates the event pools),
     # re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
     probe_on = world == 1 and os.environ.get("IAMRX_BENCH_PROBE", "1") != "0"
     PROBES = {"gs4": (0, (n + 1) ** 3, 8), "gsrb": (1, n ** 3, 8), "god_z": (2, n ** 3, 1), "pred_z": (3, n ** 3, 1)}
@@ -417,7 +445,7 @@ def main():
     if rank == 0:
         import statistics as st
         kr = kernel_rooflines(lib, n) if world == 1 else {}
-        # dominant kernel of the step by summed duration (profiles/round2_c_kernel_stats.csv): k_abec_gsrb, one colour pass of the
+        # dominant kernel of the step by summed duration (profiles/round3_kernel_stats.csv): k_abec_gsrb, one colour pass of the
         # cell-centred GSRB smoother (MAC projection, scalar diffusion); second: k_nodal_gs4 (reported beside it)
         roofline = None
         cells = float(n) ** 3
@@ -445,7 +473,7 @@ def main():
             ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
             gbps = alg / ms / 1e6
             roofline = {"kernel": "k_abec_gsrb<false> (one red or black pass of the cell-centred GSRB smoother, variable b; the dominant kernel of the "
-                                  "step, profiles/round2_c_kernel_stats.csv)", "bound": "hbm",
+                                  "step, profiles/round3_kernel_stats.csv)", "bound": "hbm",
                         "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                         "traffic": pmc_traffic("k_abec_gsrb<false> grid=%d" % (n ** 3 // 16)),
                         "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
@@ -488,11 +516,12 @@ def main():
         # prediction = velocity 24 + forcing 24 + the three face velocities 24
         zwg = (n // 16) * (n // 8) * ((n + 63) // 64)          # workgroups of one component (16 x 8 tiles, 64-plane chunks), 192 threads each
         zgrid = (zwg + 7) // 8 * 8 * 192
-        roofline_god = godunov_roofline("god_z", insitu.get("god_z"), "k_god_z<16, 8, 192, 2, false> grid=%d" % (5 * zgrid), 152.0 * cells,
+        roofline_god = godunov_roofline("god_z", insitu.get("god_z"), "k_god_z<16, 8, 192, 2, false, false> grid=%d" % (5 * zgrid), 152.0 * cells,
                                         "k_god_z<16,8> (fused z-marching Godunov advection of the 5 state components: ComputeFluxesOnBoxFromState + "
                                         "ComputeDivergence / ComputeConvectiveTerm in one launch)")
-        roofline_pred = godunov_roofline("pred_z", insitu.get("pred_z"), "k_pred_z<16, 8, 192, false> grid=%d" % zgrid, 72.0 * cells,
+        roofline_pred = godunov_roofline("pred_z", insitu.get("pred_z"), "k_pred_z<16, 8, 192, false, false> grid=%d" % zgrid, 72.0 * cells,
                                          "k_pred_z<16,8> (fused z-marching ExtrapVelToFaces)")
+        ups = upstream_shape_pass(lib, N, g, lay, a.c) if (world == 1 and not a.no_upstream_shape) else None
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -502,6 +531,9 @@ def main():
                        "cells": cells_total, "prob_c": a.c},
             "mlmg_vcycle_ms": {"mac_cc": st.median(mac_ms), "nodal": st.median(nod_ms), "tensor_visc": st.median(visc_ms)},
             "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
+            "mlmg_vcycle_ms_upstream_shape": ups[0] if ups else None,
+            "mlmg_iters_upstream_shape": ups[1] if ups else None,
+            "ms_per_step_upstream_shape": ups[2] if ups else None,
             "sections_ms_per_step": {k: v / 2 for k, v in zip(["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"], sec[:6])},
             "device_mallocs_in_timed_region": mallocs_in_loop,
             "host_syncs_per_step": syncs_in_loop / a.steps,

@@ -42,8 +42,11 @@ __global__ void __launch_bounds__(256) k_copy_plan(const CopyDesc* __restrict__ 
 void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add)
 {
     if (nd == 0) return;
+    // whole-array copies between layouts (one descriptor of millions of points) want thousands of workgroups in flight; a ghost-shell
+    // exchange (many small descriptors: the grid's y dimension) keeps its short x dimension
     long nb = (maxpts + 255) / 256;
-    if (nb > 256) nb = 256;
+    const long cap = nd >= 8 ? 256 : 4096;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_copy_plan, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, src, dst, scomp, dcomp, nc, add ? 1 : 0);
 }

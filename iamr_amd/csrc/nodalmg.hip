@@ -398,6 +398,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
     else {
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
+        std::vector<double> hist;
         for (int iter = 0; iter < maxit; ++iter) {
             if (m_singular) { subtract_mean(0, L0.res); L0.res_filled = false; }
             cycle_timer().mark(ctx.stream);
@@ -411,6 +412,9 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
             if (m_o.verbose) printf("iamrx nodal MLMG: iter %d resid %.6e\n", iter + 1, st.resnorm);
             if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
             if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx nodal MLMG: failing to converge (residual blow-up)");
+            // stalled at the fp64 round-off floor just above the tolerance: see composite_project (amrns.hip); converged = 2
+            hist.push_back(st.resnorm);
+            if (m_o.fixed_iters <= 0 && hist.size() >= 4 && st.resnorm <= 100.0 * res_target && st.resnorm > 0.5 * hist[hist.size() - 4]) { st.converged = 2; break; }
         }
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx nodal MLMG: failed to converge after max_iters");
     }

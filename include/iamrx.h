@@ -63,7 +63,7 @@ typedef struct iamrx_mg_stats {
     int iters;
     double resnorm0, rhsnorm0, resnorm;
     int bottom_iters_total;
-    int converged;
+    int converged;             /* 1: the tolerance was met; 2 (nodal solves): the residual stalled at the fp64 round-off floor within 100x of the tolerance (h <= 1/512) */
     double vcycle_ms;
     int nlevels;
 } iamrx_mg_stats;
