@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-multibox", action="store_true", help="skip the single-GPU 8-box / 64-box runs of the same problem")
     ap.add_argument("--cpu-n", type=int, default=96)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--amr-n", type=int, default=128, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
+    ap.add_argument("--amr-n", type=int, default=256, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
     ap.add_argument("--amr-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the oracle's smoother loops (the rest of the port is scalar); 0 = the CPUs this process may really use")

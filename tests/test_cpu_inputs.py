@@ -55,8 +55,13 @@ def test_rayleightaylor_keys():
     assert pr["params"]["gravity"] == -9.8 and pr["params"]["do_mom_diff"] == 0 and pr["params"]["do_cons_trac"] == 0
     pr = Inputs([LDC], ["ns.do_mom_diff=1", "ns.do_cons_trac=1"]).problem()          # Exec/run3d/regtest.3d.rayleightaylor:6-7
     assert pr["params"]["do_mom_diff"] == 1 and pr["params"]["do_cons_trac"] == 1
+    pr = Inputs([LDC], ["ns.do_temp=1", "ns.temp_cond_coef=1.e-8", "ns.do_trac2=1", "ns.do_cons_trac2=1", "ns.scal_diff_coefs=0.001 0.002",
+                        "ns.lo_bc=1 5 5", "xlo.temp=2.0", "xlo.tracer2=0.5"]).problem()          # Exec/run3d/regtest.3d.hotspot:1-4
+    p = pr["params"]
+    assert (p["do_temp"], p["temp_cond_coef"], p["do_trac2"], p["do_cons_trac2"], p["tracer_diff_coef"], p["tracer2_diff_coef"]) == (1, 1.e-8, 1, 1, 0.001, 0.002)
+    assert p["scal_bc_lo"][:4] == [1.0, 0.0, 0.5, 2.0]                      # density (default 1), tracer, tracer2, temp on x-lo: [d*4 + slot]
     with pytest.raises(NotImplementedError):
-        Inputs([LDC], ["ns.do_temp=1"]).problem()
+        Inputs([LDC], ["ns.do_LES=1"]).problem()
 
 
 def test_host_side_problem_setups():
