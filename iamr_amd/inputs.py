@@ -25,14 +25,14 @@ _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.v
                  "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
                  "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
-_IGNORED_NAMESPACES = ("mg.", "fab.", "amrex.", "amr.refinement_indicators")
+_IGNORED_NAMESPACES = ("mg.", "fab.", "fabarray.", "amrex.", "amr.refinement_indicators")
 # boundary values of the second tracer: read by upstream only with ns.do_trac2 = 1 (which raises here), unused otherwise
 # keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
 _UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
                          "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
 
 
-def read_grid_file(path, ref_ratio):
+def read_grid_file(path, ref_ratio, slab=None):
     """amr.regrid_file / amr.initial_grid_file (upstream Amr::readProbinFile-era format, e.g. Exec/run2d/test_grids/fixed_grids_2): number
     of refined levels, then per level the number of boxes and the boxes `((lo) (hi) (type))` given in the index space of the NEXT
     COARSER level.  Returns, per refined level, the boxes refined by ref_ratio[level-1] -- the level's own index space (pinned on the
@@ -52,6 +52,13 @@ def read_grid_file(path, ref_ratio):
             lo = [int(v) for v in m.group(1).split(",")]
             hi = [int(v) for v in m.group(2).split(",")]
             r = ref_ratio[l]
+            if len(lo) == 2:            # 2-D grid file of a 2-D run lifted onto a slab: (x, y) -> (x, slab, z), the whole slab thickness
+                if slab is None:
+                    raise ValueError(f"grid file {path}: two-dimensional boxes in a three-dimensional run")
+                ns_c = slab
+                for _ in range(l):
+                    ns_c *= ref_ratio[_]
+                lo, hi = [lo[0], 0, lo[1]], [hi[0], ns_c - 1, hi[1]]
             boxes.append((tuple(v * r for v in lo), tuple((v + 1) * r - 1 for v in hi)))
         out.append(boxes)
     return out
@@ -110,7 +117,12 @@ class Inputs:
             if default is None:
                 raise KeyError(f"inputs: required key {k} is missing")
             return default
-        return int(self._get(k, 1)[0])
+        v = self._get(k, 1)[0]
+        if v.lower() in ("true", "t"):           # ParmParse reads booleans into ints
+            return 1
+        if v.lower() in ("false", "f"):
+            return 0
+        return int(v)
 
     def string(self, k, default=None):
         if k not in self.table:
@@ -176,9 +188,82 @@ class Inputs:
                     do_refine_outflow=self.integer("ns.do_refine_outflow", 0), do_derefine_outflow=self.integer("ns.do_derefine_outflow", 1),
                     nbuf_outflow=self.integer("ns.Nbuf_outflow", 1))
 
+    # two-dimensional inputs ---------------------------------------------------------------------------------------------
+    def lift_2d(self):
+        """A 2-D inputs file (amr.n_cell with two entries; AMREX_SPACEDIM == 2 builds of the reference, Exec/run2d) runs as a slab of the
+        three-dimensional library: 2-D x -> x, 2-D y -> z (gravity and the hydrostatic outflow pressure act along the last coordinate in
+        both, NavierStokesBase.cpp:3560, Projection.cpp:2000), the third direction y is periodic, `slab` cells thick with cubic cells,
+        carries no flow and no variation.  The table is rewritten in place into the equivalent 3-D inputs; returns the slab thickness
+        (cells on level 0) or None for a 3-D file.  The work is `slab` times that of a true 2-D build."""
+        nc = self.table.get("amr.n_cell")
+        if nc is None or len(nc) != 2:
+            return None
+        T = self.table
+        nx, ny = int(nc[0]), int(nc[1])
+        bf = int(T.get("amr.blocking_factor", ["8"])[0])
+        slab = max(8, bf)
+        while slab < 32 and min(nx, ny) // slab > 16:          # keep the coarsest multigrid level at <= 16 x 16 cells
+            slab *= 2
+        lo = [float(v) for v in T["geometry.prob_lo"][:2]]
+        hi = [float(v) for v in T["geometry.prob_hi"][:2]]
+        dx = (hi[0] - lo[0]) / nx
+        T["amr.n_cell"] = [str(nx), str(slab), str(ny)]
+        T["geometry.prob_lo"] = [repr(lo[0]), "0.0", repr(lo[1])]
+        T["geometry.prob_hi"] = [repr(hi[0]), repr(slab * dx), repr(hi[1])]
+        per = T.get("geometry.is_periodic", ["0", "0"])
+        T["geometry.is_periodic"] = [per[0], "1", per[1]]
+        for k in ("ns.lo_bc", "ns.hi_bc"):
+            if k in T:
+                T[k] = [T[k][0], "0", T[k][1]]
+        for side in ("lo", "hi"):                               # the y faces become the z faces; velocities (u, v) -> (u, 0, v)
+            for k in [k for k in list(T) if k.startswith(f"y{side}.")]:
+                T[f"z{side}." + k.split(".", 1)[1]] = T.pop(k)
+            for d in "xz":
+                k = f"{d}{side}.velocity"
+                if k in T:
+                    T[k] = [T[k][0], "0.0", T[k][1]]
+        for k in ("prob.blob_center", "prob.velocity_ic"):
+            if k in T:
+                T[k] = [T[k][0], "0.0", T[k][1]]
+        for k in [k for k in T if k.endswith(".in_box_lo") or k.endswith(".in_box_hi")]:
+            T[k] = [T[k][0], "-1.e200" if k.endswith("lo") else "1.e200", T[k][1]]
+        if "amr.max_grid_size" in T and len(T["amr.max_grid_size"]) > 1:
+            T["amr.max_grid_size"] = T["amr.max_grid_size"][:1]
+        return slab
+
+    def physical_bcs(self, per):
+        """ns.lo_bc / ns.hi_bc (integers, the older style) or {x,y,z}{lo,hi}.type (strings) -> PhysBCType per face
+        (NavierStokes::Initialize_bcs, NavierStokes.cpp:66-250); both given for a face must agree"""
+        names = {"no_slip_wall": 5, "nsw": 5, "slip_wall": 4, "sw": 4, "mass_inflow": 1, "mi": 1, "pressure_outflow": 2, "po": 2, "symmetry": 3, "sym": 3}
+        lo = self.ints("ns.lo_bc", 3) if self.has("ns.lo_bc") else [None] * 3
+        hi = self.ints("ns.hi_bc", 3) if self.has("ns.hi_bc") else [None] * 3
+        for d, nm in enumerate("xyz"):
+            for side, arr in (("lo", lo), ("hi", hi)):
+                key = f"{nm}{side}.type"
+                if self.has(key):
+                    s = self.string(key).lower()
+                    if s in ("pressure_inflow", "pi"):
+                        raise NotImplementedError(f"inputs: {key} = {s}: not implemented upstream either (NavierStokes.cpp:171-180)")
+                    if s not in names:
+                        raise ValueError(f"inputs: {key} = {s}: no valid BC type")
+                    if per[d]:
+                        raise ValueError(f"inputs: wrong BC type for the periodic boundary {nm}{side}")
+                    if arr[d] is not None and arr[d] != names[s]:
+                        raise ValueError(f"inputs: multiple conflicting BCs specified for {nm}{side}")
+                    arr[d] = names[s]
+                    if self.has(f"{nm}{side}.pressure") and self.real(f"{nm}{side}.pressure") != 0.0:
+                        raise NotImplementedError("inputs: pressure outflow != 0 is not implemented upstream either (NavierStokes.cpp:193-196)")
+                if arr[d] is None:
+                    if per[d]:
+                        arr[d] = 0
+                    else:
+                        raise KeyError(f"inputs: no valid BC type specified for {nm}{side}")
+        return lo, hi
+
     # mapping ----------------------------------------------------------------------------------------------------------
     def problem(self):
         """-> dict(n, prob_lo, prob_hi, periodic, max_grid_size, params (kwargs of ns_params), prob (dict), max_step, stop_time)"""
+        slab = self.lift_2d()
         max_level = self.integer("amr.max_level", 0)
         fine_boxes = []
         regrid = None
@@ -200,7 +285,7 @@ class Inputs:
             if gf is not None:
                 if not os.path.isabs(gf) and self.files:
                     gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
-                fine_boxes = read_grid_file(gf, rr)[:max_level]
+                fine_boxes = read_grid_file(gf, rr, slab)[:max_level]
                 if initial_only:
                     regrid = self.refinement_indicators(max_level)
                     if not regrid["rules"]:
@@ -217,8 +302,7 @@ class Inputs:
         prob_lo = self.reals("geometry.prob_lo", 3)
         prob_hi = self.reals("geometry.prob_hi", 3)
         per = self.ints("geometry.is_periodic", 3, [0, 0, 0])
-        lo_bc = self.ints("ns.lo_bc", 3)
-        hi_bc = self.ints("ns.hi_bc", 3)
+        lo_bc, hi_bc = self.physical_bcs(per)
         for d in range(3):
             if per[d] and (lo_bc[d] != 0 or hi_bc[d] != 0):
                 raise ValueError("inputs: periodic direction with a non-Interior ns.lo_bc/hi_bc (NavierStokesBase.cpp:563-590)")
@@ -249,11 +333,18 @@ class Inputs:
                  proj_tol=self.real("proj.proj_tol", 1.0e-12), proj_abs_tol=self.real("proj.proj_abs_tol", 1.0e-16),
                  phys_lo=lo_bc, phys_hi=hi_bc)
         wlo, whi = [0.0] * 9, [0.0] * 9
+        # NavierStokes.cpp:113-160: a no-slip wall takes the tangential components of its .velocity (the wall does not move along its
+        # normal), a mass inflow all of them; slip walls, outflow and symmetry faces take none
         for d, name in enumerate("xyz"):
-            if self.has(f"{name}lo.velocity"):
-                wlo[3 * d:3 * d + 3] = self.reals(f"{name}lo.velocity", 3)
-            if self.has(f"{name}hi.velocity"):
-                whi[3 * d:3 * d + 3] = self.reals(f"{name}hi.velocity", 3)
+            for side, arr, bcs in (("lo", wlo, lo_bc), ("hi", whi, hi_bc)):
+                if not self.has(f"{name}{side}.velocity"):
+                    continue
+                v = self.reals(f"{name}{side}.velocity", 3)
+                if bcs[d] == 5:
+                    v[d] = 0.0
+                elif bcs[d] != 1:
+                    v = [0.0, 0.0, 0.0]
+                arr[3 * d:3 * d + 3] = v
         p["wall_vel_lo"], p["wall_vel_hi"] = wlo, whi
         # inflow values of the scalars: {x,y,z}{lo,hi}.density / .tracer / .tracer2 / .temp (NavierStokes::Initialize_bcs,
         # NavierStokes.cpp:66-170: defaults density 1, tracers 0, temp 1), [d*4 + slot]
@@ -285,7 +376,9 @@ class Inputs:
         else:
             raise NotImplementedError(f"inputs: prob.probtype = {probtype}; implemented: 1 (fluid at rest, LidDrivenCavity), 2 / 6 (bubble / hot spot), 4 (constant "
                                       "velocity + tracer blob), 5 (DoubleShearLayer), 7 (Euler), 10 (RayleighTaylor), 11 (TaylorGreen)")
-        out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob,
+        if slab:
+            prob["dim"] = 2
+        out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob, slab=slab,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
                    plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level,
                    check_int=self.integer("amr.check_int", -1), check_file=self.string("amr.check_file", "chk"),

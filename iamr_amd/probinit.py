@@ -21,6 +21,15 @@ def initial_state(prob, X, Y, Z, nstate=5):
     components past the tracer (tracer2, temp) as prob_init.cpp's `for nt = 2 .. nscal-1` loops set them"""
     S = np.zeros(X.shape + (nstate,))
     pt = prob["probtype"]
+    if prob.get("dim", 3) == 2:
+        # a two-dimensional problem on the (x, z) plane of a y-periodic slab (inputs.Inputs.lift_2d): the AMREX_SPACEDIM == 2 branches of
+        # prob_init.cpp see (x, y) = our (X, Z), their v is our w, distances have no third term
+        S2 = initial_state(dict(prob, dim=3, _plane=True), X, Z, np.zeros_like(Z), nstate)
+        S[..., 0], S[..., 2] = S2[..., 0], S2[..., 1]
+        S[..., 3:] = S2[..., 3:]
+        return S
+    if prob.get("_plane"):                       # evaluated by the 2-D branch above: Z is zero, the blob centre's third entry is ignored
+        prob = dict(prob, blob_center=[prob["blob_center"][0], prob["blob_center"][2], 0.0], velocity_ic=[prob["velocity_ic"][0], prob["velocity_ic"][2], 0.0])
     extra = 1.0                              # prob_init.cpp:400-403 (5), 605-608 (7)
     if pt in (2, 6):                         # init_bubble, prob_init.cpp:164-229; 6: hot bubble with temperature as the last scalar
         v = prob["velocity_ic"]

@@ -58,6 +58,21 @@ def level_arrays(ns, lay, N):
     return boxes, arrs
 
 
+def _plane(boxes, arrs, names):
+    """the (x, z) plane of a 2-D run lifted onto a y-periodic slab (inputs.Inputs.lift_2d) as 2-D boxes / arrays / names: the boxes that
+    start at y = 0, their first y-plane, the y-velocity (identically zero) dropped, z_velocity renamed"""
+    import numpy as np
+    keep = [q for q, (lo, hi) in enumerate(boxes) if lo[1] == 0]
+    comps = [0, 2] + list(range(3, len(names)))
+    for a in arrs:          # what makes the slab a 2-D run: no variation across it, no flow along it (checked on everything written)
+        scale = max(1.0, float(np.abs(a).max()))
+        if float(np.abs(a - a[:, :1]).max()) > 1e-8 * scale or float(np.abs(a[..., 1]).max()) > 1e-8 * scale:
+            raise RuntimeError("iamr_amd.run: the slab of a two-dimensional run lost its uniformity")
+    n2 = ["x_velocity", "y_velocity"] + list(names[3:])
+    return ([((boxes[q][0][0], boxes[q][0][2]), (boxes[q][1][0], boxes[q][1][2])) for q in keep],
+            [arrs[q][:, 0, :, :][..., comps].copy() for q in keep], n2)
+
+
 def write_plot_amr(amr, lays, pr, N, step, root):
     """NavierStokesBase::writePlotFile role for the hierarchy: one AMReX plotfile with every level (the five state components)"""
     from .plotfile import PlotFile, Level, state_names
@@ -67,9 +82,16 @@ def write_plot_amr(amr, lays, pr, N, step, root):
         n = [v * 2 ** l for v in pr["n"]]
         dx = [(pr["prob_hi"][d] - pr["prob_lo"][d]) / n[d] for d in range(3)]
         boxes, arrs = level_arrays(lev, lays[l], N)
-        levels.append(Level(((0, 0, 0), tuple(v - 1 for v in n)), dx, boxes, arrs, step * 2 ** l, amr.time))
+        if pr.get("slab"):
+            boxes, arrs, names2 = _plane(boxes, arrs, state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)))
+            levels.append(Level(((0, 0), (n[0] - 1, n[2] - 1)), [dx[0], dx[2]], boxes, arrs, step * 2 ** l, amr.time))
+        else:
+            levels.append(Level(((0, 0, 0), tuple(v - 1 for v in n)), dx, boxes, arrs, step * 2 ** l, amr.time))
     path = f"{root}{step:05d}"
-    PlotFile(state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)), amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
+    if pr.get("slab"):
+        PlotFile(names2, amr.time, [pr["prob_lo"][0], pr["prob_lo"][2]], [pr["prob_hi"][0], pr["prob_hi"][2]], levels).write(path)
+    else:
+        PlotFile(state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)), amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
     return path
 
 
@@ -151,8 +173,12 @@ def write_plot(ns, lay, pr, N, step, root):
         arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
         boxes.append((tuple(blo), tuple(bhi)))
     path = f"{root}{step:05d}"
-    from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step,
-                    names=state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0))).write(path)
+    names = state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0))
+    if pr.get("slab"):
+        boxes, arrs, names = _plane(boxes, arrs, names)
+        from_level_data((pr["n"][0], pr["n"][2]), (pr["prob_lo"][0], pr["prob_lo"][2]), (pr["prob_hi"][0], pr["prob_hi"][2]), boxes, arrs, ns.time, step, names=names).write(path)
+    else:
+        from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step, names=names).write(path)
     return path
 
 
