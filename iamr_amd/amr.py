@@ -80,6 +80,25 @@ class Amr:
         check(lib().iamrx_amr_set_compute_new_dt_on_regrid(self.h, int(compute_new_dt_on_regrid)))
         check(lib().iamrx_amr_set_outflow_tagging(self.h, int(do_refine_outflow), int(do_derefine_outflow), int(nbuf_outflow)))
 
+    def regrid_log(self):
+        """[(lbase, time, [boxes of level lbase + 1, boxes of level lbase + 2, ...]), ...] of the last coarse step"""
+        n = C.c_int()
+        check(lib().iamrx_amr_regrid_log_count(self.h, C.byref(n)))
+        out = []
+        for e in range(n.value):
+            lb, tm, nl = C.c_int(), C.c_double(), C.c_int()
+            nb = (C.c_int * 8)()
+            check(lib().iamrx_amr_regrid_log_event(self.h, e, C.byref(lb), C.byref(tm), C.byref(nl), nb, None))
+            tot = sum(nb[q] for q in range(nl.value))
+            arr = (C.c_int * (6 * max(tot, 1)))()
+            check(lib().iamrx_amr_regrid_log_event(self.h, e, C.byref(lb), C.byref(tm), C.byref(nl), nb, arr))
+            grids, q = [], 0
+            for l in range(nl.value):
+                grids.append([(tuple(arr[6 * (q + b):6 * (q + b) + 3]), tuple(arr[6 * (q + b) + 3:6 * (q + b) + 6])) for b in range(nb[l])])
+                q += nb[l]
+            out.append((lb.value, tm.value, grids))
+        return out
+
     def regrid(self):
         ch = C.c_int()
         check(lib().iamrx_amr_regrid(self.h, C.byref(ch)))

@@ -51,11 +51,18 @@ public:
     void set_compute_new_dt_on_regrid(int on) { rg.compute_new_dt_on_regrid = on; }
     void set_outflow_tagging(int refine, int derefine, int nbuf) { rg.do_refine_outflow = refine; rg.do_derefine_outflow = derefine; rg.nbuf_outflow = nbuf; }
     // new grids of levels 1 .. max_level from the tags of the current data (coarse to fine nesting enforced); the level-l boxes
-    std::vector<std::vector<BoxD>> make_new_grids();
+    std::vector<std::vector<BoxD>> make_new_grids(int lbase = 0);
     // install grids (levels 1 ..): new levels are filled from the old level where it existed and from the next coarser level elsewhere;
     // returns false if nothing changed
-    bool install_grids(const std::vector<std::vector<BoxD>>& grids);
-    bool regrid() { return install_grids(make_new_grids()); }
+    bool install_grids(const std::vector<std::vector<BoxD>>& grids, int lbase = 0, double cur_time = 0.0);
+    bool regrid(int lbase = 0, double cur_time = 0.0) { return install_grids(make_new_grids(lbase), lbase, cur_time); }
+    // Amr::timeStep's regrid check (okToRegrid(i) for i = level .. finest at the start of every step of every level): level_count_v[i] = steps
+    // of level i since the grids above it were last rebuilt.  regrid_log: what was rebuilt during the last coarse step (base level, time,
+    // boxes per level) -- a driver that mirrors the hierarchy elsewhere (the tests' oracle) replays it
+    std::vector<int> level_count_v;
+    struct RegridEvent { int lbase; double time; std::vector<std::vector<BoxD>> grids; };
+    std::vector<RegridEvent> regrid_log;
+    void maybe_regrid(int l, double time);
     int level_count = 0;                // coarse steps since the last regrid (Amr::level_count[0])
     // Amr::checkPoint / restart: dt_level, dt_min, n_cycle per level, level_steps, level_count, stop_time
     void get_restart_state(double* dt_lev, double* dt_mn, int* ncyc, int counters[2], double* stop) const;
@@ -81,7 +88,7 @@ private:
     int m_ratio = 2;
     void link_level(int l);
     void check_nesting(const std::vector<BoxD>& fine, const std::vector<BoxD>& crse, const Geometry& cgeom, int l) const;
-    void validate_grids(const std::vector<std::vector<BoxD>>& grids) const;   // throws before anything is modified
+    void validate_grids(const std::vector<std::vector<BoxD>>& grids, int lbase = 0) const;   // throws before anything is modified
     void compute_new_dt(bool post_regrid);
 };
 

@@ -208,8 +208,10 @@ MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bc
     const bool crse_side = (bool)fine_layout;
     MultiFab cls(layout, node_type(), 1, 0);
     MultiFab fc;
-    if (crse_side) { fc = fine_coverage(layout, fine_layout, g, fine_ratio); node_class(cls, fc, g); }
-    else { MultiFab cov = coverage(layout, g); node_class(cls, cov, g); }
+    MultiFab cnt = coverage(layout, g);                // the cells that count: cells of the level, not covered by the finer one
+    if (crse_side) { fc = fine_coverage(layout, fine_layout, g, fine_ratio); node_class(cls, fc, g); mask_mult(cnt, 0, 1, fc, true, 1); }
+    else node_class(cls, cnt, g);
+    cc_mirror_bc(g, cnt);                               // mlndlap_fillbc_cc of the cell masks: mirrored across the non-periodic faces
     // sigma and velocity restricted to the cells that count (zero elsewhere, also in the ghost cells outside the level)
     MultiFab sm(layout, cell_type(), 1, 1), um(layout, cell_type(), 3, 1);
     sm.setVal(0.0); um.setVal(0.0);
@@ -219,13 +221,14 @@ MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bc
     sm.FillBoundary(g);
     cc_mirror_bc(g, sm);
     um.FillBoundary(g);
-    {   // cells outside the physical domain keep the incoming values (inflow data; nodal_divu ignores the rest)
-        const FabD *ut = um.d_tab, *vt = vold.d_tab;
+    {   // cells outside the physical domain keep the incoming values (inflow data; nodal_divu ignores the rest) where the cell they
+        // mirror counts: the velocity is multiplied by the mirrored cell mask in compSyncResidualCoarse / Fine
+        const FabD *ut = um.d_tab, *vt = vold.d_tab, *nt = cnt.d_tab;
         const BoxD dom = g.domain;
         const int p0 = g.periodic[0], p1 = g.periodic[1], p2 = g.periodic[2];
         for_each(*layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int f) {
             const bool out = (!p0 && (i < dom.lo[0] || i > dom.hi[0])) || (!p1 && (j < dom.lo[1] || j > dom.hi[1])) || (!p2 && (k < dom.lo[2] || k > dom.hi[2]));
-            if (out) for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) = vt[f](i, j, k, n);
+            if (out && nt[f](i, j, k) != 0.0) for (int n = 0; n < 3; ++n) ut[f](i, j, k, n) = vt[f](i, j, k, n);
         });
     }
     MultiFab rhs(layout, node_type(), 1, 0), ph(layout, node_type(), 1, 1), r(layout, node_type(), 1, 1);
@@ -1037,8 +1040,30 @@ void AmrNS::post_timestep(int l, int crse_iteration)
 }
 
 // Amr::timeStep
+// Amr::timeStep's regrid block (upstream AMReX_Amr.cpp): at the start of a step of level l every level i = l .. min(finest, max_level - 1)
+// whose own step count since the last rebuild has reached regrid_int rebuilds the levels above it
+void AmrNS::maybe_regrid(int l, double time)
+{
+    if (!(rg.regrid_int > 0 && rg.max_level > 0)) return;
+    if ((int)level_count_v.size() < rg.max_level + 1) level_count_v.resize(rg.max_level + 1, 0);
+    int lev_top = std::min((int)lev.size() - 1, rg.max_level - 1);
+    for (int i = l; i <= lev_top; ++i) {
+        const int old_finest = (int)lev.size() - 1;
+        if (level_count_v[i] >= rg.regrid_int) {
+            AmrTimer t(*this, 5);
+            std::vector<std::vector<BoxD>> grids = make_new_grids(i);
+            const bool changed = install_grids(grids, i, time);
+            if (changed) regrid_log.push_back(RegridEvent{i, time, grids});
+            if (changed && i == 0 && rg.compute_new_dt_on_regrid) compute_new_dt(true);
+            for (int k = i; k <= rg.max_level; ++k) level_count_v[k] = 0;
+        }
+        if (old_finest > (int)lev.size() - 1) lev_top = std::min((int)lev.size() - 1, rg.max_level - 1);
+    }
+}
+
 void AmrNS::time_step(int l, double time, int iteration, int niter)
 {
+    maybe_regrid(l, time);
     NavierStokes& s = *lev[l];
     s.time = time;
     double dt_new;
@@ -1046,6 +1071,7 @@ void AmrNS::time_step(int l, double time, int iteration, int niter)
     dt_min[l] = iteration == 1 ? dt_new : std::min(dt_min[l], dt_new);
     s.time = time + dt_level[l];
     s.nstep += 1;
+    if ((int)level_count_v.size() > l) level_count_v[l] += 1;
     if (l < (int)lev.size() - 1) {
         const int nc = n_cycle[l + 1];
         for (int i = 1; i <= nc; ++i) time_step(l + 1, time + (i - 1) * dt_level[l + 1], i, nc);
@@ -1241,14 +1267,12 @@ void AmrNS::set_restart_state(const double* dt_lev, const double* dt_mn, const i
 double AmrNS::coarse_step()
 {
     if (level_steps > 0) compute_new_dt(false);
-    if (rg.regrid_int > 0 && rg.max_level > 0 && level_count >= rg.regrid_int) {
-        level_count = 0;
-        AmrTimer t(*this, 5);
-        if (regrid() && rg.compute_new_dt_on_regrid) compute_new_dt(true);
-    }
+    regrid_log.clear();
+    if ((int)level_count_v.size() < rg.max_level + 1) level_count_v.resize(rg.max_level + 1, 0);
+    if (!level_count_v.empty()) level_count_v[0] = level_count;      // level_count: the value checkpoints carry (Amr::level_count[0])
     time_step(0, lev[0]->time, 1, 1);
     level_steps += 1;
-    level_count += 1;
+    level_count = level_count_v.empty() ? level_count + 1 : level_count_v[0];
     for (size_t i = 0; i < lev.size(); ++i) lev[i]->dt = dt_level[i];
     return dt_level[0];
 }

@@ -57,13 +57,53 @@ bool same_boxes(std::vector<BoxD> a, std::vector<BoxD> b)
 
 }  // namespace
 
-std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
+// periodic-aware erosion of a 0/1 cell map by one cell per pass (a cell survives if its 26 neighbours do; outside a non-periodic
+// domain face nothing constrains)
+static void erode(std::vector<unsigned char>& m, const int n[3], const int per[3], int passes)
+{
+    for (int p = 0; p < passes; ++p) {
+        std::vector<unsigned char> o = m;
+        for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i) {
+            if (!o[((size_t)k * n[1] + j) * n[0] + i]) continue;
+            bool keep = true;
+            for (int dz = -1; dz <= 1 && keep; ++dz) for (int dy = -1; dy <= 1 && keep; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                int q[3] = {i + dx, j + dy, k + dz};
+                bool out = false;
+                for (int d = 0; d < 3; ++d) {
+                    if (q[d] >= 0 && q[d] < n[d]) continue;
+                    if (per[d]) q[d] = (q[d] % n[d] + n[d]) % n[d]; else out = true;
+                }
+                if (out) continue;
+                if (!o[((size_t)q[2] * n[1] + q[1]) * n[0] + q[0]]) { keep = false; break; }
+            }
+            if (!keep) m[((size_t)k * n[1] + j) * n[0] + i] = 0;
+        }
+    }
+}
+
+// lbase: the levels up to lbase keep their grids (Amr::regrid(lbase)); returns the boxes of the levels lbase + 1 ...
+std::vector<std::vector<BoxD>> AmrNS::make_new_grids(int lbase)
 {
     const int finest = (int)lev.size() - 1;
     const int max_level = rg.max_level;
     std::vector<std::vector<BoxD>> grids(max_level + 1);                 // grids[l]: boxes of level l (index space of level l), l >= 1
     const int nest_buf = 3;                                              // in cells of the level being nested (see the header comment)
-    for (int l = std::min(finest, max_level - 1); l >= 0; --l) {
+    // proper nesting domain of a regrid above level 0: the new level lbase + 1 lies at least two cells of level lbase inside that level
+    // (its three Godunov ghost cells and the interpolation stencil); tags of finer levels must lie two more cells inside, so that the
+    // boxes they lead to, grown by the nesting buffer, still fit
+    std::vector<unsigned char> allow0, allow1;
+    if (lbase > 0) {
+        const NavierStokes& b = *lev[lbase];
+        const int nn[3] = {b.g.domain.len(0), b.g.domain.len(1), b.g.domain.len(2)};
+        allow0.assign((size_t)nn[0] * nn[1] * nn[2], 0);
+        for (const BoxD& bx : b.layout->boxes)
+            for (int k = bx.lo[2]; k <= bx.hi[2]; ++k) for (int j = bx.lo[1]; j <= bx.hi[1]; ++j) for (int i = bx.lo[0]; i <= bx.hi[0]; ++i)
+                allow0[((size_t)(k - b.g.domain.lo[2]) * nn[1] + (j - b.g.domain.lo[1])) * nn[0] + (i - b.g.domain.lo[0])] = 1;
+        erode(allow0, nn, b.g.periodic, 2);
+        allow1 = allow0;
+        erode(allow1, nn, b.g.periodic, 2);
+    }
+    for (int l = std::min(finest, max_level - 1); l >= lbase; --l) {
         NavierStokes& s = *lev[l];
         const BoxD dom = s.g.domain;
         const int n0 = dom.len(0), n1 = dom.len(1), n2 = dom.len(2);
@@ -123,6 +163,18 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
         // tags outside the level's own cells cannot exist (no data there): boxes of level l+1 stay inside refine(level l) as long as
         // the clustering does not reach over the level's edge; the nesting of the OLD level l+1 in the OLD level l keeps a margin
         const int bf = std::max(1, rg.blocking_factor / m_ratio), mg = std::max(bf, rg.max_grid_size / m_ratio);
+        const unsigned char* allowed = nullptr;
+        std::vector<unsigned char> al;
+        if (lbase > 0 && l == lbase) allowed = allow0.data();
+        else if (lbase > 0) {                     // tags of a finer level: their ancestor on level lbase must lie in the inner region
+            const NavierStokes& b = *lev[lbase];
+            const int nb0 = b.g.domain.len(0), nb1 = b.g.domain.len(1);
+            const int sh = l - lbase;
+            for (int k = 0; k < n2; ++k) for (int j = 0; j < n1; ++j) for (int i = 0; i < n0; ++i) {
+                const size_t q = ((size_t)k * n1 + j) * n0 + i;
+                if (h[q] && !allow1[((size_t)(k >> sh) * nb1 + (j >> sh)) * nb0 + (i >> sh)]) h[q] = 0;
+            }
+        }
         OutflowTags oft;
         for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side)
             if (!s.g.periodic[d] && (side == 0 ? s.p.phys_lo[d] : s.p.phys_hi[d]) == phys_outflow) { oft.dir[oft.nface] = d; oft.side[oft.nface] = side; ++oft.nface; }
@@ -133,12 +185,12 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
             for (int j = 1; j <= l; ++j) { nlc = nlc * m_ratio + np; ncc = (nlc + bf - 1) / bf; nlc = ncc * bf; }
             oft.ncoarse = ncc;
         }
-        std::vector<BoxD> cb = cluster_tags(h.data(), dom, bf, mg, rg.grid_eff, rg.n_error_buf, oft.nface ? &oft : nullptr);
+        std::vector<BoxD> cb = cluster_tags(h.data(), dom, bf, mg, rg.grid_eff, rg.n_error_buf, oft.nface ? &oft : nullptr, allowed);
         for (const BoxD& b : cb) grids[l + 1].push_back(refine(b, m_ratio));
     }
     // a level can only exist if the one below it does
-    for (int l = 1; l <= max_level; ++l) if (grids[l].empty()) { for (int q = l; q <= max_level; ++q) grids[q].clear(); break; }
-    grids.erase(grids.begin());                                          // -> index 0 = level 1
+    for (int l = lbase + 1; l <= max_level; ++l) if (grids[l].empty()) { for (int q = l; q <= max_level; ++q) grids[q].clear(); break; }
+    grids.erase(grids.begin(), grids.begin() + lbase + 1);               // -> index 0 = level lbase + 1
     while (!grids.empty() && grids.back().empty()) grids.pop_back();
     return grids;
 }
@@ -146,12 +198,12 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids()
 // Everything that can be wrong with caller-supplied grids is found here, before the hierarchy is touched (install_grids moves the old
 // levels out first: a throw half way would leave it half-built): boxes non-empty, inside the level's domain, aligned to the refinement
 // ratio (a fine box covers whole coarse cells), pairwise disjoint, and every level properly nested in the one below.
-void AmrNS::validate_grids(const std::vector<std::vector<BoxD>>& grids) const
+void AmrNS::validate_grids(const std::vector<std::vector<BoxD>>& grids, int lbase) const
 {
-    BoxD dom = lev[0]->g.domain;
-    Geometry cg = lev[0]->g;
+    BoxD dom = lev[lbase]->g.domain;
+    Geometry cg = lev[lbase]->g;
     for (size_t q = 0; q < grids.size(); ++q) {
-        const int l = (int)q + 1;
+        const int l = lbase + (int)q + 1;
         if (q > 0) for (int d = 0; d < 3; ++d) { cg.domain = dom; cg.dx[d] /= (double)m_ratio; }
         dom = refine(dom, m_ratio);
         const auto& bl = grids[q];
@@ -166,36 +218,40 @@ void AmrNS::validate_grids(const std::vector<std::vector<BoxD>>& grids) const
             }
             for (size_t c = 0; c < a; ++c) if (intersect(b, bl[c]).ok()) throw Error("iamrx install_grids: boxes of level " + std::to_string(l) + " overlap");
         }
-        if (l > 1) check_nesting(bl, grids[q - 1], cg, l);
+        if (q > 0) check_nesting(bl, grids[q - 1], cg, l);
+        else if (lbase > 0) check_nesting(bl, lev[lbase]->layout->boxes, cg, l);      // the first new level inside the level that stays
     }
 }
 
-bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids)
+// grids[q]: the boxes of level lbase + 1 + q; the levels up to lbase stay as they are (Amr::regrid(lbase, time)); cur_time: the time the
+// levels above lbase have reached (a regrid that starts above level 0 can fall inside a coarse step)
+bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids, int lbase, double cur_time_in)
 {
     auto& ctx = Context::get();
-    validate_grids(grids);
-    const int old_finest = (int)lev.size() - 1, new_finest = (int)grids.size();
+    IAMRX_ASSERT(lbase >= 0 && lbase < (int)lev.size());
+    validate_grids(grids, lbase);
+    const int old_finest = (int)lev.size() - 1, new_finest = lbase + (int)grids.size();
     bool same = old_finest == new_finest;
-    for (int l = 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->layout->boxes, grids[l - 1]);
+    for (int l = lbase + 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->layout->boxes, grids[l - lbase - 1]);
     if (same) return false;
     ++m_grid_gen;
-    const double cur_time = lev[0]->time;
+    const double cur_time = lbase == 0 ? lev[0]->time : cur_time_in;
     std::vector<std::unique_ptr<NavierStokes>> old;
-    for (int l = 1; l <= old_finest; ++l) old.push_back(std::move(lev[l]));
-    lev.resize(1);
-    lev[0]->fine = nullptr;
+    for (int l = lbase + 1; l <= old_finest; ++l) old.push_back(std::move(lev[l]));
+    lev.resize(lbase + 1);
+    lev[lbase]->fine = nullptr;
     n_cycle.resize(new_finest + 1, m_ratio); dt_level.resize(new_finest + 1, 0.0); dt_min.resize(new_finest + 1, 1.e200);
     static LayoutP empty_layout;
     if (!empty_layout) empty_layout = std::make_shared<Layout>(std::vector<BoxD>{}, std::vector<int>{}, ctx.comm->rank);
-    for (int l = 1; l <= new_finest; ++l) {
+    for (int l = lbase + 1; l <= new_finest; ++l) {
         NavierStokes& c = *lev[l - 1];
         Geometry g = c.g;
         for (int d = 0; d < 3; ++d) { g.domain.lo[d] *= m_ratio; g.domain.hi[d] = (g.domain.hi[d] + 1) * m_ratio - 1; g.dx[d] /= (double)m_ratio; }
-        LayoutP nl = std::make_shared<Layout>(grids[l - 1], distribute_boxes(grids[l - 1], ctx.comm->nranks), ctx.comm->rank);
+        LayoutP nl = std::make_shared<Layout>(grids[l - lbase - 1], distribute_boxes(grids[l - lbase - 1], ctx.comm->nranks), ctx.comm->rank);
         lev.push_back(std::make_unique<NavierStokes>(g, nl, p, o));
         NavierStokes& s = *lev.back();
         s.level = l; s.ratio = m_ratio;
-        NavierStokes* ol = (l <= old_finest) ? old[l - 1].get() : nullptr;
+        NavierStokes* ol = (l <= old_finest) ? old[l - lbase - 1].get() : nullptr;
         link_level(l);
         // ---- times (init(old): setTimeLevel(cur_time, dt_old, dt_new); init(): dt = dt_crse / ratio, dt_old = (coarse dt_old) / ratio)
         const double dt_new = ol ? dt_level[l] : dt_level[l - 1] / (double)m_ratio;

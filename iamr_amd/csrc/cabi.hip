@@ -1047,6 +1047,21 @@ int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blockin
     a->amr->set_regrid(r);
     IAMRX_CATCH
 }
+int iamrx_amr_regrid_log_count(iamrx_amr a, int* nevents) { IAMRX_TRY *nevents = (int)a->amr->regrid_log.size(); IAMRX_CATCH }
+int iamrx_amr_regrid_log_event(iamrx_amr a, int event, int* lbase, double* time, int* nlevels, int* nboxes, int* boxes)
+{
+    IAMRX_TRY
+    const auto& log = a->amr->regrid_log;
+    if (event < 0 || event >= (int)log.size()) throw Error("iamrx_amr_regrid_log_event: no such event");
+    const auto& e = log[event];
+    *lbase = e.lbase; *time = e.time; *nlevels = (int)e.grids.size();
+    int q = 0;
+    for (size_t l = 0; l < e.grids.size(); ++l) {
+        if (nboxes) nboxes[l] = (int)e.grids[l].size();
+        if (boxes) for (const BoxD& b : e.grids[l]) { for (int d = 0; d < 3; ++d) { boxes[q + d] = b.lo[d]; boxes[q + 3 + d] = b.hi[d]; } q += 6; }
+    }
+    IAMRX_CATCH
+}
 int iamrx_amr_set_compute_new_dt_on_regrid(iamrx_amr a, int on) { IAMRX_TRY a->amr->set_compute_new_dt_on_regrid(on != 0); IAMRX_CATCH }
 int iamrx_amr_set_outflow_tagging(iamrx_amr a, int do_refine_outflow, int do_derefine_outflow, int nbuf_outflow)
 {

@@ -101,7 +101,7 @@ void error_tag(const Geometry& g, MultiFab& tags, const MultiFab& field, int com
 // ncoarse layers (of blocking-factor-coarsened cells) left unrefined
 struct OutflowTags { int nface = 0; int dir[6], side[6]; int mode = 0; int ncoarse = 0; };
 std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
-                               int n_error_buf, const OutflowTags* oft = nullptr);
+                               int n_error_buf, const OutflowTags* oft = nullptr, const unsigned char* allowed = nullptr /* domain-sized 0/1: where the new level may lie */);
 
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add = false);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193

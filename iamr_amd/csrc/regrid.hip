@@ -152,7 +152,7 @@ void br(const TagGrid& T, IBox b, double eff, std::vector<IBox>& out)
 // tags_host: domain-sized 0/1 array (x fastest); returns boxes of the SAME index space as the tags (the caller refines them by the
 // refinement ratio), each aligned to blocking_factor, at most max_grid_size long, disjoint, covering every tagged cell grown by n_error_buf
 std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
-                               int n_error_buf, const OutflowTags* oft)
+                               int n_error_buf, const OutflowTags* oft, const unsigned char* allowed)
 {
     const int bf = std::max(1, blocking_factor);
     int n[3], nc[3];
@@ -189,10 +189,41 @@ std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domai
             for (int k = ob.lo[2]; k <= ob.hi[2]; ++k) for (int j = ob.lo[1]; j <= ob.hi[1]; ++j) for (int i = ob.lo[0]; i <= ob.hi[0]; ++i) T.t[((size_t)k * nc[1] + j) * nc[0] + i] = 0;
         }
     }
+    // proper nesting of a regrid that starts above level 0 (Amr::regrid(lbase > 0): the tags outside the proper nesting domain are removed
+    // and the clusters are intersected with it): `allowed` marks the cells of this index space the new level may cover; a block of the
+    // blocking-factor lattice counts only if all of its cells are allowed
+    std::vector<unsigned char> okb;
+    if (allowed) {
+        okb.assign(T.t.size(), 1);
+        for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+            if (!allowed[((size_t)k * n[1] + j) * n[0] + i]) okb[((size_t)(k / bf) * nc[1] + j / bf) * nc[0] + i / bf] = 0;
+        for (size_t q = 0; q < T.t.size(); ++q) if (!okb[q]) T.t[q] = 0;
+    }
     std::vector<IBox> cl;
     IBox all;
     for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = nc[d] - 1; }
     br(T, all, grid_eff, cl);
+    if (allowed) {                       // a cluster that reaches over blocks that are not allowed: its allowed blocks, row by row
+        std::vector<IBox> cl2;
+        for (const IBox& c : cl) {
+            bool whole = true;
+            for (int k = c.lo[2]; k <= c.hi[2] && whole; ++k) for (int j = c.lo[1]; j <= c.hi[1] && whole; ++j) for (int i = c.lo[0]; i <= c.hi[0]; ++i)
+                if (!okb[((size_t)k * nc[1] + j) * nc[0] + i]) { whole = false; break; }
+            if (whole) { cl2.push_back(c); continue; }
+            for (int k = c.lo[2]; k <= c.hi[2]; ++k) for (int j = c.lo[1]; j <= c.hi[1]; ++j) {
+                int i = c.lo[0];
+                while (i <= c.hi[0]) {
+                    if (!okb[((size_t)k * nc[1] + j) * nc[0] + i]) { ++i; continue; }
+                    int e = i;
+                    while (e + 1 <= c.hi[0] && okb[((size_t)k * nc[1] + j) * nc[0] + e + 1]) ++e;
+                    IBox r; r.lo[0] = i; r.hi[0] = e; r.lo[1] = r.hi[1] = j; r.lo[2] = r.hi[2] = k;
+                    cl2.push_back(r);
+                    i = e + 1;
+                }
+            }
+        }
+        cl.swap(cl2);
+    }
     // refine to the tag index space and chop to max_grid_size
     std::vector<BoxD> out;
     const int mg = max_grid_size;

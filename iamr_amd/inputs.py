@@ -295,6 +295,8 @@ class Inputs:
                 regrid = self.refinement_indicators(max_level)
                 if not regrid["rules"]:
                     raise NotImplementedError("inputs: amr.max_level > 0 needs amr.refinement_indicators or fixed grids (amr.regrid_file)")
+        if max_level == 0 and self.has("amr.refinement_indicators"):
+            self.refinement_indicators(1)              # a single-level run reads and drops the indicator definitions, as upstream does
         if self.integer("geometry.coord_sys", 0) != 0:
             raise NotImplementedError("inputs: only Cartesian coordinates (geometry.coord_sys = 0)")
         n = self.ints("amr.n_cell", 3)

@@ -64,13 +64,42 @@ def _plane(boxes, arrs, names):
     import numpy as np
     keep = [q for q, (lo, hi) in enumerate(boxes) if lo[1] == 0]
     comps = [0, 2] + list(range(3, len(names)))
-    for a in arrs:          # what makes the slab a 2-D run: no variation across it, no flow along it (checked on everything written)
+    # what makes the slab a 2-D run: no variation across it, no flow along it (checked on everything written; enforce_plane keeps it so)
+    for a in arrs:
         scale = max(1.0, float(np.abs(a).max()))
-        if float(np.abs(a - a[:, :1]).max()) > 1e-8 * scale or float(np.abs(a[..., 1]).max()) > 1e-8 * scale:
-            raise RuntimeError("iamr_amd.run: the slab of a two-dimensional run lost its uniformity")
+        dev = max(float(np.abs(a - a[:, :1]).max()), float(np.abs(a[..., 1]).max()))
+        if dev > 1e-8 * scale:
+            raise RuntimeError(f"iamr_amd.run: the slab of a two-dimensional run lost its uniformity (deviation {dev:.3e}, scale {scale:.3e})")
     n2 = ["x_velocity", "y_velocity"] + list(names[3:])
     return ([((boxes[q][0][0], boxes[q][0][2]), (boxes[q][1][0], boxes[q][1][2])) for q in keep],
             [arrs[q][:, 0, :, :][..., comps].copy() for q in keep], n2)
+
+
+def enforce_plane(levels, pr):
+    """a two-dimensional run on its y-periodic slab (inputs.Inputs.lift_2d) after every coarse time step: the state, the pressure and its
+    gradient become their means across the slab, the velocity / gradient component along it zero.  Upstream's 2-D build has no third
+    direction to perturb; here the multigrid smoothers' (i + j + k) colouring leaves iteration error at the level of the solver
+    tolerances that varies across the slab, which a flow that amplifies perturbations would grow into real three-dimensional motion over
+    many steps.  Projecting it out each step keeps the run the 2-D run the inputs file describes (deviations removed are of the size of
+    the solver tolerances; `_plane` still checks everything written).  Single-rank runs (every box is local)."""
+    import numpy as np
+    for l, lev in enumerate(levels):
+        n = [v * 2 ** l for v in pr["n"]]
+        for which, along in ((lev.S_NEW, 1), (lev.P_NEW, None), (lev.GP_NEW, 1)):
+            mf = lev.data(which)
+            G = mf.gather_valid(n)
+            plane = G[:, :n[1]].mean(axis=1)                     # nodal in y: node n[1] is the periodic image of node 0
+            if along is not None:
+                plane[..., along] = 0.0
+            for li in range(mf.nlocal()):
+                a, lo = mf.to_numpy(li)
+                blo, bhi, _ = mf.layout.local_box(li)
+                vx = slice(blo[0] - lo[0], bhi[0] + mf.typ[0] - lo[0] + 1)
+                vz = slice(blo[2] - lo[2], bhi[2] + mf.typ[2] - lo[2] + 1)
+                vy = slice(blo[1] - lo[1], bhi[1] + mf.typ[1] - lo[1] + 1)
+                a[vx, vy, vz] = plane[blo[0]:bhi[0] + mf.typ[0] + 1, None, blo[2]:bhi[2] + mf.typ[2] + 1]
+                mf.from_numpy(a, li)
+            lev.set_data(which, mf)
 
 
 def write_plot_amr(amr, lays, pr, N, step, root):
@@ -128,6 +157,8 @@ def main_amr(pr, inp, lib, N, rank=0, world=1):
         if pr["max_step"] < 0 and pr["stop_time"] < 0:
             break
         dt = amr.coarse_step()
+        if pr.get("slab"):
+            enforce_plane(amr.levels, pr)
         lays = amr.layouts                      # a regrid during the step replaces them
         step += 1
         say(f"STEP = {step} TIME = {amr.time:.12g} DT = {dt:.12g} LEVELS = {amr.nlev} GRIDS = {[len(l.boxes) for l in lays]}")
@@ -205,6 +236,8 @@ def main(argv):
         from . import comm
         comm.init_rccl_from_torch(dist)
     pr = inp.problem()
+    if pr.get("slab") and world > 1:
+        raise NotImplementedError("iamr_amd.run: two-dimensional inputs (run on a y-periodic slab) are single-rank runs")
     if pr["fine_boxes"] or pr.get("regrid") or (pr.get("restart") and pr.get("max_level", 0) > 0):
         return main_amr(pr, inp, lib, N, rank, world)
     plot_int, plot_root = pr.get("plot_int", -1), pr.get("plot_file", "plt")
@@ -231,6 +264,8 @@ def main(argv):
         if pr["max_step"] < 0 and pr["stop_time"] < 0:
             break
         dt = ns.step()
+        if pr.get("slab"):
+            enforce_plane([ns], pr)
         step += 1
         if rank == 0:
             print(f"STEP = {step} TIME = {ns.time:.12g} DT = {dt:.12g}")

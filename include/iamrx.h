@@ -487,6 +487,13 @@ int iamrx_amr_destroy(iamrx_amr a);
 typedef struct iamrx_tag_rule { int comp, mode, nvalue, max_level, has_box; double value[8]; double box_lo[3], box_hi[3]; } iamrx_tag_rule;
 int iamrx_amr_set_regrid(iamrx_amr a, int max_level, int regrid_int, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
                          int nrules, const iamrx_tag_rule* rules);
+/* The regrids of the last iamrx_amr_coarse_step.  As in Amr::timeStep, at the start of every step of every level each level i from there up
+ * whose own step count since the grids above it were last rebuilt has reached regrid_int rebuilds the levels above it (regrid(i)), so a
+ * regrid can start above level 0 and fall inside a coarse step.  Event e: the base level (the levels up to it kept their grids), the
+ * time, the number of rebuilt levels and, level by level from lbase + 1, their boxes (nboxes[l], then 6 ints per box; boxes NULL: sizes
+ * only).  For drivers that mirror the hierarchy elsewhere. */
+int iamrx_amr_regrid_log_count(iamrx_amr a, int* nevents);
+int iamrx_amr_regrid_log_event(iamrx_amr a, int event, int* lbase, double* time, int* nlevels, int* nboxes /* [8] */, int* boxes);
 /* amr.compute_new_dt_on_regrid (default 0): 1 = after a regrid from level 0 that changed the grids the time steps are recomputed with
  * NavierStokesBase::computeNewDt(post_regrid_flag = 1) (Source/NavierStokesBase.cpp:971-982), as Amr::timeStep does; 0 = levels that
  * existed keep their dt, new levels start with dt_level[l-1] / n_cycle[l]. */

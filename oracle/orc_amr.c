@@ -1078,8 +1078,32 @@ static void post_timestep(orc_amr* a, int lev, int crse_iteration)
 }
 
 /* Amr::timeStep */
+void orc_amr_regrid_from(orc_amr* a, int lbase, double cur_time, int nnew, const int* nbox, const int* boxes);
+/* regrids to replay during the next coarse step (the grids come from the product, see orc_amr_regrid): applied at the start of the step
+ * of level `lev` at `time` for every scheduled base level >= lev, as Amr::timeStep does */
+typedef struct { int lbase, nnew, done; double time; int nbox[8]; int* boxes; } regrid_event;
+static regrid_event g_events[64];
+static int g_nevents = 0;
+void orc_amr_schedule_regrid(int lbase, double time, int nnew, const int* nbox, const int* boxes)
+{
+    regrid_event* e = &g_events[g_nevents++];
+    e->lbase = lbase; e->nnew = nnew; e->done = 0; e->time = time;
+    int tot = 0;
+    for (int q = 0; q < nnew; ++q) { e->nbox[q] = nbox[q]; tot += nbox[q]; }
+    e->boxes = (int*)malloc(sizeof(int) * 6 * (size_t)(tot > 0 ? tot : 1));
+    memcpy(e->boxes, boxes, sizeof(int) * 6 * (size_t)tot);
+}
+void orc_amr_clear_regrid_schedule(void) { for (int q = 0; q < g_nevents; ++q) free(g_events[q].boxes); g_nevents = 0; }
+
 static void time_step(orc_amr* a, int lev, double time, int iteration, int niter)
 {
+    for (int q = 0; q < g_nevents; ++q) {
+        regrid_event* e = &g_events[q];
+        if (e->done || e->lbase < lev || e->lbase >= a->nlev) continue;
+        if (fabs(e->time - time) > 1.e-9 * fmax(1.0, fabs(time)) + 1.e-300) continue;
+        orc_amr_regrid_from(a, e->lbase, time, e->nnew, e->nbox, e->boxes);
+        e->done = 1;
+    }
     orc_ns_state* s = a->lev[lev];
     s->time = time;
     const double dt_new = ns_advance(s, a->dt_level[lev], iteration, niter);
@@ -1343,15 +1367,19 @@ static void compute_new_dt(orc_amr* a, int post_regrid)
  * rebuilt coarser level elsewhere) and of Press (node_bilinear_interp + the old level's nodes); time levels
  * setTimeLevel(cur_time, dt_old, dt_new); a new level starts with dt = dt_crse / ratio.  Call between coarse steps; the caller then
  * uses orc_amr_coarse_step_post_regrid for the next step (computeNewDt with post_regrid_flag = 1). */
-void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
+void orc_amr_regrid_from(orc_amr* a, int lbase, double cur_time, int nnew, const int* nbox, const int* boxes);
+void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes) { orc_amr_regrid_from(a, 0, a->lev[0]->time, nfine, nbox, boxes); }
+
+/* Amr::regrid(lbase, time): the levels up to lbase keep their grids, nnew levels above it are (re)built from the given boxes (nbox[q],
+ * boxes: level lbase + 1 + q); cur_time: the time all of them have reached (inside a coarse step for lbase > 0) */
+void orc_amr_regrid_from(orc_amr* a, int lbase, double cur_time, int nnew, const int* nbox, const int* boxes)
 {
-    const int old_nlev = a->nlev, ratio = 2;
-    const double cur_time = a->lev[0]->time;
+    const int old_nlev = a->nlev, ratio = 2, nfine = lbase + nnew;
     orc_ns_state* old[8];
     for (int l = 0; l < 8; ++l) old[l] = l < old_nlev ? a->lev[l] : NULL;
     const int* bp = boxes;
-    a->lev[0]->fine = NULL;
-    for (int l = 1; l <= nfine; ++l) {
+    a->lev[lbase]->fine = NULL;
+    for (int l = lbase + 1; l <= nfine; ++l) {
         orc_ns_state* c = a->lev[l - 1];
         orc_geom g = c->g;
         for (int d = 0; d < 3; ++d) { g.n[d] *= ratio; g.dx[d] /= (double)ratio; }
@@ -1359,7 +1387,7 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
         orc_ns_state* ol = old[l];
         s->level = l; s->ratio = ratio;
         s->crse = c; c->fine = s;
-        s->nbox = nbox[l - 1];
+        s->nbox = nbox[l - lbase - 1];
         s->boxes = (int*)malloc(sizeof(int) * 6 * (size_t)s->nbox);
         memcpy(s->boxes, bp, sizeof(int) * 6 * (size_t)s->nbox);
         bp += 6 * s->nbox;
@@ -1432,7 +1460,7 @@ void orc_amr_regrid(orc_amr* a, int nfine, const int* nbox, const int* boxes)
         ns_make_rho_curr_time(s);
         a->lev[l] = s;
     }
-    for (int l = 1; l < old_nlev; ++l) if (old[l]) orc_ns_destroy(old[l]);
+    for (int l = lbase + 1; l < old_nlev; ++l) if (old[l]) orc_ns_destroy(old[l]);
     for (int l = nfine + 1; l < 8; ++l) a->lev[l] = NULL;
     a->nlev = nfine + 1;
 }

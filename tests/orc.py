@@ -291,6 +291,33 @@ class OrcAmr:
         self.levels = [[]] + [list(g) for g in grids]
         return L.orc_amr_coarse_step_post_regrid(self.h, C.c_int(compute_new_dt_on_regrid))
 
+    def step_with_regrids(self, events, compute_new_dt_on_regrid=0):
+        """one coarse step that replays the regrids the product did during ITS coarse step (iamr_amd.amr.Amr.regrid_log): events =
+        [(lbase, time, [boxes of level lbase + 1, ...]), ...].  A level-0 event is the regrid at the start of the step; events with
+        lbase > 0 (Amr::timeStep's okToRegrid(i) for i >= 1) are scheduled and applied when the oracle's subcycling reaches their level
+        and time."""
+        L = lib()
+        L.orc_amr_coarse_step_post_regrid.restype = C.c_double
+        L.orc_amr_compute_new_dt(self.h)
+        L.orc_amr_clear_regrid_schedule()
+        post = 0
+        cur = [list(g) for g in self.levels]
+        for lbase, tm, grids in events:
+            nb = (C.c_int * max(1, len(grids)))(*[len(g) for g in grids])
+            flat = [v for g in grids for lo, hi in g for v in (*lo, *hi)]
+            arr = (C.c_int * max(1, len(flat)))(*flat)
+            if lbase == 0:
+                L.orc_amr_regrid(self.h, len(grids), nb, arr)
+                post = compute_new_dt_on_regrid
+            else:
+                L.orc_amr_schedule_regrid(C.c_int(lbase), C.c_double(tm), len(grids), nb, arr)
+            cur = cur[:lbase + 1] + [list(g) for g in grids]
+        dt = L.orc_amr_coarse_step_post_regrid(self.h, C.c_int(post))
+        L.orc_amr_clear_regrid_schedule()
+        self.levels = cur
+        self.nlev = len(cur)
+        return dt
+
     def dt(self, lev):
         return lib().orc_amr_dt(self.h, C.c_int(lev))
 

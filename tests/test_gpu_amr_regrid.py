@@ -83,10 +83,8 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
-        if after != before:
-            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after], 1)
-        else:
-            dto = oa.step()
+        ev = amr.regrid_log()            # every regrid of the coarse step: from level 0 at its start, from level 1 at the start of a level-1 step
+        dto = oa.step_with_regrids(ev, 1) if ev else oa.step()
         assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
         _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
         had_three = had_three or amr.nlev == 3
@@ -117,11 +115,39 @@ def test_rayleigh_taylor_physics_with_regridding():
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
+        ev = amr.regrid_log()            # incl. regrids that start at level 1 inside the coarse step (regrid_int = 1)
         if after != before:
             changes += 1
-            dto = oa.regrid_then_step([[(tuple(lo), tuple(hi)) for lo, hi in g] for g in after])
-        else:
-            dto = oa.step()
+        dto = oa.step_with_regrids(ev) if ev else oa.step()
         assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
         _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
     assert changes >= 1 and amr.nlev >= 2
+
+
+def test_regrid_that_starts_above_level_zero():
+    """Amr::timeStep checks okToRegrid(i) for every level i at the start of every step of every level: with regrid_int = 1 and three levels,
+    level 1 rebuilds level 2 at the start of its second subcycle step, INSIDE the coarse step, from its own tags restricted to its proper
+    nesting domain; level 1 and level 0 keep their grids.  The log of the coarse step records it, the oracle replays it, the data agree."""
+    n0 = 16
+    l1 = [([8, 8, 8], [23, 23, 23])]
+    kw = dict(cfl=0.7, visc_coef=0.0, init_iter=2)
+
+    def fn(X, Y, Z):
+        S = _blob(X, Y, Z, (0.5, 0.5, 0.5))
+        S[..., 0] += 0.6
+        return S
+    amr, oa = _make(n0, l1, 16, kw, fn)
+    amr.set_regrid(max_level=2, regrid_int=1, rules=[dict(comp=4, mode=0, value=[0.2, 0.5])], blocking_factor=4, max_grid_size=16, n_error_buf=1)
+    amr.post_init()
+    oa.post_init()
+    bases = []
+    for step in range(3):
+        dt = amr.coarse_step()
+        ev = amr.regrid_log()
+        bases += [(lb, tm) for lb, tm, _ in ev]
+        dto = oa.step_with_regrids(ev) if ev else oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto, (step, dt, dto)
+        _compare(amr, oa, 5e-8, f"after coarse step {step + 1}")
+    assert any(lb == 1 for lb, _ in bases), bases             # a regrid with base level 1 happened ...
+    t_half = [tm for lb, tm in bases if lb == 1]
+    assert amr.nlev == 3 and len(t_half) >= 1

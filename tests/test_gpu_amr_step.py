@@ -149,6 +149,44 @@ def test_two_level_taylorgreen_matches_oracle(case):
         assert Sg[0].shape[-1] == 6 and abs(m1[c] - m0[c]) <= 1e-11
 
 
+
+@pytest.mark.parametrize("case", ["viscous", "inviscid_boxes"])
+def test_two_level_channel_refined_at_the_inflow_matches_oracle(case):
+    """the refined level touches the inflow face (Exec/run2d regtest.2d.poiseuille: the tracer blob sits next to x-lo): the coarse and fine
+    sync residuals count the velocity behind the inflow face only where the cell it mirrors counts (mlndlap_fillbc_cc of the cell masks
+    in compSyncResidualCoarse / Fine); the coarse/fine corner on the face is where an error shows.  x: inflow / outflow, y: no-slip
+    walls, z: periodic."""
+    INFLOW, OUTFLOW, NOSLIP = 1, 2, 5
+    wl = [0.0] * 9
+    wl[0] = 1.0
+    sl = [0.0] * 12
+    sl[0], sl[1] = 1.0, 0.25                                     # xlo.density, xlo.tracer
+    kw = dict(cfl=0.5, visc_coef=0.05, tracer_diff_coef=0.002, init_iter=2, init_shrink=0.3, phys_lo=[INFLOW, NOSLIP, 0],
+              phys_hi=[OUTFLOW, NOSLIP, 0], wall_vel_lo=wl, scal_bc_lo=sl)
+    fine = [([0, 8, 0], [15, 23, 31])]
+    if case == "inviscid_boxes":                                  # two boxes along the face, one of them also on the lower wall
+        kw.update(visc_coef=0.0, tracer_diff_coef=0.0)
+        fine = [([0, 0, 0], [15, 15, 31]), ([0, 16, 0], [7, 23, 31])]
+
+    def state(X, Y, Z):
+        S = np.zeros(X.shape + (5,), order="F")
+        S[..., 0] = 1.0
+        S[..., 3] = 1.0
+        S[..., 4] = np.exp(-((X - 0.15) ** 2 + (Y - 0.5) ** 2) / 0.01)
+        return S
+    amr, oa = _make(16, fine, 8, kw, state, periodic=(0, 0, 1))
+    amr.post_init()
+    oa.post_init()
+    _compare(amr, oa, 2e-8, "after post_init")
+    for step in range(2):
+        dt = amr.coarse_step()
+        dto = oa.step()
+        assert abs(dt - dto) <= 1e-8 * dto
+        _compare(amr, oa, 2e-8, f"after coarse step {step + 1}")
+    S0 = amr.levels[0].data(0).gather_valid(oa.n(0))
+    assert np.abs(S0[..., 0]).max() < 1.6                        # a wrong residual at the corner node shows as a jet along the face
+
+
 def _composite_sum_n(states, covs, dxs, comp):
     tot = 0.0
     for l, S in enumerate(states):
