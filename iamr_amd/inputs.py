@@ -52,9 +52,7 @@ def read_grid_file(path, ref_ratio, slab=None):
             lo = [int(v) for v in m.group(1).split(",")]
             hi = [int(v) for v in m.group(2).split(",")]
             r = ref_ratio[l]
-            if len(lo) == 2:            # 2-D grid file of a 2-D run lifted onto a slab: (x, y) -> (x, slab, z), the whole slab thickness
-                if slab is None:
-                    raise ValueError(f"grid file {path}: two-dimensional boxes in a three-dimensional run")
+            if len(lo) == 2 and slab is not None:   # 2-D grid file of a 2-D run lifted onto a slab: (x, y) -> (x, slab, z), the whole thickness
                 ns_c = slab
                 for _ in range(l):
                     ns_c *= ref_ratio[_]
@@ -286,6 +284,8 @@ class Inputs:
                 if not os.path.isabs(gf) and self.files:
                     gf = os.path.join(os.path.dirname(os.path.abspath(self.files[0])), gf)
                 fine_boxes = read_grid_file(gf, rr, slab)[:max_level]
+                if any(len(lo) != 3 for lev in fine_boxes for lo, hi in lev):
+                    raise ValueError(f"grid file {gf}: two-dimensional boxes in a three-dimensional run")
                 if initial_only:
                     regrid = self.refinement_indicators(max_level)
                     if not regrid["rules"]:
