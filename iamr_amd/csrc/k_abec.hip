@@ -102,13 +102,17 @@ static GsrbBC make_gsrb_bc(const Geometry& g, const DomainBC* bcs, int nbc)
 // wavefront sweeps 128 consecutive cells of a row; phi(i+-1) and the b pairs are contiguous across
 // lanes.  b arrays have either ncomp comps or 1 (broadcast).
 // SHARE: several components on one shared 1-component coefficient set (eta form of the tensor operator)
-template <bool SHARE>
+// SIG: one component, the face coefficients recomputed from the cell-centred array they were made of (AbecCoef::sig; bxt = that array)
+struct BUni { double v[3]; };
+// BMODE 0: b arrays; 1 (SIG): recomputed from AbecCoef::sig; 2 (UNI): the constants of AbecCoef::bu
+template <bool SHARE, int BMODE = 0>
 __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap,
-    const FabD* __restrict__ cfmt, CfC1 cfc)
+    const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni())
 {
+    constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
     BoxD hb = b;
@@ -136,7 +140,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
         const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
         const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
         double b1xm = 0, b1xp = 0, b1ym = 0, b1yp = 0, b1zm = 0, b1zp = 0;
-        if (bnc == 1) {
+        if (UNI) { b1xm = b1xp = bu.v[0]; b1ym = b1yp = bu.v[1]; b1zm = b1zp = bu.v[2]; }
+        else if (bnc == 1) {
             b1xm = bX(i, j, k, 0); b1xp = bX(i + 1, j, k, 0); b1ym = bY(i, j, k, 0); b1yp = bY(i, j + 1, k, 0); b1zm = bZ(i, j, k, 0); b1zp = bZ(i, j, k + 1, 0);
         }
         const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
@@ -155,9 +160,10 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             }
             // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
             const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
-            const double bxm = (bnc == 1 ? b1xm : bX(i, j, k, n)) * sx, bxp = (bnc == 1 ? b1xp : bX(i + 1, j, k, n)) * sx;
-            const double bym = (bnc == 1 ? b1ym : bY(i, j, k, n)) * sy, byp = (bnc == 1 ? b1yp : bY(i, j + 1, k, n)) * sy;
-            const double bzm = (bnc == 1 ? b1zm : bZ(i, j, k, n)) * sz, bzp = (bnc == 1 ? b1zp : bZ(i, j, k + 1, n)) * sz;
+            const bool one = UNI || bnc == 1;
+            const double bxm = (one ? b1xm : bX(i, j, k, n)) * sx, bxp = (one ? b1xp : bX(i + 1, j, k, n)) * sx;
+            const double bym = (one ? b1ym : bY(i, j, k, n)) * sy, byp = (one ? b1yp : bY(i, j + 1, k, n)) * sy;
+            const double bzm = (one ? b1zm : bZ(i, j, k, n)) * sz, bzp = (one ? b1zp : bZ(i, j, k + 1, n)) * sz;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
             const double rho = dhx * (bxm * phi(im, j, k, n) + bxp * phi(ip, j, k, n))
@@ -193,9 +199,19 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
             // tens: b holds eta (1 comp) and the 4/3 of the normal component is applied here (x 1.0 otherwise: exact)
             const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
-            const double bxm = bX(i, j, k, nb) * sx, bxp = bX(i + 1, j, k, nb) * sx;
-            const double bym = bY(i, j, k, nb) * sy, byp = bY(i, j + 1, k, nb) * sy;
-            const double bzm = bZ(i, j, k, nb) * sz, bzp = bZ(i, j, k + 1, nb) * sz;
+            double bxm, bxp, bym, byp, bzm, bzp;
+            if (SIG) {                         // mac_bcoef's expression, lower cell first
+                const double s0 = bX(i, j, k, sig_comp);
+                bxm = sig_scale / (0.5 * (bX(i - 1, j, k, sig_comp) + s0)); bxp = sig_scale / (0.5 * (s0 + bX(i + 1, j, k, sig_comp)));
+                bym = sig_scale / (0.5 * (bX(i, j - 1, k, sig_comp) + s0)); byp = sig_scale / (0.5 * (s0 + bX(i, j + 1, k, sig_comp)));
+                bzm = sig_scale / (0.5 * (bX(i, j, k - 1, sig_comp) + s0)); bzp = sig_scale / (0.5 * (s0 + bX(i, j, k + 1, sig_comp)));
+            } else if (UNI) {
+                bxm = bxp = bu.v[0] * sx; bym = byp = bu.v[1] * sy; bzm = bzp = bu.v[2] * sz;
+            } else {
+                bxm = bX(i, j, k, nb) * sx; bxp = bX(i + 1, j, k, nb) * sx;
+                bym = bY(i, j, k, nb) * sy; byp = bY(i, j + 1, k, nb) * sy;
+                bzm = bZ(i, j, k, nb) * sz; bzp = bZ(i, j, k + 1, nb) * sz;
+            }
             const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
@@ -211,6 +227,9 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
         }
     }
 }
+
+// IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given
+static bool abec_sig_on() { return tune("ABEC_SIG", 1) != 0; }
 
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
                bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts)
@@ -231,12 +250,27 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
     // the scalar (MAC projection / scalar diffusion) colour pass over whole boxes can be timed in place (bench.py)
     const bool rec = phi.ncomp == 1 && !shell_only && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
-    if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
-        hipLaunchKernelGGL(k_abec_gsrb<true>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+    BUni bu;
+    for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
+    const bool uni = c.b_uniform && c.b[0]->ncomp == 1 && abec_sig_on();
+    if (phi.ncomp == 1 && c.sig && !c.tensor_eta && abec_sig_on())
+        hipLaunchKernelGGL((k_abec_gsrb<false, 1>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                           c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.sig->d_tab, c.sig->d_tab,
+                           c.alpha, dhx, dhy, dhz, redblack, omega, 1, 1, gb, shell_only ? 1 : 0, 0, wrap ? 1 : 0, cft, cfc, c.sig_comp, c.sig_scale);
+    else if (uni && phi.ncomp > 1)
+        hipLaunchKernelGGL((k_abec_gsrb<true, 2>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                           c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu);
+    else if (uni)
+        hipLaunchKernelGGL((k_abec_gsrb<false, 2>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+                           c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu);
+    else if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
+        hipLaunchKernelGGL((k_abec_gsrb<true, 0>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
                            c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
     else
-        hipLaunchKernelGGL(k_abec_gsrb<false>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
+        hipLaunchKernelGGL((k_abec_gsrb<false, 0>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
                            c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
@@ -422,11 +456,14 @@ __device__ __forceinline__ void norm_commit(double mx, unsigned long long* out)
 }
 __device__ __forceinline__ double norm_term(double v) { const double a = fabs(v); return a == a ? a : INFINITY; }
 
+template <int BMODE>
 __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ outt, const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
-    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc, int tens, unsigned long long* __restrict__ normout)
+    double alpha, double dhx, double dhy, double dhz, int ncomp, int bnc, int tens, unsigned long long* __restrict__ normout,
+    int sig_comp, double sig_scale, BUni bu)
 {
+    constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
     int i, j, k0, k1;
@@ -441,13 +478,30 @@ __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __r
         const int nb = bnc == 1 ? 0 : n;
         const double sx = (tens && n == 0) ? 4.0 / 3.0 : 1.0, sy = (tens && n == 1) ? 4.0 / 3.0 : 1.0, sz = (tens && n == 2) ? 4.0 / 3.0 : 1.0;
         double pm = phi(i, j, k0 - 1, n), p0 = phi(i, j, k0, n);
+        // SIG: the cell-centred values march with the planes; the z-face coefficient of plane k + 1 is the upper one of plane k
+        double sm = 0.0, s0 = 0.0, bzlo = 0.0;
+        if (SIG) { sm = bX(i, j, k0 - 1, sig_comp); s0 = bX(i, j, k0, sig_comp); bzlo = sig_scale / (0.5 * (sm + s0)); }
         for (int k = k0; k <= k1; ++k) {
             const double pp = phi(i, j, k + 1, n);
             const double ax = has_a ? alpha * A(i, j, k, 0) * p0 : 0.0;
+            double bxm, bxp, bym, byp, bzm, bzp;
+            if (SIG) {                         // mac_bcoef's expression, lower cell first
+                const double sp = bX(i, j, k + 1, sig_comp);
+                bxm = sig_scale / (0.5 * (bX(i - 1, j, k, sig_comp) + s0)); bxp = sig_scale / (0.5 * (s0 + bX(i + 1, j, k, sig_comp)));
+                bym = sig_scale / (0.5 * (bX(i, j - 1, k, sig_comp) + s0)); byp = sig_scale / (0.5 * (s0 + bX(i, j + 1, k, sig_comp)));
+                bzm = bzlo; bzp = sig_scale / (0.5 * (s0 + sp));
+                bzlo = bzp; sm = s0; s0 = sp;
+            } else if (UNI) {
+                bxm = bxp = bu.v[0] * sx; bym = byp = bu.v[1] * sy; bzm = bzp = bu.v[2] * sz;
+            } else {
+                bxm = bX(i, j, k, nb) * sx; bxp = bX(i + 1, j, k, nb) * sx;
+                bym = bY(i, j, k, nb) * sy; byp = bY(i, j + 1, k, nb) * sy;
+                bzm = bZ(i, j, k, nb) * sz; bzp = bZ(i, j, k + 1, nb) * sz;
+            }
             const double y = ax
-                - dhx * ((bX(i + 1, j, k, nb) * sx) * (phi(i + 1, j, k, n) - p0) - (bX(i, j, k, nb) * sx) * (p0 - phi(i - 1, j, k, n)))
-                - dhy * ((bY(i, j + 1, k, nb) * sy) * (phi(i, j + 1, k, n) - p0) - (bY(i, j, k, nb) * sy) * (p0 - phi(i, j - 1, k, n)))
-                - dhz * ((bZ(i, j, k + 1, nb) * sz) * (pp - p0) - (bZ(i, j, k, nb) * sz) * (p0 - pm));
+                - dhx * (bxp * (phi(i + 1, j, k, n) - p0) - bxm * (p0 - phi(i - 1, j, k, n)))
+                - dhy * (byp * (phi(i, j + 1, k, n) - p0) - bym * (p0 - phi(i, j - 1, k, n)))
+                - dhz * (bzp * (pp - p0) - bzm * (p0 - pm));
             const double o = has_rhs ? rhs(i, j, k, n) - y : y;
             out(i, j, k, n) = o;
             mx = fmax(mx, norm_term(o));
@@ -470,9 +524,20 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
         Tiling t = level_tiling(l, cell_type(), 0, 8);
         const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
         if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
-        hipLaunchKernelGGL(k_abec_residual, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
+        BUni bu;
+        for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
+        if (phi.ncomp == 1 && c.sig && !c.tensor && !c.tensor_eta && abec_sig_on())
+            hipLaunchKernelGGL(k_abec_residual<1>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
+                               rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.sig->d_tab, c.sig->d_tab,
+                               c.alpha, dhx, dhy, dhz, 1, 1, 0, norm_out ? d_norm : nullptr, c.sig_comp, c.sig_scale, bu);
+        else if (c.b_uniform && c.b[0]->ncomp == 1 && abec_sig_on())
+            hipLaunchKernelGGL(k_abec_residual<2>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
+                               rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
+                               c.alpha, dhx, dhy, dhz, phi.ncomp, 1, c.tensor_eta, (norm_out && !c.tensor) ? d_norm : nullptr, 0, 1.0, bu);
+        else
+        hipLaunchKernelGGL(k_abec_residual<0>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
                            rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta, (norm_out && !c.tensor) ? d_norm : nullptr);
+                           c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta, (norm_out && !c.tensor) ? d_norm : nullptr, 0, 1.0, bu);
         if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0, norm_out ? d_norm : nullptr);
     }
     if (norm_out) {
@@ -1144,6 +1209,33 @@ void mac_bcoef(MultiFab* const b[3], const MultiFab& rho, int rho_comp, double s
             bt[f](i, j, k, 0) = scale / rf;
         });
     }
+}
+
+// ---------------------------------------------------------------------------- uniform coefficient detection
+bool mf_uniform_value(const MultiFab& m, double* v)
+{
+    auto& ctx = Context::get();
+    static double* d_out = nullptr;                      // [0] flag (1: some entry differs from the first one), [1] the first entry
+    if (!d_out) IAMRX_HIP_CHECK(hipMalloc(&d_out, 2 * sizeof(double)));
+    double h[3] = {0.0, -1.e300, -1.e300};               // flag, max of the reference values, max of their negatives
+    if (m.nlocal() > 0) {
+        IAMRX_HIP_CHECK(hipMemsetAsync(d_out, 0, 2 * sizeof(double), ctx.stream));
+        const FabD* mt = m.d_tab;
+        const BoxD b0 = m.layout->lbox(0);
+        double* out = d_out;
+        for_each(*m.layout, m.type, 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const double ref = mt[0](b0.lo[0], b0.lo[1], b0.lo[2], 0);
+            if (f == 0 && i == b0.lo[0] && j == b0.lo[1] && k == b0.lo[2]) out[1] = ref;
+            if (!(mt[f](i, j, k, 0) == ref)) out[0] = 1.0;
+        });
+        double r[2];
+        IAMRX_HIP_CHECK(hipMemcpyAsync(r, d_out, sizeof(r), hipMemcpyDeviceToHost, ctx.stream));
+        ctx.sync();
+        h[0] = r[0]; h[1] = r[1]; h[2] = -r[1];
+    }
+    if (!m.layout->replicated && ctx.comm->nranks > 1) ctx.comm->allreduce(h, 3, ReduceOp::Max);
+    *v = h[1];
+    return h[0] == 0.0 && h[1] == -h[2] && h[1] > -1.e299;
 }
 
 }  // namespace iamrx

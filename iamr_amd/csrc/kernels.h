@@ -45,7 +45,19 @@ struct AbecCoef {
     const MultiFab* b[3];     // face, ncomp comps (or 1 comp broadcast if b_ncomp == 1)
     int tensor;               // add MLTensorOp cross terms in apply/residual
     int tensor_eta = 0;       // b[d] hold the 1-component face viscosity eta_d; the kernels apply b_d(comp) = eta_d * (comp == d ? 4/3 : 1)
+    // sig != null: b[d] was made by mac_bcoef(b, *sig, sig_comp, sig_scale) and the smoother / residual kernels may recompute the face
+    // value sig_scale / (0.5 (sig(cell - e_d) + sig(cell))) from the cell-centred array instead of reading three face arrays (the same
+    // expression, hence the same doubles; one array of HBM traffic instead of three).  sig has >= 1 ghost cell, filled.
+    const MultiFab* sig = nullptr;
+    int sig_comp = 0;
+    double sig_scale = 1.0;
+    // b_uniform: every entry of the one-component b[d] equals bu[d] (constant viscosity / diffusivity: mf_uniform_value found it so);
+    // the smoother and residual kernels use the constants instead of reading the three face arrays
+    int b_uniform = 0;
+    double bu[3] = {0.0, 0.0, 0.0};
 };
+// every valid entry of component 0 of m equals one value (on all ranks): returns true and the value
+bool mf_uniform_value(const MultiFab& m, double* v);
 struct DomainBC {             // linear-operator BC of the level's domain
     int lo[3], hi[3];         // LinOpBC per face
     int maxorder;

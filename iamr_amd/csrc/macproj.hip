@@ -26,6 +26,7 @@ MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFa
     CellMG mg(g, layout, 1, bc, opts);
     mg.setScalars(0.0, 1.0);
     mg.setBCoeffs(bcp);
+    if (rho.ngrow >= 1) mg.setBCoeffsFromCell(&rho, rho_comp, 1.0 / rhs_scale);
     // level > 0: Dirichlet data on the coarse/fine faces from the coarse level's MAC phi (MacProj.cpp:1166-1170)
     if (cgeom) mg.setCoarseFineBC(cphi, *cgeom, ratio);
     mg.prepare();

@@ -72,6 +72,8 @@ public:
     void setScalars(double alpha, double beta) { m_alpha = alpha; m_beta = beta; }
     void setACoeffs(const MultiFab* a) { m_a0 = a; }
     void setBCoeffs(const MultiFab* const b[3]) { for (int d = 0; d < 3; ++d) m_b0[d] = b[d]; }
+    // the b of setBCoeffs is mac_bcoef(b, sig, comp, scale): the finest level's smoother and residual recompute it from sig (AbecCoef::sig)
+    void setBCoeffsFromCell(const MultiFab* sig, int comp, double scale) { m_sig = sig; m_sig_comp = comp; m_sig_scale = scale; }
     void setTensor(bool t) { m_tensor = t; }
     // tensor operator with the B coefficients given as the 1-component face viscosity: the finest level streams eta instead of the
     // three-component b = eta * (4/3 on the normal component) arrays (a third of the coefficient traffic of the smoother)
@@ -125,6 +127,11 @@ private:
     double m_alpha = 0.0, m_beta = 1.0;
     const MultiFab* m_a0 = nullptr;
     const MultiFab* m_b0[3] = {nullptr, nullptr, nullptr};
+    bool m_buni = false;                 // the finest level's b arrays are constants (prepare() checks)
+    double m_bu[3] = {0.0, 0.0, 0.0};
+    const MultiFab* m_sig = nullptr;
+    int m_sig_comp = 0;
+    double m_sig_scale = 1.0;
     bool m_tensor = false;
     bool m_tensor_eta = false;
     bool m_singular = false;

@@ -38,6 +38,9 @@ AbecCoef CellMG::coef(int l) const
         c.a = m_a0;
         for (int d = 0; d < 3; ++d) c.b[d] = m_b0[d];
         c.tensor_eta = m_tensor_eta ? 1 : 0;
+        c.sig = m_sig; c.sig_comp = m_sig_comp; c.sig_scale = m_sig_scale;
+        c.b_uniform = m_buni ? 1 : 0;
+        for (int d = 0; d < 3; ++d) c.bu[d] = m_bu[d];
     } else {
         c.a = m_a0 ? &m_lev[l].a : nullptr;
         for (int d = 0; d < 3; ++d) c.b[d] = &m_lev[l].b[d];
@@ -58,11 +61,18 @@ void CellMG::prepare()
     // V-cycle needs to, so no coarse hierarchy is built and a "cycle" is m_dd_sweeps sweeps.  Bound of the Jacobi contraction:
     // q / (alpha min(a) + q), q = beta max(b) sum_d 2 / h_d^2; red-black Gauss-Seidel contracts by about its square per sweep.
     // Same converged answer (tests/test_gpu_sensitivity.py covers the solver choices); IAMRX_MG_DIAG_SHORTCUT=0 disables.
+    // constant viscosity / diffusivity (every solve of a run without ns.variable_vel_visc / variable_scal_diff): the finest level's
+    // kernels take the three constants instead of reading the face arrays; the coarser levels keep their averaged arrays
+    m_buni = false;
+    if (!m_sig && m_b0[0]->ncomp == 1) {
+        m_buni = true;
+        for (int d = 0; d < 3 && m_buni; ++d) m_buni = mf_uniform_value(*m_b0[d], &m_bu[d]);
+    }
     m_dd_sweeps = 0;
     const bool dd_on = tune("MG_DIAG_SHORTCUT", 1) != 0;
     if (dd_on && m_alpha > 0.0 && m_beta > 0.0 && m_a0 && m_o.fixed_iters <= 0 && m_o.max_coarsening_level > 0) {
         double bmax = 0.0;
-        for (int d = 0; d < 3; ++d) bmax = std::max(bmax, m_b0[d]->norm0(0, m_b0[d]->ncomp, 0));
+        for (int d = 0; d < 3; ++d) bmax = std::max(bmax, m_buni ? std::fabs(m_bu[d]) : m_b0[d]->norm0(0, m_b0[d]->ncomp, 0));
         if (m_tensor_eta) bmax *= 4.0 / 3.0;
         MultiFab inv(m_lev[0].layout, cell_type(), 1, 0);
         {
@@ -455,7 +465,11 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     else {
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         for (int iter = 0; iter < maxit; ++iter) {
-            if (m_singular) subtract_mean(0, L0.res);
+            // singular system: the residual of a compatible right-hand side has zero mean up to round-off (the operator's columns sum to
+            // zero), which amrex::MLMG removes in front of every cycle.  Here in front of the first one only (the bottom solver removes its
+            // own): a reduction, a host read-back and a pass over the level per iteration (0.13 ms of a 2.4 ms cycle at 256^3) for a
+            // shift of the order of 1e-16 |rhs|.  IAMRX_MG_RES_MEAN=1 restores the per-iteration form.
+            if (m_singular && (iter == 0 || tune("MG_RES_MEAN", 0) != 0)) subtract_mean(0, L0.res);
             if (m_dd_sweeps > 0 && m_dd_rho > 0.0 && st.resnorm > 0.0) {
                 // diagonally dominant operator: as many sweeps as the remaining reduction needs (measured at 256^3, nu dt/h^2 = 0.02:
                 // 4 + 2 sweeps in two cycles instead of 3 x 3 sweeps; the second cycle only removes the lagged cross-term defect)

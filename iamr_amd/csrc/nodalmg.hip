@@ -400,7 +400,8 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         std::vector<double> hist;
         for (int iter = 0; iter < maxit; ++iter) {
-            if (m_singular) { subtract_mean(0, L0.res); L0.res_filled = false; }
+            // see CellMG::solve: the mean of the residual of a singular system is removed in front of the first cycle only
+            if (m_singular && (iter == 0 || tune("MG_RES_MEAN", 0) != 0)) { subtract_mean(0, L0.res); L0.res_filled = false; }
             cycle_timer().mark(ctx.stream);
             vcycle(st);
             cycle_timer().mark(ctx.stream);
