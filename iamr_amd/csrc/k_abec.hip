@@ -228,6 +228,214 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     }
 }
 
+// ---------------------------------------------------------------------------- GSRB, one component, software-pipelined
+// The colour pass of the scalar solves (MAC projection, scalar diffusion) on levels without coarse/fine faces.  In k_abec_gsrb the
+// compiler cannot move the loads of plane k + 1 above the store of plane k (same array), so every thread pays one full memory
+// round trip per plane.  A colour pass has no such hazard -- the neighbours of a cell of the active colour have the other colour and
+// the cell itself is written by its own thread only -- so this kernel loads the operands of NP planes, then updates them: NP round
+// trips in flight per wavefront.  Same expressions as k_abec_gsrb (same doubles).
+template <int BMODE>
+struct Gs1Ops {
+    double pc, pxm, pxp, pym, pyp, pzm, pzp, r, a;
+    double c[BMODE == 2 ? 1 : (BMODE == 1 ? 7 : 6)];   // BMODE 0: the six face coefficients; 1: sigma at the cell and its six neighbours
+    int i;
+};
+template <int BMODE, int NP>
+__global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
+    const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
+    const FabD* __restrict__ cfmt, CfC1 cfc)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    BoxD hb = b;
+    hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
+    int ih, j, k0, k1;
+    if (!tile_ijk(t, hb, ih, j, k0, k1)) return;
+    const FabD phi = phit[fab], rhs = rhst[fab], bX = bxt[fab], bY = byt[fab], bZ = bzt[fab];
+    const bool has_a = (at != nullptr) && alpha != 0.0;
+    FabD A; if (has_a) A = at[fab];
+    // coarse/fine faces as in k_abec_gsrb (a ghost cell written by cf_maintain is not read in the same pass, see the top of the file)
+    const bool cf = cfmt != nullptr;
+    FabD cfm; if (cf) cfm = cfmt[fab];
+    const double c1x = cf ? cfc.c1[0][min(b.len(0) + 1, cfc.maxorder) - 2] : 0.0, c1y = cf ? cfc.c1[1][min(b.len(1) + 1, cfc.maxorder) - 2] : 0.0;
+    const double c1z = cf ? cfc.c1[2][min(b.len(2) + 1, cfc.maxorder) - 2] : 0.0;
+    const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
+    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[0][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[0][1] : 0.0;
+    auto load = [&](int k, Gs1Ops<BMODE>& o) {
+        const int i = b.lo[0] + 2 * (ih - b.lo[0]) + ((b.lo[0] + j + k + redblack) & 1);
+        o.i = i;
+        if (i > b.hi[0]) return;
+        const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
+        const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
+        o.pc = phi(i, j, k, 0);
+        o.pxm = phi(im, j, k, 0); o.pxp = phi(ip, j, k, 0);
+        o.pym = phi(i, jm, k, 0); o.pyp = phi(i, jp, k, 0);
+        o.pzm = phi(i, j, km, 0); o.pzp = phi(i, j, kp, 0);
+        o.r = rhs(i, j, k, 0);
+        o.a = has_a ? A(i, j, k, 0) : 0.0;
+        if (BMODE == 0) {
+            o.c[0] = bX(i, j, k, 0); o.c[1] = bX(i + 1, j, k, 0); o.c[2] = bY(i, j, k, 0); o.c[3] = bY(i, j + 1, k, 0);
+            o.c[4] = bZ(i, j, k, 0); o.c[5] = bZ(i, j, k + 1, 0);
+        } else if (BMODE == 1) {
+            o.c[0] = bX(i, j, k, sig_comp);
+            o.c[1] = bX(i - 1, j, k, sig_comp); o.c[2] = bX(i + 1, j, k, sig_comp);
+            o.c[3] = bX(i, j - 1, k, sig_comp); o.c[4] = bX(i, j + 1, k, sig_comp);
+            o.c[5] = bX(i, j, k - 1, sig_comp); o.c[6] = bX(i, j, k + 1, sig_comp);
+        }
+    };
+    auto update = [&](int k, const Gs1Ops<BMODE>& o) {
+        const int i = o.i;
+        if (i > b.hi[0]) return;
+        double bxm, bxp, bym, byp, bzm, bzp;
+        if (BMODE == 0) { bxm = o.c[0]; bxp = o.c[1]; bym = o.c[2]; byp = o.c[3]; bzm = o.c[4]; bzp = o.c[5]; }
+        else if (BMODE == 1) {                 // mac_bcoef's expression, lower cell first
+            const double s0 = o.c[0];
+            bxm = sig_scale / (0.5 * (o.c[1] + s0)); bxp = sig_scale / (0.5 * (s0 + o.c[2]));
+            bym = sig_scale / (0.5 * (o.c[3] + s0)); byp = sig_scale / (0.5 * (s0 + o.c[4]));
+            bzm = sig_scale / (0.5 * (o.c[5] + s0)); bzp = sig_scale / (0.5 * (s0 + o.c[6]));
+        } else { bxm = bxp = bu.v[0]; bym = byp = bu.v[1]; bzm = bzp = bu.v[2]; }
+        double cf0 = (i == bc.dlo[0]) ? bc.cflo[0][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[0][0] : 0.0;
+        double cf2 = (k == bc.dlo[2]) ? bc.cflo[0][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[0][2] : 0.0;
+        double c1 = cf1, c4 = cf4;
+        if (cf) {
+            if (i == b.lo[0] && cfm(i - 1, j, k) == 1.0) cf0 = c1x;
+            if (i == b.hi[0] && cfm(i + 1, j, k) == 1.0) cf3 = c1x;
+            if (j == b.lo[1] && cfm(i, j - 1, k) == 1.0) c1 = c1y;
+            if (j == b.hi[1] && cfm(i, j + 1, k) == 1.0) c4 = c1y;
+            if (k == b.lo[2] && cfm(i, j, k - 1) == 1.0) cf2 = c1z;
+            if (k == b.hi[2] && cfm(i, j, k + 1) == 1.0) cf5 = c1z;
+        }
+        const double aa = has_a ? alpha * o.a : 0.0;
+        const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+        const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * cf2 + bzp * cf5));
+        const double rho = dhx * (bxm * o.pxm + bxp * o.pxp) + dhy * (bym * o.pym + byp * o.pyp) + dhz * (bzm * o.pzm + bzp * o.pzp);
+        const double res = o.r - (gamma * o.pc - rho);
+        const double pn = o.pc + omega / g_m_d * res;
+        phi(i, j, k, 0) = pn;
+        if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
+            cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
+    };
+    for (int k = k0; k <= k1; k += NP) {
+        Gs1Ops<BMODE> ops[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) if (k + q <= k1) load(k + q, ops[q]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) if (k + q <= k1) update(k + q, ops[q]);
+    }
+}
+
+// ---------------------------------------------------------------------------- GSRB, one component, pair-marching
+// A thread owns the two cells (lo + 2m, lo + 2m + 1) of a row and marches in z.  In every plane one of the two has the active colour.
+// The row pairs of phi (and of sigma, BMODE 1) are read with one 16-byte load per plane -- every byte of every cache line it touches is
+// used -- and kept in registers for three planes, so the z-neighbours cost no loads and the x-neighbours come from the pair itself or
+// from the adjacent lane; only the y-neighbours and the right-hand side are 8-byte loads at the active cell.  7 load instructions per
+// updated cell instead of 15, less than half the L1 / L2 traffic (the colour passes of k_abec_gsrb1 ran at L2 rather than HBM speed:
+// every row was fetched for three planes and by three rows of threads).  No hazards: a colour pass only writes cells of its colour and
+// only reads, besides the cell itself, cells of the other one.  Same expressions as k_abec_gsrb (same doubles).
+// BMODE 1 (AbecCoef::sig) or 2 (AbecCoef::b_uniform).
+struct D2 { double l, r; };
+__device__ __forceinline__ D2 ld2(const FabD& f, int i, int j, int k, int n)
+{
+    typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
+    const v2u v = *(const __attribute__((address_space(1))) v2u*)(f.gp() + f.off(i, j, k) + f.cs * n);
+    D2 r; r.l = v.x; r.r = v.y;
+    return r;
+}
+template <int BMODE>
+__global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __restrict__ boxes,
+    const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ sgt,
+    double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
+    const FabD* __restrict__ cfmt, CfC1 cfc)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    BoxD hb = b;
+    hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
+    int ih, j, k0, k1;
+    if (!tile_ijk(t, hb, ih, j, k0, k1)) return;
+    const FabD phi = phit[fab], rhs = rhst[fab];
+    // coarse/fine faces as in k_abec_gsrb: the ghost formula's first-interior-cell weight, and the ghost cells kept current (cf_maintain)
+    const bool cf = cfmt != nullptr;
+    FabD cfm; if (cf) cfm = cfmt[fab];
+    const double c1x = cf ? cfc.c1[0][min(b.len(0) + 1, cfc.maxorder) - 2] : 0.0, c1y = cf ? cfc.c1[1][min(b.len(1) + 1, cfc.maxorder) - 2] : 0.0;
+    const double c1z = cf ? cfc.c1[2][min(b.len(2) + 1, cfc.maxorder) - 2] : 0.0;
+    FabD S; if (BMODE == 1) S = sgt[fab];
+    const bool has_a = (at != nullptr) && alpha != 0.0;
+    FabD A; if (has_a) A = at[fab];
+    const int bx = 1 << t.bxs, tx = (int)threadIdx.x & (bx - 1);
+    const int iL = b.lo[0] + 2 * (ih - b.lo[0]), iR = iL + 1;
+    // the neighbour lane of the row exists (same wavefront, same row, inside the box)?
+    const bool laneL = tx > 0 && iL > b.lo[0], laneR = tx < bx - 1 && tx < 63 && iR + 1 <= b.hi[0];
+    const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
+    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[0][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[0][1] : 0.0;
+    auto kw = [&](int k) { return wrap ? (k < b.lo[2] ? b.hi[2] : (k > b.hi[2] ? b.lo[2] : k)) : k; };
+    D2 pb = ld2(phi, iL, j, kw(k0 - 1), 0), pc = ld2(phi, iL, j, k0, 0);
+    D2 sb, sc;
+    if (BMODE == 1) { sb = ld2(S, iL, j, k0 - 1, sig_comp); sc = ld2(S, iL, j, k0, sig_comp); }
+    for (int k = k0; k <= k1; ++k) {
+        const int par = (b.lo[0] + j + k + redblack) & 1;         // 0: the left cell of the pair is active
+        const int i = iL + par;
+        const bool live = i <= b.hi[0];
+        const D2 pa = ld2(phi, iL, j, kw(k + 1), 0);
+        D2 sa;
+        if (BMODE == 1) sa = ld2(S, iL, j, k + 1, sig_comp);
+        // x-neighbours: the other cell of the pair, and the adjacent lane's near cell (or a load where there is no such lane)
+        const double fromL = __shfl_up(pc.r, 1, 64), fromR = __shfl_down(pc.l, 1, 64);
+        double pxm, pxp;
+        if (par == 0) {
+            pxp = (wrap && i == b.hi[0]) ? (double)phi(b.lo[0], j, k, 0) : pc.r;
+            pxm = laneL ? fromL : (double)phi((wrap && i == b.lo[0]) ? b.hi[0] : i - 1, j, k, 0);
+        } else {
+            pxm = pc.l;
+            pxp = laneR ? fromR : (live ? (double)phi((wrap && i == b.hi[0]) ? b.lo[0] : i + 1, j, k, 0) : 0.0);
+        }
+        double sxm = 0.0, sxp = 0.0, sym = 0.0, syp = 0.0;
+        if (BMODE == 1) {
+            const double sfl = __shfl_up(sc.r, 1, 64), sfr = __shfl_down(sc.l, 1, 64);
+            if (par == 0) { sxp = sc.r; sxm = laneL ? sfl : (double)S(i - 1, j, k, sig_comp); }
+            else { sxm = sc.l; sxp = laneR ? sfr : (live ? (double)S(i + 1, j, k, sig_comp) : 0.0); }
+        }
+        if (live) {
+            const double p0 = par ? pc.r : pc.l;
+            const double pym = phi(i, jm, k, 0), pyp = phi(i, jp, k, 0);
+            const double pzm = par ? pb.r : pb.l, pzp = par ? pa.r : pa.l;
+            const double rr = rhs(i, j, k, 0);
+            double bxm, bxp, bym, byp, bzm, bzp;
+            if (BMODE == 1) {                  // mac_bcoef's expression, lower cell first
+                sym = S(i, j - 1, k, sig_comp); syp = S(i, j + 1, k, sig_comp);
+                const double s0 = par ? sc.r : sc.l, szm = par ? sb.r : sb.l, szp = par ? sa.r : sa.l;
+                bxm = sig_scale / (0.5 * (sxm + s0)); bxp = sig_scale / (0.5 * (s0 + sxp));
+                bym = sig_scale / (0.5 * (sym + s0)); byp = sig_scale / (0.5 * (s0 + syp));
+                bzm = sig_scale / (0.5 * (szm + s0)); bzp = sig_scale / (0.5 * (s0 + szp));
+            } else { bxm = bxp = bu.v[0]; bym = byp = bu.v[1]; bzm = bzp = bu.v[2]; }
+            double cf0 = (i == bc.dlo[0]) ? bc.cflo[0][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[0][0] : 0.0;
+            double cf2 = (k == bc.dlo[2]) ? bc.cflo[0][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[0][2] : 0.0;
+            double c1 = cf1, c4 = cf4;
+            if (cf) {
+                if (i == b.lo[0] && cfm(i - 1, j, k) == 1.0) cf0 = c1x;
+                if (i == b.hi[0] && cfm(i + 1, j, k) == 1.0) cf3 = c1x;
+                if (j == b.lo[1] && cfm(i, j - 1, k) == 1.0) c1 = c1y;
+                if (j == b.hi[1] && cfm(i, j + 1, k) == 1.0) c4 = c1y;
+                if (k == b.lo[2] && cfm(i, j, k - 1) == 1.0) cf2 = c1z;
+                if (k == b.hi[2] && cfm(i, j, k + 1) == 1.0) cf5 = c1z;
+            }
+            const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
+            const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+            const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * cf2 + bzp * cf5));
+            const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
+            const double res = rr - (gamma * p0 - rho);
+            const double pn = p0 + omega / g_m_d * res;
+            phi(i, j, k, 0) = pn;
+            if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
+                cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
+        }
+        pb = pc; pc = pa;
+        if (BMODE == 1) { sb = sc; sc = sa; }
+    }
+}
+
 // IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given
 static bool abec_sig_on() { return tune("ABEC_SIG", 1) != 0; }
 
@@ -253,7 +461,32 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     BUni bu;
     for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
     const bool uni = c.b_uniform && c.b[0]->ncomp == 1 && abec_sig_on();
-    if (phi.ncomp == 1 && c.sig && !c.tensor_eta && abec_sig_on())
+    // IAMRX_GSRB1_NP (2): planes in flight per thread of the pipelined one-component pass (0: the general kernel)
+    const int np = (int)tune("GSRB1_NP", 2);
+    const int mode = (c.sig && abec_sig_on()) ? 1 : (uni ? 2 : 0);
+    const bool pair_ok = mode != 0 && tune("GSRB2", 1) != 0 && phi.ngrow >= 1 && (mode == 2 || c.sig->ngrow >= 1);
+    // with coarse/fine faces the pipelined form would read a ghost cell that cf_maintain rewrote for the plane before: one plane in flight
+    if (np > 0 && phi.ncomp == 1 && !shell_only && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta) {
+        const FabD *t0 = mode == 1 ? c.sig->d_tab : c.b[0]->d_tab, *t1 = mode == 1 ? c.sig->d_tab : c.b[1]->d_tab, *t2 = mode == 1 ? c.sig->d_tab : c.b[2]->d_tab;
+#define IAMRX_GS1(M, N) hipLaunchKernelGGL((k_abec_gsrb1<M, N>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab, \
+                           c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc)
+        // IAMRX_GSRB2 (1): the pair-marching kernel where the coefficients are not arrays (needs a ghost layer for its 16-byte loads)
+        if (pair_ok) {
+            int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
+            Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
+            if (mode == 1)
+                hipLaunchKernelGGL((k_abec_gsrb2<1>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
+                                   c.sig->d_tab, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc);
+            else
+                hipLaunchKernelGGL((k_abec_gsrb2<2>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
+                                   nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bu, cft, cfc);
+        }
+        else if (np >= 4 && !cft) { if (mode == 1) IAMRX_GS1(1, 4); else if (mode == 2) IAMRX_GS1(2, 4); else IAMRX_GS1(0, 4); }
+        else if (np >= 2 && !cft) { if (mode == 1) IAMRX_GS1(1, 2); else if (mode == 2) IAMRX_GS1(2, 2); else IAMRX_GS1(0, 2); }
+        else { if (mode == 1) IAMRX_GS1(1, 1); else if (mode == 2) IAMRX_GS1(2, 1); else IAMRX_GS1(0, 1); }
+#undef IAMRX_GS1
+    }
+    else if (phi.ncomp == 1 && c.sig && !c.tensor_eta && abec_sig_on())
         hipLaunchKernelGGL((k_abec_gsrb<false, 1>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.sig->d_tab, c.sig->d_tab,
                            c.alpha, dhx, dhy, dhz, redblack, omega, 1, 1, gb, shell_only ? 1 : 0, 0, wrap ? 1 : 0, cft, cfc, c.sig_comp, c.sig_scale);

@@ -277,6 +277,10 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
     int roff[4], doff[4]; // offsets of that node in plane 0 of the right-hand side / the Dirichlet mask
     double rr[4];
     bool fixed[4];        // MASK: the node of this thread in pass c is a Dirichlet node (keeps its value)
+    // A node strictly inside the box has its eight cells in the box: it is never a Dirichlet node (nodal_build_dmask marks nodes with a
+    // cell outside the level, and domain faces).  The mask is read only for nodes on the box surface or in the ghost region -- a few
+    // per cent of them -- instead of 8 bytes for every node of every pass.
+    bool surf[4];
     const int rks = r.n[0] * r.n[1];
     int dks = 0;
     if constexpr (MASK) dks = dmt[fab].n[0] * dmt[fab].n[1];
@@ -298,8 +302,9 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
         rr[c] = r.gp()[roff[c] + (long)(k0 - r.lo[2]) * rks];
         if constexpr (MASK) {
             doff[c] = (int)dmt[fab].off(ri, rj, dmt[fab].lo[2]);
-            fixed[c] = dmt[fab].gp()[doff[c] + (long)(k0 - dmt[fab].lo[2]) * dks] != 0.0;
-        } else { doff[c] = 0; fixed[c] = false; }
+            surf[c] = ri <= cb.lo[0] || ri >= nhi0 || rj <= cb.lo[1] || rj >= nhi1;
+            fixed[c] = (surf[c] || k0 <= cb.lo[2] || k0 >= nhi2) ? dmt[fab].gp()[doff[c] + (long)(k0 - dmt[fab].lo[2]) * dks] != 0.0 : false;
+        } else { doff[c] = 0; fixed[c] = false; surf[c] = false; }
     }
     // footprint point of this thread in staging round `it`: array offsets (indices clamped into the arrays instead of predicated --
     // footprint points beyond the ghost width are never used by the colour passes) and LDS slot.  32-bit offsets: the launcher
@@ -371,7 +376,9 @@ __global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 rrn[c] = pr[roff[c]];
-                if constexpr (MASK) fixedn[c] = dmt[fab].gp()[doff[c] + (long)(k + 2 - dmt[fab].lo[2]) * dks] != 0.0; else fixedn[c] = false;
+                if constexpr (MASK)
+                    fixedn[c] = (surf[c] || k + 2 <= cb.lo[2] || k + 2 >= nhi2) ? dmt[fab].gp()[doff[c] + (long)(k + 2 - dmt[fab].lo[2]) * dks] != 0.0 : false;
+                else fixedn[c] = false;
             }
         }
         __syncthreads();

@@ -5,6 +5,7 @@
 // :858-923 (implicit solve); SURVEY a10, a11.
 #include "kernels.h"
 #include "launch.h"
+#include <type_traits>
 #include <vector>
 #include <cstdlib>
 #include <algorithm>
@@ -13,8 +14,13 @@ namespace iamrx {
 
 // cross flux on the d-face (i,j,k) for component n.  eta_n = b_d(comp d) * 3/4 (normal), eta_t = b_d(comp != d)
 // ETA1: eta holds the 1-component face viscosity (b_d(comp) is formed here exactly as tensor_bcoef stores it)
-template <int D, bool ETA1, class VA>
-__device__ __forceinline__ void cross_flux(const VA& v, const FabD& eta, int i, int j, int k, double dxi, double dyi, double dzi, double f[3])
+// the face viscosity of a constant-viscosity operator (AbecCoef::b_uniform) in the place of its array
+struct ConstEta {
+    double v;
+    __device__ __forceinline__ double operator()(int, int, int, int) const { return v; }
+};
+template <int D, bool ETA1, class VA, class EA>
+__device__ __forceinline__ void cross_flux(const VA& v, const EA& eta, int i, int j, int k, double dxi, double dyi, double dzi, double f[3])
 {
     constexpr double twoThirds = 2.0 / 3.0;
     const double e1 = ETA1 ? eta(i, j, k, 0) : 0.0;
@@ -115,10 +121,13 @@ struct LdsVel {
     }
 };
 
-template <bool ETA1, int TX, int TY>
+struct EtaUni { double v[3]; };
+// UNI (with ETA1): the three face viscosities are the constants eu (the arrays are not read)
+template <bool ETA1, int TX, int TY, bool UNI = false>
 __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ outt,
     const FabD* __restrict__ vt, const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
-    double dxi, double dyi, double dzi, double sbeta, unsigned long long* __restrict__ normout, int ntx, int nty, int nkc, int kcs, int xcd_cnt)
+    double dxi, double dyi, double dzi, double sbeta, unsigned long long* __restrict__ normout, int ntx, int nty, int nkc, int kcs, int xcd_cnt,
+    EtaUni eu = EtaUni())
 {
     constexpr int NT = TX * TY, W = TX + 2, H = TY + 2, PS = W * H;
     __shared__ double V[3][3 * PS];
@@ -139,7 +148,11 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
     const int tid = threadIdx.x;
     const int i = tx0 + tid % TX, j = ty0 + tid / TX;
     const bool on = i <= b.hi[0] && j <= b.hi[1];
-    const FabD out = outt[fab], v = vt[fab], ex = ext[fab], ey = eyt[fab], ez = ezt[fab];
+    const FabD out = outt[fab], v = vt[fab];
+    using EA = typename std::conditional<UNI, ConstEta, FabD>::type;
+    EA ex, ey, ez;
+    if constexpr (UNI) { ex.v = eu.v[0]; ey.v = eu.v[1]; ez.v = eu.v[2]; }
+    else { ex = ext[fab]; ey = eyt[fab]; ez = ezt[fab]; }
     const int vhx = min(tx0 + TX, b.hi[0] + 1), vhy = min(ty0 + TY, b.hi[1] + 1);      // last staged column / row (ghost included)
     auto stage = [&](int k) {
         double* dst = V[((k % 3) + 3) % 3];
@@ -203,7 +216,13 @@ void tensor_cross_terms_sub(const Geometry& g, const AbecCoef& c, MultiFab& out,
         dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal());
 #define IAMRX_TCZ(E) hipLaunchKernelGGL((k_tensor_cross_zm<E, TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, out.d_tab, vel.d_tab, \
                        c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta, normout, ntx, nty, nkc, kcs, xcd_cnt)
-        if (c.tensor_eta) IAMRX_TCZ(true); else IAMRX_TCZ(false);
+        if (c.tensor_eta && c.b_uniform && tune("ABEC_SIG", 1) != 0) {
+            EtaUni eu;
+            for (int d = 0; d < 3; ++d) eu.v[d] = c.bu[d];
+            hipLaunchKernelGGL((k_tensor_cross_zm<true, TX, TY, true>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, out.d_tab, vel.d_tab,
+                               c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], sign * c.beta, normout, ntx, nty, nkc, kcs,
+                               xcd_cnt, eu);
+        } else if (c.tensor_eta) IAMRX_TCZ(true); else IAMRX_TCZ(false);
 #undef IAMRX_TCZ
         return;
     }
