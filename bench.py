@@ -469,17 +469,24 @@ def main():
 
         gsrb_iso = kr.get("abec_gsrb_sweep")
         if gsrb_iso:
-            alg = 40.0 * cells                       # one colour pass, variable b: phi 1, rhs 1/2, b 3 reads, phi 1/2 write = 40 B/cell
+            # one colour pass of the MAC solve's smoother.  achieved / frac use SURVEY 8d's figure for the operation (GSRB sweep 80 B/cell = 40 per
+            # colour pass: phi 1, rhs 1/2, three face-coefficient arrays, phi 1/2 written), as the contract prescribes.  Since round 3 the kernel
+            # recomputes the face coefficients from the cell-centred density (AbecCoef::sig) and moves less than that: its own compulsory traffic is
+            # phi (1 + 1/2), rhs (1/2), density (1) = 24 B/cell, reported beside it (own_minimum_*); `traffic` (PMC) is to be read against that.
+            alg = 40.0 * cells
+            own = 24.0 * cells
             ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
             gbps = alg / ms / 1e6
-            roofline = {"kernel": "k_abec_gsrb<false> (one red or black pass of the cell-centred GSRB smoother, variable b; the dominant kernel of the "
-                                  "step, profiles/round3_kernel_stats.csv)", "bound": "hbm",
+            roofline = {"kernel": "k_abec_gsrb2<1> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
+                                  "face coefficients recomputed from the cell-centred density; the dominant kernel of the step, "
+                                  "profiles/round3_kernel_stats.csv)", "bound": "hbm",
                         "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                        "traffic": pmc_traffic("k_abec_gsrb<false> grid=%d" % (n ** 3 // 16)),
+                        "traffic": pmc_traffic("k_abec_gsrb2<1> grid=%d" % (n ** 3 // 64)),
                         "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
+                        "own_minimum_bytes_per_launch": own, "own_minimum_GBps": own / ms / 1e6, "frac_own_minimum": own / ms / 1e6 / 8000.0,
                         "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
                         "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
-                        "isolated_loop_ms": gsrb_iso["ms"] / 2}
+                        "isolated_loop_ms_array_coefficients": gsrb_iso["ms"] / 2}
         dom = kr.get("nodal_gs4_launch")
         roofline_gs4 = None
         if dom:
