@@ -50,3 +50,81 @@ def test_converged_answers_do_not_depend_on_unpinned_solver_choices(gpu, boxes):
         assert np.abs(S - S0).max() <= 1e-9, (name, np.abs(S - S0).max())
         assert np.abs(G - G0).max() <= 1e-7 * max(1.0, np.abs(G0).max()), (name, np.abs(G - G0).max())
         assert np.abs(P - P0).max() <= 1e-7 * max(1.0, np.abs(P0).max()), (name, np.abs(P - P0).max())
+
+
+KERNEL_FORMS = {
+    # the finest-level smoother / residual read the stored face coefficients (rounds 1-2) instead of recomputing them from the
+    # cell-centred density (MAC) or taking the three constants of a constant-viscosity operator
+    "face coefficient arrays": {"ABEC_SIG": 0},
+    # the general colour kernel instead of the lean (k_abec_gsrb1) and pair-marching (k_abec_gsrb2) ones
+    "general colour kernel": {"GSRB2": 0, "GSRB1_NP": 0},
+    "lean kernel, one plane in flight": {"GSRB2": 0, "GSRB1_NP": 1},
+    "lean kernel, four planes in flight": {"GSRB2": 0, "GSRB1_NP": 4},
+    "pair-marching, 4 planes per thread": {"GSRB2_TZ": 4},
+}
+
+
+@pytest.mark.parametrize("case", ["periodic_boxes", "channel_walls"])
+def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, case):
+    """Round 3 replaced the kernels of the cell-centred multigrid's finest level by forms that read less (coefficients recomputed from the
+    cell-centred density or taken as constants, pair-marching colour pass); each keeps the expressions of the kernel it replaces, so a run
+    under any of them is the same run bit for bit -- states, pressure, time steps.  Removing the residual mean of a singular system in
+    front of every cycle (upstream) instead of the first one only changes round-off."""
+    lib = gpu
+    from iamr_amd import ns as N
+
+    def run():
+        if case == "periodic_boxes":           # variable density, viscous, diffusive tracer; 8 boxes (ghost exchanges between the colour passes)
+            n = (32, 16, 16)
+            g = lib.Geom.make(n, prob_hi=(2.0, 1.0, 1.0))
+            lay = lib.Layout.decompose(n, 16)
+            ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.5, visc_coef=2e-2, tracer_diff_coef=1e-2, init_iter=1))
+            ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+            m = ns.data(N.NavierStokes.S_NEW)
+            G = np.zeros(tuple(v + 2 for v in n) + (5,), order="F")
+            G[1:-1, 1:-1, 1:-1] = m.gather_valid(n)
+            x = (np.arange(n[0]) + 0.5) / n[0]
+            G[1:-1, 1:-1, 1:-1, 3] = 1.0 + 0.3 * np.sin(2 * np.pi * x)[:, None, None]
+            m.set_from_global(G, (-1, -1, -1))
+            ns.set_data(N.NavierStokes.S_NEW, m)
+        else:                                   # inflow / outflow in x, no-slip walls in y, slip in z: Dirichlet and Neumann faces, odd box
+            n = (24, 12, 8)                     # lengths on the coarser multigrid levels
+            g = lib.Geom.make(n, prob_hi=(2.0, 1.0, 0.5), periodic=(0, 0, 0))
+            lay = lib.Layout.single(n)
+            wl = [0.0] * 9
+            wl[0] = 1.0
+            sl = [0.0] * 12
+            sl[0] = 1.0
+            ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.5, visc_coef=0.05, init_iter=1, init_shrink=0.3, phys_lo=[1, 5, 4], phys_hi=[2, 5, 4],
+                                                    wall_vel_lo=wl, scal_bc_lo=sl))
+            ns.init_rest(1.0)
+            m = lib.MultiFab(lay, lib.CELL, 5, 1)
+            G = np.zeros(tuple(v + 2 for v in n) + (5,), order="F")
+            G[1:-1, 1:-1, 1:-1, 0] = 1.0
+            G[1:-1, 1:-1, 1:-1, 3] = 1.0
+            m.set_from_global(G, (-1, -1, -1))
+            ns.set_data(N.NavierStokes.S_NEW, m)
+        ns.post_init(-1.0)
+        dts = [ns.step() for _ in range(2)]
+        return dts, ns.data(N.NavierStokes.S_NEW).gather_valid(n), ns.data(N.NavierStokes.P_NEW).gather_valid(n)[..., 0]
+
+    dts0, S0, P0 = run()
+    for name, keys in KERNEL_FORMS.items():
+        old = {k: lib.tuning_get(k, -1.0) for k in keys}
+        try:
+            for k, v in keys.items():
+                lib.tuning_set(k, v)
+            dts, S, P = run()
+        finally:
+            for k, v in old.items():
+                lib.tuning_set(k, {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 2, "GSRB2_TZ": 32}[k] if v < 0 else v)
+        assert dts == dts0, name
+        assert np.array_equal(S, S0), (name, np.abs(S - S0).max())
+        assert np.array_equal(P, P0), (name, np.abs(P - P0).max())
+    lib.tuning_set("MG_RES_MEAN", 1)
+    try:
+        dts, S, P = run()
+    finally:
+        lib.tuning_set("MG_RES_MEAN", 0)
+    assert np.allclose(dts, dts0, rtol=1e-9, atol=0.0)
+    assert np.abs(S - S0).max() <= 1e-9
