@@ -795,6 +795,13 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
 }
 
 // overwrite one of the level's arrays (same selectors as iamrx_ns_data) with src: problem set-up from caller data
+int iamrx_ns_derive(iamrx_ns ns, const char* name, iamrx_mf out, int ocomp)
+{
+    IAMRX_TRY
+    ns->ns->derive(name, out->mf, ocomp);
+    IAMRX_CATCH
+}
+
 int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
 {
     IAMRX_TRY

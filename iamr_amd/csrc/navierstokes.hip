@@ -243,6 +243,32 @@ void NavierStokes::swap_time_levels(double dt_)      // StateData::swapTimeLevel
 // FillPatch: copy the valid data, same-level + periodic ghost fill, then the physical-BC fill
 // (StateDataPhysBCFunct: FilccCell rules + the ext_dir functors of NS_bcfill.H).  On a refined level: FillPatchTwoLevels with the
 // coarse level's data interpolated in time (amr.hip); src must be the level's old or new State_Type data.
+void NavierStokes::derive(const std::string& name, MultiFab& out, int ocomp)
+{
+    IAMRX_ASSERT(out.type.cell() && out.layout->id == layout->id && ocomp < out.ncomp);
+    auto& ctx = Context::get();
+    const FabD* ot = out.d_tab;
+    if (name == "energy") {                                    // derkeng, NS_derive.cpp:266-295
+        const FabD* st = S[inew].d_tab;
+        for_each(*layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const FabD s = st[f];
+            const double vx = s(i, j, k, Xvel), vy = s(i, j, k, Yvel), vz = s(i, j, k, Zvel);
+            ot[f](i, j, k, ocomp) = 0.5 * s(i, j, k, Density) * (vx * vx + vy * vy + vz * vz);
+        });
+    } else if (name == "mag_vort") {                           // dermgvort on FillPatched velocities (grow_box_by_two upstream; the stencil reads one cell)
+        MultiFab vel(layout, cell_type(), 3, 1);
+        fillpatch(vel, S[inew], Xvel, 3, bc_vel);
+        derive_mag_vort(g, out, ocomp, vel, 0);
+    } else if (name == "avg_pressure") {                       // deravgpres, NS_derive.cpp:51-80
+        const FabD* pt = P[pnew].d_tab;
+        for_each(*layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+            const FabD p = pt[f];
+            ot[f](i, j, k, ocomp) = 0.125 * (p(i + 1, j, k) + p(i, j, k) + p(i + 1, j + 1, k) + p(i, j + 1, k)
+                                           + p(i + 1, j, k + 1) + p(i, j, k + 1) + p(i + 1, j + 1, k + 1) + p(i, j + 1, k + 1));
+        });
+    } else throw Error("NavierStokes::derive: unknown derived quantity '" + name + "' (energy, mag_vort, avg_pressure)");
+}
+
 void NavierStokes::fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc)
 {
     const bool is_vel = (bc == bc_vel);

@@ -1,6 +1,7 @@
 // iamr_amd/csrc/operators.h -- host-side operator layer keeping IAMR's operator API surface
 // (MacProj / Projection / Diffusion / NavierStokesBase::advance), SURVEY 8(b).
 #pragma once
+#include <string>
 #include "mf.h"
 #include "mlmg.h"
 #include "kernels.h"
@@ -243,6 +244,9 @@ public:
     double advance(double dt) { return advance(dt, 1, 1); }
     double advance(double dt, int iteration, int ncycle);   // NavierStokes::advance(time, dt, iteration, ncycle); returns the dt estimate
     double estTimeStep();                      // NavierStokesBase::estTimeStep
+    // derived quantities of the plotfile (derive_lst of NS_setup.cpp:436-449): "energy" = rho |u|^2 / 2 (derkeng), "mag_vort" = |curl u|
+    // (dermgvort, ghost cells by FillPatch), "avg_pressure" = mean of the 8 nodes of the cell (deravgpres); new-time data; out: cell, >= 1 comp
+    void derive(const std::string& name, MultiFab& out, int ocomp = 0);
     MultiFab& get_new_data(int type) { return type == 0 ? S[inew] : (type == 1 ? P[pnew] : Gp[pnew]); }
     MultiFab& get_old_data(int type) { return type == 0 ? S[1 - inew] : (type == 1 ? P[1 - pnew] : Gp[1 - pnew]); }
     MultiFab& umac(int d) { return u_mac[d]; }

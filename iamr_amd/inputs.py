@@ -23,7 +23,7 @@ _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.v
                  "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
                  "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.refinement_indicators", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
                  "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
-                 "amr.plot_vars", "amr.derive_plot_vars", "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
+                 "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
                  "ns.do_sync_proj")
 _IGNORED_NAMESPACES = ("mg.", "fab.", "fabarray.", "amrex.", "amr.refinement_indicators")
 # boundary values of the second tracer: read by upstream only with ns.do_trac2 = 1 (which raises here), unused otherwise
@@ -51,6 +51,8 @@ def read_grid_file(path, ref_ratio, slab=None):
                 raise ValueError(f"grid file {path}: cannot parse box {lines[q - 1]!r}")
             lo = [int(v) for v in m.group(1).split(",")]
             hi = [int(v) for v in m.group(2).split(",")]
+            if l >= len(ref_ratio):          # deeper than amr.max_level: read and dropped (Amr::readProbinFile: in_finest = min(in_finest, max_level))
+                continue
             r = ref_ratio[l]
             if len(lo) == 2 and slab is not None:   # 2-D grid file of a 2-D run lifted onto a slab: (x, y) -> (x, slab, z), the whole thickness
                 ns_c = slab
@@ -58,7 +60,8 @@ def read_grid_file(path, ref_ratio, slab=None):
                     ns_c *= ref_ratio[_]
                 lo, hi = [lo[0], 0, lo[1]], [hi[0], ns_c - 1, hi[1]]
             boxes.append((tuple(v * r for v in lo), tuple((v + 1) * r - 1 for v in hi)))
-        out.append(boxes)
+        if l < len(ref_ratio):
+            out.append(boxes)
     return out
 
 
@@ -121,6 +124,13 @@ class Inputs:
         if v.lower() in ("false", "f"):
             return 0
         return int(v)
+
+    def name_list(self, k, default):
+        """amr.plot_vars / amr.derive_plot_vars (Amr::initPltAndChk): ALL, NONE or a list of names; absent: `default`"""
+        v = list(self._get(k)) if k in self.table else [default]
+        if len(v) == 1 and v[0] in ("ALL", "NONE"):
+            return v[0]
+        return v
 
     def string(self, k, default=None):
         if k not in self.table:
@@ -382,7 +392,8 @@ class Inputs:
             prob["dim"] = 2
         out = dict(n=n, prob_lo=prob_lo, prob_hi=prob_hi, periodic=per, max_grid_size=mgs, params=p, prob=prob, slab=slab,
                    max_step=self.integer("max_step", -1), stop_time=self.real("stop_time", -1.0),
-                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level,
+                   plot_int=self.integer("amr.plot_int", -1), plot_file=self.string("amr.plot_file", "plt"), plot_vars=self.name_list("amr.plot_vars", "ALL"),
+                   derive_plot_vars=self.name_list("amr.derive_plot_vars", "NONE"), fine_boxes=fine_boxes, regrid=regrid, max_level=max_level,
                    check_int=self.integer("amr.check_int", -1), check_file=self.string("amr.check_file", "chk"),
                    restart=self.string("amr.restart", "") if self.has("amr.restart") else "")
         for k, dflt in _UNIMPLEMENTED_UNLESS.items():

@@ -186,6 +186,13 @@ class NavierStokes:
             nc = self.nalloc if which in (0, 1) else self.nstate
         return MultiFab(self.layout, typ, nc, ng, _handle=h, _owned=True)
 
+    def derive(self, name):
+        """derived quantity of the plotfile ("energy", "mag_vort", "avg_pressure": NavierStokes::derive) as a one-component cell MultiFab"""
+        from .lib import MultiFab, CELL
+        out = MultiFab(self.layout, CELL, 1, 0)
+        check(lib().iamrx_ns_derive(self.h, name.encode(), out.h, 0))
+        return out
+
     @property
     def nstate(self):
         """NUM_STATE (NavierStokes.cpp:43-48): u v w density tracer [tracer2] [temp]"""

@@ -200,6 +200,34 @@ def state_names(do_trac2=0, do_temp=0):
     return STATE_NAMES_3D + (["tracer2"] if do_trac2 else []) + (["temp", "divu", "dsdt"] if do_temp else [])
 
 
+DERIVE_NAMES = ["energy", "mag_vort", "avg_pressure"]          # derive_lst order (NS_setup.cpp:436-449; no particles, no time averages)
+
+
+def plot_selection(state, plot_vars="ALL", derive_plot_vars="NONE"):
+    """(indices of the state components, names of the derived quantities) a plotfile holds: amr.plot_vars picks state variables (ALL: every
+    one), amr.derive_plot_vars derived ones (ALL: the derive list in its order; default NONE) -- Amr::initPltAndChk / fillDerivePlotVarList.
+    Unknown names raise, as amrex::Amr aborts on them."""
+    if plot_vars == "ALL":
+        keep = list(range(len(state)))
+    elif plot_vars == "NONE":
+        keep = []
+    else:
+        bad = [v for v in plot_vars if v not in state]
+        if bad:
+            raise ValueError(f"amr.plot_vars: not state variables: {bad} (have {state})")
+        keep = [q for q, nm in enumerate(state) if nm in plot_vars]           # plotfile order = state order (Amr::statePlotVars is a list filled in descriptor order)
+    if derive_plot_vars == "ALL":
+        der = list(DERIVE_NAMES)
+    elif derive_plot_vars == "NONE":
+        der = []
+    else:
+        bad = [v for v in derive_plot_vars if v not in DERIVE_NAMES]
+        if bad:
+            raise ValueError(f"amr.derive_plot_vars: unknown derived quantities {bad} (have {DERIVE_NAMES})")
+        der = list(derive_plot_vars)
+    return keep, der
+
+
 def from_level_data(geom_n, prob_lo, prob_hi, boxes, arrays, time, step, names=None):
     """single-level PlotFile from per-box arrays (valid region, (nx,ny,nz,ncomp))"""
     dim = len(geom_n)

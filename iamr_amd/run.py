@@ -46,16 +46,40 @@ def build_amr(pr, lib, N, world=1):
     return amr, amr.layouts, g0
 
 
-def level_arrays(ns, lay, N):
+def level_arrays(ns, lay, N, derived=()):
+    """valid-region arrays of the level's boxes: the state components, then the derived quantities asked for (NavierStokes::derive)"""
+    import numpy as np
     S = ns.data(N.NavierStokes.S_NEW)
+    D = [ns.derive(name) for name in derived]
     boxes, arrs = [], []
     for li in range(S.nlocal()):
         a, lo = S.to_numpy(li)
         blo, bhi, gi = lay.local_box(li)
         ng = (a.shape[0] - (bhi[0] - blo[0] + 1)) // 2
-        arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
+        v = a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :]
+        arrs.append(np.concatenate([v] + [d.to_numpy(li)[0] for d in D], axis=-1) if D else v.copy())
         boxes.append((tuple(blo), tuple(bhi)))
     return boxes, arrs
+
+
+def plot_names_and_filter(pr):
+    """(names of everything level_arrays returns for this run, derived names, predicate name -> written?): amr.plot_vars picks among the
+    state variables, amr.derive_plot_vars adds derived ones (plotfile.plot_selection)"""
+    from .plotfile import state_names, plot_selection
+    state = state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0))
+    pv = pr.get("plot_vars", "ALL")
+    if pr.get("slab") and isinstance(pv, list):          # a 2-D inputs file names the plane's velocities x_velocity, y_velocity: y is the slab's z
+        pv = ["z_velocity" if v == "y_velocity" else v for v in pv]
+    keep, der = plot_selection(state, pv, pr.get("derive_plot_vars", "NONE"))
+    kept = {state[q] for q in keep} | set(der)
+    return state + der, der, kept
+
+
+def select_components(names, arrs, kept, renamed=None):
+    """drop the components amr.plot_vars does not name; `renamed`: names after _plane's renaming, same order as `names`"""
+    idx = [q for q, nm in enumerate(names) if nm in kept]
+    out = renamed if renamed is not None else names
+    return [out[q] for q in idx], [a[..., idx] for a in arrs]
 
 
 def _plane(boxes, arrs, names):
@@ -104,23 +128,27 @@ def enforce_plane(levels, pr):
 
 def write_plot_amr(amr, lays, pr, N, step, root):
     """NavierStokesBase::writePlotFile role for the hierarchy: one AMReX plotfile with every level (the five state components)"""
-    from .plotfile import PlotFile, Level, state_names
+    from .plotfile import PlotFile, Level
+    names, der, kept = plot_names_and_filter(pr)
     levels = []
     dts = amr.dts()
     for l, lev in enumerate(amr.levels):
         n = [v * 2 ** l for v in pr["n"]]
         dx = [(pr["prob_hi"][d] - pr["prob_lo"][d]) / n[d] for d in range(3)]
-        boxes, arrs = level_arrays(lev, lays[l], N)
+        boxes, arrs = level_arrays(lev, lays[l], N, der)
         if pr.get("slab"):
-            boxes, arrs, names2 = _plane(boxes, arrs, state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)))
+            boxes, arrs, names2 = _plane(boxes, arrs, names)
+            plane_names = [nm for q, nm in enumerate(names) if q != 1]
+            out_names, arrs = select_components(plane_names, arrs, kept, names2)
             levels.append(Level(((0, 0), (n[0] - 1, n[2] - 1)), [dx[0], dx[2]], boxes, arrs, step * 2 ** l, amr.time))
         else:
+            out_names, arrs = select_components(names, arrs, kept)
             levels.append(Level(((0, 0, 0), tuple(v - 1 for v in n)), dx, boxes, arrs, step * 2 ** l, amr.time))
     path = f"{root}{step:05d}"
     if pr.get("slab"):
-        PlotFile(names2, amr.time, [pr["prob_lo"][0], pr["prob_lo"][2]], [pr["prob_hi"][0], pr["prob_hi"][2]], levels).write(path)
+        PlotFile(out_names, amr.time, [pr["prob_lo"][0], pr["prob_lo"][2]], [pr["prob_hi"][0], pr["prob_hi"][2]], levels).write(path)
     else:
-        PlotFile(state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0)), amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
+        PlotFile(out_names, amr.time, pr["prob_lo"], pr["prob_hi"], levels).write(path)
     return path
 
 
@@ -192,24 +220,19 @@ def build(inp, lib, N, nranks=1, pr=None):
 
 
 def write_plot(ns, lay, pr, N, step, root):
-    """NavierStokesBase::writePlotFile role (single level, the five state components): AMReX-format plotfile <root><step:05d>.
-    Single-rank runs only (every box is local)."""
-    from .plotfile import from_level_data, state_names
-    S = ns.data(N.NavierStokes.S_NEW)
-    boxes, arrs = [], []
-    for li in range(S.nlocal()):
-        a, lo = S.to_numpy(li)
-        blo, bhi, gi = lay.local_box(li)
-        ng = (a.shape[0] - (bhi[0] - blo[0] + 1)) // 2
-        arrs.append(a[ng:a.shape[0] - ng, ng:a.shape[1] - ng, ng:a.shape[2] - ng, :].copy())
-        boxes.append((tuple(blo), tuple(bhi)))
+    """NavierStokesBase::writePlotFile role (single level): AMReX-format plotfile <root><step:05d> with the state variables of
+    amr.plot_vars and the derived quantities of amr.derive_plot_vars.  Single-rank runs only (every box is local)."""
+    from .plotfile import from_level_data
+    names, der, kept = plot_names_and_filter(pr)
+    boxes, arrs = level_arrays(ns, lay, N, der)
     path = f"{root}{step:05d}"
-    names = state_names(pr["params"].get("do_trac2", 0), pr["params"].get("do_temp", 0))
     if pr.get("slab"):
-        boxes, arrs, names = _plane(boxes, arrs, names)
-        from_level_data((pr["n"][0], pr["n"][2]), (pr["prob_lo"][0], pr["prob_lo"][2]), (pr["prob_hi"][0], pr["prob_hi"][2]), boxes, arrs, ns.time, step, names=names).write(path)
+        boxes, arrs, names2 = _plane(boxes, arrs, names)
+        out_names, arrs = select_components([nm for q, nm in enumerate(names) if q != 1], arrs, kept, names2)
+        from_level_data((pr["n"][0], pr["n"][2]), (pr["prob_lo"][0], pr["prob_lo"][2]), (pr["prob_hi"][0], pr["prob_hi"][2]), boxes, arrs, ns.time, step, names=out_names).write(path)
     else:
-        from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step, names=names).write(path)
+        out_names, arrs = select_components(names, arrs, kept)
+        from_level_data(tuple(pr["n"]), tuple(pr["prob_lo"]), tuple(pr["prob_hi"]), boxes, arrs, ns.time, step, names=out_names).write(path)
     return path
 
 

@@ -395,6 +395,11 @@ int iamrx_ns_time(iamrx_ns ns, double* time, double* dt, int* nstep);
  * 3 P_old, 4 Gp_new, 5 Gp_old, 6..8 u_mac, 9 aofs  (get_new_data/get_old_data role); 10, 11: the last two MAC potentials (the
  * initial-guess history of the MAC solve, part of a checkpoint) */
 int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out);
+/* Derived quantities of the plotfile (derive_lst, Source/NS_setup.cpp:436-449; amr.derive_plot_vars): "energy" = rho |u|^2 / 2 (derkeng,
+ * Source/NS_derive.cpp:266-295), "mag_vort" = |curl u| (dermgvort, :86-264, ghost cells by FillPatch), "avg_pressure" = mean of the eight
+ * nodes of the cell (deravgpres, :51-80) of the level's new-time data, into component ocomp of the cell-centred out (the level's layout). */
+int iamrx_ns_derive(iamrx_ns ns, const char* name, iamrx_mf out, int ocomp);
+
 /* overwrite state (0,1), pressure (2,3) or grad p (4,5) with src (same layout and ngrow; ncomp at most the array's: the leading
  * components are set): the role of NavierStokes::initData for caller-supplied initial data (Source/NavierStokes.cpp:318-420).
  * The state arrays hold u v w density tracer [tracer2] [temp], and with ns.do_temp two more components, divu and dsdt (the

@@ -156,3 +156,22 @@ def test_two_dimensional_inputs_are_lifted_onto_a_slab():
         Inputs([LDC], ["xlo.type=nsw"]).problem()                            # x is periodic in that file
     with pytest.raises(NotImplementedError):
         Inputs([os.path.join(here, "golden", "regtest.2d.poiseuille")], ["xhi.pressure=1.0"]).problem()
+
+
+def test_plot_variable_selection():
+    """amr.plot_vars / amr.derive_plot_vars (Amr::initPltAndChk): ALL / NONE / lists; defaults: every state variable, no derived one"""
+    from iamr_amd.inputs import Inputs, parse_text
+    from iamr_amd.plotfile import plot_selection, state_names
+    st = state_names(1, 0)
+    assert plot_selection(st) == (list(range(6)), [])
+    assert plot_selection(st, "ALL", "ALL") == (list(range(6)), ["energy", "mag_vort", "avg_pressure"])
+    assert plot_selection(st, ["tracer2", "density"], ["mag_vort"]) == ([3, 5], ["mag_vort"])
+    assert plot_selection(st, "NONE", ["avg_pressure", "energy"]) == ([], ["avg_pressure", "energy"])
+    with pytest.raises(ValueError):
+        plot_selection(st, ["temp"])
+    with pytest.raises(ValueError):
+        plot_selection(st, "ALL", ["vorticity"])
+    inp = Inputs.__new__(Inputs)
+    inp.table, inp.used, inp.ignored = parse_text("amr.plot_vars = density tracer\namr.derive_plot_vars = ALL\n"), set(), []
+    assert inp.name_list("amr.plot_vars", "ALL") == ["density", "tracer"] and inp.name_list("amr.derive_plot_vars", "NONE") == "ALL"
+    assert inp.name_list("amr.absent", "NONE") == "NONE"

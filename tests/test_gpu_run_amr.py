@@ -252,3 +252,66 @@ def test_reference_two_dimensional_regtest_inputs(gpu, tmp_path, capsys, name, n
         assert len(lv.dx) == 2
         for a in lv.data:
             assert a.ndim == 3 and np.isfinite(a).all() and a[..., 2].min() > 0.0
+
+
+@pytest.mark.parametrize("levels", [1, 2])
+def test_plot_vars_and_derived_plot_vars(gpu, tmp_path, capsys, levels):
+    """amr.plot_vars picks among the state variables, amr.derive_plot_vars adds derived quantities (Amr::initPltAndChk; derive_lst of
+    NS_setup.cpp:436-449): energy = rho |u|^2 / 2 (derkeng), avg_pressure = mean of the cell's eight nodes (deravgpres), mag_vort = |curl u|
+    by centred differences (dermgvort).  The reference's TaylorGreen inputs on a periodic 16^3 (32^3 refined) grid; the derived fields of
+    the plotfile against numpy on the velocities / density the same plotfile holds, and against the level's nodal pressure."""
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    root = str(tmp_path / "plt")
+    fixture = "inputs.3d.taylorgreen" if levels == 1 else "inputs.3d.taylorgreen_amr16"       # the second: fixed refined grids
+    argv = [os.path.join(HERE, "golden", fixture), "amr.n_cell=16 16 16", "max_step=2", "amr.plot_int=2", f"amr.plot_file={root}",
+            "amr.derive_plot_vars=ALL", f"amr.max_level={levels - 1}", "amr.max_grid_size=8"]
+    assert R.main(argv) == 0
+    pf = PlotFile.read(root + "00002")
+    assert pf.names == ["x_velocity", "y_velocity", "z_velocity", "density", "tracer", "energy", "mag_vort", "avg_pressure"], pf.names
+    assert len(pf.levels) == levels
+    lv = pf.levels[0]
+    n = 16
+    G = np.zeros((n, n, n, len(pf.names)))
+    for (lo, hi), a in zip(lv.boxes, lv.data):
+        G[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] = a
+    u, v, w, rho = G[..., 0], G[..., 1], G[..., 2], G[..., 3]
+    assert np.abs(G[..., 5] - 0.5 * rho * (u * u + v * v + w * w)).max() <= 1e-14
+    h = 1.0 / n                                    # periodic base level: centred differences wrap
+
+    def d(f, ax):
+        return (np.roll(f, -1, ax) - np.roll(f, 1, ax)) * (0.5 / h)
+    vort = np.sqrt((d(w, 1) - d(v, 2)) ** 2 + (d(u, 2) - d(w, 0)) ** 2 + (d(v, 0) - d(u, 1)) ** 2)
+    assert np.abs(G[..., 6] - vort).max() <= 1e-11 * max(1.0, vort.max())
+    assert G[..., 6].max() > 1.0 and np.isfinite(G[..., 7]).all() and np.abs(G[..., 7]).max() > 1e-4
+    capsys.readouterr()
+    # a selection: two state variables and one derived quantity, in state order
+    root2 = str(tmp_path / "sel")
+    assert R.main(argv[:4] + [f"amr.plot_file={root2}", "amr.plot_vars=tracer density", "amr.derive_plot_vars=avg_pressure", f"amr.max_level={levels - 1}",
+                              "amr.max_grid_size=8"]) == 0
+    pf2 = PlotFile.read(root2 + "00002")
+    assert pf2.names == ["density", "tracer", "avg_pressure"]
+    a0, b0 = pf.levels[0], pf2.levels[0]
+    for (bx, a) in zip(a0.boxes, a0.data):
+        q = b0.boxes.index(bx)
+        assert np.array_equal(b0.data[q][..., 0], a[..., 3]) and np.array_equal(b0.data[q][..., 2], a[..., 7])
+    with pytest.raises(ValueError):
+        R.main(argv[:5] + ["amr.derive_plot_vars=vorticity"])
+
+
+def test_avg_pressure_is_the_mean_of_the_cell_nodes(gpu):
+    from iamr_amd import ns as N
+    lib = gpu
+    n = (8, 8, 8)
+    g = lib.Geom.make(n)
+    lay = lib.Layout.decompose(n, 4)
+    ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.5, visc_coef=1e-2, init_iter=1))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    ns.step()
+    P = ns.data(N.NavierStokes.P_NEW).gather_valid(n)[..., 0]
+    A = ns.derive("avg_pressure").gather_valid(n)[..., 0]
+    ref = sum(P[dx:dx + 8, dy:dy + 8, dz:dz + 8] for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)) * 0.125
+    assert np.abs(A - ref).max() <= 1e-14 * max(1.0, np.abs(ref).max())
+    with pytest.raises(Exception):
+        ns.derive("no_such_quantity")
