@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
-    const FabD* __restrict__ cfmt, CfC1 cfc)
+    const FabD* __restrict__ cfmt, CfC1 cfc, int zero)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -269,10 +269,13 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
         if (i > b.hi[0]) return;
         const int im = (wrap && i == b.lo[0]) ? b.hi[0] : i - 1, ip = (wrap && i == b.hi[0]) ? b.lo[0] : i + 1;
         const int km = (wrap && k == b.lo[2]) ? b.hi[2] : k - 1, kp = (wrap && k == b.hi[2]) ? b.lo[2] : k + 1;
-        o.pc = phi(i, j, k, 0);
-        o.pxm = phi(im, j, k, 0); o.pxp = phi(ip, j, k, 0);
-        o.pym = phi(i, jm, k, 0); o.pyp = phi(i, jp, k, 0);
-        o.pzm = phi(i, j, km, 0); o.pzp = phi(i, j, kp, 0);
+        if (zero) o.pc = o.pxm = o.pxp = o.pym = o.pyp = o.pzm = o.pzp = 0.0;      // phi_is_zero: nothing to read
+        else {
+            o.pc = phi(i, j, k, 0);
+            o.pxm = phi(im, j, k, 0); o.pxp = phi(ip, j, k, 0);
+            o.pym = phi(i, jm, k, 0); o.pyp = phi(i, jp, k, 0);
+            o.pzm = phi(i, j, km, 0); o.pzp = phi(i, j, kp, 0);
+        }
         o.r = rhs(i, j, k, 0);
         o.a = has_a ? A(i, j, k, 0) : 0.0;
         if (BMODE == 0) {
@@ -287,6 +290,10 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     };
     auto update = [&](int k, const Gs1Ops<BMODE>& o) {
         const int i = o.i;
+        if (zero) {                          // the other cell of the thread's pair (lo + 2m, lo + 2m + 1): zero
+            const int iL = b.lo[0] + 2 * (ih - b.lo[0]), io = i == iL ? iL + 1 : iL;
+            if (io <= b.hi[0]) phi(io, j, k, 0) = 0.0;
+        }
         if (i > b.hi[0]) return;
         double bxm, bxp, bym, byp, bzm, bzp;
         if (BMODE == 0) { bxm = o.c[0]; bxp = o.c[1]; bym = o.c[2]; byp = o.c[3]; bzm = o.c[4]; bzp = o.c[5]; }
@@ -347,7 +354,7 @@ template <int BMODE>
 __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ sgt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
-    const FabD* __restrict__ cfmt, CfC1 cfc)
+    const FabD* __restrict__ cfmt, CfC1 cfc, int zero)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -371,20 +378,25 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
     const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
     const double cf1 = (j == bc.dlo[1]) ? bc.cflo[0][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[0][1] : 0.0;
     auto kw = [&](int k) { return wrap ? (k < b.lo[2] ? b.hi[2] : (k > b.hi[2] ? b.lo[2] : k)) : k; };
-    D2 pb = ld2(phi, iL, j, kw(k0 - 1), 0), pc = ld2(phi, iL, j, k0, 0);
+    // zero (phi_is_zero, wrap only): phi is not read; every cell of the pair is written
+    D2 pb, pc;
+    if (zero) { pb.l = pb.r = pc.l = pc.r = 0.0; }
+    else { pb = ld2(phi, iL, j, kw(k0 - 1), 0); pc = ld2(phi, iL, j, k0, 0); }
     D2 sb, sc;
     if (BMODE == 1) { sb = ld2(S, iL, j, k0 - 1, sig_comp); sc = ld2(S, iL, j, k0, sig_comp); }
     for (int k = k0; k <= k1; ++k) {
         const int par = (b.lo[0] + j + k + redblack) & 1;         // 0: the left cell of the pair is active
         const int i = iL + par;
         const bool live = i <= b.hi[0];
-        const D2 pa = ld2(phi, iL, j, kw(k + 1), 0);
+        D2 pa;
+        if (zero) { pa.l = pa.r = 0.0; } else pa = ld2(phi, iL, j, kw(k + 1), 0);
         D2 sa;
         if (BMODE == 1) sa = ld2(S, iL, j, k + 1, sig_comp);
         // x-neighbours: the other cell of the pair, and the adjacent lane's near cell (or a load where there is no such lane)
         const double fromL = __shfl_up(pc.r, 1, 64), fromR = __shfl_down(pc.l, 1, 64);
         double pxm, pxp;
-        if (par == 0) {
+        if (zero) { pxm = pxp = 0.0; }
+        else if (par == 0) {
             pxp = (wrap && i == b.hi[0]) ? (double)phi(b.lo[0], j, k, 0) : pc.r;
             pxm = laneL ? fromL : (double)phi((wrap && i == b.lo[0]) ? b.hi[0] : i - 1, j, k, 0);
         } else {
@@ -399,7 +411,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
         }
         if (live) {
             const double p0 = par ? pc.r : pc.l;
-            const double pym = phi(i, jm, k, 0), pyp = phi(i, jp, k, 0);
+            const double pym = zero ? 0.0 : (double)phi(i, jm, k, 0), pyp = zero ? 0.0 : (double)phi(i, jp, k, 0);
             const double pzm = par ? pb.r : pb.l, pzp = par ? pa.r : pa.l;
             const double rr = rhs(i, j, k, 0);
             double bxm, bxp, bym, byp, bzm, bzp;
@@ -431,6 +443,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
             if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
                 cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
         }
+        if (zero) { const int io = par ? iL : iR; if (io <= b.hi[0]) phi(io, j, k, 0) = 0.0; }
         pb = pc; pc = pa;
         if (BMODE == 1) { sb = sc; sc = sa; }
     }
@@ -439,9 +452,16 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
 // IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given
 static bool abec_sig_on() { return tune("ABEC_SIG", 1) != 0; }
 
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
-               bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts)
+bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wrap, bool has_cf)
 {
+    return tune("GSRB_ZERO", 1) != 0 && tune("GSRB1_NP", 2) > 0 && wrap && !has_cf && phi.ncomp == 1 && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta;
+}
+
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
+               bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts, bool phi_is_zero)
+{
+    IAMRX_ASSERT(!phi_is_zero || (!shell_only && abec_gsrb_zero_ok(c, phi, nbc, wrap, cfm != nullptr)));
+    const int zero = phi_is_zero ? 1 : 0;
     CfC1 cfc;
     cfc.maxorder = cftab ? cftab->maxorder : 2;
     cfc.maintain = (cf_maintain_ghosts && cfm && cftab && phi.ncomp == 1 && !shell_only) ? 1 : 0;
@@ -469,17 +489,17 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     if (np > 0 && phi.ncomp == 1 && !shell_only && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta) {
         const FabD *t0 = mode == 1 ? c.sig->d_tab : c.b[0]->d_tab, *t1 = mode == 1 ? c.sig->d_tab : c.b[1]->d_tab, *t2 = mode == 1 ? c.sig->d_tab : c.b[2]->d_tab;
 #define IAMRX_GS1(M, N) hipLaunchKernelGGL((k_abec_gsrb1<M, N>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab, \
-                           c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc)
+                           c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero)
         // IAMRX_GSRB2 (1): the pair-marching kernel where the coefficients are not arrays (needs a ghost layer for its 16-byte loads)
         if (pair_ok) {
             int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
             Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
             if (mode == 1)
                 hipLaunchKernelGGL((k_abec_gsrb2<1>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
-                                   c.sig->d_tab, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc);
+                                   c.sig->d_tab, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero);
             else
                 hipLaunchKernelGGL((k_abec_gsrb2<2>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
-                                   nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bu, cft, cfc);
+                                   nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bu, cft, cfc, zero);
         }
         else if (np >= 4 && !cft) { if (mode == 1) IAMRX_GS1(1, 4); else if (mode == 2) IAMRX_GS1(2, 4); else IAMRX_GS1(0, 4); }
         else if (np >= 2 && !cft) { if (mode == 1) IAMRX_GS1(1, 2); else if (mode == 2) IAMRX_GS1(2, 2); else IAMRX_GS1(0, 2); }
@@ -747,6 +767,8 @@ __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __r
 
 // norm_out != null: *norm_out = max norm of `out` over all components and ranks, computed by the launch that writes it last (saves
 // the separate norm pass of every multigrid iteration)
+static bool abec_residual_pairs(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab& rhs, unsigned long long* d_norm);
+
 void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs, double* norm_out)
 {
     auto& ctx = Context::get();
@@ -757,6 +779,8 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
         Tiling t = level_tiling(l, cell_type(), 0, 8);
         const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
         if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        if (rhs && abec_residual_pairs(g, c, out, phi, *rhs, norm_out ? d_norm : nullptr)) { /* done by the pair march */ }
+        else {
         BUni bu;
         for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
         if (phi.ncomp == 1 && c.sig && !c.tensor && !c.tensor_eta && abec_sig_on())
@@ -771,6 +795,7 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
         hipLaunchKernelGGL(k_abec_residual<0>, t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, out.d_tab, phi.d_tab,
                            rhs ? rhs->d_tab : nullptr, c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
                            c.alpha, dhx, dhy, dhz, phi.ncomp, c.b[0]->ncomp, c.tensor_eta, (norm_out && !c.tensor) ? d_norm : nullptr, 0, 1.0, bu);
+        }
         if (c.tensor) tensor_cross_terms_sub(g, c, out, phi, rhs ? -1.0 : 1.0, norm_out ? d_norm : nullptr);
     }
     if (norm_out) {
@@ -788,6 +813,137 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
         }
         *norm_out = v;
     }
+}
+
+// ---------------------------------------------------------------------------- residual + restriction in one pass
+// The down-leg of a V-cycle needs the residual of the smoothed correction only as the coarse level's right-hand side.  A thread owns a
+// coarse cell column (I, J) and marches through the fine planes: per plane it forms the four residuals of its fine cells
+// (2I, 2I+1) x (2J, 2J+1) -- k_abec_residual's expression, coefficients from the cell-centred array (BMODE 1) or constants (BMODE 2) --
+// from row pairs read with 16-byte loads and kept for three planes, x-neighbours from the adjacent lane, and adds them in k_cc_restrict's
+// order; every second plane it writes 0.125 x the sum.  The fine residual (a full array written and read again) never exists.  Same doubles
+// as abec_residual followed by cc_restrict.  phi: ghost cells filled; no 'a' term.
+// RESTRICT = false: the same march writes the four fine residuals per plane instead (ct: the fine output array) and reduces their max norm
+// (normout, see norm_commit) -- the residual of the convergence test with 7 sixteen-byte loads per two cells instead of 22 eight-byte ones.
+template <int BMODE, bool RESTRICT>
+__global__ void __launch_bounds__(256) k_abec_resid_restrict(Tiling t, const BoxD* __restrict__ cboxes, const FabD* __restrict__ ct,
+    const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ sgt,
+    double dhx, double dhy, double dhz, int sig_comp, double sig_scale, BUni bu, unsigned long long* __restrict__ normout)
+{
+    const int fab = blockIdx.y;
+    const BoxD cb = cboxes[fab];
+    int I, J, K0, K1;
+    double mx = 0.0;
+    if (!tile_ijk(t, cb, I, J, K0, K1)) { if (!RESTRICT && normout) norm_commit(mx, normout); return; }
+    const FabD crse = ct[fab], phi = phit[fab], rhs = rhst[fab];
+    FabD S; if (BMODE == 1) S = sgt[fab];
+    const int bx = 1 << t.bxs, tx = (int)threadIdx.x & (bx - 1);
+    const bool laneL = tx > 0 && I > cb.lo[0], laneR = tx < bx - 1 && I < cb.hi[0];
+    const int iL = 2 * I, iR = iL + 1, j0 = 2 * J;
+    auto bco = [&](double a, double b) { return sig_scale / (0.5 * (a + b)); };       // mac_bcoef's expression, lower cell first
+    // rows j0, j0 + 1 at planes k - 1 (b), k (c), k + 1 (a)
+    D2 pb[2], pc[2], pa[2], sb[2], sc[2], sa[2];
+    int k = 2 * K0;
+    for (int r = 0; r < 2; ++r) {
+        pb[r] = ld2(phi, iL, j0 + r, k - 1, 0); pc[r] = ld2(phi, iL, j0 + r, k, 0);
+        if (BMODE == 1) { sb[r] = ld2(S, iL, j0 + r, k - 1, sig_comp); sc[r] = ld2(S, iL, j0 + r, k, sig_comp); }
+    }
+    for (int K = K0; K <= K1; ++K) {
+        double s = 0.0;
+        for (int kr = 0; kr < 2; ++kr, ++k) {
+            for (int r = 0; r < 2; ++r) {
+                pa[r] = ld2(phi, iL, j0 + r, k + 1, 0);
+                if (BMODE == 1) sa[r] = ld2(S, iL, j0 + r, k + 1, sig_comp);
+            }
+            const D2 pS = ld2(phi, iL, j0 - 1, k, 0), pN = ld2(phi, iL, j0 + 2, k, 0);       // the rows below / above the pair of rows
+            D2 sS, sN;
+            if (BMODE == 1) { sS = ld2(S, iL, j0 - 1, k, sig_comp); sN = ld2(S, iL, j0 + 2, k, sig_comp); }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = j0 + r;
+                const D2 rr = ld2(rhs, iL, j, k, 0);
+                // x-neighbours of the pair: the adjacent lanes' near cells (or loads at the ends of the row segment)
+                const double fl = __shfl_up(pc[r].r, 1, 64), fr = __shfl_down(pc[r].l, 1, 64);
+                const double pxm = laneL ? fl : (double)phi(iL - 1, j, k, 0), pxp = laneR ? fr : (double)phi(iR + 1, j, k, 0);
+                const D2 pym = r == 0 ? pS : pc[0], pyp = r == 0 ? pc[1] : pN;
+                double bxl, bxc, bxr, byml, bymr, bypl, bypr, bzml, bzmr, bzpl, bzpr;        // x faces: left of iL, between, right of iR
+                if (BMODE == 1) {
+                    const double gl = __shfl_up(sc[r].r, 1, 64), gr = __shfl_down(sc[r].l, 1, 64);
+                    const double sxm = laneL ? gl : (double)S(iL - 1, j, k, sig_comp), sxp = laneR ? gr : (double)S(iR + 1, j, k, sig_comp);
+                    const D2 sym = r == 0 ? sS : sc[0], syp = r == 0 ? sc[1] : sN;
+                    bxl = bco(sxm, sc[r].l); bxc = bco(sc[r].l, sc[r].r); bxr = bco(sc[r].r, sxp);
+                    byml = bco(sym.l, sc[r].l); bymr = bco(sym.r, sc[r].r); bypl = bco(sc[r].l, syp.l); bypr = bco(sc[r].r, syp.r);
+                    bzml = bco(sb[r].l, sc[r].l); bzmr = bco(sb[r].r, sc[r].r); bzpl = bco(sc[r].l, sa[r].l); bzpr = bco(sc[r].r, sa[r].r);
+                } else {
+                    bxl = bxc = bxr = bu.v[0]; byml = bymr = bypl = bypr = bu.v[1]; bzml = bzmr = bzpl = bzpr = bu.v[2];
+                }
+                {   // cell iL
+                    const double p0 = pc[r].l;
+                    const double y = 0.0 - dhx * (bxc * (pc[r].r - p0) - bxl * (p0 - pxm)) - dhy * (bypl * (pyp.l - p0) - byml * (p0 - pym.l))
+                                   - dhz * (bzpl * (pa[r].l - p0) - bzml * (p0 - pb[r].l));
+                    const double o = rr.l - y;
+                    if (RESTRICT) s += o; else { crse(iL, j, k, 0) = o; mx = fmax(mx, norm_term(o)); }
+                }
+                {   // cell iR
+                    const double p0 = pc[r].r;
+                    const double y = 0.0 - dhx * (bxr * (pxp - p0) - bxc * (p0 - pc[r].l)) - dhy * (bypr * (pyp.r - p0) - bymr * (p0 - pym.r))
+                                   - dhz * (bzpr * (pa[r].r - p0) - bzmr * (p0 - pb[r].r));
+                    const double o = rr.r - y;
+                    if (RESTRICT) s += o; else { crse(iR, j, k, 0) = o; mx = fmax(mx, norm_term(o)); }
+                }
+            }
+            for (int r = 0; r < 2; ++r) { pb[r] = pc[r]; pc[r] = pa[r]; if (BMODE == 1) { sb[r] = sc[r]; sc[r] = sa[r]; } }
+        }
+        if (RESTRICT) crse(I, J, K, 0) = 0.125 * s;
+    }
+    if (!RESTRICT && normout) norm_commit(mx, normout);
+}
+
+bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs)
+{
+    if (tune("RESID_RESTRICT", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
+    if (phi.ncomp != 1 || c.tensor || c.tensor_eta || (c.a && c.alpha != 0.0) || phi.ngrow < 1 || rhs.ngrow != 0) return false;
+    if (c.sig) return c.sig->ngrow >= 1;
+    return c.b_uniform && c.b[0]->ncomp == 1;
+}
+
+// crse = restriction of (rhs - A phi); see k_abec_resid_restrict.  crse: the coarsened layout of phi's
+void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, const MultiFab& phi, const MultiFab& rhs)
+{
+    IAMRX_ASSERT(abec_resid_restrict_ok(c, phi, rhs));
+    if (crse.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    const Layout& l = *crse.layout;
+    Tiling t = level_tiling(l, cell_type(), 0, (int)tune("RESID_RESTRICT_TZ", 8));
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    BUni bu;
+    for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
+    if (c.sig)
+        hipLaunchKernelGGL((k_abec_resid_restrict<1, true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, crse.d_tab, phi.d_tab, rhs.d_tab, c.sig->d_tab,
+                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, nullptr);
+    else
+        hipLaunchKernelGGL((k_abec_resid_restrict<2, true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, crse.d_tab, phi.d_tab, rhs.d_tab, nullptr,
+                           dhx, dhy, dhz, 0, 1.0, bu, nullptr);
+}
+
+// the fine residual out = rhs - A phi by the same march (k_abec_resid_restrict<., false>): levels whose boxes coarsen by 2
+static bool abec_residual_pairs(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab& rhs, unsigned long long* d_norm)
+{
+    if (tune("RESID_PAIRS", 1) == 0 || !abec_resid_restrict_ok(c, phi, rhs) || out.ngrow != 0) return false;
+    const Layout& fl = *phi.layout;
+    if (!fl.coarsenable(2, 1)) return false;
+    LayoutP cl = fl.coarsened(2);
+    auto& ctx = Context::get();
+    Tiling t = level_tiling(*cl, cell_type(), 0, (int)tune("RESID_RESTRICT_TZ", 8));
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    BUni bu;
+    for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
+    if (c.sig)
+        hipLaunchKernelGGL((k_abec_resid_restrict<1, false>), t.grid(), Tiling::block(), 0, ctx.stream, t, cl->d_boxes, out.d_tab, phi.d_tab, rhs.d_tab, c.sig->d_tab,
+                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, d_norm);
+    else
+        hipLaunchKernelGGL((k_abec_resid_restrict<2, false>), t.grid(), Tiling::block(), 0, ctx.stream, t, cl->d_boxes, out.d_tab, phi.d_tab, rhs.d_tab, nullptr,
+                           dhx, dhy, dhz, 0, 1.0, bu, d_norm);
+    return true;
 }
 
 // ---------------------------------------------------------------------------- bottom solve of a small level on the device

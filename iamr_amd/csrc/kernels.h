@@ -79,7 +79,15 @@ void cf_interp_edges(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cf
 void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cfm, int ratio);
 // bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc,
-               bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr, bool cf_maintain_ghosts = false);
+               bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr, bool cf_maintain_ghosts = false,
+               bool phi_is_zero = false);
+// phi_is_zero: the pass may be told that phi is identically zero (the first pass on a multigrid correction) INSTEAD of phi being set to
+// zero in front of it -- it then reads no phi and writes every cell (the active colour its update, the other colour zero) -- if this returns
+// true for the same arguments (one component, one-component coefficients, one box spanning a periodic domain: no ghost cell is read)
+// restriction of the residual rhs - A phi straight onto the coarsened layout (one pass, the fine residual is not stored): usable if ..._ok
+bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs);
+void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, const MultiFab& phi, const MultiFab& rhs);
+bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wrap, bool has_cf);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,

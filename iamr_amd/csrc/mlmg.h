@@ -93,9 +93,10 @@ public:
     const Geometry& geom(int l) const { return m_lev[l].g; }
     void applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, bool corners = true);
     // cf_ghosts_current: the coarse/fine ghost cells are already what a fill would write (kept so by the passes themselves, k_abec.hip cf_maintain)
-    void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current = false);
+    void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current = false, bool sol_is_zero = false);
+    bool zero_first_pass_ok(int l, const MultiFab& sol) const;   // the first colour pass can take the place of sol.setVal(0) (abec_gsrb_zero_ok)
     // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
-    void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill);
+    void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero = false);
     bool fused_smoother_ok(int l) const;
     void vcycle(MGStats& st);
     MultiFab& res(int l) { return m_lev[l].res; }

@@ -197,7 +197,15 @@ static bool cf_maintain_on()
     return tune("CF_MAINTAIN", 1) != 0;
 }
 
-void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current)
+bool CellMG::zero_first_pass_ok(int l, const MultiFab& sol) const
+{
+    if (m_dd_sweeps > 0 || fused_smoother_ok(l)) return false;
+    AbecCoef c = coef(l);
+    const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
+    return abec_gsrb_zero_ok(c, sol, (int)m_bcn.size(), wrap, m_cf);
+}
+
+void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current, bool sol_is_zero)
 {
     AbecCoef c = coef(l);
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
@@ -214,7 +222,7 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, b
         // diagonally dominant shortcut: plain Gauss-Seidel -- over-relaxation leaves a (1 - omega) = 0.15 floor per sweep on an operator
         // that is almost its diagonal, where omega = 1 contracts by the square of the Jacobi factor
         abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_dd_sweeps > 0 ? dd_omega() : m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
-                  m_cf ? &m_lev[l].cftab : nullptr, maint);
+                  m_cf ? &m_lev[l].cftab : nullptr, maint, sol_is_zero && rb == 0);
         skip_fill = false;
     }
 }
@@ -243,13 +251,14 @@ bool CellMG::fused_smoother_ok(int l) const
     return true;
 }
 
-void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill)
+void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero)
 {
-    if (nsweeps <= 0) return;
+    if (nsweeps <= 0) { if (sol_is_zero) sol.setVal(0.0); return; }
     if (!fused_smoother_ok(l)) {
-        for (int i = 0; i < nsweeps; ++i) smooth(l, sol, rhs, skip_first_fill && i == 0, i > 0);
+        for (int i = 0; i < nsweeps; ++i) smooth(l, sol, rhs, skip_first_fill && i == 0, i > 0, sol_is_zero && i == 0);
         return;
     }
+    IAMRX_ASSERT(!sol_is_zero);
     Level& L = m_lev[l];
     AbecCoef c = coef(l);
     c.tensor = 0;   // the smoother acts on the ABec part; cross terms enter through the residual
@@ -386,10 +395,20 @@ void CellMG::vcycle(MGStats& st)
     const int nl = (int)m_lev.size();
     for (int l = 0; l < nl - 1; ++l) {
         Level& L = m_lev[l];
-        L.cor.setVal(0.0);
-        smooth_n(l, L.cor, L.res, m_o.nu1, true);
+        // zero initial guess of the correction: where the first colour pass reads no ghost cell it also takes the place of the fill
+        const bool z = m_o.nu1 > 0 && zero_first_pass_ok(l, L.cor);
+        if (!z) L.cor.setVal(0.0);
+        smooth_n(l, L.cor, L.res, m_o.nu1, true, z);
         applyBC(l, L.cor, false, nullptr);
-        abec_residual(L.g, coef(l), L.rescor, L.cor, &L.res);
+        const AbecCoef cl = coef(l);
+        if (abec_resid_restrict_ok(cl, L.cor, L.res)) {        // residual and restriction in one pass
+            if (m_lev[l + 1].agg) {
+                abec_resid_restrict(L.g, cl, m_lev[l + 1].tmp_d, L.cor, L.res);
+                gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
+            } else abec_resid_restrict(L.g, cl, m_lev[l + 1].res, L.cor, L.res);
+            continue;
+        }
+        abec_residual(L.g, cl, L.rescor, L.cor, &L.res);
         if (m_lev[l + 1].agg) {
             cc_restrict(m_lev[l + 1].tmp_d, L.rescor);
             gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
@@ -469,7 +488,8 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
             // zero), which amrex::MLMG removes in front of every cycle.  Here in front of the first one only (the bottom solver removes its
             // own): a reduction, a host read-back and a pass over the level per iteration (0.13 ms of a 2.4 ms cycle at 256^3) for a
             // shift of the order of 1e-16 |rhs|.  IAMRX_MG_RES_MEAN=1 restores the per-iteration form.
-            if (m_singular && (iter == 0 || tune("MG_RES_MEAN", 0) != 0)) subtract_mean(0, L0.res);
+            // (fully periodic level: the right-hand side has just lost its mean and no boundary data enters the residual -- nothing to remove)
+            if (m_singular && ((iter == 0 && has_bcdata) || tune("MG_RES_MEAN", 0) != 0)) subtract_mean(0, L0.res);
             if (m_dd_sweeps > 0 && m_dd_rho > 0.0 && st.resnorm > 0.0) {
                 // diagonally dominant operator: as many sweeps as the remaining reduction needs (measured at 256^3, nu dt/h^2 = 0.02:
                 // 4 + 2 sweeps in two cycles instead of 3 x 3 sweeps; the second cycle only removes the lagged cross-term defect)

@@ -61,7 +61,12 @@ KERNEL_FORMS = {
     "lean kernel, one plane in flight": {"GSRB2": 0, "GSRB1_NP": 1},
     "lean kernel, four planes in flight": {"GSRB2": 0, "GSRB1_NP": 4},
     "pair-marching, 4 planes per thread": {"GSRB2_TZ": 4},
+    # residual and restriction as two passes, the residual of the convergence test by the one-cell-per-thread kernel, the correction
+    # zeroed by a fill instead of by the first colour pass
+    "unfused down-leg": {"RESID_RESTRICT": 0, "RESID_PAIRS": 0, "GSRB_ZERO": 0},
+    "fused restriction only": {"RESID_PAIRS": 0},
 }
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 2, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "channel_walls"])
@@ -117,7 +122,7 @@ def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, c
             dts, S, P = run()
         finally:
             for k, v in old.items():
-                lib.tuning_set(k, {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 2, "GSRB2_TZ": 32}[k] if v < 0 else v)
+                lib.tuning_set(k, DEFAULTS[k] if v < 0 else v)
         assert dts == dts0, name
         assert np.array_equal(S, S0), (name, np.abs(S - S0).max())
         assert np.array_equal(P, P0), (name, np.abs(P - P0).max())
