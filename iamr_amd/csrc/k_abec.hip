@@ -50,6 +50,51 @@ __device__ __forceinline__ void cf_maintain(const FabD& phi, const FabD& cfm, co
     }
 }
 
+// cf_maintain for a thread that still holds the six neighbours of its cell (nb = {x-, x+, y-, y+, z-, z+}, values read before the update: they
+// have the other colour and do not change during the pass): the cells the ghost formula needs besides the updated one ARE those neighbours,
+// so the rewrite costs a mask load and a store instead of the loop of dependent loads -- in the lean kernels every wavefront holds a lane
+// next to an x face and used to run that loop once per plane (190 instead of 126 us per 256^3 colour pass on a refined level).  Same sum,
+// same order as cf_maintain.
+// per box: NX and the three weights of each direction, picked from the level's table once per thread
+struct CfDir { int nx[3]; double c1[3], c2[3], c3[3]; };
+__device__ __forceinline__ CfDir cf_dir(const BoxD& b, const CfC1& t)
+{
+    CfDir r;
+    for (int d = 0; d < 3; ++d) {
+        const int NX = min(b.len(d) + 1, t.maxorder);
+        r.nx[d] = NX;
+        const int q = NX >= 2 ? NX - 2 : 0;
+        r.c1[d] = t.c1[d][q]; r.c2[d] = t.c2[d][q]; r.c3[d] = t.c3[d][q];
+    }
+    return r;
+}
+__device__ __forceinline__ void cf_maintain_nb(const FabD& phi, const FabD& cfm, const BoxD& b, const CfDir& t, int i, int j, int k, double pnew, const double nb[6])
+{
+    const int idx[3] = {i, j, k};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int NX = t.nx[d];
+        if (NX < 2) continue;
+        const int target = NX == 2 ? 1 : 2;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int s = side == 0 ? 1 : -1, f = side == 0 ? b.lo[d] : b.hi[d];
+            if ((idx[d] - f) * s + 1 != target) continue;
+            int g[3] = {i, j, k};
+            g[d] = f - s;
+            if (cfm(g[0], g[1], g[2]) != 1.0) continue;
+            double v = 0.0;
+            if (target == 1) v += pnew * t.c1[d];
+            else {
+                v += nb[2 * d + side] * t.c1[d];                 // the cell next to the face
+                v += pnew * t.c2[d];
+                if (NX > 3) v += nb[2 * d + 1 - side] * t.c3[d];  // the third cell of the line
+            }
+            phi(g[0], g[1], g[2], 0) = v;
+        }
+    }
+}
+
 struct GsrbBC {
     int dlo[3], dhi[3];
     double cflo[3][3], cfhi[3][3];   // [comp][dir]: coefficient of the first interior cell in the ghost formula; 0 for periodic
@@ -240,7 +285,7 @@ struct Gs1Ops {
     double c[BMODE == 2 ? 1 : (BMODE == 1 ? 7 : 6)];   // BMODE 0: the six face coefficients; 1: sigma at the cell and its six neighbours
     int i;
 };
-template <int BMODE, int NP>
+template <int BMODE, int NP, bool CF>
 __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
@@ -257,10 +302,11 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
     // coarse/fine faces as in k_abec_gsrb (a ghost cell written by cf_maintain is not read in the same pass, see the top of the file)
-    const bool cf = cfmt != nullptr;
+    constexpr bool cf = CF;                 // compile-time: the instantiation for levels without coarse/fine faces carries none of this
     FabD cfm; if (cf) cfm = cfmt[fab];
-    const double c1x = cf ? cfc.c1[0][min(b.len(0) + 1, cfc.maxorder) - 2] : 0.0, c1y = cf ? cfc.c1[1][min(b.len(1) + 1, cfc.maxorder) - 2] : 0.0;
-    const double c1z = cf ? cfc.c1[2][min(b.len(2) + 1, cfc.maxorder) - 2] : 0.0;
+    CfDir cd;
+    if (cf) cd = cf_dir(b, cfc);
+    const double c1x = cf ? cd.c1[0] : 0.0, c1y = cf ? cd.c1[1] : 0.0, c1z = cf ? cd.c1[2] : 0.0;
     const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
     const double cf1 = (j == bc.dlo[1]) ? bc.cflo[0][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[0][1] : 0.0;
     auto load = [&](int k, Gs1Ops<BMODE>& o) {
@@ -321,8 +367,10 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
         const double res = o.r - (gamma * o.pc - rho);
         const double pn = o.pc + omega / g_m_d * res;
         phi(i, j, k, 0) = pn;
-        if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
-            cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
+        if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1)) {
+            const double nb[6] = {o.pxm, o.pxp, o.pym, o.pyp, o.pzm, o.pzp};
+            cf_maintain_nb(phi, cfm, b, cd, i, j, k, pn, nb);
+        }
     };
     for (int k = k0; k <= k1; k += NP) {
         Gs1Ops<BMODE> ops[NP];
@@ -350,7 +398,7 @@ __device__ __forceinline__ D2 ld2(const FabD& f, int i, int j, int k, int n)
     D2 r; r.l = v.x; r.r = v.y;
     return r;
 }
-template <int BMODE>
+template <int BMODE, bool CF>
 __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ sgt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
@@ -364,10 +412,11 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
     if (!tile_ijk(t, hb, ih, j, k0, k1)) return;
     const FabD phi = phit[fab], rhs = rhst[fab];
     // coarse/fine faces as in k_abec_gsrb: the ghost formula's first-interior-cell weight, and the ghost cells kept current (cf_maintain)
-    const bool cf = cfmt != nullptr;
+    constexpr bool cf = CF;
     FabD cfm; if (cf) cfm = cfmt[fab];
-    const double c1x = cf ? cfc.c1[0][min(b.len(0) + 1, cfc.maxorder) - 2] : 0.0, c1y = cf ? cfc.c1[1][min(b.len(1) + 1, cfc.maxorder) - 2] : 0.0;
-    const double c1z = cf ? cfc.c1[2][min(b.len(2) + 1, cfc.maxorder) - 2] : 0.0;
+    CfDir cd;
+    if (cf) cd = cf_dir(b, cfc);
+    const double c1x = cf ? cd.c1[0] : 0.0, c1y = cf ? cd.c1[1] : 0.0, c1z = cf ? cd.c1[2] : 0.0;
     FabD S; if (BMODE == 1) S = sgt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
@@ -440,8 +489,10 @@ __global__ void __launch_bounds__(256) k_abec_gsrb2(Tiling t, const BoxD* __rest
             const double res = rr - (gamma * p0 - rho);
             const double pn = p0 + omega / g_m_d * res;
             phi(i, j, k, 0) = pn;
-            if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1))
-                cf_maintain(phi, cfm, b, cfc, i, j, k, pn);
+            if (cf && cfc.maintain && (i <= b.lo[0] + 1 || i >= b.hi[0] - 1 || j <= b.lo[1] + 1 || j >= b.hi[1] - 1 || k <= b.lo[2] + 1 || k >= b.hi[2] - 1)) {
+                const double nb[6] = {pxm, pxp, pym, pyp, pzm, pzp};
+                cf_maintain_nb(phi, cfm, b, cd, i, j, k, pn, nb);
+            }
         }
         if (zero) { const int io = par ? iL : iR; if (io <= b.hi[0]) phi(io, j, k, 0) = 0.0; }
         pb = pc; pc = pa;
@@ -454,7 +505,7 @@ static bool abec_sig_on() { return tune("ABEC_SIG", 1) != 0; }
 
 bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wrap, bool has_cf)
 {
-    return tune("GSRB_ZERO", 1) != 0 && tune("GSRB1_NP", 2) > 0 && wrap && !has_cf && phi.ncomp == 1 && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta;
+    return tune("GSRB_ZERO", 1) != 0 && tune("GSRB1_NP", 1) > 0 && wrap && !has_cf && phi.ncomp == 1 && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta;
 }
 
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
@@ -481,30 +532,31 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     BUni bu;
     for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
     const bool uni = c.b_uniform && c.b[0]->ncomp == 1 && abec_sig_on();
-    // IAMRX_GSRB1_NP (2): planes in flight per thread of the pipelined one-component pass (0: the general kernel)
-    const int np = (int)tune("GSRB1_NP", 2);
+    // IAMRX_GSRB1_NP (1): planes in flight per thread of the pipelined one-component pass (0: the general kernel)
+    const int np = (int)tune("GSRB1_NP", 1);
     const int mode = (c.sig && abec_sig_on()) ? 1 : (uni ? 2 : 0);
     const bool pair_ok = mode != 0 && tune("GSRB2", 1) != 0 && phi.ngrow >= 1 && (mode == 2 || c.sig->ngrow >= 1);
     // with coarse/fine faces the pipelined form would read a ghost cell that cf_maintain rewrote for the plane before: one plane in flight
     if (np > 0 && phi.ncomp == 1 && !shell_only && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta) {
         const FabD *t0 = mode == 1 ? c.sig->d_tab : c.b[0]->d_tab, *t1 = mode == 1 ? c.sig->d_tab : c.b[1]->d_tab, *t2 = mode == 1 ? c.sig->d_tab : c.b[2]->d_tab;
-#define IAMRX_GS1(M, N) hipLaunchKernelGGL((k_abec_gsrb1<M, N>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab, \
+#define IAMRX_GS1(M, N) if (cft) IAMRX_GS1C(M, 1, true); else IAMRX_GS1C(M, N, false)
+#define IAMRX_GS1C(M, N, C) hipLaunchKernelGGL((k_abec_gsrb1<M, N, C>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab, \
                            c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero)
         // IAMRX_GSRB2 (1): the pair-marching kernel where the coefficients are not arrays (needs a ghost layer for its 16-byte loads)
         if (pair_ok) {
             int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
             Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
-            if (mode == 1)
-                hipLaunchKernelGGL((k_abec_gsrb2<1>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
-                                   c.sig->d_tab, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero);
-            else
-                hipLaunchKernelGGL((k_abec_gsrb2<2>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, c.a ? c.a->d_tab : nullptr,
-                                   nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bu, cft, cfc, zero);
+#define IAMRX_GS2(M, C, SG, SC, SS) hipLaunchKernelGGL((k_abec_gsrb2<M, C>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, \
+                                   c.a ? c.a->d_tab : nullptr, SG, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, SC, SS, bu, cft, cfc, zero)
+            if (mode == 1) { if (cft) IAMRX_GS2(1, true, c.sig->d_tab, c.sig_comp, c.sig_scale); else IAMRX_GS2(1, false, c.sig->d_tab, c.sig_comp, c.sig_scale); }
+            else { if (cft) IAMRX_GS2(2, true, nullptr, 0, 1.0); else IAMRX_GS2(2, false, nullptr, 0, 1.0); }
+#undef IAMRX_GS2
         }
-        else if (np >= 4 && !cft) { if (mode == 1) IAMRX_GS1(1, 4); else if (mode == 2) IAMRX_GS1(2, 4); else IAMRX_GS1(0, 4); }
-        else if (np >= 2 && !cft) { if (mode == 1) IAMRX_GS1(1, 2); else if (mode == 2) IAMRX_GS1(2, 2); else IAMRX_GS1(0, 2); }
-        else { if (mode == 1) IAMRX_GS1(1, 1); else if (mode == 2) IAMRX_GS1(2, 1); else IAMRX_GS1(0, 1); }
+        else if (np >= 4) { if (mode == 1) { IAMRX_GS1(1, 4); } else if (mode == 2) { IAMRX_GS1(2, 4); } else { IAMRX_GS1(0, 4); } }
+        else if (np >= 2) { if (mode == 1) { IAMRX_GS1(1, 2); } else if (mode == 2) { IAMRX_GS1(2, 2); } else { IAMRX_GS1(0, 2); } }
+        else { if (mode == 1) { IAMRX_GS1(1, 1); } else if (mode == 2) { IAMRX_GS1(2, 1); } else { IAMRX_GS1(0, 1); } }
 #undef IAMRX_GS1
+#undef IAMRX_GS1C
     }
     else if (phi.ncomp == 1 && c.sig && !c.tensor_eta && abec_sig_on())
         hipLaunchKernelGGL((k_abec_gsrb<false, 1>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
