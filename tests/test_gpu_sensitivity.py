@@ -58,7 +58,7 @@ KERNEL_FORMS = {
     "face coefficient arrays": {"ABEC_SIG": 0},
     # the general colour kernel instead of the lean (k_abec_gsrb1) and pair-marching (k_abec_gsrb2) ones
     "general colour kernel": {"GSRB2": 0, "GSRB1_NP": 0},
-    "lean kernel, one plane in flight": {"GSRB2": 0, "GSRB1_NP": 1},
+    "lean kernel, two planes in flight": {"GSRB2": 0, "GSRB1_NP": 2},
     "lean kernel, four planes in flight": {"GSRB2": 0, "GSRB1_NP": 4},
     "pair-marching, 4 planes per thread": {"GSRB2_TZ": 4},
     # residual and restriction as two passes, the residual of the convergence test by the one-cell-per-thread kernel, the correction
@@ -66,7 +66,7 @@ KERNEL_FORMS = {
     "unfused down-leg": {"RESID_RESTRICT": 0, "RESID_PAIRS": 0, "GSRB_ZERO": 0},
     "fused restriction only": {"RESID_PAIRS": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 2, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "channel_walls"])
