@@ -367,11 +367,13 @@ def main():
     ns = N.NavierStokes(g, lay, params, lib.mg_opts())
     ns.init_taylorgreen(1.0, 1.0, 1.0, a.c, 1.0)
     ns.post_init(-1.0)
-    # HIP events around every 8th finest-level launch of the two smoother kernels that lead the step's kernel time (k_abec_gsrb,
+    # HIP events around every 7th finest-level launch of the two smoother kernels that lead the step's kernel time (k_abec_gsrb,
     # k_nodal_gs4; profiles/round3_kernel_stats.csv), on their launch stream: opened during the warm-up (creates the event pools),
     # re-opened for the timed region and read after it -> roofline.avg_ms is measured inside the timed steps
     probe_on = world == 1 and os.environ.get("IAMRX_BENCH_PROBE", "1") != "0"
-    PROBES = {"gs4": (0, (n + 1) ** 3, 8), "gsrb": (1, n ** 3, 8), "god_z": (2, n ** 3, 1), "pred_z": (3, n ** 3, 1)}
+    # stride 7: a V-cycle issues 8 finest-level colour passes (the first of them the cheaper zero-initial-guess form), so a stride of 8 would
+    # time the same position of every cycle
+    PROBES = {"gs4": (0, (n + 1) ** 3, 7), "gsrb": (1, n ** 3, 7), "god_z": (2, n ** 3, 1), "pred_z": (3, n ** 3, 1)}
 
     def probes_start():
         for which, pts, stride in PROBES.values():
@@ -477,15 +479,15 @@ def main():
             own = 24.0 * cells
             ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
             gbps = alg / ms / 1e6
-            roofline = {"kernel": "k_abec_gsrb2<1> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
+            roofline = {"kernel": "k_abec_gsrb2<1, false> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
                                   "face coefficients recomputed from the cell-centred density; the dominant kernel of the step, "
                                   "profiles/round3_kernel_stats.csv)", "bound": "hbm",
                         "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                        "traffic": pmc_traffic("k_abec_gsrb2<1> grid=%d" % (n ** 3 // 64)),
+                        "traffic": pmc_traffic("k_abec_gsrb2<1, false> grid=%d" % (n ** 3 // 64)),
                         "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
                         "own_minimum_bytes_per_launch": own, "own_minimum_GBps": own / ms / 1e6, "frac_own_minimum": own / ms / 1e6 / 8000.0,
                         "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
-                        "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
+                        "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
                         "isolated_loop_ms_array_coefficients": gsrb_iso["ms"] / 2}
         dom = kr.get("nodal_gs4_launch")
         roofline_gs4 = None
@@ -500,7 +502,7 @@ def main():
                             "traffic": pmc_traffic("k_nodal_gs4<32, 16, 256, true, false, false> grid="),
                             "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
                             "launches_timed": gs4_insitu[1] if gs4_insitu else None,
-                            "timing": "HIP events around every 8th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
+                            "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
                             "isolated_loop_ms": dom["ms"]}
         # the Godunov kernels are bound by the vector pipe, not by HBM: both fractions are reported.  valu_frac =
         # wave-level vector instructions per launch (SQ_INSTS_VALU, third PMC pass of tools/collect_pmc.sh) / duration / the issue peak
