@@ -226,7 +226,9 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
 template <int TX, int TY, int NT, bool WRAP, bool MASK, bool CSIG>
 // no minimum-occupancy bound: measured at 256^3 on MI355X (profiles/round2_b_*), forcing 4 waves/SIMD on the variable-sigma variant (168 VGPRs
 // -> 128 + 41 spilled) costs 2x (325 us against 165 us per launch), 5-6 on the constant-sigma one (104 VGPRs) gains nothing / loses 35 %
-__global__ void __launch_bounds__(NT) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
+// the masked variant (levels with Dirichlet nodes: refined AMR levels, outflow faces) needs 181 VGPRs unconstrained -- 2 wavefronts per SIMD,
+// 230 us per 257^3 launch against 161 us for the unmasked one at 168 VGPRs / 3 wavefronts: it is held to 3 (a handful of spills)
+__global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk,
     const FabD* __restrict__ dmt, double csig, int ppc)
 {
@@ -485,6 +487,8 @@ template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
                        int kpar, bool wrap, const MultiFab* dmask, const double* csig)
 {
+    // (a "fat" last tile that takes the single leftover node column of a box of n = k TX cells along -- 8 x 16 instead of 9 x 17 tiles at 257^3
+    // nodes -- was measured: the two extra footprint columns / rows cost more (253 us) than the empty tiles (223 us))
     const int ntx = (l.max_len[0] + 1 + TX - 1) / TX, nty = (l.max_len[1] + 1 + TY - 1) / TY, npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
     const int nt = ntx * nty;
     // planes per workgroup (z-march): as long as the launch still fills the chip about twice over (256 CUs x 4-6 resident workgroups)
