@@ -9,6 +9,7 @@
 // The 27 stencil coefficients are written per neighbour class (corner / edge / face / centre): the
 // coefficient of a neighbour is w(class) * (sum of sigma over the cells shared with that neighbour).
 #include "kernels.h"
+#include <cstring>
 #include "launch.h"
 
 namespace iamrx {
@@ -52,10 +53,22 @@ __device__ __forceinline__ double node_Ax(const FabD& x, const FabD& s, const No
 // out = rhs - A x   (rhs null: out = A x).  z-marching: a workgroup owns a TXxTY column of nodes and walks KC planes; the
 // three x-planes and two sigma-planes it needs live in LDS (rolling), every plane is fetched from HBM once per column
 // (+ the 1-node halo ring), and the loads of plane k+2 are in flight while plane k is being evaluated.
+void nodal_residual_launch(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs, unsigned long long* d_norm);
+// normout != null: the launch also reduces the max norm of what it writes (wave maximum, one atomicMax per wavefront on the bit pattern of
+// the non-negative value, NaN -> +inf: order independent, hence deterministic; k_abec.hip's norm_commit)
+__device__ __forceinline__ void nodal_norm_commit(double mx, unsigned long long* out)
+{
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
 template <int TX, int TY>
 __global__ void __launch_bounds__(TX * TY) k_nodal_residual_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ ot, const FabD* __restrict__ xt,
-    const FabD* __restrict__ st, const FabD* __restrict__ rt, NodeW w, int ntx, int nty, int kc)
+    const FabD* __restrict__ st, const FabD* __restrict__ rt, NodeW w, int ntx, int nty, int kc, unsigned long long* __restrict__ normout)
 {
+    double mx = 0.0;
     constexpr int RX = TX + 2, RY = TY + 2, NT = TX * TY, NLD = (RX * RY + NT - 1) / NT;
     __shared__ double X[3][RY][RX];
     __shared__ double S[2][RY][RX];
@@ -128,13 +141,40 @@ __global__ void __launch_bounds__(TX * TY) k_nodal_residual_zm(const BoxD* __res
             y += w.fx * (X[a1][ly][lx - 1] * (smmm + smpm + smmp + smpp) + X[a1][ly][lx + 1] * (spmm + sppm + spmp + sppp));
             y += w.fy * (X[a1][ly - 1][lx] * (smmm + spmm + smmp + spmp) + X[a1][ly + 1][lx] * (smpm + sppm + smpp + sppp));
             y += w.fz * (X[a0][ly][lx] * (smmm + spmm + smpm + sppm) + X[a2][ly][lx] * (smmp + spmp + smpp + sppp));
-            o(i, j, k) = rt ? rt[fab](i, j, k) - y : y;
+            const double v = rt ? rt[fab](i, j, k) - y : y;
+            o(i, j, k) = v;
+            const double a = fabs(v);
+            mx = fmax(mx, a == a ? a : INFINITY);
         }
         __syncthreads();
     }
+    if (normout) nodal_norm_commit(mx, normout);
 }
 
-void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs)
+// norm_out != null: *norm_out = max norm of out over all ranks if the z-marching kernel ran (returns true); false: the caller computes it
+bool nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs, double* norm_out)
+{
+    auto& ctx = Context::get();
+    static unsigned long long* d_norm = nullptr;
+    if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, 2 * sizeof(unsigned long long)));
+    const Layout& lay = *x.layout;
+    const bool zm = tune("NODAL_RES_ZM", 1) != 0 && lay.max_len[0] >= 16 && lay.max_len[1] >= 8 && x.ngrow >= 1 && sig.ngrow >= 1;
+    const bool fused = norm_out && zm && tune("NODAL_RES_NORM", 1) != 0;
+    if (fused) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+    nodal_residual_launch(g, out, x, sig, rhs, fused ? d_norm : nullptr);
+    if (!fused) return false;
+    const bool global = !lay.replicated && ctx.comm->nranks > 1;
+    if (global) ctx.comm->allreduce_device(reinterpret_cast<double*>(d_norm), 1, ReduceOp::Max, ctx.stream);
+    unsigned long long bits = 0;
+    IAMRX_HIP_CHECK(hipMemcpyAsync(&bits, d_norm, sizeof(bits), hipMemcpyDeviceToHost, ctx.stream));
+    ctx.sync();
+    double v;
+    std::memcpy(&v, &bits, sizeof(v));
+    *norm_out = v;
+    return true;
+}
+
+void nodal_residual_launch(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs, unsigned long long* d_norm)
 {
     if (x.nlocal() == 0) return;
     const NodeW w = make_w(g);
@@ -149,7 +189,7 @@ void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const M
         const int kc = nk >= 128 ? 32 : (nk >= 32 ? 16 : nk);
         const int nck = (nk + kc - 1) / kc;
         dim3 grid((unsigned)(ntx * nty * nck), (unsigned)l.nlocal());
-        hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc);
+        hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc, d_norm);
         return;
     }
     for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {

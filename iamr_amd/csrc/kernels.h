@@ -121,7 +121,7 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
 
 
 // ---- k_nodal.hip --------------------------------------------------------------------------
-void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
+bool nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs, double* norm_out = nullptr);
 void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int color, const MultiFab* dmask = nullptr);
 // one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3), out of place: plane k from xc, planes
 // k+-1 from xn, result to xo (xo != xc; xn may be either)

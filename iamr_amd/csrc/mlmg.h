@@ -159,7 +159,7 @@ public:
     const MultiFab& sigma(int l) const { return m_lev[l].sig; }
     const Geometry& geom(int l) const { return m_lev[l].g; }
     void smooth(int l, MultiFab& x, const MultiFab& rhs);
-    void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b);
+    void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm = nullptr);   // norm: max norm of r (by the residual launch itself where it can)
     void vcycle(MGStats& st);
     // one V-cycle for the residual equation A e = r, zero initial guess; e is zero on Dirichlet nodes, its ghost nodes are filled.
     // Building block of the composite (multi-level) solver, amrns.hip.

@@ -10,7 +10,6 @@
 namespace iamrx {
 
 // kernels (k_nodal.hip)
-void nodal_residual(const Geometry& g, MultiFab& out, const MultiFab& x, const MultiFab& sig, const MultiFab* rhs);
 void nodal_restrict(MultiFab& crse, const MultiFab& fine);
 void nodal_interp_add(MultiFab& fine, const MultiFab& crse, const MultiFab& sig_fine);
 
@@ -213,11 +212,13 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
     fillbc(l, x);
 }
 
-void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b)
+void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm)
 {
     fillbc(l, x);
-    nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b);
-    if (m_lev[l].dmask()) nodal_zero_masked(r, m_lev[l].dm);
+    const bool masked = (bool)m_lev[l].dmask();
+    const bool have = nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b, (norm && !masked) ? norm : nullptr);
+    if (masked) nodal_zero_masked(r, m_lev[l].dm);
+    if (norm && !have) *norm = r.norm0(0, 1, 0);
 }
 
 void NodalMG::subtract_mean(int l, MultiFab& mf)
@@ -382,9 +383,8 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
     MultiFab::Copy(rhs, rhs_in, 0, 0, 1, 0);
     if (L0.dmask()) nodal_zero_masked(rhs, L0.dm);
     if (m_singular) subtract_mean(0, rhs);
-    residual(0, L0.res, phi, rhs);
+    residual(0, L0.res, phi, rhs, &st.resnorm0);
     L0.res_filled = false;
-    st.resnorm0 = L0.res.norm0(0, 1, 0);
     st.rhsnorm0 = rhs.norm0(0, 1, 0);
     const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
     const double res_target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
@@ -407,9 +407,8 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
             vcycle(st);
             cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, 1, 0);
-            residual(0, L0.res, phi, rhs);
+            residual(0, L0.res, phi, rhs, &st.resnorm);
             L0.res_filled = false;
-            st.resnorm = L0.res.norm0(0, 1, 0);
             st.iters = iter + 1;
             if (m_o.verbose) printf("iamrx nodal MLMG: iter %d resid %.6e\n", iter + 1, st.resnorm);
             if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
