@@ -479,11 +479,11 @@ def main():
             own = 24.0 * cells
             ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
             gbps = alg / ms / 1e6
-            roofline = {"kernel": "k_abec_gsrb2<1, false> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
+            roofline = {"kernel": "k_abec_gsrb2<1, false, false> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
                                   "face coefficients recomputed from the cell-centred density; the dominant kernel of the step, "
                                   "profiles/round3_kernel_stats.csv)", "bound": "hbm",
                         "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                        "traffic": pmc_traffic("k_abec_gsrb2<1, false> grid=%d" % (n ** 3 // 64)),
+                        "traffic": pmc_traffic("k_abec_gsrb2<1, false, false> grid=%d" % (n ** 3 // 64)),
                         "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
                         "own_minimum_bytes_per_launch": own, "own_minimum_GBps": own / ms / 1e6, "frac_own_minimum": own / ms / 1e6 / 8000.0,
                         "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
