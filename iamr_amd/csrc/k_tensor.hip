@@ -5,6 +5,7 @@
 // :858-923 (implicit solve); SURVEY a10, a11.
 #include "kernels.h"
 #include "launch.h"
+#include <cstring>
 #include <type_traits>
 #include <vector>
 #include <cstdlib>
@@ -123,11 +124,15 @@ struct LdsVel {
 
 struct EtaUni { double v[3]; };
 // UNI (with ETA1): the three face viscosities are the constants eu (the arrays are not read)
-template <bool ETA1, int TX, int TY, bool UNI = false>
+// FUSE (with UNI): the whole tensor residual / apply in this pass -- the 7-point part of the operator (k_abec_residual's expression for
+// b_d(comp) = eta_d (comp == d ? 4/3 : 1)) is formed from the velocity planes already in LDS, out = (rhs - y | y) + sbeta div(cross) is
+// written once: the three components are neither re-read from HBM nor written and read again in between.
+struct FuseArgs { const FabD* rhst; const FabD* at; double alpha, dhx, dhy, dhz; };
+template <bool ETA1, int TX, int TY, bool UNI = false, bool FUSE = false>
 __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ outt,
     const FabD* __restrict__ vt, const FabD* __restrict__ ext, const FabD* __restrict__ eyt, const FabD* __restrict__ ezt,
     double dxi, double dyi, double dzi, double sbeta, unsigned long long* __restrict__ normout, int ntx, int nty, int nkc, int kcs, int xcd_cnt,
-    EtaUni eu = EtaUni())
+    EtaUni eu = EtaUni(), FuseArgs fa = FuseArgs())
 {
     constexpr int NT = TX * TY, W = TX + 2, H = TY + 2, PS = W * H;
     __shared__ double V[3][3 * PS];
@@ -187,7 +192,18 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
             cross_flux<1, ETA1>(a, ey, i, j + 1, k, dxi, dyi, dzi, fyh);
             cross_flux<2, ETA1>(a, ez, i, j, k + 1, dxi, dyi, dzi, fzh);
             for (int n = 0; n < 3; ++n) {
-                const double o = out(i, j, k, n) + sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
+                double base;
+                if constexpr (FUSE) {
+                    const double p0 = a(i, j, k, n);
+                    const double bx = eu.v[0] * (n == 0 ? 4.0 / 3.0 : 1.0), by = eu.v[1] * (n == 1 ? 4.0 / 3.0 : 1.0), bz = eu.v[2] * (n == 2 ? 4.0 / 3.0 : 1.0);
+                    const double ax = fa.at ? fa.alpha * fa.at[fab](i, j, k, 0) * p0 : 0.0;
+                    const double y = ax
+                        - fa.dhx * (bx * (a(i + 1, j, k, n) - p0) - bx * (p0 - a(i - 1, j, k, n)))
+                        - fa.dhy * (by * (a(i, j + 1, k, n) - p0) - by * (p0 - a(i, j - 1, k, n)))
+                        - fa.dhz * (bz * (a(i, j, k + 1, n) - p0) - bz * (p0 - a(i, j, k - 1, n)));
+                    base = fa.rhst ? fa.rhst[fab](i, j, k, n) - y : y;
+                } else base = out(i, j, k, n);
+                const double o = base + sbeta * (dxi * (fxh[n] - fxl[n]) + dyi * (fyh[n] - fyl[n]) + dzi * (fzh[n] - fzl[n]));
                 out(i, j, k, n) = o;
                 const double ab = fabs(o);
                 mx = fmax(mx, ab == ab ? ab : INFINITY);
@@ -197,6 +213,52 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
         __syncthreads();
     }
     if (normout) tnorm_commit(mx, normout);
+}
+
+// out = (rhs - A vel | A vel) for the constant-viscosity tensor operator in one launch (k_tensor_cross_zm<.., FUSE>); false: not applicable,
+// the caller runs abec_residual (7-point part, then tensor_cross_terms_sub).  norm_out as in abec_residual.
+bool tensor_residual_fused(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, const MultiFab* rhs, double* norm_out)
+{
+    const Layout& l = *out.layout;
+    if (tune("TENSOR_FUSED", 1) == 0 || tune("TENSOR_CROSS_ZM", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
+    if (!c.tensor || !c.tensor_eta || !c.b_uniform || vel.ncomp != 3 || vel.ngrow < 1 || l.max_len[0] < 32 || l.max_len[1] < 8) return false;
+    auto& ctx = Context::get();
+    static unsigned long long* d_norm = nullptr;
+    if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, 2 * sizeof(unsigned long long)));
+    if (out.nlocal() > 0) {
+        if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        constexpr int TX = 32, TY = 8;
+        const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+        const int kcs = std::min(32, std::max(4, l.max_len[2] / 8));
+        const int nkc = (l.max_len[2] + kcs - 1) / kcs;
+        const int total = ntx * nty * nkc;
+        const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
+        dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal());
+        EtaUni eu;
+        for (int d = 0; d < 3; ++d) eu.v[d] = c.bu[d];
+        FuseArgs fa;
+        fa.rhst = rhs ? rhs->d_tab : nullptr;
+        fa.at = (c.a && c.alpha != 0.0) ? c.a->d_tab : nullptr;
+        fa.alpha = c.alpha;
+        fa.dhx = c.beta / (g.dx[0] * g.dx[0]); fa.dhy = c.beta / (g.dx[1] * g.dx[1]); fa.dhz = c.beta / (g.dx[2] * g.dx[2]);
+        hipLaunchKernelGGL((k_tensor_cross_zm<true, TX, TY, true, true>), grid, dim3(TX * TY), 0, ctx.stream, l.d_boxes, out.d_tab, vel.d_tab,
+                           c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], (rhs ? -1.0 : 1.0) * c.beta,
+                           norm_out ? d_norm : nullptr, ntx, nty, nkc, kcs, xcd_cnt, eu, fa);
+    }
+    if (norm_out) {
+        double v = 0.0;
+        const bool global = !l.replicated && ctx.comm->nranks > 1;
+        if (out.nlocal() == 0 && global) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        if (global) ctx.comm->allreduce_device(reinterpret_cast<double*>(d_norm), 1, ReduceOp::Max, ctx.stream);
+        if (out.nlocal() > 0 || global) {
+            unsigned long long bits = 0;
+            IAMRX_HIP_CHECK(hipMemcpyAsync(&bits, d_norm, sizeof(bits), hipMemcpyDeviceToHost, ctx.stream));
+            ctx.sync();
+            std::memcpy(&v, &bits, sizeof(v));
+        }
+        *norm_out = v;
+    }
+    return true;
 }
 
 // out += sign * beta * div(cross fluxes)

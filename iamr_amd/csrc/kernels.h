@@ -58,6 +58,8 @@ struct AbecCoef {
 };
 // every valid entry of component 0 of m equals one value (on all ranks): returns true and the value
 bool mf_uniform_value(const MultiFab& m, double* v);
+// the tensor operator's residual / apply in ONE launch where its viscosity is constant (k_tensor.hip); false: use abec_residual
+bool tensor_residual_fused(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, const MultiFab* rhs, double* norm_out);
 struct DomainBC {             // linear-operator BC of the level's domain
     int lo[3], hi[3];         // LinOpBC per face
     int maxorder;

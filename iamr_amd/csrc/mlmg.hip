@@ -30,6 +30,13 @@ CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc,
     m_lev[0].layout = std::move(layout);
 }
 
+// residual / apply of a level: the constant-viscosity tensor operator in one fused launch, everything else through abec_residual
+static void level_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab* rhs, double* norm_out = nullptr)
+{
+    if (c.tensor && tensor_residual_fused(g, c, out, phi, rhs, norm_out)) return;
+    abec_residual(g, c, out, phi, rhs, norm_out);
+}
+
 AbecCoef CellMG::coef(int l) const
 {
     AbecCoef c;
@@ -408,7 +415,7 @@ void CellMG::vcycle(MGStats& st)
             } else abec_resid_restrict(L.g, cl, m_lev[l + 1].res, L.cor, L.res);
             continue;
         }
-        abec_residual(L.g, cl, L.rescor, L.cor, &L.res);
+        level_residual(L.g, cl, L.rescor, L.cor, &L.res);
         if (m_lev[l + 1].agg) {
             cc_restrict(m_lev[l + 1].tmp_d, L.rescor);
             gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
@@ -436,7 +443,7 @@ void CellMG::apply(MultiFab& out, MultiFab& phi)
         cf_bcval(bcval);
         applyBC(0, phi, true, &bcval);
     } else applyBC(0, phi, true, nullptr);         // fully periodic, no coarse/fine faces: no boundary data to keep
-    abec_residual(m_lev[0].g, coef(0), out, phi, nullptr);
+    level_residual(m_lev[0].g, coef(0), out, phi, nullptr);
 }
 
 void CellMG::fluxes(MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_to[3])
@@ -471,7 +478,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     const MultiFab* bcvp = has_bcdata ? &bcval_own : nullptr;
 
     applyBC(0, phi, true, bcvp);
-    abec_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm0);      // the residual launch reduces its own max norm
+    level_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm0);      // the residual launch reduces its own max norm
     st.rhsnorm0 = rhs.norm0(0, nc, 0);
     const double max_norm = st.rhsnorm0 >= st.resnorm0 ? st.rhsnorm0 : st.resnorm0;
     const double res_target = std::max(atol, std::max(rtol, 1.e-16) * max_norm);
@@ -501,7 +508,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
             cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
             applyBC(0, phi, true, bcvp);
-            abec_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);
+            level_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);
             st.iters = iter + 1;
             if (m_o.verbose) printf("iamrx MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, st.resnorm, st.resnorm / max_norm);
             if (m_o.fixed_iters <= 0 && st.resnorm <= res_target) { st.converged = 1; break; }
