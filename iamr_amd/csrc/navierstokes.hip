@@ -404,11 +404,8 @@ static void floor_small(MultiFab& mf)
     });
 }
 
-void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
+void NavierStokes::compute_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
 {
-    const bool cache_on = tune("VISC_CACHE", 1) != 0;
-    const bool old_state = cache_on && m_in_advance && &Sdata == &S[1 - inew] && visc.ngrow <= 1;
-    if (old_state && m_visc_old_valid) { MultiFab::Copy(visc, m_visc_old, 0, 0, 3, visc.ngrow); return; }
     visc.setVal(1.e40);                                       // NavierStokes.cpp:1982
     if (!is_diffusive_vel()) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 3, 1);
@@ -422,11 +419,41 @@ void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
     MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
     visc.FillBoundary(g);
     first_order_extrap(visc);
-    if (old_state && visc.ngrow == 1) {
+}
+
+void NavierStokes::get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
+{
+    const bool cache_on = tune("VISC_CACHE", 1) != 0;
+    const bool old_state = cache_on && m_in_advance && &Sdata == &S[1 - inew] && visc.ngrow <= 1;
+    if (old_state) { MultiFab::Copy(visc, visc_terms_vel_old(visc), 0, 0, 3, visc.ngrow); return; }
+    compute_visc_terms_vel(visc, Sdata);
+}
+
+// the viscous terms of the old-time velocity inside an advance, one ghost cell: computed once per advance into the level's cache and
+// handed out by reference (the prediction, the advection forcing and the velocity update read them; none writes them); outside an advance
+// or with IAMRX_VISC_CACHE=0: computed into `scratch`
+const MultiFab& NavierStokes::visc_terms_vel_old(MultiFab& scratch)
+{
+    const bool cache_on = tune("VISC_CACHE", 1) != 0;
+    if (!(cache_on && m_in_advance)) {
+        if (!scratch.defined()) scratch.define(layout, cell_type(), 3, 1);
+        compute_visc_terms_vel(scratch, S[1 - inew]);
+        return scratch;
+    }
+    if (!m_visc_old_valid) {
         if (!m_visc_old.defined() || m_visc_old.layout.get() != layout.get()) m_visc_old.define(layout, cell_type(), 3, 1);
-        MultiFab::Copy(m_visc_old, visc, 0, 0, 3, 1);
+        compute_visc_terms_vel(m_visc_old, S[1 - inew]);
         m_visc_old_valid = true;
     }
+    return m_visc_old;
+}
+
+const MultiFab& NavierStokes::old_visc_or_zero(MultiFab& scratch)
+{
+    if (p.be_cn_theta != 1.0) return visc_terms_vel_old(scratch);
+    scratch.define(layout, cell_type(), 3, 1);       // fully implicit: no explicit viscous terms
+    scratch.setVal(0.0);
+    return scratch;
 }
 
 // NavierStokes::getViscTerms for the tracer (Diffusion::getViscTerms, rho_flag 0): visc = div(beta grad S(time))
@@ -552,8 +579,8 @@ double NavierStokes::predict_velocity(double dt_)
     const double tempdt = cflmax == 0 ? p.change_max : std::min(p.change_max, p.cfl / cflmax);
     // NavierStokesBase.cpp:4417-4422: on a refined level the ghost cells of the old Gradp are re-filled, the coarse data have changed
     if (level > 0) fill_gp(Gp[1 - pnew], 0.5 * (pt_old[0] + pt_old[1]));
-    MultiFab visc(layout, cell_type(), 3, 1);
-    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    MultiFab visc_s;
+    const MultiFab& visc = old_visc_or_zero(visc_s);
     MultiFab Smf(layout, cell_type(), nscal, 3);
     fillpatch(Smf, So, Density, nscal, bc_scal);
     MultiFab tf(layout, cell_type(), 3, 1);
@@ -694,8 +721,8 @@ void NavierStokes::velocity_advection(double dt_)
     }
     MultiFab Smf(layout, cell_type(), nscal, 1);
     fillpatch(Smf, So, Density, nscal, bc_scal);
-    MultiFab visc(layout, cell_type(), 3, 1);
-    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    MultiFab visc_s;
+    const MultiFab& visc = old_visc_or_zero(visc_s);
     MultiFab tf(layout, cell_type(), 3, 1), divu;
     divu_half(divu, dt_, 1, true);                               // NavierStokesBase.cpp:3377, 3421-3424
     {
@@ -780,13 +807,13 @@ void NavierStokes::advection_all(double dt_)
             for (int n = 0; n < ns_; ++n) { const double v = st[f](i, j, k, n); qt[f](i, j, k, Density + n) = fabs(v) <= 1.e-20 ? 0.0 : v; }   // floor_small
         });
     }
-    MultiFab visc(layout, cell_type(), 3, 1), svisc(layout, cell_type(), nscal, 1);
+    MultiFab visc_s, svisc(layout, cell_type(), nscal, 1);
     svisc.setVal(0.0);
+    const MultiFab& visc = old_visc_or_zero(visc_s);
     if (p.be_cn_theta != 1.0) {
-        get_visc_terms_vel(visc, So);
         MultiFab one(layout, cell_type(), 1, 1);
         for (int n = 1; n < nscal; ++n) { get_visc_terms_scalar(one, So, Density + n); MultiFab::Copy(svisc, one, 0, n, 1, 1); }
-    } else visc.setVal(0.0);
+    }
     ScalForm sf;                                 // per scalar slot: 0 convective, 1 conservative, 2 temperature
     for (int n = 0; n < MAXSCAL; ++n) sf.form[n] = (n < nscal && Density + n == Temp) ? 2 : (scal_cons[n] ? 1 : 0);
     MultiFab tf(layout, cell_type(), nstate, 1), divu;
@@ -957,8 +984,8 @@ void NavierStokes::initial_velocity_diffusion_update(double dt_)
     if (!is_diffusive_vel()) return;
     SectionTimer tm(*this, 4);
     MultiFab& So = S[1 - inew];
-    MultiFab visc(layout, cell_type(), 3, 1);
-    if (p.be_cn_theta != 1.0) get_visc_terms_vel(visc, So); else visc.setVal(0.0);
+    MultiFab visc_s;
+    const MultiFab& visc = old_visc_or_zero(visc_s);
     const FabD *nt = S[inew].d_tab, *ot = So.d_tab, *at = aofs.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_half.d_tab, *vt = visc.d_tab;
     const double grav = p.gravity;
     const bool mom = p.do_mom_diff != 0;

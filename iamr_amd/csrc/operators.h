@@ -327,6 +327,9 @@ private:
     double m_stop_time = -1.0;
     void initial_sync_project(double dt);
     void get_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
+    void compute_visc_terms_vel(MultiFab& visc, MultiFab& Sdata);
+    const MultiFab& visc_terms_vel_old(MultiFab& scratch);
+    const MultiFab& old_visc_or_zero(MultiFab& scratch);
     void advection_all(double dt);
     void fillpatch(MultiFab& dst, const MultiFab& src, int scomp, int ncomp, const BCRec* bc);
     bool is_diffusive_vel() const { return p.visc_coef > 0.0; }
