@@ -448,11 +448,17 @@ int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
 {
     IAMRX_TRY
     Geometry gg = to_geom(g);
-    if (fused == 3) {
-        // timing aid: the two k_nodal_gs4 launches of a sweep alone (no ghost fills, result left in a scratch buffer)
-        MultiFab xb(phi->mf.layout, node_type(), 1, phi->mf.ngrow);
-        nodal_gs_fused_pass(gg, phi->mf, phi->mf, xb, rhs->mf, sig->mf, 0);
-        nodal_gs_fused_pass(gg, phi->mf, xb, xb, rhs->mf, sig->mf, 1);
+    if (fused == 3 || fused == 4) {
+        // timing aid: the two smoother launches of a sweep alone (no ghost fills, result left in a scratch buffer); 4: with the index wrap
+        // of a single box that spans a periodic domain
+        static MultiFab xb;
+        if (!xb.defined() || xb.layout != phi->mf.layout || xb.ngrow != phi->mf.ngrow) xb.define(phi->mf.layout, node_type(), 1, phi->mf.ngrow);
+        const bool wrap = fused == 4;
+        if (wrap && !periodic_wrap_ok(gg, *phi->mf.layout, 4)) throw Error("iamrx_nodal_gs_sweep(4): not a single box spanning a periodic domain");
+        // IAMRX_BENCH_CSIG = c != 0: the constant-sigma variant with sigma = c (the caller's sigma array holds that constant)
+        const double cs = tune("BENCH_CSIG", 0.0);
+        nodal_gs_fused_pass(gg, phi->mf, phi->mf, xb, rhs->mf, sig->mf, 0, wrap, nullptr, cs != 0.0 ? &cs : nullptr);
+        nodal_gs_fused_pass(gg, phi->mf, xb, xb, rhs->mf, sig->mf, 1, wrap, nullptr, cs != 0.0 ? &cs : nullptr);
     } else if (fused == 2) {
         if (!nodal_smooth_small(gg, phi->mf, rhs->mf, sig->mf, 1)) throw Error("level does not qualify for the single-workgroup smoother");
         phi->mf.FillBoundary(gg);

@@ -10,6 +10,7 @@
 // coefficient of a neighbour is w(class) * (sum of sigma over the cells shared with that neighbour).
 #include "kernels.h"
 #include <cstring>
+#include <type_traits>
 #include "launch.h"
 
 namespace iamrx {
@@ -471,6 +472,339 @@ __global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(c
 #undef COL
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Register-resident form of the plane-fused pass (k_nodal_gsr): the same four colour updates of one k-parity on the same
+// shrinking regions as k_nodal_gs4, hence the same doubles, but the planes live in REGISTERS, not in LDS.
+//   * A workgroup owns a 64 x 64 footprint of nodes (tile of <= 56 x 56 + the 4-node halo of the recompute) and marches through ppc
+//     planes of its parity.  A thread owns a 2 (x) by PB (y) patch of that footprint for the whole march: x at the planes k-1, k, k+1,
+//     sigma at the cell planes k-1, k and the right-hand side of its nodes are registers.  The patch holds PB/2 nodes of every in-plane
+//     colour, so every lane updates PB/2 nodes in every colour pass (k_nodal_gs4: at most one node per thread and pass, 50-80 % of the lanes).
+//   * x-neighbours outside the patch are the adjacent lane's registers: one DPP wave shift (v_mov_b32_dpp wave_shr:1 / wave_shl:1) per
+//     dword -- a vector move, no LDS traffic.  A wavefront is two rows of 32 lanes; lanes 0 / 32 (31 / 63) receive a value of the other
+//     row, but they own the footprint's first (last) node column, which is read-only.
+//   * y-neighbours outside the patch (the row above its first row, needed by the colours with even j, and the row below its last row,
+//     needed by the colours with odd j) are the only LDS traffic: every thread publishes the first and last row of its patch -- the
+//     static planes k-1, k+1 and sigma once per plane, plane k's first row again after the two even-j passes -- into parity-split rows
+//     (conflict-free for the stride-2 access of a colour pass).  9-13 LDS reads per two node updates instead of 35 per node, two barriers
+//     per plane instead of five.
+//   * the loads of the next plane (two x planes, two sigma planes) are issued before the colour passes of the current one.
+// HBM sees each plane once per 56 x 56 tile: footprint / tile = 1.31 (k_nodal_gs4: 40 x 24 / 32 x 16 = 1.875).
+__device__ __forceinline__ double gsr_lane_lo(double v)      // the value lane - 1 holds
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);     // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double gsr_lane_hi(double v)      // the value lane + 1 holds
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);     // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct GsrGeom {
+    int ntx, nty;       // tiles per box and direction
+    int tix, tiy;       // tile pitch (even, <= 56)
+    int ppc;            // planes of one parity per workgroup
+    int xcd_chunk;      // > 0: XCD-aware order, chunks per tile
+};
+
+// the update of one node, k_nodal_gs4's expression tree: x?[db + 1][da + 1] = x(i + da, j + db, plane), s?[db + 1][da + 1] = sigma of
+// the cell (i + da, j + db, plane), da, db in {-1, 0}
+__device__ __forceinline__ double gsr_update(const NodeW& w, const double (&xm)[3][3], const double (&xc)[3][3], const double (&xp)[3][3],
+                                             const double (&sm)[2][2], const double (&sp)[2][2], double rr)
+{
+    const double smmm = sm[0][0], spmm = sm[0][1], smpm = sm[1][0], sppm = sm[1][1];
+    const double smmp = sp[0][0], spmp = sp[0][1], smpp = sp[1][0], sppp = sp[1][1];
+    const double s0 = w.c * (smmm + spmm + smpm + sppm + smmp + spmp + smpp + sppp);
+    const double x0 = xc[1][1];
+    double y = x0 * s0;
+    y += w.corner * (xm[0][0] * smmm + xm[0][2] * spmm + xm[2][0] * smpm + xm[2][2] * sppm
+                   + xp[0][0] * smmp + xp[0][2] * spmp + xp[2][0] * smpp + xp[2][2] * sppp);
+    y += w.ex * (xm[0][1] * (smmm + spmm) + xm[2][1] * (smpm + sppm) + xp[0][1] * (smmp + spmp) + xp[2][1] * (smpp + sppp));
+    y += w.ey * (xm[1][0] * (smmm + smpm) + xm[1][2] * (spmm + sppm) + xp[1][0] * (smmp + smpp) + xp[1][2] * (spmp + sppp));
+    y += w.ez * (xc[0][0] * (smmm + smmp) + xc[0][2] * (spmm + spmp) + xc[2][0] * (smpm + smpp) + xc[2][2] * (sppm + sppp));
+    y += w.fx * (xc[1][0] * (smmm + smpm + smmp + smpp) + xc[1][2] * (spmm + sppm + spmp + sppp));
+    y += w.fy * (xc[0][1] * (smmm + spmm + smmp + spmp) + xc[2][1] * (smpm + sppm + smpp + sppp));
+    y += w.fz * (xm[1][1] * (smmm + spmm + smpm + sppm) + xp[1][1] * (smmp + spmp + smpp + sppp));
+    return x0 + (rr - y) / s0;
+}
+
+template <int PB, bool WRAP, bool MASK, bool CSIG>
+__global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
+    const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, GsrGeom gg,
+    const FabD* __restrict__ dmt, double csig)
+{
+#if defined(__HIP_DEVICE_COMPILE__)    // (the host pass has no global address space: FabD::gp)
+    constexpr int NTR = 64 / PB;              // thread rows of the footprint
+    constexpr int HX = 34, RP = 2 * HX;       // parity-split row of the 64 columns + one pad column on each side
+    constexpr int NSL = NTR + 2;              // row slots: slot q + 1 belongs to thread row q
+    constexpr int BUF = NSL * RP;
+    // last rows of the patches (read as "row -1" by the thread row below): x planes k-1, k, k+1
+    __shared__ double XB[3 * BUF];
+    // first rows of the patches (read as "row PB" by the thread row above); written between the two barriers of a plane, read after the second
+    __shared__ double XT[3 * BUF];
+    // sigma lives in LDS, not in registers: a ring of three cell planes of the footprint (two in use, the third receives plane k + 1 while
+    // plane k is smoothed; plane k + 2 replaces k - 1 behind the barrier that ends plane k).  Row r, column c of the footprint sits at
+    // (r + 1) * 64 + (c & 1) * 32 + (c >> 1): parity-split columns (conflict-free stride-2 access of a colour pass), one pad row for "row -1"
+    // of the first thread row; column -1 of the first lane falls on the last even column of the same row (a value no update uses).
+    constexpr int SPL = 65 * 64;
+    __shared__ double SG[CSIG ? 1 : 3 * SPL];
+    const int fab = blockIdx.y;
+    const BoxD cb = boxes[fab];
+    int tix, tiy, pk;
+    {
+        const int nt = gg.ntx * gg.nty;
+        int t;
+        if (gg.xcd_chunk > 0) {
+            // workgroup b runs on XCD b % 8 (speed only): XCD q takes the contiguous range [q, q + 1) * total / 8 of the (chunk, tile)
+            // list -- tiles of one z-chunk, which march through the same planes at the same time and share their halo, meet in one L2
+            const int q = blockIdx.x & 7, m = blockIdx.x >> 3;
+            const int tot = nt * gg.xcd_chunk;
+            const int lo = (int)(((long)q * tot) >> 3), cnt = (int)((((long)q + 1) * tot) >> 3) - lo;
+            if (m >= cnt) return;
+            t = lo + m;
+        } else t = blockIdx.x;
+        pk = t / nt;
+        const int tt = t - pk * nt;
+        tix = tt % gg.ntx; tiy = tt / gg.ntx;
+    }
+    const int kfirst = cb.lo[2] + (((cb.lo[2] & 1) != kpar) ? 1 : 0);
+    const int k0 = kfirst + 2 * pk * gg.ppc;
+    const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;   // last valid node
+    // tiles start on even nodes: the in-plane colour of patch node (a, b) is then (a, b & 1) for every thread
+    const int tx0 = (cb.lo[0] & ~1) + tix * gg.tix, ty0 = (cb.lo[1] & ~1) + tiy * gg.tiy;
+    if (k0 > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
+    const int kend = min(k0 + 2 * (gg.ppc - 1), nhi2);
+    const int txs = max(tx0, cb.lo[0]), txe = min(tx0 + gg.tix - 1, nhi0), tys = max(ty0, cb.lo[1]), tye = min(ty0 + gg.tiy - 1, nhi1);
+    const FabD x = xct[fab], xn = xnt[fab], xo = xot[fab], r = rt[fab], s = st[fab];
+    const int ox = tx0 - 4, oy = ty0 - 4;
+    const int tid = threadIdx.x, lane = tid & 63, lx = lane & 31, q = (tid >> 6) * 2 + (lane >> 5);
+    // margins: node (a, b) belongs to the region of colour pass c (tile grown by 3 - c) iff min(mx[a], my[b]) >= c; to the tile iff >= 3
+    int mx[2], my[PB];
+    // byte offsets (unsigned 32 bit: the loads take a uniform plane pointer + a 32-bit lane offset, no 64-bit address registers)
+    unsigned xcol[2], scol[2], rcol[2], dcol[2], xrow[PB], srow[PB], rrow[PB], drow[PB];
+    unsigned surf = 0;      // MASK: bit b * 2 + a: node on the box surface or outside the box in x or y (only those can be Dirichlet nodes)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int gi = ox + 2 * lx + a;
+        mx[a] = min(gi - (txs - 3), (txe + 3) - gi);
+        int xi, si;
+        if constexpr (WRAP) { xi = wrap_node(gi, cb.lo[0], cb.hi[0]); si = wrap_cell(gi, cb.lo[0], cb.hi[0]); }
+        else { xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); }
+        xcol[a] = 8u * (unsigned)(xi - x.lo[0]);
+        scol[a] = CSIG ? 0u : 8u * (unsigned)(si - s.lo[0]);
+        rcol[a] = 8u * (unsigned)(min(max(xi, r.lo[0]), r.lo[0] + r.n[0] - 1) - r.lo[0]);
+        if constexpr (MASK) {
+            dcol[a] = 8u * (unsigned)(min(max(gi, dmt[fab].lo[0]), dmt[fab].lo[0] + dmt[fab].n[0] - 1) - dmt[fab].lo[0]);
+            if (gi <= cb.lo[0] || gi >= nhi0) surf |= 0x55555555u << a;
+        } else dcol[a] = 0;
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int gj = oy + PB * q + b;
+        my[b] = min(gj - (tys - 3), (tye + 3) - gj);
+        int xj, sj;
+        if constexpr (WRAP) { xj = wrap_node(gj, cb.lo[1], cb.hi[1]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]); }
+        else { xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1); }
+        xrow[b] = 8u * (unsigned)((xj - x.lo[1]) * x.n[0]);
+        srow[b] = CSIG ? 0u : 8u * (unsigned)((sj - s.lo[1]) * s.n[0]);
+        rrow[b] = 8u * (unsigned)((min(max(xj, r.lo[1]), r.lo[1] + r.n[1] - 1) - r.lo[1]) * r.n[0]);
+        if constexpr (MASK) {
+            drow[b] = 8u * (unsigned)((min(max(gj, dmt[fab].lo[1]), dmt[fab].lo[1] + dmt[fab].n[1] - 1) - dmt[fab].lo[1]) * dmt[fab].n[0]);
+            if (gj <= cb.lo[1] || gj >= nhi1) surf |= 3u << (2 * b);
+        } else drow[b] = 0;
+    }
+    // bit 2 PB c + 2 b + a: node (a, b) belongs to the region of colour pass c (the tile grown by 3 - c nodes); c = 3: to the tile itself
+    unsigned um[(8 * PB + 31) / 32];
+#pragma unroll
+    for (int i = 0; i < (8 * PB + 31) / 32; ++i) um[i] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int bit = 2 * PB * c + 2 * b + a;
+                if (mx[a] >= c && my[b] >= c) um[bit >> 5] |= 1u << (bit & 31);
+            }
+    const int xks = x.n[0] * x.n[1], sks = s.n[0] * s.n[1], rks = r.n[0] * r.n[1];
+    int dks = 0;
+    if constexpr (MASK) dks = dmt[fab].n[0] * dmt[fab].n[1];
+    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_node(kk, cb.lo[2], cb.hi[2]); return (long)(kk - x.lo[2]) * xks; };
+    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_cell(kk, cb.lo[2], cb.hi[2]); return (long)(kk - s.lo[2]) * sks; };
+    // LDS slots of this thread: own row slot q + 1, columns 2 lx (even half) and 2 lx + 1 (odd half); column c sits at
+    // ((c + 2) & 1) * HX + ((c + 2) >> 1)
+    const int lown = (q + 1) * RP + lx + 1;           // + HX: the odd column
+    const int lup = q * RP + lx, ldn = (q + 2) * RP + lx;
+    // column 2 lx + t, t in {-1, 0, 1, 2}, of a row whose base (slot * RP + lx) is given
+    auto lcol = [](int base, int t) { return base + (t & 1) * HX + 1 + (t >> 1); };
+
+    double Xm[PB][2], Xc[PB][2], Xp[PB][2], R[PB][2];
+    unsigned fixedm = 0;                               // MASK: Dirichlet nodes of the current plane
+    typedef const __attribute__((address_space(1))) char gbyte;
+    auto gat = [](const FabD::gdouble* plane, unsigned byteoff) -> FabD::gdouble& {
+        return *(FabD::gdouble*)((gbyte*)plane + (size_t)byteoff);
+    };
+    auto load_plane = [&](const FabD::gdouble* p, long koff, const unsigned (&col)[2], const unsigned (&row)[PB], double (&dst)[PB][2]) {
+        const FabD::gdouble* pp = p + koff;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) { dst[b][0] = gat(pp, row[b] + col[0]); dst[b][1] = gat(pp, row[b] + col[1]); }
+    };
+    auto load_mask = [&](int k) -> unsigned {
+        unsigned f = 0;
+        if constexpr (MASK) {
+            const unsigned need = (k <= cb.lo[2] || k >= nhi2) ? 0xffffffffu : surf;
+            if (need) {
+                const FabD::gdouble* pd = dmt[fab].gp() + (long)(k - dmt[fab].lo[2]) * dks;
+#pragma unroll
+                for (int b = 0; b < PB; ++b)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if ((need >> (2 * b + a)) & 1u) f |= (gat(pd, drow[b] + dcol[a]) != 0.0 ? 1u : 0u) << (2 * b + a);
+            }
+        }
+        return f;
+    };
+    auto load_rhs = [&](int k, int par) {
+        const FabD::gdouble* pr = r.gp() + (long)(k - r.lo[2]) * rks;
+#pragma unroll
+        for (int b = par; b < PB; b += 2) { R[b][0] = gat(pr, rrow[b] + rcol[0]); R[b][1] = gat(pr, rrow[b] + rcol[1]); }
+    };
+    // sigma ring: element of the own cell (a, b) of ring slot sl: sl * SPL + sgo + (b + 1) * 64 + a * 32
+    const int sgo = PB * q * 64 + lx;
+    auto ring_store = [&](int sl, const double (&T)[PB][2]) {
+        double* d = SG + sl * SPL + sgo;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) { d[(b + 1) * 64] = T[b][0]; d[(b + 1) * 64 + 32] = T[b][1]; }
+    };
+    int slm = 0, slp = 1, slf = 2;                     // ring slots of the sigma planes k - 1, k and the free one
+    double T1[PB][2];                                  // a sigma plane on its way from HBM to the ring
+    load_plane(xn.gp(), xk(k0 - 1), xcol, xrow, Xm);
+    load_plane(x.gp(), xk(k0), xcol, xrow, Xc);
+    load_plane(xn.gp(), xk(k0 + 1), xcol, xrow, Xp);
+    if constexpr (!CSIG) {
+        double T0[PB][2];
+        load_plane(s.gp(), sk(k0 - 1), scol, srow, T0); load_plane(s.gp(), sk(k0), scol, srow, T1);
+        ring_store(slm, T0); ring_store(slp, T1);
+    }
+    load_rhs(k0, 0); load_rhs(k0, 1);
+    fixedm = load_mask(k0);
+
+    for (int k = k0;; k += 2) {
+        const bool has_next = k + 2 <= kend;
+        // prefetch of plane k + 2 in two halves: the sigma cell plane k + 1 now; sigma k + 2 and the x planes k + 2, k + 3 after the even-j passes
+        double Nc[PB][2], Np[PB][2];
+        if constexpr (!CSIG) { if (has_next) load_plane(s.gp(), sk(k + 1), scol, srow, T1); }
+        // publish the patch's last row (planes k-1, k, k+1)
+        XB[lown] = Xm[PB - 1][0]; XB[lown + HX] = Xm[PB - 1][1];
+        XB[BUF + lown] = Xc[PB - 1][0]; XB[BUF + lown + HX] = Xc[PB - 1][1];
+        XB[2 * BUF + lown] = Xp[PB - 1][0]; XB[2 * BUF + lown + HX] = Xp[PB - 1][1];
+        __syncthreads();
+        const double* SGm = SG + (CSIG ? 0 : slm * SPL + sgo);
+        const double* SGp = SG + (CSIG ? 0 : slp * SPL + sgo);
+        auto pass = [&](auto cxc, auto cyc) {
+            constexpr int CX = decltype(cxc)::value, CY = decltype(cyc)::value, c = CX + 2 * CY;
+            // the column outside the patch on the side of the nodes of this pass is the adjacent lane's: one DPP shift per value, on demand
+            auto fx = [&](const double (&P)[PB][2], int bb) { if constexpr (CX == 0) return gsr_lane_lo(P[bb][1]); else return gsr_lane_hi(P[bb][0]); };
+            // the row outside the patch: LDS (row -1 for the even-j colours, row PB for the odd-j ones)
+            double em[3], ec[3], ep[3];
+            {
+                const int base = CY == 0 ? lup : ldn;
+                const double* Bx = CY == 0 ? XB : XT;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int o = lcol(base, CX + d - 1);
+                    em[d] = Bx[o]; ec[d] = Bx[BUF + o]; ep[d] = Bx[2 * BUF + o];
+                }
+            }
+#pragma unroll
+            for (int n_ = 0; n_ < PB / 2; ++n_) {
+                // the node next to the row that came from LDS first: its values die with it
+                const int n = CY == 0 ? n_ : PB / 2 - 1 - n_;
+                const int b = CY + 2 * n;
+                double vm[3][3], vc[3][3], vp[3][3], tm[2][2], tp[2][2];
+#pragma unroll
+                for (int db = -1; db <= 1; ++db)
+#pragma unroll
+                    for (int da = -1; da <= 1; ++da) {
+                        const int bb = b + db, aa = CX + da;
+                        double m_, c_, p_;
+                        if (bb < 0 || bb >= PB) { m_ = em[da + 1]; c_ = ec[da + 1]; p_ = ep[da + 1]; }
+                        else if (aa < 0 || aa > 1) { m_ = fx(Xm, bb); c_ = fx(Xc, bb); p_ = fx(Xp, bb); }
+                        else { m_ = Xm[bb][aa]; c_ = Xc[bb][aa]; p_ = Xp[bb][aa]; }
+                        vm[db + 1][da + 1] = m_; vc[db + 1][da + 1] = c_; vp[db + 1][da + 1] = p_;
+                    }
+#pragma unroll
+                for (int db = -1; db <= 0; ++db)
+#pragma unroll
+                    for (int da = -1; da <= 0; ++da) {
+                        if constexpr (CSIG) { tm[db + 1][da + 1] = csig; tp[db + 1][da + 1] = csig; }
+                        else {
+                            const int aa = CX + da;        // cell column -1, 0 or 1 of the patch
+                            const int o = (b + db + 1) * 64 + (aa < 0 ? 31 : aa * 32);
+                            tm[db + 1][da + 1] = SGm[o]; tp[db + 1][da + 1] = SGp[o];
+                        }
+                    }
+                double nv = gsr_update(w, vm, vc, vp, tm, tp, R[b][CX]);
+                // evaluated by every lane: a branch around the arithmetic would keep all lane-shifted operands (which must be formed
+                // under the full EXEC mask) alive across it; the fence also keeps the updates of a pass from being interleaved
+                // beyond what the register file holds
+#ifdef IAMRX_GSR_FENCE
+                if ((n_ % IAMRX_GSR_FENCE) == IAMRX_GSR_FENCE - 1) asm volatile("" : "+v"(nv));
+#endif
+                const int ubit = 2 * PB * c + 2 * b + CX;
+                bool upd = ((um[ubit >> 5] >> (ubit & 31)) & 1u) != 0;
+                if constexpr (MASK) upd = upd && !((fixedm >> (2 * b + CX)) & 1u);
+                Xc[b][CX] = upd ? nv : Xc[b][CX];
+            }
+        };
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        // the patch's first row: plane k now holds its colour-0 and colour-1 values, which the odd-j passes of the thread row above read.
+        // (every wavefront is past the first barrier: nobody reads the first rows of the previous plane any more)
+        XT[lown] = Xm[0][0]; XT[lown + HX] = Xm[0][1];
+        XT[BUF + lown] = Xc[0][0]; XT[BUF + lown + HX] = Xc[0][1];
+        XT[2 * BUF + lown] = Xp[0][0]; XT[2 * BUF + lown + HX] = Xp[0][1];
+        if (has_next) {
+            // right-hand side of the next plane: the even rows are free now, the odd rows after the odd-j passes
+            load_rhs(k + 2, 0);
+            if constexpr (!CSIG) {
+                ring_store(slf, T1);                                  // sigma plane k + 1: into the free slot
+                load_plane(s.gp(), sk(k + 2), scol, srow, T1);
+            }
+            load_plane(x.gp(), xk(k + 2), xcol, xrow, Nc);
+            load_plane(xn.gp(), xk(k + 3), xcol, xrow, Np);
+        }
+        __syncthreads();
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        if (has_next) load_rhs(k + 2, 1);
+        {
+            FabD::gdouble* po = xo.gp() + xk(k);
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if ((um[(2 * PB * 3 + 2 * b + a) >> 5] >> ((2 * PB * 3 + 2 * b + a) & 31)) & 1u) gat(po, xrow[b] + xcol[a]) = Xc[b][a];
+        }
+        if (!has_next) break;
+        // every wavefront is done with the sigma planes k - 1, k and the first rows of this plane
+        __syncthreads();
+        if constexpr (!CSIG) ring_store(slm, T1);                     // sigma plane k + 2 replaces k - 1
+        { const int t = slm; slm = slf; slf = slp; slp = t; }
+        // rotate: k + 1 becomes the k - 1 plane
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { Xm[b][a] = Xp[b][a]; Xc[b][a] = Nc[b][a]; Xp[b][a] = Np[b][a]; }
+        fixedm = load_mask(k + 2);
+    }
+#endif
+}
+
 // HIP-event probes around selected kernel launches (kernels.h: kernel_probe_*), on the launch stream, so that the roofline figures of the
 // dominant kernels are measured inside the running time step (bench.py)
 namespace {
@@ -561,6 +895,53 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     if (rec) kernel_probe_end(PROBE_NODAL_GS4);
 }
 
+// tiles of k_nodal_gsr: the fewest tiles of at most 56 nodes that cover the largest box (starting on an even node), equal even pitch
+static void gsr_tiles(int len_nodes, int& nt, int& pitch)
+{
+    const int span = len_nodes + 1;               // the first tile starts on the even node <= lo
+    nt = (span + 55) / 56;
+    pitch = (span + nt - 1) / nt;
+    pitch += pitch & 1;
+}
+
+template <int PB>
+static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig)
+{
+    GsrGeom gg;
+    gsr_tiles(l.max_len[0] + 1, gg.ntx, gg.tix);
+    gsr_tiles(l.max_len[1] + 1, gg.nty, gg.tiy);
+    const int npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
+    const int nt = gg.ntx * gg.nty;
+    // z-chunks: one resident workgroup per CU (PB = 4: 8 wavefronts of <= 256 registers) and ONE round of workgroups -- a second, partly
+    // filled round would cost as much as the first
+    const long slots = tune("GSR_SLOTS", 256);
+    int npl = (int)tune("GSR_NPL", 0);
+    if (npl <= 0) npl = (int)std::max<long>(1, std::min<long>(npl_all, slots / ((long)nt * l.nlocal())));
+    gg.ppc = (npl_all + npl - 1) / npl;
+    npl = (npl_all + gg.ppc - 1) / gg.ppc;
+    for (int f = 0; f < l.nlocal(); ++f) {                  // the kernel indexes with 32-bit offsets
+        const BoxD& b = l.boxes[l.local[f]];
+        IAMRX_ASSERT((long)(b.len(0) + 1 + 2 * xc.ngrow) * (b.len(1) + 1 + 2 * xc.ngrow) * (b.len(2) + 1 + 2 * xc.ngrow) < 2147483647L);
+    }
+    const long total = (long)nt * npl;
+    unsigned gx = (unsigned)total;
+    gg.xcd_chunk = 0;
+    if (tune("XCD_AWARE", 1) != 0 && total >= 16) { gg.xcd_chunk = npl; gx = 8u * (unsigned)((total + 7) / 8); }
+    dim3 grid(gx, (unsigned)l.nlocal());
+    constexpr int NT = 32 * (64 / PB);
+    const bool rec = kernel_probe_begin(PROBE_NODAL_GS4, (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1));
+#define IAMRX_GSR(W, M, C) hipLaunchKernelGGL((k_nodal_gsr<PB, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
+                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, gg, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
+    if (dmask) {
+        IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
+        IAMRX_GSR(false, true, false);
+    } else if (wrap) { if (csig) IAMRX_GSR(true, false, true); else IAMRX_GSR(true, false, false); }
+    else { if (csig) IAMRX_GSR(false, false, true); else IAMRX_GSR(false, false, false); }
+#undef IAMRX_GSR
+    if (rec) kernel_probe_end(PROBE_NODAL_GS4);
+}
+
 // one k-parity pass (kpar = 0: colours 0-3, kpar = 1: colours 4-7); wrap: see periodic_wrap_ok; needs x.ngrow >= 4, sig.ngrow >= 4, rhs.ngrow >= 3
 // true if the level is one box that spans a fully periodic domain: the smoother kernels can then read periodic images straight from
 // the valid data (wrap = true) and the ghost fills of x / rhs in front of it can be skipped
@@ -583,6 +964,12 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // tile shape: 32x16 nodes / 256 threads (40x24 footprint, 40 KB of LDS: 4 workgroups = 16 waves per CU).  Measured at 256^3
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
+    // levels whose boxes are at least GSR_MIN cells long in x and y: the register-resident kernel (IAMRX_GSR=0: k_nodal_gs4 everywhere)
+    if (tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48)) {
+        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
+        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
+        return;
+    }
     const int big = (int)tune("GS4_TILE", 0);
     if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
     else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
