@@ -504,6 +504,11 @@ __device__ __forceinline__ double gsr_lane_hi(double v)      // the value lane +
     return __hiloint2double(hi, lo);
 }
 
+// colour-pass updates of a thread that the instruction scheduler may interleave (0: no limit): the update's result passes through an empty
+// asm statement every IAMRX_GSR_FENCE nodes, which ends the scheduling region
+#ifndef IAMRX_GSR_FENCE
+#define IAMRX_GSR_FENCE 2
+#endif
 struct GsrGeom {
     int ntx, nty;       // tiles per box and direction
     int tix, tiy;       // tile pitch (even, <= 56)
@@ -671,7 +676,9 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     auto load_rhs = [&](int k, int par) {
         const FabD::gdouble* pr = r.gp() + (long)(k - r.lo[2]) * rks;
 #pragma unroll
-        for (int b = par; b < PB; b += 2) { R[b][0] = gat(pr, rrow[b] + rcol[0]); R[b][1] = gat(pr, rrow[b] + rcol[1]); }
+        for (int b = par; b < PB; b += 2) {
+            R[b][0] = gat(pr, rrow[b] + rcol[0]); R[b][1] = gat(pr, rrow[b] + rcol[1]);
+        }
     };
     // sigma ring: element of the own cell (a, b) of ring slot sl: sl * SPL + sgo + (b + 1) * 64 + a * 32
     const int sgo = PB * q * 64 + lx;
@@ -752,7 +759,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
                 // evaluated by every lane: a branch around the arithmetic would keep all lane-shifted operands (which must be formed
                 // under the full EXEC mask) alive across it; the fence also keeps the updates of a pass from being interleaved
                 // beyond what the register file holds
-#ifdef IAMRX_GSR_FENCE
+#if IAMRX_GSR_FENCE > 0
                 if ((n_ % IAMRX_GSR_FENCE) == IAMRX_GSR_FENCE - 1) asm volatile("" : "+v"(nv));
 #endif
                 const int ubit = 2 * PB * c + 2 * b + CX;
@@ -788,7 +795,9 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
             for (int b = 0; b < PB; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    if ((um[(2 * PB * 3 + 2 * b + a) >> 5] >> ((2 * PB * 3 + 2 * b + a) & 31)) & 1u) gat(po, xrow[b] + xcol[a]) = Xc[b][a];
+                    if ((um[(2 * PB * 3 + 2 * b + a) >> 5] >> ((2 * PB * 3 + 2 * b + a) & 31)) & 1u) {
+                        gat(po, xrow[b] + xcol[a]) = Xc[b][a];
+                    }
         }
         if (!has_next) break;
         // every wavefront is done with the sigma planes k - 1, k and the first rows of this plane
