@@ -112,8 +112,11 @@ def write(run, root, step, max_level=None):
     max_level = nlev - 1 if max_level is None else max_level
     dt_level, dt_min, n_cycle = (C.c_double * nlev)(), (C.c_double * nlev)(), (C.c_int * nlev)()
     counters, stop = (C.c_int * 2)(), C.c_double(-1.0)
+    nmax = max(max_level, nlev - 1) + 1
+    level_count = (C.c_int * nmax)()
     if amr is not None:
         check(L.iamrx_amr_restart_state(amr.h, 0, dt_level, dt_min, n_cycle, counters, C.byref(stop)))
+        check(L.iamrx_amr_level_counts(amr.h, 0, level_count, nmax))
     states = []
     for lev in levels:
         st = (C.c_double * 16)()
@@ -122,17 +125,24 @@ def write(run, root, step, max_level=None):
     if amr is None:
         dt_level[0], dt_min[0], n_cycle[0] = states[0][1], states[0][12], 1
         counters[0] = counters[1] = int(states[0][2])
+        level_count[0] = counters[1]
         stop.value = states[0][13]
     H = ["CheckPointVersion_1.0", "3", repr(states[0][0]), str(max_level), str(nlev - 1)]
     for l in range(max_level + 1):
         H.append(_geom_line(geoms[min(l, nlev - 1)], [geoms[0].n[d] * 2 ** l for d in range(3)]))
     H.append(" ".join(["2"] * max_level))
-    for arr in (dt_level, dt_min):
-        H.append(" ".join(repr(float(v)) for v in arr))
-    H.append(" ".join(str(int(v)) for v in n_cycle))
-    H.append(" ".join(str(int(s[2])) for s in states))           # level_steps
-    H.append(" ".join(str(int(counters[1])) for _ in range(nlev)))   # level_count
-    extra = {"stop_time": stop.value, "level_steps0": int(counters[0]), "level_count": int(counters[1]), "levels": []}
+    # Amr::checkPoint writes these five arrays with max_level + 1 entries; levels that do not exist (yet) carry what Amr gives a level
+    # that is created by a later regrid: dt of the level below / 2, n_cycle 2, no steps
+    pad = nmax - nlev
+    dtl = [float(v) for v in dt_level] + [float(dt_level[nlev - 1]) / 2 ** (i + 1) for i in range(pad)]
+    dtm = [float(v) for v in dt_min] + [float(dt_min[nlev - 1]) for i in range(pad)]
+    H.append(" ".join(repr(v) for v in dtl))
+    H.append(" ".join(repr(v) for v in dtm))
+    H.append(" ".join([str(int(v)) for v in n_cycle] + ["2"] * pad))
+    H.append(" ".join([str(int(s[2])) for s in states] + ["0"] * pad))           # level_steps
+    H.append(" ".join(str(int(v)) for v in level_count))                         # level_count
+    extra = {"stop_time": stop.value, "level_steps0": int(counters[0]), "level_count": int(counters[1]),
+             "level_counts": [int(v) for v in level_count], "levels": []}
     for l, (lev, lay, g) in enumerate(zip(levels, lays, geoms)):
         ld = os.path.join(path, f"Level_{l}")
         os.makedirs(ld, exist_ok=True)
@@ -209,10 +219,11 @@ def read_header(path):
                 level_count=level_count, boxes=boxes)
 
 
-def restart(path, geom0, params, opts=None, single_level=False):
-    """amr.restart: rebuild the run from a checkpoint directory.  geom0 / params / opts come from the inputs file, as upstream re-reads
-    them; returns an iamr_amd.amr.Amr (or a NavierStokes level if single_level and the checkpoint holds one level) that continues exactly
-    where the checkpointed run stood -- no post_init."""
+def restart(path, geom0, params, opts=None, single_level=False, stop_time=None):
+    """amr.restart: rebuild the run from a checkpoint directory.  geom0 / params / opts / stop_time come from the inputs file, as upstream
+    re-reads them (a restart with a later stop_time is the usual reason to restart; the checkpoint's own stop_time is used only if none is
+    given); returns an iamr_amd.amr.Amr (or a NavierStokes level if single_level and the checkpoint holds one level) that continues
+    exactly where the checkpointed run stood -- no post_init."""
     from . import lib as Lb
     from .lib import lib, check
     from .ns import NavierStokes
@@ -245,11 +256,15 @@ def restart(path, geom0, params, opts=None, single_level=False):
                 mf.from_numpy(a, li)
             lev.set_data(10 + q, mf)
         st = (C.c_double * 16)(*extra["levels"][l]["state"])
+        if stop_time is not None:
+            st[13] = float(stop_time)
         check(L.iamrx_ns_restart_state(lev.h, 1, st))
     if hasattr(run, "levels"):
         dt_level, dt_min = (C.c_double * nlev)(*hd["dt_level"][:nlev]), (C.c_double * nlev)(*hd["dt_min"][:nlev])
         n_cycle = (C.c_int * nlev)(*hd["n_cycle"][:nlev])
         counters = (C.c_int * 2)(extra["level_steps0"], extra["level_count"])
-        stop = C.c_double(extra["stop_time"])
+        stop = C.c_double(extra["stop_time"] if stop_time is None else float(stop_time))
         check(L.iamrx_amr_restart_state(run.h, 1, dt_level, dt_min, n_cycle, counters, C.byref(stop)))
+        lc = extra.get("level_counts", hd["level_count"])
+        check(L.iamrx_amr_level_counts(run.h, 1, (C.c_int * len(lc))(*lc), len(lc)))
     return run

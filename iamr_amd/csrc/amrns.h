@@ -67,6 +67,8 @@ public:
     // Amr::checkPoint / restart: dt_level, dt_min, n_cycle per level, level_steps, level_count, stop_time
     void get_restart_state(double* dt_lev, double* dt_mn, int* ncyc, int counters[2], double* stop) const;
     void set_restart_state(const double* dt_lev, const double* dt_mn, const int* ncyc, const int counters[2], double stop);
+    void get_level_counts(int* counts, int n) const;
+    void set_level_counts(const int* counts, int n);
     uint64_t grid_generation() const { return m_grid_gen; }   // incremented whenever the grids change
     uint64_t m_grid_gen = 0;
     // section profile of the coarse step (host clock around stream syncs, only while profile_on): [0] reflux, [1] avgDown,

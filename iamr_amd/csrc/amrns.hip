@@ -614,10 +614,15 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
         if (st.resnorm <= target) { st.converged = 1; break; }
         if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx composite nodal solve: residual blow-up");
         // the round-off floor of the fp64 residual (about 1e-12 of the right-hand side once h <= 1/512) can sit just above the requested
-        // tolerance: a residual within 100x of the target that has stopped decreasing for three iterations is as converged as fp64 allows.
+        // tolerance: a residual within 10x of the target that has lost less than 10 % over three iterations is as converged as fp64 allows.
         // amrex::MLMG would iterate to max_iter and abort; converged = 2 reports the difference
         hist.push_back(st.resnorm);
-        if (hist.size() >= 4 && st.resnorm <= 100.0 * target && st.resnorm > 0.5 * hist[hist.size() - 4]) { st.converged = 2; break; }
+        if (hist.size() >= 4 && st.resnorm <= 10.0 * target && st.resnorm > 0.9 * hist[hist.size() - 4]) {
+            st.converged = 2;
+            fprintf(stderr, "iamrx composite nodal solve: WARNING: residual %.3e stalled at the round-off floor above the target %.3e after %d iterations; accepted (converged = 2)\n",
+                    st.resnorm, target, st.iters);
+            break;
+        }
     }
     if (!st.converged) throw Error("iamrx composite nodal solve: failed to converge");
     if (singular) {                      // the solution of the singular system is fixed by a zero weighted mean over the composite unknowns
@@ -984,7 +989,6 @@ void AmrNS::level_sync(int l, int crse_iteration)
     NavierStokes &c = *lev[l], &f = *lev[l + 1];
     const int crse_dt_ratio = n_cycle[l];
     if (crse_iteration < 0) crse_iteration = crse_dt_ratio;
-    auto& ctx = Context::get();
     const double dt = dt_level[l];
     ProfScope ps_ls_("level_sync");
     std::unique_ptr<ProfScope> psec;
@@ -1252,6 +1256,17 @@ void AmrNS::get_restart_state(double* dt_lev, double* dt_mn, int* ncyc, int coun
     for (size_t l = 0; l < lev.size(); ++l) { dt_lev[l] = dt_level[l]; dt_mn[l] = dt_min[l]; ncyc[l] = n_cycle[l]; }
     counters[0] = level_steps; counters[1] = level_count;
     *stop = stop_time;
+}
+// Amr::level_count of every level (steps of level i since the last regrid that started at or below it), sized max_level + 1 in a checkpoint
+void AmrNS::get_level_counts(int* counts, int n) const
+{
+    for (int i = 0; i < n; ++i) counts[i] = i < (int)level_count_v.size() ? level_count_v[i] : 0;
+    if (n > 0 && level_count_v.empty()) counts[0] = level_count;
+}
+void AmrNS::set_level_counts(const int* counts, int n)
+{
+    level_count_v.assign(counts, counts + n);
+    if (n > 0) level_count = counts[0];
 }
 void AmrNS::set_restart_state(const double* dt_lev, const double* dt_mn, const int* ncyc, const int counters[2], double stop)
 {

@@ -1155,6 +1155,13 @@ int iamrx_amr_restart_state(iamrx_amr a, int set, double* dt_level, double* dt_m
     else a->amr->get_restart_state(dt_level, dt_min, n_cycle, counters, stop_time);
     IAMRX_CATCH
 }
+int iamrx_amr_level_counts(iamrx_amr a, int set, int* counts, int n)
+{
+    IAMRX_TRY
+    if (set) a->amr->set_level_counts(counts, n); else a->amr->get_level_counts(counts, n);
+    IAMRX_CATCH
+}
+int iamrx_ns_set_stop_time(iamrx_ns ns, double stop_time) { IAMRX_TRY ns->ns->set_stop_time(stop_time); IAMRX_CATCH }
 int iamrx_amr_reflux(iamrx_amr a, int lev) { IAMRX_TRY a->amr->reflux(lev); IAMRX_CATCH }
 int iamrx_amr_avg_down(iamrx_amr a, int lev) { IAMRX_TRY a->amr->avg_down(lev); IAMRX_CATCH }
 int iamrx_amr_mac_sync(iamrx_amr a, int lev) { IAMRX_TRY a->amr->mac_sync(lev); IAMRX_CATCH }

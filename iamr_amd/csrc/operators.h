@@ -274,6 +274,7 @@ public:
     // history of the MAC solve (this library's addition: it makes a restarted run bit-identical to the uninterrupted one).
     // v[0..15] = time, dt, nstep, st_new, st_old, pt_new[2], pt_old[2], dt_prev_mac, have_mac_prev, have_mac_prev2, dt_min_adv, stop_time, inew, pnew
     void get_restart_state(double v[16]) const;
+    void set_stop_time(double t) { m_stop_time = t; }      // amr.restart: stop_time comes from the inputs file
     void set_restart_state(const double v[16]);            // call after the arrays are set; also leaves the initial-step state
     MultiFab& mac_phi_history(int which);                  // 0: last MAC potential, 1: the one before (defined on demand)
     const Geometry& geom() const { return g; }

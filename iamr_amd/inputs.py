@@ -21,15 +21,17 @@ import re
 # ending in ".", as a prefix of a whole ParmParse namespace
 _IGNORED_KEYS = ("amr.v", "amr.verbose", "ns.v", "ns.verbose", "proj.v", "proj.verbose", "mac_proj.v", "mac_proj.verbose", "mac.v", "diffuse.v",
                  "diffuse.verbose", "nodal_proj.verbose", "ns.sum_interval", "ns.getForceVerbose", "amr.grid_log", "amr.probin_file",
-                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.refinement_indicators", "amr.n_error_buf", "amr.grid_eff", "amr.subcycling_mode",
+                 "amr.blocking_factor", "amr.regrid_int", "amr.ref_ratio", "amr.regrid_file", "amr.initial_grid_file", "amr.refinement_indicators", "amr.n_error_buf", "amr.grid_eff",
                  "amr.check_per", "amr.checkpoint_files_output", "amr.plot_files_output", "amr.plot_per",
-                 "amr.plotfile_on_restart", "amr.checkpoint_on_restart", "ns.do_reflux",
-                 "ns.do_sync_proj")
+                 "amr.plotfile_on_restart", "amr.checkpoint_on_restart")
 _IGNORED_NAMESPACES = ("mg.", "fab.", "fabarray.", "amrex.", "amr.refinement_indicators")
 # boundary values of the second tracer: read by upstream only with ns.do_trac2 = 1 (which raises here), unused otherwise
 # keys that switch physics or start-up paths this library does not have: their reference defaults are accepted, anything else raises
 _UNIMPLEMENTED_UNLESS = {"ns.variable_vel_visc": "0", "ns.variable_scal_diff": "0", "ns.do_init_proj": "1", "ns.do_mac_proj": "1",
-                         "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0"}
+                         "ns.do_init_vort_proj": "0", "ns.do_divu_sync": "0", "ns.do_scalar_update_in_order": "0",
+                         # the multi-level step always refluxes, sync-projects and subcycles (NavierStokesBase.cpp:461-462, 2562-2582;
+                         # Amr's subcycling_mode "Auto" with ratio 2 = one fine step per direction of refinement)
+                         "ns.do_reflux": "1", "ns.do_sync_proj": "1", "amr.subcycling_mode": "Auto"}
 
 
 def read_grid_file(path, ref_ratio, slab=None):

@@ -166,7 +166,7 @@ def main_amr(pr, inp, lib, N, rank=0, world=1):
         if world > 1:
             raise NotImplementedError("iamr_amd.run: amr.restart runs on one rank")
         g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
-        amr = checkpoint.restart(pr["restart"], g0, N.ns_params(**pr["params"]))
+        amr = checkpoint.restart(pr["restart"], g0, N.ns_params(**pr["params"]), stop_time=pr["stop_time"])
         if pr.get("regrid"):
             amr.set_regrid(**pr["regrid"])
         lays = amr.layouts
@@ -270,7 +270,7 @@ def main(argv):
         if world > 1:
             raise NotImplementedError("iamr_amd.run: amr.restart runs on one rank")
         g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
-        ns = checkpoint.restart(pr["restart"], g, N.ns_params(**pr["params"]), single_level=True)
+        ns = checkpoint.restart(pr["restart"], g, N.ns_params(**pr["params"]), single_level=True, stop_time=pr["stop_time"])
         lay = ns.layout
         step = checkpoint.read_header(pr["restart"])["level_steps"][0]
         print(f"RESTART from {pr['restart']}: step {step}, time {ns.time:.12g}")

@@ -520,6 +520,12 @@ int iamrx_amr_post_init(iamrx_amr a, double stop_time);      /* S_new of every l
 /* Amr::checkPoint / Amr::restart role for the hierarchy: dt_level, dt_min, n_cycle per level, counters = {level_steps, level_count},
  * stop_time.  set = 0: read, 1: write (instead of iamrx_amr_post_init, after every level has been restored). */
 int iamrx_amr_restart_state(iamrx_amr a, int set, double* dt_level, double* dt_min, int* n_cycle, int counters[2], double* stop_time);
+/* Amr::level_count of every level (the steps of level i since the last regrid that rebuilt it; Amr::timeStep regrids from level i when it
+ * reaches regrid_int), n = amr.max_level + 1 entries as Amr::checkPoint writes them.  set = 0: read (0 beyond the levels that exist) */
+int iamrx_amr_level_counts(iamrx_amr a, int set, int* counts, int n);
+/* amr.restart takes stop_time from the inputs file, not from the checkpoint (Amr::restart re-reads it): the level's own copy, which
+ * clips its time step (NavierStokesBase::computeNewDt, Source/NavierStokesBase.cpp:1011-1023) */
+int iamrx_ns_set_stop_time(iamrx_ns ns, double stop_time);
 int iamrx_amr_coarse_step(iamrx_amr a, double* dt0);         /* dt0: the level-0 time step used */
 int iamrx_amr_time(iamrx_amr a, double* time, double* dt_levels /* [nlev] or NULL */);
 /* the pieces of NavierStokesBase::post_timestep(lev) one by one (lev < finest), for a caller that drives the loop itself:
