@@ -239,6 +239,39 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, 
     IAMRX_CATCH
 }
 
+// One operation of the finest-level kernel FORMS the cell-centred multigrid selects by itself inside a solve (k_abec_gsrb2, k_abec_resid_restrict),
+// on caller data, so that they can be compared with the oracle directly at sizes that reach their multi-workgroup / plane-marching paths
+int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, double scale, const double bu[3], double beta, int op,
+                    iamrx_mf phi, iamrx_mf rhs, iamrx_mf out, double omega, const int lobc[3], const int hibc[3], int maxorder)
+{
+    IAMRX_TRY
+    Geometry gg = to_geom(g);
+    DomainBC b = to_bc(lobc, hibc, maxorder);
+    MultiFab bf[3];
+    MultiFab* bp[3];
+    for (int d = 0; d < 3; ++d) { bf[d].define(phi->mf.layout, face_type(d), 1, 0); bp[d] = &bf[d]; }
+    AbecCoef c;
+    c.alpha = 0.0; c.beta = beta; c.a = nullptr; c.tensor = 0;
+    for (int d = 0; d < 3; ++d) c.b[d] = bp[d];
+    if (coef == 1) {
+        if (!rho || rho->mf.ngrow < 1) throw Error("iamrx_abec_form: coef 1 needs rho with a filled ghost cell");
+        mac_bcoef(bp, rho->mf, rho_comp, scale);
+        c.sig = &rho->mf; c.sig_comp = rho_comp; c.sig_scale = scale;
+    } else if (coef == 2) {
+        for (int d = 0; d < 3; ++d) { bf[d].setVal(bu[d]); c.bu[d] = bu[d]; }
+        c.b_uniform = 1;
+    } else throw Error("iamrx_abec_form: coef is 1 (recomputed from rho) or 2 (uniform)");
+    const bool wrap = op == 4 || op == 5;
+    if (wrap && !periodic_wrap_ok(gg, *phi->mf.layout, 1)) throw Error("iamrx_abec_form: op 4 / 5 need one box spanning a periodic domain");
+    if (op == 0 || op == 1 || wrap) abec_gsrb(gg, c, phi->mf, rhs->mf, op & 1, omega, &b, 1, false, wrap);
+    else if (op == 2) abec_residual(gg, c, out->mf, phi->mf, &rhs->mf);
+    else if (op == 3) {
+        if (!abec_resid_restrict_ok(c, phi->mf, rhs->mf)) throw Error("iamrx_abec_form: the fused residual + restriction does not apply to these arrays");
+        abec_resid_restrict(gg, c, out->mf, phi->mf, rhs->mf);
+    } else throw Error("iamrx_abec_form: bad op");
+    IAMRX_CATCH
+}
+
 // one red+black sweep incl. the BC / ghost fills in front of each colour (fused = 1: the single-pass out-of-place kernel + the
 // black pass over the box surfaces); homogeneous BC as inside a V-cycle
 int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,

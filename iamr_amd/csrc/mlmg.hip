@@ -492,11 +492,13 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
         const int maxit = m_o.fixed_iters > 0 ? m_o.fixed_iters : m_o.max_iters;
         for (int iter = 0; iter < maxit; ++iter) {
             // singular system: the residual of a compatible right-hand side has zero mean up to round-off (the operator's columns sum to
-            // zero), which amrex::MLMG removes in front of every cycle.  Here in front of the first one only (the bottom solver removes its
+            // zero), which amrex::MLMG removes in front of every cycle.  On a fully periodic level it is not removed here (the bottom solver removes its
             // own): a reduction, a host read-back and a pass over the level per iteration (0.13 ms of a 2.4 ms cycle at 256^3) for a
             // shift of the order of 1e-16 |rhs|.  IAMRX_MG_RES_MEAN=1 restores the per-iteration form.
             // (fully periodic level: the right-hand side has just lost its mean and no boundary data enters the residual -- nothing to remove)
-            if (m_singular && ((iter == 0 && has_bcdata) || tune("MG_RES_MEAN", 0) != 0)) subtract_mean(0, L0.res);
+            // A level with walls (boundary data present) keeps the per-iteration removal: there an incompatible component could build up
+            // over many cycles and would not be projected out.
+            if (m_singular && (has_bcdata || tune("MG_RES_MEAN", 0) != 0)) subtract_mean(0, L0.res);
             if (m_dd_sweeps > 0 && m_dd_rho > 0.0 && st.resnorm > 0.0) {
                 // diagonally dominant operator: as many sweeps as the remaining reduction needs (measured at 256^3, nu dt/h^2 = 0.02:
                 // 4 + 2 sweeps in two cycles instead of 3 x 3 sweeps; the second cycle only removes the lagged cross-term defect)

@@ -402,7 +402,8 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
         for (int iter = 0; iter < maxit; ++iter) {
             // see CellMG::solve: the mean of the residual of a singular system is removed in front of the first cycle only
             const bool all_per = L0.g.periodic[0] && L0.g.periodic[1] && L0.g.periodic[2] && !L0.dmask();
-            if (m_singular && ((iter == 0 && !all_per) || tune("MG_RES_MEAN", 0) != 0)) { subtract_mean(0, L0.res); L0.res_filled = false; }
+            // (levels with Neumann walls keep amrex::MLMG's per-iteration removal: ADVICE round 3)
+            if (m_singular && (!all_per || tune("MG_RES_MEAN", 0) != 0)) { subtract_mean(0, L0.res); L0.res_filled = false; }
             cycle_timer().mark(ctx.stream);
             vcycle(st);
             cycle_timer().mark(ctx.stream);

@@ -358,6 +358,13 @@ def average_down(fine, crse, scomp=0, ncomp=None, ratio=2):
     check(lib().iamrx_average_down(fine.h, crse.h, scomp, crse.ncomp if ncomp is None else ncomp, ratio))
 
 
+def abec_form(geom, coef, op, phi, rhs, out=None, rho=None, rho_comp=0, scale=1.0, bu=(1.0, 1.0, 1.0), beta=1.0, omega=1.15, lobc=(0, 0, 0), hibc=(0, 0, 0),
+              maxorder=3):
+    """one operation of the multigrid's finest-level kernel forms (include/iamrx.h: iamrx_abec_form)"""
+    check(lib().iamrx_abec_form(C.byref(geom), int(coef), _h(rho), int(rho_comp), C.c_double(scale), (C.c_double * 3)(*[float(v) for v in bu]),
+                                C.c_double(beta), int(op), phi.h, rhs.h, _h(out), C.c_double(omega), i3(lobc), i3(hibc), int(maxorder)))
+
+
 def abec_gsrb_sweep(geom, alpha, beta, a, b, phi, rhs, omega=1.15, lobc=(0, 0, 0), hibc=(0, 0, 0), maxorder=2, fused=1):
     check(lib().iamrx_abec_gsrb_sweep(C.byref(geom), C.c_double(alpha), C.c_double(beta), _h(a), b[0].h, b[1].h, b[2].h,
                                       phi.h, rhs.h, C.c_double(omega), i3(lobc), i3(hibc), maxorder, int(fused)))

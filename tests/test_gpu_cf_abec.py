@@ -126,7 +126,9 @@ def test_cf_solve_reproduces_a_smooth_solution(orc, gpu):
     assert errs[1] < 0.3 * errs[0] and errs[1] < 5e-3, errs
 
 
-@pytest.mark.parametrize("case", ["one_box", "l_shape"])
+# big_patch: a 64 x 64 x 96 refined box in a 128^3 level -- the coarse/fine variants of the pair-marching colour pass and of
+# the fused residual / restriction (k_abec_gsrb2<1, true, .>, k_abec_resid_restrict) run their multi-workgroup rows and 32-plane marches
+@pytest.mark.parametrize("case", ["one_box", "l_shape", "big_patch"])
 def test_mac_projection_on_a_refined_level(orc, gpu, case):
     """MacProj::mac_project at level 1: coarse MAC solve on the periodic 16^3 level, then the fine solve on the refined boxes with
     the coarse phi on the coarse/fine faces; variable density.  The projected fine field is discretely divergence free on the
@@ -134,8 +136,8 @@ def test_mac_projection_on_a_refined_level(orc, gpu, case):
     lib = gpu
     L = orc.lib()
     L.orc_mac_project_cf.restype = None
-    boxes = CASES[case]
-    nf, ncr = 32, 16
+    boxes = [((32, 32, 16), (95, 95, 111))] if case == "big_patch" else CASES[case]
+    nf, ncr = (128, 64) if case == "big_patch" else (32, 16)
     n, nc = (nf,) * 3, (ncr,) * 3
     rng = np.random.default_rng(5)
     g_o, g_d, gc_o, gc_d = orc.geom(n), lib.Geom.make(n), orc.geom(nc), lib.Geom.make(nc)

@@ -1,0 +1,128 @@
+"""GPU parity, directly against the oracle, of the finest-level kernel FORMS that carry the headline since round 3:
+the pair-marching colour pass k_abec_gsrb2, the pair-marching residual and the fused residual + restriction k_abec_resid_restrict -- in the
+`sig` mode (MAC operator, face coefficients recomputed from the cell-centred density) and the `b_uniform` mode (three constants) -- and the
+fused tensor residual k_tensor_cross_zm<.., FUSE>, at 64 x 64 x 96 and beyond: sizes where a row takes several workgroups, a thread marches 32
+planes (GSRB2_TZ) and the XCD-aware tile order is on.  Through the C-ABI (iamrx_abec_form, iamrx_tensor_apply); single box, several boxes, and
+the index wrap of a periodic single box.  Bit-exact for the cell-centred kernels (same expression order as oracle/orc_abec.c, contraction off
+on both sides), 1e-12 relative for the tensor operator (different but equivalent summation order)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fields(n, seed):
+    rng = np.random.default_rng(seed)
+    ax = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rho = 1.0 + 0.4 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(4 * np.pi * Z) + 0.05 * rng.random(X.shape)
+    phi = np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y) + 0.5 * np.cos(2 * np.pi * (Z + X)) + 0.1 * rng.standard_normal(X.shape)
+    rhs = (np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Z) + 0.1 * rng.standard_normal(X.shape))[1:-1, 1:-1, 1:-1]
+
+    def wrap(a):                       # periodic ghost cells
+        for d in range(3):
+            lo = [slice(None)] * 3; hi = [slice(None)] * 3; s0 = [slice(None)] * 3; s1 = [slice(None)] * 3
+            lo[d] = 0; s0[d] = n[d]; hi[d] = n[d] + 1; s1[d] = 1
+            a[tuple(lo)] = a[tuple(s0)]; a[tuple(hi)] = a[tuple(s1)]
+        return a
+    return wrap(rho), wrap(phi), rhs
+
+
+@pytest.mark.parametrize("coef", [1, 2])
+@pytest.mark.parametrize("n,boxes", [((64, 64, 96), None), ((64, 64, 96), (32, 32, 48)), ((128, 96, 64), (64, 48, 64)), ((96, 80, 72), None)])
+def test_colour_pass_residual_and_restriction_match_the_oracle(orc, gpu, n, boxes, coef):
+    lib = gpu
+    L = orc.lib()
+    g_o, g_d = orc.geom(n), lib.Geom.make(n)
+    lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
+    rho, phi, rhs = fields(n, 7)
+    scale, bu, beta = 0.37, (0.8, 1.1, 1.3), 1.0
+    # the oracle takes face arrays: b_d = scale / (0.5 (rho(cell - e_d) + rho(cell)))  [MacProj.cpp:1098-1128's coefficients] or constants
+    b_o = []
+    for d in range(3):
+        bf = orc.Fab(n, orc.face(d), 0, 1)
+        if coef == 1:
+            lo = [slice(1, n[e] + 1) for e in range(3)]; hi = [slice(1, n[e] + 1) for e in range(3)]
+            lo[d] = slice(0, n[d] + 1); hi[d] = slice(1, n[d] + 2)
+            bf.a[..., 0] = scale / (0.5 * (rho[tuple(lo)] + rho[tuple(hi)]))
+        else:
+            bf.a[...] = bu[d]
+        b_o.append(bf)
+    lev = orc.abec_level(g_o, b_o, beta=beta)
+    phi_o = orc.Fab(n, orc.CELL, 1, 1); phi_o.a[..., 0] = phi
+    rhs_o = orc.Fab(n, orc.CELL, 0, 1); rhs_o.a[..., 0] = rhs
+    rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1,) * 3)
+    phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.set_from_global(phi[..., None], (-1,) * 3)
+    rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs[..., None], (0,) * 3)
+    kw = dict(rho=rho_d, scale=scale, bu=bu, beta=beta)
+    z3 = orc.i3([0, 0, 0])
+    single = boxes is None
+    # two full sweeps; on a single box the second one through the index-wrap form (no ghost cell is read: poison them)
+    for sweep in range(2):
+        for rb in (0, 1):
+            L.orc_fill_periodic(phi_o.ref(), C.byref(g_o), orc.i3(orc.CELL))
+            L.orc_abec_gsrb(C.byref(lev), phi_o.ref(), rhs_o.ref(), rb, C.c_double(1.15), z3, z3, 3)
+            if single and sweep == 1:
+                lib.abec_form(g_d, coef, 4 + rb, phi_d, rhs_d, **kw)
+            else:
+                phi_d.fill_boundary(g_d)
+                lib.abec_form(g_d, coef, rb, phi_d, rhs_d, **kw)
+            got, ref = phi_d.gather_valid(n), phi_o.valid(n)
+            assert np.array_equal(got, ref), ("colour pass", sweep, rb, float(np.abs(got - ref).max()))
+    # residual
+    L.orc_fill_periodic(phi_o.ref(), C.byref(g_o), orc.i3(orc.CELL))
+    y = orc.Fab(n, orc.CELL, 0, 1)
+    L.orc_abec_apply(C.byref(lev), y.ref(), phi_o.ref())
+    res_ref = rhs_o.a - y.a
+    out = lib.MultiFab(lay, lib.CELL, 1, 0)
+    phi_d.fill_boundary(g_d)
+    lib.abec_form(g_d, coef, 2, phi_d, rhs_d, out=out, **kw)
+    got = out.gather_valid(n)
+    assert np.array_equal(got, res_ref[..., 0] if res_ref.ndim == 4 and got.ndim == 3 else res_ref), float(np.abs(got - res_ref.reshape(got.shape)).max())
+    # residual + restriction in one pass against residual, then cc_restrict
+    nc = tuple(v // 2 for v in n)
+    res_f = orc.Fab(n, orc.CELL, 0, 1); res_f.a[...] = res_ref
+    crs_o = orc.Fab(nc, orc.CELL, 0, 1)
+    L.orc_cc_restrict(crs_o.ref(), res_f.ref(), orc.i3(nc))
+    clay = lib.Layout([(tuple(v // 2 for v in lo), tuple((v + 1) // 2 - 1 for v in hi)) for lo, hi in lay.boxes])
+    crs_d = lib.MultiFab(clay, lib.CELL, 1, 0)
+    lib.abec_form(g_d, coef, 3, phi_d, rhs_d, out=crs_d, **kw)
+    got, ref = crs_d.gather_valid(nc), crs_o.valid(nc)
+    assert np.array_equal(got, ref), ("restriction", float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("n,boxes", [((64, 64, 96), None), ((64, 64, 96), (32, 32, 48)), ((128, 64, 64), (64, 64, 32))])
+def test_fused_tensor_residual_matches_the_oracle(orc, gpu, n, boxes):
+    """constant viscosity: MLTensorOp::apply runs as ONE launch (k_tensor_cross_zm<.., FUSE>: 7-point part + cross terms from the velocity
+    planes in LDS); a = 0 / b = -1 as in getTensorViscTerms (Diffusion.cpp:1655-1777) and the Crank-Nicolson form a = 1, b = dt"""
+    lib = gpu
+    from iamr_amd import ns as N
+    L = orc.lib()
+    g_o, g_d = orc.geom(n), lib.Geom.make(n)
+    lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
+    ax = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rng = np.random.default_rng(4)
+    u = orc.Fab(n, orc.CELL, 1, 3)
+    u.a[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(2 * np.pi * Z)
+    u.a[..., 1] = np.cos(4 * np.pi * X) * np.sin(2 * np.pi * Y) + 0.3 * np.sin(2 * np.pi * Z)
+    u.a[..., 2] = 0.5 * np.sin(2 * np.pi * (X + Y + Z))
+    u.a[1:-1, 1:-1, 1:-1, :] += 0.01 * rng.standard_normal(tuple(n) + (3,))
+    L.orc_fill_periodic(u.ref(), C.byref(g_o), orc.i3(orc.CELL))
+    eta_o, eta_d = [], []
+    for d in range(3):
+        e = orc.Fab(n, orc.face(d), 0, 1, fill=0.013)
+        eta_o.append(e)
+        m = lib.MultiFab(lay, lib.face(d), 1, 0); m.setval(0.013); eta_d.append(m)
+    acoef = orc.Fab(n, orc.CELL, 0, 1)
+    acoef.a[..., 0] = 1.0 + 0.2 * np.cos(2 * np.pi * X[1:-1, 1:-1, 1:-1])
+    a_d = lib.MultiFab(lay, lib.CELL, 1, 0); a_d.set_from_global(acoef.a, acoef.lo)
+    u_d = lib.MultiFab(lay, lib.CELL, 3, 1); u_d.set_from_global(u.a, u.lo)
+    for (a, b, ac_o, ac_d) in ((0.0, -1.0, None, None), (1.0, 0.004, acoef, a_d)):
+        y = orc.Fab(n, orc.CELL, 0, 3)
+        L.orc_tensor_apply(C.byref(g_o), y.ref(), u.ref(), C.c_double(a), C.c_double(b), ac_o.ref() if ac_o is not None else None, orc.fabptrs(eta_o))
+        out_d = lib.MultiFab(lay, lib.CELL, 3, 0)
+        N.tensor_apply(g_d, out_d, u_d, a, b, ac_d, eta_d)
+        got = out_d.gather_valid(n)
+        assert np.abs(got - y.a).max() <= 1e-12 * np.abs(y.a).max(), (a, b, float(np.abs(got - y.a).max()))
