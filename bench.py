@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-PMC_FILE = "round3_pmc.json"
+PMC_FILE = "round4_pmc.json"
 
 
 def parse():
@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("IAMRX_BENCH_N", "256")), help="cells per direction of the per-GPU box")
     ap.add_argument("--c", type=float, default=1.0, help="prob.c (1 = fully 3-D regtest default)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = median region (SURVEY 8d: median of 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upstream-shape", action="store_true", help="skip the pass with the reference's multigrid cycle shape")
     ap.add_argument("--no-multibox", action="store_true", help="skip the single-GPU 8-box / 64-box runs of the same problem")
@@ -248,12 +249,14 @@ def amr_workload(lib, n0, steps, rank=0, world=1, dist=None, layout_gpus=None, k
 
 
 def multibox_workload(lib, n, steps=3):
-    """the main workload's n^3 problem on ONE GPU chopped into 8 and 64 boxes: what the real ghost-exchange path costs (copy plans between
-    boxes, no periodic-wrap specialisation of the single-box level: DESIGN.md section 4) -- the per-GPU cost a multi-GPU run inherits"""
+    """the main workload's n^3 problem on ONE GPU chopped into 8, 64 and 512 boxes (the last = the reference's default amr.max_grid_size = 32 at
+    256^3).  The level object merges the boxes a rank owns (mf.h: coalesce_layout, the default): the chopped level runs the single-box kernels.
+    `boxes_kept` is the same run with the merging switched off (IAMRX_COALESCE = 0): what the ghost-exchange path between boxes costs (copy
+    plans between colour passes, no index wrap, per-box tiles) -- still the per-GPU cost of any layout whose boxes do not tile rectangles"""
     from iamr_amd import ns as N
     out = {}
-    for parts in (2, 4):
-        mg = n // parts
+
+    def one(mg):
         g = lib.Geom.make((n,) * 3)
         lay = lib.Layout.decompose((n,) * 3, mg)
         ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
@@ -267,9 +270,18 @@ def multibox_workload(lib, n, steps=3):
         lib.sync()
         ms = (time.perf_counter() - t0) / steps * 1e3
         sm, sn, sv = ns.stats()
-        out[f"{parts ** 3}x{mg}^3"] = {"ms_per_step": ms, "cells_per_sec": float(n) ** 3 / ms * 1e3, "mlmg_iters": [sm.iters, sn.iters, sv.iters],
-                                       "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
-        del ns
+        return {"ms_per_step": ms, "cells_per_sec": float(n) ** 3 / ms * 1e3, "mlmg_iters": [sm.iters, sn.iters, sv.iters],
+                "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
+    for parts in (2, 4, 8):
+        mg = n // parts
+        r = one(mg)
+        if parts < 8:
+            lib.tuning_set("COALESCE", 0)
+            try:
+                r["boxes_kept"] = one(mg)
+            finally:
+                lib.tuning_set("COALESCE", 1)
+        out[f"{parts ** 3}x{mg}^3"] = r
     return out
 
 
@@ -412,26 +424,33 @@ def main():
         lib.check(lib.lib().iamrx_sync_count(C.byref(v)))
         return v.value
 
-    barrier()
+    # SURVEY 8d's protocol: `repeats` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over the ranks; the reported region is the median one
     m0 = nmalloc()
     s0 = nsync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ns.step()
-        sm, sn, sv = ns.stats()
-        mac_ms.append(sm.vcycle_ms); nod_ms.append(sn.vcycle_ms); visc_ms.append(sv.vcycle_ms)
-        mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
-    barrier()
-    el = time.perf_counter() - t0
-    insitu = probes_stop() if probe_on else {}      # name -> (mean duration in ms, number of launches timed inside the timed region)
+    regions = []
+    for _rep in range(max(1, a.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ns.step()
+            sm, sn, sv = ns.stats()
+            mac_ms.append(sm.vcycle_ms); nod_ms.append(sn.vcycle_ms); visc_ms.append(sv.vcycle_ms)
+            mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
+        barrier()
+        el_r = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el_r], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_r = float(tt.item())
+        regions.append(el_r)
+    insitu = probes_stop() if probe_on else {}      # name -> (mean duration in ms, number of launches timed inside the timed regions)
     gs4_insitu = insitu.get("gs4")
     gsrb_insitu = insitu.get("gsrb")
+    nreg = len(regions)
     mallocs_in_loop = nmalloc() - m0
-    syncs_in_loop = nsync() - s0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    syncs_in_loop = (nsync() - s0) / nreg
+    el = sorted(regions)[nreg // 2]
     cells_total = float(n) ** 3 * world
     value = cells_total * a.steps / el
 
@@ -478,14 +497,17 @@ def main():
             alg = 40.0 * cells
             own = 24.0 * cells
             ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
-            gbps = alg / ms / 1e6
+            # `achieved` / `frac`: against the kernel's OWN compulsory traffic -- it recomputes the face coefficients from the
+            # cell-centred density and so moves less than SURVEY 8d's 40 B/cell of the operation; the 8d figure is kept beside it (survey_8d_*)
+            gbps = own / ms / 1e6
             roofline = {"kernel": "k_abec_gsrb2<1, false, false> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
                                   "face coefficients recomputed from the cell-centred density; the dominant kernel of the step, "
-                                  "profiles/round3_kernel_stats.csv)", "bound": "hbm",
+                                  "profiles/round4_kernel_stats.csv)", "bound": "hbm",
                         "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                         "traffic": pmc_traffic("k_abec_gsrb2<1, false, false> grid=%d" % (n ** 3 // 64)),
-                        "algorithmic_bytes_per_launch": alg, "avg_ms": ms,
-                        "own_minimum_bytes_per_launch": own, "own_minimum_GBps": own / ms / 1e6, "frac_own_minimum": own / ms / 1e6 / 8000.0,
+                        "algorithmic_bytes_per_launch": own, "avg_ms": ms,
+                        "bytes_counted": "the kernel's own compulsory traffic, 24 B/cell per colour pass: phi read 8 + written 4, rhs 4, density 8",
+                        "survey_8d_bytes_per_launch": alg, "survey_8d_GBps": alg / ms / 1e6, "survey_8d_frac": alg / ms / 1e6 / 8000.0,
                         "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
                         "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
                         "isolated_loop_ms_array_coefficients": gsrb_iso["ms"] / 2}
@@ -496,10 +518,10 @@ def main():
             # back-to-back loop of kernel_rooflines() is kept beside it (warm L2, no interleaved fills: shorter)
             ms = gs4_insitu[0] if gs4_insitu else dom["ms"]
             gbps = dom["alg_bytes_per_launch"] / ms / 1e6
-            roofline_gs4 = {"kernel": "k_nodal_gs4<32,16,256> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch, variable sigma; second in the "
-                                      "step's kernel time)", "bound": "hbm",
+            roofline_gs4 = {"kernel": "k_nodal_gsr<4> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch, register-resident planes, variable "
+                                      "sigma; 16 B/node per launch = SURVEY 8d's 32 B/node per sweep)", "bound": "hbm",
                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                            "traffic": pmc_traffic("k_nodal_gs4<32, 16, 256, true, false, false> grid="),
+                            "traffic": pmc_traffic("k_nodal_gsr<4, true, false, false> grid="),
                             "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
                             "launches_timed": gs4_insitu[1] if gs4_insitu else None,
                             "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
@@ -533,7 +555,9 @@ def main():
         ups = upstream_shape_pass(lib, N, g, lay, a.c) if (world == 1 and not a.no_upstream_shape) else None
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": el / a.steps * 1e3, "repeats": nreg, "ms_per_step_of_each_region": [r / a.steps * 1e3 for r in regions],
+            "protocol": "median of `repeats` timed regions of `steps` steps each (SURVEY 8d), every region between barrier + synchronize, max over ranks",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"TaylorGreen 3D single level, one {n}^3 box per GPU in a {pgrid[0]}x{pgrid[1]}x{pgrid[2]} arrangement ({ntot[0]}x{ntot[1]}x{ntot[2]} cells), periodic, "
                                    f"nu=1e-4 cfl=0.7 Godunov_PLM be_cn_theta=0.5, full NavierStokes::advance per step",

@@ -232,7 +232,7 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids, int lbase
     validate_grids(grids, lbase);
     const int old_finest = (int)lev.size() - 1, new_finest = lbase + (int)grids.size();
     bool same = old_finest == new_finest;
-    for (int l = lbase + 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->layout->boxes, grids[l - lbase - 1]);
+    for (int l = lbase + 1; same && l <= new_finest; ++l) same = same_boxes(lev[l]->user_layout->boxes, grids[l - lbase - 1]);
     if (same) return false;
     ++m_grid_gen;
     const double cur_time = lbase == 0 ? lev[0]->time : cur_time_in;

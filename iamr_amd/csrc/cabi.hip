@@ -177,6 +177,20 @@ int iamrx_layout_create(int nboxes, const int* lo_hi, const int* owner, iamrx_la
     *out = h;
     IAMRX_CATCH
 }
+// the layout the level objects work on for the caller's boxes: boxes of one owner that share full faces merged (mf.h: coalesce_layout);
+// nboxes / lo_hi as in iamrx_amr_level_boxes (lo_hi NULL: query the count)
+int iamrx_layout_coalesced_boxes(iamrx_layout l, int* nboxes, int* lo_hi)
+{
+    IAMRX_TRY
+    LayoutP c = coalesce_layout(l->p);
+    const auto& bx = c->boxes;
+    if (lo_hi) {
+        if (*nboxes < (int)bx.size()) throw Error("iamrx_layout_coalesced_boxes: box capacity too small");
+        for (size_t q = 0; q < bx.size(); ++q) for (int d = 0; d < 3; ++d) { lo_hi[6 * q + d] = bx[q].lo[d]; lo_hi[6 * q + 3 + d] = bx[q].hi[d]; }
+    }
+    *nboxes = (int)bx.size();
+    IAMRX_CATCH
+}
 int iamrx_layout_destroy(iamrx_layout l) { IAMRX_TRY delete l; IAMRX_CATCH }
 int iamrx_layout_nlocal(iamrx_layout l, int* n) { IAMRX_TRY *n = l->p->nlocal(); IAMRX_CATCH }
 int iamrx_layout_local_box(iamrx_layout l, int li, int lo_hi[6], int* gi)
@@ -765,6 +779,17 @@ static NSParams to_params(const iamrx_ns_params* p)
     return q;
 }
 
+// The level works on coalesce_layout(the caller's boxes) (mf.h); its data accessors speak the caller's layout.  Ghost cells travel too:
+// first everything incl. the source's ghost cells, then the valid data on top (a destination point covered by one box's ghost cell and
+// another box's valid cell takes the valid one).
+static void relayout_copy(MultiFab& dst, const MultiFab& src, int nc)
+{
+    if (dst.layout->id == src.layout->id) { MultiFab::Copy(dst, src, 0, 0, nc, std::min(dst.ngrow, src.ngrow)); return; }
+    const int ng = std::min(dst.ngrow, src.ngrow);
+    if (ng > 0) parallel_copy(dst, src, 0, 0, nc, ng, ng, nullptr, false);
+    parallel_copy(dst, src, 0, 0, nc, 0, ng, nullptr, false);
+}
+
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
 {
     IAMRX_TRY
@@ -827,8 +852,8 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
     // copy the current contents into a library-owned MultiFab of the same shape (old/new swap every step,
     // so a stable alias would be misleading); the caller destroys it with iamrx_mf_destroy
     auto* h = new iamrx_mf_s;
-    h->mf.define(m->layout, m->type, m->ncomp, m->ngrow);
-    MultiFab::Copy(h->mf, *m, 0, 0, m->ncomp, m->ngrow);
+    h->mf.define(n.user_layout, m->type, m->ncomp, m->ngrow);
+    relayout_copy(h->mf, *m, m->ncomp);
     *out = h;
     IAMRX_CATCH
 }
@@ -837,7 +862,15 @@ int iamrx_ns_data(iamrx_ns ns, int which, iamrx_mf* out)
 int iamrx_ns_derive(iamrx_ns ns, const char* name, iamrx_mf out, int ocomp)
 {
     IAMRX_TRY
-    ns->ns->derive(name, out->mf, ocomp);
+    NavierStokes& n = *ns->ns;
+    if (out->mf.layout->id == n.lay()->id) n.derive(name, out->mf, ocomp);
+    else {
+        IAMRX_ASSERT(out->mf.layout->id == n.user_layout->id && out->mf.type.cell());
+        MultiFab t(n.lay(), cell_type(), 1, 0), u(n.user_layout, cell_type(), 1, 0);
+        n.derive(name, t, 0);
+        relayout_copy(u, t, 1);
+        MultiFab::Copy(out->mf, u, 0, ocomp, 1, 0);
+    }
     IAMRX_CATCH
 }
 
@@ -857,8 +890,8 @@ int iamrx_ns_set_data(iamrx_ns ns, int which, iamrx_mf src)
     default: throw Error("iamrx_ns_set_data: bad selector");
     }
     // fewer components than the level holds: the leading ones (the state without the divu / dsdt components a temperature run appends)
-    IAMRX_ASSERT(src->mf.ncomp <= m->ncomp && src->mf.ngrow == m->ngrow && src->mf.layout->id == m->layout->id);
-    MultiFab::Copy(*m, src->mf, 0, 0, src->mf.ncomp, m->ngrow);
+    IAMRX_ASSERT(src->mf.ncomp <= m->ncomp && src->mf.ngrow == m->ngrow && (src->mf.layout->id == m->layout->id || src->mf.layout->id == n.user_layout->id));
+    relayout_copy(*m, src->mf, src->mf.ncomp);
     IAMRX_CATCH
 }
 
@@ -1070,7 +1103,7 @@ static void amr_refresh_levels(iamrx_amr a)
     for (int l = 0; l < a->amr->nlevels(); ++l) {
         auto v = std::make_unique<iamrx_ns_s>();
         v->ns = &a->amr->level(l);
-        v->layout = a->amr->level(l).lay();
+        v->layout = a->amr->level(l).user_layout;
         for (auto& q : v->views) q = nullptr;
         a->levels.push_back(std::move(v));
     }
@@ -1148,14 +1181,14 @@ int iamrx_amr_level_layout(iamrx_amr a, int lev, iamrx_layout* out)
 {
     IAMRX_TRY
     auto* h = new iamrx_layout_s;
-    h->p = a->amr->level(lev).lay();
+    h->p = a->amr->level(lev).user_layout;
     *out = h;
     IAMRX_CATCH
 }
 int iamrx_amr_level_boxes(iamrx_amr a, int lev, int* nboxes, int* boxes /* 6 ints per box, or NULL to query the count */)
 {
     IAMRX_TRY
-    const auto& bx = a->amr->level(lev).lay()->boxes;
+    const auto& bx = a->amr->level(lev).user_layout->boxes;
     if (boxes) {
         if (*nboxes < (int)bx.size()) throw Error("iamrx_amr_level_boxes: box capacity too small");
         for (size_t q = 0; q < bx.size(); ++q) for (int d = 0; d < 3; ++d) { boxes[6 * q + d] = bx[q].lo[d]; boxes[6 * q + 3 + d] = bx[q].hi[d]; }
@@ -1249,7 +1282,7 @@ int iamrx_ns_profile(iamrx_ns ns, int enable, double sections_ms[8])
     if (enable >= 0) ns->ns->profile_sections = enable == 1 || enable == 2;
     if (enable == 2) for (int i = 0; i < 8; ++i) ns->ns->t_sections[i] = 0.0;
     if (enable == 3) {
-        const Layout& l = *ns->layout;
+        const Layout& l = *ns->ns->lay();
         gs4_probe_start((long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1), 8);
         ns->probing = true;
     }

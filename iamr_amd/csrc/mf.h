@@ -127,6 +127,11 @@ struct Layout {
     mutable std::shared_ptr<Layout> m_repl;
 };
 using LayoutP = std::shared_ptr<Layout>;
+// The boxes a rank owns, merged into as few rectangular boxes as share full faces (same cells, same owners): one process drives one GPU
+// with 288 GB, so nothing is gained from small boxes inside a rank, and every level-wide kernel runs fastest on few large ones (no ghost
+// fills between colour passes, index wrap on periodic domains).  The level objects (NavierStokes, AmrNS) work on the merged layout and
+// translate to the caller's boxes at their data accessors.  Returns l itself if nothing merges or IAMRX_COALESCE = 0.
+LayoutP coalesce_layout(const LayoutP& l);
 
 struct IndexType {
     int t[3];

@@ -732,4 +732,50 @@ void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv,
     execute_plan(plan, *this, *this, comp, comp, nc);
 }
 
+// ------------------------------------------------------------------ coalescing
+// sweeps along x, y, z until nothing merges: two boxes of one owner with equal extents in the two other directions and touching faces
+LayoutP coalesce_layout(const LayoutP& l)
+{
+    if (!l || l->replicated || tune("COALESCE", 1) == 0 || l->boxes.size() < 2) return l;
+    struct OB { BoxD b; int own; };
+    std::vector<OB> v;
+    for (size_t i = 0; i < l->boxes.size(); ++i) v.push_back({l->boxes[i], l->owner[i]});
+    bool merged_any = false, changed = true;
+    while (changed) {
+        changed = false;
+        for (int d = 0; d < 3; ++d) {
+            const int e = (d + 1) % 3, f = (d + 2) % 3;
+            std::sort(v.begin(), v.end(), [&](const OB& a, const OB& b) {
+                if (a.own != b.own) return a.own < b.own;
+                if (a.b.lo[e] != b.b.lo[e]) return a.b.lo[e] < b.b.lo[e];
+                if (a.b.hi[e] != b.b.hi[e]) return a.b.hi[e] < b.b.hi[e];
+                if (a.b.lo[f] != b.b.lo[f]) return a.b.lo[f] < b.b.lo[f];
+                if (a.b.hi[f] != b.b.hi[f]) return a.b.hi[f] < b.b.hi[f];
+                return a.b.lo[d] < b.b.lo[d];
+            });
+            std::vector<OB> w;
+            for (const OB& x : v) {
+                if (!w.empty()) {
+                    OB& y = w.back();
+                    if (y.own == x.own && y.b.lo[e] == x.b.lo[e] && y.b.hi[e] == x.b.hi[e] && y.b.lo[f] == x.b.lo[f] && y.b.hi[f] == x.b.hi[f] &&
+                        y.b.hi[d] + 1 == x.b.lo[d]) { y.b.hi[d] = x.b.hi[d]; changed = true; merged_any = true; continue; }
+                }
+                w.push_back(x);
+            }
+            v.swap(w);
+        }
+    }
+    if (!merged_any) return l;
+    // deterministic order on every rank: by owner, then z, y, x of the lower corner
+    std::sort(v.begin(), v.end(), [](const OB& a, const OB& b) {
+        if (a.own != b.own) return a.own < b.own;
+        if (a.b.lo[2] != b.b.lo[2]) return a.b.lo[2] < b.b.lo[2];
+        if (a.b.lo[1] != b.b.lo[1]) return a.b.lo[1] < b.b.lo[1];
+        return a.b.lo[0] < b.b.lo[0];
+    });
+    std::vector<BoxD> nb; std::vector<int> no;
+    for (const OB& x : v) { nb.push_back(x.b); no.push_back(x.own); }
+    return std::make_shared<Layout>(nb, no, Context::get().comm->rank);
+}
+
 }  // namespace iamrx

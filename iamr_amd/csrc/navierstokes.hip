@@ -47,7 +47,7 @@ struct SectionTimer {
 }  // namespace
 
 NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& par, const MGOpts& opts)
-    : g(geom), layout(std::move(lay)), p(par), o(opts)
+    : user_layout(lay), g(geom), layout(coalesce_layout(lay)), p(par), o(opts)
 {
     nstate = Tracer + 1;
     if (p.do_trac2) Tracer2 = nstate++;

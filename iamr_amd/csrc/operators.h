@@ -232,6 +232,8 @@ class SyncRegister;
 class AmrNS;
 class NavierStokes {
 public:
+    // the boxes as the caller (or the grid generator) gave them; `layout` below is coalesce_layout(user_layout): what the level works on
+    LayoutP user_layout;
     NavierStokes(const Geometry& g, LayoutP layout, const NSParams& p, const MGOpts& o);
     ~NavierStokes();
     void init_taylorgreen(double vfac, double a, double b, double c, double rho0);   // Source/prob/prob_init.cpp:509-560

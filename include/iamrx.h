@@ -119,6 +119,11 @@ const char* iamrx_comm_last_error(void);
 /* ---- containers (amrex::BoxArray/DistributionMapping/MultiFab role) ----------- */
 int iamrx_layout_create(int nboxes, const int* lo_hi /* 6 ints per box: lo[3],hi[3] */, const int* owner_rank,
                         iamrx_layout* out);
+/* The level objects (iamrx_ns_*, iamrx_amr_*) work on the caller's boxes MERGED: boxes of one owner rank that share a full face become one box,
+ * repeatedly (one process drives one GPU, so small boxes inside a rank only cost ghost fills and launches; the reference's amr.max_grid_size
+ * chopping -- RunningProblems.rst:362-368 -- is undone inside the level and restored at its data accessors, which keep speaking the caller's
+ * boxes).  This returns the merged boxes of a layout; IAMRX_COALESCE = 0 (iamrx_tuning_set("COALESCE", 0)) switches the merging off. */
+int iamrx_layout_coalesced_boxes(iamrx_layout l, int* nboxes, int* lo_hi /* 6 ints per box, or NULL to query the count */);
 int iamrx_layout_destroy(iamrx_layout l);
 int iamrx_layout_nlocal(iamrx_layout l, int* nlocal);
 int iamrx_layout_local_box(iamrx_layout l, int local_idx, int lo_hi[6], int* global_idx);

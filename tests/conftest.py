@@ -23,6 +23,10 @@ def gpu():
     """initialised HIP library; fails loudly (no CPU fallback) when the device or the .so is missing"""
     from iamr_amd import lib
     lib.init(0)
+    # The level objects merge the boxes a rank owns (mf.h: coalesce_layout), which would turn every multi-box case of this suite into a
+    # single-box run: the suite keeps the callers' boxes as they are, so that ghost exchanges between boxes, partial tiles and the per-box
+    # multigrid paths stay covered; tests/test_gpu_coalesce.py covers the merged mode (the library's default).
+    lib.tuning_set("COALESCE", 0)
     return lib
 
 

@@ -1,0 +1,151 @@
+"""GPU: the level objects work on the caller's boxes MERGED (mf.h: coalesce_layout -- boxes of one owner that share full faces become one box; the
+library's default, IAMRX_COALESCE = 1), which makes the time step independent of how amr.max_grid_size chopped the level
+(reference Docs/sphinx_documentation/source/RunningProblems.rst:362-368: 32 by default): a level chopped into 64 boxes runs the single-box
+kernels (index wrap on periodic domains, no ghost fills between colour passes) and gives the single-box answer TO THE BIT, while every data
+accessor keeps speaking the caller's boxes.  The rest of the suite switches the merging off (tests/conftest.py) to keep the multi-box
+paths covered."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture()
+def merged(gpu):
+    gpu.tuning_set("COALESCE", 1)
+    yield gpu
+    gpu.tuning_set("COALESCE", 0)
+
+
+def coalesced(lib, lay):
+    n = C.c_int(0)
+    lib.check(lib.lib().iamrx_layout_coalesced_boxes(lay.h, C.byref(n), None))
+    arr = (C.c_int * (6 * n.value))()
+    lib.check(lib.lib().iamrx_layout_coalesced_boxes(lay.h, C.byref(n), arr))
+    return sorted((tuple(arr[6 * q:6 * q + 3]), tuple(arr[6 * q + 3:6 * q + 6])) for q in range(n.value))
+
+
+def test_merging_rules(merged):
+    lib = merged
+    n = (32, 32, 32)
+    assert coalesced(lib, lib.Layout.decompose(n, 8)) == [((0, 0, 0), (31, 31, 31))]                     # 64 boxes -> 1
+    assert coalesced(lib, lib.Layout.decompose((48, 32, 16), (16, 32, 8))) == [((0, 0, 0), (47, 31, 15))]
+    # L-shape: three boxes -> two (the pair sharing a full face), never a box that covers cells nobody owns
+    L = lib.Layout([((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 15, 15)), ((0, 16, 0), (15, 31, 15))])
+    got = coalesced(lib, L)
+    assert len(got) == 2 and sum(np.prod([h - l + 1 for l, h in zip(lo, hi)]) for lo, hi in got) == 3 * 16 ** 3
+    # boxes of different owners stay apart
+    two = lib.Layout([((0, 0, 0), (15, 31, 31)), ((16, 0, 0), (31, 31, 31))], [0, 1])
+    assert len(coalesced(lib, two)) == 2
+    # faces that do not match: nothing merges
+    odd = lib.Layout([((0, 0, 0), (15, 15, 15)), ((16, 0, 0), (31, 7, 15))])
+    assert len(coalesced(lib, odd)) == 2
+    lib.tuning_set("COALESCE", 0)
+    assert len(coalesced(lib, lib.Layout.decompose(n, 8))) == 64
+
+
+def run_tg(lib, n, mgs, nsteps, **kw):
+    from iamr_amd import ns as NS
+    g = lib.Geom.make(n)
+    lay = lib.Layout.single(n) if mgs is None else lib.Layout.decompose(n, mgs)
+    ns = NS.NavierStokes(g, lay, NS.ns_params(init_iter=2, cfl=0.7, visc_coef=1e-3, **kw))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(nsteps)]
+    return ns, lay, dts
+
+
+def test_chopped_periodic_level_equals_the_single_box_run_to_the_bit(merged):
+    lib = merged
+    from iamr_amd import ns as NS
+    n = (64, 64, 64)
+    ns1, lay1, dt1 = run_tg(lib, n, None, 3)
+    ns64, lay64, dt64 = run_tg(lib, n, 16, 3)
+    assert dt1 == dt64 and len(lay64.boxes) == 64
+    for sel, typ in ((NS.NavierStokes.S_NEW, None), (2, "node"), (4, None)):        # state, pressure, grad p
+        A = ns1.data(sel)
+        B = ns64.data(sel)
+        assert B.nlocal() == 64                                                      # the accessor speaks the caller's boxes
+        a = A.gather_valid(n)
+        b = B.gather_valid(n)
+        assert np.array_equal(a, b), (sel, float(np.abs(a - b).max()))
+    # ghost cells of the caller's boxes are filled from the level (interior ones = the neighbour's valid data)
+    S = ns64.data(NS.NavierStokes.S_NEW)
+    full = ns1.data(NS.NavierStokes.S_NEW).gather_valid(n)
+    arr, lo = S.to_numpy(21)
+    blo, bhi, gi = lay64.local_box(21)
+    idx = [np.mod(np.arange(blo[d] - 1, bhi[d] + 2), n[d]) for d in range(3)]
+    assert np.array_equal(arr, full[np.ix_(*idx)])
+    # derived quantity on the caller's layout
+    e1, e64 = ns1.derive("energy").gather_valid(n), ns64.derive("energy").gather_valid(n)
+    assert np.array_equal(e1, e64)
+    # set_data on the caller's layout reaches the level: overwrite the state with the single-box run's and continue both
+    ns64.set_data(NS.NavierStokes.S_NEW, S)
+    assert ns1.step() == ns64.step()
+    assert np.array_equal(ns1.data(0).gather_valid(n), ns64.data(0).gather_valid(n))
+
+
+def test_wall_bounded_level_in_eight_boxes(merged):
+    """LidDrivenCavity set-up (slip / no-slip walls, moving lid, tracer diffusion): 8 boxes merged = 1 box, bit for bit"""
+    lib = merged
+    from iamr_amd import ns as NS
+    n = (32, 32, 32)
+    res = []
+    for mgs in (None, 16):
+        g = lib.Geom.make(n, periodic=(0, 0, 0))
+        lay = lib.Layout.single(n) if mgs is None else lib.Layout.decompose(n, mgs)
+        ns = NS.NavierStokes(g, lay, NS.ns_params(phys_lo=[4, 4, 5], phys_hi=[5, 5, 5], wall_vel_hi=[0.0] * 6 + [1.0, 0.0, 0.0], cfl=0.3, visc_coef=0.01,
+                                                  init_dt=0.0140625, init_shrink=0.3, init_iter=3, tracer_diff_coef=0.001))
+        ns.init_rest(1.0)
+        ns.post_init(-1.0)
+        dts = [ns.step() for _ in range(3)]
+        res.append((dts, ns.data(0).gather_valid(n), ns.data(2).gather_valid(n)))
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_two_level_hierarchy_with_a_chopped_refined_level(merged):
+    """the refined level given as 8 boxes of 16^3 that tile a cube: merged inside the level, reported as given"""
+    lib = merged
+    from iamr_amd import ns as NS
+    from iamr_amd.amr import Amr
+    n0 = 32
+    g0 = lib.Geom.make((n0,) * 3)
+    one = [((16, 16, 16), (47, 47, 47))]
+    eight = [((16 + 16 * i, 16 + 16 * j, 16 + 16 * k), (31 + 16 * i, 31 + 16 * j, 31 + 16 * k)) for k in range(2) for j in range(2) for i in range(2)]
+    out = []
+    for fine in (one, eight):
+        lays = [lib.Layout.decompose((n0,) * 3, 16 if fine is eight else n0), lib.Layout(fine)]
+        amr = Amr(g0, lays, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2, init_shrink=1.0), lib.mg_opts())
+        for l in range(2):
+            amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+        amr.post_init()
+        for _ in range(2):
+            amr.coarse_step()
+        assert [len(l.boxes) for l in amr.layouts] == [len(lays[0].boxes), len(fine)]
+        out.append([amr.levels[l].data(0).gather_valid((n0 * 2 ** l,) * 3) if l == 0 else
+                    np.concatenate([amr.levels[l].data(0).to_numpy(li)[0][1:-1, 1:-1, 1:-1].ravel() for li in range(amr.levels[l].data(0).nlocal())]) for l in range(2)])
+    assert np.array_equal(out[0][0], out[1][0])
+    # level 1: same cells in a different box order -- compare through the global array
+    amr_cells = sorted(out[0][1].tolist()) == sorted(out[1][1].tolist())
+    assert amr_cells
+
+
+def test_restart_of_a_chopped_run(merged, tmp_path, capsys):
+    """checkpoints are written and read on the caller's boxes; the restarted run continues bit for bit"""
+    from iamr_amd import run as R
+    from iamr_amd.plotfile import PlotFile
+    inp = os.path.join(HERE, "golden", "inputs.3d.taylorgreen")
+    plt, chk = str(tmp_path / "plt"), str(tmp_path / "chk")
+    args = [inp, "amr.n_cell=32 32 32", "max_step=6", "stop_time=100.0", "amr.plot_int=6", "amr.max_grid_size=8"]
+    assert R.main(args + [f"amr.plot_file={plt}", f"amr.check_file={chk}", "amr.check_int=3"]) == 0
+    plt2 = str(tmp_path / "rst")
+    assert R.main(args + [f"amr.plot_file={plt2}", "amr.check_int=-1", f"amr.restart={chk}00003"]) == 0
+    capsys.readouterr()
+    A, B = PlotFile.read(plt + "00006"), PlotFile.read(plt2 + "00006")
+    assert len(A.levels[0].boxes) == 64 and A.levels[0].boxes == B.levels[0].boxes
+    for x, y in zip(A.levels[0].data, B.levels[0].data):
+        assert np.array_equal(x, y)

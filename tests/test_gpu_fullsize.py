@@ -18,6 +18,7 @@ N = 256
 def gpu():
     from iamr_amd import lib
     lib.init(0)
+    lib.tuning_set("COALESCE", 0)        # the callers' boxes as they are (tests/conftest.py); tests/test_gpu_coalesce.py covers the merged mode
     return lib
 
 
