@@ -146,7 +146,9 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
         });
     }
     double avg = 0.0;                                            // get_scaled_abs_tol (Diffusion.cpp:193-204)
-    for (int n = 0; n < 3; ++n) avg += (1.0 / 3.0) * Rhs.norm0(n, 1, 0);
+    double rn3[3];
+    Rhs.norm0_comps(0, 3, 0, rn3);
+    for (int n = 0; n < 3; ++n) avg += (1.0 / 3.0) * rn3[n];
     const double tol_abs = visc_tol * avg;
     // Diffusion.cpp:866: FillPatch(U_new) -- of the velocity components that hold rho u* by now: neighbours and periodic images carry rho u*,
     // the physical boundary functor and the coarse level their plain velocities (as written upstream).  The caller's fill does that.

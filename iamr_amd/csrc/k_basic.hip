@@ -174,6 +174,40 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
     return finish_to_host(1, 1, np, global);
 }
 
+// per-component maxima: partials[n * np + block]
+__global__ void __launch_bounds__(256) k_norm0_comps(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
+                                                     const FabD* __restrict__ tab, int comp, int nc, double* __restrict__ partials, int np)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    const bool in = tile_ijk(t, b, i, j, k0, k1);
+    const FabD a = tab[fab];
+    for (int n = 0; n < nc; ++n) {
+        double m = 0.0;
+        if (in) for (int k = k0; k <= k1; ++k) { double v = fabs(a(i, j, k, comp + n)); m = v > m ? v : m; }
+        m = block_reduce<1>(m);
+        if (threadIdx.x == 0) partials[(size_t)n * np + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+void reduce_norm0_comps(const MultiFab& mf, int comp, int nc, int ng, double* out, bool global)
+{
+    global = global && !mf.layout->replicated;
+    auto& ctx = Context::get();
+    int np = 0;
+    if (mf.nlocal() > 0) {
+        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+        dim3 g = t.grid();
+        np = (int)(g.x * g.y);
+        ctx.ensure_scratch((size_t)nc * np + 16);
+        hipLaunchKernelGGL(k_norm0_comps, g, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, mf.type.t[0], mf.type.t[1], mf.type.t[2], ng,
+                           mf.d_tab, comp, nc, ctx.d_scratch, np);
+    } else if (!(global && ctx.comm->nranks > 1)) { for (int n = 0; n < nc; ++n) out[n] = 0.0; return; }
+    finish_to_host(1, nc, np, global);
+    for (int n = 0; n < nc; ++n) out[n] = ctx.h_scratch[n];
+}
+
 // owner mask for nodal / face data: a box owns index hi+1 in a nodal direction only on a
 // non-periodic domain boundary (elsewhere that point is the low point of a neighbouring box or a
 // periodic image)

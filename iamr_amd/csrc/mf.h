@@ -199,6 +199,13 @@ public:
     BoxD fabbox(int li) const { return grow(validbox(li), ngrow); }
 
     void setVal(double v);                              // all comps, incl. ghosts
+    // the OWNER's promise that every entry is v and stays v (constant viscosity / diffusivity arrays of a level): consumers that would
+    // otherwise scan the array for uniformity (CellMG::prepare: a pass + a host synchronisation per array and solve) take the mark
+    void mark_uniform(double v) { uniform_marked = true; uniform_value = v; }
+    bool uniform_marked = false;
+    double uniform_value = 0.0;
+    // max norms of nc components in ONE reduction / host synchronisation: out[n] = max |comp + n|
+    void norm0_comps(int comp, int nc, int ng, double* out, bool local = false) const;
     void setVal(double v, int comp, int nc, int ng);
     void FillBoundary(const Geometry& g);               // same-level + periodic ghost exchange (all comps)
     void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr, int kpar = -1);   // ngv: ghost depth per direction (<= ngrow)

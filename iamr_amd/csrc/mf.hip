@@ -2,6 +2,8 @@
 // Plays the role of AMReX MultiFab / FillBoundary at IAMR's call sites (SURVEY 2.3 "Same-level ghost
 // exchange": reference Source/MacProj.cpp:1127, Source/Projection.cpp:338-339, ...).
 #include "mf.h"
+#include <execinfo.h>
+#include <dlfcn.h>
 #include <chrono>
 #include <functional>
 #include <tuple>
@@ -160,7 +162,23 @@ std::string scope_profile_report()
     return out;
 }
 
-void Context::sync() { ++n_stream_sync; if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream)); }
+// IAMRX_SYNC_TRACE = 1: every host synchronisation prints the return addresses of its callers (resolve with addr2line -e libiamrx.so):
+// the tool behind the host_syncs_per_step figure of bench.py
+void Context::sync()
+{
+    ++n_stream_sync;
+    if (tune("SYNC_TRACE", 0) != 0) {
+        void* bt[6];
+        const int n = backtrace(bt, 6);
+        Dl_info info;
+        fprintf(stderr, "iamrx sync:");
+        for (int i = 1; i < n; ++i) {
+            if (dladdr(bt[i], &info) && info.dli_fbase) fprintf(stderr, " %lx", (unsigned long)((char*)bt[i] - (char*)info.dli_fbase));
+        }
+        fprintf(stderr, "\n");
+    }
+    if (stream) IAMRX_HIP_CHECK(hipStreamSynchronize(stream));
+}
 
 // small host->device uploads (descriptor tables, parameter blocks) without synchronising the stream: the source
 // is copied into a pinned ring buffer first, so the caller's memory may die immediately.  A slot is only reused
@@ -406,6 +424,11 @@ void MultiFab::copy_from_host(int li, const double* src)
 double MultiFab::norm0(int comp, int nc, int ng, bool local) const
 {
     return reduce_norm0(*this, comp, nc, ng, !local);
+}
+
+void MultiFab::norm0_comps(int comp, int nc, int ng, double* out, bool local) const
+{
+    reduce_norm0_comps(*this, comp, nc, ng, out, !local);
 }
 
 double MultiFab::sum_unique(const Geometry& g, int comp, bool local) const

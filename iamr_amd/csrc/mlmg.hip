@@ -73,7 +73,10 @@ void CellMG::prepare()
     m_buni = false;
     if (!m_sig && m_b0[0]->ncomp == 1) {
         m_buni = true;
-        for (int d = 0; d < 3 && m_buni; ++d) m_buni = mf_uniform_value(*m_b0[d], &m_bu[d]);
+        for (int d = 0; d < 3 && m_buni; ++d) {
+            if (m_b0[d]->uniform_marked) m_bu[d] = m_b0[d]->uniform_value;      // the owner's promise (MultiFab::mark_uniform): no scan
+            else m_buni = mf_uniform_value(*m_b0[d], &m_bu[d]);
+        }
     }
     m_dd_sweeps = 0;
     const bool dd_on = tune("MG_DIAG_SHORTCUT", 1) != 0;

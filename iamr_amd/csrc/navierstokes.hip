@@ -68,7 +68,8 @@ NavierStokes::NavierStokes(const Geometry& geom, LayoutP lay, const NSParams& pa
         u_mac[d].setVal(1.e40);                       // NavierStokesBase.cpp:673
         eta[d].define(layout, face_type(d), 1, 0);
         eta[d].setVal(p.visc_coef);
-        for (int n = 1; n < nscal; ++n) if (scal_diff[n] > 0.0) { diff_b[n][d].define(layout, face_type(d), 1, 0); diff_b[n][d].setVal(scal_diff[n]); }
+        eta[d].mark_uniform(p.visc_coef);         // no ns.variable_vel_visc: the array never changes
+        for (int n = 1; n < nscal; ++n) if (scal_diff[n] > 0.0) { diff_b[n][d].define(layout, face_type(d), 1, 0); diff_b[n][d].setVal(scal_diff[n]); diff_b[n][d].mark_uniform(scal_diff[n]); }
     }
     aofs.define(layout, cell_type(), nstate, 0);
     mac_phi.define(layout, cell_type(), 1, 1);
@@ -518,8 +519,11 @@ double NavierStokes::estTimeStep()
             }
         });
     }
+    double umax3[3], fmax3[3];
+    Sn.norm0_comps(Xvel, 3, 0, umax3);
+    tforces.norm0_comps(0, 3, 0, fmax3);
     for (int d = 0; d < 3; ++d) {
-        const double umax = Sn.norm0(d, 1, 0), fmax = tforces.norm0(d, 1, 0);
+        const double umax = umax3[d], fmax = fmax3[d];
         if (umax > small) estdt = std::min(estdt, g.dx[d] / umax);
         if (fmax > small) estdt = std::min(estdt, std::sqrt(2.0 * g.dx[d] / fmax));
     }
@@ -572,8 +576,10 @@ double NavierStokes::predict_velocity(double dt_)
     fillpatch(Umf, So, Xvel, 3, bc_vel);
     floor_small(Umf);
     double cflmax = 0.0;
+    double un3[3];
+    Umf.norm0_comps(0, 3, Umf.ngrow, un3);
     for (int n = 0; n < 3; ++n) {
-        const double c = dt_ * Umf.norm0(n, 1, Umf.ngrow) / g.dx[n];
+        const double c = dt_ * un3[n] / g.dx[n];
         if (n == 0 || c > cflmax) cflmax = c;
     }
     const double tempdt = cflmax == 0 ? p.change_max : std::min(p.change_max, p.cfl / cflmax);

@@ -1,0 +1,29 @@
+"""where the host synchronisations of a time step come from: runs 2 TaylorGreen steps (n^3, default 64) with IAMRX_SYNC_TRACE, resolves the
+caller addresses with addr2line and prints the call sites by count per step (scratch tool)"""
+import sys, os, subprocess, collections, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    from iamr_amd import lib, ns as N
+    lib.init(0)
+    n = int(sys.argv[2])
+    g = lib.Geom.make((n,) * 3); lay = lib.Layout.single((n,) * 3)
+    s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+    s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0); s.post_init(-1.0); s.step(); lib.sync()
+    lib.tuning_set("SYNC_TRACE", 1)
+    for _ in range(2): s.step()
+    lib.tuning_set("SYNC_TRACE", 0)
+    sys.exit(0)
+n = sys.argv[1] if len(sys.argv) > 1 else "64"
+r = subprocess.run([sys.executable, __file__, "child", n], capture_output=True, text=True)
+so = os.path.join(ROOT, "iamr_amd", "libiamrx.so")
+cnt = collections.Counter()
+for line in r.stderr.splitlines():
+    if line.startswith("iamrx sync:"):
+        cnt[tuple(line.split()[2:5])] += 1
+addrs = sorted({a for k in cnt for a in k})
+res = subprocess.run(["addr2line", "-f", "-C", "-e", so] + ["0x" + a for a in addrs], capture_output=True, text=True).stdout.splitlines()
+name = {a: re.sub(r"\(.*", "", res[2 * i]).replace("iamrx::", "") + ":" + res[2 * i + 1].split(":")[-1].split()[0] for i, a in enumerate(addrs)}
+print("host syncs per step:", sum(cnt.values()) / 2)
+for k, v in cnt.most_common():
+    print("%5.1f  %s" % (v / 2, " <- ".join(name[a] for a in k)))
