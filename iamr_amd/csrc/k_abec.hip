@@ -404,7 +404,7 @@ template <int BMODE, bool CF, bool MAINT>
 __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ sgt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
-    const FabD* __restrict__ cfmt, CfC1 cfc, int zero)
+    const FabD* __restrict__ cfmt, CfC1 cfc, int zero, int comp, int bq)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -427,20 +427,34 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
     // the neighbour lane of the row exists (same wavefront, same row, inside the box)?
     const bool laneL = tx > 0 && iL > b.lo[0], laneR = tx < bx - 1 && tx < 63 && iR + 1 <= b.hi[0];
     const int jm = (wrap && j == b.lo[1]) ? b.hi[1] : j - 1, jp = (wrap && j == b.hi[1]) ? b.lo[1] : j + 1;
-    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[0][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[0][1] : 0.0;
+    const double cf1 = (j == bc.dlo[1]) ? bc.cflo[bq][1] : 0.0, cf4 = (j == bc.dhi[1]) ? bc.cfhi[bq][1] : 0.0;
     auto kw = [&](int k) { return wrap ? (k < b.lo[2] ? b.hi[2] : (k > b.hi[2] ? b.lo[2] : k)) : k; };
     // zero (phi_is_zero, wrap only): phi is not read; every cell of the pair is written
     D2 pb, pc;
     if (zero) { pb.l = pb.r = pc.l = pc.r = 0.0; }
-    else { pb = ld2(phi, iL, j, kw(k0 - 1), 0); pc = ld2(phi, iL, j, k0, 0); }
+    else { pb = ld2(phi, iL, j, kw(k0 - 1), comp); pc = ld2(phi, iL, j, k0, comp); }
     D2 sb, sc;
     if (BMODE == 1) { sb = ld2(S, iL, j, k0 - 1, sig_comp); sc = ld2(S, iL, j, k0, sig_comp); }
+    // y-neighbours and right-hand side of the active cell: loaded one plane ahead like the row pair (the pass is bound by the memory latency
+    // of what a thread has in flight, not by bytes: with these three loads issued behind the arithmetic of every plane a constant-coefficient
+    // pass took as long as the MAC form that reads twice as much)
+    auto yload = [&](int k, double& ym, double& yp, double& rv) {
+        const int i = iL + ((b.lo[0] + j + k + redblack) & 1);
+        if (i <= b.hi[0] && k <= k1) {
+            ym = zero ? 0.0 : (double)phi(i, jm, k, comp); yp = zero ? 0.0 : (double)phi(i, jp, k, comp);
+            rv = rhs(i, j, k, comp);
+        } else { ym = yp = rv = 0.0; }
+    };
+    double nym, nyp, nrr;
+    yload(k0, nym, nyp, nrr);
     for (int k = k0; k <= k1; ++k) {
         const int par = (b.lo[0] + j + k + redblack) & 1;         // 0: the left cell of the pair is active
         const int i = iL + par;
         const bool live = i <= b.hi[0];
+        const double pym = nym, pyp = nyp, rr = nrr;
+        yload(k + 1, nym, nyp, nrr);
         D2 pa;
-        if (zero) { pa.l = pa.r = 0.0; } else pa = ld2(phi, iL, j, kw(k + 1), 0);
+        if (zero) { pa.l = pa.r = 0.0; } else pa = ld2(phi, iL, j, kw(k + 1), comp);
         D2 sa;
         if (BMODE == 1) sa = ld2(S, iL, j, k + 1, sig_comp);
         // x-neighbours: the other cell of the pair, and the adjacent lane's near cell (or a load where there is no such lane)
@@ -448,11 +462,11 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
         double pxm, pxp;
         if (zero) { pxm = pxp = 0.0; }
         else if (par == 0) {
-            pxp = (wrap && i == b.hi[0]) ? (double)phi(b.lo[0], j, k, 0) : pc.r;
-            pxm = laneL ? fromL : (double)phi((wrap && i == b.lo[0]) ? b.hi[0] : i - 1, j, k, 0);
+            pxp = (wrap && i == b.hi[0]) ? (double)phi(b.lo[0], j, k, comp) : pc.r;
+            pxm = laneL ? fromL : (double)phi((wrap && i == b.lo[0]) ? b.hi[0] : i - 1, j, k, comp);
         } else {
             pxm = pc.l;
-            pxp = laneR ? fromR : (live ? (double)phi((wrap && i == b.hi[0]) ? b.lo[0] : i + 1, j, k, 0) : 0.0);
+            pxp = laneR ? fromR : (live ? (double)phi((wrap && i == b.hi[0]) ? b.lo[0] : i + 1, j, k, comp) : 0.0);
         }
         // coarse/fine masks of the (up to six) ghost cells this cell's coefficient or its ghost rewrite can need: loaded here, with the data
         // of the plane, not behind the arithmetic that uses them (they used to be two dependent round trips per plane for every wavefront)
@@ -473,9 +487,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
         }
         if (live) {
             const double p0 = par ? pc.r : pc.l;
-            const double pym = zero ? 0.0 : (double)phi(i, jm, k, 0), pyp = zero ? 0.0 : (double)phi(i, jp, k, 0);
             const double pzm = par ? pb.r : pb.l, pzp = par ? pa.r : pa.l;
-            const double rr = rhs(i, j, k, 0);
             double bxm, bxp, bym, byp, bzm, bzp;
             if (BMODE == 1) {                  // mac_bcoef's expression, lower cell first
                 sym = S(i, j - 1, k, sig_comp); syp = S(i, j + 1, k, sig_comp);
@@ -484,8 +496,8 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
                 bym = sig_scale / (0.5 * (sym + s0)); byp = sig_scale / (0.5 * (s0 + syp));
                 bzm = sig_scale / (0.5 * (szm + s0)); bzp = sig_scale / (0.5 * (s0 + szp));
             } else { bxm = bxp = bu.v[0]; bym = byp = bu.v[1]; bzm = bzp = bu.v[2]; }
-            double cf0 = (i == bc.dlo[0]) ? bc.cflo[0][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[0][0] : 0.0;
-            double cf2 = (k == bc.dlo[2]) ? bc.cflo[0][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[0][2] : 0.0;
+            double cf0 = (i == bc.dlo[0]) ? bc.cflo[bq][0] : 0.0, cf3 = (i == bc.dhi[0]) ? bc.cfhi[bq][0] : 0.0;
+            double cf2 = (k == bc.dlo[2]) ? bc.cflo[bq][2] : 0.0, cf5 = (k == bc.dhi[2]) ? bc.cfhi[bq][2] : 0.0;
             double c1 = cf1, c4 = cf4;
             if (cf) {
                 if (i == b.lo[0] && mxl == 1.0) cf0 = c1x;
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
             const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
             const double res = rr - (gamma * p0 - rho);
             const double pn = p0 + omega / g_m_d * res;
-            phi(i, j, k, 0) = pn;
+            phi(i, j, k, comp) = pn;
             if (cf && MAINT) {
                 // cf_maintain_nb with the masks already in registers: (distance from the face, mask, neighbour towards / away from the face)
                 auto rewrite = [&](int d, int dist, double mask, double towards, double away, int gi, int gj, int gk) {
@@ -510,7 +522,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
                     double v = 0.0;
                     if (NX == 2) v += pn * cd.c1[d];
                     else { v += towards * cd.c1[d]; v += pn * cd.c2[d]; if (NX > 3) v += away * cd.c3[d]; }
-                    phi(gi, gj, gk, 0) = v;
+                    phi(gi, gj, gk, comp) = v;
                 };
                 rewrite(0, i - b.lo[0], mxl, pxm, pxp, b.lo[0] - 1, j, k);
                 rewrite(0, b.hi[0] - i, mxh, pxp, pxm, b.hi[0] + 1, j, k);
@@ -520,7 +532,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
                 rewrite(2, b.hi[2] - k, mzh, pzp, pzm, i, j, b.hi[2] + 1);
             }
         }
-        if (zero) { const int io = par ? iL : iR; if (io <= b.hi[0]) phi(io, j, k, 0) = 0.0; }
+        if (zero) { const int io = par ? iL : iR; if (io <= b.hi[0]) phi(io, j, k, comp) = 0.0; }
         pb = pc; pc = pa;
         if (BMODE == 1) { sb = sc; sc = sa; }
     }
@@ -573,7 +585,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
             int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
             Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
 #define IAMRX_GS2(M, C, MT, SG, SC, SS) hipLaunchKernelGGL((k_abec_gsrb2<M, C, MT>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, \
-                                   c.a ? c.a->d_tab : nullptr, SG, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, SC, SS, bu, cft, cfc, zero)
+                                   c.a ? c.a->d_tab : nullptr, SG, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, SC, SS, bu, cft, cfc, zero, 0, 0)
             const bool mt = cft && cfc.maintain;
             if (mode == 1) {
                 if (mt) IAMRX_GS2(1, true, true, c.sig->d_tab, c.sig_comp, c.sig_scale);
@@ -596,6 +608,23 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
         hipLaunchKernelGGL((k_abec_gsrb<false, 1>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.sig->d_tab, c.sig->d_tab,
                            c.alpha, dhx, dhy, dhz, redblack, omega, 1, 1, gb, shell_only ? 1 : 0, 0, wrap ? 1 : 0, cft, cfc, c.sig_comp, c.sig_scale);
+    else if (uni && phi.ncomp > 1 && !shell_only && c.b[0]->ncomp == 1 && phi.ngrow >= 1 && tune("GSRB2", 1) != 0 && tune("GSRB2_MULTI", 0) != 0) {
+        // IAMRX_GSRB2_MULTI = 1 (off by default: measured equal, 3 x 112 us against 336 us at 256^3 -- both forms move the half-used lines of
+        // the red-black layout at the achievable HBM rate): several components with constant coefficients (the tensor solves of a
+        // constant-viscosity run, the unit-coefficient tensor solve of diffuse_tensor_Vsync) as one pair-marching launch per component
+        // with its own constants b_d (x 4/3 on the normal component of the tensor operator) -- the expressions of k_abec_gsrb<true, 2>
+        int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
+        Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
+        for (int n = 0; n < phi.ncomp; ++n) {
+            BUni bn;
+            for (int d = 0; d < 3; ++d) bn.v[d] = bu.v[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
+            const int bq = gb.nbc == 1 ? 0 : (n < 3 ? n : 0);
+#define IAMRX_GS2M(C) hipLaunchKernelGGL((k_abec_gsrb2<2, C, false>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, \
+                                  c.a ? c.a->d_tab : nullptr, nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bn, cft, cfc, 0, n, bq)
+            if (cft) IAMRX_GS2M(true); else IAMRX_GS2M(false);
+#undef IAMRX_GS2M
+        }
+    }
     else if (uni && phi.ncomp > 1)
         hipLaunchKernelGGL((k_abec_gsrb<true, 2>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,

@@ -327,6 +327,7 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool g
 // ------------------------------------------------------------------ BLAS-1 style
 void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const MultiFab& y, int comp, int nc, int ng)
 {
+    trace_blas_site("lincomb", dst.layout ? dst.layout->local_cells() * nc : 0);
     if (!dst.base) return;
     const FabD *dt = dst.d_tab, *xt = x.d_tab, *yt = y.d_tab;
     for_each(*dst.layout, dst.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -337,6 +338,7 @@ void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const Mult
 
 void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, int nc, int ng)
 {
+    trace_blas_site("saxpy", y.layout ? y.layout->local_cells() * nc : 0);
     if (!y.base) return;
     const FabD *yt = y.d_tab, *xt = x.d_tab;
     for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -357,6 +359,7 @@ void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng)
 
 void mf_mult(MultiFab& y, double a, int comp, int nc, int ng)
 {
+    trace_blas_site("mult", y.layout ? y.layout->local_cells() * nc : 0);
     if (!y.base) return;
     const FabD* yt = y.d_tab;
     for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {

@@ -71,6 +71,7 @@ struct Context {
 // variables IAMRX_<KEY> that are set, changed afterwards only through iamrx_tuning_set, and read by the code at the point of use
 // (tune(key, default)) -- no function-local static caches a choice for the life of the process.
 double tune(const char* key, double dflt);
+void trace_blas_site(const char* what, long points);   // IAMRX_BLAS_TRACE (mf.hip)
 void tuning_set(const char* key, double value);
 void tuning_load_environment();          // called by Context::init
 

@@ -164,6 +164,18 @@ std::string scope_profile_report()
 
 // IAMRX_SYNC_TRACE = 1: every host synchronisation prints the return addresses of its callers (resolve with addr2line -e libiamrx.so):
 // the tool behind the host_syncs_per_step figure of bench.py
+// IAMRX_BLAS_TRACE = 1: every level-wide copy / fill / axpy prints its size and the return addresses of its callers (tools/sync_trace.py blas)
+void trace_blas_site(const char* what, long points)
+{
+    if (tune("BLAS_TRACE", 0) == 0) return;
+    void* bt[6];
+    const int n = backtrace(bt, 6);
+    Dl_info info;
+    fprintf(stderr, "iamrx blas: %s %ld", what, points);
+    for (int i = 2; i < n; ++i)
+        if (dladdr(bt[i], &info) && info.dli_fbase) fprintf(stderr, " %lx", (unsigned long)((char*)bt[i] - (char*)info.dli_fbase));
+    fprintf(stderr, "\n");
+}
 void Context::sync()
 {
     ++n_stream_sync;
@@ -379,6 +391,7 @@ void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)
 
 void MultiFab::setVal(double v)
 {
+    trace_blas_site("setVal", layout ? layout->local_cells() * ncomp : 0);
     if (!base) return;
     if (is_alias) { setVal(v, 0, ncomp, ngrow); return; }      // the fabs of an alias are not one allocation
     launch_fill(base, total_doubles, v, Context::get().stream);
@@ -396,6 +409,7 @@ void MultiFab::setVal(double v, int comp, int nc, int ng)
 
 void MultiFab::Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng)
 {
+    trace_blas_site("Copy", dst.layout ? dst.layout->local_cells() * nc : 0);
     IAMRX_ASSERT(dst.layout->id == src.layout->id || dst.layout->boxes.size() == src.layout->boxes.size());
     IAMRX_ASSERT(ng <= dst.ngrow && ng <= src.ngrow);
     if (!dst.base) return;

@@ -67,8 +67,11 @@ KERNEL_FORMS = {
     "fused restriction only": {"RESID_PAIRS": 0},
     # tensor residual as two launches (7-point part, then the cross terms) instead of one
     "unfused tensor residual": {"TENSOR_FUSED": 0},
+    # round 4: the three components of a constant-coefficient tensor colour pass as three pair-marching launches instead of one launch of
+    # the general kernel
+    "multi-component colour pass per component": {"GSRB2_MULTI": 1},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "channel_walls"])

@@ -10,20 +10,27 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     g = lib.Geom.make((n,) * 3); lay = lib.Layout.single((n,) * 3)
     s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
     s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0); s.post_init(-1.0); s.step(); lib.sync()
-    lib.tuning_set("SYNC_TRACE", 1)
+    key = os.environ.get("TRACE_KEY", "SYNC_TRACE")
+    lib.tuning_set(key, 1)
     for _ in range(2): s.step()
-    lib.tuning_set("SYNC_TRACE", 0)
+    lib.tuning_set(key, 0)
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "64"
 r = subprocess.run([sys.executable, __file__, "child", n], capture_output=True, text=True)
 so = os.path.join(ROOT, "iamr_amd", "libiamrx.so")
 cnt = collections.Counter()
+big = int(n) ** 3 // 2
 for line in r.stderr.splitlines():
     if line.startswith("iamrx sync:"):
         cnt[tuple(line.split()[2:5])] += 1
-addrs = sorted({a for k in cnt for a in k})
+    elif line.startswith("iamrx blas:"):
+        w = line.split()
+        if int(w[3]) >= big:                      # finest-level arrays only
+            cnt[(w[2],) + tuple(w[4:7])] += 1
+addrs = sorted({a for k in cnt for a in k if re.fullmatch(r"[0-9a-f]+", a) and len(a) > 3})
 res = subprocess.run(["addr2line", "-f", "-C", "-e", so] + ["0x" + a for a in addrs], capture_output=True, text=True).stdout.splitlines()
 name = {a: re.sub(r"\(.*", "", res[2 * i]).replace("iamrx::", "") + ":" + res[2 * i + 1].split(":")[-1].split()[0] for i, a in enumerate(addrs)}
-print("host syncs per step:", sum(cnt.values()) / 2)
+name.update({k: k for k in ("setVal", "Copy", "saxpy", "lincomb", "mult")})
+print("events per step:", sum(cnt.values()) / 2)
 for k, v in cnt.most_common():
     print("%5.1f  %s" % (v / 2, " <- ".join(name[a] for a in k)))
