@@ -590,7 +590,12 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     // margins: node (a, b) belongs to the region of colour pass c (tile grown by 3 - c) iff min(mx[a], my[b]) >= c; to the tile iff >= 3
     int mx[2], my[PB];
     // byte offsets (unsigned 32 bit: the loads take a uniform plane pointer + a 32-bit lane offset, no 64-bit address registers)
-    unsigned xcol[2], scol[2], rcol[2], dcol[2], xrow[PB], srow[PB], rrow[PB], drow[PB];
+    // MASK: the right-hand side and the Dirichlet mask have the shape of x (the launcher checks): one set of offsets serves the three arrays
+    unsigned xcol[2], scol[2], rcol_[MASK ? 1 : 2], xrow[PB], srow[PB], rrow_[MASK ? 1 : PB];
+    unsigned (&rcol)[2] = MASK ? xcol : *reinterpret_cast<unsigned (*)[2]>(&rcol_[0]);
+    unsigned (&rrow)[PB] = MASK ? xrow : *reinterpret_cast<unsigned (*)[PB]>(&rrow_[0]);
+    unsigned (&dcol)[2] = xcol;
+    unsigned (&drow)[PB] = xrow;
     unsigned surf = 0;      // MASK: bit b * 2 + a: node on the box surface or outside the box in x or y (only those can be Dirichlet nodes)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -601,11 +606,8 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         else { xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); }
         xcol[a] = 8u * (unsigned)(xi - x.lo[0]);
         scol[a] = CSIG ? 0u : 8u * (unsigned)(si - s.lo[0]);
-        rcol[a] = 8u * (unsigned)(min(max(xi, r.lo[0]), r.lo[0] + r.n[0] - 1) - r.lo[0]);
-        if constexpr (MASK) {
-            dcol[a] = 8u * (unsigned)(min(max(gi, dmt[fab].lo[0]), dmt[fab].lo[0] + dmt[fab].n[0] - 1) - dmt[fab].lo[0]);
-            if (gi <= cb.lo[0] || gi >= nhi0) surf |= 0x55555555u << a;
-        } else dcol[a] = 0;
+        if constexpr (!MASK) rcol[a] = 8u * (unsigned)(min(max(xi, r.lo[0]), r.lo[0] + r.n[0] - 1) - r.lo[0]);
+        if constexpr (MASK) { if (gi <= cb.lo[0] || gi >= nhi0) surf |= 0x55555555u << a; }
     }
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
@@ -616,11 +618,8 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         else { xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1); }
         xrow[b] = 8u * (unsigned)((xj - x.lo[1]) * x.n[0]);
         srow[b] = CSIG ? 0u : 8u * (unsigned)((sj - s.lo[1]) * s.n[0]);
-        rrow[b] = 8u * (unsigned)((min(max(xj, r.lo[1]), r.lo[1] + r.n[1] - 1) - r.lo[1]) * r.n[0]);
-        if constexpr (MASK) {
-            drow[b] = 8u * (unsigned)((min(max(gj, dmt[fab].lo[1]), dmt[fab].lo[1] + dmt[fab].n[1] - 1) - dmt[fab].lo[1]) * dmt[fab].n[0]);
-            if (gj <= cb.lo[1] || gj >= nhi1) surf |= 3u << (2 * b);
-        } else drow[b] = 0;
+        if constexpr (!MASK) rrow[b] = 8u * (unsigned)((min(max(xj, r.lo[1]), r.lo[1] + r.n[1] - 1) - r.lo[1]) * r.n[0]);
+        if constexpr (MASK) { if (gj <= cb.lo[1] || gj >= nhi1) surf |= 3u << (2 * b); }
     }
     // bit 2 PB c + 2 b + a: node (a, b) belongs to the region of colour pass c (the tile grown by 3 - c nodes); c = 3: to the tile itself
     unsigned um[(8 * PB + 31) / 32];
@@ -944,7 +943,7 @@ static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
                                              xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, gg, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
     if (dmask) {
         IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
-        IAMRX_GSR(false, true, false);
+        IAMRX_GSR(false, true, false);                                  // (same shape of x, rhs and mask: checked by nodal_gs_fused_pass)
     } else if (wrap) { if (csig) IAMRX_GSR(true, false, true); else IAMRX_GSR(true, false, false); }
     else { if (csig) IAMRX_GSR(false, false, true); else IAMRX_GSR(false, false, false); }
 #undef IAMRX_GSR
@@ -974,7 +973,8 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
     // levels whose boxes are at least GSR_MIN cells long in x and y: the register-resident kernel (IAMRX_GSR=0: k_nodal_gs4 everywhere)
-    if (tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48)) {
+    const bool mask_shapes_ok = !dmask || (dmask->ngrow == x.ngrow && rhs.ngrow == x.ngrow);
+    if (tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48) && mask_shapes_ok) {
         if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
         else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
         return;
