@@ -514,6 +514,7 @@ struct GsrGeom {
     int tix, tiy;       // tile pitch (even, <= 56)
     int ppc;            // planes of one parity per workgroup
     int xcd_chunk;      // > 0: XCD-aware order, chunks per tile
+    int zc, zn;         // the array the own-parity planes (zc) / the other-parity planes (zn) come from is identically zero: it is not read
 };
 
 // the update of one node, k_nodal_gs4's expression tree: x?[db + 1][da + 1] = x(i + da, j + db, plane), s?[db + 1][da + 1] = sigma of
@@ -688,9 +689,12 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     };
     int slm = 0, slp = 1, slf = 2;                     // ring slots of the sigma planes k - 1, k and the free one
     double T1[PB][2];                                  // a sigma plane on its way from HBM to the ring
-    load_plane(xn.gp(), xk(k0 - 1), xcol, xrow, Xm);
-    load_plane(x.gp(), xk(k0), xcol, xrow, Xc);
-    load_plane(xn.gp(), xk(k0 + 1), xcol, xrow, Xp);
+    auto zero_plane = [&](double (&dst)[PB][2]) {
+#pragma unroll
+        for (int b = 0; b < PB; ++b) dst[b][0] = dst[b][1] = 0.0;
+    };
+    if (gg.zn) { zero_plane(Xm); zero_plane(Xp); } else { load_plane(xn.gp(), xk(k0 - 1), xcol, xrow, Xm); load_plane(xn.gp(), xk(k0 + 1), xcol, xrow, Xp); }
+    if (gg.zc) zero_plane(Xc); else load_plane(x.gp(), xk(k0), xcol, xrow, Xc);
     if constexpr (!CSIG) {
         double T0[PB][2];
         load_plane(s.gp(), sk(k0 - 1), scol, srow, T0); load_plane(s.gp(), sk(k0), scol, srow, T1);
@@ -781,8 +785,8 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
                 ring_store(slf, T1);                                  // sigma plane k + 1: into the free slot
                 load_plane(s.gp(), sk(k + 2), scol, srow, T1);
             }
-            load_plane(x.gp(), xk(k + 2), xcol, xrow, Nc);
-            load_plane(xn.gp(), xk(k + 3), xcol, xrow, Np);
+            if (gg.zc) zero_plane(Nc); else load_plane(x.gp(), xk(k + 2), xcol, xrow, Nc);
+            if (gg.zn) zero_plane(Np); else load_plane(xn.gp(), xk(k + 3), xcol, xrow, Np);
         }
         __syncthreads();
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -914,9 +918,10 @@ static void gsr_tiles(int len_nodes, int& nt, int& pitch)
 
 template <int PB>
 static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap, const MultiFab* dmask, const double* csig)
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int zero_flags)
 {
     GsrGeom gg;
+    gg.zc = zero_flags & 1; gg.zn = (zero_flags >> 1) & 1;
     gsr_tiles(l.max_len[0] + 1, gg.ntx, gg.tix);
     gsr_tiles(l.max_len[1] + 1, gg.nty, gg.tiy);
     const int npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
@@ -962,8 +967,16 @@ bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
     return true;
 }
 
+// the register-resident kernel takes this level (and honours zero_flags: bit 0 / 1 = xc / xn is identically zero and need not be read)
+bool nodal_gsr_applies(const MultiFab& x, const MultiFab& rhs, const MultiFab* dmask)
+{
+    const Layout& l = *x.layout;
+    const bool mask_shapes_ok = !dmask || (dmask->ngrow == x.ngrow && rhs.ngrow == x.ngrow);
+    return tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48) && mask_shapes_ok;
+}
+
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap,
-                         const MultiFab* dmask, const double* csig)
+                         const MultiFab* dmask, const double* csig, int zero_flags)
 {
     const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
@@ -973,12 +986,12 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // on MI355X: 0.151 ms per launch against 0.179 ms for 32x32 / 512 threads (IAMRX_GS4_TILE=1; fewer redundant loads and
     // updates but 8-wave barriers)
     // levels whose boxes are at least GSR_MIN cells long in x and y: the register-resident kernel (IAMRX_GSR=0: k_nodal_gs4 everywhere)
-    const bool mask_shapes_ok = !dmask || (dmask->ngrow == x.ngrow && rhs.ngrow == x.ngrow);
-    if (tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48) && mask_shapes_ok) {
-        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
-        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
+    if (nodal_gsr_applies(x, rhs, dmask)) {
+        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags);
+        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags);
         return;
     }
+    IAMRX_ASSERT(zero_flags == 0);       // k_nodal_gs4 reads its inputs
     const int big = (int)tune("GS4_TILE", 0);
     if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
     else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);

@@ -158,7 +158,8 @@ public:
     const MultiFab* dmask(int l) const { return m_lev[l].dmask(); }
     const MultiFab& sigma(int l) const { return m_lev[l].sig; }
     const Geometry& geom(int l) const { return m_lev[l].g; }
-    void smooth(int l, MultiFab& x, const MultiFab& rhs);
+    // x_is_zero: x is to be taken as zero whatever it holds (the first smooth call on a correction); the call leaves x fully defined
+    void smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero = false);
     void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm = nullptr);   // norm: max norm of r (by the residual launch itself where it can)
     void vcycle(MGStats& st);
     // one V-cycle for the residual equation A e = r, zero initial guess; e is zero on Dirichlet nodes, its ghost nodes are filled.

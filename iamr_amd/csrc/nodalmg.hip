@@ -156,9 +156,14 @@ void NodalMG::fillbc(int l, MultiFab& x, int kpar)
     nodal_reflect_bc(m_lev[l].g, x, m_bc);
 }
 
-void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
+void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero)
 {
     Level& L = m_lev[l];
+    // a correction that starts from zero: on a level the register-resident kernel smooths with index wrap (no ghost nodes are read) the
+    // first sweep is told so and reads no x -- the zero fill and a third of the first sweep's traffic; everywhere else x is zeroed here
+    const bool zero_start = x_is_zero && m_o.nodal_smoother == 0 && nodal_fused() && !L.dmask() && periodic_wrap_ok(L.g, *L.layout, 4) &&
+                            nodal_gsr_applies(x, rhs, nullptr) && tune("NODAL_ZERO_START", 1) != 0;
+    if (x_is_zero && !zero_start) x.setVal(0.0);
     // small single-box periodic levels: all sweeps x colours in one single-workgroup launch
     const MultiFab* dmk = L.dmask();
     if (!dmk && m_o.nodal_smoother == 0 && nodal_small() && nodal_smooth_small(L.g, x, rhs, L.sig, m_o.nodal_sweeps)) {
@@ -186,9 +191,10 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs)
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
             if (!wrap) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
             const double* cs = m_csig ? &m_csig_val : nullptr;
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs);      // even planes: a -> b
+            const bool z = zero_start && ns == 0;
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs, z ? 3 : 0);      // even planes: a -> b
             if (!wrap) fillbc(l, *b, par_fill ? 0 : -1);                     // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs);      // odd planes: centre from a, neighbours from b
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs, z ? 1 : 0);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
@@ -304,8 +310,8 @@ void NodalMG::vcycle(MGStats& st)
     const int nl = (int)m_lev.size();
     for (int l = 0; l < nl - 1; ++l) {
         Level& L = m_lev[l];
-        L.cor.setVal(0.0);
-        for (int i = 0; i < m_o.nodal_nu1; ++i) smooth(l, L.cor, L.res);
+        if (m_o.nodal_nu1 <= 0) L.cor.setVal(0.0);
+        for (int i = 0; i < m_o.nodal_nu1; ++i) smooth(l, L.cor, L.res, i == 0);
         residual(l, L.rescor, L.cor, L.res);
         fillbc(l, L.rescor);
         if (m_lev[l + 1].agg) {

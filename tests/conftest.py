@@ -7,6 +7,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# processes the tests spawn (tests/test_gpu_dist.py: one process per rank) start their own library: they inherit the suite's choice of
+# keeping the callers' boxes (see the `gpu` fixture) through the environment
+os.environ.setdefault("IAMRX_COALESCE", os.environ.get("IAMRX_TEST_COALESCE", "0"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run through the HIP C-ABI)")
 
@@ -26,7 +31,7 @@ def gpu():
     # The level objects merge the boxes a rank owns (mf.h: coalesce_layout), which would turn every multi-box case of this suite into a
     # single-box run: the suite keeps the callers' boxes as they are, so that ghost exchanges between boxes, partial tiles and the per-box
     # multigrid paths stay covered; tests/test_gpu_coalesce.py covers the merged mode (the library's default).
-    lib.tuning_set("COALESCE", 0)
+    lib.tuning_set("COALESCE", float(os.environ.get("IAMRX_TEST_COALESCE", "0")))      # IAMRX_TEST_COALESCE=1: the whole suite on merged boxes
     return lib
 
 

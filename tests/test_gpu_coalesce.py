@@ -107,31 +107,36 @@ def test_wall_bounded_level_in_eight_boxes(merged):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
-def test_two_level_hierarchy_with_a_chopped_refined_level(merged):
-    """the refined level given as 8 boxes of 16^3 that tile a cube: merged inside the level, reported as given"""
+def test_two_level_hierarchy_merges_only_the_level_that_covers_its_domain(merged):
+    """viscous two-level run, coarse level in 8 boxes, refined level in 4: the coarse level (covers the domain) is merged, the refined level
+    keeps the caller's boxes -- the reference's tensor operator fills edge / corner ghost cells at coarse/fine boundaries box by box, so
+    its answer depends on the fine boxes at O(h^2) (2e-5 here) and merging them would answer another question.  Merged-coarse run ==
+    all-boxes-kept run to solver tolerance; both report the caller's boxes."""
     lib = merged
     from iamr_amd import ns as NS
     from iamr_amd.amr import Amr
-    n0 = 32
+    n0 = 16
     g0 = lib.Geom.make((n0,) * 3)
-    one = [((16, 16, 16), (47, 47, 47))]
-    eight = [((16 + 16 * i, 16 + 16 * j, 16 + 16 * k), (31 + 16 * i, 31 + 16 * j, 31 + 16 * k)) for k in range(2) for j in range(2) for i in range(2)]
+    cb = [((i, j, k), (i + 7, j + 7, k + 7)) for k in (0, 8) for j in (0, 8) for i in (0, 8)]
+    fb = [((8 + 8 * i, 8 + 8 * j, 8), (15 + 8 * i, 15 + 8 * j, 23)) for j in (0, 1) for i in (0, 1)]
     out = []
-    for fine in (one, eight):
-        lays = [lib.Layout.decompose((n0,) * 3, 16 if fine is eight else n0), lib.Layout(fine)]
-        amr = Amr(g0, lays, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2, init_shrink=1.0), lib.mg_opts())
+    for co in (1, 0):
+        lib.tuning_set("COALESCE", co)
+        lays = [lib.Layout(cb), lib.Layout(fb)]
+        amr = Amr(g0, lays, NS.ns_params(cfl=0.7, visc_coef=0.01, tracer_diff_coef=0.005, init_iter=2), lib.mg_opts())
         for l in range(2):
             amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
         amr.post_init()
-        for _ in range(2):
-            amr.coarse_step()
-        assert [len(l.boxes) for l in amr.layouts] == [len(lays[0].boxes), len(fine)]
-        out.append([amr.levels[l].data(0).gather_valid((n0 * 2 ** l,) * 3) if l == 0 else
-                    np.concatenate([amr.levels[l].data(0).to_numpy(li)[0][1:-1, 1:-1, 1:-1].ravel() for li in range(amr.levels[l].data(0).nlocal())]) for l in range(2)])
-    assert np.array_equal(out[0][0], out[1][0])
-    # level 1: same cells in a different box order -- compare through the global array
-    amr_cells = sorted(out[0][1].tolist()) == sorted(out[1][1].tolist())
-    assert amr_cells
+        dts = [amr.coarse_step() for _ in range(2)]
+        assert [len(l.boxes) for l in amr.layouts] == [8, 4]
+        fine = amr.levels[1].data(0)
+        out.append((dts, amr.levels[0].data(0).gather_valid((n0,) * 3),
+                    {lays[1].local_box(li)[2]: fine.to_numpy(li)[0][1:-1, 1:-1, 1:-1] for li in range(fine.nlocal())}))
+    lib.tuning_set("COALESCE", 1)
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-10, atol=0)
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-8
+    for k in out[0][2]:
+        assert np.abs(out[0][2][k] - out[1][2][k]).max() <= 1e-8
 
 
 def test_restart_of_a_chopped_run(merged, tmp_path, capsys):

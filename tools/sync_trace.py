@@ -8,8 +8,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     lib.init(0)
     n = int(sys.argv[2])
     g = lib.Geom.make((n,) * 3); lay = lib.Layout.single((n,) * 3)
-    s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
-    s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0); s.post_init(-1.0); s.step(); lib.sync()
+    if os.environ.get("TRACE_AMR"):
+        # the bench's 2-level workload (n^3 base + n^3 refined box): the events of two coarse steps
+        from iamr_amd.amr import Amr
+        lays = [lay, lib.Layout([((n // 2,) * 3, (n // 2 + n - 1,) * 3)])]
+        amr = Amr(g, lays, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+        for l in range(2): amr.levels[l].init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+        amr.post_init(); amr.coarse_step(); lib.sync()
+        class S:
+            def step(self): amr.coarse_step()
+        s = S()
+    else:
+        s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+        s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0); s.post_init(-1.0); s.step(); lib.sync()
     key = os.environ.get("TRACE_KEY", "SYNC_TRACE")
     lib.tuning_set(key, 1)
     for _ in range(2): s.step()
