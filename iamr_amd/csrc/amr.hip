@@ -115,6 +115,17 @@ void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int
     execute_plan(*it->second, dst, src, scomp, dcomp, nc, add);
 }
 
+// Between two layouts that hold the same cells in different boxes (a level's merged working layout and the caller's boxes, mf.h:
+// coalesce_layout).  Ghost cells travel too: first everything incl. the source's ghost cells, then the valid data on top (a destination
+// point covered by one box's ghost cell and another box's valid cell takes the valid one).
+void relayout_copy(MultiFab& dst, const MultiFab& src, int nc, int scomp, int dcomp)
+{
+    const int ng = std::min(dst.ngrow, src.ngrow);
+    if (dst.layout->id == src.layout->id) { MultiFab::Copy(dst, src, scomp, dcomp, nc, ng); return; }
+    if (ng > 0) parallel_copy(dst, src, scomp, dcomp, nc, ng, ng, nullptr, false);
+    parallel_copy(dst, src, scomp, dcomp, nc, 0, ng, nullptr, false);
+}
+
 // fine -> coarsened-fine layout: mean of the ratio^3 children (cells), of the ratio^2 coplanar children (faces), injection (nodes)
 static void coarsen_onto(MultiFab& cf, const MultiFab& fine, int scomp, int ncomp, int ratio)
 {

@@ -779,17 +779,6 @@ static NSParams to_params(const iamrx_ns_params* p)
     return q;
 }
 
-// The level works on coalesce_layout(the caller's boxes) (mf.h); its data accessors speak the caller's layout.  Ghost cells travel too:
-// first everything incl. the source's ghost cells, then the valid data on top (a destination point covered by one box's ghost cell and
-// another box's valid cell takes the valid one).
-static void relayout_copy(MultiFab& dst, const MultiFab& src, int nc)
-{
-    if (dst.layout->id == src.layout->id) { MultiFab::Copy(dst, src, 0, 0, nc, std::min(dst.ngrow, src.ngrow)); return; }
-    const int ng = std::min(dst.ngrow, src.ngrow);
-    if (ng > 0) parallel_copy(dst, src, 0, 0, nc, ng, ng, nullptr, false);
-    parallel_copy(dst, src, 0, 0, nc, 0, ng, nullptr, false);
-}
-
 int iamrx_ns_create(const iamrx_geom* g, iamrx_layout l, const iamrx_ns_params* p, const iamrx_mg_opts* o, iamrx_ns* out)
 {
     IAMRX_TRY

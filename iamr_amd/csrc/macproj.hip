@@ -8,11 +8,38 @@
 
 namespace iamrx {
 
+LayoutP merged_solve_layout(const Geometry& g, const LayoutP& l)
+{
+    if (!l || l->replicated || l->total_cells() != g.domain.npts()) return nullptr;
+    LayoutP ml = coalesce_layout(l);
+    return (ml->id != l->id && ml->boxes.size() < l->boxes.size()) ? ml : nullptr;
+}
+
 MGStats mlmg_mac_solve(const Geometry& g, MultiFab* const umac[3], const MultiFab& rho, int rho_comp, const MultiFab* S,
                        MultiFab& mac_phi, double rhs_scale, const DomainBC& bc, double mac_tol, double mac_abs_tol,
                        const MGOpts& opts, MultiFab* const fluxes[3], const MultiFab* cphi, const Geometry* cgeom, int ratio)
 {
     LayoutP layout = mac_phi.layout;
+    // caller-owned arrays on a level chopped at amr.max_grid_size (the operator boundary as IAMR drives it): solve on the merged boxes --
+    // no ghost fills between colour passes, index wrap on periodic domains -- and hand the results back on the caller's
+    if (!cgeom) {
+        if (LayoutP ml = merged_solve_layout(g, layout)) {
+            MultiFab um_m[3], fl_m[3], rho_m(ml, cell_type(), 1, std::min(rho.ngrow, 1)), phi_m(ml, cell_type(), 1, mac_phi.ngrow), S_m;
+            MultiFab *ump[3], *flp[3];
+            for (int d = 0; d < 3; ++d) {
+                um_m[d].define(ml, face_type(d), 1, 0); relayout_copy(um_m[d], *umac[d], 1); ump[d] = &um_m[d];
+                if (fluxes) { fl_m[d].define(ml, face_type(d), 1, 0); flp[d] = &fl_m[d]; }
+            }
+            relayout_copy(rho_m, rho, 1, rho_comp, 0);
+            relayout_copy(phi_m, mac_phi, 1);
+            if (S) { S_m.define(ml, cell_type(), 1, 0); relayout_copy(S_m, *S, 1); }
+            MGStats st = mlmg_mac_solve(g, ump, rho_m, 0, S ? &S_m : nullptr, phi_m, rhs_scale, bc, mac_tol, mac_abs_tol, opts, fluxes ? flp : nullptr,
+                                        nullptr, nullptr, ratio);
+            relayout_copy(mac_phi, phi_m, 1);
+            for (int d = 0; d < 3; ++d) { relayout_copy(*umac[d], um_m[d], 1); if (fluxes) relayout_copy(*fluxes[d], fl_m[d], 1); }
+            return st;
+        }
+    }
     MultiFab bcoef[3];
     MultiFab* bp[3];
     const MultiFab* bcp[3];

@@ -105,6 +105,10 @@ std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domai
                                int n_error_buf, const OutflowTags* oft = nullptr, const unsigned char* allowed = nullptr /* domain-sized 0/1: where the new level may lie */);
 
 void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int src_ng, int dst_ng, const Geometry* periodic_geom, bool add = false);
+// same cells, different boxes (merged working layout <-> the caller's boxes): ghost cells included, valid data last
+void relayout_copy(MultiFab& dst, const MultiFab& src, int nc, int scomp = 0, int dcomp = 0);
+// the merged layout of a caller's chopped layout if it covers the domain and merging reduces the box count; else null (mf.h: coalesce_layout)
+LayoutP merged_solve_layout(const Geometry& g, const LayoutP& l);
 // amrex::average_down (cells), average_down_faces, average_down_nodal: NavierStokesBase::avgDown_StatePress, Source/NavierStokesBase.cpp:4125-4193
 void average_down(const MultiFab& fine, MultiFab& crse, int scomp, int ncomp, int ratio);
 // StateData of one level: old/new MultiFabs and their times (old_ may be null: only one time level)

@@ -57,6 +57,21 @@ MGStats nodal_projection(const Geometry& g, MultiFab& vel, int vcomp, MultiFab& 
                          const DomainBC& bc, double rel_tol, double abs_tol, const MGOpts& opts, MultiFab* gp, bool increment_gp, const MultiFab* rhcc)
 {
     LayoutP layout = phi.layout;
+    // caller-owned arrays on a level chopped at amr.max_grid_size: project on the merged boxes (see mlmg_mac_solve); a level with a
+    // Dirichlet mask from partial coverage never qualifies (merged_solve_layout: the boxes cover the domain)
+    if (LayoutP ml = merged_solve_layout(g, layout)) {
+        MultiFab vel_m(ml, cell_type(), 3, vel.ngrow), phi_m(ml, node_type(), 1, phi.ngrow), sig_m(ml, cell_type(), 1, sig.ngrow), gp_m, rh_m;
+        relayout_copy(vel_m, vel, 3, vcomp, 0);
+        relayout_copy(phi_m, phi, 1);
+        relayout_copy(sig_m, sig, 1, sig_comp, 0);
+        if (gp) { gp_m.define(ml, cell_type(), 3, gp->ngrow); if (increment_gp) relayout_copy(gp_m, *gp, 3); }
+        if (rhcc) { rh_m.define(ml, cell_type(), 1, rhcc->ngrow); relayout_copy(rh_m, *rhcc, 1); }
+        MGStats st = nodal_projection(g, vel_m, 0, phi_m, sig_m, 0, bc, rel_tol, abs_tol, opts, gp ? &gp_m : nullptr, increment_gp, rhcc ? &rh_m : nullptr);
+        relayout_copy(vel, vel_m, 3, 0, vcomp);
+        relayout_copy(phi, phi_m, 1);
+        if (gp) relayout_copy(*gp, gp_m, 3);
+        return st;
+    }
     // set_boundary_velocity + periodic fill of the velocity ghost cells
     vel.FillBoundary(g, vcomp, 3);
     NodalMG mg(g, layout, bc, opts);

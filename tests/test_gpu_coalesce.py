@@ -154,3 +154,52 @@ def test_restart_of_a_chopped_run(merged, tmp_path, capsys):
     assert len(A.levels[0].boxes) == 64 and A.levels[0].boxes == B.levels[0].boxes
     for x, y in zip(A.levels[0].data, B.levels[0].data):
         assert np.array_equal(x, y)
+
+
+def test_operator_entries_on_caller_owned_chopped_arrays(merged):
+    """the L3 operator boundary as IAMR drives it (MacProj::mlmg_mac_solve, Projection::doMLMGNodalProjection on the level's MultiFabs, chopped at
+    amr.max_grid_size): iamrx_mlmg_mac_solve and iamrx_nodal_projection solve on the merged boxes and hand the results back on the caller's --
+    the answers of the same calls on a single box, to the bit"""
+    lib = merged
+    from iamr_amd import ns as N
+    n = (64, 32, 32)
+    g = lib.Geom.make(n, prob_hi=(2.0, 1.0, 1.0))
+    rng = np.random.default_rng(2)
+    ax = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rho = 1.0 + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.1 * np.cos(4 * np.pi * Z)
+    res = []
+    for mgs in (None, 16):
+        lay = lib.Layout.single(n) if mgs is None else lib.Layout.decompose(n, mgs)
+        um = []
+        for d in range(3):
+            t = lib.face(d)
+            axf = [(np.arange(-1, n[e] + t[e] + 1) + (0.0 if t[e] else 0.5)) / n[e] for e in range(3)]
+            Xf, Yf, Zf = np.meshgrid(*axf, indexing="ij")
+            m = lib.MultiFab(lay, t, 1, 1)
+            m.set_from_global((np.sin(2 * np.pi * Xf + d) * np.cos(2 * np.pi * Yf) + 0.5 * np.cos(2 * np.pi * Zf + 0.3 * d))[..., None], (-1,) * 3)
+            um.append(m)
+        rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1,) * 3)
+        phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.setval(0.0)
+        st = lib.mlmg_mac_solve(g, um, rho_d, 0, None, phi_d, 2.0 / 0.01, mac_tol=1e-11)
+        assert st.converged
+        div = lib.MultiFab(lay, lib.CELL, 1, 0)
+        lib.mac_divergence(g, div, um)
+        assert div.norm0() <= 1e-8
+        # nodal projection of a cell-centred field with variable sigma
+        vel = lib.MultiFab(lay, lib.CELL, 3, 1)
+        V = np.stack([np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y), np.cos(2 * np.pi * X) * np.sin(4 * np.pi * Y) + 0.2 * np.sin(2 * np.pi * Z),
+                      0.5 * np.sin(2 * np.pi * (X + Z))], axis=-1)
+        vel.set_from_global(V, (-1,) * 3)
+        sig = lib.MultiFab(lay, lib.CELL, 1, 1); sig.set_from_global((1.0 / rho)[..., None], (-1,) * 3)
+        p = lib.MultiFab(lay, lib.NODE, 1, 1); p.setval(0.0)
+        gp = lib.MultiFab(lay, lib.CELL, 3, 1); gp.setval(0.0)
+        stn = N.nodal_projection(g, vel, 0, p, sig, 0, rel_tol=1e-11, gp=gp)
+        assert stn.converged
+        res.append((st.iters, stn.iters, phi_d.gather_valid(n), [m.gather_valid(n) for m in um], vel.gather_valid(n), p.gather_valid(n), gp.gather_valid(n)))
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2])
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
