@@ -521,7 +521,7 @@ def main():
             roofline_gs4 = {"kernel": "k_nodal_gsr<4> (4 of the 8 Gauss-Seidel colours of the nodal smoother per launch, register-resident planes, variable "
                                       "sigma; 16 B/node per launch = SURVEY 8d's 32 B/node per sweep)", "bound": "hbm",
                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                            "traffic": pmc_traffic("k_nodal_gsr<4, true, false, false> grid="),
+                            "traffic": pmc_traffic("k_nodal_gsr<4, true, false, false> grid=131072"),
                             "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
                             "launches_timed": gs4_insitu[1] if gs4_insitu else None,
                             "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",

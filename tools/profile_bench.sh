@@ -11,6 +11,6 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$t
 f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 test -n "$f" && cp "$f" $out/${tag}_kernel_stats.csv
 t=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
-test -n "$t" && python $root/tools/trace_by_grid.py "$t" $out/${tag}_kernels_by_grid.csv k_nodal_gs4 k_abec_gsrb k_god_z k_pred_z
+test -n "$t" && python $root/tools/trace_by_grid.py "$t" $out/${tag}_kernels_by_grid.csv k_nodal_gsr k_nodal_gs4 k_abec_gsrb k_god_z k_pred_z
 head -12 $out/${tag}_kernel_stats.csv | cut -c1-60,200-
 head -6 $out/${tag}_kernels_by_grid.csv
