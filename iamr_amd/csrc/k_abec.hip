@@ -538,6 +538,283 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
     }
 }
 
+// ---------------------------------------------------------------------------- one-pass red + black sweep, index-wrap levels
+// k_abec_gsrb_rb: a red AND a black colour pass of a level that is one box spanning a periodic domain in ONE launch, out of place
+// (pin -> pout), with the doubles of the two k_abec_gsrb2 launches.  Why: on the natural layout a colour pass reads whole phi lines,
+// writes half of every phi line (a read-modify-write at the memory) and reads half-used rhs lines -- 536 MB (+ 134 MB of density in the
+// MAC form) per pass at 256^3, whatever the kernel does.  The sweep reads phi, rhs (and the density) once and writes every phi line
+// whole: 402 (536) MB per SWEEP.
+// A workgroup of NW wavefronts owns RW = NW / wpr rows of the box (wpr wavefronts per row: 128 cells each), rows 0 and RW - 1 as halo,
+// and marches through tz planes.  A thread owns the cell pair (lo + 2 ih, lo + 2 ih + 1) of its row and holds the pin / density / rhs
+// pairs of the planes around the current one in registers; these 16-byte loads, a plane ahead, are the ONLY global loads of the loop (the
+// halo rows add the 8-byte loads of the row outside the tile).  Everything a cell needs from another thread travels through lane shifts
+// (the pair next to it) and LDS: per plane p every thread publishes the old value and density of its BLACK cell of plane p + 1 (the x- and
+// y-neighbours of the red cells of that plane), forms the red update of plane p, publishes the new red value and the density there, and --
+// one barrier later -- forms the black update of plane p - 1 (rows 1 .. RW - 2) from the new reds around it: its pair's, the planes p - 2
+// and p of its own column (registers), the next pair's (lane shift; across the 128-cell boundary: LDS), the rows above and below (LDS).
+// (A load that is issued and consumed inside one iteration waits for every earlier load of the in-order queue, the prefetches included:
+// the first version, with such loads for the lane-0 / lane-63 neighbours and the black cell's densities, took 226 us per sweep.)
+// Every workgroup recomputes the reds of the plane below and above its chunk and of its two halo rows.
+__device__ __forceinline__ double rb_lane_lo(double v)      // the value lane - 1 holds (DPP wave_shr:1)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rb_lane_hi(double v)      // the value lane + 1 holds (DPP wave_shl:1)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(v)); return r; }
+
+template <int BMODE, int NW, bool HASA>
+__global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
+    double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk)
+{
+#if defined(__HIP_DEVICE_COMPILE__)    // (the host pass has no global address space: FabD::gp)
+    constexpr bool SG = BMODE == 1;
+    __shared__ double RED[3][NW][64];                        // new red values of the planes q - 2, q - 1, q
+    __shared__ double YM[SG ? 3 : 1][SG ? NW : 1][64];       // the face coefficients below / above those cells (every face of the grid lies
+    __shared__ double YP[SG ? 3 : 1][SG ? NW : 1][64];       // between a red and a black cell: the black update divides nothing but omega / gamma)
+    __shared__ double XF[SG ? 3 : 1][SG ? NW : 1][2];        // lanes 0 / 63: the coefficient of the face towards the neighbouring wavefront's pair
+    __shared__ double BPH[2][NW][64];                        // old values of the black cells of the planes q, q + 1
+    __shared__ double BSG[SG ? 2 : 1][SG ? NW : 1][64];      // the density at those cells
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rw = NW / wpr, r = w / wpr, xw = w - r * wpr;
+    // workgroup -> tile: consecutive workgroups go to different XCDs (8, each with its own L2); tiles that are neighbours in y (they share
+    // their halo rows) are handed to one XCD: XCD x runs the tiles x * xcd_chunk ... of the order "y-tile fastest"
+    const int tile = xcd_chunk > 0 ? ((int)blockIdx.x & 7) * xcd_chunk + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int ty = tile % nty, tzc = tile / nty;
+    const int ny = b.len(1), nz = b.len(2);
+    const int k0 = b.lo[2] + tzc * tz;
+    if (k0 > b.hi[2]) return;
+    const int kend = min(k0 + tz - 1, b.hi[2]);
+    auto wj = [&](int j) { return j < b.lo[1] ? j + ny : (j > b.hi[1] ? j - ny : j); };
+    auto wk = [&](int k) { return k < b.lo[2] ? k + nz : (k > b.hi[2] ? k - nz : k); };
+    const int jraw = b.lo[1] + ty * (rw - 2) + (r - 1);
+    const bool owner = r >= 1 && r <= rw - 2 && jraw <= b.hi[1];       // rows whose black update and output this workgroup owns
+    const int j = wj(min(jraw, b.hi[1] + 1)), jm = wj(j - 1), jp = wj(j + 1);
+    // rows whose lower / upper neighbour row is not the workgroup's row r - 1 / r + 1 (the halo rows; the row above the box in a partial
+    // tile): 8-byte loads of that row, a plane ahead
+    const bool ym_g = r == 0, yp_g = r == rw - 1 || jraw > b.hi[1];
+    const int wm = ym_g ? w : w - wpr, wp = yp_g ? w : w + wpr;
+    const int ih = xw * 64 + lane, iL = b.lo[0] + 2 * ih;
+    // x-neighbour pairs: the adjacent lane, or (lanes 0 / 63) the last / first lane of the neighbouring wavefront of the row
+    const bool hasL = lane > 0, hasR = lane < 63;
+    const int wL = r * wpr + (xw == 0 ? wpr - 1 : xw - 1), wR = r * wpr + (xw == wpr - 1 ? 0 : xw + 1);
+    auto parity = [&](int k) { return (b.lo[0] + j + k) & 1; };      // 0: the left cell of the pair is red (ny, nz even: wrap keeps it)
+    // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
+    typedef const __attribute__((address_space(1))) char gbyte;
+    typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
+    auto rowoff = [&](const FabD& f, int i, int jj) { return 8u * (unsigned)((i - f.lo[0]) + f.n[0] * (jj - f.lo[1])); };
+    auto plane = [&](const FabD& f, int k, int n) { return f.gp() + (long)f.n[0] * f.n[1] * (wk(k) - f.lo[2]) + f.cs * n; };
+    auto ld1 = [](const FabD::gdouble* pl, unsigned off) -> double { return *(const FabD::gdouble*)((gbyte*)pl + (size_t)off); };
+    auto ldpair = [](const FabD::gdouble* pl, unsigned off) { const v2u v = *(const __attribute__((address_space(1))) v2u*)((gbyte*)pl + (size_t)off); D2 r; r.l = v.x; r.r = v.y; return r; };
+    const unsigned oP = rowoff(pin, iL, j), oPy = rowoff(pin, iL, ym_g ? jm : jp);
+    const unsigned oS = SG ? rowoff(S, iL, j) : 0u, oSy = SG ? rowoff(S, iL, ym_g ? jm : jp) : 0u;
+    const unsigned oR = rowoff(rhs, iL, j), oA = HASA ? rowoff(A, iL, j) : 0u, oO = rowoff(pout, iL, j);
+    const bool y_g = ym_g || yp_g;
+    auto ldp = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(plane(f, k, n), off); };
+    // one Gauss-Seidel update: k_abec_gsrb2's expressions (no wall / coarse-fine terms on an index-wrap level: g_m_d == gamma)
+    auto face = [&](double s0, double s1) { return sig_scale / (0.5 * (s0 + s1)); };      // (the sum commutes: one value per face)
+    auto update = [&](double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
+                      double bxm, double bxp, double bym, double byp, double bzm, double bzp) {
+        const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+        // (k_abec_gsrb2 subtracts the wall terms dh * (b * 0.0 + b * 0.0) from gamma here: +-0 for finite coefficients, the same double)
+        const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
+        const double res = rr - (gamma * p0 - rho);
+        return p0 + omega / gamma * res;
+    };
+    constexpr bool has_a = HASA;
+    const D2 Z2 = {0.0, 0.0};
+    // rings: pin rows of the planes q - 1, q, q + 1; density rows q - 1 .. q + 1; rhs rows q - 1, q; new reds q - 2, q - 1, q; of the red
+    // cell's face coefficients: the pair's own face and the face towards the next pair (plane q - 1), the face above (planes q - 2, q - 1).
+    // PN / SN / RN / AN / YNN: the rows in flight.  An iteration first moves them into the rings (the only place that waits for them: they
+    // were issued a whole iteration earlier) and then issues the next loads into the same registers -- a ring rotation at the END of the
+    // iteration would wait for the loads it has just issued.
+    D2 Pm = Z2, Pc, Pp, PN, Sm = Z2, Sc = Z2, Sp = Z2, SN = Z2, Rm = Z2, Rc, RN, Am = Z2, Ac = Z2, AN = Z2;
+    double RNa = 0.0, RNm = 0.0, RNc = 0.0;
+    double bnear_m = bu.v[0], bfar_m = bu.v[0], bzp_a = bu.v[2], bzp_m = bu.v[2], bzm_c = bu.v[2];
+    // halo rows: old phi and density of the red cell's y-neighbour outside the tile, plane qq
+    struct YN { double p, s; };
+    auto yload = [&](int qq, int parq) {
+        YN y = {0.0, 0.0};
+        if (y_g) {
+            const unsigned dr = 8u * (unsigned)parq;
+            if (!zero) y.p = ld1(plane(pin, qq, comp), oPy + dr);
+            if (SG) y.s = ld1(plane(S, qq, sig_comp), oSy + dr);
+        }
+        return y;
+    };
+    double bn_prev = 0.0;
+    auto put = [&](int k, int park, double bn, double rn) {          // park 1: the left cell of the pair is the black one
+        v2u o;
+        if (park) { o.x = bn; o.y = rn; } else { o.x = rn; o.y = bn; }
+        typedef __attribute__((address_space(1))) char gwbyte;
+        *(__attribute__((address_space(1))) v2u*)((gwbyte*)(pout.gp() + (long)pout.n[0] * pout.n[1] * (k - pout.lo[2]) + pout.cs * comp) + (size_t)oO) = o;
+    };
+    int q = k0 - 1;
+    // (the state an iteration q - 1 would have left)
+    Pc = zero ? Z2 : ldp(pin, oP, q - 1, comp); Pp = zero ? Z2 : ldp(pin, oP, q, comp); PN = zero ? Z2 : ldp(pin, oP, q + 1, comp);
+    if (SG) { Sc = ldp(S, oS, q - 1, sig_comp); Sp = ldp(S, oS, q, sig_comp); SN = ldp(S, oS, q + 1, sig_comp); }
+    Rc = ldp(rhs, oR, q - 1, comp); RN = ldp(rhs, oR, q, comp);
+    if (has_a) { Ac = ldp(A, oA, q - 1, 0); AN = ldp(A, oA, q, 0); }
+    YN yn, YNN = yload(q, parity(q));
+    {   // black cells of the first plane
+        const int par = parity(q);
+        BPH[0][w][lane] = par ? Pp.l : Pp.r;
+        if (SG) BSG[0][w][lane] = par ? Sp.l : Sp.r;
+        __syncthreads();
+    }
+    // one plane; PAR = parity(q) as a type (0: the left cell of the pair is the red one of plane q): the selections of pair entries and
+    // lane-shift directions are static -- the march below runs two planes per trip, in the order the row's parity asks for
+    auto iter = [&](auto PARC, const int q) {
+        constexpr int par = decltype(PARC)::value;
+        // ---- the rows in flight enter the rings; loads of the next plane
+        // (rb_take: an explicit register move, so that the copy stays HERE and the new load lands in the register just vacated)
+        Pm = Pc; Pc = Pp; if (!zero) { Pp.l = rb_take(PN.l); Pp.r = rb_take(PN.r); }
+        if (SG) { Sm = Sc; Sc = Sp; Sp.l = rb_take(SN.l); Sp.r = rb_take(SN.r); }
+        Rm = Rc; Rc.l = rb_take(RN.l); Rc.r = rb_take(RN.r);
+        if (has_a) { Am = Ac; Ac.l = rb_take(AN.l); Ac.r = rb_take(AN.r); }
+        yn = YNN;
+        if (y_g) { if (!zero) yn.p = rb_take(YNN.p); if (SG) yn.s = rb_take(YNN.s); }
+        // the output of the previous iteration's black update (plane q - 2), BEFORE the loads: the wait for the loads at the top of the
+        // next iteration then covers nothing younger than a whole iteration (a store behind them would be waited for as well)
+        if (owner && q - 2 >= k0) put(q - 2, par, bn_prev, RNm);
+        if (q <= kend) {
+            if (!zero) PN = ldp(pin, oP, q + 2, comp);
+            if (SG) SN = ldp(S, oS, q + 2, sig_comp);
+            RN = ldp(rhs, oR, q + 1, comp);
+            if (has_a) AN = ldp(A, oA, q + 1, 0);
+            YNN = yload(q + 1, 1 - par);
+        }
+        // ---- red update of plane q
+        const int bq = (q - k0 + 1) & 1;
+        const int slot = (q - k0 + 3) % 3, slotk = (q - k0 + 2) % 3;      // ring slots of the planes q and q - 1
+        double bnear_c = bu.v[0], bfar_c = bu.v[0], bzp_c = bu.v[2];
+        {
+            // the black cell of the pair next to the red one: par 0: red = left, the pair to the left; par 1: the pair to the right
+            double nb = par == 0 ? rb_lane_lo(Pc.r) : rb_lane_hi(Pc.l), nbs = 0.0;
+            if (SG) nbs = par == 0 ? rb_lane_lo(Sc.r) : rb_lane_hi(Sc.l);
+            if (par == 0 ? !hasL : !hasR) {
+                nb = BPH[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
+                if (SG) nbs = BSG[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
+            }
+            double pym = BPH[bq][wm][lane], pyp = BPH[bq][wp][lane], sym = 0.0, syp = 0.0;
+            if (SG) { sym = BSG[bq][wm][lane]; syp = BSG[bq][wp][lane]; }
+            if (ym_g) { pym = yn.p; sym = yn.s; }
+            if (yp_g) { pyp = yn.p; syp = yn.s; }
+            const double pxm = par == 0 ? nb : Pc.l, pxp = par == 0 ? Pc.r : nb;
+            const double p0 = par ? Pc.r : Pc.l, pzm = par ? Pm.r : Pm.l, pzp = par ? Pp.r : Pp.l, rr = par ? Rc.r : Rc.l;
+            const double aa = has_a ? alpha * (par ? Ac.r : Ac.l) : 0.0;
+            double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1];
+            if (SG) {
+                const double s0 = par ? Sc.r : Sc.l;
+                bnear_c = face(s0, par ? Sc.l : Sc.r); bfar_c = face(s0, nbs);
+                bxm = par == 0 ? bfar_c : bnear_c; bxp = par == 0 ? bnear_c : bfar_c;
+                bym = face(sym, s0); byp = face(s0, syp);
+                bzm_c = face(par ? Sm.r : Sm.l, s0); bzp_c = face(s0, par ? Sp.r : Sp.l);
+            }
+            RNa = RNm; RNm = RNc;
+            RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c);
+            if (SG) {
+                YM[slot][w][lane] = bym; YP[slot][w][lane] = byp;
+                if (!hasL) XF[slot][w][0] = bfar_c;
+                if (!hasR) XF[slot][w][1] = bfar_c;
+            }
+        }
+        asm volatile("" : "+v"(RNc));          // (ends the scheduling region: the two updates of an iteration are not interleaved)
+        RED[slot][w][lane] = RNc;
+        BPH[bq ^ 1][w][lane] = par ? Pp.r : Pp.l;                // the black cells of plane q + 1 (its parity is 1 - par)
+        if (SG) BSG[bq ^ 1][w][lane] = par ? Sp.r : Sp.l;
+        __syncthreads();
+        // ---- black update of plane k = q - 1 and its output
+        const int k = q - 1;
+        if (k >= k0 && owner) {
+            constexpr int park = 1 - par;                                    // parity(k): 1: the left cell of the pair is black
+            // (the lane shifts below run under the row mask `owner`: every lane of a wavefront belongs to one row)
+            double nb = park == 1 ? rb_lane_lo(RNm) : rb_lane_hi(RNm), nbf = bu.v[0];
+            if (SG) nbf = park == 1 ? rb_lane_lo(bfar_m) : rb_lane_hi(bfar_m);
+            if (park == 1 ? !hasL : !hasR) {
+                nb = RED[slotk][park == 1 ? wL : wR][park == 1 ? 63 : 0];
+                if (SG) nbf = XF[slotk][park == 1 ? wL : wR][park == 1 ? 1 : 0];
+            }
+            const double pxm = park == 1 ? nb : RNm, pxp = park == 1 ? RNm : nb;
+            const double pym = RED[slotk][w - wpr][lane], pyp = RED[slotk][w + wpr][lane];
+            double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
+            if (SG) {
+                bxm = park == 1 ? nbf : bnear_m; bxp = park == 1 ? bnear_m : nbf;
+                bym = YP[slotk][w - wpr][lane]; byp = YM[slotk][w + wpr][lane];
+                bzm = bzp_a; bzp = bzm_c;
+            }
+            const double p0 = park ? Pm.l : Pm.r, rr = park ? Rm.l : Rm.r;
+            const double aa = has_a ? alpha * (park ? Am.l : Am.r) : 0.0;
+            const double bn = update(p0, pxm, pxp, pym, pyp, RNa, RNc, rr, aa, bxm, bxp, bym, byp, bzm, bzp);
+            bn_prev = bn;
+        }
+        if (SG) { bnear_m = bnear_c; bfar_m = bfar_c; bzp_a = bzp_m; bzp_m = bzp_c; }
+    };
+    typedef std::integral_constant<int, 0> Par0;
+    typedef std::integral_constant<int, 1> Par1;
+    if (parity(q) == 0) for (; q <= kend + 1; ++q) { iter(Par0{}, q); if (++q > kend + 1) break; iter(Par1{}, q); }
+    else                for (; q <= kend + 1; ++q) { iter(Par1{}, q); if (++q > kend + 1) break; iter(Par0{}, q); }
+    q = kend + 2;
+    if (owner && q - 2 >= k0) put(q - 2, parity(q), bn_prev, RNm);
+#endif
+}
+
+bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc)
+{
+    if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
+    const Layout& l = *phi.layout;
+    if (!periodic_wrap_ok(g, l, 4) || nbc != 1) return false;
+    const BoxD& b = l.boxes[0];
+    const int nx = b.len(0);
+    if (nx != 128 && nx != 256) return false;                      // whole rows in 1 or 2 wavefronts of a workgroup
+    if ((b.len(1) & 1) || (b.len(2) & 1) || b.len(1) < 16 || b.len(2) < 16) return false;
+    if (phi.ngrow < 1 || c.b[0]->ncomp != 1) return false;
+    if (c.sig) return phi.ncomp == 1 && c.sig->ngrow >= 1 && !(c.a && c.alpha != 0.0);
+    return c.b_uniform != 0;
+}
+
+// one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
+void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero)
+{
+    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, 1) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
+    if (pin.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    const Layout& l = *pin.layout;
+    const BoxD b = l.boxes[l.local[0]];
+    constexpr int NW = 16;
+    const int wpr = b.len(0) / 128, rw = NW / wpr;
+    const int nty = (b.len(1) + (rw - 2) - 1) / (rw - 2);
+    // z-chunks: one round of workgroups (one 1024-thread workgroup per CU)
+    int nch = std::max(1, (int)(tune("GSRB_RB_SLOTS", 256) / nty));
+    int tz = std::max(8, (b.len(2) + nch - 1) / nch);
+    nch = (b.len(2) + tz - 1) / tz;
+    const int ntile = nty * nch, xcd_chunk = tune("GSRB_RB_XCD", 1) != 0 ? (ntile + 7) / 8 : 0, nwg = xcd_chunk > 0 ? 8 * xcd_chunk : ntile;
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    const bool has_a = c.a && c.alpha != 0.0;
+    const FabD P = pin.h_tab[0], O = pout.h_tab[0], R = rhs.h_tab[0], Af = has_a ? c.a->h_tab[0] : P, Sf = c.sig ? c.sig->h_tab[0] : P;
+    const bool rec = pin.ncomp == 1 && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
+    for (int n = 0; n < pin.ncomp; ++n) {
+        BUni bn;
+        for (int d = 0; d < 3; ++d) bn.v[d] = c.bu[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
+#define IAMRX_RB(M, HA, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
+                                                  c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk)
+        if (c.sig) IAMRX_RB(1, false, c.sig_comp, c.sig_scale);
+        else if (has_a) IAMRX_RB(2, true, 0, 1.0);
+        else IAMRX_RB(2, false, 0, 1.0);
+#undef IAMRX_RB
+    }
+    if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
+}
+
 // IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given
 static bool abec_sig_on() { return tune("ABEC_SIG", 1) != 0; }
 

@@ -264,6 +264,21 @@ bool CellMG::fused_smoother_ok(int l) const
 void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero)
 {
     if (nsweeps <= 0) { if (sol_is_zero) sol.setVal(0.0); return; }
+    if (!m_cf) {
+        // one box spanning a periodic domain: red + black in one out-of-place launch per sweep (k_abec_gsrb_rb), ping-pong with the level's buffer
+        AbecCoef c = coef(l);
+        c.tensor = 0;
+        if (abec_gsrb_rb_ok(m_lev[l].g, c, sol, (int)m_bcn.size())) {
+            Level& L = m_lev[l];
+            if (!L.buf.defined()) L.buf.define(L.layout, cell_type(), m_ncomp, 1);
+            MultiFab* a = &sol;
+            MultiFab* b = &L.buf;
+            const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
+            for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0); std::swap(a, b); }
+            if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
+            return;
+        }
+    }
     if (!fused_smoother_ok(l)) {
         for (int i = 0; i < nsweeps; ++i) smooth(l, sol, rhs, skip_first_fill && i == 0, i > 0, sol_is_zero && i == 0);
         return;

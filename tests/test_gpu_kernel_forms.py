@@ -126,3 +126,48 @@ def test_fused_tensor_residual_matches_the_oracle(orc, gpu, n, boxes):
         N.tensor_apply(g_d, out_d, u_d, a, b, ac_d, eta_d)
         got = out_d.gather_valid(n)
         assert np.abs(got - y.a).max() <= 1e-12 * np.abs(y.a).max(), (a, b, float(np.abs(got - y.a).max()))
+
+
+@pytest.mark.parametrize("coef", [1, 2])
+@pytest.mark.parametrize("n", [(128, 32, 48), (256, 20, 16), (256, 64, 96)])
+def test_one_launch_red_black_sweep_matches_the_oracle(orc, gpu, n, coef):
+    """k_abec_gsrb_rb (round 4): a red and a black colour pass of an index-wrap level in one out-of-place launch -- rows of 128 / 256 cells in
+    one / two wavefronts, new reds through registers, lane shuffles and an LDS ring, halo rows and the planes below / above every z-chunk
+    recomputed; partial row tiles (20 rows in tiles of 6), several z-chunks.  The doubles of the oracle's two passes; also from a zero
+    start without reading phi."""
+    lib = gpu
+    L = orc.lib()
+    g_o, g_d = orc.geom(n), lib.Geom.make(n)
+    lay = lib.Layout.single(n)
+    rho, phi, rhs = fields(n, 9)
+    scale, bu, beta = 0.37, (0.8, 1.1, 1.3), 1.0
+    b_o = []
+    for d in range(3):
+        bf = orc.Fab(n, orc.face(d), 0, 1)
+        if coef == 1:
+            lo = [slice(1, n[e] + 1) for e in range(3)]; hi = [slice(1, n[e] + 1) for e in range(3)]
+            lo[d] = slice(0, n[d] + 1); hi[d] = slice(1, n[d] + 2)
+            bf.a[..., 0] = scale / (0.5 * (rho[tuple(lo)] + rho[tuple(hi)]))
+        else:
+            bf.a[...] = bu[d]
+        b_o.append(bf)
+    lev = orc.abec_level(g_o, b_o, beta=beta)
+    rhs_o = orc.Fab(n, orc.CELL, 0, 1); rhs_o.a[..., 0] = rhs
+    rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1,) * 3)
+    rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs[..., None], (0,) * 3)
+    kw = dict(rho=rho_d, scale=scale, bu=bu, beta=beta)
+    z3 = orc.i3([0, 0, 0])
+    for start in ("field", "zero"):
+        phi_o = orc.Fab(n, orc.CELL, 1, 1)
+        phi_o.a[..., 0] = phi if start == "field" else 0.0
+        a = lib.MultiFab(lay, lib.CELL, 1, 1); b = lib.MultiFab(lay, lib.CELL, 1, 1)
+        a.set_from_global(phi[..., None], (-1,) * 3)          # zero start: the kernel must not read it
+        b.setval(np.nan)
+        for sweep in range(2):
+            for rb in (0, 1):
+                L.orc_fill_periodic(phi_o.ref(), C.byref(g_o), orc.i3(orc.CELL))
+                L.orc_abec_gsrb(C.byref(lev), phi_o.ref(), rhs_o.ref(), rb, C.c_double(1.15), z3, z3, 3)
+            lib.abec_form(g_d, coef, 7 if (start == "zero" and sweep == 0) else 6, a, rhs_d, out=b, **kw)
+            a, b = b, a
+            got, ref = a.gather_valid(n), phi_o.valid(n)
+            assert np.array_equal(got, ref), (start, sweep, float(np.nanmax(np.abs(got - ref))), int(np.isnan(got).sum()))

@@ -70,8 +70,10 @@ KERNEL_FORMS = {
     # round 4: the three components of a constant-coefficient tensor colour pass as three pair-marching launches instead of one launch of
     # the general kernel
     "multi-component colour pass per component": {"GSRB2_MULTI": 1},
+    # round 4: two colour passes instead of the one-launch red + black sweep (index-wrap levels with 128 / 256 cells in x)
+    "two colour passes": {"GSRB_RB": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "channel_walls"])
