@@ -489,28 +489,34 @@ def main():
                 return None
 
         gsrb_iso = kr.get("abec_gsrb_sweep")
+        roofline_abec = None
         if gsrb_iso:
-            # one colour pass of the MAC solve's smoother.  achieved / frac use SURVEY 8d's figure for the operation (GSRB sweep 80 B/cell = 40 per
-            # colour pass: phi 1, rhs 1/2, three face-coefficient arrays, phi 1/2 written), as the contract prescribes.  Since round 3 the kernel
-            # recomputes the face coefficients from the cell-centred density (AbecCoef::sig) and moves less than that: its own compulsory traffic is
-            # phi (1 + 1/2), rhs (1/2), density (1) = 24 B/cell, reported beside it (own_minimum_*); `traffic` (PMC) is to be read against that.
-            alg = 40.0 * cells
-            own = 24.0 * cells
-            ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"] / 2
-            # `achieved` / `frac`: against the kernel's OWN compulsory traffic -- it recomputes the face coefficients from the
-            # cell-centred density and so moves less than SURVEY 8d's 40 B/cell of the operation; the 8d figure is kept beside it (survey_8d_*)
+            # one red + black sweep of the MAC solve's smoother in ONE launch (round 4: k_abec_gsrb_rb; rounds 1-3 timed one colour pass).
+            # achieved / frac: against the kernel's OWN compulsory traffic -- it recomputes the face coefficients from the cell-centred
+            # density (AbecCoef::sig) and so moves less than SURVEY 8d's 80 B/cell of the operation (phi 1 + 1, rhs 1, three face-coefficient
+            # arrays ...): phi read 8 + written 8, rhs 8, density 8 = 32 B/cell per sweep.  The 8d figure is kept beside it (survey_8d_*; a
+            # fraction above 1 there only says that the kernel does not move the arrays 8d counts).  `traffic` (PMC) is to be read against own.
+            alg = 80.0 * cells
+            own = 32.0 * cells
+            ms = gsrb_insitu[0] if gsrb_insitu else gsrb_iso["ms"]
             gbps = own / ms / 1e6
-            roofline = {"kernel": "k_abec_gsrb2<1, false, false> (one red or black pass of the cell-centred GSRB smoother of the MAC projection, pair-marching form, "
-                                  "face coefficients recomputed from the cell-centred density; the dominant kernel of the step, "
-                                  "profiles/round4_kernel_stats.csv)", "bound": "hbm",
-                        "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                        "traffic": pmc_traffic("k_abec_gsrb2<1, false, false> grid=%d" % (n ** 3 // 64)),
-                        "algorithmic_bytes_per_launch": own, "avg_ms": ms,
-                        "bytes_counted": "the kernel's own compulsory traffic, 24 B/cell per colour pass: phi read 8 + written 4, rhs 4, density 8",
-                        "survey_8d_bytes_per_launch": alg, "survey_8d_GBps": alg / ms / 1e6, "survey_8d_frac": alg / ms / 1e6 / 8000.0,
-                        "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
-                        "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
-                        "isolated_loop_ms_array_coefficients": gsrb_iso["ms"] / 2}
+            rw = 16 // max(1, n // 128)
+            nty = (n + rw - 3) // (rw - 2)
+            nch = max(1, 256 // nty); tzp = max(8, (n + nch - 1) // nch); nch = (n + tzp - 1) // tzp
+            rb_grid = 8 * ((nty * nch + 7) // 8) * 1024
+            roofline_abec = {"kernel": "k_abec_gsrb_rb<1, 16, false> (a red AND a black pass of the cell-centred GSRB smoother of the MAC projection in one "
+                                       "out-of-place launch, face coefficients recomputed from the cell-centred density once per face; "
+                                       "profiles/round4_kernel_stats.csv)", "bound": "hbm",
+                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                             "traffic": pmc_traffic("k_abec_gsrb_rb<1, 16, false> grid=%d" % rb_grid),
+                             "algorithmic_bytes_per_launch": own, "avg_ms": ms,
+                             "bytes_counted": "the kernel's own compulsory traffic, 32 B/cell per sweep: phi read 8 + written 8, rhs 8, density 8",
+                             "survey_8d_bytes_per_launch": alg, "survey_8d_GBps": alg / ms / 1e6, "survey_8d_frac": alg / ms / 1e6 / 8000.0,
+                             "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
+                             "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
+                             "isolated_loop_ms_array_coefficients_two_colour_passes": gsrb_iso["ms"]}
+        # the kernel with the largest summed duration of the step (profiles/round4_kernel_stats.csv: k_nodal_gsr over its launch grids, ahead of
+        # k_abec_gsrb_rb and k_god_z) is the nodal Gauss-Seidel pass: it is `roofline`; the MAC sweep and the Godunov kernels are reported beside it
         dom = kr.get("nodal_gs4_launch")
         roofline_gs4 = None
         if dom:
@@ -572,8 +578,8 @@ def main():
             "host_syncs_per_step": syncs_in_loop / a.steps,
             "transport": transport if world > 1 else "none (single GPU)",
             "kernels": kr,
-            "roofline": roofline,
-            "roofline_nodal_gs4": roofline_gs4,
+            "roofline": roofline_gs4,
+            "roofline_abec_sweep": roofline_abec,
             "roofline_godunov_advection": roofline_god,
             "roofline_godunov_prediction": roofline_pred,
         }

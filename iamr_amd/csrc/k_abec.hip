@@ -772,7 +772,8 @@ bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, 
 {
     if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
     const Layout& l = *phi.layout;
-    if (!periodic_wrap_ok(g, l, 4) || nbc != 1) return false;
+    (void)nbc;                                                     // (every side periodic: no boundary condition enters)
+    if (!periodic_wrap_ok(g, l, 4)) return false;
     const BoxD& b = l.boxes[0];
     const int nx = b.len(0);
     if (nx != 128 && nx != 256) return false;                      // whole rows in 1 or 2 wavefronts of a workgroup
