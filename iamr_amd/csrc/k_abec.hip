@@ -1899,10 +1899,9 @@ void cc_prolong_add(MultiFab& fine, const MultiFab& crse)
     if (fine.nlocal() == 0) return;
     const FabD *ft = fine.d_tab, *ct = crse.d_tab;
     const int nc = fine.ncomp;
-    for_each(*fine.layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD fa = ft[f], ca = ct[f];
-        for (int n = 0; n < nc; ++n) fa(i, j, k, n) += ca(i >> 1, j >> 1, k >> 1, n);
-    });
+    for_each_2ph(*fine.layout, cell_type(), 0, nc, Context::get().stream,
+        [=] __device__(int i, int j, int k, int f, int n) { return ft[f](i, j, k, n) + ct[f](i >> 1, j >> 1, k >> 1, n); },
+        [=] __device__(int i, int j, int k, int f, int n, double v) { ft[f](i, j, k, n) = v; });
 }
 
 void face_avgdown(MultiFab& crse, const MultiFab& fine, int dir)

@@ -330,10 +330,9 @@ void mf_lincomb(MultiFab& dst, double a, const MultiFab& x, double b, const Mult
     trace_blas_site("lincomb", dst.layout ? dst.layout->local_cells() * nc : 0);
     if (!dst.base) return;
     const FabD *dt = dst.d_tab, *xt = x.d_tab, *yt = y.d_tab;
-    for_each(*dst.layout, dst.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD d = dt[f], xx = xt[f], yy = yt[f];
-        for (int n = 0; n < nc; ++n) d(i, j, k, comp + n) = a * xx(i, j, k, comp + n) + b * yy(i, j, k, comp + n);
-    });
+    for_each_2ph(*dst.layout, dst.type, ng, nc, Context::get().stream,
+        [=] __device__(int i, int j, int k, int f, int n) { return a * xt[f](i, j, k, comp + n) + b * yt[f](i, j, k, comp + n); },
+        [=] __device__(int i, int j, int k, int f, int n, double v) { dt[f](i, j, k, comp + n) = v; });
 }
 
 void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, int nc, int ng)
@@ -341,10 +340,9 @@ void mf_saxpy(MultiFab& y, double a, const MultiFab& x, int xcomp, int ycomp, in
     trace_blas_site("saxpy", y.layout ? y.layout->local_cells() * nc : 0);
     if (!y.base) return;
     const FabD *yt = y.d_tab, *xt = x.d_tab;
-    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD yy = yt[f], xx = xt[f];
-        for (int n = 0; n < nc; ++n) yy(i, j, k, ycomp + n) += a * xx(i, j, k, xcomp + n);
-    });
+    for_each_2ph(*y.layout, y.type, ng, nc, Context::get().stream,
+        [=] __device__(int i, int j, int k, int f, int n) { return yt[f](i, j, k, ycomp + n) + a * xt[f](i, j, k, xcomp + n); },
+        [=] __device__(int i, int j, int k, int f, int n, double v) { yt[f](i, j, k, ycomp + n) = v; });
 }
 
 void mf_add_scalar(MultiFab& y, double a, int comp, int nc, int ng)
@@ -362,10 +360,9 @@ void mf_mult(MultiFab& y, double a, int comp, int nc, int ng)
     trace_blas_site("mult", y.layout ? y.layout->local_cells() * nc : 0);
     if (!y.base) return;
     const FabD* yt = y.d_tab;
-    for_each(*y.layout, y.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD yy = yt[f];
-        for (int n = 0; n < nc; ++n) yy(i, j, k, comp + n) *= a;
-    });
+    for_each_2ph(*y.layout, y.type, ng, nc, Context::get().stream,
+        [=] __device__(int i, int j, int k, int f, int n) { return yt[f](i, j, k, comp + n) * a; },
+        [=] __device__(int i, int j, int k, int f, int n, double v) { yt[f](i, j, k, comp + n) = v; });
 }
 
 }  // namespace iamrx

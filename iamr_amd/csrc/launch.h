@@ -144,6 +144,34 @@ inline void for_each(const Layout& l, const IndexType& type, int ng, hipStream_t
     Tiling t = level_tiling(l, type, ng);
     hipLaunchKernelGGL((k_for_each<F>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f);
 }
+
+// level-wide loop in two phases, for the BLAS-1 style operations: v = ld(i, j, k, fab, n) for NP planes -- every load issued before the
+// first store (destination and sources may be the same array, so a plain loop orders each load behind the previous store) -- then
+// st(i, j, k, fab, n, v)
+template <int NP, class L, class S>
+__global__ void __launch_bounds__(256) k_for_each_2ph(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, int nc, L ld, S st)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    if (!tile_ijk(t, b, i, j, k0, k1)) return;
+    for (int n = 0; n < nc; ++n)
+        for (int k = k0; k <= k1; k += NP) {
+            double v[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) v[p] = k + p <= k1 ? ld(i, j, k + p, fab, n) : 0.0;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) if (k + p <= k1) st(i, j, k + p, fab, n, v[p]);
+        }
+}
+
+template <class L, class S>
+inline void for_each_2ph(const Layout& l, const IndexType& type, int ng, int nc, hipStream_t s, L ld, S st)
+{
+    if (l.nlocal() == 0 || nc <= 0) return;
+    Tiling t = level_tiling(l, type, ng);
+    hipLaunchKernelGGL((k_for_each_2ph<4, L, S>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, nc, ld, st);
+}
 #endif
 
 }  // namespace iamrx

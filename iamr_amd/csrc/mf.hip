@@ -415,10 +415,9 @@ void MultiFab::Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, in
     if (!dst.base) return;
     const FabD* dt = dst.d_tab;
     const FabD* st = src.d_tab;
-    for_each(*dst.layout, dst.type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-        const FabD d = dt[f], s = st[f];
-        for (int n = 0; n < nc; ++n) d(i, j, k, dcomp + n) = s(i, j, k, scomp + n);
-    });
+    for_each_2ph(*dst.layout, dst.type, ng, nc, Context::get().stream,
+        [=] __device__(int i, int j, int k, int f, int n) { return st[f](i, j, k, scomp + n); },
+        [=] __device__(int i, int j, int k, int f, int n, double v) { dt[f](i, j, k, dcomp + n) = v; });
 }
 
 void MultiFab::copy_to_host(int li, double* dst) const
