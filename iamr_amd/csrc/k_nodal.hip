@@ -673,6 +673,32 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         }
         return f;
     };
+    // the mask of the next plane, as loaded: issued with the other loads in the middle of an iteration, turned into bits at its end (a load
+    // compared on the spot makes the wavefront wait for it and for every load issued before it)
+    double Mr[MASK ? PB : 1][2];
+    auto fetch_mask = [&](int k) {
+        if constexpr (MASK) {
+            const unsigned need = (k <= cb.lo[2] || k >= nhi2) ? 0xffffffffu : surf;
+            const FabD::gdouble* pd = dmt[fab].gp() + (long)(k - dmt[fab].lo[2]) * dks;
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    Mr[b][a] = 0.0;
+                    if ((need >> (2 * b + a)) & 1u) Mr[b][a] = gat(pd, drow[b] + dcol[a]);
+                }
+        }
+    };
+    auto mask_bits = [&]() -> unsigned {
+        unsigned f = 0;
+        if constexpr (MASK) {
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) f |= (Mr[b][a] != 0.0 ? 1u : 0u) << (2 * b + a);
+        }
+        return f;
+    };
     auto load_rhs = [&](int k, int par) {
         const FabD::gdouble* pr = r.gp() + (long)(k - r.lo[2]) * rks;
 #pragma unroll
@@ -787,6 +813,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
             }
             if (gg.zc) zero_plane(Nc); else load_plane(x.gp(), xk(k + 2), xcol, xrow, Nc);
             if (gg.zn) zero_plane(Np); else load_plane(xn.gp(), xk(k + 3), xcol, xrow, Np);
+            fetch_mask(k + 2);
         }
         __syncthreads();
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -812,7 +839,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int a = 0; a < 2; ++a) { Xm[b][a] = Xp[b][a]; Xc[b][a] = Nc[b][a]; Xp[b][a] = Np[b][a]; }
-        fixedm = load_mask(k + 2);
+        fixedm = mask_bits();
     }
 #endif
 }

@@ -170,8 +170,40 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
             }
         }
     };
+    // the plane after the next one travels through registers: fetched (loads issued) before the arithmetic of a plane, written to LDS at
+    // the top of the next iteration -- staged directly, every plane waited for its loads between two barriers with three workgroups per CU
+    constexpr int NE = (PS + NT - 1) / NT;
+    double pf[NE][3];
+    long pfo[NE];
+#pragma unroll
+    for (int s_ = 0; s_ < NE; ++s_) {
+        const int e = tid + s_ * NT;
+        const int ii = tx0 - 1 + e % W, jj = ty0 - 1 + e / W;
+        pfo[s_] = (e < PS && ii <= vhx && jj <= vhy) ? v.off(ii, jj, k0) : -1;      // (>= 0: the cell lies in the array)
+    }
+    const long vks = (long)v.n[0] * v.n[1];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int s_ = 0; s_ < NE; ++s_)
+            if (pfo[s_] >= 0) {
+                const long o = pfo[s_] + vks * (k - k0);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) pf[s_][n] = v.gp()[o + v.cs * n];
+            }
+    };
+    auto commit = [&](int k) {
+        double* dst = V[((k % 3) + 3) % 3];
+#pragma unroll
+        for (int s_ = 0; s_ < NE; ++s_)
+            if (pfo[s_] >= 0) {
+                const int e = tid + s_ * NT;
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dst[e + PS * n] = pf[s_][n];
+            }
+    };
     stage(k0 - 1);
     stage(k0);
+    fetch(k0 + 1);
     __syncthreads();
     LdsVel<TX, TY> a;
     a.i0 = tx0 - 1; a.j0 = ty0 - 1;
@@ -181,7 +213,8 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
         if (on) cross_flux<2, ETA1>(a, ez, i, j, k0, dxi, dyi, dzi, fzl);
     }
     for (int k = k0; k <= k1; ++k) {
-        stage(k + 1);
+        commit(k + 1);
+        if (k < k1) fetch(k + 2);
         __syncthreads();
         a.kc = k; a.pm = V[((k - 1) % 3 + 3) % 3]; a.p0 = V[(k % 3 + 3) % 3]; a.pp = V[((k + 1) % 3 + 3) % 3];
         if (on) {
