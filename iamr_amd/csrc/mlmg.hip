@@ -273,6 +273,8 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             if (!L.buf.defined()) L.buf.define(L.layout, cell_type(), m_ncomp, 1);
             MultiFab* a = &sol;
             MultiFab* b = &L.buf;
+            // from a zero start the first sweep reads no input: an odd number of sweeps starts "from" the buffer and ends in sol without a copy
+            if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
             const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
             for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0); std::swap(a, b); }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
@@ -385,11 +387,18 @@ void CellMG::bottom_solve(MGStats& st)
 {
     const int l = (int)m_lev.size() - 1;
     Level& L = m_lev[l];
-    L.cor.setVal(0.0);
     if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
+        AbecCoef c = coef(l);
+        c.tensor = 0;
+        if (!m_cf && abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size())) {
+            smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true);      // the first sweep takes the correction as zero: no fill, nothing read
+            return;
+        }
+        L.cor.setVal(0.0);
         smooth_n(l, L.cor, L.res, m_dd_sweeps, true);
         return;
     }
+    L.cor.setVal(0.0);
     if (m_o.bottom_smoother_only) {
         smooth_n(l, L.cor, L.res, m_o.nuf, true);
         return;
