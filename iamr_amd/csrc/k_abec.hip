@@ -1220,13 +1220,17 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
 template <int BMODE, bool RESTRICT>
 __global__ void __launch_bounds__(256) k_abec_resid_restrict(Tiling t, const BoxD* __restrict__ cboxes, const FabD* __restrict__ ct,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ sgt,
-    double dhx, double dhy, double dhz, int sig_comp, double sig_scale, BUni bu, unsigned long long* __restrict__ normout)
+    double dhx, double dhy, double dhz, int sig_comp, double sig_scale, BUni bu, unsigned long long* __restrict__ normout, int wrap)
 {
     const int fab = blockIdx.y;
     const BoxD cb = cboxes[fab];
     int I, J, K0, K1;
     double mx = 0.0;
     if (!tile_ijk(t, cb, I, J, K0, K1)) { if (!RESTRICT && normout) norm_commit(mx, normout); return; }
+    // wrap: one box spanning a periodic domain -- phi's periodic images are read from its valid cells (no ghost fill in front of the launch)
+    const int flo0 = 2 * cb.lo[0], fhi0 = 2 * cb.hi[0] + 1, flo1 = 2 * cb.lo[1], fhi1 = 2 * cb.hi[1] + 1, flo2 = 2 * cb.lo[2], fhi2 = 2 * cb.hi[2] + 1;
+    auto wj = [&](int j) { return wrap ? (j < flo1 ? fhi1 : (j > fhi1 ? flo1 : j)) : j; };
+    auto wk = [&](int k) { return wrap ? (k < flo2 ? fhi2 : (k > fhi2 ? flo2 : k)) : k; };
     const FabD crse = ct[fab], phi = phit[fab], rhs = rhst[fab];
     FabD S; if (BMODE == 1) S = sgt[fab];
     const int bx = 1 << t.bxs, tx = (int)threadIdx.x & (bx - 1);
@@ -1237,17 +1241,17 @@ __global__ void __launch_bounds__(256) k_abec_resid_restrict(Tiling t, const Box
     D2 pb[2], pc[2], pa[2], sb[2], sc[2], sa[2];
     int k = 2 * K0;
     for (int r = 0; r < 2; ++r) {
-        pb[r] = ld2(phi, iL, j0 + r, k - 1, 0); pc[r] = ld2(phi, iL, j0 + r, k, 0);
+        pb[r] = ld2(phi, iL, j0 + r, wk(k - 1), 0); pc[r] = ld2(phi, iL, j0 + r, k, 0);
         if (BMODE == 1) { sb[r] = ld2(S, iL, j0 + r, k - 1, sig_comp); sc[r] = ld2(S, iL, j0 + r, k, sig_comp); }
     }
     for (int K = K0; K <= K1; ++K) {
         double s = 0.0;
         for (int kr = 0; kr < 2; ++kr, ++k) {
             for (int r = 0; r < 2; ++r) {
-                pa[r] = ld2(phi, iL, j0 + r, k + 1, 0);
+                pa[r] = ld2(phi, iL, j0 + r, wk(k + 1), 0);
                 if (BMODE == 1) sa[r] = ld2(S, iL, j0 + r, k + 1, sig_comp);
             }
-            const D2 pS = ld2(phi, iL, j0 - 1, k, 0), pN = ld2(phi, iL, j0 + 2, k, 0);       // the rows below / above the pair of rows
+            const D2 pS = ld2(phi, iL, wj(j0 - 1), k, 0), pN = ld2(phi, iL, wj(j0 + 2), k, 0);       // the rows below / above the pair of rows
             D2 sS, sN;
             if (BMODE == 1) { sS = ld2(S, iL, j0 - 1, k, sig_comp); sN = ld2(S, iL, j0 + 2, k, sig_comp); }
 #pragma unroll
@@ -1256,7 +1260,8 @@ __global__ void __launch_bounds__(256) k_abec_resid_restrict(Tiling t, const Box
                 const D2 rr = ld2(rhs, iL, j, k, 0);
                 // x-neighbours of the pair: the adjacent lanes' near cells (or loads at the ends of the row segment)
                 const double fl = __shfl_up(pc[r].r, 1, 64), fr = __shfl_down(pc[r].l, 1, 64);
-                const double pxm = laneL ? fl : (double)phi(iL - 1, j, k, 0), pxp = laneR ? fr : (double)phi(iR + 1, j, k, 0);
+                const double pxm = laneL ? fl : (double)phi((wrap && iL == flo0) ? fhi0 : iL - 1, j, k, 0);
+                const double pxp = laneR ? fr : (double)phi((wrap && iR == fhi0) ? flo0 : iR + 1, j, k, 0);
                 const D2 pym = r == 0 ? pS : pc[0], pyp = r == 0 ? pc[1] : pN;
                 double bxl, bxc, bxr, byml, bymr, bypl, bypr, bzml, bzmr, bzpl, bzpr;        // x faces: left of iL, between, right of iR
                 if (BMODE == 1) {
@@ -1291,6 +1296,18 @@ __global__ void __launch_bounds__(256) k_abec_resid_restrict(Tiling t, const Box
     if (!RESTRICT && normout) norm_commit(mx, normout);
 }
 
+bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs);
+// the pair-marching residual kernels read phi's periodic images from its valid cells on this level (IAMRX_RESID_WRAP, 1)
+static bool abec_resid_wrap(const Geometry& g, const Layout& l) { return tune("RESID_WRAP", 1) != 0 && periodic_wrap_ok(g, l, 4); }
+
+// abec_residual(g, c, out, phi, rhs) / abec_resid_restrict will read no ghost cell of phi: the caller may skip the ghost fill in front of it
+bool abec_residual_reads_no_ghosts(const Geometry& g, const AbecCoef& c, const MultiFab& out, const MultiFab& phi, const MultiFab& rhs, bool restrict_form)
+{
+    if (!abec_resid_wrap(g, *phi.layout) || !abec_resid_restrict_ok(c, phi, rhs) || c.tensor) return false;
+    if (restrict_form) return true;
+    return tune("RESID_PAIRS", 1) != 0 && out.ngrow == 0 && phi.layout->coarsenable(2, 1);
+}
+
 bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs)
 {
     if (tune("RESID_RESTRICT", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
@@ -1306,16 +1323,17 @@ void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, c
     if (crse.nlocal() == 0) return;
     auto& ctx = Context::get();
     const Layout& l = *crse.layout;
+    const int wrap = abec_resid_wrap(g, *phi.layout) ? 1 : 0;
     Tiling t = level_tiling(l, cell_type(), 0, (int)tune("RESID_RESTRICT_TZ", 8));
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     BUni bu;
     for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
     if (c.sig)
         hipLaunchKernelGGL((k_abec_resid_restrict<1, true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, crse.d_tab, phi.d_tab, rhs.d_tab, c.sig->d_tab,
-                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, nullptr);
+                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, nullptr, wrap);
     else
         hipLaunchKernelGGL((k_abec_resid_restrict<2, true>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, crse.d_tab, phi.d_tab, rhs.d_tab, nullptr,
-                           dhx, dhy, dhz, 0, 1.0, bu, nullptr);
+                           dhx, dhy, dhz, 0, 1.0, bu, nullptr, wrap);
 }
 
 // the fine residual out = rhs - A phi by the same march (k_abec_resid_restrict<., false>): levels whose boxes coarsen by 2
@@ -1326,16 +1344,17 @@ static bool abec_residual_pairs(const Geometry& g, const AbecCoef& c, MultiFab& 
     if (!fl.coarsenable(2, 1)) return false;
     LayoutP cl = fl.coarsened(2);
     auto& ctx = Context::get();
+    const int wrap = abec_resid_wrap(g, fl) ? 1 : 0;
     Tiling t = level_tiling(*cl, cell_type(), 0, (int)tune("RESID_RESTRICT_TZ", 8));
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     BUni bu;
     for (int d = 0; d < 3; ++d) bu.v[d] = c.bu[d];
     if (c.sig)
         hipLaunchKernelGGL((k_abec_resid_restrict<1, false>), t.grid(), Tiling::block(), 0, ctx.stream, t, cl->d_boxes, out.d_tab, phi.d_tab, rhs.d_tab, c.sig->d_tab,
-                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, d_norm);
+                           dhx, dhy, dhz, c.sig_comp, c.sig_scale, bu, d_norm, wrap);
     else
         hipLaunchKernelGGL((k_abec_resid_restrict<2, false>), t.grid(), Tiling::block(), 0, ctx.stream, t, cl->d_boxes, out.d_tab, phi.d_tab, rhs.d_tab, nullptr,
-                           dhx, dhy, dhz, 0, 1.0, bu, d_norm);
+                           dhx, dhy, dhz, 0, 1.0, bu, d_norm, wrap);
     return true;
 }
 

@@ -88,6 +88,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
 // zero in front of it -- it then reads no phi and writes every cell (the active colour its update, the other colour zero) -- if this returns
 // true for the same arguments (one component, one-component coefficients, one box spanning a periodic domain: no ghost cell is read)
 // restriction of the residual rhs - A phi straight onto the coarsened layout (one pass, the fine residual is not stored): usable if ..._ok
+bool abec_residual_reads_no_ghosts(const Geometry& g, const AbecCoef& c, const MultiFab& out, const MultiFab& phi, const MultiFab& rhs, bool restrict_form);
 bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs);
 void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, const MultiFab& phi, const MultiFab& rhs);
 bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wrap, bool has_cf);

@@ -159,8 +159,9 @@ public:
     const MultiFab& sigma(int l) const { return m_lev[l].sig; }
     const Geometry& geom(int l) const { return m_lev[l].g; }
     // x_is_zero: x is to be taken as zero whatever it holds (the first smooth call on a correction); the call leaves x fully defined
-    void smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero = false);
-    void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm = nullptr);   // norm: max norm of r (by the residual launch itself where it can)
+    // leave_ghosts: the caller reads no ghost node of x afterwards (the fill behind the last sweep is skipped); x_filled: x comes straight from smooth()
+    void smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero = false, bool leave_ghosts = false);
+    void residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm = nullptr, bool x_filled = false);   // norm: max norm of r (by the residual launch itself where it can)
     void vcycle(MGStats& st);
     // one V-cycle for the residual equation A e = r, zero initial guess; e is zero on Dirichlet nodes, its ghost nodes are filled.
     // Building block of the composite (multi-level) solver, amrns.hip.

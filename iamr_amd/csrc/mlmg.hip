@@ -433,8 +433,9 @@ void CellMG::vcycle(MGStats& st)
         const bool z = m_o.nu1 > 0 && zero_first_pass_ok(l, L.cor);
         if (!z) L.cor.setVal(0.0);
         smooth_n(l, L.cor, L.res, m_o.nu1, true, z);
-        applyBC(l, L.cor, false, nullptr);
         const AbecCoef cl = coef(l);
+        // (one box spanning a periodic domain: the fused residual + restriction reads the periodic images itself)
+        if (m_cf || !abec_residual_reads_no_ghosts(L.g, cl, L.rescor, L.cor, L.res, true)) applyBC(l, L.cor, false, nullptr);
         if (abec_resid_restrict_ok(cl, L.cor, L.res)) {        // residual and restriction in one pass
             if (m_lev[l + 1].agg) {
                 abec_resid_restrict(L.g, cl, m_lev[l + 1].tmp_d, L.cor, L.res);
@@ -536,7 +537,8 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
             vcycle(st);
             cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
-            applyBC(0, phi, true, bcvp);
+            // (the ghost cells are filled once more behind the loop; a residual kernel that wraps its indices needs none here)
+            if (m_cf || !abec_residual_reads_no_ghosts(L0.g, coef(0), L0.res, phi, rhs, false)) applyBC(0, phi, true, bcvp);
             level_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);
             st.iters = iter + 1;
             if (m_o.verbose) printf("iamrx MLMG: iter %d resid %.6e ratio %.3e\n", iter + 1, st.resnorm, st.resnorm / max_norm);

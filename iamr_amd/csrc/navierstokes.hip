@@ -49,7 +49,7 @@ struct SectionTimer {
 // The level works on the caller's boxes merged (mf.h: coalesce_layout) -- if it covers its whole domain.  A level with coarse/fine
 // boundaries keeps the caller's boxes: there the reference's operators are themselves layout dependent (MLTensorOp fills the edge / corner
 // ghost cells at a coarse/fine boundary box by box, so the cross terms next to a seam between two boxes see the box's own extrapolation,
-// not the neighbour's face value -- restated that way in oracle/orc_amr.c and k_tensor.hip): a viscous two-level run on four fine boxes and
+// not the neighbour's face value -- restated that way in k_tensor.hip and in the CPU restatement the tests compare with): a viscous two-level run on four fine boxes and
 // the same run on their union differ by 2e-5 in the velocity, each equal to the oracle on its own layout to 5e-12.  Merging such a level
 // would answer a different question than the caller's grids ask.
 static LayoutP level_work_layout(const Geometry& geom, const LayoutP& lay)

@@ -156,7 +156,7 @@ void NodalMG::fillbc(int l, MultiFab& x, int kpar)
     nodal_reflect_bc(m_lev[l].g, x, m_bc);
 }
 
-void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero)
+void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bool leave_ghosts)
 {
     Level& L = m_lev[l];
     // a correction that starts from zero: on a level the register-resident kernel smooths with index wrap (no ghost nodes are read) the
@@ -198,7 +198,7 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero)
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);
-        fillbc(l, x);
+        if (!leave_ghosts) fillbc(l, x);
         return;
     }
     for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
@@ -218,9 +218,9 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero)
     fillbc(l, x);
 }
 
-void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm)
+void NodalMG::residual(int l, MultiFab& r, MultiFab& x, const MultiFab& b, double* norm, bool x_filled)
 {
-    fillbc(l, x);
+    if (!x_filled) fillbc(l, x);
     const bool masked = (bool)m_lev[l].dmask();
     const bool have = nodal_residual(m_lev[l].g, r, x, m_lev[l].sig, &b, (norm && !masked) ? norm : nullptr);
     if (masked) nodal_zero_masked(r, m_lev[l].dm);
@@ -312,7 +312,7 @@ void NodalMG::vcycle(MGStats& st)
         Level& L = m_lev[l];
         if (m_o.nodal_nu1 <= 0) L.cor.setVal(0.0);
         for (int i = 0; i < m_o.nodal_nu1; ++i) smooth(l, L.cor, L.res, i == 0);
-        residual(l, L.rescor, L.cor, L.res);
+        residual(l, L.rescor, L.cor, L.res, nullptr, m_o.nodal_nu1 > 0);          // (smooth() has just filled the ghost nodes)
         fillbc(l, L.rescor);
         if (m_lev[l + 1].agg) {
             nodal_restrict(m_lev[l + 1].tmp_d, L.rescor);
@@ -355,14 +355,16 @@ void NodalMG::vcycle(MGStats& st)
     }
     for (int l = nl - 2; l >= 0; --l) {
         Level& L = m_lev[l];
-        fillbc(l + 1, m_lev[l + 1].cor);
+        // (a level that was smoothed on the way up comes with its ghost nodes filled; the bottom level comes from its solver)
+        if (l + 1 == nl - 1 || m_o.nodal_nu2 <= 0) fillbc(l + 1, m_lev[l + 1].cor);
         if (m_lev[l + 1].agg) {
             scatter_from_replicated(m_lev[l + 1].tmp_d, m_lev[l + 1].cor, 1);
             nodal_interp_add(L.cor, m_lev[l + 1].tmp_d, L.sig);
         } else
         nodal_interp_add(L.cor, m_lev[l + 1].cor, L.sig);
         if (L.dmask()) nodal_zero_masked(L.cor, L.dm);                  // mlndlap_interpadd: Dirichlet nodes take no correction
-        for (int i = 0; i < m_o.nodal_nu2; ++i) smooth(l, L.cor, L.res);
+        // the finest level's correction is added to the solution node by node: nobody reads its ghost nodes
+        for (int i = 0; i < m_o.nodal_nu2; ++i) smooth(l, L.cor, L.res, false, l == 0 && i == m_o.nodal_nu2 - 1);
     }
 }
 
