@@ -529,6 +529,9 @@ def main():
                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                             "traffic": pmc_traffic("k_nodal_gsr<4, true, false, false> grid=131072"),
                             "algorithmic_bytes_per_launch": dom["alg_bytes_per_launch"], "avg_ms": ms,
+                            # a launch updates the planes of one z-parity and reads x and sigma of both: x 8 + sigma 8 + rhs 4 + output 4 B/node
+                            "two_launch_design_minimum_bytes_per_launch": 24.0 * (n + 1) ** 3,
+                            "two_launch_design_frac": 24.0 * (n + 1) ** 3 / ms / 1e6 / 8000.0,
                             "launches_timed": gs4_insitu[1] if gs4_insitu else None,
                             "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gs4_insitu else "isolated loop",
                             "isolated_loop_ms": dom["ms"]}
