@@ -72,8 +72,10 @@ KERNEL_FORMS = {
     "multi-component colour pass per component": {"GSRB2_MULTI": 1},
     # round 4: two colour passes instead of the one-launch red + black sweep (index-wrap levels with 128 / 256 cells in x)
     "two colour passes": {"GSRB_RB": 0},
+    # round 4: ghost fills in front of the pair-marching residual kernels instead of index wrap
+    "residual kernels read ghost cells": {"RESID_WRAP": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls"])
