@@ -283,8 +283,8 @@ int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, d
         if (!abec_resid_restrict_ok(c, phi->mf, rhs->mf)) throw Error("iamrx_abec_form: the fused residual + restriction does not apply to these arrays");
         abec_resid_restrict(gg, c, out->mf, phi->mf, rhs->mf);
     } else if (op == 6 || op == 7) {
-        if (!abec_gsrb_rb_ok(gg, c, phi->mf, 1)) throw Error("iamrx_abec_form: the one-launch red + black sweep does not apply to this level");
-        abec_gsrb_rb(gg, c, phi->mf, out->mf, rhs->mf, omega, op == 7);
+        if (!abec_gsrb_rb_ok(gg, c, phi->mf, 1, &b)) throw Error("iamrx_abec_form: the one-launch red + black sweep does not apply to this level");
+        abec_gsrb_rb(gg, c, phi->mf, out->mf, rhs->mf, omega, op == 7, &b, 1);
     } else throw Error("iamrx_abec_form: bad op");
     IAMRX_CATCH
 }

@@ -572,9 +572,18 @@ __device__ __forceinline__ double rb_lane_hi(double v)      // the value lane + 
 
 __device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(v)); return r; }
 
-template <int BMODE, int NW, bool HASA>
+// WALLS: the box spans a domain with non-periodic directions (no coarse/fine faces).  Nothing is read from phi's ghost cells: the value
+// beyond a domain face is the ghost formula of k_abec_bc on the values at hand, g = p0 * c1 + p_in * c2 (Neumann 1, 0; reflect-odd -1, 0;
+// homogeneous Dirichlet of order <= 3: the two Lagrange weights; p_in: the neighbour on the inner side -- for a black cell the NEW red,
+// as after the ghost fill between the colours), gamma loses dh * b * c1 there, the density beyond the face comes from its (filled) ghost
+// cell, and a black cell at an x-face forms that face's coefficient itself.  Rows / planes outside the box that a tile carries as halo
+// compute on whatever the ghost cells hold; every use of their values is replaced as above.
+struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; };
+
+template <int BMODE, int NW, bool HASA, bool WALLS = false>
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
-    double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk)
+    double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
+    RbBC bc = RbBC())
 {
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass has no global address space: FabD::gp)
     constexpr bool SG = BMODE == 1;
@@ -594,8 +603,9 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const int k0 = b.lo[2] + tzc * tz;
     if (k0 > b.hi[2]) return;
     const int kend = min(k0 + tz - 1, b.hi[2]);
-    auto wj = [&](int j) { return j < b.lo[1] ? j + ny : (j > b.hi[1] ? j - ny : j); };
-    auto wk = [&](int k) { return k < b.lo[2] ? k + nz : (k > b.hi[2] ? k - nz : k); };
+    const bool wall0 = WALLS && !bc.per[0], wall1 = WALLS && !bc.per[1], wall2 = WALLS && !bc.per[2];
+    auto wj = [&](int j) { if (wall1) return min(max(j, b.lo[1] - 1), b.hi[1] + 1); return j < b.lo[1] ? j + ny : (j > b.hi[1] ? j - ny : j); };
+    auto wk = [&](int k) { if (wall2) return min(max(k, b.lo[2] - 1), b.hi[2] + 1); return k < b.lo[2] ? k + nz : (k > b.hi[2] ? k - nz : k); };
     const int jraw = b.lo[1] + ty * (rw - 2) + (r - 1);
     const bool owner = r >= 1 && r <= rw - 2 && jraw <= b.hi[1];       // rows whose black update and output this workgroup owns
     const int j = wj(min(jraw, b.hi[1] + 1)), jm = wj(j - 1), jp = wj(j + 1);
@@ -608,27 +618,56 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const bool hasL = lane > 0, hasR = lane < 63;
     const int wL = r * wpr + (xw == 0 ? wpr - 1 : xw - 1), wR = r * wpr + (xw == wpr - 1 ? 0 : xw + 1);
     auto parity = [&](int k) { return (b.lo[0] + j + k) & 1; };      // 0: the left cell of the pair is red (ny, nz even: wrap keeps it)
+    // walls: the pair / row at a domain face (wave-uniform: wlx, whx, aty*; per lane: the first / last lane of the row)
+    const bool wlx = wall0 && xw == 0, whx = wall0 && xw == wpr - 1;
+    const bool atyl = wall1 && j == b.lo[1], atyh = wall1 && j == b.hi[1];
+    auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
     // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
     typedef const __attribute__((address_space(1))) char gbyte;
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
     auto rowoff = [&](const FabD& f, int i, int jj) { return 8u * (unsigned)((i - f.lo[0]) + f.n[0] * (jj - f.lo[1])); };
     auto plane = [&](const FabD& f, int k, int n) { return f.gp() + (long)f.n[0] * f.n[1] * (wk(k) - f.lo[2]) + f.cs * n; };
+    auto planev = [&](const FabD& f, int k, int n) {            // arrays without ghost cells
+        const int kk = wall2 ? min(max(k, b.lo[2]), b.hi[2]) : wk(k);
+        return f.gp() + (long)f.n[0] * f.n[1] * (kk - f.lo[2]) + f.cs * n;
+    };
     auto ld1 = [](const FabD::gdouble* pl, unsigned off) -> double { return *(const FabD::gdouble*)((gbyte*)pl + (size_t)off); };
     auto ldpair = [](const FabD::gdouble* pl, unsigned off) { const v2u v = *(const __attribute__((address_space(1))) v2u*)((gbyte*)pl + (size_t)off); D2 r; r.l = v.x; r.r = v.y; return r; };
     const unsigned oP = rowoff(pin, iL, j), oPy = rowoff(pin, iL, ym_g ? jm : jp);
     const unsigned oS = SG ? rowoff(S, iL, j) : 0u, oSy = SG ? rowoff(S, iL, ym_g ? jm : jp) : 0u;
-    const unsigned oR = rowoff(rhs, iL, j), oA = HASA ? rowoff(A, iL, j) : 0u, oO = rowoff(pout, iL, j);
+    // (the right-hand side and the a-term have no ghost cells: rows / planes outside the box -- whose results nobody uses -- read the nearest valid one)
+    const int jv = wall1 ? min(max(j, b.lo[1]), b.hi[1]) : j;
+    const unsigned oR = rowoff(rhs, iL, jv), oA = HASA ? rowoff(A, iL, jv) : 0u, oO = rowoff(pout, iL, jv);
     const bool y_g = ym_g || yp_g;
     auto ldp = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(plane(f, k, n), off); };
+    auto ldv = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(planev(f, k, n), off); };
     // one Gauss-Seidel update: k_abec_gsrb2's expressions (no wall / coarse-fine terms on an index-wrap level: g_m_d == gamma)
     auto face = [&](double s0, double s1) { return sig_scale / (0.5 * (s0 + s1)); };      // (the sum commutes: one value per face)
     auto update = [&](double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
-                      double bxm, double bxp, double bym, double byp, double bzm, double bzp) {
+                      double bxm, double bxp, double bym, double byp, double bzm, double bzp, int fx = 0, int fy = 0, int fz = 0) {
         const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
-        // (k_abec_gsrb2 subtracts the wall terms dh * (b * 0.0 + b * 0.0) from gamma here: +-0 for finite coefficients, the same double)
+        // k_abec_gsrb2 subtracts the wall terms dhx (bxm c_lo + bxp c_hi) + dhy (...) + dhz (...) from gamma here, c = c1 at a domain face the
+        // cell touches and 0 elsewhere: the terms with c = 0 are +-0 for finite coefficients and add nothing -- an index-wrap level keeps
+        // gamma, a cell at a wall (f? = 1: low face, 2: high face) subtracts the terms of its faces, in that order: the same double
+        double g_m_d = gamma;
+        if (WALLS) {
+            // (selections, no branches: fx differs from lane to lane; a cell away from the walls adds 0.0 three times.  The constant-coefficient
+            // form is faster with the reference's expression itself -- 118 against 140 us per 256^3 sweep)
+            if (!SG) {
+                const double c0 = fx == 1 ? bc.c1lo[0] : 0.0, c3 = fx == 2 ? bc.c1hi[0] : 0.0, c1 = fy == 1 ? bc.c1lo[1] : 0.0, c4 = fy == 2 ? bc.c1hi[1] : 0.0;
+                const double c2 = fz == 1 ? bc.c1lo[2] : 0.0, c5 = fz == 2 ? bc.c1hi[2] : 0.0;
+                g_m_d = gamma - (dhx * (bxm * c0 + bxp * c3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * c2 + bzp * c5));
+            } else {
+            double ws = 0.0;
+            ws += fx == 0 ? 0.0 : dhx * ((fx == 1 ? bxm : bxp) * (fx == 1 ? bc.c1lo[0] : bc.c1hi[0]));
+            ws += fy == 0 ? 0.0 : dhy * ((fy == 1 ? bym : byp) * (fy == 1 ? bc.c1lo[1] : bc.c1hi[1]));
+            ws += fz == 0 ? 0.0 : dhz * ((fz == 1 ? bzm : bzp) * (fz == 1 ? bc.c1lo[2] : bc.c1hi[2]));
+            g_m_d = gamma - ws;
+            }
+        }
         const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
         const double res = rr - (gamma * p0 - rho);
-        return p0 + omega / gamma * res;
+        return p0 + omega / g_m_d * res;
     };
     constexpr bool has_a = HASA;
     const D2 Z2 = {0.0, 0.0};
@@ -651,6 +690,11 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         }
         return y;
     };
+    // walls in x (density form): the density beyond the face, loaded by the first / last lane of the row a plane ahead (planes q - 1, q, in flight)
+    const bool xs_on = SG && ((wlx && !hasL) || (whx && !hasR));
+    const unsigned oSx = xs_on ? rowoff(S, (wlx && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
+    double xs_m = 0.0, xs_c = 0.0, xsN = 0.0;
+    auto xsload = [&](int qq) { return xs_on ? ld1(plane(S, qq, sig_comp), oSx) : 0.0; };
     double bn_prev = 0.0;
     auto put = [&](int k, int park, double bn, double rn) {          // park 1: the left cell of the pair is the black one
         v2u o;
@@ -662,9 +706,10 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     // (the state an iteration q - 1 would have left)
     Pc = zero ? Z2 : ldp(pin, oP, q - 1, comp); Pp = zero ? Z2 : ldp(pin, oP, q, comp); PN = zero ? Z2 : ldp(pin, oP, q + 1, comp);
     if (SG) { Sc = ldp(S, oS, q - 1, sig_comp); Sp = ldp(S, oS, q, sig_comp); SN = ldp(S, oS, q + 1, sig_comp); }
-    Rc = ldp(rhs, oR, q - 1, comp); RN = ldp(rhs, oR, q, comp);
-    if (has_a) { Ac = ldp(A, oA, q - 1, 0); AN = ldp(A, oA, q, 0); }
+    Rc = ldv(rhs, oR, q - 1, comp); RN = ldv(rhs, oR, q, comp);
+    if (has_a) { Ac = ldv(A, oA, q - 1, 0); AN = ldv(A, oA, q, 0); }
     YN yn, YNN = yload(q, parity(q));
+    if (WALLS) { xs_c = xsload(q - 1); xsN = xsload(q); }
     {   // black cells of the first plane
         const int par = parity(q);
         BPH[0][w][lane] = par ? Pp.l : Pp.r;
@@ -683,15 +728,17 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         if (has_a) { Am = Ac; Ac.l = rb_take(AN.l); Ac.r = rb_take(AN.r); }
         yn = YNN;
         if (y_g) { if (!zero) yn.p = rb_take(YNN.p); if (SG) yn.s = rb_take(YNN.s); }
+        if (WALLS && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
         // the output of the previous iteration's black update (plane q - 2), BEFORE the loads: the wait for the loads at the top of the
         // next iteration then covers nothing younger than a whole iteration (a store behind them would be waited for as well)
         if (owner && q - 2 >= k0) put(q - 2, par, bn_prev, RNm);
         if (q <= kend) {
             if (!zero) PN = ldp(pin, oP, q + 2, comp);
             if (SG) SN = ldp(S, oS, q + 2, sig_comp);
-            RN = ldp(rhs, oR, q + 1, comp);
-            if (has_a) AN = ldp(A, oA, q + 1, 0);
+            RN = ldv(rhs, oR, q + 1, comp);
+            if (has_a) AN = ldv(A, oA, q + 1, 0);
             YNN = yload(q + 1, 1 - par);
+            if (WALLS && SG) xsN = xsload(q + 1);
         }
         // ---- red update of plane q
         const int bq = (q - k0 + 1) & 1;
@@ -701,16 +748,31 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             // the black cell of the pair next to the red one: par 0: red = left, the pair to the left; par 1: the pair to the right
             double nb = par == 0 ? rb_lane_lo(Pc.r) : rb_lane_hi(Pc.l), nbs = 0.0;
             if (SG) nbs = par == 0 ? rb_lane_lo(Sc.r) : rb_lane_hi(Sc.l);
+            const double p0 = par ? Pc.r : Pc.l;
+            int fx = 0, fy = 0, fz = 0;
             if (par == 0 ? !hasL : !hasR) {
+                if (WALLS && (par == 0 ? wlx : whx)) {           // the red cell sits at an x-face of the domain
+                    nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
+                    if (SG) nbs = xs_c;
+                    fx = par == 0 ? 1 : 2;
+                } else {
                 nb = BPH[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
                 if (SG) nbs = BSG[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
+                }
             }
             double pym = BPH[bq][wm][lane], pyp = BPH[bq][wp][lane], sym = 0.0, syp = 0.0;
             if (SG) { sym = BSG[bq][wm][lane]; syp = BSG[bq][wp][lane]; }
             if (ym_g) { pym = yn.p; sym = yn.s; }
             if (yp_g) { pyp = yn.p; syp = yn.s; }
+            double pzm = par ? Pm.r : Pm.l, pzp = par ? Pp.r : Pp.l;
+            if (WALLS) {
+                if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
+                else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
+                if (wall2 && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
+                else if (wall2 && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+            }
             const double pxm = par == 0 ? nb : Pc.l, pxp = par == 0 ? Pc.r : nb;
-            const double p0 = par ? Pc.r : Pc.l, pzm = par ? Pm.r : Pm.l, pzp = par ? Pp.r : Pp.l, rr = par ? Rc.r : Rc.l;
+            const double rr = par ? Rc.r : Rc.l;
             const double aa = has_a ? alpha * (par ? Ac.r : Ac.l) : 0.0;
             double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1];
             if (SG) {
@@ -721,7 +783,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                 bzm_c = face(par ? Sm.r : Sm.l, s0); bzp_c = face(s0, par ? Sp.r : Sp.l);
             }
             RNa = RNm; RNm = RNc;
-            RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c);
+            RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c, fx, fy, fz);
             if (SG) {
                 YM[slot][w][lane] = bym; YP[slot][w][lane] = byp;
                 if (!hasL) XF[slot][w][0] = bfar_c;
@@ -740,21 +802,34 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             // (the lane shifts below run under the row mask `owner`: every lane of a wavefront belongs to one row)
             double nb = park == 1 ? rb_lane_lo(RNm) : rb_lane_hi(RNm), nbf = bu.v[0];
             if (SG) nbf = park == 1 ? rb_lane_lo(bfar_m) : rb_lane_hi(bfar_m);
+            const double p0 = park ? Pm.l : Pm.r, rr = park ? Rm.l : Rm.r;
+            int fx = 0, fy = 0, fz = 0;
             if (park == 1 ? !hasL : !hasR) {
+                if (WALLS && (park == 1 ? wlx : whx)) {          // the black cell sits at an x-face: ghost from its own value and the new red beside it
+                    nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
+                    if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
+                    fx = park == 1 ? 1 : 2;
+                } else {
                 nb = RED[slotk][park == 1 ? wL : wR][park == 1 ? 63 : 0];
                 if (SG) nbf = XF[slotk][park == 1 ? wL : wR][park == 1 ? 1 : 0];
+                }
             }
             const double pxm = park == 1 ? nb : RNm, pxp = park == 1 ? RNm : nb;
-            const double pym = RED[slotk][w - wpr][lane], pyp = RED[slotk][w + wpr][lane];
+            double pym = RED[slotk][w - wpr][lane], pyp = RED[slotk][w + wpr][lane], pzm = RNa, pzp = RNc;
+            if (WALLS) {
+                if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
+                else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
+                if (wall2 && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
+                else if (wall2 && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+            }
             double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
             if (SG) {
                 bxm = park == 1 ? nbf : bnear_m; bxp = park == 1 ? bnear_m : nbf;
                 bym = YP[slotk][w - wpr][lane]; byp = YM[slotk][w + wpr][lane];
                 bzm = bzp_a; bzp = bzm_c;
             }
-            const double p0 = park ? Pm.l : Pm.r, rr = park ? Rm.l : Rm.r;
             const double aa = has_a ? alpha * (park ? Am.l : Am.r) : 0.0;
-            const double bn = update(p0, pxm, pxp, pym, pyp, RNa, RNc, rr, aa, bxm, bxp, bym, byp, bzm, bzp);
+            const double bn = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
             bn_prev = bn;
         }
         if (SG) { bnear_m = bnear_c; bfar_m = bfar_c; bzp_a = bzp_m; bzp_m = bzp_c; }
@@ -768,13 +843,48 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
 #endif
 }
 
-bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc)
+// the ghost formula of one component's boundary conditions as the sweep kernel applies it; false: a condition it does not take
+static bool rb_make_bc(const Geometry& g, const DomainBC& bc, RbBC& r)
 {
-    if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
+    for (int d = 0; d < 3; ++d) {
+        r.per[d] = g.periodic[d] ? 1 : 0;
+        r.c1lo[d] = r.c2lo[d] = r.c1hi[d] = r.c2hi[d] = 0.0;
+        if (g.periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            const int t = side == 0 ? bc.lo[d] : bc.hi[d];
+            double c1, c2 = 0.0;
+            if (t == lo_neumann) c1 = 1.0;
+            else if (t == lo_reflect_odd) c1 = -1.0;
+            else if (t == lo_dirichlet) {
+                double c[4]; int NX;
+                dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX);
+                if (NX < 2 || NX > 3) return false;
+                c1 = c[1]; c2 = c[2];
+            } else return false;
+            (side == 0 ? r.c1lo[d] : r.c1hi[d]) = c1;
+            (side == 0 ? r.c2lo[d] : r.c2hi[d]) = c2;
+        }
+    }
+    return true;
+}
+
+// bcs: the level's boundary conditions (nbc sets: one per component, or one for all); null: fully periodic levels only.
+// IAMRX_GSRB_RB_WALLS (1): 0 = index-wrap levels only.
+bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs)
+{
+    if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("PERIODIC_WRAP", 1) == 0) return false;
     const Layout& l = *phi.layout;
-    (void)nbc;                                                     // (every side periodic: no boundary condition enters)
-    if (!periodic_wrap_ok(g, l, 4)) return false;
+    if (l.boxes.size() != 1 || l.nlocal() != 1) return false;
     const BoxD& b = l.boxes[0];
+    bool walls = false;
+    for (int d = 0; d < 3; ++d) {
+        if (b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || b.len(d) < 4) return false;
+        if (!g.periodic[d]) walls = true;
+    }
+    if (walls) {
+        if (!bcs || nbc < 1 || tune("GSRB_RB_WALLS", 1) == 0) return false;
+        for (int n = 0; n < phi.ncomp; ++n) { RbBC r; if (!rb_make_bc(g, bcs[n < nbc ? n : 0], r)) return false; }
+    }
     const int nx = b.len(0);
     if (nx != 128 && nx != 256) return false;                      // whole rows in 1 or 2 wavefronts of a workgroup
     if ((b.len(1) & 1) || (b.len(2) & 1) || b.len(1) < 16 || b.len(2) < 16) return false;
@@ -784,9 +894,11 @@ bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, 
 }
 
 // one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
-void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero)
+void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                  const DomainBC* bcs, int nbc)
 {
-    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, 1) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
+    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
+    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     if (pin.nlocal() == 0) return;
     auto& ctx = Context::get();
     const Layout& l = *pin.layout;
@@ -806,11 +918,19 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
     for (int n = 0; n < pin.ncomp; ++n) {
         BUni bn;
         for (int d = 0; d < 3; ++d) bn.v[d] = c.bu[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
-#define IAMRX_RB(M, HA, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
-                                                  c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk)
-        if (c.sig) IAMRX_RB(1, false, c.sig_comp, c.sig_scale);
-        else if (has_a) IAMRX_RB(2, true, 0, 1.0);
-        else IAMRX_RB(2, false, 0, 1.0);
+        RbBC rbc;
+        if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
+#define IAMRX_RB(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
+                                                      c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc)
+        if (walls) {
+            if (c.sig) IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale);
+            else if (has_a) IAMRX_RB(2, true, true, 0, 1.0);
+            else IAMRX_RB(2, false, true, 0, 1.0);
+        } else {
+            if (c.sig) IAMRX_RB(1, false, false, c.sig_comp, c.sig_scale);
+            else if (has_a) IAMRX_RB(2, true, false, 0, 1.0);
+            else IAMRX_RB(2, false, false, 0, 1.0);
+        }
 #undef IAMRX_RB
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);

@@ -94,8 +94,9 @@ void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, c
 bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wrap, bool has_cf);
 // one red + black sweep in ONE launch, out of place (pin -> pout), on a level that is one box spanning a periodic domain (k_abec_gsrb_rb: the
 // doubles of the two colour passes, a third of their HBM traffic); zero: pin is identically zero and is not read
-bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc);
-void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero);
+bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs = nullptr);
+void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                  const DomainBC* bcs = nullptr, int nbc = 0);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,

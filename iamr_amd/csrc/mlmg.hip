@@ -268,7 +268,7 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
         // one box spanning a periodic domain: red + black in one out-of-place launch per sweep (k_abec_gsrb_rb), ping-pong with the level's buffer
         AbecCoef c = coef(l);
         c.tensor = 0;
-        if (abec_gsrb_rb_ok(m_lev[l].g, c, sol, (int)m_bcn.size())) {
+        if (abec_gsrb_rb_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data())) {
             Level& L = m_lev[l];
             if (!L.buf.defined()) L.buf.define(L.layout, cell_type(), m_ncomp, 1);
             MultiFab* a = &sol;
@@ -276,7 +276,7 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             // from a zero start the first sweep reads no input: an odd number of sweeps starts "from" the buffer and ends in sol without a copy
             if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
             const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
-            for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0); std::swap(a, b); }
+            for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size()); std::swap(a, b); }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
             return;
         }
@@ -390,7 +390,7 @@ void CellMG::bottom_solve(MGStats& st)
     if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
         AbecCoef c = coef(l);
         c.tensor = 0;
-        if (!m_cf && abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size())) {
+        if (!m_cf && abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data())) {
             smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true);      // the first sweep takes the correction as zero: no fill, nothing read
             return;
         }

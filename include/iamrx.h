@@ -162,8 +162,9 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /
  * cell; the role of MacProj.cpp:1098-1128's coefficients), coef = 2: uniform face coefficients bu[3] (constant viscosity / diffusivity).
  * op 0 / 1: red / black colour pass on phi (ghost cells filled by the caller; abec_gsrb role); 4 / 5: the same with the index wrap of one box
  * spanning a periodic domain (no ghost cells read); 2: out = rhs - L phi; 3: out (on the layout coarsened by 2) = restriction of rhs - L phi;
- * 6: out = phi after one red + black sweep in ONE launch (one box spanning a periodic domain of 128 or 256 cells in x; out != phi, >= 1 ghost
- * cell), 7: the same with phi taken as zero without being read. */
+ * 6: out = phi after one red + black sweep in ONE launch (one box spanning the domain, 128 or 256 cells in x, every side periodic, Neumann,
+ * reflect-odd or Dirichlet of order <= 3 -- homogeneous, as inside a V-cycle; no ghost cell of phi is read; out != phi, >= 1 ghost cell),
+ * 7: the same with phi taken as zero without being read. */
 int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, double scale, const double bu[3], double beta, int op,
                     iamrx_mf phi, iamrx_mf rhs, iamrx_mf out, double omega, const int lobc[3], const int hibc[3], int maxorder);
 int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,

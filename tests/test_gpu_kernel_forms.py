@@ -171,3 +171,72 @@ def test_one_launch_red_black_sweep_matches_the_oracle(orc, gpu, n, coef):
             a, b = b, a
             got, ref = a.gather_valid(n), phi_o.valid(n)
             assert np.array_equal(got, ref), (start, sweep, float(np.nanmax(np.abs(got - ref))), int(np.isnan(got).sum()))
+
+
+PERIODIC, DIRICHLET, NEUMANN = 0, 101, 102
+WALL_CASES = {
+    # (periodic flags, low-side conditions, high-side conditions)
+    "closed box (Neumann)": ((0, 0, 0), (NEUMANN,) * 3, (NEUMANN,) * 3),
+    "walls in z": ((1, 1, 0), (PERIODIC, PERIODIC, NEUMANN), (PERIODIC, PERIODIC, NEUMANN)),
+    "channel: inflow / outflow in x, walls in y": ((0, 0, 1), (NEUMANN, NEUMANN, PERIODIC), (DIRICHLET, NEUMANN, PERIODIC)),
+    "Dirichlet everywhere": ((0, 0, 0), (DIRICHLET,) * 3, (DIRICHLET,) * 3),
+}
+
+
+@pytest.mark.parametrize("coef", [1, 2])
+@pytest.mark.parametrize("case", list(WALL_CASES))
+@pytest.mark.parametrize("n", [(128, 20, 16), (256, 32, 48)])
+def test_one_launch_sweep_with_domain_walls_matches_the_oracle(orc, gpu, n, case, coef):
+    """k_abec_gsrb_rb<., WALLS>: the one-launch sweep on a box that spans a domain with non-periodic sides.  It reads no ghost cell of phi
+    (they are poisoned here): beyond a face it applies the ghost formula of the level's homogeneous boundary condition to the values at
+    hand, as the ghost fill in front of each colour pass of the reference sequence does.  Against the oracle's fill + colour pass, twice."""
+    lib = gpu
+    L = orc.lib()
+    per, lobc, hibc = WALL_CASES[case]
+    g_o, g_d = orc.geom(n, periodic=per), lib.Geom.make(n, periodic=per)
+    lay = lib.Layout.single(n)
+    rho, phi, rhs = fields(n, 21)
+    rng = np.random.default_rng(5)
+    for d in range(3):                  # non-periodic sides: the density beyond the face is whatever the caller's fill left there
+        if per[d]:
+            continue
+        for side in (0, -1):
+            sl = [slice(None)] * 3; sl[d] = side
+            rho[tuple(sl)] = 1.0 + 0.3 * rng.random(rho[tuple(sl)].shape)
+    scale, bu, beta = 0.37, (0.8, 1.1, 1.3), 1.0
+    b_o = []
+    for d in range(3):
+        bf = orc.Fab(n, orc.face(d), 0, 1)
+        if coef == 1:
+            lo = [slice(1, n[e] + 1) for e in range(3)]; hi = [slice(1, n[e] + 1) for e in range(3)]
+            lo[d] = slice(0, n[d] + 1); hi[d] = slice(1, n[d] + 2)
+            bf.a[..., 0] = scale / (0.5 * (rho[tuple(lo)] + rho[tuple(hi)]))
+        else:
+            bf.a[...] = bu[d]
+        b_o.append(bf)
+    lev = orc.abec_level(g_o, b_o, beta=beta)
+    rhs_o = orc.Fab(n, orc.CELL, 0, 1); rhs_o.a[..., 0] = rhs
+    rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1,) * 3)
+    rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs[..., None], (0,) * 3)
+    kw = dict(rho=rho_d, scale=scale, bu=bu, beta=beta, lobc=lobc, hibc=hibc, maxorder=3)
+    lo3, hi3 = orc.i3(lobc), orc.i3(hibc)
+    for start in ("field", "zero"):
+        phi_o = orc.Fab(n, orc.CELL, 1, 1)
+        phi_o.a[..., 0] = phi if start == "field" else 0.0
+        poisoned = phi.copy()
+        for d in range(3):
+            for side in (0, -1):
+                sl = [slice(None)] * 3; sl[d] = side
+                poisoned[tuple(sl)] = np.nan
+        a = lib.MultiFab(lay, lib.CELL, 1, 1); b = lib.MultiFab(lay, lib.CELL, 1, 1)
+        a.set_from_global(poisoned[..., None], (-1,) * 3)
+        b.setval(np.nan)
+        for sweep in range(2):
+            for rb in (0, 1):
+                L.orc_fill_periodic(phi_o.ref(), C.byref(g_o), orc.i3(orc.CELL))
+                L.orc_abec_applybc(C.byref(lev), phi_o.ref(), lo3, hi3, 3, 0, None)
+                L.orc_abec_gsrb(C.byref(lev), phi_o.ref(), rhs_o.ref(), rb, C.c_double(1.15), lo3, hi3, 3)
+            lib.abec_form(g_d, coef, 7 if (start == "zero" and sweep == 0) else 6, a, rhs_d, out=b, **kw)
+            a, b = b, a
+            got, ref = a.gather_valid(n), phi_o.valid(n)
+            assert np.array_equal(got, ref), (case, start, sweep, float(np.nanmax(np.abs(got - ref))), int(np.isnan(got).sum()))

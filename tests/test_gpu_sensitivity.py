@@ -74,11 +74,12 @@ KERNEL_FORMS = {
     "two colour passes": {"GSRB_RB": 0},
     # round 4: ghost fills in front of the pair-marching residual kernels instead of index wrap
     "residual kernels read ghost cells": {"RESID_WRAP": 0},
+    "two colour passes on levels with walls": {"GSRB_RB_WALLS": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1}
 
 
-@pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls"])
+@pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls", "channel_walls_long"])
 def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, case):
     """Round 3 replaced the kernels of the cell-centred multigrid's finest level by forms that read less (coefficients recomputed from the
     cell-centred density or taken as constants, pair-marching colour pass); each keeps the expressions of the kernel it replaces, so a run
@@ -105,7 +106,9 @@ def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, c
             ns.set_data(N.NavierStokes.S_NEW, m)
         else:                                   # inflow / outflow in x, no-slip walls in y, slip in z: Dirichlet and Neumann faces, odd box
             n = (24, 12, 8)                     # lengths on the coarser multigrid levels
-            g = lib.Geom.make(n, prob_hi=(2.0, 1.0, 0.5), periodic=(0, 0, 0))
+            if case == "channel_walls_long":    # 128 cells in x: the one-launch sweep with domain walls (Neumann / Dirichlet faces of the MAC
+                n = (128, 16, 16)               # solve, no-slip / slip / outflow faces of the three viscous components)
+            g = lib.Geom.make(n, prob_hi=(n[0] / 12.0 if n[0] > 24 else 2.0, 1.0, 0.5), periodic=(0, 0, 0))
             lay = lib.Layout.single(n)
             wl = [0.0] * 9
             wl[0] = 1.0
