@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--amr-n", type=int, default=256, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
     ap.add_argument("--amr-steps", type=int, default=3)
+    ap.add_argument("--ldc-steps", type=int, default=4, help="timed steps of the secondary LidDrivenCavity workload at --n^3 (single GPU; 0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the oracle's smoother loops (the rest of the port is scalar); 0 = the CPUs this process may really use")
     return ap.parse_args()
@@ -183,6 +184,32 @@ def file_blob_sha(path):
     import hashlib
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def ldc_workload(lib, n, steps):
+    """BASELINE config C4 per GPU: the reference's regtest.3d.lid_driven_cavity (no-slip / slip walls on every side, variable-density
+    capable MAC projection with Neumann walls, tensor solve with Dirichlet walls) at n^3 on one GPU, init_dt scaled with the mesh; ms per
+    step after two warm-up steps.  A secondary figure: the level kernels with domain walls instead of index wrap."""
+    from iamr_amd import ns as NS, run as R
+    from iamr_amd.inputs import Inputs
+    inp = Inputs([os.path.join(ROOT, "tests", "golden", "regtest.3d.lid_driven_cavity")],
+                 [f"amr.n_cell={n} {n} {n}", f"amr.max_grid_size={n}", f"max_step={steps + 2}", f"ns.init_dt={0.0140625 * 64 / n}"])
+    pr = inp.problem()
+    ns, lay, g, pr = R.build(inp, lib, NS, 1, pr)
+    ns.post_init(pr["stop_time"])
+    for _ in range(2):
+        ns.step()
+    lib.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ns.step()
+    lib.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    sm, sn, sv = ns.stats()
+    return {"workload": "LidDrivenCavity 3D (regtest.3d.lid_driven_cavity), one %d^3 box, walls on every side" % n, "ms_per_step": ms,
+            "cells_per_sec": float(n) ** 3 / ms * 1e3, "steps": steps,
+            "mlmg_iters": {"mac_cc": sm.iters, "nodal": sn.iters, "tensor_visc": sv.iters},
+            "mlmg_vcycle_ms": {"mac_cc": sm.vcycle_ms, "nodal": sn.vcycle_ms, "tensor_visc": sv.vcycle_ms}}
 
 
 def amr_workload(lib, n0, steps, rank=0, world=1, dist=None, layout_gpus=None, keep=None):
@@ -591,6 +618,11 @@ def main():
         if world == 1 and not a.no_multibox:
             out["single_gpu_multibox"] = multibox_workload(lib, n)
             out["single_gpu_multibox"]["1x%d^3" % n] = {"ms_per_step": el / a.steps * 1e3, "cells_per_sec": value}
+        if world == 1 and a.ldc_steps > 0:
+            try:
+                out["lid_driven_cavity"] = ldc_workload(lib, n, a.ldc_steps)
+            except Exception as e:                      # a secondary figure must not take the bench line with it
+                out["lid_driven_cavity"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))
