@@ -129,6 +129,7 @@ private:
     const MultiFab* m_a0 = nullptr;
     const MultiFab* m_b0[3] = {nullptr, nullptr, nullptr};
     bool m_buni = false;                 // the finest level's b arrays are constants (prepare() checks)
+    bool m_buni_coarse = false;          // ... and the coarser levels use the constants too (IAMRX_MG_COARSE_UNIFORM, 1)
     double m_bu[3] = {0.0, 0.0, 0.0};
     const MultiFab* m_sig = nullptr;
     int m_sig_comp = 0;

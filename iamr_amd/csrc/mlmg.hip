@@ -51,6 +51,13 @@ AbecCoef CellMG::coef(int l) const
     } else {
         c.a = m_a0 ? &m_lev[l].a : nullptr;
         for (int d = 0; d < 3; ++d) c.b[d] = &m_lev[l].b[d];
+        // constant coefficients stay constant under the face average: the coarse levels run the constant-coefficient kernel forms too (their
+        // arrays hold the same doubles: (x + x + x + x) 0.25 = x; the eta form keeps its one-component arrays, see prepare())
+        if (m_buni_coarse) {
+            c.b_uniform = 1;
+            for (int d = 0; d < 3; ++d) c.bu[d] = m_bu[d];
+            c.tensor_eta = m_tensor_eta ? 1 : 0;
+        }
     }
     return c;
 }
@@ -78,6 +85,7 @@ void CellMG::prepare()
             else m_buni = mf_uniform_value(*m_b0[d], &m_bu[d]);
         }
     }
+    m_buni_coarse = m_buni && tune("MG_COARSE_UNIFORM", 1) != 0;
     m_dd_sweeps = 0;
     const bool dd_on = tune("MG_DIAG_SHORTCUT", 1) != 0;
     if (dd_on && m_alpha > 0.0 && m_beta > 0.0 && m_a0 && m_o.fixed_iters <= 0 && m_o.max_coarsening_level > 0) {
@@ -154,7 +162,7 @@ void CellMG::prepare()
                 // coarsening the finest level of an eta-form tensor operator: average the three-component coefficients it stands for
                 MultiFab b3;
                 const MultiFab* fb = fc.b[d];
-                if (l == 1 && m_tensor_eta) { b3.define(m_lev[0].layout, face_type(d), 3, 0); tensor_bcoef(b3, *fc.b[d], d); fb = &b3; }
+                if (l == 1 && m_tensor_eta && !m_buni_coarse) { b3.define(m_lev[0].layout, face_type(d), 3, 0); tensor_bcoef(b3, *fc.b[d], d); fb = &b3; }
                 L.b[d].define(L.layout, face_type(d), fb->ncomp, 0);
                 if (L.agg) { MultiFab t(L.dist, face_type(d), fb->ncomp, 0); face_avgdown(t, *fb, d); gather_to_replicated(L.b[d], t); }
                 else face_avgdown(L.b[d], *fb, d);
@@ -268,7 +276,8 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
         // one box spanning a periodic domain: red + black in one out-of-place launch per sweep (k_abec_gsrb_rb), ping-pong with the level's buffer
         AbecCoef c = coef(l);
         c.tensor = 0;
-        if (abec_gsrb_rb_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data())) {
+        // (finest level only: on a coarser level of 128 cells in x a march of a few planes does not beat two colour passes)
+        if (l == 0 && abec_gsrb_rb_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data())) {
             Level& L = m_lev[l];
             if (!L.buf.defined()) L.buf.define(L.layout, cell_type(), m_ncomp, 1);
             MultiFab* a = &sol;

@@ -75,8 +75,10 @@ KERNEL_FORMS = {
     # round 4: ghost fills in front of the pair-marching residual kernels instead of index wrap
     "residual kernels read ghost cells": {"RESID_WRAP": 0},
     "two colour passes on levels with walls": {"GSRB_RB_WALLS": 0},
+    # round 4: the coarser levels of a constant-coefficient operator read their (constant) coefficient arrays instead of taking the constants
+    "coefficient arrays on the coarser levels": {"MG_COARSE_UNIFORM": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1, "MG_COARSE_UNIFORM": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls", "channel_walls_long"])
