@@ -1715,19 +1715,17 @@ void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, cons
 struct BndryDesc { int fab; BoxD region; int dir, side; };
 
 struct BcParams { int bct[6]; double c[6][5]; };   // per face (2*d + side): LinOpBC type; Dirichlet weights c[0..3] and NX
+// one set for all components (nset == 1) or one per component (the tensor solves: Diffusion.cpp:724-731), in ONE launch
+struct BcParamsN { BcParams p[3]; int nset; };
 
 __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ descs, const FabD* __restrict__ phit,
-                                                 const FabD* __restrict__ bcvt, int ncomp, int comp0, BcParams P, int inhomog)
+                                                 const FabD* __restrict__ bcvt, int ncomp, int comp0, BcParamsN PN, int inhomog)
 {
     const BndryDesc bd = descs[blockIdx.y];
     const FabD phi = phit[bd.fab];
     const int nx = bd.region.len(0), ny = bd.region.len(1);
     const long npts = bd.region.npts();
     const int d = bd.dir, s = 1 - 2 * bd.side;
-    const int bct = P.bct[2 * d + bd.side];
-    if (bct != lo_neumann && bct != lo_dirichlet && bct != lo_reflect_odd) return;
-    const double* c = P.c[2 * d + bd.side];   // c[0..3] weights, c[4] = NX
-    const int NX = (int)c[4];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
         int idx[3];
         idx[0] = bd.region.lo[0] + (int)(q % nx);
@@ -1735,6 +1733,11 @@ __global__ void __launch_bounds__(256) k_abec_bc(const BndryDesc* __restrict__ d
         idx[1] = bd.region.lo[1] + (int)(r % ny);
         idx[2] = bd.region.lo[2] + (int)(r / ny);
         for (int n = comp0; n < comp0 + ncomp; ++n) {
+            const BcParams& P = PN.p[PN.nset == 1 ? 0 : n - comp0];
+            const int bct = P.bct[2 * d + bd.side];
+            if (bct != lo_neumann && bct != lo_dirichlet && bct != lo_reflect_odd) continue;
+            const double* c = P.c[2 * d + bd.side];   // c[0..3] weights, c[4] = NX
+            const int NX = (int)c[4];
             double v;
             int m[3] = {idx[0], idx[1], idx[2]};
             if (bct == lo_neumann) { m[d] += s; v = phi(m[0], m[1], m[2], n); }
@@ -1773,7 +1776,21 @@ std::map<std::array<long, 8>, BcDescCache>& bc_desc_cache()
 }
 }  // namespace
 
+static void abec_apply_domain_bc_sets(const Geometry& g, MultiFab& phi, const DomainBC* bcs, int nset, bool inhomog, const MultiFab* bcval, int comp0, int ncomp);
+
 void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0, int ncomp)
+{
+    abec_apply_domain_bc_sets(g, phi, &bc, 1, inhomog, bcval, comp0, ncomp);
+}
+
+// one boundary-condition set per component (at most 3), all components in one launch
+void abec_apply_domain_bc_percomp(const Geometry& g, MultiFab& phi, const DomainBC* bcs, int ncomp, bool inhomog, const MultiFab* bcval)
+{
+    IAMRX_ASSERT(ncomp >= 1 && ncomp <= 3 && ncomp <= phi.ncomp);
+    abec_apply_domain_bc_sets(g, phi, bcs, ncomp, inhomog, bcval, 0, ncomp);
+}
+
+static void abec_apply_domain_bc_sets(const Geometry& g, MultiFab& phi, const DomainBC* bcs, int nset, bool inhomog, const MultiFab* bcval, int comp0, int ncomp)
 {
     if (ncomp < 0) ncomp = phi.ncomp - comp0;
     bool any = false;
@@ -1810,16 +1827,21 @@ void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, 
     }
     const BcDescCache& e = it->second;
     if (e.n == 0) return;
-    BcParams P;
-    for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
-        P.bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
-        double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX);
-        for (int q = 0; q < 4; ++q) P.c[2 * d + side][q] = c[q];
-        P.c[2 * d + side][4] = NX;
+    BcParamsN PN;
+    PN.nset = nset;
+    for (int m = 0; m < 3; ++m) {
+        const DomainBC& bc = bcs[m < nset ? m : 0];
+        BcParams& P = PN.p[m];
+        for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            P.bct[2 * d + side] = side == 0 ? bc.lo[d] : bc.hi[d];
+            double c[4]; int NX; dirichlet_coefs(g.domain.len(d), bc.maxorder, c, NX);
+            for (int q = 0; q < 4; ++q) P.c[2 * d + side][q] = c[q];
+            P.c[2 * d + side][4] = NX;
+        }
     }
     long nb = (e.maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_abec_bc, dim3((unsigned)nb, (unsigned)e.n), dim3(256), 0, ctx.stream,
-                       (const BndryDesc*)e.d, phi.d_tab, bcval ? bcval->d_tab : nullptr, ncomp, comp0, P, inhomog ? 1 : 0);
+                       (const BndryDesc*)e.d, phi.d_tab, bcval ? bcval->d_tab : nullptr, ncomp, comp0, PN, inhomog ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------- coarse/fine faces

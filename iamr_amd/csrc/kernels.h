@@ -108,6 +108,7 @@ bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* b
 void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
                        double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters, const CfTab* cftab = nullptr);
 void abec_apply_domain_bc(const Geometry& g, MultiFab& phi, const DomainBC& bc, bool inhomog, const MultiFab* bcval, int comp0 = 0, int ncomp = -1);
+void abec_apply_domain_bc_percomp(const Geometry& g, MultiFab& phi, const DomainBC* bcs, int ncomp, bool inhomog, const MultiFab* bcval);
 void cc_restrict(MultiFab& crse, const MultiFab& fine);          // average of 8
 void cc_prolong_add(MultiFab& fine, const MultiFab& crse);       // piecewise constant
 void face_avgdown(MultiFab& crse, const MultiFab& fine, int dir);

@@ -180,7 +180,9 @@ void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, 
     // order: domain faces, coarse/fine faces (+ the frozen edge / corner values of the tensor operator), then the edge / corner cells
     // outside the physical domain, which are extrapolated from cells filled by the first two
     if (m_bcn.size() == 1) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
-    else   // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference Source/Diffusion.cpp:724-731)
+    else if (m_ncomp <= 3 && (int)m_bcn.size() >= m_ncomp)   // one BC per component (MLTensorOp::setDomainBC with per-component arrays, reference
+        abec_apply_domain_bc_percomp(m_lev[l].g, phi, m_bcn.data(), m_ncomp, inhomog, bcval);     // Source/Diffusion.cpp:724-731): one launch
+    else
         for (int n = 0; n < m_ncomp; ++n) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[n], inhomog, bcval, n, 1);
     if (m_cf) cf_fill_ghosts(phi, m_lev[l].cfm, m_lev[l].cftab, inhomog, bcval, m_tensor);
     if (m_tensor && corners) {
