@@ -364,7 +364,8 @@ struct CLev {
     MultiFab own, slave;    // node masks (1 / 0)
     MultiFab fcov;          // coverage by the next level of the solve (cells, 1 ghost)
     MultiFab b, x, r, y, e; // node arrays, 1 ghost
-    MultiFab bb, rb;        // scratch node arrays, 1 ghost node that stays zero: what a level hands down / the right-hand side of its correction
+    MultiFab bb;            // scratch node array, 1 ghost node that stays zero: what a level hands down (the right-hand side of a level's correction
+                            // is written into its solver's own residual array)
     DomainBC bc;            // operator BC
     double wscale;
 };
@@ -467,7 +468,7 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
         C.g = C.pl->g; C.layout = C.pl->layout;
         C.bc = op_bc(C.pl->nodal_bc);
         const bool has_fine = l < nl - 1;
-        for (MultiFab* m : {&C.b, &C.x, &C.r, &C.y, &C.e, &C.bb, &C.rb}) { m->define(C.layout, node_type(), 1, 1); m->setVal(0.0); }
+        for (MultiFab* m : {&C.b, &C.x, &C.r, &C.y, &C.e, &C.bb}) { m->define(C.layout, node_type(), 1, 1); m->setVal(0.0); }
         C.own.define(C.layout, node_type(), 1, 0); C.slave.define(C.layout, node_type(), 1, 0);
         MultiFab cls(C.layout, node_type(), 1, 0);
         MultiFab cov = coverage(C.layout, C.g);
@@ -582,17 +583,21 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
             restrict_to_crse(down, L[m].bb, L[m].g, L[m - 1].g, L[m].pl->ratio);
             acc = std::move(down);
         }
-        MultiFab& rhs = L[l].rb;
-        r_plus(rhs, L[l].r, l < nl - 1 ? &acc : nullptr);
+        // the right-hand side goes straight into the level solver's residual array and the correction is read from its correction array
+        // (valid nodes + the ghost layer it fills): no copies in and out of the V-cycle
+        r_plus(L[l].mg->res(0), L[l].r, l < nl - 1 ? &acc : nullptr);
         delete ps_dn;
-        { ProfScope ps("cp_vcycle"); L[l].mg->vcycle_correction(L[l].e, rhs, vst); }
+        { ProfScope ps("cp_vcycle"); L[l].mg->vcycle_correction_inplace(vst); }
         ProfScope ps_up("cp_interp_update");
+        MultiFab& el = L[l].mg->cor(0);
         for (int m = l; m < nl; ++m) {
+            MultiFab& em = m == l ? el : L[m].e;
             if (m > l) {                                        // e of level m = the interpolant of the coarser correction (all nodes)
-                fill_nodes(L[m - 1], L[m - 1].e);
-                node_interp_from_crse(L[m].e, L[m - 1].e, L[m - 1].g, L[m].pl->ratio, nullptr, false);
+                MultiFab& ec = m - 1 == l ? el : L[m - 1].e;
+                if (m - 1 > l) fill_nodes(L[m - 1], ec);        // (the level solver has filled the ghost nodes of its own correction)
+                node_interp_from_crse(em, ec, L[m - 1].g, L[m].pl->ratio, nullptr, false);
             }
-            const FabD *xt = L[m].x.d_tab, *et = L[m].e.d_tab, *ot = L[m].own.d_tab;                 // x += e on the unknowns
+            const FabD *xt = L[m].x.d_tab, *et = em.d_tab, *ot = L[m].own.d_tab;                 // x += e on the unknowns
             for_each(*L[m].layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
                 if (ot[f](i, j, k) != 0.0) xt[f](i, j, k) += 1.0 * et[f](i, j, k);
             });

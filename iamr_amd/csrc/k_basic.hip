@@ -120,7 +120,7 @@ template <int OP> __device__ __forceinline__ double block_reduce(double v)
 template <int OP> __global__ void __launch_bounds__(256) k_reduce_finish(const double* __restrict__ partials, int np, double* __restrict__ out)
 {
     const int q = blockIdx.x;
-    double v = 0.0;
+    double v = OP == 2 ? -1.7976931348623157e308 : 0.0;       // OP 2: maximum of signed values
     for (int i = threadIdx.x; i < np; i += 256) v = red_op<OP>(v, partials[(size_t)q * np + i]);
     v = block_reduce<OP>(v);
     if (threadIdx.x == 0) out[q] = v;
@@ -151,8 +151,9 @@ static double finish_to_host(int op, int nout, int np, bool global)
     ctx.ensure_scratch((size_t)nout * np + 16);
     double* partials = ctx.d_scratch;
     double* out = ctx.d_scratch + (size_t)nout * np;
-    if (np == 0) IAMRX_HIP_CHECK(hipMemsetAsync(out, 0, nout * sizeof(double), ctx.stream));
+    if (np == 0 && op != 2) IAMRX_HIP_CHECK(hipMemsetAsync(out, 0, nout * sizeof(double), ctx.stream));
     else if (op == 0) hipLaunchKernelGGL((k_reduce_finish<0>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
+    else if (op == 2) hipLaunchKernelGGL((k_reduce_finish<2>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
     else hipLaunchKernelGGL((k_reduce_finish<1>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, out);
     if (global && ctx.comm->nranks > 1) ctx.comm->allreduce_device(out, nout, op == 0 ? ReduceOp::Sum : ReduceOp::Max, ctx.stream);
     IAMRX_HIP_CHECK(hipMemcpyAsync(ctx.h_scratch, out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx.stream));
@@ -172,6 +173,43 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
     hipLaunchKernelGGL(k_norm0, g, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, mf.type.t[0], mf.type.t[1], mf.type.t[2], ng,
                        mf.d_tab, comp, nc, ctx.d_scratch);
     return finish_to_host(1, 1, np, global);
+}
+
+// largest and smallest value of one component in ONE pass and one read-back (partials: block maxima of v, then of -v)
+__global__ void __launch_bounds__(256) k_minmax(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
+                                                const FabD* __restrict__ tab, int comp, double* __restrict__ partials, int np)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    const bool in = tile_ijk(t, b, i, j, k0, k1);
+    const FabD a = tab[fab];
+    double hi = -1.7976931348623157e308, lo = -1.7976931348623157e308;
+    if (in) for (int k = k0; k <= k1; ++k) { const double v = a(i, j, k, comp); hi = v > hi ? v : hi; lo = -v > lo ? -v : lo; }
+    hi = block_reduce<1>(hi);
+    lo = block_reduce<1>(lo);
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = hi;
+        partials[(size_t)np + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = lo;
+    }
+}
+
+// (a rank without data of the level contributes the identity -DBL_MAX to both: k_reduce_finish<2> over zero partials)
+void reduce_minmax(const MultiFab& mf, int comp, int ng, double& mn, double& mx, bool global)
+{
+    global = global && !mf.layout->replicated;
+    auto& ctx = Context::get();
+    int np = 0;
+    if (mf.nlocal() > 0) {
+        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+        dim3 g = t.grid();
+        np = (int)(g.x * g.y);
+        ctx.ensure_scratch((size_t)2 * np + 16);
+        hipLaunchKernelGGL(k_minmax, g, Tiling::block(), 0, ctx.stream, t, mf.layout->d_boxes, mf.type.t[0], mf.type.t[1], mf.type.t[2], ng,
+                           mf.d_tab, comp, ctx.d_scratch, np);
+    }
+    finish_to_host(2, 2, np, global);
+    mx = ctx.h_scratch[0]; mn = -ctx.h_scratch[1];
 }
 
 // per-component maxima: partials[n * np + block]

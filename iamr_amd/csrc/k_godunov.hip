@@ -2291,6 +2291,8 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
         // 16 x 8 tiles (3 wavefronts, 40 KB of LDS) measured 5.8 ms for 5 components at 256^3, 16 x 16: 6.4 ms, 32 x 8: 6.4 ms;
         // bounding the registers for a third wavefront per SIMD spills (17 ms)
         if (ztx == 16 && zty == 8) IAMRX_GZ(16, 8, 2);
+        else if (ztx == 30 && !ppm) IAMRX_GZP(30, 6, 2, false);       // grown tile 32 x 8 = 256 threads exactly (4 wavefronts, 2 workgroups per CU)
+        else if (ztx == 14 && !ppm) IAMRX_GZP(14, 14, 2, false);      // grown tile 16 x 16 = 256 threads
         else if (ztx == 16) IAMRX_GZ(16, 16, 2);
         else IAMRX_GZ(32, 8, 2);
 #undef IAMRX_GZ

@@ -13,6 +13,7 @@ void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, cons
 // global: combined over the ranks (on the device, before the single read-back) unless the layout is replicated
 double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global = false);
 void reduce_norm0_comps(const MultiFab& mf, int comp, int nc, int ng, double* out, bool global = false);   // per-component maxima, one read-back
+void reduce_minmax(const MultiFab& mf, int comp, int ng, double& mn, double& mx, bool global = true);   // one pass, one read-back
 double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool global = false);   // sum over owner copies
 // nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>
 void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);

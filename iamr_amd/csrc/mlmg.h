@@ -167,6 +167,7 @@ public:
     // one V-cycle for the residual equation A e = r, zero initial guess; e is zero on Dirichlet nodes, its ghost nodes are filled.
     // Building block of the composite (multi-level) solver, amrns.hip.
     void vcycle_correction(MultiFab& e, const MultiFab& r, MGStats& st);
+    void vcycle_correction_inplace(MGStats& st);      // r in res(0) (valid nodes), e in cor(0) (valid + 1 ghost layer)
     MultiFab& res(int l) { return m_lev[l].res; }
     MultiFab& cor(int l) { return m_lev[l].cor; }
 

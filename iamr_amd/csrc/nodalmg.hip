@@ -139,11 +139,10 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
     const bool csig_on = tune("NODAL_CSIG", 1) != 0;
     m_csig = false;
     if (csig_on && !m_masked) {
-        const double smax = m_lev[0].sig.norm0(0, 1, 0);
-        MultiFab t(m_lev[0].layout, cell_type(), 1, 0);
-        MultiFab::Copy(t, m_lev[0].sig, 0, 0, 1, 0);
-        mf_add_scalar(t, -smax, 0, 1, 0);
-        if (smax > 0.0 && t.norm0(0, 1, 0) == 0.0) { m_csig = true; m_csig_val = smax; }
+        // (largest and smallest value in one pass and one read-back: sigma changes with every projection, the test runs in front of each)
+        double smin, smax;
+        reduce_minmax(m_lev[0].sig, 0, 0, smin, smax);
+        if (smax > 0.0 && smin == smax) { m_csig = true; m_csig_val = smax; }
     }
 }
 
@@ -379,6 +378,20 @@ void NodalMG::vcycle_correction(MultiFab& e, const MultiFab& r, MGStats& st)
     MultiFab::Copy(e, L0.cor, 0, 0, 1, 0);
     e.FillBoundary(L0.g);
     nodal_reflect_bc(L0.g, e, m_bc);
+}
+
+// the same on the solver's own arrays: the caller has written r to the valid nodes of res(0) and reads e from cor(0) (valid nodes + one
+// layer of ghost nodes) -- no copy in, no copy out (the composite solver calls this once per level correction)
+void NodalMG::vcycle_correction_inplace(MGStats& st)
+{
+    Level& L0 = m_lev[0];
+    if (L0.dmask()) nodal_zero_masked(L0.res, L0.dm);
+    if (m_singular) subtract_mean(0, L0.res);
+    L0.res_filled = false;
+    vcycle(st);
+    const int ngv[3] = {1, 1, 1};
+    L0.cor.FillBoundary(L0.g, 0, 1, ngv, -1);
+    nodal_reflect_bc(L0.g, L0.cor, m_bc);
 }
 
 MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)

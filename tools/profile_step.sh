@@ -19,7 +19,7 @@ a,b=idx[-2]+2,idx[-1]
 seg=rows[a+1:b]
 tot=collections.Counter(); cnt=collections.Counter()
 for r in seg:
-    nm=re.sub(r'\(.*','',r['Kernel_Name']).replace('void ','')[:60]+' g='+r['Grid_Size_X']+'x'+r['Grid_Size_Y']+'x'+r['Grid_Size_Z']
+    nm=re.sub(r'\(.*','',r['Kernel_Name']).replace('void ','')[:int(__import__('os').environ.get('NAMELEN','60'))]+' g='+r['Grid_Size_X']+'x'+r['Grid_Size_Y']+'x'+r['Grid_Size_Z']
     d=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
     tot[nm]+=d; cnt[nm]+=1
 T=sum(tot.values())
