@@ -2001,8 +2001,13 @@ static void launch_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* 
 
 static void godunov_pred_z(const Layout& l, const MultiFab& vel, const MultiFab* force, MultiFab* const umac[3], const GodParams* dP, bool bcs, bool ppm)
 {
-    if (ppm) { if (bcs) launch_pred_z<16, 8, true, true>(l, vel, force, umac, dP); else launch_pred_z<16, 8, false, true>(l, vel, force, umac, dP); }
-    else { if (bcs) launch_pred_z<16, 8, true, false>(l, vel, force, umac, dP); else launch_pred_z<16, 8, false, false>(l, vel, force, umac, dP); }
+    // 14 x 14 cells per workgroup (grown tile 16 x 16 = 256 threads, 80 KB of LDS, two workgroups per CU): 1.04 ms per 256^3 against 1.24 ms with
+    // 16 x 8 (192 threads; IAMRX_GODUNOV_PTX = 16), 1.14 ms with 30 x 6 -- see the tile shapes of k_god_z below
+    const int ptx = (int)tune("GODUNOV_PTX", 14);
+#define IAMRX_PZ(TX, TY) (ppm ? (bcs ? launch_pred_z<TX, TY, true, true>(l, vel, force, umac, dP) : launch_pred_z<TX, TY, false, true>(l, vel, force, umac, dP)) \
+                              : (bcs ? launch_pred_z<TX, TY, true, false>(l, vel, force, umac, dP) : launch_pred_z<TX, TY, false, false>(l, vel, force, umac, dP)))
+    if (ptx == 16) IAMRX_PZ(16, 8); else IAMRX_PZ(14, 14);
+#undef IAMRX_PZ
 }
 
 
@@ -2282,19 +2287,19 @@ void godunov_compute_aofs(const Geometry& g, MultiFab& aofs, int acomp, const Mu
     }
     const GodParams* dP = upload_params(make_params(g, dt, ncomp, bc, iconserv, is_velocity, use_forces_in_trans, force != nullptr, divu != nullptr));
     if (zk) {
-        const int ztx = (int)tune("GODUNOV_ZTX", 16);
-        const int zty = (int)tune("GODUNOV_ZTY", 8);
+        const int ztx = (int)tune("GODUNOV_ZTX", 14);
         const bool bcs = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
 #define IAMRX_GZP(TX, TY, W, PPM) (bcs ? launch_god_z<TX, TY, W, true, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP) \
                                        : launch_god_z<TX, TY, W, false, PPM>(l, aofs, acomp, S, ncomp, force, divu, umac, edge_out, flux_out, dP))
 #define IAMRX_GZ(TX, TY, W) (ppm ? IAMRX_GZP(TX, TY, W, true) : IAMRX_GZP(TX, TY, W, false))
-        // 16 x 8 tiles (3 wavefronts, 40 KB of LDS) measured 5.8 ms for 5 components at 256^3, 16 x 16: 6.4 ms, 32 x 8: 6.4 ms;
-        // bounding the registers for a third wavefront per SIMD spills (17 ms)
-        if (ztx == 16 && zty == 8) IAMRX_GZ(16, 8, 2);
-        else if (ztx == 30 && !ppm) IAMRX_GZP(30, 6, 2, false);       // grown tile 32 x 8 = 256 threads exactly (4 wavefronts, 2 workgroups per CU)
-        else if (ztx == 14 && !ppm) IAMRX_GZP(14, 14, 2, false);      // grown tile 16 x 16 = 256 threads
-        else if (ztx == 16) IAMRX_GZ(16, 16, 2);
-        else IAMRX_GZ(32, 8, 2);
+        // Tile shapes, 3 components at 256^3 (periodic, PLM): the 251 VGPRs of the kernel allow 8 wavefronts per CU, so a 192-thread
+        // workgroup (16 x 8 cells, grown tile 18 x 10) leaves the CU with 6 wavefronts -- two SIMDs run one -- and 128 useful columns per
+        // 192 threads: 2.46 ms.  14 x 14 cells = a grown tile of exactly 16 x 16 = 256 threads: two workgroups = 8 wavefronts per CU, 196
+        // useful columns per 256 threads, 53 KB of LDS: 1.84 ms.  30 x 6 (32 x 8 grown): 2.03 ms; 512 threads (30 x 14: 2.25 ms, 14 x 30:
+        // 2.33 ms; one workgroup per CU); round 2's 16 x 16 and 32 x 8 cells (384 threads): slower than 16 x 8.
+        // IAMRX_GODUNOV_ZTX = 16: the 16 x 8 tiles.
+        if (ztx == 16) IAMRX_GZ(16, 8, 2);
+        else IAMRX_GZ(14, 14, 2);
 #undef IAMRX_GZ
 #undef IAMRX_GZP
         return;
