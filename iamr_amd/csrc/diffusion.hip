@@ -122,9 +122,10 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
     if (want_flux) for (int d = 0; d < 3; ++d) tflux[d]->setVal(0.0);
     MultiFab cdata;
     TensorCF cf{&cdata, crse ? crse->cgeom : nullptr, crse ? crse->ratio : 2};
-    if (theta != 1.0 && !want_flux && visc_old_term) {
-        // (1 - theta) dt div tau(U^n) from viscous terms the caller has evaluated already (no fluxes wanted)
-        mf_lincomb(Rhs, (1.0 - theta) * dt, *visc_old_term, 0.0, *visc_old_term, 0, 3, 0);
+    // (1 - theta) dt div tau(U^n) from viscous terms the caller has evaluated already (no fluxes wanted): formed inside the pass below
+    // (the expression of mf_lincomb(Rhs, (1 - theta) dt, visc, 0.0, visc), then Rhs += rho u*: the same doubles, one pass less)
+    const bool from_visc = theta != 1.0 && !want_flux && visc_old_term;
+    if (from_visc) {
     } else if (theta != 1.0) {
         IAMRX_ASSERT(U_old && U_old->ngrow >= 1);
         MultiFab Soln0(layout, cell_type(), 3, 1);
@@ -135,13 +136,19 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
     } else Rhs.setVal(0.0);
     {
         const FabD *nt = U_new.d_tab, *ot = U_old ? U_old->d_tab : nullptr, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
+        const FabD* vt = from_visc ? visc_old_term->d_tab : nullptr;
+        const double va = (1.0 - theta) * dt;
         const bool mom = rho_flag == 3;                          // rho_flag 3 (NavierStokes.cpp:1016): the OLD density (Diffusion.cpp:819)
         IAMRX_ASSERT(!mom || ot);
         for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double r = mom ? ot[f](i, j, k, rho_comp) : ht[f](i, j, k, 0);
             for (int n = 0; n < 3; ++n) {
-                nt[f](i, j, k, n) *= r;                          // Diffusion.cpp:825: the state holds rho u* from here on
-                rt[f](i, j, k, n) += nt[f](i, j, k, n);
+                const double un = nt[f](i, j, k, n) * r;
+                nt[f](i, j, k, n) = un;                          // Diffusion.cpp:825: the state holds rho u* from here on
+                double rr;
+                if (vt) { const double v = vt[f](i, j, k, n); rr = va * v + 0.0 * v; }
+                else rr = rt[f](i, j, k, n);
+                rt[f](i, j, k, n) = rr + un;
             }
         });
     }
@@ -153,17 +160,17 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
     // Diffusion.cpp:866: FillPatch(U_new) -- of the velocity components that hold rho u* by now: neighbours and periodic images carry rho u*,
     // the physical boundary functor and the coarse level their plain velocities (as written upstream).  The caller's fill does that.
     if (fill_new) fill_new(U_new);
-    MultiFab Soln(layout, cell_type(), 3, 1);
-    MultiFab::Copy(Soln, U_new, Xvel, 0, 3, 1);                  // initial guess + level BC
-    MultiFab acoef(layout, cell_type(), 1, 0);
-    if (rho_flag == 3) MultiFab::Copy(acoef, U_new, rho_comp, 0, 1, 0);   // alpha = rho_new (Diffusion.cpp:893)
-    else MultiFab::Copy(acoef, rho_half, 0, 0, 1, 0);            // computeAlpha: alpha = 1 * rho_half (rho_flag 1)
+    // Soln (initial guess + level BC = U_new with its ghost cells, Diffusion.cpp:866-870; copied back at :928) is the velocity components
+    // of U_new themselves, alpha = rho_new (rho_flag 3, :893) or rho_half (computeAlpha, rho_flag 1) the arrays that hold them: no copies
+    MultiFab Soln, acoef;
+    Soln.view_of(U_new, Xvel, 3);
+    if (rho_flag == 3) acoef.view_of(U_new, rho_comp, 1);
+    else acoef.view_of(rho_half, 0, 1);
     MGOpts vo = o;
     vo.maxorder = 2;
     if (crse) { cdata.define(crse->crse_new->layout, cell_type(), 3, 0); MultiFab::Copy(cdata, *crse->crse_new, Xvel, 0, 3, 0); }      // Diffusion.cpp:876-887
     fx.fac = theta; fx.add = true;                               // computeExtensiveFluxes(..., b/dt) added to the old-time fluxes (:941-945)
     MGStats st = tensor_solve(g, Soln, Rhs, 1.0, theta * dt, &acoef, eta_np1, bc_visc, 3, visc_tol, tol_abs, vo, crse ? &cf : nullptr, want_flux ? &fx : nullptr);
-    MultiFab::Copy(U_new, Soln, 0, Xvel, 3, 1);                  // Diffusion.cpp:928
     return st;
 }
 

@@ -193,6 +193,9 @@ public:
     // cells): the library never frees or moves them (amrex::MultiFab alias over The_Arena memory)
     void alias(LayoutP l, IndexType t, int nc, int ng, double* const* fab_ptrs);
     bool is_alias = false;
+    // components [comp, comp + nc) of src as a MultiFab of their own (same boxes, same ghost width, the same memory): lets an operator
+    // that works on whole MultiFabs solve in place on part of a state array
+    void view_of(const MultiFab& src, int comp, int nc);
     void clear();
     bool defined() const { return base != nullptr || (layout && layout->nlocal() == 0); }
     int nlocal() const { return layout->nlocal(); }

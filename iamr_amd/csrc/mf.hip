@@ -354,6 +354,14 @@ void MultiFab::alias(LayoutP l, IndexType t, int nc, int ng, double* const* fab_
     d_tab = d;
 }
 
+void MultiFab::view_of(const MultiFab& src, int comp, int nc)
+{
+    IAMRX_ASSERT(src.defined() && comp >= 0 && nc >= 1 && comp + nc <= src.ncomp);
+    std::vector<double*> ptrs(src.h_tab.size());
+    for (size_t li = 0; li < ptrs.size(); ++li) ptrs[li] = src.h_tab[li].p + src.h_tab[li].cs * comp;
+    alias(src.layout, src.type, nc, src.ngrow, ptrs.data());
+}
+
 void MultiFab::clear() { release(); layout.reset(); }
 
 void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)

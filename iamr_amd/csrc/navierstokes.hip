@@ -422,13 +422,12 @@ void NavierStokes::compute_visc_terms_vel(MultiFab& visc, MultiFab& Sdata)
     if (!is_diffusive_vel()) { visc.setVal(0.0); return; }
     MultiFab stmp(layout, cell_type(), 3, 1);
     fillpatch(stmp, Sdata, Xvel, 3, bc_vel);
-    MultiFab tmp(layout, cell_type(), 3, 0);
     const MultiFab* ep[3] = {&eta[0], &eta[1], &eta[2]};
     MultiFab cdata;
     TensorCF cf{&cdata, level > 0 ? &crse->g : nullptr, ratio};
     if (level > 0) crse_state_at(cdata, state_time(Sdata), Xvel, 3);        // Diffusion.cpp:1725-1736
-    tensor_apply(g, tmp, stmp, 0.0, -1.0, nullptr, ep, bc_visc, 3, level > 0 ? &cf : nullptr);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
-    MultiFab::Copy(visc, tmp, 0, 0, 3, 0);
+    // (the operator writes the cells of visc itself: no temporary without ghost cells and no copy)
+    tensor_apply(g, visc, stmp, 0.0, -1.0, nullptr, ep, bc_visc, 3, level > 0 ? &cf : nullptr);   // a = 0, b = -1 (Diffusion.cpp:1697-1698)
     visc.FillBoundary(g);
     first_order_extrap(visc);
 }
@@ -1035,6 +1034,14 @@ void NavierStokes::velocity_diffusion_update(double dt_)
     if (want_flux) for (int d = 0; d < 3; ++d) tflux[d].define(layout, face_type(d), 3, 0);
     const bool reuse = theta != 1.0 && !want_flux && m_visc_old_valid;    // div tau(U^n) of the prediction / advection forcing
     auto refill = [this](MultiFab& U, MultiFab& from) {                   // FillPatch of the velocity: ghost cells only change
+        if (level == 0 && &U == &from) {
+            // single level: FillPatch = the valid data + same-level / periodic images + the physical boundary fill -- in place on the ghost cells
+            // (NavierStokes::fillpatch's three steps without the copy out and back)
+            const int ngv[3] = {1, 1, 1};
+            U.FillBoundary(g, Xvel, 3, ngv);
+            if (any_wall) fill_physbc_cc(g, U, Xvel, 3, bc_vel, ed_vel_lo, ed_vel_hi);
+            return;
+        }
         MultiFab tmp(layout, cell_type(), 3, 1);
         fillpatch(tmp, from, Xvel, 3, bc_vel);
         MultiFab::Copy(U, tmp, 0, Xvel, 3, 1);
@@ -1092,21 +1099,26 @@ void NavierStokes::level_project(double dt_)
             if (i > b.lo[0] && i <= b.hi[0] && j > b.lo[1] && j <= b.hi[1] && k > b.lo[2] && k <= b.hi[2]) pt[f](i, j, k) = use_old ? (double)po[f](i, j, k) : 0.0;
         });
     }
-    mf_mult(Sn, 1.0 / dt_, Xvel, 3, 1);                          // U_new *= 1/dt (:273)
+    // U_new *= 1/dt on the cells and their ghost cells (:273), U_new += Gp/rho_half (:296-300) and scaleVar's sigma = 1/rho_half (restored
+    // implicitly: rho_half is untouched) on the cells: one pass over the grown boxes
+    MultiFab sig(layout, cell_type(), 1, 1);
     {
-        const FabD *nt = Sn.d_tab, *gt = Gp[1 - pnew].d_tab, *ht = rho_half.d_tab;
-        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-            for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) += gt[f](i, j, k, n) / ht[f](i, j, k, 0);   // :296-300
+        const FabD *nt = Sn.d_tab, *gt = Gp[1 - pnew].d_tab, *ht = rho_half.d_tab, *st = sig.d_tab;
+        const BoxD* vb = layout->d_boxes;
+        const double rdt = 1.0 / dt_;
+        for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const BoxD b = vb[f];
+            const bool valid = i >= b.lo[0] && i <= b.hi[0] && j >= b.lo[1] && j <= b.hi[1] && k >= b.lo[2] && k <= b.hi[2];
+            double rh = 1.0;
+            if (valid) { rh = ht[f](i, j, k, 0); st[f](i, j, k, 0) = 1.0 / rh; }
+            for (int n = 0; n < 3; ++n) {
+                double v = nt[f](i, j, k, n) * rdt;
+                if (valid) v += gt[f](i, j, k, n) / rh;
+                nt[f](i, j, k, n) = v;
+            }
         });
     }
     set_outflow_bcs(Pn, rho_half, 0);                            // Projection.cpp:308-325 (LEVEL_PROJ)
-    MultiFab sig(layout, cell_type(), 1, 1);                     // scaleVar: sigma = 1/rho_half (restored implicitly: rho_half untouched)
-    {
-        const FabD *st = sig.d_tab, *ht = rho_half.d_tab;
-        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-            st[f](i, j, k, 0) = 1.0 / ht[f](i, j, k, 0);
-        });
-    }
     set_inflow_ghosts(Sn, 1.0 / dt_);
     const bool want_crse = fine != nullptr, want_fine = level > 0 && iteration == ncycle;
     MultiFab vold;
