@@ -400,7 +400,9 @@ __device__ __forceinline__ D2 ld2(const FabD& f, int i, int j, int k, int n)
 }
 // coarse/fine variants: at least 4 wavefronts per SIMD (<= 128 VGPRs; they need 132 / 117 unconstrained and ran at 3: 204 us per 256^3 pass
 // against 124 us for the variant without coarse/fine faces at 5)
-template <int BMODE, bool CF, bool MAINT>
+// ALLCF: every ghost cell beyond a face of the box is a coarse/fine ghost cell (a refined level that is one box strictly inside the domain):
+// the masks are the constant 1 and are not loaded
+template <int BMODE, bool CF, bool MAINT, bool ALLCF = false>
 __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, const BoxD* __restrict__ boxes,
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at, const FabD* __restrict__ sgt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
@@ -472,12 +474,18 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
         // of the plane, not behind the arithmetic that uses them (they used to be two dependent round trips per plane for every wavefront)
         double mxl = 0.0, mxh = 0.0, myl = 0.0, myh = 0.0, mzl = 0.0, mzh = 0.0;
         if (cf && live) {
+            if constexpr (ALLCF) {
+                mxl = i - b.lo[0] <= 1 ? 1.0 : 0.0; mxh = b.hi[0] - i <= 1 ? 1.0 : 0.0;
+                myl = j - b.lo[1] <= 1 ? 1.0 : 0.0; myh = b.hi[1] - j <= 1 ? 1.0 : 0.0;
+                mzl = k - b.lo[2] <= 1 ? 1.0 : 0.0; mzh = b.hi[2] - k <= 1 ? 1.0 : 0.0;
+            } else {
             if (i - b.lo[0] <= 1) mxl = cfm(b.lo[0] - 1, j, k);
             if (b.hi[0] - i <= 1) mxh = cfm(b.hi[0] + 1, j, k);
             if (j - b.lo[1] <= 1) myl = cfm(i, b.lo[1] - 1, k);
             if (b.hi[1] - j <= 1) myh = cfm(i, b.hi[1] + 1, k);
             if (k - b.lo[2] <= 1) mzl = cfm(i, j, b.lo[2] - 1);
             if (b.hi[2] - k <= 1) mzh = cfm(i, j, b.hi[2] + 1);
+            }
         }
         double sxm = 0.0, sxp = 0.0, sym = 0.0, syp = 0.0;
         if (BMODE == 1) {
@@ -985,7 +993,17 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
 #define IAMRX_GS2(M, C, MT, SG, SC, SS) hipLaunchKernelGGL((k_abec_gsrb2<M, C, MT>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, \
                                    c.a ? c.a->d_tab : nullptr, SG, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, SC, SS, bu, cft, cfc, zero, 0, 0)
             const bool mt = cft && cfc.maintain;
-            if (mode == 1) {
+            // one box strictly inside the domain (no neighbour box, no domain face, no periodic image next to it): all of its ghost cells are
+            // coarse/fine ghost cells and the maintaining colour pass takes the masks as constants.  IAMRX_GSRB2_ALLCF = 0: loads them.
+            bool allcf = mt && l.boxes.size() == 1 && l.nlocal() == 1 && tune("GSRB2_ALLCF", 1) != 0;
+            for (int d = 0; d < 3 && allcf; ++d) allcf = l.boxes[0].lo[d] > g.domain.lo[d] && l.boxes[0].hi[d] < g.domain.hi[d];
+            if (allcf) {
+                if (mode == 1) hipLaunchKernelGGL((k_abec_gsrb2<1, true, true, true>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab,
+                                   c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero, 0, 0);
+                else hipLaunchKernelGGL((k_abec_gsrb2<2, true, true, true>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab,
+                                   c.a ? c.a->d_tab : nullptr, nullptr, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, 0, 1.0, bu, cft, cfc, zero, 0, 0);
+            }
+            else if (mode == 1) {
                 if (mt) IAMRX_GS2(1, true, true, c.sig->d_tab, c.sig_comp, c.sig_scale);
                 else if (cft) IAMRX_GS2(1, true, false, c.sig->d_tab, c.sig_comp, c.sig_scale);
                 else IAMRX_GS2(1, false, false, c.sig->d_tab, c.sig_comp, c.sig_scale);

@@ -161,6 +161,14 @@ static double finish_to_host(int op, int nout, int np, bool global)
     return ctx.h_scratch[0];
 }
 
+void reduce_finish_max(int nout, int np, bool global, double* out)
+{
+    auto& ctx = Context::get();
+    if (np == 0 && !(global && ctx.comm->nranks > 1)) { for (int n = 0; n < nout; ++n) out[n] = 0.0; return; }
+    finish_to_host(1, nout, np, global);
+    for (int n = 0; n < nout; ++n) out[n] = ctx.h_scratch[n];
+}
+
 double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
 {
     global = global && !mf.layout->replicated;

@@ -145,6 +145,52 @@ inline void for_each(const Layout& l, const IndexType& type, int ng, hipStream_t
     hipLaunchKernelGGL((k_for_each<F>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f);
 }
 
+// maxima of NOUT non-negative quantities that a functor forms at every point -- f(i, j, k, fab, m) raises m[0 .. NOUT) -- in one pass
+// over the level and one read-back (no intermediate arrays; out[n] is the maximum over all ranks unless the layout is replicated)
+void reduce_finish_max(int nout, int np, bool global, double* out);      // k_basic.hip: block partials -> out (host)
+template <int NOUT, class F>
+__global__ void __launch_bounds__(256) k_reduce_max_f(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, F f,
+                                                      double* __restrict__ partials, int np)
+{
+    const int fab = blockIdx.y;
+    const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
+    int i, j, k0, k1;
+    double m[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) m[n] = 0.0;
+    if (tile_ijk(t, b, i, j, k0, k1)) for (int k = k0; k <= k1; ++k) f(i, j, k, fab, m);
+    __shared__ double sm[NOUT][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        double v = m[n];
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(v, off, 64); v = o > v ? o : v; }
+        if (lane == 0) sm[n][w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NOUT) {
+        const int n = threadIdx.x;
+        double v = sm[n][0];
+        for (int q = 1; q < 4; ++q) v = sm[n][q] > v ? sm[n][q] : v;
+        partials[(size_t)n * np + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = v;
+    }
+}
+
+template <int NOUT, class F>
+inline void reduce_max_f(const Layout& l, const IndexType& type, int ng, F f, double* out, bool global = true)
+{
+    auto& ctx = Context::get();
+    int np = 0;
+    if (l.nlocal() > 0) {
+        Tiling t = level_tiling(l, type, ng, 8);
+        dim3 g = t.grid();
+        np = (int)(g.x * g.y);
+        ctx.ensure_scratch((size_t)NOUT * np + 16);
+        hipLaunchKernelGGL((k_reduce_max_f<NOUT, F>), g, Tiling::block(), 0, ctx.stream, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f, ctx.d_scratch, np);
+    }
+    reduce_finish_max(NOUT, np, global && !l.replicated, out);
+}
+
 // level-wide loop in two phases, for the BLAS-1 style operations: v = ld(i, j, k, fab, n) for NP planes -- every load issued before the
 // first store (destination and sources may be the same array, so a plain loop orders each load behind the previous store) -- then
 // st(i, j, k, fab, n, v)

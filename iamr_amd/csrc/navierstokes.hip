@@ -514,24 +514,26 @@ double NavierStokes::estTimeStep()
     double estdt = 1.0e+20;
     MultiFab& Sn = S[inew];
     MultiFab& G = Gp[pnew];
-    MultiFab tforces(layout, cell_type(), 3, 0);
+    // max |u_d| and max |(f - Gp)_d / rho| in one pass and one read-back (the forces are not stored)
+    double umax3[3], fmax3[3];
     {
-        const FabD *st = Sn.d_tab, *gt = G.d_tab, *ft = tforces.d_tab;
+        const FabD *st = Sn.d_tab, *gt = G.d_tab;
         const double grav = p.gravity;
-        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        double mx[6];
+        reduce_max_f<6>(*layout, cell_type(), 0, [=] __device__(int i, int j, int k, int f, double (&m)[6]) {
             const double rho = st[f](i, j, k, Density);
             const double rho_inv = 1.0 / rho;
             for (int n = 0; n < 3; ++n) {
                 double fr = (fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0;
                 fr -= gt[f](i, j, k, n);
                 fr *= rho_inv;
-                ft[f](i, j, k, n) = fr;
+                const double u = fabs(st[f](i, j, k, Xvel + n)), a = fabs(fr);
+                m[n] = u > m[n] ? u : m[n];
+                m[3 + n] = a > m[3 + n] ? a : m[3 + n];
             }
-        });
+        }, mx);
+        for (int n = 0; n < 3; ++n) { umax3[n] = mx[n]; fmax3[n] = mx[3 + n]; }
     }
-    double umax3[3], fmax3[3];
-    Sn.norm0_comps(Xvel, 3, 0, umax3);
-    tforces.norm0_comps(0, 3, 0, fmax3);
     for (int d = 0; d < 3; ++d) {
         const double umax = umax3[d], fmax = fmax3[d];
         if (umax > small) estdt = std::min(estdt, g.dx[d] / umax);
@@ -584,10 +586,20 @@ double NavierStokes::predict_velocity(double dt_)
     MultiFab& So = S[1 - inew];
     MultiFab Umf(layout, cell_type(), 3, 3);
     fillpatch(Umf, So, Xvel, 3, bc_vel);
-    floor_small(Umf);
     double cflmax = 0.0;
     double un3[3];
-    Umf.norm0_comps(0, 3, Umf.ngrow, un3);
+    {   // floor_small(Umf) and the max norms of its components (ghost cells included) in one pass
+        const FabD* ut = Umf.d_tab;
+        reduce_max_f<3>(*layout, cell_type(), Umf.ngrow, [=] __device__(int i, int j, int k, int f, double (&m)[3]) {
+            const FabD a = ut[f];
+            for (int n = 0; n < 3; ++n) {
+                double v = a(i, j, k, n);
+                if (fabs(v) <= 1.e-20) { v = 0.0; a(i, j, k, n) = 0.0; }
+                const double av = fabs(v);
+                m[n] = av > m[n] ? av : m[n];
+            }
+        }, un3);
+    }
     for (int n = 0; n < 3; ++n) {
         const double c = dt_ * un3[n] / g.dx[n];
         if (n == 0 || c > cflmax) cflmax = c;
@@ -597,11 +609,10 @@ double NavierStokes::predict_velocity(double dt_)
     if (level > 0) fill_gp(Gp[1 - pnew], 0.5 * (pt_old[0] + pt_old[1]));
     MultiFab visc_s;
     const MultiFab& visc = old_visc_or_zero(visc_s);
-    MultiFab Smf(layout, cell_type(), nscal, 3);
-    fillpatch(Smf, So, Density, nscal, bc_scal);
+    // the density of the forcing: FillPatch of the old density on the cells and one ghost cell = rho_ptime (make_rho_prev_time, advance_setup)
     MultiFab tf(layout, cell_type(), 3, 1);
     {
-        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = Smf.d_tab;
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *gt = Gp[1 - pnew].d_tab, *st = rho_ptime.d_tab;
         const double grav = p.gravity;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = st[f](i, j, k, 0);
@@ -812,8 +823,9 @@ void NavierStokes::advection_all(double dt_)
     const bool mom = p.do_mom_diff != 0;
     const int ns_ = nscal;
     MultiFab Q(layout, cell_type(), nstate, 3);
+    MultiFab Smf(layout, cell_type(), nscal, 3);
     {
-        MultiFab Umf(layout, cell_type(), 3, 3), Smf(layout, cell_type(), nscal, 3);
+        MultiFab Umf(layout, cell_type(), 3, 3);
         fillpatch(Umf, So, Xvel, 3, bc_vel);
         fillpatch(Smf, So, Density, nscal, bc_scal);
         const FabD *qt = Q.d_tab, *ut = Umf.d_tab, *st = Smf.d_tab;
@@ -835,9 +847,9 @@ void NavierStokes::advection_all(double dt_)
     MultiFab tf(layout, cell_type(), nstate, 1), divu;
     divu_half(divu, dt_, 1, true);
     {
-        MultiFab R1(layout, cell_type(), 1, 1);
-        fillpatch(R1, So, Density, 1, bc_scal);              // the 1-ghost density of the forcing (velocity_advection's Smf)
-        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *wt = svisc.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = R1.d_tab, *qt = Q.d_tab;
+        // the density of the forcing (velocity_advection's one-ghost-cell FillPatch of the old density): the first component of Smf holds
+        // the same FillPatch on three ghost cells (unfloored: the floor went into Q)
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *wt = svisc.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = Smf.d_tab, *qt = Q.d_tab;
         const double grav = p.gravity;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = rt[f](i, j, k, 0);
