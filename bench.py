@@ -581,13 +581,13 @@ def main():
 
         # algorithmic bytes per cell: advection of the 5 state components in one launch = 5 x (state 8 + forcing 8 + aofs 8) + mac 24 + divu 8;
         # prediction = velocity 24 + forcing 24 + the three face velocities 24
-        zwg = (n // 16) * (n // 8) * ((n + 63) // 64)          # workgroups of one component (16 x 8 tiles, 64-plane chunks), 192 threads each
-        zgrid = (zwg + 7) // 8 * 8 * 192
-        roofline_god = godunov_roofline("god_z", insitu.get("god_z"), "k_god_z<16, 8, 192, 2, false, false> grid=%d" % (5 * zgrid), 152.0 * cells,
-                                        "k_god_z<16,8> (fused z-marching Godunov advection of the 5 state components: ComputeFluxesOnBoxFromState + "
-                                        "ComputeDivergence / ComputeConvectiveTerm in one launch)")
-        roofline_pred = godunov_roofline("pred_z", insitu.get("pred_z"), "k_pred_z<16, 8, 192, false, false> grid=%d" % zgrid, 72.0 * cells,
-                                         "k_pred_z<16,8> (fused z-marching ExtrapVelToFaces)")
+        zwg = ((n + 13) // 14) ** 2 * ((n + 63) // 64)         # workgroups of one component (14 x 14 cells, 64-plane chunks), 256 threads each
+        zgrid = (zwg + 7) // 8 * 8 * 256
+        roofline_god = godunov_roofline("god_z", insitu.get("god_z"), "k_god_z<14, 14, 256, 2, false, false> grid=%d" % (5 * zgrid), 152.0 * cells,
+                                        "k_god_z<14,14> (fused z-marching Godunov advection of the 5 state components: ComputeFluxesOnBoxFromState + "
+                                        "ComputeDivergence / ComputeConvectiveTerm in one launch; 14 x 14 cells = a grown tile of 16 x 16 = 256 threads)")
+        roofline_pred = godunov_roofline("pred_z", insitu.get("pred_z"), "k_pred_z<14, 14, 256, false, false> grid=%d" % zgrid, 72.0 * cells,
+                                         "k_pred_z<14,14> (fused z-marching ExtrapVelToFaces)")
         ups = upstream_shape_pass(lib, N, g, lay, a.c) if (world == 1 and not a.no_upstream_shape) else None
         out = {
             "metric": "cells-advanced/sec", "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -823,9 +823,18 @@ void NavierStokes::advection_all(double dt_)
     const bool mom = p.do_mom_diff != 0;
     const int ns_ = nscal;
     MultiFab Q(layout, cell_type(), nstate, 3);
-    MultiFab Smf(layout, cell_type(), nscal, 3);
-    {
-        MultiFab Umf(layout, cell_type(), 3, 3);
+    if (level == 0 && !any_wall) {
+        // single level, periodic in every direction: FillPatch = valid data + periodic / neighbour images, and the pointwise map below
+        // commutes with copying -- Q is formed on the cells from the state itself and its ghost cells are filled once (no FillPatch'ed copies)
+        const FabD *qt = Q.d_tab, *st = So.d_tab;
+        for_each(*layout, cell_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+            const double r = st[f](i, j, k, Density);
+            for (int n = 0; n < 3; ++n) qt[f](i, j, k, n) = mom ? st[f](i, j, k, Xvel + n) * r : (double)st[f](i, j, k, Xvel + n);
+            for (int n = 0; n < ns_; ++n) { const double v = st[f](i, j, k, Density + n); qt[f](i, j, k, Density + n) = fabs(v) <= 1.e-20 ? 0.0 : v; }
+        });
+        Q.FillBoundary(g);
+    } else {
+        MultiFab Umf(layout, cell_type(), 3, 3), Smf(layout, cell_type(), nscal, 3);
         fillpatch(Umf, So, Xvel, 3, bc_vel);
         fillpatch(Smf, So, Density, nscal, bc_scal);
         const FabD *qt = Q.d_tab, *ut = Umf.d_tab, *st = Smf.d_tab;
@@ -847,9 +856,8 @@ void NavierStokes::advection_all(double dt_)
     MultiFab tf(layout, cell_type(), nstate, 1), divu;
     divu_half(divu, dt_, 1, true);
     {
-        // the density of the forcing (velocity_advection's one-ghost-cell FillPatch of the old density): the first component of Smf holds
-        // the same FillPatch on three ghost cells (unfloored: the floor went into Q)
-        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *wt = svisc.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = Smf.d_tab, *qt = Q.d_tab;
+        // the density of the forcing (velocity_advection's one-ghost-cell FillPatch of the old density) = rho_ptime (make_rho_prev_time)
+        const FabD *tt = tf.d_tab, *vt = visc.d_tab, *wt = svisc.d_tab, *gt = Gp[1 - pnew].d_tab, *rt = rho_ptime.d_tab, *qt = Q.d_tab;
         const double grav = p.gravity;
         for_each(*layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
             const double rho = rt[f](i, j, k, 0);
