@@ -202,3 +202,41 @@ def test_mac_projection_on_a_refined_level(orc, gpu, case):
             hi = [bhi[e] + (1 if e == d else 0) for e in range(3)]
             uref = umf[d].a[1 + blo[0]:2 + hi[0], 1 + blo[1]:2 + hi[1], 1 + blo[2]:2 + hi[2], 0]
             assert np.abs(u[1:-1, 1:-1, 1:-1, 0] - uref).max() <= 1e-8, (d, np.abs(u[1:-1, 1:-1, 1:-1, 0] - uref).max())
+
+
+@pytest.mark.parametrize("nf,box", [(32, ((8, 8, 8), (23, 23, 23))), (128, ((32, 32, 16), (95, 95, 111)))])
+def test_constant_masks_of_a_box_inside_the_domain(gpu, nf, box):
+    """a refined level that is ONE box strictly inside the domain: the maintaining colour pass takes its coarse/fine masks as constants
+    (k_abec_gsrb2<., true, true, ALLCF>) -- the same doubles as with the masks loaded (GSRB2_ALLCF = 0)"""
+    lib = gpu
+    n, nc = (nf,) * 3, (nf // 2,) * 3
+    g_d, gc_d = lib.Geom.make(n), lib.Geom.make(nc)
+    lay, clay = lib.Layout([box]), lib.Layout.single(nc)
+    x = (np.arange(-1, nf + 1) + 0.5) / nf
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    rho = 1.0 + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.1 * np.cos(4 * np.pi * Z)
+    out = {}
+    for allcf in (0, 1):
+        old = lib.tuning_get("GSRB2_ALLCF", 1)
+        lib.tuning_set("GSRB2_ALLCF", allcf)
+        try:
+            um_d = []
+            for d in range(3):
+                t = lib.face(d)
+                shape = tuple(nf + t[e] + 2 for e in range(3)) + (1,)
+                m = lib.MultiFab(lay, t, 1, 1)
+                m.set_from_global(np.random.default_rng(20 + d).standard_normal(shape), (-1, -1, -1))
+                um_d.append(m)
+            rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1, -1, -1))
+            phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.setval(0.0)
+            cphi_d = lib.MultiFab(clay, lib.CELL, 1, 1)
+            cphi_d.set_from_global(exact(nc[0])[..., None], (-1, -1, -1))
+            st = lib.mlmg_mac_solve_cf(g_d, um_d, rho_d, 0, None, phi_d, 200.0, cphi_d, gc_d, 2, mac_tol=1e-11)
+            assert st.converged
+            out[allcf] = (st.iters, phi_d.to_numpy(0)[0].copy(), [m.to_numpy(0)[0].copy() for m in um_d])
+        finally:
+            lib.tuning_set("GSRB2_ALLCF", old)
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)

@@ -2,8 +2,9 @@
 Godunov_PPM) against the
 multi-pass kernels (k_trace / k_dir / k_aofs, tuning key GODUNOV_Z = 0) through the C-ABI on the same device data: edge states, fluxes, aofs
 and predicted face velocities agree to 1e-13 (FMA contraction may differ between the two instruction streams; both are compared with
-the oracle in tests/test_gpu_godunov.py and tests/test_gpu_walls.py).  Sizes are chosen so that a box holds partial tiles (16 x 8),
-several z-chunks and, in the wall cases, every BC branch; the periodic cases run the BC-free specialisation."""
+the oracle in tests/test_gpu_godunov.py and tests/test_gpu_walls.py).  Sizes are chosen so that a box holds partial tiles,
+several z-chunks and, in the wall cases, every BC branch; the periodic cases run the BC-free specialisation.  Both workgroup shapes of the
+fused kernels run: 14 x 14 cells (the default: a grown tile of 16 x 16 = 256 threads) and 16 x 8 (GODUNOV_ZTX / GODUNOV_PTX = 16)."""
 import os
 import numpy as np
 import pytest
@@ -32,17 +33,19 @@ def smooth(n, ng, seed, typ=(0, 0, 0)):
 
 
 class path:
-    def __init__(self, z):
-        self.z = z
+    def __init__(self, z, tile=14):
+        self.kv = {"GODUNOV_Z": z, "GODUNOV_ZTX": tile, "GODUNOV_PTX": tile}
 
     def __enter__(self):
         from iamr_amd import lib
-        self.old = lib.tuning_get("GODUNOV_Z", 1)
-        lib.tuning_set("GODUNOV_Z", self.z)
+        self.old = {k: lib.tuning_get(k, 14 if k != "GODUNOV_Z" else 1) for k in self.kv}
+        for k, v in self.kv.items():
+            lib.tuning_set(k, v)
 
     def __exit__(self, *a):
         from iamr_amd import lib
-        lib.tuning_set("GODUNOV_Z", self.old)
+        for k, v in self.old.items():
+            lib.tuning_set(k, v)
 
 
 def close(a, b, tag):
@@ -50,6 +53,7 @@ def close(a, b, tag):
     assert err <= 1e-13 * max(1.0, float(np.abs(b).max())), (tag, err)
 
 
+@pytest.mark.parametrize("tile", [14, 16], ids=["14x14", "16x8"])
 @pytest.mark.parametrize("scheme", [0, 1], ids=["plm", "ppm"])
 @pytest.mark.parametrize("n,boxes,periodic,fit", [
     ((48, 40, 72), None, (1, 1, 1), 0),
@@ -57,7 +61,7 @@ def close(a, b, tag):
     ((40, 24, 48), None, (0, 1, 0), 0),
     ((32, 32, 32), 16, (0, 1, 0), 1),
 ])
-def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme):
+def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme, tile):
     lib = gpu
     g = lib.Geom.make(n, periodic=periodic)
     lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
@@ -79,7 +83,7 @@ def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme):
         um[z] = [lib.MultiFab(lay, lib.face(d), 1, 1) for d in range(3)]
         for m in um[z]:
             m.setval(0.0)
-        with path(z):
+        with path(z, tile):
             lib.godunov_extrap_vel_to_faces(g, S, frc, um[z], dt, bc5[:3], fit, scheme=scheme)
     for d in range(3):
         close(um[1][d].gather_valid(n), um[0][d].gather_valid(n), ("umac", d))
@@ -96,7 +100,7 @@ def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme):
         aofs.setval(-7.0)
         edge = [lib.MultiFab(lay, lib.face(d), 5, 0) for d in range(3)]
         flux = [lib.MultiFab(lay, lib.face(d), 5, 0) for d in range(3)]
-        with path(z):
+        with path(z, tile):
             lib.godunov_compute_aofs(g, aofs, 1, S, 5, frc, divu, mac, (0, 0, 0, 1, 0), dt, bc5, 1, fit, edge=edge, flux=flux, scheme=scheme)
         out[z] = (aofs.gather_valid(n), [e.gather_valid(n) for e in edge], [f.gather_valid(n) for f in flux])
     assert np.all(out[1][0][..., 0] == -7.0)                   # acomp offset respected
