@@ -269,7 +269,7 @@ int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, d
     for (int d = 0; d < 3; ++d) c.b[d] = bp[d];
     if (coef == 1) {
         if (!rho || rho->mf.ngrow < 1) throw Error("iamrx_abec_form: coef 1 needs rho with a filled ghost cell");
-        mac_bcoef(bp, rho->mf, rho_comp, scale);
+        if (op != 8 && op != 9) mac_bcoef(bp, rho->mf, rho_comp, scale);
         c.sig = &rho->mf; c.sig_comp = rho_comp; c.sig_scale = scale;
     } else if (coef == 2) {
         for (int d = 0; d < 3; ++d) { bf[d].setVal(bu[d]); c.bu[d] = bu[d]; }
@@ -285,6 +285,15 @@ int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, d
     } else if (op == 6 || op == 7) {
         if (!abec_gsrb_rb_ok(gg, c, phi->mf, 1, &b)) throw Error("iamrx_abec_form: the one-launch red + black sweep does not apply to this level");
         abec_gsrb_rb(gg, c, phi->mf, out->mf, rhs->mf, omega, op == 7, &b, 1);
+    } else if (op == 8 || op == 9) {
+        // the same sweep on a level of several boxes (k_abec_rb_ghost + k_abec_gsrb_rb<.., NBR>): phi and out with two ghost layers, rhs with
+        // one, rho with two (its ghost cells beyond domain walls: the caller's); the ghost fills of the sweep are done here
+        MultiFab& p = phi->mf;
+        if (!abec_gsrb_rb_nbr_ok(gg, c, p, rhs->mf, 1, &b)) throw Error("iamrx_abec_form: the multi-box red + black sweep does not apply to this level / these arrays");
+        if (coef == 1) rho->mf.FillBoundary(gg);
+        rhs->mf.FillBoundary(gg);
+        if (op == 8) p.FillBoundary(gg);
+        abec_gsrb_rb_nbr(gg, c, p, out->mf, rhs->mf, omega, op == 9, &b, 1);
     } else throw Error("iamrx_abec_form: bad op");
     IAMRX_CATCH
 }

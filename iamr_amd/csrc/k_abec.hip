@@ -586,15 +586,61 @@ __device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_
 // as after the ghost fill between the colours), gamma loses dh * b * c1 there, the density beyond the face comes from its (filled) ghost
 // cell, and a black cell at an x-face forms that face's coefficient itself.  Rows / planes outside the box that a tile carries as halo
 // compute on whatever the ghost cells hold; every use of their values is replaced as above.
-struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; };
+// NBR ("neighbours"): the boxes of a level that covers its domain in several boxes (one launch: blockIdx.y = local box; a rank that owns
+// one box of a sharded level).  A face of a box is either a domain wall (the formula above) or OPEN: another box or a periodic image lies
+// behind it.  phi comes with TWO filled ghost layers (one FillBoundary per sweep instead of one per colour) and the small launch
+// k_abec_rb_ghost in front of this kernel has replaced every RED ghost cell next to an open face by its updated value (in place: nobody
+// else reads the old value of a red cell) -- the black update of a cell at an open face needs exactly that value.  Here the rows / planes a
+// tile carries outside its box therefore pass their ghost values through instead of updating them, and the first / last lane of a row loads
+// the ghost column beyond an open x-face a plane ahead: its old black value for the red update, its new red value for the black update.
+// rhs (and the a-term) come with one filled ghost layer, the density with two (k_abec_rb_ghost forms the face coefficients of the ghost cell).
+struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; int dlo[3], dhi[3]; };
 
-template <int BMODE, int NW, bool HASA, bool WALLS = false>
+// one Gauss-Seidel update of the sweep kernels: k_abec_gsrb2's expressions (no coarse-fine terms)
+template <bool SG, bool WALLS>
+__device__ __forceinline__ double rb_update(const RbBC& bc, double dhx, double dhy, double dhz, double omega,
+    double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
+    double bxm, double bxp, double bym, double byp, double bzm, double bzp, int fx, int fy, int fz)
+{
+    const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+    // k_abec_gsrb2 subtracts the wall terms dhx (bxm c_lo + bxp c_hi) + dhy (...) + dhz (...) from gamma here, c = c1 at a domain face the
+    // cell touches and 0 elsewhere: the terms with c = 0 are +-0 for finite coefficients and add nothing -- an index-wrap level keeps
+    // gamma, a cell at a wall (f? = 1: low face, 2: high face) subtracts the terms of its faces, in that order: the same double
+    double g_m_d = gamma;
+    if (WALLS) {
+        // (selections, no branches: fx differs from lane to lane; a cell away from the walls adds 0.0 three times.  The constant-coefficient
+        // form is faster with the reference's expression itself -- 118 against 140 us per 256^3 sweep)
+        if (!SG) {
+            const double c0 = fx == 1 ? bc.c1lo[0] : 0.0, c3 = fx == 2 ? bc.c1hi[0] : 0.0, c1 = fy == 1 ? bc.c1lo[1] : 0.0, c4 = fy == 2 ? bc.c1hi[1] : 0.0;
+            const double c2 = fz == 1 ? bc.c1lo[2] : 0.0, c5 = fz == 2 ? bc.c1hi[2] : 0.0;
+            g_m_d = gamma - (dhx * (bxm * c0 + bxp * c3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * c2 + bzp * c5));
+        } else {
+            double ws = 0.0;
+            ws += fx == 0 ? 0.0 : dhx * ((fx == 1 ? bxm : bxp) * (fx == 1 ? bc.c1lo[0] : bc.c1hi[0]));
+            ws += fy == 0 ? 0.0 : dhy * ((fy == 1 ? bym : byp) * (fy == 1 ? bc.c1lo[1] : bc.c1hi[1]));
+            ws += fz == 0 ? 0.0 : dhz * ((fz == 1 ? bzm : bzp) * (fz == 1 ? bc.c1lo[2] : bc.c1hi[2]));
+            g_m_d = gamma - ws;
+        }
+    }
+    const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
+    const double res = rr - (gamma * p0 - rho);
+    return p0 + omega / g_m_d * res;
+}
+
+template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false>
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
     double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
-    RbBC bc = RbBC())
+    RbBC bc = RbBC(), const BoxD* __restrict__ boxes = nullptr, const FabD* __restrict__ pint = nullptr, const FabD* __restrict__ poutt = nullptr,
+    const FabD* __restrict__ rhst = nullptr, const FabD* __restrict__ At = nullptr, const FabD* __restrict__ St = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass has no global address space: FabD::gp)
     constexpr bool SG = BMODE == 1;
+    if (NBR) {
+        const int fab = (int)blockIdx.y;
+        b = boxes[fab]; pin = pint[fab]; pout = poutt[fab]; rhs = rhst[fab];
+        if (HASA) A = At[fab];
+        if (SG) S = St[fab];
+    }
     __shared__ double RED[3][NW][64];                        // new red values of the planes q - 2, q - 1, q
     __shared__ double YM[SG ? 3 : 1][SG ? NW : 1][64];       // the face coefficients below / above those cells (every face of the grid lies
     __shared__ double YP[SG ? 3 : 1][SG ? NW : 1][64];       // between a red and a black cell: the black update divides nothing but omega / gamma)
@@ -611,10 +657,15 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const int k0 = b.lo[2] + tzc * tz;
     if (k0 > b.hi[2]) return;
     const int kend = min(k0 + tz - 1, b.hi[2]);
-    const bool wall0 = WALLS && !bc.per[0], wall1 = WALLS && !bc.per[1], wall2 = WALLS && !bc.per[2];
+    // walls of this box, per face (NBR: where the box touches a non-periodic side of the domain; else both faces of a non-periodic direction)
+    const bool wxl = WALLS && !bc.per[0] && (!NBR || b.lo[0] == bc.dlo[0]), wxh = WALLS && !bc.per[0] && (!NBR || b.hi[0] == bc.dhi[0]);
+    const bool wyl = WALLS && !bc.per[1] && (!NBR || b.lo[1] == bc.dlo[1]), wyh = WALLS && !bc.per[1] && (!NBR || b.hi[1] == bc.dhi[1]);
+    const bool wzl = WALLS && !bc.per[2] && (!NBR || b.lo[2] == bc.dlo[2]), wzh = WALLS && !bc.per[2] && (!NBR || b.hi[2] == bc.dhi[2]);
+    const bool wall1 = NBR || (WALLS && !bc.per[1]), wall2 = NBR || (WALLS && !bc.per[2]);      // no index wrap in y / z: ghost rows / planes
     auto wj = [&](int j) { if (wall1) return min(max(j, b.lo[1] - 1), b.hi[1] + 1); return j < b.lo[1] ? j + ny : (j > b.hi[1] ? j - ny : j); };
     auto wk = [&](int k) { if (wall2) return min(max(k, b.lo[2] - 1), b.hi[2] + 1); return k < b.lo[2] ? k + nz : (k > b.hi[2] ? k - nz : k); };
     const int jraw = b.lo[1] + ty * (rw - 2) + (r - 1);
+    const bool row_out = NBR && (jraw < b.lo[1] || jraw > b.hi[1]);      // a ghost row: its reds are k_abec_rb_ghost's
     const bool owner = r >= 1 && r <= rw - 2 && jraw <= b.hi[1];       // rows whose black update and output this workgroup owns
     const int j = wj(min(jraw, b.hi[1] + 1)), jm = wj(j - 1), jp = wj(j + 1);
     // rows whose lower / upper neighbour row is not the workgroup's row r - 1 / r + 1 (the halo rows; the row above the box in a partial
@@ -627,16 +678,17 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const int wL = r * wpr + (xw == 0 ? wpr - 1 : xw - 1), wR = r * wpr + (xw == wpr - 1 ? 0 : xw + 1);
     auto parity = [&](int k) { return (b.lo[0] + j + k) & 1; };      // 0: the left cell of the pair is red (ny, nz even: wrap keeps it)
     // walls: the pair / row at a domain face (wave-uniform: wlx, whx, aty*; per lane: the first / last lane of the row)
-    const bool wlx = wall0 && xw == 0, whx = wall0 && xw == wpr - 1;
-    const bool atyl = wall1 && j == b.lo[1], atyh = wall1 && j == b.hi[1];
+    const bool wlx = wxl && xw == 0, whx = wxh && xw == wpr - 1;
+    const bool olx = NBR && !wxl && xw == 0, ohx = NBR && !wxh && xw == wpr - 1;       // open x-faces: the ghost column is loaded
+    const bool atyl = wyl && j == b.lo[1], atyh = wyh && j == b.hi[1];
     auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
     // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
     typedef const __attribute__((address_space(1))) char gbyte;
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
     auto rowoff = [&](const FabD& f, int i, int jj) { return 8u * (unsigned)((i - f.lo[0]) + f.n[0] * (jj - f.lo[1])); };
     auto plane = [&](const FabD& f, int k, int n) { return f.gp() + (long)f.n[0] * f.n[1] * (wk(k) - f.lo[2]) + f.cs * n; };
-    auto planev = [&](const FabD& f, int k, int n) {            // arrays without ghost cells
-        const int kk = wall2 ? min(max(k, b.lo[2]), b.hi[2]) : wk(k);
+    auto planev = [&](const FabD& f, int k, int n) {            // arrays without ghost cells (NBR: with one filled layer)
+        const int kk = (wall2 && !NBR) ? min(max(k, b.lo[2]), b.hi[2]) : wk(k);
         return f.gp() + (long)f.n[0] * f.n[1] * (kk - f.lo[2]) + f.cs * n;
     };
     auto ld1 = [](const FabD::gdouble* pl, unsigned off) -> double { return *(const FabD::gdouble*)((gbyte*)pl + (size_t)off); };
@@ -644,38 +696,15 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const unsigned oP = rowoff(pin, iL, j), oPy = rowoff(pin, iL, ym_g ? jm : jp);
     const unsigned oS = SG ? rowoff(S, iL, j) : 0u, oSy = SG ? rowoff(S, iL, ym_g ? jm : jp) : 0u;
     // (the right-hand side and the a-term have no ghost cells: rows / planes outside the box -- whose results nobody uses -- read the nearest valid one)
-    const int jv = wall1 ? min(max(j, b.lo[1]), b.hi[1]) : j;
+    const int jv = (wall1 && !NBR) ? min(max(j, b.lo[1]), b.hi[1]) : j;
     const unsigned oR = rowoff(rhs, iL, jv), oA = HASA ? rowoff(A, iL, jv) : 0u, oO = rowoff(pout, iL, jv);
     const bool y_g = ym_g || yp_g;
     auto ldp = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(plane(f, k, n), off); };
     auto ldv = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(planev(f, k, n), off); };
-    // one Gauss-Seidel update: k_abec_gsrb2's expressions (no wall / coarse-fine terms on an index-wrap level: g_m_d == gamma)
     auto face = [&](double s0, double s1) { return sig_scale / (0.5 * (s0 + s1)); };      // (the sum commutes: one value per face)
     auto update = [&](double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
                       double bxm, double bxp, double bym, double byp, double bzm, double bzp, int fx = 0, int fy = 0, int fz = 0) {
-        const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
-        // k_abec_gsrb2 subtracts the wall terms dhx (bxm c_lo + bxp c_hi) + dhy (...) + dhz (...) from gamma here, c = c1 at a domain face the
-        // cell touches and 0 elsewhere: the terms with c = 0 are +-0 for finite coefficients and add nothing -- an index-wrap level keeps
-        // gamma, a cell at a wall (f? = 1: low face, 2: high face) subtracts the terms of its faces, in that order: the same double
-        double g_m_d = gamma;
-        if (WALLS) {
-            // (selections, no branches: fx differs from lane to lane; a cell away from the walls adds 0.0 three times.  The constant-coefficient
-            // form is faster with the reference's expression itself -- 118 against 140 us per 256^3 sweep)
-            if (!SG) {
-                const double c0 = fx == 1 ? bc.c1lo[0] : 0.0, c3 = fx == 2 ? bc.c1hi[0] : 0.0, c1 = fy == 1 ? bc.c1lo[1] : 0.0, c4 = fy == 2 ? bc.c1hi[1] : 0.0;
-                const double c2 = fz == 1 ? bc.c1lo[2] : 0.0, c5 = fz == 2 ? bc.c1hi[2] : 0.0;
-                g_m_d = gamma - (dhx * (bxm * c0 + bxp * c3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * c2 + bzp * c5));
-            } else {
-            double ws = 0.0;
-            ws += fx == 0 ? 0.0 : dhx * ((fx == 1 ? bxm : bxp) * (fx == 1 ? bc.c1lo[0] : bc.c1hi[0]));
-            ws += fy == 0 ? 0.0 : dhy * ((fy == 1 ? bym : byp) * (fy == 1 ? bc.c1lo[1] : bc.c1hi[1]));
-            ws += fz == 0 ? 0.0 : dhz * ((fz == 1 ? bzm : bzp) * (fz == 1 ? bc.c1lo[2] : bc.c1hi[2]));
-            g_m_d = gamma - ws;
-            }
-        }
-        const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
-        const double res = rr - (gamma * p0 - rho);
-        return p0 + omega / g_m_d * res;
+        return rb_update<SG, WALLS>(bc, dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
     };
     constexpr bool has_a = HASA;
     const D2 Z2 = {0.0, 0.0};
@@ -699,10 +728,17 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         return y;
     };
     // walls in x (density form): the density beyond the face, loaded by the first / last lane of the row a plane ahead (planes q - 1, q, in flight)
-    const bool xs_on = SG && ((wlx && !hasL) || (whx && !hasR));
-    const unsigned oSx = xs_on ? rowoff(S, (wlx && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
+    const bool xs_on = SG && (((wlx || olx) && !hasL) || ((whx || ohx) && !hasR));
+    const unsigned oSx = xs_on ? rowoff(S, ((wlx || olx) && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
     double xs_m = 0.0, xs_c = 0.0, xsN = 0.0;
     auto xsload = [&](int qq) { return xs_on ? ld1(plane(S, qq, sig_comp), oSx) : 0.0; };
+    // open x-faces: phi of the ghost column (old where it is black, k_abec_rb_ghost's new value where it is red), planes q - 1, q, in flight
+    const bool xp_on = NBR && ((olx && !hasL) || (ohx && !hasR));
+    const unsigned oPx = xp_on ? rowoff(pin, (olx && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
+    double xp_m = 0.0, xp_c = 0.0, xpN = 0.0;
+    auto xpload = [&](int qq) { return xp_on ? ld1(plane(pin, qq, comp), oPx) : 0.0; };
+    // zero start: phi is not read -- but for the ghost rows / planes of an open face, which hold k_abec_rb_ghost's reds (and zeros)
+    auto pload = [&](int kk) { return (!zero || (NBR && (row_out || kk < b.lo[2] || kk > b.hi[2]))) ? ldp(pin, oP, kk, comp) : Z2; };
     double bn_prev = 0.0;
     auto put = [&](int k, int park, double bn, double rn) {          // park 1: the left cell of the pair is the black one
         v2u o;
@@ -712,12 +748,13 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     };
     int q = k0 - 1;
     // (the state an iteration q - 1 would have left)
-    Pc = zero ? Z2 : ldp(pin, oP, q - 1, comp); Pp = zero ? Z2 : ldp(pin, oP, q, comp); PN = zero ? Z2 : ldp(pin, oP, q + 1, comp);
+    Pc = pload(q - 1); Pp = pload(q); PN = pload(q + 1);
     if (SG) { Sc = ldp(S, oS, q - 1, sig_comp); Sp = ldp(S, oS, q, sig_comp); SN = ldp(S, oS, q + 1, sig_comp); }
     Rc = ldv(rhs, oR, q - 1, comp); RN = ldv(rhs, oR, q, comp);
     if (has_a) { Ac = ldv(A, oA, q - 1, 0); AN = ldv(A, oA, q, 0); }
     YN yn, YNN = yload(q, parity(q));
-    if (WALLS) { xs_c = xsload(q - 1); xsN = xsload(q); }
+    if (WALLS || NBR) { xs_c = xsload(q - 1); xsN = xsload(q); }
+    if (NBR) { xp_c = xpload(q - 1); xpN = xpload(q); }
     {   // black cells of the first plane
         const int par = parity(q);
         BPH[0][w][lane] = par ? Pp.l : Pp.r;
@@ -730,23 +767,25 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         constexpr int par = decltype(PARC)::value;
         // ---- the rows in flight enter the rings; loads of the next plane
         // (rb_take: an explicit register move, so that the copy stays HERE and the new load lands in the register just vacated)
-        Pm = Pc; Pc = Pp; if (!zero) { Pp.l = rb_take(PN.l); Pp.r = rb_take(PN.r); }
+        Pm = Pc; Pc = Pp; if (!zero || NBR) { Pp.l = rb_take(PN.l); Pp.r = rb_take(PN.r); }
         if (SG) { Sm = Sc; Sc = Sp; Sp.l = rb_take(SN.l); Sp.r = rb_take(SN.r); }
         Rm = Rc; Rc.l = rb_take(RN.l); Rc.r = rb_take(RN.r);
         if (has_a) { Am = Ac; Ac.l = rb_take(AN.l); Ac.r = rb_take(AN.r); }
         yn = YNN;
         if (y_g) { if (!zero) yn.p = rb_take(YNN.p); if (SG) yn.s = rb_take(YNN.s); }
-        if (WALLS && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
+        if ((WALLS || NBR) && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
+        if (NBR) { xp_m = xp_c; xp_c = xp_on ? rb_take(xpN) : 0.0; }
         // the output of the previous iteration's black update (plane q - 2), BEFORE the loads: the wait for the loads at the top of the
         // next iteration then covers nothing younger than a whole iteration (a store behind them would be waited for as well)
         if (owner && q - 2 >= k0) put(q - 2, par, bn_prev, RNm);
         if (q <= kend) {
-            if (!zero) PN = ldp(pin, oP, q + 2, comp);
+            if (NBR) PN = pload(q + 2); else if (!zero) PN = ldp(pin, oP, q + 2, comp);
             if (SG) SN = ldp(S, oS, q + 2, sig_comp);
             RN = ldv(rhs, oR, q + 1, comp);
             if (has_a) AN = ldv(A, oA, q + 1, 0);
             YNN = yload(q + 1, 1 - par);
-            if (WALLS && SG) xsN = xsload(q + 1);
+            if ((WALLS || NBR) && SG) xsN = xsload(q + 1);
+            if (NBR) xpN = xpload(q + 1);
         }
         // ---- red update of plane q
         const int bq = (q - k0 + 1) & 1;
@@ -763,6 +802,9 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                     nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbs = xs_c;
                     fx = par == 0 ? 1 : 2;
+                } else if (NBR && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
+                    nb = zero ? 0.0 : xp_c;
+                    if (SG) nbs = xs_c;
                 } else {
                 nb = BPH[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
                 if (SG) nbs = BSG[bq][par == 0 ? wL : wR][par == 0 ? 63 : 0];
@@ -776,8 +818,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (WALLS) {
                 if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
                 else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
-                if (wall2 && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
-                else if (wall2 && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+                if (wzl && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
+                else if (wzh && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
             }
             const double pxm = par == 0 ? nb : Pc.l, pxp = par == 0 ? Pc.r : nb;
             const double rr = par ? Rc.r : Rc.l;
@@ -792,6 +834,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             }
             RNa = RNm; RNm = RNc;
             RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c, fx, fy, fz);
+            if (NBR && (row_out || q < b.lo[2] || q > b.hi[2])) RNc = p0;      // a ghost row / plane: already updated (k_abec_rb_ghost)
             if (SG) {
                 YM[slot][w][lane] = bym; YP[slot][w][lane] = byp;
                 if (!hasL) XF[slot][w][0] = bfar_c;
@@ -817,6 +860,9 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                     nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
                     fx = park == 1 ? 1 : 2;
+                } else if (NBR && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
+                    nb = xp_m;
+                    if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
                 } else {
                 nb = RED[slotk][park == 1 ? wL : wR][park == 1 ? 63 : 0];
                 if (SG) nbf = XF[slotk][park == 1 ? wL : wR][park == 1 ? 1 : 0];
@@ -827,8 +873,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (WALLS) {
                 if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
                 else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
-                if (wall2 && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
-                else if (wall2 && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+                if (wzl && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
+                else if (wzh && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
             }
             double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
             if (SG) {
@@ -849,6 +895,59 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     q = kend + 2;
     if (owner && q - 2 >= k0) put(q - 2, parity(q), bn_prev, RNm);
 #endif
+}
+
+// k_abec_rb_ghost: in front of k_abec_gsrb_rb<.., NBR> -- the red update of the RED ghost cells next to the open faces of every box (the
+// cells one layer outside the box whose values the black update of the box's surface cells reads), in place in pin.  Nobody else reads the
+// old value of a red cell (a red update reads the cell itself and black neighbours), and the neighbours of a ghost cell are phi's two filled
+// ghost layers.  The box behind the face computes the same update of the same cell from the same doubles with the same expression
+// (rb_update, faces per rb_face): the value is the one a ghost fill between the two colour passes would have delivered.  A ghost cell that
+// touches a domain wall in another direction applies the wall's ghost formula like the cells inside.  zero: pin counts as identically zero
+// and is not read; the black ghost cells of the open faces are then zeroed here (the sweep kernel reads them).
+// grid: x = 256-cell pieces of a face, y = 6 * local box + 2 * direction + side
+template <int BMODE, bool HASA, bool WALLS>
+__global__ void __launch_bounds__(256) k_abec_rb_ghost(const BoxD* __restrict__ boxes, const FabD* __restrict__ pint, const FabD* __restrict__ rhst,
+    const FabD* __restrict__ At, const FabD* __restrict__ St, double alpha, double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale,
+    BUni bu, int zero, int comp, RbBC bc)
+{
+    constexpr bool SG = BMODE == 1;
+    const int fab = (int)blockIdx.y / 6, face_id = (int)blockIdx.y % 6, d = face_id >> 1, side = face_id & 1;
+    const BoxD b = boxes[fab];
+    if (WALLS && !bc.per[d] && (side == 0 ? b.lo[d] == bc.dlo[d] : b.hi[d] == bc.dhi[d])) return;      // a wall: nothing behind it
+    const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
+    const int n1 = b.len(d1), n2 = b.len(d2);
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n1 * n2) return;
+    int c[3];
+    c[d] = side == 0 ? b.lo[d] - 1 : b.hi[d] + 1;
+    c[d1] = b.lo[d1] + (int)(idx % n1);
+    c[d2] = b.lo[d2] + (int)(idx / n1);
+    const int i = c[0], j = c[1], k = c[2];
+    const FabD pin = pint[fab];
+    if ((i + j + k) & 1) { if (zero) pin(i, j, k, comp) = 0.0; return; }
+    const FabD rhs = rhst[fab];
+    auto P = [&](int ii, int jj, int kk) -> double { return zero ? 0.0 : (double)pin(ii, jj, kk, comp); };
+    auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
+    const double p0 = P(i, j, k);
+    double pxm = P(i - 1, j, k), pxp = P(i + 1, j, k), pym = P(i, j - 1, k), pyp = P(i, j + 1, k), pzm = P(i, j, k - 1), pzp = P(i, j, k + 1);
+    int fx = 0, fy = 0, fz = 0;
+    if (WALLS) {
+        if (!bc.per[0]) { if (i == bc.dlo[0]) { pxm = ghost(p0, pxp, bc.c1lo[0], bc.c2lo[0]); fx = 1; } else if (i == bc.dhi[0]) { pxp = ghost(p0, pxm, bc.c1hi[0], bc.c2hi[0]); fx = 2; } }
+        if (!bc.per[1]) { if (j == bc.dlo[1]) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; } else if (j == bc.dhi[1]) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; } }
+        if (!bc.per[2]) { if (k == bc.dlo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; } else if (k == bc.dhi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; } }
+    }
+    double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
+    if (SG) {
+        const FabD S = St[fab];
+        auto fc = [&](double s0, double s1) { return sig_scale / (0.5 * (s0 + s1)); };
+        const double s0 = S(i, j, k, sig_comp);
+        bxm = fc(s0, S(i - 1, j, k, sig_comp)); bxp = fc(s0, S(i + 1, j, k, sig_comp));
+        bym = fc(S(i, j - 1, k, sig_comp), s0); byp = fc(s0, S(i, j + 1, k, sig_comp));
+        bzm = fc(S(i, j, k - 1, sig_comp), s0); bzp = fc(s0, S(i, j, k + 1, sig_comp));
+    }
+    double aa = 0.0;
+    if (HASA) { const FabD A = At[fab]; aa = alpha * A(i, j, k, 0); }
+    pin(i, j, k, comp) = rb_update<SG, WALLS>(bc, dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rhs(i, j, k, comp), aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
 }
 
 // the ghost formula of one component's boundary conditions as the sweep kernel applies it; false: a condition it does not take
@@ -878,6 +977,7 @@ static bool rb_make_bc(const Geometry& g, const DomainBC& bc, RbBC& r)
 
 // bcs: the level's boundary conditions (nbc sets: one per component, or one for all); null: fully periodic levels only.
 // IAMRX_GSRB_RB_WALLS (1): 0 = index-wrap levels only.
+// (decided from the level's global box list: every rank takes the same path -- ADVICE round 4; a rank without the box launches nothing)
 bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs)
 {
     if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("PERIODIC_WRAP", 1) == 0) return false;
@@ -899,6 +999,36 @@ bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, 
     if (phi.ngrow < 1 || c.b[0]->ncomp != 1) return false;
     if (c.sig) return phi.ncomp == 1 && c.sig->ngrow >= 1 && !(c.a && c.alpha != 0.0);
     return c.b_uniform != 0;
+}
+
+// The sweep on a level of SEVERAL boxes that covers its domain (k_abec_gsrb_rb<.., NBR>: a chopped level, the boxes of a sharded level):
+// what the level must look like -- rows of 128 or 256 cells in every box, no coarse/fine faces (the caller knows), wall conditions the
+// kernel has a ghost formula for.  The arrays: phi (both buffers) with two ghost layers, the density with two, rhs and the a-term with one
+// (abec_gsrb_rb_nbr asserts them).  IAMRX_GSRB_RB_NBR (1): 0 = colour passes with a ghost fill in front of each.
+bool abec_gsrb_rb_nbr_level_ok(const Geometry& g, const Layout& l, int ncomp, bool sig_form, bool has_a, int nbc, const DomainBC* bcs)
+{
+    if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("GSRB_RB_NBR", 1) == 0) return false;
+    if (l.boxes.size() < 2 || l.total_cells() != g.domain.npts()) return false;
+    const int nx = l.boxes[0].len(0);
+    if (nx != 128 && nx != 256) return false;
+    for (const BoxD& b : l.boxes) if (b.len(0) != nx || b.len(1) < 16 || b.len(2) < 16) return false;
+    bool walls = false;
+    for (int d = 0; d < 3; ++d) if (!g.periodic[d]) walls = true;
+    if (walls) {
+        if (!bcs || nbc < 1 || tune("GSRB_RB_WALLS", 1) == 0) return false;
+        for (int n = 0; n < ncomp; ++n) { RbBC r; if (!rb_make_bc(g, bcs[n < nbc ? n : 0], r)) return false; }
+    }
+    if (sig_form) return ncomp == 1 && !has_a;
+    return true;
+}
+
+bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs, int nbc, const DomainBC* bcs)
+{
+    const bool has_a = c.a && c.alpha != 0.0;
+    if (!abec_gsrb_rb_nbr_level_ok(g, *phi.layout, phi.ncomp, c.sig != nullptr, has_a, nbc, bcs)) return false;
+    if (phi.ngrow < 2 || rhs.ngrow < 1 || c.b[0]->ncomp != 1) return false;
+    if (c.sig) return c.sig->ngrow >= 2;
+    return c.b_uniform != 0 && (!has_a || c.a->ngrow >= 1);
 }
 
 // one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
@@ -940,6 +1070,73 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
             else IAMRX_RB(2, false, false, 0, 1.0);
         }
 #undef IAMRX_RB
+    }
+    if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
+}
+
+// the same on a level of several boxes (see k_abec_gsrb_rb<.., NBR>): pin's two ghost layers, rhs's (and the a-term's) one and the density's
+// two are filled by the caller -- neighbour boxes and periodic images; nothing is read beyond a domain wall but the density's first layer.
+// pin's red ghost cells next to open faces are overwritten (k_abec_rb_ghost); zero: pin's valid cells are not read, those ghost cells are
+// written.  pout's ghost cells are not written.
+void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                      const DomainBC* bcs, int nbc)
+{
+    IAMRX_ASSERT(abec_gsrb_rb_nbr_ok(g, c, pin, rhs, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp && pout.ncomp == pin.ncomp);
+    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+    if (pin.nlocal() == 0) return;
+    auto& ctx = Context::get();
+    const Layout& l = *pin.layout;
+    const int nbox = l.nlocal();
+    constexpr int NW = 16;
+    const int wpr = l.max_len[0] / 128, rw = NW / wpr;
+    const int nty = (l.max_len[1] + (rw - 2) - 1) / (rw - 2);
+    // z-chunks: the number of workgroups as close below a whole number of rounds (one 1024-thread workgroup per CU) as the chunk length allows
+    const int slots = (int)tune("GSRB_RB_SLOTS", 256), nz = l.max_len[2];
+    int best_nch = 1;
+    double best_eff = -1.0;
+    for (int nch = 1; nch <= std::max(1, nz / 8); ++nch) {
+        const int tzc = (nz + nch - 1) / nch;
+        if ((nz + tzc - 1) / tzc != nch) continue;
+        const long nwg = (long)nbox * nty * nch;
+        const long rounds = (nwg + slots - 1) / slots;
+        // (every chunk recomputes one plane at each end: the useful fraction of its planes)
+        const double eff = (double)nwg / (double)(rounds * slots) * (double)tzc / (double)(tzc + 2);
+        if (eff > best_eff + 1.e-9) { best_eff = eff; best_nch = nch; }
+    }
+    const int tz = (nz + best_nch - 1) / best_nch, nch = (nz + tz - 1) / tz;
+    const int ntile = nty * nch, xcd_chunk = tune("GSRB_RB_XCD", 1) != 0 ? (ntile + 7) / 8 : 0, nwg = xcd_chunk > 0 ? 8 * xcd_chunk : ntile;
+    const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
+    const bool has_a = c.a && c.alpha != 0.0;
+    const FabD* At = has_a ? c.a->d_tab : nullptr;
+    const FabD* St = c.sig ? c.sig->d_tab : nullptr;
+    const FabD Z = pin.h_tab[0];
+    const BoxD zb = l.lbox(0);
+    const long maxface = (long)std::max(l.max_len[0], l.max_len[1]) * std::max(l.max_len[1], l.max_len[2]);
+    const dim3 ggrid((unsigned)((maxface + 255) / 256), (unsigned)(6 * nbox));
+    const bool rec = pin.ncomp == 1 && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
+    for (int n = 0; n < pin.ncomp; ++n) {
+        BUni bn;
+        for (int d = 0; d < 3; ++d) bn.v[d] = c.bu[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
+        RbBC rbc;
+        for (int d = 0; d < 3; ++d) { rbc.per[d] = 1; rbc.c1lo[d] = rbc.c2lo[d] = rbc.c1hi[d] = rbc.c2hi[d] = 0.0; }
+        if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
+        for (int d = 0; d < 3; ++d) { rbc.dlo[d] = g.domain.lo[d]; rbc.dhi[d] = g.domain.hi[d]; }
+#define IAMRX_RBG(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_rb_ghost<M, HA, WL>), ggrid, dim3(256), 0, ctx.stream, l.d_boxes, pin.d_tab, rhs.d_tab, At, St, \
+                                                       c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, zero ? 1 : 0, n, rbc)
+#define IAMRX_RB(M, HA, WL, SC, SS) IAMRX_RBG(M, HA, WL, SC, SS); \
+        hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, ctx.stream, zb, Z, Z, Z, Z, Z, \
+                           c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc, l.d_boxes, pin.d_tab, pout.d_tab, rhs.d_tab, At, St)
+        if (walls) {
+            if (c.sig) { IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale); }
+            else if (has_a) { IAMRX_RB(2, true, true, 0, 1.0); }
+            else { IAMRX_RB(2, false, true, 0, 1.0); }
+        } else {
+            if (c.sig) { IAMRX_RB(1, false, false, c.sig_comp, c.sig_scale); }
+            else if (has_a) { IAMRX_RB(2, true, false, 0, 1.0); }
+            else { IAMRX_RB(2, false, false, 0, 1.0); }
+        }
+#undef IAMRX_RB
+#undef IAMRX_RBG
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }

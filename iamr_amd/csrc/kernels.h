@@ -98,6 +98,13 @@ bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wra
 bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs = nullptr);
 void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
                   const DomainBC* bcs = nullptr, int nbc = 0);
+// the same sweep on a level of several boxes that covers its domain (a chopped level, the boxes of a sharded level): k_abec_rb_ghost +
+// k_abec_gsrb_rb<.., NBR>, one two-layer ghost fill of phi per sweep in front of it (the caller's).  level_ok: the layout / boundary
+// conditions admit it (the caller then gives phi two ghost layers, rhs and the a-term one, the density two); ok: these arrays do
+bool abec_gsrb_rb_nbr_level_ok(const Geometry& g, const Layout& l, int ncomp, bool sig_form, bool has_a, int nbc, const DomainBC* bcs);
+bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs, int nbc, const DomainBC* bcs);
+void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                      const DomainBC* bcs, int nbc);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,

@@ -164,7 +164,10 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /
  * spanning a periodic domain (no ghost cells read); 2: out = rhs - L phi; 3: out (on the layout coarsened by 2) = restriction of rhs - L phi;
  * 6: out = phi after one red + black sweep in ONE launch (one box spanning the domain, 128 or 256 cells in x, every side periodic, Neumann,
  * reflect-odd or Dirichlet of order <= 3 -- homogeneous, as inside a V-cycle; no ghost cell of phi is read; out != phi, >= 1 ghost cell),
- * 7: the same with phi taken as zero without being read. */
+ * 7: the same with phi taken as zero without being read; 8 / 9: the sweep of 6 / 7 on a level of SEVERAL boxes that covers its domain (a
+ * chopped level; the boxes of a level sharded over GPUs; rows of 128 / 256 cells in every box): phi and out with two ghost layers, rhs
+ * with one, rho with two -- the entry fills them from the neighbour boxes / periodic images (one exchange per sweep instead of one per
+ * colour; rho's ghost cells beyond domain walls stay the caller's), updates the red ghost cells next to box faces in place and sweeps. */
 int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, double scale, const double bu[3], double beta, int op,
                     iamrx_mf phi, iamrx_mf rhs, iamrx_mf out, double omega, const int lobc[3], const int hibc[3], int maxorder);
 int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,

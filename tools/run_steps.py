@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from iamr_amd import lib, ns as N
 lib.init(0)
-n = 256
+n = int(os.environ.get('IAMRX_N', '256'))                             # IAMRX_N=512 IAMRX_MAXGRID=256: the shard proxy (8 boxes of 256^3)
 mg = int(os.environ.get('IAMRX_MAXGRID', str(n)))
 g = lib.Geom.make((n, n, n)); lay = lib.Layout.decompose((n, n, n), mg)     # IAMRX_MAXGRID=128: the 8-box decomposition
 s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
