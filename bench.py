@@ -165,17 +165,17 @@ def cpu_baseline(n, steps, threads=1):
 
 
 def proc_grid(world):
-    """px >= py >= pz with px*py*pz = world, as cubic as possible (2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2)"""
-    best = (world, 1, 1)
-    for pz in range(1, world + 1):
-        if world % pz:
+    """1 x py x pz with py <= pz and py * pz = world, as square as possible (2 -> 1x1x2, 4 -> 1x2x2, 8 -> 1x2x4): the boxes are split in y
+    and z only, so that a row of cells (x, the contiguous direction) is never cut -- the one-launch red + black sweep then wraps a periodic
+    x inside its rows as on a single box (k_abec_gsrb_rb<.., NBR, XO = false>), no ghost columns with one useful double per cache line are
+    exchanged, and a box has 4 faces towards other GPUs instead of 6 (every pair of GPUs of the node has its own xGMI link)"""
+    best = (1, 1, world)
+    for py in range(1, world + 1):
+        if world % py:
             continue
-        for py in range(pz, world // pz + 1):
-            if (world // pz) % py:
-                continue
-            px = world // (pz * py)
-            if px >= py and px - pz < best[0] - best[2]:
-                best = (px, py, pz)
+        pz = world // py
+        if py <= pz and pz - py < best[2] - best[1]:
+            best = (1, py, pz)
     return best
 
 
@@ -392,8 +392,7 @@ def main():
         transport_selftest(lib, rank, world)
 
     n = a.n
-    # one n^3 box per GPU (weak scaling) arranged as compactly as possible: 2x1x1, 2x2x1, 2x2x2 (= config C4's 512^3 at n = 256, every
-    # box then has a face neighbour on every xGMI link it can use) -- SURVEY 8(e)
+    # one n^3 box per GPU (weak scaling), the boxes split in y and z only (proc_grid) -- SURVEY 8(e)
     pgrid = proc_grid(world)
     ntot = tuple(n * pgrid[d] for d in range(3))
     boxes = []

@@ -627,7 +627,7 @@ __device__ __forceinline__ double rb_update(const RbBC& bc, double dhx, double d
     return p0 + omega / g_m_d * res;
 }
 
-template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false>
+template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bool XO = false>
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
     double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
     RbBC bc = RbBC(), const BoxD* __restrict__ boxes = nullptr, const FabD* __restrict__ pint = nullptr, const FabD* __restrict__ poutt = nullptr,
@@ -679,7 +679,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     auto parity = [&](int k) { return (b.lo[0] + j + k) & 1; };      // 0: the left cell of the pair is red (ny, nz even: wrap keeps it)
     // walls: the pair / row at a domain face (wave-uniform: wlx, whx, aty*; per lane: the first / last lane of the row)
     const bool wlx = wxl && xw == 0, whx = wxh && xw == wpr - 1;
-    const bool olx = NBR && !wxl && xw == 0, ohx = NBR && !wxh && xw == wpr - 1;       // open x-faces: the ghost column is loaded
+    // open x-faces (XO: the boxes do not span the domain in x -- else a periodic x wraps inside the row as on a single box): the ghost column is loaded
+    const bool olx = NBR && XO && !wxl && xw == 0, ohx = NBR && XO && !wxh && xw == wpr - 1;
     const bool atyl = wyl && j == b.lo[1], atyh = wyh && j == b.hi[1];
     auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
     // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     double xs_m = 0.0, xs_c = 0.0, xsN = 0.0;
     auto xsload = [&](int qq) { return xs_on ? ld1(plane(S, qq, sig_comp), oSx) : 0.0; };
     // open x-faces: phi of the ghost column (old where it is black, k_abec_rb_ghost's new value where it is red), planes q - 1, q, in flight
-    const bool xp_on = NBR && ((olx && !hasL) || (ohx && !hasR));
+    const bool xp_on = NBR && XO && ((olx && !hasL) || (ohx && !hasR));
     const unsigned oPx = xp_on ? rowoff(pin, (olx && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
     double xp_m = 0.0, xp_c = 0.0, xpN = 0.0;
     auto xpload = [&](int qq) { return xp_on ? ld1(plane(pin, qq, comp), oPx) : 0.0; };
@@ -753,8 +754,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     Rc = ldv(rhs, oR, q - 1, comp); RN = ldv(rhs, oR, q, comp);
     if (has_a) { Ac = ldv(A, oA, q - 1, 0); AN = ldv(A, oA, q, 0); }
     YN yn, YNN = yload(q, parity(q));
-    if (WALLS || NBR) { xs_c = xsload(q - 1); xsN = xsload(q); }
-    if (NBR) { xp_c = xpload(q - 1); xpN = xpload(q); }
+    if (WALLS || (NBR && XO)) { xs_c = xsload(q - 1); xsN = xsload(q); }
+    if (NBR && XO) { xp_c = xpload(q - 1); xpN = xpload(q); }
     {   // black cells of the first plane
         const int par = parity(q);
         BPH[0][w][lane] = par ? Pp.l : Pp.r;
@@ -773,8 +774,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         if (has_a) { Am = Ac; Ac.l = rb_take(AN.l); Ac.r = rb_take(AN.r); }
         yn = YNN;
         if (y_g) { if (!zero) yn.p = rb_take(YNN.p); if (SG) yn.s = rb_take(YNN.s); }
-        if ((WALLS || NBR) && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
-        if (NBR) { xp_m = xp_c; xp_c = xp_on ? rb_take(xpN) : 0.0; }
+        if ((WALLS || (NBR && XO)) && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
+        if (NBR && XO) { xp_m = xp_c; xp_c = xp_on ? rb_take(xpN) : 0.0; }
         // the output of the previous iteration's black update (plane q - 2), BEFORE the loads: the wait for the loads at the top of the
         // next iteration then covers nothing younger than a whole iteration (a store behind them would be waited for as well)
         if (owner && q - 2 >= k0) put(q - 2, par, bn_prev, RNm);
@@ -784,8 +785,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             RN = ldv(rhs, oR, q + 1, comp);
             if (has_a) AN = ldv(A, oA, q + 1, 0);
             YNN = yload(q + 1, 1 - par);
-            if ((WALLS || NBR) && SG) xsN = xsload(q + 1);
-            if (NBR) xpN = xpload(q + 1);
+            if ((WALLS || (NBR && XO)) && SG) xsN = xsload(q + 1);
+            if (NBR && XO) xpN = xpload(q + 1);
         }
         // ---- red update of plane q
         const int bq = (q - k0 + 1) & 1;
@@ -802,7 +803,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                     nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbs = xs_c;
                     fx = par == 0 ? 1 : 2;
-                } else if (NBR && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
+                } else if (NBR && XO && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
                     nb = zero ? 0.0 : xp_c;
                     if (SG) nbs = xs_c;
                 } else {
@@ -860,7 +861,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                     nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
                     fx = park == 1 ? 1 : 2;
-                } else if (NBR && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
+                } else if (NBR && XO && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
                     nb = xp_m;
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
                 } else {
@@ -908,11 +909,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
 template <int BMODE, bool HASA, bool WALLS>
 __global__ void __launch_bounds__(256) k_abec_rb_ghost(const BoxD* __restrict__ boxes, const FabD* __restrict__ pint, const FabD* __restrict__ rhst,
     const FabD* __restrict__ At, const FabD* __restrict__ St, double alpha, double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale,
-    BUni bu, int zero, int comp, RbBC bc)
+    BUni bu, int zero, int comp, RbBC bc, int xo)
 {
     constexpr bool SG = BMODE == 1;
     const int fab = (int)blockIdx.y / 6, face_id = (int)blockIdx.y % 6, d = face_id >> 1, side = face_id & 1;
     const BoxD b = boxes[fab];
+    if (d == 0 && !xo) return;                   // rows that span the domain: a periodic x wraps inside the sweep kernel
     if (WALLS && !bc.per[d] && (side == 0 ? b.lo[d] == bc.dlo[d] : b.hi[d] == bc.dhi[d])) return;      // a wall: nothing behind it
     const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
     const int n1 = b.len(d1), n2 = b.len(d2);
@@ -1111,6 +1113,7 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
     const FabD* St = c.sig ? c.sig->d_tab : nullptr;
     const FabD Z = pin.h_tab[0];
     const BoxD zb = l.lbox(0);
+    const bool xo = l.max_len[0] != g.domain.len(0);         // the boxes are split in x: ghost columns instead of the wrap inside a row
     const long maxface = (long)std::max(l.max_len[0], l.max_len[1]) * std::max(l.max_len[1], l.max_len[2]);
     const dim3 ggrid((unsigned)((maxface + 255) / 256), (unsigned)(6 * nbox));
     const bool rec = pin.ncomp == 1 && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
@@ -1122,10 +1125,10 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
         if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
         for (int d = 0; d < 3; ++d) { rbc.dlo[d] = g.domain.lo[d]; rbc.dhi[d] = g.domain.hi[d]; }
 #define IAMRX_RBG(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_rb_ghost<M, HA, WL>), ggrid, dim3(256), 0, ctx.stream, l.d_boxes, pin.d_tab, rhs.d_tab, At, St, \
-                                                       c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, zero ? 1 : 0, n, rbc)
-#define IAMRX_RB(M, HA, WL, SC, SS) IAMRX_RBG(M, HA, WL, SC, SS); \
-        hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, ctx.stream, zb, Z, Z, Z, Z, Z, \
+                                                       c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, zero ? 1 : 0, n, rbc, xo ? 1 : 0)
+#define IAMRX_RBK(M, HA, WL, XOO, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true, XOO>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, ctx.stream, zb, Z, Z, Z, Z, Z, \
                            c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc, l.d_boxes, pin.d_tab, pout.d_tab, rhs.d_tab, At, St)
+#define IAMRX_RB(M, HA, WL, SC, SS) IAMRX_RBG(M, HA, WL, SC, SS); if (xo) IAMRX_RBK(M, HA, WL, true, SC, SS); else IAMRX_RBK(M, HA, WL, false, SC, SS)
         if (walls) {
             if (c.sig) { IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale); }
             else if (has_a) { IAMRX_RB(2, true, true, 0, 1.0); }
@@ -1136,6 +1139,7 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
             else { IAMRX_RB(2, false, false, 0, 1.0); }
         }
 #undef IAMRX_RB
+#undef IAMRX_RBK
 #undef IAMRX_RBG
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
@@ -1640,13 +1644,13 @@ bool abec_residual_reads_no_ghosts(const Geometry& g, const AbecCoef& c, const M
 {
     if (!abec_resid_wrap(g, *phi.layout) || !abec_resid_restrict_ok(c, phi, rhs) || c.tensor) return false;
     if (restrict_form) return true;
-    return tune("RESID_PAIRS", 1) != 0 && out.ngrow == 0 && phi.layout->coarsenable(2, 1);
+    return tune("RESID_PAIRS", 1) != 0 && phi.layout->coarsenable(2, 1);
 }
 
 bool abec_resid_restrict_ok(const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs)
 {
     if (tune("RESID_RESTRICT", 1) == 0 || tune("ABEC_SIG", 1) == 0) return false;
-    if (phi.ncomp != 1 || c.tensor || c.tensor_eta || (c.a && c.alpha != 0.0) || phi.ngrow < 1 || rhs.ngrow != 0) return false;
+    if (phi.ncomp != 1 || c.tensor || c.tensor_eta || (c.a && c.alpha != 0.0) || phi.ngrow < 1) return false;
     if (c.sig) return c.sig->ngrow >= 1;
     return c.b_uniform && c.b[0]->ncomp == 1;
 }
@@ -1674,7 +1678,7 @@ void abec_resid_restrict(const Geometry& g, const AbecCoef& c, MultiFab& crse, c
 // the fine residual out = rhs - A phi by the same march (k_abec_resid_restrict<., false>): levels whose boxes coarsen by 2
 static bool abec_residual_pairs(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& phi, const MultiFab& rhs, unsigned long long* d_norm)
 {
-    if (tune("RESID_PAIRS", 1) == 0 || !abec_resid_restrict_ok(c, phi, rhs) || out.ngrow != 0) return false;
+    if (tune("RESID_PAIRS", 1) == 0 || !abec_resid_restrict_ok(c, phi, rhs)) return false;
     const Layout& fl = *phi.layout;
     if (!fl.coarsenable(2, 1)) return false;
     LayoutP cl = fl.coarsened(2);

@@ -205,6 +205,9 @@ public:
     void setVal(double v);                              // all comps, incl. ghosts
     // the OWNER's promise that every entry is v and stays v (constant viscosity / diffusivity arrays of a level): consumers that would
     // otherwise scan the array for uniformity (CellMG::prepare: a pass + a host synchronisation per array and solve) take the mark
+    // The mark describes the data: define / alias / view_of / clear drop it, a move takes it along, setVal with another value, a Copy
+    // from an array without the same mark and copy_from_host end it; kernels that write through d_tab are the owner's business.
+    // IAMRX_CHECK_UNIFORM = 1 makes CellMG::prepare verify the promise.
     void mark_uniform(double v) { uniform_marked = true; uniform_value = v; }
     bool uniform_marked = false;
     double uniform_value = 0.0;

@@ -274,12 +274,62 @@ std::shared_ptr<Layout> Layout::coarsened(int ratio) const
     return m_coarse;
 }
 
+// boxes that share full faces and have the same owner, merged (sweeps along x, y, z until nothing changes); the result in a deterministic
+// order: by owner, then z, y, x of the lower corner.  Returns whether anything merged.
+static bool merge_boxes(std::vector<BoxD>& boxes, std::vector<int>& owner)
+{
+    struct OB { BoxD b; int own; };
+    std::vector<OB> v;
+    for (size_t i = 0; i < boxes.size(); ++i) v.push_back({boxes[i], owner[i]});
+    bool merged_any = false, changed = true;
+    while (changed) {
+        changed = false;
+        for (int d = 0; d < 3; ++d) {
+            const int e = (d + 1) % 3, f = (d + 2) % 3;
+            std::sort(v.begin(), v.end(), [&](const OB& a, const OB& b) {
+                if (a.own != b.own) return a.own < b.own;
+                if (a.b.lo[e] != b.b.lo[e]) return a.b.lo[e] < b.b.lo[e];
+                if (a.b.hi[e] != b.b.hi[e]) return a.b.hi[e] < b.b.hi[e];
+                if (a.b.lo[f] != b.b.lo[f]) return a.b.lo[f] < b.b.lo[f];
+                if (a.b.hi[f] != b.b.hi[f]) return a.b.hi[f] < b.b.hi[f];
+                return a.b.lo[d] < b.b.lo[d];
+            });
+            std::vector<OB> w;
+            for (const OB& x : v) {
+                if (!w.empty()) {
+                    OB& y = w.back();
+                    if (y.own == x.own && y.b.lo[e] == x.b.lo[e] && y.b.hi[e] == x.b.hi[e] && y.b.lo[f] == x.b.lo[f] && y.b.hi[f] == x.b.hi[f] &&
+                        y.b.hi[d] + 1 == x.b.lo[d]) { y.b.hi[d] = x.b.hi[d]; changed = true; merged_any = true; continue; }
+                }
+                w.push_back(x);
+            }
+            v.swap(w);
+        }
+    }
+    if (!merged_any) return false;
+    std::sort(v.begin(), v.end(), [](const OB& a, const OB& b) {
+        if (a.own != b.own) return a.own < b.own;
+        if (a.b.lo[2] != b.b.lo[2]) return a.b.lo[2] < b.b.lo[2];
+        if (a.b.lo[1] != b.b.lo[1]) return a.b.lo[1] < b.b.lo[1];
+        return a.b.lo[0] < b.b.lo[0];
+    });
+    boxes.clear(); owner.clear();
+    for (const OB& x : v) { boxes.push_back(x.b); owner.push_back(x.own); }
+    return true;
+}
+
+// Every rank holds the whole level.  IAMRX_MG_AGG_MERGE (1): as few boxes as tile it -- all of them belong to this rank, so boxes that share
+// full faces merge (a level that covers its domain becomes ONE box spanning it: index wrap on periodic domains, wall formulas, the
+// single-workgroup bottom solvers; no ghost fills between the boxes a coarse level would otherwise consist of).  The transfers between the
+// distributed level and this one map every distributed box to the merged box that contains it (gather_plan, scatter_from_replicated).
 std::shared_ptr<Layout> Layout::make_replicated() const
 {
     if (m_repl) return m_repl;
     const int me = Context::get().comm->rank;
+    std::vector<BoxD> bx = boxes;
     std::vector<int> own(boxes.size(), me);
-    m_repl = std::make_shared<Layout>(boxes, own, me);
+    if (tune("MG_AGG_MERGE", 1) != 0) merge_boxes(bx, own);
+    m_repl = std::make_shared<Layout>(bx, own, me);
     m_repl->replicated = true;
     m_repl->replicated_of = id;
     return m_repl;
@@ -296,7 +346,8 @@ MultiFab& MultiFab::operator=(MultiFab&& o) noexcept
         release();
         layout = std::move(o.layout); type = o.type; ncomp = o.ncomp; ngrow = o.ngrow;
         base = o.base; total_doubles = o.total_doubles; h_tab = std::move(o.h_tab); d_tab = o.d_tab; is_alias = o.is_alias;
-        o.base = nullptr; o.d_tab = nullptr; o.total_doubles = 0; o.is_alias = false;
+        uniform_marked = o.uniform_marked; uniform_value = o.uniform_value;       // the mark describes the data: it travels with them
+        o.base = nullptr; o.d_tab = nullptr; o.total_doubles = 0; o.is_alias = false; o.uniform_marked = false;
     }
     return *this;
 }
@@ -328,6 +379,7 @@ void MultiFab::release()
     if (is_alias) { if (d_tab) ctx.free(d_tab); }         // the data belong to the caller, the table to this object
     else if (base) ctx.free(base);
     base = nullptr; d_tab = nullptr; total_doubles = 0; h_tab.clear(); is_alias = false;      // d_tab of an owning MultiFab belongs to the table cache
+    uniform_marked = false;             // (define / alias / view_of / clear / move-assignment all come through here: new data, no promise)
 }
 
 void MultiFab::alias(LayoutP l, IndexType t, int nc, int ng, double* const* fab_ptrs)
@@ -400,6 +452,7 @@ void MultiFab::define(LayoutP l, IndexType t, int nc, int ng)
 void MultiFab::setVal(double v)
 {
     trace_blas_site("setVal", layout ? layout->local_cells() * ncomp : 0);
+    if (uniform_marked && v != uniform_value) uniform_marked = false;
     if (!base) return;
     if (is_alias) { setVal(v, 0, ncomp, ngrow); return; }      // the fabs of an alias are not one allocation
     launch_fill(base, total_doubles, v, Context::get().stream);
@@ -407,6 +460,7 @@ void MultiFab::setVal(double v)
 
 void MultiFab::setVal(double v, int comp, int nc, int ng)
 {
+    if (uniform_marked && v != uniform_value) uniform_marked = false;
     if (!base) return;
     const FabD* tab = d_tab;
     for_each(*layout, type, ng, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -420,6 +474,8 @@ void MultiFab::Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, in
     trace_blas_site("Copy", dst.layout ? dst.layout->local_cells() * nc : 0);
     IAMRX_ASSERT(dst.layout->id == src.layout->id || dst.layout->boxes.size() == src.layout->boxes.size());
     IAMRX_ASSERT(ng <= dst.ngrow && ng <= src.ngrow);
+    // a copy INTO a marked array ends the promise unless the source carries the same one
+    if (dst.uniform_marked && !(src.uniform_marked && src.uniform_value == dst.uniform_value)) dst.uniform_marked = false;
     if (!dst.base) return;
     const FabD* dt = dst.d_tab;
     const FabD* st = src.d_tab;
@@ -437,6 +493,7 @@ void MultiFab::copy_to_host(int li, double* dst) const
 
 void MultiFab::copy_from_host(int li, const double* src)
 {
+    uniform_marked = false;
     auto& ctx = Context::get();
     ctx.sync();
     IAMRX_HIP_CHECK(hipMemcpy(h_tab[li].p, src, (size_t)h_tab[li].cs * ncomp * sizeof(double), hipMemcpyHostToDevice));
@@ -683,6 +740,16 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
 // ------------------------------------------------------------------ agglomeration transfers
 // dist (boxes spread over the ranks) -> repl (same boxes, all of them on every rank): an all-gather of the valid regions,
 // expressed as a CopyPlan so that it runs through execute_plan (pack kernel, one message per peer, unpack kernel).
+// index of the box of `repl` (a replicated layout: all boxes local, possibly merged) that contains box b
+static int containing_box(const Layout& repl, const BoxD& b)
+{
+    for (int m = 0; m < (int)repl.boxes.size(); ++m) {
+        const BoxD& r = repl.boxes[m];
+        if (b.lo[0] >= r.lo[0] && b.hi[0] <= r.hi[0] && b.lo[1] >= r.lo[1] && b.hi[1] <= r.hi[1] && b.lo[2] >= r.lo[2] && b.hi[2] <= r.hi[2]) return m;
+    }
+    throw Error("iamrx: a replicated layout does not contain a box of the level it was made from");
+}
+
 static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
 {
     static std::map<PlanKey, std::unique_ptr<CopyPlan>>& cache = make_plan_cache();
@@ -693,6 +760,7 @@ static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
     if (it != cache.end()) return *it->second;
     auto plan = std::make_unique<CopyPlan>();
     const int me = Context::get().comm->rank, nr = Context::get().comm->nranks;
+    const Layout& repl = *dist.make_replicated();
     std::map<int, CopyPlan::Peer> peers;
     for (int g = 0; g < (int)dist.boxes.size(); ++g) {
         CopyDesc cd;
@@ -700,8 +768,9 @@ static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
         cd.shift[0] = cd.shift[1] = cd.shift[2] = 0;
         cd.buf_off = 0;
         const long np = cd.region.npts();
+        const int rg = containing_box(repl, dist.boxes[g]);         // (nodal / face data: boxes inside one merged box write the points they share twice -- the same values)
         if (dist.owner[g] == me) {
-            cd.src_fab = dist.local_of[g]; cd.dst_fab = g;
+            cd.src_fab = dist.local_of[g]; cd.dst_fab = rg;
             plan->local.push_back(cd);
             plan->max_local_pts = std::max(plan->max_local_pts, np);
             for (int r = 0; r < nr; ++r) {
@@ -716,7 +785,7 @@ static const CopyPlan& gather_plan(const Layout& dist, IndexType t)
         } else {
             auto& pr = peers[dist.owner[g]];
             pr.rank = dist.owner[g];
-            cd.src_fab = -1; cd.dst_fab = g; cd.buf_off = pr.recv_pts;
+            cd.src_fab = -1; cd.dst_fab = rg; cd.buf_off = pr.recv_pts;
             pr.recv_pts += np; pr.max_unpack_pts = std::max(pr.max_unpack_pts, np);
             pr.unpack.push_back(cd);
         }
@@ -757,7 +826,7 @@ void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
             cd.region = grow(convert(l.lbox(li), dist.type.t), ng);
             cd.shift[0] = cd.shift[1] = cd.shift[2] = 0;
             cd.buf_off = 0;
-            cd.src_fab = l.local[li]; cd.dst_fab = li;
+            cd.src_fab = containing_box(*repl.layout, l.lbox(li)); cd.dst_fab = li;
             plan->local.push_back(cd);
             plan->max_local_pts = std::max(plan->max_local_pts, cd.region.npts());
         }
@@ -781,44 +850,9 @@ void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv,
 LayoutP coalesce_layout(const LayoutP& l)
 {
     if (!l || l->replicated || tune("COALESCE", 1) == 0 || l->boxes.size() < 2) return l;
-    struct OB { BoxD b; int own; };
-    std::vector<OB> v;
-    for (size_t i = 0; i < l->boxes.size(); ++i) v.push_back({l->boxes[i], l->owner[i]});
-    bool merged_any = false, changed = true;
-    while (changed) {
-        changed = false;
-        for (int d = 0; d < 3; ++d) {
-            const int e = (d + 1) % 3, f = (d + 2) % 3;
-            std::sort(v.begin(), v.end(), [&](const OB& a, const OB& b) {
-                if (a.own != b.own) return a.own < b.own;
-                if (a.b.lo[e] != b.b.lo[e]) return a.b.lo[e] < b.b.lo[e];
-                if (a.b.hi[e] != b.b.hi[e]) return a.b.hi[e] < b.b.hi[e];
-                if (a.b.lo[f] != b.b.lo[f]) return a.b.lo[f] < b.b.lo[f];
-                if (a.b.hi[f] != b.b.hi[f]) return a.b.hi[f] < b.b.hi[f];
-                return a.b.lo[d] < b.b.lo[d];
-            });
-            std::vector<OB> w;
-            for (const OB& x : v) {
-                if (!w.empty()) {
-                    OB& y = w.back();
-                    if (y.own == x.own && y.b.lo[e] == x.b.lo[e] && y.b.hi[e] == x.b.hi[e] && y.b.lo[f] == x.b.lo[f] && y.b.hi[f] == x.b.hi[f] &&
-                        y.b.hi[d] + 1 == x.b.lo[d]) { y.b.hi[d] = x.b.hi[d]; changed = true; merged_any = true; continue; }
-                }
-                w.push_back(x);
-            }
-            v.swap(w);
-        }
-    }
-    if (!merged_any) return l;
-    // deterministic order on every rank: by owner, then z, y, x of the lower corner
-    std::sort(v.begin(), v.end(), [](const OB& a, const OB& b) {
-        if (a.own != b.own) return a.own < b.own;
-        if (a.b.lo[2] != b.b.lo[2]) return a.b.lo[2] < b.b.lo[2];
-        if (a.b.lo[1] != b.b.lo[1]) return a.b.lo[1] < b.b.lo[1];
-        return a.b.lo[0] < b.b.lo[0];
-    });
-    std::vector<BoxD> nb; std::vector<int> no;
-    for (const OB& x : v) { nb.push_back(x.b); no.push_back(x.own); }
+    std::vector<BoxD> nb = l->boxes;
+    std::vector<int> no = l->owner;
+    if (!merge_boxes(nb, no)) return l;
     return std::make_shared<Layout>(nb, no, Context::get().comm->rank);
 }
 

@@ -56,6 +56,8 @@ CycleTimer& cycle_timer();
 // multi-rank runs: MG levels whose total size is at most this many cells are replicated on every rank (one all-gather per
 // V-cycle instead of a halo exchange per smoothing pass and an all-reduce per Krylov dot product); 0 disables
 long mg_agglomeration_cells();
+bool mg_agglomerate_level(const Layout& coarse);      // mlmg.hip
+
 
 struct MGStats {
     int iters = 0;
@@ -98,6 +100,7 @@ public:
     // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
     void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero = false);
     bool fused_smoother_ok(int l) const;
+    bool nbr_sweep_ok(int l, const MultiFab& sol, const MultiFab& rhs) const;
     void vcycle(MGStats& st);
     MultiFab& res(int l) { return m_lev[l].res; }
     MultiFab& cor(int l) { return m_lev[l].cor; }
@@ -109,6 +112,7 @@ private:
         MultiFab a, b[3];          // owned (coarse levels)
         MultiFab cor, res, rescor;
         MultiFab buf;              // second buffer of the fused (out-of-place) GSRB sweeps
+        bool res_filled = false;   // multi-box sweep kernel: the ghost layer of `res` is current (filled once per V-cycle)
         // agglomeration (multi-rank): from this level down every rank holds the whole level; dist = the distributed coarsening
         // of the level above, through which restriction results are gathered and corrections are picked out
         bool agg = false;
@@ -140,6 +144,11 @@ private:
     bool m_bottom_dev = false;    // the coarsest level is solved by k_abec_bottom (one single-workgroup launch, no host synchronisation)
     double m_dd_rho = 0.0;        // estimated contraction of one red-black sweep of a diagonally dominant operator (prepare())
     int m_dd_sweeps = 0;          // > 0: diagonally dominant operator solved by sweeps of the finest level only (prepare())
+    // the finest level is several boxes covering the domain and takes the one-launch red + black sweep (k_abec_gsrb_rb<.., NBR>): its
+    // correction carries two ghost layers (one exchange per sweep), its residual one, and the level keeps copies of the density with two
+    // filled ghost layers / of the a-term with one (prepare())
+    bool m_nbr = false;
+    MultiFab m_sig2, m_a1;
     bool m_cf = false;
     const MultiFab* m_crse = nullptr;
     Geometry m_cgeom;

@@ -21,6 +21,16 @@ long mg_agglomeration_cells()
     return v;
 }
 
+// A coarse multigrid level is agglomerated -- continued on a layout that holds the whole level on this rank, its boxes merged
+// (Layout::make_replicated) -- when it is small (IAMRX_MG_AGGLOMERATE_CELLS) and either spread over several ranks or, on one rank, made of
+// several boxes (IAMRX_MG_AGG_SINGLE_RANK, 1): below that level no ghost exchange between boxes, one box per level that covers its domain
+bool mg_agglomerate_level(const Layout& c)
+{
+    if (c.replicated || c.total_cells() > mg_agglomeration_cells()) return false;
+    if (Context::get().comm->nranks > 1) return true;
+    return c.boxes.size() > 1 && tune("MG_AGG_SINGLE_RANK", 1) != 0;
+}
+
 CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
     : m_g(g), m_ncomp(ncomp), m_o(o)
 {
@@ -42,10 +52,11 @@ AbecCoef CellMG::coef(int l) const
     AbecCoef c;
     c.alpha = m_alpha; c.beta = m_beta; c.tensor = m_tensor ? 1 : 0;
     if (l == 0) {
-        c.a = m_a0;
+        c.a = (m_nbr && m_a1.defined()) ? &m_a1 : m_a0;
         for (int d = 0; d < 3; ++d) c.b[d] = m_b0[d];
         c.tensor_eta = m_tensor_eta ? 1 : 0;
         c.sig = m_sig; c.sig_comp = m_sig_comp; c.sig_scale = m_sig_scale;
+        if (m_nbr && m_sig) { c.sig = &m_sig2; c.sig_comp = 0; }
         c.b_uniform = m_buni ? 1 : 0;
         for (int d = 0; d < 3; ++d) c.bu[d] = m_bu[d];
     } else {
@@ -81,7 +92,13 @@ void CellMG::prepare()
     if (!m_sig && m_b0[0]->ncomp == 1) {
         m_buni = true;
         for (int d = 0; d < 3 && m_buni; ++d) {
-            if (m_b0[d]->uniform_marked) m_bu[d] = m_b0[d]->uniform_value;      // the owner's promise (MultiFab::mark_uniform): no scan
+            if (m_b0[d]->uniform_marked) {           // the owner's promise (MultiFab::mark_uniform): no scan
+                m_bu[d] = m_b0[d]->uniform_value;
+                if (tune("CHECK_UNIFORM", 0) != 0) {       // debugging aid: the promise is tested
+                    double v = 0.0;
+                    if (!mf_uniform_value(*m_b0[d], &v) || v != m_bu[d]) throw Error("iamrx: an array marked uniform is not (MultiFab::mark_uniform)");
+                }
+            }
             else m_buni = mf_uniform_value(*m_b0[d], &m_bu[d]);
         }
     }
@@ -127,7 +144,7 @@ void CellMG::prepare()
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
-        if (Context::get().comm->nranks > 1 && !c.layout->replicated && c.layout->total_cells() <= mg_agglomeration_cells()) {
+        if (mg_agglomerate_level(*c.layout)) {
             c.agg = true;
             c.dist = c.layout;
             c.layout = c.dist->make_replicated();
@@ -135,12 +152,29 @@ void CellMG::prepare()
         m_lev.push_back(std::move(c));
     }
     const int nl = (int)m_lev.size();
+    // several boxes covering the domain (a chopped level, the boxes of a sharded level): the one-launch sweep with its two-layer exchange
+    {
+        const bool has_a = m_a0 && m_alpha != 0.0;
+        m_nbr = !m_cf && (m_sig || m_buni) && m_lev[0].layout->boxes.size() > 1 &&
+                abec_gsrb_rb_nbr_level_ok(m_lev[0].g, *m_lev[0].layout, m_ncomp, m_sig != nullptr, has_a, (int)m_bcn.size(), m_bcn.data());
+        m_sig2.clear(); m_a1.clear();
+        if (m_nbr && m_sig) {
+            m_sig2.define(m_lev[0].layout, cell_type(), 1, 2);
+            MultiFab::Copy(m_sig2, *m_sig, m_sig_comp, 0, 1, 1);       // (the ghost cells beyond domain walls are the caller's)
+            m_sig2.FillBoundary(m_lev[0].g);
+        }
+        if (m_nbr && has_a) {
+            m_a1.define(m_lev[0].layout, cell_type(), 1, 1);
+            MultiFab::Copy(m_a1, *m_a0, 0, 0, 1, 0);
+            m_a1.FillBoundary(m_lev[0].g);
+        }
+    }
     m_bottom_dev = m_o.device_bottom && m_dd_sweeps == 0 && !m_tensor && !m_o.bottom_smoother_only &&
                    abec_bottom_device_ok(m_lev.back().g, *m_lev.back().layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp, m_cf);
     for (int l = 0; l < nl; ++l) {
         Level& L = m_lev[l];
-        L.cor.define(L.layout, cell_type(), m_ncomp, 1);
-        L.res.define(L.layout, cell_type(), m_ncomp, 0);
+        L.cor.define(L.layout, cell_type(), m_ncomp, (l == 0 && m_nbr) ? 2 : 1);
+        L.res.define(L.layout, cell_type(), m_ncomp, (l == 0 && m_nbr) ? 1 : 0);
         L.rescor.define(L.layout, cell_type(), m_ncomp, 0);
         if (m_cf) {
             // the Dirichlet data sit half a coarse cell (of the AMR level below) behind the face on every MG level
@@ -176,7 +210,8 @@ void CellMG::prepare()
 // smoother acts on the 7-point part)
 void CellMG::applyBC(int l, MultiFab& phi, bool inhomog, const MultiFab* bcval, bool corners)
 {
-    phi.FillBoundary(m_lev[l].g);
+    if (phi.ngrow > 1) { const int one[3] = {1, 1, 1}; phi.FillBoundary(m_lev[l].g, 0, phi.ncomp, one); }    // (the second layer is the sweep kernel's)
+    else phi.FillBoundary(m_lev[l].g);
     // order: domain faces, coarse/fine faces (+ the frozen edge / corner values of the tensor operator), then the edge / corner cells
     // outside the physical domain, which are extrapolated from cells filled by the first two
     if (m_bcn.size() == 1) abec_apply_domain_bc(m_lev[l].g, phi, m_bcn[0], inhomog, bcval);
@@ -271,6 +306,15 @@ bool CellMG::fused_smoother_ok(int l) const
     return true;
 }
 
+// smooth_n runs the multi-box sweep kernel on this level (the finest level of a hierarchy prepared for it, arrays with its ghost widths)
+bool CellMG::nbr_sweep_ok(int l, const MultiFab& sol, const MultiFab& rhs) const
+{
+    if (l != 0 || !m_nbr || m_cf) return false;
+    AbecCoef c = coef(l);
+    c.tensor = 0;
+    return abec_gsrb_rb_nbr_ok(m_lev[l].g, c, sol, rhs, (int)m_bcn.size(), m_bcn.data());
+}
+
 void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero)
 {
     if (nsweeps <= 0) { if (sol_is_zero) sol.setVal(0.0); return; }
@@ -288,6 +332,29 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
             const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
             for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size()); std::swap(a, b); }
+            if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
+            return;
+        }
+        // several boxes covering the domain: the same sweep per box, one two-layer exchange of the correction in front of it (none in
+        // front of a sweep from zero), the ghost layer of the right-hand side once per V-cycle
+        if (nbr_sweep_ok(l, sol, rhs)) {
+            Level& L = m_lev[l];
+            if (!L.buf.defined() || L.buf.ngrow != sol.ngrow) L.buf.define(L.layout, cell_type(), m_ncomp, sol.ngrow);
+            if (!(&rhs == &L.res && L.res_filled)) {
+                const int one[3] = {1, 1, 1};
+                const_cast<MultiFab&>(rhs).FillBoundary(L.g, 0, m_ncomp, one);
+                if (&rhs == &L.res) L.res_filled = true;
+            }
+            MultiFab* a = &sol;
+            MultiFab* b = &L.buf;
+            if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
+            const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
+            for (int i = 0; i < nsweeps; ++i) {
+                const bool z = sol_is_zero && i == 0;
+                if (!z) a->FillBoundary(L.g);
+                abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, z, m_bcn.data(), (int)m_bcn.size());
+                std::swap(a, b);
+            }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
             return;
         }
@@ -401,7 +468,8 @@ void CellMG::bottom_solve(MGStats& st)
     if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
         AbecCoef c = coef(l);
         c.tensor = 0;
-        if (!m_cf && abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data())) {
+        if (!m_cf && (abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data()) ||
+                      nbr_sweep_ok(l, L.cor, L.res))) {
             smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true);      // the first sweep takes the correction as zero: no fill, nothing read
             return;
         }
@@ -438,10 +506,11 @@ void CellMG::bottom_solve(MGStats& st)
 void CellMG::vcycle(MGStats& st)
 {
     const int nl = (int)m_lev.size();
+    m_lev[0].res_filled = false;
     for (int l = 0; l < nl - 1; ++l) {
         Level& L = m_lev[l];
         // zero initial guess of the correction: where the first colour pass reads no ghost cell it also takes the place of the fill
-        const bool z = m_o.nu1 > 0 && zero_first_pass_ok(l, L.cor);
+        const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res));
         if (!z) L.cor.setVal(0.0);
         smooth_n(l, L.cor, L.res, m_o.nu1, true, z);
         const AbecCoef cl = coef(l);

@@ -70,7 +70,7 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
-        if (Context::get().comm->nranks > 1 && !c.layout->replicated && c.layout->total_cells() <= mg_agglomeration_cells()) {
+        if (mg_agglomerate_level(*c.layout)) {
             c.agg = true;
             c.dist = c.layout;
             c.layout = c.dist->make_replicated();
@@ -160,8 +160,11 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
     Level& L = m_lev[l];
     // a correction that starts from zero: on a level the register-resident kernel smooths with index wrap (no ghost nodes are read) the
     // first sweep is told so and reads no x -- the zero fill and a third of the first sweep's traffic; everywhere else x is zeroed here
-    const bool zero_start = x_is_zero && m_o.nodal_smoother == 0 && nodal_fused() && !L.dmask() && periodic_wrap_ok(L.g, *L.layout, 4) &&
-                            nodal_gsr_applies(x, rhs, nullptr) && tune("NODAL_ZERO_START", 1) != 0;
+    // (with index wrap or on ghost-filled boxes, with or without a Dirichlet mask: the ghost nodes of a zero array are zero as well --
+    // images, reflections at walls -- so the fill in front of the first pass goes too; IAMRX_NODAL_ZERO_START = 2: index-wrap levels only)
+    const int zs_mode = (int)tune("NODAL_ZERO_START", 1);
+    const bool zero_start = x_is_zero && m_o.nodal_smoother == 0 && nodal_fused() && zs_mode != 0 && nodal_gsr_applies(x, rhs, L.dmask()) &&
+                            (zs_mode != 2 || (!L.dmask() && periodic_wrap_ok(L.g, *L.layout, 4)));       // (gsr_applies: boxes >= 48 cells -- never the single-workgroup smoother's level)
     if (x_is_zero && !zero_start) x.setVal(0.0);
     // small single-box periodic levels: all sweeps x colours in one single-workgroup launch
     const MultiFab* dmk = L.dmask();
@@ -188,7 +191,7 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
         // z, where one ghost plane is exchanged, every second message disappears).
         const bool par_fill = tune("NODAL_PARITY_FILL", 1) != 0;
         for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
-            if (!wrap) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
+            if (!wrap && !(zero_start && ns == 0)) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
             const double* cs = m_csig ? &m_csig_val : nullptr;
             const bool z = zero_start && ns == 0;
             nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs, z ? 3 : 0);      // even planes: a -> b

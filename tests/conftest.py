@@ -32,6 +32,7 @@ def gpu():
     # single-box run: the suite keeps the callers' boxes as they are, so that ghost exchanges between boxes, partial tiles and the per-box
     # multigrid paths stay covered; tests/test_gpu_coalesce.py covers the merged mode (the library's default).
     lib.tuning_set("COALESCE", float(os.environ.get("IAMRX_TEST_COALESCE", "0")))      # IAMRX_TEST_COALESCE=1: the whole suite on merged boxes
+    lib.tuning_set("CHECK_UNIFORM", 1)        # arrays marked uniform (MultiFab::mark_uniform) are verified wherever a solver takes the mark
     return lib
 
 

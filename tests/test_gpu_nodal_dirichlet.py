@@ -32,13 +32,15 @@ def make_periodic_consistent(a, n, per, node=True):
             a[tuple(sl_hi)] = a[tuple(sl_lo)]
 
 
-def run_both(orc, lib, n, per, lobc, hibc, boxes, owners_cov, seed, fixed_iters=0, rtol=1e-10):
+def run_both(orc, lib, n, per, lobc, hibc, boxes, owners_cov, seed, fixed_iters=0, rtol=1e-10, sigma_const=None):
     from iamr_amd import ns as N
     L = orc.lib()
     L.orc_nodal_solve_cov.restype = None
     g_o = orc.geom(n, periodic=per)
     g_d = lib.Geom.make(n, periodic=per)
     sig, rhs, phi = setup_fields(orc, n, seed)
+    if sigma_const is not None:
+        sig.a[...] = sigma_const
     make_periodic_consistent(rhs.a, n, per)
     make_periodic_consistent(phi.a, n, per)
     lay = lib.Layout(boxes)
@@ -157,3 +159,35 @@ def test_nodal_projection_on_a_refined_level(orc, gpu, case):
         a, lo = vel_d.to_numpy(li)
         ref = vel.a[1 + blo[0]:2 + bhi[0], 1 + blo[1]:2 + bhi[1], 1 + blo[2]:2 + bhi[2], :]
         assert np.abs(a[1:-1, 1:-1, 1:-1, :] - ref).max() <= 1e-9
+
+
+GSR_CASES = {
+    # sizes at which NodalMG selects the register-resident plane-fused pass k_nodal_gsr on the finest level (boxes >= 48 cells in x and y;
+    # VERDICT round 4, weak 1a): index wrap on a periodic box, ghost-filled boxes, walls, an outflow face (masked variant), a patch of a
+    # refined level (masked), constant sigma
+    "wrap 96x64x32": dict(n=(96, 64, 32), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3, boxes=[((0, 0, 0), (95, 63, 31))]),
+    "wrap, constant sigma 64x64x32": dict(n=(64, 64, 32), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3, boxes=[((0, 0, 0), (63, 63, 31))], sigma_const=0.75),
+    "two ghost-filled boxes 128x64x32": dict(n=(128, 64, 32), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3,
+                                             boxes=[((0, 0, 0), (63, 63, 31)), ((64, 0, 0), (127, 63, 31))]),
+    "walls 64x96x16": dict(n=(64, 96, 16), per=(0, 0, 0), lobc=(NEUMANN,) * 3, hibc=(NEUMANN,) * 3, boxes=[((0, 0, 0), (63, 95, 15))]),
+    "outflow (masked) 64x64x32": dict(n=(64, 64, 32), per=(0, 1, 0), lobc=(NEUMANN, PERIODIC, NEUMANN), hibc=(DIRICHLET, PERIODIC, NEUMANN),
+                                      boxes=[((0, 0, 0), (63, 63, 31))]),
+    "refined patch (masked) 64x64x16 in 128x128x32": dict(n=(128, 128, 32), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3,
+                                                          boxes=[((24, 32, 8), (87, 95, 23))], cover=True),
+}
+
+
+@pytest.mark.parametrize("case", list(GSR_CASES))
+def test_register_resident_pass_inside_the_solver_matches_the_oracle(orc, gpu, case):
+    """one and two V-cycles of iamrx_nodal_solve in the oracle's cycle shape (4 Gauss-Seidel sweeps per smooth call, 2 + 2 calls per level)
+    against orc_nodal_solve_cov with the same number of cycles: every variant of k_nodal_gsr under the oracle at a size where it is the
+    kernel that runs.  Tolerance 1e-10 of the iterate's size: the 27-point update is summed in another order than the oracle's
+    element-by-element assembly, 16 sweeps per level and cycle."""
+    lib = gpu
+    c = GSR_CASES[case]
+    assert lib.tuning_get("GSR", 1) != 0 and lib.tuning_get("GSR_MIN", 48) <= 48
+    for iters in (1, 2):
+        st_d, st_o, got, ref = run_both(orc, lib, c["n"], c["per"], c["lobc"], c["hibc"], c["boxes"], bool(c.get("cover")), 23, fixed_iters=iters,
+                                        sigma_const=c.get("sigma_const"))
+        for g, r in zip(got, ref):
+            assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max()), (iters, float(np.abs(g - r).max()))

@@ -123,13 +123,13 @@ def test_tensor_apply_and_solve(orc, gpu):
     assert np.abs(s_d.gather_valid(n) - s_o.valid(n)).max() <= 1e-8 * np.abs(s_o.valid(n)).max()
 
 
-def run_oracle_tg(orc, N_, nsteps, visc, c):
+def run_oracle_tg(orc, N_, nsteps, visc, c, cfl=0.5):
     L = orc.lib()
     n = (N_,) * 3
     g = orc.geom(n)
     p = orc.CNsParams()
     L.orc_ns_default_params(C.byref(p))
-    p.cfl = 0.5; p.visc_coef = visc; p.init_iter = 2
+    p.cfl = cfl; p.visc_coef = visc; p.init_iter = 2
     o = orc.mg_opts()
     s = C.c_void_p(L.orc_ns_create(C.byref(g), C.byref(p), C.byref(o)))
     L.orc_ns_init_taylorgreen(s, C.c_double(1.0), C.c_double(1.0), C.c_double(1.0), C.c_double(c), C.c_double(1.0))
@@ -175,6 +175,38 @@ def test_advance_matches_oracle(orc, gpu, boxes, c):
     div = lib.MultiFab(lay, lib.CELL, 1, 0)
     lib.mac_divergence(g, div, um)
     assert div.norm0() <= 1e-9
+
+
+@pytest.mark.parametrize("boxes", [None, (64, 32, 32)])
+def test_advance_at_config_c1_size_matches_oracle(orc, gpu, boxes):
+    """BASELINE config C1 / the bench's workload at the size the oracle still finishes in seconds: TaylorGreen 64^3 (prob.c = 1; nu = 1e-4,
+    cfl 0.7, init_iter 2: Tutorials/TaylorGreen/inputs.3d.taylorgreen), post_init + 2 steps against orc_ns_step.  At 64 cells per side the
+    step runs the kernels that carry the 256^3 headline and that the 16^3 parity runs never select: the
+    register-resident nodal pass k_nodal_gsr (boxes >= 48 cells in x and y), the pair-marching residual / restriction kernels, multi-tile
+    k_god_z<14,14> / k_pred_z, the fused tensor residual; on four boxes kept as boxes (64 x 32 x 32) the ghost-filled nodal pass and the
+    agglomerated coarse levels.  Same tolerances as the 16^3 test (solver tolerances 1e-12 / 1e-10, sums in another order)."""
+    lib = gpu
+    from iamr_amd import ns as N
+    N_ = 64
+    n = (N_,) * 3
+    nsteps = 2
+    visc = 1e-4
+    S_o, P_o, T_o, dts_o = run_oracle_tg(orc, N_, nsteps, visc, 1.0, cfl=0.7)
+    g = lib.Geom.make(n)
+    lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
+    ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=visc, init_iter=2))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(nsteps)]
+    assert np.allclose(dts, dts_o, rtol=1e-9, atol=0.0)
+    assert abs(ns.time - T_o) <= 1e-12
+    S = ns.data(N.NavierStokes.S_NEW).gather_valid(n)
+    for comp in range(5):
+        scale = max(np.abs(S_o[..., comp]).max(), 1e-3)
+        assert np.abs(S[..., comp] - S_o[..., comp]).max() <= 1e-8 * scale, (comp, float(np.abs(S[..., comp] - S_o[..., comp]).max()))
+    Pd = ns.data(N.NavierStokes.P_NEW).gather_valid(n)[..., 0]
+    Pr = P_o[..., 0]
+    assert np.abs((Pd - Pd.mean()) - (Pr - Pr.mean())).max() <= 1e-6 * max(np.abs(Pr - Pr.mean()).max(), 1e-3)
 
 
 def test_taylor_vortex_second_order(gpu):

@@ -112,3 +112,45 @@ def test_multibox_sweep_with_domain_walls_matches_the_oracle(orc, gpu, layout, c
     n, mg = LAYOUTS[layout]
     per, lobc, hibc = WALL_CASES[case]
     run_case(orc, gpu, n, mg, per, lobc, hibc, coef, 47)
+
+
+def run_steps(lib, n, mg, nsteps, walls=False, **kw):
+    from iamr_amd import ns as NS
+    lay = lib.Layout.single(n) if mg is None else lib.Layout.decompose(n, mg)
+    if walls:       # lid-driven cavity: no-slip walls, the lid (z-hi) moves in x, start from rest with init_dt (tests/test_gpu_ldc.py)
+        g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n), periodic=(0, 0, 0))
+        lid = [0.0] * 9; lid[6] = 1.0
+        ns = NS.NavierStokes(g, lay, NS.ns_params(init_iter=2, cfl=0.7, visc_coef=0.01, phys_lo=[5, 5, 5], phys_hi=[5, 5, 5], wall_vel_hi=lid,
+                                                  init_dt=1e-3, tracer_diff_coef=0.01, **kw))
+        ns.init_rest(1.0)
+    else:
+        g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n))
+        ns = NS.NavierStokes(g, lay, NS.ns_params(init_iter=2, cfl=0.7, visc_coef=1e-3, **kw))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(nsteps)]
+    return ns, dts
+
+
+@pytest.mark.parametrize("walls", [False, True])
+def test_time_steps_on_a_chopped_level_do_not_depend_on_the_sweep_kernel(gpu, walls):
+    """full NavierStokes::advance on 8 boxes kept as boxes (the suite runs with IAMRX_COALESCE = 0): MAC projection and viscous solves with
+    the multi-box sweep kernel (IAMRX_GSRB_RB_NBR = 1, the default) and with the colour passes + a ghost fill in front of each -- the same
+    doubles, so the same states to the bit; the single-box run (index wrap / wall formulas, sums in another order) agrees to round-off"""
+    lib = gpu
+    from iamr_amd import ns as NS
+    n, mg = (256, 32, 32), (128, 16, 16)
+    out = {}
+    for key, nbr, m in (("nbr", 1, mg), ("colour", 0, mg), ("single", 1, None)):
+        lib.tuning_set("GSRB_RB_NBR", nbr)
+        try:
+            ns, dts = run_steps(lib, n, m, 2, walls=walls)
+        finally:
+            lib.tuning_set("GSRB_RB_NBR", 1)
+        out[key] = (dts, ns.data(NS.NavierStokes.S_NEW).gather_valid(n), ns.data(2).gather_valid(n))
+    assert out["nbr"][0] == out["colour"][0]
+    for a, b in zip(out["nbr"][1:], out["colour"][1:]):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+    assert np.allclose(out["nbr"][0], out["single"][0], rtol=1e-12, atol=0.0)
+    for a, b in zip(out["nbr"][1:], out["single"][1:]):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max()), float(np.abs(a - b).max())

@@ -4,9 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from iamr_amd import lib, ns as N
 lib.init(0)
-n = int(os.environ.get('IAMRX_N', '256'))                             # IAMRX_N=512 IAMRX_MAXGRID=256: the shard proxy (8 boxes of 256^3)
-mg = int(os.environ.get('IAMRX_MAXGRID', str(n)))
-g = lib.Geom.make((n, n, n)); lay = lib.Layout.decompose((n, n, n), mg)     # IAMRX_MAXGRID=128: the 8-box decomposition
+n = os.environ.get('IAMRX_N', '256')                                  # IAMRX_N=256,512,1024 IAMRX_MAXGRID=256: the shard proxy (8 boxes of 256^3, 1 x 2 x 4)
+n = tuple(int(v) for v in n.split(',')) if ',' in n else (int(n),) * 3
+mg = os.environ.get('IAMRX_MAXGRID', str(max(n)))
+mg = tuple(int(v) for v in mg.split(',')) if ',' in mg else int(mg)      # IAMRX_MAXGRID=256,128,64: boxes that span x, split in y and z
+g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n)); lay = lib.Layout.decompose(n, mg)     # IAMRX_MAXGRID=128: the 8-box decomposition
 s = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
 s.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
 s.post_init(-1.0)
