@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-PMC_FILE = "round4_pmc.json"
+PMC_FILE = "round5_pmc.json"
 
 
 def parse():
@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--amr-n", type=int, default=256, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
     ap.add_argument("--amr-steps", type=int, default=3)
     ap.add_argument("--ldc-steps", type=int, default=4, help="timed steps of the secondary LidDrivenCavity workload at --n^3 (single GPU; 0: skip)")
+    ap.add_argument("--no-shard-proxy", action="store_true", help="skip the single-GPU proxies of the per-GPU work of an 8-GPU run (8 boxes of --n^3 kept as boxes)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the oracle's smoother loops (the rest of the port is scalar); 0 = the CPUs this process may really use")
     return ap.parse_args()
@@ -184,6 +185,64 @@ def file_blob_sha(path):
     import hashlib
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def shard_proxy_workload(lib, n, steps=2, ldc_steps=2):
+    """What ONE GPU of an 8-GPU weak-scaling run computes, measured on one GPU: the main workload's layout of 8 ranks -- eight n^3 boxes in
+    the bench's own 1 x 2 x 4 arrangement (proc_grid(8)), periodic TaylorGreen -- and config C4's (LidDrivenCavity (2n)^3 as 2 x 2 x 2 boxes
+    of n^3: every box has three wall faces and three faces towards other boxes), both with the boxes KEPT as boxes (IAMRX_COALESCE = 0): every
+    box takes the kernels a rank that owns it would take (ghost-filled nodal passes, the multi-box red + black sweep with its two-layer
+    exchange, coarse multigrid levels agglomerated at the same size as in a multi-rank run), only the exchanges are local copies instead
+    of xGMI messages.  ms_per_box_step = ms_per_step / 8 is the per-GPU compute time of the sharded step; its ratio to the one-box step
+    (periodic: the headline; walls: lid_driven_cavity) is the weak-scaling efficiency the kernels allow before any message is sent."""
+    from iamr_amd import ns as N
+    from iamr_amd.inputs import Inputs
+    from iamr_amd import run as R
+    from iamr_amd import ns as NS
+    out = {}
+    lib.tuning_set("COALESCE", 0)
+    try:
+        pg = proc_grid(8)
+        ntot = tuple(n * pg[d] for d in range(3))
+        g = lib.Geom.make(ntot, prob_hi=tuple(float(pg[d]) for d in range(3)))
+        lay = lib.Layout.decompose(ntot, n)
+        ns = N.NavierStokes(g, lay, N.ns_params(cfl=0.7, visc_coef=1e-4, init_iter=2, init_shrink=1.0), lib.mg_opts())
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+        ns.post_init(-1.0)
+        ns.step()
+        lib.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ns.step()
+        lib.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        sm, sn, sv = ns.stats()
+        out["taylorgreen_8_boxes_1x2x4"] = {"workload": f"TaylorGreen, {ntot[0]}x{ntot[1]}x{ntot[2]} cells in 8 boxes of {n}^3 kept as boxes (the layout of --gpus 8)",
+                                            "ms_per_step": ms, "ms_per_box_step": ms / 8, "cells_per_sec": float(n) ** 3 * 8 / ms * 1e3, "steps": steps,
+                                            "mlmg_iters": [sm.iters, sn.iters, sv.iters], "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
+        del ns
+        if ldc_steps > 0:
+            n2 = 2 * n
+            inp = Inputs([os.path.join(ROOT, "tests", "golden", "regtest.3d.lid_driven_cavity")],
+                         [f"amr.n_cell={n2} {n2} {n2}", f"amr.max_grid_size={n}", f"max_step={ldc_steps + 1}", f"ns.init_dt={0.0140625 * 64 / n2}"])
+            pr = inp.problem()
+            ns, lay, g, pr = R.build(inp, lib, NS, 1, pr)
+            ns.post_init(pr["stop_time"])
+            ns.step()
+            lib.sync()
+            t0 = time.perf_counter()
+            for _ in range(ldc_steps):
+                ns.step()
+            lib.sync()
+            ms = (time.perf_counter() - t0) / ldc_steps * 1e3
+            sm, sn, sv = ns.stats()
+            out["lid_driven_cavity_8_boxes_2x2x2"] = {"workload": f"LidDrivenCavity (regtest.3d.lid_driven_cavity), {n2}^3 cells in 8 boxes of {n}^3 kept as boxes (config C4 at 8 GPUs)",
+                                                      "ms_per_step": ms, "ms_per_box_step": ms / 8, "cells_per_sec": float(n2) ** 3 / ms * 1e3, "steps": ldc_steps,
+                                                      "mlmg_iters": [sm.iters, sn.iters, sv.iters], "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
+            del ns
+    finally:
+        lib.tuning_set("COALESCE", 1)
+    return out
 
 
 def ldc_workload(lib, n, steps):
@@ -440,6 +499,7 @@ def main():
         torch.cuda.synchronize()
 
     mac_ms, nod_ms, visc_ms, mac_it, nod_it, visc_it = [], [], [], [], [], []
+    stalled = [0, 0, 0]           # solves of the timed steps that ended on the round-off-floor exit (converged == 2)
     def nmalloc():
         v = C.c_size_t()
         lib.check(lib.lib().iamrx_alloc_count(C.byref(v)))
@@ -463,6 +523,8 @@ def main():
             sm, sn, sv = ns.stats()
             mac_ms.append(sm.vcycle_ms); nod_ms.append(sn.vcycle_ms); visc_ms.append(sv.vcycle_ms)
             mac_it.append(sm.iters); nod_it.append(sn.iters); visc_it.append(sv.iters)
+            for q, stq in enumerate((sm, sn, sv)):
+                stalled[q] += 1 if stq.converged == 2 else 0
         barrier()
         el_r = time.perf_counter() - t0
         if world > 1:
@@ -599,6 +661,9 @@ def main():
                        "cells": cells_total, "prob_c": a.c},
             "mlmg_vcycle_ms": {"mac_cc": st.median(mac_ms), "nodal": st.median(nod_ms), "tensor_visc": st.median(visc_ms)},
             "mlmg_iters": {"mac_cc": st.median(mac_it), "nodal": st.median(nod_it), "tensor_visc": st.median(visc_it)},
+            # solves of the timed steps that stopped on the round-off floor of their residual (within 10x of the target, < 10 % gained over
+            # three cycles: converged == 2, a warning on stderr) instead of reaching the reference's tolerance -- of nreg * steps solves each
+            "mlmg_stalled_solves": {"mac_cc": stalled[0], "nodal": stalled[1], "tensor_visc": stalled[2], "of_solves_each": nreg * a.steps},
             "mlmg_vcycle_ms_upstream_shape": ups[0] if ups else None,
             "mlmg_iters_upstream_shape": ups[1] if ups else None,
             "ms_per_step_upstream_shape": ups[2] if ups else None,
@@ -617,6 +682,18 @@ def main():
         if world == 1 and not a.no_multibox:
             out["single_gpu_multibox"] = multibox_workload(lib, n)
             out["single_gpu_multibox"]["1x%d^3" % n] = {"ms_per_step": el / a.steps * 1e3, "cells_per_sec": value}
+        traffic_source = ("PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate rocprofv3 runs of tools/collect_pmc.sh over this script on the builder's "
+                          "lease) stored in profiles/%s and keyed by the git blob hashes of the kernel sources: not measured by this run; null when "
+                          "a kernel source differs from the one the counters were collected with" % PMC_FILE)
+        for key in ("roofline", "roofline_abec_sweep", "roofline_godunov_advection", "roofline_godunov_prediction"):
+            if out.get(key):
+                out[key]["traffic_source"] = traffic_source
+        if world == 1 and not a.no_shard_proxy and n <= 256:
+            try:
+                out["shard_proxy"] = shard_proxy_workload(lib, n, ldc_steps=2 if a.ldc_steps > 0 else 0)
+                out["shard_proxy"]["one_box_ms_per_step"] = el / a.steps * 1e3
+            except Exception as e:
+                out["shard_proxy"] = {"error": str(e)[:200]}
         if world == 1 and a.ldc_steps > 0:
             try:
                 out["lid_driven_cavity"] = ldc_workload(lib, n, a.ldc_steps)

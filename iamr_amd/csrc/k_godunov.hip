@@ -101,6 +101,43 @@ __device__ __forceinline__ double slope4v(double qmm, double qm, double qi, doub
     }
     return dsgn * fmin(dlim, fabs(dtemp));
 }
+// ---- limited slopes of a thread row (fused z-marching kernels, no boundary-condition variants).  slope4v(i) evaluates three second-order
+// limited differences: lim2 at the cells i - 1 and i + 1 and the ingredients of lim2 at i.  In a row of 16 lanes that own consecutive cells
+// every lane forms lim2 of ITS cell once and takes its neighbours' through DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: vector moves,
+// no LDS, no barrier); the first and the last column of the row evaluate the one lim2 outside the row themselves.  The slope of the cell to
+// the left (the low-side state of the lane's face) is the left lane's slope.  Same operands and expressions as slope4v: the same doubles.
+__device__ __forceinline__ double row16_lo(double v)         // the value lane - 1 of the 16-lane row holds (lane 0: its own)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_hi(double v)         // ... lane + 1 (lane 15: its own)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x101, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x101, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// slh: slope4v(a2, a1, c0, b1, b2) of the lane's cell, sll: of the cell to its left (garbage in the row's first lane: the low-side state of
+// a face nobody uses); first / last: the lane owns the first / last column of the row that is in use
+__device__ __forceinline__ void slope4_row16(double a2, double a1, double c0, double b1, double b2, bool first, bool last, double& sll, double& slh)
+{
+    const double dlft = c0 - a1, drgt = b1 - c0;
+    const double dcen = 0.5 * (dlft + drgt);
+    const double dsgn = copysign(1.0, dcen);
+    const double dlim = (dlft * drgt >= 0.0) ? 2.0 * fmin(fabs(dlft), fabs(drgt)) : 0.0;
+    const double d2 = dsgn * fmin(dlim, fabs(dcen));                   // lim2(dlft, drgt)
+    // the one limited difference outside the row: cell i - 1 for the first column, cell i + 1 for the last one
+    const double e0 = first ? a2 : c0, e1 = first ? a1 : b1, e2 = first ? c0 : b2;
+    const double de = lim2(e1 - e0, e2 - e1);
+    const double dm = row16_lo(d2), dp = row16_hi(d2);
+    const double dfm = first ? de : dm, dfp = last ? de : dp;
+    const double dtemp = 4.0 / 3.0 * dcen - 1.0 / 6.0 * (dfp + dfm);
+    slh = dsgn * fmin(dlim, fabs(dtemp));
+    sll = row16_lo(slh);
+}
 // q points at the cell, s = stride in the slope direction
 template <class P>
 __device__ __forceinline__ double slope4(P q, long s, bool edlo, bool edhi, int i, int domlo, int domhi)
@@ -1557,8 +1594,12 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
                 xh0 = ppm_trace(qc, 1L, edl0, edh0, ci, dl0, dh0, mx0, dtdx0, false);
                 (void)a3; (void)a2; (void)b1; (void)b2;
             } else {
-            const double sll = slope4v(a3, a2, a1, c0, b1, edl0, edh0, ci - 1, dl0, dh0);
-            const double slh = slope4v(a2, a1, c0, b1, b2, edl0, edh0, ci, dl0, dh0);
+            double sll, slh;
+            if constexpr (!BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
+            else {
+            sll = slope4v(a3, a2, a1, c0, b1, edl0, edh0, ci - 1, dl0, dh0);
+            slh = slope4v(a2, a1, c0, b1, b2, edl0, edh0, ci, dl0, dh0);
+            }
             xh0 = c0 + 0.5 * (-1.0 - mx0 * dtdx0) * slh;
             xl0 = a1 + 0.5 * (1.0 - mx0 * dtdx0) * sll;
             }
@@ -1852,8 +1893,12 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
                     h[c] = ppm_trace(qc, 1L, edlo, edhi, ci, dl0, dh0, vhi, dtdx0, false);
                     (void)a3; (void)a2; (void)b1; (void)b2;
                 } else {
-                const double sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, ci - 1, dl0, dh0);
-                const double slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, ci, dl0, dh0);
+                double sll, slh;
+                if constexpr (!BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
+                else {
+                sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, ci - 1, dl0, dh0);
+                slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, ci, dl0, dh0);
+                }
                 h[c] = c0 + 0.5 * (-1.0 - vhi * dtdx0) * slh;
                 l[c] = a1 + 0.5 * (1.0 - vlo * dtdx0) * sll;
                 }
