@@ -79,6 +79,13 @@ int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity)
     if (enable >= 0) scope_profile_enable(enable != 0, reset != 0);
     IAMRX_CATCH
 }
+int iamrx_exchange_counts(size_t out[4])
+{
+    IAMRX_TRY
+    auto& c = Context::get();
+    out[0] = c.n_exchange[0]; out[1] = c.exchange_doubles[0]; out[2] = c.n_exchange[1]; out[3] = c.exchange_doubles[1];
+    IAMRX_CATCH
+}
 int iamrx_sync_count(size_t* n_stream_sync) { IAMRX_TRY *n_stream_sync = Context::get().n_stream_sync; IAMRX_CATCH }
 int iamrx_alloc_count(size_t* n_device_malloc)
 {

@@ -631,7 +631,7 @@ template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bo
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
     double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
     RbBC bc = RbBC(), const BoxD* __restrict__ boxes = nullptr, const FabD* __restrict__ pint = nullptr, const FabD* __restrict__ poutt = nullptr,
-    const FabD* __restrict__ rhst = nullptr, const FabD* __restrict__ At = nullptr, const FabD* __restrict__ St = nullptr)
+    const FabD* __restrict__ rhst = nullptr, const FabD* __restrict__ At = nullptr, const FabD* __restrict__ St = nullptr, int sel = 0)
 {
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass has no global address space: FabD::gp)
     constexpr bool SG = BMODE == 1;
@@ -657,6 +657,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const int k0 = b.lo[2] + tzc * tz;
     if (k0 > b.hi[2]) return;
     const int kend = min(k0 + tz - 1, b.hi[2]);
+    if (NBR && sel != 0) {
+        // sel 1: only the tiles that read nothing outside the box (no ghost cell of phi, rhs or the coefficients: they can run while the
+        // ghost layers are still being exchanged); sel 2: only the others.  XO: every tile reads the ghost columns.
+        const bool bnd = XO || ty == 0 || b.lo[1] + (ty + 1) * (rw - 2) + 1 > b.hi[1] || tzc == 0 || kend + 2 > b.hi[2];
+        if ((sel == 1) == bnd) return;
+    }
     // walls of this box, per face (NBR: where the box touches a non-periodic side of the domain; else both faces of a non-periodic direction)
     const bool wxl = WALLS && !bc.per[0] && (!NBR || b.lo[0] == bc.dlo[0]), wxh = WALLS && !bc.per[0] && (!NBR || b.hi[0] == bc.dhi[0]);
     const bool wyl = WALLS && !bc.per[1] && (!NBR || b.lo[1] == bc.dlo[1]), wyh = WALLS && !bc.per[1] && (!NBR || b.hi[1] == bc.dhi[1]);
@@ -1076,17 +1082,25 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 
+// the sweep of this level can be issued in two parts -- the tiles that read no ghost cell (sel 1) and the others (sel 2, behind the exchange):
+// rows that span the domain (no ghost columns) and boxes tall enough for tiles in the middle
+bool abec_gsrb_rb_nbr_splits(const Geometry& g, const Layout& l)
+{
+    return l.max_len[0] == g.domain.len(0) && l.max_len[1] >= 48 && l.max_len[2] >= 32;
+}
+
 // the same on a level of several boxes (see k_abec_gsrb_rb<.., NBR>): pin's two ghost layers, rhs's (and the a-term's) one and the density's
 // two are filled by the caller -- neighbour boxes and periodic images; nothing is read beyond a domain wall but the density's first layer.
 // pin's red ghost cells next to open faces are overwritten (k_abec_rb_ghost); zero: pin's valid cells are not read, those ghost cells are
 // written.  pout's ghost cells are not written.
 void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                      const DomainBC* bcs, int nbc)
+                      const DomainBC* bcs, int nbc, int sel, hipStream_t on)
 {
     IAMRX_ASSERT(abec_gsrb_rb_nbr_ok(g, c, pin, rhs, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp && pout.ncomp == pin.ncomp);
     const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     if (pin.nlocal() == 0) return;
     auto& ctx = Context::get();
+    hipStream_t strm = on ? on : ctx.stream;
     const Layout& l = *pin.layout;
     const int nbox = l.nlocal();
     constexpr int NW = 16;
@@ -1116,7 +1130,7 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
     const bool xo = l.max_len[0] != g.domain.len(0);         // the boxes are split in x: ghost columns instead of the wrap inside a row
     const long maxface = (long)std::max(l.max_len[0], l.max_len[1]) * std::max(l.max_len[1], l.max_len[2]);
     const dim3 ggrid((unsigned)((maxface + 255) / 256), (unsigned)(6 * nbox));
-    const bool rec = pin.ncomp == 1 && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
+    const bool rec = sel == 0 && pin.ncomp == 1 && kernel_probe_begin(PROBE_ABEC_GSRB, (long)l.max_len[0] * l.max_len[1] * l.max_len[2]);
     for (int n = 0; n < pin.ncomp; ++n) {
         BUni bn;
         for (int d = 0; d < 3; ++d) bn.v[d] = c.bu[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
@@ -1124,10 +1138,10 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
         for (int d = 0; d < 3; ++d) { rbc.per[d] = 1; rbc.c1lo[d] = rbc.c2lo[d] = rbc.c1hi[d] = rbc.c2hi[d] = 0.0; }
         if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
         for (int d = 0; d < 3; ++d) { rbc.dlo[d] = g.domain.lo[d]; rbc.dhi[d] = g.domain.hi[d]; }
-#define IAMRX_RBG(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_rb_ghost<M, HA, WL>), ggrid, dim3(256), 0, ctx.stream, l.d_boxes, pin.d_tab, rhs.d_tab, At, St, \
+#define IAMRX_RBG(M, HA, WL, SC, SS) if (sel != 1) hipLaunchKernelGGL((k_abec_rb_ghost<M, HA, WL>), ggrid, dim3(256), 0, strm, l.d_boxes, pin.d_tab, rhs.d_tab, At, St, \
                                                        c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, zero ? 1 : 0, n, rbc, xo ? 1 : 0)
-#define IAMRX_RBK(M, HA, WL, XOO, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true, XOO>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, ctx.stream, zb, Z, Z, Z, Z, Z, \
-                           c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc, l.d_boxes, pin.d_tab, pout.d_tab, rhs.d_tab, At, St)
+#define IAMRX_RBK(M, HA, WL, XOO, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true, XOO>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, strm, zb, Z, Z, Z, Z, Z, \
+                           c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc, l.d_boxes, pin.d_tab, pout.d_tab, rhs.d_tab, At, St, sel)
 #define IAMRX_RB(M, HA, WL, SC, SS) IAMRX_RBG(M, HA, WL, SC, SS); if (xo) IAMRX_RBK(M, HA, WL, true, SC, SS); else IAMRX_RBK(M, HA, WL, false, SC, SS)
         if (walls) {
             if (c.sig) { IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale); }

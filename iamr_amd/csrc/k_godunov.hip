@@ -106,6 +106,11 @@ __device__ __forceinline__ double slope4v(double qmm, double qm, double qi, doub
 // every lane forms lim2 of ITS cell once and takes its neighbours' through DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: vector moves,
 // no LDS, no barrier); the first and the last column of the row evaluate the one lim2 outside the row themselves.  The slope of the cell to
 // the left (the low-side state of the lane's face) is the left lane's slope.  Same operands and expressions as slope4v: the same doubles.
+// (measured at 256^3, MI355X: ExtrapVelToFaces 1.02 -> 1.00 ms, ComputeAofs of the velocity 1.845 -> 1.877 ms -- the instructions saved are
+// not what bounds the kernels (two wavefronts per SIMD, four barriers per plane): kept as a build option, off)
+#ifndef IAMRX_GOD_ROW16
+#define IAMRX_GOD_ROW16 0
+#endif
 __device__ __forceinline__ double row16_lo(double v)         // the value lane - 1 of the 16-lane row holds (lane 0: its own)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1595,7 +1600,7 @@ __global__ void __launch_bounds__(NT, WPE) k_god_z(const BoxD* __restrict__ boxe
                 (void)a3; (void)a2; (void)b1; (void)b2;
             } else {
             double sll, slh;
-            if constexpr (!BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
+            if constexpr (IAMRX_GOD_ROW16 && !BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
             else {
             sll = slope4v(a3, a2, a1, c0, b1, edl0, edh0, ci - 1, dl0, dh0);
             slh = slope4v(a2, a1, c0, b1, b2, edl0, edh0, ci, dl0, dh0);
@@ -1894,7 +1899,7 @@ __global__ void __launch_bounds__(NT, 2) k_pred_z(const BoxD* __restrict__ boxes
                     (void)a3; (void)a2; (void)b1; (void)b2;
                 } else {
                 double sll, slh;
-                if constexpr (!BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
+                if constexpr (IAMRX_GOD_ROW16 && !BCS && PW == 16) { (void)a3; slope4_row16(a2, a1, c0, b1, b2, li == 0, ci == txe + 1, sll, slh); }
                 else {
                 sll = slope4v(a3, a2, a1, c0, b1, edlo, edhi, ci - 1, dl0, dh0);
                 slh = slope4v(a2, a1, c0, b1, b2, edlo, edhi, ci, dl0, dh0);

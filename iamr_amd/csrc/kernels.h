@@ -103,8 +103,11 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
 // conditions admit it (the caller then gives phi two ghost layers, rhs and the a-term one, the density two); ok: these arrays do
 bool abec_gsrb_rb_nbr_level_ok(const Geometry& g, const Layout& l, int ncomp, bool sig_form, bool has_a, int nbc, const DomainBC* bcs);
 bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, const MultiFab& rhs, int nbc, const DomainBC* bcs);
+// sel 0: the whole sweep; 1: only the tiles that read no ghost cell (no k_abec_rb_ghost launch); 2: k_abec_rb_ghost + the other tiles;
+// on: the stream (null: the context's).  splits: parts 1 and 2 are both non-empty (and the level has no ghost columns in x)
 void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                      const DomainBC* bcs, int nbc);
+                      const DomainBC* bcs, int nbc, int sel = 0, hipStream_t on = nullptr);
+bool abec_gsrb_rb_nbr_splits(const Geometry& g, const Layout& l);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))
 void abec_gsrb_fused(const Geometry& g, const AbecCoef& c, const MultiFab& phi_in, MultiFab& phi_out, const MultiFab& rhs, double omega,

@@ -64,6 +64,18 @@ struct Context {
     void upload_async(void* dst, const void* src, size_t bytes);
     char* h_ring = nullptr;
     size_t ring_off = 0;
+    // Second stream: halo exchanges that run beside interior work.  fork_side(): everything issued on `side` from
+    // here on sees what `stream` has been given so far; join_side(): `stream` continues after what `side` has been given.  Device blocks
+    // that side-stream work returns to the caching allocator are parked until the join (the cache is ordered by `stream` only).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // peer exchanges issued (execute_plan calls with messages) and doubles sent, by stream: [0] main (in front of the work that needs
+    // them: exposed), [1] side (beside interior work: hidden as far as that work lasts) -- tools/count_comm.py
+    size_t n_exchange[2] = {0, 0}, exchange_doubles[2] = {0, 0};
+    std::vector<void*> parked;
+    void fork_side();
+    void join_side();
+    void free_on(hipStream_t s, void* p) { if (s == stream) free(p); else parked.push_back(p); }
 };
 
 // ------------------------------------------------------------------ tuning registry
@@ -215,7 +227,8 @@ public:
     void norm0_comps(int comp, int nc, int ng, double* out, bool local = false) const;
     void setVal(double v, int comp, int nc, int ng);
     void FillBoundary(const Geometry& g);               // same-level + periodic ghost exchange (all comps)
-    void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr, int kpar = -1);   // ngv: ghost depth per direction (<= ngrow)
+    // ngv: ghost depth per direction (<= ngrow); on: the stream the exchange is issued on (null: the context's; Context::side between fork_side / join_side)
+    void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr, int kpar = -1, hipStream_t on = nullptr);
     // valid + ng ghost cells
     static void Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng);
     // dst = a*x + b*y style helpers live in blas (kernels.h)
@@ -238,7 +251,7 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
 // kpar = 0 / 1: only the z-planes of that parity (global index) are exchanged
 const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv = nullptr, int kpar = -1);
 // add: dst += src instead of dst = src (the regions of one plan must then not overlap in dst)
-void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false);
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false, hipStream_t on = nullptr);
 // multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes
 void gather_to_replicated(MultiFab& repl, const MultiFab& dist);
 void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng);

@@ -32,8 +32,27 @@ void Context::init(int dev)
     device = dev;
     IAMRX_HIP_CHECK(hipSetDevice(dev));
     if (!stream) IAMRX_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!side) {
+        IAMRX_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        IAMRX_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        IAMRX_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     if (!comm) comm = std::make_unique<Comm>();
     ensure_scratch(1 << 16);
+}
+
+void Context::fork_side()
+{
+    IAMRX_HIP_CHECK(hipEventRecord(ev_fork, stream));
+    IAMRX_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+}
+
+void Context::join_side()
+{
+    IAMRX_HIP_CHECK(hipEventRecord(ev_join, side));
+    IAMRX_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
+    for (void* p : parked) free(p);          // whoever takes these blocks next is ordered behind the side stream's work
+    parked.clear();
 }
 
 void Context::ensure_scratch(size_t n)
@@ -701,10 +720,10 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
     return ref;
 }
 
-void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add)
+void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add, hipStream_t on)
 {
     auto& ctx = Context::get();
-    hipStream_t s = ctx.stream;
+    hipStream_t s = on ? on : ctx.stream;
     // remote: pack -> exchange -> unpack
     std::vector<Message> sends, recvs;
     std::vector<double*> bufs;
@@ -724,6 +743,9 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
     if (!plan.local.empty())
         launch_copy_plan(plan.d_local, (int)plan.local.size(), plan.max_local_pts, src.d_tab, dst.d_tab, scomp, dcomp, nc, s, add);
     if (!sends.empty() || !recvs.empty()) {
+        const int cls = s == ctx.stream ? 0 : 1;
+        ++ctx.n_exchange[cls];
+        for (auto& m : sends) ctx.exchange_doubles[cls] += m.count;
         ctx.comm->exchange(sends, recvs, s);
         size_t ri = 0;
         for (auto& p : plan.peers) {
@@ -733,8 +755,8 @@ void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int 
             }
         }
     }
-    // buffers are stream-ordered: safe to return them to the cache (next user is on the same stream)
-    for (double* b : bufs) ctx.free(b);
+    // buffers are stream-ordered: safe to return them to the cache (next user is on the same stream; side stream: parked until the join)
+    for (double* b : bufs) ctx.free_on(s, b);
 }
 
 // ------------------------------------------------------------------ agglomeration transfers
@@ -838,11 +860,11 @@ void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng)
 
 void MultiFab::FillBoundary(const Geometry& g) { FillBoundary(g, 0, ncomp); }
 
-void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv, int kpar)
+void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv, int kpar, hipStream_t on)
 {
     if (ngrow == 0) return;
     const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g, ngv, kpar);
-    execute_plan(plan, *this, *this, comp, comp, nc);
+    execute_plan(plan, *this, *this, comp, comp, nc, false, on);
 }
 
 // ------------------------------------------------------------------ coalescing

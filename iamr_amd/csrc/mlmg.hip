@@ -349,10 +349,25 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             MultiFab* b = &L.buf;
             if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
             const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
+            // Overlap (IAMRX_HALO_OVERLAP, 1: on where the level exchanges with other ranks; 2: always; 0: off): the exchange of the two ghost
+            // layers, k_abec_rb_ghost and the tiles next to box faces are issued on the context's side stream, the tiles that read no
+            // ghost cell on the main stream in front of them -- the messages travel while the interior of the box is swept
+            auto& ctx = Context::get();
+            const int ov_mode = (int)tune("HALO_OVERLAP", 1);
+            const CopyPlan& fplan = fill_boundary_plan(*L.layout, cell_type(), sol.ngrow, L.g);      // (built and uploaded in front of any fork)
+            const bool overlap = ov_mode != 0 && (ov_mode == 2 || !fplan.peers.empty()) && abec_gsrb_rb_nbr_splits(L.g, *L.layout);
             for (int i = 0; i < nsweeps; ++i) {
                 const bool z = sol_is_zero && i == 0;
-                if (!z) a->FillBoundary(L.g);
-                abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, z, m_bcn.data(), (int)m_bcn.size());
+                if (z || !overlap) {
+                    if (!z) a->FillBoundary(L.g);
+                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, z, m_bcn.data(), (int)m_bcn.size());
+                } else {
+                    ctx.fork_side();
+                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 1, ctx.stream);
+                    a->FillBoundary(L.g, 0, m_ncomp, nullptr, -1, ctx.side);
+                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 2, ctx.side);
+                    ctx.join_side();
+                }
                 std::swap(a, b);
             }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);

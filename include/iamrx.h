@@ -87,6 +87,10 @@ int iamrx_tuning_get(const char* key, double default_value, double* value);
  * enabled).  Writes the accumulated report (one line per scope path: name, ms, calls) into report[capacity] first (may be NULL), then
  * enable: 1 on, 0 off, -1 unchanged; reset != 0 clears the accumulated times. */
 int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity);
+/* halo exchanges with other ranks since iamrx_init: out[0] exchanges issued on the main stream (in front of the kernel that needs the data:
+ * exposed), out[1] doubles sent by them; out[2] / out[3] the same for exchanges issued on the side stream beside interior work (the
+ * multi-box red + black sweep: hidden as far as the interior tiles last); the role of the comm rows of a TINY_PROFILE */
+int iamrx_exchange_counts(size_t out[4]);
 int iamrx_sync_count(size_t* n_stream_sync);     /* host waits on the library stream so far (scalar read-backs of norms / dot products, plan uploads) */
 /* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
  * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */

@@ -20,6 +20,9 @@ def run(rank, world, port, out_dir, agg, case="tg"):
     if case == "stack4":     # the weak-scaling layout of bench.py: one box per rank, stacked in z
         N = (16, 16, 64)
         BOXES = [((0, 0, 16 * r), (15, 15, 16 * r + 15)) for r in range(4)]
+    if case == "rows128":    # boxes whose rows span the domain, split in y and z over the ranks: the multi-box red + black sweep with its two-layer
+        N = (128, 96, 64)    # exchange, issued in two parts around the exchange (interior tiles on the main stream, the rest on the side stream)
+        BOXES = [((0, 48 * (q % 2), 32 * (q // 2)), (127, 48 * (q % 2) + 47, 32 * (q // 2) + 31)) for q in range(4)]
     if case.startswith("grid"):   # bench.py's layout for N ranks: one 16^3 box per rank on the most cubic process grid (4 -> 2x2x1, 8 -> 2x2x2)
         import bench
         nr = int(case[4:])
@@ -50,9 +53,15 @@ def run(rank, world, port, out_dir, agg, case="tg"):
     if case == "regrid":
         return run_regrid(rank, world, out_dir)
     owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
+    if case == "rows128":
+        owners = [q % world for q in range(len(BOXES))]
     lay = lib.Layout(BOXES, owners)
     if case.startswith("grid"):
         g = lib.Geom.make(N, prob_hi=tuple(N[d] / 16.0 for d in range(3)))
+        ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
+        ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    elif case == "rows128":
+        g = lib.Geom.make(N, prob_hi=(1.0, 0.75, 0.5))
         ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
         ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
     elif case == "stack4":
@@ -284,6 +293,26 @@ def test_a_rank_without_boxes_takes_part_in_the_step(tmp_path):
         assert np.array_equal(z["iters"], ref["iters"])
         key = f"box{r}"
         assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+@pytest.mark.parametrize("nr", [2, 4])
+def test_rows_that_span_the_domain_sharded_in_y_and_z(tmp_path, nr):
+    """four boxes of 128 x 48 x 32 (the shape of bench.py's multi-GPU layout: rows never cut) over 2 and 4 ranks: the MAC and viscous solves
+    run the multi-box red + black sweep with ONE two-layer ghost exchange per sweep, issued on the side stream while the tiles that read
+    no ghost cell run on the main stream (HALO_OVERLAP: on by itself where a level has peers); the coarse multigrid levels are agglomerated
+    onto one merged box per rank.  Equal to the one-rank run (same kernels on four local boxes) to round-off: the sums of the mean
+    removals and dot products are formed rank by rank."""
+    import torch.multiprocessing as mp
+    port = 37100 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "rows128"), nprocs=1, join=True)
+    mp.spawn(run, args=(nr, port + 3, str(tmp_path), None, "rows128"), nprocs=nr, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    for r in range(nr):
+        z = np.load(os.path.join(str(tmp_path), f"w{nr}_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-12, atol=0)
+        assert np.array_equal(z["iters"], ref["iters"])
+        for key in [k for k in z.files if k.startswith("box")]:
+            assert np.abs(z[key] - ref[key]).max() <= 1e-12, (key, float(np.abs(z[key] - ref[key]).max()))
 
 
 def test_two_ranks_lid_driven_cavity(tmp_path):

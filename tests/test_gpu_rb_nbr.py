@@ -154,3 +154,23 @@ def test_time_steps_on_a_chopped_level_do_not_depend_on_the_sweep_kernel(gpu, wa
     assert np.allclose(out["nbr"][0], out["single"][0], rtol=1e-12, atol=0.0)
     for a, b in zip(out["nbr"][1:], out["single"][1:]):
         assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max()), float(np.abs(a - b).max())
+
+
+def test_sweep_issued_in_two_parts_on_two_streams_gives_the_same_doubles(gpu):
+    """IAMRX_HALO_OVERLAP = 2 forces what a multi-rank run does by itself: the tiles of the sweep that read no ghost cell on the main stream,
+    the ghost exchange + k_abec_rb_ghost + the tiles next to box faces on the side stream behind a fork, joined afterwards.  Same doubles
+    as the sweep issued in one piece; TaylorGreen on four boxes of 128 x 48 x 32 (rows span the domain: no ghost columns)."""
+    lib = gpu
+    from iamr_amd import ns as NS
+    n, mg = (128, 96, 64), (128, 48, 32)
+    out = {}
+    for key, ov in (("one piece", 0), ("two parts", 2)):
+        lib.tuning_set("HALO_OVERLAP", ov)
+        try:
+            ns, dts = run_steps(lib, n, mg, 2)
+        finally:
+            lib.tuning_set("HALO_OVERLAP", 1)
+        out[key] = (dts, ns.data(NS.NavierStokes.S_NEW).gather_valid(n), ns.data(2).gather_valid(n))
+    assert out["one piece"][0] == out["two parts"][0]
+    for a, b in zip(out["one piece"][1:], out["two parts"][1:]):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())

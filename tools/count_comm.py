@@ -37,13 +37,19 @@ hist.clear()
 import ctypes as C
 def nsync():
     v = C.c_size_t(); lib.check(lib.lib().iamrx_sync_count(C.byref(v))); return v.value
-s0 = nsync()
+def xc():
+    v = (C.c_size_t * 4)(); lib.check(lib.lib().iamrx_exchange_counts(v)); return list(v)
+s0 = nsync(); x0 = xc()
 ns.step()
 syncs = nsync() - s0
+x1 = xc(); xd = [b - a for a, b in zip(x0, x1)]
 sm, sn, sv = ns.stats()
 if rank == 0:
     print(f"n={n} world={world}: per step and rank: {cnt['ex']} peer messages received ({cnt['bytes']/1e6:.1f} MB), {cnt['ar']} all-reduces; "
           f"{syncs} host synchronisations (the host-staged test transport adds two per all-reduce; RCCL reduces in place on the stream); "
           f"MG iterations mac {sm.iters} nodal {sn.iters} visc {sv.iters}")
+if rank == 0:
+    print(f"exchanges per step and rank: {xd[0]} on the main stream ({xd[1] * 8 / 1e6:.1f} MB sent; exposed: in front of the kernel that reads the ghost data), "
+          f"{xd[2]} on the side stream ({xd[3] * 8 / 1e6:.1f} MB sent; hidden behind the interior tiles of the multi-box red + black sweep)")
 if rank == 0: print("sizes (doubles: count):", sorted(hist.items()))
 dist.barrier(); dist.destroy_process_group()
