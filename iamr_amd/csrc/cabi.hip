@@ -71,7 +71,7 @@ int iamrx_finalize(void) { IAMRX_TRY Context::get().release_cache(); IAMRX_CATCH
 int iamrx_sync(void) { IAMRX_TRY Context::get().sync(); IAMRX_CATCH }
 void* iamrx_stream(void) { return (void*)Context::get().stream; }
 int iamrx_tuning_set(const char* key, double value) { IAMRX_TRY if (!key) throw Error("iamrx_tuning_set: null key"); tuning_set(key, value); IAMRX_CATCH }
-int iamrx_tuning_get(const char* key, double default_value, double* value) { IAMRX_TRY *value = tune(key, default_value); IAMRX_CATCH }
+int iamrx_tuning_get(const char* key, double default_value, double* value) { IAMRX_TRY *value = tune_by_name(key, default_value); IAMRX_CATCH }
 int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity)
 {
     IAMRX_TRY

@@ -875,9 +875,12 @@ void kernel_probe_stop(int which, double* total_ms, long* launches)
     *total_ms = ms; *launches = (long)pb.used;
     pb.on = false; pb.used = 0;
 }
+static bool g_probes_paused = false;
+void kernel_probes_pause(bool on) { g_probes_paused = on; }
 bool kernel_probe_begin(int which, long points)
 {
     KProbe& pb = g_probe[which];
+    if (g_probes_paused) return false;
     if (!(pb.on && points >= pb.min_points && (pb.seen++ % pb.stride) == 0)) return false;
     if (pb.used == pb.ev.size()) {
         hipEvent_t e0, e1;

@@ -23,6 +23,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
 enum { PROBE_NODAL_GS4 = 0, PROBE_ABEC_GSRB = 1, PROBE_GOD_Z = 2, PROBE_PRED_Z = 3, PROBE_COUNT = 4 };
 void kernel_probe_start(int which, long min_points, int stride);
 void kernel_probe_stop(int which, double* total_ms, long* launches);
+void kernel_probes_pause(bool on);      // no probe events while a launch sequence is being captured into a graph
 bool kernel_probe_begin(int which, long points);     // true: the start event was recorded, call kernel_probe_end after the launch
 void kernel_probe_end(int which);
 void gs4_probe_start(long min_nodes, int stride);

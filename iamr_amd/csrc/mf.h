@@ -82,7 +82,8 @@ struct Context {
 // Every run-time switch of the library is a key of ONE registry: filled once, at iamrx_init, from the environment
 // variables IAMRX_<KEY> that are set, changed afterwards only through iamrx_tuning_set, and read by the code at the point of use
 // (tune(key, default)) -- no function-local static caches a choice for the life of the process.
-double tune(const char* key, double dflt);
+double tune(const char* key, double dflt);             // key: a string LITERAL (looked up by address, mf.hip)
+double tune_by_name(const char* key, double dflt);     // any string
 void trace_blas_site(const char* what, long points);   // IAMRX_BLAS_TRACE (mf.hip)
 void tuning_set(const char* key, double value);
 void tuning_load_environment();          // called by Context::init

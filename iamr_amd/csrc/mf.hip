@@ -124,6 +124,12 @@ void Context::release_cache()
 namespace {
 std::map<std::string, double>& tuning_map() { static auto* m = new std::map<std::string, double>(); return *m; }
 }  // namespace
+namespace {
+struct TuneSlot { const char* key = nullptr; double val = 0.0; bool set = false; uint64_t ver = 0; };
+constexpr size_t kTuneSlots = 2048;
+TuneSlot g_tune_slots[kTuneSlots];
+uint64_t g_tune_version = 1;
+}  // namespace
 extern "C" char** environ;
 void tuning_load_environment()
 {
@@ -137,14 +143,35 @@ void tuning_load_environment()
         const double v = strtod(eq + 1, &end);
         if (end != eq + 1 && !m.count(key)) m[key] = v;           // values set through iamrx_tuning_set before init win
     }
+    ++g_tune_version;
 }
-double tune(const char* key, double dflt)
+// The registry is read at the point of use, several times per kernel launch (tile shapes, kernel forms): a std::map<std::string> lookup
+// there costs a string construction and O(log n) string compares -- of the order of a microsecond per launch on launch-bound sequences
+// (7 700 launches per coarse step of the 128^3 + 128^3 hierarchy).  The keys are string literals, so the ADDRESS identifies the call
+// site: a small open-addressed table keyed by it holds the value, tagged with the registry's version; iamrx_tuning_set bumps the version
+// (every entry is then re-read from the map on its next use).  tune_by_name: for keys that are not literals (the C-ABI getter).
+double tune_by_name(const char* key, double dflt)
 {
     auto& m = tuning_map();
     auto it = m.find(key);
     return it == m.end() ? dflt : it->second;
 }
-void tuning_set(const char* key, double value) { tuning_map()[key] = value; }
+double tune(const char* key, double dflt)
+{
+    size_t i = ((uintptr_t)key >> 2) & (kTuneSlots - 1);
+    for (int probe = 0; probe < 16; ++probe, i = (i + 1) & (kTuneSlots - 1)) {
+        TuneSlot& t = g_tune_slots[i];
+        if (t.key == key && t.ver == g_tune_version) return t.set ? t.val : dflt;
+        if (t.key == nullptr || t.ver != g_tune_version) {        // free (or stale: its owner re-reads like everybody else)
+            auto& m = tuning_map();
+            auto it = m.find(key);
+            t.key = key; t.ver = g_tune_version; t.set = it != m.end(); t.val = t.set ? it->second : 0.0;
+            return t.set ? t.val : dflt;
+        }
+    }
+    return tune_by_name(key, dflt);
+}
+void tuning_set(const char* key, double value) { tuning_map()[key] = value; ++g_tune_version; }
 
 // ---- scoped profiler
 bool ProfScope::enabled = false;

@@ -608,6 +608,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
     st.resnorm = st.resnorm0;
     if (m_o.verbose) printf("iamrx MLMG: rhs %.6e resid0 %.6e target %.3e levels %d\n", st.rhsnorm0, st.resnorm0, res_target, st.nlevels);
     double vc_ms = 0.0;
+    hipGraphExec_t vc_exec = nullptr;
     cycle_timer().used = 0;
     if (m_bottom_dev) IAMRX_HIP_CHECK(hipMemsetAsync(bottom_iters_dev(), 0, sizeof(int), ctx.stream));
     if (m_o.fixed_iters <= 0 && st.resnorm0 <= res_target) st.converged = 1;
@@ -629,6 +630,23 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
                 m_dd_sweeps = std::min(6, std::max(1, (int)std::ceil(std::log(need) / std::log(m_dd_rho))));
             }
             cycle_timer().mark(ctx.stream);
+            // IAMRX_MG_GRAPH (0): the V-cycle of a hierarchy -- a fixed sequence of launches on fixed arrays, no host synchronisation, no
+            // allocation once its lazy buffers exist -- is issued directly the first time (which defines those buffers), captured into a
+            // hipGraph the second time and replayed from the third on: one graph launch instead of ~100 kernel launches per cycle
+            const bool graph_ok = tune("MG_GRAPH", 0) != 0 && m_dd_sweeps == 0 && m_bottom_dev && ctx.comm->nranks == 1 && m_lev.size() > 1;
+            if (graph_ok && iter >= 1) {
+                if (!vc_exec) {
+                    kernel_probes_pause(true);
+                    hipGraph_t gr = nullptr;
+                    IAMRX_HIP_CHECK(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+                    vcycle(st);
+                    IAMRX_HIP_CHECK(hipStreamEndCapture(ctx.stream, &gr));
+                    IAMRX_HIP_CHECK(hipGraphInstantiate(&vc_exec, gr, nullptr, nullptr, 0));
+                    IAMRX_HIP_CHECK(hipGraphDestroy(gr));
+                    kernel_probes_pause(false);
+                }
+                IAMRX_HIP_CHECK(hipGraphLaunch(vc_exec, ctx.stream));
+            } else
             vcycle(st);
             cycle_timer().mark(ctx.stream);
             mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
@@ -643,6 +661,7 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
         if (m_o.fixed_iters <= 0 && !st.converged) throw Error("iamrx MLMG: failed to converge after max_iters");
     }
     vc_ms = cycle_timer().total_ms();          // the last residual norm has synchronised the stream
+    if (vc_exec) IAMRX_HIP_CHECK(hipGraphExecDestroy(vc_exec));
     if (st.iters > 0) st.vcycle_ms = vc_ms / st.iters;
     applyBC(0, phi, true, bcvp);
     if (m_bottom_dev && st.iters > 0) {
