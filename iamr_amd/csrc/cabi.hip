@@ -517,7 +517,8 @@ int iamrx_nodal_gs_sweep(const iamrx_geom* g, iamrx_mf phi, iamrx_mf rhs, iamrx_
     if (fused == 3 || fused == 4) {
         // timing aid: the two smoother launches of a sweep alone (no ghost fills, result left in a scratch buffer); 4: with the index wrap
         // of a single box that spans a periodic domain
-        static MultiFab xb;
+        // (scratch kept between calls of a timing loop; heap object never destroyed: no device free from a static destructor after HIP is gone)
+        static MultiFab& xb = *new MultiFab();
         if (!xb.defined() || xb.layout != phi->mf.layout || xb.ngrow != phi->mf.ngrow) xb.define(phi->mf.layout, node_type(), 1, phi->mf.ngrow);
         const bool wrap = fused == 4;
         if (wrap && !periodic_wrap_ok(gg, *phi->mf.layout, 4)) throw Error("iamrx_nodal_gs_sweep(4): not a single box spanning a periodic domain");

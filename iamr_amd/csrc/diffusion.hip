@@ -115,6 +115,9 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
                                 MultiFab* const tflux[3], double visc_tol, const MGOpts& o, const std::function<void(MultiFab&)>& fill_new)
 {
     LayoutP layout = U_new.layout;
+    // The solve runs IN PLACE on the velocity components of U_new and reads alpha from the array that holds it (views, below): U_new comes
+    // with at least one ghost layer (level boundary data / initial guess); any wider ghost region is simply not touched (the kernels index
+    // through the array descriptors; only the first layer is filled and read).  rho_half is read on the valid cells.
     IAMRX_ASSERT(U_new.ngrow >= 1 && (rho_flag == 1 || rho_flag == 3));
     MultiFab Rhs(layout, cell_type(), 3, 0);
     const bool want_flux = tflux != nullptr && tflux[0] != nullptr;
@@ -125,15 +128,14 @@ MGStats diffuse_tensor_velocity(const Geometry& g, const MultiFab* U_old, MultiF
     // (1 - theta) dt div tau(U^n) from viscous terms the caller has evaluated already (no fluxes wanted): formed inside the pass below
     // (the expression of mf_lincomb(Rhs, (1 - theta) dt, visc, 0.0, visc), then Rhs += rho u*: the same doubles, one pass less)
     const bool from_visc = theta != 1.0 && !want_flux && visc_old_term;
-    if (from_visc) {
-    } else if (theta != 1.0) {
+    if (!from_visc && theta != 1.0) {
         IAMRX_ASSERT(U_old && U_old->ngrow >= 1);
         MultiFab Soln0(layout, cell_type(), 3, 1);
         MultiFab::Copy(Soln0, *U_old, Xvel, 0, 3, 1);
         if (crse) { cdata.define(crse->crse_old->layout, cell_type(), 3, 0); MultiFab::Copy(cdata, *crse->crse_old, Xvel, 0, 3, 0); }   // Diffusion.cpp:733-744
         fx.fac = 1.0 - theta; fx.add = false;                    // computeExtensiveFluxes(..., -b/dt), b = -(1 - theta) dt
         tensor_apply(g, Rhs, Soln0, 0.0, -(1.0 - theta) * dt, nullptr, eta_n, bc_visc, 3, crse ? &cf : nullptr, want_flux ? &fx : nullptr);
-    } else Rhs.setVal(0.0);
+    } else if (!from_visc) Rhs.setVal(0.0);
     {
         const FabD *nt = U_new.d_tab, *ot = U_old ? U_old->d_tab : nullptr, *rt = Rhs.d_tab, *ht = rho_half.d_tab;
         const FabD* vt = from_visc ? visc_old_term->d_tab : nullptr;

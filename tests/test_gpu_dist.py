@@ -17,6 +17,12 @@ NSTEPS = 2
 def run(rank, world, port, out_dir, agg, case="tg"):
     sys.path.insert(0, ROOT)
     global N, BOXES
+    if case.endswith("+merge"):      # the library's default: the level objects work on the boxes a rank owns MERGED (the suite otherwise keeps them)
+        os.environ["IAMRX_COALESCE"] = "1"
+        case = case[:-6]
+    if case == "slabs":              # eight 16^3 boxes, the four of a z-slab owned by one rank: each rank merges its four into one 32 x 32 x 16 box
+        N = (32, 32, 32)
+        BOXES = [((16 * i, 16 * j, 16 * k), (16 * i + 15, 16 * j + 15, 16 * k + 15)) for k in (0, 1) for j in (0, 1) for i in (0, 1)]
     if case == "stack4":     # the weak-scaling layout of bench.py: one box per rank, stacked in z
         N = (16, 16, 64)
         BOXES = [((0, 0, 16 * r), (15, 15, 16 * r + 15)) for r in range(4)]
@@ -55,6 +61,8 @@ def run(rank, world, port, out_dir, agg, case="tg"):
     owners = list(range(len(BOXES))) if world > 1 else [0] * len(BOXES)     # case 'tg' on 3 ranks: rank 2 owns no box
     if case == "rows128":
         owners = [q % world for q in range(len(BOXES))]
+    if case == "slabs":
+        owners = [(q // 4) % world for q in range(len(BOXES))]
     lay = lib.Layout(BOXES, owners)
     if case.startswith("grid"):
         g = lib.Geom.make(N, prob_hi=tuple(N[d] / 16.0 for d in range(3)))
@@ -68,7 +76,7 @@ def run(rank, world, port, out_dir, agg, case="tg"):
         g = lib.Geom.make(N, prob_hi=(1.0, 1.0, 4.0))
         ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.7, visc_coef=1e-3, init_iter=2))
         ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
-    elif case == "tg":
+    elif case in ("tg", "slabs"):
         g = lib.Geom.make(N)
         ns = NS.NavierStokes(g, lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
         ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
@@ -221,13 +229,14 @@ def test_amr_bench_workload_sharded_over_ranks(tmp_path, nr):
     assert seen == {k for k in ref.files if "box" in k}
 
 
-def test_regrid_on_two_ranks_matches_one_rank(tmp_path):
+@pytest.mark.parametrize("merge", ["", "+merge"])
+def test_regrid_on_two_ranks_matches_one_rank(tmp_path, merge):
     """Amr::regrid with the levels spread over two ranks: same grids after every regrid, same data, both ranks own boxes of the new level"""
     import torch.multiprocessing as mp
     port = 34100 + (os.getpid() % 2000)
-    mp.spawn(run, args=(1, port, str(tmp_path), None, "regrid"), nprocs=1, join=True)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "regrid" + merge), nprocs=1, join=True)      # "+merge": level 0 merged per rank (the default mode)
     ref = np.load(os.path.join(str(tmp_path), "regrid_w1_r0.npz"))
-    mp.spawn(run, args=(2, port + 9, str(tmp_path), None, "regrid"), nprocs=2, join=True)
+    mp.spawn(run, args=(2, port + 9, str(tmp_path), None, "regrid" + merge), nprocs=2, join=True)
     seen = set()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"regrid_w2_r{r}.npz"))
@@ -293,6 +302,25 @@ def test_a_rank_without_boxes_takes_part_in_the_step(tmp_path):
         assert np.array_equal(z["iters"], ref["iters"])
         key = f"box{r}"
         assert np.abs(z[key] - ref[key]).max() <= 1e-9, np.abs(z[key] - ref[key]).max()
+
+
+def test_ranks_that_merge_their_boxes(tmp_path):
+    """the library's default mode (IAMRX_COALESCE = 1) under several ranks: every rank owns four boxes that merge into
+    one slab; the merged level objects, their data accessors (the caller's boxes) and the multigrid wrappers on merged boxes against the
+    one-rank run, whose eight boxes merge into one box spanning the domain"""
+    import torch.multiprocessing as mp
+    port = 36300 + (os.getpid() % 2000)
+    mp.spawn(run, args=(1, port, str(tmp_path), None, "slabs+merge"), nprocs=1, join=True)
+    mp.spawn(run, args=(2, port + 3, str(tmp_path), None, "slabs+merge"), nprocs=2, join=True)
+    ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    seen = 0
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
+        assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
+        for key in [k for k in z.files if k.startswith("box")]:
+            assert np.abs(z[key] - ref[key]).max() <= 1e-9, (key, float(np.abs(z[key] - ref[key]).max()))
+            seen += 1
+    assert seen == 8          # the accessors speak the caller's eight boxes
 
 
 @pytest.mark.parametrize("nr", [2, 4])
