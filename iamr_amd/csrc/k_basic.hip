@@ -411,4 +411,17 @@ void mf_mult(MultiFab& y, double a, int comp, int nc, int ng)
         [=] __device__(int i, int j, int k, int f, int n, double v) { yt[f](i, j, k, comp + n) = v; });
 }
 
+// slab levels (mf.h): every y-plane of dst takes the single y-plane of src
+void slab_duplicate(MultiFab& dst, const MultiFab& src)
+{
+    IAMRX_ASSERT(dst.ncomp == src.ncomp && dst.layout->boxes.size() == src.layout->boxes.size());
+    if (dst.nlocal() == 0) return;
+    const FabD *dt = dst.d_tab, *st = src.d_tab;
+    const int nc = dst.ncomp;
+    for_each(*dst.layout, dst.type, 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+        const FabD s = st[f];
+        for (int n = 0; n < nc; ++n) dt[f](i, j, k, n) = s(i, 0, k, n);        // (slab boxes start at y = 0: Layout::slab_coarsenable)
+    });
+}
+
 }  // namespace iamrx

@@ -136,6 +136,13 @@ struct Layout {
     mutable std::shared_ptr<Layout> m_coarse;
     mutable int m_coarse_ratio = 0;
     bool coarsenable(int ratio, int min_width) const;
+    // Slab levels (2-D inputs lifted onto a y-periodic slab): every box is two cells thick in y, which cannot
+    // be coarsened any further; x and z still can.  The next multigrid level is the coarsening by 2 in x and z with y KEPT at two cells
+    // (slab_coarsened), dx doubled in every direction; the transfers go through the ordinary coarsening by 2 (`coarsened(2)`: one cell
+    // in y, the "virtual" level) and duplicate its plane (slab_duplicate) -- valid for fields that do not vary along the slab.
+    bool slab_coarsenable(int min_width) const;
+    std::shared_ptr<Layout> slab_coarsened() const;
+    mutable std::shared_ptr<Layout> m_slab;
     // same boxes, all of them owned by this rank (on every rank)
     std::shared_ptr<Layout> make_replicated() const;
     mutable std::shared_ptr<Layout> m_repl;
@@ -254,6 +261,8 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
 // add: dst += src instead of dst = src (the regions of one plan must then not overlap in dst)
 void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false, hipStream_t on = nullptr);
 // multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes
+// dst (a slab level: two cells / three nodes in y) = the one y-plane of src (the virtual level, same boxes in x and z) in every y-plane
+void slab_duplicate(MultiFab& dst, const MultiFab& src);
 void gather_to_replicated(MultiFab& repl, const MultiFab& dist);
 void scatter_from_replicated(MultiFab& dist, const MultiFab& repl, int ng);
 

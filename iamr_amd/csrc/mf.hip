@@ -320,6 +320,28 @@ std::shared_ptr<Layout> Layout::coarsened(int ratio) const
     return m_coarse;
 }
 
+bool Layout::slab_coarsenable(int min_width) const
+{
+    for (auto& b : boxes) {
+        if (b.lo[1] != 0 || b.hi[1] != 1) return false;
+        for (int d = 0; d < 3; d += 2) {
+            if (b.len(d) % 2 != 0 || b.len(d) / 2 < min_width) return false;
+            if (((b.lo[d] % 2) + 2) % 2 != 0) return false;
+        }
+    }
+    return !boxes.empty();
+}
+
+std::shared_ptr<Layout> Layout::slab_coarsened() const
+{
+    if (m_slab) return m_slab;
+    std::vector<BoxD> cb;
+    for (auto& b : boxes) { BoxD c = coarsen(b, 2); c.lo[1] = 0; c.hi[1] = 1; cb.push_back(c); }
+    m_slab = std::make_shared<Layout>(cb, owner, Context::get().comm->rank);
+    m_slab->replicated = replicated;
+    return m_slab;
+}
+
 // boxes that share full faces and have the same owner, merged (sweeps along x, y, z until nothing changes); the result in a deterministic
 // order: by owner, then z, y, x of the lower corner.  Returns whether anything merged.
 static bool merge_boxes(std::vector<BoxD>& boxes, std::vector<int>& owner)

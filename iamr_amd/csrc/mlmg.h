@@ -3,6 +3,7 @@
 // MLNodeLaplacian as used at reference Source/MacProj.cpp:1150-1183, Source/Diffusion.cpp:715-923,
 // Source/Projection.cpp:2512-2542.
 #pragma once
+#include <functional>
 #include "mf.h"
 #include "kernels.h"
 #include <vector>
@@ -57,6 +58,8 @@ CycleTimer& cycle_timer();
 // V-cycle instead of a halo exchange per smoothing pass and an all-reduce per Krylov dot product); 0 disables
 long mg_agglomeration_cells();
 bool mg_agglomerate_level(const Layout& coarse);      // mlmg.hip
+bool mg_slab_level(const Geometry& g, const Layout& l, int min_width);      // mlmg.hip: y kept at two cells from here on
+Geometry mg_slab_geom(const Geometry& fine);
 
 
 struct MGStats {
@@ -113,6 +116,9 @@ private:
         MultiFab cor, res, rescor;
         MultiFab buf;              // second buffer of the fused (out-of-place) GSRB sweeps
         bool res_filled = false;   // multi-box sweep kernel: the ghost layer of `res` is current (filled once per V-cycle)
+        bool slab = false;         // slab level (mlmg.hip: mg_slab_level): two cells in y kept; virt = the one-plane coarsening of the level
+        LayoutP virt;              // above, through which the restrictions go (vres: their target, duplicated into res / tmp_d)
+        MultiFab vres;
         // agglomeration (multi-rank): from this level down every rank holds the whole level; dist = the distributed coarsening
         // of the level above, through which restriction results are gathered and corrections are picked out
         bool agg = false;
@@ -190,6 +196,9 @@ private:
         bool agg = false;          // see CellMG::Level
         LayoutP dist;
         MultiFab tmp_d;
+        bool slab = false;         // slab level, see CellMG::Level
+        LayoutP virt;
+        MultiFab vres;
         MultiFab xb;               // second buffer of the out-of-place fused Gauss-Seidel sweeps
         bool res_filled = false;   // the ghost nodes of `res` are current (filled once per V-cycle, not once per smooth call)
         MultiFab dm;               // Dirichlet node mask (defined only if the level has Dirichlet nodes, see NodalMG ctor)

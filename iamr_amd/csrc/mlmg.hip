@@ -31,6 +31,28 @@ bool mg_agglomerate_level(const Layout& c)
     return c.boxes.size() > 1 && tune("MG_AGG_SINGLE_RANK", 1) != 0;
 }
 
+// Slab levels (IAMRX_MG_SLAB, set by the driver for 2-D inputs lifted onto a y-periodic slab): the level is two
+// cells thick in y -- periodic, every box spanning it -- and cannot be coarsened there any more, but it can in x and z.  The multigrid then
+// continues with y KEPT at two cells and dx doubled in every direction: for fields that do not vary along the slab the y-terms of every
+// operator vanish, the two-plane level is the 2-D coarse problem (relaxed like the thick slab is), and the transfers are the ordinary ones
+// onto the one-plane coarsening of the level with its plane duplicated (Layout::slab_coarsened, slab_duplicate) -- which also projects
+// any y-dependent round-off out of the coarse levels, where the doubled dy would over-correct it.
+bool mg_slab_level(const Geometry& g, const Layout& l, int min_width)
+{
+    if (tune("MG_SLAB", 0) == 0) return false;
+    if (!g.periodic[1] || g.domain.lo[1] != 0 || g.domain.hi[1] != 1) return false;
+    for (int d = 0; d < 3; d += 2) if (g.domain.len(d) % 2 != 0 || g.domain.len(d) / 2 < min_width) return false;
+    return l.slab_coarsenable(min_width);
+}
+Geometry mg_slab_geom(const Geometry& f)
+{
+    Geometry c = f;
+    c.domain = coarsen(f.domain, 2);
+    c.domain.lo[1] = 0; c.domain.hi[1] = 1;
+    for (int d = 0; d < 3; ++d) c.dx[d] = f.dx[d] * 2.0;
+    return c;
+}
+
 CellMG::CellMG(const Geometry& g, LayoutP layout, int ncomp, const DomainBC& bc, const MGOpts& o)
     : m_g(g), m_ncomp(ncomp), m_o(o)
 {
@@ -138,12 +160,21 @@ void CellMG::prepare()
         if (m_o.device_bottom && !m_tensor && !m_o.bottom_smoother_only && abec_bottom_device_ok(f.g, *f.layout, m_bcn.data(), (int)m_bcn.size(), m_ncomp, m_cf)) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
-        if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
+        const bool iso = dom_ok && f.layout->coarsenable(2, m_o.min_width);
+        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width);
+        if (!iso && !slab) break;
         Level c;
         c.g = f.g;
+        if (slab) {
+            c.g = mg_slab_geom(f.g);
+            c.slab = true;
+            c.virt = f.layout->coarsened(2);             // the one-plane coarsening the transfers write to
+            c.layout = f.layout->slab_coarsened();
+        } else {
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
+        }
         if (mg_agglomerate_level(*c.layout)) {
             c.agg = true;
             c.dist = c.layout;
@@ -187,10 +218,20 @@ void CellMG::prepare()
         if (l > 0) {
             AbecCoef fc = coef(l - 1);
             if (L.agg) L.tmp_d.define(L.dist, cell_type(), m_ncomp, 0);
+            if (L.slab) L.vres.define(L.virt, cell_type(), m_ncomp, 0);
+            // (slab level: the transfer writes the one-plane virtual level, whose plane is duplicated into the level's two)
+            auto coarsen_into = [&](MultiFab& dst, IndexType t, int nc, const std::function<void(MultiFab&)>& op) {
+                LayoutP own = L.agg ? L.dist : L.layout;
+                MultiFab dist_arr;
+                MultiFab* target = &dst;
+                if (L.agg) { dist_arr.define(own, t, nc, 0); target = &dist_arr; }
+                if (L.slab) { MultiFab v(L.virt, t, nc, 0); op(v); slab_duplicate(*target, v); }
+                else op(*target);
+                if (L.agg) gather_to_replicated(dst, dist_arr);
+            };
             if (m_a0) {
                 L.a.define(L.layout, cell_type(), 1, 0);
-                if (L.agg) { MultiFab t(L.dist, cell_type(), 1, 0); cc_restrict(t, *fc.a); gather_to_replicated(L.a, t); }
-                else cc_restrict(L.a, *fc.a);
+                coarsen_into(L.a, cell_type(), 1, [&](MultiFab& c) { cc_restrict(c, *fc.a); });
             }
             for (int d = 0; d < 3; ++d) {
                 // coarsening the finest level of an eta-form tensor operator: average the three-component coefficients it stands for
@@ -198,8 +239,7 @@ void CellMG::prepare()
                 const MultiFab* fb = fc.b[d];
                 if (l == 1 && m_tensor_eta && !m_buni_coarse) { b3.define(m_lev[0].layout, face_type(d), 3, 0); tensor_bcoef(b3, *fc.b[d], d); fb = &b3; }
                 L.b[d].define(L.layout, face_type(d), fb->ncomp, 0);
-                if (L.agg) { MultiFab t(L.dist, face_type(d), fb->ncomp, 0); face_avgdown(t, *fb, d); gather_to_replicated(L.b[d], t); }
-                else face_avgdown(L.b[d], *fb, d);
+                coarsen_into(L.b[d], face_type(d), fb->ncomp, [&](MultiFab& c) { face_avgdown(c, *fb, d); });
             }
         }
     }
@@ -531,19 +571,18 @@ void CellMG::vcycle(MGStats& st)
         const AbecCoef cl = coef(l);
         // (one box spanning a periodic domain: the fused residual + restriction reads the periodic images itself)
         if (m_cf || !abec_residual_reads_no_ghosts(L.g, cl, L.rescor, L.cor, L.res, true)) applyBC(l, L.cor, false, nullptr);
-        if (abec_resid_restrict_ok(cl, L.cor, L.res)) {        // residual and restriction in one pass
-            if (m_lev[l + 1].agg) {
-                abec_resid_restrict(L.g, cl, m_lev[l + 1].tmp_d, L.cor, L.res);
-                gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
-            } else abec_resid_restrict(L.g, cl, m_lev[l + 1].res, L.cor, L.res);
-            continue;
+        // the restriction writes: the coarse level's residual; its distributed form (agglomerated level: gathered afterwards); or, for a
+        // slab level, the one-plane virtual level, whose plane is then duplicated
+        Level& C = m_lev[l + 1];
+        MultiFab& held = C.agg ? C.tmp_d : C.res;
+        MultiFab& target = C.slab ? C.vres : held;
+        if (abec_resid_restrict_ok(cl, L.cor, L.res)) abec_resid_restrict(L.g, cl, target, L.cor, L.res);       // residual and restriction in one pass
+        else {
+            level_residual(L.g, cl, L.rescor, L.cor, &L.res);
+            cc_restrict(target, L.rescor);
         }
-        level_residual(L.g, cl, L.rescor, L.cor, &L.res);
-        if (m_lev[l + 1].agg) {
-            cc_restrict(m_lev[l + 1].tmp_d, L.rescor);
-            gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
-        } else
-        cc_restrict(m_lev[l + 1].res, L.rescor);
+        if (C.slab) slab_duplicate(held, C.vres);
+        if (C.agg) gather_to_replicated(C.res, C.tmp_d);
     }
     bottom_solve(st);
     for (int l = nl - 2; l >= 0; --l) {

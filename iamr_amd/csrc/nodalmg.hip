@@ -64,12 +64,23 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
             (nodal_bottom_device_ok(f.g, *f.layout) || nodal_bottom_device_ok_general(f.g, *f.layout))) break;
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
-        if (!dom_ok || !f.layout->coarsenable(2, m_o.min_width)) break;
+        const bool iso = dom_ok && f.layout->coarsenable(2, m_o.min_width);
+        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width);     // (mlmg.hip: y kept at two cells, transfers through the one-plane level)
+        if (!iso && !slab) break;
         Level c;
         c.g = f.g;
+        if (slab) {
+            const Geometry sg = mg_slab_geom(f.g);
+            c.g.domain = sg.domain;
+            for (int d = 0; d < 3; ++d) c.g.dx[d] = sg.dx[d];
+            c.slab = true;
+            c.virt = f.layout->coarsened(2);
+            c.layout = f.layout->slab_coarsened();
+        } else {
         c.g.domain = coarsen(f.g.domain, 2);
         for (int d = 0; d < 3; ++d) c.g.dx[d] = f.g.dx[d] * 2.0;
         c.layout = f.layout->coarsened(2);
+        }
         if (mg_agglomerate_level(*c.layout)) {
             c.agg = true;
             c.dist = c.layout;
@@ -79,6 +90,7 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
     }
     for (auto& L : m_lev) {
         if (L.agg) L.tmp_d.define(L.dist, node_type(), 1, 1);
+        if (L.slab) L.vres.define(L.virt, node_type(), 1, 0);
         // 4 ghost layers: the plane-fused Gauss-Seidel recomputes its halo instead of exchanging it per colour
         const int ng = nodal_fused() ? 4 : 1;
         L.sig.define(L.layout, cell_type(), 1, ng);
@@ -124,12 +136,17 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
     m_lev[0].sig.FillBoundary(m_lev[0].g);
     cc_mirror_bc(m_lev[0].g, m_lev[0].sig);                // mlndlap_fillbc_cc: mirror sigma across walls
     for (size_t l = 1; l < m_lev.size(); ++l) {
-        if (m_lev[l].agg) {
-            MultiFab sd(m_lev[l].dist, cell_type(), 1, 0);
-            cc_restrict(sd, m_lev[l - 1].sig);
-            gather_to_replicated(m_lev[l].sig, sd);
-        } else
-        cc_restrict(m_lev[l].sig, m_lev[l - 1].sig);      // arithmetic average (harmonic averaging off)
+        // arithmetic average (harmonic averaging off); agglomerated level: on its distributed form, then gathered; slab level: onto the
+        // one-plane virtual level, duplicated
+        {
+            Level& C = m_lev[l];
+            MultiFab sd, sv;
+            MultiFab* held = &C.sig;
+            if (C.agg) { sd.define(C.dist, cell_type(), 1, 0); held = &sd; }
+            if (C.slab) { sv.define(C.virt, cell_type(), 1, 0); cc_restrict(sv, m_lev[l - 1].sig); slab_duplicate(*held, sv); }
+            else cc_restrict(*held, m_lev[l - 1].sig);
+            if (C.agg) gather_to_replicated(C.sig, sd);
+        }
         m_lev[l].sig.FillBoundary(m_lev[l].g);
         cc_mirror_bc(m_lev[l].g, m_lev[l].sig);
     }
@@ -316,11 +333,13 @@ void NodalMG::vcycle(MGStats& st)
         for (int i = 0; i < m_o.nodal_nu1; ++i) smooth(l, L.cor, L.res, i == 0);
         residual(l, L.rescor, L.cor, L.res, nullptr, m_o.nodal_nu1 > 0);          // (smooth() has just filled the ghost nodes)
         fillbc(l, L.rescor);
-        if (m_lev[l + 1].agg) {
-            nodal_restrict(m_lev[l + 1].tmp_d, L.rescor);
-            gather_to_replicated(m_lev[l + 1].res, m_lev[l + 1].tmp_d);
-        } else
-        nodal_restrict(m_lev[l + 1].res, L.rescor);
+        {
+            Level& C = m_lev[l + 1];
+            MultiFab& held = C.agg ? C.tmp_d : C.res;
+            nodal_restrict(C.slab ? C.vres : held, L.rescor);
+            if (C.slab) slab_duplicate(held, C.vres);
+            if (C.agg) gather_to_replicated(C.res, C.tmp_d);
+        }
         m_lev[l + 1].res_filled = false;
         if (m_lev[l + 1].dmask()) nodal_zero_masked(m_lev[l + 1].res, m_lev[l + 1].dm);   // mlndlap_restriction: 0 on Dirichlet nodes
     }

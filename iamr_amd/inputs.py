@@ -204,16 +204,18 @@ class Inputs:
         three-dimensional library: 2-D x -> x, 2-D y -> z (gravity and the hydrostatic outflow pressure act along the last coordinate in
         both, NavierStokesBase.cpp:3560, Projection.cpp:2000), the third direction y is periodic, `slab` cells thick with cubic cells,
         carries no flow and no variation.  The table is rewritten in place into the equivalent 3-D inputs; returns the slab thickness
-        (cells on level 0) or None for a 3-D file.  The work is `slab` times that of a true 2-D build."""
+        (cells on level 0) or None for a 3-D file.  The work is `slab` (8 for the default blocking factor) times that of a true 2-D build
+        (DESIGN.md section 7, row J2)."""
         nc = self.table.get("amr.n_cell")
         if nc is None or len(nc) != 2:
             return None
         T = self.table
         nx, ny = int(nc[0]), int(nc[1])
         bf = int(T.get("amr.blocking_factor", ["8"])[0])
+        # one blocking factor thick (the regrid lattice is three-dimensional).  The multigrid solvers coarsen the slab with the plane until
+        # it is two cells thick and keep it at two from there on (IAMRX_MG_SLAB, set by iamr_amd.run for these runs; mlmg.hip
+        # mg_slab_level) -- until round 4 the slab had to be 8 ... 32 cells thick for the hierarchy to reach <= 16 x 16 cells
         slab = max(8, bf)
-        while slab < 32 and min(nx, ny) // slab > 16:          # keep the coarsest multigrid level at <= 16 x 16 cells
-            slab *= 2
         lo = [float(v) for v in T["geometry.prob_lo"][:2]]
         hi = [float(v) for v in T["geometry.prob_hi"][:2]]
         dx = (hi[0] - lo[0]) / nx

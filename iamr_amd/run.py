@@ -25,6 +25,7 @@ def init_level(ns, lay, lib, N, pr, n):
 def build_amr(pr, lib, N, world=1):
     """hierarchy of fixed grids: level 0 chopped by amr.max_grid_size, the refined levels as the grid file gives them"""
     from .amr import Amr
+    lib.tuning_set("MG_SLAB", 1 if pr.get("slab") else 0)      # 2-D run on its slab: the multigrid keeps the slab two cells thick (mlmg.hip mg_slab_level)
     g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
     lays = [lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], world)] + [lib.Layout(b, [q % world for q in range(len(b))]) for b in pr["fine_boxes"]]
     amr = Amr(g0, lays, N.ns_params(**pr["params"]))
@@ -202,6 +203,7 @@ def main_amr(pr, inp, lib, N, rank=0, world=1):
 
 def build(inp, lib, N, nranks=1, pr=None):
     pr = pr if pr is not None else inp.problem()
+    lib.tuning_set("MG_SLAB", 1 if pr.get("slab") else 0)      # 2-D run on its slab: the multigrid keeps the slab two cells thick (mlmg.hip mg_slab_level)
     g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
     lay = lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], nranks)
     ns = N.NavierStokes(g, lay, N.ns_params(**pr["params"]))

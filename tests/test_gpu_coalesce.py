@@ -15,9 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture()
 def merged(gpu):
+    before = gpu.tuning_get("COALESCE", 1)        # the suite's mode (0, or 1 under IAMRX_TEST_COALESCE=1): restored afterwards
     gpu.tuning_set("COALESCE", 1)
     yield gpu
-    gpu.tuning_set("COALESCE", 0)
+    gpu.tuning_set("COALESCE", before)
 
 
 def coalesced(lib, lay):
