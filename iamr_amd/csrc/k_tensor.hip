@@ -248,6 +248,183 @@ __global__ void __launch_bounds__(TX * TY) k_tensor_cross_zm(const BoxD* __restr
     if (normout) tnorm_commit(mx, normout);
 }
 
+// Cell-centred form of the constant-viscosity tensor residual / apply (round 5).  With one face viscosity per direction (eta_x, eta_y,
+// eta_z: AbecCoef::b_uniform) the divergence of the cross fluxes telescopes: the transverse derivative on a face is the mean of two
+// central differences, the difference of two opposite faces leaves a four-point mixed second difference at the cell centre,
+//   C_ab(f) = f(+a, +b) - f(+a, -b) - f(-a, +b) + f(-a, -b),
+// and (cross_flux above, D = 0, 1, 2, summed over the six faces of a cell)
+//   div(cross)_u = q_xy (2/3 eta_x - eta_y) C_xy(v) + q_xz (2/3 eta_x - eta_z) C_xz(w)
+//   div(cross)_v = q_xy (2/3 eta_y - eta_x) C_xy(u) + q_yz (2/3 eta_y - eta_z) C_yz(w)
+//   div(cross)_w = q_xz (2/3 eta_z - eta_x) C_xz(u) + q_yz (2/3 eta_z - eta_y) C_yz(v),      q_ab = 1 / (4 h_a h_b).
+// 24 values and ~30 flops per cell instead of 80 values and ~160 flops for the five face fluxes of k_tensor_cross_zm: the same operator
+// (MLTensorOp with constant shear viscosity, Source/Diffusion.cpp:715-768, 858-923), another summation order -- 1e-12 relative against
+// the oracle's face-flux form (tests/test_gpu_kernel_forms.py), not bit for bit.  The 7-point part keeps k_abec_residual's expression.
+// Staging: a TX x TY column of cells marches through a z-chunk with a FOUR-slot ring of the 3-component velocity tile in LDS -- plane
+// k + 2 is written behind the arithmetic of plane k into the slot of plane k - 2, which nobody reads any more: one barrier per plane.
+struct TensorUniArgs {
+    double alpha, dhx, dhy, dhz;      // a-term factor, beta / h_d^2
+    double b[3][3];                   // b[n][d] = eta_d (n == d ? 4/3 : 1)
+    double cx[3][2];                  // sbeta * q * (2/3 eta - eta) of the two mixed differences of component n (order: see kernel)
+};
+template <int TX, int TY, bool RES, bool HASA>
+__global__ void __launch_bounds__(TX * TY) k_tensor_uni(const BoxD* __restrict__ boxes, const FabD* __restrict__ outt, const FabD* __restrict__ vt,
+    const FabD* __restrict__ rhst, const FabD* __restrict__ at, TensorUniArgs p, unsigned long long* __restrict__ normout,
+    int ntx, int nty, int nkc, int kcs, int xcd_cnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NT = TX * TY, W = TX + 2, H = TY + 2, PS = W * H, NE = (PS + NT - 1) / NT;
+    __shared__ double V[4][3 * PS];
+    const int fab = blockIdx.y;
+    const BoxD b = boxes[fab];
+    double mx = 0.0;
+    int bid = blockIdx.x;
+    bool live = true;
+    if (xcd_cnt > 0) {
+        bid = (bid & 7) * xcd_cnt + (bid >> 3);          // XCD-aware order, see make_tiling
+        if (bid >= ntx * nty * nkc) live = false;
+    }
+    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, kci = r1 / nty;
+    const int tx0 = b.lo[0] + tix * TX, ty0 = b.lo[1] + tiy * TY, k0 = b.lo[2] + kci * kcs;
+    if (tx0 > b.hi[0] || ty0 > b.hi[1] || k0 > b.hi[2]) live = false;
+    if (!live) { if (normout) tnorm_commit(mx, normout); return; }
+    const int k1 = min(k0 + kcs - 1, b.hi[2]);
+    const int tid = threadIdx.x;
+    const int li = tid % TX, lj = tid / TX;
+    const int i = tx0 + li, j = ty0 + lj;
+    const bool on = i <= b.hi[0] && j <= b.hi[1];
+    const FabD out = outt[fab], v = vt[fab];
+    const int vhx = min(tx0 + TX, b.hi[0] + 1), vhy = min(ty0 + TY, b.hi[1] + 1);      // last staged column / row (ghost included)
+    typedef const __attribute__((address_space(1))) char gbyte;
+    auto gat = [](const FabD::gdouble* plane, unsigned byteoff) -> FabD::gdouble& {
+        return *(FabD::gdouble*)((gbyte*)plane + (size_t)byteoff);
+    };
+    // staging elements of this thread: 32-bit byte offsets inside a plane of v (a uniform plane pointer is added per plane)
+    unsigned pfo[NE];
+    bool pfl[NE];
+#pragma unroll
+    for (int s_ = 0; s_ < NE; ++s_) {
+        const int e = tid + s_ * NT;
+        const int ii = tx0 - 1 + e % W, jj = ty0 - 1 + e / W;
+        pfl[s_] = e < PS && ii <= vhx && jj <= vhy;
+        pfo[s_] = pfl[s_] ? 8u * (unsigned)((ii - v.lo[0]) + v.n[0] * (jj - v.lo[1])) : 0u;
+    }
+    const long vks = (long)v.n[0] * v.n[1];
+    double pf[NE][3];
+    auto fetch = [&](int k) {
+        const FabD::gdouble* pl = v.gp() + vks * (k - v.lo[2]);
+#pragma unroll
+        for (int s_ = 0; s_ < NE; ++s_)
+            if (pfl[s_]) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n) pf[s_][n] = gat(pl + v.cs * n, pfo[s_]);
+            }
+    };
+    auto commit = [&](int k) {
+        double* dst = V[(k - k0 + 1) & 3];
+#pragma unroll
+        for (int s_ = 0; s_ < NE; ++s_)
+            if (pfl[s_]) {
+                const int e = tid + s_ * NT;
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dst[e + PS * n] = pf[s_][n];
+            }
+    };
+    fetch(k0 - 1); commit(k0 - 1);
+    fetch(k0); commit(k0);
+    fetch(k0 + 1); commit(k0 + 1);
+    if (k0 + 2 <= k1 + 1) fetch(k0 + 2);
+    // output / right-hand side / a-term: byte offsets of the cell inside a plane
+    const unsigned oo = on ? 8u * (unsigned)((i - out.lo[0]) + out.n[0] * (j - out.lo[1])) : 0u;
+    const long oks = (long)out.n[0] * out.n[1];
+    FabD rh = out, ac = out;
+    unsigned ro = 0, ao = 0;
+    long rks = 0, aks = 0;
+    if constexpr (RES) { rh = rhst[fab]; ro = on ? 8u * (unsigned)((i - rh.lo[0]) + rh.n[0] * (j - rh.lo[1])) : 0u; rks = (long)rh.n[0] * rh.n[1]; }
+    if constexpr (HASA) { ac = at[fab]; ao = on ? 8u * (unsigned)((i - ac.lo[0]) + ac.n[0] * (j - ac.lo[1])) : 0u; aks = (long)ac.n[0] * ac.n[1]; }
+    const int tb = (li + 1) + W * (lj + 1);
+    for (int k = k0; k <= k1; ++k) {
+        double rv[3] = {0., 0., 0.}, av = 0.0;
+        if (on) {
+            if constexpr (RES) {
+                const FabD::gdouble* pr = rh.gp() + rks * (k - rh.lo[2]);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) rv[n] = gat(pr + rh.cs * n, ro);
+            }
+            if constexpr (HASA) av = gat(ac.gp() + aks * (k - ac.lo[2]), ao);
+        }
+        __syncthreads();
+        const int s0 = (k - k0 + 1) & 3;
+        const double* P0 = V[s0] + tb;
+        const double* Pm = V[(s0 + 3) & 3] + tb;
+        const double* Pp = V[(s0 + 1) & 3] + tb;
+        if (on) {
+            // mixed differences: u -> (C_xy, C_xz), v -> (C_xy, C_yz), w -> (C_xz, C_yz)
+            const double cxy_u = (P0[W + 1] - P0[-W + 1]) - (P0[W - 1] - P0[-W - 1]);
+            const double cxz_u = (Pp[1] - Pm[1]) - (Pp[-1] - Pm[-1]);
+            const double cxy_v = (P0[PS + W + 1] - P0[PS - W + 1]) - (P0[PS + W - 1] - P0[PS - W - 1]);
+            const double cyz_v = (Pp[PS + W] - Pm[PS + W]) - (Pp[PS - W] - Pm[PS - W]);
+            const double cxz_w = (Pp[2 * PS + 1] - Pm[2 * PS + 1]) - (Pp[2 * PS - 1] - Pm[2 * PS - 1]);
+            const double cyz_w = (Pp[2 * PS + W] - Pm[2 * PS + W]) - (Pp[2 * PS - W] - Pm[2 * PS - W]);
+            const double cr[3] = { p.cx[0][0] * cxy_v + p.cx[0][1] * cxz_w, p.cx[1][0] * cxy_u + p.cx[1][1] * cyz_w, p.cx[2][0] * cxz_u + p.cx[2][1] * cyz_v };
+            FabD::gdouble* po = out.gp() + oks * (k - out.lo[2]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const double c0 = P0[PS * n];
+                const double ax = HASA ? p.alpha * av * c0 : 0.0;
+                const double y = ax
+                    - p.dhx * (p.b[n][0] * (P0[PS * n + 1] - c0) - p.b[n][0] * (c0 - P0[PS * n - 1]))
+                    - p.dhy * (p.b[n][1] * (P0[PS * n + W] - c0) - p.b[n][1] * (c0 - P0[PS * n - W]))
+                    - p.dhz * (p.b[n][2] * (Pp[PS * n] - c0) - p.b[n][2] * (c0 - Pm[PS * n]));
+                const double base = RES ? rv[n] - y : y;
+                const double o = base + cr[n];
+                gat(po + out.cs * n, oo) = o;
+                const double ab = fabs(o);
+                mx = fmax(mx, ab == ab ? ab : INFINITY);
+            }
+        }
+        // plane k + 2 into the slot of plane k - 2 (every wavefront is past this plane's barrier, i.e. done with plane k - 1's arithmetic)
+        if (k + 2 <= k1 + 1) {
+            commit(k + 2);
+            if (k + 3 <= k1 + 1) fetch(k + 3);
+        }
+    }
+    if (normout) tnorm_commit(mx, normout);
+#endif
+}
+
+template <int TX, int TY>
+static void tensor_uni_launch(const Layout& l, const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, const MultiFab* rhs,
+                              unsigned long long* d_norm)
+{
+    const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
+    const int kcs_t = (int)tune("TENSOR_UNI_KC", 0);
+    const int kcs = kcs_t > 0 ? kcs_t : std::min(32, std::max(4, l.max_len[2] / 8));
+    const int nkc = (l.max_len[2] + kcs - 1) / kcs;
+    const int total = ntx * nty * nkc;
+    const int xcd_cnt = total >= 64 ? (total + 7) / 8 : 0;
+    dim3 grid((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : total), (unsigned)l.nlocal());
+    TensorUniArgs p;
+    const bool hasa = c.a && c.alpha != 0.0;
+    const double sbeta = (rhs ? -1.0 : 1.0) * c.beta;
+    const double hi[3] = {1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]};
+    p.alpha = c.alpha;
+    p.dhx = c.beta / (g.dx[0] * g.dx[0]); p.dhy = c.beta / (g.dx[1] * g.dx[1]); p.dhz = c.beta / (g.dx[2] * g.dx[2]);
+    for (int n = 0; n < 3; ++n)
+        for (int d = 0; d < 3; ++d) p.b[n][d] = c.bu[d] * (n == d ? 4.0 / 3.0 : 1.0);
+    // component n, its two partner directions (a < b, both != n): mixed difference in the plane (n, a) of component a, in (n, b) of component b
+    for (int n = 0; n < 3; ++n) {
+        const int a = n == 0 ? 1 : 0, bq = n == 2 ? 1 : 2;
+        p.cx[n][0] = sbeta * (0.25 * hi[n] * hi[a]) * ((2.0 / 3.0) * c.bu[n] - c.bu[a]);
+        p.cx[n][1] = sbeta * (0.25 * hi[n] * hi[bq]) * ((2.0 / 3.0) * c.bu[n] - c.bu[bq]);
+    }
+    auto& ctx = Context::get();
+#define IAMRX_TU(R, A) hipLaunchKernelGGL((k_tensor_uni<TX, TY, R, A>), grid, dim3(TX * TY), 0, ctx.stream, l.d_boxes, out.d_tab, vel.d_tab, \
+                                          rhs ? rhs->d_tab : nullptr, hasa ? c.a->d_tab : nullptr, p, d_norm, ntx, nty, nkc, kcs, xcd_cnt)
+    if (rhs) { if (hasa) IAMRX_TU(true, true); else IAMRX_TU(true, false); }
+    else { if (hasa) IAMRX_TU(false, true); else IAMRX_TU(false, false); }
+#undef IAMRX_TU
+}
+
 // out = (rhs - A vel | A vel) for the constant-viscosity tensor operator in one launch (k_tensor_cross_zm<.., FUSE>); false: not applicable,
 // the caller runs abec_residual (7-point part, then tensor_cross_terms_sub).  norm_out as in abec_residual.
 bool tensor_residual_fused(const Geometry& g, const AbecCoef& c, MultiFab& out, const MultiFab& vel, const MultiFab* rhs, double* norm_out)
@@ -260,6 +437,18 @@ bool tensor_residual_fused(const Geometry& g, const AbecCoef& c, MultiFab& out, 
     if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, 2 * sizeof(unsigned long long)));
     if (out.nlocal() > 0) {
         if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
+        // the cell-centred form (k_tensor_uni) unless IAMRX_TENSOR_UNI_CC = 0 asks for the face-flux form
+        const int cc = (int)tune("TENSOR_UNI_CC", 1);
+        if (cc != 0) {
+            unsigned long long* dn = norm_out ? d_norm : nullptr;
+            switch (cc) {
+            case 2: tensor_uni_launch<32, 16>(l, g, c, out, vel, rhs, dn); break;
+            case 3: tensor_uni_launch<64, 8>(l, g, c, out, vel, rhs, dn); break;
+            case 4: tensor_uni_launch<64, 4>(l, g, c, out, vel, rhs, dn); break;
+            case 5: tensor_uni_launch<16, 16>(l, g, c, out, vel, rhs, dn); break;
+            default: tensor_uni_launch<32, 8>(l, g, c, out, vel, rhs, dn); break;
+            }
+        } else {
         constexpr int TX = 32, TY = 8;
         const int ntx = (l.max_len[0] + TX - 1) / TX, nty = (l.max_len[1] + TY - 1) / TY;
         const int kcs = std::min(32, std::max(4, l.max_len[2] / 8));
@@ -277,6 +466,7 @@ bool tensor_residual_fused(const Geometry& g, const AbecCoef& c, MultiFab& out, 
         hipLaunchKernelGGL((k_tensor_cross_zm<true, TX, TY, true, true>), grid, dim3(TX * TY), 0, ctx.stream, l.d_boxes, out.d_tab, vel.d_tab,
                            c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], (rhs ? -1.0 : 1.0) * c.beta,
                            norm_out ? d_norm : nullptr, ntx, nty, nkc, kcs, xcd_cnt, eu, fa);
+        }
     }
     if (norm_out) {
         double v = 0.0;

@@ -108,3 +108,49 @@ def test_fused_equals_multipass(gpu, n, boxes, periodic, fit, scheme, tile):
     for d in range(3):
         close(out[1][1][d], out[0][1][d], ("edge", d))
         close(out[1][2][d], out[0][2][d], ("flux", d))
+
+
+@pytest.mark.parametrize("n,boxes", [((72, 40, 48), None), ((64, 32, 64), 32)])
+def test_split_bc_launches_equal_one_launch(gpu, n, boxes):
+    """domain with walls: the tiles no boundary condition reaches run the plain code in a launch of their own (GODUNOV_SPLIT_BC = 1, thin
+    first / last z-chunks), the boundary-condition variant takes the rest -- the one launch of the variant over all tiles to 1e-13 (two
+    instantiations of the kernel: FMA contraction differs between their instruction streams; bit for bit in a STRICT_FP=1 build)"""
+    lib = gpu
+    periodic = (0, 1, 0)
+    g = lib.Geom.make(n, periodic=periodic)
+    lay = lib.Layout.decompose(n, boxes) if boxes else lib.Layout.single(n)
+    S = lib.MultiFab(lay, lib.CELL, 5, 3)
+    S.set_from_global(np.stack([(1.5 if c >= 3 else 0.0) + smooth(n, 3, 10 + c) for c in range(5)], axis=-1), (-3, -3, -3))
+    S.fill_boundary(g)
+    S.fill_physbc(g, WALL_BC5, [[0.1 * (c + 1)] * 3 for c in range(5)], [[-0.05 * (c + 1)] * 3 for c in range(5)])
+    frc = lib.MultiFab(lay, lib.CELL, 5, 1)
+    frc.set_from_global(np.stack([2.0 * smooth(n, 1, 30 + c) for c in range(5)], axis=-1), (-1, -1, -1))
+    divu = lib.MultiFab(lay, lib.CELL, 1, 1)
+    divu.set_from_global(0.3 * smooth(n, 1, 50)[..., None], (-1, -1, -1))
+    mac = []
+    for d in range(3):
+        m = lib.MultiFab(lay, lib.face(d), 1, 1)
+        m.set_from_global(smooth(n, 1, 70 + d, lib.face(d))[..., None], (-1, -1, -1))
+        mac.append(m)
+    dt = 0.4 / max(n)
+    res = {}
+    old = lib.tuning_get("GODUNOV_SPLIT_BC", 1)
+    try:
+        for split in (0, 1):
+            lib.tuning_set("GODUNOV_SPLIT_BC", split)
+            um = [lib.MultiFab(lay, lib.face(d), 1, 1) for d in range(3)]
+            for m in um:
+                m.setval(0.0)
+            lib.godunov_extrap_vel_to_faces(g, S, frc, um, dt, WALL_BC5[:3], 1, scheme=0)
+            aofs = lib.MultiFab(lay, lib.CELL, 5, 0)
+            edge = [lib.MultiFab(lay, lib.face(d), 5, 0) for d in range(3)]
+            lib.godunov_compute_aofs(g, aofs, 0, S, 5, frc, divu, mac, (0, 0, 0, 1, 0), dt, WALL_BC5, 1, 1, edge=edge, scheme=0)
+            res[split] = [m.gather_valid(n) for m in um] + [aofs.gather_valid(n)] + [e.gather_valid(n) for e in edge]
+    finally:
+        lib.tuning_set("GODUNOV_SPLIT_BC", old)
+    strict = os.environ.get("IAMRX_STRICT_FP") == "1"
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        if strict:
+            assert np.array_equal(a, b), i
+        else:
+            close(b, a, ("split", i))
