@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--amr-n", type=int, default=256, help="base-level cells per direction of the secondary 2-level AMR workload (0: skip)")
     ap.add_argument("--amr-steps", type=int, default=3)
+    ap.add_argument("--c3-n", type=int, default=512, help="base cells per direction of the secondary DoubleShearLayer 2D workload (config C3; 0: skip)")
+    ap.add_argument("--c3-steps", type=int, default=3, help="timed coarse steps of the C3 workload")
     ap.add_argument("--ldc-steps", type=int, default=4, help="timed steps of the secondary LidDrivenCavity workload at --n^3 (single GPU; 0: skip)")
     ap.add_argument("--no-shard-proxy", action="store_true", help="skip the single-GPU proxies of the per-GPU work of an 8-GPU run (8 boxes of --n^3 kept as boxes)")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -269,6 +271,41 @@ def ldc_workload(lib, n, steps):
             "cells_per_sec": float(n) ** 3 / ms * 1e3, "steps": steps,
             "mlmg_iters": {"mac_cc": sm.iters, "nodal": sn.iters, "tensor_visc": sv.iters},
             "mlmg_vcycle_ms": {"mac_cc": sm.vcycle_ms, "nodal": sn.vcycle_ms, "tensor_visc": sv.vcycle_ms}}
+
+
+def c3_workload(lib, n, steps):
+    """BASELINE config C3: DoubleShearLayer 2D, n x n base + one refined level (ratio 2) that follows the vorticity of the shear layers,
+    regridded at the start of every coarse step (regrid + SyncRegister path).  The library is three-dimensional: the 2-D inputs file runs as
+    a y-periodic slab one blocking factor (8 cells) thick (iamr_amd/inputs.py lift_2d), whose multigrid levels keep the slab at two cells
+    (IAMRX_MG_SLAB) -- the figure quotes 2-D cells: cell updates of the plane per second, the slab's 8x redundant work included in the time."""
+    from iamr_amd import ns as NS, run as R
+    from iamr_amd.inputs import Inputs
+    inp = Inputs([os.path.join(ROOT, "tests", "golden", "inputs.2d.doubleshearlayer_c3")],
+                 [f"amr.n_cell={n} {n}", f"max_step={steps + 1}", "proj.proj_tol=1.0e-10"])
+    pr = inp.problem()
+    amr, lays, g0 = R.build_amr(pr, lib, NS, 1)
+    amr.post_init(pr["stop_time"])
+    amr.coarse_step()
+    lib.sync()
+    cells2d = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        amr.coarse_step()
+        slab0 = pr["n"][1]
+        cells2d += sum(b_npts(lo, hi) for lo, hi in amr.layouts[0].boxes) // slab0
+        if amr.nlev > 1:
+            cells2d += 2 * sum(b_npts(lo, hi) for lo, hi in amr.layouts[1].boxes) // (2 * slab0)
+    lib.sync()
+    el = time.perf_counter() - t0
+    lib.tuning_set("MG_SLAB", 0)
+    fine = sum(b_npts(lo, hi) for lo, hi in amr.layouts[1].boxes) // (2 * pr["n"][1]) if amr.nlev > 1 else 0
+    return {"workload": "DoubleShearLayer 2D (config C3), %d^2 base + one refined level (ratio 2, vorticity tags, regrid every step) as a y-periodic slab of %d cells with slab multigrid levels"
+                        % (n, pr["n"][1]), "ms_per_coarse_step": el / steps * 1e3, "cells2d_per_sec": cells2d / el, "steps": steps,
+            "levels": amr.nlev, "grids": [len(l.boxes) for l in amr.layouts], "fine_level_cells2d": fine, "fine_level_cover": fine / float(4 * n * n)}
+
+
+def b_npts(lo, hi):
+    return (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1)
 
 
 def amr_workload(lib, n0, steps, rank=0, world=1, dist=None, layout_gpus=None, keep=None):
@@ -699,6 +736,11 @@ def main():
                 out["lid_driven_cavity"] = ldc_workload(lib, n, a.ldc_steps)
             except Exception as e:                      # a secondary figure must not take the bench line with it
                 out["lid_driven_cavity"] = {"error": str(e)[:200]}
+        if world == 1 and a.c3_n > 0:
+            try:
+                out["double_shear_layer_2d"] = c3_workload(lib, a.c3_n, a.c3_steps)
+            except Exception as e:
+                out["double_shear_layer_2d"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))

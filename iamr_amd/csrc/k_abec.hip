@@ -1040,16 +1040,14 @@ bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& p
 }
 
 // one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
-void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                  const DomainBC* bcs, int nbc)
+template <int NW>
+static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                            const DomainBC* bcs, int nbc)
 {
-    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
     const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
-    if (pin.nlocal() == 0) return;
     auto& ctx = Context::get();
     const Layout& l = *pin.layout;
     const BoxD b = l.boxes[l.local[0]];
-    constexpr int NW = 16;
     const int wpr = b.len(0) / 128, rw = NW / wpr;
     const int nty = (b.len(1) + (rw - 2) - 1) / (rw - 2);
     // z-chunks: one round of workgroups (one 1024-thread workgroup per CU)
@@ -1080,6 +1078,18 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
 #undef IAMRX_RB
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
+}
+void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                  const DomainBC* bcs, int nbc)
+{
+    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
+    if (pin.nlocal() == 0) return;
+    // The density form on a domain with walls needs more than the 128 VGPRs a 1024-thread workgroup leaves a thread (72 bytes of scratch per
+    // lane, 210 us per 256^3 sweep): 12 wavefronts (768 threads: 168 VGPRs) trade two of the eight rows of a tile for a spill-free loop
+    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+    const int wpr = pin.layout->boxes[pin.layout->local[0]].len(0) / 128;
+    if (walls && c.sig && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc);
+    else abec_gsrb_rb_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc);
 }
 
 // the sweep of this level can be issued in two parts -- the tiles that read no ghost cell (sel 1) and the others (sel 2, behind the exchange):

@@ -179,3 +179,14 @@ def test_plot_variable_selection():
     inp.table, inp.used, inp.ignored = parse_text("amr.plot_vars = density tracer\namr.derive_plot_vars = ALL\n"), set(), []
     assert inp.name_list("amr.plot_vars", "ALL") == ["density", "tracer"] and inp.name_list("amr.derive_plot_vars", "NONE") == "ALL"
     assert inp.name_list("amr.absent", "NONE") == "NONE"
+
+
+def test_c3_inputs_lift_onto_the_slab():
+    """tests/golden/inputs.2d.doubleshearlayer_c3 (bench.py's config C3 line): a 2-D file -> x, slab (y, periodic, 8 cells), z"""
+    import os
+    from iamr_amd.inputs import Inputs
+    inp = Inputs([os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs.2d.doubleshearlayer_c3")], ["amr.n_cell=512 512"])
+    pr = inp.problem()
+    assert pr["n"] == [512, 8, 512] and pr["slab"] == 8 and pr["periodic"] == [1, 1, 1]
+    assert pr["regrid"]["max_level"] == 1 and pr["regrid"]["regrid_int"] == 1 and pr["prob"]["probtype"] == 5
+    assert abs(pr["prob_hi"][1] - 8 * 2.0 / 512) < 1e-15

@@ -165,3 +165,14 @@ def test_c3_full_size_slab_properties(gpu):
         assert cov[ic - 4:ic + 4, :].all()
     assert not cov[2 * n // 2 - 32:2 * n // 2 + 32, :].any() and not cov[:32, :].any()
     assert 0.02 < cov.mean() < 0.5
+
+
+def test_c3_bench_workload_from_the_2d_inputs(gpu):
+    """bench.py's C3 line at a small size: the committed 2-D inputs (tests/golden/inputs.2d.doubleshearlayer_c3) lifted onto its 8-cell
+    slab with slab multigrid levels, two levels, regrid every step -- the run completes on two levels and reports the plane's cells"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.c3_workload(gpu, 128, 2)
+    assert r["levels"] == 2 and r["fine_level_cells2d"] > 0 and 0.01 < r["fine_level_cover"] < 0.6, r
+    assert r["cells2d_per_sec"] > 0 and gpu.tuning_get("MG_SLAB", 0) == 0
