@@ -103,6 +103,19 @@ struct GsrbBC {
 
 // Lagrange weights for ghost-cell extrapolation through a Dirichlet face (AMReX poly_interp_coeff):
 // points x = {0 (face), 0.5, 1.5, 2.5}, evaluated at -0.5
+// Walls handled INSIDE the colour-pass kernels (k_abec_gsrb, k_abec_gsrb1) on a level that is one box spanning its domain: the value beyond a
+// domain face is k_abec_bc's homogeneous ghost formula on the values at hand, g = p0 c1 (+ p_in c2: Dirichlet of order 3; p_in = the cell's
+// neighbour on the inner side), so no ghost cell of phi is read in a non-periodic direction and the k_abec_bc launch in front of every colour
+// pass of a smoothing call goes (LidDrivenCavity 256^3: ~770 launches of ~5.5 us per step on the coarse levels of the MAC, tensor and scalar
+// solves).  A ghost fill between the colours sees the cell at the wall with its old value and the inner neighbour (other colour) current --
+// exactly what the pass itself holds.  on = 0: the ghost cells are read (filled by the caller).  [comp][dir]
+struct WallK { int on; int per[3]; double c1lo[3][3], c2lo[3][3], c1hi[3][3], c2hi[3][3]; };
+__device__ __forceinline__ double wallk_ghost(double p0, double pin, double c1, double c2)
+{
+    double g = p0 * c1;
+    if (c2 != 0.0) g += pin * c2;
+    return g;
+}
 static void poly_interp_coeff(double xi, const double* x, int N, double* c)
 {
     for (int j = 0; j < N; ++j) {
@@ -155,7 +168,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap,
-    const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni())
+    const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni(), WallK wk = WallK())
 {
     constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
     const int fab = blockIdx.y;
@@ -211,10 +224,16 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double bzm = (one ? b1zm : bZ(i, j, k, n)) * sz, bzp = (one ? b1zp : bZ(i, j, k + 1, n)) * sz;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
-            const double rho = dhx * (bxm * phi(im, j, k, n) + bxp * phi(ip, j, k, n))
-                             + dhy * (bym * phi(i, jm, k, n) + byp * phi(i, jp, k, n))
-                             + dhz * (bzm * phi(i, j, km, n) + bzp * phi(i, j, kp, n));
             const double p0 = phi(i, j, k, n);
+            double pxm = phi(im, j, k, n), pxp = phi(ip, j, k, n), pym = phi(i, jm, k, n), pyp = phi(i, jp, k, n), pzm = phi(i, j, km, n), pzp = phi(i, j, kp, n);
+            if (wk.on) {
+                if (!wk.per[0]) { if (i == bc.dlo[0]) pxm = wallk_ghost(p0, pxp, wk.c1lo[nq][0], wk.c2lo[nq][0]); if (i == bc.dhi[0]) pxp = wallk_ghost(p0, pxm, wk.c1hi[nq][0], wk.c2hi[nq][0]); }
+                if (!wk.per[1]) { if (j == bc.dlo[1]) pym = wallk_ghost(p0, pyp, wk.c1lo[nq][1], wk.c2lo[nq][1]); if (j == bc.dhi[1]) pyp = wallk_ghost(p0, pym, wk.c1hi[nq][1], wk.c2hi[nq][1]); }
+                if (!wk.per[2]) { if (k == bc.dlo[2]) pzm = wallk_ghost(p0, pzp, wk.c1lo[nq][2], wk.c2lo[nq][2]); if (k == bc.dhi[2]) pzp = wallk_ghost(p0, pzm, wk.c1hi[nq][2], wk.c2hi[nq][2]); }
+            }
+            const double rho = dhx * (bxm * pxm + bxp * pxp)
+                             + dhy * (bym * pym + byp * pyp)
+                             + dhz * (bzm * pzm + bzp * pzp);
             const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
             phi(i, j, k, n) = p0 + omega / g_m_d * res;
         }
@@ -260,10 +279,16 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double aa = has_a ? alpha * A(i, j, k, 0) : 0.0;
             const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
-            const double rho = dhx * (bxm * phi(im, j, k, n) + bxp * phi(ip, j, k, n))
-                             + dhy * (bym * phi(i, jm, k, n) + byp * phi(i, jp, k, n))
-                             + dhz * (bzm * phi(i, j, km, n) + bzp * phi(i, j, kp, n));
             const double p0 = phi(i, j, k, n);
+            double pxm = phi(im, j, k, n), pxp = phi(ip, j, k, n), pym = phi(i, jm, k, n), pyp = phi(i, jp, k, n), pzm = phi(i, j, km, n), pzp = phi(i, j, kp, n);
+            if (wk.on) {
+                if (!wk.per[0]) { if (i == bc.dlo[0]) pxm = wallk_ghost(p0, pxp, wk.c1lo[nq][0], wk.c2lo[nq][0]); if (i == bc.dhi[0]) pxp = wallk_ghost(p0, pxm, wk.c1hi[nq][0], wk.c2hi[nq][0]); }
+                if (!wk.per[1]) { if (j == bc.dlo[1]) pym = wallk_ghost(p0, pyp, wk.c1lo[nq][1], wk.c2lo[nq][1]); if (j == bc.dhi[1]) pyp = wallk_ghost(p0, pym, wk.c1hi[nq][1], wk.c2hi[nq][1]); }
+                if (!wk.per[2]) { if (k == bc.dlo[2]) pzm = wallk_ghost(p0, pzp, wk.c1lo[nq][2], wk.c2lo[nq][2]); if (k == bc.dhi[2]) pzp = wallk_ghost(p0, pzm, wk.c1hi[nq][2], wk.c2hi[nq][2]); }
+            }
+            const double rho = dhx * (bxm * pxm + bxp * pxp)
+                             + dhy * (bym * pym + byp * pyp)
+                             + dhz * (bzm * pzm + bzp * pzp);
             const double res = rhs(i, j, k, n) - (gamma * p0 - rho);
             const double pn = p0 + omega / g_m_d * res;
             phi(i, j, k, n) = pn;
@@ -290,7 +315,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
-    const FabD* __restrict__ cfmt, CfC1 cfc, int zero)
+    const FabD* __restrict__ cfmt, CfC1 cfc, int zero, WallK wk = WallK())
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -321,6 +346,11 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
             o.pxm = phi(im, j, k, 0); o.pxp = phi(ip, j, k, 0);
             o.pym = phi(i, jm, k, 0); o.pyp = phi(i, jp, k, 0);
             o.pzm = phi(i, j, km, 0); o.pzp = phi(i, j, kp, 0);
+            if (wk.on) {          // walls inside the kernel (WallK): the ghost formula on the values just read
+                if (!wk.per[0]) { if (i == bc.dlo[0]) o.pxm = wallk_ghost(o.pc, o.pxp, wk.c1lo[0][0], wk.c2lo[0][0]); if (i == bc.dhi[0]) o.pxp = wallk_ghost(o.pc, o.pxm, wk.c1hi[0][0], wk.c2hi[0][0]); }
+                if (!wk.per[1]) { if (j == bc.dlo[1]) o.pym = wallk_ghost(o.pc, o.pyp, wk.c1lo[0][1], wk.c2lo[0][1]); if (j == bc.dhi[1]) o.pyp = wallk_ghost(o.pc, o.pym, wk.c1hi[0][1], wk.c2hi[0][1]); }
+                if (!wk.per[2]) { if (k == bc.dlo[2]) o.pzm = wallk_ghost(o.pc, o.pzp, wk.c1lo[0][2], wk.c2lo[0][2]); if (k == bc.dhi[2]) o.pzp = wallk_ghost(o.pc, o.pzm, wk.c1hi[0][2], wk.c2hi[0][2]); }
+            }
         }
         o.r = rhs(i, j, k, 0);
         o.a = has_a ? A(i, j, k, 0) : 0.0;
@@ -1177,10 +1207,50 @@ bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wra
     return tune("GSRB_ZERO", 1) != 0 && tune("GSRB1_NP", 1) > 0 && wrap && !has_cf && phi.ncomp == 1 && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta;
 }
 
-void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
-               bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts, bool phi_is_zero)
+// the colour passes of this level can apply the domain walls themselves (WallK): one box spanning a domain with non-periodic sides whose
+// boundary conditions the two-weight ghost formula covers, and a dispatch of abec_gsrb that ends in k_abec_gsrb / k_abec_gsrb1.  The caller
+// then fills periodic ghost cells only (if any) and passes walls_inkernel = true.  Rank-independent.
+bool abec_gsrb_walls_inkernel_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs, bool cf)
 {
-    IAMRX_ASSERT(!phi_is_zero || (!shell_only && abec_gsrb_zero_ok(c, phi, nbc, wrap, cfm != nullptr)));
+    if (tune("GSRB_WALLS_INKERNEL", 1) == 0 || cf || !bcs || nbc < 1 || phi.ncomp > 3 || phi.ngrow < 1) return false;
+    const Layout& l = *phi.layout;
+    if (l.boxes.size() != 1) return false;
+    const BoxD& b = l.boxes[0];
+    bool walls = false;
+    for (int d = 0; d < 3; ++d) {
+        if (b.lo[d] != g.domain.lo[d] || b.hi[d] != g.domain.hi[d] || b.len(d) < 2) return false;
+        if (!g.periodic[d]) walls = true;
+    }
+    if (!walls) return false;
+    for (int n = 0; n < phi.ncomp; ++n) { RbBC r; if (!rb_make_bc(g, bcs[n < nbc ? n : 0], r)) return false; }
+    // abec_gsrb's dispatch (below): the pair-marching kernels read the ghost cells
+    const bool uni = c.b_uniform && c.b[0]->ncomp == 1 && abec_sig_on();
+    const int np = (int)tune("GSRB1_NP", 1);
+    const int mode = (c.sig && abec_sig_on()) ? 1 : (uni ? 2 : 0);
+    const bool pair_ok = mode != 0 && tune("GSRB2", 1) != 0 && phi.ngrow >= 1 && (mode == 2 || c.sig->ngrow >= 1);
+    if (np > 0 && phi.ncomp == 1 && nbc == 1 && c.b[0]->ncomp == 1 && !c.tensor_eta) return !pair_ok;
+    if (uni && phi.ncomp > 1 && c.b[0]->ncomp == 1 && phi.ngrow >= 1 && tune("GSRB2", 1) != 0 && tune("GSRB2_MULTI", 0) != 0) return false;
+    return true;
+}
+
+void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
+               bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts, bool phi_is_zero, bool walls_inkernel)
+{
+    WallK wk;
+    wk.on = 0;
+    if (walls_inkernel) {
+        IAMRX_ASSERT(!shell_only && !wrap && abec_gsrb_walls_inkernel_ok(g, c, phi, nbc, bcs, cfm != nullptr));
+        wk.on = 1;
+        for (int n = 0; n < 3; ++n) {
+            RbBC r;
+            rb_make_bc(g, bcs[n < nbc ? n : 0], r);
+            for (int d = 0; d < 3; ++d) {
+                wk.per[d] = r.per[d];
+                wk.c1lo[n][d] = r.c1lo[d]; wk.c2lo[n][d] = r.c2lo[d]; wk.c1hi[n][d] = r.c1hi[d]; wk.c2hi[n][d] = r.c2hi[d];
+            }
+        }
+    }
+    IAMRX_ASSERT(!phi_is_zero || (!shell_only && abec_gsrb_zero_ok(c, phi, nbc, wrap || walls_inkernel, cfm != nullptr)));
     const int zero = phi_is_zero ? 1 : 0;
     CfC1 cfc;
     cfc.maxorder = cftab ? cftab->maxorder : 2;
@@ -1210,7 +1280,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
         const FabD *t0 = mode == 1 ? c.sig->d_tab : c.b[0]->d_tab, *t1 = mode == 1 ? c.sig->d_tab : c.b[1]->d_tab, *t2 = mode == 1 ? c.sig->d_tab : c.b[2]->d_tab;
 #define IAMRX_GS1(M, N) if (cft) IAMRX_GS1C(M, 1, true); else IAMRX_GS1C(M, N, false)
 #define IAMRX_GS1C(M, N, C) hipLaunchKernelGGL((k_abec_gsrb1<M, N, C>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab, \
-                           c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero)
+                           c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero, wk)
         // IAMRX_GSRB2 (1): the pair-marching kernel where the coefficients are not arrays (needs a ghost layer for its 16-byte loads)
         if (pair_ok) {
             int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
@@ -1248,7 +1318,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     else if (phi.ncomp == 1 && c.sig && !c.tensor_eta && abec_sig_on())
         hipLaunchKernelGGL((k_abec_gsrb<false, 1>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.sig->d_tab, c.sig->d_tab, c.sig->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, 1, 1, gb, shell_only ? 1 : 0, 0, wrap ? 1 : 0, cft, cfc, c.sig_comp, c.sig_scale);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, 1, 1, gb, shell_only ? 1 : 0, 0, wrap ? 1 : 0, cft, cfc, c.sig_comp, c.sig_scale, BUni(), wk);
     else if (uni && phi.ncomp > 1 && !shell_only && c.b[0]->ncomp == 1 && phi.ngrow >= 1 && tune("GSRB2", 1) != 0 && tune("GSRB2_MULTI", 0) != 0) {
         // IAMRX_GSRB2_MULTI = 1 (off by default: measured equal, 3 x 112 us against 336 us at 256^3 -- both forms move the half-used lines of
         // the red-black layout at the achievable HBM rate): several components with constant coefficients (the tensor solves of a
@@ -1269,19 +1339,19 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     else if (uni && phi.ncomp > 1)
         hipLaunchKernelGGL((k_abec_gsrb<true, 2>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu, wk);
     else if (uni)
         hipLaunchKernelGGL((k_abec_gsrb<false, 2>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, 1, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, bu, wk);
     else if (phi.ncomp > 1 && c.b[0]->ncomp == 1)
         hipLaunchKernelGGL((k_abec_gsrb<true, 0>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, BUni(), wk);
     else
         hipLaunchKernelGGL((k_abec_gsrb<false, 0>), t.grid(), Tiling::block(), 0, ctx.stream, t, l.d_boxes, phi.d_tab, rhs.d_tab,
                            c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab,
-                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc);
+                           c.alpha, dhx, dhy, dhz, redblack, omega, phi.ncomp, c.b[0]->ncomp, gb, shell_only ? 1 : 0, c.tensor_eta, wrap ? 1 : 0, cft, cfc, 0, 1.0, BUni(), wk);
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 

@@ -85,7 +85,10 @@ void cf_interp_bndry(MultiFab& bcval, const MultiFab& cpatch, const MultiFab& cf
 // bcs: nbc DomainBC entries (nbc == 1: same BC for all components; nbc == ncomp: one per component, MLTensorOp::setDomainBC)
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc,
                bool shell_only = false, bool wrap = false, const MultiFab* cfm = nullptr, const CfTab* cftab = nullptr, bool cf_maintain_ghosts = false,
-               bool phi_is_zero = false);
+               bool phi_is_zero = false, bool walls_inkernel = false);
+// walls_inkernel: the pass applies the homogeneous domain boundary conditions itself (no ghost cell of phi is read in a non-periodic direction:
+// the caller fills periodic ghost cells only) -- allowed where this returns true
+bool abec_gsrb_walls_inkernel_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs, bool cf);
 // phi_is_zero: the pass may be told that phi is identically zero (the first pass on a multigrid correction) INSTEAD of phi being set to
 // zero in front of it -- it then reads no phi and writes every cell (the active colour its update, the other colour zero) -- if this returns
 // true for the same arguments (one component, one-component coefficients, one box spanning a periodic domain: no ghost cell is read)

@@ -297,7 +297,10 @@ bool CellMG::zero_first_pass_ok(int l, const MultiFab& sol) const
     if (m_dd_sweeps > 0 || fused_smoother_ok(l)) return false;
     AbecCoef c = coef(l);
     const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
-    return abec_gsrb_zero_ok(c, sol, (int)m_bcn.size(), wrap, m_cf);
+    // (walls applied inside the colour passes: the first pass from zero reads no ghost cell either)
+    c.tensor = 0;
+    const bool wk = !wrap && abec_gsrb_walls_inkernel_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data(), m_cf);
+    return abec_gsrb_zero_ok(c, sol, (int)m_bcn.size(), wrap || wk, m_cf);
 }
 
 void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current, bool sol_is_zero)
@@ -307,8 +310,13 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, b
     // one box spanning a fully periodic domain: the kernel reads the periodic images from the valid cells, no ghost fills
     const bool wrap = !m_cf && periodic_wrap_ok(m_lev[l].g, *m_lev[l].layout, 2);
     const bool maint = m_cf && m_ncomp == 1 && !m_tensor && cf_maintain_on();
+    // one box spanning a domain with walls: the colour passes apply the wall conditions themselves (WallK, k_abec.hip) -- no k_abec_bc launch
+    // in front of a pass; periodic directions (if any) keep their ghost fill
+    const bool wk = !wrap && abec_gsrb_walls_inkernel_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data(), m_cf);
+    const bool wk_per = wk && (m_lev[l].g.periodic[0] || m_lev[l].g.periodic[1] || m_lev[l].g.periodic[2]);
     for (int rb = 0; rb < 2; ++rb) {
-        if (!skip_fill && !wrap) {
+        if (wk) { if (!skip_fill && wk_per) sol.FillBoundary(m_lev[l].g); }
+        else if (!skip_fill && !wrap) {
             if (maint && (cf_ghosts_current || rb == 1)) {        // everything but the coarse/fine ghost cells
                 sol.FillBoundary(m_lev[l].g);
                 abec_apply_domain_bc(m_lev[l].g, sol, m_bcn[0], false, nullptr);
@@ -317,7 +325,7 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, b
         // diagonally dominant shortcut: plain Gauss-Seidel -- over-relaxation leaves a (1 - omega) = 0.15 floor per sweep on an operator
         // that is almost its diagonal, where omega = 1 contracts by the square of the Jacobi factor
         abec_gsrb(m_lev[l].g, c, sol, rhs, rb, m_dd_sweeps > 0 ? dd_omega() : m_o.omega, m_bcn.data(), (int)m_bcn.size(), false, wrap, m_cf ? &m_lev[l].cfm : nullptr,
-                  m_cf ? &m_lev[l].cftab : nullptr, maint, sol_is_zero && rb == 0);
+                  m_cf ? &m_lev[l].cftab : nullptr, maint, sol_is_zero && rb == 0, wk);
         skip_fill = false;
     }
 }
