@@ -79,7 +79,7 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
     amr.post_init()
     oa.post_init()
     had_three = False
-    for step in range(4):
+    for step in range(3):              # (three coarse steps: the oracle's share of the GPU suite's time budget)
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
@@ -111,7 +111,7 @@ def test_rayleigh_taylor_physics_with_regridding():
     amr.post_init()
     oa.post_init()
     changes = 0
-    for step in range(3):
+    for step in range(2):
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
@@ -141,7 +141,7 @@ def test_regrid_that_starts_above_level_zero():
     amr.post_init()
     oa.post_init()
     bases = []
-    for step in range(3):
+    for step in range(2):
         dt = amr.coarse_step()
         ev = amr.regrid_log()
         bases += [(lb, tm) for lb, tm, _ in ev]

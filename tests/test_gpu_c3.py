@@ -57,7 +57,7 @@ def _build(lib, n, nz, vort, kw, max_grid_size, blocking_factor=4):
     return amr, prob_lo, prob_hi
 
 
-@pytest.mark.parametrize("n", [32, 64])
+@pytest.mark.parametrize("n", [32])          # (64: 50 s of oracle time; the GPU suite keeps its budget for the 64^3 step parity of test_gpu_ns.py)
 def test_double_shear_layer_slab_matches_the_oracle(gpu, n):
     """the slab (n x n x 4 base cells, C3's parameters: cfl 0.5, inviscid, periodic [-1,1]^2, regrid_int 1, ratio 2) for three coarse steps"""
     lib = gpu
