@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, int ncomp, int bnc, GsrbBC bc, int shell_only, int tens, int wrap,
-    const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni(), WallK wk = WallK())
+    const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni(), const WallK* __restrict__ wkp = nullptr)
 {
     constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
     const int fab = blockIdx.y;
@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
             const double p0 = phi(i, j, k, n);
             double pxm = phi(im, j, k, n), pxp = phi(ip, j, k, n), pym = phi(i, jm, k, n), pyp = phi(i, jp, k, n), pzm = phi(i, j, km, n), pzp = phi(i, j, kp, n);
-            if (wk.on) {
+            if (wkp) {
+                const WallK& wk = *wkp;
                 if (!wk.per[0]) { if (i == bc.dlo[0]) pxm = wallk_ghost(p0, pxp, wk.c1lo[nq][0], wk.c2lo[nq][0]); if (i == bc.dhi[0]) pxp = wallk_ghost(p0, pxm, wk.c1hi[nq][0], wk.c2hi[nq][0]); }
                 if (!wk.per[1]) { if (j == bc.dlo[1]) pym = wallk_ghost(p0, pyp, wk.c1lo[nq][1], wk.c2lo[nq][1]); if (j == bc.dhi[1]) pyp = wallk_ghost(p0, pym, wk.c1hi[nq][1], wk.c2hi[nq][1]); }
                 if (!wk.per[2]) { if (k == bc.dlo[2]) pzm = wallk_ghost(p0, pzp, wk.c1lo[nq][2], wk.c2lo[nq][2]); if (k == bc.dhi[2]) pzp = wallk_ghost(p0, pzm, wk.c1hi[nq][2], wk.c2hi[nq][2]); }
@@ -281,7 +282,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
             const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
             const double p0 = phi(i, j, k, n);
             double pxm = phi(im, j, k, n), pxp = phi(ip, j, k, n), pym = phi(i, jm, k, n), pyp = phi(i, jp, k, n), pzm = phi(i, j, km, n), pzp = phi(i, j, kp, n);
-            if (wk.on) {
+            if (wkp) {
+                const WallK& wk = *wkp;
                 if (!wk.per[0]) { if (i == bc.dlo[0]) pxm = wallk_ghost(p0, pxp, wk.c1lo[nq][0], wk.c2lo[nq][0]); if (i == bc.dhi[0]) pxp = wallk_ghost(p0, pxm, wk.c1hi[nq][0], wk.c2hi[nq][0]); }
                 if (!wk.per[1]) { if (j == bc.dlo[1]) pym = wallk_ghost(p0, pyp, wk.c1lo[nq][1], wk.c2lo[nq][1]); if (j == bc.dhi[1]) pyp = wallk_ghost(p0, pym, wk.c1hi[nq][1], wk.c2hi[nq][1]); }
                 if (!wk.per[2]) { if (k == bc.dlo[2]) pzm = wallk_ghost(p0, pzp, wk.c1lo[nq][2], wk.c2lo[nq][2]); if (k == bc.dhi[2]) pzp = wallk_ghost(p0, pzm, wk.c1hi[nq][2], wk.c2hi[nq][2]); }
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     const FabD* __restrict__ phit, const FabD* __restrict__ rhst, const FabD* __restrict__ at,
     const FabD* __restrict__ bxt, const FabD* __restrict__ byt, const FabD* __restrict__ bzt,
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
-    const FabD* __restrict__ cfmt, CfC1 cfc, int zero, WallK wk = WallK())
+    const FabD* __restrict__ cfmt, CfC1 cfc, int zero, const WallK* __restrict__ wkp = nullptr)
 {
     const int fab = blockIdx.y;
     const BoxD b = boxes[fab];
@@ -346,7 +348,8 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
             o.pxm = phi(im, j, k, 0); o.pxp = phi(ip, j, k, 0);
             o.pym = phi(i, jm, k, 0); o.pyp = phi(i, jp, k, 0);
             o.pzm = phi(i, j, km, 0); o.pzp = phi(i, j, kp, 0);
-            if (wk.on) {          // walls inside the kernel (WallK): the ghost formula on the values just read
+            if (wkp) {            // walls inside the kernel (WallK): the ghost formula on the values just read
+                const WallK& wk = *wkp;
                 if (!wk.per[0]) { if (i == bc.dlo[0]) o.pxm = wallk_ghost(o.pc, o.pxp, wk.c1lo[0][0], wk.c2lo[0][0]); if (i == bc.dhi[0]) o.pxp = wallk_ghost(o.pc, o.pxm, wk.c1hi[0][0], wk.c2hi[0][0]); }
                 if (!wk.per[1]) { if (j == bc.dlo[1]) o.pym = wallk_ghost(o.pc, o.pyp, wk.c1lo[0][1], wk.c2lo[0][1]); if (j == bc.dhi[1]) o.pyp = wallk_ghost(o.pc, o.pym, wk.c1hi[0][1], wk.c2hi[0][1]); }
                 if (!wk.per[2]) { if (k == bc.dlo[2]) o.pzm = wallk_ghost(o.pc, o.pzp, wk.c1lo[0][2], wk.c2lo[0][2]); if (k == bc.dhi[2]) o.pzp = wallk_ghost(o.pc, o.pzm, wk.c1hi[0][2], wk.c2hi[0][2]); }
@@ -1236,18 +1239,31 @@ bool abec_gsrb_walls_inkernel_ok(const Geometry& g, const AbecCoef& c, const Mul
 void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiFab& rhs, int redblack, double omega, const DomainBC* bcs, int nbc, bool shell_only,
                bool wrap, const MultiFab* cfm, const CfTab* cftab, bool cf_maintain_ghosts, bool phi_is_zero, bool walls_inkernel)
 {
-    WallK wk;
-    wk.on = 0;
+    // (the wall formulas travel as a pointer to a small device table, null when off: 300 bytes more of kernel arguments cost the colour
+    // passes of the small levels 1 us each)
+    const WallK* wk = nullptr;
     if (walls_inkernel) {
         IAMRX_ASSERT(!shell_only && !wrap && abec_gsrb_walls_inkernel_ok(g, c, phi, nbc, bcs, cfm != nullptr));
-        wk.on = 1;
+        WallK h;
+        std::memset(&h, 0, sizeof(h));
+        h.on = 1;
         for (int n = 0; n < 3; ++n) {
             RbBC r;
             rb_make_bc(g, bcs[n < nbc ? n : 0], r);
             for (int d = 0; d < 3; ++d) {
-                wk.per[d] = r.per[d];
-                wk.c1lo[n][d] = r.c1lo[d]; wk.c2lo[n][d] = r.c2lo[d]; wk.c1hi[n][d] = r.c1hi[d]; wk.c2hi[n][d] = r.c2hi[d];
+                h.per[d] = r.per[d];
+                h.c1lo[n][d] = r.c1lo[d]; h.c2lo[n][d] = r.c2lo[d]; h.c1hi[n][d] = r.c1hi[d]; h.c2hi[n][d] = r.c2hi[d];
             }
+        }
+        // device copies of the few distinct tables of a run, kept for its life
+        static std::vector<std::pair<WallK, WallK*>> tabs;
+        for (auto& t : tabs) if (std::memcmp(&t.first, &h, sizeof(h)) == 0) wk = t.second;
+        if (!wk) {
+            WallK* d = nullptr;
+            IAMRX_HIP_CHECK(hipMalloc(&d, sizeof(WallK)));
+            IAMRX_HIP_CHECK(hipMemcpy(d, &h, sizeof(WallK), hipMemcpyHostToDevice));
+            tabs.emplace_back(h, d);
+            wk = d;
         }
     }
     IAMRX_ASSERT(!phi_is_zero || (!shell_only && abec_gsrb_zero_ok(c, phi, nbc, wrap || walls_inkernel, cfm != nullptr)));

@@ -27,4 +27,6 @@ d["source_blobs"] = {f: bench.file_blob_sha("$root/iamr_amd/csrc/" + f) for f in
 d["note"] = d["note"].replace("tools/pmc_kernels.py 256", "python bench.py --steps 2 --warmup 1 --cpu-steps 0 --amr-steps 0 (kernels INSIDE the running step, keyed by kernel and launch grid)")
 json.dump(d, open(p, "w"), indent=1)
 PY
+# the raw counter CSVs (tens of MB each) stay on the box: gpurun merges at most 64 MiB back
+rm -f $out/${tag}_pmc_fetch_size.csv $out/${tag}_pmc_write_size.csv $out/${tag}_pmc_sq_insts_valu.csv
 head -30 $out/${tag}_pmc_report.txt
