@@ -115,6 +115,7 @@ private:
         MultiFab a, b[3];          // owned (coarse levels)
         MultiFab cor, res, rescor;
         MultiFab buf;              // second buffer of the fused (out-of-place) GSRB sweeps
+        int wk_flag = -1;          // the colour passes of this level apply the domain walls themselves (abec_gsrb_walls_inkernel_ok; -1: not asked yet)
         bool res_filled = false;   // multi-box sweep kernel: the ghost layer of `res` is current (filled once per V-cycle)
         bool slab = false;         // slab level (mlmg.hip: mg_slab_level): two cells in y kept; virt = the one-plane coarsening of the level
         LayoutP virt;              // above, through which the restrictions go (vres: their target, duplicated into res / tmp_d)

@@ -312,7 +312,8 @@ void CellMG::smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, b
     const bool maint = m_cf && m_ncomp == 1 && !m_tensor && cf_maintain_on();
     // one box spanning a domain with walls: the colour passes apply the wall conditions themselves (WallK, k_abec.hip) -- no k_abec_bc launch
     // in front of a pass; periodic directions (if any) keep their ghost fill
-    const bool wk = !wrap && abec_gsrb_walls_inkernel_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data(), m_cf);
+    if (m_lev[l].wk_flag < 0) m_lev[l].wk_flag = (!wrap && abec_gsrb_walls_inkernel_ok(m_lev[l].g, c, sol, (int)m_bcn.size(), m_bcn.data(), m_cf)) ? 1 : 0;
+    const bool wk = m_lev[l].wk_flag == 1;
     const bool wk_per = wk && (m_lev[l].g.periodic[0] || m_lev[l].g.periodic[1] || m_lev[l].g.periodic[2]);
     for (int rb = 0; rb < 2; ++rb) {
         if (wk) { if (!skip_fill && wk_per) sol.FillBoundary(m_lev[l].g); }
