@@ -1,13 +1,18 @@
 #!/bin/bash
-# round-5 measurement set: the default bench line, rocprofv3 kernel statistics of the same command, the PMC passes, per-step kernel tables
+# round-5 measurement set: the PMC passes (the bench line's `traffic` comes from them), the default bench line, rocprofv3 kernel statistics of
+# the same command, per-step kernel tables, host-side HIP statistics.  bash tools/r5_final.sh TAG -> gpurun_out/TAG_*, round5_pmc.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-round5_b}
+tag=${1:-round5_final}
 out=$R/gpurun_out; mkdir -p $out
 cd $R
-timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-tail -c 600 $out/${tag}_bench.json
 bash tools/collect_pmc.sh round5 > $out/${tag}_pmc.log 2>&1
-tail -5 $out/${tag}_pmc.log
+tail -3 $out/${tag}_pmc.log
+cp $out/round5_pmc.json $R/profiles/round5_pmc.json
+timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+tail -c 300 $out/${tag}_bench.json
 bash tools/profile_bench.sh $tag > $out/${tag}_profile.log 2>&1
-tail -20 $out/${tag}_profile.log
+tail -12 $out/${tag}_profile.log
 bash tools/r5_state.sh
+bash tools/r5_hip.sh > $out/${tag}_hip_host.txt 2>&1
+DBG=run_ldc_steps.py bash tools/r5_hip.sh >> $out/${tag}_hip_host.txt 2>&1
+cat $out/${tag}_hip_host.txt | grep "cadence\|ms/step"
