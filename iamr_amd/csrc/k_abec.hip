@@ -101,8 +101,6 @@ struct GsrbBC {
     int nbc;                         // 1: the same BC for every component
 };
 
-// Lagrange weights for ghost-cell extrapolation through a Dirichlet face (AMReX poly_interp_coeff):
-// points x = {0 (face), 0.5, 1.5, 2.5}, evaluated at -0.5
 // Walls handled INSIDE the colour-pass kernels (k_abec_gsrb, k_abec_gsrb1) on a level that is one box spanning its domain: the value beyond a
 // domain face is k_abec_bc's homogeneous ghost formula on the values at hand, g = p0 c1 (+ p_in c2: Dirichlet of order 3; p_in = the cell's
 // neighbour on the inner side), so no ghost cell of phi is read in a non-periodic direction and the k_abec_bc launch in front of every colour
@@ -116,6 +114,8 @@ __device__ __forceinline__ double wallk_ghost(double p0, double pin, double c1, 
     if (c2 != 0.0) g += pin * c2;
     return g;
 }
+// Lagrange weights for ghost-cell extrapolation through a Dirichlet face (AMReX poly_interp_coeff):
+// points x = {0 (face), 0.5, 1.5, 2.5}, evaluated at -0.5
 static void poly_interp_coeff(double xi, const double* x, int N, double* c)
 {
     for (int j = 0; j < N; ++j) {
@@ -1817,6 +1817,9 @@ static bool abec_residual_pairs(const Geometry& g, const AbecCoef& c, MultiFab& 
 constexpr int BOT_NT = 512;
 struct BotBC { int per[3]; int bct[6]; double c[6][5]; };
 
+// (NW = the wavefronts that hold cells: the partial sums are added in wavefront order -- k_abec_tail runs the 512-cell solve in a
+// 1024-thread workgroup and adds the same BOT_NT / 64 terms)
+template <int NW = BOT_NT / 64>
 __device__ __forceinline__ double bot_sum(double v, double* red)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1824,9 +1827,10 @@ __device__ __forceinline__ double bot_sum(double v, double* red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
-    for (int w = 0; w < BOT_NT / 64; ++w) s += red[w];
+    for (int w = 0; w < NW; ++w) s += red[w];
     return s;
 }
+template <int NW = BOT_NT / 64>
 __device__ __forceinline__ double bot_max(double v, double* red)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
@@ -1834,17 +1838,18 @@ __device__ __forceinline__ double bot_max(double v, double* red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
-    for (int w = 0; w < BOT_NT / 64; ++w) s = fmax(s, red[w]);
+    for (int w = 0; w < NW; ++w) s = fmax(s, red[w]);
     return s;
 }
 
 // ghost cells of the faces of W ((nx+2)(ny+2)(nz+2), interior filled): periodic images, then the homogeneous domain BCs (k_abec_bc)
+template <int NT = BOT_NT>
 __device__ __forceinline__ void bot_fill_ghosts(double* W, int nx, int ny, int nz, const BotBC& bc)
 {
     const int sx = 1, sy = nx + 2, sz = (nx + 2) * (ny + 2);
     const int nfx = ny * nz, nfy = nx * nz, nfz = nx * ny;
     __syncthreads();
-    for (int q = threadIdx.x; q < 2 * (nfx + nfy + nfz); q += BOT_NT) {
+    for (int q = threadIdx.x; q < 2 * (nfx + nfy + nfz); q += NT) {
         int d, side, a, b2, r = q;
         if (r < 2 * nfx) { d = 0; side = r / nfx; r %= nfx; a = r % ny; b2 = r / ny; }
         else if (r < 2 * (nfx + nfy)) { r -= 2 * nfx; d = 1; side = r / nfy; r %= nfy; a = r % nx; b2 = r / nx; }
@@ -1997,15 +2002,10 @@ bool abec_bottom_device_ok(const Geometry& g, const Layout& l, const DomainBC* b
     return b.npts() <= BOT_NT;
 }
 
-void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
-                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters, const CfTab* cftab)
+// ghost formulas of a box's six faces for the single-workgroup kernels (BotBC: the fills inside LDS; GsrbBC: the first-interior-cell weights,
+// relative to the faces of the box)
+static void make_bot_bc(const Geometry& g, const BoxD& b, const DomainBC& bc, const CfTab* cftab, BotBC& bb, GsrbBC& gb)
 {
-    const Layout& l = *cor.layout;
-    IAMRX_ASSERT(abec_bottom_device_ok(g, l, &bc, 1, cor.ncomp, cftab != nullptr) && cor.ngrow >= 1);
-    if (l.nlocal() == 0) return;
-    const BoxD b = l.boxes[0];
-    BotBC bb;
-    GsrbBC gb;                       // first-interior-cell weights of the ghost formulas, relative to the faces of the box
     gb.nbc = 1;
     for (int d = 0; d < 3; ++d) {
         const bool spans = b.lo[d] == g.domain.lo[d] && b.hi[d] == g.domain.hi[d];
@@ -2034,10 +2034,306 @@ void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, cons
             for (int n = 0; n < 3; ++n) (side == 0 ? gb.cflo[n][d] : gb.cfhi[n][d]) = first;
         }
     }
+}
+
+void abec_bottom_solve(const Geometry& g, const AbecCoef& c, MultiFab& cor, const MultiFab& res, const DomainBC& bc, bool singular,
+                       double eps_rel, int maxiter, int nub, int nuf, double omega, int* d_iters, const CfTab* cftab)
+{
+    const Layout& l = *cor.layout;
+    IAMRX_ASSERT(abec_bottom_device_ok(g, l, &bc, 1, cor.ncomp, cftab != nullptr) && cor.ngrow >= 1);
+    if (l.nlocal() == 0) return;
+    const BoxD b = l.boxes[0];
+    BotBC bb;
+    GsrbBC gb;
+    make_bot_bc(g, b, bc, cftab, bb, gb);
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     hipLaunchKernelGGL(k_abec_bottom, dim3(1), dim3(BOT_NT), 0, Context::get().stream, b, cor.d_tab, res.d_tab,
                        c.a ? c.a->d_tab : nullptr, c.b[0]->d_tab, c.b[1]->d_tab, c.b[2]->d_tab, c.alpha, dhx, dhy, dhz, bb,
                        gb, singular ? 1 : 0, eps_rel, maxiter, nub, nuf, omega, d_iters);
+}
+
+// ---------------------------------------------------------------------------- the coarse tail of a V-cycle in ONE launch
+// The last two levels of a cell-centred hierarchy -- a level F of at most 16^3 cells and the bottom level C (its coarsening by 2, at most
+// 8^3 = 512 cells: k_abec_bottom's) -- in one launch of one 1024-thread workgroup: nu1 red-black sweeps on F from zero, residual,
+// restriction, the bottom solve (BiCGStab + sweeps, k_abec_bottom's code on the first 512 threads), prolongation, nu2 sweeps.  It replaces
+// 14 launches of ~5 us (4 colour passes, ghost fill, residual, restriction, fill, bottom, prolongation, 4 colour passes) per V-cycle; a
+// thread owns up to four cells of F (coefficients, right-hand side and correction in registers), the correction with its ghost cells
+// lives in LDS (18^3 doubles), ghost cells are filled there (bot_fill_ghosts: periodic images, Neumann, reflect-odd, Dirichlet of any
+// order -- k_abec_bc's formulas).  Every expression is that of the kernel it replaces (k_abec_gsrb1, k_abec_residual, k_cc_restrict,
+// k_abec_bottom, cc_prolong_add): the same doubles (tests/test_gpu_sensitivity.py: MG_TAIL_FUSED = 0 / 1 bit for bit).
+constexpr int TAIL_NT = 1024, TAIL_CPT = 4, TAIL_NF = 16;
+struct TailLevel { BoxD b; double dhx, dhy, dhz; BotBC bc; GsrbBC gb; };
+struct TailTabs { const FabD *cor, *res, *a, *bx, *by, *bz; };
+
+__global__ void __launch_bounds__(TAIL_NT) k_abec_tail(TailLevel F, TailLevel C, TailTabs tf, TailTabs tc, double alpha, int uni, BUni bu,
+    int nu1, int nu2, double omega_gs, int singular, double eps_rel, int maxiter, int nub, int nuf, int* __restrict__ iters_out)
+{
+    constexpr int NFA = (TAIL_NF + 1) * TAIL_NF * TAIL_NF;          // a face-coefficient array of F
+    __shared__ double WF[(TAIL_NF + 2) * (TAIL_NF + 2) * (TAIL_NF + 2)];
+    __shared__ double WC[(8 + 2) * (8 + 2) * (8 + 2)];
+    __shared__ double BF[3 * NFA];                                   // F's face coefficients (arrays form): 24 doubles per thread otherwise
+    __shared__ double red[TAIL_NT / 64];
+    const int tid = threadIdx.x;
+    // ---------------------------------------------------------------- level F: the cells of this thread
+    const BoxD bF = F.b;
+    const int nxF = bF.len(0), nyF = bF.len(1), nzF = bF.len(2), ncF = nxF * nyF * nzF;
+    const int syF = nxF + 2, szF = (nxF + 2) * (nyF + 2), nwF = szF * (nzF + 2);
+    const FabD corF = tf.cor[0], resF = tf.res[0];
+    const bool has_aF = tf.a != nullptr && alpha != 0.0;
+    // face coefficients of F in LDS: bX(li, lj, lk) at li + (nxF + 1) (lj + nyF lk), bY at NFA + li + nxF (lj + (nyF + 1) lk), bZ at 2 NFA + li + nxF (lj + nyF lk)
+    const int sxy = (nxF + 1), sxz = (nxF + 1) * nyF, syy = nxF, syz = nxF * (nyF + 1), szy = nxF, szz = nxF * nyF;
+    if (!uni) {
+        const FabD bX = tf.bx[0], bY = tf.by[0], bZ = tf.bz[0];
+        for (int q = tid; q < (nxF + 1) * nyF * nzF; q += TAIL_NT) BF[q] = bX(bF.lo[0] + q % (nxF + 1), bF.lo[1] + (q / (nxF + 1)) % nyF, bF.lo[2] + q / ((nxF + 1) * nyF), 0);
+        for (int q = tid; q < nxF * (nyF + 1) * nzF; q += TAIL_NT) BF[NFA + q] = bY(bF.lo[0] + q % nxF, bF.lo[1] + (q / nxF) % (nyF + 1), bF.lo[2] + q / (nxF * (nyF + 1)), 0);
+        for (int q = tid; q < nxF * nyF * (nzF + 1); q += TAIL_NT) BF[2 * NFA + q] = bZ(bF.lo[0] + q % nxF, bF.lo[1] + (q / nxF) % nyF, bF.lo[2] + q / (nxF * nyF), 0);
+    }
+    __syncthreads();
+    bool onF[TAIL_CPT];
+    int wF[TAIL_CPT], pF[TAIL_CPT], cF[TAIL_CPT], oX[TAIL_CPT], oY[TAIL_CPT], oZ[TAIL_CPT];
+    double x[TAIL_CPT], rF[TAIL_CPT], aaF[TAIL_CPT], gamF[TAIL_CPT], gmdF[TAIL_CPT];
+    // the six face coefficients of cell m: constants or LDS
+    auto bco = [&](int m, int q) -> double {
+        if (uni) return bu.v[q >> 1];
+        switch (q) {
+        case 0: return BF[oX[m]];
+        case 1: return BF[oX[m] + 1];
+        case 2: return BF[NFA + oY[m]];
+        case 3: return BF[NFA + oY[m] + syy];
+        case 4: return BF[2 * NFA + oZ[m]];
+        default: return BF[2 * NFA + oZ[m] + szz];
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < TAIL_CPT; ++m) {
+        const int idx = tid + m * TAIL_NT;
+        onF[m] = idx < ncF;
+        const int li = onF[m] ? idx % nxF : 0, lj = onF[m] ? (idx / nxF) % nyF : 0, lk = onF[m] ? idx / (nxF * nyF) : 0;
+        const int i = bF.lo[0] + li, j = bF.lo[1] + lj, k = bF.lo[2] + lk;
+        wF[m] = (li + 1) + (lj + 1) * syF + (lk + 1) * szF;
+        oX[m] = li + sxy * lj + sxz * lk; oY[m] = li + syy * lj + syz * lk; oZ[m] = li + szy * lj + szz * lk;
+        pF[m] = (i + j + k) & 1;                                               // the cell is updated in the colour pass rb = pF
+        cF[m] = (li >> 1) + 1 + ((lj >> 1) + 1) * (C.b.len(0) + 2) + ((lk >> 1) + 1) * (C.b.len(0) + 2) * (C.b.len(1) + 2);      // its coarse cell in WC
+        x[m] = 0.0; rF[m] = 0.0; aaF[m] = 0.0;
+        if (onF[m]) {
+            if (has_aF) aaF[m] = alpha * tf.a[0](i, j, k, 0);
+            rF[m] = resF(i, j, k, 0);
+        }
+        const double bxm = bco(m, 0), bxp = bco(m, 1), bym = bco(m, 2), byp = bco(m, 3), bzm = bco(m, 4), bzp = bco(m, 5);
+        gamF[m] = aaF[m] + F.dhx * (bxm + bxp) + F.dhy * (bym + byp) + F.dhz * (bzm + bzp);
+        const double cf0 = (i == F.gb.dlo[0]) ? F.gb.cflo[0][0] : 0.0, cf3 = (i == F.gb.dhi[0]) ? F.gb.cfhi[0][0] : 0.0;
+        const double cf1 = (j == F.gb.dlo[1]) ? F.gb.cflo[0][1] : 0.0, cf4 = (j == F.gb.dhi[1]) ? F.gb.cfhi[0][1] : 0.0;
+        const double cf2 = (k == F.gb.dlo[2]) ? F.gb.cflo[0][2] : 0.0, cf5 = (k == F.gb.dhi[2]) ? F.gb.cfhi[0][2] : 0.0;
+        gmdF[m] = gamF[m] - (F.dhx * (bxm * cf0 + bxp * cf3) + F.dhy * (bym * cf1 + byp * cf4) + F.dhz * (bzm * cf2 + bzp * cf5));
+    }
+    for (int q = tid; q < nwF; q += TAIL_NT) WF[q] = 0.0;
+    // the correction with its ghost cells in LDS (every wavefront is past its reads of the previous contents: barrier first)
+    auto publishF = [&]() {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < TAIL_CPT; ++m) if (onF[m]) WF[wF[m]] = x[m];
+        bot_fill_ghosts<TAIL_NT>(WF, nxF, nyF, nzF, F.bc);
+    };
+    // nsw red-black sweeps (k_abec_gsrb1's update)
+    auto sweepsF = [&](int nsw) {
+        for (int sw = 0; sw < nsw; ++sw)
+            for (int rb = 0; rb < 2; ++rb) {
+                publishF();
+#pragma unroll
+                for (int m = 0; m < TAIL_CPT; ++m)
+                    if (onF[m] && ((pF[m] + rb) & 1) == 0) {
+                        const int w = wF[m];
+                        const double bxm = bco(m, 0), bxp = bco(m, 1), bym = bco(m, 2), byp = bco(m, 3), bzm = bco(m, 4), bzp = bco(m, 5);
+                        const double rho = F.dhx * (bxm * WF[w - 1] + bxp * WF[w + 1]) + F.dhy * (bym * WF[w - syF] + byp * WF[w + syF])
+                                         + F.dhz * (bzm * WF[w - szF] + bzp * WF[w + szF]);
+                        const double resid = rF[m] - (gamF[m] * x[m] - rho);
+                        x[m] = x[m] + omega_gs / gmdF[m] * resid;
+                    }
+            }
+    };
+    sweepsF(nu1);
+    // ---------------------------------------------------------------- residual of F (k_abec_residual), restricted onto C (k_cc_restrict)
+    publishF();
+    double rr[TAIL_CPT];
+#pragma unroll
+    for (int m = 0; m < TAIL_CPT; ++m) {
+        rr[m] = 0.0;
+        if (onF[m]) {
+            const int w = wF[m];
+            const double p0 = x[m];
+            const double bxm = bco(m, 0), bxp = bco(m, 1), bym = bco(m, 2), byp = bco(m, 3), bzm = bco(m, 4), bzp = bco(m, 5);
+            const double ax = has_aF ? aaF[m] * p0 : 0.0;
+            const double y = ax
+                - F.dhx * (bxp * (WF[w + 1] - p0) - bxm * (p0 - WF[w - 1]))
+                - F.dhy * (byp * (WF[w + syF] - p0) - bym * (p0 - WF[w - syF]))
+                - F.dhz * (bzp * (WF[w + szF] - p0) - bzm * (p0 - WF[w - szF]));
+            rr[m] = rF[m] - y;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TAIL_CPT; ++m) if (onF[m]) WF[wF[m]] = rr[m];
+    __syncthreads();
+    // ---------------------------------------------------------------- level C: k_abec_bottom's solve on the first nc threads
+    const BoxD b = C.b;
+    const int nx = b.len(0), ny = b.len(1), nz = b.len(2), nc = nx * ny * nz;
+    const int sy = nx + 2, sz = (nx + 2) * (ny + 2), nw = sz * (nz + 2);
+    const bool on = tid < nc;
+    const int li = on ? tid % nx : 0, lj = on ? (tid / nx) % ny : 0, lk = on ? tid / (nx * ny) : 0;
+    const int i = b.lo[0] + li, j = b.lo[1] + lj, k = b.lo[2] + lk;
+    const int w0 = (li + 1) + (lj + 1) * sy + (lk + 1) * sz;
+    const bool has_a = tc.a != nullptr && alpha != 0.0;
+    double bxm = 0, bxp = 0, bym = 0, byp = 0, bzm = 0, bzp = 0, aa = 0, rhs0 = 0;
+    if (on) {
+        if (uni) { bxm = bxp = bu.v[0]; bym = byp = bu.v[1]; bzm = bzp = bu.v[2]; }
+        else {
+            const FabD bX = tc.bx[0], bY = tc.by[0], bZ = tc.bz[0];
+            bxm = bX(i, j, k, 0); bxp = bX(i + 1, j, k, 0); bym = bY(i, j, k, 0); byp = bY(i, j + 1, k, 0); bzm = bZ(i, j, k, 0); bzp = bZ(i, j, k + 1, 0);
+        }
+        if (has_a) aa = alpha * tc.a[0](i, j, k, 0);
+        // the restricted residual: k_cc_restrict's sum over the 2 x 2 x 2 fine cells, in its order
+        double s = 0.0;
+        for (int kr = 0; kr < 2; ++kr)
+            for (int jr = 0; jr < 2; ++jr) {
+                const int wf = (2 * li + 1) + (2 * lj + jr + 1) * syF + (2 * lk + kr + 1) * szF;
+                s += WF[wf];
+                s += WF[wf + 1];
+            }
+        rhs0 = 0.125 * s;
+    }
+    const double dhx = C.dhx, dhy = C.dhy, dhz = C.dhz;
+    const BotBC& bc = C.bc;
+    const GsrbBC& gb = C.gb;
+    for (int q = tid; q < nw; q += TAIL_NT) WC[q] = 0.0;
+    double* const W = WC;
+    auto apply = [&](double xv) -> double {
+        __syncthreads();
+        if (on) W[w0] = xv;
+        bot_fill_ghosts<TAIL_NT>(W, nx, ny, nz, bc);
+        if (!on) return 0.0;
+        const double p0 = xv;
+        return (has_a ? aa * p0 : 0.0)
+            - dhx * (bxp * (W[w0 + 1] - p0) - bxm * (p0 - W[w0 - 1]))
+            - dhy * (byp * (W[w0 + sy] - p0) - bym * (p0 - W[w0 - sy]))
+            - dhz * (bzp * (W[w0 + sz] - p0) - bzm * (p0 - W[w0 - sz]));
+    };
+    double bb = rhs0;
+    if (singular) bb -= bot_sum(on ? rhs0 : 0.0, red) / (double)nc;
+    if (!on) bb = 0.0;
+    double xc = 0.0, r = bb, p = 0.0, v = 0.0;
+    const double rh = r;
+    const double rnorm0 = bot_max(fabs(r), red);
+    double rnorm = rnorm0;
+    int ret = 0, nit = 0;
+    if (rnorm0 != 0.0) {
+        double rho_1 = 0.0, alph = 0.0, omg = 0.0;
+        for (nit = 1; nit <= maxiter; ++nit) {
+            const double rho = bot_sum(rh * r, red);
+            if (rho == 0.0) { ret = 1; break; }
+            if (nit == 1) p = r;
+            else {
+                const double beta = (rho / rho_1) * (alph / omg);
+                p = p - omg * v;
+                p = r + beta * p;
+            }
+            v = apply(p);
+            const double rhTv = bot_sum(rh * v, red);
+            if (rhTv != 0.0) alph = rho / rhTv; else { ret = 2; break; }
+            xc = xc + alph * p;
+            const double s = r - alph * v;
+            rnorm = bot_max(fabs(s), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            const double t = apply(s);
+            const double tt = bot_sum(t * t, red), ts = bot_sum(t * s, red);
+            if (tt != 0.0) omg = ts / tt; else { ret = 3; break; }
+            xc = xc + omg * s;
+            r = s - omg * t;
+            rnorm = bot_max(fabs(r), red);
+            if (rnorm < eps_rel * rnorm0) break;
+            if (omg == 0.0) { ret = 4; break; }
+            rho_1 = rho;
+        }
+        if (ret == 0 && rnorm > eps_rel * rnorm0) ret = 8;
+        if (!((ret == 0 || ret == 8) && rnorm < rnorm0)) xc = 0.0;
+    }
+    if (tid == 0 && iters_out) atomicAdd(iters_out, nit);
+    int nsw = ret == 0 ? nub : nuf;
+    if (ret != 0) { xc = 0.0; nsw += nuf; }
+    {
+        const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
+        const double cf0 = (i == gb.dlo[0]) ? gb.cflo[0][0] : 0.0, cf3 = (i == gb.dhi[0]) ? gb.cfhi[0][0] : 0.0;
+        const double cf1 = (j == gb.dlo[1]) ? gb.cflo[0][1] : 0.0, cf4 = (j == gb.dhi[1]) ? gb.cfhi[0][1] : 0.0;
+        const double cf2 = (k == gb.dlo[2]) ? gb.cflo[0][2] : 0.0, cf5 = (k == gb.dhi[2]) ? gb.cfhi[0][2] : 0.0;
+        const double g_m_d = gamma - (dhx * (bxm * cf0 + bxp * cf3) + dhy * (bym * cf1 + byp * cf4) + dhz * (bzm * cf2 + bzp * cf5));
+        for (int sw = 0; sw < nsw; ++sw)
+            for (int rb = 0; rb < 2; ++rb) {
+                __syncthreads();
+                if (on) W[w0] = xc;
+                bot_fill_ghosts<TAIL_NT>(W, nx, ny, nz, bc);
+                if (on && ((li & 1) == ((b.lo[0] + j + k + rb) & 1))) {
+                    const double rho = dhx * (bxm * W[w0 - 1] + bxp * W[w0 + 1]) + dhy * (bym * W[w0 - sy] + byp * W[w0 + sy])
+                                     + dhz * (bzm * W[w0 - sz] + bzp * W[w0 + sz]);
+                    const double resid = rhs0 - (gamma * xc - rho);
+                    xc = xc + omega_gs / g_m_d * resid;
+                }
+            }
+    }
+    // ---------------------------------------------------------------- prolongation (cc_prolong_add) and the post-smoothing of F
+    __syncthreads();
+    if (on) W[w0] = xc;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TAIL_CPT; ++m) if (onF[m]) x[m] = x[m] + W[cF[m]];
+    sweepsF(nu2);
+#pragma unroll
+    for (int m = 0; m < TAIL_CPT; ++m)
+        if (onF[m]) {
+            const int idx = tid + m * TAIL_NT;
+            corF(bF.lo[0] + idx % nxF, bF.lo[1] + (idx / nxF) % nyF, bF.lo[2] + idx / (nxF * nyF), 0) = x[m];
+        }
+}
+
+// the last two levels of a hierarchy can run as k_abec_tail: F one box of at most 16 cells a side (4096 cells) spanning its domain, C its
+// coarsening by 2 with the device bottom solver's conditions; one component, one boundary condition set, b arrays or constants
+bool abec_tail_ok(const Geometry& gF, const Layout& lF, const Geometry& gC, const Layout& lC, const AbecCoef& cF, const DomainBC* bcs, int nbc, int ncomp)
+{
+    // opt-in (IAMRX_MG_TAIL_FUSED = 1): measured on MI355X at 256^3 -- 97.6 us per launch against ~83 us for the 14 launches it replaces (one CU
+    // does serially what they spread over the chip; 117 launches fewer per step, step time equal within the noise)
+    if (tune("MG_TAIL_FUSED", 0) == 0 || ncomp != 1 || nbc != 1 || cF.sig || cF.tensor || cF.tensor_eta) return false;
+    if (!abec_bottom_device_ok(gC, lC, bcs, nbc, ncomp, false) || lF.boxes.size() != 1) return false;
+    const BoxD bF = lF.boxes[0], bC = lC.boxes[0];
+    for (int d = 0; d < 3; ++d) {
+        if (bF.len(d) > TAIL_NF || bF.len(d) != 2 * bC.len(d) || bF.lo[d] != 2 * bC.lo[d]) return false;
+        if (bF.lo[d] != gF.domain.lo[d] || bF.hi[d] != gF.domain.hi[d]) return false;
+        if (gF.periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            const int t = side == 0 ? bcs[0].lo[d] : bcs[0].hi[d];
+            if (t != lo_neumann && t != lo_dirichlet && t != lo_reflect_odd) return false;
+        }
+    }
+    if (!cF.b_uniform && cF.b[0]->ncomp != 1) return false;
+    return bF.npts() <= (long)TAIL_NT * TAIL_CPT;
+}
+
+void abec_tail_solve(const Geometry& gF, const AbecCoef& cF, MultiFab& corF, const MultiFab& resF, const Geometry& gC, const AbecCoef& cC,
+                     const DomainBC& bc, bool singular, double eps_rel, int maxiter, int nub, int nuf, int nu1, int nu2, double omega, int* d_iters)
+{
+    const Layout& lF = *corF.layout;
+    if (lF.nlocal() == 0) return;
+    TailLevel F, C;
+    F.b = lF.boxes[0];
+    C.b = coarsen(F.b, 2);
+    make_bot_bc(gF, F.b, bc, nullptr, F.bc, F.gb);
+    make_bot_bc(gC, C.b, bc, nullptr, C.bc, C.gb);
+    F.dhx = cF.beta / (gF.dx[0] * gF.dx[0]); F.dhy = cF.beta / (gF.dx[1] * gF.dx[1]); F.dhz = cF.beta / (gF.dx[2] * gF.dx[2]);
+    C.dhx = cC.beta / (gC.dx[0] * gC.dx[0]); C.dhy = cC.beta / (gC.dx[1] * gC.dx[1]); C.dhz = cC.beta / (gC.dx[2] * gC.dx[2]);
+    const bool uni = cF.b_uniform && cC.b_uniform && abec_sig_on();
+    TailTabs tf{corF.d_tab, resF.d_tab, cF.a ? cF.a->d_tab : nullptr, cF.b[0]->d_tab, cF.b[1]->d_tab, cF.b[2]->d_tab};
+    TailTabs tc{nullptr, nullptr, cC.a ? cC.a->d_tab : nullptr, cC.b[0]->d_tab, cC.b[1]->d_tab, cC.b[2]->d_tab};
+    BUni bu;
+    for (int d = 0; d < 3; ++d) bu.v[d] = cF.bu[d];
+    hipLaunchKernelGGL(k_abec_tail, dim3(1), dim3(TAIL_NT), 0, Context::get().stream, F, C, tf, tc, cF.alpha, uni ? 1 : 0, bu, nu1, nu2, omega,
+                       singular ? 1 : 0, eps_rel, maxiter, nub, nuf, d_iters);
 }
 
 // ---------------------------------------------------------------------------- domain BC ghost fill

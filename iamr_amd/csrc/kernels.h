@@ -89,6 +89,11 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
 // walls_inkernel: the pass applies the homogeneous domain boundary conditions itself (no ghost cell of phi is read in a non-periodic direction:
 // the caller fills periodic ghost cells only) -- allowed where this returns true
 bool abec_gsrb_walls_inkernel_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs, bool cf);
+// the last two levels of a cell-centred V-cycle in one single-workgroup launch (k_abec_tail, k_abec.hip): pre-smoothing from zero, residual,
+// restriction, bottom solve, prolongation, post-smoothing -- the doubles of the launches it replaces
+bool abec_tail_ok(const Geometry& gF, const Layout& lF, const Geometry& gC, const Layout& lC, const AbecCoef& cF, const DomainBC* bcs, int nbc, int ncomp);
+void abec_tail_solve(const Geometry& gF, const AbecCoef& cF, MultiFab& corF, const MultiFab& resF, const Geometry& gC, const AbecCoef& cC,
+                     const DomainBC& bc, bool singular, double eps_rel, int maxiter, int nub, int nuf, int nu1, int nu2, double omega, int* d_iters);
 // phi_is_zero: the pass may be told that phi is identically zero (the first pass on a multigrid correction) INSTEAD of phi being set to
 // zero in front of it -- it then reads no phi and writes every cell (the active colour its update, the other colour zero) -- if this returns
 // true for the same arguments (one component, one-component coefficients, one box spanning a periodic domain: no ghost cell is read)

@@ -130,6 +130,7 @@ private:
     };
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     void bottom_solve(MGStats& st);
+    bool tail_fused() const;
     void cf_bcval(MultiFab& bcval);
     void subtract_mean(int l, MultiFab& mf);
     Geometry m_g;

@@ -567,11 +567,26 @@ void CellMG::bottom_solve(MGStats& st)
     smooth_n(l, L.cor, L.res, nn, false);
 }
 
+// the last two levels run as one launch (k_abec_tail): the bottom level is the device bottom solver's and the level above it a single box of
+// at most 16^3 cells with the same kind of faces; no agglomeration / slab transfer between the two
+bool CellMG::tail_fused() const
+{
+    const int nl = (int)m_lev.size();
+    if (nl < 2 || !m_bottom_dev || m_cf || m_dd_sweeps > 0 || m_o.nu1 <= 0) return false;
+    const Level& F = m_lev[nl - 2];
+    const Level& C = m_lev[nl - 1];
+    if (C.agg || C.slab || F.slab || fused_smoother_ok(nl - 2)) return false;
+    AbecCoef cF = coef(nl - 2);
+    return abec_tail_ok(F.g, *F.layout, C.g, *C.layout, cF, m_bcn.data(), (int)m_bcn.size(), m_ncomp);
+}
+
 void CellMG::vcycle(MGStats& st)
 {
     const int nl = (int)m_lev.size();
     m_lev[0].res_filled = false;
-    for (int l = 0; l < nl - 1; ++l) {
+    const bool tail = tail_fused();
+    const int nsm = tail ? nl - 2 : nl - 1;          // levels smoothed by the loops below
+    for (int l = 0; l < nsm; ++l) {
         Level& L = m_lev[l];
         // zero initial guess of the correction: where the first colour pass reads no ghost cell it also takes the place of the fill
         const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res));
@@ -593,8 +608,18 @@ void CellMG::vcycle(MGStats& st)
         if (C.slab) slab_duplicate(held, C.vres);
         if (C.agg) gather_to_replicated(C.res, C.tmp_d);
     }
+    if (tail) {
+        Level& F = m_lev[nl - 2];
+        Level& C = m_lev[nl - 1];
+        const long nunk = C.layout->total_cells() * m_ncomp;
+        const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+        AbecCoef cF = coef(nl - 2), cC = coef(nl - 1);
+        cF.tensor = 0; cC.tensor = 0;
+        abec_tail_solve(F.g, cF, F.cor, F.res, C.g, cC, m_bcn[0], m_singular, m_o.bottom_reltol, maxiter, m_o.nub, m_o.nuf, m_o.nu1, m_o.nu2, m_o.omega,
+                        bottom_iters_dev());
+    } else
     bottom_solve(st);
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = nsm - 1; l >= 0; --l) {
         Level& L = m_lev[l];
         if (m_lev[l + 1].agg) {
             scatter_from_replicated(m_lev[l + 1].tmp_d, m_lev[l + 1].cor, 0);

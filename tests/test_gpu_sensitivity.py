@@ -77,8 +77,12 @@ KERNEL_FORMS = {
     "two colour passes on levels with walls": {"GSRB_RB_WALLS": 0},
     # round 4: the coarser levels of a constant-coefficient operator read their (constant) coefficient arrays instead of taking the constants
     "coefficient arrays on the coarser levels": {"MG_COARSE_UNIFORM": 0},
+    # round 5: the last two levels of a V-cycle in the one single-workgroup launch k_abec_tail instead of their ~14 separate launches
+    # (opt-in: measured slower than the launches it replaces)
+    "fused coarse tail": {"MG_TAIL_FUSED": 1},
+    "fused coarse tail, coefficient arrays": {"MG_TAIL_FUSED": 1, "MG_COARSE_UNIFORM": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1, "MG_COARSE_UNIFORM": 1}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1, "MG_COARSE_UNIFORM": 1, "MG_TAIL_FUSED": 0}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls", "channel_walls_long"])
