@@ -628,33 +628,25 @@ __device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_
 // the ghost column beyond an open x-face a plane ahead: its old black value for the red update, its new red value for the black update.
 // rhs (and the a-term) come with one filled ghost layer, the density with two (k_abec_rb_ghost forms the face coefficients of the ghost cell).
 struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; int dlo[3], dhi[3]; };
+#ifndef IAMRX_RBW_EXP
+#define IAMRX_RBW_EXP 0      // timing experiments on the wall variant (wrong results): 1: no density loads beyond x-faces, 2: no wall terms in gamma, 4: no y / z wall ghosts, 8: no x-wall branch
+#endif
 
 // one Gauss-Seidel update of the sweep kernels: k_abec_gsrb2's expressions (no coarse-fine terms)
 template <bool SG, bool WALLS>
-__device__ __forceinline__ double rb_update(const RbBC& bc, double dhx, double dhy, double dhz, double omega,
+__device__ __forceinline__ double rb_update(double dhx, double dhy, double dhz, double omega,
     double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
-    double bxm, double bxp, double bym, double byp, double bzm, double bzp, int fx, int fy, int fz)
+    double bxm, double bxp, double bym, double byp, double bzm, double bzp,
+    double cxl, double cxh, double cyl, double cyh, double czl, double czh)
 {
     const double gamma = aa + dhx * (bxm + bxp) + dhy * (bym + byp) + dhz * (bzm + bzp);
     // k_abec_gsrb2 subtracts the wall terms dhx (bxm c_lo + bxp c_hi) + dhy (...) + dhz (...) from gamma here, c = c1 at a domain face the
     // cell touches and 0 elsewhere: the terms with c = 0 are +-0 for finite coefficients and add nothing -- an index-wrap level keeps
-    // gamma, a cell at a wall (f? = 1: low face, 2: high face) subtracts the terms of its faces, in that order: the same double
+    // gamma; a level with walls evaluates the reference's expression itself with the six weights of the cell (zero away from the walls).
+    // (Round 4 selected the terms by face flags instead -- `ws += f == 0 ? 0 : dh (b c)` -- which cost the density form 40 us of its 205 us
+    // per 256^3 sweep: tools/r5_rbw_exp.sh)
     double g_m_d = gamma;
-    if (WALLS) {
-        // (selections, no branches: fx differs from lane to lane; a cell away from the walls adds 0.0 three times.  The constant-coefficient
-        // form is faster with the reference's expression itself -- 118 against 140 us per 256^3 sweep)
-        if (!SG) {
-            const double c0 = fx == 1 ? bc.c1lo[0] : 0.0, c3 = fx == 2 ? bc.c1hi[0] : 0.0, c1 = fy == 1 ? bc.c1lo[1] : 0.0, c4 = fy == 2 ? bc.c1hi[1] : 0.0;
-            const double c2 = fz == 1 ? bc.c1lo[2] : 0.0, c5 = fz == 2 ? bc.c1hi[2] : 0.0;
-            g_m_d = gamma - (dhx * (bxm * c0 + bxp * c3) + dhy * (bym * c1 + byp * c4) + dhz * (bzm * c2 + bzp * c5));
-        } else {
-            double ws = 0.0;
-            ws += fx == 0 ? 0.0 : dhx * ((fx == 1 ? bxm : bxp) * (fx == 1 ? bc.c1lo[0] : bc.c1hi[0]));
-            ws += fy == 0 ? 0.0 : dhy * ((fy == 1 ? bym : byp) * (fy == 1 ? bc.c1lo[1] : bc.c1hi[1]));
-            ws += fz == 0 ? 0.0 : dhz * ((fz == 1 ? bzm : bzp) * (fz == 1 ? bc.c1lo[2] : bc.c1hi[2]));
-            g_m_d = gamma - ws;
-        }
-    }
+    if (WALLS && !(IAMRX_RBW_EXP & 2)) g_m_d = gamma - (dhx * (bxm * cxl + bxp * cxh) + dhy * (bym * cyl + byp * cyh) + dhz * (bzm * czl + bzp * czh));
     const double rho = dhx * (bxm * pxm + bxp * pxp) + dhy * (bym * pym + byp * pyp) + dhz * (bzm * pzm + bzp * pzp);
     const double res = rr - (gamma * p0 - rho);
     return p0 + omega / g_m_d * res;
@@ -742,10 +734,13 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     auto ldp = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(plane(f, k, n), off); };
     auto ldv = [&](const FabD& f, unsigned off, int k, int n) { return ldpair(planev(f, k, n), off); };
     auto face = [&](double s0, double s1) { return sig_scale / (0.5 * (s0 + s1)); };      // (the sum commutes: one value per face)
+    // wall weights of a cell: c1 of the ghost formula at a domain face it touches, 0 elsewhere (x: per lane; y: per row; z: per plane)
     auto update = [&](double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp, double rr, double aa,
-                      double bxm, double bxp, double bym, double byp, double bzm, double bzp, int fx = 0, int fy = 0, int fz = 0) {
-        return rb_update<SG, WALLS>(bc, dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
+                      double bxm, double bxp, double bym, double byp, double bzm, double bzp,
+                      double cxl = 0.0, double cxh = 0.0, double cyl = 0.0, double cyh = 0.0, double czl = 0.0, double czh = 0.0) {
+        return rb_update<SG, WALLS>(dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, cxl, cxh, cyl, cyh, czl, czh);
     };
+    const double cyl0 = atyl ? bc.c1lo[1] : 0.0, cyh0 = (atyh && !atyl) ? bc.c1hi[1] : 0.0;
     constexpr bool has_a = HASA;
     const D2 Z2 = {0.0, 0.0};
     // rings: pin rows of the planes q - 1, q, q + 1; density rows q - 1 .. q + 1; rhs rows q - 1, q; new reds q - 2, q - 1, q; of the red
@@ -768,7 +763,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         return y;
     };
     // walls in x (density form): the density beyond the face, loaded by the first / last lane of the row a plane ahead (planes q - 1, q, in flight)
-    const bool xs_on = SG && (((wlx || olx) && !hasL) || ((whx || ohx) && !hasR));
+    const bool xs_on = !(IAMRX_RBW_EXP & 1) && SG && (((wlx || olx) && !hasL) || ((whx || ohx) && !hasR));
     const unsigned oSx = xs_on ? rowoff(S, ((wlx || olx) && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
     double xs_m = 0.0, xs_c = 0.0, xsN = 0.0;
     auto xsload = [&](int qq) { return xs_on ? ld1(plane(S, qq, sig_comp), oSx) : 0.0; };
@@ -836,12 +831,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             double nb = par == 0 ? rb_lane_lo(Pc.r) : rb_lane_hi(Pc.l), nbs = 0.0;
             if (SG) nbs = par == 0 ? rb_lane_lo(Sc.r) : rb_lane_hi(Sc.l);
             const double p0 = par ? Pc.r : Pc.l;
-            int fx = 0, fy = 0, fz = 0;
+            double cxl = 0.0, cxh = 0.0, czl = 0.0, czh = 0.0;
             if (par == 0 ? !hasL : !hasR) {
-                if (WALLS && (par == 0 ? wlx : whx)) {           // the red cell sits at an x-face of the domain
+                if (WALLS && !(IAMRX_RBW_EXP & 8) && (par == 0 ? wlx : whx)) {           // the red cell sits at an x-face of the domain
                     nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbs = xs_c;
-                    fx = par == 0 ? 1 : 2;
+                    if (par == 0) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0];
                 } else if (NBR && XO && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
                     nb = zero ? 0.0 : xp_c;
                     if (SG) nbs = xs_c;
@@ -855,11 +850,11 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (ym_g) { pym = yn.p; sym = yn.s; }
             if (yp_g) { pyp = yn.p; syp = yn.s; }
             double pzm = par ? Pm.r : Pm.l, pzp = par ? Pp.r : Pp.l;
-            if (WALLS) {
-                if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
-                else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
-                if (wzl && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
-                else if (wzh && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+            if (WALLS && !(IAMRX_RBW_EXP & 4)) {
+                if (atyl) pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]);
+                else if (atyh) pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]);
+                if (wzl && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); czl = bc.c1lo[2]; }
+                else if (wzh && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); czh = bc.c1hi[2]; }
             }
             const double pxm = par == 0 ? nb : Pc.l, pxp = par == 0 ? Pc.r : nb;
             const double rr = par ? Rc.r : Rc.l;
@@ -873,7 +868,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                 bzm_c = face(par ? Sm.r : Sm.l, s0); bzp_c = face(s0, par ? Sp.r : Sp.l);
             }
             RNa = RNm; RNm = RNc;
-            RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c, fx, fy, fz);
+            RNc = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm_c, bzp_c, cxl, cxh, (IAMRX_RBW_EXP & 4) ? 0.0 : cyl0, (IAMRX_RBW_EXP & 4) ? 0.0 : cyh0, czl, czh);
             if (NBR && (row_out || q < b.lo[2] || q > b.hi[2])) RNc = p0;      // a ghost row / plane: already updated (k_abec_rb_ghost)
             if (SG) {
                 YM[slot][w][lane] = bym; YP[slot][w][lane] = byp;
@@ -894,12 +889,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             double nb = park == 1 ? rb_lane_lo(RNm) : rb_lane_hi(RNm), nbf = bu.v[0];
             if (SG) nbf = park == 1 ? rb_lane_lo(bfar_m) : rb_lane_hi(bfar_m);
             const double p0 = park ? Pm.l : Pm.r, rr = park ? Rm.l : Rm.r;
-            int fx = 0, fy = 0, fz = 0;
+            double cxl = 0.0, cxh = 0.0, czl = 0.0, czh = 0.0;
             if (park == 1 ? !hasL : !hasR) {
-                if (WALLS && (park == 1 ? wlx : whx)) {          // the black cell sits at an x-face: ghost from its own value and the new red beside it
+                if (WALLS && !(IAMRX_RBW_EXP & 8) && (park == 1 ? wlx : whx)) {          // the black cell sits at an x-face: ghost from its own value and the new red beside it
                     nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
-                    fx = park == 1 ? 1 : 2;
+                    if (park == 1) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0];
                 } else if (NBR && XO && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
                     nb = xp_m;
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
@@ -910,11 +905,11 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             }
             const double pxm = park == 1 ? nb : RNm, pxp = park == 1 ? RNm : nb;
             double pym = RED[slotk][w - wpr][lane], pyp = RED[slotk][w + wpr][lane], pzm = RNa, pzp = RNc;
-            if (WALLS) {
-                if (atyl) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; }
-                else if (atyh) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; }
-                if (wzl && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; }
-                else if (wzh && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; }
+            if (WALLS && !(IAMRX_RBW_EXP & 4)) {
+                if (atyl) pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]);
+                else if (atyh) pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]);
+                if (wzl && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); czl = bc.c1lo[2]; }
+                else if (wzh && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); czh = bc.c1hi[2]; }
             }
             double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
             if (SG) {
@@ -923,7 +918,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
                 bzm = bzp_a; bzp = bzm_c;
             }
             const double aa = has_a ? alpha * (park ? Am.l : Am.r) : 0.0;
-            const double bn = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
+            const double bn = update(p0, pxm, pxp, pym, pyp, pzm, pzp, rr, aa, bxm, bxp, bym, byp, bzm, bzp, cxl, cxh, (IAMRX_RBW_EXP & 4) ? 0.0 : cyl0, (IAMRX_RBW_EXP & 4) ? 0.0 : cyh0, czl, czh);
             bn_prev = bn;
         }
         if (SG) { bnear_m = bnear_c; bfar_m = bfar_c; bzp_a = bzp_m; bzp_m = bzp_c; }
@@ -971,11 +966,11 @@ __global__ void __launch_bounds__(256) k_abec_rb_ghost(const BoxD* __restrict__ 
     auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
     const double p0 = P(i, j, k);
     double pxm = P(i - 1, j, k), pxp = P(i + 1, j, k), pym = P(i, j - 1, k), pyp = P(i, j + 1, k), pzm = P(i, j, k - 1), pzp = P(i, j, k + 1);
-    int fx = 0, fy = 0, fz = 0;
+    double cw[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // wall weights (lo, hi) per direction, see rb_update
     if (WALLS) {
-        if (!bc.per[0]) { if (i == bc.dlo[0]) { pxm = ghost(p0, pxp, bc.c1lo[0], bc.c2lo[0]); fx = 1; } else if (i == bc.dhi[0]) { pxp = ghost(p0, pxm, bc.c1hi[0], bc.c2hi[0]); fx = 2; } }
-        if (!bc.per[1]) { if (j == bc.dlo[1]) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); fy = 1; } else if (j == bc.dhi[1]) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); fy = 2; } }
-        if (!bc.per[2]) { if (k == bc.dlo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); fz = 1; } else if (k == bc.dhi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); fz = 2; } }
+        if (!bc.per[0]) { if (i == bc.dlo[0]) { pxm = ghost(p0, pxp, bc.c1lo[0], bc.c2lo[0]); cw[0] = bc.c1lo[0]; } else if (i == bc.dhi[0]) { pxp = ghost(p0, pxm, bc.c1hi[0], bc.c2hi[0]); cw[1] = bc.c1hi[0]; } }
+        if (!bc.per[1]) { if (j == bc.dlo[1]) { pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]); cw[2] = bc.c1lo[1]; } else if (j == bc.dhi[1]) { pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]); cw[3] = bc.c1hi[1]; } }
+        if (!bc.per[2]) { if (k == bc.dlo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); cw[4] = bc.c1lo[2]; } else if (k == bc.dhi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); cw[5] = bc.c1hi[2]; } }
     }
     double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
     if (SG) {
@@ -988,7 +983,8 @@ __global__ void __launch_bounds__(256) k_abec_rb_ghost(const BoxD* __restrict__ 
     }
     double aa = 0.0;
     if (HASA) { const FabD A = At[fab]; aa = alpha * A(i, j, k, 0); }
-    pin(i, j, k, comp) = rb_update<SG, WALLS>(bc, dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rhs(i, j, k, comp), aa, bxm, bxp, bym, byp, bzm, bzp, fx, fy, fz);
+    pin(i, j, k, comp) = rb_update<SG, WALLS>(dhx, dhy, dhz, omega, p0, pxm, pxp, pym, pyp, pzm, pzp, rhs(i, j, k, comp), aa, bxm, bxp, bym, byp, bzm, bzp,
+                                              cw[0], cw[1], cw[2], cw[3], cw[4], cw[5]);
 }
 
 // the ghost formula of one component's boundary conditions as the sweep kernel applies it; false: a condition it does not take
