@@ -629,7 +629,7 @@ __device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_
 // rhs (and the a-term) come with one filled ghost layer, the density with two (k_abec_rb_ghost forms the face coefficients of the ghost cell).
 struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; int dlo[3], dhi[3]; };
 #ifndef IAMRX_RBW_EXP
-#define IAMRX_RBW_EXP 0      // timing experiments on the wall variant (wrong results): 1: no density loads beyond x-faces, 2: no wall terms in gamma, 4: no y / z wall ghosts, 8: no x-wall branch
+#define IAMRX_RBW_EXP 0      // timing experiments on the wall variant (wrong results): 1: no density loads beyond x-faces, 2: no wall terms in gamma, 4: no y / z wall ghosts, 8: no x-wall branch, 16: no face coefficient in the black x-wall branch, 32: no x wall weights, 64: no wall density in the red x-wall branch
 #endif
 
 // one Gauss-Seidel update of the sweep kernels: k_abec_gsrb2's expressions (no coarse-fine terms)
@@ -835,8 +835,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (par == 0 ? !hasL : !hasR) {
                 if (WALLS && !(IAMRX_RBW_EXP & 8) && (par == 0 ? wlx : whx)) {           // the red cell sits at an x-face of the domain
                     nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
-                    if (SG) nbs = xs_c;
-                    if (par == 0) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0];
+                    if (SG && !(IAMRX_RBW_EXP & 64)) nbs = xs_c;
+                    if (!(IAMRX_RBW_EXP & 32)) { if (par == 0) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0]; }
                 } else if (NBR && XO && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
                     nb = zero ? 0.0 : xp_c;
                     if (SG) nbs = xs_c;
@@ -893,8 +893,8 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (park == 1 ? !hasL : !hasR) {
                 if (WALLS && !(IAMRX_RBW_EXP & 8) && (park == 1 ? wlx : whx)) {          // the black cell sits at an x-face: ghost from its own value and the new red beside it
                     nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
-                    if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
-                    if (park == 1) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0];
+                    if (SG && !(IAMRX_RBW_EXP & 16)) nbf = face(park ? Sm.l : Sm.r, xs_m);
+                    if (!(IAMRX_RBW_EXP & 32)) { if (park == 1) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0]; }
                 } else if (NBR && XO && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
                     nb = xp_m;
                     if (SG) nbf = face(park ? Sm.l : Sm.r, xs_m);
@@ -1132,17 +1132,15 @@ bool abec_gsrb_rb_nbr_splits(const Geometry& g, const Layout& l)
 // two are filled by the caller -- neighbour boxes and periodic images; nothing is read beyond a domain wall but the density's first layer.
 // pin's red ghost cells next to open faces are overwritten (k_abec_rb_ghost); zero: pin's valid cells are not read, those ghost cells are
 // written.  pout's ghost cells are not written.
-void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                      const DomainBC* bcs, int nbc, int sel, hipStream_t on)
+template <int NW>
+static void abec_gsrb_rb_nbr_nw(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                                const DomainBC* bcs, int nbc, int sel, hipStream_t on)
 {
-    IAMRX_ASSERT(abec_gsrb_rb_nbr_ok(g, c, pin, rhs, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp && pout.ncomp == pin.ncomp);
     const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
-    if (pin.nlocal() == 0) return;
     auto& ctx = Context::get();
     hipStream_t strm = on ? on : ctx.stream;
     const Layout& l = *pin.layout;
     const int nbox = l.nlocal();
-    constexpr int NW = 16;
     const int wpr = l.max_len[0] / 128, rw = NW / wpr;
     const int nty = (l.max_len[1] + (rw - 2) - 1) / (rw - 2);
     // z-chunks: the number of workgroups as close below a whole number of rounds (one 1024-thread workgroup per CU) as the chunk length allows
@@ -1196,6 +1194,19 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
 #undef IAMRX_RBG
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
+}
+void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
+                      const DomainBC* bcs, int nbc, int sel, hipStream_t on)
+{
+    IAMRX_ASSERT(abec_gsrb_rb_nbr_ok(g, c, pin, rhs, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp && pout.ncomp == pin.ncomp);
+    if (pin.nlocal() == 0) return;
+    // the density form with walls or ghost columns spills at 1024 threads (76 ... 116 bytes of scratch per lane): 12 wavefronts, see abec_gsrb_rb
+    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+    const Layout& l = *pin.layout;
+    const int wpr = l.max_len[0] / 128;
+    const bool xo = l.max_len[0] != g.domain.len(0);
+    if (c.sig && (walls || xo) && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nbr_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on);
+    else abec_gsrb_rb_nbr_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on);
 }
 
 // IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given

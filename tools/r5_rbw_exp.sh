@@ -13,4 +13,4 @@ import csv,sys
 for r in csv.reader(sys.stdin): print('  ', r[0][:66], r[1], round(float(r[3])/1e3,1))"
   cd $R/iamr_amd/csrc
 done
-cd $R; timeout 600 python -m pytest tests/test_gpu_kernel_forms.py tests/test_gpu_walls.py tests/test_gpu_ldc.py tests/test_gpu_rb_nbr.py tests/test_gpu_sensitivity.py -q -x 2>&1 | tail -3
+cd $R
