@@ -509,6 +509,9 @@ __device__ __forceinline__ double gsr_lane_hi(double v)      // the value lane +
 #ifndef IAMRX_GSR_FENCE
 #define IAMRX_GSR_FENCE 2
 #endif
+#ifndef IAMRX_GSR_EXP
+#define IAMRX_GSR_EXP 0     // timing experiments on k_nodal_gsr (wrong results): 1: a product instead of the division, 2: no barriers, 4: no stores,
+#endif                      // 8: sigma taken as the constant (no ring reads), 16: no lane shifts, 32: no row exchange through LDS, 64: no sigma loads / ring stores
 struct GsrGeom {
     int ntx, nty;       // tiles per box and direction
     int tix, tiy;       // tile pitch (even, <= 56)
@@ -535,6 +538,7 @@ __device__ __forceinline__ double gsr_update(const NodeW& w, const double (&xm)[
     y += w.fx * (xc[1][0] * (smmm + smpm + smmp + smpp) + xc[1][2] * (spmm + sppm + spmp + sppp));
     y += w.fy * (xc[0][1] * (smmm + spmm + smmp + spmp) + xc[2][1] * (smpm + sppm + smpp + sppp));
     y += w.fz * (xm[1][1] * (smmm + spmm + smpm + sppm) + xp[1][1] * (smmp + spmp + smpp + sppp));
+    if (IAMRX_GSR_EXP & 1) return x0 + (rr - y) * s0;
     return x0 + (rr - y) / s0;
 }
 
@@ -728,7 +732,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     }
     load_rhs(k0, 0); load_rhs(k0, 1);
     fixedm = load_mask(k0);
-
+    double exp_sink = 0.0;      // (IAMRX_GSR_EXP & 4: keeps the arithmetic alive without the stores)
     for (int k = k0;; k += 2) {
         const bool has_next = k + 2 <= kend;
         // prefetch of plane k + 2 in two halves: the sigma cell plane k + 1 now; sigma k + 2 and the x planes k + 2, k + 3 after the even-j passes
@@ -738,13 +742,13 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         XB[lown] = Xm[PB - 1][0]; XB[lown + HX] = Xm[PB - 1][1];
         XB[BUF + lown] = Xc[PB - 1][0]; XB[BUF + lown + HX] = Xc[PB - 1][1];
         XB[2 * BUF + lown] = Xp[PB - 1][0]; XB[2 * BUF + lown + HX] = Xp[PB - 1][1];
-        __syncthreads();
+        if (!(IAMRX_GSR_EXP & 2)) __syncthreads();
         const double* SGm = SG + (CSIG ? 0 : slm * SPL + sgo);
         const double* SGp = SG + (CSIG ? 0 : slp * SPL + sgo);
         auto pass = [&](auto cxc, auto cyc) {
             constexpr int CX = decltype(cxc)::value, CY = decltype(cyc)::value, c = CX + 2 * CY;
             // the column outside the patch on the side of the nodes of this pass is the adjacent lane's: one DPP shift per value, on demand
-            auto fx = [&](const double (&P)[PB][2], int bb) { if constexpr (CX == 0) return gsr_lane_lo(P[bb][1]); else return gsr_lane_hi(P[bb][0]); };
+            auto fx = [&](const double (&P)[PB][2], int bb) { if constexpr (IAMRX_GSR_EXP & 16) return P[bb][1 - CX]; else if constexpr (CX == 0) return gsr_lane_lo(P[bb][1]); else return gsr_lane_hi(P[bb][0]); };
             // the row outside the patch: LDS (row -1 for the even-j colours, row PB for the odd-j ones)
             double em[3], ec[3], ep[3];
             {
@@ -753,7 +757,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const int o = lcol(base, CX + d - 1);
-                    em[d] = Bx[o]; ec[d] = Bx[BUF + o]; ep[d] = Bx[2 * BUF + o];
+                    if (IAMRX_GSR_EXP & 32) { em[d] = Xm[0][0]; ec[d] = Xc[0][0]; ep[d] = Xp[0][0]; } else { em[d] = Bx[o]; ec[d] = Bx[BUF + o]; ep[d] = Bx[2 * BUF + o]; }
                 }
             }
 #pragma unroll
@@ -777,7 +781,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
                 for (int db = -1; db <= 0; ++db)
 #pragma unroll
                     for (int da = -1; da <= 0; ++da) {
-                        if constexpr (CSIG) { tm[db + 1][da + 1] = csig; tp[db + 1][da + 1] = csig; }
+                        if constexpr (CSIG || (IAMRX_GSR_EXP & 8)) { tm[db + 1][da + 1] = csig; tp[db + 1][da + 1] = csig; }
                         else {
                             const int aa = CX + da;        // cell column -1, 0 or 1 of the patch
                             const int o = (b + db + 1) * 64 + (aa < 0 ? 31 : aa * 32);
@@ -815,23 +819,25 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
             if (gg.zn) zero_plane(Np); else load_plane(xn.gp(), xk(k + 3), xcol, xrow, Np);
             fetch_mask(k + 2);
         }
-        __syncthreads();
+        if (!(IAMRX_GSR_EXP & 2)) __syncthreads();
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         if (has_next) load_rhs(k + 2, 1);
         {
+            // (16-byte stores for the threads whose whole patch lies in the tile, without a branch per node, were measured: 107.3 against
+            // 108.7 us and 256 VGPRs + scratch in the ghost-filled variant -- the stores cost what their 68 MB cost, not their form)
             FabD::gdouble* po = xo.gp() + xk(k);
 #pragma unroll
             for (int b = 0; b < PB; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
                     if ((um[(2 * PB * 3 + 2 * b + a) >> 5] >> ((2 * PB * 3 + 2 * b + a) & 31)) & 1u) {
-                        gat(po, xrow[b] + xcol[a]) = Xc[b][a];
+                        if (!(IAMRX_GSR_EXP & 4)) gat(po, xrow[b] + xcol[a]) = Xc[b][a]; else exp_sink += Xc[b][a];
                     }
         }
         if (!has_next) break;
         // every wavefront is done with the sigma planes k - 1, k and the first rows of this plane
-        __syncthreads();
+        if (!(IAMRX_GSR_EXP & 2)) __syncthreads();
         if constexpr (!CSIG) ring_store(slm, T1);                     // sigma plane k + 2 replaces k - 1
         { const int t = slm; slm = slf; slf = slp; slp = t; }
         // rotate: k + 1 becomes the k - 1 plane
@@ -841,6 +847,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
             for (int a = 0; a < 2; ++a) { Xm[b][a] = Xp[b][a]; Xc[b][a] = Nc[b][a]; Xp[b][a] = Np[b][a]; }
         fixedm = mask_bits();
     }
+    if ((IAMRX_GSR_EXP & 4) && exp_sink == 1.2345e300) gat(xo.gp(), 0u) = exp_sink;
 #endif
 }
 
