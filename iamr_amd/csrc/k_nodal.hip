@@ -1524,6 +1524,9 @@ void nodal_restrict(MultiFab& crse, const MultiFab& fine)
     });
 }
 
+#ifndef IAMRX_INTERP_EXP
+#define IAMRX_INTERP_EXP 0      // timing experiments on k_nodal_interp_lds (wrong results): 1: constant side weights (no sigma loads), 2: plain store instead of the read-modify-write, 4: no divisions
+#endif
 // sigma-weighted interpolation (mlndlap_interpadd_aa)
 __device__ __forceinline__ double w_side(const FabD& s, int i, int j, int k, int d, int side)
 {
@@ -1552,8 +1555,13 @@ __device__ __forceinline__ double interp_face(const FabD& c, const FabD& s, int 
 }
 
 // the six side weights of a fine node from the 8 cells around it, summed in w_side's order
-__device__ __forceinline__ void side_weights(const FabD& s, int i, int j, int k, double w[6])
+template <class SA>
+__device__ __forceinline__ void side_weights(const SA& s, int i, int j, int k, double w[6])
 {
+#if IAMRX_INTERP_EXP & 1
+    for (int t = 0; t < 6; ++t) w[t] = 1.0 + 1e-3 * t;
+    return;
+#endif
     double g[2][2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1575,8 +1583,8 @@ __device__ __forceinline__ void side_weights(const FabD& s, int i, int j, int k,
 // the edge values inside the face values inside the centre value: ~200 dependent sigma loads for one centre node), then the tile is
 // added to the fine array with unit-stride stores.  Same expressions, same association order: bit-identical results.
 // the fine nodes of one parity class (PX, PY, PZ) of the tile, enumerated densely (all lanes busy)
-template <int PX, int PY, int PZ, int CX, int CY, int CZ>
-__device__ __forceinline__ void interp_class(double (*T)[2 * CY + 1][2 * CX + 1], const FabD& c, const FabD& s, int fi0, int fj0, int fk0,
+template <int PX, int PY, int PZ, int CX, int CY, int CZ, class SA>
+__device__ __forceinline__ void interp_class(double (*T)[2 * CY + 1][2 * CX + 1], const FabD& c, const SA& s, int fi0, int fj0, int fk0,
                                              int nhi0, int nhi1, int nhi2, int tid)
 {
     constexpr int NX = PX ? CX : CX + 1, NY = PY ? CY : CY + 1, NZ = PZ ? CZ : CZ + 1, CLS = PX + PY + PZ;
@@ -1590,7 +1598,7 @@ __device__ __forceinline__ void interp_class(double (*T)[2 * CY + 1][2 * CX + 1]
         if (CLS == 1) {
             constexpr int d = PX ? 0 : (PY ? 1 : 2);
             const double w1 = w[2 * d], w2 = w[2 * d + 1];
-            T[lz][ly][lx] = (T[lz - PZ][ly - PY][lx - PX] * w1 + T[lz + PZ][ly + PY][lx + PX] * w2) / (w1 + w2);
+            T[lz][ly][lx] = (IAMRX_INTERP_EXP & 4) ? (T[lz - PZ][ly - PY][lx - PX] * w1 + T[lz + PZ][ly + PY][lx + PX] * w2) * (w1 + w2) : (T[lz - PZ][ly - PY][lx - PX] * w1 + T[lz + PZ][ly + PY][lx + PX] * w2) / (w1 + w2);
         } else if (CLS == 2) {
             constexpr int d1 = PX ? 0 : 1, d2 = PZ ? 2 : 1;
             constexpr int ax = d1 == 0, ay = d1 == 1, by = d2 == 1, bz = d2 == 2;
@@ -1600,7 +1608,7 @@ __device__ __forceinline__ void interp_class(double (*T)[2 * CY + 1][2 * CX + 1]
             r += w2 * T[lz][ly + ay][lx + ax];
             r += w3 * T[lz - bz][ly - by][lx];
             r += w4 * T[lz + bz][ly + by][lx];
-            T[lz][ly][lx] = r / (w1 + w2 + w3 + w4);
+            T[lz][ly][lx] = (IAMRX_INTERP_EXP & 4) ? r * (w1 + w2 + w3 + w4) : r / (w1 + w2 + w3 + w4);
         } else {
             T[lz][ly][lx] = (w[0] * T[lz][ly][lx - 1] + w[1] * T[lz][ly][lx + 1] + w[2] * T[lz][ly - 1][lx] + w[3] * T[lz][ly + 1][lx]
                              + w[4] * T[lz - 1][ly][lx] + w[5] * T[lz + 1][ly][lx]) / (w[0] + w[1] + w[2] + w[3] + w[4] + w[5]);
@@ -1621,8 +1629,13 @@ __global__ void __launch_bounds__(256) k_nodal_interp_lds(const BoxD* __restrict
     const int nhi0 = vb.hi[0] + 1, nhi1 = vb.hi[1] + 1, nhi2 = vb.hi[2] + 1;
     const int fi0 = vb.lo[0] + tix * 2 * CX, fj0 = vb.lo[1] + tiy * 2 * CY, fk0 = vb.lo[2] + tiz * 2 * CZ;
     if (fi0 >= nhi0 || fj0 >= nhi1 || fk0 >= nhi2) return;
-    const FabD c = ct[fab], s = st[fab], fa = ft[fab];
+    const FabD c = ct[fab], sg = st[fab], fa = ft[fab];
     const int tid = threadIdx.x;
+    // (sigma of the tile in LDS -- one unit-stride pass, parity-split rows, no bank conflicts -- was measured twice: 230 / 235 us against 177 us.
+    // The side weights' 8 sigma loads per node and class ARE 103 of the 177 us (constant weights: 74 us, tools/r5_interp_exp.sh), but 27 KB more
+    // LDS per workgroup take the occupancy from 7 to 3 workgroups per CU, and the phases between the barriers are too short to do without it.
+    // What would work is one coarse cell per thread with its 27 sigma values in registers for all four phases -- not built.)
+    const FabD& s = sg;
 #define IAMRX_ICLS(PX, PY, PZ) interp_class<PX, PY, PZ, CX, CY, CZ>(T, c, s, fi0, fj0, fk0, nhi0, nhi1, nhi2, tid)
     IAMRX_ICLS(0, 0, 0);
     __syncthreads();
@@ -1638,7 +1651,7 @@ __global__ void __launch_bounds__(256) k_nodal_interp_lds(const BoxD* __restrict
         const int i = fi0 + lx, j = fj0 + ly, k = fk0 + lz;
         if (i > nhi0 || j > nhi1 || k > nhi2) continue;
         if ((lx == 2 * CX && i != nhi0) || (ly == 2 * CY && j != nhi1) || (lz == 2 * CZ && k != nhi2)) continue;   // the next tile owns it
-        fa(i, j, k) += T[lz][ly][lx];
+        if (IAMRX_INTERP_EXP & 2) fa(i, j, k) = T[lz][ly][lx]; else fa(i, j, k) += T[lz][ly][lx];
     }
 }
 
