@@ -301,6 +301,14 @@ int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, d
         rhs->mf.FillBoundary(gg);
         if (op == 8) p.FillBoundary(gg);
         abec_gsrb_rb_nbr(gg, c, p, out->mf, rhs->mf, omega, op == 9, &b, 1);
+    } else if (op == 10 || op == 11) {
+        // the sweep on a refined box strictly inside the domain (ratio 2): every face a coarse/fine face whose homogeneous ghost value of
+        // order `maxorder` the kernel forms itself (k_abec_gsrb_rb<.., W3>); phi's ghost cells are not read
+        if (!abec_gsrb_rb_cf_ok(gg, c, phi->mf)) throw Error("iamrx_abec_form: the coarse/fine red + black sweep does not apply to this level");
+        double loc[3];
+        for (int d = 0; d < 3; ++d) loc[d] = 0.5 * 2 * gg.dx[d];
+        const CfTab tab = cf_make_tab(loc, gg.dx, maxorder);
+        abec_gsrb_rb(gg, c, phi->mf, out->mf, rhs->mf, omega, op == 11, &b, 1, &tab);
     } else throw Error("iamrx_abec_form: bad op");
     IAMRX_CATCH
 }

@@ -627,7 +627,7 @@ __device__ __forceinline__ double rb_take(double v) { double r; asm volatile("v_
 // tile carries outside its box therefore pass their ghost values through instead of updating them, and the first / last lane of a row loads
 // the ghost column beyond an open x-face a plane ahead: its old black value for the red update, its new red value for the black update.
 // rhs (and the a-term) come with one filled ghost layer, the density with two (k_abec_rb_ghost forms the face coefficients of the ghost cell).
-struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; int dlo[3], dhi[3]; };
+struct RbBC { int per[3]; double c1lo[3], c2lo[3], c1hi[3], c2hi[3]; int dlo[3], dhi[3]; double c3lo[3] = {0.0, 0.0, 0.0}, c3hi[3] = {0.0, 0.0, 0.0}; };
 #ifndef IAMRX_RBW_EXP
 #define IAMRX_RBW_EXP 0      // timing experiments on the wall variant (wrong results): 1: no density loads beyond x-faces, 2: no wall terms in gamma, 4: no y / z wall ghosts, 8: no x-wall branch, 16: no face coefficient in the black x-wall branch, 32: no x wall weights, 64: no wall density in the red x-wall branch
 #endif
@@ -652,7 +652,11 @@ __device__ __forceinline__ double rb_update(double dhx, double dhy, double dhz, 
     return p0 + omega / g_m_d * res;
 }
 
-template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bool XO = false>
+// W3 (with WALLS, not NBR): the ghost formula has a THIRD weight, g = p0 c1 + p_in c2 + p_in2 c3 -- the homogeneous coarse/fine ghost value of
+// order 4 (k_cf_fill: the face cell, the cell behind it and the one behind that; for a red cell old black and old red, for a black cell the
+// new red and the old black: what a fill between the colours would have read).  p_in2 comes from the lane next to the face lane (x), from
+// 16-byte loads a plane ahead by the two face rows (y), and from the row registers or two direct loads at the box's last planes (z).
+template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bool XO = false, bool W3 = false>
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
     double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
     RbBC bc = RbBC(), const BoxD* __restrict__ boxes = nullptr, const FabD* __restrict__ pint = nullptr, const FabD* __restrict__ poutt = nullptr,
@@ -714,6 +718,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const bool olx = NBR && XO && !wxl && xw == 0, ohx = NBR && XO && !wxh && xw == wpr - 1;
     const bool atyl = wyl && j == b.lo[1], atyh = wyh && j == b.hi[1];
     auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
+    auto ghost3 = [](double p0, double pin_, double pin2, double c1, double c2, double c3) { return W3 ? (p0 * c1 + pin_ * c2) + pin2 * c3 : p0 * c1 + pin_ * c2; };
     // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
     typedef const __attribute__((address_space(1))) char gbyte;
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -772,6 +777,11 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     const unsigned oPx = xp_on ? rowoff(pin, (olx && !hasL) ? b.lo[0] - 1 : b.hi[0] + 1, j) : 0u;
     double xp_m = 0.0, xp_c = 0.0, xpN = 0.0;
     auto xpload = [&](int qq) { return xp_on ? ld1(plane(pin, qq, comp), oPx) : 0.0; };
+    // W3: the rows two inside a y-face of the box, for the pairs of the face rows (planes q - 1, q, in flight)
+    const bool y2_on = W3 && (atyl || atyh);
+    const unsigned oP2 = y2_on ? rowoff(pin, iL, atyl ? j + 2 : j - 2) : 0u;
+    D2 Y2m = Z2, Y2c = Z2, Y2N = Z2;
+    auto y2load = [&](int qq) { return (y2_on && !zero) ? ldp(pin, oP2, qq, comp) : Z2; };
     // zero start: phi is not read -- but for the ghost rows / planes of an open face, which hold k_abec_rb_ghost's reds (and zeros)
     auto pload = [&](int kk) { return (!zero || (NBR && (row_out || kk < b.lo[2] || kk > b.hi[2]))) ? ldp(pin, oP, kk, comp) : Z2; };
     double bn_prev = 0.0;
@@ -790,6 +800,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     YN yn, YNN = yload(q, parity(q));
     if (WALLS || (NBR && XO)) { xs_c = xsload(q - 1); xsN = xsload(q); }
     if (NBR && XO) { xp_c = xpload(q - 1); xpN = xpload(q); }
+    if (W3) { Y2c = y2load(q - 1); Y2N = y2load(q); }
     {   // black cells of the first plane
         const int par = parity(q);
         BPH[0][w][lane] = par ? Pp.l : Pp.r;
@@ -810,6 +821,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
         if (y_g) { if (!zero) yn.p = rb_take(YNN.p); if (SG) yn.s = rb_take(YNN.s); }
         if ((WALLS || (NBR && XO)) && SG) { xs_m = xs_c; xs_c = xs_on ? rb_take(xsN) : 0.0; }
         if (NBR && XO) { xp_m = xp_c; xp_c = xp_on ? rb_take(xpN) : 0.0; }
+        if (W3) { Y2m = Y2c; if (y2_on && !zero) { Y2c.l = rb_take(Y2N.l); Y2c.r = rb_take(Y2N.r); } }
         // the output of the previous iteration's black update (plane q - 2), BEFORE the loads: the wait for the loads at the top of the
         // next iteration then covers nothing younger than a whole iteration (a store behind them would be waited for as well)
         if (owner && q - 2 >= k0) put(q - 2, par, bn_prev, RNm);
@@ -821,6 +833,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             YNN = yload(q + 1, 1 - par);
             if ((WALLS || (NBR && XO)) && SG) xsN = xsload(q + 1);
             if (NBR && XO) xpN = xpload(q + 1);
+            if (W3 && y2_on && !zero) Y2N = y2load(q + 1);
         }
         // ---- red update of plane q
         const int bq = (q - k0 + 1) & 1;
@@ -831,10 +844,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             double nb = par == 0 ? rb_lane_lo(Pc.r) : rb_lane_hi(Pc.l), nbs = 0.0;
             if (SG) nbs = par == 0 ? rb_lane_lo(Sc.r) : rb_lane_hi(Sc.l);
             const double p0 = par ? Pc.r : Pc.l;
+            // (W3: the old red two cells inside an x-face = the red cell of the next pair)
+            const double x2 = W3 ? (par == 0 ? rb_lane_hi(Pc.l) : rb_lane_lo(Pc.r)) : 0.0;
             double cxl = 0.0, cxh = 0.0, czl = 0.0, czh = 0.0;
             if (par == 0 ? !hasL : !hasR) {
                 if (WALLS && !(IAMRX_RBW_EXP & 8) && (par == 0 ? wlx : whx)) {           // the red cell sits at an x-face of the domain
-                    nb = ghost(p0, par == 0 ? Pc.r : Pc.l, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0]);
+                    nb = ghost3(p0, par == 0 ? Pc.r : Pc.l, x2, par == 0 ? bc.c1lo[0] : bc.c1hi[0], par == 0 ? bc.c2lo[0] : bc.c2hi[0], par == 0 ? bc.c3lo[0] : bc.c3hi[0]);
                     if (SG && !(IAMRX_RBW_EXP & 64)) nbs = xs_c;
                     if (!(IAMRX_RBW_EXP & 32)) { if (par == 0) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0]; }
                 } else if (NBR && XO && (par == 0 ? olx : ohx)) {      // ... at an open x-face: the old black value of the ghost column
@@ -851,10 +866,18 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (yp_g) { pyp = yn.p; syp = yn.s; }
             double pzm = par ? Pm.r : Pm.l, pzp = par ? Pp.r : Pp.l;
             if (WALLS && !(IAMRX_RBW_EXP & 4)) {
-                if (atyl) pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]);
-                else if (atyh) pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]);
-                if (wzl && q == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); czl = bc.c1lo[2]; }
-                else if (wzh && q == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); czh = bc.c1hi[2]; }
+                const double y2 = W3 ? (par ? Y2c.r : Y2c.l) : 0.0;
+                if (atyl) pym = ghost3(p0, pyp, y2, bc.c1lo[1], bc.c2lo[1], bc.c3lo[1]);
+                else if (atyh) pyp = ghost3(p0, pym, y2, bc.c1hi[1], bc.c2hi[1], bc.c3hi[1]);
+                if (wzl && q == b.lo[2]) {
+                    // (W3: the old red of plane q + 2 is the row in flight: one wait per tile of the first chunk)
+                    const double z2 = W3 ? (par ? PN.r : PN.l) : 0.0;
+                    pzm = ghost3(p0, pzp, z2, bc.c1lo[2], bc.c2lo[2], bc.c3lo[2]); czl = bc.c1lo[2];
+                } else if (wzh && q == b.hi[2]) {
+                    double z2 = 0.0;
+                    if (W3 && !zero) { const D2 t2 = ldp(pin, oP, q - 2, comp); z2 = par ? t2.r : t2.l; }
+                    pzp = ghost3(p0, pzm, z2, bc.c1hi[2], bc.c2hi[2], bc.c3hi[2]); czh = bc.c1hi[2];
+                }
             }
             const double pxm = par == 0 ? nb : Pc.l, pxp = par == 0 ? Pc.r : nb;
             const double rr = par ? Rc.r : Rc.l;
@@ -889,10 +912,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             double nb = park == 1 ? rb_lane_lo(RNm) : rb_lane_hi(RNm), nbf = bu.v[0];
             if (SG) nbf = park == 1 ? rb_lane_lo(bfar_m) : rb_lane_hi(bfar_m);
             const double p0 = park ? Pm.l : Pm.r, rr = park ? Rm.l : Rm.r;
+            // (W3: the old black two cells inside an x-face = the black cell of the next pair)
+            const double x2 = W3 ? (park == 1 ? rb_lane_hi(Pm.l) : rb_lane_lo(Pm.r)) : 0.0;
             double cxl = 0.0, cxh = 0.0, czl = 0.0, czh = 0.0;
             if (park == 1 ? !hasL : !hasR) {
                 if (WALLS && !(IAMRX_RBW_EXP & 8) && (park == 1 ? wlx : whx)) {          // the black cell sits at an x-face: ghost from its own value and the new red beside it
-                    nb = ghost(p0, RNm, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0]);
+                    nb = ghost3(p0, RNm, x2, park == 1 ? bc.c1lo[0] : bc.c1hi[0], park == 1 ? bc.c2lo[0] : bc.c2hi[0], park == 1 ? bc.c3lo[0] : bc.c3hi[0]);
                     if (SG && !(IAMRX_RBW_EXP & 16)) nbf = face(park ? Sm.l : Sm.r, xs_m);
                     if (!(IAMRX_RBW_EXP & 32)) { if (park == 1) cxl = bc.c1lo[0]; else cxh = bc.c1hi[0]; }
                 } else if (NBR && XO && (park == 1 ? olx : ohx)) {     // ... at an open x-face: the new red value of the ghost column
@@ -906,10 +931,17 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             const double pxm = park == 1 ? nb : RNm, pxp = park == 1 ? RNm : nb;
             double pym = RED[slotk][w - wpr][lane], pyp = RED[slotk][w + wpr][lane], pzm = RNa, pzp = RNc;
             if (WALLS && !(IAMRX_RBW_EXP & 4)) {
-                if (atyl) pym = ghost(p0, pyp, bc.c1lo[1], bc.c2lo[1]);
-                else if (atyh) pyp = ghost(p0, pym, bc.c1hi[1], bc.c2hi[1]);
-                if (wzl && k == b.lo[2]) { pzm = ghost(p0, pzp, bc.c1lo[2], bc.c2lo[2]); czl = bc.c1lo[2]; }
-                else if (wzh && k == b.hi[2]) { pzp = ghost(p0, pzm, bc.c1hi[2], bc.c2hi[2]); czh = bc.c1hi[2]; }
+                const double y2 = W3 ? (park ? Y2m.l : Y2m.r) : 0.0;
+                if (atyl) pym = ghost3(p0, pyp, y2, bc.c1lo[1], bc.c2lo[1], bc.c3lo[1]);
+                else if (atyh) pyp = ghost3(p0, pym, y2, bc.c1hi[1], bc.c2hi[1], bc.c3hi[1]);
+                if (wzl && k == b.lo[2]) {
+                    const double z2 = W3 ? (park ? Pp.l : Pp.r) : 0.0;          // the old black of plane k + 2 = q + 1
+                    pzm = ghost3(p0, pzp, z2, bc.c1lo[2], bc.c2lo[2], bc.c3lo[2]); czl = bc.c1lo[2];
+                } else if (wzh && k == b.hi[2]) {
+                    double z2 = 0.0;
+                    if (W3 && !zero) { const D2 t2 = ldp(pin, oP, k - 2, comp); z2 = park ? t2.l : t2.r; }
+                    pzp = ghost3(p0, pzm, z2, bc.c1hi[2], bc.c2hi[2], bc.c3hi[2]); czh = bc.c1hi[2];
+                }
             }
             double bxm = bu.v[0], bxp = bu.v[0], bym = bu.v[1], byp = bu.v[1], bzm = bu.v[2], bzp = bu.v[2];
             if (SG) {
@@ -1038,6 +1070,24 @@ bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, 
     return c.b_uniform != 0;
 }
 
+// The sweep on a REFINED level that is one box strictly inside its domain (k_abec_gsrb_rb<.., WALLS, .., W3>): every face of the box is a
+// coarse/fine face, whose homogeneous ghost value (k_cf_fill, correction form) is the three-weight formula of the level's CfTab -- the
+// kernel evaluates it on the values at hand and reads no ghost cell of phi.  IAMRX_GSRB_RB_CF (1): 0 = colour passes (k_abec_gsrb2<.., CF>).
+bool abec_gsrb_rb_cf_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi)
+{
+    if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("GSRB_RB_CF", 1) == 0) return false;
+    const Layout& l = *phi.layout;
+    if (l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    const BoxD& b = l.boxes[0];
+    for (int d = 0; d < 3; ++d) if (!(b.lo[d] > g.domain.lo[d] && b.hi[d] < g.domain.hi[d])) return false;
+    const int nx = b.len(0);
+    if (nx != 128 && nx != 256) return false;
+    if ((b.len(1) & 1) || (b.len(2) & 1) || b.len(1) < 16 || b.len(2) < 16) return false;
+    if (phi.ngrow < 1 || c.b[0]->ncomp != 1) return false;
+    if (c.sig) return phi.ncomp == 1 && c.sig->ngrow >= 1 && !(c.a && c.alpha != 0.0);
+    return c.b_uniform != 0;
+}
+
 // The sweep on a level of SEVERAL boxes that covers its domain (k_abec_gsrb_rb<.., NBR>: a chopped level, the boxes of a sharded level):
 // what the level must look like -- rows of 128 or 256 cells in every box, no coarse/fine faces (the caller knows), wall conditions the
 // kernel has a ghost formula for.  The arrays: phi (both buffers) with two ghost layers, the density with two, rhs and the a-term with one
@@ -1071,9 +1121,9 @@ bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& p
 // one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
 template <int NW>
 static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                            const DomainBC* bcs, int nbc)
+                            const DomainBC* bcs, int nbc, const CfTab* cf)
 {
-    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+    const bool walls = cf != nullptr || !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     auto& ctx = Context::get();
     const Layout& l = *pin.layout;
     const BoxD b = l.boxes[l.local[0]];
@@ -1092,9 +1142,28 @@ static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab
         BUni bn;
         for (int d = 0; d < 3; ++d) bn.v[d] = c.bu[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
         RbBC rbc;
+        if (cf) {
+            // every face a coarse/fine face: k_cf_fill's weights (NX = min(len + 1, maxorder) points, the first of them the boundary value: zero here)
+            for (int d = 0; d < 3; ++d) {
+                const int NX = std::min(b.len(d) + 1, cf->maxorder);
+                const double* w = cf->c[d][NX - 2];
+                rbc.per[d] = 0;
+                rbc.c1lo[d] = rbc.c1hi[d] = w[1];
+                rbc.c2lo[d] = rbc.c2hi[d] = NX > 2 ? w[2] : 0.0;
+                rbc.c3lo[d] = rbc.c3hi[d] = NX > 3 ? w[3] : 0.0;
+                rbc.dlo[d] = b.lo[d]; rbc.dhi[d] = b.hi[d];
+            }
+        } else
         if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
 #define IAMRX_RB(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
                                                       c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc)
+#define IAMRX_RB3(M, HA, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, true, false, false, true>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
+                                                      c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc)
+        if (cf) {
+            if (c.sig) IAMRX_RB3(1, false, c.sig_comp, c.sig_scale);
+            else if (has_a) IAMRX_RB3(2, true, 0, 1.0);
+            else IAMRX_RB3(2, false, 0, 1.0);
+        } else
         if (walls) {
             if (c.sig) IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale);
             else if (has_a) IAMRX_RB(2, true, true, 0, 1.0);
@@ -1105,20 +1174,21 @@ static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab
             else IAMRX_RB(2, false, false, 0, 1.0);
         }
 #undef IAMRX_RB
+#undef IAMRX_RB3
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                  const DomainBC* bcs, int nbc)
+                  const DomainBC* bcs, int nbc, const CfTab* cf)
 {
-    IAMRX_ASSERT(abec_gsrb_rb_ok(g, c, pin, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
+    IAMRX_ASSERT((cf ? abec_gsrb_rb_cf_ok(g, c, pin) : abec_gsrb_rb_ok(g, c, pin, nbc, bcs)) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
     if (pin.nlocal() == 0) return;
     // The density form on a domain with walls needs more than the 128 VGPRs a 1024-thread workgroup leaves a thread (72 bytes of scratch per
     // lane, 210 us per 256^3 sweep): 12 wavefronts (768 threads: 168 VGPRs) trade two of the eight rows of a tile for a spill-free loop
-    const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
+    const bool walls = cf != nullptr || !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     const int wpr = pin.layout->boxes[pin.layout->local[0]].len(0) / 128;
-    if (walls && c.sig && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc);
-    else abec_gsrb_rb_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc);
+    if (walls && c.sig && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf);
+    else abec_gsrb_rb_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf);
 }
 
 // the sweep of this level can be issued in two parts -- the tiles that read no ghost cell (sel 1) and the others (sel 2, behind the exchange):

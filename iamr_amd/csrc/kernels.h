@@ -105,8 +105,10 @@ bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wra
 // one red + black sweep in ONE launch, out of place (pin -> pout), on a level that is one box spanning a periodic domain (k_abec_gsrb_rb: the
 // doubles of the two colour passes, a third of their HBM traffic); zero: pin is identically zero and is not read
 bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs = nullptr);
+// cf: the level is a refined box strictly inside its domain (abec_gsrb_rb_cf_ok): its coarse/fine ghost formula, evaluated inside the kernel
 void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                  const DomainBC* bcs = nullptr, int nbc = 0);
+                  const DomainBC* bcs = nullptr, int nbc = 0, const CfTab* cf = nullptr);
+bool abec_gsrb_rb_cf_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi);
 // the same sweep on a level of several boxes that covers its domain (a chopped level, the boxes of a sharded level): k_abec_rb_ghost +
 // k_abec_gsrb_rb<.., NBR>, one two-layer ghost fill of phi per sweep in front of it (the caller's).  level_ok: the layout / boundary
 // conditions admit it (the caller then gives phi two ghost layers, rhs and the a-term one, the density two); ok: these arrays do

@@ -104,6 +104,7 @@ public:
     void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero = false);
     bool fused_smoother_ok(int l) const;
     bool nbr_sweep_ok(int l, const MultiFab& sol, const MultiFab& rhs) const;
+    bool cf_sweep_ok(int l, const MultiFab& sol) const;
     void vcycle(MGStats& st);
     MultiFab& res(int l) { return m_lev[l].res; }
     MultiFab& cor(int l) { return m_lev[l].cor; }

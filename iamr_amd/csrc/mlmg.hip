@@ -364,9 +364,33 @@ bool CellMG::nbr_sweep_ok(int l, const MultiFab& sol, const MultiFab& rhs) const
     return abec_gsrb_rb_nbr_ok(m_lev[l].g, c, sol, rhs, (int)m_bcn.size(), m_bcn.data());
 }
 
+// smooth_n runs the sweep kernel with in-kernel coarse/fine faces on this level (a refined box strictly inside its domain, finest level)
+bool CellMG::cf_sweep_ok(int l, const MultiFab& sol) const
+{
+    if (l != 0 || !m_cf) return false;
+    AbecCoef c = coef(l);
+    c.tensor = 0;
+    return abec_gsrb_rb_cf_ok(m_lev[l].g, c, sol);
+}
+
 void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero)
 {
     if (nsweeps <= 0) { if (sol_is_zero) sol.setVal(0.0); return; }
+    if (cf_sweep_ok(l, sol)) {
+        // red + black in one out-of-place launch per sweep, the coarse/fine ghost values formed inside the kernel (no k_cf_fill, no ghost
+        // maintenance; sol's ghost cells are left stale: every reader behind a smoothing call fills them)
+        AbecCoef c = coef(l);
+        c.tensor = 0;
+        Level& L = m_lev[l];
+        if (!L.buf.defined()) L.buf.define(L.layout, cell_type(), m_ncomp, 1);
+        MultiFab* a = &sol;
+        MultiFab* b = &L.buf;
+        if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
+        const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
+        for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size(), &L.cftab); std::swap(a, b); }
+        if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
+        return;
+    }
     if (!m_cf) {
         // one box spanning a periodic domain: red + black in one out-of-place launch per sweep (k_abec_gsrb_rb), ping-pong with the level's buffer
         AbecCoef c = coef(l);
@@ -532,8 +556,8 @@ void CellMG::bottom_solve(MGStats& st)
     if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
         AbecCoef c = coef(l);
         c.tensor = 0;
-        if (!m_cf && (abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data()) ||
-                      nbr_sweep_ok(l, L.cor, L.res))) {
+        if ((!m_cf && (abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data()) ||
+                       nbr_sweep_ok(l, L.cor, L.res))) || cf_sweep_ok(l, L.cor)) {
             smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true);      // the first sweep takes the correction as zero: no fill, nothing read
             return;
         }
@@ -589,7 +613,7 @@ void CellMG::vcycle(MGStats& st)
     for (int l = 0; l < nsm; ++l) {
         Level& L = m_lev[l];
         // zero initial guess of the correction: where the first colour pass reads no ghost cell it also takes the place of the fill
-        const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res));
+        const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res) || cf_sweep_ok(l, L.cor));
         if (!z) L.cor.setVal(0.0);
         smooth_n(l, L.cor, L.res, m_o.nu1, true, z);
         const AbecCoef cl = coef(l);

@@ -171,7 +171,11 @@ int iamrx_abec_gsrb(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /
  * 7: the same with phi taken as zero without being read; 8 / 9: the sweep of 6 / 7 on a level of SEVERAL boxes that covers its domain (a
  * chopped level; the boxes of a level sharded over GPUs; rows of 128 / 256 cells in every box): phi and out with two ghost layers, rhs
  * with one, rho with two -- the entry fills them from the neighbour boxes / periodic images (one exchange per sweep instead of one per
- * colour; rho's ghost cells beyond domain walls stay the caller's), updates the red ghost cells next to box faces in place and sweeps. */
+ * colour; rho's ghost cells beyond domain walls stay the caller's), updates the red ghost cells next to box faces in place and sweeps;
+ * 10 / 11: the sweep of 6 / 7 on a REFINED level that is one box strictly inside the domain g (ratio 2 to the level below; the role of
+ * MLLinOp::setCoarseFineBC's homogeneous ghost values inside MLMG::mgVcycle on a level set up by MacProj.cpp:1166-1170): every face of the
+ * box is a coarse/fine face whose ghost value of order `maxorder` (<= 4: the face cell, the cell behind it and the one behind that) the
+ * kernel forms itself; no ghost cell of phi is read, rho's first ghost layer is the caller's (FillPatch). */
 int iamrx_abec_form(const iamrx_geom* g, int coef, iamrx_mf rho, int rho_comp, double scale, const double bu[3], double beta, int op,
                     iamrx_mf phi, iamrx_mf rhs, iamrx_mf out, double omega, const int lobc[3], const int hibc[3], int maxorder);
 int iamrx_abec_gsrb_sweep(const iamrx_geom* g, double alpha, double beta, iamrx_mf a /* may be NULL */, iamrx_mf bx, iamrx_mf by, iamrx_mf bz,

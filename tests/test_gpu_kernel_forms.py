@@ -240,3 +240,58 @@ def test_one_launch_sweep_with_domain_walls_matches_the_oracle(orc, gpu, n, case
             a, b = b, a
             got, ref = a.gather_valid(n), phi_o.valid(n)
             assert np.array_equal(got, ref), (case, start, sweep, float(np.nanmax(np.abs(got - ref))), int(np.isnan(got).sum()))
+
+
+@pytest.mark.parametrize("coef", [1, 2])
+@pytest.mark.parametrize("maxorder", [2, 3, 4])
+@pytest.mark.parametrize("nb", [(128, 20, 16), (256, 32, 48)])
+def test_one_launch_sweep_on_a_refined_box_matches_the_oracle(orc, gpu, nb, maxorder, coef):
+    """k_abec_gsrb_rb<., WALLS, ., ., W3> (round 5): the one-launch sweep on a refined level that is one box strictly inside its domain --
+    every face a coarse/fine face.  The kernel reads no ghost cell of phi (poisoned here): beyond a face it evaluates the homogeneous
+    coarse/fine ghost value of the level's maxorder (up to three cells deep: face cell, the cell behind it, the one behind that) on the
+    values at hand, as the fill in front of each colour pass of the reference sequence does (MLLinOp::setCoarseFineBC on a level set
+    up as in MacProj.cpp:1166-1170; homogeneous inside MLMG::mgVcycle).  Against the oracle's colour passes with its on-the-fly
+    coarse/fine ghost values (orc_abec_gsrb on a level with a box list), two sweeps, from a field and from a zero start."""
+    lib = gpu
+    L = orc.lib()
+    off = 8
+    n = tuple(v + 2 * off for v in nb)
+    box = (tuple([off] * 3), tuple(off + v - 1 for v in nb))
+    g_o, g_d = orc.geom(n), lib.Geom.make(n)
+    lay = lib.Layout([box])
+    rho, phi, rhs = fields(n, 33 + maxorder)
+    scale, bu, beta = 0.37, (0.8, 1.1, 1.3), 1.0
+    b_o = []
+    for d in range(3):
+        bf = orc.Fab(n, orc.face(d), 0, 1)
+        if coef == 1:
+            lo = [slice(1, n[e] + 1) for e in range(3)]; hi = [slice(1, n[e] + 1) for e in range(3)]
+            lo[d] = slice(0, n[d] + 1); hi[d] = slice(1, n[d] + 2)
+            bf.a[..., 0] = scale / (0.5 * (rho[tuple(lo)] + rho[tuple(hi)]))
+        else:
+            bf.a[...] = bu[d]
+        b_o.append(bf)
+    lev = orc.abec_level(g_o, b_o, beta=beta, boxes=[box], ratio=2)
+    rhs_o = orc.Fab(n, orc.CELL, 0, 1); rhs_o.a[..., 0] = rhs
+    rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1,) * 3)
+    rhs_d = lib.MultiFab(lay, lib.CELL, 1, 0); rhs_d.set_from_global(rhs[..., None], (0,) * 3)
+    kw = dict(rho=rho_d, scale=scale, bu=bu, beta=beta, maxorder=maxorder)
+    z3 = orc.i3([0, 0, 0])
+    inside = tuple(slice(off, off + v) for v in nb)
+    for start in ("field", "zero"):
+        phi_o = orc.Fab(n, orc.CELL, 1, 1)
+        phi_o.a[..., 0] = phi if start == "field" else 0.0
+        a = lib.MultiFab(lay, lib.CELL, 1, 1); b = lib.MultiFab(lay, lib.CELL, 1, 1)
+        loc = np.full(tuple(v + 2 for v in nb) + (1,), np.nan)          # the box with its ghost layer: ghost cells poisoned
+        loc[1:-1, 1:-1, 1:-1, 0] = phi[1:-1, 1:-1, 1:-1][inside]
+        a.from_numpy(loc)                                                # (zero start: the kernel must not read it at all)
+        b.setval(np.nan)
+        for sweep in range(2):
+            for rb in (0, 1):
+                L.orc_abec_applybc(C.byref(lev), phi_o.ref(), z3, z3, maxorder, 0, None)      # (sets the homogeneous form and the order)
+                L.orc_abec_gsrb(C.byref(lev), phi_o.ref(), rhs_o.ref(), rb, C.c_double(1.15), z3, z3, maxorder)
+            lib.abec_form(g_d, coef, 11 if (start == "zero" and sweep == 0) else 10, a, rhs_d, out=b, **kw)
+            a, b = b, a
+            got, ref = a.gather_valid(n)[..., 0][inside], phi_o.valid(n)[..., 0][inside]
+            assert not np.isnan(got).any(), (start, sweep, int(np.isnan(got).sum()))
+            assert np.array_equal(got, ref), (maxorder, start, sweep, float(np.abs(got - ref).max()), int((got != ref).sum()))
