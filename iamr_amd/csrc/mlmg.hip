@@ -613,7 +613,10 @@ void CellMG::vcycle(MGStats& st)
     for (int l = 0; l < nsm; ++l) {
         Level& L = m_lev[l];
         // zero initial guess of the correction: where the first colour pass reads no ghost cell it also takes the place of the fill
-        const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res) || cf_sweep_ok(l, L.cor));
+        // (the sweep kernel takes "zero" per component: the three components of a tensor solve start from zero too)
+        bool rb_zero = false;
+        if (l == 0 && !m_cf && m_ncomp > 1) { AbecCoef cz = coef(l); cz.tensor = 0; rb_zero = abec_gsrb_rb_ok(L.g, cz, L.cor, (int)m_bcn.size(), m_bcn.data()); }
+        const bool z = m_o.nu1 > 0 && (zero_first_pass_ok(l, L.cor) || nbr_sweep_ok(l, L.cor, L.res) || cf_sweep_ok(l, L.cor) || rb_zero);
         if (!z) L.cor.setVal(0.0);
         smooth_n(l, L.cor, L.res, m_o.nu1, true, z);
         const AbecCoef cl = coef(l);
