@@ -717,7 +717,6 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     // open x-faces (XO: the boxes do not span the domain in x -- else a periodic x wraps inside the row as on a single box): the ghost column is loaded
     const bool olx = NBR && XO && !wxl && xw == 0, ohx = NBR && XO && !wxh && xw == wpr - 1;
     const bool atyl = wyl && j == b.lo[1], atyh = wyh && j == b.hi[1];
-    auto ghost = [](double p0, double pin_, double c1, double c2) { return p0 * c1 + pin_ * c2; };
     auto ghost3 = [](double p0, double pin_, double pin2, double c1, double c2, double c3) { return W3 ? (p0 * c1 + pin_ * c2) + pin2 * c3 : p0 * c1 + pin_ * c2; };
     // loads: a uniform plane pointer (scalar registers) + a 32-bit byte offset per thread -- no 64-bit address registers per array and row
     typedef const __attribute__((address_space(1))) char gbyte;

@@ -151,6 +151,14 @@ private:
     bool m_tensor_eta = false;
     bool m_singular = false;
     bool m_bottom_dev = false;    // the coarsest level is solved by k_abec_bottom (one single-workgroup launch, no host synchronisation)
+    // tensor operator with constant viscosity whose coarsest level is one box of <= 27 cells: that level is solved DIRECTLY by one
+    // single-workgroup launch (k_dense_bottom: M = alpha diag(a) + beta B assembled from the cached operator matrix B, Gauss-Jordan
+    // with partial pivoting) instead of the host-driven BiCGStab (mlmg.hip: bottom_direct_prepare)
+    bool m_bottom_direct = false;
+    const double* m_dB = nullptr;  // the cached matrix (device, column-major, m_dN x m_dN)
+    int m_dN = 0;
+    void bottom_direct_prepare();
+    void bottom_direct_solve();
     double m_dd_rho = 0.0;        // estimated contraction of one red-black sweep of a diagonally dominant operator (prepare())
     int m_dd_sweeps = 0;          // > 0: diagonally dominant operator solved by sweeps of the finest level only (prepare())
     // the finest level is several boxes covering the domain and takes the one-launch red + black sweep (k_abec_gsrb_rb<.., NBR>): its

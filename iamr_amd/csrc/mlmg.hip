@@ -243,6 +243,7 @@ void CellMG::prepare()
             }
         }
     }
+    bottom_direct_prepare();
 }
 
 
@@ -549,6 +550,151 @@ static int* bottom_iters_dev()
     return d;
 }
 
+
+// ---------------------------------------------------------------------------- direct bottom solve of the tensor operator
+// The coarsest level of a tensor solve (MLTensorOp: three coupled components, cross terms) is 2^3 ... 3^3 cells.  amrex::MLMG hands it to
+// BiCGStab (bottom_reltol 1e-4); driven from the host that is ~60 launches and ~10 read-backs per V-cycle (0.8 ms of a 3.8 ms cycle at
+// 256^3, and the read-backs drain the launch queue).  Here the level's operator matrix is used instead: with constant viscosity the
+// operator is A = alpha diag(a) + beta B, where B (the level's geometry, boundary conditions and viscosity constants only) is built ONCE
+// per distinct level of a run -- column m = the operator kernels applied to the m-th unit vector, the same applyBC + abec_residual the
+// Krylov iteration would call -- and kept on the device; a bottom solve is then one single-workgroup launch that assembles A from B and
+// the level's a-term and solves A cor = res by Gauss-Jordan elimination with partial pivoting.  The bottom solve becomes exact instead of
+// 1e-4: the same converged solution of the solve (every tensor test compares it with the oracle's BiCGStab hierarchy).
+// IAMRX_TENSOR_BOTTOM_DIRECT (1): 0 = the host-driven BiCGStab.
+namespace {
+constexpr int DENSE_MAXN = 81;
+struct DenseEntry { std::vector<unsigned char> key; double* dB; int N; };
+std::vector<DenseEntry>& dense_cache() { static std::vector<DenseEntry> c; return c; }
+
+__global__ void k_dense_set_one(FabD x, int i, int j, int k, int n, double v) { x(i, j, k, n) = v; }
+
+__global__ void __launch_bounds__(256) k_dense_column(FabD y, BoxD b, int nc, double* col)
+{
+    const int nx = b.len(0), ny = b.len(1), ncell = nx * ny * b.len(2);
+    for (int r = (int)threadIdx.x; r < ncell * nc; r += 256) {
+        const int n = r / ncell, q = r - n * ncell;
+        const int i = q % nx, j = (q / nx) % ny, k = q / (nx * ny);
+        col[r] = y(b.lo[0] + i, b.lo[1] + j, b.lo[2] + k, n);
+    }
+}
+
+// A cor = res with A = alpha diag(a) + beta B; unknown r = comp * ncell + cell (x fastest); one workgroup, the augmented matrix in LDS
+__global__ void __launch_bounds__(256) k_dense_bottom(const double* __restrict__ B, int N, BoxD b, int nc, FabD a, int has_a, double alpha, double beta,
+                                                     FabD res, FabD cor)
+{
+    extern __shared__ double M[];               // N rows of N + 1 entries
+    __shared__ double F[DENSE_MAXN];
+    __shared__ int piv;
+    const int tid = (int)threadIdx.x, W = N + 1;
+    const int nx = b.len(0), ny = b.len(1), ncell = nx * ny * b.len(2);
+    auto cell = [&](int r, int& i, int& j, int& k, int& n) {
+        n = r / ncell; const int q = r - n * ncell;
+        i = b.lo[0] + q % nx; j = b.lo[1] + (q / nx) % ny; k = b.lo[2] + q / (nx * ny);
+    };
+    for (int idx = tid; idx < N * N; idx += 256) {
+        const int c = idx / N, r = idx - c * N;     // B is column-major: consecutive threads read consecutive entries
+        double v = beta * B[idx];
+        if (r == c && has_a) { int i, j, k, n; cell(r, i, j, k, n); v += alpha * a(i, j, k, 0); }
+        M[r * W + c] = v;
+    }
+    for (int r = tid; r < N; r += 256) { int i, j, k, n; cell(r, i, j, k, n); M[r * W + N] = res(i, j, k, n); }
+    __syncthreads();
+    for (int p = 0; p < N; ++p) {
+        if (tid < 64) {                          // pivot row: the largest |M[r][p]|, r >= p (first wavefront)
+            double best = -1.0; int bi = p;
+            for (int r = p + tid; r < N; r += 64) { const double v = fabs(M[r * W + p]); if (v > best) { best = v; bi = r; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) piv = bi;
+        }
+        __syncthreads();
+        const int pr = piv;
+        if (pr != p) for (int c = p + tid; c < W; c += 256) { const double t = M[p * W + c]; M[p * W + c] = M[pr * W + c]; M[pr * W + c] = t; }
+        __syncthreads();
+        const double d = M[p * W + p];
+        for (int r = tid; r < N; r += 256) F[r] = r == p ? 0.0 : M[r * W + p] / d;
+        __syncthreads();
+        const int nc_left = W - (p + 1);
+        for (int idx = tid; idx < N * nc_left; idx += 256) {
+            const int r = idx / nc_left, c = p + 1 + (idx - r * nc_left);
+            M[r * W + c] -= F[r] * M[p * W + c];
+        }
+        __syncthreads();
+    }
+    for (int r = tid; r < N; r += 256) { int i, j, k, n; cell(r, i, j, k, n); cor(i, j, k, n) = M[r * W + N] / M[r * W + r]; }
+}
+}  // namespace
+
+void CellMG::bottom_direct_prepare()
+{
+    m_bottom_direct = false;
+    const int l = (int)m_lev.size() - 1;
+    if (tune("TENSOR_BOTTOM_DIRECT", 1) == 0 || !m_tensor || m_dd_sweeps > 0 || l < 1 || m_o.bottom_smoother_only || !m_buni_coarse) return;
+    if (!(m_a0 && m_alpha != 0.0)) return;                   // (the tensor solves of the path all carry the density term: never singular)
+    const Level& L = m_lev[l];
+    if (L.slab || L.layout->boxes.size() != 1 || L.layout->nlocal() != 1) return;
+    const BoxD b = L.layout->boxes[0];
+    const int N = (int)b.npts() * m_ncomp;
+    // the box is the whole level: it spans the domain, or (a refined level: homogeneous coarse/fine values on its faces, k_cf_fill) it is the only one
+    if (N > DENSE_MAXN || (!m_cf && b.npts() != L.g.domain.npts()) || (m_cf && tune("TENSOR_BOTTOM_DIRECT_CF", 1) == 0)) return;
+    // what B depends on
+    std::vector<unsigned char> key;
+    auto put = [&](const void* p, size_t n) { const unsigned char* q = (const unsigned char*)p; key.insert(key.end(), q, q + n); };
+    put(L.g.domain.lo, sizeof(L.g.domain.lo)); put(L.g.domain.hi, sizeof(L.g.domain.hi)); put(L.g.dx, sizeof(L.g.dx)); put(L.g.periodic, sizeof(L.g.periodic));
+    put(&m_ncomp, sizeof(int));
+    for (const DomainBC& d : m_bcn) { put(d.lo, sizeof(d.lo)); put(d.hi, sizeof(d.hi)); put(&d.maxorder, sizeof(int)); }
+    put(m_bu, sizeof(m_bu));
+    const int te = m_tensor_eta ? 1 : 0;
+    put(&te, sizeof(int));
+    const int cf = m_cf ? 1 : 0;
+    put(&cf, sizeof(int));
+    if (m_cf) {
+        // a box that touches no side of the domain: B depends on its size only, not on where it lies (regrids move it)
+        bool inside = true;
+        for (int d = 0; d < 3; ++d) inside = inside && b.lo[d] > L.g.domain.lo[d] && b.hi[d] < L.g.domain.hi[d];
+        const int len[3] = {b.len(0), b.len(1), b.len(2)};
+        if (inside) put(len, sizeof(len)); else { put(b.lo, sizeof(b.lo)); put(b.hi, sizeof(b.hi)); }
+        put(L.cftab.c, sizeof(L.cftab.c)); put(&L.cftab.maxorder, sizeof(int));
+    }
+    for (const DenseEntry& e : dense_cache()) if (e.key == key) { m_dB = e.dB; m_dN = e.N; m_bottom_direct = true; return; }
+    // build: column m = the operator (alpha 0, beta 1) applied to the m-th unit vector under the level's homogeneous boundary conditions
+    auto& ctx = Context::get();
+    double* dB = nullptr;
+    IAMRX_HIP_CHECK(hipMalloc(&dB, sizeof(double) * (size_t)N * N));
+    MultiFab x(L.layout, cell_type(), m_ncomp, 1), y(L.layout, cell_type(), m_ncomp, 0);
+    AbecCoef c = coef(l);
+    c.alpha = 0.0; c.beta = 1.0; c.a = nullptr;
+    const int nx = b.len(0), ny = b.len(1), ncell = (int)b.npts();
+    for (int m = 0; m < N; ++m) {
+        const int n = m / ncell, q = m - n * ncell;
+        x.setVal(0.0);
+        hipLaunchKernelGGL(k_dense_set_one, dim3(1), dim3(1), 0, ctx.stream, x.h_tab[0], b.lo[0] + q % nx, b.lo[1] + (q / nx) % ny, b.lo[2] + q / (nx * ny), n, 1.0);
+        applyBC(l, x, false, nullptr);
+        abec_residual(L.g, c, y, x, nullptr);
+        hipLaunchKernelGGL(k_dense_column, dim3(1), dim3(256), 0, ctx.stream, y.h_tab[0], b, m_ncomp, dB + (size_t)m * N);
+    }
+    ctx.sync();
+    if (dense_cache().size() >= 64) {            // (a long run with many distinct coarsest levels: the oldest matrix goes)
+        IAMRX_HIP_CHECK(hipFree(dense_cache().front().dB));
+        dense_cache().erase(dense_cache().begin());
+    }
+    dense_cache().push_back(DenseEntry{key, dB, N});
+    m_dB = dB; m_dN = N; m_bottom_direct = true;
+}
+
+void CellMG::bottom_direct_solve()
+{
+    const int l = (int)m_lev.size() - 1;
+    Level& L = m_lev[l];
+    const AbecCoef c = coef(l);
+    const BoxD b = L.layout->boxes[0];
+    const size_t lds = sizeof(double) * (size_t)m_dN * (m_dN + 1);
+    hipLaunchKernelGGL(k_dense_bottom, dim3(1), dim3(256), lds, Context::get().stream, m_dB, m_dN, b, m_ncomp, c.a->h_tab[0], 1, c.alpha, c.beta,
+                       L.res.h_tab[0], L.cor.h_tab[0]);
+}
+
 void CellMG::bottom_solve(MGStats& st)
 {
     const int l = (int)m_lev.size() - 1;
@@ -565,6 +711,7 @@ void CellMG::bottom_solve(MGStats& st)
         smooth_n(l, L.cor, L.res, m_dd_sweeps, true);
         return;
     }
+    if (m_bottom_direct) { bottom_direct_solve(); return; }
     L.cor.setVal(0.0);
     if (m_o.bottom_smoother_only) {
         smooth_n(l, L.cor, L.res, m_o.nuf, true);
