@@ -656,7 +656,10 @@ __device__ __forceinline__ double rb_update(double dhx, double dhy, double dhz, 
 // order 4 (k_cf_fill: the face cell, the cell behind it and the one behind that; for a red cell old black and old red, for a black cell the
 // new red and the old black: what a fill between the colours would have read).  p_in2 comes from the lane next to the face lane (x), from
 // 16-byte loads a plane ahead by the two face rows (y), and from the row registers or two direct loads at the box's last planes (z).
-template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bool XO = false, bool W3 = false>
+// ACC: the sweep is the LAST one of a V-cycle on the finest level and `pout` is the SOLUTION: the kernel stores pout + (the swept correction)
+// instead of the correction -- the `sol += cor` pass behind the V-cycle (24 bytes per cell) becomes 8 more bytes read by this launch; the
+// solution's row pairs are fetched a plane ahead like every other load.  Same doubles (sol + 1.0 * cor).
+template <int BMODE, int NW, bool HASA, bool WALLS = false, bool NBR = false, bool XO = false, bool W3 = false, bool ACC = false>
 __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD pout, FabD rhs, FabD A, FabD S, double alpha,
     double dhx, double dhy, double dhz, double omega, int sig_comp, double sig_scale, BUni bu, int wpr, int tz, int nty, int zero, int comp, int xcd_chunk,
     RbBC bc = RbBC(), const BoxD* __restrict__ boxes = nullptr, const FabD* __restrict__ pint = nullptr, const FabD* __restrict__ poutt = nullptr,
@@ -784,9 +787,12 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
     // zero start: phi is not read -- but for the ghost rows / planes of an open face, which hold k_abec_rb_ghost's reds (and zeros)
     auto pload = [&](int kk) { return (!zero || (NBR && (row_out || kk < b.lo[2] || kk > b.hi[2]))) ? ldp(pin, oP, kk, comp) : Z2; };
     double bn_prev = 0.0;
+    D2 CN = Z2;             // ACC: the solution's pair of the plane the next `put` writes
+    auto cload = [&](int k) { return ldpair(pout.gp() + (long)pout.n[0] * pout.n[1] * (k - pout.lo[2]) + pout.cs * comp, oO); };
     auto put = [&](int k, int park, double bn, double rn) {          // park 1: the left cell of the pair is the black one
         v2u o;
         if (park) { o.x = bn; o.y = rn; } else { o.x = rn; o.y = bn; }
+        if (ACC) { o.x = CN.l + o.x; o.y = CN.r + o.y; }
         typedef __attribute__((address_space(1))) char gwbyte;
         *(__attribute__((address_space(1))) v2u*)((gwbyte*)(pout.gp() + (long)pout.n[0] * pout.n[1] * (k - pout.lo[2]) + pout.cs * comp) + (size_t)oO) = o;
     };
@@ -834,6 +840,7 @@ __global__ void __launch_bounds__(64 * NW) k_abec_gsrb_rb(BoxD b, FabD pin, FabD
             if (NBR && XO) xpN = xpload(q + 1);
             if (W3 && y2_on && !zero) Y2N = y2load(q + 1);
         }
+        if (ACC && owner && q - 1 >= k0 && q - 1 <= kend) CN = cload(q - 1);        // (consumed by the put at the top of the next iteration)
         // ---- red update of plane q
         const int bq = (q - k0 + 1) & 1;
         const int slot = (q - k0 + 3) % 3, slotk = (q - k0 + 2) % 3;      // ring slots of the planes q and q - 1
@@ -1120,7 +1127,7 @@ bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& p
 // one red + black sweep pin -> pout (pin != pout); zero: pin is identically zero and is not read
 template <int NW>
 static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                            const DomainBC* bcs, int nbc, const CfTab* cf)
+                            const DomainBC* bcs, int nbc, const CfTab* cf, bool acc)
 {
     const bool walls = cf != nullptr || !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     auto& ctx = Context::get();
@@ -1154,10 +1161,10 @@ static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab
             }
         } else
         if (walls) rb_make_bc(g, bcs[n < nbc ? n : 0], rbc);
-#define IAMRX_RB(M, HA, WL, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
+#define IAMRX_RBL(M, HA, WL, T3, AC, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, false, false, T3, AC>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
                                                       c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc)
-#define IAMRX_RB3(M, HA, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, true, false, false, true>), dim3((unsigned)nwg), dim3(64 * NW), 0, ctx.stream, b, P, O, R, Af, Sf, \
-                                                      c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc)
+#define IAMRX_RB(M, HA, WL, SC, SS) do { if (acc) IAMRX_RBL(M, HA, WL, false, true, SC, SS); else IAMRX_RBL(M, HA, WL, false, false, SC, SS); } while (0)
+#define IAMRX_RB3(M, HA, SC, SS) do { if (acc) IAMRX_RBL(M, HA, true, true, true, SC, SS); else IAMRX_RBL(M, HA, true, true, false, SC, SS); } while (0)
         if (cf) {
             if (c.sig) IAMRX_RB3(1, false, c.sig_comp, c.sig_scale);
             else if (has_a) IAMRX_RB3(2, true, 0, 1.0);
@@ -1174,11 +1181,12 @@ static void abec_gsrb_rb_nw(const Geometry& g, const AbecCoef& c, const MultiFab
         }
 #undef IAMRX_RB
 #undef IAMRX_RB3
+#undef IAMRX_RBL
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                  const DomainBC* bcs, int nbc, const CfTab* cf)
+                  const DomainBC* bcs, int nbc, const CfTab* cf, bool acc)
 {
     IAMRX_ASSERT((cf ? abec_gsrb_rb_cf_ok(g, c, pin) : abec_gsrb_rb_ok(g, c, pin, nbc, bcs)) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp);
     if (pin.nlocal() == 0) return;
@@ -1186,8 +1194,8 @@ void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, Mul
     // lane, 210 us per 256^3 sweep): 12 wavefronts (768 threads: 168 VGPRs) trade two of the eight rows of a tile for a spill-free loop
     const bool walls = cf != nullptr || !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     const int wpr = pin.layout->boxes[pin.layout->local[0]].len(0) / 128;
-    if (walls && c.sig && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf);
-    else abec_gsrb_rb_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf);
+    if (walls && c.sig && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf, acc);
+    else abec_gsrb_rb_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, cf, acc);
 }
 
 // the sweep of this level can be issued in two parts -- the tiles that read no ghost cell (sel 1) and the others (sel 2, behind the exchange):
@@ -1203,7 +1211,7 @@ bool abec_gsrb_rb_nbr_splits(const Geometry& g, const Layout& l)
 // written.  pout's ghost cells are not written.
 template <int NW>
 static void abec_gsrb_rb_nbr_nw(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                                const DomainBC* bcs, int nbc, int sel, hipStream_t on)
+                                const DomainBC* bcs, int nbc, int sel, hipStream_t on, bool acc)
 {
     const bool walls = !(g.periodic[0] && g.periodic[1] && g.periodic[2]);
     auto& ctx = Context::get();
@@ -1246,8 +1254,9 @@ static void abec_gsrb_rb_nbr_nw(const Geometry& g, const AbecCoef& c, MultiFab& 
         for (int d = 0; d < 3; ++d) { rbc.dlo[d] = g.domain.lo[d]; rbc.dhi[d] = g.domain.hi[d]; }
 #define IAMRX_RBG(M, HA, WL, SC, SS) if (sel != 1) hipLaunchKernelGGL((k_abec_rb_ghost<M, HA, WL>), ggrid, dim3(256), 0, strm, l.d_boxes, pin.d_tab, rhs.d_tab, At, St, \
                                                        c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, zero ? 1 : 0, n, rbc, xo ? 1 : 0)
-#define IAMRX_RBK(M, HA, WL, XOO, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true, XOO>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, strm, zb, Z, Z, Z, Z, Z, \
+#define IAMRX_RBKL(M, HA, WL, XOO, AC, SC, SS) hipLaunchKernelGGL((k_abec_gsrb_rb<M, NW, HA, WL, true, XOO, false, AC>), dim3((unsigned)nwg, (unsigned)nbox), dim3(64 * NW), 0, strm, zb, Z, Z, Z, Z, Z, \
                            c.alpha, dhx, dhy, dhz, omega, SC, SS, bn, wpr, tz, nty, zero ? 1 : 0, n, xcd_chunk, rbc, l.d_boxes, pin.d_tab, pout.d_tab, rhs.d_tab, At, St, sel)
+#define IAMRX_RBK(M, HA, WL, XOO, SC, SS) do { if (acc) IAMRX_RBKL(M, HA, WL, XOO, true, SC, SS); else IAMRX_RBKL(M, HA, WL, XOO, false, SC, SS); } while (0)
 #define IAMRX_RB(M, HA, WL, SC, SS) IAMRX_RBG(M, HA, WL, SC, SS); if (xo) IAMRX_RBK(M, HA, WL, true, SC, SS); else IAMRX_RBK(M, HA, WL, false, SC, SS)
         if (walls) {
             if (c.sig) { IAMRX_RB(1, false, true, c.sig_comp, c.sig_scale); }
@@ -1260,12 +1269,13 @@ static void abec_gsrb_rb_nbr_nw(const Geometry& g, const AbecCoef& c, MultiFab& 
         }
 #undef IAMRX_RB
 #undef IAMRX_RBK
+#undef IAMRX_RBKL
 #undef IAMRX_RBG
     }
     if (rec) kernel_probe_end(PROBE_ABEC_GSRB);
 }
 void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                      const DomainBC* bcs, int nbc, int sel, hipStream_t on)
+                      const DomainBC* bcs, int nbc, int sel, hipStream_t on, bool acc)
 {
     IAMRX_ASSERT(abec_gsrb_rb_nbr_ok(g, c, pin, rhs, nbc, bcs) && pin.d_tab != pout.d_tab && pout.ngrow >= 1 && rhs.ncomp == pin.ncomp && pout.ncomp == pin.ncomp);
     if (pin.nlocal() == 0) return;
@@ -1274,8 +1284,8 @@ void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, Multi
     const Layout& l = *pin.layout;
     const int wpr = l.max_len[0] / 128;
     const bool xo = l.max_len[0] != g.domain.len(0);
-    if (c.sig && (walls || xo) && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nbr_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on);
-    else abec_gsrb_rb_nbr_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on);
+    if (c.sig && (walls || xo) && 12 % wpr == 0 && 12 / wpr >= 3 && tune("GSRB_RB_NW12", 1) != 0) abec_gsrb_rb_nbr_nw<12>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on, acc);
+    else abec_gsrb_rb_nbr_nw<16>(g, c, pin, pout, rhs, omega, zero, bcs, nbc, sel, on, acc);
 }
 
 // IAMRX_ABEC_SIG (1): 0 = the smoother and the residual read the stored face coefficients also where AbecCoef::sig is given

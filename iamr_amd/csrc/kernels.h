@@ -107,7 +107,8 @@ bool abec_gsrb_zero_ok(const AbecCoef& c, const MultiFab& phi, int nbc, bool wra
 bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, int nbc, const DomainBC* bcs = nullptr);
 // cf: the level is a refined box strictly inside its domain (abec_gsrb_rb_cf_ok): its coarse/fine ghost formula, evaluated inside the kernel
 void abec_gsrb_rb(const Geometry& g, const AbecCoef& c, const MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                  const DomainBC* bcs = nullptr, int nbc = 0, const CfTab* cf = nullptr);
+                  const DomainBC* bcs = nullptr, int nbc = 0, const CfTab* cf = nullptr, bool acc = false);
+// (acc: pout is the SOLUTION of the running solve and receives pout + the swept correction -- the last sweep of a V-cycle, k_abec.hip ACC)
 bool abec_gsrb_rb_cf_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi);
 // the same sweep on a level of several boxes that covers its domain (a chopped level, the boxes of a sharded level): k_abec_rb_ghost +
 // k_abec_gsrb_rb<.., NBR>, one two-layer ghost fill of phi per sweep in front of it (the caller's).  level_ok: the layout / boundary
@@ -117,7 +118,7 @@ bool abec_gsrb_rb_nbr_ok(const Geometry& g, const AbecCoef& c, const MultiFab& p
 // sel 0: the whole sweep; 1: only the tiles that read no ghost cell (no k_abec_rb_ghost launch); 2: k_abec_rb_ghost + the other tiles;
 // on: the stream (null: the context's).  splits: parts 1 and 2 are both non-empty (and the level has no ghost columns in x)
 void abec_gsrb_rb_nbr(const Geometry& g, const AbecCoef& c, MultiFab& pin, MultiFab& pout, const MultiFab& rhs, double omega, bool zero,
-                      const DomainBC* bcs, int nbc, int sel = 0, hipStream_t on = nullptr);
+                      const DomainBC* bcs, int nbc, int sel = 0, hipStream_t on = nullptr, bool acc = false);
 bool abec_gsrb_rb_nbr_splits(const Geometry& g, const Layout& l);
 // fused red+black sweep, out of place; see k_abec.hip (the caller refreshes the ghosts of phi_out and finishes the black cells
 // on box surfaces with abec_gsrb(..., 1, ..., shell_only = true))

@@ -101,7 +101,9 @@ public:
     void smooth(int l, MultiFab& sol, const MultiFab& rhs, bool skip_fill, bool cf_ghosts_current = false, bool sol_is_zero = false);
     bool zero_first_pass_ok(int l, const MultiFab& sol) const;   // the first colour pass can take the place of sol.setVal(0) (abec_gsrb_zero_ok)
     // nsweeps red+black sweeps; uses the fused out-of-place kernel (ping-pong with a level buffer) where it applies
-    void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero = false);
+    // acc (finest level, the last smoothing call of a V-cycle): the solution of the running solve; where the sweep kernel runs its last sweep
+    // stores acc + correction into acc (m_acc_done is set: the caller skips its `sol += cor`; sol is then one sweep behind and unused)
+    void smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero = false, MultiFab* acc = nullptr);
     bool fused_smoother_ok(int l) const;
     bool nbr_sweep_ok(int l, const MultiFab& sol, const MultiFab& rhs) const;
     bool cf_sweep_ok(int l, const MultiFab& sol) const;
@@ -154,6 +156,8 @@ private:
     // tensor operator with constant viscosity whose coarsest level is one box of <= 27 cells: that level is solved DIRECTLY by one
     // single-workgroup launch (k_dense_bottom: M = alpha diag(a) + beta B assembled from the cached operator matrix B, Gauss-Jordan
     // with partial pivoting) instead of the host-driven BiCGStab (mlmg.hip: bottom_direct_prepare)
+    MultiFab* m_acc = nullptr;     // solve(): the solution array the V-cycle's last sweep may add its correction to (IAMRX_MG_ACC_LAST_SWEEP)
+    bool m_acc_done = false;
     bool m_bottom_direct = false;
     const double* m_dB = nullptr;  // the cached matrix (device, column-major, m_dN x m_dN)
     int m_dN = 0;

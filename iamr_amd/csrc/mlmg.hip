@@ -374,8 +374,9 @@ bool CellMG::cf_sweep_ok(int l, const MultiFab& sol) const
     return abec_gsrb_rb_cf_ok(m_lev[l].g, c, sol);
 }
 
-void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero)
+void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bool skip_first_fill, bool sol_is_zero, MultiFab* acc)
 {
+    if (l != 0) acc = nullptr;
     if (nsweeps <= 0) { if (sol_is_zero) sol.setVal(0.0); return; }
     if (cf_sweep_ok(l, sol)) {
         // red + black in one out-of-place launch per sweep, the coarse/fine ghost values formed inside the kernel (no k_cf_fill, no ghost
@@ -388,7 +389,12 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
         MultiFab* b = &L.buf;
         if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
         const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
-        for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size(), &L.cftab); std::swap(a, b); }
+        for (int i = 0; i < nsweeps; ++i) {
+            const bool last = acc && i == nsweeps - 1;
+            abec_gsrb_rb(L.g, c, *a, last ? *acc : *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size(), &L.cftab, last);
+            if (last) { m_acc_done = true; return; }
+            std::swap(a, b);
+        }
         if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
         return;
     }
@@ -405,7 +411,12 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             // from a zero start the first sweep reads no input: an odd number of sweeps starts "from" the buffer and ends in sol without a copy
             if (sol_is_zero && (nsweeps & 1)) std::swap(a, b);
             const double om = m_dd_sweeps > 0 ? dd_omega() : m_o.omega;
-            for (int i = 0; i < nsweeps; ++i) { abec_gsrb_rb(L.g, c, *a, *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size()); std::swap(a, b); }
+            for (int i = 0; i < nsweeps; ++i) {
+                const bool last = acc && i == nsweeps - 1;
+                abec_gsrb_rb(L.g, c, *a, last ? *acc : *b, rhs, om, sol_is_zero && i == 0, m_bcn.data(), (int)m_bcn.size(), nullptr, last);
+                if (last) { m_acc_done = true; return; }
+                std::swap(a, b);
+            }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
             return;
         }
@@ -432,16 +443,19 @@ void CellMG::smooth_n(int l, MultiFab& sol, const MultiFab& rhs, int nsweeps, bo
             const bool overlap = ov_mode != 0 && (ov_mode == 2 || !fplan.peers.empty()) && abec_gsrb_rb_nbr_splits(L.g, *L.layout);
             for (int i = 0; i < nsweeps; ++i) {
                 const bool z = sol_is_zero && i == 0;
+                const bool last = acc && i == nsweeps - 1;
+                MultiFab& out = last ? *acc : *b;
                 if (z || !overlap) {
                     if (!z) a->FillBoundary(L.g);
-                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, z, m_bcn.data(), (int)m_bcn.size());
+                    abec_gsrb_rb_nbr(L.g, c, *a, out, rhs, om, z, m_bcn.data(), (int)m_bcn.size(), 0, nullptr, last);
                 } else {
                     ctx.fork_side();
-                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 1, ctx.stream);
+                    abec_gsrb_rb_nbr(L.g, c, *a, out, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 1, ctx.stream, last);
                     a->FillBoundary(L.g, 0, m_ncomp, nullptr, -1, ctx.side);
-                    abec_gsrb_rb_nbr(L.g, c, *a, *b, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 2, ctx.side);
+                    abec_gsrb_rb_nbr(L.g, c, *a, out, rhs, om, false, m_bcn.data(), (int)m_bcn.size(), 2, ctx.side, last);
                     ctx.join_side();
                 }
+                if (last) { m_acc_done = true; return; }
                 std::swap(a, b);
             }
             if (a != &sol) MultiFab::Copy(sol, *a, 0, 0, m_ncomp, 0);
@@ -704,7 +718,7 @@ void CellMG::bottom_solve(MGStats& st)
         c.tensor = 0;
         if ((!m_cf && (abec_gsrb_rb_ok(L.g, c, L.cor, (int)m_bcn.size(), m_bcn.data()) ||
                        nbr_sweep_ok(l, L.cor, L.res))) || cf_sweep_ok(l, L.cor)) {
-            smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true);      // the first sweep takes the correction as zero: no fill, nothing read
+            smooth_n(l, L.cor, L.res, m_dd_sweeps, true, true, m_acc);      // the first sweep takes the correction as zero: no fill, nothing read
             return;
         }
         L.cor.setVal(0.0);
@@ -800,7 +814,7 @@ void CellMG::vcycle(MGStats& st)
             cc_prolong_add(L.cor, m_lev[l + 1].tmp_d);
         } else
         cc_prolong_add(L.cor, m_lev[l + 1].cor);
-        smooth_n(l, L.cor, L.res, m_o.nu2, false);
+        smooth_n(l, L.cor, L.res, m_o.nu2, false, false, l == 0 ? m_acc : nullptr);
     }
 }
 
@@ -893,10 +907,16 @@ MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double
                     kernel_probes_pause(false);
                 }
                 IAMRX_HIP_CHECK(hipGraphLaunch(vc_exec, ctx.stream));
-            } else
+            } else {
+            // IAMRX_MG_ACC_LAST_SWEEP (1): where the sweep kernel smooths the finest level its last sweep writes phi + correction into phi
+            m_acc = (tune("MG_ACC_LAST_SWEEP", 1) != 0 && phi.ngrow >= 1 && phi.layout.get() == L0.layout.get() && phi.ncomp == nc) ? &phi : nullptr;
+            m_acc_done = false;
             vcycle(st);
+            m_acc = nullptr;
+            }
             cycle_timer().mark(ctx.stream);
-            mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
+            if (!m_acc_done) mf_saxpy(phi, 1.0, L0.cor, 0, 0, nc, 0);
+            m_acc_done = false;
             // (the ghost cells are filled once more behind the loop; a residual kernel that wraps its indices needs none here)
             if (m_cf || !abec_residual_reads_no_ghosts(L0.g, coef(0), L0.res, phi, rhs, false)) applyBC(0, phi, true, bcvp);
             level_residual(L0.g, coef(0), L0.res, phi, &rhs, &st.resnorm);

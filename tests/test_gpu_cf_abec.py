@@ -240,3 +240,54 @@ def test_constant_masks_of_a_box_inside_the_domain(gpu, nf, box):
     assert np.array_equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nb", [(128, 32, 16), (256, 16, 32)])
+def test_sweep_kernel_with_coarse_fine_faces_inside_a_mac_solve(gpu, nb):
+    """round 5: on a refined level that is one box strictly inside its domain with 128 / 256 cells in x the finest multigrid level is smoothed
+    by the one-launch sweep with in-kernel coarse/fine values (k_abec_gsrb_rb<.., W3>; directly against the oracle in
+    tests/test_gpu_kernel_forms.py) instead of the maintaining colour passes, and its last sweep of a V-cycle adds the correction to the
+    solution (ACC).  Each sweep forms the doubles of the two colour passes and nothing else reads the correction's ghost cells, so the whole
+    MAC solve on the refined level (MacProj.cpp:1084-1184 with setCoarseFineBC, :1166-1170) is the same solve bit for bit: iterations,
+    potential, projected face velocities -- under IAMRX_GSRB_RB_CF = 1 / 0 and IAMRX_MG_ACC_LAST_SWEEP = 1 / 0."""
+    lib = gpu
+    off = 16
+    n = tuple(v + 2 * off for v in nb)
+    nc = tuple(v // 2 for v in n)
+    box = (tuple([off] * 3), tuple(off + v - 1 for v in nb))
+    g_d, gc_d = lib.Geom.make(n, prob_hi=tuple(v / 64.0 for v in n)), lib.Geom.make(nc, prob_hi=tuple(v / 64.0 for v in n))
+    lay, clay = lib.Layout([box]), lib.Layout.single(nc)
+    ax = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rho = 1.0 + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.1 * np.cos(4 * np.pi * Z)
+    axc = [(np.arange(-1, nc[d] + 1) + 0.5) / nc[d] for d in range(3)]
+    Xc, Yc, Zc = np.meshgrid(*axc, indexing="ij")
+    cphi = np.sin(2 * np.pi * Xc) * np.sin(2 * np.pi * Yc) * np.sin(2 * np.pi * Zc) + 0.3 * np.cos(2 * np.pi * Xc)
+    out = {}
+    for mode in ((1, 1), (0, 0), (1, 0)):
+        old = lib.tuning_get("GSRB_RB_CF", 1), lib.tuning_get("MG_ACC_LAST_SWEEP", 1)
+        lib.tuning_set("GSRB_RB_CF", mode[0]); lib.tuning_set("MG_ACC_LAST_SWEEP", mode[1])
+        try:
+            um_d = []
+            for d in range(3):
+                t = lib.face(d)
+                shape = tuple(n[e] + t[e] + 2 for e in range(3)) + (1,)
+                m = lib.MultiFab(lay, t, 1, 1)
+                m.set_from_global(np.random.default_rng(20 + d).standard_normal(shape), (-1, -1, -1))
+                um_d.append(m)
+            rho_d = lib.MultiFab(lay, lib.CELL, 1, 1); rho_d.set_from_global(rho[..., None], (-1, -1, -1))
+            phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.setval(0.0)
+            cphi_d = lib.MultiFab(clay, lib.CELL, 1, 1); cphi_d.set_from_global(cphi[..., None], (-1, -1, -1))
+            st = lib.mlmg_mac_solve_cf(g_d, um_d, rho_d, 0, None, phi_d, 200.0, cphi_d, gc_d, 2, mac_tol=1e-11)
+            assert st.converged
+            div = lib.MultiFab(lay, lib.CELL, 1, 0)
+            lib.mac_divergence(g_d, div, um_d)
+            assert div.norm0() <= 1e-7
+            out[mode] = (st.iters, phi_d.to_numpy(0)[0][1:-1, 1:-1, 1:-1].copy(), [m.to_numpy(0)[0][1:-1, 1:-1, 1:-1].copy() for m in um_d])
+        finally:
+            lib.tuning_set("GSRB_RB_CF", old[0]); lib.tuning_set("MG_ACC_LAST_SWEEP", old[1])
+    for mode in ((0, 0), (1, 0)):
+        assert out[mode][0] == out[(1, 1)][0], (mode, out[mode][0], out[(1, 1)][0])
+        assert np.array_equal(out[mode][1], out[(1, 1)][1]), (mode, float(np.abs(out[mode][1] - out[(1, 1)][1]).max()))
+        for a, b in zip(out[mode][2], out[(1, 1)][2]):
+            assert np.array_equal(a, b), mode

@@ -81,8 +81,10 @@ KERNEL_FORMS = {
     # (opt-in: measured slower than the launches it replaces)
     "fused coarse tail": {"MG_TAIL_FUSED": 1},
     "fused coarse tail, coefficient arrays": {"MG_TAIL_FUSED": 1, "MG_COARSE_UNIFORM": 0},
+    # round 5: `sol += cor` as its own pass behind the V-cycle instead of inside the last sweep of the sweep kernel (ACC)
+    "sol += cor as its own pass": {"MG_ACC_LAST_SWEEP": 0},
 }
-DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1, "MG_COARSE_UNIFORM": 1, "MG_TAIL_FUSED": 0}
+DEFAULTS = {"ABEC_SIG": 1, "GSRB2": 1, "GSRB1_NP": 1, "GSRB2_TZ": 32, "RESID_RESTRICT": 1, "RESID_PAIRS": 1, "GSRB_ZERO": 1, "TENSOR_FUSED": 1, "GSRB2_MULTI": 0, "GSRB_RB": 1, "RESID_WRAP": 1, "GSRB_RB_WALLS": 1, "MG_COARSE_UNIFORM": 1, "MG_TAIL_FUSED": 0, "MG_ACC_LAST_SWEEP": 1}
 
 
 @pytest.mark.parametrize("case", ["periodic_boxes", "periodic_one_box", "periodic_long_box", "channel_walls", "channel_walls_long"])
@@ -136,8 +138,13 @@ def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, c
     # round 5: the constant-viscosity tensor residual runs in its cell-centred form (k_tensor_uni: mixed second differences, another
     # summation order than the five face fluxes) -- the bit-for-bit family below is that of the face-flux kernels; the cell-centred form is
     # compared with it to round-off afterwards
+    # round 5 as well: the coarsest level of a constant-viscosity tensor solve is solved directly (k_dense_bottom) -- a bottom solver, one of
+    # the unpinned choices, not a kernel form: the family below keeps the Krylov bottom solver (the forms that switch the constants off would
+    # fall back to it anyway); the direct one is compared with it to the solver tolerance afterwards and in tests/test_gpu_tensor_bottom.py
     cc_old = lib.tuning_get("TENSOR_UNI_CC", 1)
+    tb_old = lib.tuning_get("TENSOR_BOTTOM_DIRECT", 1)
     lib.tuning_set("TENSOR_UNI_CC", 0)
+    lib.tuning_set("TENSOR_BOTTOM_DIRECT", 0)
     try:
         dts0, S0, P0 = run()
         for name, keys in KERNEL_FORMS.items():
@@ -156,8 +163,13 @@ def test_kernel_forms_of_the_cell_centred_multigrid_give_the_same_doubles(gpu, c
         dts, S, P = run()
         assert np.allclose(dts, dts0, rtol=1e-12, atol=0.0)
         assert np.abs(S - S0).max() <= 1e-11 and np.abs(P - P0).max() <= 1e-9 * max(1.0, np.abs(P0).max()), (np.abs(S - S0).max(), np.abs(P - P0).max())
+        lib.tuning_set("TENSOR_BOTTOM_DIRECT", 1)
+        dts, S, P = run()
+        assert np.allclose(dts, dts0, rtol=1e-9, atol=0.0)
+        assert np.abs(S - S0).max() <= 1e-9 and np.abs(P - P0).max() <= 1e-7 * max(1.0, np.abs(P0).max()), (np.abs(S - S0).max(), np.abs(P - P0).max())
     finally:
         lib.tuning_set("TENSOR_UNI_CC", cc_old)
+        lib.tuning_set("TENSOR_BOTTOM_DIRECT", tb_old)
     lib.tuning_set("MG_RES_MEAN", 1)
     try:
         dts, S, P = run()
