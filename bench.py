@@ -629,11 +629,11 @@ def main():
             nty = (n + rw - 3) // (rw - 2)
             nch = max(1, 256 // nty); tzp = max(8, (n + nch - 1) // nch); nch = (n + tzp - 1) // tzp
             rb_grid = 8 * ((nty * nch + 7) // 8) * 1024
-            roofline_abec = {"kernel": "k_abec_gsrb_rb<1, 16, false, false, false, false> (a red AND a black pass of the cell-centred GSRB smoother of the MAC projection in one "
+            roofline_abec = {"kernel": "k_abec_gsrb_rb<1, 16, false, false, false, false, false, false> (a red AND a black pass of the cell-centred GSRB smoother of the MAC projection in one "
                                        "out-of-place launch, face coefficients recomputed from the cell-centred density once per face; "
                                        "profiles/round5_kernel_stats.csv)", "bound": "hbm",
                              "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                             "traffic": pmc_traffic("k_abec_gsrb_rb<1, 16, false, false, false, false> grid=%d" % rb_grid),
+                             "traffic": pmc_traffic("k_abec_gsrb_rb<1, 16, false, false, false, false, false, false> grid=%d" % rb_grid),
                              "algorithmic_bytes_per_launch": own, "avg_ms": ms,
                              "bytes_counted": "the kernel's own compulsory traffic, 32 B/cell per sweep: phi read 8 + written 8, rhs 8, density 8",
                              "survey_8d_bytes_per_launch": alg, "survey_8d_GBps": alg / ms / 1e6, "survey_8d_frac": alg / ms / 1e6 / 8000.0,
