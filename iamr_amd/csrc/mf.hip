@@ -66,10 +66,10 @@ void Context::ensure_scratch(size_t n)
 
 // IAMRX_POISON_ALLOC=1 (debugging aid): device blocks are filled with 0xFF bytes (NaN as doubles) when they are handed out, so that a
 // kernel reading memory nobody has written shows up deterministically instead of depending on what the recycled block held before
-static bool poison_allocs()
+// (2: zeros instead -- if a result changes between 0, 1 and 2 some kernel reads memory nobody wrote)
+static int poison_allocs()
 {
-    const bool on = tune("POISON_ALLOC", 0) != 0;
-    return on;
+    return (int)tune("POISON_ALLOC", 0);
 }
 
 void* Context::alloc(size_t bytes)
@@ -84,7 +84,7 @@ void* Context::alloc(size_t bytes)
         bytes_cached -= sz;
         live_blocks[p] = sz;
         bytes_live += sz;
-        if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, 0xFF, sz, stream));      // debug: every block starts as NaNs
+        if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, poison_allocs() == 2 ? 0x00 : 0xFF, sz, stream));      // debug: every block starts as NaNs
         return p;
     }
     void* p = nullptr;
@@ -96,7 +96,7 @@ void* Context::alloc(size_t bytes)
     }
     live_blocks[p] = bytes;
     bytes_live += bytes;
-    if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, 0xFF, bytes, stream));
+    if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, poison_allocs() == 2 ? 0x00 : 0xFF, bytes, stream));
     return p;
 }
 
@@ -655,6 +655,12 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                 }
             }
         }
+        // Nodal / face data again: a ghost point of this box can also have several sources ON its own rank -- the two boxes that share the
+        // point, or (a periodic direction narrower than the ghost width: the two-cell slab levels) the images of one box under one and two
+        // periods.  Both copies land in one launch; if the sources differ in the last bit (the duplicates of a periodic node that two
+        // threads computed) the result depends on which write comes last.  Every ghost point therefore takes ONE local source: the first
+        // in the order of the loops below (regions already planned for this box are cut out of the later ones).
+        std::vector<BoxD> planned;
         for (int gs = 0; gs < nb; ++gs) {
             const bool src_mine = owner[gs] == me;
             if (!dst_mine && !src_mine) continue;
@@ -688,6 +694,15 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                         parts.swap(next);
                         if (parts.empty()) break;
                     }
+                }
+                if (nodal && dst_mine && src_mine) {
+                    for (const BoxD& c : planned) {
+                        std::vector<BoxD> next;
+                        for (const BoxD& q : parts) subtract(q, c, next);
+                        parts.swap(next);
+                        if (parts.empty()) break;
+                    }
+                    for (const BoxD& q : parts) planned.push_back(q);
                 }
                 for (auto& p0 : parts) {
                     BoxD p = p0;
