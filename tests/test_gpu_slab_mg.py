@@ -104,6 +104,42 @@ def test_nodal_solver_on_a_slab_hierarchy(slab, walls):
     assert np.abs(v1 - v0).max() <= 5e-9 * np.abs(v0).max(), float(np.abs(v1 - v0).max())
 
 
+def test_slab_nodal_solve_is_the_same_solve_every_time(slab):
+    """round 5: on a two-cell slab level with four ghost layers a ghost node is the image of the box under one period AND under two; both
+    copies used to land in one FillBoundary launch, and the duplicates of a periodic node differ in the last bit there -- which write came
+    last changed the solve from run to run (1e-10 in the pressure; the y-velocity crossed this file's 1e-13 bound depending on what ran
+    before).  A ghost point now takes one local source (mf.hip: build_fill_plan_host): the same projection, repeated, gives the same bits."""
+    lib = slab
+    from iamr_amd import ns as N
+    n = (128, 8, 64)
+    per, lobc = (0, 1, 1), (NEUMANN, PERIODIC, PERIODIC)
+    g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n), periodic=per)
+    lay = lib.Layout.single(n)
+    rho, _ = plane_fields(n, 5, True)
+    x = (np.arange(-1, n[0] + 1) + 0.5) / n[0]
+    z = (np.arange(-1, n[2] + 1) + 0.5) / n[2]
+    X, Z = np.meshgrid(x, z, indexing="ij")
+    vel = np.zeros(tuple(v + 2 for v in n) + (3,))
+    vel[..., 0] = (np.sin(np.pi * X) * np.cos(2 * np.pi * Z))[:, None, :]; vel[..., 2] = (np.cos(2 * np.pi * X) * np.sin(4 * np.pi * Z))[:, None, :]
+    vel[0, ..., 0] = -vel[1, ..., 0]; vel[-1, ..., 0] = -vel[-2, ..., 0]
+    lib.tuning_set("MG_SLAB", 1)
+    out = []
+    for rep in range(4):
+        sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global((1.0 / rho)[..., None], (-1,) * 3)
+        vel_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel_d.set_from_global(vel, (-1,) * 3)
+        p_d = lib.MultiFab(lay, lib.NODE, 1, 1); p_d.setval(0.0)
+        st = N.nodal_projection(g, vel_d, 0, p_d, sig_d, 0, lobc=lobc, hibc=lobc, rel_tol=1e-11, abs_tol=1e-16)
+        assert st.nlevels >= 5
+        out.append((st.iters, st.resnorm, vel_d.gather_valid(n), p_d.gather_valid(n)))
+        junk = [lib.MultiFab(lay, lib.NODE, 1, 4) for _ in range(3)]          # (what the allocator hands out next must not matter either)
+        for m in junk:
+            m.setval(1.0e30 * (rep + 1))
+        del junk
+    for o in out[1:]:
+        assert o[0] == out[0][0] and o[1] == out[0][1]
+        assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[3], out[0][3])
+
+
 def test_time_steps_of_a_two_dimensional_flow_on_an_eight_cell_slab(slab):
     """the Taylor vortex in the (x, z) plane on a 128 x 8 x 128 slab, viscous, three steps: slab levels on / off agree (solver tolerances);
     the flow stays two-dimensional"""
