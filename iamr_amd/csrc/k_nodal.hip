@@ -263,6 +263,19 @@ __device__ __forceinline__ int wrap_cell(int g, int lo, int hi)
     const int n = hi - lo + 1;
     return g < lo ? g + n : (g > hi ? g - n : g);
 }
+// ... or, in a direction that ends on Neumann walls (refl): the mirror image -- what nodal_reflect_bc / cc_mirror_bc write into the ghost
+// nodes / cells (even reflection about the wall node lo resp. hi + 1; sigma mirrored about the wall face): the index-wrap variants then
+// read the valid data of a wall-bounded box directly as well, no ghost fill in front of a pass
+__device__ __forceinline__ int image_node(int g, int lo, int hi, bool refl)
+{
+    if (refl) return g < lo ? 2 * lo - g : (g > hi + 1 ? 2 * (hi + 1) - g : g);
+    return wrap_node(g, lo, hi);
+}
+__device__ __forceinline__ int image_cell(int g, int lo, int hi, bool refl)
+{
+    if (refl) return g < lo ? 2 * lo - 1 - g : (g > hi ? 2 * hi + 1 - g : g);
+    return wrap_cell(g, lo, hi);
+}
 
 template <int TX, int TY, int NT, bool WRAP, bool MASK, bool CSIG>
 // no minimum-occupancy bound: measured at 256^3 on MI355X (profiles/round2_b_*), forcing 4 waves/SIMD on the variable-sigma variant (168 VGPRs
@@ -271,7 +284,7 @@ template <int TX, int TY, int NT, bool WRAP, bool MASK, bool CSIG>
 // 230 us per 257^3 launch against 161 us for the unmasked one at 168 VGPRs / 3 wavefronts: it is held to 3 (a handful of spills)
 __global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(const BoxD* __restrict__ boxes, const FabD* __restrict__ xct, const FabD* __restrict__ xnt,
     const FabD* __restrict__ xot, const FabD* __restrict__ rt, const FabD* __restrict__ st, NodeW w, int kpar, int ntx, int nty, int xcd_chunk,
-    const FabD* __restrict__ dmt, double csig, int ppc)
+    const FabD* __restrict__ dmt, double csig, int ppc, int refl)
 {
     // A workgroup owns one TXxTY tile and marches through ppc consecutive planes of its parity (k, k+2, ...).  Plane k+1 staged
     // for plane k is the k-1 plane of the next one and stays in LDS (two x planes loaded per plane instead of three); the loads of
@@ -340,7 +353,7 @@ __global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(c
         qm[c] = ly * PX + COL(lx - 1);
         // right-hand side of the node: straight to a register (issued together with the staging loads below)
         int ri = on ? pi : tx0, rj = on ? pj : ty0;
-        if constexpr (WRAP) { ri = wrap_node(ri, cb.lo[0], cb.hi[0]); rj = wrap_node(rj, cb.lo[1], cb.hi[1]); }
+        if constexpr (WRAP) { ri = image_node(ri, cb.lo[0], cb.hi[0], refl & 1); rj = image_node(rj, cb.lo[1], cb.hi[1], refl & 2); }
         roff[c] = (int)r.off(ri, rj, r.lo[2]);
         rr[c] = r.gp()[roff[c] + (long)(k0 - r.lo[2]) * rks];
         if constexpr (MASK) {
@@ -365,8 +378,8 @@ __global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(c
         if constexpr (WRAP) {
             // the box spans the periodic domain: a ghost index is the periodic image of a valid index of the SAME box, so the
             // staging reads the valid data directly and no ghost fill is needed (node hi+1 duplicates node lo)
-            xi = wrap_node(gi, cb.lo[0], cb.hi[0]); xj = wrap_node(gj, cb.lo[1], cb.hi[1]);
-            si = wrap_cell(gi, cb.lo[0], cb.hi[0]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]);
+            xi = image_node(gi, cb.lo[0], cb.hi[0], refl & 1); xj = image_node(gj, cb.lo[1], cb.hi[1], refl & 2);
+            si = image_cell(gi, cb.lo[0], cb.hi[0], refl & 1); sj = image_cell(gj, cb.lo[1], cb.hi[1], refl & 2);
         } else {
             xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1);
             si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1);
@@ -375,8 +388,8 @@ __global__ void __launch_bounds__(NT, (MASK && NT == 256 ? 3 : 1)) k_nodal_gs4(c
         soff[it] = CSIG ? 0 : (int)s.off(si, sj, s.lo[2]);
         lslot[it] = (tid + it * NT < RX * RY) ? ly * PX + COL(lx) : -1;
     }
-    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_node(kk, cb.lo[2], cb.hi[2]); return (long)(kk - x.lo[2]) * xks; };
-    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_cell(kk, cb.lo[2], cb.hi[2]); return (long)(kk - s.lo[2]) * sks; };
+    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = image_node(kk, cb.lo[2], cb.hi[2], refl & 4); return (long)(kk - x.lo[2]) * xks; };
+    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = image_cell(kk, cb.lo[2], cb.hi[2], refl & 4); return (long)(kk - s.lo[2]) * sks; };
     double* Xm = Xf;                   // plane k-1
     double* Xc = Xf + PL;              // plane k (updated in place)
     double* Xp = Xf + 2 * PL;          // plane k+1
@@ -518,6 +531,7 @@ struct GsrGeom {
     int ppc;            // planes of one parity per workgroup
     int xcd_chunk;      // > 0: XCD-aware order, chunks per tile
     int zc, zn;         // the array the own-parity planes (zc) / the other-parity planes (zn) come from is identically zero: it is not read
+    int refl;           // WRAP: bit d: direction d ends on Neumann walls -- mirror images instead of periodic ones (image_node / image_cell)
 };
 
 // the update of one node, k_nodal_gs4's expression tree: x?[db + 1][da + 1] = x(i + da, j + db, plane), s?[db + 1][da + 1] = sigma of
@@ -607,7 +621,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         const int gi = ox + 2 * lx + a;
         mx[a] = min(gi - (txs - 3), (txe + 3) - gi);
         int xi, si;
-        if constexpr (WRAP) { xi = wrap_node(gi, cb.lo[0], cb.hi[0]); si = wrap_cell(gi, cb.lo[0], cb.hi[0]); }
+        if constexpr (WRAP) { xi = image_node(gi, cb.lo[0], cb.hi[0], gg.refl & 1); si = image_cell(gi, cb.lo[0], cb.hi[0], gg.refl & 1); }
         else { xi = min(max(gi, x.lo[0]), x.lo[0] + x.n[0] - 1); si = min(max(gi, s.lo[0]), s.lo[0] + s.n[0] - 1); }
         xcol[a] = 8u * (unsigned)(xi - x.lo[0]);
         scol[a] = CSIG ? 0u : 8u * (unsigned)(si - s.lo[0]);
@@ -619,7 +633,7 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
         const int gj = oy + PB * q + b;
         my[b] = min(gj - (tys - 3), (tye + 3) - gj);
         int xj, sj;
-        if constexpr (WRAP) { xj = wrap_node(gj, cb.lo[1], cb.hi[1]); sj = wrap_cell(gj, cb.lo[1], cb.hi[1]); }
+        if constexpr (WRAP) { xj = image_node(gj, cb.lo[1], cb.hi[1], gg.refl & 2); sj = image_cell(gj, cb.lo[1], cb.hi[1], gg.refl & 2); }
         else { xj = min(max(gj, x.lo[1]), x.lo[1] + x.n[1] - 1); sj = min(max(gj, s.lo[1]), s.lo[1] + s.n[1] - 1); }
         xrow[b] = 8u * (unsigned)((xj - x.lo[1]) * x.n[0]);
         srow[b] = CSIG ? 0u : 8u * (unsigned)((sj - s.lo[1]) * s.n[0]);
@@ -642,8 +656,8 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     const int xks = x.n[0] * x.n[1], sks = s.n[0] * s.n[1], rks = r.n[0] * r.n[1];
     int dks = 0;
     if constexpr (MASK) dks = dmt[fab].n[0] * dmt[fab].n[1];
-    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_node(kk, cb.lo[2], cb.hi[2]); return (long)(kk - x.lo[2]) * xks; };
-    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = wrap_cell(kk, cb.lo[2], cb.hi[2]); return (long)(kk - s.lo[2]) * sks; };
+    auto xk = [&](int kk) -> long { if constexpr (WRAP) kk = image_node(kk, cb.lo[2], cb.hi[2], gg.refl & 4); return (long)(kk - x.lo[2]) * xks; };
+    auto sk = [&](int kk) -> long { if constexpr (WRAP) kk = image_cell(kk, cb.lo[2], cb.hi[2], gg.refl & 4); return (long)(kk - s.lo[2]) * sks; };
     // LDS slots of this thread: own row slot q + 1, columns 2 lx (even half) and 2 lx + 1 (odd half); column c sits at
     // ((c + 2) & 1) * HX + ((c + 2) >> 1)
     const int lown = (q + 1) * RP + lx + 1;           // + HX: the odd column
@@ -908,7 +922,7 @@ void gs4_probe_stop(double* total_ms, long* launches) { kernel_probe_stop(PROBE_
 
 template <int TX, int TY, int NT>
 static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap, const MultiFab* dmask, const double* csig)
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int refl)
 {
     // (a "fat" last tile that takes the single leftover node column of a box of n = k TX cells along -- 8 x 16 instead of 9 x 17 tiles at 257^3
     // nodes -- was measured: the two extra footprint columns / rows cost more (253 us) than the empty tiles (223 us))
@@ -934,7 +948,7 @@ static void gs4_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     dim3 grid(gx, (unsigned)l.nlocal());
     const bool rec = kernel_probe_begin(PROBE_NODAL_GS4, (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1));
 #define IAMRX_GS4(W, M, C) hipLaunchKernelGGL((k_nodal_gs4<TX, TY, NT, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
-                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0, ppc)
+                                             xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, ntx, nty, xcd_chunk, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0, ppc, refl)
     if (dmask) {
         IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
         IAMRX_GS4(false, true, false);
@@ -955,10 +969,11 @@ static void gsr_tiles(int len_nodes, int& nt, int& pitch)
 
 template <int PB>
 static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int zero_flags)
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int zero_flags, int refl)
 {
     GsrGeom gg;
     gg.zc = zero_flags & 1; gg.zn = (zero_flags >> 1) & 1;
+    gg.refl = wrap ? refl : 0;
     gsr_tiles(l.max_len[0] + 1, gg.ntx, gg.tix);
     gsr_tiles(l.max_len[1] + 1, gg.nty, gg.tiy);
     const int npl_all = (l.max_len[2] + 1 + 1) / 2 + 1;
@@ -1004,6 +1019,25 @@ bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len)
     return true;
 }
 
+// ... or one box that spans a domain whose non-periodic directions end on Neumann walls on both sides (the pressure of a closed or
+// channel-like domain: LidDrivenCavity): the same kernels with mirror images in those directions (refl: bit d).  No Dirichlet mask (the
+// caller checks).  IAMRX_NODAL_REFLECT_WRAP (1): 0 = ghost fills (nodal_reflect_bc) in front of every pass.
+bool nodal_wrap_or_reflect_ok(const Geometry& g, const Layout& l, const DomainBC& bc, int min_len, int* refl)
+{
+    *refl = 0;
+    if (periodic_wrap_ok(g, l, min_len)) return true;
+    if (tune("PERIODIC_WRAP", 1) == 0 || tune("NODAL_REFLECT_WRAP", 1) == 0 || l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    int r = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (l.boxes[0].lo[d] != g.domain.lo[d] || l.boxes[0].hi[d] != g.domain.hi[d] || l.boxes[0].len(d) < min_len) return false;
+        if (g.periodic[d]) continue;
+        if (bc.lo[d] != lo_neumann || bc.hi[d] != lo_neumann) return false;
+        r |= 1 << d;
+    }
+    *refl = r;
+    return true;
+}
+
 // the register-resident kernel takes this level (and honours zero_flags: bit 0 / 1 = xc / xn is identically zero and need not be read)
 bool nodal_gsr_applies(const MultiFab& x, const MultiFab& rhs, const MultiFab* dmask)
 {
@@ -1013,8 +1047,9 @@ bool nodal_gsr_applies(const MultiFab& x, const MultiFab& rhs, const MultiFab* d
 }
 
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap,
-                         const MultiFab* dmask, const double* csig, int zero_flags)
+                         const MultiFab* dmask, const double* csig, int zero_flags, int refl)
 {
+    IAMRX_ASSERT(refl == 0 || wrap);
     const MultiFab& x = xc;
     if (x.nlocal() == 0) return;
     IAMRX_ASSERT(x.ngrow >= 4 && sig.ngrow >= 4 && rhs.ngrow >= 3 && xn.ngrow == x.ngrow && xo.ngrow == x.ngrow && xo.d_tab != xc.d_tab);
@@ -1024,14 +1059,14 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // updates but 8-wave barriers)
     // levels whose boxes are at least GSR_MIN cells long in x and y: the register-resident kernel (IAMRX_GSR=0: k_nodal_gs4 everywhere)
     if (nodal_gsr_applies(x, rhs, dmask)) {
-        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags);
-        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags);
+        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl);
+        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl);
         return;
     }
     IAMRX_ASSERT(zero_flags == 0);       // k_nodal_gs4 reads its inputs
     const int big = (int)tune("GS4_TILE", 0);
-    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
-    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig);
+    if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, wrap ? refl : 0);
+    else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, wrap ? refl : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------

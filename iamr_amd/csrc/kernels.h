@@ -159,12 +159,15 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3), out of place: plane k from xc, planes
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
-                         bool wrap = false, const MultiFab* dmask = nullptr, const double* csig = nullptr, int zero_flags = 0);
+                         bool wrap = false, const MultiFab* dmask = nullptr, const double* csig = nullptr, int zero_flags = 0, int refl = 0);
+// (wrap: one box spanning its domain, images instead of ghost nodes -- periodic ones, or mirror images in the directions of refl (bit d):
+// nodal_wrap_or_reflect_ok)
 // k_nodal_gsr takes the level: then zero_flags (bit 0: xc, bit 1: xn is identically zero and is not read) may be passed
 bool nodal_gsr_applies(const MultiFab& x, const MultiFab& rhs, const MultiFab* dmask);
 void nodal_zero_masked(MultiFab& mf, const MultiFab& dmask);
 void nodal_build_dmask(const Geometry& g, MultiFab& dm, const MultiFab& cov, const DomainBC& bc);
 bool periodic_wrap_ok(const Geometry& g, const Layout& l, int min_len);
+bool nodal_wrap_or_reflect_ok(const Geometry& g, const Layout& l, const DomainBC& bc, int min_len, int* refl);
 // all sweeps x 8 colours of a small single-box periodic level in one single-workgroup launch (false: not applicable)
 bool nodal_smooth_small(const Geometry& g, MultiFab& x, const MultiFab& rhs, const MultiFab& sig, int nsweeps);
 void nodal_jacobi(const Geometry& g, MultiFab& xnew, const MultiFab& x, const MultiFab& rhs, const MultiFab& sig, const MultiFab* dmask = nullptr);

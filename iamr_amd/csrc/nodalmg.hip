@@ -180,8 +180,9 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
     // (with index wrap or on ghost-filled boxes, with or without a Dirichlet mask: the ghost nodes of a zero array are zero as well --
     // images, reflections at walls -- so the fill in front of the first pass goes too; IAMRX_NODAL_ZERO_START = 2: index-wrap levels only)
     const int zs_mode = (int)tune("NODAL_ZERO_START", 1);
+    int zs_refl = 0;
     const bool zero_start = x_is_zero && m_o.nodal_smoother == 0 && nodal_fused() && zs_mode != 0 && nodal_gsr_applies(x, rhs, L.dmask()) &&
-                            (zs_mode != 2 || (!L.dmask() && periodic_wrap_ok(L.g, *L.layout, 4)));       // (gsr_applies: boxes >= 48 cells -- never the single-workgroup smoother's level)
+                            (zs_mode != 2 || (!L.dmask() && nodal_wrap_or_reflect_ok(L.g, *L.layout, m_bc, 4, &zs_refl)));       // (gsr_applies: boxes >= 48 cells -- never the single-workgroup smoother's level)
     if (x_is_zero && !zero_start) x.setVal(0.0);
     // small single-box periodic levels: all sweeps x colours in one single-workgroup launch
     const MultiFab* dmk = L.dmask();
@@ -194,7 +195,9 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
         // sequential colour passes below.  Each sweep goes from one buffer to the other (see k_nodal_gs4).
         if (!L.xb.defined() || L.xb.ngrow != x.ngrow) L.xb.define(L.layout, node_type(), 1, x.ngrow);
         // one box spanning a fully periodic domain: the kernel takes periodic images from the valid data, no ghost fills
-        const bool wrap = !dmk && periodic_wrap_ok(L.g, *L.layout, 4);
+        // ... or a domain whose non-periodic directions end on Neumann walls: mirror images in those directions (k_nodal.hip image_node)
+        int refl = 0;
+        const bool wrap = !dmk && nodal_wrap_or_reflect_ok(L.g, *L.layout, m_bc, 4, &refl);
         if (!wrap) {
             // the right-hand side of the level's smooth calls is its residual array, unchanged within a V-cycle: fill its ghosts once
             if (&rhs == &L.res) { if (!L.res_filled) { fillbc(l, L.res); L.res_filled = true; } }
@@ -211,9 +214,9 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
             if (!wrap && !(zero_start && ns == 0)) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
             const double* cs = m_csig ? &m_csig_val : nullptr;
             const bool z = zero_start && ns == 0;
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs, z ? 3 : 0);      // even planes: a -> b
+            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs, z ? 3 : 0, refl);      // even planes: a -> b
             if (!wrap) fillbc(l, *b, par_fill ? 0 : -1);                     // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs, z ? 1 : 0);      // odd planes: centre from a, neighbours from b
+            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs, z ? 1 : 0, refl);      // odd planes: centre from a, neighbours from b
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);

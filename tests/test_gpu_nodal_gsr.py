@@ -124,3 +124,50 @@ def test_solver_iterates_identical_to_lds_kernel(gpu, case, pb):
     for a, b in zip(ref, got):
         assert np.isfinite(b).all()
         assert np.array_equal(a, b), (case, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("n,per", [((128, 96, 64), (0, 0, 0)), ((96, 64, 128), (0, 1, 0)), ((64, 64, 64), (1, 0, 0)), ((32, 24, 16), (0, 0, 0))])
+def test_mirror_images_at_neumann_walls_equal_the_ghost_fills(gpu, n, per):
+    """round 5: one box spanning a domain whose non-periodic directions end on Neumann walls (the pressure of LidDrivenCavity, of a channel):
+    the index-wrap variants of k_nodal_gsr / k_nodal_gs4 take the MIRROR image of a node / cell beyond a wall (image_node / image_cell) --
+    the value nodal_reflect_bc / cc_mirror_bc would have written into the ghost node / cell -- and no ghost fill runs in front of a pass
+    (Projection.cpp:2385-2567's solve on a closed domain; mlndlap_fillbc_cc / mlndlap_applybc roles).  The same doubles: a whole nodal
+    projection under IAMRX_NODAL_REFLECT_WRAP = 1 / 0 gives the same iterations, pressure and velocity bit for bit (the ghost-fill form
+    is the one the oracle tests of tests/test_gpu_walls.py pin)."""
+    lib = gpu
+    from iamr_amd import ns as N
+    g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n), periodic=per)
+    lay = lib.Layout.single(n)
+    lobc = tuple(PERIODIC if per[d] else NEUMANN for d in range(3))
+    rng = np.random.default_rng(8)
+    ax = [(np.arange(-1, n[d] + 1) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rho = 1.0 + 0.4 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(2 * np.pi * Z) + 0.1 * rng.random(X.shape)
+    vel = np.zeros(X.shape + (3,))
+    vel[..., 0] = np.sin(np.pi * X) * np.cos(2 * np.pi * Y) + 0.1 * rng.standard_normal(X.shape)
+    vel[..., 1] = np.sin(np.pi * Y) * np.cos(2 * np.pi * Z) + 0.1 * rng.standard_normal(X.shape)
+    vel[..., 2] = np.sin(np.pi * Z) * np.cos(2 * np.pi * X) + 0.1 * rng.standard_normal(X.shape)
+    for d in range(3):
+        sl0 = [slice(None)] * 3; sl1 = [slice(None)] * 3; sh0 = [slice(None)] * 3; sh1 = [slice(None)] * 3
+        sl0[d] = 0; sl1[d] = 1; sh0[d] = -1; sh1[d] = -2
+        if per[d]:
+            s0 = [slice(None)] * 3; s1 = [slice(None)] * 3
+            s0[d] = n[d]; s1[d] = 1
+            vel[tuple(sl0)] = vel[tuple(s0)]; vel[tuple(sh0)] = vel[tuple(s1)]
+            rho[tuple(sl0)] = rho[tuple(s0)]; rho[tuple(sh0)] = rho[tuple(s1)]
+        else:
+            vel[tuple(sl0)] = vel[tuple(sl1)]; vel[tuple(sh0)] = vel[tuple(sh1)]
+            vel[tuple(sl0) + (d,)] = -vel[tuple(sl1) + (d,)]; vel[tuple(sh0) + (d,)] = -vel[tuple(sh1) + (d,)]      # no flow through the walls
+            rho[tuple(sl0)] = rho[tuple(sl1)]; rho[tuple(sh0)] = rho[tuple(sh1)]
+    out = {}
+    for mode in (1, 0):
+        with tuning(lib, NODAL_REFLECT_WRAP=(mode, 1)):
+            sig_d = lib.MultiFab(lay, lib.CELL, 1, 1); sig_d.set_from_global((1.0 / rho)[..., None], (-1,) * 3)
+            vel_d = lib.MultiFab(lay, lib.CELL, 3, 1); vel_d.set_from_global(vel, (-1,) * 3)
+            p_d = lib.MultiFab(lay, lib.NODE, 1, 1); p_d.setval(0.0)
+            st = N.nodal_projection(g, vel_d, 0, p_d, sig_d, 0, lobc=lobc, hibc=lobc, rel_tol=1e-10, abs_tol=1e-16)
+            assert st.converged >= 1
+            out[mode] = (st.iters, st.resnorm, vel_d.gather_valid(n), p_d.gather_valid(n))
+    assert out[1][0] == out[0][0] and out[1][1] == out[0][1], (out[1][:2], out[0][:2])
+    assert np.array_equal(out[1][3], out[0][3]), float(np.abs(out[1][3] - out[0][3]).max())
+    assert np.array_equal(out[1][2], out[0][2])
