@@ -124,3 +124,54 @@ def test_host_fill_plan_two_ranks_messages_match():
     send10 = p1[(p1[:, 0] == 1) & (p1[:, 1] == 0)]
     recv01 = p0[(p0[:, 0] == 2) & (p0[:, 1] == 1)]
     assert np.array_equal(send10[:, 4:14], recv01[:, 4:14])
+
+
+@pytest.mark.parametrize("n,boxes,ng", [((16, 2, 8), [((0, 0, 0), (15, 1, 7))], 4),                                     # a two-cell slab level, four ghost layers
+                                        ((16, 8, 8), [((i0, j0, 0), (i0 + 7, j0 + 3, 7)) for i0 in (0, 8) for j0 in (0, 4)], 2),
+                                        ((8, 4, 4), [((0, 0, 0), (7, 3, 3))], 4)])
+def test_host_fill_plan_gives_every_nodal_ghost_point_one_local_source(n, boxes, ng):
+    """round 5: nodal boxes share the points on their faces and a periodic direction narrower than the ghost width maps a box onto a ghost
+    point under one AND under two periods -- two local descriptors writing one ghost point in one launch, with sources that may differ in
+    the last bit (the duplicates of a periodic node): a write-write race (found on the slab levels, tests/test_gpu_slab_mg.py).  The plan
+    now keeps one local source per ghost point: no two local descriptors of a destination box overlap, every ghost point is still
+    covered, and the values are the periodic images."""
+    from iamr_amd import lib
+    typ = (1, 1, 1)
+    geom = lib.Geom.make(n)
+    desc = host_plan(lib, boxes, [0] * len(boxes), 0, typ, ng, geom)
+    loc = desc[desc[:, 0] == 0]
+    count = {}
+    for b, (lo, hi) in enumerate(boxes):
+        flo = [lo[d] - ng for d in range(3)]
+        shape = [hi[d] - lo[d] + 1 + typ[d] + 2 * ng for d in range(3)]
+        count[b] = (np.zeros(shape, dtype=np.int64), flo)
+    for d in loc:
+        t = int(d[3])
+        c, flo = count[t]
+        sl = tuple(slice(int(d[4 + q]) - flo[q], int(d[7 + q]) - flo[q] + 1) for q in range(3))
+        c[sl] += 1
+    for b, (lo, hi) in enumerate(boxes):
+        c, flo = count[b]
+        valid = tuple(slice(ng, ng + hi[d] - lo[d] + 1 + typ[d]) for d in range(3))
+        assert c[valid].max() == 0                     # nothing is copied onto a box's own valid points
+        ghost = np.ones(c.shape, dtype=bool); ghost[valid] = False
+        assert c[ghost].min() == 1 and c[ghost].max() == 1, (int(c[ghost].min()), int(c[ghost].max()))
+    # and the values: periodic images of a node field whose duplicates agree
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal(n)
+
+    def gval(I, J, K):
+        return G[np.mod(I, n[0]), np.mod(J, n[1]), np.mod(K, n[2])]
+    fabs, los = {}, {}
+    for b, (lo, hi) in enumerate(boxes):
+        flo = [lo[d] - ng for d in range(3)]
+        I, J, K = np.meshgrid(*[np.arange(flo[d], hi[d] + typ[d] + ng + 1) for d in range(3)], indexing="ij")
+        a = np.full(I.shape, np.nan)
+        v = tuple(slice(ng, ng + hi[d] - lo[d] + 1 + typ[d]) for d in range(3))
+        a[v] = gval(I[v], J[v], K[v])
+        fabs[b], los[b] = a, flo
+    apply_plan_numpy(desc, fabs, los)
+    for b in fabs:
+        flo = los[b]
+        I, J, K = np.meshgrid(*[np.arange(flo[d], flo[d] + fabs[b].shape[d]) for d in range(3)], indexing="ij")
+        assert np.array_equal(fabs[b], gval(I, J, K))
