@@ -194,6 +194,64 @@ void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, con
     });
 }
 
+// MacProj::mac_sync_compute, the form NavierStokes::mac_sync uses (Source/MacProj.cpp:488-731), on caller-owned arrays: the forcing of the
+// velocity trace = gravity + viscous terms - grad p (divided by rho unless the momentum form is advected, :598-640), then ComputeAofs with
+// is_sync = true for the velocities (-> Vsync) and for all scalars (-> Ssync).  Svel / Sscal: the FillPatch-ed state at prev_time with three
+// ghost cells (Svel = rho u under do_mom_diff, :536-553; Sscal starts with the density); visc_vel (3 comps) / tf_scal (nscal comps: the
+// scalars' forcing as :641-683 assemble it) with one ghost cell, null = zero.  The fluxes come back for the registers (:707-727, the caller's).
+void mac_sync_compute(const Geometry& g, MultiFab* const ucorr[3], MultiFab& Vsync, MultiFab& Ssync, const MultiFab& Svel, const MultiFab& Sscal, int nscal,
+                      const MultiFab* visc_vel, const MultiFab* tf_scal, const MultiFab& gradp, const MultiFab* divu, MultiFab* const umac[3],
+                      const int* iconserv_scal, bool do_mom_diff, double gravity, double dt, const BCRec* bc_vel, const BCRec* bc_scal,
+                      bool use_forces_in_trans, int scheme, MultiFab* const flux_vel[3], MultiFab* const flux_scal[3])
+{
+    auto& ctx = Context::get();
+    const LayoutP& layout = Svel.layout;
+    MultiFab tfv(layout, cell_type(), 3, 1), tfs0;
+    if (!tf_scal) { tfs0.define(layout, cell_type(), nscal, 1); tfs0.setVal(0.0); tf_scal = &tfs0; }
+    {
+        const FabD *tt = tfv.d_tab, *gt = gradp.d_tab, *st = Sscal.d_tab, *vt = visc_vel ? visc_vel->d_tab : nullptr;
+        const bool mom = do_mom_diff;
+        const double grav = gravity;
+        for_each(*layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
+            const double rho = st[fb](i, j, k, 0);
+            for (int n = 0; n < 3; ++n) {
+                double t = ((fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0) + (vt ? (double)vt[fb](i, j, k, n) : 0.0) - gt[fb](i, j, k, n);
+                if (!mom) t /= rho;
+                tt[fb](i, j, k, n) = t;
+            }
+        });
+    }
+    const int icv[3] = {do_mom_diff ? 1 : 0, do_mom_diff ? 1 : 0, do_mom_diff ? 1 : 0};
+    godunov_compute_aofs_sync(g, Vsync, 0, Svel, 3, &tfv, divu, umac, ucorr, icv, dt, bc_vel, true, use_forces_in_trans, flux_vel, scheme);
+    godunov_compute_aofs_sync(g, Ssync, 0, Sscal, nscal, tf_scal, divu, umac, ucorr, iconserv_scal, dt, bc_scal, false, use_forces_in_trans, flux_scal, scheme);
+}
+
+// MacProj::mac_sync_compute, the form with edge states handed in (Source/MacProj.cpp:733-786: ComputeAofs with known_edgestate and is_sync,
+// one component): flux = edgestate(edge_comp) * Ucorr * area (NavierStokesBase.cpp:4681-4683), Sync(sync_indx) -= -div(flux) / vol
+// (:4826-4832); flux_out (optional, one component) for the caller's advective flux register (FineAdd with the sync sign, :5083-5096)
+void mac_sync_compute_edge(const Geometry& g, MultiFab* const ucorr[3], MultiFab& Sync, int sync_indx, MultiFab* const edgestate[3], int edge_comp,
+                           MultiFab* const flux_out[3])
+{
+    auto& ctx = Context::get();
+    const LayoutP& layout = Sync.layout;
+    MultiFab fl[3];
+    for (int d = 0; d < 3; ++d) {
+        if (!flux_out) fl[d].define(layout, face_type(d), 1, 0);
+        const double area = g.dx[(d + 1) % 3] * g.dx[(d + 2) % 3];
+        const FabD *et = edgestate[d]->d_tab, *ut = ucorr[d]->d_tab, *ft = (flux_out ? flux_out[d] : &fl[d])->d_tab;
+        const int ec = edge_comp;
+        for_each(*layout, face_type(d), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { ft[f](i, j, k) = et[f](i, j, k, ec) * ut[f](i, j, k) * area; });
+    }
+    const FabD *fx = (flux_out ? flux_out[0] : &fl[0])->d_tab, *fy = (flux_out ? flux_out[1] : &fl[1])->d_tab, *fz = (flux_out ? flux_out[2] : &fl[2])->d_tab;
+    const FabD* st = Sync.d_tab;
+    const double qvol = 1.0 / (g.dx[0] * g.dx[1] * g.dx[2]);
+    const int sc = sync_indx;
+    for_each(*layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+        const double upd = -1.0 * qvol * ((fx[f](i + 1, j, k) - fx[f](i, j, k)) + (fy[f](i, j + 1, k) - fy[f](i, j, k)) + (fz[f](i, j, k + 1) - fz[f](i, j, k)));
+        st[f](i, j, k, sc) -= upd;
+    });
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // sync residuals
 MultiFab amr_sync_resid(NavierStokes& ns, const MultiFab& vold, const MultiFab& phi, const MultiFab& sig, bool crse_side, const MultiFab* rhcc)
@@ -300,6 +358,18 @@ SyncRegister::SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, co
     });
     ctx.sync();
     ctx.free(d_nb);
+}
+
+// SyncRegister::CompAdd (SyncRegister.cpp:302-348): the residual of a sync projection on the levels above, formed on the fine side of THIS
+// register's interface, is zeroed on the nodes of the next finer level's boxes (Pgrids: that level's boxes in the index space of the
+// residual, periodic images included) and then added like a fine residual
+void SyncRegister::CompAdd(MultiFab& sync_resid_fine, const Geometry& fgeom, const LayoutP& finer, int finer_ratio, double mult)
+{
+    MultiFab vsf(sync_resid_fine.layout, node_type(), 1, 0);
+    MultiFab fc = fine_coverage(sync_resid_fine.layout, finer, fgeom, finer_ratio);
+    node_class(vsf, fc, fgeom);
+    mask_mult(sync_resid_fine, 0, 1, vsf, true, 0);
+    FineAdd(sync_resid_fine, mult);
 }
 
 void SyncRegister::CrseInit(const MultiFab& resid, double mult)
@@ -431,6 +501,88 @@ void comp_residual(std::vector<CLev>& L, int lmin = 0)        // r = b - A x on 
 }
 
 }  // namespace
+
+// Projection::initialVelocityProject (Source/Projection.cpp:615-838) on caller-owned arrays: on every level of the solve the pressure is
+// zeroed (:640-648), sigma = 1 (rho_wgt_vel_proj = 0) or 1 / rho (:689-730 with scaleVar), rhcc = -divu (:732-743, 783-788), and the
+// velocities are projected on the composite grid without touching grad p (increment_gp = false; gp of the levels receives grad phi);
+// pres[l] returns phi.  Inflow ghost velocities count in full (inflow_scale 1).
+MGStats initial_velocity_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[], const int vcomp[], MultiFab* const pres[], const MultiFab* const rho[],
+                                 const int rho_comp[], const MultiFab* const divu[], const int divu_comp[], double proj_tol, double proj_abs_tol, const MGOpts& o)
+{
+    auto& ctx = Context::get();
+    const int nl = (int)PL.size();
+    std::vector<MultiFab> sig(nl), rc(nl);
+    std::vector<const MultiFab*> sigp(nl), rcp(nl, nullptr);
+    bool have_divu = false;
+    for (int l = 0; l < nl; ++l) {
+        pres[l]->setVal(0.0);
+        sig[l].define(PL[l].layout, cell_type(), 1, 0);
+        if (rho && rho[l]) {
+            const FabD *st = sig[l].d_tab, *rt = rho[l]->d_tab;
+            const int rcmp = rho_comp ? rho_comp[l] : 0;
+            for_each(*PL[l].layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / rt[f](i, j, k, rcmp); });
+        } else sig[l].setVal(1.0);
+        sigp[l] = &sig[l];
+        if (divu && divu[l]) {
+            rc[l].define(PL[l].layout, cell_type(), 1, 0);
+            MultiFab::Copy(rc[l], *divu[l], divu_comp ? divu_comp[l] : 0, 0, 1, 0);
+            mf_mult(rc[l], -1.0, 0, 1, 0);
+            rcp[l] = &rc[l];
+            have_divu = true;
+        }
+    }
+    return composite_project(PL, vel, vcomp, pres, sigp.data(), nullptr, proj_tol, proj_abs_tol, false, 1.0, o, have_divu ? rcp.data() : nullptr);
+}
+
+// Projection::initialSyncProject (Source/Projection.cpp:970-1185) on caller-owned arrays: U_new <- (U_new - U_old) / dt (ConvertUnew, :1100-1101),
+// sigma = 1 / rho_half (scaleVar, :1112-1118), the velocities averaged down level by level (:1120-1136), rhcc = -(divu_new - divu_old) / dt
+// (:1008-1075, 1142-1148), composite projection with increment_gp = true (the levels' gp accumulate grad phi); phi[l] (the old-time pressure
+// array of the caller, zeroed first, :1002) returns the correction, which is added to pres_new[l] (:1166-1170).  vel_new keeps the projected
+// acceleration, as upstream's does until NavierStokesBase::resetState.
+MGStats initial_sync_project(const std::vector<ProjLevel>& PL, MultiFab* const vel_new[], const int vcomp[], const MultiFab* const vel_old[], MultiFab* const phi[],
+                             MultiFab* const pres_new[], const MultiFab* const rho_half[], const MultiFab* const divu_new[], const MultiFab* const divu_old[],
+                             const int divu_comp[], double dt, double proj_tol, double proj_abs_tol, const MGOpts& o)
+{
+    auto& ctx = Context::get();
+    const int nl = (int)PL.size();
+    std::vector<MultiFab> sig(nl), rc(nl);
+    std::vector<const MultiFab*> sigp(nl), rcp(nl, nullptr);
+    bool have_divu = false;
+    for (int l = 0; l < nl; ++l) {
+        phi[l]->setVal(0.0);
+        {
+            const double dt_inv = 1. / dt;
+            const FabD *nt = vel_new[l]->d_tab, *ot = vel_old[l]->d_tab;
+            const int vc = vcomp[l];
+            for_each(*PL[l].layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
+                for (int n = 0; n < 3; ++n) nt[f](i, j, k, vc + n) = (nt[f](i, j, k, vc + n) - ot[f](i, j, k, vc + n)) * dt_inv;   // ConvertUnew
+            });
+        }
+        sig[l].define(PL[l].layout, cell_type(), 1, 0);
+        const FabD *st = sig[l].d_tab, *ht = rho_half[l]->d_tab;
+        for_each(*PL[l].layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / ht[f](i, j, k); });
+        sigp[l] = &sig[l];
+        if (divu_new && divu_new[l] && divu_old && divu_old[l]) {
+            const int dc = divu_comp ? divu_comp[l] : 0;
+            rc[l].define(PL[l].layout, cell_type(), 1, 0);
+            MultiFab::Copy(rc[l], *divu_new[l], dc, 0, 1, 0);
+            mf_saxpy(rc[l], -1.0, *divu_old[l], dc, 0, 1, 0);
+            mf_mult(rc[l], -1.0 / dt, 0, 1, 0);
+            rcp[l] = &rc[l];
+            have_divu = true;
+        }
+    }
+    for (int l = nl - 1; l >= 1; --l) {
+        MultiFab vf(PL[l].layout, cell_type(), 3, 0), vc(PL[l - 1].layout, cell_type(), 3, 0);
+        MultiFab::Copy(vf, *vel_new[l], vcomp[l], 0, 3, 0);
+        MultiFab::Copy(vc, *vel_new[l - 1], vcomp[l - 1], 0, 3, 0);
+        average_down(vf, vc, 0, 3, PL[l].ratio);
+        MultiFab::Copy(*vel_new[l - 1], vc, 0, vcomp[l - 1], 3, 0);
+    }
+    MGStats st = composite_project(PL, vel_new, vcomp, phi, sigp.data(), nullptr, proj_tol, proj_abs_tol, true, 0.0, o, have_divu ? rcp.data() : nullptr);
+    if (pres_new) for (int l = 0; l < nl; ++l) if (pres_new[l]) mf_saxpy(*pres_new[l], 1.0, *phi[l], 0, 0, 1, 1);
+    return st;
+}
 
 MGStats AmrNS::composite_project(int c0, int nl, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
                                  const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MultiFab* const rhcc[])
@@ -622,7 +774,7 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
         // tolerance: a residual within 10x of the target that has lost less than 10 % over three iterations is as converged as fp64 allows.
         // amrex::MLMG would iterate to max_iter and abort; converged = 2 reports the difference
         hist.push_back(st.resnorm);
-        if (hist.size() >= 4 && st.resnorm <= 10.0 * target && st.resnorm > 0.9 * hist[hist.size() - 4]) {
+        if (mg_stalled_at_floor(hist, st.resnorm0, target, tune("MG_STALL_FAST", 1) != 0)) {
             st.converged = 2;
             fprintf(stderr, "iamrx composite nodal solve: WARNING: residual %.3e stalled at the round-off floor above the target %.3e after %d iterations; accepted (converged = 2)\n",
                     st.resnorm, target, st.iters);
@@ -814,7 +966,7 @@ void AmrNS::mac_sync(int l)
                 for (int n = 0; n < 3; ++n) ut[fb](i, j, k, n) *= r;
             });
         }
-        MultiFab tfv(c.layout, cell_type(), 3, 1), tfs(c.layout, cell_type(), c.nscal, 1), divu;
+        MultiFab tfs(c.layout, cell_type(), c.nscal, 1), divu;
         tfs.setVal(0.0);
         c.divu_half(divu, dt, 1, false);                             // getDivCond(nghost_force, prev_time), MacProj.cpp:562
         // viscous forcing at the old time (MacProj.cpp:566-572): getViscTerms(visc_terms, 0, num_state_comps, prev_time)
@@ -831,26 +983,12 @@ void AmrNS::mac_sync(int l)
                 MultiFab::Copy(tfs, sv, 0, n, 1, 1);
             }
         }
-        {
-            const FabD *tt = tfv.d_tab, *gt = c.Gp[1 - c.pnew].d_tab, *st = Sc.d_tab, *vt = vvisc.d_tab;
-            const double grav = c.p.gravity;
-            for_each(*c.layout, cell_type(), 1, ctx.stream, [=] __device__(int i, int j, int k, int fb) {
-                const double rho = st[fb](i, j, k, 0);
-                for (int n = 0; n < 3; ++n) {
-                    double t = ((fabs(grav) > 0.0001 && n == 2) ? grav * rho : 0.0) + vt[fb](i, j, k, n) - gt[fb](i, j, k, n);
-                    if (!mom) t /= rho;
-                    tt[fb](i, j, k, n) = t;
-                }
-            });
-        }
         MultiFab* um[3] = {&c.u_mac[0], &c.u_mac[1], &c.u_mac[2]};
-        const int icv[3] = {mom ? 1 : 0, mom ? 1 : 0, mom ? 1 : 0};
-        const int* ics = c.scal_cons;
         MultiFab flv[3], fls[3];
         MultiFab *flvp[3], *flsp[3];
         for (int d = 0; d < 3; ++d) { flv[d].define(c.layout, face_type(d), 3, 0); fls[d].define(c.layout, face_type(d), c.nscal, 0); flvp[d] = &flv[d]; flsp[d] = &fls[d]; }
-        godunov_compute_aofs_sync(c.g, c.Vsync, 0, Smf, 3, &tfv, &divu, um, uc, icv, dt, c.bc_vel, true, c.p.use_forces_in_trans != 0, flvp, c.p.use_ppm);
-        godunov_compute_aofs_sync(c.g, c.Ssync, 0, Sc, c.nscal, &tfs, &divu, um, uc, ics, dt, c.bc_scal, false, c.p.use_forces_in_trans != 0, flsp, c.p.use_ppm);
+        mac_sync_compute(c.g, uc, c.Vsync, c.Ssync, Smf, Sc, c.nscal, &vvisc, &tfs, c.Gp[1 - c.pnew], &divu, um, c.scal_cons, mom, c.p.gravity, dt, c.bc_vel,
+                         c.bc_scal, c.p.use_forces_in_trans != 0, c.p.use_ppm, flvp, flsp);
         for (int d = 0; d < 3; ++d) {            // NavierStokesBase.cpp:5083-5096 with sync_factor = -1
             f.reg_adv->CrseInit(flv[d], d, 0, 0, 3, dt, true);
             f.reg_adv->CrseInit(fls[d], d, 0, Density, c.nscal, dt, true);
@@ -975,11 +1113,7 @@ MGStats ml_sync_project(const ProjLevel PL[2], MultiFab& pres_crse, MultiFab& ve
     MGStats st = composite_project(pl, vel, vcomp, phi, sig, &rhnd, sync_tol, abs_tol, true, 0.0, o);
     if (want_resid) {
         MultiFab r = sync_resid(C.g, C.layout, C.nodal_bc, LayoutP(), 2, vold_c, phi_c, sig_c);
-        MultiFab vsf(C.layout, node_type(), 1, 0);                    // CompAdd: zero on the nodes of the coarsened level-(l+1) boxes
-        MultiFab fc = fine_coverage(C.layout, F.layout, C.g, F.ratio);
-        node_class(vsf, fc, C.g);
-        mask_mult(r, 0, 1, vsf, true, 0);
-        crse_sync_reg->FineAdd(r, 1.0 / (double)crse_dt_ratio);
+        crse_sync_reg->CompAdd(r, C.g, F.layout, F.ratio, 1.0 / (double)crse_dt_ratio);
     }
     mf_saxpy(pres_crse, 1.0, phi_c, 0, 0, 1, 1);
     mf_saxpy(pres_fine, 1.0, phi_f, 0, 0, 1, 1);
@@ -1117,19 +1251,17 @@ void AmrNS::post_init(double stop_time_)
     if (p.init_vel_iter <= 0) { for (auto& s : lev) { s->P[1 - s->pnew].setVal(0.0); s->Gp[1 - s->pnew].setVal(0.0); } }
     else
     for (int iter = 0; iter < p.init_vel_iter; ++iter) {             // Projection::initialVelocityProject
+        std::vector<ProjLevel> PL(nl);
+        std::vector<const MultiFab*> dvp(nl, nullptr);
+        std::vector<int> dvc(nl, 0);
         for (int l = 0; l < nl; ++l) {
             NavierStokes& s = *lev[l];
-            s.P[1 - s.pnew].setVal(0.0);
-            sig[l].define(s.layout, cell_type(), 1, 0); sig[l].setVal(1.0);      // rho_wgt_vel_proj = 0
-            vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
-            if (have_divu) {                                         // rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788
-                rc[l].define(s.layout, cell_type(), 1, 0);
-                MultiFab::Copy(rc[l], s.S[s.inew], s.Divu, 0, 1, 0);
-                mf_mult(rc[l], -1.0, 0, 1, 0);
-                rcp[l] = &rc[l];
-            }
+            PL[l] = proj_level(l);
+            vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew];
+            if (have_divu) { dvp[l] = &s.S[s.inew]; dvc[l] = s.Divu; }      // rhcc = -getDivCond(cur_divu_time), Projection.cpp:732-743, 783-788
         }
-        lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, false, 1.0, have_divu ? rcp.data() : nullptr);
+        lev[0]->st_nodal = initial_velocity_project(PL, vel.data(), vcomp.data(), phi.data(), nullptr /* rho_wgt_vel_proj = 0 */, nullptr,
+                                                    have_divu ? dvp.data() : nullptr, dvc.data(), p.proj_tol, p.proj_abs_tol, o);
         for (auto& s : lev) for (int q = 0; q < 2; ++q) { s->P[q].setVal(0.0); s->Gp[q].setVal(0.0); }
     }
     for (auto& s : lev) s->initial_step = true;
@@ -1188,37 +1320,20 @@ void AmrNS::post_init(double stop_time_)
         for (int iter = 0; iter < p.init_iter; ++iter) {
             for (int k = 0; k < nl; ++k) lev[k]->advance(dt_init, 1, 1);
             // Projection::initialSyncProject (Projection.cpp:970-1185)
-            for (int l = 0; l < nl; ++l) {
-                NavierStokes& s = *lev[l];
-                s.P[1 - s.pnew].setVal(0.0);
-                {
-                    const double dt_inv = 1. / dt_init;
-                    const FabD *nt = s.S[s.inew].d_tab, *ot = s.S[1 - s.inew].d_tab;
-                    for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
-                        for (int n = 0; n < 3; ++n) nt[f](i, j, k, n) = (nt[f](i, j, k, n) - ot[f](i, j, k, n)) * dt_inv;   // ConvertUnew
-                    });
+            {
+                std::vector<ProjLevel> PL(nl);
+                std::vector<const MultiFab*> vold(nl), rh(nl), dn(nl, nullptr), dol(nl, nullptr);
+                std::vector<MultiFab*> pn(nl);
+                std::vector<int> dvc(nl, 0);
+                for (int l = 0; l < nl; ++l) {
+                    NavierStokes& s = *lev[l];
+                    PL[l] = proj_level(l);
+                    vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; vold[l] = &s.S[1 - s.inew]; phi[l] = &s.P[1 - s.pnew]; pn[l] = &s.P[s.pnew]; rh[l] = &s.rho_half;
+                    if (have_divu) { dn[l] = &s.S[s.inew]; dol[l] = &s.S[1 - s.inew]; dvc[l] = s.Divu; }
                 }
-                sig[l].define(s.layout, cell_type(), 1, 0);
-                const FabD *st = sig[l].d_tab, *ht = s.rho_half.d_tab;
-                for_each(*s.layout, cell_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) { st[f](i, j, k) = 1.0 / ht[f](i, j, k); });
-                vel[l] = &s.S[s.inew]; vcomp[l] = Xvel; phi[l] = &s.P[1 - s.pnew]; sigp[l] = &sig[l];
-                if (have_divu) {                                     // rhcc = -(divu(strt_time + dt) - divu(strt_time)) / dt, Projection.cpp:1008-1075, 1142-1148
-                    rc[l].define(s.layout, cell_type(), 1, 0);
-                    MultiFab::Copy(rc[l], s.S[s.inew], s.Divu, 0, 1, 0);
-                    mf_saxpy(rc[l], -1.0, s.S[1 - s.inew], s.Divu, 0, 1, 0);
-                    mf_mult(rc[l], -1.0 / dt_init, 0, 1, 0);
-                    rcp[l] = &rc[l];
-                }
+                lev[0]->st_nodal = initial_sync_project(PL, vel.data(), vcomp.data(), vold.data(), phi.data(), pn.data(), rh.data(), have_divu ? dn.data() : nullptr,
+                                                        have_divu ? dol.data() : nullptr, dvc.data(), dt_init, p.proj_tol, p.proj_abs_tol, o);
             }
-            for (int l = fin; l >= 1; --l) {
-                MultiFab vf(lev[l]->layout, cell_type(), 3, 0), vc(lev[l - 1]->layout, cell_type(), 3, 0);
-                MultiFab::Copy(vf, *vel[l], Xvel, 0, 3, 0);
-                MultiFab::Copy(vc, *vel[l - 1], Xvel, 0, 3, 0);
-                average_down(vf, vc, 0, 3, lev[l]->ratio);
-                MultiFab::Copy(*vel[l - 1], vc, 0, Xvel, 3, 0);
-            }
-            lev[0]->st_nodal = composite_project(0, nl, vel.data(), vcomp.data(), phi.data(), sigp.data(), nullptr, p.proj_tol, p.proj_abs_tol, true, 0.0, have_divu ? rcp.data() : nullptr);
-            for (auto& s : lev) mf_saxpy(s->P[s->pnew], 1.0, s->P[1 - s->pnew], 0, 0, 1, 1);
             for (int k = fin - 1; k >= 0; --k) avg_down(k);
             for (auto& s : lev) {                                     // resetState(strt_time, dt_init, dt_init)
                 s->inew = 1 - s->inew;

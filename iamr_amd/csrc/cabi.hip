@@ -79,6 +79,7 @@ int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity)
     if (enable >= 0) scope_profile_enable(enable != 0, reset != 0);
     IAMRX_CATCH
 }
+int iamrx_coalesce_merge_count(size_t* n) { IAMRX_TRY *n = coalesce_merge_count(); IAMRX_CATCH }
 int iamrx_exchange_counts(size_t out[4])
 {
     IAMRX_TRY
@@ -107,6 +108,11 @@ int iamrx_mem_info(size_t* live, size_t* cached)
 int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
                          int max_desc, int* desc, int* ndesc)
 {
+    return iamrx_host_fill_plan_wall_ext(nboxes, lo_hi, owner, rank, type, ngrow, g, 0, max_desc, desc, ndesc);
+}
+int iamrx_host_fill_plan_wall_ext(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
+                                  int wall_ext, int max_desc, int* desc, int* ndesc)
+{
     IAMRX_TRY
     std::vector<BoxD> b(nboxes);
     std::vector<int> own(nboxes), local_of(nboxes, -1), local;
@@ -118,7 +124,7 @@ int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int ran
     CopyPlan plan;
     std::map<int, CopyPlan::Peer> peers;
     IndexType t{{type[0], type[1], type[2]}};
-    build_fill_plan_host(b, own, local_of, rank, t, ngrow, to_geom(g), plan, peers);
+    build_fill_plan_host(b, own, local_of, rank, t, ngrow, to_geom(g), plan, peers, nullptr, -1, wall_ext);
     int n = 0;
     auto emit = [&](int kind, int peer, const CopyDesc& cd) {
         if (n < max_desc && desc) {
@@ -1019,6 +1025,33 @@ int iamrx_syncreg_crse_init(iamrx_syncreg r, iamrx_mf sync_resid_crse, double mu
 int iamrx_syncreg_fine_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, double mult) { IAMRX_TRY r->sr->FineAdd(sync_resid_fine->mf, mult); IAMRX_CATCH }
 int iamrx_syncreg_init_rhs(iamrx_syncreg r, iamrx_mf rhs) { IAMRX_TRY r->sr->InitRHS(rhs->mf); IAMRX_CATCH }
 
+// a level of a multi-level nodal projection on caller-owned data.  Ghost velocities outside inflow faces: the caller's data count in full
+// where the projection asks for them (inflow_scale 1: initialVelocityProject), and are zeroed for increments that carry no inflow data
+// (inflow_scale 0: the sync projections, initialSyncProject; Projection::set_boundary_velocity, Source/Projection.cpp:2570-2663)
+static ProjLevel to_proj_level(const iamrx_proj_level* in)
+{
+    ProjLevel P;
+    P.g = to_geom(in->geom); P.layout = in->layout->p; P.ratio = in->ratio;
+    P.nodal_bc = to_bc(in->lobc, in->hibc, 2);
+    P.gp = in->gp ? &in->gp->mf : nullptr;
+    const Geometry g = P.g;
+    const DomainBC bc = P.nodal_bc;
+    P.set_inflow = [g, bc](MultiFab& vel, double scale) {
+        if (scale == 1.0) return;
+        for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+            if (g.periodic[d] || (side == 0 ? bc.lo[d] : bc.hi[d]) != lo_inflow) continue;
+            const int face = side == 0 ? g.domain.lo[d] - 1 : g.domain.hi[d] + 1;
+            const FabD* vt = vel.d_tab;
+            const int dd = d;
+            const double sc = scale;
+            for_each(*vel.layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
+                if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) vt[f](i, j, k, dd) *= sc;
+            });
+        }
+    };
+    return P;
+}
+
 // Projection::MLsyncProject on caller-owned data (amrns.hip ml_sync_project)
 int iamrx_mlsync_project(const iamrx_proj_level* crse, const iamrx_proj_level* fine, iamrx_mf pres_crse, iamrx_mf vel_crse, int vcomp_crse, iamrx_mf pres_fine,
                          iamrx_mf vel_fine, int vcomp_fine, iamrx_mf rho_crse, iamrx_mf rho_fine, iamrx_mf Vsync, iamrx_mf V_corr, iamrx_mf phi_crse,
@@ -1027,28 +1060,7 @@ int iamrx_mlsync_project(const iamrx_proj_level* crse, const iamrx_proj_level* f
 {
     IAMRX_TRY
     MGOpts op = to_opts(o);
-    ProjLevel PL[2];
-    const iamrx_proj_level* in[2] = {crse, fine};
-    for (int l = 0; l < 2; ++l) {
-        ProjLevel& P = PL[l];
-        P.g = to_geom(in[l]->geom); P.layout = in[l]->layout->p; P.ratio = in[l]->ratio;
-        P.nodal_bc = to_bc(in[l]->lobc, in[l]->hibc, 2);
-        P.gp = in[l]->gp ? &in[l]->gp->mf : nullptr;
-        const Geometry g = P.g;
-        const DomainBC bc = P.nodal_bc;
-        // the sync increments carry no inflow data: ghost velocities outside inflow faces are zero (inflow_scale = 0, Projection.cpp:2570-2663)
-        P.set_inflow = [g, bc](MultiFab& vel, double) {
-            for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
-                if (g.periodic[d] || (side == 0 ? bc.lo[d] : bc.hi[d]) != lo_inflow) continue;
-                const int face = side == 0 ? g.domain.lo[d] - 1 : g.domain.hi[d] + 1;
-                const FabD* vt = vel.d_tab;
-                const int dd = d;
-                for_each(*vel.layout, cell_type(), 1, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
-                    if ((dd == 0 ? i : (dd == 1 ? j : k)) == face) vt[f](i, j, k, dd) = 0.0;
-                });
-            }
-        };
-    }
+    ProjLevel PL[2] = {to_proj_level(crse), to_proj_level(fine)};
     MGStats s = ml_sync_project(PL, pres_crse->mf, vel_crse->mf, vcomp_crse, pres_fine->mf, vel_fine->mf, vcomp_fine, rho_crse->mf, rho_fine->mf, Vsync->mf,
                                 V_corr->mf, phi_crse->mf, phi_fine->mf, *rhs_sync_reg->sr, crse_sync_reg ? crse_sync_reg->sr.get() : nullptr, dt, crse_iteration,
                                 crse_dt_ratio, sync_tol, abs_tol, op);
@@ -1079,6 +1091,85 @@ int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acom
     MultiFab* fl[3] = {flux_x ? &flux_x->mf : nullptr, flux_y ? &flux_y->mf : nullptr, flux_z ? &flux_z->mf : nullptr};
     godunov_compute_aofs_sync(to_geom(g), sync->mf, acomp, S->mf, ncomp, force ? &force->mf : nullptr, divu ? &divu->mf : nullptr, um, uc,
                               iconserv, dt, bc.data(), is_velocity != 0, use_forces_in_trans != 0, flux_x ? fl : nullptr, scheme);
+    IAMRX_CATCH
+}
+
+int iamrx_syncreg_comp_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, const iamrx_geom* fgeom, iamrx_layout finer, int finer_ratio, double mult)
+{
+    IAMRX_TRY
+    r->sr->CompAdd(sync_resid_fine->mf, to_geom(fgeom), finer->p, finer_ratio, mult);
+    IAMRX_CATCH
+}
+
+int iamrx_mac_sync_compute(const iamrx_geom* g, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z, iamrx_mf Vsync, iamrx_mf Ssync, iamrx_mf S_vel,
+                           iamrx_mf S_scal, int nscal, iamrx_mf visc_vel, iamrx_mf tforce_scal, iamrx_mf gradp, iamrx_mf divu, iamrx_mf umac_x,
+                           iamrx_mf umac_y, iamrx_mf umac_z, const int* iconserv_scal, int do_mom_diff, double gravity, double dt, const int* bcrec_vel,
+                           const int* bcrec_scal, int use_forces_in_trans, int scheme, iamrx_mf fluxv_x, iamrx_mf fluxv_y, iamrx_mf fluxv_z,
+                           iamrx_mf fluxs_x, iamrx_mf fluxs_y, iamrx_mf fluxs_z)
+{
+    IAMRX_TRY
+    std::vector<BCRec> bv(3), bs(nscal);
+    for (int n = 0; n < 3; ++n) for (int d = 0; d < 3; ++d) { bv[n].lo[d] = bcrec_vel ? bcrec_vel[6 * n + d] : 0; bv[n].hi[d] = bcrec_vel ? bcrec_vel[6 * n + 3 + d] : 0; }
+    for (int n = 0; n < nscal; ++n) for (int d = 0; d < 3; ++d) { bs[n].lo[d] = bcrec_scal ? bcrec_scal[6 * n + d] : 0; bs[n].hi[d] = bcrec_scal ? bcrec_scal[6 * n + 3 + d] : 0; }
+    MultiFab* um[3] = {&umac_x->mf, &umac_y->mf, &umac_z->mf};
+    MultiFab* uc[3] = {&ucorr_x->mf, &ucorr_y->mf, &ucorr_z->mf};
+    MultiFab* fv[3] = {fluxv_x ? &fluxv_x->mf : nullptr, fluxv_y ? &fluxv_y->mf : nullptr, fluxv_z ? &fluxv_z->mf : nullptr};
+    MultiFab* fs[3] = {fluxs_x ? &fluxs_x->mf : nullptr, fluxs_y ? &fluxs_y->mf : nullptr, fluxs_z ? &fluxs_z->mf : nullptr};
+    mac_sync_compute(to_geom(g), uc, Vsync->mf, Ssync->mf, S_vel->mf, S_scal->mf, nscal, visc_vel ? &visc_vel->mf : nullptr, tforce_scal ? &tforce_scal->mf : nullptr,
+                     gradp->mf, divu ? &divu->mf : nullptr, um, iconserv_scal, do_mom_diff != 0, gravity, dt, bv.data(), bs.data(), use_forces_in_trans != 0, scheme,
+                     fluxv_x ? fv : nullptr, fluxs_x ? fs : nullptr);
+    IAMRX_CATCH
+}
+
+int iamrx_mac_sync_compute_edge(const iamrx_geom* g, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z, iamrx_mf Sync, int sync_indx, iamrx_mf edge_x,
+                                iamrx_mf edge_y, iamrx_mf edge_z, int edge_comp, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z)
+{
+    IAMRX_TRY
+    MultiFab* uc[3] = {&ucorr_x->mf, &ucorr_y->mf, &ucorr_z->mf};
+    MultiFab* ed[3] = {&edge_x->mf, &edge_y->mf, &edge_z->mf};
+    MultiFab* fl[3] = {flux_x ? &flux_x->mf : nullptr, flux_y ? &flux_y->mf : nullptr, flux_z ? &flux_z->mf : nullptr};
+    mac_sync_compute_edge(to_geom(g), uc, Sync->mf, sync_indx, ed, edge_comp, flux_x ? fl : nullptr);
+    IAMRX_CATCH
+}
+
+int iamrx_initial_velocity_project(int nlev, const iamrx_proj_level* levels, const iamrx_mf* vel, const int* vcomp, const iamrx_mf* pres, const iamrx_mf* rho,
+                                   const int* rho_comp, const iamrx_mf* divu, const int* divu_comp, double proj_tol, double proj_abs_tol,
+                                   const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    std::vector<ProjLevel> PL(nlev);
+    std::vector<MultiFab*> v(nlev), p(nlev);
+    std::vector<const MultiFab*> r(nlev, nullptr), dv(nlev, nullptr);
+    for (int l = 0; l < nlev; ++l) {
+        PL[l] = to_proj_level(&levels[l]);
+        v[l] = &vel[l]->mf; p[l] = &pres[l]->mf;
+        if (rho && rho[l]) r[l] = &rho[l]->mf;
+        if (divu && divu[l]) dv[l] = &divu[l]->mf;
+    }
+    MGStats s = initial_velocity_project(PL, v.data(), vcomp, p.data(), rho ? r.data() : nullptr, rho_comp, divu ? dv.data() : nullptr, divu_comp, proj_tol,
+                                         proj_abs_tol, to_opts(o));
+    if (st) from_stats(s, st);
+    IAMRX_CATCH
+}
+
+int iamrx_initial_sync_project(int nlev, const iamrx_proj_level* levels, const iamrx_mf* vel_new, const int* vcomp, const iamrx_mf* vel_old, const iamrx_mf* phi,
+                               const iamrx_mf* pres_new, const iamrx_mf* rho_half, const iamrx_mf* divu_new, const iamrx_mf* divu_old, const int* divu_comp,
+                               double dt, double proj_tol, double proj_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st)
+{
+    IAMRX_TRY
+    std::vector<ProjLevel> PL(nlev);
+    std::vector<MultiFab*> vn(nlev), ph(nlev), pn(nlev, nullptr);
+    std::vector<const MultiFab*> vo(nlev), rh(nlev), dn(nlev, nullptr), dol(nlev, nullptr);
+    for (int l = 0; l < nlev; ++l) {
+        PL[l] = to_proj_level(&levels[l]);
+        vn[l] = &vel_new[l]->mf; vo[l] = &vel_old[l]->mf; ph[l] = &phi[l]->mf; rh[l] = &rho_half[l]->mf;
+        if (pres_new && pres_new[l]) pn[l] = &pres_new[l]->mf;
+        if (divu_new && divu_new[l]) dn[l] = &divu_new[l]->mf;
+        if (divu_old && divu_old[l]) dol[l] = &divu_old[l]->mf;
+    }
+    MGStats s = initial_sync_project(PL, vn.data(), vcomp, vo.data(), ph.data(), pres_new ? pn.data() : nullptr, rh.data(), divu_new ? dn.data() : nullptr,
+                                     divu_old ? dol.data() : nullptr, divu_comp, dt, proj_tol, proj_abs_tol, to_opts(o));
+    if (st) from_stats(s, st);
     IAMRX_CATCH
 }
 

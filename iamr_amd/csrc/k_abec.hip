@@ -1057,7 +1057,7 @@ bool abec_gsrb_rb_ok(const Geometry& g, const AbecCoef& c, const MultiFab& phi, 
 {
     if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("PERIODIC_WRAP", 1) == 0) return false;
     const Layout& l = *phi.layout;
-    if (l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    if (l.boxes.size() != 1) return false;             // (decided on the GLOBAL box list: every rank takes the same path, a rank that does not own the box launches nothing)
     const BoxD& b = l.boxes[0];
     bool walls = false;
     for (int d = 0; d < 3; ++d) {
@@ -1083,7 +1083,7 @@ bool abec_gsrb_rb_cf_ok(const Geometry& g, const AbecCoef& c, const MultiFab& ph
 {
     if (tune("GSRB_RB", 1) == 0 || tune("ABEC_SIG", 1) == 0 || tune("GSRB_RB_CF", 1) == 0) return false;
     const Layout& l = *phi.layout;
-    if (l.boxes.size() != 1 || l.nlocal() != 1) return false;
+    if (l.boxes.size() != 1) return false;             // (decided on the GLOBAL box list: every rank takes the same path, a rank that does not own the box launches nothing)
     const BoxD& b = l.boxes[0];
     for (int d = 0; d < 3; ++d) if (!(b.lo[d] > g.domain.lo[d] && b.hi[d] < g.domain.hi[d])) return false;
     const int nx = b.len(0);

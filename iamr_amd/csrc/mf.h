@@ -153,6 +153,7 @@ using LayoutP = std::shared_ptr<Layout>;
 // fills between colour passes, index wrap on periodic domains).  The level objects (NavierStokes, AmrNS) work on the merged layout and
 // translate to the caller's boxes at their data accessors.  Returns l itself if nothing merges or IAMRX_COALESCE = 0.
 LayoutP coalesce_layout(const LayoutP& l);
+size_t coalesce_merge_count();     // calls of coalesce_layout that merged boxes so far (the test suite's two-mode runner asks, tests/conftest.py)
 
 struct IndexType {
     int t[3];
@@ -237,6 +238,10 @@ public:
     void FillBoundary(const Geometry& g);               // same-level + periodic ghost exchange (all comps)
     // ngv: ghost depth per direction (<= ngrow); on: the stream the exchange is issued on (null: the context's; Context::side between fork_side / join_side)
     void FillBoundary(const Geometry& g, int comp, int nc, const int* ngv = nullptr, int kpar = -1, hipStream_t on = nullptr);
+    // FillBoundary of cell-centred data whose boxes ALSO hand on the first `ext` ghost layers they hold beyond the non-periodic sides of the
+    // domain (a boundary fill their owner made): afterwards the edge / corner ghost cells beyond a wall next to a box-box face equal the
+    // face ghost cells of the box next door (CellMG's two-layer density copy)
+    void FillBoundaryWallExt(const Geometry& g, int ext);
     // valid + ng ghost cells
     static void Copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, int ng);
     // dst = a*x + b*y style helpers live in blas (kernels.h)
@@ -253,11 +258,11 @@ private:
 // host-only plan construction (no device access; unit-testable on CPU)
 void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
                           IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv = nullptr,
-                          int kpar = -1);
+                          int kpar = -1, int wall_ext = 0);
 
 // plan cache: FillBoundary plans keyed by (layout id, type, ngrow, periodicity, domain)
 // kpar = 0 / 1: only the z-planes of that parity (global index) are exchanged
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv = nullptr, int kpar = -1);
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv = nullptr, int kpar = -1, int wall_ext = 0);
 // add: dst += src instead of dst = src (the regions of one plan must then not overlap in dst)
 void execute_plan(const CopyPlan& plan, MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int nc, bool add = false, hipStream_t on = nullptr);
 // multigrid agglomeration: all-gather of the valid regions into a replicated copy of the level / pick-out of the own boxes

@@ -591,7 +591,7 @@ CopyPlan::~CopyPlan()
 }
 
 struct PlanKey {
-    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3]; int ngv[3]; int kpar;
+    uint64_t layout_id; IndexType t; int ng; int per[3]; int dlo[3], dhi[3]; int ngv[3]; int kpar; int wall_ext;
     bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -607,8 +607,22 @@ static CopyDesc* upload(const std::vector<CopyDesc>& v)
 
 // host-only construction of a ghost-exchange plan (no device access: unit-testable on CPU)
 void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>& owner, const std::vector<int>& local_of, int me,
-                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv, int kpar)
+                          IndexType t, int ng, const Geometry& g, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, const int* ngv, int kpar,
+                          int wall_ext)
 {
+    // wall_ext > 0 (cell-centred data): a SOURCE box that touches a non-periodic side of the domain also supplies its first wall_ext
+    // ghost cells beyond that side (the values its owner put there: a boundary fill), so that the edge ghost cells of its neighbours
+    // beyond the wall -- (wall + 1, lo - 1) seen from the box next door -- hold exactly what the source box itself reads there.
+    auto src_valid = [&](int gs) {
+        BoxD sv = convert(boxes[gs], t.t);
+        if (wall_ext > 0)
+            for (int d = 0; d < 3; ++d) {
+                if (g.periodic[d]) continue;
+                if (boxes[gs].lo[d] == g.domain.lo[d]) sv.lo[d] -= wall_ext;
+                if (boxes[gs].hi[d] == g.domain.hi[d]) sv.hi[d] += wall_ext;
+            }
+        return sv;
+    };
     // ngv: ghost depth to fill per direction (<= ng; nullptr: ng everywhere).  A consumer whose stencil reaches less far in one
     // direction (the plane-fused nodal smoother: 4 nodes in-plane, 1 plane in z) exchanges correspondingly thinner slabs.
     const int gv[3] = {ngv ? ngv[0] : ng, ngv ? ngv[1] : ng, ngv ? ngv[2] : ng};
@@ -647,7 +661,7 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                 for (int sy = smin[1]; sy <= smax[1]; ++sy)
                 for (int sx = smin[0]; sx <= smax[0]; ++sx) {
                     if (gs == gd && sx == 0 && sy == 0 && sz == 0) continue;
-                    BoxD svalid = convert(boxes[gs], t.t);
+                    BoxD svalid = src_valid(gs);
                     const int sh[3] = {sx * g.domain.len(0), sy * g.domain.len(1), sz * g.domain.len(2)};
                     for (int d = 0; d < 3; ++d) svalid = shift(svalid, d, sh[d]);
                     BoxD is = intersect(dgrown, svalid);
@@ -658,12 +672,26 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
         // Nodal / face data again: a ghost point of this box can also have several sources ON its own rank -- the two boxes that share the
         // point, or (a periodic direction narrower than the ghost width: the two-cell slab levels) the images of one box under one and two
         // periods.  Both copies land in one launch; if the sources differ in the last bit (the duplicates of a periodic node that two
-        // threads computed) the result depends on which write comes last.  Every ghost point therefore takes ONE local source: the first
-        // in the order of the loops below (regions already planned for this box are cut out of the later ones).
+        // threads computed) the result depends on which write comes last.  Every ghost point therefore takes ONE source: the first
+        // in the order of the loops below (regions already planned for this box are cut out of the later ones).  The rule covers remote
+        // sources as well (two regions of one peer, or of two peers, holding the same ghost node: one unpack launch per peer writes
+        // them): it is evaluated over ALL sources of the box, in the global order, by every rank that owns the box or one of its sources,
+        // so the sender's pack list and the receiver's unpack list stay the same list.
         std::vector<BoxD> planned;
+        if (nodal && !dst_mine) {
+            // a box of another rank: does any box of mine reach its ghost region at all?
+            bool involved = false;
+            for (int gs = 0; gs < nb && !involved; ++gs) {
+                if (owner[gs] != me) continue;
+                BoxD sv = src_valid(gs);
+                for (int d = 0; d < 3; ++d) { sv.lo[d] -= smax[d] * g.domain.len(d); sv.hi[d] += smax[d] * g.domain.len(d); }
+                if (intersect(dgrown, sv).ok()) involved = true;
+            }
+            if (!involved) continue;
+        }
         for (int gs = 0; gs < nb; ++gs) {
             const bool src_mine = owner[gs] == me;
-            if (!dst_mine && !src_mine) continue;
+            if (!nodal && !dst_mine && !src_mine) continue;
             const bool remote_src = owner[gs] != owner[gd];
             for (int sz = smin[2]; sz <= smax[2]; ++sz)
             for (int sy = smin[1]; sy <= smax[1]; ++sy)
@@ -671,7 +699,7 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                 if (gs == gd && sx == 0 && sy == 0 && sz == 0) continue;
                 // source valid box translated INTO the destination's index frame
                 int sh[3] = {sx * g.domain.len(0), sy * g.domain.len(1), sz * g.domain.len(2)};
-                BoxD svalid = convert(boxes[gs], t.t);
+                BoxD svalid = src_valid(gs);
                 for (int d = 0; d < 3; ++d) svalid = shift(svalid, d, sh[d]);
                 BoxD is = intersect(dgrown, svalid);
                 if (!is.ok()) continue;
@@ -695,7 +723,7 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                         if (parts.empty()) break;
                     }
                 }
-                if (nodal && dst_mine && src_mine) {
+                if (nodal) {
                     for (const BoxD& c : planned) {
                         std::vector<BoxD> next;
                         for (const BoxD& q : parts) subtract(q, c, next);
@@ -703,6 +731,7 @@ void build_fill_plan_host(const std::vector<BoxD>& boxes, const std::vector<int>
                         if (parts.empty()) break;
                     }
                     for (const BoxD& q : parts) planned.push_back(q);
+                    if (!dst_mine && !src_mine) continue;      // (somebody else's pair: book-keeping only)
                 }
                 for (auto& p0 : parts) {
                     BoxD p = p0;
@@ -757,21 +786,21 @@ static std::map<PlanKey, std::unique_ptr<CopyPlan>>& make_plan_cache()
     return *c;
 }
 
-const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv, int kpar)
+const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const Geometry& g, const int* ngv, int kpar, int wall_ext)
 {
     static std::map<PlanKey, std::unique_ptr<CopyPlan>>& cache = make_plan_cache();
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     key.layout_id = l.id; key.t = t; key.ng = ng;
     for (int d = 0; d < 3; ++d) key.ngv[d] = ngv ? ngv[d] : ng;
-    key.kpar = kpar;
+    key.kpar = kpar; key.wall_ext = wall_ext;
     for (int d = 0; d < 3; ++d) { key.per[d] = g.periodic[d]; key.dlo[d] = g.domain.lo[d]; key.dhi[d] = g.domain.hi[d]; }
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
 
     auto plan = std::make_unique<CopyPlan>();
     std::map<int, CopyPlan::Peer> peers;
-    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv, kpar);
+    build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv, kpar, wall_ext);
     plan->d_local = upload(plan->local);
     for (auto& kv : peers) {
         kv.second.d_pack = upload(kv.second.pack);
@@ -931,14 +960,26 @@ void MultiFab::FillBoundary(const Geometry& g, int comp, int nc, const int* ngv,
     execute_plan(plan, *this, *this, comp, comp, nc, false, on);
 }
 
+void MultiFab::FillBoundaryWallExt(const Geometry& g, int ext)
+{
+    if (ngrow == 0) return;
+    if (!type.cell() || ext > ngrow) throw Error("iamrx: FillBoundaryWallExt needs cell-centred data with at least `ext` ghost layers");
+    const CopyPlan& plan = fill_boundary_plan(*layout, type, ngrow, g, nullptr, -1, ext);
+    execute_plan(plan, *this, *this, 0, 0, ncomp, false, nullptr);
+}
+
 // ------------------------------------------------------------------ coalescing
 // sweeps along x, y, z until nothing merges: two boxes of one owner with equal extents in the two other directions and touching faces
+static size_t g_coalesce_merges = 0;
+size_t coalesce_merge_count() { return g_coalesce_merges; }
+
 LayoutP coalesce_layout(const LayoutP& l)
 {
     if (!l || l->replicated || tune("COALESCE", 1) == 0 || l->boxes.size() < 2) return l;
     std::vector<BoxD> nb = l->boxes;
     std::vector<int> no = l->owner;
     if (!merge_boxes(nb, no)) return l;
+    ++g_coalesce_merges;
     return std::make_shared<Layout>(nb, no, Context::get().comm->rank);
 }
 

@@ -10,6 +10,27 @@
 
 namespace iamrx {
 
+// The fp64 round-off floor of a residual (about 1e-12 of the right-hand side once h <= 1/256) can sit just above the requested tolerance.
+// hist: the residual norms after each cycle so far (hist.back() = the current one), r0: the norm in front of the first cycle.  Two signs
+// of the floor, both only for a residual within 10x of the target:
+//   (a) a COLLAPSE of the convergence rate -- the last cycle gained less than a factor 2 although some earlier cycle of this solve gained
+//       more than a factor 5: a solve that converges slowly does so from its first cycle on, one that hits the floor stops from one cycle
+//       to the next (round 6: one cycle to notice instead of three; IAMRX_MG_STALL_FAST = 0 keeps (b) only);
+//   (b) less than 10 % lost over three cycles (rounds 3-5).
+// amrex::MLMG has no such exit (it iterates to max_iter and aborts): the solvers report converged = 2 and a warning.
+inline bool mg_stalled_at_floor(const std::vector<double>& hist, double r0, double target, bool fast)
+{
+    const size_t n = hist.size();
+    if (n == 0 || !(hist[n - 1] <= 10.0 * target)) return false;
+    if (n >= 4 && hist[n - 1] > 0.9 * hist[n - 4]) return true;
+    if (!fast || n < 2) return false;
+    const double last = hist[n - 1] / hist[n - 2];
+    double best = 1.0, prev = r0;
+    for (size_t i = 0; i + 1 < n; ++i) { if (prev > 0.0) best = std::min(best, hist[i] / prev); prev = hist[i]; }
+    return last > 0.5 && best < 0.2;
+}
+
+
 struct MGOpts {
     int nu1 = 2, nu2 = 2, nuf = 8, nub = 0;
     int max_iters = 200;

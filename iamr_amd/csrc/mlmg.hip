@@ -191,8 +191,12 @@ void CellMG::prepare()
         m_sig2.clear(); m_a1.clear();
         if (m_nbr && m_sig) {
             m_sig2.define(m_lev[0].layout, cell_type(), 1, 2);
-            MultiFab::Copy(m_sig2, *m_sig, m_sig_comp, 0, 1, 1);       // (the ghost cells beyond domain walls are the caller's)
-            m_sig2.FillBoundary(m_lev[0].g);
+            // the caller's promise (as for the colour passes): one FACE ghost layer of the density filled, beyond domain walls too.  The
+            // sweep also reads edge ghost cells -- beyond a wall AND behind a box-box face: what the box next door holds in its face ghost
+            // cells there (it forms the same red update from them) -- so those are taken from the neighbour's copy, not from whatever the
+            // caller's edge cells hold (poisoned edge cells must not change the answer)
+            MultiFab::Copy(m_sig2, *m_sig, m_sig_comp, 0, 1, 1);
+            m_sig2.FillBoundaryWallExt(m_lev[0].g, 1);
         }
         if (m_nbr && has_a) {
             m_a1.define(m_lev[0].layout, cell_type(), 1, 1);

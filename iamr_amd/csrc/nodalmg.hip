@@ -462,9 +462,7 @@ MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, doubl
             if (!(st.resnorm < 1.e20 * max_norm)) throw Error("iamrx nodal MLMG: failing to converge (residual blow-up)");
             // stalled at the fp64 round-off floor just above the tolerance: see composite_project (amrns.hip); converged = 2
             hist.push_back(st.resnorm);
-            // (a residual within 10x of the target that has lost less than 10 % over three cycles: a solve that merely converges slowly
-            // -- 0.8 per cycle halves the residual in three -- keeps iterating to max_iters and aborts as amrex::MLMG does)
-            if (m_o.fixed_iters <= 0 && hist.size() >= 4 && st.resnorm <= 10.0 * res_target && st.resnorm > 0.9 * hist[hist.size() - 4]) {
+            if (m_o.fixed_iters <= 0 && mg_stalled_at_floor(hist, st.resnorm0, res_target, tune("MG_STALL_FAST", 1) != 0)) {
                 st.converged = 2;
                 fprintf(stderr, "iamrx nodal MLMG: WARNING: residual %.3e stalled at the round-off floor above the target %.3e after %d cycles; accepted (converged = 2)\n",
                         st.resnorm, res_target, st.iters);

@@ -155,6 +155,15 @@ void godunov_compute_aofs_sync(const Geometry& g, MultiFab& sync, int acomp, con
                                const MultiFab* divu, MultiFab* const umac[3], MultiFab* const ucorr[3], const int* iconserv, double dt,
                                const BCRec* bc, bool is_velocity, bool use_forces_in_trans, MultiFab* const flux_out[3], int scheme = 0);
 
+// MacProj::mac_sync_compute on caller-owned arrays (amrns.hip): the form of NavierStokes::mac_sync (Source/MacProj.cpp:488-731) and the form
+// with known edge states (:733-786)
+void mac_sync_compute(const Geometry& g, MultiFab* const ucorr[3], MultiFab& Vsync, MultiFab& Ssync, const MultiFab& Svel, const MultiFab& Sscal, int nscal,
+                      const MultiFab* visc_vel, const MultiFab* tf_scal, const MultiFab& gradp, const MultiFab* divu, MultiFab* const umac[3],
+                      const int* iconserv_scal, bool do_mom_diff, double gravity, double dt, const BCRec* bc_vel, const BCRec* bc_scal,
+                      bool use_forces_in_trans, int scheme, MultiFab* const flux_vel[3], MultiFab* const flux_scal[3]);
+void mac_sync_compute_edge(const Geometry& g, MultiFab* const ucorr[3], MultiFab& Sync, int sync_indx, MultiFab* const edgestate[3], int edge_comp,
+                           MultiFab* const flux_out[3]);
+
 // SyncRegister (Source/SyncRegister.cpp): nodal values on the faces of the coarsened fine boxes, kept as ONE single-valued nodal
 // MultiFab on the coarse level's layout + the node masks that InitRHS needs
 class SyncRegister {
@@ -162,6 +171,8 @@ public:
     SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, const Geometry& fgeom, int ratio, const int phys_lo[3], const int phys_hi[3]);
     void CrseInit(const MultiFab& sync_resid_crse, double mult);          // SyncRegister.cpp:306-318
     void FineAdd(const MultiFab& sync_resid_fine, double mult);           // :350-607
+    // :302-348; finer: the boxes of the level above the residual's (ratio finer_ratio to it), fgeom: the residual's level.  Modifies the residual.
+    void CompAdd(MultiFab& sync_resid_fine, const Geometry& fgeom, const LayoutP& finer, int finer_ratio, double mult);
     void InitRHS(MultiFab& rhs);                                          // :47-304
     const MultiFab& reg() const { return m_reg; }
     const MultiFab& vs_fine() const { return m_vsfine; }                  // node class of the coarse nodes w.r.t. the fine level: 0 untouched, 1 inside, 2 on its boundary
@@ -192,6 +203,13 @@ struct ProjLevel {
 MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[], const int vcomp[], MultiFab* const phi[], const MultiFab* const sig[],
                           const MultiFab* rhnd, double rtol, double atol, bool increment_gp, double inflow_scale, const MGOpts& o,
                           const MultiFab* const rhcc[] = nullptr);
+// Projection::initialVelocityProject / initialSyncProject (Source/Projection.cpp:615-838, 970-1185) on caller-owned arrays of the levels
+// PL[0 .. nl-1] (amrns.hip; the hierarchy's post_init calls the same functions)
+MGStats initial_velocity_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[], const int vcomp[], MultiFab* const pres[], const MultiFab* const rho[],
+                                 const int rho_comp[], const MultiFab* const divu[], const int divu_comp[], double proj_tol, double proj_abs_tol, const MGOpts& o);
+MGStats initial_sync_project(const std::vector<ProjLevel>& PL, MultiFab* const vel_new[], const int vcomp[], const MultiFab* const vel_old[], MultiFab* const phi[],
+                             MultiFab* const pres_new[], const MultiFab* const rho_half[], const MultiFab* const divu_new[], const MultiFab* const divu_old[],
+                             const int divu_comp[], double dt, double proj_tol, double proj_abs_tol, const MGOpts& o);
 // compSyncResidualCoarse (fine_layout given: the level's nodes that touch both cells covered by fine_layout and cells that are not, formed
 // with the uncovered cells) / compSyncResidualFine (fine_layout null: the nodes of the level's own boundary inside the domain)
 MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bcn, const LayoutP& fine_layout, int fine_ratio, const MultiFab& vold,

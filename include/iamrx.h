@@ -91,6 +91,9 @@ int iamrx_scope_profile(int enable, int reset, char* report, size_t capacity);
  * exposed), out[1] doubles sent by them; out[2] / out[3] the same for exchanges issued on the side stream beside interior work (the
  * multi-box red + black sweep: hidden as far as the interior tiles last); the role of the comm rows of a TINY_PROFILE */
 int iamrx_exchange_counts(size_t out[4]);
+/* how often the level objects have merged a caller's boxes so far (IAMRX_COALESCE = 1, the default): lets a test
+ * harness tell the calls whose result depends on that mode (tests/conftest.py runs those in both).  No counterpart upstream. */
+int iamrx_coalesce_merge_count(size_t* n);
 int iamrx_sync_count(size_t* n_stream_sync);     /* host waits on the library stream so far (scalar read-backs of norms / dot products, plan uploads) */
 /* HIP-event stopwatch on the library stream (the role of BL_PROFILE / ParallelDescriptor::second() pairs,
  * e.g. Source/NavierStokesBase.cpp:2088-2107): start records an event, stop records + waits and returns ms */
@@ -154,6 +157,11 @@ int iamrx_mf_norm0(iamrx_mf m, int comp, int ncomp, int ngrow, double* out);   /
  * (src index = dst index + shift), buffer offset in points, 2 pad.  Call with desc == NULL to size. */
 int iamrx_host_fill_plan(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
                          int max_desc, int* desc, int* ndesc);
+/* the same for a fill whose SOURCE boxes also hand on their first `wall_ext` ghost layers beyond the non-periodic sides of the domain
+ * (cell-centred data; the two-layer density copy of the multi-box sweep: the edge ghost cells beyond a wall behind a box-box face take
+ * the face ghost values of the box next door).  No counterpart upstream: amrex::FillBoundary copies valid cells only. */
+int iamrx_host_fill_plan_wall_ext(int nboxes, const int* lo_hi, const int* owner, int rank, const int type[3], int ngrow, const iamrx_geom* g,
+                                  int wall_ext, int max_desc, int* desc, int* ndesc);
 
 /* ---- cell-centred linear operator primitives (amrex::MLABecLaplacian role) ---- */
 /* one red or black Gauss-Seidel pass of (alpha*a - beta div b grad) phi = rhs; ghost cells of phi must be filled */
@@ -493,6 +501,44 @@ int iamrx_godunov_compute_aofs_sync(const iamrx_geom* g, iamrx_mf sync, int acom
                                     iamrx_mf umac_x, iamrx_mf umac_y, iamrx_mf umac_z, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z,
                                     const int* iconserv, double dt, const int* bcrec, int is_velocity, int use_forces_in_trans,
                                     iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z, int scheme);
+
+/* SyncRegister::CompAdd (Source/SyncRegister.H:45, SyncRegister.cpp:302-348): sync_resid_fine (nodal, on the fine side of r's interface; the
+ * residual a sync projection of the levels above leaves on that level) is zeroed on the nodes of the boxes of `finer` (the next finer level,
+ * ratio finer_ratio to the residual's level whose geometry is fgeom; periodic images included: upstream's Pgrids) and added like FineAdd
+ * with `mult`.  The residual array is modified, as upstream's is. */
+int iamrx_syncreg_comp_add(iamrx_syncreg r, iamrx_mf sync_resid_fine, const iamrx_geom* fgeom, iamrx_layout finer, int finer_ratio, double mult);
+/* MacProj::mac_sync_compute, the form NavierStokes::mac_sync calls (Source/MacProj.H:60-75, MacProj.cpp:488-731), on caller-owned arrays of one
+ * level: the velocity forcing gravity * rho (z) + visc_vel - gradp, divided by rho unless do_mom_diff (:598-640), then ComputeAofs with
+ * is_sync = true for the three velocities (Vsync -= update) and for the nscal scalars starting with the density (Ssync -= update), both
+ * traced with umac and fluxed with ucorr.  S_vel (3 comps; rho u under do_mom_diff, :536-553) / S_scal (nscal comps): the state at
+ * prev_time with 3 filled ghost cells; visc_vel (3) / tforce_scal (nscal, the scalars' forcing as :641-683 assemble it) / gradp (3) / divu
+ * (1): 1 ghost cell, visc_vel / tforce_scal / divu may be NULL (zero).  fluxv_* (3 comps) / fluxs_* (nscal comps), optional: the fluxes
+ * for the caller's advective registers (CrseInit / FineAdd with the sync sign, Source/NavierStokesBase.cpp:5083-5096; the FineAdd of ucorr
+ * to the mac register, MacProj.cpp:707-727, is the caller's as well: iamrx_fluxreg_fineadd). */
+int iamrx_mac_sync_compute(const iamrx_geom* g, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z, iamrx_mf Vsync, iamrx_mf Ssync, iamrx_mf S_vel,
+                           iamrx_mf S_scal, int nscal, iamrx_mf visc_vel, iamrx_mf tforce_scal, iamrx_mf gradp, iamrx_mf divu, iamrx_mf umac_x,
+                           iamrx_mf umac_y, iamrx_mf umac_z, const int* iconserv_scal, int do_mom_diff, double gravity, double dt, const int* bcrec_vel,
+                           const int* bcrec_scal, int use_forces_in_trans, int scheme, iamrx_mf fluxv_x, iamrx_mf fluxv_y, iamrx_mf fluxv_z,
+                           iamrx_mf fluxs_x, iamrx_mf fluxs_y, iamrx_mf fluxs_z);
+/* MacProj::mac_sync_compute, the form with the half-time edge states handed in (Source/MacProj.H:77-94, MacProj.cpp:733-786; one component):
+ * flux = edge(edge_comp) * ucorr * area, Sync(sync_indx) -= -div(flux) / vol; flux_* (optional, 1 comp) return the fluxes */
+int iamrx_mac_sync_compute_edge(const iamrx_geom* g, iamrx_mf ucorr_x, iamrx_mf ucorr_y, iamrx_mf ucorr_z, iamrx_mf Sync, int sync_indx, iamrx_mf edge_x,
+                                iamrx_mf edge_y, iamrx_mf edge_z, int edge_comp, iamrx_mf flux_x, iamrx_mf flux_y, iamrx_mf flux_z);
+/* Projection::initialVelocityProject (Source/Projection.H:116-121, Projection.cpp:615-838) on caller-owned arrays of the levels
+ * levels[0 .. nlev-1] (coarsest first): pres[l] (nodal, 1 ghost) is zeroed and returns phi; vel[l] (velocity at vcomp[l], 1 ghost cell with
+ * the inflow data) is projected on the composite grid, div(sigma grad phi) = div(vel) - <divu>, vel -= sigma grad phi, sigma = 1
+ * (rho == NULL: rho_wgt_vel_proj = 0) or 1 / rho[l](rho_comp[l]); divu / divu_comp: the constraint of a variable-divergence run or NULL;
+ * levels[l].gp (optional) receives grad phi. */
+int iamrx_initial_velocity_project(int nlev, const iamrx_proj_level* levels, const iamrx_mf* vel, const int* vcomp, const iamrx_mf* pres, const iamrx_mf* rho,
+                                   const int* rho_comp, const iamrx_mf* divu, const int* divu_comp, double proj_tol, double proj_abs_tol,
+                                   const iamrx_mg_opts* o, iamrx_mg_stats* st);
+/* Projection::initialSyncProject (Source/Projection.H:123-134, Projection.cpp:970-1185) on caller-owned arrays: vel_new <- (vel_new - vel_old) / dt,
+ * sigma = 1 / rho_half, velocities averaged down, rhcc = -(divu_new - divu_old) / dt (NULL: none), composite projection that ACCUMULATES
+ * grad phi in levels[l].gp; phi[l] (the caller's old-time pressure array, zeroed first) returns the correction, which is also added to
+ * pres_new[l] (may be NULL).  vel_new keeps the projected acceleration (upstream resets the state afterwards, NavierStokesBase::resetState). */
+int iamrx_initial_sync_project(int nlev, const iamrx_proj_level* levels, const iamrx_mf* vel_new, const int* vcomp, const iamrx_mf* vel_old, const iamrx_mf* phi,
+                               const iamrx_mf* pres_new, const iamrx_mf* rho_half, const iamrx_mf* divu_new, const iamrx_mf* divu_old, const int* divu_comp,
+                               double dt, double proj_tol, double proj_abs_tol, const iamrx_mg_opts* o, iamrx_mg_stats* st);
 
 /* ---- multi-level time step ------------------------------------------------------------------------------------
  * One coarse time step of a hierarchy of levels with subcycling = amrex::Amr::coarseTimeStep -> timeStep(level): advance(level),

@@ -2,14 +2,14 @@
 library's default, IAMRX_COALESCE = 1), which makes the time step independent of how amr.max_grid_size chopped the level
 (reference Docs/sphinx_documentation/source/RunningProblems.rst:362-368: 32 by default): a level chopped into 64 boxes runs the single-box
 kernels (index wrap on periodic domains, no ghost fills between colour passes) and gives the single-box answer TO THE BIT, while every data
-accessor keeps speaking the caller's boxes.  The rest of the suite switches the merging off (tests/conftest.py) to keep the multi-box
-paths covered."""
+accessor keeps speaking the caller's boxes.  The rest of the suite runs every test whose level objects merge boxes in both modes
+(tests/conftest.py)."""
 import ctypes as C
 import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.merged_only]      # the tests below switch the mode themselves
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 

@@ -7,7 +7,9 @@ import sys
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# one box per rank in most cases (nothing to merge); the cases with several boxes per rank say which mode they want ("+merge"), so the
+# whole module runs with IAMRX_COALESCE = 0 in the environment of the rank processes unless a case sets it (tests/conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.boxes_kept]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = (16, 16, 16)
 BOXES = [((0, 0, 0), (15, 15, 7)), ((0, 0, 8), (15, 15, 15))]
@@ -453,3 +455,61 @@ def test_rccl_transport_single_rank(tmp_path):
     dts = [ns.step() for _ in range(2)]
     assert np.array_equal(np.array(dts), z["dts"])
     assert np.array_equal(ns.data(NS.NavierStokes.S_NEW).gather_valid(n), z["S"])
+
+
+def _rccl_pair(rank, out_dir):
+    """one process per DEVICE (rank r drives device r): the RCCL transport between two GPUs -- ncclCommInitRank from a unique id handed over
+    through a file, the exchange probe, bench.py's transport self-test, then two TaylorGreen steps on one 16 x 16 x 8 box per rank"""
+    sys.path.insert(0, ROOT)
+    import time
+    from iamr_amd import lib
+    from iamr_amd import ns as NS
+    lib.init(rank)
+    Lb = lib.lib()
+    Lb.iamrx_comm_last_error.restype = C.c_char_p
+    idf = os.path.join(out_dir, "rccl_id.bin")
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        assert Lb.iamrx_comm_get_unique_id(buf) == 0, Lb.iamrx_comm_last_error()
+        with open(idf + ".tmp", "wb") as f:
+            f.write(bytes(buf))
+        os.replace(idf + ".tmp", idf)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idf):
+            assert time.time() - t0 < 120, "rank 0 never published the RCCL unique id"
+            time.sleep(0.05)
+        buf = (C.c_char * 128).from_buffer_copy(open(idf, "rb").read())
+    assert Lb.iamrx_comm_init_rccl(buf, rank, 2) == 0, Lb.iamrx_comm_last_error()
+    assert Lb.iamrx_comm_probe_exchange(1 - rank, C.c_long(1 << 20)) == 0, Lb.iamrx_comm_last_error()
+    import bench
+    bench.transport_selftest(lib, rank, 2)
+    lay = lib.Layout(BOXES, [0, 1])
+    ns = NS.NavierStokes(lib.Geom.make(N), lay, NS.ns_params(cfl=0.5, visc_coef=1e-2))
+    ns.init_taylorgreen(1.0, 1.0, 1.0, 1.0, 1.0)
+    ns.post_init(-1.0)
+    dts = [ns.step() for _ in range(NSTEPS)]
+    S = ns.data(NS.NavierStokes.S_NEW)
+    a, lo = S.to_numpy(0)
+    np.savez(os.path.join(out_dir, f"rccl2_r{rank}.npz"), dts=np.array(dts), box=a[1:-1, 1:-1, 1:-1, :])
+
+
+def test_rccl_transport_between_two_devices(tmp_path):
+    """the first thing a multi-GPU lease should run.  Needs two visible devices; on the one-GPU development /
+    grading box it is SKIPPED LOUDLY (the skip reason and a line on stderr say that RCCL has still only run as a one-rank loop-back)."""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        msg = (f"RCCL BETWEEN TWO DEVICES NOT EXERCISED: {nd} device(s) visible -- grouped ncclSend/ncclRecv + ncclAllReduce across xGMI "
+               "remain untested on hardware (tests/test_gpu_dist.py::test_rccl_transport_between_two_devices runs as soon as 2 GPUs are visible)")
+        print("\n*** " + msg + " ***", file=sys.stderr, flush=True)
+        pytest.skip(msg)
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_pair, args=(str(tmp_path),), nprocs=2, join=True)
+    mp.spawn(run, args=(1, 29600 + (os.getpid() % 2000), str(tmp_path), None), nprocs=1, join=True)      # the same two boxes on one rank
+    one = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"rccl2_r{r}.npz"))
+        assert np.allclose(z["dts"], one["dts"], rtol=1e-12, atol=0.0)
+        ref = one[f"box{r}"]
+        assert np.abs(z["box"] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())

@@ -10,7 +10,7 @@ All runs go through the C-ABI (iamrx_ns_*)."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.boxes_kept]     # the 8-GPU box layouts on one GPU: boxes kept (tests/conftest.py)
 N = 256
 
 
@@ -18,7 +18,6 @@ N = 256
 def gpu():
     from iamr_amd import lib
     lib.init(0)
-    lib.tuning_set("COALESCE", 0)        # the callers' boxes as they are (tests/conftest.py); tests/test_gpu_coalesce.py covers the merged mode
     return lib
 
 

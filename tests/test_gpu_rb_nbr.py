@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from test_gpu_kernel_forms import fields, WALL_CASES
+from test_gpu_kernel_forms import fields, WALL_CASES, NEUMANN, DIRICHLET
 
 pytestmark = pytest.mark.gpu
 
@@ -132,9 +132,10 @@ def run_steps(lib, n, mg, nsteps, walls=False, **kw):
     return ns, dts
 
 
+@pytest.mark.boxes_kept
 @pytest.mark.parametrize("walls", [False, True])
 def test_time_steps_on_a_chopped_level_do_not_depend_on_the_sweep_kernel(gpu, walls):
-    """full NavierStokes::advance on 8 boxes kept as boxes (the suite runs with IAMRX_COALESCE = 0): MAC projection and viscous solves with
+    """full NavierStokes::advance on 8 boxes kept as boxes (IAMRX_COALESCE = 0: the `boxes_kept` marker): MAC projection and viscous solves with
     the multi-box sweep kernel (IAMRX_GSRB_RB_NBR = 1, the default) and with the colour passes + a ghost fill in front of each -- the same
     doubles, so the same states to the bit; the single-box run (index wrap / wall formulas, sums in another order) agrees to round-off"""
     lib = gpu
@@ -156,6 +157,7 @@ def test_time_steps_on_a_chopped_level_do_not_depend_on_the_sweep_kernel(gpu, wa
         assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max()), float(np.abs(a - b).max())
 
 
+@pytest.mark.boxes_kept
 def test_sweep_issued_in_two_parts_on_two_streams_gives_the_same_doubles(gpu):
     """IAMRX_HALO_OVERLAP = 2 forces what a multi-rank run does by itself: the tiles of the sweep that read no ghost cell on the main stream,
     the ghost exchange + k_abec_rb_ghost + the tiles next to box faces on the side stream behind a fork, joined afterwards.  Same doubles
@@ -174,3 +176,71 @@ def test_sweep_issued_in_two_parts_on_two_streams_gives_the_same_doubles(gpu):
     assert out["one piece"][0] == out["two parts"][0]
     for a, b in zip(out["one piece"][1:], out["two parts"][1:]):
         assert np.array_equal(a, b), float(np.abs(a - b).max())
+
+
+@pytest.mark.boxes_kept
+@pytest.mark.parametrize("case", ["channel: inflow / outflow in x, walls in y", "Dirichlet everywhere", "walls in z"])
+def test_mac_solve_does_not_read_the_callers_edge_ghost_cells_of_the_density(gpu, case):
+    """the multi-box sweep reads the density in EDGE ghost cells -- beyond a domain wall and behind a box-box face
+    -- which the colour passes never touched.  CellMG fills them itself (FillBoundaryWallExt: what the box next door holds in its face ghost
+    cells there), so a caller that fills only the face layer of rho gets the answer of a caller that fills everything, to the bit, and the
+    answer of the colour passes."""
+    lib = gpu
+    per, lobc, hibc = WALL_CASES[case]
+    n, mg = (256, 32, 32), (128, 16, 16)
+    g = lib.Geom.make(n, prob_hi=tuple(v / n[0] for v in n), periodic=per)
+    lay = lib.Layout.decompose(n, mg)
+    rng = np.random.default_rng(77)
+    rho = 1.0 + 0.5 * rng.random(tuple(v + 2 for v in n))
+    for d in range(3):
+        if per[d]:
+            lo = [slice(None)] * 3; hi = [slice(None)] * 3; s0 = [slice(None)] * 3; s1 = [slice(None)] * 3
+            lo[d] = 0; s0[d] = n[d]; hi[d] = n[d] + 1; s1[d] = 1
+            rho[tuple(lo)] = rho[tuple(s0)]; rho[tuple(hi)] = rho[tuple(s1)]
+    um = []
+    for d in range(3):
+        shp = tuple(n[e] + (1 if e == d else 0) for e in range(3))
+        u = rng.standard_normal(shp)
+        if per[d]:
+            sl0 = [slice(None)] * 3; sl1 = [slice(None)] * 3; sl0[d] = 0; sl1[d] = n[d]
+            u[tuple(sl1)] = u[tuple(sl0)]
+        else:
+            sl0 = [slice(None)] * 3; sl1 = [slice(None)] * 3; sl0[d] = 0; sl1[d] = n[d]
+            if lobc[d] == NEUMANN: u[tuple(sl0)] = 0.0
+            if hibc[d] == NEUMANN: u[tuple(sl1)] = 0.0
+        um.append(u)
+    def solve(poison, nbr):
+        lib.tuning_set("GSRB_RB_NBR", nbr)
+        rho_d = lib.MultiFab(lay, lib.CELL, 1, 1)
+        rho_d.set_from_global(rho[..., None], (-1,) * 3)
+        if poison:
+            for li in range(rho_d.nlocal()):
+                a, flo = rho_d.to_numpy(li)
+                I, J, K = np.meshgrid(*[np.arange(flo[d], flo[d] + a.shape[d]) for d in range(3)], indexing="ij")
+                blo, bhi, _ = lay.local_box(li)
+                idx = (I, J, K)
+                outside = [(idx[d] < blo[d]) | (idx[d] > bhi[d]) for d in range(3)]
+                beyond = [((idx[d] < 0) | (idx[d] >= n[d])) if not per[d] else np.zeros(I.shape, bool) for d in range(3)]
+                nout = outside[0].astype(int) + outside[1].astype(int) + outside[2].astype(int)
+                edge = (nout >= 2) & (beyond[0] | beyond[1] | beyond[2])
+                a[edge, 0] = np.nan
+                rho_d.from_numpy(a, li)
+        um_d = []
+        for d in range(3):
+            m = lib.MultiFab(lay, lib.face(d), 1, 0)
+            m.set_from_global(um[d][..., None], (0, 0, 0))
+            um_d.append(m)
+        phi_d = lib.MultiFab(lay, lib.CELL, 1, 1); phi_d.setval(0.0)
+        st = lib.mlmg_mac_solve(g, um_d, rho_d, 0, None, phi_d, 200.0, lobc=lobc, hibc=hibc, mac_tol=1e-10, opts=lib.mg_opts(maxorder=3))
+        return st, phi_d.gather_valid(n)[..., 0], [m.gather_valid(n)[..., 0] for m in um_d]
+    try:
+        st0, p0, u0 = solve(False, 1)
+        st1, p1, u1 = solve(True, 1)
+        st2, p2, u2 = solve(True, 0)
+    finally:
+        lib.tuning_set("GSRB_RB_NBR", 1)
+    assert st0.converged >= 1 and st1.converged >= 1
+    assert not np.isnan(p1).any()
+    assert np.array_equal(p0, p1) and all(np.array_equal(a, b) for a, b in zip(u0, u1))
+    assert st1.iters == st2.iters
+    assert np.array_equal(p1, p2), float(np.abs(p1 - p2).max())
