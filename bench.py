@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--amr-steps", type=int, default=3)
     ap.add_argument("--c3-n", type=int, default=512, help="base cells per direction of the secondary DoubleShearLayer 2D workload (config C3; 0: skip)")
     ap.add_argument("--c3-steps", type=int, default=3, help="timed coarse steps of the C3 workload")
+    ap.add_argument("--rt-n", type=int, default=256, help="base cells per direction of the secondary RayleighTaylor workload (config C5: 3 levels; 0: skip)")
+    ap.add_argument("--rt-steps", type=int, default=2, help="timed coarse steps of the C5 workload (after 4 coarse steps that build the 3 levels)")
     ap.add_argument("--ldc-steps", type=int, default=4, help="timed steps of the secondary LidDrivenCavity workload at --n^3 (single GPU; 0: skip)")
     ap.add_argument("--no-shard-proxy", action="store_true", help="skip the single-GPU proxies of the per-GPU work of an 8-GPU run (8 boxes of --n^3 kept as boxes)")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -202,6 +204,7 @@ def shard_proxy_workload(lib, n, steps=2, ldc_steps=2):
     from iamr_amd import run as R
     from iamr_amd import ns as NS
     out = {}
+    coalesce_before = lib.tuning_get("COALESCE", 1)
     lib.tuning_set("COALESCE", 0)
     try:
         pg = proc_grid(8)
@@ -243,7 +246,7 @@ def shard_proxy_workload(lib, n, steps=2, ldc_steps=2):
                                                       "mlmg_iters": [sm.iters, sn.iters, sv.iters], "mlmg_vcycle_ms": [sm.vcycle_ms, sn.vcycle_ms, sv.vcycle_ms]}
             del ns
     finally:
-        lib.tuning_set("COALESCE", 1)
+        lib.tuning_set("COALESCE", coalesce_before)
     return out
 
 
@@ -297,11 +300,55 @@ def c3_workload(lib, n, steps):
             cells2d += 2 * sum(b_npts(lo, hi) for lo, hi in amr.layouts[1].boxes) // (2 * slab0)
     lib.sync()
     el = time.perf_counter() - t0
-    lib.tuning_set("MG_SLAB", 0)
     fine = sum(b_npts(lo, hi) for lo, hi in amr.layouts[1].boxes) // (2 * pr["n"][1]) if amr.nlev > 1 else 0
     return {"workload": "DoubleShearLayer 2D (config C3), %d^2 base + one refined level (ratio 2, vorticity tags, regrid every step) as a y-periodic slab of %d cells with slab multigrid levels"
                         % (n, pr["n"][1]), "ms_per_coarse_step": el / steps * 1e3, "cells2d_per_sec": cells2d / el, "steps": steps,
             "levels": amr.nlev, "grids": [len(l.boxes) for l in amr.layouts], "fine_level_cells2d": fine, "fine_level_cover": fine / float(4 * n * n)}
+
+
+def rt_workload(lib, n, steps, warm=4, **mg_kw):
+    """BASELINE config C5 per GPU: the reference's regtest.3d.rayleightaylor, unmodified but for amr.n_cell = n^3 (variable density, gravity 1e9,
+    Godunov_PPM, do_mom_diff, do_cons_trac, slip walls in z, max_level 2 on the vorticity, regrid every 2nd coarse step, subcycled).  The
+    hierarchy grows from the base level to three levels within `warm` coarse steps; then `steps` coarse steps are timed (regrids included, as
+    the reference's Run time includes them).  cells advanced per coarse step = sum over levels of cells x 2^level sub-steps."""
+    from iamr_amd import ns as NS, run as R
+    from iamr_amd.inputs import Inputs
+    inp = Inputs([os.path.join(ROOT, "tests", "golden", "regtest.3d.rayleightaylor")],
+                 [f"amr.n_cell={n} {n} {n}", f"amr.max_grid_size={max(32, n // 2)}", f"max_step={warm + steps + 2}"])
+    pr = inp.problem()
+    amr, lays, g0 = R.build_amr(pr, lib, NS, 1, **mg_kw)
+    amr.post_init(pr["stop_time"])
+    for _ in range(warm):
+        amr.coarse_step()
+    lib.sync()
+    cells = 0
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        amr.coarse_step()
+        lib.sync()
+        per_step.append((time.perf_counter() - t1) * 1e3)
+        cells += sum((2 ** l) * sum(b_npts(lo, hi) for lo, hi in amr.layouts[l].boxes) for l in range(amr.nlev))
+    el = time.perf_counter() - t0
+    st, stm = amr.sync_stats()
+    levels = amr.nlev
+    grids = [len(l.boxes) for l in amr.layouts]
+    lev_cells = [sum(b_npts(lo, hi) for lo, hi in l.boxes) for l in amr.layouts]
+    amr.profile(1)
+    for _ in range(2):
+        amr.coarse_step()
+    sec, lsec = amr.profile(0)
+    names = ["predict_velocity", "mac_project", "advection", "updates", "viscous", "nodal_project"]
+    sections = {"reflux": sec[0] / 2, "avg_down": sec[1] / 2, "mac_sync_solve": sec[2] / 2, "mac_sync_rest": sec[3] / 2, "level_sync": sec[4] / 2, "regrid": sec[5] / 2}
+    for l in range(min(amr.nlev, 4)):
+        sections[f"advance_level{l}"] = sec[8 + l] / 2
+        sections[f"advance_level{l}_sections"] = {k: v / 2 for k, v in zip(names, lsec[l][:6])}
+    return {"workload": "RayleighTaylor 3D (config C5; regtest.3d.rayleightaylor with amr.n_cell = %d^3): variable density, gravity, Godunov_PPM, do_mom_diff, "
+                        "do_cons_trac, slip walls in z, 3 levels from vorticity tags (ratio 2, subcycled, regrid every 2nd coarse step), one GPU" % n,
+            "ms_per_coarse_step": el / steps * 1e3, "ms_of_each_coarse_step": per_step, "cells_advanced_per_sec": cells / el, "coarse_steps": steps,
+            "warmup_coarse_steps": warm, "levels": levels, "grids": grids, "cells_per_level": lev_cells,
+            "sync_project_iters": st.iters, "mac_sync_iters": stm.iters, "sections_ms_per_coarse_step": sections}
 
 
 def b_npts(lo, hi):
@@ -399,11 +446,12 @@ def multibox_workload(lib, n, steps=3):
         mg = n // parts
         r = one(mg)
         if parts < 8:
+            before = lib.tuning_get("COALESCE", 1)
             lib.tuning_set("COALESCE", 0)
             try:
                 r["boxes_kept"] = one(mg)
             finally:
-                lib.tuning_set("COALESCE", 1)
+                lib.tuning_set("COALESCE", before)
         out[f"{parts ** 3}x{mg}^3"] = r
     return out
 
@@ -741,6 +789,11 @@ def main():
                 out["double_shear_layer_2d"] = c3_workload(lib, a.c3_n, a.c3_steps)
             except Exception as e:
                 out["double_shear_layer_2d"] = {"error": str(e)[:200]}
+        if world == 1 and a.rt_n > 0 and a.rt_steps > 0:
+            try:
+                out["rayleigh_taylor"] = rt_workload(lib, a.rt_n, a.rt_steps)
+            except Exception as e:
+                out["rayleigh_taylor"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.cpu_threads if a.cpu_threads > 0 else usable_cpus())
         print(json.dumps(out))

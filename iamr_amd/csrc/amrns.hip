@@ -317,6 +317,22 @@ MultiFab sync_resid(const Geometry& g, const LayoutP& layout, const DomainBC& bc
 
 // ------------------------------------------------------------------------------------------------------------------------
 // SyncRegister
+namespace {
+struct RegSlab { int fab; BoxD region; };
+__global__ void __launch_bounds__(256) k_set_slabs(const RegSlab* __restrict__ slabs, const FabD* __restrict__ tab, double v)
+{
+    const RegSlab s = slabs[blockIdx.y];
+    const FabD a = tab[s.fab];
+    const int nx = s.region.len(0), ny = s.region.len(1);
+    const long npts = s.region.npts();
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += (long)gridDim.x * 256) {
+        const int i = s.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        a(i, s.region.lo[1] + (int)(r % ny), s.region.lo[2] + (int)(r / ny)) = v;
+    }
+}
+}  // namespace
+
 SyncRegister::SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, const Geometry& fgeom, int ratio, const int phys_lo[3], const int phys_hi[3])
     : m_fine(std::move(fine)), m_crse(std::move(crse)), m_cgeom(cgeom), m_fgeom(fgeom), m_ratio(ratio)
 {
@@ -341,23 +357,38 @@ SyncRegister::SyncRegister(LayoutP fine, LayoutP crse, const Geometry& cgeom, co
             nb.push_back(q);
         }
     }
+    // m_onreg = 1 on those nodes.  Rasterised: the six face slabs of every nodal box, clipped to every local coarse fab they reach, set by one
+    // launch over the list of slabs (round 6: a loop over all boxes per coarse node took 0.4 s per register on a level of 431 boxes)
     auto& ctx = Context::get();
-    BoxD* d_nb = (BoxD*)ctx.alloc(std::max<size_t>(1, nb.size()) * sizeof(BoxD));
-    if (!nb.empty()) IAMRX_HIP_CHECK(hipMemcpyAsync(d_nb, nb.data(), nb.size() * sizeof(BoxD), hipMemcpyHostToDevice, ctx.stream));
-    ctx.sync();
-    const int nnb = (int)nb.size();
-    const FabD* ot = m_onreg.d_tab;
-    for_each(*m_crse, node_type(), 0, ctx.stream, [=] __device__(int i, int j, int k, int f) {
-        double on = 0.0;
-        for (int b = 0; b < nnb; ++b) {
-            const BoxD q = d_nb[b];
-            if (!q.contains(i, j, k)) continue;
-            if (i == q.lo[0] || i == q.hi[0] || j == q.lo[1] || j == q.hi[1] || k == q.lo[2] || k == q.hi[2]) { on = 1.0; break; }
+    m_onreg.setVal(0.0);
+    std::vector<RegSlab> slabs;
+    long maxpts = 1;
+    for (int li = 0; li < m_onreg.nlocal(); ++li) {
+        const BoxD vb = m_onreg.validbox(li);
+        for (const BoxD& q : nb) {
+            const BoxD in = intersect(q, vb);
+            if (!in.ok()) continue;
+            for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
+                const int face = side == 0 ? q.lo[d] : q.hi[d];
+                if (face < in.lo[d] || face > in.hi[d]) continue;
+                BoxD r = in; r.lo[d] = r.hi[d] = face;
+                slabs.push_back(RegSlab{li, r});
+                maxpts = std::max(maxpts, r.npts());
+            }
         }
-        ot[f](i, j, k) = on;
-    });
-    ctx.sync();
-    ctx.free(d_nb);
+    }
+    if (!slabs.empty()) {
+        RegSlab* d_s = (RegSlab*)ctx.alloc(slabs.size() * sizeof(RegSlab));
+        IAMRX_HIP_CHECK(hipMemcpyAsync(d_s, slabs.data(), slabs.size() * sizeof(RegSlab), hipMemcpyHostToDevice, ctx.stream));
+        const unsigned nbk = (unsigned)std::min<long>(64, (maxpts + 255) / 256);
+        // (gridDim.y is limited to 65535: chunks of slabs)
+        for (size_t s0 = 0; s0 < slabs.size(); s0 += 65535) {
+            const unsigned ns = (unsigned)std::min<size_t>(65535, slabs.size() - s0);
+            hipLaunchKernelGGL(k_set_slabs, dim3(nbk, ns), dim3(256), 0, ctx.stream, d_s + s0, m_onreg.d_tab, 1.0);
+        }
+        ctx.sync();
+        ctx.free(d_s);
+    }
 }
 
 // SyncRegister::CompAdd (SyncRegister.cpp:302-348): the residual of a sync projection on the levels above, formed on the fine side of THIS

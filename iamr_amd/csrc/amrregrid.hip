@@ -84,6 +84,7 @@ static void erode(std::vector<unsigned char>& m, const int n[3], const int per[3
 // lbase: the levels up to lbase keep their grids (Amr::regrid(lbase)); returns the boxes of the levels lbase + 1 ...
 std::vector<std::vector<BoxD>> AmrNS::make_new_grids(int lbase)
 {
+    ProfScope ps_prof_("regrid_make_grids");
     const int finest = (int)lev.size() - 1;
     const int max_level = rg.max_level;
     std::vector<std::vector<BoxD>> grids(max_level + 1);                 // grids[l]: boxes of level l (index space of level l), l >= 1
@@ -227,6 +228,7 @@ void AmrNS::validate_grids(const std::vector<std::vector<BoxD>>& grids, int lbas
 // levels above lbase have reached (a regrid that starts above level 0 can fall inside a coarse step)
 bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids, int lbase, double cur_time_in)
 {
+    ProfScope ps_prof_("regrid_install");
     auto& ctx = Context::get();
     IAMRX_ASSERT(lbase >= 0 && lbase < (int)lev.size());
     validate_grids(grids, lbase);

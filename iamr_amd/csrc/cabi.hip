@@ -43,7 +43,7 @@ static MGOpts to_opts(const iamrx_mg_opts* o)
     r.omega = o->omega; r.maxorder = o->maxorder; r.max_coarsening_level = o->max_coarsening_level;
     r.min_width = o->min_width; r.nodal_sweeps = o->nodal_sweeps; r.nodal_smoother = o->nodal_smoother;
     r.verbose = o->verbose; r.bottom_smoother_only = o->bottom_smoother_only; r.fixed_iters = o->fixed_iters;
-    r.nodal_nu1 = o->nodal_nu1; r.nodal_nu2 = o->nodal_nu2; r.device_bottom = o->device_bottom;
+    r.nodal_nu1 = o->nodal_nu1; r.nodal_nu2 = o->nodal_nu2; r.device_bottom = o->device_bottom; r.slab = o->slab;
     return r;
 }
 
@@ -172,7 +172,7 @@ void iamrx_mg_default_opts(iamrx_mg_opts* o)
     o->bottom_maxiter = d.bottom_maxiter; o->bottom_reltol = d.bottom_reltol; o->omega = d.omega; o->maxorder = d.maxorder;
     o->max_coarsening_level = d.max_coarsening_level; o->min_width = d.min_width; o->nodal_sweeps = d.nodal_sweeps;
     o->nodal_smoother = d.nodal_smoother; o->verbose = d.verbose; o->bottom_smoother_only = d.bottom_smoother_only;
-    o->fixed_iters = d.fixed_iters; o->nodal_nu1 = d.nodal_nu1; o->nodal_nu2 = d.nodal_nu2; o->device_bottom = d.device_bottom;
+    o->fixed_iters = d.fixed_iters; o->nodal_nu1 = d.nodal_nu1; o->nodal_nu2 = d.nodal_nu2; o->device_bottom = d.device_bottom; o->slab = d.slab;
 }
 
 int iamrx_layout_create(int nboxes, const int* lo_hi, const int* owner, iamrx_layout* out)

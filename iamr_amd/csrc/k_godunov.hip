@@ -1510,11 +1510,27 @@ static GodTileList god_tile_lists(const Layout& l, const Geometry& g, int TX, in
 {
     struct Entry { std::vector<long> key; int4* d[2]; int n[2]; int xc[2]; };
     static std::vector<Entry> cache;
+    // entries leave with their layout (a regridding run on a domain with walls makes a new layout per regrid: ADVICE round 5) ...
+    static const bool registered = [] {
+        register_layout_evictor([](uint64_t lid) {
+            bool any = false;
+            for (const Entry& e : cache) any = any || (uint64_t)e.key[0] == lid;
+            if (!any) return;
+            Context::get().sync();
+            for (auto it = cache.begin(); it != cache.end();) {
+                if ((uint64_t)it->key[0] != lid) { ++it; continue; }
+                for (int c = 0; c < 2; ++c) if (it->d[c]) (void)hipFree(it->d[c]);
+                it = cache.erase(it);
+            }
+        });
+        return true;
+    }();
+    (void)registered;
     std::vector<long> key = {(long)l.id, TX, TY, zc.n};
     for (int i = 0; i <= zc.n; ++i) key.push_back(zc.start[i]);
     for (int d = 0; d < 3; ++d) { key.push_back(g.domain.lo[d]); key.push_back(g.domain.hi[d]); key.push_back(g.periodic[d]); }
     for (const Entry& e : cache) if (e.key == key) return GodTileList{{e.d[0], e.d[1]}, {e.n[0], e.n[1]}, {e.xc[0], e.xc[1]}};
-    if (cache.size() >= 64) {
+    if (cache.size() >= 64) {                    // ... (fallback: other tile shapes / chunkings of living layouts)
         Context::get().sync();
         for (Entry& e : cache) for (int c = 0; c < 2; ++c) if (e.d[c]) IAMRX_HIP_CHECK(hipFree(e.d[c]));
         cache.clear();

@@ -798,6 +798,7 @@ const CopyPlan& fill_boundary_plan(const Layout& l, IndexType t, int ng, const G
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
 
+    ProfScope ps_prof_("fill_plan_build");
     auto plan = std::make_unique<CopyPlan>();
     std::map<int, CopyPlan::Peer> peers;
     build_fill_plan_host(l.boxes, l.owner, l.local_of, Context::get().comm->rank, t, ng, g, *plan, peers, ngv, kpar, wall_ext);

@@ -7,6 +7,7 @@
 #include "mf.h"
 #include "kernels.h"
 #include <vector>
+#include <memory>
 
 namespace iamrx {
 
@@ -53,6 +54,7 @@ struct MGOpts {
     // single-workgroup device BiCGStab (k_abec_bottom, no host synchronisation); 0 = coarsen to min_width and drive BiCGStab from the
     // host (upstream's shape; same converged solution, iteration counts may differ by one)
     int device_bottom = 1;
+    int slab = 0;                 // 2-D problem on a thin periodic slab: keep the slab at two cells, coarsen the plane (mg_slab_level)
 };
 
 // V-cycle wall time without draining the stream: HIP events recorded in front of and behind every cycle on the launch stream; the
@@ -79,7 +81,7 @@ CycleTimer& cycle_timer();
 // V-cycle instead of a halo exchange per smoothing pass and an all-reduce per Krylov dot product); 0 disables
 long mg_agglomeration_cells();
 bool mg_agglomerate_level(const Layout& coarse);      // mlmg.hip
-bool mg_slab_level(const Geometry& g, const Layout& l, int min_width);      // mlmg.hip: y kept at two cells from here on
+bool mg_slab_level(const Geometry& g, const Layout& l, int min_width, bool slab_problem);      // mlmg.hip: y kept at two cells from here on
 Geometry mg_slab_geom(const Geometry& fine);
 
 
@@ -181,6 +183,7 @@ private:
     bool m_acc_done = false;
     bool m_bottom_direct = false;
     const double* m_dB = nullptr;  // the cached matrix (device, column-major, m_dN x m_dN)
+    std::shared_ptr<double> m_dBh;            // keeps m_dB alive when the cache evicts its entry
     int m_dN = 0;
     void bottom_direct_prepare();
     void bottom_direct_solve();

@@ -37,9 +37,9 @@ bool mg_agglomerate_level(const Layout& c)
 // operator vanish, the two-plane level is the 2-D coarse problem (relaxed like the thick slab is), and the transfers are the ordinary ones
 // onto the one-plane coarsening of the level with its plane duplicated (Layout::slab_coarsened, slab_duplicate) -- which also projects
 // any y-dependent round-off out of the coarse levels, where the doubled dy would over-correct it.
-bool mg_slab_level(const Geometry& g, const Layout& l, int min_width)
+bool mg_slab_level(const Geometry& g, const Layout& l, int min_width, bool slab_problem)
 {
-    if (tune("MG_SLAB", 0) == 0) return false;
+    if (!slab_problem && tune("MG_SLAB", 0) == 0) return false;
     if (!g.periodic[1] || g.domain.lo[1] != 0 || g.domain.hi[1] != 1) return false;
     for (int d = 0; d < 3; d += 2) if (g.domain.len(d) % 2 != 0 || g.domain.len(d) / 2 < min_width) return false;
     return l.slab_coarsenable(min_width);
@@ -97,6 +97,7 @@ AbecCoef CellMG::coef(int l) const
 
 void CellMG::prepare()
 {
+    ProfScope ps_prof_("cmg_prepare");
     IAMRX_ASSERT(m_b0[0] && m_b0[1] && m_b0[2]);
     // singular <=> no 'a' term and no Dirichlet boundary (MLABecLaplacian::m_is_singular)
     m_singular = !(m_alpha != 0.0 && m_a0);
@@ -161,7 +162,7 @@ void CellMG::prepare()
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         const bool iso = dom_ok && f.layout->coarsenable(2, m_o.min_width);
-        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width);
+        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width, m_o.slab != 0);
         if (!iso && !slab) break;
         Level c;
         c.g = f.g;
@@ -581,7 +582,9 @@ static int* bottom_iters_dev()
 // IAMRX_TENSOR_BOTTOM_DIRECT (1): 0 = the host-driven BiCGStab.
 namespace {
 constexpr int DENSE_MAXN = 81;
-struct DenseEntry { std::vector<unsigned char> key; double* dB; int N; };
+// (the matrix is shared between the cache and every solver prepared with it: an entry evicted from the cache lives until the last
+// CellMG that holds it is gone -- ADVICE round 5)
+struct DenseEntry { std::vector<unsigned char> key; std::shared_ptr<double> dB; int N; };
 std::vector<DenseEntry>& dense_cache() { static std::vector<DenseEntry> c; return c; }
 
 __global__ void k_dense_set_one(FabD x, int i, int j, int k, int n, double v) { x(i, j, k, n) = v; }
@@ -676,7 +679,7 @@ void CellMG::bottom_direct_prepare()
         if (inside) put(len, sizeof(len)); else { put(b.lo, sizeof(b.lo)); put(b.hi, sizeof(b.hi)); }
         put(L.cftab.c, sizeof(L.cftab.c)); put(&L.cftab.maxorder, sizeof(int));
     }
-    for (const DenseEntry& e : dense_cache()) if (e.key == key) { m_dB = e.dB; m_dN = e.N; m_bottom_direct = true; return; }
+    for (const DenseEntry& e : dense_cache()) if (e.key == key) { m_dBh = e.dB; m_dB = e.dB.get(); m_dN = e.N; m_bottom_direct = true; return; }
     // build: column m = the operator (alpha 0, beta 1) applied to the m-th unit vector under the level's homogeneous boundary conditions
     auto& ctx = Context::get();
     double* dB = nullptr;
@@ -694,12 +697,10 @@ void CellMG::bottom_direct_prepare()
         hipLaunchKernelGGL(k_dense_column, dim3(1), dim3(256), 0, ctx.stream, y.h_tab[0], b, m_ncomp, dB + (size_t)m * N);
     }
     ctx.sync();
-    if (dense_cache().size() >= 64) {            // (a long run with many distinct coarsest levels: the oldest matrix goes)
-        IAMRX_HIP_CHECK(hipFree(dense_cache().front().dB));
-        dense_cache().erase(dense_cache().begin());
-    }
-    dense_cache().push_back(DenseEntry{key, dB, N});
-    m_dB = dB; m_dN = N; m_bottom_direct = true;
+    if (dense_cache().size() >= 64) dense_cache().erase(dense_cache().begin());      // (many distinct coarsest levels: the oldest entry leaves the cache)
+    std::shared_ptr<double> h(dB, [](double* q) { (void)hipFree(q); });
+    dense_cache().push_back(DenseEntry{key, h, N});
+    m_dBh = h; m_dB = dB; m_dN = N; m_bottom_direct = true;
 }
 
 void CellMG::bottom_direct_solve()
@@ -715,6 +716,7 @@ void CellMG::bottom_direct_solve()
 
 void CellMG::bottom_solve(MGStats& st)
 {
+    ProfScope ps_prof_("cmg_bottom");
     const int l = (int)m_lev.size() - 1;
     Level& L = m_lev[l];
     if (m_dd_sweeps > 0) {                 // diagonally dominant operator: no hierarchy, see prepare()
@@ -841,6 +843,7 @@ void CellMG::fluxes(MultiFab& phi, MultiFab* const flux[3], MultiFab* const add_
 
 MGStats CellMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)
 {
+    ProfScope ps_prof_("cmg_solve");
     auto& ctx = Context::get();
     MGStats st;
     st.nlevels = (int)m_lev.size();

@@ -43,6 +43,7 @@ static int* nodal_bottom_iters_dev()
 
 NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const MGOpts& o) : m_g(g), m_bc(bc_in), m_o(o)
 {
+    ProfScope ps_prof_("nmg_ctor");
     // the operator does not distinguish inflow faces from walls (the difference is in div(u), nodal_divu)
     for (int d = 0; d < 3; ++d) { if (m_bc.lo[d] == lo_inflow) m_bc.lo[d] = lo_neumann; if (m_bc.hi[d] == lo_inflow) m_bc.hi[d] = lo_neumann; }
     const DomainBC& bc = m_bc;
@@ -65,7 +66,7 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
         bool dom_ok = true;
         for (int d = 0; d < 3; ++d) if (f.g.domain.len(d) % 2 != 0 || f.g.domain.len(d) / 2 < m_o.min_width) dom_ok = false;
         const bool iso = dom_ok && f.layout->coarsenable(2, m_o.min_width);
-        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width);     // (mlmg.hip: y kept at two cells, transfers through the one-plane level)
+        const bool slab = !iso && mg_slab_level(f.g, *f.layout, m_o.min_width, m_o.slab != 0);     // (mlmg.hip: y kept at two cells, transfers through the one-plane level)
         if (!iso && !slab) break;
         Level c;
         c.g = f.g;
@@ -132,6 +133,7 @@ NodalMG::NodalMG(const Geometry& g, LayoutP layout, const DomainBC& bc_in, const
 
 void NodalMG::setSigma(const MultiFab& sig, int comp)
 {
+    ProfScope ps_prof_("nmg_setsigma");
     MultiFab::Copy(m_lev[0].sig, sig, comp, 0, 1, 0);
     m_lev[0].sig.FillBoundary(m_lev[0].g);
     cc_mirror_bc(m_lev[0].g, m_lev[0].sig);                // mlndlap_fillbc_cc: mirror sigma across walls
@@ -421,6 +423,7 @@ void NodalMG::vcycle_correction_inplace(MGStats& st)
 
 MGStats NodalMG::solve(MultiFab& phi, const MultiFab& rhs_in, double rtol, double atol)
 {
+    ProfScope ps_prof_("nmg_solve");
     auto& ctx = Context::get();
     MGStats st;
     st.nlevels = (int)m_lev.size();

@@ -45,7 +45,7 @@ class MgOpts(C.Structure):
                 ("maxorder", C.c_int), ("max_coarsening_level", C.c_int), ("min_width", C.c_int),
                 ("nodal_sweeps", C.c_int), ("nodal_smoother", C.c_int), ("verbose", C.c_int),
                 ("bottom_smoother_only", C.c_int), ("fixed_iters", C.c_int), ("nodal_nu1", C.c_int), ("nodal_nu2", C.c_int),
-                ("device_bottom", C.c_int)]
+                ("device_bottom", C.c_int), ("slab", C.c_int)]
 
 
 class MgStats(C.Structure):
@@ -342,6 +342,10 @@ class SyncRegister:
     def FineAdd(self, sync_resid_fine, mult):
         check(lib().iamrx_syncreg_fine_add(self.h, sync_resid_fine.h, C.c_double(mult)))
 
+    def CompAdd(self, sync_resid_fine, fgeom, finer_layout, finer_ratio, mult):
+        """Source/SyncRegister.cpp:302-348: zero the residual on the nodes of the next finer level's boxes, then FineAdd (modifies the residual)"""
+        check(lib().iamrx_syncreg_comp_add(self.h, sync_resid_fine.h, C.byref(fgeom), finer_layout.h, int(finer_ratio), C.c_double(mult)))
+
     def InitRHS(self, rhs):
         check(lib().iamrx_syncreg_init_rhs(self.h, rhs.h))
 
@@ -568,4 +572,67 @@ def mlsync_project(crse, fine, pres_crse, vel_crse, pres_fine, vel_fine, rho_crs
     check(lib().iamrx_mlsync_project(C.byref(pc), C.byref(pf), pres_crse.h, vel_crse.h, int(vcomp_crse), pres_fine.h, vel_fine.h, int(vcomp_fine), rho_crse.h,
                                      rho_fine.h, Vsync.h, V_corr.h, phi_crse.h, phi_fine.h, rhs_sync_reg.h, crse_sync_reg.h if crse_sync_reg is not None else None,
                                      C.c_double(dt), int(crse_iteration), int(crse_dt_ratio), C.c_double(sync_tol), C.c_double(abs_tol), C.byref(o), C.byref(st)))
+    return st
+
+
+# ---- round 6: MacProj::mac_sync_compute, SyncRegister::CompAdd, Projection::initial*Project on caller-owned data ----------------------
+def mac_sync_compute(geom, ucorr, Vsync, Ssync, S_vel, S_scal, nscal, gradp, umac, iconserv_scal, dt, visc_vel=None, tforce_scal=None, divu=None,
+                     do_mom_diff=0, gravity=0.0, bc_vel=None, bc_scal=None, use_forces_in_trans=0, scheme=0, flux_vel=None, flux_scal=None):
+    """MacProj::mac_sync_compute as NavierStokes::mac_sync calls it (Source/MacProj.cpp:488-731)"""
+    ic = (C.c_int * nscal)(*[int(x) for x in iconserv_scal])
+    fv = [None] * 3 if flux_vel is None else flux_vel
+    fs = [None] * 3 if flux_scal is None else flux_scal
+    check(lib().iamrx_mac_sync_compute(C.byref(geom), ucorr[0].h, ucorr[1].h, ucorr[2].h, Vsync.h, Ssync.h, S_vel.h, S_scal.h, int(nscal), _h(visc_vel),
+                                       _h(tforce_scal), gradp.h, _h(divu), umac[0].h, umac[1].h, umac[2].h, ic, int(do_mom_diff), C.c_double(gravity),
+                                       C.c_double(dt), _bcrec(3, bc_vel), _bcrec(nscal, bc_scal), int(use_forces_in_trans), int(scheme),
+                                       _h(fv[0]), _h(fv[1]), _h(fv[2]), _h(fs[0]), _h(fs[1]), _h(fs[2])))
+
+
+def mac_sync_compute_edge(geom, ucorr, Sync, sync_indx, edge, edge_comp, flux=None):
+    """MacProj::mac_sync_compute with known edge states (Source/MacProj.cpp:733-786)"""
+    f = [None] * 3 if flux is None else flux
+    check(lib().iamrx_mac_sync_compute_edge(C.byref(geom), ucorr[0].h, ucorr[1].h, ucorr[2].h, Sync.h, int(sync_indx), edge[0].h, edge[1].h, edge[2].h,
+                                            int(edge_comp), _h(f[0]), _h(f[1]), _h(f[2])))
+
+
+def _proj_levels(levels, keep):
+    arr = (ProjLevel * len(levels))()
+    for q, (g, lay, lo, hi, r, gp) in enumerate(levels):
+        keep.append(g)
+        arr[q] = ProjLevel(C.cast(C.pointer(g), C.c_void_p), lay.h, i3(lo), i3(hi), int(r), _h(gp) if gp is not None else None)
+    return arr
+
+
+def _hv(mfs, n):
+    a = (C.c_void_p * n)()
+    for q in range(n):
+        a[q] = None if (mfs is None or mfs[q] is None) else mfs[q].h
+    return a
+
+
+def initial_velocity_project(levels, vel, vcomp, pres, rho=None, rho_comp=None, divu=None, divu_comp=None, proj_tol=1e-12, proj_abs_tol=1e-16, opts=None):
+    """Projection::initialVelocityProject (Source/Projection.cpp:615-838); levels: [(geom, layout, lobc, hibc, ratio, gp or None)], coarsest first"""
+    n = len(levels)
+    st = MgStats(); o = opts if opts is not None else mg_opts(); keep = []
+    pl = _proj_levels(levels, keep)
+    vc = (C.c_int * n)(*[int(v) for v in vcomp])
+    rc = (C.c_int * n)(*[int(v) for v in (rho_comp or [0] * n)])
+    dc = (C.c_int * n)(*[int(v) for v in (divu_comp or [0] * n)])
+    check(lib().iamrx_initial_velocity_project(n, pl, _hv(vel, n), vc, _hv(pres, n), _hv(rho, n) if rho is not None else None, rc,
+                                               _hv(divu, n) if divu is not None else None, dc, C.c_double(proj_tol), C.c_double(proj_abs_tol), C.byref(o), C.byref(st)))
+    return st
+
+
+def initial_sync_project(levels, vel_new, vcomp, vel_old, phi, rho_half, dt, pres_new=None, divu_new=None, divu_old=None, divu_comp=None, proj_tol=1e-12,
+                         proj_abs_tol=1e-16, opts=None):
+    """Projection::initialSyncProject (Source/Projection.cpp:970-1185)"""
+    n = len(levels)
+    st = MgStats(); o = opts if opts is not None else mg_opts(); keep = []
+    pl = _proj_levels(levels, keep)
+    vc = (C.c_int * n)(*[int(v) for v in vcomp])
+    dc = (C.c_int * n)(*[int(v) for v in (divu_comp or [0] * n)])
+    check(lib().iamrx_initial_sync_project(n, pl, _hv(vel_new, n), vc, _hv(vel_old, n), _hv(phi, n), _hv(pres_new, n) if pres_new is not None else None,
+                                           _hv(rho_half, n), _hv(divu_new, n) if divu_new is not None else None,
+                                           _hv(divu_old, n) if divu_old is not None else None, dc, C.c_double(dt), C.c_double(proj_tol),
+                                           C.c_double(proj_abs_tol), C.byref(o), C.byref(st)))
     return st

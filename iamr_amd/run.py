@@ -22,13 +22,15 @@ def init_level(ns, lay, lib, N, pr, n):
         ns.init_taylorgreen(pb["vfac"], pb["a"], pb["b"], pb["c"], pb["rho0"])
 
 
-def build_amr(pr, lib, N, world=1):
+def build_amr(pr, lib, N, world=1, **mg_kw):
     """hierarchy of fixed grids: level 0 chopped by amr.max_grid_size, the refined levels as the grid file gives them"""
     from .amr import Amr
-    lib.tuning_set("MG_SLAB", 1 if pr.get("slab") else 0)      # 2-D run on its slab: the multigrid keeps the slab two cells thick (mlmg.hip mg_slab_level)
+    # 2-D run on its slab: the multigrid keeps the slab two cells thick (mlmg.hip mg_slab_level) -- a property of THIS problem's solvers,
+    # handed over in their options (not process-wide tuning: ADVICE round 5)
+    opts = lib.mg_opts(slab=1 if pr.get("slab") else 0, **mg_kw)
     g0 = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
     lays = [lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], world)] + [lib.Layout(b, [q % world for q in range(len(b))]) for b in pr["fine_boxes"]]
-    amr = Amr(g0, lays, N.ns_params(**pr["params"]))
+    amr = Amr(g0, lays, N.ns_params(**pr["params"]), opts)
     for l, lev in enumerate(amr.levels):
         init_level(lev, lays[l], lib, N, pr, [v * 2 ** l for v in pr["n"]])
     if pr.get("regrid"):
@@ -203,10 +205,10 @@ def main_amr(pr, inp, lib, N, rank=0, world=1):
 
 def build(inp, lib, N, nranks=1, pr=None):
     pr = pr if pr is not None else inp.problem()
-    lib.tuning_set("MG_SLAB", 1 if pr.get("slab") else 0)      # 2-D run on its slab: the multigrid keeps the slab two cells thick (mlmg.hip mg_slab_level)
+    opts = lib.mg_opts(slab=1 if pr.get("slab") else 0)        # (see build_amr)
     g = lib.Geom.make(pr["n"], prob_lo=pr["prob_lo"], prob_hi=pr["prob_hi"], periodic=pr["periodic"])
     lay = lib.Layout.decompose(tuple(pr["n"]), pr["max_grid_size"], nranks)
-    ns = N.NavierStokes(g, lay, N.ns_params(**pr["params"]))
+    ns = N.NavierStokes(g, lay, N.ns_params(**pr["params"]), opts)
     pb = pr["prob"]
     if pb["probtype"] == 1:
         ns.init_rest(pb["rho0"])

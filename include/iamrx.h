@@ -57,6 +57,10 @@ typedef struct iamrx_mg_opts {
      * device launch (BiCGStab to bottom_reltol + nub sweeps, no host synchronisation); 0 = coarsen to min_width, host-driven BiCGStab
      * (amrex::MLMG's shape).  Same converged solution. */
     int device_bottom;
+    /* 1: the level is a 2-D problem lifted onto a thin periodic slab (iamr_amd/inputs.py lift_2d): once the slab is two cells thick the
+     * multigrid keeps it at two cells and coarsens the plane only.  0 (default): ordinary coarsening.  A property
+     * of the problem handed to each solver, not process-wide state (the IAMRX_MG_SLAB switch still forces it for tests). */
+    int slab;
 } iamrx_mg_opts;
 
 typedef struct iamrx_mg_stats {
