@@ -39,18 +39,40 @@ void build_parallel_copy_plan_host(const std::vector<BoxD>& dboxes, const std::v
 {
     int smin[3] = {0, 0, 0}, smax[3] = {0, 0, 0};
     if (pg) for (int d = 0; d < 3; ++d) if (pg->periodic[d]) { smin[d] = -1; smax[d] = 1; }
+    // (source boxes that meet a destination region through a bin index, mf.h BoxBins: the same descriptors in the same order as a scan
+    // of every (dst, src, shift) triple -- source ascending, then the z, y, x shift)
+    std::vector<BoxD> sregs(sboxes.size());
+    for (size_t gs = 0; gs < sboxes.size(); ++gs) sregs[gs] = grow(convert(sboxes[gs], t.t), src_ng);
+    const BoxBins index(sregs);
+    struct Cand { int gs, sx, sy, sz; };
+    std::vector<Cand> cand;
+    std::vector<int> hits;
     for (int gd = 0; gd < (int)dboxes.size(); ++gd) {
         const bool dst_mine = downer[gd] == me;
         const BoxD dreg = grow(convert(dboxes[gd], t.t), dst_ng);
-        for (int gs = 0; gs < (int)sboxes.size(); ++gs) {
-            const bool src_mine = sowner[gs] == me;
-            if (!dst_mine && !src_mine) continue;
-            for (int sz = smin[2]; sz <= smax[2]; ++sz)
-            for (int sy = smin[1]; sy <= smax[1]; ++sy)
-            for (int sx = smin[0]; sx <= smax[0]; ++sx) {
+        cand.clear();
+        for (int sz = smin[2]; sz <= smax[2]; ++sz)
+        for (int sy = smin[1]; sy <= smax[1]; ++sy)
+        for (int sx = smin[0]; sx <= smax[0]; ++sx) {
+            BoxD q = dreg;
+            if (pg) { const int s3[3] = {sx * pg->domain.len(0), sy * pg->domain.len(1), sz * pg->domain.len(2)}; for (int d = 0; d < 3; ++d) { q.lo[d] -= s3[d]; q.hi[d] -= s3[d]; } }
+            index.query(q, hits);
+            for (int gs : hits) cand.push_back(Cand{gs, sx, sy, sz});
+        }
+        std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) {
+            if (a.gs != b.gs) return a.gs < b.gs;
+            if (a.sz != b.sz) return a.sz < b.sz;
+            if (a.sy != b.sy) return a.sy < b.sy;
+            return a.sx < b.sx;
+        });
+        for (const Cand& c : cand) {
+            {
+                const int gs = c.gs, sx = c.sx, sy = c.sy, sz = c.sz;
+                const bool src_mine = sowner[gs] == me;
+                if (!dst_mine && !src_mine) continue;
                 int sh[3] = {0, 0, 0};
                 if (pg) { sh[0] = sx * pg->domain.len(0); sh[1] = sy * pg->domain.len(1); sh[2] = sz * pg->domain.len(2); }
-                BoxD sreg = grow(convert(sboxes[gs], t.t), src_ng);
+                BoxD sreg = sregs[gs];
                 for (int d = 0; d < 3; ++d) sreg = shift(sreg, d, sh[d]);
                 const BoxD is = intersect(dreg, sreg);
                 if (!is.ok()) continue;

@@ -778,6 +778,10 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
             if (m > l) {                                        // e of level m = the interpolant of the coarser correction (all nodes)
                 MultiFab& ec = m - 1 == l ? el : L[m - 1].e;
                 if (m - 1 > l) fill_nodes(L[m - 1], ec);        // (the level solver has filled the ghost nodes of its own correction)
+                if (m == nl - 1) {                              // nobody interpolates from the finest level: x += interpolant on its unknowns, one pass
+                    node_interp_from_crse(L[m].x, ec, L[m - 1].g, L[m].pl->ratio, &L[m].own, true);
+                    continue;
+                }
                 node_interp_from_crse(em, ec, L[m - 1].g, L[m].pl->ratio, nullptr, false);
             }
             const FabD *xt = L[m].x.d_tab, *et = em.d_tab, *ot = L[m].own.d_tab;                 // x += e on the unknowns

@@ -97,6 +97,51 @@ void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, cons
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, s, d, dst, buf, pts_total, dcomp, nc, add ? 1 : 0);
 }
 
+// ---- the same over a flat work list: workgroup b takes COPY_CHUNK points of descriptor work[b].x starting at work[b].y * COPY_CHUNK
+template <int MODE>       // 0 copy, 1 pack, 2 unpack
+__global__ void __launch_bounds__(256) k_copy_work(const CopyDesc* __restrict__ descs, const int2* __restrict__ work, const FabD* __restrict__ src,
+                                                   const FabD* __restrict__ dst, double* __restrict__ buf, long pts_total, int scomp, int dcomp, int nc, int add)
+{
+    const int2 e = work[blockIdx.x];
+    const CopyDesc cd = descs[e.x];
+    const int nx = cd.region.len(0), ny = cd.region.len(1);
+    const long npts = cd.npts();
+    FabD s, d;
+    if (MODE != 2) s = src[cd.src_fab];
+    if (MODE != 1) d = dst[cd.dst_fab];
+#pragma unroll
+    for (int u = 0; u < COPY_CHUNK / 256; ++u) {
+        const long q = (long)e.y * COPY_CHUNK + u * 256 + threadIdx.x;
+        if (q >= npts) break;
+        const int i = cd.region.lo[0] + (int)(q % nx);
+        const long r = q / nx;
+        const int j = cd.region.lo[1] + (int)(r % ny);
+        const int k = cd.region.lo[2] + cd.kstep * (int)(r / ny);
+        for (int n = 0; n < nc; ++n) {
+            if (MODE == 0) {
+                const double v = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+                if (add) d(i, j, k, dcomp + n) += v; else d(i, j, k, dcomp + n) = v;
+            } else if (MODE == 1) buf[cd.buf_off + q + pts_total * n] = s(i + cd.shift[0], j + cd.shift[1], k + cd.shift[2], scomp + n);
+            else {
+                const double v = buf[cd.buf_off + q + pts_total * n];
+                if (add) d(i, j, k, dcomp + n) += v; else d(i, j, k, dcomp + n) = v;
+            }
+        }
+    }
+}
+void launch_copy_plan_w(const CopyDesc* d, const int2* w, int nw, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add)
+{
+    if (nw > 0) hipLaunchKernelGGL((k_copy_work<0>), dim3((unsigned)nw), dim3(256), 0, s, d, w, src, dst, (double*)nullptr, 0L, scomp, dcomp, nc, add ? 1 : 0);
+}
+void launch_pack_w(const CopyDesc* d, const int2* w, int nw, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s)
+{
+    if (nw > 0) hipLaunchKernelGGL((k_copy_work<1>), dim3((unsigned)nw), dim3(256), 0, s, d, w, src, (const FabD*)nullptr, buf, pts_total, scomp, 0, nc, 0);
+}
+void launch_unpack_w(const CopyDesc* d, const int2* w, int nw, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add)
+{
+    if (nw > 0) hipLaunchKernelGGL((k_copy_work<2>), dim3((unsigned)nw), dim3(256), 0, s, d, w, (const FabD*)nullptr, dst, const_cast<double*>(buf), pts_total, 0, dcomp, nc, add ? 1 : 0);
+}
+
 // ------------------------------------------------------------------ reductions
 // wavefront (64 lanes) shuffle reduction, then LDS across the 4 waves of the workgroup
 template <int OP> __device__ __forceinline__ double red_op(double a, double b)
@@ -129,7 +174,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_reduce_finish(const d
 __global__ void __launch_bounds__(256) k_norm0(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
                                                const FabD* __restrict__ tab, int comp, int nc, double* __restrict__ partials)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     double m = 0.0;
@@ -174,7 +219,7 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
     global = global && !mf.layout->replicated;
     if (mf.nlocal() == 0) return (global && Context::get().comm->nranks > 1) ? finish_to_host(1, 1, 0, true) : 0.0;
     auto& ctx = Context::get();
-    Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+    Tiling t = level_tiling(*mf.layout, mf.type, ng, 8, true);
     dim3 g = t.grid();
     const int np = (int)(g.x * g.y);
     ctx.ensure_scratch((size_t)np + 16);
@@ -187,7 +232,7 @@ double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global)
 __global__ void __launch_bounds__(256) k_minmax(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
                                                 const FabD* __restrict__ tab, int comp, double* __restrict__ partials, int np)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     const bool in = tile_ijk(t, b, i, j, k0, k1);
@@ -209,7 +254,7 @@ void reduce_minmax(const MultiFab& mf, int comp, int ng, double& mn, double& mx,
     auto& ctx = Context::get();
     int np = 0;
     if (mf.nlocal() > 0) {
-        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8, true);
         dim3 g = t.grid();
         np = (int)(g.x * g.y);
         ctx.ensure_scratch((size_t)2 * np + 16);
@@ -224,7 +269,7 @@ void reduce_minmax(const MultiFab& mf, int comp, int ng, double& mn, double& mx,
 __global__ void __launch_bounds__(256) k_norm0_comps(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng,
                                                      const FabD* __restrict__ tab, int comp, int nc, double* __restrict__ partials, int np)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     const bool in = tile_ijk(t, b, i, j, k0, k1);
@@ -243,7 +288,7 @@ void reduce_norm0_comps(const MultiFab& mf, int comp, int nc, int ng, double* ou
     auto& ctx = Context::get();
     int np = 0;
     if (mf.nlocal() > 0) {
-        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8);
+        Tiling t = level_tiling(*mf.layout, mf.type, ng, 8, true);
         dim3 g = t.grid();
         np = (int)(g.x * g.y);
         ctx.ensure_scratch((size_t)nc * np + 16);
@@ -291,7 +336,7 @@ __global__ void __launch_bounds__(256) k_dots(Tiling t, const BoxD* __restrict__
                                               const FabD* x0, const FabD* y0, const FabD* x1, const FabD* y1,
                                               int comp, int nc, double* __restrict__ partials, int np)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD cb = boxes[fab];
     const BoxD b = dev_grow_convert(cb, own.type[0], own.type[1], own.type[2], 0);
     int i, j, k0, k1;
@@ -326,7 +371,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
     const bool global = !local && !m.layout->replicated && ctx.comm->nranks > 1;
     if (m.nlocal() == 0 && global) { finish_to_host(0, nout, 0, true); for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q]; }
     if (m.nlocal() > 0) {
-        Tiling t = level_tiling(*m.layout, m.type, 0, 8);
+        Tiling t = level_tiling(*m.layout, m.type, 0, 8, true);
         dim3 gr = t.grid();
         const int np = (int)(gr.x * gr.y);
         ctx.ensure_scratch((size_t)np * nout + 16);
@@ -342,7 +387,7 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
 __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own,
                                                     const FabD* __restrict__ tab, int comp, double* __restrict__ partials)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD cb = boxes[fab];
     const BoxD b = dev_grow_convert(cb, own.type[0], own.type[1], own.type[2], 0);
     int i, j, k0, k1;
@@ -361,7 +406,7 @@ double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool g
     global = global && !mf.layout->replicated;
     if (mf.nlocal() == 0) return (global && Context::get().comm->nranks > 1) ? finish_to_host(0, 1, 0, true) : 0.0;
     auto& ctx = Context::get();
-    Tiling t = level_tiling(*mf.layout, mf.type, 0, 8);
+    Tiling t = level_tiling(*mf.layout, mf.type, 0, 8, true);
     dim3 gr = t.grid();
     const int np = (int)(gr.x * gr.y);
     ctx.ensure_scratch((size_t)np + 16);

@@ -10,6 +10,10 @@ void launch_fill(double* p, size_t n, double v, hipStream_t s);
 void launch_copy_plan(const CopyDesc* d, int nd, long maxpts, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add = false);
 void launch_pack(const CopyDesc* d, int nd, long maxpts, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s);
 void launch_unpack(const CopyDesc* d, int nd, long maxpts, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add = false);
+// the same three over a flat work list (mf.h CopyWork: nw entries (descriptor, chunk)): one workgroup per COPY_CHUNK points that exist
+void launch_copy_plan_w(const CopyDesc* d, const int2* w, int nw, const FabD* src, const FabD* dst, int scomp, int dcomp, int nc, hipStream_t s, bool add);
+void launch_pack_w(const CopyDesc* d, const int2* w, int nw, const FabD* src, double* buf, long pts_total, int scomp, int nc, hipStream_t s);
+void launch_unpack_w(const CopyDesc* d, const int2* w, int nw, const FabD* dst, const double* buf, long pts_total, int dcomp, int nc, hipStream_t s, bool add);
 // global: combined over the ranks (on the device, before the single read-back) unless the layout is replicated
 double reduce_norm0(const MultiFab& mf, int comp, int nc, int ng, bool global = false);
 void reduce_norm0_comps(const MultiFab& mf, int comp, int nc, int ng, double* out, bool global = false);   // per-component maxima, one read-back

@@ -20,7 +20,15 @@ struct Tiling {
     int tz;             // z points per thread
     int nfab;
     int xcd_cnt;        // > 0: XCD-aware order, tiles per XCD (see tile_ijk)
-    dim3 grid() const { return dim3((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : ntx * nty * ntz), (unsigned)(nfab > 0 ? nfab : 1), 1); }
+    // flat tile list (level_tiling with allow_list on a level whose boxes differ in size): workgroup b takes entry b = (fab, i0, j0,
+    // k0 | log2(BX) << 26) -- offsets inside the box -- instead of tile b of box blockIdx.y in a grid sized for the LARGEST box
+    const int4* list = nullptr;
+    int nlist = 0;
+    dim3 grid() const
+    {
+        if (list) return dim3((unsigned)nlist, 1, 1);
+        return dim3((unsigned)(xcd_cnt > 0 ? 8 * xcd_cnt : ntx * nty * ntz), (unsigned)(nfab > 0 ? nfab : 1), 1);
+    }
     static dim3 block() { return dim3(256, 1, 1); }
 };
 
@@ -51,12 +59,25 @@ inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
     return t;
 }
 
-// tiling for the local boxes of `l` converted to `type` and grown by ng
-inline Tiling level_tiling(const Layout& l, const IndexType& type, int ng, int tz = 4)
+// (mf.hip) cached flat tile list of the local boxes of l (converted to type, grown by ng), tz planes per thread; *total = its length
+const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int tz, int* total);
+
+// tiling for the local boxes of `l` converted to `type` and grown by ng.  allow_list: the kernel takes its box from tile_fab(t), so a level
+// whose boxes differ in size (a regridded refined level and its multigrid levels: boxes of 2 ... 32 cells side by side) may be given a flat
+// list of the tiles that exist -- the grid of the plain form is sized for the largest box, and on such levels most of its workgroups
+// find nothing to do (round 6: the Krylov iterations on the coarsest level of BASELINE config C5, 3 x per launch)
+inline Tiling level_tiling(const Layout& l, const IndexType& type, int ng, int tz = 4, bool allow_list = false)
 {
     int ml[3];
     for (int d = 0; d < 3; ++d) ml[d] = l.max_len[d] + type.t[d] + 2 * ng;
-    return make_tiling(ml, l.nlocal(), tz);
+    Tiling t = make_tiling(ml, l.nlocal(), tz);
+    if (allow_list && l.nlocal() >= 4 && tune("TILE_LISTS", 1) != 0) {
+        int n = 0;
+        const int4* lst = level_tile_list(l, type, ng, t.tz, &n);
+        const long plain = (long)t.ntx * t.nty * t.ntz * l.nlocal();
+        if (lst && 4L * n <= 3L * plain) { t.list = lst; t.nlist = n; t.xcd_cnt = 0; }
+    }
+    return t;
 }
 
 // Boundary-region descriptor lists (which ghost slabs of which box lie outside the domain / on a wall) depend only on the layout, the
@@ -98,8 +119,21 @@ inline const D* cached_descs(std::map<std::array<long, 10>, std::tuple<D*, int, 
 
 #ifdef __HIPCC__
 // decode (i, j, k-range) of this thread inside box b; returns false if (i,j) is outside
+// the box of this workgroup (kernels launched with a tiling that may carry a flat list)
+__device__ __forceinline__ int tile_fab(const Tiling& t) { return t.list ? t.list[blockIdx.x].x : (int)blockIdx.y; }
+
 __device__ __forceinline__ bool tile_ijk(const Tiling& t, const BoxD& b, int& i, int& j, int& k0, int& k1)
 {
+    if (t.list) {
+        const int4 e = t.list[blockIdx.x];
+        const int bxs = (int)((unsigned)e.w >> 26), tid = threadIdx.x;
+        i = b.lo[0] + e.y + (tid & ((1 << bxs) - 1));
+        j = b.lo[1] + e.z + (tid >> bxs);
+        k0 = b.lo[2] + (e.w & 0x3ffffff);
+        k1 = k0 + t.tz - 1;
+        if (k1 > b.hi[2]) k1 = b.hi[2];
+        return i <= b.hi[0] && j <= b.hi[1] && k0 <= b.hi[2];
+    }
     const int bx = 1 << t.bxs;
     const int tid = threadIdx.x;
     const int tx = tid & (bx - 1), ty = tid >> t.bxs;
@@ -130,7 +164,7 @@ __device__ __forceinline__ BoxD dev_grow_convert(BoxD b, int t0, int t1, int t2,
 template <class F>
 __global__ void __launch_bounds__(256) k_for_each(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, F f)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     if (!tile_ijk(t, b, i, j, k0, k1)) return;
@@ -141,7 +175,7 @@ template <class F>
 inline void for_each(const Layout& l, const IndexType& type, int ng, hipStream_t s, F f)
 {
     if (l.nlocal() == 0) return;
-    Tiling t = level_tiling(l, type, ng);
+    Tiling t = level_tiling(l, type, ng, 4, true);
     hipLaunchKernelGGL((k_for_each<F>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f);
 }
 
@@ -152,7 +186,7 @@ template <int NOUT, class F>
 __global__ void __launch_bounds__(256) k_reduce_max_f(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, F f,
                                                       double* __restrict__ partials, int np)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     double m[NOUT];
@@ -182,7 +216,7 @@ inline void reduce_max_f(const Layout& l, const IndexType& type, int ng, F f, do
     auto& ctx = Context::get();
     int np = 0;
     if (l.nlocal() > 0) {
-        Tiling t = level_tiling(l, type, ng, 8);
+        Tiling t = level_tiling(l, type, ng, 8, true);
         dim3 g = t.grid();
         np = (int)(g.x * g.y);
         ctx.ensure_scratch((size_t)NOUT * np + 16);
@@ -197,7 +231,7 @@ inline void reduce_max_f(const Layout& l, const IndexType& type, int ng, F f, do
 template <int NP, class L, class S>
 __global__ void __launch_bounds__(256) k_for_each_2ph(Tiling t, const BoxD* __restrict__ boxes, int t0, int t1, int t2, int ng, int nc, L ld, S st)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = dev_grow_convert(boxes[fab], t0, t1, t2, ng);
     int i, j, k0, k1;
     if (!tile_ijk(t, b, i, j, k0, k1)) return;
@@ -215,7 +249,7 @@ template <class L, class S>
 inline void for_each_2ph(const Layout& l, const IndexType& type, int ng, int nc, hipStream_t s, L ld, S st)
 {
     if (l.nlocal() == 0 || nc <= 0) return;
-    Tiling t = level_tiling(l, type, ng);
+    Tiling t = level_tiling(l, type, ng, 4, true);
     hipLaunchKernelGGL((k_for_each_2ph<4, L, S>), t.grid(), Tiling::block(), 0, s, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, nc, ld, st);
 }
 #endif

@@ -175,16 +175,23 @@ struct CopyDesc {
     __host__ __device__ long npts() const { return (long)region.len(0) * region.len(1) * nk(); }
 };
 
+// Flat work list of a descriptor list (built on first use, execute_plan): entry (descriptor, chunk of COPY_CHUNK points).  The plain launch
+// gives EVERY descriptor as many workgroups as the largest one needs; a ghost exchange of a regridded level has tens of thousands of
+// descriptors of very different sizes (40 k for the nodal data of 431 boxes), so most of those workgroups found nothing to do (round 6).
+constexpr int COPY_CHUNK = 1024;
+struct CopyWork { int2* d = nullptr; int n = 0; bool built = false; };
 struct CopyPlan {
     std::vector<CopyDesc> local;           // host copy
     CopyDesc* d_local = nullptr;
     long max_local_pts = 0;
+    mutable CopyWork w_local;
     // remote: per peer, pack list (src_fab regions -> send buffer) and unpack list (recv buffer -> dst_fab)
     struct Peer {
         int rank;
         std::vector<CopyDesc> pack, unpack;
         CopyDesc *d_pack = nullptr, *d_unpack = nullptr;
         long send_pts = 0, recv_pts = 0, max_pack_pts = 0, max_unpack_pts = 0;
+        mutable CopyWork w_pack, w_unpack;
     };
     std::vector<Peer> peers;
     ~CopyPlan();
@@ -253,6 +260,20 @@ public:
 
 private:
     void release();
+};
+
+// Uniform bin index over a list of boxes (host): the boxes that meet a region without a scan of the whole list (round 6: the copy-plan
+// builders visited every (box, box, periodic shift) triple -- quadratic in the number of boxes of a regridded level).
+struct BoxBins {
+    std::vector<BoxD> b;
+    BoxD bbox;
+    int bsz[3] = {4, 4, 4}, nbin[3] = {1, 1, 1};
+    std::vector<std::vector<int>> bins;
+    mutable std::vector<int> stamp;
+    mutable int stamp_id = 0;
+    explicit BoxBins(std::vector<BoxD> boxes);
+    // indices (ascending) of the boxes that intersect q
+    void query(const BoxD& q, std::vector<int>& out) const;
 };
 
 // host-only plan construction (no device access; unit-testable on CPU)

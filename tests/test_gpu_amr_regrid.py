@@ -11,6 +11,9 @@ import orc
 from test_gpu_amr_step import _make, _compare
 
 pytestmark = pytest.mark.gpu
+# IAMRX_TEST_LONG = 1: the longer variants the suite ran before its time budget was cut in round 5 (one more coarse step per case, the 64^2
+# C3 slab parity, two coarse steps in front of the plotfile comparison) -- kept, not deleted
+LONG = __import__("os").environ.get("IAMRX_TEST_LONG") == "1"
 
 
 def _blob(X, Y, Z, c):
@@ -79,7 +82,7 @@ def test_three_levels_stay_properly_nested_and_match_the_oracle():
     amr.post_init()
     oa.post_init()
     had_three = False
-    for step in range(3):              # (three coarse steps: the oracle's share of the GPU suite's time budget)
+    for step in range(4 if LONG else 3):              # (three coarse steps: the oracle's share of the GPU suite's time budget)
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
@@ -111,7 +114,7 @@ def test_rayleigh_taylor_physics_with_regridding():
     amr.post_init()
     oa.post_init()
     changes = 0
-    for step in range(2):
+    for step in range(3 if LONG else 2):
         before = [list(l.boxes) for l in amr.layouts[1:]]
         dt = amr.coarse_step()
         after = [list(l.boxes) for l in amr.layouts[1:]]
@@ -141,7 +144,7 @@ def test_regrid_that_starts_above_level_zero():
     amr.post_init()
     oa.post_init()
     bases = []
-    for step in range(2):
+    for step in range(3 if LONG else 2):
         dt = amr.coarse_step()
         ev = amr.regrid_log()
         bases += [(lb, tm) for lb, tm, _ in ev]

@@ -15,6 +15,9 @@ import orc
 from test_gpu_amr_step import _compare
 
 pytestmark = pytest.mark.gpu
+# IAMRX_TEST_LONG = 1: the longer variants the suite ran before its time budget was cut in round 5 (one more coarse step per case, the 64^2
+# C3 slab parity, two coarse steps in front of the plotfile comparison) -- kept, not deleted
+LONG = __import__("os").environ.get("IAMRX_TEST_LONG") == "1"
 
 PROB_LO, PROB_HI_XY = -1.0, 1.0
 
@@ -57,7 +60,7 @@ def _build(lib, n, nz, vort, kw, max_grid_size, blocking_factor=4):
     return amr, prob_lo, prob_hi
 
 
-@pytest.mark.parametrize("n", [32])          # (64: 50 s of oracle time; the GPU suite keeps its budget for the 64^3 step parity of test_gpu_ns.py)
+@pytest.mark.parametrize("n", [32, 64] if LONG else [32])          # (64: 50 s of oracle time; the GPU suite keeps its budget for the 64^3 step parity of test_gpu_ns.py)
 def test_double_shear_layer_slab_matches_the_oracle(gpu, n):
     """the slab (n x n x 4 base cells, C3's parameters: cfl 0.5, inviscid, periodic [-1,1]^2, regrid_int 1, ratio 2) for three coarse steps"""
     lib = gpu

@@ -8,6 +8,9 @@ import pytest
 import orc
 
 pytestmark = pytest.mark.gpu
+# IAMRX_TEST_LONG = 1: the longer variants the suite ran before its time budget was cut in round 5 (one more coarse step per case, the 64^2
+# C3 slab parity, two coarse steps in front of the plotfile comparison) -- kept, not deleted
+LONG = __import__("os").environ.get("IAMRX_TEST_LONG") == "1"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -17,11 +20,12 @@ def test_inputs_file_run_on_three_levels_and_its_plotfile(gpu, tmp_path, capsys)
     from iamr_amd.inputs import Inputs
     inp_file = os.path.join(HERE, "golden", "inputs.3d.taylorgreen_amr16")
     root = str(tmp_path / "plt")
-    assert R.main([inp_file, f"amr.plot_file={root}", "max_step=1", "amr.plot_int=1"]) == 0      # (one coarse step: the oracle's share of the suite's time)
+    nstep = 2 if LONG else 1                      # (one coarse step: the oracle's share of the suite's time)
+    assert R.main([inp_file, f"amr.plot_file={root}", f"max_step={nstep}", f"amr.plot_int={nstep}"]) == 0
     out = capsys.readouterr().out
     steps = [l for l in out.splitlines() if l.startswith("STEP =")]
-    assert len(steps) == 1 and "PLOTFILE:" in out
-    pf = PlotFile.read(root + "00001")
+    assert len(steps) == nstep and "PLOTFILE:" in out
+    pf = PlotFile.read(root + f"{nstep:05d}")
     assert len(pf.levels) == 3 and pf.ref_ratio == [2, 2] and pf.names == ["x_velocity", "y_velocity", "z_velocity", "density", "tracer"]
     assert [lv.domain[1] for lv in pf.levels] == [(15, 15, 15), (31, 31, 31), (63, 63, 63)]
     assert pf.levels[1].boxes == [((4, 4, 4), (27, 27, 27))] and len(pf.levels[2].boxes) == 2 and len(pf.levels[0].boxes) == 8
@@ -32,7 +36,8 @@ def test_inputs_file_run_on_three_levels_and_its_plotfile(gpu, tmp_path, capsys)
     for l in range(3):
         oa.set_state(l, orc.taylorgreen_state(*oa.cell_centres(l), c=1.0))
     oa.post_init()
-    oa.step()
+    for _ in range(nstep):
+        oa.step()
     assert abs(pf.time - oa.time()) <= 1e-9 * oa.time()
     for l in range(3):
         So = oa.state(l)

@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rm -rf /tmp/pmc_$c
-    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $root/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-multibox --no-shard-proxy --no-upstream-shape --amr-steps 0 --ldc-steps 0 > $out/${tag}_pmc_$c.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $root/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-multibox --no-shard-proxy --no-upstream-shape --amr-steps 0 --ldc-steps 0 --c3-n 0 --rt-n 0 > $out/${tag}_pmc_$c.log 2>&1
     f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
     test -n "$f" && cp "$f" $out/${tag}_pmc_$(echo $c | tr A-Z a-z).csv
 done

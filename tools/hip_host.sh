@@ -1,6 +1,6 @@
 #!/bin/bash
 # host side of a step: HIP runtime API statistics (rocprofv3 --hip-runtime-trace --stats) of tools/${DBG:-run_steps.py} and the host's
-# launch-to-launch cadence between synchronisation points
+# launch-to-launch cadence between synchronisation points (round 5: tools/r5_hip.sh)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ph
