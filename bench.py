@@ -597,8 +597,14 @@ def main():
 
     # SURVEY 8d's protocol: `repeats` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides and reduced
     # with MAX over the ranks; the reported region is the median one
+    def nexch():
+        v = (C.c_size_t * 4)()
+        lib.check(lib.lib().iamrx_exchange_counts(v))
+        return list(v)
+
     m0 = nmalloc()
     s0 = nsync()
+    x0 = nexch()
     regions = []
     for _rep in range(max(1, a.repeats)):
         barrier()
@@ -623,6 +629,12 @@ def main():
     nreg = len(regions)
     mallocs_in_loop = nmalloc() - m0
     syncs_in_loop = (nsync() - s0) / nreg
+    x1 = nexch()
+    nst = max(1, nreg * a.steps)
+    # halo exchanges of this rank per step: issued on the main stream in front of the kernel that needs them (exposed) / on the side stream
+    # beside interior work (hidden as far as that work lasts), iamrx_exchange_counts; N = 1: none
+    exch = {"exposed_per_step": (x1[0] - x0[0]) / nst, "exposed_MB_per_step": (x1[1] - x0[1]) * 8 / 1e6 / nst,
+            "overlapped_per_step": (x1[2] - x0[2]) / nst, "overlapped_MB_per_step": (x1[3] - x0[3]) * 8 / 1e6 / nst}
     el = sorted(regions)[nreg // 2]
     cells_total = float(n) ** 3 * world
     value = cells_total * a.steps / el
@@ -756,6 +768,7 @@ def main():
             "device_mallocs_in_timed_region": mallocs_in_loop,
             "host_syncs_per_step": syncs_in_loop / a.steps,
             "transport": transport if world > 1 else "none (single GPU)",
+            "halo_exchanges_rank0": exch,
             "kernels": kr,
             "roofline": roofline_gs4,
             "roofline_abec_sweep": roofline_abec,

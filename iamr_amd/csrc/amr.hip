@@ -17,7 +17,7 @@ namespace iamrx {
 
 namespace {
 struct PCKey {
-    uint64_t dl, sl; IndexType t; int dng, sng; int per[3]; int dlo[3], dhi[3];
+    uint64_t dl, sl; IndexType t; int dng, sng; int per[3]; int dlo[3], dhi[3]; int unique;
     bool operator<(const PCKey& o) const { return std::memcmp(this, &o, sizeof(PCKey)) < 0; }
 };
 CopyDesc* upload_descs(const std::vector<CopyDesc>& v)
@@ -31,12 +31,18 @@ CopyDesc* upload_descs(const std::vector<CopyDesc>& v)
 }
 }  // namespace
 
+namespace { void box_diff(const BoxD& b, const BoxD& cut, std::vector<BoxD>& out); }   // b minus cut (below)
+
 // host-only plan construction (rank `me`): every rank walks (dst box, src box, periodic image) in the same order, so the
 // pack order of a sender equals the unpack order of its receiver
 void build_parallel_copy_plan_host(const std::vector<BoxD>& dboxes, const std::vector<int>& downer, const std::vector<int>& dlocal_of,
                                    const std::vector<BoxD>& sboxes, const std::vector<int>& sowner, const std::vector<int>& slocal_of, int me,
-                                   IndexType t, int dst_ng, int src_ng, const Geometry* pg, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers)
+                                   IndexType t, int dst_ng, int src_ng, const Geometry* pg, CopyPlan& plan, std::map<int, CopyPlan::Peer>& peers, bool unique)
 {
+    // unique (a plain copy, not an accumulation, of nodal / face data: boxes share the points on their faces): every destination point takes ONE source -- the first in the global order below -- as in
+    // the FillBoundary plans (mf.hip).  Without it two descriptors of one launch wrote the same point, and where the copies differ in the
+    // last bits (the two boxes' values of a shared pressure node, stale ghost cells) the result depended on which workgroup came last
+    // (round 6: found when the work lists changed the order and a two-rank regrid moved by 1e-8).
     int smin[3] = {0, 0, 0}, smax[3] = {0, 0, 0};
     if (pg) for (int d = 0; d < 3; ++d) if (pg->periodic[d]) { smin[d] = -1; smax[d] = 1; }
     // (source boxes that meet a destination region through a bin index, mf.h BoxBins: the same descriptors in the same order as a scan
@@ -65,17 +71,29 @@ void build_parallel_copy_plan_host(const std::vector<BoxD>& dboxes, const std::v
             if (a.sy != b.sy) return a.sy < b.sy;
             return a.sx < b.sx;
         });
+        std::vector<BoxD> planned;
         for (const Cand& c : cand) {
-            {
-                const int gs = c.gs, sx = c.sx, sy = c.sy, sz = c.sz;
-                const bool src_mine = sowner[gs] == me;
-                if (!dst_mine && !src_mine) continue;
-                int sh[3] = {0, 0, 0};
-                if (pg) { sh[0] = sx * pg->domain.len(0); sh[1] = sy * pg->domain.len(1); sh[2] = sz * pg->domain.len(2); }
-                BoxD sreg = sregs[gs];
-                for (int d = 0; d < 3; ++d) sreg = shift(sreg, d, sh[d]);
-                const BoxD is = intersect(dreg, sreg);
-                if (!is.ok()) continue;
+            const int gs = c.gs, sx = c.sx, sy = c.sy, sz = c.sz;
+            const bool src_mine = sowner[gs] == me;
+            if (!unique && !dst_mine && !src_mine) continue;
+            int sh[3] = {0, 0, 0};
+            if (pg) { sh[0] = sx * pg->domain.len(0); sh[1] = sy * pg->domain.len(1); sh[2] = sz * pg->domain.len(2); }
+            BoxD sreg = sregs[gs];
+            for (int d = 0; d < 3; ++d) sreg = shift(sreg, d, sh[d]);
+            const BoxD is0 = intersect(dreg, sreg);
+            if (!is0.ok()) continue;
+            std::vector<BoxD> parts{is0};
+            if (unique) {
+                for (const BoxD& q : planned) {
+                    std::vector<BoxD> next;
+                    for (const BoxD& pp : parts) box_diff(pp, q, next);
+                    parts.swap(next);
+                    if (parts.empty()) break;
+                }
+                for (const BoxD& pp : parts) planned.push_back(pp);
+                if (!dst_mine && !src_mine) continue;          // (somebody else's pair: book-keeping only, so that every rank cuts the same pieces)
+            }
+            for (const BoxD& is : parts) {
                 CopyDesc cd;
                 cd.region = is;
                 for (int d = 0; d < 3; ++d) cd.shift[d] = -sh[d];
@@ -117,6 +135,13 @@ void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int
     PCKey key;
     std::memset(&key, 0, sizeof(key));
     key.dl = dst.layout->id; key.sl = src.layout->id; key.t = dst.type; key.dng = dst_ng; key.sng = src_ng;
+    // a plain copy whose sources can overlap takes one source per destination point (see build_parallel_copy_plan_host)
+    // (nodal / face data only: the copies of a shared point are the same value up to rounding.  Copies that take ghost CELLS as sources --
+    // the translation between a level's merged and its caller's layout -- keep every overlapping descriptor: there the copies can be
+    // different things (one box's filled ghost cell, another's stale one; the valid data follow in a second pass), and "first" instead of
+    // "whichever workgroup comes last" changed results by 6e-4 in tests/test_gpu_dist.py)
+    const bool unique = !add && !dst.type.cell() && tune("PCOPY_UNIQUE", 1) != 0;
+    key.unique = unique ? 1 : 0;
     if (periodic_geom) for (int d = 0; d < 3; ++d) { key.per[d] = periodic_geom->periodic[d]; key.dlo[d] = periodic_geom->domain.lo[d]; key.dhi[d] = periodic_geom->domain.hi[d]; }
     auto it = cache.find(key);
     if (it == cache.end()) {
@@ -124,7 +149,7 @@ void parallel_copy(MultiFab& dst, const MultiFab& src, int scomp, int dcomp, int
         std::map<int, CopyPlan::Peer> peers;
         const Layout &dl = *dst.layout, &sl = *src.layout;
         build_parallel_copy_plan_host(dl.boxes, dl.owner, dl.local_of, sl.boxes, sl.owner, sl.local_of, Context::get().comm->rank,
-                                      dst.type, dst_ng, src_ng, periodic_geom, *plan, peers);
+                                      dst.type, dst_ng, src_ng, periodic_geom, *plan, peers, unique);
         plan->d_local = upload_descs(plan->local);
         for (auto& kv : peers) {
             kv.second.d_pack = upload_descs(kv.second.pack);
@@ -234,6 +259,7 @@ const FPInfo& fp_info(const Layout& dl, const Layout& fl, int ng, int ratio, con
     for (int d = 0; d < 3; ++d) { key.per[d] = fgeom.periodic[d]; key.dlo[d] = fgeom.domain.lo[d]; key.dhi[d] = fgeom.domain.hi[d]; }
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
+    ProfScope ps_prof_("fp_info_build");
     auto info = std::make_unique<FPInfo>();
     const int me = Context::get().comm->rank;
     // fine valid boxes and their periodic images
@@ -250,10 +276,16 @@ const FPInfo& fp_info(const Layout& dl, const Layout& fl, int ng, int ratio, con
     for (int d = 0; d < 3; ++d) if (fgeom.periodic[d]) { dext.lo[d] -= ng; dext.hi[d] += ng; }
     std::vector<BoxD> fboxes, cboxes;
     std::vector<int> owners, dst_of;
+    // (the covered boxes that can cut a destination region through a bin index, mf.h BoxBins: a scan of all of them for every
+    // destination box was quadratic in the number of boxes of a regridded level; same order, same pieces)
+    const BoxBins cov_index(covered);
+    std::vector<int> hits;
     for (int g = 0; g < (int)dl.boxes.size(); ++g) {
         std::vector<BoxD> todo{intersect(grow(dl.boxes[g], ng), dext)};
         if (!todo[0].ok()) continue;
-        for (auto& c : covered) {
+        cov_index.query(todo[0], hits);
+        for (int ci : hits) {
+            const BoxD& c = covered[ci];
             std::vector<BoxD> next;
             for (auto& t : todo) box_diff(t, c, next);
             todo.swap(next);

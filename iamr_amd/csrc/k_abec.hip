@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb(Tiling t, const BoxD* __restr
     const FabD* __restrict__ cfmt, CfC1 cfc, int sig_comp = 0, double sig_scale = 1.0, BUni bu = BUni(), const WallK* __restrict__ wkp = nullptr)
 {
     constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = boxes[fab];
     BoxD hb = b;
     hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k_abec_gsrb1(Tiling t, const BoxD* __rest
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
     const FabD* __restrict__ cfmt, CfC1 cfc, int zero, const WallK* __restrict__ wkp = nullptr)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = boxes[fab];
     BoxD hb = b;
     hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
     double alpha, double dhx, double dhy, double dhz, int redblack, double omega, GsrbBC bc, int wrap, int sig_comp, double sig_scale, BUni bu,
     const FabD* __restrict__ cfmt, CfC1 cfc, int zero, int comp, int bq)
 {
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = boxes[fab];
     BoxD hb = b;
     hb.hi[0] = b.lo[0] + (b.len(0) + 1) / 2 - 1;
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256, (CF ? 4 : 1)) k_abec_gsrb2(Tiling t, cons
     FabD S; if (BMODE == 1) S = sgt[fab];
     const bool has_a = (at != nullptr) && alpha != 0.0;
     FabD A; if (has_a) A = at[fab];
-    const int bx = 1 << t.bxs, tx = (int)threadIdx.x & (bx - 1);
+    const int bx = 1 << tile_bxs(t), tx = (int)threadIdx.x & (bx - 1);
     const int iL = b.lo[0] + 2 * (ih - b.lo[0]), iR = iL + 1;
     // the neighbour lane of the row exists (same wavefront, same row, inside the box)?
     const bool laneL = tx > 0 && iL > b.lo[0], laneR = tx < bx - 1 && tx < 63 && iR + 1 <= b.hi[0];
@@ -1365,8 +1365,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
     if (phi.nlocal() == 0) return;
     auto& ctx = Context::get();
     const Layout& l = *phi.layout;
-    int ml[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
-    Tiling t = make_tiling(ml, l.nlocal(), 8);
+    Tiling t = pair_tiling(l, 8);                 // (a flat tile list on a level of unequal boxes: launch.h)
     const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
     GsrbBC gb = make_gsrb_bc(g, bcs, nbc);
     // the scalar (MAC projection / scalar diffusion) colour pass over whole boxes can be timed in place (bench.py)
@@ -1386,8 +1385,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
                            c.a ? c.a->d_tab : nullptr, t0, t1, t2, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, c.sig_comp, c.sig_scale, bu, cft, cfc, zero, wk)
         // IAMRX_GSRB2 (1): the pair-marching kernel where the coefficients are not arrays (needs a ghost layer for its 16-byte loads)
         if (pair_ok) {
-            int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
-            Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
+            Tiling t2 = pair_tiling(l, (int)tune("GSRB2_TZ", 32));
 #define IAMRX_GS2(M, C, MT, SG, SC, SS) hipLaunchKernelGGL((k_abec_gsrb2<M, C, MT>), t2.grid(), Tiling::block(), 0, ctx.stream, t2, l.d_boxes, phi.d_tab, rhs.d_tab, \
                                    c.a ? c.a->d_tab : nullptr, SG, c.alpha, dhx, dhy, dhz, redblack, omega, gb, wrap ? 1 : 0, SC, SS, bu, cft, cfc, zero, 0, 0)
             const bool mt = cft && cfc.maintain;
@@ -1427,8 +1425,7 @@ void abec_gsrb(const Geometry& g, const AbecCoef& c, MultiFab& phi, const MultiF
         // the red-black layout at the achievable HBM rate): several components with constant coefficients (the tensor solves of a
         // constant-viscosity run, the unit-coefficient tensor solve of diffuse_tensor_Vsync) as one pair-marching launch per component
         // with its own constants b_d (x 4/3 on the normal component of the tensor operator) -- the expressions of k_abec_gsrb<true, 2>
-        int ml2[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
-        Tiling t2 = make_tiling(ml2, l.nlocal(), (int)tune("GSRB2_TZ", 32));
+        Tiling t2 = pair_tiling(l, (int)tune("GSRB2_TZ", 32));
         for (int n = 0; n < phi.ncomp; ++n) {
             BUni bn;
             for (int d = 0; d < 3; ++d) bn.v[d] = bu.v[d] * ((c.tensor_eta && n == d) ? 4.0 / 3.0 : 1.0);
@@ -1646,7 +1643,7 @@ __global__ void __launch_bounds__(256) k_abec_residual(Tiling t, const BoxD* __r
     int sig_comp, double sig_scale, BUni bu)
 {
     constexpr bool SIG = BMODE == 1, UNI = BMODE == 2;
-    const int fab = blockIdx.y;
+    const int fab = tile_fab(t);
     const BoxD b = boxes[fab];
     int i, j, k0, k1;
     double mx = 0.0;
@@ -1705,7 +1702,7 @@ void abec_residual(const Geometry& g, const AbecCoef& c, MultiFab& out, const Mu
     if (norm_out && !d_norm) IAMRX_HIP_CHECK(hipMalloc(&d_norm, 2 * sizeof(unsigned long long)));
     if (phi.nlocal() > 0) {
         const Layout& l = *phi.layout;
-        Tiling t = level_tiling(l, cell_type(), 0, 8);
+        Tiling t = level_tiling(l, cell_type(), 0, 8, true);        // (a flat tile list on a level of unequal boxes: launch.h)
         const double dhx = c.beta / (g.dx[0] * g.dx[0]), dhy = c.beta / (g.dx[1] * g.dx[1]), dhz = c.beta / (g.dx[2] * g.dx[2]);
         if (norm_out) IAMRX_HIP_CHECK(hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx.stream));
         if (rhs && abec_residual_pairs(g, c, out, phi, *rhs, norm_out ? d_norm : nullptr)) { /* done by the pair march */ }
@@ -2589,15 +2586,19 @@ void cf_build_mask(const Geometry& g, MultiFab& cfm)
 // grid: x = points of one ghost slab, y = box, z = the six slabs of the one-cell shell around the box (slab 2 d + side: the ghost layer
 // of direction d, transverse ranges grown by one so that edges and corners are covered; a cell on an edge belongs to two or three
 // slabs and receives the same value from each).  The shell is 6 n^2 points, the grown box the kernel used to scan (n + 2)^3.
+// list (a level of many unequal boxes, cf_fill_ghosts): entry b = (box, slab, first point of the workgroup) instead of a grid sized for the
+// largest slab of the largest box
 __global__ void __launch_bounds__(256) k_cf_fill(const BoxD* __restrict__ boxes, const FabD* __restrict__ phit,
-    const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog, int edges)
+    const FabD* __restrict__ bcvt, const FabD* __restrict__ cfmt, int ncomp, CfTab tab, int inhomog, int edges, const int4* __restrict__ list)
 {
-    const int fab = blockIdx.y;
+    int fab = blockIdx.y, slab = blockIdx.z;
+    long q0 = (long)blockIdx.x * 256;
+    if (list) { const int4 e = list[blockIdx.x]; fab = e.x; slab = e.y; q0 = e.z; }
     const BoxD vb = boxes[fab];
-    const int sd = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int sd = slab >> 1, side = slab & 1;
     const int da = sd == 0 ? 1 : 0, db = sd == 2 ? 1 : 2;                // transverse directions, da < db
     const int na = vb.len(da) + 2, nb = vb.len(db) + 2;
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long q = q0 + threadIdx.x;
     if (q >= (long)na * nb) return;
     int idx3[3];
     idx3[sd] = side == 0 ? vb.lo[sd] - 1 : vb.hi[sd] + 1;
@@ -2638,8 +2639,26 @@ void cf_fill_ghosts(MultiFab& phi, const MultiFab& cfm, const CfTab& tab, bool i
     int m[3] = {l.max_len[0] + 2, l.max_len[1] + 2, l.max_len[2] + 2};
     std::sort(m, m + 3);
     const long maxpts = (long)m[1] * m[2];                    // the largest slab
+    if (l.nlocal() >= 4 && tune("TILE_LISTS", 1) != 0) {
+        int n = 0;
+        const int4* lst = layout_int4_list(l, {2, 0, 0, 0, 0}, [&](std::vector<int4>& h) {
+            for (int f = 0; f < l.nlocal(); ++f) {
+                const BoxD b = l.lbox(f);
+                for (int sl = 0; sl < 6; ++sl) {
+                    const int sd = sl >> 1, da = sd == 0 ? 1 : 0, db = sd == 2 ? 1 : 2;
+                    const long np = (long)(b.len(da) + 2) * (b.len(db) + 2);
+                    for (long q0 = 0; q0 < np; q0 += 256) h.push_back(make_int4(f, sl, (int)q0, 0));
+                }
+            }
+        }, &n);
+        if (lst && 4L * n <= 3L * ((maxpts + 255) / 256) * l.nlocal() * 6) {
+            hipLaunchKernelGGL(k_cf_fill, dim3((unsigned)n), dim3(256), 0, Context::get().stream,
+                               l.d_boxes, phi.d_tab, bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0, lst);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_cf_fill, dim3((unsigned)((maxpts + 255) / 256), (unsigned)l.nlocal(), 6u), dim3(256), 0, Context::get().stream,
-                       l.d_boxes, phi.d_tab, bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0);
+                       l.d_boxes, phi.d_tab, bcval ? bcval->d_tab : nullptr, cfm.d_tab, phi.ncomp, tab, inhomog ? 1 : 0, edges ? 1 : 0, (const int4*)nullptr);
 }
 
 // bcval(edge / corner coarse-fine ghost cells) = the coarse data of cpatch interpolated to the cell centre, quadratically in every

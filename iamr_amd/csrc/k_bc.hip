@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_nodal_reflect(const ReflDesc* __restric
     }
 }
 
-void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc)
+void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc, hipStream_t on)
 {
     if (mf.nlocal() == 0 || mf.ngrow == 0) return;
     auto& ctx = Context::get();
@@ -166,7 +166,7 @@ void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc)
         }, nd, maxpts);
     if (nd == 0) return;
     long nb = (maxpts + 255) / 256; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_nodal_reflect, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, ctx.stream, dd, mf.d_tab, W, mf.ncomp);
+    hipLaunchKernelGGL(k_nodal_reflect, dim3((unsigned)nb, (unsigned)nd), dim3(256), 0, on ? on : ctx.stream, dd, mf.d_tab, W, mf.ncomp);
 }
 
 // cell-centred mirror across every non-periodic wall (mlndlap_fillbc_cc for sigma): reflect_even on all faces

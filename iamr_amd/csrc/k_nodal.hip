@@ -67,16 +67,19 @@ __device__ __forceinline__ void nodal_norm_commit(double mx, unsigned long long*
 }
 template <int TX, int TY>
 __global__ void __launch_bounds__(TX * TY) k_nodal_residual_zm(const BoxD* __restrict__ boxes, const FabD* __restrict__ ot, const FabD* __restrict__ xt,
-    const FabD* __restrict__ st, const FabD* __restrict__ rt, NodeW w, int ntx, int nty, int kc, unsigned long long* __restrict__ normout)
+    const FabD* __restrict__ st, const FabD* __restrict__ rt, NodeW w, int ntx, int nty, int kc, unsigned long long* __restrict__ normout,
+    const int4* __restrict__ list)
 {
     double mx = 0.0;
     constexpr int RX = TX + 2, RY = TY + 2, NT = TX * TY, NLD = (RX * RY + NT - 1) / NT;
     __shared__ double X[3][RY][RX];
     __shared__ double S[2][RY][RX];
-    const int fab = blockIdx.y;
+    // list (a level of many unequal boxes): entry b = (box, tile x, tile y, z-chunk) of the tiles that exist, instead of the tile grid of the
+    // largest box for every box
+    int fab = blockIdx.y, tix, tiy, ck;
+    if (list) { const int4 e = list[blockIdx.x]; fab = e.x; tix = e.y; tiy = e.z; ck = e.w; }
+    else { const int bid = blockIdx.x; tix = bid % ntx; const int r1 = bid / ntx; tiy = r1 % nty; ck = r1 / nty; }
     const BoxD cb = boxes[fab];
-    const int bid = blockIdx.x;
-    const int tix = bid % ntx, r1 = bid / ntx, tiy = r1 % nty, ck = r1 / nty;
     const int nhi0 = cb.hi[0] + 1, nhi1 = cb.hi[1] + 1, nhi2 = cb.hi[2] + 1;
     const int tx0 = cb.lo[0] + tix * TX, ty0 = cb.lo[1] + tiy * TY, k0 = cb.lo[2] + ck * kc;
     if (tx0 > nhi0 || ty0 > nhi1 || k0 > nhi2) return;
@@ -189,8 +192,24 @@ void nodal_residual_launch(const Geometry& g, MultiFab& out, const MultiFab& x, 
         const int nk = l.max_len[2] + 1;
         const int kc = nk >= 128 ? 32 : (nk >= 32 ? 16 : nk);
         const int nck = (nk + kc - 1) / kc;
+        if (l.nlocal() >= 4 && tune("TILE_LISTS", 1) != 0) {
+            int n = 0;
+            const int4* lst = layout_int4_list(l, {3, TX, TY, kc, 0}, [&](std::vector<int4>& h) {
+                for (int f = 0; f < l.nlocal(); ++f) {
+                    const BoxD b = l.lbox(f);
+                    const int bx = (b.len(0) + 1 + TX - 1) / TX, by = (b.len(1) + 1 + TY - 1) / TY, bk = (b.len(2) + 1 + kc - 1) / kc;
+                    for (int c = 0; c < bk; ++c) for (int ty = 0; ty < by; ++ty) for (int tx = 0; tx < bx; ++tx) h.push_back(make_int4(f, tx, ty, c));
+                }
+            }, &n);
+            if (lst && 4L * n <= 3L * ntx * nty * nck * l.nlocal()) {
+                hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), dim3((unsigned)n), dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc,
+                                   d_norm, lst);
+                return;
+            }
+        }
         dim3 grid((unsigned)(ntx * nty * nck), (unsigned)l.nlocal());
-        hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc, d_norm);
+        hipLaunchKernelGGL((k_nodal_residual_zm<TX, TY>), grid, dim3(TX * TY), 0, Context::get().stream, l.d_boxes, ot, xt, st, rt, w, ntx, nty, kc, d_norm,
+                           (const int4*)nullptr);
         return;
     }
     for_each(*x.layout, node_type(), 0, Context::get().stream, [=] __device__(int i, int j, int k, int f) {
@@ -532,6 +551,7 @@ struct GsrGeom {
     int xcd_chunk;      // > 0: XCD-aware order, chunks per tile
     int zc, zn;         // the array the own-parity planes (zc) / the other-parity planes (zn) come from is identically zero: it is not read
     int refl;           // WRAP: bit d: direction d ends on Neumann walls -- mirror images instead of periodic ones (image_node / image_cell)
+    int sel;            // 1: only the tiles whose footprint and planes lie inside the box (they read no ghost node of x), 2: only the others, 0: all
 };
 
 // the update of one node, k_nodal_gs4's expression tree: x?[db + 1][da + 1] = x(i + da, j + db, plane), s?[db + 1][da + 1] = sigma of
@@ -603,6 +623,11 @@ __global__ void __launch_bounds__(32 * (64 / PB)) k_nodal_gsr(const BoxD* __rest
     if (k0 > nhi2 || tx0 > nhi0 || ty0 > nhi1) return;
     const int kend = min(k0 + 2 * (gg.ppc - 1), nhi2);
     const int txs = max(tx0, cb.lo[0]), txe = min(tx0 + gg.tix - 1, nhi0), tys = max(ty0, cb.lo[1]), tye = min(ty0 + gg.tiy - 1, nhi1);
+    if (gg.sel != 0) {
+        // two-part issue around a ghost exchange (NodalMG::smooth): colour pass c works on the tile grown by 3 - c and reads one node further
+        const bool inner = txs - 4 >= cb.lo[0] && txe + 4 <= nhi0 && tys - 4 >= cb.lo[1] && tye + 4 <= nhi1 && k0 - 1 >= cb.lo[2] && kend + 1 <= nhi2;
+        if ((gg.sel == 1) != inner) return;
+    }
     const FabD x = xct[fab], xn = xnt[fab], xo = xot[fab], r = rt[fab], s = st[fab];
     const int ox = tx0 - 4, oy = ty0 - 4;
     const int tid = threadIdx.x, lane = tid & 63, lx = lane & 31, q = (tid >> 6) * 2 + (lane >> 5);
@@ -969,9 +994,11 @@ static void gsr_tiles(int len_nodes, int& nt, int& pitch)
 
 template <int PB>
 static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig,
-                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int zero_flags, int refl)
+                       int kpar, bool wrap, const MultiFab* dmask, const double* csig, int zero_flags, int refl, int sel, hipStream_t on)
 {
     GsrGeom gg;
+    gg.sel = sel;
+    hipStream_t strm = on ? on : Context::get().stream;
     gg.zc = zero_flags & 1; gg.zn = (zero_flags >> 1) & 1;
     gg.refl = wrap ? refl : 0;
     gsr_tiles(l.max_len[0] + 1, gg.ntx, gg.tix);
@@ -995,8 +1022,8 @@ static void gsr_launch(const Layout& l, const Geometry& g, const MultiFab& xc, c
     if (tune("XCD_AWARE", 1) != 0 && total >= 16) { gg.xcd_chunk = npl; gx = 8u * (unsigned)((total + 7) / 8); }
     dim3 grid(gx, (unsigned)l.nlocal());
     constexpr int NT = 32 * (64 / PB);
-    const bool rec = kernel_probe_begin(PROBE_NODAL_GS4, (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1));
-#define IAMRX_GSR(W, M, C) hipLaunchKernelGGL((k_nodal_gsr<PB, W, M, C>), grid, dim3(NT), 0, Context::get().stream, l.d_boxes, xc.d_tab, xn.d_tab, \
+    const bool rec = sel == 0 && !on && kernel_probe_begin(PROBE_NODAL_GS4, (long)(l.max_len[0] + 1) * (l.max_len[1] + 1) * (l.max_len[2] + 1));
+#define IAMRX_GSR(W, M, C) hipLaunchKernelGGL((k_nodal_gsr<PB, W, M, C>), grid, dim3(NT), 0, strm, l.d_boxes, xc.d_tab, xn.d_tab, \
                                              xo.d_tab, rhs.d_tab, sig.d_tab, make_w(g), kpar, gg, dmask ? dmask->d_tab : nullptr, csig ? *csig : 0.0)
     if (dmask) {
         IAMRX_ASSERT(!wrap && dmask->ngrow >= 3 && !csig);
@@ -1046,8 +1073,19 @@ bool nodal_gsr_applies(const MultiFab& x, const MultiFab& rhs, const MultiFab* d
     return tune("GSR", 1) != 0 && l.max_len[0] >= tune("GSR_MIN", 48) && l.max_len[1] >= tune("GSR_MIN", 48) && mask_shapes_ok;
 }
 
+// the level is smoothed by k_nodal_gsr and its boxes hold tiles whose footprint lies inside the box (>= 3 tiles in x and y: 113 nodes)
+bool nodal_gsr_splits(const MultiFab& x, const MultiFab& rhs, const MultiFab* dmask)
+{
+    if (x.nlocal() == 0 || !nodal_gsr_applies(x, rhs, dmask)) return false;
+    const Layout& l = *x.layout;
+    int ntx, nty, p;
+    gsr_tiles(l.max_len[0] + 1, ntx, p);
+    gsr_tiles(l.max_len[1] + 1, nty, p);
+    return ntx >= 3 && nty >= 3 && l.max_len[2] >= 16;
+}
+
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar, bool wrap,
-                         const MultiFab* dmask, const double* csig, int zero_flags, int refl)
+                         const MultiFab* dmask, const double* csig, int zero_flags, int refl, int sel, hipStream_t on)
 {
     IAMRX_ASSERT(refl == 0 || wrap);
     const MultiFab& x = xc;
@@ -1059,11 +1097,11 @@ void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& 
     // updates but 8-wave barriers)
     // levels whose boxes are at least GSR_MIN cells long in x and y: the register-resident kernel (IAMRX_GSR=0: k_nodal_gs4 everywhere)
     if (nodal_gsr_applies(x, rhs, dmask)) {
-        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl);
-        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl);
+        if (tune("GSR_PB", 4) == 8) gsr_launch<8>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl, sel, on);
+        else gsr_launch<4>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, zero_flags, refl, sel, on);
         return;
     }
-    IAMRX_ASSERT(zero_flags == 0);       // k_nodal_gs4 reads its inputs
+    IAMRX_ASSERT(zero_flags == 0 && sel == 0 && !on);       // k_nodal_gs4 reads its inputs; the two-part issue is k_nodal_gsr's
     const int big = (int)tune("GS4_TILE", 0);
     if (big && l.max_len[1] + 1 > 16) gs4_launch<32, 32, 512>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, wrap ? refl : 0);
     else gs4_launch<32, 16, 256>(l, g, xc, xn, xo, rhs, sig, kpar, wrap, dmask, csig, wrap ? refl : 0);

@@ -42,7 +42,7 @@ struct DomainBC;
 // physical-BC fill of cell-centred ghost cells outside the domain; extdir_lo/hi[n*3+d] constant ext_dir values
 void fill_physbc_cc(const Geometry& g, MultiFab& mf, int scomp, int ncomp, const BCRec* bc, const double* extdir_lo, const double* extdir_hi);
 
-void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc);   // ghost nodes: even reflection about Neumann walls
+void nodal_reflect_bc(const Geometry& g, MultiFab& mf, const DomainBC& bc, hipStream_t on = nullptr);   // ghost nodes: even reflection about Neumann walls
 void cc_mirror_bc(const Geometry& g, MultiFab& mf);                           // cell-centred mirror across all non-periodic walls
 
 // ---- k_abec.hip ---------------------------------------------------------------------------
@@ -163,7 +163,11 @@ void nodal_gs_color(const Geometry& g, MultiFab& x, const MultiFab& rhs, const M
 // one k-parity pass of the plane-fused 8-colour GS (arrays need ngrow >= 4 / 3), out of place: plane k from xc, planes
 // k+-1 from xn, result to xo (xo != xc; xn may be either)
 void nodal_gs_fused_pass(const Geometry& g, const MultiFab& xc, const MultiFab& xn, MultiFab& xo, const MultiFab& rhs, const MultiFab& sig, int kpar,
-                         bool wrap = false, const MultiFab* dmask = nullptr, const double* csig = nullptr, int zero_flags = 0, int refl = 0);
+                         bool wrap = false, const MultiFab* dmask = nullptr, const double* csig = nullptr, int zero_flags = 0, int refl = 0,
+                         int sel = 0, hipStream_t on = nullptr);
+// sel (k_nodal_gsr only): 1 = the tiles that read no ghost node of x (footprint and planes inside the box), 2 = the others, 0 = all; on: the
+// stream of the launch (null: the context's).  nodal_gsr_splits: the level has tiles of the first kind
+bool nodal_gsr_splits(const MultiFab& x, const MultiFab& rhs, const MultiFab* dmask);
 // (wrap: one box spanning its domain, images instead of ghost nodes -- periodic ones, or mirror images in the directions of refl (bit d):
 // nodal_wrap_or_reflect_ok)
 // k_nodal_gsr takes the level: then zero_flags (bit 0: xc, bit 1: xn is identically zero and is not read) may be passed

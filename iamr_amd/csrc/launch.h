@@ -60,7 +60,9 @@ inline Tiling make_tiling(const int maxlen[3], int nfab, int tz = 4)
 }
 
 // (mf.hip) cached flat tile list of the local boxes of l (converted to type, grown by ng), tz planes per thread; *total = its length
-const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int tz, int* total);
+const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int tz, int* total, int xdiv = 1);
+// (mf.hip) any other device-resident int4 work list that belongs to a layout: built once per (layout, subkey), freed with the layout
+const int4* layout_int4_list(const Layout& l, const std::array<long, 5>& subkey, const std::function<void(std::vector<int4>&)>& build, int* total);
 
 // tiling for the local boxes of `l` converted to `type` and grown by ng.  allow_list: the kernel takes its box from tile_fab(t), so a level
 // whose boxes differ in size (a regridded refined level and its multigrid levels: boxes of 2 ... 32 cells side by side) may be given a flat
@@ -117,10 +119,25 @@ inline const D* cached_descs(std::map<std::array<long, 10>, std::tuple<D*, int, 
     return std::get<0>(it->second);
 }
 
+// the same for kernels that index a box through cell PAIRS in x (k_abec_gsrb2: tile space = the box with (len + 1) / 2 columns)
+inline Tiling pair_tiling(const Layout& l, int tz)
+{
+    int ml[3] = {(l.max_len[0] + 1) / 2, l.max_len[1], l.max_len[2]};
+    Tiling t = make_tiling(ml, l.nlocal(), tz);
+    if (l.nlocal() >= 4 && tune("TILE_LISTS", 1) != 0) {
+        int n = 0;
+        const int4* lst = level_tile_list(l, IndexType{{0, 0, 0}}, 0, t.tz, &n, 2);
+        const long plain = (long)t.ntx * t.nty * t.ntz * l.nlocal();
+        if (lst && 4L * n <= 3L * plain) { t.list = lst; t.nlist = n; t.xcd_cnt = 0; }
+    }
+    return t;
+}
+
 #ifdef __HIPCC__
 // decode (i, j, k-range) of this thread inside box b; returns false if (i,j) is outside
-// the box of this workgroup (kernels launched with a tiling that may carry a flat list)
+// the box of this workgroup (kernels launched with a tiling that may carry a flat list) and log2 of its row length in threads
 __device__ __forceinline__ int tile_fab(const Tiling& t) { return t.list ? t.list[blockIdx.x].x : (int)blockIdx.y; }
+__device__ __forceinline__ int tile_bxs(const Tiling& t) { return t.list ? (int)((unsigned)t.list[blockIdx.x].w >> 26) : t.bxs; }
 
 __device__ __forceinline__ bool tile_ijk(const Tiling& t, const BoxD& b, int& i, int& j, int& k0, int& k1)
 {

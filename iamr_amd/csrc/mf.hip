@@ -614,7 +614,9 @@ static CopyDesc* upload(const std::vector<CopyDesc>& v)
 }
 
 // ------------------------------------------------------------------ flat tile lists (launch.h: level_tiling with allow_list)
-const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int tz, int* total)
+// a device-resident list of int4 work items that belongs to a layout (flat tile lists, the ghost-shell list of k_cf_fill ...): built once
+// per (layout, subkey) by `build`, freed with the layout
+const int4* layout_int4_list(const Layout& l, const std::array<long, 5>& subkey, const std::function<void(std::vector<int4>&)>& build, int* total)
 {
     struct Entry { int4* d; int n; };
     using Key = std::array<long, 6>;
@@ -633,22 +635,16 @@ const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int 
         });
         return *c;
     }();
-    const Key key = {(long)l.id, type.t[0] + 2 * type.t[1] + 4 * type.t[2], ng, tz, 0, 0};
+    const Key key = {(long)l.id, subkey[0], subkey[1], subkey[2], subkey[3], subkey[4]};
     auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<int4> h;
-        for (int f = 0; f < l.nlocal(); ++f) {
-            const BoxD b = grow(convert(l.lbox(f), type.t), ng);
-            int bx = 64, bxs = 6;
-            while (bx > 4 && bx / 2 >= b.len(0)) { bx /= 2; --bxs; }
-            const int by = 256 / bx;
-            for (int k0 = 0; k0 < b.len(2); k0 += tz)
-                for (int j0 = 0; j0 < b.len(1); j0 += by)
-                    for (int i0 = 0; i0 < b.len(0); i0 += bx) h.push_back(make_int4(f, i0, j0, k0 | (bxs << 26)));
-        }
+        build(h);
         Entry e{nullptr, (int)h.size()};
         if (!h.empty()) {
             auto& ctx = Context::get();
+            // (stream-ordered like every use of the caching allocator's blocks: the block may have belonged to an array whose last
+            // kernel is still in flight on the launch stream -- a copy on the null stream would overtake it)
             e.d = (int4*)ctx.alloc(h.size() * sizeof(int4));
             IAMRX_HIP_CHECK(hipMemcpyAsync(e.d, h.data(), h.size() * sizeof(int4), hipMemcpyHostToDevice, ctx.stream));
             ctx.sync();
@@ -657,6 +653,22 @@ const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int 
     }
     *total = it->second.n;
     return it->second.d;
+}
+
+const int4* level_tile_list(const Layout& l, const IndexType& type, int ng, int tz, int* total, int xdiv)
+{
+    return layout_int4_list(l, {1, type.t[0] + 2 * type.t[1] + 4 * type.t[2], ng, tz, xdiv}, [&](std::vector<int4>& h) {
+        for (int f = 0; f < l.nlocal(); ++f) {
+            BoxD b = grow(convert(l.lbox(f), type.t), ng);
+            if (xdiv > 1) b.hi[0] = b.lo[0] + (b.len(0) + xdiv - 1) / xdiv - 1;       // tile space of a kernel that owns xdiv cells per thread
+            int bx = 64, bxs = 6;
+            while (bx > 4 && bx / 2 >= b.len(0)) { bx /= 2; --bxs; }
+            const int by = 256 / bx;
+            for (int k0 = 0; k0 < b.len(2); k0 += tz)
+                for (int j0 = 0; j0 < b.len(1); j0 += by)
+                    for (int i0 = 0; i0 < b.len(0); i0 += bx) h.push_back(make_int4(f, i0, j0, k0 | (bxs << 26)));
+        }
+    }, total);
 }
 
 BoxBins::BoxBins(std::vector<BoxD> boxes) : b(std::move(boxes))
@@ -943,9 +955,11 @@ static bool copy_work(const std::vector<CopyDesc>& descs, long maxpts, CopyWork&
                     for (long c = 0; c < nch; ++c) h.push_back(make_int2((int)q, (int)c));
                 }
                 auto& ctx = Context::get();
+                // (ordered on the launch stream like every use of the caching allocator's blocks, then waited for: the first use of a plan may
+                // come from the side stream)
                 w.d = (int2*)ctx.alloc(h.size() * sizeof(int2));
-                // (the first use may come from a side stream: a blocking copy, once per plan)
-                IAMRX_HIP_CHECK(hipMemcpy(w.d, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+                IAMRX_HIP_CHECK(hipMemcpyAsync(w.d, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, ctx.stream));
+                ctx.sync();
                 w.n = (int)h.size();
             }
         }

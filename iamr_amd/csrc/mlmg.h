@@ -246,7 +246,7 @@ private:
     int bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, double eps_abs, int& niters);
     bool bottom_on_device();     // the coarsest level is solved by k_nodal_bottom (single-workgroup launch, no host synchronisation)
     void subtract_mean(int l, MultiFab& mf);
-    void fillbc(int l, MultiFab& x, int kpar = -1);   // kpar = 0 / 1: refresh the ghost nodes of the z-planes of that parity only
+    void fillbc(int l, MultiFab& x, int kpar = -1, hipStream_t on = nullptr);   // kpar = 0 / 1: refresh the ghost nodes of the z-planes of that parity only
     Geometry m_g;
     DomainBC m_bc;
     MGOpts m_o;

@@ -166,12 +166,12 @@ void NodalMG::setSigma(const MultiFab& sig, int comp)
 }
 
 // ghost nodes: same-level + periodic images, then even reflection about Neumann walls
-void NodalMG::fillbc(int l, MultiFab& x, int kpar)
+void NodalMG::fillbc(int l, MultiFab& x, int kpar, hipStream_t on)
 {
     // the plane-fused smoother recomputes a 4-node halo in-plane but reaches only one plane up and down: exchange 1 plane in z
     const int ngv[3] = {x.ngrow, x.ngrow, 1};
-    x.FillBoundary(m_lev[l].g, 0, x.ncomp, ngv, kpar);
-    nodal_reflect_bc(m_lev[l].g, x, m_bc);
+    x.FillBoundary(m_lev[l].g, 0, x.ncomp, ngv, kpar, on);
+    nodal_reflect_bc(m_lev[l].g, x, m_bc, on);
 }
 
 void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bool leave_ghosts)
@@ -212,13 +212,39 @@ void NodalMG::smooth(int l, MultiFab& x, const MultiFab& rhs, bool x_is_zero, bo
         // pass: the odd planes before the even pass, the even planes before the odd pass (half the halo volume; on boxes stacked in
         // z, where one ghost plane is exchanged, every second message disappears).
         const bool par_fill = tune("NODAL_PARITY_FILL", 1) != 0;
-        for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
-            if (!wrap && !(zero_start && ns == 0)) fillbc(l, *a, (ns == 0 || !par_fill) ? -1 : 1);
+        // Overlap (IAMRX_HALO_OVERLAP as for the cell-centred sweep, CellMG::smooth_n; round 6): a pass of k_nodal_gsr whose ghost nodes have
+        // to be refreshed first is issued in two parts -- the tiles whose footprint and planes lie inside their box on the main stream; the
+        // exchange, the wall reflection and the remaining tiles on the context's side stream behind a fork -- and joined: the messages
+        // travel while the interior tiles run.  The two parts write disjoint nodes; the same doubles as the one-piece pass.
+        auto& ctx = Context::get();
+        const int ov_mode = (int)tune("HALO_OVERLAP", 1);
+        bool overlap = false;
+        if (!wrap && ov_mode != 0 && nodal_gsr_splits(x, rhs, dmk)) {
+            const int ngv[3] = {x.ngrow, x.ngrow, 1};
+            // (the plans are built and uploaded in front of any fork)
+            bool peers = false;
+            for (int kp = -1; kp <= 1; ++kp) peers = !fill_boundary_plan(*L.layout, node_type(), x.ngrow, L.g, ngv, kp).peers.empty() || peers;
+            overlap = ov_mode == 2 || peers;
+        }
+        auto pass = [&](MultiFab& filled, int fill_kpar, bool do_fill, const MultiFab& xc_, const MultiFab& xn_, MultiFab& xo_, int kpar, int zf) {
             const double* cs = m_csig ? &m_csig_val : nullptr;
+            if (do_fill && overlap) {
+                ctx.fork_side();
+                nodal_gs_fused_pass(L.g, xc_, xn_, xo_, rhs, L.sig, kpar, wrap, dmk, cs, zf, refl, 1, ctx.stream);
+                fillbc(l, filled, fill_kpar, ctx.side);
+                nodal_gs_fused_pass(L.g, xc_, xn_, xo_, rhs, L.sig, kpar, wrap, dmk, cs, zf, refl, 2, ctx.side);
+                ctx.join_side();
+                return;
+            }
+            if (do_fill) fillbc(l, filled, fill_kpar);
+            nodal_gs_fused_pass(L.g, xc_, xn_, xo_, rhs, L.sig, kpar, wrap, dmk, cs, zf, refl);
+        };
+        for (int ns = 0; ns < m_o.nodal_sweeps; ++ns) {
             const bool z = zero_start && ns == 0;
-            nodal_gs_fused_pass(L.g, *a, *a, *b, rhs, L.sig, 0, wrap, dmk, cs, z ? 3 : 0, refl);      // even planes: a -> b
-            if (!wrap) fillbc(l, *b, par_fill ? 0 : -1);                     // ghost images of the new even planes
-            nodal_gs_fused_pass(L.g, *a, *b, *b, rhs, L.sig, 1, wrap, dmk, cs, z ? 1 : 0, refl);      // odd planes: centre from a, neighbours from b
+            // even planes: a -> b (ghost nodes of a refreshed first: all planes in front of the first sweep, then the odd ones)
+            pass(*a, (ns == 0 || !par_fill) ? -1 : 1, !wrap && !z, *a, *a, *b, 0, z ? 3 : 0);
+            // odd planes: centre from a, neighbours from b (the ghost images of b's new even planes first)
+            pass(*b, par_fill ? 0 : -1, !wrap, *a, *b, *b, 1, z ? 1 : 0);
             std::swap(a, b);
         }
         if (a != &x) MultiFab::Copy(x, *a, 0, 0, 1, 0);

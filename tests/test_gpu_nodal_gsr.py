@@ -171,3 +171,28 @@ def test_mirror_images_at_neumann_walls_equal_the_ghost_fills(gpu, n, per):
     assert out[1][0] == out[0][0] and out[1][1] == out[0][1], (out[1][:2], out[0][:2])
     assert np.array_equal(out[1][3], out[0][3]), float(np.abs(out[1][3] - out[0][3]).max())
     assert np.array_equal(out[1][2], out[0][2])
+
+
+@pytest.mark.boxes_kept
+@pytest.mark.parametrize("case", ["periodic", "walls", "patch"])
+def test_pass_issued_in_two_parts_on_two_streams_gives_the_same_doubles(gpu, case):
+    """round 6: IAMRX_HALO_OVERLAP = 2 forces what a multi-rank run does by itself -- every pass of k_nodal_gsr whose
+    ghost nodes are refreshed first is issued as the tiles that read no ghost node on the main stream, and the exchange + wall reflection +
+    the remaining tiles on the side stream behind a fork, joined afterwards.  Same doubles as the one-piece pass (HALO_OVERLAP = 0), on two
+    boxes of 128 x 128 cells in-plane (3 x 3 tiles each: one interior tile per box and z-chunk), with walls, and on a refined patch (mask)."""
+    lib = gpu
+    if case == "periodic":
+        kw = dict(n=(256, 128, 64), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3, boxes=[((0, 0, 0), (127, 127, 63)), ((128, 0, 0), (255, 127, 63))])
+    elif case == "walls":
+        kw = dict(n=(128, 256, 48), per=(0, 0, 0), lobc=(NEUMANN,) * 3, hibc=(NEUMANN,) * 3, boxes=[((0, 0, 0), (127, 127, 47)), ((0, 128, 0), (127, 255, 47))])
+    else:
+        kw = dict(n=(320, 192, 64), per=(1, 1, 1), lobc=(PERIODIC,) * 3, hibc=(PERIODIC,) * 3, boxes=[((32, 32, 8), (159, 159, 55)), ((160, 32, 8), (287, 159, 55))])
+    out = {}
+    for ov in (0, 2):
+        lib.tuning_set("HALO_OVERLAP", ov)
+        try:
+            out[ov] = solve_case(lib, seed=5, sigma_const=False, iters=2, **kw)
+        finally:
+            lib.tuning_set("HALO_OVERLAP", 1)
+    for a, b in zip(out[0], out[2]):
+        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a - b).max())
