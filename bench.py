@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-PMC_FILE = "round5_pmc.json"
+PMC_FILE = "round6_pmc.json"
 
 
 def parse():
@@ -691,7 +691,7 @@ def main():
             rb_grid = 8 * ((nty * nch + 7) // 8) * 1024
             roofline_abec = {"kernel": "k_abec_gsrb_rb<1, 16, false, false, false, false, false, false> (a red AND a black pass of the cell-centred GSRB smoother of the MAC projection in one "
                                        "out-of-place launch, face coefficients recomputed from the cell-centred density once per face; "
-                                       "profiles/round5_kernel_stats.csv)", "bound": "hbm",
+                                       "profiles/round6_final_kernel_stats.csv)", "bound": "hbm",
                              "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                              "traffic": pmc_traffic("k_abec_gsrb_rb<1, 16, false, false, false, false, false, false> grid=%d" % rb_grid),
                              "algorithmic_bytes_per_launch": own, "avg_ms": ms,
@@ -700,7 +700,7 @@ def main():
                              "launches_timed": gsrb_insitu[1] if gsrb_insitu else None,
                              "timing": "HIP events around every 7th finest-level launch inside the timed steps" if gsrb_insitu else "isolated loop",
                              "isolated_loop_ms_array_coefficients_two_colour_passes": gsrb_iso["ms"]}
-        # the kernel with the largest summed duration of the step (profiles/round5_kernel_stats.csv: k_nodal_gsr over its launch grids, ahead of
+        # the kernel with the largest summed duration of the step (profiles/round6_final_kernel_stats.csv: k_nodal_gsr over its launch grids, ahead of
         # k_abec_gsrb_rb and k_god_z) is the nodal Gauss-Seidel pass: it is `roofline`; the MAC sweep and the Godunov kernels are reported beside it
         dom = kr.get("nodal_gs4_launch")
         roofline_gs4 = None

@@ -26,6 +26,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "both_box_modes: run in both box modes regardless of the merge counter")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a hung rendezvous or device wait must cost one test, not the driver's whole GPU-test budget (pytest-timeout is in the image)
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if "gpu" in it.keywords and it.get_closest_marker("timeout") is None:
+                it.add_marker(pytest.mark.timeout(420))
+
+
 @pytest.fixture(scope="session")
 def orc():
     import orc as _orc

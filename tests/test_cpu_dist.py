@@ -150,7 +150,10 @@ def worker(rank, world, port, out_dir):
 def test_two_rank_gloo_halo_exchange_matches_single_rank(orc, tmp_path):
     import torch.multiprocessing as mp
     ref = reference_single_box(orc)
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:        # a free port (a pid-derived one can collide with a lingering socket)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.zeros(N)
     gmax = []

@@ -16,6 +16,15 @@ BOXES = [((0, 0, 0), (15, 15, 7)), ((0, 0, 8), (15, 15, 15))]
 NSTEPS = 2
 
 
+def free_port():
+    """a TCP port nobody listens on right now (a port derived from the pid collided with a lingering socket once in round 6: the rendezvous
+    of one test then waited ten minutes inside the driver's time budget)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run(rank, world, port, out_dir, agg, case="tg"):
     sys.path.insert(0, ROOT)
     global N, BOXES
@@ -215,10 +224,10 @@ def test_amr_bench_workload_sharded_over_ranks(tmp_path, nr):
     """the AMR workload of bench.py --gpus nr (base level and refined level each one box per GPU) on nr ranks sharing the GPU: every box of
     both levels, the time steps and the iteration counts of the sync solves equal the run of ONE rank holding the same 2 nr boxes"""
     import torch.multiprocessing as mp
-    port = 33100 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, f"amrbench{nr}"), nprocs=1, join=True)
     ref = np.load(os.path.join(str(tmp_path), "amrbench_w1_r0.npz"))
-    mp.spawn(run, args=(nr, port + 7, str(tmp_path), None, f"amrbench{nr}"), nprocs=nr, join=True)
+    mp.spawn(run, args=(nr, free_port(), str(tmp_path), None, f"amrbench{nr}"), nprocs=nr, join=True)
     seen = set()
     for r in range(nr):
         z = np.load(os.path.join(str(tmp_path), f"amrbench_w{nr}_r{r}.npz"))
@@ -235,10 +244,10 @@ def test_amr_bench_workload_sharded_over_ranks(tmp_path, nr):
 def test_regrid_on_two_ranks_matches_one_rank(tmp_path, merge):
     """Amr::regrid with the levels spread over two ranks: same grids after every regrid, same data, both ranks own boxes of the new level"""
     import torch.multiprocessing as mp
-    port = 34100 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "regrid" + merge), nprocs=1, join=True)      # "+merge": level 0 merged per rank (the default mode)
     ref = np.load(os.path.join(str(tmp_path), "regrid_w1_r0.npz"))
-    mp.spawn(run, args=(2, port + 9, str(tmp_path), None, "regrid" + merge), nprocs=2, join=True)
+    mp.spawn(run, args=(2, free_port(), str(tmp_path), None, "regrid" + merge), nprocs=2, join=True)
     seen = set()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"regrid_w2_r{r}.npz"))
@@ -256,10 +265,10 @@ def test_two_level_hierarchy_on_two_ranks(tmp_path):
     """the multi-level time step (subcycling, registers, MAC sync incl. the viscous solves, composite sync projection, multi-level
     initialisation) with the boxes of BOTH levels distributed over two ranks sharing the GPU: every box equals the one-rank result"""
     import torch.multiprocessing as mp
-    port = 37100 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "amr"), nprocs=1, join=True)
     ref = np.load(os.path.join(str(tmp_path), "amr_w1_r0.npz"))
-    mp.spawn(run, args=(2, port + 5, str(tmp_path), None, "amr"), nprocs=2, join=True)
+    mp.spawn(run, args=(2, free_port(), str(tmp_path), None, "amr"), nprocs=2, join=True)
     seen = set()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"amr_w2_r{r}.npz"))
@@ -276,9 +285,9 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, agg):
     """agg: multigrid agglomeration threshold in cells (None: default, every coarse level of this small problem is replicated on
     both ranks; "0": all levels stay distributed; "64": only the 4^3 and 2^3 levels are replicated)"""
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), agg), nprocs=1, join=True)
-    mp.spawn(run, args=(2, port, str(tmp_path), agg), nprocs=2, join=True)
+    mp.spawn(run, args=(2, free_port(), str(tmp_path), agg), nprocs=2, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
@@ -292,9 +301,9 @@ def test_a_rank_without_boxes_takes_part_in_the_step(tmp_path):
     """more ranks than boxes (AMReX allows it; coarse AMR levels routinely have fewer grids than ranks): rank 2 owns nothing, launches
     no kernels, but joins every reduction and exchange; ranks 0 and 1 reproduce the 1-rank result"""
     import torch.multiprocessing as mp
-    port = 35600 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None), nprocs=1, join=True)
-    mp.spawn(run, args=(3, port, str(tmp_path), None), nprocs=3, join=True)
+    mp.spawn(run, args=(3, free_port(), str(tmp_path), None), nprocs=3, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     idle = np.load(os.path.join(str(tmp_path), "w3_r2.npz"))
     assert not [k for k in idle.files if k.startswith("box")] and np.allclose(idle["dts"], ref["dts"], rtol=1e-10, atol=0)
@@ -311,9 +320,9 @@ def test_ranks_that_merge_their_boxes(tmp_path):
     one slab; the merged level objects, their data accessors (the caller's boxes) and the multigrid wrappers on merged boxes against the
     one-rank run, whose eight boxes merge into one box spanning the domain"""
     import torch.multiprocessing as mp
-    port = 36300 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "slabs+merge"), nprocs=1, join=True)
-    mp.spawn(run, args=(2, port + 3, str(tmp_path), None, "slabs+merge"), nprocs=2, join=True)
+    mp.spawn(run, args=(2, free_port(), str(tmp_path), None, "slabs+merge"), nprocs=2, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     seen = 0
     for r in range(2):
@@ -333,9 +342,9 @@ def test_rows_that_span_the_domain_sharded_in_y_and_z(tmp_path, nr):
     onto one merged box per rank.  Equal to the one-rank run (same kernels on four local boxes) to round-off: the sums of the mean
     removals and dot products are formed rank by rank."""
     import torch.multiprocessing as mp
-    port = 37100 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "rows128"), nprocs=1, join=True)
-    mp.spawn(run, args=(nr, port + 3, str(tmp_path), None, "rows128"), nprocs=nr, join=True)
+    mp.spawn(run, args=(nr, free_port(), str(tmp_path), None, "rows128"), nprocs=nr, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(nr):
         z = np.load(os.path.join(str(tmp_path), f"w{nr}_r{r}.npz"))
@@ -348,9 +357,9 @@ def test_rows_that_span_the_domain_sharded_in_y_and_z(tmp_path, nr):
 def test_two_ranks_lid_driven_cavity(tmp_path):
     """wall BCs (physical BC fills, Neumann projections, per-component tensor BCs, tracer diffusion) across a rank boundary"""
     import torch.multiprocessing as mp
-    port = 31600 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "ldc"), nprocs=1, join=True)
-    mp.spawn(run, args=(2, port, str(tmp_path), None, "ldc"), nprocs=2, join=True)
+    mp.spawn(run, args=(2, free_port(), str(tmp_path), None, "ldc"), nprocs=2, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"w2_r{r}.npz"))
@@ -364,11 +373,11 @@ def test_four_ranks_stacked_boxes_like_the_bench(tmp_path):
     """bench.py's weak-scaling layout (one box per rank stacked in z, domain 16 x 16 x 64) on 4 ranks sharing the GPU, with the
     default agglomeration threshold and with a threshold that keeps the first coarse level distributed: same result as one rank"""
     import torch.multiprocessing as mp
-    port = 33600 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, "stack4"), nprocs=1, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for agg in (None, "1024"):
-        mp.spawn(run, args=(4, port + 7, str(tmp_path), agg, "stack4"), nprocs=4, join=True)
+        mp.spawn(run, args=(4, free_port(), str(tmp_path), agg, "stack4"), nprocs=4, join=True)
         for r in range(4):
             z = np.load(os.path.join(str(tmp_path), f"w4_r{r}.npz"))
             assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
@@ -382,10 +391,10 @@ def test_bench_process_grid_layouts(tmp_path, nr):
     """the box layout bench.py builds for 4 / 8 GPUs (proc_grid: 2x2x1 / 2x2x2, every rank has a neighbour in each refined direction,
     SURVEY 8e) on nr ranks sharing the GPU over the callback transport: same result as one rank holding all boxes"""
     import torch.multiprocessing as mp
-    port = 36100 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(run, args=(1, port, str(tmp_path), None, f"grid{nr}"), nprocs=1, join=True)
     ref = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
-    mp.spawn(run, args=(nr, port + 11, str(tmp_path), None, f"grid{nr}"), nprocs=nr, join=True)
+    mp.spawn(run, args=(nr, free_port(), str(tmp_path), None, f"grid{nr}"), nprocs=nr, join=True)
     for r in range(nr):
         z = np.load(os.path.join(str(tmp_path), f"w{nr}_r{r}.npz"))
         assert np.allclose(z["dts"], ref["dts"], rtol=1e-10, atol=0)
@@ -400,7 +409,7 @@ def test_bench_script_multi_rank_path(tmp_path):
     import json
     import subprocess
     env = dict(os.environ, IAMRX_BENCH_TRANSPORT="gloo", MASTER_ADDR="127.0.0.1", IAMRX_BENCH_N="32")     # "--n" would be eaten by torchrun
-    port = 35600 + (os.getpid() % 2000)
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -506,7 +515,7 @@ def test_rccl_transport_between_two_devices(tmp_path):
         pytest.skip(msg)
     import torch.multiprocessing as mp
     mp.spawn(_rccl_pair, args=(str(tmp_path),), nprocs=2, join=True)
-    mp.spawn(run, args=(1, 29600 + (os.getpid() % 2000), str(tmp_path), None), nprocs=1, join=True)      # the same two boxes on one rank
+    mp.spawn(run, args=(1, free_port(), str(tmp_path), None), nprocs=1, join=True)      # the same two boxes on one rank
     one = np.load(os.path.join(str(tmp_path), "w1_r0.npz"))
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), f"rccl2_r{r}.npz"))

@@ -7,7 +7,7 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --no-cpu-baseline > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --no-cpu-baseline --rt-n 0 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 test -n "$f" && cp "$f" $out/${tag}_kernel_stats.csv
 t=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
