@@ -50,6 +50,6 @@ if rank == 0:
           f"MG iterations mac {sm.iters} nodal {sn.iters} visc {sv.iters}")
 if rank == 0:
     print(f"exchanges per step and rank: {xd[0]} on the main stream ({xd[1] * 8 / 1e6:.1f} MB sent; exposed: in front of the kernel that reads the ghost data), "
-          f"{xd[2]} on the side stream ({xd[3] * 8 / 1e6:.1f} MB sent; hidden behind the interior tiles of the multi-box red + black sweep)")
+          f"{xd[2]} on the side stream ({xd[3] * 8 / 1e6:.1f} MB sent; hidden behind the interior tiles of the multi-box red + black sweep and of the nodal passes)")
 if rank == 0: print("sizes (doubles: count):", sorted(hist.items()))
 dist.barrier(); dist.destroy_process_group()
