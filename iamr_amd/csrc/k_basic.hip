@@ -206,6 +206,19 @@ static double finish_to_host(int op, int nout, int np, bool global)
     return ctx.h_scratch[0];
 }
 
+// the same, results left ON THE DEVICE at d_out[0 .. nout) (no read-back, no host synchronisation): the device-resident Krylov loop
+// (krylov.h) consumes them from there.  op 0: sums, 1: maxima of absolute values
+void reduce_finish_dev(int op, int nout, int np, bool global, double* d_out)
+{
+    auto& ctx = Context::get();
+    ctx.ensure_scratch((size_t)nout * np + 16);
+    double* partials = ctx.d_scratch;
+    if (np == 0) IAMRX_HIP_CHECK(hipMemsetAsync(d_out, 0, nout * sizeof(double), ctx.stream));
+    else if (op == 0) hipLaunchKernelGGL((k_reduce_finish<0>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, d_out);
+    else hipLaunchKernelGGL((k_reduce_finish<1>), dim3(nout), dim3(256), 0, ctx.stream, partials, np, d_out);
+    if (global && ctx.comm->nranks > 1) ctx.comm->allreduce_device(d_out, nout, op == 0 ? ReduceOp::Sum : ReduceOp::Max, ctx.stream);
+}
+
 void reduce_finish_max(int nout, int np, bool global, double* out)
 {
     auto& ctx = Context::get();
@@ -382,6 +395,27 @@ void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, i
         finish_to_host(0, nout, np, global);
         for (int q = 0; q < nout; ++q) out[q] = ctx.h_scratch[q];
     }
+}
+
+// dot products left on the device (see reduce_finish_dev)
+void reduce_dots_dev(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* d_out, bool local)
+{
+    IAMRX_ASSERT(nout == 1 || nout == 2);
+    auto& ctx = Context::get();
+    const MultiFab& m = *x[0];
+    const bool global = !local && !m.layout->replicated && ctx.comm->nranks > 1;
+    int np = 0;
+    if (m.nlocal() > 0) {
+        Tiling t = level_tiling(*m.layout, m.type, 0, 8, true);
+        dim3 gr = t.grid();
+        np = (int)(gr.x * gr.y);
+        ctx.ensure_scratch((size_t)np * nout + 16);
+        const OwnerInfo own = make_owner(m, g);
+        hipLaunchKernelGGL(k_dots, gr, Tiling::block(), 0, ctx.stream, t, m.layout->d_boxes, own, nout,
+                           x[0]->d_tab, y[0]->d_tab, nout > 1 ? x[1]->d_tab : nullptr, nout > 1 ? y[1]->d_tab : nullptr,
+                           comp, nc, ctx.d_scratch, np);
+    }
+    reduce_finish_dev(0, nout, np, global, d_out);
 }
 
 __global__ void __launch_bounds__(256) k_sum_unique(Tiling t, const BoxD* __restrict__ boxes, OwnerInfo own,

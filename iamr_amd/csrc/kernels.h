@@ -21,6 +21,8 @@ void reduce_minmax(const MultiFab& mf, int comp, int ng, double& mn, double& mx,
 double reduce_sum_unique(const MultiFab& mf, int comp, const Geometry& g, bool global = false);   // sum over owner copies
 // nout simultaneous dot products over the valid region, owner-masked for nodal data: out[q] = <x_q, y_q>
 void reduce_dots(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* out, bool local = false);
+// ... with the results left on the device (no read-back): krylov.h
+void reduce_dots_dev(int nout, const MultiFab* const* x, const MultiFab* const* y, int comp, int nc, const Geometry& g, double* d_out, bool local = false);
 // y = a*x + b*y etc. (valid region + ng)
 // HIP-event probe around the k_nodal_gs4 launches of levels with >= min_nodes nodes per box (see k_nodal.hip)
 // HIP-event probes around the launches of one kernel family on levels with at least min_points cells / nodes per box (every stride-th one)

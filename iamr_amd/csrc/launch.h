@@ -242,6 +242,23 @@ inline void reduce_max_f(const Layout& l, const IndexType& type, int ng, F f, do
     reduce_finish_max(NOUT, np, global && !l.replicated, out);
 }
 
+// the same with the maxima left on the device at d_out (k_basic.hip reduce_finish_dev; no read-back); f may write arrays as a side effect
+void reduce_finish_dev(int op, int nout, int np, bool global, double* d_out);
+template <int NOUT, class F>
+inline void reduce_max_f_dev(const Layout& l, const IndexType& type, int ng, F f, double* d_out, bool global = true)
+{
+    auto& ctx = Context::get();
+    int np = 0;
+    if (l.nlocal() > 0) {
+        Tiling t = level_tiling(l, type, ng, 8, true);
+        dim3 g = t.grid();
+        np = (int)(g.x * g.y);
+        ctx.ensure_scratch((size_t)NOUT * np + 16);
+        hipLaunchKernelGGL((k_reduce_max_f<NOUT, F>), g, Tiling::block(), 0, ctx.stream, t, l.d_boxes, type.t[0], type.t[1], type.t[2], ng, f, ctx.d_scratch, np);
+    }
+    reduce_finish_dev(1, NOUT, np, global && !l.replicated, d_out);
+}
+
 // level-wide loop in two phases, for the BLAS-1 style operations: v = ld(i, j, k, fab, n) for NP planes -- every load issued before the
 // first store (destination and sources may be the same array, so a plain loop orders each load behind the previous store) -- then
 // st(i, j, k, fab, n, v)

@@ -3,6 +3,7 @@
 // of k_abec.hip / k_tensor.hip.  Reference call sites: Source/MacProj.cpp:1150-1183 (MAC solve,
 // mac_tol 1e-12, max_order 4), Source/Diffusion.cpp:837-929 (tensor solve, visc_tol 1e-10, max_order 2).
 #include "mlmg.h"
+#include "krylov.h"
 #include "launch.h"
 #include <chrono>
 #include <cmath>
@@ -521,6 +522,11 @@ int CellMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel, 
     // (observed: ~175 iterations per V-cycle on a 2^3 level whose rhs is at round-off level).  Cap at 2N.
     const long nunk = (long)g.domain.npts() * nc;
     const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+    if (tune("KRYLOV_DEVICE", 1) != 0 && (Context::get().comm->nranks == 1 || L.layout->replicated)) {
+        // krylov.h: the same loop with its scalars on the device (one status word per iteration comes back, one iteration late)
+        ret = bicgstab_device(*L.layout, cell_type(), nc, g, sol, r, rh, ph, sh, v, t, rnorm0, eps_rel, eps_abs, maxiter,
+                              [&](MultiFab& out, MultiFab& in) { applyBC(l, in, false, nullptr); abec_residual(g, c, out, in, nullptr); }, nit, rnorm);
+    } else
     for (; nit <= maxiter; ++nit) {
         double rho;
         { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&r}; reduce_dots(1, xs, ys, 0, nc, g, &rho); }

@@ -3,6 +3,7 @@
 // with Gauss-Seidel on, harmonic average off, max_fmg_iter 0, proj_tol 1e-12 / sync_tol 1e-10).
 #include "mlmg.h"
 #include "launch.h"
+#include "krylov.h"
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -306,6 +307,15 @@ int NodalMG::bicgstab(int l, MultiFab& sol, const MultiFab& rhs, double eps_rel,
     long nunk = 1;
     for (int d = 0; d < 3; ++d) nunk *= g.domain.len(d) + (g.periodic[d] ? 0 : 1);
     const int maxiter = (int)std::min<long>(m_o.bottom_maxiter, std::max<long>(8, 2 * nunk));
+    if (tune("KRYLOV_DEVICE", 1) != 0 && (Context::get().comm->nranks == 1 || L.layout->replicated)) {
+        // krylov.h: the same loop with its scalars on the device (one status word per iteration comes back, one iteration late)
+        ret = bicgstab_device(*L.layout, node_type(), 1, g, sol, r, rh, ph, sh, v, t, rnorm0, eps_rel, eps_abs, maxiter,
+                              [&](MultiFab& out, MultiFab& in) {
+                                  fillbc(l, in);
+                                  nodal_residual(g, out, in, L.sig, nullptr);
+                                  if (L.dmask()) nodal_zero_masked(out, L.dm);
+                              }, nit, rnorm);
+    } else
     for (; nit <= maxiter; ++nit) {
         double rho;
         { const MultiFab* xs[1] = {&rh}; const MultiFab* ys[1] = {&r}; reduce_dots(1, xs, ys, 0, 1, g, &rho); }
