@@ -19,8 +19,16 @@ lib.sync()
 print("MARK_BEGIN", flush=True)
 m = lib.MultiFab(lib.Layout.single((7, 7, 7)), lib.CELL, 1, 0)
 m.setval(1.0); m.setval(1.0); m.setval(1.0); lib.sync()   # marker: three consecutive tiny fills
+import ctypes as C
+if os.environ.get("AMR_SCOPES"):      # scope profile (ProfScope: the stream is drained at both ends of every scope) of the four steps
+    lib.check(lib.lib().iamrx_scope_profile(1, 1, None, C.c_size_t(0)))
 t0 = time.perf_counter()
 for _ in range(4): amr.coarse_step()
 lib.sync()
 print("ms/step", (time.perf_counter() - t0) * 250)
+if os.environ.get("AMR_SCOPES"):
+    buf = C.create_string_buffer(1 << 16)
+    lib.check(lib.lib().iamrx_scope_profile(0, 0, buf, C.c_size_t(1 << 16)))
+    print("scope profile (four coarse steps):")
+    print(buf.value.decode())
 m.setval(2.0); m.setval(2.0); m.setval(2.0); lib.sync()
