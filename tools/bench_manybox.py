@@ -24,6 +24,8 @@ def layouts():
             else: mixed += [((16 * (i + q), 16 * j, 16 * k), (16 * (i + q) + 15, 16 * j + 15, 16 * k + 15)) for q in range(4) for k in range(3)]
     out.append((f"{len(mixed)} mixed boxes 16^3 and 64x16x48 (1.77 M cells)", (192, 192, 48), mixed))
     out.append(("1 box 192x192x48 (1.77 M cells)", (192, 192, 48), [((0, 0, 0), (191, 191, 47))]))
+    b8 = [((8 * i, 8 * j, 8 * k), (8 * i + 7, 8 * j + 7, 8 * k + 7)) for k in range(3) for j in range(12) for i in range(12)]
+    out.append(("432 boxes of 8^3 (221 k cells)", (96, 96, 24), b8))
     tiny = [((4 * i, 4 * j, 4 * k), (4 * i + 3, 4 * j + 3, 4 * k + 3)) for k in range(3) for j in range(12) for i in range(12)]
     out.append(("432 boxes of 4^3 (27 k cells)", (48, 48, 12), tiny))
     return out
@@ -39,3 +41,12 @@ for name, n, boxes in layouts():
         out = C.c_double()
         t_norm = ev(lambda: lib.check(L.iamrx_mf_norm0(a.h, 0, 1, 0, C.byref(out))), 20)
         print(f"{name:55s} {tn}: copy {t_copy:7.1f} us  setval {t_set:7.1f} us  fill_boundary {t_fb:7.1f} us  norm0 (incl. read-back) {t_norm:7.1f} us", flush=True)
+    # the nodal operator of a Krylov iteration on such a level: the z-marching LDS kernel (tiles of 32 x 8 nodes) against the plain per-node form
+    x = lib.MultiFab(lay, lib.NODE, 1, 1); r = lib.MultiFab(lay, lib.NODE, 1, 0); sg = lib.MultiFab(lay, lib.CELL, 1, 1)
+    x.setval(1.0); sg.setval(1.0)
+    ts = []
+    for zm in (1, 0):
+        lib.tuning_set("NODAL_RES_ZM", zm)
+        ts.append(ev(lambda: lib.check(L.iamrx_nodal_residual(C.byref(g), r.h, x.h, sg.h, None))))
+    lib.tuning_set("NODAL_RES_ZM", 1)
+    print(f"{name:55s} nodal residual: z-marching {ts[0]:7.1f} us  per-node {ts[1]:7.1f} us", flush=True)
