@@ -832,11 +832,10 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
     for (int l = 0; l < nl; ++l) {
         CLev& C = L[l];
         MultiFab::Copy(*phi[l], C.x, 0, 0, 1, 1);
-        MultiFab sg(C.layout, cell_type(), 1, 0);
-        MultiFab::Copy(sg, *sig[l], 0, 0, 1, 0);
-        nodal_mknewu(C.g, vel[l], vcomp[l], *phi[l], &sg, C.pl->gp, increment_gp);
+        nodal_mknewu(C.g, vel[l], vcomp[l], *phi[l], sig[l], C.pl->gp, increment_gp);       // (sigma is component 0 of sig[l], as for setSigma above)
     }
     for (int l = nl - 1; l >= 1; --l) {                  // NodalProjector::averageDown(vel)
+        if (vcomp[l] == vcomp[l - 1]) { average_down(*vel[l], *vel[l - 1], vcomp[l], 3, L[l].pl->ratio); continue; }
         MultiFab vf(L[l].layout, cell_type(), 3, 0), vc(L[l - 1].layout, cell_type(), 3, 0);
         MultiFab::Copy(vf, *vel[l], vcomp[l], 0, 3, 0);
         MultiFab::Copy(vc, *vel[l - 1], vcomp[l - 1], 0, 3, 0);
