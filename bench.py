@@ -323,6 +323,9 @@ def rt_workload(lib, n, steps, warm=4, **mg_kw):
     lib.sync()
     cells = 0
     per_step = []
+    import ctypes as C
+    nm0 = C.c_size_t(0)
+    lib.check(lib.lib().iamrx_alloc_count(C.byref(nm0)))
     t0 = time.perf_counter()
     for _ in range(steps):
         t1 = time.perf_counter()
@@ -331,6 +334,8 @@ def rt_workload(lib, n, steps, warm=4, **mg_kw):
         per_step.append((time.perf_counter() - t1) * 1e3)
         cells += sum((2 ** l) * sum(b_npts(lo, hi) for lo, hi in amr.layouts[l].boxes) for l in range(amr.nlev))
     el = time.perf_counter() - t0
+    nm1 = C.c_size_t(0)
+    lib.check(lib.lib().iamrx_alloc_count(C.byref(nm1)))
     st, stm = amr.sync_stats()
     levels = amr.nlev
     grids = [len(l.boxes) for l in amr.layouts]
@@ -347,7 +352,7 @@ def rt_workload(lib, n, steps, warm=4, **mg_kw):
     return {"workload": "RayleighTaylor 3D (config C5; regtest.3d.rayleightaylor with amr.n_cell = %d^3): variable density, gravity, Godunov_PPM, do_mom_diff, "
                         "do_cons_trac, slip walls in z, 3 levels from vorticity tags (ratio 2, subcycled, regrid every 2nd coarse step), one GPU" % n,
             "ms_per_coarse_step": el / steps * 1e3, "ms_of_each_coarse_step": per_step, "cells_advanced_per_sec": cells / el, "coarse_steps": steps,
-            "warmup_coarse_steps": warm, "levels": levels, "grids": grids, "cells_per_level": lev_cells,
+            "warmup_coarse_steps": warm, "device_mallocs_in_timed_steps": nm1.value - nm0.value, "levels": levels, "grids": grids, "cells_per_level": lev_cells,
             "sync_project_iters": st.iters, "mac_sync_iters": stm.iters, "sections_ms_per_coarse_step": sections}
 
 

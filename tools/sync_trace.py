@@ -30,6 +30,7 @@ n = sys.argv[1] if len(sys.argv) > 1 else "64"
 r = subprocess.run([sys.executable, __file__, "child", n], capture_output=True, text=True)
 so = os.path.join(ROOT, "iamr_amd", "libiamrx.so")
 cnt = collections.Counter()
+pts = collections.Counter()      # blas sites: points touched (array points x components), summed
 big = int(n) ** 3 // 2
 for line in r.stderr.splitlines():
     if line.startswith("iamrx sync:"):
@@ -38,10 +39,17 @@ for line in r.stderr.splitlines():
         w = line.split()
         if int(w[3]) >= big:                      # finest-level arrays only
             cnt[(w[2],) + tuple(w[4:7])] += 1
+            pts[(w[2],) + tuple(w[4:7])] += int(w[3])
 addrs = sorted({a for k in cnt for a in k if re.fullmatch(r"[0-9a-f]+", a) and len(a) > 3})
 res = subprocess.run(["addr2line", "-f", "-C", "-e", so] + ["0x" + a for a in addrs], capture_output=True, text=True).stdout.splitlines()
 name = {a: re.sub(r"\(.*", "", res[2 * i]).replace("iamrx::", "") + ":" + res[2 * i + 1].split(":")[-1].split()[0] for i, a in enumerate(addrs)}
 name.update({k: k for k in ("setVal", "Copy", "saxpy", "lincomb", "mult")})
 print("events per step:", sum(cnt.values()) / 2)
-for k, v in cnt.most_common():
-    print("%5.1f  %s" % (v / 2, " <- ".join(name[a] for a in k)))
+if os.environ.get("TRACE_KEY") == "BLAS_TRACE":       # by points touched (in units of one finest-level array), not by count
+    unit = 2.0 * int(n) ** 3
+    print("array passes per step (points / n^3):", sum(pts.values()) / unit)
+    for k, v in pts.most_common():
+        print("%6.2f  (%4.1f x)  %s" % (v / unit, cnt[k] / 2, " <- ".join(name[a] for a in k)))
+else:
+    for k, v in cnt.most_common():
+        print("%5.1f  %s" % (v / 2, " <- ".join(name[a] for a in k)))
