@@ -286,6 +286,8 @@ bool AmrNS::install_grids(const std::vector<std::vector<BoxD>>& grids, int lbase
         s.inew = 0; s.pnew = 0;
         s.set_time_level(cur_time, dt_old, dt_new);
         s.initial_step = false; s.initial_iter = false;
+        s.profile_sections = profile_on;                           // the section profile of a run goes on across a regrid
+        if (ol) for (int q = 0; q < 8; ++q) s.t_sections[q] = ol->t_sections[q];
         PROF_NEXT(pri, "ri_fill_data");
         // ---- data: FillPatch(old, S_new / P_new / Gp_new) resp. FillCoarsePatch: the old level's cells where it existed, the
         // (already rebuilt) coarser level interpolated elsewhere
