@@ -67,9 +67,17 @@ static void erode(std::vector<unsigned char>& m, const int n[3], const int per[3
     const int r = passes;
     const size_t sx = 1, sy = (size_t)n[0], sz = (size_t)n[0] * n[1];
     const size_t str[3] = {sx, sy, sz};
-    std::vector<unsigned char> o;
+    if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return;
+    // `o`: the map before the pass of a direction.  Only rows the pass reads are copied: x and y passes stay inside a plane, the z pass
+    // reaches r planes beyond the bounding box (all planes if that wraps around).  (A copy of the whole map per direction and a range / wrap
+    // test per cell in the x pass were 150 ms of every regrid above level 0 on a 512^3 index space.)
+    std::unique_ptr<unsigned char[]> o(new unsigned char[m.size()]);      // (not zeroed: only what is copied below is read)
     for (int d = 0; d < 3; ++d) {
-        o = m;
+        int ka = lo[2], kb = hi[2];
+        if (d == 2) { ka -= r; kb += r; if (ka < 0 || kb >= n[2]) { ka = 0; kb = n[2] - 1; } }
+        if (d == 1) std::memcpy(&o[(size_t)ka * sz], &m[(size_t)ka * sz], (size_t)(kb - ka + 1) * sz);      // (the y pass reads rows j +- r: whole planes)
+        else if (d == 2) std::memcpy(&o[(size_t)ka * sz], &m[(size_t)ka * sz], (size_t)(kb - ka + 1) * sz);
+        else for (int k = ka; k <= kb; ++k) for (int j = lo[1]; j <= hi[1]; ++j) std::memcpy(&o[(size_t)k * sz + (size_t)j * sy], &m[(size_t)k * sz + (size_t)j * sy], (size_t)n[0]);
         for (int k = lo[2]; k <= hi[2]; ++k) for (int j = lo[1]; j <= hi[1]; ++j) {
             const int c3[3] = {0, j, k};
             for (int dd = -r; dd <= r; ++dd) {
@@ -77,10 +85,12 @@ static void erode(std::vector<unsigned char>& m, const int n[3], const int per[3
                 if (d == 0) {
                     unsigned char* row = &m[(size_t)k * sz + (size_t)j * sy];
                     const unsigned char* orow = &o[(size_t)k * sz + (size_t)j * sy];
-                    for (int i = lo[0]; i <= hi[0]; ++i) {
-                        int q = i + dd;
-                        if (q < 0 || q >= n[0]) { if (!per[0]) continue; q = (q % n[0] + n[0]) % n[0]; }
-                        row[i] &= orow[q];
+                    // the cells whose neighbour i + dd lies inside the row: a plain shifted AND; the few at the ends: the periodic image (or nothing)
+                    const int ia = std::max(lo[0], -dd), ib = std::min(hi[0], n[0] - 1 - dd);
+                    for (int i = ia; i <= ib; ++i) row[i] &= orow[i + dd];
+                    if (per[0]) {
+                        for (int i = lo[0]; i < ia && i <= hi[0]; ++i) row[i] &= orow[((i + dd) % n[0] + n[0]) % n[0]];
+                        for (int i = std::max(ib + 1, lo[0]); i <= hi[0]; ++i) row[i] &= orow[((i + dd) % n[0] + n[0]) % n[0]];
                     }
                 } else {
                     int q = c3[d] + dd;

@@ -48,6 +48,12 @@ struct Context {
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     size_t bytes_live = 0, bytes_cached = 0;
+    // round 6: the blocks are carved out of large chunks and a freed block merges with its free neighbours (IAMRX_ARENA, mf.hip): free_addr
+    // holds the same free blocks by address, chunk_end the end of every chunk by its start (blocks never merge across chunks)
+    std::map<char*, size_t> free_addr;
+    std::map<char*, char*> chunk_end;
+    bool arena = true;
+    size_t bytes_chunks = 0;
     size_t n_device_malloc = 0;    // hipMalloc calls (cache misses): must stay flat inside the time loop
     size_t n_stream_sync = 0;      // host waits on the stream (Context::sync): reductions read back, plan uploads
     double* d_scratch = nullptr;   // reduction scratch

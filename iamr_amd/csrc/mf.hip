@@ -32,6 +32,7 @@ void Context::init(int dev)
     if (e != hipSuccess || ndev == 0)
         throw Error("iamrx: no HIP device available -- the product path has no CPU fallback");
     device = dev;
+    if (live_blocks.empty() && chunk_end.empty() && free_blocks.empty()) arena = tune("ARENA", 1) != 0;      // (fixed for the life of the allocator's blocks)
     IAMRX_HIP_CHECK(hipSetDevice(dev));
     if (!stream) IAMRX_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!side) {
@@ -74,10 +75,81 @@ static int poison_allocs()
     return (int)tune("POISON_ALLOC", 0);
 }
 
+// The device allocator (The_Arena's role).  hipMalloc maps pages at 25-35 GB/s and synchronises, so nothing inside a time step may reach it.
+// Rounds 1-5 cached whole hipMalloc blocks by size: exact for a run whose arrays keep their sizes, but every regrid of a GROWING level
+// asks for arrays a few per cent larger than anything in the cache (config C5: 3 457 hipMalloc calls, 226 GB mapped, 6.7 s of a 37 s run)
+// while the blocks of the levels it replaced pile up unused.  Round 6 (IAMRX_ARENA = 1, default): blocks are carved (best fit, split) out
+// of chunks of at least 1/8 of what is mapped so far (>= 256 MB), and a block that comes back merges with its free neighbours inside its
+// chunk -- the space of the old level's arrays becomes one extent the new level's arrays are cut from.  Ordering is the cache's: a block
+// handed out again is used behind its previous owner on `stream` (side-stream users park theirs until the join).
+namespace {
+void arena_insert_free(Context& c, char* p, size_t sz)
+{
+    // merge with the free block that ends at p and the one that starts at p + sz, unless a chunk boundary lies between
+    auto chunk_of = [&](char* q) { auto it = c.chunk_end.upper_bound(q); --it; return it; };
+    const auto ck = chunk_of(p);
+    auto nx = c.free_addr.lower_bound(p);
+    if (nx != c.free_addr.begin()) {
+        auto pv = std::prev(nx);
+        if (pv->first + pv->second == p && pv->first >= ck->first) {
+            auto rng = c.free_blocks.equal_range(pv->second);
+            for (auto it = rng.first; it != rng.second; ++it) if (it->second == (void*)pv->first) { c.free_blocks.erase(it); break; }
+            p = pv->first; sz += pv->second;
+            c.free_addr.erase(pv);
+        }
+    }
+    nx = c.free_addr.lower_bound(p + sz);
+    if (nx != c.free_addr.end() && nx->first == p + sz && p + sz < ck->second) {
+        auto rng = c.free_blocks.equal_range(nx->second);
+        for (auto it = rng.first; it != rng.second; ++it) if (it->second == (void*)nx->first) { c.free_blocks.erase(it); break; }
+        sz += nx->second;
+        c.free_addr.erase(nx);
+    }
+    c.free_addr[p] = sz;
+    c.free_blocks.emplace(sz, (void*)p);
+}
+}  // namespace
+
 void* Context::alloc(size_t bytes)
 {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~size_t(255);
+    if (arena) {
+        auto it = free_blocks.lower_bound(bytes);
+        if (it == free_blocks.end()) {
+            // a new chunk: the request, or 1/8 of everything mapped so far if that is more (at least 256 MB: small runs map one chunk)
+            size_t csz = std::max(bytes, std::max(size_t(256) << 20, bytes_chunks / 8));
+            csz = (csz + ((size_t(2) << 20) - 1)) & ~((size_t(2) << 20) - 1);
+            void* q = nullptr;
+            ++n_device_malloc;
+            static const bool trace = tune("ALLOC_TRACE", 0) != 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t e = hipMalloc(&q, csz);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                release_cache();
+                csz = (bytes + ((size_t(2) << 20) - 1)) & ~((size_t(2) << 20) - 1);
+                IAMRX_HIP_CHECK(hipMalloc(&q, csz));
+            }
+            if (trace) fprintf(stderr, "iamrx alloc: chunk of %.1f MB for a request of %.1f MB: %.2f ms (mapped %.1f GB, live %.1f GB)\n", csz / 1048576.0, bytes / 1048576.0,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (bytes_chunks + csz) / 1073741824.0, bytes_live / 1073741824.0);
+            chunk_end[(char*)q] = (char*)q + csz;
+            bytes_chunks += csz;
+            bytes_cached += csz;
+            arena_insert_free(*this, (char*)q, csz);
+            it = free_blocks.lower_bound(bytes);
+        }
+        char* p = (char*)it->second;
+        const size_t have = it->first;
+        free_blocks.erase(it);
+        free_addr.erase(p);
+        if (have > bytes) arena_insert_free(*this, p + bytes, have - bytes);       // (no neighbour to merge with: p was one free extent)
+        bytes_cached -= bytes;
+        live_blocks[p] = bytes;
+        bytes_live += bytes;
+        if (poison_allocs()) IAMRX_HIP_CHECK(hipMemsetAsync(p, poison_allocs() == 2 ? 0x00 : 0xFF, bytes, stream));
+        return p;
+    }
     auto it = free_blocks.lower_bound(bytes);
     if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + 4096) {
         void* p = it->second;
@@ -110,13 +182,29 @@ void Context::free(void* p)
     size_t sz = it->second;
     live_blocks.erase(it);
     bytes_live -= sz;
-    free_blocks.emplace(sz, p);
     bytes_cached += sz;
+    if (arena) arena_insert_free(*this, (char*)p, sz);
+    else free_blocks.emplace(sz, p);
 }
 
+// returns what nobody uses to the driver: cached blocks (IAMRX_ARENA = 0) / chunks that are free from end to end
 void Context::release_cache()
 {
     sync();
+    if (arena) {
+        for (auto ck = chunk_end.begin(); ck != chunk_end.end();) {
+            auto f = free_addr.find(ck->first);
+            const size_t csz = (size_t)(ck->second - ck->first);
+            if (f == free_addr.end() || f->second != csz) { ++ck; continue; }
+            auto rng = free_blocks.equal_range(csz);
+            for (auto it = rng.first; it != rng.second; ++it) if (it->second == (void*)ck->first) { free_blocks.erase(it); break; }
+            free_addr.erase(f);
+            (void)hipFree(ck->first);
+            bytes_cached -= csz; bytes_chunks -= csz;
+            ck = chunk_end.erase(ck);
+        }
+        return;
+    }
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     free_blocks.clear();
     bytes_cached = 0;
