@@ -26,6 +26,8 @@ t0 = time.perf_counter()
 for _ in range(4): amr.coarse_step()
 lib.sync()
 print("ms/step", (time.perf_counter() - t0) * 250)
+st, stm = amr.sync_stats()
+print("sync project iterations of the last coarse step", st.iters, "residual", st.resnorm, "of", st.resnorm0, "; mac sync iterations", stm.iters)
 if os.environ.get("AMR_SCOPES"):
     buf = C.create_string_buffer(1 << 16)
     lib.check(lib.lib().iamrx_scope_profile(0, 0, buf, C.c_size_t(1 << 16)))
