@@ -695,7 +695,11 @@ MGStats composite_project(const std::vector<ProjLevel>& PL, MultiFab* const vel[
         // below it, no bottom solve: the level underneath is its coarse grid, as in amrex::MLMG's composite cycle (mgFcycle / oneIter: smooth,
         // restrict the residual to the AMR level below, interpolate its correction, smooth).  0: a V-cycle of the level's own hierarchy.
         const int fine_smooth = (int)tune("CP_FINE_SMOOTH", 1);
-        if (l > 0 && fine_smooth > 0) { mo.max_coarsening_level = 0; mo.bottom_smoother_only = 1; mo.nuf = fine_smooth; }
+        if (l > 0 && fine_smooth > 0) {
+            mo.max_coarsening_level = 0; mo.bottom_smoother_only = 1; mo.nuf = fine_smooth;
+            const int sw = (int)tune("CP_FINE_SWEEPS", 0);             // > 0: sweeps per smoother call of these corrections (default: the solver's)
+            if (sw > 0) mo.nodal_sweeps = sw;
+        }
         C.mg = std::make_unique<NodalMG>(C.g, C.layout, C.pl->nodal_bc, mo);
         C.mg->setSigma(*sig[l], 0);
     }
