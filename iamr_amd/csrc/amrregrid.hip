@@ -62,7 +62,7 @@ bool same_boxes(std::vector<BoxD> a, std::vector<BoxD> b)
 // domain face nothing constrains).  Erosion by a cube is separable and `passes` erosions by one cell are one erosion by `passes` cells:
 // three 1-D minima over 2 passes + 1 cells, along x, y and z, restricted to the bounding box [lo, hi] of the cells that are set (nothing
 // outside it can survive) -- round 6: the 27-neighbour loop over the whole 512^3 index space of a level cost 0.6 s per regrid above level 0
-static void erode(std::vector<unsigned char>& m, const int n[3], const int per[3], int passes, const int lo[3], const int hi[3])
+void erode_map(std::vector<unsigned char>& m, const int n[3], const int per[3], int passes, const int lo[3], const int hi[3])
 {
     const int r = passes;
     const size_t sx = 1, sy = (size_t)n[0], sz = (size_t)n[0] * n[1];
@@ -126,9 +126,9 @@ std::vector<std::vector<BoxD>> AmrNS::make_new_grids(int lbase)
             for (int k = bx.lo[2]; k <= bx.hi[2]; ++k) for (int j = bx.lo[1]; j <= bx.hi[1]; ++j)
                 std::memset(&allow0[((size_t)(k - b.g.domain.lo[2]) * nn[1] + (j - b.g.domain.lo[1])) * nn[0] + (bx.lo[0] - b.g.domain.lo[0])], 1, (size_t)bx.len(0));
         }
-        erode(allow0, nn, b.g.periodic, 2, blo, bhi);
+        erode_map(allow0, nn, b.g.periodic, 2, blo, bhi);
         allow1 = allow0;
-        erode(allow1, nn, b.g.periodic, 2, blo, bhi);
+        erode_map(allow1, nn, b.g.periodic, 2, blo, bhi);
     }
     for (int l = std::min(finest, max_level - 1); l >= lbase; --l) {
         NavierStokes& s = *lev[l];

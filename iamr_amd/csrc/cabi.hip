@@ -442,6 +442,30 @@ int iamrx_error_tag(const iamrx_geom* g, iamrx_mf tags, iamrx_mf field, int comp
     IAMRX_TRY error_tag(to_geom(g), tags->mf, field->mf, comp, mode, value, level, realbox_lo, realbox_hi); IAMRX_CATCH
 }
 
+// the host side of the grid generation on host arrays (no device needed: tests of the regrid's host logic)
+int iamrx_host_cluster_tags(const unsigned char* tags, const int dom_lo[3], const int dom_hi[3], int blocking_factor, int max_grid_size, double grid_eff,
+                            int n_error_buf, const unsigned char* allowed, int* boxes, int* nboxes)
+{
+    IAMRX_TRY
+    BoxD dom;
+    for (int d = 0; d < 3; ++d) { dom.lo[d] = dom_lo[d]; dom.hi[d] = dom_hi[d]; }
+    std::vector<BoxD> bx = cluster_tags(tags, dom, blocking_factor, max_grid_size, grid_eff, n_error_buf, nullptr, allowed);
+    if ((int)bx.size() > *nboxes) throw Error("iamrx_host_cluster_tags: box capacity too small");
+    *nboxes = (int)bx.size();
+    for (size_t q = 0; q < bx.size(); ++q) for (int d = 0; d < 3; ++d) { boxes[6 * q + d] = bx[q].lo[d]; boxes[6 * q + 3 + d] = bx[q].hi[d]; }
+    IAMRX_CATCH
+}
+int iamrx_host_erode(unsigned char* map, const int n[3], const int periodic[3], int passes)
+{
+    IAMRX_TRY
+    std::vector<unsigned char> m(map, map + (size_t)n[0] * n[1] * n[2]);
+    int lo[3] = {n[0], n[1], n[2]}, hi[3] = {-1, -1, -1};
+    for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i)
+        if (m[((size_t)k * n[1] + j) * n[0] + i]) { const int c[3] = {i, j, k}; for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], c[d]); hi[d] = std::max(hi[d], c[d]); } }
+    erode_map(m, n, periodic, passes, lo, hi);
+    std::copy(m.begin(), m.end(), map);
+    IAMRX_CATCH
+}
 int iamrx_cluster_tags(const iamrx_geom* g, iamrx_mf tags, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
                        int* boxes, int* nboxes)
 {

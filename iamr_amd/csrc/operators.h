@@ -101,6 +101,9 @@ void error_tag(const Geometry& g, MultiFab& tags, const MultiFab& field, int com
 // manual_tags_placement at the outflow faces (NavierStokesBase.cpp:2112-2215): mode 1 do_refine_outflow, 2 do_derefine_outflow with
 // ncoarse layers (of blocking-factor-coarsened cells) left unrefined
 struct OutflowTags { int nface = 0; int dir[6], side[6]; int mode = 0; int ncoarse = 0; };
+// periodic-aware erosion of a 0/1 cell map by `passes` cells inside the bounding box [lo, hi] of its set cells (amrregrid.hip: the proper
+// nesting domain of a regrid above level 0)
+void erode_map(std::vector<unsigned char>& m, const int n[3], const int per[3], int passes, const int lo[3], const int hi[3]);
 std::vector<BoxD> cluster_tags(const unsigned char* tags_host, const BoxD& domain, int blocking_factor, int max_grid_size, double grid_eff,
                                int n_error_buf, const OutflowTags* oft = nullptr, const unsigned char* allowed = nullptr /* domain-sized 0/1: where the new level may lie */);
 

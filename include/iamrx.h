@@ -357,6 +357,13 @@ int iamrx_error_tag(const iamrx_geom* g, iamrx_mf tags, iamrx_mf field, int comp
  * (6 ints each: lo, hi); *nboxes in: capacity of boxes, out: number of boxes (error if the capacity is too small). */
 int iamrx_cluster_tags(const iamrx_geom* g, iamrx_mf tags, int blocking_factor, int max_grid_size, double grid_eff, int n_error_buf,
                        int* boxes, int* nboxes);
+/* The host side of the same on HOST arrays (no device is touched): tags / allowed: one byte per cell of [dom_lo, dom_hi], x fastest; allowed
+ * (may be NULL): cells the new level may cover (Amr::regrid(lbase > 0): the proper nesting domain) -- a block of the blocking-factor
+ * lattice counts only if all of its cells are allowed.  iamrx_host_erode: the erosion that forms that domain (a cell survives `passes`
+ * passes if its 26 neighbours do; periodic images count, nothing constrains beyond a non-periodic face), in place. */
+int iamrx_host_cluster_tags(const unsigned char* tags, const int dom_lo[3], const int dom_hi[3], int blocking_factor, int max_grid_size, double grid_eff,
+                            int n_error_buf, const unsigned char* allowed, int* boxes, int* nboxes);
+int iamrx_host_erode(unsigned char* map, const int n[3], const int periodic[3], int passes);
 
 /* ---- Diffusion operator entries on caller-owned data (the operator-level boundary) -------------------------------------
  * What NavierStokes::scalar_diffusion_update / velocity_diffusion_update / mac_sync hand to the reference's Diffusion class, for a host
