@@ -11,6 +11,7 @@ t0 = time.perf_counter()
 kw = {}
 if os.environ.get("RT_BSO"): kw["bottom_smoother_only"] = int(os.environ["RT_BSO"])
 if os.environ.get("RT_NUF"): kw["nuf"] = int(os.environ["RT_NUF"])
+if os.environ.get("RT_BRTOL"): kw["bottom_reltol"] = float(os.environ["RT_BRTOL"])
 import ctypes as C
 if os.environ.get("RT_SCOPES"):
     # scope profile (ProfScope: stream drained at both ends of every scope) of everything after post_init
